@@ -1,0 +1,460 @@
+"""CPU oracle for the DiffGFDN hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This file restates, op for op and cast for cast, what the reference
+(orchidas/DiffGFDN, /root/reference) computes on the frequency-sampled GFDN path:
+feedback-matrix parameterisation, per-bin resolvent, transfer functions of the three
+model variants, the sub-FDN (colorless) responses, the EDR / EDC / directional-EDC /
+colorless losses and one optimiser step of the grid trainer.  Every function cites the
+reference file:line it follows.  Gradients come from torch autograd on this forward.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it -- as the checker / CPU baseline, never as the thing shipped or measured on the
+GPU.  The product package ``diffgfdn_amd`` must not import anything from ``oracle/``.
+
+Parity pinning: the reference's own tests hold no vectors for this path,
+so the oracle is pinned against outputs of the reference itself, imported in the build
+container by ``tests/golden/gen_golden.py`` and committed as ``tests/golden/*.npz``
+(``tests/test_oracle_golden.py`` checks every one).  Pieces whose reference source is an
+absent third-party package (slope2noise.decay_kernel envelopes, spaudiopy analysis
+matrix, pyfar FIR taps) are taken as INPUT arrays: parity is unpinned for those inputs
+themselves and pinned for everything downstream of them.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+F32_EPS = float(torch.finfo(torch.float32).eps)
+
+
+# --------------------------------------------------------------------------------------
+# small helpers  (reference: src/diff_gfdn/utils.py)
+# --------------------------------------------------------------------------------------
+def db(x: torch.Tensor, is_squared: bool = False, min_value: float = -200.0) -> torch.Tensor:
+    """utils.py:16-40 -- factor*log10(|x| + eps_f32), clipped below at min_value."""
+    factor = 10.0 if is_squared else 20.0
+    y = factor * torch.log10(torch.abs(x) + F32_EPS)
+    return y.clip(min=min_value)
+
+
+def db2lin(x, is_squared: bool = False):
+    """utils.py:43-59."""
+    e = 0.1 if is_squared else 0.05
+    if torch.is_tensor(x):
+        return torch.pow(10.0, x * e)
+    return np.power(10.0, np.asarray(x) * e)
+
+
+def ms_to_samps(ms: float, fs: float) -> int:
+    """utils.py:62-80 (scalar branch: int() truncation)."""
+    return int(ms * 1e-3 * fs)
+
+
+def to_complex(x: torch.Tensor) -> torch.Tensor:
+    """utils.py:144-146."""
+    return torch.complex(x, torch.zeros_like(x))
+
+
+def decay_times_to_gain_per_sample(t60, delays, fs):
+    """absorption_filters.py:40-53 -- gamma = 10^(0.05 * (-60 m / (fs T60)))."""
+    if torch.is_tensor(t60):
+        return db2lin(-60 * delays / (fs * t60))
+    return db2lin(-60 * np.asarray(delays) / (fs * t60))
+
+
+# --------------------------------------------------------------------------------------
+# feedback-matrix parameterisation  (reference: src/diff_gfdn/feedback_loop.py)
+# --------------------------------------------------------------------------------------
+def skew(X: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:16-25."""
+    A = X.triu(1)
+    return A - A.transpose(-1, -2)
+
+
+def ortho_param(X: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:270 -- expm(skew(X))."""
+    return torch.matrix_exp(skew(X))
+
+
+def nd_unitary(alpha: torch.Tensor, N: int):
+    """feedback_loop.py:39-87 -- recursive Givens product; N == 1 returns python int 1."""
+    assert len(alpha) == N * (N - 1) // 2
+    if N == 1:
+        return 1
+    rot = torch.eye(N, dtype=alpha.dtype)
+    start = (N - 1) * (N - 2) // 2
+    cur = alpha[start:]
+    for i in range(N - 1):
+        R = torch.eye(N, dtype=alpha.dtype)
+        R[i, i] = torch.cos(cur[i])
+        R[i, -1] = -torch.sin(cur[i])
+        R[-1, i] = torch.sin(cur[i])
+        R[-1, -1] = torch.cos(cur[i])
+        rot = torch.mm(R, rot)
+    big = torch.eye(N, dtype=alpha.dtype)
+    big[:N - 1, :N - 1] = nd_unitary(alpha[:start], N - 1)
+    return torch.mm(rot, big)
+
+
+def block_mixing_matrix(M: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:393-404 -- block (i,j) = Q_i @ Q_j (diagonal blocks are Q_i^2)."""
+    G, n, _ = M.shape
+    Q = [ortho_param(M[i]) for i in range(G)]
+    out = torch.zeros((G * n, G * n), dtype=M.dtype)
+    for i in range(G):
+        for j in range(G):
+            out[i * n:(i + 1) * n, j * n:(j + 1) * n] = torch.mm(Q[i], Q[j])
+    return out
+
+
+def coupled_feedback_matrix(M: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:406-411, 424-455 (SCALAR coupling) -- A = block_M o kron(Phi, 1)."""
+    G, n, _ = M.shape
+    block_M = block_mixing_matrix(M)
+    phi = nd_unitary(alpha.clamp(min=-np.pi, max=np.pi), G)
+    if G == 1:
+        # torch.kron(1, ones) raises in the reference -> falls back to block_M (:441-445)
+        return block_M
+    return block_M * torch.kron(phi, torch.ones((n, n), dtype=M.dtype))
+
+
+def feedback_loop_forward(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Tensor,
+                          A: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:326-391, scalar gains & scalar/random coupling.
+
+    z (K,) c128, delays (N,) f32, gamma (N,) real, A (N,N) real f32.
+    Returns P (K,N,N) complex64 = inv(diag(z^m)/gamma - A) computed in c128."""
+    K = len(z)
+    D = torch.diag_embed(torch.unsqueeze(z, dim=-1) ** delays)            # :330
+    Gamma = to_complex(torch.diag(gamma))                                  # :347
+    Acplx = to_complex(A).unsqueeze(0).repeat(K, 1, 1)                     # :359
+    Gamma_inv = torch.diag(1.0 / torch.diagonal(Gamma))                    # :385
+    Ddecay = D * Gamma_inv.unsqueeze(0).repeat(K, 1, 1)                    # :386
+    return torch.linalg.inv(Ddecay - Acplx).to(torch.complex64)            # :391
+
+
+# --------------------------------------------------------------------------------------
+# models  (reference: src/diff_gfdn/model.py)
+# --------------------------------------------------------------------------------------
+def sub_fdn_output(z: torch.Tensor, M: torch.Tensor, input_gains: torch.Tensor,
+                   output_gains: torch.Tensor, delays: torch.Tensor
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """model.py:209-252 -- raw M_g (not expm), no absorption.  Returns Hout (K,G) c64,
+    Hout_per_del (N,K,G) c64."""
+    G, n, _ = M.shape
+    K = len(z)
+    N = G * n
+    Hout = torch.zeros((K, G), dtype=torch.complex64)
+    Hpd = torch.zeros((N, K, G), dtype=torch.complex64)
+    for k in range(G):
+        idx = torch.arange(k * n, (k + 1) * n)
+        C = to_complex(output_gains[idx].expand(n, K))
+        B = to_complex(input_gains[idx].expand(n, K))
+        Ak = M[k].unsqueeze(0).repeat(K, 1, 1)
+        D = torch.diag_embed(torch.unsqueeze(z, dim=-1) ** delays[idx])
+        P = torch.linalg.inv(D - Ak).to(torch.complex64)
+        H_tmp = torch.einsum('kn, knm -> knm', C.permute(1, 0), P).permute(1, -1, 0)
+        Hpd[idx, :, k] = torch.einsum('nmk, mk -> nk', H_tmp, B)
+        H = torch.einsum('kn, knm -> km', C.permute(1, 0), P).permute(1, 0)
+        Hout[..., k] = torch.einsum('mk, mk -> k', H, B)
+    return Hout, Hpd
+
+
+def var_receiver_forward(z: torch.Tensor, input_gains: torch.Tensor,
+                         output_gains: torch.Tensor, receiver_gains: torch.Tensor,
+                         P: torch.Tensor, direct: torch.Tensor, n_per_group: int
+                         ) -> torch.Tensor:
+    """model.py:569-619 (DiffGFDNVarReceiverPos.forward, MLP-gain branch).
+
+    receiver_gains (B,G) = sigmoid-scaled MLP output; P (K,N,N) c64; direct (B,K) c128."""
+    Bsz = receiver_gains.shape[0]
+    N = input_gains.shape[0]
+    K = len(z)
+    C_init = to_complex(output_gains.expand(Bsz, N, K))                     # :583-585
+    expanded = receiver_gains.repeat_interleave(n_per_group, dim=1)         # gain_filters.py:526
+    Cg = expanded.unsqueeze(-1).repeat(1, 1, K)                             # gain_filters.py:530
+    C = to_complex(Cg) * C_init                                             # :592
+    Bm = to_complex(input_gains.expand(Bsz, N, K))                          # :608-610
+    Htemp = torch.einsum('knb, knm -> kmb', C.permute(-1, 1, 0), P).permute(-1, 1, 0)
+    return torch.einsum('bmk, bmk -> bk', Htemp, Bm) + direct              # :619
+
+
+def single_pos_forward(z, input_gains, output_gains, input_scalars, output_scalars, P,
+                       direct, n_per_group):
+    """model.py:779-836 (DiffGFDNSinglePos.forward, scalar in/out branch)."""
+    N = input_gains.shape[0]
+    K = len(z)
+    G = output_scalars.shape[0]
+    C_init = to_complex(output_gains.expand(N, K))
+    B_init = to_complex(input_gains.expand(N, K))
+    C = to_complex(output_scalars.expand(G, K).repeat_interleave(n_per_group, dim=0)) * C_init
+    Bm = to_complex(input_scalars.expand(G, K).repeat_interleave(n_per_group, dim=0)) * B_init
+    Htemp = torch.einsum('kn, knm -> km', C.permute(-1, 0), P)
+    H = torch.einsum('ki, ik -> k', Htemp, Bm)
+    return H + direct
+
+
+def directional_forward(z, input_gains, output_gains, sh_gains, P, G: int, n_per_group: int):
+    """model.py:1043-1088 (DiffDirectionalFDNVarReceiverPos.forward).
+
+    sh_gains (B,G,n_per_group) already L2-normalised (spatial_sampling/model.py:78-80).
+    Note Htemp = einsum('knm,bnk->bmk') contracts P's FIRST index (P^T b); no d(z)."""
+    Bsz = sh_gains.shape[0]
+    N = input_gains.shape[0]
+    K = len(z)
+    cur = output_gains.reshape(G, n_per_group).unsqueeze(0).unsqueeze(-1)
+    C_init = to_complex(cur.expand(Bsz, G, n_per_group, K))
+    sg = sh_gains.reshape(Bsz, G, n_per_group, 1).repeat(1, 1, 1, K)
+    C = to_complex(sg) * C_init
+    Bm = to_complex(input_gains.expand(Bsz, N, K))
+    Htemp = torch.einsum('knm, bnk -> bmk', P, Bm).reshape(Bsz, G, n_per_group, K)
+    return (C * Htemp).sum(dim=1)
+
+
+def normalise_sh_weights(w: torch.Tensor) -> torch.Tensor:
+    """spatial_sampling/model.py:78-80."""
+    return w / (torch.norm(w, dim=-1, keepdim=True) + 1e-6)
+
+
+def sh_to_directional(analysis_matrix: torch.Tensor, H_sh: torch.Tensor) -> torch.Tensor:
+    """trainer.py:853-865 -- einsum('jl,blk->bjk')."""
+    return torch.einsum('jl, blk -> bjk', to_complex(analysis_matrix), H_sh)
+
+
+# --------------------------------------------------------------------------------------
+# position -> gain MLP  (reference: src/diff_gfdn/dnn.py, gain_filters.py)
+# --------------------------------------------------------------------------------------
+def sinusoidal_encoding(pos: torch.Tensor, num_fourier_features: int) -> torch.Tensor:
+    """dnn.py:89-126 -- output tensor is float32 (torch.zeros default), freqs log-spaced 1..32."""
+    P, F = pos.shape
+    enc = torch.zeros(P, F * num_fourier_features * 2)
+    freqs = torch.exp(torch.linspace(np.log(1.0), np.log(32.0), num_fourier_features))
+    s = 0
+    for k in range(num_fourier_features):
+        enc[:, s:s + 2 * F] = torch.cat((torch.sin(freqs[k] * np.pi * pos),
+                                         torch.cos(freqs[k] * np.pi * pos)), dim=-1)
+        s += 2 * F
+    return enc
+
+
+def mlp_forward(x: torch.Tensor, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]],
+                norms: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
+    """dnn.py:331-400 -- [Linear, LayerNorm, ReLU] x (1+hidden), then Linear."""
+    h = x
+    for i, (W, b) in enumerate(weights[:-1]):
+        h = torch.nn.functional.linear(h, W, b)
+        g, beta = norms[i]
+        h = torch.nn.functional.layer_norm(h, (h.shape[-1],), g, beta)
+        h = torch.relu(h)
+    W, b = weights[-1]
+    return torch.nn.functional.linear(h, W, b)
+
+
+def scaled_sigmoid(x, lo: float, hi: float):
+    """dnn.py:21-36."""
+    return lo + (hi - lo) * (1.0 / (1 + torch.exp(-x)))
+
+
+# --------------------------------------------------------------------------------------
+# losses  (reference: src/diff_gfdn/losses.py, colorless_fdn/losses.py)
+# --------------------------------------------------------------------------------------
+def stft_onesided(rir: torch.Tensor, win_size: int, hop_size: int) -> torch.Tensor:
+    """losses.py:501-535 -- zero-pad to a multiple of hop, periodic Hann (float32 window,
+    as torch.hann_window default), center=False, one-sided, un-normalised."""
+    T = rir.shape[-1]
+    if T % hop_size != 0:
+        extra = hop_size * int(np.ceil(T / hop_size)) - T
+        rir = torch.nn.functional.pad(rir, (0, extra))
+    window = torch.hann_window(win_size)
+    return torch.stft(rir, win_size, hop_length=hop_size, win_length=win_size,
+                      window=window, center=False, normalized=False, onesided=True,
+                      return_complex=True)
+
+
+def edr_from_stft(S: torch.Tensor) -> torch.Tensor:
+    """losses.py:556-575 -- float32 buffer, frame loop of tail sums, db(is_squared)."""
+    edr = torch.zeros(S.shape, dtype=torch.float32)
+    for m in range(S.shape[-1]):
+        edr[..., m] = torch.sum(torch.abs(S[..., m:]) ** 2, axis=-1)
+    return db(edr, is_squared=True)
+
+
+def edr_loss(target: torch.Tensor, achieved: torch.Tensor, win_size: int = 4096,
+             hop_size: int = 2048, reduced_pole_radius: Optional[float] = None,
+             freq_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """losses.py:430-495 -- irfft(n = K) (!), STFT, EDR in dB, per-item normalised L1, summed."""
+    t_rir = torch.fft.irfft(target, target.shape[-1])
+    a_rir = torch.fft.irfft(achieved, achieved.shape[-1])
+    if reduced_pole_radius is not None:
+        a_rir = a_rir * torch.pow(1.0 / reduced_pole_radius, torch.arange(0, a_rir.shape[-1]))
+    t_edr = edr_from_stft(stft_onesided(t_rir, win_size, hop_size))
+    a_edr = edr_from_stft(stft_onesided(a_rir, win_size, hop_size))
+    freq_loss = torch.sum(torch.abs(t_edr - a_edr), dim=-1)
+    if freq_weights is not None:
+        freq_loss = freq_loss * freq_weights
+    if t_edr.ndim == 3:
+        per_item = torch.div(torch.sum(freq_loss, dim=-1),
+                             torch.sum(torch.abs(t_edr), dim=[-1, -2]))
+        return torch.sum(per_item)
+    return torch.div(torch.sum(freq_loss), torch.sum(torch.abs(t_edr)))
+
+
+def edr_frequency_weights(sample_rate: float, win_size: int) -> torch.Tensor:
+    """losses.py:419-428, 49-57 -- inverse scaled sigmoid, 2 below ~1 kHz -> 1 above.
+
+    NB the reference passes (bottom, top) swapped into (top, bottom) slots: reproduced."""
+    freqs = torch.tensor(np.fft.rfftfreq(win_size, d=1.0 / sample_rate))
+    scale, cutoff, top, bottom = 10 ** (-2.5), 1e3, 2.0, 1.0
+    # scaled_shifted_sigmoid_inverse(x, scale_factor, cutoff, top=bottom_arg, bottom=top_arg)
+    t_, b_ = bottom, top
+    return b_ + torch.div((t_ - b_), (1 + torch.exp(scale * (freqs - cutoff))))
+
+
+def schroeder(signal: torch.Tensor) -> torch.Tensor:
+    """losses.py:187-199."""
+    return torch.flip(torch.cumsum(torch.flip(signal ** 2, dims=[-1]), dim=-1), dims=[-1])
+
+
+def edc_loss(target: torch.Tensor, achieved: torch.Tensor, max_ir_len_samps: int,
+             mixing_time_samps: int, mask_index: Optional[torch.Tensor] = None
+             ) -> torch.Tensor:
+    """losses.py:201-238 (broadband branch).  mask_index: kept time indices (the reference
+    draws argwhere(bernoulli(U(0,1))) of shape (M,1) -- pass the same tensor to reproduce)."""
+    L = min(max_ir_len_samps, target.shape[-1])
+    t_rir = torch.fft.irfft(target, target.shape[-1])[..., mixing_time_samps:L]
+    a_rir = torch.fft.irfft(achieved, achieved.shape[-1])[..., mixing_time_samps:L]
+    t_edc = schroeder(t_rir)
+    a_edc = schroeder(a_rir)
+    if mask_index is None:
+        mask_index = torch.arange(0, t_rir.shape[-1], dtype=torch.int32)
+    return torch.mean(torch.abs(db(t_edc[..., mask_index], is_squared=True) -
+                                db(a_edc[..., mask_index], is_squared=True)))
+
+
+def directional_edc_loss(H_pred: torch.Tensor, amps_true: torch.Tensor,
+                         envelopes: torch.Tensor, mixing_time_samps: int,
+                         edc_len_samps: int, mask_index: Optional[torch.Tensor] = None):
+    """losses.py:333-371 -- irfft with default n = 2(K-1); envelopes (S,T) are an INPUT
+    (slope2noise.decay_kernel is an absent dependency: parity unpinned for them)."""
+    pred_rir = torch.fft.irfft(H_pred)[..., mixing_time_samps:edc_len_samps + mixing_time_samps]
+    edc_pred = schroeder(pred_rir)
+    edc_true = torch.einsum('bjk, kt -> bjt', amps_true.to(torch.float32), envelopes)
+    if mask_index is None:
+        mask_index = torch.arange(0, pred_rir.shape[-1], dtype=torch.int32)
+    return torch.mean(torch.abs(db(edc_true[..., mask_index], is_squared=True) -
+                                db(edc_pred[..., mask_index], is_squared=True)))
+
+
+def sparsity_loss(A: torch.Tensor) -> torch.Tensor:
+    """colorless_fdn/losses.py:7-17."""
+    N = A.shape[-1]
+    return -(torch.sum(torch.abs(A)) - (N * np.sqrt(N))) / (N * (np.sqrt(N) - 1))
+
+
+def mse_loss(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
+    """colorless_fdn/losses.py:20-41 (1-D branch)."""
+    return torch.mean(torch.pow(torch.abs(y_pred) - torch.abs(y_true), 2), dim=-1)
+
+
+def amse_loss(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
+    """colorless_fdn/losses.py:44-73 (1-D branch): exponent 4 where |y|-|t| > 1 else 2."""
+    gT = 2 * torch.ones(y_pred.shape, dtype=torch.float32)
+    gT = gT + 2 * torch.gt(torch.abs(y_pred) - torch.abs(y_true), 1).type(torch.uint8)
+    return torch.mean(torch.pow(torch.abs(y_pred) - torch.abs(y_true), gT), dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# one full model evaluation + trainer step  (reference: trainer.py:259-332, 452-477)
+# --------------------------------------------------------------------------------------
+class GridModelParams:
+    """Plain container of what DiffGFDNVarReceiverPos holds (state_dict surface, App. B)."""
+
+    def __init__(self, sample_rate: float, delays: Sequence[int], num_groups: int,
+                 input_gains: torch.Tensor, output_gains: torch.Tensor, M: torch.Tensor,
+                 alpha: torch.Tensor, common_decay_times: np.ndarray,
+                 mlp_weights, mlp_norms, num_fourier_features: int):
+        self.sample_rate = sample_rate
+        self.delays = torch.tensor(list(delays), dtype=torch.float32)
+        self.num_groups = num_groups
+        self.n_per_group = len(delays) // num_groups
+        self.input_gains = input_gains
+        self.output_gains = output_gains
+        self.M = M
+        self.alpha = alpha
+        self.common_decay_times = common_decay_times
+        self.mlp_weights = mlp_weights
+        self.mlp_norms = mlp_norms
+        self.num_fourier_features = num_fourier_features
+
+    def gamma(self) -> torch.Tensor:
+        """model.py:155-163 -- float64 numpy db2lin, flattened into a (float64) tensor."""
+        n = self.n_per_group
+        cdt = np.squeeze(self.common_decay_times)
+        dl = self.delays.numpy().astype(np.int64)
+        vals = [decay_times_to_gain_per_sample(cdt[i], dl[i * n:(i + 1) * n], self.sample_rate).tolist()
+                for i in range(self.num_groups)]
+        return torch.flatten(torch.tensor(vals))
+
+    def receiver_gains(self, norm_pos: torch.Tensor) -> torch.Tensor:
+        """gain_filters.py:497-524."""
+        enc = sinusoidal_encoding(norm_pos, self.num_fourier_features)
+        raw = mlp_forward(enc, self.mlp_weights, self.mlp_norms)
+        return scaled_sigmoid(raw.view(-1), -1.0, 1.0).view(norm_pos.shape[0], self.num_groups)
+
+
+def grid_model_forward(p: GridModelParams, batch: Dict[str, torch.Tensor],
+                       use_colorless_loss: bool = True):
+    """model.py:569-625."""
+    z = batch['z_values']
+    A = coupled_feedback_matrix(p.M, p.alpha)
+    P = feedback_loop_forward(z, p.delays, p.gamma(), A)
+    g = p.receiver_gains(batch['norm_listener_position'])
+    H = var_receiver_forward(z, p.input_gains, p.output_gains, g, P,
+                             batch['target_early_response'], p.n_per_group)
+    if use_colorless_loss:
+        return H, sub_fdn_output(z, p.M, p.input_gains, p.output_gains, p.delays)
+    return H
+
+
+def grid_losses(p: GridModelParams, batch, H, H_sub, *, edr_weight=1.0, edc_weight=1.0,
+                spectral_weight=1.0, sparsity_weight=1.0, use_asym=False,
+                subband_filter: Optional[torch.Tensor] = None,
+                edc_mask: Optional[torch.Tensor] = None, mixing_time_ms: float = 20.0):
+    """trainer.py:259-315 (omni branch) incl. the sparsity-overwrite quirk (:305-308)."""
+    fs = p.sample_rate
+    if subband_filter is not None:
+        H = H * subband_filter                                              # trainer.py:459
+    if p.common_decay_times is None:
+        max_ms = 2000
+    else:
+        max_ms = float(np.max(p.common_decay_times)) * 1e3                  # trainer.py:56-59
+    tgt = batch['target_rir_response']
+    losses = {
+        'edc_loss': edc_weight * edc_loss(tgt, H, ms_to_samps(max_ms, fs),
+                                          ms_to_samps(mixing_time_ms, fs), edc_mask),
+        'edr_loss': edr_weight * edr_loss(tgt, H),
+    }
+    if H_sub is not None:
+        spec = 0.0
+        spars = 0.0
+        crit = amse_loss if use_asym else mse_loss
+        for k in range(p.num_groups):
+            hk = H_sub[0][..., k]
+            spec = spec + spectral_weight * crit(hk, torch.ones_like(hk))
+            spars = sparsity_weight * sparsity_loss(ortho_param(p.M[k]))   # overwritten!
+        losses['spectral_loss'] = spec
+        losses['sparsity_loss'] = spars
+    return losses
+
+
+def normalize_io_gains(p: GridModelParams, H_sub) -> None:
+    """trainer.py:317-332 -- b_n, c_n /= (mean_k |Hout[k,g]|^2)^(1/4), in place."""
+    with torch.no_grad():
+        energy = torch.mean(torch.pow(torch.abs(H_sub[0]), 2), dim=0)
+        n = p.n_per_group
+        for prm in (p.input_gains, p.output_gains):
+            for k in range(p.num_groups):
+                prm.data[k * n:(k + 1) * n] /= torch.pow(energy[k], 1 / 4)

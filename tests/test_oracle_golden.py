@@ -1,0 +1,209 @@
+"""Pin the CPU oracle (oracle/gfdn_oracle.py) to the golden vectors generated from the
+reference itself (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gfdn_oracle as orc
+from tests.helpers import batch_from, load, mlp_from_state, rel_err
+
+TOL = 1e-9          # float64 restatement vs float64 reference
+TOL32 = 2e-5        # where the reference itself runs in float32 / complex64
+
+
+def grid_params(fx, prefix="sd_", nff=4, requires_grad=False):
+    lin, norm = mlp_from_state(fx, prefix)
+    t = lambda k: torch.tensor(fx[prefix + k]).clone().requires_grad_(requires_grad)
+    if requires_grad:
+        lin = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in lin]
+        norm = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in norm]
+    alpha = torch.tensor(fx[prefix + "feedback_loop.alpha"]).clone()
+    if requires_grad and not bool(fx["zero_coupling"]):
+        alpha.requires_grad_(True)
+    return orc.GridModelParams(float(fx["fs"]), fx["delays"].tolist(), int(fx["G"]),
+                               t("input_gains"), t("output_gains"), t("feedback_loop.M"), alpha,
+                               fx["T60"][None, :], lin, norm, nff)
+
+
+@pytest.mark.parametrize("tag", ["zc", "cp", "g1"])
+def test_f1_feedback_loop(tag):
+    fx = load("f1_feedback_loop.npz")
+    M = torch.tensor(fx[f"{tag}_M"]).requires_grad_(True)
+    alpha = torch.tensor(fx[f"{tag}_alpha"]).requires_grad_(tag == "cp")
+    A = orc.coupled_feedback_matrix(M, alpha)
+    assert rel_err(A.detach(), fx[f"{tag}_A"]) < 1e-6
+    P = orc.feedback_loop_forward(torch.tensor(fx["z"]), torch.tensor(fx[f"{tag}_delays"], dtype=torch.float32),
+                                  torch.tensor(fx[f"{tag}_gamma"]), A)
+    assert P.dtype == torch.complex64
+    assert rel_err(P.detach(), fx[f"{tag}_P"]) < TOL32
+    (P.abs() ** 2).sum().backward()
+    assert rel_err(M.grad, fx[f"{tag}_grad_M"]) < 1e-4
+    if tag == "cp":
+        assert rel_err(alpha.grad, fx[f"{tag}_grad_alpha"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz"])
+def test_f2_forward(name):
+    fx = load(name)
+    p = grid_params(fx)
+    batch = batch_from(fx)
+    H, (Hout, Hpd) = orc.grid_model_forward(p, batch)
+    assert rel_err(p.receiver_gains(batch["norm_listener_position"]).detach(), fx["receiver_gains"]) < 1e-6
+    assert H.dtype == torch.complex128
+    assert rel_err(H.detach(), fx["H"]) < TOL32
+    assert rel_err(Hout.detach(), fx["Hout"]) < TOL32
+    n = int(fx["nper"])
+    for g in range(int(fx["G"])):
+        assert rel_err(Hpd[g * n:(g + 1) * n, :, g].detach(), fx["Hout_per_del_nz"][g]) < TOL32
+
+
+@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz"])
+def test_f3_losses(name):
+    fx = load(name)
+    fs = float(fx["fs"])
+    tgt = torch.tensor(fx["batch_target_rir_response"])
+    H = torch.tensor(fx["H"]).requires_grad_(True)
+    l = orc.edr_loss(tgt, H, int(fx["win"]), int(fx["hop"]))
+    g, = torch.autograd.grad(l, H)
+    assert abs(l.item() - float(fx["loss_edr"])) < 1e-6 * abs(float(fx["loss_edr"]))
+    assert rel_err(g, fx["grad_edr_H"]) < 1e-5
+    max_samps = orc.ms_to_samps(float(np.max(fx["T60"])) * 1e3, fs)
+    l = orc.edc_loss(tgt, H, max_samps, orc.ms_to_samps(20.0, fs))
+    g, = torch.autograd.grad(l, H)
+    assert abs(l.item() - float(fx["loss_edc"])) < TOL * abs(float(fx["loss_edc"])) + 1e-12
+    assert rel_err(g, fx["grad_edc_H"]) < 1e-8
+    Hout = torch.tensor(fx["Hout"]).requires_grad_(True)
+    for nm, fn in (("mse", orc.mse_loss), ("amse", orc.amse_loss)):
+        for k in range(int(fx["G"])):
+            l = fn(Hout[..., k], torch.ones_like(Hout[..., k]))
+            g, = torch.autograd.grad(l, Hout)
+            assert abs(l.item() - fx[f"loss_{nm}"][k]) < 1e-6 * abs(fx[f"loss_{nm}"][k])
+            assert rel_err(g[..., k], fx[f"grad_{nm}_Hout"][k]) < 1e-5
+    M = torch.tensor(fx["sd_feedback_loop.M"])
+    for k in range(int(fx["G"])):
+        assert abs(orc.sparsity_loss(orc.ortho_param(M[k])).item() - fx["loss_sparsity"][k]) < 1e-6
+
+
+@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False)])
+def test_f4_train_step(name, asym):
+    """normalize + losses + backward: per-loss values and every parameter gradient."""
+    fx = load(name)
+    p = grid_params(fx, requires_grad=True)
+    batch = batch_from(fx)
+    with torch.no_grad():
+        _, Hs = orc.grid_model_forward(p, batch)
+    orc.normalize_io_gains(p, Hs)
+    assert rel_err(p.input_gains.detach(), fx["sdn_input_gains"]) < 1e-5
+    assert rel_err(p.output_gains.detach(), fx["sdn_output_gains"]) < 1e-5
+    H, Hs = orc.grid_model_forward(p, batch)
+    import tests.test_oracle_golden as me  # noqa: F401
+    # scaled STFT for the small cases, as in gen_golden
+    losses = grid_losses_scaled(p, batch, H, Hs, fx, asym)
+    total = sum(losses.values())
+    total.backward()
+    for k, v in losses.items():
+        ref = float(fx["step_" + k])
+        assert abs(float(v.detach()) - ref) < 2e-5 * abs(ref) + 1e-9, (k, float(v.detach()), ref)
+    assert abs(total.item() - float(fx["step_total"])) < 2e-5 * abs(float(fx["step_total"]))
+    assert rel_err(p.input_gains.grad, fx["grad_input_gains"]) < 2e-4
+    assert rel_err(p.output_gains.grad, fx["grad_output_gains"]) < 2e-4
+    assert rel_err(p.M.grad, fx["grad_feedback_loop.M"]) < 2e-4
+    if not bool(fx["zero_coupling"]):
+        assert rel_err(p.alpha.grad, fx["grad_feedback_loop.alpha"]) < 2e-4
+    lin_idx = sorted(int(k.split(".")[-2]) for k in fx if k.startswith("grad_output_scalars.mlp.model.") and k.endswith("weight"))
+    li = ni = 0
+    for i in lin_idx:
+        gw = fx[f"grad_output_scalars.mlp.model.{i}.weight"]
+        if gw.ndim == 2:
+            assert rel_err(p.mlp_weights[li][0].grad, gw) < 5e-4
+            li += 1
+        else:
+            assert rel_err(p.mlp_norms[ni][0].grad, gw) < 5e-4
+            ni += 1
+
+
+def grid_losses_scaled(p, batch, H, Hs, fx, asym):
+    """orc.grid_losses with the fixture's scaled-down STFT window (weights as gen_golden F4)."""
+    fs = p.sample_rate
+    tgt = batch["target_rir_response"]
+    max_samps = orc.ms_to_samps(float(np.max(p.common_decay_times)) * 1e3, fs)
+    out = {"edc_loss": 10.0 * orc.edc_loss(tgt, H, max_samps, orc.ms_to_samps(20.0, fs)),
+           "edr_loss": 1.0 * orc.edr_loss(tgt, H, int(fx["win"]), int(fx["hop"]))}
+    crit = orc.amse_loss if asym else orc.mse_loss
+    spec = 0.0
+    for k in range(p.num_groups):
+        hk = Hs[0][..., k]
+        spec = spec + 1.0 * crit(hk, torch.ones_like(hk))
+        spars = 2.0 * orc.sparsity_loss(orc.ortho_param(p.M[k]))
+    out["spectral_loss"] = spec
+    out["sparsity_loss"] = spars
+    return out
+
+
+def test_f3b_subband_mask_weights():
+    fx = load("f3b_subband_mask.npz")
+    fs = float(fx["fs"])
+    H = torch.tensor(fx["H"]).requires_grad_(True)
+    tgt = torch.tensor(fx["target"])
+    Hs = H * torch.tensor(fx["filt"])
+    w = orc.edr_frequency_weights(fs, 256)
+    assert rel_err(w, fx["freq_weights"]) < 1e-12
+    l = orc.edr_loss(tgt, Hs, 256, 128, freq_weights=w)
+    g, = torch.autograd.grad(l, H, retain_graph=True)
+    assert abs(l.item() - float(fx["loss_edr_w"])) < 1e-6 * abs(float(fx["loss_edr_w"]))
+    assert rel_err(g, fx["grad_edr_w"]) < 1e-5
+    max_samps = orc.ms_to_samps(float(np.max(fx["T60"])) * 1e3, fs)
+    l = orc.edc_loss(tgt, Hs, max_samps, orc.ms_to_samps(20.0, fs), torch.tensor(fx["edc_mask_index"]))
+    g, = torch.autograd.grad(l, H)
+    assert abs(l.item() - float(fx["loss_edc_masked"])) < TOL * abs(float(fx["loss_edc_masked"]))
+    assert rel_err(g, fx["grad_edc_masked"]) < 1e-8
+
+
+def test_f5_single_pos():
+    fx = load("f5_single_pos.npz")
+    M = torch.tensor(fx["sd_feedback_loop.M"])
+    alpha = torch.tensor(fx["sd_feedback_loop.alpha"])
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    n = int(fx["nper"])
+    G = int(fx["G"])
+    A = orc.coupled_feedback_matrix(M, alpha)
+    z = torch.tensor(fx["z"])
+    gamma = torch.tensor(fx["sd_delay_filters"])
+    P = orc.feedback_loop_forward(z, delays, gamma, A)
+    H = orc.single_pos_forward(z, torch.tensor(fx["sd_input_gains"]), torch.tensor(fx["sd_output_gains"]),
+                               torch.tensor(fx["sd_input_scalars"]), torch.tensor(fx["sd_output_scalars"]),
+                               P, torch.tensor(fx["early"]), n)
+    assert rel_err(H, fx["H"]) < TOL32
+    Hout, _ = orc.sub_fdn_output(z, M, torch.tensor(fx["sd_input_gains"]), torch.tensor(fx["sd_output_gains"]), delays)
+    assert rel_err(Hout, fx["Hout"]) < TOL32
+    Hd = torch.tensor(fx["H"]).requires_grad_(True)
+    l = orc.edr_loss(torch.tensor(fx["target"]), Hd, 256, 128)
+    g, = torch.autograd.grad(l, Hd)
+    assert abs(l.item() - float(fx["loss_edr"])) < 1e-6 * abs(float(fx["loss_edr"]))
+    assert rel_err(g, fx["grad_edr_H"]) < 1e-5
+
+
+def test_f6_directional():
+    fx = load("f6_directional.npz")
+    fs = float(fx["fs"])
+    G, n = int(fx["G"]), int(fx["nper"])
+    batch = batch_from(fx)
+    z = batch["z_values"]
+    M = torch.tensor(fx["sd_feedback_loop.M"])
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    A = orc.coupled_feedback_matrix(M, torch.tensor(fx["sd_feedback_loop.alpha"]))
+    P = orc.feedback_loop_forward(z, delays, torch.tensor(fx["sd_delay_filters"]), A)
+    lin, norm = mlp_from_state(fx, root="sh_output_scalars.mlp.model.")
+    enc = orc.sinusoidal_encoding(batch["norm_listener_position"], 3)
+    w = orc.mlp_forward(enc, lin, norm).reshape(-1, G, n)
+    w = orc.normalise_sh_weights(w)
+    assert rel_err(w.detach(), fx["sh_gains"]) < 1e-5
+    H_sh = orc.directional_forward(z, torch.tensor(fx["sd_input_gains"]), torch.tensor(fx["sd_output_gains"]),
+                                   w, P, G, n)
+    assert rel_err(H_sh.detach(), fx["H_sh"]) < TOL32
+    H_dir = orc.sh_to_directional(torch.tensor(fx["analysis_matrix"]), H_sh)
+    assert rel_err(H_dir.detach(), fx["H_dir"]) < TOL32
+    edc_len = orc.ms_to_samps(float(fx["edc_len_ms"]), fs)
+    l = orc.directional_edc_loss(H_dir, torch.tensor(fx["amps"]), torch.tensor(fx["envelopes"]),
+                                 orc.ms_to_samps(20.0, fs), edc_len)
+    assert abs(l.item() - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
