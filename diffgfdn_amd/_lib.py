@@ -1,0 +1,77 @@
+"""ctypes binding of the C-ABI shared library (include/diffgfdn_hip.h).
+
+The library is built in-tree by ``make -C diffgfdn_amd/csrc`` (``__graft_entry__.build``) into
+``diffgfdn_amd/lib/libdiffgfdn_hip.so``.  There is NO fallback: if the library is missing or a
+call returns an error, a ``RuntimeError`` is raised -- the product path never silently runs
+anything else.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
+ABI_VERSION = 1
+
+_P = c_void_p
+
+# name -> (restype, [argtypes])   -- mirrors include/diffgfdn_hip.h line by line
+SIGNATURES = {
+    "gfdn_abi_version": (c_int, []),
+    "gfdn_zprep": (c_int, [_P, c_int, _P, _P, _P]),
+    "gfdn_solve_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "gfdn_solve_bwd_work_bytes": (c_size_t, [c_int, c_int]),
+    "gfdn_solve_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "gfdn_compose_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
+    "gfdn_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfdn_compose_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_compose_sh_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
+    "gfdn_compose_sh_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gfdn_compose_sh_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_spectral_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "gfdn_bluestein_table_bytes": (c_size_t, [c_int]),
+    "gfdn_bluestein_table_init": (c_int, [c_int, _P]),
+    "gfdn_bluestein_work_bytes": (c_size_t, [c_int, c_int]),
+    "gfdn_irfft_odd_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_odd_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),
+    "gfdn_irfft_pow2_fwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_pow2_bwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_stft_nframes": (c_int, [c_int, c_int]),
+    "gfdn_stft_power": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gfdn_stft_power_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "gfdn_edr_work_bytes": (c_size_t, [c_int, c_int]),
+    "gfdn_edr_target": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "gfdn_edr_loss": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "gfdn_edc_target": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach the signatures.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"diffgfdn_amd: HIP library not built ({LIB_PATH}); run `make -C diffgfdn_amd/csrc` "
+            "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.gfdn_abi_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError(f"diffgfdn_amd: ABI version mismatch (library {ver}, python {ABI_VERSION})")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported size"}.get(rc, f"hipError_t {rc}")
+        raise RuntimeError(f"diffgfdn_amd: {what} failed: {kind}")

@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 kernels of the DiffGFDN hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/diffgfdn_hip.h"
+
+#define GFDN_LAUNCH_CHECK()                      \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+#define F32_EPS 1.1920928955078125e-07f
+#define TEN_OVER_LN10 4.3429448190325175f
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cinv(float2 a) {
+  float d = 1.0f / (a.x * a.x + a.y * a.y);
+  return make_float2(a.x * d, -a.y * d);
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// 10*log10(|x| + eps_f32) clipped below at -200 dB  (reference utils.py:32-40)
+__device__ __forceinline__ float db_pow(float x) {
+  float y = 10.0f * log10f(fabsf(x) + F32_EPS);
+  return fmaxf(y, -200.0f);
+}
+
+// sum over the 64 lanes of a wavefront
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// deterministic block sum (blockDim.x multiple of 64, <= 1024); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* lds /* >= 16 floats */) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += lds[i];
+  return s;
+}
+
+// dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
+template <typename K>
+static inline int ensure_dyn_lds(K kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline int next_pow2(int v) { return 1 << ilog2(v); }

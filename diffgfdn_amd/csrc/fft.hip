@@ -1,0 +1,522 @@
+// FFT kernels of the loss front end, for gfx950.
+//
+// (1) irfft(X, n) with n ODD (losses.py:207-213, :442-445 call torch.fft.irfft(X, n = K) with
+//     K = nfft/2 + 1 = 65 537, a Fermat prime; only bins 0..(n-1)/2 are used).  Implemented as a
+//     one-sided Bluestein chirp-z transform: the (n+1)/2 input bins are chirp-modulated,
+//     circularly convolved with the conjugate chirp by power-of-two FFTs of length
+//     L >= n + (n-1)/2 (2^17 at n = 65 537), de-chirped, and the real part kept.  The length-L
+//     FFT is a four-step L = L1 x L2 factorisation; because forward FFT, spectrum product and
+//     inverse FFT act on the same L2-rows, they are fused into ONE row kernel and the
+//     spectrum is never transposed:
+//        k_blu_col_fwd : chirp * input, FFT over n1 (column tiles through LDS), twiddle
+//        k_blu_row     : FFT over n2, * chirp spectrum, inverse FFT over k2, conj twiddle
+//        k_blu_col_inv : inverse FFT over k1, de-chirp, real part / adjoint epilogue
+//     The adjoint (backward) runs the same three kernels with conjugated chirps.
+// (2) |STFT|^2 with a periodic Hann window, hop = win/2, center = False (losses.py:501-535):
+//     two real frames are packed into one complex FFT held in LDS; the adjoint recomputes
+//     the frame spectra and scatters window * gradient with atomic adds (two frames per
+//     sample, so the sum is order-independent).
+//
+// All FFTs are radix-4 (+ one radix-2) Stockham autosort passes in LDS with ping-pong
+// buffers.  Twiddles come from a quarter-period table built in LDS with sincospif (exact
+// argument reduction for power-of-two lengths), w2 = w1^2, w3 = w1 w2.
+#include "common.h"
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// LDS Stockham FFT.  x, y: ping-pong buffers with `nseq` sequences of length n, sequence
+// stride ss.  tw4: quarter table, tw4[j] = exp(-2 pi i j / tn), j < tn/4, tn >= n (pow2).
+// inverse = true uses conjugated twiddles (un-normalised).  Returns the buffer that holds the
+// result.  Every thread of the block must call it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq, int ss,
+                                           bool inverse, const float2* tw4, int tn) {
+  const int nthr = blockDim.x;
+  int nn = n, s = 1, ls = 0;  // ls = log2(s)
+  const float sgn = inverse ? -1.0f : 1.0f;
+  while (nn >= 4) {
+    const int m = nn >> 2;
+    const int tws = tn / nn;
+    const int per = n >> 2;  // butterflies per sequence
+    for (int idx = threadIdx.x; idx < nseq * per; idx += nthr) {
+      const int seq = idx / per, i = idx - seq * per;
+      const int p = i >> ls, q = i & (s - 1);
+      float2 w1 = tw4[p * tws];
+      w1.y *= sgn;
+      const float2 w2 = cmul(w1, w1);
+      const float2 w3 = cmul(w1, w2);
+      const float2* xb = x + seq * ss;
+      float2* yb = y + seq * ss;
+      const float2 a = xb[q + s * p];
+      const float2 b = xb[q + s * (p + m)];
+      const float2 c = xb[q + s * (p + 2 * m)];
+      const float2 d = xb[q + s * (p + 3 * m)];
+      const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d);
+      float2 bmd = csub(b, d);
+      // forward: -j (b - d);  inverse: +j (b - d)
+      float2 jbmd = make_float2(sgn * bmd.y, -sgn * bmd.x);  // = -j*bmd (fwd)
+      yb[q + s * (4 * p + 0)] = cadd(apc, bpd);
+      yb[q + s * (4 * p + 1)] = cmul(w1, cadd(amc, jbmd));
+      yb[q + s * (4 * p + 2)] = cmul(w2, csub(apc, bpd));
+      yb[q + s * (4 * p + 3)] = cmul(w3, csub(amc, jbmd));
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+    nn = m;
+    s <<= 2;
+    ls += 2;
+  }
+  if (nn == 2) {
+    const int per = n >> 1;  // here s == n/2, p == 0
+    for (int idx = threadIdx.x; idx < nseq * per; idx += nthr) {
+      const int seq = idx / per, q = idx - seq * per;
+      const float2* xb = x + seq * ss;
+      float2* yb = y + seq * ss;
+      const float2 a = xb[q], b = xb[q + s];
+      yb[q] = cadd(a, b);
+      yb[q + s] = csub(a, b);
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
+// quarter twiddle table for length tn into LDS (tn/4 entries; at least 1)
+__device__ __forceinline__ void build_tw4(float2* tw4, int tn) {
+  const int cnt = tn >= 4 ? tn / 4 : 1;
+  for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+    float s, c;
+    sincospif(2.0f * (float)j / (float)tn, &s, &c);
+    tw4[j] = make_float2(c, -s);
+  }
+}
+
+// W_L^e = exp(-2 pi i e / L) from a two-level table: hi[e >> LOBITS] * lo[e & (2^LOBITS - 1)]
+#define TW_LOBITS 8
+__device__ __forceinline__ void build_tw2(float2* hi, float2* lo, int L) {
+  const int nlo = L < (1 << TW_LOBITS) ? L : (1 << TW_LOBITS);
+  const int nhi = L / nlo;
+  for (int j = threadIdx.x; j < nlo; j += blockDim.x) {
+    float s, c;
+    sincospif(2.0f * (float)j / (float)L, &s, &c);
+    lo[j] = make_float2(c, -s);
+  }
+  for (int j = threadIdx.x; j < nhi; j += blockDim.x) {
+    float s, c;
+    sincospif(2.0f * (float)j / (float)nhi, &s, &c);
+    hi[j] = make_float2(c, -s);
+  }
+}
+__device__ __forceinline__ float2 tw2(const float2* hi, const float2* lo, int e, int L) {
+  const int nlo = L < (1 << TW_LOBITS) ? L : (1 << TW_LOBITS);
+  return cmul(hi[e / nlo], lo[e & (nlo - 1)]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Bluestein geometry + host-side table construction
+// ------------------------------------------------------------------------------------------
+struct BluGeom {
+  int n, nin, L, L1, L2;
+};
+static BluGeom blu_geom(int n) {
+  BluGeom g;
+  g.n = n;
+  g.nin = (n - 1) / 2 + 1;
+  int L = 16;
+  while (L < n + g.nin - 1) L <<= 1;
+  g.L = L;
+  int p = ilog2(L);
+  g.L1 = 1 << (p / 2);
+  g.L2 = L / g.L1;
+  return g;
+}
+
+static void host_fft(std::vector<std::complex<double>>& a) {  // in-place radix-2, forward
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t i = 0; i < n; i += len) {
+      for (size_t k = 0; k < len / 2; ++k) {
+        double ang = -2.0 * M_PI * (double)k / (double)len;
+        std::complex<double> w(cos(ang), sin(ang));
+        std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+        a[i + k] = u + v;
+        a[i + k + len / 2] = u - v;
+      }
+    }
+  }
+}
+
+extern "C" size_t gfdn_bluestein_table_bytes(int n) {
+  if (n < 3 || (n & 1) == 0) return 0;
+  BluGeom g = blu_geom(n);
+  return ((size_t)g.n + (size_t)g.L) * sizeof(float2);
+}
+
+extern "C" size_t gfdn_bluestein_work_bytes(int n, int batch) {
+  if (n < 3 || (n & 1) == 0 || batch <= 0) return 0;
+  BluGeom g = blu_geom(n);
+  return (size_t)batch * g.L * sizeof(float2);
+}
+
+// table = [ chirp w_t = exp(+i pi t^2 / n), t < n | chat[k1*L2 + k2] = FFT_L(conj chirp kernel)[k1 + L1 k2] ]
+extern "C" int gfdn_bluestein_table_init(int n, void* table) {
+  if (n < 3 || (n & 1) == 0 || !table) return GFDN_E_BADARG;
+  BluGeom g = blu_geom(n);
+  std::vector<float2> host((size_t)g.n + g.L);
+  std::vector<std::complex<double>> ker(g.L, std::complex<double>(0.0, 0.0));
+  auto chirp = [&](long long m) {
+    long long r = (long long)(((unsigned long long)(m * m)) % (unsigned long long)(2LL * n));
+    double ang = M_PI * (double)r / (double)n;
+    return std::complex<double>(cos(ang), sin(ang));
+  };
+  for (int t = 0; t < n; ++t) {
+    std::complex<double> w = chirp(t);
+    host[t] = make_float2((float)w.real(), (float)w.imag());
+  }
+  // kernel c_m = conj(w_m), m in [-(nin-1), n-1], placed circularly
+  for (int m = -(g.nin - 1); m <= n - 1; ++m) {
+    long long am = m < 0 ? -m : m;
+    ker[(size_t)((m + g.L) % g.L)] = std::conj(chirp(am));
+  }
+  host_fft(ker);
+  for (int k1 = 0; k1 < g.L1; ++k1)
+    for (int k2 = 0; k2 < g.L2; ++k2) {
+      std::complex<double> v = ker[(size_t)k1 + (size_t)g.L1 * k2];
+      host[(size_t)g.n + (size_t)k1 * g.L2 + k2] = make_float2((float)v.real(), (float)v.imag());
+    }
+  hipError_t e = hipMemcpy(table, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice);
+  return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------
+// Bluestein kernels.  Column tile: TC adjacent columns n2, LDS layout [col][row] (stride L1+1).
+// ------------------------------------------------------------------------------------------
+#define BLU_TC 8
+#define BLU_TR 4
+
+struct BluArgs {
+  BluGeom g;
+  const float2* chirp;  // n
+  const float2* chat;   // L, [k1][k2]
+  float2* work;         // batch * L
+  int adjoint;          // 0: X -> x ; 1: gx -> gX
+  // forward: in = X (complex, ld_in), out = x (real, ld_out); adjoint: in = gx (real), out = gX (complex)
+  const void* in;
+  int ld_in;
+  void* out;
+  int ld_out;
+};
+
+extern __shared__ float2 dyn_lds[];
+
+__global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
+  const BluGeom g = a.g;
+  const int L1 = g.L1, L2 = g.L2, L = g.L;
+  const int tc = L2 < BLU_TC ? L2 : BLU_TC;
+  const int ss = L1 + 1;
+  float2* bufA = dyn_lds;
+  float2* bufB = bufA + tc * ss;
+  float2* tw4 = bufB + tc * ss;          // L1/4 (>=1)
+  float2* thi = tw4 + (L1 >= 4 ? L1 / 4 : 1);
+  float2* tlo = thi + (L >> TW_LOBITS > 0 ? (L >> TW_LOBITS) : 1);
+  const int b = blockIdx.y, c0 = blockIdx.x * tc;
+  build_tw4(tw4, L1);
+  build_tw2(thi, tlo, L);
+  // load + chirp
+  for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
+    const int n1 = idx / tc, cc = idx - n1 * tc;
+    const int t = n1 * L2 + c0 + cc;
+    float2 v = make_float2(0.f, 0.f);
+    if (!a.adjoint) {
+      if (t < g.nin) {
+        float2 X = ((const float2*)a.in)[(size_t)b * a.ld_in + t];
+        if (t == 0) X = make_float2(0.5f * X.x, 0.f);   // X'_0 = Re X_0 (factor 2 applied at the end)
+        v = cmul(X, a.chirp[t]);
+      }
+    } else {
+      if (t < g.n) {
+        float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
+        float2 w = a.chirp[t];
+        v = make_float2(gx * w.x, -gx * w.y);           // gx * conj(w_t)
+      }
+    }
+    bufA[cc * ss + n1] = v;
+  }
+  __syncthreads();
+  float2* r = lds_fft(bufA, bufB, L1, tc, ss, false, tw4, L1);
+  // twiddle W_L^{n2 k1}, store [k1][n2]
+  float2* wk = a.work + (size_t)b * L;
+  for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
+    const int k1 = idx / tc, cc = idx - k1 * tc;
+    const int n2 = c0 + cc;
+    float2 v = cmul(r[cc * ss + k1], tw2(thi, tlo, (int)(((long long)n2 * k1) & (L - 1)), L));
+    wk[(size_t)k1 * L2 + n2] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_blu_row(BluArgs a) {
+  const BluGeom g = a.g;
+  const int L1 = g.L1, L2 = g.L2, L = g.L;
+  const int tr = L1 < BLU_TR ? L1 : BLU_TR;
+  const int ss = L2;
+  float2* bufA = dyn_lds;
+  float2* bufB = bufA + tr * ss;
+  float2* tw4 = bufB + tr * ss;
+  float2* thi = tw4 + (L2 >= 4 ? L2 / 4 : 1);
+  float2* tlo = thi + (L >> TW_LOBITS > 0 ? (L >> TW_LOBITS) : 1);
+  const int b = blockIdx.y, r0 = blockIdx.x * tr;
+  build_tw4(tw4, L2);
+  build_tw2(thi, tlo, L);
+  float2* wk = a.work + (size_t)b * L + (size_t)r0 * L2;
+  for (int idx = threadIdx.x; idx < tr * L2; idx += blockDim.x) bufA[idx] = wk[idx];
+  __syncthreads();
+  float2* r = lds_fft(bufA, bufB, L2, tr, ss, false, tw4, L2);
+  float2* o = (r == bufA) ? bufB : bufA;
+  const float2* chat = a.chat + (size_t)r0 * L2;
+  for (int idx = threadIdx.x; idx < tr * L2; idx += blockDim.x) {
+    float2 ch = chat[idx];
+    if (a.adjoint) ch.y = -ch.y;
+    r[idx] = cmul(r[idx], ch);
+  }
+  __syncthreads();
+  float2* r2 = lds_fft(r, o, L2, tr, ss, true, tw4, L2);
+  for (int idx = threadIdx.x; idx < tr * L2; idx += blockDim.x) {
+    const int rr = idx / L2, n2 = idx - rr * L2;
+    const int k1 = r0 + rr;
+    float2 w = tw2(thi, tlo, (int)(((long long)n2 * k1) & (L - 1)), L);
+    wk[idx] = cmulc(r2[idx], w);   // * conj twiddle
+  }
+}
+
+__global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
+  const BluGeom g = a.g;
+  const int L1 = g.L1, L2 = g.L2, L = g.L;
+  const int tc = L2 < BLU_TC ? L2 : BLU_TC;
+  const int ss = L1 + 1;
+  float2* bufA = dyn_lds;
+  float2* bufB = bufA + tc * ss;
+  float2* tw4 = bufB + tc * ss;
+  const int b = blockIdx.y, c0 = blockIdx.x * tc;
+  build_tw4(tw4, L1);
+  const float2* wk = a.work + (size_t)b * L;
+  for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
+    const int k1 = idx / tc, cc = idx - k1 * tc;
+    bufA[cc * ss + k1] = wk[(size_t)k1 * L2 + c0 + cc];
+  }
+  __syncthreads();
+  float2* r = lds_fft(bufA, bufB, L1, tc, ss, true, tw4, L1);
+  const float base = 1.0f / ((float)g.n * (float)L);
+  for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
+    const int n1 = idx / tc, cc = idx - n1 * tc;
+    const int t = n1 * L2 + c0 + cc;
+    const float2 v = r[cc * ss + n1];
+    if (!a.adjoint) {
+      if (t < g.n) {
+        const float2 w = a.chirp[t];
+        ((float*)a.out)[(size_t)b * a.ld_out + t] = 2.0f * base * (v.x * w.x - v.y * w.y);
+      }
+    } else {
+      if (t < a.ld_out) {
+        float2 o = make_float2(0.f, 0.f);
+        if (t < g.nin) {
+          const float2 w = a.chirp[t];
+          o = cmulc(v, w);                           // conj(w_k) * conv
+          if (t == 0) o = make_float2(o.x * base, 0.f);
+          else o = cscale(o, 2.0f * base);
+        }
+        ((float2*)a.out)[(size_t)b * a.ld_out + t] = o;
+      }
+    }
+  }
+}
+
+static size_t blu_col_lds(const BluGeom& g) {
+  int tc = g.L2 < BLU_TC ? g.L2 : BLU_TC;
+  size_t e = (size_t)2 * tc * (g.L1 + 1) + (g.L1 >= 4 ? g.L1 / 4 : 1) +
+             ((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS);
+  return e * sizeof(float2);
+}
+static size_t blu_row_lds(const BluGeom& g) {
+  int tr = g.L1 < BLU_TR ? g.L1 : BLU_TR;
+  size_t e = (size_t)2 * tr * g.L2 + (g.L2 >= 4 ? g.L2 / 4 : 1) +
+             ((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS);
+  return e * sizeof(float2);
+}
+
+static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
+                   int ld_out, void* work, int adjoint, hipStream_t s) {
+  if (!table || !in || !out || !work) return GFDN_E_BADARG;
+  if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
+  BluGeom g = blu_geom(n);
+  if (g.L1 > 1024 || g.L2 > 2048) return GFDN_E_UNSUPPORTED;
+  if (!adjoint && (ld_in < g.nin || ld_out < n)) return GFDN_E_BADARG;
+  if (adjoint && (ld_in < n || ld_out < g.nin || ld_out > g.L)) return GFDN_E_BADARG;
+  BluArgs a;
+  a.g = g;
+  a.chirp = (const float2*)table;
+  a.chat = a.chirp + g.n;
+  a.work = (float2*)work;
+  a.adjoint = adjoint;
+  a.in = in;
+  a.ld_in = ld_in;
+  a.out = out;
+  a.ld_out = ld_out;
+  const int tc = g.L2 < BLU_TC ? g.L2 : BLU_TC;
+  const int tr = g.L1 < BLU_TR ? g.L1 : BLU_TR;
+  size_t lc = blu_col_lds(g), lr = blu_row_lds(g);
+  if (lc > 160 * 1024 || lr > 160 * 1024) return GFDN_E_UNSUPPORTED;
+  int rc;
+  if ((rc = ensure_dyn_lds(k_blu_col_fwd, lc))) return rc;
+  if ((rc = ensure_dyn_lds(k_blu_row, lr))) return rc;
+  if ((rc = ensure_dyn_lds(k_blu_col_inv, lc))) return rc;
+  hipLaunchKernelGGL(k_blu_col_fwd, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_blu_row, dim3(g.L1 / tr, batch), dim3(256), lr, s, a);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_blu_col_inv, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_irfft_odd_fwd(const void* table, int n, const float* X, int ldx, int batch,
+                                  float* x, int ldo, void* work, void* stream) {
+  return blu_run(table, n, X, ldx, batch, x, ldo, work, 0, (hipStream_t)stream);
+}
+extern "C" int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, int ldo, int batch,
+                                  float* gX, int ldx, void* work, void* stream) {
+  return blu_run(table, n, gx, ldo, batch, gX, ldx, work, 1, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// |STFT|^2, periodic Hann, hop = win/2, center = False; two frames per complex FFT.
+// ------------------------------------------------------------------------------------------
+extern "C" int gfdn_stft_nframes(int T, int win) {
+  if (T <= 0 || win < 4 || (win & (win - 1))) return GFDN_E_BADARG;
+  const int hop = win / 2;
+  const int Tp = ((T + hop - 1) / hop) * hop;
+  if (Tp < win) return 0;
+  return (Tp - win) / hop + 1;
+}
+
+__device__ __forceinline__ float hann_periodic(int j, int W) {
+  return 0.5f - 0.5f * cospif(2.0f * (float)j / (float)W);
+}
+
+// loads frames (m, m+1) of signal b into z = fr_m + i fr_{m+1}
+__device__ __forceinline__ void stft_load_pair(const float* __restrict__ x, int T, int W, int m,
+                                               int nframes, float2* buf) {
+  const int hop = W >> 1;
+  for (int j = threadIdx.x; j < W; j += blockDim.x) {
+    const float h = hann_periodic(j, W);
+    const int ta = m * hop + j, tb = ta + hop;
+    const float va = ta < T ? x[ta] : 0.f;
+    const float vb = (m + 1 < nframes && tb < T) ? x[tb] : 0.f;
+    buf[j] = make_float2(h * va, h * vb);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ x, int ld, int T,
+                                                    int W, int nframes, float* __restrict__ P) {
+  float2* bufA = dyn_lds;
+  float2* bufB = bufA + W;
+  float2* tw4 = bufB + W;
+  const int b = blockIdx.y, m = blockIdx.x * 2, nf = W / 2 + 1;
+  build_tw4(tw4, W);
+  stft_load_pair(x + (size_t)b * ld, T, W, m, nframes, bufA);
+  __syncthreads();
+  const float2* Z = lds_fft(bufA, bufB, W, 1, W, false, tw4, W);
+  float* Pa = P + ((size_t)b * nframes + m) * nf;
+  const bool has_b = m + 1 < nframes;
+  for (int f = threadIdx.x; f < nf; f += blockDim.x) {
+    const float2 zf = Z[f], zc = Z[(W - f) & (W - 1)];
+    // S_a = (Z_f + conj Z_{W-f})/2 ; S_b = (Z_f - conj Z_{W-f})/(2i)
+    const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+    const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+    Pa[f] = sa.x * sa.x + sa.y * sa.y;
+    if (has_b) Pa[nf + f] = sb.x * sb.x + sb.y * sb.y;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stft_power_bwd(const float* __restrict__ x, int ld, int T,
+                                                        int W, int nframes,
+                                                        const float* __restrict__ gP,
+                                                        float* __restrict__ gx) {
+  float2* bufA = dyn_lds;
+  float2* bufB = bufA + W;
+  float2* tw4 = bufB + W;
+  const int b = blockIdx.y, m = blockIdx.x * 2, nf = W / 2 + 1, hop = W >> 1;
+  build_tw4(tw4, W);
+  stft_load_pair(x + (size_t)b * ld, T, W, m, nframes, bufA);
+  __syncthreads();
+  float2* Z = lds_fft(bufA, bufB, W, 1, W, false, tw4, W);
+  float2* O = (Z == bufA) ? bufB : bufA;
+  const float* ga = gP + ((size_t)b * nframes + m) * nf;
+  const bool has_b = m + 1 < nframes;
+  // U = Ga_sym + i Gb_sym, built pairwise (f, W-f) in place
+  for (int f = threadIdx.x; f <= W / 2; f += blockDim.x) {
+    const int fc = (W - f) & (W - 1);
+    const float2 zf = Z[f], zc = Z[fc];
+    const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+    const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+    const float pa = ga[f], pb = has_b ? ga[nf + f] : 0.f;
+    float2 Ga = cscale(sa, 2.0f * pa);  // G = 2 gP S
+    float2 Gb = cscale(sb, 2.0f * pb);
+    if (f == 0 || f == W / 2) {
+      // real-only bins: U_f = Re Ga + i Re Gb
+      Z[f] = make_float2(Ga.x, Gb.x);
+    } else {
+      // U_f = Ga/2 + i Gb/2 ; U_{W-f} = conj(Ga)/2 + i conj(Gb)/2
+      Z[f] = make_float2(0.5f * (Ga.x - Gb.y), 0.5f * (Ga.y + Gb.x));
+      Z[fc] = make_float2(0.5f * (Ga.x + Gb.y), 0.5f * (-Ga.y + Gb.x));
+    }
+  }
+  __syncthreads();
+  const float2* u = lds_fft(Z, O, W, 1, W, true, tw4, W);
+  float* g = gx + (size_t)b * ld;
+  for (int j = threadIdx.x; j < W; j += blockDim.x) {
+    const float h = hann_periodic(j, W);
+    const int ta = m * hop + j, tb = ta + hop;
+    if (ta < T) atomicAdd(&g[ta], h * u[j].x);
+    if (has_b && tb < T) atomicAdd(&g[tb], h * u[j].y);
+  }
+}
+
+static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }
+
+extern "C" int gfdn_stft_power(const float* x, int ld, int T, int batch, int win, float* P,
+                               void* stream) {
+  if (!x || !P || batch <= 0 || ld < T) return GFDN_E_BADARG;
+  int nframes = gfdn_stft_nframes(T, win);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  if (stft_lds(win) > 160 * 1024) return GFDN_E_UNSUPPORTED;
+  int rc = ensure_dyn_lds(k_stft_power, stft_lds(win));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stft_power, dim3((nframes + 1) / 2, batch), dim3(256), stft_lds(win),
+                     (hipStream_t)stream, x, ld, T, win, nframes, P);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_stft_power_bwd(const float* x, int ld, int T, int batch, int win,
+                                   const float* gP, float* gx, void* stream) {
+  if (!x || !gP || !gx || batch <= 0 || ld < T) return GFDN_E_BADARG;
+  int nframes = gfdn_stft_nframes(T, win);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  if (stft_lds(win) > 160 * 1024) return GFDN_E_UNSUPPORTED;
+  int rc = ensure_dyn_lds(k_stft_power_bwd, stft_lds(win));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stft_power_bwd, dim3((nframes + 1) / 2, batch), dim3(256), stft_lds(win),
+                     (hipStream_t)stream, x, ld, T, win, nframes, gP, gx);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,279 @@
+// Energy-decay losses on the time-domain RIRs, for gfx950.
+//
+// EDR (losses.py:556-575, :478-492): EDR[f][m] = 10 log10(sum_{tau >= m} |S[f][tau]|^2 + eps),
+//   per item sum_{f,m} wf[f] |EDR_t - EDR_a| / sum |EDR_t|, summed over the batch.
+// EDC (losses.py:187-238): Schroeder integral of x[start:start+len]^2, dB, mean |difference|
+//   over batch x kept indices.
+// Both are evaluated fused with their gradients: the loss is a scalar, so the backward of
+// the dB / L1 stage is produced in the same pass that produces the value.
+// All cross-thread sums use fixed-order reductions (no float atomics): bitwise reproducible.
+#include "common.h"
+
+// out[r] = scale * sum_c part[r][c] * (rowscale ? 1/rowscale[r] : 1)
+__global__ void k_row_sum(const float* __restrict__ part, int rows, int cols,
+                          const float* __restrict__ rowdiv, float* __restrict__ out) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = 0; c < cols; ++c) s += part[(size_t)r * cols + c];
+  out[r] = rowdiv ? s / rowdiv[r] : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// EDR
+// ------------------------------------------------------------------------------------------
+#define EDR_MAX_FBLK 64   // nfreq <= 64*256
+
+// target: P -> EDR dB in place; part[b][fblk] = sum |EDR|
+__global__ __launch_bounds__(256) void k_edr_target(float* __restrict__ P, int nframes, int nfreq,
+                                                    float* __restrict__ part) {
+  __shared__ float s_red[16];
+  const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  float sabs = 0.f;
+  if (f < nfreq) {
+    float* p = P + (size_t)b * nframes * nfreq + f;
+    float E = 0.f;
+    for (int m = nframes - 1; m >= 0; --m) {
+      E += p[(size_t)m * nfreq];
+      float d = db_pow(E);
+      p[(size_t)m * nfreq] = d;
+      sabs += fabsf(d);
+    }
+  }
+  sabs = block_sum(sabs, s_red);
+  if (threadIdx.x == 0) part[b * gridDim.x + blockIdx.x] = sabs;
+}
+
+// achieved: part[b][fblk] = sum_{f,m} wf |T - EDR| ; optionally P <- gscale/sum_abs[b] * dloss/dP
+__global__ __launch_bounds__(256) void k_edr_loss(float* __restrict__ P,
+                                                  const float* __restrict__ Tdb,
+                                                  const float* __restrict__ sum_abs,
+                                                  const float* __restrict__ wf, int nframes,
+                                                  int nfreq, float gscale, int want_grad,
+                                                  float* __restrict__ part) {
+  __shared__ float s_red[16];
+  const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (f < nfreq) {
+    float* p = P + (size_t)b * nframes * nfreq + f;
+    const float* t = Tdb + (size_t)b * nframes * nfreq + f;
+    const float w = wf ? wf[f] : 1.0f;
+    const float gs = want_grad ? gscale * w / sum_abs[b] : 0.f;
+    float E = 0.f;
+    for (int m = nframes - 1; m >= 0; --m) {
+      E += p[(size_t)m * nfreq];
+      const float lin = fabsf(E) + F32_EPS;
+      const float raw = 10.0f * log10f(lin);
+      const float d = fmaxf(raw, -200.0f);
+      const float diff = t[(size_t)m * nfreq] - d;
+      acc += w * fabsf(diff);
+      if (want_grad) {
+        // d|diff|/dEDR = -sign(diff); dEDR/dE = (10/ln10)/(E+eps) unless clipped
+        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+        p[(size_t)m * nfreq] = -sg * dE * gs;
+      }
+    }
+    if (want_grad) {
+      // E_m = sum_{tau >= m} P_tau  =>  gP_tau = sum_{m <= tau} gE_m
+      float run = 0.f;
+      for (int m = 0; m < nframes; ++m) {
+        run += p[(size_t)m * nfreq];
+        p[(size_t)m * nfreq] = run;
+      }
+    }
+  }
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) part[b * gridDim.x + blockIdx.x] = acc;
+}
+
+// work: per-(item, frequency-block) partial sums, reduced in a fixed order by k_row_sum
+extern "C" size_t gfdn_edr_work_bytes(int batch, int nfreq) {
+  return (size_t)batch * ((nfreq + 255) / 256) * sizeof(float);
+}
+
+extern "C" int gfdn_edr_target(float* P, int batch, int nframes, int nfreq, float* sum_abs,
+                               void* work, void* stream) {
+  if (!P || !sum_abs || !work || batch <= 0 || nframes <= 0 || nfreq <= 0) return GFDN_E_BADARG;
+  const int fblk = (nfreq + 255) / 256;
+  if (fblk > EDR_MAX_FBLK) return GFDN_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)work;
+  hipLaunchKernelGGL(k_edr_target, dim3(fblk, batch), dim3(256), 0, s, P, nframes, nfreq, part);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_row_sum, dim3((batch + 63) / 64), dim3(64), 0, s, part, batch, fblk,
+                     (const float*)nullptr, sum_abs);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs, const float* wf,
+                             int batch, int nframes, int nfreq, float gscale, int want_grad,
+                             float* loss_item, void* work, void* stream) {
+  if (!P || !T_db || !sum_abs || !loss_item || !work || batch <= 0 || nframes <= 0 || nfreq <= 0)
+    return GFDN_E_BADARG;
+  const int fblk = (nfreq + 255) / 256;
+  if (fblk > EDR_MAX_FBLK) return GFDN_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)work;
+  hipLaunchKernelGGL(k_edr_loss, dim3(fblk, batch), dim3(256), 0, s, P, T_db, sum_abs, wf, nframes,
+                     nfreq, gscale, want_grad, part);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_row_sum, dim3((batch + 63) / 64), dim3(64), 0, s, part, batch, fblk, sum_abs,
+                     loss_item);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// EDC: one 1024-thread block per item; tiles of 4096 samples, 4 contiguous samples per thread
+// ------------------------------------------------------------------------------------------
+#define EDC_THREADS 1024
+#define EDC_V 4
+#define EDC_TILE (EDC_THREADS * EDC_V)
+
+// inclusive scan over the block of one value per thread, in thread order; returns the
+// inclusive prefix for this thread and the block total through *total.
+__device__ __forceinline__ float block_scan_incl(float v, float* lds /* >= 32 floats */,
+                                                 float* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  __syncthreads();
+  if (lane == 63) lds[w] = v;
+  __syncthreads();
+  float pre = 0.f, tot = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) {
+    float t = lds[i];
+    if (i < w) pre += t;
+    tot += t;
+  }
+  *total = tot;
+  return v + pre;
+}
+
+// suffix sums of x^2 over [start, start+len): processes tiles from the END; calls
+// fn(i, edc_i, x_i) for every index in the window.
+template <typename F>
+__device__ __forceinline__ void edc_suffix(const float* __restrict__ xw, int len, float* lds, F fn) {
+  float carry = 0.f;
+  const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    // reversed coordinate j = len-1-i ; thread handles j0..j0+3
+    const int j0 = tile * EDC_TILE + threadIdx.x * EDC_V;
+    float v[EDC_V], xv[EDC_V];
+    float loc = 0.f;
+#pragma unroll
+    for (int u = 0; u < EDC_V; ++u) {
+      const int j = j0 + u;
+      xv[u] = (j < len) ? xw[len - 1 - j] : 0.f;
+      loc += xv[u] * xv[u];
+      v[u] = loc;
+    }
+    float tot;
+    const float incl = block_scan_incl(loc, lds, &tot);
+    const float excl = incl - loc + carry;
+#pragma unroll
+    for (int u = 0; u < EDC_V; ++u) {
+      const int j = j0 + u;
+      if (j < len) fn(len - 1 - j, excl + v[u], xv[u]);
+    }
+    carry += tot;
+  }
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void k_edc_target(const float* __restrict__ x, int ld,
+                                                            int start, int len,
+                                                            float* __restrict__ Tdb) {
+  __shared__ float s_scan[32];
+  const int b = blockIdx.x;
+  const float* xw = x + (size_t)b * ld + start;
+  float* t = Tdb + (size_t)b * len;
+  edc_suffix(xw, len, s_scan, [&](int i, float edc, float) { t[i] = db_pow(edc); });
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void k_edc_loss(const float* __restrict__ x, int ld,
+                                                          int start, int len,
+                                                          const float* __restrict__ Tdb,
+                                                          const float* __restrict__ maskw,
+                                                          float inv_count, float gscale,
+                                                          float* __restrict__ loss_item,
+                                                          float* __restrict__ gx) {
+  __shared__ float s_scan[32];
+  __shared__ float s_red[16];
+  const int b = blockIdx.x;
+  const float* xw = x + (size_t)b * ld + start;
+  const float* t = Tdb + (size_t)b * len;
+  float* gw = gx ? gx + (size_t)b * ld + start : nullptr;
+  float acc = 0.f;
+  edc_suffix(xw, len, s_scan, [&](int i, float edc, float) {
+    const float lin = fabsf(edc) + F32_EPS;
+    const float raw = 10.0f * log10f(lin);
+    const float d = fmaxf(raw, -200.0f);
+    const float diff = t[i] - d;
+    const float mw = maskw ? maskw[i] : 1.0f;
+    acc += mw * fabsf(diff);
+    if (gw) {
+      const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+      const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+      gw[i] = -sg * dE * mw * inv_count * gscale;   // dL/dEDC_i, staged in place
+    }
+  });
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) loss_item[b] = acc * inv_count;
+  if (!gx) return;
+  // EDC_i = sum_{j >= i} x_j^2  =>  dL/dx_j = 2 x_j sum_{i <= j} dL/dEDC_i   (forward prefix scan)
+  __syncthreads();
+  float carry = 0.f;
+  const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int i0 = tile * EDC_TILE + threadIdx.x * EDC_V;
+    float v[EDC_V];
+    float loc = 0.f;
+#pragma unroll
+    for (int u = 0; u < EDC_V; ++u) {
+      const int i = i0 + u;
+      loc += (i < len) ? gw[i] : 0.f;
+      v[u] = loc;
+    }
+    float tot;
+    const float incl = block_scan_incl(loc, s_scan, &tot);
+    const float excl = incl - loc + carry;
+#pragma unroll
+    for (int u = 0; u < EDC_V; ++u) {
+      const int i = i0 + u;
+      if (i < len) gw[i] = 2.0f * xw[i] * (excl + v[u]);
+    }
+    carry += tot;
+  }
+  // zeros outside the window
+  float* g = gx + (size_t)b * ld;
+  for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = 0.f;
+  for (int i = start + len + threadIdx.x; i < ld; i += blockDim.x) g[i] = 0.f;
+}
+
+extern "C" int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float* T_db,
+                               void* stream) {
+  if (!x || !T_db || batch <= 0 || start < 0 || len <= 0 || start + len > ld) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_edc_target, dim3(batch), dim3(EDC_THREADS), 0, (hipStream_t)stream, x, ld,
+                     start, len, T_db);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len,
+                             const float* T_db, const float* maskw, float inv_count, float gscale,
+                             float* loss_item, float* gx, void* stream) {
+  if (!x || !T_db || !loss_item || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
+    return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_edc_loss, dim3(batch), dim3(EDC_THREADS), 0, (hipStream_t)stream, x, ld,
+                     start, len, T_db, maskw, inv_count, gscale, loss_item, gx);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_abi_version(void) { return GFDN_ABI_VERSION; }

@@ -1,0 +1,676 @@
+// Per-bin resolvent solve of the frequency-sampled GFDN and its output stage, for gfx950.
+//
+// Reference maths (orchidas/DiffGFDN, src/diff_gfdn): feedback_loop.py:326-391 forms
+// D = diag(z^m), Gamma, A for every bin as dense (K,N,N) complex128 tensors, inverts them with
+// torch.linalg.inv, and model.py:615-619 contracts the inverse with c and b.  Here every bin is
+// one small linear SOLVE that lives entirely in registers of a group of NP lanes (one matrix
+// row per lane, Gauss-Jordan with virtual partial pivoting, pivot rows broadcast with
+// ds_bpermute), 64/NP bins per wavefront; nothing of size K*N*N ever exists.
+//
+// Phase accuracy: z^m is evaluated as exp(m ln|z|) * exp(2 pi i frac(m * turns)) with the
+// product and its reduction to [-1/2, 1/2] in float64 and only the final sincospi in float32.
+// A naive float32 z**m is off by 1e-3 at m ~ 1600; this is at 1e-7.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// z -> (turns, log radius)
+// ------------------------------------------------------------------------------------------
+__global__ void k_zprep(const double* __restrict__ z, int K, double* __restrict__ turns,
+                        double* __restrict__ logr) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double re = z[2 * k], im = z[2 * k + 1];
+  turns[k] = atan2(im, re) * 0.15915494309189535;  // 1/(2 pi)
+  logr[k] = 0.5 * log(re * re + im * im);
+}
+
+extern "C" int gfdn_zprep(const double* z, int K, double* turns, double* logr, void* stream) {
+  if (!z || !turns || !logr || K <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_zprep, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, K,
+                     turns, logr);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// z_k^{m} * inv_gamma for one delay line
+__device__ __forceinline__ float2 zeta_pow(const double* __restrict__ turns,
+                                           const double* __restrict__ logr, int k, float m,
+                                           float inv_gamma) {
+  double t = (double)m * turns[k];
+  t -= rint(t);
+  float s, c;
+  sincospif(2.0f * (float)t, &s, &c);
+  float mag = inv_gamma;
+  if (logr) mag *= (float)exp((double)m * logr[k]);
+  return make_float2(c * mag, s * mag);
+}
+
+// ------------------------------------------------------------------------------------------
+// Gauss-Jordan on an n x n complex system spread over NP lanes (lane r holds row r).
+// On return the lane whose pivot column is `pivcol` holds x[pivcol] = rhs * pivinv.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ float2 gauss_jordan(float2 (&row)[NP], float2 rhs, int n, int r,
+                                               int& pivcol) {
+  const bool active = r < n;
+  bool used = !active;
+  float2 pivinv = make_float2(0.f, 0.f);
+  pivcol = -1;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    if (j < n) {  // wave-uniform
+      float mag = used ? -1.0f : (row[j].x * row[j].x + row[j].y * row[j].y);
+      int best = r;
+#pragma unroll
+      for (int off = NP / 2; off >= 1; off >>= 1) {
+        float om = __shfl_xor(mag, off, NP);
+        int ol = __shfl_xor(best, off, NP);
+        bool take = (om > mag) || (om == mag && ol < best);
+        mag = take ? om : mag;
+        best = take ? ol : best;
+      }
+      float2 pr[NP];
+#pragma unroll
+      for (int c = j; c < NP; ++c) {
+        if (c < n) {
+          pr[c].x = __shfl(row[c].x, best, NP);
+          pr[c].y = __shfl(row[c].y, best, NP);
+        }
+      }
+      float2 prhs;
+      prhs.x = __shfl(rhs.x, best, NP);
+      prhs.y = __shfl(rhs.y, best, NP);
+      float2 inv = cinv(pr[j]);
+      if (r == best) {
+        used = true;
+        pivcol = j;
+        pivinv = inv;
+      } else if (active) {
+        float2 f = cmul(row[j], inv);
+#pragma unroll
+        for (int c = j + 1; c < NP; ++c) {
+          if (c < n) {
+            row[c].x -= f.x * pr[c].x - f.y * pr[c].y;
+            row[c].y -= f.x * pr[c].y + f.y * pr[c].x;
+          }
+        }
+        rhs.x -= f.x * prhs.x - f.y * prhs.y;
+        rhs.y -= f.x * prhs.y + f.y * prhs.x;
+        row[j] = make_float2(0.f, 0.f);
+      }
+    }
+  }
+  return cmul(rhs, pivinv);
+}
+
+// row r of  diag(zeta) - A   (swap=false: A[r][c];  swap=true: A[c][r])
+template <int NP>
+__device__ __forceinline__ void build_row(float2 (&row)[NP], const float* __restrict__ Ablk,
+                                          int n, int r, bool swap, float2 diag) {
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    float a = 0.f;
+    if (c < n && r < n) a = swap ? Ablk[c * n + r] : Ablk[r * n + c];
+    row[c] = make_float2(-a, 0.f);
+    if (c == r) row[c] = make_float2(diag.x - a, diag.y);
+  }
+}
+
+struct SolveArgs {
+  const double* turns;
+  const double* logr;
+  int K, nblk, nper;
+  const float* A;
+  const float* delays;
+  const float* inv_gamma;
+  const float* b;
+  int transpose;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_fwd(SolveArgs a, float2* __restrict__ Y) {
+  constexpr int SPB = 256 / NP;
+  const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
+  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
+  const int k = blockIdx.x * SPB + grp;
+  const bool valid = k < a.K;
+  const int kk = valid ? k : a.K - 1;
+  const int i = blk * n + (r < n ? r : 0);
+  float2 zeta = zeta_pow(a.turns, a.logr, kk, a.delays[i], a.inv_gamma[i]);
+  float2 row[NP];
+  build_row<NP>(row, a.A + (size_t)blk * n * n, n, r, a.transpose != 0, zeta);
+  float2 rhs = make_float2(r < n ? a.b[i] : 0.f, 0.f);
+  int pivcol;
+  float2 y = gauss_jordan<NP>(row, rhs, n, r, pivcol);
+  if (valid && pivcol >= 0) Y[(size_t)k * N + blk * n + pivcol] = y;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __restrict__ gY,
+                                                   float* __restrict__ partial) {
+  constexpr int SPB = 256 / NP;
+  __shared__ float2 s_perm[256];
+  __shared__ float s_acc[256 * (NP + 2)];
+  const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
+  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
+  const bool active = r < n;
+  const int i = blk * n + (active ? r : 0);
+  const float* Ablk = a.A + (size_t)blk * n * n;
+  const float m_i = a.delays[i], ig_i = a.inv_gamma[i], b_i = active ? a.b[i] : 0.f;
+  const bool tr = a.transpose != 0;
+
+  float acc[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) acc[c] = 0.f;
+  float accb = 0.f, accg = 0.f;
+
+  for (int k0 = blockIdx.x * SPB; k0 < a.K; k0 += gridDim.x * SPB) {
+    const int k = k0 + grp;
+    const bool valid = k < a.K;
+    const int kk = valid ? k : a.K - 1;
+    // unit-magnitude phase separately: d T_ii / d inv_gamma = z^m
+    float2 zpow = zeta_pow(a.turns, a.logr, kk, m_i, 1.0f);
+    float2 zeta = cscale(zpow, ig_i);
+    float2 row[NP];
+    int pivcol;
+    // forward system  T y = b
+    build_row<NP>(row, Ablk, n, r, tr, zeta);
+    float2 y = gauss_jordan<NP>(row, make_float2(b_i, 0.f), n, r, pivcol);
+    __syncthreads();
+    if (pivcol >= 0) s_perm[grp * NP + pivcol] = y;
+    __syncthreads();
+    float2 ynat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    // adjoint system  T^H w = gY   (row r of T^H = conj of column r of T)
+    build_row<NP>(row, Ablk, n, r, !tr, cconj(zeta));
+    float2 g = active ? gY[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    float2 w = gauss_jordan<NP>(row, g, n, r, pivcol);
+    __syncthreads();
+    if (pivcol >= 0) s_perm[grp * NP + pivcol] = w;
+    __syncthreads();
+    float2 wnat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    if (!valid) { ynat = make_float2(0.f, 0.f); wnat = make_float2(0.f, 0.f); }
+    // gT_ij = -w_i conj(y_j);  T = D - A  (or D - A^T)
+    //   transpose=0: gA[i][j] = Re(w_i conj(y_j));  transpose=1: gA[i][j] = Re(w_j conj(y_i))
+    const float2 mine = tr ? ynat : wnat;
+    const float2 other = tr ? wnat : ynat;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      if (c < n) {
+        float ox = __shfl(other.x, c, NP), oy = __shfl(other.y, c, NP);
+        acc[c] += mine.x * ox + mine.y * oy;
+      }
+    }
+    accb += wnat.x;
+    // g inv_gamma_i = Re(conj(gT_ii) z^m) = -Re(conj(w_i) y_i z^m)
+    float2 yz = cmul(ynat, zpow);
+    accg -= wnat.x * yz.x + wnat.y * yz.y;
+  }
+  // deterministic reduction over the SPB lane groups of this block
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NP; ++c) s_acc[(grp * NP + r) * (NP + 2) + c] = acc[c];
+  s_acc[(grp * NP + r) * (NP + 2) + NP] = accb;
+  s_acc[(grp * NP + r) * (NP + 2) + NP + 1] = accg;
+  __syncthreads();
+  const int per = n * n + 2 * n;
+  float* out = partial + ((size_t)blockIdx.x * a.nblk + blk) * per;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    int rr, cc;
+    if (e < n * n) { rr = e / n; cc = e % n; }
+    else if (e < n * n + n) { rr = e - n * n; cc = NP; }
+    else { rr = e - n * n - n; cc = NP + 1; }
+    float s = 0.f;
+    for (int g2 = 0; g2 < SPB; ++g2) s += s_acc[(g2 * NP + rr) * (NP + 2) + cc];
+    out[e] = s;
+  }
+}
+
+// out[e] = sum_p partial[p][e]   (fixed order)
+__global__ void k_reduce_partials(const float* __restrict__ partial, int nparts, int per,
+                                  float* __restrict__ out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * per + e];
+  out[e] = s;
+}
+
+// scatter the reduced [nblk][n*n + 2n] record into gA, gb, ginv_gamma
+__global__ void k_solve_bwd_finish(const float* __restrict__ partial, int nparts, int nblk, int n,
+                                   float* __restrict__ gA, float* __restrict__ gb,
+                                   float* __restrict__ gig) {
+  const int per = n * n + 2 * n;
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nblk * per) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * nblk * per + e];
+  int blk = e / per, o = e % per;
+  if (o < n * n) gA[(size_t)blk * n * n + o] = s;
+  else if (o < n * n + n) gb[blk * n + (o - n * n)] = s;
+  else gig[blk * n + (o - n * n - n)] = s;
+}
+
+static int pick_np(int nper) {
+  if (nper <= 4) return 4;
+  if (nper <= 8) return 8;
+  if (nper <= 16) return 16;
+  return 32;
+}
+
+static int check_solve_args(const double* turns, int K, int nblk, int nper, const float* A,
+                            const float* delays, const float* ig, const float* b) {
+  if (!turns || !A || !delays || !ig || !b) return GFDN_E_BADARG;
+  if (K <= 0 || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > GFDN_MAX_BLOCK) return GFDN_E_UNSUPPORTED;
+  return 0;
+}
+
+extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                              const float* A, const float* delays, const float* inv_gamma,
+                              const float* b, int transpose, float* Y, void* stream) {
+  int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
+  if (rc) return rc;
+  if (!Y) return GFDN_E_BADARG;
+  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose};
+  const int np = pick_np(nper);
+  const int spb = 256 / np;
+  dim3 grid((K + spb - 1) / spb, nblk), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (np) {
+    case 4: hipLaunchKernelGGL(k_solve_fwd<4>, grid, block, 0, s, a, (float2*)Y); break;
+    case 8: hipLaunchKernelGGL(k_solve_fwd<8>, grid, block, 0, s, a, (float2*)Y); break;
+    case 16: hipLaunchKernelGGL(k_solve_fwd<16>, grid, block, 0, s, a, (float2*)Y); break;
+    default: hipLaunchKernelGGL(k_solve_fwd<32>, grid, block, 0, s, a, (float2*)Y); break;
+  }
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t gfdn_solve_bwd_work_bytes(int nblk, int nper) {
+  return (size_t)GFDN_PARTIAL_BLOCKS * nblk * (nper * nper + 2 * nper) * sizeof(float);
+}
+
+extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                              const float* A, const float* delays, const float* inv_gamma,
+                              const float* b, int transpose, const float* gY, float* gA,
+                              float* gb, float* ginv_gamma, void* work, void* stream) {
+  int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
+  if (rc) return rc;
+  if (!gY || !gA || !gb || !ginv_gamma || !work) return GFDN_E_BADARG;
+  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose};
+  const int np = pick_np(nper);
+  const int spb = 256 / np;
+  int nparts = (K + spb - 1) / spb;
+  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  dim3 grid(nparts, nblk), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)work;
+  switch (np) {
+    case 4: hipLaunchKernelGGL(k_solve_bwd<4>, grid, block, 0, s, a, (const float2*)gY, partial); break;
+    case 8: hipLaunchKernelGGL(k_solve_bwd<8>, grid, block, 0, s, a, (const float2*)gY, partial); break;
+    case 16: hipLaunchKernelGGL(k_solve_bwd<16>, grid, block, 0, s, a, (const float2*)gY, partial); break;
+    default: hipLaunchKernelGGL(k_solve_bwd<32>, grid, block, 0, s, a, (const float2*)gY, partial); break;
+  }
+  GFDN_LAUNCH_CHECK();
+  const int tot = nblk * (nper * nper + 2 * nper);
+  hipLaunchKernelGGL(k_solve_bwd_finish, dim3((tot + 255) / 256), dim3(256), 0, s, partial, nparts,
+                     nblk, nper, gA, gb, ginv_gamma);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// output stage
+// ------------------------------------------------------------------------------------------
+#define COMPOSE_BCH 8
+__global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ Y, int K, int G,
+                                                     int nper, const float* __restrict__ c,
+                                                     const float* __restrict__ rgain, int B,
+                                                     const float2* __restrict__ direct, int ldd,
+                                                     const float2* __restrict__ filt,
+                                                     float2* __restrict__ H, int ldh,
+                                                     float2* __restrict__ S_out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int N = G * nper;
+  float2 S[GFDN_MAX_GROUPS];
+#pragma unroll
+  for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+    S[g] = make_float2(0.f, 0.f);
+    if (g < G) {
+      for (int i = 0; i < nper; ++i) {
+        float2 y = Y[(size_t)k * N + g * nper + i];
+        float cc = c[g * nper + i];
+        S[g].x += cc * y.x;
+        S[g].y += cc * y.y;
+      }
+      if (S_out && blockIdx.y == 0) S_out[(size_t)g * K + k] = S[g];
+    }
+  }
+  float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
+  const int b0 = blockIdx.y * COMPOSE_BCH;
+  for (int bb = 0; bb < COMPOSE_BCH; ++bb) {
+    const int b = b0 + bb;
+    if (b >= B) break;
+    float2 h = direct ? direct[(size_t)b * ldd + k] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+      if (g < G) {
+        float rg = rgain[b * G + g];
+        h.x += rg * S[g].x;
+        h.y += rg * S[g].y;
+      }
+    }
+    if (filt) h = cmul(h, f);
+    H[(size_t)b * ldh + k] = h;
+  }
+}
+
+extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const float* c,
+                                const float* rgain, int B, const float* direct, int ldd,
+                                const float* filt, float* H, int ldh, float* S_out,
+                                void* stream) {
+  if (!Y || !c || !rgain || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
+  if (G > GFDN_MAX_GROUPS) return GFDN_E_UNSUPPORTED;
+  if (ldh < K || (direct && ldd < K)) return GFDN_E_BADARG;
+  dim3 grid((K + 255) / 256, (B + COMPOSE_BCH - 1) / COMPOSE_BCH);
+  hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), 0, (hipStream_t)stream, (const float2*)Y, K,
+                     G, nper, c, rgain, B, (const float2*)direct, ldd, (const float2*)filt,
+                     (float2*)H, ldh, (float2*)S_out);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// gS[g][k] = sum_b rgain[b][g] conj(filt_k) gH[b][k];  gY[k][n] = c_n gS[g(n)][k];
+// gc partial[blockIdx.x][n] = sum_{k in block} Re(conj(gS) Y);  S[g][k] stored for pass B.
+__global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict__ Y, int K, int G,
+                                                       int nper, const float* __restrict__ c,
+                                                       const float* __restrict__ rgain, int B,
+                                                       const float2* __restrict__ filt,
+                                                       const float2* __restrict__ gH, int ldh,
+                                                       float2* __restrict__ gY,
+                                                       float2* __restrict__ S_work,
+                                                       float* __restrict__ gc_partial) {
+  __shared__ float s_gc[4][64];
+  const int N = G * nper;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 4 * 64; e += 256) (&s_gc[0][0])[e] = 0.f;
+  __syncthreads();
+  for (int k0 = blockIdx.x * 256; k0 < K; k0 += gridDim.x * 256) {
+    const int k = k0 + threadIdx.x;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    float2 gS[GFDN_MAX_GROUPS];
+#pragma unroll
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) gS[g] = make_float2(0.f, 0.f);
+    float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+      float2 gh = gH[(size_t)b * ldh + kk];
+      if (filt) gh = cmul(gh, fc);
+#pragma unroll
+      for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+        if (g < G) {
+          float rg = rgain[b * G + g];
+          gS[g].x += rg * gh.x;
+          gS[g].y += rg * gh.y;
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+      if (g < G) {
+        float2 Sg = make_float2(0.f, 0.f);
+        for (int i = 0; i < nper; ++i) {
+          const int n = g * nper + i;
+          float2 y = Y[(size_t)kk * N + n];
+          float cc = c[n];
+          Sg.x += cc * y.x;
+          Sg.y += cc * y.y;
+          if (valid) gY[(size_t)k * N + n] = cscale(gS[g], cc);
+          float v = valid ? (gS[g].x * y.x + gS[g].y * y.y) : 0.f;
+          v = wave_sum(v);
+          if (lane == 0) s_gc[wv][n] += v;   // one writer per (wave, n): deterministic
+        }
+        if (valid) S_work[(size_t)g * K + k] = Sg;
+      }
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256)
+    gc_partial[(size_t)blockIdx.x * N + n] = s_gc[0][n] + s_gc[1][n] + s_gc[2][n] + s_gc[3][n];
+}
+
+// grgain[b][g] = sum_k Re(conj(gH'[b][k]) S[g][k]),  gH' = conj(filt) gH
+__global__ __launch_bounds__(256) void k_compose_bwd_b(const float2* __restrict__ S_work, int K,
+                                                       int G, const float2* __restrict__ filt,
+                                                       const float2* __restrict__ gH, int ldh,
+                                                       float* __restrict__ grgain) {
+  __shared__ float s_red[16];
+  const int b = blockIdx.x;
+  float acc[GFDN_MAX_GROUPS];
+#pragma unroll
+  for (int g = 0; g < GFDN_MAX_GROUPS; ++g) acc[g] = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float2 gh = gH[(size_t)b * ldh + k];
+    if (filt) gh = cmul(gh, cconj(filt[k]));
+#pragma unroll
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+      if (g < G) {
+        float2 s = S_work[(size_t)g * K + k];
+        acc[g] += gh.x * s.x + gh.y * s.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+    if (g < G) {
+      float s = block_sum(acc[g], s_red);
+      if (threadIdx.x == 0) grgain[b * G + g] = s;
+    }
+  }
+}
+
+static size_t compose_partial_bytes(int G, int nper) {
+  return (size_t)GFDN_PARTIAL_BLOCKS * G * nper * sizeof(float);
+}
+// gc partial slots followed by a (G, K) complex copy of S for the second pass
+extern "C" size_t gfdn_compose_bwd_work_bytes(int K, int G, int nper, int B) {
+  (void)B;
+  return compose_partial_bytes(G, nper) + (size_t)G * K * sizeof(float2);
+}
+
+extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const float* c,
+                                const float* rgain, int B, const float* filt, const float* gH,
+                                int ldh, float* gY, float* gc, float* grgain, void* work,
+                                void* stream) {
+  if (!Y || !c || !rgain || !gH || !gY || !gc || !grgain || !work) return GFDN_E_BADARG;
+  if (K <= 0 || G <= 0 || nper <= 0 || B <= 0 || ldh < K) return GFDN_E_BADARG;
+  if (G > GFDN_MAX_GROUPS || G * nper > 64) return GFDN_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = G * nper;
+  int nparts = (K + 255) / 256;
+  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  float* gc_partial = (float*)work;
+  float2* S_work = (float2*)((char*)work + compose_partial_bytes(G, nper));
+  hipLaunchKernelGGL(k_compose_bwd_a, dim3(nparts), dim3(256), 0, s, (const float2*)Y, K, G, nper,
+                     c, rgain, B, (const float2*)filt, (const float2*)gH, ldh, (float2*)gY, S_work,
+                     gc_partial);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_partials, dim3((N + 255) / 256), dim3(256), 0, s, gc_partial, nparts,
+                     N, gc);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_compose_bwd_b, dim3(B), dim3(256), 0, s, S_work, K, G,
+                     (const float2*)filt, (const float2*)gH, ldh, grgain);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// directional (SH-domain) output stage, model.py:1056-1088
+//   H[b][l][k] = filt_k * sum_g w[b][g][l] c[g*nper+l] Y[k][g*nper+l]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compose_sh_fwd(const float2* __restrict__ Y, int K, int G,
+                                                        int nper, const float* __restrict__ c,
+                                                        const float* __restrict__ w, int B,
+                                                        const float2* __restrict__ filt,
+                                                        float2* __restrict__ H) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int N = G * nper;
+  const int b = blockIdx.y;
+  float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
+  for (int l = 0; l < nper; ++l) {
+    float2 h = make_float2(0.f, 0.f);
+    for (int g = 0; g < G; ++g) {
+      const int n = g * nper + l;
+      float2 y = Y[(size_t)k * N + n];
+      float s = w[(size_t)b * N + n] * c[n];
+      h.x += s * y.x;
+      h.y += s * y.y;
+    }
+    if (filt) h = cmul(h, f);
+    H[((size_t)b * nper + l) * K + k] = h;
+  }
+}
+
+extern "C" int gfdn_compose_sh_fwd(const float* Y, int K, int G, int nper, const float* c,
+                                   const float* w, int B, const float* filt, float* H,
+                                   void* stream) {
+  if (!Y || !c || !w || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_compose_sh_fwd, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)Y, K, G, nper, c, w, B, (const float2*)filt, (float2*)H);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// pass A: per k: gY[k][n] = c_n sum_b w[b][n] gH'[b][l(n)][k]; gc partial; per (b,n) handled in pass B
+__global__ __launch_bounds__(256) void k_compose_sh_bwd_a(const float2* __restrict__ Y, int K, int G,
+                                                          int nper, const float* __restrict__ c,
+                                                          const float* __restrict__ w, int B,
+                                                          const float2* __restrict__ filt,
+                                                          const float2* __restrict__ gH,
+                                                          float2* __restrict__ gY,
+                                                          float* __restrict__ gc_partial) {
+  __shared__ float s_gc[4][64];
+  const int N = G * nper;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 4 * 64; e += 256) (&s_gc[0][0])[e] = 0.f;
+  __syncthreads();
+  for (int k0 = blockIdx.x * 256; k0 < K; k0 += gridDim.x * 256) {
+    const int k = k0 + threadIdx.x;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
+    for (int n = 0; n < N; ++n) {
+      const int l = n % nper;
+      float2 acc = make_float2(0.f, 0.f);
+      for (int b = 0; b < B; ++b) {
+        float2 gh = gH[((size_t)b * nper + l) * K + kk];
+        float wb = w[(size_t)b * N + n];
+        acc.x += wb * gh.x;
+        acc.y += wb * gh.y;
+      }
+      if (filt) acc = cmul(acc, fc);
+      float2 y = Y[(size_t)kk * N + n];
+      if (valid) gY[(size_t)k * N + n] = cscale(acc, c[n]);
+      float v = valid ? (acc.x * y.x + acc.y * y.y) : 0.f;
+      v = wave_sum(v);
+      if (lane == 0) s_gc[wv][n] += v;
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256)
+    gc_partial[(size_t)blockIdx.x * N + n] = s_gc[0][n] + s_gc[1][n] + s_gc[2][n] + s_gc[3][n];
+}
+
+// pass B: gw[b][n] = c_n sum_k Re(conj(gH'[b][l][k]) Y[k][n])
+__global__ __launch_bounds__(256) void k_compose_sh_bwd_b(const float2* __restrict__ Y, int K, int G,
+                                                          int nper, const float* __restrict__ c,
+                                                          const float2* __restrict__ filt,
+                                                          const float2* __restrict__ gH,
+                                                          float* __restrict__ gw) {
+  __shared__ float s_red[16];
+  const int N = G * nper;
+  const int b = blockIdx.y, n = blockIdx.x, l = n % nper;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float2 gh = gH[((size_t)b * nper + l) * K + k];
+    if (filt) gh = cmul(gh, cconj(filt[k]));
+    float2 y = Y[(size_t)k * N + n];
+    acc += gh.x * y.x + gh.y * y.y;
+  }
+  float s = block_sum(acc, s_red);
+  if (threadIdx.x == 0) gw[(size_t)b * N + n] = s * c[n];
+}
+
+extern "C" size_t gfdn_compose_sh_bwd_work_bytes(int G, int nper, int B) {
+  (void)B;
+  return (size_t)GFDN_PARTIAL_BLOCKS * G * nper * sizeof(float);
+}
+
+extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const float* c,
+                                   const float* w, int B, const float* filt, const float* gH,
+                                   float* gY, float* gc, float* gw, void* work, void* stream) {
+  if (!Y || !c || !w || !gH || !gY || !gc || !gw || !work) return GFDN_E_BADARG;
+  if (K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
+  if (G * nper > 64) return GFDN_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = G * nper;
+  int nparts = (K + 255) / 256;
+  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  float* gc_partial = (float*)work;
+  hipLaunchKernelGGL(k_compose_sh_bwd_a, dim3(nparts), dim3(256), 0, s, (const float2*)Y, K, G, nper,
+                     c, w, B, (const float2*)filt, (const float2*)gH, (float2*)gY, gc_partial);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_partials, dim3((N + 255) / 256), dim3(256), 0, s, gc_partial, nparts,
+                     N, gc);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_compose_sh_bwd_b, dim3(N, B), dim3(256), 0, s, (const float2*)Y, K, G, nper,
+                     c, (const float2*)filt, (const float2*)gH, gw);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// colorless statistics of the sub-FDN responses
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_spectral_stats(const float2* __restrict__ S, int G, int K,
+                                                         int asym, float scale,
+                                                         float* __restrict__ energy,
+                                                         float* __restrict__ loss,
+                                                         float2* __restrict__ gS) {
+  __shared__ float s_red[16];
+  const int g = blockIdx.x;
+  const float invK = 1.0f / (float)K;
+  float e = 0.f, l = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float2 s = S[(size_t)g * K + k];
+    float p = s.x * s.x + s.y * s.y;
+    float mag = sqrtf(p);
+    float d = mag - 1.0f;
+    e += p;
+    float d2 = d * d;
+    bool four = asym && (d > 1.0f);
+    l += four ? d2 * d2 : d2;
+    if (gS) {
+      float dl = four ? 4.0f * d2 * d : 2.0f * d;   // d loss / d |S|
+      float f = (mag > 0.f) ? scale * invK * dl / mag : 0.f;
+      gS[(size_t)g * K + k] = make_float2(f * s.x, f * s.y);
+    }
+  }
+  e = block_sum(e, s_red);
+  l = block_sum(l, s_red);
+  if (threadIdx.x == 0) {
+    energy[g] = e * invK;
+    loss[g] = l * invK;
+  }
+}
+
+extern "C" int gfdn_spectral_stats(const float* S, int G, int K, int asym, float scale,
+                                   float* energy, float* loss, float* gS, void* stream) {
+  if (!S || !energy || !loss || G <= 0 || K <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_spectral_stats, dim3(G), dim3(1024), 0, (hipStream_t)stream,
+                     (const float2*)S, G, K, asym, scale, energy, loss, (float2*)gS);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,316 @@
+"""Tensor-level wrappers of the C-ABI entry points (one python function per C function).
+
+Every function takes / returns ``torch`` tensors that live on the GPU; outputs and scratch
+buffers are allocated here with torch (PyTorch owns all memory, the library owns none) and the
+launch goes onto ``torch.cuda.current_stream()``.  Inputs on the CPU raise: there is no CPU
+fallback in the product path.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_c64 = torch.complex64
+_f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("diffgfdn_amd HIP ops need CUDA/HIP tensors (no CPU fallback)")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(_f32).contiguous()
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(_c64).contiguous()
+
+
+def _work(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+def zprep(z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """z (K,) complex128 -> (turns, logr) float64."""
+    _need_gpu(z)
+    z = z.detach().to(torch.complex128).contiguous()
+    K = z.numel()
+    turns = torch.empty(K, dtype=torch.float64, device=z.device)
+    logr = torch.empty(K, dtype=torch.float64, device=z.device)
+    _lib.check(_lib.load().gfdn_zprep(_p(z), K, _p(turns), _p(logr), _stream()), "gfdn_zprep")
+    return turns, logr
+
+
+def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False) -> torch.Tensor:
+    """A (nblk,nper,nper) f32, delays/inv_gamma/b (N,) f32 -> Y (K,N) complex64."""
+    _need_gpu(turns, A)
+    A, delays, inv_gamma, b = _f(A), _f(delays), _f(inv_gamma), _f(b)
+    nblk, nper, _ = A.shape
+    K = turns.numel()
+    Y = torch.empty((K, nblk * nper), dtype=_c64, device=A.device)
+    _lib.check(_lib.load().gfdn_solve_fwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
+                                          _p(inv_gamma), _p(b), int(transpose), _p(Y), _stream()),
+               "gfdn_solve_fwd")
+    return Y
+
+
+def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False):
+    """-> gA (nblk,nper,nper), gb (N,), ginv_gamma (N,)  (float32)."""
+    _need_gpu(turns, A, gY)
+    A, delays, inv_gamma, b, gY = _f(A), _f(delays), _f(inv_gamma), _f(b), _c(gY)
+    nblk, nper, _ = A.shape
+    K = turns.numel()
+    lib = _lib.load()
+    gA = torch.empty_like(A)
+    gb = torch.empty(nblk * nper, dtype=_f32, device=A.device)
+    gig = torch.empty_like(gb)
+    work = _work(lib.gfdn_solve_bwd_work_bytes(nblk, nper), A.device)
+    _lib.check(lib.gfdn_solve_bwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
+                                  _p(inv_gamma), _p(b), int(transpose), _p(gY), _p(gA), _p(gb),
+                                  _p(gig), _p(work), _stream()), "gfdn_solve_bwd")
+    return gA, gb, gig
+
+
+def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False):
+    """Y (K,N) c64, c (N,), rgain (B,G) -> H (B,K) c64 [, S (G,K) c64]."""
+    _need_gpu(Y, c, rgain)
+    Y, c, rgain = _c(Y), _f(c), _f(rgain)
+    K, N = Y.shape
+    B, G = rgain.shape
+    assert G * nper == N
+    direct = None if direct is None else _c(direct)
+    filt = None if filt is None else _c(filt)
+    H = torch.empty((B, K), dtype=_c64, device=Y.device)
+    S = torch.empty((G, K), dtype=_c64, device=Y.device) if want_S else None
+    _lib.check(_lib.load().gfdn_compose_fwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(direct),
+                                            K if direct is not None else 0, _p(filt), _p(H), K,
+                                            _p(S), _stream()), "gfdn_compose_fwd")
+    return (H, S) if want_S else H
+
+
+def compose_bwd(Y, c, rgain, nper, gH, filt=None):
+    """-> gY (K,N) c64, gc (N,), grgain (B,G)."""
+    _need_gpu(Y, gH)
+    Y, c, rgain, gH = _c(Y), _f(c), _f(rgain), _c(gH)
+    K, N = Y.shape
+    B, G = rgain.shape
+    filt = None if filt is None else _c(filt)
+    lib = _lib.load()
+    gY = torch.empty_like(Y)
+    gc = torch.empty(N, dtype=_f32, device=Y.device)
+    grg = torch.empty((B, G), dtype=_f32, device=Y.device)
+    work = _work(lib.gfdn_compose_bwd_work_bytes(K, G, nper, B), Y.device)
+    _lib.check(lib.gfdn_compose_bwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(filt), _p(gH), K,
+                                    _p(gY), _p(gc), _p(grg), _p(work), _stream()),
+               "gfdn_compose_bwd")
+    return gY, gc, grg
+
+
+def compose_sh_fwd(Y, c, w, G, nper, filt=None):
+    """Y (K,N), c (N,), w (B,G,nper) -> H_sh (B,nper,K) c64."""
+    _need_gpu(Y, w)
+    Y, c, w = _c(Y), _f(c), _f(w)
+    K, N = Y.shape
+    B = w.shape[0]
+    filt = None if filt is None else _c(filt)
+    H = torch.empty((B, nper, K), dtype=_c64, device=Y.device)
+    _lib.check(_lib.load().gfdn_compose_sh_fwd(_p(Y), K, G, nper, _p(c), _p(w), B, _p(filt), _p(H),
+                                               _stream()), "gfdn_compose_sh_fwd")
+    return H
+
+
+def compose_sh_bwd(Y, c, w, G, nper, gH, filt=None):
+    """-> gY (K,N), gc (N,), gw (B,G,nper)."""
+    _need_gpu(Y, gH)
+    Y, c, w, gH = _c(Y), _f(c), _f(w), _c(gH)
+    K, N = Y.shape
+    B = w.shape[0]
+    filt = None if filt is None else _c(filt)
+    lib = _lib.load()
+    gY = torch.empty_like(Y)
+    gc = torch.empty(N, dtype=_f32, device=Y.device)
+    gw = torch.empty((B, G, nper), dtype=_f32, device=Y.device)
+    work = _work(lib.gfdn_compose_sh_bwd_work_bytes(G, nper, B), Y.device)
+    _lib.check(lib.gfdn_compose_sh_bwd(_p(Y), K, G, nper, _p(c), _p(w), B, _p(filt), _p(gH), _p(gY),
+                                       _p(gc), _p(gw), _p(work), _stream()), "gfdn_compose_sh_bwd")
+    return gY, gc, gw
+
+
+def spectral_stats(S, asym: bool, scale: float = 1.0, want_grad: bool = True):
+    """S (G,K) c64 -> energy (G,), loss (G,), gS (G,K) or None."""
+    _need_gpu(S)
+    S = _c(S)
+    G, K = S.shape
+    energy = torch.empty(G, dtype=_f32, device=S.device)
+    loss = torch.empty(G, dtype=_f32, device=S.device)
+    gS = torch.empty_like(S) if want_grad else None
+    _lib.check(_lib.load().gfdn_spectral_stats(_p(S), G, K, int(asym), float(scale), _p(energy),
+                                               _p(loss), _p(gS), _stream()), "gfdn_spectral_stats")
+    return energy, loss, gS
+
+
+# ------------------------------------------------------------------------------------------------
+_blu_tables = {}
+
+
+def bluestein_table(n: int, device) -> torch.Tensor:
+    """Plan data for irfft(X, n), n odd (cached per (n, device))."""
+    key = (int(n), str(device))
+    t = _blu_tables.get(key)
+    if t is None:
+        lib = _lib.load()
+        nbytes = lib.gfdn_bluestein_table_bytes(int(n))
+        if nbytes == 0:
+            raise RuntimeError(f"irfft_odd: n={n} must be odd and >= 3")
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(lib.gfdn_bluestein_table_init(int(n), _p(t)), "gfdn_bluestein_table_init")
+        _blu_tables[key] = t
+    return t
+
+
+def irfft_odd_fwd(X, n: int) -> torch.Tensor:
+    """X (batch, >= (n+1)/2) c64 -> x (batch, n) float32 = torch.fft.irfft(X, n), n odd."""
+    _need_gpu(X)
+    X = _c(X)
+    batch, ldx = X.shape
+    lib = _lib.load()
+    table = bluestein_table(n, X.device)
+    x = torch.empty((batch, n), dtype=_f32, device=X.device)
+    work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
+    _lib.check(lib.gfdn_irfft_odd_fwd(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work),
+                                      _stream()), "gfdn_irfft_odd_fwd")
+    return x
+
+
+def irfft_odd_bwd(gx, n: int, ldx: int) -> torch.Tensor:
+    """gx (batch, n) f32 -> gX (batch, ldx) c64 (adjoint of irfft_odd_fwd)."""
+    _need_gpu(gx)
+    gx = _f(gx)
+    batch = gx.shape[0]
+    lib = _lib.load()
+    table = bluestein_table(n, gx.device)
+    gX = torch.empty((batch, ldx), dtype=_c64, device=gx.device)
+    work = _work(lib.gfdn_bluestein_work_bytes(n, batch), gx.device)
+    _lib.check(lib.gfdn_irfft_odd_bwd(_p(table), n, _p(gx), gx.shape[1], batch, _p(gX), ldx,
+                                      _p(work), _stream()), "gfdn_irfft_odd_bwd")
+    return gX
+
+
+def irfft_pow2_fwd(X, n: int) -> torch.Tensor:
+    _need_gpu(X)
+    X = _c(X)
+    batch, ldx = X.shape
+    lib = _lib.load()
+    x = torch.empty((batch, n), dtype=_f32, device=X.device)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(n, batch), X.device)
+    _lib.check(lib.gfdn_irfft_pow2_fwd(n, _p(X), ldx, batch, _p(x), n, _p(work), _stream()),
+               "gfdn_irfft_pow2_fwd")
+    return x
+
+
+def irfft_pow2_bwd(gx, n: int) -> torch.Tensor:
+    _need_gpu(gx)
+    gx = _f(gx)
+    batch = gx.shape[0]
+    lib = _lib.load()
+    gX = torch.empty((batch, n // 2 + 1), dtype=_c64, device=gx.device)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(n, batch), gx.device)
+    _lib.check(lib.gfdn_irfft_pow2_bwd(n, _p(gx), gx.shape[1], batch, _p(gX), n // 2 + 1, _p(work),
+                                       _stream()), "gfdn_irfft_pow2_bwd")
+    return gX
+
+
+# ------------------------------------------------------------------------------------------------
+def stft_nframes(T: int, win: int) -> int:
+    nf = _lib.load().gfdn_stft_nframes(int(T), int(win))
+    if nf <= 0:
+        raise RuntimeError(f"stft: signal of {T} samples too short for window {win} (or win not 2^p)")
+    return nf
+
+
+def stft_power(x, win: int) -> torch.Tensor:
+    """x (batch, T) f32 -> P (batch, nframes, win/2+1) = |STFT|^2."""
+    _need_gpu(x)
+    x = _f(x)
+    batch, T = x.shape
+    nf = stft_nframes(T, win)
+    P = torch.empty((batch, nf, win // 2 + 1), dtype=_f32, device=x.device)
+    _lib.check(_lib.load().gfdn_stft_power(_p(x), T, T, batch, win, _p(P), _stream()),
+               "gfdn_stft_power")
+    return P
+
+
+def stft_power_bwd(x, win: int, gP, gx_accum: torch.Tensor) -> torch.Tensor:
+    """Accumulates d<gP, P>/dx into gx_accum (batch, T) and returns it."""
+    _need_gpu(x, gP, gx_accum)
+    x = _f(x)
+    batch, T = x.shape
+    assert gx_accum.dtype == _f32 and gx_accum.is_contiguous() and gx_accum.shape == x.shape
+    _lib.check(_lib.load().gfdn_stft_power_bwd(_p(x), T, T, batch, win, _p(gP), _p(gx_accum),
+                                               _stream()), "gfdn_stft_power_bwd")
+    return gx_accum
+
+
+def edr_target(P: torch.Tensor):
+    """In place: P (batch, nframes, nfreq) -> EDR dB.  Returns (T_db (= P), sum_abs (batch,))."""
+    _need_gpu(P)
+    assert P.dtype == _f32 and P.is_contiguous()
+    batch, nframes, nfreq = P.shape
+    lib = _lib.load()
+    sum_abs = torch.empty(batch, dtype=_f32, device=P.device)
+    work = _work(lib.gfdn_edr_work_bytes(batch, nfreq), P.device)
+    _lib.check(lib.gfdn_edr_target(_p(P), batch, nframes, nfreq, _p(sum_abs), _p(work), _stream()),
+               "gfdn_edr_target")
+    return P, sum_abs
+
+
+def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = True):
+    """In place on P (achieved |STFT|^2): returns loss_item (batch,); P becomes dloss/dP."""
+    _need_gpu(P, T_db)
+    assert P.dtype == _f32 and P.is_contiguous() and T_db.is_contiguous()
+    batch, nframes, nfreq = P.shape
+    lib = _lib.load()
+    wf = None if wf is None else _f(wf)
+    loss_item = torch.empty(batch, dtype=_f32, device=P.device)
+    work = _work(lib.gfdn_edr_work_bytes(batch, nfreq), P.device)
+    _lib.check(lib.gfdn_edr_loss(_p(P), _p(T_db), _p(sum_abs), _p(wf), batch, nframes, nfreq,
+                                 float(gscale), int(want_grad), _p(loss_item), _p(work), _stream()),
+               "gfdn_edr_loss")
+    return loss_item
+
+
+def edc_target(x, start: int, length: int) -> torch.Tensor:
+    _need_gpu(x)
+    x = _f(x)
+    batch, ld = x.shape
+    T_db = torch.empty((batch, length), dtype=_f32, device=x.device)
+    _lib.check(_lib.load().gfdn_edc_target(_p(x), ld, batch, start, length, _p(T_db), _stream()),
+               "gfdn_edc_target")
+    return T_db
+
+
+def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
+             gscale: float = 1.0, want_grad: bool = True):
+    """-> loss_item (batch,), gx (batch, ld) or None."""
+    _need_gpu(x, T_db)
+    x = _f(x)
+    batch, ld = x.shape
+    maskw = None if maskw is None else _f(maskw)
+    loss_item = torch.empty(batch, dtype=_f32, device=x.device)
+    gx = torch.empty_like(x) if want_grad else None
+    _lib.check(_lib.load().gfdn_edc_loss(_p(x), ld, batch, start, length, _p(T_db), _p(maskw),
+                                         float(inv_count), float(gscale), _p(loss_item), _p(gx),
+                                         _stream()), "gfdn_edc_loss")
+    return loss_item, gx

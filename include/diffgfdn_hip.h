@@ -1,0 +1,164 @@
+/*
+ * diffgfdn_hip.h -- C ABI of the MI355X (gfx950) hot path of DiffGFDN.
+ *
+ * The reference (orchidas/DiffGFDN) is pure Python and has no FFI of its own: the path below
+ * sits behind torch.nn.Module classes.  This header is therefore the boundary a maintainer
+ * would bind with ctypes (INTEGRATION.md shows the stub); each entry point cites the
+ * reference code it replaces (paths relative to the reference's src/diff_gfdn/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; PyTorch (or any caller) owns all
+ *     buffers, the library never allocates or frees device memory and keeps no global state;
+ *   - every launch is asynchronous on the caller's hipStream_t (passed as void*); the only
+ *     synchronous call is gfdn_bluestein_table_init (plan creation);
+ *   - complex values are interleaved float pairs (re, im) = torch.complex64; "c128" marks
+ *     interleaved doubles = torch.complex128;
+ *   - return value: 0 on success, a hipError_t (> 0) from the runtime, or a negative
+ *     GFDN_E_* code for argument errors.  Nothing is launched when an error is returned.
+ *   - matrices are row-major; "bin-major" means index [k][n] with the delay line fastest.
+ */
+#ifndef DIFFGFDN_HIP_H
+#define DIFFGFDN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFDN_ABI_VERSION 1
+#define GFDN_E_BADARG (-1)
+#define GFDN_E_UNSUPPORTED (-2)
+#define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
+#define GFDN_MAX_GROUPS 8      /* largest number of groups the compose kernels take   */
+#define GFDN_PARTIAL_BLOCKS 256 /* per-launch partial-sum slots of the reducing kernels */
+
+int gfdn_abi_version(void);
+
+/* ---- frequency grid --------------------------------------------------------------------
+ * z (K complex128, dataloader.py:552-566 `z_values`) -> turns[k] = arg(z_k)/2pi and
+ * logr[k] = ln|z_k| in float64, so that z^m is evaluated with an exactly reduced phase
+ * (feedback_loop.py:330 does z**delays in complex128).                                   */
+int gfdn_zprep(const double* z_c128, int K, double* turns, double* logr, void* stream);
+
+/* ---- per-bin resolvent solve  (feedback_loop.py:326-391, model.py:237-240, :615-619) ---
+ * For every bin k and diagonal block q (nblk blocks of size nper, N = nblk*nper):
+ *     T_k = diag(z_k^{m_i} * inv_gamma_i) - A_q            (transpose = 0)
+ *     T_k = diag(z_k^{m_i} * inv_gamma_i) - A_q^T          (transpose = 1, model.py:1083)
+ *     Y[k][q*nper + i] = (T_k^{-1} b)_i
+ * A: (nblk, nper, nper) real; zero inter-group coupling -> nblk = G blocks (Q_g^2 for the
+ * damped loop, raw M_g for the sub-FDNs); coupled feedback matrix -> nblk = 1, nper = N.
+ * Replaces torch.linalg.inv + the einsums: the inverse is never formed.
+ * logr may be NULL (unit circle).                                                         */
+int gfdn_solve_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                   const float* A, const float* delays, const float* inv_gamma,
+                   const float* b, int transpose, float* Y_c64, void* stream);
+
+/* Backward of gfdn_solve_fwd: given gY (K, N) complex64 (= dL/dRe + i dL/dIm of Y) returns
+ *   gA (nblk,nper,nper), gb (N), ginv_gamma (N).
+ * work: gfdn_solve_bwd_work_bytes(nblk, nper) bytes of scratch.  Sums over bins are formed
+ * in a fixed order (per-block partials + a second pass): results are bitwise reproducible. */
+size_t gfdn_solve_bwd_work_bytes(int nblk, int nper);
+int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                   const float* A, const float* delays, const float* inv_gamma,
+                   const float* b, int transpose, const float* gY_c64, float* gA, float* gb,
+                   float* ginv_gamma, void* work, void* stream);
+
+/* ---- output stage  (model.py:583-619, gain_filters.py:526-534, trainer.py:459) ----------
+ *   S[g][k]  = sum_{n in group g} c_n Y[k][n]
+ *   H[b][k]  = (sum_g rgain[b][g] S[g][k] + direct[b][k]) * filt[k]
+ * rgain: (B, G) receiver gains (MLP output, or eye(G) to obtain the sub-FDN responses
+ * model.py:243-250); direct (B, ldd) complex64 or NULL; filt (K) complex64 or NULL;
+ * S_out (G, K) complex64 or NULL.                                                         */
+int gfdn_compose_fwd(const float* Y_c64, int K, int G, int nper, const float* c,
+                     const float* rgain, int B, const float* direct_c64, int ldd,
+                     const float* filt_c64, float* H_c64, int ldh, float* S_out_c64,
+                     void* stream);
+
+/* Backward: gH (B, ldh) complex64 (gradient w.r.t. the FILTERED H when filt != NULL) ->
+ *   gY (K, N) complex64, gc (N), grgain (B, G).   work: gfdn_compose_bwd_work_bytes(). */
+size_t gfdn_compose_bwd_work_bytes(int K, int G, int nper, int B);
+int gfdn_compose_bwd(const float* Y_c64, int K, int G, int nper, const float* c,
+                     const float* rgain, int B, const float* filt_c64, const float* gH_c64,
+                     int ldh, float* gY_c64, float* gc, float* grgain, void* work, void* stream);
+
+/* Directional output stage (model.py:1056-1088): H_sh[b][l][k] = sum_g w[b][g][l] c_{g,l} Y[k][g*nper+l]
+ * and its backward.                                                                       */
+int gfdn_compose_sh_fwd(const float* Y_c64, int K, int G, int nper, const float* c,
+                        const float* w, int B, const float* filt_c64, float* H_c64,
+                        void* stream);
+size_t gfdn_compose_sh_bwd_work_bytes(int G, int nper, int B);
+int gfdn_compose_sh_bwd(const float* Y_c64, int K, int G, int nper, const float* c,
+                        const float* w, int B, const float* filt_c64, const float* gH_c64,
+                        float* gY_c64, float* gc, float* gw, void* work, void* stream);
+
+/* ---- colorless statistics of the sub-FDN responses  (colorless_fdn/losses.py:20-73,
+ * trainer.py:323-324).  S (G, K) complex64.  Per group g:
+ *   energy[g] = mean_k |S|^2 ;  loss[g] = mean_k (|S|-1)^p, p = 2, or (asym) 4 where |S|-1 > 1.
+ * gS (G, K) complex64 = scale * dloss[g]/dS, or NULL.                                     */
+int gfdn_spectral_stats(const float* S_c64, int G, int K, int asym, float scale,
+                        float* energy, float* loss, float* gS_c64, void* stream);
+
+/* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
+ * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's
+ * algorithm on power-of-two FFTs of length L >= n + (n-1)/2.
+ * table: gfdn_bluestein_table_bytes(n) bytes, filled once by gfdn_bluestein_table_init
+ * (host computes chirp / chirp spectrum / twiddles in float64; synchronous).
+ * work: gfdn_bluestein_work_bytes(n, batch).  X: (batch, ldx) complex64, only the first
+ * (n+1)/2 bins are read.  x: (batch, ldo) float.                                          */
+size_t gfdn_bluestein_table_bytes(int n);
+int gfdn_bluestein_table_init(int n, void* table);
+size_t gfdn_bluestein_work_bytes(int n, int batch);
+int gfdn_irfft_odd_fwd(const void* table, int n, const float* X_c64, int ldx, int batch,
+                       float* x, int ldo, void* work, void* stream);
+/* adjoint: gx (batch, ldo) -> gX (batch, ldx) complex64; bins above (n-1)/2 are set to 0. */
+int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, int ldo, int batch,
+                       float* gX_c64, int ldx, void* work, void* stream);
+
+/* ---- power-of-two inverse real FFT (utils.py:169 get_response, losses.py:344: default
+ * n = 2(K-1)): x = irfft(X[0..n/2], n), n = 2^p >= 16 (imaginary parts of the DC and Nyquist
+ * bins are ignored, as torch does), and its adjoint gX = d<gx, x>/dX (bins 0..n/2).
+ * work: gfdn_irfft_pow2_work_bytes(n, batch).                                            */
+size_t gfdn_irfft_pow2_work_bytes(int n, int batch);
+int gfdn_irfft_pow2_fwd(int n, const float* X_c64, int ldx, int batch, float* x, int ldo,
+                        void* work, void* stream);
+int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, float* gX_c64, int ldx,
+                        void* work, void* stream);
+
+/* ---- EDR  (losses.py:501-575: STFT Hann(win) hop win/2 center=False, tail energy, dB) ----
+ * x: (batch, ld) float, T valid samples, implicitly zero-padded to a multiple of hop.
+ * nframes = gfdn_stft_nframes(T, win).  P: (batch, nframes, win/2+1) float = |STFT|^2.    */
+int gfdn_stft_nframes(int T, int win);
+int gfdn_stft_power(const float* x, int ld, int T, int batch, int win, float* P, void* stream);
+/* in place: P -> EDR in dB (10 log10(sum_{tau>=m} P + eps), clipped at -200); sum_abs[b] =
+ * sum |EDR| (the per-item normaliser of losses.py:487-490).                               */
+size_t gfdn_edr_work_bytes(int batch, int nfreq);
+int gfdn_edr_target(float* P_inout, int batch, int nframes, int nfreq, float* sum_abs,
+                    void* work, void* stream);
+/* achieved side: loss_item[b] = sum_{f,m} wf[f] |T_db - EDR| / sum_abs[b]  (losses.py:478-492)
+ * and, when want_grad, P is overwritten with gscale * dloss/dP.                           */
+int gfdn_edr_loss(float* P_inout, const float* T_db, const float* sum_abs, const float* wf,
+                  int batch, int nframes, int nfreq, float gscale, int want_grad,
+                  float* loss_item, void* work, void* stream);
+/* adjoint of gfdn_stft_power: gx[b][t] += dL/dx from gP (atomic adds of exactly two frames
+ * per sample, hence order-independent).                                                   */
+int gfdn_stft_power_bwd(const float* x, int ld, int T, int batch, int win, const float* gP,
+                        float* gx, void* stream);
+
+/* ---- EDC  (losses.py:187-238: Schroeder integral of x[start:start+len]^2, dB, mean |diff|)
+ * T_db (batch, len) float: target EDC in dB from gfdn_edc_target.
+ * maskw (len) float weights (1 = kept index, 0 = dropped; losses.py:221-227) or NULL;
+ * inv_count = 1 / (global batch * number of kept indices).
+ * loss_item[b] = inv_count * sum_i maskw_i |T_db - EDC_db|; gx (batch, ld), when not NULL,
+ * is fully overwritten with gscale * dloss/dx (zeros outside the window).                 */
+int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float* T_db,
+                    void* stream);
+int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const float* T_db,
+                  const float* maskw, float inv_count, float gscale, float* loss_item,
+                  float* gx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFGFDN_HIP_H */

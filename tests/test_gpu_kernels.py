@@ -1,0 +1,237 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point against the float64 CPU maths of
+the oracle / torch on the same seeded inputs.  Tolerances are float32-level (1e-4 relative is
+the north-star bar; most kernels sit at 1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gfdn_oracle as orc
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffgfdn_amd import hip_ops
+    return hip_ops
+
+
+DEV = "cuda"
+
+
+def _grid(nfft):
+    return torch.tensor(np.exp(1j * 2 * np.pi * np.fft.rfftfreq(nfft)))
+
+
+def _primes(n, lo, hi, seed):
+    import sympy as sp
+    pr = np.array(list(sp.primerange(lo, hi)))
+    rng = np.random.RandomState(seed)
+    return np.r_[pr[rng.permutation(len(pr))][:n - 1], sp.nextprime(hi)].astype(np.float32)
+
+
+def _dense_from_blocks(A):
+    return torch.block_diag(*[A[i] for i in range(A.shape[0])])
+
+
+@pytest.mark.parametrize("nblk,nper,transpose,radius", [
+    (3, 4, False, 1.0), (4, 4, False, 1.0), (1, 12, False, 1.0), (1, 16, False, 1.0003),
+    (3, 9, True, 1.0), (4, 8, False, 1.0), (1, 27, True, 1.0), (1, 32, False, 1.0), (2, 3, False, 1.0)])
+def test_solve_fwd_bwd(ops, nblk, nper, transpose, radius):
+    torch.manual_seed(nblk * 100 + nper)
+    N = nblk * nper
+    nfft = 2048
+    z = _grid(nfft) * radius
+    K = z.numel()
+    delays = torch.tensor(_primes(N, 640, 1600, 3))
+    gamma = torch.tensor(10 ** (-3 * delays.double().numpy() / (32000 * 0.8)))
+    A = torch.stack([orc.ortho_param(torch.randn(nper, nper, dtype=torch.float64) / np.sqrt(nper))
+                     for _ in range(nblk)])
+    b = torch.randn(N, dtype=torch.float64) / N
+    gY = torch.randn(K, N, dtype=torch.complex128)
+
+    # float64 CPU reference with autograd
+    Ad = A.clone().requires_grad_(True)
+    bd = b.clone().requires_grad_(True)
+    ig = (1.0 / gamma).clone().requires_grad_(True)
+    D = torch.diag_embed((z[:, None] ** delays.double()) * ig)
+    Afull = _dense_from_blocks(Ad).to(torch.complex128)
+    T = D - (Afull.T if transpose else Afull)
+    Yref = torch.linalg.solve(T, bd.to(torch.complex128).expand(K, N).unsqueeze(-1)).squeeze(-1)
+    (Yref.real * gY.real + Yref.imag * gY.imag).sum().backward()
+
+    turns, logr = ops.zprep(z.to(DEV))
+    Y = ops.solve_fwd(turns, logr if radius != 1.0 else None, A.to(DEV), delays.to(DEV),
+                      (1.0 / gamma).to(DEV), b.to(DEV), transpose)
+    assert rel_err(Y.cpu(), Yref.detach()) < 2e-5
+    gA, gb, gig = ops.solve_bwd(turns, logr if radius != 1.0 else None, A.to(DEV), delays.to(DEV),
+                                (1.0 / gamma).to(DEV), b.to(DEV), gY.to(DEV), transpose)
+    assert rel_err(gA.cpu(), Ad.grad) < 1e-4
+    assert rel_err(gb.cpu(), bd.grad) < 1e-4
+    assert rel_err(gig.cpu(), ig.grad) < 1e-4
+
+
+@pytest.mark.parametrize("G,nper,B,use_filt,use_direct", [(3, 4, 5, True, True), (4, 4, 32, False, True),
+                                                          (2, 8, 3, True, False), (3, 9, 9, False, False)])
+def test_compose_fwd_bwd(ops, G, nper, B, use_filt, use_direct):
+    torch.manual_seed(G * 10 + nper)
+    K, N = 1025, G * nper
+    Y = torch.randn(K, N, dtype=torch.complex128)
+    c = torch.randn(N, dtype=torch.float64).requires_grad_(True)
+    rg = torch.randn(B, G, dtype=torch.float64).requires_grad_(True)
+    direct = torch.randn(B, K, dtype=torch.complex128) if use_direct else None
+    filt = torch.randn(K, dtype=torch.complex128) if use_filt else None
+    gH = torch.randn(B, K, dtype=torch.complex128)
+    Yd = Y.clone().requires_grad_(True)
+    S = (Yd * c).reshape(K, G, nper).sum(-1).T                       # (G,K)
+    H = rg.to(torch.complex128) @ S
+    if use_direct:
+        H = H + direct
+    if use_filt:
+        H = H * filt
+    (H.real * gH.real + H.imag * gH.imag).sum().backward()
+
+    d = lambda t: None if t is None else t.to(DEV)
+    Hk, Sk = ops.compose_fwd(d(Y), d(c), d(rg), nper, d(direct), d(filt), want_S=True)
+    assert rel_err(Hk.cpu(), H.detach()) < 1e-5
+    assert rel_err(Sk.cpu(), S.detach()) < 1e-5
+    gY, gc, grg = ops.compose_bwd(d(Y), d(c), d(rg), nper, d(gH), d(filt))
+    assert rel_err(gY.cpu(), Yd.grad) < 1e-5
+    assert rel_err(gc.cpu(), c.grad) < 1e-4
+    assert rel_err(grg.cpu(), rg.grad) < 1e-4
+
+
+def test_compose_sh_fwd_bwd(ops):
+    torch.manual_seed(5)
+    G, nper, B, K = 3, 9, 4, 777
+    N = G * nper
+    Y = torch.randn(K, N, dtype=torch.complex128).requires_grad_(True)
+    c = torch.randn(N, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(B, G, nper, dtype=torch.float64).requires_grad_(True)
+    filt = torch.randn(K, dtype=torch.complex128)
+    gH = torch.randn(B, nper, K, dtype=torch.complex128)
+    Yg = (Y * c).T.reshape(G, nper, K)                                  # (G,nper,K)
+    H = (w.unsqueeze(-1).to(torch.complex128) * Yg.unsqueeze(0)).sum(1) * filt
+    (H.real * gH.real + H.imag * gH.imag).sum().backward()
+    d = lambda t: t.detach().to(DEV)
+    Hk = ops.compose_sh_fwd(d(Y), d(c), d(w), G, nper, d(filt))
+    assert rel_err(Hk.cpu(), H.detach()) < 1e-5
+    gY, gc, gw = ops.compose_sh_bwd(d(Y), d(c), d(w), G, nper, d(gH), d(filt))
+    assert rel_err(gY.cpu(), Y.grad) < 1e-5
+    assert rel_err(gc.cpu(), c.grad) < 1e-4
+    assert rel_err(gw.cpu(), w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("asym", [False, True])
+def test_spectral_stats(ops, asym):
+    torch.manual_seed(1)
+    G, K = 3, 4097
+    S = (torch.randn(G, K, dtype=torch.complex128) * 1.5).requires_grad_(True)
+    fn = orc.amse_loss if asym else orc.mse_loss
+    losses = torch.stack([fn(S[g], torch.ones_like(S[g])) for g in range(G)])
+    (losses.sum() * 0.7).backward()
+    energy, loss, gS = ops.spectral_stats(S.detach().to(DEV), asym, 0.7)
+    assert rel_err(loss.cpu(), losses.detach()) < 1e-5
+    assert rel_err(energy.cpu(), (S.detach().abs() ** 2).mean(-1)) < 1e-5
+    assert rel_err(gS.cpu(), S.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,batch", [(257, 3), (4097, 2), (65537, 2), (1025, 1), (33, 2)])
+def test_irfft_odd(ops, n, batch):
+    torch.manual_seed(n)
+    X = torch.randn(batch, n, dtype=torch.complex128, requires_grad=True)
+    x = torch.fft.irfft(X, n)
+    gx = torch.randn(batch, n, dtype=torch.float64)
+    (x * gx).sum().backward()
+    xk = ops.irfft_odd_fwd(X.detach().to(DEV), n)
+    assert rel_err(xk.cpu(), x.detach()) < 5e-6
+    gX = ops.irfft_odd_bwd(gx.to(DEV), n, n)
+    assert rel_err(gX.cpu(), X.grad) < 5e-6
+
+
+@pytest.mark.parametrize("n,batch", [(512, 3), (8192, 2), (131072, 2), (16, 1)])
+def test_irfft_pow2(ops, n, batch):
+    torch.manual_seed(n)
+    X = torch.randn(batch, n // 2 + 1, dtype=torch.complex128, requires_grad=True)
+    x = torch.fft.irfft(X)
+    gx = torch.randn(batch, n, dtype=torch.float64)
+    (x * gx).sum().backward()
+    xk = ops.irfft_pow2_fwd(X.detach().to(DEV), n)
+    assert rel_err(xk.cpu(), x.detach()) < 5e-6
+    gX = ops.irfft_pow2_bwd(gx.to(DEV), n)
+    assert rel_err(gX.cpu(), X.grad) < 5e-6
+
+
+@pytest.mark.parametrize("T,win,batch", [(257, 64, 3), (65537, 4096, 2), (4097, 512, 2), (1024, 256, 1)])
+def test_stft_power(ops, T, win, batch):
+    torch.manual_seed(T)
+    x = torch.randn(batch, T, dtype=torch.float64, requires_grad=True)
+    S = orc.stft_onesided(x, win, win // 2)                               # (batch, F, frames)
+    P = (S.abs() ** 2).transpose(1, 2)                                    # (batch, frames, F)
+    gP = torch.rand_like(P)
+    (P * gP).sum().backward()
+    Pk = ops.stft_power(x.detach().to(DEV), win)
+    assert Pk.shape == P.shape
+    assert rel_err(Pk.cpu(), P.detach()) < 5e-6
+    gx = torch.zeros(batch, T, dtype=torch.float32, device=DEV)
+    ops.stft_power_bwd(x.detach().to(DEV), win, gP.float().to(DEV).contiguous(), gx)
+    assert rel_err(gx.cpu(), x.grad) < 5e-6
+
+
+@pytest.mark.parametrize("use_wf", [False, True])
+def test_edr_loss_kernels(ops, use_wf):
+    torch.manual_seed(3)
+    batch, nframes, nfreq = 3, 32, 2049
+    env = torch.exp(-torch.arange(nframes, dtype=torch.float64) / 6.0)[None, :, None]
+    Pt = torch.rand(batch, nframes, nfreq, dtype=torch.float64) * env
+    Pa = (torch.rand(batch, nframes, nfreq, dtype=torch.float64) * env * 1.3).requires_grad_(True)
+    wf = torch.rand(nfreq, dtype=torch.float64) + 0.5 if use_wf else None
+
+    def edr_db(P):
+        E = torch.flip(torch.cumsum(torch.flip(P, dims=[1]), dim=1), dims=[1])
+        return orc.db(E.float(), is_squared=True) if not P.requires_grad else orc.db(E, is_squared=True)
+
+    Tdb = edr_db(Pt).double()
+    Adb = edr_db(Pa)
+    fl = torch.abs(Tdb - Adb).sum(1)
+    if use_wf:
+        fl = fl * wf
+    item = fl.sum(-1) / Tdb.abs().sum(dim=[1, 2])
+    (item.sum() * 2.0).backward()
+
+    Tk, sabs = ops.edr_target(Pt.float().to(DEV).contiguous())
+    assert rel_err(Tk.cpu(), Tdb) < 1e-5
+    assert rel_err(sabs.cpu(), Tdb.abs().sum(dim=[1, 2])) < 1e-5
+    Pk = Pa.detach().float().to(DEV).contiguous()
+    li = ops.edr_loss(Pk, Tk, sabs, None if wf is None else wf.to(DEV), gscale=2.0)
+    assert rel_err(li.cpu(), item.detach()) < 1e-4
+    # gradient: sign flips where |diff| ~ 0 are measure-zero; compare in L1 norm
+    g = Pk.cpu().double()
+    num = (g - Pa.grad).abs().sum() / Pa.grad.abs().sum()
+    assert num < 1e-3
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_edc_loss_kernels(ops, masked):
+    torch.manual_seed(4)
+    batch, ld, start, length = 3, 65537, 640, 47360
+    t = torch.arange(ld, dtype=torch.float64)
+    xt = torch.randn(batch, ld, dtype=torch.float64) * torch.exp(-t / 9000.0)
+    xa = (torch.randn(batch, ld, dtype=torch.float64) * torch.exp(-t / 7000.0) * 0.8).requires_grad_(True)
+    mask = (torch.rand(length) < 0.5).double() if masked else torch.ones(length, dtype=torch.float64)
+    cnt = mask.sum().item()
+    Tdb = orc.db(orc.schroeder(xt[:, start:start + length]), is_squared=True)
+    Adb = orc.db(orc.schroeder(xa[:, start:start + length]), is_squared=True)
+    loss = ((Tdb - Adb).abs() * mask).sum() / (batch * cnt)
+    (loss * 10.0).backward()
+    Tk = ops.edc_target(xt.float().to(DEV), start, length)
+    assert rel_err(Tk.cpu(), Tdb) < 2e-5
+    li, gx = ops.edc_loss(xa.detach().float().to(DEV), start, length, Tk,
+                          mask.to(DEV) if masked else None, 1.0 / (batch * cnt), 10.0)
+    assert abs(li.sum().item() - loss.item()) < 1e-4 * abs(loss.item())
+    num = (gx.cpu().double() - xa.grad).abs().sum() / xa.grad.abs().sum()
+    assert num < 1e-3
+    assert float(gx[:, :start].abs().max()) == 0.0 and float(gx[:, start + length:].abs().max()) == 0.0
