@@ -1,0 +1,217 @@
+"""Dataset front end: RIRs -> frequency responses on the z grid, resident in HBM.
+
+Mirror of the reference's src/diff_gfdn/dataloader.py for the grid-of-receivers case:
+RoomDataset.__init__ (:188-254: rfft of the RIRs), early_late_split (:300-325: 20 ms mixing time,
+5 ms Hann fades applied IN PLACE on views of ``rirs`` after the full-RIR rfft), MultiRIRDataset
+(:515-600: z = polar(r, 2 pi rfftfreq(nfft))), custom_collate (:674-704: batch dict), load_dataset
+(:780-867: fixed 10 % test split with its own generator, then random train/valid split).
+
+MI355X layout: one process keeps the whole grid on its GPU -- 838 receivers x 65 537 bins of
+complex64 for the direct path (0.44 GB) plus, once computed, the model-independent target EDR
+(838 x 32 x 2049 f32, 0.22 GB) and EDC (838 x 47 360 f32, 0.16 GB); a batch is an index list.
+The three load-time rFFTs are one-off: they run as batched torch.fft calls on the device in
+float64 (SURVEY §8 f-4 ranks a hand-written front-end kernel last).
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip_ops as ops
+
+
+def ms_to_samps(ms: float, fs: float) -> int:
+    return int(ms * 1e-3 * fs)
+
+
+class RoomDataset:
+    """RIR grid of one (coupled) room, reference dataloader.py:185-422."""
+
+    def __init__(self, num_rooms: int, sample_rate: float, source_position: np.ndarray,
+                 receiver_position: np.ndarray, rirs: np.ndarray, common_decay_times,
+                 room_dims=None, room_start_coord=None, band_centre_hz=None, amplitudes=None,
+                 noise_floor=None, absorption_coeffs=None, aperture_coords=None,
+                 mixing_time_ms: float = 20.0, nfft: Optional[int] = None,
+                 grid_spacing_m: float = 0.3, device: str = 'cuda', chunk: int = 128):
+        self.sample_rate = sample_rate
+        self.num_rooms = num_rooms
+        self.source_position = np.asarray(source_position)
+        self.receiver_position = np.asarray(receiver_position)
+        self.rirs = rirs
+        self.band_centre_hz = band_centre_hz
+        self.common_decay_times = np.asarray(common_decay_times)
+        self.amplitudes = amplitudes
+        self.noise_floor = noise_floor
+        self.num_rec = self.receiver_position.shape[0]
+        self.num_src = self.source_position.shape[0] if self.source_position.ndim > 1 else 1
+        self.rir_length = self.rirs.shape[-1]
+        self.mixing_time_ms = mixing_time_ms
+        self.nfft = nfft
+        self._eps = 1e-12
+        self.device = device
+        self._front_end(chunk)
+
+    @property
+    def num_freq_bins(self) -> int:
+        if self.nfft is not None:
+            return self.nfft
+        max_rt60_samps = self.common_decay_times.max() * self.sample_rate
+        return int(np.power(2, np.ceil(np.log2(max_rt60_samps))))
+
+    @property
+    def norm_receiver_position(self) -> np.ndarray:
+        p = self.receiver_position
+        lo, hi = p.min(axis=0), p.max(axis=0)
+        return (p - lo) / ((hi - lo) + self._eps)
+
+    @property
+    def freq_bins_rad(self) -> np.ndarray:
+        return np.fft.rfftfreq(self.num_freq_bins) * 2 * np.pi
+
+    def _front_end(self, chunk: int):
+        """rfft(full) -> in-place fades -> rfft(late), rfft(early)  (reference :250, :300-325)."""
+        nfft = self.num_freq_bins
+        K = nfft // 2 + 1
+        fs = self.sample_rate
+        mix = ms_to_samps(self.mixing_time_ms, fs)
+        win = ms_to_samps(5.0, fs)
+        w = np.hanning(win)
+        R = self.num_rec
+        dev = self.device
+        self.rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
+        self.early_rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
+        self.late_rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
+        fade_out = torch.tensor(w[win // 2:], device=dev)
+        fade_in = torch.tensor(w[:win // 2], device=dev)
+        for r0 in range(0, R, chunk):
+            blk = torch.as_tensor(self.rirs[r0:r0 + chunk], dtype=torch.float64, device=dev)
+            self.rir_mag_response[r0:r0 + chunk] = torch.fft.rfft(blk, n=nfft, dim=-1)
+            # the reference windows views of self.rirs in place AFTER the full-RIR rfft
+            ko = win - win // 2                   # reference slices [-win // 2:] == ceil(win / 2)
+            blk[:, mix - ko:mix] *= fade_out
+            blk[:, mix:mix + win // 2] *= fade_in
+            self.late_rir_mag_response[r0:r0 + chunk] = torch.fft.rfft(blk[:, mix:], n=nfft, dim=-1)
+            self.early_rir_mag_response[r0:r0 + chunk] = torch.fft.rfft(blk[:, :mix], n=nfft, dim=-1)
+            if isinstance(self.rirs, np.ndarray):
+                self.rirs[r0:r0 + chunk] = blk.cpu().numpy()     # keep the in-place side effect
+
+
+class MultiRIRDataset(torch.utils.data.Dataset):
+    """Frequency-domain grid dataset, reference dataloader.py:515-600; tensors live on the GPU."""
+
+    def __init__(self, device, room_data: RoomDataset, new_sampling_radius: Optional[float] = None):
+        self.device = device
+        self.source_position = torch.tensor(np.atleast_2d(room_data.source_position), device=device)
+        self.listener_positions = torch.tensor(room_data.receiver_position, device=device)
+        self.norm_listener_position = torch.tensor(room_data.norm_receiver_position, device=device)
+        w = torch.tensor(room_data.freq_bins_rad, device=device)
+        r = 1.0 if new_sampling_radius in (1.0, None) else float(new_sampling_radius)
+        self.z_values = torch.polar(r * torch.ones_like(w), w)
+        self.rir_mag_response = room_data.rir_mag_response
+        self.late_rir_mag_response = room_data.late_rir_mag_response
+        self.early_rir_mag_response = room_data.early_rir_mag_response
+        self.edr_store = None     # (T_db (R,frames,F), sum_abs (R,)) once precomputed
+        self.edc_store = None     # ((start, length), T_db (R,length))
+
+    def __len__(self):
+        return self.listener_positions.shape[0]
+
+    def __getitem__(self, idx: int):
+        return int(idx)
+
+    # model-independent loss targets for the whole grid (SURVEY §8d "precomputed once")
+    def precompute_decay_targets(self, win: int, edc_start: int, edc_len: int, chunk: int = 64):
+        R = len(self)
+        nf = ops.stft_nframes(self.rir_mag_response.shape[-1], win)
+        T_edr = torch.empty((R, nf, win // 2 + 1), dtype=torch.float32, device=self.device)
+        sum_abs = torch.empty(R, dtype=torch.float32, device=self.device)
+        T_edc = torch.empty((R, edc_len), dtype=torch.float32, device=self.device)
+        K = self.rir_mag_response.shape[-1]
+        for r0 in range(0, R, chunk):
+            x = ops.irfft_odd_fwd(self.rir_mag_response[r0:r0 + chunk], K)
+            P = ops.stft_power(x, win)
+            t, s = ops.edr_target(P)
+            T_edr[r0:r0 + chunk], sum_abs[r0:r0 + chunk] = t, s
+            T_edc[r0:r0 + chunk] = ops.edc_target(x, edc_start, edc_len)
+        self.edr_store = (win, T_edr, sum_abs)
+        self.edc_store = ((edc_start, edc_len), T_edc)
+
+    def collate(self, indices: Sequence[int], lean: bool = False) -> Dict:
+        """Batch dict with the reference's keys (custom_collate :674-704) + 'receiver_index'.
+        ``lean`` skips gathering responses the training step does not read (the late response
+        always; the full target response when its EDR / EDC are already in the stores)."""
+        idx = torch.as_tensor(list(indices), dtype=torch.long, device=self.device)
+        B = idx.numel()
+        batch = {
+            'z_values': self.z_values,
+            'source_position': self.source_position[0].expand(B, -1),
+            'listener_position': self.listener_positions[idx],
+            'norm_listener_position': self.norm_listener_position[idx],
+            'target_early_response': self.early_rir_mag_response[idx],
+            'receiver_index': idx,
+        }
+        if not lean:
+            batch['target_late_response'] = self.late_rir_mag_response[idx]
+        if not lean or self.edr_store is None or self.edc_store is None:
+            batch['target_rir_response'] = self.rir_mag_response[idx]
+        if self.edr_store is not None:
+            win, T, s = self.edr_store
+            batch['edr_target'] = (win, T[idx], s[idx])
+        if self.edc_store is not None:
+            (st, ln), T = self.edc_store
+            batch['edc_target'] = ((st, ln), T[idx])
+        return batch
+
+
+def split_dataset(dataset, train_valid_split_ratio: float, test_ratio: Optional[float] = None,
+                  test_seed: int = 4314) -> Tuple[List[int], List[int], List[int]]:
+    """Index lists (train, valid, test): fixed test split drawn with its own generator
+    (reference create_fixed_test_split :707-728), then a random split of the remainder with the
+    global generator (reference :829-843)."""
+    n = len(dataset)
+    test: List[int] = []
+    remaining = list(range(n))
+    if test_ratio:
+        gen = torch.Generator().manual_seed(test_seed)
+        perm = torch.randperm(n, generator=gen).tolist()
+        nt = int(n * test_ratio)
+        test, remaining = perm[:nt], perm[nt:]
+    nrem = len(remaining)
+    ntrain = int(train_valid_split_ratio * nrem)
+    perm = torch.randperm(nrem).tolist()
+    train = [remaining[i] for i in perm[:ntrain]]
+    valid = [remaining[i] for i in perm[ntrain:]]
+    return train, valid, test
+
+
+class GridLoader:
+    """Minimal DataLoader over index lists: shuffles with the global torch generator and yields
+    collated batch dicts.  Optionally shards every batch over the ranks of a process group
+    (data-parallel over receiver positions)."""
+
+    def __init__(self, dataset: MultiRIRDataset, indices: Sequence[int], batch_size: int,
+                 shuffle: bool = True, drop_last: bool = False, rank: int = 0, world_size: int = 1,
+                 lean: bool = False):
+        self.dataset = dataset
+        self.indices = list(indices)
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.drop_last = drop_last
+        self.rank, self.world_size = rank, world_size
+        self.lean = lean
+
+    def __len__(self):
+        n = len(self.indices)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = self.indices
+        if self.shuffle:
+            perm = torch.randperm(len(order)).tolist()
+            order = [order[i] for i in perm]
+        for i in range(len(self)):
+            chunk = order[i * self.batch_size:(i + 1) * self.batch_size]
+            if self.world_size > 1:
+                chunk = chunk[self.rank::self.world_size]
+            if chunk:
+                yield self.dataset.collate(chunk, lean=self.lean)

@@ -1,0 +1,228 @@
+"""Feedback loop of the GFDN: orthogonal feedback-matrix parameterisation and the per-bin
+resolvent (D_m(z) Gamma^{-1} - A)^{-1}.
+
+Interface mirror of the reference's src/diff_gfdn/feedback_loop.py (FeedbackLoop :146-509,
+constructor :148-160, forward :326-391).  Differences in HOW, not WHAT:
+  * the reference materialises D, Gamma, A as (K, N, N) complex128 tensors and calls
+    torch.linalg.inv; here the per-bin systems are SOLVED by the HIP kernel
+    (csrc/solve.hip) against whichever right-hand side the caller needs
+    (:meth:`resolvent_apply` -- the models use b, never the inverse);
+  * with zero inter-group coupling A = blockdiag(Q_g Q_g) (reference :393-404 with Phi = I), so
+    the kernel works on G independent n x n blocks instead of one N x N matrix;
+  * ``forward(z)`` still returns the explicit (K, N, N) complex64 inverse for API parity (N solves).
+The tiny parameterisation (expm of skew matrices, Givens rotations) stays on torch ops on the
+device: G^2 products of 4x4..16x16 matrices per step.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .config import CouplingMatrixType
+from .functional import FrequencyGrid, ResolventSolve
+
+
+class Skew(nn.Module):
+    """X -> triu(X,1) - triu(X,1)^T   (reference :16-25)."""
+
+    def forward(self, X: torch.Tensor) -> torch.Tensor:
+        A = X.triu(1)
+        return A - A.transpose(-1, -2)
+
+
+class MatrixExponential(nn.Module):
+    """reference :28-36."""
+
+    def forward(self, X: torch.Tensor) -> torch.Tensor:
+        return torch.matrix_exp(X)
+
+
+class ND_Unitary(nn.Module):
+    """N x N rotation from N(N-1)/2 Givens angles, U_n = R_{n-2}..R_0 diag(U_{n-1}, 1)
+    (reference :39-87).  N == 1 returns the python int 1, as the reference does."""
+
+    def forward(self, alpha: torch.Tensor, N: int):
+        assert len(alpha) == N * (N - 1) // 2
+        if N == 1:
+            return 1
+        eye = torch.eye(N, dtype=alpha.dtype, device=alpha.device)
+        start = (N - 1) * (N - 2) // 2
+        cur = alpha[start:]
+        rot = eye
+        for i in range(N - 1):
+            c, s = torch.cos(cur[i]), torch.sin(cur[i])
+            R = eye.clone()
+            R[i, i] = c
+            R[i, -1] = -s
+            R[-1, i] = s
+            R[-1, -1] = c
+            rot = R @ rot
+        big = eye.clone()
+        big[:N - 1, :N - 1] = self.forward(alpha[:start], N - 1)
+        return rot @ big
+
+
+def decay_times_to_gain_per_sample(common_decay_times, delay_length_samp, fs):
+    """gamma = 10^(0.05 * (-60 m / (fs T60)))   (reference absorption_filters.py:40-53)."""
+    if isinstance(common_decay_times, torch.Tensor):
+        return torch.pow(10.0, (-60 * delay_length_samp / (fs * common_decay_times)) * 0.05)
+    return np.power(10.0, (-60 * np.array(delay_length_samp) / (fs * common_decay_times)) * 0.05)
+
+
+class FeedbackLoop(nn.Module):
+
+    def __init__(self,
+                 sample_rate: float,
+                 num_groups: int,
+                 num_delay_lines_per_group: int,
+                 delays: torch.Tensor,
+                 use_absorption_filters: bool,
+                 coupling_matrix_type: CouplingMatrixType = None,
+                 use_zero_coupling: bool = True,
+                 coupling_matrix_order: Optional[int] = None,
+                 colorless_feedback_matrix: Optional[torch.Tensor] = None,
+                 gains: Optional[torch.Tensor] = None,
+                 common_decay_times: Optional[List] = None,
+                 device: torch.device = 'cpu'):
+        super().__init__()
+        if use_absorption_filters:
+            raise NotImplementedError("frequency-dependent absorption filters: SURVEY §8 f-2 (next)")
+        if coupling_matrix_type == CouplingMatrixType.FILTER:
+            raise NotImplementedError("paraunitary FILTER coupling: SURVEY §8 f-2 (next)")
+        self.sample_rate = sample_rate
+        self.num_groups = num_groups
+        self.num_delay_lines_per_group = num_delay_lines_per_group
+        # non-persistent buffers: follow .to(device) without adding state-dict keys
+        self.register_buffer('delays', torch.as_tensor(delays, dtype=torch.float32).clone(),
+                             persistent=False)
+        self.num_delays = len(self.delays)
+        self.use_absorption_filters = use_absorption_filters
+        self.use_zero_coupling = use_zero_coupling
+        self.device = device
+        self.coupling_matrix_type = coupling_matrix_type
+        self.coupling_matrix_order = coupling_matrix_order
+        self.ortho_param = nn.Sequential(Skew(), MatrixExponential())
+        self._init_absorption(gains, common_decay_times)
+        self._init_feedback_matrix(colorless_feedback_matrix)
+
+    # -- reference :193-258 (scalar-gain branches) ------------------------------------------------
+    def _init_absorption(self, gains, common_decay_times):
+        G, n = self.num_groups, self.num_delay_lines_per_group
+        self.learn_decay_times = gains is None
+        if gains is None:
+            if common_decay_times is None:
+                init = 0.1 + (2.0 - 0.1) * torch.rand(G)
+            else:
+                init = torch.tensor(np.asarray(common_decay_times).squeeze())
+            self.common_decay_times = nn.Parameter(init)
+            self.delays_by_group = [self.delays[i:i + n] for i in range(0, self.num_delays, n)]
+        else:
+            # plain attribute like the reference (:258); moved by _apply below, and re-linked to
+            # the owning model's persistent ``delay_filters`` buffer by DiffGFDN._apply
+            self.delay_line_gains = torch.as_tensor(gains)
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        if not self.learn_decay_times:
+            self.delay_line_gains = fn(self.delay_line_gains)
+        return self
+
+    def current_gains(self) -> torch.Tensor:
+        """gamma_n (N,), differentiable w.r.t. learnable decay times (reference :221-232)."""
+        if self.learn_decay_times:
+            dev = self.common_decay_times.device
+            return torch.cat([decay_times_to_gain_per_sample(
+                self.common_decay_times[i], self.delays_by_group[i].to(dev),
+                torch.tensor(self.sample_rate, device=dev)) for i in range(self.num_groups)])
+        return self.delay_line_gains
+
+    # -- reference :260-324 ------------------------------------------------------------------------
+    def _init_feedback_matrix(self, colorless_feedback_matrix):
+        G, n = self.num_groups, self.num_delay_lines_per_group
+        if self.coupling_matrix_type == CouplingMatrixType.RANDOM:
+            self.random_feedback_matrix = nn.Parameter(
+                (2 * torch.rand(self.num_delays, self.num_delays) - 1) / np.sqrt(n))
+            return
+        if colorless_feedback_matrix is not None:
+            self.register_buffer('M', colorless_feedback_matrix.clone().detach(), persistent=False)
+        else:
+            self.M = nn.Parameter((2 * torch.rand(G, n, n) - 1) / np.sqrt(n))
+        self.nd_unitary = ND_Unitary()
+        if self.use_zero_coupling:
+            self.register_buffer("alpha", torch.zeros(G * (G - 1) // 2))
+        else:
+            self.alpha = nn.Parameter(np.pi / 4 * torch.rand(G * (G - 1) // 2, dtype=torch.float32))
+
+    # -- reference :393-455 ------------------------------------------------------------------------
+    def group_rotations(self) -> torch.Tensor:
+        """Q_g = expm(skew(M_g)), (G, n, n)."""
+        return self.ortho_param(self.M)
+
+    def construct_block_mixing_matrix(self) -> torch.Tensor:
+        Q = self.group_rotations()
+        G, n = self.num_groups, self.num_delay_lines_per_group
+        blocks = torch.einsum('iab,jbc->iajc', Q, Q)          # block (i,j) = Q_i Q_j
+        return blocks.reshape(G * n, G * n)
+
+    def construct_coupling_matrix(self):
+        alpha = self.alpha.clamp(min=-np.pi, max=np.pi)
+        return self.nd_unitary(alpha, self.num_groups)
+
+    def get_coupled_feedback_matrix(self) -> torch.Tensor:
+        """A = block_M o kron(Phi, 1) as complex64 (N, N)   (reference :424-455)."""
+        A = self._real_feedback_matrix()
+        return torch.complex(A, torch.zeros_like(A))
+
+    def _real_feedback_matrix(self) -> torch.Tensor:
+        if self.coupling_matrix_type == CouplingMatrixType.RANDOM:
+            return self.ortho_param(self.random_feedback_matrix)
+        block_M = self.construct_block_mixing_matrix()
+        self.phi = self.construct_coupling_matrix()
+        if self.num_groups == 1:
+            return block_M                       # reference falls back to block_M (:441-445)
+        n = self.num_delay_lines_per_group
+        ones = torch.ones((n, n), dtype=block_M.dtype, device=block_M.device)
+        return block_M * torch.kron(self.phi, ones)
+
+    def feedback_blocks(self) -> torch.Tensor:
+        """What the solver consumes: (G, n, n) diagonal blocks Q_g Q_g when the groups are
+        uncoupled, else the dense (1, N, N) matrix."""
+        if self.coupling_matrix_type != CouplingMatrixType.RANDOM and self.use_zero_coupling:
+            Q = self.group_rotations()
+            return Q @ Q
+        return self._real_feedback_matrix().unsqueeze(0)
+
+    # -- the hot path ------------------------------------------------------------------------------
+    def resolvent_apply(self, z: torch.Tensor, b: torch.Tensor,
+                        transpose: bool = False) -> torch.Tensor:
+        """Y[k] = (D(z_k) Gamma^{-1} - A)^{-1} b  -> (K, N) complex64; A^T when ``transpose``."""
+        grid = FrequencyGrid.of(z)
+        A = self.feedback_blocks()
+        dev = A.device
+        inv_gamma = 1.0 / self.current_gains().to(dev)
+        return ResolventSolve.apply(A, inv_gamma.to(torch.float32), b.reshape(-1).to(dev),
+                                    grid, self.delays.to(dev), transpose)
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        """Explicit (K, N, N) complex64 inverse, for API parity with reference :326-391."""
+        N = self.num_delays
+        dev = z.device
+        cols = [self.resolvent_apply(z, torch.eye(N, device=dev)[j]) for j in range(N)]
+        self.coupled_feedback_matrix = self.get_coupled_feedback_matrix()
+        return torch.stack(cols, dim=-1)
+
+    @torch.no_grad()
+    def get_param_dict(self) -> Dict:
+        out = {'delay_line_gains': self.current_gains()}
+        if hasattr(self, 'common_decay_times'):
+            out['common_decay_times'] = self.common_decay_times
+        A = self.get_coupled_feedback_matrix()
+        out['coupled_feedback_matrix'] = A.squeeze().cpu().numpy()
+        if self.coupling_matrix_type != CouplingMatrixType.RANDOM:
+            if not self.use_zero_coupling:
+                out['coupling_coefficient'] = self.alpha.squeeze().cpu().numpy()
+            out['coupling_matrix'] = (self.phi.squeeze().cpu().numpy()
+                                      if torch.is_tensor(self.phi) else np.asarray(self.phi))
+            out['individual_mixing_matrix'] = self.M.squeeze().cpu().numpy()
+        return out

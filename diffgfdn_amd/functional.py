@@ -1,0 +1,151 @@
+"""torch.autograd Functions over the HIP kernels (diffgfdn_amd.hip_ops).
+
+Each Function is one differentiable stage of the hot path; forward and backward both run
+hand-written kernels, torch only carries the tensors.  Gradient conventions are PyTorch's
+(complex grad = dL/dRe + i dL/dIm).
+"""
+from typing import Optional
+
+import torch
+
+from . import hip_ops as ops
+
+
+class FrequencyGrid:
+    """(turns, logr) of a z grid, computed once per distinct ``z_values`` tensor.
+
+    reference: dataloader.py:552-566 builds z = polar(r, 2 pi rfftfreq(nfft)); the models raise
+    it to the delay lengths every forward (feedback_loop.py:330)."""
+
+    _cache = {}
+
+    def __init__(self, z: torch.Tensor):
+        self.K = z.numel()
+        self.turns, logr = ops.zprep(z)
+        # the unit circle is by far the common case: skip the radius factor entirely
+        self.on_unit_circle = bool((logr.abs().max() < 1e-12).item())
+        self.logr = None if self.on_unit_circle else logr
+
+    @classmethod
+    def of(cls, z: torch.Tensor) -> "FrequencyGrid":
+        key = (z.data_ptr(), z.numel(), z._version, str(z.device))
+        g = cls._cache.get(key)
+        if g is None:
+            if len(cls._cache) > 8:
+                cls._cache.clear()
+            g = cls(z)
+            cls._cache[key] = g
+        return g
+
+
+class ResolventSolve(torch.autograd.Function):
+    """Y[k] = (diag(z_k^m inv_gamma) - A)^{-1} b   (A^T when transpose)."""
+
+    @staticmethod
+    def forward(ctx, A, inv_gamma, b, grid: FrequencyGrid, delays, transpose: bool):
+        Y = ops.solve_fwd(grid.turns, grid.logr, A, delays, inv_gamma, b, transpose)
+        ctx.save_for_backward(A, inv_gamma, b, delays)
+        ctx.grid = grid
+        ctx.transpose = transpose
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        A, inv_gamma, b, delays = ctx.saved_tensors
+        g = ctx.grid
+        gA, gb, gig = ops.solve_bwd(g.turns, g.logr, A, delays, inv_gamma, b, gY.contiguous(),
+                                    ctx.transpose)
+        return gA.to(A.dtype), gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None
+
+
+class OutputStage(torch.autograd.Function):
+    """H[b][k] = (sum_g rgain[b][g] sum_{n in g} c_n Y[k][n] + direct[b][k]) * filt[k]."""
+
+    @staticmethod
+    def forward(ctx, Y, c, rgain, nper: int, direct, filt):
+        H = ops.compose_fwd(Y, c, rgain, nper, direct, filt)
+        ctx.save_for_backward(Y, c, rgain, filt)
+        ctx.nper = nper
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        Y, c, rgain, filt = ctx.saved_tensors
+        gY, gc, grg = ops.compose_bwd(Y, c, rgain, ctx.nper, gH.contiguous(), filt)
+        return gY, gc.to(c.dtype).reshape(c.shape), grg.to(rgain.dtype), None, None, None
+
+
+class SHOutputStage(torch.autograd.Function):
+    """H_sh[b][l][k] = filt[k] * sum_g w[b][g][l] c_{g,l} Y[k][g nper + l]  (model.py:1056-1088)."""
+
+    @staticmethod
+    def forward(ctx, Y, c, w, G: int, nper: int, filt):
+        H = ops.compose_sh_fwd(Y, c, w, G, nper, filt)
+        ctx.save_for_backward(Y, c, w, filt)
+        ctx.G, ctx.nper = G, nper
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        Y, c, w, filt = ctx.saved_tensors
+        gY, gc, gw = ops.compose_sh_bwd(Y, c, w, ctx.G, ctx.nper, gH.contiguous(), filt)
+        return gY, gc.to(c.dtype).reshape(c.shape), gw.to(w.dtype).reshape(w.shape), None, None, None
+
+
+class SpectralLoss(torch.autograd.Function):
+    """sum_g mean_k (|S[g][k]| - 1)^p  (colorless_fdn/losses.py:20-73); gradient fused."""
+
+    @staticmethod
+    def forward(ctx, S, asym: bool):
+        energy, loss, gS = ops.spectral_stats(S, asym, 1.0, want_grad=S.requires_grad)
+        ctx.save_for_backward(gS)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (gS,) = ctx.saved_tensors
+        return gS * gloss.to(gS.dtype).unsqueeze(-1), None
+
+
+class IrfftOdd(torch.autograd.Function):
+    """x = torch.fft.irfft(X, n) for odd n (losses.py:207-213, :442-445)."""
+
+    @staticmethod
+    def forward(ctx, X, n: int):
+        ctx.n, ctx.ldx = n, X.shape[-1]
+        return ops.irfft_odd_fwd(X, n)
+
+    @staticmethod
+    def backward(ctx, gx):
+        return ops.irfft_odd_bwd(gx.contiguous(), ctx.n, ctx.ldx), None
+
+
+class IrfftPow2(torch.autograd.Function):
+    """x = torch.fft.irfft(X) with n = 2 (K-1) a power of two (utils.py:169, losses.py:344)."""
+
+    @staticmethod
+    def forward(ctx, X):
+        n = 2 * (X.shape[-1] - 1)
+        ctx.n = n
+        return ops.irfft_pow2_fwd(X, n)
+
+    @staticmethod
+    def backward(ctx, gx):
+        return ops.irfft_pow2_bwd(gx.contiguous(), ctx.n)
+
+
+def irfft_like_torch(X: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+    """torch.fft.irfft(X, n) along the last axis for the two lengths the reference uses:
+    n = X.shape[-1] odd, or the default n = 2 (K - 1) = 2^p."""
+    shape = X.shape
+    K = shape[-1]
+    X2 = X.reshape(-1, K)
+    if n is None:
+        n = 2 * (K - 1)
+    if n % 2 == 1:
+        x = IrfftOdd.apply(X2, n)
+    elif n == 2 * (K - 1) and (n & (n - 1)) == 0:
+        x = IrfftPow2.apply(X2)
+    else:
+        raise NotImplementedError(f"irfft length {n} for {K} bins is not on the reference's path")
+    return x.reshape(*shape[:-1], n)

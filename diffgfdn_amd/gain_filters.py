@@ -1,0 +1,134 @@
+"""Receiver-position dependent output gains (reference src/diff_gfdn/gain_filters.py:436-555 and
+src/spatial_sampling/model.py:17-190).  Small MLPs on PyTorch; what they feed -- the output
+stage over K bins -- runs in the HIP kernels and takes the (B, G) gains directly instead of the
+reference's (B, N, K) repeated tensor."""
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .config import BeamformerType, FeatureEncodingType
+from .dnn import MLP, MLP_SkipConnections, ScaledSigmoid, SinusoidalEncoding
+
+
+class Gains_from_MLP(nn.Module):
+    """Scalar gain per (receiver, group) in (-1, 1) from the normalised receiver position."""
+
+    def __init__(self, num_groups: int, num_delay_lines_per_group: int, num_fourier_features: int,
+                 num_hidden_layers: int, num_neurons: int,
+                 encoding_type: FeatureEncodingType = FeatureEncodingType.SINE,
+                 position_type: str = "output_gains", device: Optional[torch.device] = 'cpu',
+                 gain_limits: Optional[Tuple] = None):
+        super().__init__()
+        if encoding_type != FeatureEncodingType.SINE:
+            raise NotImplementedError("only sinusoidal encoding is on the accelerated path")
+        self.num_groups = num_groups
+        self.num_delay_lines_per_group = num_delay_lines_per_group
+        self.position_type = position_type
+        self.encoding_type = encoding_type
+        self.device = device
+        self.encoder = SinusoidalEncoding(num_fourier_features)
+        self.mlp = MLP(3 * num_fourier_features * 2, num_hidden_layers, num_neurons, num_groups,
+                       num_biquads_in_cascade=1, num_params=1)
+        lo, hi = (-1.0, 1.0) if gain_limits is None else gain_limits
+        self.scaled_sigmoid = ScaledSigmoid(lower_limit=lo, upper_limit=hi)
+
+    def group_gains(self, x: Dict) -> torch.Tensor:
+        """(B, G) gains -- what the HIP output stage consumes."""
+        position = x['norm_listener_position'] if self.position_type == "output_gains" \
+            else x['source_position']
+        w = self.mlp.model[0].weight
+        enc = self.encoder(position.to(w.device))
+        raw = self.mlp(enc.to(w.dtype))
+        self.gains = self.scaled_sigmoid(raw.view(-1)).view(position.shape[0], self.num_groups)
+        return self.gains
+
+    def forward(self, x: Dict) -> torch.Tensor:
+        """Reference-shaped output (B, N, K) (gain_filters.py:526-534); kept for API parity, the
+        models call :meth:`group_gains`."""
+        g = self.group_gains(x)
+        return g.repeat_interleave(self.num_delay_lines_per_group, dim=1).unsqueeze(-1).repeat(
+            1, 1, len(x['z_values']))
+
+    def get_parameters(self):
+        return self.gains
+
+    @torch.no_grad()
+    def get_param_dict(self, x: Dict) -> Dict:
+        self.group_gains(x)
+        return {'gains': self.gains.squeeze().cpu().numpy()}
+
+
+class Directional_Beamforming_Weights_from_MLP(nn.Module):
+    """SH-domain receiver weights (B, G, (order+1)^2) (reference spatial_sampling/model.py:117-190).
+
+    The analysis matrix (J x (order+1)^2) comes from spaudiopy in the reference
+    (model.py:52-76), which is not part of this build: pass it as ``analysis_matrix``."""
+
+    def __init__(self, num_groups: int, ambi_order: int, num_fourier_features: int,
+                 num_hidden_layers: int, num_neurons: int, desired_directions=None,
+                 device: Optional[torch.device] = 'cpu',
+                 beamformer_type: Optional[BeamformerType] = None,
+                 use_skip_connections: Optional[bool] = False,
+                 analysis_matrix: Optional[np.ndarray] = None):
+        super().__init__()
+        self.num_groups = num_groups
+        self.device = device
+        self.ambi_order = ambi_order
+        self.num_fourier_features = num_fourier_features
+        self.num_out_features = (ambi_order + 1) ** 2
+        if analysis_matrix is None:
+            analysis_matrix = self._design_filterbank(beamformer_type, desired_directions)
+        self.register_buffer('analysis_matrix',
+                             torch.as_tensor(np.asarray(analysis_matrix), dtype=torch.float32),
+                             persistent=False)
+        self.encoder = SinusoidalEncoding(num_fourier_features)
+        cls = MLP_SkipConnections if use_skip_connections else MLP
+        self.mlp = cls(3 * num_fourier_features * 2, num_hidden_layers, num_neurons, num_groups,
+                       num_biquads_in_cascade=1, num_params=self.num_out_features)
+
+    def _design_filterbank(self, beamformer_type, desired_directions):
+        try:
+            import spaudiopy as sp   # optional third-party dependency of the reference
+        except ImportError as exc:
+            raise RuntimeError("spaudiopy is not installed: pass analysis_matrix explicitly") from exc
+        if beamformer_type == BeamformerType.MAX_DI:
+            mw = sp.sph.cardioid_modal_weights(self.ambi_order)
+        elif beamformer_type == BeamformerType.MAX_RE:
+            mw = sp.sph.maxre_modal_weights(self.ambi_order)
+        elif beamformer_type == BeamformerType.BUTTER:
+            mw = sp.sph.butterworth_modal_weights(self.ambi_order, k=5, n_c=3)
+        else:
+            mw = np.ones(self.ambi_order + 1)
+        A, _ = sp.sph.design_sph_filterbank(self.ambi_order, desired_directions[0, :],
+                                            np.pi / 2 - desired_directions[1, :], mw,
+                                            mode='energy', sh_type='real')
+        return A
+
+    @staticmethod
+    def normalise_weights(weights: torch.Tensor) -> torch.Tensor:
+        return weights / (torch.norm(weights, dim=-1, keepdim=True) + 1e-6)
+
+    def forward(self, x: Dict, normalise_weights: bool = False) -> torch.Tensor:
+        position = x['norm_listener_position']
+        w0 = next(self.mlp.parameters())
+        enc = self.encoder(position.to(w0.device))
+        self.weights = self.mlp(enc.to(w0.dtype)).reshape(position.shape[0], self.num_groups,
+                                                          self.num_out_features)
+        if normalise_weights:
+            self.weights = self.normalise_weights(self.weights)
+        return self.weights
+
+    def get_directional_amplitudes(self) -> torch.Tensor:
+        out = torch.einsum('jn, bkn-> bjk', self.analysis_matrix, self.weights)
+        return 1.0 / (1 + torch.exp(-out))
+
+    def get_parameters(self):
+        return self.weights
+
+    @torch.no_grad()
+    def get_param_dict(self, x: Dict, normalise_weights: bool = False) -> Dict:
+        self.forward(x, normalise_weights=normalise_weights)
+        return {'beamformer_weights': self.weights.squeeze().cpu().numpy(),
+                'directional_weights': self.get_directional_amplitudes().squeeze().cpu().numpy()}

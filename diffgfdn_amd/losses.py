@@ -1,0 +1,315 @@
+"""Energy-decay losses on the MI355X hot path.
+
+Interface mirror of the reference's src/diff_gfdn/losses.py: ``edr_loss`` (:377-495),
+``edc_loss`` (:149-281, broadband branch), ``directional_edc_loss`` (:284-371) with the same
+constructor arguments and ``forward(target_response, achieved_response) -> 0-dim tensor``.
+
+Pipeline per call (all HIP kernels, csrc/fft.hip + csrc/losses.hip):
+    H (B,K) --irfft(n = K, odd: Bluestein)--> rir (B,K) --|STFT|^2--> EDR dB --> L1 ratio
+                                                   \\--x^2 suffix-scan--> EDC dB --> mean |diff|
+The loss is a scalar, so the backward of every stage is produced in the same call when the
+achieved response requires grad and is handed to autograd as a saved tensor.  The target side
+(EDR / EDC of the measured RIRs) does not depend on the model: it is computed once per distinct
+target tensor and cached (:class:`DecayTargets`).
+
+Not on the accelerated path (reference defaults leave them off): ERB grouping
+(``use_erb_grouping``), sub-band EDC (``band_centre_hz``), ``reg_loss``.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip_ops as ops
+from .functional import IrfftPow2
+
+
+def ms_to_samps(ms: float, fs: float) -> int:
+    """int() truncation, reference utils.py:62-80."""
+    return int(ms * 1e-3 * fs)
+
+
+def edr_frequency_weights(sample_rate: float, win_size: int) -> torch.Tensor:
+    """reference losses.py:419-428 with :49-57: 2 + (1 - 2) / (1 + exp(10^-2.5 (f - 1000)))
+    (the reference passes `bottom, top` into the `top, bottom` slots; reproduced)."""
+    freqs = torch.tensor(np.fft.rfftfreq(win_size, d=1.0 / sample_rate))
+    return 2.0 + (1.0 - 2.0) / (1 + torch.exp(10 ** (-2.5) * (freqs - 1e3)))
+
+
+def _as_batch(X: torch.Tensor) -> torch.Tensor:
+    return X.reshape(-1, X.shape[-1])
+
+
+def time_response_odd(X: torch.Tensor) -> torch.Tensor:
+    """rir = torch.fft.irfft(X, n = X.shape[-1])  (reference losses.py:207-213, :442-445)."""
+    n = X.shape[-1]
+    if n % 2 == 0:
+        raise NotImplementedError("irfft(X, n=K) with even K is not produced by the reference's grids")
+    return ops.irfft_odd_fwd(_as_batch(X), n)
+
+
+class DecayTargets:
+    """EDR / EDC of the TARGET responses, computed once and cached.
+
+    A target tensor is identified by (data_ptr, shape, version).  ``edr``: (T_db (B,frames,F),
+    sum_abs (B,)); ``edc``: T_db (B, len)."""
+
+    def __init__(self, max_entries: int = 64):
+        self._rir: Dict = {}
+        self._edr: Dict = {}
+        self._edc: Dict = {}
+        self.max_entries = max_entries
+
+    @staticmethod
+    def _key(t: torch.Tensor, *extra):
+        return (t.data_ptr(), tuple(t.shape), t._version, str(t.device)) + extra
+
+    def _trim(self, d: Dict):
+        if len(d) >= self.max_entries:
+            d.clear()
+
+    # every entry keeps a reference to its key tensor: the storage cannot be freed and re-used
+    # by another tensor while the entry is alive, so (data_ptr, version) identifies the contents
+    def rir(self, target: torch.Tensor) -> torch.Tensor:
+        k = self._key(target)
+        r = self._rir.get(k)
+        if r is None:
+            self._trim(self._rir)
+            r = (time_response_odd(target), target)
+            self._rir[k] = r
+        return r[0]
+
+    def edr(self, target: torch.Tensor, win: int):
+        k = self._key(target, win)
+        e = self._edr.get(k)
+        if e is None:
+            self._trim(self._edr)
+            P = ops.stft_power(self.rir(target), win)
+            e = (ops.edr_target(P), target)
+            self._edr[k] = e
+        return e[0]
+
+    def edc(self, target: torch.Tensor, start: int, length: int):
+        k = self._key(target, start, length)
+        e = self._edc.get(k)
+        if e is None:
+            self._trim(self._edc)
+            e = (ops.edc_target(self.rir(target), start, length), target)
+            self._edc[k] = e
+        return e[0]
+
+    def drop_rirs(self):
+        self._rir.clear()
+
+
+_default_targets = DecayTargets()
+
+
+class _ScalarLossWithSavedGrad(torch.autograd.Function):
+    """loss value + precomputed dloss/dH (saved) -> autograd node."""
+
+    @staticmethod
+    def forward(ctx, H, loss_value, gH):
+        ctx.save_for_backward(gH)
+        ctx.h_shape = H.shape
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gH,) = ctx.saved_tensors
+        return (gH * g).reshape(ctx.h_shape), None, None
+
+
+def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win: int = 4096,
+                 edr_weight: float = 1.0, edc_weight: float = 1.0, use_edr: bool = True,
+                 use_edc: bool = True, edc_start: int = 640, edc_len: Optional[int] = None,
+                 edc_maskw: Optional[torch.Tensor] = None, edc_count: Optional[float] = None,
+                 freq_weights: Optional[torch.Tensor] = None,
+                 reduced_pole_radius: Optional[float] = None,
+                 global_batch: Optional[int] = None,
+                 targets: Optional[DecayTargets] = None,
+                 edr_target: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                 edc_target: Optional[torch.Tensor] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
+
+    Returns (total, edr, edc) with total = edr_weight * edr + edc_weight * edc carrying the
+    gradient; ``edr`` / ``edc`` are detached values (trainer.py:280-288 logs them separately).
+    ``global_batch``: number of items the EDC mean runs over (the local batch unless the batch
+    is sharded over ranks).  ``edr_target`` = (T_db, sum_abs) / ``edc_target`` = T_db
+    may be passed precomputed (dataset-level store); otherwise they are derived from ``target``
+    through the cache."""
+    targets = targets or _default_targets
+    Hb = _as_batch(H)
+    B, K = Hb.shape
+    want_grad = H.requires_grad and torch.is_grad_enabled()
+    x = ops.irfft_odd_fwd(Hb, K)
+    env = None
+    if reduced_pole_radius is not None and reduced_pole_radius != 1.0:
+        # losses.py:447-451: undo sampling on a larger circle (EDR only in the reference)
+        env = torch.pow(torch.tensor(1.0 / reduced_pole_radius, dtype=torch.float64, device=x.device),
+                        torch.arange(K, device=x.device, dtype=torch.float64)).to(torch.float32)
+    zero = torch.zeros((), dtype=torch.float32, device=x.device)
+    gx = None
+    edc_val, edr_val = zero, zero
+    if use_edc:
+        L = edc_len if edc_len is not None else K - edc_start
+        T_db = edc_target if edc_target is not None else targets.edc(target, edc_start, L)
+        count = float(L) if edc_count is None else float(edc_count)
+        nb = B if global_batch is None else global_batch
+        li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, 1.0 / (nb * count), edc_weight,
+                              want_grad)
+        edc_val = li.sum()
+    if use_edr:
+        T_edr, sum_abs = edr_target if edr_target is not None else targets.edr(target, win)
+        xe = x if env is None else x * env
+        P = ops.stft_power(xe, win)
+        li = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad)
+        edr_val = li.sum()
+        if want_grad:
+            if gx is None:
+                gx = torch.zeros_like(x)
+            if env is None:
+                ops.stft_power_bwd(xe, win, P, gx)
+            else:
+                ge = ops.stft_power_bwd(xe, win, P, torch.zeros_like(x))
+                gx = gx + ge * env
+    total_val = edr_weight * edr_val + edc_weight * edc_val
+    if want_grad:
+        gH = ops.irfft_odd_bwd(gx, K, K)
+        total = _ScalarLossWithSavedGrad.apply(H, total_val, gH)
+    else:
+        total = total_val
+    return total, edr_val.detach(), edc_val.detach()
+
+
+class edr_loss(nn.Module):
+    """Difference between the EDRs of two RIRs in dB (reference losses.py:377-495)."""
+
+    def __init__(self, sample_rate: float, win_size: int = 2 ** 12, hop_size: int = 2 ** 11,
+                 reduced_pole_radius: Optional[float] = None, use_erb_grouping: bool = False,
+                 time_axis: int = -1, freq_axis: int = -2, use_weight_fn: bool = False):
+        super().__init__()
+        if use_erb_grouping:
+            raise NotImplementedError("ERB grouping is off in every north-star config (SURVEY §2b)")
+        if hop_size * 2 != win_size:
+            raise NotImplementedError("the reference asserts hop == win // 2 (losses.py:524)")
+        self.sample_rate = sample_rate
+        self.win_size = win_size
+        self.hop_size = hop_size
+        self.use_erb_grouping = use_erb_grouping
+        self.reduced_pole_radius = reduced_pole_radius
+        self.time_axis = time_axis
+        self.freq_axis = freq_axis
+        self.use_weight_fn = use_weight_fn
+        self.erb_filters = None
+        self.freqs_hz = np.fft.rfftfreq(win_size, d=1.0 / sample_rate)
+        if use_weight_fn:
+            self.frequency_weights = edr_frequency_weights(sample_rate, win_size)
+        self.targets = _default_targets
+
+    def forward(self, target_response: torch.Tensor, achieved_response: torch.Tensor) -> torch.Tensor:
+        assert target_response.shape == achieved_response.shape
+        wf = self.frequency_weights.to(achieved_response.device) if self.use_weight_fn else None
+        total, _, _ = decay_losses(achieved_response, target_response, win=self.win_size,
+                                   use_edc=False, freq_weights=wf,
+                                   reduced_pole_radius=self.reduced_pole_radius,
+                                   targets=self.targets)
+        return total
+
+
+class edc_loss(nn.Module):
+    """Broadband EDC loss in dB (reference losses.py:149-281)."""
+
+    def __init__(self, max_ir_len_ms: float, sample_rate: float, band_centre_hz: Optional[List] = None,
+                 mixing_time_ms: float = 20.0, use_mask: bool = False):
+        super().__init__()
+        if band_centre_hz is not None:
+            raise NotImplementedError("sub-band EDC is never enabled by the trainer (trainer.py:81-83)")
+        self.max_ir_len_samps = ms_to_samps(max_ir_len_ms, sample_rate)
+        self.band_centre_hz = band_centre_hz
+        self.mixing_time_samps = ms_to_samps(mixing_time_ms, sample_rate)
+        self.use_mask = use_mask
+        self.targets = _default_targets
+
+    def window(self, K: int) -> Tuple[int, int]:
+        L = min(self.max_ir_len_samps, K)
+        return self.mixing_time_samps, L - self.mixing_time_samps
+
+    def draw_mask(self, length: int, device) -> Tuple[Optional[torch.Tensor], float]:
+        """Random time mask of losses.py:221-223, drawn from the global CPU generator exactly as
+        the reference does (uniform_ then bernoulli) so seeded runs see the same indices."""
+        if not self.use_mask:
+            return None, float(length)
+        probs = torch.empty(length).uniform_(0, 1)
+        keep = torch.bernoulli(probs)
+        return keep.to(device=device, dtype=torch.float32), float(keep.sum().item())
+
+    def forward(self, target_response: torch.Tensor, achieved_response: torch.Tensor,
+                mask_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        K = achieved_response.shape[-1]
+        start, length = self.window(K)
+        if mask_index is not None:
+            maskw = torch.zeros(length, dtype=torch.float32, device=achieved_response.device)
+            maskw[mask_index.reshape(-1).long().to(maskw.device)] = 1.0
+            count = float(mask_index.numel())
+        else:
+            maskw, count = self.draw_mask(length, achieved_response.device)
+        total, _, _ = decay_losses(achieved_response, target_response, use_edr=False,
+                                   edc_start=start, edc_len=length, edc_maskw=maskw,
+                                   edc_count=count, targets=self.targets)
+        return total
+
+
+class directional_edc_loss(nn.Module):
+    """Mean |dB| between the EDCs of predicted directional RIRs and a common-slope model
+    (reference losses.py:284-371).
+
+    The reference builds ``envelopes`` (slopes x time) with slope2noise.utils.decay_kernel, an
+    un-vendored dependency: pass them as ``envelopes``.  When omitted, the stated formula
+    exp(-13.8155 t / T60) (EDC of an exponential decay, unit at t = 0) is used; parity for that
+    formula is unpinned."""
+
+    def __init__(self, common_decay_times, edc_len_ms: float, fs: float, mixing_time_ms: float = 20.0,
+                 use_mask: bool = False, envelopes: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.mixing_time_samps = ms_to_samps(mixing_time_ms, fs)
+        self.use_mask = use_mask
+        self.edc_len_samps = ms_to_samps(edc_len_ms, fs)
+        if envelopes is None:
+            cdt = np.asarray(common_decay_times, dtype=np.float64).reshape(-1)
+            t = np.linspace(0, (self.edc_len_samps - 1) / fs, self.edc_len_samps)
+            envelopes = torch.tensor(np.exp(-13.815510557964274 * t[None, :] / cdt[:, None]),
+                                     dtype=torch.float32)
+        self.register_buffer('envelopes', torch.as_tensor(envelopes, dtype=torch.float32),
+                             persistent=False)
+
+    def forward(self, H_pred: torch.Tensor, amps_true: torch.Tensor) -> torch.Tensor:
+        """H_pred (B, J, K) complex, amps_true (B, J, S)."""
+        B, J, K = H_pred.shape
+        n = 2 * (K - 1)
+        # python slicing in the reference (:344-346) silently truncates at the end of the IR
+        start = self.mixing_time_samps
+        L = min(self.edc_len_samps, n - start)
+        if L <= 0:
+            raise ValueError("EDC window starts beyond the impulse-response length")
+        want_grad = H_pred.requires_grad and torch.is_grad_enabled()
+        Hb = H_pred.reshape(B * J, K)
+        x = ops.irfft_pow2_fwd(Hb, n)
+        # true EDC from the common-slope amplitudes (einsum 'bjk,kt->bjt'), then dB
+        edc_true = torch.einsum('bjk, kt -> bjt', amps_true.to(torch.float32).to(x.device),
+                                self.envelopes[:, :L].to(x.device)).reshape(B * J, L)
+        T_db = (10.0 * torch.log10(edc_true.abs() + torch.finfo(torch.float32).eps)).clip(min=-200.0)
+        if self.use_mask:
+            keep = torch.bernoulli(torch.empty(L).uniform_(0, 1))
+            maskw, count = keep.to(device=x.device, dtype=torch.float32), float(keep.sum().item())
+        else:
+            maskw, count = None, float(L)
+        li, gx = ops.edc_loss(x, start, L, T_db.contiguous(), maskw, 1.0 / (B * J * count), 1.0,
+                              want_grad)
+        val = li.sum()
+        if not want_grad:
+            return val
+        gH = ops.irfft_pow2_bwd(gx, n).reshape(B, J, K)
+        return _ScalarLossWithSavedGrad.apply(H_pred, val, gH)

@@ -1,0 +1,290 @@
+"""Differentiable GFDN models on the MI355X hot path.
+
+Interface mirror of the reference's src/diff_gfdn/model.py: DiffGFDN (:24-299),
+DiffGFDNVarReceiverPos (:502-661), DiffGFDNSinglePos (:667-969),
+DiffDirectionalFDNVarReceiverPos (:975-1126) -- same constructor arguments, same
+``forward(x: Dict)`` contract, same parameter / buffer names (state dicts interchange).
+
+What changes is the evaluation: the reference forms P = inv(D Gamma^{-1} - A) for every bin and
+contracts (B, N, K) temporaries with einsum; here one per-bin SOLVE y = P b is shared by the
+whole batch (b does not depend on the receiver) and the position-dependent part is the
+bandwidth-bound output stage  H[b,k] = sum_g gain[b,g] sum_{n in g} c_n y_n[k] + d[b,k],
+both hand-written HIP kernels (csrc/solve.hip).  Outputs are complex64 (the reference's are
+complex128 only because the complex128 direct path is added to a complex64 result).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+from .feedback_loop import FeedbackLoop, decay_times_to_gain_per_sample
+from .functional import FrequencyGrid, OutputStage, ResolventSolve, SHOutputStage
+from .gain_filters import Directional_Beamforming_Weights_from_MLP, Gains_from_MLP
+
+
+class DiffGFDN(nn.Module):
+    """Parent module (reference model.py:24-299)."""
+
+    def __init__(self, sample_rate: int, num_groups: int, delays: List[int], device: torch.device,
+                 feedback_loop_config: FeedbackLoopConfig, use_absorption_filters: bool,
+                 learn_common_decay_times: bool, common_decay_times: Optional[List] = None,
+                 band_centre_hz: Optional[List] = None, colorless_fdn_params: Optional[List] = None,
+                 use_colorless_loss: bool = False):
+        super().__init__()
+        if use_absorption_filters:
+            raise NotImplementedError("frequency-dependent absorption: SURVEY §8 f-2 (next)")
+        self.sample_rate = sample_rate
+        self.device = device
+        self.num_groups = num_groups
+        self.num_delay_lines = len(delays)
+        self.num_delay_lines_per_group = int(self.num_delay_lines / self.num_groups)
+        self.use_absorption_filters = use_absorption_filters
+        self.band_centre_hz = band_centre_hz
+        self.common_decay_times = common_decay_times
+        self.learn_common_decay_times = learn_common_decay_times
+        self.use_colorless_loss = use_colorless_loss
+        n = self.num_delay_lines_per_group
+        self.delays_by_group = [torch.tensor(delays[i:i + n]) for i in range(0, self.num_delay_lines, n)]
+        self.register_buffer('delay_buffer', torch.tensor(delays, dtype=torch.float32))
+        self._init_io_gains(colorless_fdn_params)
+        self._init_absorption()
+        self._init_feedback(feedback_loop_config, colorless_fdn_params)
+
+    @property
+    def delays(self) -> torch.Tensor:
+        return self.delay_buffer
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        if self.gain_per_sample is not None:
+            # keep the loop's gains aliased to the checkpointed buffer (load_state_dict copies in place)
+            self.feedback_loop.delay_line_gains = self.delay_filters
+        return self
+
+    # reference :95-122 -- draws input_gains then output_gains, (2 randn - 1)/N
+    def _init_io_gains(self, colorless_fdn_params):
+        N = self.num_delay_lines
+        if colorless_fdn_params is None:
+            self.input_gains = nn.Parameter((2 * torch.randn(N, 1) - 1) / N)
+            self.output_gains = nn.Parameter((2 * torch.randn(N, 1) - 1) / N)
+        else:
+            G = self.num_groups
+            self.register_buffer('input_gains', torch.tensor(
+                [colorless_fdn_params[i].opt_input_gains.tolist() for i in range(G)]).view(-1, 1),
+                persistent=False)
+            self.register_buffer('output_gains', torch.tensor(
+                [colorless_fdn_params[i].opt_output_gains.tolist() for i in range(G)]).view(-1, 1),
+                persistent=False)
+
+    # reference :124-166 (broadband gains branch)
+    def _init_absorption(self):
+        if self.common_decay_times is None or self.learn_common_decay_times:
+            self.gain_per_sample = None
+            return
+        cdt = np.squeeze(self.common_decay_times)
+        cdt = np.atleast_1d(cdt)
+        vals = [decay_times_to_gain_per_sample(cdt[i], self.delays_by_group[i].numpy(),
+                                               self.sample_rate).tolist()
+                for i in range(self.num_groups)]
+        self.gain_per_sample = torch.flatten(torch.tensor(vals))
+        self.register_buffer('delay_filters', self.gain_per_sample)
+
+    # reference :168-207
+    def _init_feedback(self, cfg: FeedbackLoopConfig, colorless_fdn_params):
+        M0 = None
+        if colorless_fdn_params is not None:
+            M0 = torch.stack([torch.from_numpy(colorless_fdn_params[i].opt_feedback_matrix)
+                              for i in range(self.num_groups)], dim=0).to(torch.float32)
+        self.feedback_loop = FeedbackLoop(
+            self.sample_rate, self.num_groups, self.num_delay_lines_per_group, self.delay_buffer,
+            self.use_absorption_filters, gains=self.gain_per_sample,
+            use_zero_coupling=cfg.use_zero_coupling, common_decay_times=self.common_decay_times,
+            coupling_matrix_type=cfg.coupling_matrix_type, coupling_matrix_order=cfg.pu_matrix_order,
+            colorless_feedback_matrix=M0)
+
+    # -- hot-path pieces ---------------------------------------------------------------------------
+    def delay_line_responses(self, z: torch.Tensor, transpose: bool = False,
+                             b: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """y_n[k] = ((D Gamma^{-1} - A)^{-1} b)_n  -> (K, N) complex64."""
+        b = self.input_gains if b is None else b
+        return self.feedback_loop.resolvent_apply(z, b, transpose)
+
+    def sub_fdn_responses(self, z: torch.Tensor) -> torch.Tensor:
+        """Un-damped per-group responses y^(g) = (D - M_g)^{-1} b_g with the RAW parameter M_g
+        (reference model.py:237-240) -> (K, N) complex64."""
+        grid = FrequencyGrid.of(z)
+        M = self.feedback_loop.M
+        ones = torch.ones(self.num_delay_lines, dtype=torch.float32, device=M.device)
+        return ResolventSolve.apply(M, ones, self.input_gains.reshape(-1), grid,
+                                    self.delay_buffer, False)
+
+    def sub_fdn_group_sums(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(S (G, K), Ysub (K, N)):  S[g][k] = sum_{n in g} c_n y^(g)_n[k] = Hout[k, g]."""
+        Ysub = self.sub_fdn_responses(z)
+        G = self.num_groups
+        eye = torch.eye(G, dtype=torch.float32, device=Ysub.device)
+        S = OutputStage.apply(Ysub, self.output_gains.reshape(-1), eye,
+                              self.num_delay_lines_per_group, None, None)
+        return S, Ysub
+
+    def sub_fdn_output(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(Hout (K, G), Hout_per_del (N, K, G)) as reference model.py:209-252."""
+        S, Ysub = self.sub_fdn_group_sums(z)
+        G, n, N = self.num_groups, self.num_delay_lines_per_group, self.num_delay_lines
+        K = Ysub.shape[0]
+        scaled = (Ysub * self.output_gains.reshape(1, N)).T                 # (N, K): c_n y_n
+        Hpd = torch.zeros((N, K, G), dtype=torch.complex64, device=Ysub.device)
+        for g in range(G):
+            Hpd[g * n:(g + 1) * n, :, g] = scaled[g * n:(g + 1) * n]
+        return S.T, Hpd
+
+    @torch.no_grad()
+    def get_param_dict(self) -> Dict:
+        out = {'delays': self.delay_buffer.squeeze().cpu().numpy(),
+               'gains_per_sample': self.feedback_loop.current_gains().squeeze().cpu().numpy(),
+               'input_gains': self.input_gains.squeeze().cpu().numpy(),
+               'output_gains': self.output_gains.squeeze().cpu().numpy()}
+        out.update({k: v for k, v in self.feedback_loop.get_param_dict().items()
+                    if k in ('coupled_feedback_matrix', 'individual_mixing_matrix', 'coupling_matrix')})
+        return out
+
+
+class DiffGFDNVarReceiverPos(DiffGFDN):
+    """GFDN for a grid of receiver positions, output gains from an MLP (reference :502-661)."""
+
+    def __init__(self, sample_rate: int, num_groups: int, delays: List[int], device: torch.device,
+                 feedback_loop_config: FeedbackLoopConfig, output_filter_config: OutputFilterConfig,
+                 use_absorption_filters: bool, learn_common_decay_times: Optional[bool] = False,
+                 common_decay_times: Optional[List] = None, band_centre_hz: Optional[List] = None,
+                 colorless_fdn_params: Optional[List] = None, use_colorless_loss: bool = False):
+        super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
+                         use_absorption_filters, learn_common_decay_times, common_decay_times,
+                         band_centre_hz, colorless_fdn_params, use_colorless_loss)
+        if output_filter_config.use_svfs:
+            raise NotImplementedError("SVF output filters: SURVEY §8 f-2 (next)")
+        self.use_svf_in_output = False
+        self.input_scalars = torch.ones(self.num_groups, 1)
+        self.output_scalars = Gains_from_MLP(
+            self.num_groups, self.num_delay_lines_per_group,
+            output_filter_config.num_fourier_features, output_filter_config.num_hidden_layers,
+            output_filter_config.num_neurons_per_layer, output_filter_config.encoding_type)
+
+    def forward(self, x: Dict, output_scalars: Optional[torch.Tensor] = None,
+                subband_filter: Optional[torch.Tensor] = None):
+        """H(z) = c(z)^T (D Gamma^{-1} - A)^{-1} b + d(z)   (reference :569-625).
+
+        ``subband_filter`` (K,) optionally fuses the trainer's H * filter (trainer.py:459) into
+        the output stage; default None returns the unfiltered H exactly like the reference."""
+        z = x['z_values']
+        self.batch_size = x['listener_position'].shape[0]
+        if output_scalars is None:
+            rgain = self.output_scalars.group_gains(x)
+        else:
+            assert output_scalars.shape == (self.batch_size, self.num_groups)
+            rgain = output_scalars
+        Y = self.delay_line_responses(z)
+        H = OutputStage.apply(Y, self.output_gains.reshape(-1), rgain.to(torch.float32),
+                              self.num_delay_lines_per_group, x['target_early_response'],
+                              subband_filter)
+        if self.use_colorless_loss:
+            return H, self.sub_fdn_output(z)
+        return H
+
+    @torch.no_grad()
+    def get_param_dict_inference(self, data: Dict) -> Dict:
+        return {'output_scalars': self.output_scalars.get_param_dict(data)['gains']}
+
+    @torch.no_grad()
+    def get_param_dict(self) -> Dict:
+        out = super().get_param_dict()
+        out['input_scalars'] = self.input_scalars.squeeze().cpu().numpy()
+        return out
+
+
+class DiffGFDNSinglePos(DiffGFDN):
+    """GFDN for one source-receiver pair with learnable per-group scalars (reference :667-969)."""
+
+    def __init__(self, sample_rate: int, num_groups: int, delays: List[int], device: torch.device,
+                 feedback_loop_config: FeedbackLoopConfig, output_filter_config: OutputFilterConfig,
+                 use_absorption_filters: bool, learn_common_decay_times: Optional[bool] = False,
+                 common_decay_times: Optional[List] = None, band_centre_hz: Optional[List] = None,
+                 colorless_fdn_params: Optional[List] = None, use_colorless_loss: bool = False,
+                 input_filter_config: Optional[OutputFilterConfig] = None):
+        super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
+                         use_absorption_filters, learn_common_decay_times, common_decay_times,
+                         band_centre_hz, colorless_fdn_params, use_colorless_loss)
+        if output_filter_config.use_svfs or (input_filter_config is not None and input_filter_config.use_svfs):
+            raise NotImplementedError("SVF input/output filters: SURVEY §8 f-2 (next)")
+        self.use_svf_in_input = False
+        self.use_svf_in_output = False
+        G = self.num_groups
+        self.input_scalars = nn.Parameter(torch.ones(G, 1) / np.sqrt(G))     # reference :749-750
+        self.output_scalars = nn.Parameter(torch.ones(G, 1) / np.sqrt(G))    # reference :776-777
+
+    def forward(self, x: Dict):
+        """reference :779-836; inputs are (K,) tensors, output H is (K,)."""
+        z = x['z_values']
+        n = self.num_delay_lines_per_group
+        b = self.input_scalars.repeat_interleave(n, dim=0) * self.input_gains
+        Y = self.delay_line_responses(z, b=b)
+        H = OutputStage.apply(Y, self.output_gains.reshape(-1), self.output_scalars.reshape(1, -1),
+                              n, x['target_early_response'].reshape(1, -1), None)
+        H = H.reshape(-1)
+        if self.use_colorless_loss:
+            return H, self.sub_fdn_output(z)
+        return H
+
+    @torch.no_grad()
+    def get_param_dict(self) -> Dict:
+        out = super().get_param_dict()
+        out['absorption_coeffs'] = self.feedback_loop.current_gains()
+        out['output_scalars'] = self.output_scalars.squeeze().cpu().numpy()
+        out['input_scalars'] = self.input_scalars.squeeze().cpu().numpy()
+        return out
+
+
+class DiffDirectionalFDNVarReceiverPos(DiffGFDN):
+    """Directional FDN with SH-domain output gains (reference :975-1126)."""
+
+    def __init__(self, sample_rate: int, num_groups: int, delays: List[int], device: torch.device,
+                 feedback_loop_config: FeedbackLoopConfig, output_filter_config: OutputFilterConfig,
+                 ambi_order: int, desired_directions=None, use_absorption_filters: bool = False,
+                 learn_common_decay_times: Optional[bool] = False,
+                 common_decay_times: Optional[List] = None, band_centre_hz: Optional[List] = None,
+                 colorless_fdn_params: Optional[List] = None, use_colorless_loss: bool = False,
+                 analysis_matrix=None):
+        super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
+                         use_absorption_filters, learn_common_decay_times, common_decay_times,
+                         band_centre_hz, colorless_fdn_params, use_colorless_loss)
+        self.ambi_order = ambi_order
+        assert self.num_delay_lines_per_group == (ambi_order + 1) ** 2, \
+            "Number of delay lines per group must be equal to the number of ambisonics channels"
+        self.input_scalars = torch.ones(self.num_groups, 1)
+        self.use_svf_in_output = False
+        self.sh_output_scalars = Directional_Beamforming_Weights_from_MLP(
+            self.num_groups, ambi_order, output_filter_config.num_fourier_features,
+            output_filter_config.num_hidden_layers, output_filter_config.num_neurons_per_layer,
+            desired_directions=desired_directions,
+            beamformer_type=output_filter_config.beamformer_type,
+            use_skip_connections=output_filter_config.use_skip_connections,
+            analysis_matrix=analysis_matrix)
+
+    def forward(self, x: Dict, subband_filter: Optional[torch.Tensor] = None):
+        """H_sh (B, (order+1)^2, K)   (reference :1043-1094).  NB the reference contracts the FIRST
+        index of P with b (einsum 'knm,bnk->bmk'), i.e. P^T b -> transpose solve."""
+        z = x['z_values']
+        self.batch_size = x['listener_position'].shape[0]
+        w = self.sh_output_scalars(x, normalise_weights=True)
+        Y = self.delay_line_responses(z, transpose=True)
+        H = SHOutputStage.apply(Y, self.output_gains.reshape(-1), w.to(torch.float32),
+                                self.num_groups, self.num_delay_lines_per_group, subband_filter)
+        if self.use_colorless_loss:
+            return H, self.sub_fdn_output(z)
+        return H
+
+    @torch.no_grad()
+    def get_param_dict_inference(self, data: Dict, normalise_weights: bool = False) -> Dict:
+        return {'output_scalars':
+                self.sh_output_scalars.get_param_dict(data, normalise_weights)['beamformer_weights']}

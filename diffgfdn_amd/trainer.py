@@ -1,0 +1,319 @@
+"""Trainer of the differentiable GFDN on the MI355X hot path.
+
+Counterpart of the reference's src/diff_gfdn/trainer.py: Trainer (:26-332) and
+VarReceiverPosTrainer (:338-564) with identical step semantics --
+  * loss = w_edr EDR + w_edc EDC + sum_g w_spec (a)MSE(Hout[:,g], 1) + w_sp sparsity(Q_last)
+    (calculate_losses :259-315; the sparsity term is ASSIGNED per group, so only the last group
+    counts -- reproduced);
+  * normalize (:317-332): before every step, b_n, c_n /= (mean_k |Hout[k,g]|^2)^(1/4);
+  * Adam with per-name learning-rate groups and StepLR(10, 0.1) (init_scheduler :152-228);
+  * checkpoints model_e{e}.pt of the state dict (save_model :249-257).
+The step itself runs the fused path: one per-bin solve shared by the batch, the output stage
+with the sub-band filter folded in, ONE irfft of H feeding both decay losses, one adjoint.
+
+Multi-GPU: one process per GPU; a batch of receiver positions is sharded over the
+ranks; after backward every rank contributes its gradients to ONE flat fp32 all-reduce (RCCL
+over xGMI).  Position-independent terms (colorless + sparsity) are pre-divided by the world
+size so that the sum equals the single-process gradient.
+"""
+import os
+import time
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .colorless_losses import amse_loss, group_spectral_loss, mse_loss, sparsity_loss
+from .config import TrainerConfig
+from .functional import OutputStage, irfft_like_torch
+from .hip_ops import spectral_stats
+from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
+from .model import DiffGFDN
+
+
+@torch.no_grad()
+def get_response(x, net, output_scalars=None):
+    """(H, [H_sub_fdn,] h) with h = irfft(H) at the default length n = 2(K-1)
+    (reference utils.py:149-179)."""
+    if getattr(net, 'use_colorless_loss', False):
+        H, H_sub = net(x, output_scalars) if output_scalars is not None else net(x)
+        return H, H_sub, irfft_like_torch(H)
+    H = net(x)
+    return H, irfft_like_torch(H)
+
+
+class FlatGradAllReduce:
+    """One flat fp32 buffer for all parameter gradients -> a single all-reduce per step."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def __call__(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+
+class Trainer:
+    """Parent class (reference trainer.py:26-332)."""
+
+    def __init__(self, net: DiffGFDN, trainer_config: TrainerConfig,
+                 subband_filter_freq_resp: Optional[torch.Tensor] = None,
+                 process_group=None, stft_win: int = 4096):
+        self.net = net
+        self.device = trainer_config.device
+        self.max_epochs = trainer_config.max_epochs
+        self.patience = 5
+        self.early_stop = 0
+        self.train_dir = Path(trainer_config.train_dir).resolve()
+        self.ir_dir = Path(trainer_config.ir_dir).resolve()
+        self.use_reg_loss = trainer_config.use_reg_loss
+        if self.use_reg_loss:
+            raise NotImplementedError("reg_loss needs the SVF output filters (SURVEY §8 f-2)")
+        self.use_colorless_loss = trainer_config.use_colorless_loss
+        self.reduced_pole_radius = trainer_config.reduced_pole_radius
+        self.subband_process_config = trainer_config.subband_process_config
+        self.use_directional_fdn = getattr(net, 'ambi_order', None) is not None
+        # the reference derives the sub-band filter from pyfar FIR taps (trainer.py:112-150);
+        # pyfar is not part of this build: the (K,) response is an input
+        self.subband_filter_freq_resp = subband_filter_freq_resp
+        if self.subband_process_config is not None and subband_filter_freq_resp is None:
+            raise ValueError("subband_process_config set: pass subband_filter_freq_resp (K,) explicitly")
+        self.config = trainer_config
+        self.stft_win = stft_win
+        self.init_scheduler(trainer_config)
+
+        if net.common_decay_times is None:
+            max_ir_len_ms = 2000
+        else:
+            max_ir_len_ms = float(np.max(np.asarray(net.common_decay_times))) * 1e3
+        self.max_ir_len_ms = max_ir_len_ms
+        if self.use_directional_fdn:
+            self.criterion = [directional_edc_loss(net.common_decay_times, max_ir_len_ms,
+                                                   net.sample_rate,
+                                                   use_mask=trainer_config.use_edc_mask)]
+            self.loss_weights = torch.tensor([trainer_config.edc_loss_weight])
+        else:
+            self.criterion = [
+                edr_loss(net.sample_rate, win_size=stft_win, hop_size=stft_win // 2,
+                         reduced_pole_radius=(None if self.reduced_pole_radius == 1.0
+                                              else self.reduced_pole_radius),
+                         use_erb_grouping=trainer_config.use_erb_edr_loss,
+                         use_weight_fn=trainer_config.use_frequency_weighting),
+                edc_loss(max_ir_len_ms, net.sample_rate, use_mask=trainer_config.use_edc_mask),
+            ]
+            self.loss_weights = torch.tensor([trainer_config.edr_loss_weight,
+                                              trainer_config.edc_loss_weight])
+        if self.use_colorless_loss:
+            spec = amse_loss() if trainer_config.use_asym_spectral_loss else mse_loss()
+            self.colorless_criterion = [spec, sparsity_loss()]
+            self.colorless_loss_weights = torch.tensor([trainer_config.spectral_loss_weight,
+                                                        trainer_config.sparsity_loss_weight])
+        # data-parallel state
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self._allreduce = (FlatGradAllReduce(net.parameters(), process_group)
+                           if self.world_size > 1 else None)
+
+    # reference :152-228
+    def init_scheduler(self, cfg: TrainerConfig):
+        named = list(self.net.named_parameters())
+        pick = lambda pred: [p for n, p in named if pred(n)]
+        keys = ('feedback_loop.alpha', 'input_gains', 'output_gains', 'output_svf_params',
+                'output_scalars', 'sh_output_scalars', 'input_scalars')
+        groups = [
+            {'params': pick(lambda n: 'feedback_loop.alpha' in n), 'lr': cfg.coupling_angle_lr},
+            {'params': pick(lambda n: 'output_gains' in n), 'lr': cfg.io_lr},
+            {'params': pick(lambda n: 'input_gains' in n), 'lr': cfg.io_lr},
+            {'params': pick(lambda n: 'output_svf_params' in n), 'lr': cfg.io_lr},
+            {'params': pick(lambda n: 'input_scalars' in n), 'lr': cfg.io_lr},
+            {'params': pick(lambda n: 'output_scalars' in n or 'sh_output_scalars' in n), 'lr': cfg.io_lr},
+        ]
+        other = pick(lambda n: not any(k in n for k in keys))
+        if other:
+            groups.append({'params': other, 'lr': cfg.lr})
+        self.optimizer = torch.optim.Adam(groups)
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=10, gamma=0.1)
+
+    def save_model(self, e: int):
+        if self.rank != 0:
+            return
+        d = os.path.join(self.train_dir, 'checkpoints')
+        os.makedirs(d, exist_ok=True)
+        torch.save(self.net.state_dict(), os.path.join(d, 'model_e' + str(e) + '.pt'))
+
+    # reference :259-315 -- drop-in: separate loss modules on (H, H_sub_fdn)
+    def calculate_losses(self, data: Dict, H: torch.Tensor, H_sub_fdn: Optional[Tuple] = None) -> Dict:
+        if self.use_directional_fdn:
+            all_losses = {'edc_loss': self.loss_weights[0].item() * self.criterion[0](
+                H, data['target_common_slope_amps'])}
+        else:
+            tgt = data['target_rir_response']
+            all_losses = {
+                'edc_loss': self.loss_weights[1].item() * self.criterion[1](tgt, H),
+                'edr_loss': self.loss_weights[0].item() * self.criterion[0](tgt, H),
+            }
+        if self.use_colorless_loss:
+            spectral, sparsity = 0.0, 0.0
+            fl = self.net.feedback_loop
+            for k in range(self.net.num_groups):
+                hk = H_sub_fdn[0][..., k]
+                spectral = spectral + self.colorless_loss_weights[0].item() * self.colorless_criterion[0](
+                    hk, torch.ones_like(hk))
+                sparsity = self.colorless_loss_weights[1].item() * self.colorless_criterion[1](
+                    fl.ortho_param(fl.M[k]))
+            all_losses.update({'spectral_loss': spectral, 'sparsity_loss': sparsity})
+        return all_losses
+
+    # reference :317-332
+    @torch.no_grad()
+    def normalize(self, data: Dict):
+        if not self.use_colorless_loss:
+            return
+        S, _ = self.net.sub_fdn_group_sums(data['z_values'])
+        energy, _, _ = spectral_stats(S, False, 1.0, want_grad=False)
+        scale = torch.pow(energy, 0.25).repeat_interleave(self.net.num_delay_lines_per_group).view(-1, 1)
+        for name, prm in self.net.named_parameters():
+            if name in ('input_gains', 'output_gains'):
+                prm.data /= scale.to(prm.dtype)
+
+
+class VarReceiverPosTrainer(Trainer):
+    """Grid-of-receivers trainer (reference trainer.py:338-564)."""
+
+    def _decay_window(self, K: int) -> Tuple[int, int]:
+        return self.criterion[1].window(K)
+
+    def _step_losses(self, data: Dict, draw_mask: bool = True) -> Dict:
+        """Fused forward + losses of one batch (train_step :452-471 / valid_step :479-498)."""
+        net, cfg = self.net, self.config
+        z = data['z_values']
+        n = net.num_delay_lines_per_group
+        filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
+        rgain = net.output_scalars.group_gains(data)
+        Y = net.delay_line_responses(z)
+        H = OutputStage.apply(Y, net.output_gains.reshape(-1), rgain.to(torch.float32), n,
+                              data['target_early_response'], filt)
+        K = H.shape[-1]
+        start, length = self._decay_window(K)
+        maskw, count = self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length))
+        if maskw is not None and self.world_size > 1:
+            dist.broadcast(maskw, src=0, group=self.process_group)   # same time mask on all ranks
+            count = float(maskw.sum().item())
+        B = H.shape[0]
+        gb = B
+        if self.world_size > 1:
+            nb = torch.tensor([B], device=H.device)
+            dist.all_reduce(nb, group=self.process_group)
+            gb = int(nb.item())
+        edr_t = data.get('edr_target')
+        edc_t = data.get('edc_target')
+        wf = self.criterion[0].frequency_weights.to(H.device) if cfg.use_frequency_weighting else None
+        total, edr_v, edc_v = decay_losses(
+            H, data.get('target_rir_response'), win=self.stft_win,
+            edr_weight=cfg.edr_loss_weight, edc_weight=cfg.edc_loss_weight,
+            edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
+            freq_weights=wf,
+            reduced_pole_radius=None if self.reduced_pole_radius == 1.0 else self.reduced_pole_radius,
+            global_batch=gb,
+            edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
+            edc_target=None if edc_t is None else edc_t[1])
+        losses = {'edc_loss': cfg.edc_loss_weight * edc_v, 'edr_loss': cfg.edr_loss_weight * edr_v}
+        if self.use_colorless_loss:
+            S, _ = net.sub_fdn_group_sums(z)
+            spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
+            fl = net.feedback_loop
+            sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
+                fl.ortho_param(fl.M[net.num_groups - 1]))          # last group only (:305-308)
+            extra = (spectral + sparsity) / self.world_size        # position independent
+            total = total + extra
+            losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
+        losses['_total'] = total
+        return losses
+
+    def train_step(self, data: Dict):
+        """normalize is called by the loop, as in the reference (:373-379)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        losses = self._step_losses(data)
+        total = losses.pop('_total')
+        total.backward()
+        if self._allreduce is not None:
+            self._allreduce()
+        self.optimizer.step()
+        return sum(losses.values()), losses
+
+    @torch.no_grad()
+    def valid_step(self, data: Dict):
+        losses = self._step_losses(data)
+        losses.pop('_total')
+        return sum(losses.values()), losses
+
+    def train(self, train_dataset, valid_dataset, save_irs: bool = False):
+        self.train_loss, self.valid_loss = [], []
+        self.individual_train_loss, self.individual_valid_loss = [], []
+        st = time.time()
+        self.save_model(-1)
+        for epoch in range(self.max_epochs):
+            st_epoch = time.time()
+            agg_t, agg_v = {}, {}
+            for data in train_dataset:
+                self.normalize(data)
+                _, cur = self.train_step(data)
+                for k, v in cur.items():
+                    agg_t[k] = agg_t.get(k, 0.0) + v.detach()
+            for data in valid_dataset:
+                _, cur = self.valid_step(data)
+                for k, v in cur.items():
+                    agg_v[k] = agg_v.get(k, 0.0) + v.detach()
+            self.scheduler.step()
+            nt, nv = max(len(train_dataset), 1), max(len(valid_dataset), 1)
+            agg_t = {k: float(v) / nt for k, v in agg_t.items()}     # one sync per epoch
+            agg_v = {k: float(v) / nv for k, v in agg_v.items()}
+            self.train_loss.append(sum(agg_t.values()))
+            self.valid_loss.append(sum(agg_v.values()))
+            self.individual_train_loss.append(agg_t)
+            self.individual_valid_loss.append(agg_v)
+            self.save_model(epoch)
+            if self.rank == 0:
+                print(f"epoch {epoch}: train {self.train_loss[-1]:.4f} valid {self.valid_loss[-1]:.4f} "
+                      f"({time.time() - st_epoch:.2f} s) " +
+                      " ".join(f"{k}={v:.4f}" for k, v in agg_t.items()))
+            if epoch >= 1:
+                self.early_stop = self.early_stop + 1 if abs(self.valid_loss[-2] - self.valid_loss[-1]) <= 1e-3 else 0
+            if self.early_stop == self.patience:
+                break
+        self.train_time = time.time() - st
+
+    @torch.no_grad()
+    def save_ir(self, input_features: Dict, norm: bool = True):
+        """Impulse responses of one batch (reference :503-564 minus the wav writing): h (B, nfft)."""
+        out = get_response(input_features, self.net)
+        h = out[-1]
+        if self.reduced_pole_radius is not None and self.reduced_pole_radius != 1.0:
+            h = h * torch.pow(torch.tensor(1.0 / self.reduced_pole_radius, device=h.device),
+                              torch.arange(h.shape[-1], device=h.device))
+        if norm:
+            h = h / torch.max(torch.abs(h))
+        return out[0], h
