@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Benchmark of the DiffGFDN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): N = 16 delay lines (4 groups x 4), 500 Hz octave band,
+838-receiver synthetic grid, nfft = 131 072 (K = 65 537 bins), fs = 32 kHz, batch of 32 receiver
+positions per optimiser step, losses EDR(w=1) + EDC(w=10, random mask) + asymmetric spectral(w=1)
++ sparsity(w=2), Adam -- the recipe of the reference's src/run_subband_training_treble.py:105-154.
+
+One "step" = what the reference's training loop does per batch (trainer.py:373-379):
+normalize (no-grad sub-FDN forward + in-place rescale of b, c) + train_step (forward, losses,
+backward, [all-reduce], Adam), on 32 receivers drawn from the grid.  Inputs are resident in HBM
+before the timed region.  Metric: RIR-frames/s = receivers x 32 EDR frames / second, summed over
+ranks (weak scaling: every rank steps its own 32-receiver shard of a 32N global batch and the
+parameter gradients are summed by one flat RCCL all-reduce).
+
+The JSON line also carries
+  roofline     : HBM roofline of the dominant kernel, timed live with HIP events on the launch
+                 stream inside the timed region;
+  cpu_baseline : the same step on the host cores by the CPU oracle (oracle/cpu_trainer.py, a
+                 restatement pinned to the reference; kind "port"), rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS = 32000.0
+NFFT = 131072
+K = NFFT // 2 + 1
+NUM_RECEIVERS = 838
+G, NPER = 4, 4
+BATCH = 32
+FRAMES = 32
+WIN = 4096
+HBM_PEAK_GBS = 8000.0
+# compulsory HBM bytes per RIR (fwd + bwd, fp32 / complex64 storage)
+ALG_BYTES_PER_RIR = 2811048
+DOMINANT_KERNEL = None               # set after profiling (profiles/)
+DOMINANT_ALG_BYTES_PER_UNIT = 0
+
+
+def octave_band_response(centre_hz: float, fs: float, nfft: int, numtaps: int = 2049) -> np.ndarray:
+    """(K,) response of a linear-phase octave band-pass FIR (stands in for the pyfar taps the
+    reference loads, trainer.py:116-128 -- the taps are input data on this path)."""
+    from scipy.signal import firwin
+    lo, hi = centre_hz / np.sqrt(2.0), centre_hz * np.sqrt(2.0)
+    taps = firwin(numtaps, [lo, hi], pass_zero=False, fs=fs)
+    return np.fft.rfft(taps, n=nfft)
+
+
+def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS):
+    from diffgfdn_amd.config import (CouplingMatrixType, DiffGFDNConfig, FeedbackLoopConfig,
+                                     OutputFilterConfig, SubbandProcessingConfig, TrainerConfig)
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset, split_dataset
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.synthetic import synthetic_room
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+
+    room = synthetic_room(num_receivers, G, FS, 64000, seed=0)
+    ds = RoomDataset(G, FS, room['source_position'], room['receiver_position'], room['rirs'],
+                     room['common_decay_times'], nfft=NFFT, device=device)
+    data = MultiRIRDataset(device, ds)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    cfg = DiffGFDNConfig(num_groups=G, num_delay_lines=G * NPER, sample_rate=FS, seed=23463 + 500)
+    delays = cfg.delay_length_samps
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=5, num_neurons_per_layer=16,
+                            num_fourier_features=20)
+    net = DiffGFDNVarReceiverPos(FS, G, delays, device, fl, of, use_absorption_filters=False,
+                                 common_decay_times=room['common_decay_times'],
+                                 use_colorless_loss=True).to(device)
+    tc = TrainerConfig(batch_size=BATCH, num_freq_bins=NFFT, max_epochs=20, lr=1e-3, io_lr=1e-2,
+                       use_edc_mask=True, use_colorless_loss=True, edc_loss_weight=10,
+                       sparsity_loss_weight=2, use_asym_spectral_loss=True, device='cuda',
+                       train_dir='/tmp/gfdn_bench/train', ir_dir='/tmp/gfdn_bench/ir',
+                       subband_process_config=SubbandProcessingConfig(
+                           centre_frequency=500.0, frequency_range=(63, 8000), num_fraction_octaves=1))
+    filt = torch.tensor(octave_band_response(500.0, FS, NFFT), device=device).to(torch.complex64)
+    trainer = VarReceiverPosTrainer(net, tc, subband_filter_freq_resp=filt)
+    start, length = trainer.criterion[1].window(K)
+    data.precompute_decay_targets(WIN, start, length)
+    train_idx, valid_idx, test_idx = split_dataset(data, 0.8, test_ratio=0.1)
+    return room, data, net, trainer, train_idx, filt, delays
+
+
+def cpu_baseline(room, delays, filt_np, steps: int = 2):
+    """The same optimiser step on the host cores with the CPU oracle (reference restatement)."""
+    from oracle import gfdn_oracle as orc
+    from oracle.cpu_trainer import OracleGridTrainer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.RandomState(1)
+    idx = rng.permutation(room['rirs'].shape[0])[:BATCH]
+    rirs = room['rirs'][idx].copy()
+    pos = room['receiver_position']
+    npos = (pos - pos.min(0)) / ((pos.max(0) - pos.min(0)) + 1e-12)
+    mix, win = int(20e-3 * FS), int(5e-3 * FS)
+    w = np.hanning(win)
+    full = np.fft.rfft(rirs, n=NFFT, axis=-1)
+    early = rirs[:, :mix].copy()
+    early[:, -(win // 2):] *= w[win // 2:]
+    batch = {'z_values': torch.tensor(np.exp(1j * 2 * np.pi * np.fft.rfftfreq(NFFT))),
+             'norm_listener_position': torch.tensor(npos[idx]),
+             'listener_position': torch.tensor(pos[idx]),
+             'target_early_response': torch.tensor(np.fft.rfft(early, n=NFFT, axis=-1)),
+             'target_rir_response': torch.tensor(full)}
+    torch.manual_seed(0)
+    from diffgfdn_amd.dnn import MLP
+    mlp = MLP(120, 5, 16, G, 1, 1)
+    lin = [(m.weight.detach().clone(), m.bias.detach().clone()) for m in mlp.model if isinstance(m, torch.nn.Linear)]
+    norm = [(m.weight.detach().clone(), m.bias.detach().clone()) for m in mlp.model if isinstance(m, torch.nn.LayerNorm)]
+    N = G * NPER
+    p = orc.GridModelParams(FS, delays, G, (2 * torch.randn(N, 1) - 1) / N, (2 * torch.randn(N, 1) - 1) / N,
+                            (2 * torch.rand(G, NPER, NPER) - 1) / np.sqrt(NPER), torch.zeros(G * (G - 1) // 2),
+                            room['common_decay_times'], lin, norm, 20)
+    tr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
+                           sparsity_weight=2.0, use_asym=True, subband_filter=torch.tensor(filt_np))
+    L = min(orc.ms_to_samps(float(np.max(room['common_decay_times'])) * 1e3, FS), K) - mix
+    times = []
+    for s in range(steps + 1):           # first step is warm-up (allocator, thread pools)
+        mask = torch.argwhere(torch.bernoulli(torch.empty(L).uniform_(0, 1)))
+        t0 = time.time()
+        tr.normalize(batch)
+        tr.train_step(batch, mask)
+        times.append(time.time() - t0)
+    sec = float(np.mean(times[1:]))
+    return {'value': BATCH * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{steps} optimiser steps (normalize + fwd + EDR/EDC/colorless losses + bwd + Adam) of the '
+                      f'same workload, batch {BATCH}, after 1 warm-up step; {sec:.2f} s/step',
+            'sec_per_step': sec}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # host-side torch ops on tiny CPU tensors (mask draw, index lists) crawl when the intra-op pool
+    # spans all 256 host cores (measured 30 ms/step at 128 threads vs 6 ms at 4)
+    torch.set_num_threads(min(4, os.cpu_count() or 1))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    from diffgfdn_amd import hip_ops
+    hip_ops.kernel_timer.watch = DOMINANT_KERNEL
+    room, data, net, trainer, train_idx, filt, delays = build_workload(device, seed=1234,
+                                                                      num_receivers=args.receivers)
+    # every rank draws its own receivers (different shards of a 32*world global batch)
+    gen = torch.Generator().manual_seed(100 + rank)
+    train_idx_t = torch.tensor(train_idx)
+
+    def one_step():
+        sel = train_idx_t[torch.randperm(len(train_idx), generator=gen)[:BATCH]].tolist()
+        batch = data.collate(sel, lean=True)
+        trainer.normalize(batch)
+        return trainer.train_step(batch)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    hip_ops.kernel_timer.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, parts = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ktimes = hip_ops.kernel_timer.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    rirs_per_s = BATCH * world * args.steps / elapsed
+    value = rirs_per_s * FRAMES
+
+    if rank == 0:
+        out = {
+            'metric': 'RIR-frames/sec', 'value': value, 'unit': 'RIR-frames/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'N=16 GFDN (4 groups x 4), 500 Hz octave band, 838-receiver grid, '
+                                   'nfft 131072 (K=65537), batch 32 receivers/step/GPU; step = normalize + '
+                                   'fwd + EDR/EDC(mask)/colorless losses + bwd + Adam',
+                       'receivers': args.receivers, 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
+                       'delay_lines': G * NPER, 'bins': K, 'rirs_per_s': rirs_per_s,
+                       'final_loss': float(total)},
+        }
+        dom = ktimes if ktimes else None
+        if dom:
+            dom['alg_bytes_per_unit'] = DOMINANT_ALG_BYTES_PER_UNIT
+            units = dom['units_per_launch']
+            achieved = units * dom['alg_bytes_per_unit'] / (dom['avg_ms'] * 1e-3) / 1e9
+            out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': dom.get('traffic'),
+                               'kernel': dom['kernel'], 'avg_launch_us': dom['avg_ms'] * 1e3,
+                               'launches': dom['launches'],
+                               'alg_bytes_per_launch': units * dom['alg_bytes_per_unit']}
+        out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(room, delays, filt.cpu().numpy().astype(np.complex128),
+                                               steps=args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -225,25 +225,29 @@ __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __
   }
 }
 
-// out[e] = sum_p partial[p][e]   (fixed order)
-__global__ void k_reduce_partials(const float* __restrict__ partial, int nparts, int per,
-                                  float* __restrict__ out) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per) return;
+// out[e] = sum_p partial[p][e]; one 256-thread block per output element, fixed-order tree
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial,
+                                                         int nparts, int per,
+                                                         float* __restrict__ out) {
+  __shared__ float s_red[16];
+  const int e = blockIdx.x;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * per + e];
-  out[e] = s;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * per + e];
+  s = block_sum(s, s_red);
+  if (threadIdx.x == 0) out[e] = s;
 }
 
 // scatter the reduced [nblk][n*n + 2n] record into gA, gb, ginv_gamma
-__global__ void k_solve_bwd_finish(const float* __restrict__ partial, int nparts, int nblk, int n,
+__global__ __launch_bounds__(256) void k_solve_bwd_finish(const float* __restrict__ partial, int nparts, int nblk, int n,
                                    float* __restrict__ gA, float* __restrict__ gb,
                                    float* __restrict__ gig) {
+  __shared__ float s_red[16];
   const int per = n * n + 2 * n;
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nblk * per) return;
+  const int e = blockIdx.x;                       // one block per output element
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * nblk * per + e];
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * nblk * per + e];
+  s = block_sum(s, s_red);
+  if (threadIdx.x != 0) return;
   int blk = e / per, o = e % per;
   if (o < n * n) gA[(size_t)blk * n * n + o] = s;
   else if (o < n * n + n) gb[blk * n + (o - n * n)] = s;
@@ -313,7 +317,7 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
   }
   GFDN_LAUNCH_CHECK();
   const int tot = nblk * (nper * nper + 2 * nper);
-  hipLaunchKernelGGL(k_solve_bwd_finish, dim3((tot + 255) / 256), dim3(256), 0, s, partial, nparts,
+  hipLaunchKernelGGL(k_solve_bwd_finish, dim3(tot), dim3(256), 0, s, partial, nparts,
                      nblk, nper, gA, gb, ginv_gamma);
   GFDN_LAUNCH_CHECK();
   return 0;
@@ -440,17 +444,19 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
     gc_partial[(size_t)blockIdx.x * N + n] = s_gc[0][n] + s_gc[1][n] + s_gc[2][n] + s_gc[3][n];
 }
 
-// grgain[b][g] = sum_k Re(conj(gH'[b][k]) S[g][k]),  gH' = conj(filt) gH
+// grgain[b][g] = sum_k Re(conj(gH'[b][k]) S[g][k]),  gH' = conj(filt) gH.
+// grid (k-chunks, B): partial[(b*G+g)*nchunk + chunk], then k_sum_rows (fixed order).
+#define CB_CHUNK 1024
 __global__ __launch_bounds__(256) void k_compose_bwd_b(const float2* __restrict__ S_work, int K,
                                                        int G, const float2* __restrict__ filt,
                                                        const float2* __restrict__ gH, int ldh,
-                                                       float* __restrict__ grgain) {
+                                                       float* __restrict__ partial) {
   __shared__ float s_red[16];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y, k0 = blockIdx.x * CB_CHUNK, nchunk = gridDim.x;
   float acc[GFDN_MAX_GROUPS];
 #pragma unroll
   for (int g = 0; g < GFDN_MAX_GROUPS; ++g) acc[g] = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) {
+  for (int k = k0 + threadIdx.x; k < k0 + CB_CHUNK && k < K; k += 256) {
     float2 gh = gH[(size_t)b * ldh + k];
     if (filt) gh = cmul(gh, cconj(filt[k]));
 #pragma unroll
@@ -465,9 +471,19 @@ __global__ __launch_bounds__(256) void k_compose_bwd_b(const float2* __restrict_
   for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
     if (g < G) {
       float s = block_sum(acc[g], s_red);
-      if (threadIdx.x == 0) grgain[b * G + g] = s;
+      if (threadIdx.x == 0) partial[(size_t)(b * G + g) * nchunk + blockIdx.x] = s;
     }
   }
+}
+
+// out[r] = sum_c part[r][c], one wavefront per row, fixed order
+__global__ __launch_bounds__(64) void k_sum_rows(const float* __restrict__ part, int cols,
+                                                 float* __restrict__ out) {
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 64) s += part[(size_t)r * cols + c];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[r] = s;
 }
 
 static size_t compose_partial_bytes(int G, int nper) {
@@ -475,8 +491,9 @@ static size_t compose_partial_bytes(int G, int nper) {
 }
 // gc partial slots followed by a (G, K) complex copy of S for the second pass
 extern "C" size_t gfdn_compose_bwd_work_bytes(int K, int G, int nper, int B) {
-  (void)B;
-  return compose_partial_bytes(G, nper) + (size_t)G * K * sizeof(float2);
+  const size_t nchunk = (size_t)(K + 1023) / 1024;
+  return compose_partial_bytes(G, nper) + (size_t)G * K * sizeof(float2) +
+         (size_t)B * G * nchunk * sizeof(float);
 }
 
 extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const float* c,
@@ -496,11 +513,14 @@ extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const fl
                      c, rgain, B, (const float2*)filt, (const float2*)gH, ldh, (float2*)gY, S_work,
                      gc_partial);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials, dim3((N + 255) / 256), dim3(256), 0, s, gc_partial, nparts,
-                     N, gc);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, gc_partial, nparts, N, gc);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compose_bwd_b, dim3(B), dim3(256), 0, s, S_work, K, G,
-                     (const float2*)filt, (const float2*)gH, ldh, grgain);
+  const int nchunk = (K + CB_CHUNK - 1) / CB_CHUNK;
+  float* rg_partial = (float*)((char*)S_work + (size_t)G * K * sizeof(float2));
+  hipLaunchKernelGGL(k_compose_bwd_b, dim3(nchunk, B), dim3(256), 0, s, S_work, K, G,
+                     (const float2*)filt, (const float2*)gH, ldh, rg_partial);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_rows, dim3(B * G), dim3(64), 0, s, rg_partial, nchunk, grgain);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -622,8 +642,7 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
   hipLaunchKernelGGL(k_compose_sh_bwd_a, dim3(nparts), dim3(256), 0, s, (const float2*)Y, K, G, nper,
                      c, w, B, (const float2*)filt, (const float2*)gH, (float2*)gY, gc_partial);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials, dim3((N + 255) / 256), dim3(256), 0, s, gc_partial, nparts,
-                     N, gc);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, gc_partial, nparts, N, gc);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_compose_sh_bwd_b, dim3(N, B), dim3(256), 0, s, (const float2*)Y, K, G, nper,
                      c, (const float2*)filt, (const float2*)gH, gw);

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .config import CouplingMatrixType
-from .functional import FrequencyGrid, ResolventSolve
+from .functional import FrequencyGrid, OrthoParam, ResolventSolve
 
 
 class Skew(nn.Module):
@@ -36,6 +36,21 @@ class MatrixExponential(nn.Module):
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
         return torch.matrix_exp(X)
+
+
+class OrthoParamModule(nn.Sequential):
+    """``ortho_param`` of the reference (:270: nn.Sequential(Skew(), MatrixExponential())) with the
+    CUDA path routed to the HIP kernel, for one (n, n) matrix or a (G, n, n) stack."""
+
+    def __init__(self):
+        super().__init__(Skew(), MatrixExponential())
+
+    def forward(self, X: torch.Tensor) -> torch.Tensor:
+        if X.is_cuda and X.dtype == torch.float32 and X.shape[-1] <= 32:
+            M = X if X.ndim == 3 else X.unsqueeze(0)
+            Q = OrthoParam.apply(M.contiguous())[0]
+            return Q if X.ndim == 3 else Q[0]
+        return super().forward(X)
 
 
 class ND_Unitary(nn.Module):
@@ -102,7 +117,7 @@ class FeedbackLoop(nn.Module):
         self.device = device
         self.coupling_matrix_type = coupling_matrix_type
         self.coupling_matrix_order = coupling_matrix_order
-        self.ortho_param = nn.Sequential(Skew(), MatrixExponential())
+        self.ortho_param = OrthoParamModule()
         self._init_absorption(gains, common_decay_times)
         self._init_feedback_matrix(colorless_feedback_matrix)
 
@@ -156,7 +171,9 @@ class FeedbackLoop(nn.Module):
 
     # -- reference :393-455 ------------------------------------------------------------------------
     def group_rotations(self) -> torch.Tensor:
-        """Q_g = expm(skew(M_g)), (G, n, n)."""
+        """Q_g = expm(skew(M_g)), (G, n, n) -- HIP kernel on the device (csrc/ortho.hip)."""
+        if self.M.is_cuda:
+            return OrthoParam.apply(self.M)[0]
         return self.ortho_param(self.M)
 
     def construct_block_mixing_matrix(self) -> torch.Tensor:
@@ -189,6 +206,8 @@ class FeedbackLoop(nn.Module):
         """What the solver consumes: (G, n, n) diagonal blocks Q_g Q_g when the groups are
         uncoupled, else the dense (1, N, N) matrix."""
         if self.coupling_matrix_type != CouplingMatrixType.RANDOM and self.use_zero_coupling:
+            if self.M.is_cuda:
+                return OrthoParam.apply(self.M)[1]
             Q = self.group_rotations()
             return Q @ Q
         return self._real_feedback_matrix().unsqueeze(0)

@@ -38,6 +38,22 @@ class FrequencyGrid:
         return g
 
 
+class OrthoParam(torch.autograd.Function):
+    """(Q, QQ) = (expm(skew(M)), expm(skew(M))^2) for M (G, n, n)  (feedback_loop.py:16-36, :270,
+    :393-404), forward and adjoint in one HIP kernel each."""
+
+    @staticmethod
+    def forward(ctx, M):
+        Q, QQ = ops.ortho_fwd(M, True, True)
+        ctx.save_for_backward(M)
+        return Q, QQ
+
+    @staticmethod
+    def backward(ctx, gQ, gQQ):
+        (M,) = ctx.saved_tensors
+        return ops.ortho_bwd(M, gQ.contiguous(), gQQ.contiguous()).to(M.dtype)
+
+
 class ResolventSolve(torch.autograd.Function):
     """Y[k] = (diag(z_k^m inv_gamma) - A)^{-1} b   (A^T when transpose)."""
 

@@ -53,6 +53,29 @@ def zprep(z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return turns, logr
 
 
+def ortho_fwd(M, want_Q=True, want_QQ=False):
+    """M (G,n,n) -> (Q = expm(skew(M)), QQ = Q @ Q); entries not requested are None."""
+    _need_gpu(M)
+    M = _f(M)
+    G, n, _ = M.shape
+    Q = torch.empty_like(M) if want_Q else None
+    QQ = torch.empty_like(M) if want_QQ else None
+    _lib.check(_lib.load().gfdn_ortho_fwd(_p(M), G, n, _p(Q), _p(QQ), _stream()), "gfdn_ortho_fwd")
+    return Q, QQ
+
+
+def ortho_bwd(M, gQ=None, gQQ=None):
+    _need_gpu(M)
+    M = _f(M)
+    G, n, _ = M.shape
+    gQ = None if gQ is None else _f(gQ)
+    gQQ = None if gQQ is None else _f(gQQ)
+    gM = torch.empty_like(M)
+    _lib.check(_lib.load().gfdn_ortho_bwd(_p(M), G, n, _p(gQ), _p(gQQ), _p(gM), _stream()),
+               "gfdn_ortho_bwd")
+    return gM
+
+
 def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False) -> torch.Tensor:
     """A (nblk,nper,nper) f32, delays/inv_gamma/b (N,) f32 -> Y (K,N) complex64."""
     _need_gpu(turns, A)
@@ -314,3 +337,43 @@ def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.
                                          float(inv_count), float(gscale), _p(loss_item), _p(gx),
                                          _stream()), "gfdn_edc_loss")
     return loss_item, gx
+
+
+# ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """HIP-event timing of ONE watched kernel on the launch stream (bench.py's roofline leg).
+
+    ``watch`` names a kernel stage; wrappers that launch exactly that kernel bracket the launch
+    with a pair of events on ``torch.cuda.current_stream()`` (the stream the C-ABI call launches
+    on) while the timer is active.  Inactive (the default) it costs one attribute test."""
+
+    def __init__(self):
+        self.watch = None
+        self.active = False
+        self._events = []
+
+    def start(self):
+        self._events = []
+        self.active = self.watch is not None
+
+    def bracket(self, name: str, units: int):
+        if self.active and name == self.watch:
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            self._events.append((s, e, units))
+            s.record()
+            return e
+        return None
+
+    def stop(self):
+        self.active = False
+        if not self._events:
+            return {}
+        torch.cuda.synchronize()
+        ms = [s.elapsed_time(e) for s, e, _ in self._events]
+        units = [u for _, _, u in self._events]
+        return {'kernel': self.watch, 'launches': len(ms), 'avg_ms': sum(ms) / len(ms),
+                'min_ms': min(ms), 'units_per_launch': sum(units) / len(units)}
+
+
+kernel_timer = KernelTimer()

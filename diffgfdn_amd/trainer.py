@@ -246,7 +246,7 @@ class VarReceiverPosTrainer(Trainer):
             spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
             fl = net.feedback_loop
             sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
-                fl.ortho_param(fl.M[net.num_groups - 1]))          # last group only (:305-308)
+                fl.group_rotations()[net.num_groups - 1])          # last group only (:305-308)
             extra = (spectral + sparsity) / self.world_size        # position independent
             total = total + extra
             losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})

@@ -1,0 +1,71 @@
+"""CPU restatement of one optimiser step of the reference grid trainer -- TEST INFRASTRUCTURE.
+
+normalize (trainer.py:317-332) + train_step (trainer.py:452-477) with Adam parameter groups
+(trainer.py:152-228), built on oracle/gfdn_oracle.py.  Used by tests (F4 fixture: post-Adam state)
+and by bench.py's ``cpu_baseline`` leg (kind "port": the reference itself cannot travel to the
+GPU box).  Never imported by the product package."""
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import gfdn_oracle as orc
+
+
+class OracleGridTrainer:
+    def __init__(self, params: orc.GridModelParams, *, lr=1e-3, io_lr=1e-2, coupling_angle_lr=1e-2,
+                 edr_weight=1.0, edc_weight=1.0, spectral_weight=1.0, sparsity_weight=1.0,
+                 use_asym=False, win=4096, hop=2048, subband_filter: Optional[torch.Tensor] = None,
+                 learn_alpha: bool = False):
+        self.p = params
+        self.w = dict(edr=edr_weight, edc=edc_weight, spec=spectral_weight, spars=sparsity_weight)
+        self.use_asym = use_asym
+        self.win, self.hop = win, hop
+        self.subband_filter = subband_filter
+        p = params
+        for t in (p.input_gains, p.output_gains, p.M):
+            t.requires_grad_(True)
+        mlp = [t for pair in list(p.mlp_weights) + list(p.mlp_norms) for t in pair]
+        for t in mlp:
+            t.requires_grad_(True)
+        groups = []
+        if learn_alpha:
+            p.alpha.requires_grad_(True)
+            groups.append({'params': [p.alpha], 'lr': coupling_angle_lr})
+        groups += [{'params': [p.output_gains], 'lr': io_lr}, {'params': [p.input_gains], 'lr': io_lr},
+                   {'params': mlp, 'lr': io_lr},          # names contain 'output_scalars'
+                   {'params': [p.M], 'lr': lr}]
+        self.optimizer = torch.optim.Adam(groups)
+
+    def losses(self, batch: Dict, edc_mask: Optional[torch.Tensor] = None) -> Dict:
+        p = self.p
+        H, Hs = orc.grid_model_forward(p, batch)
+        if self.subband_filter is not None:
+            H = H * self.subband_filter
+        fs = p.sample_rate
+        tgt = batch['target_rir_response']
+        max_samps = orc.ms_to_samps(float(np.max(p.common_decay_times)) * 1e3, fs)
+        out = {'edc_loss': self.w['edc'] * orc.edc_loss(tgt, H, max_samps, orc.ms_to_samps(20.0, fs), edc_mask),
+               'edr_loss': self.w['edr'] * orc.edr_loss(tgt, H, self.win, self.hop)}
+        crit = orc.amse_loss if self.use_asym else orc.mse_loss
+        spec = 0.0
+        for k in range(p.num_groups):
+            hk = Hs[0][..., k]
+            spec = spec + self.w['spec'] * crit(hk, torch.ones_like(hk))
+            spars = self.w['spars'] * orc.sparsity_loss(orc.ortho_param(p.M[k]))
+        out['spectral_loss'] = spec
+        out['sparsity_loss'] = spars
+        return out
+
+    def normalize(self, batch: Dict):
+        with torch.no_grad():
+            _, Hs = orc.grid_model_forward(self.p, batch)
+        orc.normalize_io_gains(self.p, Hs)
+
+    def train_step(self, batch: Dict, edc_mask: Optional[torch.Tensor] = None):
+        self.optimizer.zero_grad()
+        losses = self.losses(batch, edc_mask)
+        total = sum(losses.values())
+        total.backward()
+        self.optimizer.step()
+        return total.item(), {k: float(v.detach()) for k, v in losses.items()}

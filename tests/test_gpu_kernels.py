@@ -74,6 +74,26 @@ def test_solve_fwd_bwd(ops, nblk, nper, transpose, radius):
     assert rel_err(gig.cpu(), ig.grad) < 1e-4
 
 
+@pytest.mark.parametrize("G,n", [(4, 4), (3, 9), (2, 16), (1, 27), (3, 2), (1, 32)])
+def test_ortho_param(ops, G, n):
+    torch.manual_seed(G * 7 + n)
+    M = ((2 * torch.rand(G, n, n, dtype=torch.float64) - 1) / np.sqrt(n) * 1.7).requires_grad_(True)
+    Q = orc.ortho_param(M)
+    QQ = Q @ Q
+    gQ = torch.randn_like(Q) * 30.0
+    gQQ = torch.randn_like(Q)
+    ((Q * gQ).sum() + (QQ * gQQ).sum()).backward()
+    Qk, QQk = ops.ortho_fwd(M.detach().float().to(DEV), True, True)
+    assert rel_err(Qk.cpu(), Q.detach()) < 2e-6
+    assert rel_err(QQk.cpu(), QQ.detach()) < 2e-6
+    gM = ops.ortho_bwd(M.detach().float().to(DEV), gQ.float().to(DEV), gQQ.float().to(DEV))
+    assert rel_err(gM.cpu(), M.grad) < 2e-5
+    gM1 = ops.ortho_bwd(M.detach().float().to(DEV), gQ.float().to(DEV), None)
+    M2 = M.detach().clone().requires_grad_(True)
+    (orc.ortho_param(M2) * gQ).sum().backward()
+    assert rel_err(gM1.cpu(), M2.grad) < 2e-5
+
+
 @pytest.mark.parametrize("G,nper,B,use_filt,use_direct", [(3, 4, 5, True, True), (4, 4, 32, False, True),
                                                           (2, 8, 3, True, False), (3, 9, 9, False, False)])
 def test_compose_fwd_bwd(ops, G, nper, B, use_filt, use_direct):

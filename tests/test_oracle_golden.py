@@ -207,3 +207,22 @@ def test_f6_directional():
     l = orc.directional_edc_loss(H_dir, torch.tensor(fx["amps"]), torch.tensor(fx["envelopes"]),
                                  orc.ms_to_samps(20.0, fs), edc_len)
     assert abs(l.item() - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+
+
+@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False)])
+def test_f4_adam_state(name, asym):
+    """oracle/cpu_trainer.py (the bench's CPU baseline) reproduces the reference's post-Adam state."""
+    from oracle.cpu_trainer import OracleGridTrainer
+    fx = load(name)
+    p = grid_params(fx)
+    batch = batch_from(fx)
+    tr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, coupling_angle_lr=1e-2, edr_weight=1.0, edc_weight=10.0,
+                           spectral_weight=1.0, sparsity_weight=2.0, use_asym=asym, win=int(fx["win"]),
+                           hop=int(fx["hop"]), learn_alpha=not bool(fx["zero_coupling"]))
+    tr.normalize(batch)
+    total, parts = tr.train_step(batch)
+    assert abs(total - float(fx["step_total"])) < 2e-5 * abs(float(fx["step_total"]))
+    assert rel_err(p.input_gains.detach(), fx["sda_input_gains"]) < 1e-5
+    assert rel_err(p.output_gains.detach(), fx["sda_output_gains"]) < 1e-5
+    assert rel_err(p.M.detach(), fx["sda_feedback_loop.M"]) < 1e-5
+    assert rel_err(p.mlp_weights[0][0].detach(), fx["sda_output_scalars.mlp.model.0.weight"]) < 1e-4
