@@ -88,7 +88,9 @@ def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS):
                        subband_process_config=SubbandProcessingConfig(
                            centre_frequency=500.0, frequency_range=(63, 8000), num_fraction_octaves=1))
     filt = torch.tensor(octave_band_response(500.0, FS, NFFT), device=device).to(torch.complex64)
-    trainer = VarReceiverPosTrainer(net, tc, subband_filter_freq_resp=filt)
+    pg = dist.group.WORLD if dist.is_initialized() else None
+    trainer = VarReceiverPosTrainer(net, tc, subband_filter_freq_resp=filt, process_group=pg,
+                                    capturable=True)
     start, length = trainer.criterion[1].window(K)
     data.precompute_decay_targets(WIN, start, length)
     train_idx, valid_idx, test_idx = split_dataset(data, 0.8, test_ratio=0.1)
@@ -148,6 +150,7 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
     args = ap.parse_args()
@@ -175,11 +178,16 @@ def main():
     gen = torch.Generator().manual_seed(100 + rank)
     train_idx_t = torch.tensor(train_idx)
 
+    step = trainer.graphed(data, BATCH)      # normalize + train_step as HIP-graph replays
+
     def one_step():
         sel = train_idx_t[torch.randperm(len(train_idx), generator=gen)[:BATCH]].tolist()
-        batch = data.collate(sel, lean=True)
-        trainer.normalize(batch)
-        return trainer.train_step(batch)
+        if args.eager:
+            batch = data.collate(sel, lean=True)
+            trainer.normalize(batch)
+            return trainer.train_step(batch)
+        losses = step(sel)
+        return losses['_total'], losses
 
     for _ in range(args.warmup):
         one_step()
@@ -216,6 +224,7 @@ def main():
                                    'fwd + EDR/EDC(mask)/colorless losses + bwd + Adam',
                        'receivers': args.receivers, 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
                        'delay_lines': G * NPER, 'bins': K, 'rirs_per_s': rirs_per_s,
+                       'launch': 'eager' if args.eager else 'hip_graph',
                        'final_loss': float(total)},
         }
         dom = ktimes if ktimes else None

@@ -56,11 +56,26 @@ __device__ __forceinline__ float block_sum(float v, float* lds /* >= 16 floats *
 }
 
 // dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
+// The largest size already granted per kernel is remembered (a benign process-wide cache) so that
+// steady-state launches -- and launches under HIP graph capture -- make no runtime API call.
+static inline int ensure_dyn_lds_ptr(const void* fn, size_t bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  static const void* fns[32];
+  static size_t granted[32];
+  static int count = 0;
+  int slot = -1;
+  for (int i = 0; i < count; ++i)
+    if (fns[i] == fn) { slot = i; break; }
+  if (slot >= 0 && bytes <= granted[slot]) return 0;
+  int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (rc != 0) return rc;
+  if (slot < 0 && count < 32) { slot = count++; fns[slot] = fn; }
+  if (slot >= 0) granted[slot] = bytes;
+  return 0;
+}
 template <typename K>
 static inline int ensure_dyn_lds(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return 0;
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return ensure_dyn_lds_ptr(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 static inline int ilog2(int v) {

@@ -136,11 +136,14 @@ class MultiRIRDataset(torch.utils.data.Dataset):
         self.edr_store = (win, T_edr, sum_abs)
         self.edc_store = ((edc_start, edc_len), T_edc)
 
-    def collate(self, indices: Sequence[int], lean: bool = False) -> Dict:
+    def collate(self, indices, lean: bool = False) -> Dict:
         """Batch dict with the reference's keys (custom_collate :674-704) + 'receiver_index'.
         ``lean`` skips gathering responses the training step does not read (the late response
         always; the full target response when its EDR / EDC are already in the stores)."""
-        idx = torch.as_tensor(list(indices), dtype=torch.long, device=self.device)
+        if torch.is_tensor(indices):
+            idx = indices          # device index tensor (static buffer under graph replay)
+        else:
+            idx = torch.as_tensor(list(indices), dtype=torch.long, device=self.device)
         B = idx.numel()
         batch = {
             'z_values': self.z_values,

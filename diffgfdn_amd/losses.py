@@ -125,6 +125,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  edr_weight: float = 1.0, edc_weight: float = 1.0, use_edr: bool = True,
                  use_edc: bool = True, edc_start: int = 640, edc_len: Optional[int] = None,
                  edc_maskw: Optional[torch.Tensor] = None, edc_count: Optional[float] = None,
+                 edc_maskw_prenormalised: bool = False,
                  freq_weights: Optional[torch.Tensor] = None,
                  reduced_pole_radius: Optional[float] = None,
                  global_batch: Optional[int] = None,
@@ -158,8 +159,10 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         T_db = edc_target if edc_target is not None else targets.edc(target, edc_start, L)
         count = float(L) if edc_count is None else float(edc_count)
         nb = B if global_batch is None else global_batch
-        li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, 1.0 / (nb * count), edc_weight,
-                              want_grad)
+        # pre-normalised weights already carry 1 / (items * kept indices): no host scalar varies
+        # from step to step, which keeps the launch arguments static under graph replay
+        inv = 1.0 if edc_maskw_prenormalised else 1.0 / (nb * count)
+        li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
         edc_val = li.sum()
     if use_edr:
         T_edr, sum_abs = edr_target if edr_target is not None else targets.edr(target, win)

@@ -80,7 +80,7 @@ class Trainer:
 
     def __init__(self, net: DiffGFDN, trainer_config: TrainerConfig,
                  subband_filter_freq_resp: Optional[torch.Tensor] = None,
-                 process_group=None, stft_win: int = 4096):
+                 process_group=None, stft_win: int = 4096, capturable: bool = False):
         self.net = net
         self.device = trainer_config.device
         self.max_epochs = trainer_config.max_epochs
@@ -102,6 +102,7 @@ class Trainer:
             raise ValueError("subband_process_config set: pass subband_filter_freq_resp (K,) explicitly")
         self.config = trainer_config
         self.stft_win = stft_win
+        self.capturable = capturable
         self.init_scheduler(trainer_config)
 
         if net.common_decay_times is None:
@@ -154,7 +155,16 @@ class Trainer:
         other = pick(lambda n: not any(k in n for k in keys))
         if other:
             groups.append({'params': other, 'lr': cfg.lr})
-        self.optimizer = torch.optim.Adam(groups)
+        if self.capturable:
+            # device-resident step counters and learning rates: the update can be replayed from a
+            # HIP graph, and StepLR rewrites the lr tensors in place
+            groups = [g for g in groups if g['params']]
+            dev = groups[0]['params'][0].device
+            for g in groups:
+                g['lr'] = torch.tensor(float(g['lr']), device=dev)
+            self.optimizer = torch.optim.Adam(groups, capturable=True, foreach=True)
+        else:
+            self.optimizer = torch.optim.Adam(groups)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=10, gamma=0.1)
 
     def save_model(self, e: int):
@@ -206,8 +216,11 @@ class VarReceiverPosTrainer(Trainer):
     def _decay_window(self, K: int) -> Tuple[int, int]:
         return self.criterion[1].window(K)
 
-    def _step_losses(self, data: Dict, draw_mask: bool = True) -> Dict:
-        """Fused forward + losses of one batch (train_step :452-471 / valid_step :479-498)."""
+    def _step_losses(self, data: Dict, draw_mask: bool = True,
+                     mask_prenorm: Optional[torch.Tensor] = None) -> Dict:
+        """Fused forward + losses of one batch (train_step :452-471 / valid_step :479-498).
+        ``mask_prenorm``: EDC time weights already divided by (global batch x kept indices), in a
+        static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
         net, cfg = self.net, self.config
         z = data['z_values']
         n = net.num_delay_lines_per_group
@@ -218,16 +231,20 @@ class VarReceiverPosTrainer(Trainer):
                               data['target_early_response'], filt)
         K = H.shape[-1]
         start, length = self._decay_window(K)
-        maskw, count = self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length))
-        if maskw is not None and self.world_size > 1:
-            dist.broadcast(maskw, src=0, group=self.process_group)   # same time mask on all ranks
-            count = float(maskw.sum().item())
         B = H.shape[0]
         gb = B
-        if self.world_size > 1:
-            nb = torch.tensor([B], device=H.device)
-            dist.all_reduce(nb, group=self.process_group)
-            gb = int(nb.item())
+        if mask_prenorm is not None:
+            maskw, count = mask_prenorm, None
+        else:
+            maskw, count = (self.criterion[1].draw_mask(length, H.device) if draw_mask
+                            else (None, float(length)))
+            if maskw is not None and self.world_size > 1:
+                dist.broadcast(maskw, src=0, group=self.process_group)   # same mask on all ranks
+                count = float(maskw.sum().item())
+            if self.world_size > 1:
+                nb = torch.tensor([B], device=H.device)
+                dist.all_reduce(nb, group=self.process_group)
+                gb = int(nb.item())
         edr_t = data.get('edr_target')
         edc_t = data.get('edc_target')
         wf = self.criterion[0].frequency_weights.to(H.device) if cfg.use_frequency_weighting else None
@@ -235,7 +252,7 @@ class VarReceiverPosTrainer(Trainer):
             H, data.get('target_rir_response'), win=self.stft_win,
             edr_weight=cfg.edr_loss_weight, edc_weight=cfg.edc_loss_weight,
             edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
-            freq_weights=wf,
+            edc_maskw_prenormalised=mask_prenorm is not None, freq_weights=wf,
             reduced_pole_radius=None if self.reduced_pole_radius == 1.0 else self.reduced_pole_radius,
             global_batch=gb,
             edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
@@ -252,6 +269,10 @@ class VarReceiverPosTrainer(Trainer):
             losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
         losses['_total'] = total
         return losses
+
+    def graphed(self, dataset, batch_size: int) -> "GraphedTrainStep":
+        """normalize + train_step of a fixed-size batch as one HIP graph replay."""
+        return GraphedTrainStep(self, dataset, batch_size)
 
     def train_step(self, data: Dict):
         """normalize is called by the loop, as in the reference (:373-379)."""
@@ -317,3 +338,147 @@ class VarReceiverPosTrainer(Trainer):
         if norm:
             h = h / torch.max(torch.abs(h))
         return out[0], h
+
+
+class GraphedTrainStep:
+    """One optimiser step (collate -> normalize -> forward -> losses -> backward -> [all-reduce] ->
+    Adam) captured into HIP graphs and replayed: ~400 kernel launches per step collapse into one
+    (two with the RCCL all-reduce between them) graph launch, which removes the host launch
+    overhead that dominates the eager step (profiles/).
+
+    Per step the host only writes two static device buffers: the receiver indices of the batch and
+    the EDC time-mask weights (drawn from the CPU generator exactly like the reference,
+    losses.py:221-223, then divided by global-batch x kept-indices).  Requires a trainer built
+    with ``capturable=True`` and a fixed batch size."""
+
+    def __init__(self, trainer: "VarReceiverPosTrainer", dataset, batch_size: int):
+        if not trainer.capturable:
+            raise ValueError("build the trainer with capturable=True to replay steps from a graph")
+        self.tr, self.ds, self.B = trainer, dataset, batch_size
+        dev = dataset.device
+        K = dataset.rir_mag_response.shape[-1]
+        self.start, self.length = trainer._decay_window(K)
+        self.gb = batch_size * trainer.world_size
+        # replayed launches read the targets through the static index buffer: they must come from
+        # the dataset-level store (a by-pointer cache would go stale under replay)
+        if (dataset.edr_store is None or dataset.edc_store is None
+                or dataset.edr_store[0] != trainer.stft_win
+                or dataset.edc_store[0] != (self.start, self.length)):
+            dataset.precompute_decay_targets(trainer.stft_win, self.start, self.length)
+        self.idx = torch.zeros(batch_size, dtype=torch.long, device=dev)
+        self.maskw = torch.full((self.length,), 1.0 / (self.gb * self.length), dtype=torch.float32,
+                                device=dev)
+        self._host_mask = torch.empty(self.length, dtype=torch.float32).pin_memory()
+        self._host_idx = torch.empty(batch_size, dtype=torch.long).pin_memory()
+        self.graph_a = self.graph_b = None
+        self.losses = None
+
+    # -- pieces -------------------------------------------------------------------------------
+    def _fwd_bwd(self):
+        tr = self.tr
+        batch = self.ds.collate(self.idx, lean=True)
+        tr.normalize(batch)
+        tr.optimizer.zero_grad(set_to_none=True)
+        losses = tr._step_losses(batch, mask_prenorm=self.maskw)
+        losses['_total'].backward()
+        return losses
+
+    def _flatten(self):
+        ar = self.tr._allreduce
+        off = 0
+        for p in ar.params:
+            n = p.numel()
+            ar.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+
+    def _unflatten_and_step(self):
+        ar = self.tr._allreduce
+        if ar is not None:
+            off = 0
+            for p in ar.params:
+                n = p.numel()
+                p.grad.copy_(ar.flat[off:off + n].view_as(p))
+                off += n
+        self.tr.optimizer.step()
+
+    def _eager(self):
+        losses = self._fwd_bwd()
+        if self.tr._allreduce is not None:
+            self._flatten()
+            dist.all_reduce(self.tr._allreduce.flat, group=self.tr.process_group)
+        self._unflatten_and_step()
+        return losses
+
+    # -- capture ------------------------------------------------------------------------------
+    def capture(self, indices):
+        """Warm up (eagerly, on a side stream), restore every parameter / optimizer tensor IN PLACE
+        so that the warm-up leaves no trace, then record the graphs."""
+        tr = self.tr
+        rng_state = torch.get_rng_state()                  # capture is RNG-neutral
+        self._load_inputs(indices)
+        params = [p for p in tr.net.parameters()]
+        saved_p = [p.detach().clone() for p in params]
+        state_tensors = lambda: [t for st in tr.optimizer.state.values() for t in st.values()
+                                 if torch.is_tensor(t)]
+        saved_s = [t.detach().clone() for t in state_tensors()]   # empty for a fresh optimizer
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._eager()
+            # undo the warm-up IN PLACE (the graphs will reference these very tensors)
+            for p, sp in zip(params, saved_p):
+                p.data.copy_(sp)
+            if saved_s:
+                for t, st in zip(state_tensors(), saved_s):
+                    t.copy_(st)
+            else:
+                for t in state_tensors():
+                    t.zero_()                              # fresh Adam state: zeros, step 0
+            tr.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        if tr._allreduce is None:
+            with torch.cuda.graph(self.graph_a):
+                self.losses = self._fwd_bwd()
+                self._unflatten_and_step()
+        else:
+            with torch.cuda.graph(self.graph_a):
+                self.losses = self._fwd_bwd()
+                self._flatten()
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self._unflatten_and_step()
+        self.losses = {k: v for k, v in self.losses.items()}
+        torch.set_rng_state(rng_state)
+        return self
+
+    def _load_inputs(self, indices):
+        tr = self.tr
+        self._host_idx.copy_(torch.as_tensor(list(indices), dtype=torch.long))
+        self.idx.copy_(self._host_idx, non_blocking=True)
+        crit = tr.criterion[1]
+        if crit.use_mask:
+            keep = torch.bernoulli(torch.empty(self.length).uniform_(0, 1))
+            if tr.world_size > 1:
+                # one mask for all ranks: rank 0's draw wins
+                keep = keep.to(self.maskw.device)
+                dist.broadcast(keep, src=0, group=tr.process_group)
+                cnt = keep.sum()
+                self.maskw.copy_(keep / (cnt * self.gb))
+            else:
+                self._host_mask.copy_(keep / (float(keep.sum()) * self.gb))
+                self.maskw.copy_(self._host_mask, non_blocking=True)
+
+    def __call__(self, indices):
+        """Run one optimiser step on the receivers ``indices``; returns the static loss tensors
+        (valid until the next call)."""
+        if self.graph_a is None:
+            self.capture(indices)
+        self._load_inputs(indices)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            dist.all_reduce(self.tr._allreduce.flat, group=self.tr.process_group)
+            self.graph_b.replay()
+        return self.losses
