@@ -46,8 +46,16 @@ WIN = 4096
 HBM_PEAK_GBS = 8000.0
 # compulsory HBM bytes per RIR (fwd + bwd, fp32 / complex64 storage)
 ALG_BYTES_PER_RIR = 2811048
-DOMINANT_KERNEL = None               # set after profiling (profiles/)
-DOMINANT_ALG_BYTES_PER_UNIT = 0
+# Dominant hand-written kernel by total time in profiles/r01_bench_kernel_stats.csv: the row pass of
+# the Bluestein irfft (forward FFT over n2, chirp-spectrum product, inverse FFT over k2).  Its
+# algorithmic bytes per RIR: one read + one write of the L = 2^17 point complex64
+# work row block = 2 * 131072 * 8 B (the chirp spectrum is shared by the batch and L2-resident).
+DOMINANT_KERNEL = 'k_blu_row'
+DOMINANT_ALG_BYTES_PER_UNIT = 2 * 131072 * 8
+# HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_*.csv), or None
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 68290765   # 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, batch 32
+ROOFLINE_EAGER_STEPS = 20
+CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
 
 
 def octave_band_response(centre_hz: float, fs: float, nfft: int, numtaps: int = 2049) -> np.ndarray:
@@ -101,7 +109,7 @@ def cpu_baseline(room, delays, filt_np, steps: int = 2):
     """The same optimiser step on the host cores with the CPU oracle (reference restatement)."""
     from oracle import gfdn_oracle as orc
     from oracle.cpu_trainer import OracleGridTrainer
-    cores = os.cpu_count() or 1
+    cores = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     rng = np.random.RandomState(1)
     idx = rng.permutation(room['rirs'].shape[0])[:BATCH]
@@ -171,7 +179,6 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from diffgfdn_amd import hip_ops
-    hip_ops.kernel_timer.watch = DOMINANT_KERNEL
     room, data, net, trainer, train_idx, filt, delays = build_workload(device, seed=1234,
                                                                       num_receivers=args.receivers)
     # every rank draws its own receivers (different shards of a 32*world global batch)
@@ -195,7 +202,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    hip_ops.kernel_timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         total, parts = one_step()
@@ -204,7 +210,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ktimes = hip_ops.kernel_timer.stop()
+
+    # roofline leg: the graph replays above cannot carry per-kernel events, so the SAME step is run
+    # ROOFLINE_EAGER_STEPS more times with host launches and the dominant kernel bracketed by HIP
+    # events on the launch stream (same kernels, same shapes, same data)
+    ktimes = {}
+    if rank == 0:
+        hip_ops.kernel_timer.watch = DOMINANT_KERNEL
+        hip_ops.kernel_timer.start()
+        for _ in range(ROOFLINE_EAGER_STEPS):
+            sel = train_idx_t[torch.randperm(len(train_idx), generator=gen)[:BATCH]].tolist()
+            batch = data.collate(sel, lean=True)
+            with torch.no_grad():
+                trainer.normalize(batch)
+            lo = trainer._step_losses(batch, mask_prenorm=step.maskw)   # no collectives inside
+            lo['_total'].backward()          # no optimizer step / all-reduce: kernel timing only
+        ktimes = hip_ops.kernel_timer.stop()
+        trainer.optimizer.zero_grad(set_to_none=True)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,7 +255,8 @@ def main():
             units = dom['units_per_launch']
             achieved = units * dom['alg_bytes_per_unit'] / (dom['avg_ms'] * 1e-3) / 1e9
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': dom.get('traffic'),
+                               'frac': achieved / HBM_PEAK_GBS,
+                               'traffic': DOMINANT_TRAFFIC_BYTES_PER_LAUNCH,
                                'kernel': dom['kernel'], 'avg_launch_us': dom['avg_ms'] * 1e3,
                                'launches': dom['launches'],
                                'alg_bytes_per_launch': units * dom['alg_bytes_per_unit']}

@@ -354,7 +354,7 @@ static size_t blu_row_lds(const BluGeom& g) {
 }
 
 static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
-                   int ld_out, void* work, int adjoint, hipStream_t s) {
+                   int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
   BluGeom g = blu_geom(n);
@@ -379,13 +379,25 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if ((rc = ensure_dyn_lds(k_blu_col_fwd, lc))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_row, lr))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_col_inv, lc))) return rc;
-  hipLaunchKernelGGL(k_blu_col_fwd, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_blu_row, dim3(g.L1 / tr, batch), dim3(256), lr, s, a);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_blu_col_inv, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
-  GFDN_LAUNCH_CHECK();
+  if (stages & 1) {
+    hipLaunchKernelGGL(k_blu_col_fwd, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
+    GFDN_LAUNCH_CHECK();
+  }
+  if (stages & 2) {
+    hipLaunchKernelGGL(k_blu_row, dim3(g.L1 / tr, batch), dim3(256), lr, s, a);
+    GFDN_LAUNCH_CHECK();
+  }
+  if (stages & 4) {
+    hipLaunchKernelGGL(k_blu_col_inv, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
+    GFDN_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" int gfdn_irfft_odd_stages(const void* table, int n, const void* in, int ld_in, int batch,
+                                     void* out, int ld_out, void* work, int adjoint, int stages,
+                                     void* stream) {
+  return blu_run(table, n, in, ld_in, batch, out, ld_out, work, adjoint, (hipStream_t)stream, stages);
 }
 
 extern "C" int gfdn_irfft_odd_fwd(const void* table, int n, const float* X, int ldx, int batch,

@@ -212,6 +212,9 @@ def irfft_odd_fwd(X, n: int) -> torch.Tensor:
     table = bluestein_table(n, X.device)
     x = torch.empty((batch, n), dtype=_f32, device=X.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
+    if kernel_timer.active and kernel_timer.watch == 'k_blu_row':
+        _staged_bluestein(lib, table, n, X, ldx, batch, x, n, work, 0)
+        return x
     _lib.check(lib.gfdn_irfft_odd_fwd(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work),
                                       _stream()), "gfdn_irfft_odd_fwd")
     return x
@@ -226,9 +229,23 @@ def irfft_odd_bwd(gx, n: int, ldx: int) -> torch.Tensor:
     table = bluestein_table(n, gx.device)
     gX = torch.empty((batch, ldx), dtype=_c64, device=gx.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), gx.device)
+    if kernel_timer.active and kernel_timer.watch == 'k_blu_row':
+        _staged_bluestein(lib, table, n, gx, gx.shape[1], batch, gX, ldx, work, 1)
+        return gX
     _lib.check(lib.gfdn_irfft_odd_bwd(_p(table), n, _p(gx), gx.shape[1], batch, _p(gX), ldx,
                                       _p(work), _stream()), "gfdn_irfft_odd_bwd")
     return gX
+
+
+def _staged_bluestein(lib, table, n, src, ld_in, batch, dst, ld_out, work, adjoint):
+    """Same three launches as the fused entry point, with HIP events around the row kernel."""
+    args = (_p(table), n, _p(src), ld_in, batch, _p(dst), ld_out, _p(work), adjoint)
+    _lib.check(lib.gfdn_irfft_odd_stages(*args, 1, _stream()), "gfdn_irfft_odd_stages[col]")
+    end = kernel_timer.bracket('k_blu_row', batch)
+    _lib.check(lib.gfdn_irfft_odd_stages(*args, 2, _stream()), "gfdn_irfft_odd_stages[row]")
+    if end is not None:
+        end.record()
+    _lib.check(lib.gfdn_irfft_odd_stages(*args, 4, _stream()), "gfdn_irfft_odd_stages[inv]")
 
 
 def irfft_pow2_fwd(X, n: int) -> torch.Tensor:

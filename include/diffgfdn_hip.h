@@ -124,6 +124,14 @@ int gfdn_irfft_odd_fwd(const void* table, int n, const float* X_c64, int ldx, in
 int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, int ldo, int batch,
                        float* gX_c64, int ldx, void* work, void* stream);
 
+/* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
+ * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so
+ * that one kernel can be bracketed by HIP events on the launch stream (bench.py's roofline leg).
+ * adjoint = 0: in = X (complex), out = x (real); adjoint = 1: in = gx (real), out = gX.     */
+int gfdn_irfft_odd_stages(const void* table, int n, const void* in, int ld_in, int batch,
+                          void* out, int ld_out, void* work, int adjoint, int stages,
+                          void* stream);
+
 /* ---- power-of-two inverse real FFT (utils.py:169 get_response, losses.py:344: default
  * n = 2(K-1)): x = irfft(X[0..n/2], n), n = 2^p >= 16 (imaginary parts of the DC and Nyquist
  * bins are ignored, as torch does), and its adjoint gX = d<gx, x>/dX (bins 0..n/2).
