@@ -266,6 +266,7 @@ def main():
                                                steps=args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0 may still be in its roofline / baseline legs
         dist.destroy_process_group()
 
 

@@ -1,0 +1,250 @@
+// Receiver-position -> group-gain network in two launches, for gfx950.
+//
+// reference: gain_filters.py:497-534 (Gains_from_MLP.forward), dnn.py:89-126 (SinusoidalEncoding),
+// dnn.py:331-400 (MLP = [Linear, LayerNorm, ReLU] x nl, then Linear), dnn.py:21-36 (ScaledSigmoid).
+// The network is tiny (batch 32; 120 -> 16 x 6 -> 4 on the 500 Hz band, at most 120 -> 128 x 4 -> G on the
+// top bands), so on the GPU it is pure launch overhead: ~30 launches forward and ~60 backward in
+// torch.  Here one workgroup per receiver runs the whole stack with the activations in LDS:
+//   forward : encoding (float64 sin/cos of f32(freq*pi)*x, as the reference), layers, sigmoid scaling;
+//             saves xhat (normalised pre-affine activations) and rstd per layer for the backward
+//   backward: per-receiver parameter-gradient partials, summed over receivers by a fixed-order pass
+// Parameters arrive packed in ONE flat float buffer in named_parameters() order:
+//   [W0 (H x in) | b0 | gamma0 | beta0 | W1 (H x H) | b1 | gamma1 | beta1 | ... | Wout (G x H) | bout].
+#include "common.h"
+
+#define MLP_T 256
+#define LN_EPS 1e-5f
+
+struct MlpDims {
+  int B, F, in_dim, H, nl, G;   // F fourier features, in_dim = 6 F, nl = 1 + hidden layers
+  float lo, hi;                 // ScaledSigmoid limits
+};
+
+__device__ __forceinline__ size_t mlp_layer_off(const MlpDims& d, int l) {
+  // offset of W_l in the flat parameter buffer
+  if (l == 0) return 0;
+  size_t first = (size_t)d.H * d.in_dim + 3 * (size_t)d.H;
+  return first + (size_t)(l - 1) * ((size_t)d.H * d.H + 3 * (size_t)d.H);
+}
+__host__ __device__ static inline size_t mlp_param_count(const MlpDims& d) {
+  return (size_t)d.H * d.in_dim + 3 * (size_t)d.H + (size_t)(d.nl - 1) * ((size_t)d.H * d.H + 3 * (size_t)d.H) +
+         (size_t)d.G * d.H + d.G;
+}
+
+extern __shared__ float mlp_lds[];
+
+__device__ __forceinline__ void mlp_encode(const MlpDims& d, const double* __restrict__ pos,
+                                           const float* __restrict__ freq_pi, float* a) {
+  // dnn.py:112-124: per frequency k: [sin(f_k pi x) (3) | cos(f_k pi x) (3)], stored as float32
+  const double* p = pos + (size_t)blockIdx.x * 3;
+  for (int e = threadIdx.x; e < d.in_dim; e += blockDim.x) {
+    const int k = e / 6, r = e - 6 * k;
+    const double arg = (double)freq_pi[k] * p[r % 3];
+    a[e] = (float)(r < 3 ? sin(arg) : cos(arg));
+  }
+}
+
+__global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __restrict__ pos,
+                                                   const float* __restrict__ freq_pi,
+                                                   const float* __restrict__ w,
+                                                   float* __restrict__ gains,     // (B, G)
+                                                   float* __restrict__ xhat,      // (B, nl, H)
+                                                   float* __restrict__ rstd) {    // (B, nl)
+  const int amax = d.in_dim > d.H ? d.in_dim : d.H;
+  float* a = mlp_lds;            // current activations
+  float* h = a + amax;           // pre-norm outputs
+  float* red = h + d.H;          // 16 floats
+  const int b = blockIdx.x, H = d.H;
+  mlp_encode(d, pos, freq_pi, a);
+  __syncthreads();
+  for (int l = 0; l < d.nl; ++l) {
+    const int n_in = l == 0 ? d.in_dim : H;
+    const float* W = w + mlp_layer_off(d, l);
+    const float* bias = W + (size_t)H * n_in;
+    const float* gamma = bias + H;
+    const float* beta = gamma + H;
+    float hv = 0.f;
+    const int j = threadIdx.x;
+    if (j < H) {
+      hv = bias[j];
+      for (int i = 0; i < n_in; ++i) hv += W[(size_t)j * n_in + i] * a[i];
+    }
+    const float mean = block_sum(j < H ? hv : 0.f, red) / (float)H;
+    const float dv = j < H ? hv - mean : 0.f;
+    const float var = block_sum(dv * dv, red) / (float)H;
+    const float rs = rsqrtf(var + LN_EPS);
+    __syncthreads();
+    if (j < H) {
+      const float xh = dv * rs;
+      xhat[((size_t)b * d.nl + l) * H + j] = xh;
+      a[j] = fmaxf(xh * gamma[j] + beta[j], 0.f);
+    }
+    if (j == 0) rstd[(size_t)b * d.nl + l] = rs;
+    __syncthreads();
+  }
+  const float* Wout = w + mlp_layer_off(d, d.nl);
+  const float* bout = Wout + (size_t)d.G * H;
+  for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
+    float raw = bout[g];
+    for (int i = 0; i < H; ++i) raw += Wout[(size_t)g * H + i] * a[i];
+    gains[(size_t)b * d.G + g] = d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw)));
+  }
+}
+
+__global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __restrict__ pos,
+                                                   const float* __restrict__ freq_pi,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ gains,
+                                                   const float* __restrict__ xhat,
+                                                   const float* __restrict__ rstd,
+                                                   const float* __restrict__ ggains,   // (B, G)
+                                                   float* __restrict__ partial) {      // (B, P)
+  const int amax = d.in_dim > d.H ? d.in_dim : d.H;
+  float* aprev = mlp_lds;        // activations entering the current layer
+  float* da = aprev + amax;      // gradient w.r.t. the current layer's output (H)
+  float* dh = da + d.H;          // gradient w.r.t. the linear output (H)
+  float* draw = dh + d.H;        // (G)
+  float* red = draw + d.G;       // 16
+  const int b = blockIdx.x, H = d.H, G = d.G;
+  const size_t P = mlp_param_count(d);
+  float* gp = partial + (size_t)b * P;
+  // output layer
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    const float sg = (gains[(size_t)b * G + g] - d.lo) / (d.hi - d.lo);
+    draw[g] = ggains[(size_t)b * G + g] * (d.hi - d.lo) * sg * (1.0f - sg);
+  }
+  {
+    const int l = d.nl - 1;
+    const float* W = w + mlp_layer_off(d, l);
+    const int n_in = l == 0 ? d.in_dim : H;
+    const float* gamma = W + (size_t)H * n_in + H;
+    const float* beta = gamma + H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x)
+      aprev[i] = fmaxf(xhat[((size_t)b * d.nl + l) * H + i] * gamma[i] + beta[i], 0.f);
+  }
+  __syncthreads();
+  const size_t offOut = mlp_layer_off(d, d.nl);
+  const float* Wout = w + offOut;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) {
+      gp[offOut + (size_t)g * H + i] = draw[g] * aprev[i];
+      acc += Wout[(size_t)g * H + i] * draw[g];
+    }
+    da[i] = acc;
+  }
+  for (int g = threadIdx.x; g < G; g += blockDim.x) gp[offOut + (size_t)G * H + g] = draw[g];
+  __syncthreads();
+  // hidden blocks, last to first
+  for (int l = d.nl - 1; l >= 0; --l) {
+    const int n_in = l == 0 ? d.in_dim : H;
+    const size_t offW = mlp_layer_off(d, l);
+    const float* W = w + offW;
+    const float* gamma = W + (size_t)H * n_in + H;
+    const float* beta = gamma + H;
+    const size_t offb = offW + (size_t)H * n_in, offg = offb + H, offbeta = offg + H;
+    const int j = threadIdx.x;
+    float xh = 0.f, dxh = 0.f;
+    if (j < H) {
+      xh = xhat[((size_t)b * d.nl + l) * H + j];
+      const float y = xh * gamma[j] + beta[j];
+      const float dy = y > 0.f ? da[j] : 0.f;
+      gp[offg + j] = dy * xh;
+      gp[offbeta + j] = dy;
+      dxh = dy * gamma[j];
+    }
+    const float m1 = block_sum(dxh, red) / (float)H;
+    const float m2 = block_sum(dxh * xh, red) / (float)H;
+    const float rs = rstd[(size_t)b * d.nl + l];
+    __syncthreads();
+    if (j < H) {
+      const float v = rs * (dxh - m1 - xh * m2);
+      dh[j] = v;
+      gp[offb + j] = v;
+    }
+    // activations that entered this layer
+    if (l == 0) {
+      mlp_encode(d, pos, freq_pi, aprev);
+    } else {
+      const float* Wp = w + mlp_layer_off(d, l - 1);
+      const int n_in_p = (l - 1) == 0 ? d.in_dim : H;
+      const float* gam_p = Wp + (size_t)H * n_in_p + H;
+      const float* bet_p = gam_p + H;
+      for (int i = threadIdx.x; i < H; i += blockDim.x)
+        aprev[i] = fmaxf(xhat[((size_t)b * d.nl + (l - 1)) * H + i] * gam_p[i] + bet_p[i], 0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
+      const float ai = aprev[i];
+      float acc = 0.f;
+      for (int jj = 0; jj < H; ++jj) {
+        const float v = dh[jj];
+        gp[offW + (size_t)jj * n_in + i] = v * ai;      // coalesced over i
+        acc += W[(size_t)jj * n_in + i] * v;
+      }
+      if (l > 0) da[i] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// gflat[p] = sum_b partial[b][p]
+__global__ void k_mlp_reduce(const float* __restrict__ partial, int B, size_t P,
+                             float* __restrict__ gflat) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += partial[(size_t)b * P + p];
+  gflat[p] = s;
+}
+
+static int mlp_dims(int B, int F, int H, int n_hidden, int G, float lo, float hi, MlpDims* d) {
+  if (B <= 0 || F <= 0 || H <= 0 || n_hidden < 0 || G <= 0) return GFDN_E_BADARG;
+  if (H > MLP_T || G > MLP_T || 6 * F > 4096) return GFDN_E_UNSUPPORTED;
+  d->B = B; d->F = F; d->in_dim = 6 * F; d->H = H; d->nl = 1 + n_hidden; d->G = G; d->lo = lo; d->hi = hi;
+  return 0;
+}
+static size_t mlp_lds_bytes(const MlpDims& d) {
+  const int amax = d.in_dim > d.H ? d.in_dim : d.H;
+  return ((size_t)amax + 2 * (size_t)d.H + d.G + 16) * sizeof(float);
+}
+
+extern "C" size_t gfdn_mlp_param_count(int F, int H, int n_hidden, int G) {
+  MlpDims d;
+  if (mlp_dims(1, F, H, n_hidden, G, -1.f, 1.f, &d)) return 0;
+  return mlp_param_count(d);
+}
+extern "C" size_t gfdn_mlp_bwd_work_bytes(int B, int F, int H, int n_hidden, int G) {
+  return (size_t)B * gfdn_mlp_param_count(F, H, n_hidden, G) * sizeof(float);
+}
+
+extern "C" int gfdn_mlp_gains_fwd(const double* pos, const float* freq_pi, const float* w, int B,
+                                  int F, int H, int n_hidden, int G, float lo, float hi, float* gains,
+                                  float* xhat, float* rstd, void* stream) {
+  MlpDims d;
+  int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
+  if (rc) return rc;
+  if (!pos || !freq_pi || !w || !gains || !xhat || !rstd) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_mlp_fwd, dim3(B), dim3(MLP_T), mlp_lds_bytes(d), (hipStream_t)stream, d, pos,
+                     freq_pi, w, gains, xhat, rstd);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_mlp_gains_bwd(const double* pos, const float* freq_pi, const float* w, int B,
+                                  int F, int H, int n_hidden, int G, float lo, float hi,
+                                  const float* gains, const float* xhat, const float* rstd,
+                                  const float* ggains, float* gw, void* work, void* stream) {
+  MlpDims d;
+  int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
+  if (rc) return rc;
+  if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mlp_bwd, dim3(B), dim3(MLP_T), mlp_lds_bytes(d), s, d, pos, freq_pi, w, gains, xhat,
+                     rstd, ggains, (float*)work);
+  GFDN_LAUNCH_CHECK();
+  const size_t P = mlp_param_count(d);
+  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (const float*)work, B, P, gw);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -653,16 +653,17 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
 // ------------------------------------------------------------------------------------------
 // colorless statistics of the sub-FDN responses
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_spectral_stats(const float2* __restrict__ S, int G, int K,
-                                                         int asym, float scale,
-                                                         float* __restrict__ energy,
-                                                         float* __restrict__ loss,
-                                                         float2* __restrict__ gS) {
+#define SPEC_CHUNK 2048
+// grid (chunks, G): partial[(g*2 + {0: energy, 1: loss}) * nchunk + chunk]
+__global__ __launch_bounds__(256) void k_spectral_stats(const float2* __restrict__ S, int G, int K,
+                                                        int asym, float scale,
+                                                        float* __restrict__ partial,
+                                                        float2* __restrict__ gS) {
   __shared__ float s_red[16];
-  const int g = blockIdx.x;
+  const int g = blockIdx.y, k0 = blockIdx.x * SPEC_CHUNK, nchunk = gridDim.x;
   const float invK = 1.0f / (float)K;
   float e = 0.f, l = 0.f;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+  for (int k = k0 + threadIdx.x; k < k0 + SPEC_CHUNK && k < K; k += 256) {
     float2 s = S[(size_t)g * K + k];
     float p = s.x * s.x + s.y * s.y;
     float mag = sqrtf(p);
@@ -680,16 +681,39 @@ __global__ __launch_bounds__(1024) void k_spectral_stats(const float2* __restric
   e = block_sum(e, s_red);
   l = block_sum(l, s_red);
   if (threadIdx.x == 0) {
-    energy[g] = e * invK;
-    loss[g] = l * invK;
+    partial[(size_t)(g * 2 + 0) * nchunk + blockIdx.x] = e * invK;
+    partial[(size_t)(g * 2 + 1) * nchunk + blockIdx.x] = l * invK;
+  }
+}
+// rows (g, {energy, loss}) -> energy[g], loss[g]
+__global__ __launch_bounds__(64) void k_spectral_finish(const float* __restrict__ partial, int nchunk,
+                                                        float* __restrict__ energy,
+                                                        float* __restrict__ loss) {
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 64) s += partial[(size_t)r * nchunk + c];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    if (r & 1) loss[r >> 1] = s;
+    else energy[r >> 1] = s;
   }
 }
 
+extern "C" size_t gfdn_spectral_stats_work_bytes(int G, int K) {
+  return (size_t)2 * G * ((K + SPEC_CHUNK - 1) / SPEC_CHUNK) * sizeof(float);
+}
+
 extern "C" int gfdn_spectral_stats(const float* S, int G, int K, int asym, float scale,
-                                   float* energy, float* loss, float* gS, void* stream) {
-  if (!S || !energy || !loss || G <= 0 || K <= 0) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_spectral_stats, dim3(G), dim3(1024), 0, (hipStream_t)stream,
-                     (const float2*)S, G, K, asym, scale, energy, loss, (float2*)gS);
+                                   float* energy, float* loss, float* gS, void* work,
+                                   void* stream) {
+  if (!S || !energy || !loss || !work || G <= 0 || K <= 0) return GFDN_E_BADARG;
+  const int nchunk = (K + SPEC_CHUNK - 1) / SPEC_CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_spectral_stats, dim3(nchunk, G), dim3(256), 0, s, (const float2*)S, G, K, asym,
+                     scale, (float*)work, (float2*)gS);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_spectral_finish, dim3(2 * G), dim3(64), 0, s, (const float*)work, nchunk, energy,
+                     loss);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -54,6 +54,36 @@ class OrthoParam(torch.autograd.Function):
         return ops.ortho_bwd(M, gQ.contiguous(), gQQ.contiguous()).to(M.dtype)
 
 
+class MlpGains(torch.autograd.Function):
+    """gains (B, G) = ScaledSigmoid(MLP(SinusoidalEncoding(pos)))  (gain_filters.py:497-524) in one
+    launch; parameters are passed as separate tensors (autograd hands each its gradient) and packed
+    into one flat buffer with a single cat."""
+
+    @staticmethod
+    def forward(ctx, pos, freq_pi, H, n_hidden, G, lo, hi, *params):
+        w = torch.cat([p.reshape(-1) for p in params])
+        gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, n_hidden, G, lo, hi)
+        ctx.save_for_backward(pos, freq_pi, w, gains, xhat, rstd)
+        ctx.cfg = (H, n_hidden, G, lo, hi)
+        ctx.shapes = [p.shape for p in params]
+        return gains
+
+    @staticmethod
+    def backward(ctx, ggains):
+        pos, freq_pi, w, gains, xhat, rstd = ctx.saved_tensors
+        H, n_hidden, G, lo, hi = ctx.cfg
+        gw = ops.mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd,
+                               ggains.contiguous())
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for v in shp:
+                n *= v
+            grads.append(gw[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, None, None, None) + tuple(grads)
+
+
 class ResolventSolve(torch.autograd.Function):
     """Y[k] = (diag(z_k^m inv_gamma) - A)^{-1} b   (A^T when transpose)."""
 

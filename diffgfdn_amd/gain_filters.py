@@ -2,6 +2,7 @@
 src/spatial_sampling/model.py:17-190).  Small MLPs on PyTorch; what they feed -- the output
 stage over K bins -- runs in the HIP kernels and takes the (B, G) gains directly instead of the
 reference's (B, N, K) repeated tensor."""
+import math
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -33,11 +34,33 @@ class Gains_from_MLP(nn.Module):
                        num_biquads_in_cascade=1, num_params=1)
         lo, hi = (-1.0, 1.0) if gain_limits is None else gain_limits
         self.scaled_sigmoid = ScaledSigmoid(lower_limit=lo, upper_limit=hi)
+        self._freq_pi = None
+
+    def _fused_ok(self, position: torch.Tensor) -> bool:
+        lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
+        H = lin[0].out_features
+        return (position.is_cuda and position.shape[-1] == 3 and lin[0].weight.is_cuda
+                and lin[0].weight.dtype == torch.float32 and H <= 256 and self.num_groups <= 256
+                and all(m.out_features == H for m in lin[:-1]))
 
     def group_gains(self, x: Dict) -> torch.Tensor:
-        """(B, G) gains -- what the HIP output stage consumes."""
+        """(B, G) gains -- what the HIP output stage consumes.  On the GPU the encoding, the MLP and
+        the sigmoid run as one fused kernel (csrc/mlp.hip); the torch modules below are the same
+        network (their parameters ARE the kernel's weights) and serve as the CPU / odd-shape path."""
         position = x['norm_listener_position'] if self.position_type == "output_gains" \
             else x['source_position']
+        if self._fused_ok(position):
+            from .functional import MlpGains
+            lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
+            if self._freq_pi is None or self._freq_pi.device != position.device:
+                n = self.encoder.num_fourier_features
+                f = torch.exp(torch.linspace(math.log(1.0), math.log(32.0), n, device=position.device))
+                self._freq_pi = (f * math.pi).contiguous()
+            params = [p for m in self.mlp.model for p in m.parameters()]
+            self.gains = MlpGains.apply(position, self._freq_pi, lin[0].out_features, len(lin) - 2,
+                                        self.num_groups, self.scaled_sigmoid.lower_limit,
+                                        self.scaled_sigmoid.upper_limit, *params)
+            return self.gains
         w = self.mlp.model[0].weight
         enc = self.encoder(position.to(w.device))
         raw = self.mlp(enc.to(w.dtype))

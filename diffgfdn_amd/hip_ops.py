@@ -179,8 +179,10 @@ def spectral_stats(S, asym: bool, scale: float = 1.0, want_grad: bool = True):
     energy = torch.empty(G, dtype=_f32, device=S.device)
     loss = torch.empty(G, dtype=_f32, device=S.device)
     gS = torch.empty_like(S) if want_grad else None
-    _lib.check(_lib.load().gfdn_spectral_stats(_p(S), G, K, int(asym), float(scale), _p(energy),
-                                               _p(loss), _p(gS), _stream()), "gfdn_spectral_stats")
+    lib = _lib.load()
+    work = _work(lib.gfdn_spectral_stats_work_bytes(G, K), S.device)
+    _lib.check(lib.gfdn_spectral_stats(_p(S), G, K, int(asym), float(scale), _p(energy), _p(loss),
+                                       _p(gS), _p(work), _stream()), "gfdn_spectral_stats")
     return energy, loss, gS
 
 
@@ -354,6 +356,47 @@ def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.
                                          float(inv_count), float(gscale), _p(loss_item), _p(gx),
                                          _stream()), "gfdn_edc_loss")
     return loss_item, gx
+
+
+def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float):
+    """pos (B,3) f64, freq_pi (F,) f32, w packed params -> gains (B,G), xhat (B,nl,H), rstd (B,nl)."""
+    _need_gpu(pos, w)
+    pos = pos.detach().to(torch.float64).contiguous()
+    w = _f(w)
+    B, F = pos.shape[0], freq_pi.numel()
+    lib = _lib.load()
+    if w.numel() != lib.gfdn_mlp_param_count(F, H, n_hidden, G):
+        raise RuntimeError("mlp_gains: packed parameter count does not match the layer sizes")
+    nl = 1 + n_hidden
+    gains = torch.empty((B, G), dtype=_f32, device=pos.device)
+    xhat = torch.empty((B, nl, H), dtype=_f32, device=pos.device)
+    rstd = torch.empty((B, nl), dtype=_f32, device=pos.device)
+    _lib.check(lib.gfdn_mlp_gains_fwd(_p(pos), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
+                                      float(hi), _p(gains), _p(xhat), _p(rstd), _stream()),
+               "gfdn_mlp_gains_fwd")
+    return gains, xhat, rstd
+
+
+def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains):
+    _need_gpu(pos, w, ggains)
+    pos = pos.detach().to(torch.float64).contiguous()
+    w, ggains = _f(w), _f(ggains)
+    B, F = pos.shape[0], freq_pi.numel()
+    lib = _lib.load()
+    gw = torch.empty_like(w)
+    work = _work(lib.gfdn_mlp_bwd_work_bytes(B, F, H, n_hidden, G), pos.device)
+    _lib.check(lib.gfdn_mlp_gains_bwd(_p(pos), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
+                                      float(hi), _p(gains), _p(xhat), _p(rstd), _p(ggains), _p(gw),
+                                      _p(work), _stream()), "gfdn_mlp_gains_bwd")
+    return gw
+
+
+def adam_step(p, g, m, v, seg, lr_seg, step_count, beta1, beta2, eps):
+    """In-place fused Adam update of the flat buffers (all float32 on the GPU; seg uint8)."""
+    _need_gpu(p, g)
+    _lib.check(_lib.load().gfdn_adam_step(_p(p), _p(g), _p(m), _p(v), _p(seg), _p(lr_seg),
+                                          _p(step_count), p.numel(), float(beta1), float(beta2),
+                                          float(eps), _stream()), "gfdn_adam_step")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ from .functional import OutputStage, irfft_like_torch
 from .hip_ops import spectral_stats
 from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
 from .model import DiffGFDN
+from .optim import FlatAdam
 
 
 @torch.no_grad()
@@ -135,8 +136,14 @@ class Trainer:
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        self._allreduce = (FlatGradAllReduce(net.parameters(), process_group)
-                           if self.world_size > 1 else None)
+        self._allreduce = None
+        if self.world_size > 1:
+            if isinstance(self.optimizer, FlatAdam):
+                opt, pg = self.optimizer, process_group
+                # grads are packed into the flat buffer by the caller (inside the captured graph)
+                self._allreduce = lambda: dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=pg)
+            else:
+                self._allreduce = FlatGradAllReduce(net.parameters(), process_group)
 
     # reference :152-228
     def init_scheduler(self, cfg: TrainerConfig):
@@ -156,13 +163,9 @@ class Trainer:
         if other:
             groups.append({'params': other, 'lr': cfg.lr})
         if self.capturable:
-            # device-resident step counters and learning rates: the update can be replayed from a
-            # HIP graph, and StepLR rewrites the lr tensors in place
-            groups = [g for g in groups if g['params']]
-            dev = groups[0]['params'][0].device
-            for g in groups:
-                g['lr'] = torch.tensor(float(g['lr']), device=dev)
-            self.optimizer = torch.optim.Adam(groups, capturable=True, foreach=True)
+            # flat-buffer fused Adam (csrc/optim.hip): step counter and learning rates live on the
+            # device, so the update replays from a HIP graph; same maths as torch.optim.Adam
+            self.optimizer = FlatAdam([g for g in groups if g['params']])
         else:
             self.optimizer = torch.optim.Adam(groups)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=10, gamma=0.1)
@@ -281,6 +284,8 @@ class VarReceiverPosTrainer(Trainer):
         total = losses.pop('_total')
         total.backward()
         if self._allreduce is not None:
+            if isinstance(self.optimizer, FlatAdam):
+                self.optimizer.pack_grads()
             self._allreduce()
         self.optimizer.step()
         return sum(losses.values()), losses
@@ -309,6 +314,8 @@ class VarReceiverPosTrainer(Trainer):
                 for k, v in cur.items():
                     agg_v[k] = agg_v.get(k, 0.0) + v.detach()
             self.scheduler.step()
+            if isinstance(self.optimizer, FlatAdam):
+                self.optimizer.sync_lr()
             nt, nv = max(len(train_dataset), 1), max(len(valid_dataset), 1)
             agg_t = {k: float(v) / nt for k, v in agg_t.items()}     # one sync per epoch
             agg_v = {k: float(v) / nv for k, v in agg_v.items()}
@@ -343,7 +350,7 @@ class VarReceiverPosTrainer(Trainer):
 class GraphedTrainStep:
     """One optimiser step (collate -> normalize -> forward -> losses -> backward -> [all-reduce] ->
     Adam) captured into HIP graphs and replayed: ~400 kernel launches per step collapse into one
-    (two with the RCCL all-reduce between them) graph launch, which removes the host launch
+    (two with the RCCL all-reduce of the flat gradient buffer between them) graph launch, which removes the host launch
     overhead that dominates the eager step (profiles/).
 
     Per step the host only writes two static device buffers: the receiver indices of the batch and
@@ -383,30 +390,12 @@ class GraphedTrainStep:
         losses['_total'].backward()
         return losses
 
-    def _flatten(self):
-        ar = self.tr._allreduce
-        off = 0
-        for p in ar.params:
-            n = p.numel()
-            ar.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-
-    def _unflatten_and_step(self):
-        ar = self.tr._allreduce
-        if ar is not None:
-            off = 0
-            for p in ar.params:
-                n = p.numel()
-                p.grad.copy_(ar.flat[off:off + n].view_as(p))
-                off += n
-        self.tr.optimizer.step()
-
     def _eager(self):
         losses = self._fwd_bwd()
+        self.tr.optimizer.pack_grads()
         if self.tr._allreduce is not None:
-            self._flatten()
-            dist.all_reduce(self.tr._allreduce.flat, group=self.tr.process_group)
-        self._unflatten_and_step()
+            self.tr._allreduce()
+        self.tr.optimizer.step()
         return losses
 
     # -- capture ------------------------------------------------------------------------------
@@ -418,8 +407,7 @@ class GraphedTrainStep:
         self._load_inputs(indices)
         params = [p for p in tr.net.parameters()]
         saved_p = [p.detach().clone() for p in params]
-        state_tensors = lambda: [t for st in tr.optimizer.state.values() for t in st.values()
-                                 if torch.is_tensor(t)]
+        state_tensors = tr.optimizer.state_tensors
         saved_s = [t.detach().clone() for t in state_tensors()]   # empty for a fresh optimizer
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -442,14 +430,16 @@ class GraphedTrainStep:
         if tr._allreduce is None:
             with torch.cuda.graph(self.graph_a):
                 self.losses = self._fwd_bwd()
-                self._unflatten_and_step()
+                tr.optimizer.pack_grads()
+                tr.optimizer.step()
         else:
+            # forward + backward + pack | all-reduce of the flat gradient buffer (eager RCCL) | Adam
             with torch.cuda.graph(self.graph_a):
                 self.losses = self._fwd_bwd()
-                self._flatten()
+                tr.optimizer.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-                self._unflatten_and_step()
+                tr.optimizer.step()
         self.losses = {k: v for k, v in self.losses.items()}
         torch.set_rng_state(rng_state)
         return self
@@ -479,6 +469,6 @@ class GraphedTrainStep:
         self._load_inputs(indices)
         self.graph_a.replay()
         if self.graph_b is not None:
-            dist.all_reduce(self.tr._allreduce.flat, group=self.tr.process_group)
+            self.tr._allreduce()
             self.graph_b.replay()
         return self.losses

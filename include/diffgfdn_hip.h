@@ -105,8 +105,9 @@ int gfdn_compose_sh_bwd(const float* Y_c64, int K, int G, int nper, const float*
  * trainer.py:323-324).  S (G, K) complex64.  Per group g:
  *   energy[g] = mean_k |S|^2 ;  loss[g] = mean_k (|S|-1)^p, p = 2, or (asym) 4 where |S|-1 > 1.
  * gS (G, K) complex64 = scale * dloss[g]/dS, or NULL.                                     */
+size_t gfdn_spectral_stats_work_bytes(int G, int K);
 int gfdn_spectral_stats(const float* S_c64, int G, int K, int asym, float scale,
-                        float* energy, float* loss, float* gS_c64, void* stream);
+                        float* energy, float* loss, float* gS_c64, void* work, void* stream);
 
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's
@@ -173,6 +174,31 @@ int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float
 int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const float* T_db,
                   const float* maskw, float inv_count, float gscale, float* loss_item,
                   float* gx, void* stream);
+
+/* ---- receiver-position -> group-gain network  (gain_filters.py:497-534; dnn.py:89-126, :331-400,
+ * :21-36).  pos (B,3) float64 normalised coordinates; freq_pi (F) float32 = f32(freq_k * pi);
+ * w: all parameters packed in named_parameters() order
+ *   [W0 (H x 6F) | b0 | gamma0 | beta0 | W1 (H x H) | b1 | gamma1 | beta1 | ... | Wout (G x H) | bout];
+ * gains (B,G) = lo + (hi-lo) sigmoid(MLP(encoding(pos))).  xhat (B, 1+n_hidden, H) and rstd
+ * (B, 1+n_hidden) are saved for the backward, which returns gw (same packing as w).        */
+size_t gfdn_mlp_param_count(int F, int H, int n_hidden, int G);
+size_t gfdn_mlp_bwd_work_bytes(int B, int F, int H, int n_hidden, int G);
+int gfdn_mlp_gains_fwd(const double* pos, const float* freq_pi, const float* w, int B, int F, int H,
+                       int n_hidden, int G, float lo, float hi, float* gains, float* xhat,
+                       float* rstd, void* stream);
+int gfdn_mlp_gains_bwd(const double* pos, const float* freq_pi, const float* w, int B, int F, int H,
+                       int n_hidden, int G, float lo, float hi, const float* gains,
+                       const float* xhat, const float* rstd, const float* ggains, float* gw,
+                       void* work, void* stream);
+
+/* ---- optimiser step  (trainer.py:152-228, :475: torch.optim.Adam with per-name lr groups) ----------
+ * All parameters are views into one flat fp32 buffer p (n floats), gradients into g, Adam moments
+ * into m, v.  seg[i] (uint8) = learning-rate group of element i, lr_seg[group] the group's lr (device,
+ * so that StepLR edits it without re-recording a HIP graph), step_count (device float) the number of
+ * updates done so far -- advanced by one by this call.                                          */
+int gfdn_adam_step(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                   const float* lr_seg, float* step_count, int n, float beta1, float beta2,
+                   float eps, void* stream);
 
 #ifdef __cplusplus
 }

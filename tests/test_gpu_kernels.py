@@ -255,3 +255,31 @@ def test_edc_loss_kernels(ops, masked):
     num = (gx.cpu().double() - xa.grad).abs().sum() / xa.grad.abs().sum()
     assert num < 1e-3
     assert float(gx[:, :start].abs().max()) == 0.0 and float(gx[:, start + length:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,F,H,n_hidden,G", [(32, 20, 16, 5, 4), (5, 4, 16, 2, 3), (7, 10, 128, 3, 3), (3, 20, 8, 1, 2)])
+def test_mlp_gains_fused(ops, B, F, H, n_hidden, G):
+    """Fused encoding + MLP + sigmoid kernel vs the torch modules (same parameters), fwd + bwd."""
+    from diffgfdn_amd.gain_filters import Gains_from_MLP
+    torch.manual_seed(B + H)
+    mod = Gains_from_MLP(G, 4, F, n_hidden, H)
+    for m in mod.mlp.model:                      # non-trivial LayerNorm affine and biases
+        if isinstance(m, (torch.nn.LayerNorm, torch.nn.Linear)):
+            with torch.no_grad():
+                m.bias.add_(0.1 * torch.randn_like(m.bias))
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.add_(0.2 * torch.randn_like(m.weight))
+    pos = torch.rand(B, 3, dtype=torch.float64)
+    x = {"norm_listener_position": pos, "z_values": torch.zeros(4)}
+    g_ref = mod.group_gains(x)                   # CPU torch path
+    gg = torch.randn(B, G)
+    (g_ref * gg).sum().backward()
+    ref_grads = [p.grad.clone() for p in mod.parameters()]
+    mod.zero_grad()
+    mod = mod.to(DEV)
+    xg = {"norm_listener_position": pos.to(DEV), "z_values": torch.zeros(4, device=DEV)}
+    g = mod.group_gains(xg)                      # fused HIP path
+    assert rel_err(g.detach().cpu(), g_ref.detach()) < 2e-5
+    (g * gg.to(DEV)).sum().backward()
+    for p, r in zip(mod.parameters(), ref_grads):
+        assert rel_err(p.grad.cpu(), r) < 2e-4
