@@ -126,74 +126,102 @@ extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs, 
 }
 
 // ------------------------------------------------------------------------------------------
-// EDC: one 1024-thread block per item; tiles of 4096 samples, 4 contiguous samples per thread
+// EDC: one 1024-thread block per item.  Every iteration covers EDC_S striped sub-tiles of 4096 samples:
+// thread t owns samples [s*4096 + 4t, +4) of each sub-tile s, so every load is a coalesced 16 B per lane
+// and all EDC_S loads of a thread are in flight together (the kernel is latency-, not bandwidth-bound);
+// the EDC_S block scans run side by side through one pair of barriers.
 // ------------------------------------------------------------------------------------------
 #define EDC_THREADS 1024
 #define EDC_V 4
-#define EDC_TILE (EDC_THREADS * EDC_V)
+#define EDC_S 4
+#define EDC_SUB (EDC_THREADS * EDC_V)
+#define EDC_TILE (EDC_SUB * EDC_S)
 
-// inclusive scan over the block of one value per thread, in thread order; returns the
-// inclusive prefix for this thread and the block total through *total.
-__device__ __forceinline__ float block_scan_incl(float v, float* lds /* >= 32 floats */,
-                                                 float* total) {
+// EDC_S simultaneous inclusive block scans (thread order); v[s] -> inclusive prefix, tot[s] = block total
+__device__ __forceinline__ void block_scan_multi(float (&v)[EDC_S], float (&tot)[EDC_S],
+                                                 float* lds /* >= 16*EDC_S floats */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    float o = __shfl_up(v, off, 64);
-    if (lane >= off) v += o;
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      float o = __shfl_up(v[s], off, 64);
+      if (lane >= off) v[s] += o;
+    }
   }
   __syncthreads();
-  if (lane == 63) lds[w] = v;
+  if (lane == 63) {
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) lds[s * 16 + w] = v[s];
+  }
   __syncthreads();
-  float pre = 0.f, tot = 0.f;
   const int nw = blockDim.x >> 6;
-  for (int i = 0; i < nw; ++i) {
-    float t = lds[i];
-    if (i < w) pre += t;
-    tot += t;
+#pragma unroll
+  for (int s = 0; s < EDC_S; ++s) {
+    float pre = 0.f, t = 0.f;
+    for (int i = 0; i < nw; ++i) {
+      float q = lds[s * 16 + i];
+      if (i < w) pre += q;
+      t += q;
+    }
+    v[s] += pre;
+    tot[s] = t;
   }
-  *total = tot;
-  return v + pre;
 }
 
-// suffix sums of x^2 over [start, start+len): processes tiles from the END; calls
-// fn(i, edc_i, x_i) for every index in the window.
-template <typename F>
-__device__ __forceinline__ void edc_suffix(const float* __restrict__ xw, int len, float* lds, F fn) {
+// running sums of f(j) over j = 0..len-1 in index order; calls fn(j, inclusive_sum_j, value_j).
+// get(j) returns the value at position j (callers map j to memory: reversed for the suffix sum).
+template <typename G, typename F>
+__device__ __forceinline__ void edc_scan(int len, float* lds, G get, F fn) {
   float carry = 0.f;
   const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
   for (int tile = 0; tile < ntiles; ++tile) {
-    // reversed coordinate j = len-1-i ; thread handles j0..j0+3
-    const int j0 = tile * EDC_TILE + threadIdx.x * EDC_V;
-    float v[EDC_V], xv[EDC_V];
-    float loc = 0.f;
+    float val[EDC_S][EDC_V], pre[EDC_S][EDC_V], loc[EDC_S], tot[EDC_S];
 #pragma unroll
-    for (int u = 0; u < EDC_V; ++u) {
-      const int j = j0 + u;
-      xv[u] = (j < len) ? xw[len - 1 - j] : 0.f;
-      loc += xv[u] * xv[u];
-      v[u] = loc;
-    }
-    float tot;
-    const float incl = block_scan_incl(loc, lds, &tot);
-    const float excl = incl - loc + carry;
+    for (int s = 0; s < EDC_S; ++s) {
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      float run = 0.f;
 #pragma unroll
-    for (int u = 0; u < EDC_V; ++u) {
-      const int j = j0 + u;
-      if (j < len) fn(len - 1 - j, excl + v[u], xv[u]);
+      for (int u = 0; u < EDC_V; ++u) {
+        const int j = j0 + u;
+        val[s][u] = (j < len) ? get(j) : 0.f;
+        run += val[s][u];
+        pre[s][u] = run;
+      }
+      loc[s] = run;
     }
-    carry += tot;
+    float incl[EDC_S];
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) incl[s] = loc[s];
+    block_scan_multi(incl, tot, lds);
+    float base = carry;
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const float excl = base + incl[s] - loc[s];
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+#pragma unroll
+      for (int u = 0; u < EDC_V; ++u) {
+        const int j = j0 + u;
+        if (j < len) fn(j, excl + pre[s][u], val[s][u]);
+      }
+      base += tot[s];
+    }
+    carry = base;
+    __syncthreads();     // lds is reused by the next iteration
   }
 }
 
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_target(const float* __restrict__ x, int ld,
                                                             int start, int len,
                                                             float* __restrict__ Tdb) {
-  __shared__ float s_scan[32];
+  __shared__ float s_scan[16 * EDC_S];
   const int b = blockIdx.x;
   const float* xw = x + (size_t)b * ld + start;
   float* t = Tdb + (size_t)b * len;
-  edc_suffix(xw, len, s_scan, [&](int i, float edc, float) { t[i] = db_pow(edc); });
+  // suffix sums of x^2: scan the reversed sequence j -> i = len-1-j
+  edc_scan(len, s_scan,
+           [&](int j) { const float v = xw[len - 1 - j]; return v * v; },
+           [&](int j, float edc, float) { t[len - 1 - j] = db_pow(edc); });
 }
 
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_loss(const float* __restrict__ x, int ld,
@@ -203,53 +231,37 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_loss(const float* __restric
                                                           float inv_count, float gscale,
                                                           float* __restrict__ loss_item,
                                                           float* __restrict__ gx) {
-  __shared__ float s_scan[32];
+  __shared__ float s_scan[16 * EDC_S];
   __shared__ float s_red[16];
   const int b = blockIdx.x;
   const float* xw = x + (size_t)b * ld + start;
   const float* t = Tdb + (size_t)b * len;
   float* gw = gx ? gx + (size_t)b * ld + start : nullptr;
   float acc = 0.f;
-  edc_suffix(xw, len, s_scan, [&](int i, float edc, float) {
-    const float lin = fabsf(edc) + F32_EPS;
-    const float raw = 10.0f * log10f(lin);
-    const float d = fmaxf(raw, -200.0f);
-    const float diff = t[i] - d;
-    const float mw = maskw ? maskw[i] : 1.0f;
-    acc += mw * fabsf(diff);
-    if (gw) {
-      const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-      const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
-      gw[i] = -sg * dE * mw * inv_count * gscale;   // dL/dEDC_i, staged in place
-    }
-  });
+  edc_scan(len, s_scan,
+           [&](int j) { const float v = xw[len - 1 - j]; return v * v; },
+           [&](int j, float edc, float) {
+             const int i = len - 1 - j;
+             const float lin = fabsf(edc) + F32_EPS;
+             const float raw = 10.0f * log10f(lin);
+             const float d = fmaxf(raw, -200.0f);
+             const float diff = t[i] - d;
+             const float mw = maskw ? maskw[i] : 1.0f;
+             acc += mw * fabsf(diff);
+             if (gw) {
+               const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+               const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+               gw[i] = -sg * dE * mw * inv_count * gscale;   // dL/dEDC_i, staged in place
+             }
+           });
   acc = block_sum(acc, s_red);
   if (threadIdx.x == 0) loss_item[b] = acc * inv_count;
   if (!gx) return;
   // EDC_i = sum_{j >= i} x_j^2  =>  dL/dx_j = 2 x_j sum_{i <= j} dL/dEDC_i   (forward prefix scan)
   __syncthreads();
-  float carry = 0.f;
-  const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int i0 = tile * EDC_TILE + threadIdx.x * EDC_V;
-    float v[EDC_V];
-    float loc = 0.f;
-#pragma unroll
-    for (int u = 0; u < EDC_V; ++u) {
-      const int i = i0 + u;
-      loc += (i < len) ? gw[i] : 0.f;
-      v[u] = loc;
-    }
-    float tot;
-    const float incl = block_scan_incl(loc, s_scan, &tot);
-    const float excl = incl - loc + carry;
-#pragma unroll
-    for (int u = 0; u < EDC_V; ++u) {
-      const int i = i0 + u;
-      if (i < len) gw[i] = 2.0f * xw[i] * (excl + v[u]);
-    }
-    carry += tot;
-  }
+  edc_scan(len, s_scan,
+           [&](int i) { return gw[i]; },
+           [&](int i, float cum, float) { gw[i] = 2.0f * xw[i] * cum; });
   // zeros outside the window
   float* g = gx + (size_t)b * ld;
   for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = 0.f;

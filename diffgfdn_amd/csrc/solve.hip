@@ -699,6 +699,26 @@ __global__ __launch_bounds__(64) void k_spectral_finish(const float* __restrict_
   }
 }
 
+// trainer.py:323-332: b_n, c_n /= energy_g^(1/4) for n in group g, in place
+__global__ void k_normalize_io(const float* __restrict__ energy, float* __restrict__ b,
+                               float* __restrict__ c, int N, int nper) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float s = powf(energy[n / nper], 0.25f);
+  b[n] /= s;
+  c[n] /= s;
+}
+
+extern "C" int gfdn_normalize_io(const float* energy, float* b, float* c, int G, int nper,
+                                 void* stream) {
+  if (!energy || !b || !c || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  const int N = G * nper;
+  hipLaunchKernelGGL(k_normalize_io, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, energy, b, c,
+                     N, nper);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t gfdn_spectral_stats_work_bytes(int G, int K) {
   return (size_t)2 * G * ((K + SPEC_CHUNK - 1) / SPEC_CHUNK) * sizeof(float);
 }

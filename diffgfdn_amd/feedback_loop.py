@@ -118,6 +118,8 @@ class FeedbackLoop(nn.Module):
         self.coupling_matrix_type = coupling_matrix_type
         self.coupling_matrix_order = coupling_matrix_order
         self.ortho_param = OrthoParamModule()
+        self._ortho_cache = None
+        self._inv_gamma_cache = None
         self._init_absorption(gains, common_decay_times)
         self._init_feedback_matrix(colorless_feedback_matrix)
 
@@ -170,10 +172,25 @@ class FeedbackLoop(nn.Module):
             self.alpha = nn.Parameter(np.pi / 4 * torch.rand(G * (G - 1) // 2, dtype=torch.float32))
 
     # -- reference :393-455 ------------------------------------------------------------------------
+    def _ortho(self):
+        """(Q, QQ) of the current parameters, shared by the solve and the sparsity loss of ONE
+        forward: callers open a scope with :meth:`new_forward` (models and the trainer step do),
+        inside which the pair is evaluated once.  The key (version counter, grad mode) only guards
+        against misuse inside a scope."""
+        M = self.M
+        key = (M.data_ptr(), M._version, torch.is_grad_enabled() and M.requires_grad)
+        if self._ortho_cache is None or self._ortho_cache[0] != key:
+            self._ortho_cache = (key, OrthoParam.apply(M))
+        return self._ortho_cache[1]
+
+    def new_forward(self):
+        """Drop per-forward caches (parameters may have been updated in place by a fused kernel)."""
+        self._ortho_cache = None
+
     def group_rotations(self) -> torch.Tensor:
         """Q_g = expm(skew(M_g)), (G, n, n) -- HIP kernel on the device (csrc/ortho.hip)."""
         if self.M.is_cuda:
-            return OrthoParam.apply(self.M)[0]
+            return self._ortho()[0]
         return self.ortho_param(self.M)
 
     def construct_block_mixing_matrix(self) -> torch.Tensor:
@@ -207,7 +224,7 @@ class FeedbackLoop(nn.Module):
         uncoupled, else the dense (1, N, N) matrix."""
         if self.coupling_matrix_type != CouplingMatrixType.RANDOM and self.use_zero_coupling:
             if self.M.is_cuda:
-                return OrthoParam.apply(self.M)[1]
+                return self._ortho()[1]
             Q = self.group_rotations()
             return Q @ Q
         return self._real_feedback_matrix().unsqueeze(0)
@@ -219,9 +236,15 @@ class FeedbackLoop(nn.Module):
         grid = FrequencyGrid.of(z)
         A = self.feedback_blocks()
         dev = A.device
-        inv_gamma = 1.0 / self.current_gains().to(dev)
-        return ResolventSolve.apply(A, inv_gamma.to(torch.float32), b.reshape(-1).to(dev),
-                                    grid, self.delays.to(dev), transpose)
+        if self.learn_decay_times:
+            inv_gamma = (1.0 / self.current_gains().to(dev)).to(torch.float32)
+        else:
+            g = self.delay_line_gains
+            key = (g.data_ptr(), g._version, str(dev))
+            if self._inv_gamma_cache is None or self._inv_gamma_cache[0] != key:
+                self._inv_gamma_cache = (key, (1.0 / g.to(dev)).to(torch.float32))
+            inv_gamma = self._inv_gamma_cache[1]
+        return ResolventSolve.apply(A, inv_gamma, b.reshape(-1), grid, self.delays, transpose)
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """Explicit (K, N, N) complex64 inverse, for API parity with reference :326-391."""

@@ -186,6 +186,16 @@ def spectral_stats(S, asym: bool, scale: float = 1.0, want_grad: bool = True):
     return energy, loss, gS
 
 
+def normalize_io(energy, b, c, G: int, nper: int):
+    """In place: b[n], c[n] /= energy[group(n)]^(1/4)  (b, c float32 contiguous, N = G*nper)."""
+    _need_gpu(energy, b, c)
+    for t in (b, c):
+        if t.dtype != _f32 or not t.is_contiguous() or t.numel() != G * nper:
+            raise RuntimeError("normalize_io: gains must be contiguous float32 of G*nper elements")
+    _lib.check(_lib.load().gfdn_normalize_io(_p(energy), _p(b), _p(c), G, nper, _stream()),
+               "gfdn_normalize_io")
+
+
 # ------------------------------------------------------------------------------------------------
 _blu_tables = {}
 

@@ -48,6 +48,7 @@ class DiffGFDN(nn.Module):
         n = self.num_delay_lines_per_group
         self.delays_by_group = [torch.tensor(delays[i:i + n]) for i in range(0, self.num_delay_lines, n)]
         self.register_buffer('delay_buffer', torch.tensor(delays, dtype=torch.float32))
+        self._ones = self._eye = None
         self._init_io_gains(colorless_fdn_params)
         self._init_absorption()
         self._init_feedback(feedback_loop_config, colorless_fdn_params)
@@ -116,16 +117,16 @@ class DiffGFDN(nn.Module):
         (reference model.py:237-240) -> (K, N) complex64."""
         grid = FrequencyGrid.of(z)
         M = self.feedback_loop.M
-        ones = torch.ones(self.num_delay_lines, dtype=torch.float32, device=M.device)
-        return ResolventSolve.apply(M, ones, self.input_gains.reshape(-1), grid,
+        if self._ones is None or self._ones.device != M.device:
+            self._ones = torch.ones(self.num_delay_lines, dtype=torch.float32, device=M.device)
+            self._eye = torch.eye(self.num_groups, dtype=torch.float32, device=M.device)
+        return ResolventSolve.apply(M, self._ones, self.input_gains.reshape(-1), grid,
                                     self.delay_buffer, False)
 
     def sub_fdn_group_sums(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """(S (G, K), Ysub (K, N)):  S[g][k] = sum_{n in g} c_n y^(g)_n[k] = Hout[k, g]."""
         Ysub = self.sub_fdn_responses(z)
-        G = self.num_groups
-        eye = torch.eye(G, dtype=torch.float32, device=Ysub.device)
-        S = OutputStage.apply(Ysub, self.output_gains.reshape(-1), eye,
+        S = OutputStage.apply(Ysub, self.output_gains.reshape(-1), self._eye,
                               self.num_delay_lines_per_group, None, None)
         return S, Ysub
 
@@ -178,6 +179,7 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
         ``subband_filter`` (K,) optionally fuses the trainer's H * filter (trainer.py:459) into
         the output stage; default None returns the unfiltered H exactly like the reference."""
         z = x['z_values']
+        self.feedback_loop.new_forward()
         self.batch_size = x['listener_position'].shape[0]
         if output_scalars is None:
             rgain = self.output_scalars.group_gains(x)
@@ -226,6 +228,7 @@ class DiffGFDNSinglePos(DiffGFDN):
     def forward(self, x: Dict):
         """reference :779-836; inputs are (K,) tensors, output H is (K,)."""
         z = x['z_values']
+        self.feedback_loop.new_forward()
         n = self.num_delay_lines_per_group
         b = self.input_scalars.repeat_interleave(n, dim=0) * self.input_gains
         Y = self.delay_line_responses(z, b=b)
@@ -275,6 +278,7 @@ class DiffDirectionalFDNVarReceiverPos(DiffGFDN):
         """H_sh (B, (order+1)^2, K)   (reference :1043-1094).  NB the reference contracts the FIRST
         index of P with b (einsum 'knm,bnk->bmk'), i.e. P^T b -> transpose solve."""
         z = x['z_values']
+        self.feedback_loop.new_forward()
         self.batch_size = x['listener_position'].shape[0]
         w = self.sh_output_scalars(x, normalise_weights=True)
         Y = self.delay_line_responses(z, transpose=True)

@@ -95,6 +95,8 @@ class FlatAdam(torch.optim.Optimizer):
         b1, b2 = self.defaults['betas']
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.seg,
                       self.lr_seg, self.step_count, b1, b2, self.defaults['eps'])
+        # the kernel wrote the parameters through raw pointers: tell autograd / version-keyed caches
+        torch.autograd.graph.increment_version(self._params)
 
     def state_tensors(self):
         return [self.exp_avg, self.exp_avg_sq, self.step_count]

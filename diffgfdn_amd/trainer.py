@@ -28,7 +28,7 @@ import torch.distributed as dist
 from .colorless_losses import amse_loss, group_spectral_loss, mse_loss, sparsity_loss
 from .config import TrainerConfig
 from .functional import OutputStage, irfft_like_torch
-from .hip_ops import spectral_stats
+from .hip_ops import normalize_io, spectral_stats
 from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
 from .model import DiffGFDN
 from .optim import FlatAdam
@@ -207,10 +207,9 @@ class Trainer:
             return
         S, _ = self.net.sub_fdn_group_sums(data['z_values'])
         energy, _, _ = spectral_stats(S, False, 1.0, want_grad=False)
-        scale = torch.pow(energy, 0.25).repeat_interleave(self.net.num_delay_lines_per_group).view(-1, 1)
-        for name, prm in self.net.named_parameters():
-            if name in ('input_gains', 'output_gains'):
-                prm.data /= scale.to(prm.dtype)
+        net = self.net
+        normalize_io(energy, net.input_gains.data, net.output_gains.data, net.num_groups,
+                     net.num_delay_lines_per_group)
 
 
 class VarReceiverPosTrainer(Trainer):
@@ -225,6 +224,7 @@ class VarReceiverPosTrainer(Trainer):
         ``mask_prenorm``: EDC time weights already divided by (global batch x kept indices), in a
         static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
         net, cfg = self.net, self.config
+        net.feedback_loop.new_forward()
         z = data['z_values']
         n = net.num_delay_lines_per_group
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None

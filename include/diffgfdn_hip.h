@@ -109,6 +109,10 @@ size_t gfdn_spectral_stats_work_bytes(int G, int K);
 int gfdn_spectral_stats(const float* S_c64, int G, int K, int asym, float scale,
                         float* energy, float* loss, float* gS_c64, void* work, void* stream);
 
+/* Energy normalisation of the input / output gains (trainer.py:317-332): for n in group g,
+ * b[n] /= energy[g]^(1/4), c[n] /= energy[g]^(1/4), in place (float32, N = G * nper).        */
+int gfdn_normalize_io(const float* energy, float* b, float* c, int G, int nper, void* stream);
+
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's
  * algorithm on power-of-two FFTs of length L >= n + (n-1)/2.
