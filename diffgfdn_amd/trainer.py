@@ -16,6 +16,7 @@ ranks; after backward every rank contributes its gradients to ONE flat fp32 all-
 over xGMI).  Position-independent terms (colorless + sparsity) are pre-divided by the world
 size so that the sum equals the single-process gradient.
 """
+import contextlib
 import os
 import time
 from pathlib import Path
@@ -26,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from .colorless_losses import amse_loss, group_spectral_loss, mse_loss, sparsity_loss
-from .config import TrainerConfig
+from .config import CouplingMatrixType, TrainerConfig
 from .functional import OutputStage, irfft_like_torch
 from .hip_ops import normalize_io, spectral_stats
 from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
@@ -215,6 +216,15 @@ class Trainer:
 class VarReceiverPosTrainer(Trainer):
     """Grid-of-receivers trainer (reference trainer.py:338-564)."""
 
+    concurrent_branches = True
+
+    def _side_stream(self):
+        if not self.concurrent_branches or not next(self.net.parameters()).is_cuda:
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def _decay_window(self, K: int) -> Tuple[int, int]:
         return self.criterion[1].window(K)
 
@@ -224,9 +234,28 @@ class VarReceiverPosTrainer(Trainer):
         ``mask_prenorm``: EDC time weights already divided by (global batch x kept indices), in a
         static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
         net, cfg = self.net, self.config
-        net.feedback_loop.new_forward()
+        fl = net.feedback_loop
+        fl.new_forward()
         z = data['z_values']
         n = net.num_delay_lines_per_group
+        # the colorless branch (sub-FDN solve -> spectral / sparsity losses) shares nothing with the
+        # main branch but the parameters: fork it onto a side stream (small grids that leave most
+        # of the 256 CUs idle); autograd replays each backward op on its forward stream
+        extra, colorless = None, {}
+        side = self._side_stream() if self.use_colorless_loss else None
+        if self.use_colorless_loss:
+            main = torch.cuda.current_stream()
+            if fl.M.is_cuda and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
+                fl.group_rotations()                      # (Q, QQ) once, before the fork
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                S, _ = net.sub_fdn_group_sums(z)
+                spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
+                sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
+                    fl.group_rotations()[net.num_groups - 1])      # last group only (:305-308)
+                extra = (spectral + sparsity) / self.world_size    # position independent
+                colorless = {'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()}
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
         rgain = net.output_scalars.group_gains(data)
         Y = net.delay_line_responses(z)
@@ -261,15 +290,12 @@ class VarReceiverPosTrainer(Trainer):
             edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
             edc_target=None if edc_t is None else edc_t[1])
         losses = {'edc_loss': cfg.edc_loss_weight * edc_v, 'edr_loss': cfg.edr_loss_weight * edr_v}
-        if self.use_colorless_loss:
-            S, _ = net.sub_fdn_group_sums(z)
-            spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
-            fl = net.feedback_loop
-            sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
-                fl.group_rotations()[net.num_groups - 1])          # last group only (:305-308)
-            extra = (spectral + sparsity) / self.world_size        # position independent
+        if extra is not None:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                extra.record_stream(torch.cuda.current_stream())
             total = total + extra
-            losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
+            losses.update(colorless)
         losses['_total'] = total
         return losses
 
