@@ -131,7 +131,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  global_batch: Optional[int] = None,
                  targets: Optional[DecayTargets] = None,
                  edr_target: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                 edc_target: Optional[torch.Tensor] = None
+                 edc_target: Optional[torch.Tensor] = None,
+                 side_stream: Optional["torch.cuda.Stream"] = None
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
@@ -140,7 +141,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     ``global_batch``: number of items the EDC mean runs over (the local batch unless the batch
     is sharded over ranks).  ``edr_target`` = (T_db, sum_abs) / ``edc_target`` = T_db
     may be passed precomputed (dataset-level store); otherwise they are derived from ``target``
-    through the cache."""
+    through the cache.  ``side_stream``: run the EDC kernel (one block per item, latency-bound)
+    beside the STFT -> EDR chain instead of in front of it."""
     targets = targets or _default_targets
     Hb = _as_batch(H)
     B, K = Hb.shape
@@ -154,6 +156,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     zero = torch.zeros((), dtype=torch.float32, device=x.device)
     gx = None
     edc_val, edr_val = zero, zero
+    main = torch.cuda.current_stream() if x.is_cuda else None
+    fork = side_stream is not None and use_edc and use_edr
     if use_edc:
         L = edc_len if edc_len is not None else K - edc_start
         T_db = edc_target if edc_target is not None else targets.edc(target, edc_start, L)
@@ -162,14 +166,26 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         # pre-normalised weights already carry 1 / (items * kept indices): no host scalar varies
         # from step to step, which keeps the launch arguments static under graph replay
         inv = 1.0 if edc_maskw_prenormalised else 1.0 / (nb * count)
-        li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
-        edc_val = li.sum()
+        if fork:
+            side_stream.wait_stream(main)
+            with torch.cuda.stream(side_stream):
+                li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
+                edc_val = li.sum()
+                x.record_stream(side_stream)
+        else:
+            li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
+            edc_val = li.sum()
     if use_edr:
         T_edr, sum_abs = edr_target if edr_target is not None else targets.edr(target, win)
         xe = x if env is None else x * env
         P = ops.stft_power(xe, win)
         li = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad)
         edr_val = li.sum()
+        if fork:
+            main.wait_stream(side_stream)       # gx (written by the EDC kernel) is accumulated into below
+            for t in (gx, edc_val):
+                if t is not None:
+                    t.record_stream(main)
         if want_grad:
             if gx is None:
                 gx = torch.zeros_like(x)

@@ -218,6 +218,13 @@ class VarReceiverPosTrainer(Trainer):
 
     concurrent_branches = True
 
+    def _side_stream2(self):
+        if not self.concurrent_branches or not next(self.net.parameters()).is_cuda:
+            return None
+        if getattr(self, '_side2', None) is None:
+            self._side2 = torch.cuda.Stream()
+        return self._side2
+
     def _side_stream(self):
         if not self.concurrent_branches or not next(self.net.parameters()).is_cuda:
             return None
@@ -288,7 +295,8 @@ class VarReceiverPosTrainer(Trainer):
             reduced_pole_radius=None if self.reduced_pole_radius == 1.0 else self.reduced_pole_radius,
             global_batch=gb,
             edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
-            edc_target=None if edc_t is None else edc_t[1])
+            edc_target=None if edc_t is None else edc_t[1],
+            side_stream=self._side_stream2())
         losses = {'edc_loss': cfg.edc_loss_weight * edc_v, 'edr_loss': cfg.edr_loss_weight * edr_v}
         if extra is not None:
             if side is not None:
