@@ -42,6 +42,8 @@ SIGNATURES = {
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_irfft_pow2_fwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_irfft_pow2_bwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_rfft_pow2": (c_int, [c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_sh_to_directional": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_stft_nframes": (c_int, [c_int, c_int]),
     "gfdn_stft_power": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "gfdn_stft_power_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_p2_inv_b(P2Geom g, const float2* __rest
 }
 // ---- adjoint pass A: t = n1 L2 + n2 ; tile over n2 ; FFT over n1 ; work[k1][n2]
 __global__ __launch_bounds__(256) void k_p2_adj_a(P2Geom g, const float* __restrict__ gx, int ldo,
-                                                  float2* __restrict__ work) {
+                                                  int T, float2* __restrict__ work) {
   const int L1 = g.L1, L2 = g.L2, n = g.n, tc = L2 < P2_TC ? L2 : P2_TC, ss = L1 + 1;
   float2* bufA = dyn_lds; float2* bufB = bufA + tc * ss; float2* tw4 = bufB + tc * ss;
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void k_p2_adj_a(P2Geom g, const float* __restr
   const float* gb = gx + (size_t)b * ldo;
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
     const int n1 = idx / tc, cc = idx - n1 * tc;
-    bufA[cc * ss + n1] = make_float2(gb[(size_t)n1 * L2 + c0 + cc], 0.f);
+    const int t = n1 * L2 + c0 + cc;
+    bufA[cc * ss + n1] = make_float2(t < T ? gb[t] : 0.f, 0.f);     // zero padding beyond T
   }
   __syncthreads();
   float2* r = p2_fft(bufA, bufB, L1, tc, ss, false, tw4, L1);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_p2_adj_a(P2Geom g, const float* __restr
 }
 // ---- adjoint pass B: rows k1 (tile), FFT over n2, gX[k1 + L1 k2] for k <= n/2
 __global__ __launch_bounds__(256) void k_p2_adj_b(P2Geom g, const float2* __restrict__ work,
-                                                  float2* __restrict__ gX, int ldx) {
+                                                  float2* __restrict__ gX, int ldx, int plain) {
   const int L1 = g.L1, L2 = g.L2, n = g.n, tc = L1 < P2_TC ? L1 : P2_TC, ss = L2 + 1;
   float2* bufA = dyn_lds; float2* bufB = bufA + tc * ss; float2* tw4 = bufB + tc * ss;
   const int b = blockIdx.y, r0 = blockIdx.x * tc;
@@ -176,8 +177,10 @@ __global__ __launch_bounds__(256) void k_p2_adj_b(P2Geom g, const float2* __rest
     const int k = r0 + rr + L1 * k2;
     if (k <= n / 2) {
       float2 v = r[rr * ss + k2];
-      if (k == 0 || k == n / 2) v = make_float2(sc * v.x, 0.f);
-      else v = cscale(v, 2.0f * sc);
+      if (!plain) {                                  // adjoint-of-irfft scaling
+        if (k == 0 || k == n / 2) v = make_float2(sc * v.x, 0.f);
+        else v = cscale(v, 2.0f * sc);
+      }
       o[k] = v;
     }
   }
@@ -210,10 +213,26 @@ extern "C" int gfdn_irfft_pow2_fwd(int n, const float* X, int ldx, int batch, fl
   return 0;
 }
 
+static int p2_forward_real(int n, const float* gx, int ldo, int T, int batch, float* gX, int ldx,
+                           void* work, void* stream, int plain);
+
 extern "C" int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, float* gX, int ldx,
                                    void* work, void* stream) {
+  if (ldo < n) return GFDN_E_BADARG;
+  return p2_forward_real(n, gx, ldo, n, batch, gX, ldx, work, stream, 0);
+}
+
+// X = rfft(x[0:T], n): the dataset front end (dataloader.py:250, :320-325)
+extern "C" int gfdn_rfft_pow2(int n, const float* x, int ld, int T, int batch, float* X, int ldx,
+                              void* work, void* stream) {
+  if (T <= 0 || T > n || ld < T) return GFDN_E_BADARG;
+  return p2_forward_real(n, x, ld, T, batch, X, ldx, work, stream, 1);
+}
+
+static int p2_forward_real(int n, const float* gx, int ldo, int T, int batch, float* gX, int ldx,
+                           void* work, void* stream, int plain) {
   if (!gx || !gX || !work || n < 16 || (n & (n - 1)) || batch <= 0) return GFDN_E_BADARG;
-  if (ldx < n / 2 + 1 || ldo < n) return GFDN_E_BADARG;
+  if (ldx < n / 2 + 1) return GFDN_E_BADARG;
   P2Geom g = p2_geom(n);
   if (g.L2 > 2048) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
@@ -222,10 +241,10 @@ extern "C" int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, f
   if ((rc = ensure_dyn_lds(k_p2_adj_a, p2_lds(g.L1, tca)))) return rc;
   if ((rc = ensure_dyn_lds(k_p2_adj_b, p2_lds(g.L2, tcb)))) return rc;
   hipLaunchKernelGGL(k_p2_adj_a, dim3(g.L2 / tca, batch), dim3(256), p2_lds(g.L1, tca), s, g, gx,
-                     ldo, (float2*)work);
+                     ldo, T, (float2*)work);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_p2_adj_b, dim3(g.L1 / tcb, batch), dim3(256), p2_lds(g.L2, tcb), s, g,
-                     (const float2*)work, (float2*)gX, ldx);
+                     (const float2*)work, (float2*)gX, ldx, plain);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -651,6 +651,39 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
 }
 
 // ------------------------------------------------------------------------------------------
+// SH domain -> directional responses, trainer.py:853-865: H_dir[b][j][k] = sum_l A[j][l] H_sh[b][l][k]
+// and its adjoint gH_sh[b][l][k] = sum_j A[j][l] gH_dir[b][j][k]   (A real, J x C)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sh_mix(const float* __restrict__ A, int J, int C, int K,
+                                                const float2* __restrict__ in, float2* __restrict__ out,
+                                                int adjoint) {
+  const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (k >= K) return;
+  const int nin = adjoint ? J : C, nout = adjoint ? C : J;
+  const float2* ib = in + (size_t)b * nin * K;
+  float2* ob = out + (size_t)b * nout * K;
+  for (int o = 0; o < nout; ++o) {
+    float2 acc = make_float2(0.f, 0.f);
+    for (int i = 0; i < nin; ++i) {
+      const float a = adjoint ? A[i * C + o] : A[o * C + i];
+      const float2 v = ib[(size_t)i * K + k];
+      acc.x += a * v.x;
+      acc.y += a * v.y;
+    }
+    ob[(size_t)o * K + k] = acc;
+  }
+}
+
+extern "C" int gfdn_sh_to_directional(const float* A, int J, int C, int K, int B, const float* in,
+                                      float* out, int adjoint, void* stream) {
+  if (!A || !in || !out || J <= 0 || C <= 0 || K <= 0 || B <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_sh_mix, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, A, J, C, K,
+                     (const float2*)in, (float2*)out, adjoint);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // colorless statistics of the sub-FDN responses
 // ------------------------------------------------------------------------------------------
 #define SPEC_CHUNK 2048

@@ -9,8 +9,8 @@ RoomDataset.__init__ (:188-254: rfft of the RIRs), early_late_split (:300-325: 2
 MI355X layout: one process keeps the whole grid on its GPU -- 838 receivers x 65 537 bins of
 complex64 for the direct path (0.44 GB) plus, once computed, the model-independent target EDR
 (838 x 32 x 2049 f32, 0.22 GB) and EDC (838 x 47 360 f32, 0.16 GB); a batch is an index list.
-The three load-time rFFTs are one-off: they run as batched torch.fft calls on the device in
-float64 (SURVEY §8 f-4 ranks a hand-written front-end kernel last).
+The three load-time rFFTs run on the library's own power-of-two real FFT (csrc/pow2.hip,
+``gfdn_rfft_pow2``) in float32 -> complex64, which is the precision every consumer works in.
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -83,15 +83,16 @@ class RoomDataset:
         self.late_rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
         fade_out = torch.tensor(w[win // 2:], device=dev)
         fade_in = torch.tensor(w[:win // 2], device=dev)
+        rfft = lambda t: ops.rfft_pow2(t.to(torch.float32).contiguous(), nfft)
         for r0 in range(0, R, chunk):
             blk = torch.as_tensor(self.rirs[r0:r0 + chunk], dtype=torch.float64, device=dev)
-            self.rir_mag_response[r0:r0 + chunk] = torch.fft.rfft(blk, n=nfft, dim=-1)
+            self.rir_mag_response[r0:r0 + chunk] = rfft(blk)
             # the reference windows views of self.rirs in place AFTER the full-RIR rfft
             ko = win - win // 2                   # reference slices [-win // 2:] == ceil(win / 2)
             blk[:, mix - ko:mix] *= fade_out
             blk[:, mix:mix + win // 2] *= fade_in
-            self.late_rir_mag_response[r0:r0 + chunk] = torch.fft.rfft(blk[:, mix:], n=nfft, dim=-1)
-            self.early_rir_mag_response[r0:r0 + chunk] = torch.fft.rfft(blk[:, :mix], n=nfft, dim=-1)
+            self.late_rir_mag_response[r0:r0 + chunk] = rfft(blk[:, mix:])
+            self.early_rir_mag_response[r0:r0 + chunk] = rfft(blk[:, :mix])
             if isinstance(self.rirs, np.ndarray):
                 self.rirs[r0:r0 + chunk] = blk.cpu().numpy()     # keep the in-place side effect
 

@@ -138,6 +138,20 @@ class SHOutputStage(torch.autograd.Function):
         return gY, gc.to(c.dtype).reshape(c.shape), gw.to(w.dtype).reshape(w.shape), None, None, None
 
 
+class SHToDirectional(torch.autograd.Function):
+    """H_dir = einsum('jl,blk->bjk', A, H_sh)  (trainer.py:853-865)."""
+
+    @staticmethod
+    def forward(ctx, A, H_sh):
+        ctx.save_for_backward(A)
+        return ops.sh_to_directional(A, H_sh, False)
+
+    @staticmethod
+    def backward(ctx, gH):
+        (A,) = ctx.saved_tensors
+        return None, ops.sh_to_directional(A, gH.contiguous(), True)
+
+
 class SpectralLoss(torch.autograd.Function):
     """sum_g mean_k (|S[g][k]| - 1)^p  (colorless_fdn/losses.py:20-73); gradient fused."""
 

@@ -284,6 +284,32 @@ def irfft_pow2_bwd(gx, n: int) -> torch.Tensor:
     return gX
 
 
+def rfft_pow2(x, n: int) -> torch.Tensor:
+    """x (batch, T <= n) float32 -> rfft(x, n) (batch, n/2+1) complex64."""
+    _need_gpu(x)
+    x = _f(x)
+    batch, T = x.shape
+    lib = _lib.load()
+    X = torch.empty((batch, n // 2 + 1), dtype=_c64, device=x.device)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(n, batch), x.device)
+    _lib.check(lib.gfdn_rfft_pow2(n, _p(x), T, T, batch, _p(X), n // 2 + 1, _p(work), _stream()),
+               "gfdn_rfft_pow2")
+    return X
+
+
+def sh_to_directional(A, H, adjoint: bool = False) -> torch.Tensor:
+    """A (J,C) real, H (B,C,K) complex -> (B,J,K); adjoint maps (B,J,K) -> (B,C,K)."""
+    _need_gpu(A, H)
+    A, H = _f(A), _c(H)
+    J, C = A.shape
+    B, nin, K = H.shape
+    assert nin == (J if adjoint else C)
+    out = torch.empty((B, C if adjoint else J, K), dtype=_c64, device=H.device)
+    _lib.check(_lib.load().gfdn_sh_to_directional(_p(A), J, C, K, B, _p(H), _p(out), int(adjoint),
+                                                  _stream()), "gfdn_sh_to_directional")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def stft_nframes(T: int, win: int) -> int:
     nf = _lib.load().gfdn_stft_nframes(int(T), int(win))

@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from .colorless_losses import amse_loss, group_spectral_loss, mse_loss, sparsity_loss
 from .config import CouplingMatrixType, TrainerConfig
-from .functional import OutputStage, irfft_like_torch
+from .functional import OutputStage, SHToDirectional, irfft_like_torch
 from .hip_ops import normalize_io, spectral_stats
 from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
 from .model import DiffGFDN
@@ -213,6 +213,47 @@ class Trainer:
                      net.num_delay_lines_per_group)
 
 
+    # epoch loop shared by the grid / directional trainers (reference :345-424, :697-769)
+    def train(self, train_dataset, valid_dataset, save_irs: bool = False):
+        self.train_loss, self.valid_loss = [], []
+        self.individual_train_loss, self.individual_valid_loss = [], []
+        st = time.time()
+        self.save_model(-1)
+        for epoch in range(self.max_epochs):
+            st_epoch = time.time()
+            agg_t, agg_v = {}, {}
+            for data in train_dataset:
+                self.normalize(data)
+                _, cur = self.train_step(data)
+                for k, v in cur.items():
+                    agg_t[k] = agg_t.get(k, 0.0) + v.detach()
+            for data in valid_dataset:
+                _, cur = self.valid_step(data)
+                for k, v in cur.items():
+                    agg_v[k] = agg_v.get(k, 0.0) + v.detach()
+            self.scheduler.step()
+            if isinstance(self.optimizer, FlatAdam):
+                self.optimizer.sync_lr()
+            nt, nv = max(len(train_dataset), 1), max(len(valid_dataset), 1)
+            agg_t = {k: float(v) / nt for k, v in agg_t.items()}     # one sync per epoch
+            agg_v = {k: float(v) / nv for k, v in agg_v.items()}
+            self.train_loss.append(sum(agg_t.values()))
+            self.valid_loss.append(sum(agg_v.values()))
+            self.individual_train_loss.append(agg_t)
+            self.individual_valid_loss.append(agg_v)
+            self.save_model(epoch)
+            if self.rank == 0:
+                print(f"epoch {epoch}: train {self.train_loss[-1]:.4f} valid {self.valid_loss[-1]:.4f} "
+                      f"({time.time() - st_epoch:.2f} s) " +
+                      " ".join(f"{k}={v:.4f}" for k, v in agg_t.items()))
+            if epoch >= 1:
+                self.early_stop = self.early_stop + 1 if abs(self.valid_loss[-2] - self.valid_loss[-1]) <= 1e-3 else 0
+            if self.early_stop == self.patience:
+                break
+        self.train_time = time.time() - st
+
+
+
 class VarReceiverPosTrainer(Trainer):
     """Grid-of-receivers trainer (reference trainer.py:338-564)."""
 
@@ -330,44 +371,6 @@ class VarReceiverPosTrainer(Trainer):
         losses.pop('_total')
         return sum(losses.values()), losses
 
-    def train(self, train_dataset, valid_dataset, save_irs: bool = False):
-        self.train_loss, self.valid_loss = [], []
-        self.individual_train_loss, self.individual_valid_loss = [], []
-        st = time.time()
-        self.save_model(-1)
-        for epoch in range(self.max_epochs):
-            st_epoch = time.time()
-            agg_t, agg_v = {}, {}
-            for data in train_dataset:
-                self.normalize(data)
-                _, cur = self.train_step(data)
-                for k, v in cur.items():
-                    agg_t[k] = agg_t.get(k, 0.0) + v.detach()
-            for data in valid_dataset:
-                _, cur = self.valid_step(data)
-                for k, v in cur.items():
-                    agg_v[k] = agg_v.get(k, 0.0) + v.detach()
-            self.scheduler.step()
-            if isinstance(self.optimizer, FlatAdam):
-                self.optimizer.sync_lr()
-            nt, nv = max(len(train_dataset), 1), max(len(valid_dataset), 1)
-            agg_t = {k: float(v) / nt for k, v in agg_t.items()}     # one sync per epoch
-            agg_v = {k: float(v) / nv for k, v in agg_v.items()}
-            self.train_loss.append(sum(agg_t.values()))
-            self.valid_loss.append(sum(agg_v.values()))
-            self.individual_train_loss.append(agg_t)
-            self.individual_valid_loss.append(agg_v)
-            self.save_model(epoch)
-            if self.rank == 0:
-                print(f"epoch {epoch}: train {self.train_loss[-1]:.4f} valid {self.valid_loss[-1]:.4f} "
-                      f"({time.time() - st_epoch:.2f} s) " +
-                      " ".join(f"{k}={v:.4f}" for k, v in agg_t.items()))
-            if epoch >= 1:
-                self.early_stop = self.early_stop + 1 if abs(self.valid_loss[-2] - self.valid_loss[-1]) <= 1e-3 else 0
-            if self.early_stop == self.patience:
-                break
-        self.train_time = time.time() - st
-
     @torch.no_grad()
     def save_ir(self, input_features: Dict, norm: bool = True):
         """Impulse responses of one batch (reference :503-564 minus the wav writing): h (B, nfft)."""
@@ -379,6 +382,102 @@ class VarReceiverPosTrainer(Trainer):
         if norm:
             h = h / torch.max(torch.abs(h))
         return out[0], h
+
+
+class DirectionalFDNVarReceiverPosTrainer(Trainer):
+    """Directional FDN over a grid of receivers (reference trainer.py:690-921): SH-domain response ->
+    sub-band filter -> directional responses (analysis matrix) -> directional EDC loss against the
+    common-slope amplitudes, plus the colorless terms."""
+
+    concurrent_branches = False
+
+    def convert_ambi_rir_to_directional_rir(self, H_sh: torch.Tensor) -> torch.Tensor:
+        """einsum('jl,blk->bjk', A_sh, H_sh)  (reference :853-865) as one streaming kernel."""
+        return SHToDirectional.apply(self.net.sh_output_scalars.analysis_matrix, H_sh)
+
+    def _step_losses(self, data: Dict) -> Dict:
+        net, cfg = self.net, self.config
+        filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
+        out = net(data, subband_filter=filt)
+        H_sh, H_sub = out if net.use_colorless_loss else (out, None)
+        H_dir = self.convert_ambi_rir_to_directional_rir(H_sh)
+        edc = cfg.edc_loss_weight * self.criterion[0](H_dir, data['target_common_slope_amps'])
+        losses = {'edc_loss': edc.detach()}
+        total = edc
+        if self.use_colorless_loss:
+            S = H_sub[0].T.contiguous()
+            spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
+            fl = net.feedback_loop
+            sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
+                fl.group_rotations()[net.num_groups - 1])
+            total = total + (spectral + sparsity) / self.world_size
+            losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
+        losses['_total'] = total
+        return losses
+
+    def train_step(self, data: Dict):
+        self.optimizer.zero_grad(set_to_none=True)
+        losses = self._step_losses(data)
+        total = losses.pop('_total')
+        total.backward()
+        if self._allreduce is not None:
+            if isinstance(self.optimizer, FlatAdam):
+                self.optimizer.pack_grads()
+            self._allreduce()
+        self.optimizer.step()
+        return sum(losses.values()), losses
+
+    @torch.no_grad()
+    def valid_step(self, data: Dict):
+        losses = self._step_losses(data)
+        losses.pop('_total')
+        return sum(losses.values()), losses
+
+
+class SinglePosTrainer(Trainer):
+    """One source-receiver pair (reference trainer.py:570-684; the reference's own train_step has
+    unbound variables on the colorless / no-sub-band branches, SURVEY §8c -- this is the working
+    counterpart).  ``data``: dict of (K,) tensors z_values, target_rir_response, target_early_response."""
+
+    def _step_losses(self, data: Dict) -> Dict:
+        net, cfg = self.net, self.config
+        out = net(data)
+        H, H_sub = out if net.use_colorless_loss else (out, None)
+        if self.subband_process_config is not None:
+            H = H * self.subband_filter_freq_resp
+        K = H.shape[-1]
+        start, length = self.criterion[1].window(K)
+        maskw, count = self.criterion[1].draw_mask(length, H.device)
+        total, edr_v, edc_v = decay_losses(
+            H, data['target_rir_response'], win=self.stft_win, edr_weight=cfg.edr_loss_weight,
+            edc_weight=cfg.edc_loss_weight, edc_start=start, edc_len=length, edc_maskw=maskw,
+            edc_count=count,
+            reduced_pole_radius=None if self.reduced_pole_radius == 1.0 else self.reduced_pole_radius)
+        losses = {'edc_loss': cfg.edc_loss_weight * edc_v, 'edr_loss': cfg.edr_loss_weight * edr_v}
+        if self.use_colorless_loss:
+            S = H_sub[0].T.contiguous()
+            spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
+            fl = net.feedback_loop
+            sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
+                fl.group_rotations()[net.num_groups - 1])
+            total = total + spectral + sparsity
+            losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
+        losses['_total'] = total
+        return losses
+
+    def train_step(self, data: Dict):
+        self.optimizer.zero_grad(set_to_none=True)
+        losses = self._step_losses(data)
+        total = losses.pop('_total')
+        total.backward()
+        self.optimizer.step()
+        return sum(losses.values()), losses
+
+    @torch.no_grad()
+    def valid_step(self, data: Dict):
+        losses = self._step_losses(data)
+        losses.pop('_total')
+        return sum(losses.values()), losses
 
 
 class GraphedTrainStep:

@@ -101,6 +101,12 @@ int gfdn_compose_sh_bwd(const float* Y_c64, int K, int G, int nper, const float*
                         const float* w, int B, const float* filt_c64, const float* gH_c64,
                         float* gY_c64, float* gc, float* gw, void* work, void* stream);
 
+/* SH-domain -> directional responses (trainer.py:853-865, einsum 'jl,blk->bjk'):
+ * adjoint = 0: in = H_sh (B, C, K) -> out = H_dir (B, J, K);  adjoint = 1: in = gH_dir -> out = gH_sh.
+ * A: (J, C) real analysis matrix.                                                              */
+int gfdn_sh_to_directional(const float* A, int J, int C, int K, int B, const float* in_c64,
+                           float* out_c64, int adjoint, void* stream);
+
 /* ---- colorless statistics of the sub-FDN responses  (colorless_fdn/losses.py:20-73,
  * trainer.py:323-324).  S (G, K) complex64.  Per group g:
  *   energy[g] = mean_k |S|^2 ;  loss[g] = mean_k (|S|-1)^p, p = 2, or (asym) 4 where |S|-1 > 1.
@@ -146,6 +152,12 @@ int gfdn_irfft_pow2_fwd(int n, const float* X_c64, int ldx, int batch, float* x,
                         void* work, void* stream);
 int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, float* gX_c64, int ldx,
                         void* work, void* stream);
+
+/* Dataset front end (dataloader.py:250, :320-325: scipy.fft.rfft(rirs, n = nfft)):
+ * X (batch, ldx >= n/2+1) complex64 = rfft(x[b][0:T] zero-padded to n), n = 2^p, T <= n.
+ * work: gfdn_irfft_pow2_work_bytes(n, batch).                                                  */
+int gfdn_rfft_pow2(int n, const float* x, int ld, int T, int batch, float* X_c64, int ldx,
+                   void* work, void* stream);
 
 /* ---- EDR  (losses.py:501-575: STFT Hann(win) hop win/2 center=False, tail energy, dB) ----
  * x: (batch, ld) float, T valid samples, implicitly zero-padded to a multiple of hop.
