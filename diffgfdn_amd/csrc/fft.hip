@@ -32,11 +32,61 @@
 // inverse = true uses conjugated twiddles (un-normalised).  Returns the buffer that holds the
 // result.  Every thread of the block must call it.
 // ------------------------------------------------------------------------------------------
+// in-place 8-point DFT, natural-order output; sgn = +1 forward (e^-), -1 inverse
+__device__ __forceinline__ void bfly8(float2 (&a)[8], float sgn) {
+  const float r = 0.70710678118654752f;
+  float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+  float2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
+  float2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
+  float2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
+  b5 = make_float2(r * (b5.x + sgn * b5.y), r * (b5.y - sgn * b5.x));      // * W8^1
+  b6 = make_float2(sgn * b6.y, -sgn * b6.x);                               // * W8^2 = -j
+  b7 = make_float2(r * (-b7.x + sgn * b7.y), r * (-b7.y - sgn * b7.x));    // * W8^3
+  float2 c0 = cadd(b0, b2), c2 = csub(b0, b2), c1 = cadd(b1, b3), t = csub(b1, b3);
+  float2 c3 = make_float2(sgn * t.y, -sgn * t.x);
+  float2 d0 = cadd(b4, b6), d2 = csub(b4, b6), d1 = cadd(b5, b7);
+  t = csub(b5, b7);
+  float2 d3 = make_float2(sgn * t.y, -sgn * t.x);
+  a[0] = cadd(c0, c1); a[4] = csub(c0, c1); a[2] = cadd(c2, c3); a[6] = csub(c2, c3);
+  a[1] = cadd(d0, d1); a[5] = csub(d0, d1); a[3] = cadd(d2, d3); a[7] = csub(d2, d3);
+}
+// a[u] *= w^u, u = 1..7
+__device__ __forceinline__ void twiddle8(float2 (&a)[8], float2 w1) {
+  const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+  a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3); a[4] = cmul(a[4], w4);
+  a[5] = cmul(a[5], cmul(w4, w1)); a[6] = cmul(a[6], cmul(w3, w3)); a[7] = cmul(a[7], cmul(w4, w3));
+}
+
 __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq, int ss,
                                            bool inverse, const float2* tw4, int tn) {
   const int nthr = blockDim.x;
   int nn = n, s = 1, ls = 0;  // ls = log2(s)
   const float sgn = inverse ? -1.0f : 1.0f;
+  while (nn >= 8) {           // radix-8 Stockham passes
+    const int m = nn >> 3;
+    const int tws = tn / nn;
+    const int per = n >> 3;
+    for (int idx = threadIdx.x; idx < nseq * per; idx += nthr) {
+      const int seq = idx / per, i = idx - seq * per;
+      const int p = i >> ls, q = i & (s - 1);
+      float2 w1 = tw4[p * tws];
+      w1.y *= sgn;
+      const float2* xb = x + seq * ss;
+      float2* yb = y + seq * ss;
+      float2 a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = xb[q + s * (p + k * m)];
+      bfly8(a, sgn);
+      twiddle8(a, w1);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) yb[q + s * (8 * p + u)] = a[u];
+    }
+    __syncthreads();
+    float2* t = x; x = y; y = t;
+    nn = m;
+    s <<= 3;
+    ls += 3;
+  }
   while (nn >= 4) {
     const int m = nn >> 2;
     const int tws = tn / nn;
@@ -298,6 +348,79 @@ __global__ __launch_bounds__(256) void k_blu_row(BluArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Row pass for L2 = 512: one WAVEFRONT per row, 8 points per lane, radix-8 x 3.
+// forward FFT -> chirp-spectrum product -> inverse FFT -> conj twiddle are chained through registers;
+// between the passes the wave exchanges data through its own padded 512-point LDS region
+// (index i -> i + (i >> 3): conflict-free for the stride-8 / stride-64 patterns below).  A wave's LDS
+// operations execute in program order, so no barrier is needed between its own write and read.
+// ------------------------------------------------------------------------------------------
+#define ROW512_PAD(i) ((i) + ((i) >> 3))
+#define ROW512_LDS 576   // 512 + 512/8
+
+__device__ __forceinline__ void row512_fft(float2 (&a)[8], float2* buf, const float2* tw4, int lane,
+                                           float sgn) {
+  // pass 1: nn = 512, m = 64, s = 1: inputs a[k] = x[lane + 64 k]
+  bfly8(a, sgn);
+  {
+    float2 w1 = tw4[lane];            // W_512^lane
+    w1.y *= sgn;
+    twiddle8(a, w1);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) buf[ROW512_PAD(8 * lane + u)] = a[u];
+  // pass 2: nn = 64, m = 8, s = 8: p = lane >> 3, q = lane & 7; inputs x[q + 8 (p + 8 k)] = x[lane + 64 k]
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = buf[ROW512_PAD(lane + 64 * k)];
+  bfly8(a, sgn);
+  {
+    float2 w1 = tw4[(lane >> 3) * 8];  // W_64^p = W_512^(8 p)
+    w1.y *= sgn;
+    twiddle8(a, w1);
+  }
+  const int base = (lane & 7) + 64 * (lane >> 3);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) buf[ROW512_PAD(base + 8 * u)] = a[u];
+  // pass 3: nn = 8, m = 1, s = 64: inputs x[lane + 64 k]; outputs X[lane + 64 u] stay in registers
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = buf[ROW512_PAD(lane + 64 * k)];
+  bfly8(a, sgn);
+}
+
+__global__ __launch_bounds__(256) void k_blu_row512(BluArgs a) {
+  const BluGeom g = a.g;
+  const int L2 = 512, L = g.L;
+  float2* tw4 = dyn_lds;                    // 128 entries: W_512^j, j < 128
+  float2* thi = tw4 + 128;
+  float2* tlo = thi + ((L >> TW_LOBITS) > 0 ? (L >> TW_LOBITS) : 1);
+  float2* bufs = tlo + (1 << TW_LOBITS);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  build_tw4(tw4, 512);
+  build_tw2(thi, tlo, L);
+  __syncthreads();
+  const int b = blockIdx.y, k1 = blockIdx.x * 4 + wave;
+  float2* buf = bufs + wave * ROW512_LDS;
+  float2* wk = a.work + (size_t)b * L + (size_t)k1 * L2;
+  float2 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = wk[lane + 64 * k];
+  row512_fft(v, buf, tw4, lane, 1.0f);
+  const float2* chat = a.chat + (size_t)k1 * L2;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    float2 ch = chat[lane + 64 * u];
+    if (a.adjoint) ch.y = -ch.y;
+    v[u] = cmul(v[u], ch);
+  }
+  row512_fft(v, buf, tw4, lane, -1.0f);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int n2 = lane + 64 * u;
+    const float2 w = tw2(thi, tlo, (int)(((long long)n2 * k1) & (L - 1)), L);
+    wk[n2] = cmulc(v[u], w);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   const BluGeom g = a.g;
   const int L1 = g.L1, L2 = g.L2, L = g.L;
@@ -384,7 +507,13 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 2) {
-    hipLaunchKernelGGL(k_blu_row, dim3(g.L1 / tr, batch), dim3(256), lr, s, a);
+    if (g.L2 == 512 && g.L1 % 4 == 0) {
+      const size_t lr5 = (128 + ((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS) +
+                          4 * ROW512_LDS) * sizeof(float2);
+      hipLaunchKernelGGL(k_blu_row512, dim3(g.L1 / 4, batch), dim3(256), lr5, s, a);
+    } else {
+      hipLaunchKernelGGL(k_blu_row, dim3(g.L1 / tr, batch), dim3(256), lr, s, a);
+    }
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 4) {

@@ -118,3 +118,35 @@ def test_flat_grad_allreduce_sums_over_ranks():
             assert float(got.abs().max()) == 0.0          # missing grads enter the sum as zeros
         else:
             assert torch.allclose(got, q.grad, rtol=1e-5, atol=1e-6)
+
+
+def _band_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffgfdn_amd.subband import band_assignment, sum_bands
+    freqs = [63, 125, 250, 500, 1000, 2000, 4000]
+    mine = band_assignment(freqs, world)[rank]
+    # "filtered RIRs" of a band: a deterministic function of the band, (receivers=3, samples=8)
+    local = [torch.full((3, 8), float(f)) + torch.arange(8.0) for f in mine]
+    total = sum_bands(local)
+    if rank == 0:
+        ret["total"] = total
+        ret["mine"] = mine
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_parallel_assignment_and_sum():
+    from diffgfdn_amd.subband import band_assignment
+    freqs = [63, 125, 250, 500, 1000, 2000, 4000]
+    parts = band_assignment(freqs, 8)
+    assert sorted(f for p in parts for f in p) == freqs and len(parts) == 8 and parts[7] == []
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_band_worker, args=(world, port, ret), nprocs=world, join=True)
+    expect = sum(torch.full((3, 8), float(f)) + torch.arange(8.0) for f in freqs)
+    assert torch.equal(ret["total"], expect)
+    assert ret["mine"] == freqs[0::2]

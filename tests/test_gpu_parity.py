@@ -466,3 +466,16 @@ def test_rfft_front_end_kernel_and_sh_mix():
     g = torch.randn(2, 5, 300, dtype=torch.complex64)
     back = ops.sh_to_directional(A.to(DEV), g.to(DEV), adjoint=True)
     assert rel_err(back.cpu(), torch.einsum('jl,bjk->blk', A.to(torch.complex64), g)) < 1e-5
+
+
+def test_band_recombination_filter():
+    """full_convolve == scipy.signal.fftconvolve(h, taps, 'full') (reference run_subband_training_treble.py:321-324)."""
+    from scipy.signal import fftconvolve
+    from diffgfdn_amd.subband import full_convolve
+    rng = np.random.RandomState(0)
+    h = rng.randn(3, 8192)
+    taps = rng.randn(301) * np.hanning(301)
+    y = full_convolve(torch.tensor(h, dtype=torch.float32, device=DEV), torch.tensor(taps, dtype=torch.float32))
+    ref = np.stack([fftconvolve(h[i], taps, mode="full") for i in range(3)])
+    assert y.shape == ref.shape
+    assert rel_err(y.cpu(), ref) < 1e-5
