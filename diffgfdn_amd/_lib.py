@@ -32,6 +32,8 @@ SIGNATURES = {
     "gfdn_compose_sh_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_spectral_stats_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_spectral_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
+    "gfdn_colorless_terms": (c_int, [_P, c_int, _P, c_int, c_float, c_float, c_float, _P, _P, _P]),
+    "gfdn_weighted_sums": (c_int, [_P, c_float, _P, c_float, c_int, _P, _P]),
     "gfdn_normalize_io": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "gfdn_bluestein_table_bytes": (c_size_t, [c_int]),
     "gfdn_bluestein_table_init": (c_int, [c_int, _P]),
@@ -50,13 +52,14 @@ SIGNATURES = {
     "gfdn_edr_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_edr_target": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_edr_loss": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
-    "gfdn_edc_target": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gfdn_edc_work_bytes": (c_size_t, [c_int]),
+    "gfdn_edc_target": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_mlp_param_count": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfdn_mlp_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "gfdn_mlp_gains_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_mlp_gains_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_adam_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P]),
-    "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P]),
+    "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P]),
 }
 
 _lib = None

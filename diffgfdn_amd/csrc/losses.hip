@@ -126,18 +126,23 @@ extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs, 
 }
 
 // ------------------------------------------------------------------------------------------
-// EDC: one 1024-thread block per item.  Every iteration covers EDC_S striped sub-tiles of 4096 samples:
-// thread t owns samples [s*4096 + 4t, +4) of each sub-tile s, so every load is a coalesced 16 B per lane
-// and all EDC_S loads of a thread are in flight together (the kernel is latency-, not bandwidth-bound);
-// the EDC_S block scans run side by side through one pair of barriers.
+// EDC.  The window of every item is cut into EDC_NSEG contiguous segments, one 256-thread block each
+// (32 items x 8 segments = 256 blocks, one per CU).  Scans are made global by carries:
+//   k_edc_segsum : energy of every segment
+//   k_edc_seg_fwd: carry-in = energy of all LATER segments; suffix scan inside the segment ->
+//                  EDC, dB, |diff| partial sum, dL/dEDC staged in gx, segment sum of dL/dEDC
+//   k_edc_seg_bwd: carry-in = dL/dEDC of all EARLIER segments; prefix scan -> dL/dx; item loss
+// Inside a block every iteration covers EDC_S striped sub-tiles (thread t owns samples
+// [s*1024 + 4t, +4) of sub-tile s): coalesced 16 B per lane, EDC_S loads in flight, and the EDC_S
+// block scans share one pair of barriers.  All sums are fixed-order (bitwise reproducible).
 // ------------------------------------------------------------------------------------------
-#define EDC_THREADS 1024
+#define EDC_THREADS 256
 #define EDC_V 4
 #define EDC_S 4
 #define EDC_SUB (EDC_THREADS * EDC_V)
 #define EDC_TILE (EDC_SUB * EDC_S)
+#define EDC_NSEG 8
 
-// EDC_S simultaneous inclusive block scans (thread order); v[s] -> inclusive prefix, tot[s] = block total
 __device__ __forceinline__ void block_scan_multi(float (&v)[EDC_S], float (&tot)[EDC_S],
                                                  float* lds /* >= 16*EDC_S floats */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -169,14 +174,12 @@ __device__ __forceinline__ void block_scan_multi(float (&v)[EDC_S], float (&tot)
   }
 }
 
-// running sums of f(j) over j = 0..len-1 in index order; calls fn(j, inclusive_sum_j, value_j).
-// get(j) returns the value at position j (callers map j to memory: reversed for the suffix sum).
+// running sums over j = 0..len-1 (index order) starting from `carry`; fn(j, inclusive_sum_j, value_j)
 template <typename G, typename F>
-__device__ __forceinline__ void edc_scan(int len, float* lds, G get, F fn) {
-  float carry = 0.f;
+__device__ __forceinline__ void edc_scan(int len, float carry, float* lds, G get, F fn) {
   const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
   for (int tile = 0; tile < ntiles; ++tile) {
-    float val[EDC_S][EDC_V], pre[EDC_S][EDC_V], loc[EDC_S], tot[EDC_S];
+    float val[EDC_S][EDC_V], pre[EDC_S][EDC_V], loc[EDC_S], tot[EDC_S], incl[EDC_S];
 #pragma unroll
     for (int s = 0; s < EDC_S; ++s) {
       const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
@@ -189,10 +192,8 @@ __device__ __forceinline__ void edc_scan(int len, float* lds, G get, F fn) {
         pre[s][u] = run;
       }
       loc[s] = run;
+      incl[s] = run;
     }
-    float incl[EDC_S];
-#pragma unroll
-    for (int s = 0; s < EDC_S; ++s) incl[s] = loc[s];
     block_scan_multi(incl, tot, lds);
     float base = carry;
 #pragma unroll
@@ -211,79 +212,160 @@ __device__ __forceinline__ void edc_scan(int len, float* lds, G get, F fn) {
   }
 }
 
-__global__ __launch_bounds__(EDC_THREADS) void k_edc_target(const float* __restrict__ x, int ld,
-                                                            int start, int len,
-                                                            float* __restrict__ Tdb) {
-  __shared__ float s_scan[16 * EDC_S];
-  const int b = blockIdx.x;
-  const float* xw = x + (size_t)b * ld + start;
-  float* t = Tdb + (size_t)b * len;
-  // suffix sums of x^2: scan the reversed sequence j -> i = len-1-j
-  edc_scan(len, s_scan,
-           [&](int j) { const float v = xw[len - 1 - j]; return v * v; },
-           [&](int j, float edc, float) { t[len - 1 - j] = db_pow(edc); });
+__device__ __forceinline__ void edc_segment(int len, int seg, int* s0, int* slen) {
+  int per = (len + EDC_NSEG - 1) / EDC_NSEG;
+  per = (per + 3) & ~3;
+  const int a = seg * per;
+  *s0 = a < len ? a : len;
+  const int e = a + per < len ? a + per : len;
+  *slen = e > *s0 ? e - *s0 : 0;
 }
 
-__global__ __launch_bounds__(EDC_THREADS) void k_edc_loss(const float* __restrict__ x, int ld,
-                                                          int start, int len,
-                                                          const float* __restrict__ Tdb,
-                                                          const float* __restrict__ maskw,
-                                                          float inv_count, float gscale,
-                                                          float* __restrict__ loss_item,
-                                                          float* __restrict__ gx) {
+// segsum[b][seg] = sum of x^2 over the segment
+__global__ __launch_bounds__(EDC_THREADS) void k_edc_segsum(const float* __restrict__ x, int ld,
+                                                            int start, int len,
+                                                            float* __restrict__ segsum) {
+  __shared__ float s_red[16];
+  const int seg = blockIdx.x, b = blockIdx.y;
+  int s0, sl;
+  edc_segment(len, seg, &s0, &sl);
+  const float* xw = x + (size_t)b * ld + start + s0;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < sl; i += blockDim.x) acc += xw[i] * xw[i];
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) segsum[b * EDC_NSEG + seg] = acc;
+}
+
+__device__ __forceinline__ float later_segments(const float* segsum, int b, int seg) {
+  float c = 0.f;
+  for (int s2 = EDC_NSEG - 1; s2 > seg; --s2) c += segsum[b * EDC_NSEG + s2];
+  return c;
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void k_edc_target(const float* __restrict__ x, int ld,
+                                                            int start, int len,
+                                                            const float* __restrict__ segsum,
+                                                            float* __restrict__ Tdb) {
+  __shared__ float s_scan[16 * EDC_S];
+  const int seg = blockIdx.x, b = blockIdx.y;
+  int s0, sl;
+  edc_segment(len, seg, &s0, &sl);
+  const float* xw = x + (size_t)b * ld + start + s0;
+  float* t = Tdb + (size_t)b * len + s0;
+  edc_scan(sl, later_segments(segsum, b, seg), s_scan,
+           [&](int j) { const float v = xw[sl - 1 - j]; return v * v; },
+           [&](int j, float edc, float) { t[sl - 1 - j] = db_pow(edc); });
+}
+
+// work layout: segsum[B][NSEG] | partial[B][NSEG] | gsum[B][NSEG]
+__global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __restrict__ x, int ld,
+                                                             int start, int len,
+                                                             const float* __restrict__ Tdb,
+                                                             const float* __restrict__ maskw,
+                                                             float inv_count, float gscale,
+                                                             float* __restrict__ work,
+                                                             float* __restrict__ gx, int batch) {
   __shared__ float s_scan[16 * EDC_S];
   __shared__ float s_red[16];
-  const int b = blockIdx.x;
-  const float* xw = x + (size_t)b * ld + start;
-  const float* t = Tdb + (size_t)b * len;
-  float* gw = gx ? gx + (size_t)b * ld + start : nullptr;
-  float acc = 0.f;
-  edc_scan(len, s_scan,
-           [&](int j) { const float v = xw[len - 1 - j]; return v * v; },
+  const int seg = blockIdx.x, b = blockIdx.y;
+  const float* segsum = work;
+  float* partial = work + (size_t)batch * EDC_NSEG;
+  float* gsum = partial + (size_t)batch * EDC_NSEG;
+  int s0, sl;
+  edc_segment(len, seg, &s0, &sl);
+  const float* xw = x + (size_t)b * ld + start + s0;
+  const float* t = Tdb + (size_t)b * len + s0;
+  const float* mw = maskw ? maskw + s0 : nullptr;
+  float* gw = gx ? gx + (size_t)b * ld + start + s0 : nullptr;
+  float acc = 0.f, gacc = 0.f;
+  edc_scan(sl, later_segments(segsum, b, seg), s_scan,
+           [&](int j) { const float v = xw[sl - 1 - j]; return v * v; },
            [&](int j, float edc, float) {
-             const int i = len - 1 - j;
+             const int i = sl - 1 - j;
              const float lin = fabsf(edc) + F32_EPS;
              const float raw = 10.0f * log10f(lin);
              const float d = fmaxf(raw, -200.0f);
              const float diff = t[i] - d;
-             const float mw = maskw ? maskw[i] : 1.0f;
-             acc += mw * fabsf(diff);
+             const float m = mw ? mw[i] : 1.0f;
+             acc += m * fabsf(diff);
              if (gw) {
                const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
                const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
-               gw[i] = -sg * dE * mw * inv_count * gscale;   // dL/dEDC_i, staged in place
+               const float g = -sg * dE * m * inv_count * gscale;   // dL/dEDC_i, staged in place
+               gw[i] = g;
+               gacc += g;
              }
            });
   acc = block_sum(acc, s_red);
-  if (threadIdx.x == 0) loss_item[b] = acc * inv_count;
+  gacc = block_sum(gacc, s_red);
+  if (threadIdx.x == 0) {
+    partial[b * EDC_NSEG + seg] = acc;
+    gsum[b * EDC_NSEG + seg] = gacc;
+  }
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_bwd(const float* __restrict__ x, int ld,
+                                                             int start, int len, float inv_count,
+                                                             const float* __restrict__ work,
+                                                             float* __restrict__ loss_item,
+                                                             float* __restrict__ gx, int batch) {
+  __shared__ float s_scan[16 * EDC_S];
+  const int seg = blockIdx.x, b = blockIdx.y;
+  const float* partial = work + (size_t)batch * EDC_NSEG;
+  const float* gsum = partial + (size_t)batch * EDC_NSEG;
+  if (seg == 0 && threadIdx.x == 0) {
+    float l = 0.f;
+    for (int s2 = 0; s2 < EDC_NSEG; ++s2) l += partial[b * EDC_NSEG + s2];
+    loss_item[b] = l * inv_count;
+  }
   if (!gx) return;
+  int s0, sl;
+  edc_segment(len, seg, &s0, &sl);
+  const float* xw = x + (size_t)b * ld + start + s0;
+  float* gw = gx + (size_t)b * ld + start + s0;
+  float carry = 0.f;
+  for (int s2 = 0; s2 < seg; ++s2) carry += gsum[b * EDC_NSEG + s2];
   // EDC_i = sum_{j >= i} x_j^2  =>  dL/dx_j = 2 x_j sum_{i <= j} dL/dEDC_i   (forward prefix scan)
-  __syncthreads();
-  edc_scan(len, s_scan,
-           [&](int i) { return gw[i]; },
+  edc_scan(sl, carry, s_scan, [&](int i) { return gw[i]; },
            [&](int i, float cum, float) { gw[i] = 2.0f * xw[i] * cum; });
   // zeros outside the window
   float* g = gx + (size_t)b * ld;
-  for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = 0.f;
-  for (int i = start + len + threadIdx.x; i < ld; i += blockDim.x) g[i] = 0.f;
+  if (seg == 0)
+    for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = 0.f;
+  if (seg == EDC_NSEG - 1)
+    for (int i = start + len + threadIdx.x; i < ld; i += blockDim.x) g[i] = 0.f;
 }
 
+extern "C" size_t gfdn_edc_work_bytes(int batch) { return (size_t)3 * batch * EDC_NSEG * sizeof(float); }
+
 extern "C" int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float* T_db,
-                               void* stream) {
-  if (!x || !T_db || batch <= 0 || start < 0 || len <= 0 || start + len > ld) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_edc_target, dim3(batch), dim3(EDC_THREADS), 0, (hipStream_t)stream, x, ld,
-                     start, len, T_db);
+                               void* work, void* stream) {
+  if (!x || !T_db || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
+    return GFDN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_edc_segsum, dim3(EDC_NSEG, batch), dim3(EDC_THREADS), 0, s, x, ld, start, len,
+                     (float*)work);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_target, dim3(EDC_NSEG, batch), dim3(EDC_THREADS), 0, s, x, ld, start, len,
+                     (const float*)work, T_db);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len,
                              const float* T_db, const float* maskw, float inv_count, float gscale,
-                             float* loss_item, float* gx, void* stream) {
-  if (!x || !T_db || !loss_item || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
+                             float* loss_item, float* gx, void* work, void* stream) {
+  if (!x || !T_db || !loss_item || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
     return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_edc_loss, dim3(batch), dim3(EDC_THREADS), 0, (hipStream_t)stream, x, ld,
-                     start, len, T_db, maskw, inv_count, gscale, loss_item, gx);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
+  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, maskw, inv_count, gscale,
+                     (float*)work, gx, batch);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
+                     loss_item, gx, batch);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

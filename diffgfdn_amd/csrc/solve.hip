@@ -732,6 +732,73 @@ __global__ __launch_bounds__(64) void k_spectral_finish(const float* __restrict_
   }
 }
 
+// Scalar loss bookkeeping of one step in ONE launch (trainer.py:298-313, :473):
+//   spectral = w_spec * sum_g loss_g ;  sparsity = w_sparse * -(sum|Q_last| - n sqrt n)/(n (sqrt n - 1))
+//   out = { (spectral + sparsity) * inv_world, spectral, sparsity }
+//   gQ (G,n,n) = d out[0] / dQ : zero except the last group, -w_sparse inv_world sign(Q)/(n (sqrt n - 1))
+__global__ __launch_bounds__(256) void k_colorless_terms(const float* __restrict__ loss_g, int G,
+                                                         const float* __restrict__ Q, int n,
+                                                         float w_spec, float w_sparse, float inv_world,
+                                                         float* __restrict__ out, float* __restrict__ gQ) {
+  __shared__ float s_red[16];
+  const float* Ql = Q + (size_t)(G - 1) * n * n;
+  const float denom = (float)n * (sqrtf((float)n) - 1.0f);
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) acc += fabsf(Ql[e]);
+  acc = block_sum(acc, s_red);
+  if (gQ) {
+    for (int e = threadIdx.x; e < G * n * n; e += blockDim.x) {
+      float g = 0.f;
+      if (e >= (G - 1) * n * n) {
+        const float q = Q[e];
+        g = -w_sparse * inv_world / denom * (q > 0.f ? 1.f : (q < 0.f ? -1.f : 0.f));
+      }
+      gQ[e] = g;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float sp = 0.f;
+    for (int g = 0; g < G; ++g) sp += loss_g[g];
+    sp *= w_spec;
+    const float sparsity = w_sparse * (-(acc - (float)n * sqrtf((float)n)) / denom);
+    out[0] = (sp + sparsity) * inv_world;
+    out[1] = sp;
+    out[2] = sparsity;
+  }
+}
+
+extern "C" int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, int n, float w_spec,
+                                    float w_sparse, float inv_world, float* out3, float* gQ,
+                                    void* stream) {
+  if (!loss_g || !Q || !out3 || G <= 0 || n <= 1) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_colorless_terms, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_g, G, Q, n,
+                     w_spec, w_sparse, inv_world, out3, gQ);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// out = { wa * sum(a) + wb * sum(b), wa * sum(a), wb * sum(b) }   (either input may be NULL)
+__global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ a, float wa,
+                                                      const float* __restrict__ b, float wb, int n,
+                                                      float* __restrict__ out) {
+  float sa = 0.f, sb = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    if (a) sa += a[i];
+    if (b) sb += b[i];
+  }
+  sa = wave_sum(sa) * wa;
+  sb = wave_sum(sb) * wb;
+  if (threadIdx.x == 0) { out[0] = sa + sb; out[1] = sa; out[2] = sb; }
+}
+
+extern "C" int gfdn_weighted_sums(const float* a, float wa, const float* b, float wb, int n,
+                                  float* out3, void* stream) {
+  if ((!a && !b) || !out3 || n <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_weighted_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, a, wa, b, wb, n, out3);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
 // trainer.py:323-332: b_n, c_n /= energy_g^(1/4) for n in group g, in place
 __global__ void k_normalize_io(const float* __restrict__ energy, float* __restrict__ b,
                                float* __restrict__ c, int N, int nper) {

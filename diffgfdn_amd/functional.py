@@ -167,6 +167,30 @@ class SpectralLoss(torch.autograd.Function):
         return gS * gloss.to(gS.dtype).unsqueeze(-1), None
 
 
+class ColorlessTerms(torch.autograd.Function):
+    """(w_spec sum_g spectral_g + w_sparse sparsity(Q_last)) * inv_world and its two weighted parts
+    (trainer.py:298-313) from S (G, K) and Q (G, n, n): spectral statistics kernel + one bookkeeping
+    launch; both gradients are produced in the forward.  ``unit_grad``: the caller guarantees the
+    upstream gradient of output[0] is 1 (loss.backward() on a plain sum), which skips two rescales."""
+
+    @staticmethod
+    def forward(ctx, S, Q, asym, w_spec, w_sparse, inv_world, unit_grad):
+        need = S.requires_grad or Q.requires_grad
+        _, loss_g, gS = ops.spectral_stats(S, asym, w_spec * inv_world, want_grad=need)
+        out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need)
+        ctx.save_for_backward(gS, gQ)
+        ctx.unit_grad = unit_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gS, gQ = ctx.saved_tensors
+        if ctx.unit_grad:
+            return gS, gQ, None, None, None, None, None
+        g = gout[0]
+        return gS * g.to(gS.dtype), gQ * g, None, None, None, None, None
+
+
 class IrfftOdd(torch.autograd.Function):
     """x = torch.fft.irfft(X, n) for odd n (losses.py:207-213, :442-445)."""
 

@@ -186,6 +186,29 @@ def spectral_stats(S, asym: bool, scale: float = 1.0, want_grad: bool = True):
     return energy, loss, gS
 
 
+def colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=True):
+    """-> out3 = [(spectral + sparsity) * inv_world, spectral, sparsity], gQ (G,n,n) or None."""
+    _need_gpu(loss_g, Q)
+    loss_g, Q = _f(loss_g), _f(Q)
+    G, n, _ = Q.shape
+    out = torch.empty(3, dtype=_f32, device=Q.device)
+    gQ = torch.empty_like(Q) if want_grad else None
+    _lib.check(_lib.load().gfdn_colorless_terms(_p(loss_g), G, _p(Q), n, float(w_spec), float(w_sparse),
+                                                float(inv_world), _p(out), _p(gQ), _stream()),
+               "gfdn_colorless_terms")
+    return out, gQ
+
+
+def weighted_sums(a, wa, b, wb):
+    """-> [wa sum(a) + wb sum(b), wa sum(a), wb sum(b)] (float32, 3)."""
+    ref = a if a is not None else b
+    _need_gpu(ref)
+    out = torch.empty(3, dtype=_f32, device=ref.device)
+    _lib.check(_lib.load().gfdn_weighted_sums(_p(a), float(wa), _p(b), float(wb), ref.numel(), _p(out),
+                                              _stream()), "gfdn_weighted_sums")
+    return out
+
+
 def normalize_io(energy, b, c, G: int, nper: int):
     """In place: b[n], c[n] /= energy[group(n)]^(1/4)  (b, c float32 contiguous, N = G*nper)."""
     _need_gpu(energy, b, c)
@@ -374,7 +397,9 @@ def edc_target(x, start: int, length: int) -> torch.Tensor:
     x = _f(x)
     batch, ld = x.shape
     T_db = torch.empty((batch, length), dtype=_f32, device=x.device)
-    _lib.check(_lib.load().gfdn_edc_target(_p(x), ld, batch, start, length, _p(T_db), _stream()),
+    lib = _lib.load()
+    work = _work(lib.gfdn_edc_work_bytes(batch), x.device)
+    _lib.check(lib.gfdn_edc_target(_p(x), ld, batch, start, length, _p(T_db), _p(work), _stream()),
                "gfdn_edc_target")
     return T_db
 
@@ -388,9 +413,11 @@ def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.
     maskw = None if maskw is None else _f(maskw)
     loss_item = torch.empty(batch, dtype=_f32, device=x.device)
     gx = torch.empty_like(x) if want_grad else None
-    _lib.check(_lib.load().gfdn_edc_loss(_p(x), ld, batch, start, length, _p(T_db), _p(maskw),
-                                         float(inv_count), float(gscale), _p(loss_item), _p(gx),
-                                         _stream()), "gfdn_edc_loss")
+    lib = _lib.load()
+    work = _work(lib.gfdn_edc_work_bytes(batch), x.device)
+    _lib.check(lib.gfdn_edc_loss(_p(x), ld, batch, start, length, _p(T_db), _p(maskw),
+                                 float(inv_count), float(gscale), _p(loss_item), _p(gx), _p(work),
+                                 _stream()), "gfdn_edc_loss")
     return loss_item, gx
 
 

@@ -110,15 +110,18 @@ class _ScalarLossWithSavedGrad(torch.autograd.Function):
     """loss value + precomputed dloss/dH (saved) -> autograd node."""
 
     @staticmethod
-    def forward(ctx, H, loss_value, gH):
+    def forward(ctx, H, loss_value, gH, unit_grad=False):
         ctx.save_for_backward(gH)
         ctx.h_shape = H.shape
+        ctx.unit_grad = unit_grad
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, g):
         (gH,) = ctx.saved_tensors
-        return (gH * g).reshape(ctx.h_shape), None, None
+        if ctx.unit_grad:            # caller guarantees d(total)/d(loss) == 1: skip a pass over gH
+            return gH.reshape(ctx.h_shape), None, None, None
+        return (gH * g).reshape(ctx.h_shape), None, None, None
 
 
 def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win: int = 4096,
@@ -132,17 +135,20 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  targets: Optional[DecayTargets] = None,
                  edr_target: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  edc_target: Optional[torch.Tensor] = None,
-                 side_stream: Optional["torch.cuda.Stream"] = None
+                 side_stream: Optional["torch.cuda.Stream"] = None,
+                 unit_grad: bool = False
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
-    Returns (total, edr, edc) with total = edr_weight * edr + edc_weight * edc carrying the
-    gradient; ``edr`` / ``edc`` are detached values (trainer.py:280-288 logs them separately).
+    Returns (total, w_edr * edr, w_edc * edc) with total = their sum carrying the gradient; the two
+    parts are detached values (trainer.py:280-288 logs them separately).
     ``global_batch``: number of items the EDC mean runs over (the local batch unless the batch
     is sharded over ranks).  ``edr_target`` = (T_db, sum_abs) / ``edc_target`` = T_db
     may be passed precomputed (dataset-level store); otherwise they are derived from ``target``
     through the cache.  ``side_stream``: run the EDC kernel (one block per item, latency-bound)
-    beside the STFT -> EDR chain instead of in front of it."""
+    beside the STFT -> EDR chain instead of in front of it.  ``unit_grad``: the caller guarantees
+    that the returned total enters the final loss with weight 1 (skips one rescale of dL/dH).
+    The returned ``edr`` / ``edc`` are the WEIGHTED parts."""
     targets = targets or _default_targets
     Hb = _as_batch(H)
     B, K = Hb.shape
@@ -153,9 +159,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         # losses.py:447-451: undo sampling on a larger circle (EDR only in the reference)
         env = torch.pow(torch.tensor(1.0 / reduced_pole_radius, dtype=torch.float64, device=x.device),
                         torch.arange(K, device=x.device, dtype=torch.float64)).to(torch.float32)
-    zero = torch.zeros((), dtype=torch.float32, device=x.device)
     gx = None
-    edc_val, edr_val = zero, zero
+    li_edc = li_edr = None
     main = torch.cuda.current_stream() if x.is_cuda else None
     fork = side_stream is not None and use_edc and use_edr
     if use_edc:
@@ -169,21 +174,18 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         if fork:
             side_stream.wait_stream(main)
             with torch.cuda.stream(side_stream):
-                li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
-                edc_val = li.sum()
+                li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
                 x.record_stream(side_stream)
         else:
-            li, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
-            edc_val = li.sum()
+            li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
     if use_edr:
         T_edr, sum_abs = edr_target if edr_target is not None else targets.edr(target, win)
         xe = x if env is None else x * env
         P = ops.stft_power(xe, win)
-        li = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad)
-        edr_val = li.sum()
+        li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad)
         if fork:
             main.wait_stream(side_stream)       # gx (written by the EDC kernel) is accumulated into below
-            for t in (gx, edc_val):
+            for t in (gx, li_edc):
                 if t is not None:
                     t.record_stream(main)
         if want_grad:
@@ -194,13 +196,13 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
             else:
                 ge = ops.stft_power_bwd(xe, win, P, torch.zeros_like(x))
                 gx = gx + ge * env
-    total_val = edr_weight * edr_val + edc_weight * edc_val
+    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
     if want_grad:
         gH = ops.irfft_odd_bwd(gx, K, K)
-        total = _ScalarLossWithSavedGrad.apply(H, total_val, gH)
+        total = _ScalarLossWithSavedGrad.apply(H, sums[0], gH, unit_grad)
     else:
-        total = total_val
-    return total, edr_val.detach(), edc_val.detach()
+        total = sums[0]
+    return total, sums[1], sums[2]
 
 
 class edr_loss(nn.Module):

@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from .colorless_losses import amse_loss, group_spectral_loss, mse_loss, sparsity_loss
 from .config import CouplingMatrixType, TrainerConfig
-from .functional import OutputStage, SHToDirectional, irfft_like_torch
+from .functional import ColorlessTerms, OutputStage, SHToDirectional, irfft_like_torch
 from .hip_ops import normalize_io, spectral_stats
 from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
 from .model import DiffGFDN
@@ -299,11 +299,13 @@ class VarReceiverPosTrainer(Trainer):
                 side.wait_stream(main)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 S, _ = net.sub_fdn_group_sums(z)
-                spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
-                sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
-                    fl.group_rotations()[net.num_groups - 1])      # last group only (:305-308)
-                extra = (spectral + sparsity) / self.world_size    # position independent
-                colorless = {'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()}
+                # spectral + sparsity (last group only, :305-308), weighted, / world size (position
+                # independent terms), values and gradients in two launches
+                terms = ColorlessTerms.apply(S, fl.group_rotations(), cfg.use_asym_spectral_loss,
+                                             cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
+                                             1.0 / self.world_size, True)
+                extra = terms[0]
+                colorless = {'spectral_loss': terms[1].detach(), 'sparsity_loss': terms[2].detach()}
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
         # (measured: running the gain network on a side stream beside the solve costs +0.2 ms per step
         # in cross-stream joins of its backward -- it stays on the main stream)
@@ -339,8 +341,8 @@ class VarReceiverPosTrainer(Trainer):
             global_batch=gb,
             edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
             edc_target=None if edc_t is None else edc_t[1],
-            side_stream=self._side_stream2())
-        losses = {'edc_loss': cfg.edc_loss_weight * edc_v, 'edr_loss': cfg.edr_loss_weight * edr_v}
+            side_stream=self._side_stream2(), unit_grad=True)
+        losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
         if extra is not None:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
@@ -455,7 +457,7 @@ class SinglePosTrainer(Trainer):
             edc_weight=cfg.edc_loss_weight, edc_start=start, edc_len=length, edc_maskw=maskw,
             edc_count=count,
             reduced_pole_radius=None if self.reduced_pole_radius == 1.0 else self.reduced_pole_radius)
-        losses = {'edc_loss': cfg.edc_loss_weight * edc_v, 'edr_loss': cfg.edr_loss_weight * edr_v}
+        losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
         if self.use_colorless_loss:
             S = H_sub[0].T.contiguous()
             spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)

@@ -115,6 +115,16 @@ size_t gfdn_spectral_stats_work_bytes(int G, int K);
 int gfdn_spectral_stats(const float* S_c64, int G, int K, int asym, float scale,
                         float* energy, float* loss, float* gS_c64, void* work, void* stream);
 
+/* Scalar loss bookkeeping of one step (trainer.py:298-313): loss_g (G) per-group spectral losses,
+ * Q (G,n,n) rotations.  out3 = { (w_spec sum_g loss_g + sparsity) * inv_world, w_spec sum_g loss_g,
+ * sparsity } with sparsity = w_sparse * sparsity_loss(Q[G-1]) (colorless_fdn/losses.py:7-17; only the
+ * last group counts, trainer.py:305-308).  gQ (G,n,n), optional: d out3[0] / dQ.              */
+int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, int n, float w_spec,
+                         float w_sparse, float inv_world, float* out3, float* gQ, void* stream);
+/* out3 = { wa sum(a) + wb sum(b), wa sum(a), wb sum(b) } over n items (a or b may be NULL).  */
+int gfdn_weighted_sums(const float* a, float wa, const float* b, float wb, int n, float* out3,
+                       void* stream);
+
 /* Energy normalisation of the input / output gains (trainer.py:317-332): for n in group g,
  * b[n] /= energy[g]^(1/4), c[n] /= energy[g]^(1/4), in place (float32, N = G * nper).        */
 int gfdn_normalize_io(const float* energy, float* b, float* c, int G, int nper, void* stream);
@@ -185,11 +195,12 @@ int gfdn_stft_power_bwd(const float* x, int ld, int T, int batch, int win, const
  * inv_count = 1 / (global batch * number of kept indices).
  * loss_item[b] = inv_count * sum_i maskw_i |T_db - EDC_db|; gx (batch, ld), when not NULL,
  * is fully overwritten with gscale * dloss/dx (zeros outside the window).                 */
+size_t gfdn_edc_work_bytes(int batch);
 int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float* T_db,
-                    void* stream);
+                    void* work, void* stream);
 int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const float* T_db,
                   const float* maskw, float inv_count, float gscale, float* loss_item,
-                  float* gx, void* stream);
+                  float* gx, void* work, void* stream);
 
 /* ---- receiver-position -> group-gain network  (gain_filters.py:497-534; dnn.py:89-126, :331-400,
  * :21-36).  pos (B,3) float64 normalised coordinates; freq_pi (F) float32 = f32(freq_k * pi);

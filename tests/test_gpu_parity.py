@@ -344,7 +344,7 @@ def test_full_size_forward_and_losses_vs_oracle():
         assert rel_err(Hout.detach().cpu(), Houto) < TOL
         l_edr = orc.edr_loss(batch["target_rir_response"], Ho)
         l_edc = orc.edc_loss(batch["target_rir_response"], Ho, orc.ms_to_samps(1500.0, 32000.0), 640)
-    total, edr_v, edc_v = decay_losses(H, dbatch["target_rir_response"], edc_start=640, edc_len=48000 - 640)
+    total, edr_v, edc_v = decay_losses(H, dbatch["target_rir_response"], edc_start=640, edc_len=48000 - 640)  # weights 1
     assert abs(edr_v.item() - l_edr.item()) < TOL * abs(l_edr.item())
     assert abs(edc_v.item() - l_edc.item()) < TOL * abs(l_edc.item())
     total.backward()
