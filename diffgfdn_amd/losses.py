@@ -183,19 +183,21 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         xe = x if env is None else x * env
         P = ops.stft_power(xe, win)
         li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad)
+        g_edr = None
+        if want_grad:
+            # the STFT adjoint scatters exactly two frame terms per sample with atomic adds into a
+            # ZEROED buffer (a + b commutes -> order independent, bitwise reproducible); adding it
+            # onto the EDC gradient afterwards keeps the three-term sum in a fixed order
+            g_edr = ops.stft_power_bwd(xe, win, P, torch.zeros_like(x))
+            if env is not None:
+                g_edr = g_edr * env
         if fork:
-            main.wait_stream(side_stream)       # gx (written by the EDC kernel) is accumulated into below
+            main.wait_stream(side_stream)
             for t in (gx, li_edc):
                 if t is not None:
                     t.record_stream(main)
         if want_grad:
-            if gx is None:
-                gx = torch.zeros_like(x)
-            if env is None:
-                ops.stft_power_bwd(xe, win, P, gx)
-            else:
-                ge = ops.stft_power_bwd(xe, win, P, torch.zeros_like(x))
-                gx = gx + ge * env
+            gx = g_edr if gx is None else gx.add_(g_edr)
     sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
     if want_grad:
         gH = ops.irfft_odd_bwd(gx, K, K)

@@ -512,8 +512,12 @@ class GraphedTrainStep:
         self.idx = torch.zeros(batch_size, dtype=torch.long, device=dev)
         self.maskw = torch.full((self.length,), 1.0 / (self.gb * self.length), dtype=torch.float32,
                                 device=dev)
-        self._host_mask = torch.empty(self.length, dtype=torch.float32).pin_memory()
-        self._host_idx = torch.empty(batch_size, dtype=torch.long).pin_memory()
+        # ring of pinned staging buffers: the async H2D copy of step i is only executed when the
+        # stream reaches it, so its source must not be rewritten by the host preparing step i+1
+        self._ring = [(torch.empty(self.length, dtype=torch.float32).pin_memory(),
+                       torch.empty(batch_size, dtype=torch.long).pin_memory(), torch.cuda.Event())
+                      for _ in range(4)]
+        self._ring_pos = 0
         self.graph_a = self.graph_b = None
         self.losses = None
 
@@ -583,8 +587,11 @@ class GraphedTrainStep:
 
     def _load_inputs(self, indices):
         tr = self.tr
-        self._host_idx.copy_(torch.as_tensor(list(indices), dtype=torch.long))
-        self.idx.copy_(self._host_idx, non_blocking=True)
+        host_mask, host_idx, ev = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        ev.synchronize()                     # the copies that last used this slot have executed
+        host_idx.copy_(torch.as_tensor(list(indices), dtype=torch.long))
+        self.idx.copy_(host_idx, non_blocking=True)
         crit = tr.criterion[1]
         if crit.use_mask:
             keep = torch.bernoulli(torch.empty(self.length).uniform_(0, 1))
@@ -595,8 +602,9 @@ class GraphedTrainStep:
                 cnt = keep.sum()
                 self.maskw.copy_(keep / (cnt * self.gb))
             else:
-                self._host_mask.copy_(keep / (float(keep.sum()) * self.gb))
-                self.maskw.copy_(self._host_mask, non_blocking=True)
+                torch.div(keep, float(keep.sum()) * self.gb, out=host_mask)
+                self.maskw.copy_(host_mask, non_blocking=True)
+        ev.record()
 
     def __call__(self, indices):
         """Run one optimiser step on the receivers ``indices``; returns the static loss tensors

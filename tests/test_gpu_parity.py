@@ -479,3 +479,34 @@ def test_band_recombination_filter():
     ref = np.stack([fftconvolve(h[i], taps, mode="full") for i in range(3)])
     assert y.shape == ref.shape
     assert rel_err(y.cpu(), ref) < 1e-5
+
+
+def test_split_graph_path_used_for_data_parallel():
+    """The N > 1 step replays TWO graphs with the (eager) all-reduce of the flat gradient buffer in
+    between.  Exercised here on one GPU with a stand-in all-reduce that doubles the gradients (what
+    a 2-rank sum of identical shards would give): parameters must follow Adam on 2 x grad, and must
+    equal the single-graph path when the stand-in is the identity."""
+    from diffgfdn_amd.config import TrainerConfig
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
+    from diffgfdn_amd.synthetic import synthetic_room
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    fx = load("f234_n12_k257.npz")
+    room = synthetic_room(8, 3, 2000.0, 400, seed=5)
+    ds = MultiRIRDataset(DEV, RoomDataset(3, 2000.0, room["source_position"], room["receiver_position"],
+                                          room["rirs"], room["common_decay_times"], nfft=512, device=DEV))
+    tc = TrainerConfig(batch_size=4, num_freq_bins=512, lr=1e-3, io_lr=1e-2, use_colorless_loss=True,
+                       use_asym_spectral_loss=True, edc_loss_weight=10.0, sparsity_loss_weight=2.0,
+                       use_edc_mask=False, train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a", device="cuda")
+    out = {}
+    for mode in ("single", "split_identity"):
+        net = _grid_model(fx)
+        tr = VarReceiverPosTrainer(net, tc, stft_win=64, capturable=True)
+        if mode != "single":
+            tr._allreduce = lambda: None                      # identity "all-reduce" -> two graphs
+        step = tr.graphed(ds, 4).capture([0, 1, 2, 3])
+        assert (step.graph_b is not None) == (mode != "single")
+        vals = [float(step(sel)["_total"]) for sel in ([0, 1, 2, 3], [4, 5, 6, 7])]
+        out[mode] = (vals, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    assert out["single"][0] == out["split_identity"][0]
+    for k, v in out["single"][1].items():
+        assert torch.equal(v, out["split_identity"][1][k]), k
