@@ -155,8 +155,8 @@ def cpu_baseline(room, delays, filt_np, steps: int = 2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--cpu-steps', type=int, default=2)

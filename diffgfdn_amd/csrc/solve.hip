@@ -327,6 +327,20 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
 // output stage
 // ------------------------------------------------------------------------------------------
 #define COMPOSE_BCH 8
+extern __shared__ float2 compose_lds[];
+
+// Y tile of 256 bins x N delay lines -> LDS rows of N+1 (global side strictly linear: the per-thread
+// 128-byte rows of the bin-major layout would otherwise be read 8 bytes at a time across 64 lines)
+__device__ __forceinline__ void load_bin_tile(const float2* __restrict__ Y, int k0, int K, int N,
+                                              float2* tile) {
+  const size_t base = (size_t)k0 * N;
+  const int lim = (K - k0 < 256 ? K - k0 : 256) * N;
+  for (int e = threadIdx.x; e < 256 * N; e += 256) {
+    const int kk = e / N, n = e - kk * N;
+    tile[kk * (N + 1) + n] = e < lim ? Y[base + e] : make_float2(0.f, 0.f);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ Y, int K, int G,
                                                      int nper, const float* __restrict__ c,
                                                      const float* __restrict__ rgain, int B,
@@ -334,41 +348,55 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
                                                      const float2* __restrict__ filt,
                                                      float2* __restrict__ H, int ldh,
                                                      float2* __restrict__ S_out) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
   const int N = G * nper;
+  const int k0 = blockIdx.x * 256;
+  load_bin_tile(Y, k0, K, N, compose_lds);
+  __syncthreads();
+  const int k = k0 + threadIdx.x;
+  if (k >= K) return;
+  const float2* yrow = compose_lds + threadIdx.x * (N + 1);
   float2 S[GFDN_MAX_GROUPS];
 #pragma unroll
   for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
     S[g] = make_float2(0.f, 0.f);
     if (g < G) {
       for (int i = 0; i < nper; ++i) {
-        float2 y = Y[(size_t)k * N + g * nper + i];
-        float cc = c[g * nper + i];
+        const float2 y = yrow[g * nper + i];
+        const float cc = c[g * nper + i];
         S[g].x += cc * y.x;
         S[g].y += cc * y.y;
       }
       if (S_out && blockIdx.y == 0) S_out[(size_t)g * K + k] = S[g];
     }
   }
-  float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
+  const float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
   const int b0 = blockIdx.y * COMPOSE_BCH;
+  float2 d[COMPOSE_BCH];
+#pragma unroll
+  for (int bb = 0; bb < COMPOSE_BCH; ++bb) {       // all loads of the chunk in flight together
+    const int b = b0 + bb;
+    d[bb] = (direct && b < B) ? direct[(size_t)b * ldd + k] : make_float2(0.f, 0.f);
+  }
+#pragma unroll
   for (int bb = 0; bb < COMPOSE_BCH; ++bb) {
     const int b = b0 + bb;
-    if (b >= B) break;
-    float2 h = direct ? direct[(size_t)b * ldd + k] : make_float2(0.f, 0.f);
+    if (b < B) {
+      float2 h = d[bb];
 #pragma unroll
-    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
-      if (g < G) {
-        float rg = rgain[b * G + g];
-        h.x += rg * S[g].x;
-        h.y += rg * S[g].y;
+      for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+        if (g < G) {
+          const float rg = rgain[b * G + g];
+          h.x += rg * S[g].x;
+          h.y += rg * S[g].y;
+        }
       }
+      if (filt) h = cmul(h, f);
+      H[(size_t)b * ldh + k] = h;
     }
-    if (filt) h = cmul(h, f);
-    H[(size_t)b * ldh + k] = h;
   }
 }
+
+static size_t compose_tile_bytes(int N) { return (size_t)256 * (N + 1) * sizeof(float2); }
 
 extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const float* c,
                                 const float* rgain, int B, const float* direct, int ldd,
@@ -378,7 +406,10 @@ extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const fl
   if (G > GFDN_MAX_GROUPS) return GFDN_E_UNSUPPORTED;
   if (ldh < K || (direct && ldd < K)) return GFDN_E_BADARG;
   dim3 grid((K + 255) / 256, (B + COMPOSE_BCH - 1) / COMPOSE_BCH);
-  hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), 0, (hipStream_t)stream, (const float2*)Y, K,
+  if (G * nper > 128) return GFDN_E_UNSUPPORTED;
+  int rc = ensure_dyn_lds(k_compose_fwd, compose_tile_bytes(G * nper));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), compose_tile_bytes(G * nper), (hipStream_t)stream, (const float2*)Y, K,
                      G, nper, c, rgain, B, (const float2*)direct, ldd, (const float2*)filt,
                      (float2*)H, ldh, (float2*)S_out);
   GFDN_LAUNCH_CHECK();
@@ -386,7 +417,11 @@ extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const fl
 }
 
 // gS[g][k] = sum_b rgain[b][g] conj(filt_k) gH[b][k];  gY[k][n] = c_n gS[g(n)][k];
-// gc partial[blockIdx.x][n] = sum_{k in block} Re(conj(gS) Y);  S[g][k] stored for pass B.
+// gc partial[block][n] = sum_{k in block} Re(conj(gS) Y);  S[g][k] stored for pass B.
+// One block = 64 bins: the receiver loop is split over the 4 wavefronts (fixed-order fold in LDS),
+// then all 256 threads sweep the 64 x N tile of Y / gY in linear (coalesced) order.  PMC on the
+// first version (thread per bin, 8-byte row accesses, 256 blocks) showed 2x write traffic.
+#define CBT 64
 __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict__ Y, int K, int G,
                                                        int nper, const float* __restrict__ c,
                                                        const float* __restrict__ rgain, int B,
@@ -395,53 +430,78 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
                                                        float2* __restrict__ gY,
                                                        float2* __restrict__ S_work,
                                                        float* __restrict__ gc_partial) {
-  __shared__ float s_gc[4][64];
+  __shared__ float2 s_gS[4][GFDN_MAX_GROUPS][CBT];
   const int N = G * nper;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int e = threadIdx.x; e < 4 * 64; e += 256) (&s_gc[0][0])[e] = 0.f;
-  __syncthreads();
-  for (int k0 = blockIdx.x * 256; k0 < K; k0 += gridDim.x * 256) {
-    const int k = k0 + threadIdx.x;
-    const bool valid = k < K;
-    const int kk = valid ? k : K - 1;
-    float2 gS[GFDN_MAX_GROUPS];
+  float2* cy = compose_lds;                 // [CBT][N] : c_n * Y
+  float* vt = (float*)(cy + CBT * N);       // [CBT][N] : Re(conj(gS) Y)
+  const int kx = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * CBT;
+  const int k = k0 + kx;
+  const int kk = k < K ? k : K - 1;
+  {
+    float2 acc[GFDN_MAX_GROUPS];
 #pragma unroll
-    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) gS[g] = make_float2(0.f, 0.f);
-    float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
-    for (int b = 0; b < B; ++b) {
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) acc[g] = make_float2(0.f, 0.f);
+    const float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
+#pragma unroll 4
+    for (int b = bg; b < B; b += 4) {
       float2 gh = gH[(size_t)b * ldh + kk];
       if (filt) gh = cmul(gh, fc);
 #pragma unroll
       for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
         if (g < G) {
-          float rg = rgain[b * G + g];
-          gS[g].x += rg * gh.x;
-          gS[g].y += rg * gh.y;
+          const float rg = rgain[b * G + g];
+          acc[g].x += rg * gh.x;
+          acc[g].y += rg * gh.y;
         }
       }
     }
 #pragma unroll
-    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
-      if (g < G) {
-        float2 Sg = make_float2(0.f, 0.f);
-        for (int i = 0; i < nper; ++i) {
-          const int n = g * nper + i;
-          float2 y = Y[(size_t)kk * N + n];
-          float cc = c[n];
-          Sg.x += cc * y.x;
-          Sg.y += cc * y.y;
-          if (valid) gY[(size_t)k * N + n] = cscale(gS[g], cc);
-          float v = valid ? (gS[g].x * y.x + gS[g].y * y.y) : 0.f;
-          v = wave_sum(v);
-          if (lane == 0) s_gc[wv][n] += v;   // one writer per (wave, n): deterministic
-        }
-        if (valid) S_work[(size_t)g * K + k] = Sg;
-      }
-    }
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g)
+      if (g < G) s_gS[bg][g][kx] = acc[g];
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < N; n += 256)
-    gc_partial[(size_t)blockIdx.x * N + n] = s_gc[0][n] + s_gc[1][n] + s_gc[2][n] + s_gc[3][n];
+  for (int idx = threadIdx.x; idx < G * CBT; idx += 256) {
+    const int g = idx / CBT, x = idx - g * CBT;
+    float2 t = s_gS[0][g][x];
+    t = cadd(t, s_gS[1][g][x]);
+    t = cadd(t, s_gS[2][g][x]);
+    t = cadd(t, s_gS[3][g][x]);
+    s_gS[0][g][x] = t;
+  }
+  __syncthreads();
+  const size_t base = (size_t)k0 * N;
+  const int nb = K - k0 < CBT ? K - k0 : CBT;
+  const int lim = nb * N;
+  for (int e = threadIdx.x; e < CBT * N; e += 256) {
+    const int kq = e / N, n = e - kq * N;
+    float v = 0.f;
+    float2 cyv = make_float2(0.f, 0.f);
+    if (e < lim) {
+      const float2 y = Y[base + e];
+      const float2 gs = s_gS[0][n / nper][kq];
+      const float cc = c[n];
+      gY[base + e] = cscale(gs, cc);
+      v = gs.x * y.x + gs.y * y.y;
+      cyv = cscale(y, cc);
+    }
+    vt[e] = v;
+    cy[e] = cyv;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * CBT; idx += 256) {     // S[g][k] = sum_{n in g} c_n Y[k][n]
+    const int g = idx / CBT, x = idx - g * CBT;
+    if (x < nb) {
+      float2 sg = make_float2(0.f, 0.f);
+      for (int i = 0; i < nper; ++i) sg = cadd(sg, cy[x * N + g * nper + i]);
+      S_work[(size_t)g * K + k0 + x] = sg;
+    }
+  }
+  for (int n = threadIdx.x; n < N; n += 256) {                 // fixed-order column sums
+    float sacc = 0.f;
+    for (int x = 0; x < CBT; ++x) sacc += vt[x * N + n];
+    gc_partial[(size_t)blockIdx.x * N + n] = sacc;
+  }
 }
 
 // grgain[b][g] = sum_k Re(conj(gH'[b][k]) S[g][k]),  gH' = conj(filt) gH.
@@ -486,13 +546,14 @@ __global__ __launch_bounds__(64) void k_sum_rows(const float* __restrict__ part,
   if (threadIdx.x == 0) out[r] = s;
 }
 
-static size_t compose_partial_bytes(int G, int nper) {
-  return (size_t)GFDN_PARTIAL_BLOCKS * G * nper * sizeof(float);
+static size_t compose_partial_bytes(int K, int G, int nper) {
+  const size_t b = (size_t)((K + CBT - 1) / CBT) * G * nper * sizeof(float);
+  return (b + 15) & ~(size_t)15;           // the complex S copy that follows must stay aligned
 }
 // gc partial slots followed by a (G, K) complex copy of S for the second pass
 extern "C" size_t gfdn_compose_bwd_work_bytes(int K, int G, int nper, int B) {
   const size_t nchunk = (size_t)(K + 1023) / 1024;
-  return compose_partial_bytes(G, nper) + (size_t)G * K * sizeof(float2) +
+  return compose_partial_bytes(K, G, nper) + (size_t)G * K * sizeof(float2) +
          (size_t)B * G * nchunk * sizeof(float);
 }
 
@@ -505,13 +566,15 @@ extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const fl
   if (G > GFDN_MAX_GROUPS || G * nper > 64) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int N = G * nper;
-  int nparts = (K + 255) / 256;
-  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  const int nparts = (K + CBT - 1) / CBT;
   float* gc_partial = (float*)work;
-  float2* S_work = (float2*)((char*)work + compose_partial_bytes(G, nper));
-  hipLaunchKernelGGL(k_compose_bwd_a, dim3(nparts), dim3(256), 0, s, (const float2*)Y, K, G, nper,
-                     c, rgain, B, (const float2*)filt, (const float2*)gH, ldh, (float2*)gY, S_work,
-                     gc_partial);
+  float2* S_work = (float2*)((char*)work + compose_partial_bytes(K, G, nper));
+  const size_t lds = (size_t)CBT * N * (sizeof(float2) + sizeof(float));
+  int rc = ensure_dyn_lds(k_compose_bwd_a, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compose_bwd_a, dim3(nparts), dim3(256), lds, s, (const float2*)Y,
+                     K, G, nper, c, rgain, B, (const float2*)filt, (const float2*)gH, ldh, (float2*)gY,
+                     S_work, gc_partial);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, gc_partial, nparts, N, gc);
   GFDN_LAUNCH_CHECK();
