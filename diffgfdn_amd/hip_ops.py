@@ -113,12 +113,19 @@ def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False):
     K, N = Y.shape
     B, G = rgain.shape
     assert G * nper == N
-    direct = None if direct is None else _c(direct)
+    ldd = 0
+    if direct is not None:
+        direct = direct.detach()
+        # a row-strided view (e.g. the first K bins of longer rows) is consumed in place
+        if not (direct.dtype == _c64 and direct.dim() == 2 and direct.stride(1) == 1
+                and direct.stride(0) >= K and direct.shape[1] >= K):
+            direct = _c(direct)
+        ldd = direct.stride(0)
     filt = None if filt is None else _c(filt)
     H = torch.empty((B, K), dtype=_c64, device=Y.device)
     S = torch.empty((G, K), dtype=_c64, device=Y.device) if want_S else None
     _lib.check(_lib.load().gfdn_compose_fwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(direct),
-                                            K if direct is not None else 0, _p(filt), _p(H), K,
+                                            ldd, _p(filt), _p(H), K,
                                             _p(S), _stream()), "gfdn_compose_fwd")
     return (H, S) if want_S else H
 

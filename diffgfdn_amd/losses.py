@@ -136,7 +136,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  edr_target: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  edc_target: Optional[torch.Tensor] = None,
                  side_stream: Optional["torch.cuda.Stream"] = None,
-                 unit_grad: bool = False
+                 unit_grad: bool = False, n_time: Optional[int] = None
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
@@ -148,10 +148,15 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     through the cache.  ``side_stream``: run the EDC kernel (one block per item, latency-bound)
     beside the STFT -> EDR chain instead of in front of it.  ``unit_grad``: the caller guarantees
     that the returned total enters the final loss with weight 1 (skips one rescale of dL/dH).
-    The returned ``edr`` / ``edc`` are the WEIGHTED parts."""
+    The returned ``edr`` / ``edc`` are the WEIGHTED parts.  ``n_time``: length of the time response
+    (= number of bins K of the full grid); H may then hold only the (K+1)/2 bins the transform
+    irfft(X, n = K) actually reads."""
     targets = targets or _default_targets
     Hb = _as_batch(H)
-    B, K = Hb.shape
+    B, ldx = Hb.shape
+    K = ldx if n_time is None else n_time
+    if ldx < (K + 1) // 2:
+        raise ValueError("H holds fewer bins than irfft(X, n) reads")
     want_grad = H.requires_grad and torch.is_grad_enabled()
     x = ops.irfft_odd_fwd(Hb, K)
     env = None
@@ -200,7 +205,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
             gx = g_edr if gx is None else gx.add_(g_edr)
     sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
     if want_grad:
-        gH = ops.irfft_odd_bwd(gx, K, K)
+        gH = ops.irfft_odd_bwd(gx, K, ldx)
         total = _ScalarLossWithSavedGrad.apply(H, sums[0], gH, unit_grad)
     else:
         total = sums[0]

@@ -310,10 +310,17 @@ class VarReceiverPosTrainer(Trainer):
         # (measured: running the gain network on a side stream beside the solve costs +0.2 ms per step
         # in cross-stream joins of its backward -- it stays on the main stream)
         rgain = net.output_scalars.group_gains(data)
-        Y = net.delay_line_responses(z)
+        # the decay losses transform H with irfft(H, n = K) (losses.py:207-213, :442-445), which reads
+        # bins 0..(K-1)/2 only: the main branch of the TRAINING step is evaluated on those bins alone
+        # (solve, output stage and their backward do half the work; losses and gradients are the
+        # same numbers -- the upper bins have exactly zero gradient)
+        K = z.shape[-1]
+        Ku = (K + 1) // 2 if K % 2 == 1 else K
+        zu = z[:Ku]
+        Y = net.delay_line_responses(zu)
         H = OutputStage.apply(Y, net.output_gains.reshape(-1), rgain.to(torch.float32), n,
-                              data['target_early_response'], filt)
-        K = H.shape[-1]
+                              data['target_early_response'][:, :Ku],
+                              None if filt is None else filt[:Ku])
         start, length = self._decay_window(K)
         B = H.shape[0]
         gb = B
@@ -341,7 +348,7 @@ class VarReceiverPosTrainer(Trainer):
             global_batch=gb,
             edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
             edc_target=None if edc_t is None else edc_t[1],
-            side_stream=self._side_stream2(), unit_grad=True)
+            side_stream=self._side_stream2(), unit_grad=True, n_time=K)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
         if extra is not None:
             if side is not None:
