@@ -12,6 +12,11 @@
 //        k_blu_row     : FFT over n2, * chirp spectrum, inverse FFT over k2, conj twiddle
 //        k_blu_col_inv : inverse FFT over k1, de-chirp, real part / adjoint epilogue
 //     The adjoint (backward) runs the same three kernels with conjugated chirps.
+//     When n is a Fermat prime (n - 1 = 2^m: 17, 257, 65 537 -- the north-star K) Rader's algorithm
+//     is used instead: with g = 3 a primitive root, x[g^-b] = (X'_0 + sum_a Y[g^a] w^(g^(a-b)))/n is a
+//     cyclic correlation of length n - 1 = 2^16, HALF the one-sided Bluestein length, run by the very
+//     same kernels with a gather (k = g^a) in front and a scatter (t = g^-b) behind; the adjoint
+//     multiplies by conj(chat) (-1)^f and swaps the roles of the two index tables.
 // (2) |STFT|^2 with a periodic Hann window, hop = win/2, center = False (losses.py:501-535):
 //     two real frames are packed into one complex FFT held in LDS; the adjoint recomputes
 //     the frame spectra and scatters window * gradient with atomic adds (two frames per
@@ -169,6 +174,10 @@ __device__ __forceinline__ float2 tw2(const float2* hi, const float2* lo, int e,
 // ------------------------------------------------------------------------------------------
 // Bluestein geometry + host-side table construction
 // ------------------------------------------------------------------------------------------
+#define BLU_TC 8      // columns per tile of the column passes
+#define BLU_TR 4      // rows per block of the generic row pass
+#define COL_IT 8      // load iterations issued together in the column passes
+
 struct BluGeom {
   int n, nin, L, L1, L2;
 };
@@ -182,6 +191,44 @@ static BluGeom blu_geom(int n) {
   int p = ilog2(L);
   g.L1 = 1 << (p / 2);
   g.L2 = L / g.L1;
+  return g;
+}
+
+// Rader applies when n is prime with n - 1 a power of two (Fermat primes) and 3 is a primitive root
+static unsigned long long mulmod(unsigned long long a, unsigned long long b, unsigned long long m) {
+  return (a * b) % m;   // operands < 2^17: no overflow
+}
+static unsigned long long powmod(unsigned long long b, unsigned long long e, unsigned long long m) {
+  unsigned long long r = 1 % m;
+  b %= m;
+  while (e) {
+    if (e & 1) r = mulmod(r, b, m);
+    b = mulmod(b, b, m);
+    e >>= 1;
+  }
+  return r;
+}
+static bool rader_ok(int n) {
+  if (n < 17 || n > 65537) return false;
+  const int N = n - 1;
+  if (N & (N - 1)) return false;
+  for (int d = 3; d * d <= n; d += 2)
+    if (n % d == 0) return false;
+  return powmod(3, (unsigned long long)N / 2, (unsigned long long)n) == (unsigned long long)(n - 1);
+}
+static BluGeom rader_geom(int n) {
+  BluGeom g;
+  g.n = n;
+  g.nin = (n - 1) / 2 + 1;
+  g.L = n - 1;
+  if (g.L >= 32768) {
+    g.L2 = 512;                       // the wave-per-row kernel
+    g.L1 = g.L / 512;
+  } else {
+    const int p = ilog2(g.L);
+    g.L1 = 1 << (p / 2);
+    g.L2 = g.L / g.L1;
+  }
   return g;
 }
 
@@ -208,19 +255,55 @@ static void host_fft(std::vector<std::complex<double>>& a) {  // in-place radix-
 
 extern "C" size_t gfdn_bluestein_table_bytes(int n) {
   if (n < 3 || (n & 1) == 0) return 0;
+  if (rader_ok(n)) return (size_t)(n - 1) * (sizeof(float2) + 2 * sizeof(int));
   BluGeom g = blu_geom(n);
   return ((size_t)g.n + (size_t)g.L) * sizeof(float2);
 }
 
 extern "C" size_t gfdn_bluestein_work_bytes(int n, int batch) {
   if (n < 3 || (n & 1) == 0 || batch <= 0) return 0;
-  BluGeom g = blu_geom(n);
-  return (size_t)batch * g.L * sizeof(float2);
+  BluGeom g = rader_ok(n) ? rader_geom(n) : blu_geom(n);
+  const int tc = g.L2 < BLU_TC ? g.L2 : BLU_TC;
+  return (size_t)batch * g.L * sizeof(float2) + (size_t)batch * (g.L2 / tc) * sizeof(float);
+}
+
+// Rader table = [ chat[k1*L2 + k2] = FFT_N(v_rev)[k1 + L1 k2], v[c] = exp(2 pi i g^c / n) | perm | iperm ]
+static int rader_table_init(int n, void* table) {
+  BluGeom g = rader_geom(n);
+  const int N = g.L;
+  std::vector<int> perm(N), iperm(N);
+  unsigned long long v = 1;
+  for (int a = 0; a < N; ++a) {
+    perm[a] = (int)v;
+    v = mulmod(v, 3, (unsigned long long)n);
+  }
+  for (int b = 0; b < N; ++b) iperm[b] = perm[(N - b) % N];      // g^-b = g^(N-b)
+  std::vector<std::complex<double>> ker(N);
+  for (int c = 0; c < N; ++c) {
+    const double ang = 2.0 * M_PI * (double)perm[(N - c) % N] / (double)n;   // v_rev[c] = v[-c]
+    ker[c] = std::complex<double>(cos(ang), sin(ang));
+  }
+  host_fft(ker);
+  std::vector<float2> chat(N);
+  for (int k1 = 0; k1 < g.L1; ++k1)
+    for (int k2 = 0; k2 < g.L2; ++k2) {
+      const std::complex<double> q = ker[(size_t)k1 + (size_t)g.L1 * k2];
+      chat[(size_t)k1 * g.L2 + k2] = make_float2((float)q.real(), (float)q.imag());
+    }
+  char* t = (char*)table;
+  hipError_t e = hipMemcpy(t, chat.data(), (size_t)N * sizeof(float2), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpy(t + (size_t)N * sizeof(float2), perm.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpy(t + (size_t)N * (sizeof(float2) + sizeof(int)), iperm.data(), (size_t)N * sizeof(int),
+                hipMemcpyHostToDevice);
+  return (int)e;
 }
 
 // table = [ chirp w_t = exp(+i pi t^2 / n), t < n | chat[k1*L2 + k2] = FFT_L(conj chirp kernel)[k1 + L1 k2] ]
 extern "C" int gfdn_bluestein_table_init(int n, void* table) {
   if (n < 3 || (n & 1) == 0 || !table) return GFDN_E_BADARG;
+  if (rader_ok(n)) return rader_table_init(n, table);
   BluGeom g = blu_geom(n);
   std::vector<float2> host((size_t)g.n + g.L);
   std::vector<std::complex<double>> ker(g.L, std::complex<double>(0.0, 0.0));
@@ -251,11 +334,14 @@ extern "C" int gfdn_bluestein_table_init(int n, void* table) {
 // ------------------------------------------------------------------------------------------
 // Bluestein kernels.  Column tile: TC adjacent columns n2, LDS layout [col][row] (stride L1+1).
 // ------------------------------------------------------------------------------------------
-#define BLU_TC 8
-#define BLU_TR 4
 
 struct BluArgs {
   BluGeom g;
+  int rader;            // 0: Bluestein (chirp-z)   1: Rader (n prime, n - 1 = L)
+  const int* perm;      // rader: perm[a]  = g^a  mod n   (spectrum index of convolution slot a)
+  const int* iperm;     // rader: iperm[b] = g^-b mod n   (time index of convolution slot b)
+  float* edge;          // rader: per-(item, column block) partial sums for the t = 0 / k = 0 terms
+  int nedge;            // rader: partials per item
   const float2* chirp;  // n
   const float2* chat;   // L, [k1][k2]
   float2* work;         // batch * L
@@ -270,6 +356,7 @@ struct BluArgs {
 extern __shared__ float2 dyn_lds[];
 
 __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
+  __shared__ float s_edge[16];
   const BluGeom g = a.g;
   const int L1 = g.L1, L2 = g.L2, L = g.L;
   const int tc = L2 < BLU_TC ? L2 : BLU_TC;
@@ -282,25 +369,54 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
   build_tw4(tw4, L1);
   build_tw2(thi, tlo, L);
-  // load + chirp
-  for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
-    const int n1 = idx / tc, cc = idx - n1 * tc;
-    const int t = n1 * L2 + c0 + cc;
-    float2 v = make_float2(0.f, 0.f);
-    if (!a.adjoint) {
-      if (t < g.nin) {
-        float2 X = ((const float2*)a.in)[(size_t)b * a.ld_in + t];
-        if (t == 0) X = make_float2(0.5f * X.x, 0.f);   // X'_0 = Re X_0 (factor 2 applied at the end)
-        v = cmul(X, a.chirp[t]);
-      }
-    } else {
-      if (t < g.n) {
-        float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
-        float2 w = a.chirp[t];
-        v = make_float2(gx * w.x, -gx * w.y);           // gx * conj(w_t)
+  // load (+ chirp / Rader gather).  The loads of COL_IT iterations are issued together: with a
+  // runtime trip count the compiler would serialise one (dependent) global load chain per
+  // iteration and the kernel would sit at ~1 load latency per 256 elements.
+  float edge = 0.f;                    // Rader: partial sum for the t = 0 / k = 0 terms
+  for (int base = 0; base < tc * L1; base += COL_IT * 256) {
+    float2 vals[COL_IT];
+    int slot[COL_IT];
+#pragma unroll
+    for (int it = 0; it < COL_IT; ++it) {
+      const int idx = base + it * 256 + threadIdx.x;
+      slot[it] = -1;
+      vals[it] = make_float2(0.f, 0.f);
+      if (idx < tc * L1) {
+        const int n1 = idx / tc, cc = idx - n1 * tc;
+        const int t = n1 * L2 + c0 + cc;
+        slot[it] = cc * ss + n1;
+        if (a.rader) {
+          if (!a.adjoint) {              // u[a] = Y[g^a], Y the Hermitian extension of X
+            const int k = a.perm[t];
+            const float2* Xb = (const float2*)a.in + (size_t)b * a.ld_in;
+            if (k < g.nin) { vals[it] = Xb[k]; edge += vals[it].x; }
+            else vals[it] = cconj(Xb[g.n - k]);
+          } else {                       // G[b] = gx[g^-b]
+            vals[it] = make_float2(((const float*)a.in)[(size_t)b * a.ld_in + a.iperm[t]], 0.f);
+            edge += vals[it].x;
+          }
+        } else if (!a.adjoint) {
+          if (t < g.nin) {
+            float2 X = ((const float2*)a.in)[(size_t)b * a.ld_in + t];
+            if (t == 0) X = make_float2(0.5f * X.x, 0.f);   // X'_0 = Re X_0 (factor 2 applied at the end)
+            vals[it] = cmul(X, a.chirp[t]);
+          }
+        } else {
+          if (t < g.n) {
+            const float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
+            const float2 w = a.chirp[t];
+            vals[it] = make_float2(gx * w.x, -gx * w.y);     // gx * conj(w_t)
+          }
+        }
       }
     }
-    bufA[cc * ss + n1] = v;
+#pragma unroll
+    for (int it = 0; it < COL_IT; ++it)
+      if (slot[it] >= 0) bufA[slot[it]] = vals[it];
+  }
+  if (a.rader) {                       // one partial per block, folded by k_blu_col_inv
+    edge = block_sum(edge, s_edge);
+    if (threadIdx.x == 0) a.edge[(size_t)b * gridDim.x + blockIdx.x] = edge;
   }
   __syncthreads();
   float2* r = lds_fft(bufA, bufB, L1, tc, ss, false, tw4, L1);
@@ -335,7 +451,10 @@ __global__ __launch_bounds__(256) void k_blu_row(BluArgs a) {
   const float2* chat = a.chat + (size_t)r0 * L2;
   for (int idx = threadIdx.x; idx < tr * L2; idx += blockDim.x) {
     float2 ch = chat[idx];
-    if (a.adjoint) ch.y = -ch.y;
+    if (a.adjoint) {
+      ch.y = -ch.y;
+      if (a.rader && ((r0 + idx / L2) & 1)) ch = make_float2(-ch.x, -ch.y);   // (-1)^f, f = k1 + L1 k2
+    }
     r[idx] = cmul(r[idx], ch);
   }
   __syncthreads();
@@ -409,7 +528,10 @@ __global__ __launch_bounds__(256) void k_blu_row512(BluArgs a) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     float2 ch = chat[lane + 64 * u];
-    if (a.adjoint) ch.y = -ch.y;
+    if (a.adjoint) {
+      ch.y = -ch.y;
+      if (a.rader && (k1 & 1)) ch = make_float2(-ch.x, -ch.y);               // (-1)^f, f = k1 + L1 k2
+    }
     v[u] = cmul(v[u], ch);
   }
   row512_fft(v, buf, tw4, lane, -1.0f);
@@ -432,9 +554,41 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
   build_tw4(tw4, L1);
   const float2* wk = a.work + (size_t)b * L;
-  for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
-    const int k1 = idx / tc, cc = idx - k1 * tc;
-    bufA[cc * ss + k1] = wk[(size_t)k1 * L2 + c0 + cc];
+  for (int base = 0; base < tc * L1; base += COL_IT * 256) {
+    float2 vals[COL_IT];
+#pragma unroll
+    for (int it = 0; it < COL_IT; ++it) {
+      const int idx = base + it * 256 + threadIdx.x;
+      if (idx < tc * L1) {
+        const int k1 = idx / tc, cc = idx - k1 * tc;
+        vals[it] = wk[(size_t)k1 * L2 + c0 + cc];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < COL_IT; ++it) {
+      const int idx = base + it * 256 + threadIdx.x;
+      if (idx < tc * L1) {
+        const int k1 = idx / tc, cc = idx - k1 * tc;
+        bufA[cc * ss + k1] = vals[it];
+      }
+    }
+  }
+  if (a.rader && blockIdx.x == 0 && threadIdx.x == 0) {
+    // t = 0 / k = 0 terms from the column blocks' partial sums (fixed order)
+    float sum = 0.f;
+    for (int e = 0; e < a.nedge; ++e) sum += a.edge[(size_t)b * a.nedge + e];
+    if (!a.adjoint) {   // x[0] = (X'_0 + 2 sum_{k>=1} Re X_k) / n
+      const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
+      ((float*)a.out)[(size_t)b * a.ld_out] = (x0 + 2.0f * sum) / (float)g.n;
+    } else {            // gX[0] = sum_t gx[t] / n
+      const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in];
+      ((float2*)a.out)[(size_t)b * a.ld_out] = make_float2((sum + g0) / (float)g.n, 0.f);
+    }
+  }
+  if (a.rader && a.adjoint) {          // bins above (n-1)/2 carry no gradient
+    float2* o = (float2*)a.out + (size_t)b * a.ld_out;
+    for (int k = g.nin + blockIdx.x * 256 + threadIdx.x; k < a.ld_out; k += gridDim.x * 256)
+      o[k] = make_float2(0.f, 0.f);
   }
   __syncthreads();
   float2* r = lds_fft(bufA, bufB, L1, tc, ss, true, tw4, L1);
@@ -443,7 +597,20 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
     const int n1 = idx / tc, cc = idx - n1 * tc;
     const int t = n1 * L2 + c0 + cc;
     const float2 v = r[cc * ss + n1];
-    if (!a.adjoint) {
+    if (a.rader) {
+      const float invL = 1.0f / (float)L, invn = 1.0f / (float)g.n;
+      if (!a.adjoint) {              // x[g^-b] = (X'_0 + S[b]) / n
+        const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
+        ((float*)a.out)[(size_t)b * a.ld_out + a.iperm[t]] = (x0 + v.x * invL) * invn;
+      } else {                       // gX[k] = 2 conj(W[a]) + (2/n) gx[0],  k = g^a <= (n-1)/2
+        const int k = a.perm[t];
+        if (k < g.nin) {
+          const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in];
+          const float sc = 2.0f * invL * invn;
+          ((float2*)a.out)[(size_t)b * a.ld_out + k] = make_float2(sc * v.x + 2.0f * invn * g0, -sc * v.y);
+        }
+      }
+    } else if (!a.adjoint) {
       if (t < g.n) {
         const float2 w = a.chirp[t];
         ((float*)a.out)[(size_t)b * a.ld_out + t] = 2.0f * base * (v.x * w.x - v.y * w.y);
@@ -480,15 +647,28 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
                    int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
-  BluGeom g = blu_geom(n);
+  const bool rader = rader_ok(n);
+  BluGeom g = rader ? rader_geom(n) : blu_geom(n);
   if (g.L1 > 1024 || g.L2 > 2048) return GFDN_E_UNSUPPORTED;
   if (!adjoint && (ld_in < g.nin || ld_out < n)) return GFDN_E_BADARG;
-  if (adjoint && (ld_in < n || ld_out < g.nin || ld_out > g.L)) return GFDN_E_BADARG;
+  if (adjoint && (ld_in < n || ld_out < g.nin || (!rader && ld_out > g.L))) return GFDN_E_BADARG;
   BluArgs a;
   a.g = g;
-  a.chirp = (const float2*)table;
-  a.chat = a.chirp + g.n;
+  a.rader = rader ? 1 : 0;
+  if (rader) {
+    a.chirp = nullptr;
+    a.chat = (const float2*)table;
+    a.perm = (const int*)((const char*)table + (size_t)g.L * sizeof(float2));
+    a.iperm = a.perm + g.L;
+  } else {
+    a.perm = a.iperm = nullptr;
+    a.chirp = (const float2*)table;
+    a.chat = a.chirp + g.n;
+  }
   a.work = (float2*)work;
+  const int tc0 = g.L2 < BLU_TC ? g.L2 : BLU_TC;
+  a.nedge = g.L2 / tc0;
+  a.edge = (float*)((char*)work + (size_t)batch * g.L * sizeof(float2));   // after the work blocks
   a.adjoint = adjoint;
   a.in = in;
   a.ld_in = ld_in;

@@ -39,9 +39,12 @@ def test_library_exports_every_declared_symbol(lib):
 def test_host_side_queries(lib):
     assert lib.gfdn_stft_nframes(65537, 4096) == 32          # losses.py:512-535 at K = 65 537
     assert lib.gfdn_stft_nframes(100, 4096) == 0
-    assert lib.gfdn_bluestein_table_bytes(65537) == (65537 + 131072) * 8
+    # 65 537 is a Fermat prime -> Rader on 2^16 points: chirp spectrum + two int32 index tables
+    assert lib.gfdn_bluestein_table_bytes(65537) == 65536 * (8 + 4 + 4)
+    assert lib.gfdn_bluestein_work_bytes(65537, 32) == 32 * 65536 * 8 + 32 * 64 * 4
+    # 4097 = 17 * 241 -> Bluestein on 2^13 >= 4097 + 2048 points: chirp (n) + chirp spectrum (L)
+    assert lib.gfdn_bluestein_table_bytes(4097) == (4097 + 8192) * 8
     assert lib.gfdn_bluestein_table_bytes(65536) == 0        # even length: not this transform
-    assert lib.gfdn_bluestein_work_bytes(65537, 32) == 32 * 131072 * 8
     assert lib.gfdn_solve_bwd_work_bytes(4, 4) == 256 * 4 * (16 + 8) * 4
     assert lib.gfdn_irfft_pow2_work_bytes(131072, 2) == 2 * 131072 * 8
     # argument errors are reported before anything is launched
