@@ -67,12 +67,15 @@ __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq
   const int nthr = blockDim.x;
   int nn = n, s = 1, ls = 0;  // ls = log2(s)
   const float sgn = inverse ? -1.0f : 1.0f;
+  const int ln = 31 - __clz(n);          // n, tn are powers of two: shifts instead of divisions
+  const int ltn = 31 - __clz(tn);
+  int lnn = ln;
   while (nn >= 8) {           // radix-8 Stockham passes
     const int m = nn >> 3;
-    const int tws = tn / nn;
-    const int per = n >> 3;
+    const int tws = 1 << (ltn - lnn);
+    const int per = n >> 3, lper = ln - 3;
     for (int idx = threadIdx.x; idx < nseq * per; idx += nthr) {
-      const int seq = idx / per, i = idx - seq * per;
+      const int seq = idx >> lper, i = idx & (per - 1);
       const int p = i >> ls, q = i & (s - 1);
       float2 w1 = tw4[p * tws];
       w1.y *= sgn;
@@ -89,15 +92,16 @@ __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq
     __syncthreads();
     float2* t = x; x = y; y = t;
     nn = m;
+    lnn -= 3;
     s <<= 3;
     ls += 3;
   }
   while (nn >= 4) {
     const int m = nn >> 2;
-    const int tws = tn / nn;
-    const int per = n >> 2;  // butterflies per sequence
+    const int tws = 1 << (ltn - lnn);
+    const int per = n >> 2, lper = ln - 2;  // butterflies per sequence
     for (int idx = threadIdx.x; idx < nseq * per; idx += nthr) {
-      const int seq = idx / per, i = idx - seq * per;
+      const int seq = idx >> lper, i = idx & (per - 1);
       const int p = i >> ls, q = i & (s - 1);
       float2 w1 = tw4[p * tws];
       w1.y *= sgn;
@@ -121,13 +125,14 @@ __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq
     __syncthreads();
     float2* t = x; x = y; y = t;
     nn = m;
+    lnn -= 2;
     s <<= 2;
     ls += 2;
   }
   if (nn == 2) {
-    const int per = n >> 1;  // here s == n/2, p == 0
+    const int per = n >> 1, lper = ln - 1;  // here s == n/2, p == 0
     for (int idx = threadIdx.x; idx < nseq * per; idx += nthr) {
-      const int seq = idx / per, q = idx - seq * per;
+      const int seq = idx >> lper, q = idx & (per - 1);
       const float2* xb = x + seq * ss;
       float2* yb = y + seq * ss;
       const float2 a = xb[q], b = xb[q + s];
@@ -167,8 +172,8 @@ __device__ __forceinline__ void build_tw2(float2* hi, float2* lo, int L) {
   }
 }
 __device__ __forceinline__ float2 tw2(const float2* hi, const float2* lo, int e, int L) {
-  const int nlo = L < (1 << TW_LOBITS) ? L : (1 << TW_LOBITS);
-  return cmul(hi[e / nlo], lo[e & (nlo - 1)]);
+  if (L >= (1 << TW_LOBITS)) return cmul(hi[e >> TW_LOBITS], lo[e & ((1 << TW_LOBITS) - 1)]);
+  return lo[e];             // L < 256: hi has the single entry 1
 }
 
 // ------------------------------------------------------------------------------------------
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   float2* thi = tw4 + (L1 >= 4 ? L1 / 4 : 1);
   float2* tlo = thi + (L >> TW_LOBITS > 0 ? (L >> TW_LOBITS) : 1);
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
+  const int ltc = 31 - __clz(tc);
   build_tw4(tw4, L1);
   build_tw2(thi, tlo, L);
   // load (+ chirp / Rader gather).  The loads of COL_IT iterations are issued together: with a
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
       slot[it] = -1;
       vals[it] = make_float2(0.f, 0.f);
       if (idx < tc * L1) {
-        const int n1 = idx / tc, cc = idx - n1 * tc;
+        const int n1 = idx >> ltc, cc = idx & (tc - 1);
         const int t = n1 * L2 + c0 + cc;
         slot[it] = cc * ss + n1;
         if (a.rader) {
@@ -423,9 +429,9 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   // twiddle W_L^{n2 k1}, store [k1][n2]
   float2* wk = a.work + (size_t)b * L;
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
-    const int k1 = idx / tc, cc = idx - k1 * tc;
+    const int k1 = idx >> ltc, cc = idx & (tc - 1);
     const int n2 = c0 + cc;
-    float2 v = cmul(r[cc * ss + k1], tw2(thi, tlo, (int)(((long long)n2 * k1) & (L - 1)), L));
+    float2 v = cmul(r[cc * ss + k1], tw2(thi, tlo, (n2 * k1) & (L - 1), L));   // n2 k1 < L1 L2 = L
     wk[(size_t)k1 * L2 + n2] = v;
   }
 }
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256) void k_blu_row512(BluArgs a) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int n2 = lane + 64 * u;
-    const float2 w = tw2(thi, tlo, (int)(((long long)n2 * k1) & (L - 1)), L);
+    const float2 w = tw2(thi, tlo, (n2 * k1) & (L - 1), L);
     wk[n2] = cmulc(v[u], w);
   }
 }
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   float2* bufB = bufA + tc * ss;
   float2* tw4 = bufB + tc * ss;
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
+  const int ltc = 31 - __clz(tc);
   build_tw4(tw4, L1);
   const float2* wk = a.work + (size_t)b * L;
   for (int base = 0; base < tc * L1; base += COL_IT * 256) {
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
     for (int it = 0; it < COL_IT; ++it) {
       const int idx = base + it * 256 + threadIdx.x;
       if (idx < tc * L1) {
-        const int k1 = idx / tc, cc = idx - k1 * tc;
+        const int k1 = idx >> ltc, cc = idx & (tc - 1);
         vals[it] = wk[(size_t)k1 * L2 + c0 + cc];
       }
     }
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
     for (int it = 0; it < COL_IT; ++it) {
       const int idx = base + it * 256 + threadIdx.x;
       if (idx < tc * L1) {
-        const int k1 = idx / tc, cc = idx - k1 * tc;
+        const int k1 = idx >> ltc, cc = idx & (tc - 1);
         bufA[cc * ss + k1] = vals[it];
       }
     }
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   float2* r = lds_fft(bufA, bufB, L1, tc, ss, true, tw4, L1);
   const float base = 1.0f / ((float)g.n * (float)L);
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
-    const int n1 = idx / tc, cc = idx - n1 * tc;
+    const int n1 = idx >> ltc, cc = idx & (tc - 1);
     const int t = n1 * L2 + c0 + cc;
     const float2 v = r[cc * ss + n1];
     if (a.rader) {
