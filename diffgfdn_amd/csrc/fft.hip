@@ -347,6 +347,7 @@ struct BluArgs {
   const int* iperm;     // rader: iperm[b] = g^-b mod n   (time index of convolution slot b)
   float* edge;          // rader: per-(item, column block) partial sums for the t = 0 / k = 0 terms
   int nedge;            // rader: partials per item
+  int batch;
   const float2* chirp;  // n
   const float2* chat;   // L, [k1][k2]
   float2* work;         // batch * L
@@ -360,6 +361,25 @@ struct BluArgs {
 
 extern __shared__ float2 dyn_lds[];
 
+// XCD-aware block -> (tile, item) map.  Workgroups are dealt round-robin over the 8 XCDs by linear id
+// (blocks id and id + 8 share an XCD); each XCD has its own 4 MB L2.  All tiles of one item are given
+// ids of one residue class mod 8, so an item's spectrum (0.26 MB), work block (0.5 MB) and output stay
+// in ONE L2 across the three kernels: the Rader gather / scatter and the transposed work-block
+// accesses then hit L2 instead of over-fetching from HBM (PMC: 62 MB fetched vs 17 MB compulsory
+// before).  Placement only affects speed, never correctness; any batch not a multiple of 8 uses the
+// plain map.
+__device__ __forceinline__ void xcd_item_map(int ntiles, int batch, int& tile, int& b) {
+  const int id = blockIdx.x;
+  if ((batch & 7) == 0) {
+    const int j = id >> 3, q = j / ntiles;
+    b = (id & 7) + 8 * q;
+    tile = j - q * ntiles;
+  } else {
+    b = id / ntiles;
+    tile = id - b * ntiles;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   __shared__ float s_edge[16];
   const BluGeom g = a.g;
@@ -371,7 +391,9 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   float2* tw4 = bufB + tc * ss;          // L1/4 (>=1)
   float2* thi = tw4 + (L1 >= 4 ? L1 / 4 : 1);
   float2* tlo = thi + (L >> TW_LOBITS > 0 ? (L >> TW_LOBITS) : 1);
-  const int b = blockIdx.y, c0 = blockIdx.x * tc;
+  int tile, b;
+  xcd_item_map(L2 / tc, a.batch, tile, b);
+  const int c0 = tile * tc;
   const int ltc = 31 - __clz(tc);
   build_tw4(tw4, L1);
   build_tw2(thi, tlo, L);
@@ -422,7 +444,7 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   }
   if (a.rader) {                       // one partial per block, folded by k_blu_col_inv
     edge = block_sum(edge, s_edge);
-    if (threadIdx.x == 0) a.edge[(size_t)b * gridDim.x + blockIdx.x] = edge;
+    if (threadIdx.x == 0) a.edge[(size_t)b * a.nedge + tile] = edge;
   }
   __syncthreads();
   float2* r = lds_fft(bufA, bufB, L1, tc, ss, false, tw4, L1);
@@ -446,7 +468,9 @@ __global__ __launch_bounds__(256) void k_blu_row(BluArgs a) {
   float2* tw4 = bufB + tr * ss;
   float2* thi = tw4 + (L2 >= 4 ? L2 / 4 : 1);
   float2* tlo = thi + (L >> TW_LOBITS > 0 ? (L >> TW_LOBITS) : 1);
-  const int b = blockIdx.y, r0 = blockIdx.x * tr;
+  int tile, b;
+  xcd_item_map(L1 / tr, a.batch, tile, b);
+  const int r0 = tile * tr;
   build_tw4(tw4, L2);
   build_tw2(thi, tlo, L);
   float2* wk = a.work + (size_t)b * L + (size_t)r0 * L2;
@@ -523,7 +547,9 @@ __global__ __launch_bounds__(256) void k_blu_row512(BluArgs a) {
   build_tw4(tw4, 512);
   build_tw2(thi, tlo, L);
   __syncthreads();
-  const int b = blockIdx.y, k1 = blockIdx.x * 4 + wave;
+  int tile, b;
+  xcd_item_map(g.L1 / 4, a.batch, tile, b);
+  const int k1 = tile * 4 + wave;
   float2* buf = bufs + wave * ROW512_LDS;
   float2* wk = a.work + (size_t)b * L + (size_t)k1 * L2;
   float2 v[8];
@@ -557,7 +583,9 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   float2* bufA = dyn_lds;
   float2* bufB = bufA + tc * ss;
   float2* tw4 = bufB + tc * ss;
-  const int b = blockIdx.y, c0 = blockIdx.x * tc;
+  int tile, b;
+  xcd_item_map(L2 / tc, a.batch, tile, b);
+  const int c0 = tile * tc;
   const int ltc = 31 - __clz(tc);
   build_tw4(tw4, L1);
   const float2* wk = a.work + (size_t)b * L;
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
       }
     }
   }
-  if (a.rader && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (a.rader && tile == 0 && threadIdx.x == 0) {
     // t = 0 / k = 0 terms from the column blocks' partial sums (fixed order)
     float sum = 0.f;
     for (int e = 0; e < a.nedge; ++e) sum += a.edge[(size_t)b * a.nedge + e];
@@ -594,7 +622,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   }
   if (a.rader && a.adjoint) {          // bins above (n-1)/2 carry no gradient
     float2* o = (float2*)a.out + (size_t)b * a.ld_out;
-    for (int k = g.nin + blockIdx.x * 256 + threadIdx.x; k < a.ld_out; k += gridDim.x * 256)
+    for (int k = g.nin + tile * 256 + threadIdx.x; k < a.ld_out; k += (L2 / tc) * 256)
       o[k] = make_float2(0.f, 0.f);
   }
   __syncthreads();
@@ -676,6 +704,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   const int tc0 = g.L2 < BLU_TC ? g.L2 : BLU_TC;
   a.nedge = g.L2 / tc0;
   a.edge = (float*)((char*)work + (size_t)batch * g.L * sizeof(float2));   // after the work blocks
+  a.batch = batch;
   a.adjoint = adjoint;
   a.in = in;
   a.ld_in = ld_in;
@@ -690,21 +719,21 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if ((rc = ensure_dyn_lds(k_blu_row, lr))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_col_inv, lc))) return rc;
   if (stages & 1) {
-    hipLaunchKernelGGL(k_blu_col_fwd, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
+    hipLaunchKernelGGL(k_blu_col_fwd, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 2) {
     if (g.L2 == 512 && g.L1 % 4 == 0) {
       const size_t lr5 = (128 + ((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS) +
                           4 * ROW512_LDS) * sizeof(float2);
-      hipLaunchKernelGGL(k_blu_row512, dim3(g.L1 / 4, batch), dim3(256), lr5, s, a);
+      hipLaunchKernelGGL(k_blu_row512, dim3((g.L1 / 4) * batch), dim3(256), lr5, s, a);
     } else {
-      hipLaunchKernelGGL(k_blu_row, dim3(g.L1 / tr, batch), dim3(256), lr, s, a);
+      hipLaunchKernelGGL(k_blu_row, dim3((g.L1 / tr) * batch), dim3(256), lr, s, a);
     }
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 4) {
-    hipLaunchKernelGGL(k_blu_col_inv, dim3(g.L2 / tc, batch), dim3(256), lc, s, a);
+    hipLaunchKernelGGL(k_blu_col_inv, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
