@@ -371,3 +371,52 @@ extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int l
 }
 
 extern "C" int gfdn_abi_version(void) { return GFDN_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// EDC time mask drawn on the device (losses.py:221-227): iid fair bits from Philox4x32-10.
+// One block; thread i produces bits 128 i .. 128 i + 127; the kept count is a fixed-order block sum.
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+#define MASK_MAX_LEN 131072
+__global__ __launch_bounds__(1024) void k_draw_mask(unsigned long long seed, unsigned long long* state,
+                                                    int len, float scale, float* maskw) {
+  __shared__ unsigned words[MASK_MAX_LEN / 32];
+  __shared__ float red[16];
+  const unsigned long long step = state[0];
+  const int nchunk = (len + 127) >> 7;
+  float cnt = 0.f;
+  for (int i = threadIdx.x; i < nchunk; i += blockDim.x) {
+    unsigned c[4] = {(unsigned)i, 0u, (unsigned)step, (unsigned)(step >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int t0 = i * 128 + w * 32, left = len - t0;
+      unsigned v = c[w];
+      if (left < 32) v = left <= 0 ? 0u : (v & ((1u << left) - 1u));
+      words[i * 4 + w] = v;
+      cnt += (float)__popc(v);
+    }
+  }
+  const float count = block_sum(cnt, red);          // exact: integers below 2^24
+  const float wgt = count > 0.f ? scale / count : 0.f;
+  for (int t = threadIdx.x; t < len; t += blockDim.x)
+    maskw[t] = ((words[t >> 5] >> (t & 31)) & 1u) ? wgt : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) state[0] = step + 1ull;
+}
+
+extern "C" int gfdn_draw_mask(unsigned long long seed, unsigned long long* state, int len, float scale,
+                              float* maskw, void* stream) {
+  if (!state || !maskw || len <= 0 || len > MASK_MAX_LEN) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_draw_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, seed, state, len, scale, maskw);
+  return (int)hipGetLastError();
+}

@@ -428,6 +428,23 @@ def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.
     return loss_item, gx
 
 
+def draw_mask(seed: int, state, length: int, scale: float, out=None):
+    """Fair-coin EDC time mask drawn on the device (counter-based; ``state`` is a 1-element int64
+    step counter that the kernel advances) -> maskw (length,) = kept * scale / count."""
+    _need_gpu(state)
+    if state.dtype != torch.int64 or state.numel() != 1:
+        raise RuntimeError("draw_mask: state must be a 1-element int64 device tensor")
+    if out is None:
+        out = torch.empty(length, dtype=_f32, device=state.device)
+    _need_gpu(out)
+    if out.dtype != _f32 or out.numel() != length or not out.is_contiguous():
+        raise RuntimeError("draw_mask: out must be a contiguous float32 tensor of the mask length")
+    lib = _lib.load()
+    _lib.check(lib.gfdn_draw_mask(int(seed) & 0xFFFFFFFFFFFFFFFF, _p(state), int(length), float(scale),
+                                  _p(out), _stream()), "gfdn_draw_mask")
+    return out
+
+
 def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float):
     """pos (B,3) f64, freq_pi (F,) f32, w packed params -> gains (B,G), xhat (B,nl,H), rstd (B,nl)."""
     _need_gpu(pos, w)

@@ -29,6 +29,7 @@ import torch.distributed as dist
 from .colorless_losses import amse_loss, group_spectral_loss, mse_loss, sparsity_loss
 from .config import CouplingMatrixType, TrainerConfig
 from .functional import ColorlessTerms, OutputStage, SHToDirectional, irfft_like_torch
+from . import hip_ops as ops
 from .hip_ops import normalize_io, spectral_stats
 from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
 from .model import DiffGFDN
@@ -359,9 +360,10 @@ class VarReceiverPosTrainer(Trainer):
         losses['_total'] = total
         return losses
 
-    def graphed(self, dataset, batch_size: int) -> "GraphedTrainStep":
+    def graphed(self, dataset, batch_size: int, mask_source: str = "device",
+                mask_seed: Optional[int] = None) -> "GraphedTrainStep":
         """normalize + train_step of a fixed-size batch as one HIP graph replay."""
-        return GraphedTrainStep(self, dataset, batch_size)
+        return GraphedTrainStep(self, dataset, batch_size, mask_source, mask_seed)
 
     def train_step(self, data: Dict):
         """normalize is called by the loop, as in the reference (:373-379)."""
@@ -497,15 +499,22 @@ class GraphedTrainStep:
     (two with the RCCL all-reduce of the flat gradient buffer between them) graph launch, which removes the host launch
     overhead that dominates the eager step (profiles/).
 
-    Per step the host only writes two static device buffers: the receiver indices of the batch and
-    the EDC time-mask weights (drawn from the CPU generator exactly like the reference,
-    losses.py:221-223, then divided by global-batch x kept-indices).  Requires a trainer built
-    with ``capturable=True`` and a fixed batch size."""
+    Per step the host only writes one static device buffer, the receiver indices of the batch.
+    The EDC time mask (losses.py:221-223) is drawn INSIDE the graph by a counter-based device
+    generator (``mask_source='device'``, the default): the CPU draw costs ~0.5 ms per step on the
+    host, which is as long as the whole GPU step, and in a data-parallel job every rank derives
+    the same mask from the shared seed with no broadcast.  ``mask_source='host'`` keeps the
+    reference's CPU draw (uniform_ then bernoulli from torch's global generator), staged through
+    pinned memory.  Requires a trainer built with ``capturable=True`` and a fixed batch size."""
 
-    def __init__(self, trainer: "VarReceiverPosTrainer", dataset, batch_size: int):
+    def __init__(self, trainer: "VarReceiverPosTrainer", dataset, batch_size: int,
+                 mask_source: str = "device", mask_seed: Optional[int] = None):
         if not trainer.capturable:
             raise ValueError("build the trainer with capturable=True to replay steps from a graph")
+        if mask_source not in ("device", "host"):
+            raise ValueError("mask_source must be 'device' or 'host'")
         self.tr, self.ds, self.B = trainer, dataset, batch_size
+        self.mask_source = mask_source
         dev = dataset.device
         K = dataset.rir_mag_response.shape[-1]
         self.start, self.length = trainer._decay_window(K)
@@ -525,12 +534,22 @@ class GraphedTrainStep:
                        torch.empty(batch_size, dtype=torch.long).pin_memory(), torch.cuda.Event())
                       for _ in range(4)]
         self._ring_pos = 0
+        self.mask_state = torch.zeros(1, dtype=torch.long, device=dev)     # draws made so far
+        if mask_seed is None:
+            seed_t = torch.randint(0, 2 ** 62, (1,), dtype=torch.long)      # torch.manual_seed governs it
+            if trainer.world_size > 1:                                      # one seed for all ranks, once
+                seed_t = seed_t.to(dev)
+                dist.broadcast(seed_t, src=0, group=trainer.process_group)
+            mask_seed = int(seed_t.item())
+        self.mask_seed = int(mask_seed)
         self.graph_a = self.graph_b = None
         self.losses = None
 
     # -- pieces -------------------------------------------------------------------------------
     def _fwd_bwd(self):
         tr = self.tr
+        if self.mask_source == "device" and tr.criterion[1].use_mask:
+            ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
         batch = self.ds.collate(self.idx, lean=True)
         tr.normalize(batch)
         tr.optimizer.zero_grad(set_to_none=True)
@@ -571,6 +590,7 @@ class GraphedTrainStep:
             else:
                 for t in state_tensors():
                     t.zero_()                              # fresh Adam state: zeros, step 0
+            self.mask_state.zero_()
             tr.optimizer.zero_grad(set_to_none=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -600,7 +620,7 @@ class GraphedTrainStep:
         host_idx.copy_(torch.as_tensor(list(indices), dtype=torch.long))
         self.idx.copy_(host_idx, non_blocking=True)
         crit = tr.criterion[1]
-        if crit.use_mask:
+        if crit.use_mask and self.mask_source == "host":
             keep = torch.bernoulli(torch.empty(self.length).uniform_(0, 1))
             if tr.world_size > 1:
                 # one mask for all ranks: rank 0's draw wins

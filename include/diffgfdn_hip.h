@@ -202,6 +202,18 @@ int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const f
                   const float* maskw, float inv_count, float gscale, float* loss_item,
                   float* gx, void* work, void* stream);
 
+/* ---- EDC time mask on the device  (losses.py:221-227: mask = argwhere(bernoulli(U(0,1))) over the
+ * window -- marginally every index is kept with probability 1/2, independently).
+ * Counter-based draw: bit t of the mask is bit (t mod 128) of Philox4x32-10(counter = (t / 128, 0,
+ * step_lo, step_hi), key = (seed_lo, seed_hi)), step = state[0] (uint64, device), which the kernel
+ * then increments -- so a HIP-graph replay draws a fresh mask without any host work, and every rank
+ * of a data-parallel job that starts from the same (seed, state) draws the SAME mask with no broadcast.
+ * maskw[t] = bit_t * scale / count, count = number of kept indices (all zeros if count == 0);
+ * scale = 1 / global batch makes maskw the "pre-normalised" weights gfdn_edc_loss takes with
+ * inv_count = 1.  len <= 131072.                                                                  */
+int gfdn_draw_mask(unsigned long long seed, unsigned long long* state, int len, float scale,
+                   float* maskw, void* stream);
+
 /* ---- receiver-position -> group-gain network  (gain_filters.py:497-534; dnn.py:89-126, :331-400,
  * :21-36).  pos (B,3) float64 normalised coordinates; freq_pi (F) float32 = f32(freq_k * pi);
  * w: all parameters packed in named_parameters() order

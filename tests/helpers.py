@@ -30,3 +30,24 @@ def rel_err(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def philox_mask(seed: int, step: int, length: int, scale: float):
+    """numpy restatement of gfdn_draw_mask (include/diffgfdn_hip.h): bit t of the mask is bit
+    (t mod 128) of Philox4x32-10(counter = (t // 128, 0, step_lo, step_hi), key = seed)."""
+    n = (length + 127) // 128
+    M = np.uint64(0xFFFFFFFF)
+    c = [np.arange(n, dtype=np.uint64), np.zeros(n, np.uint64),
+         np.full(n, step & 0xFFFFFFFF, np.uint64), np.full(n, (step >> 32) & 0xFFFFFFFF, np.uint64)]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & M, p1 >> np.uint64(32), p1 & M
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    words = np.stack(c, axis=1).reshape(-1).astype(np.uint32)              # word 4 i + w
+    bits = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:length]
+    count = int(bits.sum())
+    w = np.float32(scale) / np.float32(count) if count else np.float32(0)
+    return bits.astype(np.float32) * w, count

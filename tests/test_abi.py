@@ -68,3 +68,15 @@ def test_product_package_does_not_import_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_philox_restatement_known_answer():
+    """tests/helpers.philox_mask (the checker of gfdn_draw_mask) reproduces the published
+    Philox4x32-10 known-answer vector for an all-zero counter and key."""
+    import numpy as np
+    from tests.helpers import philox_mask
+    m, count = philox_mask(0, 0, 128, 1.0)
+    bits = (m > 0).astype(np.uint64).reshape(4, 32)
+    words = [int((b << np.arange(32, dtype=np.uint64)).sum()) for b in bits]
+    assert words == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert count == sum(bin(w).count("1") for w in words)

@@ -283,3 +283,22 @@ def test_mlp_gains_fused(ops, B, F, H, n_hidden, G):
     (g * gg.to(DEV)).sum().backward()
     for p, r in zip(mod.parameters(), ref_grads):
         assert rel_err(p.grad.cpu(), r) < 2e-4
+
+
+@pytest.mark.parametrize("length", [1, 127, 128, 129, 4097, 47360, 131072])
+def test_draw_mask_bit_exact(length):
+    """gfdn_draw_mask == the numpy Philox restatement, bit for bit; the counter advances per call."""
+    from diffgfdn_amd import hip_ops as ops
+    from tests.helpers import philox_mask
+    seed = 0x1234_5678_9ABC_DEF0
+    state = torch.full((1,), 5, dtype=torch.long, device=DEV)
+    out = torch.empty(length, dtype=torch.float32, device=DEV)
+    for step in (5, 6, 7):
+        ops.draw_mask(seed, state, length, 1.0 / 32, out=out)
+        want, count = philox_mask(seed, step, length, 1.0 / 32)
+        assert int(state.item()) == step + 1
+        assert np.array_equal(out.cpu().numpy(), want), (length, step)
+    if length >= 4097:
+        kept = (out > 0).float().mean().item()
+        assert abs(kept - 0.5) < 4 * 0.5 / np.sqrt(length)
+        assert abs(out.double().sum().item() * 32 - 1.0) < 1e-5

@@ -176,7 +176,7 @@ def test_graphed_step_equals_eager_step():
         net = _grid_model(fx)
         tr = VarReceiverPosTrainer(net, tc, stft_win=512, capturable=(mode == "graph"))
         if mode == "graph":
-            step = tr.graphed(ds, 4).capture([0, 1, 2, 3])
+            step = tr.graphed(ds, 4, mask_source="host").capture([0, 1, 2, 3])
         torch.manual_seed(77)
         tot = []
         for sel in ([0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]):
@@ -195,6 +195,52 @@ def test_graphed_step_equals_eager_step():
     # the capturable and the default update, so the state is compared at 5e-4
     for k in s0:
         assert rel_err(s1[k], s0[k]) < 5e-4, k
+
+
+def test_graphed_step_device_mask():
+    """The graph draws the EDC time mask itself (gfdn_draw_mask): every replay must equal an eager
+    step that is handed the mask the Philox restatement predicts for (seed, replay number)."""
+    from diffgfdn_amd.config import TrainerConfig
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
+    from diffgfdn_amd.synthetic import synthetic_room
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    from tests.helpers import philox_mask
+    fx = load("f234_n16_k4097_cp.npz")
+    room = synthetic_room(12, 4, 8000.0, 5000, seed=2)
+    ds = MultiRIRDataset(DEV, RoomDataset(4, 8000.0, room["source_position"], room["receiver_position"],
+                                          room["rirs"], room["common_decay_times"], nfft=8192, device=DEV))
+    tc = TrainerConfig(batch_size=4, num_freq_bins=8192, lr=1e-3, io_lr=1e-2, coupling_angle_lr=1e-2,
+                       use_colorless_loss=True, use_asym_spectral_loss=True, edc_loss_weight=10.0,
+                       sparsity_loss_weight=2.0, use_edc_mask=True, train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a",
+                       device="cuda")
+    sels = ([0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11])
+    net = _grid_model(fx)
+    tr = VarReceiverPosTrainer(net, tc, stft_win=512, capturable=True)
+    step = tr.graphed(ds, 4, mask_seed=4242).capture(sels[0])
+    assert int(step.mask_state.item()) == 0                     # the warm-up left no trace
+    got = [float(step(sel)["_total"]) for sel in sels]
+    assert int(step.mask_state.item()) == len(sels)
+    last = step.maskw.cpu().numpy()
+    want_last, _ = philox_mask(4242, len(sels) - 1, step.length, 1.0 / 4)
+    assert np.array_equal(last, want_last)
+
+    net2 = _grid_model(fx)
+    tr2 = VarReceiverPosTrainer(net2, tc, stft_win=512, capturable=True)
+    want = []
+    for i, sel in enumerate(sels):
+        b = ds.collate(sel)
+        tr2.normalize(b)
+        tr2.optimizer.zero_grad(set_to_none=True)
+        mw = torch.tensor(philox_mask(4242, i, step.length, 1.0 / 4)[0], device=DEV)
+        losses = tr2._step_losses(b, mask_prenorm=mw)
+        losses["_total"].backward()
+        tr2.optimizer.pack_grads()
+        tr2.optimizer.step()
+        want.append(float(losses["_total"]))
+    for a, b in zip(got, want):
+        assert abs(a - b) < 1e-5 * abs(b), (got, want)
+    for k, v in net.state_dict().items():
+        assert rel_err(v.detach().cpu(), net2.state_dict()[k].detach().cpu()) < 5e-4, k
 
 
 def test_f3b_subband_mask_weights():
