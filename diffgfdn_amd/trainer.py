@@ -278,7 +278,7 @@ class VarReceiverPosTrainer(Trainer):
         return self.criterion[1].window(K)
 
     def _step_losses(self, data: Dict, draw_mask: bool = True,
-                     mask_prenorm: Optional[torch.Tensor] = None) -> Dict:
+                     mask_prenorm: Optional[torch.Tensor] = None, normalize_first: bool = False) -> Dict:
         """Fused forward + losses of one batch (train_step :452-471 / valid_step :479-498).
         ``mask_prenorm``: EDC time weights already divided by (global batch x kept indices), in a
         static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
@@ -294,11 +294,18 @@ class VarReceiverPosTrainer(Trainer):
         side = self._side_stream() if self.use_colorless_loss else None
         if self.use_colorless_loss:
             main = torch.cuda.current_stream()
-            if fl.M.is_cuda and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
-                fl.group_rotations()                      # (Q, QQ) once, before the fork
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                # normalize (:317-332) and the rotations (Q, QQ) lead the side branch while the main
+                # stream evaluates the gain network; the main solve waits for them only
+                if normalize_first:
+                    self.normalize(data)
+                if fl.M.is_cuda and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
+                    fl.group_rotations()
+                if side is not None:
+                    ready = torch.cuda.Event()
+                    ready.record(side)
                 S, _ = net.sub_fdn_group_sums(z)
                 # spectral + sparsity (last group only, :305-308), weighted, / world size (position
                 # independent terms), values and gradients in two launches
@@ -308,9 +315,9 @@ class VarReceiverPosTrainer(Trainer):
                 extra = terms[0]
                 colorless = {'spectral_loss': terms[1].detach(), 'sparsity_loss': terms[2].detach()}
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
-        # (measured: running the gain network on a side stream beside the solve costs +0.2 ms per step
-        # in cross-stream joins of its backward -- it stays on the main stream)
         rgain = net.output_scalars.group_gains(data)
+        if side is not None:
+            torch.cuda.current_stream().wait_event(ready)
         # the decay losses transform H with irfft(H, n = K) (losses.py:207-213, :442-445), which reads
         # bins 0..(K-1)/2 only: the main branch of the TRAINING step is evaluated on those bins alone
         # (solve, output stage and their backward do half the work; losses and gradients are the
@@ -551,9 +558,12 @@ class GraphedTrainStep:
         if self.mask_source == "device" and tr.criterion[1].use_mask:
             ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
         batch = self.ds.collate(self.idx, lean=True)
-        tr.normalize(batch)
         tr.optimizer.zero_grad(set_to_none=True)
-        losses = tr._step_losses(batch, mask_prenorm=self.maskw)
+        if os.environ.get("GFDN_AB") == "1":
+            tr.normalize(batch)
+            losses = tr._step_losses(batch, mask_prenorm=self.maskw)
+        else:
+            losses = tr._step_losses(batch, mask_prenorm=self.maskw, normalize_first=True)
         losses['_total'].backward()
         return losses
 
