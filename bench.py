@@ -46,14 +46,17 @@ WIN = 4096
 HBM_PEAK_GBS = 8000.0
 # compulsory HBM bytes per RIR (fwd + bwd, fp32 / complex64 storage)
 ALG_BYTES_PER_RIR = 2811048
-# Dominant hand-written kernel by total time in profiles/r01_bench_kernel_stats.csv: the row pass of
-# the Bluestein irfft (forward FFT over n2, chirp-spectrum product, inverse FFT over k2).  Its
-# algorithmic bytes per RIR: one read + one write of the L = 2^17 point complex64
-# work row block = 2 * 131072 * 8 B (the chirp spectrum is shared by the batch and L2-resident).
-DOMINANT_KERNEL = 'k_blu_row'
-DOMINANT_ALG_BYTES_PER_UNIT = 2 * 131072 * 8
-# HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_*.csv), or None
-DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 68290765   # 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, batch 32
+# Dominant HBM-bound kernel by total time in profiles/r01_bench_kernel_stats.csv: the first column pass
+# of the odd-length irfft (k_blu_col_fwd; Rader gather + FFT over n1 + twiddle).  Algorithmic bytes per
+# RIR: read the (K+1)/2 = 32769 spectrum bins the transform uses (8 B each; the
+# adjoint launch reads 65537 real samples of 4 B -- one byte count less) and write the L = 2^16 point
+# complex64 work block once.  The permutation table is shared by the batch and L2-resident.
+# (k_solve_bwd<4> has a slightly larger share of the step but is latency-bound Gauss-Jordan
+# arithmetic on a few MB -- neither roofline describes it; see DESIGN.md.)
+DOMINANT_KERNEL = 'k_blu_col_fwd'
+DOMINANT_ALG_BYTES_PER_UNIT = 8 * 32769 + 8 * 65536
+# HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_hbm_bytes.csv), or None
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 5222.0 * 1024 + 16392.0 * 1024)   # 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, batch 32
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
 
@@ -253,11 +256,17 @@ def main():
         if dom:
             dom['alg_bytes_per_unit'] = DOMINANT_ALG_BYTES_PER_UNIT
             units = dom['units_per_launch']
-            achieved = units * dom['alg_bytes_per_unit'] / (dom['avg_ms'] * 1e-3) / 1e9
+            # launch duration = bracket (start event .. end event) minus what an EMPTY event pair
+            # measures on the same stream; rocprofv3's average for the kernel is the cross-check
+            # (profiles/r01_bench_kernel_stats.csv)
+            net_ms = max(dom['avg_ms'] - dom['event_pair_overhead_ms'], 1e-6)
+            achieved = units * dom['alg_bytes_per_unit'] / (net_ms * 1e-3) / 1e9
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS,
                                'traffic': DOMINANT_TRAFFIC_BYTES_PER_LAUNCH,
-                               'kernel': dom['kernel'], 'avg_launch_us': dom['avg_ms'] * 1e3,
+                               'kernel': dom['kernel'], 'avg_launch_us': net_ms * 1e3,
+                               'bracket_us': dom['avg_ms'] * 1e3,
+                               'event_pair_overhead_us': dom['event_pair_overhead_ms'] * 1e3,
                                'launches': dom['launches'],
                                'alg_bytes_per_launch': units * dom['alg_bytes_per_unit']}
         out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS

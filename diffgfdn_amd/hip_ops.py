@@ -254,7 +254,7 @@ def irfft_odd_fwd(X, n: int) -> torch.Tensor:
     table = bluestein_table(n, X.device)
     x = torch.empty((batch, n), dtype=_f32, device=X.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
-    if kernel_timer.active and kernel_timer.watch == 'k_blu_row':
+    if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
         _staged_bluestein(lib, table, n, X, ldx, batch, x, n, work, 0)
         return x
     _lib.check(lib.gfdn_irfft_odd_fwd(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work),
@@ -271,7 +271,7 @@ def irfft_odd_bwd(gx, n: int, ldx: int) -> torch.Tensor:
     table = bluestein_table(n, gx.device)
     gX = torch.empty((batch, ldx), dtype=_c64, device=gx.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), gx.device)
-    if kernel_timer.active and kernel_timer.watch == 'k_blu_row':
+    if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
         _staged_bluestein(lib, table, n, gx, gx.shape[1], batch, gX, ldx, work, 1)
         return gX
     _lib.check(lib.gfdn_irfft_odd_bwd(_p(table), n, _p(gx), gx.shape[1], batch, _p(gX), ldx,
@@ -279,15 +279,17 @@ def irfft_odd_bwd(gx, n: int, ldx: int) -> torch.Tensor:
     return gX
 
 
+_BLU_STAGES = {'k_blu_col_fwd': 1, 'k_blu_row': 2, 'k_blu_col_inv': 4}
+
+
 def _staged_bluestein(lib, table, n, src, ld_in, batch, dst, ld_out, work, adjoint):
-    """Same three launches as the fused entry point, with HIP events around the row kernel."""
+    """Same three launches as the fused entry point, with HIP events around the watched one."""
     args = (_p(table), n, _p(src), ld_in, batch, _p(dst), ld_out, _p(work), adjoint)
-    _lib.check(lib.gfdn_irfft_odd_stages(*args, 1, _stream()), "gfdn_irfft_odd_stages[col]")
-    end = kernel_timer.bracket('k_blu_row', batch)
-    _lib.check(lib.gfdn_irfft_odd_stages(*args, 2, _stream()), "gfdn_irfft_odd_stages[row]")
-    if end is not None:
-        end.record()
-    _lib.check(lib.gfdn_irfft_odd_stages(*args, 4, _stream()), "gfdn_irfft_odd_stages[inv]")
+    for name, stage in _BLU_STAGES.items():
+        end = kernel_timer.bracket(name, batch)
+        _lib.check(lib.gfdn_irfft_odd_stages(*args, stage, _stream()), "gfdn_irfft_odd_stages[%s]" % name)
+        if end is not None:
+            end.record()
 
 
 def irfft_pow2_fwd(X, n: int) -> torch.Tensor:
@@ -519,8 +521,19 @@ class KernelTimer:
         torch.cuda.synchronize()
         ms = [s.elapsed_time(e) for s, e, _ in self._events]
         units = [u for _, _, u in self._events]
+        # what an event pair with NOTHING between its records measures on this stream: the part of
+        # every bracket that is not the kernel (reported beside the raw figure, never hidden)
+        empty = []
+        for _ in range(32):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            e.record()
+            empty.append((s, e))
+        torch.cuda.synchronize()
+        overhead = sorted(s.elapsed_time(e) for s, e in empty)[len(empty) // 2]
         return {'kernel': self.watch, 'launches': len(ms), 'avg_ms': sum(ms) / len(ms),
-                'min_ms': min(ms), 'units_per_launch': sum(units) / len(units)}
+                'min_ms': min(ms), 'units_per_launch': sum(units) / len(units),
+                'event_pair_overhead_ms': overhead}
 
 
 kernel_timer = KernelTimer()

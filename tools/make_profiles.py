@@ -1,0 +1,77 @@
+"""Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/r01_*).
+usage: python tools/make_profiles.py [round_tag]   (default r01)"""
+import collections, csv, glob, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(ROOT, 'gpurun_out')
+dst = os.path.join(ROOT, 'profiles')
+
+def one(pattern):
+    return glob.glob(os.path.join(src, pattern), recursive=True)[0]
+
+# 1. bench line
+line = [l for l in open(os.path.join(src, f'{tag}_bench_n1.json')) if l.startswith('{')][-1]
+bench = json.loads(line)
+open(os.path.join(dst, f'{tag}_bench_n1.json'), 'w').write(line)
+# 2. kernel stats
+stats = one(f'{tag}_stats/**/*kernel_stats.csv')
+shutil.copy(stats, os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
+rows = list(csv.DictReader(open(stats)))
+total_ms = sum(float(r['TotalDurationNs']) for r in rows) / 1e6
+# 3. PMC summary: per (kernel, grid) average FETCH_SIZE / WRITE_SIZE (KB) over launches
+pmc = collections.defaultdict(dict)
+for kind, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(one(f'{tag}_pmc_{kind}/**/*counter_collection.csv'))):
+        if r['Counter_Name'] == ctr and r['Kernel_Name'].startswith('k_') or r['Kernel_Name'].startswith('void k_'):
+            acc[(r['Kernel_Name'].split('(')[0].replace('void ', ''), int(r['Grid_Size']))].append(float(r['Counter_Value']))
+    for k, v in acc.items():
+        pmc[k][ctr] = sum(v) / len(v)
+        pmc[k]['launches'] = len(v)
+with open(os.path.join(dst, f'{tag}_pmc_hbm_bytes.csv'), 'w') as f:
+    f.write('kernel,grid_size,launches,FETCH_SIZE_KB_raw,WRITE_SIZE_KB,read_MB_x2_corrected,write_MB,hbm_traffic_MB\n')
+    for (k, g), d in sorted(pmc.items()):
+        fe, wr = d.get('FETCH_SIZE', 0.0), d.get('WRITE_SIZE', 0.0)
+        f.write(f"{k},{g},{d['launches']},{fe:.1f},{wr:.1f},{2*fe*1024/1e6:.2f},{wr*1024/1e6:.2f},{(2*fe+wr)*1024/1e6:.2f}\n")
+# 4. one replayed step as a timeline
+tl = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'timeline.py'), os.path.join(src, f'{tag}_stats'), '100'],
+                    capture_output=True, text=True).stdout
+open(os.path.join(dst, f'{tag}_graph_step_timeline.txt'), 'w').write(
+    "one HIP-graph replay of the training step (steady state): start us, end us, duration, HW queue, kernel\n" + tl)
+# 5. README
+dom = bench.get('roofline', {})
+name = dom.get('kernel', '')
+drow = next((r for r in rows if r['Name'].startswith(name)), None)
+grid32 = {k: d for (k, g), d in pmc.items() if k == name}
+with open(os.path.join(dst, 'README.md'), 'w') as f:
+    f.write(f"""# profiles/ -- round {tag[1:]}
+All files come from ONE `gpurun` call (tools/run_measurements.sh) on one MI355X (gfx950, ROCm 7.2); `bench.py` is
+the command the driver runs (N = 1, workload = BASELINE.json configs[1]).  Rebuilt by tools/make_profiles.py.
+
+| file | command | what it holds |
+|---|---|---|
+| `{tag}_bench_n1.json` | `python bench.py` | the bench JSON line (graph-replay steps, roofline leg, CPU baseline) |
+| `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` | per-kernel totals / averages (includes the one-off dataset front end and the 20 eager roofline steps) |
+| `{tag}_pmc_hbm_bytes.csv` | `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --eager`, and the same with `--pmc WRITE_SIZE` (separate passes) | average FETCH_SIZE / WRITE_SIZE per launch of every hand-written kernel, by grid size; read bytes corrected x2 for gfx950 as MI355X_MICROARCH.md prescribes |
+| `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
+
+## bench line
+`{bench['value']:.0f} {bench['unit']}` = {bench['ms_per_step']:.4f} ms/step on 1 GPU;
+cpu_baseline {bench.get('cpu_baseline', {}).get('value', float('nan')):.1f} {bench['unit']} ({bench.get('cpu_baseline', {}).get('cores')} threads, kind {bench.get('cpu_baseline', {}).get('kind')}).
+
+## Roofline kernel: `{name}`
+bench.py (HIP events, {dom.get('launches')} launches): bracket {dom.get('bracket_us', float('nan')):.1f} us - empty event pair {dom.get('event_pair_overhead_us', float('nan')):.1f} us
+= **{dom.get('avg_launch_us', float('nan')):.1f} us**; rocprofv3 average over {drow['Calls'] if drow else '?'} launches of the stats run: **{float(drow['AverageNs'])/1e3 if drow else float('nan'):.1f} us**
+(that average also covers the 64-receiver launches of the one-off target precompute).
+Algorithmic bytes per launch {dom.get('alg_bytes_per_launch', 0)/1e6:.2f} MB -> achieved {dom.get('achieved', 0):.0f} GB/s = {dom.get('frac', 0):.3f} of {dom.get('peak')} GB/s.
+PMC traffic per launch (`traffic`): {(dom.get('traffic') or 0)/1e6:.2f} MB.
+
+## Top kernels by total time (stats run)
+
+| kernel | calls | total ms | avg us | % |
+|---|---|---|---|---|
+""")
+    for r in rows[:26]:
+        f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |\n")
+    f.write(f"\nTotal GPU time in the trace: {total_ms:.1f} ms.\n")
+print(open(os.path.join(dst, 'README.md')).read()[:3000])
