@@ -24,7 +24,7 @@ SIGNATURES = {
     "gfdn_solve_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "gfdn_solve_bwd_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_solve_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
-    "gfdn_compose_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
+    "gfdn_compose_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     "gfdn_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfdn_compose_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "gfdn_compose_sh_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
@@ -39,27 +39,27 @@ SIGNATURES = {
     "gfdn_bluestein_table_init": (c_int, [c_int, _P]),
     "gfdn_bluestein_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_irfft_odd_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
-    "gfdn_irfft_odd_bwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
-    "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
+    "gfdn_irfft_odd_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_irfft_pow2_fwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_irfft_pow2_bwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_rfft_pow2": (c_int, [c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_sh_to_directional": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_stft_nframes": (c_int, [c_int, c_int]),
-    "gfdn_stft_power": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "gfdn_stft_power": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_stft_power_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_edr_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_edr_target": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
-    "gfdn_edr_loss": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "gfdn_edr_loss": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     "gfdn_edc_work_bytes": (c_size_t, [c_int]),
     "gfdn_edc_target": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_mlp_param_count": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfdn_mlp_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "gfdn_mlp_gains_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
-    "gfdn_mlp_gains_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_mlp_gains_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_mlp_gains_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_adam_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P]),
-    "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_draw_mask": (c_int, [ctypes.c_ulonglong, _P, c_int, c_float, _P, _P]),
 }
 

@@ -352,6 +352,7 @@ struct BluArgs {
   const float2* chat;   // L, [k1][k2]
   float2* work;         // batch * L
   int adjoint;          // 0: X -> x ; 1: gx -> gX
+  const float* in2;     // adjoint only: optional second real input, summed in on load (in + in2)
   // forward: in = X (complex, ld_in), out = x (real, ld_out); adjoint: in = gx (real), out = gX (complex)
   const void* in;
   int ld_in;
@@ -420,8 +421,11 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
             if (k < g.nin) { vals[it] = Xb[k]; edge += vals[it].x; }
             else vals[it] = cconj(Xb[g.n - k]);
           } else {                       // G[b] = gx[g^-b]
-            vals[it] = make_float2(((const float*)a.in)[(size_t)b * a.ld_in + a.iperm[t]], 0.f);
-            edge += vals[it].x;
+            const size_t src = (size_t)b * a.ld_in + a.iperm[t];
+            float v = ((const float*)a.in)[src];
+            if (a.in2) v += a.in2[src];
+            vals[it] = make_float2(v, 0.f);
+            edge += v;
           }
         } else if (!a.adjoint) {
           if (t < g.nin) {
@@ -431,7 +435,8 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
           }
         } else {
           if (t < g.n) {
-            const float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
+            float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
+            if (a.in2) gx += a.in2[(size_t)b * a.ld_in + t];
             const float2 w = a.chirp[t];
             vals[it] = make_float2(gx * w.x, -gx * w.y);     // gx * conj(w_t)
           }
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
       const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
       ((float*)a.out)[(size_t)b * a.ld_out] = (x0 + 2.0f * sum) / (float)g.n;
     } else {            // gX[0] = sum_t gx[t] / n
-      const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in];
+      const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
       ((float2*)a.out)[(size_t)b * a.ld_out] = make_float2((sum + g0) / (float)g.n, 0.f);
     }
   }
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
       } else {                       // gX[k] = 2 conj(W[a]) + (2/n) gx[0],  k = g^a <= (n-1)/2
         const int k = a.perm[t];
         if (k < g.nin) {
-          const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in];
+          const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
           const float sc = 2.0f * invL * invn;
           ((float2*)a.out)[(size_t)b * a.ld_out + k] = make_float2(sc * v.x + 2.0f * invn * g0, -sc * v.y);
         }
@@ -679,7 +684,8 @@ static size_t blu_row_lds(const BluGeom& g) {
 }
 
 static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
-                   int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7) {
+                   int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7,
+                   const float* in2 = nullptr) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
   const bool rader = rader_ok(n);
@@ -707,6 +713,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   a.batch = batch;
   a.adjoint = adjoint;
   a.in = in;
+  a.in2 = adjoint ? in2 : nullptr;
   a.ld_in = ld_in;
   a.out = out;
   a.ld_out = ld_out;
@@ -739,19 +746,19 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   return 0;
 }
 
-extern "C" int gfdn_irfft_odd_stages(const void* table, int n, const void* in, int ld_in, int batch,
-                                     void* out, int ld_out, void* work, int adjoint, int stages,
-                                     void* stream) {
-  return blu_run(table, n, in, ld_in, batch, out, ld_out, work, adjoint, (hipStream_t)stream, stages);
+extern "C" int gfdn_irfft_odd_stages(const void* table, int n, const void* in, const float* in2,
+                                     int ld_in, int batch, void* out, int ld_out, void* work,
+                                     int adjoint, int stages, void* stream) {
+  return blu_run(table, n, in, ld_in, batch, out, ld_out, work, adjoint, (hipStream_t)stream, stages, in2);
 }
 
 extern "C" int gfdn_irfft_odd_fwd(const void* table, int n, const float* X, int ldx, int batch,
                                   float* x, int ldo, void* work, void* stream) {
   return blu_run(table, n, X, ldx, batch, x, ldo, work, 0, (hipStream_t)stream);
 }
-extern "C" int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, int ldo, int batch,
-                                  float* gX, int ldx, void* work, void* stream) {
-  return blu_run(table, n, gx, ldo, batch, gX, ldx, work, 1, (hipStream_t)stream);
+extern "C" int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
+                                  int batch, float* gX, int ldx, void* work, void* stream) {
+  return blu_run(table, n, gx, ldo, batch, gX, ldx, work, 1, (hipStream_t)stream, 7, gx2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -783,11 +790,18 @@ __device__ __forceinline__ void stft_load_pair(const float* __restrict__ x, int 
 }
 
 __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ x, int ld, int T,
-                                                    int W, int nframes, float* __restrict__ P) {
+                                                    int W, int nframes, float* __restrict__ P,
+                                                    float* __restrict__ zero_buf) {
   float2* bufA = dyn_lds;
   float2* bufB = bufA + W;
   float2* tw4 = bufB + W;
   const int b = blockIdx.y, m = blockIdx.x * 2, nf = W / 2 + 1;
+  if (zero_buf) {      // clear the adjoint's accumulation buffer: this block's W samples, the last block the tail
+    float* zb = zero_buf + (size_t)b * ld;
+    const int t0 = m * (W >> 1);
+    const int t1 = (blockIdx.x == gridDim.x - 1) ? ld : t0 + W;
+    for (int t = t0 + threadIdx.x; t < t1 && t < ld; t += blockDim.x) zb[t] = 0.f;
+  }
   build_tw4(tw4, W);
   stft_load_pair(x + (size_t)b * ld, T, W, m, nframes, bufA);
   __syncthreads();
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(256) void k_stft_power_bwd(const float* __restrict_
 static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }
 
 extern "C" int gfdn_stft_power(const float* x, int ld, int T, int batch, int win, float* P,
-                               void* stream) {
+                               float* zero_buf, void* stream) {
   if (!x || !P || batch <= 0 || ld < T) return GFDN_E_BADARG;
   int nframes = gfdn_stft_nframes(T, win);
   if (nframes <= 0) return GFDN_E_BADARG;
@@ -859,7 +873,7 @@ extern "C" int gfdn_stft_power(const float* x, int ld, int T, int batch, int win
   int rc = ensure_dyn_lds(k_stft_power, stft_lds(win));
   if (rc) return rc;
   hipLaunchKernelGGL(k_stft_power, dim3((nframes + 1) / 2, batch), dim3(256), stft_lds(win),
-                     (hipStream_t)stream, x, ld, T, win, nframes, P);
+                     (hipStream_t)stream, x, ld, T, win, nframes, P, zero_buf);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -11,12 +11,13 @@
 
 // out[r] = scale * sum_c part[r][c] * (rowscale ? 1/rowscale[r] : 1)
 __global__ void k_row_sum(const float* __restrict__ part, int rows, int cols,
-                          const float* __restrict__ rowdiv, float* __restrict__ out) {
+                          const float* __restrict__ rowdiv, const long long* __restrict__ divrows,
+                          float* __restrict__ out) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float s = 0.f;
   for (int c = 0; c < cols; ++c) s += part[(size_t)r * cols + c];
-  out[r] = rowdiv ? s / rowdiv[r] : s;
+  out[r] = rowdiv ? s / rowdiv[divrows ? divrows[r] : r] : s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void k_edr_target(float* __restrict__ P, int n
 __global__ __launch_bounds__(256) void k_edr_loss(float* __restrict__ P,
                                                   const float* __restrict__ Tdb,
                                                   const float* __restrict__ sum_abs,
+                                                  const long long* __restrict__ trows,
                                                   const float* __restrict__ wf, int nframes,
                                                   int nfreq, float gscale, int want_grad,
                                                   float* __restrict__ part) {
@@ -56,9 +58,10 @@ __global__ __launch_bounds__(256) void k_edr_loss(float* __restrict__ P,
   float acc = 0.f;
   if (f < nfreq) {
     float* p = P + (size_t)b * nframes * nfreq + f;
-    const float* t = Tdb + (size_t)b * nframes * nfreq + f;
+    const size_t tb = trows ? (size_t)trows[b] : (size_t)b;
+    const float* t = Tdb + tb * nframes * nfreq + f;
     const float w = wf ? wf[f] : 1.0f;
-    const float gs = want_grad ? gscale * w / sum_abs[b] : 0.f;
+    const float gs = want_grad ? gscale * w / sum_abs[tb] : 0.f;
     float E = 0.f;
     for (int m = nframes - 1; m >= 0; --m) {
       E += p[(size_t)m * nfreq];
@@ -102,13 +105,13 @@ extern "C" int gfdn_edr_target(float* P, int batch, int nframes, int nfreq, floa
   hipLaunchKernelGGL(k_edr_target, dim3(fblk, batch), dim3(256), 0, s, P, nframes, nfreq, part);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_row_sum, dim3((batch + 63) / 64), dim3(64), 0, s, part, batch, fblk,
-                     (const float*)nullptr, sum_abs);
+                     (const float*)nullptr, (const long long*)nullptr, sum_abs);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs, const float* wf,
-                             int batch, int nframes, int nfreq, float gscale, int want_grad,
+extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs,
+                             const long long* target_rows, const float* wf, int batch, int nframes, int nfreq, float gscale, int want_grad,
                              float* loss_item, void* work, void* stream) {
   if (!P || !T_db || !sum_abs || !loss_item || !work || batch <= 0 || nframes <= 0 || nfreq <= 0)
     return GFDN_E_BADARG;
@@ -116,11 +119,11 @@ extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs, 
   if (fblk > EDR_MAX_FBLK) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)work;
-  hipLaunchKernelGGL(k_edr_loss, dim3(fblk, batch), dim3(256), 0, s, P, T_db, sum_abs, wf, nframes,
-                     nfreq, gscale, want_grad, part);
+  hipLaunchKernelGGL(k_edr_loss, dim3(fblk, batch), dim3(256), 0, s, P, T_db, sum_abs, target_rows, wf,
+                     nframes, nfreq, gscale, want_grad, part);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_row_sum, dim3((batch + 63) / 64), dim3(64), 0, s, part, batch, fblk, sum_abs,
-                     loss_item);
+                     target_rows, loss_item);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_target(const float* __restr
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __restrict__ x, int ld,
                                                              int start, int len,
                                                              const float* __restrict__ Tdb,
+                                                             const long long* __restrict__ trows,
                                                              const float* __restrict__ maskw,
                                                              float inv_count, float gscale,
                                                              float* __restrict__ work,
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
   const float* xw = x + (size_t)b * ld + start + s0;
-  const float* t = Tdb + (size_t)b * len + s0;
+  const float* t = Tdb + (trows ? (size_t)trows[b] : (size_t)b) * len + s0;
   const float* mw = maskw ? maskw + s0 : nullptr;
   float* gw = gx ? gx + (size_t)b * ld + start + s0 : nullptr;
   float acc = 0.f, gacc = 0.f;
@@ -353,7 +357,8 @@ extern "C" int gfdn_edc_target(const float* x, int ld, int batch, int start, int
 }
 
 extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len,
-                             const float* T_db, const float* maskw, float inv_count, float gscale,
+                             const float* T_db, const long long* target_rows, const float* maskw,
+                             float inv_count, float gscale,
                              float* loss_item, float* gx, void* work, void* stream) {
   if (!x || !T_db || !loss_item || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
     return GFDN_E_BADARG;
@@ -361,7 +366,7 @@ extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int l
   dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
   hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, maskw, inv_count, gscale,
+  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, target_rows, maskw, inv_count, gscale,
                      (float*)work, gx, batch);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,

@@ -18,6 +18,7 @@
 struct MlpDims {
   int B, F, in_dim, H, nl, G;   // F fourier features, in_dim = 6 F, nl = 1 + hidden layers
   float lo, hi;                 // ScaledSigmoid limits
+  const long long* rows;        // item b encodes pos[rows[b]] (NULL: pos[b])
 };
 
 __device__ __forceinline__ size_t mlp_layer_off(const MlpDims& d, int l) {
@@ -36,7 +37,7 @@ extern __shared__ float mlp_lds[];
 __device__ __forceinline__ void mlp_encode(const MlpDims& d, const double* __restrict__ pos,
                                            const float* __restrict__ freq_pi, float* a) {
   // dnn.py:112-124: per frequency k: [sin(f_k pi x) (3) | cos(f_k pi x) (3)], stored as float32
-  const double* p = pos + (size_t)blockIdx.x * 3;
+  const double* p = pos + (d.rows ? (size_t)d.rows[blockIdx.x] : (size_t)blockIdx.x) * 3;
   for (int e = threadIdx.x; e < d.in_dim; e += blockDim.x) {
     const int k = e / 6, r = e - 6 * k;
     const double arg = (double)freq_pi[k] * p[r % 3];
@@ -202,6 +203,7 @@ static int mlp_dims(int B, int F, int H, int n_hidden, int G, float lo, float hi
   if (B <= 0 || F <= 0 || H <= 0 || n_hidden < 0 || G <= 0) return GFDN_E_BADARG;
   if (H > MLP_T || G > MLP_T || 6 * F > 4096) return GFDN_E_UNSUPPORTED;
   d->B = B; d->F = F; d->in_dim = 6 * F; d->H = H; d->nl = 1 + n_hidden; d->G = G; d->lo = lo; d->hi = hi;
+  d->rows = nullptr;
   return 0;
 }
 static size_t mlp_lds_bytes(const MlpDims& d) {
@@ -218,12 +220,13 @@ extern "C" size_t gfdn_mlp_bwd_work_bytes(int B, int F, int H, int n_hidden, int
   return (size_t)B * gfdn_mlp_param_count(F, H, n_hidden, G) * sizeof(float);
 }
 
-extern "C" int gfdn_mlp_gains_fwd(const double* pos, const float* freq_pi, const float* w, int B,
-                                  int F, int H, int n_hidden, int G, float lo, float hi, float* gains,
-                                  float* xhat, float* rstd, void* stream) {
+extern "C" int gfdn_mlp_gains_fwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                  const float* w, int B, int F, int H, int n_hidden, int G, float lo,
+                                  float hi, float* gains, float* xhat, float* rstd, void* stream) {
   MlpDims d;
   int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
   if (rc) return rc;
+  d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd) return GFDN_E_BADARG;
   hipLaunchKernelGGL(k_mlp_fwd, dim3(B), dim3(MLP_T), mlp_lds_bytes(d), (hipStream_t)stream, d, pos,
                      freq_pi, w, gains, xhat, rstd);
@@ -231,13 +234,14 @@ extern "C" int gfdn_mlp_gains_fwd(const double* pos, const float* freq_pi, const
   return 0;
 }
 
-extern "C" int gfdn_mlp_gains_bwd(const double* pos, const float* freq_pi, const float* w, int B,
-                                  int F, int H, int n_hidden, int G, float lo, float hi,
-                                  const float* gains, const float* xhat, const float* rstd,
+extern "C" int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                  const float* w, int B, int F, int H, int n_hidden, int G, float lo,
+                                  float hi, const float* gains, const float* xhat, const float* rstd,
                                   const float* ggains, float* gw, void* work, void* stream) {
   MlpDims d;
   int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
   if (rc) return rc;
+  d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_mlp_bwd, dim3(B), dim3(MLP_T), mlp_lds_bytes(d), s, d, pos, freq_pi, w, gains, xhat,

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
                                                      int nper, const float* __restrict__ c,
                                                      const float* __restrict__ rgain, int B,
                                                      const float2* __restrict__ direct, int ldd,
+                                                     const long long* __restrict__ drows,
                                                      const float2* __restrict__ filt,
                                                      float2* __restrict__ H, int ldh,
                                                      float2* __restrict__ S_out) {
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
 #pragma unroll
   for (int bb = 0; bb < COMPOSE_BCH; ++bb) {       // all loads of the chunk in flight together
     const int b = b0 + bb;
-    d[bb] = (direct && b < B) ? direct[(size_t)b * ldd + k] : make_float2(0.f, 0.f);
+    d[bb] = (direct && b < B) ? direct[(size_t)(drows ? drows[b] : b) * ldd + k] : make_float2(0.f, 0.f);
   }
 #pragma unroll
   for (int bb = 0; bb < COMPOSE_BCH; ++bb) {
@@ -400,8 +401,8 @@ static size_t compose_tile_bytes(int N) { return (size_t)256 * (N + 1) * sizeof(
 
 extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const float* c,
                                 const float* rgain, int B, const float* direct, int ldd,
-                                const float* filt, float* H, int ldh, float* S_out,
-                                void* stream) {
+                                const long long* direct_rows, const float* filt, float* H, int ldh,
+                                float* S_out, void* stream) {
   if (!Y || !c || !rgain || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
   if (G > GFDN_MAX_GROUPS) return GFDN_E_UNSUPPORTED;
   if (ldh < K || (direct && ldd < K)) return GFDN_E_BADARG;
@@ -410,8 +411,8 @@ extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const fl
   int rc = ensure_dyn_lds(k_compose_fwd, compose_tile_bytes(G * nper));
   if (rc) return rc;
   hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), compose_tile_bytes(G * nper), (hipStream_t)stream, (const float2*)Y, K,
-                     G, nper, c, rgain, B, (const float2*)direct, ldd, (const float2*)filt,
-                     (float2*)H, ldh, (float2*)S_out);
+                     G, nper, c, rgain, B, (const float2*)direct, ldd, direct ? direct_rows : nullptr,
+                     (const float2*)filt, (float2*)H, ldh, (float2*)S_out);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

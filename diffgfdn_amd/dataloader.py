@@ -140,12 +140,29 @@ class MultiRIRDataset(torch.utils.data.Dataset):
     def collate(self, indices, lean: bool = False) -> Dict:
         """Batch dict with the reference's keys (custom_collate :674-704) + 'receiver_index'.
         ``lean`` skips gathering responses the training step does not read (the late response
-        always; the full target response when its EDR / EDC are already in the stores)."""
+        always; the full target response when its EDR / EDC are already in the stores).
+        ``lean="rows"`` gathers NOTHING: the per-receiver entries are the dataset-level stores over
+        all receivers and 'row_index' holds the batch's indices into them -- only consumers that
+        honour 'row_index' (VarReceiverPosTrainer._step_losses and the kernels under it) may be
+        given such a batch."""
         if torch.is_tensor(indices):
             idx = indices          # device index tensor (static buffer under graph replay)
         else:
             idx = torch.as_tensor(list(indices), dtype=torch.long, device=self.device)
         B = idx.numel()
+        if lean == "rows":
+            if self.edr_store is None or self.edc_store is None:
+                raise RuntimeError('collate(lean="rows") needs precompute_decay_targets() first')
+            return {
+                'z_values': self.z_values,
+                'source_position': self.source_position[0].expand(B, -1),
+                'norm_listener_position': self.norm_listener_position,
+                'target_early_response': self.early_rir_mag_response,
+                'edr_target': self.edr_store,
+                'edc_target': self.edc_store,
+                'receiver_index': idx,
+                'row_index': idx,
+            }
         batch = {
             'z_values': self.z_values,
             'source_position': self.source_position[0].expand(B, -1),

@@ -57,12 +57,27 @@ class OrthoParam(torch.autograd.Function):
 class MlpGains(torch.autograd.Function):
     """gains (B, G) = ScaledSigmoid(MLP(SinusoidalEncoding(pos)))  (gain_filters.py:497-524) in one
     launch; parameters are passed as separate tensors (autograd hands each its gradient) and packed
-    into one flat buffer with a single cat."""
+    into one flat buffer with a single cat -- or with no copy at all when they already are
+    consecutive views of one buffer (FlatAdam's parameter buffer).  ``rows``: optional int64 index,
+    item b uses pos[rows[b]] (pos = positions of ALL receivers)."""
 
     @staticmethod
-    def forward(ctx, pos, freq_pi, H, n_hidden, G, lo, hi, *params):
-        w = torch.cat([p.reshape(-1) for p in params])
-        gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, n_hidden, G, lo, hi)
+    def _packed(params):
+        p0 = params[0]
+        off = 0
+        for p in params:
+            if (not p.is_contiguous() or p.dtype != torch.float32
+                    or p.data_ptr() != p0.data_ptr() + 4 * off
+                    or p.untyped_storage().data_ptr() != p0.untyped_storage().data_ptr()):
+                return torch.cat([q.reshape(-1) for q in params])
+            off += p.numel()
+        return torch.as_strided(p0.detach(), (off,), (1,), p0.storage_offset())
+
+    @staticmethod
+    def forward(ctx, pos, rows, freq_pi, H, n_hidden, G, lo, hi, *params):
+        w = MlpGains._packed(params)
+        gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, rows)
+        ctx.rows = rows
         ctx.save_for_backward(pos, freq_pi, w, gains, xhat, rstd)
         ctx.cfg = (H, n_hidden, G, lo, hi)
         ctx.shapes = [p.shape for p in params]
@@ -73,7 +88,7 @@ class MlpGains(torch.autograd.Function):
         pos, freq_pi, w, gains, xhat, rstd = ctx.saved_tensors
         H, n_hidden, G, lo, hi = ctx.cfg
         gw = ops.mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd,
-                               ggains.contiguous())
+                               ggains.contiguous(), ctx.rows)
         grads, off = [], 0
         for shp in ctx.shapes:
             n = 1
@@ -81,7 +96,7 @@ class MlpGains(torch.autograd.Function):
                 n *= v
             grads.append(gw[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 class ResolventSolve(torch.autograd.Function):
@@ -108,8 +123,8 @@ class OutputStage(torch.autograd.Function):
     """H[b][k] = (sum_g rgain[b][g] sum_{n in g} c_n Y[k][n] + direct[b][k]) * filt[k]."""
 
     @staticmethod
-    def forward(ctx, Y, c, rgain, nper: int, direct, filt):
-        H = ops.compose_fwd(Y, c, rgain, nper, direct, filt)
+    def forward(ctx, Y, c, rgain, nper: int, direct, filt, direct_rows=None):
+        H = ops.compose_fwd(Y, c, rgain, nper, direct, filt, direct_rows=direct_rows)
         ctx.save_for_backward(Y, c, rgain, filt)
         ctx.nper = nper
         return H
@@ -118,7 +133,7 @@ class OutputStage(torch.autograd.Function):
     def backward(ctx, gH):
         Y, c, rgain, filt = ctx.saved_tensors
         gY, gc, grg = ops.compose_bwd(Y, c, rgain, ctx.nper, gH.contiguous(), filt)
-        return gY, gc.to(c.dtype).reshape(c.shape), grg.to(rgain.dtype), None, None, None
+        return gY, gc.to(c.dtype).reshape(c.shape), grg.to(rgain.dtype), None, None, None, None
 
 
 class SHOutputStage(torch.autograd.Function):

@@ -49,6 +49,11 @@ class Gains_from_MLP(nn.Module):
         network (their parameters ARE the kernel's weights) and serve as the CPU / odd-shape path."""
         position = x['norm_listener_position'] if self.position_type == "output_gains" \
             else x['source_position']
+        # 'row_index' (MultiRIRDataset.collate(..., lean="rows")): positions are the store of ALL
+        # receivers and the batch is the int64 index into it
+        rows = x.get('row_index') if self.position_type == "output_gains" else None
+        if rows is not None and not self._fused_ok(position):
+            position, rows = position[rows], None
         if self._fused_ok(position):
             from .functional import MlpGains
             lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
@@ -57,7 +62,7 @@ class Gains_from_MLP(nn.Module):
                 f = torch.exp(torch.linspace(math.log(1.0), math.log(32.0), n, device=position.device))
                 self._freq_pi = (f * math.pi).contiguous()
             params = [p for m in self.mlp.model for p in m.parameters()]
-            self.gains = MlpGains.apply(position, self._freq_pi, lin[0].out_features, len(lin) - 2,
+            self.gains = MlpGains.apply(position, rows, self._freq_pi, lin[0].out_features, len(lin) - 2,
                                         self.num_groups, self.scaled_sigmoid.lower_limit,
                                         self.scaled_sigmoid.upper_limit, *params)
             return self.gains

@@ -106,8 +106,21 @@ def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False):
     return gA, gb, gig
 
 
-def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False):
-    """Y (K,N) c64, c (N,), rgain (B,G) -> H (B,K) c64 [, S (G,K) c64]."""
+def _rows(rows, n_items: int, store_rows: int):
+    """Validate a row-indirection index (int64 device vector of n_items entries)."""
+    if rows is None:
+        return None
+    _need_gpu(rows)
+    if rows.dtype != torch.int64 or rows.dim() != 1 or rows.numel() != n_items or not rows.is_contiguous():
+        raise RuntimeError("row indirection: expected a contiguous int64 device vector with one entry per item")
+    if store_rows <= 0:
+        raise RuntimeError("row indirection: empty store")
+    return rows
+
+
+def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False, direct_rows=None):
+    """Y (K,N) c64, c (N,), rgain (B,G) -> H (B,K) c64 [, S (G,K) c64].
+    ``direct_rows``: item b adds row direct_rows[b] of ``direct`` (a store of all receivers)."""
     _need_gpu(Y, c, rgain)
     Y, c, rgain = _c(Y), _f(c), _f(rgain)
     K, N = Y.shape
@@ -122,10 +135,13 @@ def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False):
             direct = _c(direct)
         ldd = direct.stride(0)
     filt = None if filt is None else _c(filt)
+    direct_rows = None if direct is None else _rows(direct_rows, B, direct.shape[0])
+    if direct is not None and direct_rows is None and direct.shape[0] != B:
+        raise RuntimeError("compose_fwd: direct must have one row per item (or pass direct_rows)")
     H = torch.empty((B, K), dtype=_c64, device=Y.device)
     S = torch.empty((G, K), dtype=_c64, device=Y.device) if want_S else None
     _lib.check(_lib.load().gfdn_compose_fwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(direct),
-                                            ldd, _p(filt), _p(H), K,
+                                            ldd, _p(direct_rows), _p(filt), _p(H), K,
                                             _p(S), _stream()), "gfdn_compose_fwd")
     return (H, S) if want_S else H
 
@@ -255,26 +271,32 @@ def irfft_odd_fwd(X, n: int) -> torch.Tensor:
     x = torch.empty((batch, n), dtype=_f32, device=X.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
     if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
-        _staged_bluestein(lib, table, n, X, ldx, batch, x, n, work, 0)
+        _staged_bluestein(lib, table, n, X, None, ldx, batch, x, n, work, 0)
         return x
     _lib.check(lib.gfdn_irfft_odd_fwd(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work),
                                       _stream()), "gfdn_irfft_odd_fwd")
     return x
 
 
-def irfft_odd_bwd(gx, n: int, ldx: int) -> torch.Tensor:
-    """gx (batch, n) f32 -> gX (batch, ldx) c64 (adjoint of irfft_odd_fwd)."""
+def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None) -> torch.Tensor:
+    """gx (batch, n) f32 -> gX (batch, ldx) c64 (adjoint of irfft_odd_fwd).  ``gx2``: optional second
+    gradient of the same shape; the transform is applied to gx + gx2 (summed on load)."""
     _need_gpu(gx)
     gx = _f(gx)
     batch = gx.shape[0]
+    if gx2 is not None:
+        _need_gpu(gx2)
+        gx2 = _f(gx2)
+        if gx2.shape != gx.shape:
+            raise RuntimeError("irfft_odd_bwd: gx2 must have the shape of gx")
     lib = _lib.load()
     table = bluestein_table(n, gx.device)
     gX = torch.empty((batch, ldx), dtype=_c64, device=gx.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), gx.device)
     if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
-        _staged_bluestein(lib, table, n, gx, gx.shape[1], batch, gX, ldx, work, 1)
+        _staged_bluestein(lib, table, n, gx, gx2, gx.shape[1], batch, gX, ldx, work, 1)
         return gX
-    _lib.check(lib.gfdn_irfft_odd_bwd(_p(table), n, _p(gx), gx.shape[1], batch, _p(gX), ldx,
+    _lib.check(lib.gfdn_irfft_odd_bwd(_p(table), n, _p(gx), _p(gx2), gx.shape[1], batch, _p(gX), ldx,
                                       _p(work), _stream()), "gfdn_irfft_odd_bwd")
     return gX
 
@@ -282,9 +304,9 @@ def irfft_odd_bwd(gx, n: int, ldx: int) -> torch.Tensor:
 _BLU_STAGES = {'k_blu_col_fwd': 1, 'k_blu_row': 2, 'k_blu_col_inv': 4}
 
 
-def _staged_bluestein(lib, table, n, src, ld_in, batch, dst, ld_out, work, adjoint):
+def _staged_bluestein(lib, table, n, src, src2, ld_in, batch, dst, ld_out, work, adjoint):
     """Same three launches as the fused entry point, with HIP events around the watched one."""
-    args = (_p(table), n, _p(src), ld_in, batch, _p(dst), ld_out, _p(work), adjoint)
+    args = (_p(table), n, _p(src), _p(src2), ld_in, batch, _p(dst), ld_out, _p(work), adjoint)
     for name, stage in _BLU_STAGES.items():
         end = kernel_timer.bracket(name, batch)
         _lib.check(lib.gfdn_irfft_odd_stages(*args, stage, _stream()), "gfdn_irfft_odd_stages[%s]" % name)
@@ -350,14 +372,19 @@ def stft_nframes(T: int, win: int) -> int:
     return nf
 
 
-def stft_power(x, win: int) -> torch.Tensor:
-    """x (batch, T) f32 -> P (batch, nframes, win/2+1) = |STFT|^2."""
+def stft_power(x, win: int, zero_buf=None) -> torch.Tensor:
+    """x (batch, T) f32 -> P (batch, nframes, win/2+1) = |STFT|^2.  ``zero_buf``: a (batch, T) float32
+    buffer cleared by the same launch (the accumulation buffer of stft_power_bwd)."""
     _need_gpu(x)
     x = _f(x)
     batch, T = x.shape
     nf = stft_nframes(T, win)
+    if zero_buf is not None:
+        _need_gpu(zero_buf)
+        if zero_buf.dtype != _f32 or zero_buf.shape != x.shape or not zero_buf.is_contiguous():
+            raise RuntimeError("stft_power: zero_buf must be a contiguous float32 buffer shaped like x")
     P = torch.empty((batch, nf, win // 2 + 1), dtype=_f32, device=x.device)
-    _lib.check(_lib.load().gfdn_stft_power(_p(x), T, T, batch, win, _p(P), _stream()),
+    _lib.check(_lib.load().gfdn_stft_power(_p(x), T, T, batch, win, _p(P), _p(zero_buf), _stream()),
                "gfdn_stft_power")
     return P
 
@@ -386,16 +413,21 @@ def edr_target(P: torch.Tensor):
     return P, sum_abs
 
 
-def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = True):
-    """In place on P (achieved |STFT|^2): returns loss_item (batch,); P becomes dloss/dP."""
+def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = True, rows=None):
+    """In place on P (achieved |STFT|^2): returns loss_item (batch,); P becomes dloss/dP.
+    ``rows``: item b compares against row rows[b] of the (all-receiver) target store."""
     _need_gpu(P, T_db)
-    assert P.dtype == _f32 and P.is_contiguous() and T_db.is_contiguous()
+    assert P.dtype == _f32 and P.is_contiguous() and T_db.is_contiguous() and T_db.dtype == _f32
     batch, nframes, nfreq = P.shape
+    rows = _rows(rows, batch, T_db.shape[0])
+    if tuple(T_db.shape[1:]) != (nframes, nfreq) or (rows is None and T_db.shape[0] != batch) \
+            or sum_abs.numel() != T_db.shape[0]:
+        raise RuntimeError("edr_loss: target shape does not match the achieved EDR")
     lib = _lib.load()
     wf = None if wf is None else _f(wf)
     loss_item = torch.empty(batch, dtype=_f32, device=P.device)
     work = _work(lib.gfdn_edr_work_bytes(batch, nfreq), P.device)
-    _lib.check(lib.gfdn_edr_loss(_p(P), _p(T_db), _p(sum_abs), _p(wf), batch, nframes, nfreq,
+    _lib.check(lib.gfdn_edr_loss(_p(P), _p(T_db), _p(sum_abs), _p(rows), _p(wf), batch, nframes, nfreq,
                                  float(gscale), int(want_grad), _p(loss_item), _p(work), _stream()),
                "gfdn_edr_loss")
     return loss_item
@@ -414,17 +446,21 @@ def edc_target(x, start: int, length: int) -> torch.Tensor:
 
 
 def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
-             gscale: float = 1.0, want_grad: bool = True):
-    """-> loss_item (batch,), gx (batch, ld) or None."""
+             gscale: float = 1.0, want_grad: bool = True, rows=None):
+    """-> loss_item (batch,), gx (batch, ld) or None.  ``rows``: as in edr_loss."""
     _need_gpu(x, T_db)
     x = _f(x)
     batch, ld = x.shape
+    rows = _rows(rows, batch, T_db.shape[0])
+    if T_db.dtype != _f32 or not T_db.is_contiguous() or T_db.shape[-1] != length \
+            or (rows is None and T_db.shape[0] != batch):
+        raise RuntimeError("edc_loss: target shape does not match the window")
     maskw = None if maskw is None else _f(maskw)
     loss_item = torch.empty(batch, dtype=_f32, device=x.device)
     gx = torch.empty_like(x) if want_grad else None
     lib = _lib.load()
     work = _work(lib.gfdn_edc_work_bytes(batch), x.device)
-    _lib.check(lib.gfdn_edc_loss(_p(x), ld, batch, start, length, _p(T_db), _p(maskw),
+    _lib.check(lib.gfdn_edc_loss(_p(x), ld, batch, start, length, _p(T_db), _p(rows), _p(maskw),
                                  float(inv_count), float(gscale), _p(loss_item), _p(gx), _p(work),
                                  _stream()), "gfdn_edc_loss")
     return loss_item, gx
@@ -447,12 +483,14 @@ def draw_mask(seed: int, state, length: int, scale: float, out=None):
     return out
 
 
-def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float):
-    """pos (B,3) f64, freq_pi (F,) f32, w packed params -> gains (B,G), xhat (B,nl,H), rstd (B,nl)."""
+def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float, rows=None):
+    """pos (B,3) f64, freq_pi (F,) f32, w packed params -> gains (B,G), xhat (B,nl,H), rstd (B,nl).
+    ``rows``: item b encodes pos[rows[b]] (pos = the positions of all receivers)."""
     _need_gpu(pos, w)
     pos = pos.detach().to(torch.float64).contiguous()
     w = _f(w)
-    B, F = pos.shape[0], freq_pi.numel()
+    B, F = (pos.shape[0] if rows is None else rows.numel()), freq_pi.numel()
+    rows = _rows(rows, B, pos.shape[0])
     lib = _lib.load()
     if w.numel() != lib.gfdn_mlp_param_count(F, H, n_hidden, G):
         raise RuntimeError("mlp_gains: packed parameter count does not match the layer sizes")
@@ -460,21 +498,22 @@ def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi:
     gains = torch.empty((B, G), dtype=_f32, device=pos.device)
     xhat = torch.empty((B, nl, H), dtype=_f32, device=pos.device)
     rstd = torch.empty((B, nl), dtype=_f32, device=pos.device)
-    _lib.check(lib.gfdn_mlp_gains_fwd(_p(pos), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
+    _lib.check(lib.gfdn_mlp_gains_fwd(_p(pos), _p(rows), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
                                       float(hi), _p(gains), _p(xhat), _p(rstd), _stream()),
                "gfdn_mlp_gains_fwd")
     return gains, xhat, rstd
 
 
-def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains):
+def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains, rows=None):
     _need_gpu(pos, w, ggains)
     pos = pos.detach().to(torch.float64).contiguous()
     w, ggains = _f(w), _f(ggains)
-    B, F = pos.shape[0], freq_pi.numel()
+    B, F = (pos.shape[0] if rows is None else rows.numel()), freq_pi.numel()
+    rows = _rows(rows, B, pos.shape[0])
     lib = _lib.load()
     gw = torch.empty_like(w)
     work = _work(lib.gfdn_mlp_bwd_work_bytes(B, F, H, n_hidden, G), pos.device)
-    _lib.check(lib.gfdn_mlp_gains_bwd(_p(pos), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
+    _lib.check(lib.gfdn_mlp_gains_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
                                       float(hi), _p(gains), _p(xhat), _p(rstd), _p(ggains), _p(gw),
                                       _p(work), _stream()), "gfdn_mlp_gains_bwd")
     return gw

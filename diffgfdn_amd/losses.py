@@ -136,7 +136,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  edr_target: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                  edc_target: Optional[torch.Tensor] = None,
                  side_stream: Optional["torch.cuda.Stream"] = None,
-                 unit_grad: bool = False, n_time: Optional[int] = None
+                 unit_grad: bool = False, n_time: Optional[int] = None,
+                 target_rows: Optional[torch.Tensor] = None
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
@@ -150,7 +151,10 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     that the returned total enters the final loss with weight 1 (skips one rescale of dL/dH).
     The returned ``edr`` / ``edc`` are the WEIGHTED parts.  ``n_time``: length of the time response
     (= number of bins K of the full grid); H may then hold only the (K+1)/2 bins the transform
-    irfft(X, n = K) actually reads."""
+    irfft(X, n = K) actually reads.  ``target_rows``: int64 index; ``edr_target`` / ``edc_target``
+    are then stores over ALL receivers and item b compares against row target_rows[b]."""
+    if target_rows is not None and (edr_target is None and use_edr or edc_target is None and use_edc):
+        raise ValueError("target_rows needs precomputed target stores")
     targets = targets or _default_targets
     Hb = _as_batch(H)
     B, ldx = Hb.shape
@@ -164,7 +168,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         # losses.py:447-451: undo sampling on a larger circle (EDR only in the reference)
         env = torch.pow(torch.tensor(1.0 / reduced_pole_radius, dtype=torch.float64, device=x.device),
                         torch.arange(K, device=x.device, dtype=torch.float64)).to(torch.float32)
-    gx = None
+    gx = gx2 = None
     li_edc = li_edr = None
     main = torch.cuda.current_stream() if x.is_cuda else None
     fork = side_stream is not None and use_edc and use_edr
@@ -179,21 +183,24 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         if fork:
             side_stream.wait_stream(main)
             with torch.cuda.stream(side_stream):
-                li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
+                li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad,
+                                          rows=target_rows)
                 x.record_stream(side_stream)
         else:
-            li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad)
+            li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad,
+                                      rows=target_rows)
     if use_edr:
         T_edr, sum_abs = edr_target if edr_target is not None else targets.edr(target, win)
         xe = x if env is None else x * env
-        P = ops.stft_power(xe, win)
-        li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad)
-        g_edr = None
+        # the STFT adjoint scatters exactly two frame terms per sample with atomic adds into a
+        # ZEROED buffer (a + b commutes -> order independent, bitwise reproducible), cleared by
+        # the forward STFT launch; the adjoint irfft then reads EDC gradient + this buffer, in
+        # that order, so the three-term sum has a fixed order too
+        g_edr = torch.empty_like(x) if want_grad else None
+        P = ops.stft_power(xe, win, zero_buf=g_edr)
+        li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad, rows=target_rows)
         if want_grad:
-            # the STFT adjoint scatters exactly two frame terms per sample with atomic adds into a
-            # ZEROED buffer (a + b commutes -> order independent, bitwise reproducible); adding it
-            # onto the EDC gradient afterwards keeps the three-term sum in a fixed order
-            g_edr = ops.stft_power_bwd(xe, win, P, torch.zeros_like(x))
+            g_edr = ops.stft_power_bwd(xe, win, P, g_edr)
             if env is not None:
                 g_edr = g_edr * env
         if fork:
@@ -202,10 +209,10 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                 if t is not None:
                     t.record_stream(main)
         if want_grad:
-            gx = g_edr if gx is None else gx.add_(g_edr)
+            gx, gx2 = (g_edr, None) if gx is None else (gx, g_edr)
     sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
     if want_grad:
-        gH = ops.irfft_odd_bwd(gx, K, ldx)
+        gH = ops.irfft_odd_bwd(gx, K, ldx, gx2)
         total = _ScalarLossWithSavedGrad.apply(H, sums[0], gH, unit_grad)
     else:
         total = sums[0]

@@ -326,9 +326,10 @@ class VarReceiverPosTrainer(Trainer):
         Ku = (K + 1) // 2 if K % 2 == 1 else K
         zu = z[:Ku]
         Y = net.delay_line_responses(zu)
+        rows = data.get('row_index')         # collate(lean="rows"): per-receiver entries are stores
         H = OutputStage.apply(Y, net.output_gains.reshape(-1), rgain.to(torch.float32), n,
                               data['target_early_response'][:, :Ku],
-                              None if filt is None else filt[:Ku])
+                              None if filt is None else filt[:Ku], rows)
         start, length = self._decay_window(K)
         B = H.shape[0]
         gb = B
@@ -356,7 +357,7 @@ class VarReceiverPosTrainer(Trainer):
             global_batch=gb,
             edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
             edc_target=None if edc_t is None else edc_t[1],
-            side_stream=self._side_stream2(), unit_grad=True, n_time=K)
+            side_stream=self._side_stream2(), unit_grad=True, n_time=K, target_rows=rows)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
         if extra is not None:
             if side is not None:
@@ -557,13 +558,10 @@ class GraphedTrainStep:
         tr = self.tr
         if self.mask_source == "device" and tr.criterion[1].use_mask:
             ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
-        batch = self.ds.collate(self.idx, lean=True)
+        # no gather: the kernels read the dataset-level stores through the static index buffer
+        batch = self.ds.collate(self.idx, lean="rows")
         tr.optimizer.zero_grad(set_to_none=True)
-        if os.environ.get("GFDN_AB") == "1":
-            tr.normalize(batch)
-            losses = tr._step_losses(batch, mask_prenorm=self.maskw)
-        else:
-            losses = tr._step_losses(batch, mask_prenorm=self.maskw, normalize_first=True)
+        losses = tr._step_losses(batch, mask_prenorm=self.maskw, normalize_first=True)
         losses['_total'].backward()
         return losses
 

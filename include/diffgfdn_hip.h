@@ -78,11 +78,15 @@ int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int
  *   H[b][k]  = (sum_g rgain[b][g] S[g][k] + direct[b][k]) * filt[k]
  * rgain: (B, G) receiver gains (MLP output, or eye(G) to obtain the sub-FDN responses
  * model.py:243-250); direct (B, ldd) complex64 or NULL; filt (K) complex64 or NULL;
- * S_out (G, K) complex64 or NULL.                                                         */
+ * S_out (G, K) complex64 or NULL.
+ * Row indirection (here and in gfdn_edr_loss / gfdn_edc_loss / gfdn_mlp_gains_*): when the int64
+ * device array `*_rows` (B entries) is not NULL, item b reads row rows[b] of a dataset-level
+ * store (all receivers) instead of row b of a gathered batch -- the gather of custom_collate
+ * (dataloader.py:674-704) never materialises.  The caller guarantees 0 <= rows[b] < store rows. */
 int gfdn_compose_fwd(const float* Y_c64, int K, int G, int nper, const float* c,
                      const float* rgain, int B, const float* direct_c64, int ldd,
-                     const float* filt_c64, float* H_c64, int ldh, float* S_out_c64,
-                     void* stream);
+                     const long long* direct_rows, const float* filt_c64, float* H_c64, int ldh,
+                     float* S_out_c64, void* stream);
 
 /* Backward: gH (B, ldh) complex64 (gradient w.r.t. the FILTERED H when filt != NULL) ->
  *   gY (K, N) complex64, gc (N), grgain (B, G).   work: gfdn_compose_bwd_work_bytes(). */
@@ -141,15 +145,17 @@ int gfdn_bluestein_table_init(int n, void* table);
 size_t gfdn_bluestein_work_bytes(int n, int batch);
 int gfdn_irfft_odd_fwd(const void* table, int n, const float* X_c64, int ldx, int batch,
                        float* x, int ldo, void* work, void* stream);
-/* adjoint: gx (batch, ldo) -> gX (batch, ldx) complex64; bins above (n-1)/2 are set to 0. */
-int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, int ldo, int batch,
-                       float* gX_c64, int ldx, void* work, void* stream);
+/* adjoint: gx (batch, ldo) -> gX (batch, ldx) complex64; bins above (n-1)/2 are set to 0.
+ * gx2: optional second gradient of the same shape, summed in on load (gx + gx2, in that
+ * order) -- the EDC and EDR gradients of one response meet here without an add kernel.   */
+int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
+                       int batch, float* gX_c64, int ldx, void* work, void* stream);
 
 /* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
  * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so
  * that one kernel can be bracketed by HIP events on the launch stream (bench.py's roofline leg).
- * adjoint = 0: in = X (complex), out = x (real); adjoint = 1: in = gx (real), out = gX.     */
-int gfdn_irfft_odd_stages(const void* table, int n, const void* in, int ld_in, int batch,
+ * adjoint = 0: in = X (complex), out = x (real); adjoint = 1: in = gx (real) [+ in2], out = gX. */
+int gfdn_irfft_odd_stages(const void* table, int n, const void* in, const float* in2, int ld_in, int batch,
                           void* out, int ld_out, void* work, int adjoint, int stages,
                           void* stream);
 
@@ -171,18 +177,22 @@ int gfdn_rfft_pow2(int n, const float* x, int ld, int T, int batch, float* X_c64
 
 /* ---- EDR  (losses.py:501-575: STFT Hann(win) hop win/2 center=False, tail energy, dB) ----
  * x: (batch, ld) float, T valid samples, implicitly zero-padded to a multiple of hop.
- * nframes = gfdn_stft_nframes(T, win).  P: (batch, nframes, win/2+1) float = |STFT|^2.    */
+ * nframes = gfdn_stft_nframes(T, win).  P: (batch, nframes, win/2+1) float = |STFT|^2.
+ * zero_buf: optional (batch, ld) float buffer cleared by the same launch (the accumulation
+ * buffer gfdn_stft_power_bwd will add into), or NULL.                                     */
 int gfdn_stft_nframes(int T, int win);
-int gfdn_stft_power(const float* x, int ld, int T, int batch, int win, float* P, void* stream);
+int gfdn_stft_power(const float* x, int ld, int T, int batch, int win, float* P, float* zero_buf,
+                    void* stream);
 /* in place: P -> EDR in dB (10 log10(sum_{tau>=m} P + eps), clipped at -200); sum_abs[b] =
  * sum |EDR| (the per-item normaliser of losses.py:487-490).                               */
 size_t gfdn_edr_work_bytes(int batch, int nfreq);
 int gfdn_edr_target(float* P_inout, int batch, int nframes, int nfreq, float* sum_abs,
                     void* work, void* stream);
 /* achieved side: loss_item[b] = sum_{f,m} wf[f] |T_db - EDR| / sum_abs[b]  (losses.py:478-492)
- * and, when want_grad, P is overwritten with gscale * dloss/dP.                           */
-int gfdn_edr_loss(float* P_inout, const float* T_db, const float* sum_abs, const float* wf,
-                  int batch, int nframes, int nfreq, float gscale, int want_grad,
+ * and, when want_grad, P is overwritten with gscale * dloss/dP.  target_rows: row indirection
+ * into T_db / sum_abs (see gfdn_compose_fwd) or NULL.                                      */
+int gfdn_edr_loss(float* P_inout, const float* T_db, const float* sum_abs,
+                  const long long* target_rows, const float* wf, int batch, int nframes, int nfreq, float gscale, int want_grad,
                   float* loss_item, void* work, void* stream);
 /* adjoint of gfdn_stft_power: gx[b][t] += dL/dx from gP (atomic adds of exactly two frames
  * per sample, hence order-independent).                                                   */
@@ -199,7 +209,7 @@ size_t gfdn_edc_work_bytes(int batch);
 int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float* T_db,
                     void* work, void* stream);
 int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const float* T_db,
-                  const float* maskw, float inv_count, float gscale, float* loss_item,
+                  const long long* target_rows, const float* maskw, float inv_count, float gscale, float* loss_item,
                   float* gx, void* work, void* stream);
 
 /* ---- EDC time mask on the device  (losses.py:221-227: mask = argwhere(bernoulli(U(0,1))) over the
@@ -218,15 +228,16 @@ int gfdn_draw_mask(unsigned long long seed, unsigned long long* state, int len, 
  * :21-36).  pos (B,3) float64 normalised coordinates; freq_pi (F) float32 = f32(freq_k * pi);
  * w: all parameters packed in named_parameters() order
  *   [W0 (H x 6F) | b0 | gamma0 | beta0 | W1 (H x H) | b1 | gamma1 | beta1 | ... | Wout (G x H) | bout];
+ * pos_rows: row indirection into pos (see gfdn_compose_fwd) or NULL.
  * gains (B,G) = lo + (hi-lo) sigmoid(MLP(encoding(pos))).  xhat (B, 1+n_hidden, H) and rstd
  * (B, 1+n_hidden) are saved for the backward, which returns gw (same packing as w).        */
 size_t gfdn_mlp_param_count(int F, int H, int n_hidden, int G);
 size_t gfdn_mlp_bwd_work_bytes(int B, int F, int H, int n_hidden, int G);
-int gfdn_mlp_gains_fwd(const double* pos, const float* freq_pi, const float* w, int B, int F, int H,
-                       int n_hidden, int G, float lo, float hi, float* gains, float* xhat,
+int gfdn_mlp_gains_fwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                       const float* w, int B, int F, int H, int n_hidden, int G, float lo, float hi, float* gains, float* xhat,
                        float* rstd, void* stream);
-int gfdn_mlp_gains_bwd(const double* pos, const float* freq_pi, const float* w, int B, int F, int H,
-                       int n_hidden, int G, float lo, float hi, const float* gains,
+int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                       const float* w, int B, int F, int H, int n_hidden, int G, float lo, float hi, const float* gains,
                        const float* xhat, const float* rstd, const float* ggains, float* gw,
                        void* work, void* stream);
 

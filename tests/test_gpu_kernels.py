@@ -302,3 +302,68 @@ def test_draw_mask_bit_exact(length):
         kept = (out > 0).float().mean().item()
         assert abs(kept - 0.5) < 4 * 0.5 / np.sqrt(length)
         assert abs(out.double().sum().item() * 32 - 1.0) < 1e-5
+
+
+def test_row_indirection_equals_gather(ops):
+    """Every kernel that takes a `*_rows` index reads row rows[b] of the all-receiver store and
+    gives bit-identical results to the same call on the gathered batch (custom_collate :674-704)."""
+    torch.manual_seed(5)
+    R, B, K, G, nper = 11, 6, 700, 3, 2
+    rows = torch.tensor([7, 0, 10, 3, 3, 5], device=DEV)
+    # output stage
+    Y = torch.randn(K, G * nper, dtype=torch.complex64, device=DEV)
+    c = torch.randn(G * nper, device=DEV)
+    rg = torch.randn(B, G, device=DEV)
+    store = torch.randn(R, K + 50, dtype=torch.complex64, device=DEV)
+    Ha = ops.compose_fwd(Y, c, rg, nper, store[:, :K], None, direct_rows=rows)
+    Hb = ops.compose_fwd(Y, c, rg, nper, store[rows][:, :K].contiguous(), None)
+    assert torch.equal(torch.view_as_real(Ha), torch.view_as_real(Hb))
+    with pytest.raises(RuntimeError):
+        ops.compose_fwd(Y, c, rg, nper, store[:, :K], None)          # store without rows
+    # EDR
+    T, win = 3000, 256
+    xs = torch.randn(R, T, device=DEV) * torch.exp(-torch.arange(T, device=DEV) / 600.0)
+    Tdb, sabs = ops.edr_target(ops.stft_power(xs, win))
+    x = torch.randn(B, T, device=DEV) * torch.exp(-torch.arange(T, device=DEV) / 500.0)
+    Pa, Pb = ops.stft_power(x, win), ops.stft_power(x, win)
+    la = ops.edr_loss(Pa, Tdb, sabs, None, 1.0, True, rows=rows)
+    lb = ops.edr_loss(Pb, Tdb[rows].contiguous(), sabs[rows].contiguous(), None, 1.0, True)
+    assert torch.equal(la, lb) and torch.equal(Pa, Pb)
+    # EDC
+    start, L = 100, 2500
+    Te = ops.edc_target(xs, start, L)
+    la, ga = ops.edc_loss(x, start, L, Te, None, 1.0 / (B * L), 1.0, True, rows=rows)
+    lb, gb = ops.edc_loss(x, start, L, Te[rows].contiguous(), None, 1.0 / (B * L), 1.0, True)
+    assert torch.equal(la, lb) and torch.equal(ga, gb)
+    # gain network
+    from diffgfdn_amd.gain_filters import Gains_from_MLP
+    mod = Gains_from_MLP(G, nper, 5, 2, 16).to(DEV)
+    pos = torch.rand(R, 3, dtype=torch.float64, device=DEV)
+    z = torch.zeros(4, device=DEV)
+    ga = mod.group_gains({"norm_listener_position": pos, "z_values": z, "row_index": rows})
+    ga.square().sum().backward()
+    grads_a = [p.grad.clone() for p in mod.parameters()]
+    mod.zero_grad()
+    gb = mod.group_gains({"norm_listener_position": pos[rows], "z_values": z})
+    gb.square().sum().backward()
+    assert torch.equal(ga, gb)
+    for a, p in zip(grads_a, mod.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+def test_stft_zero_fill_and_two_input_adjoint(ops):
+    """gfdn_stft_power clears the adjoint's accumulation buffer in the same launch;
+    gfdn_irfft_odd_bwd(gx, gx2) == gfdn_irfft_odd_bwd(gx + gx2)."""
+    torch.manual_seed(6)
+    for T, win in ((3000, 256), (257, 64), (4096, 512)):
+        x = torch.randn(3, T, device=DEV)
+        buf = torch.full_like(x, float("nan"))
+        P = ops.stft_power(x, win, zero_buf=buf)
+        assert torch.equal(buf, torch.zeros_like(x))
+        assert torch.equal(P, ops.stft_power(x, win))
+    for n in (257, 65537, 1001):
+        ld = (n + 1) // 2
+        a, b = torch.randn(4, n, device=DEV), torch.randn(4, n, device=DEV)
+        two = ops.irfft_odd_bwd(a, n, ld, b)
+        one = ops.irfft_odd_bwd(a + b, n, ld)
+        assert torch.equal(torch.view_as_real(two), torch.view_as_real(one))
