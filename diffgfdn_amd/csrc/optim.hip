@@ -9,13 +9,15 @@
 #include "common.h"
 
 // step_count: device float holding t-1 on entry; every thread uses t = step_count + 1.
-// A separate 1-thread kernel advances the counter afterwards (no intra-launch race).
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
+// advance != 0 (single-block launches only): the block writes t back after a barrier that every
+// thread reaches after its read; multi-block launches leave it to the 1-thread kernel below
+// (no intra-launch race).
+__global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v,
                                               const unsigned char* __restrict__ seg,
                                               const float* __restrict__ lr_seg,
-                                              const float* __restrict__ step_count, int n, float b1,
-                                              float b2, float eps) {
+                                              float* __restrict__ step_count, int n, float b1,
+                                              float b2, float eps, int advance) {
   const float t = step_count[0] + 1.0f;
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
@@ -28,6 +30,10 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= (lr_seg[seg[i]] / bc1) * (mi / denom);
   }
+  if (advance) {
+    __syncthreads();
+    if (threadIdx.x == 0) step_count[0] = t;
+  }
 }
 __global__ void k_adam_advance(float* step_count) {
   if (threadIdx.x == 0 && blockIdx.x == 0) step_count[0] += 1.0f;
@@ -38,10 +44,16 @@ extern "C" int gfdn_adam_step(float* p, const float* g, float* m, float* v, cons
                               float eps, void* stream) {
   if (!p || !g || !m || !v || !seg || !lr_seg || !step_count || n <= 0) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  if (n <= 16 * 1024) {          // one block: update + counter advance in a single launch
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
+                       beta1, beta2, eps, 1);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
-                     beta1, beta2, eps);
+                     beta1, beta2, eps, 0);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, s, step_count);
   GFDN_LAUNCH_CHECK();

@@ -193,16 +193,22 @@ class ColorlessTerms(torch.autograd.Function):
         need = S.requires_grad or Q.requires_grad
         _, loss_g, gS = ops.spectral_stats(S, asym, w_spec * inv_world, want_grad=need)
         out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the two report outputs
         ctx.save_for_backward(gS, gQ)
         ctx.unit_grad = unit_grad
-        return out
+        # three 0-dim outputs of the node itself (indexing the result outside would put a
+        # select-backward = zero fill + copy in front of the gradient)
+        total, spec, sparse = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(spec, sparse)
+        return total, spec, sparse
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, g, _g1, _g2):
         gS, gQ = ctx.saved_tensors
+        if g is None:
+            return (None,) * 7
         if ctx.unit_grad:
             return gS, gQ, None, None, None, None, None
-        g = gout[0]
         return gS * g.to(gS.dtype), gQ * g, None, None, None, None, None
 
 

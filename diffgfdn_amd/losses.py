@@ -124,6 +124,32 @@ class _ScalarLossWithSavedGrad(torch.autograd.Function):
         return (gH * g).reshape(ctx.h_shape), None, None, None
 
 
+class _DecayTotal(torch.autograd.Function):
+    """[w_edr sum(edr_items) + w_edc sum(edc_items), w_edr sum(.), w_edc sum(.)] as three 0-dim outputs
+    of ONE bookkeeping launch, the first carrying the precomputed dloss/dH.  The outputs are created
+    inside the node: no clone, no select-backward (zero fill + copy) on the way to the loss."""
+
+    @staticmethod
+    def forward(ctx, H, gH, unit_grad, li_edr, w_edr, li_edc, w_edc):
+        sums = ops.weighted_sums(li_edr, w_edr, li_edc, w_edc)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the two report outputs
+        ctx.save_for_backward(gH)
+        ctx.h_shape = H.shape
+        ctx.unit_grad = unit_grad
+        total, edr, edc = sums[0], sums[1], sums[2]
+        ctx.mark_non_differentiable(edr, edc)
+        return total, edr, edc
+
+    @staticmethod
+    def backward(ctx, g, _g1, _g2):
+        (gH,) = ctx.saved_tensors
+        if g is None:
+            return (None,) * 7
+        if ctx.unit_grad:
+            return gH.reshape(ctx.h_shape), None, None, None, None, None, None
+        return (gH * g).reshape(ctx.h_shape), None, None, None, None, None, None
+
+
 def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win: int = 4096,
                  edr_weight: float = 1.0, edc_weight: float = 1.0, use_edr: bool = True,
                  use_edc: bool = True, edc_start: int = 640, edc_len: Optional[int] = None,
@@ -210,13 +236,11 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                     t.record_stream(main)
         if want_grad:
             gx, gx2 = (g_edr, None) if gx is None else (gx, g_edr)
-    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
     if want_grad:
         gH = ops.irfft_odd_bwd(gx, K, ldx, gx2)
-        total = _ScalarLossWithSavedGrad.apply(H, sums[0], gH, unit_grad)
-    else:
-        total = sums[0]
-    return total, sums[1], sums[2]
+        return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight)
+    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
+    return sums[0], sums[1], sums[2]
 
 
 class edr_loss(nn.Module):

@@ -278,7 +278,8 @@ class VarReceiverPosTrainer(Trainer):
         return self.criterion[1].window(K)
 
     def _step_losses(self, data: Dict, draw_mask: bool = True,
-                     mask_prenorm: Optional[torch.Tensor] = None, normalize_first: bool = False) -> Dict:
+                     mask_prenorm: Optional[torch.Tensor] = None, normalize_first: bool = False,
+                     defer_total: bool = False) -> Dict:
         """Fused forward + losses of one batch (train_step :452-471 / valid_step :479-498).
         ``mask_prenorm``: EDC time weights already divided by (global batch x kept indices), in a
         static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
@@ -359,13 +360,19 @@ class VarReceiverPosTrainer(Trainer):
             edc_target=None if edc_t is None else edc_t[1],
             side_stream=self._side_stream2(), unit_grad=True, n_time=K, target_rows=rows)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
+        heads = [total]
         if extra is not None:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
                 extra.record_stream(torch.cuda.current_stream())
-            total = total + extra
+            heads.append(extra)
             losses.update(colorless)
-        losses['_total'] = total
+        # ``defer_total``: the caller back-propagates the heads directly (unit upstream gradients)
+        # and forms the reported sum afterwards, off the path to the backward pass
+        if defer_total:
+            losses['_heads'] = heads
+        else:
+            losses['_total'] = total if extra is None else total + extra
         return losses
 
     def graphed(self, dataset, batch_size: int, mask_source: str = "device",
@@ -378,6 +385,7 @@ class VarReceiverPosTrainer(Trainer):
         self.optimizer.zero_grad(set_to_none=True)
         losses = self._step_losses(data)
         total = losses.pop('_total')
+        losses.pop('_heads', None)
         total.backward()
         if self._allreduce is not None:
             if isinstance(self.optimizer, FlatAdam):
@@ -390,6 +398,7 @@ class VarReceiverPosTrainer(Trainer):
     def valid_step(self, data: Dict):
         losses = self._step_losses(data)
         losses.pop('_total')
+        losses.pop('_heads', None)
         return sum(losses.values()), losses
 
     @torch.no_grad()
@@ -543,6 +552,7 @@ class GraphedTrainStep:
                       for _ in range(4)]
         self._ring_pos = 0
         self.mask_state = torch.zeros(1, dtype=torch.long, device=dev)     # draws made so far
+        self._one = torch.ones((), dtype=torch.float32, device=dev)        # root gradient of the heads
         if mask_seed is None:
             seed_t = torch.randint(0, 2 ** 62, (1,), dtype=torch.long)      # torch.manual_seed governs it
             if trainer.world_size > 1:                                      # one seed for all ranks, once
@@ -557,12 +567,17 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         tr = self.tr
         if self.mask_source == "device" and tr.criterion[1].use_mask:
+            # (measured: drawing it on the EDC side stream adds a third branch at the head of the graph
+            # and the executor then serialises the whole front: +0.05 ms)
             ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
         # no gather: the kernels read the dataset-level stores through the static index buffer
         batch = self.ds.collate(self.idx, lean="rows")
         tr.optimizer.zero_grad(set_to_none=True)
-        losses = tr._step_losses(batch, mask_prenorm=self.maskw, normalize_first=True)
-        losses['_total'].backward()
+        losses = tr._step_losses(batch, mask_prenorm=self.maskw, normalize_first=True, defer_total=True)
+        heads = losses.pop('_heads')
+        torch.autograd.backward(heads, [self._one] * len(heads))      # no ones-fill, no add in front
+        with torch.no_grad():
+            losses['_total'] = heads[0].detach() if len(heads) == 1 else heads[0].detach() + heads[1].detach()
         return losses
 
     def _eager(self):
