@@ -418,44 +418,93 @@ extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const fl
 }
 
 // gS[g][k] = sum_b rgain[b][g] conj(filt_k) gH[b][k];  gY[k][n] = c_n gS[g(n)][k];
-// gc partial[block][n] = sum_{k in block} Re(conj(gS) Y);  S[g][k] stored for pass B.
-// One block = 64 bins: the receiver loop is split over the 4 wavefronts (fixed-order fold in LDS),
-// then all 256 threads sweep the 64 x N tile of Y / gY in linear (coalesced) order.  PMC on the
-// first version (thread per bin, 8-byte row accesses, 256 blocks) showed 2x write traffic.
+// gc partial[block][n] = sum_{k in block} Re(conj(gS) Y);
+// grgain partial[(b,g)][block] = sum_{k in block} Re(conj(gH'[b][k]) S[g][k]),  S[g][k] = sum_{n in g} c_n Y[k][n].
+// One block = 64 bins.  The Y tile is staged once in LDS (row stride N+1: the per-lane row reads of
+// the S prologue then spread over the banks); the receiver loop is split over the 4 wavefronts: each
+// gH value is read once and serves both gS (fixed-order fold in LDS) and its own receiver-gain partial
+// (wave reduction over the 64 bins) -- the second pass over gH of the first version is gone.  Then all
+// 256 threads sweep the 64 x N tile for gY and the gc products in linear (coalesced) order.
 #define CBT 64
+#define CB_RB 16
 __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict__ Y, int K, int G,
                                                        int nper, const float* __restrict__ c,
                                                        const float* __restrict__ rgain, int B,
                                                        const float2* __restrict__ filt,
                                                        const float2* __restrict__ gH, int ldh,
                                                        float2* __restrict__ gY,
-                                                       float2* __restrict__ S_work,
+                                                       float* __restrict__ rg_partial,
                                                        float* __restrict__ gc_partial) {
-  __shared__ float2 s_gS[4][GFDN_MAX_GROUPS][CBT];
-  const int N = G * nper;
-  float2* cy = compose_lds;                 // [CBT][N] : c_n * Y
-  float* vt = (float*)(cy + CBT * N);       // [CBT][N] : Re(conj(gS) Y)
+  const int N = G * nper, NS = N + 1;
+  float2* yt = compose_lds;                 // [CBT][N+1] : Y tile
+  float* vt = (float*)(yt + CBT * NS);      // [CBT][N]   : Re(conj(gS) Y)
+  float* pp = vt + CBT * N;                 // [CB_RB * G][65] : per-bin receiver-gain products, then reused as
+  float2 (*s_gS)[GFDN_MAX_GROUPS][CBT] = (float2 (*)[GFDN_MAX_GROUPS][CBT])pp;   // [4][MAX_GROUPS][CBT] gS fold
   const int kx = threadIdx.x & 63, bg = threadIdx.x >> 6;
-  const int k0 = blockIdx.x * CBT;
+  const int k0 = blockIdx.x * CBT, nparts = gridDim.x;
   const int k = k0 + kx;
-  const int kk = k < K ? k : K - 1;
+  const bool live = k < K;
+  const int kk = live ? k : K - 1;
+  const size_t base = (size_t)k0 * N;
+  const int nb = K - k0 < CBT ? K - k0 : CBT;
+  const int lim = nb * N;
+  for (int e = threadIdx.x; e < CBT * N; e += 256) {
+    const int kq = e / N, n = e - kq * N;
+    yt[kq * NS + n] = e < lim ? Y[base + e] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
   {
-    float2 acc[GFDN_MAX_GROUPS];
+    float2 Sl[GFDN_MAX_GROUPS], acc[GFDN_MAX_GROUPS];
 #pragma unroll
-    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) acc[g] = make_float2(0.f, 0.f);
+    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+      acc[g] = make_float2(0.f, 0.f);
+      Sl[g] = make_float2(0.f, 0.f);
+      if (g < G)
+        for (int i = 0; i < nper; ++i) {
+          const float2 y = yt[kx * NS + g * nper + i];
+          const float cc = c[g * nper + i];
+          Sl[g].x += cc * y.x;
+          Sl[g].y += cc * y.y;
+        }
+    }
     const float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
-#pragma unroll 4
-    for (int b = bg; b < B; b += 4) {
-      float2 gh = gH[(size_t)b * ldh + kk];
-      if (filt) gh = cmul(gh, fc);
+    // receivers in chunks of CB_RB: per-lane products go to LDS rows (stride 65: the column sums
+    // below then walk distinct banks) and 2 threads per (b, g) add them up in a fixed order --
+    // an order of magnitude fewer instructions than one wave reduction per (b, g)
+    for (int b0 = 0; b0 < B; b0 += CB_RB) {
+      float2 ghv[CB_RB / 4];
 #pragma unroll
-      for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
-        if (g < G) {
-          const float rg = rgain[b * G + g];
-          acc[g].x += rg * gh.x;
-          acc[g].y += rg * gh.y;
+      for (int i = 0; i < CB_RB / 4; ++i) {        // this wave's receivers of the chunk: loads in flight together
+        const int b = b0 + bg + 4 * i;
+        ghv[i] = (live && b < B) ? gH[(size_t)b * ldh + kk] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < CB_RB / 4; ++i) {
+        const int b = b0 + bg + 4 * i;
+        if (b < B) {
+          float2 gh = ghv[i];
+          if (filt) gh = cmul(gh, fc);
+#pragma unroll
+          for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+            if (g < G) {
+              const float rg = rgain[b * G + g];
+              acc[g].x += rg * gh.x;
+              acc[g].y += rg * gh.y;
+              pp[((b - b0) * G + g) * 65 + kx] = gh.x * Sl[g].x + gh.y * Sl[g].y;
+            }
+          }
         }
       }
+      __syncthreads();
+      const int nout = (B - b0 < CB_RB ? B - b0 : CB_RB) * G;
+      for (int o2 = threadIdx.x; o2 < nout * 2; o2 += 256) {
+        const int o = o2 >> 1, h = o2 & 1;
+        float sacc = 0.f;
+        for (int j = 0; j < 32; ++j) sacc += pp[o * 65 + h * 32 + j];
+        sacc += __shfl_xor(sacc, 1);
+        if (h == 0) rg_partial[(size_t)(b0 * G + o) * nparts + blockIdx.x] = sacc;
+      }
+      __syncthreads();
     }
 #pragma unroll
     for (int g = 0; g < GFDN_MAX_GROUPS; ++g)
@@ -471,33 +520,18 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
     s_gS[0][g][x] = t;
   }
   __syncthreads();
-  const size_t base = (size_t)k0 * N;
-  const int nb = K - k0 < CBT ? K - k0 : CBT;
-  const int lim = nb * N;
   for (int e = threadIdx.x; e < CBT * N; e += 256) {
     const int kq = e / N, n = e - kq * N;
     float v = 0.f;
-    float2 cyv = make_float2(0.f, 0.f);
     if (e < lim) {
-      const float2 y = Y[base + e];
+      const float2 y = yt[kq * NS + n];
       const float2 gs = s_gS[0][n / nper][kq];
-      const float cc = c[n];
-      gY[base + e] = cscale(gs, cc);
+      gY[base + e] = cscale(gs, c[n]);
       v = gs.x * y.x + gs.y * y.y;
-      cyv = cscale(y, cc);
     }
     vt[e] = v;
-    cy[e] = cyv;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < G * CBT; idx += 256) {     // S[g][k] = sum_{n in g} c_n Y[k][n]
-    const int g = idx / CBT, x = idx - g * CBT;
-    if (x < nb) {
-      float2 sg = make_float2(0.f, 0.f);
-      for (int i = 0; i < nper; ++i) sg = cadd(sg, cy[x * N + g * nper + i]);
-      S_work[(size_t)g * K + k0 + x] = sg;
-    }
-  }
   for (int n = threadIdx.x; n < N; n += 256) {                 // fixed-order column sums
     float sacc = 0.f;
     for (int x = 0; x < CBT; ++x) sacc += vt[x * N + n];
@@ -505,35 +539,22 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
   }
 }
 
-// grgain[b][g] = sum_k Re(conj(gH'[b][k]) S[g][k]),  gH' = conj(filt) gH.
-// grid (k-chunks, B): partial[(b*G+g)*nchunk + chunk], then k_sum_rows (fixed order).
-#define CB_CHUNK 1024
-__global__ __launch_bounds__(256) void k_compose_bwd_b(const float2* __restrict__ S_work, int K,
-                                                       int G, const float2* __restrict__ filt,
-                                                       const float2* __restrict__ gH, int ldh,
-                                                       float* __restrict__ partial) {
-  __shared__ float s_red[16];
-  const int b = blockIdx.y, k0 = blockIdx.x * CB_CHUNK, nchunk = gridDim.x;
-  float acc[GFDN_MAX_GROUPS];
-#pragma unroll
-  for (int g = 0; g < GFDN_MAX_GROUPS; ++g) acc[g] = 0.f;
-  for (int k = k0 + threadIdx.x; k < k0 + CB_CHUNK && k < K; k += 256) {
-    float2 gh = gH[(size_t)b * ldh + k];
-    if (filt) gh = cmul(gh, cconj(filt[k]));
-#pragma unroll
-    for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
-      if (g < G) {
-        float2 s = S_work[(size_t)g * K + k];
-        acc[g] += gh.x * s.x + gh.y * s.y;
-      }
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
-    if (g < G) {
-      float s = block_sum(acc[g], s_red);
-      if (threadIdx.x == 0) partial[(size_t)(b * G + g) * nchunk + blockIdx.x] = s;
-    }
+// gc[n] = sum_p gc_partial[p][n]  (blocks 0..N-1);  grgain[r] = sum_p rg_partial[r][p]  (blocks N..):
+// one wavefront per output, lane-strided partial sums then a wave reduction -- a fixed order.
+__global__ __launch_bounds__(64) void k_compose_finish(const float* __restrict__ gc_partial,
+                                                       const float* __restrict__ rg_partial,
+                                                       int nparts, int N, float* __restrict__ gc,
+                                                       float* __restrict__ grgain) {
+  float s = 0.f;
+  if ((int)blockIdx.x < N) {
+    for (int p = threadIdx.x; p < nparts; p += 64) s += gc_partial[(size_t)p * N + blockIdx.x];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) gc[blockIdx.x] = s;
+  } else {
+    const int r = blockIdx.x - N;
+    for (int p = threadIdx.x; p < nparts; p += 64) s += rg_partial[(size_t)r * nparts + p];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) grgain[r] = s;
   }
 }
 
@@ -549,13 +570,12 @@ __global__ __launch_bounds__(64) void k_sum_rows(const float* __restrict__ part,
 
 static size_t compose_partial_bytes(int K, int G, int nper) {
   const size_t b = (size_t)((K + CBT - 1) / CBT) * G * nper * sizeof(float);
-  return (b + 15) & ~(size_t)15;           // the complex S copy that follows must stay aligned
+  return (b + 15) & ~(size_t)15;
 }
-// gc partial slots followed by a (G, K) complex copy of S for the second pass
+// gc partial slots [tiles][N] followed by the receiver-gain partial slots [B*G][tiles]
 extern "C" size_t gfdn_compose_bwd_work_bytes(int K, int G, int nper, int B) {
-  const size_t nchunk = (size_t)(K + 1023) / 1024;
-  return compose_partial_bytes(K, G, nper) + (size_t)G * K * sizeof(float2) +
-         (size_t)B * G * nchunk * sizeof(float);
+  const size_t tiles = (size_t)(K + CBT - 1) / CBT;
+  return compose_partial_bytes(K, G, nper) + (size_t)B * G * tiles * sizeof(float);
 }
 
 extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const float* c,
@@ -569,22 +589,18 @@ extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const fl
   const int N = G * nper;
   const int nparts = (K + CBT - 1) / CBT;
   float* gc_partial = (float*)work;
-  float2* S_work = (float2*)((char*)work + compose_partial_bytes(K, G, nper));
-  const size_t lds = (size_t)CBT * N * (sizeof(float2) + sizeof(float));
+  float* rg_partial = (float*)((char*)work + compose_partial_bytes(K, G, nper));
+  size_t uni = (size_t)CB_RB * G * 65 * sizeof(float);
+  if (uni < (size_t)4 * GFDN_MAX_GROUPS * CBT * sizeof(float2)) uni = (size_t)4 * GFDN_MAX_GROUPS * CBT * sizeof(float2);
+  const size_t lds = (size_t)CBT * (N + 1) * sizeof(float2) + (size_t)CBT * N * sizeof(float) + uni;
   int rc = ensure_dyn_lds(k_compose_bwd_a, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_compose_bwd_a, dim3(nparts), dim3(256), lds, s, (const float2*)Y,
                      K, G, nper, c, rgain, B, (const float2*)filt, (const float2*)gH, ldh, (float2*)gY,
-                     S_work, gc_partial);
+                     rg_partial, gc_partial);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, gc_partial, nparts, N, gc);
-  GFDN_LAUNCH_CHECK();
-  const int nchunk = (K + CB_CHUNK - 1) / CB_CHUNK;
-  float* rg_partial = (float*)((char*)S_work + (size_t)G * K * sizeof(float2));
-  hipLaunchKernelGGL(k_compose_bwd_b, dim3(nchunk, B), dim3(256), 0, s, S_work, K, G,
-                     (const float2*)filt, (const float2*)gH, ldh, rg_partial);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_rows, dim3(B * G), dim3(64), 0, s, rg_partial, nchunk, grgain);
+  hipLaunchKernelGGL(k_compose_finish, dim3(N + B * G), dim3(64), 0, s, gc_partial, rg_partial, nparts,
+                     N, gc, grgain);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
