@@ -90,6 +90,66 @@ __global__ __launch_bounds__(256) void k_edr_loss(float* __restrict__ P,
   if (threadIdx.x == 0) part[b * gridDim.x + blockIdx.x] = acc;
 }
 
+// Same maths for nframes <= EDR_RF with the whole frame column of P and of the target in registers:
+// all 2 x nframes loads of a thread are in flight before the dependent dB / prefix chains start
+// (the loop version above waits one memory latency per frame; measured 27 -> see profiles/).
+// (One block per item, which would make the second launch unnecessary, is bound by what a single CU
+// can stream: 35 us.)
+#define EDR_RF 32
+__global__ __launch_bounds__(256) void k_edr_loss_cols(float* __restrict__ P,
+                                                       const float* __restrict__ Tdb,
+                                                       const float* __restrict__ sum_abs,
+                                                       const long long* __restrict__ trows,
+                                                       const float* __restrict__ wf, int nframes,
+                                                       int nfreq, float gscale, int want_grad,
+                                                       float* __restrict__ part) {
+  __shared__ float s_red[16];
+  const int b = blockIdx.y;
+  const size_t tb = trows ? (size_t)trows[b] : (size_t)b;
+  const float inv_norm = 1.0f / sum_abs[tb];
+  float acc = 0.f;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f < nfreq) {
+    float* p = P + (size_t)b * nframes * nfreq + f;
+    const float* t = Tdb + tb * nframes * nfreq + f;
+    float pv[EDR_RF], tv[EDR_RF];
+#pragma unroll
+    for (int m = 0; m < EDR_RF; ++m) {
+      pv[m] = m < nframes ? p[(size_t)m * nfreq] : 0.f;
+      tv[m] = m < nframes ? t[(size_t)m * nfreq] : 0.f;
+    }
+    const float w = wf ? wf[f] : 1.0f;
+    const float gs = want_grad ? gscale * w * inv_norm : 0.f;
+    float E = 0.f;
+#pragma unroll
+    for (int m = EDR_RF - 1; m >= 0; --m) {
+      if (m < nframes) {
+        E += pv[m];
+        const float lin = fabsf(E) + F32_EPS;
+        const float raw = 10.0f * log10f(lin);
+        const float d = fmaxf(raw, -200.0f);
+        const float diff = tv[m] - d;
+        acc += w * fabsf(diff);
+        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+        pv[m] = -sg * dE * gs;
+      }
+    }
+    if (want_grad) {
+      float run = 0.f;
+#pragma unroll
+      for (int m = 0; m < EDR_RF; ++m) {
+        if (m < nframes) {
+          run += pv[m];
+          p[(size_t)m * nfreq] = run;
+        }
+      }
+    }
+  }
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) part[b * gridDim.x + blockIdx.x] = acc;
+}
+
 // work: per-(item, frequency-block) partial sums, reduced in a fixed order by k_row_sum
 extern "C" size_t gfdn_edr_work_bytes(int batch, int nfreq) {
   return (size_t)batch * ((nfreq + 255) / 256) * sizeof(float);
@@ -113,15 +173,20 @@ extern "C" int gfdn_edr_target(float* P, int batch, int nframes, int nfreq, floa
 extern "C" int gfdn_edr_loss(float* P, const float* T_db, const float* sum_abs,
                              const long long* target_rows, const float* wf, int batch, int nframes, int nfreq, float gscale, int want_grad,
                              float* loss_item, void* work, void* stream) {
-  if (!P || !T_db || !sum_abs || !loss_item || !work || batch <= 0 || nframes <= 0 || nfreq <= 0)
+  if (!P || !T_db || !sum_abs || !work || batch <= 0 || nframes <= 0 || nfreq <= 0)
     return GFDN_E_BADARG;
   const int fblk = (nfreq + 255) / 256;
   if (fblk > EDR_MAX_FBLK) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)work;
-  hipLaunchKernelGGL(k_edr_loss, dim3(fblk, batch), dim3(256), 0, s, P, T_db, sum_abs, target_rows, wf,
-                     nframes, nfreq, gscale, want_grad, part);
+  if (nframes <= EDR_RF)
+    hipLaunchKernelGGL(k_edr_loss_cols, dim3(fblk, batch), dim3(256), 0, s, P, T_db, sum_abs, target_rows, wf,
+                       nframes, nfreq, gscale, want_grad, part);
+  else
+    hipLaunchKernelGGL(k_edr_loss, dim3(fblk, batch), dim3(256), 0, s, P, T_db, sum_abs, target_rows, wf,
+                       nframes, nfreq, gscale, want_grad, part);
   GFDN_LAUNCH_CHECK();
+  if (!loss_item) return 0;       // deferred: the caller sums the partials (gfdn_weighted_sums)
   hipLaunchKernelGGL(k_row_sum, dim3((batch + 63) / 64), dim3(64), 0, s, part, batch, fblk, sum_abs,
                      target_rows, loss_item);
   GFDN_LAUNCH_CHECK();

@@ -857,13 +857,21 @@ extern "C" int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, 
   return 0;
 }
 
-// out = { wa * sum(a) + wb * sum(b), wa * sum(a), wb * sum(b) }   (either input may be NULL)
-__global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ a, float wa,
+// out = { wa * sum(a) + wb * sum(b), wa * sum(a), wb * sum(b) }   (either input may be NULL);
+// item i of a = (sum of its a_cols partials) / a_div[a_rows ? a_rows[i] : i]  (a_div optional)
+__global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ a, int a_cols,
+                                                      const float* __restrict__ a_div,
+                                                      const long long* __restrict__ a_rows, float wa,
                                                       const float* __restrict__ b, float wb, int n,
                                                       float* __restrict__ out) {
   float sa = 0.f, sb = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) {
-    if (a) sa += a[i];
+    if (a) {
+      float v = 0.f;
+      for (int c = 0; c < a_cols; ++c) v += a[(size_t)i * a_cols + c];
+      if (a_div) v /= a_div[a_rows ? a_rows[i] : i];
+      sa += v;
+    }
     if (b) sb += b[i];
   }
   sa = wave_sum(sa) * wa;
@@ -871,10 +879,11 @@ __global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ 
   if (threadIdx.x == 0) { out[0] = sa + sb; out[1] = sa; out[2] = sb; }
 }
 
-extern "C" int gfdn_weighted_sums(const float* a, float wa, const float* b, float wb, int n,
-                                  float* out3, void* stream) {
-  if ((!a && !b) || !out3 || n <= 0) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_weighted_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, a, wa, b, wb, n, out3);
+extern "C" int gfdn_weighted_sums(const float* a, int a_cols, const float* a_div, const long long* a_rows,
+                                  float wa, const float* b, float wb, int n, float* out3, void* stream) {
+  if ((!a && !b) || !out3 || n <= 0 || (a && a_cols <= 0)) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_weighted_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, a, a_cols, a_div, a_rows,
+                     wa, b, wb, n, out3);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -222,13 +222,23 @@ def colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=True):
     return out, gQ
 
 
-def weighted_sums(a, wa, b, wb):
-    """-> [wa sum(a) + wb sum(b), wa sum(a), wb sum(b)] (float32, 3)."""
+def weighted_sums(a, wa, b, wb, a_div=None, a_rows=None):
+    """-> [wa sum(a) + wb sum(b), wa sum(a), wb sum(b)] (float32, 3).  ``a`` may be (n, cols) partial
+    sums per item (edr_loss(defer=True)), divided per item by a_div[a_rows[i]]."""
     ref = a if a is not None else b
     _need_gpu(ref)
+    n = ref.shape[0] if ref.dim() == 2 else ref.numel()
+    cols = a.shape[1] if (a is not None and a.dim() == 2) else 1
+    if a is not None:
+        a = _f(a)
+    if a is not None and b is not None and b.numel() != n:
+        raise RuntimeError("weighted_sums: a and b must hold the same number of items")
+    a_rows = None if a_div is None else _rows(a_rows, n, a_div.numel())
+    if a_div is not None and a_rows is None and a_div.numel() != n:
+        raise RuntimeError("weighted_sums: a_div must have one entry per item (or pass a_rows)")
     out = torch.empty(3, dtype=_f32, device=ref.device)
-    _lib.check(_lib.load().gfdn_weighted_sums(_p(a), float(wa), _p(b), float(wb), ref.numel(), _p(out),
-                                              _stream()), "gfdn_weighted_sums")
+    _lib.check(_lib.load().gfdn_weighted_sums(_p(a), cols, _p(a_div), _p(a_rows), float(wa), _p(b),
+                                              float(wb), n, _p(out), _stream()), "gfdn_weighted_sums")
     return out
 
 
@@ -413,9 +423,12 @@ def edr_target(P: torch.Tensor):
     return P, sum_abs
 
 
-def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = True, rows=None):
+def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = True, rows=None,
+             defer: bool = False):
     """In place on P (achieved |STFT|^2): returns loss_item (batch,); P becomes dloss/dP.
-    ``rows``: item b compares against row rows[b] of the (all-receiver) target store."""
+    ``rows``: item b compares against row rows[b] of the (all-receiver) target store.
+    ``defer``: return the (batch, tiles) partial sums instead (not yet divided by sum_abs), to be
+    finished by weighted_sums(part, ..., a_div=sum_abs, a_rows=rows)."""
     _need_gpu(P, T_db)
     assert P.dtype == _f32 and P.is_contiguous() and T_db.is_contiguous() and T_db.dtype == _f32
     batch, nframes, nfreq = P.shape
@@ -425,6 +438,13 @@ def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = T
         raise RuntimeError("edr_loss: target shape does not match the achieved EDR")
     lib = _lib.load()
     wf = None if wf is None else _f(wf)
+    if defer:
+        part = torch.empty((batch, lib.gfdn_edr_work_bytes(batch, nfreq) // (4 * batch)), dtype=_f32,
+                           device=P.device)
+        _lib.check(lib.gfdn_edr_loss(_p(P), _p(T_db), _p(sum_abs), _p(rows), _p(wf), batch, nframes, nfreq,
+                                     float(gscale), int(want_grad), None, _p(part), _stream()),
+                   "gfdn_edr_loss")
+        return part
     loss_item = torch.empty(batch, dtype=_f32, device=P.device)
     work = _work(lib.gfdn_edr_work_bytes(batch, nfreq), P.device)
     _lib.check(lib.gfdn_edr_loss(_p(P), _p(T_db), _p(sum_abs), _p(rows), _p(wf), batch, nframes, nfreq,

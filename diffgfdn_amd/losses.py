@@ -130,8 +130,8 @@ class _DecayTotal(torch.autograd.Function):
     inside the node: no clone, no select-backward (zero fill + copy) on the way to the loss."""
 
     @staticmethod
-    def forward(ctx, H, gH, unit_grad, li_edr, w_edr, li_edc, w_edc):
-        sums = ops.weighted_sums(li_edr, w_edr, li_edc, w_edc)
+    def forward(ctx, H, gH, unit_grad, li_edr, w_edr, li_edc, w_edc, edr_div=None, edr_rows=None):
+        sums = ops.weighted_sums(li_edr, w_edr, li_edc, w_edc, edr_div, edr_rows)
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the two report outputs
         ctx.save_for_backward(gH)
         ctx.h_shape = H.shape
@@ -144,10 +144,10 @@ class _DecayTotal(torch.autograd.Function):
     def backward(ctx, g, _g1, _g2):
         (gH,) = ctx.saved_tensors
         if g is None:
-            return (None,) * 7
+            return (None,) * 9
         if ctx.unit_grad:
-            return gH.reshape(ctx.h_shape), None, None, None, None, None, None
-        return (gH * g).reshape(ctx.h_shape), None, None, None, None, None, None
+            return (gH.reshape(ctx.h_shape),) + (None,) * 8
+        return ((gH * g).reshape(ctx.h_shape),) + (None,) * 8
 
 
 def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win: int = 4096,
@@ -195,7 +195,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         env = torch.pow(torch.tensor(1.0 / reduced_pole_radius, dtype=torch.float64, device=x.device),
                         torch.arange(K, device=x.device, dtype=torch.float64)).to(torch.float32)
     gx = gx2 = None
-    li_edc = li_edr = None
+    li_edc = li_edr = edr_div = edr_rows = None
     main = torch.cuda.current_stream() if x.is_cuda else None
     fork = side_stream is not None and use_edc and use_edr
     if use_edc:
@@ -224,7 +224,10 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         # that order, so the three-term sum has a fixed order too
         g_edr = torch.empty_like(x) if want_grad else None
         P = ops.stft_power(xe, win, zero_buf=g_edr)
-        li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad, rows=target_rows)
+        # (the per-item reduction of the EDR partials is deferred into the bookkeeping launch)
+        li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad, rows=target_rows,
+                              defer=True)
+        edr_div, edr_rows = sum_abs, target_rows
         if want_grad:
             g_edr = ops.stft_power_bwd(xe, win, P, g_edr)
             if env is not None:
@@ -238,8 +241,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
             gx, gx2 = (g_edr, None) if gx is None else (gx, g_edr)
     if want_grad:
         gH = ops.irfft_odd_bwd(gx, K, ldx, gx2)
-        return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight)
-    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight)   # [total, w_edr edr, w_edc edc]
+        return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows)
+    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows)   # [total, w_edr edr, w_edc edc]
     return sums[0], sums[1], sums[2]
 
 

@@ -125,9 +125,12 @@ int gfdn_spectral_stats(const float* S_c64, int G, int K, int asym, float scale,
  * last group counts, trainer.py:305-308).  gQ (G,n,n), optional: d out3[0] / dQ.              */
 int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, int n, float w_spec,
                          float w_sparse, float inv_world, float* out3, float* gQ, void* stream);
-/* out3 = { wa sum(a) + wb sum(b), wa sum(a), wb sum(b) } over n items (a or b may be NULL).  */
-int gfdn_weighted_sums(const float* a, float wa, const float* b, float wb, int n, float* out3,
-                       void* stream);
+/* out3 = { wa sum(a) + wb sum(b), wa sum(a), wb sum(b) } over n items (a or b may be NULL).
+ * Item i of a is the sum of its a_cols partials (a: (n, a_cols), a_cols = 1 for plain items),
+ * divided by a_div[a_rows ? a_rows[i] : i] when a_div != NULL -- the deferred form of
+ * gfdn_edr_loss (loss_item = NULL) hands its per-tile partials and normalisers straight here. */
+int gfdn_weighted_sums(const float* a, int a_cols, const float* a_div, const long long* a_rows,
+                       float wa, const float* b, float wb, int n, float* out3, void* stream);
 
 /* Energy normalisation of the input / output gains (trainer.py:317-332): for n in group g,
  * b[n] /= energy[g]^(1/4), c[n] /= energy[g]^(1/4), in place (float32, N = G * nper).        */
@@ -190,7 +193,9 @@ int gfdn_edr_target(float* P_inout, int batch, int nframes, int nfreq, float* su
                     void* work, void* stream);
 /* achieved side: loss_item[b] = sum_{f,m} wf[f] |T_db - EDR| / sum_abs[b]  (losses.py:478-492)
  * and, when want_grad, P is overwritten with gscale * dloss/dP.  target_rows: row indirection
- * into T_db / sum_abs (see gfdn_compose_fwd) or NULL.                                      */
+ * into T_db / sum_abs (see gfdn_compose_fwd) or NULL.  loss_item = NULL defers the last reduction:
+ * work then holds (batch, ceil(nfreq/256)) partial sums of wf |T_db - EDR|, NOT yet divided by
+ * sum_abs, for gfdn_weighted_sums (one launch less between this call and the STFT adjoint). */
 int gfdn_edr_loss(float* P_inout, const float* T_db, const float* sum_abs,
                   const long long* target_rows, const float* wf, int batch, int nframes, int nfreq, float gscale, int want_grad,
                   float* loss_item, void* work, void* stream);

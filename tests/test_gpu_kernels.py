@@ -201,10 +201,12 @@ def test_stft_power(ops, T, win, batch):
     assert rel_err(gx.cpu(), x.grad) < 5e-6
 
 
-@pytest.mark.parametrize("use_wf", [False, True])
-def test_edr_loss_kernels(ops, use_wf):
+@pytest.mark.parametrize("use_wf,nframes,nfreq", [(False, 32, 2049), (True, 32, 2049), (True, 7, 129),
+                                                  (False, 40, 513), (True, 33, 2049)])
+def test_edr_loss_kernels(ops, use_wf, nframes, nfreq):
+    """(nframes <= 32: one block per item with the frame column in registers; above: the tiled kernel)"""
     torch.manual_seed(3)
-    batch, nframes, nfreq = 3, 32, 2049
+    batch = 3
     env = torch.exp(-torch.arange(nframes, dtype=torch.float64) / 6.0)[None, :, None]
     Pt = torch.rand(batch, nframes, nfreq, dtype=torch.float64) * env
     Pa = (torch.rand(batch, nframes, nfreq, dtype=torch.float64) * env * 1.3).requires_grad_(True)
