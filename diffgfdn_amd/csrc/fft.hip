@@ -776,6 +776,9 @@ __device__ __forceinline__ float hann_periodic(int j, int W) {
   return 0.5f - 0.5f * cospif(2.0f * (float)j / (float)W);
 }
 
+#ifndef STFT_T
+#define STFT_T 512   // threads per frame pair (win 4096: one radix-8 butterfly per thread per pass)
+#endif
 // loads frames (m, m+1) of signal b into z = fr_m + i fr_{m+1}
 __device__ __forceinline__ void stft_load_pair(const float* __restrict__ x, int T, int W, int m,
                                                int nframes, float2* buf) {
@@ -789,7 +792,7 @@ __device__ __forceinline__ void stft_load_pair(const float* __restrict__ x, int 
   }
 }
 
-__global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ x, int ld, int T,
+__global__ __launch_bounds__(STFT_T) void k_stft_power(const float* __restrict__ x, int ld, int T,
                                                     int W, int nframes, float* __restrict__ P,
                                                     float* __restrict__ zero_buf) {
   float2* bufA = dyn_lds;
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(256) void k_stft_power(const float* __restrict__ x,
   }
 }
 
-__global__ __launch_bounds__(256) void k_stft_power_bwd(const float* __restrict__ x, int ld, int T,
+__global__ __launch_bounds__(STFT_T) void k_stft_power_bwd(const float* __restrict__ x, int ld, int T,
                                                         int W, int nframes,
                                                         const float* __restrict__ gP,
                                                         float* __restrict__ gx) {
@@ -872,7 +875,7 @@ extern "C" int gfdn_stft_power(const float* x, int ld, int T, int batch, int win
   if (stft_lds(win) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_stft_power, stft_lds(win));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_stft_power, dim3((nframes + 1) / 2, batch), dim3(256), stft_lds(win),
+  hipLaunchKernelGGL(k_stft_power, dim3((nframes + 1) / 2, batch), dim3(STFT_T), stft_lds(win),
                      (hipStream_t)stream, x, ld, T, win, nframes, P, zero_buf);
   GFDN_LAUNCH_CHECK();
   return 0;
@@ -886,7 +889,7 @@ extern "C" int gfdn_stft_power_bwd(const float* x, int ld, int T, int batch, int
   if (stft_lds(win) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_stft_power_bwd, stft_lds(win));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_stft_power_bwd, dim3((nframes + 1) / 2, batch), dim3(256), stft_lds(win),
+  hipLaunchKernelGGL(k_stft_power_bwd, dim3((nframes + 1) / 2, batch), dim3(STFT_T), stft_lds(win),
                      (hipStream_t)stream, x, ld, T, win, nframes, gP, gx);
   GFDN_LAUNCH_CHECK();
   return 0;
