@@ -33,6 +33,8 @@ SIGNATURES = {
     "gfdn_spectral_stats_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_spectral_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "gfdn_colorless_terms": (c_int, [_P, c_int, _P, c_int, c_float, c_float, c_float, _P, _P, _P]),
+    "gfdn_subfdn_normalize_work_bytes": (c_size_t, [c_int]),
+    "gfdn_subfdn_normalize": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),
     "gfdn_normalize_io": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "gfdn_bluestein_table_bytes": (c_size_t, [c_int]),

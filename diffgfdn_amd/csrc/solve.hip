@@ -324,6 +324,94 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
 }
 
 // ------------------------------------------------------------------------------------------
+// normalize (trainer.py:317-332) in two launches: energy of the sub-FDN responses, then the rescale.
+//   Hout[k][g] = sum_{n in g} c_n y_n,  y = (diag(z_k^m) - M_g)^{-1} b_g   (model.py:237-250)
+//   E_g = mean_k |Hout[k][g]|^2;   b_n, c_n /= E_g^(1/4)  for n in g.
+// The solve kernel's lanes already hold y_n: the group sum is a reduction over the NP lanes of a
+// system, |.|^2 is accumulated over the block's bins, per-block partials are folded in a fixed order.
+// Neither Y (K x N) nor Hout is written.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void k_subfdn_energy(SolveArgs a, const float* __restrict__ c,
+                                                       float* __restrict__ partial) {
+  constexpr int SPB = 256 / NP;
+  __shared__ float s_red[16];
+  const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
+  const int blk = blockIdx.y, n = a.nper;
+  const int i = blk * n + (r < n ? r : 0);
+  const float m_i = a.delays[i], ig_i = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
+  const float b_i = r < n ? a.b[i] : 0.f;
+  float acc = 0.f;
+  for (int k0 = blockIdx.x * SPB; k0 < a.K; k0 += gridDim.x * SPB) {
+    const int k = k0 + grp;
+    const bool valid = k < a.K;
+    const int kk = valid ? k : a.K - 1;
+    const float2 zeta = zeta_pow(a.turns, a.logr, kk, m_i, ig_i);
+    float2 row[NP];
+    build_row<NP>(row, a.A + (size_t)blk * n * n, n, r, a.transpose != 0, zeta);
+    int pivcol;
+    const float2 y = gauss_jordan<NP>(row, make_float2(b_i, 0.f), n, r, pivcol);
+    float2 s = make_float2(0.f, 0.f);
+    if (pivcol >= 0) s = cscale(y, c[blk * n + pivcol]);
+#pragma unroll
+    for (int o = NP >> 1; o > 0; o >>= 1) {       // sum over the lanes of this system (any order of
+      s.x += __shfl_xor(s.x, o, NP);              // columns: the butterfly is symmetric)
+      s.y += __shfl_xor(s.y, o, NP);
+    }
+    if (valid && r == 0) acc += s.x * s.x + s.y * s.y;
+  }
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partial[(size_t)blk * gridDim.x + blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_subfdn_rescale(const float* __restrict__ partial, int nparts,
+                                                       int K, int nper, float* __restrict__ b,
+                                                       float* __restrict__ c, float* __restrict__ energy) {
+  const int g = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 64) s += partial[(size_t)g * nparts + p];
+  s = wave_sum(s);
+  const float E = s / (float)K;
+  if (energy && threadIdx.x == 0) energy[g] = E;
+  const float d = powf(E, 0.25f);
+  for (int i = threadIdx.x; i < nper; i += 64) {
+    b[g * nper + i] /= d;
+    c[g * nper + i] /= d;
+  }
+}
+
+extern "C" size_t gfdn_subfdn_normalize_work_bytes(int G) {
+  return (size_t)G * GFDN_PARTIAL_BLOCKS * sizeof(float);
+}
+
+extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, int K, int G, int nper,
+                                     const float* M, const float* delays, float* b, float* c,
+                                     float* energy, void* work, void* stream) {
+  if (!turns || !M || !delays || !b || !c || !work) return GFDN_E_BADARG;
+  if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > GFDN_MAX_BLOCK) return GFDN_E_UNSUPPORTED;
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0};
+  const int np = pick_np(nper);
+  const int spb = 256 / np;
+  int nparts = (K + spb - 1) / spb;
+  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  dim3 grid(nparts, G), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)work;
+  switch (np) {
+    case 4: hipLaunchKernelGGL(k_subfdn_energy<4>, grid, block, 0, s, a, (const float*)c, partial); break;
+    case 8: hipLaunchKernelGGL(k_subfdn_energy<8>, grid, block, 0, s, a, (const float*)c, partial); break;
+    case 16: hipLaunchKernelGGL(k_subfdn_energy<16>, grid, block, 0, s, a, (const float*)c, partial); break;
+    default: hipLaunchKernelGGL(k_subfdn_energy<32>, grid, block, 0, s, a, (const float*)c, partial); break;
+  }
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_subfdn_rescale, dim3(G), dim3(64), 0, s, (const float*)partial, nparts, K, nper, b, c,
+                     energy);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // output stage
 // ------------------------------------------------------------------------------------------
 #define COMPOSE_BCH 8

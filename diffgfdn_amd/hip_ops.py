@@ -242,6 +242,24 @@ def weighted_sums(a, wa, b, wb, a_div=None, a_rows=None):
     return out
 
 
+def subfdn_normalize(turns, logr, M, delays, b, c, want_energy: bool = False):
+    """Trainer.normalize in two launches: in place b[n], c[n] /= E_g^(1/4) with E_g the mean energy of
+    group g's sub-FDN response (raw blocks M (G,nper,nper), no absorption).  Returns E (G,) or None."""
+    _need_gpu(turns, M, b, c)
+    M, delays = _f(M), _f(delays)
+    G, nper, _ = M.shape
+    for t in (b, c):
+        if t.dtype != _f32 or not t.is_contiguous() or t.numel() != G * nper:
+            raise RuntimeError("subfdn_normalize: gains must be contiguous float32 of G*nper elements")
+    lib = _lib.load()
+    energy = torch.empty(G, dtype=_f32, device=M.device) if want_energy else None
+    work = _work(lib.gfdn_subfdn_normalize_work_bytes(G), M.device)
+    _lib.check(lib.gfdn_subfdn_normalize(_p(turns), _p(logr), turns.numel(), G, nper, _p(M), _p(delays),
+                                         _p(b), _p(c), _p(energy), _p(work), _stream()),
+               "gfdn_subfdn_normalize")
+    return energy
+
+
 def normalize_io(energy, b, c, G: int, nper: int):
     """In place: b[n], c[n] /= energy[group(n)]^(1/4)  (b, c float32 contiguous, N = G*nper)."""
     _need_gpu(energy, b, c)

@@ -207,11 +207,13 @@ class Trainer:
     def normalize(self, data: Dict):
         if not self.use_colorless_loss:
             return
-        S, _ = self.net.sub_fdn_group_sums(data['z_values'])
-        energy, _, _ = spectral_stats(S, False, 1.0, want_grad=False)
         net = self.net
-        normalize_io(energy, net.input_gains.data, net.output_gains.data, net.num_groups,
-                     net.num_delay_lines_per_group)
+        # energy of the sub-FDN responses and the in-place rescale of b, c in two launches
+        # (gfdn_subfdn_normalize); the responses themselves are never written
+        from .functional import FrequencyGrid
+        grid = FrequencyGrid.of(data['z_values'])
+        ops.subfdn_normalize(grid.turns, grid.logr, net.feedback_loop.M.detach(), net.delay_buffer,
+                             net.input_gains.data, net.output_gains.data)
 
 
     # epoch loop shared by the grid / directional trainers (reference :345-424, :697-769)

@@ -136,6 +136,15 @@ int gfdn_weighted_sums(const float* a, int a_cols, const float* a_div, const lon
  * b[n] /= energy[g]^(1/4), c[n] /= energy[g]^(1/4), in place (float32, N = G * nper).        */
 int gfdn_normalize_io(const float* energy, float* b, float* c, int G, int nper, void* stream);
 
+/* The whole of Trainer.normalize (trainer.py:317-332) in two launches, without writing the sub-FDN
+ * responses: E_g = mean_k |sum_{n in g} c_n y_n[k]|^2 with y = (diag(z_k^m) - M_g)^{-1} b_g
+ * (model.py:237-250: raw M_g (G, nper, nper), no absorption), then b_n, c_n /= E_g^(1/4) in place.
+ * energy (G), optional: E_g as used.  work: gfdn_subfdn_normalize_work_bytes(G).                 */
+size_t gfdn_subfdn_normalize_work_bytes(int G);
+int gfdn_subfdn_normalize(const double* turns, const double* logr, int K, int G, int nper,
+                          const float* M, const float* delays, float* b, float* c, float* energy,
+                          void* work, void* stream);
+
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's
  * algorithm on power-of-two FFTs of length L >= n + (n-1)/2.

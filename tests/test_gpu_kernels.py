@@ -369,3 +369,35 @@ def test_stft_zero_fill_and_two_input_adjoint(ops):
         two = ops.irfft_odd_bwd(a, n, ld, b)
         one = ops.irfft_odd_bwd(a + b, n, ld)
         assert torch.equal(torch.view_as_real(two), torch.view_as_real(one))
+
+
+@pytest.mark.parametrize("G,nper,nfft", [(4, 4, 1024), (3, 4, 2048), (2, 8, 512), (1, 6, 256), (3, 9, 512)])
+def test_subfdn_normalize(ops, G, nper, nfft):
+    """gfdn_subfdn_normalize == sub-FDN solve -> group sums -> mean energy -> b, c /= E^(1/4)
+    (trainer.py:317-332) done with the separate kernels and with the oracle."""
+    torch.manual_seed(G * 10 + nper)
+    N = G * nper
+    z = _grid(nfft)
+    from diffgfdn_amd.functional import FrequencyGrid
+    grid = FrequencyGrid.of(z.to(DEV))
+    M = (0.3 * torch.randn(G, nper, nper)).to(DEV)
+    delays = torch.tensor(_primes(N, 20, 400, 3), dtype=torch.float32, device=DEV)
+    b0, c0 = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    # reference chain with the separate kernels
+    ones = torch.ones(N, device=DEV)
+    Y = ops.solve_fwd(grid.turns, grid.logr, M, delays, ones, b0)
+    _, S = ops.compose_fwd(Y, c0, torch.eye(G, device=DEV), nper, None, None, want_S=True)
+    E_ref = (S.abs().double() ** 2).mean(dim=1)
+    b1, c1 = b0.clone(), c0.clone()
+    E = ops.subfdn_normalize(grid.turns, grid.logr, M, delays, b1, c1, want_energy=True)
+    assert rel_err(E.cpu(), E_ref.cpu()) < 1e-5
+    sc = E_ref.pow(0.25).repeat_interleave(nper).float()
+    assert rel_err(b1.cpu(), (b0 / sc).cpu()) < 1e-5 and rel_err(c1.cpu(), (c0 / sc).cpu()) < 1e-5
+    # oracle: dense inverse of the same system
+    zc = z.to(torch.complex128)
+    Dk = zc[:, None] ** delays.cpu().double()[None, :]
+    Md = torch.block_diag(*[M[g].cpu().double() for g in range(G)]).to(torch.complex128)
+    P = torch.linalg.inv(torch.diag_embed(Dk) - Md[None])
+    Yo = P @ b0.cpu().double().to(torch.complex128)
+    So = (Yo * c0.cpu().double()).reshape(-1, G, nper).sum(-1)
+    assert rel_err(E.cpu(), (So.abs() ** 2).mean(0)) < 1e-4
