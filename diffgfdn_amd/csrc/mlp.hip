@@ -13,12 +13,14 @@
 #include "common.h"
 
 #define MLP_T 256
+#define MLP_STAGE_MAX 7168     // floats: parameter sets up to 28 KB are staged in LDS (twice in the backward)
 #define LN_EPS 1e-5f
 
 struct MlpDims {
   int B, F, in_dim, H, nl, G;   // F fourier features, in_dim = 6 F, nl = 1 + hidden layers
   float lo, hi;                 // ScaledSigmoid limits
   const long long* rows;        // item b encodes pos[rows[b]] (NULL: pos[b])
+  int stage;                    // 1: the packed parameters (+ the receiver's saved activations) fit in LDS
 };
 
 __device__ __forceinline__ size_t mlp_layer_off(const MlpDims& d, int l) {
@@ -56,6 +58,23 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
   float* h = a + amax;           // pre-norm outputs
   float* red = h + d.H;          // 16 floats
   const int b = blockIdx.x, H = d.H;
+  // small networks: ONE round of global loads brings every parameter into LDS; the layer chain then
+  // never waits on memory again (it was one dependent global-load latency per layer)
+  // Likewise the saved activations go to LDS first and to memory once at the end: every
+  // __syncthreads() waits for ALL outstanding global stores of the wave (vmcnt covers stores on
+  // gfx9), so a store inside the layer loop costs a full write round trip per barrier.
+  float* xout = xhat + (size_t)b * d.nl * H;
+  float* rout = rstd + (size_t)b * d.nl;
+  float* xs = xout;
+  float* rsv = rout;
+  if (d.stage) {
+    float* wl = red + 16;
+    const int P = (int)mlp_param_count(d);
+    for (int p = threadIdx.x; p < P; p += blockDim.x) wl[p] = w[p];
+    w = wl;
+    xs = wl + P;
+    rsv = xs + d.nl * H;
+  }
   mlp_encode(d, pos, freq_pi, a);
   __syncthreads();
   for (int l = 0; l < d.nl; ++l) {
@@ -77,10 +96,10 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
     __syncthreads();
     if (j < H) {
       const float xh = dv * rs;
-      xhat[((size_t)b * d.nl + l) * H + j] = xh;
+      xs[l * H + j] = xh;
       a[j] = fmaxf(xh * gamma[j] + beta[j], 0.f);
     }
-    if (j == 0) rstd[(size_t)b * d.nl + l] = rs;
+    if (j == 0) rsv[l] = rs;
     __syncthreads();
   }
   const float* Wout = w + mlp_layer_off(d, d.nl);
@@ -89,6 +108,10 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
     float raw = bout[g];
     for (int i = 0; i < H; ++i) raw += Wout[(size_t)g * H + i] * a[i];
     gains[(size_t)b * d.G + g] = d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw)));
+  }
+  if (d.stage) {
+    for (int p = threadIdx.x; p < d.nl * H; p += blockDim.x) xout[p] = xs[p];
+    for (int p = threadIdx.x; p < d.nl; p += blockDim.x) rout[p] = rsv[p];
   }
 }
 
@@ -109,6 +132,19 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
   const int b = blockIdx.x, H = d.H, G = d.G;
   const size_t P = mlp_param_count(d);
   float* gp = partial + (size_t)b * P;
+  xhat += (size_t)b * d.nl * H;
+  rstd += (size_t)b * d.nl;
+  if (d.stage) {                 // parameters and this receiver's saved activations -> LDS, one load round
+    float* wl = red + 16;
+    float* xl = wl + P;
+    float* rl = xl + d.nl * H;
+    for (int p = threadIdx.x; p < (int)P; p += blockDim.x) wl[p] = w[p];
+    for (int p = threadIdx.x; p < d.nl * H; p += blockDim.x) xl[p] = xhat[p];
+    for (int p = threadIdx.x; p < d.nl; p += blockDim.x) rl[p] = rstd[p];
+    w = wl; xhat = xl; rstd = rl;
+    gp = rl + d.nl;              // gradient partials are collected in LDS and written once at the end
+    __syncthreads();
+  }
   // output layer
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     const float sg = (gains[(size_t)b * G + g] - d.lo) / (d.hi - d.lo);
@@ -121,7 +157,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
     const float* gamma = W + (size_t)H * n_in + H;
     const float* beta = gamma + H;
     for (int i = threadIdx.x; i < H; i += blockDim.x)
-      aprev[i] = fmaxf(xhat[((size_t)b * d.nl + l) * H + i] * gamma[i] + beta[i], 0.f);
+      aprev[i] = fmaxf(xhat[(size_t)l * H + i] * gamma[i] + beta[i], 0.f);
   }
   __syncthreads();
   const size_t offOut = mlp_layer_off(d, d.nl);
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
     const int j = threadIdx.x;
     float xh = 0.f, dxh = 0.f;
     if (j < H) {
-      xh = xhat[((size_t)b * d.nl + l) * H + j];
+      xh = xhat[(size_t)l * H + j];
       const float y = xh * gamma[j] + beta[j];
       const float dy = y > 0.f ? da[j] : 0.f;
       gp[offg + j] = dy * xh;
@@ -156,7 +192,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
     }
     const float m1 = block_sum(dxh, red) / (float)H;
     const float m2 = block_sum(dxh * xh, red) / (float)H;
-    const float rs = rstd[(size_t)b * d.nl + l];
+    const float rs = rstd[l];
     __syncthreads();
     if (j < H) {
       const float v = rs * (dxh - m1 - xh * m2);
@@ -172,7 +208,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
       const float* gam_p = Wp + (size_t)H * n_in_p + H;
       const float* bet_p = gam_p + H;
       for (int i = threadIdx.x; i < H; i += blockDim.x)
-        aprev[i] = fmaxf(xhat[((size_t)b * d.nl + (l - 1)) * H + i] * gam_p[i] + bet_p[i], 0.f);
+        aprev[i] = fmaxf(xhat[(size_t)(l - 1) * H + i] * gam_p[i] + bet_p[i], 0.f);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
@@ -186,6 +222,10 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
       if (l > 0) da[i] = acc;
     }
     __syncthreads();
+  }
+  if (d.stage) {
+    float* gout = partial + (size_t)b * P;
+    for (int p = threadIdx.x; p < (int)P; p += blockDim.x) gout[p] = gp[p];
   }
 }
 
@@ -204,11 +244,23 @@ static int mlp_dims(int B, int F, int H, int n_hidden, int G, float lo, float hi
   if (H > MLP_T || G > MLP_T || 6 * F > 4096) return GFDN_E_UNSUPPORTED;
   d->B = B; d->F = F; d->in_dim = 6 * F; d->H = H; d->nl = 1 + n_hidden; d->G = G; d->lo = lo; d->hi = hi;
   d->rows = nullptr;
+  d->stage = mlp_param_count(*d) <= MLP_STAGE_MAX ? 1 : 0;
   return 0;
+}
+// threads per receiver: the layer width rounded up to whole wavefronts.  A 16-neuron layer on one
+// wavefront turns every block barrier / block reduction of the layer chain into wave-level ops
+// (measured: 31 -> see profiles/ for k_mlp_bwd at H = 16).
+static int mlp_threads(const MlpDims& d) {
+  if (d.stage) return MLP_T;     // the staging loop wants every lane issuing loads
+  const int wdt = d.H > d.G ? d.H : d.G;
+  int t = 64 * ((wdt + 63) / 64);
+  return t > MLP_T ? MLP_T : t;
 }
 static size_t mlp_lds_bytes(const MlpDims& d) {
   const int amax = d.in_dim > d.H ? d.in_dim : d.H;
-  return ((size_t)amax + 2 * (size_t)d.H + d.G + 16) * sizeof(float);
+  size_t n = (size_t)amax + 2 * (size_t)d.H + d.G + 16;
+  if (d.stage) n += 2 * mlp_param_count(d) + (size_t)d.nl * d.H + d.nl;   // weights [+ gradient partials] + saved activations
+  return n * sizeof(float);
 }
 
 extern "C" size_t gfdn_mlp_param_count(int F, int H, int n_hidden, int G) {
@@ -228,7 +280,7 @@ extern "C" int gfdn_mlp_gains_fwd(const double* pos, const long long* pos_rows, 
   if (rc) return rc;
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_mlp_fwd, dim3(B), dim3(MLP_T), mlp_lds_bytes(d), (hipStream_t)stream, d, pos,
+  hipLaunchKernelGGL(k_mlp_fwd, dim3(B), dim3(mlp_threads(d)), mlp_lds_bytes(d), (hipStream_t)stream, d, pos,
                      freq_pi, w, gains, xhat, rstd);
   GFDN_LAUNCH_CHECK();
   return 0;
@@ -244,7 +296,7 @@ extern "C" int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, 
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_mlp_bwd, dim3(B), dim3(MLP_T), mlp_lds_bytes(d), s, d, pos, freq_pi, w, gains, xhat,
+  hipLaunchKernelGGL(k_mlp_bwd, dim3(B), dim3(mlp_threads(d)), mlp_lds_bytes(d), s, d, pos, freq_pi, w, gains, xhat,
                      rstd, ggains, (float*)work);
   GFDN_LAUNCH_CHECK();
   const size_t P = mlp_param_count(d);
