@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void k_solve_fwd(SolveArgs a, float2* __restri
   if (valid && pivcol >= 0) Y[(size_t)k * N + blk * n + pivcol] = y;
 }
 
+// Ysaved: the forward solution (K, N) when the caller still holds it (the re-solve is skipped),
+// or NULL.
 template <int NP>
 __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __restrict__ gY,
+                                                   const float2* __restrict__ Ysaved,
                                                    float* __restrict__ partial) {
   constexpr int SPB = 256 / NP;
   __shared__ float2 s_perm[256];
@@ -174,12 +177,17 @@ __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __
     float2 row[NP];
     int pivcol;
     // forward system  T y = b
-    build_row<NP>(row, Ablk, n, r, tr, zeta);
-    float2 y = gauss_jordan<NP>(row, make_float2(b_i, 0.f), n, r, pivcol);
-    __syncthreads();
-    if (pivcol >= 0) s_perm[grp * NP + pivcol] = y;
-    __syncthreads();
-    float2 ynat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    float2 ynat;
+    if (Ysaved) {
+      ynat = active ? Ysaved[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    } else {
+      build_row<NP>(row, Ablk, n, r, tr, zeta);
+      float2 y = gauss_jordan<NP>(row, make_float2(b_i, 0.f), n, r, pivcol);
+      __syncthreads();
+      if (pivcol >= 0) s_perm[grp * NP + pivcol] = y;
+      __syncthreads();
+      ynat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    }
     // adjoint system  T^H w = gY   (row r of T^H = conj of column r of T)
     build_row<NP>(row, Ablk, n, r, !tr, cconj(zeta));
     float2 g = active ? gY[(size_t)kk * N + i] : make_float2(0.f, 0.f);
@@ -296,8 +304,8 @@ extern "C" size_t gfdn_solve_bwd_work_bytes(int nblk, int nper) {
 
 extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
                               const float* A, const float* delays, const float* inv_gamma,
-                              const float* b, int transpose, const float* gY, float* gA,
-                              float* gb, float* ginv_gamma, void* work, void* stream) {
+                              const float* b, int transpose, const float* gY, const float* Y,
+                              float* gA, float* gb, float* ginv_gamma, void* work, void* stream) {
   int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
   if (rc) return rc;
   if (!gY || !gA || !gb || !ginv_gamma || !work) return GFDN_E_BADARG;
@@ -310,10 +318,10 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
   switch (np) {
-    case 4: hipLaunchKernelGGL(k_solve_bwd<4>, grid, block, 0, s, a, (const float2*)gY, partial); break;
-    case 8: hipLaunchKernelGGL(k_solve_bwd<8>, grid, block, 0, s, a, (const float2*)gY, partial); break;
-    case 16: hipLaunchKernelGGL(k_solve_bwd<16>, grid, block, 0, s, a, (const float2*)gY, partial); break;
-    default: hipLaunchKernelGGL(k_solve_bwd<32>, grid, block, 0, s, a, (const float2*)gY, partial); break;
+    case 4: hipLaunchKernelGGL(k_solve_bwd<4>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    case 8: hipLaunchKernelGGL(k_solve_bwd<8>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    case 16: hipLaunchKernelGGL(k_solve_bwd<16>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    default: hipLaunchKernelGGL(k_solve_bwd<32>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
   }
   GFDN_LAUNCH_CHECK();
   const int tot = nblk * (nper * nper + 2 * nper);

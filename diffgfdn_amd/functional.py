@@ -105,17 +105,19 @@ class ResolventSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, inv_gamma, b, grid: FrequencyGrid, delays, transpose: bool):
         Y = ops.solve_fwd(grid.turns, grid.logr, A, delays, inv_gamma, b, transpose)
-        ctx.save_for_backward(A, inv_gamma, b, delays)
+        # Y is kept alive by its consumer's backward anyway (the output stage reads it): saving
+        # it here costs nothing and the backward kernel skips re-solving the forward system
+        ctx.save_for_backward(A, inv_gamma, b, delays, Y)
         ctx.grid = grid
         ctx.transpose = transpose
         return Y
 
     @staticmethod
     def backward(ctx, gY):
-        A, inv_gamma, b, delays = ctx.saved_tensors
+        A, inv_gamma, b, delays, Y = ctx.saved_tensors
         g = ctx.grid
         gA, gb, gig = ops.solve_bwd(g.turns, g.logr, A, delays, inv_gamma, b, gY.contiguous(),
-                                    ctx.transpose)
+                                    ctx.transpose, Y=Y)
         return gA.to(A.dtype), gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None
 
 

@@ -89,19 +89,24 @@ def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False) -> torch.Te
     return Y
 
 
-def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False):
-    """-> gA (nblk,nper,nper), gb (N,), ginv_gamma (N,)  (float32)."""
+def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None):
+    """-> gA (nblk,nper,nper), gb (N,), ginv_gamma (N,)  (float32).  ``Y``: the forward solution
+    (K, N) if still at hand -- the kernel then does not re-solve the forward system."""
     _need_gpu(turns, A, gY)
     A, delays, inv_gamma, b, gY = _f(A), _f(delays), _f(inv_gamma), _f(b), _c(gY)
     nblk, nper, _ = A.shape
     K = turns.numel()
+    if Y is not None:
+        Y = _c(Y)
+        if tuple(Y.shape) != (K, nblk * nper):
+            raise RuntimeError("solve_bwd: Y must be the (K, N) forward solution")
     lib = _lib.load()
     gA = torch.empty_like(A)
     gb = torch.empty(nblk * nper, dtype=_f32, device=A.device)
     gig = torch.empty_like(gb)
     work = _work(lib.gfdn_solve_bwd_work_bytes(nblk, nper), A.device)
     _lib.check(lib.gfdn_solve_bwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
-                                  _p(inv_gamma), _p(b), int(transpose), _p(gY), _p(gA), _p(gb),
+                                  _p(inv_gamma), _p(b), int(transpose), _p(gY), _p(Y), _p(gA), _p(gb),
                                   _p(gig), _p(work), _stream()), "gfdn_solve_bwd")
     return gA, gb, gig
 

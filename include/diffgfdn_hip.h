@@ -65,13 +65,15 @@ int gfdn_solve_fwd(const double* turns, const double* logr, int K, int nblk, int
 
 /* Backward of gfdn_solve_fwd: given gY (K, N) complex64 (= dL/dRe + i dL/dIm of Y) returns
  *   gA (nblk,nper,nper), gb (N), ginv_gamma (N).
+ * Y: the forward solution of gfdn_solve_fwd for the same arguments when the caller still holds it
+ * (the kernel then skips re-solving T y = b), or NULL.
  * work: gfdn_solve_bwd_work_bytes(nblk, nper) bytes of scratch.  Sums over bins are formed
  * in a fixed order (per-block partials + a second pass): results are bitwise reproducible. */
 size_t gfdn_solve_bwd_work_bytes(int nblk, int nper);
 int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
                    const float* A, const float* delays, const float* inv_gamma,
-                   const float* b, int transpose, const float* gY_c64, float* gA, float* gb,
-                   float* ginv_gamma, void* work, void* stream);
+                   const float* b, int transpose, const float* gY_c64, const float* Y_c64,
+                   float* gA, float* gb, float* ginv_gamma, void* work, void* stream);
 
 /* ---- output stage  (model.py:583-619, gain_filters.py:526-534, trainer.py:459) ----------
  *   S[g][k]  = sum_{n in group g} c_n Y[k][n]

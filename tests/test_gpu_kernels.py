@@ -72,6 +72,12 @@ def test_solve_fwd_bwd(ops, nblk, nper, transpose, radius):
     assert rel_err(gA.cpu(), Ad.grad) < 1e-4
     assert rel_err(gb.cpu(), bd.grad) < 1e-4
     assert rel_err(gig.cpu(), ig.grad) < 1e-4
+    # with the saved forward solution (no re-solve inside the kernel)
+    gA2, gb2, gig2 = ops.solve_bwd(turns, logr if radius != 1.0 else None, A.to(DEV), delays.to(DEV),
+                                   (1.0 / gamma).to(DEV), b.to(DEV), gY.to(DEV), transpose, Y=Y)
+    assert rel_err(gA2.cpu(), Ad.grad) < 1e-4
+    assert rel_err(gb2.cpu(), bd.grad) < 1e-4
+    assert rel_err(gig2.cpu(), ig.grad) < 1e-4
 
 
 @pytest.mark.parametrize("G,n", [(4, 4), (3, 9), (2, 16), (1, 27), (3, 2), (1, 32)])
