@@ -20,7 +20,7 @@ SIGNATURES = {
     "gfdn_abi_version": (c_int, []),
     "gfdn_zprep": (c_int, [_P, c_int, _P, _P, _P]),
     "gfdn_ortho_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P]),
-    "gfdn_ortho_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
+    "gfdn_ortho_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_solve_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "gfdn_solve_bwd_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_solve_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),

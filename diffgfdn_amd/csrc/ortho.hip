@@ -16,20 +16,12 @@ extern __shared__ double ortho_lds[];
 #define EXPM_DEG 12
 #define EXPM_THETA 0.5
 
-// C = A * B (m x m, row-major) ; all threads participate
-__device__ __forceinline__ void mm(const double* A, const double* B, double* C, int m, double scale) {
-  for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
-    const int i = e / m, j = e - i * m;
-    double acc = 0.0;
-    for (int k = 0; k < m; ++k) acc += A[i * m + k] * B[k * m + j];
-    C[e] = acc * scale;
-  }
-  __syncthreads();
-}
-
-// R = expm(A) in place helpers: A (scaled in place), P, R, T are m*m LDS arrays; s_tmp >= m+1 doubles
-__device__ __forceinline__ void expm_lds(double* A, double* P, double* R, double* T, double* s_tmp,
-                                         int m) {
+// expm(A): A (scaled in place), P, R, T are m*m LDS arrays; s_tmp >= m+1 doubles.  Returns the array
+// that holds the result (R, or one of the scratch arrays after the ping-pong of the squarings).
+// Every Taylor / squaring step is ONE pass + ONE barrier: the product, its accumulation into R
+// (element e is owned by one thread) and the role swap of the buffers need no second pass.
+__device__ __forceinline__ double* expm_lds(double* A, double* P, double* R, double* T, double* s_tmp,
+                                            int m) {
   // 1-norm = max column sum
   for (int j = threadIdx.x; j < m; j += blockDim.x) {
     double c = 0.0;
@@ -55,16 +47,34 @@ __device__ __forceinline__ void expm_lds(double* A, double* P, double* R, double
     R[e] = a + (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int k = 2; k <= EXPM_DEG; ++k) {
-    mm(P, A, T, m, 1.0 / (double)k);           // T = P A / k
-    for (int e = threadIdx.x; e < m * m; e += blockDim.x) { P[e] = T[e]; R[e] += T[e]; }
+  double* Pc = P;
+  double* Tc = T;
+  for (int k = 2; k <= EXPM_DEG; ++k) {          // Tc = Pc A / k ; R += Tc
+    const double inv = 1.0 / (double)k;
+    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+      const int i = e / m, j = e - i * m;
+      double acc = 0.0;
+      for (int q = 0; q < m; ++q) acc += Pc[i * m + q] * A[q * m + j];
+      acc *= inv;
+      Tc[e] = acc;
+      R[e] += acc;
+    }
     __syncthreads();
+    double* t = Pc; Pc = Tc; Tc = t;
   }
+  double* Rc = R;
+  double* Sc = Tc;                               // free scratch
   for (int i = 0; i < s; ++i) {
-    mm(R, R, T, m, 1.0);
-    for (int e = threadIdx.x; e < m * m; e += blockDim.x) R[e] = T[e];
+    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+      const int r = e / m, c = e - r * m;
+      double acc = 0.0;
+      for (int q = 0; q < m; ++q) acc += Rc[r * m + q] * Rc[q * m + c];
+      Sc[e] = acc;
+    }
     __syncthreads();
+    double* t = Rc; Rc = Sc; Sc = t;
   }
+  return Rc;
 }
 
 __device__ __forceinline__ double skew_elem(const float* M, int n, int i, int j) {
@@ -83,17 +93,24 @@ __global__ __launch_bounds__(256) void k_ortho_fwd(const float* __restrict__ M, 
   const float* Mg = M + (size_t)blockIdx.x * n * n;
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) A[e] = skew_elem(Mg, n, e / n, e % n);
   __syncthreads();
-  expm_lds(A, P, R, T, tmp, n);
-  if (Q) for (int e = threadIdx.x; e < n * n; e += blockDim.x) Q[(size_t)blockIdx.x * n * n + e] = (float)R[e];
-  if (QQ) {
-    mm(R, R, T, n, 1.0);
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) QQ[(size_t)blockIdx.x * n * n + e] = (float)T[e];
+  const double* E = expm_lds(A, P, R, T, tmp, n);
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    if (Q) Q[(size_t)blockIdx.x * n * n + e] = (float)E[e];
+    if (QQ) {
+      const int i = e / n, j = e - i * n;
+      double acc = 0.0;
+      for (int q = 0; q < n; ++q) acc += E[i * n + q] * E[q * n + j];
+      QQ[(size_t)blockIdx.x * n * n + e] = (float)acc;
+    }
   }
 }
 
+// Qsaved: Q_g from the forward (float32) when the caller still holds it -- the n x n exponential
+// that G needs is then not recomputed -- or NULL.
 __global__ __launch_bounds__(256) void k_ortho_bwd(const float* __restrict__ M, int n,
                                                    const float* __restrict__ gQ,
                                                    const float* __restrict__ gQQ,
+                                                   const float* __restrict__ Qsaved,
                                                    float* __restrict__ gM) {
   const int m = 2 * n;
   double* A = ortho_lds;          // m*m
@@ -108,15 +125,22 @@ __global__ __launch_bounds__(256) void k_ortho_bwd(const float* __restrict__ M, 
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) Gt[e] = gQ ? (double)gQ[off + e] : 0.0;
   __syncthreads();
   if (gQQ) {
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) A[e] = skew_elem(Mg, n, e / n, e % n);
-    __syncthreads();
-    expm_lds(A, P, R, T, tmp, n);                 // R (n x n) = Q
+    const double* Qd;
+    if (Qsaved) {
+      for (int e = threadIdx.x; e < n * n; e += blockDim.x) R[e] = (double)Qsaved[off + e];
+      __syncthreads();
+      Qd = R;
+    } else {
+      for (int e = threadIdx.x; e < n * n; e += blockDim.x) A[e] = skew_elem(Mg, n, e / n, e % n);
+      __syncthreads();
+      Qd = expm_lds(A, P, R, T, tmp, n);          // (n x n) = Q
+    }
     for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
       const int i = e / n, j = e - i * n;
       double acc = 0.0;
       for (int k = 0; k < n; ++k) {
         // (gQQ Q^T)_ij = sum_k gQQ_ik Q_jk ;  (Q^T gQQ)_ij = sum_k Q_ki gQQ_kj
-        acc += (double)gQQ[off + i * n + k] * R[j * n + k] + R[k * n + i] * (double)gQQ[off + k * n + j];
+        acc += (double)gQQ[off + i * n + k] * Qd[j * n + k] + Qd[k * n + i] * (double)gQQ[off + k * n + j];
       }
       Gt[e] += acc;
     }
@@ -147,12 +171,12 @@ __global__ __launch_bounds__(256) void k_ortho_bwd(const float* __restrict__ M, 
     A[e] = v;
   }
   __syncthreads();
-  expm_lds(A, P, R, T, tmp, m);
-  // gX = gmax * R[0:n, n:2n];  gM = triu(gX - gX^T, 1)
+  const double* E = expm_lds(A, P, R, T, tmp, m);
+  // gX = gmax * E[0:n, n:2n];  gM = triu(gX - gX^T, 1)
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     const int i = e / n, j = e - i * n;
     double v = 0.0;
-    if (i < j) v = gmax * (R[i * m + n + j] - R[j * m + n + i]);
+    if (i < j) v = gmax * (E[i * m + n + j] - E[j * m + n + i]);
     gM[off + e] = (float)v;
   }
 }
@@ -174,12 +198,12 @@ extern "C" int gfdn_ortho_fwd(const float* M, int G, int n, float* Q, float* QQ,
 }
 
 extern "C" int gfdn_ortho_bwd(const float* M, int G, int n, const float* gQ, const float* gQQ,
-                              float* gM, void* stream) {
+                              const float* Q, float* gM, void* stream) {
   if (!M || !gM || (!gQ && !gQQ) || G <= 0 || n <= 0) return GFDN_E_BADARG;
   if (n > GFDN_MAX_BLOCK || ortho_bwd_lds(n) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_ortho_bwd, ortho_bwd_lds(n));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ortho_bwd, dim3(G), dim3(256), ortho_bwd_lds(n), (hipStream_t)stream, M, n, gQ, gQQ, gM);
+  hipLaunchKernelGGL(k_ortho_bwd, dim3(G), dim3(256), ortho_bwd_lds(n), (hipStream_t)stream, M, n, gQ, gQQ, Q, gM);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

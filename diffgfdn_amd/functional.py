@@ -45,13 +45,13 @@ class OrthoParam(torch.autograd.Function):
     @staticmethod
     def forward(ctx, M):
         Q, QQ = ops.ortho_fwd(M, True, True)
-        ctx.save_for_backward(M)
+        ctx.save_for_backward(M, Q)
         return Q, QQ
 
     @staticmethod
     def backward(ctx, gQ, gQQ):
-        (M,) = ctx.saved_tensors
-        return ops.ortho_bwd(M, gQ.contiguous(), gQQ.contiguous()).to(M.dtype)
+        M, Q = ctx.saved_tensors
+        return ops.ortho_bwd(M, gQ.contiguous(), gQQ.contiguous(), Q).to(M.dtype)
 
 
 class MlpGains(torch.autograd.Function):

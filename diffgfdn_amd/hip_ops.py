@@ -64,14 +64,19 @@ def ortho_fwd(M, want_Q=True, want_QQ=False):
     return Q, QQ
 
 
-def ortho_bwd(M, gQ=None, gQQ=None):
+def ortho_bwd(M, gQ=None, gQQ=None, Q=None):
+    """``Q``: the forward's Q (G, n, n) if still at hand (skips one matrix exponential)."""
     _need_gpu(M)
     M = _f(M)
     G, n, _ = M.shape
     gQ = None if gQ is None else _f(gQ)
     gQQ = None if gQQ is None else _f(gQQ)
+    if Q is not None:
+        Q = _f(Q)
+        if Q.shape != M.shape:
+            raise RuntimeError("ortho_bwd: Q must have the shape of M")
     gM = torch.empty_like(M)
-    _lib.check(_lib.load().gfdn_ortho_bwd(_p(M), G, n, _p(gQ), _p(gQQ), _p(gM), _stream()),
+    _lib.check(_lib.load().gfdn_ortho_bwd(_p(M), G, n, _p(gQ), _p(gQQ), _p(Q), _p(gM), _stream()),
                "gfdn_ortho_bwd")
     return gM
 

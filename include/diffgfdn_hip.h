@@ -45,10 +45,11 @@ int gfdn_zprep(const double* z_c128, int K, double* turns, double* logr, void* s
 /* ---- orthogonal feedback-matrix parameterisation  (feedback_loop.py:16-36, :270, :393-404) -----
  * M (G, n, n) raw parameters.  X_g = triu(M_g,1) - triu(M_g,1)^T,  Q_g = expm(X_g) -> Q (G,n,n),
  * QQ_g = Q_g Q_g (the diagonal blocks of the feedback matrix under zero coupling) -> QQ (G,n,n).
- * Either output may be NULL.  Backward: gQ / gQQ (either may be NULL) -> gM (G,n,n).           */
+ * Either output may be NULL.  Backward: gQ / gQQ (either may be NULL) -> gM (G,n,n); Q: the
+ * forward's Q when the caller still holds it (saves recomputing the n x n exponential) or NULL. */
 int gfdn_ortho_fwd(const float* M, int G, int n, float* Q, float* QQ, void* stream);
-int gfdn_ortho_bwd(const float* M, int G, int n, const float* gQ, const float* gQQ, float* gM,
-                   void* stream);
+int gfdn_ortho_bwd(const float* M, int G, int n, const float* gQ, const float* gQQ, const float* Q,
+                   float* gM, void* stream);
 
 /* ---- per-bin resolvent solve  (feedback_loop.py:326-391, model.py:237-240, :615-619) ---
  * For every bin k and diagonal block q (nblk blocks of size nper, N = nblk*nper):

@@ -94,6 +94,8 @@ def test_ortho_param(ops, G, n):
     assert rel_err(QQk.cpu(), QQ.detach()) < 2e-6
     gM = ops.ortho_bwd(M.detach().float().to(DEV), gQ.float().to(DEV), gQQ.float().to(DEV))
     assert rel_err(gM.cpu(), M.grad) < 2e-5
+    gMq = ops.ortho_bwd(M.detach().float().to(DEV), gQ.float().to(DEV), gQQ.float().to(DEV), Qk)   # saved Q
+    assert rel_err(gMq.cpu(), M.grad) < 2e-5
     gM1 = ops.ortho_bwd(M.detach().float().to(DEV), gQ.float().to(DEV), None)
     M2 = M.detach().clone().requires_grad_(True)
     (orc.ortho_param(M2) * gQ).sum().backward()
