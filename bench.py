@@ -4,17 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): N = 16 delay lines (4 groups x 4), 500 Hz octave band,
-838-receiver synthetic grid, nfft = 131 072 (K = 65 537 bins), fs = 32 kHz, batch of 32 receiver
-positions per optimiser step, losses EDR(w=1) + EDC(w=10, random mask) + asymmetric spectral(w=1)
-+ sparsity(w=2), Adam -- the recipe of the reference's src/run_subband_training_treble.py:105-154.
+Workload (the configuration BASELINE.json's metric is quoted on -- "N=16 delay lines, 838 pos x 7
+bands" -- which fits one GPU): 7 octave-band GFDNs (63 Hz ... 4 kHz), each N = 16 delay lines
+(4 groups x 4) on its own 838-receiver synthetic grid, nfft = 131 072 (K = 65 537 bins), fs = 32 kHz,
+batch of 32 receiver positions per band per optimiser step, losses EDR(w=1) + EDC(w=10, random mask)
++ asymmetric spectral(w=1) + sparsity(w=2), Adam -- the recipe of the reference's
+src/run_subband_training_treble.py:105-154, which trains the bands one after another; here the band
+bank (diffgfdn_amd/bandbank.py) steps all of them with one launch per stage.  ``--bands 1`` runs
+BASELINE.json configs[1] alone (the 500 Hz band).
 
-One "step" = what the reference's training loop does per batch (trainer.py:373-379):
+One "step" = what the reference's training loop does per batch (trainer.py:373-379), for every band:
 normalize (no-grad sub-FDN forward + in-place rescale of b, c) + train_step (forward, losses,
-backward, [all-reduce], Adam), on 32 receivers drawn from the grid.  Inputs are resident in HBM
-before the timed region.  Metric: RIR-frames/s = receivers x 32 EDR frames / second, summed over
-ranks (weak scaling: every rank steps its own 32-receiver shard of a 32N global batch and the
-parameter gradients are summed by one flat RCCL all-reduce).
+backward, [all-reduce], Adam), on 32 receivers per band drawn from the band's grid.  Inputs are
+resident in HBM before the timed region.  Metric: RIR-frames/s = bands x receivers x 32 EDR frames /
+second, summed over ranks (weak scaling: every rank steps its own 32-receiver shard per band of a
+32N global batch and the parameter gradients are summed by one flat RCCL all-reduce).
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel, timed live with HIP events on the launch
@@ -41,6 +45,7 @@ K = NFFT // 2 + 1
 NUM_RECEIVERS = 838
 G, NPER = 4, 4
 BATCH = 32
+BAND_CENTRES = (63.0, 125.0, 250.0, 500.0, 1000.0, 2000.0, 4000.0)
 FRAMES = 32
 WIN = 4096
 HBM_PEAK_GBS = 8000.0
@@ -56,7 +61,8 @@ ALG_BYTES_PER_RIR = 2811048
 DOMINANT_KERNEL = 'k_blu_col_fwd'
 DOMINANT_ALG_BYTES_PER_UNIT = 8 * 32769 + 8 * 65536
 # HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_hbm_bytes.csv), or None
-DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 5222.0 * 1024 + 16392.0 * 1024)   # 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, batch 32
+# (profiles/r01_pmc_hbm_bytes.csv), by items per launch
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = {32: int(2 * 5222.0 * 1024 + 16392.0 * 1024)}   # 2 x FETCH_SIZE (gfx950) + WRITE_SIZE
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
 
@@ -70,7 +76,8 @@ def octave_band_response(centre_hz: float, fs: float, nfft: int, numtaps: int = 
     return np.fft.rfft(taps, n=nfft)
 
 
-def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS):
+def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS, centre_hz: float = 500.0,
+                   room_seed: int = 0, make_trainer: bool = True):
     from diffgfdn_amd.config import (CouplingMatrixType, DiffGFDNConfig, FeedbackLoopConfig,
                                      OutputFilterConfig, SubbandProcessingConfig, TrainerConfig)
     from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset, split_dataset
@@ -78,13 +85,13 @@ def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS):
     from diffgfdn_amd.synthetic import synthetic_room
     from diffgfdn_amd.trainer import VarReceiverPosTrainer
 
-    room = synthetic_room(num_receivers, G, FS, 64000, seed=0)
+    room = synthetic_room(num_receivers, G, FS, 64000, seed=room_seed)
     ds = RoomDataset(G, FS, room['source_position'], room['receiver_position'], room['rirs'],
                      room['common_decay_times'], nfft=NFFT, device=device)
     data = MultiRIRDataset(device, ds)
     torch.manual_seed(seed)
     np.random.seed(seed)
-    cfg = DiffGFDNConfig(num_groups=G, num_delay_lines=G * NPER, sample_rate=FS, seed=23463 + 500)
+    cfg = DiffGFDNConfig(num_groups=G, num_delay_lines=G * NPER, sample_rate=FS, seed=23463 + int(centre_hz))
     delays = cfg.delay_length_samps
     fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
     of = OutputFilterConfig(use_svfs=False, num_hidden_layers=5, num_neurons_per_layer=16,
@@ -97,15 +104,46 @@ def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS):
                        sparsity_loss_weight=2, use_asym_spectral_loss=True, device='cuda',
                        train_dir='/tmp/gfdn_bench/train', ir_dir='/tmp/gfdn_bench/ir',
                        subband_process_config=SubbandProcessingConfig(
-                           centre_frequency=500.0, frequency_range=(63, 8000), num_fraction_octaves=1))
-    filt = torch.tensor(octave_band_response(500.0, FS, NFFT), device=device).to(torch.complex64)
+                           centre_frequency=centre_hz, frequency_range=(63, 8000), num_fraction_octaves=1))
+    filt = torch.tensor(octave_band_response(centre_hz, FS, NFFT), device=device).to(torch.complex64)
+    train_idx, valid_idx, test_idx = split_dataset(data, 0.8, test_ratio=0.1)
+    if not make_trainer:
+        return room, data, net, tc, train_idx, filt, delays
     pg = dist.group.WORLD if dist.is_initialized() else None
     trainer = VarReceiverPosTrainer(net, tc, subband_filter_freq_resp=filt, process_group=pg,
                                     capturable=True)
     start, length = trainer.criterion[1].window(K)
     data.precompute_decay_targets(WIN, start, length)
-    train_idx, valid_idx, test_idx = split_dataset(data, 0.8, test_ratio=0.1)
     return room, data, net, trainer, train_idx, filt, delays
+
+
+def build_bank_workload(device, seed: int, centres, num_receivers: int = NUM_RECEIVERS):
+    """One model + dataset per octave band (run_subband_training_treble.py:175-204), stacked into a
+    band bank.  Returns the 500 Hz band's room / delays / filter for the CPU baseline leg."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    nets, datasets, filts, splits = [], [], [], []
+    cpu_leg = None
+    for q, f in enumerate(centres):
+        room, data, net, tc, train_idx, filt, delays = build_workload(
+            device, seed + q, num_receivers, centre_hz=f, room_seed=q, make_trainer=False)
+        nets.append(net)
+        datasets.append(data)
+        filts.append(filt)
+        splits.append(train_idx)
+        if cpu_leg is None or f == 500.0:          # the CPU baseline leg times the 500 Hz band
+            cpu_leg = (room, delays, filt)
+    bank = BandBank(nets)
+    pg = dist.group.WORLD if dist.is_initialized() else None
+    trainer = BandBankTrainer(bank, tc, subband_filter_freq_resp=torch.stack(filts), process_group=pg,
+                              band_names=[int(f) for f in centres])
+    sds = BandStackedDataset(datasets, free_sources=True)
+    start, length = trainer._decay_window(K)
+    sds.precompute_decay_targets(WIN, start, length)
+    for d in datasets:                       # only the stacked stores are read from here on
+        d.rir_mag_response = d.late_rir_mag_response = None
+    sds.rir_mag_response = torch.empty((1, K), dtype=torch.complex64, device=device)   # shape carrier
+    torch.cuda.empty_cache()
+    return cpu_leg, sds, bank, trainer, splits
 
 
 def cpu_baseline(room, delays, filt_np, steps: int = 2):
@@ -164,7 +202,11 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
+    ap.add_argument('--bands', type=int, default=len(BAND_CENTRES),
+                    help='octave bands stepped together (1 = BASELINE.json configs[1], the 500 Hz band alone)')
     args = ap.parse_args()
+    if not 1 <= args.bands <= len(BAND_CENTRES):
+        raise SystemExit(f"--bands must be 1..{len(BAND_CENTRES)}")
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -182,18 +224,30 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from diffgfdn_amd import hip_ops
-    room, data, net, trainer, train_idx, filt, delays = build_workload(device, seed=1234,
-                                                                      num_receivers=args.receivers)
-    # every rank draws its own receivers (different shards of a 32*world global batch)
+    nbands = args.bands
+    if nbands == 1:
+        room, data, net, trainer, train_idx, filt, delays = build_workload(device, seed=1234,
+                                                                          num_receivers=args.receivers)
+        splits = [train_idx]
+        centres = (500.0,)
+    else:
+        centres = BAND_CENTRES[:nbands]
+        (room, delays, filt), data, net, trainer, splits = build_bank_workload(device, 1234, centres,
+                                                                               args.receivers)
+    # every rank draws its own receivers (different shards of a 32*world global batch per band)
     gen = torch.Generator().manual_seed(100 + rank)
-    train_idx_t = torch.tensor(train_idx)
+    splits_t = [torch.tensor(s) for s in splits]
+
+    def draw():
+        sel = [t[torch.randperm(len(t), generator=gen)[:BATCH]].tolist() for t in splits_t]
+        return sel[0] if nbands == 1 else data.global_rows(sel)
 
     step = trainer.graphed(data, BATCH)      # normalize + train_step as HIP-graph replays
 
     def one_step():
-        sel = train_idx_t[torch.randperm(len(train_idx), generator=gen)[:BATCH]].tolist()
+        sel = draw()
         if args.eager:
-            batch = data.collate(sel, lean=True)
+            batch = data.collate(sel, lean=True) if nbands == 1 else data.collate(sel)
             trainer.normalize(batch)
             return trainer.train_step(batch)
         losses = step(sel)
@@ -221,13 +275,19 @@ def main():
     if rank == 0:
         hip_ops.kernel_timer.watch = DOMINANT_KERNEL
         hip_ops.kernel_timer.start()
+        ones = torch.ones(nbands, device=device)
         for _ in range(ROOFLINE_EAGER_STEPS):
-            sel = train_idx_t[torch.randperm(len(train_idx), generator=gen)[:BATCH]].tolist()
-            batch = data.collate(sel, lean=True)
+            sel = draw()
+            batch = data.collate(sel, lean=True) if nbands == 1 else data.collate(sel)
             with torch.no_grad():
                 trainer.normalize(batch)
-            lo = trainer._step_losses(batch, mask_prenorm=step.maskw)   # no collectives inside
-            lo['_total'].backward()          # no optimizer step / all-reduce: kernel timing only
+            # no optimizer step / all-reduce (no collectives inside): kernel timing only
+            if nbands == 1:
+                lo = trainer._step_losses(batch, mask_prenorm=step.maskw)
+                lo['_total'].backward()
+            else:
+                lo = trainer._step_losses(batch, mask_prenorm=step.maskw, defer_total=True)
+                torch.autograd.backward(lo['_heads'], [ones, ones])
         ktimes = hip_ops.kernel_timer.stop()
         trainer.optimizer.zero_grad(set_to_none=True)
     if world > 1:
@@ -235,7 +295,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    rirs_per_s = BATCH * world * args.steps / elapsed
+    rirs_per_s = nbands * BATCH * world * args.steps / elapsed
     value = rirs_per_s * FRAMES
 
     if rank == 0:
@@ -244,13 +304,16 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'N=16 GFDN (4 groups x 4), 500 Hz octave band, 838-receiver grid, '
-                                   'nfft 131072 (K=65537), batch 32 receivers/step/GPU; step = normalize + '
-                                   'fwd + EDR/EDC(mask)/colorless losses + bwd + Adam',
-                       'receivers': args.receivers, 'batch_per_gpu': BATCH, 'global_batch': BATCH * world,
+            'config': {'workload': f'{nbands} octave-band GFDN(s) ({", ".join(str(int(f)) for f in centres)} Hz), each '
+                                   f'N=16 (4 groups x 4) on a {args.receivers}-receiver grid, nfft 131072 (K=65537), '
+                                   'batch 32 receivers/band/step/GPU; step = normalize + fwd + EDR/EDC(mask)/'
+                                   'colorless losses + bwd + Adam for every band'
+                                   + (' (band bank: one launch per stage for all bands)' if nbands > 1 else ''),
+                       'bands': nbands, 'receivers': args.receivers, 'batch_per_band_per_gpu': BATCH,
+                       'rirs_per_step_per_gpu': nbands * BATCH, 'global_batch_per_band': BATCH * world,
                        'delay_lines': G * NPER, 'bins': K, 'rirs_per_s': rirs_per_s,
                        'launch': 'eager' if args.eager else 'hip_graph',
-                       'final_loss': float(total)},
+                       'final_loss': [float(v) for v in total.reshape(-1).tolist()]},
         }
         dom = ktimes if ktimes else None
         if dom:
@@ -263,7 +326,7 @@ def main():
             achieved = units * dom['alg_bytes_per_unit'] / (net_ms * 1e-3) / 1e9
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS,
-                               'traffic': DOMINANT_TRAFFIC_BYTES_PER_LAUNCH,
+                               'traffic': DOMINANT_TRAFFIC_BYTES_PER_LAUNCH.get(int(round(units))),
                                'kernel': dom['kernel'], 'avg_launch_us': net_ms * 1e3,
                                'bracket_us': dom['avg_ms'] * 1e3,
                                'event_pair_overhead_us': dom['event_pair_overhead_ms'] * 1e3,

@@ -27,12 +27,19 @@ SIGNATURES = {
     "gfdn_compose_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     "gfdn_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfdn_compose_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_compose_banded_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
+    "gfdn_compose_banded_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gfdn_compose_banded_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "gfdn_compose_sh_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
     "gfdn_compose_sh_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_compose_sh_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_spectral_stats_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_spectral_stats": (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "gfdn_colorless_terms": (c_int, [_P, c_int, _P, c_int, c_float, c_float, c_float, _P, _P, _P]),
+    "gfdn_colorless_terms_banded": (c_int, [_P, c_int, c_int, _P, c_int, c_float, c_float, c_float, _P, _P, _P]),
+    "gfdn_weighted_sums_banded": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, c_int, _P, _P]),
+    "gfdn_mlp_gains_banded_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_mlp_gains_banded_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_subfdn_normalize_work_bytes": (c_size_t, [c_int]),
     "gfdn_subfdn_normalize": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),

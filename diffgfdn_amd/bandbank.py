@@ -1,0 +1,511 @@
+"""Band bank: the octave-band GFDNs of one room stepped in lockstep, one launch per stage for ALL bands.
+
+The reference trains one independent DiffGFDNVarReceiverPos per octave band, one after another
+(src/run_subband_training_treble.py:175-204: ``for k in range(len(freqs_list))`` builds the band's
+config, dataset, model and ``VarReceiverPosTrainer`` and calls ``train``).  The bands share neither
+parameters nor data, only their SHAPE: same number of groups and delay lines per group, same MLP
+sizes, same frequency grid, same batch size.  On an MI355X a single band at batch 32 fills a
+fraction of the 256 CUs (the step is a dependency chain of small launches), so the
+bank evaluates the same chain ONCE with every stage widened over the bands:
+
+  * the per-bin solve takes the bands' diagonal blocks side by side (nblk = bands x G blocks of one
+    ``gfdn_solve_*`` launch; delays / absorption gains / input gains are per-lane arrays anyway);
+  * the output stage, the gain network, the colorless bookkeeping and the loss totals run their
+    band-stacked entry points (``gfdn_*_banded``, include/diffgfdn_hip.h): items are band-major
+    (item = band x B + b) and every band reads its own parameter row;
+  * irfft / STFT / EDR / EDC are per-item kernels already: they see bands x B items;
+  * all bands' parameters live in ONE flat Adam buffer (one update launch, one all-reduce).
+
+Results per band are those of the band's own trainer (tests/test_gpu_bank.py checks losses, gradients
+and the post-Adam state of every band against single-band steps and the CPU oracle).  Each band's
+``nn.Module`` stays alive: its parameters are views into the bank's stacked tensors, so
+``nets[i].state_dict()`` is the reference-shaped checkpoint of band i at any time.
+
+Supported layout (the reference's sub-band recipe, run_subband_training_treble.py:105-154): SCALAR
+coupling with zero inter-group coupling, fixed common decay times, MLP output gains.  Other layouts
+train band by band with ``subband.train_bands``.
+"""
+import contextlib
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import hip_ops as ops
+from .config import CouplingMatrixType, TrainerConfig
+from .functional import ColorlessTerms, FrequencyGrid, MlpGains, OrthoParam, OutputStage, ResolventSolve
+from .losses import decay_losses, edc_loss
+from .optim import FlatAdam
+
+
+class BandBank(nn.Module):
+    """``nets``: one DiffGFDNVarReceiverPos per band, already on the GPU, identical in shape.
+
+    Stacked leaves (what autograd and Adam see):
+        input_gains, output_gains (bands, N);  feedback_loop_M (bands, G, n, n);
+        output_scalars_w (bands, P) -- every band's MLP parameters packed in named_parameters() order.
+    The names keep the substrings the reference selects learning-rate groups by
+    (trainer.py:157-216: 'input_gains', 'output_gains', 'output_scalars' -> io_lr, the rest -> lr)."""
+
+    def __init__(self, nets: Sequence[nn.Module]):
+        super().__init__()
+        nets = list(nets)
+        if not nets:
+            raise ValueError("BandBank needs at least one band")
+        n0 = nets[0]
+        G, n = n0.num_groups, n0.num_delay_lines_per_group
+        for net in nets:
+            fl = net.feedback_loop
+            if (net.num_groups, net.num_delay_lines_per_group) != (G, n):
+                raise ValueError("BandBank: bands must have the same groups x delay lines per group")
+            if fl.coupling_matrix_type == CouplingMatrixType.RANDOM or not fl.use_zero_coupling:
+                raise NotImplementedError("BandBank: zero inter-group coupling only (train other layouts "
+                                          "band by band with subband.train_bands)")
+            if fl.learn_decay_times or not isinstance(fl.M, nn.Parameter):
+                raise NotImplementedError("BandBank: fixed decay times and a learnable M per band")
+            if not hasattr(net, 'output_scalars') or not hasattr(net.output_scalars, 'mlp'):
+                raise NotImplementedError("BandBank: DiffGFDNVarReceiverPos with MLP output gains")
+            if not net.input_gains.is_cuda:
+                raise RuntimeError("BandBank needs the band models on the GPU (no CPU fallback)")
+            if net.sample_rate != n0.sample_rate:
+                raise ValueError("BandBank: one sample rate")
+        object.__setattr__(self, 'nets', nets)            # not sub-modules: no duplicate parameters
+        self.num_bands = len(nets)
+        self.num_groups, self.num_delay_lines_per_group = G, n
+        self.num_delay_lines = G * n
+        self.sample_rate = n0.sample_rate
+        self.use_colorless_loss = all(net.use_colorless_loss for net in nets)
+        N = G * n
+        gm = n0.output_scalars
+        lin = [m for m in gm.mlp.model if isinstance(m, nn.Linear)]
+        self._mlp_cfg = (lin[0].out_features, len(lin) - 2, gm.encoder.num_fourier_features,
+                         float(gm.scaled_sigmoid.lower_limit), float(gm.scaled_sigmoid.upper_limit))
+        self._mlp_params = [[p for m in net.output_scalars.mlp.model for p in m.parameters()] for net in nets]
+        shapes = [tuple(p.shape) for p in self._mlp_params[0]]
+        for ps in self._mlp_params:
+            if [tuple(p.shape) for p in ps] != shapes:
+                raise ValueError("BandBank: the bands' gain networks must have the same layer sizes")
+        with torch.no_grad():
+            self.input_gains = nn.Parameter(torch.stack([net.input_gains.detach().reshape(N) for net in nets]))
+            self.output_gains = nn.Parameter(torch.stack([net.output_gains.detach().reshape(N) for net in nets]))
+            self.feedback_loop_M = nn.Parameter(torch.stack([net.feedback_loop.M.detach() for net in nets]))
+            self.output_scalars_w = nn.Parameter(torch.stack(
+                [torch.cat([p.detach().reshape(-1) for p in ps]) for ps in self._mlp_params]))
+            self.register_buffer('delays', torch.cat([net.delay_buffer.to(torch.float32) for net in nets]),
+                                 persistent=False)
+            self.register_buffer('inv_gamma', torch.cat(
+                [(1.0 / net.feedback_loop.delay_line_gains.to(torch.float32)) for net in nets]).contiguous(),
+                persistent=False)
+            dev = self.input_gains.device
+            self.register_buffer('_ones', torch.ones(self.num_bands * N, dtype=torch.float32, device=dev),
+                                 persistent=False)
+            self.register_buffer('_eye', torch.eye(G, dtype=torch.float32, device=dev).repeat(self.num_bands, 1),
+                                 persistent=False)
+            f = torch.exp(torch.linspace(np.log(1.0), np.log(32.0), self._mlp_cfg[2], device=dev))
+            self.register_buffer('_freq_pi', (f * np.pi).to(torch.float32).contiguous(), persistent=False)
+        self.relink()
+
+    def relink(self):
+        """Point every band model's parameters at the bank's (current) storage.  Call again after
+        anything that re-homes the leaves (FlatAdam moves them into its flat buffer)."""
+        N = self.num_delay_lines
+        for i, net in enumerate(self.nets):
+            net.input_gains.data = self.input_gains.data[i].view(N, 1)
+            net.output_gains.data = self.output_gains.data[i].view(N, 1)
+            net.feedback_loop.M.data = self.feedback_loop_M.data[i]
+            off = 0
+            for p in self._mlp_params[i]:
+                k = p.numel()
+                p.data = self.output_scalars_w.data[i, off:off + k].view(p.shape)
+                off += k
+
+    def band_state_dict(self, band: int) -> Dict[str, torch.Tensor]:
+        """Reference-shaped state dict of one band (DiffGFDNVarReceiverPos.state_dict keys)."""
+        return self.nets[band].state_dict()
+
+    # -- stages, every one a single launch over all bands -----------------------------------------
+    def _blocks(self) -> torch.Tensor:
+        G, n = self.num_groups, self.num_delay_lines_per_group
+        return self.feedback_loop_M.view(self.num_bands * G, n, n)
+
+    @torch.no_grad()
+    def normalize(self, z: torch.Tensor):
+        """Trainer.normalize (trainer.py:317-332) for every band: b_n, c_n /= E_g^(1/4)."""
+        grid = FrequencyGrid.of(z)
+        ops.subfdn_normalize(grid.turns, grid.logr, self._blocks().detach(), self.delays,
+                             self.input_gains.data.view(-1), self.output_gains.data.view(-1))
+
+    def rotations(self):
+        """(Q, QQ) (bands*G, n, n): Q_g = expm(skew(M_g)), QQ_g = Q_g Q_g (feedback_loop.py:393-404)."""
+        return OrthoParam.apply(self._blocks())
+
+    def sub_fdn_group_sums(self, z: torch.Tensor) -> torch.Tensor:
+        """S (bands*G, K): un-damped sub-FDN responses Hout[k, g] of every band (model.py:209-252)."""
+        grid = FrequencyGrid.of(z)
+        Ysub = ResolventSolve.apply(self._blocks(), self._ones, self.input_gains.view(-1), grid, self.delays,
+                                    False)
+        return OutputStage.apply(Ysub, self.output_gains.view(-1), self._eye,
+                                 self.num_delay_lines_per_group, None, None, None, self.num_bands)
+
+    def delay_line_responses(self, z: torch.Tensor, QQ: torch.Tensor) -> torch.Tensor:
+        """Y (K, bands*N): y = (D Gamma^-1 - blockdiag(Q_g Q_g))^-1 b for every band."""
+        return ResolventSolve.apply(QQ, self.inv_gamma, self.input_gains.view(-1), FrequencyGrid.of(z),
+                                    self.delays, False)
+
+    def group_gains(self, positions: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """(bands*B, G) receiver gains; item i encodes positions[rows[i]] with band i // B's network."""
+        H, n_hidden, _, lo, hi = self._mlp_cfg
+        return MlpGains.apply(positions, rows, self._freq_pi, H, n_hidden, self.num_groups, lo, hi,
+                              self.output_scalars_w)
+
+
+class BandStackedDataset:
+    """The bands' MultiRIRDataset stores stacked band-major: row = band * R + receiver.
+
+    Same ``collate(rows, lean="rows")`` contract as MultiRIRDataset (dataloader.py here,
+    custom_collate dataloader.py:674-704 in the reference): nothing is gathered, the batch is an
+    int64 vector of global rows into the stores."""
+
+    def __init__(self, datasets: Sequence, free_sources: bool = False):
+        ds0 = datasets[0]
+        self.device = ds0.device
+        self.num_bands = len(datasets)
+        self.R = len(ds0)
+        for d in datasets:
+            if len(d) != self.R or d.z_values.shape != ds0.z_values.shape:
+                raise ValueError("BandStackedDataset: every band needs the same receivers and frequency grid")
+        self.z_values = ds0.z_values
+        self.datasets = list(datasets)
+        self.norm_listener_position = torch.cat([d.norm_listener_position for d in datasets])
+        self.listener_positions = torch.cat([d.listener_positions for d in datasets])
+        self.early_rir_mag_response = torch.cat([d.early_rir_mag_response for d in datasets])
+        self.rir_mag_response = ds0.rir_mag_response          # shape carrier (K); targets come from the stores
+        self.source_position = ds0.source_position
+        self.edr_store = self.edc_store = None
+        if free_sources:
+            for d in datasets:
+                d.early_rir_mag_response = None
+
+    def __len__(self):
+        return self.R
+
+    def precompute_decay_targets(self, win: int, edc_start: int, edc_len: int, chunk: int = 64):
+        edr_T, edr_s, edc_T = [], [], []
+        for d in self.datasets:
+            if (d.edr_store is None or d.edc_store is None or d.edr_store[0] != win
+                    or d.edc_store[0] != (edc_start, edc_len)):
+                d.precompute_decay_targets(win, edc_start, edc_len, chunk)
+            edr_T.append(d.edr_store[1])
+            edr_s.append(d.edr_store[2])
+            edc_T.append(d.edc_store[1])
+        self.edr_store = (win, torch.cat(edr_T), torch.cat(edr_s))
+        self.edc_store = ((edc_start, edc_len), torch.cat(edc_T))
+        for d in self.datasets:                  # the stacked copies are the live ones
+            d.edr_store = d.edc_store = None
+
+    def global_rows(self, per_band: Sequence[Sequence[int]]) -> List[int]:
+        """per_band[q] = receiver indices of band q's batch -> band-major global rows."""
+        if len(per_band) != self.num_bands or len({len(s) for s in per_band}) != 1:
+            raise ValueError("global_rows: one equally sized index list per band")
+        return [q * self.R + int(i) for q, sel in enumerate(per_band) for i in sel]
+
+    def collate(self, rows, lean="rows") -> Dict:
+        if lean != "rows":
+            raise ValueError('BandStackedDataset serves lean="rows" batches only')
+        if self.edr_store is None or self.edc_store is None:
+            raise RuntimeError('collate needs precompute_decay_targets() first')
+        idx = rows if torch.is_tensor(rows) else torch.as_tensor(list(rows), dtype=torch.long, device=self.device)
+        return {'z_values': self.z_values, 'norm_listener_position': self.norm_listener_position,
+                'target_early_response': self.early_rir_mag_response, 'edr_target': self.edr_store,
+                'edc_target': self.edc_store, 'receiver_index': idx, 'row_index': idx}
+
+
+class BandFlatAdam(FlatAdam):
+    """FlatAdam whose learning-rate table is per (group, band): a band that has stopped early
+    (trainer.py:410-418) keeps stepping with lr = 0, i.e. its parameters no longer move."""
+
+    def __init__(self, groups, num_bands: int):
+        self.num_bands = num_bands
+        self.band_active = [True] * num_bands
+        super().__init__(groups)
+        ng = len(self.param_groups)
+        if ng * num_bands > 255:
+            raise ValueError("too many (group, band) learning-rate segments")
+        # every leaf is (bands, ...) contiguous: band q owns the q-th equal chunk of its flat range
+        seg = self.seg.cpu()
+        off = 0
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                k = p.numel() // num_bands
+                for q in range(num_bands):
+                    seg[off + q * k: off + (q + 1) * k] = gi * num_bands + q
+                off += p.numel()
+        self.seg = seg.to(self.flat_param.device)
+        self.lr_seg = torch.zeros(ng * num_bands, dtype=torch.float32, device=self.flat_param.device)
+        self._lr_host = None
+        self.sync_lr()
+
+    def sync_lr(self):
+        if not hasattr(self, 'band_active') or self.lr_seg.numel() != len(self.param_groups) * self.num_bands:
+            return            # called from the base constructor before the table exists
+        lrs = [float(g['lr']) * (1.0 if self.band_active[q] else 0.0)
+               for g in self.param_groups for q in range(self.num_bands)]
+        if lrs != self._lr_host:
+            self.lr_seg.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            self._lr_host = lrs
+
+
+class BandBankTrainer:
+    """VarReceiverPosTrainer (trainer.py:338-564) for a BandBank: the same step, all bands at once.
+
+    ``subband_filter_freq_resp``: (bands, K) complex responses of the bands' sub-band filters
+    (trainer.py:112-150 derives them from pyfar FIR taps; they are input data here).
+    Losses are (bands,) vectors; band q's entries equal what band q's own trainer reports."""
+
+    capturable = True
+    concurrent_branches = True
+
+    def __init__(self, bank: BandBank, trainer_config: TrainerConfig,
+                 subband_filter_freq_resp: Optional[torch.Tensor] = None, process_group=None,
+                 stft_win: int = 4096, band_names: Optional[Sequence] = None):
+        cfg = trainer_config
+        if not cfg.use_colorless_loss or not bank.use_colorless_loss:
+            raise NotImplementedError("BandBankTrainer follows the sub-band recipe (colorless loss on)")
+        if cfg.use_reg_loss or cfg.use_erb_edr_loss or cfg.use_frequency_weighting or cfg.reduced_pole_radius != 1.0:
+            raise NotImplementedError("BandBankTrainer: plain EDR + EDC + colorless losses on the unit circle")
+        self.net, self.config = bank, cfg
+        self.num_bands = bank.num_bands
+        self.band_names = list(band_names) if band_names is not None else list(range(self.num_bands))
+        self.max_epochs, self.patience = cfg.max_epochs, 5
+        self.train_dir = cfg.train_dir
+        self.stft_win = stft_win
+        self.subband_filter_freq_resp = None
+        if cfg.subband_process_config is not None:
+            if subband_filter_freq_resp is None or subband_filter_freq_resp.shape[0] != self.num_bands:
+                raise ValueError("pass subband_filter_freq_resp as (bands, K)")
+            self.subband_filter_freq_resp = subband_filter_freq_resp.to(torch.complex64).contiguous()
+        self._filt_u = None
+        # Adam groups by the reference's name rules (init_scheduler :152-228)
+        groups = [{'params': [bank.output_gains], 'lr': cfg.io_lr},
+                  {'params': [bank.input_gains], 'lr': cfg.io_lr},
+                  {'params': [bank.output_scalars_w], 'lr': cfg.io_lr},
+                  {'params': [bank.feedback_loop_M], 'lr': cfg.lr}]
+        self.optimizer = BandFlatAdam(groups, self.num_bands)
+        bank.relink()                               # the leaves now live in the flat buffer
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=10, gamma=0.1)
+        # one EDC window for all bands (trainer.py:56-59: T60max of the band's decay times)
+        lens = {float(np.max(np.asarray(net.common_decay_times))) * 1e3 if net.common_decay_times is not None
+                else 2000.0 for net in bank.nets}
+        if len(lens) != 1:
+            raise NotImplementedError("BandBankTrainer: bands with different longest decay times have different "
+                                      "EDC windows; train those band by band (subband.train_bands)")
+        self.max_ir_len_ms = lens.pop()
+        self.criterion = [None, edc_loss(self.max_ir_len_ms, bank.sample_rate, use_mask=cfg.use_edc_mask)]
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self._allreduce = None
+        if self.world_size > 1:
+            opt, pg = self.optimizer, process_group
+            self._allreduce = lambda: dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=pg)
+        self._side = self._side2 = None
+
+    def _decay_window(self, K: int):
+        return self.criterion[1].window(K)
+
+    def _stream(self, which: str):
+        if not self.concurrent_branches or which in getattr(self, '_disabled_streams', ()):
+            return None
+        if getattr(self, which) is None:
+            setattr(self, which, torch.cuda.Stream())
+        return getattr(self, which)
+
+    @torch.no_grad()
+    def normalize(self, data: Dict):
+        self.net.normalize(data['z_values'])
+
+    def _step_losses(self, data: Dict, draw_mask: bool = True, mask_prenorm: Optional[torch.Tensor] = None,
+                     normalize_first: bool = False, defer_total: bool = False) -> Dict:
+        """Forward + losses of one band-major batch (rows = data['row_index'], bands x B items);
+        stream structure as VarReceiverPosTrainer._step_losses."""
+        bank, cfg, nb = self.net, self.config, self.num_bands
+        z = data['z_values']
+        rows = data['row_index']
+        Btot = rows.numel()
+        if Btot % nb:
+            raise ValueError("the batch must hold the same number of receivers for every band")
+        Bper = Btot // nb
+        main = torch.cuda.current_stream()
+        side = self._stream('_side')
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            if normalize_first:
+                self.normalize(data)
+            Q, QQ = bank.rotations()
+            if side is not None:
+                ready = torch.cuda.Event()
+                ready.record(side)
+            S = bank.sub_fdn_group_sums(z)
+            extra, spec, sparse = ColorlessTerms.apply(S, Q, cfg.use_asym_spectral_loss, cfg.spectral_loss_weight,
+                                                       cfg.sparsity_loss_weight, 1.0 / self.world_size, True, nb)
+        rgain = bank.group_gains(data['norm_listener_position'], rows)
+        if side is not None:
+            main.wait_event(ready)
+            # QQ was allocated on the side stream and is read by the main stream's solve (forward AND
+            # backward): without this its block returns to the side stream's pool the moment autograd
+            # drops it, and a side-stream kernel of the colorless backward may overwrite it while the
+            # main solve backward still reads it (seen as wrong dL/dM, dL/db under graph replay)
+            QQ.record_stream(main)
+        K = z.shape[-1]
+        Ku = (K + 1) // 2 if K % 2 == 1 else K          # irfft(X, n = K) reads bins 0..(K-1)/2 only
+        Y = bank.delay_line_responses(z[:Ku], QQ)
+        filt = None
+        if self.subband_filter_freq_resp is not None:
+            if self._filt_u is None or self._filt_u.shape[-1] != Ku:
+                self._filt_u = self.subband_filter_freq_resp[:, :Ku].contiguous()
+            filt = self._filt_u
+        H = OutputStage.apply(Y, bank.output_gains.view(-1), rgain, bank.num_delay_lines_per_group,
+                              data['target_early_response'][:, :Ku], filt, rows, nb)
+        start, length = self._decay_window(K)
+        gb = Bper
+        if mask_prenorm is not None:
+            maskw, count = mask_prenorm, None
+        else:
+            maskw, count = (self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length)))
+            if maskw is not None and self.world_size > 1:
+                dist.broadcast(maskw, src=0, group=self.process_group)
+                count = float(maskw.sum().item())
+            gb = Bper * self.world_size
+        edr_t, edc_t = data['edr_target'], data['edc_target']
+        total, edr_v, edc_v = decay_losses(
+            H, None, win=self.stft_win, edr_weight=cfg.edr_loss_weight, edc_weight=cfg.edc_loss_weight,
+            edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
+            edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
+            edr_target=(edr_t[1], edr_t[2]), edc_target=edc_t[1], side_stream=self._stream('_side2'),
+            unit_grad=True, n_time=K, target_rows=rows, nbands=nb)
+        losses = {'edc_loss': edc_v, 'edr_loss': edr_v, 'spectral_loss': spec.detach(),
+                  'sparsity_loss': sparse.detach()}
+        if side is not None:
+            main.wait_stream(side)
+            extra.record_stream(main)
+        if defer_total:
+            losses['_heads'] = [total, extra]
+        else:
+            losses['_total'] = total + extra
+        return losses
+
+    def _ones(self, dev):
+        if getattr(self, '_unit', None) is None:
+            self._unit = torch.ones(self.num_bands, dtype=torch.float32, device=dev)
+        return self._unit
+
+    def train_step(self, data: Dict):
+        """One optimiser step of every band (trainer.py:452-477); returns ((bands,) totals, parts)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        losses = self._step_losses(data, defer_total=True)
+        heads = losses.pop('_heads')
+        one = self._ones(heads[0].device)
+        torch.autograd.backward(heads, [one] * len(heads))
+        self.optimizer.pack_grads()
+        if self._allreduce is not None:
+            self._allreduce()
+        self.optimizer.step()
+        return sum(losses.values()), losses
+
+    @torch.no_grad()
+    def valid_step(self, data: Dict):
+        losses = self._step_losses(data)
+        losses.pop('_total')
+        return sum(losses.values()), losses
+
+    def graphed(self, dataset: BandStackedDataset, batch_per_band: int, mask_source: str = "device",
+                mask_seed: Optional[int] = None):
+        """normalize + train_step of bands x batch_per_band receivers as one HIP-graph replay."""
+        from .trainer import GraphedTrainStep
+        return GraphedTrainStep(self, dataset, batch_per_band * self.num_bands, mask_source, mask_seed)
+
+    def save_model(self, e: int):
+        """checkpoints/model_e{e}.pt per band under train_dir/band_<name>/ (save_model :249-257)."""
+        if self.rank != 0:
+            return
+        for q, name in enumerate(self.band_names):
+            d = os.path.join(self.train_dir, f'band_{name}', 'checkpoints')
+            os.makedirs(d, exist_ok=True)
+            torch.save(self.net.band_state_dict(q), os.path.join(d, 'model_e' + str(e) + '.pt'))
+
+    def train(self, dataset: BandStackedDataset, train_indices: Sequence[Sequence[int]],
+              valid_indices: Sequence[Sequence[int]], batch_size: Optional[int] = None,
+              save_checkpoints: bool = True, log: bool = True):
+        """Epoch loop of every band in lockstep (trainer.py:345-424): per band its own shuffled
+        receiver order, normalize + train_step per batch, validation, StepLR, early stopping
+        (a stopped band's learning rates drop to 0; the loop ends when every band has stopped).
+        ``train_indices[q]`` / ``valid_indices[q]``: band q's receiver indices (load_dataset's split)."""
+        nb = self.num_bands
+        B = batch_size or self.config.batch_size
+        ntr = len(train_indices[0])
+        if any(len(t) != ntr for t in train_indices) or len({len(v) for v in valid_indices}) != 1:
+            raise ValueError("BandBankTrainer.train: the bands' splits must have equal sizes")
+        K = dataset.z_values.shape[-1]
+        start, length = self._decay_window(K)
+        dataset.precompute_decay_targets(self.stft_win, start, length)
+        step = self.graphed(dataset, B)
+        self.train_loss = [[] for _ in range(nb)]
+        self.valid_loss = [[] for _ in range(nb)]
+        self.individual_train_loss, self.individual_valid_loss = [], []
+        early = [0] * nb
+        st = time.time()
+        if save_checkpoints:
+            self.save_model(-1)
+        for epoch in range(self.max_epochs):
+            t0 = time.time()
+            orders = [[train_indices[q][i] for i in torch.randperm(ntr).tolist()] for q in range(nb)]
+            agg_t, nsteps = {}, 0
+            for i0 in range(0, ntr, B):
+                sel = [o[i0:i0 + B] for o in orders]
+                rows = dataset.global_rows(sel)
+                if len(sel[0]) == B:
+                    cur = step(rows)                                  # replayed graph
+                    cur = {k: v for k, v in cur.items() if not k.startswith('_')}
+                else:                                                 # ragged tail: host launches
+                    batch = dataset.collate(rows)
+                    self.normalize(batch)
+                    _, cur = self.train_step(batch)
+                for k, v in cur.items():
+                    agg_t[k] = agg_t.get(k, 0.0) + v.detach()
+                nsteps += 1
+            agg_v, nv = {}, 0
+            nval = len(valid_indices[0])
+            for i0 in range(0, nval, B):
+                rows = dataset.global_rows([v[i0:i0 + B] for v in valid_indices])
+                _, cur = self.valid_step(dataset.collate(rows))
+                for k, v in cur.items():
+                    agg_v[k] = agg_v.get(k, 0.0) + v.detach()
+                nv += 1
+            self.scheduler.step()
+            tl = (sum(agg_t.values()) / max(nsteps, 1)).tolist()      # one sync per epoch
+            vl = (sum(agg_v.values()) / max(nv, 1)).tolist() if agg_v else [0.0] * nb
+            self.individual_train_loss.append({k: (v / max(nsteps, 1)).tolist() for k, v in agg_t.items()})
+            self.individual_valid_loss.append({k: (v / max(nv, 1)).tolist() for k, v in agg_v.items()})
+            for q in range(nb):
+                if not self.optimizer.band_active[q]:
+                    continue
+                self.train_loss[q].append(tl[q])
+                self.valid_loss[q].append(vl[q])
+                if epoch >= 1:
+                    early[q] = early[q] + 1 if abs(self.valid_loss[q][-2] - self.valid_loss[q][-1]) <= 1e-3 else 0
+                if early[q] == self.patience:
+                    self.optimizer.band_active[q] = False
+            self.optimizer.sync_lr()
+            if save_checkpoints:
+                self.save_model(epoch)
+            if log and self.rank == 0:
+                print(f"epoch {epoch}: " + " ".join(f"[{self.band_names[q]}] {tl[q]:.3f}/{vl[q]:.3f}"
+                                                    for q in range(nb)) + f" ({time.time() - t0:.2f} s)")
+            if not any(self.optimizer.band_active):
+                break
+        self.train_time = time.time() - st

@@ -21,6 +21,7 @@ struct MlpDims {
   float lo, hi;                 // ScaledSigmoid limits
   const long long* rows;        // item b encodes pos[rows[b]] (NULL: pos[b])
   int stage;                    // 1: the packed parameters (+ the receiver's saved activations) fit in LDS
+  int Bper;                     // items per band: item b uses the parameter set b / Bper (w is (bands, P))
 };
 
 __device__ __forceinline__ size_t mlp_layer_off(const MlpDims& d, int l) {
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
   float* h = a + amax;           // pre-norm outputs
   float* red = h + d.H;          // 16 floats
   const int b = blockIdx.x, H = d.H;
+  w += (size_t)(b / d.Bper) * mlp_param_count(d);
   // small networks: ONE round of global loads brings every parameter into LDS; the layer chain then
   // never waits on memory again (it was one dependent global-load latency per layer)
   // Likewise the saved activations go to LDS first and to memory once at the end: every
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
   float* red = draw + d.G;       // 16
   const int b = blockIdx.x, H = d.H, G = d.G;
   const size_t P = mlp_param_count(d);
+  w += (size_t)(b / d.Bper) * P;
   float* gp = partial + (size_t)b * P;
   xhat += (size_t)b * d.nl * H;
   rstd += (size_t)b * d.nl;
@@ -229,11 +232,13 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
   }
 }
 
-// gflat[p] = sum_b partial[b][p]
+// gflat[band][p] = sum_{b in band} partial[b][p]   (B items per band, band = blockIdx.y)
 __global__ void k_mlp_reduce(const float* __restrict__ partial, int B, size_t P,
                              float* __restrict__ gflat) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
+  partial += (size_t)blockIdx.y * B * P;
+  gflat += (size_t)blockIdx.y * P;
   float s = 0.f;
   for (int b = 0; b < B; ++b) s += partial[(size_t)b * P + p];
   gflat[p] = s;
@@ -244,6 +249,7 @@ static int mlp_dims(int B, int F, int H, int n_hidden, int G, float lo, float hi
   if (H > MLP_T || G > MLP_T || 6 * F > 4096) return GFDN_E_UNSUPPORTED;
   d->B = B; d->F = F; d->in_dim = 6 * F; d->H = H; d->nl = 1 + n_hidden; d->G = G; d->lo = lo; d->hi = hi;
   d->rows = nullptr;
+  d->Bper = B;
   d->stage = mlp_param_count(*d) <= MLP_STAGE_MAX ? 1 : 0;
   return 0;
 }
@@ -275,9 +281,20 @@ extern "C" size_t gfdn_mlp_bwd_work_bytes(int B, int F, int H, int n_hidden, int
 extern "C" int gfdn_mlp_gains_fwd(const double* pos, const long long* pos_rows, const float* freq_pi,
                                   const float* w, int B, int F, int H, int n_hidden, int G, float lo,
                                   float hi, float* gains, float* xhat, float* rstd, void* stream) {
+  return gfdn_mlp_gains_banded_fwd(pos, pos_rows, freq_pi, w, 1, B, F, H, n_hidden, G, lo, hi, gains, xhat,
+                                   rstd, stream);
+}
+
+extern "C" int gfdn_mlp_gains_banded_fwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                         const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                                         int G, float lo, float hi, float* gains, float* xhat, float* rstd,
+                                         void* stream) {
   MlpDims d;
+  if (nbands <= 0 || Bper <= 0) return GFDN_E_BADARG;
+  const int B = nbands * Bper;
   int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
   if (rc) return rc;
+  d.Bper = Bper;
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd) return GFDN_E_BADARG;
   hipLaunchKernelGGL(k_mlp_fwd, dim3(B), dim3(mlp_threads(d)), mlp_lds_bytes(d), (hipStream_t)stream, d, pos,
@@ -290,9 +307,21 @@ extern "C" int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, 
                                   const float* w, int B, int F, int H, int n_hidden, int G, float lo,
                                   float hi, const float* gains, const float* xhat, const float* rstd,
                                   const float* ggains, float* gw, void* work, void* stream) {
+  return gfdn_mlp_gains_banded_bwd(pos, pos_rows, freq_pi, w, 1, B, F, H, n_hidden, G, lo, hi, gains, xhat,
+                                   rstd, ggains, gw, work, stream);
+}
+
+extern "C" int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                         const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                                         int G, float lo, float hi, const float* gains, const float* xhat,
+                                         const float* rstd, const float* ggains, float* gw, void* work,
+                                         void* stream) {
   MlpDims d;
+  if (nbands <= 0 || Bper <= 0) return GFDN_E_BADARG;
+  const int B = nbands * Bper;
   int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
   if (rc) return rc;
+  d.Bper = Bper;
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
@@ -300,7 +329,7 @@ extern "C" int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, 
                      rstd, ggains, (float*)work);
   GFDN_LAUNCH_CHECK();
   const size_t P = mlp_param_count(d);
-  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, (const float*)work, B, P, gw);
+  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((P + 255) / 256), nbands), dim3(256), 0, s, (const float*)work, Bper, P, gw);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

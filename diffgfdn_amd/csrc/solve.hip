@@ -427,13 +427,15 @@ extern __shared__ float2 compose_lds[];
 
 // Y tile of 256 bins x N delay lines -> LDS rows of N+1 (global side strictly linear: the per-thread
 // 128-byte rows of the bin-major layout would otherwise be read 8 bytes at a time across 64 lines)
-__device__ __forceinline__ void load_bin_tile(const float2* __restrict__ Y, int k0, int K, int N,
+// ldy: row stride of Y in elements (N for one band; nbands * N when the bands' delay lines sit side by
+// side in one (K, nbands * N) solve output -- each bin then contributes one contiguous run of N values)
+__device__ __forceinline__ void load_bin_tile(const float2* __restrict__ Y, int k0, int K, int N, int ldy,
                                               float2* tile) {
-  const size_t base = (size_t)k0 * N;
+  const size_t base = (size_t)k0 * ldy;
   const int lim = (K - k0 < 256 ? K - k0 : 256) * N;
   for (int e = threadIdx.x; e < 256 * N; e += 256) {
     const int kk = e / N, n = e - kk * N;
-    tile[kk * (N + 1) + n] = e < lim ? Y[base + e] : make_float2(0.f, 0.f);
+    tile[kk * (N + 1) + n] = e < lim ? Y[base + (size_t)kk * ldy + n] : make_float2(0.f, 0.f);
   }
 }
 
@@ -444,10 +446,21 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
                                                      const long long* __restrict__ drows,
                                                      const float2* __restrict__ filt,
                                                      float2* __restrict__ H, int ldh,
-                                                     float2* __restrict__ S_out) {
+                                                     float2* __restrict__ S_out, int ldy, int ldf) {
   const int N = G * nper;
   const int k0 = blockIdx.x * 256;
-  load_bin_tile(Y, k0, K, N, compose_lds);
+  {   // band blockIdx.z: its delay lines, gains, items (B per band) and filter row
+    const int band = blockIdx.z;
+    Y += (size_t)band * N;
+    c += (size_t)band * N;
+    rgain += (size_t)band * B * G;
+    if (drows) drows += (size_t)band * B;
+    else if (direct) direct += (size_t)band * B * ldd;
+    if (filt) filt += (size_t)band * ldf;
+    H += (size_t)band * B * ldh;
+    if (S_out) S_out += (size_t)band * G * K;
+  }
+  load_bin_tile(Y, k0, K, N, ldy, compose_lds);
   __syncthreads();
   const int k = k0 + threadIdx.x;
   if (k >= K) return;
@@ -495,22 +508,30 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
 
 static size_t compose_tile_bytes(int N) { return (size_t)256 * (N + 1) * sizeof(float2); }
 
-extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const float* c,
-                                const float* rgain, int B, const float* direct, int ldd,
-                                const long long* direct_rows, const float* filt, float* H, int ldh,
-                                float* S_out, void* stream) {
-  if (!Y || !c || !rgain || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
-  if (G > GFDN_MAX_GROUPS) return GFDN_E_UNSUPPORTED;
-  if (ldh < K || (direct && ldd < K)) return GFDN_E_BADARG;
-  dim3 grid((K + 255) / 256, (B + COMPOSE_BCH - 1) / COMPOSE_BCH);
+extern "C" int gfdn_compose_banded_fwd(const float* Y, int K, int nbands, int G, int nper, const float* c,
+                                       const float* rgain, int B, const float* direct, int ldd,
+                                       const long long* direct_rows, const float* filt, int ldf,
+                                       float* H, int ldh, float* S_out, void* stream) {
+  if (!Y || !c || !rgain || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0 || nbands <= 0) return GFDN_E_BADARG;
+  if (G > GFDN_MAX_GROUPS || nbands > 65535) return GFDN_E_UNSUPPORTED;
+  if (ldh < K || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
+  dim3 grid((K + 255) / 256, (B + COMPOSE_BCH - 1) / COMPOSE_BCH, nbands);
   if (G * nper > 128) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_compose_fwd, compose_tile_bytes(G * nper));
   if (rc) return rc;
   hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), compose_tile_bytes(G * nper), (hipStream_t)stream, (const float2*)Y, K,
                      G, nper, c, rgain, B, (const float2*)direct, ldd, direct ? direct_rows : nullptr,
-                     (const float2*)filt, (float2*)H, ldh, (float2*)S_out);
+                     (const float2*)filt, (float2*)H, ldh, (float2*)S_out, nbands * G * nper, ldf);
   GFDN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gfdn_compose_fwd(const float* Y, int K, int G, int nper, const float* c,
+                                const float* rgain, int B, const float* direct, int ldd,
+                                const long long* direct_rows, const float* filt, float* H, int ldh,
+                                float* S_out, void* stream) {
+  return gfdn_compose_banded_fwd(Y, K, 1, G, nper, c, rgain, B, direct, ldd, direct_rows, filt, K, H, ldh,
+                                 S_out, stream);
 }
 
 // gS[g][k] = sum_b rgain[b][g] conj(filt_k) gH[b][k];  gY[k][n] = c_n gS[g(n)][k];
@@ -530,8 +551,19 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
                                                        const float2* __restrict__ gH, int ldh,
                                                        float2* __restrict__ gY,
                                                        float* __restrict__ rg_partial,
-                                                       float* __restrict__ gc_partial) {
+                                                       float* __restrict__ gc_partial, int ldy, int ldf) {
   const int N = G * nper, NS = N + 1;
+  {   // band blockIdx.y (see k_compose_fwd)
+    const int band = blockIdx.y;
+    Y += (size_t)band * N;
+    gY += (size_t)band * N;
+    c += (size_t)band * N;
+    rgain += (size_t)band * B * G;
+    if (filt) filt += (size_t)band * ldf;
+    gH += (size_t)band * B * ldh;
+    rg_partial += (size_t)band * B * G * gridDim.x;
+    gc_partial += (size_t)band * gridDim.x * N;
+  }
   float2* yt = compose_lds;                 // [CBT][N+1] : Y tile
   float* vt = (float*)(yt + CBT * NS);      // [CBT][N]   : Re(conj(gS) Y)
   float* pp = vt + CBT * N;                 // [CB_RB * G][65] : per-bin receiver-gain products, then reused as
@@ -541,12 +573,12 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
   const int k = k0 + kx;
   const bool live = k < K;
   const int kk = live ? k : K - 1;
-  const size_t base = (size_t)k0 * N;
+  const size_t base = (size_t)k0 * ldy;
   const int nb = K - k0 < CBT ? K - k0 : CBT;
   const int lim = nb * N;
   for (int e = threadIdx.x; e < CBT * N; e += 256) {
     const int kq = e / N, n = e - kq * N;
-    yt[kq * NS + n] = e < lim ? Y[base + e] : make_float2(0.f, 0.f);
+    yt[kq * NS + n] = e < lim ? Y[base + (size_t)kq * ldy + n] : make_float2(0.f, 0.f);
   }
   __syncthreads();
   {
@@ -622,7 +654,7 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
     if (e < lim) {
       const float2 y = yt[kq * NS + n];
       const float2 gs = s_gS[0][n / nper][kq];
-      gY[base + e] = cscale(gs, c[n]);
+      gY[base + (size_t)kq * ldy + n] = cscale(gs, c[n]);
       v = gs.x * y.x + gs.y * y.y;
     }
     vt[e] = v;
@@ -639,9 +671,16 @@ __global__ __launch_bounds__(256) void k_compose_bwd_a(const float2* __restrict_
 // one wavefront per output, lane-strided partial sums then a wave reduction -- a fixed order.
 __global__ __launch_bounds__(64) void k_compose_finish(const float* __restrict__ gc_partial,
                                                        const float* __restrict__ rg_partial,
-                                                       int nparts, int N, float* __restrict__ gc,
+                                                       int nparts, int N, int BG, float* __restrict__ gc,
                                                        float* __restrict__ grgain) {
   float s = 0.f;
+  {   // band blockIdx.y
+    const int band = blockIdx.y;
+    gc_partial += (size_t)band * nparts * N;
+    rg_partial += (size_t)band * BG * nparts;
+    gc += (size_t)band * N;
+    grgain += (size_t)band * BG;
+  }
   if ((int)blockIdx.x < N) {
     for (int p = threadIdx.x; p < nparts; p += 64) s += gc_partial[(size_t)p * N + blockIdx.x];
     s = wave_sum(s);
@@ -674,29 +713,42 @@ extern "C" size_t gfdn_compose_bwd_work_bytes(int K, int G, int nper, int B) {
   return compose_partial_bytes(K, G, nper) + (size_t)B * G * tiles * sizeof(float);
 }
 
+extern "C" size_t gfdn_compose_banded_bwd_work_bytes(int K, int nbands, int G, int nper, int B) {
+  const size_t tiles = (size_t)(K + CBT - 1) / CBT;
+  return (size_t)nbands * compose_partial_bytes(K, G, nper) + (size_t)nbands * B * G * tiles * sizeof(float);
+}
+
 extern "C" int gfdn_compose_bwd(const float* Y, int K, int G, int nper, const float* c,
                                 const float* rgain, int B, const float* filt, const float* gH,
                                 int ldh, float* gY, float* gc, float* grgain, void* work,
                                 void* stream) {
+  return gfdn_compose_banded_bwd(Y, K, 1, G, nper, c, rgain, B, filt, K, gH, ldh, gY, gc, grgain, work, stream);
+}
+
+extern "C" int gfdn_compose_banded_bwd(const float* Y, int K, int nbands, int G, int nper, const float* c,
+                                       const float* rgain, int B, const float* filt, int ldf,
+                                       const float* gH, int ldh, float* gY, float* gc, float* grgain,
+                                       void* work, void* stream) {
   if (!Y || !c || !rgain || !gH || !gY || !gc || !grgain || !work) return GFDN_E_BADARG;
-  if (K <= 0 || G <= 0 || nper <= 0 || B <= 0 || ldh < K) return GFDN_E_BADARG;
-  if (G > GFDN_MAX_GROUPS || G * nper > 64) return GFDN_E_UNSUPPORTED;
+  if (K <= 0 || G <= 0 || nper <= 0 || B <= 0 || ldh < K || nbands <= 0) return GFDN_E_BADARG;
+  if (filt && nbands > 1 && ldf < K) return GFDN_E_BADARG;
+  if (G > GFDN_MAX_GROUPS || G * nper > 64 || nbands > 65535) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int N = G * nper;
   const int nparts = (K + CBT - 1) / CBT;
   float* gc_partial = (float*)work;
-  float* rg_partial = (float*)((char*)work + compose_partial_bytes(K, G, nper));
+  float* rg_partial = (float*)((char*)work + (size_t)nbands * compose_partial_bytes(K, G, nper));
   size_t uni = (size_t)CB_RB * G * 65 * sizeof(float);
   if (uni < (size_t)4 * GFDN_MAX_GROUPS * CBT * sizeof(float2)) uni = (size_t)4 * GFDN_MAX_GROUPS * CBT * sizeof(float2);
   const size_t lds = (size_t)CBT * (N + 1) * sizeof(float2) + (size_t)CBT * N * sizeof(float) + uni;
   int rc = ensure_dyn_lds(k_compose_bwd_a, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_compose_bwd_a, dim3(nparts), dim3(256), lds, s, (const float2*)Y,
+  hipLaunchKernelGGL(k_compose_bwd_a, dim3(nparts, nbands), dim3(256), lds, s, (const float2*)Y,
                      K, G, nper, c, rgain, B, (const float2*)filt, (const float2*)gH, ldh, (float2*)gY,
-                     rg_partial, gc_partial);
+                     rg_partial, gc_partial, nbands * N, ldf);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compose_finish, dim3(N + B * G), dim3(64), 0, s, gc_partial, rg_partial, nparts,
-                     N, gc, grgain);
+  hipLaunchKernelGGL(k_compose_finish, dim3(N + B * G, nbands), dim3(64), 0, s, gc_partial, rg_partial, nparts,
+                     N, B * G, gc, grgain);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -917,6 +969,13 @@ __global__ __launch_bounds__(256) void k_colorless_terms(const float* __restrict
                                                          float w_spec, float w_sparse, float inv_world,
                                                          float* __restrict__ out, float* __restrict__ gQ) {
   __shared__ float s_red[16];
+  {   // one block per band: its G groups, its three outputs
+    const int band = blockIdx.x;
+    loss_g += (size_t)band * G;
+    Q += (size_t)band * G * n * n;
+    if (gQ) gQ += (size_t)band * G * n * n;
+    out += (size_t)band * 3;
+  }
   const float* Ql = Q + (size_t)(G - 1) * n * n;
   const float denom = (float)n * (sqrtf((float)n) - 1.0f);
   float acc = 0.f;
@@ -943,14 +1002,20 @@ __global__ __launch_bounds__(256) void k_colorless_terms(const float* __restrict
   }
 }
 
-extern "C" int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, int n, float w_spec,
-                                    float w_sparse, float inv_world, float* out3, float* gQ,
-                                    void* stream) {
-  if (!loss_g || !Q || !out3 || G <= 0 || n <= 1) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_colorless_terms, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_g, G, Q, n,
+extern "C" int gfdn_colorless_terms_banded(const float* loss_g, int nbands, int G, const float* Q, int n,
+                                           float w_spec, float w_sparse, float inv_world, float* out3,
+                                           float* gQ, void* stream) {
+  if (!loss_g || !Q || !out3 || G <= 0 || n <= 1 || nbands <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_colorless_terms, dim3(nbands), dim3(256), 0, (hipStream_t)stream, loss_g, G, Q, n,
                      w_spec, w_sparse, inv_world, out3, gQ);
   GFDN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, int n, float w_spec,
+                                    float w_sparse, float inv_world, float* out3, float* gQ,
+                                    void* stream) {
+  return gfdn_colorless_terms_banded(loss_g, 1, G, Q, n, w_spec, w_sparse, inv_world, out3, gQ, stream);
 }
 
 // out = { wa * sum(a) + wb * sum(b), wa * sum(a), wb * sum(b) }   (either input may be NULL);
@@ -961,6 +1026,14 @@ __global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ 
                                                       const float* __restrict__ b, float wb, int n,
                                                       float* __restrict__ out) {
   float sa = 0.f, sb = 0.f;
+  {   // one block per band: its n items, its three outputs
+    const size_t i0 = (size_t)blockIdx.x * n;
+    if (a) a += i0 * a_cols;
+    if (a_rows) a_rows += i0;
+    else if (a_div) a_div += i0;
+    if (b) b += i0;
+    out += (size_t)blockIdx.x * 3;
+  }
   for (int i = threadIdx.x; i < n; i += 64) {
     if (a) {
       float v = 0.f;
@@ -975,13 +1048,19 @@ __global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ 
   if (threadIdx.x == 0) { out[0] = sa + sb; out[1] = sa; out[2] = sb; }
 }
 
-extern "C" int gfdn_weighted_sums(const float* a, int a_cols, const float* a_div, const long long* a_rows,
-                                  float wa, const float* b, float wb, int n, float* out3, void* stream) {
-  if ((!a && !b) || !out3 || n <= 0 || (a && a_cols <= 0)) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_weighted_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, a, a_cols, a_div, a_rows,
+extern "C" int gfdn_weighted_sums_banded(const float* a, int a_cols, const float* a_div, const long long* a_rows,
+                                         float wa, const float* b, float wb, int n, int nbands, float* out3,
+                                         void* stream) {
+  if ((!a && !b) || !out3 || n <= 0 || nbands <= 0 || (a && a_cols <= 0)) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_weighted_sums, dim3(nbands), dim3(64), 0, (hipStream_t)stream, a, a_cols, a_div, a_rows,
                      wa, b, wb, n, out3);
   GFDN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gfdn_weighted_sums(const float* a, int a_cols, const float* a_div, const long long* a_rows,
+                                  float wa, const float* b, float wb, int n, float* out3, void* stream) {
+  return gfdn_weighted_sums_banded(a, a_cols, a_div, a_rows, wa, b, wb, n, 1, out3, stream);
 }
 
 // trainer.py:323-332: b_n, c_n /= energy_g^(1/4) for n in group g, in place

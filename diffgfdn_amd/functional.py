@@ -75,8 +75,10 @@ class MlpGains(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, rows, freq_pi, H, n_hidden, G, lo, hi, *params):
-        w = MlpGains._packed(params)
-        gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, rows)
+        # band-stacked call (BandBank): ONE parameter tensor (nbands, P), each row a packed set
+        ctx.nbands = params[0].shape[0] if len(params) == 1 and params[0].dim() == 2 else 1
+        w = params[0].detach() if ctx.nbands > 1 or len(params) == 1 else MlpGains._packed(params)
+        gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, rows, ctx.nbands)
         ctx.rows = rows
         ctx.save_for_backward(pos, freq_pi, w, gains, xhat, rstd)
         ctx.cfg = (H, n_hidden, G, lo, hi)
@@ -88,7 +90,9 @@ class MlpGains(torch.autograd.Function):
         pos, freq_pi, w, gains, xhat, rstd = ctx.saved_tensors
         H, n_hidden, G, lo, hi = ctx.cfg
         gw = ops.mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd,
-                               ggains.contiguous(), ctx.rows)
+                               ggains.contiguous(), ctx.rows, ctx.nbands)
+        if len(ctx.shapes) == 1:
+            return (None,) * 8 + (gw.view(ctx.shapes[0]),)
         grads, off = [], 0
         for shp in ctx.shapes:
             n = 1
@@ -125,17 +129,17 @@ class OutputStage(torch.autograd.Function):
     """H[b][k] = (sum_g rgain[b][g] sum_{n in g} c_n Y[k][n] + direct[b][k]) * filt[k]."""
 
     @staticmethod
-    def forward(ctx, Y, c, rgain, nper: int, direct, filt, direct_rows=None):
-        H = ops.compose_fwd(Y, c, rgain, nper, direct, filt, direct_rows=direct_rows)
+    def forward(ctx, Y, c, rgain, nper: int, direct, filt, direct_rows=None, nbands: int = 1):
+        H = ops.compose_fwd(Y, c, rgain, nper, direct, filt, direct_rows=direct_rows, nbands=nbands)
         ctx.save_for_backward(Y, c, rgain, filt)
-        ctx.nper = nper
+        ctx.nper, ctx.nbands = nper, nbands
         return H
 
     @staticmethod
     def backward(ctx, gH):
         Y, c, rgain, filt = ctx.saved_tensors
-        gY, gc, grg = ops.compose_bwd(Y, c, rgain, ctx.nper, gH.contiguous(), filt)
-        return gY, gc.to(c.dtype).reshape(c.shape), grg.to(rgain.dtype), None, None, None, None
+        gY, gc, grg = ops.compose_bwd(Y, c, rgain, ctx.nper, gH.contiguous(), filt, ctx.nbands)
+        return gY, gc.to(c.dtype).reshape(c.shape), grg.to(rgain.dtype), None, None, None, None, None
 
 
 class SHOutputStage(torch.autograd.Function):
@@ -191,16 +195,22 @@ class ColorlessTerms(torch.autograd.Function):
     upstream gradient of output[0] is 1 (loss.backward() on a plain sum), which skips two rescales."""
 
     @staticmethod
-    def forward(ctx, S, Q, asym, w_spec, w_sparse, inv_world, unit_grad):
+    def forward(ctx, S, Q, asym, w_spec, w_sparse, inv_world, unit_grad, nbands: int = 1):
         need = S.requires_grad or Q.requires_grad
         _, loss_g, gS = ops.spectral_stats(S, asym, w_spec * inv_world, want_grad=need)
-        out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need)
+        out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need, nbands=nbands)
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the two report outputs
         ctx.save_for_backward(gS, gQ)
         ctx.unit_grad = unit_grad
-        # three 0-dim outputs of the node itself (indexing the result outside would put a
-        # select-backward = zero fill + copy in front of the gradient)
-        total, spec, sparse = out[0], out[1], out[2]
+        if nbands > 1:
+            if not unit_grad:
+                raise ValueError("band-stacked colorless terms are back-propagated with unit gradients")
+            # (nbands,) vectors: column views of the (nbands, 3) record, created inside the node
+            total, spec, sparse = out[:, 0], out[:, 1], out[:, 2]
+        else:
+            # three 0-dim outputs of the node itself (indexing the result outside would put a
+            # select-backward = zero fill + copy in front of the gradient)
+            total, spec, sparse = out[0], out[1], out[2]
         ctx.mark_non_differentiable(spec, sparse)
         return total, spec, sparse
 
@@ -208,10 +218,10 @@ class ColorlessTerms(torch.autograd.Function):
     def backward(ctx, g, _g1, _g2):
         gS, gQ = ctx.saved_tensors
         if g is None:
-            return (None,) * 7
+            return (None,) * 8
         if ctx.unit_grad:
-            return gS, gQ, None, None, None, None, None
-        return gS * g.to(gS.dtype), gQ * g, None, None, None, None, None
+            return gS, gQ, None, None, None, None, None, None
+        return gS * g.to(gS.dtype), gQ * g, None, None, None, None, None, None
 
 
 class IrfftOdd(torch.autograd.Function):

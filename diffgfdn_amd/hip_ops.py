@@ -128,14 +128,19 @@ def _rows(rows, n_items: int, store_rows: int):
     return rows
 
 
-def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False, direct_rows=None):
+def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False, direct_rows=None,
+                nbands: int = 1):
     """Y (K,N) c64, c (N,), rgain (B,G) -> H (B,K) c64 [, S (G,K) c64].
-    ``direct_rows``: item b adds row direct_rows[b] of ``direct`` (a store of all receivers)."""
+    ``direct_rows``: item b adds row direct_rows[b] of ``direct`` (a store of all receivers).
+    ``nbands`` > 1: band-stacked (include/diffgfdn_hip.h): Y (K, nbands*N), c (nbands*N,), rgain
+    (nbands*Bper, G) band-major items, filt (nbands, K) -> H (nbands*Bper, K) [, S (nbands*G, K)]."""
     _need_gpu(Y, c, rgain)
     Y, c, rgain = _c(Y), _f(c), _f(rgain)
-    K, N = Y.shape
-    B, G = rgain.shape
-    assert G * nper == N
+    K, Ntot = Y.shape
+    Btot, G = rgain.shape
+    if Ntot != nbands * G * nper or Btot % nbands or c.numel() != Ntot:
+        raise RuntimeError("compose_fwd: shapes do not match nbands x (G x nper) delay lines")
+    B = Btot // nbands
     ldd = 0
     if direct is not None:
         direct = direct.detach()
@@ -145,32 +150,49 @@ def compose_fwd(Y, c, rgain, nper, direct=None, filt=None, want_S=False, direct_
             direct = _c(direct)
         ldd = direct.stride(0)
     filt = None if filt is None else _c(filt)
-    direct_rows = None if direct is None else _rows(direct_rows, B, direct.shape[0])
-    if direct is not None and direct_rows is None and direct.shape[0] != B:
+    if filt is not None and filt.numel() != nbands * K:
+        raise RuntimeError("compose_fwd: filt must hold K bins per band")
+    direct_rows = None if direct is None else _rows(direct_rows, Btot, direct.shape[0])
+    if direct is not None and direct_rows is None and direct.shape[0] != Btot:
         raise RuntimeError("compose_fwd: direct must have one row per item (or pass direct_rows)")
-    H = torch.empty((B, K), dtype=_c64, device=Y.device)
-    S = torch.empty((G, K), dtype=_c64, device=Y.device) if want_S else None
-    _lib.check(_lib.load().gfdn_compose_fwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(direct),
-                                            ldd, _p(direct_rows), _p(filt), _p(H), K,
-                                            _p(S), _stream()), "gfdn_compose_fwd")
+    H = torch.empty((Btot, K), dtype=_c64, device=Y.device)
+    S = torch.empty((nbands * G, K), dtype=_c64, device=Y.device) if want_S else None
+    if nbands == 1:
+        _lib.check(_lib.load().gfdn_compose_fwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(direct),
+                                                ldd, _p(direct_rows), _p(filt), _p(H), K,
+                                                _p(S), _stream()), "gfdn_compose_fwd")
+    else:
+        _lib.check(_lib.load().gfdn_compose_banded_fwd(_p(Y), K, nbands, G, nper, _p(c), _p(rgain), B,
+                                                       _p(direct), ldd, _p(direct_rows), _p(filt), K,
+                                                       _p(H), K, _p(S), _stream()),
+                   "gfdn_compose_banded_fwd")
     return (H, S) if want_S else H
 
 
-def compose_bwd(Y, c, rgain, nper, gH, filt=None):
-    """-> gY (K,N) c64, gc (N,), grgain (B,G)."""
+def compose_bwd(Y, c, rgain, nper, gH, filt=None, nbands: int = 1):
+    """-> gY (K,N) c64, gc (N,), grgain (B,G)  (band-stacked shapes as in compose_fwd)."""
     _need_gpu(Y, gH)
     Y, c, rgain, gH = _c(Y), _f(c), _f(rgain), _c(gH)
     K, N = Y.shape
-    B, G = rgain.shape
+    Btot, G = rgain.shape
+    if N != nbands * G * nper or Btot % nbands or tuple(gH.shape) != (Btot, K):
+        raise RuntimeError("compose_bwd: shapes do not match nbands x (G x nper) delay lines")
+    B = Btot // nbands
     filt = None if filt is None else _c(filt)
     lib = _lib.load()
     gY = torch.empty_like(Y)
     gc = torch.empty(N, dtype=_f32, device=Y.device)
-    grg = torch.empty((B, G), dtype=_f32, device=Y.device)
-    work = _work(lib.gfdn_compose_bwd_work_bytes(K, G, nper, B), Y.device)
-    _lib.check(lib.gfdn_compose_bwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(filt), _p(gH), K,
-                                    _p(gY), _p(gc), _p(grg), _p(work), _stream()),
-               "gfdn_compose_bwd")
+    grg = torch.empty((Btot, G), dtype=_f32, device=Y.device)
+    if nbands == 1:
+        work = _work(lib.gfdn_compose_bwd_work_bytes(K, G, nper, B), Y.device)
+        _lib.check(lib.gfdn_compose_bwd(_p(Y), K, G, nper, _p(c), _p(rgain), B, _p(filt), _p(gH), K,
+                                        _p(gY), _p(gc), _p(grg), _p(work), _stream()),
+                   "gfdn_compose_bwd")
+    else:
+        work = _work(lib.gfdn_compose_banded_bwd_work_bytes(K, nbands, G, nper, B), Y.device)
+        _lib.check(lib.gfdn_compose_banded_bwd(_p(Y), K, nbands, G, nper, _p(c), _p(rgain), B, _p(filt), K,
+                                               _p(gH), K, _p(gY), _p(gc), _p(grg), _p(work), _stream()),
+                   "gfdn_compose_banded_bwd")
     return gY, gc, grg
 
 
@@ -219,22 +241,33 @@ def spectral_stats(S, asym: bool, scale: float = 1.0, want_grad: bool = True):
     return energy, loss, gS
 
 
-def colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=True):
-    """-> out3 = [(spectral + sparsity) * inv_world, spectral, sparsity], gQ (G,n,n) or None."""
+def colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=True, nbands: int = 1):
+    """-> out3 = [(spectral + sparsity) * inv_world, spectral, sparsity], gQ (G,n,n) or None.
+    ``nbands`` > 1: loss_g (nbands*G,), Q (nbands*G,n,n) -> out (nbands, 3)."""
     _need_gpu(loss_g, Q)
     loss_g, Q = _f(loss_g), _f(Q)
-    G, n, _ = Q.shape
-    out = torch.empty(3, dtype=_f32, device=Q.device)
+    Gtot, n, _ = Q.shape
+    if Gtot % nbands or loss_g.numel() != Gtot:
+        raise RuntimeError("colorless_terms: one spectral loss per group, groups divisible by nbands")
+    G = Gtot // nbands
     gQ = torch.empty_like(Q) if want_grad else None
-    _lib.check(_lib.load().gfdn_colorless_terms(_p(loss_g), G, _p(Q), n, float(w_spec), float(w_sparse),
-                                                float(inv_world), _p(out), _p(gQ), _stream()),
-               "gfdn_colorless_terms")
+    if nbands == 1:
+        out = torch.empty(3, dtype=_f32, device=Q.device)
+        _lib.check(_lib.load().gfdn_colorless_terms(_p(loss_g), G, _p(Q), n, float(w_spec), float(w_sparse),
+                                                    float(inv_world), _p(out), _p(gQ), _stream()),
+                   "gfdn_colorless_terms")
+    else:
+        out = torch.empty((nbands, 3), dtype=_f32, device=Q.device)
+        _lib.check(_lib.load().gfdn_colorless_terms_banded(_p(loss_g), nbands, G, _p(Q), n, float(w_spec),
+                                                           float(w_sparse), float(inv_world), _p(out),
+                                                           _p(gQ), _stream()), "gfdn_colorless_terms_banded")
     return out, gQ
 
 
-def weighted_sums(a, wa, b, wb, a_div=None, a_rows=None):
+def weighted_sums(a, wa, b, wb, a_div=None, a_rows=None, nbands: int = 1):
     """-> [wa sum(a) + wb sum(b), wa sum(a), wb sum(b)] (float32, 3).  ``a`` may be (n, cols) partial
-    sums per item (edr_loss(defer=True)), divided per item by a_div[a_rows[i]]."""
+    sums per item (edr_loss(defer=True)), divided per item by a_div[a_rows[i]].
+    ``nbands`` > 1: the n items are band-major, -> (nbands, 3) sums per band."""
     ref = a if a is not None else b
     _need_gpu(ref)
     n = ref.shape[0] if ref.dim() == 2 else ref.numel()
@@ -246,6 +279,14 @@ def weighted_sums(a, wa, b, wb, a_div=None, a_rows=None):
     a_rows = None if a_div is None else _rows(a_rows, n, a_div.numel())
     if a_div is not None and a_rows is None and a_div.numel() != n:
         raise RuntimeError("weighted_sums: a_div must have one entry per item (or pass a_rows)")
+    if nbands > 1:
+        if n % nbands:
+            raise RuntimeError("weighted_sums: items must divide evenly into bands")
+        out = torch.empty((nbands, 3), dtype=_f32, device=ref.device)
+        _lib.check(_lib.load().gfdn_weighted_sums_banded(_p(a), cols, _p(a_div), _p(a_rows), float(wa), _p(b),
+                                                         float(wb), n // nbands, nbands, _p(out), _stream()),
+                   "gfdn_weighted_sums_banded")
+        return out
     out = torch.empty(3, dtype=_f32, device=ref.device)
     _lib.check(_lib.load().gfdn_weighted_sums(_p(a), cols, _p(a_div), _p(a_rows), float(wa), _p(b),
                                               float(wb), n, _p(out), _stream()), "gfdn_weighted_sums")
@@ -531,28 +572,36 @@ def draw_mask(seed: int, state, length: int, scale: float, out=None):
     return out
 
 
-def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float, rows=None):
+def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float, rows=None,
+                  nbands: int = 1):
     """pos (B,3) f64, freq_pi (F,) f32, w packed params -> gains (B,G), xhat (B,nl,H), rstd (B,nl).
-    ``rows``: item b encodes pos[rows[b]] (pos = the positions of all receivers)."""
+    ``rows``: item b encodes pos[rows[b]] (pos = the positions of all receivers).
+    ``nbands`` > 1: w (nbands, P), items band-major (item i uses parameter set i // (B / nbands))."""
     _need_gpu(pos, w)
     pos = pos.detach().to(torch.float64).contiguous()
     w = _f(w)
     B, F = (pos.shape[0] if rows is None else rows.numel()), freq_pi.numel()
     rows = _rows(rows, B, pos.shape[0])
     lib = _lib.load()
-    if w.numel() != lib.gfdn_mlp_param_count(F, H, n_hidden, G):
+    if w.numel() != nbands * lib.gfdn_mlp_param_count(F, H, n_hidden, G) or B % nbands:
         raise RuntimeError("mlp_gains: packed parameter count does not match the layer sizes")
     nl = 1 + n_hidden
     gains = torch.empty((B, G), dtype=_f32, device=pos.device)
     xhat = torch.empty((B, nl, H), dtype=_f32, device=pos.device)
     rstd = torch.empty((B, nl), dtype=_f32, device=pos.device)
+    if nbands > 1:
+        _lib.check(lib.gfdn_mlp_gains_banded_fwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,
+                                                 n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat),
+                                                 _p(rstd), _stream()), "gfdn_mlp_gains_banded_fwd")
+        return gains, xhat, rstd
     _lib.check(lib.gfdn_mlp_gains_fwd(_p(pos), _p(rows), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
                                       float(hi), _p(gains), _p(xhat), _p(rstd), _stream()),
                "gfdn_mlp_gains_fwd")
     return gains, xhat, rstd
 
 
-def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains, rows=None):
+def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains, rows=None,
+                  nbands: int = 1):
     _need_gpu(pos, w, ggains)
     pos = pos.detach().to(torch.float64).contiguous()
     w, ggains = _f(w), _f(ggains)
@@ -561,6 +610,12 @@ def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, gg
     lib = _lib.load()
     gw = torch.empty_like(w)
     work = _work(lib.gfdn_mlp_bwd_work_bytes(B, F, H, n_hidden, G), pos.device)
+    if nbands > 1:
+        _lib.check(lib.gfdn_mlp_gains_banded_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,
+                                                 n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat),
+                                                 _p(rstd), _p(ggains), _p(gw), _p(work), _stream()),
+                   "gfdn_mlp_gains_banded_bwd")
+        return gw
     _lib.check(lib.gfdn_mlp_gains_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), B, F, H, n_hidden, G, float(lo),
                                       float(hi), _p(gains), _p(xhat), _p(rstd), _p(ggains), _p(gw),
                                       _p(work), _stream()), "gfdn_mlp_gains_bwd")

@@ -130,13 +130,19 @@ class _DecayTotal(torch.autograd.Function):
     inside the node: no clone, no select-backward (zero fill + copy) on the way to the loss."""
 
     @staticmethod
-    def forward(ctx, H, gH, unit_grad, li_edr, w_edr, li_edc, w_edc, edr_div=None, edr_rows=None):
-        sums = ops.weighted_sums(li_edr, w_edr, li_edc, w_edc, edr_div, edr_rows)
+    def forward(ctx, H, gH, unit_grad, li_edr, w_edr, li_edc, w_edc, edr_div=None, edr_rows=None,
+                nbands: int = 1):
+        sums = ops.weighted_sums(li_edr, w_edr, li_edc, w_edc, edr_div, edr_rows, nbands)
         ctx.set_materialize_grads(False)      # no zero-filled gradients for the two report outputs
         ctx.save_for_backward(gH)
         ctx.h_shape = H.shape
         ctx.unit_grad = unit_grad
-        total, edr, edc = sums[0], sums[1], sums[2]
+        if nbands > 1:
+            if not unit_grad:
+                raise ValueError("band-stacked decay losses are back-propagated with unit gradients")
+            total, edr, edc = sums[:, 0], sums[:, 1], sums[:, 2]      # (nbands,) per-band sums
+        else:
+            total, edr, edc = sums[0], sums[1], sums[2]
         ctx.mark_non_differentiable(edr, edc)
         return total, edr, edc
 
@@ -144,10 +150,10 @@ class _DecayTotal(torch.autograd.Function):
     def backward(ctx, g, _g1, _g2):
         (gH,) = ctx.saved_tensors
         if g is None:
-            return (None,) * 9
+            return (None,) * 10
         if ctx.unit_grad:
-            return (gH.reshape(ctx.h_shape),) + (None,) * 8
-        return ((gH * g).reshape(ctx.h_shape),) + (None,) * 8
+            return (gH.reshape(ctx.h_shape),) + (None,) * 9
+        return ((gH * g).reshape(ctx.h_shape),) + (None,) * 9
 
 
 def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win: int = 4096,
@@ -163,7 +169,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  edc_target: Optional[torch.Tensor] = None,
                  side_stream: Optional["torch.cuda.Stream"] = None,
                  unit_grad: bool = False, n_time: Optional[int] = None,
-                 target_rows: Optional[torch.Tensor] = None
+                 target_rows: Optional[torch.Tensor] = None, nbands: int = 1
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
@@ -178,7 +184,9 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     The returned ``edr`` / ``edc`` are the WEIGHTED parts.  ``n_time``: length of the time response
     (= number of bins K of the full grid); H may then hold only the (K+1)/2 bins the transform
     irfft(X, n = K) actually reads.  ``target_rows``: int64 index; ``edr_target`` / ``edc_target``
-    are then stores over ALL receivers and item b compares against row target_rows[b]."""
+    are then stores over ALL receivers and item b compares against row target_rows[b].
+    ``nbands`` > 1: the items are band-major batches of ``nbands`` independent models (BandBank); the
+    three results are then (nbands,) vectors of per-band sums (``global_batch`` = items per band)."""
     if target_rows is not None and (edr_target is None and use_edr or edc_target is None and use_edc):
         raise ValueError("target_rows needs precomputed target stores")
     targets = targets or _default_targets
@@ -202,7 +210,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         L = edc_len if edc_len is not None else K - edc_start
         T_db = edc_target if edc_target is not None else targets.edc(target, edc_start, L)
         count = float(L) if edc_count is None else float(edc_count)
-        nb = B if global_batch is None else global_batch
+        nb = B // nbands if global_batch is None else global_batch
         # pre-normalised weights already carry 1 / (items * kept indices): no host scalar varies
         # from step to step, which keeps the launch arguments static under graph replay
         inv = 1.0 if edc_maskw_prenormalised else 1.0 / (nb * count)
@@ -241,8 +249,11 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
             gx, gx2 = (g_edr, None) if gx is None else (gx, g_edr)
     if want_grad:
         gH = ops.irfft_odd_bwd(gx, K, ldx, gx2)
-        return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows)
-    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows)   # [total, w_edr edr, w_edc edc]
+        return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows,
+                                 nbands)
+    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows, nbands)   # [total, w_edr edr, w_edc edc]
+    if nbands > 1:
+        return sums[:, 0], sums[:, 1], sums[:, 2]
     return sums[0], sums[1], sums[2]
 
 

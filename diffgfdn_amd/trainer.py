@@ -537,7 +537,12 @@ class GraphedTrainStep:
         dev = dataset.device
         K = dataset.rir_mag_response.shape[-1]
         self.start, self.length = trainer._decay_window(K)
-        self.gb = batch_size * trainer.world_size
+        # a band bank (bandbank.BandBankTrainer) steps ``num_bands`` independent models at once: the
+        # batch holds batch_size / num_bands receivers per model, and loss heads are (bands,) vectors
+        self.num_bands = getattr(trainer, 'num_bands', 1)
+        if batch_size % self.num_bands:
+            raise ValueError("batch size must be a multiple of the number of bands")
+        self.gb = batch_size // self.num_bands * trainer.world_size
         # replayed launches read the targets through the static index buffer: they must come from
         # the dataset-level store (a by-pointer cache would go stale under replay)
         if (dataset.edr_store is None or dataset.edc_store is None
@@ -554,7 +559,8 @@ class GraphedTrainStep:
                       for _ in range(4)]
         self._ring_pos = 0
         self.mask_state = torch.zeros(1, dtype=torch.long, device=dev)     # draws made so far
-        self._one = torch.ones((), dtype=torch.float32, device=dev)        # root gradient of the heads
+        self._one = torch.ones(() if self.num_bands == 1 else (self.num_bands,), dtype=torch.float32,
+                               device=dev)                                  # root gradient of the heads
         if mask_seed is None:
             seed_t = torch.randint(0, 2 ** 62, (1,), dtype=torch.long)      # torch.manual_seed governs it
             if trainer.world_size > 1:                                      # one seed for all ranks, once
@@ -634,6 +640,10 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
                 tr.optimizer.step()
         self.losses = {k: v for k, v in self.losses.items()}
+        # the recorded launches hold raw pointers into the frequency grids (turns / log radius): keep
+        # the grid objects alive as long as the graphs (the by-pointer cache may drop them)
+        from .functional import FrequencyGrid
+        self._grids = list(FrequencyGrid._cache.values())
         torch.set_rng_state(rng_state)
         return self
 

@@ -98,6 +98,24 @@ int gfdn_compose_bwd(const float* Y_c64, int K, int G, int nper, const float* c,
                      const float* rgain, int B, const float* filt_c64, const float* gH_c64,
                      int ldh, float* gY_c64, float* gc, float* grgain, void* work, void* stream);
 
+/* ---- band-stacked variants  (run_subband_training_treble.py:175-204: one independent model per
+ * octave band, trained one after another by the reference).  Here `nbands` models of identical
+ * shape are stepped by ONE launch each: their delay lines sit side by side in one solve
+ * (gfdn_solve_* with nblk = nbands * G blocks, Y (K, nbands * N)), items are band-major
+ * (item i = band * B + b, B items per band), per-band arrays are stacked along the first axis:
+ * c (nbands, N), rgain (nbands * B, G), filt (nbands, ldf) complex64, S_out (nbands * G, K),
+ * gc (nbands, N), grgain (nbands * B, G).  nbands = 1 is the plain entry point.
+ * direct / direct_rows: item i reads row direct_rows[i] of ONE store (all bands' receivers). */
+int gfdn_compose_banded_fwd(const float* Y_c64, int K, int nbands, int G, int nper, const float* c,
+                            const float* rgain, int B, const float* direct_c64, int ldd,
+                            const long long* direct_rows, const float* filt_c64, int ldf,
+                            float* H_c64, int ldh, float* S_out_c64, void* stream);
+size_t gfdn_compose_banded_bwd_work_bytes(int K, int nbands, int G, int nper, int B);
+int gfdn_compose_banded_bwd(const float* Y_c64, int K, int nbands, int G, int nper, const float* c,
+                            const float* rgain, int B, const float* filt_c64, int ldf,
+                            const float* gH_c64, int ldh, float* gY_c64, float* gc, float* grgain,
+                            void* work, void* stream);
+
 /* Directional output stage (model.py:1056-1088): H_sh[b][l][k] = sum_g w[b][g][l] c_{g,l} Y[k][g*nper+l]
  * and its backward.                                                                       */
 int gfdn_compose_sh_fwd(const float* Y_c64, int K, int G, int nper, const float* c,
@@ -128,12 +146,22 @@ int gfdn_spectral_stats(const float* S_c64, int G, int K, int asym, float scale,
  * last group counts, trainer.py:305-308).  gQ (G,n,n), optional: d out3[0] / dQ.              */
 int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, int n, float w_spec,
                          float w_sparse, float inv_world, float* out3, float* gQ, void* stream);
+/* band-stacked: loss_g (nbands * G), Q (nbands * G, n, n) -> out3 (nbands, 3), gQ (nbands * G, n, n);
+ * the sparsity term of band q is taken on ITS last group.                                      */
+int gfdn_colorless_terms_banded(const float* loss_g, int nbands, int G, const float* Q, int n,
+                                float w_spec, float w_sparse, float inv_world, float* out3, float* gQ,
+                                void* stream);
 /* out3 = { wa sum(a) + wb sum(b), wa sum(a), wb sum(b) } over n items (a or b may be NULL).
  * Item i of a is the sum of its a_cols partials (a: (n, a_cols), a_cols = 1 for plain items),
  * divided by a_div[a_rows ? a_rows[i] : i] when a_div != NULL -- the deferred form of
  * gfdn_edr_loss (loss_item = NULL) hands its per-tile partials and normalisers straight here. */
 int gfdn_weighted_sums(const float* a, int a_cols, const float* a_div, const long long* a_rows,
                        float wa, const float* b, float wb, int n, float* out3, void* stream);
+
+/* band-stacked: n items per band, nbands * n items in all -> out3 (nbands, 3). */
+int gfdn_weighted_sums_banded(const float* a, int a_cols, const float* a_div, const long long* a_rows,
+                              float wa, const float* b, float wb, int n, int nbands, float* out3,
+                              void* stream);
 
 /* Energy normalisation of the input / output gains (trainer.py:317-332): for n in group g,
  * b[n] /= energy[g]^(1/4), c[n] /= energy[g]^(1/4), in place (float32, N = G * nper).        */
@@ -257,6 +285,18 @@ int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, const float
                        const float* w, int B, int F, int H, int n_hidden, int G, float lo, float hi, const float* gains,
                        const float* xhat, const float* rstd, const float* ggains, float* gw,
                        void* work, void* stream);
+
+/* band-stacked: w (nbands, P) one parameter set per band, item i = band * Bper + b uses set i / Bper;
+ * gains / xhat / rstd / ggains have nbands * Bper rows; gw (nbands, P);
+ * work: gfdn_mlp_bwd_work_bytes(nbands * Bper, ...).                                           */
+int gfdn_mlp_gains_banded_fwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                              const float* w, int nbands, int Bper, int F, int H, int n_hidden, int G,
+                              float lo, float hi, float* gains, float* xhat, float* rstd, void* stream);
+int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, const float* freq_pi,
+                              const float* w, int nbands, int Bper, int F, int H, int n_hidden, int G,
+                              float lo, float hi, const float* gains, const float* xhat,
+                              const float* rstd, const float* ggains, float* gw, void* work,
+                              void* stream);
 
 /* ---- optimiser step  (trainer.py:152-228, :475: torch.optim.Adam with per-name lr groups) ----------
  * All parameters are views into one flat fp32 buffer p (n floats), gradients into g, Adam moments

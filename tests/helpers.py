@@ -27,8 +27,8 @@ def mlp_from_state(fx, prefix="sd_", root="output_scalars.mlp.model."):
 
 
 def rel_err(a, b):
-    a = np.asarray(a)
-    b = np.asarray(b)
+    a = np.asarray(a, dtype=np.complex128 if np.iscomplexobj(np.asarray(a)) else np.float64)
+    b = np.asarray(b, dtype=np.complex128 if np.iscomplexobj(np.asarray(b)) else np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
 
 

@@ -1,0 +1,280 @@
+"""Band bank on the MI355X (diffgfdn_amd/bandbank.py): all octave bands stepped by one launch per stage.
+
+Parity chain: the band-stacked C entry points against the plain ones on the same data; one bank step
+(normalize + forward + losses + backward + Adam) against every band's OWN trainer step and against the
+CPU oracle; the graph-replayed bank step against the eager one; per-band checkpoints load back into
+the reference-shaped module."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import philox_mask, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FS, NFFT, WIN = 8000.0, 8192, 512
+G, NPER = 3, 4
+BANDS = (250.0, 500.0, 1000.0)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _band_filters():
+    from scipy.signal import firwin
+    out = []
+    for f in BANDS:
+        taps = firwin(257, [f / np.sqrt(2), f * np.sqrt(2)], pass_zero=False, fs=FS)
+        out.append(np.fft.rfft(taps, n=NFFT))
+    return np.stack(out)
+
+
+def _delays(q):
+    base = [173, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 401]
+    return [d + 2 * q for d in base]
+
+
+def _build_net(q):
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    torch.manual_seed(100 + q)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    T60 = np.linspace(0.2, 0.5, G)[None, :]
+    return DiffGFDNVarReceiverPos(FS, G, _delays(q), DEV, fl, of, use_absorption_filters=False,
+                                  common_decay_times=T60, use_colorless_loss=True).to(DEV)
+
+
+def _build_data(q, R=12):
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
+    from diffgfdn_amd.synthetic import synthetic_room
+    room = synthetic_room(R, G, FS, 5000, seed=10 + q, t60_range=(0.2, 0.5))
+    ds = MultiRIRDataset(DEV, RoomDataset(G, FS, room["source_position"], room["receiver_position"],
+                                          room["rirs"].copy(), room["common_decay_times"], nfft=NFFT, device=DEV))
+    return room, ds
+
+
+def _tc(mask=True, **kw):
+    from diffgfdn_amd.config import SubbandProcessingConfig, TrainerConfig
+    return TrainerConfig(batch_size=4, num_freq_bins=NFFT, lr=1e-3, io_lr=1e-2, use_colorless_loss=True,
+                         use_asym_spectral_loss=True, edc_loss_weight=10.0, sparsity_loss_weight=2.0,
+                         use_edc_mask=mask, train_dir="/tmp/gfdn_bank/t", ir_dir="/tmp/gfdn_bank/a", device="cuda",
+                         subband_process_config=SubbandProcessingConfig(
+                             centre_frequency=500.0, frequency_range=(63, 8000), num_fraction_octaves=1), **kw)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_banded_kernels_equal_plain_kernels():
+    from diffgfdn_amd import hip_ops as ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nb, K, B, R = 3, 1000, 5, 9
+    N = G * NPER
+    Y = torch.randn(K, nb * N, 2, generator=g).to(DEV)
+    Y = torch.view_as_complex(Y)
+    c = torch.randn(nb * N, generator=g).to(DEV)
+    rgain = torch.randn(nb * B, G, generator=g).to(DEV)
+    direct = torch.view_as_complex(torch.randn(nb * R, K, 2, generator=g).to(DEV))
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=g)[:B]], device=DEV)
+    filt = torch.view_as_complex(torch.randn(nb, K, 2, generator=g).to(DEV))
+    gH = torch.view_as_complex(torch.randn(nb * B, K, 2, generator=g).to(DEV))
+    H, S = ops.compose_fwd(Y, c, rgain, NPER, direct, filt, want_S=True, direct_rows=rows, nbands=nb)
+    gY, gc, grg = ops.compose_bwd(Y, c, rgain, NPER, gH, filt, nbands=nb)
+    for q in range(nb):
+        Yq = Y[:, q * N:(q + 1) * N].contiguous()
+        sl = slice(q * B, (q + 1) * B)
+        Hq, Sq = ops.compose_fwd(Yq, c[q * N:(q + 1) * N], rgain[sl], NPER, direct, filt[q], want_S=True,
+                                 direct_rows=rows[sl].contiguous())
+        assert torch.equal(H[sl], Hq) and torch.equal(S[q * G:(q + 1) * G], Sq)
+        gYq, gcq, grgq = ops.compose_bwd(Yq, c[q * N:(q + 1) * N], rgain[sl], NPER, gH[sl].contiguous(), filt[q])
+        assert torch.equal(gY[:, q * N:(q + 1) * N], gYq)
+        assert torch.equal(gc[q * N:(q + 1) * N], gcq) and torch.equal(grg[sl], grgq)
+    # gain network: one packed parameter row per band
+    lib_P = ops._lib.load().gfdn_mlp_param_count(4, 16, 2, G)
+    w = (0.3 * torch.randn(nb, lib_P, generator=g)).to(DEV)
+    pos = torch.rand(nb * R, 3, generator=g, dtype=torch.float64).to(DEV)
+    fpi = (torch.exp(torch.linspace(0, np.log(32.0), 4)) * np.pi).to(DEV)
+    gains, xhat, rstd = ops.mlp_gains_fwd(pos, fpi, w, 16, 2, G, -1.0, 1.0, rows, nbands=nb)
+    gg = torch.randn(nb * B, G, generator=g).to(DEV)
+    gw = ops.mlp_gains_bwd(pos, fpi, w, 16, 2, G, -1.0, 1.0, gains, xhat, rstd, gg, rows, nbands=nb)
+    for q in range(nb):
+        sl = slice(q * B, (q + 1) * B)
+        rq = rows[sl].contiguous()
+        gq, xq, sq = ops.mlp_gains_fwd(pos, fpi, w[q], 16, 2, G, -1.0, 1.0, rq)
+        assert torch.equal(gains[sl], gq) and torch.equal(xhat[sl], xq) and torch.equal(rstd[sl], sq)
+        gwq = ops.mlp_gains_bwd(pos, fpi, w[q], 16, 2, G, -1.0, 1.0, gq, xq, sq, gg[sl].contiguous(), rq)
+        assert torch.equal(gw[q], gwq)
+    # bookkeeping
+    lg = torch.rand(nb * G, generator=g).to(DEV)
+    Q = torch.randn(nb * G, NPER, NPER, generator=g).to(DEV)
+    out, gQ = ops.colorless_terms(lg, Q, 1.0, 2.0, 0.5, nbands=nb)
+    a = torch.rand(nb * B, 3, generator=g).to(DEV)
+    div = torch.rand(nb * R, generator=g).to(DEV) + 0.5
+    b = torch.rand(nb * B, generator=g).to(DEV)
+    ws = ops.weighted_sums(a, 1.5, b, 10.0, div, rows, nbands=nb)
+    for q in range(nb):
+        oq, gQq = ops.colorless_terms(lg[q * G:(q + 1) * G], Q[q * G:(q + 1) * G], 1.0, 2.0, 0.5)
+        assert torch.equal(out[q], oq) and torch.equal(gQ[q * G:(q + 1) * G], gQq)
+        sl = slice(q * B, (q + 1) * B)
+        wq = ops.weighted_sums(a[sl].contiguous(), 1.5, b[sl].contiguous(), 10.0, div, rows[sl].contiguous())
+        assert torch.equal(ws[q], wq)
+
+
+def _bank_setup(mask=True):
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    nets = [_build_net(q) for q in range(len(BANDS))]
+    data = [_build_data(q) for q in range(len(BANDS))]
+    filt = torch.tensor(_band_filters(), device=DEV).to(torch.complex64)
+    bank = BandBank(nets)
+    tr = BandBankTrainer(bank, _tc(mask), subband_filter_freq_resp=filt, stft_win=WIN, band_names=BANDS)
+    sds = BandStackedDataset([d for _, d in data])
+    start, length = tr._decay_window(NFFT // 2 + 1)
+    sds.precompute_decay_targets(WIN, start, length)
+    return nets, data, filt, bank, tr, sds, (start, length)
+
+
+def test_bank_step_equals_band_steps_and_oracle():
+    """One bank step == every band's own VarReceiverPosTrainer step (same kernels, same mask), and the
+    bank's per-band losses / post-Adam gains match the CPU oracle of the reference step."""
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    from oracle import gfdn_oracle as orc
+    from oracle.cpu_trainer import OracleGridTrainer
+    nets, data, filt, bank, tr, sds, (start, length) = _bank_setup()
+    sels = [[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]]
+    mw_np, count = philox_mask(99, 0, length, 1.0 / 4)
+    mw = torch.tensor(mw_np, device=DEV)
+    sd0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
+
+    batch = sds.collate(sds.global_rows(sels))
+    tr.normalize(batch)
+    tr.optimizer.zero_grad(set_to_none=True)
+    losses = tr._step_losses(batch, mask_prenorm=mw, defer_total=True)
+    heads = losses.pop("_heads")
+    torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
+    tr.optimizer.step()
+    got = {k: v.detach().cpu().numpy() for k, v in losses.items()}
+    assert got["edr_loss"].shape == (len(BANDS),)
+
+    for q in range(len(BANDS)):
+        ref_net = _build_net(q)
+        ref_net.load_state_dict(sd0[q], strict=True)
+        rtr = VarReceiverPosTrainer(ref_net, _tc(True), subband_filter_freq_resp=filt[q], stft_win=WIN,
+                                    capturable=True)
+        ds = data[q][1]
+        ds.precompute_decay_targets(WIN, start, length)
+        b = ds.collate(sels[q], lean=True)
+        rtr.normalize(b)
+        rtr.optimizer.zero_grad(set_to_none=True)
+        rl = rtr._step_losses(b, mask_prenorm=mw)
+        rl.pop("_total").backward()
+        rtr.optimizer.step()
+        for k, v in rl.items():
+            assert abs(float(v) - got[k][q]) <= 1e-6 * abs(float(v)) + 1e-9, (q, k, float(v), got[k][q])
+        for k, v in ref_net.state_dict().items():
+            assert rel_err(nets[q].state_dict()[k].detach().cpu(), v.detach().cpu()) < 1e-5, (q, k)
+
+    # CPU oracle of the reference step for every band (float64 restatement pinned to the golden vectors)
+    keep = torch.argwhere(torch.tensor(mw_np) > 0)
+    for q in range(len(BANDS)):
+        room, _ = data[q]
+        sd = sd0[q]
+        lin, norm = [], []
+        for i in range(64):
+            k = f"output_scalars.mlp.model.{i}.weight"
+            if k in sd:
+                (lin if sd[k].ndim == 2 else norm).append((sd[k].clone(), sd[f"output_scalars.mlp.model.{i}.bias"].clone()))
+        p = orc.GridModelParams(FS, _delays(q), G, sd["input_gains"].clone(), sd["output_gains"].clone(),
+                                sd["feedback_loop.M"].clone(), sd["feedback_loop.alpha"].clone(),
+                                np.linspace(0.2, 0.5, G)[None, :], lin, norm, 4)
+        otr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
+                                sparsity_weight=2.0, use_asym=True, win=WIN, hop=WIN // 2,
+                                subband_filter=filt[q].cpu().to(torch.complex128))
+        _, dq = data[q]
+        idx = torch.tensor(sels[q])
+        # the dataset front end runs in float32 on the device; the oracle takes ITS responses so that
+        # the comparison isolates the step (the front end has its own parity test, F7)
+        ob = {"z_values": dq.z_values.cpu(),
+              "norm_listener_position": dq.norm_listener_position[idx].cpu(),
+              "listener_position": dq.listener_positions[idx].cpu(),
+              "target_early_response": dq.early_rir_mag_response[idx].cpu().to(torch.complex128),
+              "target_rir_response": dq.rir_mag_response[idx].cpu().to(torch.complex128)}
+        otr.normalize(ob)
+        ototal, oparts = otr.train_step(ob, keep)
+        for k, v in oparts.items():
+            assert abs(got[k][q] - v) < 1e-4 * abs(v) + 1e-7, (q, k, got[k][q], v)
+        for name in ("input_gains", "output_gains"):
+            a = getattr(nets[q], name).detach().cpu()
+            assert rel_err(a, getattr(p, name).detach()) < 1e-4, (q, name)
+
+
+def test_graphed_bank_step_equals_eager_bank_step():
+    nets, data, filt, bank, tr, sds, (start, length) = _bank_setup()
+    sel_steps = [[[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]],
+                 [[1, 2, 4, 6], [0, 5, 7, 9], [3, 8, 10, 11]],
+                 [[8, 9, 10, 11], [3, 4, 6, 10], [0, 1, 2, 5]]]
+    step = tr.graphed(sds, 4, mask_seed=777).capture(sds.global_rows(sel_steps[0]))
+    got, got_grad = [], []
+    for s in sel_steps:
+        got.append(step(sds.global_rows(s))["_total"].detach().cpu().numpy().copy())
+        got_grad.append(tr.optimizer.flat_grad.detach().cpu().numpy().copy())
+    assert int(step.mask_state.item()) == len(sel_steps)
+
+    nets2, data2, filt2, bank2, tr2, sds2, _ = _bank_setup()
+    want = []
+    for i, s in enumerate(sel_steps):
+        b = sds2.collate(sds2.global_rows(s))
+        tr2.normalize(b)
+        tr2.optimizer.zero_grad(set_to_none=True)
+        mw = torch.tensor(philox_mask(777, i, length, 1.0 / 4)[0], device=DEV)
+        losses = tr2._step_losses(b, mask_prenorm=mw, defer_total=True)
+        heads = losses.pop("_heads")
+        torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
+        tr2.optimizer.pack_grads()
+        if i == 0:
+            # same state, same inputs: the replayed gradients are the eager ones to the last bit (Adam's
+            # first update is sign(g), so the loss comparison below could not see a wrong magnitude)
+            assert np.array_equal(tr2.optimizer.flat_grad.cpu().numpy(), got_grad[0])
+        tr2.optimizer.step()
+        want.append((heads[0].detach() + heads[1].detach()).cpu().numpy())
+    for a, b in zip(got, want):
+        assert np.allclose(a, b, rtol=1e-5, atol=0), (got, want)
+    for q in range(len(BANDS)):
+        for k, v in nets[q].state_dict().items():
+            assert rel_err(v.detach().cpu(), nets2[q].state_dict()[k].detach().cpu()) < 5e-4, (q, k)
+
+
+def test_bank_training_loop_checkpoints_and_band_freeze(tmp_path):
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    nets = [_build_net(q) for q in range(len(BANDS))]
+    data = [_build_data(q, R=14) for q in range(len(BANDS))]
+    filt = torch.tensor(_band_filters(), device=DEV).to(torch.complex64)
+    tc = _tc(True, max_epochs=2)
+    tc.train_dir = str(tmp_path)
+    bank = BandBank(nets)
+    tr = BandBankTrainer(bank, tc, subband_filter_freq_resp=filt, stft_win=WIN, band_names=[int(f) for f in BANDS])
+    sds = BandStackedDataset([d for _, d in data])
+    g = torch.Generator().manual_seed(0)
+    splits = [torch.randperm(14, generator=g).tolist() for _ in BANDS]
+    train = [s[:10] for s in splits]           # 2 full batches + a ragged tail of 2 per band
+    valid = [s[10:] for s in splits]
+    tr.train(sds, train, valid, batch_size=4, log=False)
+    assert len(tr.train_loss[0]) == 2 and all(np.isfinite(tr.train_loss[q]).all() for q in range(len(BANDS)))
+    for q, f in enumerate(BANDS):
+        sd = torch.load(tmp_path / f"band_{int(f)}" / "checkpoints" / "model_e1.pt")
+        fresh = _build_net(q)
+        fresh.load_state_dict(sd, strict=True)                      # reference-shaped keys
+        for k, v in nets[q].state_dict().items():
+            assert torch.equal(v.cpu(), sd[k].cpu()), (q, k)
+    # a stopped band no longer moves, the others do
+    tr.optimizer.band_active[1] = False
+    tr.optimizer.sync_lr()
+    before = [{k: v.detach().clone() for k, v in n.state_dict().items()} for n in nets]
+    b = sds.collate(sds.global_rows([t[:4] for t in train]))
+    tr.normalize(b)
+    frozen_after_norm = {k: v.detach().clone() for k, v in nets[1].state_dict().items()}
+    tr.train_step(b)
+    for k, v in nets[1].state_dict().items():
+        assert torch.equal(v, frozen_after_norm[k]), k
+    assert not torch.equal(nets[0].state_dict()["feedback_loop.M"], before[0]["feedback_loop.M"])

@@ -218,7 +218,10 @@ def test_graphed_step_device_mask():
     tr = VarReceiverPosTrainer(net, tc, stft_win=512, capturable=True)
     step = tr.graphed(ds, 4, mask_seed=4242).capture(sels[0])
     assert int(step.mask_state.item()) == 0                     # the warm-up left no trace
-    got = [float(step(sel)["_total"]) for sel in sels]
+    got, got_grad = [], []
+    for sel in sels:
+        got.append(float(step(sel)["_total"]))
+        got_grad.append(tr.optimizer.flat_grad.detach().cpu().numpy().copy())
     assert int(step.mask_state.item()) == len(sels)
     last = step.maskw.cpu().numpy()
     want_last, _ = philox_mask(4242, len(sels) - 1, step.length, 1.0 / 4)
@@ -235,6 +238,8 @@ def test_graphed_step_device_mask():
         losses = tr2._step_losses(b, mask_prenorm=mw)
         losses["_total"].backward()
         tr2.optimizer.pack_grads()
+        if i == 0:      # same state and inputs: replayed gradients equal the eager ones to the last bit
+            assert np.array_equal(tr2.optimizer.flat_grad.cpu().numpy(), got_grad[0])
         tr2.optimizer.step()
         want.append(float(losses["_total"]))
     for a, b in zip(got, want):
