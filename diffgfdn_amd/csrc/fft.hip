@@ -865,6 +865,206 @@ __global__ __launch_bounds__(STFT_T) void k_stft_power_bwd(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// win = 4096 (the reference's STFT, losses.py:512-535): register-resident radix-16 x 3.
+// 256 threads per frame pair, 16 points per thread; thread i starts with x[i + 256 k] (loaded straight
+// from memory, windowed), the three passes exchange through ONE padded LDS buffer (34 KB -> 4 blocks
+// per CU; the generic ping-pong Stockham needs 74 KB, 2 blocks, and its stride-8 writes collide in the
+// banks), and thread i ends with the bins X[i + 256 u].  Twiddle bases come from sincospif per thread
+// (the pass-1 angle 2 pi i / 4096 also yields the Hann window by angle addition): no tables.
+// ------------------------------------------------------------------------------------------
+#define S4K_T 256
+#define S4K_PAD(i) ((i) + ((i) >> 4))
+#define S4K_LDS (4096 + 256)
+
+// 16-point DFT, natural order in and out; sgn = +1 forward (e^-), -1 inverse
+__device__ __forceinline__ void bfly16(float2 (&a)[16], float sgn) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
+  float2 b[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {       // 4-point DFTs over n2 (elements j, j+4, j+8, j+12) -> index q
+    const float2 x0 = a[j], x1 = a[j + 4], x2 = a[j + 8], x3 = a[j + 12];
+    const float2 p = cadd(x0, x2), m = csub(x0, x2), q = cadd(x1, x3), t = csub(x1, x3);
+    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);       // -j t (forward)
+    b[j][0] = cadd(p, q);
+    b[j][1] = cadd(m, jt);
+    b[j][2] = csub(p, q);
+    b[j][3] = csub(m, jt);
+  }
+  // twiddles W16^(j q)
+  auto tw = [&](float2 v, float cr, float ci) {   // v * (cr - i sgn ci)
+    return make_float2(v.x * cr + sgn * v.y * ci, v.y * cr - sgn * v.x * ci);
+  };
+  b[1][1] = tw(b[1][1], c1, s1);   b[1][2] = tw(b[1][2], r, r);     b[1][3] = tw(b[1][3], s1, c1);
+  b[2][1] = tw(b[2][1], r, r);     b[2][2] = tw(b[2][2], 0.f, 1.f); b[2][3] = tw(b[2][3], -r, r);
+  b[3][1] = tw(b[3][1], s1, c1);   b[3][2] = tw(b[3][2], -r, r);    b[3][3] = tw(b[3][3], -c1, -s1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {       // 4-point DFTs over j -> X[q + 4 s]
+    const float2 x0 = b[0][q], x1 = b[1][q], x2 = b[2][q], x3 = b[3][q];
+    const float2 p = cadd(x0, x2), m = csub(x0, x2), qq = cadd(x1, x3), t = csub(x1, x3);
+    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);
+    a[q] = cadd(p, qq);
+    a[q + 4] = cadd(m, jt);
+    a[q + 8] = csub(p, qq);
+    a[q + 12] = csub(m, jt);
+  }
+}
+// a[u] *= w^u, u = 1..15 (powers by squaring: every factor is at most 3 products away from w)
+__device__ __forceinline__ void twiddle16(float2 (&a)[16], float2 w1) {
+  const float2 w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+  const float2 w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+  a[1] = cmul(a[1], w1);  a[2] = cmul(a[2], w2);  a[3] = cmul(a[3], w3);  a[4] = cmul(a[4], w4);
+  a[5] = cmul(a[5], w5);  a[6] = cmul(a[6], w6);  a[7] = cmul(a[7], w7);  a[8] = cmul(a[8], w8);
+  a[9] = cmul(a[9], cmul(w8, w1));   a[10] = cmul(a[10], cmul(w8, w2)); a[11] = cmul(a[11], cmul(w8, w3));
+  a[12] = cmul(a[12], cmul(w8, w4)); a[13] = cmul(a[13], cmul(w8, w5)); a[14] = cmul(a[14], cmul(w8, w6));
+  a[15] = cmul(a[15], cmul(w8, w7));
+}
+// in: a[k] = x[i + 256 k]; out: a[u] = X[i + 256 u].  w1 = (cos, -sin)(2 pi i / 4096).  Every thread of the
+// 256-thread block calls it; buf is free on entry (callers that used it synchronise first) and holds
+// nothing of value on exit.
+__device__ __forceinline__ void fft4096(float2 (&a)[16], float2* buf, int i, float2 w1, float sgn) {
+  bfly16(a, sgn);
+  w1.y *= sgn;
+  twiddle16(a, w1);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(16 * i + u)] = a[u];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
+  bfly16(a, sgn);
+  {
+    float sn, cs;
+    sincospif(2.0f * (float)(i >> 4) / 256.0f, &sn, &cs);     // W_256^p, p = i >> 4
+    twiddle16(a, make_float2(cs, -sgn * sn));
+  }
+  __syncthreads();
+  const int base = (i & 15) + 256 * (i >> 4);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(base + 16 * u)] = a[u];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
+  bfly16(a, sgn);
+}
+
+// windowed frame pair z[j] = hann(j) (x[m hop + j] + i x[(m+1) hop + j]) at j = i + 256 k; also returns the
+// pass-1 twiddle base and keeps the window values for the adjoint's epilogue
+__device__ __forceinline__ void s4k_load(const float* __restrict__ x, int T, int m, int nframes, int i,
+                                         float2 (&a)[16], float (&h)[16], float2& w1) {
+  float sn, cs;
+  sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
+  w1 = make_float2(cs, -sn);
+  const bool has_b = m + 1 < nframes;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    // cos(theta_i + k pi / 8) by angle addition (theta_i = 2 pi i / 4096)
+    float sk, ck;
+    sincospif((float)k * 0.125f, &sk, &ck);      // compile-time constants after unrolling
+    h[k] = 0.5f - 0.5f * (cs * ck - sn * sk);
+    const int ta = m * 2048 + i + 256 * k, tb = ta + 2048;
+    const float va = ta < T ? x[ta] : 0.f;
+    const float vb = (has_b && tb < T) ? x[tb] : 0.f;
+    a[k] = make_float2(h[k] * va, h[k] * vb);
+  }
+}
+
+__global__ __launch_bounds__(S4K_T) void k_stft4k_power(const float* __restrict__ x, int ld, int T,
+                                                        int nframes, float* __restrict__ P,
+                                                        float* __restrict__ zero_buf) {
+  float2* buf = dyn_lds;
+  const int b = blockIdx.y, m = blockIdx.x * 2, nf = 2049, i = threadIdx.x;
+  if (zero_buf) {
+    float* zb = zero_buf + (size_t)b * ld;
+    const int t0 = m * 2048;
+    const int t1 = (blockIdx.x == gridDim.x - 1) ? ld : t0 + 4096;
+    for (int t = t0 + i; t < t1 && t < ld; t += S4K_T) zb[t] = 0.f;
+  }
+  float2 a[16], w1;
+  float h[16];
+  s4k_load(x + (size_t)b * ld, T, m, nframes, i, a, h, w1);
+  fft4096(a, buf, i, w1, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+  __syncthreads();
+  float* Pa = P + ((size_t)b * nframes + m) * nf;
+  const bool has_b = m + 1 < nframes;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const float2 zf = a[u], zc = buf[S4K_PAD((4096 - f) & 4095)];
+      // S_a = (Z_f + conj Z_{W-f})/2 ; S_b = (Z_f - conj Z_{W-f})/(2i)
+      const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+      Pa[f] = sa.x * sa.x + sa.y * sa.y;
+      if (has_b) Pa[nf + f] = sb.x * sb.x + sb.y * sb.y;
+    }
+  }
+}
+
+// Adjoint: recompute the pair's spectrum, build the Hermitian-symmetrised gradient spectrum in place,
+// one inverse FFT for both frames, window, scatter (two frame terms per sample, added atomically into a
+// zeroed buffer: order-free).  (Measured: walking two pairs per block to halve the atomics is SLOWER --
+// 194 vs 138 us at 224 items -- the kernel is bound by registers / occupancy, not by the L2 atomics.)
+__global__ __launch_bounds__(S4K_T) void k_stft4k_power_bwd(const float* __restrict__ x, int ld, int T,
+                                                            int nframes, const float* __restrict__ gP,
+                                                            float* __restrict__ gx) {
+  float2* buf = dyn_lds;
+  const int b = blockIdx.y, m = blockIdx.x * 2, nf = 2049, i = threadIdx.x;
+  float2 a[16], w1;
+  {
+    float h[16];
+    s4k_load(x + (size_t)b * ld, T, m, nframes, i, a, h, w1);
+  }
+  fft4096(a, buf, i, w1, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+  __syncthreads();
+  const float* ga = gP + ((size_t)b * nframes + m) * nf;
+  const bool has_b = m + 1 < nframes;
+  // U = Ga_sym + i Gb_sym for the pair (f, W - f), from Z_f and Z_{W-f} (both re-read from LDS: the
+  // register copy is dead here).  The pair is handled by exactly one thread (the owner of f <= W/2) and
+  // nobody else reads either slot, so U_f and U_{W-f} overwrite the two slots in place with no barrier
+#pragma unroll 3
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const int fc = (4096 - f) & 4095;
+      const float2 zf = buf[S4K_PAD(f)], zc = buf[S4K_PAD(fc)];
+      const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+      const float pa = ga[f], pb = has_b ? ga[nf + f] : 0.f;
+      const float2 Ga = cscale(sa, 2.0f * pa), Gb = cscale(sb, 2.0f * pb);   // G = 2 gP S
+      if (f == 0 || f == 2048) {
+        buf[S4K_PAD(f)] = make_float2(Ga.x, Gb.x);                           // real-only bins
+      } else {
+        buf[S4K_PAD(f)] = make_float2(0.5f * (Ga.x - Gb.y), 0.5f * (Ga.y + Gb.x));      // U_f
+        buf[S4K_PAD(fc)] = make_float2(0.5f * (Ga.x + Gb.y), 0.5f * (-Ga.y + Gb.x));    // U_{W-f}
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
+  __syncthreads();
+  fft4096(a, buf, i, w1, -1.0f);
+  float* g = gx + (size_t)b * ld + m * 2048 + i;
+  const int lim_a = T - m * 2048 - i, lim_b = has_b ? lim_a - 2048 : 0;     // sample j valid iff j < lim
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    float sk, ck;
+    sincospif((float)u * 0.125f, &sk, &ck);
+    const float hw = 0.5f - 0.5f * (w1.x * ck + w1.y * sk);     // w1 = (cos, -sin) theta_i
+    const int j = 256 * u;
+    if (j < lim_a) atomicAdd(g + j, hw * a[u].x);
+    if (j < lim_b) atomicAdd(g + j + 2048, hw * a[u].y);
+    if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the address arithmetic of later chunks out of this one
+  }
+}
+
 static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }
 
 extern "C" int gfdn_stft_power(const float* x, int ld, int T, int batch, int win, float* P,
@@ -872,6 +1072,12 @@ extern "C" int gfdn_stft_power(const float* x, int ld, int T, int batch, int win
   if (!x || !P || batch <= 0 || ld < T) return GFDN_E_BADARG;
   int nframes = gfdn_stft_nframes(T, win);
   if (nframes <= 0) return GFDN_E_BADARG;
+  if (win == 4096) {
+    hipLaunchKernelGGL(k_stft4k_power, dim3((nframes + 1) / 2, batch), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                       (hipStream_t)stream, x, ld, T, nframes, P, zero_buf);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   if (stft_lds(win) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_stft_power, stft_lds(win));
   if (rc) return rc;
@@ -886,6 +1092,12 @@ extern "C" int gfdn_stft_power_bwd(const float* x, int ld, int T, int batch, int
   if (!x || !gP || !gx || batch <= 0 || ld < T) return GFDN_E_BADARG;
   int nframes = gfdn_stft_nframes(T, win);
   if (nframes <= 0) return GFDN_E_BADARG;
+  if (win == 4096) {
+    hipLaunchKernelGGL(k_stft4k_power_bwd, dim3((nframes + 1) / 2, batch), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                       (hipStream_t)stream, x, ld, T, nframes, gP, gx);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   if (stft_lds(win) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_stft_power_bwd, stft_lds(win));
   if (rc) return rc;

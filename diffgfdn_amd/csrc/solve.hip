@@ -262,6 +262,217 @@ __global__ __launch_bounds__(256) void k_solve_bwd_finish(const float* __restric
   else gig[blk * n + (o - n * n - n)] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// n <= 4 (the north-star layout: N = 16 = 4 groups x 4): ONE THREAD per system.  The 4 x 4 complex
+// matrix, the right-hand side and the pivot bookkeeping live in registers with compile-time indices
+// (fully unrolled; the pivot row is picked with selects), so a wavefront solves 64 systems with no
+// cross-lane traffic at all -- the NP-lane kernels above solve 16 per wave and spend most of their
+// issue slots in ds_bpermute.  Same elimination order and the same pivot rule (largest |.|^2 among
+// the unused rows, lowest row on ties) as gauss_jordan<NP>.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 sel4(int i, float2 a0, float2 a1, float2 a2, float2 a3) {
+  float2 lo = (i == 1) ? a1 : a0, hi = (i == 3) ? a3 : a2;
+  return (i >= 2) ? hi : lo;
+}
+
+// solves m x = r in place (m, r destroyed); rows / columns >= n must be the identity with zero rhs
+__device__ __forceinline__ void gj4(float2 (&m)[4][4], float2 (&r)[4], float2 (&x)[4]) {
+  bool used[4] = {false, false, false, false};
+  int piv[4];
+  float2 pinv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float bm = -1.0f;
+    int best = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float mag = used[i] ? -1.0f : (m[i][j].x * m[i][j].x + m[i][j].y * m[i][j].y);
+      const bool take = mag > bm;
+      bm = take ? mag : bm;
+      best = take ? i : best;
+    }
+    float2 pr[4];
+#pragma unroll
+    for (int c = j; c < 4; ++c) pr[c] = sel4(best, m[0][c], m[1][c], m[2][c], m[3][c]);
+    const float2 prhs = sel4(best, r[0], r[1], r[2], r[3]);
+    const float2 inv = cinv(pr[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool isp = (i == best);
+      used[i] = used[i] || isp;
+      float2 f = cmul(m[i][j], inv);
+      if (isp) f = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int c = j + 1; c < 4; ++c) {
+        m[i][c].x -= f.x * pr[c].x - f.y * pr[c].y;
+        m[i][c].y -= f.x * pr[c].y + f.y * pr[c].x;
+      }
+      r[i].x -= f.x * prhs.x - f.y * prhs.y;
+      r[i].y -= f.x * prhs.y + f.y * prhs.x;
+    }
+    piv[j] = best;
+    pinv[j] = inv;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = cmul(sel4(piv[j], r[0], r[1], r[2], r[3]), pinv[j]);
+}
+
+// m = diag(zeta) - A  (swap: - A^T; conj_t: the conjugate transpose of that, for the adjoint system)
+__device__ __forceinline__ void build4(float2 (&m)[4][4], const float* __restrict__ Ablk, int n, bool swap,
+                                       const float2 (&zeta)[4], bool adj) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float av = 0.f;
+      if (r < n && c < n) av = (swap != adj) ? Ablk[c * n + r] : Ablk[r * n + c];
+      m[r][c] = make_float2(-av, 0.f);
+      if (r == c) {
+        if (r < n) m[r][c] = make_float2(zeta[r].x - av, adj ? -zeta[r].y : zeta[r].y);
+        else m[r][c] = make_float2(1.f, 0.f);
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_solve4_fwd(SolveArgs a, float2* __restrict__ Y) {
+  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.K) return;
+  float2 zeta[4], rhs[4], m[4][4], y[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = blk * n + (r < n ? r : 0);
+    zeta[r] = zeta_pow(a.turns, a.logr, k, a.delays[i], a.inv_gamma ? a.inv_gamma[i] : 1.0f);
+    rhs[r] = make_float2(r < n ? a.b[i] : 0.f, 0.f);
+  }
+  build4(m, a.A + (size_t)blk * n * n, n, a.transpose != 0, zeta, false);
+  gj4(m, rhs, y);
+  float2* out = Y + (size_t)k * N + blk * n;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r < n) out[r] = y[r];
+}
+
+// partial[(part * nblk + blk) * per + e], per = n n + 2 n, laid out as k_solve_bwd does
+__global__ __launch_bounds__(256) void k_solve4_bwd(SolveArgs a, const float2* __restrict__ gY,
+                                                    const float2* __restrict__ Ysaved,
+                                                    float* __restrict__ partial) {
+  __shared__ float s_w[4][24];
+  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
+  const float* Ablk = a.A + (size_t)blk * n * n;
+  const bool tr = a.transpose != 0;
+  float m_i[4], ig_i[4], b_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = blk * n + (r < n ? r : 0);
+    m_i[r] = a.delays[i];
+    ig_i[r] = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
+    b_i[r] = r < n ? a.b[i] : 0.f;
+  }
+  float acc[24];
+#pragma unroll
+  for (int e = 0; e < 24; ++e) acc[e] = 0.f;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {
+    float2 zpow[4], zeta[4], m[4][4], y[4], w[4], rhs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      zpow[r] = zeta_pow(a.turns, a.logr, k, m_i[r], 1.0f);   // d T_ii / d inv_gamma = z^m
+      zeta[r] = cscale(zpow[r], ig_i[r]);
+    }
+    const size_t row = (size_t)k * N + blk * n;
+    if (Ysaved) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = r < n ? Ysaved[row + r] : make_float2(0.f, 0.f);
+    } else {
+      build4(m, Ablk, n, tr, zeta, false);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rhs[r] = make_float2(b_i[r], 0.f);
+      gj4(m, rhs, y);
+    }
+    // adjoint system T^H w = gY
+    build4(m, Ablk, n, tr, zeta, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rhs[r] = r < n ? gY[row + r] : make_float2(0.f, 0.f);
+    gj4(m, rhs, w);
+    // gT_ij = -w_i conj(y_j), T = D - A (or D - A^T):
+    //   transpose = 0: gA[i][j] = Re(w_i conj(y_j));  transpose = 1: gA[i][j] = Re(w_j conj(y_i))
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float2 p = tr ? y[i] : w[i], q = tr ? w[j] : y[j];
+        acc[i * 4 + j] += p.x * q.x + p.y * q.y;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[16 + i] += w[i].x;
+      const float2 yz = cmul(y[i], zpow[i]);      // g inv_gamma_i = -Re(conj(w_i) y_i z^m)
+      acc[20 + i] -= w[i].x * yz.x + w[i].y * yz.y;
+    }
+  }
+  // fixed-order block reduction: wave butterflies, then the 4 wave partials in order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 24; ++e) {
+    const float v = wave_sum(acc[e]);
+    if (lane == 0) s_w[wv][e] = v;
+  }
+  __syncthreads();
+  const int per = n * n + 2 * n;
+  float* out = partial + ((size_t)blockIdx.x * a.nblk + blk) * per;
+  for (int e = threadIdx.x; e < per; e += 256) {
+    int src;
+    if (e < n * n) src = (e / n) * 4 + (e % n);
+    else if (e < n * n + n) src = 16 + (e - n * n);
+    else src = 20 + (e - n * n - n);
+    out[e] = ((s_w[0][src] + s_w[1][src]) + s_w[2][src]) + s_w[3][src];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_subfdn4_energy(SolveArgs a, const float* __restrict__ c,
+                                                        float* __restrict__ partial) {
+  __shared__ float s_red[16];
+  const int blk = blockIdx.y, n = a.nper;
+  float m_i[4], ig_i[4], b_i[4], c_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = blk * n + (r < n ? r : 0);
+    m_i[r] = a.delays[i];
+    ig_i[r] = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
+    b_i[r] = r < n ? a.b[i] : 0.f;
+    c_i[r] = r < n ? c[i] : 0.f;
+  }
+  float acc = 0.f;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {
+    float2 zeta[4], m[4][4], y[4], rhs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      zeta[r] = zeta_pow(a.turns, a.logr, k, m_i[r], ig_i[r]);
+      rhs[r] = make_float2(b_i[r], 0.f);
+    }
+    build4(m, a.A + (size_t)blk * n * n, n, a.transpose != 0, zeta, false);
+    gj4(m, rhs, y);
+    float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s.x += c_i[r] * y[r].x; s.y += c_i[r] * y[r].y; }
+    acc += s.x * s.x + s.y * s.y;
+  }
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partial[(size_t)blk * gridDim.x + blockIdx.x] = acc;
+}
+
+// number of 256-bin slices a reducing thread-per-system launch cuts K into: enough blocks to fill the
+// chip (>= ~1024 with the nblk blocks of the y dimension), at most GFDN_PARTIAL_BLOCKS
+static int solve4_parts(int K, int nblk) {
+  const int full = (K + 255) / 256;
+  int want = (1024 + nblk - 1) / nblk;
+  if (want < 8) want = 8;
+  int parts = full < want ? full : want;
+  if (parts > GFDN_PARTIAL_BLOCKS) parts = GFDN_PARTIAL_BLOCKS;
+  return parts;
+}
+
 static int pick_np(int nper) {
   if (nper <= 4) return 4;
   if (nper <= 8) return 8;
@@ -288,6 +499,11 @@ extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, in
   const int spb = 256 / np;
   dim3 grid((K + spb - 1) / spb, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (np == 4) {
+    hipLaunchKernelGGL(k_solve4_fwd, dim3((K + 255) / 256, nblk), block, 0, s, a, (float2*)Y);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   switch (np) {
     case 4: hipLaunchKernelGGL(k_solve_fwd<4>, grid, block, 0, s, a, (float2*)Y); break;
     case 8: hipLaunchKernelGGL(k_solve_fwd<8>, grid, block, 0, s, a, (float2*)Y); break;
@@ -314,11 +530,12 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  if (np == 4) nparts = solve4_parts(K, nblk);
   dim3 grid(nparts, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
   switch (np) {
-    case 4: hipLaunchKernelGGL(k_solve_bwd<4>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    case 4: hipLaunchKernelGGL(k_solve4_bwd, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     case 8: hipLaunchKernelGGL(k_solve_bwd<8>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     case 16: hipLaunchKernelGGL(k_solve_bwd<16>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     default: hipLaunchKernelGGL(k_solve_bwd<32>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
@@ -403,11 +620,12 @@ extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, in
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  if (np == 4) nparts = solve4_parts(K, G);
   dim3 grid(nparts, G), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
   switch (np) {
-    case 4: hipLaunchKernelGGL(k_subfdn_energy<4>, grid, block, 0, s, a, (const float*)c, partial); break;
+    case 4: hipLaunchKernelGGL(k_subfdn4_energy, grid, block, 0, s, a, (const float*)c, partial); break;
     case 8: hipLaunchKernelGGL(k_subfdn_energy<8>, grid, block, 0, s, a, (const float*)c, partial); break;
     case 16: hipLaunchKernelGGL(k_subfdn_energy<16>, grid, block, 0, s, a, (const float*)c, partial); break;
     default: hipLaunchKernelGGL(k_subfdn_energy<32>, grid, block, 0, s, a, (const float*)c, partial); break;

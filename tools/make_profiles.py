@@ -7,7 +7,8 @@ src = os.path.join(ROOT, 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
 def one(pattern):
-    return glob.glob(os.path.join(src, pattern), recursive=True)[0]
+    # gpurun merges into gpurun_out/ without clearing it: take the NEWEST match
+    return max(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
 
 # 1. bench line
 line = [l for l in open(os.path.join(src, f'{tag}_bench_n1.json')) if l.startswith('{')][-1]

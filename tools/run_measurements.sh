@@ -1,5 +1,6 @@
 set -x
 cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/r01_stats gpurun_out/r01_pmc_fetch gpurun_out/r01_pmc_write
 timeout 600 python -m pytest tests -q -m gpu 2>&1 | tail -2
 timeout 400 python bench.py > gpurun_out/r01_bench_n1.json 2> gpurun_out/r01_bench_n1.err; tail -c 1500 gpurun_out/r01_bench_n1.json
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 """Print the kernel timeline of one steady-state step from a rocprofv3 kernel trace (diagnostic).
 usage: python tools/timeline.py <dir with *_kernel_trace.csv> [step_number]"""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
