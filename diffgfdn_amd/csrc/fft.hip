@@ -62,6 +62,49 @@ __device__ __forceinline__ void twiddle8(float2 (&a)[8], float2 w1) {
   a[5] = cmul(a[5], cmul(w4, w1)); a[6] = cmul(a[6], cmul(w3, w3)); a[7] = cmul(a[7], cmul(w4, w3));
 }
 
+// 16-point DFT, natural order in and out; sgn = +1 forward (e^-), -1 inverse
+__device__ __forceinline__ void bfly16(float2 (&a)[16], float sgn) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
+  float2 b[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {       // 4-point DFTs over n2 (elements j, j+4, j+8, j+12) -> index q
+    const float2 x0 = a[j], x1 = a[j + 4], x2 = a[j + 8], x3 = a[j + 12];
+    const float2 p = cadd(x0, x2), m = csub(x0, x2), q = cadd(x1, x3), t = csub(x1, x3);
+    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);       // -j t (forward)
+    b[j][0] = cadd(p, q);
+    b[j][1] = cadd(m, jt);
+    b[j][2] = csub(p, q);
+    b[j][3] = csub(m, jt);
+  }
+  // twiddles W16^(j q)
+  auto tw = [&](float2 v, float cr, float ci) {   // v * (cr - i sgn ci)
+    return make_float2(v.x * cr + sgn * v.y * ci, v.y * cr - sgn * v.x * ci);
+  };
+  b[1][1] = tw(b[1][1], c1, s1);   b[1][2] = tw(b[1][2], r, r);     b[1][3] = tw(b[1][3], s1, c1);
+  b[2][1] = tw(b[2][1], r, r);     b[2][2] = tw(b[2][2], 0.f, 1.f); b[2][3] = tw(b[2][3], -r, r);
+  b[3][1] = tw(b[3][1], s1, c1);   b[3][2] = tw(b[3][2], -r, r);    b[3][3] = tw(b[3][3], -c1, -s1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {       // 4-point DFTs over j -> X[q + 4 s]
+    const float2 x0 = b[0][q], x1 = b[1][q], x2 = b[2][q], x3 = b[3][q];
+    const float2 p = cadd(x0, x2), m = csub(x0, x2), qq = cadd(x1, x3), t = csub(x1, x3);
+    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);
+    a[q] = cadd(p, qq);
+    a[q + 4] = cadd(m, jt);
+    a[q + 8] = csub(p, qq);
+    a[q + 12] = csub(m, jt);
+  }
+}
+// a[u] *= w^u, u = 1..15 (powers by squaring: every factor is at most 3 products away from w)
+__device__ __forceinline__ void twiddle16(float2 (&a)[16], float2 w1) {
+  const float2 w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
+  const float2 w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+  a[1] = cmul(a[1], w1);  a[2] = cmul(a[2], w2);  a[3] = cmul(a[3], w3);  a[4] = cmul(a[4], w4);
+  a[5] = cmul(a[5], w5);  a[6] = cmul(a[6], w6);  a[7] = cmul(a[7], w7);  a[8] = cmul(a[8], w8);
+  a[9] = cmul(a[9], cmul(w8, w1));   a[10] = cmul(a[10], cmul(w8, w2)); a[11] = cmul(a[11], cmul(w8, w3));
+  a[12] = cmul(a[12], cmul(w8, w4)); a[13] = cmul(a[13], cmul(w8, w5)); a[14] = cmul(a[14], cmul(w8, w6));
+  a[15] = cmul(a[15], cmul(w8, w7));
+}
+
 __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq, int ss,
                                            bool inverse, const float2* tw4, int tn) {
   const int nthr = blockDim.x;
@@ -381,6 +424,95 @@ __device__ __forceinline__ void xcd_item_map(int ntiles, int batch, int& tile, i
   }
 }
 
+
+// input element t of the length-L work sequence of item b (chirp product / Rader gather), all four modes;
+// `edge` accumulates the Rader t = 0 / k = 0 partial sums
+__device__ __forceinline__ float2 blu_load_elem(const BluArgs& a, int b, int t, float& edge) {
+  const BluGeom& g = a.g;
+  float2 v = make_float2(0.f, 0.f);
+  if (a.rader) {
+    if (!a.adjoint) {              // u[a] = Y[g^a], Y the Hermitian extension of X
+      const int k = a.perm[t];
+      const float2* Xb = (const float2*)a.in + (size_t)b * a.ld_in;
+      if (k < g.nin) { v = Xb[k]; edge += v.x; }
+      else v = cconj(Xb[g.n - k]);
+    } else {                       // G[b] = gx[g^-b]
+      const size_t src = (size_t)b * a.ld_in + a.iperm[t];
+      float r = ((const float*)a.in)[src];
+      if (a.in2) r += a.in2[src];
+      v = make_float2(r, 0.f);
+      edge += r;
+    }
+  } else if (!a.adjoint) {
+    if (t < g.nin) {
+      float2 X = ((const float2*)a.in)[(size_t)b * a.ld_in + t];
+      if (t == 0) X = make_float2(0.5f * X.x, 0.f);   // X'_0 = Re X_0 (factor 2 applied at the end)
+      v = cmul(X, a.chirp[t]);
+    }
+  } else {
+    if (t < g.n) {
+      float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
+      if (a.in2) gx += a.in2[(size_t)b * a.ld_in + t];
+      const float2 w = a.chirp[t];
+      v = make_float2(gx * w.x, -gx * w.y);     // gx * conj(w_t)
+    }
+  }
+  return v;
+}
+
+// output element t (value v of the inverse column pass) of item b, all four modes
+__device__ __forceinline__ void blu_store_elem(const BluArgs& a, int b, int t, float2 v) {
+  const BluGeom& g = a.g;
+  const int L = g.L;
+  if (a.rader) {
+    const float invL = 1.0f / (float)L, invn = 1.0f / (float)g.n;
+    if (!a.adjoint) {              // x[g^-b] = (X'_0 + S[b]) / n
+      const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
+      ((float*)a.out)[(size_t)b * a.ld_out + a.iperm[t]] = (x0 + v.x * invL) * invn;
+    } else {                       // gX[k] = 2 conj(W[a]) + (2/n) gx[0],  k = g^a <= (n-1)/2
+      const int k = a.perm[t];
+      if (k < g.nin) {
+        const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
+        const float sc = 2.0f * invL * invn;
+        ((float2*)a.out)[(size_t)b * a.ld_out + k] = make_float2(sc * v.x + 2.0f * invn * g0, -sc * v.y);
+      }
+    }
+  } else {
+    const float base = 1.0f / ((float)g.n * (float)L);
+    if (!a.adjoint) {
+      if (t < g.n) {
+        const float2 w = a.chirp[t];
+        ((float*)a.out)[(size_t)b * a.ld_out + t] = 2.0f * base * (v.x * w.x - v.y * w.y);
+      }
+    } else {
+      if (t < a.ld_out) {
+        float2 o = make_float2(0.f, 0.f);
+        if (t < g.nin) {
+          const float2 w = a.chirp[t];
+          o = cmulc(v, w);                           // conj(w_k) * conv
+          if (t == 0) o = make_float2(o.x * base, 0.f);
+          else o = cscale(o, 2.0f * base);
+        }
+        ((float2*)a.out)[(size_t)b * a.ld_out + t] = o;
+      }
+    }
+  }
+}
+
+// Rader: t = 0 / k = 0 terms from the column blocks' partial sums (fixed order); one thread per item
+__device__ __forceinline__ void blu_edge_fold(const BluArgs& a, int b) {
+  const BluGeom& g = a.g;
+  float sum = 0.f;
+  for (int e = 0; e < a.nedge; ++e) sum += a.edge[(size_t)b * a.nedge + e];
+  if (!a.adjoint) {   // x[0] = (X'_0 + 2 sum_{k>=1} Re X_k) / n
+    const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
+    ((float*)a.out)[(size_t)b * a.ld_out] = (x0 + 2.0f * sum) / (float)g.n;
+  } else {            // gX[0] = sum_t gx[t] / n
+    const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
+    ((float2*)a.out)[(size_t)b * a.ld_out] = make_float2((sum + g0) / (float)g.n, 0.f);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
   __shared__ float s_edge[16];
   const BluGeom g = a.g;
@@ -414,33 +546,7 @@ __global__ __launch_bounds__(256) void k_blu_col_fwd(BluArgs a) {
         const int n1 = idx >> ltc, cc = idx & (tc - 1);
         const int t = n1 * L2 + c0 + cc;
         slot[it] = cc * ss + n1;
-        if (a.rader) {
-          if (!a.adjoint) {              // u[a] = Y[g^a], Y the Hermitian extension of X
-            const int k = a.perm[t];
-            const float2* Xb = (const float2*)a.in + (size_t)b * a.ld_in;
-            if (k < g.nin) { vals[it] = Xb[k]; edge += vals[it].x; }
-            else vals[it] = cconj(Xb[g.n - k]);
-          } else {                       // G[b] = gx[g^-b]
-            const size_t src = (size_t)b * a.ld_in + a.iperm[t];
-            float v = ((const float*)a.in)[src];
-            if (a.in2) v += a.in2[src];
-            vals[it] = make_float2(v, 0.f);
-            edge += v;
-          }
-        } else if (!a.adjoint) {
-          if (t < g.nin) {
-            float2 X = ((const float2*)a.in)[(size_t)b * a.ld_in + t];
-            if (t == 0) X = make_float2(0.5f * X.x, 0.f);   // X'_0 = Re X_0 (factor 2 applied at the end)
-            vals[it] = cmul(X, a.chirp[t]);
-          }
-        } else {
-          if (t < g.n) {
-            float gx = ((const float*)a.in)[(size_t)b * a.ld_in + t];
-            if (a.in2) gx += a.in2[(size_t)b * a.ld_in + t];
-            const float2 w = a.chirp[t];
-            vals[it] = make_float2(gx * w.x, -gx * w.y);     // gx * conj(w_t)
-          }
-        }
+        vals[it] = blu_load_elem(a, b, t, edge);
       }
     }
 #pragma unroll
@@ -613,18 +719,7 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
       }
     }
   }
-  if (a.rader && tile == 0 && threadIdx.x == 0) {
-    // t = 0 / k = 0 terms from the column blocks' partial sums (fixed order)
-    float sum = 0.f;
-    for (int e = 0; e < a.nedge; ++e) sum += a.edge[(size_t)b * a.nedge + e];
-    if (!a.adjoint) {   // x[0] = (X'_0 + 2 sum_{k>=1} Re X_k) / n
-      const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
-      ((float*)a.out)[(size_t)b * a.ld_out] = (x0 + 2.0f * sum) / (float)g.n;
-    } else {            // gX[0] = sum_t gx[t] / n
-      const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
-      ((float2*)a.out)[(size_t)b * a.ld_out] = make_float2((sum + g0) / (float)g.n, 0.f);
-    }
-  }
+  if (a.rader && tile == 0 && threadIdx.x == 0) blu_edge_fold(a, b);
   if (a.rader && a.adjoint) {          // bins above (n-1)/2 carry no gradient
     float2* o = (float2*)a.out + (size_t)b * a.ld_out;
     for (int k = g.nin + tile * 256 + threadIdx.x; k < a.ld_out; k += (L2 / tc) * 256)
@@ -632,41 +727,104 @@ __global__ __launch_bounds__(256) void k_blu_col_inv(BluArgs a) {
   }
   __syncthreads();
   float2* r = lds_fft(bufA, bufB, L1, tc, ss, true, tw4, L1);
-  const float base = 1.0f / ((float)g.n * (float)L);
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
     const int n1 = idx >> ltc, cc = idx & (tc - 1);
-    const int t = n1 * L2 + c0 + cc;
-    const float2 v = r[cc * ss + n1];
-    if (a.rader) {
-      const float invL = 1.0f / (float)L, invn = 1.0f / (float)g.n;
-      if (!a.adjoint) {              // x[g^-b] = (X'_0 + S[b]) / n
-        const float x0 = ((const float2*)a.in)[(size_t)b * a.ld_in].x;
-        ((float*)a.out)[(size_t)b * a.ld_out + a.iperm[t]] = (x0 + v.x * invL) * invn;
-      } else {                       // gX[k] = 2 conj(W[a]) + (2/n) gx[0],  k = g^a <= (n-1)/2
-        const int k = a.perm[t];
-        if (k < g.nin) {
-          const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
-          const float sc = 2.0f * invL * invn;
-          ((float2*)a.out)[(size_t)b * a.ld_out + k] = make_float2(sc * v.x + 2.0f * invn * g0, -sc * v.y);
-        }
-      }
-    } else if (!a.adjoint) {
-      if (t < g.n) {
-        const float2 w = a.chirp[t];
-        ((float*)a.out)[(size_t)b * a.ld_out + t] = 2.0f * base * (v.x * w.x - v.y * w.y);
-      }
-    } else {
-      if (t < a.ld_out) {
-        float2 o = make_float2(0.f, 0.f);
-        if (t < g.nin) {
-          const float2 w = a.chirp[t];
-          o = cmulc(v, w);                           // conj(w_k) * conv
-          if (t == 0) o = make_float2(o.x * base, 0.f);
-          else o = cscale(o, 2.0f * base);
-        }
-        ((float2*)a.out)[(size_t)b * a.ld_out + t] = o;
-      }
-    }
+    blu_store_elem(a, b, n1 * L2 + c0 + cc, r[cc * ss + n1]);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Column passes for L1 = 128 (the north-star geometry 128 x 512): ONE WAVEFRONT per tile of 8 columns,
+// 16 points per lane, radix-16 x radix-8 chained through registers and a wave-private LDS block -- no
+// block barrier after the twiddle tables are built (the block-wide Stockham version above spends its
+// time in barriers and half-idle radix-8 passes: 1024 points per 256 threads).
+//   lane = 8 l + c:  c = column of the tile (fastest: global accesses are 64-byte runs, as before),
+//                    l = row phase.  Pass 1 holds rows n1 = l + 8 k (k < 16) and transforms over k;
+//   pass 2 holds u in {l, l + 8} x j < 8 and transforms over j:  k1 = u + 16 v.
+// LDS block per wave: [c][j][u] with strides (164, 17, 1): both the pass-1 writes and the pass-2 reads
+// touch 32 distinct 8-byte bank slots per half-wave.
+// ------------------------------------------------------------------------------------------
+#define CW_S 164
+#define CW_LDS (8 * CW_S)
+
+// v[k] = x[l + 8 k] -> out0[v'] = X[l + 16 v'], out1[v'] = X[l + 8 + 16 v']; sgn as in bfly8
+__device__ __forceinline__ void col128_fft(float2 (&v)[16], float2* buf, int l, int c, float sgn) {
+  bfly16(v, sgn);
+  {
+    float sn, cs;
+    sincospif(2.0f * (float)l / 128.0f, &sn, &cs);            // W_128^l
+    twiddle16(v, make_float2(cs, -sgn * sn));
+  }
+  float2* bc = buf + c * CW_S;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) bc[17 * l + u] = v[u];
+  // (a wave's LDS operations execute in order: no barrier between its own write and read)
+  float2 y0[8], y1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { y0[j] = bc[17 * j + l]; y1[j] = bc[17 * j + l + 8]; }
+  bfly8(y0, sgn);
+  bfly8(y1, sgn);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { v[q] = y0[q]; v[8 + q] = y1[q]; }
+}
+
+__global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
+  const BluGeom g = a.g;
+  const int L2 = g.L2, L = g.L;
+  float2* thi = dyn_lds;
+  float2* tlo = thi + ((L >> TW_LOBITS) > 0 ? (L >> TW_LOBITS) : 1);
+  float2* bufs = tlo + (1 << TW_LOBITS);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & 7, l = lane >> 3;
+  build_tw2(thi, tlo, L);
+  int tb, b;
+  xcd_item_map(L2 / 32, a.batch, tb, b);
+  const int tile = tb * 4 + wave, c0 = tile * 8;
+  float edge = 0.f;
+  float2 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = blu_load_elem(a, b, (l + 8 * k) * L2 + c0 + c, edge);
+  if (a.rader) {                       // one partial per tile, folded by the inverse column pass
+    edge = wave_sum(edge);
+    if (lane == 0) a.edge[(size_t)b * a.nedge + tile] = edge;
+  }
+  __syncthreads();                     // twiddle tables
+  col128_fft(v, bufs + wave * CW_LDS, l, c, 1.0f);
+  // twiddle W_L^{n2 k1}, store [k1][n2]
+  float2* wk = a.work + (size_t)b * L;
+  const int n2 = c0 + c;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k1 = l + 8 * (q >> 3) + 16 * (q & 7);
+    wk[(size_t)k1 * L2 + n2] = cmul(v[q], tw2(thi, tlo, (n2 * k1) & (L - 1), L));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
+  const BluGeom g = a.g;
+  const int L2 = g.L2, L = g.L;
+  float2* bufs = dyn_lds;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & 7, l = lane >> 3;
+  int tb, b;
+  xcd_item_map(L2 / 32, a.batch, tb, b);
+  const int tile = tb * 4 + wave, c0 = tile * 8;
+  const float2* wk = a.work + (size_t)b * L;
+  float2 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = wk[(size_t)(l + 8 * k) * L2 + c0 + c];
+  if (a.rader && tb == 0 && threadIdx.x == 0) blu_edge_fold(a, b);
+  if (a.rader && a.adjoint) {          // bins above (n-1)/2 carry no gradient
+    float2* o = (float2*)a.out + (size_t)b * a.ld_out;
+    for (int k = g.nin + tb * 256 + threadIdx.x; k < a.ld_out; k += (L2 / 32) * 256)
+      o[k] = make_float2(0.f, 0.f);
+  }
+  col128_fft(v, bufs + wave * CW_LDS, l, c, -1.0f);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
+    blu_store_elem(a, b, n1 * L2 + c0 + c, v[q]);
   }
 }
 
@@ -725,8 +883,14 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if ((rc = ensure_dyn_lds(k_blu_col_fwd, lc))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_row, lr))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_col_inv, lc))) return rc;
+  const bool col128 = g.L1 == 128 && g.L2 % 32 == 0 && tc == 8;       // wave-per-tile column kernels
+  const size_t tw2_elems = (size_t)((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS);
   if (stages & 1) {
-    hipLaunchKernelGGL(k_blu_col_fwd, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
+    if (col128)
+      hipLaunchKernelGGL(k_blu_col128_fwd, dim3((g.L2 / 32) * batch), dim3(256),
+                         (tw2_elems + 4 * CW_LDS) * sizeof(float2), s, a);
+    else
+      hipLaunchKernelGGL(k_blu_col_fwd, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 2) {
@@ -740,7 +904,10 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 4) {
-    hipLaunchKernelGGL(k_blu_col_inv, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
+    if (col128)
+      hipLaunchKernelGGL(k_blu_col128_inv, dim3((g.L2 / 32) * batch), dim3(256), 4 * CW_LDS * sizeof(float2), s, a);
+    else
+      hipLaunchKernelGGL(k_blu_col_inv, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
@@ -878,48 +1045,6 @@ __global__ __launch_bounds__(STFT_T) void k_stft_power_bwd(const float* __restri
 #define S4K_PAD(i) ((i) + ((i) >> 4))
 #define S4K_LDS (4096 + 256)
 
-// 16-point DFT, natural order in and out; sgn = +1 forward (e^-), -1 inverse
-__device__ __forceinline__ void bfly16(float2 (&a)[16], float sgn) {
-  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
-  float2 b[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {       // 4-point DFTs over n2 (elements j, j+4, j+8, j+12) -> index q
-    const float2 x0 = a[j], x1 = a[j + 4], x2 = a[j + 8], x3 = a[j + 12];
-    const float2 p = cadd(x0, x2), m = csub(x0, x2), q = cadd(x1, x3), t = csub(x1, x3);
-    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);       // -j t (forward)
-    b[j][0] = cadd(p, q);
-    b[j][1] = cadd(m, jt);
-    b[j][2] = csub(p, q);
-    b[j][3] = csub(m, jt);
-  }
-  // twiddles W16^(j q)
-  auto tw = [&](float2 v, float cr, float ci) {   // v * (cr - i sgn ci)
-    return make_float2(v.x * cr + sgn * v.y * ci, v.y * cr - sgn * v.x * ci);
-  };
-  b[1][1] = tw(b[1][1], c1, s1);   b[1][2] = tw(b[1][2], r, r);     b[1][3] = tw(b[1][3], s1, c1);
-  b[2][1] = tw(b[2][1], r, r);     b[2][2] = tw(b[2][2], 0.f, 1.f); b[2][3] = tw(b[2][3], -r, r);
-  b[3][1] = tw(b[3][1], s1, c1);   b[3][2] = tw(b[3][2], -r, r);    b[3][3] = tw(b[3][3], -c1, -s1);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {       // 4-point DFTs over j -> X[q + 4 s]
-    const float2 x0 = b[0][q], x1 = b[1][q], x2 = b[2][q], x3 = b[3][q];
-    const float2 p = cadd(x0, x2), m = csub(x0, x2), qq = cadd(x1, x3), t = csub(x1, x3);
-    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);
-    a[q] = cadd(p, qq);
-    a[q + 4] = cadd(m, jt);
-    a[q + 8] = csub(p, qq);
-    a[q + 12] = csub(m, jt);
-  }
-}
-// a[u] *= w^u, u = 1..15 (powers by squaring: every factor is at most 3 products away from w)
-__device__ __forceinline__ void twiddle16(float2 (&a)[16], float2 w1) {
-  const float2 w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
-  const float2 w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
-  a[1] = cmul(a[1], w1);  a[2] = cmul(a[2], w2);  a[3] = cmul(a[3], w3);  a[4] = cmul(a[4], w4);
-  a[5] = cmul(a[5], w5);  a[6] = cmul(a[6], w6);  a[7] = cmul(a[7], w7);  a[8] = cmul(a[8], w8);
-  a[9] = cmul(a[9], cmul(w8, w1));   a[10] = cmul(a[10], cmul(w8, w2)); a[11] = cmul(a[11], cmul(w8, w3));
-  a[12] = cmul(a[12], cmul(w8, w4)); a[13] = cmul(a[13], cmul(w8, w5)); a[14] = cmul(a[14], cmul(w8, w6));
-  a[15] = cmul(a[15], cmul(w8, w7));
-}
 // in: a[k] = x[i + 256 k]; out: a[u] = X[i + 256 u].  w1 = (cos, -sin)(2 pi i / 4096).  Every thread of the
 // 256-thread block calls it; buf is free on entry (callers that used it synchronise first) and holds
 // nothing of value on exit.

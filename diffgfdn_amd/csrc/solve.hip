@@ -335,63 +335,110 @@ __device__ __forceinline__ void build4(float2 (&m)[4][4], const float* __restric
     }
 }
 
+// Work item w = k * nblk + blk (block index fastest): consecutive threads then touch consecutive
+// n * 8-byte chunks of the bin-major (K, nblk * n) arrays -- Y, gY and the saved solution are read and
+// written as one linear stream.  (With one block index per workgroup every lane reads 32 bytes out of a
+// different 128-byte line: 4x the traffic; measured 103 us for the 28-block backward at K = 65 537.)
+// The per-block constants (A, delays, gains) come from an LDS table instead of scalar registers.
+#define S4_MAXBLK 64           // blocks whose constants fit the LDS table (28 floats each)
+struct S4Const { float A[16], m[4], ig[4], b[4]; };
+
+__device__ __forceinline__ void s4_stage(const SolveArgs& a, S4Const* tab) {
+  const int n = a.nper;
+  for (int e = threadIdx.x; e < a.nblk * 28; e += blockDim.x) {
+    const int blk = e / 28, f = e - blk * 28;
+    float v = 0.f;
+    if (f < 16) {
+      const int r = f >> 2, c = f & 3;
+      if (r < n && c < n) v = a.A[(size_t)blk * n * n + r * n + c];
+    } else {
+      const int r = (f - 16) & 3, which = (f - 16) >> 2;
+      const int i = blk * n + (r < n ? r : 0);
+      if (which == 0) v = a.delays[i];
+      else if (which == 1) v = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
+      else v = r < n ? a.b[i] : 0.f;
+    }
+    ((float*)&tab[blk])[f] = v;
+  }
+}
+
+// m = diag(zeta) - A from the staged 4 x 4 block (zero-padded); swap / adj as build4
+__device__ __forceinline__ void build4c(float2 (&m)[4][4], const S4Const& cst, int n, bool swap,
+                                        const float2 (&zeta)[4], bool adj) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float av = (swap != adj) ? cst.A[c * 4 + r] : cst.A[r * 4 + c];
+      m[r][c] = make_float2(-av, 0.f);
+      if (r == c) {
+        if (r < n) m[r][c] = make_float2(zeta[r].x - av, adj ? -zeta[r].y : zeta[r].y);
+        else m[r][c] = make_float2(1.f, 0.f);
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_solve4_fwd(SolveArgs a, float2* __restrict__ Y) {
-  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= a.K) return;
+  __shared__ S4Const tab[S4_MAXBLK];
+  s4_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper;
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= (long long)a.K * a.nblk) return;
+  const int k = (int)(w / a.nblk), blk = (int)(w - (long long)k * a.nblk);
+  const S4Const cst = tab[blk];
   float2 zeta[4], rhs[4], m[4][4], y[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int i = blk * n + (r < n ? r : 0);
-    zeta[r] = zeta_pow(a.turns, a.logr, k, a.delays[i], a.inv_gamma ? a.inv_gamma[i] : 1.0f);
-    rhs[r] = make_float2(r < n ? a.b[i] : 0.f, 0.f);
+    zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+    rhs[r] = make_float2(cst.b[r], 0.f);
   }
-  build4(m, a.A + (size_t)blk * n * n, n, a.transpose != 0, zeta, false);
+  build4c(m, cst, n, a.transpose != 0, zeta, false);
   gj4(m, rhs, y);
-  float2* out = Y + (size_t)k * N + blk * n;
+  float2* out = Y + (size_t)w * n;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (r < n) out[r] = y[r];
 }
 
-// partial[(part * nblk + blk) * per + e], per = n n + 2 n, laid out as k_solve_bwd does
+// partial[(part * nblk + blk) * per + e], per = n n + 2 n, laid out as k_solve_bwd does.
+// Work items stride by gridDim.x * S4_ITEMS, a multiple of nblk: a thread keeps its block index.
 __global__ __launch_bounds__(256) void k_solve4_bwd(SolveArgs a, const float2* __restrict__ gY,
                                                     const float2* __restrict__ Ysaved,
-                                                    float* __restrict__ partial) {
-  __shared__ float s_w[4][24];
-  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
-  const float* Ablk = a.A + (size_t)blk * n * n;
+                                                    float* __restrict__ partial, int items) {
+  __shared__ S4Const tab[S4_MAXBLK];
+  extern __shared__ float s4_acc[];          // [items][25]
+  s4_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper, nblk = a.nblk;
   const bool tr = a.transpose != 0;
-  float m_i[4], ig_i[4], b_i[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = blk * n + (r < n ? r : 0);
-    m_i[r] = a.delays[i];
-    ig_i[r] = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
-    b_i[r] = r < n ? a.b[i] : 0.f;
-  }
+  const bool live = (int)threadIdx.x < items;            // items = the largest multiple of nblk <= 256
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  const S4Const cst = tab[blk];
   float acc[24];
 #pragma unroll
   for (int e = 0; e < 24; ++e) acc[e] = 0.f;
-  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
     float2 zpow[4], zeta[4], m[4][4], y[4], w[4], rhs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      zpow[r] = zeta_pow(a.turns, a.logr, k, m_i[r], 1.0f);   // d T_ii / d inv_gamma = z^m
-      zeta[r] = cscale(zpow[r], ig_i[r]);
+      zpow[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], 1.0f);   // d T_ii / d inv_gamma = z^m
+      zeta[r] = cscale(zpow[r], cst.ig[r]);
     }
-    const size_t row = (size_t)k * N + blk * n;
+    const size_t row = ((size_t)k * nblk + blk) * n;
     if (Ysaved) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) y[r] = r < n ? Ysaved[row + r] : make_float2(0.f, 0.f);
     } else {
-      build4(m, Ablk, n, tr, zeta, false);
+      build4c(m, cst, n, tr, zeta, false);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rhs[r] = make_float2(b_i[r], 0.f);
+      for (int r = 0; r < 4; ++r) rhs[r] = make_float2(cst.b[r], 0.f);
       gj4(m, rhs, y);
     }
     // adjoint system T^H w = gY
-    build4(m, Ablk, n, tr, zeta, true);
+    build4c(m, cst, n, tr, zeta, true);
 #pragma unroll
     for (int r = 0; r < 4; ++r) rhs[r] = r < n ? gY[row + r] : make_float2(0.f, 0.f);
     gj4(m, rhs, w);
@@ -411,65 +458,76 @@ __global__ __launch_bounds__(256) void k_solve4_bwd(SolveArgs a, const float2* _
       acc[20 + i] -= w[i].x * yz.x + w[i].y * yz.y;
     }
   }
-  // fixed-order block reduction: wave butterflies, then the 4 wave partials in order
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // fixed-order reduction over the threads of each block index (stride 25: conflict-free rows)
+  if (live) {
 #pragma unroll
-  for (int e = 0; e < 24; ++e) {
-    const float v = wave_sum(acc[e]);
-    if (lane == 0) s_w[wv][e] = v;
+    for (int e = 0; e < 24; ++e) s4_acc[threadIdx.x * 25 + e] = acc[e];
   }
   __syncthreads();
   const int per = n * n + 2 * n;
-  float* out = partial + ((size_t)blockIdx.x * a.nblk + blk) * per;
-  for (int e = threadIdx.x; e < per; e += 256) {
+  for (int o = threadIdx.x; o < nblk * per; o += 256) {
+    const int bq = o / per, e = o - bq * per;
     int src;
     if (e < n * n) src = (e / n) * 4 + (e % n);
     else if (e < n * n + n) src = 16 + (e - n * n);
     else src = 20 + (e - n * n - n);
-    out[e] = ((s_w[0][src] + s_w[1][src]) + s_w[2][src]) + s_w[3][src];
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s4_acc[t * 25 + src];
+    partial[((size_t)blockIdx.x * nblk + bq) * per + e] = sum;
   }
 }
 
+// partial[blk * gridDim.x + part]: energy of the group sums over this block's bins
 __global__ __launch_bounds__(256) void k_subfdn4_energy(SolveArgs a, const float* __restrict__ c,
-                                                        float* __restrict__ partial) {
-  __shared__ float s_red[16];
-  const int blk = blockIdx.y, n = a.nper;
-  float m_i[4], ig_i[4], b_i[4], c_i[4];
+                                                        float* __restrict__ partial, int items) {
+  __shared__ S4Const tab[S4_MAXBLK];
+  __shared__ float s_e[256];
+  s4_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper, nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  const S4Const cst = tab[blk];
+  float c_i[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = blk * n + (r < n ? r : 0);
-    m_i[r] = a.delays[i];
-    ig_i[r] = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
-    b_i[r] = r < n ? a.b[i] : 0.f;
-    c_i[r] = r < n ? c[i] : 0.f;
-  }
+  for (int r = 0; r < 4; ++r) c_i[r] = r < n ? c[blk * n + r] : 0.f;
   float acc = 0.f;
-  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
     float2 zeta[4], m[4][4], y[4], rhs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      zeta[r] = zeta_pow(a.turns, a.logr, k, m_i[r], ig_i[r]);
-      rhs[r] = make_float2(b_i[r], 0.f);
+      zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+      rhs[r] = make_float2(cst.b[r], 0.f);
     }
-    build4(m, a.A + (size_t)blk * n * n, n, a.transpose != 0, zeta, false);
+    build4c(m, cst, n, a.transpose != 0, zeta, false);
     gj4(m, rhs, y);
     float2 s = make_float2(0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s.x += c_i[r] * y[r].x; s.y += c_i[r] * y[r].y; }
     acc += s.x * s.x + s.y * s.y;
   }
-  acc = block_sum(acc, s_red);
-  if (threadIdx.x == 0) partial[(size_t)blk * gridDim.x + blockIdx.x] = acc;
+  s_e[threadIdx.x] = live ? acc : 0.f;
+  __syncthreads();
+  for (int bq = threadIdx.x; bq < nblk; bq += 256) {
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s_e[t];
+    partial[(size_t)bq * gridDim.x + blockIdx.x] = sum;
+  }
 }
 
 // number of 256-bin slices a reducing thread-per-system launch cuts K into: enough blocks to fill the
 // chip (>= ~1024 with the nblk blocks of the y dimension), at most GFDN_PARTIAL_BLOCKS
+#define S4_MAX_PARTS 2048       // partial-sum slots of the reducing thread-per-system launches
+static int solve4_items(int nblk) { return (256 / nblk) * nblk; }
 static int solve4_parts(int K, int nblk) {
-  const int full = (K + 255) / 256;
-  int want = (1024 + nblk - 1) / nblk;
-  if (want < 8) want = 8;
-  int parts = full < want ? full : want;
-  if (parts > GFDN_PARTIAL_BLOCKS) parts = GFDN_PARTIAL_BLOCKS;
+  const int rows = 256 / nblk;                       // bins one workgroup covers per sweep
+  const int full = (K + rows - 1) / rows;
+  // ~2 bins per thread, at least 1024 workgroups when there is that much work
+  int parts = (K + 2 * rows - 1) / (2 * rows);
+  if (parts < 1024) parts = full < 1024 ? full : 1024;
+  if (parts > S4_MAX_PARTS) parts = S4_MAX_PARTS;
   return parts;
 }
 
@@ -499,8 +557,9 @@ extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, in
   const int spb = 256 / np;
   dim3 grid((K + spb - 1) / spb, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (np == 4) {
-    hipLaunchKernelGGL(k_solve4_fwd, dim3((K + 255) / 256, nblk), block, 0, s, a, (float2*)Y);
+  if (np == 4 && nblk <= S4_MAXBLK) {
+    const long long items = (long long)K * nblk;
+    hipLaunchKernelGGL(k_solve4_fwd, dim3((unsigned)((items + 255) / 256)), block, 0, s, a, (float2*)Y);
     GFDN_LAUNCH_CHECK();
     return 0;
   }
@@ -515,7 +574,8 @@ extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, in
 }
 
 extern "C" size_t gfdn_solve_bwd_work_bytes(int nblk, int nper) {
-  return (size_t)GFDN_PARTIAL_BLOCKS * nblk * (nper * nper + 2 * nper) * sizeof(float);
+  const int parts = nper <= 4 ? S4_MAX_PARTS : GFDN_PARTIAL_BLOCKS;
+  return (size_t)parts * nblk * (nper * nper + 2 * nper) * sizeof(float);
 }
 
 extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
@@ -530,12 +590,23 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
-  if (np == 4) nparts = solve4_parts(K, nblk);
+  const bool lin = np == 4 && nblk <= S4_MAXBLK;
+  if (lin) nparts = solve4_parts(K, nblk);
   dim3 grid(nparts, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
+  if (lin) {
+    const int items = solve4_items(nblk);
+    hipLaunchKernelGGL(k_solve4_bwd, dim3(nparts), block, (size_t)items * 25 * sizeof(float), s, a,
+                       (const float2*)gY, (const float2*)Y, partial, items);
+    GFDN_LAUNCH_CHECK();
+    const int tot4 = nblk * (nper * nper + 2 * nper);
+    hipLaunchKernelGGL(k_solve_bwd_finish, dim3(tot4), dim3(256), 0, s, partial, nparts, nblk, nper, gA, gb, ginv_gamma);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   switch (np) {
-    case 4: hipLaunchKernelGGL(k_solve4_bwd, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    case 4: hipLaunchKernelGGL(k_solve_bwd<4>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     case 8: hipLaunchKernelGGL(k_solve_bwd<8>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     case 16: hipLaunchKernelGGL(k_solve_bwd<16>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     default: hipLaunchKernelGGL(k_solve_bwd<32>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
@@ -606,7 +677,7 @@ __global__ __launch_bounds__(64) void k_subfdn_rescale(const float* __restrict__
 }
 
 extern "C" size_t gfdn_subfdn_normalize_work_bytes(int G) {
-  return (size_t)G * GFDN_PARTIAL_BLOCKS * sizeof(float);
+  return (size_t)G * S4_MAX_PARTS * sizeof(float);
 }
 
 extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, int K, int G, int nper,
@@ -620,12 +691,20 @@ extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, in
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
-  if (np == 4) nparts = solve4_parts(K, G);
+  const bool lin = np == 4 && G <= S4_MAXBLK;
+  if (lin) nparts = solve4_parts(K, G);
   dim3 grid(nparts, G), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
+  if (lin) {
+    hipLaunchKernelGGL(k_subfdn4_energy, dim3(nparts), block, 0, s, a, (const float*)c, partial, solve4_items(G));
+    GFDN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_subfdn_rescale, dim3(G), dim3(64), 0, s, (const float*)partial, nparts, K, nper, b, c, energy);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   switch (np) {
-    case 4: hipLaunchKernelGGL(k_subfdn4_energy, grid, block, 0, s, a, (const float*)c, partial); break;
+    case 4: hipLaunchKernelGGL(k_subfdn_energy<4>, grid, block, 0, s, a, (const float*)c, partial); break;
     case 8: hipLaunchKernelGGL(k_subfdn_energy<8>, grid, block, 0, s, a, (const float*)c, partial); break;
     case 16: hipLaunchKernelGGL(k_subfdn_energy<16>, grid, block, 0, s, a, (const float*)c, partial); break;
     default: hipLaunchKernelGGL(k_subfdn_energy<32>, grid, block, 0, s, a, (const float*)c, partial); break;
