@@ -42,6 +42,10 @@ SIGNATURES = {
     "gfdn_mlp_gains_banded_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_subfdn_normalize_work_bytes": (c_size_t, [c_int]),
     "gfdn_subfdn_normalize": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_subfdn_colorless_work_bytes": (c_size_t, [c_int, c_int]),
+    "gfdn_subfdn_colorless_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_spectral_stats_binmajor": (c_int, [_P, c_int, c_int, _P, c_int, c_float, _P, _P, _P, _P]),
+    "gfdn_subfdn_colorless_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),
     "gfdn_normalize_io": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "gfdn_bluestein_table_bytes": (c_size_t, [c_int]),

@@ -37,7 +37,8 @@ from torch import nn
 
 from . import hip_ops as ops
 from .config import CouplingMatrixType, TrainerConfig
-from .functional import ColorlessTerms, FrequencyGrid, MlpGains, OrthoParam, OutputStage, ResolventSolve
+from .functional import (ColorlessTerms, FrequencyGrid, MlpGains, OrthoParam, OutputStage, ResolventSolve,
+                         SubFdnColorless)
 from .losses import decay_losses, edc_loss
 from .optim import FlatAdam
 
@@ -341,26 +342,51 @@ class BandBankTrainer:
         Bper = Btot // nb
         main = torch.cuda.current_stream()
         side = self._stream('_side')
-        if side is not None:
-            side.wait_stream(main)
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            if normalize_first:
-                self.normalize(data)
-            Q, QQ = bank.rotations()
+        fused = bank.num_delay_lines_per_group <= 4 and nb * bank.num_groups <= 64
+        if fused:
+            # colorless branch = one node on the side stream: [normalize +] sub-FDN solve -> (main may go on)
+            # -> spectral / sparsity terms -> their gradients; the rotations lead the main stream instead
             if side is not None:
+                side.wait_stream(main)
+            Q, QQ = bank.rotations()
+            rot_done = None
+            if side is not None:
+                rot_done = torch.cuda.Event()
+                rot_done.record(main)
                 ready = torch.cuda.Event()
-                ready.record(side)
-            S = bank.sub_fdn_group_sums(z)
-            extra, spec, sparse = ColorlessTerms.apply(S, Q, cfg.use_asym_spectral_loss, cfg.spectral_loss_weight,
-                                                       cfg.sparsity_loss_weight, 1.0 / self.world_size, True, nb)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if side is not None:
+                    Q.record_stream(side)
+                extra, spec, sparse, _ = SubFdnColorless.apply(
+                    bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q,
+                    FrequencyGrid.of(z), bank.delays, normalize_first, cfg.use_asym_spectral_loss,
+                    cfg.spectral_loss_weight, cfg.sparsity_loss_weight, 1.0 / self.world_size, nb,
+                    torch.is_grad_enabled(),
+                    (lambda: ready.record(side)) if side is not None else None,
+                    (lambda: side.wait_event(rot_done)) if side is not None else None)
+        else:
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if normalize_first:
+                    self.normalize(data)
+                Q, QQ = bank.rotations()
+                if side is not None:
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                S = bank.sub_fdn_group_sums(z)
+                extra, spec, sparse = ColorlessTerms.apply(S, Q, cfg.use_asym_spectral_loss,
+                                                           cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
+                                                           1.0 / self.world_size, True, nb)
         rgain = bank.group_gains(data['norm_listener_position'], rows)
         if side is not None:
             main.wait_event(ready)
-            # QQ was allocated on the side stream and is read by the main stream's solve (forward AND
-            # backward): without this its block returns to the side stream's pool the moment autograd
-            # drops it, and a side-stream kernel of the colorless backward may overwrite it while the
-            # main solve backward still reads it (seen as wrong dL/dM, dL/db under graph replay)
-            QQ.record_stream(main)
+            # a tensor allocated on one stream and read on the other must be recorded there: otherwise its
+            # block returns to the allocating stream's pool the moment autograd drops it and a kernel of
+            # that stream may overwrite it while the other stream still reads it (seen as wrong dL/dM,
+            # dL/db under graph replay when QQ came from the side stream)
+            if not fused:
+                QQ.record_stream(main)
         K = z.shape[-1]
         Ku = (K + 1) // 2 if K % 2 == 1 else K          # irfft(X, n = K) reads bins 0..(K-1)/2 only
         Y = bank.delay_line_responses(z[:Ku], QQ)

@@ -676,6 +676,253 @@ __global__ __launch_bounds__(64) void k_subfdn_rescale(const float* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Colorless side branch in three launches (n <= 4): the un-damped sub-FDN responses feed BOTH
+// Trainer.normalize (trainer.py:317-332: E_g = mean_k |Hout[k, g]|^2, b, c /= E_g^(1/4)) and the spectral
+// loss of the step that follows (trainer.py:298-304) -- and since y = (D - M_g)^-1 b is linear in b, the
+// responses after the rescale are the ones before it times a per-group constant:
+//      y'_n = y_n / d_g,   Hout'[k, g] = Hout[k, g] / d_g^2,   d_g = E_g^(1/4).
+// So ONE solve per step serves both (the step used to solve the sub-FDNs twice, write Y, read it back in
+// the output stage, and run the generic output-stage backward on G "receivers"):
+//   forward : y (saved, raw), group sums S[k][g] (bin-major, raw), energy partials        -> rescale
+//   stats   : loss_g and dL/dS' on S' = S / d_g^2
+//   backward: adjoint solve with rhs c'_n dL/dS', on y' = y / d_g: dL/dM_g, dL/db', dL/dc'
+// `energy` == NULL everywhere means "no rescale happened" (d_g = 1): the plain colorless forward.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_subfdn4_fwd(SolveArgs a, const float* __restrict__ c,
+                                                     float2* __restrict__ Y, float2* __restrict__ S,
+                                                     float* __restrict__ partial, int items) {
+  __shared__ S4Const tab[S4_MAXBLK];
+  __shared__ float s_e[256];
+  s4_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper, nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  const S4Const cst = tab[blk];
+  float c_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c_i[r] = r < n ? c[blk * n + r] : 0.f;
+  float acc = 0.f;
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
+    float2 zeta[4], m[4][4], y[4], rhs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+      rhs[r] = make_float2(cst.b[r], 0.f);
+    }
+    build4c(m, cst, n, false, zeta, false);
+    gj4(m, rhs, y);
+    const size_t w = (size_t)k * nblk + blk;
+    float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r < n) Y[w * n + r] = y[r];
+      s.x += c_i[r] * y[r].x;
+      s.y += c_i[r] * y[r].y;
+    }
+    S[w] = s;
+    acc += s.x * s.x + s.y * s.y;
+  }
+  s_e[threadIdx.x] = live ? acc : 0.f;
+  __syncthreads();
+  for (int bq = threadIdx.x; bq < nblk; bq += 256) {
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s_e[t];
+    partial[(size_t)bq * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
+// energy[g] = sum_p partial[g][p] / K;  with b, c given: b_n, c_n /= energy_g^(1/4) in place
+__global__ __launch_bounds__(256) void k_subfdn_energy_finish(const float* __restrict__ partial, int nparts,
+                                                              int K, int nper, float* __restrict__ b,
+                                                              float* __restrict__ c,
+                                                              float* __restrict__ energy) {
+  __shared__ float s_red[16];
+  const int g = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)g * nparts + p];
+  s = block_sum(s, s_red);
+  const float E = s / (float)K;
+  if (energy && threadIdx.x == 0) energy[g] = E;
+  if (b && c) {
+    const float d = powf(E, 0.25f);
+    for (int i = threadIdx.x; i < nper; i += 256) {
+      b[g * nper + i] /= d;
+      c[g * nper + i] /= d;
+    }
+  }
+}
+
+// S (K, G) bin-major, raw; S' = S / sqrt(energy_g) (energy NULL: S' = S).
+//   loss partial[g][part] = sum over this block's bins of (|S'| - 1)^p / K;  gS[k][g] = scale dloss_g/dS'
+__global__ __launch_bounds__(256) void k_spectral_stats_bm(const float2* __restrict__ S, int G, int K,
+                                                           const float* __restrict__ energy, int asym,
+                                                           float scale, float* __restrict__ partial,
+                                                           float2* __restrict__ gS, int items) {
+  __shared__ float s_e[256];
+  const bool live = (int)threadIdx.x < items;
+  const int g = live ? threadIdx.x % G : 0;
+  const int krow = threadIdx.x / G, rows = items / G;
+  const float sc = energy ? 1.0f / sqrtf(energy[g]) : 1.0f;     // 1 / d_g^2
+  const float invK = 1.0f / (float)K;
+  float l = 0.f;
+  for (int k = blockIdx.x * rows + krow; live && k < K; k += gridDim.x * rows) {
+    const size_t w = (size_t)k * G + g;
+    float2 s = S[w];
+    s.x *= sc; s.y *= sc;
+    const float p = s.x * s.x + s.y * s.y;
+    const float mag = sqrtf(p);
+    const float d = mag - 1.0f;
+    const float d2 = d * d;
+    const bool four = asym && (d > 1.0f);
+    l += four ? d2 * d2 : d2;
+    if (gS) {
+      const float dl = four ? 4.0f * d2 * d : 2.0f * d;   // d loss / d |S'|
+      const float f = (mag > 0.f) ? scale * invK * dl / mag : 0.f;
+      gS[w] = make_float2(f * s.x, f * s.y);
+    }
+  }
+  s_e[threadIdx.x] = live ? l * invK : 0.f;
+  __syncthreads();
+  for (int bq = threadIdx.x; bq < G; bq += 256) {
+    float sum = 0.f;
+    for (int t = bq; t < items; t += G) sum += s_e[t];
+    partial[(size_t)bq * gridDim.x + blockIdx.x] = sum;
+  }
+}
+__global__ __launch_bounds__(256) void k_rows_sum256(const float* __restrict__ partial, int nparts,
+                                                     float* __restrict__ out) {
+  __shared__ float s_red[16];
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)blockIdx.x * nparts + p];
+  s = block_sum(s, s_red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// partial[(part * nblk + blk) * per + e], per = n n + 2 n: [gM | gb | gc]
+__global__ __launch_bounds__(256) void k_subfdn4_bwd(SolveArgs a, const float* __restrict__ c,
+                                                     const float* __restrict__ energy,
+                                                     const float2* __restrict__ Yraw,
+                                                     const float2* __restrict__ gS,
+                                                     float* __restrict__ partial, int items) {
+  __shared__ S4Const tab[S4_MAXBLK];
+  extern __shared__ float s4_acc[];          // [items][25]
+  s4_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper, nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  const S4Const cst = tab[blk];
+  const float ys = energy ? 1.0f / powf(energy[blk], 0.25f) : 1.0f;      // y' = y / d_g
+  float c_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c_i[r] = r < n ? c[blk * n + r] : 0.f;
+  float acc[24];
+#pragma unroll
+  for (int e = 0; e < 24; ++e) acc[e] = 0.f;
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
+    float2 zeta[4], m[4][4], y[4], w[4], rhs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+    const size_t wi = (size_t)k * nblk + blk;
+    const float2 gs = gS[wi];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      y[r] = r < n ? cscale(Yraw[wi * n + r], ys) : make_float2(0.f, 0.f);
+      rhs[r] = cscale(gs, c_i[r]);                     // dL/dy'_r = c'_r dL/dS'
+    }
+    build4c(m, cst, n, false, zeta, true);             // T^H w = dL/dy'
+    gj4(m, rhs, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i * 4 + j] += w[i].x * y[j].x + w[i].y * y[j].y;   // gM_ij = Re(w_i conj(y'_j))
+      acc[16 + i] += w[i].x;                                                            // gb'_i = Re(w_i)
+      acc[20 + i] += gs.x * y[i].x + gs.y * y[i].y;                                     // gc'_i = Re(conj(gS') y'_i)
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 24; ++e) s4_acc[threadIdx.x * 25 + e] = acc[e];
+  }
+  __syncthreads();
+  const int per = n * n + 2 * n;
+  for (int o = threadIdx.x; o < nblk * per; o += 256) {
+    const int bq = o / per, e = o - bq * per;
+    int src;
+    if (e < n * n) src = (e / n) * 4 + (e % n);
+    else if (e < n * n + n) src = 16 + (e - n * n);
+    else src = 20 + (e - n * n - n);
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s4_acc[t * 25 + src];
+    partial[((size_t)blockIdx.x * nblk + bq) * per + e] = sum;
+  }
+}
+
+extern "C" size_t gfdn_subfdn_colorless_work_bytes(int G, int nper) {
+  return (size_t)S4_MAX_PARTS * G * (nper * nper + 2 * nper) * sizeof(float);
+}
+
+extern "C" int gfdn_subfdn_colorless_fwd(const double* turns, const double* logr, int K, int G, int nper,
+                                         const float* M, const float* delays, float* b, float* c,
+                                         int normalize, float* Y, float* S, float* energy, void* work,
+                                         void* stream) {
+  if (!turns || !M || !delays || !b || !c || !Y || !S || !energy || !work) return GFDN_E_BADARG;
+  if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 4 || G > S4_MAXBLK) return GFDN_E_UNSUPPORTED;
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0};
+  const int nparts = solve4_parts(K, G);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_subfdn4_fwd, dim3(nparts), dim3(256), 0, s, a, (const float*)c, (float2*)Y, (float2*)S,
+                     (float*)work, solve4_items(G));
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_subfdn_energy_finish, dim3(G), dim3(256), 0, s, (const float*)work, nparts, K, nper,
+                     normalize ? b : nullptr, normalize ? c : nullptr, energy);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_spectral_stats_binmajor(const float* S, int G, int K, const float* energy, int asym,
+                                            float scale, float* loss, float* gS, void* work, void* stream) {
+  if (!S || !loss || !work || G <= 0 || K <= 0) return GFDN_E_BADARG;
+  if (G > 256) return GFDN_E_UNSUPPORTED;
+  const int nparts = solve4_parts(K, G);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_spectral_stats_bm, dim3(nparts), dim3(256), 0, s, (const float2*)S, G, K, energy, asym,
+                     scale, (float*)work, (float2*)gS, solve4_items(G));
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rows_sum256, dim3(G), dim3(256), 0, s, (const float*)work, nparts, loss);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr, int K, int G, int nper,
+                                         const float* M, const float* delays, const float* b,
+                                         const float* c, const float* energy, const float* Y,
+                                         const float* gS, float* gM, float* gb, float* gc, void* work,
+                                         void* stream) {
+  if (!turns || !M || !delays || !b || !c || !Y || !gS || !gM || !gb || !gc || !work) return GFDN_E_BADARG;
+  if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 4 || G > S4_MAXBLK) return GFDN_E_UNSUPPORTED;
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0};
+  const int nparts = solve4_parts(K, G), items = solve4_items(G);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_subfdn4_bwd, dim3(nparts), dim3(256), (size_t)items * 25 * sizeof(float), s, a, c, energy,
+                     (const float2*)Y, (const float2*)gS, (float*)work, items);
+  GFDN_LAUNCH_CHECK();
+  // the record layout [n n | n | n] of k_solve_bwd_finish, with gc in the third slot
+  hipLaunchKernelGGL(k_solve_bwd_finish, dim3(G * (nper * nper + 2 * nper)), dim3(256), 0, s, (const float*)work,
+                     nparts, G, nper, gM, gb, gc);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t gfdn_subfdn_normalize_work_bytes(int G) {
   return (size_t)G * S4_MAX_PARTS * sizeof(float);
 }

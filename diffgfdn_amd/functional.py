@@ -224,6 +224,51 @@ class ColorlessTerms(torch.autograd.Function):
         return gS * g.to(gS.dtype), gQ * g, None, None, None, None, None, None
 
 
+class SubFdnColorless(torch.autograd.Function):
+    """The whole colorless side branch as ONE node (n <= 4; include/diffgfdn_hip.h "colorless side branch,
+    fused"): [normalize +] sub-FDN responses -> group sums -> spectral losses + sparsity -> their gradients.
+    Inputs M (G, n, n) raw blocks, b, c (N,) gains, Q (G, n, n) rotations (for the sparsity term).
+    ``normalize``: Trainer.normalize (trainer.py:317-332) is applied first, IN PLACE on b.data / c.data, from
+    the very responses the loss then uses (one solve instead of two).  Gradients are produced in the forward
+    (the loss is a scalar head back-propagated with unit gradient); the backward only hands them over.
+    ``after_solve``: optional callable run right after the forward solve + rescale were launched (the trainer
+    records the event the main branch waits on); ``before_terms``: run before Q is first read."""
+
+    @staticmethod
+    def forward(ctx, M, b, c, Q, grid: FrequencyGrid, delays, normalize, asym, w_spec, w_sparse, inv_world,
+                nbands, want_grad, after_solve=None, before_terms=None):
+        # (grad mode is always off inside Function.forward: the caller passes torch.is_grad_enabled())
+        need = want_grad and (M.requires_grad or b.requires_grad or c.requires_grad)
+        Y, S, energy = ops.subfdn_colorless_fwd(grid.turns, grid.logr, M, delays, b.data, c.data, normalize)
+        if after_solve is not None:
+            after_solve()
+        en = energy if normalize else None
+        loss_g, gS = ops.spectral_stats_binmajor(S, en, asym, w_spec * inv_world, want_grad=need)
+        if before_terms is not None:
+            before_terms()
+        out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need, nbands=nbands)
+        grads = (None, None, None)
+        if need:
+            grads = ops.subfdn_colorless_bwd(grid.turns, grid.logr, M, delays, b.data, c.data, en, Y, gS)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(gQ, *[g for g in grads if g is not None])
+        ctx.shapes = (M.shape, b.shape, c.shape)
+        if nbands > 1:
+            total, spec, sparse = out[:, 0], out[:, 1], out[:, 2]
+        else:
+            total, spec, sparse = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(spec, sparse, energy)
+        return total, spec, sparse, energy
+
+    @staticmethod
+    def backward(ctx, g, _g1, _g2, _g3):
+        if g is None or len(ctx.saved_tensors) < 4:
+            return (None,) * 15
+        gQ, gM, gb, gc = ctx.saved_tensors         # unit upstream gradient by contract (see forward)
+        sM, sb, sc = ctx.shapes
+        return (gM.view(sM), gb.view(sb), gc.view(sc), gQ) + (None,) * 11
+
+
 class IrfftOdd(torch.autograd.Function):
     """x = torch.fft.irfft(X, n) for odd n (losses.py:207-213, :442-445)."""
 

@@ -311,6 +311,60 @@ def subfdn_normalize(turns, logr, M, delays, b, c, want_energy: bool = False):
     return energy
 
 
+def subfdn_colorless_fwd(turns, logr, M, delays, b, c, normalize: bool):
+    """Fused sub-FDN forward of the colorless branch (nper <= 4): raw responses Y (K, G*nper), raw group sums
+    S (K, G) BIN-MAJOR, energy (G) = mean_k |S|^2; ``normalize``: b, c /= energy^(1/4) IN PLACE."""
+    _need_gpu(turns, M, b, c)
+    M, delays = _f(M), _f(delays)
+    G, nper, _ = M.shape
+    for t in (b, c):
+        if t.dtype != _f32 or not t.is_contiguous() or t.numel() != G * nper:
+            raise RuntimeError("subfdn_colorless_fwd: gains must be contiguous float32 of G*nper elements")
+    K = turns.numel()
+    lib = _lib.load()
+    Y = torch.empty((K, G * nper), dtype=_c64, device=M.device)
+    S = torch.empty((K, G), dtype=_c64, device=M.device)
+    energy = torch.empty(G, dtype=_f32, device=M.device)
+    work = _work(lib.gfdn_subfdn_colorless_work_bytes(G, nper), M.device)
+    _lib.check(lib.gfdn_subfdn_colorless_fwd(_p(turns), _p(logr), K, G, nper, _p(M), _p(delays), _p(b), _p(c),
+                                             int(bool(normalize)), _p(Y), _p(S), _p(energy), _p(work), _stream()),
+               "gfdn_subfdn_colorless_fwd")
+    return Y, S, energy
+
+
+def spectral_stats_binmajor(S, energy, asym: bool, scale: float = 1.0, want_grad: bool = True):
+    """S (K, G) bin-major raw group sums, energy (G) or None -> loss (G,) on S' = S / sqrt(energy), gS (K, G)."""
+    _need_gpu(S)
+    S = _c(S)
+    K, G = S.shape
+    loss = torch.empty(G, dtype=_f32, device=S.device)
+    gS = torch.empty_like(S) if want_grad else None
+    lib = _lib.load()
+    work = _work(lib.gfdn_subfdn_colorless_work_bytes(G, 4), S.device)
+    _lib.check(lib.gfdn_spectral_stats_binmajor(_p(S), G, K, _p(energy), int(asym), float(scale), _p(loss), _p(gS),
+                                                _p(work), _stream()), "gfdn_spectral_stats_binmajor")
+    return loss, gS
+
+
+def subfdn_colorless_bwd(turns, logr, M, delays, b, c, energy, Y, gS):
+    """-> gM (G,nper,nper), gb (N,), gc (N,) of sum_g <gS[:, g], S'[:, g]> at the current (rescaled) b, c."""
+    _need_gpu(turns, M, Y, gS)
+    M, delays, b, c = _f(M), _f(delays), _f(b), _f(c)
+    G, nper, _ = M.shape
+    K = turns.numel()
+    if tuple(Y.shape) != (K, G * nper) or tuple(gS.shape) != (K, G):
+        raise RuntimeError("subfdn_colorless_bwd: Y (K, G*nper) and gS (K, G) expected")
+    lib = _lib.load()
+    gM = torch.empty_like(M)
+    gb = torch.empty(G * nper, dtype=_f32, device=M.device)
+    gc = torch.empty_like(gb)
+    work = _work(lib.gfdn_subfdn_colorless_work_bytes(G, nper), M.device)
+    _lib.check(lib.gfdn_subfdn_colorless_bwd(_p(turns), _p(logr), K, G, nper, _p(M), _p(delays), _p(b), _p(c),
+                                             _p(energy), _p(_c(Y)), _p(_c(gS)), _p(gM), _p(gb), _p(gc), _p(work),
+                                             _stream()), "gfdn_subfdn_colorless_bwd")
+    return gM, gb, gc
+
+
 def normalize_io(energy, b, c, G: int, nper: int):
     """In place: b[n], c[n] /= energy[group(n)]^(1/4)  (b, c float32 contiguous, N = G*nper)."""
     _need_gpu(energy, b, c)

@@ -176,6 +176,28 @@ int gfdn_subfdn_normalize(const double* turns, const double* logr, int K, int G,
                           const float* M, const float* delays, float* b, float* c, float* energy,
                           void* work, void* stream);
 
+/* ---- colorless side branch, fused (nper <= 4, G <= 64 blocks; bands stack as more blocks)  --------
+ * Trainer.normalize and the spectral loss of the step that follows it read the SAME un-damped sub-FDN
+ * responses (model.py:209-252) up to a per-group constant: y = (D - M_g)^-1 b_g is linear in b, so after
+ * b, c /= d_g (d_g = E_g^(1/4), trainer.py:323-332) the responses are y / d_g and Hout[:, g] / d_g^2.
+ *   fwd  : Y (K, G*nper) complex64 raw responses, S (K, G) complex64 raw group sums sum_{n in g} c_n y_n
+ *          (BIN-MAJOR), energy (G) = mean_k |S[k][g]|^2; normalize != 0: b, c /= energy^(1/4) in place.
+ *   stats: loss (G) = mean_k (|S'| - 1)^p (p as gfdn_spectral_stats) on S' = S / sqrt(energy_g)
+ *          (energy == NULL: S' = S); gS (K, G) complex64 = scale * dloss_g / dS', or NULL.
+ *   bwd  : with the CURRENT (rescaled) b, c and the energy the forward returned (NULL if it did not
+ *          normalize): gM (G, nper, nper), gb (N), gc (N) of sum_g <gS[:, g], S'[:, g]>.
+ * work: gfdn_subfdn_colorless_work_bytes(G, nper) for each call.                                     */
+size_t gfdn_subfdn_colorless_work_bytes(int G, int nper);
+int gfdn_subfdn_colorless_fwd(const double* turns, const double* logr, int K, int G, int nper,
+                              const float* M, const float* delays, float* b, float* c, int normalize,
+                              float* Y_c64, float* S_c64, float* energy, void* work, void* stream);
+int gfdn_spectral_stats_binmajor(const float* S_c64, int G, int K, const float* energy, int asym,
+                                 float scale, float* loss, float* gS_c64, void* work, void* stream);
+int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr, int K, int G, int nper,
+                              const float* M, const float* delays, const float* b, const float* c,
+                              const float* energy, const float* Y_c64, const float* gS_c64, float* gM,
+                              float* gb, float* gc, void* work, void* stream);
+
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's
  * algorithm on power-of-two FFTs of length L >= n + (n-1)/2.

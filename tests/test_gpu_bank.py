@@ -225,10 +225,11 @@ def test_graphed_bank_step_equals_eager_bank_step():
     want = []
     for i, s in enumerate(sel_steps):
         b = sds2.collate(sds2.global_rows(s))
-        tr2.normalize(b)
         tr2.optimizer.zero_grad(set_to_none=True)
         mw = torch.tensor(philox_mask(777, i, length, 1.0 / 4)[0], device=DEV)
-        losses = tr2._step_losses(b, mask_prenorm=mw, defer_total=True)
+        # normalize inside the step, as the captured graph does (the fused colorless branch rescales b, c
+        # from the same sub-FDN solve the loss uses; a separate tr2.normalize() differs in the last bits)
+        losses = tr2._step_losses(b, mask_prenorm=mw, defer_total=True, normalize_first=True)
         heads = losses.pop("_heads")
         torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
         tr2.optimizer.pack_grads()
@@ -278,3 +279,41 @@ def test_bank_training_loop_checkpoints_and_band_freeze(tmp_path):
     for k, v in nets[1].state_dict().items():
         assert torch.equal(v, frozen_after_norm[k]), k
     assert not torch.equal(nets[0].state_dict()["feedback_loop.M"], before[0]["feedback_loop.M"])
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_fused_colorless_branch_equals_separate_kernels(normalize):
+    """gfdn_subfdn_colorless_fwd / spectral_stats_binmajor / subfdn_colorless_bwd against the chain they replace:
+    subfdn_normalize, solve (raw M), output stage on eye(G), spectral statistics and the two backward kernels."""
+    from diffgfdn_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    nblk, n, K = 6, 4, 3001
+    N = nblk * n
+    z = torch.tensor(np.exp(1j * 2 * np.pi * np.fft.rfftfreq(2 * (K - 1))), device=DEV)
+    turns, _ = ops.zprep(z)
+    M = ((2 * torch.rand(nblk, n, n, generator=g) - 1) / 2).to(DEV)
+    delays = torch.tensor([173., 181, 191, 193] * nblk, device=DEV) + torch.arange(N, device=DEV)
+    b0 = ((2 * torch.randn(N, generator=g) - 1) / N).to(DEV)
+    c0 = ((2 * torch.randn(N, generator=g) - 1) / N).to(DEV)
+    ones = torch.ones(N, device=DEV)
+    eye = torch.eye(nblk, device=DEV)
+    # separate chain
+    b, c = b0.clone(), c0.clone()
+    if normalize:
+        ops.subfdn_normalize(turns, None, M, delays, b, c)
+    Y = ops.solve_fwd(turns, None, M, delays, ones, b)
+    S = ops.compose_fwd(Y, c, eye, n)                                   # (nblk, K)
+    _, loss, gS = ops.spectral_stats(S, True, 0.7, True)
+    gY, gc, _ = ops.compose_bwd(Y, c, eye, n, gS)
+    gM, gb, _ = ops.solve_bwd(turns, None, M, delays, ones, b, gY, Y=Y)
+    # fused
+    b2, c2 = b0.clone(), c0.clone()
+    Y2, S2, en = ops.subfdn_colorless_fwd(turns, None, M, delays, b2, c2, normalize)
+    loss2, gS2 = ops.spectral_stats_binmajor(S2, en if normalize else None, True, 0.7, True)
+    gM2, gb2, gc2 = ops.subfdn_colorless_bwd(turns, None, M, delays, b2, c2, en if normalize else None, Y2, gS2)
+    assert rel_err(b2.cpu(), b.cpu()) < 2e-6 and rel_err(c2.cpu(), c.cpu()) < 2e-6
+    assert rel_err(loss2.cpu(), loss.cpu()) < 1e-5
+    assert rel_err(torch.view_as_real(gS2.T.contiguous()).cpu(), torch.view_as_real(gS).cpu()) < 1e-5
+    assert rel_err(gM2.cpu(), gM.cpu()) < 2e-5
+    assert rel_err(gb2.cpu(), gb.cpu()) < 2e-5
+    assert rel_err(gc2.cpu(), gc.cpu()) < 2e-5
