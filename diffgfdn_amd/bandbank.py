@@ -344,26 +344,26 @@ class BandBankTrainer:
         side = self._stream('_side')
         fused = bank.num_delay_lines_per_group <= 4 and nb * bank.num_groups <= 64
         if fused:
-            # colorless branch = one node on the side stream: [normalize +] sub-FDN solve -> (main may go on)
-            # -> spectral / sparsity terms -> their gradients; the rotations lead the main stream instead
+            # the sub-FDN solve (+ rescale of b, c) leads the MAIN stream: everything of the main branch hangs
+            # on it; the rotations and the gain network lead the side stream, followed there by the tail of
+            # the colorless node (statistics, loss terms, adjoint kernel)
+            rgain = None
             if side is not None:
                 side.wait_stream(main)
-            Q, QQ = bank.rotations()
-            rot_done = None
-            if side is not None:
-                rot_done = torch.cuda.Event()
-                rot_done.record(main)
-                ready = torch.cuda.Event()
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                if side is not None:
-                    Q.record_stream(side)
-                extra, spec, sparse, _ = SubFdnColorless.apply(
-                    bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q,
-                    FrequencyGrid.of(z), bank.delays, normalize_first, cfg.use_asym_spectral_loss,
-                    cfg.spectral_loss_weight, cfg.sparsity_loss_weight, 1.0 / self.world_size, nb,
-                    torch.is_grad_enabled(),
-                    (lambda: ready.record(side)) if side is not None else None,
-                    (lambda: side.wait_event(rot_done)) if side is not None else None)
+                with torch.cuda.stream(side):
+                    Q, QQ = bank.rotations()
+                    rot_done = torch.cuda.Event()
+                    rot_done.record(side)
+                    rgain = bank.group_gains(data['norm_listener_position'], rows)
+                    mlp_done = torch.cuda.Event()
+                    mlp_done.record(side)
+            else:
+                Q, QQ = bank.rotations()
+            extra, spec, sparse, _ = SubFdnColorless.apply(
+                bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q,
+                FrequencyGrid.of(z), bank.delays, normalize_first, cfg.use_asym_spectral_loss,
+                cfg.spectral_loss_weight, cfg.sparsity_loss_weight, 1.0 / self.world_size, nb,
+                torch.is_grad_enabled(), side)
         else:
             if side is not None:
                 side.wait_stream(main)
@@ -378,14 +378,18 @@ class BandBankTrainer:
                 extra, spec, sparse = ColorlessTerms.apply(S, Q, cfg.use_asym_spectral_loss,
                                                            cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
                                                            1.0 / self.world_size, True, nb)
-        rgain = bank.group_gains(data['norm_listener_position'], rows)
-        if side is not None:
-            main.wait_event(ready)
-            # a tensor allocated on one stream and read on the other must be recorded there: otherwise its
-            # block returns to the allocating stream's pool the moment autograd drops it and a kernel of
-            # that stream may overwrite it while the other stream still reads it (seen as wrong dL/dM,
-            # dL/db under graph replay when QQ came from the side stream)
-            if not fused:
+        # a tensor allocated on one stream and read on the other must be recorded there: otherwise its block
+        # returns to the allocating stream's pool the moment autograd drops it and a kernel of that stream may
+        # overwrite it while the other stream still reads it (seen as wrong dL/dM, dL/db under graph replay)
+        if fused and side is not None:
+            main.wait_event(rot_done)
+            QQ.record_stream(main)
+        elif fused:
+            rgain = bank.group_gains(data['norm_listener_position'], rows)
+        else:
+            rgain = bank.group_gains(data['norm_listener_position'], rows)
+            if side is not None:
+                main.wait_event(ready)
                 QQ.record_stream(main)
         K = z.shape[-1]
         Ku = (K + 1) // 2 if K % 2 == 1 else K          # irfft(X, n = K) reads bins 0..(K-1)/2 only
@@ -395,6 +399,9 @@ class BandBankTrainer:
             if self._filt_u is None or self._filt_u.shape[-1] != Ku:
                 self._filt_u = self.subband_filter_freq_resp[:, :Ku].contiguous()
             filt = self._filt_u
+        if fused and side is not None:
+            main.wait_event(mlp_done)
+            rgain.record_stream(main)
         H = OutputStage.apply(Y, bank.output_gains.view(-1), rgain, bank.num_delay_lines_per_group,
                               data['target_early_response'][:, :Ku], filt, rows, nb)
         start, length = self._decay_window(K)

@@ -4,6 +4,7 @@ Each Function is one differentiable stage of the hot path; forward and backward 
 hand-written kernels, torch only carries the tensors.  Gradient conventions are PyTorch's
 (complex grad = dL/dRe + i dL/dIm).
 """
+import contextlib
 from typing import Optional
 
 import torch
@@ -231,25 +232,33 @@ class SubFdnColorless(torch.autograd.Function):
     ``normalize``: Trainer.normalize (trainer.py:317-332) is applied first, IN PLACE on b.data / c.data, from
     the very responses the loss then uses (one solve instead of two).  Gradients are produced in the forward
     (the loss is a scalar head back-propagated with unit gradient); the backward only hands them over.
-    ``after_solve``: optional callable run right after the forward solve + rescale were launched (the trainer
-    records the event the main branch waits on); ``before_terms``: run before Q is first read."""
+    ``tail_stream``: the solve + rescale are launched on the current stream (the main branch needs their
+    result first); statistics, loss terms and the adjoint kernel then run on ``tail_stream``, which the caller
+    joins before it reads the outputs."""
 
     @staticmethod
     def forward(ctx, M, b, c, Q, grid: FrequencyGrid, delays, normalize, asym, w_spec, w_sparse, inv_world,
-                nbands, want_grad, after_solve=None, before_terms=None):
+                nbands, want_grad, tail_stream=None):
         # (grad mode is always off inside Function.forward: the caller passes torch.is_grad_enabled())
         need = want_grad and (M.requires_grad or b.requires_grad or c.requires_grad)
         Y, S, energy = ops.subfdn_colorless_fwd(grid.turns, grid.logr, M, delays, b.data, c.data, normalize)
-        if after_solve is not None:
-            after_solve()
         en = energy if normalize else None
-        loss_g, gS = ops.spectral_stats_binmajor(S, en, asym, w_spec * inv_world, want_grad=need)
-        if before_terms is not None:
-            before_terms()
-        out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need, nbands=nbands)
-        grads = (None, None, None)
-        if need:
-            grads = ops.subfdn_colorless_bwd(grid.turns, grid.logr, M, delays, b.data, c.data, en, Y, gS)
+        if tail_stream is not None:
+            tail_stream.wait_stream(torch.cuda.current_stream())
+            for t in (Y, S, energy):
+                t.record_stream(tail_stream)
+        with torch.cuda.stream(tail_stream) if tail_stream is not None else contextlib.nullcontext():
+            loss_g, gS = ops.spectral_stats_binmajor(S, en, asym, w_spec * inv_world, want_grad=need)
+            out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need, nbands=nbands)
+            grads = (None, None, None)
+            if need:
+                grads = ops.subfdn_colorless_bwd(grid.turns, grid.logr, M, delays, b.data, c.data, en, Y, gS)
+        if tail_stream is not None:
+            # produced on the tail stream, handed to autograd as this node's (= the calling stream's) results
+            here = torch.cuda.current_stream()
+            for t in (out, gQ) + tuple(grads):
+                if t is not None:
+                    t.record_stream(here)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(gQ, *[g for g in grads if g is not None])
         ctx.shapes = (M.shape, b.shape, c.shape)
@@ -263,10 +272,10 @@ class SubFdnColorless(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g1, _g2, _g3):
         if g is None or len(ctx.saved_tensors) < 4:
-            return (None,) * 15
+            return (None,) * 14
         gQ, gM, gb, gc = ctx.saved_tensors         # unit upstream gradient by contract (see forward)
         sM, sb, sc = ctx.shapes
-        return (gM.view(sM), gb.view(sb), gc.view(sc), gQ) + (None,) * 11
+        return (gM.view(sM), gb.view(sb), gc.view(sc), gQ) + (None,) * 10
 
 
 class IrfftOdd(torch.autograd.Function):
