@@ -359,11 +359,14 @@ class BandBankTrainer:
                     mlp_done.record(side)
             else:
                 Q, QQ = bank.rotations()
-            extra, spec, sparse, _ = SubFdnColorless.apply(
-                bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q,
-                FrequencyGrid.of(z), bank.delays, normalize_first, cfg.use_asym_spectral_loss,
-                cfg.spectral_loss_weight, cfg.sparsity_loss_weight, 1.0 / self.world_size, nb,
-                torch.is_grad_enabled(), side)
+            gridK = FrequencyGrid.of(z)
+            with torch.no_grad():
+                Ys, Ss, en = ops.subfdn_colorless_fwd(gridK.turns, gridK.logr, bank._blocks(), bank.delays,
+                                                      bank.input_gains.data.view(-1), bank.output_gains.data.view(-1),
+                                                      normalize_first)
+            if side is not None:
+                sub_done = torch.cuda.Event()
+                sub_done.record(main)
         else:
             if side is not None:
                 side.wait_stream(main)
@@ -404,6 +407,18 @@ class BandBankTrainer:
             rgain.record_stream(main)
         H = OutputStage.apply(Y, bank.output_gains.view(-1), rgain, bank.num_delay_lines_per_group,
                               data['target_early_response'][:, :Ku], filt, rows, nb)
+        if fused:
+            # the loss side of the colorless branch is issued AFTER the main solve / output stage (the graph
+            # executor launches nodes in capture order: its small kernels would otherwise sit in front of them)
+            if side is not None:
+                side.wait_event(sub_done)
+                for t in (Ys, Ss, en):
+                    t.record_stream(side)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                extra, spec, sparse = SubFdnColorless.apply(
+                    bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q, Ys, Ss, en, gridK,
+                    bank.delays, normalize_first, cfg.use_asym_spectral_loss, cfg.spectral_loss_weight,
+                    cfg.sparsity_loss_weight, 1.0 / self.world_size, nb, torch.is_grad_enabled())
         start, length = self._decay_window(K)
         gb = Bper
         if mask_prenorm is not None:

@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
                                                      const long long* __restrict__ drows,
                                                      const float2* __restrict__ filt,
                                                      float2* __restrict__ H, int ldh,
-                                                     float2* __restrict__ S_out, int ldy, int ldf) {
+                                                     float2* __restrict__ S_out, int ldy, int ldf, int rpb) {
   const int N = G * nper;
   const int k0 = blockIdx.x * 256;
   {   // band blockIdx.z: its delay lines, gains, items (B per band) and filter row
@@ -1024,28 +1024,32 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
     }
   }
   const float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
-  const int b0 = blockIdx.y * COMPOSE_BCH;
-  float2 d[COMPOSE_BCH];
+  // receivers [blockIdx.y * rpb, + rpb) in chunks of COMPOSE_BCH: with many (bin tile, band) units in the
+  // launch one workgroup serves ALL receivers of its band, so the Y tile is staged once, not B / 8 times
+  const int bend = (int)(blockIdx.y + 1) * rpb < B ? (int)(blockIdx.y + 1) * rpb : B;
+  for (int b0 = blockIdx.y * rpb; b0 < bend; b0 += COMPOSE_BCH) {
+    float2 d[COMPOSE_BCH];
 #pragma unroll
-  for (int bb = 0; bb < COMPOSE_BCH; ++bb) {       // all loads of the chunk in flight together
-    const int b = b0 + bb;
-    d[bb] = (direct && b < B) ? direct[(size_t)(drows ? drows[b] : b) * ldd + k] : make_float2(0.f, 0.f);
-  }
+    for (int bb = 0; bb < COMPOSE_BCH; ++bb) {       // all loads of the chunk in flight together
+      const int b = b0 + bb;
+      d[bb] = (direct && b < bend) ? direct[(size_t)(drows ? drows[b] : b) * ldd + k] : make_float2(0.f, 0.f);
+    }
 #pragma unroll
-  for (int bb = 0; bb < COMPOSE_BCH; ++bb) {
-    const int b = b0 + bb;
-    if (b < B) {
-      float2 h = d[bb];
+    for (int bb = 0; bb < COMPOSE_BCH; ++bb) {
+      const int b = b0 + bb;
+      if (b < bend) {
+        float2 h = d[bb];
 #pragma unroll
-      for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
-        if (g < G) {
-          const float rg = rgain[b * G + g];
-          h.x += rg * S[g].x;
-          h.y += rg * S[g].y;
+        for (int g = 0; g < GFDN_MAX_GROUPS; ++g) {
+          if (g < G) {
+            const float rg = rgain[b * G + g];
+            h.x += rg * S[g].x;
+            h.y += rg * S[g].y;
+          }
         }
+        if (filt) h = cmul(h, f);
+        H[(size_t)b * ldh + k] = h;
       }
-      if (filt) h = cmul(h, f);
-      H[(size_t)b * ldh + k] = h;
     }
   }
 }
@@ -1059,13 +1063,17 @@ extern "C" int gfdn_compose_banded_fwd(const float* Y, int K, int nbands, int G,
   if (!Y || !c || !rgain || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0 || nbands <= 0) return GFDN_E_BADARG;
   if (G > GFDN_MAX_GROUPS || nbands > 65535) return GFDN_E_UNSUPPORTED;
   if (ldh < K || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
-  dim3 grid((K + 255) / 256, (B + COMPOSE_BCH - 1) / COMPOSE_BCH, nbands);
+  // receivers per workgroup: all of the band's when (bin tiles x bands) alone fills the chip
+  const int ktiles = (K + 255) / 256;
+  int rpb = COMPOSE_BCH;
+  if ((long long)ktiles * nbands >= 768) rpb = ((B + COMPOSE_BCH - 1) / COMPOSE_BCH) * COMPOSE_BCH;
+  dim3 grid(ktiles, (B + rpb - 1) / rpb, nbands);
   if (G * nper > 128) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_compose_fwd, compose_tile_bytes(G * nper));
   if (rc) return rc;
   hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), compose_tile_bytes(G * nper), (hipStream_t)stream, (const float2*)Y, K,
                      G, nper, c, rgain, B, (const float2*)direct, ldd, direct ? direct_rows : nullptr,
-                     (const float2*)filt, (float2*)H, ldh, (float2*)S_out, nbands * G * nper, ldf);
+                     (const float2*)filt, (float2*)H, ldh, (float2*)S_out, nbands * G * nper, ldf, rpb);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

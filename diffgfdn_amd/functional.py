@@ -226,39 +226,25 @@ class ColorlessTerms(torch.autograd.Function):
 
 
 class SubFdnColorless(torch.autograd.Function):
-    """The whole colorless side branch as ONE node (n <= 4; include/diffgfdn_hip.h "colorless side branch,
-    fused"): [normalize +] sub-FDN responses -> group sums -> spectral losses + sparsity -> their gradients.
-    Inputs M (G, n, n) raw blocks, b, c (N,) gains, Q (G, n, n) rotations (for the sparsity term).
-    ``normalize``: Trainer.normalize (trainer.py:317-332) is applied first, IN PLACE on b.data / c.data, from
-    the very responses the loss then uses (one solve instead of two).  Gradients are produced in the forward
-    (the loss is a scalar head back-propagated with unit gradient); the backward only hands them over.
-    ``tail_stream``: the solve + rescale are launched on the current stream (the main branch needs their
-    result first); statistics, loss terms and the adjoint kernel then run on ``tail_stream``, which the caller
-    joins before it reads the outputs."""
+    """Loss side of the colorless branch as ONE node (n <= 4; include/diffgfdn_hip.h "colorless side branch,
+    fused"): group sums -> spectral losses + sparsity -> their gradients w.r.t. M (G, n, n) raw blocks, the
+    gains b, c (N,) and the rotations Q (G, n, n).  ``Y, S, energy`` come from ``ops.subfdn_colorless_fwd``
+    (the caller launches it first: the main branch hangs on its rescale of b, c -- Trainer.normalize,
+    trainer.py:317-332, applied from the very responses the loss uses, one solve instead of two);
+    ``normalized`` tells whether that call rescaled b, c.  Gradients are produced in the forward (the loss is
+    a scalar head back-propagated with unit gradient); the backward only hands them over."""
 
     @staticmethod
-    def forward(ctx, M, b, c, Q, grid: FrequencyGrid, delays, normalize, asym, w_spec, w_sparse, inv_world,
-                nbands, want_grad, tail_stream=None):
+    def forward(ctx, M, b, c, Q, Y, S, energy, grid: FrequencyGrid, delays, normalized, asym, w_spec, w_sparse,
+                inv_world, nbands, want_grad):
         # (grad mode is always off inside Function.forward: the caller passes torch.is_grad_enabled())
         need = want_grad and (M.requires_grad or b.requires_grad or c.requires_grad)
-        Y, S, energy = ops.subfdn_colorless_fwd(grid.turns, grid.logr, M, delays, b.data, c.data, normalize)
-        en = energy if normalize else None
-        if tail_stream is not None:
-            tail_stream.wait_stream(torch.cuda.current_stream())
-            for t in (Y, S, energy):
-                t.record_stream(tail_stream)
-        with torch.cuda.stream(tail_stream) if tail_stream is not None else contextlib.nullcontext():
-            loss_g, gS = ops.spectral_stats_binmajor(S, en, asym, w_spec * inv_world, want_grad=need)
-            out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need, nbands=nbands)
-            grads = (None, None, None)
-            if need:
-                grads = ops.subfdn_colorless_bwd(grid.turns, grid.logr, M, delays, b.data, c.data, en, Y, gS)
-        if tail_stream is not None:
-            # produced on the tail stream, handed to autograd as this node's (= the calling stream's) results
-            here = torch.cuda.current_stream()
-            for t in (out, gQ) + tuple(grads):
-                if t is not None:
-                    t.record_stream(here)
+        en = energy if normalized else None
+        loss_g, gS = ops.spectral_stats_binmajor(S, en, asym, w_spec * inv_world, want_grad=need)
+        out, gQ = ops.colorless_terms(loss_g, Q, w_spec, w_sparse, inv_world, want_grad=need, nbands=nbands)
+        grads = (None, None, None)
+        if need:
+            grads = ops.subfdn_colorless_bwd(grid.turns, grid.logr, M, delays, b.data, c.data, en, Y, gS)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(gQ, *[g for g in grads if g is not None])
         ctx.shapes = (M.shape, b.shape, c.shape)
@@ -266,16 +252,16 @@ class SubFdnColorless(torch.autograd.Function):
             total, spec, sparse = out[:, 0], out[:, 1], out[:, 2]
         else:
             total, spec, sparse = out[0], out[1], out[2]
-        ctx.mark_non_differentiable(spec, sparse, energy)
-        return total, spec, sparse, energy
+        ctx.mark_non_differentiable(spec, sparse)
+        return total, spec, sparse
 
     @staticmethod
-    def backward(ctx, g, _g1, _g2, _g3):
+    def backward(ctx, g, _g1, _g2):
         if g is None or len(ctx.saved_tensors) < 4:
-            return (None,) * 14
+            return (None,) * 16
         gQ, gM, gb, gc = ctx.saved_tensors         # unit upstream gradient by contract (see forward)
         sM, sb, sc = ctx.shapes
-        return (gM.view(sM), gb.view(sb), gc.view(sc), gQ) + (None,) * 10
+        return (gM.view(sM), gb.view(sb), gc.view(sc), gQ) + (None,) * 12
 
 
 class IrfftOdd(torch.autograd.Function):
