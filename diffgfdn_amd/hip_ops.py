@@ -434,7 +434,9 @@ def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None) -> torch.Tensor:
     return gX
 
 
-_BLU_STAGES = {'k_blu_col_fwd': 1, 'k_blu_row': 2, 'k_blu_col_inv': 4}
+# stage bit of gfdn_irfft_odd_stages by the kernel that runs it at the north-star length (n = 65 537: Rader on the
+# 128 x 512 geometry; other lengths run k_blu_col_fwd / k_blu_row / k_blu_col_inv under the same bits)
+_BLU_STAGES = {'k_blu_col128_fwd': 1, 'k_blu_row512': 2, 'k_blu_col128_inv': 4}
 
 
 def _staged_bluestein(lib, table, n, src, src2, ld_in, batch, dst, ld_out, work, adjoint):
