@@ -1,7 +1,7 @@
 """Differentiable GFDN models on the MI355X hot path.
 
 Interface mirror of the reference's src/diff_gfdn/model.py: DiffGFDN (:24-299),
-DiffGFDNVarReceiverPos (:502-661), DiffGFDNSinglePos (:667-969),
+DiffGFDNVarSourceReceiverPos (:303-452), DiffGFDNVarReceiverPos (:502-661), DiffGFDNSinglePos (:667-969),
 DiffDirectionalFDNVarReceiverPos (:975-1126) -- same constructor arguments, same
 ``forward(x: Dict)`` contract, same parameter / buffer names (state dicts interchange).
 
@@ -203,6 +203,73 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
         out = super().get_param_dict()
         out['input_scalars'] = self.input_scalars.squeeze().cpu().numpy()
         return out
+
+
+class DiffGFDNVarSourceReceiverPos(DiffGFDN):
+    """GFDN for a grid of source AND receiver positions: per-group input gains from the source position and
+    output gains from the receiver position, one MLP each (reference model.py:303-452).
+
+    H[b,k] = sum_{g,g'} r[b,g] s[b,g'] c_g^T P_{g g'}(z_k) b_{g'} + d[b,k].  With zero inter-group coupling P is
+    block diagonal, the solve y = P b is shared by the batch exactly as in DiffGFDNVarReceiverPos and the two
+    gains simply multiply in the output stage; with coupling, one solve per source group (b masked to the
+    group) gives the G x G group transfer functions, contracted with the gains by torch ops on the device."""
+
+    def __init__(self, sample_rate: int, num_groups: int, delays: List[int], device: torch.device,
+                 feedback_loop_config: FeedbackLoopConfig, output_filter_config: OutputFilterConfig,
+                 input_filter_config: OutputFilterConfig, use_absorption_filters: bool,
+                 learn_common_decay_times: bool, common_decay_times: Optional[List] = None,
+                 band_centre_hz: Optional[List] = None, colorless_fdn_params: Optional[List] = None,
+                 use_colorless_loss: bool = False):
+        super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
+                         use_absorption_filters, learn_common_decay_times, common_decay_times,
+                         band_centre_hz, colorless_fdn_params, use_colorless_loss)
+        if output_filter_config.use_svfs or input_filter_config.use_svfs:
+            raise NotImplementedError("SVF input/output filters: SURVEY §8 f-2 (next)")
+        self.use_svf_in_output = False
+        self.use_svf_in_input = False
+        n = self.num_delay_lines_per_group
+        self.output_scalars = Gains_from_MLP(
+            self.num_groups, n, output_filter_config.num_fourier_features,
+            output_filter_config.num_hidden_layers, output_filter_config.num_neurons_per_layer,
+            output_filter_config.encoding_type, position_type="output_gains")
+        self.input_scalars = Gains_from_MLP(
+            self.num_groups, n, input_filter_config.num_fourier_features,
+            input_filter_config.num_hidden_layers, input_filter_config.num_neurons_per_layer,
+            input_filter_config.encoding_type, position_type="input_gains")
+
+    def forward(self, x: Dict, subband_filter: Optional[torch.Tensor] = None):
+        z = x['z_values']
+        self.feedback_loop.new_forward()
+        self.batch_size = x['listener_position'].shape[0]
+        G, n = self.num_groups, self.num_delay_lines_per_group
+        r = self.output_scalars.group_gains(x).to(torch.float32)          # (B, G) from the receiver position
+        s = self.input_scalars.group_gains(x).to(torch.float32)           # (B, G) from the source position
+        fl = self.feedback_loop
+        if fl.use_zero_coupling and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
+            Y = self.delay_line_responses(z)
+            H = OutputStage.apply(Y, self.output_gains.reshape(-1), r * s, n, x['target_early_response'],
+                                  subband_filter)
+        else:
+            # T[k, g, g'] = c_g^T P_{g g'} b_{g'}: one solve per source group
+            b = self.input_gains.reshape(G, n)
+            cols = []
+            for gs in range(G):
+                mask = torch.zeros_like(b)
+                mask[gs] = 1.0
+                Yg = self.delay_line_responses(z, b=(b * mask).reshape(-1, 1))          # (K, N)
+                cols.append((Yg * self.output_gains.reshape(1, -1)).reshape(-1, G, n).sum(-1))   # (K, G)
+            T = torch.stack(cols, dim=-1)                                                # (K, G, G')
+            H = torch.einsum('bg,bh,kgh->bk', r.to(T.dtype), s.to(T.dtype), T) + x['target_early_response']
+            if subband_filter is not None:
+                H = H * subband_filter
+        if self.use_colorless_loss:
+            return H, self.sub_fdn_output(z)
+        return H
+
+    @torch.no_grad()
+    def get_param_dict_inference(self, data: Dict) -> Dict:
+        return {'output_scalars': self.output_scalars.get_param_dict(data)['gains'],
+                'input_scalars': self.input_scalars.get_param_dict(data)['gains']}
 
 
 class DiffGFDNSinglePos(DiffGFDN):

@@ -182,6 +182,26 @@ def var_receiver_forward(z: torch.Tensor, input_gains: torch.Tensor,
     return torch.einsum('bmk, bmk -> bk', Htemp, Bm) + direct              # :619
 
 
+def var_source_receiver_forward(z: torch.Tensor, input_gains: torch.Tensor, output_gains: torch.Tensor,
+                                receiver_gains: torch.Tensor, source_gains: torch.Tensor,
+                                P: torch.Tensor, direct: torch.Tensor, n_per_group: int) -> torch.Tensor:
+    """model.py:402-452 (DiffGFDNVarSourceReceiverPos.forward, MLP-gain branches on both sides).
+
+    receiver_gains, source_gains (B,G) = sigmoid-scaled outputs of the two MLPs (gain_filters.py:497-534; the
+    input-side network reads x['source_position'], :503-505); P (K,N,N) c64; direct (B,K) c128."""
+    Bsz = receiver_gains.shape[0]
+    N = input_gains.shape[0]
+    K = len(z)
+    C_init = to_complex(output_gains.expand(Bsz, N, K))                     # :416-418
+    B_init = to_complex(input_gains.expand(Bsz, N, K))                      # :419-421
+    rg = receiver_gains.repeat_interleave(n_per_group, dim=1).unsqueeze(-1).repeat(1, 1, K)
+    sg = source_gains.repeat_interleave(n_per_group, dim=1).unsqueeze(-1).repeat(1, 1, K)
+    C = to_complex(rg) * C_init                                             # :427
+    Bm = to_complex(sg) * B_init                                            # :432
+    Htemp = torch.einsum('knb, knm -> kmb', C.permute(-1, 1, 0), P).permute(-1, 1, 0)   # :437-438
+    return torch.einsum('bmk, bmk -> bk', Htemp, Bm) + direct              # :444
+
+
 def single_pos_forward(z, input_gains, output_gains, input_scalars, output_scalars, P,
                        direct, n_per_group):
     """model.py:779-836 (DiffGFDNSinglePos.forward, scalar in/out branch)."""

@@ -26,7 +26,7 @@ from diff_gfdn.config.config import (CouplingMatrixType, FeedbackLoopConfig,  # 
 from diff_gfdn.feedback_loop import FeedbackLoop  # noqa: E402
 from diff_gfdn.losses import directional_edc_loss, edc_loss, edr_loss  # noqa: E402
 from diff_gfdn.model import (DiffDirectionalFDNVarReceiverPos, DiffGFDNSinglePos,  # noqa: E402
-                             DiffGFDNVarReceiverPos)
+                             DiffGFDNVarReceiverPos, DiffGFDNVarSourceReceiverPos)
 from diff_gfdn.trainer import VarReceiverPosTrainer  # noqa: E402
 import diff_gfdn.losses as ref_losses  # noqa: E402
 import spatial_sampling.model as ss_model  # noqa: E402
@@ -351,6 +351,33 @@ def gen_f7_front_end():
     print('F7 done')
 
 
+def gen_f8_source_receiver():
+    """DiffGFDNVarSourceReceiverPos (model.py:303-452): gains from the receiver AND the source position."""
+    fs, nfft, G, nper, B = 2000.0, 512, 3, 4, 4
+    delays = prime_delays(G * nper, lo=20, hi=90, seed=4)
+    for tag, zero in (('zc', True), ('cp', False)):
+        batch, T60 = synth_batch(B, nfft, fs, G, 400, 31)
+        rng = np.random.RandomState(77)
+        batch['source_position'] = torch.tensor(rng.uniform(0, 1, (B, 3)))
+        torch.manual_seed(12)
+        np.random.seed(12)
+        fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=zero)
+        of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+        net = DiffGFDNVarSourceReceiverPos(fs, G, delays, 'cpu', fl, of, of, use_absorption_filters=False,
+                                           learn_common_decay_times=False,
+                                           common_decay_times=np.asarray(T60)[None, :], use_colorless_loss=True)
+        H, (Hout, _) = net(batch)
+        loss = (H.abs() ** 2).sum()
+        loss.backward()
+        out = {'fs': fs, 'nfft': nfft, 'G': G, 'nper': nper, 'delays': np.array(delays), 'T60': T60,
+               'zero_coupling': zero, 'H': c2np(H), 'Hout': c2np(Hout), 'loss': loss.item()}
+        out.update(batch_to_np(batch))
+        out.update(state_np(net))
+        out.update({'grad_' + k: c2np(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+        np.savez_compressed(os.path.join(HERE, f'f8_source_receiver_{tag}.npz'), **out)
+    print('F8 done')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1_feedback_loop()
@@ -363,3 +390,4 @@ if __name__ == '__main__':
     gen_f5_single_pos()
     gen_f6_directional()
     gen_f7_front_end()
+    gen_f8_source_receiver()

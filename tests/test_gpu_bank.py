@@ -317,3 +317,23 @@ def test_fused_colorless_branch_equals_separate_kernels(normalize):
     assert rel_err(gM2.cpu(), gM.cpu()) < 2e-5
     assert rel_err(gb2.cpu(), gb.cpu()) < 2e-5
     assert rel_err(gc2.cpu(), gc.cpu()) < 2e-5
+
+
+def test_bank_split_graph_path_for_data_parallel():
+    """N > 1 replays two graphs with the all-reduce of the flat gradient buffer (ALL bands) between them;
+    with an identity stand-in the result must equal the single-graph path bit for bit."""
+    out = {}
+    sel = [[[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]], [[1, 2, 4, 6], [0, 5, 7, 9], [3, 8, 10, 11]]]
+    for mode in ("single", "split_identity"):
+        nets, data, filt, bank, tr, sds, _ = _bank_setup()
+        if mode != "single":
+            tr._allreduce = lambda: None
+        step = tr.graphed(sds, 4, mask_seed=5).capture(sds.global_rows(sel[0]))
+        assert (step.graph_b is not None) == (mode != "single")
+        vals = [step(sds.global_rows(s))["_total"].cpu().numpy().copy() for s in sel]
+        out[mode] = (vals, [{k: v.detach().cpu().clone() for k, v in n.state_dict().items()} for n in nets])
+    for a, b in zip(out["single"][0], out["split_identity"][0]):
+        assert np.array_equal(a, b)
+    for q in range(len(BANDS)):
+        for k, v in out["single"][1][q].items():
+            assert torch.equal(v, out["split_identity"][1][q][k]), (q, k)

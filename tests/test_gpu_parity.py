@@ -561,3 +561,28 @@ def test_split_graph_path_used_for_data_parallel():
     assert out["single"][0] == out["split_identity"][0]
     for k, v in out["single"][1].items():
         assert torch.equal(v, out["split_identity"][1][k]), k
+
+
+@pytest.mark.parametrize("tag", ["zc", "cp"])
+def test_f8_source_receiver_model(tag):
+    """DiffGFDNVarSourceReceiverPos (source AND receiver gain networks) vs the reference's forward and the
+    gradients of sum |H|^2 w.r.t. every parameter (fixture F8; model.py:303-452)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarSourceReceiverPos
+    fx = load(f"f8_source_receiver_{tag}.npz")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=bool(fx["zero_coupling"]))
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarSourceReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of, of,
+                                       use_absorption_filters=False, learn_common_decay_times=False,
+                                       common_decay_times=fx["T60"][None, :], use_colorless_loss=True)
+    net.load_state_dict(_state(fx), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx))
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu().numpy(), fx["H"]) < TOL
+    assert rel_err(Hout.detach().cpu().numpy(), fx["Hout"]) < TOL
+    (H.abs() ** 2).sum().backward()
+    for name_, prm in net.named_parameters():
+        ref = fx["grad_" + name_]
+        got = prm.grad.cpu().numpy()
+        assert np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_

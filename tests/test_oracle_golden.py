@@ -226,3 +226,26 @@ def test_f4_adam_state(name, asym):
     assert rel_err(p.output_gains.detach(), fx["sda_output_gains"]) < 1e-5
     assert rel_err(p.M.detach(), fx["sda_feedback_loop.M"]) < 1e-5
     assert rel_err(p.mlp_weights[0][0].detach(), fx["sda_output_scalars.mlp.model.0.weight"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["zc", "cp"])
+def test_f8_source_receiver_forward(tag):
+    """oracle var_source_receiver_forward vs DiffGFDNVarSourceReceiverPos of the reference (model.py:402-452)."""
+    from tests.helpers import mlp_from_state
+    fx = load(f"f8_source_receiver_{tag}.npz")
+    batch = batch_from(fx)
+    G, nper = int(fx["G"]), int(fx["nper"])
+    M, alpha = torch.tensor(fx["sd_feedback_loop.M"]), torch.tensor(fx["sd_feedback_loop.alpha"])
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    lin_o, norm_o = mlp_from_state(fx, root="output_scalars.mlp.model.")
+    lin_i, norm_i = mlp_from_state(fx, root="input_scalars.mlp.model.")
+    p = orc.GridModelParams(float(fx["fs"]), fx["delays"].tolist(), G, torch.tensor(fx["sd_input_gains"]),
+                            torch.tensor(fx["sd_output_gains"]), M, alpha, fx["T60"][None, :], lin_o, norm_o, 4)
+    A = orc.coupled_feedback_matrix(M, alpha) if tag == "cp" else orc.coupled_feedback_matrix(M, torch.zeros_like(alpha))
+    P = orc.feedback_loop_forward(batch["z_values"], delays, p.gamma(), A)
+    r = p.receiver_gains(batch["norm_listener_position"])
+    enc = orc.sinusoidal_encoding(batch["source_position"], 4)
+    s = orc.scaled_sigmoid(orc.mlp_forward(enc, lin_i, norm_i).view(-1), -1.0, 1.0).view(-1, G)
+    H = orc.var_source_receiver_forward(batch["z_values"], p.input_gains, p.output_gains, r, s, P,
+                                        batch["target_early_response"], nper)
+    assert rel_err(H.detach().numpy(), fx["H"]) < 1e-6
