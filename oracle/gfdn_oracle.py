@@ -202,6 +202,22 @@ def var_source_receiver_forward(z: torch.Tensor, input_gains: torch.Tensor, outp
     return torch.einsum('bmk, bmk -> bk', Htemp, Bm) + direct              # :444
 
 
+def colorless_fdn_forward(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Tensor,
+                          input_gains: torch.Tensor, output_gains: torch.Tensor, W: torch.Tensor):
+    """colorless_fdn/model.py:63-92 (ColorlessFDN.forward): one group, dense feedback matrix
+    Q = ortho_param(W) (CouplingMatrixType.RANDOM, feedback_loop.py:350-352).  -> (H (K,), H_per_del (N, K))."""
+    N = input_gains.shape[0]
+    K = len(z)
+    P = feedback_loop_forward(z, delays, gamma, ortho_param(W))
+    C = to_complex(output_gains.expand(N, K))                               # :74-75
+    Bm = to_complex(input_gains)                                            # :78
+    Htemp = torch.einsum('kn, knm -> km', C.permute(-1, 0), P)              # :84
+    H = torch.einsum('ik, kj -> ij', Htemp, Bm).squeeze()                   # :86
+    H_tmp = torch.einsum('kn, knm -> knm', C.permute(1, 0), P).permute(1, -1, 0)   # :89-90
+    H_per_del = torch.einsum('nmk, mk -> nk', H_tmp, Bm)                    # :91
+    return H, H_per_del
+
+
 def single_pos_forward(z, input_gains, output_gains, input_scalars, output_scalars, P,
                        direct, n_per_group):
     """model.py:779-836 (DiffGFDNSinglePos.forward, scalar in/out branch)."""

@@ -378,6 +378,38 @@ def gen_f8_source_receiver():
     print('F8 done')
 
 
+def gen_f9_colorless_fdn():
+    """ColorlessFDN prototype (colorless_fdn/model.py:12-111) + the trainer's loss and normalisation
+    (colorless_fdn/trainer.py:95-143)."""
+    from diff_gfdn.colorless_fdn.model import ColorlessFDN
+    from diff_gfdn.colorless_fdn.losses import amse_loss as c_amse, sparsity_loss as c_sparse
+    from diff_gfdn.utils import get_frequency_samples
+    fs, N = 8000.0, 8
+    delays = prime_delays(N, lo=160, hi=400, seed=6)
+    torch.manual_seed(15)
+    np.random.seed(15)
+    net = ColorlessFDN(fs, delays, 'cpu', nominal_t60=10.0)
+    z = get_frequency_samples(600)
+    out = {'fs': fs, 'delays': np.array(delays), 'z': c2np(z)}
+    out.update(state_np(net))
+    H, Hpd = net(z)
+    out['H'], out['Hpd'] = c2np(H), c2np(Hpd)
+    fl = net.feedback_loop
+    loss = c_amse()(H, torch.ones(len(z))) + 1.5 * c_sparse()(fl.ortho_param(fl.random_feedback_matrix))
+    loss.backward()
+    out['loss'] = loss.item()
+    out.update({'grad_' + k: c2np(p.grad) for k, p in net.named_parameters()})
+    vloss = c_amse()(H, torch.ones(len(z))) + c_amse()(Hpd, torch.ones_like(Hpd)) \
+        + 1.5 * c_sparse()(fl.ortho_param(fl.random_feedback_matrix))
+    out['valid_loss'] = vloss.item()
+    with torch.no_grad():                                   # trainer.normalize (:133-143)
+        energy = torch.sum(torch.abs(H) ** 2) / H.shape[0]
+        out['norm_input_gains'] = c2np(net.input_gains / torch.pow(energy, 1 / 4))
+        out['norm_output_gains'] = c2np(net.output_gains / torch.pow(energy, 1 / 4))
+    np.savez_compressed(os.path.join(HERE, 'f9_colorless_fdn.npz'), **out)
+    print('F9 done')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1_feedback_loop()
@@ -391,3 +423,4 @@ if __name__ == '__main__':
     gen_f6_directional()
     gen_f7_front_end()
     gen_f8_source_receiver()
+    gen_f9_colorless_fdn()

@@ -249,3 +249,15 @@ def test_f8_source_receiver_forward(tag):
     H = orc.var_source_receiver_forward(batch["z_values"], p.input_gains, p.output_gains, r, s, P,
                                         batch["target_early_response"], nper)
     assert rel_err(H.detach().numpy(), fx["H"]) < 1e-6
+
+
+def test_f9_colorless_fdn_forward():
+    """oracle colorless_fdn_forward vs the reference's ColorlessFDN (colorless_fdn/model.py:63-92)."""
+    fx = load("f9_colorless_fdn.npz")
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    gamma = torch.tensor(orc.decay_times_to_gain_per_sample(10.0, fx["delays"], float(fx["fs"])))
+    H, Hpd = orc.colorless_fdn_forward(torch.tensor(fx["z"]), delays, gamma, torch.tensor(fx["sd_input_gains"]),
+                                       torch.tensor(fx["sd_output_gains"]),
+                                       torch.tensor(fx["sd_feedback_loop.random_feedback_matrix"]))
+    assert rel_err(H.numpy(), fx["H"]) < 1e-6
+    assert rel_err(Hpd.numpy(), fx["Hpd"]) < 1e-6
