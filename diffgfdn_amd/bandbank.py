@@ -208,6 +208,22 @@ class BandStackedDataset:
         for d in self.datasets:                  # the stacked copies are the live ones
             d.edr_store = d.edc_store = None
 
+    def slot_ordered(self, bins: torch.Tensor, conj: torch.Tensor):
+        """(z_s (1 + S,) complex128, early_s (bands*R, 1 + S) complex64): the frequency grid and the early-response
+        store on the slot-ordered grid of ``ops.irfft_slot_order`` -- column 0 = bin 0, column 1 + s = bin bins[s],
+        conjugated where conj[s] (a real signal's spectrum at conj(z) is the conjugate).  Built once, cached."""
+        if getattr(self, '_slot_cache', None) is None:
+            z = self.z_values
+            zs = torch.cat([z[:1], torch.where(conj, z[bins].conj(), z[bins])])
+            E = self.early_rir_mag_response
+            out = torch.empty((E.shape[0], 1 + bins.numel()), dtype=E.dtype, device=E.device)
+            out[:, 0] = E[:, 0]
+            for r0 in range(0, E.shape[0], 512):                      # bounded temporaries
+                blk = E[r0:r0 + 512][:, bins]
+                out[r0:r0 + 512, 1:] = torch.where(conj, blk.conj(), blk)
+            self._slot_cache = (zs, out)
+        return self._slot_cache
+
     def global_rows(self, per_band: Sequence[Sequence[int]]) -> List[int]:
         """per_band[q] = receiver indices of band q's batch -> band-major global rows."""
         if len(per_band) != self.num_bands or len({len(s) for s in per_band}) != 1:
@@ -222,7 +238,7 @@ class BandStackedDataset:
         idx = rows if torch.is_tensor(rows) else torch.as_tensor(list(rows), dtype=torch.long, device=self.device)
         return {'z_values': self.z_values, 'norm_listener_position': self.norm_listener_position,
                 'target_early_response': self.early_rir_mag_response, 'edr_target': self.edr_store,
-                'edc_target': self.edc_store, 'receiver_index': idx, 'row_index': idx}
+                'edc_target': self.edc_store, 'receiver_index': idx, 'row_index': idx, 'dataset': self}
 
 
 class BandFlatAdam(FlatAdam):
@@ -269,6 +285,7 @@ class BandBankTrainer:
 
     capturable = True
     concurrent_branches = True
+    use_slot_order = True        # evaluate the main branch on the irfft's slot-ordered grid when the length has one
 
     def __init__(self, bank: BandBank, trainer_config: TrainerConfig,
                  subband_filter_freq_resp: Optional[torch.Tensor] = None, process_group=None,
@@ -396,17 +413,32 @@ class BandBankTrainer:
                 QQ.record_stream(main)
         K = z.shape[-1]
         Ku = (K + 1) // 2 if K % 2 == 1 else K          # irfft(X, n = K) reads bins 0..(K-1)/2 only
-        Y = bank.delay_line_responses(z[:Ku], QQ)
+        # Slot order (n = 65 537): the irfft's natural input order is a fixed permutation of the bins, some of them
+        # conjugated; solve and output stage are pointwise in the bin, so they are evaluated directly on the
+        # permuted grid { z_k or conj(z_k) } against the (once) permuted early-response store and filter, and
+        # the transform needs neither the gather in front nor the scatter behind its adjoint.
+        order = ops.irfft_slot_order(K, z.device) if (self.use_slot_order and 'dataset' in data) else None
+        if order is not None:
+            zu, direct = data['dataset'].slot_ordered(*order)
+        else:
+            zu, direct = z[:Ku], data['target_early_response'][:, :Ku]
+        Y = bank.delay_line_responses(zu, QQ)
         filt = None
         if self.subband_filter_freq_resp is not None:
-            if self._filt_u is None or self._filt_u.shape[-1] != Ku:
-                self._filt_u = self.subband_filter_freq_resp[:, :Ku].contiguous()
-            filt = self._filt_u
+            if self._filt_u is None or self._filt_u[0] != (Ku, order is not None):
+                F = self.subband_filter_freq_resp
+                if order is not None:
+                    bins, conj = order
+                    Fu = torch.cat([F[:, :1], torch.where(conj, F[:, bins].conj(), F[:, bins])], dim=1)
+                else:
+                    Fu = F[:, :Ku]
+                self._filt_u = ((Ku, order is not None), Fu.contiguous())
+            filt = self._filt_u[1]
         if fused and side is not None:
             main.wait_event(mlp_done)
             rgain.record_stream(main)
         H = OutputStage.apply(Y, bank.output_gains.view(-1), rgain, bank.num_delay_lines_per_group,
-                              data['target_early_response'][:, :Ku], filt, rows, nb)
+                              direct, filt, rows, nb)
         if fused:
             # the loss side of the colorless branch is issued AFTER the main solve / output stage (the graph
             # executor launches nodes in capture order: its small kernels would otherwise sit in front of them)
@@ -435,7 +467,7 @@ class BandBankTrainer:
             edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
             edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
             edr_target=(edr_t[1], edr_t[2]), edc_target=edc_t[1], side_stream=self._stream('_side2'),
-            unit_grad=True, n_time=K, target_rows=rows, nbands=nb)
+            unit_grad=True, n_time=K, target_rows=rows, nbands=nb, slot_order=order is not None)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v, 'spectral_loss': spec.detach(),
                   'sparsity_loss': sparse.detach()}
         if side is not None:

@@ -391,6 +391,7 @@ struct BluArgs {
   float* edge;          // rader: per-(item, column block) partial sums for the t = 0 / k = 0 terms
   int nedge;            // rader: partials per item
   int batch;
+  int slot;             // Rader + col128: the SPECTRUM side is in slot order (gfdn_irfft_odd_slot_order): no gather / scatter
   const float2* chirp;  // n
   const float2* chat;   // L, [k1][k2]
   float2* work;         // batch * L
@@ -783,8 +784,20 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
   const int tile = tb * 4 + wave, c0 = tile * 8;
   float edge = 0.f;
   float2 v[16];
+  if (a.slot && !a.adjoint) {
+    // spectrum in slot order: X[0] = bin 0, X[1 + s] = u[s] for s < L/2, and u[s + L/2] = conj(u[s]) -- rows
+    // n1 and n1 + 64 of a column are conjugates, both held by this lane: 8 coalesced loads, no gather
+    const float2* Xs = (const float2*)a.in + (size_t)b * a.ld_in + 1;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = blu_load_elem(a, b, (l + 8 * k) * L2 + c0 + c, edge);
+    for (int k = 0; k < 8; ++k) {
+      v[k] = Xs[(size_t)(l + 8 * k) * L2 + c0 + c];
+      v[k + 8] = cconj(v[k]);
+      edge += v[k].x;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = blu_load_elem(a, b, (l + 8 * k) * L2 + c0 + c, edge);
+  }
   if (a.rader) {                       // one partial per tile, folded by the inverse column pass
     edge = wave_sum(edge);
     if (lane == 0) a.edge[(size_t)b * a.nedge + tile] = edge;
@@ -821,6 +834,21 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
       o[k] = make_float2(0.f, 0.f);
   }
   col128_fft(v, bufs + wave * CW_LDS, l, c, -1.0f);
+  if (a.slot && a.adjoint) {
+    // gradient w.r.t. the slot-ordered spectrum: dL/du[s] for s < L/2 (rows n1 < 64) takes the same form
+    // 2 conj(W[s]) / (n L) + (2 / n) gx[0] whether the slot holds X[k] or conj(X[n - k]) (the partner slot's
+    // term is the conjugate, W[s + L/2] = conj(W[s])): coalesced stores, no permutation table
+    const float invL = 1.0f / (float)L, invn = 1.0f / (float)g.n;
+    const float g0 = ((const float*)a.in)[(size_t)b * a.ld_in] + (a.in2 ? a.in2[(size_t)b * a.ld_in] : 0.f);
+    const float sc = 2.0f * invL * invn;
+    float2* o = (float2*)a.out + (size_t)b * a.ld_out + 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
+      if (n1 < 64) o[(size_t)n1 * L2 + c0 + c] = make_float2(sc * v[q].x + 2.0f * invn * g0, -sc * v[q].y);
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
@@ -841,9 +869,15 @@ static size_t blu_row_lds(const BluGeom& g) {
   return e * sizeof(float2);
 }
 
+static bool slot_order_ok(int n) {
+  if (!rader_ok(n)) return false;
+  const BluGeom g = rader_geom(n);
+  return g.L1 == 128 && g.L2 == 512;
+}
+
 static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
                    int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7,
-                   const float* in2 = nullptr) {
+                   const float* in2 = nullptr, int slot = 0) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
   const bool rader = rader_ok(n);
@@ -869,6 +903,8 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   a.nedge = g.L2 / tc0;
   a.edge = (float*)((char*)work + (size_t)batch * g.L * sizeof(float2));   // after the work blocks
   a.batch = batch;
+  a.slot = slot;
+  if (slot && !slot_order_ok(n)) return GFDN_E_UNSUPPORTED;
   a.adjoint = adjoint;
   a.in = in;
   a.in2 = adjoint ? in2 : nullptr;
@@ -915,8 +951,35 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
 
 extern "C" int gfdn_irfft_odd_stages(const void* table, int n, const void* in, const float* in2,
                                      int ld_in, int batch, void* out, int ld_out, void* work,
-                                     int adjoint, int stages, void* stream) {
-  return blu_run(table, n, in, ld_in, batch, out, ld_out, work, adjoint, (hipStream_t)stream, stages, in2);
+                                     int adjoint, int stages, int slots, void* stream) {
+  return blu_run(table, n, in, ld_in, batch, out, ld_out, work, adjoint, (hipStream_t)stream, stages, in2, slots);
+}
+
+// Slot order of the spectrum side (Rader, n = 65 537): slot s < (n-1)/2 holds u[s] = X[k] (conj = 0) or
+// conj(X[k]) (conj = 1) with k = bins[s] in 1..(n-1)/2, where 3^s mod n is k or n - k.  A caller that evaluates
+// its spectrum directly on the grid points { z_k or conj(z_k) } (pointwise models do) hands X[0] = bin 0,
+// X[1 + s] = u[s] to the *_slots entry points and the transform needs no gather; the adjoint returns the
+// gradient in the same order.
+extern "C" int gfdn_irfft_odd_slot_order(int n, int* bins, int* conj) {
+  if (!bins || !conj) return GFDN_E_BADARG;
+  if (n < 3 || !slot_order_ok(n)) return GFDN_E_UNSUPPORTED;
+  const int half = (n - 1) / 2;
+  unsigned long long v = 1;
+  for (int s = 0; s < half; ++s) {
+    const int k = (int)v;
+    bins[s] = k <= half ? k : n - k;
+    conj[s] = k <= half ? 0 : 1;
+    v = mulmod(v, 3, (unsigned long long)n);
+  }
+  return 0;
+}
+extern "C" int gfdn_irfft_odd_slots_fwd(const void* table, int n, const float* Xs, int ldx, int batch,
+                                        float* x, int ldo, void* work, void* stream) {
+  return blu_run(table, n, Xs, ldx, batch, x, ldo, work, 0, (hipStream_t)stream, 7, nullptr, 1);
+}
+extern "C" int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
+                                        int batch, float* gXs, int ldx, void* work, void* stream) {
+  return blu_run(table, n, gx, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, gx2, 1);
 }
 
 extern "C" int gfdn_irfft_odd_fwd(const void* table, int n, const float* X, int ldx, int batch,

@@ -394,8 +394,30 @@ def bluestein_table(n: int, device) -> torch.Tensor:
     return t
 
 
-def irfft_odd_fwd(X, n: int) -> torch.Tensor:
-    """X (batch, >= (n+1)/2) c64 -> x (batch, n) float32 = torch.fft.irfft(X, n), n odd."""
+_slot_orders = {}
+
+
+def irfft_slot_order(n: int, device):
+    """(bins (s,) int64, conj (s,) bool) on ``device`` for the slot-ordered spectrum of irfft(X, n) -- slot s holds
+    X[bins[s]] (conjugated where conj[s]) -- or None when this length has no slot-order path."""
+    key = (int(n), str(device))
+    if key not in _slot_orders:
+        import ctypes
+        half = (int(n) - 1) // 2
+        bins = (ctypes.c_int * max(half, 1))()
+        conj = (ctypes.c_int * max(half, 1))()
+        rc = _lib.load().gfdn_irfft_odd_slot_order(int(n), bins, conj) if n >= 3 and n % 2 == 1 else -2
+        if rc == 0:
+            _slot_orders[key] = (torch.tensor(list(bins), dtype=torch.int64, device=device),
+                                 torch.tensor(list(conj), dtype=torch.bool, device=device))
+        else:
+            _slot_orders[key] = None
+    return _slot_orders[key]
+
+
+def irfft_odd_fwd(X, n: int, slots: bool = False) -> torch.Tensor:
+    """X (batch, >= (n+1)/2) c64 -> x (batch, n) float32 = torch.fft.irfft(X, n), n odd.
+    ``slots``: X is in slot order (irfft_slot_order): X[:, 0] = bin 0, X[:, 1 + s] = slot s."""
     _need_gpu(X)
     X = _c(X)
     batch, ldx = X.shape
@@ -404,16 +426,17 @@ def irfft_odd_fwd(X, n: int) -> torch.Tensor:
     x = torch.empty((batch, n), dtype=_f32, device=X.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
     if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
-        _staged_bluestein(lib, table, n, X, None, ldx, batch, x, n, work, 0)
+        _staged_bluestein(lib, table, n, X, None, ldx, batch, x, n, work, 0, slots)
         return x
-    _lib.check(lib.gfdn_irfft_odd_fwd(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work),
-                                      _stream()), "gfdn_irfft_odd_fwd")
+    fn = lib.gfdn_irfft_odd_slots_fwd if slots else lib.gfdn_irfft_odd_fwd
+    _lib.check(fn(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work), _stream()), "gfdn_irfft_odd_fwd")
     return x
 
 
-def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None) -> torch.Tensor:
+def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None, slots: bool = False) -> torch.Tensor:
     """gx (batch, n) f32 -> gX (batch, ldx) c64 (adjoint of irfft_odd_fwd).  ``gx2``: optional second
-    gradient of the same shape; the transform is applied to gx + gx2 (summed on load)."""
+    gradient of the same shape; the transform is applied to gx + gx2 (summed on load).
+    ``slots``: gX comes back in slot order (ldx must be (n + 1) / 2)."""
     _need_gpu(gx)
     gx = _f(gx)
     batch = gx.shape[0]
@@ -426,11 +449,14 @@ def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None) -> torch.Tensor:
     table = bluestein_table(n, gx.device)
     gX = torch.empty((batch, ldx), dtype=_c64, device=gx.device)
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), gx.device)
+    if slots and ldx != (n + 1) // 2:
+        raise RuntimeError("irfft_odd_bwd(slots=True): the slot-ordered gradient has (n + 1) / 2 columns")
     if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
-        _staged_bluestein(lib, table, n, gx, gx2, gx.shape[1], batch, gX, ldx, work, 1)
+        _staged_bluestein(lib, table, n, gx, gx2, gx.shape[1], batch, gX, ldx, work, 1, slots)
         return gX
-    _lib.check(lib.gfdn_irfft_odd_bwd(_p(table), n, _p(gx), _p(gx2), gx.shape[1], batch, _p(gX), ldx,
-                                      _p(work), _stream()), "gfdn_irfft_odd_bwd")
+    fn = lib.gfdn_irfft_odd_slots_bwd if slots else lib.gfdn_irfft_odd_bwd
+    _lib.check(fn(_p(table), n, _p(gx), _p(gx2), gx.shape[1], batch, _p(gX), ldx, _p(work), _stream()),
+               "gfdn_irfft_odd_bwd")
     return gX
 
 
@@ -439,12 +465,13 @@ def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None) -> torch.Tensor:
 _BLU_STAGES = {'k_blu_col128_fwd': 1, 'k_blu_row512': 2, 'k_blu_col128_inv': 4}
 
 
-def _staged_bluestein(lib, table, n, src, src2, ld_in, batch, dst, ld_out, work, adjoint):
+def _staged_bluestein(lib, table, n, src, src2, ld_in, batch, dst, ld_out, work, adjoint, slots=False):
     """Same three launches as the fused entry point, with HIP events around the watched one."""
     args = (_p(table), n, _p(src), _p(src2), ld_in, batch, _p(dst), ld_out, _p(work), adjoint)
     for name, stage in _BLU_STAGES.items():
         end = kernel_timer.bracket(name, batch)
-        _lib.check(lib.gfdn_irfft_odd_stages(*args, stage, _stream()), "gfdn_irfft_odd_stages[%s]" % name)
+        _lib.check(lib.gfdn_irfft_odd_stages(*args, stage, int(bool(slots)), _stream()),
+                   "gfdn_irfft_odd_stages[%s]" % name)
         if end is not None:
             end.record()
 

@@ -169,7 +169,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  edc_target: Optional[torch.Tensor] = None,
                  side_stream: Optional["torch.cuda.Stream"] = None,
                  unit_grad: bool = False, n_time: Optional[int] = None,
-                 target_rows: Optional[torch.Tensor] = None, nbands: int = 1
+                 target_rows: Optional[torch.Tensor] = None, nbands: int = 1, slot_order: bool = False
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
@@ -186,7 +186,9 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     irfft(X, n = K) actually reads.  ``target_rows``: int64 index; ``edr_target`` / ``edc_target``
     are then stores over ALL receivers and item b compares against row target_rows[b].
     ``nbands`` > 1: the items are band-major batches of ``nbands`` independent models (BandBank); the
-    three results are then (nbands,) vectors of per-band sums (``global_batch`` = items per band)."""
+    three results are then (nbands,) vectors of per-band sums (``global_batch`` = items per band).
+    ``slot_order``: H was evaluated on the slot-ordered grid of ``ops.irfft_slot_order(n_time)`` (column 0 =
+    bin 0, column 1 + s = slot s): the transform then needs no gather and dL/dH comes back in the same order."""
     if target_rows is not None and (edr_target is None and use_edr or edc_target is None and use_edc):
         raise ValueError("target_rows needs precomputed target stores")
     targets = targets or _default_targets
@@ -196,7 +198,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     if ldx < (K + 1) // 2:
         raise ValueError("H holds fewer bins than irfft(X, n) reads")
     want_grad = H.requires_grad and torch.is_grad_enabled()
-    x = ops.irfft_odd_fwd(Hb, K)
+    x = ops.irfft_odd_fwd(Hb, K, slots=slot_order)
     env = None
     if reduced_pole_radius is not None and reduced_pole_radius != 1.0:
         # losses.py:447-451: undo sampling on a larger circle (EDR only in the reference)
@@ -248,7 +250,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         if want_grad:
             gx, gx2 = (g_edr, None) if gx is None else (gx, g_edr)
     if want_grad:
-        gH = ops.irfft_odd_bwd(gx, K, ldx, gx2)
+        gH = ops.irfft_odd_bwd(gx, K, ldx, gx2, slots=slot_order)
         return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows,
                                  nbands)
     sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows, nbands)   # [total, w_edr edr, w_edc edc]

@@ -216,12 +216,26 @@ int gfdn_irfft_odd_fwd(const void* table, int n, const float* X_c64, int ldx, in
 int gfdn_irfft_odd_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
                        int batch, float* gX_c64, int ldx, void* work, void* stream);
 
+/* Slot order (n = 65 537, Rader): the transform's natural input order is u[s] = Y[3^s mod n] (Y the Hermitian
+ * extension of X).  gfdn_irfft_odd_slot_order fills HOST arrays bins[s], conj[s], s < (n-1)/2, such that
+ * u[s] = conj[s] ? conj(X[bins[s]]) : X[bins[s]] (and u[s + (n-1)/2] = conj(u[s])).  A model that is evaluated
+ * pointwise on the frequency grid (the solve and the output stage are) can be evaluated directly on the grid
+ * points { conj[s] ? conj(z_bins[s]) : z_bins[s] } and hand Xs[0] = X[0], Xs[1 + s] = u[s] to the *_slots entry
+ * points: no gather in the forward transform, no scatter in the adjoint (gXs comes back in the same order).
+ * GFDN_E_UNSUPPORTED for other lengths.                                                              */
+int gfdn_irfft_odd_slot_order(int n, int* bins_host, int* conj_host);
+int gfdn_irfft_odd_slots_fwd(const void* table, int n, const float* Xs_c64, int ldx, int batch,
+                             float* x, int ldo, void* work, void* stream);
+int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
+                             int batch, float* gXs_c64, int ldx, void* work, void* stream);
+
 /* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
  * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so
  * that one kernel can be bracketed by HIP events on the launch stream (bench.py's roofline leg).
- * adjoint = 0: in = X (complex), out = x (real); adjoint = 1: in = gx (real) [+ in2], out = gX. */
+ * adjoint = 0: in = X (complex), out = x (real); adjoint = 1: in = gx (real) [+ in2], out = gX;
+ * slots != 0: spectrum side in slot order (see above). */
 int gfdn_irfft_odd_stages(const void* table, int n, const void* in, const float* in2, int ld_in, int batch,
-                          void* out, int ld_out, void* work, int adjoint, int stages,
+                          void* out, int ld_out, void* work, int adjoint, int stages, int slots,
                           void* stream);
 
 /* ---- power-of-two inverse real FFT (utils.py:169 get_response, losses.py:344: default

@@ -337,3 +337,87 @@ def test_bank_split_graph_path_for_data_parallel():
     for q in range(len(BANDS)):
         for k, v in out["single"][1][q].items():
             assert torch.equal(v, out["split_identity"][1][q][k]), (q, k)
+
+
+def test_irfft_slot_order_equals_natural_order():
+    """n = 65 537: the slot-ordered entry points (no gather / scatter on the spectrum side) against the natural
+    ones on the permuted data; the order itself against 3^s mod n."""
+    from diffgfdn_amd import hip_ops as ops
+    n = 65537
+    bins, conj = ops.irfft_slot_order(n, DEV)
+    half = (n - 1) // 2
+    assert bins.shape == (half,) and int(bins.min()) == 1 and int(bins.max()) == half
+    assert sorted(bins.tolist()) == list(range(1, half + 1))                 # a permutation of 1..(n-1)/2
+    for s_ in (0, 1, 2, 17, 4099, half - 1):
+        k = pow(3, s_, n)
+        assert int(bins[s_]) == (k if k <= half else n - k) and bool(conj[s_]) == (k > half)
+    assert ops.irfft_slot_order(257, DEV) is None                           # only the 128 x 512 geometry has it
+    g = torch.Generator().manual_seed(3)
+    B = 3
+    X = torch.view_as_complex(torch.randn(B, half + 1, 2, generator=g)).to(DEV)
+    Xs = torch.cat([X[:, :1], torch.where(conj, X[:, bins].conj(), X[:, bins])], dim=1).contiguous()
+    x = ops.irfft_odd_fwd(X, n)
+    xs = ops.irfft_odd_fwd(Xs, n, slots=True)
+    assert rel_err(xs.cpu(), x.cpu()) < 1e-6
+    gx = torch.randn(B, n, generator=g).to(DEV)
+    gx2 = torch.randn(B, n, generator=g).to(DEV)
+    gX = ops.irfft_odd_bwd(gx, n, half + 1, gx2)
+    gXs = ops.irfft_odd_bwd(gx, n, half + 1, gx2, slots=True)
+    want = torch.cat([gX[:, :1], torch.where(conj, gX[:, bins].conj(), gX[:, bins])], dim=1)
+    assert rel_err(torch.view_as_real(gXs).cpu(), torch.view_as_real(want).cpu()) < 1e-6
+
+
+def test_bank_step_slot_order_equals_natural_order_full_size():
+    """nfft = 131 072 (K = 65 537, the north-star length): one bank step with the main branch evaluated on the
+    irfft's slot-ordered grid against the same step on the natural grid -- losses and every gradient."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    from diffgfdn_amd.config import (CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig,
+                                     SubbandProcessingConfig, TrainerConfig)
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.synthetic import synthetic_room
+    from scipy.signal import firwin
+    fs, nfft, G, nper, R, B = 32000.0, 131072, 4, 4, 6, 2
+    K = nfft // 2 + 1
+    centres = (250.0, 1000.0)
+    delays = [[641, 701, 809, 907, 1009, 1103, 1201, 1301, 1399, 1409, 1423, 1427, 1429, 1433, 1439, 1601],
+              [643, 709, 811, 911, 1013, 1109, 1213, 1303, 1381, 1411, 1423, 1427, 1447, 1451, 1453, 1601]]
+    filt = torch.tensor(np.stack([np.fft.rfft(firwin(1025, [f / np.sqrt(2), f * np.sqrt(2)], pass_zero=False,
+                                                     fs=fs), n=nfft) for f in centres]), device=DEV).to(torch.complex64)
+    res = {}
+    for mode in (True, False):
+        nets, dss = [], []
+        for q in range(2):
+            room = synthetic_room(R, G, fs, 40000, seed=40 + q)
+            dss.append(MultiRIRDataset(DEV, RoomDataset(G, fs, room["source_position"], room["receiver_position"],
+                                                        room["rirs"], room["common_decay_times"], nfft=nfft, device=DEV)))
+            torch.manual_seed(200 + q)
+            fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+            of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+            nets.append(DiffGFDNVarReceiverPos(fs, G, delays[q], DEV, fl, of, use_absorption_filters=False,
+                                               common_decay_times=room["common_decay_times"],
+                                               use_colorless_loss=True).to(DEV))
+        tc = TrainerConfig(batch_size=B, num_freq_bins=nfft, lr=1e-3, io_lr=1e-2, use_colorless_loss=True,
+                           use_asym_spectral_loss=True, edc_loss_weight=10.0, sparsity_loss_weight=2.0,
+                           use_edc_mask=False, train_dir="/tmp/gfdn_bank/t", ir_dir="/tmp/gfdn_bank/a", device="cuda",
+                           subband_process_config=SubbandProcessingConfig(centre_frequency=500.0,
+                                                                          frequency_range=(63, 8000),
+                                                                          num_fraction_octaves=1))
+        bank = BandBank(nets)
+        tr = BandBankTrainer(bank, tc, subband_filter_freq_resp=filt, band_names=centres)
+        tr.use_slot_order = mode
+        sds = BandStackedDataset(dss)
+        start, length = tr._decay_window(K)
+        sds.precompute_decay_targets(4096, start, length)
+        batch = sds.collate(sds.global_rows([[0, 3], [1, 4]]))
+        tr.normalize(batch)
+        tr.optimizer.zero_grad(set_to_none=True)
+        losses = tr._step_losses(batch, draw_mask=False, defer_total=True)
+        heads = losses.pop("_heads")
+        torch.autograd.backward(heads, [torch.ones(2, device=DEV)] * 2)
+        tr.optimizer.pack_grads()
+        res[mode] = ({k: v.detach().cpu().numpy() for k, v in losses.items()}, tr.optimizer.flat_grad.cpu().numpy().copy())
+    for k in res[True][0]:
+        assert np.allclose(res[True][0][k], res[False][0][k], rtol=2e-5, atol=0), (k, res[True][0][k], res[False][0][k])
+    ga, gb = res[True][1], res[False][1]
+    assert np.abs(ga - gb).max() < 2e-4 * np.abs(gb).max()

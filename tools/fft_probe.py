@@ -16,7 +16,7 @@ for so in sorted(glob.glob(os.path.join(os.path.dirname(__file__), '_probe', 'ff
     lib.gfdn_bluestein_table_bytes.restype = ctypes.c_size_t; lib.gfdn_bluestein_table_bytes.argtypes = [I]
     lib.gfdn_bluestein_work_bytes.restype = ctypes.c_size_t; lib.gfdn_bluestein_work_bytes.argtypes = [I, I]
     lib.gfdn_bluestein_table_init.argtypes = [I, P]
-    lib.gfdn_irfft_odd_stages.argtypes = [P, I, P, P, I, I, P, I, P, I, I, P]
+    lib.gfdn_irfft_odd_stages.argtypes = [P, I, P, P, I, I, P, I, P, I, I, I, P]
     lib.gfdn_stft_power.argtypes = [P, I, I, I, I, P, P, P]
     lib.gfdn_stft_power_bwd.argtypes = [P, I, I, I, I, P, P, P]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -26,8 +26,9 @@ for so in sorted(glob.glob(os.path.join(os.path.dirname(__file__), '_probe', 'ff
     xo = torch.empty(B, K, device=dev); gX = torch.empty(B, (K + 1) // 2, dtype=torch.complex64, device=dev)
     Pw = torch.empty(B, 32, 2049, device=dev); gx = torch.zeros(B, K, device=dev)
     def stage(adj, stg):
-        if adj: return lambda: lib.gfdn_irfft_odd_stages(p(table), K, p(x), None, K, B, p(gX), (K + 1) // 2, p(work), 1, stg, st)
-        return lambda: lib.gfdn_irfft_odd_stages(p(table), K, p(X), None, (K + 1) // 2, B, p(xo), K, p(work), 0, stg, st)
+        if adj: return lambda: lib.gfdn_irfft_odd_stages(p(table), K, p(x), None, K, B, p(gX), (K + 1) // 2, p(work), 1, stg, SLOTS, st)
+        return lambda: lib.gfdn_irfft_odd_stages(p(table), K, p(X), None, (K + 1) // 2, B, p(xo), K, p(work), 0, stg, SLOTS, st)
+    SLOTS = int(os.environ.get('SLOTS', '0'))
     fns = [('col_fwd', stage(0, 1)), ('row', stage(0, 2)), ('col_inv', stage(0, 4)), ('irfft', stage(0, 7)),
            ('a.col_fwd', stage(1, 1)), ('a.row', stage(1, 2)), ('a.col_inv', stage(1, 4)), ('a.irfft', stage(1, 7)),
            ('stft', lambda: lib.gfdn_stft_power(p(x), K, K, B, WIN, p(Pw), None, st)),
