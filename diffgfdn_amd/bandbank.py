@@ -286,6 +286,7 @@ class BandBankTrainer:
     capturable = True
     concurrent_branches = True
     use_slot_order = True        # evaluate the main branch on the irfft's slot-ordered grid when the length has one
+    use_pairs = True             # ... and carry two items per transform, time signals pair-interleaved
 
     def __init__(self, bank: BandBank, trainer_config: TrainerConfig,
                  subband_filter_freq_resp: Optional[torch.Tensor] = None, process_group=None,
@@ -467,7 +468,8 @@ class BandBankTrainer:
             edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
             edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
             edr_target=(edr_t[1], edr_t[2]), edc_target=edc_t[1], side_stream=self._stream('_side2'),
-            unit_grad=True, n_time=K, target_rows=rows, nbands=nb, slot_order=order is not None)
+            unit_grad=True, n_time=K, target_rows=rows, nbands=nb, slot_order=order is not None,
+            pairs=order is not None and self.use_pairs and self.stft_win == 4096)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v, 'spectral_loss': spec.detach(),
                   'sparsity_loss': sparse.detach()}
         if side is not None:

@@ -391,6 +391,8 @@ struct BluArgs {
   float* edge;          // rader: per-(item, column block) partial sums for the t = 0 / k = 0 terms
   int nedge;            // rader: partials per item
   int batch;
+  int pair;             // slot mode only: items 2b, 2b+1 share one transform; time signals pair-interleaved (float2)
+  int items;            // number of items (rows of the spectrum side)
   int slot;             // Rader + col128: the SPECTRUM side is in slot order (gfdn_irfft_odd_slot_order): no gather / scatter
   const float2* chirp;  // n
   const float2* chat;   // L, [k1][k2]
@@ -782,9 +784,38 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
   int tb, b;
   xcd_item_map(L2 / 32, a.batch, tb, b);
   const int tile = tb * 4 + wave, c0 = tile * 8;
-  float edge = 0.f;
+  float edge = 0.f, edge2 = 0.f;
   float2 v[16];
-  if (a.slot && !a.adjoint) {
+  const int b1 = a.pair ? 2 * b : b;
+  const bool two = a.pair && b1 + 1 < a.items;
+  if (a.pair && !a.adjoint) {
+    // two slot-ordered spectra ride one transform as u1 + i u2 (the results are real: they come back as the
+    // real / imaginary part -- see k_blu_col128_inv); rows n1 and n1 + 64 hold conj(u1) + i conj(u2)
+    const float2* X1 = (const float2*)a.in + (size_t)b1 * a.ld_in + 1;
+    const float2* X2 = X1 + a.ld_in;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t idx = (size_t)(l + 8 * k) * L2 + c0 + c;
+      const float2 p = X1[idx], q = two ? X2[idx] : make_float2(0.f, 0.f);
+      v[k] = make_float2(p.x - q.y, p.y + q.x);
+      v[k + 8] = make_float2(p.x + q.y, q.x - p.y);
+      edge += p.x;
+      edge2 += q.x;
+    }
+  } else if (a.pair) {
+    // adjoint: the pair-interleaved real gradients ARE the complex input G1 + i G2
+    const float2* G = (const float2*)a.in + (size_t)b * a.ld_in;
+    const float2* G2 = a.in2 ? (const float2*)a.in2 + (size_t)b * a.ld_in : nullptr;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int src = a.iperm[(l + 8 * k) * L2 + c0 + c];
+      float2 gv = G[src];
+      if (G2) { const float2 g2 = G2[src]; gv.x += g2.x; gv.y += g2.y; }
+      v[k] = gv;
+      edge += gv.x;
+      edge2 += gv.y;
+    }
+  } else if (a.slot && !a.adjoint) {
     // spectrum in slot order: X[0] = bin 0, X[1 + s] = u[s] for s < L/2, and u[s + L/2] = conj(u[s]) -- rows
     // n1 and n1 + 64 of a column are conjugates, both held by this lane: 8 coalesced loads, no gather
     const float2* Xs = (const float2*)a.in + (size_t)b * a.ld_in + 1;
@@ -798,9 +829,13 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = blu_load_elem(a, b, (l + 8 * k) * L2 + c0 + c, edge);
   }
-  if (a.rader) {                       // one partial per tile, folded by the inverse column pass
+  if (a.rader) {                       // one partial per (item, tile), folded by the inverse column pass
     edge = wave_sum(edge);
-    if (lane == 0) a.edge[(size_t)b * a.nedge + tile] = edge;
+    if (lane == 0) a.edge[(size_t)b1 * a.nedge + tile] = edge;
+    if (two) {
+      edge2 = wave_sum(edge2);
+      if (lane == 0) a.edge[(size_t)(b1 + 1) * a.nedge + tile] = edge2;
+    }
   }
   __syncthreads();                     // twiddle tables
   col128_fft(v, bufs + wave * CW_LDS, l, c, 1.0f);
@@ -827,6 +862,58 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
   float2 v[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) v[k] = wk[(size_t)(l + 8 * k) * L2 + c0 + c];
+  if (a.pair) {
+    const int b1 = 2 * b;
+    const bool two = b1 + 1 < a.items;
+    const float invL = 1.0f / (float)L, invn = 1.0f / (float)g.n;
+    float sum1 = 0.f, sum2 = 0.f;
+    const bool folder = tb == 0 && threadIdx.x == 0;
+    if (folder) {                        // t = 0 / k = 0 terms (fixed order)
+      for (int e = 0; e < a.nedge; ++e) {
+        sum1 += a.edge[(size_t)b1 * a.nedge + e];
+        if (two) sum2 += a.edge[(size_t)(b1 + 1) * a.nedge + e];
+      }
+    }
+    col128_fft(v, bufs + wave * CW_LDS, l, c, -1.0f);
+    if (!a.adjoint) {
+      // the two real results are the real / imaginary part: ONE 8-byte scatter per slot serves both items
+      const float2* X = (const float2*)a.in;
+      const float x01 = X[(size_t)b1 * a.ld_in].x, x02 = two ? X[(size_t)(b1 + 1) * a.ld_in].x : 0.f;
+      float2* xo = (float2*)a.out + (size_t)b * a.ld_out;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
+        xo[a.iperm[n1 * L2 + c0 + c]] = make_float2((x01 + v[q].x * invL) * invn, (x02 + v[q].y * invL) * invn);
+      }
+      if (folder) xo[0] = make_float2((x01 + 2.0f * sum1) * invn, (x02 + 2.0f * sum2) * invn);
+    } else {
+      // W = W1 + i W2 with W_j[s + L/2] = conj(W_j[s]) (real inputs, kernel symmetry): the two gradients
+      // separate from the slot pair (s, s + L/2) = rows (n1, n1 + 64), held by this lane (q, q ^ 4)
+      const float2* G = (const float2*)a.in + (size_t)b * a.ld_in;
+      float2 g0 = G[0];
+      if (a.in2) { const float2 t2 = ((const float2*)a.in2 + (size_t)b * a.ld_in)[0]; g0.x += t2.x; g0.y += t2.y; }
+      const float sc = 2.0f * invL * invn;
+      float2* o1 = (float2*)a.out + (size_t)b1 * a.ld_out;
+      float2* o2 = o1 + a.ld_out;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
+        if (n1 < 64) {
+          const float2 p = v[q ^ 4];
+          const float2 W1 = make_float2(0.5f * (v[q].x + p.x), 0.5f * (v[q].y - p.y));
+          const float2 W2 = make_float2(0.5f * (v[q].y + p.y), -0.5f * (v[q].x - p.x));
+          const size_t idx = 1 + (size_t)n1 * L2 + c0 + c;
+          o1[idx] = make_float2(sc * W1.x + 2.0f * invn * g0.x, -sc * W1.y);
+          if (two) o2[idx] = make_float2(sc * W2.x + 2.0f * invn * g0.y, -sc * W2.y);
+        }
+      }
+      if (folder) {
+        o1[0] = make_float2((sum1 + g0.x) * invn, 0.f);
+        if (two) o2[0] = make_float2((sum2 + g0.y) * invn, 0.f);
+      }
+    }
+    return;
+  }
   if (a.rader && tb == 0 && threadIdx.x == 0) blu_edge_fold(a, b);
   if (a.rader && a.adjoint) {          // bins above (n-1)/2 carry no gradient
     float2* o = (float2*)a.out + (size_t)b * a.ld_out;
@@ -885,6 +972,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if (g.L1 > 1024 || g.L2 > 2048) return GFDN_E_UNSUPPORTED;
   if (!adjoint && (ld_in < g.nin || ld_out < n)) return GFDN_E_BADARG;
   if (adjoint && (ld_in < n || ld_out < g.nin || (!rader && ld_out > g.L))) return GFDN_E_BADARG;
+  if (slot && adjoint && ld_out != g.nin) return GFDN_E_BADARG;
   BluArgs a;
   a.g = g;
   a.rader = rader ? 1 : 0;
@@ -903,8 +991,11 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   a.nedge = g.L2 / tc0;
   a.edge = (float*)((char*)work + (size_t)batch * g.L * sizeof(float2));   // after the work blocks
   a.batch = batch;
-  a.slot = slot;
+  a.items = batch;
+  a.slot = slot ? 1 : 0;
+  a.pair = slot == 2 ? 1 : 0;
   if (slot && !slot_order_ok(n)) return GFDN_E_UNSUPPORTED;
+  if (a.pair) a.batch = (batch + 1) / 2;          // work blocks = item pairs
   a.adjoint = adjoint;
   a.in = in;
   a.in2 = adjoint ? in2 : nullptr;
@@ -923,7 +1014,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   const size_t tw2_elems = (size_t)((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS);
   if (stages & 1) {
     if (col128)
-      hipLaunchKernelGGL(k_blu_col128_fwd, dim3((g.L2 / 32) * batch), dim3(256),
+      hipLaunchKernelGGL(k_blu_col128_fwd, dim3((g.L2 / 32) * a.batch), dim3(256),
                          (tw2_elems + 4 * CW_LDS) * sizeof(float2), s, a);
     else
       hipLaunchKernelGGL(k_blu_col_fwd, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
@@ -933,7 +1024,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
     if (g.L2 == 512 && g.L1 % 4 == 0) {
       const size_t lr5 = (128 + ((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS) +
                           4 * ROW512_LDS) * sizeof(float2);
-      hipLaunchKernelGGL(k_blu_row512, dim3((g.L1 / 4) * batch), dim3(256), lr5, s, a);
+      hipLaunchKernelGGL(k_blu_row512, dim3((g.L1 / 4) * a.batch), dim3(256), lr5, s, a);
     } else {
       hipLaunchKernelGGL(k_blu_row, dim3((g.L1 / tr) * batch), dim3(256), lr, s, a);
     }
@@ -941,7 +1032,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   }
   if (stages & 4) {
     if (col128)
-      hipLaunchKernelGGL(k_blu_col128_inv, dim3((g.L2 / 32) * batch), dim3(256), 4 * CW_LDS * sizeof(float2), s, a);
+      hipLaunchKernelGGL(k_blu_col128_inv, dim3((g.L2 / 32) * a.batch), dim3(256), 4 * CW_LDS * sizeof(float2), s, a);
     else
       hipLaunchKernelGGL(k_blu_col_inv, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
     GFDN_LAUNCH_CHECK();
@@ -980,6 +1071,17 @@ extern "C" int gfdn_irfft_odd_slots_fwd(const void* table, int n, const float* X
 extern "C" int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
                                         int batch, float* gXs, int ldx, void* work, void* stream) {
   return blu_run(table, n, gx, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, gx2, 1);
+}
+
+// Pairs: slot-ordered spectra in, pair-interleaved time signals out (x2: (ceil(batch / 2), ldo) float2, item 2p
+// in .x, item 2p + 1 in .y) and the adjoint of that -- two items per complex transform.
+extern "C" int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs, int ldx, int batch,
+                                        float* x2, int ldo, void* work, void* stream) {
+  return blu_run(table, n, Xs, ldx, batch, x2, ldo, work, 0, (hipStream_t)stream, 7, nullptr, 2);
+}
+extern "C" int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
+                                        int batch, float* gXs, int ldx, void* work, void* stream) {
+  return blu_run(table, n, gx2, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, gx2b, 2);
 }
 
 extern "C" int gfdn_irfft_odd_fwd(const void* table, int n, const float* X, int ldx, int batch,
@@ -1251,6 +1353,151 @@ __global__ __launch_bounds__(S4K_T) void k_stft4k_power_bwd(const float* __restr
     if (j < lim_b) atomicAdd(g + j + 2048, hw * a[u].y);
     if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the address arithmetic of later chunks out of this one
   }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Pair-interleaved signals (x2 (pairs, ld) float2: item 2p in .x, item 2p + 1 in .y -- the layout the paired
+// irfft produces and consumes): the float2 sample IS the complex FFT input, so one complex FFT carries ONE
+// frame of TWO items (instead of two frames of one item); the Hermitian split is the same.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void s4k_load_pair(const float2* __restrict__ x2, int T, int m, int i,
+                                              float2 (&a)[16], float2& w1) {
+  float sn, cs;
+  sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
+  w1 = make_float2(cs, -sn);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float sk, ck;
+    sincospif((float)k * 0.125f, &sk, &ck);
+    const float h = 0.5f - 0.5f * (cs * ck - sn * sk);
+    const int t = m * 2048 + i + 256 * k;
+    const float2 v = t < T ? x2[t] : make_float2(0.f, 0.f);
+    a[k] = make_float2(h * v.x, h * v.y);
+  }
+}
+
+__global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power(const float2* __restrict__ x2, int ld, int T,
+                                                             int nframes, int items, float* __restrict__ P,
+                                                             float2* __restrict__ zero_buf) {
+  float2* buf = dyn_lds;
+  const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
+  const int b1 = 2 * p;
+  const bool two = b1 + 1 < items;
+  if (zero_buf) {      // clear the adjoint's accumulation buffer: this frame's first hop, the last frame the tail
+    float2* zb = zero_buf + (size_t)p * ld;
+    const int t0 = m * 2048;
+    const int t1 = (m == (int)gridDim.x - 1) ? ld : t0 + 2048;
+    for (int t = t0 + i; t < t1 && t < ld; t += S4K_T) zb[t] = make_float2(0.f, 0.f);
+  }
+  float2 a[16], w1;
+  s4k_load_pair(x2 + (size_t)p * ld, T, m, i, a, w1);
+  fft4096(a, buf, i, w1, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+  __syncthreads();
+  float* P1 = P + ((size_t)b1 * nframes + m) * nf;
+  float* P2 = P1 + (size_t)nframes * nf;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const float2 zf = a[u], zc = buf[S4K_PAD((4096 - f) & 4095)];
+      const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+      P1[f] = sa.x * sa.x + sa.y * sa.y;
+      if (two) P2[f] = sb.x * sb.x + sb.y * sb.y;
+    }
+  }
+}
+
+__global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
+                                                                 int nframes, int items,
+                                                                 const float* __restrict__ gP,
+                                                                 float2* __restrict__ gx2) {
+  float2* buf = dyn_lds;
+  const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
+  const int b1 = 2 * p;
+  const bool two = b1 + 1 < items;
+  float2 a[16], w1;
+  s4k_load_pair(x2 + (size_t)p * ld, T, m, i, a, w1);
+  fft4096(a, buf, i, w1, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+  __syncthreads();
+  const float* ga = gP + ((size_t)b1 * nframes + m) * nf;
+  const float* gb = ga + (size_t)nframes * nf;
+#pragma unroll 3
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const int fc = (4096 - f) & 4095;
+      const float2 zf = buf[S4K_PAD(f)], zc = buf[S4K_PAD(fc)];
+      const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+      const float pa = ga[f], pb = two ? gb[f] : 0.f;
+      const float2 Ga = cscale(sa, 2.0f * pa), Gb = cscale(sb, 2.0f * pb);   // G = 2 gP S
+      if (f == 0 || f == 2048) {
+        buf[S4K_PAD(f)] = make_float2(Ga.x, Gb.x);
+      } else {
+        buf[S4K_PAD(f)] = make_float2(0.5f * (Ga.x - Gb.y), 0.5f * (Ga.y + Gb.x));
+        buf[S4K_PAD(fc)] = make_float2(0.5f * (Ga.x + Gb.y), 0.5f * (-Ga.y + Gb.x));
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
+  __syncthreads();
+  fft4096(a, buf, i, w1, -1.0f);
+  // Scatter with CONTIGUOUS atomics: lane L of a wave adds component (L & 1) of the wave's sample (L >> 1)
+  // [+ 32 in the second instruction], fetched from the owning lane by shuffle -- each instruction covers 256
+  // consecutive bytes.  (Adding .x and .y from the owning lane puts every instruction on 8-byte strides: twice
+  // the (instruction, cache line) pairs at the L2 atomic units, 236 vs 127 us.)
+  const int lane = i & 63, wbase = i & ~63;
+  const int comp = lane & 1, s0 = lane >> 1;
+  float* gw = (float*)(gx2 + (size_t)p * ld + m * 2048 + wbase);     // this wave's 64 samples of chunk u = 0
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    float sk, ck;
+    sincospif((float)u * 0.125f, &sk, &ck);
+    const float hw = 0.5f - 0.5f * (w1.x * ck + w1.y * sk);
+    const float vx = hw * a[u].x, vy = hw * a[u].y;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sidx = s0 + 32 * h;                                  // sample of this wave served by this lane
+      const float ox = __shfl(vx, sidx, 64), oy = __shfl(vy, sidx, 64);
+      const int t = m * 2048 + 256 * u + wbase + sidx;
+      if (t < T && (comp == 0 || two)) atomicAdd(gw + 2 * (256 * u + 32 * h) + lane, comp ? oy : ox);
+    }
+  }
+}
+
+extern "C" int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P,
+                                     float* zero_buf2, void* stream) {
+  if (!x2 || !P || items <= 0 || ld < T) return GFDN_E_BADARG;
+  if (win != 4096) return GFDN_E_UNSUPPORTED;
+  const int nframes = gfdn_stft_nframes(T, win);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_stft4k_pair_power, dim3(nframes, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                     (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, P, (float2*)zero_buf2);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
+                                         float* gx2, void* stream) {
+  if (!x2 || !gP || !gx2 || items <= 0 || ld < T) return GFDN_E_BADARG;
+  if (win != 4096) return GFDN_E_UNSUPPORTED;
+  const int nframes = gfdn_stft_nframes(T, win);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_stft4k_pair_power_bwd, dim3(nframes, (items + 1) / 2), dim3(S4K_T),
+                     S4K_LDS * sizeof(float2), (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, gP,
+                     (float2*)gx2);
+  GFDN_LAUNCH_CHECK();
+  return 0;
 }
 
 static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }

@@ -415,10 +415,27 @@ def irfft_slot_order(n: int, device):
     return _slot_orders[key]
 
 
-def irfft_odd_fwd(X, n: int, slots: bool = False) -> torch.Tensor:
+def irfft_odd_fwd(X, n: int, slots: bool = False, pairs: bool = False) -> torch.Tensor:
     """X (batch, >= (n+1)/2) c64 -> x (batch, n) float32 = torch.fft.irfft(X, n), n odd.
-    ``slots``: X is in slot order (irfft_slot_order): X[:, 0] = bin 0, X[:, 1 + s] = slot s."""
+    ``slots``: X is in slot order (irfft_slot_order): X[:, 0] = bin 0, X[:, 1 + s] = slot s.
+    ``pairs`` (with slots): two items per transform; returns x2 (ceil(batch / 2), n, 2) float32, item 2p in
+    [..., 0], item 2p + 1 in [..., 1] (zeros for the missing partner of an odd batch)."""
     _need_gpu(X)
+    if pairs:
+        if not slots:
+            raise RuntimeError("irfft_odd_fwd(pairs=True) takes slot-ordered spectra")
+        X = _c(X)
+        batch, ldx = X.shape
+        lib = _lib.load()
+        table = bluestein_table(n, X.device)
+        x2 = torch.empty(((batch + 1) // 2, n, 2), dtype=_f32, device=X.device)
+        work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
+        if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
+            _staged_bluestein(lib, table, n, X, None, ldx, batch, x2, n, work, 0, 2)
+            return x2
+        _lib.check(lib.gfdn_irfft_odd_pairs_fwd(_p(table), n, _p(X), ldx, batch, _p(x2), n, _p(work), _stream()),
+                   "gfdn_irfft_odd_pairs_fwd")
+        return x2
     X = _c(X)
     batch, ldx = X.shape
     lib = _lib.load()
@@ -431,6 +448,27 @@ def irfft_odd_fwd(X, n: int, slots: bool = False) -> torch.Tensor:
     fn = lib.gfdn_irfft_odd_slots_fwd if slots else lib.gfdn_irfft_odd_fwd
     _lib.check(fn(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work), _stream()), "gfdn_irfft_odd_fwd")
     return x
+
+
+def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None) -> torch.Tensor:
+    """Adjoint of irfft_odd_fwd(slots=True, pairs=True): g2 (ceil(batch / 2), n, 2) f32 pair-interleaved gradients
+    [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order."""
+    _need_gpu(g2)
+    npairs = (batch + 1) // 2
+    for t in (g2, g2b):
+        if t is not None and (t.dtype != _f32 or not t.is_contiguous() or tuple(t.shape) != (npairs, n, 2)):
+            raise RuntimeError("irfft_odd_pairs_bwd: pair-interleaved float32 gradients (pairs, n, 2) expected")
+    lib = _lib.load()
+    table = bluestein_table(n, g2.device)
+    ldx = (n + 1) // 2
+    gX = torch.empty((batch, ldx), dtype=_c64, device=g2.device)
+    work = _work(lib.gfdn_bluestein_work_bytes(n, batch), g2.device)
+    if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
+        _staged_bluestein(lib, table, n, g2, g2b, n, batch, gX, ldx, work, 1, 2)
+        return gX
+    _lib.check(lib.gfdn_irfft_odd_pairs_bwd(_p(table), n, _p(g2), _p(g2b), n, batch, _p(gX), ldx, _p(work),
+                                            _stream()), "gfdn_irfft_odd_pairs_bwd")
+    return gX
 
 
 def irfft_odd_bwd(gx, n: int, ldx: int, gx2=None, slots: bool = False) -> torch.Tensor:
@@ -470,7 +508,7 @@ def _staged_bluestein(lib, table, n, src, src2, ld_in, batch, dst, ld_out, work,
     args = (_p(table), n, _p(src), _p(src2), ld_in, batch, _p(dst), ld_out, _p(work), adjoint)
     for name, stage in _BLU_STAGES.items():
         end = kernel_timer.bracket(name, batch)
-        _lib.check(lib.gfdn_irfft_odd_stages(*args, stage, int(bool(slots)), _stream()),
+        _lib.check(lib.gfdn_irfft_odd_stages(*args, stage, int(slots), _stream()),
                    "gfdn_irfft_odd_stages[%s]" % name)
         if end is not None:
             end.record()
@@ -560,6 +598,53 @@ def stft_power_bwd(x, win: int, gP, gx_accum: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.load().gfdn_stft_power_bwd(_p(x), T, T, batch, win, _p(gP), _p(gx_accum),
                                                _stream()), "gfdn_stft_power_bwd")
     return gx_accum
+
+
+def stft_power_pairs(x2, items: int, win: int, zero_buf=None) -> torch.Tensor:
+    """x2 (ceil(items / 2), T, 2) pair-interleaved signals -> P (items, nframes, win/2+1) = |STFT|^2 (win = 4096).
+    ``zero_buf``: a buffer shaped like x2, cleared by the same launch (accumulation buffer of the adjoint)."""
+    _need_gpu(x2)
+    if x2.dtype != _f32 or not x2.is_contiguous() or x2.dim() != 3 or x2.shape[2] != 2 or x2.shape[0] != (items + 1) // 2:
+        raise RuntimeError("stft_power_pairs: x2 must be contiguous float32 (ceil(items / 2), T, 2)")
+    T = x2.shape[1]
+    nf = stft_nframes(T, win)
+    if zero_buf is not None and (zero_buf.dtype != _f32 or zero_buf.shape != x2.shape or not zero_buf.is_contiguous()):
+        raise RuntimeError("stft_power_pairs: zero_buf must be shaped like x2")
+    P = torch.empty((items, nf, win // 2 + 1), dtype=_f32, device=x2.device)
+    _lib.check(_lib.load().gfdn_stft_power_pairs(_p(x2), T, T, items, win, _p(P), _p(zero_buf), _stream()),
+               "gfdn_stft_power_pairs")
+    return P
+
+
+def stft_power_pairs_bwd(x2, items: int, win: int, gP, g2_accum: torch.Tensor) -> torch.Tensor:
+    """Accumulates d<gP, P>/dx2 into g2_accum (shaped like x2) and returns it."""
+    _need_gpu(x2, gP, g2_accum)
+    assert g2_accum.dtype == _f32 and g2_accum.is_contiguous() and g2_accum.shape == x2.shape
+    T = x2.shape[1]
+    _lib.check(_lib.load().gfdn_stft_power_pairs_bwd(_p(x2), T, T, items, win, _p(gP), _p(g2_accum), _stream()),
+               "gfdn_stft_power_pairs_bwd")
+    return g2_accum
+
+
+def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
+                   gscale: float = 1.0, want_grad: bool = True, rows=None):
+    """edc_loss on pair-interleaved signals x2 (ceil(items / 2), T, 2) -> loss_item (items,), g2 like x2 or None."""
+    _need_gpu(x2, T_db)
+    T = x2.shape[1]
+    rows = _rows(rows, items, T_db.shape[0])
+    if T_db.dtype != _f32 or not T_db.is_contiguous() or T_db.shape[-1] != length \
+            or (rows is None and T_db.shape[0] != items):
+        raise RuntimeError("edc_loss_pairs: target shape does not match the window")
+    maskw = None if maskw is None else _f(maskw)
+    loss_item = torch.empty(items, dtype=_f32, device=x2.device)
+    # the missing partner of an odd batch is never written by the kernel: its lane must read as zero
+    g2 = (torch.zeros_like(x2) if items % 2 else torch.empty_like(x2)) if want_grad else None
+    lib = _lib.load()
+    work = _work(lib.gfdn_edc_work_bytes(items), x2.device)
+    _lib.check(lib.gfdn_edc_loss_pairs(_p(x2), T, items, start, length, _p(T_db), _p(rows), _p(maskw),
+                                       float(inv_count), float(gscale), _p(loss_item), _p(g2), _p(work),
+                                       _stream()), "gfdn_edc_loss_pairs")
+    return loss_item, g2
 
 
 def edr_target(P: torch.Tensor):

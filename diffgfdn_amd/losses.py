@@ -15,6 +15,7 @@ target tensor and cached (:class:`DecayTargets`).
 Not on the accelerated path (reference defaults leave them off): ERB grouping
 (``use_erb_grouping``), sub-band EDC (``band_centre_hz``), ``reg_loss``.
 """
+import contextlib
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -169,8 +170,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  edc_target: Optional[torch.Tensor] = None,
                  side_stream: Optional["torch.cuda.Stream"] = None,
                  unit_grad: bool = False, n_time: Optional[int] = None,
-                 target_rows: Optional[torch.Tensor] = None, nbands: int = 1, slot_order: bool = False
-                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                 target_rows: Optional[torch.Tensor] = None, nbands: int = 1, slot_order: bool = False,
+                 pairs: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
     Returns (total, w_edr * edr, w_edc * edc) with total = their sum carrying the gradient; the two
@@ -188,7 +189,18 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     ``nbands`` > 1: the items are band-major batches of ``nbands`` independent models (BandBank); the
     three results are then (nbands,) vectors of per-band sums (``global_batch`` = items per band).
     ``slot_order``: H was evaluated on the slot-ordered grid of ``ops.irfft_slot_order(n_time)`` (column 0 =
-    bin 0, column 1 + s = slot s): the transform then needs no gather and dL/dH comes back in the same order."""
+    bin 0, column 1 + s = slot s): the transform then needs no gather and dL/dH comes back in the same order.
+    ``pairs`` (with slot_order, win 4096, precomputed targets): two items ride one complex transform and the time
+    signals stay pair-interleaved (float2) through the STFT / EDC kernels: one 8-byte scatter / gather per slot
+    serves two items and the transform passes move half the work blocks."""
+    if pairs:
+        return _decay_losses_pairs(H, win=win, edr_weight=edr_weight, edc_weight=edc_weight, edc_start=edc_start,
+                                   edc_len=edc_len, edc_maskw=edc_maskw, edc_count=edc_count,
+                                   edc_maskw_prenormalised=edc_maskw_prenormalised, global_batch=global_batch,
+                                   edr_target=edr_target, edc_target=edc_target, side_stream=side_stream,
+                                   unit_grad=unit_grad, n_time=n_time, target_rows=target_rows, nbands=nbands,
+                                   slot_order=slot_order, freq_weights=freq_weights,
+                                   reduced_pole_radius=reduced_pole_radius)
     if target_rows is not None and (edr_target is None and use_edr or edc_target is None and use_edc):
         raise ValueError("target_rows needs precomputed target stores")
     targets = targets or _default_targets
@@ -254,6 +266,53 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows,
                                  nbands)
     sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, edr_div, edr_rows, nbands)   # [total, w_edr edr, w_edc edc]
+    if nbands > 1:
+        return sums[:, 0], sums[:, 1], sums[:, 2]
+    return sums[0], sums[1], sums[2]
+
+
+def _decay_losses_pairs(H, *, win, edr_weight, edc_weight, edc_start, edc_len, edc_maskw, edc_count,
+                        edc_maskw_prenormalised, global_batch, edr_target, edc_target, side_stream, unit_grad,
+                        n_time, target_rows, nbands, slot_order, freq_weights, reduced_pole_radius):
+    """decay_losses on pair-interleaved time signals (see there); EDR and EDC both on, targets precomputed."""
+    if not slot_order or win != 4096 or edr_target is None or edc_target is None or n_time is None:
+        raise ValueError("pairs: slot-ordered H, win 4096 and precomputed EDR / EDC targets are required")
+    if reduced_pole_radius is not None and reduced_pole_radius != 1.0:
+        raise NotImplementedError("pairs: unit-circle sampling only")
+    Hb = _as_batch(H)
+    B = Hb.shape[0]
+    K = n_time
+    want_grad = H.requires_grad and torch.is_grad_enabled()
+    x2 = ops.irfft_odd_fwd(Hb, K, slots=True, pairs=True)
+    main = torch.cuda.current_stream()
+    L = edc_len if edc_len is not None else K - edc_start
+    count = float(L) if edc_count is None else float(edc_count)
+    nb = B // nbands if global_batch is None else global_batch
+    inv = 1.0 if edc_maskw_prenormalised else 1.0 / (nb * count)
+    fork = side_stream is not None
+    if fork:
+        side_stream.wait_stream(main)
+    with torch.cuda.stream(side_stream) if fork else contextlib.nullcontext():
+        li_edc, g_edc = ops.edc_loss_pairs(x2, B, edc_start, L, edc_target, edc_maskw, inv, edc_weight, want_grad,
+                                           rows=target_rows)
+        if fork:
+            x2.record_stream(side_stream)
+    T_edr, sum_abs = edr_target
+    g_edr = torch.empty_like(x2) if want_grad else None
+    P = ops.stft_power_pairs(x2, B, win, zero_buf=g_edr)
+    li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad, rows=target_rows, defer=True)
+    if want_grad:
+        g_edr = ops.stft_power_pairs_bwd(x2, B, win, P, g_edr)
+    if fork:
+        main.wait_stream(side_stream)
+        for t in (g_edc, li_edc):
+            if t is not None:
+                t.record_stream(main)
+    if want_grad:
+        # (EDC gradient first, the STFT adjoint's buffer second: the same three-term order as the plain path)
+        gH = ops.irfft_odd_pairs_bwd(g_edc, K, B, g_edr)
+        return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, sum_abs, target_rows, nbands)
+    sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, sum_abs, target_rows, nbands)
     if nbands > 1:
         return sums[:, 0], sums[:, 1], sums[:, 2]
     return sums[0], sums[1], sums[2]

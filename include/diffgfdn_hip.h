@@ -229,11 +229,28 @@ int gfdn_irfft_odd_slots_fwd(const void* table, int n, const float* Xs_c64, int 
 int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const float* gx2, int ldo,
                              int batch, float* gXs_c64, int ldx, void* work, void* stream);
 
+/* Pairs: two items per complex transform.  Spectra in slot order as above (batch rows); the TIME signals are
+ * pair-interleaved: x2 (ceil(batch / 2), ldo) float2 with item 2p in .x and item 2p + 1 in .y (.y = 0 / ignored
+ * for the missing partner of an odd batch) -- one 8-byte scatter / gather per slot serves two items, and the
+ * three passes move half the work blocks.  gfdn_stft_power_pairs(_bwd) and gfdn_edc_loss_pairs consume and
+ * produce that layout (win = 4096 only); P, T_db, loss_item stay per item.                           */
+int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs_c64, int ldx, int batch,
+                             float* x2, int ldo, void* work, void* stream);
+int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
+                             int batch, float* gXs_c64, int ldx, void* work, void* stream);
+int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P, float* zero_buf2,
+                          void* stream);
+int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
+                              float* gx2, void* stream);
+int gfdn_edc_loss_pairs(const float* x2, int ld, int items, int start, int len, const float* T_db,
+                        const long long* target_rows, const float* maskw, float inv_count, float gscale,
+                        float* loss_item, float* gx2, void* work, void* stream);
+
 /* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
  * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so
  * that one kernel can be bracketed by HIP events on the launch stream (bench.py's roofline leg).
  * adjoint = 0: in = X (complex), out = x (real); adjoint = 1: in = gx (real) [+ in2], out = gX;
- * slots != 0: spectrum side in slot order (see above). */
+ * slots = 1: spectrum side in slot order; slots = 2: slot order + pair-interleaved time signals (see above). */
 int gfdn_irfft_odd_stages(const void* table, int n, const void* in, const float* in2, int ld_in, int batch,
                           void* out, int ld_out, void* work, int adjoint, int stages, int slots,
                           void* stream);

@@ -421,3 +421,56 @@ def test_bank_step_slot_order_equals_natural_order_full_size():
         assert np.allclose(res[True][0][k], res[False][0][k], rtol=2e-5, atol=0), (k, res[True][0][k], res[False][0][k])
     ga, gb = res[True][1], res[False][1]
     assert np.abs(ga - gb).max() < 2e-4 * np.abs(gb).max()
+
+
+@pytest.mark.parametrize("B", [4, 3])
+def test_pair_interleaved_kernels_equal_per_item_kernels(B):
+    """Two items per complex transform / pair-interleaved time signals (irfft pairs, STFT pairs, EDC pairs)
+    against the per-item kernels on the same data; odd batch = last pair half empty."""
+    from diffgfdn_amd import hip_ops as ops
+    n, win, start, L = 65537, 4096, 640, 47360
+    half = (n - 1) // 2
+    g = torch.Generator().manual_seed(B)
+    Xs = torch.view_as_complex(torch.randn(B, half + 1, 2, generator=g)).to(DEV)
+    npairs = (B + 1) // 2
+
+    def split(t2):                      # (pairs, n, 2) -> (B, n)
+        return t2.permute(0, 2, 1).reshape(2 * npairs, -1)[:B].contiguous()
+
+    def join(t):                        # (B, n) -> (pairs, n, 2), zero partner
+        pad = torch.zeros((2 * npairs, t.shape[1]), dtype=t.dtype, device=t.device)
+        pad[:B] = t
+        return pad.reshape(npairs, 2, -1).permute(0, 2, 1).contiguous()
+
+    x = ops.irfft_odd_fwd(Xs, n, slots=True)
+    x2 = ops.irfft_odd_fwd(Xs, n, slots=True, pairs=True)
+    assert x2.shape == (npairs, n, 2)
+    assert rel_err(split(x2).cpu(), x.cpu()) < 2e-6
+    if B % 2:
+        assert float(x2[-1, :, 1].abs().max()) < 1e-6 * float(x.abs().max())
+    # adjoint with two inputs
+    ga = torch.randn(B, n, generator=g).to(DEV)
+    gb = torch.randn(B, n, generator=g).to(DEV)
+    want = ops.irfft_odd_bwd(ga, n, half + 1, gb, slots=True)
+    got = ops.irfft_odd_pairs_bwd(join(ga), n, B, join(gb))
+    assert rel_err(torch.view_as_real(got).cpu(), torch.view_as_real(want).cpu()) < 2e-6
+    # STFT
+    xs = x.contiguous()
+    xj = join(xs)
+    P = ops.stft_power(xs, win)
+    buf = torch.full_like(xj, 7.0)
+    Pp = ops.stft_power_pairs(xj, B, win, zero_buf=buf)
+    assert rel_err(Pp.cpu(), P.cpu()) < 2e-6 and float(buf.abs().max()) == 0.0
+    gP = torch.rand(P.shape, generator=g).to(DEV)
+    gx = ops.stft_power_bwd(xs, win, gP, torch.zeros_like(xs))
+    g2 = ops.stft_power_pairs_bwd(xj, B, win, gP, buf)
+    assert rel_err(split(g2).cpu(), gx.cpu()) < 2e-6
+    # EDC
+    tgt = ops.edc_target(torch.randn(B, n, generator=g).to(DEV) * 0.01, start, L)
+    mw = (torch.rand(L, generator=g) > 0.5).float().to(DEV) / (B * L / 2)
+    li, ge = ops.edc_loss(xs, start, L, tgt, mw, 1.0, 10.0, True)
+    lip, gep = ops.edc_loss_pairs(xj, B, start, L, tgt, mw, 1.0, 10.0, True)
+    assert rel_err(lip.cpu(), li.cpu()) < 1e-6
+    assert rel_err(split(gep).cpu(), ge.cpu()) < 1e-6
+    if B % 2:
+        assert float(gep[-1, :, 1].abs().max()) == 0.0
