@@ -52,16 +52,16 @@ HBM_PEAK_GBS = 8000.0
 # compulsory HBM bytes per RIR (fwd + bwd, fp32 / complex64 storage)
 ALG_BYTES_PER_RIR = 2811048
 # Dominant kernel by total time in profiles/r01_bench_kernel_stats.csv: the first column pass of the
-# odd-length irfft (k_blu_col128_fwd; Rader gather + FFT over n1 + twiddle), HBM-bound.  Algorithmic bytes
-# per RIR: read the (K+1)/2 = 32769 spectrum bins the transform uses (8 B each; the
-# adjoint launch reads 2 x 65537 real samples of 4 B -- never fewer bytes) and write the L = 2^16 point
-# complex64 work block once.  The permutation table is shared by the batch and L2-resident.
+# odd-length irfft (k_blu_col128_fwd; input side + FFT over n1 + twiddle), HBM-bound, one forward and one
+# adjoint launch per step (the roofline leg averages both).  Two items share one transform, so per RIR
+# (DESIGN.md §kernels): the forward launch reads the item's slot-ordered spectrum (8 B x 32769) and writes half
+# a work block (8 B x 2^16 / 2) = 524 296 B; the adjoint launch gathers two real inputs (2 x 4 B x 65537) and
+# writes half a work block = 786 440 B.  Average per launch and RIR: 655 368 B.
 DOMINANT_KERNEL = 'k_blu_col128_fwd'
-DOMINANT_ALG_BYTES_PER_UNIT = 8 * 32769 + 8 * 65536
-# HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_hbm_bytes.csv), or None
-# (profiles/r01_pmc_hbm_bytes.csv), by items per launch
-DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = {32: int(2 * 10347.9 * 1024 / 2 + 32784.0 * 1024 / 2),       # (64-item rows / 2)
-                                     224: int(2 * 48219.5 * 1024 + 114771.2 * 1024)}   # 2 x FETCH_SIZE (gfx950) + WRITE_SIZE
+DOMINANT_ALG_BYTES_PER_UNIT = (8 * 32769 + 4 * 65536 + 2 * 4 * 65537 + 4 * 65536) // 2
+# HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_hbm_bytes.csv), by items per launch:
+# 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, averaged over the forward and the adjoint launch like the duration
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = {224: int(2 * 167721.6 * 1024 + 57413.8 * 1024)}
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
 
