@@ -637,10 +637,9 @@ def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, in
         raise RuntimeError("edc_loss_pairs: target shape does not match the window")
     maskw = None if maskw is None else _f(maskw)
     loss_item = torch.empty(items, dtype=_f32, device=x2.device)
-    # the missing partner of an odd batch is never written by the kernel: its lane must read as zero
-    g2 = (torch.zeros_like(x2) if items % 2 else torch.empty_like(x2)) if want_grad else None
+    g2 = torch.empty_like(x2) if want_grad else None      # (the kernel writes zeros for a missing partner)
     lib = _lib.load()
-    work = _work(lib.gfdn_edc_work_bytes(items), x2.device)
+    work = _work(lib.gfdn_edc_work_bytes(items + 1), x2.device)
     _lib.check(lib.gfdn_edc_loss_pairs(_p(x2), T, items, start, length, _p(T_db), _p(rows), _p(maskw),
                                        float(inv_count), float(gscale), _p(loss_item), _p(g2), _p(work),
                                        _stream()), "gfdn_edc_loss_pairs")

@@ -233,7 +233,8 @@ int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const fl
  * pair-interleaved: x2 (ceil(batch / 2), ldo) float2 with item 2p in .x and item 2p + 1 in .y (.y = 0 / ignored
  * for the missing partner of an odd batch) -- one 8-byte scatter / gather per slot serves two items, and the
  * three passes move half the work blocks.  gfdn_stft_power_pairs(_bwd) and gfdn_edc_loss_pairs consume and
- * produce that layout (win = 4096 only); P, T_db, loss_item stay per item.                           */
+ * produce that layout (win = 4096 only); P, T_db, loss_item stay per item; gfdn_edc_loss_pairs takes
+ * gfdn_edc_work_bytes(items + 1) bytes of work.                                                       */
 int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs_c64, int ldx, int batch,
                              float* x2, int ldo, void* work, void* stream);
 int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
