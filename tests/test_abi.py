@@ -45,7 +45,8 @@ def test_host_side_queries(lib):
     # 4097 = 17 * 241 -> Bluestein on 2^13 >= 4097 + 2048 points: chirp (n) + chirp spectrum (L)
     assert lib.gfdn_bluestein_table_bytes(4097) == (4097 + 8192) * 8
     assert lib.gfdn_bluestein_table_bytes(65536) == 0        # even length: not this transform
-    assert lib.gfdn_solve_bwd_work_bytes(4, 4) == 256 * 4 * (16 + 8) * 4
+    assert lib.gfdn_solve_bwd_work_bytes(4, 4) == 2048 * 4 * (16 + 8) * 4    # n <= 4: 2048 partial-sum slots
+    assert lib.gfdn_solve_bwd_work_bytes(2, 16) == 256 * 2 * (256 + 32) * 4
     assert lib.gfdn_irfft_pow2_work_bytes(131072, 2) == 2 * 131072 * 8
     # argument errors are reported before anything is launched
     assert lib.gfdn_solve_fwd(None, None, 0, 0, 0, None, None, None, None, 0, None, None) == -1
