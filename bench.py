@@ -201,11 +201,15 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
+    ap.add_argument('--classic', action='store_true',
+                    help='with --bands 1: the per-band VarReceiverPosTrainer path instead of a one-band bank')
     ap.add_argument('--bands', type=int, default=len(BAND_CENTRES),
                     help='octave bands stepped together (1 = BASELINE.json configs[1], the 500 Hz band alone)')
     args = ap.parse_args()
     if not 1 <= args.bands <= len(BAND_CENTRES):
         raise SystemExit(f"--bands must be 1..{len(BAND_CENTRES)}")
+    if args.classic and args.bands != 1:
+        raise SystemExit("--classic steps one band: use --bands 1")
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -224,13 +228,14 @@ def main():
 
     from diffgfdn_amd import hip_ops
     nbands = args.bands
-    if nbands == 1:
+    use_bank = not args.classic
+    if not use_bank:
         room, data, net, trainer, train_idx, filt, delays = build_workload(device, seed=1234,
                                                                           num_receivers=args.receivers)
         splits = [train_idx]
         centres = (500.0,)
     else:
-        centres = BAND_CENTRES[:nbands]
+        centres = BAND_CENTRES[:nbands] if nbands > 1 else (500.0,)
         (room, delays, filt), data, net, trainer, splits = build_bank_workload(device, 1234, centres,
                                                                                args.receivers)
     # every rank draws its own receivers (different shards of a 32*world global batch per band)
@@ -239,14 +244,14 @@ def main():
 
     def draw():
         sel = [t[torch.randperm(len(t), generator=gen)[:BATCH]].tolist() for t in splits_t]
-        return sel[0] if nbands == 1 else data.global_rows(sel)
+        return sel[0] if not use_bank else data.global_rows(sel)
 
     step = trainer.graphed(data, BATCH)      # normalize + train_step as HIP-graph replays
 
     def one_step():
         sel = draw()
         if args.eager:
-            batch = data.collate(sel, lean=True) if nbands == 1 else data.collate(sel)
+            batch = data.collate(sel, lean=True) if not use_bank else data.collate(sel)
             trainer.normalize(batch)
             return trainer.train_step(batch)
         losses = step(sel)
@@ -274,14 +279,14 @@ def main():
     if rank == 0:
         hip_ops.kernel_timer.watch = DOMINANT_KERNEL
         hip_ops.kernel_timer.start()
-        ones = torch.ones(nbands, device=device)
+        ones = torch.ones(() if nbands == 1 else (nbands,), device=device)
         for _ in range(ROOFLINE_EAGER_STEPS):
             sel = draw()
-            batch = data.collate(sel, lean=True) if nbands == 1 else data.collate(sel)
+            batch = data.collate(sel, lean=True) if not use_bank else data.collate(sel)
             with torch.no_grad():
                 trainer.normalize(batch)
             # no optimizer step / all-reduce (no collectives inside): kernel timing only
-            if nbands == 1:
+            if not use_bank:
                 lo = trainer._step_losses(batch, mask_prenorm=step.maskw)
                 lo['_total'].backward()
             else:
@@ -307,7 +312,7 @@ def main():
                                    f'N=16 (4 groups x 4) on a {args.receivers}-receiver grid, nfft 131072 (K=65537), '
                                    'batch 32 receivers/band/step/GPU; step = normalize + fwd + EDR/EDC(mask)/'
                                    'colorless losses + bwd + Adam for every band'
-                                   + (' (band bank: one launch per stage for all bands)' if nbands > 1 else ''),
+                                   + (' (band bank: one launch per stage for all bands)' if use_bank else ''),
                        'bands': nbands, 'receivers': args.receivers, 'batch_per_band_per_gpu': BATCH,
                        'rirs_per_step_per_gpu': nbands * BATCH, 'global_batch_per_band': BATCH * world,
                        'delay_lines': G * NPER, 'bins': K, 'rirs_per_s': rirs_per_s,

@@ -332,6 +332,9 @@ class BandBankTrainer:
             opt, pg = self.optimizer, process_group
             self._allreduce = lambda: dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=pg)
         self._side = self._side2 = None
+        # leaves are first touched on one stream and receive gradients from the other by design (§5.1): the
+        # engine synchronises them; its per-backward warning about that would only hide real messages
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     def _decay_window(self, K: int):
         return self.criterion[1].window(K)
@@ -483,7 +486,8 @@ class BandBankTrainer:
 
     def _ones(self, dev):
         if getattr(self, '_unit', None) is None:
-            self._unit = torch.ones(self.num_bands, dtype=torch.float32, device=dev)
+            self._unit = torch.ones(() if self.num_bands == 1 else (self.num_bands,), dtype=torch.float32,
+                                    device=dev)
         return self._unit
 
     def train_step(self, data: Dict):
