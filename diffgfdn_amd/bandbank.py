@@ -66,6 +66,8 @@ class BandBank(nn.Module):
             if fl.coupling_matrix_type == CouplingMatrixType.RANDOM or not fl.use_zero_coupling:
                 raise NotImplementedError("BandBank: zero inter-group coupling only (train other layouts "
                                           "band by band with subband.train_bands)")
+            if fl.use_absorption_filters:
+                raise NotImplementedError("BandBank: scalar absorption gains (the sub-band recipe)")
             if fl.learn_decay_times or not isinstance(fl.M, nn.Parameter):
                 raise NotImplementedError("BandBank: fixed decay times and a learnable M per band")
             if not hasattr(net, 'output_scalars') or not hasattr(net.output_scalars, 'mlp'):

@@ -125,7 +125,15 @@ struct SolveArgs {
   const float* inv_gamma;
   const float* b;
   int transpose;
+  // frequency-dependent absorption (feedback_loop.py:332-344, :376-381): igz[k][i] = 1 / Gamma_i(z_k), complex,
+  // (K, N); NULL: the scalar inv_gamma above.  With igz the scalar table must hold ones.
+  const float2* igz;
 };
+
+// zeta_i(z_k) = z_k^{m_i} / gamma_i  (scalar gain)  or  z_k^{m_i} / Gamma_i(z_k)  (absorption filter)
+__device__ __forceinline__ float2 zeta_abs(const SolveArgs& a, int k, int i, float2 zeta) {
+  return a.igz ? cmul(zeta, a.igz[(size_t)k * (a.nblk * a.nper) + i]) : zeta;
+}
 
 template <int NP>
 __global__ __launch_bounds__(256) void k_solve_fwd(SolveArgs a, float2* __restrict__ Y) {
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void k_solve_fwd(SolveArgs a, float2* __restri
   const bool valid = k < a.K;
   const int kk = valid ? k : a.K - 1;
   const int i = blk * n + (r < n ? r : 0);
-  float2 zeta = zeta_pow(a.turns, a.logr, kk, a.delays[i], a.inv_gamma[i]);
+  float2 zeta = zeta_abs(a, kk, i, zeta_pow(a.turns, a.logr, kk, a.delays[i], a.inv_gamma[i]));
   float2 row[NP];
   build_row<NP>(row, a.A + (size_t)blk * n * n, n, r, a.transpose != 0, zeta);
   float2 rhs = make_float2(r < n ? a.b[i] : 0.f, 0.f);
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __
     const int kk = valid ? k : a.K - 1;
     // unit-magnitude phase separately: d T_ii / d inv_gamma = z^m
     float2 zpow = zeta_pow(a.turns, a.logr, kk, m_i, 1.0f);
-    float2 zeta = cscale(zpow, ig_i);
+    float2 zeta = zeta_abs(a, kk, i, cscale(zpow, ig_i));
     float2 row[NP];
     int pivcol;
     // forward system  T y = b
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(256) void k_solve4_fwd(SolveArgs a, float2* __restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+    if (r < n) zeta[r] = zeta_abs(a, k, blk * n + r, zeta[r]);
     rhs[r] = make_float2(cst.b[r], 0.f);
   }
   build4c(m, cst, n, a.transpose != 0, zeta, false);
@@ -426,6 +435,7 @@ __global__ __launch_bounds__(256) void k_solve4_bwd(SolveArgs a, const float2* _
     for (int r = 0; r < 4; ++r) {
       zpow[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], 1.0f);   // d T_ii / d inv_gamma = z^m
       zeta[r] = cscale(zpow[r], cst.ig[r]);
+      if (r < n) zeta[r] = zeta_abs(a, k, blk * n + r, zeta[r]);
     }
     const size_t row = ((size_t)k * nblk + blk) * n;
     if (Ysaved) {
@@ -546,13 +556,13 @@ static int check_solve_args(const double* turns, int K, int nblk, int nper, cons
   return 0;
 }
 
-extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
-                              const float* A, const float* delays, const float* inv_gamma,
-                              const float* b, int transpose, float* Y, void* stream) {
+static int solve_fwd_run(const double* turns, const double* logr, int K, int nblk, int nper,
+                         const float* A, const float* delays, const float* inv_gamma,
+                         const float* b, int transpose, float* Y, void* stream, const float2* g_igz) {
   int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
   if (rc) return rc;
   if (!Y) return GFDN_E_BADARG;
-  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose};
+  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz};
   const int np = pick_np(nper);
   const int spb = 256 / np;
   dim3 grid((K + spb - 1) / spb, nblk), block(256);
@@ -573,19 +583,59 @@ extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, in
   return 0;
 }
 
+extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                              const float* A, const float* delays, const float* inv_gamma,
+                              const float* b, int transpose, float* Y, void* stream) {
+  return solve_fwd_run(turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, Y, stream, nullptr);
+}
+// frequency-dependent absorption: ones (N) = a device vector of ones (the scalar gains are folded into igz)
+extern "C" int gfdn_solve_absorb_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                                     const float* A, const float* delays, const float* ones,
+                                     const float* inv_gamma_bins_c64, const float* b, int transpose, float* Y,
+                                     void* stream) {
+  if (!inv_gamma_bins_c64) return GFDN_E_BADARG;
+  return solve_fwd_run(turns, logr, K, nblk, nper, A, delays, ones, b, transpose, Y, stream,
+                       (const float2*)inv_gamma_bins_c64);
+}
+
 extern "C" size_t gfdn_solve_bwd_work_bytes(int nblk, int nper) {
   const int parts = nper <= 4 ? S4_MAX_PARTS : GFDN_PARTIAL_BLOCKS;
   return (size_t)parts * nblk * (nper * nper + 2 * nper) * sizeof(float);
 }
 
+static int solve_bwd_run(const double* turns, const double* logr, int K, int nblk, int nper,
+                         const float* A, const float* delays, const float* inv_gamma,
+                         const float* b, int transpose, const float* gY, const float* Y,
+                         float* gA, float* gb, float* ginv_gamma, void* work, void* stream,
+                         const float2* g_igz);
+
 extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
                               const float* A, const float* delays, const float* inv_gamma,
                               const float* b, int transpose, const float* gY, const float* Y,
                               float* gA, float* gb, float* ginv_gamma, void* work, void* stream) {
+  return solve_bwd_run(turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, gY, Y, gA, gb, ginv_gamma,
+                       work, stream, nullptr);
+}
+// (the absorption filters are fixed: ginv_scratch (N) receives a by-product without meaning)
+extern "C" int gfdn_solve_absorb_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                                     const float* A, const float* delays, const float* ones,
+                                     const float* inv_gamma_bins_c64, const float* b, int transpose,
+                                     const float* gY, const float* Y, float* gA, float* gb,
+                                     float* ginv_scratch, void* work, void* stream) {
+  if (!inv_gamma_bins_c64) return GFDN_E_BADARG;
+  return solve_bwd_run(turns, logr, K, nblk, nper, A, delays, ones, b, transpose, gY, Y, gA, gb, ginv_scratch,
+                       work, stream, (const float2*)inv_gamma_bins_c64);
+}
+
+static int solve_bwd_run(const double* turns, const double* logr, int K, int nblk, int nper,
+                         const float* A, const float* delays, const float* inv_gamma,
+                         const float* b, int transpose, const float* gY, const float* Y,
+                         float* gA, float* gb, float* ginv_gamma, void* work, void* stream,
+                         const float2* g_igz) {
   int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
   if (rc) return rc;
   if (!gY || !gA || !gb || !ginv_gamma || !work) return GFDN_E_BADARG;
-  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose};
+  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz};
   const int np = pick_np(nper);
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
@@ -876,7 +926,7 @@ extern "C" int gfdn_subfdn_colorless_fwd(const double* turns, const double* logr
   if (!turns || !M || !delays || !b || !c || !Y || !S || !energy || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4 || G > S4_MAXBLK) return GFDN_E_UNSUPPORTED;
-  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0};
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr};
   const int nparts = solve4_parts(K, G);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_subfdn4_fwd, dim3(nparts), dim3(256), 0, s, a, (const float*)c, (float2*)Y, (float2*)S,
@@ -910,7 +960,7 @@ extern "C" int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr
   if (!turns || !M || !delays || !b || !c || !Y || !gS || !gM || !gb || !gc || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4 || G > S4_MAXBLK) return GFDN_E_UNSUPPORTED;
-  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0};
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr};
   const int nparts = solve4_parts(K, G), items = solve4_items(G);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_subfdn4_bwd, dim3(nparts), dim3(256), (size_t)items * 25 * sizeof(float), s, a, c, energy,
@@ -933,7 +983,7 @@ extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, in
   if (!turns || !M || !delays || !b || !c || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > GFDN_MAX_BLOCK) return GFDN_E_UNSUPPORTED;
-  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0};
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr};
   const int np = pick_np(nper);
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;

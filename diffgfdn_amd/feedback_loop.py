@@ -101,8 +101,9 @@ class FeedbackLoop(nn.Module):
                  common_decay_times: Optional[List] = None,
                  device: torch.device = 'cpu'):
         super().__init__()
-        if use_absorption_filters:
-            raise NotImplementedError("frequency-dependent absorption filters: SURVEY §8 f-2 (next)")
+        if use_absorption_filters and gains is None:
+            raise NotImplementedError("absorption filters are fixed designs (reference :200-201 'Cannot learn "
+                                      "absorption filters yet'): pass their coefficients as ``gains``")
         if coupling_matrix_type == CouplingMatrixType.FILTER:
             raise NotImplementedError("paraunitary FILTER coupling: SURVEY §8 f-2 (next)")
         self.sample_rate = sample_rate
@@ -134,6 +135,14 @@ class FeedbackLoop(nn.Module):
                 init = torch.tensor(np.asarray(common_decay_times).squeeze())
             self.common_decay_times = nn.Parameter(init)
             self.delays_by_group = [self.delays[i:i + n] for i in range(0, self.num_delays, n)]
+        elif self.use_absorption_filters:
+            # (N, S, 3, 2) second-order sections [..., 0] numerator / [..., 1] denominator (GEQ design,
+            # reference :246-255) or (N, order, 2) direct-form IIR (Prony design, :238-243): coefficient DATA;
+            # the responses Gamma_i(z_k) are evaluated once per frequency grid (absorption_response)
+            self.delay_line_gains = torch.as_tensor(gains)
+            if self.delay_line_gains.ndim not in (3, 4) or self.delay_line_gains.shape[-1] != 2:
+                raise ValueError("absorption filter coefficients: (N, S, 3, 2) SOS or (N, order, 2) IIR")
+            self._abs_cache = None
         else:
             # plain attribute like the reference (:258); moved by _apply below, and re-linked to
             # the owning model's persistent ``delay_filters`` buffer by DiffGFDN._apply
@@ -143,7 +152,41 @@ class FeedbackLoop(nn.Module):
         super()._apply(fn, *args, **kwargs)
         if not self.learn_decay_times:
             self.delay_line_gains = fn(self.delay_line_gains)
+            if self.use_absorption_filters:
+                self._abs_cache = None
         return self
+
+    def absorption_response(self, z: torch.Tensor) -> torch.Tensor:
+        """Gamma_i(z_k) (N, K) complex64 of the per-line absorption filters: cascades of second-order sections
+        prod_s (b0 + b1 z^-1 + b2 z^-2) / (a0 + a1 z^-1 + a2 z^-2) (gain_filters.py:221-241, accumulated in
+        complex64 like the reference) or direct-form IIR with the reference's +1e-9 in the denominator
+        (gain_filters.py:180-198)."""
+        g = self.delay_line_gains.to(z.device)
+        z = z.to(torch.complex128)
+        zi = 1.0 / z
+        if g.ndim == 4:
+            H = torch.ones((g.shape[0], z.numel()), dtype=torch.complex64, device=z.device)
+            for s_ in range(g.shape[1]):
+                b, a = g[:, s_, :, 0].to(torch.float64), g[:, s_, :, 1].to(torch.float64)
+                num = b[:, 0:1] + b[:, 1:2] * zi[None, :] + b[:, 2:3] * zi[None, :] ** 2
+                den = a[:, 0:1] + a[:, 1:2] * zi[None, :] + a[:, 2:3] * zi[None, :] ** 2
+                H = (H * (num / den)).to(torch.complex64)
+            return H
+        num = torch.zeros((g.shape[0], z.numel()), dtype=torch.complex64, device=z.device)
+        den = torch.zeros_like(num)
+        for k in range(g.shape[1]):
+            zk = torch.pow(z, -k)
+            num = (num + g[:, k, 0].to(torch.float64)[:, None] * zk[None, :]).to(torch.complex64)
+            den = (den + g[:, k, 1].to(torch.float64)[:, None] * zk[None, :]).to(torch.complex64)
+        return num / (den + 1e-9)
+
+    def _inv_gamma_bins(self, z: torch.Tensor) -> torch.Tensor:
+        """(K, N) complex64 = 1 / Gamma_i(z_k), cached per frequency grid (the filters are fixed)."""
+        key = (z.data_ptr(), z.numel(), z._version, str(z.device))
+        if self._abs_cache is None or self._abs_cache[0] != key:
+            G = self.absorption_response(z)
+            self._abs_cache = (key, (1.0 / G.to(torch.complex128)).to(torch.complex64).T.contiguous(), z)
+        return self._abs_cache[1]
 
     def current_gains(self) -> torch.Tensor:
         """gamma_n (N,), differentiable w.r.t. learnable decay times (reference :221-232)."""
@@ -236,6 +279,11 @@ class FeedbackLoop(nn.Module):
         grid = FrequencyGrid.of(z)
         A = self.feedback_blocks()
         dev = A.device
+        if self.use_absorption_filters:
+            if getattr(self, '_ones_n', None) is None or self._ones_n.device != dev:
+                self._ones_n = torch.ones(self.num_delays, dtype=torch.float32, device=dev)
+            return ResolventSolve.apply(A, self._ones_n, b.reshape(-1), grid, self.delays, transpose,
+                                        self._inv_gamma_bins(z))
         if self.learn_decay_times:
             inv_gamma = (1.0 / self.current_gains().to(dev)).to(torch.float32)
         else:

@@ -81,20 +81,30 @@ def ortho_bwd(M, gQ=None, gQQ=None, Q=None):
     return gM
 
 
-def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False) -> torch.Tensor:
-    """A (nblk,nper,nper) f32, delays/inv_gamma/b (N,) f32 -> Y (K,N) complex64."""
+def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False, inv_gamma_bins=None) -> torch.Tensor:
+    """A (nblk,nper,nper) f32, delays/inv_gamma/b (N,) f32 -> Y (K,N) complex64.
+    ``inv_gamma_bins`` (K, N) complex64 = 1 / Gamma_i(z_k): frequency-dependent absorption (``inv_gamma`` must
+    then be ones)."""
     _need_gpu(turns, A)
     A, delays, inv_gamma, b = _f(A), _f(delays), _f(inv_gamma), _f(b)
     nblk, nper, _ = A.shape
     K = turns.numel()
     Y = torch.empty((K, nblk * nper), dtype=_c64, device=A.device)
+    if inv_gamma_bins is not None:
+        igz = _c(inv_gamma_bins)
+        if tuple(igz.shape) != (K, nblk * nper):
+            raise RuntimeError("solve_fwd: inv_gamma_bins must be (K, N)")
+        _lib.check(_lib.load().gfdn_solve_absorb_fwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
+                                                     _p(inv_gamma), _p(igz), _p(b), int(transpose), _p(Y),
+                                                     _stream()), "gfdn_solve_absorb_fwd")
+        return Y
     _lib.check(_lib.load().gfdn_solve_fwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
                                           _p(inv_gamma), _p(b), int(transpose), _p(Y), _stream()),
                "gfdn_solve_fwd")
     return Y
 
 
-def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None):
+def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None, inv_gamma_bins=None):
     """-> gA (nblk,nper,nper), gb (N,), ginv_gamma (N,)  (float32).  ``Y``: the forward solution
     (K, N) if still at hand -- the kernel then does not re-solve the forward system."""
     _need_gpu(turns, A, gY)
@@ -110,6 +120,14 @@ def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None)
     gb = torch.empty(nblk * nper, dtype=_f32, device=A.device)
     gig = torch.empty_like(gb)
     work = _work(lib.gfdn_solve_bwd_work_bytes(nblk, nper), A.device)
+    if inv_gamma_bins is not None:
+        igz = _c(inv_gamma_bins)
+        if tuple(igz.shape) != (K, nblk * nper):
+            raise RuntimeError("solve_bwd: inv_gamma_bins must be (K, N)")
+        _lib.check(lib.gfdn_solve_absorb_bwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays), _p(inv_gamma),
+                                             _p(igz), _p(b), int(transpose), _p(gY), _p(Y), _p(gA), _p(gb), _p(gig),
+                                             _p(work), _stream()), "gfdn_solve_absorb_bwd")
+        return gA, gb, None
     _lib.check(lib.gfdn_solve_bwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
                                   _p(inv_gamma), _p(b), int(transpose), _p(gY), _p(Y), _p(gA), _p(gb),
                                   _p(gig), _p(work), _stream()), "gfdn_solve_bwd")

@@ -31,10 +31,17 @@ class DiffGFDN(nn.Module):
                  feedback_loop_config: FeedbackLoopConfig, use_absorption_filters: bool,
                  learn_common_decay_times: bool, common_decay_times: Optional[List] = None,
                  band_centre_hz: Optional[List] = None, colorless_fdn_params: Optional[List] = None,
-                 use_colorless_loss: bool = False):
+                 use_colorless_loss: bool = False, absorption_filter_coeffs: Optional[torch.Tensor] = None):
+        """``absorption_filter_coeffs`` (N, S, 3, 2) [SOS, GEQ design] or (N, order, 2) [IIR, Prony design]: the
+        per-line absorption filters when ``use_absorption_filters``.  The reference DESIGNS them from the decay
+        times at construction (model.py:131-153 -> absorption_filters.py:108-155, an L-BFGS graphic-equaliser
+        fit: pre-processing outside this path) and keeps the result in the checkpoint as the ``delay_filters``
+        buffer -- that tensor is what is passed here."""
         super().__init__()
-        if use_absorption_filters:
-            raise NotImplementedError("frequency-dependent absorption: SURVEY §8 f-2 (next)")
+        if use_absorption_filters and absorption_filter_coeffs is None:
+            raise NotImplementedError("use_absorption_filters: pass absorption_filter_coeffs (the reference's "
+                                      "'delay_filters' buffer); the GEQ / Prony filter DESIGN is not part of this path")
+        self._absorption_coeffs = absorption_filter_coeffs
         self.sample_rate = sample_rate
         self.device = device
         self.num_groups = num_groups
@@ -81,6 +88,12 @@ class DiffGFDN(nn.Module):
 
     # reference :124-166 (broadband gains branch)
     def _init_absorption(self):
+        if self.use_absorption_filters:
+            self.gain_per_sample = torch.as_tensor(self._absorption_coeffs, dtype=torch.float32).clone()
+            if self.gain_per_sample.shape[0] != self.num_delay_lines:
+                raise ValueError("absorption_filter_coeffs: one filter per delay line")
+            self.register_buffer('delay_filters', self.gain_per_sample)
+            return
         if self.common_decay_times is None or self.learn_common_decay_times:
             self.gain_per_sample = None
             return
@@ -159,10 +172,11 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
                  feedback_loop_config: FeedbackLoopConfig, output_filter_config: OutputFilterConfig,
                  use_absorption_filters: bool, learn_common_decay_times: Optional[bool] = False,
                  common_decay_times: Optional[List] = None, band_centre_hz: Optional[List] = None,
-                 colorless_fdn_params: Optional[List] = None, use_colorless_loss: bool = False):
+                 colorless_fdn_params: Optional[List] = None, use_colorless_loss: bool = False,
+                 absorption_filter_coeffs: Optional[torch.Tensor] = None):
         super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
                          use_absorption_filters, learn_common_decay_times, common_decay_times,
-                         band_centre_hz, colorless_fdn_params, use_colorless_loss)
+                         band_centre_hz, colorless_fdn_params, use_colorless_loss, absorption_filter_coeffs)
         if output_filter_config.use_svfs:
             raise NotImplementedError("SVF output filters: SURVEY §8 f-2 (next)")
         self.use_svf_in_output = False

@@ -76,6 +76,20 @@ int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int
                    const float* b, int transpose, const float* gY_c64, const float* Y_c64,
                    float* gA, float* gb, float* ginv_gamma, void* work, void* stream);
 
+/* Frequency-dependent absorption (feedback_loop.py:332-344, :376-381: Gamma(z) = diag of per-line filter
+ * responses, GEQ / Prony designs of absorption_filters.py): T_k = diag(z_k^{m_i} / Gamma_i(z_k)) - A.
+ * inv_gamma_bins (K, N) complex64 = 1 / Gamma_i(z_k); ones (N) = device vector of ones.  The filters are
+ * fixed (not learnable in the reference either): no gradient w.r.t. them.                          */
+int gfdn_solve_absorb_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                          const float* A, const float* delays, const float* ones,
+                          const float* inv_gamma_bins_c64, const float* b, int transpose, float* Y_c64,
+                          void* stream);
+int gfdn_solve_absorb_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                          const float* A, const float* delays, const float* ones,
+                          const float* inv_gamma_bins_c64, const float* b, int transpose,
+                          const float* gY_c64, const float* Y_c64, float* gA, float* gb,
+                          float* ginv_scratch, void* work, void* stream);
+
 /* ---- output stage  (model.py:583-619, gain_filters.py:526-534, trainer.py:459) ----------
  *   S[g][k]  = sum_{n in group g} c_n Y[k][n]
  *   H[b][k]  = (sum_g rgain[b][g] S[g][k] + direct[b][k]) * filt[k]

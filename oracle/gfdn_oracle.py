@@ -136,6 +136,38 @@ def feedback_loop_forward(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Te
     return torch.linalg.inv(Ddecay - Acplx).to(torch.complex64)            # :391
 
 
+def sos_response(z: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
+    """gain_filters.py:221-241 (SOSFilter.forward) for N cascades: coeffs (N, S, 3, 2), [..., 0] numerator,
+    [..., 1] denominator -> (N, K) complex64 (the reference accumulates the product in complex64)."""
+    N, S = coeffs.shape[:2]
+    out = []
+    for n in range(N):
+        H = torch.ones(len(z), dtype=torch.complex64)
+        for k in range(S):
+            b, a = coeffs[n, k, :, 0], coeffs[n, k, :, 1]
+            H *= torch.div(b[0] + b[1] * torch.pow(z, -1) + b[2] * torch.pow(z, -2),
+                           a[0] + a[1] * torch.pow(z, -1) + a[2] * torch.pow(z, -2))
+        out.append(H)
+    return torch.stack(out)
+
+
+def feedback_loop_forward_absorption(z: torch.Tensor, delays: torch.Tensor, coeffs: torch.Tensor,
+                                     A: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:326-391 with use_absorption_filters (SOS list branch :335-341, :376-381):
+    P (K,N,N) c64 = inv(diag(z^m) Gamma(z)^-1 - A)."""
+    K = len(z)
+    N = len(delays)
+    D = torch.diag_embed(torch.unsqueeze(z, dim=-1) ** delays)
+    Gamma = torch.zeros((N, N, K), dtype=torch.complex64)
+    G = sos_response(z, coeffs)
+    for k in range(N):
+        Gamma[k, k, :] = G[k]
+    Acplx = to_complex(A).unsqueeze(0).repeat(K, 1, 1)
+    Gamma_inv = torch.diag_embed(1.0 / torch.diagonal(Gamma), dim1=0, dim2=1)
+    Ddecay = D * Gamma_inv.permute(-1, 0, 1)
+    return torch.linalg.inv(Ddecay - Acplx).to(torch.complex64)
+
+
 # --------------------------------------------------------------------------------------
 # models  (reference: src/diff_gfdn/model.py)
 # --------------------------------------------------------------------------------------

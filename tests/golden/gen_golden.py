@@ -410,6 +410,33 @@ def gen_f9_colorless_fdn():
     print('F9 done')
 
 
+def gen_f10_absorption_filters():
+    """DiffGFDNVarReceiverPos with frequency-dependent absorption (use_absorption_filters: GEQ-designed SOS per
+    delay line, model.py:131-153, feedback_loop.py:332-344): the designed coefficients are stored as data."""
+    fs, nfft, G, nper, B = 8000.0, 1024, 2, 4, 3
+    delays = prime_delays(G * nper, lo=160, hi=400, seed=3)
+    band_centre_hz = [125.0, 250.0, 500.0, 1000.0, 2000.0]
+    T60 = np.stack([np.linspace(0.5, 0.25, 5), np.linspace(0.9, 0.4, 5)], axis=1)     # (bands, G)
+    batch, _ = synth_batch(B, nfft, fs, G, 900, 41, T60=[0.4, 0.7])
+    torch.manual_seed(19)
+    np.random.seed(19)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=False)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(fs, G, delays, 'cpu', fl, of, use_absorption_filters=True,
+                                 common_decay_times=T60, band_centre_hz=band_centre_hz, use_colorless_loss=True)
+    H, (Hout, _) = net(batch)
+    loss = (H.abs() ** 2).sum()
+    loss.backward()
+    out = {'fs': fs, 'nfft': nfft, 'G': G, 'nper': nper, 'delays': np.array(delays), 'T60': T60,
+           'band_centre_hz': np.array(band_centre_hz), 'H': c2np(H), 'Hout': c2np(Hout), 'loss': loss.item(),
+           'P_small': c2np(net.feedback_loop(batch['z_values'][:64]))}
+    out.update(batch_to_np(batch))
+    out.update(state_np(net))
+    out.update({'grad_' + k: c2np(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+    np.savez_compressed(os.path.join(HERE, 'f10_absorption_filters.npz'), **out)
+    print('F10 done', out['sd_delay_filters'].shape)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1_feedback_loop()
@@ -424,3 +451,4 @@ if __name__ == '__main__':
     gen_f7_front_end()
     gen_f8_source_receiver()
     gen_f9_colorless_fdn()
+    gen_f10_absorption_filters()

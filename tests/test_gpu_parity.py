@@ -632,3 +632,33 @@ def test_f9_colorless_fdn_prototype(tmp_path):
     tr.train(batches[:3], batches[3:])
     assert tr.train_loss[-1] < tr.train_loss[0]
     assert (tmp_path / "colorless-fdn" / "checkpoints" / "model_e2.pt").exists()
+
+
+def test_f10_absorption_filters_model():
+    """use_absorption_filters: per-line absorption FILTERS Gamma_i(z) inside the per-bin solve (fixture F10: the
+    reference designs the GEQ sections, we take its coefficients as data): explicit inverse, forward, gradients."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    fx = load("f10_absorption_filters.npz")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=False)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    coeffs = torch.tensor(fx["sd_delay_filters"])
+    net = DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                                 use_absorption_filters=True, common_decay_times=fx["T60"],
+                                 band_centre_hz=fx["band_centre_hz"].tolist(), use_colorless_loss=True,
+                                 absorption_filter_coeffs=coeffs)
+    net.load_state_dict(_state(fx), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx))
+    P = net.feedback_loop(batch["z_values"][:64].contiguous())
+    assert rel_err(P.detach().cpu().numpy(), fx["P_small"]) < TOL
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu().numpy(), fx["H"]) < TOL
+    assert rel_err(Hout.detach().cpu().numpy(), fx["Hout"]) < TOL
+    (H.abs() ** 2).sum().backward()
+    for name_, prm in net.named_parameters():
+        ref = fx["grad_" + name_]
+        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+    with pytest.raises(NotImplementedError):
+        DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                               use_absorption_filters=True, common_decay_times=fx["T60"])

@@ -261,3 +261,14 @@ def test_f9_colorless_fdn_forward():
                                        torch.tensor(fx["sd_feedback_loop.random_feedback_matrix"]))
     assert rel_err(H.numpy(), fx["H"]) < 1e-6
     assert rel_err(Hpd.numpy(), fx["Hpd"]) < 1e-6
+
+
+def test_f10_absorption_filter_feedback_loop():
+    """oracle resolvent with frequency-dependent absorption (SOS per delay line) vs the reference's
+    FeedbackLoop.forward with use_absorption_filters (feedback_loop.py:332-344, :376-391)."""
+    fx = load("f10_absorption_filters.npz")
+    z = torch.tensor(fx["batch_z_values"])[:64]
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    A = orc.coupled_feedback_matrix(torch.tensor(fx["sd_feedback_loop.M"]), torch.tensor(fx["sd_feedback_loop.alpha"]))
+    P = orc.feedback_loop_forward_absorption(z, delays, torch.tensor(fx["sd_delay_filters"]), A)
+    assert rel_err(P.detach().numpy(), fx["P_small"]) < 1e-5
