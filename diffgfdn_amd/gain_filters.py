@@ -13,6 +13,99 @@ from .config import BeamformerType, FeatureEncodingType
 from .dnn import MLP, MLP_SkipConnections, ScaledSigmoid, SinusoidalEncoding
 
 
+def svf_cutoff_frequencies(sample_rate: float) -> torch.Tensor:
+    """Normalised SVF cut-offs pi f / fs of the 11-section equaliser: low shelf at 62.5 / sqrt 2 Hz, peaking
+    sections at the octaves 62.5 ... 16 000 Hz, high shelf at 16 000 sqrt 2 Hz (reference filters/geq.py:9-56
+    ``eq_freqs`` with its defaults, gain_filters.py:299-303 -- no tangent pre-warping, as there)."""
+    centre, c = [], 31.25
+    while c < 16000:
+        c = c * 2.0
+        centre.append(c)
+    f = [centre[0] / np.power(2, 0.5)] + centre + [centre[-1] * np.power(2, 0.5)]
+    return torch.pi * torch.tensor(f) / sample_rate
+
+
+def svf_cascade_response(z: torch.Tensor, cutoff: torch.Tensor, raw_params: torch.Tensor,
+                         compress_pole_factor: float = 1.0) -> torch.Tensor:
+    """Frequency response (..., K) complex64 of cascades of state-variable-filter sections.
+
+    raw_params (..., S, 2): unconstrained [resonance, gain dB] per section, mapped through the reference's scaled
+    sigmoids (resonance in (1e-6, 1), gain in (-6, 6) dB; gain_filters.py:327-330, model.py:733-737); section 0 is
+    a low shelf, the last a high shelf, the others peaking (gain_filters.py:372-380); SVF -> biquad as
+    ``BiquadCascade.from_svf_coeffs`` (:117-151, mixing coefficients of ``SVF.__post_init__`` :36-103); response
+    as ``SOSFilter.forward`` (:221-241), accumulated in complex64."""
+    dev = raw_params.device
+    S = raw_params.shape[-2]
+    R = 1e-6 + (1.0 - 1e-6) * torch.sigmoid(raw_params[..., 0])
+    G = torch.pow(10.0, (-6.0 + 12.0 * torch.sigmoid(raw_params[..., 1])) * 0.05)      # db2lin
+    # coefficients as the reference forms them: float64 cut-offs times float32 parameters, stored as float32
+    f = cutoff.to(dev).to(torch.float64)
+    R, G = R.to(torch.float64), G.to(torch.float64)
+    idx = torch.arange(S, device=dev)
+    low, high = (idx == 0), (idx == S - 1)
+    one = torch.ones_like(G)
+    m_lp = torch.where(low, G, one)
+    m_hp = torch.where(high, G, one)
+    m_bp = torch.where(low | high, 2 * R * torch.sqrt(G), 2 * R * G)
+    cpf = compress_pole_factor
+    b0 = f ** 2 * m_lp + f * m_bp + m_hp
+    b1 = (2 * f ** 2 * m_lp - 2 * m_hp) * cpf
+    b2 = (f ** 2 * m_lp - f * m_bp + m_hp) * cpf ** 2
+    a0 = f ** 2 + 2 * R * f + 1
+    a1 = (2 * f ** 2 - 2) * cpf + torch.zeros_like(R)
+    a2 = (f ** 2 - 2 * R * f + 1) * cpf ** 2
+    # the sections are evaluated in complex128 (b0 + b1 z^-1 + b2 z^-2 cancels to O(f^2) at low frequencies: in
+    # complex64 the shelves lose 3 digits there), the running product is kept in complex64 like the reference
+    zi = 1.0 / z.to(torch.complex128)
+    zi2 = zi * zi
+    H = None
+    for k in range(S):
+        c = lambda t: t[..., k].to(torch.float32).to(torch.float64).unsqueeze(-1)
+        sec = ((c(b0) + c(b1) * zi + c(b2) * zi2) / (c(a0) + c(a1) * zi + c(a2) * zi2)).to(torch.complex64)
+        H = sec if H is None else H * sec
+    return H
+
+
+class SVF_from_MLP(nn.Module):
+    """Receiver-position dependent SVF output (or source-position dependent input) filters: per (position,
+    group) a cascade of 11 state-variable sections whose [resonance, gain] come from an MLP (reference
+    gain_filters.py:262-402).  ``forward`` returns the reference's (B, N, K) tensor; the models use
+    :meth:`group_responses` (B, G, K)."""
+
+    def __init__(self, sample_rate: float, num_groups: int, num_delay_lines_per_group: int,
+                 num_fourier_features: int, num_hidden_layers: int, num_neurons: int,
+                 encoding_type: FeatureEncodingType = FeatureEncodingType.SINE,
+                 compress_pole_factor: Optional[float] = 1.0, position_type: str = "output_gains",
+                 device: Optional[torch.device] = 'cpu'):
+        super().__init__()
+        if encoding_type != FeatureEncodingType.SINE:
+            raise NotImplementedError("only sinusoidal encoding is on the accelerated path")
+        self.num_groups = num_groups
+        self.num_delay_lines_per_group = num_delay_lines_per_group
+        self.num_delay_lines = num_groups * num_delay_lines_per_group
+        self.position_type = position_type
+        self.encoding_type = encoding_type
+        self.compress_pole_factor = compress_pole_factor
+        self.device = device
+        self.svf_cutoff_freqs = svf_cutoff_frequencies(sample_rate)
+        self.num_biquads = len(self.svf_cutoff_freqs)
+        self.encoder = SinusoidalEncoding(num_fourier_features)
+        self.mlp = MLP(3 * num_fourier_features * 2, num_hidden_layers, num_neurons, num_groups,
+                       self.num_biquads, num_params=2)
+
+    def group_responses(self, x: Dict) -> torch.Tensor:
+        # NB the reference feeds the RAW listener position here (:340-342), not the normalised one
+        position = x['listener_position'] if self.position_type == "output_gains" else x['source_position']
+        w = self.mlp.model[0].weight
+        enc = self.encoder(position.to(w.device))
+        self.svf_params = self.mlp(enc.to(w.dtype))                             # (B, G, S, 2) raw
+        return svf_cascade_response(x['z_values'].to(w.device), self.svf_cutoff_freqs, self.svf_params,
+                                    self.compress_pole_factor)
+
+    def forward(self, x: Dict) -> torch.Tensor:
+        return self.group_responses(x).repeat_interleave(self.num_delay_lines_per_group, dim=1)
+
+
 class Gains_from_MLP(nn.Module):
     """Scalar gain per (receiver, group) in (-1, 1) from the normalised receiver position."""
 

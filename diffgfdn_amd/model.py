@@ -21,7 +21,8 @@ from torch import nn
 from .config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
 from .feedback_loop import FeedbackLoop, decay_times_to_gain_per_sample
 from .functional import FrequencyGrid, OutputStage, ResolventSolve, SHOutputStage
-from .gain_filters import Directional_Beamforming_Weights_from_MLP, Gains_from_MLP
+from .gain_filters import (Directional_Beamforming_Weights_from_MLP, Gains_from_MLP, SVF_from_MLP,
+                           svf_cascade_response, svf_cutoff_frequencies)
 
 
 class DiffGFDN(nn.Module):
@@ -125,6 +126,25 @@ class DiffGFDN(nn.Module):
         b = self.input_gains if b is None else b
         return self.feedback_loop.resolvent_apply(z, b, transpose)
 
+    def group_transfer(self, z: torch.Tensor) -> torch.Tensor:
+        """T (K, G, G'):  T[k, g, g'] = c_g^T P_{g g'}(z_k) b_{g'}  -- the group-to-group transfer functions every
+        frequency-dependent in/out filter multiplies (H = sum_{g,g'} Cout_g T_{g g'} Cin_{g'}).  Zero coupling:
+        one solve, diagonal in (g, g'); coupled feedback matrix: one solve per source group."""
+        G, n = self.num_groups, self.num_delay_lines_per_group
+        fl = self.feedback_loop
+        c = self.output_gains.reshape(1, -1)
+        if fl.use_zero_coupling and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
+            S = (self.delay_line_responses(z) * c).reshape(-1, G, n).sum(-1)                    # (K, G)
+            return torch.diag_embed(S)
+        b = self.input_gains.reshape(G, n)
+        cols = []
+        for gs in range(G):
+            mask = torch.zeros_like(b)
+            mask[gs] = 1.0
+            Yg = self.delay_line_responses(z, b=(b * mask).reshape(-1, 1))
+            cols.append((Yg * c).reshape(-1, G, n).sum(-1))
+        return torch.stack(cols, dim=-1)
+
     def sub_fdn_responses(self, z: torch.Tensor) -> torch.Tensor:
         """Un-damped per-group responses y^(g) = (D - M_g)^{-1} b_g with the RAW parameter M_g
         (reference model.py:237-240) -> (K, N) complex64."""
@@ -177,14 +197,22 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
         super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
                          use_absorption_filters, learn_common_decay_times, common_decay_times,
                          band_centre_hz, colorless_fdn_params, use_colorless_loss, absorption_filter_coeffs)
-        if output_filter_config.use_svfs:
-            raise NotImplementedError("SVF output filters: SURVEY §8 f-2 (next)")
-        self.use_svf_in_output = False
+        self.use_svf_in_output = output_filter_config.use_svfs
         self.input_scalars = torch.ones(self.num_groups, 1)
-        self.output_scalars = Gains_from_MLP(
-            self.num_groups, self.num_delay_lines_per_group,
-            output_filter_config.num_fourier_features, output_filter_config.num_hidden_layers,
-            output_filter_config.num_neurons_per_layer, output_filter_config.encoding_type)
+        if self.use_svf_in_output:
+            # receiver-position dependent SVF cascades (reference :544-555): the output "gains" become (B, G, K)
+            # complex responses; the solve is still shared by the batch, the contraction with the responses is
+            # evaluated by torch ops on the device (first version of SURVEY §8 f-2: correct, not yet fused)
+            self.output_filters = SVF_from_MLP(
+                self.sample_rate, self.num_groups, self.num_delay_lines_per_group,
+                output_filter_config.num_fourier_features, output_filter_config.num_hidden_layers,
+                output_filter_config.num_neurons_per_layer, output_filter_config.encoding_type,
+                output_filter_config.compress_pole_factor)
+        else:
+            self.output_scalars = Gains_from_MLP(
+                self.num_groups, self.num_delay_lines_per_group,
+                output_filter_config.num_fourier_features, output_filter_config.num_hidden_layers,
+                output_filter_config.num_neurons_per_layer, output_filter_config.encoding_type)
 
     def forward(self, x: Dict, output_scalars: Optional[torch.Tensor] = None,
                 subband_filter: Optional[torch.Tensor] = None):
@@ -195,6 +223,15 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
         z = x['z_values']
         self.feedback_loop.new_forward()
         self.batch_size = x['listener_position'].shape[0]
+        if self.use_svf_in_output:
+            Co = self.output_filters.group_responses(x)                                  # (B, G, K)
+            T = self.group_transfer(z)                                                   # (K, G, G')
+            H = torch.einsum('bgk,kg->bk', Co, T.sum(-1)) + x['target_early_response']
+            if subband_filter is not None:
+                H = H * subband_filter
+            if self.use_colorless_loss:
+                return H, self.sub_fdn_output(z)
+            return H
         if output_scalars is None:
             rgain = self.output_scalars.group_gains(x)
         else:
@@ -298,19 +335,44 @@ class DiffGFDNSinglePos(DiffGFDN):
         super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
                          use_absorption_filters, learn_common_decay_times, common_decay_times,
                          band_centre_hz, colorless_fdn_params, use_colorless_loss)
-        if output_filter_config.use_svfs or (input_filter_config is not None and input_filter_config.use_svfs):
-            raise NotImplementedError("SVF input/output filters: SURVEY §8 f-2 (next)")
-        self.use_svf_in_input = False
-        self.use_svf_in_output = False
+        self.use_svf_in_input = input_filter_config.use_svfs if input_filter_config is not None else False
+        self.use_svf_in_output = output_filter_config.use_svfs
         G = self.num_groups
-        self.input_scalars = nn.Parameter(torch.ones(G, 1) / np.sqrt(G))     # reference :749-750
-        self.output_scalars = nn.Parameter(torch.ones(G, 1) / np.sqrt(G))    # reference :776-777
+        if self.use_svf_in_output or self.use_svf_in_input:
+            self.svf_cutoff_freqs = svf_cutoff_frequencies(self.sample_rate)
+            self.num_biquads = len(self.svf_cutoff_freqs)
+            self.compress_pole_factor = output_filter_config.compress_pole_factor
+        # draws in the reference's order: source side first (:723-724), [resonance ~ randn, gain = 0 dB]
+        if self.use_svf_in_input:
+            init = torch.randn(G, self.num_biquads, 2)
+            init[..., 1] = 0.0
+            self.input_svf_params = nn.Parameter(init)                       # reference :729-737
+        else:
+            self.input_scalars = nn.Parameter(torch.ones(G, 1) / np.sqrt(G))     # reference :749-750
+        if self.use_svf_in_output:
+            init = torch.randn(G, self.num_biquads, 2)
+            init[..., 1] = 0.0
+            self.output_svf_params = nn.Parameter(init)                      # reference :756-764
+        else:
+            self.output_scalars = nn.Parameter(torch.ones(G, 1) / np.sqrt(G))    # reference :776-777
 
     def forward(self, x: Dict):
         """reference :779-836; inputs are (K,) tensors, output H is (K,)."""
         z = x['z_values']
         self.feedback_loop.new_forward()
         n = self.num_delay_lines_per_group
+        if self.use_svf_in_input or self.use_svf_in_output:
+            # per-group SVF cascades on either side (reference get_filter :838-911): H = sum_{g,g'} Co_g T_{g g'} Ci_{g'}
+            K = z.numel()
+            T = self.group_transfer(z)                                                   # (K, G, G')
+            Co = (svf_cascade_response(z, self.svf_cutoff_freqs, self.output_svf_params, self.compress_pole_factor)
+                  if self.use_svf_in_output else self.output_scalars.to(torch.complex64).expand(-1, K))
+            Ci = (svf_cascade_response(z, self.svf_cutoff_freqs, self.input_svf_params, self.compress_pole_factor)
+                  if self.use_svf_in_input else self.input_scalars.to(torch.complex64).expand(-1, K))
+            H = torch.einsum('gk,kgh,hk->k', Co, T, Ci) + x['target_early_response'].reshape(-1)
+            if self.use_colorless_loss:
+                return H, self.sub_fdn_output(z)
+            return H
         b = self.input_scalars.repeat_interleave(n, dim=0) * self.input_gains
         Y = self.delay_line_responses(z, b=b)
         H = OutputStage.apply(Y, self.output_gains.reshape(-1), self.output_scalars.reshape(1, -1),

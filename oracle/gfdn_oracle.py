@@ -136,6 +136,55 @@ def feedback_loop_forward(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Te
     return torch.linalg.inv(Ddecay - Acplx).to(torch.complex64)            # :391
 
 
+def svf_cutoff_freqs(fs: float) -> torch.Tensor:
+    """filters/geq.py:9-56 (eq_freqs defaults) + gain_filters.py:299-303 / model.py:711-716."""
+    centre, c = [], 31.25
+    while c < 16000:
+        centre.append(c * np.power(2, 1.0))
+        c = centre[-1]
+    centre = torch.tensor(centre)
+    sc = torch.tensor([centre[0] / np.power(2, 0.5), centre[-1] * np.power(2, 0.5)])
+    return torch.pi * torch.cat((torch.tensor([sc[0]]), centre, torch.tensor([sc[-1]]))) / fs
+
+
+def svf_biquad_cascade(cutoffs: torch.Tensor, params: torch.Tensor, cpf: float):
+    """One cascade: params (S, 2) = constrained [resonance, gain dB] -> (num (S,3), den (S,3)) float32
+    (gain_filters.py:36-103 SVF mixing coefficients, :117-151 from_svf_coeffs)."""
+    S = params.shape[0]
+    num = torch.zeros((S, 3))
+    den = torch.zeros((S, 3))
+    for i in range(S):
+        f, R = cutoffs[i], params[i, 0]
+        G = db2lin(params[i, 1])
+        if i == 0:
+            m_lp, m_bp, m_hp = G, 2 * R * torch.sqrt(G), torch.ones_like(G)          # lowshelf
+        elif i == S - 1:
+            m_lp, m_bp, m_hp = torch.ones_like(G), 2 * R * torch.sqrt(G), G          # highshelf
+        else:
+            m_lp, m_bp, m_hp = torch.ones_like(G), 2 * R * G, torch.ones_like(G)     # peaking
+        num[i, 0] = f ** 2 * m_lp + f * m_bp + m_hp
+        num[i, 1] = (2 * f ** 2 * m_lp - 2 * m_hp) * cpf
+        num[i, 2] = (f ** 2 * m_lp - f * m_bp + m_hp) * cpf ** 2
+        den[i, 0] = f ** 2 + 2 * R * f + 1
+        den[i, 1] = (2 * f ** 2 - 2) * cpf
+        den[i, 2] = (f ** 2 - 2 * R * f + 1) * cpf ** 2
+    return num, den
+
+
+def svf_group_responses(z: torch.Tensor, fs: float, raw_params: torch.Tensor, cpf: float = 1.0) -> torch.Tensor:
+    """raw (..., S, 2) unconstrained -> (..., K) complex64 cascade responses: scaled sigmoids (gain_filters.py:
+    327-330 / model.py:733-737, :853-866), SVF -> biquads, SOSFilter.forward (:221-241)."""
+    cut = svf_cutoff_freqs(fs)
+    lead = raw_params.shape[:-2]
+    flat = raw_params.reshape(-1, raw_params.shape[-2], 2)
+    out = []
+    for q in range(flat.shape[0]):
+        prm = torch.stack([scaled_sigmoid(flat[q, :, 0], 1e-6, 1.0), scaled_sigmoid(flat[q, :, 1], -6.0, 6.0)], dim=-1)
+        num, den = svf_biquad_cascade(cut, prm, cpf)
+        out.append(sos_response(z, torch.stack((num, den), dim=-1).unsqueeze(0))[0])
+    return torch.stack(out).reshape(*lead, len(z))
+
+
 def sos_response(z: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
     """gain_filters.py:221-241 (SOSFilter.forward) for N cascades: coeffs (N, S, 3, 2), [..., 0] numerator,
     [..., 1] denominator -> (N, K) complex64 (the reference accumulates the product in complex64)."""

@@ -437,6 +437,47 @@ def gen_f10_absorption_filters():
     print('F10 done', out['sd_delay_filters'].shape)
 
 
+def gen_f11_svf_filters():
+    """SVF output filters from an MLP on the grid model (gain_filters.py:262-402, model.py:544-592) and learnable
+    SVF input + output filters on the single-position model (model.py:723-778, get_filter :838-911)."""
+    fs, nfft, G, nper, B = 8000.0, 512, 2, 4, 3
+    delays = prime_delays(G * nper, lo=160, hi=400, seed=8)
+    batch, T60 = synth_batch(B, nfft, fs, G, 450, 51, T60=[0.3, 0.6])
+    out = {'fs': fs, 'nfft': nfft, 'G': G, 'nper': nper, 'delays': np.array(delays), 'T60': T60}
+    out.update(batch_to_np(batch))
+    # (a) grid model, zero coupling
+    torch.manual_seed(23)
+    np.random.seed(23)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                            compress_pole_factor=0.98)
+    net = DiffGFDNVarReceiverPos(fs, G, delays, 'cpu', fl, of, use_absorption_filters=False,
+                                 common_decay_times=np.asarray(T60)[None, :], use_colorless_loss=True)
+    H, (Hout, _) = net(batch)
+    loss = (H.abs() ** 2).sum()
+    loss.backward()
+    out.update({'grid_H': c2np(H), 'grid_Hout': c2np(Hout), 'grid_Co': c2np(net.output_filters(batch)[:, ::nper, :])})
+    out.update(state_np(net, 'gsd_'))
+    out.update({'ggrad_' + k: c2np(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+    # (b) single position, coupled, SVFs on both sides
+    torch.manual_seed(29)
+    np.random.seed(29)
+    fl2 = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=False)
+    of2 = OutputFilterConfig(use_svfs=True, compress_pole_factor=1.0)
+    sp = DiffGFDNSinglePos(fs, G, delays, 'cpu', fl2, of2, use_absorption_filters=False,
+                           common_decay_times=np.asarray(T60)[None, :], use_colorless_loss=True,
+                           input_filter_config=of2)
+    x = {'z_values': batch['z_values'], 'target_early_response': batch['target_early_response'][0].clone()}
+    # (the reference's get_filter deep-copies non-leaf tensors, model.py:905-908, which torch refuses while
+    # recording gradients: its SVF single-position forward only runs under no_grad -- forward values are pinned)
+    with torch.no_grad():
+        Hs, (Hsout, _) = sp(x)
+    out.update({'sp_H': c2np(Hs), 'sp_Hout': c2np(Hsout)})
+    out.update(state_np(sp, 'ssd_'))
+    np.savez_compressed(os.path.join(HERE, 'f11_svf_filters.npz'), **out)
+    print('F11 done')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1_feedback_loop()
@@ -452,3 +493,4 @@ if __name__ == '__main__':
     gen_f8_source_receiver()
     gen_f9_colorless_fdn()
     gen_f10_absorption_filters()
+    gen_f11_svf_filters()

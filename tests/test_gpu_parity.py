@@ -662,3 +662,41 @@ def test_f10_absorption_filters_model():
     with pytest.raises(NotImplementedError):
         DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
                                use_absorption_filters=True, common_decay_times=fx["T60"])
+
+
+def test_f11_svf_filters():
+    """SVF output filters from an MLP on the grid model and learnable SVF input / output filters on the
+    single-position model (fixture F11; gain_filters.py:262-402, model.py:544-592, :723-778, :838-911)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNSinglePos, DiffGFDNVarReceiverPos
+    fx = load("f11_svf_filters.npz")
+    fs, G, delays = float(fx["fs"]), int(fx["G"]), fx["delays"].tolist()
+    batch = _to_dev(batch_from(fx))
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                            compress_pole_factor=0.98)
+    net = DiffGFDNVarReceiverPos(fs, G, delays, DEV, fl, of, use_absorption_filters=False,
+                                 common_decay_times=fx["T60"][None, :], use_colorless_loss=True)
+    net.load_state_dict(_state(fx, "gsd_"), strict=True)
+    net = net.to(DEV)
+    Co = net.output_filters.group_responses(batch)
+    assert rel_err(Co.detach().cpu().numpy(), fx["grid_Co"]) < 2e-5
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu().numpy(), fx["grid_H"]) < TOL
+    (H.abs() ** 2).sum().backward()
+    for name_, prm in net.named_parameters():
+        ref = fx["ggrad_" + name_]
+        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+    # single position: SVF cascades on both sides, coupled feedback matrix
+    fl2 = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=False)
+    of2 = OutputFilterConfig(use_svfs=True, compress_pole_factor=1.0)
+    sp = DiffGFDNSinglePos(fs, G, delays, DEV, fl2, of2, use_absorption_filters=False,
+                           common_decay_times=fx["T60"][None, :], use_colorless_loss=True, input_filter_config=of2)
+    sp.load_state_dict(_state(fx, "ssd_"), strict=True)
+    sp = sp.to(DEV)
+    x = {"z_values": batch["z_values"], "target_early_response": batch["target_early_response"][0].clone()}
+    Hs, (Hsout, _) = sp(x)
+    assert rel_err(Hs.detach().cpu().numpy(), fx["sp_H"]) < TOL
+    assert rel_err(Hsout.detach().cpu().numpy(), fx["sp_Hout"]) < TOL
+    (Hs.abs() ** 2).sum().backward()            # the reference cannot back-propagate here (see the fixture script)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sp.parameters())

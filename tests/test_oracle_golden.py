@@ -272,3 +272,16 @@ def test_f10_absorption_filter_feedback_loop():
     A = orc.coupled_feedback_matrix(torch.tensor(fx["sd_feedback_loop.M"]), torch.tensor(fx["sd_feedback_loop.alpha"]))
     P = orc.feedback_loop_forward_absorption(z, delays, torch.tensor(fx["sd_delay_filters"]), A)
     assert rel_err(P.detach().numpy(), fx["P_small"]) < 1e-5
+
+
+def test_f11_svf_responses():
+    """oracle SVF -> biquad -> cascade response vs the reference's SVF_from_MLP output (gain_filters.py:334-402)."""
+    from tests.helpers import mlp_from_state
+    fx = load("f11_svf_filters.npz")
+    G = int(fx["G"])
+    lin, norm = mlp_from_state(fx, prefix="gsd_", root="output_filters.mlp.model.")
+    pos = torch.tensor(fx["batch_listener_position"])            # RAW positions for the SVF network
+    enc = orc.sinusoidal_encoding(pos, 4)
+    raw = orc.mlp_forward(enc, lin, norm).view(pos.shape[0], G, 11, 2)
+    Co = orc.svf_group_responses(torch.tensor(fx["batch_z_values"]), float(fx["fs"]), raw, 0.98)
+    assert rel_err(Co.detach().numpy(), fx["grid_Co"]) < 2e-6
