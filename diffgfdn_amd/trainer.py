@@ -225,8 +225,12 @@ class Trainer:
         for epoch in range(self.max_epochs):
             st_epoch = time.time()
             agg_t, agg_v = {}, {}
+            svf = getattr(self.net, 'use_svf_in_output', False)
+            if svf:                       # full-band GFDN: b, c are normalised once per epoch (reference :365-369)
+                self.normalize(next(iter(train_dataset)))
             for data in train_dataset:
-                self.normalize(data)
+                if not svf:
+                    self.normalize(data)
                 _, cur = self.train_step(data)
                 for k, v in cur.items():
                     agg_t[k] = agg_t.get(k, 0.0) + v.detach()
@@ -286,6 +290,8 @@ class VarReceiverPosTrainer(Trainer):
         ``mask_prenorm``: EDC time weights already divided by (global batch x kept indices), in a
         static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
         net, cfg = self.net, self.config
+        if getattr(net, 'use_svf_in_output', False):
+            return self._step_losses_module_forward(data, draw_mask, defer_total)
         fl = net.feedback_loop
         fl.new_forward()
         z = data['z_values']
@@ -375,6 +381,35 @@ class VarReceiverPosTrainer(Trainer):
             losses['_heads'] = heads
         else:
             losses['_total'] = total if extra is None else total + extra
+        return losses
+
+    def _step_losses_module_forward(self, data: Dict, draw_mask: bool, defer_total: bool) -> Dict:
+        """Step losses through the model's own forward (SVF output filters: the (B, G, K) filter responses make the
+        output stage receiver- AND bin-dependent, model.py:588-592) -- same loss kernels, full bin range."""
+        net, cfg = self.net, self.config
+        filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
+        if 'target_rir_response' not in data or 'listener_position' not in data:
+            raise ValueError("SVF output filters: collate full batches (no lean='rows')")
+        out = net(data, subband_filter=filt)
+        H, H_sub = out if net.use_colorless_loss else (out, None)
+        K = H.shape[-1]
+        start, length = self._decay_window(K)
+        maskw, count = (self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length)))
+        total, edr_v, edc_v = decay_losses(
+            H, data['target_rir_response'], win=self.stft_win, edr_weight=cfg.edr_loss_weight,
+            edc_weight=cfg.edc_loss_weight, edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count)
+        losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
+        if self.use_colorless_loss:
+            S = H_sub[0].T.contiguous()
+            spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
+            sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
+                net.feedback_loop.group_rotations()[net.num_groups - 1])
+            total = total + (spectral + sparsity) / self.world_size
+            losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
+        if defer_total:
+            losses['_heads'] = [total]
+        else:
+            losses['_total'] = total
         return losses
 
     def graphed(self, dataset, batch_size: int, mask_source: str = "device",

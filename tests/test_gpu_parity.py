@@ -700,3 +700,28 @@ def test_f11_svf_filters():
     assert rel_err(Hsout.detach().cpu().numpy(), fx["sp_Hout"]) < TOL
     (Hs.abs() ** 2).sum().backward()            # the reference cannot back-propagate here (see the fixture script)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sp.parameters())
+
+
+def test_svf_grid_trainer_steps():
+    """VarReceiverPosTrainer on a grid model with SVF output filters: normalize + a few optimiser steps run on the
+    module-forward path and lower the loss."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    fx = load("f11_svf_filters.npz")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                            compress_pole_factor=0.98)
+    net = DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                                 use_absorption_filters=False, common_decay_times=fx["T60"][None, :],
+                                 use_colorless_loss=True)
+    net.load_state_dict(_state(fx, "gsd_"), strict=True)
+    net = net.to(DEV)
+    tc = TrainerConfig(batch_size=3, num_freq_bins=int(fx["nfft"]), lr=1e-2, io_lr=1e-2, use_colorless_loss=True,
+                       use_asym_spectral_loss=True, edc_loss_weight=1.0, sparsity_loss_weight=1.0,
+                       use_edc_mask=False, train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a", device="cuda")
+    tr = VarReceiverPosTrainer(net, tc, stft_win=64)
+    batch = _to_dev(batch_from(fx))
+    tr.normalize(batch)
+    vals = [float(tr.train_step(batch)[0]) for _ in range(8)]
+    assert all(np.isfinite(vals)) and vals[-1] < vals[0]
