@@ -290,26 +290,16 @@ __device__ __forceinline__ void edc_segment(int len, int seg, int* s0, int* slen
 }
 
 // segsum[b][seg] = sum of x^2 over the segment
-// xs = 1: x is (batch, ld) float, item b = row b;  xs = 2: x is pair-interleaved (ceil(batch / 2), ld) float2,
-// item b = lane (b & 1) of row b >> 1 (the layout of the paired irfft): element i of item b sits at
-// edc_row(x, b, ld, xs)[i * xs]
-__device__ __forceinline__ const float* edc_row(const float* x, int b, int ld, int xs) {
-  return xs == 2 ? x + (size_t)(b >> 1) * ld * 2 + (b & 1) : x + (size_t)b * ld;
-}
-__device__ __forceinline__ float* edc_row(float* x, int b, int ld, int xs) {
-  return xs == 2 ? x + (size_t)(b >> 1) * ld * 2 + (b & 1) : x + (size_t)b * ld;
-}
-
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_segsum(const float* __restrict__ x, int ld,
                                                             int start, int len,
-                                                            float* __restrict__ segsum, int xs) {
+                                                            float* __restrict__ segsum) {
   __shared__ float s_red[16];
   const int seg = blockIdx.x, b = blockIdx.y;
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
-  const float* xw = edc_row(x, b, ld, xs) + (size_t)(start + s0) * xs;
+  const float* xw = x + (size_t)b * ld + start + s0;
   float acc = 0.f;
-  for (int i = threadIdx.x; i < sl; i += blockDim.x) acc += xw[i * xs] * xw[i * xs];
+  for (int i = threadIdx.x; i < sl; i += blockDim.x) acc += xw[i] * xw[i];
   acc = block_sum(acc, s_red);
   if (threadIdx.x == 0) segsum[b * EDC_NSEG + seg] = acc;
 }
@@ -343,7 +333,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
                                                              const float* __restrict__ maskw,
                                                              float inv_count, float gscale,
                                                              float* __restrict__ work,
-                                                             float* __restrict__ gx, int batch, int xs) {
+                                                             float* __restrict__ gx, int batch) {
   __shared__ float s_scan[16 * EDC_S];
   __shared__ float s_red[16];
   const int seg = blockIdx.x, b = blockIdx.y;
@@ -352,13 +342,13 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
   float* gsum = partial + (size_t)batch * EDC_NSEG;
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
-  const float* xw = edc_row(x, b, ld, xs) + (size_t)(start + s0) * xs;
+  const float* xw = x + (size_t)b * ld + start + s0;
   const float* t = Tdb + (trows ? (size_t)trows[b] : (size_t)b) * len + s0;
   const float* mw = maskw ? maskw + s0 : nullptr;
-  float* gw = gx ? edc_row(gx, b, ld, xs) + (size_t)(start + s0) * xs : nullptr;
+  float* gw = gx ? gx + (size_t)b * ld + start + s0 : nullptr;
   float acc = 0.f, gacc = 0.f;
   edc_scan(sl, later_segments(segsum, b, seg), s_scan,
-           [&](int j) { const float v = xw[(sl - 1 - j) * xs]; return v * v; },
+           [&](int j) { const float v = xw[sl - 1 - j]; return v * v; },
            [&](int j, float edc, float) {
              const int i = sl - 1 - j;
              const float lin = fabsf(edc) + F32_EPS;
@@ -371,7 +361,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
                const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
                const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
                const float g = -sg * dE * m * inv_count * gscale;   // dL/dEDC_i, staged in place
-               gw[i * xs] = g;
+               gw[i] = g;
                gacc += g;
              }
            });
@@ -387,7 +377,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_bwd(const float* __rest
                                                              int start, int len, float inv_count,
                                                              const float* __restrict__ work,
                                                              float* __restrict__ loss_item,
-                                                             float* __restrict__ gx, int batch, int xs) {
+                                                             float* __restrict__ gx, int batch) {
   __shared__ float s_scan[16 * EDC_S];
   const int seg = blockIdx.x, b = blockIdx.y;
   const float* partial = work + (size_t)batch * EDC_NSEG;
@@ -400,19 +390,19 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_bwd(const float* __rest
   if (!gx) return;
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
-  const float* xw = edc_row(x, b, ld, xs) + (size_t)(start + s0) * xs;
-  float* gw = edc_row(gx, b, ld, xs) + (size_t)(start + s0) * xs;
+  const float* xw = x + (size_t)b * ld + start + s0;
+  float* gw = gx + (size_t)b * ld + start + s0;
   float carry = 0.f;
   for (int s2 = 0; s2 < seg; ++s2) carry += gsum[b * EDC_NSEG + s2];
   // EDC_i = sum_{j >= i} x_j^2  =>  dL/dx_j = 2 x_j sum_{i <= j} dL/dEDC_i   (forward prefix scan)
-  edc_scan(sl, carry, s_scan, [&](int i) { return gw[i * xs]; },
-           [&](int i, float cum, float) { gw[i * xs] = 2.0f * xw[i * xs] * cum; });
+  edc_scan(sl, carry, s_scan, [&](int i) { return gw[i]; },
+           [&](int i, float cum, float) { gw[i] = 2.0f * xw[i] * cum; });
   // zeros outside the window
-  float* g = edc_row(gx, b, ld, xs);
+  float* g = gx + (size_t)b * ld;
   if (seg == 0)
-    for (int i = threadIdx.x; i < start; i += blockDim.x) g[i * xs] = 0.f;
+    for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = 0.f;
   if (seg == EDC_NSEG - 1)
-    for (int i = start + len + threadIdx.x; i < ld; i += blockDim.x) g[i * xs] = 0.f;
+    for (int i = start + len + threadIdx.x; i < ld; i += blockDim.x) g[i] = 0.f;
 }
 
 
@@ -420,7 +410,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_bwd(const float* __rest
 // EDC on pair-interleaved signals (x2 (pairs, ld) float2: item 2p in .x, item 2p + 1 in .y): one block
 // scans BOTH items of a pair -- every quantity of the scans is a float2, loads and stores are coalesced
 // 8-byte accesses (running the per-item kernels over the interleaved layout with an element stride of 2
-// halves the efficiency of every access: 127 + 98 us vs 95 + 79 us beside the STFT kernels).
+// halved the efficiency of every access: 127 + 98 us vs 95 + 79 us beside the STFT kernels).
 // Same segmentation, carries and summation order per item as the kernels above: identical numbers.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -636,28 +626,10 @@ extern "C" int gfdn_edc_target(const float* x, int ld, int batch, int start, int
     return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_edc_segsum, dim3(EDC_NSEG, batch), dim3(EDC_THREADS), 0, s, x, ld, start, len,
-                     (float*)work, 1);
+                     (float*)work);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_target, dim3(EDC_NSEG, batch), dim3(EDC_THREADS), 0, s, x, ld, start, len,
                      (const float*)work, T_db);
-  GFDN_LAUNCH_CHECK();
-  return 0;
-}
-
-static int edc_loss_run(const float* x, int ld, int batch, int start, int len, const float* T_db,
-                        const long long* target_rows, const float* maskw, float inv_count, float gscale,
-                        float* loss_item, float* gx, void* work, void* stream, int xs) {
-  if (!x || !T_db || !loss_item || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
-    return GFDN_E_BADARG;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
-  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work, xs);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, target_rows, maskw, inv_count, gscale,
-                     (float*)work, gx, batch, xs);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
-                     loss_item, gx, batch, xs);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -666,8 +638,19 @@ extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int l
                              const float* T_db, const long long* target_rows, const float* maskw,
                              float inv_count, float gscale,
                              float* loss_item, float* gx, void* work, void* stream) {
-  return edc_loss_run(x, ld, batch, start, len, T_db, target_rows, maskw, inv_count, gscale, loss_item, gx, work,
-                      stream, 1);
+  if (!x || !T_db || !loss_item || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
+    return GFDN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
+  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, target_rows, maskw, inv_count, gscale,
+                     (float*)work, gx, batch);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
+                     loss_item, gx, batch);
+  GFDN_LAUNCH_CHECK();
+  return 0;
 }
 
 // work: gfdn_edc_work_bytes(items + 1)  (per-item slots for 2 * ceil(items / 2) items)
