@@ -516,7 +516,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_segsum(const float2* _
   }
 }
 
-__global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_seg_fwd(const float2* __restrict__ x2, int ld, int start,
+__global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float2* __restrict__ x2, int ld, int start,
                                                                   int len, const float* __restrict__ Tdb,
                                                                   const long long* __restrict__ trows,
                                                                   const float* __restrict__ maskw,
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_seg_fwd(const float2* 
   }
 }
 
-__global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_seg_bwd(const float2* __restrict__ x2, int ld, int start,
+__global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_bwd(const float2* __restrict__ x2, int ld, int start,
                                                                   int len, float inv_count,
                                                                   const float* __restrict__ work,
                                                                   float* __restrict__ loss_item,
