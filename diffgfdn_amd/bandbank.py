@@ -63,7 +63,7 @@ class BandBank(nn.Module):
             fl = net.feedback_loop
             if (net.num_groups, net.num_delay_lines_per_group) != (G, n):
                 raise ValueError("BandBank: bands must have the same groups x delay lines per group")
-            if fl.coupling_matrix_type == CouplingMatrixType.RANDOM or not fl.use_zero_coupling:
+            if not fl.uncoupled:
                 raise NotImplementedError("BandBank: zero inter-group coupling only (train other layouts "
                                           "band by band with subband.train_bands)")
             if fl.use_absorption_filters:

@@ -669,6 +669,216 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FILTER coupling (feedback_loop.py:362-373, :441-455): the inter-group coupling is a paraunitary FIR matrix
+// Phi(z) (G x G, order P), so the feedback matrix is frequency dependent,
+//     A(z_k)[i][j] = BM[i][j] * Phi_k[g(i)][g(j)],    BM = block mixing matrix (real, N x N),
+// with Phi_k = sum_p Phi_p z_k^-p (K, G, G) complex64 evaluated by the caller.  One dense N x N system per
+// bin on NP lanes as k_solve_fwd / k_solve_bwd; the backward also returns dL/dPhi_k per bin.
+// ------------------------------------------------------------------------------------------
+struct PhiArgs {
+  const double* turns;
+  const double* logr;
+  int K, N, nper;              // N = G * nper
+  const float* BM;             // (N, N)
+  const float2* Phi;           // (K, G, G)
+  const float* delays;
+  const float* inv_gamma;
+  const float* b;
+};
+
+template <int NP>
+__device__ __forceinline__ void build_row_phi(float2 (&row)[NP], const PhiArgs& a, int k, int r, bool adj,
+                                              float2 diag) {
+  const int N = a.N, G = N / a.nper;
+  const float2* Ph = a.Phi + (size_t)k * G * G;
+  const int gr = (r < N ? r : 0) / a.nper;
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    float2 v = make_float2(0.f, 0.f);
+    if (c < N && r < N) {
+      const int gc = c / a.nper;
+      // T = D - A;  adjoint: row r of T^H = conj of column r of T
+      const float2 ph = adj ? cconj(Ph[gc * G + gr]) : Ph[gr * G + gc];
+      const float bm = adj ? a.BM[c * N + r] : a.BM[r * N + c];
+      v = make_float2(-bm * ph.x, -bm * ph.y);
+    }
+    if (c == r) v = make_float2(v.x + diag.x, v.y + diag.y);
+    row[c] = v;
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_phi_fwd(PhiArgs a, float2* __restrict__ Y) {
+  constexpr int SPB = 256 / NP;
+  const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
+  const int N = a.N;
+  const int k = blockIdx.x * SPB + grp;
+  const bool valid = k < a.K;
+  const int kk = valid ? k : a.K - 1;
+  const int i = r < N ? r : 0;
+  const float2 zeta = zeta_pow(a.turns, a.logr, kk, a.delays[i], a.inv_gamma[i]);
+  float2 row[NP];
+  build_row_phi<NP>(row, a, kk, r, false, zeta);
+  int pivcol;
+  const float2 y = gauss_jordan<NP>(row, make_float2(r < N ? a.b[i] : 0.f, 0.f), N, r, pivcol);
+  if (valid && pivcol >= 0) Y[(size_t)k * N + pivcol] = y;
+}
+
+// partial[part][N N + 2 N] (gBM | gb | unused), gPhi (K, G, G) written per bin
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_phi_bwd(PhiArgs a, const float2* __restrict__ gY,
+                                                       const float2* __restrict__ Ysaved,
+                                                       float* __restrict__ partial,
+                                                       float2* __restrict__ gPhi) {
+  constexpr int SPB = 256 / NP;
+  __shared__ float2 s_perm[256];
+  __shared__ float s_acc[256 * (NP + 2)];
+  __shared__ float2 s_phi[256 * GFDN_MAX_GROUPS];
+  const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
+  const int N = a.N, G = N / a.nper;
+  const bool active = r < N;
+  const int i = active ? r : 0;
+  const int gr = i / a.nper;
+  const float m_i = a.delays[i], ig_i = a.inv_gamma[i];
+  float acc[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) acc[c] = 0.f;
+  float accb = 0.f, accg = 0.f;
+  for (int k0 = blockIdx.x * SPB; k0 < a.K; k0 += gridDim.x * SPB) {
+    const int k = k0 + grp;
+    const bool valid = k < a.K;
+    const int kk = valid ? k : a.K - 1;
+    const float2 zeta = zeta_pow(a.turns, a.logr, kk, m_i, ig_i);
+    const float2 ynat = active ? Ysaved[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    float2 row[NP];
+    int pivcol;
+    build_row_phi<NP>(row, a, kk, r, true, cconj(zeta));
+    const float2 g = active ? gY[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    const float2 w = gauss_jordan<NP>(row, g, N, r, pivcol);
+    __syncthreads();
+    if (pivcol >= 0) s_perm[grp * NP + pivcol] = w;
+    __syncthreads();
+    float2 wnat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    if (!valid) wnat = make_float2(0.f, 0.f);
+    // gA[r][c] = w_r conj(y_c)  (complex);  gBM[r][c] += Re(conj(Phi[g(r)][g(c)]) gA[r][c]);
+    // gPhi[g(r)][g'] += sum_{c in g'} BM[r][c] gA[r][c]   (summed over the rows of group g(r) below)
+    const float2* Ph = a.Phi + (size_t)kk * G * G;
+    float2 sphi[GFDN_MAX_GROUPS];
+#pragma unroll
+    for (int q = 0; q < GFDN_MAX_GROUPS; ++q) sphi[q] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      if (c < N) {
+        const float yx = __shfl(ynat.x, c, NP), yy = __shfl(ynat.y, c, NP);
+        const float2 ga = make_float2(wnat.x * yx + wnat.y * yy, wnat.y * yx - wnat.x * yy);   // w conj(y)
+        const int gc = c / a.nper;
+        const float2 ph = Ph[gr * G + gc];
+        acc[c] += ph.x * ga.x + ph.y * ga.y;
+        const float bm = active ? a.BM[i * N + c] : 0.f;
+#pragma unroll
+        for (int q = 0; q < GFDN_MAX_GROUPS; ++q)
+          if (q == gc) { sphi[q].x += bm * ga.x; sphi[q].y += bm * ga.y; }
+      }
+    }
+    accb += wnat.x;
+    {  // g inv_gamma_i = -Re(conj(w_i) y_i z^m), as k_solve_bwd
+      const float2 yz = cmul(ynat, zeta_pow(a.turns, a.logr, kk, m_i, 1.0f));
+      accg -= wnat.x * yz.x + wnat.y * yz.y;
+    }
+#pragma unroll
+    for (int q = 0; q < GFDN_MAX_GROUPS; ++q) s_phi[(grp * NP + r) * GFDN_MAX_GROUPS + q] = sphi[q];
+    __syncthreads();
+    if (valid) {
+      for (int e = r; e < G * G; e += NP) {
+        const int gq = e / G, gp = e - gq * G;
+        float2 t = make_float2(0.f, 0.f);
+        for (int rr = gq * a.nper; rr < (gq + 1) * a.nper; ++rr) t = cadd(t, s_phi[(grp * NP + rr) * GFDN_MAX_GROUPS + gp]);
+        gPhi[(size_t)k * G * G + e] = t;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NP; ++c) s_acc[(grp * NP + r) * (NP + 2) + c] = acc[c];
+  s_acc[(grp * NP + r) * (NP + 2) + NP] = accb;
+  s_acc[(grp * NP + r) * (NP + 2) + NP + 1] = accg;
+  __syncthreads();
+  const int per = N * N + 2 * N;
+  float* out = partial + (size_t)blockIdx.x * per;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    int rr, cc;
+    if (e < N * N) { rr = e / N; cc = e % N; }
+    else if (e < N * N + N) { rr = e - N * N; cc = NP; }
+    else { rr = e - N * N - N; cc = NP + 1; }
+    float sum = 0.f;
+    for (int g2 = 0; g2 < SPB; ++g2) sum += s_acc[(g2 * NP + rr) * (NP + 2) + cc];
+    out[e] = sum;
+  }
+}
+
+static int phi_args_ok(const double* turns, int K, int G, int nper, const float* BM, const float* Phi,
+                       const float* delays, const float* ig, const float* b) {
+  if (!turns || !BM || !Phi || !delays || !ig || !b || K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (G > GFDN_MAX_GROUPS || G * nper > GFDN_MAX_BLOCK) return GFDN_E_UNSUPPORTED;
+  return 0;
+}
+
+extern "C" int gfdn_solve_phi_fwd(const double* turns, const double* logr, int K, int G, int nper,
+                                  const float* BM, const float* Phi_c64, const float* delays,
+                                  const float* inv_gamma, const float* b, float* Y, void* stream) {
+  int rc = phi_args_ok(turns, K, G, nper, BM, Phi_c64, delays, inv_gamma, b);
+  if (rc) return rc;
+  if (!Y) return GFDN_E_BADARG;
+  PhiArgs a{turns, logr, K, G * nper, nper, BM, (const float2*)Phi_c64, delays, inv_gamma, b};
+  const int np = pick_np(G * nper), spb = 256 / np;
+  dim3 grid((K + spb - 1) / spb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (np) {
+    case 4: hipLaunchKernelGGL(k_solve_phi_fwd<4>, grid, block, 0, s, a, (float2*)Y); break;
+    case 8: hipLaunchKernelGGL(k_solve_phi_fwd<8>, grid, block, 0, s, a, (float2*)Y); break;
+    case 16: hipLaunchKernelGGL(k_solve_phi_fwd<16>, grid, block, 0, s, a, (float2*)Y); break;
+    default: hipLaunchKernelGGL(k_solve_phi_fwd<32>, grid, block, 0, s, a, (float2*)Y); break;
+  }
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t gfdn_solve_phi_bwd_work_bytes(int G, int nper) {
+  const int N = G * nper;
+  return (size_t)GFDN_PARTIAL_BLOCKS * (N * N + 2 * N) * sizeof(float);
+}
+
+extern "C" int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, int nper,
+                                  const float* BM, const float* Phi_c64, const float* delays,
+                                  const float* inv_gamma, const float* b, const float* gY, const float* Y,
+                                  float* gBM, float* gb, float* ginv_gamma, float* gPhi_c64, void* work,
+                                  void* stream) {
+  int rc = phi_args_ok(turns, K, G, nper, BM, Phi_c64, delays, inv_gamma, b);
+  if (rc) return rc;
+  if (!gY || !Y || !gBM || !gb || !ginv_gamma || !gPhi_c64 || !work) return GFDN_E_BADARG;
+  const int N = G * nper;
+  PhiArgs a{turns, logr, K, N, nper, BM, (const float2*)Phi_c64, delays, inv_gamma, b};
+  const int np = pick_np(N), spb = 256 / np;
+  int nparts = (K + spb - 1) / spb;
+  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
+  dim3 grid(nparts), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)work;
+  switch (np) {
+    case 4: hipLaunchKernelGGL(k_solve_phi_bwd<4>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial, (float2*)gPhi_c64); break;
+    case 8: hipLaunchKernelGGL(k_solve_phi_bwd<8>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial, (float2*)gPhi_c64); break;
+    case 16: hipLaunchKernelGGL(k_solve_phi_bwd<16>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial, (float2*)gPhi_c64); break;
+    default: hipLaunchKernelGGL(k_solve_phi_bwd<32>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial, (float2*)gPhi_c64); break;
+  }
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_solve_bwd_finish, dim3(N * N + 2 * N), dim3(256), 0, s, partial, nparts, 1, N, gBM, gb, ginv_gamma);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // normalize (trainer.py:317-332) in two launches: energy of the sub-FDN responses, then the rescale.
 //   Hout[k][g] = sum_{n in g} c_n y_n,  y = (diag(z_k^m) - M_g)^{-1} b_g   (model.py:237-250)

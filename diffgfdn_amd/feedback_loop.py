@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .config import CouplingMatrixType
-from .functional import FrequencyGrid, OrthoParam, ResolventSolve
+from .functional import FrequencyGrid, OrthoParam, ResolventSolve, ResolventSolveFilter
 
 
 class Skew(nn.Module):
@@ -78,6 +78,41 @@ class ND_Unitary(nn.Module):
         return rot @ big
 
 
+def matrix_convolution(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Product of two polynomial matrices (M, N, K) x (N, Q, R) -> (M, Q, K + R - 1): C[m, q] = sum_n A[m, n] * B[n, q]
+    with * the full linear convolution along the last axis (utils.py:216-239).  One einsum per tap of the shorter
+    factor, out of place, so that autograd sees ordinary tensor ops."""
+    K, R = A.shape[-1], B.shape[-1]
+    if K <= R:
+        terms = [nn.functional.pad(torch.einsum('mn,nqr->mqr', A[..., i], B), (i, K - 1 - i)) for i in range(K)]
+    else:
+        terms = [nn.functional.pad(torch.einsum('mnk,nq->mqk', A, B[..., j]), (j, R - 1 - j)) for j in range(R)]
+    return torch.stack(terms).sum(0)
+
+
+class FIRParaunitary(nn.Module):
+    """FIR paraunitary matrix (N, N, order) as a cascade of order-1 Householder factors
+    I - (1 - z^-1) v v^T times a unitary matrix (reference :90-143)."""
+
+    def __init__(self, N: int, order: int):
+        super().__init__()
+        self.N = N
+        self.order = order
+
+    def construct_elementary_householder_matrix(self, unit_vector: torch.Tensor) -> torch.Tensor:
+        assert len(unit_vector) == self.N
+        vv = torch.outer(unit_vector, unit_vector)
+        return torch.stack([torch.eye(self.N, dtype=vv.dtype, device=vv.device) - vv, vv], dim=-1)
+
+    def forward(self, unitary_matrix: torch.Tensor, unit_vectors: torch.Tensor) -> torch.Tensor:
+        assert unitary_matrix.shape == (self.N, self.N)
+        assert unit_vectors.shape == (self.N, self.order - 1)
+        poly = torch.eye(self.N, dtype=unit_vectors.dtype, device=unit_vectors.device)[..., None]
+        for k in range(self.order - 1):
+            poly = matrix_convolution(self.construct_elementary_householder_matrix(unit_vectors[:, k]), poly)
+        return matrix_convolution(poly, unitary_matrix.reshape(self.N, self.N, 1))
+
+
 def decay_times_to_gain_per_sample(common_decay_times, delay_length_samp, fs):
     """gamma = 10^(0.05 * (-60 m / (fs T60)))   (reference absorption_filters.py:40-53)."""
     if isinstance(common_decay_times, torch.Tensor):
@@ -104,8 +139,9 @@ class FeedbackLoop(nn.Module):
         if use_absorption_filters and gains is None:
             raise NotImplementedError("absorption filters are fixed designs (reference :200-201 'Cannot learn "
                                       "absorption filters yet'): pass their coefficients as ``gains``")
-        if coupling_matrix_type == CouplingMatrixType.FILTER:
-            raise NotImplementedError("paraunitary FILTER coupling: SURVEY §8 f-2 (next)")
+        if coupling_matrix_type == CouplingMatrixType.FILTER and use_absorption_filters:
+            raise NotImplementedError("FILTER coupling with absorption filters: the FILTER solve kernel takes scalar "
+                                      "absorption gains")
         self.sample_rate = sample_rate
         self.num_groups = num_groups
         self.num_delay_lines_per_group = num_delay_lines_per_group
@@ -121,6 +157,8 @@ class FeedbackLoop(nn.Module):
         self.ortho_param = OrthoParamModule()
         self._ortho_cache = None
         self._inv_gamma_cache = None
+        self._zp_cache = None
+        self._eps = 1e-9
         self._init_absorption(gains, common_decay_times)
         self._init_feedback_matrix(colorless_feedback_matrix)
 
@@ -208,6 +246,12 @@ class FeedbackLoop(nn.Module):
             self.register_buffer('M', colorless_feedback_matrix.clone().detach(), persistent=False)
         else:
             self.M = nn.Parameter((2 * torch.rand(G, n, n) - 1) / np.sqrt(n))
+        if self.coupling_matrix_type == CouplingMatrixType.FILTER:
+            # order - 1 Householder vectors and the zeroth-order unitary factor (reference :311-323)
+            self.unit_vectors = nn.Parameter(torch.randn(G, self.coupling_matrix_order - 1))
+            self.unitary_matrix = nn.Parameter((2 * torch.rand(G, G) - 1) / np.sqrt(G))
+            self.fir_paraunitary = FIRParaunitary(G, self.coupling_matrix_order)
+            return
         self.nd_unitary = ND_Unitary()
         if self.use_zero_coupling:
             self.register_buffer("alpha", torch.zeros(G * (G - 1) // 2))
@@ -242,12 +286,29 @@ class FeedbackLoop(nn.Module):
         blocks = torch.einsum('iab,jbc->iajc', Q, Q)          # block (i,j) = Q_i Q_j
         return blocks.reshape(G * n, G * n)
 
+    @property
+    def uncoupled(self) -> bool:
+        """A = blockdiag(Q_g Q_g): SCALAR coupling with the angles fixed at zero (reference :296-304)."""
+        return (self.coupling_matrix_type not in (CouplingMatrixType.RANDOM, CouplingMatrixType.FILTER)
+                and self.use_zero_coupling)
+
     def construct_coupling_matrix(self):
+        if self.coupling_matrix_type == CouplingMatrixType.FILTER:
+            # (G, G, order) paraunitary FIR matrix from unit-norm Householder vectors (reference :413-420)
+            v = self.unit_vectors / (torch.norm(self.unit_vectors, dim=0, keepdim=True) + self._eps)
+            return self.fir_paraunitary(self.ortho_param(self.unitary_matrix), v)
         alpha = self.alpha.clamp(min=-np.pi, max=np.pi)
         return self.nd_unitary(alpha, self.num_groups)
 
     def get_coupled_feedback_matrix(self) -> torch.Tensor:
-        """A = block_M o kron(Phi, 1) as complex64 (N, N)   (reference :424-455)."""
+        """A = block_M o kron(Phi, 1) as complex64 (N, N), or (N, N, order) with A[..., p] = block_M o kron(Phi_p, 1)
+        for FILTER coupling   (reference :424-455)."""
+        if self.coupling_matrix_type == CouplingMatrixType.FILTER:
+            block_M = self.construct_block_mixing_matrix()
+            self.phi = self.construct_coupling_matrix()
+            n = self.num_delay_lines_per_group
+            A = block_M[..., None] * self.phi.repeat_interleave(n, 0).repeat_interleave(n, 1)
+            return torch.complex(A, torch.zeros_like(A))
         A = self._real_feedback_matrix()
         return torch.complex(A, torch.zeros_like(A))
 
@@ -265,7 +326,7 @@ class FeedbackLoop(nn.Module):
     def feedback_blocks(self) -> torch.Tensor:
         """What the solver consumes: (G, n, n) diagonal blocks Q_g Q_g when the groups are
         uncoupled, else the dense (1, N, N) matrix."""
-        if self.coupling_matrix_type != CouplingMatrixType.RANDOM and self.use_zero_coupling:
+        if self.uncoupled:
             if self.M.is_cuda:
                 return self._ortho()[1]
             Q = self.group_rotations()
@@ -277,6 +338,8 @@ class FeedbackLoop(nn.Module):
                         transpose: bool = False) -> torch.Tensor:
         """Y[k] = (D(z_k) Gamma^{-1} - A)^{-1} b  -> (K, N) complex64; A^T when ``transpose``."""
         grid = FrequencyGrid.of(z)
+        if self.coupling_matrix_type == CouplingMatrixType.FILTER:
+            return self._resolvent_apply_filter(z, grid, b, transpose)
         A = self.feedback_blocks()
         dev = A.device
         if self.use_absorption_filters:
@@ -294,6 +357,28 @@ class FeedbackLoop(nn.Module):
             inv_gamma = self._inv_gamma_cache[1]
         return ResolventSolve.apply(A, inv_gamma, b.reshape(-1), grid, self.delays, transpose)
 
+    def coupling_response(self, z: torch.Tensor, phi: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Phi(z_k) = sum_p Phi_p z_k^-p -> (K, G, G) complex64 (the frequency dependence of reference :362-373);
+        the powers z_k^-p are tabulated once per grid in complex128."""
+        key = (z.data_ptr(), z.numel(), z._version, str(z.device))
+        if self._zp_cache is None or self._zp_cache[0] != key:
+            p = torch.arange(self.coupling_matrix_order, device=z.device, dtype=torch.float64)
+            zp = torch.exp(-p[None, :] * torch.log(z.to(torch.complex128))[:, None])
+            self._zp_cache = (key, zp.to(torch.complex64), z)
+        phi = self.construct_coupling_matrix() if phi is None else phi
+        return torch.einsum('ghp,kp->kgh', phi.to(torch.complex64), self._zp_cache[1])
+
+    def _resolvent_apply_filter(self, z, grid, b, transpose):
+        BM = self.construct_block_mixing_matrix()
+        self.phi = self.construct_coupling_matrix()
+        Phi = self.coupling_response(z, self.phi)
+        if transpose:
+            BM, Phi = BM.T, Phi.transpose(1, 2)
+        dev = BM.device
+        inv_gamma = (1.0 / self.current_gains().to(dev)).to(torch.float32)
+        return ResolventSolveFilter.apply(BM.contiguous(), Phi.contiguous(), inv_gamma, b.reshape(-1), grid,
+                                          self.delays, self.num_delay_lines_per_group)
+
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """Explicit (K, N, N) complex64 inverse, for API parity with reference :326-391."""
         N = self.num_delays
@@ -310,7 +395,7 @@ class FeedbackLoop(nn.Module):
         A = self.get_coupled_feedback_matrix()
         out['coupled_feedback_matrix'] = A.squeeze().cpu().numpy()
         if self.coupling_matrix_type != CouplingMatrixType.RANDOM:
-            if not self.use_zero_coupling:
+            if not self.use_zero_coupling and hasattr(self, 'alpha'):
                 out['coupling_coefficient'] = self.alpha.squeeze().cpu().numpy()
             out['coupling_matrix'] = (self.phi.squeeze().cpu().numpy()
                                       if torch.is_tensor(self.phi) else np.asarray(self.phi))

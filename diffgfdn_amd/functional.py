@@ -129,6 +129,26 @@ class ResolventSolve(torch.autograd.Function):
                 None, None, None, None)
 
 
+class ResolventSolveFilter(torch.autograd.Function):
+    """Y[k] = (diag(z_k^m inv_gamma) - BM o kron(Phi_k, 1))^{-1} b: paraunitary FILTER coupling
+    (feedback_loop.py:362-373, :441-455), Phi (K, G, G) complex64 per bin."""
+
+    @staticmethod
+    def forward(ctx, BM, Phi, inv_gamma, b, grid: FrequencyGrid, delays, nper: int):
+        Y = ops.solve_phi_fwd(grid.turns, grid.logr, BM, Phi, nper, delays, inv_gamma, b)
+        ctx.save_for_backward(BM, Phi, inv_gamma, b, delays, Y)
+        ctx.grid, ctx.nper = grid, nper
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        BM, Phi, inv_gamma, b, delays, Y = ctx.saved_tensors
+        g = ctx.grid
+        gBM, gb, gig, gPhi = ops.solve_phi_bwd(g.turns, g.logr, BM, Phi, ctx.nper, delays, inv_gamma, b,
+                                               gY.contiguous(), Y)
+        return gBM.to(BM.dtype), gPhi, gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None
+
+
 class OutputStage(torch.autograd.Function):
     """H[b][k] = (sum_g rgain[b][g] sum_{n in g} c_n Y[k][n] + direct[b][k]) * filt[k]."""
 

@@ -134,6 +134,40 @@ def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None,
     return gA, gb, gig
 
 
+def solve_phi_fwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b) -> torch.Tensor:
+    """FILTER coupling: A(z_k) = BM o kron(Phi_k, 1).  BM (N, N) f32, Phi (K, G, G) complex64 -> Y (K, N)."""
+    _need_gpu(turns, BM, Phi)
+    BM, delays, inv_gamma, b, Phi = _f(BM), _f(delays), _f(inv_gamma), _f(b), _c(Phi)
+    K, G = turns.numel(), Phi.shape[-1]
+    if tuple(Phi.shape) != (K, G, G) or tuple(BM.shape) != (G * nper, G * nper):
+        raise RuntimeError("solve_phi_fwd: Phi must be (K, G, G) and BM (G nper, G nper)")
+    Y = torch.empty((K, G * nper), dtype=_c64, device=BM.device)
+    _lib.check(_lib.load().gfdn_solve_phi_fwd(_p(turns), _p(logr), K, G, nper, _p(BM), _p(Phi), _p(delays),
+                                              _p(inv_gamma), _p(b), _p(Y), _stream()), "gfdn_solve_phi_fwd")
+    return Y
+
+
+def solve_phi_bwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b, gY, Y):
+    """-> gBM (N, N), gb (N,), ginv_gamma (N,) float32 and gPhi (K, G, G) complex64 (per bin)."""
+    _need_gpu(turns, BM, Phi, gY, Y)
+    BM, delays, inv_gamma, b, Phi, gY, Y = _f(BM), _f(delays), _f(inv_gamma), _f(b), _c(Phi), _c(gY), _c(Y)
+    K, G = turns.numel(), Phi.shape[-1]
+    N = G * nper
+    if tuple(Phi.shape) != (K, G, G) or tuple(BM.shape) != (N, N) or tuple(Y.shape) != (K, N) \
+            or tuple(gY.shape) != (K, N):
+        raise RuntimeError("solve_phi_bwd: shape mismatch")
+    lib = _lib.load()
+    gBM = torch.empty_like(BM)
+    gb = torch.empty(N, dtype=_f32, device=BM.device)
+    gig = torch.empty_like(gb)
+    gPhi = torch.empty_like(Phi)
+    work = _work(lib.gfdn_solve_phi_bwd_work_bytes(G, nper), BM.device)
+    _lib.check(lib.gfdn_solve_phi_bwd(_p(turns), _p(logr), K, G, nper, _p(BM), _p(Phi), _p(delays), _p(inv_gamma),
+                                      _p(b), _p(gY), _p(Y), _p(gBM), _p(gb), _p(gig), _p(gPhi), _p(work),
+                                      _stream()), "gfdn_solve_phi_bwd")
+    return gBM, gb, gig, gPhi
+
+
 def _rows(rows, n_items: int, store_rows: int):
     """Validate a row-indirection index (int64 device vector of n_items entries)."""
     if rows is None:

@@ -133,7 +133,7 @@ class DiffGFDN(nn.Module):
         G, n = self.num_groups, self.num_delay_lines_per_group
         fl = self.feedback_loop
         c = self.output_gains.reshape(1, -1)
-        if fl.use_zero_coupling and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
+        if fl.uncoupled:
             S = (self.delay_line_responses(z) * c).reshape(-1, G, n).sum(-1)                    # (K, G)
             return torch.diag_embed(S)
         b = self.input_gains.reshape(G, n)
@@ -296,7 +296,7 @@ class DiffGFDNVarSourceReceiverPos(DiffGFDN):
         r = self.output_scalars.group_gains(x).to(torch.float32)          # (B, G) from the receiver position
         s = self.input_scalars.group_gains(x).to(torch.float32)           # (B, G) from the source position
         fl = self.feedback_loop
-        if fl.use_zero_coupling and fl.coupling_matrix_type != CouplingMatrixType.RANDOM:
+        if fl.uncoupled:
             Y = self.delay_line_responses(z)
             H = OutputStage.apply(Y, self.output_gains.reshape(-1), r * s, n, x['target_early_response'],
                                   subband_filter)

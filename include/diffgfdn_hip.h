@@ -90,6 +90,19 @@ int gfdn_solve_absorb_bwd(const double* turns, const double* logr, int K, int nb
                           const float* gY_c64, const float* Y_c64, float* gA, float* gb,
                           float* ginv_scratch, void* work, void* stream);
 
+/* FILTER coupling (feedback_loop.py:90-143, :362-373, :441-455): A(z_k)[i][j] = BM[i][j] Phi_k[g(i)][g(j)] with the
+ * paraunitary FIR coupling matrix evaluated per bin, Phi (K, G, G) complex64, and the real block mixing matrix
+ * BM (N, N), N = G * nper <= 32.  Backward: gBM (N, N), gb (N), ginv_gamma (N), gPhi (K, G, G) complex64
+ * (per bin); work: gfdn_solve_phi_bwd_work_bytes(G, nper).                                          */
+int gfdn_solve_phi_fwd(const double* turns, const double* logr, int K, int G, int nper, const float* BM,
+                       const float* Phi_c64, const float* delays, const float* inv_gamma, const float* b,
+                       float* Y_c64, void* stream);
+size_t gfdn_solve_phi_bwd_work_bytes(int G, int nper);
+int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, int nper, const float* BM,
+                       const float* Phi_c64, const float* delays, const float* inv_gamma, const float* b,
+                       const float* gY_c64, const float* Y_c64, float* gBM, float* gb, float* ginv_gamma,
+                       float* gPhi_c64, void* work, void* stream);
+
 /* ---- output stage  (model.py:583-619, gain_filters.py:526-534, trainer.py:459) ----------
  *   S[g][k]  = sum_{n in group g} c_n Y[k][n]
  *   H[b][k]  = (sum_g rgain[b][g] S[g][k] + direct[b][k]) * filt[k]

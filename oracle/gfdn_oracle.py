@@ -136,6 +136,63 @@ def feedback_loop_forward(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Te
     return torch.linalg.inv(Ddecay - Acplx).to(torch.complex64)            # :391
 
 
+def matrix_convolution(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """utils.py:216-239 -- polynomial-matrix product (M, N, K) x (N, Q, R) -> (M, Q, K + R - 1); the reference
+    convolves entry by entry with torchaudio.functional.convolve(mode='full') (torchaudio is absent here: the
+    full linear convolution is written out)."""
+    M, N, K = A.shape
+    _, Q, R = B.shape
+    C = torch.zeros((M, Q, K + R - 1), dtype=A.dtype)
+    for row in range(M):
+        for col in range(Q):
+            for it in range(N):
+                for i in range(K):
+                    C[row, col, i:i + R] = C[row, col, i:i + R] + A[row, it, i] * B[it, col, :]
+    return C
+
+
+def fir_paraunitary(unitary_matrix: torch.Tensor, unit_vectors: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:90-143 -- cascade of order-1 Householder factors I - (1 - z^-1) v v^T (one per column of
+    ``unit_vectors`` (N, order - 1)), then the unitary zeroth-order factor -> (N, N, order)."""
+    N = unitary_matrix.shape[0]
+    poly = torch.eye(N, dtype=unit_vectors.dtype)[..., None]
+    for k in range(unit_vectors.shape[1]):
+        vv = torch.outer(unit_vectors[:, k], unit_vectors[:, k])
+        house = torch.stack([torch.eye(N, dtype=vv.dtype) - vv, vv], dim=-1)        # :106-117
+        poly = matrix_convolution(house, poly)
+    return matrix_convolution(poly, unitary_matrix.reshape(N, N, 1))
+
+
+def filter_coupling_matrix(raw_unitary: torch.Tensor, raw_unit_vectors: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:413-420 -- FILTER coupling Phi (G, G, order) from the raw parameters."""
+    v = raw_unit_vectors / (torch.norm(raw_unit_vectors, dim=0, keepdim=True) + 1e-9)
+    return fir_paraunitary(ortho_param(raw_unitary), v)
+
+
+def filter_coupled_feedback_matrix(M: torch.Tensor, phi: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:447-455 -- A[..., p] = block_M o kron(Phi_p, 1), (N, N, order) complex."""
+    G, n, _ = M.shape
+    block_M = block_mixing_matrix(M)
+    ones = torch.ones((n, n), dtype=M.dtype)
+    A = torch.stack([block_M * torch.kron(phi[..., p].contiguous(), ones) for p in range(phi.shape[-1])], dim=-1)
+    return to_complex(A)
+
+
+def feedback_loop_forward_filter(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Tensor,
+                                 A_poly: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:326-391 with FILTER coupling (:362-373): A(z_k) = sum_p A_p z_k^-p.
+    A_poly (N, N, order) complex64 -> P (K, N, N) complex64."""
+    K = len(z)
+    order = A_poly.shape[-1]
+    D = torch.diag_embed(torch.unsqueeze(z, dim=-1) ** delays)
+    zp = (z.view(-1, 1) ** -torch.arange(0, order)).permute(1, 0)                  # (order, K)
+    A = torch.einsum('jim,mn->jimn', A_poly, zp)
+    A = torch.sum(A, dim=2).permute(2, 0, 1).to(torch.complex64)
+    Gamma_inv = torch.diag(1.0 / torch.diagonal(to_complex(torch.diag(gamma))))
+    Ddecay = D * Gamma_inv.unsqueeze(0).repeat(K, 1, 1)
+    return torch.linalg.inv(Ddecay - A).to(torch.complex64)
+
+
 def svf_cutoff_freqs(fs: float) -> torch.Tensor:
     """filters/geq.py:9-56 (eq_freqs defaults) + gain_filters.py:299-303 / model.py:711-716."""
     centre, c = [], 31.25

@@ -478,6 +478,61 @@ def gen_f11_svf_filters():
     print('F11 done')
 
 
+def full_convolve(a, b, mode='full'):
+    """Stand-in for torchaudio.functional.convolve(mode='full') on 1-D tensors (torchaudio is not in this image;
+    SURVEY §8c(iv)): the full linear convolution, through conv1d so that autograd follows it."""
+    assert mode == 'full' and a.ndim == 1 and b.ndim == 1
+    return torch.nn.functional.conv1d(a[None, None], b.flip(0)[None, None], padding=len(b) - 1).reshape(-1)
+
+
+def gen_f12_filter_coupling():
+    """Paraunitary FILTER coupling (feedback_loop.py:90-143, :311-323, :362-373, :413-455): the loop alone
+    (Phi, A, P and the gradients of sum |P|^2) and the grid model on top of it."""
+    import types
+    import diff_gfdn.utils as ref_utils
+    ref_utils.Faudio = types.SimpleNamespace(convolve=full_convolve)
+    from diff_gfdn.absorption_filters import decay_times_to_gain_per_sample
+    out = {}
+    fs, nfft, G, nper, order = 8000.0, 512, 3, 4, 6
+    z = torch.tensor(np.exp(1j * 2 * np.pi * np.fft.rfftfreq(nfft)))
+    torch.manual_seed(31)
+    delays = prime_delays(G * nper, lo=20, hi=100, seed=2)
+    T60 = np.linspace(0.1, 0.4, G)
+    gains = torch.flatten(torch.tensor([
+        decay_times_to_gain_per_sample(T60[i], delays[i * nper:(i + 1) * nper], fs).tolist() for i in range(G)]))
+    loop = FeedbackLoop(fs, G, nper, torch.tensor(delays, dtype=torch.float32), False,
+                        coupling_matrix_type=CouplingMatrixType.FILTER, coupling_matrix_order=order, gains=gains)
+    P = loop(z)
+    loss = (P.abs() ** 2).sum()
+    loss.backward()
+    out.update({'loop_delays': np.array(delays), 'loop_gamma': c2np(gains), 'loop_M': c2np(loop.M),
+                'loop_unit_vectors': c2np(loop.unit_vectors), 'loop_unitary_matrix': c2np(loop.unitary_matrix),
+                'loop_phi': c2np(loop.phi), 'loop_A': c2np(loop.coupled_feedback_matrix), 'loop_P': c2np(P),
+                'loop_grad_M': c2np(loop.M.grad), 'loop_grad_unit_vectors': c2np(loop.unit_vectors.grad),
+                'loop_grad_unitary_matrix': c2np(loop.unitary_matrix.grad), 'z': c2np(z), 'fs': fs,
+                'order': order})
+    # grid model
+    G2, nper2, B, order2 = 2, 4, 3, 5
+    delays2 = prime_delays(G2 * nper2, lo=160, hi=400, seed=6)
+    batch, T60b = synth_batch(B, 1024, fs, G2, 900, 61, T60=[0.4, 0.7])
+    torch.manual_seed(37)
+    np.random.seed(37)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.FILTER, pu_matrix_order=order2)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(fs, G2, delays2, 'cpu', fl, of, use_absorption_filters=False,
+                                 common_decay_times=np.asarray(T60b)[None, :], use_colorless_loss=True)
+    H, (Hout, _) = net(batch)
+    lossm = (H.abs() ** 2).sum()
+    lossm.backward()
+    out.update({'net_nfft': 1024, 'net_G': G2, 'net_nper': nper2, 'net_order': order2, 'net_delays': np.array(delays2),
+                'net_T60': T60b, 'net_H': c2np(H), 'net_Hout': c2np(Hout), 'net_loss': lossm.item()})
+    out.update(batch_to_np(batch, 'net_batch_'))
+    out.update(state_np(net, 'net_sd_'))
+    out.update({'net_grad_' + k: c2np(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+    np.savez_compressed(os.path.join(HERE, 'f12_filter_coupling.npz'), **out)
+    print('F12 done', sorted(k for k in out if k.startswith('net_grad_')))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1_feedback_loop()
@@ -494,3 +549,4 @@ if __name__ == '__main__':
     gen_f9_colorless_fdn()
     gen_f10_absorption_filters()
     gen_f11_svf_filters()
+    gen_f12_filter_coupling()

@@ -725,3 +725,106 @@ def test_svf_grid_trainer_steps():
     tr.normalize(batch)
     vals = [float(tr.train_step(batch)[0]) for _ in range(8)]
     assert all(np.isfinite(vals)) and vals[-1] < vals[0]
+
+
+@pytest.mark.parametrize("G,nper,K", [(2, 2, 33), (3, 4, 257), (3, 5, 100), (4, 4, 1025), (8, 4, 77)])
+def test_filter_coupling_solve_kernels(G, nper, K):
+    """gfdn_solve_phi_fwd / _bwd (frequency-dependent feedback matrix A(z_k) = BM o kron(Phi_k, 1)) against
+    torch.linalg.solve in complex128 and its autograd gradients."""
+    from diffgfdn_amd.functional import FrequencyGrid, ResolventSolveFilter
+    g = torch.Generator().manual_seed(100 * G + nper)
+    N = G * nper
+    Q, _ = torch.linalg.qr(torch.randn(N, N, generator=g, dtype=torch.float64))
+    BM = Q.to(torch.float32).to(DEV).requires_grad_(True)
+    Phi = (torch.randn(K, G, G, 2, generator=g) * 0.5)
+    Phi = torch.view_as_complex(Phi).to(DEV).requires_grad_(True)
+    delays = torch.randint(20, 90, (N,), generator=g).to(torch.float32).to(DEV)
+    ig = (1.0 + 0.2 * torch.rand(N, generator=g)).to(DEV).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+    z = torch.exp(1j * np.pi * torch.arange(K, dtype=torch.float64) / (K - 1)).to(torch.complex128).to(DEV)
+    wgt = torch.view_as_complex(torch.randn(K, N, 2, generator=g)).to(DEV)
+    Y = ResolventSolveFilter.apply(BM, Phi, ig, b, FrequencyGrid.of(z), delays, nper)
+    (Y * wgt).real.sum().backward()
+    got = [BM.grad.clone(), Phi.grad.clone(), ig.grad.clone(), b.grad.clone()]
+    # float64 torch reference
+    BMr, Phir, igr, br = [t.detach().to(torch.complex128 if t.is_complex() else torch.float64).requires_grad_(True)
+                          for t in (BM, Phi, ig, b)]
+    A = BMr[None].to(torch.complex128) * Phir.repeat_interleave(nper, 1).repeat_interleave(nper, 2)
+    D = torch.diag_embed(z[:, None] ** delays.to(torch.float64)[None, :] * igr[None, :])
+    Yr = torch.linalg.solve(D - A, br.to(torch.complex128)[None, :, None].expand(K, N, 1)).squeeze(-1)
+    assert rel_err(Y.detach().cpu(), Yr.detach().cpu()) < TOL
+    (Yr * wgt.to(torch.complex128)).real.sum().backward()
+    for a, r in zip(got, (BMr, Phir, igr, br)):
+        assert rel_err(a.cpu(), r.grad.cpu()) < 5e-4
+
+
+def test_f12_filter_coupling():
+    """Paraunitary FILTER coupling (fixture F12; feedback_loop.py:90-143, :311-323, :362-373, :413-455): coupling
+    polynomial, polynomial feedback matrix, explicit inverse and gradients of the loop; transfer function and
+    gradients of the grid model."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.feedback_loop import FeedbackLoop
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    fx = load("f12_filter_coupling.npz")
+    M = fx["loop_M"]
+    G, n, _ = M.shape
+    loop = FeedbackLoop(float(fx["fs"]), G, n, torch.tensor(fx["loop_delays"], dtype=torch.float32), False,
+                        coupling_matrix_type=CouplingMatrixType.FILTER, coupling_matrix_order=int(fx["order"]),
+                        gains=torch.tensor(fx["loop_gamma"]))
+    with torch.no_grad():
+        loop.M.copy_(torch.tensor(M))
+        loop.unit_vectors.copy_(torch.tensor(fx["loop_unit_vectors"]))
+        loop.unitary_matrix.copy_(torch.tensor(fx["loop_unitary_matrix"]))
+    loop = loop.to(DEV)
+    P = loop(torch.tensor(fx["z"]).to(DEV))
+    assert rel_err(loop.phi.detach().cpu(), fx["loop_phi"]) < 1e-5
+    assert rel_err(loop.coupled_feedback_matrix.detach().cpu(), fx["loop_A"]) < 1e-5
+    assert rel_err(P.detach().cpu(), fx["loop_P"]) < TOL
+    (P.abs() ** 2).sum().backward()
+    assert rel_err(loop.M.grad.cpu(), fx["loop_grad_M"]) < 5e-4
+    assert rel_err(loop.unit_vectors.grad.cpu(), fx["loop_grad_unit_vectors"]) < 5e-4
+    assert rel_err(loop.unitary_matrix.grad.cpu(), fx["loop_grad_unitary_matrix"]) < 5e-4
+    # grid model
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.FILTER, pu_matrix_order=int(fx["net_order"]))
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["net_G"]), fx["net_delays"].tolist(), DEV, fl, of,
+                                 use_absorption_filters=False, common_decay_times=fx["net_T60"][None, :],
+                                 use_colorless_loss=True)
+    net.load_state_dict(_state(fx, "net_sd_"), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx, "net_batch_"))
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu(), fx["net_H"]) < TOL
+    assert rel_err(Hout.detach().cpu(), fx["net_Hout"]) < TOL
+    (H.abs() ** 2).sum().backward()
+    for name_, prm in net.named_parameters():
+        ref = fx["net_grad_" + name_]
+        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 1e-3, name_
+
+
+def test_filter_coupling_trainer_steps():
+    """VarReceiverPosTrainer on a grid model with paraunitary FILTER coupling: normalize + a few optimiser steps lower
+    the loss and move the coupling parameters (unit_vectors, unitary_matrix ride in the default lr group)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    fx = load("f12_filter_coupling.npz")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.FILTER, pu_matrix_order=int(fx["net_order"]))
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["net_G"]), fx["net_delays"].tolist(), DEV, fl, of,
+                                 use_absorption_filters=False, common_decay_times=fx["net_T60"][None, :],
+                                 use_colorless_loss=True)
+    net.load_state_dict(_state(fx, "net_sd_"), strict=True)
+    net = net.to(DEV)
+    uv0 = net.feedback_loop.unit_vectors.detach().clone()
+    um0 = net.feedback_loop.unitary_matrix.detach().clone()
+    tc = TrainerConfig(batch_size=3, num_freq_bins=int(fx["net_nfft"]), lr=1e-2, io_lr=1e-2, use_colorless_loss=True,
+                       use_asym_spectral_loss=True, edc_loss_weight=1.0, sparsity_loss_weight=1.0,
+                       use_edc_mask=False, train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a", device="cuda")
+    tr = VarReceiverPosTrainer(net, tc, stft_win=64)
+    batch = _to_dev(batch_from(fx, "net_batch_"))
+    tr.normalize(batch)
+    vals = [float(tr.train_step(batch)[0]) for _ in range(8)]
+    assert all(np.isfinite(vals)) and vals[-1] < vals[0]
+    assert float((net.feedback_loop.unit_vectors.detach() - uv0).abs().max()) > 0
+    assert float((net.feedback_loop.unitary_matrix.detach() - um0).abs().max()) > 0

@@ -285,3 +285,43 @@ def test_f11_svf_responses():
     raw = orc.mlp_forward(enc, lin, norm).view(pos.shape[0], G, 11, 2)
     Co = orc.svf_group_responses(torch.tensor(fx["batch_z_values"]), float(fx["fs"]), raw, 0.98)
     assert rel_err(Co.detach().numpy(), fx["grid_Co"]) < 2e-6
+
+
+def test_f12_filter_coupling():
+    """oracle paraunitary FILTER coupling (Householder cascade, polynomial feedback matrix, per-bin resolvent) vs the
+    reference's FeedbackLoop with CouplingMatrixType.FILTER (feedback_loop.py:90-143, :362-373, :413-455), then
+    the grid model's transfer function on top of it."""
+    fx = load("f12_filter_coupling.npz")
+    M = torch.tensor(fx["loop_M"]).requires_grad_(True)
+    uv = torch.tensor(fx["loop_unit_vectors"]).requires_grad_(True)
+    um = torch.tensor(fx["loop_unitary_matrix"]).requires_grad_(True)
+    phi = orc.filter_coupling_matrix(um, uv)
+    assert rel_err(phi.detach(), fx["loop_phi"]) < 1e-5
+    A = orc.filter_coupled_feedback_matrix(M, phi)
+    assert rel_err(A.detach(), fx["loop_A"]) < 1e-5
+    P = orc.feedback_loop_forward_filter(torch.tensor(fx["z"]), torch.tensor(fx["loop_delays"], dtype=torch.float32),
+                                         torch.tensor(fx["loop_gamma"]), A)
+    assert rel_err(P.detach(), fx["loop_P"]) < TOL32
+    (P.abs() ** 2).sum().backward()
+    # float32 polynomial products summed in a different order than the reference's conv1d: 3e-4 on the gradients
+    assert rel_err(M.grad, fx["loop_grad_M"]) < 3e-4
+    assert rel_err(uv.grad, fx["loop_grad_unit_vectors"]) < 3e-4
+    assert rel_err(um.grad, fx["loop_grad_unitary_matrix"]) < 3e-4
+    # grid model: H = c^T P(z) b with receiver gains from the MLP
+    G, nper = int(fx["net_G"]), int(fx["net_nper"])
+    sd = lambda k: torch.tensor(fx["net_sd_" + k])
+    lin, norm = mlp_from_state(fx, prefix="net_sd_", root="output_scalars.mlp.model.")
+    z = torch.tensor(fx["net_batch_z_values"])
+    delays = torch.tensor(fx["net_delays"], dtype=torch.float32)
+    gamma = torch.cat([orc.decay_times_to_gain_per_sample(torch.tensor(fx["net_T60"][g]),
+                                                          delays[g * nper:(g + 1) * nper], float(fx["fs"]))
+                       for g in range(G)])
+    phi2 = orc.filter_coupling_matrix(sd("feedback_loop.unitary_matrix"), sd("feedback_loop.unit_vectors"))
+    P2 = orc.feedback_loop_forward_filter(z, delays, gamma,
+                                          orc.filter_coupled_feedback_matrix(sd("feedback_loop.M"), phi2))
+    p = orc.GridModelParams(float(fx["fs"]), fx["net_delays"].tolist(), G, sd("input_gains"), sd("output_gains"),
+                            sd("feedback_loop.M"), torch.zeros(G * (G - 1) // 2), fx["net_T60"][None, :], lin, norm, 4)
+    r = p.receiver_gains(torch.tensor(fx["net_batch_norm_listener_position"]))
+    H = orc.var_receiver_forward(z, sd("input_gains"), sd("output_gains"), r, P2,
+                                 torch.tensor(fx["net_batch_target_early_response"]), nper)
+    assert rel_err(H.detach(), fx["net_H"]) < TOL32
