@@ -64,7 +64,7 @@ SIGNATURES = {
     "gfdn_irfft_odd_pairs_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_irfft_odd_pairs_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_stft_power_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gfdn_edc_loss_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),

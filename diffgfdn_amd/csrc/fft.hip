@@ -1031,8 +1031,15 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
     GFDN_LAUNCH_CHECK();
   }
   if (stages & 4) {
-    if (col128)
-      hipLaunchKernelGGL(k_blu_col128_inv, dim3((g.L2 / 32) * a.batch), dim3(256), 4 * CW_LDS * sizeof(float2), s, a);
+    if (col128) {
+      // The pair forward pass SCATTERS 8-byte slots over the pair's whole output (512 KB): lines leave L2 partly
+      // written when too many pairs are in flight per XCD (PMC: 4.8 x the algorithmic write bytes).  Twice the
+      // LDS per block caps a CU at two blocks = four pairs per XCD: 70 -> 60 us (one block per CU: 62 us;
+      // non-temporal loads of the work block: no gain).  The adjoint's stores are coalesced and keep 3 blocks.
+      const size_t linv = (size_t)((a.pair && !a.adjoint) ? 2 : 1) * 4 * CW_LDS * sizeof(float2);
+      if ((rc = ensure_dyn_lds(k_blu_col128_inv, linv))) return rc;
+      hipLaunchKernelGGL(k_blu_col128_inv, dim3((g.L2 / 32) * a.batch), dim3(256), linv, s, a);
+    }
     else
       hipLaunchKernelGGL(k_blu_col_inv, dim3((g.L2 / tc) * batch), dim3(256), lc, s, a);
     GFDN_LAUNCH_CHECK();
@@ -1412,12 +1419,12 @@ __global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power(const float2* __res
   }
 }
 
-__global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
+__global__ __launch_bounds__(S4K_T, 4) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
                                                                  int nframes, int items,
                                                                  const float* __restrict__ gP,
-                                                                 float2* __restrict__ gx2) {
+                                                                 const float2* base2, float2* gx2, int parity) {
   float2* buf = dyn_lds;
-  const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
+  const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
   const bool two = b1 + 1 < items;
   float2 a[16], w1;
@@ -1452,27 +1459,29 @@ __global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power_bwd(const float2* _
   for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
   __syncthreads();
   fft4096(a, buf, i, w1, -1.0f);
-  // Scatter with CONTIGUOUS atomics: lane L of a wave adds component (L & 1) of the wave's sample (L >> 1)
-  // [+ 32 in the second instruction], fetched from the owning lane by shuffle -- each instruction covers 256
-  // consecutive bytes.  (Adding .x and .y from the owning lane puts every instruction on 8-byte strides: twice
-  // the (instruction, cache line) pairs at the L2 atomic units, 236 vs 127 us.)
-  const int lane = i & 63, wbase = i & ~63;
-  const int comp = lane & 1, s0 = lane >> 1;
-  float* gw = (float*)(gx2 + (size_t)p * ld + m * 2048 + wbase);     // this wave's 64 samples of chunk u = 0
+  // Frames of one parity tile the time axis without overlap (hop = win / 2): the even launch STORES
+  // base + contribution (and base alone past the last even frame), the odd launch that follows adds its
+  // contribution with a plain read-modify-write.  No atomics (they cost 50 of 139 us here), no cleared buffer.
+  float2* g = gx2 + (size_t)p * ld;
+  const float2* src = parity ? g : (base2 ? base2 + (size_t)p * ld : nullptr);
+  const int tlim = parity ? T : ld;
+  // the transform's outputs wait in the thread's own LDS slots while a rolled loop adds them to the gradient
+  // signal: the epilogue then needs a handful of registers instead of the sixteen outputs plus sixteen loads
+  __syncthreads();
 #pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+#pragma unroll 4
   for (int u = 0; u < 16; ++u) {
-    float sk, ck;
-    sincospif((float)u * 0.125f, &sk, &ck);
-    const float hw = 0.5f - 0.5f * (w1.x * ck + w1.y * sk);
-    const float vx = hw * a[u].x, vy = hw * a[u].y;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int sidx = s0 + 32 * h;                                  // sample of this wave served by this lane
-      const float ox = __shfl(vx, sidx, 64), oy = __shfl(vy, sidx, 64);
-      const int t = m * 2048 + 256 * u + wbase + sidx;
-      if (t < T && (comp == 0 || two)) atomicAdd(gw + 2 * (256 * u + 32 * h) + lane, comp ? oy : ox);
+    const int j = i + 256 * u, t = m * 2048 + j;
+    if (t < tlim) {
+      const float2 o = src ? src[t] : make_float2(0.f, 0.f);
+      const float hw = t < T ? 0.5f - 0.5f * cospif((float)j * (1.0f / 2048.0f)) : 0.f;
+      const float2 v = buf[S4K_PAD(j)];
+      g[t] = make_float2(o.x + hw * v.x, o.y + (two ? hw * v.y : 0.f));
     }
   }
+  if (!parity && m + 2 >= nframes)
+    for (int t = (m + 2) * 2048 + i; t < ld; t += S4K_T) g[t] = src ? src[t] : make_float2(0.f, 0.f);
 }
 
 extern "C" int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P,
@@ -1488,15 +1497,19 @@ extern "C" int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, 
 }
 
 extern "C" int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
-                                         float* gx2, void* stream) {
+                                         const float* base2, float* gx2, void* stream) {
   if (!x2 || !gP || !gx2 || items <= 0 || ld < T) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = gfdn_stft_nframes(T, win);
   if (nframes <= 0) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_stft4k_pair_power_bwd, dim3(nframes, (items + 1) / 2), dim3(S4K_T),
-                     S4K_LDS * sizeof(float2), (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, gP,
-                     (float2*)gx2);
-  GFDN_LAUNCH_CHECK();
+  for (int parity = 0; parity < 2; ++parity) {
+    const int nb = (nframes + 1 - parity) / 2;
+    if (nb == 0) continue;
+    hipLaunchKernelGGL(k_stft4k_pair_power_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T),
+                       S4K_LDS * sizeof(float2), (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, gP,
+                       (const float2*)base2, (float2*)gx2, parity);
+    GFDN_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -445,43 +445,6 @@ __device__ __forceinline__ void block_scan_multi2(float2 (&v)[EDC_S], float2 (&t
   }
 }
 
-template <typename G, typename F>
-__device__ __forceinline__ void edc_scan2(int len, float2 carry, float2* lds, G get, F fn) {
-  const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    float2 val[EDC_S][EDC_V], pre[EDC_S][EDC_V], loc[EDC_S], tot[EDC_S], incl[EDC_S];
-#pragma unroll
-    for (int s = 0; s < EDC_S; ++s) {
-      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
-      float2 run = make_float2(0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < EDC_V; ++u) {
-        const int j = j0 + u;
-        val[s][u] = (j < len) ? get(j) : make_float2(0.f, 0.f);
-        run = f2add(run, val[s][u]);
-        pre[s][u] = run;
-      }
-      loc[s] = run;
-      incl[s] = run;
-    }
-    block_scan_multi2(incl, tot, lds);
-    float2 base = carry;
-#pragma unroll
-    for (int s = 0; s < EDC_S; ++s) {
-      const float2 excl = make_float2(base.x + incl[s].x - loc[s].x, base.y + incl[s].y - loc[s].y);
-      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
-#pragma unroll
-      for (int u = 0; u < EDC_V; ++u) {
-        const int j = j0 + u;
-        if (j < len) fn(j, f2add(excl, pre[s][u]), val[s][u]);
-      }
-      base = f2add(base, tot[s]);
-    }
-    carry = base;
-    __syncthreads();
-  }
-}
-
 __device__ __forceinline__ float block_sum2(float2& v, float* lds /* >= 32 floats */) {
   v.x = wave_sum(v.x);
   v.y = wave_sum(v.y);
@@ -493,6 +456,26 @@ __device__ __forceinline__ float block_sum2(float2& v, float* lds /* >= 32 float
   for (int i = 0; i < nw; ++i) { sx += lds[i]; sy += lds[16 + i]; }
   v = make_float2(sx, sy);
   return sx;
+}
+
+// 16-byte accesses at 4-byte alignment (rows of odd length start on 8-byte boundaries only): four consecutive
+// pair samples / four consecutive floats per thread in two / one memory instructions
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void ld4_f2(const float2* p, float2 (&o)[4]) {
+  const f4u a = *(const f4u*)p, b = *(const f4u*)(p + 2);
+  o[0] = make_float2(a.x, a.y); o[1] = make_float2(a.z, a.w);
+  o[2] = make_float2(b.x, b.y); o[3] = make_float2(b.z, b.w);
+}
+__device__ __forceinline__ void st4_f2(float2* p, const float2 (&v)[4]) {
+  f4u a, b;
+  a.x = v[0].x; a.y = v[0].y; a.z = v[1].x; a.w = v[1].y;
+  b.x = v[2].x; b.y = v[2].y; b.z = v[3].x; b.w = v[3].y;
+  *(f4u*)p = a;
+  *(f4u*)(p + 2) = b;
+}
+__device__ __forceinline__ void ld4_f(const float* p, float (&o)[4]) {
+  const f4u a = *(const f4u*)p;
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
 }
 
 // work layout (items padded to 2 * pairs): segsum[I][NSEG] | partial[I][NSEG] | gsum[I][NSEG]
@@ -539,36 +522,108 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float
   const float* mw = maskw ? maskw + s0 : nullptr;
   float2* gw = gx2 ? gx2 + (size_t)p * ld + start + s0 : nullptr;
   float2 acc = make_float2(0.f, 0.f), gacc = make_float2(0.f, 0.f);
-  const float2 carry = make_float2(later_segments(segsum, b1, seg), later_segments(segsum, b2, seg));
-  edc_scan2(sl, carry, s_scan,
-            [&](int j) { const float2 v = xw[sl - 1 - j]; return make_float2(v.x * v.x, v.y * v.y); },
-            [&](int j, float2 edc, float2) {
-              const int i = sl - 1 - j;
-              const float m = mw ? mw[i] : 1.0f;
-              float2 g = make_float2(0.f, 0.f);
-              {
-                const float lin = fabsf(edc.x) + F32_EPS;
-                const float raw = 10.0f * log10f(lin);
-                const float diff = t1[i] - fmaxf(raw, -200.0f);
-                acc.x += m * fabsf(diff);
-                const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-                const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
-                g.x = -sg * dE * m * inv_count * gscale;
-              }
-              if (two) {
-                const float lin = fabsf(edc.y) + F32_EPS;
-                const float raw = 10.0f * log10f(lin);
-                const float diff = t2[i] - fmaxf(raw, -200.0f);
-                acc.y += m * fabsf(diff);
-                const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-                const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
-                g.y = -sg * dE * m * inv_count * gscale;
-              }
-              if (gw) {
-                gw[i] = g;                      // dL/dEDC_i, staged in place
-                gacc = f2add(gacc, g);
-              }
-            });
+  float2 carry = make_float2(later_segments(segsum, b1, seg), later_segments(segsum, b2, seg));
+  // Suffix scan of x^2 over the segment, tile by tile from its END (scan element j = sample sl - 1 - j).  Every
+  // load of a tile (samples, both targets) is issued before the block scan: four consecutive samples per thread
+  // and sub-tile as 16-byte accesses; the running sums inside a thread are re-accumulated after the scan in the
+  // same order instead of being kept in registers.
+  const int ntiles = (sl + EDC_TILE - 1) / EDC_TILE;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    float2 val[EDC_S][EDC_V], loc[EDC_S], incl[EDC_S], tot[EDC_S];
+    float ta[EDC_S][EDC_V], tb[EDC_S][EDC_V];
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      const int ilo = sl - 1 - j0 - (EDC_V - 1);            // lowest sample index of the group
+      if (ilo >= 0) {
+        float2 xv[4];
+        float t4[4];
+        ld4_f2(xw + ilo, xv);
+#pragma unroll
+        for (int u = 0; u < EDC_V; ++u) val[s][u] = make_float2(xv[3 - u].x * xv[3 - u].x, xv[3 - u].y * xv[3 - u].y);
+        ld4_f(t1 + ilo, t4);
+#pragma unroll
+        for (int u = 0; u < EDC_V; ++u) ta[s][u] = t4[3 - u];
+        if (two) {
+          ld4_f(t2 + ilo, t4);
+#pragma unroll
+          for (int u = 0; u < EDC_V; ++u) tb[s][u] = t4[3 - u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < EDC_V; ++u) {
+          const int i = sl - 1 - j0 - u;
+          const float2 v = i >= 0 ? xw[i] : make_float2(0.f, 0.f);
+          val[s][u] = make_float2(v.x * v.x, v.y * v.y);
+          ta[s][u] = i >= 0 ? t1[i] : 0.f;
+          tb[s][u] = (i >= 0 && two) ? t2[i] : 0.f;
+        }
+      }
+      float2 run = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < EDC_V; ++u) run = f2add(run, val[s][u]);
+      loc[s] = run;
+      incl[s] = run;
+    }
+    block_scan_multi2(incl, tot, s_scan);
+    float2 base = carry;
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const float2 excl = make_float2(base.x + incl[s].x - loc[s].x, base.y + incl[s].y - loc[s].y);
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      const int ilo = sl - 1 - j0 - (EDC_V - 1);
+      float m4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      if (mw) {
+        if (ilo >= 0) ld4_f(mw + ilo, m4);
+        else {
+#pragma unroll
+          for (int u = 0; u < EDC_V; ++u) { const int i = ilo + u; m4[u] = i >= 0 ? mw[i] : 0.f; }
+        }
+      }
+      float2 gq[4];
+      float2 run = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < EDC_V; ++u) {
+        run = f2add(run, val[s][u]);
+        const float2 edc = f2add(excl, run);
+        const bool in = ilo + (EDC_V - 1 - u) >= 0;
+        const float m = m4[EDC_V - 1 - u];
+        float2 g = make_float2(0.f, 0.f);
+        if (in) {
+          {
+            const float lin = fabsf(edc.x) + F32_EPS;
+            const float raw = 10.0f * log10f(lin);
+            const float diff = ta[s][u] - fmaxf(raw, -200.0f);
+            acc.x += m * fabsf(diff);
+            const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+            const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+            g.x = -sg * dE * m * inv_count * gscale;
+          }
+          if (two) {
+            const float lin = fabsf(edc.y) + F32_EPS;
+            const float raw = 10.0f * log10f(lin);
+            const float diff = tb[s][u] - fmaxf(raw, -200.0f);
+            acc.y += m * fabsf(diff);
+            const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+            const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+            g.y = -sg * dE * m * inv_count * gscale;
+          }
+          gacc = f2add(gacc, g);
+        }
+        gq[EDC_V - 1 - u] = g;
+      }
+      if (gw) {                                             // dL/dEDC_i, staged in place
+        if (ilo >= 0) st4_f2(gw + ilo, gq);
+        else {
+#pragma unroll
+          for (int u = 0; u < EDC_V; ++u) if (ilo + u >= 0) gw[ilo + u] = gq[u];
+        }
+      }
+      base = f2add(base, tot[s]);
+    }
+    carry = base;
+    __syncthreads();
+  }
   block_sum2(acc, s_red);
   block_sum2(gacc, s_red);
   if (threadIdx.x == 0) {
@@ -606,11 +661,55 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_bwd(const float
     carry.x += gsum[b1 * EDC_NSEG + s2];
     carry.y += gsum[b2 * EDC_NSEG + s2];
   }
-  edc_scan2(sl, carry, s_scan, [&](int i) { return gw[i]; },
-            [&](int i, float2 cum, float2) {
-              const float2 xv = xw[i];
-              gw[i] = make_float2(2.0f * xv.x * cum.x, 2.0f * xv.y * cum.y);
-            });
+  // prefix scan of the staged dL/dEDC, times 2 x: samples and staged terms of a tile are loaded together (16-byte
+  // accesses) before the block scan
+  const int ntiles = (sl + EDC_TILE - 1) / EDC_TILE;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    float2 val[EDC_S][EDC_V], xs[EDC_S][EDC_V], loc[EDC_S], incl[EDC_S], tot[EDC_S];
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      if (j0 + EDC_V <= sl) {
+        ld4_f2(gw + j0, val[s]);
+        ld4_f2(xw + j0, xs[s]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < EDC_V; ++u) {
+          const bool in = j0 + u < sl;
+          val[s][u] = in ? gw[j0 + u] : make_float2(0.f, 0.f);
+          xs[s][u] = in ? xw[j0 + u] : make_float2(0.f, 0.f);
+        }
+      }
+      float2 run = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < EDC_V; ++u) run = f2add(run, val[s][u]);
+      loc[s] = run;
+      incl[s] = run;
+    }
+    block_scan_multi2(incl, tot, s_scan);
+    float2 base = carry;
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const float2 excl = make_float2(base.x + incl[s].x - loc[s].x, base.y + incl[s].y - loc[s].y);
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      float2 out[4];
+      float2 run = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < EDC_V; ++u) {
+        run = f2add(run, val[s][u]);
+        const float2 cum = f2add(excl, run);
+        out[u] = make_float2(2.0f * xs[s][u].x * cum.x, 2.0f * xs[s][u].y * cum.y);
+      }
+      if (j0 + EDC_V <= sl) st4_f2(gw + j0, out);
+      else {
+#pragma unroll
+        for (int u = 0; u < EDC_V; ++u) if (j0 + u < sl) gw[j0 + u] = out[u];
+      }
+      base = f2add(base, tot[s]);
+    }
+    carry = base;
+    __syncthreads();
+  }
   float2* g = gx2 + (size_t)p * ld;
   if (seg == 0)
     for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = make_float2(0.f, 0.f);

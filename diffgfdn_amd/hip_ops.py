@@ -668,14 +668,18 @@ def stft_power_pairs(x2, items: int, win: int, zero_buf=None) -> torch.Tensor:
     return P
 
 
-def stft_power_pairs_bwd(x2, items: int, win: int, gP, g2_accum: torch.Tensor) -> torch.Tensor:
-    """Accumulates d<gP, P>/dx2 into g2_accum (shaped like x2) and returns it."""
-    _need_gpu(x2, gP, g2_accum)
-    assert g2_accum.dtype == _f32 and g2_accum.is_contiguous() and g2_accum.shape == x2.shape
+def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None) -> torch.Tensor:
+    """-> base + d<gP, P>/dx2, shaped like x2 (``base``: another gradient of the same layout, e.g. the EDC loss's;
+    ``out`` may be ``base`` itself).  Stored, not accumulated: ``out`` needs no clearing."""
+    _need_gpu(x2, gP)
+    out = torch.empty_like(x2) if out is None else out
+    for t in (base, out):
+        if t is not None and (t.dtype != _f32 or not t.is_contiguous() or t.shape != x2.shape or not t.is_cuda):
+            raise RuntimeError("stft_power_pairs_bwd: base / out must be shaped like x2")
     T = x2.shape[1]
-    _lib.check(_lib.load().gfdn_stft_power_pairs_bwd(_p(x2), T, T, items, win, _p(gP), _p(g2_accum), _stream()),
-               "gfdn_stft_power_pairs_bwd")
-    return g2_accum
+    _lib.check(_lib.load().gfdn_stft_power_pairs_bwd(_p(x2), T, T, items, win, _p(gP), _p(base), _p(out),
+                                                     _stream()), "gfdn_stft_power_pairs_bwd")
+    return out
 
 
 def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,

@@ -298,19 +298,18 @@ def _decay_losses_pairs(H, *, win, edr_weight, edc_weight, edc_start, edc_len, e
         if fork:
             x2.record_stream(side_stream)
     T_edr, sum_abs = edr_target
-    g_edr = torch.empty_like(x2) if want_grad else None
-    P = ops.stft_power_pairs(x2, B, win, zero_buf=g_edr)
+    P = ops.stft_power_pairs(x2, B, win)
     li_edr = ops.edr_loss(P, T_edr, sum_abs, freq_weights, edr_weight, want_grad, rows=target_rows, defer=True)
-    if want_grad:
-        g_edr = ops.stft_power_pairs_bwd(x2, B, win, P, g_edr)
     if fork:
         main.wait_stream(side_stream)
         for t in (g_edc, li_edc):
             if t is not None:
                 t.record_stream(main)
     if want_grad:
-        # (EDC gradient first, the STFT adjoint's buffer second: the same three-term order as the plain path)
-        gH = ops.irfft_odd_pairs_bwd(g_edc, K, B, g_edr)
+        # the STFT adjoint stores EDC gradient + its own contribution (two non-overlapping frame sets, no atomics)
+        # into the EDC buffer: one gradient signal for the transform's adjoint to gather
+        g = ops.stft_power_pairs_bwd(x2, B, win, P, base=g_edc, out=g_edc)
+        gH = ops.irfft_odd_pairs_bwd(g, K, B)
         return _DecayTotal.apply(H, gH, unit_grad, li_edr, edr_weight, li_edc, edc_weight, sum_abs, target_rows, nbands)
     sums = ops.weighted_sums(li_edr, edr_weight, li_edc, edc_weight, sum_abs, target_rows, nbands)
     if nbands > 1:

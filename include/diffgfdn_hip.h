@@ -261,7 +261,9 @@ int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const fl
  * for the missing partner of an odd batch) -- one 8-byte scatter / gather per slot serves two items, and the
  * three passes move half the work blocks.  gfdn_stft_power_pairs(_bwd) and gfdn_edc_loss_pairs consume and
  * produce that layout (win = 4096 only); P, T_db, loss_item stay per item; gfdn_edc_loss_pairs takes
- * gfdn_edc_work_bytes(items + 1) bytes of work.                                                       */
+ * gfdn_edc_work_bytes(items + 1) bytes of work.  gfdn_stft_power_pairs_bwd STORES gx2 = base2 + d<gP, P>/dx2
+ * (base2: another gradient of the same layout or NULL; may alias gx2): even frames first, odd frames in a second
+ * launch -- frames of one parity do not overlap, so there are no atomics and gx2 needs no clearing.   */
 int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs_c64, int ldx, int batch,
                              float* x2, int ldo, void* work, void* stream);
 int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
@@ -269,7 +271,7 @@ int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const f
 int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P, float* zero_buf2,
                           void* stream);
 int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
-                              float* gx2, void* stream);
+                              const float* base2, float* gx2, void* stream);
 int gfdn_edc_loss_pairs(const float* x2, int ld, int items, int start, int len, const float* T_db,
                         const long long* target_rows, const float* maskw, float inv_count, float gscale,
                         float* loss_item, float* gx2, void* work, void* stream);

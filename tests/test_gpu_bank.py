@@ -463,8 +463,17 @@ def test_pair_interleaved_kernels_equal_per_item_kernels(B):
     assert rel_err(Pp.cpu(), P.cpu()) < 2e-6 and float(buf.abs().max()) == 0.0
     gP = torch.rand(P.shape, generator=g).to(DEV)
     gx = ops.stft_power_bwd(xs, win, gP, torch.zeros_like(xs))
-    g2 = ops.stft_power_pairs_bwd(xj, B, win, gP, buf)
+    g2 = ops.stft_power_pairs_bwd(xj, B, win, gP, out=torch.full_like(xj, 7.0))     # stored: no clearing needed
     assert rel_err(split(g2).cpu(), gx.cpu()) < 2e-6
+    if B % 2:
+        assert float(g2[-1, :, 1].abs().max()) == 0.0
+    base = join(gb)
+    keep = base.clone()
+    g3 = ops.stft_power_pairs_bwd(xj, B, win, gP, base=base, out=base)               # base + adjoint, in place
+    assert g3.data_ptr() == base.data_ptr()
+    assert rel_err(split(g3).cpu(), (gx + gb).cpu()) < 2e-6
+    g4 = ops.stft_power_pairs_bwd(xj, B, win, gP, base=keep)
+    assert torch.equal(g4, g3)
     # EDC
     tgt = ops.edc_target(torch.randn(B, n, generator=g).to(DEV) * 0.01, start, L)
     mw = (torch.rand(L, generator=g) > 0.5).float().to(DEV) / (B * L / 2)
