@@ -55,13 +55,13 @@ ALG_BYTES_PER_RIR = 2811048
 # odd-length irfft (k_blu_col128_fwd; input side + FFT over n1 + twiddle), HBM-bound, one forward and one
 # adjoint launch per step (the roofline leg averages both).  Two items share one transform, so per RIR
 # (DESIGN.md §kernels): the forward launch reads the item's slot-ordered spectrum (8 B x 32769) and writes half
-# a work block (8 B x 2^16 / 2) = 524 296 B; the adjoint launch gathers two real inputs (2 x 4 B x 65537) and
-# writes half a work block = 786 440 B.  Average per launch and RIR: 655 368 B.
+# a work block (8 B x 2^16 / 2) = 524 296 B; the adjoint launch gathers ONE real input (4 B x 65537: the STFT
+# adjoint already added the EDC gradient) and writes half a work block = 524 292 B.  Average: 524 294 B.
 DOMINANT_KERNEL = 'k_blu_col128_fwd'
-DOMINANT_ALG_BYTES_PER_UNIT = (8 * 32769 + 4 * 65536 + 2 * 4 * 65537 + 4 * 65536) // 2
+DOMINANT_ALG_BYTES_PER_UNIT = (8 * 32769 + 4 * 65536 + 4 * 65537 + 4 * 65536) // 2
 # HBM traffic per launch from rocprofv3 --pmc passes (profiles/r01_pmc_hbm_bytes.csv), by items per launch:
 # 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, averaged over the forward and the adjoint launch like the duration
-DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = {224: int(2 * 167721.6 * 1024 + 57413.8 * 1024)}
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = {224: int(2 * 30323.8 * 1024 + 57400.2 * 1024)}
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
 

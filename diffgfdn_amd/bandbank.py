@@ -457,6 +457,9 @@ class BandBankTrainer:
                     bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q, Ys, Ss, en, gridK,
                     bank.delays, normalize_first, cfg.use_asym_spectral_loss, cfg.spectral_loss_weight,
                     cfg.sparsity_loss_weight, 1.0 / self.world_size, nb, torch.is_grad_enabled())
+                if side is not None:
+                    tail_done = torch.cuda.Event()
+                    tail_done.record(side)
         start, length = self._decay_window(K)
         gb = Bper
         if mask_prenorm is not None:
@@ -474,7 +477,8 @@ class BandBankTrainer:
             edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
             edr_target=(edr_t[1], edr_t[2]), edc_target=edc_t[1], side_stream=self._stream('_side2'),
             unit_grad=True, n_time=K, target_rows=rows, nbands=nb, slot_order=order is not None,
-            pairs=order is not None and self.use_pairs and self.stft_win == 4096)
+            pairs=order is not None and self.use_pairs and self.stft_win == 4096,
+            join_event=tail_done if (fused and side is not None) else None)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v, 'spectral_loss': spec.detach(),
                   'sparsity_loss': sparse.detach()}
         if side is not None:

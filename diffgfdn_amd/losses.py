@@ -171,7 +171,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  side_stream: Optional["torch.cuda.Stream"] = None,
                  unit_grad: bool = False, n_time: Optional[int] = None,
                  target_rows: Optional[torch.Tensor] = None, nbands: int = 1, slot_order: bool = False,
-                 pairs: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                 pairs: bool = False, join_event=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
     Returns (total, w_edr * edr, w_edc * edc) with total = their sum carrying the gradient; the two
@@ -200,7 +200,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                                    edr_target=edr_target, edc_target=edc_target, side_stream=side_stream,
                                    unit_grad=unit_grad, n_time=n_time, target_rows=target_rows, nbands=nbands,
                                    slot_order=slot_order, freq_weights=freq_weights,
-                                   reduced_pole_radius=reduced_pole_radius)
+                                   reduced_pole_radius=reduced_pole_radius, join_event=join_event)
     if target_rows is not None and (edr_target is None and use_edr or edc_target is None and use_edc):
         raise ValueError("target_rows needs precomputed target stores")
     targets = targets or _default_targets
@@ -273,8 +273,10 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
 
 def _decay_losses_pairs(H, *, win, edr_weight, edc_weight, edc_start, edc_len, edc_maskw, edc_count,
                         edc_maskw_prenormalised, global_batch, edr_target, edc_target, side_stream, unit_grad,
-                        n_time, target_rows, nbands, slot_order, freq_weights, reduced_pole_radius):
-    """decay_losses on pair-interleaved time signals (see there); EDR and EDC both on, targets precomputed."""
+                        n_time, target_rows, nbands, slot_order, freq_weights, reduced_pole_radius, join_event=None):
+    """decay_losses on pair-interleaved time signals (see there); EDR and EDC both on, targets precomputed.
+    ``join_event``: an event of another branch of the step that the loss kernels wait for behind the transform
+    (scheduling only: it pulls that branch in front of the loss kernels instead of beside their adjoints)."""
     if not slot_order or win != 4096 or edr_target is None or edc_target is None or n_time is None:
         raise ValueError("pairs: slot-ordered H, win 4096 and precomputed EDR / EDC targets are required")
     if reduced_pole_radius is not None and reduced_pole_radius != 1.0:
@@ -285,6 +287,8 @@ def _decay_losses_pairs(H, *, win, edr_weight, edc_weight, edc_start, edc_len, e
     want_grad = H.requires_grad and torch.is_grad_enabled()
     x2 = ops.irfft_odd_fwd(Hb, K, slots=True, pairs=True)
     main = torch.cuda.current_stream()
+    if join_event is not None:
+        main.wait_event(join_event)
     L = edc_len if edc_len is not None else K - edc_start
     count = float(L) if edc_count is None else float(edc_count)
     nb = B // nbands if global_batch is None else global_batch
