@@ -24,6 +24,8 @@ SIGNATURES = {
     "gfdn_solve_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "gfdn_solve_bwd_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_solve_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_solve_precise_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "gfdn_solve_precise_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_solve_absorb_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P]),
     "gfdn_solve_absorb_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_solve_phi_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),

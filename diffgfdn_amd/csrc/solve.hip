@@ -46,30 +46,73 @@ __device__ __forceinline__ float2 zeta_pow(const double* __restrict__ turns,
 }
 
 // ------------------------------------------------------------------------------------------
+// Complex arithmetic traits of the lane-parallel solve kernels: float2 (default) or double2 (the
+// "precise" entry points: matrix entries and elimination in float64, for systems whose condition number
+// eats float32 -- the lossless prototype at T60 = 10 s sits at ~1e4, where the reference's complex128
+// inverse is 1e-4-exact and float32 is not).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cinv(double2 a) {
+  const double d = 1.0 / (a.x * a.x + a.y * a.y);
+  return make_double2(a.x * d, -a.y * d);
+}
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ double2 zeta_pow_d(const double* __restrict__ turns, const double* __restrict__ logr,
+                                              int k, float m, double inv_gamma) {
+  double t = (double)m * turns[k];
+  t -= rint(t);
+  double s, c;
+  sincospi(2.0 * t, &s, &c);
+  double mag = inv_gamma;
+  if (logr) mag *= exp((double)m * logr[k]);
+  return make_double2(c * mag, s * mag);
+}
+template <typename C> struct Cx;
+template <> struct Cx<float2> {
+  typedef float R;
+  static __device__ __forceinline__ float2 mk(float x, float y) { return make_float2(x, y); }
+  static __device__ __forceinline__ float2 zeta(const double* t, const double* l, int k, float m, float ig) {
+    return zeta_pow(t, l, k, m, ig);
+  }
+  template <typename A> static __device__ __forceinline__ float ig(const A& a, int i) { return a.inv_gamma[i]; }
+};
+template <> struct Cx<double2> {
+  typedef double R;
+  static __device__ __forceinline__ double2 mk(double x, double y) { return make_double2(x, y); }
+  static __device__ __forceinline__ double2 zeta(const double* t, const double* l, int k, float m, double ig) {
+    return zeta_pow_d(t, l, k, m, ig);
+  }
+  template <typename A> static __device__ __forceinline__ double ig(const A& a, int i) { return a.ig64[i]; }
+};
+
+// ------------------------------------------------------------------------------------------
 // Gauss-Jordan on an n x n complex system spread over NP lanes (lane r holds row r).
 // On return the lane whose pivot column is `pivcol` holds x[pivcol] = rhs * pivinv.
 // ------------------------------------------------------------------------------------------
-template <int NP>
-__device__ __forceinline__ float2 gauss_jordan(float2 (&row)[NP], float2 rhs, int n, int r,
-                                               int& pivcol) {
+template <int NP, typename C = float2>
+__device__ __forceinline__ C gauss_jordan(C (&row)[NP], C rhs, int n, int r, int& pivcol) {
+  typedef typename Cx<C>::R R;
   const bool active = r < n;
   bool used = !active;
-  float2 pivinv = make_float2(0.f, 0.f);
+  C pivinv = Cx<C>::mk(0, 0);
   pivcol = -1;
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     if (j < n) {  // wave-uniform
-      float mag = used ? -1.0f : (row[j].x * row[j].x + row[j].y * row[j].y);
+      R mag = used ? (R)-1 : (row[j].x * row[j].x + row[j].y * row[j].y);
       int best = r;
 #pragma unroll
       for (int off = NP / 2; off >= 1; off >>= 1) {
-        float om = __shfl_xor(mag, off, NP);
+        R om = __shfl_xor(mag, off, NP);
         int ol = __shfl_xor(best, off, NP);
         bool take = (om > mag) || (om == mag && ol < best);
         mag = take ? om : mag;
         best = take ? ol : best;
       }
-      float2 pr[NP];
+      C pr[NP];
 #pragma unroll
       for (int c = j; c < NP; ++c) {
         if (c < n) {
@@ -77,16 +120,16 @@ __device__ __forceinline__ float2 gauss_jordan(float2 (&row)[NP], float2 rhs, in
           pr[c].y = __shfl(row[c].y, best, NP);
         }
       }
-      float2 prhs;
+      C prhs;
       prhs.x = __shfl(rhs.x, best, NP);
       prhs.y = __shfl(rhs.y, best, NP);
-      float2 inv = cinv(pr[j]);
+      C inv = cinv(pr[j]);
       if (r == best) {
         used = true;
         pivcol = j;
         pivinv = inv;
       } else if (active) {
-        float2 f = cmul(row[j], inv);
+        C f = cmul(row[j], inv);
 #pragma unroll
         for (int c = j + 1; c < NP; ++c) {
           if (c < n) {
@@ -96,7 +139,7 @@ __device__ __forceinline__ float2 gauss_jordan(float2 (&row)[NP], float2 rhs, in
         }
         rhs.x -= f.x * prhs.x - f.y * prhs.y;
         rhs.y -= f.x * prhs.y + f.y * prhs.x;
-        row[j] = make_float2(0.f, 0.f);
+        row[j] = Cx<C>::mk(0, 0);
       }
     }
   }
@@ -104,15 +147,15 @@ __device__ __forceinline__ float2 gauss_jordan(float2 (&row)[NP], float2 rhs, in
 }
 
 // row r of  diag(zeta) - A   (swap=false: A[r][c];  swap=true: A[c][r])
-template <int NP>
-__device__ __forceinline__ void build_row(float2 (&row)[NP], const float* __restrict__ Ablk,
-                                          int n, int r, bool swap, float2 diag) {
+template <int NP, typename C = float2>
+__device__ __forceinline__ void build_row(C (&row)[NP], const float* __restrict__ Ablk,
+                                          int n, int r, bool swap, C diag) {
 #pragma unroll
   for (int c = 0; c < NP; ++c) {
     float a = 0.f;
     if (c < n && r < n) a = swap ? Ablk[c * n + r] : Ablk[r * n + c];
-    row[c] = make_float2(-a, 0.f);
-    if (c == r) row[c] = make_float2(diag.x - a, diag.y);
+    row[c] = Cx<C>::mk(-a, 0);
+    if (c == r) row[c] = Cx<C>::mk(diag.x - a, diag.y);
   }
 }
 
@@ -128,14 +171,20 @@ struct SolveArgs {
   // frequency-dependent absorption (feedback_loop.py:332-344, :376-381): igz[k][i] = 1 / Gamma_i(z_k), complex,
   // (K, N); NULL: the scalar inv_gamma above.  With igz the scalar table must hold ones.
   const float2* igz;
+  const double* ig64;     // precise entry points: 1 / gamma in float64 (inv_gamma is then unused)
 };
 
 // zeta_i(z_k) = z_k^{m_i} / gamma_i  (scalar gain)  or  z_k^{m_i} / Gamma_i(z_k)  (absorption filter)
 __device__ __forceinline__ float2 zeta_abs(const SolveArgs& a, int k, int i, float2 zeta) {
   return a.igz ? cmul(zeta, a.igz[(size_t)k * (a.nblk * a.nper) + i]) : zeta;
 }
+__device__ __forceinline__ double2 zeta_abs(const SolveArgs& a, int k, int i, double2 zeta) {
+  if (!a.igz) return zeta;
+  const float2 g = a.igz[(size_t)k * (a.nblk * a.nper) + i];
+  return cmul(zeta, make_double2(g.x, g.y));
+}
 
-template <int NP>
+template <int NP, typename C = float2>
 __global__ __launch_bounds__(256) void k_solve_fwd(SolveArgs a, float2* __restrict__ Y) {
   constexpr int SPB = 256 / NP;
   const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
@@ -144,30 +193,31 @@ __global__ __launch_bounds__(256) void k_solve_fwd(SolveArgs a, float2* __restri
   const bool valid = k < a.K;
   const int kk = valid ? k : a.K - 1;
   const int i = blk * n + (r < n ? r : 0);
-  float2 zeta = zeta_abs(a, kk, i, zeta_pow(a.turns, a.logr, kk, a.delays[i], a.inv_gamma[i]));
-  float2 row[NP];
-  build_row<NP>(row, a.A + (size_t)blk * n * n, n, r, a.transpose != 0, zeta);
-  float2 rhs = make_float2(r < n ? a.b[i] : 0.f, 0.f);
+  C zeta = zeta_abs(a, kk, i, Cx<C>::zeta(a.turns, a.logr, kk, a.delays[i], Cx<C>::ig(a, i)));
+  C row[NP];
+  build_row<NP, C>(row, a.A + (size_t)blk * n * n, n, r, a.transpose != 0, zeta);
+  C rhs = Cx<C>::mk(r < n ? a.b[i] : 0.f, 0);
   int pivcol;
-  float2 y = gauss_jordan<NP>(row, rhs, n, r, pivcol);
-  if (valid && pivcol >= 0) Y[(size_t)k * N + blk * n + pivcol] = y;
+  C y = gauss_jordan<NP, C>(row, rhs, n, r, pivcol);
+  if (valid && pivcol >= 0) Y[(size_t)k * N + blk * n + pivcol] = make_float2((float)y.x, (float)y.y);
 }
 
 // Ysaved: the forward solution (K, N) when the caller still holds it (the re-solve is skipped),
 // or NULL.
-template <int NP>
+template <int NP, typename C = float2>
 __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __restrict__ gY,
                                                    const float2* __restrict__ Ysaved,
                                                    float* __restrict__ partial) {
   constexpr int SPB = 256 / NP;
-  __shared__ float2 s_perm[256];
+  __shared__ C s_perm[256];
   __shared__ float s_acc[256 * (NP + 2)];
   const int r = threadIdx.x % NP, grp = threadIdx.x / NP;
   const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
   const bool active = r < n;
   const int i = blk * n + (active ? r : 0);
   const float* Ablk = a.A + (size_t)blk * n * n;
-  const float m_i = a.delays[i], ig_i = a.inv_gamma[i], b_i = active ? a.b[i] : 0.f;
+  const float m_i = a.delays[i], b_i = active ? a.b[i] : 0.f;
+  const typename Cx<C>::R ig_i = Cx<C>::ig(a, i);
   const bool tr = a.transpose != 0;
 
   float acc[NP];
@@ -180,46 +230,48 @@ __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __
     const bool valid = k < a.K;
     const int kk = valid ? k : a.K - 1;
     // unit-magnitude phase separately: d T_ii / d inv_gamma = z^m
-    float2 zpow = zeta_pow(a.turns, a.logr, kk, m_i, 1.0f);
-    float2 zeta = zeta_abs(a, kk, i, cscale(zpow, ig_i));
-    float2 row[NP];
+    typedef typename Cx<C>::R R;
+    C zpow = Cx<C>::zeta(a.turns, a.logr, kk, m_i, 1.0f);
+    C zeta = zeta_abs(a, kk, i, cscale(zpow, ig_i));
+    C row[NP];
     int pivcol;
     // forward system  T y = b
-    float2 ynat;
+    C ynat;
     if (Ysaved) {
-      ynat = active ? Ysaved[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+      const float2 ys = active ? Ysaved[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+      ynat = Cx<C>::mk(ys.x, ys.y);
     } else {
-      build_row<NP>(row, Ablk, n, r, tr, zeta);
-      float2 y = gauss_jordan<NP>(row, make_float2(b_i, 0.f), n, r, pivcol);
+      build_row<NP, C>(row, Ablk, n, r, tr, zeta);
+      C y = gauss_jordan<NP, C>(row, Cx<C>::mk(b_i, 0), n, r, pivcol);
       __syncthreads();
       if (pivcol >= 0) s_perm[grp * NP + pivcol] = y;
       __syncthreads();
-      ynat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+      ynat = active ? s_perm[grp * NP + r] : Cx<C>::mk(0, 0);
     }
     // adjoint system  T^H w = gY   (row r of T^H = conj of column r of T)
-    build_row<NP>(row, Ablk, n, r, !tr, cconj(zeta));
-    float2 g = active ? gY[(size_t)kk * N + i] : make_float2(0.f, 0.f);
-    float2 w = gauss_jordan<NP>(row, g, n, r, pivcol);
+    build_row<NP, C>(row, Ablk, n, r, !tr, cconj(zeta));
+    const float2 gs = active ? gY[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    C w = gauss_jordan<NP, C>(row, Cx<C>::mk(gs.x, gs.y), n, r, pivcol);
     __syncthreads();
     if (pivcol >= 0) s_perm[grp * NP + pivcol] = w;
     __syncthreads();
-    float2 wnat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
-    if (!valid) { ynat = make_float2(0.f, 0.f); wnat = make_float2(0.f, 0.f); }
+    C wnat = active ? s_perm[grp * NP + r] : Cx<C>::mk(0, 0);
+    if (!valid) { ynat = Cx<C>::mk(0, 0); wnat = Cx<C>::mk(0, 0); }
     // gT_ij = -w_i conj(y_j);  T = D - A  (or D - A^T)
     //   transpose=0: gA[i][j] = Re(w_i conj(y_j));  transpose=1: gA[i][j] = Re(w_j conj(y_i))
-    const float2 mine = tr ? ynat : wnat;
-    const float2 other = tr ? wnat : ynat;
+    const C mine = tr ? ynat : wnat;
+    const C other = tr ? wnat : ynat;
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
       if (c < n) {
-        float ox = __shfl(other.x, c, NP), oy = __shfl(other.y, c, NP);
-        acc[c] += mine.x * ox + mine.y * oy;
+        R ox = __shfl(other.x, c, NP), oy = __shfl(other.y, c, NP);
+        acc[c] += (float)(mine.x * ox + mine.y * oy);
       }
     }
-    accb += wnat.x;
+    accb += (float)wnat.x;
     // g inv_gamma_i = Re(conj(gT_ii) z^m) = -Re(conj(w_i) y_i z^m)
-    float2 yz = cmul(ynat, zpow);
-    accg -= wnat.x * yz.x + wnat.y * yz.y;
+    C yz = cmul(ynat, zpow);
+    accg -= (float)(wnat.x * yz.x + wnat.y * yz.y);
   }
   // deterministic reduction over the SPB lane groups of this block
   __syncthreads();
@@ -558,15 +610,27 @@ static int check_solve_args(const double* turns, int K, int nblk, int nper, cons
 
 static int solve_fwd_run(const double* turns, const double* logr, int K, int nblk, int nper,
                          const float* A, const float* delays, const float* inv_gamma,
-                         const float* b, int transpose, float* Y, void* stream, const float2* g_igz) {
-  int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
+                         const float* b, int transpose, float* Y, void* stream, const float2* g_igz,
+                         const double* ig64 = nullptr) {
+  const bool precise = ig64 != nullptr;
+  int rc = check_solve_args(turns, K, nblk, nper, A, delays, precise ? delays : inv_gamma, b);
   if (rc) return rc;
   if (!Y) return GFDN_E_BADARG;
-  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz};
+  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz, ig64};
   const int np = pick_np(nper);
   const int spb = 256 / np;
   dim3 grid((K + spb - 1) / spb, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (precise) {
+    switch (np) {
+      case 4: hipLaunchKernelGGL((k_solve_fwd<4, double2>), grid, block, 0, s, a, (float2*)Y); break;
+      case 8: hipLaunchKernelGGL((k_solve_fwd<8, double2>), grid, block, 0, s, a, (float2*)Y); break;
+      case 16: hipLaunchKernelGGL((k_solve_fwd<16, double2>), grid, block, 0, s, a, (float2*)Y); break;
+      default: hipLaunchKernelGGL((k_solve_fwd<32, double2>), grid, block, 0, s, a, (float2*)Y); break;
+    }
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   if (np == 4 && nblk <= S4_MAXBLK) {
     const long long items = (long long)K * nblk;
     hipLaunchKernelGGL(k_solve4_fwd, dim3((unsigned)((items + 255) / 256)), block, 0, s, a, (float2*)Y);
@@ -588,6 +652,14 @@ extern "C" int gfdn_solve_fwd(const double* turns, const double* logr, int K, in
                               const float* b, int transpose, float* Y, void* stream) {
   return solve_fwd_run(turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, Y, stream, nullptr);
 }
+// float64 matrix entries and elimination (ill-conditioned systems: the lossless prototype); same arguments
+extern "C" int gfdn_solve_precise_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                                      const float* A, const float* delays, const double* inv_gamma_f64,
+                                      const float* b, int transpose, float* Y, void* stream) {
+  if (!inv_gamma_f64) return GFDN_E_BADARG;
+  return solve_fwd_run(turns, logr, K, nblk, nper, A, delays, nullptr, b, transpose, Y, stream, nullptr,
+                       inv_gamma_f64);
+}
 // frequency-dependent absorption: ones (N) = a device vector of ones (the scalar gains are folded into igz)
 extern "C" int gfdn_solve_absorb_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
                                      const float* A, const float* delays, const float* ones,
@@ -607,7 +679,7 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
                          const float* A, const float* delays, const float* inv_gamma,
                          const float* b, int transpose, const float* gY, const float* Y,
                          float* gA, float* gb, float* ginv_gamma, void* work, void* stream,
-                         const float2* g_igz);
+                         const float2* g_igz, const double* ig64 = nullptr);
 
 extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
                               const float* A, const float* delays, const float* inv_gamma,
@@ -615,6 +687,14 @@ extern "C" int gfdn_solve_bwd(const double* turns, const double* logr, int K, in
                               float* gA, float* gb, float* ginv_gamma, void* work, void* stream) {
   return solve_bwd_run(turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, gY, Y, gA, gb, ginv_gamma,
                        work, stream, nullptr);
+}
+extern "C" int gfdn_solve_precise_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                                      const float* A, const float* delays, const double* inv_gamma_f64,
+                                      const float* b, int transpose, const float* gY, const float* Y,
+                                      float* gA, float* gb, float* ginv_gamma, void* work, void* stream) {
+  if (!inv_gamma_f64) return GFDN_E_BADARG;
+  return solve_bwd_run(turns, logr, K, nblk, nper, A, delays, nullptr, b, transpose, gY, Y, gA, gb, ginv_gamma,
+                       work, stream, nullptr, inv_gamma_f64);
 }
 // (the absorption filters are fixed: ginv_scratch (N) receives a by-product without meaning)
 extern "C" int gfdn_solve_absorb_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
@@ -631,16 +711,17 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
                          const float* A, const float* delays, const float* inv_gamma,
                          const float* b, int transpose, const float* gY, const float* Y,
                          float* gA, float* gb, float* ginv_gamma, void* work, void* stream,
-                         const float2* g_igz) {
-  int rc = check_solve_args(turns, K, nblk, nper, A, delays, inv_gamma, b);
+                         const float2* g_igz, const double* ig64) {
+  const bool precise = ig64 != nullptr;
+  int rc = check_solve_args(turns, K, nblk, nper, A, delays, precise ? delays : inv_gamma, b);
   if (rc) return rc;
   if (!gY || !gA || !gb || !ginv_gamma || !work) return GFDN_E_BADARG;
-  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz};
+  SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz, ig64};
   const int np = pick_np(nper);
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
-  const bool lin = np == 4 && nblk <= S4_MAXBLK;
+  const bool lin = !precise && np == 4 && nblk <= S4_MAXBLK;
   if (lin) nparts = solve4_parts(K, nblk);
   dim3 grid(nparts, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -655,6 +736,14 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
     GFDN_LAUNCH_CHECK();
     return 0;
   }
+  if (precise) {
+    switch (np) {
+      case 4: hipLaunchKernelGGL((k_solve_bwd<4, double2>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      case 8: hipLaunchKernelGGL((k_solve_bwd<8, double2>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      case 16: hipLaunchKernelGGL((k_solve_bwd<16, double2>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      default: hipLaunchKernelGGL((k_solve_bwd<32, double2>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    }
+  } else
   switch (np) {
     case 4: hipLaunchKernelGGL(k_solve_bwd<4>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
     case 8: hipLaunchKernelGGL(k_solve_bwd<8>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
@@ -1136,7 +1225,7 @@ extern "C" int gfdn_subfdn_colorless_fwd(const double* turns, const double* logr
   if (!turns || !M || !delays || !b || !c || !Y || !S || !energy || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4 || G > S4_MAXBLK) return GFDN_E_UNSUPPORTED;
-  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr};
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr, nullptr};
   const int nparts = solve4_parts(K, G);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_subfdn4_fwd, dim3(nparts), dim3(256), 0, s, a, (const float*)c, (float2*)Y, (float2*)S,
@@ -1170,7 +1259,7 @@ extern "C" int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr
   if (!turns || !M || !delays || !b || !c || !Y || !gS || !gM || !gb || !gc || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4 || G > S4_MAXBLK) return GFDN_E_UNSUPPORTED;
-  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr};
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr, nullptr};
   const int nparts = solve4_parts(K, G), items = solve4_items(G);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_subfdn4_bwd, dim3(nparts), dim3(256), (size_t)items * 25 * sizeof(float), s, a, c, energy,
@@ -1193,7 +1282,7 @@ extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, in
   if (!turns || !M || !delays || !b || !c || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > GFDN_MAX_BLOCK) return GFDN_E_UNSUPPORTED;
-  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr};
+  SolveArgs a{turns, logr, K, G, nper, M, delays, nullptr, b, 0, nullptr, nullptr};
   const int np = pick_np(nper);
   const int spb = 256 / np;
   int nparts = (K + spb - 1) / spb;

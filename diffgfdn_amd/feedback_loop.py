@@ -134,8 +134,11 @@ class FeedbackLoop(nn.Module):
                  colorless_feedback_matrix: Optional[torch.Tensor] = None,
                  gains: Optional[torch.Tensor] = None,
                  common_decay_times: Optional[List] = None,
-                 device: torch.device = 'cpu'):
+                 device: torch.device = 'cpu', precise_solve: bool = False):
         super().__init__()
+        # float64 per-bin systems (the reference always inverts in complex128; float32 is 1e-4-exact at the decay
+        # times of the room models, not at the lossless prototype's T60 = 10 s)
+        self.precise_solve = precise_solve
         if use_absorption_filters and gains is None:
             raise NotImplementedError("absorption filters are fixed designs (reference :200-201 'Cannot learn "
                                       "absorption filters yet'): pass their coefficients as ``gains``")
@@ -347,7 +350,10 @@ class FeedbackLoop(nn.Module):
                 self._ones_n = torch.ones(self.num_delays, dtype=torch.float32, device=dev)
             return ResolventSolve.apply(A, self._ones_n, b.reshape(-1), grid, self.delays, transpose,
                                         self._inv_gamma_bins(z))
-        if self.learn_decay_times:
+        if self.precise_solve:
+            # float64 inverse gains: at pole radii ~0.9999 the float32 rounding of gamma alone moves the peaks
+            inv_gamma = 1.0 / self.current_gains().to(dev).to(torch.float64)
+        elif self.learn_decay_times:
             inv_gamma = (1.0 / self.current_gains().to(dev)).to(torch.float32)
         else:
             g = self.delay_line_gains
@@ -355,7 +361,8 @@ class FeedbackLoop(nn.Module):
             if self._inv_gamma_cache is None or self._inv_gamma_cache[0] != key:
                 self._inv_gamma_cache = (key, (1.0 / g.to(dev)).to(torch.float32))
             inv_gamma = self._inv_gamma_cache[1]
-        return ResolventSolve.apply(A, inv_gamma, b.reshape(-1), grid, self.delays, transpose)
+        return ResolventSolve.apply(A, inv_gamma, b.reshape(-1), grid, self.delays, transpose, None,
+                                    self.precise_solve)
 
     def coupling_response(self, z: torch.Tensor, phi: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Phi(z_k) = sum_p Phi_p z_k^-p -> (K, G, G) complex64 (the frequency dependence of reference :362-373);

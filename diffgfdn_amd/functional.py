@@ -108,10 +108,13 @@ class ResolventSolve(torch.autograd.Function):
     """Y[k] = (diag(z_k^m inv_gamma) - A)^{-1} b   (A^T when transpose)."""
 
     @staticmethod
-    def forward(ctx, A, inv_gamma, b, grid: FrequencyGrid, delays, transpose: bool, inv_gamma_bins=None):
+    def forward(ctx, A, inv_gamma, b, grid: FrequencyGrid, delays, transpose: bool, inv_gamma_bins=None,
+                precise: bool = False):
         """``inv_gamma_bins`` (K, N) complex64: fixed frequency-dependent absorption 1 / Gamma_i(z_k)
-        (feedback_loop.py:332-344); ``inv_gamma`` is then a vector of ones."""
-        Y = ops.solve_fwd(grid.turns, grid.logr, A, delays, inv_gamma, b, transpose, inv_gamma_bins)
+        (feedback_loop.py:332-344); ``inv_gamma`` is then a vector of ones.  ``precise``: float64 matrix entries
+        and elimination (the reference inverts in complex128, feedback_loop.py:389-391)."""
+        Y = ops.solve_fwd(grid.turns, grid.logr, A, delays, inv_gamma, b, transpose, inv_gamma_bins, precise)
+        ctx.precise = precise
         # Y is kept alive by its consumer's backward anyway (the output stage reads it): saving
         # it here costs nothing and the backward kernel skips re-solving the forward system
         ctx.save_for_backward(A, inv_gamma, b, delays, Y, inv_gamma_bins)
@@ -124,9 +127,9 @@ class ResolventSolve(torch.autograd.Function):
         A, inv_gamma, b, delays, Y, igz = ctx.saved_tensors
         g = ctx.grid
         gA, gb, gig = ops.solve_bwd(g.turns, g.logr, A, delays, inv_gamma, b, gY.contiguous(),
-                                    ctx.transpose, Y=Y, inv_gamma_bins=igz)
+                                    ctx.transpose, Y=Y, inv_gamma_bins=igz, precise=ctx.precise)
         return (gA.to(A.dtype), None if gig is None else gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape),
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class ResolventSolveFilter(torch.autograd.Function):

@@ -33,6 +33,10 @@ def _f(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(_f32).contiguous()
 
 
+def _f64(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float64).contiguous()
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(_c64).contiguous()
 
@@ -81,16 +85,20 @@ def ortho_bwd(M, gQ=None, gQQ=None, Q=None):
     return gM
 
 
-def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False, inv_gamma_bins=None) -> torch.Tensor:
+def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False, inv_gamma_bins=None,
+              precise: bool = False) -> torch.Tensor:
     """A (nblk,nper,nper) f32, delays/inv_gamma/b (N,) f32 -> Y (K,N) complex64.
     ``inv_gamma_bins`` (K, N) complex64 = 1 / Gamma_i(z_k): frequency-dependent absorption (``inv_gamma`` must
-    then be ones)."""
+    then be ones).  ``precise``: matrix entries and elimination in float64 (ill-conditioned systems)."""
     _need_gpu(turns, A)
-    A, delays, inv_gamma, b = _f(A), _f(delays), _f(inv_gamma), _f(b)
+    A, delays, b = _f(A), _f(delays), _f(b)
+    inv_gamma = _f64(inv_gamma) if precise else _f(inv_gamma)
     nblk, nper, _ = A.shape
     K = turns.numel()
     Y = torch.empty((K, nblk * nper), dtype=_c64, device=A.device)
     if inv_gamma_bins is not None:
+        if precise:
+            raise NotImplementedError("solve_fwd: precise with absorption filters")
         igz = _c(inv_gamma_bins)
         if tuple(igz.shape) != (K, nblk * nper):
             raise RuntimeError("solve_fwd: inv_gamma_bins must be (K, N)")
@@ -98,17 +106,20 @@ def solve_fwd(turns, logr, A, delays, inv_gamma, b, transpose=False, inv_gamma_b
                                                      _p(inv_gamma), _p(igz), _p(b), int(transpose), _p(Y),
                                                      _stream()), "gfdn_solve_absorb_fwd")
         return Y
-    _lib.check(_lib.load().gfdn_solve_fwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
-                                          _p(inv_gamma), _p(b), int(transpose), _p(Y), _stream()),
-               "gfdn_solve_fwd")
+    lib = _lib.load()
+    fn, name = (lib.gfdn_solve_precise_fwd, "gfdn_solve_precise_fwd") if precise else (lib.gfdn_solve_fwd, "gfdn_solve_fwd")
+    _lib.check(fn(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays), _p(inv_gamma), _p(b), int(transpose), _p(Y),
+                  _stream()), name)
     return Y
 
 
-def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None, inv_gamma_bins=None):
+def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None, inv_gamma_bins=None,
+              precise: bool = False):
     """-> gA (nblk,nper,nper), gb (N,), ginv_gamma (N,)  (float32).  ``Y``: the forward solution
     (K, N) if still at hand -- the kernel then does not re-solve the forward system."""
     _need_gpu(turns, A, gY)
-    A, delays, inv_gamma, b, gY = _f(A), _f(delays), _f(inv_gamma), _f(b), _c(gY)
+    A, delays, b, gY = _f(A), _f(delays), _f(b), _c(gY)
+    inv_gamma = _f64(inv_gamma) if precise else _f(inv_gamma)
     nblk, nper, _ = A.shape
     K = turns.numel()
     if Y is not None:
@@ -128,9 +139,9 @@ def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None,
                                              _p(igz), _p(b), int(transpose), _p(gY), _p(Y), _p(gA), _p(gb), _p(gig),
                                              _p(work), _stream()), "gfdn_solve_absorb_bwd")
         return gA, gb, None
-    _lib.check(lib.gfdn_solve_bwd(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays),
-                                  _p(inv_gamma), _p(b), int(transpose), _p(gY), _p(Y), _p(gA), _p(gb),
-                                  _p(gig), _p(work), _stream()), "gfdn_solve_bwd")
+    fn, name = (lib.gfdn_solve_precise_bwd, "gfdn_solve_precise_bwd") if precise else (lib.gfdn_solve_bwd, "gfdn_solve_bwd")
+    _lib.check(fn(_p(turns), _p(logr), K, nblk, nper, _p(A), _p(delays), _p(inv_gamma), _p(b), int(transpose),
+                  _p(gY), _p(Y), _p(gA), _p(gb), _p(gig), _p(work), _stream()), name)
     return gA, gb, gig
 
 

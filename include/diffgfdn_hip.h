@@ -76,6 +76,20 @@ int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int
                    const float* b, int transpose, const float* gY_c64, const float* Y_c64,
                    float* gA, float* gb, float* ginv_gamma, void* work, void* stream);
 
+/* "Precise" variants of gfdn_solve_fwd / _bwd: matrix entries (z^m / gamma in float64 from the exactly reduced phase)
+ * and the elimination in float64, results rounded to complex64 / float32 at the end -- what the reference's
+ * complex128 torch.linalg.inv (feedback_loop.py:389-391) delivers.  For ill-conditioned systems (the lossless
+ * prototype, colorless_fdn/model.py:63-92, at T60 = 10 s: condition ~1e4).  The inverse gains come in FLOAT64
+ * (N): at pole radii of 0.9999 the float32 rounding of gamma alone moves the resonance peaks by 6e-4.  Same
+ * other arguments and work size; lane-parallel kernels only (no thread-per-system shortcut).          */
+int gfdn_solve_precise_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                           const float* A, const float* delays, const double* inv_gamma_f64, const float* b,
+                           int transpose, float* Y_c64, void* stream);
+int gfdn_solve_precise_bwd(const double* turns, const double* logr, int K, int nblk, int nper,
+                           const float* A, const float* delays, const double* inv_gamma_f64, const float* b,
+                           int transpose, const float* gY_c64, const float* Y_c64, float* gA, float* gb,
+                           float* ginv_gamma, void* work, void* stream);
+
 /* Frequency-dependent absorption (feedback_loop.py:332-344, :376-381: Gamma(z) = diag of per-line filter
  * responses, GEQ / Prony designs of absorption_filters.py): T_k = diag(z_k^{m_i} / Gamma_i(z_k)) - A.
  * inv_gamma_bins (K, N) complex64 = 1 / Gamma_i(z_k); ones (N) = device vector of ones.  The filters are

@@ -600,15 +600,25 @@ def test_f9_colorless_fdn_prototype(tmp_path):
     net = net.to(DEV)
     z = torch.tensor(fx["z"]).to(DEV)
     H, Hpd = net(z)
-    # The prototype is almost lossless (nominal T60 = 10 s: pole radius 0.9999), so D Gamma^-1 - Q has a
-    # condition number ~1e4 at the resonances: float32 matrix entries (z^m) and a float32 solve are good to
-    # ~1e-3 of the peak there, where the reference inverts in complex128.  PTOL is the tolerance of this
-    # fixture (losses, which average over the grid, hold the usual 1e-4 x 10); a float64 thread-per-system
-    # solve for the prototype is listed in DESIGN.md §8.
+    # The reference's prototype runs on a COMPLEX64 grid (colorless_fdn/dataloader.py) and evaluates z ** m in
+    # complex64 (feedback_loop.py:330): a phase error of ~m eps32 (1e-4 in the entries of D for delays of a few
+    # hundred samples), which the per-bin systems (condition number ~80 at T60 = 10 s) amplify to 6e-4 of the peak
+    # response -- noise of the reference itself: the fixture sits 6.1e-4 from a float64 evaluation of the same
+    # formula.  Here z^m comes from the exactly reduced phase, so the comparison with the fixture carries PTOL and
+    # the comparison with the float64 evaluation (below) the usual tolerance.
     PTOL = 2e-3
     assert rel_err(H.detach().cpu().numpy(), fx["H"]) < PTOL
     assert rel_err(Hpd.detach().cpu().numpy(), fx["Hpd"]) < PTOL
     fl = net.feedback_loop
+    with torch.no_grad():                                      # float64 evaluation of c^T (D / gamma - Q)^-1 b
+        z64 = z.to(torch.complex128)
+        D = torch.diag_embed(z64[:, None] ** fl.delays.double()[None, :] / fl.current_gains().double().to(DEV)[None, :])
+        Q64 = fl.ortho_param(fl.random_feedback_matrix).double().to(torch.complex128)
+        y64 = torch.linalg.solve(D - Q64[None], net.input_gains.double().to(torch.complex128).reshape(1, -1, 1)
+                                 .expand(len(z), -1, 1)).squeeze(-1)
+        H64 = (y64 * net.output_gains.double().reshape(1, -1)).sum(-1)
+    assert rel_err(H.detach().cpu().numpy(), H64.cpu().numpy()) < 1e-5
+    assert 3e-4 < rel_err(fx["H"], H64.cpu().numpy()) < 1e-3       # the reference's own complex64 z ** m
     ones = torch.ones(len(z), device=DEV)
     loss = amse_loss()(H, ones) + 1.5 * sparsity_loss()(fl.ortho_param(fl.random_feedback_matrix))
     assert abs(loss.item() - float(fx["loss"])) < 1e-3 * abs(float(fx["loss"]))
@@ -828,3 +838,35 @@ def test_filter_coupling_trainer_steps():
     assert all(np.isfinite(vals)) and vals[-1] < vals[0]
     assert float((net.feedback_loop.unit_vectors.detach() - uv0).abs().max()) > 0
     assert float((net.feedback_loop.unitary_matrix.detach() - um0).abs().max()) > 0
+
+
+@pytest.mark.parametrize("N,K", [(8, 1025), (16, 513), (24, 300)])
+def test_precise_solve(N, K):
+    """gfdn_solve_precise_fwd / _bwd (float64 matrix entries, float64 inverse gains, float64 elimination) on nearly
+    lossless systems (T60 = 30 s at 48 kHz, delays up to 4000 samples: condition numbers of 1e3..1e5), against
+    torch.linalg.solve in complex128 and its autograd gradients; the float32 kernels on the same systems for scale."""
+    from diffgfdn_amd.functional import FrequencyGrid, ResolventSolve
+    g = torch.Generator().manual_seed(7 * N + K)
+    Q, _ = torch.linalg.qr(torch.randn(N, N, generator=g, dtype=torch.float64))
+    A = Q.to(torch.float32).to(DEV).unsqueeze(0).requires_grad_(True)
+    delays = torch.randint(800, 4000, (N,), generator=g).to(torch.float32).to(DEV)
+    gamma = 10.0 ** (-3.0 * delays.double() / (48000.0 * 30.0))
+    ig = (1.0 / gamma).requires_grad_(True)                    # float64
+    b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+    z = torch.exp(1j * np.pi * torch.arange(K, dtype=torch.float64) / (K - 1)).to(torch.complex128).to(DEV)
+    wgt = torch.view_as_complex(torch.randn(K, N, 2, generator=g)).to(DEV)
+    grid = FrequencyGrid.of(z)
+    Y = ResolventSolve.apply(A, ig, b, grid, delays, False, None, True)
+    (Y * wgt).real.sum().backward()
+    got = [A.grad.clone(), ig.grad.clone(), b.grad.clone()]
+    Ar, igr, br = [t.detach().double().requires_grad_(True) for t in (A, ig, b)]
+    D = torch.diag_embed(z[:, None] ** delays.double()[None, :] * igr[None, :])
+    Yr = torch.linalg.solve(D - Ar[0].to(torch.complex128)[None], br.to(torch.complex128)[None, :, None]
+                            .expand(K, N, 1)).squeeze(-1)
+    assert rel_err(Y.detach().cpu(), Yr.detach().cpu()) < 1e-6
+    (Yr * wgt.to(torch.complex128)).real.sum().backward()
+    for a, r in zip(got, (Ar, igr, br)):
+        assert rel_err(a.cpu(), r.grad.cpu()) < 1e-5
+    with torch.no_grad():
+        Y32 = ResolventSolve.apply(A.detach(), ig.detach().float(), b.detach(), grid, delays, False)
+    assert rel_err(Y32.cpu(), Yr.detach().cpu()) > 10 * rel_err(Y.detach().cpu(), Yr.detach().cpu())
