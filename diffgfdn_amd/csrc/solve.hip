@@ -48,7 +48,7 @@ __device__ __forceinline__ float2 zeta_pow(const double* __restrict__ turns,
 // ------------------------------------------------------------------------------------------
 // Complex arithmetic traits of the lane-parallel solve kernels: float2 (default) or double2 (the
 // "precise" entry points: matrix entries and elimination in float64, for systems whose condition number
-// eats float32 -- the lossless prototype at T60 = 10 s sits at ~1e4, where the reference's complex128
+// eats float32 -- nearly lossless loops, T60 of tens of seconds: 1e3..1e5 -- where the reference's complex128
 // inverse is 1e-4-exact and float32 is not).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {

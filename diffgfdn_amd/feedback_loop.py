@@ -137,7 +137,7 @@ class FeedbackLoop(nn.Module):
                  device: torch.device = 'cpu', precise_solve: bool = False):
         super().__init__()
         # float64 per-bin systems (the reference always inverts in complex128; float32 is 1e-4-exact at the decay
-        # times of the room models, not at the lossless prototype's T60 = 10 s)
+        # times of the room models, not for nearly lossless loops with T60 of tens of seconds)
         self.precise_solve = precise_solve
         if use_absorption_filters and gains is None:
             raise NotImplementedError("absorption filters are fixed designs (reference :200-201 'Cannot learn "

@@ -78,9 +78,9 @@ int gfdn_solve_bwd(const double* turns, const double* logr, int K, int nblk, int
 
 /* "Precise" variants of gfdn_solve_fwd / _bwd: matrix entries (z^m / gamma in float64 from the exactly reduced phase)
  * and the elimination in float64, results rounded to complex64 / float32 at the end -- what the reference's
- * complex128 torch.linalg.inv (feedback_loop.py:389-391) delivers.  For ill-conditioned systems (the lossless
- * prototype, colorless_fdn/model.py:63-92, at T60 = 10 s: condition ~1e4).  The inverse gains come in FLOAT64
- * (N): at pole radii of 0.9999 the float32 rounding of gamma alone moves the resonance peaks by 6e-4.  Same
+ * complex128 torch.linalg.inv (feedback_loop.py:389-391) delivers.  For nearly lossless loops (T60 of tens of
+ * seconds: condition numbers of 1e3..1e5, where float32 entries no longer hold 1e-4).  The inverse gains come in
+ * FLOAT64 (N): at pole radii of 0.9999 the float32 rounding of gamma alone moves the resonance peaks.  Same
  * other arguments and work size; lane-parallel kernels only (no thread-per-system shortcut).          */
 int gfdn_solve_precise_fwd(const double* turns, const double* logr, int K, int nblk, int nper,
                            const float* A, const float* delays, const double* inv_gamma_f64, const float* b,
