@@ -203,9 +203,15 @@ def main():
     ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
     ap.add_argument('--classic', action='store_true',
                     help='with --bands 1: the per-band VarReceiverPosTrainer path instead of a one-band bank')
+    ap.add_argument('--lines-per-group', type=int, default=NPER,
+                    help='delay lines per group (4 groups): 8 gives the N = 32 configuration (with --classic --bands 1)')
     ap.add_argument('--bands', type=int, default=len(BAND_CENTRES),
                     help='octave bands stepped together (1 = BASELINE.json configs[1], the 500 Hz band alone)')
     args = ap.parse_args()
+    if args.lines_per_group != NPER:
+        if not (args.classic or args.lines_per_group <= 4):
+            ap.error('--lines-per-group > 4 needs --classic --bands 1 (the band bank fuses 4 x 4 blocks)')
+        globals()['NPER'] = args.lines_per_group
     if not 1 <= args.bands <= len(BAND_CENTRES):
         raise SystemExit(f"--bands must be 1..{len(BAND_CENTRES)}")
     if args.classic and args.bands != 1:
