@@ -579,6 +579,238 @@ __global__ __launch_bounds__(256) void k_subfdn4_energy(SolveArgs a, const float
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Thread-per-system kernels for 4 < n <= 8 (the N = 32 layout: 4 groups x 8 lines).  Same structure as the
+// 4 x 4 kernels above: one thread eliminates one zero-padded 8 x 8 complex system held in registers with
+// compile-time indices (LU with partial pivoting by conditional row swaps, back substitution) -- no
+// cross-lane traffic, where the 8-lane kernels spend their time in ~200 dependent ds_bpermutes per system
+// (131 k systems: 60-77 us -> see DESIGN.md).  The backward keeps its 80 per-thread accumulators in LDS
+// columns ([e][thread]: conflict-free), which leaves the registers to the matrix.
+// ------------------------------------------------------------------------------------------
+#define S8_MAXBLK 32
+struct S8Const { float A[64], m[8], ig[8], b[8]; };          // 88 floats
+
+__device__ __forceinline__ void s8_stage(const SolveArgs& a, S8Const* tab) {
+  const int n = a.nper;
+  for (int e = threadIdx.x; e < a.nblk * 88; e += blockDim.x) {
+    const int blk = e / 88, f = e - blk * 88;
+    float v = 0.f;
+    if (f < 64) {
+      const int r = f >> 3, c = f & 7;
+      if (r < n && c < n) v = a.A[(size_t)blk * n * n + r * n + c];
+    } else {
+      const int r = (f - 64) & 7, which = (f - 64) >> 3;
+      const int i = blk * n + (r < n ? r : 0);
+      if (which == 0) v = a.delays[i];
+      else if (which == 1) v = a.inv_gamma ? a.inv_gamma[i] : 1.0f;
+      else v = r < n ? a.b[i] : 0.f;
+    }
+    ((float*)&tab[blk])[f] = v;
+  }
+}
+
+__device__ __forceinline__ void build8c(float2 (&m)[8][8], const S8Const& cst, int n, bool swap,
+                                        const float2 (&zeta)[8], bool adj) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float av = (swap != adj) ? cst.A[c * 8 + r] : cst.A[r * 8 + c];
+      m[r][c] = make_float2(-av, 0.f);
+      if (r == c) {
+        if (r < n) m[r][c] = make_float2(zeta[r].x - av, adj ? -zeta[r].y : zeta[r].y);
+        else m[r][c] = make_float2(1.f, 0.f);
+      }
+    }
+}
+
+// x = m^-1 r  (m, r destroyed)
+__device__ __forceinline__ void lu8(float2 (&m)[8][8], float2 (&r)[8], float2 (&x)[8]) {
+  float2 inv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float best = m[j][j].x * m[j][j].x + m[j][j].y * m[j][j].y;
+    int bi = j;
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      const float mg = m[i][j].x * m[i][j].x + m[i][j].y * m[i][j].y;
+      if (mg > best) { best = mg; bi = i; }
+    }
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      const bool sw = bi == i;
+#pragma unroll
+      for (int c = j; c < 8; ++c) {
+        const float2 t = m[j][c];
+        m[j][c] = sw ? m[i][c] : t;
+        m[i][c] = sw ? t : m[i][c];
+      }
+      const float2 t = r[j];
+      r[j] = sw ? r[i] : t;
+      r[i] = sw ? t : r[i];
+    }
+    inv[j] = cinv(m[j][j]);
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      const float2 f = cmul(m[i][j], inv[j]);
+#pragma unroll
+      for (int c = j + 1; c < 8; ++c) {
+        m[i][c].x -= f.x * m[j][c].x - f.y * m[j][c].y;
+        m[i][c].y -= f.x * m[j][c].y + f.y * m[j][c].x;
+      }
+      r[i].x -= f.x * r[j].x - f.y * r[j].y;
+      r[i].y -= f.x * r[j].y + f.y * r[j].x;
+    }
+  }
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    float2 sacc = r[j];
+#pragma unroll
+    for (int c = j + 1; c < 8; ++c) {
+      sacc.x -= m[j][c].x * x[c].x - m[j][c].y * x[c].y;
+      sacc.y -= m[j][c].x * x[c].y + m[j][c].y * x[c].x;
+    }
+    x[j] = cmul(sacc, inv[j]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_solve8_fwd(SolveArgs a, float2* __restrict__ Y) {
+  __shared__ S8Const tab[S8_MAXBLK];
+  s8_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper;
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= (long long)a.K * a.nblk) return;
+  const int k = (int)(w / a.nblk), blk = (int)(w - (long long)k * a.nblk);
+  const S8Const& cst = tab[blk];
+  float2 zeta[8], rhs[8], m[8][8], y[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+    if (r < n) zeta[r] = zeta_abs(a, k, blk * n + r, zeta[r]);
+    rhs[r] = make_float2(cst.b[r], 0.f);
+  }
+  build8c(m, cst, n, a.transpose != 0, zeta, false);
+  lu8(m, rhs, y);
+  float2* out = Y + (size_t)w * n;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (r < n) out[r] = y[r];
+}
+
+// partial layout as k_solve4_bwd; accumulators acc[e][thread] in LDS, e < 80 (8 x 8 | 8 | 8)
+#ifndef S8_BWD_T
+#define S8_BWD_T 128
+#endif
+#ifndef S8_BWD_MINW
+#define S8_BWD_MINW 2
+#endif
+__global__ __launch_bounds__(S8_BWD_T, S8_BWD_MINW) void k_solve8_bwd(SolveArgs a, const float2* __restrict__ gY,
+                                                    const float2* __restrict__ Ysaved,
+                                                    float* __restrict__ partial, int items) {
+  __shared__ S8Const tab[S8_MAXBLK];
+  extern __shared__ float s8_acc[];          // [80][S8_BWD_T]
+  s8_stage(a, tab);
+  for (int e = 0; e < 80; ++e) s8_acc[e * S8_BWD_T + threadIdx.x] = 0.f;
+  __syncthreads();
+  const int n = a.nper, nblk = a.nblk;
+  const bool tr = a.transpose != 0;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  const S8Const& cst = tab[blk];
+  float* acc = s8_acc + threadIdx.x;
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
+    // the forward solution comes from the caller (Ysaved is mandatory here) and is loaded only AFTER the adjoint
+    // solve; z^m is recovered from the diagonal term (zeta / inv_gamma): the elimination has the registers.
+    // (The fence keeps the block's 88 LDS constants from being hoisted out of the loop into registers.)
+    asm volatile("" ::: "memory");
+    float2 zeta[8], w[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+      if (r < n) zeta[r] = zeta_abs(a, k, blk * n + r, zeta[r]);
+    }
+    const size_t row = ((size_t)k * nblk + blk) * n;
+    {
+      float2 m[8][8], rhs[8];
+      build8c(m, cst, n, tr, zeta, true);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rhs[r] = r < n ? gY[row + r] : make_float2(0.f, 0.f);
+      lu8(m, rhs, w);
+    }
+    float2 y[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) y[r] = r < n ? Ysaved[row + r] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float2 p = tr ? y[i] : w[i], q = tr ? w[j] : y[j];
+        acc[(i * 8 + j) * S8_BWD_T] += p.x * q.x + p.y * q.y;
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[(64 + i) * S8_BWD_T] += w[i].x;
+      const float2 yz = cmul(y[i], cscale(zeta[i], 1.0f / cst.ig[i]));     // y_i z^m  (g inv_gamma_i = -Re(conj(w_i) y_i z^m))
+      acc[(72 + i) * S8_BWD_T] -= w[i].x * yz.x + w[i].y * yz.y;
+    }
+  }
+  __syncthreads();
+  const int per = n * n + 2 * n;
+  for (int o = threadIdx.x; o < nblk * per; o += S8_BWD_T) {
+    const int bq = o / per, e = o - bq * per;
+    int src;
+    if (e < n * n) src = (e / n) * 8 + (e % n);
+    else if (e < n * n + n) src = 64 + (e - n * n);
+    else src = 72 + (e - n * n - n);
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s8_acc[src * S8_BWD_T + t];
+    partial[((size_t)blockIdx.x * nblk + bq) * per + e] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_subfdn8_energy(SolveArgs a, const float* __restrict__ c,
+                                                        float* __restrict__ partial, int items) {
+  __shared__ S8Const tab[S8_MAXBLK];
+  __shared__ float s_e[256];
+  s8_stage(a, tab);
+  __syncthreads();
+  const int n = a.nper, nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  const S8Const& cst = tab[blk];
+  float c_i[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) c_i[r] = r < n ? c[blk * n + r] : 0.f;
+  float acc = 0.f;
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
+    asm volatile("" ::: "memory");                     // (LDS constants re-read per system, not kept in registers)
+    float2 zeta[8], m[8][8], y[8], rhs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      zeta[r] = zeta_pow(a.turns, a.logr, k, cst.m[r], cst.ig[r]);
+      rhs[r] = make_float2(cst.b[r], 0.f);
+    }
+    build8c(m, cst, n, a.transpose != 0, zeta, false);
+    lu8(m, rhs, y);
+    float2 sg = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sg.x += c_i[r] * y[r].x; sg.y += c_i[r] * y[r].y; }
+    acc += sg.x * sg.x + sg.y * sg.y;
+  }
+  s_e[threadIdx.x] = live ? acc : 0.f;
+  __syncthreads();
+  for (int bq = threadIdx.x; bq < nblk; bq += 256) {
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s_e[t];
+    partial[(size_t)bq * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
 // number of 256-bin slices a reducing thread-per-system launch cuts K into: enough blocks to fill the
 // chip (>= ~1024 with the nblk blocks of the y dimension), at most GFDN_PARTIAL_BLOCKS
 #define S4_MAX_PARTS 2048       // partial-sum slots of the reducing thread-per-system launches
@@ -637,6 +869,12 @@ static int solve_fwd_run(const double* turns, const double* logr, int K, int nbl
     GFDN_LAUNCH_CHECK();
     return 0;
   }
+  if (np == 8 && nblk <= S8_MAXBLK) {
+    const long long items = (long long)K * nblk;
+    hipLaunchKernelGGL(k_solve8_fwd, dim3((unsigned)((items + 255) / 256)), block, 0, s, a, (float2*)Y);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   switch (np) {
     case 4: hipLaunchKernelGGL(k_solve_fwd<4>, grid, block, 0, s, a, (float2*)Y); break;
     case 8: hipLaunchKernelGGL(k_solve_fwd<8>, grid, block, 0, s, a, (float2*)Y); break;
@@ -671,7 +909,7 @@ extern "C" int gfdn_solve_absorb_fwd(const double* turns, const double* logr, in
 }
 
 extern "C" size_t gfdn_solve_bwd_work_bytes(int nblk, int nper) {
-  const int parts = nper <= 4 ? S4_MAX_PARTS : GFDN_PARTIAL_BLOCKS;
+  const int parts = nper <= 8 ? S4_MAX_PARTS : GFDN_PARTIAL_BLOCKS;
   return (size_t)parts * nblk * (nper * nper + 2 * nper) * sizeof(float);
 }
 
@@ -722,7 +960,8 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
   const bool lin = !precise && np == 4 && nblk <= S4_MAXBLK;
-  if (lin) nparts = solve4_parts(K, nblk);
+  const bool lin8 = !precise && np == 8 && nblk <= S8_MAXBLK && Y != nullptr;   // (needs the saved solution)
+  if (lin || lin8) nparts = solve4_parts(K, nblk);
   dim3 grid(nparts, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
@@ -733,6 +972,17 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
     GFDN_LAUNCH_CHECK();
     const int tot4 = nblk * (nper * nper + 2 * nper);
     hipLaunchKernelGGL(k_solve_bwd_finish, dim3(tot4), dim3(256), 0, s, partial, nparts, nblk, nper, gA, gb, ginv_gamma);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
+  if (lin8) {
+    const size_t lds8 = (size_t)80 * S8_BWD_T * sizeof(float);
+    if ((rc = ensure_dyn_lds(k_solve8_bwd, lds8))) return rc;
+    hipLaunchKernelGGL(k_solve8_bwd, dim3(nparts), dim3(S8_BWD_T), lds8, s, a, (const float2*)gY,
+                       (const float2*)Y, partial, (S8_BWD_T / nblk) * nblk);
+    GFDN_LAUNCH_CHECK();
+    const int tot8 = nblk * (nper * nper + 2 * nper);
+    hipLaunchKernelGGL(k_solve_bwd_finish, dim3(tot8), dim3(256), 0, s, partial, nparts, nblk, nper, gA, gb, ginv_gamma);
     GFDN_LAUNCH_CHECK();
     return 0;
   }
@@ -1288,12 +1538,14 @@ extern "C" int gfdn_subfdn_normalize(const double* turns, const double* logr, in
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
   const bool lin = np == 4 && G <= S4_MAXBLK;
-  if (lin) nparts = solve4_parts(K, G);
+  const bool lin8 = np == 8 && G <= S8_MAXBLK;
+  if (lin || lin8) nparts = solve4_parts(K, G);
   dim3 grid(nparts, G), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)work;
-  if (lin) {
-    hipLaunchKernelGGL(k_subfdn4_energy, dim3(nparts), block, 0, s, a, (const float*)c, partial, solve4_items(G));
+  if (lin || lin8) {
+    if (lin) hipLaunchKernelGGL(k_subfdn4_energy, dim3(nparts), block, 0, s, a, (const float*)c, partial, solve4_items(G));
+    else hipLaunchKernelGGL(k_subfdn8_energy, dim3(nparts), block, 0, s, a, (const float*)c, partial, solve4_items(G));
     GFDN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_subfdn_rescale, dim3(G), dim3(64), 0, s, (const float*)partial, nparts, K, nper, b, c, energy);
     GFDN_LAUNCH_CHECK();
