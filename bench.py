@@ -145,8 +145,41 @@ def build_bank_workload(device, seed: int, centres, num_receivers: int = NUM_REC
     return cpu_leg, sds, bank, trainer, splits
 
 
-def cpu_baseline(room, delays, filt_np, steps: int = 2):
-    """The same optimiser step on the host cores with the CPU oracle (reference restatement)."""
+def hip_losses_at(init, batch, delays, room, filt_np, device):
+    """Loss terms of the HIP path at the parameters / batch the CPU baseline starts from (normalize, then one
+    forward + losses, no step): the other side of ``loss_delta_vs_cpu``."""
+    from diffgfdn_amd.config import (CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig,
+                                     SubbandProcessingConfig, TrainerConfig)
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=5, num_neurons_per_layer=16, num_fourier_features=20)
+    net = DiffGFDNVarReceiverPos(FS, G, delays, device, fl, of, use_absorption_filters=False,
+                                 common_decay_times=room['common_decay_times'], use_colorless_loss=True).to(device)
+    with torch.no_grad():
+        net.input_gains.copy_(init['input_gains'])
+        net.output_gains.copy_(init['output_gains'])
+        net.feedback_loop.M.copy_(init['M'])
+    net.output_scalars.mlp.load_state_dict(init['mlp'])
+    tc = TrainerConfig(batch_size=BATCH, num_freq_bins=NFFT, max_epochs=1, lr=1e-3, io_lr=1e-2, use_edc_mask=False,
+                       use_colorless_loss=True, edc_loss_weight=10, sparsity_loss_weight=2,
+                       use_asym_spectral_loss=True, device='cuda', train_dir='/tmp/gfdn_bench/train',
+                       ir_dir='/tmp/gfdn_bench/ir',
+                       subband_process_config=SubbandProcessingConfig(centre_frequency=500.0, frequency_range=(63, 8000),
+                                                                      num_fraction_octaves=1))
+    tr = VarReceiverPosTrainer(net, tc, subband_filter_freq_resp=torch.tensor(filt_np, device=device).to(torch.complex64))
+    b = {k: v.to(device) for k, v in batch.items()}
+    with torch.no_grad():
+        tr.normalize(b)
+        out = tr._step_losses(b, draw_mask=False)
+    torch.cuda.synchronize()
+    return {k: float(v) for k, v in out.items() if k.endswith('_loss')}
+
+
+def cpu_baseline(room, delays, filt_np, steps: int = 2, device=None):
+    """The same optimiser step on the host cores with the CPU oracle (reference restatement); with ``device`` also
+    the loss terms of the HIP path on the same parameters and batch (``loss_delta_vs_cpu``, the metric's
+    "EDR loss delta vs ref")."""
     from oracle import gfdn_oracle as orc
     from oracle.cpu_trainer import OracleGridTrainer
     cores = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
@@ -175,21 +208,30 @@ def cpu_baseline(room, delays, filt_np, steps: int = 2):
     p = orc.GridModelParams(FS, delays, G, (2 * torch.randn(N, 1) - 1) / N, (2 * torch.randn(N, 1) - 1) / N,
                             (2 * torch.rand(G, NPER, NPER) - 1) / np.sqrt(NPER), torch.zeros(G * (G - 1) // 2),
                             room['common_decay_times'], lin, norm, 20)
+    init = {'input_gains': p.input_gains.detach().clone(), 'output_gains': p.output_gains.detach().clone(),
+            'M': p.M.detach().clone(), 'mlp': {k: v.detach().clone() for k, v in mlp.state_dict().items()}}
     tr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
                            sparsity_weight=2.0, use_asym=True, subband_filter=torch.tensor(filt_np))
     L = min(orc.ms_to_samps(float(np.max(room['common_decay_times'])) * 1e3, FS), K) - mix
-    times = []
+    times, first = [], None
     for s in range(steps + 1):           # first step is warm-up (allocator, thread pools)
         mask = torch.argwhere(torch.bernoulli(torch.empty(L).uniform_(0, 1)))
         t0 = time.time()
         tr.normalize(batch)
-        tr.train_step(batch, mask)
+        _, terms = tr.train_step(batch, mask)
         times.append(time.time() - t0)
+        first = terms if first is None else first      # loss terms at the initial (normalized) parameters
     sec = float(np.mean(times[1:]))
-    return {'value': BATCH * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{steps} optimiser steps (normalize + fwd + EDR/EDC/colorless losses + bwd + Adam) of the '
-                      f'same workload, batch {BATCH}, after 1 warm-up step; {sec:.2f} s/step',
-            'sec_per_step': sec}
+    out = {'value': BATCH * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{steps} optimiser steps (normalize + fwd + EDR/EDC/colorless losses + bwd + Adam) of the '
+                     f'same workload, batch {BATCH}, after 1 warm-up step; {sec:.2f} s/step',
+           'sec_per_step': sec}
+    if device is not None:
+        # mask-free terms only (the EDC term of the CPU step used a random time mask)
+        ours = hip_losses_at(init, batch, delays, room, filt_np, device)
+        out['loss_delta_vs_cpu'] = {k: {'cpu': first[k], 'hip': ours[k], 'rel': abs(ours[k] - first[k]) / abs(first[k])}
+                                    for k in ('edr_loss', 'spectral_loss', 'sparsity_loss')}
+    return out
 
 
 def main():
@@ -344,7 +386,7 @@ def main():
                                'alg_bytes_per_launch': units * dom['alg_bytes_per_unit']}
         out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(room, delays, filt.cpu().numpy().astype(np.complex128),
+            out['cpu_baseline'] = cpu_baseline(room, delays, filt.cpu().numpy().astype(np.complex128), device=device,
                                                steps=args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
