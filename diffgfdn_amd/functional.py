@@ -152,6 +152,24 @@ class ResolventSolveFilter(torch.autograd.Function):
         return gBM.to(BM.dtype), gPhi, gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None
 
 
+class SosOutputStage(torch.autograd.Function):
+    """H[b][k] = sum_g cascade_{b,g}(z_k) T[k][g] + direct[b][k]: second-order-section cascades (SVF output filters,
+    gain_filters.py:221-241, :262-402) contracted with the group transfer functions (model.py:588-619) in one
+    kernel; coef (B, G, S, 6) float32 biquad coefficients, T (K, G) complex64."""
+
+    @staticmethod
+    def forward(ctx, coef, T, direct, z):
+        H = ops.sos_compose_fwd(coef, z, T, direct)
+        ctx.save_for_backward(coef, T, z)
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        coef, T, z = ctx.saved_tensors
+        gcoef, gT = ops.sos_compose_bwd(coef, z, T, gH.contiguous())
+        return gcoef.to(coef.dtype), gT.to(T.dtype), None, None
+
+
 class OutputStage(torch.autograd.Function):
     """H[b][k] = (sum_g rgain[b][g] sum_{n in g} c_n Y[k][n] + direct[b][k]) * filt[k]."""
 

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from .config import BeamformerType, FeatureEncodingType
+from . import hip_ops as ops
 from .dnn import MLP, MLP_SkipConnections, ScaledSigmoid, SinusoidalEncoding
 
 
@@ -25,20 +26,19 @@ def svf_cutoff_frequencies(sample_rate: float) -> torch.Tensor:
     return torch.pi * torch.tensor(f) / sample_rate
 
 
-def svf_cascade_response(z: torch.Tensor, cutoff: torch.Tensor, raw_params: torch.Tensor,
-                         compress_pole_factor: float = 1.0) -> torch.Tensor:
-    """Frequency response (..., K) complex64 of cascades of state-variable-filter sections.
+def svf_biquad_coefficients(cutoff: torch.Tensor, raw_params: torch.Tensor,
+                            compress_pole_factor: float = 1.0) -> torch.Tensor:
+    """(..., S, 6) float32 biquad coefficients [b0 b1 b2 a0 a1 a2] of cascades of state-variable-filter sections.
 
     raw_params (..., S, 2): unconstrained [resonance, gain dB] per section, mapped through the reference's scaled
     sigmoids (resonance in (1e-6, 1), gain in (-6, 6) dB; gain_filters.py:327-330, model.py:733-737); section 0 is
     a low shelf, the last a high shelf, the others peaking (gain_filters.py:372-380); SVF -> biquad as
-    ``BiquadCascade.from_svf_coeffs`` (:117-151, mixing coefficients of ``SVF.__post_init__`` :36-103); response
-    as ``SOSFilter.forward`` (:221-241), accumulated in complex64."""
+    ``BiquadCascade.from_svf_coeffs`` (:117-151, mixing coefficients of ``SVF.__post_init__`` :36-103).  Formed as
+    the reference does -- float64 cut-offs times float32 parameters -- and stored as float32."""
     dev = raw_params.device
     S = raw_params.shape[-2]
     R = 1e-6 + (1.0 - 1e-6) * torch.sigmoid(raw_params[..., 0])
     G = torch.pow(10.0, (-6.0 + 12.0 * torch.sigmoid(raw_params[..., 1])) * 0.05)      # db2lin
-    # coefficients as the reference forms them: float64 cut-offs times float32 parameters, stored as float32
     f = cutoff.to(dev).to(torch.float64)
     R, G = R.to(torch.float64), G.to(torch.float64)
     idx = torch.arange(S, device=dev)
@@ -54,16 +54,35 @@ def svf_cascade_response(z: torch.Tensor, cutoff: torch.Tensor, raw_params: torc
     a0 = f ** 2 + 2 * R * f + 1
     a1 = (2 * f ** 2 - 2) * cpf + torch.zeros_like(R)
     a2 = (f ** 2 - 2 * R * f + 1) * cpf ** 2
-    # the sections are evaluated in complex128 (b0 + b1 z^-1 + b2 z^-2 cancels to O(f^2) at low frequencies: in
-    # complex64 the shelves lose 3 digits there), the running product is kept in complex64 like the reference
+    return torch.stack([b0, b1, b2, a0, a1, a2], dim=-1).to(torch.float32)
+
+
+def sos_cascade_response(z: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    """Frequency response (..., K) complex64 of the cascades coef (..., S, 6), as ``SOSFilter.forward``
+    (gain_filters.py:221-241).  The sections are evaluated in complex128 (b0 + b1 z^-1 + b2 z^-2 cancels to O(f^2)
+    at low frequencies: in complex64 the shelves lose 3 digits there), the running product is kept in complex64 like
+    the reference.  Device tensors without a gradient go through the HIP kernel (csrc/svf.hip: same arithmetic, no
+    (..., K) intermediates); gradients flow through the torch expression here or, for the receiver-dependent output
+    filters of the grid model, through :class:`~diffgfdn_amd.functional.SosOutputStage`."""
+    if coef.is_cuda and not (coef.requires_grad and torch.is_grad_enabled()):
+        lead = coef.shape[:-2]
+        out = ops.sos_response(coef.reshape(-1, coef.shape[-2], 6), z.to(coef.device))
+        return out.reshape(*lead, z.numel())
     zi = 1.0 / z.to(torch.complex128)
     zi2 = zi * zi
     H = None
-    for k in range(S):
-        c = lambda t: t[..., k].to(torch.float32).to(torch.float64).unsqueeze(-1)
-        sec = ((c(b0) + c(b1) * zi + c(b2) * zi2) / (c(a0) + c(a1) * zi + c(a2) * zi2)).to(torch.complex64)
+    for k in range(coef.shape[-2]):
+        c = lambda j: coef[..., k, j].to(torch.float64).unsqueeze(-1)
+        sec = ((c(0) + c(1) * zi + c(2) * zi2) / (c(3) + c(4) * zi + c(5) * zi2)).to(torch.complex64)
         H = sec if H is None else H * sec
     return H
+
+
+def svf_cascade_response(z: torch.Tensor, cutoff: torch.Tensor, raw_params: torch.Tensor,
+                         compress_pole_factor: float = 1.0) -> torch.Tensor:
+    """Frequency response (..., K) complex64 of cascades of state-variable-filter sections:
+    :func:`svf_biquad_coefficients` then :func:`sos_cascade_response`."""
+    return sos_cascade_response(z, svf_biquad_coefficients(cutoff, raw_params, compress_pole_factor))
 
 
 class SVF_from_MLP(nn.Module):
@@ -93,14 +112,18 @@ class SVF_from_MLP(nn.Module):
         self.mlp = MLP(3 * num_fourier_features * 2, num_hidden_layers, num_neurons, num_groups,
                        self.num_biquads, num_params=2)
 
-    def group_responses(self, x: Dict) -> torch.Tensor:
+    def biquad_coefficients(self, x: Dict) -> torch.Tensor:
+        """(B, G, S, 6) float32 biquad coefficients of the cascades at the batch's positions."""
         # NB the reference feeds the RAW listener position here (:340-342), not the normalised one
         position = x['listener_position'] if self.position_type == "output_gains" else x['source_position']
         w = self.mlp.model[0].weight
         enc = self.encoder(position.to(w.device))
         self.svf_params = self.mlp(enc.to(w.dtype))                             # (B, G, S, 2) raw
-        return svf_cascade_response(x['z_values'].to(w.device), self.svf_cutoff_freqs, self.svf_params,
-                                    self.compress_pole_factor)
+        return svf_biquad_coefficients(self.svf_cutoff_freqs, self.svf_params, self.compress_pole_factor)
+
+    def group_responses(self, x: Dict) -> torch.Tensor:
+        w = self.mlp.model[0].weight
+        return sos_cascade_response(x['z_values'].to(w.device), self.biquad_coefficients(x))
 
     def forward(self, x: Dict) -> torch.Tensor:
         return self.group_responses(x).repeat_interleave(self.num_delay_lines_per_group, dim=1)

@@ -5,6 +5,7 @@ buffers are allocated here with torch (PyTorch owns all memory, the library owns
 launch goes onto ``torch.cuda.current_stream()``.  Inputs on the CPU raise: there is no CPU
 fallback in the product path.
 """
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -177,6 +178,58 @@ def solve_phi_bwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b, gY, Y):
                                       _p(b), _p(gY), _p(Y), _p(gBM), _p(gb), _p(gig), _p(gPhi), _p(work),
                                       _stream()), "gfdn_solve_phi_bwd")
     return gBM, gb, gig, gPhi
+
+
+def _z128(z: torch.Tensor) -> torch.Tensor:
+    return z.detach().to(torch.complex128).contiguous()
+
+
+def sos_response(coef, z) -> torch.Tensor:
+    """coef (R, S, 6) f32 [b0 b1 b2 a0 a1 a2], z (K,) complex -> (R, K) complex64 responses of the R cascades
+    (sections in float64, rounded to complex64, running product in complex64)."""
+    _need_gpu(coef, z)
+    coef, z = _f(coef), _z128(z)
+    R, S, six = coef.shape
+    if six != 6:
+        raise RuntimeError("sos_response: coef must be (R, S, 6)")
+    out = torch.empty((R, z.numel()), dtype=_c64, device=coef.device)
+    _lib.check(_lib.load().gfdn_sos_response(_p(coef), R, S, _p(z), z.numel(), _p(out), _stream()), "gfdn_sos_response")
+    return out
+
+
+def sos_compose_fwd(coef, z, T, direct=None) -> torch.Tensor:
+    """H[b][k] = sum_g cascade_{b,g}(z_k) T[k][g] + direct[b][k]: coef (B, G, S, 6) f32, T (K, G) c64,
+    direct (B, K) c64 or None -> (B, K) c64."""
+    _need_gpu(coef, z, T)
+    coef, z, T = _f(coef), _z128(z), _c(T)
+    B, G, S, six = coef.shape
+    K = z.numel()
+    if six != 6 or tuple(T.shape) != (K, G):
+        raise RuntimeError("sos_compose_fwd: coef (B, G, S, 6), T (K, G)")
+    if direct is not None:
+        direct = _c(direct)
+        if tuple(direct.shape) != (B, K):
+            raise RuntimeError("sos_compose_fwd: direct must be (B, K)")
+    H = torch.empty((B, K), dtype=_c64, device=coef.device)
+    _lib.check(_lib.load().gfdn_sos_compose_fwd(_p(coef), B, G, S, _p(z), K, _p(T), _p(direct), K, _p(H), _stream()),
+               "gfdn_sos_compose_fwd")
+    return H
+
+
+def sos_compose_bwd(coef, z, T, gH):
+    """-> gcoef (B, G, S, 6) f32, gT (K, G) c64."""
+    _need_gpu(coef, z, T, gH)
+    coef, z, T, gH = _f(coef), _z128(z), _c(T), _c(gH)
+    B, G, S, _ = coef.shape
+    K = z.numel()
+    lib = _lib.load()
+    tc, cc = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.gfdn_sos_compose_bwd_chunks(B, K, ctypes.byref(tc), ctypes.byref(cc)), "gfdn_sos_compose_bwd_chunks")
+    gT_part = torch.empty((tc.value, K, G), dtype=_c64, device=coef.device)
+    gc_part = torch.empty((B * G, cc.value, S, 6), dtype=_f32, device=coef.device)
+    _lib.check(lib.gfdn_sos_compose_bwd(_p(coef), B, G, S, _p(z), K, _p(T), _p(gH), _p(gT_part), _p(gc_part),
+                                        _stream()), "gfdn_sos_compose_bwd")
+    return gc_part.sum(1).reshape(B, G, S, 6), gT_part.sum(0)
 
 
 def _rows(rows, n_items: int, store_rows: int):

@@ -20,7 +20,7 @@ from torch import nn
 
 from .config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
 from .feedback_loop import FeedbackLoop, decay_times_to_gain_per_sample
-from .functional import FrequencyGrid, OutputStage, ResolventSolve, SHOutputStage
+from .functional import FrequencyGrid, OutputStage, ResolventSolve, SHOutputStage, SosOutputStage
 from .gain_filters import (Directional_Beamforming_Weights_from_MLP, Gains_from_MLP, SVF_from_MLP,
                            svf_cascade_response, svf_cutoff_frequencies)
 
@@ -224,9 +224,11 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
         self.feedback_loop.new_forward()
         self.batch_size = x['listener_position'].shape[0]
         if self.use_svf_in_output:
-            Co = self.output_filters.group_responses(x)                                  # (B, G, K)
-            T = self.group_transfer(z)                                                   # (K, G, G')
-            H = torch.einsum('bgk,kg->bk', Co, T.sum(-1)) + x['target_early_response']
+            # H = sum_g Co[b][g][k] T[k][g] + d[b][k] with the (B, G, K) filter responses evaluated inside the
+            # contraction kernel (csrc/svf.hip) from their biquad coefficients
+            coef = self.output_filters.biquad_coefficients(x)                            # (B, G, S, 6)
+            T = self.group_transfer(z).sum(-1)                                           # (K, G)
+            H = SosOutputStage.apply(coef, T.contiguous(), x['target_early_response'], z)
             if subband_filter is not None:
                 H = H * subband_filter
             if self.use_colorless_loss:

@@ -117,6 +117,22 @@ int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, in
                        const float* gY_c64, const float* Y_c64, float* gBM, float* gb, float* ginv_gamma,
                        float* gPhi_c64, void* work, void* stream);
 
+/* ---- second-order-section cascades: SVF output filters  (gain_filters.py:221-241 SOSFilter.forward, :262-402
+ * SVF_from_MLP, model.py:588-619) -------------------------------------------------------------------------
+ * coef (R, S, 6) float32 = b0 b1 b2 a0 a1 a2 per section (S <= 12), z (K) complex128.  Sections are evaluated in
+ * float64 and rounded to complex64, the running product is complex64.
+ *   gfdn_sos_response:    out[r][k] = prod_s (b0 + b1 z^-1 + b2 z^-2) / (a0 + a1 z^-1 + a2 z^-2)   (R, K) c64
+ *   gfdn_sos_compose_fwd: H[b][k] = sum_g response_{b G + g}(z_k) T[k][g] + direct[b][k]   (rows receiver-major,
+ *                         G <= 8; T (K, G) c64 = group transfer functions; direct (B, ldd) c64 or NULL)
+ *   gfdn_sos_compose_bwd: gT_partial (t_chunks, K, G) c64 and gcoef_partial (B G, c_chunks, S, 6) f32, to be
+ *                         summed over their chunk axis (chunk counts from gfdn_sos_compose_bwd_chunks)          */
+int gfdn_sos_response(const float* coef, int R, int S, const double* z_c128, int K, float* out_c64, void* stream);
+int gfdn_sos_compose_fwd(const float* coef, int B, int G, int S, const double* z_c128, int K, const float* T_c64,
+                         const float* direct_c64, int ldd, float* H_c64, void* stream);
+int gfdn_sos_compose_bwd_chunks(int B, int K, int* t_chunks, int* c_chunks);
+int gfdn_sos_compose_bwd(const float* coef, int B, int G, int S, const double* z_c128, int K, const float* T_c64,
+                         const float* gH_c64, float* gT_partial_c64, float* gcoef_partial, void* stream);
+
 /* ---- output stage  (model.py:583-619, gain_filters.py:526-534, trainer.py:459) ----------
  *   S[g][k]  = sum_{n in group g} c_n Y[k][n]
  *   H[b][k]  = (sum_g rgain[b][g] S[g][k] + direct[b][k]) * filt[k]

@@ -410,3 +410,38 @@ def test_subfdn_normalize(ops, G, nper, nfft):
     Yo = P @ b0.cpu().double().to(torch.complex128)
     So = (Yo * c0.cpu().double()).reshape(-1, G, nper).sum(-1)
     assert rel_err(E.cpu(), (So.abs() ** 2).mean(0)) < 1e-4
+
+
+@pytest.mark.parametrize("B,G,S,K", [(3, 2, 11, 257), (5, 4, 11, 1500), (2, 3, 4, 64), (9, 1, 12, 300)])
+def test_sos_cascade_kernels(ops, B, G, S, K):
+    """gfdn_sos_response / gfdn_sos_compose_fwd / _bwd (SVF output filters fused with the output contraction) against
+    the torch expression of the same arithmetic (gain_filters.sos_cascade_response) and its autograd gradients."""
+    from diffgfdn_amd.functional import SosOutputStage
+    from diffgfdn_amd.gain_filters import sos_cascade_response, svf_biquad_coefficients, svf_cutoff_frequencies
+    g = torch.Generator().manual_seed(B * 100 + S)
+    cut = svf_cutoff_frequencies(32000.0)[:S] if S <= 11 else torch.cat([svf_cutoff_frequencies(32000.0),
+                                                                         torch.tensor([0.9])])
+    raw = torch.randn(B, G, S, 2, generator=g)
+    coef = svf_biquad_coefficients(cut, raw, 0.98).to(DEV)
+    z = torch.exp(1j * np.pi * (torch.arange(K, dtype=torch.float64) + 0.25) / K).to(DEV)
+    T = torch.view_as_complex(torch.randn(K, G, 2, generator=g)).to(DEV)
+    direct = torch.view_as_complex(torch.randn(B, K, 2, generator=g)).to(DEV)
+    wgt = torch.view_as_complex(torch.randn(B, K, 2, generator=g)).to(DEV)
+    # torch expression (gradients through autograd)
+    cr = coef.clone().requires_grad_(True)
+    Tr = T.clone().requires_grad_(True)
+    Co = sos_cascade_response(z, cr)                       # requires_grad -> the torch branch
+    Href = torch.einsum('bgk,kg->bk', Co, Tr) + direct
+    (Href * wgt.conj()).real.sum().backward()
+    # kernels
+    assert rel_err(ops.sos_response(coef.reshape(B * G, S, 6), z).reshape(B, G, K).cpu(), Co.detach().cpu()) < 2e-6
+    assert rel_err(sos_cascade_response(z, coef).cpu(), Co.detach().cpu()) < 2e-6      # no grad: the HIP branch
+    ck = coef.clone().requires_grad_(True)
+    Tk = T.clone().requires_grad_(True)
+    H = SosOutputStage.apply(ck, Tk, direct, z)
+    assert rel_err(H.detach().cpu(), Href.detach().cpu()) < 2e-6
+    (H * wgt.conj()).real.sum().backward()
+    assert rel_err(Tk.grad.cpu(), Tr.grad.cpu()) < 1e-5
+    assert rel_err(ck.grad.cpu(), cr.grad.cpu()) < 1e-4
+    H0 = SosOutputStage.apply(coef, T, None, z)
+    assert rel_err(H0.cpu(), (Href - direct).detach().cpu()) < 2e-6
