@@ -412,7 +412,8 @@ def test_subfdn_normalize(ops, G, nper, nfft):
     assert rel_err(E.cpu(), (So.abs() ** 2).mean(0)) < 1e-4
 
 
-@pytest.mark.parametrize("B,G,S,K", [(3, 2, 11, 257), (5, 4, 11, 1500), (2, 3, 4, 64), (9, 1, 12, 300)])
+@pytest.mark.parametrize("B,G,S,K", [(3, 2, 11, 257), (5, 4, 11, 1500), (2, 3, 4, 64), (9, 1, 12, 300),
+                                     (2, 4, 11, 65537), (33, 4, 11, 4100)])
 def test_sos_cascade_kernels(ops, B, G, S, K):
     """gfdn_sos_response / gfdn_sos_compose_fwd / _bwd (SVF output filters fused with the output contraction) against
     the torch expression of the same arithmetic (gain_filters.sos_cascade_response) and its autograd gradients."""
