@@ -157,6 +157,7 @@ class MultiRIRDataset(torch.utils.data.Dataset):
                 'z_values': self.z_values,
                 'source_position': self.source_position[0].expand(B, -1),
                 'norm_listener_position': self.norm_listener_position,
+                'listener_position': self.listener_positions,
                 'target_early_response': self.early_rir_mag_response,
                 'edr_target': self.edr_store,
                 'edc_target': self.edc_store,

@@ -106,7 +106,8 @@ class SVF_from_MLP(nn.Module):
         self.encoding_type = encoding_type
         self.compress_pole_factor = compress_pole_factor
         self.device = device
-        self.svf_cutoff_freqs = svf_cutoff_frequencies(sample_rate)
+        # non-persistent buffer: follows .to(device) (no host-to-device copy inside a captured step), no state-dict key
+        self.register_buffer('svf_cutoff_freqs', svf_cutoff_frequencies(sample_rate), persistent=False)
         self.num_biquads = len(self.svf_cutoff_freqs)
         self.encoder = SinusoidalEncoding(num_fourier_features)
         self.mlp = MLP(3 * num_fourier_features * 2, num_hidden_layers, num_neurons, num_groups,

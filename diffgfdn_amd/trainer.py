@@ -291,7 +291,7 @@ class VarReceiverPosTrainer(Trainer):
         static device buffer (graph replay); otherwise the mask is drawn here like the reference."""
         net, cfg = self.net, self.config
         if getattr(net, 'use_svf_in_output', False):
-            return self._step_losses_module_forward(data, draw_mask, defer_total)
+            return self._step_losses_module_forward(data, draw_mask, defer_total, mask_prenorm)
         fl = net.feedback_loop
         fl.new_forward()
         z = data['z_values']
@@ -383,21 +383,38 @@ class VarReceiverPosTrainer(Trainer):
             losses['_total'] = total if extra is None else total + extra
         return losses
 
-    def _step_losses_module_forward(self, data: Dict, draw_mask: bool, defer_total: bool) -> Dict:
+    def _step_losses_module_forward(self, data: Dict, draw_mask: bool, defer_total: bool,
+                                    mask_prenorm: Optional[torch.Tensor] = None) -> Dict:
         """Step losses through the model's own forward (SVF output filters: the (B, G, K) filter responses make the
-        output stage receiver- AND bin-dependent, model.py:588-592) -- same loss kernels, full bin range."""
+        output stage receiver- AND bin-dependent, model.py:588-592) -- same loss kernels, full bin range.  A
+        ``lean="rows"`` batch (dataset-level stores + 'row_index', graph replay) is gathered here for the model;
+        the decay targets are still read from the stores through the rows."""
         net, cfg = self.net, self.config
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
-        if 'target_rir_response' not in data or 'listener_position' not in data:
-            raise ValueError("SVF output filters: collate full batches (no lean='rows')")
-        out = net(data, subband_filter=filt)
+        rows = data.get('row_index')
+        if 'listener_position' not in data or ('target_rir_response' not in data and 'edr_target' not in data):
+            raise ValueError("SVF output filters: the batch needs raw listener positions and decay targets")
+        fwd = data
+        if rows is not None:
+            fwd = dict(data)
+            for key in ('listener_position', 'norm_listener_position', 'target_early_response'):
+                fwd[key] = data[key].index_select(0, rows)
+        out = net(fwd, subband_filter=filt)
         H, H_sub = out if net.use_colorless_loss else (out, None)
         K = H.shape[-1]
         start, length = self._decay_window(K)
-        maskw, count = (self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length)))
+        gb = H.shape[0] * self.world_size
+        if mask_prenorm is not None:
+            maskw, count = mask_prenorm, None
+        else:
+            maskw, count = (self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length)))
+        edr_t, edc_t = data.get('edr_target'), data.get('edc_target')
         total, edr_v, edc_v = decay_losses(
-            H, data['target_rir_response'], win=self.stft_win, edr_weight=cfg.edr_loss_weight,
-            edc_weight=cfg.edc_loss_weight, edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count)
+            H, data.get('target_rir_response'), win=self.stft_win, edr_weight=cfg.edr_loss_weight,
+            edc_weight=cfg.edc_loss_weight, edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
+            edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
+            edr_target=None if edr_t is None else (edr_t[1], edr_t[2]),
+            edc_target=None if edc_t is None else edc_t[1], n_time=K, target_rows=rows)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v}
         if self.use_colorless_loss:
             S = H_sub[0].T.contiguous()

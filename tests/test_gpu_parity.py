@@ -870,3 +870,48 @@ def test_precise_solve(N, K):
     with torch.no_grad():
         Y32 = ResolventSolve.apply(A.detach(), ig.detach().float(), b.detach(), grid, delays, False)
     assert rel_err(Y32.cpu(), Yr.detach().cpu()) > 10 * rel_err(Y.detach().cpu(), Yr.detach().cpu())
+
+
+def test_svf_graphed_step_equals_eager_step():
+    """Grid model with SVF output filters: the step replayed from a HIP graph (rows batch gathered for the model's
+    forward, decay targets from the dataset stores) equals the eager step on collated batches -- same host masks,
+    same state; b, c normalised once per epoch as the reference does for full-band models (trainer.py:365-369)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.synthetic import synthetic_room
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    room = synthetic_room(12, 3, 8000.0, 5000, seed=3)
+    ds = MultiRIRDataset(DEV, RoomDataset(3, 8000.0, room["source_position"], room["receiver_position"],
+                                          room["rirs"], room["common_decay_times"], nfft=8192, device=DEV))
+    tc = TrainerConfig(batch_size=4, num_freq_bins=8192, lr=1e-3, io_lr=1e-2, use_colorless_loss=True,
+                       use_asym_spectral_loss=True, edc_loss_weight=10.0, sparsity_loss_weight=2.0, use_edc_mask=True,
+                       train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a", device="cuda")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                            compress_pole_factor=0.98)
+    delays = [173, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 401]
+    sels = ([0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11])
+    results = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        net = DiffGFDNVarReceiverPos(8000.0, 3, delays, DEV, fl, of, use_absorption_filters=False,
+                                     common_decay_times=room["common_decay_times"], use_colorless_loss=True).to(DEV)
+        tr = VarReceiverPosTrainer(net, tc, stft_win=512, capturable=(mode == "graph"))
+        tr.normalize(ds.collate(sels[0]))
+        if mode == "graph":
+            step = tr.graphed(ds, 4, mask_source="host").capture(sels[0])
+        torch.manual_seed(77)
+        tot = []
+        for sel in sels:
+            if mode == "eager":
+                t, _ = tr.train_step(ds.collate(sel))
+                tot.append(float(t))
+            else:
+                tot.append(float(step(sel)["_total"]))
+        results.append((tot, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+    (t0, s0), (t1, s1) = results
+    for a, b in zip(t0, t1):
+        assert abs(a - b) < 1e-5 * abs(a), (t0, t1)
+    for k in s0:
+        assert rel_err(s1[k], s0[k]) < 5e-4, k
