@@ -1910,27 +1910,49 @@ extern "C" int gfdn_compose_banded_bwd(const float* Y, int K, int nbands, int G,
 // directional (SH-domain) output stage, model.py:1056-1088
 //   H[b][l][k] = filt_k * sum_g w[b][g][l] c[g*nper+l] Y[k][g*nper+l]
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compose_sh_fwd(const float2* __restrict__ Y, int K, int G,
-                                                        int nper, const float* __restrict__ c,
-                                                        const float* __restrict__ w, int B,
-                                                        const float2* __restrict__ filt,
-                                                        float2* __restrict__ H) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+// Y tile of SH_TB bins x N lines staged through LDS once per workgroup (linear global reads; the per-thread rows of
+// the bin-major layout are 8 N bytes apart) and reused by the SH_BCH receivers of the workgroup; w[b][n] c[n] from an
+// LDS table.  (One thread per (bin, receiver) reading Y straight from memory took 1.22 ms at N = 36, B = 32.)
+#define SH_TB 128
+#define SH_BCH 8
+__global__ __launch_bounds__(SH_TB) void k_compose_sh_fwd(const float2* __restrict__ Y, int K, int G,
+                                                          int nper, const float* __restrict__ c,
+                                                          const float* __restrict__ w, int B,
+                                                          const float2* __restrict__ filt,
+                                                          float2* __restrict__ H) {
+  const int N = G * nper, NS = N + 1 + (N & 1);          // odd row stride: conflict-free rows
+  float2* yt = compose_lds;                              // [SH_TB][NS]
+  float* sw = (float*)(yt + SH_TB * NS);                 // [SH_BCH][N]
+  const int k0 = blockIdx.x * SH_TB, b0 = blockIdx.y * SH_BCH;
+  const int nbin = K - k0 < SH_TB ? K - k0 : SH_TB;
+  const int nb = B - b0 < SH_BCH ? B - b0 : SH_BCH;
+  const size_t base = (size_t)k0 * N;
+  for (int e = threadIdx.x; e < nbin * N; e += SH_TB) {
+    const int kq = e / N, n = e - kq * N;
+    yt[kq * NS + n] = Y[base + e];
+  }
+  for (int e = threadIdx.x; e < nb * N; e += SH_TB) {
+    const int bb = e / N, n = e - bb * N;
+    sw[e] = w[(size_t)(b0 + bb) * N + n] * c[n];
+  }
+  __syncthreads();
+  const int k = k0 + threadIdx.x;
   if (k >= K) return;
-  const int N = G * nper;
-  const int b = blockIdx.y;
-  float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
-  for (int l = 0; l < nper; ++l) {
-    float2 h = make_float2(0.f, 0.f);
-    for (int g = 0; g < G; ++g) {
-      const int n = g * nper + l;
-      float2 y = Y[(size_t)k * N + n];
-      float s = w[(size_t)b * N + n] * c[n];
-      h.x += s * y.x;
-      h.y += s * y.y;
+  const float2 f = filt ? filt[k] : make_float2(1.f, 0.f);
+  const float2* yrow = yt + threadIdx.x * NS;
+  for (int bb = 0; bb < nb; ++bb) {
+    const float* sb = sw + bb * N;
+    for (int l = 0; l < nper; ++l) {
+      float2 h = make_float2(0.f, 0.f);
+      for (int g = 0; g < G; ++g) {
+        const int n = g * nper + l;
+        const float2 y = yrow[n];
+        h.x += sb[n] * y.x;
+        h.y += sb[n] * y.y;
+      }
+      if (filt) h = cmul(h, f);
+      H[((size_t)(b0 + bb) * nper + l) * K + k] = h;
     }
-    if (filt) h = cmul(h, f);
-    H[((size_t)b * nper + l) * K + k] = h;
   }
 }
 
@@ -1938,8 +1960,12 @@ extern "C" int gfdn_compose_sh_fwd(const float* Y, int K, int G, int nper, const
                                    const float* w, int B, const float* filt, float* H,
                                    void* stream) {
   if (!Y || !c || !w || !H || K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_compose_sh_fwd, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
-                     (const float2*)Y, K, G, nper, c, w, B, (const float2*)filt, (float2*)H);
+  const int N = G * nper, NS = N + 1 + (N & 1);
+  const size_t lds = (size_t)SH_TB * NS * sizeof(float2) + (size_t)SH_BCH * N * sizeof(float);
+  int rc = ensure_dyn_lds(k_compose_sh_fwd, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compose_sh_fwd, dim3((K + SH_TB - 1) / SH_TB, (B + SH_BCH - 1) / SH_BCH), dim3(SH_TB), lds,
+                     (hipStream_t)stream, (const float2*)Y, K, G, nper, c, w, B, (const float2*)filt, (float2*)H);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -2035,21 +2061,35 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
 // SH domain -> directional responses, trainer.py:853-865: H_dir[b][j][k] = sum_l A[j][l] H_sh[b][l][k]
 // and its adjoint gH_sh[b][l][k] = sum_j A[j][l] gH_dir[b][j][k]   (A real, J x C)
 // ------------------------------------------------------------------------------------------
+// out[b][o][k] = sum_i A'[o][i] in[b][i][k]: the inputs of a bin are loaded ONCE into registers (the version that
+// re-read all of them for every output issued nin x nout loads per thread: 383 us for 151 -> 268 MB)
+#define SHMIX_MAX 32
 __global__ __launch_bounds__(256) void k_sh_mix(const float* __restrict__ A, int J, int C, int K,
                                                 const float2* __restrict__ in, float2* __restrict__ out,
                                                 int adjoint) {
+  __shared__ float s_a[SHMIX_MAX * SHMIX_MAX];
+  const int nin = adjoint ? J : C, nout = adjoint ? C : J;
+  for (int e = threadIdx.x; e < nout * nin; e += 256) {         // s_a[o][i]
+    const int o = e / nin, i = e - o * nin;
+    s_a[e] = adjoint ? A[i * C + o] : A[o * C + i];
+  }
+  __syncthreads();
   const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   if (k >= K) return;
-  const int nin = adjoint ? J : C, nout = adjoint ? C : J;
   const float2* ib = in + (size_t)b * nin * K;
   float2* ob = out + (size_t)b * nout * K;
+  float2 v[SHMIX_MAX];
+#pragma unroll
+  for (int i = 0; i < SHMIX_MAX; ++i) v[i] = i < nin ? ib[(size_t)i * K + k] : make_float2(0.f, 0.f);
   for (int o = 0; o < nout; ++o) {
     float2 acc = make_float2(0.f, 0.f);
-    for (int i = 0; i < nin; ++i) {
-      const float a = adjoint ? A[i * C + o] : A[o * C + i];
-      const float2 v = ib[(size_t)i * K + k];
-      acc.x += a * v.x;
-      acc.y += a * v.y;
+    const float* ar = s_a + o * nin;
+#pragma unroll
+    for (int i = 0; i < SHMIX_MAX; ++i) {
+      if (i < nin) {
+        acc.x += ar[i] * v[i].x;
+        acc.y += ar[i] * v[i].y;
+      }
     }
     ob[(size_t)o * K + k] = acc;
   }
@@ -2058,6 +2098,7 @@ __global__ __launch_bounds__(256) void k_sh_mix(const float* __restrict__ A, int
 extern "C" int gfdn_sh_to_directional(const float* A, int J, int C, int K, int B, const float* in,
                                       float* out, int adjoint, void* stream) {
   if (!A || !in || !out || J <= 0 || C <= 0 || K <= 0 || B <= 0) return GFDN_E_BADARG;
+  if (J > SHMIX_MAX || C > SHMIX_MAX) return GFDN_E_UNSUPPORTED;
   hipLaunchKernelGGL(k_sh_mix, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, A, J, C, K,
                      (const float2*)in, (float2*)out, adjoint);
   GFDN_LAUNCH_CHECK();
