@@ -1915,6 +1915,8 @@ extern "C" int gfdn_compose_banded_bwd(const float* Y, int K, int nbands, int G,
 // LDS table.  (One thread per (bin, receiver) reading Y straight from memory took 1.22 ms at N = 36, B = 32.)
 #define SH_TB 128
 #define SH_BCH 8
+#define GFDN_MAX_SH_LINES 64      // delay lines the SH output stage's backward keeps in registers
+#define GFDN_SH_MAX_TILES 4096    // bin tiles (of SH_TB) its partial sums are sized for
 __global__ __launch_bounds__(SH_TB) void k_compose_sh_fwd(const float2* __restrict__ Y, int K, int G,
                                                           int nper, const float* __restrict__ c,
                                                           const float* __restrict__ w, int B,
@@ -1970,69 +1972,85 @@ extern "C" int gfdn_compose_sh_fwd(const float* Y, int K, int G, int nper, const
   return 0;
 }
 
-// pass A: per k: gY[k][n] = c_n sum_b w[b][n] gH'[b][l(n)][k]; gc partial; per (b,n) handled in pass B
-__global__ __launch_bounds__(256) void k_compose_sh_bwd_a(const float2* __restrict__ Y, int K, int G,
+// Backward of the SH output stage in ONE pass over gH per tile of SH_TB bins (Y tile staged once, every gH element
+// loaded once):  gY[k][n] = c_n sum_b w[b][n] gH'[b][l(n)][k],  gc[n] = sum_k Re(conj(acc) ...),
+// gw[b][n] = c_n sum_k Re(conj(gH'[b][l][k]) Y[k][n])   (gH' = gH conj(filt)).  The sums over the bins are wave
+// reductions (per wave and (b, n) one LDS slot, no barrier inside the receiver loop); per-tile partials
+// [tile][(B + 1) N] (gw rows, then the gc row) are reduced by k_reduce_partials.
+// (Two kernels that looped over all receivers per (bin, line) and over all bins per (receiver, line), both with
+// 8 N-byte strided Y accesses, took 531 + 426 us.)
+__global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd(const float2* __restrict__ Y, int K, int G,
                                                           int nper, const float* __restrict__ c,
                                                           const float* __restrict__ w, int B,
                                                           const float2* __restrict__ filt,
                                                           const float2* __restrict__ gH,
                                                           float2* __restrict__ gY,
-                                                          float* __restrict__ gc_partial) {
-  __shared__ float s_gc[4][64];
-  const int N = G * nper;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int e = threadIdx.x; e < 4 * 64; e += 256) (&s_gc[0][0])[e] = 0.f;
+                                                          float* __restrict__ partial) {
+  const int N = G * nper, NS = N + 1 + (N & 1);
+  constexpr int NW = SH_TB / 64;
+  float2* yt = compose_lds;                              // [SH_TB][NS]
+  float* sw = (float*)(yt + SH_TB * NS);                 // [B][N]
+  float* sg = sw + B * N;                                // [NW][(B + 1) N]: per-wave sums over the bins
+  const int k0 = blockIdx.x * SH_TB;
+  const int nbin = K - k0 < SH_TB ? K - k0 : SH_TB;
+  const size_t base = (size_t)k0 * N;
+  for (int e = threadIdx.x; e < SH_TB * N; e += SH_TB) {
+    const int kq = e / N, n = e - kq * N;
+    yt[kq * NS + n] = e < nbin * N ? Y[base + e] : make_float2(0.f, 0.f);
+  }
+  for (int e = threadIdx.x; e < B * N; e += SH_TB) sw[e] = w[e];
   __syncthreads();
-  for (int k0 = blockIdx.x * 256; k0 < K; k0 += gridDim.x * 256) {
-    const int k = k0 + threadIdx.x;
-    const bool valid = k < K;
-    const int kk = valid ? k : K - 1;
-    float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
-    for (int n = 0; n < N; ++n) {
-      const int l = n % nper;
-      float2 acc = make_float2(0.f, 0.f);
-      for (int b = 0; b < B; ++b) {
-        float2 gh = gH[((size_t)b * nper + l) * K + kk];
-        float wb = w[(size_t)b * N + n];
-        acc.x += wb * gh.x;
-        acc.y += wb * gh.y;
+  const int k = k0 + threadIdx.x;
+  const bool valid = k < K;
+  const int kk = valid ? k : K - 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
+  float2* yrow = yt + threadIdx.x * NS;
+  float* sgw = sg + (size_t)wv * (B + 1) * N;
+  float2 acc[GFDN_MAX_SH_LINES];
+#pragma unroll
+  for (int n = 0; n < GFDN_MAX_SH_LINES; ++n) acc[n] = make_float2(0.f, 0.f);
+  for (int b = 0; b < B; ++b) {
+#pragma unroll
+    for (int n = 0; n < GFDN_MAX_SH_LINES; ++n) {
+      if (n < N) {
+        const int l = n % nper;
+        float2 gh = valid ? gH[((size_t)b * nper + l) * K + kk] : make_float2(0.f, 0.f);   // (G loads of one line: L1)
+        if (filt) gh = cmul(gh, fc);
+        const float wb = sw[b * N + n];
+        acc[n].x += wb * gh.x;
+        acc[n].y += wb * gh.y;
+        const float2 y = yrow[n];
+        const float v = wave_sum(gh.x * y.x + gh.y * y.y);
+        if (lane == 0) sgw[b * N + n] = v;
       }
-      if (filt) acc = cmul(acc, fc);
-      float2 y = Y[(size_t)kk * N + n];
-      if (valid) gY[(size_t)k * N + n] = cscale(acc, c[n]);
-      float v = valid ? (acc.x * y.x + acc.y * y.y) : 0.f;
-      v = wave_sum(v);
-      if (lane == 0) s_gc[wv][n] += v;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < GFDN_MAX_SH_LINES; ++n) {
+    if (n < N) {
+      const float2 y = yrow[n];
+      const float v = wave_sum(valid ? (acc[n].x * y.x + acc[n].y * y.y) : 0.f);
+      if (lane == 0) sgw[B * N + n] = v;
+      yrow[n] = cscale(acc[n], c[n]);                    // gY through the tile: linear global writes below
     }
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < N; n += 256)
-    gc_partial[(size_t)blockIdx.x * N + n] = s_gc[0][n] + s_gc[1][n] + s_gc[2][n] + s_gc[3][n];
-}
-
-// pass B: gw[b][n] = c_n sum_k Re(conj(gH'[b][l][k]) Y[k][n])
-__global__ __launch_bounds__(256) void k_compose_sh_bwd_b(const float2* __restrict__ Y, int K, int G,
-                                                          int nper, const float* __restrict__ c,
-                                                          const float2* __restrict__ filt,
-                                                          const float2* __restrict__ gH,
-                                                          float* __restrict__ gw) {
-  __shared__ float s_red[16];
-  const int N = G * nper;
-  const int b = blockIdx.y, n = blockIdx.x, l = n % nper;
-  float acc = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float2 gh = gH[((size_t)b * nper + l) * K + k];
-    if (filt) gh = cmul(gh, cconj(filt[k]));
-    float2 y = Y[(size_t)k * N + n];
-    acc += gh.x * y.x + gh.y * y.y;
+  float* out = partial + (size_t)blockIdx.x * (B + 1) * N;
+  for (int e = threadIdx.x; e < (B + 1) * N; e += SH_TB) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += sg[(size_t)q * (B + 1) * N + e];
+    out[e] = e < B * N ? sum * c[e % N] : sum;
   }
-  float s = block_sum(acc, s_red);
-  if (threadIdx.x == 0) gw[(size_t)b * N + n] = s * c[n];
+  for (int e = threadIdx.x; e < nbin * N; e += SH_TB) {
+    const int kq = e / N, n = e - kq * N;
+    gY[base + e] = yt[kq * NS + n];
+  }
 }
 
 extern "C" size_t gfdn_compose_sh_bwd_work_bytes(int G, int nper, int B) {
-  (void)B;
-  return (size_t)GFDN_PARTIAL_BLOCKS * G * nper * sizeof(float);
+  return (size_t)GFDN_SH_MAX_TILES * (B + 1) * G * nper * sizeof(float);
 }
 
 extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const float* c,
@@ -2040,19 +2058,23 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
                                    float* gY, float* gc, float* gw, void* work, void* stream) {
   if (!Y || !c || !w || !gH || !gY || !gc || !gw || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
-  if (G * nper > 64) return GFDN_E_UNSUPPORTED;
+  const int N = G * nper, NS = N + 1 + (N & 1);
+  const int ntiles = (K + SH_TB - 1) / SH_TB;
+  if (N > GFDN_MAX_SH_LINES || ntiles > GFDN_SH_MAX_TILES) return GFDN_E_UNSUPPORTED;
+  const size_t lds = (size_t)SH_TB * NS * sizeof(float2) +
+                     ((size_t)B * N + (size_t)(SH_TB / 64) * (B + 1) * N) * sizeof(float);
+  if (lds > 160 * 1024) return GFDN_E_UNSUPPORTED;
+  int rc = ensure_dyn_lds(k_compose_sh_bwd, lds);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int N = G * nper;
-  int nparts = (K + 255) / 256;
-  if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
-  float* gc_partial = (float*)work;
-  hipLaunchKernelGGL(k_compose_sh_bwd_a, dim3(nparts), dim3(256), 0, s, (const float2*)Y, K, G, nper,
-                     c, w, B, (const float2*)filt, (const float2*)gH, (float2*)gY, gc_partial);
+  float* partial = (float*)work;
+  hipLaunchKernelGGL(k_compose_sh_bwd, dim3(ntiles), dim3(SH_TB), lds, s, (const float2*)Y, K, G, nper, c, w, B,
+                     (const float2*)filt, (const float2*)gH, (float2*)gY, partial);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, gc_partial, nparts, N, gc);
+  // partial[tile][(B + 1) N]: rows 0..B-1 -> gw (B, N), row B -> gc (N)
+  hipLaunchKernelGGL(k_reduce_partials, dim3(B * N), dim3(256), 0, s, partial, ntiles, (B + 1) * N, gw);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compose_sh_bwd_b, dim3(N, B), dim3(256), 0, s, (const float2*)Y, K, G, nper,
-                     c, (const float2*)filt, (const float2*)gH, gw);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, partial + (size_t)B * N, ntiles, (B + 1) * N, gc);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
