@@ -2,15 +2,19 @@
 // Used where the reference calls torch.fft.irfft with the default length n = 2(K-1):
 // utils.py:169 (get_response / IR export) and losses.py:344 (directional EDC loss).
 //
-// Four-step factorisation n = L1 x L2 with both passes tiled through LDS so that every global
+// Real data through ONE complex transform of half the length, m = n / 2 (z[j] = x[2j] + i x[2j+1]):
+//   inverse:  Z[k] = (X[k] + conj X[m-k]) + i e^{+2 pi i k / n} (X[k] - conj X[m-k]),  z = IFFT_m(Z),  x = z / n
+//   forward:  Zf = FFT_m(z),  F[k] = 1/2 [(Zf[k] + conj Zf[m-k]) - i e^{-2 pi i k / n} (Zf[k] - conj Zf[m-k])]
+// (the full-length complex transform this replaces moved twice the work block and did twice the butterflies:
+// 2.15 ms for the four passes of 512 responses of 131 072 samples).
+// Four-step factorisation m = L1 x L2 with both passes tiled through LDS so that every global
 // access is contiguous along the tile:
-//   inverse  pass A: tile of adjacent k1, inverse FFT over k2 (stride L1), conj twiddle,
+//   inverse  pass A: tile of adjacent k1, Z formed on load, inverse FFT over k2 (stride L1), conj twiddle,
 //                    store transposed  work[n2][k1]
-//            pass B: tile of adjacent n2 rows, inverse FFT over k1, x[n1 L2 + n2]
-//   adjoint  pass A: tile of adjacent n2, FFT over n1 (stride L2), twiddle, work[k1][n2]
-//            pass B: tile of adjacent k1 rows, FFT over n2, gX[k1 + L1 k2] (k <= n/2)
-// The Hermitian half of the spectrum is expanded on the fly; the complex transform is full
-// length (2x redundant for real data) -- these calls are off the training hot path.
+//            pass B: tile of adjacent n2 rows, inverse FFT over k1, (x[2j], x[2j+1]) = z[j] / n, j = n1 L2 + n2
+//   forward  pass A: tile of adjacent n2, z formed on load, FFT over n1 (stride L2), twiddle, work[k1][n2]
+//            pass B: tile of rows k1 that holds the mirror rows L1 - k1 as well (F[k] needs Zf[m-k]), FFT over n2,
+//                    F[k1 + L1 k2] for k <= m
 #include "common.h"
 
 extern __shared__ float2 dyn_lds[];
@@ -77,19 +81,19 @@ __device__ __forceinline__ float2 p2_tw(int e, int L) {
 
 #define P2_TC 8
 
-struct P2Geom { int n, L1, L2; };
+struct P2Geom { int n, m, L1, L2; };          // n real samples, m = n / 2 = L1 L2 complex points
 static P2Geom p2_geom(int n) {
-  P2Geom g; g.n = n;
-  int p = ilog2(n);
+  P2Geom g; g.n = n; g.m = n / 2;
+  int p = ilog2(g.m);
   g.L1 = 1 << (p / 2);
-  g.L2 = n / g.L1;
+  g.L2 = g.m / g.L1;
   return g;
 }
 
 // ---- inverse pass A: k = k1 + L1 k2 ; tile over k1
 __global__ __launch_bounds__(256) void k_p2_inv_a(P2Geom g, const float2* __restrict__ X, int ldx,
                                                   float2* __restrict__ work) {
-  const int L1 = g.L1, L2 = g.L2, n = g.n, tc = L1 < P2_TC ? L1 : P2_TC, ss = L2 + 1;
+  const int L1 = g.L1, L2 = g.L2, n = g.n, m = g.m, tc = L1 < P2_TC ? L1 : P2_TC, ss = L2 + 1;
   float2* bufA = dyn_lds; float2* bufB = bufA + tc * ss; float2* tw4 = bufB + tc * ss;
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
   p2_tw4(tw4, L2);
@@ -97,29 +101,31 @@ __global__ __launch_bounds__(256) void k_p2_inv_a(P2Geom g, const float2* __rest
   for (int idx = threadIdx.x; idx < tc * L2; idx += blockDim.x) {
     const int k2 = idx / tc, cc = idx - k2 * tc;
     const int k = c0 + cc + L1 * k2;
-    float2 v;
-    if (k <= n / 2) { v = Xb[k]; if (k == 0 || k == n / 2) v.y = 0.f; }
-    else { v = Xb[n - k]; v.y = -v.y; }
-    bufA[cc * ss + k2] = v;
+    float2 a = Xb[k], bc = Xb[m - k];
+    bc.y = -bc.y;
+    if (k == 0) { a.y = 0.f; bc.y = 0.f; }            // irfft ignores Im X[0], Im X[n/2]
+    const float2 e = cadd(a, bc);
+    const float2 o = cmulc(csub(a, bc), p2_tw(k, n));    // (a - bc) e^{+2 pi i k / n}
+    bufA[cc * ss + k2] = make_float2(e.x - o.y, e.y + o.x);
   }
   __syncthreads();
   float2* r = p2_fft(bufA, bufB, L2, tc, ss, true, tw4, L2);
-  float2* wk = work + (size_t)b * n;
+  float2* wk = work + (size_t)b * m;
   for (int idx = threadIdx.x; idx < tc * L2; idx += blockDim.x) {
     const int n2 = idx / tc, cc = idx - n2 * tc;
     const int k1 = c0 + cc;
-    const float2 w = p2_tw((int)(((long long)n2 * k1) & (n - 1)), n);
+    const float2 w = p2_tw((int)(((long long)n2 * k1) & (m - 1)), m);
     wk[(size_t)n2 * L1 + k1] = cmulc(r[cc * ss + n2], w);
   }
 }
-// ---- inverse pass B: rows n2 (tile), inverse FFT over k1, x[n1 L2 + n2]
+// ---- inverse pass B: rows n2 (tile), inverse FFT over k1, (x[2j], x[2j+1]) = z[j] / n with j = n1 L2 + n2
 __global__ __launch_bounds__(256) void k_p2_inv_b(P2Geom g, const float2* __restrict__ work,
                                                   float* __restrict__ x, int ldo) {
-  const int L1 = g.L1, L2 = g.L2, n = g.n, tc = L2 < P2_TC ? L2 : P2_TC, ss = L1 + 1;
+  const int L1 = g.L1, L2 = g.L2, n = g.n, m = g.m, tc = L2 < P2_TC ? L2 : P2_TC, ss = L1 + 1;
   float2* bufA = dyn_lds; float2* bufB = bufA + tc * ss; float2* tw4 = bufB + tc * ss;
   const int b = blockIdx.y, r0 = blockIdx.x * tc;
   p2_tw4(tw4, L1);
-  const float2* wk = work + (size_t)b * n + (size_t)r0 * L1;
+  const float2* wk = work + (size_t)b * m + (size_t)r0 * L1;
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
     const int rr = idx / L1, k1 = idx - rr * L1;
     bufA[rr * ss + k1] = wk[idx];
@@ -130,43 +136,62 @@ __global__ __launch_bounds__(256) void k_p2_inv_b(P2Geom g, const float2* __rest
   float* xb = x + (size_t)b * ldo;
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
     const int n1 = idx / tc, rr = idx - n1 * tc;
-    xb[(size_t)n1 * L2 + r0 + rr] = sc * r[rr * ss + n1].x;
+    const size_t j = (size_t)n1 * L2 + r0 + rr;
+    const float2 v = r[rr * ss + n1];
+    xb[2 * j] = sc * v.x;
+    xb[2 * j + 1] = sc * v.y;
   }
 }
-// ---- adjoint pass A: t = n1 L2 + n2 ; tile over n2 ; FFT over n1 ; work[k1][n2]
+
+// ---- forward pass A: j = n1 L2 + n2 ; z[j] = x[2j] + i x[2j+1] ; tile over n2 ; FFT over n1 ; work[k1][n2]
 __global__ __launch_bounds__(256) void k_p2_adj_a(P2Geom g, const float* __restrict__ gx, int ldo,
                                                   int T, float2* __restrict__ work) {
-  const int L1 = g.L1, L2 = g.L2, n = g.n, tc = L2 < P2_TC ? L2 : P2_TC, ss = L1 + 1;
+  const int L1 = g.L1, L2 = g.L2, m = g.m, tc = L2 < P2_TC ? L2 : P2_TC, ss = L1 + 1;
   float2* bufA = dyn_lds; float2* bufB = bufA + tc * ss; float2* tw4 = bufB + tc * ss;
   const int b = blockIdx.y, c0 = blockIdx.x * tc;
   p2_tw4(tw4, L1);
   const float* gb = gx + (size_t)b * ldo;
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
     const int n1 = idx / tc, cc = idx - n1 * tc;
-    const int t = n1 * L2 + c0 + cc;
-    bufA[cc * ss + n1] = make_float2(t < T ? gb[t] : 0.f, 0.f);     // zero padding beyond T
+    const int t = 2 * (n1 * L2 + c0 + cc);
+    bufA[cc * ss + n1] = make_float2(t < T ? gb[t] : 0.f, t + 1 < T ? gb[t + 1] : 0.f);    // zero padding beyond T
   }
   __syncthreads();
   float2* r = p2_fft(bufA, bufB, L1, tc, ss, false, tw4, L1);
-  float2* wk = work + (size_t)b * n;
+  float2* wk = work + (size_t)b * m;
   for (int idx = threadIdx.x; idx < tc * L1; idx += blockDim.x) {
     const int k1 = idx / tc, cc = idx - k1 * tc;
     const int n2 = c0 + cc;
-    const float2 w = p2_tw((int)(((long long)n2 * k1) & (n - 1)), n);
+    const float2 w = p2_tw((int)(((long long)n2 * k1) & (m - 1)), m);
     wk[(size_t)k1 * L2 + n2] = cmul(r[cc * ss + k1], w);
   }
 }
-// ---- adjoint pass B: rows k1 (tile), FFT over n2, gX[k1 + L1 k2] for k <= n/2
+
+// rows of tile q: with L1 <= P2_TC all rows; else the four rows 4q .. 4q+3 and their mirrors L1 - k1 (tile 0 holds
+// row 0, which mirrors onto itself, and takes row L1 / 2 -- the other self-mirrored row -- in the free slot)
+__device__ __forceinline__ int p2_tile_row(int L1, int q, int i) {
+  if (L1 <= P2_TC) return i;
+  if (i < 4) return 4 * q + i;
+  if (q == 0 && i == 7) return L1 / 2;
+  return L1 - 4 * q - 3 + (i - 4);
+}
+__device__ __forceinline__ int p2_tile_mirror(int L1, int q, int i, int k1) {
+  if (k1 == 0 || 2 * k1 == L1) return i;
+  if (L1 <= P2_TC) return L1 - k1;
+  return i < 4 ? 7 - i : 7 - i;             // rows[4 + j] = L1 - 4q - 3 + j mirrors rows[3 - j]
+}
+
+// ---- forward pass B: rows k1 (+ mirrors), FFT over n2, F[k1 + L1 k2] for k <= m
 __global__ __launch_bounds__(256) void k_p2_adj_b(P2Geom g, const float2* __restrict__ work,
                                                   float2* __restrict__ gX, int ldx, int plain) {
-  const int L1 = g.L1, L2 = g.L2, n = g.n, tc = L1 < P2_TC ? L1 : P2_TC, ss = L2 + 1;
+  const int L1 = g.L1, L2 = g.L2, n = g.n, m = g.m, tc = L1 < P2_TC ? L1 : P2_TC, ss = L2 + 1;
   float2* bufA = dyn_lds; float2* bufB = bufA + tc * ss; float2* tw4 = bufB + tc * ss;
-  const int b = blockIdx.y, r0 = blockIdx.x * tc;
+  const int b = blockIdx.y, q = blockIdx.x;
   p2_tw4(tw4, L2);
-  const float2* wk = work + (size_t)b * n + (size_t)r0 * L2;
+  const float2* wk = work + (size_t)b * m;
   for (int idx = threadIdx.x; idx < tc * L2; idx += blockDim.x) {
     const int rr = idx / L2, n2 = idx - rr * L2;
-    bufA[rr * ss + n2] = wk[idx];
+    bufA[rr * ss + n2] = wk[(size_t)p2_tile_row(L1, q, rr) * L2 + n2];
   }
   __syncthreads();
   float2* r = p2_fft(bufA, bufB, L2, tc, ss, false, tw4, L2);
@@ -174,23 +199,29 @@ __global__ __launch_bounds__(256) void k_p2_adj_b(P2Geom g, const float2* __rest
   const float sc = 1.0f / (float)n;
   for (int idx = threadIdx.x; idx < tc * L2; idx += blockDim.x) {
     const int k2 = idx / tc, rr = idx - k2 * tc;
-    const int k = r0 + rr + L1 * k2;
-    if (k <= n / 2) {
-      float2 v = r[rr * ss + k2];
-      if (!plain) {                                  // adjoint-of-irfft scaling
-        if (k == 0 || k == n / 2) v = make_float2(sc * v.x, 0.f);
-        else v = cscale(v, 2.0f * sc);
-      }
-      o[k] = v;
+    const int k1 = p2_tile_row(L1, q, rr);
+    const int k = k1 + L1 * k2;
+    const int rp = p2_tile_mirror(L1, q, rr, k1);
+    const int k2p = k1 == 0 ? (L2 - k2) & (L2 - 1) : L2 - 1 - k2;
+    const float2 zk = r[rr * ss + k2], zp = cconj(r[rp * ss + k2p]);
+    const float2 e = cadd(zk, zp), d = cmul(csub(zk, zp), p2_tw(k, n));      // (zk - zp) e^{-2 pi i k / n}
+    float2 v = make_float2(0.5f * (e.x + d.y), 0.5f * (e.y - d.x));           // 1/2 (e - i d)
+    if (!plain) {                                  // adjoint-of-irfft scaling
+      if (k == 0) v = make_float2(sc * v.x, 0.f);
+      else v = cscale(v, 2.0f * sc);
+    }
+    o[k] = v;
+    if (k == 0) {                                  // k = m (Nyquist): Re Zf[0] - Im Zf[0]
+      const float ny = zk.x - zk.y;
+      o[m] = make_float2(plain ? ny : sc * ny, 0.f);
     }
   }
 }
-
 static size_t p2_lds(int len, int tc) { return ((size_t)2 * tc * (len + 1) + (len >= 4 ? len / 4 : 1)) * sizeof(float2); }
 
 extern "C" size_t gfdn_irfft_pow2_work_bytes(int n, int batch) {
   if (n < 16 || (n & (n - 1)) || batch <= 0) return 0;
-  return (size_t)batch * n * sizeof(float2);
+  return (size_t)batch * n * sizeof(float2);       // (the half-length transform uses the first half)
 }
 
 extern "C" int gfdn_irfft_pow2_fwd(int n, const float* X, int ldx, int batch, float* x, int ldo,

@@ -181,7 +181,8 @@ def test_irfft_odd(ops, n, batch):
     assert rel_err(gX.cpu(), X.grad) < 5e-6
 
 
-@pytest.mark.parametrize("n,batch", [(512, 3), (8192, 2), (131072, 2), (16, 1)])
+@pytest.mark.parametrize("n,batch", [(512, 3), (8192, 2), (131072, 2), (16, 1), (32, 2), (64, 1), (128, 2), (256, 3),
+                                     (1024, 1), (262144, 1)])
 def test_irfft_pow2(ops, n, batch):
     torch.manual_seed(n)
     X = torch.randn(batch, n // 2 + 1, dtype=torch.complex128, requires_grad=True)
