@@ -1972,25 +1972,28 @@ extern "C" int gfdn_compose_sh_fwd(const float* Y, int K, int G, int nper, const
   return 0;
 }
 
-// Backward of the SH output stage in ONE pass over gH per tile of SH_TB bins (Y tile staged once, every gH element
-// loaded once):  gY[k][n] = c_n sum_b w[b][n] gH'[b][l(n)][k],  gc[n] = sum_k Re(conj(acc) ...),
-// gw[b][n] = c_n sum_k Re(conj(gH'[b][l][k]) Y[k][n])   (gH' = gH conj(filt)).  The sums over the bins are wave
-// reductions (per wave and (b, n) one LDS slot, no barrier inside the receiver loop); per-tile partials
-// [tile][(B + 1) N] (gw rows, then the gc row) are reduced by k_reduce_partials.
-// (Two kernels that looped over all receivers per (bin, line) and over all bins per (receiver, line), both with
-// 8 N-byte strided Y accesses, took 531 + 426 us.)
-__global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd(const float2* __restrict__ Y, int K, int G,
-                                                          int nper, const float* __restrict__ c,
-                                                          const float* __restrict__ w, int B,
-                                                          const float2* __restrict__ filt,
-                                                          const float2* __restrict__ gH,
-                                                          float2* __restrict__ gY,
-                                                          float* __restrict__ partial) {
+// Backward of the SH output stage (gH' = gH conj(filt)) in two launches, each reading gH once:
+//   k_compose_sh_bwd_y: thread per bin over a staged Y tile: gY[k][n] = c_n sum_b w[b][n] gH'[b][l(n)][k] (written
+//                       through the tile: linear stores) and per-tile partials of gc[n] = sum_k Re(acc conj Y);
+//   k_compose_sh_bwd_w: gw[b][n] = c_n sum_k Re(conj(gH'[b][l][k]) Y[k][n]) as a split-K product per SH channel l:
+//                       a workgroup stages (receivers x 64 bins) of gH' and (64 bins x G) of Y in LDS, thread (b, g)
+//                       accumulates its dot product over SH_KC bins; partials [chunk][b][n].
+// (The first version looped over all receivers per (bin, line) and over all bins per (receiver, line), both with
+// 8 N-byte strided Y accesses: 531 + 426 us; one fused pass with a wave reduction per (receiver, line): 524 us.)
+__global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd_y(const float2* __restrict__ Y, int K, int G,
+                                                            int nper, const float* __restrict__ c,
+                                                            const float* __restrict__ w, int B,
+                                                            const float2* __restrict__ filt,
+                                                            const float2* __restrict__ gH,
+                                                            float2* __restrict__ gY,
+                                                            float* __restrict__ gc_partial) {
   const int N = G * nper, NS = N + 1 + (N & 1);
   constexpr int NW = SH_TB / 64;
   float2* yt = compose_lds;                              // [SH_TB][NS]
-  float* sw = (float*)(yt + SH_TB * NS);                 // [B][N]
-  float* sg = sw + B * N;                                // [NW][(B + 1) N]: per-wave sums over the bins
+  float2* sgh = yt + SH_TB * NS;                         // [nper][SH_TB]
+  float* sw = (float*)(sgh + nper * SH_TB);              // [B][N]
+  float* sg = sw + B * N;                                // [NW][N]
+  int* lch = (int*)(sg + NW * N);                        // [N]: SH channel of line n
   const int k0 = blockIdx.x * SH_TB;
   const int nbin = K - k0 < SH_TB ? K - k0 : SH_TB;
   const size_t base = (size_t)k0 * N;
@@ -1999,6 +2002,7 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd(const float2* __restri
     yt[kq * NS + n] = e < nbin * N ? Y[base + e] : make_float2(0.f, 0.f);
   }
   for (int e = threadIdx.x; e < B * N; e += SH_TB) sw[e] = w[e];
+  for (int e = threadIdx.x; e < N; e += SH_TB) lch[e] = e % nper;
   __syncthreads();
   const int k = k0 + threadIdx.x;
   const bool valid = k < K;
@@ -2006,23 +2010,25 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd(const float2* __restri
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
   float2* yrow = yt + threadIdx.x * NS;
-  float* sgw = sg + (size_t)wv * (B + 1) * N;
   float2 acc[GFDN_MAX_SH_LINES];
 #pragma unroll
   for (int n = 0; n < GFDN_MAX_SH_LINES; ++n) acc[n] = make_float2(0.f, 0.f);
+  // per receiver: the thread's nper gradient values go to its own LDS column, then every line n (static register
+  // index) picks the value of its channel l(n) from there  (a register array indexed by l(n) would go to scratch;
+  // testing n % nper == l per (channel, line) cost 642 us)
   for (int b = 0; b < B; ++b) {
+    const float* swb = sw + b * N;
+    for (int l = 0; l < nper; ++l) {
+      float2 gh = valid ? gH[((size_t)b * nper + l) * K + kk] : make_float2(0.f, 0.f);
+      if (filt) gh = cmul(gh, fc);
+      sgh[l * SH_TB + threadIdx.x] = gh;
+    }
 #pragma unroll
     for (int n = 0; n < GFDN_MAX_SH_LINES; ++n) {
       if (n < N) {
-        const int l = n % nper;
-        float2 gh = valid ? gH[((size_t)b * nper + l) * K + kk] : make_float2(0.f, 0.f);   // (G loads of one line: L1)
-        if (filt) gh = cmul(gh, fc);
-        const float wb = sw[b * N + n];
-        acc[n].x += wb * gh.x;
-        acc[n].y += wb * gh.y;
-        const float2 y = yrow[n];
-        const float v = wave_sum(gh.x * y.x + gh.y * y.y);
-        if (lane == 0) sgw[b * N + n] = v;
+        const float2 gh = sgh[lch[n] * SH_TB + threadIdx.x];
+        acc[n].x += swb[n] * gh.x;
+        acc[n].y += swb[n] * gh.y;
       }
     }
   }
@@ -2031,17 +2037,16 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd(const float2* __restri
     if (n < N) {
       const float2 y = yrow[n];
       const float v = wave_sum(valid ? (acc[n].x * y.x + acc[n].y * y.y) : 0.f);
-      if (lane == 0) sgw[B * N + n] = v;
+      if (lane == 0) sg[wv * N + n] = v;
       yrow[n] = cscale(acc[n], c[n]);                    // gY through the tile: linear global writes below
     }
   }
   __syncthreads();
-  float* out = partial + (size_t)blockIdx.x * (B + 1) * N;
-  for (int e = threadIdx.x; e < (B + 1) * N; e += SH_TB) {
+  for (int e = threadIdx.x; e < N; e += SH_TB) {
     float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < NW; ++q) sum += sg[(size_t)q * (B + 1) * N + e];
-    out[e] = e < B * N ? sum * c[e % N] : sum;
+    for (int q = 0; q < NW; ++q) sum += sg[q * N + e];
+    gc_partial[(size_t)blockIdx.x * N + e] = sum;
   }
   for (int e = threadIdx.x; e < nbin * N; e += SH_TB) {
     const int kq = e / N, n = e - kq * N;
@@ -2049,8 +2054,59 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd(const float2* __restri
   }
 }
 
+#define SH_KT 64               // bins per staged sub-tile
+#define SH_KC 512              // bins per workgroup (partials: K / SH_KC per (b, n))
+__global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd_w(const float2* __restrict__ Y, int K, int G,
+                                                            int nper, const float* __restrict__ c, int B,
+                                                            const float2* __restrict__ filt,
+                                                            const float2* __restrict__ gH,
+                                                            float* __restrict__ partial) {
+  const int N = G * nper;
+  const int rb = SH_TB / G;                              // receivers per workgroup
+  float2* ta = compose_lds;                              // [rb][SH_KT + 1]
+  float2* ty = ta + rb * (SH_KT + 1);                    // [SH_KT][G]
+  const int l = blockIdx.y, b0 = blockIdx.z * rb;
+  const int nb = B - b0 < rb ? B - b0 : rb;
+  const int bb = threadIdx.x / G, g = threadIdx.x - bb * G;
+  const bool mine = bb < nb;
+  const int kbeg = blockIdx.x * SH_KC;
+  float acc = 0.f;
+  for (int ks = kbeg; ks < kbeg + SH_KC && ks < K; ks += SH_KT) {
+    for (int e = threadIdx.x; e < rb * SH_KT; e += SH_TB) {
+      const int r = e / SH_KT, kq = e - r * SH_KT;
+      const int k = ks + kq;
+      float2 v = make_float2(0.f, 0.f);
+      if (r < nb && k < K) {
+        v = gH[((size_t)(b0 + r) * nper + l) * K + k];
+        if (filt) v = cmul(v, cconj(filt[k]));
+      }
+      ta[r * (SH_KT + 1) + kq] = v;
+    }
+    for (int e = threadIdx.x; e < SH_KT * G; e += SH_TB) {
+      const int kq = e / G, gg = e - kq * G;
+      const int k = ks + kq;
+      ty[e] = k < K ? Y[(size_t)k * N + gg * nper + l] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    if (mine) {
+      const float2* ar = ta + bb * (SH_KT + 1);
+#pragma unroll 8
+      for (int kq = 0; kq < SH_KT; ++kq) {
+        const float2 a = ar[kq], y = ty[kq * G + g];
+        acc += a.x * y.x + a.y * y.y;
+      }
+    }
+    __syncthreads();
+  }
+  if (mine) {
+    const int n = g * nper + l;
+    partial[((size_t)blockIdx.x * B + b0 + bb) * N + n] = acc * c[n];
+  }
+}
+
 extern "C" size_t gfdn_compose_sh_bwd_work_bytes(int G, int nper, int B) {
-  return (size_t)GFDN_SH_MAX_TILES * (B + 1) * G * nper * sizeof(float);
+  // gw partials [K / SH_KC][B][N], then gc partials [K / SH_TB][N]
+  return ((size_t)(GFDN_SH_MAX_TILES * SH_TB / SH_KC) * B + GFDN_SH_MAX_TILES) * G * nper * sizeof(float);
 }
 
 extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const float* c,
@@ -2059,22 +2115,27 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
   if (!Y || !c || !w || !gH || !gY || !gc || !gw || !work) return GFDN_E_BADARG;
   if (K <= 0 || G <= 0 || nper <= 0 || B <= 0) return GFDN_E_BADARG;
   const int N = G * nper, NS = N + 1 + (N & 1);
-  const int ntiles = (K + SH_TB - 1) / SH_TB;
-  if (N > GFDN_MAX_SH_LINES || ntiles > GFDN_SH_MAX_TILES) return GFDN_E_UNSUPPORTED;
-  const size_t lds = (size_t)SH_TB * NS * sizeof(float2) +
-                     ((size_t)B * N + (size_t)(SH_TB / 64) * (B + 1) * N) * sizeof(float);
+  const int ntiles = (K + SH_TB - 1) / SH_TB, nchunks = (K + SH_KC - 1) / SH_KC;
+  if (N > GFDN_MAX_SH_LINES || G > SH_TB || ntiles > GFDN_SH_MAX_TILES) return GFDN_E_UNSUPPORTED;
+  const size_t lds = ((size_t)SH_TB * NS + (size_t)nper * SH_TB) * sizeof(float2) +
+                     ((size_t)B * N + (size_t)(SH_TB / 64) * N + N) * sizeof(float);
   if (lds > 160 * 1024) return GFDN_E_UNSUPPORTED;
-  int rc = ensure_dyn_lds(k_compose_sh_bwd, lds);
+  int rc = ensure_dyn_lds(k_compose_sh_bwd_y, lds);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  float* partial = (float*)work;
-  hipLaunchKernelGGL(k_compose_sh_bwd, dim3(ntiles), dim3(SH_TB), lds, s, (const float2*)Y, K, G, nper, c, w, B,
-                     (const float2*)filt, (const float2*)gH, (float2*)gY, partial);
+  float* gw_partial = (float*)work;
+  float* gc_partial = gw_partial + (size_t)nchunks * B * N;
+  hipLaunchKernelGGL(k_compose_sh_bwd_y, dim3(ntiles), dim3(SH_TB), lds, s, (const float2*)Y, K, G, nper, c, w, B,
+                     (const float2*)filt, (const float2*)gH, (float2*)gY, gc_partial);
   GFDN_LAUNCH_CHECK();
-  // partial[tile][(B + 1) N]: rows 0..B-1 -> gw (B, N), row B -> gc (N)
-  hipLaunchKernelGGL(k_reduce_partials, dim3(B * N), dim3(256), 0, s, partial, ntiles, (B + 1) * N, gw);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, gc_partial, ntiles, N, gc);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(N), dim3(256), 0, s, partial + (size_t)B * N, ntiles, (B + 1) * N, gc);
+  const int rb = SH_TB / G;
+  const size_t ldsw = ((size_t)rb * (SH_KT + 1) + (size_t)SH_KT * G) * sizeof(float2);
+  hipLaunchKernelGGL(k_compose_sh_bwd_w, dim3(nchunks, nper, (B + rb - 1) / rb), dim3(SH_TB), ldsw, s,
+                     (const float2*)Y, K, G, nper, c, B, (const float2*)filt, (const float2*)gH, gw_partial);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_partials, dim3(B * N), dim3(256), 0, s, gw_partial, nchunks, B * N, gw);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
