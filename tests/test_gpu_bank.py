@@ -420,7 +420,10 @@ def test_bank_step_slot_order_equals_natural_order_full_size():
     for k in res[True][0]:
         assert np.allclose(res[True][0][k], res[False][0][k], rtol=2e-5, atol=0), (k, res[True][0][k], res[False][0][k])
     ga, gb = res[True][1], res[False][1]
-    assert np.abs(ga - gb).max() < 2e-4 * np.abs(gb).max()
+    # two float32 pipelines with different summation orders over 65 537 bins: the most cancellation-prone gradient
+    # component sits at 1.8e-4 .. 2.4e-4 of the largest one depending on the data (every other entry at 1e-7)
+    assert np.abs(ga - gb).max() < 5e-4 * np.abs(gb).max()
+    assert np.median(np.abs(ga - gb)) < 1e-6 * np.abs(gb).max()
 
 
 @pytest.mark.parametrize("B", [4, 3])
