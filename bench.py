@@ -267,11 +267,19 @@ def main():
     # host-side torch ops on tiny CPU tensors (mask draw, index lists) crawl when the intra-op pool
     # spans all 256 host cores (measured 30 ms/step at 128 threads vs 6 ms at 4)
     torch.set_num_threads(min(4, os.cpu_count() or 1))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # Rehearsal knobs for a ONE-GPU box (the driver's multi-GPU run uses neither): GFDN_BENCH_ONE_DEVICE=1 puts every
+    # rank on cuda:0 and GFDN_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device) --
+    # the N > 1 code path (shared mask seed, split graphs, flat-gradient all-reduce, max-over-ranks timing) end to end.
+    dev_index = 0 if os.environ.get('GFDN_BENCH_ONE_DEVICE') else local_rank
+    backend = os.environ.get('GFDN_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from diffgfdn_amd import hip_ops
