@@ -243,6 +243,66 @@ __device__ __forceinline__ void block_scan_multi(float (&v)[EDC_S], float (&tot)
 }
 
 // running sums over j = 0..len-1 (index order) starting from `carry`; fn(j, inclusive_sum_j, value_j)
+// 16-byte accesses at 4-byte alignment (rows of odd length start on 8-byte boundaries only): four consecutive
+// pair samples / four consecutive floats per thread in two / one memory instructions
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void ld4_f2(const float2* p, float2 (&o)[4]) {
+  const f4u a = *(const f4u*)p, b = *(const f4u*)(p + 2);
+  o[0] = make_float2(a.x, a.y); o[1] = make_float2(a.z, a.w);
+  o[2] = make_float2(b.x, b.y); o[3] = make_float2(b.z, b.w);
+}
+__device__ __forceinline__ void st4_f2(float2* p, const float2 (&v)[4]) {
+  f4u a, b;
+  a.x = v[0].x; a.y = v[0].y; a.z = v[1].x; a.w = v[1].y;
+  b.x = v[2].x; b.y = v[2].y; b.z = v[3].x; b.w = v[3].y;
+  *(f4u*)p = a;
+  *(f4u*)(p + 2) = b;
+}
+__device__ __forceinline__ void ld4_f(const float* p, float (&o)[4]) {
+  const f4u a = *(const f4u*)p;
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+}
+__device__ __forceinline__ void st4_f(float* p, const float (&v)[4]) {
+  f4u a;
+  a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3];
+  *(f4u*)p = a;
+}
+
+// Group form of edc_scan: ``load(s, j0, nv, val)`` fills the EDC_V consecutive scan elements j0 .. j0 + 3 of sub-tile
+// s (nv of them inside the segment; it may also fetch whatever else ``fn`` needs for them into arrays of its own) and
+// ``fn(s, j0, nv, excl, val)`` receives the exclusive prefix in front of the group.  Every load of a tile is issued
+// before the block scan, four consecutive elements per thread as one 16-byte access; the running sums inside a
+// group are re-accumulated by ``fn`` in the same order instead of being kept in registers.
+template <typename L, typename F>
+__device__ __forceinline__ void edc_scan_v(int len, float carry, float* lds, L load, F fn) {
+  const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    float val[EDC_S][EDC_V], loc[EDC_S], tot[EDC_S], incl[EDC_S];
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      const int nv = len - j0 >= EDC_V ? EDC_V : (len > j0 ? len - j0 : 0);
+      load(s, j0, nv, val[s]);
+      float run = 0.f;
+#pragma unroll
+      for (int u = 0; u < EDC_V; ++u) run += val[s][u];
+      loc[s] = run;
+      incl[s] = run;
+    }
+    block_scan_multi(incl, tot, lds);
+    float base = carry;
+#pragma unroll
+    for (int s = 0; s < EDC_S; ++s) {
+      const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
+      const int nv = len - j0 >= EDC_V ? EDC_V : (len > j0 ? len - j0 : 0);
+      fn(s, j0, nv, base + incl[s] - loc[s], val[s]);
+      base += tot[s];
+    }
+    carry = base;
+    __syncthreads();     // lds is reused by the next iteration
+  }
+}
+
 template <typename G, typename F>
 __device__ __forceinline__ void edc_scan(int len, float carry, float* lds, G get, F fn) {
   const int ntiles = (len + EDC_TILE - 1) / EDC_TILE;
@@ -347,24 +407,66 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
   const float* mw = maskw ? maskw + s0 : nullptr;
   float* gw = gx ? gx + (size_t)b * ld + start + s0 : nullptr;
   float acc = 0.f, gacc = 0.f;
-  edc_scan(sl, later_segments(segsum, b, seg), s_scan,
-           [&](int j) { const float v = xw[sl - 1 - j]; return v * v; },
-           [&](int j, float edc, float) {
-             const int i = sl - 1 - j;
-             const float lin = fabsf(edc) + F32_EPS;
-             const float raw = 10.0f * log10f(lin);
-             const float d = fmaxf(raw, -200.0f);
-             const float diff = t[i] - d;
-             const float m = mw ? mw[i] : 1.0f;
-             acc += m * fabsf(diff);
-             if (gw) {
-               const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-               const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
-               const float g = -sg * dE * m * inv_count * gscale;   // dL/dEDC_i, staged in place
-               gw[i] = g;
-               gacc += g;
-             }
-           });
+  // suffix scan from the END of the segment: scan element j = sample sl - 1 - j
+  float tv[EDC_S][EDC_V];
+  edc_scan_v(sl, later_segments(segsum, b, seg), s_scan,
+             [&](int s, int j0, int nv, float (&val)[EDC_V]) {
+               const int ilo = sl - 1 - j0 - (EDC_V - 1);
+               if (nv == EDC_V) {
+                 float xv[4], t4[4];
+                 ld4_f(xw + ilo, xv);
+                 ld4_f(t + ilo, t4);
+#pragma unroll
+                 for (int u = 0; u < EDC_V; ++u) { val[u] = xv[3 - u] * xv[3 - u]; tv[s][u] = t4[3 - u]; }
+               } else {
+#pragma unroll
+                 for (int u = 0; u < EDC_V; ++u) {
+                   const int i = sl - 1 - j0 - u;
+                   const float v = u < nv ? xw[i] : 0.f;
+                   val[u] = v * v;
+                   tv[s][u] = u < nv ? t[i] : 0.f;
+                 }
+               }
+             },
+             [&](int s, int j0, int nv, float excl, const float (&val)[EDC_V]) {
+               const int ilo = sl - 1 - j0 - (EDC_V - 1);
+               float m4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+               if (mw) {
+                 if (nv == EDC_V) ld4_f(mw + ilo, m4);
+                 else {
+#pragma unroll
+                   for (int u = 0; u < EDC_V; ++u) m4[u] = ilo + u >= 0 ? mw[ilo + u] : 0.f;
+                 }
+               }
+               float gq[4] = {0.f, 0.f, 0.f, 0.f};
+               float run = 0.f;
+#pragma unroll
+               for (int u = 0; u < EDC_V; ++u) {
+                 run += val[u];
+                 if (u < nv) {
+                   const float edc = excl + run;
+                   const float lin = fabsf(edc) + F32_EPS;
+                   const float raw = 10.0f * log10f(lin);
+                   const float d = fmaxf(raw, -200.0f);
+                   const float diff = tv[s][u] - d;
+                   const float m = m4[EDC_V - 1 - u];
+                   acc += m * fabsf(diff);
+                   const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+                   const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+                   const float g = -sg * dE * m * inv_count * gscale;   // dL/dEDC_i, staged in place
+                   gq[EDC_V - 1 - u] = g;
+                   gacc += g;
+                 }
+               }
+               if (gw) {
+                 if (nv == EDC_V) st4_f(gw + ilo, gq);
+                 else {
+#pragma unroll
+                   for (int u = 0; u < EDC_V; ++u) if (ilo + u >= 0) gw[ilo + u] = gq[u];
+                 }
+               }
+             });
+  if (!gw) gacc = 0.f;
   acc = block_sum(acc, s_red);
   gacc = block_sum(gacc, s_red);
   if (threadIdx.x == 0) {
@@ -395,8 +497,34 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_bwd(const float* __rest
   float carry = 0.f;
   for (int s2 = 0; s2 < seg; ++s2) carry += gsum[b * EDC_NSEG + s2];
   // EDC_i = sum_{j >= i} x_j^2  =>  dL/dx_j = 2 x_j sum_{i <= j} dL/dEDC_i   (forward prefix scan)
-  edc_scan(sl, carry, s_scan, [&](int i) { return gw[i]; },
-           [&](int i, float cum, float) { gw[i] = 2.0f * xw[i] * cum; });
+  float xs[EDC_S][EDC_V];
+  edc_scan_v(sl, carry, s_scan,
+             [&](int s, int j0, int nv, float (&val)[EDC_V]) {
+               if (nv == EDC_V) {
+                 ld4_f(gw + j0, val);
+                 ld4_f(xw + j0, xs[s]);
+               } else {
+#pragma unroll
+                 for (int u = 0; u < EDC_V; ++u) {
+                   val[u] = u < nv ? gw[j0 + u] : 0.f;
+                   xs[s][u] = u < nv ? xw[j0 + u] : 0.f;
+                 }
+               }
+             },
+             [&](int s, int j0, int nv, float excl, const float (&val)[EDC_V]) {
+               float out[4];
+               float run = 0.f;
+#pragma unroll
+               for (int u = 0; u < EDC_V; ++u) {
+                 run += val[u];
+                 out[u] = 2.0f * xs[s][u] * (excl + run);
+               }
+               if (nv == EDC_V) st4_f(gw + j0, out);
+               else {
+#pragma unroll
+                 for (int u = 0; u < EDC_V; ++u) if (u < nv) gw[j0 + u] = out[u];
+               }
+             });
   // zeros outside the window
   float* g = gx + (size_t)b * ld;
   if (seg == 0)
@@ -456,26 +584,6 @@ __device__ __forceinline__ float block_sum2(float2& v, float* lds /* >= 32 float
   for (int i = 0; i < nw; ++i) { sx += lds[i]; sy += lds[16 + i]; }
   v = make_float2(sx, sy);
   return sx;
-}
-
-// 16-byte accesses at 4-byte alignment (rows of odd length start on 8-byte boundaries only): four consecutive
-// pair samples / four consecutive floats per thread in two / one memory instructions
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ void ld4_f2(const float2* p, float2 (&o)[4]) {
-  const f4u a = *(const f4u*)p, b = *(const f4u*)(p + 2);
-  o[0] = make_float2(a.x, a.y); o[1] = make_float2(a.z, a.w);
-  o[2] = make_float2(b.x, b.y); o[3] = make_float2(b.z, b.w);
-}
-__device__ __forceinline__ void st4_f2(float2* p, const float2 (&v)[4]) {
-  f4u a, b;
-  a.x = v[0].x; a.y = v[0].y; a.z = v[1].x; a.w = v[1].y;
-  b.x = v[2].x; b.y = v[2].y; b.z = v[3].x; b.w = v[3].y;
-  *(f4u*)p = a;
-  *(f4u*)(p + 2) = b;
-}
-__device__ __forceinline__ void ld4_f(const float* p, float (&o)[4]) {
-  const f4u a = *(const f4u*)p;
-  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
 }
 
 // work layout (items padded to 2 * pairs): segsum[I][NSEG] | partial[I][NSEG] | gsum[I][NSEG]
