@@ -737,7 +737,8 @@ def test_svf_grid_trainer_steps():
     assert all(np.isfinite(vals)) and vals[-1] < vals[0]
 
 
-@pytest.mark.parametrize("G,nper,K", [(2, 2, 33), (3, 4, 257), (3, 5, 100), (4, 4, 1025), (8, 4, 77)])
+@pytest.mark.parametrize("G,nper,K", [(2, 2, 33), (3, 4, 257), (3, 5, 100), (4, 4, 1025), (8, 4, 77), (4, 4, 20001),
+                                      (2, 4, 9000)])
 def test_filter_coupling_solve_kernels(G, nper, K):
     """gfdn_solve_phi_fwd / _bwd (frequency-dependent feedback matrix A(z_k) = BM o kron(Phi_k, 1)) against
     torch.linalg.solve in complex128 and its autograd gradients."""
