@@ -31,6 +31,7 @@ SIGNATURES = {
     "gfdn_solve_phi_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_solve_phi_bwd_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_solve_phi_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_svf_coefficients": (c_int, [_P, _P, ctypes.c_double, c_int, c_int, _P, _P, _P]),
     "gfdn_sos_response": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_sos_compose_fwd": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_sos_compose_bwd_chunks": (c_int, [c_int, c_int, _P, _P]),

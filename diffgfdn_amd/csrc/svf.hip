@@ -246,3 +246,76 @@ extern "C" int gfdn_sos_compose_bwd(const float* coef, int B, int G, int S, cons
   GFDN_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// SVF parameters -> biquad coefficients (gain_filters.py:327-330 scaled sigmoids, :36-103 SVF mixing coefficients,
+// :117-151 BiquadCascade.from_svf_coeffs), one thread per (cascade, section); the torch expression of the same map
+// is ~40 elementwise launches forward and ~80 backward on (B, G, 11) tensors.
+//   R = 1e-6 + (1 - 1e-6) sigmoid(r0),  Gn = 10^((-6 + 12 sigmoid(r1)) / 20)
+//   section 0: low shelf (m_lp = Gn, m_bp = 2 R sqrt Gn), last: high shelf (m_hp = Gn, m_bp = 2 R sqrt Gn),
+//   others: peaking (m_bp = 2 R Gn);  b = [f^2 m_lp + f m_bp + m_hp, (2 f^2 m_lp - 2 m_hp) p, (f^2 m_lp - f m_bp + m_hp) p^2],
+//   a = [f^2 + 2 R f + 1, (2 f^2 - 2) p, (f^2 - 2 R f + 1) p^2]   (f: normalised cut-off, p: pole compression factor)
+// evaluated in float64 like the reference (float64 cut-offs times float32 parameters) and stored as float32.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void svf_terms(const float* raw, double f, double p, int s, int S, double (&c)[6],
+                                          double (&dR)[6], double (&dG)[6], double& R_r0, double& G_r1) {
+  const double e0 = 1.0 / (1.0 + exp(-(double)raw[0])), e1 = 1.0 / (1.0 + exp(-(double)raw[1]));
+  // the reference forms R and G in float32 (sigmoid outputs of the float32 network), then promotes
+  const double R = (double)(float)(1e-6 + (1.0 - 1e-6) * e0);
+  const double Gn = (double)(float)pow(10.0, (-6.0 + 12.0 * e1) * 0.05);
+  R_r0 = (1.0 - 1e-6) * e0 * (1.0 - e0);
+  G_r1 = Gn * 2.302585092994046 * 0.05 * 12.0 * e1 * (1.0 - e1);
+  const bool low = s == 0, high = s == S - 1;
+  const double sq = sqrt(Gn);
+  const double m_lp = low ? Gn : 1.0, m_hp = high ? Gn : 1.0;
+  const double m_bp = (low || high) ? 2.0 * R * sq : 2.0 * R * Gn;
+  const double dlp_dG = low ? 1.0 : 0.0, dhp_dG = high ? 1.0 : 0.0;
+  const double dbp_dR = (low || high) ? 2.0 * sq : 2.0 * Gn;
+  const double dbp_dG = (low || high) ? R / sq : 2.0 * R;
+  const double f2 = f * f, p2 = p * p;
+  c[0] = f2 * m_lp + f * m_bp + m_hp;
+  c[1] = (2.0 * f2 * m_lp - 2.0 * m_hp) * p;
+  c[2] = (f2 * m_lp - f * m_bp + m_hp) * p2;
+  c[3] = f2 + 2.0 * R * f + 1.0;
+  c[4] = (2.0 * f2 - 2.0) * p;
+  c[5] = (f2 - 2.0 * R * f + 1.0) * p2;
+  dR[0] = f * dbp_dR;  dR[1] = 0.0;  dR[2] = -f * dbp_dR * p2;  dR[3] = 2.0 * f;  dR[4] = 0.0;  dR[5] = -2.0 * f * p2;
+  dG[0] = f2 * dlp_dG + f * dbp_dG + dhp_dG;
+  dG[1] = (2.0 * f2 * dlp_dG - 2.0 * dhp_dG) * p;
+  dG[2] = (f2 * dlp_dG - f * dbp_dG + dhp_dG) * p2;
+  dG[3] = dG[4] = dG[5] = 0.0;
+}
+
+// raw (R, S, 2) -> coef (R, S, 6);  with gcoef: graw (R, S, 2) instead
+__global__ __launch_bounds__(256) void k_svf_coef(const float* __restrict__ raw, const double* __restrict__ cutoff,
+                                                  double cpf, int R, int S, const float* __restrict__ gcoef,
+                                                  float* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * S) return;
+  const int s = e % S;
+  double c[6], dR[6], dG[6], R_r0, G_r1;
+  svf_terms(raw + 2 * (size_t)e, cutoff[s], cpf, s, S, c, dR, dG, R_r0, G_r1);
+  if (!gcoef) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[6 * (size_t)e + j] = (float)c[j];
+  } else {
+    double gR = 0.0, gG = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double g = (double)gcoef[6 * (size_t)e + j];
+      gR += g * dR[j];
+      gG += g * dG[j];
+    }
+    out[2 * (size_t)e] = (float)(gR * R_r0);
+    out[2 * (size_t)e + 1] = (float)(gG * G_r1);
+  }
+}
+
+extern "C" int gfdn_svf_coefficients(const float* raw, const double* cutoff, double compress_pole_factor, int R, int S,
+                                     const float* gcoef, float* out, void* stream) {
+  if (!raw || !cutoff || !out || R <= 0 || S <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_svf_coef, dim3((R * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, cutoff,
+                     compress_pole_factor, R, S, gcoef, out);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

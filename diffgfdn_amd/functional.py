@@ -152,6 +152,22 @@ class ResolventSolveFilter(torch.autograd.Function):
         return gBM.to(BM.dtype), gPhi, gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None
 
 
+class SvfCoefficients(torch.autograd.Function):
+    """Unconstrained SVF parameters (..., S, 2) -> biquad coefficients (..., S, 6) in one launch each way
+    (gain_filters.py:327-330, :36-103, :117-151)."""
+
+    @staticmethod
+    def forward(ctx, raw, cutoff, compress_pole_factor: float):
+        ctx.save_for_backward(raw, cutoff)
+        ctx.cpf = compress_pole_factor
+        return ops.svf_coefficients(raw, cutoff, compress_pole_factor)
+
+    @staticmethod
+    def backward(ctx, gcoef):
+        raw, cutoff = ctx.saved_tensors
+        return ops.svf_coefficients(raw, cutoff, ctx.cpf, gcoef.contiguous()).to(raw.dtype), None, None
+
+
 class SosOutputStage(torch.autograd.Function):
     """H[b][k] = sum_g cascade_{b,g}(z_k) T[k][g] + direct[b][k]: second-order-section cascades (SVF output filters,
     gain_filters.py:221-241, :262-402) contracted with the group transfer functions (model.py:588-619) in one

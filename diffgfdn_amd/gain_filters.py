@@ -34,7 +34,12 @@ def svf_biquad_coefficients(cutoff: torch.Tensor, raw_params: torch.Tensor,
     sigmoids (resonance in (1e-6, 1), gain in (-6, 6) dB; gain_filters.py:327-330, model.py:733-737); section 0 is
     a low shelf, the last a high shelf, the others peaking (gain_filters.py:372-380); SVF -> biquad as
     ``BiquadCascade.from_svf_coeffs`` (:117-151, mixing coefficients of ``SVF.__post_init__`` :36-103).  Formed as
-    the reference does -- float64 cut-offs times float32 parameters -- and stored as float32."""
+    the reference does -- float64 cut-offs times float32 parameters -- and stored as float32.  Device tensors go
+    through one HIP launch each way (csrc/svf.hip); the torch expression below is the CPU / reference form."""
+    if raw_params.is_cuda and raw_params.dtype == torch.float32:
+        from .functional import SvfCoefficients
+        return SvfCoefficients.apply(raw_params.contiguous(), cutoff.to(raw_params.device).to(torch.float64),
+                                     1.0 if compress_pole_factor is None else float(compress_pole_factor))
     dev = raw_params.device
     S = raw_params.shape[-2]
     R = 1e-6 + (1.0 - 1e-6) * torch.sigmoid(raw_params[..., 0])

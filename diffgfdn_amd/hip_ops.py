@@ -184,6 +184,28 @@ def _z128(z: torch.Tensor) -> torch.Tensor:
     return z.detach().to(torch.complex128).contiguous()
 
 
+def svf_coefficients(raw, cutoff, compress_pole_factor: float, gcoef=None) -> torch.Tensor:
+    """raw (..., S, 2) f32 unconstrained SVF parameters, cutoff (S,) float64 -> biquad coefficients (..., S, 6) f32;
+    with ``gcoef`` (..., S, 6): the gradient with respect to raw instead."""
+    _need_gpu(raw, cutoff)
+    raw = _f(raw)
+    cutoff = _f64(cutoff)
+    S = raw.shape[-2]
+    R = raw.numel() // (2 * S)
+    if raw.shape[-1] != 2 or cutoff.numel() != S:
+        raise RuntimeError("svf_coefficients: raw (..., S, 2), cutoff (S,)")
+    if gcoef is not None:
+        gcoef = _f(gcoef)
+        if tuple(gcoef.shape) != tuple(raw.shape[:-1]) + (6,):
+            raise RuntimeError("svf_coefficients: gcoef must be (..., S, 6)")
+        out = torch.empty_like(raw)
+    else:
+        out = torch.empty(tuple(raw.shape[:-1]) + (6,), dtype=_f32, device=raw.device)
+    _lib.check(_lib.load().gfdn_svf_coefficients(_p(raw), _p(cutoff), float(compress_pole_factor), R, S, _p(gcoef),
+                                                 _p(out), _stream()), "gfdn_svf_coefficients")
+    return out
+
+
 def sos_response(coef, z) -> torch.Tensor:
     """coef (R, S, 6) f32 [b0 b1 b2 a0 a1 a2], z (K,) complex -> (R, K) complex64 responses of the R cascades
     (sections in float64, rounded to complex64, running product in complex64)."""

@@ -126,6 +126,11 @@ int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, in
  *                         G <= 8; T (K, G) c64 = group transfer functions; direct (B, ldd) c64 or NULL)
  *   gfdn_sos_compose_bwd: gT_partial (t_chunks, K, G) c64 and gcoef_partial (B G, c_chunks, S, 6) f32, to be
  *                         summed over their chunk axis (chunk counts from gfdn_sos_compose_bwd_chunks)          */
+/* SVF parameters -> biquad coefficients (gain_filters.py:327-330, :36-103, :117-151): raw (R, S, 2) unconstrained
+ * [resonance, gain] per section, cutoff (S) float64 normalised cut-offs; gcoef == NULL: out = coef (R, S, 6);
+ * else out = d<gcoef, coef>/draw (R, S, 2).                                                                  */
+int gfdn_svf_coefficients(const float* raw, const double* cutoff, double compress_pole_factor, int R, int S,
+                          const float* gcoef, float* out, void* stream);
 int gfdn_sos_response(const float* coef, int R, int S, const double* z_c128, int K, float* out_c64, void* stream);
 int gfdn_sos_compose_fwd(const float* coef, int B, int G, int S, const double* z_c128, int K, const float* T_c64,
                          const float* direct_c64, int ldd, float* H_c64, void* stream);

@@ -447,3 +447,21 @@ def test_sos_cascade_kernels(ops, B, G, S, K):
     assert rel_err(ck.grad.cpu(), cr.grad.cpu()) < 1e-4
     H0 = SosOutputStage.apply(coef, T, None, z)
     assert rel_err(H0.cpu(), (Href - direct).detach().cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("shape,S,cpf", [((5, 4), 11, 0.98), ((3,), 11, 1.0), ((2, 2), 4, 0.9)])
+def test_svf_coefficient_kernel(ops, shape, S, cpf):
+    """gfdn_svf_coefficients (SVF parameters -> biquad coefficients, and the adjoint) against the torch expression
+    of the same map on the CPU and its autograd gradient."""
+    from diffgfdn_amd.gain_filters import svf_biquad_coefficients, svf_cutoff_frequencies
+    g = torch.Generator().manual_seed(S + len(shape))
+    cut = svf_cutoff_frequencies(32000.0)[:S]
+    raw = (torch.randn(*shape, S, 2, generator=g) * 1.5).requires_grad_(True)
+    want = svf_biquad_coefficients(cut, raw, cpf)                       # CPU tensors: torch expression
+    wgt = torch.randn(want.shape, generator=g)
+    (want * wgt).sum().backward()
+    rk = raw.detach().to(DEV).requires_grad_(True)
+    got = svf_biquad_coefficients(cut, rk, cpf)                         # device tensors: the kernel
+    assert rel_err(got.detach().cpu(), want.detach()) < 1e-6
+    (got * wgt.to(DEV)).sum().backward()
+    assert rel_err(rk.grad.cpu(), raw.grad) < 1e-5
