@@ -109,7 +109,8 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
   for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
     float raw = bout[g];
     for (int i = 0; i < H; ++i) raw += Wout[(size_t)g * H + i] * a[i];
-    gains[(size_t)b * d.G + g] = d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw)));
+    // hi <= lo: no output activation (the SVF network hands its raw outputs to the SVF -> biquad map)
+    gains[(size_t)b * d.G + g] = d.hi > d.lo ? d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw))) : raw;
   }
   if (d.stage) {
     for (int p = threadIdx.x; p < d.nl * H; p += blockDim.x) xout[p] = xs[p];
@@ -150,8 +151,12 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
   }
   // output layer
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    const float sg = (gains[(size_t)b * G + g] - d.lo) / (d.hi - d.lo);
-    draw[g] = ggains[(size_t)b * G + g] * (d.hi - d.lo) * sg * (1.0f - sg);
+    if (d.hi > d.lo) {
+      const float sg = (gains[(size_t)b * G + g] - d.lo) / (d.hi - d.lo);
+      draw[g] = ggains[(size_t)b * G + g] * (d.hi - d.lo) * sg * (1.0f - sg);
+    } else {
+      draw[g] = ggains[(size_t)b * G + g];
+    }
   }
   {
     const int l = d.nl - 1;

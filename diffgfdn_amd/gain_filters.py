@@ -115,16 +115,40 @@ class SVF_from_MLP(nn.Module):
         self.register_buffer('svf_cutoff_freqs', svf_cutoff_frequencies(sample_rate), persistent=False)
         self.num_biquads = len(self.svf_cutoff_freqs)
         self.encoder = SinusoidalEncoding(num_fourier_features)
+        self._freq_pi = None
         self.mlp = MLP(3 * num_fourier_features * 2, num_hidden_layers, num_neurons, num_groups,
                        self.num_biquads, num_params=2)
 
-    def biquad_coefficients(self, x: Dict) -> torch.Tensor:
-        """(B, G, S, 6) float32 biquad coefficients of the cascades at the batch's positions."""
+    def _fused_ok(self, position: torch.Tensor) -> bool:
+        lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
+        H = lin[0].out_features
+        return (position.is_cuda and position.shape[-1] == 3 and lin[0].weight.is_cuda
+                and lin[0].weight.dtype == torch.float32 and H <= 256 and lin[-1].out_features <= 256
+                and all(m.out_features == H for m in lin[:-1]))
+
+    def raw_parameters(self, x: Dict) -> torch.Tensor:
+        """(B, G, S, 2) unconstrained [resonance, gain] per section from the network.  On the GPU encoding and MLP
+        run as the fused kernel of csrc/mlp.hip (no output activation); the torch modules are the same network."""
         # NB the reference feeds the RAW listener position here (:340-342), not the normalised one
         position = x['listener_position'] if self.position_type == "output_gains" else x['source_position']
         w = self.mlp.model[0].weight
-        enc = self.encoder(position.to(w.device))
-        self.svf_params = self.mlp(enc.to(w.dtype))                             # (B, G, S, 2) raw
+        position = position.to(w.device)
+        if self._fused_ok(position):
+            from .functional import MlpGains
+            lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
+            if self._freq_pi is None or self._freq_pi.device != position.device:
+                n = self.encoder.num_fourier_features
+                f = torch.exp(torch.linspace(math.log(1.0), math.log(32.0), n, device=position.device))
+                self._freq_pi = (f * math.pi).contiguous()
+            params = [p for m in self.mlp.model for p in m.parameters()]
+            raw = MlpGains.apply(position.to(torch.float64).contiguous(), None, self._freq_pi, lin[0].out_features,
+                                 len(lin) - 2, lin[-1].out_features, 0.0, 0.0, *params)
+            return raw.view(position.shape[0], self.num_groups, self.num_biquads, 2)
+        return self.mlp(self.encoder(position).to(w.dtype))
+
+    def biquad_coefficients(self, x: Dict) -> torch.Tensor:
+        """(B, G, S, 6) float32 biquad coefficients of the cascades at the batch's positions."""
+        self.svf_params = self.raw_parameters(x)                                # (B, G, S, 2) raw
         return svf_biquad_coefficients(self.svf_cutoff_freqs, self.svf_params, self.compress_pole_factor)
 
     def group_responses(self, x: Dict) -> torch.Tensor:

@@ -465,3 +465,25 @@ def test_svf_coefficient_kernel(ops, shape, S, cpf):
     assert rel_err(got.detach().cpu(), want.detach()) < 1e-6
     (got * wgt.to(DEV)).sum().backward()
     assert rel_err(rk.grad.cpu(), raw.grad) < 1e-5
+
+
+def test_svf_network_on_fused_mlp_kernel():
+    """SVF_from_MLP.raw_parameters on the device (fused encoding + MLP kernel, no output activation) against the
+    same torch modules on the CPU, values and parameter gradients."""
+    import copy
+    from diffgfdn_amd.gain_filters import SVF_from_MLP
+    torch.manual_seed(9)
+    net = SVF_from_MLP(32000.0, 3, 4, num_fourier_features=6, num_hidden_layers=3, num_neurons=16,
+                       compress_pole_factor=0.98)
+    ref = copy.deepcopy(net)
+    net = net.to(DEV)
+    pos = torch.rand(7, 3, dtype=torch.float64) * 6.0
+    want = ref.raw_parameters({'listener_position': pos})
+    got = net.raw_parameters({'listener_position': pos.to(DEV)})
+    assert got.shape == want.shape == (7, 3, 11, 2)
+    assert rel_err(got.detach().cpu(), want.detach()) < 2e-5
+    wgt = torch.randn(want.shape)
+    (want * wgt).sum().backward()
+    (got * wgt.to(DEV)).sum().backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < 2e-4, k
