@@ -258,6 +258,11 @@ class Trainer:
             if self.early_stop == self.patience:
                 break
         self.train_time = time.time() - st
+        if save_irs:                       # reference :429-449: the trained IRs of both splits as wav files
+            for split, prefix in ((train_dataset, "ir"), (valid_dataset, "valid_ir")):
+                for data in split:
+                    self.save_ir(data, directory=self.ir_dir, src_pos=data['source_position'],
+                                 rec_pos=data['listener_position'], filename_prefix=prefix)
 
 
 
@@ -456,8 +461,12 @@ class VarReceiverPosTrainer(Trainer):
         return sum(losses.values()), losses
 
     @torch.no_grad()
-    def save_ir(self, input_features: Dict, norm: bool = True):
-        """Impulse responses of one batch (reference :503-564 minus the wav writing): h (B, nfft)."""
+    def save_ir(self, input_features: Dict, directory: Optional[str] = None, src_pos: Optional[torch.Tensor] = None,
+                rec_pos: Optional[torch.Tensor] = None, filename_prefix: str = "ir", norm: bool = True):
+        """Impulse responses of one batch (reference :503-564): h = irfft(H) on the device, the pole-radius
+        envelope undone, optional peak normalisation; with ``directory`` one 32-bit float stereo wav (h, h) per
+        receiver, named like the reference's files, and the reference's return value (H or (H, H_sub_fdn));
+        without it nothing is written and (H, h (B, nfft)) comes back."""
         out = get_response(input_features, self.net)
         h = out[-1]
         if self.reduced_pole_radius is not None and self.reduced_pole_radius != 1.0:
@@ -465,7 +474,26 @@ class VarReceiverPosTrainer(Trainer):
                               torch.arange(h.shape[-1], device=h.device))
         if norm:
             h = h / torch.max(torch.abs(h))
-        return out[0], h
+        if directory is None:
+            return out[0], h
+        from scipy.io import wavfile            # (torchaudio.save in the reference; host side either way)
+        os.makedirs(directory, exist_ok=True)
+        rec_pos = input_features['listener_position'] if rec_pos is None else rec_pos
+        src_pos = input_features['source_position'] if src_pos is None else src_pos
+        rec_pos, src_pos = rec_pos.detach().cpu(), src_pos.detach().cpu()
+        num_src = 1 if src_pos.ndim == 1 or bool(torch.all(src_pos == src_pos[0])) else src_pos.shape[0]
+        hc = h.detach().to(torch.float32).cpu().numpy()
+        fs = int(self.net.sample_rate)
+        for s_ in range(num_src):
+            for r in range(rec_pos.shape[0]):
+                if num_src == 1:
+                    name = (f'{filename_prefix}_({rec_pos[r, 0]:.2f}, {rec_pos[r, 1]:.2f}, {rec_pos[r, 2]:.2f}).wav')
+                else:
+                    name = (f'{filename_prefix}_src_pos=({src_pos[s_, 0]:.2f}, {src_pos[s_, 1]:.2f}, '
+                            f'{src_pos[s_, 2]:.2f})_rec_pos=({rec_pos[r, 0]:.2f}, {rec_pos[r, 1]:.2f}, '
+                            f'{rec_pos[r, 2]:.2f}).wav')
+                wavfile.write(os.path.join(str(directory), name), fs, np.stack((hc[r], hc[r]), axis=1))
+        return (out[0], out[1]) if self.use_colorless_loss else out[0]
 
 
 class DirectionalFDNVarReceiverPosTrainer(Trainer):

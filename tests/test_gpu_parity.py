@@ -916,3 +916,29 @@ def test_svf_graphed_step_equals_eager_step():
         assert abs(a - b) < 1e-5 * abs(a), (t0, t1)
     for k in s0:
         assert rel_err(s1[k], s0[k]) < 5e-4, k
+
+
+def test_save_ir_writes_reference_named_wavs(tmp_path):
+    """VarReceiverPosTrainer.save_ir (trainer.py:503-564): h = irfft(H) per receiver as 32-bit float stereo wav files
+    with the reference's file names; the samples equal torch.fft.irfft of the returned response."""
+    from scipy.io import wavfile
+    from diffgfdn_amd.config import TrainerConfig
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    fx = load("f234_n12_k257.npz")
+    net = _grid_model(fx)
+    tc = TrainerConfig(batch_size=4, num_freq_bins=int(fx["nfft"]), use_colorless_loss=True, train_dir=str(tmp_path / "t"),
+                       ir_dir=str(tmp_path / "ir"), device="cuda")
+    tr = VarReceiverPosTrainer(net, tc, stft_win=int(fx["win"]))
+    batch = _to_dev(batch_from(fx))
+    H, Hsub = tr.save_ir(batch, directory=str(tmp_path / "ir"), src_pos=batch["source_position"],
+                         rec_pos=batch["listener_position"], norm=False)
+    rec = batch["listener_position"].cpu()
+    want = torch.fft.irfft(H.detach().cpu().to(torch.complex128)).numpy()
+    for r in range(rec.shape[0]):
+        name = f'ir_({rec[r, 0]:.2f}, {rec[r, 1]:.2f}, {rec[r, 2]:.2f}).wav'
+        fs, data = wavfile.read(str(tmp_path / "ir" / name))
+        assert fs == int(fx["fs"]) and data.dtype == np.float32 and data.shape == (want.shape[1], 2)
+        assert np.array_equal(data[:, 0], data[:, 1])
+        assert rel_err(data[:, 0], want[r]) < 1e-5
+    H2, h = tr.save_ir(batch, norm=True)                      # nothing written: (H, h)
+    assert abs(float(h.abs().max()) - 1.0) < 1e-6 and rel_err(H2.cpu(), H.cpu()) == 0.0
