@@ -174,6 +174,21 @@ class ColorlessFDNTrainer:
                 break
         self.train_time = time.time() - st
 
+    @torch.no_grad()
+    def save_ir(self, directory: str, filename: str = 'colorless_fdn_ir.wav', norm: bool = False):
+        """Impulse response of the prototype on the trainer's grid as a 32-bit float stereo wav (reference :146-160).
+        An export utility: the grid has 2 fs points, so the inverse transform (length 2 (K - 1), neither of the
+        training path's two lengths) is the library's."""
+        from scipy.io import wavfile
+        H, _ = self.net(self.z)
+        h = torch.fft.irfft(H)
+        if norm:
+            h = h / torch.max(torch.abs(h))
+        os.makedirs(directory, exist_ok=True)
+        hc = h.to(torch.float32).cpu().numpy()
+        wavfile.write(os.path.join(directory, filename), int(self.net.sample_rate), np.stack((hc, hc), axis=1))
+        return h
+
     def save_model(self, e: int):
         d = os.path.join(self.train_dir, 'checkpoints')
         os.makedirs(d, exist_ok=True)

@@ -637,6 +637,11 @@ def test_f9_colorless_fdn_prototype(tmp_path):
     tr = ColorlessFDNTrainer(net2, tc, alpha=1.5, lr=0.01, max_epochs=3, batch_size=600)
     assert rel_err(net2.input_gains.detach().cpu().numpy(), fx["norm_input_gains"]) < 1e-3
     assert rel_err(net2.output_gains.detach().cpu().numpy(), fx["norm_output_gains"]) < 1e-3
+    from scipy.io import wavfile
+    h = tr.save_ir(str(tmp_path / "ir"))
+    fs_w, data = wavfile.read(str(tmp_path / "ir" / "colorless_fdn_ir.wav"))
+    assert fs_w == int(fx["fs"]) and data.dtype == np.float32 and data.shape == (h.numel(), 2)
+    assert np.array_equal(data[:, 0], h.float().cpu().numpy())
     ds = ColorlessFDNDataset(1200, DEV)
     batches = [(ds.input[i:i + 300], ds.labels[i:i + 300]) for i in range(0, 1200, 300)]
     tr.train(batches[:3], batches[3:])
