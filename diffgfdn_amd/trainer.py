@@ -47,6 +47,27 @@ def get_response(x, net, output_scalars=None):
     return H, irfft_like_torch(H)
 
 
+def ir_filenames(filename_prefix: str, src_pos: torch.Tensor, rec_pos: torch.Tensor):
+    """One file name per receiver as the reference writes them (trainer.py:537-556); yields (receiver, name)."""
+    src_pos, rec_pos = src_pos.detach().cpu(), rec_pos.detach().cpu()
+    num_src = 1 if src_pos.ndim == 1 or bool(torch.all(src_pos == src_pos[0])) else src_pos.shape[0]
+    for s_ in range(num_src):
+        for r in range(rec_pos.shape[0]):
+            if num_src == 1:
+                yield r, f'{filename_prefix}_({rec_pos[r, 0]:.2f}, {rec_pos[r, 1]:.2f}, {rec_pos[r, 2]:.2f}).wav'
+            else:
+                yield r, (f'{filename_prefix}_src_pos=({src_pos[s_, 0]:.2f}, {src_pos[s_, 1]:.2f}, '
+                          f'{src_pos[s_, 2]:.2f})_rec_pos=({rec_pos[r, 0]:.2f}, {rec_pos[r, 1]:.2f}, '
+                          f'{rec_pos[r, 2]:.2f}).wav')
+
+
+def write_wav(path: str, sample_rate: int, samples: np.ndarray):
+    """32-bit float wav, samples (T, channels) -- the host side of the reference's torchaudio.save calls."""
+    from scipy.io import wavfile
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    wavfile.write(path, int(sample_rate), np.ascontiguousarray(samples, dtype=np.float32))
+
+
 class FlatGradAllReduce:
     """One flat fp32 buffer for all parameter gradients -> a single all-reduce per step."""
 
@@ -476,23 +497,11 @@ class VarReceiverPosTrainer(Trainer):
             h = h / torch.max(torch.abs(h))
         if directory is None:
             return out[0], h
-        from scipy.io import wavfile            # (torchaudio.save in the reference; host side either way)
-        os.makedirs(directory, exist_ok=True)
         rec_pos = input_features['listener_position'] if rec_pos is None else rec_pos
         src_pos = input_features['source_position'] if src_pos is None else src_pos
-        rec_pos, src_pos = rec_pos.detach().cpu(), src_pos.detach().cpu()
-        num_src = 1 if src_pos.ndim == 1 or bool(torch.all(src_pos == src_pos[0])) else src_pos.shape[0]
         hc = h.detach().to(torch.float32).cpu().numpy()
-        fs = int(self.net.sample_rate)
-        for s_ in range(num_src):
-            for r in range(rec_pos.shape[0]):
-                if num_src == 1:
-                    name = (f'{filename_prefix}_({rec_pos[r, 0]:.2f}, {rec_pos[r, 1]:.2f}, {rec_pos[r, 2]:.2f}).wav')
-                else:
-                    name = (f'{filename_prefix}_src_pos=({src_pos[s_, 0]:.2f}, {src_pos[s_, 1]:.2f}, '
-                            f'{src_pos[s_, 2]:.2f})_rec_pos=({rec_pos[r, 0]:.2f}, {rec_pos[r, 1]:.2f}, '
-                            f'{rec_pos[r, 2]:.2f}).wav')
-                wavfile.write(os.path.join(str(directory), name), fs, np.stack((hc[r], hc[r]), axis=1))
+        for r, name in ir_filenames(filename_prefix, src_pos, rec_pos):
+            write_wav(os.path.join(str(directory), name), self.net.sample_rate, np.stack((hc[r], hc[r]), axis=1))
         return (out[0], out[1]) if self.use_colorless_loss else out[0]
 
 
@@ -506,6 +515,19 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
     def convert_ambi_rir_to_directional_rir(self, H_sh: torch.Tensor) -> torch.Tensor:
         """einsum('jl,blk->bjk', A_sh, H_sh)  (reference :853-865) as one streaming kernel."""
         return SHToDirectional.apply(self.net.sh_output_scalars.analysis_matrix, H_sh)
+
+    @torch.no_grad()
+    def save_ir(self, input_features: Dict, directory: str, src_pos: torch.Tensor, rec_pos: torch.Tensor,
+                filename_prefix: str = "ir", norm: bool = True):
+        """One multi-channel wav (the SH channels) per receiver (reference :868-921)."""
+        out = get_response(input_features, self.net)
+        h = out[-1]                                                   # (B, L, nfft)
+        if norm:
+            h = h / torch.max(torch.abs(h))
+        hc = h.detach().to(torch.float32).cpu().numpy()
+        for r, name in ir_filenames(filename_prefix, src_pos, rec_pos):
+            write_wav(os.path.join(str(directory), name), self.net.sample_rate, hc[r].T)
+        return (out[0], out[1]) if self.use_colorless_loss else out[0]
 
     def _step_losses(self, data: Dict) -> Dict:
         net, cfg = self.net, self.config
@@ -550,6 +572,20 @@ class SinglePosTrainer(Trainer):
     """One source-receiver pair (reference trainer.py:570-684; the reference's own train_step has
     unbound variables on the colorless / no-sub-band branches, SURVEY §8c -- this is the working
     counterpart).  ``data``: dict of (K,) tensors z_values, target_rir_response, target_early_response."""
+
+    @torch.no_grad()
+    def save_ir(self, data: Dict, directory: str, filename_prefix: str = 'ir', norm: bool = False):
+        """The modelled impulse response as one stereo wav (reference :664-684)."""
+        h = get_response(data, self.net)[-1].reshape(-1)
+        if self.reduced_pole_radius is not None and self.reduced_pole_radius != 1.0:
+            h = h * torch.pow(torch.tensor(1.0 / self.reduced_pole_radius, device=h.device),
+                              torch.arange(h.shape[-1], device=h.device))
+        if norm:
+            h = h / torch.max(torch.abs(h))
+        hc = h.detach().to(torch.float32).cpu().numpy()
+        write_wav(os.path.join(str(directory), filename_prefix + '.wav'), self.net.sample_rate,
+                  np.stack((hc, hc), axis=1))
+        return h
 
     def _step_losses(self, data: Dict) -> Dict:
         net, cfg = self.net, self.config

@@ -473,6 +473,15 @@ def test_directional_trainer_step():
     before = net.output_gains.detach().clone()
     total, parts = tr.train_step(batch)
     assert torch.isfinite(total) and not torch.equal(before, net.output_gains.detach())
+    # IR export: one wav per receiver with the SH channels (reference :868-921)
+    import tempfile
+    from scipy.io import wavfile
+    with tempfile.TemporaryDirectory() as d:
+        tr.save_ir(batch, d, batch["source_position"], batch["listener_position"], norm=False)
+        rec = batch["listener_position"].cpu()
+        fs_w, data = wavfile.read(f'{d}/ir_({rec[0, 0]:.2f}, {rec[0, 1]:.2f}, {rec[0, 2]:.2f}).wav')
+        nch = (int(fx["order"]) + 1) ** 2
+        assert fs_w == int(fs) and data.shape == (2 * (batch["z_values"].numel() - 1), nch)
 
 
 def test_single_pos_trainer_step_matches_oracle():
@@ -501,6 +510,13 @@ def test_single_pos_trainer_step_matches_oracle():
     assert abs(float(losses["edc_loss"]) - 10.0 * l_edc.item()) < TOL * abs(10.0 * l_edc.item())
     total, _ = tr.train_step(x)
     assert torch.isfinite(total)
+    import tempfile
+    from scipy.io import wavfile
+    with tempfile.TemporaryDirectory() as d:                      # IR export (reference :664-684)
+        h = tr.save_ir(x, d, filename_prefix="single", norm=True)
+        fs_w, data = wavfile.read(d + "/single.wav")
+        assert data.shape == (h.numel(), 2) and abs(float(np.abs(data).max()) - 1.0) < 1e-6
+        assert np.array_equal(data[:, 0], data[:, 1])
 
 
 def test_rfft_front_end_kernel_and_sh_mix():
