@@ -237,3 +237,160 @@ class GridLoader:
                 chunk = chunk[self.rank::self.world_size]
             if chunk:
                 yield self.dataset.collate(chunk, lean=self.lean)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Single measured / simulated RIR (config 1: one source-receiver pair) and the reference's loader entry points
+# ------------------------------------------------------------------------------------------------------------
+class RIRData:
+    """One RIR with its full / early / late frequency responses (reference dataloader.py:76-180).  Host-side numpy
+    like the reference: one response of a few seconds.  ``early_late_split`` applies the 5 ms fades IN PLACE on
+    views of ``rir`` exactly as the reference does (:160-170), so ``rir_mag_response`` -- a property evaluated
+    afterwards -- is the spectrum of the faded signal there too."""
+
+    def __init__(self, common_decay_times, band_centre_hz=None, amplitudes=None, room_dims=None,
+                 absorption_coeffs=None, mixing_time_ms: float = 20.0, nfft: Optional[int] = None, wav_path=None,
+                 rir: Optional[np.ndarray] = None, sample_rate: Optional[float] = None):
+        if wav_path is None and rir is None:
+            raise AttributeError("Either the path to the wav file or the RIR itself must be specified")
+        if wav_path is not None and rir is None:
+            assert str(wav_path).endswith('.wav'), "provide the path to the .wav file"
+            from scipy.io import wavfile           # (soundfile in the reference)
+            try:
+                sample_rate, rir = wavfile.read(str(wav_path))
+            except Exception as exc:
+                raise FileNotFoundError(f"File was not found at {str(wav_path)}") from exc
+            if np.issubdtype(rir.dtype, np.integer):
+                rir = rir.astype(np.float64) / np.iinfo(rir.dtype).max
+            rir = np.array(rir, dtype=np.float64)
+        self.rir = rir
+        self.sample_rate = sample_rate
+        self.common_decay_times = common_decay_times
+        self.band_centre_hz = band_centre_hz
+        self.amplitudes = amplitudes
+        self.mixing_time_ms = mixing_time_ms
+        self.room_dims = room_dims
+        self.absorption_coeffs = absorption_coeffs
+        self.nfft = nfft
+        self.early_late_split()
+
+    @property
+    def num_freq_bins(self) -> int:
+        if self.nfft is not None:
+            return self.nfft
+        max_rt60_samps = np.asarray(self.common_decay_times).max() * self.sample_rate
+        return int(np.power(2, np.ceil(np.log2(max_rt60_samps))))
+
+    @property
+    def freq_bins_rad(self) -> np.ndarray:
+        return np.fft.rfftfreq(self.num_freq_bins) * 2 * np.pi
+
+    @property
+    def freq_bins_hz(self) -> np.ndarray:
+        return np.fft.rfftfreq(self.num_freq_bins, d=1.0 / self.sample_rate)
+
+    @property
+    def rir_mag_response(self) -> np.ndarray:
+        return np.fft.rfft(self.rir, n=self.num_freq_bins)
+
+    def early_late_split(self, win_len_ms: float = 5.0):
+        mixing_time_samps = ms_to_samps(self.mixing_time_ms, self.sample_rate)
+        win_len_samps = ms_to_samps(win_len_ms, self.sample_rate)
+        window = np.hanning(win_len_samps)
+        fade_in_win, fade_out_win = window[:win_len_samps // 2], window[win_len_samps // 2:]
+        self.early_rir = self.rir[:mixing_time_samps]           # views: the fades land in self.rir
+        self.late_rir = self.rir[mixing_time_samps:]
+        self.early_rir[-win_len_samps // 2:] *= fade_out_win
+        self.late_rir[:win_len_samps // 2] *= fade_in_win
+        self.late_rir_mag_response = np.fft.rfft(self.late_rir, n=self.num_freq_bins)
+        self.early_rir_mag_response = np.fft.rfft(self.early_rir, n=self.num_freq_bins)
+
+
+class SingleRIRDataset(torch.utils.data.Dataset):
+    """The bins of ONE response as dataset items (reference :603-658): a batch holds a set of bins; with
+    ``batch_size = len(dataset)`` and no shuffling it is the whole grid, which is how the single-position models
+    are stepped (DiffGFDNSinglePos takes (K,) tensors)."""
+
+    def __init__(self, device, rir_data: RIRData, new_sampling_radius: Optional[float] = None):
+        self.device = device
+        w = torch.tensor(rir_data.freq_bins_rad, device=device)
+        if new_sampling_radius in (1.0, None):
+            self.z_values = torch.polar(torch.ones_like(w), w)
+        else:
+            assert new_sampling_radius > 1.0
+            self.z_values = torch.polar(new_sampling_radius * torch.ones_like(w), w)
+        self.rir_mag_response = torch.tensor(rir_data.rir_mag_response, device=device)
+        self.late_rir_mag_response = torch.tensor(rir_data.late_rir_mag_response, device=device)
+        self.early_rir_mag_response = torch.tensor(rir_data.early_rir_mag_response, device=device)
+
+    def __len__(self):
+        return len(self.z_values)
+
+    def __getitem__(self, idx: int) -> Dict:
+        return {'z_values': self.z_values[idx], 'target_rir_response': self.rir_mag_response[idx],
+                'target_early_response': self.early_rir_mag_response[idx],
+                'target_late_response': self.late_rir_mag_response[idx]}
+
+
+def to_device(data_class, device):
+    """Move all tensor / ndarray attributes to ``device`` (reference :661-671)."""
+    for name, value in list(data_class.__dict__.items()):
+        if isinstance(value, torch.Tensor):
+            setattr(data_class, name, value.to(device))
+        elif isinstance(value, np.ndarray):
+            setattr(data_class, name, torch.tensor(value, device=device))
+    if hasattr(data_class, 'device'):
+        data_class.device = device
+    return data_class
+
+
+def get_device():
+    return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
+def create_fixed_test_split(dataset, test_ratio: float = 0.1, seed: int = 4314) -> Tuple[List[int], List[int]]:
+    """(test indices, remaining indices) drawn with a generator of their own (reference :707-724)."""
+    gen = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(len(dataset), generator=gen).tolist()
+    nt = int(len(dataset) * test_ratio)
+    return perm[:nt], perm[nt:]
+
+
+def get_dataloader(dataset, batch_size: int, shuffle: bool = True, device='cpu', drop_last: bool = True,
+                   custom_collate_fn=None, indices: Optional[Sequence[int]] = None):
+    """Batches of ``dataset`` (reference :748-772).  A grid dataset yields collated batch dicts straight from its
+    device-resident stores (:class:`GridLoader`: an index list per batch, no per-item gather on the host); any
+    other dataset goes through ``torch.utils.data.DataLoader`` as in the reference."""
+    if isinstance(dataset, MultiRIRDataset):
+        idx = list(range(len(dataset))) if indices is None else list(indices)
+        return GridLoader(dataset, idx, batch_size, shuffle=shuffle, drop_last=drop_last)
+    kw = dict(batch_size=batch_size, shuffle=shuffle, drop_last=drop_last,
+              generator=torch.Generator(device=device) if shuffle else None)
+    if custom_collate_fn is not None:
+        kw['collate_fn'] = custom_collate_fn
+    return torch.utils.data.DataLoader(dataset, **kw)
+
+
+def load_dataset(room_data, device, train_valid_split_ratio: float = 0.8, batch_size: int = 32, shuffle: bool = True,
+                 new_sampling_radius: Optional[float] = None, drop_last: bool = False,
+                 hold_out_test_set: bool = False, test_set_ratio: Optional[float] = None,
+                 test_set_seed: Optional[int] = None):
+    """Training / validation (/ test) loaders of a :class:`RoomDataset`, or the single loader of an
+    :class:`RIRData` (reference :780-867; same arguments)."""
+    if isinstance(room_data, RoomDataset):
+        dataset = MultiRIRDataset(device, room_data, new_sampling_radius=new_sampling_radius)
+        if hold_out_test_set:
+            train, valid, test = split_dataset(dataset, train_valid_split_ratio,
+                                               test_ratio=0.1 if test_set_ratio is None else test_set_ratio,
+                                               **({} if test_set_seed is None else {'test_seed': test_set_seed}))
+        else:
+            train, valid, test = split_dataset(dataset, train_valid_split_ratio)
+        loaders = [GridLoader(dataset, train, batch_size, shuffle=shuffle, drop_last=drop_last),
+                   GridLoader(dataset, valid, batch_size, shuffle=shuffle, drop_last=drop_last)]
+        if hold_out_test_set:
+            loaders.append(GridLoader(dataset, test, batch_size, shuffle=False, drop_last=False))
+        return tuple(loaders)
+    if isinstance(room_data, RIRData):
+        dataset = SingleRIRDataset(device, room_data, new_sampling_radius=new_sampling_radius)
+        return get_dataloader(dataset, batch_size=batch_size, shuffle=shuffle, device=device, drop_last=drop_last)
+    raise TypeError("load_dataset: RoomDataset or RIRData expected")

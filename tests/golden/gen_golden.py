@@ -533,6 +533,22 @@ def gen_f12_filter_coupling():
     print('F12 done', sorted(k for k in out if k.startswith('net_grad_')))
 
 
+def gen_f13_single_rir_data():
+    """RIRData / SingleRIRDataset (dataloader.py:76-180, :603-658): responses of one RIR and the z grid."""
+    from diff_gfdn.dataloader import RIRData, SingleRIRDataset
+    rng = np.random.RandomState(13)
+    fs = 8000.0
+    rir = rng.randn(6000) * np.exp(-np.arange(6000) / 1500.0)
+    out = {'fs': fs, 'rir': rir.copy(), 'T60': np.array([[0.6]])}
+    d = RIRData(np.array([[0.6]]), None, rir=rir.copy(), sample_rate=fs, nfft=8192, mixing_time_ms=20.0)
+    ds = SingleRIRDataset('cpu', d, new_sampling_radius=1.0002)
+    out.update({'nfft': 8192, 'rir_after': d.rir.copy(), 'full': d.rir_mag_response, 'early': d.early_rir_mag_response,
+                'late': d.late_rir_mag_response, 'z': c2np(ds.z_values), 'auto_bins': RIRData(
+                    np.array([[0.6]]), None, rir=rir.copy(), sample_rate=fs).num_freq_bins})
+    np.savez_compressed(os.path.join(HERE, 'f13_single_rir_data.npz'), **out)
+    print('F13 done')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_f1_feedback_loop()
@@ -550,3 +566,4 @@ if __name__ == '__main__':
     gen_f10_absorption_filters()
     gen_f11_svf_filters()
     gen_f12_filter_coupling()
+    gen_f13_single_rir_data()

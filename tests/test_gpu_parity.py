@@ -963,3 +963,25 @@ def test_save_ir_writes_reference_named_wavs(tmp_path):
         assert rel_err(data[:, 0], want[r]) < 1e-5
     H2, h = tr.save_ir(batch, norm=True)                      # nothing written: (H, h)
     assert abs(float(h.abs().max()) - 1.0) < 1e-6 and rel_err(H2.cpu(), H.cpu()) == 0.0
+
+
+def test_load_dataset_grid_loaders():
+    """load_dataset on a RoomDataset (reference dataloader.py:780-867): train / valid / held-out test loaders over
+    disjoint receiver sets, batches with the reference's collate keys, tensors resident on the device."""
+    from diffgfdn_amd.dataloader import RoomDataset, get_dataloader, load_dataset
+    from diffgfdn_amd.synthetic import synthetic_room
+    room = synthetic_room(20, 3, 8000.0, 5000, seed=5)
+    rd = RoomDataset(3, 8000.0, room["source_position"], room["receiver_position"], room["rirs"],
+                     room["common_decay_times"], nfft=8192, device=DEV)
+    torch.manual_seed(3)
+    train, valid, test = load_dataset(rd, DEV, train_valid_split_ratio=0.75, batch_size=4, hold_out_test_set=True,
+                                      test_set_ratio=0.1, test_set_seed=99)
+    sets = [set(l.indices) for l in (train, valid, test)]
+    assert sets[0] | sets[1] | sets[2] == set(range(20)) and sum(len(s_) for s_ in sets) == 20
+    assert len(sets[2]) == 2 and len(sets[0]) == int(0.75 * 18)
+    b = next(iter(train))
+    for key in ("z_values", "source_position", "listener_position", "norm_listener_position",
+                "target_early_response", "target_late_response", "target_rir_response"):
+        assert key in b and b[key].is_cuda
+    assert b["target_rir_response"].shape == (4, 4097)
+    assert len(get_dataloader(train.dataset, 5, shuffle=False, drop_last=True)) == 4

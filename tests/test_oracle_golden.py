@@ -325,3 +325,20 @@ def test_f12_filter_coupling():
     H = orc.var_receiver_forward(z, sd("input_gains"), sd("output_gains"), r, P2,
                                  torch.tensor(fx["net_batch_target_early_response"]), nper)
     assert rel_err(H.detach(), fx["net_H"]) < TOL32
+
+
+def test_f13_single_rir_data():
+    """RIRData / SingleRIRDataset / load_dataset for one measured response (dataloader.py:76-180, :603-658, :780-867)
+    against the reference's: in-place fades, the three spectra, the z grid outside the unit circle."""
+    from diffgfdn_amd.dataloader import RIRData, SingleRIRDataset, load_dataset
+    fx = load("f13_single_rir_data.npz")
+    d = RIRData(fx["T60"], None, rir=fx["rir"].copy(), sample_rate=float(fx["fs"]), nfft=int(fx["nfft"]))
+    assert np.array_equal(d.rir, fx["rir_after"])
+    for name, ref in (("rir_mag_response", "full"), ("early_rir_mag_response", "early"), ("late_rir_mag_response", "late")):
+        assert rel_err(getattr(d, name), fx[ref]) < 1e-12
+    assert RIRData(fx["T60"], None, rir=fx["rir"].copy(), sample_rate=float(fx["fs"])).num_freq_bins == int(fx["auto_bins"])
+    ds = SingleRIRDataset("cpu", d, new_sampling_radius=1.0002)
+    assert rel_err(ds.z_values.numpy(), fx["z"]) < 1e-14
+    batch = next(iter(load_dataset(d, "cpu", batch_size=len(ds), shuffle=False)))
+    assert rel_err(batch["target_early_response"].numpy(), fx["early"]) < 1e-12
+    assert set(batch) == {"z_values", "target_rir_response", "target_early_response", "target_late_response"}
