@@ -167,18 +167,20 @@ __global__ __launch_bounds__(256) void k_p2_adj_a(P2Geom g, const float* __restr
   }
 }
 
-// rows of tile q: with L1 <= P2_TC all rows; else the four rows 4q .. 4q+3 and their mirrors L1 - k1 (tile 0 holds
-// row 0, which mirrors onto itself, and takes row L1 / 2 -- the other self-mirrored row -- in the free slot)
+// rows of tile q: with L1 <= P2_TC all rows; else the P2_TC / 2 rows h q .. h q + h - 1 and their mirrors L1 - k1
+// (tile 0 holds row 0, which mirrors onto itself, and takes row L1 / 2 -- the other self-mirrored row -- in the
+// free slot)
+#define P2_H (P2_TC / 2)
 __device__ __forceinline__ int p2_tile_row(int L1, int q, int i) {
   if (L1 <= P2_TC) return i;
-  if (i < 4) return 4 * q + i;
-  if (q == 0 && i == 7) return L1 / 2;
-  return L1 - 4 * q - 3 + (i - 4);
+  if (i < P2_H) return P2_H * q + i;
+  if (q == 0 && i == P2_TC - 1) return L1 / 2;
+  return L1 - P2_H * q - (P2_H - 1) + (i - P2_H);
 }
 __device__ __forceinline__ int p2_tile_mirror(int L1, int q, int i, int k1) {
   if (k1 == 0 || 2 * k1 == L1) return i;
   if (L1 <= P2_TC) return L1 - k1;
-  return i < 4 ? 7 - i : 7 - i;             // rows[4 + j] = L1 - 4q - 3 + j mirrors rows[3 - j]
+  return P2_TC - 1 - i;                     // rows[h + j] = L1 - h q - (h - 1) + j mirrors rows[h - 1 - j]
 }
 
 // ---- forward pass B: rows k1 (+ mirrors), FFT over n2, F[k1 + L1 k2] for k <= m
