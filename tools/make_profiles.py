@@ -54,6 +54,7 @@ the command the driver runs (N = 1, workload = BASELINE.json configs[1]).  Rebui
 | `{tag}_bench_n1.json` | `python bench.py` | the bench JSON line (graph-replay steps, roofline leg, CPU baseline) |
 | `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` | per-kernel totals / averages (includes the one-off dataset front end and the 20 eager roofline steps) |
 | `{tag}_pmc_hbm_bytes.csv` | `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --eager`, and the same with `--pmc WRITE_SIZE` (separate passes) | average FETCH_SIZE / WRITE_SIZE per launch of every hand-written kernel, by grid size; read bytes corrected x2 for gfx950 as MI355X_MICROARCH.md prescribes |
+| `{tag}_pmc_l2_valu.csv` | `tools/run_pmc_extra.sh` (a separate `gpurun` call): `rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum` and `--pmc SQ_INSTS_VALU SQ_WAVES` on `bench.py --eager`, summarised by `tools/make_pmc_extra.py` | L2 requests / hit rate and VALU instructions per wave, per kernel and launch: what the request-rate and instruction-bound statements of DESIGN.md §4 rest on |
 | `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
 
 ## bench line
