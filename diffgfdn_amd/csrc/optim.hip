@@ -17,7 +17,8 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const floa
                                               const unsigned char* __restrict__ seg,
                                               const float* __restrict__ lr_seg,
                                               float* __restrict__ step_count, int n, float b1,
-                                              float b2, float eps, int advance) {
+                                              float b2, float eps, int advance,
+                                              unsigned int* __restrict__ block_counter) {
   const float t = step_count[0] + 1.0f;
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
@@ -33,29 +34,57 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const floa
   if (advance) {
     __syncthreads();
     if (threadIdx.x == 0) step_count[0] = t;
+  } else if (block_counter) {
+    // multi-block launch: the LAST workgroup to finish writes t back -- every workgroup has read the counter by the
+    // time it reports in -- and re-arms the block counter for the next launch (no second kernel for the increment)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(block_counter, 1u) == gridDim.x - 1) {
+        step_count[0] = t;
+        block_counter[0] = 0u;
+      }
+    }
   }
 }
 __global__ void k_adam_advance(float* step_count) {
   if (threadIdx.x == 0 && blockIdx.x == 0) step_count[0] += 1.0f;
 }
 
-extern "C" int gfdn_adam_step(float* p, const float* g, float* m, float* v, const unsigned char* seg,
-                              const float* lr_seg, float* step_count, int n, float beta1, float beta2,
-                              float eps, void* stream) {
+static int adam_step_run(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                         const float* lr_seg, float* step_count, int n, float beta1, float beta2,
+                         float eps, unsigned int* block_counter, void* stream) {
   if (!p || !g || !m || !v || !seg || !lr_seg || !step_count || n <= 0) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (n <= 16 * 1024) {          // one block: update + counter advance in a single launch
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
-                       beta1, beta2, eps, 1);
+                       beta1, beta2, eps, 1, (unsigned int*)nullptr);
     GFDN_LAUNCH_CHECK();
     return 0;
   }
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
-                     beta1, beta2, eps, 0);
+                     beta1, beta2, eps, 0, block_counter);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, s, step_count);
-  GFDN_LAUNCH_CHECK();
+  if (!block_counter) {
+    hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, s, step_count);
+    GFDN_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" int gfdn_adam_step(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                              const float* lr_seg, float* step_count, int n, float beta1, float beta2,
+                              float eps, void* stream) {
+  return adam_step_run(p, g, m, v, seg, lr_seg, step_count, n, beta1, beta2, eps, nullptr, stream);
+}
+
+// block_counter: one zero-initialised uint32 owned by the optimiser (re-armed by every launch): the update and the
+// advance of step_count are then ONE launch whatever n is
+extern "C" int gfdn_adam_step_counted(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                                      const float* lr_seg, float* step_count, int n, float beta1, float beta2,
+                                      float eps, unsigned int* block_counter, void* stream) {
+  if (!block_counter) return GFDN_E_BADARG;
+  return adam_step_run(p, g, m, v, seg, lr_seg, step_count, n, beta1, beta2, eps, block_counter, stream);
 }

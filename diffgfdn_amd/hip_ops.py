@@ -931,9 +931,17 @@ def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, gg
     return gw
 
 
-def adam_step(p, g, m, v, seg, lr_seg, step_count, beta1, beta2, eps):
-    """In-place fused Adam update of the flat buffers (all float32 on the GPU; seg uint8)."""
+def adam_step(p, g, m, v, seg, lr_seg, step_count, beta1, beta2, eps, block_counter=None):
+    """In-place fused Adam update of the flat buffers (all float32 on the GPU; seg uint8).  ``block_counter``: a
+    zero-initialised int32 tensor of one element owned by the optimiser -- update and counter advance are then one
+    launch for any size."""
     _need_gpu(p, g)
+    if block_counter is not None:
+        _lib.check(_lib.load().gfdn_adam_step_counted(_p(p), _p(g), _p(m), _p(v), _p(seg), _p(lr_seg),
+                                                      _p(step_count), p.numel(), float(beta1), float(beta2),
+                                                      float(eps), _p(block_counter), _stream()),
+                   "gfdn_adam_step_counted")
+        return
     _lib.check(_lib.load().gfdn_adam_step(_p(p), _p(g), _p(m), _p(v), _p(seg), _p(lr_seg),
                                           _p(step_count), p.numel(), float(beta1), float(beta2),
                                           float(eps), _stream()), "gfdn_adam_step")

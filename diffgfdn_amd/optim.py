@@ -39,6 +39,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._block_counter = torch.zeros(1, dtype=torch.int32, device=dev)      # see gfdn_adam_step_counted
         seg = torch.empty(n, dtype=torch.uint8)
         self._grad_views, self._params = [], []
         off = 0
@@ -94,7 +95,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._packed = False
         b1, b2 = self.defaults['betas']
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.seg,
-                      self.lr_seg, self.step_count, b1, b2, self.defaults['eps'])
+                      self.lr_seg, self.step_count, b1, b2, self.defaults['eps'], self._block_counter)
         # the kernel wrote the parameters through raw pointers: tell autograd / version-keyed caches
         torch.autograd.graph.increment_version(self._params)
 

@@ -424,6 +424,11 @@ int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, cons
 int gfdn_adam_step(float* p, const float* g, float* m, float* v, const unsigned char* seg,
                    const float* lr_seg, float* step_count, int n, float beta1, float beta2,
                    float eps, void* stream);
+/* the same in ONE launch for any n: block_counter = a zero-initialised uint32 of the caller's (the last workgroup to
+ * finish advances step_count and re-arms it)                                                              */
+int gfdn_adam_step_counted(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                           const float* lr_seg, float* step_count, int n, float beta1, float beta2,
+                           float eps, unsigned int* block_counter, void* stream);
 
 #ifdef __cplusplus
 }
