@@ -471,18 +471,20 @@ class BandBankTrainer:
                 count = float(maskw.sum().item())
             gb = Bper * self.world_size
         edr_t, edc_t = data['edr_target'], data['edc_target']
+        pairs_path = order is not None and self.use_pairs and self.stft_win == 4096
         total, edr_v, edc_v = decay_losses(
             H, None, win=self.stft_win, edr_weight=cfg.edr_loss_weight, edc_weight=cfg.edc_loss_weight,
             edc_start=start, edc_len=length, edc_maskw=maskw, edc_count=count,
             edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
             edr_target=(edr_t[1], edr_t[2]), edc_target=edc_t[1], side_stream=self._stream('_side2'),
             unit_grad=True, n_time=K, target_rows=rows, nbands=nb, slot_order=order is not None,
-            pairs=order is not None and self.use_pairs and self.stft_win == 4096,
+            pairs=pairs_path,
             join_event=tail_done if (fused and side is not None) else None)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v, 'spectral_loss': spec.detach(),
                   'sparsity_loss': sparse.detach()}
         if side is not None:
-            main.wait_stream(side)
+            if not (fused and pairs_path):        # (the pair path already joined the side branch behind the transform)
+                main.wait_stream(side)
             extra.record_stream(main)
         if defer_total:
             losses['_heads'] = [total, extra]
