@@ -1574,17 +1574,20 @@ extern __shared__ float2 compose_lds[];
 // 128-byte rows of the bin-major layout would otherwise be read 8 bytes at a time across 64 lines)
 // ldy: row stride of Y in elements (N for one band; nbands * N when the bands' delay lines sit side by
 // side in one (K, nbands * N) solve output -- each bin then contributes one contiguous run of N values)
+#ifndef CF_T
+#define CF_T 256          // bins per workgroup of the output stage (128: no faster)
+#endif
 __device__ __forceinline__ void load_bin_tile(const float2* __restrict__ Y, int k0, int K, int N, int ldy,
                                               float2* tile) {
   const size_t base = (size_t)k0 * ldy;
-  const int lim = (K - k0 < 256 ? K - k0 : 256) * N;
-  for (int e = threadIdx.x; e < 256 * N; e += 256) {
+  const int lim = (K - k0 < CF_T ? K - k0 : CF_T) * N;
+  for (int e = threadIdx.x; e < CF_T * N; e += CF_T) {
     const int kk = e / N, n = e - kk * N;
     tile[kk * (N + 1) + n] = e < lim ? Y[base + (size_t)kk * ldy + n] : make_float2(0.f, 0.f);
   }
 }
 
-__global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ Y, int K, int G,
+__global__ __launch_bounds__(CF_T) void k_compose_fwd(const float2* __restrict__ Y, int K, int G,
                                                      int nper, const float* __restrict__ c,
                                                      const float* __restrict__ rgain, int B,
                                                      const float2* __restrict__ direct, int ldd,
@@ -1593,7 +1596,7 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
                                                      float2* __restrict__ H, int ldh,
                                                      float2* __restrict__ S_out, int ldy, int ldf, int rpb) {
   const int N = G * nper;
-  const int k0 = blockIdx.x * 256;
+  const int k0 = blockIdx.x * CF_T;
   {   // band blockIdx.z: its delay lines, gains, items (B per band) and filter row
     const int band = blockIdx.z;
     Y += (size_t)band * N;
@@ -1655,7 +1658,7 @@ __global__ __launch_bounds__(256) void k_compose_fwd(const float2* __restrict__ 
   }
 }
 
-static size_t compose_tile_bytes(int N) { return (size_t)256 * (N + 1) * sizeof(float2); }
+static size_t compose_tile_bytes(int N) { return (size_t)CF_T * (N + 1) * sizeof(float2); }
 
 extern "C" int gfdn_compose_banded_fwd(const float* Y, int K, int nbands, int G, int nper, const float* c,
                                        const float* rgain, int B, const float* direct, int ldd,
@@ -1665,14 +1668,14 @@ extern "C" int gfdn_compose_banded_fwd(const float* Y, int K, int nbands, int G,
   if (G > GFDN_MAX_GROUPS || nbands > 65535) return GFDN_E_UNSUPPORTED;
   if (ldh < K || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
   // receivers per workgroup: all of the band's when (bin tiles x bands) alone fills the chip
-  const int ktiles = (K + 255) / 256;
+  const int ktiles = (K + CF_T - 1) / CF_T;
   int rpb = COMPOSE_BCH;
   if ((long long)ktiles * nbands >= 768) rpb = ((B + COMPOSE_BCH - 1) / COMPOSE_BCH) * COMPOSE_BCH;
   dim3 grid(ktiles, (B + rpb - 1) / rpb, nbands);
   if (G * nper > 128) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_compose_fwd, compose_tile_bytes(G * nper));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_compose_fwd, grid, dim3(256), compose_tile_bytes(G * nper), (hipStream_t)stream, (const float2*)Y, K,
+  hipLaunchKernelGGL(k_compose_fwd, grid, dim3(CF_T), compose_tile_bytes(G * nper), (hipStream_t)stream, (const float2*)Y, K,
                      G, nper, c, rgain, B, (const float2*)direct, ldd, direct ? direct_rows : nullptr,
                      (const float2*)filt, (float2*)H, ldh, (float2*)S_out, nbands * G * nper, ldf, rpb);
   GFDN_LAUNCH_CHECK();
