@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void s4k_load_pair(const float2* __restrict__ x2, int
   }
 }
 
-__global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power(const float2* __restrict__ x2, int ld, int T,
+__global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power(const float2* __restrict__ x2, int ld, int T,
                                                              int nframes, int items, float* __restrict__ P,
                                                              float2* __restrict__ zero_buf) {
   float2* buf = dyn_lds;
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(S4K_T) void k_stft4k_pair_power(const float2* __res
   }
 }
 
-__global__ __launch_bounds__(S4K_T, 4) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
+__global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
                                                                  int nframes, int items,
                                                                  const float* __restrict__ gP,
                                                                  const float2* base2, float2* gx2, int parity) {
