@@ -58,6 +58,19 @@ SIGNATURES = {
     "gfdn_subfdn_colorless_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "gfdn_spectral_stats_binmajor": (c_int, [_P, c_int, c_int, _P, c_int, c_float, _P, _P, _P, _P]),
     "gfdn_subfdn_colorless_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_tf_coefs_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "gfdn_tf_coefs_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_tf_parts": (c_int, [c_int, c_int]),
+    "gfdn_tf_work_bytes": (c_size_t, [c_int]),
+    "gfdn_tf_gpart_bytes": (c_size_t, [c_int]),
+    "gfdn_tf_eval": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_tf_energy": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_tf_colorless": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, _P]),
+    "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
+    "gfdn_tf_compose_parts": (c_int, [c_int]),
+    "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P]),
+    "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),
     "gfdn_normalize_io": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "gfdn_bluestein_table_bytes": (c_size_t, [c_int]),

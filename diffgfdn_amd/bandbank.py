@@ -39,6 +39,7 @@ from . import hip_ops as ops
 from .config import CouplingMatrixType, TrainerConfig
 from .functional import (ColorlessTerms, FrequencyGrid, MlpGains, OrthoParam, OutputStage, ResolventSolve,
                          SubFdnColorless)
+from .bankstep import FusedBankStep
 from .losses import decay_losses, edc_loss
 from .optim import FlatAdam
 
@@ -289,6 +290,7 @@ class BandBankTrainer:
     concurrent_branches = True
     use_slot_order = True        # evaluate the main branch on the irfft's slot-ordered grid when the length has one
     use_pairs = True             # ... and carry two items per transform, time signals pair-interleaved
+    use_fused = True             # blocks of <= 4 lines: the explicit launch sequence on the polynomial form (bankstep.py)
 
     def __init__(self, bank: BandBank, trainer_config: TrainerConfig,
                  subband_filter_freq_resp: Optional[torch.Tensor] = None, process_group=None,
@@ -334,6 +336,7 @@ class BandBankTrainer:
             opt, pg = self.optimizer, process_group
             self._allreduce = lambda: dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=pg)
         self._side = self._side2 = None
+        self._fused = FusedBankStep(self) if (self.use_fused and FusedBankStep.supported(self)) else None
         # leaves are first touched on one stream and receive gradients from the other by design (§5.1): the
         # engine synchronises them; its per-backward warning about that would only hide real messages
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -351,6 +354,39 @@ class BandBankTrainer:
     @torch.no_grad()
     def normalize(self, data: Dict):
         self.net.normalize(data['z_values'])
+
+    def _filter_on(self, Ku: int, order) -> Optional[torch.Tensor]:
+        """(bands, Ku) sub-band filter responses on the bins the main branch is evaluated on (slot order when the
+        irfft length has one); built once."""
+        if self.subband_filter_freq_resp is None:
+            return None
+        if self._filt_u is None or self._filt_u[0] != (Ku, order is not None):
+            F = self.subband_filter_freq_resp
+            if order is not None:
+                bins, conj = order
+                Fu = torch.cat([F[:, :1], torch.where(conj, F[:, bins].conj(), F[:, bins])], dim=1)
+            else:
+                Fu = F[:, :Ku]
+            self._filt_u = ((Ku, order is not None), Fu.contiguous())
+        return self._filt_u[1]
+
+    def _draw_edc_mask(self, length: int, Bper: int, device, draw_mask: bool = True):
+        """(maskw, 1 / (global batch x kept indices)) drawn like the reference (losses.py:221-227), the same on all
+        ranks."""
+        maskw, count = (self.criterion[1].draw_mask(length, device) if draw_mask else (None, float(length)))
+        if maskw is not None and self.world_size > 1:
+            dist.broadcast(maskw, src=0, group=self.process_group)
+            count = float(maskw.sum().item())
+        return maskw, 1.0 / (Bper * self.world_size * count)
+
+    def _fused_step(self, data: Dict, train: bool, draw_mask: bool = True):
+        rows = data['row_index']
+        K = data['z_values'].shape[-1]
+        _, length = self._decay_window(K)
+        maskw, inv = self._draw_edc_mask(length, rows.numel() // self.num_bands, rows.device, draw_mask)
+        losses = self._fused.run(data, maskw, inv, normalize_first=False, train=train, allreduce=self._allreduce)
+        losses.pop('_total')
+        return sum(losses.values()), losses
 
     def _step_losses(self, data: Dict, draw_mask: bool = True, mask_prenorm: Optional[torch.Tensor] = None,
                      normalize_first: bool = False, defer_total: bool = False) -> Dict:
@@ -429,17 +465,7 @@ class BandBankTrainer:
         else:
             zu, direct = z[:Ku], data['target_early_response'][:, :Ku]
         Y = bank.delay_line_responses(zu, QQ)
-        filt = None
-        if self.subband_filter_freq_resp is not None:
-            if self._filt_u is None or self._filt_u[0] != (Ku, order is not None):
-                F = self.subband_filter_freq_resp
-                if order is not None:
-                    bins, conj = order
-                    Fu = torch.cat([F[:, :1], torch.where(conj, F[:, bins].conj(), F[:, bins])], dim=1)
-                else:
-                    Fu = F[:, :Ku]
-                self._filt_u = ((Ku, order is not None), Fu.contiguous())
-            filt = self._filt_u[1]
+        filt = self._filter_on(Ku, order)
         if fused and side is not None:
             main.wait_event(mlp_done)
             rgain.record_stream(main)
@@ -500,6 +526,8 @@ class BandBankTrainer:
 
     def train_step(self, data: Dict):
         """One optimiser step of every band (trainer.py:452-477); returns ((bands,) totals, parts)."""
+        if self._fused is not None:
+            return self._fused_step(data, train=True)
         self.optimizer.zero_grad(set_to_none=True)
         losses = self._step_losses(data, defer_total=True)
         heads = losses.pop('_heads')
@@ -513,6 +541,8 @@ class BandBankTrainer:
 
     @torch.no_grad()
     def valid_step(self, data: Dict):
+        if self._fused is not None:
+            return self._fused_step(data, train=False)
         losses = self._step_losses(data)
         losses.pop('_total')
         return sum(losses.values()), losses

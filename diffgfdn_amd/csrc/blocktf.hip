@@ -1,0 +1,781 @@
+// Block transfer functions in polynomial form, for gfx950 (blocks of n <= 4 delay lines, zero coupling).
+//
+// Reference maths (orchidas/DiffGFDN, src/diff_gfdn): with zero inter-group coupling the feedback matrix is
+// block diagonal (feedback_loop.py:393-404, :439-443) and every receiver sees the loop only through the
+// group transfer functions
+//        T_g(z) = c_g^T (D_g(z) Gamma_g^-1 - A_g)^-1 b_g          (model.py:583-619: H = sum_g gain_g T_g + d),
+// the sub-FDN responses of the colorless loss being the same expression with the raw M_g and no absorption
+// (model.py:209-252).  For a block of n <= 4 lines this is a ratio of two MULTILINEAR polynomials in the n
+// phasors zeta_i = z^{m_i} / gamma_i:
+//        det(D' - A)           = sum_{S subset [n]} q_S prod_{i in S} zeta_i ,   q_S = (-1)^{|S^c|} det A[S^c, S^c]
+//        c^T adj(D' - A) b     = det(D' - A + b c^T) - det(D' - A)               (matrix determinant lemma)
+//                              = sum_S (q_S(A - b c^T) - q_S(A)) prod_{i in S} zeta_i ,
+// 2 x 16 real coefficients per block that do not depend on the bin.  The per-bin work drops from a pivoted
+// 4 x 4 complex elimination (~1000 VALU instructions, csrc/solve.hip k_solve4_*) to 4 sincos + 11 complex
+// products + two 16-term forms + one division (~260), the delay-line responses Y (K, N) never exist, and the
+// backward is 30 real accumulators per block (dL/dcoef) followed by a bin-independent map coef -> (A, b, c)
+// done once per block in float64.  The coefficient records carry the products of 1 / gamma_i, so that the
+// per-bin phasors are pure powers of z: prod_{i in S} z^{m_i}.
+//
+// Record layout: coef (nblk, 32) float32 = [P_S, S = 0..15 | Q_S, S = 0..15], S a bit mask over the lines of
+// the block (bit i = line i; masks with bits >= n hold zeros).  T = (sum_S P_S e_S) / (sum_S Q_S e_S).
+#include "common.h"
+
+#define TF_MAXBLK 64
+#define TF_REC 32
+#define TF_MAXG 4                // groups per band the output-stage kernels take (one wavefront per group)
+#define TF_MAX_PARTS 2048
+
+__device__ __forceinline__ float2 tf_zpow(const double* __restrict__ turns, const double* __restrict__ logr,
+                                          int k, float m) {
+  double t = (double)m * turns[k];
+  t -= rint(t);
+  float s, c;
+  sincospif(2.0f * (float)t, &s, &c);
+  if (logr) {
+    const float mag = (float)exp((double)m * logr[k]);
+    c *= mag;
+    s *= mag;
+  }
+  return make_float2(c, s);
+}
+
+// e[S] = prod_{i in S} z_k^{m_i}   (e[0] is never read: the empty product)
+__device__ __forceinline__ void tf_phasors(const double* __restrict__ turns, const double* __restrict__ logr,
+                                           int k, const float (&m)[4], float2 (&e)[16]) {
+  e[1] = tf_zpow(turns, logr, k, m[0]);
+  e[2] = tf_zpow(turns, logr, k, m[1]);
+  e[4] = tf_zpow(turns, logr, k, m[2]);
+  e[8] = tf_zpow(turns, logr, k, m[3]);
+  e[3] = cmul(e[1], e[2]);
+  e[5] = cmul(e[1], e[4]);
+  e[6] = cmul(e[2], e[4]);
+  e[9] = cmul(e[1], e[8]);
+  e[10] = cmul(e[2], e[8]);
+  e[12] = cmul(e[4], e[8]);
+  e[7] = cmul(e[3], e[4]);
+  e[11] = cmul(e[3], e[8]);
+  e[13] = cmul(e[5], e[8]);
+  e[14] = cmul(e[6], e[8]);
+  e[15] = cmul(e[3], e[12]);
+}
+
+__device__ __forceinline__ void tf_numden(const float (&P)[16], const float (&Q)[16], const float2 (&e)[16],
+                                          float2& num, float2& den) {
+  num = make_float2(P[0], 0.f);
+  den = make_float2(Q[0], 0.f);
+#pragma unroll
+  for (int S = 1; S < 16; ++S) {
+    num.x += P[S] * e[S].x;
+    num.y += P[S] * e[S].y;
+    den.x += Q[S] * e[S].x;
+    den.y += Q[S] * e[S].y;
+  }
+}
+
+struct TfBlock { float P[16], Q[16], m[4]; };      // 36 floats
+
+// record of block blk from global memory (delays zero-padded: absent lines get the phasor 1 and zero coefficients)
+__device__ __forceinline__ void tf_load(const float* __restrict__ coef, const float* __restrict__ delays,
+                                        int blk, int n, float (&P)[16], float (&Q)[16], float (&m)[4]) {
+#pragma unroll
+  for (int S = 0; S < 16; ++S) {
+    P[S] = coef[(size_t)blk * TF_REC + S];
+    Q[S] = coef[(size_t)blk * TF_REC + 16 + S];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = r < n ? delays[blk * n + r] : 0.f;
+}
+
+__device__ __forceinline__ void tf_stage(const float* __restrict__ coef, const float* __restrict__ delays,
+                                         int blk0, int nb, int n, TfBlock* tab) {
+  for (int t = threadIdx.x; t < nb * 36; t += blockDim.x) {
+    const int q = t / 36, f = t - q * 36;
+    float v;
+    if (f < 32) v = coef[(size_t)(blk0 + q) * TF_REC + f];
+    else v = (f - 32) < n ? delays[(blk0 + q) * n + (f - 32)] : 0.f;
+    ((float*)&tab[q])[f] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// coefficient records (float64 inside: the numerator is a difference of determinants)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double tf_det3(const double* a, int r0, int r1, int r2, int c0, int c1, int c2) {
+  return a[r0 * 4 + c0] * (a[r1 * 4 + c1] * a[r2 * 4 + c2] - a[r1 * 4 + c2] * a[r2 * 4 + c1]) -
+         a[r0 * 4 + c1] * (a[r1 * 4 + c0] * a[r2 * 4 + c2] - a[r1 * 4 + c2] * a[r2 * 4 + c0]) +
+         a[r0 * 4 + c2] * (a[r1 * 4 + c0] * a[r2 * 4 + c1] - a[r1 * 4 + c1] * a[r2 * 4 + c0]);
+}
+// det of a[ri[0..t-1]][ci[0..t-1]], a row-major 4 x 4, t <= 4
+__device__ double tf_det(const double* a, const int* ri, const int* ci, int t) {
+  if (t == 0) return 1.0;
+  if (t == 1) return a[ri[0] * 4 + ci[0]];
+  if (t == 2) return a[ri[0] * 4 + ci[0]] * a[ri[1] * 4 + ci[1]] - a[ri[0] * 4 + ci[1]] * a[ri[1] * 4 + ci[0]];
+  if (t == 3) return tf_det3(a, ri[0], ri[1], ri[2], ci[0], ci[1], ci[2]);
+  return a[ri[0] * 4 + ci[0]] * tf_det3(a, ri[1], ri[2], ri[3], ci[1], ci[2], ci[3]) -
+         a[ri[0] * 4 + ci[1]] * tf_det3(a, ri[1], ri[2], ri[3], ci[0], ci[2], ci[3]) +
+         a[ri[0] * 4 + ci[2]] * tf_det3(a, ri[1], ri[2], ri[3], ci[0], ci[1], ci[3]) -
+         a[ri[0] * 4 + ci[3]] * tf_det3(a, ri[1], ri[2], ri[3], ci[0], ci[1], ci[2]);
+}
+
+// sA[0] = A (zero-padded 4 x 4), sA[1] = A - b c^T, sig[i] = 1 / gamma_i, all float64
+__device__ __forceinline__ void tf_stage_block(const float* __restrict__ A, const float* __restrict__ b,
+                                               const float* __restrict__ c, const float* __restrict__ ig,
+                                               int blk, int n, int tid, double (*sA)[16], double* sig) {
+  if (tid < 16) {
+    const int i = tid >> 2, j = tid & 3;
+    const bool in = i < n && j < n;
+    const double a = in ? (double)A[(size_t)blk * n * n + i * n + j] : 0.0;
+    const double bc = in ? (double)b[blk * n + i] * (double)c[blk * n + j] : 0.0;
+    sA[0][tid] = a;
+    sA[1][tid] = a - bc;
+  }
+  if (tid < 4) sig[tid] = (tid < n && ig) ? (double)ig[blk * n + tid] : 1.0;
+}
+
+__global__ __launch_bounds__(64) void k_tf_coefs(const float* __restrict__ A, const float* __restrict__ b,
+                                                 const float* __restrict__ c, const float* __restrict__ ig,
+                                                 int n, float* __restrict__ coef) {
+  __shared__ double sA[2][16], sq[2][16], sig[4];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  tf_stage_block(A, b, c, ig, blk, n, tid, sA, sig);
+  __syncthreads();
+  if (tid < 32) {
+    const int v = tid >> 4, S = tid & 15;
+    double q = 0.0;
+    if ((S >> n) == 0) {
+      int T[4], t = 0;
+      for (int i = 0; i < n; ++i)
+        if (!((S >> i) & 1)) T[t++] = i;
+      q = tf_det(sA[v], T, T, t);
+      if (t & 1) q = -q;
+    }
+    sq[v][S] = q;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    double igp = 1.0;
+    for (int i = 0; i < 4; ++i)
+      if ((tid >> i) & 1) igp *= sig[i];
+    coef[(size_t)blk * TF_REC + tid] = (float)((sq[1][tid] - sq[0][tid]) * igp);
+    coef[(size_t)blk * TF_REC + 16 + tid] = (float)(sq[0][tid] * igp);
+  }
+}
+
+extern "C" int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c, const float* inv_gamma,
+                                 int nblk, int nper, float* coef, void* stream) {
+  if (!A || !b || !c || !coef || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 4) return GFDN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tf_coefs, dim3(nblk), dim3(64), 0, (hipStream_t)stream, A, b, c, inv_gamma, nper, coef);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// dL/dcoef records -> dL/dA, dL/db, dL/dc for up to two coefficient sets that share b, c (set 0: the damped loop,
+// A0 = Q Q with 1 / gamma; set 1: the sub-FDNs, A1 = raw M).  grec_s (nblk, 32): the summed records.
+struct TfBwdSet {
+  const float* A;
+  const float* ig;
+  const float* grec;
+  float* gA;
+};
+__global__ __launch_bounds__(64) void k_tf_coefs_bwd(TfBwdSet s0, TfBwdSet s1, const float* __restrict__ b,
+                                                     const float* __restrict__ c, int n, float* __restrict__ gb,
+                                                     float* __restrict__ gc) {
+  __shared__ double sA[2][2][16], sig[2][4], sgq[2][2][16], sgA[2][2][16];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int nsets = s1.A ? 2 : 1;
+  tf_stage_block(s0.A, b, c, s0.ig, blk, n, tid, sA[0], sig[0]);
+  if (nsets == 2) tf_stage_block(s1.A, b, c, s1.ig, blk, n, tid, sA[1], sig[1]);
+  __syncthreads();
+  if (tid < 32 * nsets) {
+    const int s = tid >> 5, v = (tid >> 4) & 1, S = tid & 15;
+    const float* grec = (s ? s1.grec : s0.grec) + (size_t)blk * TF_REC;
+    double igp = 1.0;
+    for (int i = 0; i < 4; ++i)
+      if ((S >> i) & 1) igp *= sig[s][i];
+    double g = 0.0;
+    if ((S >> n) == 0 && S != (1 << n) - 1)            // (the full set's determinant is the constant 1)
+      g = v ? (double)grec[S] * igp : ((double)grec[16 + S] - (double)grec[S]) * igp;
+    sgq[s][v][S] = g;
+  }
+  __syncthreads();
+  if (tid < 32 * nsets) {
+    const int s = tid >> 5, v = (tid >> 4) & 1, i = (tid >> 2) & 3, j = tid & 3;
+    double acc = 0.0;
+    if (i < n && j < n) {
+      for (int S = 0; S < (1 << n); ++S) {
+        if (((S >> i) & 1) || ((S >> j) & 1)) continue;
+        int Ti[4], Tj[4], ti = 0, tj = 0, pi = 0, pj = 0, t = 0;
+        for (int l = 0; l < n; ++l) {
+          if ((S >> l) & 1) continue;
+          if (l == i) pi = t; else Ti[ti++] = l;
+          if (l == j) pj = t; else Tj[tj++] = l;
+          ++t;
+        }
+        double cof = tf_det(sA[s][v], Ti, Tj, t - 1);
+        if ((pi + pj + t) & 1) cof = -cof;                 // cofactor sign (-1)^(pi+pj) times (-1)^|T|
+        acc += sgq[s][v][S] * cof;
+      }
+    }
+    sgA[s][v][i * 4 + j] = acc;
+  }
+  __syncthreads();
+  if (tid < 16 * nsets) {
+    const int s = tid >> 4, i = (tid >> 2) & 3, j = tid & 3;
+    const TfBwdSet& st = s ? s1 : s0;
+    if (i < n && j < n && st.gA) st.gA[(size_t)blk * n * n + i * n + j] = (float)(sgA[s][0][i * 4 + j] + sgA[s][1][i * 4 + j]);
+  } else if (tid >= 32 && tid < 36) {
+    const int i = tid - 32;
+    if (i < n && gb) {
+      double acc = 0.0;
+      for (int s = 0; s < nsets; ++s)
+        for (int j = 0; j < n; ++j) acc -= sgA[s][1][i * 4 + j] * (double)c[blk * n + j];
+      gb[blk * n + i] = (float)acc;
+    }
+  } else if (tid >= 48 && tid < 52) {
+    const int j = tid - 48;
+    if (j < n && gc) {
+      double acc = 0.0;
+      for (int s = 0; s < nsets; ++s)
+        for (int i = 0; i < n; ++i) acc -= sgA[s][1][i * 4 + j] * (double)b[blk * n + i];
+      gc[blk * n + j] = (float)acc;
+    }
+  }
+}
+
+extern "C" int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const float* grec0, const float* A1,
+                                 const float* inv_gamma1, const float* grec1, const float* b, const float* c,
+                                 int nblk, int nper, float* gA0, float* gA1, float* gb, float* gc, void* stream) {
+  if (!A0 || !grec0 || !b || !c || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (A1 && !grec1) return GFDN_E_BADARG;
+  if (nper > 4) return GFDN_E_UNSUPPORTED;
+  TfBwdSet s0{A0, inv_gamma0, grec0, gA0};
+  TfBwdSet s1{A1, inv_gamma1, grec1, gA1};
+  hipLaunchKernelGGL(k_tf_coefs_bwd, dim3(nblk), dim3(64), 0, (hipStream_t)stream, s0, s1, b, c, nper, gb, gc);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// out0[r] (r < n0) / out1[r - n0] = sum_p part[r][p]: one wavefront per row, fixed order
+// pick_out (optional): rows r < n0 with r % 32 == 15 also go to pick_out[r / 32] (the loss partials of the
+// colorless pass, parked in the slot of P_full).
+__global__ __launch_bounds__(256) void k_tf_rows_sum(const float* __restrict__ part, int cols, int rows,
+                                                     float* __restrict__ out0, int n0, float* __restrict__ out1,
+                                                     float* __restrict__ pick_out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* row = part + (size_t)r * cols;
+  int p = lane;
+  for (; p + 192 < cols; p += 256) {
+    s0 += row[p];
+    s1 += row[p + 64];
+    s2 += row[p + 128];
+    s3 += row[p + 192];
+  }
+  for (; p < cols; p += 64) s0 += row[p];
+  const float s = wave_sum((s0 + s1) + (s2 + s3));
+  if (lane == 0) {
+    if (r < n0) {
+      out0[r] = s;
+      if (pick_out && (r & 31) == 15) pick_out[r >> 5] = s;
+    } else {
+      out1[r - n0] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// thread-per-(bin, block) launches
+// ------------------------------------------------------------------------------------------
+struct TfArgs {
+  const double* turns;
+  const double* logr;
+  int K, nblk, nper;
+  const float* coef;
+  const float* delays;
+  const float* scale;      // per block, multiplies T (NULL: 1)
+};
+
+static int tf_items(int nblk) { return (256 / nblk) * nblk; }
+static int tf_parts_host(int K, int nblk) {
+  const int rows = 256 / nblk;
+  const int full = (K + rows - 1) / rows;
+  int parts = (K + 8 * rows - 1) / (8 * rows);
+  if (parts < 1024) parts = full < 1024 ? full : 1024;
+  if (parts > TF_MAX_PARTS) parts = TF_MAX_PARTS;
+  return parts;
+}
+extern "C" int gfdn_tf_parts(int K, int nblk) {
+  if (K <= 0 || nblk <= 0 || nblk > TF_MAXBLK) return 0;
+  return tf_parts_host(K, nblk);
+}
+
+static int tf_args_ok(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays) {
+  if (!turns || !coef || !delays || K <= 0 || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 4 || nblk > TF_MAXBLK) return GFDN_E_UNSUPPORTED;
+  return 0;
+}
+
+// T[k][blk] (bin-major) = scale_blk * Num / Den
+__global__ __launch_bounds__(256) void k_tf_eval(TfArgs a, float2* __restrict__ T) {
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= (long long)a.K * a.nblk) return;
+  const int k = (int)(w / a.nblk), blk = (int)(w - (long long)k * a.nblk);
+  float P[16], Q[16], m[4];
+  tf_load(a.coef, a.delays, blk, a.nper, P, Q, m);
+  float2 e[16], num, den;
+  tf_phasors(a.turns, a.logr, k, m, e);
+  tf_numden(P, Q, e, num, den);
+  float2 t = cmul(num, cinv(den));
+  if (a.scale) t = cscale(t, a.scale[blk]);
+  T[w] = t;
+}
+
+extern "C" int gfdn_tf_eval(const double* turns, const double* logr, int K, int nblk, int nper,
+                            const float* coef, const float* delays, const float* scale, float* T,
+                            void* stream) {
+  int rc = tf_args_ok(turns, K, nblk, nper, coef, delays);
+  if (rc) return rc;
+  if (!T) return GFDN_E_BADARG;
+  TfArgs a{turns, logr, K, nblk, nper, coef, delays, scale};
+  const long long items = (long long)K * nblk;
+  hipLaunchKernelGGL(k_tf_eval, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                     (float2*)T);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// partial[blk * gridDim.x + part] = sum over this workgroup's bins of |T|^2
+__global__ __launch_bounds__(256) void k_tf_energy(TfArgs a, float* __restrict__ partial, int items) {
+  __shared__ float s_e[256];
+  const int nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  float P[16], Q[16], m[4];
+  tf_load(a.coef, a.delays, blk, a.nper, P, Q, m);
+  float acc = 0.f;
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
+    float2 e[16], num, den;
+    tf_phasors(a.turns, a.logr, k, m, e);
+    tf_numden(P, Q, e, num, den);
+    acc += (num.x * num.x + num.y * num.y) / (den.x * den.x + den.y * den.y);
+  }
+  s_e[threadIdx.x] = live ? acc : 0.f;
+  __syncthreads();
+  for (int bq = threadIdx.x; bq < nblk; bq += 256) {
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s_e[t];
+    partial[(size_t)bq * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
+// E = sum / K -> energy, scale = E^(-1/2) (what T and the numerator coefficients scale by once b, c are
+// divided by E^(1/4): trainer.py:317-332), and the in-place rescale of b, c
+__global__ __launch_bounds__(256) void k_tf_energy_finish(const float* __restrict__ partial, int nparts, int K,
+                                                          int nper, float* __restrict__ b, float* __restrict__ c,
+                                                          float* __restrict__ energy, float* __restrict__ scale) {
+  __shared__ float s_red[16];
+  const int g = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)g * nparts + p];
+  s = block_sum(s, s_red);
+  const float E = s / (float)K;
+  if (threadIdx.x == 0) {
+    if (energy) energy[g] = E;
+    if (scale) scale[g] = 1.0f / sqrtf(E);
+  }
+  if (b && c) {
+    const float d = powf(E, 0.25f);
+    for (int i = threadIdx.x; i < nper; i += 256) {
+      b[g * nper + i] /= d;
+      c[g * nper + i] /= d;
+    }
+  }
+}
+
+extern "C" size_t gfdn_tf_work_bytes(int nblk) {
+  return (size_t)TF_MAX_PARTS * (nblk > 0 ? nblk : 1) * sizeof(float);
+}
+
+extern "C" int gfdn_tf_energy(const double* turns, const double* logr, int K, int nblk, int nper,
+                              const float* coef, const float* delays, float* b, float* c, float* energy,
+                              float* scale, void* work, void* stream) {
+  int rc = tf_args_ok(turns, K, nblk, nper, coef, delays);
+  if (rc) return rc;
+  if (!work || (!b) != (!c)) return GFDN_E_BADARG;
+  TfArgs a{turns, logr, K, nblk, nper, coef, delays, nullptr};
+  const int nparts = tf_parts_host(K, nblk);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tf_energy, dim3(nparts), dim3(256), 0, s, a, (float*)work, tf_items(nblk));
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_tf_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, nparts, K, nper, b, c,
+                     energy, scale);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Colorless pass (colorless_fdn/losses.py:20-73 on Hout[:, g], trainer.py:298-304): S' = scale T,
+// loss_g = mean_k (|S'| - 1)^p (p = 4 where asym and |S'| - 1 > 1, else 2), and dL/dcoef of
+// gscale * sum_g loss_g with respect to the records of S' (numerator coefficients P' = scale P):
+//     dL/dP'_S = Re(gS' conj(e_S / Den)) ,   dL/dQ_S = -Re(gS' conj(S' e_S / Den)).
+// gpart[(blk * 32 + e) * nparts + part]: e < 15 dL/dP'_S, e = 15 the loss partial, 16 + S dL/dQ_S.
+__global__ __launch_bounds__(256) void k_tf_colorless(TfArgs a, int asym, float gscale, float* __restrict__ gpart,
+                                                      int items) {
+  extern __shared__ float tf_acc[];        // [items][33]
+  const int nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  float P[16], Q[16], m[4];
+  tf_load(a.coef, a.delays, blk, a.nper, P, Q, m);
+  const float sc = a.scale ? a.scale[blk] : 1.0f;
+  const float invK = 1.0f / (float)a.K;
+  float aP[16], aQ[16];
+#pragma unroll
+  for (int S = 0; S < 16; ++S) aP[S] = aQ[S] = 0.f;
+#pragma unroll 1
+  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
+    float2 e[16], num, den;
+    tf_phasors(a.turns, a.logr, k, m, e);
+    tf_numden(P, Q, e, num, den);
+    const float2 dinv = cinv(den);
+    const float2 s = cscale(cmul(num, dinv), sc);
+    const float mag = sqrtf(s.x * s.x + s.y * s.y);
+    const float d = mag - 1.0f, d2 = d * d;
+    const bool four = asym && (d > 1.0f);
+    aP[15] += (four ? d2 * d2 : d2) * invK;
+    const float dl = four ? 4.0f * d2 * d : 2.0f * d;
+    const float f = (mag > 0.f) ? gscale * invK * dl / mag : 0.f;
+    const float2 gs = make_float2(f * s.x, f * s.y);
+    const float2 u = cmulc(gs, dinv);                  // gS' conj(1 / Den)
+    const float2 v = cmulc(u, s);                      // u conj(S')
+    aP[0] += u.x;
+    aQ[0] -= v.x;
+#pragma unroll
+    for (int S = 1; S < 16; ++S) {
+      if (S < 15) aP[S] += u.x * e[S].x + u.y * e[S].y;
+      aQ[S] -= v.x * e[S].x + v.y * e[S].y;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int S = 0; S < 16; ++S) {
+      tf_acc[threadIdx.x * 33 + S] = aP[S];
+      tf_acc[threadIdx.x * 33 + 16 + S] = aQ[S];
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < nblk * TF_REC; o += 256) {
+    const int bq = o >> 5, e = o & 31;
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += tf_acc[t * 33 + e];
+    gpart[(size_t)o * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
+extern "C" size_t gfdn_tf_gpart_bytes(int nblk) {
+  return (size_t)TF_MAX_PARTS * (nblk > 0 ? nblk : 1) * TF_REC * sizeof(float);
+}
+
+extern "C" int gfdn_tf_colorless(const double* turns, const double* logr, int K, int nblk, int nper,
+                                 const float* coef, const float* delays, const float* scale, int asym,
+                                 float gscale, float* grec, float* loss, void* work, void* stream) {
+  int rc = tf_args_ok(turns, K, nblk, nper, coef, delays);
+  if (rc) return rc;
+  if (!grec || !work) return GFDN_E_BADARG;
+  TfArgs a{turns, logr, K, nblk, nper, coef, delays, scale};
+  const int nparts = tf_parts_host(K, nblk), items = tf_items(nblk);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tf_colorless, dim3(nparts), dim3(256), (size_t)items * 33 * sizeof(float), s, a, asym, gscale,
+                     (float*)work, items);
+  GFDN_LAUNCH_CHECK();
+  const int rows = nblk * TF_REC;
+  hipLaunchKernelGGL(k_tf_rows_sum, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)work, nparts, rows, grec, rows,
+                     (float*)nullptr, loss);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// output stage straight from the coefficient records (model.py:583-619 with trainer.py:459 folded in):
+//   H[b][k] = (sum_g rgain[b][g] scale_g T_g(z_k) + direct[rows[b]][k]) * filt[k]
+// band-stacked: blocks band * G + g, items band * B + b, filter row band.
+// ------------------------------------------------------------------------------------------
+struct TfCompose {
+  const double* turns;
+  const double* logr;
+  int K, G, nper, B;
+  const float* coef;
+  const float* delays;
+  const float* scale;
+  const float* rgain;
+  const float2* filt;
+  int ldf;
+};
+
+#define TFC_BCH 8
+__global__ __launch_bounds__(256) void k_tf_compose_fwd(TfCompose a, const float2* __restrict__ direct, int ldd,
+                                                        const long long* __restrict__ drows,
+                                                        float2* __restrict__ H, int ldh) {
+  __shared__ TfBlock tab[TF_MAXG];
+  const int band = blockIdx.y, G = a.G, B = a.B;
+  tf_stage(a.coef, a.delays, band * G, G, a.nper, tab);
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.K) return;
+  const float* rgain = a.rgain + (size_t)band * B * G;
+  if (drows) drows += (size_t)band * B;
+  else if (direct) direct += (size_t)band * B * ldd;
+  H += (size_t)band * B * ldh;
+  // the first receivers' direct-path loads fly while the transfer functions are evaluated (with one wave of
+  // workgroups on the chip the launch would otherwise run as a compute phase followed by a memory phase)
+  float2 d[TFC_BCH];
+#pragma unroll
+  for (int bb = 0; bb < TFC_BCH; ++bb)
+    d[bb] = (direct && bb < B) ? direct[(size_t)(drows ? drows[bb] : bb) * ldd + k] : make_float2(0.f, 0.f);
+  float2 T[TF_MAXG];
+#pragma unroll
+  for (int g = 0; g < TF_MAXG; ++g) {
+    T[g] = make_float2(0.f, 0.f);
+    if (g < G) {
+      float2 e[16], num, den;
+      tf_phasors(a.turns, a.logr, k, tab[g].m, e);
+      tf_numden(tab[g].P, tab[g].Q, e, num, den);
+      T[g] = cmul(num, cinv(den));
+      if (a.scale) T[g] = cscale(T[g], a.scale[band * G + g]);
+    }
+  }
+  const float2 f = a.filt ? a.filt[(size_t)band * a.ldf + k] : make_float2(1.f, 0.f);
+  for (int b0 = 0; b0 < B; b0 += TFC_BCH) {
+    float2 dn[TFC_BCH];
+#pragma unroll
+    for (int bb = 0; bb < TFC_BCH; ++bb) {               // next chunk's loads in flight over this chunk's stores
+      const int b = b0 + TFC_BCH + bb;
+      dn[bb] = (direct && b < B) ? direct[(size_t)(drows ? drows[b] : b) * ldd + k] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int bb = 0; bb < TFC_BCH; ++bb) {
+      const int b = b0 + bb;
+      if (b < B) {
+        float2 h = d[bb];
+#pragma unroll
+        for (int g = 0; g < TF_MAXG; ++g) {
+          if (g < G) {
+            const float rg = rgain[b * G + g];
+            h.x += rg * T[g].x;
+            h.y += rg * T[g].y;
+          }
+        }
+        if (a.filt) h = cmul(h, f);
+        H[(size_t)b * ldh + k] = h;
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < TFC_BCH; ++bb) d[bb] = dn[bb];
+  }
+}
+
+static int tf_compose_ok(const double* turns, int K, int nbands, int G, int nper, int B, const float* coef,
+                         const float* delays, const float* rgain) {
+  if (!turns || !coef || !delays || !rgain || K <= 0 || nbands <= 0 || G <= 0 || nper <= 0 || B <= 0)
+    return GFDN_E_BADARG;
+  if (nper > 4 || G > TF_MAXG || nbands > 65535) return GFDN_E_UNSUPPORTED;
+  return 0;
+}
+
+extern "C" int gfdn_tf_compose_fwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
+                                   const float* coef, const float* delays, const float* scale,
+                                   const float* rgain, int B, const float* direct, int ldd,
+                                   const long long* direct_rows, const float* filt, int ldf, float* H, int ldh,
+                                   void* stream) {
+  int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
+  if (rc) return rc;
+  if (!H || ldh < K || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
+  TfCompose a{turns, logr, K, G, nper, B, coef, delays, scale, rgain, (const float2*)filt, ldf};
+  hipLaunchKernelGGL(k_tf_compose_fwd, dim3((K + 255) / 256, nbands), dim3(256), 0, (hipStream_t)stream, a,
+                     (const float2*)direct, ldd, direct ? direct_rows : nullptr, (float2*)H, ldh);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward of the output stage: reads dL/dH once and leaves
+//   gpart[((band * G + g) * 32 + e) * nparts + part] : dL/dcoef partials of the (scaled) records, as k_tf_colorless
+//   rg_partial[(band * B * G + b * G + g) * nparts + part] : partials of dL/drgain[b][g] = sum_k Re(gW conj(T'_g)).
+// One workgroup = 4 wavefronts sweeps tiles of 64 bins: wavefront g evaluates T'_g for the tile's bins and keeps
+// the phasors in registers; the receiver loop is split over the wavefronts (each dL/dH value is read once and
+// serves dL/dT' and its receiver-gain product, summed over the bins in a fixed order through LDS); then
+// wavefront g folds dL/dT'_g into its 30 coefficient accumulators, reduced over the lanes once per launch.
+#define TFB_T 64
+#define TFB_RB 16
+__global__ __launch_bounds__(256, 2) void k_tf_compose_bwd(TfCompose a, const float2* __restrict__ gH, int ldh,
+                                                        float* __restrict__ gpart, float* __restrict__ rg_partial) {
+  __shared__ TfBlock tab[TF_MAXG];
+  __shared__ float2 s_T[TF_MAXG][TFB_T];
+  __shared__ float2 s_g[4][TF_MAXG][TFB_T];
+  __shared__ float pp[TFB_RB * TF_MAXG][TFB_T + 1];
+  const int band = blockIdx.y, G = a.G, B = a.B, nparts = gridDim.x;
+  tf_stage(a.coef, a.delays, band * G, G, a.nper, tab);
+  __syncthreads();
+  // (wave index made wave-uniform for the compiler: the receiver-gain reads become scalar loads)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* rgain = a.rgain + (size_t)band * B * G;
+  gH += (size_t)band * B * ldh;
+  const float sc = (a.scale && w < G) ? a.scale[band * G + w] : 1.0f;
+  float aP[16], aQ[16];
+#pragma unroll
+  for (int S = 0; S < 16; ++S) aP[S] = aQ[S] = 0.f;
+  // receiver-gain sums this thread owns: outputs o = threadIdx.x >> 1 of every receiver chunk
+  float rgacc[4] = {0.f, 0.f, 0.f, 0.f};                 // chunks of TFB_RB receivers: B <= 64
+  const int ntiles = (a.K + TFB_T - 1) / TFB_T;
+  for (int tile = blockIdx.x; tile < ntiles; tile += nparts) {
+    const int k = tile * TFB_T + lane;
+    const bool live = k < a.K;
+    const int kk = live ? k : a.K - 1;
+    float2 ghn[TFB_RB / 4];
+#pragma unroll
+    for (int i = 0; i < TFB_RB / 4; ++i) {               // chunk 0 of dL/dH flies while T is evaluated
+      const int b = w + 4 * i;
+      ghn[i] = (live && b < B) ? gH[(size_t)b * ldh + kk] : make_float2(0.f, 0.f);
+    }
+    float2 e[16], dinv = make_float2(0.f, 0.f), Tw = make_float2(0.f, 0.f);
+    if (w < G) {
+      float2 num, den;
+      tf_phasors(a.turns, a.logr, kk, tab[w].m, e);
+      tf_numden(tab[w].P, tab[w].Q, e, num, den);
+      dinv = cinv(den);
+      Tw = cscale(cmul(num, dinv), sc);
+      s_T[w][lane] = Tw;
+    }
+    __syncthreads();
+    float2 Sl[TF_MAXG], acc[TF_MAXG];
+#pragma unroll
+    for (int g = 0; g < TF_MAXG; ++g) {
+      acc[g] = make_float2(0.f, 0.f);
+      Sl[g] = g < G ? s_T[g][lane] : make_float2(0.f, 0.f);
+    }
+    const float2 fc = a.filt ? cconj(a.filt[(size_t)band * a.ldf + kk]) : make_float2(1.f, 0.f);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const int b0 = ch * TFB_RB;
+      if (b0 >= B) break;                                // (uniform)
+      float2 ghv[TFB_RB / 4];
+#pragma unroll
+      for (int i = 0; i < TFB_RB / 4; ++i) {
+        ghv[i] = ghn[i];
+        const int b = b0 + TFB_RB + w + 4 * i;           // next chunk
+        ghn[i] = (live && b < B) ? gH[(size_t)b * ldh + kk] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < TFB_RB / 4; ++i) {
+        const int b = b0 + w + 4 * i;
+        if (b < B) {
+          float2 gh = ghv[i];
+          if (a.filt) gh = cmul(gh, fc);
+#pragma unroll
+          for (int g = 0; g < TF_MAXG; ++g) {
+            if (g < G) {
+              const float rg = rgain[b * G + g];
+              acc[g].x += rg * gh.x;
+              acc[g].y += rg * gh.y;
+              pp[(b - b0) * G + g][lane] = gh.x * Sl[g].x + gh.y * Sl[g].y;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int nout = (B - b0 < TFB_RB ? B - b0 : TFB_RB) * G;
+      {
+        const int o = threadIdx.x >> 1, h = threadIdx.x & 1;
+        float sacc = 0.f;
+        if (o < nout)
+          for (int j = 0; j < 32; ++j) sacc += pp[o][h * 32 + j];
+        sacc += __shfl_xor(sacc, 1);
+        rgacc[ch] += sacc;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < TF_MAXG; ++g)
+      if (g < G) s_g[w][g][lane] = acc[g];
+    __syncthreads();
+    if (w < G) {
+      float2 gt = s_g[0][w][lane];
+      gt = cadd(gt, s_g[1][w][lane]);
+      gt = cadd(gt, s_g[2][w][lane]);
+      gt = cadd(gt, s_g[3][w][lane]);
+      const float2 u = cmulc(gt, dinv);               // dL/dT' conj(1 / Den)   (zero beyond K: gH loads were zero)
+      const float2 v = cmulc(u, Tw);
+      aP[0] += u.x;
+      aQ[0] -= v.x;
+#pragma unroll
+      for (int S = 1; S < 16; ++S) {
+        if (S < 15) aP[S] += u.x * e[S].x + u.y * e[S].y;
+        aQ[S] -= v.x * e[S].x + v.y * e[S].y;
+      }
+    }
+    __syncthreads();
+  }
+  if (w < G) {
+    float* out = gpart + (size_t)(band * G + w) * TF_REC * nparts + blockIdx.x;
+#pragma unroll
+    for (int S = 0; S < 16; ++S) {
+      const float p = wave_sum(aP[S]), q = wave_sum(aQ[S]);
+      if (lane == 0) {
+        out[(size_t)S * nparts] = p;
+        out[(size_t)(16 + S) * nparts] = q;
+      }
+    }
+  }
+  {
+    const int o = threadIdx.x >> 1, h = threadIdx.x & 1;
+    if (h == 0) {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        const int b0 = ch * TFB_RB;
+        if (b0 >= B) break;
+        const int nout = (B - b0 < TFB_RB ? B - b0 : TFB_RB) * G;
+        if (o < nout) rg_partial[((size_t)band * B * G + (size_t)b0 * G + o) * nparts + blockIdx.x] = rgacc[ch];
+      }
+    }
+  }
+}
+
+static int tf_compose_parts_host(int K) {
+  const int tiles = (K + TFB_T - 1) / TFB_T;
+  int parts = (tiles + 3) / 4;                   // ~4 tiles per workgroup
+  if (parts > TF_MAX_PARTS) parts = TF_MAX_PARTS;
+  return parts < 1 ? 1 : parts;
+}
+extern "C" int gfdn_tf_compose_parts(int K) { return K > 0 ? tf_compose_parts_host(K) : 0; }
+extern "C" size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G, int B) {
+  if (K <= 0 || nbands <= 0 || G <= 0 || B <= 0) return 0;
+  return (size_t)nbands * G * (TF_REC + B) * tf_compose_parts_host(K) * sizeof(float);
+}
+
+extern "C" int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
+                                   const float* coef, const float* delays, const float* scale,
+                                   const float* rgain, int B, const float* filt, int ldf, const float* gH,
+                                   int ldh, float* grec, float* grgain, void* work, void* stream) {
+  int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
+  if (rc) return rc;
+  if (!gH || !grec || !grgain || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
+  if (B > 4 * TFB_RB) return GFDN_E_UNSUPPORTED;
+  TfCompose a{turns, logr, K, G, nper, B, coef, delays, scale, rgain, (const float2*)filt, ldf};
+  const int nparts = tf_compose_parts_host(K);
+  hipStream_t s = (hipStream_t)stream;
+  // work = [record partials (nbands G 32 rows) | receiver-gain partials (nbands B G rows)], nparts columns each
+  float* gpart = (float*)work;
+  float* rg_partial = gpart + (size_t)nbands * G * TF_REC * nparts;
+  hipLaunchKernelGGL(k_tf_compose_bwd, dim3(nparts, nbands), dim3(256), 0, s, a, (const float2*)gH, ldh, gpart,
+                     rg_partial);
+  GFDN_LAUNCH_CHECK();
+  const int n0 = nbands * G * TF_REC, rows = n0 + nbands * B * G;
+  hipLaunchKernelGGL(k_tf_rows_sum, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)work, nparts, rows, grec, n0,
+                     grgain, (float*)nullptr);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of the DiffGFDN hot path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -56,13 +57,16 @@ __device__ __forceinline__ float block_sum(float v, float* lds /* >= 16 floats *
 }
 
 // dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
-// The largest size already granted per kernel is remembered (a benign process-wide cache) so that
-// steady-state launches -- and launches under HIP graph capture -- make no runtime API call.
+// The largest size already granted per kernel is remembered (a process-wide cache, the library's only global
+// state, guarded by a mutex: launches may come from several host threads) so that steady-state launches -- and
+// launches under HIP graph capture -- make no runtime API call.
 static inline int ensure_dyn_lds_ptr(const void* fn, size_t bytes) {
   if (bytes <= 48 * 1024) return 0;
   static const void* fns[32];
   static size_t granted[32];
   static int count = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   int slot = -1;
   for (int i = 0; i < count; ++i)
     if (fns[i] == fn) { slot = i; break; }

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_ortho_bwd(const float* __restrict__ M, 
                                                    const float* __restrict__ gQ,
                                                    const float* __restrict__ gQQ,
                                                    const float* __restrict__ Qsaved,
+                                                   const float* __restrict__ gM_add,
                                                    float* __restrict__ gM) {
   const int m = 2 * n;
   double* A = ortho_lds;          // m*m
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void k_ortho_bwd(const float* __restrict__ M, 
     const int i = e / n, j = e - i * n;
     double v = 0.0;
     if (i < j) v = gmax * (E[i * m + n + j] - E[j * m + n + i]);
+    if (gM_add) v += (double)gM_add[off + e];      // a gradient that reaches M directly (the raw blocks of the sub-FDNs)
     gM[off + e] = (float)v;
   }
 }
@@ -197,13 +199,19 @@ extern "C" int gfdn_ortho_fwd(const float* M, int G, int n, float* Q, float* QQ,
   return 0;
 }
 
-extern "C" int gfdn_ortho_bwd(const float* M, int G, int n, const float* gQ, const float* gQQ,
-                              const float* Q, float* gM, void* stream) {
+extern "C" int gfdn_ortho_bwd_add(const float* M, int G, int n, const float* gQ, const float* gQQ,
+                                  const float* Q, const float* gM_add, float* gM, void* stream) {
   if (!M || !gM || (!gQ && !gQQ) || G <= 0 || n <= 0) return GFDN_E_BADARG;
   if (n > GFDN_MAX_BLOCK || ortho_bwd_lds(n) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_ortho_bwd, ortho_bwd_lds(n));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ortho_bwd, dim3(G), dim3(256), ortho_bwd_lds(n), (hipStream_t)stream, M, n, gQ, gQQ, Q, gM);
+  hipLaunchKernelGGL(k_ortho_bwd, dim3(G), dim3(256), ortho_bwd_lds(n), (hipStream_t)stream, M, n, gQ, gQQ, Q, gM_add,
+                     gM);
   GFDN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gfdn_ortho_bwd(const float* M, int G, int n, const float* gQ, const float* gQQ,
+                              const float* Q, float* gM, void* stream) {
+  return gfdn_ortho_bwd_add(M, G, n, gQ, gQQ, Q, nullptr, gM, stream);
 }

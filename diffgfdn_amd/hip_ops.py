@@ -514,6 +514,174 @@ def normalize_io(energy, b, c, G: int, nper: int):
 
 
 # ------------------------------------------------------------------------------------------------
+# block transfer functions in polynomial form (csrc/blocktf.hip; nper <= 4, zero coupling)
+def tf_coefs(A, b, c, inv_gamma=None, out=None) -> torch.Tensor:
+    """A (nblk, n, n), b, c (nblk*n), inv_gamma (nblk*n) or None -> coef (nblk, 32) float32 records
+    [P_S | Q_S] with T(z) = sum_S P_S e_S / sum_S Q_S e_S, e_S = prod_{i in S} z^{m_i}."""
+    _need_gpu(A, b, c)
+    A, b, c = _f(A), _f(b).reshape(-1), _f(c).reshape(-1)
+    nblk, n, _ = A.shape
+    if n > 4:
+        raise RuntimeError("tf_coefs: blocks of at most 4 delay lines")
+    if b.numel() != nblk * n or c.numel() != nblk * n:
+        raise RuntimeError("tf_coefs: b, c must hold nblk * n gains")
+    ig = None if inv_gamma is None else _f(inv_gamma).reshape(-1)
+    if ig is not None and ig.numel() != nblk * n:
+        raise RuntimeError("tf_coefs: inv_gamma must hold nblk * n gains")
+    coef = torch.empty((nblk, 32), dtype=_f32, device=A.device) if out is None else out
+    _lib.check(_lib.load().gfdn_tf_coefs_fwd(_p(A), _p(b), _p(c), _p(ig), nblk, n, _p(coef), _stream()),
+               "gfdn_tf_coefs_fwd")
+    return coef
+
+
+def tf_parts(K: int, nblk: int) -> int:
+    n = _lib.load().gfdn_tf_parts(int(K), int(nblk))
+    if n <= 0:
+        raise RuntimeError("tf_parts: unsupported number of blocks")
+    return n
+
+
+def tf_gpart(nblk: int, device) -> torch.Tensor:
+    """Partial-record buffer (max parts, nblk, 32) float32 of the reducing launches."""
+    return torch.empty(_lib.load().gfdn_tf_gpart_bytes(nblk) // 4, dtype=_f32, device=device)
+
+
+def tf_eval(turns, logr, coef, delays, nper: int, scale=None) -> torch.Tensor:
+    """-> T (K, nblk) complex64 bin-major."""
+    _need_gpu(turns, coef, delays)
+    coef, delays = _f(coef), _f(delays)
+    nblk, K = coef.shape[0], turns.numel()
+    if delays.numel() != nblk * nper:
+        raise RuntimeError("tf_eval: delays must hold nblk * nper entries")
+    scale = None if scale is None else _f(scale)
+    T = torch.empty((K, nblk), dtype=_c64, device=coef.device)
+    _lib.check(_lib.load().gfdn_tf_eval(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(scale), _p(T),
+                                        _stream()), "gfdn_tf_eval")
+    return T
+
+
+def tf_energy(turns, logr, coef, delays, nper: int, b=None, c=None, want_energy=True, want_scale=True, work=None):
+    """energy (nblk) = mean_k |T|^2, scale = energy^(-1/2); b, c (float32, contiguous): rescaled in place."""
+    _need_gpu(turns, coef, delays)
+    coef, delays = _f(coef), _f(delays)
+    nblk, K = coef.shape[0], turns.numel()
+    for t in (b, c):
+        if t is not None and (t.dtype != _f32 or not t.is_contiguous() or t.numel() != nblk * nper):
+            raise RuntimeError("tf_energy: gains must be contiguous float32 of nblk*nper elements")
+    lib = _lib.load()
+    energy = torch.empty(nblk, dtype=_f32, device=coef.device) if want_energy else None
+    scale = torch.empty(nblk, dtype=_f32, device=coef.device) if want_scale else None
+    work = _work(lib.gfdn_tf_work_bytes(nblk), coef.device) if work is None else work
+    _lib.check(lib.gfdn_tf_energy(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(b), _p(c), _p(energy),
+                                  _p(scale), _p(work), _stream()), "gfdn_tf_energy")
+    return energy, scale
+
+
+def tf_colorless(turns, logr, coef, delays, nper: int, scale, asym: bool, gscale: float, work=None):
+    """-> (grec (nblk, 32) gradient records of gscale * sum_blk loss_blk for the (scaled) sub-FDN records,
+    loss (nblk,) = mean_k (|scale T| - 1)^p)."""
+    _need_gpu(turns, coef, delays)
+    coef, delays = _f(coef), _f(delays)
+    nblk, K = coef.shape[0], turns.numel()
+    scale = None if scale is None else _f(scale)
+    work = tf_gpart(nblk, coef.device) if work is None else work
+    grec = torch.empty((nblk, 32), dtype=_f32, device=coef.device)
+    loss = torch.empty(nblk, dtype=_f32, device=coef.device)
+    _lib.check(_lib.load().gfdn_tf_colorless(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(scale),
+                                             int(asym), float(gscale), _p(grec), _p(loss), _p(work), _stream()),
+               "gfdn_tf_colorless")
+    return grec, loss
+
+
+def tf_compose_fwd(turns, logr, coef, delays, nper: int, rgain, scale=None, direct=None, filt=None,
+                   direct_rows=None, nbands: int = 1, out=None) -> torch.Tensor:
+    """H (nbands*B, K) complex64 from the records (band-stacked as compose_fwd)."""
+    _need_gpu(turns, coef, rgain)
+    coef, delays, rgain = _f(coef), _f(delays), _f(rgain)
+    K = turns.numel()
+    Btot, G = rgain.shape
+    if coef.shape[0] != nbands * G or Btot % nbands or delays.numel() != nbands * G * nper:
+        raise RuntimeError("tf_compose_fwd: shapes do not match nbands x G blocks")
+    ldd = 0
+    if direct is not None:
+        direct = direct.detach()
+        if not (direct.dtype == _c64 and direct.dim() == 2 and direct.stride(1) == 1 and direct.stride(0) >= K
+                and direct.shape[1] >= K):
+            direct = _c(direct)
+        ldd = direct.stride(0)
+    filt = None if filt is None else _c(filt)
+    if filt is not None and filt.numel() != nbands * K:
+        raise RuntimeError("tf_compose_fwd: filt must hold K bins per band")
+    direct_rows = None if direct is None else _rows(direct_rows, Btot, direct.shape[0])
+    if direct is not None and direct_rows is None and direct.shape[0] != Btot:
+        raise RuntimeError("tf_compose_fwd: direct must have one row per item (or pass direct_rows)")
+    scale = None if scale is None else _f(scale)
+    H = torch.empty((Btot, K), dtype=_c64, device=coef.device) if out is None else out
+    _lib.check(_lib.load().gfdn_tf_compose_fwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays),
+                                               _p(scale), _p(rgain), Btot // nbands, _p(direct), ldd,
+                                               _p(direct_rows), _p(filt), K, _p(H), K, _stream()),
+               "gfdn_tf_compose_fwd")
+    return H
+
+
+def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, scale=None, filt=None, nbands: int = 1,
+                   grgain=None, work=None):
+    """-> (grec (nbands*G, 32) gradient records, grgain (nbands*B, G))."""
+    _need_gpu(turns, coef, rgain, gH)
+    coef, delays, rgain, gH = _f(coef), _f(delays), _f(rgain), _c(gH)
+    K = turns.numel()
+    Btot, G = rgain.shape
+    if coef.shape[0] != nbands * G or Btot % nbands or tuple(gH.shape) != (Btot, K):
+        raise RuntimeError("tf_compose_bwd: shapes do not match nbands x G blocks")
+    filt = None if filt is None else _c(filt)
+    scale = None if scale is None else _f(scale)
+    lib = _lib.load()
+    grec = torch.empty((nbands * G, 32), dtype=_f32, device=coef.device)
+    grgain = torch.empty((Btot, G), dtype=_f32, device=coef.device) if grgain is None else grgain
+    if work is None:
+        work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G, Btot // nbands), coef.device)
+    _lib.check(lib.gfdn_tf_compose_bwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays), _p(scale),
+                                       _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(grgain),
+                                       _p(work), _stream()), "gfdn_tf_compose_bwd")
+    return grec, grgain
+
+
+def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):
+    """Gradient records -> (gA0, gA1 or None, gb, gc); b, c: the gains the records' gradients refer to."""
+    _need_gpu(A0, grec0, b, c)
+    A0, b, c, grec0 = _f(A0), _f(b).reshape(-1), _f(c).reshape(-1), _f(grec0)
+    nblk, n, _ = A0.shape
+    ig0 = None if ig0 is None else _f(ig0).reshape(-1)
+    dev = A0.device
+    if tuple(grec0.shape) != (nblk, 32) or (grec1 is not None and tuple(grec1.shape) != (nblk, 32)):
+        raise RuntimeError("tf_coefs_bwd: gradient records must be (nblk, 32)")
+    gA0 = torch.empty_like(A0) if gA0 is None else gA0
+    gb = torch.empty(nblk * n, dtype=_f32, device=dev) if gb is None else gb
+    gc = torch.empty(nblk * n, dtype=_f32, device=dev) if gc is None else gc
+    if A1 is not None:
+        A1, grec1 = _f(A1), _f(grec1)
+        ig1 = None if ig1 is None else _f(ig1).reshape(-1)
+        gA1 = torch.empty_like(A1) if gA1 is None else gA1
+    _lib.check(_lib.load().gfdn_tf_coefs_bwd(_p(A0), _p(ig0), _p(grec0), _p(A1), _p(ig1), _p(grec1), _p(b), _p(c),
+                                             nblk, n, _p(gA0), _p(gA1), _p(gb), _p(gc), _stream()),
+               "gfdn_tf_coefs_bwd")
+    return gA0, gA1, gb, gc
+
+
+def ortho_bwd_add(M, gQ, gQQ, Q, gM_add, out=None):
+    """ortho_bwd with ``gM_add`` (G, n, n) added to the result; ``out``: where to write gM."""
+    _need_gpu(M)
+    M = _f(M)
+    G, n, _ = M.shape
+    gM = torch.empty_like(M) if out is None else out
+    _lib.check(_lib.load().gfdn_ortho_bwd_add(_p(M), G, n, _p(None if gQ is None else _f(gQ)),
+                                              _p(None if gQQ is None else _f(gQQ)), _p(None if Q is None else _f(Q)),
+                                              _p(None if gM_add is None else _f(gM_add)), _p(gM), _stream()),
+               "gfdn_ortho_bwd_add")
+    return gM
+
+
+# ------------------------------------------------------------------------------------------------
 _blu_tables = {}
 
 
@@ -910,14 +1078,17 @@ def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi:
 
 
 def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains, rows=None,
-                  nbands: int = 1):
+                  nbands: int = 1, out=None):
+    """-> gw shaped like w (``out``: a contiguous float32 buffer of that size to write it into)."""
     _need_gpu(pos, w, ggains)
     pos = pos.detach().to(torch.float64).contiguous()
     w, ggains = _f(w), _f(ggains)
     B, F = (pos.shape[0] if rows is None else rows.numel()), freq_pi.numel()
     rows = _rows(rows, B, pos.shape[0])
     lib = _lib.load()
-    gw = torch.empty_like(w)
+    if out is not None and (out.dtype != _f32 or not out.is_contiguous() or out.numel() != w.numel()):
+        raise RuntimeError("mlp_gains_bwd: out must be a contiguous float32 buffer of the parameter count")
+    gw = torch.empty_like(w) if out is None else out
     work = _work(lib.gfdn_mlp_bwd_work_bytes(B, F, H, n_hidden, G), pos.device)
     if nbands > 1:
         _lib.check(lib.gfdn_mlp_gains_banded_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,

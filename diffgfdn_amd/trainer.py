@@ -704,7 +704,20 @@ class GraphedTrainStep:
             losses['_total'] = heads[0].detach() if len(heads) == 1 else heads[0].detach() + heads[1].detach()
         return losses
 
+    def _fused_fwd_bwd(self, opt_step: bool):
+        """The band bank's explicit launch sequence (bankstep.FusedBankStep): mask draw, normalize, forward, losses,
+        backward into the flat gradient buffer [, all-reduce, Adam]."""
+        tr = self.tr
+        draw = None
+        if self.mask_source == "device" and tr.criterion[1].use_mask:
+            draw = lambda: ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
+        batch = self.ds.collate(self.idx, lean="rows")
+        return tr._fused.run(batch, self.maskw, 1.0, normalize_first=True, train=True, allreduce=tr._allreduce,
+                             opt_step=opt_step, mask_draw=draw)
+
     def _eager(self):
+        if getattr(self.tr, '_fused', None) is not None:
+            return self._fused_fwd_bwd(opt_step=True)
         losses = self._fwd_bwd()
         self.tr.optimizer.pack_grads()
         if self.tr._allreduce is not None:
@@ -742,16 +755,23 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
+        fused = getattr(tr, '_fused', None) is not None
         if tr._allreduce is None:
             with torch.cuda.graph(self.graph_a):
-                self.losses = self._fwd_bwd()
-                tr.optimizer.pack_grads()
-                tr.optimizer.step()
+                if fused:
+                    self.losses = self._fused_fwd_bwd(opt_step=True)
+                else:
+                    self.losses = self._fwd_bwd()
+                    tr.optimizer.pack_grads()
+                    tr.optimizer.step()
         else:
             # forward + backward + pack | all-reduce of the flat gradient buffer (eager RCCL) | Adam
             with torch.cuda.graph(self.graph_a):
-                self.losses = self._fwd_bwd()
-                tr.optimizer.pack_grads()
+                if fused:
+                    self.losses = self._fused_fwd_bwd(opt_step=False)
+                else:
+                    self.losses = self._fwd_bwd()
+                    tr.optimizer.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
                 tr.optimizer.step()

@@ -50,6 +50,10 @@ int gfdn_zprep(const double* z_c128, int K, double* turns, double* logr, void* s
 int gfdn_ortho_fwd(const float* M, int G, int n, float* Q, float* QQ, void* stream);
 int gfdn_ortho_bwd(const float* M, int G, int n, const float* gQ, const float* gQQ, const float* Q,
                    float* gM, void* stream);
+/* as gfdn_ortho_bwd, plus gM_add (G,n,n) or NULL added to the result: a gradient that reaches M directly
+ * (the sub-FDNs of the colorless loss use the raw M_g, model.py:237-240).                               */
+int gfdn_ortho_bwd_add(const float* M, int G, int n, const float* gQ, const float* gQQ, const float* Q,
+                       const float* gM_add, float* gM, void* stream);
 
 /* ---- per-bin resolvent solve  (feedback_loop.py:326-391, model.py:237-240, :615-619) ---
  * For every bin k and diagonal block q (nblk blocks of size nper, N = nblk*nper):
@@ -259,6 +263,60 @@ int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr, int K, in
                               const float* M, const float* delays, const float* b, const float* c,
                               const float* energy, const float* Y_c64, const float* gS_c64, float* gM,
                               float* gb, float* gc, void* work, void* stream);
+
+/* ---- block transfer functions in polynomial form (nper <= 4, zero coupling)  ---------------------------
+ * With zero inter-group coupling (feedback_loop.py:298-303, :439-443) a receiver sees the loop only through
+ *     T_g(z) = c_g^T (D_g(z) Gamma_g^-1 - A_g)^-1 b_g      (model.py:583-619; sub-FDNs: model.py:237-250),
+ * which for a block of n <= 4 lines is a ratio of multilinear polynomials in the phasors z^{m_i}:
+ *     T = (sum_S P_S e_S) / (sum_S Q_S e_S),   e_S = prod_{i in S} z^{m_i},  S subset of the block's lines,
+ *     Q_S = (-1)^{|S^c|} det A[S^c, S^c] prod_{i in S} 1/gamma_i,
+ *     P_S = ((-1)^{|S^c|} det (A - b c^T)[S^c, S^c]) prod_{i in S} 1/gamma_i - Q_S   (matrix determinant lemma).
+ * coef (nblk, 32) float32 = [P_S (16) | Q_S (16)], S a bit mask (bit i = line i of the block).  The delay-line
+ * responses (K, N) of gfdn_solve_* are never formed; dL/d(A, b, c) goes through dL/dcoef (30 sums over the bins
+ * per block) and a bin-independent float64 map per block.
+ *   coefs_fwd : A (nblk, nper, nper), b, c (nblk*nper), inv_gamma (nblk*nper) or NULL (ones) -> coef.
+ *   eval      : T (K, nblk) complex64 BIN-MAJOR = scale_blk * T_blk(z_k)  (scale (nblk) or NULL).
+ *   energy    : Trainer.normalize (trainer.py:317-332) from the records of the sub-FDNs: energy (nblk) =
+ *               mean_k |T|^2 (optional), scale (nblk) = energy^(-1/2) (optional: what T -- and the numerator
+ *               records -- scale by once b, c are divided by energy^(1/4)), b, c (both or neither) rescaled in
+ *               place.  work: gfdn_tf_work_bytes(nblk).
+ *   colorless : spectral loss of the sub-FDNs (colorless_fdn/losses.py:20-73, trainer.py:298-304) on
+ *               S' = scale T: loss (nblk, optional) = mean_k (|S'| - 1)^p per block and the gradient record
+ *               grec (nblk, 32) of L = gscale * sum_blk loss_blk: entry S < 15 dL/dP'_S (P' = scale P), 16 + S
+ *               dL/dQ_S (entry 15 holds loss_blk).  work: gfdn_tf_gpart_bytes(nblk).
+ *   compose   : H[b][k] = (sum_g rgain[b][g] scale_g T_g(z_k) + direct[rows[b]][k]) filt[k], band-stacked as
+ *               gfdn_compose_banded_* (blocks band*G + g, items band*B + b); the backward reads dL/dH once and
+ *               returns the gradient records grec (nbands*G, 32) and grgain (nbands*B, G).  G <= 4, B <= 64.
+ *               work: gfdn_tf_compose_bwd_work_bytes.
+ *   coefs_bwd : maps gradient records to dL/dA, dL/db, dL/dc for up to two record sets sharing b, c (set 0:
+ *               damped loop, A0 = Q Q; set 1: sub-FDNs, A1 = raw M, or A1 = NULL): gA0, gA1 (nblk, nper, nper),
+ *               gb, gc (nblk*nper) = the sum over the sets.  b, c: the values the records' gradients refer to.  */
+int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c, const float* inv_gamma, int nblk,
+                      int nper, float* coef, void* stream);
+int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const float* grec0, const float* A1,
+                      const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
+                      int nper, float* gA0, float* gA1, float* gb, float* gc, void* stream);
+int gfdn_tf_parts(int K, int nblk);
+size_t gfdn_tf_work_bytes(int nblk);
+size_t gfdn_tf_gpart_bytes(int nblk);
+int gfdn_tf_eval(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                 const float* delays, const float* scale, float* T_c64, void* stream);
+int gfdn_tf_energy(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                   const float* delays, float* b, float* c, float* energy, float* scale, void* work,
+                   void* stream);
+int gfdn_tf_colorless(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                      const float* delays, const float* scale, int asym, float gscale, float* grec,
+                      float* loss, void* work, void* stream);
+int gfdn_tf_compose_fwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
+                        const float* coef, const float* delays, const float* scale, const float* rgain, int B,
+                        const float* direct_c64, int ldd, const long long* direct_rows, const float* filt_c64,
+                        int ldf, float* H_c64, int ldh, void* stream);
+int gfdn_tf_compose_parts(int K);
+size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G, int B);
+int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
+                        const float* coef, const float* delays, const float* scale, const float* rgain, int B,
+                        const float* filt_c64, int ldf, const float* gH_c64, int ldh, float* grec,
+                        float* grgain, void* work, void* stream);
 
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's

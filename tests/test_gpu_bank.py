@@ -225,25 +225,78 @@ def test_graphed_bank_step_equals_eager_bank_step():
     want = []
     for i, s in enumerate(sel_steps):
         b = sds2.collate(sds2.global_rows(s))
-        tr2.optimizer.zero_grad(set_to_none=True)
         mw = torch.tensor(philox_mask(777, i, length, 1.0 / 4)[0], device=DEV)
-        # normalize inside the step, as the captured graph does (the fused colorless branch rescales b, c
-        # from the same sub-FDN solve the loss uses; a separate tr2.normalize() differs in the last bits)
-        losses = tr2._step_losses(b, mask_prenorm=mw, defer_total=True, normalize_first=True)
-        heads = losses.pop("_heads")
-        torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
-        tr2.optimizer.pack_grads()
+        # normalize inside the step, as the captured graph does
+        if tr2._fused is not None:
+            losses = tr2._fused.run(b, mw, 1.0, normalize_first=True, train=True, opt_step=False)
+            total = losses["_total"]
+        else:
+            tr2.optimizer.zero_grad(set_to_none=True)
+            losses = tr2._step_losses(b, mask_prenorm=mw, defer_total=True, normalize_first=True)
+            heads = losses.pop("_heads")
+            torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
+            tr2.optimizer.pack_grads()
+            total = heads[0].detach() + heads[1].detach()
         if i == 0:
             # same state, same inputs: the replayed gradients are the eager ones to the last bit (Adam's
             # first update is sign(g), so the loss comparison below could not see a wrong magnitude)
             assert np.array_equal(tr2.optimizer.flat_grad.cpu().numpy(), got_grad[0])
         tr2.optimizer.step()
-        want.append((heads[0].detach() + heads[1].detach()).cpu().numpy())
+        want.append(total.cpu().numpy())
     for a, b in zip(got, want):
         assert np.allclose(a, b, rtol=1e-5, atol=0), (got, want)
     for q in range(len(BANDS)):
         for k, v in nets[q].state_dict().items():
             assert rel_err(v.detach().cpu(), nets2[q].state_dict()[k].detach().cpu()) < 5e-4, (q, k)
+
+
+@pytest.mark.parametrize("mask", [True, False])
+def test_fused_bank_step_equals_autograd_bank_step(mask):
+    """The explicit launch sequence on the polynomial form of the block transfer functions (bankstep.py) against the
+    autograd path on the per-bin elimination kernels: per-band losses, every gradient, the post-Adam state -- and
+    the no-grad (validation) form of the same step."""
+    from diffgfdn_amd.bandbank import BandBankTrainer
+    sels = [[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]]
+    res = {}
+    for fused in (True, False):
+        BandBankTrainer.use_fused = fused
+        try:
+            nets, data, filt, bank, tr, sds, (start, length) = _bank_setup(mask)
+        finally:
+            BandBankTrainer.use_fused = True
+        assert (tr._fused is not None) == fused
+        mw = torch.tensor(philox_mask(99, 0, length, 1.0 / 4)[0], device=DEV) if mask else \
+            torch.full((length,), 1.0 / (4 * length), device=DEV)
+        batch = sds.collate(sds.global_rows(sels))
+        if fused:
+            vl = tr._fused.run(batch, mw, 1.0, normalize_first=False, train=False)
+            losses = tr._fused.run(batch, mw, 1.0, normalize_first=True, train=True, opt_step=False)
+            # validation form == training form's values when nothing is rescaled in between
+            vl2 = tr._fused.run(batch, mw, 1.0, normalize_first=False, train=False)
+            for k in ("spectral_loss", "sparsity_loss"):
+                assert np.allclose(vl2[k].cpu().numpy(), losses[k].cpu().numpy(), rtol=2e-5), k
+            assert not np.allclose(vl["spectral_loss"].cpu().numpy(), vl2["spectral_loss"].cpu().numpy(), rtol=1e-3)
+        else:
+            tr.optimizer.zero_grad(set_to_none=True)
+            losses = tr._step_losses(batch, mask_prenorm=mw, defer_total=True, normalize_first=True)
+            heads = losses.pop("_heads")
+            torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
+            tr.optimizer.pack_grads()
+            losses["_total"] = heads[0].detach() + heads[1].detach()
+        grad = tr.optimizer.flat_grad.detach().cpu().numpy().copy()
+        tr.optimizer.step()
+        res[fused] = ({k: v.detach().cpu().numpy() for k, v in losses.items()}, grad,
+                      tr.optimizer.flat_param.detach().cpu().numpy().copy(), tr.optimizer)
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=2e-5, atol=1e-7), (k, res[True][0][k], v)
+    ga, gb = res[True][1], res[False][1]
+    # per leaf (the leaves' gradients differ by orders of magnitude)
+    off = 0
+    for p in res[False][3]._params:
+        sl = slice(off, off + p.numel())
+        assert np.abs(ga[sl] - gb[sl]).max() < 2e-4 * np.abs(gb[sl]).max(), (off, np.abs(ga[sl] - gb[sl]).max(), np.abs(gb[sl]).max())
+        off += p.numel()
+    assert rel_err(res[True][2], res[False][2]) < 1e-4
 
 
 def test_bank_training_loop_checkpoints_and_band_freeze(tmp_path):

@@ -1,0 +1,172 @@
+"""Block transfer functions in polynomial form (csrc/blocktf.hip) against a float64 / complex128 torch
+restatement of the same quantities from the per-bin SOLVE (feedback_loop.py:326-391, model.py:209-252,
+:583-619): records + evaluation, normalisation energy, colorless loss + gradients, output stage forward and
+backward, and the record -> (A, b, c) map."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _grid(K, radius=1.0, seed=0):
+    k = torch.arange(K, dtype=torch.float64)
+    z = torch.polar(torch.full((K,), radius, dtype=torch.float64), np.pi * k / (K - 1))
+    return z
+
+
+def _blocks(nblk, n, seed, orth=False):
+    g = torch.Generator().manual_seed(seed)
+    A = (2 * torch.rand(nblk, n, n, generator=g, dtype=torch.float64) - 1) / np.sqrt(n)
+    if orth:
+        X = torch.triu(A, 1)
+        Q = torch.linalg.matrix_exp(X - X.transpose(1, 2))
+        A = Q @ Q
+    b = (2 * torch.randn(nblk * n, generator=g, dtype=torch.float64) - 1) / (nblk * n) * 3
+    c = (2 * torch.randn(nblk * n, generator=g, dtype=torch.float64) - 1) / (nblk * n) * 3
+    primes = [641, 653, 701, 809, 977, 1031, 1201, 1301, 1423, 1511, 1583, 1601, 659, 743, 887, 1093]
+    delays = torch.tensor([primes[(7 * i + seed) % len(primes)] + 2 * (i // len(primes)) for i in range(nblk * n)],
+                          dtype=torch.float64)
+    ig = 1.0 / 10 ** (-3 * delays / (32000.0 * (0.3 + 1.2 * torch.rand(nblk * n, generator=g, dtype=torch.float64))))
+    return A, b, c, delays, ig
+
+
+def _T_ref(z, A, b, c, delays, ig):
+    """T (K, nblk) complex128 by the per-bin solve."""
+    nblk, n, _ = A.shape
+    out = []
+    for q in range(nblk):
+        sl = slice(q * n, (q + 1) * n)
+        D = torch.diag_embed(z[:, None] ** delays[sl][None, :] * ig[sl][None, :])
+        Pm = D - A[q].to(torch.complex128)[None]
+        y = torch.linalg.solve(Pm, b[sl].to(torch.complex128)[None, :, None].expand(z.numel(), n, 1))
+        out.append((c[sl].to(torch.complex128)[None, :] * y[..., 0]).sum(-1))
+    return torch.stack(out, dim=1)
+
+
+@pytest.mark.parametrize("n,nblk,radius,orth", [(4, 6, 1.0, True), (4, 28, 1.0, False), (3, 5, 1.0, True),
+                                                 (2, 3, 1.0, False), (4, 4, 1.0002, True), (1, 2, 1.0, False)])
+def test_records_and_evaluation(n, nblk, radius, orth):
+    from diffgfdn_amd import hip_ops as ops
+    K = 2049
+    z = _grid(K, radius)
+    A, b, c, delays, ig = _blocks(nblk, n, 3, orth)
+    if not orth:
+        ig = torch.ones_like(ig)
+    turns, logr = ops.zprep(z.to(DEV))
+    coef = ops.tf_coefs(A.to(DEV), b.to(DEV), c.to(DEV), None if not orth else ig.to(DEV))
+    T = ops.tf_eval(turns, logr if radius != 1.0 else None, coef, delays.to(DEV), n)
+    ref = _T_ref(z, A.float().double(), b.float().double(), c.float().double(), delays, ig.float().double())
+    assert rel_err(T.cpu().numpy(), ref.numpy()) < 2e-5
+    # energy + scale + in-place rescale (trainer.py:317-332)
+    bb, cc = b.float().to(DEV).contiguous(), c.float().to(DEV).contiguous()
+    energy, scale = ops.tf_energy(turns, logr if radius != 1.0 else None, coef, delays.to(DEV), n, bb, cc)
+    E = (ref.abs() ** 2).mean(0)
+    assert rel_err(energy.cpu().numpy(), E.numpy()) < 2e-5
+    assert rel_err(scale.cpu().numpy(), (E ** -0.5).numpy()) < 2e-5
+    d = (E ** 0.25).repeat_interleave(n)
+    assert rel_err(bb.cpu().numpy(), (b.float().double() / d).numpy()) < 1e-5
+    assert rel_err(cc.cpu().numpy(), (c.float().double() / d).numpy()) < 1e-5
+
+
+def _colorless_ref(z, M, b, c, delays, s, asym, gscale):
+    ones = torch.ones_like(delays)
+    S = _T_ref(z, M, b, c, delays, ones) * s[None, :]
+    d = S.abs() - 1
+    per = torch.where((d > 1) & asym, d ** 4, d ** 2) if asym else d ** 2
+    loss_g = per.mean(0)
+    return gscale * loss_g.sum(), loss_g
+
+
+@pytest.mark.parametrize("n,nblk,asym", [(4, 28, True), (4, 6, False), (3, 4, True)])
+def test_colorless_pass_and_record_adjoint(n, nblk, asym):
+    """loss_g and d(gscale sum_g loss_g)/d(M, b, c) at the scaled responses against float64 autograd."""
+    from diffgfdn_amd import hip_ops as ops
+    K = 4097
+    z = _grid(K)
+    M, b, c, delays, _ = _blocks(nblk, n, 5)
+    b, c = b * 4, c * 4                                  # responses around 1 and beyond: both branches of amse
+    M, b, c = M.float().double(), b.float().double(), c.float().double()
+    s = (0.5 + torch.rand(nblk, dtype=torch.float64)).float().double()
+    gscale = 0.7
+    turns, _ = ops.zprep(z.to(DEV))
+    # records of the SCALED responses are taken at b' c'^T = s b c^T: b' = sqrt(s) b, c' = sqrt(s) c
+    rs = s.sqrt().repeat_interleave(n)
+    bp, cp = (b * rs).requires_grad_(), (c * rs).requires_grad_()
+    Mr = M.clone().requires_grad_()
+    L, loss_g = _colorless_ref(z, Mr, bp, cp, delays, torch.ones(nblk, dtype=torch.float64), asym, gscale)
+    L.backward()
+    coef = ops.tf_coefs(M.to(DEV), b.to(DEV), c.to(DEV))
+    grec, loss = ops.tf_colorless(turns, None, coef, delays.to(DEV), n, s.to(DEV), asym, gscale)
+    assert rel_err(loss.cpu().numpy(), loss_g.detach().numpy()) < 2e-5
+    assert torch.equal(grec[:, 15], loss)
+    # one record set through the two-set entry point: set 0 a dummy with zero gradient records
+    gA0, gM, gb, gc = ops.tf_coefs_bwd(M.to(DEV), None, torch.zeros_like(grec), bp.detach().float().to(DEV),
+                                       cp.detach().float().to(DEV), A1=M.to(DEV), grec1=grec)
+    assert float(gA0.abs().max()) == 0.0
+    assert rel_err(gM.cpu().numpy(), Mr.grad.numpy()) < 1e-4
+    assert rel_err(gb.cpu().numpy(), bp.grad.numpy()) < 1e-4
+    assert rel_err(gc.cpu().numpy(), cp.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("n,G,nbands,B,K", [(4, 4, 3, 8, 1500), (4, 3, 1, 5, 777), (3, 4, 2, 32, 1025), (4, 4, 7, 32, 4100)])
+def test_output_stage_from_records(n, G, nbands, B, K):
+    """H = (sum_g rgain s_g T_g + direct[rows]) filt and the adjoint: grgain, gQQ, gb, gc against autograd."""
+    from diffgfdn_amd import hip_ops as ops
+    nblk = nbands * G
+    z = _grid(K)
+    A, b, c, delays, ig = _blocks(nblk, n, 11, orth=True)
+    A, b, c, ig = A.float().double(), b.float().double(), c.float().double(), ig.float().double()
+    g = torch.Generator().manual_seed(1)
+    s = (0.5 + torch.rand(nblk, generator=g, dtype=torch.float64)).float().double()
+    rgain = (2 * torch.rand(nbands * B, G, generator=g, dtype=torch.float64) - 1).float().double()
+    R = 3 * B
+    direct = torch.randn(nbands * R, K, generator=g, dtype=torch.complex128).to(torch.complex64)
+    rows = torch.stack([q * R + torch.randperm(R, generator=g)[:B] for q in range(nbands)]).reshape(-1)
+    filt = torch.randn(nbands, K, generator=g, dtype=torch.complex128).to(torch.complex64)
+    W = torch.randn(nbands * B, K, generator=g, dtype=torch.complex128).to(torch.complex64)     # dL/dH
+
+    rs = s.sqrt().repeat_interleave(n)
+    bp, cp = (b * rs).requires_grad_(), (c * rs).requires_grad_()
+    Ar, rg = A.clone().requires_grad_(), rgain.clone().requires_grad_()
+    T = _T_ref(z, Ar, bp, cp, delays, ig)                                           # scaled responses (K, nblk)
+    Tb = T.reshape(K, nbands, G).permute(1, 2, 0)                                    # (nbands, G, K)
+    H = (torch.einsum('qbg,qgk->qbk', rg.reshape(nbands, B, G).to(torch.complex128), Tb)
+         + direct[rows].to(torch.complex128).reshape(nbands, B, K)) * filt.to(torch.complex128)[:, None, :]
+    H = H.reshape(nbands * B, K)
+    L = (H.real * W.real.double() + H.imag * W.imag.double()).sum()
+    L.backward()
+
+    turns, _ = ops.zprep(z.to(DEV))
+    coef = ops.tf_coefs(A.to(DEV), b.to(DEV), c.to(DEV), ig.to(DEV))
+    dl = delays.to(DEV)
+    Hd = ops.tf_compose_fwd(turns, None, coef, dl, n, rgain.to(DEV), s.to(DEV), direct.to(DEV), filt.to(DEV),
+                            rows.to(DEV), nbands)
+    assert rel_err(Hd.cpu().numpy(), H.detach().numpy()) < 2e-5
+    grec, grg = ops.tf_compose_bwd(turns, None, coef, dl, n, rgain.to(DEV), W.to(DEV), s.to(DEV), filt.to(DEV), nbands)
+    assert rel_err(grg.cpu().numpy(), rg.grad.numpy()) < 1e-4
+    gA, _, gb, gc = ops.tf_coefs_bwd(A.to(DEV), ig.to(DEV), grec, bp.detach().float().to(DEV),
+                                     cp.detach().float().to(DEV))
+    assert rel_err(gA.cpu().numpy(), Ar.grad.numpy()) < 1e-4
+    assert rel_err(gb.cpu().numpy(), bp.grad.numpy()) < 1e-4
+    assert rel_err(gc.cpu().numpy(), cp.grad.numpy()) < 1e-4
+
+
+def test_ortho_bwd_add():
+    from diffgfdn_amd import hip_ops as ops
+    torch.manual_seed(0)
+    M = torch.randn(5, 4, 4, device=DEV) * 0.4
+    gQ, gQQ, add = torch.randn_like(M), torch.randn_like(M), torch.randn_like(M)
+    Q, _ = ops.ortho_fwd(M, True, False)
+    base = ops.ortho_bwd(M, gQ, gQQ, Q)
+    out = ops.ortho_bwd_add(M, gQ, gQQ, Q, add)
+    assert torch.allclose(out, base + add, atol=1e-6, rtol=1e-6)
