@@ -64,12 +64,13 @@ SIGNATURES = {
     "gfdn_tf_work_bytes": (c_size_t, [c_int]),
     "gfdn_tf_gpart_bytes": (c_size_t, [c_int]),
     "gfdn_tf_eval": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
-    "gfdn_tf_energy": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gfdn_tf_colorless": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, _P]),
-    "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
-    "gfdn_tf_compose_parts": (c_int, [c_int]),
-    "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P]),
+    "gfdn_tf_energy": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_double, _P]),
+    "gfdn_tf_colorless": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_double, _P]),
+    "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
+    "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
+    "gfdn_tf_gain_grad_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfdn_tf_gain_grad": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),
     "gfdn_normalize_io": (c_int, [_P, _P, _P, c_int, c_int, _P]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "gfdn_irfft_odd_pairs_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_stft_power_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "gfdn_stft_power_pairs_bwd_phase": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "gfdn_edc_loss_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),

@@ -7,14 +7,14 @@ sub-FDN forward, b, c /= E^(1/4)), forward (model.py:569-625), losses (trainer.p
 feedback loop only through the group transfer functions T_g(z) -- ratios of multilinear polynomials in the phasors
 z^{m_i} with 2 x 16 real coefficients per block -- so the step is
 
-    side  : records of the raw blocks M_g -> energy pass (normalize: b, c rescaled in place, scale_g)
-            -> [mask draw] -> colorless pass (spectral loss + dL/drecords) -> sparsity gradient
-    side2 : gain network forward ................................ EDC scans ........ gain network backward
-    main  : Q, QQ = expm -> records of Q_g Q_g (at the rescaled b, c) -> output stage H -> irfft -> STFT / EDR
-            -> STFT adjoint -> irfft adjoint -> output-stage adjoint (dL/drecords, dL/dgains)
-            -> records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint -> [all-reduce] -> Adam
+    main  : records of the raw blocks M_g -> energy pass -> finish (normalize: b, c rescaled in place, scale_g)
+            -> output stage H -> irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint -> output-stage adjoint
+            (dL/dgains, then dL/drecords) -> records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint
+            -> [all-reduce] -> Adam
+    side  : Q, QQ = expm -> records of Q_g Q_g ........ colorless pass (spectral loss + dL/drecords), sparsity
+    side2 : gain network forward, mask draw ........... EDC scans ........... gain network backward
 
-26 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
+about 35 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
 accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve never exist.  The autograd
 path of ``BandBankTrainer._step_losses`` (per-bin elimination kernels) stays as the general fallback and as the
 cross-check of this one (tests/test_gpu_bank.py).
@@ -28,8 +28,8 @@ from .functional import FrequencyGrid
 
 
 class FusedBankStep:
-    """Explicit forward / backward of ``BandBankTrainer`` for blocks of <= 4 lines, <= 4 groups, <= 64 receivers
-    per band.  ``supported(trainer)`` tells whether a trainer's layout qualifies."""
+    """Explicit forward / backward of ``BandBankTrainer`` for blocks of <= 4 lines and <= 4 groups per band.
+    ``supported(trainer)`` tells whether a trainer's layout qualifies."""
 
     @staticmethod
     def supported(trainer) -> bool:
@@ -54,61 +54,6 @@ class FusedBankStep:
         self._keep = []
 
     # ------------------------------------------------------------------------------------------
-    def _decay_middle(self, H, K, rows, maskw, inv, want_grad, order, edr_t, edc_t, start, length):
-        """irfft -> EDR / EDC losses -> dL/dH (slot order / pair-interleaved when the length allows it).
-        Returns (li_edr partials, li_edc, gH or None, sums = per-band [total, w_edr edr, w_edc edc])."""
-        tr, cfg = self.tr, self.tr.config
-        main = torch.cuda.current_stream()
-        side2 = tr._stream('_side2')
-        B = H.shape[0]
-        win = tr.stft_win
-        pairs = order is not None and tr.use_pairs and win == 4096
-        keep = self._keep
-        if pairs:
-            x = ops.irfft_odd_fwd(H, K, slots=True, pairs=True)
-        else:
-            x = ops.irfft_odd_fwd(H, K, slots=order is not None)
-        keep.append(x)
-        if side2 is not None:
-            side2.wait_stream(main)
-        with torch.cuda.stream(side2) if side2 is not None else _null():
-            if pairs:
-                li_edc, g_edc = ops.edc_loss_pairs(x, B, start, length, edc_t, maskw, inv, cfg.edc_loss_weight,
-                                                   want_grad, rows=rows)
-            else:
-                li_edc, g_edc = ops.edc_loss(x, start, length, edc_t, maskw, inv, cfg.edc_loss_weight, want_grad,
-                                             rows=rows)
-            keep.extend((li_edc, g_edc))
-        T_edr, sum_abs = edr_t
-        if pairs:
-            P = ops.stft_power_pairs(x, B, win)
-            g_edr = None
-        else:
-            g_edr = torch.empty_like(x) if want_grad else None
-            P = ops.stft_power(x, win, zero_buf=g_edr)
-        li_edr = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, want_grad, rows=rows, defer=True)
-        keep.extend((P, li_edr, g_edr))
-        if side2 is not None:
-            main.wait_stream(side2)
-        # the reported sums ride the EDC stream beside the adjoint kernels
-        if side2 is not None:
-            side2.wait_stream(main)
-        with torch.cuda.stream(side2) if side2 is not None else _null():
-            sums = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows,
-                                     tr.num_bands)
-            self._ev_sums = torch.cuda.Event()
-            self._ev_sums.record()
-        gH = None
-        if want_grad:
-            if pairs:
-                g = ops.stft_power_pairs_bwd(x, B, win, P, base=g_edc, out=g_edc)
-                gH = ops.irfft_odd_pairs_bwd(g, K, B)
-            else:
-                g_edr = ops.stft_power_bwd(x, win, P, g_edr)
-                gH = ops.irfft_odd_bwd(g_edc, K, H.shape[1], g_edr, slots=order is not None)
-            keep.append(gH)
-        return li_edr, li_edc, gH, sums
-
     @torch.no_grad()
     def run(self, data: Dict, maskw: Optional[torch.Tensor], inv: float, normalize_first: bool, train: bool,
             allreduce=None, opt_step: bool = True, mask_draw=None) -> Dict:
@@ -116,22 +61,27 @@ class FusedBankStep:
         weights (None: no mask), ``inv``: what the EDC terms are divided by beyond the weights (1 when the weights are
         pre-normalised).  ``train``: gradients into the flat buffer, [all-reduce,] Adam (``opt_step=False`` stops in front
         of the all-reduce: the caller runs it and the update).  ``mask_draw``: callable that fills ``maskw`` on the
-        device (run on the side stream, off the path to the output stage).  Returns the loss dict of
-        ``BandBankTrainer._step_losses`` (+ '_total')."""
+        device (run on the EDC stream, off the path to the output stage).  Returns the loss dict of
+        ``BandBankTrainer._step_losses`` (+ '_total').
+
+        Scheduling rules (measured on the replayed graph, profiles/): a dependency that crosses streams costs
+        8-12 us when the waiting stream is idle at the moment of the signal and nothing when the signal came earlier;
+        and at a fork the graph keeps the FIRST captured successor on the producer's hardware queue.  So the critical
+        chain stays on the main stream, its next kernel is captured before anything is forked off a node, and the
+        side branches are arranged to finish early."""
         tr = self.tr
         bank, cfg, nb = tr.net, tr.config, tr.num_bands
         G, n = bank.num_groups, bank.num_delay_lines_per_group
         z, rows = data['z_values'], data['row_index']
         Btot = rows.numel()
-        if Btot % nb or Btot // nb > 64:
-            raise ValueError("the batch must hold the same number (<= 64) of receivers for every band")
+        if Btot % nb:
+            raise ValueError("the batch must hold the same number of receivers for every band")
         K = z.shape[-1]
         keep = self._keep
         main = torch.cuda.current_stream()
         side, side2 = tr._stream('_side'), tr._stream('_side2')
-        for s_ in (side, side2):
-            if s_ is not None:
-                s_.wait_stream(main)
+        on_side = (lambda: torch.cuda.stream(side)) if side is not None else _null
+        on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
         M = bank._blocks().detach()
         b, c = bank.input_gains.data.view(-1), bank.output_gains.data.view(-1)
         delays, ig = bank.delays, bank.inv_gamma
@@ -145,78 +95,134 @@ class FusedBankStep:
         gridU = FrequencyGrid.of(zu)
         filt = tr._filter_on(Ku, order)
         inv_world = 1.0 / tr.world_size
-        ev_norm, ev_mlp, ev_side = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-
-        # side: records of the raw blocks -> normalize (trainer.py:317-332)
-        with torch.cuda.stream(side) if side is not None else _null():
-            coef_sub = ops.tf_coefs(M, b, c, None)
-            scale = None
-            if normalize_first:
-                _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False)
-            ev_norm.record()
-            keep.extend((coef_sub, scale))
-        # side2: receiver gains (gain_filters.py:497-536)
         Hh, n_hidden, _, lo, hi = bank._mlp_cfg
         w = bank.output_scalars_w.detach()
-        with torch.cuda.stream(side2) if side2 is not None else _null():
+        start, length = tr._decay_window(K)
+        edr_t, edc_t = data['edr_target'], data['edc_target']
+        T_edr, sum_abs, T_edc = edr_t[1], edr_t[2], edc_t[1]
+        win = tr.stft_win
+        pairs = order is not None and tr.use_pairs and win == 4096
+        ev = {k: torch.cuda.Event() for k in ('start', 'g', 'mlp', 'norm', 'x', 'edc', 'mid', 'side', 'sums', 'grg',
+                                              'mlpb')}
+
+        # ---- head.  main: records of the raw blocks -> energy pass -> finish (normalize, trainer.py:317-332);
+        # side: rotations + records of the damped loop (taken at the gains BEFORE the rescale and scaled afterwards:
+        # T is bilinear in b, c, T(b', c') = scale T(b, c)); side2: receiver gains (gain_filters.py:497-536), mask
+        ev['start'].record()
+        # (the head is a serial chain on the main stream: forking the rotations off it and joining again costs more
+        # than the 10 us they take.  Captured BEFORE the fork below: the graph lays its hardware queues out along a
+        # depth-first walk of the nodes in capture order, and the chain captured first keeps its queue through every
+        # later join -- a chain that changes queue pays ~10 us per change)
+        Q, QQ = ops.ortho_fwd(M, True, True)
+        coef = ops.tf_coefs(QQ, b, c, ig)
+        coef_sub = ops.tf_coefs(M, b, c, None)
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['start'])
             rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G,
                                                   lo, hi, rows, nb)
-            ev_mlp.record()
-            keep.extend((rgain, xhat, rstd))
+            ev['mlp'].record()
             # the EDC time mask is drawn on the stream that runs the EDC scans.  (Drawn on `side`, with the reported
             # total on `side` waiting for the sums of `side2`, the two forked streams depend on each other in both
             # directions -- hipStreamEndCapture of ROCm 7.2 segfaults on that topology.)
             if mask_draw is not None:
                 mask_draw()
-        # main: rotations, records of the damped loop at the rescaled gains, output stage
-        Q, QQ = ops.ortho_fwd(M, True, True)
-        main.wait_event(ev_norm)
-        coef = ops.tf_coefs(QQ, b, c, ig)
-        main.wait_event(ev_mlp)
-        H = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, None, direct, filt, rows, nb)
-        keep.extend((Q, QQ, coef, H))
-        # side: colorless pass + sparsity gradient + the reported colorless terms (issued behind the
-        # output stage: the graph executor launches nodes in capture order)
-        if side is not None:
-            side.wait_stream(main)             # Q
-        with torch.cuda.stream(side) if side is not None else _null():
+        scale = ework = None
+        if normalize_first:
+            _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
+                                     dturn=gridK.dturn)
+        ev['norm'].record()
+        main.wait_event(ev['mlp'])
+        H, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, scale, direct, filt, rows, nb,
+                                   save_T=True)
+        keep.extend((coef_sub, ework, Q, QQ, coef, rgain, xhat, rstd, scale, H, Ts))
+
+        # ---- irfft (slot order / pair-interleaved when the length allows it), then the colorless branch on `side`
+        if pairs:
+            x = ops.irfft_odd_fwd(H, K, slots=True, pairs=True)
+        else:
+            x = ops.irfft_odd_fwd(H, K, slots=order is not None)
+        ev['x'].record()
+        keep.append(x)
+
+        # ---- decay losses.  main: STFT -> EDR; side2: EDC scans
+        if pairs:
+            P = ops.stft_power_pairs(x, Btot, win)
+            g_edr = None
+        else:
+            g_edr = torch.empty_like(x) if train else None
+            P = ops.stft_power(x, win, zero_buf=g_edr)
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['x'])
+            if pairs:
+                li_edc, g_edc = ops.edc_loss_pairs(x, Btot, start, length, T_edc, maskw, inv, cfg.edc_loss_weight,
+                                                   train, rows=rows)
+            else:
+                li_edc, g_edc = ops.edc_loss(x, start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train,
+                                             rows=rows)
+            ev['edc'].record()
+        li_edr = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rows, defer=True)
+        ev['mid'].record()
+        keep.extend((P, g_edr, li_edc, g_edc, li_edr))
+        gH = None
+        if train:
+            if pairs:
+                # even frames first, alone; the EDC gradient joins with the odd frames (the EDC scans are the
+                # longer of the two branches: the main stream would otherwise sit idle until they finish)
+                g = ops.stft_power_pairs_bwd(x, Btot, win, P, phase=0)
+                main.wait_event(ev['edc'])
+                ops.stft_power_pairs_bwd(x, Btot, win, P, base=g_edc, out=g, phase=1)
+                ev['g'].record()
+                gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
+                keep.append(g)
+            else:
+                g_edr = ops.stft_power_bwd(x, win, P, g_edr)
+                main.wait_event(ev['edc'])
+                ev['g'].record()
+                gH = ops.irfft_odd_bwd(g_edc, K, H.shape[1], g_edr, slots=order is not None)
+            keep.append(gH)
+        else:
+            main.wait_event(ev['edc'])
+            ev['g'].record()
+        # side: the colorless pass (VALU-bound) beside the memory-bound transform adjoint
+        with on_side():
+            torch.cuda.current_stream().wait_event(ev['g'])
             grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
-                                                cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world)
+                                                cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
+                                                dturn=gridK.dturn)
             out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
                                            inv_world, want_grad=train, nbands=nb)
-            ev_side.record()
-            keep.extend((grec_sub, loss_g, gQ))
-        start, length = tr._decay_window(K)
-        edr_t, edc_t = data['edr_target'], data['edc_target']
-        li_edr, li_edc, gH, sums = self._decay_middle(H, K, rows, maskw, inv, train, order, (edr_t[1], edr_t[2]),
-                                                      edc_t[1], start, length)
-        with torch.cuda.stream(side) if side is not None else _null():       # the reported total, beside the adjoints
-            torch.cuda.current_stream().wait_event(self._ev_sums)
+            ev['side'].record()
+        keep.extend((grec_sub, loss_g, out3, gQ))
+        # the reported sums and total (off the gradient path): side2 behind the EDC scans, side behind its colorless terms
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['mid'])
+            sums = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
+            ev['sums'].record()
+        with on_side():
+            torch.cuda.current_stream().wait_event(ev['sums'])
             total = (sums[:, 0] + out3[:, 0]) if nb > 1 else (sums[0] + out3[0])
-            keep.extend((sums, out3))
+        keep.extend((sums, total))
+
         if train:
-            grec, grg = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, None, filt, nb)
-            keep.extend((grec, grg))
-            ev_cb, ev_mlpb = torch.cuda.Event(), torch.cuda.Event()
-            ev_cb.record()
-            if side2 is not None:
-                side2.wait_event(ev_cb)
-            with torch.cuda.stream(side2) if side2 is not None else _null():
+            # ---- backward of the output stage: gains pass -> (side2: gain network backward) | records pass
+            grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
+            ev['grg'].record()
+            grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb)
+            with on_side2():
+                torch.cuda.current_stream().wait_event(ev['grg'])
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
-                ev_mlpb.record()
-            main.wait_event(ev_side)
+                ev['mlpb'].record()
+            main.wait_event(ev['side'])
             gQQ, gMsub, _, _ = ops.tf_coefs_bwd(QQ, ig, grec, b, c, A1=M, grec1=grec_sub, gb=self.g_b, gc=self.g_c)
             ops.ortho_bwd_add(M, gQ, gQQ, Q, gMsub, out=self.g_M)
-            keep.extend((gQQ, gMsub))
-            main.wait_event(ev_mlpb)
+            keep.extend((grg, grec, gQQ, gMsub))
+            main.wait_event(ev['mlpb'])
             tr.optimizer._packed = True               # the flat gradient buffer is complete
             if opt_step:
                 if allreduce is not None:
                     allreduce()
                 tr.optimizer.step()
-        else:
-            main.wait_event(ev_side)
         if nb > 1:
             losses = {'edc_loss': sums[:, 2], 'edr_loss': sums[:, 1], 'spectral_loss': out3[:, 1],
                       'sparsity_loss': out3[:, 2], '_total': total}
@@ -231,6 +237,8 @@ class FusedBankStep:
 
 
 class _null:
+    """no-op context (a branch that has no stream of its own runs inline on the main stream)"""
+
     def __enter__(self):
         return None
 

@@ -40,7 +40,22 @@ __device__ __forceinline__ float2 tf_zpow(const double* __restrict__ turns, cons
   return make_float2(c, s);
 }
 
-// e[S] = prod_{i in S} z_k^{m_i}   (e[0] is never read: the empty product)
+// e[S] = prod_{i in S} e_i from the four single-line phasors e[1], e[2], e[4], e[8]  (e[0] is never read)
+__device__ __forceinline__ void tf_subsets(float2 (&e)[16]) {
+  e[3] = cmul(e[1], e[2]);
+  e[5] = cmul(e[1], e[4]);
+  e[6] = cmul(e[2], e[4]);
+  e[9] = cmul(e[1], e[8]);
+  e[10] = cmul(e[2], e[8]);
+  e[12] = cmul(e[4], e[8]);
+  e[7] = cmul(e[3], e[4]);
+  e[11] = cmul(e[3], e[8]);
+  e[13] = cmul(e[5], e[8]);
+  e[14] = cmul(e[6], e[8]);
+  e[15] = cmul(e[3], e[12]);
+}
+
+// e[S] = prod_{i in S} z_k^{m_i}
 __device__ __forceinline__ void tf_phasors(const double* __restrict__ turns, const double* __restrict__ logr,
                                            int k, const float (&m)[4], float2 (&e)[16]) {
   e[1] = tf_zpow(turns, logr, k, m[0]);
@@ -373,6 +388,62 @@ __global__ __launch_bounds__(256) void k_tf_energy(TfArgs a, float* __restrict__
   }
 }
 
+// Uniform grids on the unit circle (turns[k] = turns[0] + k dturn: the reference's z = exp(2 pi i rfftfreq), dataloader.py:
+// 552-566): a thread takes RUNS of TF_RUN consecutive bins, evaluates the four phasors exactly at the head of a run
+// and steps them by the constant rotations z_1^{m_i} inside it -- 4 complex products per bin instead of 4 float64
+// range reductions + sincos (the rounding of TF_RUN - 1 products, ~1e-7 per step, stays far below the 1e-5 the
+// evaluation itself carries).
+#define TF_RUN 8
+__device__ __forceinline__ float2 tf_rot(double dturn, float m) {
+  double t = (double)m * dturn;
+  t -= rint(t);
+  float s, c;
+  sincospif(2.0f * (float)t, &s, &c);
+  return make_float2(c, s);
+}
+
+__global__ __launch_bounds__(256) void k_tf_energy_runs(TfArgs a, double dturn, float* __restrict__ partial, int items) {
+  __shared__ float s_e[256];
+  const int nblk = a.nblk;
+  const bool live = (int)threadIdx.x < items;
+  const int blk = live ? threadIdx.x % nblk : 0;
+  const int krow = threadIdx.x / nblk, rows = items / nblk;
+  float P[16], Q[16], m[4];
+  tf_load(a.coef, a.delays, blk, a.nper, P, Q, m);
+  const float2 r0 = tf_rot(dturn, m[0]), r1 = tf_rot(dturn, m[1]), r2 = tf_rot(dturn, m[2]), r3 = tf_rot(dturn, m[3]);
+  const int nruns = (a.K + TF_RUN - 1) / TF_RUN;
+  float acc = 0.f;
+#pragma unroll 1
+  for (int run = blockIdx.x * rows + krow; live && run < nruns; run += gridDim.x * rows) {
+    const int k0 = run * TF_RUN;
+    float2 e[16];
+    e[1] = tf_zpow(a.turns, nullptr, k0, m[0]);
+    e[2] = tf_zpow(a.turns, nullptr, k0, m[1]);
+    e[4] = tf_zpow(a.turns, nullptr, k0, m[2]);
+    e[8] = tf_zpow(a.turns, nullptr, k0, m[3]);
+#pragma unroll 2
+    for (int j = 0; j < TF_RUN; ++j) {
+      if (k0 + j < a.K) {
+        float2 num, den;
+        tf_subsets(e);
+        tf_numden(P, Q, e, num, den);
+        acc += (num.x * num.x + num.y * num.y) / (den.x * den.x + den.y * den.y);
+        e[1] = cmul(e[1], r0);
+        e[2] = cmul(e[2], r1);
+        e[4] = cmul(e[4], r2);
+        e[8] = cmul(e[8], r3);
+      }
+    }
+  }
+  s_e[threadIdx.x] = live ? acc : 0.f;
+  __syncthreads();
+  for (int bq = threadIdx.x; bq < nblk; bq += 256) {
+    float sum = 0.f;
+    for (int t = bq; t < items; t += nblk) sum += s_e[t];
+    partial[(size_t)bq * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
 // E = sum / K -> energy, scale = E^(-1/2) (what T and the numerator coefficients scale by once b, c are
 // divided by E^(1/4): trainer.py:317-332), and the in-place rescale of b, c
 __global__ __launch_bounds__(256) void k_tf_energy_finish(const float* __restrict__ partial, int nparts, int K,
@@ -403,18 +474,25 @@ extern "C" size_t gfdn_tf_work_bytes(int nblk) {
 
 extern "C" int gfdn_tf_energy(const double* turns, const double* logr, int K, int nblk, int nper,
                               const float* coef, const float* delays, float* b, float* c, float* energy,
-                              float* scale, void* work, void* stream) {
+                              float* scale, void* work, int phase, double dturn, void* stream) {
   int rc = tf_args_ok(turns, K, nblk, nper, coef, delays);
   if (rc) return rc;
-  if (!work || (!b) != (!c)) return GFDN_E_BADARG;
+  if (!work || (!b) != (!c) || !(phase & 3)) return GFDN_E_BADARG;
   TfArgs a{turns, logr, K, nblk, nper, coef, delays, nullptr};
   const int nparts = tf_parts_host(K, nblk);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tf_energy, dim3(nparts), dim3(256), 0, s, a, (float*)work, tf_items(nblk));
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_tf_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, nparts, K, nper, b, c,
-                     energy, scale);
-  GFDN_LAUNCH_CHECK();
+  if (phase & 1) {
+    if (dturn != 0.0 && !logr)
+      hipLaunchKernelGGL(k_tf_energy_runs, dim3(nparts), dim3(256), 0, s, a, dturn, (float*)work, tf_items(nblk));
+    else
+      hipLaunchKernelGGL(k_tf_energy, dim3(nparts), dim3(256), 0, s, a, (float*)work, tf_items(nblk));
+    GFDN_LAUNCH_CHECK();
+  }
+  if (phase & 2) {
+    hipLaunchKernelGGL(k_tf_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, nparts, K, nper, b, c,
+                       energy, scale);
+    GFDN_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -423,8 +501,9 @@ extern "C" int gfdn_tf_energy(const double* turns, const double* logr, int K, in
 // gscale * sum_g loss_g with respect to the records of S' (numerator coefficients P' = scale P):
 //     dL/dP'_S = Re(gS' conj(e_S / Den)) ,   dL/dQ_S = -Re(gS' conj(S' e_S / Den)).
 // gpart[(blk * 32 + e) * nparts + part]: e < 15 dL/dP'_S, e = 15 the loss partial, 16 + S dL/dQ_S.
-__global__ __launch_bounds__(256) void k_tf_colorless(TfArgs a, int asym, float gscale, float* __restrict__ gpart,
-                                                      int items) {
+template <bool RUNS>
+__global__ __launch_bounds__(256) void k_tf_colorless(TfArgs a, double dturn, int asym, float gscale,
+                                                      float* __restrict__ gpart, int items) {
   extern __shared__ float tf_acc[];        // [items][33]
   const int nblk = a.nblk;
   const bool live = (int)threadIdx.x < items;
@@ -434,31 +513,56 @@ __global__ __launch_bounds__(256) void k_tf_colorless(TfArgs a, int asym, float 
   tf_load(a.coef, a.delays, blk, a.nper, P, Q, m);
   const float sc = a.scale ? a.scale[blk] : 1.0f;
   const float invK = 1.0f / (float)a.K;
+  float2 r0, r1, r2, r3;
+  if (RUNS) {
+    r0 = tf_rot(dturn, m[0]);
+    r1 = tf_rot(dturn, m[1]);
+    r2 = tf_rot(dturn, m[2]);
+    r3 = tf_rot(dturn, m[3]);
+  }
   float aP[16], aQ[16];
 #pragma unroll
   for (int S = 0; S < 16; ++S) aP[S] = aQ[S] = 0.f;
+  constexpr int RUN = RUNS ? TF_RUN : 1;
+  const int nruns = (a.K + RUN - 1) / RUN;
 #pragma unroll 1
-  for (int k = blockIdx.x * rows + krow; live && k < a.K; k += gridDim.x * rows) {
-    float2 e[16], num, den;
-    tf_phasors(a.turns, a.logr, k, m, e);
-    tf_numden(P, Q, e, num, den);
-    const float2 dinv = cinv(den);
-    const float2 s = cscale(cmul(num, dinv), sc);
-    const float mag = sqrtf(s.x * s.x + s.y * s.y);
-    const float d = mag - 1.0f, d2 = d * d;
-    const bool four = asym && (d > 1.0f);
-    aP[15] += (four ? d2 * d2 : d2) * invK;
-    const float dl = four ? 4.0f * d2 * d : 2.0f * d;
-    const float f = (mag > 0.f) ? gscale * invK * dl / mag : 0.f;
-    const float2 gs = make_float2(f * s.x, f * s.y);
-    const float2 u = cmulc(gs, dinv);                  // gS' conj(1 / Den)
-    const float2 v = cmulc(u, s);                      // u conj(S')
-    aP[0] += u.x;
-    aQ[0] -= v.x;
+  for (int run = blockIdx.x * rows + krow; live && run < nruns; run += gridDim.x * rows) {
+    const int k0 = run * RUN;
+    float2 e[16];
+    e[1] = tf_zpow(a.turns, RUNS ? nullptr : a.logr, k0, m[0]);
+    e[2] = tf_zpow(a.turns, RUNS ? nullptr : a.logr, k0, m[1]);
+    e[4] = tf_zpow(a.turns, RUNS ? nullptr : a.logr, k0, m[2]);
+    e[8] = tf_zpow(a.turns, RUNS ? nullptr : a.logr, k0, m[3]);
+#pragma unroll 1
+    for (int j = 0; j < RUN; ++j) {
+      if (k0 + j >= a.K) break;
+      float2 num, den;
+      tf_subsets(e);
+      tf_numden(P, Q, e, num, den);
+      const float2 dinv = cinv(den);
+      const float2 s = cscale(cmul(num, dinv), sc);
+      const float mag = sqrtf(s.x * s.x + s.y * s.y);
+      const float d = mag - 1.0f, d2 = d * d;
+      const bool four = asym && (d > 1.0f);
+      aP[15] += (four ? d2 * d2 : d2) * invK;
+      const float dl = four ? 4.0f * d2 * d : 2.0f * d;
+      const float f = (mag > 0.f) ? gscale * invK * dl / mag : 0.f;
+      const float2 gs = make_float2(f * s.x, f * s.y);
+      const float2 u = cmulc(gs, dinv);                  // gS' conj(1 / Den)
+      const float2 v = cmulc(u, s);                      // u conj(S')
+      aP[0] += u.x;
+      aQ[0] -= v.x;
 #pragma unroll
-    for (int S = 1; S < 16; ++S) {
-      if (S < 15) aP[S] += u.x * e[S].x + u.y * e[S].y;
-      aQ[S] -= v.x * e[S].x + v.y * e[S].y;
+      for (int S = 1; S < 16; ++S) {
+        if (S < 15) aP[S] += u.x * e[S].x + u.y * e[S].y;
+        aQ[S] -= v.x * e[S].x + v.y * e[S].y;
+      }
+      if (RUNS) {
+        e[1] = cmul(e[1], r0);
+        e[2] = cmul(e[2], r1);
+        e[4] = cmul(e[4], r2);
+        e[8] = cmul(e[8], r3);
+      }
     }
   }
   if (live) {
@@ -483,15 +587,19 @@ extern "C" size_t gfdn_tf_gpart_bytes(int nblk) {
 
 extern "C" int gfdn_tf_colorless(const double* turns, const double* logr, int K, int nblk, int nper,
                                  const float* coef, const float* delays, const float* scale, int asym,
-                                 float gscale, float* grec, float* loss, void* work, void* stream) {
+                                 float gscale, float* grec, float* loss, void* work, double dturn, void* stream) {
   int rc = tf_args_ok(turns, K, nblk, nper, coef, delays);
   if (rc) return rc;
   if (!grec || !work) return GFDN_E_BADARG;
   TfArgs a{turns, logr, K, nblk, nper, coef, delays, scale};
   const int nparts = tf_parts_host(K, nblk), items = tf_items(nblk);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tf_colorless, dim3(nparts), dim3(256), (size_t)items * 33 * sizeof(float), s, a, asym, gscale,
-                     (float*)work, items);
+  if (dturn != 0.0 && !logr)
+    hipLaunchKernelGGL(k_tf_colorless<true>, dim3(nparts), dim3(256), (size_t)items * 33 * sizeof(float), s, a, dturn,
+                       asym, gscale, (float*)work, items);
+  else
+    hipLaunchKernelGGL(k_tf_colorless<false>, dim3(nparts), dim3(256), (size_t)items * 33 * sizeof(float), s, a, 0.0,
+                       asym, gscale, (float*)work, items);
   GFDN_LAUNCH_CHECK();
   const int rows = nblk * TF_REC;
   hipLaunchKernelGGL(k_tf_rows_sum, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)work, nparts, rows, grec, rows,
@@ -520,7 +628,7 @@ struct TfCompose {
 #define TFC_BCH 8
 __global__ __launch_bounds__(256) void k_tf_compose_fwd(TfCompose a, const float2* __restrict__ direct, int ldd,
                                                         const long long* __restrict__ drows,
-                                                        float2* __restrict__ H, int ldh) {
+                                                        float2* __restrict__ H, int ldh, float2* __restrict__ Tsave) {
   __shared__ TfBlock tab[TF_MAXG];
   const int band = blockIdx.y, G = a.G, B = a.B;
   tf_stage(a.coef, a.delays, band * G, G, a.nper, tab);
@@ -547,6 +655,7 @@ __global__ __launch_bounds__(256) void k_tf_compose_fwd(TfCompose a, const float
       tf_numden(tab[g].P, tab[g].Q, e, num, den);
       T[g] = cmul(num, cinv(den));
       if (a.scale) T[g] = cscale(T[g], a.scale[band * G + g]);
+      if (Tsave) Tsave[(size_t)(band * G + g) * a.K + k] = T[g];
     }
   }
   const float2 f = a.filt ? a.filt[(size_t)band * a.ldf + k] : make_float2(1.f, 0.f);
@@ -591,155 +700,139 @@ extern "C" int gfdn_tf_compose_fwd(const double* turns, const double* logr, int 
                                    const float* coef, const float* delays, const float* scale,
                                    const float* rgain, int B, const float* direct, int ldd,
                                    const long long* direct_rows, const float* filt, int ldf, float* H, int ldh,
-                                   void* stream) {
+                                   float* Tsave, void* stream) {
   int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
   if (rc) return rc;
   if (!H || ldh < K || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
   TfCompose a{turns, logr, K, G, nper, B, coef, delays, scale, rgain, (const float2*)filt, ldf};
   hipLaunchKernelGGL(k_tf_compose_fwd, dim3((K + 255) / 256, nbands), dim3(256), 0, (hipStream_t)stream, a,
-                     (const float2*)direct, ldd, direct ? direct_rows : nullptr, (float2*)H, ldh);
+                     (const float2*)direct, ldd, direct ? direct_rows : nullptr, (float2*)H, ldh, (float2*)Tsave);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
 
-// Backward of the output stage: reads dL/dH once and leaves
-//   gpart[((band * G + g) * 32 + e) * nparts + part] : dL/dcoef partials of the (scaled) records, as k_tf_colorless
-//   rg_partial[(band * B * G + b * G + g) * nparts + part] : partials of dL/drgain[b][g] = sum_k Re(gW conj(T'_g)).
-// One workgroup = 4 wavefronts sweeps tiles of 64 bins: wavefront g evaluates T'_g for the tile's bins and keeps
-// the phasors in registers; the receiver loop is split over the wavefronts (each dL/dH value is read once and
-// serves dL/dT' and its receiver-gain product, summed over the bins in a fixed order through LDS); then
-// wavefront g folds dL/dT'_g into its 30 coefficient accumulators, reduced over the lanes once per launch.
+// Backward of the output stage, two streaming launches over dL/dH (the second read comes from the last-level cache):
+//   gains  : rg_partial[(band * B * G + b * G + g) * nchunk + chunk] = partial of
+//            dL/drgain[b][g] = sum_k Re(dL/dH[b][k] conj(filt[k] T'_g[k]))  -- 8 receivers x a stripe of bins per
+//            workgroup, 32 per-thread sums, one block reduction at the end;
+//   records: gpart[((band * G + g) * 32 + e) * nparts + part] = dL/dcoef partials of the (scaled) records, as
+//            k_tf_colorless -- wavefront g of a workgroup owns group g for tiles of 64 bins: it folds the receivers'
+//            dL/dH into dL/dT'_g = conj(filt) sum_b rgain[b][g] dL/dH[b] (the four wavefronts read the same lines:
+//            L1 hits), rebuilds the phasors and the denominator, and adds into its 30 accumulators; no LDS, no
+//            barrier.  T' = the forward's saved (scaled, unfiltered) group transfer functions (nbands * G, K).
 #define TFB_T 64
-#define TFB_RB 16
-__global__ __launch_bounds__(256, 2) void k_tf_compose_bwd(TfCompose a, const float2* __restrict__ gH, int ldh,
-                                                        float* __restrict__ gpart, float* __restrict__ rg_partial) {
+#define TFG_R 8
+__global__ __launch_bounds__(256) void k_tf_gain_grad(const float2* __restrict__ Tsave, int K, int G, int B,
+                                                      const float2* __restrict__ filt, int ldf,
+                                                      const float2* __restrict__ gH, int ldh,
+                                                      float* __restrict__ rg_partial, int ngrp) {
+  __shared__ float s_red[4][TFG_R * TF_MAXG];
+  const int band = blockIdx.y / ngrp, b0 = (blockIdx.y - band * ngrp) * TFG_R;
+  const int nr = B - b0 < TFG_R ? B - b0 : TFG_R;
+  const float2* T0 = Tsave + (size_t)band * G * K;
+  const float2* g0 = gH + ((size_t)band * B + b0) * ldh;
+  float acc[TFG_R][TF_MAXG];
+#pragma unroll
+  for (int r = 0; r < TFG_R; ++r)
+#pragma unroll
+    for (int g = 0; g < TF_MAXG; ++g) acc[r][g] = 0.f;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+    float2 gh[TFG_R];
+#pragma unroll
+    for (int r = 0; r < TFG_R; ++r) gh[r] = r < nr ? g0[(size_t)r * ldh + k] : make_float2(0.f, 0.f);
+    const float2 f = filt ? filt[(size_t)band * ldf + k] : make_float2(1.f, 0.f);
+    float2 w[TF_MAXG];
+#pragma unroll
+    for (int g = 0; g < TF_MAXG; ++g) w[g] = g < G ? cmul(f, T0[(size_t)g * K + k]) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < TFG_R; ++r)
+#pragma unroll
+      for (int g = 0; g < TF_MAXG; ++g) acc[r][g] += gh[r].x * w[g].x + gh[r].y * w[g].y;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < TFG_R; ++r)
+#pragma unroll
+    for (int g = 0; g < TF_MAXG; ++g) {
+      const float v = wave_sum(acc[r][g]);
+      if (lane == 0) s_red[wv][r * TF_MAXG + g] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < TFG_R * TF_MAXG) {
+    const int r = threadIdx.x / TF_MAXG, g = threadIdx.x % TF_MAXG;
+    if (r < nr && g < G) {
+      const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+      rg_partial[((size_t)band * B * G + (size_t)(b0 + r) * G + g) * gridDim.x + blockIdx.x] = v;
+    }
+  }
+}
+
+#define TFR_BCH 8
+__global__ __launch_bounds__(256) void k_tf_compose_bwd_rec(TfCompose a, const float2* __restrict__ Tsave,
+                                                            const float2* __restrict__ gH, int ldh,
+                                                            float* __restrict__ gpart) {
   __shared__ TfBlock tab[TF_MAXG];
-  __shared__ float2 s_T[TF_MAXG][TFB_T];
-  __shared__ float2 s_g[4][TF_MAXG][TFB_T];
-  __shared__ float pp[TFB_RB * TF_MAXG][TFB_T + 1];
   const int band = blockIdx.y, G = a.G, B = a.B, nparts = gridDim.x;
   tf_stage(a.coef, a.delays, band * G, G, a.nper, tab);
   __syncthreads();
   // (wave index made wave-uniform for the compiler: the receiver-gain reads become scalar loads)
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const float* rgain = a.rgain + (size_t)band * B * G;
+  if (w >= G) return;
+  const float* rgain = a.rgain + (size_t)band * B * G + w;
   gH += (size_t)band * B * ldh;
-  const float sc = (a.scale && w < G) ? a.scale[band * G + w] : 1.0f;
+  const float2* Tp = Tsave + (size_t)(band * G + w) * a.K;
+  float Q[16], m[4];
+#pragma unroll
+  for (int S = 0; S < 16; ++S) Q[S] = tab[w].Q[S];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = tab[w].m[r];
   float aP[16], aQ[16];
 #pragma unroll
   for (int S = 0; S < 16; ++S) aP[S] = aQ[S] = 0.f;
-  // receiver-gain sums this thread owns: outputs o = threadIdx.x >> 1 of every receiver chunk
-  float rgacc[4] = {0.f, 0.f, 0.f, 0.f};                 // chunks of TFB_RB receivers: B <= 64
   const int ntiles = (a.K + TFB_T - 1) / TFB_T;
   for (int tile = blockIdx.x; tile < ntiles; tile += nparts) {
     const int k = tile * TFB_T + lane;
     const bool live = k < a.K;
     const int kk = live ? k : a.K - 1;
-    float2 ghn[TFB_RB / 4];
+    float2 acc = make_float2(0.f, 0.f);
+    for (int b0 = 0; b0 < B; b0 += TFR_BCH) {
+      float2 gh[TFR_BCH];
 #pragma unroll
-    for (int i = 0; i < TFB_RB / 4; ++i) {               // chunk 0 of dL/dH flies while T is evaluated
-      const int b = w + 4 * i;
-      ghn[i] = (live && b < B) ? gH[(size_t)b * ldh + kk] : make_float2(0.f, 0.f);
-    }
-    float2 e[16], dinv = make_float2(0.f, 0.f), Tw = make_float2(0.f, 0.f);
-    if (w < G) {
-      float2 num, den;
-      tf_phasors(a.turns, a.logr, kk, tab[w].m, e);
-      tf_numden(tab[w].P, tab[w].Q, e, num, den);
-      dinv = cinv(den);
-      Tw = cscale(cmul(num, dinv), sc);
-      s_T[w][lane] = Tw;
-    }
-    __syncthreads();
-    float2 Sl[TF_MAXG], acc[TF_MAXG];
+      for (int i = 0; i < TFR_BCH; ++i)
+        gh[i] = (live && b0 + i < B) ? gH[(size_t)(b0 + i) * ldh + kk] : make_float2(0.f, 0.f);
 #pragma unroll
-    for (int g = 0; g < TF_MAXG; ++g) {
-      acc[g] = make_float2(0.f, 0.f);
-      Sl[g] = g < G ? s_T[g][lane] : make_float2(0.f, 0.f);
-    }
-    const float2 fc = a.filt ? cconj(a.filt[(size_t)band * a.ldf + kk]) : make_float2(1.f, 0.f);
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      const int b0 = ch * TFB_RB;
-      if (b0 >= B) break;                                // (uniform)
-      float2 ghv[TFB_RB / 4];
-#pragma unroll
-      for (int i = 0; i < TFB_RB / 4; ++i) {
-        ghv[i] = ghn[i];
-        const int b = b0 + TFB_RB + w + 4 * i;           // next chunk
-        ghn[i] = (live && b < B) ? gH[(size_t)b * ldh + kk] : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < TFB_RB / 4; ++i) {
-        const int b = b0 + w + 4 * i;
-        if (b < B) {
-          float2 gh = ghv[i];
-          if (a.filt) gh = cmul(gh, fc);
-#pragma unroll
-          for (int g = 0; g < TF_MAXG; ++g) {
-            if (g < G) {
-              const float rg = rgain[b * G + g];
-              acc[g].x += rg * gh.x;
-              acc[g].y += rg * gh.y;
-              pp[(b - b0) * G + g][lane] = gh.x * Sl[g].x + gh.y * Sl[g].y;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      const int nout = (B - b0 < TFB_RB ? B - b0 : TFB_RB) * G;
-      {
-        const int o = threadIdx.x >> 1, h = threadIdx.x & 1;
-        float sacc = 0.f;
-        if (o < nout)
-          for (int j = 0; j < 32; ++j) sacc += pp[o][h * 32 + j];
-        sacc += __shfl_xor(sacc, 1);
-        rgacc[ch] += sacc;
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int g = 0; g < TF_MAXG; ++g)
-      if (g < G) s_g[w][g][lane] = acc[g];
-    __syncthreads();
-    if (w < G) {
-      float2 gt = s_g[0][w][lane];
-      gt = cadd(gt, s_g[1][w][lane]);
-      gt = cadd(gt, s_g[2][w][lane]);
-      gt = cadd(gt, s_g[3][w][lane]);
-      const float2 u = cmulc(gt, dinv);               // dL/dT' conj(1 / Den)   (zero beyond K: gH loads were zero)
-      const float2 v = cmulc(u, Tw);
-      aP[0] += u.x;
-      aQ[0] -= v.x;
-#pragma unroll
-      for (int S = 1; S < 16; ++S) {
-        if (S < 15) aP[S] += u.x * e[S].x + u.y * e[S].y;
-        aQ[S] -= v.x * e[S].x + v.y * e[S].y;
+      for (int i = 0; i < TFR_BCH; ++i) {
+        const float rg = b0 + i < B ? rgain[(b0 + i) * G] : 0.f;
+        acc.x += rg * gh[i].x;
+        acc.y += rg * gh[i].y;
       }
     }
-    __syncthreads();
-  }
-  if (w < G) {
-    float* out = gpart + (size_t)(band * G + w) * TF_REC * nparts + blockIdx.x;
+    if (a.filt) acc = cmulc(acc, a.filt[(size_t)band * a.ldf + kk]);      // dL/dT' (zero beyond K)
+    float2 e[16];
+    tf_phasors(a.turns, a.logr, kk, m, e);
+    float2 den = make_float2(Q[0], 0.f);
 #pragma unroll
-    for (int S = 0; S < 16; ++S) {
-      const float p = wave_sum(aP[S]), q = wave_sum(aQ[S]);
-      if (lane == 0) {
-        out[(size_t)S * nparts] = p;
-        out[(size_t)(16 + S) * nparts] = q;
-      }
+    for (int S = 1; S < 16; ++S) {
+      den.x += Q[S] * e[S].x;
+      den.y += Q[S] * e[S].y;
+    }
+    const float2 u = cmulc(acc, cinv(den));             // dL/dT' conj(1 / Den)
+    const float2 v = cmulc(u, Tp[kk]);
+    aP[0] += u.x;
+    aQ[0] -= v.x;
+#pragma unroll
+    for (int S = 1; S < 16; ++S) {
+      if (S < 15) aP[S] += u.x * e[S].x + u.y * e[S].y;
+      aQ[S] -= v.x * e[S].x + v.y * e[S].y;
     }
   }
-  {
-    const int o = threadIdx.x >> 1, h = threadIdx.x & 1;
-    if (h == 0) {
+  float* out = gpart + (size_t)(band * G + w) * TF_REC * nparts + blockIdx.x;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        const int b0 = ch * TFB_RB;
-        if (b0 >= B) break;
-        const int nout = (B - b0 < TFB_RB ? B - b0 : TFB_RB) * G;
-        if (o < nout) rg_partial[((size_t)band * B * G + (size_t)b0 * G + o) * nparts + blockIdx.x] = rgacc[ch];
-      }
+  for (int S = 0; S < 16; ++S) {
+    const float p = wave_sum(aP[S]), q = wave_sum(aQ[S]);
+    if (lane == 0) {
+      out[(size_t)S * nparts] = p;
+      out[(size_t)(16 + S) * nparts] = q;
     }
   }
 }
@@ -750,32 +843,54 @@ static int tf_compose_parts_host(int K) {
   if (parts > TF_MAX_PARTS) parts = TF_MAX_PARTS;
   return parts < 1 ? 1 : parts;
 }
-extern "C" int gfdn_tf_compose_parts(int K) { return K > 0 ? tf_compose_parts_host(K) : 0; }
-extern "C" size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G, int B) {
+static int tf_gain_chunks_host(int K) {
+  int c = (K + 1023) / 1024;                     // ~4 bins per thread
+  if (c > 32) c = 32;
+  return c < 1 ? 1 : c;
+}
+extern "C" size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G) {
+  if (K <= 0 || nbands <= 0 || G <= 0) return 0;
+  return (size_t)nbands * G * TF_REC * tf_compose_parts_host(K) * sizeof(float);
+}
+extern "C" size_t gfdn_tf_gain_grad_work_bytes(int K, int nbands, int G, int B) {
   if (K <= 0 || nbands <= 0 || G <= 0 || B <= 0) return 0;
-  return (size_t)nbands * G * (TF_REC + B) * tf_compose_parts_host(K) * sizeof(float);
+  return (size_t)nbands * G * B * tf_gain_chunks_host(K) * sizeof(float);
+}
+
+extern "C" int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave, const float* filt, int ldf,
+                                 const float* gH, int ldh, float* grgain, void* work, void* stream) {
+  if (!Tsave || !gH || !grgain || !work || K <= 0 || nbands <= 0 || G <= 0 || B <= 0 || ldh < K ||
+      (filt && nbands > 1 && ldf < K))
+    return GFDN_E_BADARG;
+  if (G > TF_MAXG || nbands * ((B + TFG_R - 1) / TFG_R) > 65535) return GFDN_E_UNSUPPORTED;
+  const int nchunk = tf_gain_chunks_host(K), ngrp = (B + TFG_R - 1) / TFG_R;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tf_gain_grad, dim3(nchunk, nbands * ngrp), dim3(256), 0, s, (const float2*)Tsave, K, G, B,
+                     (const float2*)filt, ldf, (const float2*)gH, ldh, (float*)work, ngrp);
+  GFDN_LAUNCH_CHECK();
+  const int nrg = nbands * B * G;
+  hipLaunchKernelGGL(k_tf_rows_sum, dim3((nrg + 3) / 4), dim3(256), 0, s, (const float*)work, nchunk, nrg, grgain, nrg,
+                     (float*)nullptr, (float*)nullptr);
+  GFDN_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
-                                   const float* coef, const float* delays, const float* scale,
+                                   const float* coef, const float* delays, const float* Tsave,
                                    const float* rgain, int B, const float* filt, int ldf, const float* gH,
-                                   int ldh, float* grec, float* grgain, void* work, void* stream) {
+                                   int ldh, float* grec, void* work, void* stream) {
   int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
   if (rc) return rc;
-  if (!gH || !grec || !grgain || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
-  if (B > 4 * TFB_RB) return GFDN_E_UNSUPPORTED;
-  TfCompose a{turns, logr, K, G, nper, B, coef, delays, scale, rgain, (const float2*)filt, ldf};
+  if (!Tsave || !gH || !grec || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
+  TfCompose a{turns, logr, K, G, nper, B, coef, delays, nullptr, rgain, (const float2*)filt, ldf};
   const int nparts = tf_compose_parts_host(K);
   hipStream_t s = (hipStream_t)stream;
-  // work = [record partials (nbands G 32 rows) | receiver-gain partials (nbands B G rows)], nparts columns each
-  float* gpart = (float*)work;
-  float* rg_partial = gpart + (size_t)nbands * G * TF_REC * nparts;
-  hipLaunchKernelGGL(k_tf_compose_bwd, dim3(nparts, nbands), dim3(256), 0, s, a, (const float2*)gH, ldh, gpart,
-                     rg_partial);
+  hipLaunchKernelGGL(k_tf_compose_bwd_rec, dim3(nparts, nbands), dim3(256), 0, s, a, (const float2*)Tsave,
+                     (const float2*)gH, ldh, (float*)work);
   GFDN_LAUNCH_CHECK();
-  const int n0 = nbands * G * TF_REC, rows = n0 + nbands * B * G;
-  hipLaunchKernelGGL(k_tf_rows_sum, dim3((rows + 3) / 4), dim3(256), 0, s, (const float*)work, nparts, rows, grec, n0,
-                     grgain, (float*)nullptr);
+  const int n0 = nbands * G * TF_REC;
+  hipLaunchKernelGGL(k_tf_rows_sum, dim3((n0 + 3) / 4), dim3(256), 0, s, (const float*)work, nparts, n0, grec, n0,
+                     (float*)nullptr, (float*)nullptr);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -1422,7 +1422,8 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power(const float2* __
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
                                                                  int nframes, int items,
                                                                  const float* __restrict__ gP,
-                                                                 const float2* base2, float2* gx2, int parity) {
+                                                                 const float2* base2, float2* gx2, int parity,
+                                                                 int late_base) {
   float2* buf = dyn_lds;
   const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
@@ -1462,8 +1463,12 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
   // Frames of one parity tile the time axis without overlap (hop = win / 2): the even launch STORES
   // base + contribution (and base alone past the last even frame), the odd launch that follows adds its
   // contribution with a plain read-modify-write.  No atomics (they cost 50 of 139 us here), no cleared buffer.
+  // late_base: the ODD launch adds base2 (everywhere, also where no odd frame reaches), the even launch stores its
+  // contribution alone -- it then does not depend on the producer of base2 (the EDC scans on another stream).
   float2* g = gx2 + (size_t)p * ld;
-  const float2* src = parity ? g : (base2 ? base2 + (size_t)p * ld : nullptr);
+  const float2* bs = base2 ? base2 + (size_t)p * ld : nullptr;
+  const float2* src = parity ? g : (late_base ? nullptr : bs);
+  const float2* add = (parity && late_base) ? bs : nullptr;
   const int tlim = parity ? T : ld;
   // the transform's outputs wait in the thread's own LDS slots while a rolled loop adds them to the gradient
   // signal: the epilogue then needs a handful of registers instead of the sixteen outputs plus sixteen loads
@@ -1474,7 +1479,8 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
   for (int u = 0; u < 16; ++u) {
     const int j = i + 256 * u, t = m * 2048 + j;
     if (t < tlim) {
-      const float2 o = src ? src[t] : make_float2(0.f, 0.f);
+      float2 o = src ? src[t] : make_float2(0.f, 0.f);
+      if (add) o = cadd(o, add[t]);
       const float hw = t < T ? 0.5f - 0.5f * cospif((float)j * (1.0f / 2048.0f)) : 0.f;
       const float2 v = buf[S4K_PAD(j)];
       g[t] = make_float2(o.x + hw * v.x, o.y + (two ? hw * v.y : 0.f));
@@ -1482,6 +1488,12 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
   }
   if (!parity && m + 2 >= nframes)
     for (int t = (m + 2) * 2048 + i; t < ld; t += S4K_T) g[t] = src ? src[t] : make_float2(0.f, 0.f);
+  if (add) {      // samples no odd frame covers: the first hop, and whatever lies beyond the last odd frame
+    if (m == 1)
+      for (int t = i; t < 2048 && t < ld; t += S4K_T) g[t] = cadd(g[t], add[t]);
+    if (m + 2 >= nframes)
+      for (int t = (m * 2048 + 4096 < T ? m * 2048 + 4096 : T) + i; t < ld; t += S4K_T) g[t] = cadd(g[t], add[t]);
+  }
 }
 
 extern "C" int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P,
@@ -1496,21 +1508,34 @@ extern "C" int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, 
   return 0;
 }
 
-extern "C" int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
-                                         const float* base2, float* gx2, void* stream) {
+static int stft_pairs_bwd_run(const float* x2, int ld, int T, int items, int win, const float* gP,
+                              const float* base2, float* gx2, int phases, int late_base, void* stream) {
   if (!x2 || !gP || !gx2 || items <= 0 || ld < T) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = gfdn_stft_nframes(T, win);
   if (nframes <= 0) return GFDN_E_BADARG;
+  if (late_base && nframes < 2) return GFDN_E_UNSUPPORTED;
   for (int parity = 0; parity < 2; ++parity) {
     const int nb = (nframes + 1 - parity) / 2;
-    if (nb == 0) continue;
+    if (nb == 0 || !((phases >> parity) & 1)) continue;
     hipLaunchKernelGGL(k_stft4k_pair_power_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T),
                        S4K_LDS * sizeof(float2), (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, gP,
-                       (const float2*)base2, (float2*)gx2, parity);
+                       (const float2*)base2, (float2*)gx2, parity, late_base);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
+                                         const float* base2, float* gx2, void* stream) {
+  return stft_pairs_bwd_run(x2, ld, T, items, win, gP, base2, gx2, 3, 0, stream);
+}
+
+extern "C" int gfdn_stft_power_pairs_bwd_phase(const float* x2, int ld, int T, int items, int win, const float* gP,
+                                               const float* base2, float* gx2, int phase, void* stream) {
+  if (phase != 0 && phase != 1) return GFDN_E_BADARG;
+  if (phase == 1 && gx2 == base2) return GFDN_E_BADARG;
+  return stft_pairs_bwd_run(x2, ld, T, items, win, gP, phase ? base2 : nullptr, gx2, 1 << phase, 1, stream);
 }
 
 static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }

@@ -26,6 +26,14 @@ class FrequencyGrid:
         # the unit circle is by far the common case: skip the radius factor entirely
         self.on_unit_circle = bool((logr.abs().max() < 1e-12).item())
         self.logr = None if self.on_unit_circle else logr
+        # uniform grids on the unit circle (the reference's z = exp(2 pi i rfftfreq(nfft)), dataloader.py:552-566):
+        # the step in turns, else 0 -- kernels that walk consecutive bins may then rotate instead of re-evaluating
+        self.dturn = 0.0
+        if self.on_unit_circle and self.K > 2:
+            d = float(((self.turns[-1] - self.turns[0]) / (self.K - 1)).item())
+            k = torch.arange(self.K, dtype=torch.float64, device=self.turns.device)
+            if d != 0.0 and bool(((self.turns - (self.turns[0] + k * d)).abs().max() < 1e-13).item()):
+                self.dturn = d
 
     @classmethod
     def of(cls, z: torch.Tensor) -> "FrequencyGrid":

@@ -560,8 +560,11 @@ def tf_eval(turns, logr, coef, delays, nper: int, scale=None) -> torch.Tensor:
     return T
 
 
-def tf_energy(turns, logr, coef, delays, nper: int, b=None, c=None, want_energy=True, want_scale=True, work=None):
-    """energy (nblk) = mean_k |T|^2, scale = energy^(-1/2); b, c (float32, contiguous): rescaled in place."""
+def tf_energy(turns, logr, coef, delays, nper: int, b=None, c=None, want_energy=True, want_scale=True, work=None,
+              phase: int = 3, energy=None, scale=None, dturn: float = 0.0):
+    """energy (nblk) = mean_k |T|^2, scale = energy^(-1/2); b, c (float32, contiguous): rescaled in place.
+    ``phase``: 1 = only the pass over the bins (partial sums into ``work``; returns work), 2 = only the finish
+    from that ``work``, 3 = both.  ``dturn`` != 0: the grid is uniform on the unit circle with that step (turns)."""
     _need_gpu(turns, coef, delays)
     coef, delays = _f(coef), _f(delays)
     nblk, K = coef.shape[0], turns.numel()
@@ -569,15 +572,17 @@ def tf_energy(turns, logr, coef, delays, nper: int, b=None, c=None, want_energy=
         if t is not None and (t.dtype != _f32 or not t.is_contiguous() or t.numel() != nblk * nper):
             raise RuntimeError("tf_energy: gains must be contiguous float32 of nblk*nper elements")
     lib = _lib.load()
-    energy = torch.empty(nblk, dtype=_f32, device=coef.device) if want_energy else None
-    scale = torch.empty(nblk, dtype=_f32, device=coef.device) if want_scale else None
+    if phase & 2:
+        energy = torch.empty(nblk, dtype=_f32, device=coef.device) if (want_energy and energy is None) else energy
+        scale = torch.empty(nblk, dtype=_f32, device=coef.device) if (want_scale and scale is None) else scale
     work = _work(lib.gfdn_tf_work_bytes(nblk), coef.device) if work is None else work
     _lib.check(lib.gfdn_tf_energy(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(b), _p(c), _p(energy),
-                                  _p(scale), _p(work), _stream()), "gfdn_tf_energy")
-    return energy, scale
+                                  _p(scale), _p(work), int(phase), float(dturn), _stream()), "gfdn_tf_energy")
+    return work if phase == 1 else (energy, scale)
 
 
-def tf_colorless(turns, logr, coef, delays, nper: int, scale, asym: bool, gscale: float, work=None):
+def tf_colorless(turns, logr, coef, delays, nper: int, scale, asym: bool, gscale: float, work=None,
+                 dturn: float = 0.0):
     """-> (grec (nblk, 32) gradient records of gscale * sum_blk loss_blk for the (scaled) sub-FDN records,
     loss (nblk,) = mean_k (|scale T| - 1)^p)."""
     _need_gpu(turns, coef, delays)
@@ -588,14 +593,16 @@ def tf_colorless(turns, logr, coef, delays, nper: int, scale, asym: bool, gscale
     grec = torch.empty((nblk, 32), dtype=_f32, device=coef.device)
     loss = torch.empty(nblk, dtype=_f32, device=coef.device)
     _lib.check(_lib.load().gfdn_tf_colorless(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(scale),
-                                             int(asym), float(gscale), _p(grec), _p(loss), _p(work), _stream()),
+                                             int(asym), float(gscale), _p(grec), _p(loss), _p(work), float(dturn),
+                                             _stream()),
                "gfdn_tf_colorless")
     return grec, loss
 
 
 def tf_compose_fwd(turns, logr, coef, delays, nper: int, rgain, scale=None, direct=None, filt=None,
-                   direct_rows=None, nbands: int = 1, out=None) -> torch.Tensor:
-    """H (nbands*B, K) complex64 from the records (band-stacked as compose_fwd)."""
+                   direct_rows=None, nbands: int = 1, out=None, save_T: bool = False):
+    """H (nbands*B, K) complex64 from the records (band-stacked as compose_fwd); ``save_T``: also returns the
+    scaled, unfiltered group transfer functions (nbands*G, K) complex64 that tf_compose_bwd takes back."""
     _need_gpu(turns, coef, rgain)
     coef, delays, rgain = _f(coef), _f(delays), _f(rgain)
     K = turns.numel()
@@ -617,33 +624,52 @@ def tf_compose_fwd(turns, logr, coef, delays, nper: int, rgain, scale=None, dire
         raise RuntimeError("tf_compose_fwd: direct must have one row per item (or pass direct_rows)")
     scale = None if scale is None else _f(scale)
     H = torch.empty((Btot, K), dtype=_c64, device=coef.device) if out is None else out
+    Ts = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if save_T else None
     _lib.check(_lib.load().gfdn_tf_compose_fwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays),
                                                _p(scale), _p(rgain), Btot // nbands, _p(direct), ldd,
-                                               _p(direct_rows), _p(filt), K, _p(H), K, _stream()),
+                                               _p(direct_rows), _p(filt), K, _p(H), K, _p(Ts), _stream()),
                "gfdn_tf_compose_fwd")
-    return H
+    return (H, Ts) if save_T else H
 
 
-def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, scale=None, filt=None, nbands: int = 1,
-                   grgain=None, work=None):
-    """-> (grec (nbands*G, 32) gradient records, grgain (nbands*B, G))."""
-    _need_gpu(turns, coef, rgain, gH)
-    coef, delays, rgain, gH = _f(coef), _f(delays), _f(rgain), _c(gH)
+def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, work=None) -> torch.Tensor:
+    """grgain (nbands*B, G) = sum_k Re(dL/dH[b][k] conj(filt[k] T'_g[k])); ``Tsave`` (nbands*G, K) from
+    tf_compose_fwd(save_T=True)."""
+    _need_gpu(Tsave, gH)
+    Tsave, gH = _c(Tsave), _c(gH)
+    Btot, K = gH.shape
+    if Btot % nbands or tuple(Tsave.shape) != (nbands * G, K):
+        raise RuntimeError("tf_gain_grad: shapes do not match nbands x G blocks")
+    filt = None if filt is None else _c(filt)
+    lib = _lib.load()
+    B = Btot // nbands
+    grgain = torch.empty((Btot, G), dtype=_f32, device=gH.device) if grgain is None else grgain
+    if work is None:
+        work = _work(lib.gfdn_tf_gain_grad_work_bytes(K, nbands, G, B), gH.device)
+    _lib.check(lib.gfdn_tf_gain_grad(K, nbands, G, B, _p(Tsave), _p(filt), K, _p(gH), K, _p(grgain), _p(work),
+                                     _stream()), "gfdn_tf_gain_grad")
+    return grgain
+
+
+def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=None, nbands: int = 1, work=None):
+    """-> grec (nbands*G, 32): gradient records of the scaled records; ``Tsave``: the forward's saved group transfer
+    functions (tf_compose_fwd(save_T=True))."""
+    _need_gpu(turns, coef, rgain, gH, Tsave)
+    coef, delays, rgain, gH, Tsave = _f(coef), _f(delays), _f(rgain), _c(gH), _c(Tsave)
     K = turns.numel()
     Btot, G = rgain.shape
-    if coef.shape[0] != nbands * G or Btot % nbands or tuple(gH.shape) != (Btot, K):
+    if coef.shape[0] != nbands * G or Btot % nbands or tuple(gH.shape) != (Btot, K) \
+            or tuple(Tsave.shape) != (nbands * G, K):
         raise RuntimeError("tf_compose_bwd: shapes do not match nbands x G blocks")
     filt = None if filt is None else _c(filt)
-    scale = None if scale is None else _f(scale)
     lib = _lib.load()
     grec = torch.empty((nbands * G, 32), dtype=_f32, device=coef.device)
-    grgain = torch.empty((Btot, G), dtype=_f32, device=coef.device) if grgain is None else grgain
     if work is None:
-        work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G, Btot // nbands), coef.device)
-    _lib.check(lib.gfdn_tf_compose_bwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays), _p(scale),
-                                       _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(grgain),
-                                       _p(work), _stream()), "gfdn_tf_compose_bwd")
-    return grec, grgain
+        work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G), coef.device)
+    _lib.check(lib.gfdn_tf_compose_bwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays), _p(Tsave),
+                                       _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(work),
+                                       _stream()), "gfdn_tf_compose_bwd")
+    return grec
 
 
 def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):
@@ -922,11 +948,23 @@ def stft_power_pairs(x2, items: int, win: int, zero_buf=None) -> torch.Tensor:
     return P
 
 
-def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None) -> torch.Tensor:
+def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None, phase=None) -> torch.Tensor:
     """-> base + d<gP, P>/dx2, shaped like x2 (``base``: another gradient of the same layout, e.g. the EDC loss's;
-    ``out`` may be ``base`` itself).  Stored, not accumulated: ``out`` needs no clearing."""
+    ``out`` may be ``base`` itself).  Stored, not accumulated: ``out`` needs no clearing.
+    ``phase`` 0 / 1: one of the two launches (even / odd frames) with the base added by the SECOND one, so that
+    the first does not wait for the producer of ``base`` (``out`` must then not alias ``base``)."""
     _need_gpu(x2, gP)
     out = torch.empty_like(x2) if out is None else out
+    if phase is not None:
+        if phase == 1 and base is not None and base.data_ptr() == out.data_ptr():
+            raise RuntimeError("stft_power_pairs_bwd(phase=1): out must not alias base")
+        for t in (base, out):
+            if t is not None and (t.dtype != _f32 or not t.is_contiguous() or t.shape != x2.shape or not t.is_cuda):
+                raise RuntimeError("stft_power_pairs_bwd: base / out must be shaped like x2")
+        _lib.check(_lib.load().gfdn_stft_power_pairs_bwd_phase(_p(x2), x2.shape[1], x2.shape[1], items, win, _p(gP),
+                                                               _p(base), _p(out), int(phase), _stream()),
+                   "gfdn_stft_power_pairs_bwd_phase")
+        return out
     for t in (base, out):
         if t is not None and (t.dtype != _f32 or not t.is_contiguous() or t.shape != x2.shape or not t.is_cuda):
             raise RuntimeError("stft_power_pairs_bwd: base / out must be shaped like x2")

@@ -279,15 +279,20 @@ int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr, int K, in
  *   energy    : Trainer.normalize (trainer.py:317-332) from the records of the sub-FDNs: energy (nblk) =
  *               mean_k |T|^2 (optional), scale (nblk) = energy^(-1/2) (optional: what T -- and the numerator
  *               records -- scale by once b, c are divided by energy^(1/4)), b, c (both or neither) rescaled in
- *               place.  work: gfdn_tf_work_bytes(nblk).
+ *               place.  phase: 1 = the pass over the bins only (partial sums into work), 2 = the finish only
+ *               (energy, scale, rescale -- the only part that writes b, c), 3 = both.  work: gfdn_tf_work_bytes(nblk).
+ *               dturn (energy, colorless): != 0 asserts a uniform grid on the unit circle, turns[k] = turns[0] +
+ *               k dturn (logr NULL) -- the passes then step the phasors through runs of 8 bins by constant
+ *               rotations instead of one exact evaluation per bin; 0: any grid.
  *   colorless : spectral loss of the sub-FDNs (colorless_fdn/losses.py:20-73, trainer.py:298-304) on
  *               S' = scale T: loss (nblk, optional) = mean_k (|S'| - 1)^p per block and the gradient record
  *               grec (nblk, 32) of L = gscale * sum_blk loss_blk: entry S < 15 dL/dP'_S (P' = scale P), 16 + S
  *               dL/dQ_S (entry 15 holds loss_blk).  work: gfdn_tf_gpart_bytes(nblk).
  *   compose   : H[b][k] = (sum_g rgain[b][g] scale_g T_g(z_k) + direct[rows[b]][k]) filt[k], band-stacked as
- *               gfdn_compose_banded_* (blocks band*G + g, items band*B + b); the backward reads dL/dH once and
- *               returns the gradient records grec (nbands*G, 32) and grgain (nbands*B, G).  G <= 4, B <= 64.
- *               work: gfdn_tf_compose_bwd_work_bytes.
+ *               gfdn_compose_banded_* (blocks band*G + g, items band*B + b); Tsave (nbands*G, K) complex64,
+ *               optional: the scaled, unfiltered scale_g T_g(z_k), which the backward takes back.  The backward
+ *               is two streaming passes over dL/dH: gain_grad -> grgain (nbands*B, G), compose_bwd -> the gradient
+ *               records grec (nbands*G, 32) of the SCALED records.  G <= 4.  work: the *_work_bytes queries.
  *   coefs_bwd : maps gradient records to dL/dA, dL/db, dL/dc for up to two record sets sharing b, c (set 0:
  *               damped loop, A0 = Q Q; set 1: sub-FDNs, A1 = raw M, or A1 = NULL): gA0, gA1 (nblk, nper, nper),
  *               gb, gc (nblk*nper) = the sum over the sets.  b, c: the values the records' gradients refer to.  */
@@ -303,20 +308,22 @@ int gfdn_tf_eval(const double* turns, const double* logr, int K, int nblk, int n
                  const float* delays, const float* scale, float* T_c64, void* stream);
 int gfdn_tf_energy(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
                    const float* delays, float* b, float* c, float* energy, float* scale, void* work,
-                   void* stream);
+                   int phase, double dturn, void* stream);
 int gfdn_tf_colorless(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
                       const float* delays, const float* scale, int asym, float gscale, float* grec,
-                      float* loss, void* work, void* stream);
+                      float* loss, void* work, double dturn, void* stream);
 int gfdn_tf_compose_fwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
                         const float* coef, const float* delays, const float* scale, const float* rgain, int B,
                         const float* direct_c64, int ldd, const long long* direct_rows, const float* filt_c64,
-                        int ldf, float* H_c64, int ldh, void* stream);
-int gfdn_tf_compose_parts(int K);
-size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G, int B);
+                        int ldf, float* H_c64, int ldh, float* Tsave_c64, void* stream);
+size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G);
 int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
-                        const float* coef, const float* delays, const float* scale, const float* rgain, int B,
-                        const float* filt_c64, int ldf, const float* gH_c64, int ldh, float* grec,
-                        float* grgain, void* work, void* stream);
+                        const float* coef, const float* delays, const float* Tsave_c64, const float* rgain, int B,
+                        const float* filt_c64, int ldf, const float* gH_c64, int ldh, float* grec, void* work,
+                        void* stream);
+size_t gfdn_tf_gain_grad_work_bytes(int K, int nbands, int G, int B);
+int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave_c64, const float* filt_c64, int ldf,
+                      const float* gH_c64, int ldh, float* grgain, void* work, void* stream);
 
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's
@@ -356,7 +363,10 @@ int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const fl
  * produce that layout (win = 4096 only); P, T_db, loss_item stay per item; gfdn_edc_loss_pairs takes
  * gfdn_edc_work_bytes(items + 1) bytes of work.  gfdn_stft_power_pairs_bwd STORES gx2 = base2 + d<gP, P>/dx2
  * (base2: another gradient of the same layout or NULL; may alias gx2): even frames first, odd frames in a second
- * launch -- frames of one parity do not overlap, so there are no atomics and gx2 needs no clearing.   */
+ * launch -- frames of one parity do not overlap, so there are no atomics and gx2 needs no clearing.
+ * gfdn_stft_power_pairs_bwd_phase runs ONE of the two launches with the base added by the SECOND: phase 0 = even
+ * frames, gx2 = their contribution alone (base2 ignored: the launch does not wait for whoever produces it);
+ * phase 1 = odd frames, gx2 += contribution + base2 everywhere (base2 must not alias gx2).  0 then 1 = the above. */
 int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs_c64, int ldx, int batch,
                              float* x2, int ldo, void* work, void* stream);
 int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
@@ -365,6 +375,8 @@ int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, fl
                           void* stream);
 int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,
                               const float* base2, float* gx2, void* stream);
+int gfdn_stft_power_pairs_bwd_phase(const float* x2, int ld, int T, int items, int win, const float* gP,
+                                    const float* base2, float* gx2, int phase, void* stream);
 int gfdn_edc_loss_pairs(const float* x2, int ld, int items, int start, int len, const float* T_db,
                         const long long* target_rows, const float* maskw, float inv_count, float gscale,
                         float* loss_item, float* gx2, void* work, void* stream);

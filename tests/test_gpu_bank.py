@@ -530,6 +530,10 @@ def test_pair_interleaved_kernels_equal_per_item_kernels(B):
     assert rel_err(split(g3).cpu(), (gx + gb).cpu()) < 2e-6
     g4 = ops.stft_power_pairs_bwd(xj, B, win, gP, base=keep)
     assert torch.equal(g4, g3)
+    # the two launches on their own, base added by the second: the same sums in the same order
+    g5 = ops.stft_power_pairs_bwd(xj, B, win, gP, out=torch.full_like(xj, 3.0), phase=0)
+    g5 = ops.stft_power_pairs_bwd(xj, B, win, gP, base=keep, out=g5, phase=1)
+    assert torch.equal(g5, g3)
     # EDC
     tgt = ops.edc_target(torch.randn(B, n, generator=g).to(DEV) * 0.01, start, L)
     mw = (torch.rand(L, generator=g) > 0.5).float().to(DEV) / (B * L / 2)

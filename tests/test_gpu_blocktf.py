@@ -72,6 +72,9 @@ def test_records_and_evaluation(n, nblk, radius, orth):
     energy, scale = ops.tf_energy(turns, logr if radius != 1.0 else None, coef, delays.to(DEV), n, bb, cc)
     E = (ref.abs() ** 2).mean(0)
     assert rel_err(energy.cpu().numpy(), E.numpy()) < 2e-5
+    if radius == 1.0:          # uniform grid on the unit circle: the pass that steps the phasors by constant rotations
+        e2, _ = ops.tf_energy(turns, None, coef, delays.to(DEV), n, dturn=0.5 / (K - 1))
+        assert rel_err(e2.cpu().numpy(), E.numpy()) < 2e-5
     assert rel_err(scale.cpu().numpy(), (E ** -0.5).numpy()) < 2e-5
     d = (E ** 0.25).repeat_interleave(n)
     assert rel_err(bb.cpu().numpy(), (b.float().double() / d).numpy()) < 1e-5
@@ -87,8 +90,9 @@ def _colorless_ref(z, M, b, c, delays, s, asym, gscale):
     return gscale * loss_g.sum(), loss_g
 
 
+@pytest.mark.parametrize("runs", [False, True])
 @pytest.mark.parametrize("n,nblk,asym", [(4, 28, True), (4, 6, False), (3, 4, True)])
-def test_colorless_pass_and_record_adjoint(n, nblk, asym):
+def test_colorless_pass_and_record_adjoint(n, nblk, asym, runs):
     """loss_g and d(gscale sum_g loss_g)/d(M, b, c) at the scaled responses against float64 autograd."""
     from diffgfdn_amd import hip_ops as ops
     K = 4097
@@ -106,7 +110,8 @@ def test_colorless_pass_and_record_adjoint(n, nblk, asym):
     L, loss_g = _colorless_ref(z, Mr, bp, cp, delays, torch.ones(nblk, dtype=torch.float64), asym, gscale)
     L.backward()
     coef = ops.tf_coefs(M.to(DEV), b.to(DEV), c.to(DEV))
-    grec, loss = ops.tf_colorless(turns, None, coef, delays.to(DEV), n, s.to(DEV), asym, gscale)
+    grec, loss = ops.tf_colorless(turns, None, coef, delays.to(DEV), n, s.to(DEV), asym, gscale,
+                                  dturn=0.5 / (K - 1) if runs else 0.0)
     assert rel_err(loss.cpu().numpy(), loss_g.detach().numpy()) < 2e-5
     assert torch.equal(grec[:, 15], loss)
     # one record set through the two-set entry point: set 0 a dummy with zero gradient records
@@ -118,7 +123,8 @@ def test_colorless_pass_and_record_adjoint(n, nblk, asym):
     assert rel_err(gc.cpu().numpy(), cp.grad.numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("n,G,nbands,B,K", [(4, 4, 3, 8, 1500), (4, 3, 1, 5, 777), (3, 4, 2, 32, 1025), (4, 4, 7, 32, 4100)])
+@pytest.mark.parametrize("n,G,nbands,B,K", [(4, 4, 3, 8, 1500), (4, 3, 1, 5, 777), (3, 4, 2, 32, 1025), (4, 4, 7, 32, 4100),
+                                             (4, 2, 2, 13, 3000)])
 def test_output_stage_from_records(n, G, nbands, B, K):
     """H = (sum_g rgain s_g T_g + direct[rows]) filt and the adjoint: grgain, gQQ, gb, gc against autograd."""
     from diffgfdn_amd import hip_ops as ops
@@ -149,10 +155,12 @@ def test_output_stage_from_records(n, G, nbands, B, K):
     turns, _ = ops.zprep(z.to(DEV))
     coef = ops.tf_coefs(A.to(DEV), b.to(DEV), c.to(DEV), ig.to(DEV))
     dl = delays.to(DEV)
-    Hd = ops.tf_compose_fwd(turns, None, coef, dl, n, rgain.to(DEV), s.to(DEV), direct.to(DEV), filt.to(DEV),
-                            rows.to(DEV), nbands)
+    Hd, Ts = ops.tf_compose_fwd(turns, None, coef, dl, n, rgain.to(DEV), s.to(DEV), direct.to(DEV), filt.to(DEV),
+                                rows.to(DEV), nbands, save_T=True)
     assert rel_err(Hd.cpu().numpy(), H.detach().numpy()) < 2e-5
-    grec, grg = ops.tf_compose_bwd(turns, None, coef, dl, n, rgain.to(DEV), W.to(DEV), s.to(DEV), filt.to(DEV), nbands)
+    assert rel_err(Ts.cpu().numpy(), T.detach().T.numpy()) < 2e-5
+    grg = ops.tf_gain_grad(Ts, W.to(DEV), G, filt.to(DEV), nbands)
+    grec = ops.tf_compose_bwd(turns, None, coef, dl, n, rgain.to(DEV), W.to(DEV), Ts, filt.to(DEV), nbands)
     assert rel_err(grg.cpu().numpy(), rg.grad.numpy()) < 1e-4
     gA, _, gb, gc = ops.tf_coefs_bwd(A.to(DEV), ig.to(DEV), grec, bp.detach().float().to(DEV),
                                      cp.detach().float().to(DEV))
