@@ -7,12 +7,12 @@ sub-FDN forward, b, c /= E^(1/4)), forward (model.py:569-625), losses (trainer.p
 feedback loop only through the group transfer functions T_g(z) -- ratios of multilinear polynomials in the phasors
 z^{m_i} with 2 x 16 real coefficients per block -- so the step is
 
-    main  : records of the raw blocks M_g -> energy pass -> finish (normalize: b, c rescaled in place, scale_g)
-            -> output stage H -> irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint -> output-stage adjoint
-            (dL/dgains, then dL/drecords) -> records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint
-            -> [all-reduce] -> Adam
-    side  : Q, QQ = expm -> records of Q_g Q_g ........ colorless pass (spectral loss + dL/drecords), sparsity
-    side2 : gain network forward, mask draw ........... EDC scans ........... gain network backward
+    main  : Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g -> energy pass -> finish (normalize: b, c
+            rescaled in place, scale_g) -> output stage H -> irfft -> STFT -> EDR -> STFT adjoint (even frames, then
+            odd frames + EDC gradient) -> irfft adjoint -> output-stage adjoint (dL/dgains, then dL/drecords)
+            -> records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint -> [all-reduce] -> Adam
+    side2 : gain network forward, mask draw ... EDC scans, colorless pass (spectral loss + dL/drecords), sparsity,
+            reported sums ... gain network backward
 
 about 35 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
 accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve never exist.  The autograd
@@ -102,7 +102,7 @@ class FusedBankStep:
         T_edr, sum_abs, T_edc = edr_t[1], edr_t[2], edc_t[1]
         win = tr.stft_win
         pairs = order is not None and tr.use_pairs and win == 4096
-        ev = {k: torch.cuda.Event() for k in ('start', 'g', 'mlp', 'norm', 'x', 'edc', 'mid', 'side', 'sums', 'grg',
+        ev = {k: torch.cuda.Event() for k in ('start', 'g', 'mlp', 'norm', 'x', 'edc', 'side', 'grg',
                                               'mlpb')}
 
         # ---- head.  main: records of the raw blocks -> energy pass -> finish (normalize, trainer.py:317-332);
@@ -161,7 +161,6 @@ class FusedBankStep:
                                              rows=rows)
             ev['edc'].record()
         li_edr = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rows, defer=True)
-        ev['mid'].record()
         keep.extend((P, g_edr, li_edc, g_edc, li_edr))
         gH = None
         if train:
@@ -183,26 +182,20 @@ class FusedBankStep:
         else:
             main.wait_event(ev['edc'])
             ev['g'].record()
-        # side: the colorless pass (VALU-bound) beside the memory-bound transform adjoint
-        with on_side():
-            torch.cuda.current_stream().wait_event(ev['g'])
+        # the colorless pass rides the EDC stream behind the scans (a third stream would share a hardware queue with
+        # this one anyway, and the graph then runs it last: measured)
+        with on_side2():
             grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
                                                 cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
                                                 dturn=gridK.dturn)
             out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
                                            inv_world, want_grad=train, nbands=nb)
             ev['side'].record()
-        keep.extend((grec_sub, loss_g, out3, gQ))
-        # the reported sums and total (off the gradient path): side2 behind the EDC scans, side behind its colorless terms
-        with on_side2():
-            torch.cuda.current_stream().wait_event(ev['mid'])
+            # the reported sums and total (off the gradient path) behind it: their inputs are complete once the
+            # transform adjoint may start, and no other stream is involved
             sums = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
-            ev['sums'].record()
-        with on_side():
-            torch.cuda.current_stream().wait_event(ev['sums'])
             total = (sums[:, 0] + out3[:, 0]) if nb > 1 else (sums[0] + out3[0])
-        keep.extend((sums, total))
-
+        keep.extend((grec_sub, loss_g, out3, gQ, sums, total))
         if train:
             # ---- backward of the output stage: gains pass -> (side2: gain network backward) | records pass
             grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
