@@ -1,0 +1,194 @@
+"""Full-size (nfft = 131 072, K = 65 537, N = 16) BACKWARD parity against the CPU oracle.
+
+The production configuration runs kernels that exist only at this size (Rader on 2^16 points, slot-ordered spectra,
+two items per transform, the 4096-point register FFTs), so the gradients -- not only the forward values -- are
+pinned to the oracle here, with the device's Philox time mask handed to the oracle as the reference's index set
+(losses.py:221-227):
+  (i)  VarReceiverPosTrainer (per-bin elimination kernels through autograd), batch 2;
+  (ii) a 2-band BandBankTrainer on the graph-replayed explicit step (polynomial-form block transfer functions,
+       slot order, pair-interleaved signals), batch 2 per band.
+Compared: every weighted loss term (1e-4 relative, the north star's bar), every parameter gradient (max-norm per
+tensor, 2e-3), and the parameters after the Adam update."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gfdn_oracle as orc
+from oracle.cpu_trainer import OracleGridTrainer
+from tests.helpers import philox_mask, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FS, NFFT, G, NPER, R, B = 32000.0, 131072, 4, 4, 6, 2
+K = NFFT // 2 + 1
+CENTRES = (250.0, 1000.0)
+DELAYS = [[641, 701, 809, 907, 1009, 1103, 1201, 1301, 1399, 1409, 1423, 1427, 1429, 1433, 1439, 1601],
+          [643, 709, 811, 911, 1013, 1109, 1213, 1303, 1381, 1411, 1423, 1427, 1447, 1451, 1453, 1601]]
+LOSS_TOL, GRAD_TOL = 1e-4, 2e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _filters():
+    from scipy.signal import firwin
+    return np.stack([np.fft.rfft(firwin(1025, [f / np.sqrt(2), f * np.sqrt(2)], pass_zero=False, fs=FS), n=NFFT)
+                     for f in CENTRES])
+
+
+def _band(q):
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.synthetic import synthetic_room
+    room = synthetic_room(R, G, FS, 40000, seed=40 + q)
+    ds = MultiRIRDataset(DEV, RoomDataset(G, FS, room["source_position"], room["receiver_position"], room["rirs"],
+                                          room["common_decay_times"], nfft=NFFT, device=DEV))
+    torch.manual_seed(200 + q)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(FS, G, DELAYS[q], DEV, fl, of, use_absorption_filters=False,
+                                 common_decay_times=room["common_decay_times"], use_colorless_loss=True).to(DEV)
+    return room, ds, net
+
+
+def _tc():
+    from diffgfdn_amd.config import SubbandProcessingConfig, TrainerConfig
+    return TrainerConfig(batch_size=B, num_freq_bins=NFFT, lr=1e-3, io_lr=1e-2, use_colorless_loss=True,
+                         use_asym_spectral_loss=True, edc_loss_weight=10.0, sparsity_loss_weight=2.0,
+                         use_edc_mask=True, train_dir="/tmp/gfdn_full/t", ir_dir="/tmp/gfdn_full/a", device="cuda",
+                         subband_process_config=SubbandProcessingConfig(centre_frequency=500.0,
+                                                                        frequency_range=(63, 8000),
+                                                                        num_fraction_octaves=1))
+
+
+def _oracle_step(sd, q, room, ds, sel, filt_q, keep):
+    """normalize + train_step of the CPU oracle from the state dict ``sd`` on receivers ``sel``; returns the loss
+    parts, the gradients and the parameters after Adam, keyed like the model's state dict."""
+    lin, norm, names = [], [], []
+    for i in range(64):
+        k = f"output_scalars.mlp.model.{i}.weight"
+        if k in sd:
+            pair = (sd[k].clone(), sd[f"output_scalars.mlp.model.{i}.bias"].clone())
+            (lin if sd[k].ndim == 2 else norm).append(pair)
+            names.append((f"output_scalars.mlp.model.{i}", pair))
+    p = orc.GridModelParams(FS, DELAYS[q], G, sd["input_gains"].clone(), sd["output_gains"].clone(),
+                            sd["feedback_loop.M"].clone(), sd["feedback_loop.alpha"].clone(),
+                            room["common_decay_times"], lin, norm, 4)
+    otr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
+                            sparsity_weight=2.0, use_asym=True, subband_filter=filt_q.cpu().to(torch.complex128))
+    idx = torch.tensor(sel)
+    ob = {"z_values": ds.z_values.cpu(),
+          "norm_listener_position": ds.norm_listener_position[idx].cpu(),
+          "listener_position": ds.listener_positions[idx].cpu(),
+          "target_early_response": ds.early_rir_mag_response[idx].cpu().to(torch.complex128),
+          "target_rir_response": ds.rir_mag_response[idx].cpu().to(torch.complex128)}
+    otr.normalize(ob)
+    _, parts = otr.train_step(ob, keep)
+    grads = {"input_gains": p.input_gains.grad, "output_gains": p.output_gains.grad, "feedback_loop.M": p.M.grad}
+    after = {"input_gains": p.input_gains.detach(), "output_gains": p.output_gains.detach(),
+             "feedback_loop.M": p.M.detach()}
+    for base, (w, bias) in names:
+        grads[base + ".weight"], grads[base + ".bias"] = w.grad, bias.grad
+        after[base + ".weight"], after[base + ".bias"] = w.detach(), bias.detach()
+    return parts, grads, after
+
+
+def _check(tag, parts_hip, grads_hip, after_hip, before, parts, grads, after):
+    for k, v in parts.items():
+        assert abs(parts_hip[k] - v) <= LOSS_TOL * abs(v) + 1e-7, (tag, k, parts_hip[k], v)
+    worst = {}
+    for k, g in grads.items():
+        gh = np.asarray(grads_hip[k], dtype=np.float64).reshape(-1)
+        go = g.numpy().astype(np.float64).reshape(-1)
+        worst[k] = np.abs(gh - go).max() / (np.abs(go).max() + 1e-300)
+        assert worst[k] < GRAD_TOL, (tag, k, worst[k])
+        # Adam's first step moves every entry by lr g / (|g| + eps): the update of M (which normalize leaves alone) is
+        # compared where the gradient is not at the noise floor of float32 sums over 65 537 bins
+        if k == "feedback_loop.M":
+            b0 = np.asarray(before[k], dtype=np.float64).reshape(-1)
+            d_hip = np.asarray(after_hip[k], dtype=np.float64).reshape(-1) - b0
+            d_ora = after[k].numpy().astype(np.float64).reshape(-1) - b0
+            big = np.abs(go) > 1e-3 * np.abs(go).max()
+            assert np.abs(d_hip[big] - d_ora[big]).max() < 1e-3 * np.abs(d_ora[big]).max(), (tag, k)
+    return worst
+
+
+def _mask(seed, step, length, gb):
+    mw_np, _ = philox_mask(seed, step, length, 1.0 / gb)
+    return torch.tensor(mw_np, device=DEV), torch.argwhere(torch.tensor(mw_np) > 0)
+
+
+def test_full_size_single_band_backward_vs_oracle():
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    room, ds, net = _band(0)
+    filt = torch.tensor(_filters()[0], device=DEV).to(torch.complex64)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = VarReceiverPosTrainer(net, _tc(), subband_filter_freq_resp=filt, capturable=True)
+    start, length = tr._decay_window(K)
+    mw, keep = _mask(4242, 0, length, B)
+    sel = [1, 4]
+    batch = ds.collate(sel)
+    tr.normalize(batch)
+    tr.optimizer.zero_grad(set_to_none=True)
+    losses = tr._step_losses(batch, mask_prenorm=mw)
+    losses.pop("_total").backward()
+    grads_hip = {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters() if p.grad is not None}
+    tr.optimizer.step()
+    parts_hip = {k: float(v) for k, v in losses.items() if k.endswith("_loss")}
+    after_hip = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    parts, grads, after = _oracle_step(sd0, 0, room, ds, sel, filt, keep)
+    worst = _check("single", parts_hip, grads_hip, after_hip, {k: v.numpy() for k, v in sd0.items()}, parts, grads,
+                   after)
+    for name in ("input_gains", "output_gains"):         # normalize + Adam: the full update of the gains
+        assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, name
+    print("single-band full-size gradient deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_full_size_bank_graph_step_backward_vs_oracle():
+    """The path bench.py times: 2 bands, graph replay of the explicit step (slot order, pairs), device-drawn mask."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    bands = [_band(q) for q in range(2)]
+    filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
+    nets = [b_[2] for b_ in bands]
+    sd0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
+    bank = BandBank(nets)
+    tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=CENTRES)
+    assert tr._fused is not None
+    sds = BandStackedDataset([b_[1] for b_ in bands])
+    start, length = tr._decay_window(K)
+    sds.precompute_decay_targets(4096, start, length)
+    sels = [[0, 3], [1, 4]]
+    seed = 31337
+    step = tr.graphed(sds, B, mask_seed=seed).capture(sds.global_rows(sels))
+    out = step(sds.global_rows(sels))
+    torch.cuda.synchronize()
+    assert int(step.mask_state.item()) == 1
+    _, keep = _mask(seed, 0, length, B)
+    flat = tr.optimizer.flat_grad.detach().cpu().numpy()
+    views = {}
+    off = 0
+    for p in tr.optimizer._params:
+        views[id(p)] = flat[off:off + p.numel()].reshape(tuple(p.shape))
+        off += p.numel()
+    N = G * NPER
+    for q in range(2):
+        parts_hip = {k: float(v[q]) for k, v in out.items() if k.endswith("_loss")}
+        grads_hip = {"input_gains": views[id(bank.input_gains)][q].reshape(N, 1),
+                     "output_gains": views[id(bank.output_gains)][q].reshape(N, 1),
+                     "feedback_loop.M": views[id(bank.feedback_loop_M)][q]}
+        gw, o = views[id(bank.output_scalars_w)][q], 0
+        names = [n_ for n_, _ in nets[q].output_scalars.mlp.model.named_parameters()]
+        for n_, prm in zip(names, bank._mlp_params[q]):
+            grads_hip["output_scalars.mlp.model." + n_] = gw[o:o + prm.numel()].reshape(tuple(prm.shape))
+            o += prm.numel()
+        after_hip = {k: v.detach().cpu().numpy() for k, v in nets[q].state_dict().items()}
+        parts, grads, after = _oracle_step(sd0[q], q, bands[q][0], bands[q][1], sels[q], filt[q], keep)
+        worst = _check(f"bank[{q}]", parts_hip, grads_hip, after_hip, {k: v.numpy() for k, v in sd0[q].items()}, parts,
+                       grads, after)
+        for name in ("input_gains", "output_gains"):
+            assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, (q, name)
+        print(f"bank band {q} full-size gradient deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
