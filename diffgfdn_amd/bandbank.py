@@ -244,14 +244,26 @@ class BandStackedDataset:
                 'edc_target': self.edc_store, 'receiver_index': idx, 'row_index': idx, 'dataset': self}
 
 
+def bank_shards(orders: Sequence[Sequence[int]], batch: int, rank: int = 0, world_size: int = 1):
+    """Steps of one pass over the bands' receiver orders (equal lengths): yields, per step, THIS RANK's receivers of
+    every band -- an equal share of the band's (global) batch of ``batch`` receivers (dataloader.rank_shard), the same
+    number of steps on every rank, a ragged tail smaller than the world skipped everywhere."""
+    from .dataloader import rank_shard
+    n = len(orders[0])
+    for i0 in range(0, n, batch):
+        if min(batch, n - i0) // world_size == 0:
+            continue
+        yield [rank_shard(o[i0:i0 + batch], rank, world_size) for o in orders]
+
+
 class BandFlatAdam(FlatAdam):
     """FlatAdam whose learning-rate table is per (group, band): a band that has stopped early
     (trainer.py:410-418) keeps stepping with lr = 0, i.e. its parameters no longer move."""
 
-    def __init__(self, groups, num_bands: int):
+    def __init__(self, groups, num_bands: int, extra_slots: int = 0):
         self.num_bands = num_bands
         self.band_active = [True] * num_bands
-        super().__init__(groups)
+        super().__init__(groups, extra_slots=extra_slots)
         ng = len(self.param_groups)
         if ng * num_bands > 255:
             raise ValueError("too many (group, band) learning-rate segments")
@@ -317,7 +329,8 @@ class BandBankTrainer:
                   {'params': [bank.input_gains], 'lr': cfg.io_lr},
                   {'params': [bank.output_scalars_w], 'lr': cfg.io_lr},
                   {'params': [bank.feedback_loop_M], 'lr': cfg.lr}]
-        self.optimizer = BandFlatAdam(groups, self.num_bands)
+        # (3 loss slots per band ride the gradient bucket of a data-parallel job: EDR, EDC, colorless share)
+        self.optimizer = BandFlatAdam(groups, self.num_bands, extra_slots=3 * self.num_bands)
         bank.relink()                               # the leaves now live in the flat buffer
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=10, gamma=0.1)
         # one EDC window for all bands (trainer.py:56-59: T60max of the band's decay times)
@@ -334,7 +347,9 @@ class BandBankTrainer:
         self._allreduce = None
         if self.world_size > 1:
             opt, pg = self.optimizer, process_group
-            self._allreduce = lambda: dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=pg)
+            # ONE collective per step: gradients of all bands + the loss terms of all bands
+            self._allreduce = lambda: dist.all_reduce(opt.bucket, op=dist.ReduceOp.SUM, group=pg)
+        self.allreduce_in_graph = True      # capture the all-reduce inside the step's HIP graph (RCCL is capturable)
         self._side = self._side2 = None
         self._fused = FusedBankStep(self) if (self.use_fused and FusedBankStep.supported(self)) else None
         # leaves are first touched on one stream and receive gradients from the other by design (§5.1): the
@@ -343,6 +358,12 @@ class BandBankTrainer:
 
     def _decay_window(self, K: int):
         return self.criterion[1].window(K)
+
+    @property
+    def _reduced_step_losses(self) -> bool:
+        """True when a training step's reported decay losses are already the whole job's (the explicit step
+        all-reduces them in the gradient bucket)."""
+        return self._fused is not None and self.world_size > 1
 
     def _stream(self, which: str):
         if not self.concurrent_branches or which in getattr(self, '_disabled_streams', ()):
@@ -574,25 +595,35 @@ class BandBankTrainer:
         ntr = len(train_indices[0])
         if any(len(t) != ntr for t in train_indices) or len({len(v) for v in valid_indices}) != 1:
             raise ValueError("BandBankTrainer.train: the bands' splits must have equal sizes")
+        world, rank = self.world_size, self.rank
+        if B // world == 0:
+            raise ValueError("BandBankTrainer.train: the batch is smaller than the number of ranks")
         K = dataset.z_values.shape[-1]
         start, length = self._decay_window(K)
         dataset.precompute_decay_targets(self.stft_win, start, length)
-        step = self.graphed(dataset, B)
+        Bl = B // world                       # this rank's receivers per band of a full batch (global batch B)
+        step = self.graphed(dataset, Bl)
         self.train_loss = [[] for _ in range(nb)]
         self.valid_loss = [[] for _ in range(nb)]
         self.individual_train_loss, self.individual_valid_loss = [], []
         early = [0] * nb
+        # data-parallel: every rank must walk the SAME shuffled orders (it takes its share of every batch): one seed
+        # for all ranks, drawn once; a single process keeps the global generator, as the reference does
+        gen = None
+        if world > 1:
+            seed_t = torch.randint(0, 2 ** 62, (1,), dtype=torch.long).to(dataset.device)
+            dist.broadcast(seed_t, src=0, group=self.process_group)
+            gen = torch.Generator().manual_seed(int(seed_t.item()))
         st = time.time()
         if save_checkpoints:
             self.save_model(-1)
         for epoch in range(self.max_epochs):
             t0 = time.time()
-            orders = [[train_indices[q][i] for i in torch.randperm(ntr).tolist()] for q in range(nb)]
+            orders = [[train_indices[q][i] for i in torch.randperm(ntr, generator=gen).tolist()] for q in range(nb)]
             agg_t, nsteps = {}, 0
-            for i0 in range(0, ntr, B):
-                sel = [o[i0:i0 + B] for o in orders]
+            for sel in bank_shards(orders, B, rank, world):
                 rows = dataset.global_rows(sel)
-                if len(sel[0]) == B:
+                if len(sel[0]) == Bl:
                     cur = step(rows)                                  # replayed graph
                     cur = {k: v for k, v in cur.items() if not k.startswith('_')}
                 else:                                                 # ragged tail: host launches
@@ -603,14 +634,19 @@ class BandBankTrainer:
                     agg_t[k] = agg_t.get(k, 0.0) + v.detach()
                 nsteps += 1
             agg_v, nv = {}, 0
-            nval = len(valid_indices[0])
-            for i0 in range(0, nval, B):
-                rows = dataset.global_rows([v[i0:i0 + B] for v in valid_indices])
-                _, cur = self.valid_step(dataset.collate(rows))
+            for sel in bank_shards(valid_indices, B, rank, world):
+                _, cur = self.valid_step(dataset.collate(dataset.global_rows(sel)))
                 for k, v in cur.items():
                     agg_v[k] = agg_v.get(k, 0.0) + v.detach()
                 nv += 1
             self.scheduler.step()
+            if world > 1 and not self._reduced_step_losses:
+                # (per-step values are rank shares unless the step itself reduced them with the gradients)
+                from .trainer import reduce_epoch_losses
+                agg_t = reduce_epoch_losses(agg_t, self.process_group)
+            if world > 1:
+                from .trainer import reduce_epoch_losses
+                agg_v = reduce_epoch_losses(agg_v, self.process_group)
             tl = (sum(agg_t.values()) / max(nsteps, 1)).tolist()      # one sync per epoch
             vl = (sum(agg_v.values()) / max(nv, 1)).tolist() if agg_v else [0.0] * nb
             self.individual_train_loss.append({k: (v / max(nsteps, 1)).tolist() for k, v in agg_t.items()})

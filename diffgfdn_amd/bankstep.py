@@ -212,10 +212,16 @@ class FusedBankStep:
             keep.extend((grg, grec, gQQ, gMsub))
             main.wait_event(ev['mlpb'])
             tr.optimizer._packed = True               # the flat gradient buffer is complete
+            if allreduce is not None:
+                # data-parallel: this rank's loss terms ride the gradient bucket -- [EDR | EDC | colorless share] per
+                # band behind the gradients -- and ONE all-reduce sums both over the ranks
+                slots = tr.optimizer.extra.view(3, nb)
+                torch.stack((sums.reshape(nb, 3)[:, 1], sums.reshape(nb, 3)[:, 2], out3.reshape(nb, 3)[:, 0]),
+                            out=slots)
             if opt_step:
-                if allreduce is not None:
-                    allreduce()
-                tr.optimizer.step()
+                red = self.finish(allreduce)
+                if red is not None:
+                    sums, total = red
         if nb > 1:
             losses = {'edc_loss': sums[:, 2], 'edr_loss': sums[:, 1], 'spectral_loss': out3[:, 1],
                       'sparsity_loss': out3[:, 2], '_total': total}
@@ -227,6 +233,23 @@ class FusedBankStep:
                 main.wait_stream(s_)
         keep.clear()          # every consumer is ordered before the next step's first launch on each stream
         return losses
+
+
+    # -- the part of a data-parallel step behind the gradients ------------------------------------------------------
+    def finish(self, allreduce):
+        """[all-reduce of the bucket,] Adam.  Returns (sums, total) rebuilt from the reduced loss slots -- the whole
+        job's EDR / EDC terms and total per band -- or None for a single process."""
+        tr = self.tr
+        nb = tr.num_bands
+        red = None
+        if allreduce is not None:
+            allreduce()
+            slots = tr.optimizer.extra.view(3, nb)
+            total = slots.sum(dim=0)
+            sums = torch.stack((total, slots[0], slots[1]), dim=1)          # [total, w_edr edr, w_edc edc] per band
+            red = (sums, total) if nb > 1 else (sums[0], total[0])
+        tr.optimizer.step()
+        return red
 
 
 class _null:

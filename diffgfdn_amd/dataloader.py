@@ -206,10 +206,22 @@ def split_dataset(dataset, train_valid_split_ratio: float, test_ratio: Optional[
     return train, valid, test
 
 
+def rank_shard(chunk: Sequence[int], rank: int, world_size: int) -> List[int]:
+    """This rank's share of one (global) batch: EQUAL shares on every rank -- ``len(chunk) // world_size`` items,
+    rank r taking chunk[r::world_size] of the first ``world_size * share`` -- so that every rank runs the same
+    number of steps with the same collectives (a rank with an empty or a longer shard would leave the others
+    waiting in an all-reduce).  Up to ``world_size - 1`` items of a ragged tail are dropped; a chunk smaller than
+    the world gives [] on EVERY rank (the caller skips that step everywhere)."""
+    share = len(chunk) // world_size
+    return list(chunk[:share * world_size][rank::world_size]) if share > 0 else []
+
+
 class GridLoader:
     """Minimal DataLoader over index lists: shuffles with the global torch generator and yields
     collated batch dicts.  Optionally shards every batch over the ranks of a process group
-    (data-parallel over receiver positions)."""
+    (data-parallel over receiver positions): every rank then takes an EQUAL share of every batch
+    (``rank_shard``) and batches smaller than the world are skipped on all ranks alike -- the ranks must shuffle with
+    the same generator state (seed them identically), as they must for any data-parallel loader."""
 
     def __init__(self, dataset: MultiRIRDataset, indices: Sequence[int], batch_size: int,
                  shuffle: bool = True, drop_last: bool = False, rank: int = 0, world_size: int = 1,
@@ -222,21 +234,27 @@ class GridLoader:
         self.rank, self.world_size = rank, world_size
         self.lean = lean
 
+    def _bounds(self):
+        n, B = len(self.indices), self.batch_size
+        nb = n // B if self.drop_last else (n + B - 1) // B
+        out = [(i * B, min((i + 1) * B, n)) for i in range(nb)]
+        if self.world_size > 1:
+            out = [(a, b) for a, b in out if b - a >= self.world_size]
+        return out
+
     def __len__(self):
-        n = len(self.indices)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return len(self._bounds())
 
     def __iter__(self):
         order = self.indices
         if self.shuffle:
             perm = torch.randperm(len(order)).tolist()
             order = [order[i] for i in perm]
-        for i in range(len(self)):
-            chunk = order[i * self.batch_size:(i + 1) * self.batch_size]
+        for a, b in self._bounds():
+            chunk = order[a:b]
             if self.world_size > 1:
-                chunk = chunk[self.rank::self.world_size]
-            if chunk:
-                yield self.dataset.collate(chunk, lean=self.lean)
+                chunk = rank_shard(chunk, self.rank, self.world_size)
+            yield self.dataset.collate(chunk, lean=self.lean)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -20,7 +20,11 @@ from . import hip_ops as ops
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 extra_slots: int = 0):
+        """``extra_slots``: floats appended to the gradient buffer (``bucket`` = gradients + slots, ``extra`` = the
+        slots): a data-parallel trainer parks its per-rank loss terms there, so that ONE all-reduce of ``bucket``
+        carries the gradients and the loss scalars ("[all parameter grads | per-loss partial sums]")."""
         defaults = dict(lr=lr, betas=betas, eps=eps)
         super().__init__(params, defaults)
         self.param_groups = [g for g in self.param_groups if len(g['params']) > 0]
@@ -35,7 +39,9 @@ class FlatAdam(torch.optim.Optimizer):
                 raise TypeError("FlatAdam handles float32 parameters")
         n = sum(p.numel() for _, p in plist)
         self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.bucket = torch.zeros(n + int(extra_slots), dtype=torch.float32, device=dev)
+        self.flat_grad = self.bucket[:n]
+        self.extra = self.bucket[n:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -58,13 +58,37 @@ def render_band(net, batches, taps: torch.Tensor) -> torch.Tensor:
     return torch.cat(out, dim=0)
 
 
-def sum_bands(local_band_rirs: Sequence[torch.Tensor], group=None, dst: int = 0) -> Optional[torch.Tensor]:
+def sum_bands(local_band_rirs: Sequence[torch.Tensor], group=None, dst: int = 0, device=None) -> Optional[torch.Tensor]:
     """Sum of the filtered RIRs over ALL bands (reference :358 ``groupby('position').apply(sum)``):
     local sum over this rank's bands, then one reduce to ``dst``.  Returns the total on ``dst``,
-    None elsewhere.  Ranks without bands contribute zeros of the right shape (pass [] and rely on
-    ``like``-shaped broadcasting is not possible, so every rank must hold at least the shape)."""
-    total = torch.stack(list(local_band_rirs), dim=0).sum(dim=0)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(total, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        return total if dist.get_rank(group) == dst else None
-    return total
+    None elsewhere.  A rank WITHOUT bands (8 ranks, 7 bands) passes []: the shape, dtype of the result are agreed
+    on first (an all-reduce MAX of a 3-word header) and the rank contributes zeros; ``device`` is where it builds
+    them (default: the current CUDA device, or the CPU when there is none)."""
+    local = list(local_band_rirs)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        if not local:
+            raise ValueError("sum_bands: no bands")
+        return torch.stack(local, dim=0).sum(dim=0)
+    if local:
+        total = torch.stack(local, dim=0).sum(dim=0)
+        if total.dim() != 2:
+            raise ValueError("sum_bands: (receivers, samples) tensors expected")
+        device = total.device
+    else:
+        total = None
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    dtypes = [torch.float32, torch.float64]
+    head = torch.tensor([0, 0, 0] if total is None else [total.shape[0], total.shape[1], dtypes.index(total.dtype)],
+                        dtype=torch.int64, device=device)
+    dist.all_reduce(head, op=dist.ReduceOp.MAX, group=group)
+    shape, dtype = (int(head[0]), int(head[1])), dtypes[int(head[2])]
+    if total is None:
+        if shape[0] == 0:
+            raise ValueError("sum_bands: no rank holds a band")
+        total = torch.zeros(shape, dtype=dtype, device=device)
+    elif tuple(total.shape) != shape:
+        raise ValueError("sum_bands: the ranks' band responses differ in shape")
+    dist.reduce(total, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return total if dist.get_rank(group) == dst else None

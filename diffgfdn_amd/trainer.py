@@ -99,6 +99,30 @@ class FlatGradAllReduce:
             off += n
 
 
+def reduce_epoch_losses(agg: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+    """Per-epoch loss aggregates of a data-parallel job -> the values of the WHOLE job, identical on every rank
+    (one all-reduce of one small tensor): the decay terms are per-rank shares of the global loss (EDR: sum over the
+    rank's items, EDC: the rank's share of the global mean) and add up; the colorless terms are the same on every
+    rank and are averaged.  The early-stopping test (reference trainer.py:418-424) must run on these -- a decision
+    taken from rank-local values can differ between ranks, and the rank that leaves the epoch loop alone leaves the
+    others waiting in the next all-reduce."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not agg:
+        return agg
+    keys = sorted(agg)
+    world = dist.get_world_size(group)
+    vals = [torch.as_tensor(agg[k], dtype=torch.float32).reshape(-1) for k in keys]
+    sizes = [v.numel() for v in vals]
+    dev = next((v.device for v in vals if v.is_cuda), vals[0].device)
+    flat = torch.cat([v.to(dev) for v in vals])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, off = {}, 0
+    for k, v, n in zip(keys, vals, sizes):
+        t = flat[off:off + n].reshape(torch.as_tensor(agg[k]).shape)
+        out[k] = t if k in ('edr_loss', 'edc_loss') else t / world
+        off += n
+    return out
+
+
 class Trainer:
     """Parent class (reference trainer.py:26-332)."""
 
@@ -263,6 +287,9 @@ class Trainer:
             if isinstance(self.optimizer, FlatAdam):
                 self.optimizer.sync_lr()
             nt, nv = max(len(train_dataset), 1), max(len(valid_dataset), 1)
+            # data-parallel: the whole job's values, the same on every rank (the early-stop test below depends on it)
+            agg_t = reduce_epoch_losses(agg_t, self.process_group)
+            agg_v = reduce_epoch_losses(agg_v, self.process_group)
             agg_t = {k: float(v) / nt for k, v in agg_t.items()}     # one sync per epoch
             agg_v = {k: float(v) / nv for k, v in agg_v.items()}
             self.train_loss.append(sum(agg_t.values()))
@@ -754,18 +781,24 @@ class GraphedTrainStep:
             tr.optimizer.zero_grad(set_to_none=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph_a = torch.cuda.CUDAGraph()
         fused = getattr(tr, '_fused', None) is not None
-        if tr._allreduce is None:
+        in_graph = tr._allreduce is not None and getattr(tr, 'allreduce_in_graph', False) and \
+            self._collective_is_capturable()
+        self.allreduce_in_graph = in_graph
+        self.graph_a = torch.cuda.CUDAGraph()
+        if tr._allreduce is None or in_graph:
+            # ONE graph: forward, backward, [all-reduce of the gradient bucket (RCCL is capturable),] Adam
             with torch.cuda.graph(self.graph_a):
                 if fused:
                     self.losses = self._fused_fwd_bwd(opt_step=True)
                 else:
                     self.losses = self._fwd_bwd()
                     tr.optimizer.pack_grads()
+                    if tr._allreduce is not None:
+                        tr._allreduce()
                     tr.optimizer.step()
         else:
-            # forward + backward + pack | all-reduce of the flat gradient buffer (eager RCCL) | Adam
+            # forward + backward + pack | all-reduce of the gradient bucket (eager RCCL) | Adam
             with torch.cuda.graph(self.graph_a):
                 if fused:
                     self.losses = self._fused_fwd_bwd(opt_step=False)
@@ -774,7 +807,11 @@ class GraphedTrainStep:
                     tr.optimizer.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-                tr.optimizer.step()
+                if fused:
+                    red = tr._fused.finish(lambda: None)          # (the collective itself runs between the replays)
+                    self._apply_reduced(red)
+                else:
+                    tr.optimizer.step()
         self.losses = {k: v for k, v in self.losses.items()}
         # the recorded launches hold raw pointers into the frequency grids (turns / log radius): keep
         # the grid objects alive as long as the graphs (the by-pointer cache may drop them)
@@ -782,6 +819,43 @@ class GraphedTrainStep:
         self._grids = list(FrequencyGrid._cache.values())
         torch.set_rng_state(rng_state)
         return self
+
+    def _apply_reduced(self, red):
+        """Split-graph data-parallel step: the second graph rebuilt the decay losses from the reduced slots."""
+        if red is None:
+            return
+        sums, total = red
+        nb = self.num_bands
+        self.losses = dict(self.losses)
+        self.losses['edr_loss'] = sums[:, 1] if nb > 1 else sums[1]
+        self.losses['edc_loss'] = sums[:, 2] if nb > 1 else sums[2]
+        self.losses['_total'] = total
+
+    def _collective_is_capturable(self) -> bool:
+        """Probe: capture the trainer's collective on a scratch tensor in a throw-away graph and replay it.  Any
+        error -> the step falls back to two graphs with the collective between them (the same result)."""
+        tr = self.tr
+        pg = getattr(tr, 'process_group', None)
+        if not dist.is_initialized() or dist.get_backend(pg) != 'nccl':
+            return False               # (gloo rehearsals: host-side collectives cannot be captured)
+        try:
+            probe = torch.ones(64, dtype=torch.float32, device=self.idx.device)
+            dist.all_reduce(probe, group=pg)                     # communicator set up outside the capture
+            torch.cuda.synchronize()
+            probe.fill_(1.0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                dist.all_reduce(probe, group=pg)
+            g.replay()
+            torch.cuda.synchronize()
+            ok = bool((probe == float(dist.get_world_size(pg))).all().item())
+            del g
+            return ok
+        except Exception as e:                                   # noqa: BLE001 -- any failure means "do not capture"
+            if getattr(tr, 'rank', 0) == 0:
+                print(f"[diffgfdn_amd] all-reduce not capturable here ({type(e).__name__}: {e}); two-graph step")
+            torch.cuda.synchronize()
+            return False
 
     def _load_inputs(self, indices):
         tr = self.tr

@@ -150,3 +150,105 @@ def test_band_parallel_assignment_and_sum():
     expect = sum(torch.full((3, 8), float(f)) + torch.arange(8.0) for f in freqs)
     assert torch.equal(ret["total"], expect)
     assert ret["mine"] == freqs[0::2]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# equal step counts on every rank (ragged tails), epoch aggregates, bandless ranks, the bank's bucket / mask code
+# ---------------------------------------------------------------------------------------------------------------
+def test_rank_shards_are_equal_and_cover_full_batches():
+    from diffgfdn_amd.bandbank import bank_shards
+    from diffgfdn_amd.dataloader import GridLoader, rank_shard
+    for world in (2, 3, 8):
+        for n in range(0, 40):
+            chunk = list(range(100, 100 + n))
+            shares = [rank_shard(chunk, r, world) for r in range(world)]
+            assert len({len(s) for s in shares}) == 1                       # the same size on every rank
+            flat = sorted(i for s in shares for i in s)
+            assert flat == chunk[:(n // world) * world]                     # disjoint, only the ragged rest dropped
+    # loader: tails smaller than the world are skipped on ALL ranks; every rank yields the same number of batches
+
+    class _DS:
+        def collate(self, idx, lean=False):
+            return list(idx)
+
+    for world in (2, 8):
+        for n in (64, 65, 66, 67, 71, 72, 3):
+            per_rank = [list(GridLoader(_DS(), list(range(n)), batch_size=32, shuffle=False, rank=r, world_size=world))
+                        for r in range(world)]
+            assert len({len(b) for b in per_rank}) == 1, (world, n)
+            assert all(len(b) == len(GridLoader(_DS(), list(range(n)), 32, False, rank=0, world_size=world))
+                       for b in per_rank)
+            for step in zip(*per_rank):
+                assert len({len(s) for s in step}) == 1 and len(step[0]) > 0
+    # bank: per band the same receivers as the single-process batch, split over the ranks
+    orders = [list(range(10, 48)), list(range(60, 98))]                     # 38 receivers per band, batch 16
+    for world in (1, 2, 4):
+        steps = [list(bank_shards(orders, 16, r, world)) for r in range(world)]
+        assert len({len(s) for s in steps}) == 1
+        for i, per_rank in enumerate(zip(*steps)):
+            for q in range(2):
+                got = sorted(x for sel in per_rank for x in sel[q])
+                full = orders[q][16 * i:16 * (i + 1)]
+                assert got == full[:(len(full) // world) * world]
+
+
+def _epoch_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from diffgfdn_amd.bandbank import BandBankTrainer
+    from diffgfdn_amd.bankstep import FusedBankStep
+    from diffgfdn_amd.losses import edc_loss
+    from diffgfdn_amd.subband import band_assignment, sum_bands
+    from diffgfdn_amd.trainer import reduce_epoch_losses
+    # (1) epoch aggregates: decay terms add up over the ranks, colorless terms are the same everywhere
+    agg = {"edr_loss": torch.tensor([1.0 + rank, 2.0]), "edc_loss": torch.tensor([0.5, 0.25 * (rank + 1)]),
+           "spectral_loss": torch.tensor([3.0, 4.0]), "sparsity_loss": torch.tensor([0.1, 0.2])}
+    red = reduce_epoch_losses(agg)
+    # (2) 8 bands-less-one style: rank 1 holds no band here
+    freqs = [63, 125, 250]
+    mine = band_assignment(freqs, world)[rank] if rank == 0 else []
+    mine = freqs if rank == 0 else []
+    total = sum_bands([torch.full((3, 8), float(f)) for f in mine], device=torch.device("cpu"))
+    # (3) the bank trainer's mask / weighting code on a stand-in trainer: same mask on every rank, 1 / (B_global count)
+    fake = SimpleNamespace(criterion=[None, edc_loss(1500.0, 8000.0, use_mask=True)], world_size=world,
+                           process_group=None)
+    torch.manual_seed(100 + rank)                                             # ranks draw DIFFERENT masks ...
+    maskw, inv = BandBankTrainer._draw_edc_mask(fake, 640, 4, torch.device("cpu"))
+    # (4) the explicit step's bucket: loss slots behind the gradients, one all-reduce, totals rebuilt from the slots
+    nb, n = 2, 5
+    bucket = torch.zeros(n + 3 * nb)
+    bucket[:n] = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    bucket[n:].view(3, nb).copy_(torch.tensor([[1.0, 2.0], [10.0, 20.0], [0.5, 0.25]]) * (rank + 1))
+    stepped = []
+    opt = SimpleNamespace(bucket=bucket, extra=bucket[n:], flat_grad=bucket[:n], step=lambda: stepped.append(1))
+    tr = SimpleNamespace(num_bands=nb, optimizer=opt)
+    sums, tot = FusedBankStep.finish(SimpleNamespace(tr=tr), lambda: dist.all_reduce(opt.bucket))
+    ret[rank] = {"red": {k: v.clone() for k, v in red.items()}, "total": total, "mask": maskw.clone(), "inv": inv,
+                 "grad": bucket[:n].clone(), "sums": sums.clone(), "tot": tot.clone(), "stepped": len(stepped)}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_epoch_reduction_bandless_rank_mask_and_bucket():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_epoch_worker, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    for k in r0["red"]:
+        assert torch.equal(r0["red"][k], r1["red"][k]), k                  # identical on every rank
+    assert torch.equal(r0["red"]["edr_loss"], torch.tensor([3.0, 4.0]))      # (1 + 2, 2 + 2)
+    assert torch.equal(r0["red"]["edc_loss"], torch.tensor([1.0, 0.75]))
+    assert torch.equal(r0["red"]["spectral_loss"], torch.tensor([3.0, 4.0]))
+    assert torch.allclose(r0["red"]["sparsity_loss"], torch.tensor([0.1, 0.2]))
+    assert torch.equal(r0["total"], torch.full((3, 8), 63.0 + 125.0 + 250.0)) and r1["total"] is None
+    assert torch.equal(r0["mask"], r1["mask"])                               # rank 0's draw wins
+    count = float(r0["mask"].sum())
+    assert r0["inv"] == r1["inv"] == 1.0 / (4 * world * count)
+    assert torch.equal(r0["grad"], torch.arange(5, dtype=torch.float32) * 3) and torch.equal(r0["grad"], r1["grad"])
+    assert torch.equal(r0["sums"][:, 1], torch.tensor([3.0, 6.0])) and torch.equal(r0["sums"][:, 2], torch.tensor([30.0, 60.0]))
+    assert torch.equal(r0["tot"], torch.tensor([3.0 + 30.0 + 1.5, 6.0 + 60.0 + 0.75]))
+    assert r0["stepped"] == r1["stepped"] == 1

@@ -392,6 +392,49 @@ def test_bank_split_graph_path_for_data_parallel():
             assert torch.equal(v, out["split_identity"][1][q][k]), (q, k)
 
 
+def test_bank_allreduce_captured_inside_the_graph():
+    """Data-parallel step as ONE graph: the all-reduce of the gradient bucket (gradients + loss slots) is captured
+    with the kernels.  A one-rank RCCL group makes the collective the identity: results must equal the plain
+    single-process graph bit for bit, the reported losses must come back from the reduced slots."""
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        out = {}
+        sel = [[[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]], [[1, 2, 4, 6], [0, 5, 7, 9], [3, 8, 10, 11]]]
+        for mode in ("single", "in_graph", "split"):
+            nets, data, filt, bank, tr, sds, _ = _bank_setup()
+            if mode != "single":
+                opt = tr.optimizer
+                tr._allreduce = lambda opt=opt: dist.all_reduce(opt.bucket)
+                tr.allreduce_in_graph = mode == "in_graph"
+            step = tr.graphed(sds, 4, mask_seed=5).capture(sds.global_rows(sel[0]))
+            if mode == "in_graph":
+                assert step.allreduce_in_graph and step.graph_b is None
+            if mode == "split":
+                assert step.graph_b is not None
+            vals = []
+            for s in sel:
+                r = step(sds.global_rows(s))
+                vals.append({k: v.detach().cpu().numpy().copy() for k, v in r.items()})
+            out[mode] = (vals, [{k: v.detach().cpu().clone() for k, v in n.state_dict().items()} for n in nets])
+        for mode in ("in_graph", "split"):
+            for a, b in zip(out["single"][0], out[mode][0]):
+                for k in a:
+                    assert np.allclose(a[k], b[k], rtol=1e-6, atol=0), (mode, k)      # (total: a different order of adds)
+            for q in range(len(BANDS)):
+                for k, v in out["single"][1][q].items():
+                    assert torch.equal(v, out[mode][1][q][k]), (mode, q, k)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_irfft_slot_order_equals_natural_order():
     """n = 65 537: the slot-ordered entry points (no gather / scatter on the spectrum side) against the natural
     ones on the permuted data; the order itself against 3^s mod n."""
