@@ -198,6 +198,9 @@ class BandStackedDataset:
         return self.R
 
     def precompute_decay_targets(self, win: int, edc_start: int, edc_len: int, chunk: int = 64):
+        if (self.edr_store is not None and self.edc_store is not None and self.edr_store[0] == win
+                and self.edc_store[0] == (edc_start, edc_len)):
+            return                      # the stacked stores already hold these targets
         edr_T, edr_s, edc_T = [], [], []
         for d in self.datasets:
             if (d.edr_store is None or d.edc_store is None or d.edr_store[0] != win
@@ -606,6 +609,7 @@ class BandBankTrainer:
         self.train_loss = [[] for _ in range(nb)]
         self.valid_loss = [[] for _ in range(nb)]
         self.individual_train_loss, self.individual_valid_loss = [], []
+        self.epoch_times = []
         early = [0] * nb
         # data-parallel: every rank must walk the SAME shuffled orders (it takes its share of every batch): one seed
         # for all ranks, drawn once; a single process keeps the global generator, as the reference does
@@ -663,6 +667,7 @@ class BandBankTrainer:
             self.optimizer.sync_lr()
             if save_checkpoints:
                 self.save_model(epoch)
+            self.epoch_times.append(time.time() - t0)
             if log and self.rank == 0:
                 print(f"epoch {epoch}: " + " ".join(f"[{self.band_names[q]}] {tl[q]:.3f}/{vl[q]:.3f}"
                                                     for q in range(nb)) + f" ({time.time() - t0:.2f} s)")
