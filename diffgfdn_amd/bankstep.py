@@ -53,6 +53,110 @@ class FusedBankStep:
         self._zero_loss = torch.zeros(nblk, dtype=torch.float32, device=dev)
         self._keep = []
 
+    # 2: the loss middle as two half-batch chains on two streams.  Measured on the 7-band step: 0.692 vs 0.705 ms
+    # (-2 %) for 13 more launches -- the chains run in phase, each kind of unit stays contended -- so it is off.
+    halves = 1
+
+    # ------------------------------------------------------------------------------------------
+    def _decay_middle(self, H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc, start, length, ev, main,
+                      side2):
+        """One chain over the whole batch: main: irfft -> STFT -> EDR -> STFT adjoint (even frames, then odd frames +
+        EDC gradient) -> irfft adjoint; side2: EDC scans.  Records ev['x'] / ev['edc'] / ev['g']."""
+        tr, cfg, keep = self.tr, self.tr.config, self._keep
+        Btot, win = H.shape[0], tr.stft_win
+        on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
+        if pairs:
+            x = ops.irfft_odd_fwd(H, K, slots=True, pairs=True)
+        else:
+            x = ops.irfft_odd_fwd(H, K, slots=order is not None)
+        ev['x'].record()
+        if pairs:
+            P = ops.stft_power_pairs(x, Btot, win)
+            g_edr = None
+        else:
+            g_edr = torch.empty_like(x) if train else None
+            P = ops.stft_power(x, win, zero_buf=g_edr)
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['x'])
+            if pairs:
+                li_edc, g_edc = ops.edc_loss_pairs(x, Btot, start, length, T_edc, maskw, inv, cfg.edc_loss_weight,
+                                                   train, rows=rows)
+            else:
+                li_edc, g_edc = ops.edc_loss(x, start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train,
+                                             rows=rows)
+            ev['edc'].record()
+        li_edr = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rows, defer=True)
+        keep.extend((x, P, g_edr, li_edc, g_edc, li_edr))
+        gH = None
+        if train:
+            if pairs:
+                # even frames first, alone; the EDC gradient joins with the odd frames (the EDC scans are the
+                # longer of the two branches: the main stream would otherwise sit idle until they finish)
+                g = ops.stft_power_pairs_bwd(x, Btot, win, P, phase=0)
+                main.wait_event(ev['edc'])
+                ops.stft_power_pairs_bwd(x, Btot, win, P, base=g_edc, out=g, phase=1)
+                ev['g'].record()
+                gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
+                keep.append(g)
+            else:
+                g_edr = ops.stft_power_bwd(x, win, P, g_edr)
+                main.wait_event(ev['edc'])
+                ev['g'].record()
+                gH = ops.irfft_odd_bwd(g_edc, K, H.shape[1], g_edr, slots=order is not None)
+            keep.append(gH)
+        else:
+            main.wait_event(ev['edc'])
+            ev['g'].record()
+        return li_edr, li_edc, gH
+
+    def _decay_middle_halves(self, H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start, length, ev, main, side,
+                             side2):
+        """The same kernels on two halves of the batch as two independent chains (first half on the main stream, second
+        on ``side``): every stage of the middle is either memory-bound (transform passes, EDR columns, EDC scans) or
+        VALU-bound (the 4096-point FFTs of the STFT and its adjoint), and two chains out of step fill one kind of unit
+        with the other chain's other kind of work.  Items are independent through the whole middle (pairs do not
+        straddle the halves): the numbers are those of the single chain."""
+        tr, cfg, keep = self.tr, self.tr.config, self._keep
+        Btot, win = H.shape[0], tr.stft_win
+        h = Btot // 2
+        ldx = H.shape[1]
+        li_edr = torch.empty((Btot, ops.edr_partial_cols(Btot, win // 2 + 1)), dtype=torch.float32, device=H.device)
+        li_edc = torch.empty(Btot, dtype=torch.float32, device=H.device)
+        gH = torch.empty((Btot, ldx), dtype=torch.complex64, device=H.device) if train else None
+        ev_h, ev_b = ev['h'], torch.cuda.Event()          # (ev['h']: H complete)
+
+        def chain(lo):
+            Hh, rw = H[lo:lo + h], rows[lo:lo + h].contiguous()
+            x = ops.irfft_odd_fwd(Hh, K, slots=True, pairs=True)
+            P = ops.stft_power_pairs(x, h, win)
+            le = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rw, defer=True,
+                              out=li_edr[lo:lo + h])
+            lc, g_edc = ops.edc_loss_pairs(x, h, start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train, rows=rw,
+                                           out=li_edc[lo:lo + h])
+            keep.extend((x, P, le, lc, g_edc, rw))
+            if train:
+                g = ops.stft_power_pairs_bwd(x, h, win, P, base=g_edc, out=g_edc)
+                ops.irfft_odd_pairs_bwd(g, K, h, out=gH[lo:lo + h])
+
+        # (first half captured first: it keeps the main chain's hardware queue; the mask is drawn on side2 at the head
+        # of the step, both chains read it)
+        main.wait_event(ev['mask'])
+        chain(0)
+        if self.halves == 3:             # (debug: both chains on the main stream)
+            chain(h)
+        else:
+            with torch.cuda.stream(side):
+                torch.cuda.current_stream().wait_event(ev_h)
+                torch.cuda.current_stream().wait_event(ev['mask'])
+                chain(h)
+                ev_b.record()
+            main.wait_event(ev_b)
+        ev['x'].record()
+        ev['edc'].record()
+        ev['g'].record()
+        keep.extend((li_edr, li_edc, gH))
+        return li_edr, li_edc, gH
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, data: Dict, maskw: Optional[torch.Tensor], inv: float, normalize_first: bool, train: bool,
@@ -102,7 +206,7 @@ class FusedBankStep:
         T_edr, sum_abs, T_edc = edr_t[1], edr_t[2], edc_t[1]
         win = tr.stft_win
         pairs = order is not None and tr.use_pairs and win == 4096
-        ev = {k: torch.cuda.Event() for k in ('start', 'g', 'mlp', 'norm', 'x', 'edc', 'side', 'grg',
+        ev = {k: torch.cuda.Event() for k in ('start', 'g', 'h', 'mlp', 'mask', 'norm', 'x', 'edc', 'side', 'grg',
                                               'mlpb')}
 
         # ---- head.  main: records of the raw blocks -> energy pass -> finish (normalize, trainer.py:317-332);
@@ -126,6 +230,7 @@ class FusedBankStep:
             # directions -- hipStreamEndCapture of ROCm 7.2 segfaults on that topology.)
             if mask_draw is not None:
                 mask_draw()
+            ev['mask'].record()
         scale = ework = None
         if normalize_first:
             _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
@@ -136,66 +241,33 @@ class FusedBankStep:
                                    save_T=True)
         keep.extend((coef_sub, ework, Q, QQ, coef, rgain, xhat, rstd, scale, H, Ts))
 
-        # ---- irfft (slot order / pair-interleaved when the length allows it), then the colorless branch on `side`
-        if pairs:
-            x = ops.irfft_odd_fwd(H, K, slots=True, pairs=True)
+        # ---- decay losses: irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint, EDC scans beside them
+        ev['h'].record()
+        want_halves = self.halves >= 2 and pairs and Btot % 4 == 0 and side is not None
+        if want_halves:
+            li_edr, li_edc, gH = self._decay_middle_halves(H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start,
+                                                           length, ev, main, side, side2)
         else:
-            x = ops.irfft_odd_fwd(H, K, slots=order is not None)
-        ev['x'].record()
-        keep.append(x)
-
-        # ---- decay losses.  main: STFT -> EDR; side2: EDC scans
-        if pairs:
-            P = ops.stft_power_pairs(x, Btot, win)
-            g_edr = None
-        else:
-            g_edr = torch.empty_like(x) if train else None
-            P = ops.stft_power(x, win, zero_buf=g_edr)
-        with on_side2():
-            torch.cuda.current_stream().wait_event(ev['x'])
-            if pairs:
-                li_edc, g_edc = ops.edc_loss_pairs(x, Btot, start, length, T_edc, maskw, inv, cfg.edc_loss_weight,
-                                                   train, rows=rows)
-            else:
-                li_edc, g_edc = ops.edc_loss(x, start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train,
-                                             rows=rows)
-            ev['edc'].record()
-        li_edr = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rows, defer=True)
-        keep.extend((P, g_edr, li_edc, g_edc, li_edr))
-        gH = None
-        if train:
-            if pairs:
-                # even frames first, alone; the EDC gradient joins with the odd frames (the EDC scans are the
-                # longer of the two branches: the main stream would otherwise sit idle until they finish)
-                g = ops.stft_power_pairs_bwd(x, Btot, win, P, phase=0)
-                main.wait_event(ev['edc'])
-                ops.stft_power_pairs_bwd(x, Btot, win, P, base=g_edc, out=g, phase=1)
-                ev['g'].record()
-                gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
-                keep.append(g)
-            else:
-                g_edr = ops.stft_power_bwd(x, win, P, g_edr)
-                main.wait_event(ev['edc'])
-                ev['g'].record()
-                gH = ops.irfft_odd_bwd(g_edc, K, H.shape[1], g_edr, slots=order is not None)
-            keep.append(gH)
-        else:
-            main.wait_event(ev['edc'])
-            ev['g'].record()
+            li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
+                                                    start, length, ev, main, side2)
         # the colorless pass rides the EDC stream behind the scans (a third stream would share a hardware queue with
         # this one anyway, and the graph then runs it last: measured)
         with on_side2():
+            if want_halves:        # (no EDC scans in front of it on this stream: H complete = gains rescaled, scale set)
+                torch.cuda.current_stream().wait_event(ev['h'])
             grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
                                                 cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
                                                 dturn=gridK.dturn)
             out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
                                            inv_world, want_grad=train, nbands=nb)
             ev['side'].record()
-            # the reported sums and total (off the gradient path) behind it: their inputs are complete once the
-            # transform adjoint may start, and no other stream is involved
-            sums = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
-            total = (sums[:, 0] + out3[:, 0]) if nb > 1 else (sums[0] + out3[0])
-        keep.extend((grec_sub, loss_g, out3, gQ, sums, total))
+        keep.extend((grec_sub, loss_g, out3, gQ))
+
+        def report():
+            """the reported sums and total (off the gradient path)"""
+            s_ = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
+            return s_, ((s_[:, 0] + out3[:, 0]) if nb > 1 else (s_[0] + out3[0]))
+
         if train:
             # ---- backward of the output stage: gains pass -> (side2: gain network backward) | records pass
             grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
@@ -203,6 +275,7 @@ class FusedBankStep:
             grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb)
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['grg'])
+                sums, total = report()            # (behind a fork the step has anyway: the EDR terms come from main)
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
                 ev['mlpb'].record()
@@ -222,6 +295,11 @@ class FusedBankStep:
                 red = self.finish(allreduce)
                 if red is not None:
                     sums, total = red
+        else:
+            with on_side2():
+                torch.cuda.current_stream().wait_event(ev['g'])
+                sums, total = report()
+        keep.extend((sums, total))
         if nb > 1:
             losses = {'edc_loss': sums[:, 2], 'edr_loss': sums[:, 1], 'spectral_loss': out3[:, 1],
                       'sparsity_loss': out3[:, 2], '_total': total}

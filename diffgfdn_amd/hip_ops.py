@@ -782,9 +782,9 @@ def irfft_odd_fwd(X, n: int, slots: bool = False, pairs: bool = False) -> torch.
     return x
 
 
-def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None) -> torch.Tensor:
+def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None) -> torch.Tensor:
     """Adjoint of irfft_odd_fwd(slots=True, pairs=True): g2 (ceil(batch / 2), n, 2) f32 pair-interleaved gradients
-    [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order."""
+    [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order (``out``: where to write it)."""
     _need_gpu(g2)
     npairs = (batch + 1) // 2
     for t in (g2, g2b):
@@ -793,7 +793,9 @@ def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None) -> torch.Tensor:
     lib = _lib.load()
     table = bluestein_table(n, g2.device)
     ldx = (n + 1) // 2
-    gX = torch.empty((batch, ldx), dtype=_c64, device=g2.device)
+    if out is not None and (out.dtype != _c64 or not out.is_contiguous() or tuple(out.shape) != (batch, ldx)):
+        raise RuntimeError("irfft_odd_pairs_bwd: out must be a contiguous complex64 (batch, (n + 1) / 2) tensor")
+    gX = torch.empty((batch, ldx), dtype=_c64, device=g2.device) if out is None else out
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), g2.device)
     if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
         _staged_bluestein(lib, table, n, g2, g2b, n, batch, gX, ldx, work, 1, 2)
@@ -975,7 +977,7 @@ def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None, phas
 
 
 def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
-                   gscale: float = 1.0, want_grad: bool = True, rows=None):
+                   gscale: float = 1.0, want_grad: bool = True, rows=None, out=None):
     """edc_loss on pair-interleaved signals x2 (ceil(items / 2), T, 2) -> loss_item (items,), g2 like x2 or None."""
     _need_gpu(x2, T_db)
     T = x2.shape[1]
@@ -984,7 +986,9 @@ def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, in
             or (rows is None and T_db.shape[0] != items):
         raise RuntimeError("edc_loss_pairs: target shape does not match the window")
     maskw = None if maskw is None else _f(maskw)
-    loss_item = torch.empty(items, dtype=_f32, device=x2.device)
+    if out is not None and (out.dtype != _f32 or not out.is_contiguous() or out.numel() != items):
+        raise RuntimeError("edc_loss_pairs: out must be a contiguous float32 vector with one entry per item")
+    loss_item = torch.empty(items, dtype=_f32, device=x2.device) if out is None else out
     g2 = torch.empty_like(x2) if want_grad else None      # (the kernel writes zeros for a missing partner)
     lib = _lib.load()
     work = _work(lib.gfdn_edc_work_bytes(items + 1), x2.device)
@@ -992,6 +996,11 @@ def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, in
                                        float(inv_count), float(gscale), _p(loss_item), _p(g2), _p(work),
                                        _stream()), "gfdn_edc_loss_pairs")
     return loss_item, g2
+
+
+def edr_partial_cols(batch: int, nfreq: int) -> int:
+    """Columns of the deferred partial sums of edr_loss(defer=True)."""
+    return _lib.load().gfdn_edr_work_bytes(int(batch), int(nfreq)) // (4 * int(batch))
 
 
 def edr_target(P: torch.Tensor):
@@ -1008,7 +1017,7 @@ def edr_target(P: torch.Tensor):
 
 
 def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = True, rows=None,
-             defer: bool = False):
+             defer: bool = False, out=None):
     """In place on P (achieved |STFT|^2): returns loss_item (batch,); P becomes dloss/dP.
     ``rows``: item b compares against row rows[b] of the (all-receiver) target store.
     ``defer``: return the (batch, tiles) partial sums instead (not yet divided by sum_abs), to be
@@ -1023,8 +1032,10 @@ def edr_loss(P, T_db, sum_abs, wf=None, gscale: float = 1.0, want_grad: bool = T
     lib = _lib.load()
     wf = None if wf is None else _f(wf)
     if defer:
-        part = torch.empty((batch, lib.gfdn_edr_work_bytes(batch, nfreq) // (4 * batch)), dtype=_f32,
-                           device=P.device)
+        cols = lib.gfdn_edr_work_bytes(batch, nfreq) // (4 * batch)
+        if out is not None and (out.dtype != _f32 or not out.is_contiguous() or tuple(out.shape) != (batch, cols)):
+            raise RuntimeError("edr_loss(defer=True): out must be a contiguous float32 (batch, partial columns) tensor")
+        part = torch.empty((batch, cols), dtype=_f32, device=P.device) if out is None else out
         _lib.check(lib.gfdn_edr_loss(_p(P), _p(T_db), _p(sum_abs), _p(rows), _p(wf), batch, nframes, nfreq,
                                      float(gscale), int(want_grad), None, _p(part), _stream()),
                    "gfdn_edr_loss")
