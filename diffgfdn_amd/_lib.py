@@ -59,6 +59,7 @@ SIGNATURES = {
     "gfdn_spectral_stats_binmajor": (c_int, [_P, c_int, c_int, _P, c_int, c_float, _P, _P, _P, _P]),
     "gfdn_subfdn_colorless_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_tf_coefs_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    "gfdn_tf_coefs_fwd2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gfdn_tf_coefs_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_parts": (c_int, [c_int, c_int]),
     "gfdn_tf_work_bytes": (c_size_t, [c_int]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "gfdn_tf_gain_grad_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfdn_tf_gain_grad": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gfdn_exp_contract_mfma": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),
     "gfdn_normalize_io": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "gfdn_bluestein_table_bytes": (c_size_t, [c_int]),

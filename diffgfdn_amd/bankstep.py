@@ -218,8 +218,7 @@ class FusedBankStep:
         # depth-first walk of the nodes in capture order, and the chain captured first keeps its queue through every
         # later join -- a chain that changes queue pays ~10 us per change)
         Q, QQ = ops.ortho_fwd(M, True, True)
-        coef = ops.tf_coefs(QQ, b, c, ig)
-        coef_sub = ops.tf_coefs(M, b, c, None)
+        coef, coef_sub = ops.tf_coefs2(QQ, ig, M, None, b, c)
         with on_side2():
             torch.cuda.current_stream().wait_event(ev['start'])
             rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G,

@@ -148,11 +148,18 @@ __device__ __forceinline__ void tf_stage_block(const float* __restrict__ A, cons
   if (tid < 4) sig[tid] = (tid < n && ig) ? (double)ig[blk * n + tid] : 1.0;
 }
 
-__global__ __launch_bounds__(64) void k_tf_coefs(const float* __restrict__ A, const float* __restrict__ b,
-                                                 const float* __restrict__ c, const float* __restrict__ ig,
-                                                 int n, float* __restrict__ coef) {
+// blocks [0, nblk): set 0 (A0, ig0 -> coef0); blocks [nblk, 2 nblk): set 1 (A1, ig1 -> coef1), same b, c
+__global__ __launch_bounds__(64) void k_tf_coefs(const float* __restrict__ A0, const float* __restrict__ ig0,
+                                                 float* __restrict__ coef0, const float* __restrict__ A1,
+                                                 const float* __restrict__ ig1, float* __restrict__ coef1,
+                                                 const float* __restrict__ b, const float* __restrict__ c,
+                                                 int nblk, int n) {
   __shared__ double sA[2][16], sq[2][16], sig[4];
-  const int blk = blockIdx.x, tid = threadIdx.x;
+  const bool second = (int)blockIdx.x >= nblk;
+  const int blk = second ? blockIdx.x - nblk : blockIdx.x, tid = threadIdx.x;
+  const float* A = second ? A1 : A0;
+  const float* ig = second ? ig1 : ig0;
+  float* coef = second ? coef1 : coef0;
   tf_stage_block(A, b, c, ig, blk, n, tid, sA, sig);
   __syncthreads();
   if (tid < 32) {
@@ -181,7 +188,20 @@ extern "C" int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c,
                                  int nblk, int nper, float* coef, void* stream) {
   if (!A || !b || !c || !coef || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4) return GFDN_E_UNSUPPORTED;
-  hipLaunchKernelGGL(k_tf_coefs, dim3(nblk), dim3(64), 0, (hipStream_t)stream, A, b, c, inv_gamma, nper, coef);
+  hipLaunchKernelGGL(k_tf_coefs, dim3(nblk), dim3(64), 0, (hipStream_t)stream, A, inv_gamma, coef, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr, b, c, nblk, nper);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// two record sets sharing b, c in ONE launch (the damped loop's Q Q with 1 / gamma and the sub-FDNs' raw M)
+extern "C" int gfdn_tf_coefs_fwd2(const float* A0, const float* inv_gamma0, float* coef0, const float* A1,
+                                  const float* inv_gamma1, float* coef1, const float* b, const float* c, int nblk,
+                                  int nper, void* stream) {
+  if (!A0 || !A1 || !b || !c || !coef0 || !coef1 || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 4) return GFDN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tf_coefs, dim3(2 * nblk), dim3(64), 0, (hipStream_t)stream, A0, inv_gamma0, coef0, A1, inv_gamma1,
+                     coef1, b, c, nblk, nper);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -534,6 +534,22 @@ def tf_coefs(A, b, c, inv_gamma=None, out=None) -> torch.Tensor:
     return coef
 
 
+def tf_coefs2(A0, ig0, A1, ig1, b, c):
+    """Records of two sets of blocks sharing b, c in one launch -> (coef0, coef1), each (nblk, 32)."""
+    _need_gpu(A0, A1, b, c)
+    A0, A1, b, c = _f(A0), _f(A1), _f(b).reshape(-1), _f(c).reshape(-1)
+    nblk, n, _ = A0.shape
+    if n > 4 or A1.shape != A0.shape or b.numel() != nblk * n or c.numel() != nblk * n:
+        raise RuntimeError("tf_coefs2: two sets of nblk blocks of at most 4 lines, b, c of nblk * n gains")
+    ig0 = None if ig0 is None else _f(ig0).reshape(-1)
+    ig1 = None if ig1 is None else _f(ig1).reshape(-1)
+    c0 = torch.empty((nblk, 32), dtype=_f32, device=A0.device)
+    c1 = torch.empty((nblk, 32), dtype=_f32, device=A0.device)
+    _lib.check(_lib.load().gfdn_tf_coefs_fwd2(_p(A0), _p(ig0), _p(c0), _p(A1), _p(ig1), _p(c1), _p(b), _p(c), nblk, n,
+                                              _stream()), "gfdn_tf_coefs_fwd2")
+    return c0, c1
+
+
 def tf_parts(K: int, nblk: int) -> int:
     n = _lib.load().gfdn_tf_parts(int(K), int(nblk))
     if n <= 0:

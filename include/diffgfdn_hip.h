@@ -274,7 +274,8 @@ int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr, int K, in
  * coef (nblk, 32) float32 = [P_S (16) | Q_S (16)], S a bit mask (bit i = line i of the block).  The delay-line
  * responses (K, N) of gfdn_solve_* are never formed; dL/d(A, b, c) goes through dL/dcoef (30 sums over the bins
  * per block) and a bin-independent float64 map per block.
- *   coefs_fwd : A (nblk, nper, nper), b, c (nblk*nper), inv_gamma (nblk*nper) or NULL (ones) -> coef.
+ *   coefs_fwd : A (nblk, nper, nper), b, c (nblk*nper), inv_gamma (nblk*nper) or NULL (ones) -> coef;
+ *               coefs_fwd2: two record sets sharing b, c in one launch.
  *   eval      : T (K, nblk) complex64 BIN-MAJOR = scale_blk * T_blk(z_k)  (scale (nblk) or NULL).
  *   energy    : Trainer.normalize (trainer.py:317-332) from the records of the sub-FDNs: energy (nblk) =
  *               mean_k |T|^2 (optional), scale (nblk) = energy^(-1/2) (optional: what T -- and the numerator
@@ -298,6 +299,9 @@ int gfdn_subfdn_colorless_bwd(const double* turns, const double* logr, int K, in
  *               gb, gc (nblk*nper) = the sum over the sets.  b, c: the values the records' gradients refer to.  */
 int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c, const float* inv_gamma, int nblk,
                       int nper, float* coef, void* stream);
+int gfdn_tf_coefs_fwd2(const float* A0, const float* inv_gamma0, float* coef0, const float* A1,
+                       const float* inv_gamma1, float* coef1, const float* b, const float* c, int nblk, int nper,
+                       void* stream);
 int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const float* grec0, const float* A1,
                       const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
                       int nper, float* gA0, float* gA1, float* gb, float* gc, void* stream);
@@ -324,6 +328,15 @@ int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nban
 size_t gfdn_tf_gain_grad_work_bytes(int K, int nbands, int G, int B);
 int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave_c64, const float* filt_c64, int ldf,
                       const float* gH_c64, int ldh, float* grgain, void* work, void* stream);
+
+/* ---- measurement kernel for BASELINE.json configs[4] ("fp32 vs bf16 feedback-matmul on MFMA") ------------------
+ * The reference's dense formulation (feedback_loop.py:389-391 explicit resolvent P (K, N, N); model.py:615-619
+ * einsum contraction with the output gains) for N = B = 32: H[b][k] = sum_m (sum_n C[b][n] P_k[n][m]) bvec[m], one
+ * wavefront per bin on the matrix cores -- use_bf16 != 0: v_mfma_f32_32x32x16_bf16 on operands rounded to bfloat16;
+ * 0: v_mfma_f32_32x32x2_f32.  P (K, 32, 32) complex64, C (32, 32), bvec (32) float32 -> H (32, K) complex64.  Not on
+ * the product path (which never forms P); tools/mfma_experiment.py times it against that path.                     */
+int gfdn_exp_contract_mfma(const float* P_c64, int K, const float* C, const float* bvec, int use_bf16,
+                           float* H_c64, void* stream);
 
 /* ---- odd-length inverse real FFT  (losses.py:207-213, :442-445: irfft(X, n = K)) ---------
  * x[t] = irfft(X[0..(n-1)/2], n), n odd (65 537 = 2^16+1 at nfft = 131 072), by Bluestein's

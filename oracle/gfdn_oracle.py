@@ -564,8 +564,14 @@ class GridModelParams:
         self.num_fourier_features = num_fourier_features
 
     def gamma(self) -> torch.Tensor:
-        """model.py:155-163 -- float64 numpy db2lin, flattened into a (float64) tensor."""
+        """model.py:155-163 -- float64 numpy db2lin, flattened into a (float64) tensor.  ``common_decay_times`` given
+        as a torch tensor = the learnable decay times of feedback_loop.py:205-232: the same expression as a
+        differentiable function of T60 (one gain vector per group, concatenated)."""
         n = self.n_per_group
+        if torch.is_tensor(self.common_decay_times):
+            t60 = self.common_decay_times.reshape(-1)
+            return torch.cat([torch.pow(10.0, (-60 * self.delays[i * n:(i + 1) * n] / (self.sample_rate * t60[i])) * 0.05)
+                              for i in range(self.num_groups)])
         cdt = np.squeeze(self.common_decay_times)
         dl = self.delays.numpy().astype(np.int64)
         vals = [decay_times_to_gain_per_sample(cdt[i], dl[i * n:(i + 1) * n], self.sample_rate).tolist()

@@ -549,8 +549,43 @@ def gen_f13_single_rir_data():
     print('F13 done')
 
 
+def gen_f14_learnable_decay_times():
+    """F14: learnable common decay times (feedback_loop.py:205-232, model.py:127-153): the gains are the
+    differentiable function 10^(-3 m / (fs T60_g)) of an nn.Parameter; forward H, decay losses, gradients of every
+    parameter incl. feedback_loop.common_decay_times.  (The reference evaluates the gains ONCE, in the constructor:
+    the fixture is the first forward / backward, where that equals re-evaluating them.)"""
+    fs, nfft, G, nper, B, T, win, hop, seed = 4000.0, 1024, 3, 4, 3, 900, 128, 64, 21
+    delays = prime_delays(G * nper, lo=int(20e-3 * fs), hi=int(50e-3 * fs), seed=seed)
+    batch, T60 = synth_batch(B, nfft, fs, G, T, seed)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(fs, G, delays, 'cpu', fl, of, use_absorption_filters=False,
+                                 learn_common_decay_times=True, common_decay_times=np.asarray(T60)[None, :],
+                                 use_colorless_loss=False)
+    out = {'fs': fs, 'nfft': nfft, 'G': G, 'nper': nper, 'delays': np.array(delays), 'T60': T60, 'win': win, 'hop': hop}
+    out.update(batch_to_np(batch))
+    out.update(state_np(net))
+    H = net(batch)
+    out['H'] = c2np(H)
+    tgt = batch['target_rir_response']
+    l_edr = edr_loss(fs, win_size=win, hop_size=hop)(tgt, H)
+    l_edc = edc_loss(float(np.max(T60)) * 1e3, fs, use_mask=False)(tgt, H)
+    (l_edr + 10.0 * l_edc).backward()
+    out['loss_edr'], out['loss_edc'] = l_edr.item(), l_edc.item()
+    for name, prm in net.named_parameters():
+        out['grad_' + name] = c2np(prm.grad)
+    np.savez_compressed(os.path.join(HERE, 'f14_learnable_decay_times.npz'), **out)
+    print('F14 done', l_edr.item(), l_edc.item(), out['grad_feedback_loop.common_decay_times'])
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'new':          # only the fixtures added in round 2
+        gen_f2_f3_f4('n32_k1025', G=4, nper=8, nfft=2048, fs=8000.0, B=3, T=2000, win=256, hop=128, seed=13)
+        gen_f14_learnable_decay_times()
+        sys.exit(0)
     gen_f1_feedback_loop()
     # small: nfft 512 (K = 257, Fermat prime -> prime-length irfft quirk), scaled STFT
     gen_f2_f3_f4('n12_k257', G=3, nper=4, nfft=512, fs=2000.0, B=4, T=400, win=64, hop=32)
@@ -567,3 +602,6 @@ if __name__ == '__main__':
     gen_f11_svf_filters()
     gen_f12_filter_coupling()
     gen_f13_single_rir_data()
+    # N = 32 (4 groups x 8 lines: BASELINE config 5), nfft 2048 (K = 1025 = 5^2 41)
+    gen_f2_f3_f4('n32_k1025', G=4, nper=8, nfft=2048, fs=8000.0, B=3, T=2000, win=256, hop=128, seed=13)
+    gen_f14_learnable_decay_times()

@@ -67,6 +67,10 @@ def test_records_and_evaluation(n, nblk, radius, orth):
     T = ops.tf_eval(turns, logr if radius != 1.0 else None, coef, delays.to(DEV), n)
     ref = _T_ref(z, A.float().double(), b.float().double(), c.float().double(), delays, ig.float().double())
     assert rel_err(T.cpu().numpy(), ref.numpy()) < 2e-5
+    c0, c1 = ops.tf_coefs2(A.to(DEV), None if not orth else ig.to(DEV), A.transpose(1, 2).contiguous().to(DEV), None,
+                           b.to(DEV), c.to(DEV))
+    assert torch.equal(c0, coef)
+    assert torch.equal(c1, ops.tf_coefs(A.transpose(1, 2).contiguous().to(DEV), b.to(DEV), c.to(DEV)))
     # energy + scale + in-place rescale (trainer.py:317-332)
     bb, cc = b.float().to(DEV).contiguous(), c.float().to(DEV).contiguous()
     energy, scale = ops.tf_energy(turns, logr if radius != 1.0 else None, coef, delays.to(DEV), n, bb, cc)

@@ -66,7 +66,7 @@ def test_f1_feedback_loop(tag):
         assert rel_err(loop.alpha.grad.cpu(), fx[f"{tag}_grad_alpha"]) < 5e-4
 
 
-@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz"])
+@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz", "f234_n32_k1025.npz"])
 def test_f2_model_forward(name):
     fx = load(name)
     net = _grid_model(fx)
@@ -83,7 +83,7 @@ def test_f2_model_forward(name):
     assert float(Hpd[0:n, :, 1].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz"])
+@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz", "f234_n32_k1025.npz"])
 def test_f3_losses(name):
     from diffgfdn_amd.colorless_losses import amse_loss, mse_loss, sparsity_loss
     from diffgfdn_amd.losses import edc_loss, edr_loss
@@ -113,7 +113,8 @@ def test_f3_losses(name):
         assert abs(sparsity_loss()(Q).item() - fx["loss_sparsity"][k]) < 1e-5
 
 
-@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False)])
+@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False),
+                                       ("f234_n32_k1025.npz", True)])
 def test_f4_train_step(name, asym):
     """normalize + fused step + Adam against the reference trainer (values, grads, new state)."""
     from diffgfdn_amd.config import TrainerConfig
@@ -155,6 +156,37 @@ def test_f4_train_step(name, asym):
     for k, v in d.items():
         ref = float(fx["step_" + k])
         assert abs(float(v) - ref) < TOL * abs(ref) + 1e-7, (k, float(v), ref)
+
+
+def test_f14_learnable_decay_times():
+    """Learnable common decay times (feedback_loop.py:205-232): H, the decay losses and every gradient incl.
+    dL/dT60 of the MODULE against the reference's first forward / backward (fixture F14)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.losses import edc_loss, edr_loss
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    fx = load("f14_learnable_decay_times.npz")
+    fs = float(fx["fs"])
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net = DiffGFDNVarReceiverPos(fs, int(fx["G"]), fx["delays"].tolist(), DEV, fl, of, use_absorption_filters=False,
+                                 learn_common_decay_times=True, common_decay_times=fx["T60"][None, :],
+                                 use_colorless_loss=False)
+    net.load_state_dict(_state(fx), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx))
+    H = net(batch)
+    assert rel_err(H.detach().cpu(), fx["H"]) < TOL
+    tgt = batch["target_rir_response"]
+    l_edr = edr_loss(fs, win_size=int(fx["win"]), hop_size=int(fx["hop"]))(tgt, H)
+    l_edc = edc_loss(float(np.max(fx["T60"])) * 1e3, fs, use_mask=False)(tgt, H)
+    assert abs(l_edr.item() - float(fx["loss_edr"])) < TOL * abs(float(fx["loss_edr"]))
+    assert abs(l_edc.item() - float(fx["loss_edc"])) < TOL * abs(float(fx["loss_edc"]))
+    (l_edr + 10.0 * l_edc).backward()
+    for name_, prm in net.named_parameters():
+        ref = fx["grad_" + name_]
+        err = np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < 2e-3, (name_, err)
+    assert net.feedback_loop.common_decay_times.grad is not None
 
 
 def test_graphed_step_equals_eager_step():

@@ -42,7 +42,7 @@ def test_f1_feedback_loop(tag):
         assert rel_err(alpha.grad, fx[f"{tag}_grad_alpha"]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz"])
+@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz", "f234_n32_k1025.npz"])
 def test_f2_forward(name):
     fx = load(name)
     p = grid_params(fx)
@@ -57,7 +57,7 @@ def test_f2_forward(name):
         assert rel_err(Hpd[g * n:(g + 1) * n, :, g].detach(), fx["Hout_per_del_nz"][g]) < TOL32
 
 
-@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz"])
+@pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz", "f234_n32_k1025.npz"])
 def test_f3_losses(name):
     fx = load(name)
     fs = float(fx["fs"])
@@ -84,7 +84,8 @@ def test_f3_losses(name):
         assert abs(orc.sparsity_loss(orc.ortho_param(M[k])).item() - fx["loss_sparsity"][k]) < 1e-6
 
 
-@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False)])
+@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False),
+                                       ("f234_n32_k1025.npz", True)])
 def test_f4_train_step(name, asym):
     """normalize + losses + backward: per-loss values and every parameter gradient."""
     fx = load(name)
@@ -209,7 +210,8 @@ def test_f6_directional():
     assert abs(l.item() - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
 
 
-@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False)])
+@pytest.mark.parametrize("name,asym", [("f234_n12_k257.npz", True), ("f234_n16_k4097_cp.npz", False),
+                                       ("f234_n32_k1025.npz", True)])
 def test_f4_adam_state(name, asym):
     """oracle/cpu_trainer.py (the bench's CPU baseline) reproduces the reference's post-Adam state."""
     from oracle.cpu_trainer import OracleGridTrainer
@@ -342,3 +344,30 @@ def test_f13_single_rir_data():
     batch = next(iter(load_dataset(d, "cpu", batch_size=len(ds), shuffle=False)))
     assert rel_err(batch["target_early_response"].numpy(), fx["early"]) < 1e-12
     assert set(batch) == {"z_values", "target_rir_response", "target_early_response", "target_late_response"}
+
+
+def test_f14_learnable_decay_times():
+    """Learnable common decay times (feedback_loop.py:205-232): the gains as a differentiable function of T60;
+    forward H, decay losses and every gradient incl. dL/dT60 against the reference."""
+    fx = load("f14_learnable_decay_times.npz")
+    lin, norm = mlp_from_state(fx)
+    lin = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in lin]
+    norm = [(w.requires_grad_(True), b.requires_grad_(True)) for w, b in norm]
+    t = lambda k: torch.tensor(fx["sd_" + k]).clone().requires_grad_(True)
+    T60 = torch.tensor(fx["sd_feedback_loop.common_decay_times"]).clone().requires_grad_(True)
+    p = orc.GridModelParams(float(fx["fs"]), fx["delays"].tolist(), int(fx["G"]), t("input_gains"), t("output_gains"),
+                            t("feedback_loop.M"), torch.tensor(fx["sd_feedback_loop.alpha"]), T60, lin, norm, 4)
+    batch = batch_from(fx)
+    H = orc.grid_model_forward(p, batch, use_colorless_loss=False)
+    assert rel_err(H.detach(), fx["H"]) < TOL32
+    fs = float(fx["fs"])
+    tgt = batch["target_rir_response"]
+    l_edr = orc.edr_loss(tgt, H, int(fx["win"]), int(fx["hop"]))
+    l_edc = orc.edc_loss(tgt, H, orc.ms_to_samps(float(np.max(fx["T60"])) * 1e3, fs), orc.ms_to_samps(20.0, fs))
+    assert abs(l_edr.item() - float(fx["loss_edr"])) < 2e-5 * abs(float(fx["loss_edr"]))
+    assert abs(l_edc.item() - float(fx["loss_edc"])) < 2e-5 * abs(float(fx["loss_edc"]))
+    (l_edr + 10.0 * l_edc).backward()
+    assert rel_err(T60.grad, fx["grad_feedback_loop.common_decay_times"]) < 2e-4
+    assert rel_err(p.M.grad, fx["grad_feedback_loop.M"]) < 2e-4
+    assert rel_err(p.input_gains.grad, fx["grad_input_gains"]) < 2e-4
+    assert rel_err(p.output_gains.grad, fx["grad_output_gains"]) < 2e-4

@@ -1,8 +1,8 @@
-"""Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/r01_*).
-usage: python tools/make_profiles.py [round_tag]   (default r01)"""
+"""Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/<tag>_*).
+usage: python tools/make_profiles.py [round_tag]   (default r02)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 src = os.path.join(ROOT, 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -43,37 +43,65 @@ open(os.path.join(dst, f'{tag}_graph_step_timeline.txt'), 'w').write(
 dom = bench.get('roofline', {})
 name = dom.get('kernel', '')
 drow = next((r for r in rows if r['Name'].startswith(name)), None)
-grid32 = {k: d for (k, g), d in pmc.items() if k == name}
 with open(os.path.join(dst, 'README.md'), 'w') as f:
     f.write(f"""# profiles/ -- round {tag[1:]}
-All files come from ONE `gpurun` call (tools/run_measurements.sh) on one MI355X (gfx950, ROCm 7.2); `bench.py` is
-the command the driver runs (N = 1, workload = BASELINE.json configs[1]).  Rebuilt by tools/make_profiles.py.
+All `{tag}_*` files come from ONE `gpurun` call (`bash tools/run_measurements.sh {tag}`) on one MI355X (gfx950, ROCm 7.2);
+`bench.py` is the command the driver runs (N = 1, workload = the 7-band configuration BASELINE.json's metric is quoted
+on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` files are the previous round's, kept for comparison.
 
 | file | command | what it holds |
 |---|---|---|
-| `{tag}_bench_n1.json` | `python bench.py` | the bench JSON line (graph-replay steps, roofline leg, CPU baseline) |
-| `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` | per-kernel totals / averages (includes the one-off dataset front end and the 20 eager roofline steps) |
+| `{tag}_bench_n1.json` | `python bench.py` | the bench JSON line (graph-replay steps, roofline leg, CPU baseline with `loss_delta_vs_cpu`) |
+| `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` | per-kernel totals / averages (includes the one-off dataset front end, the 20 host-launched roofline steps and the 60 isolated launches of the roofline kernel) |
 | `{tag}_pmc_hbm_bytes.csv` | `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --eager`, and the same with `--pmc WRITE_SIZE` (separate passes) | average FETCH_SIZE / WRITE_SIZE per launch of every hand-written kernel, by grid size; read bytes corrected x2 for gfx950 as MI355X_MICROARCH.md prescribes |
-| `{tag}_pmc_l2_valu.csv` | `tools/run_pmc_extra.sh` (a separate `gpurun` call): `rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum` and `--pmc SQ_INSTS_VALU SQ_WAVES` on `bench.py --eager`, summarised by `tools/make_pmc_extra.py` | L2 requests / hit rate and VALU instructions per wave, per kernel and launch: what the request-rate and instruction-bound statements of DESIGN.md §4 rest on |
 | `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
+
+`bench.py` reads `{tag}_pmc_hbm_bytes.csv` (`roofline.traffic`) and `{tag}_bench_kernel_stats.csv` (`roofline.top`) at run
+time, so every fraction in the bench line can be recomputed from this directory.
 
 ## bench line
 `{bench['value']:.0f} {bench['unit']}` = {bench['ms_per_step']:.4f} ms/step on 1 GPU;
 cpu_baseline {bench.get('cpu_baseline', {}).get('value', float('nan')):.1f} {bench['unit']} ({bench.get('cpu_baseline', {}).get('cores')} threads, kind {bench.get('cpu_baseline', {}).get('kind')}).
 
 ## Roofline kernel: `{name}`
-bench.py (HIP events, {dom.get('launches')} launches): bracket {dom.get('bracket_us', float('nan')):.1f} us - empty event pair {dom.get('event_pair_overhead_us', float('nan')):.1f} us
-= **{dom.get('avg_launch_us', float('nan')):.1f} us**; rocprofv3 average over {drow['Calls'] if drow else '?'} launches of the stats run: **{float(drow['AverageNs'])/1e3 if drow else float('nan'):.1f} us**
-(that average also covers the 64-receiver launches of the one-off target precompute).
-Algorithmic bytes per launch {dom.get('alg_bytes_per_launch', 0)/1e6:.2f} MB -> achieved {dom.get('achieved', 0):.0f} GB/s = {dom.get('frac', 0):.3f} of {dom.get('peak')} GB/s.
-PMC traffic per launch (`traffic`): {(dom.get('traffic') or 0)/1e6:.2f} MB.
+bench.py, in the step (HIP events around every launch during 20 host-launched steps of the timed launch sequence, raw
+bracket): **{dom.get('avg_launch_us', float('nan')):.1f} us**; alone on the chip: {dom.get('isolated_us', float('nan')):.1f} us;
+rocprofv3 average over {drow['Calls'] if drow else '?'} launches of the stats run: **{float(drow['AverageNs'])/1e3 if drow else float('nan'):.1f} us**
+(that average covers the replayed steps, the host-launched steps, the isolated launches and the 64-receiver launches of the
+one-off target precompute).
+Algorithmic bytes per launch {dom.get('alg_bytes_per_launch', 0)/1e6:.2f} MB -> achieved {dom.get('achieved', 0):.0f} GB/s = {dom.get('frac', 0):.3f} of {dom.get('peak')} GB/s (in the step).
 
 ## Top kernels by total time (stats run)
 
 | kernel | calls | total ms | avg us | % |
 |---|---|---|---|---|
 """)
-    for r in rows[:26]:
+    for r in rows[:30]:
         f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |\n")
     f.write(f"\nTotal GPU time in the trace: {total_ms:.1f} ms.\n")
-print(open(os.path.join(dst, 'README.md')).read()[:3000])
+    # HBM traffic of one step: the kernels of the replayed step (timeline) x the PMC traffic of their launches (per
+    # kernel the grid with most launches = the step's)
+    f.write("\n## HBM traffic per step (PMC, 2 x FETCH_SIZE + WRITE_SIZE)\n\n| kernel | launches per step | MB per launch | MB per step |\n|---|---|---|---|\n")
+    best = {}
+    for (k, g), d in pmc.items():
+        if k not in best or d['launches'] > best[k]['launches']:
+            best[k] = d
+    counts = collections.Counter()
+    for line in tl.splitlines():
+        parts = line.split()
+        if len(parts) >= 6 and parts[2].startswith('d='):
+            nm = line.split('q=')[1].split(None, 1)[1].split('(')[0].replace('void ', '').strip()
+            counts[nm] += 1
+    tot = 0.0
+    rowsout = []
+    for nm, c in counts.items():
+        d = best.get(nm)
+        if d is None:
+            continue
+        mb = (2 * d.get('FETCH_SIZE', 0.0) + d.get('WRITE_SIZE', 0.0)) * 1024 / 1e6
+        rowsout.append((mb * c, nm, c, mb))
+        tot += mb * c
+    for t_, nm, c, mb in sorted(rowsout, reverse=True):
+        f.write(f"| `{nm}` | {c} | {mb:.1f} | {t_:.1f} |\n")
+    f.write(f"\nSum over the step's launches: **{tot / 1e3:.2f} GB** (algorithmic: {224 * 2811048 / 1e9:.2f} GB; round 1: 2.47 GB).\n")
+print(open(os.path.join(dst, 'README.md')).read()[-3500:])
