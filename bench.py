@@ -369,6 +369,99 @@ def isolated_kernel_us(device, items: int, iters: int = 30):
     return ops.kernel_timer.stop()
 
 
+def run_directional(args, device, rank, world):
+    """BASELINE.json configs[3]: directional DiffGFDN, 2nd-order ambisonics (9 SH channels per group), 7 bands, 838
+    receivers -- G = 3 groups x 9 lines (N = 27), J = 12 directions, batch 32 receivers per band and step; every
+    band's step (SH-domain forward, directional responses, directional EDC loss, backward, Adam) is one HIP-graph
+    replay, the bands run one after another (reference: DirectionalFDNVarReceiverPosTrainer, trainer.py:690-921).
+    The analysis matrix and the common-slope amplitudes are synthetic inputs (spaudiopy / the dataset are absent)."""
+    from diffgfdn_amd import hip_ops
+    from diffgfdn_amd.config import (CouplingMatrixType, DiffGFDNConfig, FeedbackLoopConfig, OutputFilterConfig,
+                                     TrainerConfig)
+    from diffgfdn_amd.model import DiffDirectionalFDNVarReceiverPos
+    from diffgfdn_amd.trainer import DirectionalFDNVarReceiverPosTrainer
+    Gd, order, J, R = 3, 2, 12, args.receivers
+    L = (order + 1) ** 2
+    nb = args.bands
+    rng = np.random.RandomState(7)
+    z = torch.exp(1j * np.pi * torch.arange(K, dtype=torch.float64) / (K - 1)).to(device)
+    steps = []
+    for q in range(nb):
+        torch.manual_seed(500 + q)
+        delays = DiffGFDNConfig(num_groups=Gd, num_delay_lines=Gd * L, sample_rate=FS, seed=23463 + q).delay_length_samps
+        fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+        of = OutputFilterConfig(use_svfs=False, num_hidden_layers=5, num_neurons_per_layer=16, num_fourier_features=20)
+        A = rng.randn(J, L).astype(np.float32)
+        net = DiffDirectionalFDNVarReceiverPos(FS, Gd, delays, device, fl, of, ambi_order=order,
+                                               common_decay_times=np.linspace(0.5, 1.4, Gd)[None, :],
+                                               use_colorless_loss=True, analysis_matrix=A).to(device)
+        tc = TrainerConfig(use_colorless_loss=True, use_asym_spectral_loss=True, edc_loss_weight=10.0,
+                           sparsity_loss_weight=2.0, use_edc_mask=False, lr=1e-3, io_lr=1e-2, device='cuda',
+                           train_dir='/tmp/gfdn_bench/dir_t', ir_dir='/tmp/gfdn_bench/dir_a')
+        tr = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
+        store = {'listener_position': torch.tensor(rng.uniform(0, 10, (R, 3)), device=device),
+                 'norm_listener_position': torch.tensor(rng.uniform(0, 1, (R, 3)), device=device),
+                 'target_common_slope_amps': torch.tensor(rng.uniform(0.1, 1.0, (R, J, Gd)), device=device)}
+        idx = torch.arange(BATCH, device=device)
+        batch = {'z_values': z, 'source_position': torch.zeros(BATCH, 3, device=device, dtype=torch.float64)}
+        batch.update({k: v[idx].clone() for k, v in store.items()})
+        steps.append((tr, tr.graphed(batch).capture(), store))
+    gen = torch.Generator().manual_seed(100 + rank)
+
+    def one_step():
+        for tr, step, store in steps:
+            sel = torch.randperm(R, generator=gen)[:BATCH].to(device)
+            for k, v in store.items():
+                step.batch[k].copy_(v.index_select(0, sel))
+            out = step()
+        return out
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, parts = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    # roofline leg: the power-of-two irfft of the 32 x 12 directional responses (both passes), in the step
+    tr, step, store = steps[0]
+    hip_ops.kernel_timer.watch = 'irfft_pow2_fwd'
+    hip_ops.kernel_timer.start()
+    for _ in range(10):
+        tr.train_step(step.batch)
+    kt = hip_ops.kernel_timer.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rirs_per_s = nb * BATCH * world * args.steps / elapsed
+    out = {'metric': 'RIR-frames/sec', 'value': rirs_per_s * FRAMES, 'unit': 'RIR-frames/s', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'directional DiffGFDN: {nb} octave bands one after another, each {Gd} groups x {L} SH '
+                                  f'channels (N = {Gd * L}), {J} directions, {R} receivers, nfft 131072, batch {BATCH} '
+                                  'receivers/band/step/GPU; step = SH forward + directional EDC + colorless losses + bwd + '
+                                  'Adam per band, one HIP-graph replay per band', 'bands': nb, 'receivers': R,
+                       'directions': J, 'delay_lines': Gd * L, 'rirs_per_s': rirs_per_s,
+                       'ms_per_band_step': 1e3 * elapsed / args.steps / nb,
+                       'final_loss': float(total)}}
+    if kt:
+        units = kt['units_per_launch']                      # directional responses per launch (32 x 12)
+        per = 8 * K + 2 * 8 * 65536 + 4 * NFFT              # spectrum in, work block out and in, samples out
+        us = kt['avg_ms'] * 1e3
+        out['roofline'] = {'bound': 'hbm', 'achieved': units * per / us / 1e3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': units * per / us / 1e3 / HBM_PEAK_GBS, 'traffic': None,
+                           'kernel': 'k_p2_inv_a + k_p2_inv_b (irfft, n = 131072, of the directional responses)',
+                           'avg_launch_us': us, 'launches': kt['launches'], 'alg_bytes_per_unit': per,
+                           'units_per_launch': units, 'measured': 'HIP events around both passes in 10 host-launched steps'}
+    return out
+
+
 def self_launch(args) -> int:
     """N > 1 without a launcher: start N fresh ranks (nothing in this process has touched the GPU)."""
     with socket.socket() as s:
@@ -388,6 +481,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak: 32 receivers per band per RANK; strong: the global batch of 32 per band split over ranks')
+    ap.add_argument('--config', choices=('omni', 'directional'), default='omni',
+                    help='omni: BASELINE.json configs[1]/[2] (the headline); directional: configs[3] (2nd-order ambisonics)')
     ap.add_argument('--epoch', action='store_true',
                     help='time whole epochs (19 train + 5 validation steps + checkpoints); --steps = epochs timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -446,6 +541,16 @@ def main():
         dist.all_gather_object(seen, (rank, dev_index, socket.gethostname()))
         ranks_seen = sorted(r for r, _, _ in seen)
         assert ranks_seen == list(range(world)), ranks_seen
+
+    if args.config == 'directional':
+        out = run_directional(args, device, rank, world)
+        if rank == 0:
+            out['ranks_seen'] = ranks_seen
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from diffgfdn_amd import hip_ops
     nbands = args.bands

@@ -871,8 +871,11 @@ def irfft_pow2_fwd(X, n: int) -> torch.Tensor:
     lib = _lib.load()
     x = torch.empty((batch, n), dtype=_f32, device=X.device)
     work = _work(lib.gfdn_irfft_pow2_work_bytes(n, batch), X.device)
+    end = kernel_timer.bracket('irfft_pow2_fwd', batch)        # (both passes of the transform as one unit)
     _lib.check(lib.gfdn_irfft_pow2_fwd(n, _p(X), ldx, batch, _p(x), n, _p(work), _stream()),
                "gfdn_irfft_pow2_fwd")
+    if end is not None:
+        end.record()
     return x
 
 

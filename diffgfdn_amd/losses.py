@@ -435,8 +435,10 @@ class directional_edc_loss(nn.Module):
         Hb = H_pred.reshape(B * J, K)
         x = ops.irfft_pow2_fwd(Hb, n)
         # true EDC from the common-slope amplitudes (einsum 'bjk,kt->bjt'), then dB
+        if self.envelopes.device != x.device:              # (once: a host -> device copy cannot be graph-captured)
+            self.envelopes = self.envelopes.to(x.device)
         edc_true = torch.einsum('bjk, kt -> bjt', amps_true.to(torch.float32).to(x.device),
-                                self.envelopes[:, :L].to(x.device)).reshape(B * J, L)
+                                self.envelopes[:, :L]).reshape(B * J, L)
         T_db = (10.0 * torch.log10(edc_true.abs() + torch.finfo(torch.float32).eps)).clip(min=-200.0)
         if self.use_mask:
             keep = torch.bernoulli(torch.empty(L).uniform_(0, 1))

@@ -539,6 +539,10 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
 
     concurrent_branches = False
 
+    def graphed(self, example_batch: Dict) -> "GraphedModuleStep":
+        """train_step on batches shaped like ``example_batch`` as one HIP-graph replay."""
+        return GraphedModuleStep(self, example_batch)
+
     def convert_ambi_rir_to_directional_rir(self, H_sh: torch.Tensor) -> torch.Tensor:
         """einsum('jl,blk->bjk', A_sh, H_sh)  (reference :853-865) as one streaming kernel."""
         return SHToDirectional.apply(self.net.sh_output_scalars.analysis_matrix, H_sh)
@@ -653,6 +657,62 @@ class SinglePosTrainer(Trainer):
         losses = self._step_losses(data)
         losses.pop('_total')
         return sum(losses.values()), losses
+
+
+class GraphedModuleStep:
+    """``trainer.train_step(batch)`` of a trainer whose forward goes through the model's own module (directional
+    and single-position models) captured into ONE HIP graph.  The batch lives in static device buffers that
+    ``__call__`` refreshes in place; warm-up and capture run on ONE private stream -- autograd pins every
+    parameter's AccumulateGrad node to the stream of its first backward, and a capture that has to hop to another
+    stream and back dies in hipStreamEndCapture (ROCm 7.2).  Needs ``capturable=True`` (flat Adam with device-side
+    step counter and learning rates) and a loss path without host reads (``use_edc_mask=False``: the reference
+    draws that mask on the host)."""
+
+    def __init__(self, trainer, example_batch: Dict):
+        if not trainer.capturable:
+            raise ValueError("build the trainer with capturable=True to replay steps from a graph")
+        if getattr(trainer.config, 'use_edc_mask', False):
+            raise NotImplementedError("GraphedModuleStep: use_edc_mask draws on the host every step")
+        self.tr = trainer
+        self.batch = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        self.stream = torch.cuda.Stream()
+        self.graph = None
+        self.out = None
+
+    def capture(self):
+        tr = self.tr
+        params = list(tr.net.parameters())
+        saved_p = [p.detach().clone() for p in params]
+        saved_s = [t.detach().clone() for t in tr.optimizer.state_tensors()]
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for _ in range(3):
+                tr.train_step(self.batch)
+            for p, sp in zip(params, saved_p):                 # the warm-up leaves no trace
+                p.data.copy_(sp)
+            for t, st in zip(tr.optimizer.state_tensors(), saved_s):
+                t.copy_(st)
+            tr.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            total, parts = tr.train_step(self.batch)
+        self.out = (total, parts)
+        from .functional import FrequencyGrid
+        self._grids = list(FrequencyGrid._cache.values())      # (raw pointers into the grids were recorded)
+        torch.cuda.synchronize()
+        return self
+
+    def __call__(self, batch: Optional[Dict] = None):
+        if batch is not None:
+            for k, v in batch.items():
+                dst = self.batch.get(k)
+                if torch.is_tensor(v) and torch.is_tensor(dst) and v.data_ptr() != dst.data_ptr():
+                    dst.copy_(v, non_blocking=True)
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        return self.out
 
 
 class GraphedTrainStep:

@@ -363,6 +363,42 @@ def test_f6_directional():
     assert rel_err(crit_default.envelopes, fx["envelopes"]) < 1e-5
 
 
+def test_directional_graphed_step_equals_eager_step():
+    """DirectionalFDNVarReceiverPosTrainer.graphed: replaying the captured step == host launches (values, state)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
+    from diffgfdn_amd.model import DiffDirectionalFDNVarReceiverPos
+    from diffgfdn_amd.trainer import DirectionalFDNVarReceiverPosTrainer
+    fx = load("f6_directional.npz")
+    fs = float(fx["fs"])
+    res = {}
+    batch0 = _to_dev(batch_from(fx))
+    batch0["target_common_slope_amps"] = torch.tensor(fx["amps"]).to(DEV)
+    for mode in ("eager", "graph"):
+        fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+        of = OutputFilterConfig(use_svfs=False, num_hidden_layers=1, num_neurons_per_layer=8, num_fourier_features=3)
+        net = DiffDirectionalFDNVarReceiverPos(fs, int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                                               ambi_order=int(fx["order"]), common_decay_times=fx["T60"][None, :],
+                                               use_colorless_loss=True, analysis_matrix=fx["analysis_matrix"])
+        net.load_state_dict(_state(fx), strict=True)
+        net = net.to(DEV)
+        tc = TrainerConfig(use_colorless_loss=True, edc_loss_weight=1.0, use_edc_mask=False, lr=1e-3, io_lr=1e-2,
+                           train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a", device="cuda")
+        tr = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
+        tr.criterion[0].edc_len_samps = int(float(fx["edc_len_ms"]) * 1e-3 * fs)
+        tr.criterion[0].envelopes = torch.tensor(fx["envelopes"], dtype=torch.float32)
+        vals = []
+        step = tr.graphed(batch0) if mode == "graph" else None
+        for i in range(3):
+            b = dict(batch0)
+            b["target_common_slope_amps"] = batch0["target_common_slope_amps"] * (1.0 + 0.1 * i)
+            total, _ = step(b) if step is not None else tr.train_step(b)
+            vals.append(float(total))
+        res[mode] = (vals, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    assert np.allclose(res["eager"][0], res["graph"][0], rtol=1e-5), res
+    for k, v in res["eager"][1].items():
+        assert rel_err(res["graph"][1][k], v) < 1e-5, k
+
+
 def test_f7_front_end():
     from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
     fx = load("f7_front_end.npz")

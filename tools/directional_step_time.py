@@ -27,7 +27,33 @@ batch = {'z_values': z, 'listener_position': torch.rand(B, 3, device=dev, dtype=
          'source_position': torch.zeros(B, 3, device=dev, dtype=torch.float64),
          'target_early_response': torch.randn(B, K, dtype=torch.complex128, device=dev) * 0.01,
          'target_common_slope_amps': torch.rand(B, J, G, dtype=torch.float64, device=dev)}
-for it in range(8):
+if len(sys.argv) > 1 and sys.argv[1] == 'graph':
+    pass
+for it in range(0 if (len(sys.argv) > 1 and sys.argv[1] == 'graph') else 8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     tot, _ = tr.train_step(batch)
     torch.cuda.synchronize(); print(f'directional eager step {1e3*(time.perf_counter()-t0):.2f} ms loss {float(tot):.4f}', flush=True)
+
+# the same step replayed from a HIP graph (static batch tensors; capturable flat Adam).  Warm-up and capture run on ONE
+# stream: autograd pins every parameter's AccumulateGrad node to the stream of its first backward, and a capture that
+# has to hop to that stream and back dies in hipStreamEndCapture.
+if len(sys.argv) > 1 and sys.argv[1] == 'graph':
+    net = DiffDirectionalFDNVarReceiverPos(fs, G, delays, dev, fl, of, ambi_order=order, common_decay_times=T60,
+                                           use_colorless_loss=True, analysis_matrix=A).to(dev)
+    tr2 = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
+    cs = torch.cuda.Stream()
+    cs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cs):
+        for _ in range(3):
+            tr2.train_step(batch)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cs):
+        tot, parts = tr2.train_step(batch)
+    torch.cuda.synchronize()
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize(); print(f'directional graph step {1e3*(time.perf_counter()-t0)/20:.3f} ms loss {float(tot):.4f}', flush=True)
+    sys.exit(0)
