@@ -58,6 +58,22 @@ def render_band(net, batches, taps: torch.Tensor) -> torch.Tensor:
     return torch.cat(out, dim=0)
 
 
+@torch.no_grad()
+def infer_bands(freqs: Sequence[float], load_band: Callable[[float], tuple], rank: int = 0, world_size: int = 1,
+                group=None, dst: int = 0) -> Optional[torch.Tensor]:
+    """The reference's ``inferencing`` (:207-375) over the ranks of a job: this rank renders ITS bands
+    (``load_band(freq)`` -> (net with the trained state loaded, batches, FIR taps of the band's reconstructing
+    filter)), filters them (``render_band``) and the bands are summed per receiver on ``dst`` (``sum_bands``; a rank
+    without bands contributes zeros).  Returns the full-band RIRs (receivers, nfft + taps - 1) on ``dst``."""
+    local, device = [], None
+    for f in band_assignment(freqs, world_size)[rank]:
+        net, batches, taps = load_band(f)
+        net.eval()
+        local.append(render_band(net, batches, taps))
+        device = local[-1].device
+    return sum_bands(local, group=group, dst=dst, device=device)
+
+
 def sum_bands(local_band_rirs: Sequence[torch.Tensor], group=None, dst: int = 0, device=None) -> Optional[torch.Tensor]:
     """Sum of the filtered RIRs over ALL bands (reference :358 ``groupby('position').apply(sum)``):
     local sum over this rank's bands, then one reduce to ``dst``.  Returns the total on ``dst``,
