@@ -268,13 +268,17 @@ class FusedBankStep:
             return s_, ((s_[:, 0] + out3[:, 0]) if nb > 1 else (s_[0] + out3[0]))
 
         if train:
-            # ---- backward of the output stage: gains pass -> (side2: gain network backward) | records pass
-            grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
-            ev['grg'].record()
+            # ---- backward of the output stage.  Its two passes are independent and both stream dL/dH: the records pass
+            # stays on the main stream, the gains pass (-> gain network backward) runs beside it on side2 -- together
+            # 50 us instead of 29 + 45 one after the other.  The reported sums go in front of the gains pass (their
+            # inputs are long complete; behind it they would sit on the path to Adam).
+            ev['grg'].record()                    # (dL/dH complete)
             grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb)
             with on_side2():
+                torch.cuda.current_stream().wait_event(ev['g'])
+                sums, total = report()
                 torch.cuda.current_stream().wait_event(ev['grg'])
-                sums, total = report()            # (behind a fork the step has anyway: the EDR terms come from main)
+                grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
                 ev['mlpb'].record()

@@ -237,6 +237,154 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward for layers of at most 64 neurons (the north-star network: 120 -> 16 x 6 -> 4): ONE WAVEFRONT per
+// receiver, MLP_RB receivers per workgroup.  The layer chain of a receiver is a serial string of 16-wide steps;
+// on a 256-thread workgroup every step pays block barriers and two block reductions, here they are wave-level
+// (LDS traffic of one wave executes in order).  The chain only leaves per-layer vectors in LDS (activations
+// entering the layer, dL/d(linear output), dL/d(affine output)); the parameter gradients are outer products of
+// those, assembled at the end by the whole workgroup and summed over its receivers in a fixed order: one partial
+// row per workgroup instead of one per receiver for the reduction pass.
+// ------------------------------------------------------------------------------------------
+#define MLP_RB 8
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__host__ __device__ static inline int mlp_rb_stride(const MlpDims& d) {
+  // per receiver: A0 (in_dim) | A (nl, H) | XH (nl, H) | DH (nl, H) | DY (nl, H) | RS (nl) | DRAW (G)
+  return d.in_dim + 4 * d.nl * d.H + d.nl + d.G;
+}
+
+__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const double* __restrict__ pos,
+                                                               const float* __restrict__ freq_pi,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ gains,
+                                                               const float* __restrict__ xhat,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ ggains,   // (B, G)
+                                                               float* __restrict__ partial) {      // (B / MLP_RB, P)
+  const int H = d.H, G = d.G, nl = d.nl, P = (int)mlp_param_count(d);
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int b = blockIdx.x * MLP_RB + r;
+  float* wl = mlp_lds;
+  const int RS_ = mlp_rb_stride(d);
+  float* mine = wl + P + (size_t)r * RS_;
+  float* A0 = mine;
+  float* A = A0 + d.in_dim;
+  float* XH = A + nl * H;
+  float* DH = XH + nl * H;
+  float* DY = DH + nl * H;
+  float* RS = DY + nl * H;
+  float* DRAW = RS + nl;
+  w += (size_t)(b / d.Bper) * P;                 // (all receivers of a workgroup belong to one band)
+  for (int p = threadIdx.x; p < P; p += blockDim.x) wl[p] = w[p];
+  // this receiver's saved activations and encoding
+  for (int p = lane; p < nl * H; p += 64) XH[p] = xhat[(size_t)b * nl * H + p];
+  if (lane < nl) RS[lane] = rstd[(size_t)b * nl + lane];
+  {
+    const double* pp = pos + (d.rows ? (size_t)d.rows[b] : (size_t)b) * 3;
+    for (int e = lane; e < d.in_dim; e += 64) {
+      const int k = e / 6, q = e - 6 * k;
+      const double arg = (double)freq_pi[k] * pp[q % 3];
+      A0[e] = (float)(q < 3 ? sin(arg) : cos(arg));
+    }
+  }
+  if (lane < G) {
+    const float gg = ggains[(size_t)b * G + lane];
+    if (d.hi > d.lo) {
+      const float sg = (gains[(size_t)b * G + lane] - d.lo) / (d.hi - d.lo);
+      DRAW[lane] = gg * (d.hi - d.lo) * sg * (1.0f - sg);
+    } else {
+      DRAW[lane] = gg;
+    }
+  }
+  __syncthreads();                               // parameters staged
+  for (int p = lane; p < nl * H; p += 64) {      // A[l] = relu(xhat_l gamma_l + beta_l): what leaves layer l
+    const int l = p / H, j = p - l * H;
+    const float* W = wl + mlp_layer_off(d, l);
+    const int n_in = l == 0 ? d.in_dim : H;
+    const float* gamma = W + (size_t)H * n_in + H;
+    A[p] = fmaxf(XH[p] * gamma[j] + gamma[H + j], 0.f);
+  }
+  wave_lds_sync();
+  // output layer: dL/dA[nl-1]
+  float da = 0.f;
+  {
+    const float* Wout = wl + mlp_layer_off(d, nl);
+    if (lane < H)
+      for (int g = 0; g < G; ++g) da += Wout[(size_t)g * H + lane] * DRAW[g];
+  }
+  for (int l = nl - 1; l >= 0; --l) {
+    const int n_in = l == 0 ? d.in_dim : H;
+    const float* W = wl + mlp_layer_off(d, l);
+    const float* gamma = W + (size_t)H * n_in + H;
+    float xh = 0.f, dxh = 0.f, dy = 0.f;
+    if (lane < H) {
+      xh = XH[l * H + lane];
+      const float y = xh * gamma[lane] + gamma[H + lane];
+      dy = y > 0.f ? da : 0.f;
+      dxh = dy * gamma[lane];
+    }
+    const float m1 = wave_sum(dxh) / (float)H;
+    const float m2 = wave_sum(dxh * xh) / (float)H;
+    if (lane < H) {
+      DY[l * H + lane] = dy;
+      DH[l * H + lane] = RS[l] * (dxh - m1 - xh * m2);
+    }
+    wave_lds_sync();
+    if (l > 0) {
+      da = 0.f;
+      if (lane < H)
+        for (int jj = 0; jj < H; ++jj) da += W[(size_t)jj * n_in + lane] * DH[l * H + jj];
+    }
+  }
+  __syncthreads();
+  // parameter gradients of the workgroup's receivers, fixed order over r
+  const float* base = wl + P;
+  float* gout = partial + (size_t)blockIdx.x * P;
+  const int offOut = (int)mlp_layer_off(d, nl);
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float sum = 0.f;
+    if (p >= offOut) {
+      const int q = p - offOut;
+      if (q < G * H) {
+        const int g = q / H, i = q - g * H;
+        for (int rr = 0; rr < MLP_RB; ++rr) {
+          const float* m = base + (size_t)rr * RS_;
+          sum += m[d.in_dim + 4 * nl * H + nl + g] * m[d.in_dim + (nl - 1) * H + i];
+        }
+      } else {
+        const int g = q - G * H;
+        for (int rr = 0; rr < MLP_RB; ++rr) sum += (base + (size_t)rr * RS_)[d.in_dim + 4 * nl * H + nl + g];
+      }
+    } else {
+      const int first = H * d.in_dim + 3 * H, per = H * H + 3 * H;
+      const int l = p < first ? 0 : 1 + (p - first) / per;
+      const int q = p < first ? p : (p - first) - (l - 1) * per;
+      const int n_in = l == 0 ? d.in_dim : H;
+      const int oA = d.in_dim, oXH = oA + nl * H, oDH = oXH + nl * H, oDY = oDH + nl * H;
+      if (q < H * n_in) {
+        const int j = q / n_in, i = q - j * n_in;
+        const int oact = l == 0 ? i : oA + (l - 1) * H + i;
+        for (int rr = 0; rr < MLP_RB; ++rr) {
+          const float* m = base + (size_t)rr * RS_;
+          sum += m[oDH + l * H + j] * m[oact];
+        }
+      } else {
+        const int kind = (q - H * n_in) / H, j = (q - H * n_in) - kind * H;
+        for (int rr = 0; rr < MLP_RB; ++rr) {
+          const float* m = base + (size_t)rr * RS_;
+          sum += kind == 0 ? m[oDH + l * H + j]
+                           : (kind == 1 ? m[oDY + l * H + j] * m[oXH + l * H + j] : m[oDY + l * H + j]);
+        }
+      }
+    }
+    gout[p] = sum;
+  }
+}
+
 // gflat[band][p] = sum_{b in band} partial[b][p]   (B items per band, band = blockIdx.y)
 __global__ void k_mlp_reduce(const float* __restrict__ partial, int B, size_t P,
                              float* __restrict__ gflat) {
@@ -330,10 +478,22 @@ extern "C" int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
+  const size_t P = mlp_param_count(d);
+  if (d.stage && H <= 64 && G <= 64 && Bper % MLP_RB == 0) {
+    const size_t lds = (P + (size_t)MLP_RB * mlp_rb_stride(d)) * sizeof(float);
+    int erc = ensure_dyn_lds(k_mlp_bwd_waves, lds);
+    if (erc) return erc;
+    hipLaunchKernelGGL(k_mlp_bwd_waves, dim3(B / MLP_RB), dim3(64 * MLP_RB), lds, s, d, pos, freq_pi, w, gains, xhat,
+                       rstd, ggains, (float*)work);
+    GFDN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((P + 255) / 256), nbands), dim3(256), 0, s, (const float*)work,
+                       Bper / MLP_RB, P, gw);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_mlp_bwd, dim3(B), dim3(mlp_threads(d)), mlp_lds_bytes(d), s, d, pos, freq_pi, w, gains, xhat,
                      rstd, ggains, (float*)work);
   GFDN_LAUNCH_CHECK();
-  const size_t P = mlp_param_count(d);
   hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((P + 255) / 256), nbands), dim3(256), 0, s, (const float*)work, Bper, P, gw);
   GFDN_LAUNCH_CHECK();
   return 0;

@@ -269,7 +269,8 @@ def test_edc_loss_kernels(ops, masked):
     assert float(gx[:, :start].abs().max()) == 0.0 and float(gx[:, start + length:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,F,H,n_hidden,G", [(32, 20, 16, 5, 4), (5, 4, 16, 2, 3), (7, 10, 128, 3, 3), (3, 20, 8, 1, 2)])
+@pytest.mark.parametrize("B,F,H,n_hidden,G", [(32, 20, 16, 5, 4), (5, 4, 16, 2, 3), (7, 10, 128, 3, 3), (3, 20, 8, 1, 2),
+                                              (16, 10, 64, 2, 5), (8, 4, 24, 0, 3)])
 def test_mlp_gains_fused(ops, B, F, H, n_hidden, G):
     """Fused encoding + MLP + sigmoid kernel vs the torch modules (same parameters), fwd + bwd."""
     from diffgfdn_amd.gain_filters import Gains_from_MLP

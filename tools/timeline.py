@@ -14,3 +14,13 @@ for r in seg:
     s, e = int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0
     print(f"{s/1e3:8.1f} {e/1e3:8.1f} d={(e-s)/1e3:6.1f} q={r['Queue_Id']:>3s} {r['Kernel_Name'][:64]}")
 print("kernels:", len(seg), " span us:", (int(seg[-1]['End_Timestamp']) - t0) / 1e3)
+# steady-state period: start of the step's first kernel to the next step's (median over the replayed steps)
+import statistics
+starts = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith('k_ortho_fwd'))
+per = [(b - a) / 1e3 for a, b in zip(starts, starts[1:])]
+ends = sorted(int(r['End_Timestamp']) for r in rows if r['Kernel_Name'].startswith('k_adam('))
+import bisect
+gaps = [(starts[i] - e) / 1e3 for e in ends for i in [bisect.bisect_left(starts, e)] if i < len(starts)]
+if per and gaps:
+    print(f"period us: median {statistics.median(per):.1f}  (10th pct {sorted(per)[len(per)//10]:.1f});"
+          f"  last kernel of a step -> first kernel of the next: median {statistics.median(gaps):.1f}")
