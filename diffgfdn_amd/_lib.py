@@ -61,6 +61,7 @@ SIGNATURES = {
     "gfdn_tf_coefs_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     "gfdn_tf_coefs_fwd2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gfdn_tf_coefs_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_tf_param_grads": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_tf_parts": (c_int, [c_int, c_int]),
     "gfdn_tf_work_bytes": (c_size_t, [c_int]),
     "gfdn_tf_gpart_bytes": (c_size_t, [c_int]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "gfdn_tf_energy": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_double, _P]),
     "gfdn_tf_colorless": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_double, _P]),
     "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
+    "gfdn_tf_compose_parts": (c_int, [c_int]),
     "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_tf_gain_grad_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -273,7 +273,7 @@ class FusedBankStep:
             # 50 us instead of 29 + 45 one after the other.  The reported sums go in front of the gains pass (their
             # inputs are long complete; behind it they would sit on the path to Adam).
             ev['grg'].record()                    # (dL/dH complete)
-            grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb)
+            grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb, partial=True)
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
                 sums, total = report()
@@ -283,9 +283,10 @@ class FusedBankStep:
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
                 ev['mlpb'].record()
             main.wait_event(ev['side'])
-            gQQ, gMsub, _, _ = ops.tf_coefs_bwd(QQ, ig, grec, b, c, A1=M, grec1=grec_sub, gb=self.g_b, gc=self.g_c)
-            ops.ortho_bwd_add(M, gQ, gQQ, Q, gMsub, out=self.g_M)
-            keep.extend((grg, grec, gQQ, gMsub))
+            # records (partial rows of the records pass + the colorless pass's) -> dL/dM, dL/db, dL/dc: one launch
+            ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
+                               gM=self.g_M)
+            keep.extend((grg, grec))
             main.wait_event(ev['mlpb'])
             tr.optimizer._packed = True               # the flat gradient buffer is complete
             if allreduce is not None:

@@ -20,6 +20,7 @@
 // Record layout: coef (nblk, 32) float32 = [P_S, S = 0..15 | Q_S, S = 0..15], S a bit mask over the lines of
 // the block (bit i = line i; masks with bits >= n hold zeros).  T = (sum_S P_S e_S) / (sum_S Q_S e_S).
 #include "common.h"
+#include "ortho_dev.h"
 
 #define TF_MAXBLK 64
 #define TF_REC 32
@@ -214,18 +215,24 @@ struct TfBwdSet {
   const float* grec;
   float* gA;
 };
-__global__ __launch_bounds__(64) void k_tf_coefs_bwd(TfBwdSet s0, TfBwdSet s1, const float* __restrict__ b,
-                                                     const float* __restrict__ c, int n, float* __restrict__ gb,
-                                                     float* __restrict__ gc) {
-  __shared__ double sA[2][2][16], sig[2][4], sgq[2][2][16], sgA[2][2][16];
-  const int blk = blockIdx.x, tid = threadIdx.x;
+// One block's share, run by threads tid < 64 of a workgroup (every thread of the workgroup must call it: barriers).
+// grec0 / grec1: this block's 32 summed records (global or LDS).  lA0 / lA1 (optional, LDS, n x n row-major):
+// dL/dA of the two sets rounded to float32 as the global outputs are, for a consumer in the same kernel.
+__device__ __forceinline__ void tf_coefs_bwd_block(const TfBwdSet& s0, const TfBwdSet& s1, const float* grec0,
+                                                   const float* grec1, const float* __restrict__ b,
+                                                   const float* __restrict__ c, int n, int blk, int tid,
+                                                   float* __restrict__ gb, float* __restrict__ gc, float* lA0,
+                                                   float* lA1) {
+  __shared__ double sA[2][2][16], sig[2][4], sgq[2][2][16], sgA[2][2][16], spart[4][64];
   const int nsets = s1.A ? 2 : 1;
-  tf_stage_block(s0.A, b, c, s0.ig, blk, n, tid, sA[0], sig[0]);
-  if (nsets == 2) tf_stage_block(s1.A, b, c, s1.ig, blk, n, tid, sA[1], sig[1]);
+  if (tid < 64) {
+    tf_stage_block(s0.A, b, c, s0.ig, blk, n, tid, sA[0], sig[0]);
+    if (nsets == 2) tf_stage_block(s1.A, b, c, s1.ig, blk, n, tid, sA[1], sig[1]);
+  }
   __syncthreads();
   if (tid < 32 * nsets) {
     const int s = tid >> 5, v = (tid >> 4) & 1, S = tid & 15;
-    const float* grec = (s ? s1.grec : s0.grec) + (size_t)blk * TF_REC;
+    const float* grec = s ? grec1 : grec0;
     double igp = 1.0;
     for (int i = 0; i < 4; ++i)
       if ((S >> i) & 1) igp *= sig[s][i];
@@ -235,11 +242,14 @@ __global__ __launch_bounds__(64) void k_tf_coefs_bwd(TfBwdSet s0, TfBwdSet s1, c
     sgq[s][v][S] = g;
   }
   __syncthreads();
-  if (tid < 32 * nsets) {
-    const int s = tid >> 5, v = (tid >> 4) & 1, i = (tid >> 2) & 3, j = tid & 3;
+  {
+    // cofactor sums: thread (chunk, s, v, i, j) takes the subsets S = chunk, chunk + nch, ... (nch = wavefronts of the
+    // workgroup: the 16 subsets of an entry are a chain of LDS-latency-bound determinants), fixed-order fold after
+    const int t64 = tid & 63, chunk = tid >> 6, nch = ((int)blockDim.x >> 6) < 4 ? ((int)blockDim.x >> 6) : 4;
+    const int s = t64 >> 5, v = (t64 >> 4) & 1, i = (t64 >> 2) & 3, j = t64 & 3;
     double acc = 0.0;
-    if (i < n && j < n) {
-      for (int S = 0; S < (1 << n); ++S) {
+    if (chunk < nch && s < nsets && i < n && j < n) {
+      for (int S = chunk; S < (1 << n); S += nch) {
         if (((S >> i) & 1) || ((S >> j) & 1)) continue;
         int Ti[4], Tj[4], ti = 0, tj = 0, pi = 0, pj = 0, t = 0;
         for (int l = 0; l < n; ++l) {
@@ -253,13 +263,26 @@ __global__ __launch_bounds__(64) void k_tf_coefs_bwd(TfBwdSet s0, TfBwdSet s1, c
         acc += sgq[s][v][S] * cof;
       }
     }
+    if (chunk < 4) spart[chunk][t64] = acc;
+  }
+  __syncthreads();
+  if (tid < 32 * nsets) {
+    const int s = tid >> 5, v = (tid >> 4) & 1, i = (tid >> 2) & 3, j = tid & 3;
+    const int nch = ((int)blockDim.x >> 6) < 4 ? ((int)blockDim.x >> 6) : 4;
+    double acc = spart[0][tid];
+    for (int ch = 1; ch < nch; ++ch) acc += spart[ch][tid];
     sgA[s][v][i * 4 + j] = acc;
   }
   __syncthreads();
   if (tid < 16 * nsets) {
     const int s = tid >> 4, i = (tid >> 2) & 3, j = tid & 3;
     const TfBwdSet& st = s ? s1 : s0;
-    if (i < n && j < n && st.gA) st.gA[(size_t)blk * n * n + i * n + j] = (float)(sgA[s][0][i * 4 + j] + sgA[s][1][i * 4 + j]);
+    if (i < n && j < n) {
+      const float v = (float)(sgA[s][0][i * 4 + j] + sgA[s][1][i * 4 + j]);
+      if (st.gA) st.gA[(size_t)blk * n * n + i * n + j] = v;
+      float* l = s ? lA1 : lA0;
+      if (l) l[i * n + j] = v;
+    }
   } else if (tid >= 32 && tid < 36) {
     const int i = tid - 32;
     if (i < n && gb) {
@@ -279,6 +302,14 @@ __global__ __launch_bounds__(64) void k_tf_coefs_bwd(TfBwdSet s0, TfBwdSet s1, c
   }
 }
 
+__global__ __launch_bounds__(256) void k_tf_coefs_bwd(TfBwdSet s0, TfBwdSet s1, const float* __restrict__ b,
+                                                     const float* __restrict__ c, int n, float* __restrict__ gb,
+                                                     float* __restrict__ gc) {
+  const int blk = blockIdx.x;
+  tf_coefs_bwd_block(s0, s1, s0.grec + (size_t)blk * TF_REC, s1.grec ? s1.grec + (size_t)blk * TF_REC : nullptr, b, c, n,
+                     blk, threadIdx.x, gb, gc, nullptr, nullptr);
+}
+
 extern "C" int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const float* grec0, const float* A1,
                                  const float* inv_gamma1, const float* grec1, const float* b, const float* c,
                                  int nblk, int nper, float* gA0, float* gA1, float* gb, float* gc, void* stream) {
@@ -287,7 +318,67 @@ extern "C" int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const
   if (nper > 4) return GFDN_E_UNSUPPORTED;
   TfBwdSet s0{A0, inv_gamma0, grec0, gA0};
   TfBwdSet s1{A1, inv_gamma1, grec1, gA1};
-  hipLaunchKernelGGL(k_tf_coefs_bwd, dim3(nblk), dim3(64), 0, (hipStream_t)stream, s0, s1, b, c, nper, gb, gc);
+  hipLaunchKernelGGL(k_tf_coefs_bwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, s0, s1, b, c, nper, gb, gc);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// The tail of the band bank's backward in ONE launch, one workgroup per block (group): sum the partial record rows of
+// the output-stage adjoint (gpart0[(blk * 32 + e) * nparts0 + p], as k_tf_compose_bwd_rec leaves them; nparts0 = 1:
+// summed records), records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) as k_tf_coefs_bwd, then the adjoint of
+// Q = expm(skew(M)), QQ = Q Q as k_ortho_bwd with dL/dM_raw added: dL/dM.  Same arithmetic as the three separate
+// launches (row sums in the order of k_tf_rows_sum, dL/dQQ and dL/dM_raw rounded to float32 in between): the results
+// are bit-identical, which is how tests/test_gpu_blocktf.py checks it.
+__global__ __launch_bounds__(256) void k_tf_param_grads(TfBwdSet s0, TfBwdSet s1, int nparts0, const float* __restrict__ b,
+                                                        const float* __restrict__ c, int n, const float* __restrict__ M,
+                                                        const float* __restrict__ gQ, const float* __restrict__ Q,
+                                                        float* __restrict__ gb, float* __restrict__ gc,
+                                                        float* __restrict__ gM) {
+  extern __shared__ double tfp_lds[];
+  __shared__ float srec[TF_REC], sG[2][16];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (nparts0 > 1) {
+    const int lane = tid & 63, nw = blockDim.x >> 6;
+    for (int r = tid >> 6; r < TF_REC; r += nw) {
+      const float* row = s0.grec + ((size_t)blk * TF_REC + r) * nparts0;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int p = lane;
+      for (; p + 192 < nparts0; p += 256) {
+        a0 += row[p];
+        a1 += row[p + 64];
+        a2 += row[p + 128];
+        a3 += row[p + 192];
+      }
+      for (; p < nparts0; p += 64) a0 += row[p];
+      const float sum = wave_sum((a0 + a1) + (a2 + a3));
+      if (lane == 0) srec[r] = sum;
+    }
+  } else if (tid < TF_REC) {
+    srec[tid] = s0.grec[(size_t)blk * TF_REC + tid];
+  }
+  __syncthreads();
+  tf_coefs_bwd_block(s0, s1, srec, s1.grec ? s1.grec + (size_t)blk * TF_REC : nullptr, b, c, n, blk, tid, gb, gc, sG[0],
+                     sG[1]);
+  __syncthreads();
+  const size_t off = (size_t)blk * n * n;
+  ortho_bwd_group(tfp_lds, M + off, n, gQ ? gQ + off : nullptr, sG[0], Q ? Q + off : nullptr, s1.A ? sG[1] : nullptr,
+                  gM + off);
+}
+
+extern "C" int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, const float* grec0, int nparts0,
+                                   const float* A1, const float* inv_gamma1, const float* grec1, const float* b,
+                                   const float* c, int nblk, int nper, const float* M, const float* gQ, const float* Q,
+                                   float* gb, float* gc, float* gM, void* stream) {
+  if (!A0 || !grec0 || !b || !c || !M || !gM || nblk <= 0 || nper <= 0 || nparts0 <= 0) return GFDN_E_BADARG;
+  if (A1 && !grec1) return GFDN_E_BADARG;
+  if (nper > 4) return GFDN_E_UNSUPPORTED;
+  TfBwdSet s0{A0, inv_gamma0, grec0, nullptr};
+  TfBwdSet s1{A1, inv_gamma1, grec1, nullptr};
+  const size_t lds = ortho_bwd_lds_doubles(nper) * sizeof(double);
+  // (four wavefronts: measured 29 us against 50 with one -- the row sums want the loads of several rows in flight, and
+  // the barriers of the later stages cost nothing measurable)
+  hipLaunchKernelGGL(k_tf_param_grads, dim3(nblk), dim3(256), lds, (hipStream_t)stream, s0, s1, nparts0, b, c, nper, M, gQ,
+                     Q, gb, gc, gM);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -868,6 +959,7 @@ static int tf_gain_chunks_host(int K) {
   if (c > 32) c = 32;
   return c < 1 ? 1 : c;
 }
+extern "C" int gfdn_tf_compose_parts(int K) { return K > 0 ? tf_compose_parts_host(K) : 0; }
 extern "C" size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G) {
   if (K <= 0 || nbands <= 0 || G <= 0) return 0;
   return (size_t)nbands * G * TF_REC * tf_compose_parts_host(K) * sizeof(float);
@@ -901,13 +993,14 @@ extern "C" int gfdn_tf_compose_bwd(const double* turns, const double* logr, int 
                                    int ldh, float* grec, void* work, void* stream) {
   int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
   if (rc) return rc;
-  if (!Tsave || !gH || !grec || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
+  if (!Tsave || !gH || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
   TfCompose a{turns, logr, K, G, nper, B, coef, delays, nullptr, rgain, (const float2*)filt, ldf};
   const int nparts = tf_compose_parts_host(K);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_tf_compose_bwd_rec, dim3(nparts, nbands), dim3(256), 0, s, a, (const float2*)Tsave,
                      (const float2*)gH, ldh, (float*)work);
   GFDN_LAUNCH_CHECK();
+  if (!grec) return 0;          // the partial rows stay in work: gfdn_tf_param_grads(..., nparts0 = gfdn_tf_compose_parts(K))
   const int n0 = nbands * G * TF_REC;
   hipLaunchKernelGGL(k_tf_rows_sum, dim3((n0 + 3) / 4), dim3(256), 0, s, (const float*)work, nparts, n0, grec, n0,
                      (float*)nullptr, (float*)nullptr);

@@ -667,9 +667,11 @@ def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, wor
     return grgain
 
 
-def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=None, nbands: int = 1, work=None):
+def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=None, nbands: int = 1, work=None,
+                   partial: bool = False):
     """-> grec (nbands*G, 32): gradient records of the scaled records; ``Tsave``: the forward's saved group transfer
-    functions (tf_compose_fwd(save_T=True))."""
+    functions (tf_compose_fwd(save_T=True)).  ``partial``: skip the sum over the workgroups' partial rows and return
+    them (nbands*G, 32, parts) for ``tf_param_grads``, which sums them itself."""
     _need_gpu(turns, coef, rgain, gH, Tsave)
     coef, delays, rgain, gH, Tsave = _f(coef), _f(delays), _f(rgain), _c(gH), _c(Tsave)
     K = turns.numel()
@@ -679,13 +681,44 @@ def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=
         raise RuntimeError("tf_compose_bwd: shapes do not match nbands x G blocks")
     filt = None if filt is None else _c(filt)
     lib = _lib.load()
-    grec = torch.empty((nbands * G, 32), dtype=_f32, device=coef.device)
-    if work is None:
-        work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G), coef.device)
+    if partial:
+        grec = None
+        work = torch.empty((nbands * G, 32, lib.gfdn_tf_compose_parts(K)), dtype=_f32, device=coef.device)
+    else:
+        grec = torch.empty((nbands * G, 32), dtype=_f32, device=coef.device)
+        if work is None:
+            work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G), coef.device)
     _lib.check(lib.gfdn_tf_compose_bwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays), _p(Tsave),
                                        _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(work),
                                        _stream()), "gfdn_tf_compose_bwd")
-    return grec
+    return work if partial else grec
+
+
+def tf_param_grads(A0, ig0, grec0, b, c, M, A1=None, ig1=None, grec1=None, gQ=None, Q=None, gb=None, gc=None, gM=None):
+    """Tail of the block-transfer-function backward in one launch: ``grec0`` (nblk, 32) summed records or
+    (nblk, 32, parts) partial rows (tf_compose_bwd(partial=True)) [+ ``grec1`` (nblk, 32) of a second record set on
+    ``A1``] -> (gM, gb, gc) with the orthogonal parameterisation's adjoint folded in (``gQ``: gradient reaching Q
+    directly, ``Q``: the forward's)."""
+    _need_gpu(A0, grec0, b, c, M)
+    A0, b, c, grec0, M = _f(A0), _f(b).reshape(-1), _f(c).reshape(-1), _f(grec0), _f(M)
+    nblk, n, _ = A0.shape
+    nparts0 = 1 if grec0.dim() == 2 else grec0.shape[2]
+    if tuple(grec0.shape[:2]) != (nblk, 32) or (grec1 is not None and tuple(grec1.shape) != (nblk, 32)) \
+            or tuple(M.shape) != (nblk, n, n):
+        raise RuntimeError("tf_param_grads: records must be (nblk, 32[, parts]), M (nblk, n, n)")
+    dev = A0.device
+    ig0 = None if ig0 is None else _f(ig0).reshape(-1)
+    if A1 is not None:
+        A1, grec1 = _f(A1), _f(grec1)
+        ig1 = None if ig1 is None else _f(ig1).reshape(-1)
+    gb = torch.empty(nblk * n, dtype=_f32, device=dev) if gb is None else gb
+    gc = torch.empty(nblk * n, dtype=_f32, device=dev) if gc is None else gc
+    gM = torch.empty_like(M) if gM is None else gM
+    _lib.check(_lib.load().gfdn_tf_param_grads(_p(A0), _p(ig0), _p(grec0), nparts0, _p(A1), _p(ig1), _p(grec1), _p(b),
+                                               _p(c), nblk, n, _p(M), _p(None if gQ is None else _f(gQ)),
+                                               _p(None if Q is None else _f(Q)), _p(gb), _p(gc), _p(gM), _stream()),
+               "gfdn_tf_param_grads")
+    return gM, gb, gc
 
 
 def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):

@@ -305,6 +305,15 @@ int gfdn_tf_coefs_fwd2(const float* A0, const float* inv_gamma0, float* coef0, c
 int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const float* grec0, const float* A1,
                       const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
                       int nper, float* gA0, float* gA1, float* gb, float* gc, void* stream);
+/* The tail of the backward in one launch (one workgroup per block): [sum of the partial record rows the output-stage
+ * adjoint left in its work buffer: grec0 = that buffer, nparts0 = gfdn_tf_compose_parts(K); nparts0 = 1: grec0 (nblk,
+ * 32) summed records] -> records to (dL/dQQ, dL/dM_raw, dL/db, dL/dc) as gfdn_tf_coefs_bwd -> adjoint of
+ * Q = expm(skew(M)), QQ = Q Q as gfdn_ortho_bwd_add (gQ: a gradient that reaches Q directly, or NULL; Q: the forward's
+ * Q or NULL): gM (nblk, nper, nper), gb, gc (nblk*nper).  Bit-identical to the separate launches.  */
+int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, const float* grec0, int nparts0, const float* A1,
+                        const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
+                        int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc, float* gM,
+                        void* stream);
 int gfdn_tf_parts(int K, int nblk);
 size_t gfdn_tf_work_bytes(int nblk);
 size_t gfdn_tf_gpart_bytes(int nblk);
@@ -320,6 +329,7 @@ int gfdn_tf_compose_fwd(const double* turns, const double* logr, int K, int nban
                         const float* coef, const float* delays, const float* scale, const float* rgain, int B,
                         const float* direct_c64, int ldd, const long long* direct_rows, const float* filt_c64,
                         int ldf, float* H_c64, int ldh, float* Tsave_c64, void* stream);
+int gfdn_tf_compose_parts(int K);   /* partial rows per record entry that gfdn_tf_compose_bwd(grec = NULL) leaves in work */
 size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G);
 int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
                         const float* coef, const float* delays, const float* Tsave_c64, const float* rgain, int B,

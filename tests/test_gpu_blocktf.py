@@ -182,3 +182,40 @@ def test_ortho_bwd_add():
     base = ops.ortho_bwd(M, gQ, gQQ, Q)
     out = ops.ortho_bwd_add(M, gQ, gQQ, Q, add)
     assert torch.allclose(out, base + add, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,G,nbands,B,K,two_sets", [(4, 4, 7, 32, 4100, True), (3, 4, 2, 8, 1025, True),
+                                                      (4, 2, 1, 5, 40000, False), (2, 3, 2, 4, 600, True)])
+def test_param_grads_equals_separate_launches(n, G, nbands, B, K, two_sets):
+    """gfdn_tf_param_grads (partial-row sums + records -> dL/dA, dL/db, dL/dc + expm adjoint in one launch) against
+    compose_bwd's own row sum -> tf_coefs_bwd -> ortho_bwd_add: bit for bit."""
+    from diffgfdn_amd import hip_ops as ops
+    nblk = nbands * G
+    g = torch.Generator().manual_seed(n * 100 + G)
+    M = (0.4 * torch.randn(nblk, n, n, generator=g)).to(DEV)
+    Q, QQ = ops.ortho_fwd(M, True, True)
+    _, b, c, delays, ig = _blocks(nblk, n, 5, orth=True)
+    b, c, ig, dl = b.float().to(DEV), c.float().to(DEV), ig.float().to(DEV), delays.to(DEV)
+    z = _grid(K)
+    turns, _ = ops.zprep(z.to(DEV))
+    coef = ops.tf_coefs(QQ, b, c, ig)
+    rgain = (2 * torch.rand(nbands * B, G, generator=g) - 1).to(DEV)
+    s = (0.5 + torch.rand(nblk, generator=g)).to(DEV)
+    W = torch.randn(nbands * B, K, generator=g, dtype=torch.complex64).to(DEV)
+    R = 2 * B
+    direct = torch.randn(nbands * R, K, generator=g, dtype=torch.complex64).to(DEV)
+    rows = torch.stack([q * R + torch.randperm(R, generator=g)[:B] for q in range(nbands)]).reshape(-1).to(DEV)
+    _, Ts = ops.tf_compose_fwd(turns, None, coef, dl, n, rgain, s, direct, None, rows, nbands, save_T=True)
+    grec = ops.tf_compose_bwd(turns, None, coef, dl, n, rgain, W, Ts, None, nbands)
+    parts = ops.tf_compose_bwd(turns, None, coef, dl, n, rgain, W, Ts, None, nbands, partial=True)
+    assert parts.shape[:2] == (nblk, 32) and torch.equal(parts.sum(-1).isfinite(), torch.ones_like(grec, dtype=torch.bool))
+    gQ = torch.randn(nblk, n, n, generator=g).to(DEV)
+    grec1 = torch.randn(nblk, 32, generator=g).to(DEV) if two_sets else None
+    gQQ, gMsub, gb, gc = ops.tf_coefs_bwd(QQ, ig, grec, b, c, A1=M if two_sets else None, grec1=grec1)
+    want = ops.ortho_bwd_add(M, gQ, gQQ, Q, gMsub)
+    for g0 in (parts, grec):                         # partial rows summed in the kernel / records already summed
+        gM, gb2, gc2 = ops.tf_param_grads(QQ, ig, g0, b, c, M, A1=M if two_sets else None, grec1=grec1, gQ=gQ, Q=Q)
+        assert torch.equal(gM, want) and torch.equal(gb2, gb) and torch.equal(gc2, gc)
+    # without the forward's Q the kernel rebuilds it (float64): equal up to the rounding of the saved float32 Q
+    gM3, _, _ = ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M if two_sets else None, grec1=grec1, gQ=gQ)
+    assert torch.allclose(gM3, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
