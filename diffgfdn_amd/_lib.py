@@ -60,6 +60,7 @@ SIGNATURES = {
     "gfdn_subfdn_colorless_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_tf_coefs_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     "gfdn_tf_coefs_fwd2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "gfdn_tf_ortho_coefs": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_coefs_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_param_grads": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_tf_parts": (c_int, [c_int, c_int]),

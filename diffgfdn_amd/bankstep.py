@@ -7,7 +7,7 @@ sub-FDN forward, b, c /= E^(1/4)), forward (model.py:569-625), losses (trainer.p
 feedback loop only through the group transfer functions T_g(z) -- ratios of multilinear polynomials in the phasors
 z^{m_i} with 2 x 16 real coefficients per block -- so the step is
 
-    main  : Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g -> energy pass -> finish (normalize: b, c
+    main  : [Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g: one launch] -> energy pass -> finish (normalize: b, c
             rescaled in place, scale_g) -> output stage H -> irfft -> STFT -> EDR -> STFT adjoint (even frames, then
             odd frames + EDC gradient) -> irfft adjoint -> output-stage adjoint (dL/dgains, then dL/drecords)
             -> records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint -> [all-reduce] -> Adam
@@ -217,8 +217,7 @@ class FusedBankStep:
         # than the 10 us they take.  Captured BEFORE the fork below: the graph lays its hardware queues out along a
         # depth-first walk of the nodes in capture order, and the chain captured first keeps its queue through every
         # later join -- a chain that changes queue pays ~10 us per change)
-        Q, QQ = ops.ortho_fwd(M, True, True)
-        coef, coef_sub = ops.tf_coefs2(QQ, ig, M, None, b, c)
+        Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
         with on_side2():
             torch.cuda.current_stream().wait_event(ev['start'])
             rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G,

@@ -135,13 +135,14 @@ __device__ double tf_det(const double* a, const int* ri, const int* ci, int t) {
 }
 
 // sA[0] = A (zero-padded 4 x 4), sA[1] = A - b c^T, sig[i] = 1 / gamma_i, all float64
-__device__ __forceinline__ void tf_stage_block(const float* __restrict__ A, const float* __restrict__ b,
+// (Ablk: the block's n x n matrix, global or LDS)
+__device__ __forceinline__ void tf_stage_block(const float* Ablk, const float* __restrict__ b,
                                                const float* __restrict__ c, const float* __restrict__ ig,
                                                int blk, int n, int tid, double (*sA)[16], double* sig) {
   if (tid < 16) {
     const int i = tid >> 2, j = tid & 3;
     const bool in = i < n && j < n;
-    const double a = in ? (double)A[(size_t)blk * n * n + i * n + j] : 0.0;
+    const double a = in ? (double)Ablk[i * n + j] : 0.0;
     const double bc = in ? (double)b[blk * n + i] * (double)c[blk * n + j] : 0.0;
     sA[0][tid] = a;
     sA[1][tid] = a - bc;
@@ -149,40 +150,84 @@ __device__ __forceinline__ void tf_stage_block(const float* __restrict__ A, cons
   if (tid < 4) sig[tid] = (tid < n && ig) ? (double)ig[blk * n + tid] : 1.0;
 }
 
-// blocks [0, nblk): set 0 (A0, ig0 -> coef0); blocks [nblk, 2 nblk): set 1 (A1, ig1 -> coef1), same b, c
-__global__ __launch_bounds__(64) void k_tf_coefs(const float* __restrict__ A0, const float* __restrict__ ig0,
-                                                 float* __restrict__ coef0, const float* __restrict__ A1,
-                                                 const float* __restrict__ ig1, float* __restrict__ coef1,
-                                                 const float* __restrict__ b, const float* __restrict__ c,
-                                                 int nblk, int n) {
-  __shared__ double sA[2][16], sq[2][16], sig[4];
-  const bool second = (int)blockIdx.x >= nblk;
-  const int blk = second ? blockIdx.x - nblk : blockIdx.x, tid = threadIdx.x;
-  const float* A = second ? A1 : A0;
-  const float* ig = second ? ig1 : ig0;
-  float* coef = second ? coef1 : coef0;
-  tf_stage_block(A, b, c, ig, blk, n, tid, sA, sig);
+// Records of block blk for one or two sets (A1blk = NULL: one) sharing b, c, by threads tid < 64 of a workgroup (every
+// thread must call it: barriers).  A0blk / A1blk: the block's matrices (global or LDS).
+__device__ __forceinline__ void tf_coefs_block(const float* A0blk, const float* __restrict__ ig0,
+                                               float* __restrict__ coef0, const float* A1blk,
+                                               const float* __restrict__ ig1, float* __restrict__ coef1,
+                                               const float* __restrict__ b, const float* __restrict__ c, int blk, int n,
+                                               int tid) {
+  __shared__ double sA[2][2][16], sq[2][2][16], sig[2][4];
+  const int nsets = A1blk ? 2 : 1;
+  if (tid < 64) {
+    tf_stage_block(A0blk, b, c, ig0, blk, n, tid, sA[0], sig[0]);
+    if (nsets == 2) tf_stage_block(A1blk, b, c, ig1, blk, n, tid, sA[1], sig[1]);
+  }
   __syncthreads();
-  if (tid < 32) {
-    const int v = tid >> 4, S = tid & 15;
+  if (tid < 32 * nsets) {
+    const int st = tid >> 5, v = (tid >> 4) & 1, S = tid & 15;
     double q = 0.0;
     if ((S >> n) == 0) {
       int T[4], t = 0;
       for (int i = 0; i < n; ++i)
         if (!((S >> i) & 1)) T[t++] = i;
-      q = tf_det(sA[v], T, T, t);
+      q = tf_det(sA[st][v], T, T, t);
       if (t & 1) q = -q;
     }
-    sq[v][S] = q;
+    sq[st][v][S] = q;
   }
   __syncthreads();
-  if (tid < 16) {
+  if (tid < 32 * nsets && (tid & 31) < 16) {
+    const int st = tid >> 5, S = tid & 15;
     double igp = 1.0;
     for (int i = 0; i < 4; ++i)
-      if ((tid >> i) & 1) igp *= sig[i];
-    coef[(size_t)blk * TF_REC + tid] = (float)((sq[1][tid] - sq[0][tid]) * igp);
-    coef[(size_t)blk * TF_REC + 16 + tid] = (float)(sq[0][tid] * igp);
+      if ((S >> i) & 1) igp *= sig[st][i];
+    float* coef = st ? coef1 : coef0;
+    coef[(size_t)blk * TF_REC + S] = (float)((sq[st][1][S] - sq[st][0][S]) * igp);
+    coef[(size_t)blk * TF_REC + 16 + S] = (float)(sq[st][0][S] * igp);
   }
+}
+
+// workgroup blk < nblk: the records of block blk for set 0 (A0, ig0 -> coef0) and, with A1, set 1 (A1, ig1 -> coef1)
+__global__ __launch_bounds__(64) void k_tf_coefs(const float* __restrict__ A0, const float* __restrict__ ig0,
+                                                 float* __restrict__ coef0, const float* __restrict__ A1,
+                                                 const float* __restrict__ ig1, float* __restrict__ coef1,
+                                                 const float* __restrict__ b, const float* __restrict__ c, int n) {
+  const int blk = blockIdx.x;
+  tf_coefs_block(A0 + (size_t)blk * n * n, ig0, coef0, A1 ? A1 + (size_t)blk * n * n : nullptr, ig1, coef1, b, c, blk, n,
+                 threadIdx.x);
+}
+
+// Head of the band bank's step in ONE launch, one workgroup per group: Q = expm(skew(M)), QQ = Q Q (k_ortho_fwd), then
+// the records of the damped loop (A = QQ with 1 / gamma -> coef0) and of the sub-FDN (A = raw M -> coef1) as k_tf_coefs;
+// QQ passes through its float32 rounding in between, so the records equal those of the two separate launches bit for bit.
+__global__ __launch_bounds__(256) void k_tf_ortho_coefs(const float* __restrict__ M, int n, const float* __restrict__ ig0,
+                                                        const float* __restrict__ b, const float* __restrict__ c,
+                                                        float* __restrict__ Q, float* __restrict__ QQ,
+                                                        float* __restrict__ coef0, float* __restrict__ coef1) {
+  extern __shared__ double tfh_lds[];
+  __shared__ float lQQ[16];
+  double* A = tfh_lds;
+  double* P = A + n * n;
+  double* R = P + n * n;
+  double* T = R + n * n;
+  double* tmp = T + n * n;
+  const int blk = blockIdx.x;
+  const float* Mg = M + (size_t)blk * n * n;
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) A[e] = skew_elem(Mg, n, e / n, e % n);
+  __syncthreads();
+  const double* E = expm_lds(A, P, R, T, tmp, n);
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    Q[(size_t)blk * n * n + e] = (float)E[e];
+    const int i = e / n, j = e - i * n;
+    double acc = 0.0;
+    for (int q = 0; q < n; ++q) acc += E[i * n + q] * E[q * n + j];
+    const float v = (float)acc;
+    QQ[(size_t)blk * n * n + e] = v;
+    lQQ[e] = v;
+  }
+  __syncthreads();
+  tf_coefs_block(lQQ, ig0, coef0, coef1 ? Mg : nullptr, nullptr, coef1, b, c, blk, n, threadIdx.x);
 }
 
 extern "C" int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c, const float* inv_gamma,
@@ -190,7 +235,7 @@ extern "C" int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c,
   if (!A || !b || !c || !coef || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4) return GFDN_E_UNSUPPORTED;
   hipLaunchKernelGGL(k_tf_coefs, dim3(nblk), dim3(64), 0, (hipStream_t)stream, A, inv_gamma, coef, (const float*)nullptr,
-                     (const float*)nullptr, (float*)nullptr, b, c, nblk, nper);
+                     (const float*)nullptr, (float*)nullptr, b, c, nper);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -201,8 +246,19 @@ extern "C" int gfdn_tf_coefs_fwd2(const float* A0, const float* inv_gamma0, floa
                                   int nper, void* stream) {
   if (!A0 || !A1 || !b || !c || !coef0 || !coef1 || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4) return GFDN_E_UNSUPPORTED;
-  hipLaunchKernelGGL(k_tf_coefs, dim3(2 * nblk), dim3(64), 0, (hipStream_t)stream, A0, inv_gamma0, coef0, A1, inv_gamma1,
-                     coef1, b, c, nblk, nper);
+  hipLaunchKernelGGL(k_tf_coefs, dim3(nblk), dim3(64), 0, (hipStream_t)stream, A0, inv_gamma0, coef0, A1, inv_gamma1,
+                     coef1, b, c, nper);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_tf_ortho_coefs(const float* M, const float* inv_gamma, const float* b, const float* c, int nblk,
+                                   int nper, float* Q, float* QQ, float* coef, float* coef_sub, void* stream) {
+  if (!M || !b || !c || !Q || !QQ || !coef || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 4) return GFDN_E_UNSUPPORTED;
+  const size_t lds = ((size_t)4 * nper * nper + nper + 2) * sizeof(double);
+  hipLaunchKernelGGL(k_tf_ortho_coefs, dim3(nblk), dim3(256), lds, (hipStream_t)stream, M, nper, inv_gamma, b, c, Q, QQ,
+                     coef, coef_sub);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -226,8 +282,8 @@ __device__ __forceinline__ void tf_coefs_bwd_block(const TfBwdSet& s0, const TfB
   __shared__ double sA[2][2][16], sig[2][4], sgq[2][2][16], sgA[2][2][16], spart[4][64];
   const int nsets = s1.A ? 2 : 1;
   if (tid < 64) {
-    tf_stage_block(s0.A, b, c, s0.ig, blk, n, tid, sA[0], sig[0]);
-    if (nsets == 2) tf_stage_block(s1.A, b, c, s1.ig, blk, n, tid, sA[1], sig[1]);
+    tf_stage_block(s0.A + (size_t)blk * n * n, b, c, s0.ig, blk, n, tid, sA[0], sig[0]);
+    if (nsets == 2) tf_stage_block(s1.A + (size_t)blk * n * n, b, c, s1.ig, blk, n, tid, sA[1], sig[1]);
   }
   __syncthreads();
   if (tid < 32 * nsets) {

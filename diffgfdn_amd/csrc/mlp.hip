@@ -118,6 +118,84 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Layers of at most 64 neurons (the north-star network: 120 -> 16 x 6 -> 4): ONE WAVEFRONT per receiver, MLP_RB
+// receivers per workgroup, the packed parameters staged in LDS once per workgroup.  A receiver's layer chain is a
+// serial string of 16-wide steps: on a 256-thread workgroup per receiver every step pays block barriers and two block
+// reductions; here they are wave-level (the LDS traffic of one wave executes in order).  Same arithmetic, same order.
+// ------------------------------------------------------------------------------------------
+#define MLP_RB 8
+// LDS hand-over between the lanes of ONE wavefront: its LDS operations execute in order, so all that is needed is that
+// the writes have been issued (lgkmcnt) and that the compiler keeps the order.  Deliberately NOT a fence: a release
+// fence also waits for the wave's outstanding GLOBAL stores (vmcnt counts stores on gfx9) -- a write round trip per use.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_fwd_waves(MlpDims d, const double* __restrict__ pos,
+                                                               const float* __restrict__ freq_pi,
+                                                               const float* __restrict__ w,
+                                                               float* __restrict__ gains,     // (B, G)
+                                                               float* __restrict__ xhat,      // (B, nl, H)
+                                                               float* __restrict__ rstd) {    // (B, nl)
+  // a few workgroups of dependent 16-wide steps, launched beside kernels that fill every SIMD with VALU work (the
+  // energy pass; the output-stage adjoint): without priority the chain advances at the SIMD's round-robin share
+  __builtin_amdgcn_s_setprio(3);
+  const int H = d.H, nl = d.nl, P = (int)mlp_param_count(d);
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int b = blockIdx.x * MLP_RB + r;
+  const int amax = d.in_dim > H ? d.in_dim : H;
+  float* wl = mlp_lds;
+  float* a = wl + P + (size_t)r * (amax + nl * H + nl);      // this receiver's current activations
+  float* xs = a + amax;                          // saved activations: collected here, written once at the end
+  float* rsv = xs + nl * H;
+  w += (size_t)(b / d.Bper) * P;                 // (all receivers of a workgroup belong to one band)
+  for (int p = threadIdx.x; p < P; p += blockDim.x) wl[p] = w[p];
+  {
+    const double* pp = pos + (d.rows ? (size_t)d.rows[b] : (size_t)b) * 3;
+    for (int e = lane; e < d.in_dim; e += 64) {
+      const int k = e / 6, q = e - 6 * k;
+      const double arg = (double)freq_pi[k] * pp[q % 3];
+      a[e] = (float)(q < 3 ? sin(arg) : cos(arg));
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < nl; ++l) {
+    const int n_in = l == 0 ? d.in_dim : H;
+    const float* W = wl + mlp_layer_off(d, l);
+    const float* bias = W + (size_t)H * n_in;
+    const float* gamma = bias + H;
+    const float* beta = gamma + H;
+    float hv = 0.f;
+    if (lane < H) {
+      hv = bias[lane];
+      for (int i = 0; i < n_in; ++i) hv += W[(size_t)lane * n_in + i] * a[i];
+    }
+    const float mean = wave_sum(lane < H ? hv : 0.f) / (float)H;
+    const float dv = lane < H ? hv - mean : 0.f;
+    const float var = wave_sum(dv * dv) / (float)H;
+    const float rs = rsqrtf(var + LN_EPS);
+    wave_lds_sync();                             // every lane has read a[] of this layer
+    if (lane < H) {
+      const float xh = dv * rs;
+      xs[l * H + lane] = xh;
+      a[lane] = fmaxf(xh * gamma[lane] + beta[lane], 0.f);
+    }
+    if (lane == 0) rsv[l] = rs;
+    wave_lds_sync();
+  }
+  const float* Wout = wl + mlp_layer_off(d, nl);
+  const float* bout = Wout + (size_t)d.G * H;
+  if (lane < d.G) {
+    float raw = bout[lane];
+    for (int i = 0; i < H; ++i) raw += Wout[(size_t)lane * H + i] * a[i];
+    gains[(size_t)b * d.G + lane] = d.hi > d.lo ? d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw))) : raw;
+  }
+  for (int p = lane; p < nl * H; p += 64) xhat[(size_t)b * nl * H + p] = xs[p];
+  if (lane < nl) rstd[(size_t)b * nl + lane] = rsv[lane];
+}
+
 __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __restrict__ pos,
                                                    const float* __restrict__ freq_pi,
                                                    const float* __restrict__ w,
@@ -238,20 +316,11 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward for layers of at most 64 neurons (the north-star network: 120 -> 16 x 6 -> 4): ONE WAVEFRONT per
-// receiver, MLP_RB receivers per workgroup.  The layer chain of a receiver is a serial string of 16-wide steps;
-// on a 256-thread workgroup every step pays block barriers and two block reductions, here they are wave-level
-// (LDS traffic of one wave executes in order).  The chain only leaves per-layer vectors in LDS (activations
+// Backward, one wavefront per receiver as k_mlp_fwd_waves.  The chain only leaves per-layer vectors in LDS (activations
 // entering the layer, dL/d(linear output), dL/d(affine output)); the parameter gradients are outer products of
 // those, assembled at the end by the whole workgroup and summed over its receivers in a fixed order: one partial
 // row per workgroup instead of one per receiver for the reduction pass.
 // ------------------------------------------------------------------------------------------
-#define MLP_RB 8
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __host__ __device__ static inline int mlp_rb_stride(const MlpDims& d) {
   // per receiver: A0 (in_dim) | A (nl, H) | XH (nl, H) | DH (nl, H) | DY (nl, H) | RS (nl) | DRAW (G)
   return d.in_dim + 4 * d.nl * d.H + d.nl + d.G;
@@ -265,6 +334,7 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const 
                                                                const float* __restrict__ rstd,
                                                                const float* __restrict__ ggains,   // (B, G)
                                                                float* __restrict__ partial) {      // (B / MLP_RB, P)
+  __builtin_amdgcn_s_setprio(3);                 // (as k_mlp_fwd_waves)
   const int H = d.H, G = d.G, nl = d.nl, P = (int)mlp_param_count(d);
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int b = blockIdx.x * MLP_RB + r;
@@ -450,6 +520,16 @@ extern "C" int gfdn_mlp_gains_banded_fwd(const double* pos, const long long* pos
   d.Bper = Bper;
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd) return GFDN_E_BADARG;
+  if (d.stage && H <= 64 && G <= 64 && Bper % MLP_RB == 0) {
+    const int amax = d.in_dim > H ? d.in_dim : H;
+    const size_t lds = (mlp_param_count(d) + (size_t)MLP_RB * (amax + d.nl * H + d.nl)) * sizeof(float);
+    rc = ensure_dyn_lds(k_mlp_fwd_waves, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mlp_fwd_waves, dim3(B / MLP_RB), dim3(64 * MLP_RB), lds, (hipStream_t)stream, d, pos, freq_pi, w,
+                       gains, xhat, rstd);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_mlp_fwd, dim3(B), dim3(mlp_threads(d)), mlp_lds_bytes(d), (hipStream_t)stream, d, pos,
                      freq_pi, w, gains, xhat, rstd);
   GFDN_LAUNCH_CHECK();

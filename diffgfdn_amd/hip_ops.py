@@ -721,6 +721,21 @@ def tf_param_grads(A0, ig0, grec0, b, c, M, A1=None, ig1=None, grec1=None, gQ=No
     return gM, gb, gc
 
 
+def tf_ortho_coefs(M, ig, b, c, sub: bool = True):
+    """Head of the block-transfer-function step in one launch: (Q, QQ, coef of (QQ, 1 / gamma), coef_sub of (M, 1) or
+    None) -- ``ortho_fwd`` + ``tf_coefs2`` with the same numbers."""
+    _need_gpu(M, b, c)
+    M, b, c = _f(M), _f(b).reshape(-1), _f(c).reshape(-1)
+    nblk, n, _ = M.shape
+    ig = None if ig is None else _f(ig).reshape(-1)
+    Q, QQ = torch.empty_like(M), torch.empty_like(M)
+    coef = torch.empty((nblk, 32), dtype=_f32, device=M.device)
+    coef_sub = torch.empty((nblk, 32), dtype=_f32, device=M.device) if sub else None
+    _lib.check(_lib.load().gfdn_tf_ortho_coefs(_p(M), _p(ig), _p(b), _p(c), nblk, n, _p(Q), _p(QQ), _p(coef),
+                                               _p(coef_sub), _stream()), "gfdn_tf_ortho_coefs")
+    return Q, QQ, coef, coef_sub
+
+
 def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):
     """Gradient records -> (gA0, gA1 or None, gb, gc); b, c: the gains the records' gradients refer to."""
     _need_gpu(A0, grec0, b, c)

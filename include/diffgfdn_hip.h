@@ -302,6 +302,11 @@ int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c, const floa
 int gfdn_tf_coefs_fwd2(const float* A0, const float* inv_gamma0, float* coef0, const float* A1,
                        const float* inv_gamma1, float* coef1, const float* b, const float* c, int nblk, int nper,
                        void* stream);
+/* Head of the step in one launch (one workgroup per block): Q = expm(skew(M)), QQ = Q Q as gfdn_ortho_fwd, then the
+ * records of (QQ, inv_gamma) -> coef and, with coef_sub != NULL, of (M, gamma = 1) -> coef_sub as gfdn_tf_coefs_fwd2.
+ * M, Q, QQ (nblk, nper, nper).  Bit-identical to the separate launches.  */
+int gfdn_tf_ortho_coefs(const float* M, const float* inv_gamma, const float* b, const float* c, int nblk, int nper,
+                        float* Q, float* QQ, float* coef, float* coef_sub, void* stream);
 int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const float* grec0, const float* A1,
                       const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
                       int nper, float* gA0, float* gA1, float* gb, float* gc, void* stream);

@@ -219,3 +219,20 @@ def test_param_grads_equals_separate_launches(n, G, nbands, B, K, two_sets):
     # without the forward's Q the kernel rebuilds it (float64): equal up to the rounding of the saved float32 Q
     gM3, _, _ = ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M if two_sets else None, grec1=grec1, gQ=gQ)
     assert torch.allclose(gM3, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("n,nblk", [(4, 28), (3, 5), (2, 4), (1, 3)])
+def test_ortho_coefs_equals_separate_launches(n, nblk):
+    """gfdn_tf_ortho_coefs (expm + both record sets in one launch) against ortho_fwd -> tf_coefs2: bit for bit."""
+    from diffgfdn_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(n)
+    M = (0.5 * torch.randn(nblk, n, n, generator=g)).to(DEV)
+    _, b, c, _, ig = _blocks(nblk, n, 9, orth=True)
+    b, c, ig = b.float().to(DEV), c.float().to(DEV), ig.float().to(DEV)
+    Q0, QQ0 = ops.ortho_fwd(M, True, True)
+    c0, c1 = ops.tf_coefs2(QQ0, ig, M, None, b, c)
+    Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
+    assert torch.equal(Q, Q0) and torch.equal(QQ, QQ0) and torch.equal(coef, c0) and torch.equal(coef_sub, c1)
+    _, _, coef_only, none = ops.tf_ortho_coefs(M, ig, b, c, sub=False)
+    assert none is None and torch.equal(coef_only, c0)
+    assert torch.equal(ops.tf_coefs(QQ0, b, c, ig), c0)

@@ -1,35 +1,45 @@
-"""Time variants of the MLP kernels (diagnostic): python tools/mlp_probe.py  (variants built by tools/build_mlp_variants.sh)"""
-import ctypes, glob, os, sys, time
-import torch
+"""Hot-loop timing of the small kernels of the step (diagnostic): back-to-back launches, HIP events."""
+import os, sys, time
+import torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-P = ctypes.c_void_p
+from diffgfdn_amd import hip_ops as ops
 dev = torch.device('cuda', 0)
-B, F, H, nh, G = 32, 20, 16, 5, 4
-torch.manual_seed(0)
-pos = torch.rand(838, 3, dtype=torch.float64, device=dev)
-rows = torch.randint(0, 838, (B,), device=dev)
-freq = (torch.exp(torch.linspace(0, 3.4657, F, device=dev)) * 3.14159265).float()
-def p(t): return None if t is None else ctypes.c_void_p(t.data_ptr())
-for so in sorted(glob.glob(os.path.join(os.path.dirname(__file__), '_probe', 'mlp_*.so'))):
-    lib = ctypes.CDLL(so)
-    lib.gfdn_mlp_param_count.restype = ctypes.c_size_t
-    lib.gfdn_mlp_param_count.argtypes = [ctypes.c_int] * 4
-    lib.gfdn_mlp_bwd_work_bytes.restype = ctypes.c_size_t
-    lib.gfdn_mlp_bwd_work_bytes.argtypes = [ctypes.c_int] * 5
-    n = lib.gfdn_mlp_param_count(F, H, nh, G)
-    w = (0.2 * torch.randn(n, device=dev)).float()
-    gains = torch.empty(B, G, device=dev); xhat = torch.empty(B, nh + 1, H, device=dev); rstd = torch.empty(B, nh + 1, device=dev)
-    gg = torch.randn(B, G, device=dev); gw = torch.empty_like(w)
-    work = torch.empty(lib.gfdn_mlp_bwd_work_bytes(B, F, H, nh, G) // 4, device=dev)
-    lib.gfdn_mlp_gains_fwd.argtypes = [P, P, P, P] + [ctypes.c_int] * 5 + [ctypes.c_float] * 2 + [P] * 4
-    lib.gfdn_mlp_gains_bwd.argtypes = [P, P, P, P] + [ctypes.c_int] * 5 + [ctypes.c_float] * 2 + [P] * 7
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    def fwd(): assert lib.gfdn_mlp_gains_fwd(p(pos), p(rows), p(freq), p(w), B, F, H, nh, G, -1.0, 1.0, p(gains), p(xhat), p(rstd), st) == 0
-    def bwd(): assert lib.gfdn_mlp_gains_bwd(p(pos), p(rows), p(freq), p(w), B, F, H, nh, G, -1.0, 1.0, p(gains), p(xhat), p(rstd), p(gg), p(gw), p(work), st) == 0
-    res = []
-    for fn in (fwd, bwd):
-        for _ in range(20): fn()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(500): fn()
-        torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 500 * 1e6)
-    print(f"{os.path.basename(so):28s} fwd {res[0]:6.1f} us  bwd(+reduce) {res[1]:6.1f} us  gains[0]={gains[0].tolist()}", flush=True)
+nb, Bper, G, F, H, nh = 7, 32, 4, 20, 16, 5
+B = nb * Bper
+g = torch.Generator().manual_seed(0)
+P = ops._lib.load().gfdn_mlp_param_count(F, H, nh, G)
+w = (0.3 * torch.randn(nb, P, generator=g)).to(dev)
+R = 838
+pos = torch.rand(nb * R, 3, generator=g, dtype=torch.float64).to(dev)
+rows = torch.stack([q * R + torch.randperm(R, generator=g)[:Bper] for q in range(nb)]).reshape(-1).to(dev)
+fpi = (torch.exp(torch.linspace(0, np.log(32.0), F)) * np.pi).to(dev)
+big = torch.empty(512 * 1024 * 1024 // 4, device=dev)
+
+def timeit(fn, n=200, flush=False):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    if not flush:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+    tot = 0.0
+    for _ in range(20):
+        big.add_(1.0)                      # 1 GB of traffic: caches and TLBs cold
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1) * 1e3
+    return tot / 20
+
+gains, xhat, rstd = ops.mlp_gains_fwd(pos, fpi, w, H, nh, G, -1.0, 1.0, rows, nbands=nb)
+gg = torch.randn(B, G, generator=g).to(dev)
+out = torch.empty(nb, P, device=dev)
+M = (0.4 * torch.randn(nb * G, 4, 4, generator=g)).to(dev)
+b = torch.randn(nb * G * 4, generator=g).to(dev); c = torch.randn(nb * G * 4, generator=g).to(dev)
+ig = (1.0 + 0.01 * torch.rand(nb * G * 4, generator=g)).to(dev)
+for name, fn in [('mlp_fwd', lambda: ops.mlp_gains_fwd(pos, fpi, w, H, nh, G, -1.0, 1.0, rows, nbands=nb)),
+                 ('mlp_bwd', lambda: ops.mlp_gains_bwd(pos, fpi, w, H, nh, G, -1.0, 1.0, gains, xhat, rstd, gg, rows, nbands=nb, out=out)),
+                 ('ortho_coefs', lambda: ops.tf_ortho_coefs(M, ig, b, c)),
+                 ('empty-ish (fill 64 floats)', lambda: out[0, :64].zero_())]:
+    print(f"{name:28s} hot {timeit(fn):7.2f} us   cold {timeit(fn, flush=True):7.2f} us")
