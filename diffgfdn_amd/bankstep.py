@@ -160,12 +160,13 @@ class FusedBankStep:
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, data: Dict, maskw: Optional[torch.Tensor], inv: float, normalize_first: bool, train: bool,
-            allreduce=None, opt_step: bool = True, mask_draw=None) -> Dict:
+            allreduce=None, opt_step: bool = True, mask_draw=None, tail=None) -> Dict:
         """One step of every band on the band-major batch ``data`` (collate(lean="rows")).  ``maskw``: EDC time
         weights (None: no mask), ``inv``: what the EDC terms are divided by beyond the weights (1 when the weights are
         pre-normalised).  ``train``: gradients into the flat buffer, [all-reduce,] Adam (``opt_step=False`` stops in front
         of the all-reduce: the caller runs it and the update).  ``mask_draw``: callable that fills ``maskw`` on the
-        device (run on the EDC stream, off the path to the output stage).  Returns the loss dict of
+        device (run on the EDC stream, off the path to the output stage).  ``tail``: callable run on the side stream
+        behind the last reader of the batch's receiver indices (GraphedTrainStep fetches the next step's there).  Returns the loss dict of
         ``BandBankTrainer._step_losses`` (+ '_total').
 
         Scheduling rules (measured on the replayed graph, profiles/): a dependency that crosses streams costs
@@ -281,6 +282,9 @@ class FusedBankStep:
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
                 ev['mlpb'].record()
+                if tail is not None:
+                    tail()                # (every reader of ``rows`` is ordered before this point: main's are in
+                                          # front of ev['grg'], this stream's are its own earlier launches)
             main.wait_event(ev['side'])
             # records (partial rows of the records pass + the colorless pass's) -> dL/dM, dL/db, dL/dc: one launch
             ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,

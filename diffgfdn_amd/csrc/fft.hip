@@ -1384,9 +1384,13 @@ __device__ __forceinline__ void s4k_load_pair(const float2* __restrict__ x2, int
   }
 }
 
+// wave priority of the pair STFT kernels (they are the main chain; the colorless pass and the EDC scans that run beside
+// them have slack)
+#define STFT_PAIR_PRIO 0
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power(const float2* __restrict__ x2, int ld, int T,
                                                              int nframes, int items, float* __restrict__ P,
                                                              float2* __restrict__ zero_buf) {
+  if (STFT_PAIR_PRIO) __builtin_amdgcn_s_setprio(STFT_PAIR_PRIO);
   float2* buf = dyn_lds;
   const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
@@ -1424,6 +1428,7 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
                                                                  const float* __restrict__ gP,
                                                                  const float2* base2, float2* gx2, int parity,
                                                                  int late_base) {
+  if (STFT_PAIR_PRIO) __builtin_amdgcn_s_setprio(STFT_PAIR_PRIO);
   float2* buf = dyn_lds;
   const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;

@@ -88,3 +88,26 @@ extern "C" int gfdn_adam_step_counted(float* p, const float* g, float* m, float*
   if (!block_counter) return GFDN_E_BADARG;
   return adam_step_run(p, g, m, v, seg, lr_seg, step_count, n, beta1, beta2, eps, block_counter, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// Receiver schedule of a graph-replayed epoch (trainer.py:373-379: the DataLoader fixes the batches of an epoch when
+// the epoch starts).  The host uploads the epoch's batches once -- table (len, B) of dataset rows -- and every replayed
+// step ends with this launch: idx <- table[pos mod len], pos <- pos + 1, on the device.  The next step then finds its
+// receivers in the static index buffer without a host copy in front of it.
+// state[0] = pos, state[1] = len (>= 1).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pick_rows(const long long* __restrict__ table, long long* __restrict__ state,
+                                                   long long* __restrict__ idx, int B) {
+  const long long len = state[1] > 0 ? state[1] : 1;
+  const long long row = state[0] % len;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) idx[i] = table[row * B + i];
+  __syncthreads();
+  if (threadIdx.x == 0) state[0] = state[0] + 1;
+}
+
+extern "C" int gfdn_pick_rows(const long long* table, long long* state, long long* idx, int B, void* stream) {
+  if (!table || !state || !idx || B <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(256), 0, (hipStream_t)stream, table, state, idx, B);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

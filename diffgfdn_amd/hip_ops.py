@@ -1283,3 +1283,13 @@ class KernelTimer:
 
 
 kernel_timer = KernelTimer()
+
+
+def pick_rows(table, state, idx):
+    """idx <- table[state[0] mod state[1]]; state[0] += 1 (device-side; one launch).  table (len, B) int64."""
+    _need_gpu(table, state, idx)
+    if table.dtype != torch.long or state.dtype != torch.long or idx.dtype != torch.long or table.dim() != 2 \
+            or table.shape[1] != idx.numel() or state.numel() != 2 or not table.is_contiguous():
+        raise RuntimeError("pick_rows: table (len, B) int64 contiguous, state (2) int64, idx (B) int64")
+    _lib.check(_lib.load().gfdn_pick_rows(_p(table), _p(state), _p(idx), idx.numel(), _stream()), "gfdn_pick_rows")
+    return idx

@@ -773,6 +773,48 @@ class GraphedTrainStep:
         self.mask_seed = int(mask_seed)
         self.graph_a = self.graph_b = None
         self.losses = None
+        # receiver schedule (load_schedule / run_next): the batches of an epoch live on the device and every step ends
+        # by fetching the next step's receivers into ``idx`` -- no host copy in front of a replay
+        self.sched_cap = 1024
+        self.sched = torch.zeros((self.sched_cap, batch_size), dtype=torch.long, device=dev)
+        self.sched_state = torch.tensor([0, 1], dtype=torch.long, device=dev)        # {position, length}
+
+    # -- receiver schedule --------------------------------------------------------------------
+    def _pick_next(self):
+        ops.pick_rows(self.sched, self.sched_state, self.idx)
+
+    def load_schedule(self, batches):
+        """Upload the receivers of the next ``len(batches)`` steps (each ``batch_size`` dataset rows; at most
+        ``sched_cap`` steps) and point the step at the first of them; ``run_next()`` then replays one step per call.
+        The reference's DataLoader likewise fixes an epoch's batches when the epoch starts (trainer.py:373-379)."""
+        t = torch.as_tensor([list(b) for b in batches], dtype=torch.long)
+        n = t.shape[0]
+        if n == 0 or n > self.sched_cap or t.shape[1] != self.B:
+            raise ValueError(f"load_schedule: 1..{self.sched_cap} batches of {self.B} receivers")
+        self.sched[:n].copy_(t)
+        self.sched_state.copy_(torch.tensor([0, n], dtype=torch.long))
+        self._pick_next()                                 # idx <- first batch, position 1
+        return n
+
+    def run_next(self):
+        """One optimiser step on the next batch of the loaded schedule (wraps around at its end); returns the static
+        loss tensors (valid until the next step)."""
+        if self.graph_a is None:
+            self.capture(None)
+        self._load_inputs(None)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self.tr._allreduce()
+            self.graph_b.replay()
+        return self.losses
+
+    def run_schedule(self, batches):
+        """Generator over the steps of ``batches`` (any number: uploaded in chunks of ``sched_cap``)."""
+        batches = list(batches)
+        for i0 in range(0, len(batches), self.sched_cap):
+            n = self.load_schedule(batches[i0:i0 + self.sched_cap])
+            for _ in range(n):
+                yield self.run_next()
 
     # -- pieces -------------------------------------------------------------------------------
     def _fwd_bwd(self):
@@ -800,7 +842,7 @@ class GraphedTrainStep:
             draw = lambda: ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
         batch = self.ds.collate(self.idx, lean="rows")
         return tr._fused.run(batch, self.maskw, 1.0, normalize_first=True, train=True, allreduce=tr._allreduce,
-                             opt_step=opt_step, mask_draw=draw)
+                             opt_step=opt_step, mask_draw=draw, tail=self._pick_next)
 
     def _eager(self):
         if getattr(self.tr, '_fused', None) is not None:
@@ -810,6 +852,7 @@ class GraphedTrainStep:
         if self.tr._allreduce is not None:
             self.tr._allreduce()
         self.tr.optimizer.step()
+        self._pick_next()
         return losses
 
     # -- capture ------------------------------------------------------------------------------
@@ -819,6 +862,7 @@ class GraphedTrainStep:
         tr = self.tr
         rng_state = torch.get_rng_state()                  # capture is RNG-neutral
         self._load_inputs(indices)
+        saved_sched = (self.sched_state.clone(), self.idx.clone())     # (the warm-up steps advance the schedule)
         params = [p for p in tr.net.parameters()]
         saved_p = [p.detach().clone() for p in params]
         state_tensors = tr.optimizer.state_tensors
@@ -838,6 +882,8 @@ class GraphedTrainStep:
                 for t in state_tensors():
                     t.zero_()                              # fresh Adam state: zeros, step 0
             self.mask_state.zero_()
+            self.sched_state.copy_(saved_sched[0])
+            self.idx.copy_(saved_sched[1])
             tr.optimizer.zero_grad(set_to_none=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -857,6 +903,7 @@ class GraphedTrainStep:
                     if tr._allreduce is not None:
                         tr._allreduce()
                     tr.optimizer.step()
+                    self._pick_next()
         else:
             # forward + backward + pack | all-reduce of the gradient bucket (eager RCCL) | Adam
             with torch.cuda.graph(self.graph_a):
@@ -872,6 +919,7 @@ class GraphedTrainStep:
                     self._apply_reduced(red)
                 else:
                     tr.optimizer.step()
+                    self._pick_next()
         self.losses = {k: v for k, v in self.losses.items()}
         # the recorded launches hold raw pointers into the frequency grids (turns / log radius): keep
         # the grid objects alive as long as the graphs (the by-pointer cache may drop them)
@@ -921,10 +969,13 @@ class GraphedTrainStep:
         tr = self.tr
         host_mask, host_idx, ev = self._ring[self._ring_pos]
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-        ev.synchronize()                     # the copies that last used this slot have executed
-        host_idx.copy_(torch.as_tensor(list(indices), dtype=torch.long))
-        self.idx.copy_(host_idx, non_blocking=True)
         crit = tr.criterion[1]
+        if indices is None and not (crit.use_mask and self.mask_source == "host"):
+            return                           # schedule mode: the previous step (or load_schedule) has filled idx
+        ev.synchronize()                     # the copies that last used this slot have executed
+        if indices is not None:
+            host_idx.copy_(torch.as_tensor(list(indices), dtype=torch.long))
+            self.idx.copy_(host_idx, non_blocking=True)
         if crit.use_mask and self.mask_source == "host":
             keep = torch.bernoulli(torch.empty(self.length).uniform_(0, 1))
             if tr.world_size > 1:

@@ -514,6 +514,10 @@ int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, cons
                               const float* rstd, const float* ggains, float* gw, void* work,
                               void* stream);
 
+/* Receiver schedule of a replayed epoch (reference trainer.py:373-379: the DataLoader fixes an epoch's batches when the
+ * epoch starts): table (len, B) int64 dataset rows uploaded once; each call copies row state[0] mod state[1] into idx
+ * (B) and advances state[0], on the device.  state: two int64 {position, len}.  */
+int gfdn_pick_rows(const long long* table, long long* state, long long* idx, int B, void* stream);
 /* ---- optimiser step  (trainer.py:152-228, :475: torch.optim.Adam with per-name lr groups) ----------
  * All parameters are views into one flat fp32 buffer p (n floats), gradients into g, Adam moments
  * into m, v.  seg[i] (uint8) = learning-rate group of element i, lr_seg[group] the group's lr (device,

@@ -250,6 +250,38 @@ def test_graphed_bank_step_equals_eager_bank_step():
             assert rel_err(v.detach().cpu(), nets2[q].state_dict()[k].detach().cpu()) < 5e-4, (q, k)
 
 
+def test_scheduled_steps_equal_per_call_steps():
+    """load_schedule / run_next (the epoch's batches on the device, every step fetching the next one's receivers
+    itself) against step(rows) per call with the host copy in front: same batches -> bit-equal losses and parameters;
+    the schedule wraps around and chunks beyond its capacity."""
+    _, _, _, _, ta, stacked, _ = _bank_setup(mask=True)
+    _, _, _, _, tb, _, _ = _bank_setup(mask=True)
+    for pa, pb in zip(ta.net.parameters(), tb.net.parameters()):
+        assert torch.equal(pa, pb)
+    B = 4
+    batches = [[1, 5, 7, 10], [0, 2, 3, 11], [4, 6, 8, 9], [2, 3, 5, 7], [11, 0, 9, 1]]
+    rows = [stacked.global_rows([b] * len(BANDS)) for b in batches]
+    sa = ta.graphed(stacked, B, mask_seed=99)
+    sb = tb.graphed(stacked, B, mask_seed=99)
+    sb.sched_cap = 2                                   # 5 steps -> three uploads
+    per_call = [{k: v.clone() for k, v in sa(r).items()} for r in rows]
+    sched = [{k: v.clone() for k, v in out.items()} for out in sb.run_schedule(rows)]
+    for a, b in zip(per_call, sched):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for pa, pb in zip(ta.net.parameters(), tb.net.parameters()):
+        assert torch.equal(pa, pb)
+    # wrap-around: a schedule of two batches run three times = batches 0, 1, 0
+    sb.load_schedule(rows[:2])
+    for r in (rows[0], rows[1], rows[0]):
+        a = {k: v.clone() for k, v in sa(r).items()}
+        b = sb.run_next()
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    with pytest.raises(ValueError):
+        sb.load_schedule([rows[0][:-1]])
+
+
 @pytest.mark.parametrize("mask", [True, False])
 def test_fused_bank_step_equals_autograd_bank_step(mask):
     """The explicit launch sequence on the polynomial form of the block transfer functions (bankstep.py) against the

@@ -5,22 +5,21 @@
 set -e
 cd "$(dirname "$0")/../diffgfdn_amd/csrc"
 mkdir -p ../../tools/_probe
+rm -f ../../tools/_probe/libv_*.so
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
 OUT=../../tools/_probe
 mk() { # name file sed-expr
-  sed "$3" $2 > /tmp/v_$1.hip
-  cp /tmp/v_$1.hip ./_v_$1.hip
+  sed "$3" $2 > ./_v_$1.hip
   /opt/rocm/bin/hipcc $FLAGS -c _v_$1.hip -o /tmp/v_$1.o
   rm -f _v_$1.hip
   OBJS=""
-  for f in solve ortho fft pow2 losses optim mlp svf; do
+  for f in solve ortho fft pow2 losses optim mlp svf blocktf mfma_exp; do
     if [ "$f.hip" = "$2" ]; then OBJS="$OBJS /tmp/v_$1.o"; else OBJS="$OBJS $f.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT/libv_$1.so
 }
 cp ../lib/libdiffgfdn_hip.so $OUT/libv_base.so
-mk colfadj2 fft.hip 's/(tw2_elems + 4 \* CW_LDS) \* sizeof(float2), s, a);/(tw2_elems + (a.adjoint \&\& a.pair ? 8 : 4) * CW_LDS) * sizeof(float2), s, a);/' &
-mk rpb16 solve.hip 's/if ((long long)ktiles \* nbands >= 768) rpb = ((B + COMPOSE_BCH - 1) \/ COMPOSE_BCH) \* COMPOSE_BCH;/if ((long long)ktiles * nbands >= 768) rpb = 16;/' &
-mk edr128 losses.hip 's/const int f = blockIdx.x \* 256 + threadIdx.x;/const int f = blockIdx.x * blockDim.x + threadIdx.x;/; s/hipLaunchKernelGGL(k_edr_loss_cols, dim3(fblk, batch), dim3(256)/hipLaunchKernelGGL(k_edr_loss_cols, dim3(2 * fblk, batch), dim3(128)/' &
+mk prio1 fft.hip 's/#define STFT_PAIR_PRIO 0/#define STFT_PAIR_PRIO 1/' &
+mk prio2 fft.hip 's/#define STFT_PAIR_PRIO 0/#define STFT_PAIR_PRIO 2/' &
 wait
 ls $OUT/libv_*.so

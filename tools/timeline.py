@@ -16,7 +16,8 @@ for r in seg:
 print("kernels:", len(seg), " span us:", (int(seg[-1]['End_Timestamp']) - t0) / 1e3)
 # steady-state period: start of the step's first kernel to the next step's (median over the replayed steps)
 import statistics
-starts = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith('k_ortho_fwd'))
+head = seg[first]['Kernel_Name'].split('(')[0]
+starts = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith(head + '('))
 per = [(b - a) / 1e3 for a, b in zip(starts, starts[1:])]
 ends = sorted(int(r['End_Timestamp']) for r in rows if r['Kernel_Name'].startswith('k_adam('))
 import bisect
