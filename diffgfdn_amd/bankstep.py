@@ -240,6 +240,19 @@ class FusedBankStep:
                                    save_T=True)
         keep.extend((coef_sub, ework, Q, QQ, coef, rgain, xhat, rstd, scale, H, Ts))
 
+        # ---- colorless pass (spectral loss + dL/drecords of the sub-FDNs, sparsity): on the EDC stream in front of the
+        # scans, beside the output stage and the transform (behind the scans it ran beside the STFT adjoint: same step
+        # time either way, measured)
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['norm'])
+            grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
+                                                cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
+                                                dturn=gridK.dturn)
+            out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
+                                           inv_world, want_grad=train, nbands=nb)
+            ev['side'].record()
+        keep.extend((grec_sub, loss_g, out3, gQ))
+
         # ---- decay losses: irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint, EDC scans beside them
         ev['h'].record()
         want_halves = self.halves >= 2 and pairs and Btot % 4 == 0 and side is not None
@@ -249,19 +262,6 @@ class FusedBankStep:
         else:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
                                                     start, length, ev, main, side2)
-        # the colorless pass rides the EDC stream behind the scans (a third stream would share a hardware queue with
-        # this one anyway, and the graph then runs it last: measured)
-        with on_side2():
-            if want_halves:        # (no EDC scans in front of it on this stream: H complete = gains rescaled, scale set)
-                torch.cuda.current_stream().wait_event(ev['h'])
-            grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
-                                                cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
-                                                dturn=gridK.dturn)
-            out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
-                                           inv_world, want_grad=train, nbands=nb)
-            ev['side'].record()
-        keep.extend((grec_sub, loss_g, out3, gQ))
-
         def report():
             """the reported sums and total (off the gradient path)"""
             s_ = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
@@ -285,7 +285,7 @@ class FusedBankStep:
                 if tail is not None:
                     tail()                # (every reader of ``rows`` is ordered before this point: main's are in
                                           # front of ev['grg'], this stream's are its own earlier launches)
-            main.wait_event(ev['side'])
+            main.wait_event(ev['side'])          # (signalled long ago; dropping it measured no gain: 0.667 vs 0.663 ms)
             # records (partial rows of the records pass + the colorless pass's) -> dL/dM, dL/db, dL/dc: one launch
             ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
                                gM=self.g_M)
