@@ -284,12 +284,35 @@ class Directional_Beamforming_Weights_from_MLP(nn.Module):
     def normalise_weights(weights: torch.Tensor) -> torch.Tensor:
         return weights / (torch.norm(weights, dim=-1, keepdim=True) + 1e-6)
 
+    def _fused_ok(self, position: torch.Tensor) -> bool:
+        if not isinstance(self.mlp, MLP) or isinstance(self.mlp, MLP_SkipConnections):
+            return False
+        lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
+        H = lin[0].out_features
+        return (position.is_cuda and position.shape[-1] == 3 and lin[0].weight.is_cuda
+                and lin[0].weight.dtype == torch.float32 and H <= 256
+                and self.num_groups * self.num_out_features <= 256 and all(m.out_features == H for m in lin[:-1]))
+
     def forward(self, x: Dict, normalise_weights: bool = False) -> torch.Tensor:
         position = x['norm_listener_position']
         w0 = next(self.mlp.parameters())
-        enc = self.encoder(position.to(w0.device))
-        self.weights = self.mlp(enc.to(w0.dtype)).reshape(position.shape[0], self.num_groups,
-                                                          self.num_out_features)
+        if self._fused_ok(position):
+            # encoding + [Linear, LayerNorm, ReLU] stack + output Linear as ONE launch each way (csrc/mlp.hip, no
+            # output activation) instead of ~30 + ~60 torch launches
+            from .functional import MlpGains
+            lin = [m for m in self.mlp.model if isinstance(m, nn.Linear)]
+            if getattr(self, '_freq_pi', None) is None or self._freq_pi.device != position.device:
+                f = torch.exp(torch.linspace(math.log(1.0), math.log(32.0), self.num_fourier_features,
+                                             device=position.device))
+                self._freq_pi = (f * math.pi).contiguous()
+            params = [p for m in self.mlp.model for p in m.parameters()]
+            raw = MlpGains.apply(position, None, self._freq_pi, lin[0].out_features, len(lin) - 2,
+                                 self.num_groups * self.num_out_features, 0.0, 0.0, *params)
+            self.weights = raw.reshape(position.shape[0], self.num_groups, self.num_out_features)
+        else:
+            enc = self.encoder(position.to(w0.device))
+            self.weights = self.mlp(enc.to(w0.dtype)).reshape(position.shape[0], self.num_groups,
+                                                              self.num_out_features)
         if normalise_weights:
             self.weights = self.normalise_weights(self.weights)
         return self.weights
