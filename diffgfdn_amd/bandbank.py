@@ -355,6 +355,12 @@ class BandBankTrainer:
         self.allreduce_in_graph = True      # capture the all-reduce inside the step's HIP graph (RCCL is capturable)
         self._side = self._side2 = None
         self._fused = FusedBankStep(self) if (self.use_fused and FusedBankStep.supported(self)) else None
+        if self.use_fused and self._fused is None and self.rank == 0:
+            import warnings
+            warnings.warn("BandBankTrainer: this layout (more than 4 lines per group, more than 4 groups per band or more "
+                          "than 64 blocks in the bank) is outside the explicit block-transfer-function step; the bank "
+                          "steps through the per-bin elimination kernels under autograd (same results, slower)",
+                          RuntimeWarning, stacklevel=2)
         # leaves are first touched on one stream and receive gradients from the other by design (§5.1): the
         # engine synchronises them; its per-backward warning about that would only hide real messages
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)

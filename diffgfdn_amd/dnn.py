@@ -1,4 +1,7 @@
-"""Position -> gain networks (stay on PyTorch / hipBLASLt: tiny dense layers).
+"""Position -> gain networks: the module tree that holds the parameters (and the CPU / odd-shape path).  On the GPU the
+networks of this path run as ONE fused launch each way (csrc/mlp.hip: encoding + [Linear, LayerNorm, ReLU] stack +
+output layer [+ sigmoid]) through gain_filters.Gains_from_MLP / SVF_from_MLP / Directional_Beamforming_Weights_from_MLP,
+whose kernels read these modules' parameters in place; skip-connection networks stay on torch / hipBLASLt.
 
 Mirrors the module tree and state-dict keys of the reference's src/diff_gfdn/dnn.py
 (SinusoidalEncoding :89-126, ScaledSigmoid :21-36, MLP :331-400, MLP_SkipConnections :284-328)
