@@ -487,6 +487,8 @@ def main():
                     help='time whole epochs (19 train + 5 validation steps + checkpoints); --steps = epochs timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
+    ap.add_argument('--pipe-steps', type=int, default=None,
+                    help='steps per graph of the pipelined chain (even; 0: one step per graph); default: the trainer\'s')
     ap.add_argument('--per-step-copy', action='store_true',
                     help='hand every step its receivers by a host copy in front of the replay (diagnostic; default: the '
                          'batches go to the device as one schedule)')
@@ -613,6 +615,8 @@ def main():
             return sel[0] if not use_bank else data.global_rows(sel)
 
         step = trainer.graphed(data, b_local)      # normalize + train_step as ONE HIP-graph replay
+        if args.pipe_steps is not None:
+            step.pipe_steps = args.pipe_steps
 
         def one_step():
             sel = draw()

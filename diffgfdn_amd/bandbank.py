@@ -328,10 +328,11 @@ class BandBankTrainer:
             self.subband_filter_freq_resp = subband_filter_freq_resp.to(torch.complex64).contiguous()
         self._filt_u = None
         # Adam groups by the reference's name rules (init_scheduler :152-228)
+        # (the gain network last: its range of the flat buffers can then be stepped on its own, bankstep.py)
         groups = [{'params': [bank.output_gains], 'lr': cfg.io_lr},
                   {'params': [bank.input_gains], 'lr': cfg.io_lr},
-                  {'params': [bank.output_scalars_w], 'lr': cfg.io_lr},
-                  {'params': [bank.feedback_loop_M], 'lr': cfg.lr}]
+                  {'params': [bank.feedback_loop_M], 'lr': cfg.lr},
+                  {'params': [bank.output_scalars_w], 'lr': cfg.io_lr}]
         # (3 loss slots per band ride the gradient bucket of a data-parallel job: EDR, EDC, colorless share)
         self.optimizer = BandFlatAdam(groups, self.num_bands, extra_slots=3 * self.num_bands)
         bank.relink()                               # the leaves now live in the flat buffer

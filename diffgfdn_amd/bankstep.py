@@ -52,6 +52,10 @@ class FusedBankStep:
         nblk = bank.num_bands * bank.num_groups
         self._zero_loss = torch.zeros(nblk, dtype=torch.float32, device=dev)
         self._keep = []
+        self._keep_prev = []
+        self.w_range = opt.flat_range(bank.output_scalars_w)
+        if self.w_range[1] != opt.flat_grad.numel():
+            raise RuntimeError("the gain network's parameters must close the flat buffers (BandBankTrainer's group order)")
 
     # 2: the loss middle as two half-batch chains on two streams.  Measured on the 7-band step: 0.692 vs 0.705 ms
     # (-2 %) for 13 more launches -- the chains run in phase, each kind of unit stays contended -- so it is off.
@@ -160,13 +164,15 @@ class FusedBankStep:
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, data: Dict, maskw: Optional[torch.Tensor], inv: float, normalize_first: bool, train: bool,
-            allreduce=None, opt_step: bool = True, mask_draw=None, tail=None) -> Dict:
+            allreduce=None, opt_step: bool = True, mask_draw=None, tail=None, pipe=None) -> Dict:
         """One step of every band on the band-major batch ``data`` (collate(lean="rows")).  ``maskw``: EDC time
         weights (None: no mask), ``inv``: what the EDC terms are divided by beyond the weights (1 when the weights are
         pre-normalised).  ``train``: gradients into the flat buffer, [all-reduce,] Adam (``opt_step=False`` stops in front
         of the all-reduce: the caller runs it and the update).  ``mask_draw``: callable that fills ``maskw`` on the
         device (run on the EDC stream, off the path to the output stage).  ``tail``: callable run on the side stream
-        behind the last reader of the batch's receiver indices (GraphedTrainStep fetches the next step's there).  Returns the loss dict of
+        behind the last reader of the batch's receiver indices (GraphedTrainStep fetches the next step's there).
+        ``pipe``: a :class:`StepPipe` -- this call is one step of a chain captured into one graph in which the side
+        stream runs ahead (see the class).  Returns the loss dict of
         ``BandBankTrainer._step_losses`` (+ '_total').
 
         Scheduling rules (measured on the replayed graph, profiles/): a dependency that crosses streams costs
@@ -219,11 +225,18 @@ class FusedBankStep:
         # depth-first walk of the nodes in capture order, and the chain captured first keeps its queue through every
         # later join -- a chain that changes queue pays ~10 us per change)
         Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
+        if pipe is not None and (not train or allreduce is not None or not opt_step or side2 is None):
+            raise ValueError("a pipelined step is a single-process training step with its optimiser update")
         with on_side2():
-            torch.cuda.current_stream().wait_event(ev['start'])
-            rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G,
-                                                  lo, hi, rows, nb)
-            ev['mlp'].record()
+            if pipe is None or pipe.first:
+                torch.cuda.current_stream().wait_event(ev['start'])
+            if pipe is None:
+                rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
+                                                      G, lo, hi, rows, nb)
+                ev['mlp'].record()
+            else:
+                # the previous step of the chain (or the prologue) has left this step's receiver gains in the pipe
+                rgain, xhat, rstd = pipe.cur
             # the EDC time mask is drawn on the stream that runs the EDC scans.  (Drawn on `side`, with the reported
             # total on `side` waiting for the sums of `side2`, the two forked streams depend on each other in both
             # directions -- hipStreamEndCapture of ROCm 7.2 segfaults on that topology.)
@@ -235,7 +248,10 @@ class FusedBankStep:
             _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                      dturn=gridK.dturn)
         ev['norm'].record()
-        main.wait_event(ev['mlp'])
+        if pipe is None:
+            main.wait_event(ev['mlp'])
+        elif pipe.ready is not None:
+            main.wait_event(pipe.ready)
         H, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, scale, direct, filt, rows, nb,
                                    save_T=True)
         keep.extend((coef_sub, ework, Q, QQ, coef, rgain, xhat, rstd, scale, H, Ts))
@@ -281,15 +297,33 @@ class FusedBankStep:
                 grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
-                ev['mlpb'].record()
-                if tail is not None:
-                    tail()                # (every reader of ``rows`` is ordered before this point: main's are in
+                if pipe is not None:
+                    # the gain network's range of the flat buffers is stepped HERE, behind its gradient, on this
+                    # stream; then the next step's receivers and its receiver gains -- the main stream never waits
+                    # for this branch again until the next output stage needs them
+                    tr.optimizer.step_range(*self.w_range, second=True)
+                    if tail is not None:
+                        tail()
+                    ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rows,
+                                      nb, out=pipe.nxt)
+                    pipe.ready_next = torch.cuda.Event()
+                    pipe.ready_next.record()
+                else:
+                    ev['mlpb'].record()
+                    if tail is not None:
+                        tail()            # (every reader of ``rows`` is ordered before this point: main's are in
                                           # front of ev['grg'], this stream's are its own earlier launches)
             main.wait_event(ev['side'])          # (signalled long ago; dropping it measured no gain: 0.667 vs 0.663 ms)
             # records (partial rows of the records pass + the colorless pass's) -> dL/dM, dL/db, dL/dc: one launch
             ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
                                gM=self.g_M)
             keep.extend((grg, grec))
+            if pipe is not None:
+                # everything but the gain network, straight behind its gradients
+                tr.optimizer.step_range(0, self.w_range[0], second=False)
+                torch.autograd.graph.increment_version(tr.optimizer._params)
+                sums_total = (sums, total)
+                return self._finish_pipe(pipe, sums_total, out3, nb, main, side, side2)
             main.wait_event(ev['mlpb'])
             tr.optimizer._packed = True               # the flat gradient buffer is complete
             if allreduce is not None:
@@ -320,6 +354,32 @@ class FusedBankStep:
         return losses
 
 
+    def _finish_pipe(self, pipe, sums_total, out3, nb, main, side, side2):
+        """End of one step of a pipelined chain: no join with the side stream (only the chain's last step joins, which
+        stream capture needs); this step's tensors stay referenced until the END of the next step -- by then every
+        stream has passed a point ordered behind their last readers (the allocator hands a freed block only to the
+        stream it was allocated on, but main-stream blocks are read on the side stream too)."""
+        sums, total = sums_total
+        keep = self._keep
+        keep.extend((sums, total))
+        if nb > 1:
+            losses = {'edc_loss': sums[:, 2], 'edr_loss': sums[:, 1], 'spectral_loss': out3[:, 1],
+                      'sparsity_loss': out3[:, 2], '_total': total}
+        else:
+            losses = {'edc_loss': sums[2], 'edr_loss': sums[1], 'spectral_loss': out3[1], 'sparsity_loss': out3[2],
+                      '_total': total}
+        if pipe.last:
+            for s_ in (side, side2):
+                if s_ is not None:
+                    main.wait_stream(s_)
+            self._keep_prev = []
+            keep.clear()
+        else:
+            self._keep_prev = list(keep)
+            keep.clear()
+        pipe.advance()
+        return losses
+
     # -- the part of a data-parallel step behind the gradients ------------------------------------------------------
     def finish(self, allreduce):
         """[all-reduce of the bucket,] Adam.  Returns (sums, total) rebuilt from the reduced loss slots -- the whole
@@ -335,6 +395,48 @@ class FusedBankStep:
             red = (sums, total) if nb > 1 else (sums[0], total[0])
         tr.optimizer.step()
         return red
+
+
+class StepPipe:
+    """State of a chain of explicit steps captured into ONE graph with the side stream running ahead of the main one.
+
+    In a single step the main stream waits for the side stream twice where nothing but latency is gained or lost: at
+    the head (the receiver gains of the batch, ~12 us behind the side stream's fork) and at the tail (Adam behind the
+    gain network's backward, ~15 us), and every step ends with a join and starts with a fork (~11 us).  In a chain the
+    side stream steps the gain network's parameters itself, fetches the next step's receivers and evaluates their gains
+    right behind the gain network's backward of the current step; the main stream steps everything else straight
+    behind its own last gradient kernel and goes on with the next step.  The numbers are those of the single steps,
+    bit for bit (tests/test_gpu_bank.py).
+
+    ``bufs``: two sets of (gains (B, G), xhat (B, nl, H), rstd (B, nl)) owned by the caller: step i of the chain reads
+    set i % 2 and fills set (i + 1) % 2, so a chain of EVEN length leaves the next chain's first set filled."""
+
+    def __init__(self, bufs, steps: int):
+        if steps % 2:
+            raise ValueError("a pipelined chain has an even number of steps")
+        self.bufs, self.steps, self.i = bufs, steps, 0
+        self.ready = None            # event behind the gains of the CURRENT step (None: produced before this chain)
+        self.ready_next = None
+
+    @property
+    def cur(self):
+        return self.bufs[self.i % 2]
+
+    @property
+    def nxt(self):
+        return self.bufs[(self.i + 1) % 2]
+
+    @property
+    def first(self):
+        return self.i == 0
+
+    @property
+    def last(self):
+        return self.i == self.steps - 1
+
+    def advance(self):
+        self.i += 1
+        self.ready, self.ready_next = self.ready_next, None
 
 
 class _null:

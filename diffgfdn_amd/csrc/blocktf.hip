@@ -889,10 +889,12 @@ extern "C" int gfdn_tf_compose_fwd(const double* turns, const double* logr, int 
 //            barrier.  T' = the forward's saved (scaled, unfiltered) group transfer functions (nbands * G, K).
 #define TFB_T 64
 #define TFG_R 8
+#define TFG_PRIO 0       // wave priority of the gains pass (it heads the longer branch of the tail)
 __global__ __launch_bounds__(256) void k_tf_gain_grad(const float2* __restrict__ Tsave, int K, int G, int B,
                                                       const float2* __restrict__ filt, int ldf,
                                                       const float2* __restrict__ gH, int ldh,
                                                       float* __restrict__ rg_partial, int ngrp) {
+  if (TFG_PRIO) __builtin_amdgcn_s_setprio(TFG_PRIO);
   __shared__ float s_red[4][TFG_R * TF_MAXG];
   const int band = blockIdx.y / ngrp, b0 = (blockIdx.y - band * ngrp) * TFG_R;
   const int nr = B - b0 < TFG_R ? B - b0 : TFG_R;

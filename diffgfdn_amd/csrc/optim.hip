@@ -18,7 +18,8 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const floa
                                               const float* __restrict__ lr_seg,
                                               float* __restrict__ step_count, int n, float b1,
                                               float b2, float eps, int advance,
-                                              unsigned int* __restrict__ block_counter) {
+                                              unsigned int* __restrict__ block_counter,
+                                              float* __restrict__ mirror) {
   const float t = step_count[0] + 1.0f;
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
@@ -33,7 +34,10 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const floa
   }
   if (advance) {
     __syncthreads();
-    if (threadIdx.x == 0) step_count[0] = t;
+    if (threadIdx.x == 0) {
+      step_count[0] = t;
+      if (mirror) mirror[0] = t;
+    }
   } else if (block_counter) {
     // multi-block launch: the LAST workgroup to finish writes t back -- every workgroup has read the counter by the
     // time it reports in -- and re-arms the block counter for the next launch (no second kernel for the increment)
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const floa
       __threadfence();
       if (atomicAdd(block_counter, 1u) == gridDim.x - 1) {
         step_count[0] = t;
+        if (mirror) mirror[0] = t;
         block_counter[0] = 0u;
       }
     }
@@ -53,19 +58,19 @@ __global__ void k_adam_advance(float* step_count) {
 
 static int adam_step_run(float* p, const float* g, float* m, float* v, const unsigned char* seg,
                          const float* lr_seg, float* step_count, int n, float beta1, float beta2,
-                         float eps, unsigned int* block_counter, void* stream) {
+                         float eps, unsigned int* block_counter, void* stream, float* mirror = nullptr) {
   if (!p || !g || !m || !v || !seg || !lr_seg || !step_count || n <= 0) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (n <= 16 * 1024) {          // one block: update + counter advance in a single launch
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
-                       beta1, beta2, eps, 1, (unsigned int*)nullptr);
+                       beta1, beta2, eps, 1, (unsigned int*)nullptr, mirror);
     GFDN_LAUNCH_CHECK();
     return 0;
   }
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
-                     beta1, beta2, eps, 0, block_counter);
+                     beta1, beta2, eps, 0, block_counter, mirror);
   GFDN_LAUNCH_CHECK();
   if (!block_counter) {
     hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(64), 0, s, step_count);
@@ -87,6 +92,16 @@ extern "C" int gfdn_adam_step_counted(float* p, const float* g, float* m, float*
                                       float eps, unsigned int* block_counter, void* stream) {
   if (!block_counter) return GFDN_E_BADARG;
   return adam_step_run(p, g, m, v, seg, lr_seg, step_count, n, beta1, beta2, eps, block_counter, stream);
+}
+
+// The same with a second counter kept equal to step_count (mirror <- t).  An optimiser that sometimes steps two ranges of
+// its buffer from two streams gives each range its own counter (a range reads and advances only its own: no ordering
+// between the two launches is needed) and keeps them equal through this entry point when it steps the whole buffer.
+extern "C" int gfdn_adam_step_mirrored(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                                       const float* lr_seg, float* step_count, float* mirror, int n, float beta1,
+                                       float beta2, float eps, unsigned int* block_counter, void* stream) {
+  if (!block_counter || !mirror) return GFDN_E_BADARG;
+  return adam_step_run(p, g, m, v, seg, lr_seg, step_count, n, beta1, beta2, eps, block_counter, stream, mirror);
 }
 
 // ------------------------------------------------------------------------------------------

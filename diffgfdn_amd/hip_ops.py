@@ -1166,10 +1166,11 @@ def draw_mask(seed: int, state, length: int, scale: float, out=None):
 
 
 def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi: float, rows=None,
-                  nbands: int = 1):
+                  nbands: int = 1, out=None):
     """pos (B,3) f64, freq_pi (F,) f32, w packed params -> gains (B,G), xhat (B,nl,H), rstd (B,nl).
     ``rows``: item b encodes pos[rows[b]] (pos = the positions of all receivers).
-    ``nbands`` > 1: w (nbands, P), items band-major (item i uses parameter set i // (B / nbands))."""
+    ``nbands`` > 1: w (nbands, P), items band-major (item i uses parameter set i // (B / nbands)).
+    ``out``: (gains, xhat, rstd) buffers to fill."""
     _need_gpu(pos, w)
     pos = pos.detach().to(torch.float64).contiguous()
     w = _f(w)
@@ -1179,9 +1180,15 @@ def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi:
     if w.numel() != nbands * lib.gfdn_mlp_param_count(F, H, n_hidden, G) or B % nbands:
         raise RuntimeError("mlp_gains: packed parameter count does not match the layer sizes")
     nl = 1 + n_hidden
-    gains = torch.empty((B, G), dtype=_f32, device=pos.device)
-    xhat = torch.empty((B, nl, H), dtype=_f32, device=pos.device)
-    rstd = torch.empty((B, nl), dtype=_f32, device=pos.device)
+    if out is not None:
+        gains, xhat, rstd = out
+        if tuple(gains.shape) != (B, G) or tuple(xhat.shape) != (B, nl, H) or tuple(rstd.shape) != (B, nl) \
+                or any(t.dtype != _f32 or not t.is_contiguous() for t in out):
+            raise RuntimeError("mlp_gains_fwd: out = (gains (B, G), xhat (B, nl, H), rstd (B, nl)) float32 contiguous")
+    else:
+        gains = torch.empty((B, G), dtype=_f32, device=pos.device)
+        xhat = torch.empty((B, nl, H), dtype=_f32, device=pos.device)
+        rstd = torch.empty((B, nl), dtype=_f32, device=pos.device)
     if nbands > 1:
         _lib.check(lib.gfdn_mlp_gains_banded_fwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,
                                                  n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat),
@@ -1218,11 +1225,17 @@ def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, gg
     return gw
 
 
-def adam_step(p, g, m, v, seg, lr_seg, step_count, beta1, beta2, eps, block_counter=None):
+def adam_step(p, g, m, v, seg, lr_seg, step_count, beta1, beta2, eps, block_counter=None, mirror=None):
     """In-place fused Adam update of the flat buffers (all float32 on the GPU; seg uint8).  ``block_counter``: a
     zero-initialised int32 tensor of one element owned by the optimiser -- update and counter advance are then one
-    launch for any size."""
+    launch for any size.  ``mirror``: a second counter that receives the advanced count too."""
     _need_gpu(p, g)
+    if mirror is not None:
+        _lib.check(_lib.load().gfdn_adam_step_mirrored(_p(p), _p(g), _p(m), _p(v), _p(seg), _p(lr_seg),
+                                                       _p(step_count), _p(mirror), p.numel(), float(beta1),
+                                                       float(beta2), float(eps), _p(block_counter), _stream()),
+                   "gfdn_adam_step_mirrored")
+        return
     if block_counter is not None:
         _lib.check(_lib.load().gfdn_adam_step_counted(_p(p), _p(g), _p(m), _p(v), _p(seg), _p(lr_seg),
                                                       _p(step_count), p.numel(), float(beta1), float(beta2),

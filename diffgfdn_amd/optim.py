@@ -46,6 +46,10 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
         self._block_counter = torch.zeros(1, dtype=torch.int32, device=dev)      # see gfdn_adam_step_counted
+        # second counter, always equal to step_count after a step: `step_range(..., second=True)` reads and advances
+        # this one, so that two ranges can be stepped from two streams without ordering the launches
+        self.step_count2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._block_counter2 = torch.zeros(1, dtype=torch.int32, device=dev)
         seg = torch.empty(n, dtype=torch.uint8)
         self._grad_views, self._params = [], []
         off = 0
@@ -101,9 +105,30 @@ class FlatAdam(torch.optim.Optimizer):
         self._packed = False
         b1, b2 = self.defaults['betas']
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.seg,
-                      self.lr_seg, self.step_count, b1, b2, self.defaults['eps'], self._block_counter)
+                      self.lr_seg, self.step_count, b1, b2, self.defaults['eps'], self._block_counter,
+                      mirror=self.step_count2)
         # the kernel wrote the parameters through raw pointers: tell autograd / version-keyed caches
         torch.autograd.graph.increment_version(self._params)
 
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int, second: bool = False):
+        """Adam update of the flat range [lo, hi) only, on the current stream.  A step split in two covers the buffer
+        with ONE ``second=False`` call and ONE ``second=True`` call (any order, any streams): each advances its own
+        counter (``step_count`` / ``step_count2``), which the unsplit :meth:`step` keeps equal."""
+        b1, b2 = self.defaults['betas']
+        sl = slice(lo, hi)
+        cnt, blk = (self.step_count2, self._block_counter2) if second else (self.step_count, self._block_counter)
+        ops.adam_step(self.flat_param[sl], self.flat_grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.seg[sl],
+                      self.lr_seg, cnt, b1, b2, self.defaults['eps'], blk)
+        self._packed = False
+
+    def flat_range(self, param) -> tuple:
+        """(lo, hi) of ``param`` in the flat buffers."""
+        for p, v in zip(self._params, self._grad_views):
+            if p is param:
+                lo = (v.data_ptr() - self.flat_grad.data_ptr()) // 4
+                return lo, lo + v.numel()
+        raise KeyError("not a parameter of this optimiser")
+
     def state_tensors(self):
-        return [self.exp_avg, self.exp_avg_sq, self.step_count]
+        return [self.exp_avg, self.exp_avg_sq, self.step_count, self.step_count2]

@@ -771,7 +771,7 @@ class GraphedTrainStep:
                 dist.broadcast(seed_t, src=0, group=trainer.process_group)
             mask_seed = int(seed_t.item())
         self.mask_seed = int(mask_seed)
-        self.graph_a = self.graph_b = None
+        self.graph_a = self.graph_b = self.graph_p = None
         self.losses = None
         # receiver schedule (load_schedule / run_next): the batches of an epoch live on the device and every step ends
         # by fetching the next step's receivers into ``idx`` -- no host copy in front of a replay
@@ -809,12 +809,75 @@ class GraphedTrainStep:
         return self.losses
 
     def run_schedule(self, batches):
-        """Generator over the steps of ``batches`` (any number: uploaded in chunks of ``sched_cap``)."""
+        """Generator over the steps of ``batches`` (any number: uploaded in chunks of ``sched_cap``).  Where the
+        pipelined chain applies (:meth:`_pipe_ok`) the steps run ``pipe_steps`` at a time from one graph and the rest
+        from the single-step graph -- same numbers either way."""
         batches = list(batches)
         for i0 in range(0, len(batches), self.sched_cap):
             n = self.load_schedule(batches[i0:i0 + self.sched_cap])
-            for _ in range(n):
+            done = 0
+            S = self.pipe_steps
+            if self._pipe_ok() and n >= S:
+                if self.graph_p is None:
+                    self.capture_pipe()
+                self._pipe_prologue()
+                while n - done >= S:
+                    self.graph_p.replay()
+                    for losses in self.pipe_losses:
+                        yield losses
+                    done += S
+            for _ in range(n - done):
                 yield self.run_next()
+
+    # -- pipelined chain of explicit bank steps (bankstep.StepPipe) -----------------------------
+    # steps per graph of the pipelined chain (even; 0: single-step graphs only).  OFF by default: measured on the 7-band
+    # step, same box, 400 steps: 0.681 ms single-step graphs, 0.692 / 0.688 / 0.688 ms with 2 / 4 / 8 steps per graph.
+    # Under rocprofv3 the interior steps of a chain are 35 us shorter (no wait for the gains at the head, Adam straight
+    # behind the last gradient kernel, no join), but the chain's last step waits for the side stream's run-ahead work
+    # (+60 us per graph) and without the profiler's per-kernel serialisation the interior gain is not there either.
+    pipe_steps = 0
+
+    def _pipe_ok(self) -> bool:
+        tr = self.tr
+        return (self.pipe_steps >= 2 and self.pipe_steps % 2 == 0 and getattr(tr, '_fused', None) is not None
+                and tr._allreduce is None and tr._stream('_side2') is not None
+                and not (tr.criterion[1].use_mask and self.mask_source == "host"))
+
+    def _mlp_args(self):
+        bank = self.tr.net
+        Hh, n_hidden, _, lo, hi = bank._mlp_cfg
+        return (self.ds.norm_listener_position, bank._freq_pi, bank.output_scalars_w.detach(), Hh, n_hidden,
+                bank.num_groups, lo, hi, self.idx, self.num_bands)
+
+    def _pipe_prologue(self):
+        """Receiver gains of the batch in ``idx`` at the current parameters -> the chain's first buffer set."""
+        ops.mlp_gains_fwd(*self._mlp_args(), out=self._pipe_bufs[0])
+
+    def capture_pipe(self):
+        """Record ``pipe_steps`` explicit steps as ONE graph with the side stream running ahead (StepPipe)."""
+        from .bankstep import StepPipe
+        if self.graph_a is None:
+            self.capture(None)                      # (warm-up of every kernel, lazy initialisations)
+        bank = self.tr.net
+        Hh, n_hidden = bank._mlp_cfg[0], bank._mlp_cfg[1]
+        dev, G, nl = self.idx.device, bank.num_groups, 1 + n_hidden
+        mk = lambda: (torch.empty((self.B, G), dtype=torch.float32, device=dev),
+                      torch.empty((self.B, nl, Hh), dtype=torch.float32, device=dev),
+                      torch.empty((self.B, nl), dtype=torch.float32, device=dev))
+        self._pipe_bufs = [mk(), mk()]
+        pipe = StepPipe(self._pipe_bufs, self.pipe_steps)
+        rng_state = torch.get_rng_state()
+        torch.cuda.synchronize()
+        self.graph_p = torch.cuda.CUDAGraph()
+        losses = []
+        with torch.cuda.graph(self.graph_p):
+            for _ in range(self.pipe_steps):
+                losses.append(dict(self._fused_fwd_bwd(opt_step=True, pipe=pipe)))
+        self.pipe_losses = losses
+        from .functional import FrequencyGrid
+        self._grids = list(FrequencyGrid._cache.values())
+        torch.set_rng_state(rng_state)
+        return self
 
     # -- pieces -------------------------------------------------------------------------------
     def _fwd_bwd(self):
@@ -833,7 +896,7 @@ class GraphedTrainStep:
             losses['_total'] = heads[0].detach() if len(heads) == 1 else heads[0].detach() + heads[1].detach()
         return losses
 
-    def _fused_fwd_bwd(self, opt_step: bool):
+    def _fused_fwd_bwd(self, opt_step: bool, pipe=None):
         """The band bank's explicit launch sequence (bankstep.FusedBankStep): mask draw, normalize, forward, losses,
         backward into the flat gradient buffer [, all-reduce, Adam]."""
         tr = self.tr
@@ -842,7 +905,7 @@ class GraphedTrainStep:
             draw = lambda: ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
         batch = self.ds.collate(self.idx, lean="rows")
         return tr._fused.run(batch, self.maskw, 1.0, normalize_first=True, train=True, allreduce=tr._allreduce,
-                             opt_step=opt_step, mask_draw=draw, tail=self._pick_next)
+                             opt_step=opt_step, mask_draw=draw, tail=self._pick_next, pipe=pipe)
 
     def _eager(self):
         if getattr(self.tr, '_fused', None) is not None:

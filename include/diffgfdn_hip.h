@@ -531,6 +531,11 @@ int gfdn_adam_step(float* p, const float* g, float* m, float* v, const unsigned 
 int gfdn_adam_step_counted(float* p, const float* g, float* m, float* v, const unsigned char* seg,
                            const float* lr_seg, float* step_count, int n, float beta1, float beta2,
                            float eps, unsigned int* block_counter, void* stream);
+/* the same, also writing the advanced count to `mirror` (a second counter of the caller's that must stay equal to
+ * step_count: an optimiser that steps two ranges of its buffer from two streams keeps one counter per range)  */
+int gfdn_adam_step_mirrored(float* p, const float* g, float* m, float* v, const unsigned char* seg,
+                            const float* lr_seg, float* step_count, float* mirror, int n, float beta1, float beta2,
+                            float eps, unsigned int* block_counter, void* stream);
 
 #ifdef __cplusplus
 }

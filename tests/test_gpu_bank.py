@@ -250,6 +250,39 @@ def test_graphed_bank_step_equals_eager_bank_step():
             assert rel_err(v.detach().cpu(), nets2[q].state_dict()[k].detach().cpu()) < 5e-4, (q, k)
 
 
+@pytest.mark.parametrize("S", [2, 4])
+def test_pipelined_chain_equals_single_steps(S):
+    """run_schedule with ``pipe_steps`` steps per graph (side stream running ahead: the gain network's parameters
+    stepped on it, the next step's receivers and gains fetched behind its backward; bankstep.StepPipe) against the same
+    batches stepped one graph replay at a time: bit-equal losses of every step and bit-equal parameters / Adam state."""
+    _, _, _, _, ta, stacked, _ = _bank_setup(mask=True)
+    _, _, _, _, tb, _, _ = _bank_setup(mask=True)
+    B = 4
+    batches = [[1, 5, 7, 10], [0, 2, 3, 11], [4, 6, 8, 9], [2, 3, 5, 7], [11, 0, 9, 1], [3, 4, 5, 6], [7, 8, 9, 10]]
+    rows = [stacked.global_rows([b] * len(BANDS)) for b in batches]
+    sa = ta.graphed(stacked, B, mask_seed=5)
+    sb = tb.graphed(stacked, B, mask_seed=5)
+    sa.pipe_steps, sb.pipe_steps = 0, S
+    assert sb._pipe_ok() and not sa._pipe_ok()
+    single = [{k: v.clone() for k, v in out.items()} for out in sa.run_schedule(rows)]
+    piped = [{k: v.clone() for k, v in out.items()} for out in sb.run_schedule(rows)]
+    assert sb.graph_p is not None and len(piped) == len(rows)
+    for i, (a, b) in enumerate(zip(single, piped)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k)
+    for pa, pb in zip(ta.net.parameters(), tb.net.parameters()):
+        assert torch.equal(pa, pb)
+    for a, b in zip(ta.optimizer.state_tensors(), tb.optimizer.state_tensors()):
+        assert torch.equal(a, b)
+    assert float(tb.optimizer.step_count.item()) == len(rows) == float(tb.optimizer.step_count2.item())
+    # a second schedule on the same graphs (the chain's buffers are refilled by the prologue)
+    single = [{k: v.clone() for k, v in out.items()} for out in sa.run_schedule(rows[::-1])]
+    piped = [{k: v.clone() for k, v in out.items()} for out in sb.run_schedule(rows[::-1])]
+    for i, (a, b) in enumerate(zip(single, piped)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k)
+
+
 def test_scheduled_steps_equal_per_call_steps():
     """load_schedule / run_next (the epoch's batches on the device, every step fetching the next one's receivers
     itself) against step(rows) per call with the host copy in front: same batches -> bit-equal losses and parameters;

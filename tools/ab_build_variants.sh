@@ -19,7 +19,7 @@ mk() { # name file sed-expr
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT/libv_$1.so
 }
 cp ../lib/libdiffgfdn_hip.so $OUT/libv_base.so
-mk prio1 fft.hip 's/#define STFT_PAIR_PRIO 0/#define STFT_PAIR_PRIO 1/' &
-mk prio2 fft.hip 's/#define STFT_PAIR_PRIO 0/#define STFT_PAIR_PRIO 2/' &
+mk ggprio2 blocktf.hip 's/#define TFG_PRIO 0/#define TFG_PRIO 2/' &
+mk ggprio3 blocktf.hip 's/#define TFG_PRIO 0/#define TFG_PRIO 3/' &
 wait
 ls $OUT/libv_*.so
