@@ -703,6 +703,13 @@ class GraphedModuleStep:
         torch.cuda.synchronize()
         return self
 
+    def __del__(self):
+        try:                                 # (as GraphedTrainStep.__del__)
+            if self.graph is not None:
+                torch.cuda.synchronize()
+        except Exception:        # noqa: BLE001
+            pass
+
     def __call__(self, batch: Optional[Dict] = None):
         if batch is not None:
             for k, v in batch.items():
@@ -870,7 +877,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph_p = torch.cuda.CUDAGraph()
         losses = []
-        with torch.cuda.graph(self.graph_p):
+        with torch.cuda.graph(self.graph_p, stream=self._capture_stream):
             for _ in range(self.pipe_steps):
                 losses.append(dict(self._fused_fwd_bwd(opt_step=True, pipe=pipe)))
         self.pipe_losses = losses
@@ -930,7 +937,9 @@ class GraphedTrainStep:
         saved_p = [p.detach().clone() for p in params]
         state_tensors = tr.optimizer.state_tensors
         saved_s = [t.detach().clone() for t in state_tensors()]   # empty for a fresh optimizer
-        side = torch.cuda.Stream()
+        # warm-up AND capture on ONE private stream: autograd pins every parameter's AccumulateGrad node to the stream of
+        # its first backward; a capture on another stream then hops to that stream and back for every parameter
+        side = self._capture_stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
@@ -957,7 +966,7 @@ class GraphedTrainStep:
         self.graph_a = torch.cuda.CUDAGraph()
         if tr._allreduce is None or in_graph:
             # ONE graph: forward, backward, [all-reduce of the gradient bucket (RCCL is capturable),] Adam
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, stream=side):
                 if fused:
                     self.losses = self._fused_fwd_bwd(opt_step=True)
                 else:
@@ -969,14 +978,14 @@ class GraphedTrainStep:
                     self._pick_next()
         else:
             # forward + backward + pack | all-reduce of the gradient bucket (eager RCCL) | Adam
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, stream=side):
                 if fused:
                     self.losses = self._fused_fwd_bwd(opt_step=False)
                 else:
                     self.losses = self._fwd_bwd()
                     tr.optimizer.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), stream=side):
                 if fused:
                     red = tr._fused.finish(lambda: None)          # (the collective itself runs between the replays)
                     self._apply_reduced(red)
@@ -990,6 +999,15 @@ class GraphedTrainStep:
         self._grids = list(FrequencyGrid._cache.values())
         torch.set_rng_state(rng_state)
         return self
+
+    def __del__(self):
+        # a graph executable must not be destroyed while its last launch is still in flight (its kernel-argument
+        # buffers go with it): drain the device first
+        try:
+            if self.graph_a is not None or self.graph_p is not None:
+                torch.cuda.synchronize()
+        except Exception:        # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _apply_reduced(self, red):
         """Split-graph data-parallel step: the second graph rebuilt the decay losses from the reduced slots."""
