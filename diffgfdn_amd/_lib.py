@@ -69,7 +69,8 @@ SIGNATURES = {
     "gfdn_tf_eval": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_energy": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_double, _P]),
     "gfdn_tf_colorless": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_double, _P]),
-    "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P]),
+    "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P,
+                                    _P]),
     "gfdn_tf_compose_parts": (c_int, [c_int]),
     "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "gfdn_irfft_odd_slots_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_irfft_odd_slots_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_irfft_odd_pairs_fwd": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_odd_pairs_compose_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P,
+                                                 _P, c_int, _P, c_int, _P]),
     "gfdn_irfft_odd_pairs_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_stft_power_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -7,14 +7,16 @@ sub-FDN forward, b, c /= E^(1/4)), forward (model.py:569-625), losses (trainer.p
 feedback loop only through the group transfer functions T_g(z) -- ratios of multilinear polynomials in the phasors
 z^{m_i} with 2 x 16 real coefficients per block -- so the step is
 
-    main  : [Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g: one launch] -> energy pass -> finish (normalize: b, c
-            rescaled in place, scale_g) -> output stage H -> irfft -> STFT -> EDR -> STFT adjoint (even frames, then
-            odd frames + EDC gradient) -> irfft adjoint -> output-stage adjoint (dL/dgains, then dL/drecords)
-            -> records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint -> [all-reduce] -> Adam
-    side2 : gain network forward, mask draw ... EDC scans, colorless pass (spectral loss + dL/drecords), sparsity,
-            reported sums ... gain network backward
+    main  : [Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g: one launch] -> energy pass -> finish
+            (normalize: b, c rescaled in place, scale_g) -> group transfer functions T -> irfft whose first pass forms
+            the output stage H from T, the receiver gains and the early-response store (H is never stored) -> STFT
+            -> EDR -> STFT adjoint (even frames, then odd frames + EDC gradient) -> irfft adjoint -> output-stage
+            adjoint (dL/drecords) -> [records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint: one launch]
+            -> [all-reduce] -> Adam
+    side2 : gain network forward, mask draw, colorless pass (spectral loss + dL/drecords), sparsity ... EDC scans,
+            reported sums ... output-stage adjoint (dL/dgains) -> gain network backward -> next step's receivers
 
-about 35 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
+33 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
 accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve never exist.  The autograd
 path of ``BandBankTrainer._step_losses`` (per-bin elimination kernels) stays as the general fallback and as the
 cross-check of this one (tests/test_gpu_bank.py).
@@ -61,15 +63,21 @@ class FusedBankStep:
     # (-2 %) for 13 more launches -- the chains run in phase, each kind of unit stays contended -- so it is off.
     halves = 1
 
+    # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
+    # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
+    fold_output_stage = True
+
     # ------------------------------------------------------------------------------------------
     def _decay_middle(self, H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc, start, length, ev, main,
-                      side2):
+                      side2, x_fn=None, Btot=None):
         """One chain over the whole batch: main: irfft -> STFT -> EDR -> STFT adjoint (even frames, then odd frames +
         EDC gradient) -> irfft adjoint; side2: EDC scans.  Records ev['x'] / ev['edc'] / ev['g']."""
         tr, cfg, keep = self.tr, self.tr.config, self._keep
-        Btot, win = H.shape[0], tr.stft_win
+        Btot, win = (H.shape[0] if Btot is None else Btot), tr.stft_win
         on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
-        if pairs:
+        if x_fn is not None:              # (the output stage rides the transform's first pass: H is never stored)
+            x = x_fn()
+        elif pairs:
             x = ops.irfft_odd_fwd(H, K, slots=True, pairs=True)
         else:
             x = ops.irfft_odd_fwd(H, K, slots=order is not None)
@@ -106,7 +114,8 @@ class FusedBankStep:
                 g_edr = ops.stft_power_bwd(x, win, P, g_edr)
                 main.wait_event(ev['edc'])
                 ev['g'].record()
-                gH = ops.irfft_odd_bwd(g_edc, K, H.shape[1], g_edr, slots=order is not None)
+                gH = ops.irfft_odd_bwd(g_edc, K, (K + 1) // 2 if order is not None else H.shape[1], g_edr,
+                                       slots=order is not None)
             keep.append(gH)
         else:
             main.wait_event(ev['edc'])
@@ -252,8 +261,18 @@ class FusedBankStep:
             main.wait_event(ev['mlp'])
         elif pipe.ready is not None:
             main.wait_event(pipe.ready)
+        fold = (self.fold_output_stage and pairs and K == 65537 and (Btot // nb) % 2 == 0 and G <= 4
+                and self.halves < 2)
         H, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, scale, direct, filt, rows, nb,
-                                   save_T=True)
+                                   save_T=True, want_H=not fold)
+        x_fn = None
+        if fold:
+            Tq, H = H, None
+
+            def x_fn():
+                x2, h0 = ops.irfft_odd_pairs_compose_fwd(direct, rows, Tq, rgain, filt, K, nb)
+                keep.extend((h0, Tq))
+                return x2
         keep.extend((coef_sub, ework, Q, QQ, coef, rgain, xhat, rstd, scale, H, Ts))
 
         # ---- colorless pass (spectral loss + dL/drecords of the sub-FDNs, sparsity): on the EDC stream in front of the
@@ -277,7 +296,7 @@ class FusedBankStep:
                                                            length, ev, main, side, side2)
         else:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
-                                                    start, length, ev, main, side2)
+                                                    start, length, ev, main, side2, x_fn=x_fn, Btot=Btot)
         def report():
             """the reported sums and total (off the gradient path)"""
             s_ = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)

@@ -795,7 +795,8 @@ struct TfCompose {
 #define TFC_BCH 8
 __global__ __launch_bounds__(256) void k_tf_compose_fwd(TfCompose a, const float2* __restrict__ direct, int ldd,
                                                         const long long* __restrict__ drows,
-                                                        float2* __restrict__ H, int ldh, float2* __restrict__ Tsave) {
+                                                        float2* __restrict__ H, int ldh, float2* __restrict__ Tsave,
+                                                        float2* __restrict__ Tquad) {
   __shared__ TfBlock tab[TF_MAXG];
   const int band = blockIdx.y, G = a.G, B = a.B;
   tf_stage(a.coef, a.delays, band * G, G, a.nper, tab);
@@ -805,7 +806,8 @@ __global__ __launch_bounds__(256) void k_tf_compose_fwd(TfCompose a, const float
   const float* rgain = a.rgain + (size_t)band * B * G;
   if (drows) drows += (size_t)band * B;
   else if (direct) direct += (size_t)band * B * ldd;
-  H += (size_t)band * B * ldh;
+  if (H) H += (size_t)band * B * ldh;
+  else direct = nullptr;
   // the first receivers' direct-path loads fly while the transfer functions are evaluated (with one wave of
   // workgroups on the chip the launch would otherwise run as a compute phase followed by a memory phase)
   float2 d[TFC_BCH];
@@ -825,6 +827,12 @@ __global__ __launch_bounds__(256) void k_tf_compose_fwd(TfCompose a, const float
       if (Tsave) Tsave[(size_t)(band * G + g) * a.K + k] = T[g];
     }
   }
+  if (Tquad) {                         // the band's four transfer functions of a bin side by side (zeros beyond G)
+    float4* q = (float4*)(Tquad + ((size_t)band * a.K + k) * 4);
+    q[0] = make_float4(T[0].x, T[0].y, T[1].x, T[1].y);
+    q[1] = make_float4(T[2].x, T[2].y, T[3].x, T[3].y);
+  }
+  if (!H) return;                      // transfer functions only (the transform's first pass forms H itself)
   const float2 f = a.filt ? a.filt[(size_t)band * a.ldf + k] : make_float2(1.f, 0.f);
   for (int b0 = 0; b0 < B; b0 += TFC_BCH) {
     float2 dn[TFC_BCH];
@@ -867,13 +875,14 @@ extern "C" int gfdn_tf_compose_fwd(const double* turns, const double* logr, int 
                                    const float* coef, const float* delays, const float* scale,
                                    const float* rgain, int B, const float* direct, int ldd,
                                    const long long* direct_rows, const float* filt, int ldf, float* H, int ldh,
-                                   float* Tsave, void* stream) {
+                                   float* Tsave, float* Tquad, void* stream) {
   int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
   if (rc) return rc;
-  if (!H || ldh < K || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
+  if ((!H && !Tsave && !Tquad) || (H && ldh < K) || (direct && ldd < K) || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
   TfCompose a{turns, logr, K, G, nper, B, coef, delays, scale, rgain, (const float2*)filt, ldf};
   hipLaunchKernelGGL(k_tf_compose_fwd, dim3((K + 255) / 256, nbands), dim3(256), 0, (hipStream_t)stream, a,
-                     (const float2*)direct, ldd, direct ? direct_rows : nullptr, (float2*)H, ldh, (float2*)Tsave);
+                     (const float2*)direct, ldd, direct ? direct_rows : nullptr, (float2*)H, ldh, (float2*)Tsave,
+                     (float2*)Tquad);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -383,8 +383,24 @@ extern "C" int gfdn_bluestein_table_init(int n, void* table) {
 // Bluestein kernels.  Column tile: TC adjacent columns n2, LDS layout [col][row] (stride L1+1).
 // ------------------------------------------------------------------------------------------
 
+// Output stage of the block-transfer-function step folded into the first pass of the paired forward transform
+// (k_blu_col128_fwd): the spectrum H[b][k] = (sum_g rgain[b][g] T_g[k] + direct[rows[b]][k]) * filt[band][k] is formed
+// while the pass loads it, from the saved group transfer functions T (nbands * G, ldt) -- 7 MB that stay in the
+// last-level cache -- instead of being written by one kernel and read back by the next (2 x 58.7 MB at 224 items).
+struct BluCompose {
+  const float2* T;        // (nbands, ldt, 4): the band's (<= 4) group transfer functions of a column side by side --
+                          // one 32-byte access per slot.  NULL: plain transform (the spectrum is `in`)
+  int ldt;
+  const float* rgain;     // (items, G)
+  const float2* filt;     // (nbands, ldf) or NULL
+  int ldf, G, Bper;       // Bper: items per band
+  const long long* rows;  // item b reads direct row rows[b] (NULL: row b)
+  float* h0;              // (items): Re H[b][0], written by the first pass, read by the last
+};
+
 struct BluArgs {
   BluGeom g;
+  BluCompose cmp;
   int rader;            // 0: Bluestein (chirp-z)   1: Rader (n prime, n - 1 = L)
   const int* perm;      // rader: perm[a]  = g^a  mod n   (spectrum index of convolution slot a)
   const int* iperm;     // rader: iperm[b] = g^-b mod n   (time index of convolution slot b)
@@ -788,7 +804,65 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
   float2 v[16];
   const int b1 = a.pair ? 2 * b : b;
   const bool two = a.pair && b1 + 1 < a.items;
-  if (a.pair && !a.adjoint) {
+  if (a.pair && !a.adjoint && a.cmp.T) {
+    // as the branch below, with the two spectra formed on the fly (BluCompose): same operations in the same order as
+    // k_tf_compose_fwd
+    const BluCompose& cm = a.cmp;
+    const int band = b1 / cm.Bper, G = cm.G;
+    const float2* D1 = (const float2*)a.in + (size_t)(cm.rows ? cm.rows[b1] : b1) * a.ld_in;
+    const float2* D2 = two ? (const float2*)a.in + (size_t)(cm.rows ? cm.rows[b1 + 1] : b1 + 1) * a.ld_in : D1;
+    const float4* T0 = (const float4*)(cm.T + (size_t)band * cm.ldt * 4);
+    const float2* F = cm.filt ? cm.filt + (size_t)band * cm.ldf : nullptr;
+    float rg1[4], rg2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      rg1[g] = g < G ? cm.rgain[(size_t)b1 * G + g] : 0.f;
+      rg2[g] = (g < G && two) ? cm.rgain[(size_t)(b1 + 1) * G + g] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t col = (size_t)(l + 8 * k) * L2 + c0 + c + 1;
+      float2 p = D1[col], q = two ? D2[col] : make_float2(0.f, 0.f);
+      const float4 t01 = T0[2 * col], t23 = T0[2 * col + 1];
+      const float2 tg[4] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w), make_float2(t23.x, t23.y),
+                            make_float2(t23.z, t23.w)};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < G) {
+          p.x += rg1[g] * tg[g].x;
+          p.y += rg1[g] * tg[g].y;
+          q.x += rg2[g] * tg[g].x;
+          q.y += rg2[g] * tg[g].y;
+        }
+      }
+      if (F) {
+        const float2 f = F[col];
+        p = cmul(p, f);
+        q = cmul(q, f);
+      }
+      if (!two) q = make_float2(0.f, 0.f);
+      v[k] = make_float2(p.x - q.y, p.y + q.x);
+      v[k + 8] = make_float2(p.x + q.y, q.x - p.y);
+      edge += p.x;
+      edge2 += q.x;
+    }
+    if (tile == 0 && lane == 0) {            // bin 0 of both items (the last pass adds it to every sample)
+#pragma unroll 1
+      for (int it = 0; it < (two ? 2 : 1); ++it) {
+        const float2* D = it ? D2 : D1;
+        float2 h = D[0];
+        const float2* tq = (const float2*)T0;
+        for (int g = 0; g < G; ++g) {
+          const float rg = cm.rgain[(size_t)(b1 + it) * G + g];
+          const float2 t = tq[g];
+          h.x += rg * t.x;
+          h.y += rg * t.y;
+        }
+        if (F) h = cmul(h, F[0]);
+        cm.h0[b1 + it] = h.x;
+      }
+    }
+  } else if (a.pair && !a.adjoint) {
     // two slot-ordered spectra ride one transform as u1 + i u2 (the results are real: they come back as the
     // real / imaginary part -- see k_blu_col128_inv); rows n1 and n1 + 64 hold conj(u1) + i conj(u2)
     const float2* X1 = (const float2*)a.in + (size_t)b1 * a.ld_in + 1;
@@ -878,7 +952,8 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
     if (!a.adjoint) {
       // the two real results are the real / imaginary part: ONE 8-byte scatter per slot serves both items
       const float2* X = (const float2*)a.in;
-      const float x01 = X[(size_t)b1 * a.ld_in].x, x02 = two ? X[(size_t)(b1 + 1) * a.ld_in].x : 0.f;
+      const float x01 = a.cmp.T ? a.cmp.h0[b1] : X[(size_t)b1 * a.ld_in].x;
+      const float x02 = two ? (a.cmp.T ? a.cmp.h0[b1 + 1] : X[(size_t)(b1 + 1) * a.ld_in].x) : 0.f;
       float2* xo = (float2*)a.out + (size_t)b * a.ld_out;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -964,7 +1039,7 @@ static bool slot_order_ok(int n) {
 
 static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
                    int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7,
-                   const float* in2 = nullptr, int slot = 0) {
+                   const float* in2 = nullptr, int slot = 0, const BluCompose* cmp = nullptr) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
   const bool rader = rader_ok(n);
@@ -975,6 +1050,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if (slot && adjoint && ld_out != g.nin) return GFDN_E_BADARG;
   BluArgs a;
   a.g = g;
+  a.cmp = cmp ? *cmp : BluCompose{nullptr, 0, nullptr, nullptr, 0, 0, 1, nullptr, nullptr};
   a.rader = rader ? 1 : 0;
   if (rader) {
     a.chirp = nullptr;
@@ -1011,6 +1087,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if ((rc = ensure_dyn_lds(k_blu_row, lr))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_col_inv, lc))) return rc;
   const bool col128 = g.L1 == 128 && g.L2 % 32 == 0 && tc == 8;       // wave-per-tile column kernels
+  if (cmp && !(col128 && a.pair && !adjoint && rader)) return GFDN_E_UNSUPPORTED;
   const size_t tw2_elems = (size_t)((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS);
   if (stages & 1) {
     if (col128)
@@ -1085,6 +1162,26 @@ extern "C" int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* g
 extern "C" int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs, int ldx, int batch,
                                         float* x2, int ldo, void* work, void* stream) {
   return blu_run(table, n, Xs, ldx, batch, x2, ldo, work, 0, (hipStream_t)stream, 7, nullptr, 2);
+}
+// The paired forward transform with the output stage of the block-transfer-function step folded into its first pass:
+// x2 = irfft_n(H) for H[b][k] = (sum_g rgain[b][g] T[band * G + g][k] + direct[rows[b]][k]) * filt[band][k], items
+// band-major (batch = nbands * Bper), every array slot-ordered with column 0 = bin 0; H itself is never stored.
+// T (nbands, ldt, 4): gfdn_tf_compose_fwd's Tquad.  stages: 7 = the whole transform (bit 0 / 1 / 2: first / middle /
+// last pass alone, for timing a pass between events).  h0: `batch` floats of scratch that must stay untouched until the
+// call's kernels have run.
+extern "C" int gfdn_irfft_odd_pairs_compose_fwd(const void* table, int n, const float* direct_c64, int ldd,
+                                                const long long* direct_rows, const float* T_c64, int ldt,
+                                                const float* rgain, const float* filt_c64, int ldf, int nbands, int G,
+                                                int batch, float* h0, float* x2, int ldo, void* work, int stages,
+                                                void* stream) {
+  if (!direct_c64 || !T_c64 || !rgain || !h0 || nbands <= 0 || G <= 0 || batch <= 0 || batch % nbands) return GFDN_E_BADARG;
+  if (G > 4) return GFDN_E_UNSUPPORTED;
+  const int half = (n - 1) / 2 + 1;
+  if (ldd < half || ldt < half || (filt_c64 && ldf < half)) return GFDN_E_BADARG;
+  if ((batch / nbands) % 2) return GFDN_E_UNSUPPORTED;          // (a pair must not straddle two bands)
+  BluCompose cm{(const float2*)T_c64, ldt, rgain, (const float2*)filt_c64, ldf, G, batch / nbands, direct_rows, h0};
+  if (!(stages & 7)) return GFDN_E_BADARG;
+  return blu_run(table, n, direct_c64, ldd, batch, x2, ldo, work, 0, (hipStream_t)stream, stages & 7, nullptr, 2, &cm);
 }
 extern "C" int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
                                         int batch, float* gXs, int ldx, void* work, void* stream) {

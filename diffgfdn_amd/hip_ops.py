@@ -616,9 +616,11 @@ def tf_colorless(turns, logr, coef, delays, nper: int, scale, asym: bool, gscale
 
 
 def tf_compose_fwd(turns, logr, coef, delays, nper: int, rgain, scale=None, direct=None, filt=None,
-                   direct_rows=None, nbands: int = 1, out=None, save_T: bool = False):
+                   direct_rows=None, nbands: int = 1, out=None, save_T: bool = False, want_H: bool = True):
     """H (nbands*B, K) complex64 from the records (band-stacked as compose_fwd); ``save_T``: also returns the
-    scaled, unfiltered group transfer functions (nbands*G, K) complex64 that tf_compose_bwd takes back."""
+    scaled, unfiltered group transfer functions (nbands*G, K) complex64 that tf_compose_bwd takes back.
+    ``want_H=False`` (with save_T): the transfer functions only -- returns (Tquad (nbands, K, 4), Tsave), Tquad being
+    what irfft_odd_pairs_compose_fwd takes (it forms H inside the transform)."""
     _need_gpu(turns, coef, rgain)
     coef, delays, rgain = _f(coef), _f(delays), _f(rgain)
     K = turns.numel()
@@ -639,12 +641,18 @@ def tf_compose_fwd(turns, logr, coef, delays, nper: int, rgain, scale=None, dire
     if direct is not None and direct_rows is None and direct.shape[0] != Btot:
         raise RuntimeError("tf_compose_fwd: direct must have one row per item (or pass direct_rows)")
     scale = None if scale is None else _f(scale)
-    H = torch.empty((Btot, K), dtype=_c64, device=coef.device) if out is None else out
+    if not want_H and not save_T:
+        raise RuntimeError("tf_compose_fwd: nothing to compute")
+    H = None if not want_H else (torch.empty((Btot, K), dtype=_c64, device=coef.device) if out is None else out)
     Ts = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if save_T else None
+    # without H: also the band's transfer functions of a bin side by side (nbands, K, 4), for the transform's first pass
+    Tq = torch.empty((nbands, K, 4), dtype=_c64, device=coef.device) if not want_H else None
     _lib.check(_lib.load().gfdn_tf_compose_fwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays),
                                                _p(scale), _p(rgain), Btot // nbands, _p(direct), ldd,
-                                               _p(direct_rows), _p(filt), K, _p(H), K, _p(Ts), _stream()),
+                                               _p(direct_rows), _p(filt), K, _p(H), K, _p(Ts), _p(Tq), _stream()),
                "gfdn_tf_compose_fwd")
+    if not want_H:
+        return Tq, Ts
     return (H, Ts) if save_T else H
 
 
@@ -844,6 +852,38 @@ def irfft_odd_fwd(X, n: int, slots: bool = False, pairs: bool = False) -> torch.
     fn = lib.gfdn_irfft_odd_slots_fwd if slots else lib.gfdn_irfft_odd_fwd
     _lib.check(fn(_p(table), n, _p(X), ldx, batch, _p(x), n, _p(work), _stream()), "gfdn_irfft_odd_fwd")
     return x
+
+
+def irfft_odd_pairs_compose_fwd(direct, rows, T, rgain, filt, n: int, nbands: int) -> torch.Tensor:
+    """x2 = irfft_odd_fwd(H, n, slots=True, pairs=True) for the output stage's H = (sum_g rgain T_g + direct[rows]) filt
+    formed inside the transform's first pass (H is never stored).  direct (R, (n+1)/2) c64 slot-ordered store, rows
+    (batch) int64 or None, T (nbands, (n+1)/2, 4) c64 (tf_compose_fwd(want_H=False)[0]), rgain (batch, G), filt
+    (nbands, (n+1)/2) c64 or None.  Returns (x2, h0)."""
+    _need_gpu(direct, T, rgain)
+    direct, T, rgain = _c(direct), _c(T), _f(rgain)
+    batch, G = rgain.shape
+    half = (n + 1) // 2
+    if direct.shape[1] != half or tuple(T.shape) != (nbands, half, 4) or batch % nbands:
+        raise RuntimeError("irfft_odd_pairs_compose_fwd: shapes do not match nbands x G blocks / (n + 1) / 2 columns")
+    filt = None if filt is None else _c(filt)
+    rows = None if rows is None else _rows(rows, batch, direct.shape[0])
+    lib = _lib.load()
+    table = bluestein_table(n, direct.device)
+    x2 = torch.empty((batch // 2, n, 2), dtype=_f32, device=direct.device)
+    h0 = torch.empty(batch, dtype=_f32, device=direct.device)
+    work = _work(lib.gfdn_bluestein_work_bytes(n, batch), direct.device)
+    args = (_p(table), n, _p(direct), half, _p(rows), _p(T), half, _p(rgain), _p(filt), half, nbands, G, batch, _p(h0),
+            _p(x2), n, _p(work))
+    if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:        # the three passes with events around one
+        for name, stage in _BLU_STAGES.items():
+            end = kernel_timer.bracket(name, batch)
+            _lib.check(lib.gfdn_irfft_odd_pairs_compose_fwd(*args, stage, _stream()),
+                       "gfdn_irfft_odd_pairs_compose_fwd[%s]" % name)
+            if end is not None:
+                end.record()
+        return x2, h0
+    _lib.check(lib.gfdn_irfft_odd_pairs_compose_fwd(*args, 7, _stream()), "gfdn_irfft_odd_pairs_compose_fwd")
+    return x2, h0
 
 
 def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None) -> torch.Tensor:

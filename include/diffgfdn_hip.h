@@ -333,7 +333,7 @@ int gfdn_tf_colorless(const double* turns, const double* logr, int K, int nblk, 
 int gfdn_tf_compose_fwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
                         const float* coef, const float* delays, const float* scale, const float* rgain, int B,
                         const float* direct_c64, int ldd, const long long* direct_rows, const float* filt_c64,
-                        int ldf, float* H_c64, int ldh, float* Tsave_c64, void* stream);
+                        int ldf, float* H_c64, int ldh, float* Tsave_c64, float* Tquad_c64, void* stream);
 int gfdn_tf_compose_parts(int K);   /* partial rows per record entry that gfdn_tf_compose_bwd(grec = NULL) leaves in work */
 size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G);
 int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
@@ -397,6 +397,18 @@ int gfdn_irfft_odd_slots_bwd(const void* table, int n, const float* gx, const fl
  * phase 1 = odd frames, gx2 += contribution + base2 everywhere (base2 must not alias gx2).  0 then 1 = the above. */
 int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* Xs_c64, int ldx, int batch,
                              float* x2, int ldo, void* work, void* stream);
+/* gfdn_irfft_odd_pairs_fwd with the output stage of the block-transfer-function step (gfdn_tf_compose_fwd) folded into
+ * its first pass: x2 = irfft_n(H), H[b][k] = (sum_g rgain[b][g] T[band * G + g][k] + direct[rows[b]][k]) * filt[band][k]
+ * (model.py:583-619, trainer.py:459, losses.py:207-213), formed while the pass loads it; H is never stored (same operations as
+ * gfdn_tf_compose_fwd in the same order: x2 agrees to float32 rounding).  T (nbands, ldt, 4) = gfdn_tf_compose_fwd's
+ * Tquad output (the band's group transfer functions of a column side by side, zeros beyond G; its H_c64 may be NULL);
+ * items band-major, batch = nbands * Bper with Bper even; slot-ordered columns, column 0 = bin 0; h0: batch floats of
+ * scratch.  stages = 7: the whole transform (bits 0 / 1 / 2 = its three passes, as gfdn_irfft_odd_stages).
+ * n = 65537 (the 128 x 512 Rader geometry) only: GFDN_E_UNSUPPORTED otherwise.  */
+int gfdn_irfft_odd_pairs_compose_fwd(const void* table, int n, const float* direct_c64, int ldd,
+                                     const long long* direct_rows, const float* T_c64, int ldt, const float* rgain,
+                                     const float* filt_c64, int ldf, int nbands, int G, int batch, float* h0,
+                                     float* x2, int ldo, void* work, int stages, void* stream);
 int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
                              int batch, float* gXs_c64, int ldx, void* work, void* stream);
 int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P, float* zero_buf2,

@@ -236,3 +236,44 @@ def test_ortho_coefs_equals_separate_launches(n, nblk):
     _, _, coef_only, none = ops.tf_ortho_coefs(M, ig, b, c, sub=False)
     assert none is None and torch.equal(coef_only, c0)
     assert torch.equal(ops.tf_coefs(QQ0, b, c, ig), c0)
+
+
+@pytest.mark.parametrize("nbands,B,G,with_filt", [(2, 4, 4, True), (1, 6, 3, False), (3, 2, 2, True)])
+def test_output_stage_folded_into_the_transform(nbands, B, G, with_filt):
+    """gfdn_irfft_odd_pairs_compose_fwd (H formed inside the first pass of the paired transform, never stored) against
+    tf_compose_fwd -> irfft_odd_fwd(slots, pairs): the time signals agree to float32 rounding; Tsave without H equals Tsave."""
+    from diffgfdn_amd import hip_ops as ops
+    n, npts = 4, 65537
+    half = (npts + 1) // 2
+    nblk = nbands * G
+    g = torch.Generator().manual_seed(nbands * 10 + B)
+    A, b, c, delays, ig = _blocks(nblk, n, 3, orth=True)
+    A, b, c, ig, dl = A.float().to(DEV), b.float().to(DEV), c.float().to(DEV), ig.float().to(DEV), delays.to(DEV)
+    z = torch.exp(2j * np.pi * torch.rand(half, generator=g, dtype=torch.float64)).to(DEV)     # any grid: the test is algebraic
+    turns, _ = ops.zprep(z)
+    coef = ops.tf_coefs(A, b, c, ig)
+    s = (0.5 + torch.rand(nblk, generator=g)).to(DEV)
+    rgain = (2 * torch.rand(nbands * B, G, generator=g) - 1).to(DEV)
+    R = 3 * B
+    direct = (torch.randn(nbands * R, half, generator=g, dtype=torch.float32)
+              + 1j * torch.randn(nbands * R, half, generator=g, dtype=torch.float32)).to(torch.complex64).to(DEV)
+    rows = torch.stack([q * R + torch.randperm(R, generator=g)[:B] for q in range(nbands)]).reshape(-1).to(DEV)
+    filt = None
+    if with_filt:
+        filt = (torch.randn(nbands, half, generator=g) + 1j * torch.randn(nbands, half, generator=g)).to(torch.complex64).to(DEV)
+    H, Ts = ops.tf_compose_fwd(turns, None, coef, dl, n, rgain, s, direct, filt, rows, nbands, save_T=True)
+    Tq, Ts2 = ops.tf_compose_fwd(turns, None, coef, dl, n, rgain, s, direct, filt, rows, nbands, save_T=True, want_H=False)
+    assert torch.equal(Ts, Ts2) and tuple(Tq.shape) == (nbands, half, 4)
+    for q in range(nbands):
+        for gi in range(4):
+            assert torch.equal(Tq[q, :, gi], Ts[q * G + gi] if gi < G else torch.zeros_like(Ts[0]))
+    want = ops.irfft_odd_fwd(H, npts, slots=True, pairs=True)
+    got, h0 = ops.irfft_odd_pairs_compose_fwd(direct, rows, Tq, rgain, filt, npts, nbands)
+    # (the same operations in the same order; the compiler contracts multiply-adds differently in the two kernels)
+    assert torch.allclose(h0, H[:, 0].real, rtol=1e-6, atol=1e-6)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-6 * scale
+    if nbands > 1 and B > 2:                      # an odd number of items per band: a pair would straddle two bands
+        keep = torch.cat([torch.arange(q * B, q * B + B - 1) for q in range(nbands)]).to(DEV)
+        with pytest.raises(RuntimeError):
+            ops.irfft_odd_pairs_compose_fwd(direct, rows[keep], Tq, rgain[keep], filt, npts, nbands)

@@ -206,6 +206,7 @@ def test_half_batch_chains_equal_single_chain():
         bank = BandBank([b_[2] for b_ in bands])
         tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=CENTRES)
         tr._fused.halves = halves
+        tr._fused.fold_output_stage = False       # (the half-batch chains take H from the stored output stage)
         sds = BandStackedDataset([b_[1] for b_ in bands])
         start, length = tr._decay_window(K)
         sds.precompute_decay_targets(4096, start, length)
