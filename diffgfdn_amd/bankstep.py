@@ -312,6 +312,13 @@ class FusedBankStep:
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
                 sums, total = report()
+                if allreduce is not None:
+                    # data-parallel: this rank's loss terms ride the gradient bucket -- [EDR | EDC | colorless share]
+                    # per band behind the gradients -- and ONE all-reduce sums both over the ranks.
+                    # Written here, off the path: the main stream's wait for this branch covers it
+                    slots = tr.optimizer.extra.view(3, nb)
+                    torch.stack((sums.reshape(nb, 3)[:, 1], sums.reshape(nb, 3)[:, 2], out3.reshape(nb, 3)[:, 0]),
+                                out=slots)
                 torch.cuda.current_stream().wait_event(ev['grg'])
                 grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
@@ -345,12 +352,6 @@ class FusedBankStep:
                 return self._finish_pipe(pipe, sums_total, out3, nb, main, side, side2)
             main.wait_event(ev['mlpb'])
             tr.optimizer._packed = True               # the flat gradient buffer is complete
-            if allreduce is not None:
-                # data-parallel: this rank's loss terms ride the gradient bucket -- [EDR | EDC | colorless share] per
-                # band behind the gradients -- and ONE all-reduce sums both over the ranks
-                slots = tr.optimizer.extra.view(3, nb)
-                torch.stack((sums.reshape(nb, 3)[:, 1], sums.reshape(nb, 3)[:, 2], out3.reshape(nb, 3)[:, 0]),
-                            out=slots)
             if opt_step:
                 red = self.finish(allreduce)
                 if red is not None:
@@ -408,11 +409,12 @@ class FusedBankStep:
         red = None
         if allreduce is not None:
             allreduce()
+        tr.optimizer.step()                  # (straight behind the collective: the reported sums below are not on the path)
+        if allreduce is not None:
             slots = tr.optimizer.extra.view(3, nb)
             total = slots.sum(dim=0)
             sums = torch.stack((total, slots[0], slots[1]), dim=1)          # [total, w_edr edr, w_edc edc] per band
             red = (sums, total) if nb > 1 else (sums[0], total[0])
-        tr.optimizer.step()
         return red
 
 
