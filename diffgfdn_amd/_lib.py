@@ -63,6 +63,7 @@ SIGNATURES = {
     "gfdn_tf_ortho_coefs": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_coefs_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_param_grads": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_tf_rows_sum": (c_int, [_P, c_int, c_int, _P, _P]),
     "gfdn_tf_parts": (c_int, [c_int, c_int]),
     "gfdn_tf_work_bytes": (c_size_t, [c_int]),
     "gfdn_tf_gpart_bytes": (c_size_t, [c_int]),
@@ -92,6 +93,9 @@ SIGNATURES = {
     "gfdn_irfft_odd_pairs_compose_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P,
                                                  _P, c_int, _P, c_int, _P]),
     "gfdn_irfft_odd_pairs_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_odd_pairs_gains_parts": (c_int, [c_int]),
+    "gfdn_irfft_odd_pairs_gains_bwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P,
+                                               _P, c_int, _P]),
     "gfdn_stft_power_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd_phase": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),

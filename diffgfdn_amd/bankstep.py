@@ -66,10 +66,15 @@ class FusedBankStep:
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
     # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
     fold_output_stage = True
+    # The mirror image -- the gains pass of the adjoint inside the LAST pass of the adjoint transform
+    # (gfdn_irfft_odd_pairs_gains_bwd: dL/dH used while it is in registers) -- is OFF: measured 0.676 against 0.664 ms.
+    # The gains pass it removes runs beside the records pass on the side stream, off the main chain, while the
+    # accumulation lengthens a pass that is ON it.
+    fold_gains = False
 
     # ------------------------------------------------------------------------------------------
     def _decay_middle(self, H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc, start, length, ev, main,
-                      side2, x_fn=None, Btot=None):
+                      side2, x_fn=None, Btot=None, gains=None):
         """One chain over the whole batch: main: irfft -> STFT -> EDR -> STFT adjoint (even frames, then odd frames +
         EDC gradient) -> irfft adjoint; side2: EDC scans.  Records ev['x'] / ev['edc'] / ev['g']."""
         tr, cfg, keep = self.tr, self.tr.config, self._keep
@@ -108,7 +113,11 @@ class FusedBankStep:
                 main.wait_event(ev['edc'])
                 ops.stft_power_pairs_bwd(x, Btot, win, P, base=g_edc, out=g, phase=1)
                 ev['g'].record()
-                gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
+                if gains is not None:     # (the gains pass of the output stage's adjoint rides the last pass)
+                    gH, self._gpart = ops.irfft_odd_pairs_bwd(g, K, Btot, gains=gains)
+                    keep.append(self._gpart)
+                else:
+                    gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
                 keep.append(g)
             else:
                 g_edr = ops.stft_power_bwd(x, win, P, g_edr)
@@ -296,7 +305,8 @@ class FusedBankStep:
                                                            length, ev, main, side, side2)
         else:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
-                                                    start, length, ev, main, side2, x_fn=x_fn, Btot=Btot)
+                                                    start, length, ev, main, side2, x_fn=x_fn, Btot=Btot,
+                                                    gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None)
         def report():
             """the reported sums and total (off the gradient path)"""
             s_ = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
@@ -320,7 +330,10 @@ class FusedBankStep:
                     torch.stack((sums.reshape(nb, 3)[:, 1], sums.reshape(nb, 3)[:, 2], out3.reshape(nb, 3)[:, 0]),
                                 out=slots)
                 torch.cuda.current_stream().wait_event(ev['grg'])
-                grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
+                if fold and self.fold_gains:
+                    grg = ops.tf_rows_sum(self._gpart)
+                else:
+                    grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
                                   xhat, rstd, grg, rows, nb, out=self.g_w)
                 if pipe is not None:

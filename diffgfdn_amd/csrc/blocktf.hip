@@ -489,6 +489,16 @@ static int tf_parts_host(int K, int nblk) {
   if (parts > TF_MAX_PARTS) parts = TF_MAX_PARTS;
   return parts;
 }
+// out[r] = sum_p part[r * cols + p], one wavefront per row, fixed order (the second stage of every partial-sum scheme
+// of this file; also used for the gains partials of gfdn_irfft_odd_pairs_gains_bwd)
+extern "C" int gfdn_tf_rows_sum(const float* part, int cols, int rows, float* out, void* stream) {
+  if (!part || !out || cols <= 0 || rows <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_tf_rows_sum, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, cols, rows, out, rows,
+                     (float*)nullptr, (float*)nullptr);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gfdn_tf_parts(int K, int nblk) {
   if (K <= 0 || nblk <= 0 || nblk > TF_MAXBLK) return 0;
   return tf_parts_host(K, nblk);

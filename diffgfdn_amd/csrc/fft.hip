@@ -396,6 +396,9 @@ struct BluCompose {
   int ldf, G, Bper;       // Bper: items per band
   const long long* rows;  // item b reads direct row rows[b] (NULL: row b)
   float* h0;              // (items): Re H[b][0], written by the first pass, read by the last
+  // adjoint: the gains pass of the output stage's adjoint folded into the LAST pass -- partial sums of
+  // dL/drgain[b][g] = sum_k Re(dL/dH[b][k] conj(filt[k] T'_g[k])), gpart[(b * G + g) * ntile + tile], ntile = L2 / 8
+  float* gpart;
 };
 
 struct BluArgs {
@@ -970,6 +973,15 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
       const float sc = 2.0f * invL * invn;
       float2* o1 = (float2*)a.out + (size_t)b1 * a.ld_out;
       float2* o2 = o1 + a.ld_out;
+      // gains pass of the output stage's adjoint, folded in (BluCompose): every gradient value is used while it is in
+      // a register -- dL/drgain[b][g] += Re(dL/dH[b][k] conj(filt[k] T'_g[k])) -- instead of being read back by a
+      // launch of its own beside the records pass
+      const BluCompose& cm = a.cmp;
+      const bool gains = cm.T != nullptr;
+      const int band = gains ? b1 / cm.Bper : 0;
+      const float4* TQ = gains ? (const float4*)(cm.T + (size_t)band * cm.ldt * 4) : nullptr;
+      const float2* F = (gains && cm.filt) ? cm.filt + (size_t)band * cm.ldf : nullptr;
+      float ga1[4] = {0.f, 0.f, 0.f, 0.f}, ga2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
@@ -978,13 +990,51 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
           const float2 W1 = make_float2(0.5f * (v[q].x + p.x), 0.5f * (v[q].y - p.y));
           const float2 W2 = make_float2(0.5f * (v[q].y + p.y), -0.5f * (v[q].x - p.x));
           const size_t idx = 1 + (size_t)n1 * L2 + c0 + c;
-          o1[idx] = make_float2(sc * W1.x + 2.0f * invn * g0.x, -sc * W1.y);
-          if (two) o2[idx] = make_float2(sc * W2.x + 2.0f * invn * g0.y, -sc * W2.y);
+          const float2 h1 = make_float2(sc * W1.x + 2.0f * invn * g0.x, -sc * W1.y);
+          const float2 h2 = make_float2(sc * W2.x + 2.0f * invn * g0.y, -sc * W2.y);
+          o1[idx] = h1;
+          if (two) o2[idx] = h2;
+          if (gains) {
+            const float4 t01 = TQ[2 * idx], t23 = TQ[2 * idx + 1];
+            const float2 fk = F ? F[idx] : make_float2(1.f, 0.f);
+            const float2 w0 = cmul(fk, make_float2(t01.x, t01.y)), w1 = cmul(fk, make_float2(t01.z, t01.w));
+            const float2 w2 = cmul(fk, make_float2(t23.x, t23.y)), w3 = cmul(fk, make_float2(t23.z, t23.w));
+            ga1[0] += h1.x * w0.x + h1.y * w0.y;
+            ga1[1] += h1.x * w1.x + h1.y * w1.y;
+            ga1[2] += h1.x * w2.x + h1.y * w2.y;
+            ga1[3] += h1.x * w3.x + h1.y * w3.y;
+            ga2[0] += h2.x * w0.x + h2.y * w0.y;
+            ga2[1] += h2.x * w1.x + h2.y * w1.y;
+            ga2[2] += h2.x * w2.x + h2.y * w2.y;
+            ga2[3] += h2.x * w3.x + h2.y * w3.y;
+          }
         }
       }
       if (folder) {
-        o1[0] = make_float2((sum1 + g0.x) * invn, 0.f);
-        if (two) o2[0] = make_float2((sum2 + g0.y) * invn, 0.f);
+        const float2 h1 = make_float2((sum1 + g0.x) * invn, 0.f), h2 = make_float2((sum2 + g0.y) * invn, 0.f);
+        o1[0] = h1;
+        if (two) o2[0] = h2;
+        if (gains) {                       // bin 0 (column 0): h is real
+          const float2* tq = (const float2*)TQ;
+          const float2 fk = F ? F[0] : make_float2(1.f, 0.f);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float2 w = cmul(fk, tq[g]);
+            ga1[g] += h1.x * w.x;
+            ga2[g] += h2.x * w.x;
+          }
+        }
+      }
+      if (gains) {
+        const int ntile = L2 / 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float s1 = wave_sum(ga1[g]), s2 = wave_sum(ga2[g]);
+          if (lane == 0 && g < cm.G) {
+            cm.gpart[((size_t)b1 * cm.G + g) * ntile + tile] = s1;
+            if (two) cm.gpart[((size_t)(b1 + 1) * cm.G + g) * ntile + tile] = s2;
+          }
+        }
       }
     }
     return;
@@ -1050,7 +1100,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if (slot && adjoint && ld_out != g.nin) return GFDN_E_BADARG;
   BluArgs a;
   a.g = g;
-  a.cmp = cmp ? *cmp : BluCompose{nullptr, 0, nullptr, nullptr, 0, 0, 1, nullptr, nullptr};
+  a.cmp = cmp ? *cmp : BluCompose{nullptr, 0, nullptr, nullptr, 0, 0, 1, nullptr, nullptr, nullptr};
   a.rader = rader ? 1 : 0;
   if (rader) {
     a.chirp = nullptr;
@@ -1087,7 +1137,7 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   if ((rc = ensure_dyn_lds(k_blu_row, lr))) return rc;
   if ((rc = ensure_dyn_lds(k_blu_col_inv, lc))) return rc;
   const bool col128 = g.L1 == 128 && g.L2 % 32 == 0 && tc == 8;       // wave-per-tile column kernels
-  if (cmp && !(col128 && a.pair && !adjoint && rader)) return GFDN_E_UNSUPPORTED;
+  if (cmp && !(col128 && a.pair && rader)) return GFDN_E_UNSUPPORTED;
   const size_t tw2_elems = (size_t)((g.L >> TW_LOBITS) > 0 ? (g.L >> TW_LOBITS) : 1) + (1 << TW_LOBITS);
   if (stages & 1) {
     if (col128)
@@ -1179,13 +1229,33 @@ extern "C" int gfdn_irfft_odd_pairs_compose_fwd(const void* table, int n, const 
   const int half = (n - 1) / 2 + 1;
   if (ldd < half || ldt < half || (filt_c64 && ldf < half)) return GFDN_E_BADARG;
   if ((batch / nbands) % 2) return GFDN_E_UNSUPPORTED;          // (a pair must not straddle two bands)
-  BluCompose cm{(const float2*)T_c64, ldt, rgain, (const float2*)filt_c64, ldf, G, batch / nbands, direct_rows, h0};
+  BluCompose cm{(const float2*)T_c64, ldt, rgain, (const float2*)filt_c64, ldf, G, batch / nbands, direct_rows, h0, nullptr};
   if (!(stages & 7)) return GFDN_E_BADARG;
   return blu_run(table, n, direct_c64, ldd, batch, x2, ldo, work, 0, (hipStream_t)stream, stages & 7, nullptr, 2, &cm);
 }
 extern "C" int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
                                         int batch, float* gXs, int ldx, void* work, void* stream) {
   return blu_run(table, n, gx2, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, gx2b, 2);
+}
+
+// The paired adjoint transform with the GAINS pass of the output stage's adjoint folded into its last pass: besides
+// gXs = dL/dH (as gfdn_irfft_odd_pairs_bwd) it leaves the partial sums of dL/drgain[b][g] = sum_k Re(dL/dH[b][k]
+// conj(filt[band][k] T'[band][k][g])) in gpart[(b * G + g) * parts + p], parts = gfdn_irfft_odd_pairs_gains_parts(n)
+// (sum the rows in a fixed order: gfdn_tf_rows_sum).  T (nbands, ldt, 4): gfdn_tf_compose_fwd's Tquad.
+extern "C" int gfdn_irfft_odd_pairs_gains_parts(int n) {
+  if (n < 3 || !rader_ok(n)) return 0;
+  return rader_geom(n).L2 / 8;
+}
+extern "C" int gfdn_irfft_odd_pairs_gains_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
+                                              int batch, float* gXs, int ldx, const float* T_c64, int ldt,
+                                              const float* filt_c64, int ldf, int nbands, int G, float* gpart,
+                                              void* work, int stages, void* stream) {
+  if (!T_c64 || !gpart || nbands <= 0 || G <= 0 || batch <= 0 || batch % nbands || !(stages & 7)) return GFDN_E_BADARG;
+  if (G > 4 || (batch / nbands) % 2) return GFDN_E_UNSUPPORTED;
+  const int half = (n - 1) / 2 + 1;
+  if (ldt < half || (filt_c64 && ldf < half)) return GFDN_E_BADARG;
+  BluCompose cm{(const float2*)T_c64, ldt, nullptr, (const float2*)filt_c64, ldf, G, batch / nbands, nullptr, nullptr, gpart};
+  return blu_run(table, n, gx2, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, stages & 7, gx2b, 2, &cm);
 }
 
 extern "C" int gfdn_irfft_odd_fwd(const void* table, int n, const float* X, int ldx, int batch,

@@ -886,9 +886,21 @@ def irfft_odd_pairs_compose_fwd(direct, rows, T, rgain, filt, n: int, nbands: in
     return x2, h0
 
 
-def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None) -> torch.Tensor:
+def tf_rows_sum(part: torch.Tensor) -> torch.Tensor:
+    """part (..., cols) float32 -> sums over the last axis (one wavefront per row, fixed order)."""
+    _need_gpu(part)
+    part = _f(part)
+    cols = part.shape[-1]
+    out = torch.empty(part.shape[:-1], dtype=_f32, device=part.device)
+    _lib.check(_lib.load().gfdn_tf_rows_sum(_p(part), cols, out.numel(), _p(out), _stream()), "gfdn_tf_rows_sum")
+    return out
+
+
+def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None):
     """Adjoint of irfft_odd_fwd(slots=True, pairs=True): g2 (ceil(batch / 2), n, 2) f32 pair-interleaved gradients
-    [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order (``out``: where to write it)."""
+    [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order (``out``: where to write it).
+    ``gains`` = (Tquad (nbands, (n+1)/2, 4), filt (nbands, (n+1)/2) or None, nbands, G): the gains pass of the output
+    stage's adjoint rides the last pass -- returns (gX, gpart (batch, G, parts)); tf_rows_sum(gpart) = dL/drgain."""
     _need_gpu(g2)
     npairs = (batch + 1) // 2
     for t in (g2, g2b):
@@ -901,6 +913,25 @@ def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None) -> torch.Ten
         raise RuntimeError("irfft_odd_pairs_bwd: out must be a contiguous complex64 (batch, (n + 1) / 2) tensor")
     gX = torch.empty((batch, ldx), dtype=_c64, device=g2.device) if out is None else out
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), g2.device)
+    if gains is not None:
+        Tq, filt, nbands, G = gains
+        Tq = _c(Tq)
+        filt = None if filt is None else _c(filt)
+        if tuple(Tq.shape) != (nbands, ldx, 4) or batch % nbands:
+            raise RuntimeError("irfft_odd_pairs_bwd: gains = (Tquad (nbands, (n+1)/2, 4), filt, nbands, G)")
+        gpart = torch.empty((batch, G, lib.gfdn_irfft_odd_pairs_gains_parts(n)), dtype=_f32, device=g2.device)
+        args = (_p(table), n, _p(g2), _p(g2b), n, batch, _p(gX), ldx, _p(Tq), ldx, _p(filt), ldx, nbands, G, _p(gpart),
+                _p(work))
+        if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
+            for name, stage in _BLU_STAGES.items():
+                end = kernel_timer.bracket(name, batch)
+                _lib.check(lib.gfdn_irfft_odd_pairs_gains_bwd(*args, stage, _stream()),
+                           "gfdn_irfft_odd_pairs_gains_bwd[%s]" % name)
+                if end is not None:
+                    end.record()
+        else:
+            _lib.check(lib.gfdn_irfft_odd_pairs_gains_bwd(*args, 7, _stream()), "gfdn_irfft_odd_pairs_gains_bwd")
+        return gX, gpart
     if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
         _staged_bluestein(lib, table, n, g2, g2b, n, batch, gX, ldx, work, 1, 2)
         return gX

@@ -319,6 +319,8 @@ int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, const float* g
                         const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
                         int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc, float* gM,
                         void* stream);
+/* out[r] = sum_p part[r * cols + p]: one wavefront per row, fixed order */
+int gfdn_tf_rows_sum(const float* part, int cols, int rows, float* out, void* stream);
 int gfdn_tf_parts(int K, int nblk);
 size_t gfdn_tf_work_bytes(int nblk);
 size_t gfdn_tf_gpart_bytes(int nblk);
@@ -411,6 +413,15 @@ int gfdn_irfft_odd_pairs_compose_fwd(const void* table, int n, const float* dire
                                      float* x2, int ldo, void* work, int stages, void* stream);
 int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
                              int batch, float* gXs_c64, int ldx, void* work, void* stream);
+/* gfdn_irfft_odd_pairs_bwd with the GAINS pass of the output stage's adjoint (gfdn_tf_gain_grad) folded into its last
+ * pass: every value of dL/dH is used while it is in a register.  gpart[(b * G + g) * parts + p], parts =
+ * gfdn_irfft_odd_pairs_gains_parts(n): partial sums of dL/drgain[b][g] = sum_k Re(dL/dH[b][k] conj(filt[band][k]
+ * T'[band][k][g])) -- sum each row with gfdn_tf_rows_sum.  T (nbands, ldt, 4): gfdn_tf_compose_fwd's Tquad (scaled).
+ * stages as gfdn_irfft_odd_stages; n = 65537 only.  */
+int gfdn_irfft_odd_pairs_gains_parts(int n);
+int gfdn_irfft_odd_pairs_gains_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo, int batch,
+                                   float* gXs_c64, int ldx, const float* T_c64, int ldt, const float* filt_c64, int ldf,
+                                   int nbands, int G, float* gpart, void* work, int stages, void* stream);
 int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, int win, float* P, float* zero_buf2,
                           void* stream);
 int gfdn_stft_power_pairs_bwd(const float* x2, int ld, int T, int items, int win, const float* gP,

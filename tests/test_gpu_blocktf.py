@@ -277,3 +277,30 @@ def test_output_stage_folded_into_the_transform(nbands, B, G, with_filt):
         keep = torch.cat([torch.arange(q * B, q * B + B - 1) for q in range(nbands)]).to(DEV)
         with pytest.raises(RuntimeError):
             ops.irfft_odd_pairs_compose_fwd(direct, rows[keep], Tq, rgain[keep], filt, npts, nbands)
+
+
+@pytest.mark.parametrize("nbands,B,G,with_filt", [(2, 4, 4, True), (1, 6, 3, False)])
+def test_gains_pass_folded_into_the_adjoint_transform(nbands, B, G, with_filt):
+    """gfdn_irfft_odd_pairs_gains_bwd: dL/dH equals gfdn_irfft_odd_pairs_bwd's bit for bit, and the row sums of its gains
+    partials equal gfdn_tf_gain_grad on that dL/dH (other summation order: float32 rounding)."""
+    from diffgfdn_amd import hip_ops as ops
+    npts = 65537
+    half = (npts + 1) // 2
+    g = torch.Generator().manual_seed(5 * nbands + B)
+    batch = nbands * B
+    g2 = torch.randn(batch // 2, npts, 2, generator=g).to(DEV)
+    Ts = (torch.randn(nbands * G, half, generator=g) + 1j * torch.randn(nbands * G, half, generator=g)).to(torch.complex64).to(DEV)
+    Tq = torch.zeros(nbands, half, 4, dtype=torch.complex64, device=DEV)
+    for q in range(nbands):
+        for gi in range(G):
+            Tq[q, :, gi] = Ts[q * G + gi]
+    filt = None
+    if with_filt:
+        filt = (torch.randn(nbands, half, generator=g) + 1j * torch.randn(nbands, half, generator=g)).to(torch.complex64).to(DEV)
+    gH0 = ops.irfft_odd_pairs_bwd(g2, npts, batch)
+    gH, gpart = ops.irfft_odd_pairs_bwd(g2, npts, batch, gains=(Tq, filt, nbands, G))
+    assert torch.equal(gH, gH0)
+    want = ops.tf_gain_grad(Ts, gH0, G, filt, nbands)
+    got = ops.tf_rows_sum(gpart)
+    assert tuple(got.shape) == (batch, G)
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
