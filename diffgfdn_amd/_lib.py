@@ -123,6 +123,7 @@ SIGNATURES = {
     "gfdn_adam_step_counted": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P, _P]),
     "gfdn_adam_step_mirrored": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_float, c_float, c_float, _P, _P]),
     "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_edc_loss_model": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_draw_mask": (c_int, [ctypes.c_ulonglong, _P, c_int, c_float, _P, _P]),
 }
 

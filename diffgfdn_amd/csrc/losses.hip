@@ -393,7 +393,9 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
                                                              const float* __restrict__ maskw,
                                                              float inv_count, float gscale,
                                                              float* __restrict__ work,
-                                                             float* __restrict__ gx, int batch) {
+                                                             float* __restrict__ gx, int batch,
+                                                             const float* __restrict__ amps, int S,
+                                                             const float* __restrict__ env, int ld_env) {
   __shared__ float s_scan[16 * EDC_S];
   __shared__ float s_red[16];
   const int seg = blockIdx.x, b = blockIdx.y;
@@ -403,7 +405,11 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
   const float* xw = x + (size_t)b * ld + start + s0;
-  const float* t = Tdb + (trows ? (size_t)trows[b] : (size_t)b) * len + s0;
+  // target: a stored EDC in dB (Tdb), or the common-slope model evaluated on the fly (losses.py:354-359: einsum
+  // 'bjk,kt->bjt' of the item's amplitudes with the slope envelopes, then dB) -- amps (items, S), env (S, ld_env)
+  const float* t = Tdb ? Tdb + (trows ? (size_t)trows[b] : (size_t)b) * len + s0 : nullptr;
+  const float* am = amps ? amps + (size_t)b * S : nullptr;
+  const float* ev = env ? env + s0 : nullptr;
   const float* mw = maskw ? maskw + s0 : nullptr;
   float* gw = gx ? gx + (size_t)b * ld + start + s0 : nullptr;
   float acc = 0.f, gacc = 0.f;
@@ -415,7 +421,20 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
                if (nv == EDC_V) {
                  float xv[4], t4[4];
                  ld4_f(xw + ilo, xv);
-                 ld4_f(t + ilo, t4);
+                 if (t) {
+                   ld4_f(t + ilo, t4);
+                 } else {
+                   float lin[4] = {0.f, 0.f, 0.f, 0.f};
+                   for (int k = 0; k < S; ++k) {
+                     float e4[4];
+                     ld4_f(ev + (size_t)k * ld_env + ilo, e4);
+                     const float ak = am[k];
+#pragma unroll
+                     for (int u = 0; u < 4; ++u) lin[u] += ak * e4[u];
+                   }
+#pragma unroll
+                   for (int u = 0; u < 4; ++u) t4[u] = fmaxf(10.0f * log10f(fabsf(lin[u]) + F32_EPS), -200.0f);
+                 }
 #pragma unroll
                  for (int u = 0; u < EDC_V; ++u) { val[u] = xv[3 - u] * xv[3 - u]; tv[s][u] = t4[3 - u]; }
                } else {
@@ -424,7 +443,16 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
                    const int i = sl - 1 - j0 - u;
                    const float v = u < nv ? xw[i] : 0.f;
                    val[u] = v * v;
-                   tv[s][u] = u < nv ? t[i] : 0.f;
+                   float tt = 0.f;
+                   if (u < nv) {
+                     if (t) tt = t[i];
+                     else {
+                       float lin = 0.f;
+                       for (int k = 0; k < S; ++k) lin += am[k] * ev[(size_t)k * ld_env + i];
+                       tt = fmaxf(10.0f * log10f(fabsf(lin) + F32_EPS), -200.0f);
+                     }
+                   }
+                   tv[s][u] = tt;
                  }
                }
              },
@@ -852,7 +880,29 @@ extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int l
   hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, target_rows, maskw, inv_count, gscale,
-                     (float*)work, gx, batch);
+                     (float*)work, gx, batch, (const float*)nullptr, 0, (const float*)nullptr, 0);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
+                     loss_item, gx, batch);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// gfdn_edc_loss against the common-slope MODEL instead of a stored target (directional loss, losses.py:354-359):
+// target EDC of item b = sum_k amps[b][k] env[k][t] over the window samples t < len, in dB (|.| + eps, clipped at
+// -200) -- evaluated inside the scan; the (items, len) target and the five passes that build it never exist.
+extern "C" int gfdn_edc_loss_model(const float* x, int ld, int batch, int start, int len, const float* amps, int S,
+                                   const float* env, int ld_env, const float* maskw, float inv_count, float gscale,
+                                   float* loss_item, float* gx, void* work, void* stream) {
+  if (!x || !amps || !env || !loss_item || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld || S <= 0 ||
+      ld_env < len)
+    return GFDN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
+  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, (const float*)nullptr,
+                     (const long long*)nullptr, maskw, inv_count, gscale, (float*)work, gx, batch, amps, S, env, ld_env);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
                      loss_item, gx, batch);

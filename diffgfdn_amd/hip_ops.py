@@ -1114,6 +1114,27 @@ def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None, phas
     return out
 
 
+def edc_loss_model(x, start: int, length: int, amps, env, maskw=None, inv_count: float = 1.0, gscale: float = 1.0,
+                   want_grad: bool = True):
+    """edc_loss against the common-slope model: target EDC of item b = sum_k amps[b][k] env[k][:length] (in dB inside
+    the kernel).  x (B, T) f32, amps (B, S) f32, env (S, >= length) f32 -> (loss_item (B,), gx like x or None)."""
+    _need_gpu(x, amps, env)
+    x, amps, env = _f(x), _f(amps), _f(env)
+    B, T = x.shape
+    S = amps.shape[1]
+    if amps.shape[0] != B or env.shape[0] != S or env.shape[1] < length:
+        raise RuntimeError("edc_loss_model: amps (B, S), env (S, >= length)")
+    maskw = None if maskw is None else _f(maskw)
+    loss_item = torch.empty(B, dtype=_f32, device=x.device)
+    gx = torch.empty_like(x) if want_grad else None
+    lib = _lib.load()
+    work = _work(lib.gfdn_edc_work_bytes(B), x.device)
+    _lib.check(lib.gfdn_edc_loss_model(_p(x), T, B, start, length, _p(amps), S, _p(env), env.shape[1], _p(maskw),
+                                       float(inv_count), float(gscale), _p(loss_item), _p(gx), _p(work), _stream()),
+               "gfdn_edc_loss_model")
+    return loss_item, gx
+
+
 def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
                    gscale: float = 1.0, want_grad: bool = True, rows=None, out=None):
     """edc_loss on pair-interleaved signals x2 (ceil(items / 2), T, 2) -> loss_item (items,), g2 like x2 or None."""

@@ -437,16 +437,15 @@ class directional_edc_loss(nn.Module):
         # true EDC from the common-slope amplitudes (einsum 'bjk,kt->bjt'), then dB
         if self.envelopes.device != x.device:              # (once: a host -> device copy cannot be graph-captured)
             self.envelopes = self.envelopes.to(x.device)
-        edc_true = torch.einsum('bjk, kt -> bjt', amps_true.to(torch.float32).to(x.device),
-                                self.envelopes[:, :L]).reshape(B * J, L)
-        T_db = (10.0 * torch.log10(edc_true.abs() + torch.finfo(torch.float32).eps)).clip(min=-200.0)
         if self.use_mask:
             keep = torch.bernoulli(torch.empty(L).uniform_(0, 1))
             maskw, count = keep.to(device=x.device, dtype=torch.float32), float(keep.sum().item())
         else:
             maskw, count = None, float(L)
-        li, gx = ops.edc_loss(x, start, L, T_db.contiguous(), maskw, 1.0 / (B * J * count), 1.0,
-                              want_grad)
+        # (the einsum 'bjk,kt->bjt' of the amplitudes with the envelopes, |.| + eps, dB and the clip at -200 happen
+        # inside the EDC scan: the (B J, L) target and the six passes over it that built it never exist)
+        amps = amps_true.to(device=x.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
+        li, gx = ops.edc_loss_model(x, start, L, amps, self.envelopes, maskw, 1.0 / (B * J * count), 1.0, want_grad)
         val = li.sum()
         if not want_grad:
             return val

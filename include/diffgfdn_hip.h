@@ -495,6 +495,12 @@ int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float
 int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const float* T_db,
                   const long long* target_rows, const float* maskw, float inv_count, float gscale, float* loss_item,
                   float* gx, void* work, void* stream);
+/* gfdn_edc_loss against the common-slope MODEL of the directional loss (losses.py:354-359) instead of a stored target:
+ * target EDC of item b = sum_k amps[b][k] env[k][t] (amps (batch, S), env (S, ld_env >= len)), |.| + eps in dB clipped
+ * at -200, evaluated inside the scan -- the (batch, len) target and the passes that build it never exist.  */
+int gfdn_edc_loss_model(const float* x, int ld, int batch, int start, int len, const float* amps, int S,
+                        const float* env, int ld_env, const float* maskw, float inv_count, float gscale,
+                        float* loss_item, float* gx, void* work, void* stream);
 
 /* ---- EDC time mask on the device  (losses.py:221-227: mask = argwhere(bernoulli(U(0,1))) over the
  * window -- marginally every index is kept with probability 1/2, independently).

@@ -488,3 +488,23 @@ def test_svf_network_on_fused_mlp_kernel():
     (got * wgt.to(DEV)).sum().backward()
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad.cpu(), q.grad) < 2e-4, k
+
+
+@pytest.mark.parametrize("B,T,start,length,S,masked", [(6, 9000, 37, 8100, 3, False), (3, 5000, 0, 4097, 1, True),
+                                                        (5, 70000, 960, 47360, 4, False)])
+def test_edc_loss_against_the_common_slope_model(ops, B, T, start, length, S, masked):
+    """gfdn_edc_loss_model (target EDC = amps . envelopes in dB, evaluated inside the scan) == gfdn_edc_loss on the
+    target built with torch as directional_edc_loss used to (losses.py:354-359)."""
+    g = torch.Generator().manual_seed(B * 7 + S)
+    x = torch.randn(B, T, generator=g).to(DEV) * torch.exp(-torch.arange(T, device=DEV) / (0.2 * T))
+    amps = (0.1 + torch.rand(B, S, generator=g)).to(DEV)
+    t = torch.arange(length + 50, dtype=torch.float32)
+    env = torch.stack([torch.exp(-13.8 * t / ((0.2 + 0.3 * k) * T)) for k in range(S)]).to(DEV)
+    Tdb = (10.0 * torch.log10((amps @ env[:, :length]).abs() + torch.finfo(torch.float32).eps)).clip(min=-200.0)
+    maskw = None
+    if masked:
+        maskw = (torch.rand(length, generator=g) < 0.5).float().to(DEV)
+    li0, g0 = ops.edc_loss(x, start, length, Tdb.contiguous(), maskw, 1.0 / (B * length), 2.0)
+    li1, g1 = ops.edc_loss_model(x, start, length, amps, env, maskw, 1.0 / (B * length), 2.0)
+    assert torch.allclose(li0, li1, rtol=2e-5, atol=1e-6)
+    assert float((g0 - g1).abs().sum()) < 1e-3 * float(g0.abs().sum())
