@@ -163,9 +163,17 @@ class DiffGFDN(nn.Module):
                               self.num_delay_lines_per_group, None, None)
         return S, Ysub
 
+    # ``Hout_per_del`` (N, K, G) of :meth:`sub_fdn_output` costs five passes over a 42 MB tensor at K = 65 537, N = 27 and
+    # no loss of this path reads it: the trainers switch it off for the models they step (the reference returns it
+    # always, so it stays the default for everyone else)
+    per_delay_output = True
+
     def sub_fdn_output(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(Hout (K, G), Hout_per_del (N, K, G)) as reference model.py:209-252."""
+        """(Hout (K, G), Hout_per_del (N, K, G)) as reference model.py:209-252 (Hout_per_del: None when
+        ``per_delay_output`` is off)."""
         S, Ysub = self.sub_fdn_group_sums(z)
+        if not self.per_delay_output:
+            return S.T, None
         G, n, N = self.num_groups, self.num_delay_lines_per_group, self.num_delay_lines
         K = Ysub.shape[0]
         scaled = (Ysub * self.output_gains.reshape(1, N)).T                 # (N, K): c_n y_n

@@ -130,6 +130,8 @@ class Trainer:
                  subband_filter_freq_resp: Optional[torch.Tensor] = None,
                  process_group=None, stft_win: int = 4096, capturable: bool = False):
         self.net = net
+        if hasattr(net, 'per_delay_output'):
+            net.per_delay_output = False          # (no loss reads Hout_per_del; see DiffGFDN.per_delay_output)
         self.device = trainer_config.device
         self.max_epochs = trainer_config.max_epochs
         self.patience = 5
