@@ -293,6 +293,181 @@ __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Blocks of 9 ... 12 lines (the directional model: 9 SH channels per group): NP = n lanes per system, PACKED -- 64 / NP
+// systems per wavefront (7 for n = 9) instead of the 4 that the power-of-two kernel above fits with 16 lanes each, seven
+// of them idle.  Lane groups of a non-power-of-two size have no xor butterfly: the pivot search reads the NP candidates
+// with NP shuffles (every lane of the group reaches the same choice, ties to the lowest row as above) and rows are
+// broadcast from an explicit source lane.  Same arithmetic, same pivots: the results equal the 16-lane kernel's.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ float2 gauss_jordan_pk(float2 (&row)[NP], float2 rhs, int n, int r, int base, int& pivcol) {
+  const bool active = r < n;
+  bool used = !active;
+  float2 pivinv = make_float2(0.f, 0.f);
+  pivcol = -1;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    if (j < n) {  // wave-uniform
+      const float mag = used ? -1.0f : (row[j].x * row[j].x + row[j].y * row[j].y);
+      float bm = -2.0f;
+      int best = 0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const float om = __shfl(mag, base + i, 64);
+        if (om > bm) { bm = om; best = i; }
+      }
+      float2 pr[NP];
+#pragma unroll
+      for (int c = j; c < NP; ++c) {
+        if (c < n) {
+          pr[c].x = __shfl(row[c].x, base + best, 64);
+          pr[c].y = __shfl(row[c].y, base + best, 64);
+        }
+      }
+      float2 prhs;
+      prhs.x = __shfl(rhs.x, base + best, 64);
+      prhs.y = __shfl(rhs.y, base + best, 64);
+      const float2 inv = cinv(pr[j]);
+      if (r == best) {
+        used = true;
+        pivcol = j;
+        pivinv = inv;
+      } else if (active) {
+        const float2 f = cmul(row[j], inv);
+#pragma unroll
+        for (int c = j + 1; c < NP; ++c) {
+          if (c < n) {
+            row[c].x -= f.x * pr[c].x - f.y * pr[c].y;
+            row[c].y -= f.x * pr[c].y + f.y * pr[c].x;
+          }
+        }
+        rhs.x -= f.x * prhs.x - f.y * prhs.y;
+        rhs.y -= f.x * prhs.y + f.y * prhs.x;
+        row[j] = make_float2(0.f, 0.f);
+      }
+    }
+  }
+  return cmul(rhs, pivinv);
+}
+
+// lane -> (system of the wave, row): the last 64 - NP (64 / NP) lanes of a wave idle (row index NP: inactive)
+template <int NP>
+struct PkLane {
+  int r, base, grp;
+  bool ok;
+  __device__ __forceinline__ PkLane() {
+    constexpr int GPW = 64 / NP;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g0 = lane / NP;
+    ok = g0 < GPW;
+    const int gl = ok ? g0 : GPW - 1;
+    r = ok ? lane - gl * NP : NP;
+    base = gl * NP;
+    grp = wv * GPW + gl;
+  }
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_fwd_pk(SolveArgs a, float2* __restrict__ Y) {
+  constexpr int SPB = 4 * (64 / NP);
+  const PkLane<NP> L;
+  const int r = L.r, blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
+  const int k = blockIdx.x * SPB + L.grp;
+  const bool valid = L.ok && k < a.K;
+  const int kk = k < a.K ? k : a.K - 1;
+  const int i = blk * n + (r < n ? r : 0);
+  const float2 zeta = zeta_abs(a, kk, i, Cx<float2>::zeta(a.turns, a.logr, kk, a.delays[i], Cx<float2>::ig(a, i)));
+  float2 row[NP];
+  build_row<NP, float2>(row, a.A + (size_t)blk * n * n, n, r, a.transpose != 0, zeta);
+  const float2 rhs = make_float2(r < n ? a.b[i] : 0.f, 0.f);
+  int pivcol;
+  const float2 y = gauss_jordan_pk<NP>(row, rhs, n, r, L.base, pivcol);
+  if (valid && pivcol >= 0) Y[(size_t)k * N + blk * n + pivcol] = y;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_bwd_pk(SolveArgs a, const float2* __restrict__ gY,
+                                                      const float2* __restrict__ Ysaved,
+                                                      float* __restrict__ partial) {
+  constexpr int SPB = 4 * (64 / NP);
+  __shared__ float2 s_perm[256];
+  __shared__ float s_acc[SPB * NP * (NP + 2)];
+  const PkLane<NP> L;
+  const int r = L.r, grp = L.grp, base = L.base;
+  const int blk = blockIdx.y, n = a.nper, N = a.nblk * a.nper;
+  const bool active = r < n;
+  const int i = blk * n + (active ? r : 0);
+  const float* Ablk = a.A + (size_t)blk * n * n;
+  const float m_i = a.delays[i], b_i = active ? a.b[i] : 0.f;
+  const float ig_i = Cx<float2>::ig(a, i);
+  const bool tr = a.transpose != 0;
+
+  float acc[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) acc[c] = 0.f;
+  float accb = 0.f, accg = 0.f;
+
+  for (int k0 = blockIdx.x * SPB; k0 < a.K; k0 += gridDim.x * SPB) {
+    const int k = k0 + grp;
+    const bool valid = L.ok && k < a.K;
+    const int kk = k < a.K ? k : a.K - 1;
+    const float2 zpow = Cx<float2>::zeta(a.turns, a.logr, kk, m_i, 1.0f);
+    const float2 zeta = zeta_abs(a, kk, i, cscale(zpow, ig_i));
+    float2 row[NP];
+    int pivcol;
+    float2 ynat;
+    if (Ysaved) {
+      ynat = active ? Ysaved[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    } else {
+      build_row<NP, float2>(row, Ablk, n, r, tr, zeta);
+      const float2 y = gauss_jordan_pk<NP>(row, make_float2(b_i, 0.f), n, r, base, pivcol);
+      __syncthreads();
+      if (pivcol >= 0) s_perm[grp * NP + pivcol] = y;
+      __syncthreads();
+      ynat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    }
+    build_row<NP, float2>(row, Ablk, n, r, !tr, cconj(zeta));
+    const float2 gs = active ? gY[(size_t)kk * N + i] : make_float2(0.f, 0.f);
+    const float2 w = gauss_jordan_pk<NP>(row, gs, n, r, base, pivcol);
+    __syncthreads();
+    if (pivcol >= 0) s_perm[grp * NP + pivcol] = w;
+    __syncthreads();
+    float2 wnat = active ? s_perm[grp * NP + r] : make_float2(0.f, 0.f);
+    if (!valid) { ynat = make_float2(0.f, 0.f); wnat = make_float2(0.f, 0.f); }
+    const float2 mine = tr ? ynat : wnat;
+    const float2 other = tr ? wnat : ynat;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      if (c < n) {
+        const float ox = __shfl(other.x, base + c, 64), oy = __shfl(other.y, base + c, 64);
+        acc[c] += mine.x * ox + mine.y * oy;
+      }
+    }
+    accb += wnat.x;
+    const float2 yz = cmul(ynat, zpow);
+    accg -= wnat.x * yz.x + wnat.y * yz.y;
+  }
+  __syncthreads();
+  if (L.ok) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c) s_acc[(grp * NP + r) * (NP + 2) + c] = acc[c];
+    s_acc[(grp * NP + r) * (NP + 2) + NP] = accb;
+    s_acc[(grp * NP + r) * (NP + 2) + NP + 1] = accg;
+  }
+  __syncthreads();
+  const int per = n * n + 2 * n;
+  float* out = partial + ((size_t)blockIdx.x * a.nblk + blk) * per;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    int rr, cc;
+    if (e < n * n) { rr = e / n; cc = e % n; }
+    else if (e < n * n + n) { rr = e - n * n; cc = NP; }
+    else { rr = e - n * n - n; cc = NP + 1; }
+    float sum = 0.f;
+    for (int g2 = 0; g2 < SPB; ++g2) sum += s_acc[(g2 * NP + rr) * (NP + 2) + cc];
+    out[e] = sum;
+  }
+}
+
 // out[e] = sum_p partial[p][e]; one 256-thread block per output element, fixed-order tree
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial,
                                                          int nparts, int per,
@@ -851,9 +1026,20 @@ static int solve_fwd_run(const double* turns, const double* logr, int K, int nbl
   if (!Y) return GFDN_E_BADARG;
   SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz, ig64};
   const int np = pick_np(nper);
-  const int spb = 256 / np;
+  const int pk = (!precise && nper >= 9 && nper <= 12) ? nper : 0;       // packed lane groups (k_solve_fwd_pk)
+  const int spb = pk ? 4 * (64 / pk) : 256 / np;
   dim3 grid((K + spb - 1) / spb, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (pk) {
+    switch (pk) {
+      case 9: hipLaunchKernelGGL(k_solve_fwd_pk<9>, grid, block, 0, s, a, (float2*)Y); break;
+      case 10: hipLaunchKernelGGL(k_solve_fwd_pk<10>, grid, block, 0, s, a, (float2*)Y); break;
+      case 11: hipLaunchKernelGGL(k_solve_fwd_pk<11>, grid, block, 0, s, a, (float2*)Y); break;
+      default: hipLaunchKernelGGL(k_solve_fwd_pk<12>, grid, block, 0, s, a, (float2*)Y); break;
+    }
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   if (precise) {
     switch (np) {
       case 4: hipLaunchKernelGGL((k_solve_fwd<4, double2>), grid, block, 0, s, a, (float2*)Y); break;
@@ -957,7 +1143,8 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
   if (!gY || !gA || !gb || !ginv_gamma || !work) return GFDN_E_BADARG;
   SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz, ig64};
   const int np = pick_np(nper);
-  const int spb = 256 / np;
+  const int pk = (!precise && nper >= 9 && nper <= 12) ? nper : 0;       // packed lane groups (k_solve_bwd_pk)
+  const int spb = pk ? 4 * (64 / pk) : 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
   const bool lin = !precise && np == 4 && nblk <= S4_MAXBLK;
@@ -987,7 +1174,14 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
     GFDN_LAUNCH_CHECK();
     return 0;
   }
-  if (precise) {
+  if (pk) {
+    switch (pk) {
+      case 9: hipLaunchKernelGGL(k_solve_bwd_pk<9>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      case 10: hipLaunchKernelGGL(k_solve_bwd_pk<10>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      case 11: hipLaunchKernelGGL(k_solve_bwd_pk<11>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      default: hipLaunchKernelGGL(k_solve_bwd_pk<12>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+    }
+  } else if (precise) {
     switch (np) {
       case 4: hipLaunchKernelGGL((k_solve_bwd<4, double2>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
       case 8: hipLaunchKernelGGL((k_solve_bwd<8, double2>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;

@@ -40,7 +40,8 @@ def _dense_from_blocks(A):
 @pytest.mark.parametrize("nblk,nper,transpose,radius", [
     (3, 4, False, 1.0), (4, 4, False, 1.0), (1, 12, False, 1.0), (1, 16, False, 1.0003),
     (3, 9, True, 1.0), (4, 8, False, 1.0), (1, 27, True, 1.0), (1, 32, False, 1.0), (2, 3, False, 1.0),
-    (2, 5, True, 1.0), (3, 7, False, 1.0), (4, 8, True, 1.0), (2, 6, False, 1.0003)])
+    (2, 5, True, 1.0), (3, 7, False, 1.0), (4, 8, True, 1.0), (2, 6, False, 1.0003), (3, 9, False, 1.0003),
+    (2, 10, True, 1.0), (3, 11, False, 1.0), (2, 12, True, 1.0)])
 def test_solve_fwd_bwd(ops, nblk, nper, transpose, radius):
     torch.manual_seed(nblk * 100 + nper)
     N = nblk * nper
