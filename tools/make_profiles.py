@@ -55,6 +55,9 @@ on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` files are t
 | `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` | per-kernel totals / averages (includes the one-off dataset front end, the 20 host-launched roofline steps and the 60 isolated launches of the roofline kernel) |
 | `{tag}_pmc_hbm_bytes.csv` | `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --eager`, and the same with `--pmc WRITE_SIZE` (separate passes) | average FETCH_SIZE / WRITE_SIZE per launch of every hand-written kernel, by grid size; read bytes corrected x2 for gfx950 as MI355X_MICROARCH.md prescribes |
 | `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
+| `{tag}_directional_kernels.txt` | `bash tools/run_dir_profile.sh` (its own gpurun call) | kernel totals of the graph-replayed directional band-step (BASELINE.json configs[3]) |
+| `{tag}_n32_kernels.txt` | `bash tools/run_n32_profile.sh` (its own gpurun call) | kernel totals of the replayed 7-band step at N = 32 (configs[4]) |
+| `{tag}_mfma_experiment.json` | `python tools/mfma_experiment.py` (its own gpurun call) | configs[4]'s bf16 / f32 MFMA contraction against the solve path: time and deviation of H |
 
 `bench.py` reads `{tag}_pmc_hbm_bytes.csv` (`roofline.traffic`) and `{tag}_bench_kernel_stats.csv` (`roofline.top`) at run
 time, so every fraction in the bench line can be recomputed from this directory.
