@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = c_void_p
 

@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define GFDN_ABI_VERSION 1
+/* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
+ * receiver schedule; every entry point of version 1 keeps its signature */
+#define GFDN_ABI_VERSION 2
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
