@@ -25,6 +25,9 @@ CENTRES = (250.0, 1000.0)
 DELAYS = [[641, 701, 809, 907, 1009, 1103, 1201, 1301, 1399, 1409, 1423, 1427, 1429, 1433, 1439, 1601],
           [643, 709, 811, 911, 1013, 1109, 1213, 1303, 1381, 1411, 1423, 1427, 1447, 1451, 1453, 1601]]
 LOSS_TOL, GRAD_TOL = 1e-4, 2e-3
+# BASELINE.json configs[4]: N = 32 = 4 groups x 8 lines (mutually prime delays, as DiffGFDNConfig draws them)
+DELAYS32 = [571, 593, 613, 631, 653, 673, 691, 709, 733, 751, 769, 787, 809, 827, 853, 877, 907, 929, 947, 967, 983, 1009,
+            1031, 1051, 1069, 1091, 1109, 1129, 1151, 1171, 1193, 1213]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -39,7 +42,7 @@ def _filters():
                      for f in CENTRES])
 
 
-def _band(q):
+def _band(q, delays=None):
     from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
     from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
     from diffgfdn_amd.model import DiffGFDNVarReceiverPos
@@ -50,7 +53,7 @@ def _band(q):
     torch.manual_seed(200 + q)
     fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
     of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
-    net = DiffGFDNVarReceiverPos(FS, G, DELAYS[q], DEV, fl, of, use_absorption_filters=False,
+    net = DiffGFDNVarReceiverPos(FS, G, DELAYS[q] if delays is None else delays, DEV, fl, of, use_absorption_filters=False,
                                  common_decay_times=room["common_decay_times"], use_colorless_loss=True).to(DEV)
     return room, ds, net
 
@@ -65,7 +68,7 @@ def _tc():
                                                                         num_fraction_octaves=1))
 
 
-def _oracle_step(sd, q, room, ds, sel, filt_q, keep):
+def _oracle_step(sd, q, room, ds, sel, filt_q, keep, delays=None):
     """normalize + train_step of the CPU oracle from the state dict ``sd`` on receivers ``sel``; returns the loss
     parts, the gradients and the parameters after Adam, keyed like the model's state dict."""
     lin, norm, names = [], [], []
@@ -75,7 +78,8 @@ def _oracle_step(sd, q, room, ds, sel, filt_q, keep):
             pair = (sd[k].clone(), sd[f"output_scalars.mlp.model.{i}.bias"].clone())
             (lin if sd[k].ndim == 2 else norm).append(pair)
             names.append((f"output_scalars.mlp.model.{i}", pair))
-    p = orc.GridModelParams(FS, DELAYS[q], G, sd["input_gains"].clone(), sd["output_gains"].clone(),
+    p = orc.GridModelParams(FS, DELAYS[q] if delays is None else delays, G, sd["input_gains"].clone(),
+                            sd["output_gains"].clone(),
                             sd["feedback_loop.M"].clone(), sd["feedback_loop.alpha"].clone(),
                             room["common_decay_times"], lin, norm, 4)
     otr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
@@ -146,6 +150,33 @@ def test_full_size_single_band_backward_vs_oracle():
     for name in ("input_gains", "output_gains"):         # normalize + Adam: the full update of the gains
         assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, name
     print("single-band full-size gradient deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_full_size_n32_backward_vs_oracle():
+    """BASELINE.json configs[4] (N = 32 = 4 groups x 8 lines) at K = 65 537: losses, every gradient and the Adam update of
+    the module on the thread-per-system 8 x 8 elimination kernels (k_solve8_fwd / _bwd, k_subfdn8_energy) against the
+    oracle -- the float32 leg of the configuration whose bf16 leg DESIGN section 8 measures and rejects."""
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    room, ds, net = _band(0, DELAYS32)
+    assert net.num_delay_lines_per_group == 8
+    filt = torch.tensor(_filters()[0], device=DEV).to(torch.complex64)
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr = VarReceiverPosTrainer(net, _tc(), subband_filter_freq_resp=filt, capturable=True)
+    start, length = tr._decay_window(K)
+    mw, keep = _mask(99, 0, length, B)
+    sel = [0, 5]
+    batch = ds.collate(sel)
+    tr.normalize(batch)
+    tr.optimizer.zero_grad(set_to_none=True)
+    losses = tr._step_losses(batch, mask_prenorm=mw)
+    losses.pop("_total").backward()
+    grads_hip = {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters() if p.grad is not None}
+    tr.optimizer.step()
+    parts_hip = {k: float(v) for k, v in losses.items() if k.endswith("_loss")}
+    after_hip = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    parts, grads, after = _oracle_step(sd0, 0, room, ds, sel, filt, keep, DELAYS32)
+    worst = _check("n32", parts_hip, grads_hip, after_hip, {k: v.numpy() for k, v in sd0.items()}, parts, grads, after)
+    print("N = 32 full-size gradient deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
 def test_full_size_bank_graph_step_backward_vs_oracle():
