@@ -19,7 +19,7 @@ mk() { # name file sed-expr
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT/libv_$1.so
 }
 cp ../lib/libdiffgfdn_hip.so $OUT/libv_base.so
-mk ggprio2 blocktf.hip 's/#define TFG_PRIO 0/#define TFG_PRIO 2/' &
-mk ggprio3 blocktf.hip 's/#define TFG_PRIO 0/#define TFG_PRIO 3/' &
+# mk <name> <file.hip> '<sed expression>' &      e.g.:
+# mk p2tc16 pow2.hip 's/#define P2_TC 8/#define P2_TC 16/' &
 wait
 ls $OUT/libv_*.so

@@ -7,7 +7,7 @@ for i in $(seq $R); do
 for f in tools/_probe/libv_*.so; do
   v=$(basename $f .so)
   cp $f diffgfdn_amd/lib/libdiffgfdn_hip.so
-  timeout -k 10 200 python bench.py --no-cpu-baseline --steps 400 2>/dev/null | python -c "
+  timeout -k 10 200 python bench.py --no-cpu-baseline ${BENCH_ARGS:---steps 400} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(sys.argv[1], d['ms_per_step'])" "$v"
