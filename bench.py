@@ -96,6 +96,26 @@ PROFILE_TAG = 'r02'
 REFERENCE_EPOCH_S_PER_BAND = 139.1   # reference trainer, N = 16, 8 vCPU, one band, one epoch
 
 
+def collective_version():
+    try:
+        v = torch.cuda.nccl.version()            # (on ROCm this is RCCL's version)
+        return '.'.join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:                       # noqa: BLE001 -- informational only
+        return f'unknown ({type(e).__name__})'
+
+
+def library_stamp():
+    """What the loaded C-ABI library was built from: the stamp __graft_entry__.build() wrote beside it (digest of the
+    sources, compiler) checked against the sha256 of the file this process loaded and the sources in the tree."""
+    import __graft_entry__ as ge
+    from diffgfdn_amd import _lib
+    stamp = ge.build_stamp() or {}
+    lib_sha = ge._sha256(_lib.LIB_PATH)
+    return {'hipcc': stamp.get('hipcc'), 'flags': stamp.get('flags'), 'lib_sha256': lib_sha,
+            'stamp_matches_library': stamp.get('lib_sha256') == lib_sha,
+            'stamp_matches_sources': stamp.get('sources_sha256') == ge.source_digest()}
+
+
 def octave_band_response(centre_hz: float, fs: float, nfft: int, numtaps: int = 2049) -> np.ndarray:
     """(K,) response of a linear-phase octave band-pass FIR (stands in for the pyfar taps the
     reference loads, trainer.py:116-128 -- the taps are input data on this path)."""
@@ -486,6 +506,8 @@ def main():
     ap.add_argument('--epoch', action='store_true',
                     help='time whole epochs (19 train + 5 validation steps + checkpoints); --steps = epochs timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--captured-allreduce', action='store_true',
+                    help='N > 1: capture the RCCL all-reduce inside the step graph (when every rank can)')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--pipe-steps', type=int, default=None,
                     help='steps per graph of the pipelined chain (even; 0: one step per graph); default: the trainer\'s')
@@ -535,7 +557,7 @@ def main():
     backend = os.environ.get('GFDN_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    ranks_seen = [0]
+    ranks_seen, rank_devices = [0], [dev_index]
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -546,6 +568,7 @@ def main():
         dist.all_gather_object(seen, (rank, dev_index, socket.gethostname()))
         ranks_seen = sorted(r for r, _, _ in seen)
         assert ranks_seen == list(range(world)), ranks_seen
+        rank_devices = [d for _, d, _ in sorted(seen)]
 
     if args.config == 'directional':
         out = run_directional(args, device, rank, world)
@@ -614,6 +637,12 @@ def main():
             sel = [t[torch.randperm(len(t), generator=gen)[:b_local]].tolist() for t in splits_t]
             return sel[0] if not use_bank else data.global_rows(sel)
 
+        # N > 1: the step is two graphs with the (eager) RCCL all-reduce of the gradient bucket between them unless
+        # --captured-allreduce asks for the collective INSIDE one graph; that structure is taken only when every rank's
+        # capture probe agrees (GraphedTrainStep.capture: MIN over the group), so the ranks can never be on different
+        # structures.  The two-graph step is the default because it needs nothing of RCCL but an ordinary all-reduce.
+        if world > 1:
+            trainer.allreduce_in_graph = bool(args.captured_allreduce)
         step = trainer.graphed(data, b_local)      # normalize + train_step as ONE HIP-graph replay
         if args.pipe_steps is not None:
             step.pipe_steps = args.pipe_steps
@@ -697,7 +726,11 @@ def main():
                        'bands': nbands, 'receivers': args.receivers, 'batch_per_band_per_gpu': b_local,
                        'rirs_per_step_per_gpu': nbands * b_local, 'global_batch_per_band': b_local * world,
                        'delay_lines': G * NPER, 'bins': K, 'rirs_per_s': rirs_per_s,
-                       'launch': graph_mode,
+                       'launch': graph_mode, 'rank_devices': rank_devices,
+                       'collective': (None if world == 1 else
+                                      {'backend': dist.get_backend(), 'library_version': collective_version(),
+                                       'per_step': 'ONE all-reduce (sum) of [gradients of all bands | 3 loss slots per band]',
+                                       'floats': int(trainer.optimizer.bucket.numel())}),
                        'final_loss': [float(v) for v in torch.as_tensor(total).reshape(-1).tolist()]},
         }
         if epoch_info is not None:
@@ -719,6 +752,7 @@ def main():
                                'launches': ktimes['launches'], 'alg_bytes_per_unit': per,
                                'alg_bytes_per_launch': units * per, 'units_per_launch': units,
                                'top': roofline_top(int(round(units)))}
+        out['build'] = library_stamp()
         out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS
         out['whole_step_alg_GBs'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9
         if world == 1 and not args.no_cpu_baseline:

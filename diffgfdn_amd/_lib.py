@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P = c_void_p
 
@@ -31,6 +31,9 @@ SIGNATURES = {
     "gfdn_solve_phi_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_solve_phi_bwd_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_solve_phi_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_solve_phi_absorb_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gfdn_solve_phi_absorb_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                          _P]),
     "gfdn_svf_coefficients": (c_int, [_P, _P, ctypes.c_double, c_int, c_int, _P, _P, _P]),
     "gfdn_sos_response": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_sos_compose_fwd": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
@@ -99,6 +102,9 @@ SIGNATURES = {
     "gfdn_stft_power_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd_phase": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "gfdn_stft_power_pairs_bwd_planar": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P]),
+    "gfdn_decay_items_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, c_float,
+                                     c_float, c_int, _P, _P, _P, _P, _P]),
     "gfdn_edc_loss_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),

@@ -40,7 +40,7 @@ from .config import CouplingMatrixType, TrainerConfig
 from .functional import (ColorlessTerms, FrequencyGrid, MlpGains, OrthoParam, OutputStage, ResolventSolve,
                          SubFdnColorless)
 from .bankstep import FusedBankStep
-from .losses import decay_losses, edc_loss
+from .losses import decay_losses, edc_loss, shard_loss_scales
 from .optim import FlatAdam
 
 
@@ -470,7 +470,7 @@ class BandBankTrainer:
                 S = bank.sub_fdn_group_sums(z)
                 extra, spec, sparse = ColorlessTerms.apply(S, Q, cfg.use_asym_spectral_loss,
                                                            cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
-                                                           1.0 / self.world_size, True, nb)
+                                                           shard_loss_scales(self.world_size, 1, 1.0)['colorless'], True, nb)
         # a tensor allocated on one stream and read on the other must be recorded there: otherwise its block
         # returns to the allocating stream's pool the moment autograd drops it and a kernel of that stream may
         # overwrite it while the other stream still reads it (seen as wrong dL/dM, dL/db under graph replay)
@@ -513,7 +513,8 @@ class BandBankTrainer:
                 extra, spec, sparse = SubFdnColorless.apply(
                     bank._blocks(), bank.input_gains.view(-1), bank.output_gains.view(-1), Q, Ys, Ss, en, gridK,
                     bank.delays, normalize_first, cfg.use_asym_spectral_loss, cfg.spectral_loss_weight,
-                    cfg.sparsity_loss_weight, 1.0 / self.world_size, nb, torch.is_grad_enabled())
+                    cfg.sparsity_loss_weight, shard_loss_scales(self.world_size, 1, 1.0)['colorless'], nb,
+                    torch.is_grad_enabled())
                 if side is not None:
                     tail_done = torch.cuda.Event()
                     tail_done.record(side)

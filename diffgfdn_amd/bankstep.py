@@ -21,12 +21,14 @@ accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve
 path of ``BandBankTrainer._step_losses`` (per-bin elimination kernels) stays as the general fallback and as the
 cross-check of this one (tests/test_gpu_bank.py).
 """
+import os
 from typing import Dict, Optional
 
 import torch
 
 from . import hip_ops as ops
 from .functional import FrequencyGrid
+from .losses import shard_loss_scales
 
 
 class FusedBankStep:
@@ -71,6 +73,9 @@ class FusedBankStep:
     # The gains pass it removes runs beside the records pass on the side stream, off the main chain, while the
     # accumulation lengthens a pass that is ON it.
     fold_gains = False
+    # STFT -> EDR and the EDC term as ONE launch, one workgroup per item (gfdn_decay_items_fwd) instead of the pair STFT,
+    # the EDR column kernel and the three EDC scans.
+    fuse_decay = os.environ.get('GFDN_FUSE_DECAY', '0') == '1'      # (OFF: measured slower; the switch is for same-box A/B runs)
 
     # ------------------------------------------------------------------------------------------
     def _decay_middle(self, H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc, start, length, ev, main,
@@ -87,6 +92,29 @@ class FusedBankStep:
         else:
             x = ops.irfft_odd_fwd(H, K, slots=order is not None)
         ev['x'].record()
+        if pairs and self.fuse_decay and win == 4096 and start + length <= x.shape[1]:
+            # ONE launch per item for STFT -> EDR and the whole EDC term (csrc/decay.hip): |STFT|^2 never reaches memory,
+            # the EDR kernel and the three EDC scans do not run; the EDC gradient comes back planar and joins in the
+            # odd-frame launch of the STFT adjoint
+            main.wait_event(ev['mask'])
+            gP, li_edr, li_edc, dxe = ops.decay_items_fwd(x, Btot, win, T_edr, sum_abs, rows, None, cfg.edr_loss_weight,
+                                                          start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train)
+            ev['edc'].record()
+            keep.extend((x, gP, li_edr, li_edc, dxe))
+            gH = None
+            if train:
+                g = ops.stft_power_pairs_bwd_planar(x, Btot, win, gP, 0)
+                ops.stft_power_pairs_bwd_planar(x, Btot, win, gP, 1, out=g, base=dxe, start=start)
+                ev['g'].record()
+                if gains is not None:
+                    gH, self._gpart = ops.irfft_odd_pairs_bwd(g, K, Btot, gains=gains)
+                    keep.append(self._gpart)
+                else:
+                    gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
+                keep.extend((g, gH))
+            else:
+                ev['g'].record()
+            return li_edr, li_edc, gH
         if pairs:
             P = ops.stft_power_pairs(x, Btot, win)
             g_edr = None
@@ -223,7 +251,7 @@ class FusedBankStep:
             zu, direct = z[:Ku], data['target_early_response'][:, :Ku]
         gridU = FrequencyGrid.of(zu)
         filt = tr._filter_on(Ku, order)
-        inv_world = 1.0 / tr.world_size
+        inv_world = shard_loss_scales(tr.world_size, 1, 1.0)['colorless']
         Hh, n_hidden, _, lo, hi = bank._mlp_cfg
         w = bank.output_scalars_w.detach()
         start, length = tr._decay_window(K)

@@ -177,11 +177,17 @@ class ColorlessFDNTrainer:
     @torch.no_grad()
     def save_ir(self, directory: str, filename: str = 'colorless_fdn_ir.wav', norm: bool = False):
         """Impulse response of the prototype on the trainer's grid as a 32-bit float stereo wav (reference :146-160).
-        An export utility: the grid has 2 fs points, so the inverse transform (length 2 (K - 1), neither of the
-        training path's two lengths) is the library's."""
+        The inverse transform has length n = 2 (K - 1): the power-of-two kernel (gfdn_irfft_pow2_fwd) when n is one;
+        otherwise (the reference's default grid has 2 fs points) the response is brought to the host, where the wav is
+        written anyway, and transformed there -- no FFT library runs on the device on any path of this package."""
         from scipy.io import wavfile
+        from . import hip_ops as ops
         H, _ = self.net(self.z)
-        h = torch.fft.irfft(H)
+        n = 2 * (H.shape[-1] - 1)
+        if n >= 8 and n & (n - 1) == 0 and H.is_cuda:
+            h = ops.irfft_pow2_fwd(H.reshape(1, -1).to(torch.complex64), n).reshape(-1)
+        else:
+            h = torch.from_numpy(np.fft.irfft(H.detach().cpu().numpy().astype(np.complex128), n=n)).to(H.device)
         if norm:
             h = h / torch.max(torch.abs(h))
         os.makedirs(directory, exist_ok=True)

@@ -26,6 +26,7 @@
 // buffers.  Twiddles come from a quarter-period table built in LDS with sincospif (exact
 // argument reduction for power-of-two lengths), w2 = w1^2, w3 = w1 w2.
 #include "common.h"
+#include "fft4k_dev.h"
 
 #include <cmath>
 #include <complex>
@@ -60,49 +61,6 @@ __device__ __forceinline__ void twiddle8(float2 (&a)[8], float2 w1) {
   const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
   a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3); a[4] = cmul(a[4], w4);
   a[5] = cmul(a[5], cmul(w4, w1)); a[6] = cmul(a[6], cmul(w3, w3)); a[7] = cmul(a[7], cmul(w4, w3));
-}
-
-// 16-point DFT, natural order in and out; sgn = +1 forward (e^-), -1 inverse
-__device__ __forceinline__ void bfly16(float2 (&a)[16], float sgn) {
-  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
-  float2 b[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {       // 4-point DFTs over n2 (elements j, j+4, j+8, j+12) -> index q
-    const float2 x0 = a[j], x1 = a[j + 4], x2 = a[j + 8], x3 = a[j + 12];
-    const float2 p = cadd(x0, x2), m = csub(x0, x2), q = cadd(x1, x3), t = csub(x1, x3);
-    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);       // -j t (forward)
-    b[j][0] = cadd(p, q);
-    b[j][1] = cadd(m, jt);
-    b[j][2] = csub(p, q);
-    b[j][3] = csub(m, jt);
-  }
-  // twiddles W16^(j q)
-  auto tw = [&](float2 v, float cr, float ci) {   // v * (cr - i sgn ci)
-    return make_float2(v.x * cr + sgn * v.y * ci, v.y * cr - sgn * v.x * ci);
-  };
-  b[1][1] = tw(b[1][1], c1, s1);   b[1][2] = tw(b[1][2], r, r);     b[1][3] = tw(b[1][3], s1, c1);
-  b[2][1] = tw(b[2][1], r, r);     b[2][2] = tw(b[2][2], 0.f, 1.f); b[2][3] = tw(b[2][3], -r, r);
-  b[3][1] = tw(b[3][1], s1, c1);   b[3][2] = tw(b[3][2], -r, r);    b[3][3] = tw(b[3][3], -c1, -s1);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {       // 4-point DFTs over j -> X[q + 4 s]
-    const float2 x0 = b[0][q], x1 = b[1][q], x2 = b[2][q], x3 = b[3][q];
-    const float2 p = cadd(x0, x2), m = csub(x0, x2), qq = cadd(x1, x3), t = csub(x1, x3);
-    const float2 jt = make_float2(sgn * t.y, -sgn * t.x);
-    a[q] = cadd(p, qq);
-    a[q + 4] = cadd(m, jt);
-    a[q + 8] = csub(p, qq);
-    a[q + 12] = csub(m, jt);
-  }
-}
-// a[u] *= w^u, u = 1..15 (powers by squaring: every factor is at most 3 products away from w)
-__device__ __forceinline__ void twiddle16(float2 (&a)[16], float2 w1) {
-  const float2 w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
-  const float2 w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
-  a[1] = cmul(a[1], w1);  a[2] = cmul(a[2], w2);  a[3] = cmul(a[3], w3);  a[4] = cmul(a[4], w4);
-  a[5] = cmul(a[5], w5);  a[6] = cmul(a[6], w6);  a[7] = cmul(a[7], w7);  a[8] = cmul(a[8], w8);
-  a[9] = cmul(a[9], cmul(w8, w1));   a[10] = cmul(a[10], cmul(w8, w2)); a[11] = cmul(a[11], cmul(w8, w3));
-  a[12] = cmul(a[12], cmul(w8, w4)); a[13] = cmul(a[13], cmul(w8, w5)); a[14] = cmul(a[14], cmul(w8, w6));
-  a[15] = cmul(a[15], cmul(w8, w7));
 }
 
 __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, int n, int nseq, int ss,
@@ -1380,38 +1338,6 @@ __global__ __launch_bounds__(STFT_T) void k_stft_power_bwd(const float* __restri
 // banks), and thread i ends with the bins X[i + 256 u].  Twiddle bases come from sincospif per thread
 // (the pass-1 angle 2 pi i / 4096 also yields the Hann window by angle addition): no tables.
 // ------------------------------------------------------------------------------------------
-#define S4K_T 256
-#define S4K_PAD(i) ((i) + ((i) >> 4))
-#define S4K_LDS (4096 + 256)
-
-// in: a[k] = x[i + 256 k]; out: a[u] = X[i + 256 u].  w1 = (cos, -sin)(2 pi i / 4096).  Every thread of the
-// 256-thread block calls it; buf is free on entry (callers that used it synchronise first) and holds
-// nothing of value on exit.
-__device__ __forceinline__ void fft4096(float2 (&a)[16], float2* buf, int i, float2 w1, float sgn) {
-  bfly16(a, sgn);
-  w1.y *= sgn;
-  twiddle16(a, w1);
-#pragma unroll
-  for (int u = 0; u < 16; ++u) buf[S4K_PAD(16 * i + u)] = a[u];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
-  bfly16(a, sgn);
-  {
-    float sn, cs;
-    sincospif(2.0f * (float)(i >> 4) / 256.0f, &sn, &cs);     // W_256^p, p = i >> 4
-    twiddle16(a, make_float2(cs, -sgn * sn));
-  }
-  __syncthreads();
-  const int base = (i & 15) + 256 * (i >> 4);
-#pragma unroll
-  for (int u = 0; u < 16; ++u) buf[S4K_PAD(base + 16 * u)] = a[u];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
-  bfly16(a, sgn);
-}
-
 // windowed frame pair z[j] = hann(j) (x[m hop + j] + i x[(m+1) hop + j]) at j = i + 256 k; also returns the
 // pass-1 twiddle base and keeps the window values for the adjoint's epilogue
 __device__ __forceinline__ void s4k_load(const float* __restrict__ x, int T, int m, int nframes, int i,
@@ -1551,6 +1477,15 @@ __device__ __forceinline__ void s4k_load_pair(const float2* __restrict__ x2, int
   }
 }
 
+// (cos, sin)(u pi / 8), u = 0..15: the Hann window of the adjoint's rolled epilogue
+__constant__ float2 c_hann_cs[16] = {
+    {1.0f, 0.0f}, {0.92387953251128674f, 0.38268343236508977f}, {0.70710678118654752f, 0.70710678118654752f},
+    {0.38268343236508977f, 0.92387953251128674f}, {0.0f, 1.0f}, {-0.38268343236508977f, 0.92387953251128674f},
+    {-0.70710678118654752f, 0.70710678118654752f}, {-0.92387953251128674f, 0.38268343236508977f}, {-1.0f, 0.0f},
+    {-0.92387953251128674f, -0.38268343236508977f}, {-0.70710678118654752f, -0.70710678118654752f},
+    {-0.38268343236508977f, -0.92387953251128674f}, {0.0f, -1.0f}, {0.38268343236508977f, -0.92387953251128674f},
+    {0.70710678118654752f, -0.70710678118654752f}, {0.92387953251128674f, -0.38268343236508977f}};
+
 // wave priority of the pair STFT kernels (they are the main chain; the colorless pass and the EDC scans that run beside
 // them have slack)
 #define STFT_PAIR_PRIO 0
@@ -1594,7 +1529,8 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
                                                                  int nframes, int items,
                                                                  const float* __restrict__ gP,
                                                                  const float2* base2, float2* gx2, int parity,
-                                                                 int late_base) {
+                                                                 int late_base, const float* __restrict__ pbase,
+                                                                 int pstart, int plen) {
   if (STFT_PAIR_PRIO) __builtin_amdgcn_s_setprio(STFT_PAIR_PRIO);
   float2* buf = dyn_lds;
   const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
@@ -1641,6 +1577,15 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
   const float2* bs = base2 ? base2 + (size_t)p * ld : nullptr;
   const float2* src = parity ? g : (late_base ? nullptr : bs);
   const float2* add = (parity && late_base) ? bs : nullptr;
+  // planar base (odd launch only): per-item rows of plen floats covering the samples [pstart, pstart + plen) -- the EDC
+  // gradient of the fused decay kernel (decay.hip), zero elsewhere
+  const float* pb1 = (parity && pbase) ? pbase + (size_t)b1 * plen : nullptr;
+  const float* pb2 = (pb1 && two) ? pb1 + plen : nullptr;
+  auto padd = [&](int t) {
+    const int tt = t - pstart;
+    if (tt < 0 || tt >= plen) return make_float2(0.f, 0.f);
+    return make_float2(pb1[tt], pb2 ? pb2[tt] : 0.f);
+  };
   const int tlim = parity ? T : ld;
   // the transform's outputs wait in the thread's own LDS slots while a rolled loop adds them to the gradient
   // signal: the epilogue then needs a handful of registers instead of the sixteen outputs plus sixteen loads
@@ -1653,7 +1598,10 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
     if (t < tlim) {
       float2 o = src ? src[t] : make_float2(0.f, 0.f);
       if (add) o = cadd(o, add[t]);
-      const float hw = t < T ? 0.5f - 0.5f * cospif((float)j * (1.0f / 2048.0f)) : 0.f;
+      if (pb1) o = cadd(o, padd(t));
+      // periodic Hann at j = i + 256 u by angle addition from the pass-1 twiddle base w1 = (cos, -sin) theta_i and the
+      // sixteen constants (cos, sin)(u pi / 8) -- two multiply-adds instead of a cospif per sample
+      const float hw = t < T ? 0.5f - 0.5f * (w1.x * c_hann_cs[u].x + w1.y * c_hann_cs[u].y) : 0.f;
       const float2 v = buf[S4K_PAD(j)];
       g[t] = make_float2(o.x + hw * v.x, o.y + (two ? hw * v.y : 0.f));
     }
@@ -1665,6 +1613,12 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2
       for (int t = i; t < 2048 && t < ld; t += S4K_T) g[t] = cadd(g[t], add[t]);
     if (m + 2 >= nframes)
       for (int t = (m * 2048 + 4096 < T ? m * 2048 + 4096 : T) + i; t < ld; t += S4K_T) g[t] = cadd(g[t], add[t]);
+  }
+  if (pb1) {
+    if (m == 1)
+      for (int t = i; t < 2048 && t < ld; t += S4K_T) g[t] = cadd(g[t], padd(t));
+    if (m + 2 >= nframes)
+      for (int t = (m * 2048 + 4096 < T ? m * 2048 + 4096 : T) + i; t < ld; t += S4K_T) g[t] = cadd(g[t], padd(t));
   }
 }
 
@@ -1681,7 +1635,8 @@ extern "C" int gfdn_stft_power_pairs(const float* x2, int ld, int T, int items, 
 }
 
 static int stft_pairs_bwd_run(const float* x2, int ld, int T, int items, int win, const float* gP,
-                              const float* base2, float* gx2, int phases, int late_base, void* stream) {
+                              const float* base2, float* gx2, int phases, int late_base, void* stream,
+                              const float* pbase = nullptr, int pstart = 0, int plen = 0) {
   if (!x2 || !gP || !gx2 || items <= 0 || ld < T) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = gfdn_stft_nframes(T, win);
@@ -1692,7 +1647,7 @@ static int stft_pairs_bwd_run(const float* x2, int ld, int T, int items, int win
     if (nb == 0 || !((phases >> parity) & 1)) continue;
     hipLaunchKernelGGL(k_stft4k_pair_power_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T),
                        S4K_LDS * sizeof(float2), (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, gP,
-                       (const float2*)base2, (float2*)gx2, parity, late_base);
+                       (const float2*)base2, (float2*)gx2, parity, late_base, pbase, pstart, plen);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
@@ -1708,6 +1663,15 @@ extern "C" int gfdn_stft_power_pairs_bwd_phase(const float* x2, int ld, int T, i
   if (phase != 0 && phase != 1) return GFDN_E_BADARG;
   if (phase == 1 && gx2 == base2) return GFDN_E_BADARG;
   return stft_pairs_bwd_run(x2, ld, T, items, win, gP, phase ? base2 : nullptr, gx2, 1 << phase, 1, stream);
+}
+
+extern "C" int gfdn_stft_power_pairs_bwd_planar(const float* x2, int ld, int T, int items, int win, const float* gP,
+                                                const float* pbase, int pstart, int plen, float* gx2, int phase,
+                                                void* stream) {
+  if (phase != 0 && phase != 1) return GFDN_E_BADARG;
+  if (phase == 1 && pbase && (pstart < 0 || plen <= 0)) return GFDN_E_BADARG;
+  return stft_pairs_bwd_run(x2, ld, T, items, win, gP, nullptr, gx2, 1 << phase, 1, stream, phase ? pbase : nullptr,
+                            pstart, plen);
 }
 
 static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }

@@ -1220,7 +1220,15 @@ struct PhiArgs {
   const float* delays;
   const float* inv_gamma;
   const float* b;
+  const float2* ig_bins;       // (K, N) complex 1 / Gamma_i(z_k) of absorption FILTERS (feedback_loop.py:332-344,
+                               // :376-381), multiplying inv_gamma; NULL: scalar gains only
 };
+
+// diagonal entry z_k^{m_i} inv_gamma_i [ / Gamma_i(z_k) ]
+__device__ __forceinline__ float2 phi_zeta(const PhiArgs& a, int k, int i, float m, float ig) {
+  const float2 z = zeta_pow(a.turns, a.logr, k, m, ig);
+  return a.ig_bins ? cmul(z, a.ig_bins[(size_t)k * a.N + i]) : z;
+}
 
 template <int NP>
 __device__ __forceinline__ void build_row_phi(float2 (&row)[NP], const PhiArgs& a, int k, int r, bool adj,
@@ -1252,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_solve_phi_fwd(PhiArgs a, float2* __rest
   const bool valid = k < a.K;
   const int kk = valid ? k : a.K - 1;
   const int i = r < N ? r : 0;
-  const float2 zeta = zeta_pow(a.turns, a.logr, kk, a.delays[i], a.inv_gamma[i]);
+  const float2 zeta = phi_zeta(a, kk, i, a.delays[i], a.inv_gamma[i]);
   float2 row[NP];
   build_row_phi<NP>(row, a, kk, r, false, zeta);
   int pivcol;
@@ -1284,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_solve_phi_bwd(PhiArgs a, const float2* 
     const int k = k0 + grp;
     const bool valid = k < a.K;
     const int kk = valid ? k : a.K - 1;
-    const float2 zeta = zeta_pow(a.turns, a.logr, kk, m_i, ig_i);
+    const float2 zeta = phi_zeta(a, kk, i, m_i, ig_i);
     const float2 ynat = active ? Ysaved[(size_t)kk * N + i] : make_float2(0.f, 0.f);
     float2 row[NP];
     int pivcol;
@@ -1317,8 +1325,8 @@ __global__ __launch_bounds__(256) void k_solve_phi_bwd(PhiArgs a, const float2* 
       }
     }
     accb += wnat.x;
-    {  // g inv_gamma_i = -Re(conj(w_i) y_i z^m), as k_solve_bwd
-      const float2 yz = cmul(ynat, zeta_pow(a.turns, a.logr, kk, m_i, 1.0f));
+    {  // g inv_gamma_i = -Re(conj(w_i) y_i z^m [/ Gamma_i(z_k)]), as k_solve_bwd
+      const float2 yz = cmul(ynat, phi_zeta(a, kk, i, m_i, 1.0f));
       accg -= wnat.x * yz.x + wnat.y * yz.y;
     }
 #pragma unroll
@@ -1360,13 +1368,15 @@ static int phi_args_ok(const double* turns, int K, int G, int nper, const float*
   return 0;
 }
 
-extern "C" int gfdn_solve_phi_fwd(const double* turns, const double* logr, int K, int G, int nper,
-                                  const float* BM, const float* Phi_c64, const float* delays,
-                                  const float* inv_gamma, const float* b, float* Y, void* stream) {
+extern "C" int gfdn_solve_phi_absorb_fwd(const double* turns, const double* logr, int K, int G, int nper,
+                                         const float* BM, const float* Phi_c64, const float* delays,
+                                         const float* inv_gamma, const float* inv_gamma_bins_c64, const float* b,
+                                         float* Y, void* stream) {
   int rc = phi_args_ok(turns, K, G, nper, BM, Phi_c64, delays, inv_gamma, b);
   if (rc) return rc;
   if (!Y) return GFDN_E_BADARG;
-  PhiArgs a{turns, logr, K, G * nper, nper, BM, (const float2*)Phi_c64, delays, inv_gamma, b};
+  PhiArgs a{turns, logr, K, G * nper, nper, BM, (const float2*)Phi_c64, delays, inv_gamma, b,
+            (const float2*)inv_gamma_bins_c64};
   const int np = pick_np(G * nper), spb = 256 / np;
   dim3 grid((K + spb - 1) / spb), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -1380,21 +1390,28 @@ extern "C" int gfdn_solve_phi_fwd(const double* turns, const double* logr, int K
   return 0;
 }
 
+extern "C" int gfdn_solve_phi_fwd(const double* turns, const double* logr, int K, int G, int nper,
+                                  const float* BM, const float* Phi_c64, const float* delays,
+                                  const float* inv_gamma, const float* b, float* Y, void* stream) {
+  return gfdn_solve_phi_absorb_fwd(turns, logr, K, G, nper, BM, Phi_c64, delays, inv_gamma, nullptr, b, Y, stream);
+}
+
 extern "C" size_t gfdn_solve_phi_bwd_work_bytes(int G, int nper) {
   const int N = G * nper;
   return (size_t)GFDN_PARTIAL_BLOCKS * (N * N + 2 * N) * sizeof(float);
 }
 
-extern "C" int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, int nper,
-                                  const float* BM, const float* Phi_c64, const float* delays,
-                                  const float* inv_gamma, const float* b, const float* gY, const float* Y,
-                                  float* gBM, float* gb, float* ginv_gamma, float* gPhi_c64, void* work,
-                                  void* stream) {
+extern "C" int gfdn_solve_phi_absorb_bwd(const double* turns, const double* logr, int K, int G, int nper,
+                                         const float* BM, const float* Phi_c64, const float* delays,
+                                         const float* inv_gamma, const float* inv_gamma_bins_c64, const float* b,
+                                         const float* gY, const float* Y, float* gBM, float* gb, float* ginv_gamma,
+                                         float* gPhi_c64, void* work, void* stream) {
   int rc = phi_args_ok(turns, K, G, nper, BM, Phi_c64, delays, inv_gamma, b);
   if (rc) return rc;
   if (!gY || !Y || !gBM || !gb || !ginv_gamma || !gPhi_c64 || !work) return GFDN_E_BADARG;
   const int N = G * nper;
-  PhiArgs a{turns, logr, K, N, nper, BM, (const float2*)Phi_c64, delays, inv_gamma, b};
+  PhiArgs a{turns, logr, K, N, nper, BM, (const float2*)Phi_c64, delays, inv_gamma, b,
+            (const float2*)inv_gamma_bins_c64};
   const int np = pick_np(N), spb = 256 / np;
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
@@ -1411,6 +1428,15 @@ extern "C" int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K
   hipLaunchKernelGGL(k_solve_bwd_finish, dim3(N * N + 2 * N), dim3(256), 0, s, partial, nparts, 1, N, gBM, gb, ginv_gamma);
   GFDN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, int nper,
+                                  const float* BM, const float* Phi_c64, const float* delays,
+                                  const float* inv_gamma, const float* b, const float* gY, const float* Y,
+                                  float* gBM, float* gb, float* ginv_gamma, float* gPhi_c64, void* work,
+                                  void* stream) {
+  return gfdn_solve_phi_absorb_bwd(turns, logr, K, G, nper, BM, Phi_c64, delays, inv_gamma, nullptr, b, gY, Y, gBM, gb,
+                                   ginv_gamma, gPhi_c64, work, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -142,9 +142,6 @@ class FeedbackLoop(nn.Module):
         if use_absorption_filters and gains is None:
             raise NotImplementedError("absorption filters are fixed designs (reference :200-201 'Cannot learn "
                                       "absorption filters yet'): pass their coefficients as ``gains``")
-        if coupling_matrix_type == CouplingMatrixType.FILTER and use_absorption_filters:
-            raise NotImplementedError("FILTER coupling with absorption filters: the FILTER solve kernel takes scalar "
-                                      "absorption gains")
         self.sample_rate = sample_rate
         self.num_groups = num_groups
         self.num_delay_lines_per_group = num_delay_lines_per_group
@@ -382,6 +379,13 @@ class FeedbackLoop(nn.Module):
         if transpose:
             BM, Phi = BM.T, Phi.transpose(1, 2)
         dev = BM.device
+        if self.use_absorption_filters:
+            # absorption FILTERS on the lines as well (reference :332-344, :376-381 in the same pass as :362-373): the
+            # per-bin complex inverse responses ride the diagonal, the real factor is one
+            if getattr(self, '_ones_n', None) is None or self._ones_n.device != dev:
+                self._ones_n = torch.ones(self.num_delays, dtype=torch.float32, device=dev)
+            return ResolventSolveFilter.apply(BM.contiguous(), Phi.contiguous(), self._ones_n, b.reshape(-1), grid,
+                                              self.delays, self.num_delay_lines_per_group, self._inv_gamma_bins(z))
         inv_gamma = (1.0 / self.current_gains().to(dev)).to(torch.float32)
         return ResolventSolveFilter.apply(BM.contiguous(), Phi.contiguous(), inv_gamma, b.reshape(-1), grid,
                                           self.delays, self.num_delay_lines_per_group)

@@ -145,10 +145,12 @@ class ResolventSolveFilter(torch.autograd.Function):
     (feedback_loop.py:362-373, :441-455), Phi (K, G, G) complex64 per bin."""
 
     @staticmethod
-    def forward(ctx, BM, Phi, inv_gamma, b, grid: FrequencyGrid, delays, nper: int):
-        Y = ops.solve_phi_fwd(grid.turns, grid.logr, BM, Phi, nper, delays, inv_gamma, b)
+    def forward(ctx, BM, Phi, inv_gamma, b, grid: FrequencyGrid, delays, nper: int, inv_gamma_bins=None):
+        # ``inv_gamma_bins`` (K, N) complex64: 1 / Gamma_i(z_k) of fixed absorption filters (feedback_loop.py:332-344,
+        # :376-381) -- data, no gradient
+        Y = ops.solve_phi_fwd(grid.turns, grid.logr, BM, Phi, nper, delays, inv_gamma, b, inv_gamma_bins)
         ctx.save_for_backward(BM, Phi, inv_gamma, b, delays, Y)
-        ctx.grid, ctx.nper = grid, nper
+        ctx.grid, ctx.nper, ctx.igb = grid, nper, inv_gamma_bins
         return Y
 
     @staticmethod
@@ -156,8 +158,9 @@ class ResolventSolveFilter(torch.autograd.Function):
         BM, Phi, inv_gamma, b, delays, Y = ctx.saved_tensors
         g = ctx.grid
         gBM, gb, gig, gPhi = ops.solve_phi_bwd(g.turns, g.logr, BM, Phi, ctx.nper, delays, inv_gamma, b,
-                                               gY.contiguous(), Y)
-        return gBM.to(BM.dtype), gPhi, gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None
+                                               gY.contiguous(), Y, ctx.igb)
+        return (gBM.to(BM.dtype), gPhi, gig.to(inv_gamma.dtype), gb.to(b.dtype).reshape(b.shape), None, None, None,
+                None)
 
 
 class SvfCoefficients(torch.autograd.Function):

@@ -146,27 +146,35 @@ def solve_bwd(turns, logr, A, delays, inv_gamma, b, gY, transpose=False, Y=None,
     return gA, gb, gig
 
 
-def solve_phi_fwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b) -> torch.Tensor:
-    """FILTER coupling: A(z_k) = BM o kron(Phi_k, 1).  BM (N, N) f32, Phi (K, G, G) complex64 -> Y (K, N)."""
+def solve_phi_fwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b, inv_gamma_bins=None) -> torch.Tensor:
+    """FILTER coupling: A(z_k) = BM o kron(Phi_k, 1).  BM (N, N) f32, Phi (K, G, G) complex64 -> Y (K, N).
+    ``inv_gamma_bins`` (K, N) complex64: 1 / Gamma_i(z_k) of absorption filters on the lines (multiplies inv_gamma)."""
     _need_gpu(turns, BM, Phi)
     BM, delays, inv_gamma, b, Phi = _f(BM), _f(delays), _f(inv_gamma), _f(b), _c(Phi)
     K, G = turns.numel(), Phi.shape[-1]
     if tuple(Phi.shape) != (K, G, G) or tuple(BM.shape) != (G * nper, G * nper):
         raise RuntimeError("solve_phi_fwd: Phi must be (K, G, G) and BM (G nper, G nper)")
+    igb = None
+    if inv_gamma_bins is not None:
+        igb = _c(inv_gamma_bins)
+        if tuple(igb.shape) != (K, G * nper):
+            raise RuntimeError("solve_phi_fwd: inv_gamma_bins must be (K, N)")
     Y = torch.empty((K, G * nper), dtype=_c64, device=BM.device)
-    _lib.check(_lib.load().gfdn_solve_phi_fwd(_p(turns), _p(logr), K, G, nper, _p(BM), _p(Phi), _p(delays),
-                                              _p(inv_gamma), _p(b), _p(Y), _stream()), "gfdn_solve_phi_fwd")
+    _lib.check(_lib.load().gfdn_solve_phi_absorb_fwd(_p(turns), _p(logr), K, G, nper, _p(BM), _p(Phi), _p(delays),
+                                                     _p(inv_gamma), _p(igb), _p(b), _p(Y), _stream()),
+               "gfdn_solve_phi_absorb_fwd")
     return Y
 
 
-def solve_phi_bwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b, gY, Y):
+def solve_phi_bwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b, gY, Y, inv_gamma_bins=None):
     """-> gBM (N, N), gb (N,), ginv_gamma (N,) float32 and gPhi (K, G, G) complex64 (per bin)."""
     _need_gpu(turns, BM, Phi, gY, Y)
     BM, delays, inv_gamma, b, Phi, gY, Y = _f(BM), _f(delays), _f(inv_gamma), _f(b), _c(Phi), _c(gY), _c(Y)
     K, G = turns.numel(), Phi.shape[-1]
     N = G * nper
+    igb = None if inv_gamma_bins is None else _c(inv_gamma_bins)
     if tuple(Phi.shape) != (K, G, G) or tuple(BM.shape) != (N, N) or tuple(Y.shape) != (K, N) \
-            or tuple(gY.shape) != (K, N):
+            or tuple(gY.shape) != (K, N) or (igb is not None and tuple(igb.shape) != (K, N)):
         raise RuntimeError("solve_phi_bwd: shape mismatch")
     lib = _lib.load()
     gBM = torch.empty_like(BM)
@@ -174,9 +182,9 @@ def solve_phi_bwd(turns, logr, BM, Phi, nper, delays, inv_gamma, b, gY, Y):
     gig = torch.empty_like(gb)
     gPhi = torch.empty_like(Phi)
     work = _work(lib.gfdn_solve_phi_bwd_work_bytes(G, nper), BM.device)
-    _lib.check(lib.gfdn_solve_phi_bwd(_p(turns), _p(logr), K, G, nper, _p(BM), _p(Phi), _p(delays), _p(inv_gamma),
-                                      _p(b), _p(gY), _p(Y), _p(gBM), _p(gb), _p(gig), _p(gPhi), _p(work),
-                                      _stream()), "gfdn_solve_phi_bwd")
+    _lib.check(lib.gfdn_solve_phi_absorb_bwd(_p(turns), _p(logr), K, G, nper, _p(BM), _p(Phi), _p(delays),
+                                             _p(inv_gamma), _p(igb), _p(b), _p(gY), _p(Y), _p(gBM), _p(gb), _p(gig),
+                                             _p(gPhi), _p(work), _stream()), "gfdn_solve_phi_absorb_bwd")
     return gBM, gb, gig, gPhi
 
 
@@ -1111,6 +1119,62 @@ def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None, phas
     T = x2.shape[1]
     _lib.check(_lib.load().gfdn_stft_power_pairs_bwd(_p(x2), T, T, items, win, _p(gP), _p(base), _p(out),
                                                      _stream()), "gfdn_stft_power_pairs_bwd")
+    return out
+
+
+def decay_items_fwd(x2, items: int, win: int, T_edr, sum_abs, rows, wf, edr_gscale: float, start: int, length: int,
+                    T_edc, maskw, inv_count: float, edc_gscale: float, want_grad: bool = True):
+    """Fused decay-loss forward on pair-interleaved signals x2 (ceil(items / 2), T, 2) (csrc/decay.hip): |STFT|^2 ->
+    EDR term, Schroeder EDC term and both dB-stage adjoints in ONE launch, one workgroup per item.
+    -> (gP (items, nframes, win/2+1) = d(edr term)/d|STFT|^2 or None, edr_part (items, 1) = sum |dEDR| per item, to
+    be divided by sum_abs[rows] (weighted_sums), edc_loss (items,), dxe (items, length) = d(edc term)/dx over the
+    window [start, start + length) or None)."""
+    _need_gpu(x2, T_edr, T_edc, sum_abs)
+    if x2.dtype != _f32 or not x2.is_contiguous() or x2.dim() != 3 or x2.shape[2] != 2 or x2.shape[0] != (items + 1) // 2:
+        raise RuntimeError("decay_items_fwd: x2 must be contiguous float32 (ceil(items / 2), T, 2)")
+    T = x2.shape[1]
+    nf = stft_nframes(T, win)
+    nfreq = win // 2 + 1
+    rows = _rows(rows, items, T_edr.shape[0])
+    if T_edr.dtype != _f32 or not T_edr.is_contiguous() or tuple(T_edr.shape[1:]) != (nf, nfreq) \
+            or sum_abs.numel() != T_edr.shape[0] or (rows is None and T_edr.shape[0] != items):
+        raise RuntimeError("decay_items_fwd: EDR target shape does not match the achieved EDR")
+    if T_edc.dtype != _f32 or not T_edc.is_contiguous() or T_edc.shape[-1] != length \
+            or T_edc.shape[0] != T_edr.shape[0]:
+        raise RuntimeError("decay_items_fwd: EDC target shape does not match the window / the EDR store")
+    wf = None if wf is None else _f(wf)
+    maskw = None if maskw is None else _f(maskw)
+    dev = x2.device
+    gP = torch.empty((items, nf, nfreq), dtype=_f32, device=dev) if want_grad else None
+    dxe = torch.empty((items, length), dtype=_f32, device=dev) if want_grad else None
+    part = torch.empty((items, 1), dtype=_f32, device=dev)
+    edc = torch.empty(items, dtype=_f32, device=dev)
+    _lib.check(_lib.load().gfdn_decay_items_fwd(_p(x2), T, T, items, win, _p(T_edr), _p(_f(sum_abs)), _p(rows), _p(wf),
+                                                float(edr_gscale), int(start), int(length), _p(T_edc), _p(maskw),
+                                                float(inv_count), float(edc_gscale), int(want_grad), _p(gP), _p(part),
+                                                _p(edc), _p(dxe), _stream()), "gfdn_decay_items_fwd")
+    return gP, part, edc, dxe
+
+
+def stft_power_pairs_bwd_planar(x2, items: int, win: int, gP, phase: int, out=None, base=None, start: int = 0):
+    """One launch of the pair STFT adjoint (phase 0: even frames, stores; phase 1: odd frames, adds) with a PLANAR base
+    gradient added by the second one: ``base`` (items, length) float32 = another gradient w.r.t. the samples
+    [start, start + length) of every item (decay_items_fwd's dxe), zero elsewhere."""
+    _need_gpu(x2, gP)
+    out = torch.empty_like(x2) if out is None else out
+    if out.dtype != _f32 or not out.is_contiguous() or out.shape != x2.shape:
+        raise RuntimeError("stft_power_pairs_bwd_planar: out must be shaped like x2")
+    plen = 0
+    if base is not None:
+        if base.dtype != _f32 or not base.is_contiguous() or base.dim() != 2 or base.shape[0] != items:
+            raise RuntimeError("stft_power_pairs_bwd_planar: base must be contiguous float32 (items, length)")
+        plen = base.shape[1]
+        if start < 0 or start + plen > x2.shape[1]:
+            raise RuntimeError("stft_power_pairs_bwd_planar: the base window leaves the signal")
+    T = x2.shape[1]
+    _lib.check(_lib.load().gfdn_stft_power_pairs_bwd_planar(_p(x2), T, T, items, win, _p(gP), _p(base), int(start),
+                                                            int(plen), _p(out), int(phase), _stream()),
+               "gfdn_stft_power_pairs_bwd_planar")
     return out
 
 

@@ -157,6 +157,22 @@ class _DecayTotal(torch.autograd.Function):
         return ((gH * g).reshape(ctx.h_shape),) + (None,) * 9
 
 
+def shard_loss_scales(world_size: int, global_batch: int, mask_count: float) -> Dict[str, float]:
+    """What a rank multiplies its LOCAL loss sums with so that ONE all-reduce (sum) of gradients and loss slots over the
+    ranks equals the single-process step on the whole batch (reference losses.py:478-492, :235-238,
+    trainer.py:298-308):
+      'edr'       -- the EDR term is a SUM over items of per-item ratios: local sums add up as they are;
+      'edc'       -- the EDC term is a MEAN over (global batch x kept time indices): every local |dB| term carries
+                     1 / (global_batch * mask_count), the same time mask on every rank;
+      'colorless' -- spectral and sparsity terms do not depend on the receiver: every rank evaluates them in full and
+                     contributes 1 / world_size of them.
+    The trainers (VarReceiverPosTrainer._step_losses, bankstep.FusedBankStep.run, decay_losses) take their factors from
+    here; tests/test_distributed_cpu.py drives the same function with the CPU oracle as the compute."""
+    if world_size < 1 or global_batch < 1 or mask_count <= 0:
+        raise ValueError("shard_loss_scales: world_size, global_batch >= 1 and mask_count > 0")
+    return {'edr': 1.0, 'edc': 1.0 / (float(global_batch) * float(mask_count)), 'colorless': 1.0 / float(world_size)}
+
+
 def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win: int = 4096,
                  edr_weight: float = 1.0, edc_weight: float = 1.0, use_edr: bool = True,
                  use_edc: bool = True, edc_start: int = 640, edc_len: Optional[int] = None,
@@ -227,7 +243,7 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
         nb = B // nbands if global_batch is None else global_batch
         # pre-normalised weights already carry 1 / (items * kept indices): no host scalar varies
         # from step to step, which keeps the launch arguments static under graph replay
-        inv = 1.0 if edc_maskw_prenormalised else 1.0 / (nb * count)
+        inv = 1.0 if edc_maskw_prenormalised else shard_loss_scales(1, nb, count)['edc']
         if fork:
             side_stream.wait_stream(main)
             with torch.cuda.stream(side_stream):

@@ -31,7 +31,7 @@ from .config import CouplingMatrixType, TrainerConfig
 from .functional import ColorlessTerms, OutputStage, SHToDirectional, irfft_like_torch
 from . import hip_ops as ops
 from .hip_ops import normalize_io, spectral_stats
-from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps
+from .losses import decay_losses, directional_edc_loss, edc_loss, edr_loss, ms_to_samps, shard_loss_scales
 from .model import DiffGFDN
 from .optim import FlatAdam
 
@@ -375,7 +375,7 @@ class VarReceiverPosTrainer(Trainer):
                 # independent terms), values and gradients in two launches
                 terms = ColorlessTerms.apply(S, fl.group_rotations(), cfg.use_asym_spectral_loss,
                                              cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
-                                             1.0 / self.world_size, True)
+                                             shard_loss_scales(self.world_size, 1, 1.0)['colorless'], True)
                 extra = terms[0]
                 colorless = {'spectral_loss': terms[1].detach(), 'sparsity_loss': terms[2].detach()}
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
@@ -962,8 +962,12 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         fused = getattr(tr, '_fused', None) is not None
-        in_graph = tr._allreduce is not None and getattr(tr, 'allreduce_in_graph', False) and \
-            self._collective_is_capturable()
+        # One step structure for the WHOLE group: every rank probes for itself (the probe never raises), then the
+        # verdicts are reduced with MIN -- a rank that cannot capture the collective takes every other rank with it to
+        # the two-graph step, so no two ranks ever pair a captured all-reduce with an eager one (a hang)
+        in_graph = False
+        if tr._allreduce is not None and getattr(tr, 'allreduce_in_graph', False):
+            in_graph = self._all_ranks_agree(self._collective_is_capturable())
         self.allreduce_in_graph = in_graph
         self.graph_a = torch.cuda.CUDAGraph()
         if tr._allreduce is None or in_graph:
@@ -1021,6 +1025,20 @@ class GraphedTrainStep:
         self.losses['edr_loss'] = sums[:, 1] if nb > 1 else sums[1]
         self.losses['edc_loss'] = sums[:, 2] if nb > 1 else sums[2]
         self.losses['_total'] = total
+
+    def _all_ranks_agree(self, ok: bool) -> bool:
+        """MIN of the ranks' verdicts (one small collective, issued by every rank whatever its own verdict)."""
+        tr = self.tr
+        pg = getattr(tr, 'process_group', None)
+        if not dist.is_initialized() or dist.get_world_size(pg) == 1:
+            return bool(ok)
+        on_host = dist.get_backend(pg) != 'nccl'
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cpu' if on_host else self.idx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=pg)
+        agreed = bool(int(t.item()))
+        if ok and not agreed and getattr(tr, 'rank', 0) == 0:
+            print("[diffgfdn_amd] another rank cannot capture the all-reduce: two-graph step on every rank")
+        return agreed
 
     def _collective_is_capturable(self) -> bool:
         """Probe: capture the trainer's collective on a scratch tensor in a throw-away graph and replay it.  Any

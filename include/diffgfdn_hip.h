@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
  * receiver schedule; every entry point of version 1 keeps its signature */
-#define GFDN_ABI_VERSION 2
+#define GFDN_ABI_VERSION 3
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
@@ -122,6 +122,18 @@ int gfdn_solve_phi_bwd(const double* turns, const double* logr, int K, int G, in
                        const float* Phi_c64, const float* delays, const float* inv_gamma, const float* b,
                        const float* gY_c64, const float* Y_c64, float* gBM, float* gb, float* ginv_gamma,
                        float* gPhi_c64, void* work, void* stream);
+/* The same systems with absorption FILTERS on the delay lines (feedback_loop.py:332-344, :376-381 together with the
+ * FILTER coupling of :362-373 -- the reference's forward handles both in one pass): the diagonal entry of line i at bin
+ * k is z_k^{m_i} inv_gamma[i] inv_gamma_bins[k][i], inv_gamma_bins (K, N) complex64 = 1 / Gamma_i(z_k) (NULL: the
+ * entry points above).  The filters are fixed designs: ginv_gamma is the gradient w.r.t. the REAL factor inv_gamma.   */
+int gfdn_solve_phi_absorb_fwd(const double* turns, const double* logr, int K, int G, int nper, const float* BM,
+                              const float* Phi_c64, const float* delays, const float* inv_gamma,
+                              const float* inv_gamma_bins_c64, const float* b, float* Y_c64, void* stream);
+int gfdn_solve_phi_absorb_bwd(const double* turns, const double* logr, int K, int G, int nper, const float* BM,
+                              const float* Phi_c64, const float* delays, const float* inv_gamma,
+                              const float* inv_gamma_bins_c64, const float* b, const float* gY_c64,
+                              const float* Y_c64, float* gBM, float* gb, float* ginv_gamma, float* gPhi_c64,
+                              void* work, void* stream);
 
 /* ---- second-order-section cascades: SVF output filters  (gain_filters.py:221-241 SOSFilter.forward, :262-402
  * SVF_from_MLP, model.py:588-619) -------------------------------------------------------------------------
@@ -433,6 +445,30 @@ int gfdn_stft_power_pairs_bwd_phase(const float* x2, int ld, int T, int items, i
 int gfdn_edc_loss_pairs(const float* x2, int ld, int items, int start, int len, const float* T_db,
                         const long long* target_rows, const float* maskw, float inv_count, float gscale,
                         float* loss_item, float* gx2, void* work, void* stream);
+
+/* Fused decay-loss forward, one workgroup per item (csrc/decay.hip; win = 4096): replaces gfdn_stft_power_pairs ->
+ * gfdn_edr_loss and gfdn_edc_loss_pairs on the training path.  Restates src/diff_gfdn/losses.py:430-495 (edr_loss),
+ * :501-575 (get_stft_torch, get_edr_from_stft), :201-238 (edc_loss), :187-199 (schroeder_backward_integral) with the
+ * element-wise arithmetic of the unfused kernels.  The item walks its frames last to first, |STFT|^2 of eight frames at
+ * a time staying in LDS; |STFT|^2 never reaches memory.
+ *   x2 (ceil(items / 2), ld) float2 pair-interleaved signals of T samples; T_edr_db (rows, nframes, 2049), sum_abs
+ *   (rows), T_edc_db (rows, len): the target stores, item b compares against row target_rows[b] (NULL: b); wf (2049)
+ *   or NULL: frequency weights (losses.py:419-428); maskw (len) or NULL: EDC time weights.
+ *   edr_part[b] = sum_{f,m} wf |EDR_t - EDR_a| (divide by sum_abs[row]: gfdn_weighted_sums with one column);
+ *   edc_loss_item[b] = inv_count * sum_t maskw |EDC_t - EDC_a|.
+ *   want_grad: gP (items, nframes, 2049) = edr_gscale / sum_abs * d(edr term)/d|STFT|^2 (input of the STFT adjoint);
+ *   dxe (items, len) = edc_gscale * d(edc term)/dx over the samples [start, start + len) (planar, per item).
+ * gfdn_stft_power_pairs_bwd_planar: gfdn_stft_power_pairs_bwd_phase whose second launch (phase 1) adds that planar
+ * base (rows of plen floats covering [pstart, pstart + plen), zero elsewhere) instead of a pair-interleaved one.   */
+int gfdn_decay_items_fwd(const float* x2, int ld, int T, int items, int win,
+                         const float* T_edr_db, const float* sum_abs, const long long* target_rows,
+                         const float* wf, float edr_gscale,
+                         int start, int len, const float* T_edc_db, const float* maskw, float inv_count,
+                         float edc_gscale, int want_grad,
+                         float* gP, float* edr_part, float* edc_loss_item, float* dxe, void* stream);
+int gfdn_stft_power_pairs_bwd_planar(const float* x2, int ld, int T, int items, int win, const float* gP,
+                                     const float* pbase, int pstart, int plen, float* gx2, int phase,
+                                     void* stream);
 
 /* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
  * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so

@@ -274,6 +274,26 @@ def feedback_loop_forward_absorption(z: torch.Tensor, delays: torch.Tensor, coef
     return torch.linalg.inv(Ddecay - Acplx).to(torch.complex64)
 
 
+def feedback_loop_forward_filter_absorption(z: torch.Tensor, delays: torch.Tensor, coeffs: torch.Tensor,
+                                            A_poly: torch.Tensor) -> torch.Tensor:
+    """feedback_loop.py:326-391 with BOTH frequency-dependent parts: absorption filters on the lines (SOS list
+    branch :335-341, Gamma_inv per bin :376-381) and FILTER coupling A(z_k) = sum_p A_p z_k^-p (:362-373).
+    coeffs (N, S, 3, 2), A_poly (N, N, order) complex64 -> P (K, N, N) complex64."""
+    K, N = len(z), len(delays)
+    order = A_poly.shape[-1]
+    D = torch.diag_embed(torch.unsqueeze(z, dim=-1) ** delays)
+    Gamma = torch.zeros((N, N, K), dtype=torch.complex64)
+    G = sos_response(z, coeffs)
+    for k in range(N):
+        Gamma[k, k, :] = G[k]
+    zp = (z.view(-1, 1) ** -torch.arange(0, order)).permute(1, 0)
+    A = torch.einsum('jim,mn->jimn', A_poly, zp)
+    A = torch.sum(A, dim=2).permute(2, 0, 1).to(torch.complex64)
+    Gamma_inv = torch.diag_embed(1.0 / torch.diagonal(Gamma), dim1=0, dim2=1)
+    Ddecay = D * Gamma_inv.permute(-1, 0, 1)
+    return torch.linalg.inv(Ddecay - A).to(torch.complex64)
+
+
 # --------------------------------------------------------------------------------------
 # models  (reference: src/diff_gfdn/model.py)
 # --------------------------------------------------------------------------------------

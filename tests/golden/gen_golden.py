@@ -533,6 +533,57 @@ def gen_f12_filter_coupling():
     print('F12 done', sorted(k for k in out if k.startswith('net_grad_')))
 
 
+def gen_f15_full_band_and_filter_absorption():
+    """(a) The full-band configuration as the reference runs it (data/config/treble_data_grid_training_full_band_
+    colorless_loss.yml:5-6, :22-26): SVF output filters from a 10 x 64 MLP on 20 Fourier features TOGETHER WITH
+    absorption filters on the delay lines, N = 12 = 3 groups x 4, scalar coupling (gain_filters.py:262-402,
+    feedback_loop.py:332-344, :376-381, model.py:544-619).  (b) FILTER coupling together with absorption filters: the
+    reference's FeedbackLoop.forward handles both in one pass (feedback_loop.py:362-386)."""
+    import types
+    import diff_gfdn.utils as ref_utils
+    ref_utils.Faudio = types.SimpleNamespace(convolve=full_convolve)
+    fs, nfft, G, nper, B = 8000.0, 1024, 3, 4, 3
+    band_centre_hz = [125.0, 250.0, 500.0, 1000.0, 2000.0]
+    T60 = np.stack([np.linspace(0.5, 0.25, 5), np.linspace(0.9, 0.4, 5), np.linspace(0.7, 0.3, 5)], axis=1)   # (bands, G)
+    delays = prime_delays(G * nper, lo=160, hi=400, seed=12)
+    batch, _ = synth_batch(B, nfft, fs, G, 900, 71, T60=[0.4, 0.7, 0.55])
+    out = {'fs': fs, 'nfft': nfft, 'G': G, 'nper': nper, 'delays': np.array(delays), 'T60': T60,
+           'band_centre_hz': np.array(band_centre_hz)}
+    out.update(batch_to_np(batch))
+    # (a) SVF output filters + absorption filters, the YAML's network
+    torch.manual_seed(43)
+    np.random.seed(43)
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR)
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=10, num_neurons_per_layer=64, num_fourier_features=20)
+    net = DiffGFDNVarReceiverPos(fs, G, delays, 'cpu', fl, of, use_absorption_filters=True, common_decay_times=T60,
+                                 band_centre_hz=band_centre_hz, use_colorless_loss=True)
+    H, (Hout, _) = net(batch)
+    loss = (H.abs() ** 2).sum()
+    loss.backward()
+    out.update({'fb_H': c2np(H), 'fb_Hout': c2np(Hout), 'fb_loss': loss.item(),
+                'fb_compress_pole_factor': float(of.compress_pole_factor),
+                'fb_use_zero_coupling': bool(fl.use_zero_coupling)})
+    out.update(state_np(net, 'fb_sd_'))
+    out.update({'fb_grad_' + k: c2np(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+    # (b) FILTER coupling + absorption filters
+    order = 4
+    torch.manual_seed(47)
+    np.random.seed(47)
+    fl2 = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.FILTER, pu_matrix_order=order)
+    of2 = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    net2 = DiffGFDNVarReceiverPos(fs, G, delays, 'cpu', fl2, of2, use_absorption_filters=True, common_decay_times=T60,
+                                  band_centre_hz=band_centre_hz, use_colorless_loss=True)
+    H2, (Hout2, _) = net2(batch)
+    loss2 = (H2.abs() ** 2).sum()
+    loss2.backward()
+    out.update({'fa_order': order, 'fa_H': c2np(H2), 'fa_Hout': c2np(Hout2), 'fa_loss': loss2.item(),
+                'fa_P_small': c2np(net2.feedback_loop(batch['z_values'][:48]))})
+    out.update(state_np(net2, 'fa_sd_'))
+    out.update({'fa_grad_' + k: c2np(p.grad) for k, p in net2.named_parameters() if p.grad is not None})
+    np.savez_compressed(os.path.join(HERE, 'f15_full_band.npz'), **out)
+    print('F15 done', out['fb_sd_delay_filters'].shape, sorted(k for k in out if k.startswith('fa_grad_')))
+
+
 def gen_f13_single_rir_data():
     """RIRData / SingleRIRDataset (dataloader.py:76-180, :603-658): responses of one RIR and the z grid."""
     from diff_gfdn.dataloader import RIRData, SingleRIRDataset
@@ -586,6 +637,9 @@ if __name__ == '__main__':
         gen_f2_f3_f4('n32_k1025', G=4, nper=8, nfft=2048, fs=8000.0, B=3, T=2000, win=256, hop=128, seed=13)
         gen_f14_learnable_decay_times()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'r3':           # only the fixture added in round 3
+        gen_f15_full_band_and_filter_absorption()
+        sys.exit(0)
     gen_f1_feedback_loop()
     # small: nfft 512 (K = 257, Fermat prime -> prime-length irfft quirk), scaled STFT
     gen_f2_f3_f4('n12_k257', G=3, nper=4, nfft=512, fs=2000.0, B=4, T=400, win=64, hop=32)
@@ -605,3 +659,4 @@ if __name__ == '__main__':
     # N = 32 (4 groups x 8 lines: BASELINE config 5), nfft 2048 (K = 1025 = 5^2 41)
     gen_f2_f3_f4('n32_k1025', G=4, nper=8, nfft=2048, fs=8000.0, B=3, T=2000, win=256, hop=128, seed=13)
     gen_f14_learnable_decay_times()
+    gen_f15_full_band_and_filter_absorption()

@@ -17,19 +17,25 @@ from tests.test_oracle_golden import grid_params
 
 
 def _local_loss(p, batch, fx, world, global_batch, asym):
-    """The trainer's weighting (diffgfdn_amd/trainer.py::_step_losses) with oracle losses."""
+    """A rank's share of the step loss: the oracle's LOCAL sums times the factors the trainers themselves use
+    (diffgfdn_amd.losses.shard_loss_scales -- VarReceiverPosTrainer._step_losses, FusedBankStep.run and decay_losses
+    take theirs from the same function)."""
+    from diffgfdn_amd.losses import shard_loss_scales
     fs = p.sample_rate
     H, Hs = orc.grid_model_forward(p, batch)
     tgt = batch["target_rir_response"]
     B = H.shape[0]
     edr = orc.edr_loss(tgt, H, int(fx["win"]), int(fx["hop"]))                 # sum over local items
     L = orc.ms_to_samps(float(np.max(p.common_decay_times)) * 1e3, fs)
-    edc_local_mean = orc.edc_loss(tgt, H, L, orc.ms_to_samps(20.0, fs))        # mean over local items
-    edc = edc_local_mean * B / global_batch                                    # -> share of the global mean
+    mix = orc.ms_to_samps(20.0, fs)
+    count = min(L, tgt.shape[-1]) - mix                                        # kept time indices (no mask: all)
+    scale = shard_loss_scales(world, global_batch, count)
+    edc_local_sum = orc.edc_loss(tgt, H, L, mix) * B * count                   # sum of |dB| over local items x indices
     crit = orc.amse_loss if asym else orc.mse_loss
     spec = sum(crit(Hs[0][..., k], torch.ones_like(Hs[0][..., k])) for k in range(p.num_groups))
     spars = orc.sparsity_loss(orc.ortho_param(p.M[p.num_groups - 1]))
-    return 1.0 * edr + 10.0 * edc + (1.0 * spec + 2.0 * spars) / world
+    return (1.0 * scale["edr"] * edr + 10.0 * scale["edc"] * edc_local_sum
+            + scale["colorless"] * (1.0 * spec + 2.0 * spars))
 
 
 def _params_list(p):
@@ -252,3 +258,30 @@ def test_epoch_reduction_bandless_rank_mask_and_bucket():
     assert torch.equal(r0["sums"][:, 1], torch.tensor([3.0, 6.0])) and torch.equal(r0["sums"][:, 2], torch.tensor([30.0, 60.0]))
     assert torch.equal(r0["tot"], torch.tensor([3.0 + 30.0 + 1.5, 6.0 + 60.0 + 0.75]))
     assert r0["stepped"] == r1["stepped"] == 1
+
+
+def _agree_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from diffgfdn_amd.trainer import GraphedTrainStep
+    me = SimpleNamespace(tr=SimpleNamespace(process_group=None, rank=rank), idx=torch.zeros(1, dtype=torch.long))
+    # rank 1 "cannot capture": BOTH ranks must end on the two-graph structure; all able: both capture
+    ret[f"mixed{rank}"] = GraphedTrainStep._all_ranks_agree(me, rank == 0)
+    ret[f"all{rank}"] = GraphedTrainStep._all_ranks_agree(me, True)
+    ret[f"none{rank}"] = GraphedTrainStep._all_ranks_agree(me, False)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_step_structure_is_agreed_over_the_group():
+    """One rank failing the capture probe takes every rank to the two-graph step (a captured all-reduce on one rank
+    against an eager one on another would hang): GraphedTrainStep._all_ranks_agree is a MIN over the group."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 777) % 2000)
+    mp.spawn(_agree_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[f"mixed{r}"] is False and ret[f"all{r}"] is True and ret[f"none{r}"] is False

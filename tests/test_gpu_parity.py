@@ -902,6 +902,65 @@ def test_f12_filter_coupling():
         assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 1e-3, name_
 
 
+def test_f15_full_band_svf_with_absorption_filters():
+    """The full-band configuration as the reference runs it (fixture F15a; data/config/treble_data_grid_training_full_
+    band_colorless_loss.yml:5-6, :22-26): SVF output filters from the 10 x 64 network on 20 Fourier features TOGETHER
+    with absorption filters on the delay lines, N = 12 = 3 x 4 -- forward, sub-FDN output and every parameter
+    gradient against the reference (gain_filters.py:262-402, feedback_loop.py:332-344, :376-381, model.py:544-619)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    fx = load("f15_full_band.npz")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR,
+                            use_zero_coupling=bool(fx["fb_use_zero_coupling"]))
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=10, num_neurons_per_layer=64, num_fourier_features=20,
+                            compress_pole_factor=float(fx["fb_compress_pole_factor"]))
+    coeffs = torch.tensor(fx["fb_sd_delay_filters"])
+    net = DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                                 use_absorption_filters=True, common_decay_times=fx["T60"],
+                                 band_centre_hz=fx["band_centre_hz"].tolist(), use_colorless_loss=True,
+                                 absorption_filter_coeffs=coeffs)
+    net.load_state_dict(_state(fx, "fb_sd_"), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx))
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu().numpy(), fx["fb_H"]) < TOL
+    assert rel_err(Hout.detach().cpu().numpy(), fx["fb_Hout"]) < TOL
+    (H.abs() ** 2).sum().backward()
+    worst = {}
+    for name_, prm in net.named_parameters():
+        ref = fx["fb_grad_" + name_]
+        worst[name_] = np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert worst[name_] < 2e-3, (name_, worst[name_])
+
+
+def test_f15_filter_coupling_with_absorption_filters():
+    """FILTER coupling TOGETHER with absorption filters (fixture F15b; the reference's forward handles both in one pass,
+    feedback_loop.py:362-386): explicit inverse on a few bins, forward and every gradient of the grid model, through
+    gfdn_solve_phi_absorb_fwd / _bwd (per-bin complex 1 / Gamma_i(z_k) on the diagonal of the complex-A systems)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    fx = load("f15_full_band.npz")
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.FILTER, pu_matrix_order=int(fx["fa_order"]))
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    coeffs = torch.tensor(fx["fa_sd_delay_filters"])
+    net = DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                                 use_absorption_filters=True, common_decay_times=fx["T60"],
+                                 band_centre_hz=fx["band_centre_hz"].tolist(), use_colorless_loss=True,
+                                 absorption_filter_coeffs=coeffs)
+    net.load_state_dict(_state(fx, "fa_sd_"), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx))
+    P = net.feedback_loop(batch["z_values"][:48].contiguous())
+    assert rel_err(P.detach().cpu().numpy(), fx["fa_P_small"]) < TOL
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu().numpy(), fx["fa_H"]) < TOL
+    assert rel_err(Hout.detach().cpu().numpy(), fx["fa_Hout"]) < TOL
+    (H.abs() ** 2).sum().backward()
+    for name_, prm in net.named_parameters():
+        ref = fx["fa_grad_" + name_]
+        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+
+
 def test_filter_coupling_trainer_steps():
     """VarReceiverPosTrainer on a grid model with paraunitary FILTER coupling: normalize + a few optimiser steps lower
     the loss and move the coupling parameters (unit_vectors, unitary_matrix ride in the default lr group)."""

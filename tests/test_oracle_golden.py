@@ -329,6 +329,56 @@ def test_f12_filter_coupling():
     assert rel_err(H.detach(), fx["net_H"]) < TOL32
 
 
+def test_f15_filter_coupling_with_absorption_filters():
+    """oracle resolvent with FILTER coupling AND absorption filters (feedback_loop.py:362-386 in one pass) vs the
+    reference's explicit inverse on the fixture's first bins, then the grid model's transfer function on top of it."""
+    fx = load("f15_full_band.npz")
+    G, nper = int(fx["G"]), int(fx["nper"])
+    sd = lambda k: torch.tensor(fx["fa_sd_" + k])
+    z = torch.tensor(fx["batch_z_values"])
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    phi = orc.filter_coupling_matrix(sd("feedback_loop.unitary_matrix"), sd("feedback_loop.unit_vectors"))
+    A = orc.filter_coupled_feedback_matrix(sd("feedback_loop.M"), phi)
+    P = orc.feedback_loop_forward_filter_absorption(z[:48], delays, sd("delay_filters"), A)
+    assert rel_err(P.detach(), fx["fa_P_small"]) < TOL32
+    lin, norm = mlp_from_state_(fx, "fa_sd_")
+    p = orc.GridModelParams(float(fx["fs"]), fx["delays"].tolist(), G, sd("input_gains"), sd("output_gains"),
+                            sd("feedback_loop.M"), torch.zeros(G * (G - 1) // 2), fx["T60"], lin, norm, 4)
+    r = p.receiver_gains(torch.tensor(fx["batch_norm_listener_position"]))
+    Pfull = orc.feedback_loop_forward_filter_absorption(z, delays, sd("delay_filters"), A)
+    H = orc.var_receiver_forward(z, sd("input_gains"), sd("output_gains"), r, Pfull,
+                                 torch.tensor(fx["batch_target_early_response"]), nper)
+    assert rel_err(H.detach(), fx["fa_H"]) < TOL32
+
+
+def test_f15_full_band_svf_with_absorption_filters():
+    """oracle restatement of the full-band configuration (SVF output filters from the 10 x 64 network on RAW positions,
+    gain_filters.py:334-402, times the output gains, contracted with the absorption-filter resolvent,
+    model.py:583-619, feedback_loop.py:332-344) vs the reference's forward."""
+    from tests.helpers import mlp_from_state
+    fx = load("f15_full_band.npz")
+    G, nper = int(fx["G"]), int(fx["nper"])
+    sd = lambda k: torch.tensor(fx["fb_sd_" + k])
+    z = torch.tensor(fx["batch_z_values"])
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    lin, norm = mlp_from_state(fx, prefix="fb_sd_", root="output_filters.mlp.model.")
+    pos = torch.tensor(fx["batch_listener_position"])
+    raw = orc.mlp_forward(orc.sinusoidal_encoding(pos, 20), lin, norm).view(pos.shape[0], G, 11, 2)
+    Co = orc.svf_group_responses(z, float(fx["fs"]), raw, float(fx["fb_compress_pole_factor"]))      # (B, G, K)
+    A = orc.coupled_feedback_matrix(sd("feedback_loop.M"), sd("feedback_loop.alpha"))
+    P = orc.feedback_loop_forward_absorption(z, delays, sd("delay_filters"), A)
+    C = Co.repeat_interleave(nper, dim=1) * orc.to_complex(sd("output_gains").expand(pos.shape[0], G * nper, len(z)))
+    Bm = orc.to_complex(sd("input_gains").expand(pos.shape[0], G * nper, len(z)))
+    Htemp = torch.einsum('knb, knm -> kmb', C.permute(-1, 1, 0), P).permute(-1, 1, 0)
+    H = torch.einsum('bmk, bmk -> bk', Htemp, Bm) + torch.tensor(fx["batch_target_early_response"])
+    assert rel_err(H.detach(), fx["fb_H"]) < TOL32
+
+
+def mlp_from_state_(fx, prefix):
+    from tests.helpers import mlp_from_state
+    return mlp_from_state(fx, prefix=prefix, root="output_scalars.mlp.model.")
+
+
 def test_f13_single_rir_data():
     """RIRData / SingleRIRDataset / load_dataset for one measured response (dataloader.py:76-180, :603-658, :780-867)
     against the reference's: in-place fades, the three spectra, the z grid outside the unit circle."""
