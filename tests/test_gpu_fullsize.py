@@ -103,7 +103,7 @@ def _oracle_step(sd, q, room, ds, sel, filt_q, keep, delays=None, n_fourier=4):
     return parts, grads, after
 
 
-def _check(tag, parts_hip, grads_hip, after_hip, before, parts, grads, after, grad_tol=None):
+def _check(tag, parts_hip, grads_hip, after_hip, before, parts, grads, after, grad_tol=None, grad_tol_M=None):
     grad_tol = GRAD_TOL if grad_tol is None else grad_tol
     for k, v in parts.items():
         assert abs(parts_hip[k] - v) <= LOSS_TOL * abs(v) + 1e-7, (tag, k, parts_hip[k], v)
@@ -112,7 +112,8 @@ def _check(tag, parts_hip, grads_hip, after_hip, before, parts, grads, after, gr
         gh = np.asarray(grads_hip[k], dtype=np.float64).reshape(-1)
         go = g.numpy().astype(np.float64).reshape(-1)
         worst[k] = np.abs(gh - go).max() / (np.abs(go).max() + 1e-300)
-        assert worst[k] < grad_tol, (tag, k, worst[k])
+        assert worst[k] < (grad_tol_M if (grad_tol_M is not None and k == "feedback_loop.M") else grad_tol), \
+            (tag, k, worst[k])
         # Adam's first step moves every entry by lr g / (|g| + eps): the update of M (which normalize leaves alone) is
         # compared where the gradient is not at the noise floor of float32 sums over 65 537 bins
         if k == "feedback_loop.M":
@@ -232,9 +233,11 @@ def test_full_size_bench_shape_vs_oracle():
     """EXACTLY what bench.py times (BASELINE.json's headline configuration): 7 octave bands x 32 receivers per step =
     224-item launches, N = 16 (4 x 4), the 5 x 16 gain network on 20 Fourier features, bench.py's own workload builder,
     one replay of the captured explicit bank step (slot order, pair-interleaved signals, XCD item maps, device-drawn
-    mask) -- every loss term of every band against the CPU oracle to 1e-4, every parameter gradient to 5e-4 of its
-    largest entry (worst deviations printed; the float32 noise floor of these gradients is characterised in DESIGN.md
-    section 2)."""
+    mask) -- every loss term of every band against the CPU oracle to 1e-4; the gradients of the gains and of the gain
+    network to 2e-4 of their largest entry (measured: <= 6e-5), dL/dM to 1e-3 (measured: <= 6.4e-4).  dL/dM is the SKEW
+    part of the matrix-exponential adjoint of dL/d(Q Q): its largest entry is two orders of magnitude below dL/d(Q Q)'s,
+    so the 1e-6 float32 accuracy of dL/d(Q Q) (tools/grad_stage_probe.py: records path against complex128 autograd on
+    the same dL/dH) appears amplified by that ratio."""
     import bench
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
     dev = torch.device("cuda", 0)
@@ -284,7 +287,8 @@ def test_full_size_bench_shape_vs_oracle():
             after_hip = {k: v.detach().cpu().numpy() for k, v in nets[q].state_dict().items()}
             parts, grads, after = _oracle_step(sd0[q], q, rooms[q], datas[q], sels[q], filts[q], keep, delays_l[q], nfeat)
             worst = _check(f"bench[{int(centres[q])} Hz]", parts_hip, grads_hip, after_hip,
-                           {k: v.numpy() for k, v in sd0[q].items()}, parts, grads, after, grad_tol=5e-4)
+                           {k: v.numpy() for k, v in sd0[q].items()}, parts, grads, after, grad_tol=2e-4,
+                           grad_tol_M=1e-3)
             for name in ("input_gains", "output_gains"):
                 assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, (q, name)
             for k, v in worst.items():
