@@ -1,0 +1,600 @@
+// Block transfer functions in polynomial form for blocks of 5..8 delay lines (the N = 32 = 4 x 8 layout of
+// BASELINE.json configs[4]), zero coupling, for gfx950 -- with the polynomial evaluation on the matrix cores.
+//
+// Reference maths (orchidas/DiffGFDN, src/diff_gfdn): the resolvent of one block, X(z) = D(z) Gamma^-1 - A
+// (feedback_loop.py:326-391), enters the model only through  y = X^-1 b  (delay-line responses),  T = c^T y  (group
+// transfer function, model.py:583-619; sub-FDN responses with the raw M and no absorption, model.py:209-252)  and, in the
+// backward pass,  w = X^-T c:   dT = w^T dA y,  dT/db = w,  dT/dc = y.   By Cramer's rule every one of these is a ratio of
+// MULTILINEAR polynomials in the n phasors zeta_i = z^{m_i} / gamma_i,
+//     det X          = sum_S DET_S e_S ,        DET_S = det((-A)[S^c, S^c]) prod_{i in S} 1/gamma_i ,  e_S = prod_{i in S} z^{m_i}
+//     (adj(X) b)_i   = sum_S Y_{i,S} e_S ,      Y_{i,S} = det(((-A) with column i := b)[S^c, S^c]) prod 1/gamma   (i in S^c)
+//     (adj(X)^T c)_j = sum_S W_{j,S} e_S ,      W_{j,S} = det(((-A) with row j := c)[S^c, S^c]) prod 1/gamma      (j in S^c)
+// 17 polynomials x 256 real coefficients per block, built once per step in float64 (k_tf8_coefs).  With the subsets
+// split as S = (S1 over lines 0..3, S2 over lines 4..7), a polynomial is the bilinear form  e1^T C e2  of a REAL 16 x 16
+// coefficient matrix with the two complex subset-phasor vectors of a bin, and C e2 for 64 bins at a time is a GEMM:
+// v_mfma_f32_16x16x4_f32 (exact float32 products, float32 accumulate) with A = C (lane l: C[S1 = l & 15][S2 = 4 ks + (l >> 4)],
+// i.e. coef[64 ks + l]: one coalesced load), B = Re / Im of e2 of sixteen bins.  The thread-per-system 8 x 8 complex
+// eliminations of csrc/solve.hip (k_solve8_fwd / _bwd, k_subfdn8_energy: ~2500 VALU instructions per system at one wave
+// per SIMD) become ~64 MFMAs + ~800 VALU instructions per 64 bins for the forward polynomials and ~550 MFMAs for all 17.
+// The backward needs no adjoint elimination and no records -> parameter map: the per-bin y and w give dL/dA, dL/db,
+// dL/dc directly (80 per-lane accumulators, fixed-order sums).
+//
+// Scaling convention (trainer.py:317-332 normalize): the coefficient records are built from the gains BEFORE the rescale
+// (b_old, c_old); afterwards the gain buffers hold b' = b_old sqrt(s), c' = c_old sqrt(s), s = scale = E^(-1/2), and
+// T' = T(b', c') = s T(b_old, c_old) = sqrt(s) sum_i c'_i y_old_i.  Gradients w.r.t. the rescaled parameters:
+// dL/dA = s acc_A, dL/db' = sqrt(s) acc_b, dL/dc' = sqrt(s) acc_c with the accumulators taken on the old polynomials.
+#include "common.h"
+#include "ortho_dev.h"
+
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+#define T8_NPOLY 17
+#define T8_REC (T8_NPOLY * 256)        // floats per block: [poly][S], S = S1 + 16 S2
+#define T8_ACC 80                      // 64 dL/dA (row-major 8 x 8) | 8 dL/db | 8 dL/dc
+#define T8_MAXBLK 64
+#define T8_MAX_PARTS 256
+#define T8_WAVES 4
+#define T8_LDS_BYTES ((size_t)T8_WAVES * 2 * 16 * 64 * sizeof(float2))
+
+// ------------------------------------------------------------------------------------------
+// coefficient records (float64): determinants of masked 8 x 8 matrices, partial pivoting by row selects
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double t8_det(double (&m)[8][8]) {
+  double det = 1.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double best = fabs(m[j][j]);
+    int bi = j;
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      const double v = fabs(m[i][j]);
+      if (v > best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      const bool sw = bi == i;
+#pragma unroll
+      for (int c = j; c < 8; ++c) {
+        const double t = m[j][c];
+        m[j][c] = sw ? m[i][c] : t;
+        m[i][c] = sw ? t : m[i][c];
+      }
+    }
+    if (bi != j) det = -det;
+    const double p = m[j][j];
+    det *= p;
+    const double inv = p != 0.0 ? 1.0 / p : 0.0;
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      const double f = m[i][j] * inv;
+#pragma unroll
+      for (int c = j + 1; c < 8; ++c) m[i][c] -= f * m[j][c];
+    }
+  }
+  return det;
+}
+
+// grid (nblk, sets, 9): z = 0 the determinant polynomial, z = 1 + i the numerators of y_i and w_i; thread S = subset
+__global__ __launch_bounds__(256) void k_tf8_coefs(const float* __restrict__ A0, const float* __restrict__ ig0,
+                                                   float* __restrict__ coef0, const float* __restrict__ A1,
+                                                   const float* __restrict__ ig1, float* __restrict__ coef1,
+                                                   const float* __restrict__ b, const float* __restrict__ c, int n) {
+  __shared__ double sA[64], sb[8], sc[8], sig[8];
+  const int blk = blockIdx.x, set = blockIdx.y, task = blockIdx.z, S = threadIdx.x;
+  const float* A = (set ? A1 : A0) + (size_t)blk * n * n;
+  const float* ig = set ? ig1 : ig0;
+  float* coef = (set ? coef1 : coef0) + (size_t)blk * T8_REC;
+  if (S < 64) {
+    const int i = S >> 3, j = S & 7;
+    sA[S] = (i < n && j < n) ? -(double)A[i * n + j] : 0.0;
+  }
+  if (S < 8) {
+    sb[S] = S < n ? (double)b[blk * n + S] : 0.0;
+    sc[S] = S < n ? (double)c[blk * n + S] : 0.0;
+    sig[S] = (S < n && ig) ? (double)ig[blk * n + S] : 1.0;
+  }
+  __syncthreads();
+  const bool absent = (S >> n) != 0;              // the subset names a line the block does not have: coefficient 0
+  double igp = 1.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if ((S >> i) & 1) igp *= sig[i];
+  // (-A) with column `col` := b or row `row` := c (-1: untouched), restricted to the complement of S: lines of S -- and
+  // the lines beyond n -- become unit rows / columns, which leaves the determinant of the restriction
+  auto masked_det = [&](int col, int row) {
+    double m[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const bool in = !((S >> r) & 1) && !((S >> cc) & 1) && r < n && cc < n;
+        double v = sA[r * 8 + cc];
+        if (cc == col) v = sb[r];
+        if (r == row) v = sc[cc];
+        m[r][cc] = in ? v : (r == cc ? 1.0 : 0.0);
+      }
+    return t8_det(m);
+  };
+  if (task == 0) {
+    coef[S] = absent ? 0.f : (float)(masked_det(-1, -1) * igp);
+  } else {
+    const int i = task - 1;
+    const bool none = absent || i >= n || ((S >> i) & 1);
+    coef[(1 + i) * 256 + S] = none ? 0.f : (float)(masked_det(i, -1) * igp);
+    coef[(9 + i) * 256 + S] = none ? 0.f : (float)(masked_det(-1, i) * igp);
+  }
+}
+
+extern "C" int gfdn_tf8_coefs(const float* A0, const float* inv_gamma0, float* coef0, const float* A1,
+                              const float* inv_gamma1, float* coef1, const float* b, const float* c, int nblk, int nper,
+                              void* stream) {
+  if (!A0 || !coef0 || !b || !c || nblk <= 0 || nper <= 0 || (A1 && !coef1)) return GFDN_E_BADARG;
+  if (nper > 8 || nblk > T8_MAXBLK) return GFDN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tf8_coefs, dim3(nblk, A1 ? 2 : 1, 9), dim3(256), 0, (hipStream_t)stream, A0, inv_gamma0, coef0, A1,
+                     inv_gamma1, coef1, b, c, nper);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// passes over the bins: one workgroup = four wavefronts on ONE block, a wavefront = tiles of 64 bins (lane = bin)
+// ------------------------------------------------------------------------------------------
+struct T8Args {
+  const double* turns;
+  int K, nblk, nper;
+  const float* coef;         // (nblk, 17, 256)
+  const float* delays;       // (nblk * nper)
+  const float* c;            // (nblk * nper) output gains as they are NOW (see the scaling convention)
+  const float* scale;        // (nblk) s = E^(-1/2), or NULL (the energy pass: gains not yet rescaled, factor 1)
+  // T8_TSAVE
+  float2* Tsave;             // (nblk, K)
+  float2* Tquad;             // (nblk / G, K, 4) or NULL
+  int G;
+  // T8_COLORLESS
+  int asym;
+  float gscale;
+  float* lossp;              // (nblk, nparts) partial losses
+  // T8_BWD
+  const float* rgain;        // (nblk / G * B, G)
+  const float2* gH;          // (nblk / G * B, ldh)
+  int ldh;
+  const float2* filt;        // (nblk / G, ldf) or NULL
+  int ldf, B;
+  float* part;               // T8_ENERGY: [blk * nparts + p]; heavy modes: [(blk * T8_ACC + e) * nparts + p]
+};
+
+enum { T8_ENERGY = 0, T8_TSAVE = 1, T8_COLORLESS = 2, T8_BWD = 3 };
+
+extern __shared__ float2 t8_lds[];
+
+__device__ __forceinline__ float2 t8_zpow(const double* __restrict__ turns, int k, float m) {
+  double t = (double)m * turns[k];
+  t -= rint(t);
+  float s, c;
+  sincospif(2.0f * (float)t, &s, &c);
+  return make_float2(c, s);
+}
+
+// subset products of four phasors, written to the wave's [S][lane] image
+__device__ __forceinline__ void t8_stage_subsets(float2 p0, float2 p1, float2 p2, float2 p3, float2* img, int lane) {
+  float2 e[16];
+  e[0] = make_float2(1.f, 0.f);
+  e[1] = p0; e[2] = p1; e[4] = p2; e[8] = p3;
+  e[3] = cmul(e[1], e[2]);
+  e[5] = cmul(e[1], e[4]);
+  e[6] = cmul(e[2], e[4]);
+  e[9] = cmul(e[1], e[8]);
+  e[10] = cmul(e[2], e[8]);
+  e[12] = cmul(e[4], e[8]);
+  e[7] = cmul(e[3], e[4]);
+  e[11] = cmul(e[3], e[8]);
+  e[13] = cmul(e[5], e[8]);
+  e[14] = cmul(e[6], e[8]);
+  e[15] = cmul(e[3], e[12]);
+#pragma unroll
+  for (int S = 0; S < 16; ++S) img[S * 64 + lane] = e[S];
+}
+
+// NP polynomials of the wave's 64 bins: val[p] (lane = bin) = e1^T C_p e2, the A operands A[p][ks] already in registers
+template <int NP>
+__device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* E1, const float2* E2, int lane,
+                                         float2 (&val)[NP]) {
+  const int q = lane >> 4, cidx = lane & 15;
+  // (rolled: unrolled, the scheduler interleaves the four column groups' MFMA chains and keeps all their accumulators
+  // -- 4 x 2 x 4 NP registers -- alive at once)
+#pragma unroll 1
+  for (int cg = 0; cg < 4; ++cg) {
+    f32x4 are[NP], aim[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      are[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      aim[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float2 b2 = E2[(4 * ks + q) * 64 + 16 * cg + cidx];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        are[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][ks], b2.x, are[p], 0, 0, 0);
+        aim[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][ks], b2.y, aim[p], 0, 0, 0);
+      }
+    }
+    float2 e1v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e1v[r] = E1[(4 * q + r) * 64 + 16 * cg + cidx];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // D[S1 = 4 q + r][bin] = (C e2)[S1]: times e1[S1], summed over the S1 of this lane ...
+        s.x += are[p][r] * e1v[r].x - aim[p][r] * e1v[r].y;
+        s.y += are[p][r] * e1v[r].y + aim[p][r] * e1v[r].x;
+      }
+      // ... and over the four lanes that hold the other S1 of the same bin
+      s.x += __shfl_xor(s.x, 16, 64);
+      s.y += __shfl_xor(s.y, 16, 64);
+      s.x += __shfl_xor(s.x, 32, 64);
+      s.y += __shfl_xor(s.y, 32, 64);
+      if (q == cg) val[p] = s;          // bin 16 cg + cidx = this lane
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
+  __shared__ float s_red[T8_WAVES][257];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int blk = blockIdx.y, n = a.nper, K = a.K;
+  float2* E1 = t8_lds + wv * 2048;
+  float2* E2 = E1 + 1024;
+  const float* coef = a.coef + (size_t)blk * T8_REC;
+  float m[8], cg_[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    m[r] = r < n ? a.delays[blk * n + r] : 0.f;
+    cg_[r] = r < n ? a.c[blk * n + r] : 0.f;
+  }
+  const float sc = a.scale ? a.scale[blk] : 1.0f;
+  const float tmul = a.scale ? sqrtf(sc) : 1.0f;          // T' = tmul sum_i c_i y_i (scaling convention above)
+  constexpr bool HEAVY = MODE == T8_COLORLESS || MODE == T8_BWD;
+  // light modes: the determinant and the numerator P = sum_i c_i Y_i as two A-operand sets held in registers
+  float AL[2][4];
+  if (!HEAVY) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      AL[0][ks] = coef[64 * ks + lane];
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p += cg_[i] * coef[(1 + i) * 256 + 64 * ks + lane];
+      AL[1][ks] = p;
+    }
+  }
+  float acc0 = 0.f;                                      // energy / loss partial
+  f32x4 accD = (f32x4){0.f, 0.f, 0.f, 0.f};              // heavy modes: the 16 x 16 tile [dL/dA | dL/db ; dL/dc] (below)
+  const int ntiles = (K + 63) >> 6;
+  const float invK = 1.0f / (float)K;
+  const int band = a.G > 0 ? blk / a.G : 0, g = a.G > 0 ? blk - band * a.G : 0;
+#pragma unroll 1
+  for (int tile = blockIdx.x * T8_WAVES + wv; tile < ntiles; tile += gridDim.x * T8_WAVES) {
+    const int k = tile * 64 + lane;
+    const bool live = k < K;
+    const int kk = live ? k : K - 1;
+    // the output-stage adjoint folds the receivers' dL/dH first: the loads fly over the phasors
+    float2 gs = make_float2(0.f, 0.f);
+    if (MODE == T8_BWD && live) {
+      const float2* gh = a.gH + (size_t)band * a.B * a.ldh + kk;
+      const float* rg = a.rgain + (size_t)band * a.B * a.G + g;
+      for (int bb = 0; bb < a.B; ++bb) {
+        const float2 v = gh[(size_t)bb * a.ldh];
+        const float r = rg[bb * a.G];
+        gs.x += r * v.x;
+        gs.y += r * v.y;
+      }
+      if (a.filt) gs = cmulc(gs, a.filt[(size_t)band * a.ldf + kk]);      // dL/dT' = conj(filt) sum_b rgain dL/dH
+    }
+    asm volatile("" ::: "memory");
+    t8_stage_subsets(t8_zpow(a.turns, kk, m[0]), t8_zpow(a.turns, kk, m[1]), t8_zpow(a.turns, kk, m[2]),
+                     t8_zpow(a.turns, kk, m[3]), E1, lane);
+    t8_stage_subsets(t8_zpow(a.turns, kk, m[4]), t8_zpow(a.turns, kk, m[5]), t8_zpow(a.turns, kk, m[6]),
+                     t8_zpow(a.turns, kk, m[7]), E2, lane);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS image: no block barrier)
+    if (!HEAVY) {
+      float2 val[2];
+      t8_polys<2>(AL, E1, E2, lane, val);
+      const float2 t = cmul(val[1], cinv(val[0]));           // sum_i c_i y_i
+      if (MODE == T8_ENERGY) {
+        if (live) acc0 += t.x * t.x + t.y * t.y;
+      } else {
+        const float2 ts = cscale(t, tmul);
+        if (live) {
+          a.Tsave[(size_t)blk * K + k] = ts;
+          if (a.Tquad) {
+            float2* qd = a.Tquad + ((size_t)band * K + k) * 4;
+            qd[g] = ts;
+            if (g == a.G - 1)
+              for (int z = a.G; z < 4; ++z) qd[z] = make_float2(0.f, 0.f);
+          }
+        }
+      }
+    } else {
+      // all 17 polynomials in three batches (6 + 6 + 5): A operands from the (L1-resident) records
+      float2 val[T8_NPOLY];
+      {
+        float A6[6][4];
+        float2 v6[6];
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+#pragma unroll
+          for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) A6[p][ks] = coef[(6 * bt + p) * 256 + 64 * ks + lane];
+          t8_polys<6>(A6, E1, E2, lane, v6);
+#pragma unroll
+          for (int p = 0; p < 6; ++p) val[6 * bt + p] = v6[p];
+        }
+        float A5[5][4];
+        float2 v5[5];
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) A5[p][ks] = coef[(12 + p) * 256 + 64 * ks + lane];
+        t8_polys<5>(A5, E1, E2, lane, v5);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) val[12 + p] = v5[p];
+      }
+      const float2 dinv = cinv(val[0]);
+      float2 y[8], w[8];
+      float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        y[i] = cmul(val[1 + i], dinv);
+        w[i] = cmul(val[9 + i], dinv);
+        t.x += cg_[i] * y[i].x;
+        t.y += cg_[i] * y[i].y;
+      }
+      if (MODE == T8_COLORLESS) {
+        // colorless_fdn/losses.py:20-73 on the scaled sub-FDN response, as k_tf_colorless
+        const float2 s = cscale(t, tmul);
+        const float mag = sqrtf(s.x * s.x + s.y * s.y);
+        const float d = mag - 1.0f, d2 = d * d;
+        const bool four = a.asym && (d > 1.0f);
+        const float dl = four ? 4.0f * d2 * d : 2.0f * d;
+        const float f = (mag > 0.f && live) ? a.gscale * invK * dl / mag : 0.f;
+        gs = make_float2(f * s.x, f * s.y);
+        if (live) acc0 += (four ? d2 * d2 : d2) * invK;
+      }
+      // dL = Re(conj(gs) dT'):  dT' = w'^T dA y' , dT'/db' = w' , dT'/dc' = y'  (old polynomials here, factors in the finish).
+      // Summed over the bins, dL/dA[i][j] = sum Re(gw_i y_j), gw_i = conj(gs) w_i, is itself a product of two
+      // (9 x 2 bins) matrices -- rows gw_0..7 and conj(gs), columns y_0..7 and 1: row 8 collects dL/dc, column 8 dL/db --
+      // so the 80 sums of a wavefront live in ONE 16 x 16 MFMA tile (four registers per lane) instead of 80 accumulators
+      // per lane: the two factors go through the wave's LDS image (the subset phasors are dead by now), k = (bin, Re / Im).
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        E1[i * 64 + lane] = make_float2(gs.x * w[i].x + gs.y * w[i].y, gs.x * w[i].y - gs.y * w[i].x);   // conj(gs) w_i
+        E2[i * 64 + lane] = y[i];
+      }
+      E1[8 * 64 + lane] = make_float2(gs.x, -gs.y);
+      E2[8 * 64 + lane] = make_float2(1.f, 0.f);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        const int rc = lane & 15, kq = lane >> 4, part = kq & 1;
+#pragma unroll 4
+        for (int t2 = 0; t2 < 32; ++t2) {
+          const int bin = 2 * t2 + (kq >> 1);
+          const float2 a2 = rc < 9 ? E1[rc * 64 + bin] : make_float2(0.f, 0.f);
+          const float2 b2 = rc < 9 ? E2[rc * 64 + bin] : make_float2(0.f, 0.f);
+          accD = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -a2.y : a2.x, part ? b2.y : b2.x, accD, 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // fixed-order sums over the four waves
+  if (MODE == T8_TSAVE) return;
+  const int nparts = gridDim.x;
+  {
+    const float v = wave_sum(acc0);
+    if (lane == 0) s_red[wv][256] = v;
+  }
+  if (HEAVY) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wv][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = accD[r];    // D[row][col]
+  }
+  __syncthreads();
+  if (!HEAVY) {
+    if (tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < T8_WAVES; ++w2) s += s_red[w2][256];
+      a.part[(size_t)blk * nparts + blockIdx.x] = s;
+    }
+    return;
+  }
+  for (int e = tid; e <= T8_ACC; e += blockDim.x) {
+    // e < 64: dL/dA[i][j] = D[i][j];  64 + i: dL/db_i = D[i][8];  72 + j: dL/dc_j = D[8][j];  80: the loss partial
+    const int src = e < 64 ? (e >> 3) * 16 + (e & 7) : (e < 72 ? (e - 64) * 16 + 8 : (e < 80 ? 8 * 16 + (e - 72) : 256));
+    float s = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < T8_WAVES; ++w2) s += s_red[w2][src];
+    if (e < T8_ACC) a.part[((size_t)blk * T8_ACC + e) * nparts + blockIdx.x] = s;
+    else if (a.lossp) a.lossp[(size_t)blk * nparts + blockIdx.x] = s;
+  }
+}
+
+static int t8_parts_host(int K) {
+  const int tiles = (K + 63) / 64, wg = (tiles + T8_WAVES - 1) / T8_WAVES;
+  int parts = (wg + 3) / 4;                    // ~4 tiles per wavefront
+  if (parts < 1) parts = 1;
+  if (parts > T8_MAX_PARTS) parts = T8_MAX_PARTS;
+  return parts;
+}
+
+extern "C" int gfdn_tf8_parts(int K) { return K > 0 ? t8_parts_host(K) : 0; }
+
+static int t8_ok(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays, const float* c) {
+  if (!turns || !coef || !delays || !c || K <= 0 || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (nper > 8 || nblk > T8_MAXBLK) return GFDN_E_UNSUPPORTED;
+  return 0;
+}
+
+template <int MODE>
+static int t8_launch(const T8Args& a, hipStream_t s) {
+  int rc = ensure_dyn_lds(k_tf8_pass<MODE>, T8_LDS_BYTES);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tf8_pass<MODE>, dim3(t8_parts_host(a.K), a.nblk), dim3(64 * T8_WAVES), T8_LDS_BYTES, s, a);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// energy partials of the (unscaled) responses sum_i c_i y_i: part[blk * gfdn_tf8_parts(K) + p]; finish with
+// gfdn_tf_energy(..., phase = 2) semantics through gfdn_tf8_energy_finish below
+extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
+                               float* b, float* c, float* energy, float* scale, void* work, void* stream);
+
+// finish of the energy pass: E, scale = E^(-1/2), in-place rescale of b, c (trainer.py:317-332)
+__global__ __launch_bounds__(256) void k_tf8_energy_finish(const float* __restrict__ partial, int nparts, int K, int nper,
+                                                           float* __restrict__ b, float* __restrict__ c,
+                                                           float* __restrict__ energy, float* __restrict__ scale) {
+  __shared__ float s_r[16];
+  const int g = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)g * nparts + p];
+  s = block_sum(s, s_r);
+  const float E = s / (float)K;
+  if (threadIdx.x == 0) {
+    if (energy) energy[g] = E;
+    if (scale) scale[g] = 1.0f / sqrtf(E);
+  }
+  if (b && c) {
+    const float d = powf(E, 0.25f);
+    for (int i = threadIdx.x; i < nper; i += 256) {
+      b[g * nper + i] /= d;
+      c[g * nper + i] /= d;
+    }
+  }
+}
+
+extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
+                               float* b, float* c, float* energy, float* scale, void* work, void* stream) {
+  int rc = t8_ok(turns, K, nblk, nper, coef, delays, c);
+  if (rc) return rc;
+  if (!work || !b) return GFDN_E_BADARG;
+  T8Args a{};
+  a.turns = turns; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = nullptr;
+  a.part = (float*)work;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = t8_launch<T8_ENERGY>(a, s))) return rc;
+  hipLaunchKernelGGL(k_tf8_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, t8_parts_host(K), K, nper, b, c,
+                     energy, scale);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef,
+                              const float* delays, const float* c, const float* scale, float* Tsave, float* Tquad,
+                              void* stream) {
+  int rc = t8_ok(turns, K, nbands * G, nper, coef, delays, c);
+  if (rc) return rc;
+  if (!Tsave || G <= 0 || G > 4) return GFDN_E_BADARG;
+  T8Args a{};
+  a.turns = turns; a.K = K; a.nblk = nbands * G; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
+  a.Tsave = (float2*)Tsave; a.Tquad = (float2*)Tquad; a.G = G;
+  return t8_launch<T8_TSAVE>(a, (hipStream_t)stream);
+}
+
+// work: gfdn_tf8_part_bytes(nblk, K) for part, nblk * gfdn_tf8_parts(K) floats for lossp
+extern "C" size_t gfdn_tf8_part_bytes(int nblk, int K) {
+  return (size_t)(nblk > 0 ? nblk : 1) * T8_ACC * t8_parts_host(K > 0 ? K : 1) * sizeof(float);
+}
+
+extern "C" int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
+                                  const float* c, const float* scale, int asym, float gscale, float* part, float* lossp,
+                                  float* loss, void* stream) {
+  int rc = t8_ok(turns, K, nblk, nper, coef, delays, c);
+  if (rc) return rc;
+  if (!part || !lossp || !loss) return GFDN_E_BADARG;
+  T8Args a{};
+  a.turns = turns; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
+  a.asym = asym; a.gscale = gscale; a.part = part; a.lossp = lossp;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = t8_launch<T8_COLORLESS>(a, s))) return rc;
+  return gfdn_tf_rows_sum(lossp, t8_parts_host(K), nblk, loss, stream);
+}
+
+extern "C" int gfdn_tf8_compose_bwd(const double* turns, int K, int nbands, int G, int nper, const float* coef,
+                                    const float* delays, const float* c, const float* scale, const float* rgain, int B,
+                                    const float* filt_c64, int ldf, const float* gH_c64, int ldh, float* part,
+                                    void* stream) {
+  int rc = t8_ok(turns, K, nbands * G, nper, coef, delays, c);
+  if (rc) return rc;
+  if (!rgain || !gH_c64 || !part || G <= 0 || G > 4 || B <= 0 || ldh < K || (filt_c64 && ldf < K)) return GFDN_E_BADARG;
+  T8Args a{};
+  a.turns = turns; a.K = K; a.nblk = nbands * G; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
+  a.G = G; a.rgain = rgain; a.gH = (const float2*)gH_c64; a.ldh = ldh; a.filt = (const float2*)filt_c64; a.ldf = ldf;
+  a.B = B; a.part = part;
+  return t8_launch<T8_BWD>(a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tail: partial rows -> dL/dQQ (set 0), dL/dM_raw (set 1), dL/db, dL/dc, then the adjoint of Q = expm(skew(M)), QQ = Q Q
+// (k_ortho_bwd with dL/dM_raw added) -- one workgroup per block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict__ part0, int np0,
+                                                         const float* __restrict__ part1, int np1,
+                                                         const float* __restrict__ scale, int n,
+                                                         const float* __restrict__ M, const float* __restrict__ gQ,
+                                                         const float* __restrict__ Q, float* __restrict__ gb,
+                                                         float* __restrict__ gc, float* __restrict__ gM) {
+  extern __shared__ double t8p_lds[];
+  __shared__ float srec[2][T8_ACC], sG[2][64];
+  const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+  for (int r = tid >> 6; r < 2 * T8_ACC; r += nw) {
+    const int set = r / T8_ACC, e = r - set * T8_ACC;
+    const float* p = set ? part1 : part0;
+    const int np = set ? np1 : np0;
+    float s = 0.f;
+    if (p) {
+      const float* row = p + ((size_t)blk * T8_ACC + e) * np;
+      for (int i = lane; i < np; i += 64) s += row[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) srec[set][e] = s;
+  }
+  __syncthreads();
+  const float sc = scale ? scale[blk] : 1.0f, rs = sqrtf(sc);
+  if (tid < 2 * n * n) {
+    const int set = tid / (n * n), e = tid - set * n * n, i = e / n, j = e - i * n;
+    sG[set][e] = sc * srec[set][i * 8 + j];
+  } else if (tid >= 128 && tid < 128 + n) {
+    const int i = tid - 128;
+    gb[blk * n + i] = rs * (srec[0][64 + i] + srec[1][64 + i]);
+  } else if (tid >= 192 && tid < 192 + n) {
+    const int j = tid - 192;
+    gc[blk * n + j] = rs * (srec[0][72 + j] + srec[1][72 + j]);
+  }
+  __syncthreads();
+  const size_t off = (size_t)blk * n * n;
+  ortho_bwd_group(t8p_lds, M + off, n, gQ ? gQ + off : nullptr, sG[0], Q ? Q + off : nullptr, part1 ? sG[1] : nullptr,
+                  gM + off);
+}
+
+extern "C" int gfdn_tf8_param_grads(const float* part0, int nparts0, const float* part1, int nparts1, const float* scale,
+                                    int nblk, int nper, const float* M, const float* gQ, const float* Q, float* gb,
+                                    float* gc, float* gM, void* stream) {
+  if (!part0 || !M || !gb || !gc || !gM || nblk <= 0 || nper <= 0 || nparts0 <= 0 || (part1 && nparts1 <= 0))
+    return GFDN_E_BADARG;
+  if (nper > 8) return GFDN_E_UNSUPPORTED;
+  const size_t lds = ortho_bwd_lds_doubles(nper) * sizeof(double);
+  int rc = ensure_dyn_lds(k_tf8_param_grads, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tf8_param_grads, dim3(nblk), dim3(256), lds, (hipStream_t)stream, part0, nparts0, part1, nparts1,
+                     scale, nper, M, gQ, Q, gb, gc, gM);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

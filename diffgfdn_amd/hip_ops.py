@@ -752,6 +752,118 @@ def tf_ortho_coefs(M, ig, b, c, sub: bool = True):
     return Q, QQ, coef, coef_sub
 
 
+# ---- blocks of 5..8 lines: polynomial form on the matrix cores (csrc/blocktf8.hip) ---------------------------------------
+def tf8_coefs(A0, ig0, b, c, A1=None, ig1=None):
+    """Coefficient records (nblk, 17, 256) float32 of (A0, 1 / gamma0) [and (A1, 1 / gamma1)] sharing b, c: the
+    determinant polynomial and the numerators of y = X^-1 b and w = X^-T c (see the kernel file)."""
+    _need_gpu(A0, b, c)
+    A0, b, c = _f(A0), _f(b).reshape(-1), _f(c).reshape(-1)
+    nblk, n, _ = A0.shape
+    if b.numel() != nblk * n or c.numel() != nblk * n:
+        raise RuntimeError("tf8_coefs: b, c must hold nblk * n gains")
+    ig0 = None if ig0 is None else _f(ig0).reshape(-1)
+    c0 = torch.empty((nblk, 17, 256), dtype=_f32, device=A0.device)
+    c1 = None
+    if A1 is not None:
+        A1 = _f(A1)
+        ig1 = None if ig1 is None else _f(ig1).reshape(-1)
+        c1 = torch.empty((nblk, 17, 256), dtype=_f32, device=A0.device)
+    _lib.check(_lib.load().gfdn_tf8_coefs(_p(A0), _p(ig0), _p(c0), _p(A1), _p(ig1), _p(c1), _p(b), _p(c), nblk, n,
+                                          _stream()), "gfdn_tf8_coefs")
+    return c0, c1
+
+
+def tf8_parts(K: int) -> int:
+    return _lib.load().gfdn_tf8_parts(int(K))
+
+
+def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False):
+    """normalize (trainer.py:317-332) on the records ``coef`` of the raw sub-FDN blocks: E = mean_k |sum_i c_i y_i|^2,
+    -> (energy or None, scale = E^(-1/2)); b, c (float32, contiguous) are divided by E^(1/4) IN PLACE."""
+    _need_gpu(turns, coef, delays, b, c)
+    coef, delays = _f(coef), _f(delays)
+    nblk, K = coef.shape[0], turns.numel()
+    for t in (b, c):
+        if t.dtype != _f32 or not t.is_contiguous() or t.numel() != nblk * nper:
+            raise RuntimeError("tf8_energy: gains must be contiguous float32 of nblk * nper elements")
+    lib = _lib.load()
+    energy = torch.empty(nblk, dtype=_f32, device=coef.device) if want_energy else None
+    scale = torch.empty(nblk, dtype=_f32, device=coef.device)
+    work = torch.empty(nblk * lib.gfdn_tf8_parts(K), dtype=_f32, device=coef.device)
+    _lib.check(lib.gfdn_tf8_energy(_p(turns), K, nblk, nper, _p(coef), _p(delays), _p(b), _p(c), _p(energy), _p(scale),
+                                   _p(work), _stream()), "gfdn_tf8_energy")
+    return energy, scale
+
+
+def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, quad: bool = True):
+    """Scaled group transfer functions T' (nbands * G, K) complex64 [+ Tquad (nbands, K, 4)] from the records."""
+    _need_gpu(turns, coef, delays, c)
+    coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
+    K = turns.numel()
+    if coef.shape[0] != nbands * G:
+        raise RuntimeError("tf8_tsave: records do not match nbands x G blocks")
+    scale = None if scale is None else _f(scale)
+    Ts = torch.empty((nbands * G, K), dtype=_c64, device=coef.device)
+    Tq = torch.empty((nbands, K, 4), dtype=_c64, device=coef.device) if quad else None
+    _lib.check(_lib.load().gfdn_tf8_tsave(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c), _p(scale), _p(Ts),
+                                          _p(Tq), _stream()), "gfdn_tf8_tsave")
+    return Ts, Tq
+
+
+def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: float):
+    """Colorless pass on the records of the raw sub-FDN blocks -> (part (nblk, 80, parts) gradient partials, loss (nblk,))."""
+    _need_gpu(turns, coef, delays, c)
+    coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
+    nblk, K = coef.shape[0], turns.numel()
+    lib = _lib.load()
+    parts = lib.gfdn_tf8_parts(K)
+    part = torch.empty((nblk, 80, parts), dtype=_f32, device=coef.device)
+    lossp = torch.empty((nblk, parts), dtype=_f32, device=coef.device)
+    loss = torch.empty(nblk, dtype=_f32, device=coef.device)
+    _lib.check(lib.gfdn_tf8_colorless(_p(turns), K, nblk, nper, _p(coef), _p(delays), _p(c), _p(None if scale is None else _f(scale)),
+                                      int(asym), float(gscale), _p(part), _p(lossp), _p(loss), _stream()),
+               "gfdn_tf8_colorless")
+    return part, loss
+
+
+def tf8_compose_bwd(turns, coef, delays, nper: int, c, scale, rgain, gH, filt=None, nbands: int = 1):
+    """Gradient partials (nbands * G, 80, parts) of the output stage from dL/dH (nbands * B, K)."""
+    _need_gpu(turns, coef, delays, c, rgain, gH)
+    coef, delays, c, rgain, gH = _f(coef), _f(delays), _f(c).reshape(-1), _f(rgain), _c(gH)
+    K = turns.numel()
+    Btot, G = rgain.shape
+    if coef.shape[0] != nbands * G or Btot % nbands or gH.shape[0] != Btot or gH.shape[1] < K:
+        raise RuntimeError("tf8_compose_bwd: shapes do not match nbands x G blocks")
+    filt = None if filt is None else _c(filt)
+    if filt is not None and filt.numel() != nbands * K:
+        raise RuntimeError("tf8_compose_bwd: filt must hold K bins per band")
+    lib = _lib.load()
+    part = torch.empty((nbands * G, 80, lib.gfdn_tf8_parts(K)), dtype=_f32, device=coef.device)
+    _lib.check(lib.gfdn_tf8_compose_bwd(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c),
+                                        _p(None if scale is None else _f(scale)), _p(rgain), Btot // nbands, _p(filt), K,
+                                        _p(gH), gH.stride(0), _p(part), _stream()), "gfdn_tf8_compose_bwd")
+    return part
+
+
+def tf8_param_grads(part0, part1, scale, M, gQ=None, Q=None, gb=None, gc=None, gM=None):
+    """Tail: partial rows of set 0 (damped loop) [and set 1 (raw sub-FDN blocks)] -> (gM, gb, gc)."""
+    _need_gpu(part0, M)
+    M = _f(M)
+    nblk, n, _ = M.shape
+    if part0.dim() != 3 or tuple(part0.shape[:2]) != (nblk, 80) or (part1 is not None and tuple(part1.shape[:2]) != (nblk, 80)):
+        raise RuntimeError("tf8_param_grads: partials must be (nblk, 80, parts)")
+    dev = M.device
+    gb = torch.empty(nblk * n, dtype=_f32, device=dev) if gb is None else gb
+    gc = torch.empty(nblk * n, dtype=_f32, device=dev) if gc is None else gc
+    gM = torch.empty_like(M) if gM is None else gM
+    _lib.check(_lib.load().gfdn_tf8_param_grads(_p(_f(part0)), part0.shape[2], _p(None if part1 is None else _f(part1)),
+                                                0 if part1 is None else part1.shape[2],
+                                                _p(None if scale is None else _f(scale)), nblk, n, _p(M),
+                                                _p(None if gQ is None else _f(gQ)), _p(None if Q is None else _f(Q)),
+                                                _p(gb), _p(gc), _p(gM), _stream()), "gfdn_tf8_param_grads")
+    return gM, gb, gc
+
+
 def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):
     """Gradient records -> (gA0, gA1 or None, gb, gc); b, c: the gains the records' gradients refer to."""
     _need_gpu(A0, grec0, b, c)
