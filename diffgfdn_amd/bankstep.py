@@ -38,7 +38,7 @@ class FusedBankStep:
     @staticmethod
     def supported(trainer) -> bool:
         bank = trainer.net
-        return (bank.num_delay_lines_per_group <= 4 and bank.num_groups <= 4
+        return (bank.num_delay_lines_per_group <= 8 and bank.num_groups <= 4
                 and bank.num_bands * bank.num_groups <= 64)
 
     def __init__(self, trainer):
@@ -270,7 +270,16 @@ class FusedBankStep:
         # than the 10 us they take.  Captured BEFORE the fork below: the graph lays its hardware queues out along a
         # depth-first walk of the nodes in capture order, and the chain captured first keeps its queue through every
         # later join -- a chain that changes queue pays ~10 us per change)
-        Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
+        # blocks of 5..8 lines: the same step on the 17-polynomial records of csrc/blocktf8.hip (evaluation on the matrix
+        # cores; unit-circle grids)
+        big = n > 4
+        if big and (gridK.logr is not None):
+            raise NotImplementedError("blocks of more than four lines: the explicit step takes grids on the unit circle")
+        if big:
+            Q, QQ = ops.ortho_fwd(M, True, True)
+            coef, coef_sub = ops.tf8_coefs(QQ, ig, b, c, A1=M)
+        else:
+            Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
         if pipe is not None and (not train or allreduce is not None or not opt_step or side2 is None):
             raise ValueError("a pipelined step is a single-process training step with its optimiser update")
         with on_side2():
@@ -291,8 +300,11 @@ class FusedBankStep:
             ev['mask'].record()
         scale = ework = None
         if normalize_first:
-            _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
-                                     dturn=gridK.dturn)
+            if big:
+                _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c)
+            else:
+                _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
+                                         dturn=gridK.dturn)
         ev['norm'].record()
         if pipe is None:
             main.wait_event(ev['mlp'])
@@ -300,8 +312,21 @@ class FusedBankStep:
             main.wait_event(pipe.ready)
         fold = (self.fold_output_stage and pairs and K == 65537 and (Btot // nb) % 2 == 0 and G <= 4
                 and self.halves < 2)
-        H, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, scale, direct, filt, rows, nb,
-                                   save_T=True, want_H=not fold)
+        if big:
+            Ts, Tq8 = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=True)
+            if fold:
+                H = Tq8
+            else:
+                # (sizes the folded transform does not take: the output stage as tensor operations -- small grids only)
+                Bb = Btot // nb
+                Hs = torch.einsum('qbg,qgk->qbk', rgain.reshape(nb, Bb, G).to(torch.complex64), Ts.reshape(nb, G, -1))
+                Hs = Hs + direct[rows].reshape(nb, Bb, -1)[..., :Ts.shape[1]]
+                if filt is not None:
+                    Hs = Hs * filt.reshape(nb, 1, -1)
+                H = Hs.reshape(Btot, -1).contiguous()
+        else:
+            H, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, scale, direct, filt, rows, nb,
+                                       save_T=True, want_H=not fold)
         x_fn = None
         if fold:
             Tq, H = H, None
@@ -317,9 +342,13 @@ class FusedBankStep:
         # time either way, measured)
         with on_side2():
             torch.cuda.current_stream().wait_event(ev['norm'])
-            grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
-                                                cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
-                                                dturn=gridK.dturn)
+            if big:
+                grec_sub, loss_g = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
+                                                     cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world)
+            else:
+                grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
+                                                    cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
+                                                    dturn=gridK.dturn)
             out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
                                            inv_world, want_grad=train, nbands=nb)
             ev['side'].record()
@@ -346,7 +375,10 @@ class FusedBankStep:
             # 50 us instead of 29 + 45 one after the other.  The reported sums go in front of the gains pass (their
             # inputs are long complete; behind it they would sit on the path to Adam).
             ev['grg'].record()                    # (dL/dH complete)
-            grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb, partial=True)
+            if big:
+                grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rgain, gH, filt, nb)
+            else:
+                grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb, partial=True)
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
                 sums, total = report()
@@ -382,8 +414,12 @@ class FusedBankStep:
                                           # front of ev['grg'], this stream's are its own earlier launches)
             main.wait_event(ev['side'])          # (signalled long ago; dropping it measured no gain: 0.667 vs 0.663 ms)
             # records (partial rows of the records pass + the colorless pass's) -> dL/dM, dL/db, dL/dc: one launch
-            ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
-                               gM=self.g_M)
+            if big:
+                ops.tf8_param_grads(QQ, ig, grec, b, c, M, A1=M, part1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
+                                    gM=self.g_M)
+            else:
+                ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
+                                   gM=self.g_M)
             keep.extend((grg, grec))
             if pipe is not None:
                 # everything but the gain network, straight behind its gradients

@@ -1,40 +1,46 @@
 // Block transfer functions in polynomial form for blocks of 5..8 delay lines (the N = 32 = 4 x 8 layout of
-// BASELINE.json configs[4]), zero coupling, for gfx950 -- with the polynomial evaluation on the matrix cores.
+// BASELINE.json configs[4]), zero coupling, for gfx950 -- with the polynomial evaluation AND the gradient accumulation on
+// the matrix cores.
 //
 // Reference maths (orchidas/DiffGFDN, src/diff_gfdn): the resolvent of one block, X(z) = D(z) Gamma^-1 - A
-// (feedback_loop.py:326-391), enters the model only through  y = X^-1 b  (delay-line responses),  T = c^T y  (group
-// transfer function, model.py:583-619; sub-FDN responses with the raw M and no absorption, model.py:209-252)  and, in the
-// backward pass,  w = X^-T c:   dT = w^T dA y,  dT/db = w,  dT/dc = y.   By Cramer's rule every one of these is a ratio of
-// MULTILINEAR polynomials in the n phasors zeta_i = z^{m_i} / gamma_i,
-//     det X          = sum_S DET_S e_S ,        DET_S = det((-A)[S^c, S^c]) prod_{i in S} 1/gamma_i ,  e_S = prod_{i in S} z^{m_i}
-//     (adj(X) b)_i   = sum_S Y_{i,S} e_S ,      Y_{i,S} = det(((-A) with column i := b)[S^c, S^c]) prod 1/gamma   (i in S^c)
-//     (adj(X)^T c)_j = sum_S W_{j,S} e_S ,      W_{j,S} = det(((-A) with row j := c)[S^c, S^c]) prod 1/gamma      (j in S^c)
-// 17 polynomials x 256 real coefficients per block, built once per step in float64 (k_tf8_coefs).  With the subsets
-// split as S = (S1 over lines 0..3, S2 over lines 4..7), a polynomial is the bilinear form  e1^T C e2  of a REAL 16 x 16
-// coefficient matrix with the two complex subset-phasor vectors of a bin, and C e2 for 64 bins at a time is a GEMM:
-// v_mfma_f32_16x16x4_f32 (exact float32 products, float32 accumulate) with A = C (lane l: C[S1 = l & 15][S2 = 4 ks + (l >> 4)],
-// i.e. coef[64 ks + l]: one coalesced load), B = Re / Im of e2 of sixteen bins.  The thread-per-system 8 x 8 complex
-// eliminations of csrc/solve.hip (k_solve8_fwd / _bwd, k_subfdn8_energy: ~2500 VALU instructions per system at one wave
-// per SIMD) become ~64 MFMAs + ~800 VALU instructions per 64 bins for the forward polynomials and ~550 MFMAs for all 17.
-// The backward needs no adjoint elimination and no records -> parameter map: the per-bin y and w give dL/dA, dL/db,
-// dL/dc directly (80 per-lane accumulators, fixed-order sums).
+// (feedback_loop.py:326-391), enters the model only through the group transfer function T = c^T X^-1 b (model.py:583-619;
+// sub-FDN responses with the raw M and no absorption, model.py:209-252).  As for the blocks of <= 4 lines
+// (csrc/blocktf.hip) T is a ratio of MULTILINEAR polynomials in the n phasors zeta_i = z^{m_i} / gamma_i,
+//     det X           = sum_S Q_S e_S ,   Q_S = det((-A)[S^c, S^c]) prod_{i in S} 1/gamma_i ,   e_S = prod_{i in S} z^{m_i}
+//     c^T adj(X) b    = sum_S P_S e_S ,   P_S = sum_i c_i Y_{i,S} ,  Y_{i,S} = det(((-A) with column i := b)[S^c, S^c]) prod 1/gamma
+//                                         = -det([[(-A), b], [c^T, 0]] restricted to S^c and the border) prod 1/gamma ,
+// 2 x 256 real coefficients per block (records: the determinant polynomial and the eight Y_i, built in float64).
+// With the subsets split as S = (S1 over lines 0..3, S2 over lines 4..7) a polynomial is the bilinear form e1^T C e2 of a
+// REAL 16 x 16 coefficient matrix with the two complex subset-phasor vectors of a bin, and C e2 for 64 bins at a time is a
+// GEMM: v_mfma_f32_16x16x4_f32 (exact float32 products, float32 accumulate), A = C (lane l: C[S1 = l & 15][S2 = 4 ks + (l >> 4)]
+// = coef[64 ks + l]: one coalesced load), B = Re / Im of e2 of sixteen bins.  The backward is the transpose of the same
+// product: with dL = Re(conj(g) dT), T = P / Q,
+//     dL/dP_S = sum_k Re(u_k e_S(k)) ,  u = conj(g) / Q ;     dL/dQ_S = -sum_k Re(u_k T_k e_S(k)) ,
+// i.e. the (16 x 2 bins) x (2 bins x 16) products (u e1) e2^T summed over the bins -- two 16 x 16 MFMA accumulator tiles
+// per wavefront hold all 512 gradient records.  The records -> (dL/dA, dL/db, dL/dc) map is bin independent: cofactors of
+// the 256 masked 8 x 8 and bordered 9 x 9 matrices of a block, in float64 (k_tf8_rec_grads).  The thread-per-system 8 x 8
+// complex eliminations of csrc/solve.hip (k_solve8_fwd / _bwd, k_subfdn8_energy: ~2500 VALU instructions per system at one
+// wave per SIMD) become ~128 MFMAs + ~1400 VALU instructions per 64 bins, forward and backward together.
 //
-// Scaling convention (trainer.py:317-332 normalize): the coefficient records are built from the gains BEFORE the rescale
-// (b_old, c_old); afterwards the gain buffers hold b' = b_old sqrt(s), c' = c_old sqrt(s), s = scale = E^(-1/2), and
-// T' = T(b', c') = s T(b_old, c_old) = sqrt(s) sum_i c'_i y_old_i.  Gradients w.r.t. the rescaled parameters:
-// dL/dA = s acc_A, dL/db' = sqrt(s) acc_b, dL/dc' = sqrt(s) acc_c with the accumulators taken on the old polynomials.
+// Scaling convention (trainer.py:317-332 normalize): the records are built from the gains BEFORE the rescale (b_old,
+// c_old); afterwards the gain buffers hold b' = b_old sqrt(s), c' = c_old sqrt(s), s = scale = E^(-1/2), and
+// T' = T(b', c') = P(b', c') / Q with P(b', c')_S = sqrt(s) sum_i c'_i Y_{i,S}(b_old): the passes take the CURRENT c and s and
+// work on the records of the current gains; the gradient map reads the current gains as well.
 #include "common.h"
 #include "ortho_dev.h"
 
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 
-#define T8_NPOLY 17
+#define T8_NPOLY 9
 #define T8_REC (T8_NPOLY * 256)        // floats per block: [poly][S], S = S1 + 16 S2
-#define T8_ACC 80                      // 64 dL/dA (row-major 8 x 8) | 8 dL/db | 8 dL/dc
+#define T8_ACC 80                      // 64 dL/dA (row-major 8 x 8) | 8 dL/db | 8 dL/dc (output of the gradient map)
+#define T8_GREC 512                    // gradient records of a block: dL/dP_S (256) | dL/dQ_S (256), S = S1 + 16 S2
 #define T8_MAXBLK 64
 #define T8_MAX_PARTS 256
 #define T8_WAVES 4
-#define T8_LDS_BYTES ((size_t)T8_WAVES * 2 * 16 * 64 * sizeof(float2))
+#define T8_P 66                        // row pitch (float2) of the waves' [S][bin] images: rows 16 B apart in the banks, so
+                                       // that the 16 rows x 2 bins a gradient MFMA step reads hit 64 distinct banks
+#define T8_LDS_BYTES ((size_t)T8_WAVES * 2 * 16 * T8_P * sizeof(float2))
 
 // ------------------------------------------------------------------------------------------
 // coefficient records (float64): determinants of masked 8 x 8 matrices, partial pivoting by row selects
@@ -74,12 +80,12 @@ __device__ __forceinline__ double t8_det(double (&m)[8][8]) {
   return det;
 }
 
-// grid (nblk, sets, 9): z = 0 the determinant polynomial, z = 1 + i the numerators of y_i and w_i; thread S = subset
+// grid (nblk, sets, 9): z = 0 the determinant polynomial, z = 1 + i the numerator polynomial of y_i = (X^-1 b)_i; thread S = subset
 __global__ __launch_bounds__(256) void k_tf8_coefs(const float* __restrict__ A0, const float* __restrict__ ig0,
                                                    float* __restrict__ coef0, const float* __restrict__ A1,
                                                    const float* __restrict__ ig1, float* __restrict__ coef1,
                                                    const float* __restrict__ b, const float* __restrict__ c, int n) {
-  __shared__ double sA[64], sb[8], sc[8], sig[8];
+  __shared__ double sA[64], sb[8], sig[8];
   const int blk = blockIdx.x, set = blockIdx.y, task = blockIdx.z, S = threadIdx.x;
   const float* A = (set ? A1 : A0) + (size_t)blk * n * n;
   const float* ig = set ? ig1 : ig0;
@@ -90,7 +96,6 @@ __global__ __launch_bounds__(256) void k_tf8_coefs(const float* __restrict__ A0,
   }
   if (S < 8) {
     sb[S] = S < n ? (double)b[blk * n + S] : 0.0;
-    sc[S] = S < n ? (double)c[blk * n + S] : 0.0;
     sig[S] = (S < n && ig) ? (double)ig[blk * n + S] : 1.0;
   }
   __syncthreads();
@@ -99,9 +104,9 @@ __global__ __launch_bounds__(256) void k_tf8_coefs(const float* __restrict__ A0,
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     if ((S >> i) & 1) igp *= sig[i];
-  // (-A) with column `col` := b or row `row` := c (-1: untouched), restricted to the complement of S: lines of S -- and
+  // (-A) with column `col` := b (-1: untouched), restricted to the complement of S: lines of S -- and
   // the lines beyond n -- become unit rows / columns, which leaves the determinant of the restriction
-  auto masked_det = [&](int col, int row) {
+  auto masked_det = [&](int col) {
     double m[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
@@ -110,18 +115,16 @@ __global__ __launch_bounds__(256) void k_tf8_coefs(const float* __restrict__ A0,
         const bool in = !((S >> r) & 1) && !((S >> cc) & 1) && r < n && cc < n;
         double v = sA[r * 8 + cc];
         if (cc == col) v = sb[r];
-        if (r == row) v = sc[cc];
         m[r][cc] = in ? v : (r == cc ? 1.0 : 0.0);
       }
     return t8_det(m);
   };
   if (task == 0) {
-    coef[S] = absent ? 0.f : (float)(masked_det(-1, -1) * igp);
+    coef[S] = absent ? 0.f : (float)(masked_det(-1) * igp);
   } else {
     const int i = task - 1;
     const bool none = absent || i >= n || ((S >> i) & 1);
-    coef[(1 + i) * 256 + S] = none ? 0.f : (float)(masked_det(i, -1) * igp);
-    coef[(9 + i) * 256 + S] = none ? 0.f : (float)(masked_det(-1, i) * igp);
+    coef[(1 + i) * 256 + S] = none ? 0.f : (float)(masked_det(i) * igp);
   }
 }
 
@@ -160,7 +163,7 @@ struct T8Args {
   int ldh;
   const float2* filt;        // (nblk / G, ldf) or NULL
   int ldf, B;
-  float* part;               // T8_ENERGY: [blk * nparts + p]; heavy modes: [(blk * T8_ACC + e) * nparts + p]
+  float* part;               // T8_ENERGY: [blk * nparts + p]; heavy modes: [(blk * T8_GREC + e) * nparts + p]
 };
 
 enum { T8_ENERGY = 0, T8_TSAVE = 1, T8_COLORLESS = 2, T8_BWD = 3 };
@@ -192,7 +195,7 @@ __device__ __forceinline__ void t8_stage_subsets(float2 p0, float2 p1, float2 p2
   e[14] = cmul(e[6], e[8]);
   e[15] = cmul(e[3], e[12]);
 #pragma unroll
-  for (int S = 0; S < 16; ++S) img[S * 64 + lane] = e[S];
+  for (int S = 0; S < 16; ++S) img[S * T8_P + lane] = e[S];
 }
 
 // NP polynomials of the wave's 64 bins: val[p] (lane = bin) = e1^T C_p e2, the A operands A[p][ks] already in registers
@@ -212,7 +215,7 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const float2 b2 = E2[(4 * ks + q) * 64 + 16 * cg + cidx];
+      const float2 b2 = E2[(4 * ks + q) * T8_P + 16 * cg + cidx];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         are[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][ks], b2.x, are[p], 0, 0, 0);
@@ -221,7 +224,7 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
     }
     float2 e1v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) e1v[r] = E1[(4 * q + r) * 64 + 16 * cg + cidx];
+    for (int r = 0; r < 4; ++r) e1v[r] = E1[(4 * q + r) * T8_P + 16 * cg + cidx];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       float2 s = make_float2(0.f, 0.f);
@@ -243,35 +246,32 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
 
 template <int MODE>
 __global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
-  __shared__ float s_red[T8_WAVES][257];
+  __shared__ float s_red[T8_WAVES][T8_GREC + 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int blk = blockIdx.y, n = a.nper, K = a.K;
-  float2* E1 = t8_lds + wv * 2048;
-  float2* E2 = E1 + 1024;
+  float2* E1 = t8_lds + wv * (2 * 16 * T8_P);
+  float2* E2 = E1 + 16 * T8_P;
   const float* coef = a.coef + (size_t)blk * T8_REC;
-  float m[8], cg_[8];
+  float m[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    m[r] = r < n ? a.delays[blk * n + r] : 0.f;
-    cg_[r] = r < n ? a.c[blk * n + r] : 0.f;
-  }
+  for (int r = 0; r < 8; ++r) m[r] = r < n ? a.delays[blk * n + r] : 0.f;
   const float sc = a.scale ? a.scale[blk] : 1.0f;
-  const float tmul = a.scale ? sqrtf(sc) : 1.0f;          // T' = tmul sum_i c_i y_i (scaling convention above)
+  const float tmul = a.scale ? sqrtf(sc) : 1.0f;
   constexpr bool HEAVY = MODE == T8_COLORLESS || MODE == T8_BWD;
-  // light modes: the determinant and the numerator P = sum_i c_i Y_i as two A-operand sets held in registers
+  // the two coefficient matrices of the CURRENT gains as MFMA A operands, in registers for the whole launch:
+  // AL[0] = Q (determinant), AL[1] = P = tmul sum_i c_i Y_i (scaling convention above)
   float AL[2][4];
-  if (!HEAVY) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      AL[0][ks] = coef[64 * ks + lane];
-      float p = 0.f;
+  for (int ks = 0; ks < 4; ++ks) {
+    AL[0][ks] = coef[64 * ks + lane];
+    float p = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) p += cg_[i] * coef[(1 + i) * 256 + 64 * ks + lane];
-      AL[1][ks] = p;
-    }
+    for (int i = 0; i < 8; ++i) p += (i < n ? a.c[blk * n + i] : 0.f) * coef[(1 + i) * 256 + 64 * ks + lane];
+    AL[1][ks] = tmul * p;
   }
   float acc0 = 0.f;                                      // energy / loss partial
-  f32x4 accD = (f32x4){0.f, 0.f, 0.f, 0.f};              // heavy modes: the 16 x 16 tile [dL/dA | dL/db ; dL/dc] (below)
+  f32x4 accP = (f32x4){0.f, 0.f, 0.f, 0.f};              // heavy modes: dL/dP[S1][S2] and dL/dQ[S1][S2], lane l register r
+  f32x4 accQ = (f32x4){0.f, 0.f, 0.f, 0.f};              // = entry [S1 = 4 (l >> 4) + r][S2 = l & 15]
   const int ntiles = (K + 63) >> 6;
   const float invK = 1.0f / (float)K;
   const int band = a.G > 0 ? blk / a.G : 0, g = a.G > 0 ? blk - band * a.G : 0;
@@ -300,96 +300,61 @@ __global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
                      t8_zpow(a.turns, kk, m[7]), E2, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS image: no block barrier)
-    if (!HEAVY) {
-      float2 val[2];
-      t8_polys<2>(AL, E1, E2, lane, val);
-      const float2 t = cmul(val[1], cinv(val[0]));           // sum_i c_i y_i
-      if (MODE == T8_ENERGY) {
-        if (live) acc0 += t.x * t.x + t.y * t.y;
-      } else {
-        const float2 ts = cscale(t, tmul);
-        if (live) {
-          a.Tsave[(size_t)blk * K + k] = ts;
-          if (a.Tquad) {
-            float2* qd = a.Tquad + ((size_t)band * K + k) * 4;
-            qd[g] = ts;
-            if (g == a.G - 1)
-              for (int z = a.G; z < 4; ++z) qd[z] = make_float2(0.f, 0.f);
-          }
+    float2 val[2];
+    t8_polys<2>(AL, E1, E2, lane, val);
+    const float2 dinv = cinv(val[0]);
+    const float2 t = cmul(val[1], dinv);                     // T' = P / Q at the current gains
+    if (MODE == T8_ENERGY) {
+      if (live) acc0 += t.x * t.x + t.y * t.y;
+    } else if (MODE == T8_TSAVE) {
+      if (live) {
+        a.Tsave[(size_t)blk * K + k] = t;
+        if (a.Tquad) {
+          float2* qd = a.Tquad + ((size_t)band * K + k) * 4;
+          qd[g] = t;
+          if (g == a.G - 1)
+            for (int z = a.G; z < 4; ++z) qd[z] = make_float2(0.f, 0.f);
         }
       }
     } else {
-      // all 17 polynomials in three batches (6 + 6 + 5): A operands from the (L1-resident) records
-      float2 val[T8_NPOLY];
-      {
-        float A6[6][4];
-        float2 v6[6];
-#pragma unroll
-        for (int bt = 0; bt < 2; ++bt) {
-#pragma unroll
-          for (int p = 0; p < 6; ++p)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) A6[p][ks] = coef[(6 * bt + p) * 256 + 64 * ks + lane];
-          t8_polys<6>(A6, E1, E2, lane, v6);
-#pragma unroll
-          for (int p = 0; p < 6; ++p) val[6 * bt + p] = v6[p];
-        }
-        float A5[5][4];
-        float2 v5[5];
-#pragma unroll
-        for (int p = 0; p < 5; ++p)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) A5[p][ks] = coef[(12 + p) * 256 + 64 * ks + lane];
-        t8_polys<5>(A5, E1, E2, lane, v5);
-#pragma unroll
-        for (int p = 0; p < 5; ++p) val[12 + p] = v5[p];
-      }
-      const float2 dinv = cinv(val[0]);
-      float2 y[8], w[8];
-      float2 t = make_float2(0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        y[i] = cmul(val[1 + i], dinv);
-        w[i] = cmul(val[9 + i], dinv);
-        t.x += cg_[i] * y[i].x;
-        t.y += cg_[i] * y[i].y;
-      }
       if (MODE == T8_COLORLESS) {
         // colorless_fdn/losses.py:20-73 on the scaled sub-FDN response, as k_tf_colorless
-        const float2 s = cscale(t, tmul);
-        const float mag = sqrtf(s.x * s.x + s.y * s.y);
+        const float mag = sqrtf(t.x * t.x + t.y * t.y);
         const float d = mag - 1.0f, d2 = d * d;
         const bool four = a.asym && (d > 1.0f);
         const float dl = four ? 4.0f * d2 * d : 2.0f * d;
         const float f = (mag > 0.f && live) ? a.gscale * invK * dl / mag : 0.f;
-        gs = make_float2(f * s.x, f * s.y);
+        gs = make_float2(f * t.x, f * t.y);
         if (live) acc0 += (four ? d2 * d2 : d2) * invK;
       }
-      // dL = Re(conj(gs) dT'):  dT' = w'^T dA y' , dT'/db' = w' , dT'/dc' = y'  (old polynomials here, factors in the finish).
-      // Summed over the bins, dL/dA[i][j] = sum Re(gw_i y_j), gw_i = conj(gs) w_i, is itself a product of two
-      // (9 x 2 bins) matrices -- rows gw_0..7 and conj(gs), columns y_0..7 and 1: row 8 collects dL/dc, column 8 dL/db --
-      // so the 80 sums of a wavefront live in ONE 16 x 16 MFMA tile (four registers per lane) instead of 80 accumulators
-      // per lane: the two factors go through the wave's LDS image (the subset phasors are dead by now), k = (bin, Re / Im).
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // dL = Re(conj(gs) dT'), dT' = (dP - T' dQ) / Q:  dL/dP[S1][S2] += Re(u e1[S1] e2[S2]), u = conj(gs) / Q, and
+      // dL/dQ[S1][S2] += Re(-u T' e1[S1] e2[S2]) -- (16 x 2 bins) x (2 bins x 16) products with k = (bin, Re / Im): the
+      // rows u e1[S1] replace e1 in the wave's LDS image (every lane rewrites its own column), the columns are e2
+      const float2 u = make_float2(gs.x * dinv.x + gs.y * dinv.y, gs.x * dinv.y - gs.y * dinv.x);    // conj(gs) / Q
+      const int rc = lane & 15, kq = lane >> 4, part = kq & 1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        E1[i * 64 + lane] = make_float2(gs.x * w[i].x + gs.y * w[i].y, gs.x * w[i].y - gs.y * w[i].x);   // conj(gs) w_i
-        E2[i * 64 + lane] = y[i];
-      }
-      E1[8 * 64 + lane] = make_float2(gs.x, -gs.y);
-      E2[8 * 64 + lane] = make_float2(1.f, 0.f);
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      {
-        const int rc = lane & 15, kq = lane >> 4, part = kq & 1;
+      for (int pass = 0; pass < 2; ++pass) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (pass == 0) {
+#pragma unroll
+          for (int S1 = 0; S1 < 16; ++S1) E1[S1 * T8_P + lane] = cmul(E1[S1 * T8_P + lane], u);
+        } else {
+          // (u e1 -> -u T' e1: multiply the stored rows by -T')
+          const float2 mt = make_float2(-t.x, -t.y);
+#pragma unroll
+          for (int S1 = 0; S1 < 16; ++S1) E1[S1 * T8_P + lane] = live ? cmul(E1[S1 * T8_P + lane], mt) : make_float2(0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 acc = pass ? accQ : accP;
 #pragma unroll 4
         for (int t2 = 0; t2 < 32; ++t2) {
           const int bin = 2 * t2 + (kq >> 1);
-          const float2 a2 = rc < 9 ? E1[rc * 64 + bin] : make_float2(0.f, 0.f);
-          const float2 b2 = rc < 9 ? E2[rc * 64 + bin] : make_float2(0.f, 0.f);
-          accD = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -a2.y : a2.x, part ? b2.y : b2.x, accD, 0, 0, 0);
+          const float2 a2 = E1[rc * T8_P + bin], b2 = E2[rc * T8_P + bin];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -a2.y : a2.x, part ? b2.y : b2.x, acc, 0, 0, 0);
         }
+        if (pass) accQ = acc; else accP = acc;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -400,29 +365,31 @@ __global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
   const int nparts = gridDim.x;
   {
     const float v = wave_sum(acc0);
-    if (lane == 0) s_red[wv][256] = v;
+    if (lane == 0) s_red[wv][T8_GREC] = v;
   }
   if (HEAVY) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_red[wv][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = accD[r];    // D[row][col]
+    for (int r = 0; r < 4; ++r) {
+      const int S1 = 4 * (lane >> 4) + r, S2 = lane & 15;
+      s_red[wv][S1 + 16 * S2] = accP[r];
+      s_red[wv][256 + S1 + 16 * S2] = accQ[r];
+    }
   }
   __syncthreads();
   if (!HEAVY) {
     if (tid == 0) {
       float s = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < T8_WAVES; ++w2) s += s_red[w2][256];
+      for (int w2 = 0; w2 < T8_WAVES; ++w2) s += s_red[w2][T8_GREC];
       a.part[(size_t)blk * nparts + blockIdx.x] = s;
     }
     return;
   }
-  for (int e = tid; e <= T8_ACC; e += blockDim.x) {
-    // e < 64: dL/dA[i][j] = D[i][j];  64 + i: dL/db_i = D[i][8];  72 + j: dL/dc_j = D[8][j];  80: the loss partial
-    const int src = e < 64 ? (e >> 3) * 16 + (e & 7) : (e < 72 ? (e - 64) * 16 + 8 : (e < 80 ? 8 * 16 + (e - 72) : 256));
+  for (int e = tid; e <= T8_GREC; e += blockDim.x) {
     float s = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < T8_WAVES; ++w2) s += s_red[w2][src];
-    if (e < T8_ACC) a.part[((size_t)blk * T8_ACC + e) * nparts + blockIdx.x] = s;
+    for (int w2 = 0; w2 < T8_WAVES; ++w2) s += s_red[w2][e];
+    if (e < T8_GREC) a.part[((size_t)blk * T8_GREC + e) * nparts + blockIdx.x] = s;
     else if (a.lossp) a.lossp[(size_t)blk * nparts + blockIdx.x] = s;
   }
 }
@@ -510,7 +477,7 @@ extern "C" int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int
 
 // work: gfdn_tf8_part_bytes(nblk, K) for part, nblk * gfdn_tf8_parts(K) floats for lossp
 extern "C" size_t gfdn_tf8_part_bytes(int nblk, int K) {
-  return (size_t)(nblk > 0 ? nblk : 1) * T8_ACC * t8_parts_host(K > 0 ? K : 1) * sizeof(float);
+  return (size_t)(nblk > 0 ? nblk : 1) * T8_GREC * t8_parts_host(K > 0 ? K : 1) * sizeof(float);
 }
 
 extern "C" int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
@@ -539,6 +506,175 @@ extern "C" int gfdn_tf8_compose_bwd(const double* turns, int K, int nbands, int 
   a.G = G; a.rgain = rgain; a.gH = (const float2*)gH_c64; a.ldh = ldh; a.filt = (const float2*)filt_c64; a.ldf = ldf;
   a.B = B; a.part = part;
   return t8_launch<T8_BWD>(a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Gradient records -> (dL/dA, dL/db, dL/dc), float64, one workgroup per (block, set), thread S = subset.
+//   Q_S = igp_S det(M_S) ,             M_S = (-A) restricted to S^c (unit rows / columns on S and beyond n)
+//   P_S = -igp_S det(B_S) ,            B_S = [[M_S, b on S^c], [c^T on S^c, 0]]   (9 x 9, b, c the CURRENT gains)
+//   dL/dA_ij = sum_S igp_S (gP_S Cof(B_S)_ij - gQ_S Cof(M_S)_ij)        (i, j in S^c;  d(-A) = -dA)
+//   dL/db_i  = -sum_S igp_S gP_S Cof(B_S)_{i,8} ,   dL/dc_j = -sum_S igp_S gP_S Cof(B_S)_{8,j}
+// Cofactor matrices as det * inverse^T from an in-register Gauss-Jordan inversion with partial pivoting (row swaps by
+// selects: compile-time indices only); a vanishing pivot is replaced by 1e-150 (the product det * inverse keeps the
+// finite limit).  out[(blk * 80 + e)]: e < 64 dL/dA, 64 + i dL/db_i, 72 + j dL/dc_j -- the layout k_tf8_param_grads sums.
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ double t8_inverse(double (&m)[N][N]) {
+  double det = 1.0;
+  int perm[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double best = fabs(m[k][k]);
+    int p = k;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const double v = fabs(m[i][k]);
+      if (v > best) { best = v; p = i; }
+    }
+    perm[k] = p;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const bool sw = p == i;
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        const double t = m[k][c];
+        m[k][c] = sw ? m[i][c] : t;
+        m[i][c] = sw ? t : m[i][c];
+      }
+    }
+    if (p != k) det = -det;
+    double piv = m[k][k];
+    if (fabs(piv) < 1e-150) piv = piv < 0.0 ? -1e-150 : 1e-150;
+    det *= piv;
+    const double pinv = 1.0 / piv;
+    m[k][k] = 1.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) m[k][c] *= pinv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i == k) continue;
+      const double f = m[i][k];
+      m[i][k] = 0.0;
+#pragma unroll
+      for (int c = 0; c < N; ++c) m[i][c] -= f * m[k][c];
+    }
+  }
+  // (P A)^-1 = A^-1 P^T: undo the row swaps as column swaps, last first
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+    for (int c = k + 1; c < N; ++c) {
+      const bool sw = perm[k] == c;
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const double t = m[r][k];
+        m[r][k] = sw ? m[r][c] : t;
+        m[r][c] = sw ? t : m[r][c];
+      }
+    }
+  }
+  return det;
+}
+
+__device__ __forceinline__ double t8_wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_tf8_rec_grads(const float* __restrict__ A0, const float* __restrict__ ig0,
+                                                       const float* __restrict__ part0, int np0,
+                                                       const float* __restrict__ A1, const float* __restrict__ ig1,
+                                                       const float* __restrict__ part1, int np1,
+                                                       const float* __restrict__ b, const float* __restrict__ c, int n,
+                                                       float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ double sA[64], sb[8], sc[8], sig[8], sred[4][T8_ACC];
+  const int blk = blockIdx.x, set = blockIdx.y, S = threadIdx.x, lane = S & 63, wv = S >> 6;
+  const float* A = (set ? A1 : A0) + (size_t)blk * n * n;
+  const float* ig = set ? ig1 : ig0;
+  const float* part = set ? part1 : part0;
+  const int np = set ? np1 : np0;
+  float* out = (set ? out1 : out0) + (size_t)blk * T8_ACC;
+  if (S < 64) {
+    const int i = S >> 3, j = S & 7;
+    sA[S] = (i < n && j < n) ? -(double)A[i * n + j] : 0.0;
+  }
+  if (S < 8) {
+    sb[S] = S < n ? (double)b[blk * n + S] : 0.0;
+    sc[S] = S < n ? (double)c[blk * n + S] : 0.0;
+    sig[S] = (S < n && ig) ? (double)ig[blk * n + S] : 1.0;
+  }
+  // this subset's two gradient records, summed over the passes' partial rows in a fixed order
+  double gP = 0.0, gQ = 0.0;
+  {
+    const float* rp = part + ((size_t)blk * T8_GREC + S) * np;
+    const float* rq = part + ((size_t)blk * T8_GREC + 256 + S) * np;
+    float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int i = 0;
+    for (; i + 1 < np; i += 2) { p0 += rp[i]; p1 += rp[i + 1]; q0 += rq[i]; q1 += rq[i + 1]; }
+    if (i < np) { p0 += rp[i]; q0 += rq[i]; }
+    gP = (double)(p0 + p1);
+    gQ = (double)(q0 + q1);
+  }
+  __syncthreads();
+  const bool absent = (S >> n) != 0, full = S == (1 << n) - 1;      // (the full set's coefficients are constants)
+  double igp = 1.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if ((S >> i) & 1) igp *= sig[i];
+  const double wq = (absent || full) ? 0.0 : -gQ * igp, wp = (absent || full) ? 0.0 : gP * igp;
+  // (each matrix's contributions are summed over the wave as soon as its cofactors exist: the 8 x 8 inverse, 128
+  // registers, is dead before the 9 x 9 one, 162 registers, is built)
+  {
+    double m[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const bool in = !((S >> r) & 1) && !((S >> cc) & 1) && r < n && cc < n;
+        m[r][cc] = in ? sA[r * 8 + cc] : (r == cc ? 1.0 : 0.0);
+      }
+    const double wd = wq * t8_inverse<8>(m);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = !((S >> i) & 1) && !((S >> j) & 1) && i < n && j < n;
+        const double v = t8_wave_sum_d(in ? wd * m[j][i] : 0.0);        // Cof = det inverse^T
+        if (lane == 0) sred[wv][i * 8 + j] = v;
+      }
+  }
+  {
+    double m[9][9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 9; ++cc) {
+        const bool rin = r == 8 || (!((S >> r) & 1) && r < n), cin = cc == 8 || (!((S >> cc) & 1) && cc < n);
+        double v;
+        if (r < 8 && cc < 8) v = (rin && cin) ? sA[r * 8 + cc] : (r == cc ? 1.0 : 0.0);
+        else if (r < 8) v = rin ? sb[r] : 0.0;                       // border column: b on S^c
+        else if (cc < 8) v = cin ? sc[cc] : 0.0;                     // border row: c on S^c
+        else v = 0.0;
+        m[r][cc] = v;
+      }
+    const double wd = wp * t8_inverse<9>(m);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool iin = !((S >> i) & 1) && i < n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = iin && !((S >> j) & 1) && j < n;
+        const double v = t8_wave_sum_d(in ? wd * m[j][i] : 0.0);
+        if (lane == 0) sred[wv][i * 8 + j] += v;
+      }
+      const double vb = t8_wave_sum_d(iin ? -wd * m[8][i] : 0.0);      // Cof(B)_{i,8} = det inverse[8][i]
+      const double vc = t8_wave_sum_d(iin ? -wd * m[i][8] : 0.0);      // Cof(B)_{8,i} = det inverse[i][8]
+      if (lane == 0) { sred[wv][64 + i] = vb; sred[wv][72 + i] = vc; }
+    }
+  }
+  __syncthreads();
+  if (S < T8_ACC) out[S] = (float)((sred[0][S] + sred[1][S]) + (sred[2][S] + sred[3][S]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -584,17 +720,27 @@ __global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict
                   gM + off);
 }
 
-extern "C" int gfdn_tf8_param_grads(const float* part0, int nparts0, const float* part1, int nparts1, const float* scale,
-                                    int nblk, int nper, const float* M, const float* gQ, const float* Q, float* gb,
-                                    float* gc, float* gM, void* stream) {
-  if (!part0 || !M || !gb || !gc || !gM || nblk <= 0 || nper <= 0 || nparts0 <= 0 || (part1 && nparts1 <= 0))
+extern "C" size_t gfdn_tf8_param_grads_work_bytes(int nblk) { return (size_t)2 * (nblk > 0 ? nblk : 1) * T8_ACC * sizeof(float); }
+
+extern "C" int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* part0, int nparts0,
+                                    const float* A1, const float* inv_gamma1, const float* part1, int nparts1,
+                                    const float* b, const float* c, int nblk, int nper, const float* M, const float* gQ,
+                                    const float* Q, float* gb, float* gc, float* gM, void* work, void* stream) {
+  if (!A0 || !part0 || !b || !c || !M || !gb || !gc || !gM || !work || nblk <= 0 || nper <= 0 || nparts0 <= 0 ||
+      (A1 && (!part1 || nparts1 <= 0)))
     return GFDN_E_BADARG;
   if (nper > 8) return GFDN_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* out0 = (float*)work;
+  float* out1 = out0 + (size_t)nblk * T8_ACC;
+  hipLaunchKernelGGL(k_tf8_rec_grads, dim3(nblk, A1 ? 2 : 1), dim3(256), 0, s, A0, inv_gamma0, part0, nparts0, A1, inv_gamma1,
+                     part1, nparts1, b, c, nper, out0, out1);
+  GFDN_LAUNCH_CHECK();
   const size_t lds = ortho_bwd_lds_doubles(nper) * sizeof(double);
   int rc = ensure_dyn_lds(k_tf8_param_grads, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_tf8_param_grads, dim3(nblk), dim3(256), lds, (hipStream_t)stream, part0, nparts0, part1, nparts1,
-                     scale, nper, M, gQ, Q, gb, gc, gM);
+  hipLaunchKernelGGL(k_tf8_param_grads, dim3(nblk), dim3(256), lds, s, (const float*)out0, 1, A1 ? (const float*)out1 : nullptr,
+                     1, (const float*)nullptr, nper, M, gQ, Q, gb, gc, gM);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

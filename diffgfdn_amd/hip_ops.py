@@ -754,20 +754,20 @@ def tf_ortho_coefs(M, ig, b, c, sub: bool = True):
 
 # ---- blocks of 5..8 lines: polynomial form on the matrix cores (csrc/blocktf8.hip) ---------------------------------------
 def tf8_coefs(A0, ig0, b, c, A1=None, ig1=None):
-    """Coefficient records (nblk, 17, 256) float32 of (A0, 1 / gamma0) [and (A1, 1 / gamma1)] sharing b, c: the
-    determinant polynomial and the numerators of y = X^-1 b and w = X^-T c (see the kernel file)."""
+    """Coefficient records (nblk, 9, 256) float32 of (A0, 1 / gamma0) [and (A1, 1 / gamma1)] sharing b: the determinant
+    polynomial and the numerators of y = X^-1 b (see the kernel file; c is read by the passes)."""
     _need_gpu(A0, b, c)
     A0, b, c = _f(A0), _f(b).reshape(-1), _f(c).reshape(-1)
     nblk, n, _ = A0.shape
     if b.numel() != nblk * n or c.numel() != nblk * n:
         raise RuntimeError("tf8_coefs: b, c must hold nblk * n gains")
     ig0 = None if ig0 is None else _f(ig0).reshape(-1)
-    c0 = torch.empty((nblk, 17, 256), dtype=_f32, device=A0.device)
+    c0 = torch.empty((nblk, 9, 256), dtype=_f32, device=A0.device)
     c1 = None
     if A1 is not None:
         A1 = _f(A1)
         ig1 = None if ig1 is None else _f(ig1).reshape(-1)
-        c1 = torch.empty((nblk, 17, 256), dtype=_f32, device=A0.device)
+        c1 = torch.empty((nblk, 9, 256), dtype=_f32, device=A0.device)
     _lib.check(_lib.load().gfdn_tf8_coefs(_p(A0), _p(ig0), _p(c0), _p(A1), _p(ig1), _p(c1), _p(b), _p(c), nblk, n,
                                           _stream()), "gfdn_tf8_coefs")
     return c0, c1
@@ -811,13 +811,13 @@ def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, qua
 
 
 def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: float):
-    """Colorless pass on the records of the raw sub-FDN blocks -> (part (nblk, 80, parts) gradient partials, loss (nblk,))."""
+    """Colorless pass on the records of the raw sub-FDN blocks -> (part (nblk, 512, parts) gradient records, loss (nblk,))."""
     _need_gpu(turns, coef, delays, c)
     coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
     nblk, K = coef.shape[0], turns.numel()
     lib = _lib.load()
     parts = lib.gfdn_tf8_parts(K)
-    part = torch.empty((nblk, 80, parts), dtype=_f32, device=coef.device)
+    part = torch.empty((nblk, 512, parts), dtype=_f32, device=coef.device)
     lossp = torch.empty((nblk, parts), dtype=_f32, device=coef.device)
     loss = torch.empty(nblk, dtype=_f32, device=coef.device)
     _lib.check(lib.gfdn_tf8_colorless(_p(turns), K, nblk, nper, _p(coef), _p(delays), _p(c), _p(None if scale is None else _f(scale)),
@@ -827,7 +827,7 @@ def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: 
 
 
 def tf8_compose_bwd(turns, coef, delays, nper: int, c, scale, rgain, gH, filt=None, nbands: int = 1):
-    """Gradient partials (nbands * G, 80, parts) of the output stage from dL/dH (nbands * B, K)."""
+    """Gradient records (nbands * G, 512, parts) of the output stage from dL/dH (nbands * B, K)."""
     _need_gpu(turns, coef, delays, c, rgain, gH)
     coef, delays, c, rgain, gH = _f(coef), _f(delays), _f(c).reshape(-1), _f(rgain), _c(gH)
     K = turns.numel()
@@ -838,29 +838,36 @@ def tf8_compose_bwd(turns, coef, delays, nper: int, c, scale, rgain, gH, filt=No
     if filt is not None and filt.numel() != nbands * K:
         raise RuntimeError("tf8_compose_bwd: filt must hold K bins per band")
     lib = _lib.load()
-    part = torch.empty((nbands * G, 80, lib.gfdn_tf8_parts(K)), dtype=_f32, device=coef.device)
+    part = torch.empty((nbands * G, 512, lib.gfdn_tf8_parts(K)), dtype=_f32, device=coef.device)
     _lib.check(lib.gfdn_tf8_compose_bwd(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c),
                                         _p(None if scale is None else _f(scale)), _p(rgain), Btot // nbands, _p(filt), K,
                                         _p(gH), gH.stride(0), _p(part), _stream()), "gfdn_tf8_compose_bwd")
     return part
 
 
-def tf8_param_grads(part0, part1, scale, M, gQ=None, Q=None, gb=None, gc=None, gM=None):
-    """Tail: partial rows of set 0 (damped loop) [and set 1 (raw sub-FDN blocks)] -> (gM, gb, gc)."""
-    _need_gpu(part0, M)
-    M = _f(M)
+def tf8_param_grads(A0, ig0, part0, b, c, M, A1=None, ig1=None, part1=None, gQ=None, Q=None, gb=None, gc=None, gM=None):
+    """Tail of the 8-line step: gradient records of set 0 (A0 = Q Q, 1 / gamma0) [and set 1 (A1 = raw M)] ->
+    (gM, gb, gc) w.r.t. the CURRENT gains b, c, with the orthogonal parameterisation's adjoint folded in."""
+    _need_gpu(A0, part0, b, c, M)
+    A0, M, b, c = _f(A0), _f(M), _f(b).reshape(-1), _f(c).reshape(-1)
     nblk, n, _ = M.shape
-    if part0.dim() != 3 or tuple(part0.shape[:2]) != (nblk, 80) or (part1 is not None and tuple(part1.shape[:2]) != (nblk, 80)):
-        raise RuntimeError("tf8_param_grads: partials must be (nblk, 80, parts)")
+    if part0.dim() != 3 or tuple(part0.shape[:2]) != (nblk, 512) or \
+            (part1 is not None and (A1 is None or tuple(part1.shape[:2]) != (nblk, 512))):
+        raise RuntimeError("tf8_param_grads: records must be (nblk, 512, parts)")
     dev = M.device
+    ig0 = None if ig0 is None else _f(ig0).reshape(-1)
+    ig1 = None if ig1 is None else _f(ig1).reshape(-1)
     gb = torch.empty(nblk * n, dtype=_f32, device=dev) if gb is None else gb
     gc = torch.empty(nblk * n, dtype=_f32, device=dev) if gc is None else gc
     gM = torch.empty_like(M) if gM is None else gM
-    _lib.check(_lib.load().gfdn_tf8_param_grads(_p(_f(part0)), part0.shape[2], _p(None if part1 is None else _f(part1)),
-                                                0 if part1 is None else part1.shape[2],
-                                                _p(None if scale is None else _f(scale)), nblk, n, _p(M),
-                                                _p(None if gQ is None else _f(gQ)), _p(None if Q is None else _f(Q)),
-                                                _p(gb), _p(gc), _p(gM), _stream()), "gfdn_tf8_param_grads")
+    lib = _lib.load()
+    work = torch.empty(lib.gfdn_tf8_param_grads_work_bytes(nblk) // 4, dtype=_f32, device=dev)
+    _lib.check(lib.gfdn_tf8_param_grads(_p(A0), _p(ig0), _p(_f(part0)), part0.shape[2],
+                                        _p(None if A1 is None else _f(A1)), _p(ig1),
+                                        _p(None if part1 is None else _f(part1)), 0 if part1 is None else part1.shape[2],
+                                        _p(b), _p(c), nblk, n, _p(M), _p(None if gQ is None else _f(gQ)),
+                                        _p(None if Q is None else _f(Q)), _p(gb), _p(gc), _p(gM), _p(work), _stream()),
+               "gfdn_tf8_param_grads")
     return gM, gb, gc
 
 

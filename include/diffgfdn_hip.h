@@ -363,23 +363,24 @@ int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave_c64, c
 /* ---- block transfer functions for blocks of 5..8 lines (BASELINE.json configs[4]: N = 32 = 4 groups x 8 lines) -----
  * csrc/blocktf8.hip.  The same reference maths as the gfdn_tf_* family (feedback_loop.py:326-391 resolvent of one block,
  * model.py:583-619 output stage, model.py:209-252 sub-FDN responses, trainer.py:317-332 normalize,
- * colorless_fdn/losses.py:20-73) with the polynomial evaluation on the matrix cores (v_mfma_f32_16x16x4_f32): per block
- * 17 multilinear polynomials in the 8 phasors z^{m_i} -- det X, the numerators of y = X^-1 b and of w = X^-T c -- 256
- * real coefficients each, coef (nblk, 17, 256) float32 with the subset index S = S1 + 16 S2 (S1: lines 0..3, S2: 4..7).
- * Unit-circle grids only (turns; no log radius).  Scaling convention: coefficients are built from the gains BEFORE
- * normalize's rescale; the passes take the CURRENT output gains c and scale (NULL before the rescale).
- *   gfdn_tf8_coefs      : records of (A0, 1/gamma0) -> coef0 and optionally (A1, 1/gamma1) -> coef1, sharing b, c.
- *   gfdn_tf8_energy     : E_blk = mean_k |sum_i c_i y_i|^2 -> energy, scale = E^(-1/2), b, c /= E^(1/4) in place;
- *                         work: nblk * gfdn_tf8_parts(K) floats.
+ * colorless_fdn/losses.py:20-73) with the polynomial evaluation AND the gradient-record accumulation on the matrix
+ * cores (v_mfma_f32_16x16x4_f32): T = P / Q, 256 real coefficients each, subset index S = S1 + 16 S2 (S1: lines 0..3,
+ * S2: 4..7).  coef (nblk, 9, 256) float32: the determinant polynomial Q and the numerators Y_i of y_i = (X^-1 b)_i
+ * (P = sum_i c_i Y_i is formed from the CURRENT output gains when a pass starts).  Unit-circle grids only (turns).
+ * Scaling convention: coefficients are built from the gains BEFORE normalize's rescale; the passes take the CURRENT c
+ * and scale (NULL before the rescale) and work on the records of the current gains.
+ *   gfdn_tf8_coefs      : records of (A0, 1/gamma0) -> coef0 and optionally (A1, 1/gamma1) -> coef1, sharing b.
+ *   gfdn_tf8_energy     : E_blk = mean_k |T|^2 -> energy, scale = E^(-1/2), b, c /= E^(1/4) in place; work: nblk *
+ *                         gfdn_tf8_parts(K) floats.
  *   gfdn_tf8_tsave      : T' (nbands * G, K) complex64 scaled group transfer functions (+ Tquad (nbands, K, 4), the
  *                         layout gfdn_irfft_odd_pairs_compose_fwd consumes), G <= 4.
- *   gfdn_tf8_colorless  : loss[blk] = mean_k (|T'| - 1)^p and the gradient partials of gscale * sum loss.
- *   gfdn_tf8_compose_bwd: gradient partials of the output stage, dL/dT'_g = conj(filt) sum_b rgain[b][g] dL/dH[b].
- *     part[(blk * 80 + e) * gfdn_tf8_parts(K) + p]: e < 64 dL/dA (8 x 8 row-major), 64 + i dL/db_i, 72 + j dL/dc_j, on the
- *     unscaled polynomials (gfdn_tf8_part_bytes).
- *   gfdn_tf8_param_grads: sums the partial rows of set 0 (damped loop, A = Q Q) and set 1 (sub-FDN, A = raw M), applies
- *     the scale factors, writes dL/db, dL/dc and dL/dM through the adjoint of Q = expm(skew(M)), Q Q (as gfdn_ortho_bwd
- *     with dL/dM_raw added; gQ: a gradient that reaches Q directly, e.g. the sparsity term's).                        */
+ *   gfdn_tf8_colorless  : loss[blk] = mean_k (|T'| - 1)^p and the gradient records of gscale * sum loss.
+ *   gfdn_tf8_compose_bwd: gradient records of the output stage, dL/dT'_g = conj(filt) sum_b rgain[b][g] dL/dH[b].
+ *     part[(blk * 512 + e) * gfdn_tf8_parts(K) + p]: e < 256 dL/dP_S, 256 + S dL/dQ_S (gfdn_tf8_part_bytes).
+ *   gfdn_tf8_param_grads: records -> dL/dA (cofactors of the 256 masked 8 x 8 / bordered 9 x 9 matrices per block and
+ *     set, float64) for set 0 (damped loop, A0 = Q Q, 1/gamma0) and set 1 (sub-FDN, A1 = raw M), dL/db, dL/dc w.r.t. the
+ *     CURRENT gains b, c, then dL/dM through the adjoint of Q = expm(skew(M)), Q Q (as gfdn_ortho_bwd with dL/dM_raw
+ *     added; gQ: a gradient that reaches Q directly, e.g. the sparsity term's).  work: gfdn_tf8_param_grads_work_bytes. */
 int gfdn_tf8_coefs(const float* A0, const float* inv_gamma0, float* coef0, const float* A1, const float* inv_gamma1,
                    float* coef1, const float* b, const float* c, int nblk, int nper, void* stream);
 int gfdn_tf8_parts(int K);
@@ -394,9 +395,11 @@ int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const flo
 int gfdn_tf8_compose_bwd(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
                          const float* c, const float* scale, const float* rgain, int B, const float* filt_c64, int ldf,
                          const float* gH_c64, int ldh, float* part, void* stream);
-int gfdn_tf8_param_grads(const float* part0, int nparts0, const float* part1, int nparts1, const float* scale, int nblk,
-                         int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc, float* gM,
-                         void* stream);
+size_t gfdn_tf8_param_grads_work_bytes(int nblk);
+int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* part0, int nparts0, const float* A1,
+                         const float* inv_gamma1, const float* part1, int nparts1, const float* b, const float* c,
+                         int nblk, int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc,
+                         float* gM, void* work, void* stream);
 
 /* ---- measurement kernel for BASELINE.json configs[4] ("fp32 vs bf16 feedback-matmul on MFMA") ------------------
  * The reference's dense formulation (feedback_loop.py:389-391 explicit resolvent P (K, N, N); model.py:615-619

@@ -364,6 +364,70 @@ def test_fused_bank_step_equals_autograd_bank_step(mask):
     assert rel_err(res[True][2], res[False][2]) < 1e-4
 
 
+def _build_net8(q):
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    torch.manual_seed(300 + q)
+    base = [173, 179, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283,
+            293, 401]
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    T60 = np.linspace(0.2, 0.5, G)[None, :]
+    return DiffGFDNVarReceiverPos(FS, G, [d + 2 * q for d in base], DEV, fl, of, use_absorption_filters=False,
+                                  common_decay_times=T60, use_colorless_loss=True).to(DEV)
+
+
+@pytest.mark.parametrize("mask", [True, False])
+def test_fused_bank_step_eight_line_blocks_equals_autograd_bank_step(mask):
+    """BASELINE.json configs[4]'s layout (blocks of 8 lines): the explicit step on the 17-polynomial records evaluated on
+    the matrix cores (csrc/blocktf8.hip) against the autograd path on the per-bin elimination kernels -- per-band
+    losses, every gradient, the post-Adam state."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    sels = [[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]]
+    res = {}
+    for fused in (True, False):
+        BandBankTrainer.use_fused = fused
+        try:
+            nets = [_build_net8(q) for q in range(len(BANDS))]
+            data = [_build_data(q) for q in range(len(BANDS))]
+            filt = torch.tensor(_band_filters(), device=DEV).to(torch.complex64)
+            bank = BandBank(nets)
+            tr = BandBankTrainer(bank, _tc(mask), subband_filter_freq_resp=filt, stft_win=WIN, band_names=BANDS)
+        finally:
+            BandBankTrainer.use_fused = True
+        assert bank.num_delay_lines_per_group == 8 and (tr._fused is not None) == fused
+        sds = BandStackedDataset([d for _, d in data])
+        start, length = tr._decay_window(NFFT // 2 + 1)
+        sds.precompute_decay_targets(WIN, start, length)
+        mw = torch.tensor(philox_mask(99, 0, length, 1.0 / 4)[0], device=DEV) if mask else \
+            torch.full((length,), 1.0 / (4 * length), device=DEV)
+        batch = sds.collate(sds.global_rows(sels))
+        if fused:
+            losses = tr._fused.run(batch, mw, 1.0, normalize_first=True, train=True, opt_step=False)
+        else:
+            tr.optimizer.zero_grad(set_to_none=True)
+            losses = tr._step_losses(batch, mask_prenorm=mw, defer_total=True, normalize_first=True)
+            heads = losses.pop("_heads")
+            torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
+            tr.optimizer.pack_grads()
+            losses["_total"] = heads[0].detach() + heads[1].detach()
+        grad = tr.optimizer.flat_grad.detach().cpu().numpy().copy()
+        tr.optimizer.step()
+        res[fused] = ({k: v.detach().cpu().numpy() for k, v in losses.items()}, grad,
+                      tr.optimizer.flat_param.detach().cpu().numpy().copy(), tr.optimizer)
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=5e-5, atol=1e-7), (k, res[True][0][k], v)
+    ga, gb = res[True][1], res[False][1]
+    off = 0
+    for p in res[False][3]._params:
+        sl = slice(off, off + p.numel())
+        # (two float32 paths against each other; dL/dM is the skew part of the matrix-exponential adjoint, which
+        # amplifies the rounding of dL/d(Q Q) on BOTH sides: DESIGN.md section 2)
+        assert np.abs(ga[sl] - gb[sl]).max() < 1e-3 * np.abs(gb[sl]).max(), (off, np.abs(ga[sl] - gb[sl]).max(), np.abs(gb[sl]).max())
+        off += p.numel()
+    assert rel_err(res[True][2], res[False][2]) < 1e-4
+
+
 def test_bank_training_loop_checkpoints_and_band_freeze(tmp_path):
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
     nets = [_build_net(q) for q in range(len(BANDS))]
