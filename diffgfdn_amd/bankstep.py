@@ -301,7 +301,7 @@ class FusedBankStep:
         scale = ework = None
         if normalize_first:
             if big:
-                _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c)
+                _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c, dturn=gridK.dturn)
             else:
                 _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                          dturn=gridK.dturn)
@@ -344,7 +344,8 @@ class FusedBankStep:
             torch.cuda.current_stream().wait_event(ev['norm'])
             if big:
                 grec_sub, loss_g = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
-                                                     cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world)
+                                                     cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
+                                                     dturn=gridK.dturn)
             else:
                 grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
                                                     cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,

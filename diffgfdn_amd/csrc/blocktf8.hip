@@ -37,10 +37,11 @@ typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 #define T8_GREC 512                    // gradient records of a block: dL/dP_S (256) | dL/dQ_S (256), S = S1 + 16 S2
 #define T8_MAXBLK 64
 #define T8_MAX_PARTS 256
-#define T8_WAVES 4
+#define T8_WAVES 4                     // wavefronts per workgroup (measured: 2 per workgroup, four workgroups per CU, is 10 % slower)
 #define T8_P 66                        // row pitch (float2) of the waves' [S][bin] images: rows 16 B apart in the banks, so
                                        // that the 16 rows x 2 bins a gradient MFMA step reads hit 64 distinct banks
-#define T8_LDS_BYTES ((size_t)T8_WAVES * 2 * 16 * T8_P * sizeof(float2))
+#define T8_IMG (2 * 16 * T8_P + 64)     // float2 per wavefront: the two [S][bin] images and one row of 64 per-bin values
+#define T8_LDS_BYTES ((size_t)T8_WAVES * T8_IMG * sizeof(float2))
 
 // ------------------------------------------------------------------------------------------
 // coefficient records (float64): determinants of masked 8 x 8 matrices, partial pivoting by row selects
@@ -144,8 +145,10 @@ extern "C" int gfdn_tf8_coefs(const float* A0, const float* inv_gamma0, float* c
 // ------------------------------------------------------------------------------------------
 struct T8Args {
   const double* turns;
+  double dturn;              // != 0: the grid is uniform on the unit circle with this step (turns[k] = turns[0] + k dturn):
+                             // a wavefront then steps its phasors from tile to tile by constant rotations
   int K, nblk, nper;
-  const float* coef;         // (nblk, 17, 256)
+  const float* coef;         // (nblk, 9, 256)
   const float* delays;       // (nblk * nper)
   const float* c;            // (nblk * nper) output gains as they are NOW (see the scaling convention)
   const float* scale;        // (nblk) s = E^(-1/2), or NULL (the energy pass: gains not yet rescaled, factor 1)
@@ -203,9 +206,9 @@ template <int NP>
 __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* E1, const float2* E2, int lane,
                                          float2 (&val)[NP]) {
   const int q = lane >> 4, cidx = lane & 15;
-  // (rolled: unrolled, the scheduler interleaves the four column groups' MFMA chains and keeps all their accumulators
-  // -- 4 x 2 x 4 NP registers -- alive at once)
-#pragma unroll 1
+  // (unrolled: the scheduler interleaves the four column groups' MFMA chains with the previous groups' dot products --
+  // 4 x 2 x 4 NP accumulator registers alive at once, 64 for the two polynomials of a pass)
+#pragma unroll
   for (int cg = 0; cg < 4; ++cg) {
     f32x4 are[NP], aim[NP];
 #pragma unroll
@@ -218,8 +221,13 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
       const float2 b2 = E2[(4 * ks + q) * T8_P + 16 * cg + cidx];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+#ifdef T8_DIAG_NO_MFMA
+        are[p][0] += A[p][ks] * b2.x;
+        aim[p][0] += A[p][ks] * b2.y;
+#else
         are[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][ks], b2.x, are[p], 0, 0, 0);
         aim[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][ks], b2.y, aim[p], 0, 0, 0);
+#endif
       }
     }
     float2 e1v[4];
@@ -235,22 +243,25 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
         s.y += are[p][r] * e1v[r].y + aim[p][r] * e1v[r].x;
       }
       // ... and over the four lanes that hold the other S1 of the same bin
+#ifndef T8_DIAG_NO_SHFL
       s.x += __shfl_xor(s.x, 16, 64);
       s.y += __shfl_xor(s.y, 16, 64);
       s.x += __shfl_xor(s.x, 32, 64);
       s.y += __shfl_xor(s.y, 32, 64);
+#endif
       if (q == cg) val[p] = s;          // bin 16 cg + cidx = this lane
     }
   }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
+__global__ __launch_bounds__(64 * T8_WAVES, 8 / T8_WAVES) void k_tf8_pass(T8Args a) {
   __shared__ float s_red[T8_WAVES][T8_GREC + 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int blk = blockIdx.y, n = a.nper, K = a.K;
-  float2* E1 = t8_lds + wv * (2 * 16 * T8_P);
+  float2* E1 = t8_lds + wv * T8_IMG;
   float2* E2 = E1 + 16 * T8_P;
+  float2* TT = E2 + 16 * T8_P;
   const float* coef = a.coef + (size_t)blk * T8_REC;
   float m[8];
 #pragma unroll
@@ -274,6 +285,17 @@ __global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
   f32x4 accQ = (f32x4){0.f, 0.f, 0.f, 0.f};              // = entry [S1 = 4 (l >> 4) + r][S2 = l & 15]
   const int ntiles = (K + 63) >> 6;
   const float invK = 1.0f / (float)K;
+  float2 ph[8], rot[8];
+  int iter = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    ph[r] = make_float2(1.f, 0.f);
+    double tr = (double)m[r] * a.dturn * 64.0 * (double)(gridDim.x * T8_WAVES);
+    tr -= rint(tr);
+    float sn, cs;
+    sincospif(2.0f * (float)tr, &sn, &cs);
+    rot[r] = make_float2(cs, sn);
+  }
   const int band = a.G > 0 ? blk / a.G : 0, g = a.G > 0 ? blk - band * a.G : 0;
 #pragma unroll 1
   for (int tile = blockIdx.x * T8_WAVES + wv; tile < ntiles; tile += gridDim.x * T8_WAVES) {
@@ -294,10 +316,24 @@ __global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
       if (a.filt) gs = cmulc(gs, a.filt[(size_t)band * a.ldf + kk]);      // dL/dT' = conj(filt) sum_b rgain dL/dH
     }
     asm volatile("" ::: "memory");
-    t8_stage_subsets(t8_zpow(a.turns, kk, m[0]), t8_zpow(a.turns, kk, m[1]), t8_zpow(a.turns, kk, m[2]),
-                     t8_zpow(a.turns, kk, m[3]), E1, lane);
-    t8_stage_subsets(t8_zpow(a.turns, kk, m[4]), t8_zpow(a.turns, kk, m[5]), t8_zpow(a.turns, kk, m[6]),
-                     t8_zpow(a.turns, kk, m[7]), E2, lane);
+    // phasors z_k^{m_i}: exact (float64 range reduction + sincospif) -- or, on a uniform grid, exact every eighth tile of
+    // the wavefront and stepped by the constant rotation z_1^{m_i (tile stride)} in between (eight complex products per
+    // bin instead of eight range reductions; the rounding of seven steps, ~1e-7 each, stays far below the 1e-5 the
+    // evaluation itself carries -- as the TF_RUN runs of csrc/blocktf.hip)
+#ifdef T8_DIAG_NO_PHASE
+    if (iter == 0) {
+#else
+    if (a.dturn == 0.0 || (iter & 7) == 0 || !live) {
+#endif
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ph[r] = t8_zpow(a.turns, kk, m[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ph[r] = cmul(ph[r], rot[r]);
+    }
+    ++iter;
+    t8_stage_subsets(ph[0], ph[1], ph[2], ph[3], E1, lane);
+    t8_stage_subsets(ph[4], ph[5], ph[6], ph[7], E2, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS image: no block barrier)
     float2 val[2];
@@ -332,29 +368,32 @@ __global__ __launch_bounds__(64 * T8_WAVES, 2) void k_tf8_pass(T8Args a) {
       // rows u e1[S1] replace e1 in the wave's LDS image (every lane rewrites its own column), the columns are e2
       const float2 u = make_float2(gs.x * dinv.x + gs.y * dinv.y, gs.x * dinv.y - gs.y * dinv.x);    // conj(gs) / Q
       const int rc = lane & 15, kq = lane >> 4, part = kq & 1;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (pass == 0) {
-#pragma unroll
-          for (int S1 = 0; S1 < 16; ++S1) E1[S1 * T8_P + lane] = cmul(E1[S1 * T8_P + lane], u);
-        } else {
-          // (u e1 -> -u T' e1: multiply the stored rows by -T')
-          const float2 mt = make_float2(-t.x, -t.y);
-#pragma unroll
-          for (int S1 = 0; S1 < 16; ++S1) E1[S1 * T8_P + lane] = live ? cmul(E1[S1 * T8_P + lane], mt) : make_float2(0.f, 0.f);
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        f32x4 acc = pass ? accQ : accP;
+      for (int S1 = 0; S1 < 16; ++S1) E1[S1 * T8_P + lane] = cmul(E1[S1 * T8_P + lane], u);           // rows u e1[S1]
+      TT[lane] = live ? make_float2(-t.x, -t.y) : make_float2(0.f, 0.f);                               // -T' of the bin
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // one loop for both record sets, two accumulators each (even / odd steps): four independent MFMA chains; the
+      // rows of dL/dQ are the rows of dL/dP times -T' of the bin
+      f32x4 p0 = accP, p1 = (f32x4){0.f, 0.f, 0.f, 0.f}, q0 = accQ, q1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int t2 = 0; t2 < 32; ++t2) {
-          const int bin = 2 * t2 + (kq >> 1);
-          const float2 a2 = E1[rc * T8_P + bin], b2 = E2[rc * T8_P + bin];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -a2.y : a2.x, part ? b2.y : b2.x, acc, 0, 0, 0);
-        }
-        if (pass) accQ = acc; else accP = acc;
+      for (int t2 = 0; t2 < 32; t2 += 2) {
+        const int bin0 = 2 * t2 + (kq >> 1), bin1 = bin0 + 2;
+        const float2 a0 = E1[rc * T8_P + bin0], b0 = E2[rc * T8_P + bin0], m0 = TT[bin0];
+        const float2 a1 = E1[rc * T8_P + bin1], b1 = E2[rc * T8_P + bin1], m1 = TT[bin1];
+        const float2 c0 = cmul(a0, m0), c1 = cmul(a1, m1);
+        const float bb0 = part ? b0.y : b0.x, bb1 = part ? b1.y : b1.x;
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -a0.y : a0.x, bb0, p0, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -c0.y : c0.x, bb0, q0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -a1.y : a1.x, bb1, p1, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(part ? -c1.y : c1.x, bb1, q1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        accP[r] = p0[r] + p1[r];
+        accQ[r] = q0[r] + q1[r];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -422,7 +461,7 @@ static int t8_launch(const T8Args& a, hipStream_t s) {
 // energy partials of the (unscaled) responses sum_i c_i y_i: part[blk * gfdn_tf8_parts(K) + p]; finish with
 // gfdn_tf_energy(..., phase = 2) semantics through gfdn_tf8_energy_finish below
 extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
-                               float* b, float* c, float* energy, float* scale, void* work, void* stream);
+                               float* b, float* c, float* energy, float* scale, void* work, double dturn, void* stream);
 
 // finish of the energy pass: E, scale = E^(-1/2), in-place rescale of b, c (trainer.py:317-332)
 __global__ __launch_bounds__(256) void k_tf8_energy_finish(const float* __restrict__ partial, int nparts, int K, int nper,
@@ -448,12 +487,12 @@ __global__ __launch_bounds__(256) void k_tf8_energy_finish(const float* __restri
 }
 
 extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
-                               float* b, float* c, float* energy, float* scale, void* work, void* stream) {
+                               float* b, float* c, float* energy, float* scale, void* work, double dturn, void* stream) {
   int rc = t8_ok(turns, K, nblk, nper, coef, delays, c);
   if (rc) return rc;
   if (!work || !b) return GFDN_E_BADARG;
   T8Args a{};
-  a.turns = turns; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = nullptr;
+  a.turns = turns; a.dturn = dturn; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = nullptr;
   a.part = (float*)work;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = t8_launch<T8_ENERGY>(a, s))) return rc;
@@ -482,12 +521,12 @@ extern "C" size_t gfdn_tf8_part_bytes(int nblk, int K) {
 
 extern "C" int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
                                   const float* c, const float* scale, int asym, float gscale, float* part, float* lossp,
-                                  float* loss, void* stream) {
+                                  float* loss, double dturn, void* stream) {
   int rc = t8_ok(turns, K, nblk, nper, coef, delays, c);
   if (rc) return rc;
   if (!part || !lossp || !loss) return GFDN_E_BADARG;
   T8Args a{};
-  a.turns = turns; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
+  a.turns = turns; a.dturn = dturn; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
   a.asym = asym; a.gscale = gscale; a.part = part; a.lossp = lossp;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = t8_launch<T8_COLORLESS>(a, s))) return rc;
@@ -589,12 +628,14 @@ __global__ __launch_bounds__(256) void k_tf8_rec_grads(const float* __restrict__
                                                        const float* __restrict__ b, const float* __restrict__ c, int n,
                                                        float* __restrict__ out0, float* __restrict__ out1) {
   __shared__ double sA[64], sb[8], sc[8], sig[8], sred[4][T8_ACC];
-  const int blk = blockIdx.x, set = blockIdx.y, S = threadIdx.x, lane = S & 63, wv = S >> 6;
+  // blockIdx.z = 0: the masked 8 x 8 matrices (dL/dQ_S -> dL/dA), 1: the bordered 9 x 9 ones (dL/dP_S -> dL/dA, dL/db,
+  // dL/dc); the two halves land in out[.. + 0] and out[.. + nblk * 2 * 80] and are added by k_tf8_param_grads
+  const int blk = blockIdx.x, set = blockIdx.y, half = blockIdx.z, S = threadIdx.x, lane = S & 63, wv = S >> 6;
   const float* A = (set ? A1 : A0) + (size_t)blk * n * n;
   const float* ig = set ? ig1 : ig0;
   const float* part = set ? part1 : part0;
   const int np = set ? np1 : np0;
-  float* out = (set ? out1 : out0) + (size_t)blk * T8_ACC;
+  float* out = (set ? out1 : out0) + (size_t)blk * T8_ACC + (size_t)half * gridDim.x * 2 * T8_ACC;
   if (S < 64) {
     const int i = S >> 3, j = S & 7;
     sA[S] = (i < n && j < n) ? -(double)A[i * n + j] : 0.0;
@@ -623,9 +664,9 @@ __global__ __launch_bounds__(256) void k_tf8_rec_grads(const float* __restrict__
   for (int i = 0; i < 8; ++i)
     if ((S >> i) & 1) igp *= sig[i];
   const double wq = (absent || full) ? 0.0 : -gQ * igp, wp = (absent || full) ? 0.0 : gP * igp;
-  // (each matrix's contributions are summed over the wave as soon as its cofactors exist: the 8 x 8 inverse, 128
-  // registers, is dead before the 9 x 9 one, 162 registers, is built)
-  {
+  if (S < T8_ACC) { sred[0][S] = 0.0; sred[1][S] = 0.0; sred[2][S] = 0.0; sred[3][S] = 0.0; }
+  __syncthreads();
+  if (half == 0) {
     double m[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
@@ -643,8 +684,7 @@ __global__ __launch_bounds__(256) void k_tf8_rec_grads(const float* __restrict__
         const double v = t8_wave_sum_d(in ? wd * m[j][i] : 0.0);        // Cof = det inverse^T
         if (lane == 0) sred[wv][i * 8 + j] = v;
       }
-  }
-  {
+  } else {
     double m[9][9];
 #pragma unroll
     for (int r = 0; r < 9; ++r)
@@ -666,7 +706,7 @@ __global__ __launch_bounds__(256) void k_tf8_rec_grads(const float* __restrict__
       for (int j = 0; j < 8; ++j) {
         const bool in = iin && !((S >> j) & 1) && j < n;
         const double v = t8_wave_sum_d(in ? wd * m[j][i] : 0.0);
-        if (lane == 0) sred[wv][i * 8 + j] += v;
+        if (lane == 0) sred[wv][i * 8 + j] = v;
       }
       const double vb = t8_wave_sum_d(iin ? -wd * m[8][i] : 0.0);      // Cof(B)_{i,8} = det inverse[8][i]
       const double vc = t8_wave_sum_d(iin ? -wd * m[i][8] : 0.0);      // Cof(B)_{8,i} = det inverse[i][8]
@@ -686,7 +726,8 @@ __global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict
                                                          const float* __restrict__ scale, int n,
                                                          const float* __restrict__ M, const float* __restrict__ gQ,
                                                          const float* __restrict__ Q, float* __restrict__ gb,
-                                                         float* __restrict__ gc, float* __restrict__ gM) {
+                                                         float* __restrict__ gc, float* __restrict__ gM, int half2) {
+  // half2 > 0: every row has a second half at + half2 floats (the 9 x 9 contributions of k_tf8_rec_grads), added here
   extern __shared__ double t8p_lds[];
   __shared__ float srec[2][T8_ACC], sG[2][64];
   const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
@@ -697,7 +738,7 @@ __global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict
     float s = 0.f;
     if (p) {
       const float* row = p + ((size_t)blk * T8_ACC + e) * np;
-      for (int i = lane; i < np; i += 64) s += row[i];
+      for (int i = lane; i < np; i += 64) s += row[i] + (half2 > 0 ? row[i + half2] : 0.f);
     }
     s = wave_sum(s);
     if (lane == 0) srec[set][e] = s;
@@ -720,7 +761,7 @@ __global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict
                   gM + off);
 }
 
-extern "C" size_t gfdn_tf8_param_grads_work_bytes(int nblk) { return (size_t)2 * (nblk > 0 ? nblk : 1) * T8_ACC * sizeof(float); }
+extern "C" size_t gfdn_tf8_param_grads_work_bytes(int nblk) { return (size_t)4 * (nblk > 0 ? nblk : 1) * T8_ACC * sizeof(float); }
 
 extern "C" int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* part0, int nparts0,
                                     const float* A1, const float* inv_gamma1, const float* part1, int nparts1,
@@ -733,14 +774,14 @@ extern "C" int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, co
   hipStream_t s = (hipStream_t)stream;
   float* out0 = (float*)work;
   float* out1 = out0 + (size_t)nblk * T8_ACC;
-  hipLaunchKernelGGL(k_tf8_rec_grads, dim3(nblk, A1 ? 2 : 1), dim3(256), 0, s, A0, inv_gamma0, part0, nparts0, A1, inv_gamma1,
-                     part1, nparts1, b, c, nper, out0, out1);
+  hipLaunchKernelGGL(k_tf8_rec_grads, dim3(nblk, A1 ? 2 : 1, 2), dim3(256), 0, s, A0, inv_gamma0, part0, nparts0, A1,
+                     inv_gamma1, part1, nparts1, b, c, nper, out0, out1);
   GFDN_LAUNCH_CHECK();
   const size_t lds = ortho_bwd_lds_doubles(nper) * sizeof(double);
   int rc = ensure_dyn_lds(k_tf8_param_grads, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_tf8_param_grads, dim3(nblk), dim3(256), lds, s, (const float*)out0, 1, A1 ? (const float*)out1 : nullptr,
-                     1, (const float*)nullptr, nper, M, gQ, Q, gb, gc, gM);
+                     1, (const float*)nullptr, nper, M, gQ, Q, gb, gc, gM, nblk * 2 * T8_ACC);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

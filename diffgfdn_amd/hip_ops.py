@@ -777,7 +777,7 @@ def tf8_parts(K: int) -> int:
     return _lib.load().gfdn_tf8_parts(int(K))
 
 
-def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False):
+def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False, dturn: float = 0.0):
     """normalize (trainer.py:317-332) on the records ``coef`` of the raw sub-FDN blocks: E = mean_k |sum_i c_i y_i|^2,
     -> (energy or None, scale = E^(-1/2)); b, c (float32, contiguous) are divided by E^(1/4) IN PLACE."""
     _need_gpu(turns, coef, delays, b, c)
@@ -791,7 +791,7 @@ def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False):
     scale = torch.empty(nblk, dtype=_f32, device=coef.device)
     work = torch.empty(nblk * lib.gfdn_tf8_parts(K), dtype=_f32, device=coef.device)
     _lib.check(lib.gfdn_tf8_energy(_p(turns), K, nblk, nper, _p(coef), _p(delays), _p(b), _p(c), _p(energy), _p(scale),
-                                   _p(work), _stream()), "gfdn_tf8_energy")
+                                   _p(work), float(dturn), _stream()), "gfdn_tf8_energy")
     return energy, scale
 
 
@@ -810,7 +810,7 @@ def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, qua
     return Ts, Tq
 
 
-def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: float):
+def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: float, dturn: float = 0.0):
     """Colorless pass on the records of the raw sub-FDN blocks -> (part (nblk, 512, parts) gradient records, loss (nblk,))."""
     _need_gpu(turns, coef, delays, c)
     coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
@@ -821,7 +821,7 @@ def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: 
     lossp = torch.empty((nblk, parts), dtype=_f32, device=coef.device)
     loss = torch.empty(nblk, dtype=_f32, device=coef.device)
     _lib.check(lib.gfdn_tf8_colorless(_p(turns), K, nblk, nper, _p(coef), _p(delays), _p(c), _p(None if scale is None else _f(scale)),
-                                      int(asym), float(gscale), _p(part), _p(lossp), _p(loss), _stream()),
+                                      int(asym), float(gscale), _p(part), _p(lossp), _p(loss), float(dturn), _stream()),
                "gfdn_tf8_colorless")
     return part, loss
 

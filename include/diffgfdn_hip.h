@@ -368,7 +368,9 @@ int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave_c64, c
  * S2: 4..7).  coef (nblk, 9, 256) float32: the determinant polynomial Q and the numerators Y_i of y_i = (X^-1 b)_i
  * (P = sum_i c_i Y_i is formed from the CURRENT output gains when a pass starts).  Unit-circle grids only (turns).
  * Scaling convention: coefficients are built from the gains BEFORE normalize's rescale; the passes take the CURRENT c
- * and scale (NULL before the rescale) and work on the records of the current gains.
+ * and scale (NULL before the rescale) and work on the records of the current gains.  dturn != 0 (energy, colorless):
+ * the grid is uniform on the unit circle with that step in turns -- the phasors are then stepped by constant rotations
+ * between exact evaluations, as the gfdn_tf_* passes do.
  *   gfdn_tf8_coefs      : records of (A0, 1/gamma0) -> coef0 and optionally (A1, 1/gamma1) -> coef1, sharing b.
  *   gfdn_tf8_energy     : E_blk = mean_k |T|^2 -> energy, scale = E^(-1/2), b, c /= E^(1/4) in place; work: nblk *
  *                         gfdn_tf8_parts(K) floats.
@@ -386,12 +388,12 @@ int gfdn_tf8_coefs(const float* A0, const float* inv_gamma0, float* coef0, const
 int gfdn_tf8_parts(int K);
 size_t gfdn_tf8_part_bytes(int nblk, int K);
 int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays, float* b,
-                    float* c, float* energy, float* scale, void* work, void* stream);
+                    float* c, float* energy, float* scale, void* work, double dturn, void* stream);
 int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
                    const float* c, const float* scale, float* Tsave_c64, float* Tquad_c64, void* stream);
 int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
                        const float* c, const float* scale, int asym, float gscale, float* part, float* lossp,
-                       float* loss, void* stream);
+                       float* loss, double dturn, void* stream);
 int gfdn_tf8_compose_bwd(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
                          const float* c, const float* scale, const float* rgain, int B, const float* filt_c64, int ldf,
                          const float* gH_c64, int ldh, float* part, void* stream);

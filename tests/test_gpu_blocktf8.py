@@ -49,6 +49,10 @@ def test_records_transfer_functions_and_normalize(n, nblk, orth, K):
     E = (ref.abs() ** 2).mean(0)
     assert rel_err(energy.cpu().numpy(), E.numpy()) < 5e-5
     assert rel_err(scale.cpu().numpy(), (E ** -0.5).numpy()) < 5e-5
+    # uniform grid: phasors stepped by constant rotations between exact evaluations
+    b2, c2 = b.float().to(DEV).contiguous(), c.float().to(DEV).contiguous()
+    e2, _ = ops.tf8_energy(turns, coef, delays.to(DEV), n, b2, c2, want_energy=True, dturn=0.5 / (K - 1))
+    assert rel_err(e2.cpu().numpy(), E.numpy()) < 5e-5
     d = (E ** 0.25).repeat_interleave(n)
     assert rel_err(cc.cpu().numpy(), (c / d).numpy()) < 1e-5 and rel_err(bb.cpu().numpy(), (b / d).numpy()) < 1e-5
     Ts2, _ = ops.tf8_tsave(turns, coef, delays.to(DEV), n, cc, scale, nb, G, quad=False)
@@ -61,11 +65,12 @@ def _ortho(M):
     return Q, Q @ Q
 
 
+@pytest.mark.parametrize("runs", [False, True])
 @pytest.mark.parametrize("n,nblk,asym", [(8, 8, True), (6, 3, False)])
-def test_colorless_pass_and_gradients(n, nblk, asym):
+def test_colorless_pass_and_gradients(n, nblk, asym, runs):
     """loss_g and d(gscale sum_g loss_g)/d(M, b, c) of the raw sub-FDN blocks against float64 autograd."""
     from diffgfdn_amd import hip_ops as ops
-    K = 4097
+    K = 40001
     z = _grid(K)
     M, b, c, delays, _ = _blocks(nblk, n, 5)
     b, c = b * 6, c * 6
@@ -82,7 +87,8 @@ def test_colorless_pass_and_gradients(n, nblk, asym):
     (gscale * loss_g.sum()).backward()
     turns, _ = ops.zprep(z.to(DEV))
     coef, _ = ops.tf8_coefs(M.to(DEV), None, b.to(DEV), c.to(DEV))
-    part, loss = ops.tf8_colorless(turns, coef, delays.to(DEV), n, cp.detach().float().to(DEV), s.to(DEV), asym, gscale)
+    part, loss = ops.tf8_colorless(turns, coef, delays.to(DEV), n, cp.detach().float().to(DEV), s.to(DEV), asym, gscale,
+                                   dturn=0.5 / (K - 1) if runs else 0.0)
     assert rel_err(loss.cpu().numpy(), loss_g.detach().numpy()) < 5e-5
     # tail with an empty first set: dL/dM_raw reaches M directly
     zero = torch.zeros_like(part)

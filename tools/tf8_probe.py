@@ -3,6 +3,9 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffgfdn_amd import _lib
+if '--lib' in sys.argv:
+    _lib.LIB_PATH = sys.argv[sys.argv.index('--lib') + 1]
 from diffgfdn_amd import hip_ops as ops
 
 dev = 'cuda'
@@ -41,9 +44,9 @@ def timed(fn, it=20):
 
 bb, cc = b.clone(), c.clone()
 print(f"coefs (2 sets)        {timed(lambda: ops.tf8_coefs(QQ, ig, b, c, A1=M)):8.1f} us")
-print(f"energy   K = {K}  {timed(lambda: ops.tf8_energy(turns, coef_sub, delays, n, bb.copy_(b), cc.copy_(c))):8.1f} us")
+print(f"energy   K = {K}  {timed(lambda: ops.tf8_energy(turns, coef_sub, delays, n, bb.copy_(b), cc.copy_(c), dturn=0.5 / (K - 1))):8.1f} us")
 print(f"tsave    K = {Ku}  {timed(lambda: ops.tf8_tsave(turns_u, coef, delays, n, c, scale, nb, G)):8.1f} us")
-print(f"colorless K = {K} {timed(lambda: ops.tf8_colorless(turns, coef_sub, delays, n, c, scale, True, 1.0)):8.1f} us")
+print(f"colorless K = {K} {timed(lambda: ops.tf8_colorless(turns, coef_sub, delays, n, c, scale, True, 1.0, dturn=0.5 / (K - 1))):8.1f} us")
 print(f"bwd      K = {Ku}  {timed(lambda: ops.tf8_compose_bwd(turns_u, coef, delays, n, c, scale, rgain, gH, filt, nb)):8.1f} us")
 part = ops.tf8_compose_bwd(turns_u, coef, delays, n, c, scale, rgain, gH, filt, nb)
 part2, _ = ops.tf8_colorless(turns, coef_sub, delays, n, c, scale, True, 1.0)
