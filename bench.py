@@ -92,8 +92,18 @@ ALG_BYTES_PER_UNIT = {
 }
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
-PROFILE_TAG = 'r02'
+PROFILE_TAG = 'r03'
 REFERENCE_EPOCH_S_PER_BAND = 139.1   # reference trainer, N = 16, 8 vCPU, one band, one epoch
+
+
+def host_cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def collective_version():
@@ -304,7 +314,9 @@ def cpu_baseline(room, delays, filt_np, steps: int = 2, device=None):
                       'mlp': torch.cat(packed).double().numpy().copy()}
     sec = float(np.mean(times[1:]))
     out = {'value': BATCH * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
-           'sample': f'{steps} optimiser steps (normalize + fwd + EDR/EDC/colorless losses + bwd + Adam) of ONE band '
+           'host_cpu': host_cpu_model(), 'host_logical_cpus': os.cpu_count(),
+           'sample': f'host CPU {host_cpu_model()} ({os.cpu_count()} logical CPUs, {cores} threads used); '
+                     f'{steps} optimiser steps (normalize + fwd + EDR/EDC/colorless losses + bwd + Adam) of ONE band '
                      f'(500 Hz) of the same workload, batch {BATCH}, after 1 warm-up step; {sec:.2f} s/step.  The CPU '
                      'step recomputes the target EDR / EDC of its batch every step, as the reference does; the GPU '
                      'step reads them from stores precomputed once per dataset before the timed region '
@@ -350,29 +362,36 @@ def pmc_traffic_bytes(kernel: str):
 
 
 def roofline_top(units: int, n: int = 10):
-    """The longest kernels of the committed rocprofv3 stats with algorithmic bytes, measured traffic and fractions."""
-    path = _profile('bench_kernel_stats.csv')
+    """The kernels of the REPLAYED step by time per step (profiles/<tag>_step_kernel_durations.csv: durations inside 100
+    consecutive graph replays, nothing else) with algorithmic bytes, measured traffic and fractions; the whole-run
+    rocprofv3 average (which also covers host-launched, isolated and one-off launches) is kept beside each."""
+    path, whole = _profile('step_kernel_durations.csv'), _profile('bench_kernel_stats.csv')
     if path is None:
         return None
+    run_avg = {}
+    if whole is not None:
+        for r in csv.DictReader(open(whole)):
+            run_avg.setdefault(r['Name'].split('(')[0].replace('void ', '').split('<')[0], float(r['AverageNs']) / 1e3)
     out = []
     for r in csv.DictReader(open(path)):
-        name = r['Name'].split('(')[0].replace('void ', '').split('<')[0]
-        if not (name.startswith('k_') or name.startswith('void k_')):
+        name = r['kernel']
+        if not name.startswith('k_'):
             continue
-        avg_us = float(r['AverageNs']) / 1e3
-        e = {'kernel': name, 'calls': int(r['Calls']), 'avg_us': avg_us, 'pct_of_gpu_time': float(r['Percentage'])}
+        us = float(r['avg_us_in_step'])
+        e = {'kernel': name, 'launches_per_step': float(r['launches_per_step']), 'in_step_us': us,
+             'us_per_step': float(r['us_per_step']), 'whole_run_avg_us': run_avg.get(name)}
         per = ALG_BYTES_PER_UNIT.get(name)
         if per is not None:
             alg = per * units
-            e.update({'alg_bytes_per_launch': alg, 'achieved_GBs': alg / avg_us / 1e3,
-                      'frac': alg / avg_us / 1e3 / HBM_PEAK_GBS})
+            e.update({'alg_bytes_per_launch': alg, 'achieved_GBs': alg / us / 1e3, 'frac': alg / us / 1e3 / HBM_PEAK_GBS})
             tr = pmc_traffic_bytes(name)
             if tr:
                 e.update({'traffic': tr, 'traffic_over_alg': tr / alg})
         out.append(e)
         if len(out) == n:
             break
-    return {'source': f'profiles/{PROFILE_TAG}_bench_kernel_stats.csv + profiles/{PROFILE_TAG}_pmc_hbm_bytes.csv',
+    return {'source': f'profiles/{PROFILE_TAG}_step_kernel_durations.csv (in-step durations) + profiles/{PROFILE_TAG}_pmc_hbm_bytes.csv'
+                      f' + profiles/{PROFILE_TAG}_bench_kernel_stats.csv (whole-run averages)',
             'kernels': out}
 
 
@@ -514,7 +533,7 @@ def main():
     ap.add_argument('--per-step-copy', action='store_true',
                     help='hand every step its receivers by a host copy in front of the replay (diagnostic; default: the '
                          'batches go to the device as one schedule)')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--receivers', type=int, default=NUM_RECEIVERS)
     ap.add_argument('--classic', action='store_true',
                     help='with --bands 1: the per-band VarReceiverPosTrainer path instead of a one-band bank')

@@ -1,8 +1,8 @@
 """Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/<tag>_*).
-usage: python tools/make_profiles.py [round_tag]   (default r02)"""
+usage: python tools/make_profiles.py [round_tag]   (default r03)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src = os.path.join(ROOT, 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -39,6 +39,25 @@ tl = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'timeline.py'),
                     capture_output=True, text=True).stdout
 open(os.path.join(dst, f'{tag}_graph_step_timeline.txt'), 'w').write(
     "one HIP-graph replay of the training step (steady state): start us, end us, duration, HW queue, kernel\n" + tl)
+# 4b. per-kernel durations INSIDE the replayed steps only (the timed region of the bench): the kernel trace between the
+# Adam launches of 100 consecutive steady-state replays -- no host-launched roofline steps, no isolated launches, no
+# one-off dataset kernels
+trace = one(f'{tag}_stats/**/*kernel_trace.csv')
+trows = list(csv.DictReader(open(trace)))
+trows.sort(key=lambda r: int(r['Start_Timestamp']))
+adam = [i for i, r in enumerate(trows) if r['Kernel_Name'].startswith('k_adam(')]
+lo, hi = adam[60], adam[160]
+nsteps = 100
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in trows[lo + 1:hi + 1]:
+    k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
+    agg[k][0] += 1
+    agg[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+with open(os.path.join(dst, f'{tag}_step_kernel_durations.csv'), 'w') as f:
+    f.write('kernel,launches_per_step,avg_us_in_step,us_per_step\n')
+    for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        f.write(f"{k},{cnt / nsteps:.2f},{us / cnt:.2f},{us / nsteps:.2f}\n")
+step_span = (int(trows[hi]['End_Timestamp']) - int(trows[lo]['End_Timestamp'])) / 1e3 / nsteps
 # 5. README
 dom = bench.get('roofline', {})
 name = dom.get('kernel', '')
@@ -47,7 +66,7 @@ with open(os.path.join(dst, 'README.md'), 'w') as f:
     f.write(f"""# profiles/ -- round {tag[1:]}
 All `{tag}_*` files come from ONE `gpurun` call (`bash tools/run_measurements.sh {tag}`) on one MI355X (gfx950, ROCm 7.2);
 `bench.py` is the command the driver runs (N = 1, workload = the 7-band configuration BASELINE.json's metric is quoted
-on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` files are the previous round's, kept for comparison.
+on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` / `r02_*` files are the previous rounds', kept for comparison.
 
 | file | command | what it holds |
 |---|---|---|
@@ -55,12 +74,14 @@ on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` files are t
 | `{tag}_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` | per-kernel totals / averages (includes the one-off dataset front end, the 20 host-launched roofline steps and the 60 isolated launches of the roofline kernel) |
 | `{tag}_pmc_hbm_bytes.csv` | `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --eager`, and the same with `--pmc WRITE_SIZE` (separate passes) | average FETCH_SIZE / WRITE_SIZE per launch of every hand-written kernel, by grid size; read bytes corrected x2 for gfx950 as MI355X_MICROARCH.md prescribes |
 | `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
+| `{tag}_step_kernel_durations.csv` | from the kernel trace of the stats run | per kernel: launches per step, average duration and microseconds per step over 100 consecutive REPLAYED steps only (what `roofline.top` of the bench line is built from) |
 | `{tag}_directional_kernels.txt` | `bash tools/run_dir_profile.sh` (its own gpurun call) | kernel totals of the graph-replayed directional band-step (BASELINE.json configs[3]) |
 | `{tag}_n32_kernels.txt` | `bash tools/run_n32_profile.sh` (its own gpurun call) | kernel totals of the replayed 7-band step at N = 32 (configs[4]) |
 | `{tag}_mfma_experiment.json` | `python tools/mfma_experiment.py` (its own gpurun call) | configs[4]'s bf16 / f32 MFMA contraction against the solve path: time and deviation of H |
 
-`bench.py` reads `{tag}_pmc_hbm_bytes.csv` (`roofline.traffic`) and `{tag}_bench_kernel_stats.csv` (`roofline.top`) at run
-time, so every fraction in the bench line can be recomputed from this directory.
+`bench.py` reads `{tag}_pmc_hbm_bytes.csv` (`roofline.traffic`), `{tag}_step_kernel_durations.csv` (`roofline.top`: in-step
+durations) and `{tag}_bench_kernel_stats.csv` (whole-run averages beside them) at run time, so every fraction in the bench
+line can be recomputed from this directory.  Replayed step period in the stats run: {step_span:.1f} us.
 
 ## bench line
 `{bench['value']:.0f} {bench['unit']}` = {bench['ms_per_step']:.4f} ms/step on 1 GPU;

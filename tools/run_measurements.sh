@@ -1,11 +1,11 @@
-# One gpurun call that produces everything profiles/ holds for a round:  bash tools/run_measurements.sh [tag]
+# One gpurun call that produces everything profiles/ holds for a round:  bash tools/run_measurements.sh [tag] [notests]
 # (steps are chained with &&: nothing runs on the GPU after a failed or timed-out step)
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
-timeout 600 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 && \
+if [ "$2" != "notests" ]; then timeout 1000 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 || exit 1; fi
 timeout 400 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err && tail -c 1500 $OUT/${TAG}_bench_n1.json && \
 cd /tmp && export TMPDIR=/tmp && \
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1 && \
