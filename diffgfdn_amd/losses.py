@@ -438,8 +438,12 @@ class directional_edc_loss(nn.Module):
         self.register_buffer('envelopes', torch.as_tensor(envelopes, dtype=torch.float32),
                              persistent=False)
 
-    def forward(self, H_pred: torch.Tensor, amps_true: torch.Tensor) -> torch.Tensor:
-        """H_pred (B, J, K) complex, amps_true (B, J, S)."""
+    def forward(self, H_pred: torch.Tensor, amps_true: torch.Tensor, weight: float = 1.0,
+                unit_grad: bool = False) -> torch.Tensor:
+        """H_pred (B, J, K) complex, amps_true (B, J, S) -> ``weight`` x the loss (reference: weight 1).
+        ``unit_grad``: the caller guarantees that the returned value enters the total with factor 1 -- the weight then
+        rides the EDC kernel's gradient scale and the backward hands the saved dL/dH on as it is (no pass over the
+        (B J, K) gradient to multiply it by the upstream scalar: 2 x 201 MB at 32 receivers x 12 directions)."""
         B, J, K = H_pred.shape
         n = 2 * (K - 1)
         # python slicing in the reference (:344-346) silently truncates at the end of the IR
@@ -461,9 +465,10 @@ class directional_edc_loss(nn.Module):
         # (the einsum 'bjk,kt->bjt' of the amplitudes with the envelopes, |.| + eps, dB and the clip at -200 happen
         # inside the EDC scan: the (B J, L) target and the six passes over it that built it never exist)
         amps = amps_true.to(device=x.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
-        li, gx = ops.edc_loss_model(x, start, L, amps, self.envelopes, maskw, 1.0 / (B * J * count), 1.0, want_grad)
-        val = li.sum()
+        li, gx = ops.edc_loss_model(x, start, L, amps, self.envelopes, maskw, 1.0 / (B * J * count), float(weight),
+                                    want_grad)
+        val = li.sum() if weight == 1.0 else li.sum() * float(weight)
         if not want_grad:
             return val
         gH = ops.irfft_pow2_bwd(gx, n).reshape(B, J, K)
-        return _ScalarLossWithSavedGrad.apply(H_pred, val, gH)
+        return _ScalarLossWithSavedGrad.apply(H_pred, val, gH, unit_grad)

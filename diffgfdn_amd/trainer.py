@@ -568,7 +568,9 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         out = net(data, subband_filter=filt)
         H_sh, H_sub = out if net.use_colorless_loss else (out, None)
         H_dir = self.convert_ambi_rir_to_directional_rir(H_sh)
-        edc = cfg.edc_loss_weight * self.criterion[0](H_dir, data['target_common_slope_amps'])
+        # (the weight rides the kernel's gradient scale and the term enters the total with factor 1: the backward skips
+        # the pass that would multiply the (B J, K) gradient by the upstream scalar)
+        edc = self.criterion[0](H_dir, data['target_common_slope_amps'], weight=cfg.edc_loss_weight, unit_grad=True)
         losses = {'edc_loss': edc.detach()}
         total = edc
         if self.use_colorless_loss:

@@ -1,0 +1,52 @@
+"""Which torch operators does one directional band-step launch beside the hand-written kernels?  (diagnostic, GPU)
+usage: python tools/dir_ops_probe.py"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv = sys.argv[:1]
+import bench
+from torch.profiler import profile, ProfilerActivity
+
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+
+
+class A:
+    receivers, bands, warmup, steps = 64, 1, 2, 2
+
+
+# build exactly as bench.run_directional does, one band, without timing
+from diffgfdn_amd.config import CouplingMatrixType, DiffGFDNConfig, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
+from diffgfdn_amd.model import DiffDirectionalFDNVarReceiverPos
+from diffgfdn_amd.trainer import DirectionalFDNVarReceiverPosTrainer
+Gd, order, J, R = 3, 2, 12, 64
+L = (order + 1) ** 2
+rng = np.random.RandomState(7)
+K, FS, BATCH = bench.K, bench.FS, bench.BATCH
+z = torch.exp(1j * np.pi * torch.arange(K, dtype=torch.float64) / (K - 1)).to(dev)
+torch.manual_seed(500)
+delays = DiffGFDNConfig(num_groups=Gd, num_delay_lines=Gd * L, sample_rate=FS, seed=23463).delay_length_samps
+fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+of = OutputFilterConfig(use_svfs=False, num_hidden_layers=5, num_neurons_per_layer=16, num_fourier_features=20)
+net = DiffDirectionalFDNVarReceiverPos(FS, Gd, delays, dev, fl, of, ambi_order=order,
+                                       common_decay_times=np.linspace(0.5, 1.4, Gd)[None, :], use_colorless_loss=True,
+                                       analysis_matrix=rng.randn(J, L).astype(np.float32)).to(dev)
+tc = TrainerConfig(use_colorless_loss=True, use_asym_spectral_loss=True, edc_loss_weight=10.0, sparsity_loss_weight=2.0,
+                   use_edc_mask=False, lr=1e-3, io_lr=1e-2, device='cuda', train_dir='/tmp/gfdn_bench/dir_t',
+                   ir_dir='/tmp/gfdn_bench/dir_a')
+tr = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
+batch = {'z_values': z, 'source_position': torch.zeros(BATCH, 3, device=dev, dtype=torch.float64),
+         'listener_position': torch.tensor(rng.uniform(0, 10, (BATCH, 3)), device=dev),
+         'norm_listener_position': torch.tensor(rng.uniform(0, 1, (BATCH, 3)), device=dev),
+         'target_common_slope_amps': torch.tensor(rng.uniform(0.1, 1.0, (BATCH, J, Gd)), device=dev)}
+for _ in range(3):
+    tr.train_step(batch)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    tr.train_step(batch)
+    torch.cuda.synchronize()
+rows = [e for e in prof.key_averages(group_by_stack_n=4) if e.key.startswith('aten::') and e.device_time_total > 0]
+rows.sort(key=lambda e: -e.device_time_total)
+for e in rows[:45]:
+    where = ' <- '.join(s.split('/')[-1] for s in e.stack[:3] if 'diffgfdn_amd' in s or 'torch/optim' in s or 'autograd' in s)
+    print(f"{e.key:34s} n={e.count:3d} dev={e.device_time_total:8.1f} us  {where[:120]}")
