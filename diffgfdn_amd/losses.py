@@ -472,3 +472,36 @@ class directional_edc_loss(nn.Module):
             return val
         gH = ops.irfft_pow2_bwd(gx, n).reshape(B, J, K)
         return _ScalarLossWithSavedGrad.apply(H_pred, val, gH, unit_grad)
+
+    def forward_sh(self, H_sh: torch.Tensor, analysis_matrix: torch.Tensor, amps_true: torch.Tensor,
+                   weight: float = 1.0, unit_grad: bool = False) -> torch.Tensor:
+        """``forward(einsum('jl,blk->bjk', A, H_sh), amps_true)`` (reference trainer.py:853-865 followed by
+        losses.py:333-371) with the two linear maps in the other order: the inverse transform runs on the C
+        SH-domain responses of a receiver and the analysis matrix mixes the TIME signals into the J directions (A is
+        real: irfft(A H) = A irfft(H)) -- C instead of J transforms per receiver each way (9 instead of 12 at order 2),
+        and the (B, J, K) directional spectra and their gradient never exist.  H_sh (B, C, K) complex, A (J, C)."""
+        B, C, K = H_sh.shape
+        J = analysis_matrix.shape[0]
+        n = 2 * (K - 1)
+        start = self.mixing_time_samps
+        L = min(self.edc_len_samps, n - start)
+        if L <= 0:
+            raise ValueError("EDC window starts beyond the impulse-response length")
+        if self.use_mask:
+            raise NotImplementedError("forward_sh: the randomly masked variant goes through forward()")
+        want_grad = H_sh.requires_grad and torch.is_grad_enabled()
+        x_sh = ops.irfft_pow2_fwd(H_sh.reshape(B * C, K), n)                       # (B C, n)
+        if self.envelopes.device != x_sh.device:
+            self.envelopes = self.envelopes.to(x_sh.device)
+        # pairs of real samples as complex numbers: the streaming mix kernel of the spectra serves the signals too
+        x_dir = ops.sh_to_directional(analysis_matrix, torch.view_as_complex(x_sh.view(B, C, n // 2, 2)), False)
+        x_dir = torch.view_as_real(x_dir).view(B * J, n)
+        amps = amps_true.to(device=x_sh.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
+        li, gx = ops.edc_loss_model(x_dir, start, L, amps, self.envelopes, None, 1.0 / (B * J * float(L)), float(weight),
+                                    want_grad)
+        val = li.sum() if weight == 1.0 else li.sum() * float(weight)
+        if not want_grad:
+            return val
+        gx_sh = ops.sh_to_directional(analysis_matrix, torch.view_as_complex(gx.view(B, J, n // 2, 2)), True)
+        gH = ops.irfft_pow2_bwd(torch.view_as_real(gx_sh).view(B * C, n), n).reshape(B, C, K)
+        return _ScalarLossWithSavedGrad.apply(H_sh, val, gH, unit_grad)

@@ -540,6 +540,9 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
     common-slope amplitudes, plus the colorless terms."""
 
     concurrent_branches = False
+    # directional EDC term on irfft(H_sh) mixed in the time domain (losses.directional_edc_loss.forward_sh) instead of
+    # irfft(A H_sh): same numbers to rounding, 3/4 of the transforms at order 2
+    mix_in_time = True
 
     def graphed(self, example_batch: Dict) -> "GraphedModuleStep":
         """train_step on batches shaped like ``example_batch`` as one HIP-graph replay."""
@@ -567,10 +570,16 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
         out = net(data, subband_filter=filt)
         H_sh, H_sub = out if net.use_colorless_loss else (out, None)
-        H_dir = self.convert_ambi_rir_to_directional_rir(H_sh)
         # (the weight rides the kernel's gradient scale and the term enters the total with factor 1: the backward skips
-        # the pass that would multiply the (B J, K) gradient by the upstream scalar)
-        edc = self.criterion[0](H_dir, data['target_common_slope_amps'], weight=cfg.edc_loss_weight, unit_grad=True)
+        # the pass that would multiply the gradient by the upstream scalar)
+        crit = self.criterion[0]
+        if self.mix_in_time and not crit.use_mask:
+            # SH -> directional conversion behind the inverse transform (linear maps commute): C transforms per receiver
+            edc = crit.forward_sh(H_sh, net.sh_output_scalars.analysis_matrix, data['target_common_slope_amps'],
+                                  weight=cfg.edc_loss_weight, unit_grad=True)
+        else:
+            H_dir = self.convert_ambi_rir_to_directional_rir(H_sh)
+            edc = crit(H_dir, data['target_common_slope_amps'], weight=cfg.edc_loss_weight, unit_grad=True)
         losses = {'edc_loss': edc.detach()}
         total = edc
         if self.use_colorless_loss:

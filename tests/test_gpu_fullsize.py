@@ -391,3 +391,16 @@ def test_directional_full_size_forward_backward_vs_oracle():
         ref = prm[name].grad.numpy()
         err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
         assert err < GRAD_TOL, (name, err)
+
+    # ---- the trainer's route: inverse transform of the SH-domain responses, analysis matrix applied to the time signals
+    # (directional_edc_loss.forward_sh): same loss, same gradients
+    net.zero_grad(set_to_none=True)
+    loss2 = crit.forward_sh(net(batch), Adev, amps.to(DEV))
+    loss2.backward()
+    assert abs(loss2.item() - loss_o.item()) < LOSS_TOL * abs(loss_o.item())
+    for name, p_ in net.named_parameters():
+        if name not in prm or prm[name].grad is None:
+            continue
+        ref = prm[name].grad.numpy()
+        err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < GRAD_TOL, ('forward_sh', name, err)
