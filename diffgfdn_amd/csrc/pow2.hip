@@ -16,6 +16,7 @@
 //            pass B: tile of rows k1 that holds the mirror rows L1 - k1 as well (F[k] needs Zf[m-k]), FFT over n2,
 //                    F[k1 + L1 k2] for k <= m
 #include "common.h"
+#include "fft4k_dev.h"
 
 extern __shared__ float2 dyn_lds[];
 
@@ -219,6 +220,182 @@ __global__ __launch_bounds__(256) void k_p2_adj_b(P2Geom g, const float2* __rest
     }
   }
 }
+// ------------------------------------------------------------------------------------------
+// n = 131 072 (m = 65 536 = 256 x 256): the same four passes with the 256-point transforms held in registers.
+// Sixteen threads share one transform: thread r holds x[r + 16 j], j = 0..15 -> 16-point butterfly over j, twiddle
+// W_256^(r p), ONE exchange through LDS (thread p collects index p of the sixteen threads), 16-point butterfly over r
+// -> X[p + 16 s].  A workgroup of 256 threads carries 16 transforms.  In the passes that walk columns of the (256, 256)
+// block (inverse A, forward A) the 16 adjacent columns are the fast thread index: every global access is a 128-byte
+// segment per half-wave straight from / to registers; in the passes that walk rows (inverse B, forward B) the position
+// in the row is the fast index (128-byte segments again), the exchange stays inside a wave (no block barrier) and the
+// results reach their transposed places through one LDS tile.  The generic Stockham passes above (radix 4, eight barriers
+// per pass, 8-column tiles = 64-byte segments) took 154-208 us per pass of 384 transforms; see DESIGN §4.
+// ------------------------------------------------------------------------------------------
+#define PW_CP 292      // LDS slots per column of the column passes (16 x 17 + 20: a wave's 64 accesses fall 2 per bank pair)
+#define PW_RP 272      // ... per row of the row passes (16 x 17)
+#define PW_TP 18       // pitch of the (256, 16) transposed tile of inverse pass B
+#define PW_OP 257      // pitch of the (16, 256) tile of forward pass B
+#define PW_LDS 4672    // float2 slots: max(16 * PW_CP, 16 * PW_RP, 256 * PW_TP, 16 * PW_OP)
+
+// (cos, sin)(2 pi j / 32), j = 0..15
+__constant__ float2 c_pw32[16] = {
+    {1.0f, 0.0f}, {0.98078528040323043f, 0.19509032201612825f}, {0.92387953251128674f, 0.38268343236508977f},
+    {0.83146961230254524f, 0.55557023301960218f}, {0.70710678118654752f, 0.70710678118654752f},
+    {0.55557023301960218f, 0.83146961230254524f}, {0.38268343236508977f, 0.92387953251128674f},
+    {0.19509032201612825f, 0.98078528040323043f}, {0.0f, 1.0f}, {-0.19509032201612825f, 0.98078528040323043f},
+    {-0.38268343236508977f, 0.92387953251128674f}, {-0.55557023301960218f, 0.83146961230254524f},
+    {-0.70710678118654752f, 0.70710678118654752f}, {-0.83146961230254524f, 0.55557023301960218f},
+    {-0.92387953251128674f, 0.38268343236508977f}, {-0.98078528040323043f, 0.19509032201612825f}};
+
+// in: a[j] = x[r + 16 j]; out: a[s] = X[r + 16 s], X[q] = sum x[k] e^(-sgn 2 pi i k q / 256).  `seq`: the transform's 16 x 17
+// LDS slots.  BLOCK: the sixteen threads sit in different waves (block barrier) or in one (LDS operations of a wave
+// execute in order: none).
+template <bool BLOCK>
+__device__ __forceinline__ void pw_fft256(float2 (&a)[16], float2* seq, int r, float sgn) {
+  bfly16(a, sgn);
+  {
+    float sn, cs;
+    sincospif(2.0f * (float)r / 256.0f, &sn, &cs);
+    twiddle16(a, make_float2(cs, -sgn * sn));
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) seq[17 * r + p] = a[p];
+  if (BLOCK) __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q] = seq[17 * q + r];
+  bfly16(a, sgn);
+}
+// a[s] *= t0 step^s
+__device__ __forceinline__ void pw_twiddle(float2 (&a)[16], float2 t0, float2 step) {
+  twiddle16(a, step);
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) a[s_] = cmul(a[s_], t0);
+}
+__device__ __forceinline__ float2 pw_cis(float turns) {        // e^(2 pi i turns)
+  float sn, cs;
+  sincospif(2.0f * turns, &sn, &cs);
+  return make_float2(cs, sn);
+}
+
+// inverse pass A: columns k1 = c0 + cc, Z formed on load, inverse transform over k2, twiddle e^(+2 pi i n2 k1 / m), work[n2][k1]
+__global__ __launch_bounds__(256) void k_pw_inv_a(const float2* __restrict__ X, int ldx, float2* __restrict__ work) {
+  constexpr int m = 65536, n = 131072;
+  float2* buf = dyn_lds;
+  const int b = blockIdx.y, c0 = blockIdx.x * 16;
+  const int cc = threadIdx.x & 15, r = threadIdx.x >> 4, k1 = c0 + cc;
+  const float2* Xb = X + (size_t)b * ldx;
+  const float2 e0 = pw_cis((float)(k1 + 256 * r) / (float)n);          // e^(+2 pi i k / n) at j = 0
+  float2 a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k1 + 256 * (r + 16 * j);
+    float2 x = Xb[k], bc = Xb[m - k];
+    bc.y = -bc.y;
+    if (k == 0) { x.y = 0.f; bc.y = 0.f; }                // irfft ignores Im X[0], Im X[n/2]
+    const float2 e = cadd(x, bc);
+    const float2 o = cmul(csub(x, bc), cmul(e0, c_pw32[j]));
+    a[j] = make_float2(e.x - o.y, e.y + o.x);
+  }
+  pw_fft256<true>(a, buf + cc * PW_CP, r, -1.0f);
+  pw_twiddle(a, pw_cis((float)(r * k1) / (float)m), pw_cis((float)k1 / 4096.0f));
+  float2* wk = work + (size_t)b * m + k1;
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) wk[(size_t)(r + 16 * s_) * 256] = a[s_];
+}
+// inverse pass B: rows n2 = r0 + rr, inverse transform over k1, (x[2j], x[2j+1]) = z[j] / n with j = n1 256 + n2
+__global__ __launch_bounds__(256) void k_pw_inv_b(const float2* __restrict__ work, float* __restrict__ x, int ldo) {
+  constexpr int m = 65536, n = 131072;
+  float2* buf = dyn_lds;
+  const int b = blockIdx.y, r0 = blockIdx.x * 16;
+  const int r = threadIdx.x & 15, rr = threadIdx.x >> 4;
+  const float2* wk = work + (size_t)b * m + (size_t)(r0 + rr) * 256 + r;
+  float2 a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = wk[16 * j];
+  pw_fft256<false>(a, buf + rr * PW_RP, r, -1.0f);
+  __syncthreads();
+  const float sc = 1.0f / (float)n;
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) buf[(r + 16 * s_) * PW_TP + rr] = cscale(a[s_], sc);
+  __syncthreads();
+  float2* xb = (float2*)(x + (size_t)b * ldo) + r0 + (threadIdx.x & 15);
+  const int nlo = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n1 = nlo + 16 * i;
+    xb[(size_t)n1 * 256] = buf[n1 * PW_TP + (threadIdx.x & 15)];
+  }
+}
+// forward pass A: columns n2 = c0 + cc, z[j] = (x[2j], x[2j+1]) (zero beyond T), transform over n1, twiddle, work[k1][n2]
+__global__ __launch_bounds__(256) void k_pw_fwd_a(const float* __restrict__ gx, int ldo, int T, float2* __restrict__ work) {
+  constexpr int m = 65536;
+  float2* buf = dyn_lds;
+  const int b = blockIdx.y, c0 = blockIdx.x * 16;
+  const int cc = threadIdx.x & 15, r = threadIdx.x >> 4, n2 = c0 + cc;
+  const float* gb = gx + (size_t)b * ldo;
+  const bool vec = (ldo & 1) == 0;
+  float2 a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int t = 2 * ((r + 16 * j) * 256 + n2);
+    if (vec && t + 1 < T) a[j] = *(const float2*)(gb + t);
+    else a[j] = make_float2(t < T ? gb[t] : 0.f, t + 1 < T ? gb[t + 1] : 0.f);
+  }
+  pw_fft256<true>(a, buf + cc * PW_CP, r, 1.0f);
+  pw_twiddle(a, pw_cis(-(float)(r * n2) / (float)m), pw_cis(-(float)n2 / 4096.0f));
+  float2* wk = work + (size_t)b * m + n2;
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) wk[(size_t)(r + 16 * s_) * 256] = a[s_];
+}
+// rows of tile q of forward pass B: k1 = 8 q + i (i < 8) and their mirrors 256 - k1 (slot 15 - i); tile 0 holds row 0, which
+// mirrors onto itself, and row 128 -- the other self-mirrored row -- in the free slot 15
+__device__ __forceinline__ int pw_tile_row(int q, int i) {
+  if (i < 8) return 8 * q + i;
+  if (q == 0 && i == 15) return 128;
+  return 256 - 8 * q - 7 + (i - 8);
+}
+// forward pass B: rows k1 (+ mirrors), transform over n2, F[k1 + 256 k2] for k <= m
+__global__ __launch_bounds__(256) void k_pw_fwd_b(const float2* __restrict__ work, float2* __restrict__ gX, int ldx, int plain) {
+  constexpr int m = 65536, n = 131072;
+  float2* buf = dyn_lds;
+  const int b = blockIdx.y, q = blockIdx.x;
+  const int r = threadIdx.x & 15, i = threadIdx.x >> 4;
+  const float2* wk = work + (size_t)b * m + (size_t)pw_tile_row(q, i) * 256 + r;
+  float2 a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = wk[16 * j];
+  pw_fft256<false>(a, buf + i * PW_RP, r, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) buf[i * PW_OP + r + 16 * s_] = a[s_];
+  __syncthreads();
+  const int ii = threadIdx.x & 15, klo = threadIdx.x >> 4;
+  const int k1 = pw_tile_row(q, ii);
+  const bool self = k1 == 0 || k1 == 128;
+  const int rp = self ? ii : 15 - ii;
+  float2* o = gX + (size_t)b * ldx;
+  const float sc = 1.0f / (float)n;
+  const float2 e0 = pw_cis(-(float)(k1 + 256 * klo) / (float)n);        // e^(-2 pi i k / n) at u = 0
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k2 = klo + 16 * u, k = k1 + 256 * k2;
+    const int k2p = k1 == 0 ? (256 - k2) & 255 : 255 - k2;
+    const float2 zk = buf[ii * PW_OP + k2], zp = cconj(buf[rp * PW_OP + k2p]);
+    const float2 e = cadd(zk, zp), d = cmul(csub(zk, zp), cmulc(e0, c_pw32[u]));   // (zk - zp) e^{-2 pi i k / n}
+    float2 v = make_float2(0.5f * (e.x + d.y), 0.5f * (e.y - d.x));                   // 1/2 (e - i d)
+    if (!plain) {                                  // adjoint-of-irfft scaling
+      if (k == 0) v = make_float2(sc * v.x, 0.f);
+      else v = cscale(v, 2.0f * sc);
+    }
+    o[k] = v;
+    if (k == 0) {                                  // k = m (Nyquist): Re Zf[0] - Im Zf[0]
+      const float ny = zk.x - zk.y;
+      o[m] = make_float2(plain ? ny : sc * ny, 0.f);
+    }
+  }
+}
+static bool pw_ok(const P2Geom& g) { return g.L1 == 256 && g.L2 == 256; }
+
 static size_t p2_lds(int len, int tc) { return ((size_t)2 * tc * (len + 1) + (len >= 4 ? len / 4 : 1)) * sizeof(float2); }
 
 extern "C" size_t gfdn_irfft_pow2_work_bytes(int n, int batch) {
@@ -233,6 +410,13 @@ extern "C" int gfdn_irfft_pow2_fwd(int n, const float* X, int ldx, int batch, fl
   P2Geom g = p2_geom(n);
   if (g.L2 > 2048) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (pw_ok(g) && (ldo & 1) == 0) {
+    hipLaunchKernelGGL(k_pw_inv_a, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)X, ldx, (float2*)work);
+    GFDN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pw_inv_b, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)work, x, ldo);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   const int tca = g.L1 < P2_TC ? g.L1 : P2_TC, tcb = g.L2 < P2_TC ? g.L2 : P2_TC;
   int rc;
   if ((rc = ensure_dyn_lds(k_p2_inv_a, p2_lds(g.L2, tca)))) return rc;
@@ -269,6 +453,14 @@ static int p2_forward_real(int n, const float* gx, int ldo, int T, int batch, fl
   P2Geom g = p2_geom(n);
   if (g.L2 > 2048) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (pw_ok(g)) {
+    hipLaunchKernelGGL(k_pw_fwd_a, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, gx, ldo, T, (float2*)work);
+    GFDN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pw_fwd_b, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)work, (float2*)gX, ldx,
+                       plain);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   const int tca = g.L2 < P2_TC ? g.L2 : P2_TC, tcb = g.L1 < P2_TC ? g.L1 : P2_TC;
   int rc;
   if ((rc = ensure_dyn_lds(k_p2_adj_a, p2_lds(g.L1, tca)))) return rc;

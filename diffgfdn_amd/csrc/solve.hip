@@ -2328,9 +2328,156 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd_w(const float2* __rest
   }
 }
 
+// Both gradients of the SH output stage from ONE pass over gH (nper = 1, 4, 9, 16: ambisonics orders 0..3).  A workgroup
+// owns SHF_TB bins; its four waves split the receivers, lane = bin.  Per receiver a thread loads its nper gradient
+// values (coalesced 512-byte rows), accumulates acc[n] += w[b][n] gH'[b][l(n)] in registers (static indices: g and l are
+// unrolled) and forms Re(conj(gH') Y[k][n]), summed over the wave's 64 bins -> one partial row of gw per (tile, b).
+// The waves' acc are then summed through LDS (two rounds), wave 0 writes gY through the staged Y tile and the tile's
+// partial of gc.  1025 workgroups x 4 waves instead of 513 x 2 that looped over every receiver, and the second launch
+// (k_compose_sh_bwd_w, another 151 MB read of gH) is gone.
+#define SHF_TB 64
+template <int NPER>
+__global__ __launch_bounds__(256) void k_compose_sh_bwd_fused(const float2* __restrict__ Y, int K, int G,
+                                                              const float* __restrict__ c,
+                                                              const float* __restrict__ w, int B,
+                                                              const float2* __restrict__ filt,
+                                                              const float2* __restrict__ gH,
+                                                              float2* __restrict__ gY,
+                                                              float* __restrict__ partial) {
+  constexpr int MAXG = NPER <= 4 ? 8 : 4;              // groups the accumulators are sized for
+  constexpr int NL = MAXG * NPER;
+  const int N = G * NPER, NS = N + 1 + (N & 1);
+  float2* yt = compose_lds;                              // [SHF_TB][NS]
+  float2* red = yt + SHF_TB * NS;                        // [2][N][SHF_TB]
+  float* sw = (float*)(red + 2 * N * SHF_TB);            // [B][N]
+  const int tile = blockIdx.x, k0 = tile * SHF_TB;
+  const int nbin = K - k0 < SHF_TB ? K - k0 : SHF_TB;
+  const size_t base = (size_t)k0 * N;
+  for (int e = threadIdx.x; e < SHF_TB * N; e += 256) {
+    const int kq = e / N, n = e - kq * N;
+    yt[kq * NS + n] = e < nbin * N ? Y[base + e] : make_float2(0.f, 0.f);
+  }
+  for (int e = threadIdx.x; e < B * N; e += 256) sw[e] = w[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = k0 + lane;
+  const bool valid = k < K;
+  const int kk = valid ? k : K - 1;
+  const float2 fc = filt ? cconj(filt[kk]) : make_float2(1.f, 0.f);
+  const float2* yrow = yt + lane * NS;
+  float2 acc[NL];
+#pragma unroll
+  for (int n = 0; n < NL; ++n) acc[n] = make_float2(0.f, 0.f);
+  // partial rows: [tile][B * N + N] = gw of the tile's bins per (b, n), then gc per n
+  float* prow = partial + (size_t)tile * ((size_t)B * N + N);
+  for (int b = wv; b < B; b += 4) {
+    float2 gh[NPER];
+#pragma unroll
+    for (int l = 0; l < NPER; ++l) {
+      float2 v = valid ? gH[((size_t)b * NPER + l) * K + kk] : make_float2(0.f, 0.f);
+      if (filt) v = cmul(v, fc);
+      gh[l] = v;
+    }
+    const float* swb = sw + b * N;
+    float mine = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+      if (g < G) {
+#pragma unroll
+        for (int l = 0; l < NPER; ++l) {
+          const int n = g * NPER + l;
+          const float s = swb[n];
+          acc[n].x += s * gh[l].x;
+          acc[n].y += s * gh[l].y;
+          const float2 y = yrow[n];
+          const float v = wave_sum(gh[l].x * y.x + gh[l].y * y.y);
+          if (lane == n) mine = v;
+        }
+      }
+    }
+    if (lane < N) prow[(size_t)b * N + lane] = mine * c[lane];
+  }
+  // acc over the four waves: 2, 3 -> LDS -> 0, 1; 1 -> LDS -> 0
+  if (wv >= 2) {
+#pragma unroll
+    for (int n = 0; n < NL; ++n) if (n < N) red[((wv - 2) * N + n) * SHF_TB + lane] = acc[n];
+  }
+  __syncthreads();
+  if (wv < 2) {
+#pragma unroll
+    for (int n = 0; n < NL; ++n) if (n < N) { const float2 o = red[(wv * N + n) * SHF_TB + lane]; acc[n].x += o.x; acc[n].y += o.y; }
+  }
+  __syncthreads();
+  if (wv == 1) {
+#pragma unroll
+    for (int n = 0; n < NL; ++n) if (n < N) red[n * SHF_TB + lane] = acc[n];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float mine = 0.f;
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+      if (n < N) {
+        const float2 o = red[n * SHF_TB + lane];
+        const float2 a = make_float2(acc[n].x + o.x, acc[n].y + o.y);
+        const float2 y = yrow[n];
+        const float v = wave_sum(valid ? (a.x * y.x + a.y * y.y) : 0.f);
+        if (lane == n) mine = v;
+        yt[lane * NS + n] = cscale(a, c[n]);               // gY through the tile: linear global writes below
+      }
+    }
+    if (lane < N) prow[(size_t)B * N + lane] = mine;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nbin * N; e += 256) {
+    const int kq = e / N, n = e - kq * N;
+    gY[base + e] = yt[kq * NS + n];
+  }
+}
+
+// rows [nparts][per1 + per2] -> out1 (per1), out2 (per2)
+__global__ __launch_bounds__(256) void k_reduce_partials2(const float* __restrict__ partial, int nparts, int per1, int per2,
+                                                          float* __restrict__ out1, float* __restrict__ out2) {
+  __shared__ float s_red[16];
+  const int e = blockIdx.x, per = per1 + per2;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += partial[(size_t)p * per + e];
+  s = block_sum(s, s_red);
+  if (threadIdx.x == 0) {
+    if (e < per1) out1[e] = s;
+    else out2[e - per1] = s;
+  }
+}
+
+template <int NPER>
+static int compose_sh_bwd_fused(const float2* Y, int K, int G, const float* c, const float* w, int B, const float2* filt,
+                                const float2* gH, float2* gY, float* gc, float* gw, float* work, hipStream_t s) {
+  const int N = G * NPER, NS = N + 1 + (N & 1), ntiles = (K + SHF_TB - 1) / SHF_TB;
+  const size_t lds = ((size_t)SHF_TB * NS + (size_t)2 * N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);
+  int rc = ensure_dyn_lds(k_compose_sh_bwd_fused<NPER>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_compose_sh_bwd_fused<NPER>, dim3(ntiles), dim3(256), lds, s, Y, K, G, c, w, B, filt, gH, gY, work);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_partials2, dim3(B * N + N), dim3(256), 0, s, work, ntiles, B * N, N, gw, gc);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+// (the fused pass takes nper in {1, 4, 9, 16}, lane-indexed rows of N <= 64 lines and what fits the LDS)
+static bool compose_sh_fused_ok(int K, int G, int nper, int B) {
+  if (nper != 1 && nper != 4 && nper != 9 && nper != 16) return false;
+  const int maxg = nper <= 4 ? 8 : 4;
+  const int N = G * nper, NS = N + 1 + (N & 1);
+  if (G > maxg || N > 64) return false;
+  const size_t lds = ((size_t)SHF_TB * NS + (size_t)2 * N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);
+  return lds <= 64 * 1024 && (K + SHF_TB - 1) / SHF_TB <= GFDN_SH_MAX_TILES * (SH_TB / SHF_TB);
+}
+
 extern "C" size_t gfdn_compose_sh_bwd_work_bytes(int G, int nper, int B) {
   // gw partials [K / SH_KC][B][N], then gc partials [K / SH_TB][N]
-  return ((size_t)(GFDN_SH_MAX_TILES * SH_TB / SH_KC) * B + GFDN_SH_MAX_TILES) * G * nper * sizeof(float);
+  const size_t two_pass = ((size_t)(GFDN_SH_MAX_TILES * SH_TB / SH_KC) * B + GFDN_SH_MAX_TILES) * G * nper * sizeof(float);
+  // fused pass: [tiles of SHF_TB bins][B N + N]
+  const size_t fused = (size_t)GFDN_SH_MAX_TILES * (SH_TB / SHF_TB) * ((size_t)B + 1) * G * nper * sizeof(float);
+  return two_pass > fused ? two_pass : fused;
 }
 
 extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const float* c,
@@ -2343,10 +2490,19 @@ extern "C" int gfdn_compose_sh_bwd(const float* Y, int K, int G, int nper, const
   if (N > GFDN_MAX_SH_LINES || G > SH_TB || ntiles > GFDN_SH_MAX_TILES) return GFDN_E_UNSUPPORTED;
   const size_t lds = ((size_t)SH_TB * NS + (size_t)nper * SH_TB) * sizeof(float2) +
                      ((size_t)B * N + (size_t)(SH_TB / 64) * N + N) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (compose_sh_fused_ok(K, G, nper, B)) {
+    const float2 *Yc = (const float2*)Y, *fl = (const float2*)filt, *gh = (const float2*)gH;
+    switch (nper) {
+      case 1: return compose_sh_bwd_fused<1>(Yc, K, G, c, w, B, fl, gh, (float2*)gY, gc, gw, (float*)work, s);
+      case 4: return compose_sh_bwd_fused<4>(Yc, K, G, c, w, B, fl, gh, (float2*)gY, gc, gw, (float*)work, s);
+      case 9: return compose_sh_bwd_fused<9>(Yc, K, G, c, w, B, fl, gh, (float2*)gY, gc, gw, (float*)work, s);
+      default: return compose_sh_bwd_fused<16>(Yc, K, G, c, w, B, fl, gh, (float2*)gY, gc, gw, (float*)work, s);
+    }
+  }
   if (lds > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_compose_sh_bwd_y, lds);
   if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
   float* gw_partial = (float*)work;
   float* gc_partial = gw_partial + (size_t)nchunks * B * N;
   hipLaunchKernelGGL(k_compose_sh_bwd_y, dim3(ntiles), dim3(SH_TB), lds, s, (const float2*)Y, K, G, nper, c, w, B,

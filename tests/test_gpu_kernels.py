@@ -196,6 +196,17 @@ def test_irfft_pow2(ops, n, batch):
     assert rel_err(gX.cpu(), X.grad) < 5e-6
 
 
+@pytest.mark.parametrize("n,T,batch", [(131072, 65537, 3), (131072, 131072, 1), (131072, 99998, 2), (4096, 1001, 2)])
+def test_rfft_pow2_zero_padded(ops, n, T, batch):
+    """X = rfft(x[:T], n) (dataloader.py:250, :320-325): odd and even lengths below n, the register-resident 256 x 256 passes
+    at n = 131 072 and the generic ones."""
+    torch.manual_seed(T)
+    x = torch.randn(batch, T, dtype=torch.float64)
+    X = torch.fft.rfft(x, n)
+    Xk = ops.rfft_pow2(x.float().to(DEV), n)
+    assert rel_err(Xk.cpu(), X) < 5e-6
+
+
 @pytest.mark.parametrize("T,win,batch", [(257, 64, 3), (65537, 4096, 2), (4097, 512, 2), (1024, 256, 1)])
 def test_stft_power(ops, T, win, batch):
     torch.manual_seed(T)
