@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256) void k_pw_inv_b(const float2* __restrict__ wor
   }
 }
 // forward pass A: columns n2 = c0 + cc, z[j] = (x[2j], x[2j+1]) (zero beyond T), transform over n1, twiddle, work[k1][n2]
-__global__ __launch_bounds__(256) void k_pw_fwd_a(const float* __restrict__ gx, int ldo, int T, float2* __restrict__ work) {
+// (samples outside [t_lo, T) count as zero and are not read)
+__global__ __launch_bounds__(256) void k_pw_fwd_a(const float* __restrict__ gx, int ldo, int t_lo, int T,
+                                                  float2* __restrict__ work) {
   constexpr int m = 65536;
   float2* buf = dyn_lds;
   const int b = blockIdx.y, c0 = blockIdx.x * 16;
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) void k_pw_fwd_a(const float* __restrict__ gx, 
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int t = 2 * ((r + 16 * j) * 256 + n2);
-    if (vec && t + 1 < T) a[j] = *(const float2*)(gb + t);
-    else a[j] = make_float2(t < T ? gb[t] : 0.f, t + 1 < T ? gb[t + 1] : 0.f);
+    if (vec && t >= t_lo && t + 1 < T) a[j] = *(const float2*)(gb + t);
+    else a[j] = make_float2((t >= t_lo && t < T) ? gb[t] : 0.f, (t + 1 >= t_lo && t + 1 < T) ? gb[t + 1] : 0.f);
   }
   pw_fft256<true>(a, buf + cc * PW_CP, r, 1.0f);
   pw_twiddle(a, pw_cis(-(float)(r * n2) / (float)m), pw_cis(-(float)n2 / 4096.0f));
@@ -431,7 +433,7 @@ extern "C" int gfdn_irfft_pow2_fwd(int n, const float* X, int ldx, int batch, fl
 }
 
 static int p2_forward_real(int n, const float* gx, int ldo, int T, int batch, float* gX, int ldx,
-                           void* work, void* stream, int plain);
+                           void* work, void* stream, int plain, int t_lo = 0);
 
 extern "C" int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, float* gX, int ldx,
                                    void* work, void* stream) {
@@ -446,15 +448,24 @@ extern "C" int gfdn_rfft_pow2(int n, const float* x, int ld, int T, int batch, f
   return p2_forward_real(n, x, ld, T, batch, X, ldx, work, stream, 1);
 }
 
+// adjoint of irfft for a gradient that vanishes outside the samples [t_lo, t_hi): nothing outside the window is read
+// (it may be uninitialised).  n = 131 072 only (the register-resident passes).
+extern "C" int gfdn_irfft_pow2_bwd_window(int n, const float* gx, int ldo, int batch, int t_lo, int t_hi, float* gX, int ldx,
+                                          void* work, void* stream) {
+  if (ldo < n || t_lo < 0 || t_hi > n || t_lo >= t_hi) return GFDN_E_BADARG;
+  if (n != 131072) return GFDN_E_UNSUPPORTED;
+  return p2_forward_real(n, gx, ldo, t_hi, batch, gX, ldx, work, stream, 0, t_lo);
+}
+
 static int p2_forward_real(int n, const float* gx, int ldo, int T, int batch, float* gX, int ldx,
-                           void* work, void* stream, int plain) {
+                           void* work, void* stream, int plain, int t_lo) {
   if (!gx || !gX || !work || n < 16 || (n & (n - 1)) || batch <= 0) return GFDN_E_BADARG;
   if (ldx < n / 2 + 1) return GFDN_E_BADARG;
   P2Geom g = p2_geom(n);
   if (g.L2 > 2048) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (pw_ok(g)) {
-    hipLaunchKernelGGL(k_pw_fwd_a, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, gx, ldo, T, (float2*)work);
+    hipLaunchKernelGGL(k_pw_fwd_a, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, gx, ldo, t_lo, T, (float2*)work);
     GFDN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pw_fwd_b, dim3(16, batch), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)work, (float2*)gX, ldx,
                        plain);

@@ -1125,13 +1125,19 @@ def irfft_pow2_fwd(X, n: int) -> torch.Tensor:
     return x
 
 
-def irfft_pow2_bwd(gx, n: int) -> torch.Tensor:
+def irfft_pow2_bwd(gx, n: int, window=None) -> torch.Tensor:
+    """gX = d<gx, irfft(X, n)>/dX.  ``window`` = (lo, hi): gx vanishes outside the samples [lo, hi) and whatever the
+    buffer holds there is not read (n = 131 072)."""
     _need_gpu(gx)
     gx = _f(gx)
     batch = gx.shape[0]
     lib = _lib.load()
     gX = torch.empty((batch, n // 2 + 1), dtype=_c64, device=gx.device)
     work = _work(lib.gfdn_irfft_pow2_work_bytes(n, batch), gx.device)
+    if window is not None:
+        _lib.check(lib.gfdn_irfft_pow2_bwd_window(n, _p(gx), gx.shape[1], batch, int(window[0]), int(window[1]), _p(gX),
+                                                  n // 2 + 1, _p(work), _stream()), "gfdn_irfft_pow2_bwd_window")
+        return gX
     _lib.check(lib.gfdn_irfft_pow2_bwd(n, _p(gx), gx.shape[1], batch, _p(gX), n // 2 + 1, _p(work),
                                        _stream()), "gfdn_irfft_pow2_bwd")
     return gX
@@ -1315,6 +1321,33 @@ def edc_loss_model(x, start: int, length: int, amps, env, maskw=None, inv_count:
     _lib.check(lib.gfdn_edc_loss_model(_p(x), T, B, start, length, _p(amps), S, _p(env), env.shape[1], _p(maskw),
                                        float(inv_count), float(gscale), _p(loss_item), _p(gx), _p(work), _stream()),
                "gfdn_edc_loss_model")
+    return loss_item, gx
+
+
+def edc_mixed_supported(C: int, J: int) -> bool:
+    """Channel / direction counts gfdn_edc_loss_model_mixed is built for."""
+    return C in (1, 4, 9, 16) and J <= 16
+
+
+def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None, inv_count: float = 1.0,
+                         gscale: float = 1.0, want_grad: bool = True):
+    """edc_loss_model on the directional signals A x_sh without forming them: x_sh (B, C, T) f32, A (J, C), amps (B J, S),
+    env (S, >= length) -> (loss_item (B J,), gx_sh like x_sh or None).  gx_sh is written on the window samples
+    [start, start + length) ONLY: hand it to irfft_pow2_bwd(..., window=(start, start + length))."""
+    _need_gpu(x_sh, A, amps, env)
+    x_sh, A, amps, env = _f(x_sh), _f(A), _f(amps), _f(env)
+    B, C, T = x_sh.shape
+    J, S = A.shape[0], amps.shape[1]
+    if A.shape[1] != C or amps.shape[0] != B * J or env.shape[0] != S or env.shape[1] < length:
+        raise RuntimeError("edc_loss_model_mixed: A (J, C), amps (B J, S), env (S, >= length)")
+    maskw = None if maskw is None else _f(maskw)
+    loss_item = torch.empty(B * J, dtype=_f32, device=x_sh.device)
+    gx = torch.empty_like(x_sh) if want_grad else None
+    lib = _lib.load()
+    work = _work(lib.gfdn_edc_mixed_work_bytes(B, J, length), x_sh.device)
+    _lib.check(lib.gfdn_edc_loss_model_mixed(_p(x_sh), T, B, C, _p(A), J, start, length, _p(amps), S, _p(env),
+                                             env.shape[1], _p(maskw), float(inv_count), float(gscale), _p(loss_item),
+                                             _p(gx), _p(work), _stream()), "gfdn_edc_loss_model_mixed")
     return loss_item, gx
 
 

@@ -493,10 +493,20 @@ class directional_edc_loss(nn.Module):
         x_sh = ops.irfft_pow2_fwd(H_sh.reshape(B * C, K), n)                       # (B C, n)
         if self.envelopes.device != x_sh.device:
             self.envelopes = self.envelopes.to(x_sh.device)
+        amps = amps_true.to(device=x_sh.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
+        if n == 131072 and ops.edc_mixed_supported(C, J):
+            # the J directional samples formed in registers inside the EDC kernels (csrc/edcmix.hip): neither the
+            # directional signals nor their gradient exist, the adjoint transform reads the EDC window only
+            li, gx_sh = ops.edc_loss_model_mixed(x_sh.view(B, C, n), analysis_matrix, start, L, amps, self.envelopes, None,
+                                                 1.0 / (B * J * float(L)), float(weight), want_grad)
+            val = li.sum() if weight == 1.0 else li.sum() * float(weight)
+            if not want_grad:
+                return val
+            gH = ops.irfft_pow2_bwd(gx_sh.view(B * C, n), n, window=(start, start + L)).reshape(B, C, K)
+            return _ScalarLossWithSavedGrad.apply(H_sh, val, gH, unit_grad)
         # pairs of real samples as complex numbers: the streaming mix kernel of the spectra serves the signals too
         x_dir = ops.sh_to_directional(analysis_matrix, torch.view_as_complex(x_sh.view(B, C, n // 2, 2)), False)
         x_dir = torch.view_as_real(x_dir).view(B * J, n)
-        amps = amps_true.to(device=x_sh.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
         li, gx = ops.edc_loss_model(x_dir, start, L, amps, self.envelopes, None, 1.0 / (B * J * float(L)), float(weight),
                                     want_grad)
         val = li.sum() if weight == 1.0 else li.sum() * float(weight)

@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
  * receiver schedule; every entry point of version 1 keeps its signature */
-#define GFDN_ABI_VERSION 3
+#define GFDN_ABI_VERSION 4
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
@@ -531,6 +531,10 @@ int gfdn_irfft_pow2_fwd(int n, const float* X_c64, int ldx, int batch, float* x,
                         void* work, void* stream);
 int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, float* gX_c64, int ldx,
                         void* work, void* stream);
+/* The adjoint for a gradient that vanishes outside the samples [t_lo, t_hi) (the EDC window of losses.py:344-346): nothing
+ * outside the window is read -- it may be uninitialised.  n = 131 072 (GFDN_E_UNSUPPORTED otherwise).               */
+int gfdn_irfft_pow2_bwd_window(int n, const float* gx, int ldo, int batch, int t_lo, int t_hi, float* gX_c64, int ldx,
+                               void* work, void* stream);
 
 /* Dataset front end (dataloader.py:250, :320-325: scipy.fft.rfft(rirs, n = nfft)):
  * X (batch, ldx >= n/2+1) complex64 = rfft(x[b][0:T] zero-padded to n), n = 2^p, T <= n.
@@ -582,6 +586,16 @@ int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const f
 int gfdn_edc_loss_model(const float* x, int ld, int batch, int start, int len, const float* amps, int S,
                         const float* env, int ld_env, const float* maskw, float inv_count, float gscale,
                         float* loss_item, float* gx, void* work, void* stream);
+/* The same loss on the directional signals x_dir[b][j] = sum_c A[j][c] x_sh[b][c] (trainer.py:853-865: einsum
+ * 'jl,blk->bjk' with the real analysis matrix A (J, C), applied here behind the inverse transform -- the maps commute)
+ * WITHOUT forming them: x_sh (B C, ld) holds the C SH-domain time signals of every receiver, the J directional samples
+ * live in registers.  amps (B J, S); loss_item (B J); gx_sh (B C, ld), when not NULL, receives gscale * dloss/dx_sh on the
+ * window samples [start, start + len) ONLY (pair it with gfdn_irfft_pow2_bwd_window).  C in {1, 4, 9, 16}, J <= 16.
+ * work: gfdn_edc_mixed_work_bytes(B, J, len).                                                                          */
+size_t gfdn_edc_mixed_work_bytes(int B, int J, int len);
+int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,
+                              const float* amps, int S, const float* env, int ld_env, const float* maskw,
+                              float inv_count, float gscale, float* loss_item, float* gx_sh, void* work, void* stream);
 
 /* ---- EDC time mask on the device  (losses.py:221-227: mask = argwhere(bernoulli(U(0,1))) over the
  * window -- marginally every index is kept with probability 1/2, independently).

@@ -522,6 +522,49 @@ def test_edc_loss_against_the_common_slope_model(ops, B, T, start, length, S, ma
     assert float((g0 - g1).abs().sum()) < 1e-3 * float(g0.abs().sum())
 
 
+@pytest.mark.parametrize("B,C,J,T,start,length,S,masked", [(3, 9, 12, 9000, 38, 8100, 3, False),
+                                                             (2, 4, 5, 5000, 0, 4097, 1, True),
+                                                             (2, 9, 12, 131072, 960, 67200, 3, False),
+                                                             (1, 16, 16, 3000, 11, 512, 2, False),
+                                                             (2, 1, 2, 2000, 7, 1500, 8, True)])
+def test_edc_loss_of_directional_signals_formed_in_registers(ops, B, C, J, T, start, length, S, masked):
+    """gfdn_edc_loss_model_mixed (csrc/edcmix.hip: x_dir = A x_sh formed in registers, segments of 512 samples, dL/dEDC
+    recomputed instead of staged) against gfdn_edc_loss_model on the explicitly mixed signals (trainer.py:853-865 +
+    losses.py:333-371), loss per (receiver, direction) and dL/dx_sh; the gradient is written on the window only."""
+    g = torch.Generator().manual_seed(B * 7 + S + C)
+    x_sh = (torch.randn(B, C, T, generator=g) * torch.exp(-torch.arange(T) / (0.2 * T))).to(DEV)
+    A = torch.randn(J, C, generator=g).to(DEV)
+    amps = (0.1 + torch.rand(B * J, S, generator=g)).to(DEV)
+    t = torch.arange(length + 50, dtype=torch.float32)
+    env = torch.stack([torch.exp(-13.8 * t / ((0.2 + 0.3 * k) * T)) for k in range(S)]).to(DEV)
+    maskw = (torch.rand(length, generator=g) < 0.5).float().to(DEV) if masked else None
+    inv = 1.0 / (B * J * length)
+    x_dir = torch.einsum('jc,bct->bjt', A.double(), x_sh.double()).float().reshape(B * J, T).contiguous()
+    li0, g0 = ops.edc_loss_model(x_dir, start, length, amps, env, maskw, inv, 2.0)
+    gsh0 = torch.einsum('jc,bjt->bct', A.double(), g0.reshape(B, J, T).double())
+    li1, g1 = ops.edc_loss_model_mixed(x_sh, A, start, length, amps, env, maskw, inv, 2.0)
+    assert torch.allclose(li0, li1, rtol=5e-5, atol=1e-7)
+    win = slice(start, start + length)
+    assert rel_err(g1[:, :, win].cpu().double(), gsh0[:, :, win].cpu()) < 5e-5
+    # loss only
+    li2, g2 = ops.edc_loss_model_mixed(x_sh, A, start, length, amps, env, maskw, inv, 2.0, want_grad=False)
+    assert g2 is None and torch.equal(li1, li2)
+
+
+def test_irfft_pow2_adjoint_reads_the_window_only(ops):
+    """gfdn_irfft_pow2_bwd_window: the adjoint of a gradient that vanishes outside [lo, hi) -- the buffer may hold anything
+    there (NaN here)."""
+    n, lo, hi = 131072, 961, 68160
+    gx = torch.zeros(3, n, device=DEV)
+    gx[:, lo:hi] = torch.randn(3, hi - lo, generator=torch.Generator().manual_seed(1)).to(DEV)
+    want = ops.irfft_pow2_bwd(gx, n)
+    dirty = gx.clone()
+    dirty[:, :lo] = float('nan')
+    dirty[:, hi:] = float('nan')
+    got = ops.irfft_pow2_bwd(dirty, n, window=(lo, hi))
+    assert torch.equal(got, want)
+
+
 def test_mfma_contraction_f32_exact_bf16_outside_the_bar(ops):
     """BASELINE.json configs[4], "fp32 vs bf16 feedback-matmul on MFMA" (gfdn_exp_contract_mfma: the reference's dense
     formulation, feedback_loop.py:389-391 + model.py:615-619, one 32 x 32 x 32 product per bin on the matrix cores):
