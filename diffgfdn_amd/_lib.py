@@ -121,6 +121,8 @@ SIGNATURES = {
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_irfft_pow2_fwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_irfft_pow2_bwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_rownorm_fwd": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
+    "gfdn_rownorm_bwd": (c_int, [_P, c_int, c_int, c_float, _P, _P, _P]),
     "gfdn_irfft_pow2_bwd_window": (c_int, [c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_edc_mixed_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_edc_loss_model_mixed": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,

@@ -12,7 +12,7 @@
 //   k_em_carry  : exclusive SUFFIX sums of seg over s (the energy behind the segment)
 //   k_em_fwd    : EDC_j(t) = carry + suffix scan inside the segment -> dB, |target - EDC| -> partial loss, dL/dEDC;
 //                 part[b][j][s] = loss of the segment, gs[b][j][s] = sum of dL/dEDC over the segment
-//   k_em_carry  : exclusive PREFIX sums of gs over s; loss_item[b][j] = inv_count * sum_s part
+//   k_em_carry  : exclusive PREFIX sums of gs over s; loss_item[b][j] = gscale inv_count sum_s part (the weighted term)
 //   k_em_bwd    : dL/dEDC recomputed as in k_em_fwd (not staged), prefix scan inside the segment + carry
 //                 -> dL/dx_dir = 2 x_dir prefix -> dL/dx_sh[c] = sum_j A[j][c] dL/dx_dir[j], stored for the window only
 //                 (the adjoint transform is told the window, gfdn_irfft_pow2_bwd_window: nothing outside is read).
@@ -316,8 +316,8 @@ static int em_run(EmArgs a, hipStream_t s) {
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_em_fwd<C, JT>), grid, block, 0, s, a);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_em_carry, dim3(a.B * a.J), dim3(64), 0, s, a.gs, a.nseg, 0, (const float*)a.part, a.inv_count,
-                     a.loss_item);
+  hipLaunchKernelGGL(k_em_carry, dim3(a.B * a.J), dim3(64), 0, s, a.gs, a.nseg, 0, (const float*)a.part,
+                     a.inv_count * a.gscale, a.loss_item);
   GFDN_LAUNCH_CHECK();
   if (a.gx) {
     hipLaunchKernelGGL((k_em_bwd<C, JT>), grid, block, 0, s, a);

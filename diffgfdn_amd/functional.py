@@ -63,6 +63,21 @@ class OrthoParam(torch.autograd.Function):
         return ops.ortho_bwd(M, gQ.contiguous(), gQQ.contiguous(), Q).to(M.dtype)
 
 
+class RowNormalise(torch.autograd.Function):
+    """w / (||w||_2 + 1e-6) over the last axis (reference spatial_sampling/model.py:117-190 ``normalise_weights``): one
+    launch each way instead of 3 + 11 tensor operators."""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.save_for_backward(w)
+        return ops.rownorm_fwd(w, 1e-6)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (w,) = ctx.saved_tensors
+        return ops.rownorm_bwd(w, gy.contiguous(), 1e-6)
+
+
 class MlpGains(torch.autograd.Function):
     """gains (B, G) = ScaledSigmoid(MLP(SinusoidalEncoding(pos)))  (gain_filters.py:497-524) in one
     launch; parameters are passed as separate tensors (autograd hands each its gradient) and packed

@@ -282,6 +282,9 @@ class Directional_Beamforming_Weights_from_MLP(nn.Module):
 
     @staticmethod
     def normalise_weights(weights: torch.Tensor) -> torch.Tensor:
+        if weights.is_cuda and weights.dtype == torch.float32:
+            from .functional import RowNormalise
+            return RowNormalise.apply(weights.contiguous())
         return weights / (torch.norm(weights, dim=-1, keepdim=True) + 1e-6)
 
     def _fused_ok(self, position: torch.Tensor) -> bool:

@@ -1324,6 +1324,25 @@ def edc_loss_model(x, start: int, length: int, amps, env, maskw=None, inv_count:
     return loss_item, gx
 
 
+def rownorm_fwd(w, eps: float = 1e-6) -> torch.Tensor:
+    """w (..., len) f32 -> w / (||w||_2 + eps) over the last axis."""
+    _need_gpu(w)
+    w = _f(w)
+    y = torch.empty_like(w)
+    _lib.check(_lib.load().gfdn_rownorm_fwd(_p(w), w.numel() // w.shape[-1], w.shape[-1], float(eps), _p(y), _stream()),
+               "gfdn_rownorm_fwd")
+    return y
+
+
+def rownorm_bwd(w, gy, eps: float = 1e-6) -> torch.Tensor:
+    _need_gpu(w, gy)
+    w, gy = _f(w), _f(gy)
+    gw = torch.empty_like(w)
+    _lib.check(_lib.load().gfdn_rownorm_bwd(_p(w), w.numel() // w.shape[-1], w.shape[-1], float(eps), _p(gy), _p(gw),
+                                            _stream()), "gfdn_rownorm_bwd")
+    return gw
+
+
 def edc_mixed_supported(C: int, J: int) -> bool:
     """Channel / direction counts gfdn_edc_loss_model_mixed is built for."""
     return C in (1, 4, 9, 16) and J <= 16
@@ -1332,7 +1351,7 @@ def edc_mixed_supported(C: int, J: int) -> bool:
 def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None, inv_count: float = 1.0,
                          gscale: float = 1.0, want_grad: bool = True):
     """edc_loss_model on the directional signals A x_sh without forming them: x_sh (B, C, T) f32, A (J, C), amps (B J, S),
-    env (S, >= length) -> (loss_item (B J,), gx_sh like x_sh or None).  gx_sh is written on the window samples
+    env (S, >= length) -> (loss_item (B J,) TIMES gscale, gx_sh like x_sh or None).  gx_sh is written on the window samples
     [start, start + length) ONLY: hand it to irfft_pow2_bwd(..., window=(start, start + length))."""
     _need_gpu(x_sh, A, amps, env)
     x_sh, A, amps, env = _f(x_sh), _f(A), _f(amps), _f(env)

@@ -499,7 +499,7 @@ class directional_edc_loss(nn.Module):
             # directional signals nor their gradient exist, the adjoint transform reads the EDC window only
             li, gx_sh = ops.edc_loss_model_mixed(x_sh.view(B, C, n), analysis_matrix, start, L, amps, self.envelopes, None,
                                                  1.0 / (B * J * float(L)), float(weight), want_grad)
-            val = li.sum() if weight == 1.0 else li.sum() * float(weight)
+            val = li.sum()                                     # (the kernel's items carry the weight)
             if not want_grad:
                 return val
             gH = ops.irfft_pow2_bwd(gx_sh.view(B * C, n), n, window=(start, start + L)).reshape(B, C, K)

