@@ -348,10 +348,10 @@ def _profile(name):
     return path if os.path.exists(path) else None
 
 
-def pmc_traffic_bytes(kernel: str):
+def pmc_traffic_bytes(kernel: str, table: str = 'pmc_hbm_bytes.csv'):
     """2 x FETCH_SIZE + WRITE_SIZE per launch of ``kernel`` from the committed rocprofv3 --pmc summary (gfx950
     correction as MI355X_MICROARCH.md prescribes), for the grid the step launches (the row with most launches)."""
-    path = _profile('pmc_hbm_bytes.csv')
+    path = _profile(table)
     if path is None:
         return None
     rows = [r for r in csv.DictReader(open(path)) if r['kernel'] == kernel]
@@ -467,7 +467,7 @@ def run_directional(args, device, rank, world):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # roofline leg: the power-of-two irfft of the 32 x 12 directional responses (both passes), in the step
+    # roofline leg: the power-of-two irfft of the 32 x 9 SH-domain responses (both passes), in the step
     tr, step, store = steps[0]
     hip_ops.kernel_timer.watch = 'irfft_pow2_fwd'
     hip_ops.kernel_timer.start()
@@ -490,15 +490,61 @@ def run_directional(args, device, rank, world):
                        'ms_per_band_step': 1e3 * elapsed / args.steps / nb,
                        'final_loss': float(total)}}
     if kt:
-        units = kt['units_per_launch']                      # directional responses per launch (32 x 12)
+        units = kt['units_per_launch']                      # SH-domain responses per launch (32 receivers x 9 channels)
         per = 8 * K + 2 * 8 * 65536 + 4 * NFFT              # spectrum in, work block out and in, samples out
         us = kt['avg_ms'] * 1e3
+        ta, tb = (pmc_traffic_bytes(k, 'directional_pmc_hbm_bytes.csv') for k in ('k_pw_inv_a', 'k_pw_inv_b'))
         out['roofline'] = {'bound': 'hbm', 'achieved': units * per / us / 1e3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': units * per / us / 1e3 / HBM_PEAK_GBS, 'traffic': None,
-                           'kernel': 'k_p2_inv_a + k_p2_inv_b (irfft, n = 131072, of the directional responses)',
+                           'frac': units * per / us / 1e3 / HBM_PEAK_GBS,
+                           'traffic': (ta + tb) if (ta and tb) else None,
+                           'traffic_source': f'profiles/{PROFILE_TAG}_directional_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE of '
+                                             'both passes, separate --pmc runs)',
+                           'kernel': 'k_pw_inv_a + k_pw_inv_b (irfft, n = 131072, of the SH-domain responses: the two '
+                                     'register-resident 256 x 256 passes)',
                            'avg_launch_us': us, 'launches': kt['launches'], 'alg_bytes_per_unit': per,
                            'units_per_launch': units, 'measured': 'HIP events around both passes in 10 host-launched steps'}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_directional(steps[0][0], z, Gd, L, J)
     return out
+
+
+def cpu_baseline_directional(tr, z, Gd, L, J, receivers: int = 2):
+    """One band-step of the directional model on the host cores with the CPU oracle (oracle/cpu_trainer.py
+    directional_band_step: forward, directional EDC loss, backward under autograd in float64 / complex128) on a bounded
+    sample -- ``receivers`` of the 32 receivers of a band-step, the band's current parameters -- and the same step's loss on
+    the HIP path beside it."""
+    from oracle import gfdn_oracle as orc
+    from oracle.cpu_trainer import directional_band_step
+    cores = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    net = tr.net
+    rng = np.random.RandomState(3)
+    pos = torch.tensor(rng.uniform(0, 1, (receivers, 3)))
+    amps = torch.tensor(rng.uniform(0.1, 1.0, (receivers, J, Gd)))
+    crit = tr.criterion[0]
+    state = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    delays = [int(d) for d in net.delays.detach().cpu().reshape(-1).tolist()]
+    nff = net.sh_output_scalars.num_fourier_features
+    t0 = time.time()
+    loss_c, _, _, _ = directional_band_step(state, delays, net.sh_output_scalars.analysis_matrix.cpu().numpy(), z.cpu(), pos,
+                                            amps, crit.envelopes.cpu(), Gd, L, nff, crit.mixing_time_samps,
+                                            crit.edc_len_samps, edc_weight=tr.config.edc_loss_weight)
+    sec = time.time() - t0
+    torch.set_num_threads(min(4, os.cpu_count() or 1))
+    dev = z.device
+    with torch.no_grad():
+        batch = {'z_values': z, 'source_position': torch.zeros(receivers, 3, device=dev, dtype=torch.float64),
+                 'listener_position': (10 * pos).to(dev), 'norm_listener_position': pos.to(dev),
+                 'target_common_slope_amps': amps.to(dev)}
+        loss_h = float(tr._step_losses(batch)['edc_loss'])
+    return {'value': receivers * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
+            'host_cpu': host_cpu_model(), 'host_logical_cpus': os.cpu_count(), 'sec_per_step': sec,
+            'sample': f'host CPU {host_cpu_model()} ({os.cpu_count()} logical CPUs, {cores} threads used); ONE band-step '
+                      f'(SH-domain forward, directional EDC loss, backward; no optimiser update) at {receivers} of the 32 '
+                      f'receivers of a band-step, no warm-up; {sec:.1f} s.  The feedback-loop solve (65 537 bins x 27 lines) '
+                      'does not depend on the number of receivers: the per-receiver rate of a full batch would be higher',
+            'loss_delta_vs_cpu': {'edc_loss': {'cpu': float(loss_c), 'hip': loss_h,
+                                               'rel': abs(loss_h - float(loss_c)) / abs(float(loss_c))}}}
 
 
 def self_launch(args) -> int:

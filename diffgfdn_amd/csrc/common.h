@@ -44,6 +44,46 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Prefix / suffix sums over the 64 lanes of a wave on the VALU: DPP row shifts inside the rows of 16 lanes, the row
+// totals through v_readlane -- no LDS crossbar (ds_bpermute, which __shfl_* compile to, issues on the LDS pipe: a kernel
+// that scans a dozen values per thread is bound by it).  Fixed summation order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_shifted(float v) {       // v + (lane shifted by CTRL inside its row, 0 where none)
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// inclusive prefix sum (lane i: v_0 + ... + v_i); total = sum of the wave
+__device__ __forceinline__ float wave_scan_incl(float v, float& total) {
+  v = dpp_add_shifted<0x111>(v);        // row_shr:1
+  v = dpp_add_shifted<0x112>(v);        // row_shr:2
+  v = dpp_add_shifted<0x114>(v);        // row_shr:4
+  v = dpp_add_shifted<0x118>(v);        // row_shr:8
+  const float t0 = readlane_f(v, 15), t1 = readlane_f(v, 31), t2 = readlane_f(v, 47), t3 = readlane_f(v, 63);
+  const int row = (threadIdx.x & 63) >> 4;
+  const float add = (row >= 1 ? t0 : 0.f) + (row >= 2 ? t1 : 0.f) + (row >= 3 ? t2 : 0.f);
+  total = ((t0 + t1) + t2) + t3;
+  return v + add;
+}
+// inclusive suffix sum (lane i: v_i + ... + v_63)
+__device__ __forceinline__ float wave_scan_incl_rev(float v, float& total) {
+  v = dpp_add_shifted<0x101>(v);        // row_shl:1
+  v = dpp_add_shifted<0x102>(v);
+  v = dpp_add_shifted<0x104>(v);
+  v = dpp_add_shifted<0x108>(v);
+  const float t0 = readlane_f(v, 0), t1 = readlane_f(v, 16), t2 = readlane_f(v, 32), t3 = readlane_f(v, 48);
+  const int row = (threadIdx.x & 63) >> 4;
+  const float add = (row <= 2 ? t3 : 0.f) + (row <= 1 ? t2 : 0.f) + (row <= 0 ? t1 : 0.f);
+  total = ((t3 + t2) + t1) + t0;
+  return v + add;
+}
+__device__ __forceinline__ float wave_sum_valu(float v) {         // the wave's sum in every lane
+  float total;
+  wave_scan_incl(v, total);
+  return total;
+}
+
 // deterministic block sum (blockDim.x multiple of 64, <= 1024); result valid in every thread
 __device__ __forceinline__ float block_sum(float v, float* lds /* >= 16 floats */) {
   v = wave_sum(v);

@@ -81,7 +81,7 @@ template <int JT>
 __device__ __forceinline__ void em_block_sums(float (&v)[JT], float* lds) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j < JT; ++j) v[j] = wave_sum(v[j]);
+  for (int j = 0; j < JT; ++j) v[j] = wave_sum_valu(v[j]);
   __syncthreads();
   if (lane == 0) {
 #pragma unroll
@@ -97,20 +97,16 @@ __device__ __forceinline__ void em_block_sums(float (&v)[JT], float* lds) {
 template <bool REV, int JT>
 __device__ __forceinline__ void em_block_scan_excl(float (&v)[JT], float* lds) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float own[JT];
+  float own[JT], tot[JT];
 #pragma unroll
   for (int j = 0; j < JT; ++j) {
     own[j] = v[j];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float o = REV ? __shfl_down(v[j], off, 64) : __shfl_up(v[j], off, 64);
-      if (REV ? (lane + off < 64) : (lane >= off)) v[j] += o;
-    }
+    v[j] = REV ? wave_scan_incl_rev(v[j], tot[j]) : wave_scan_incl(v[j], tot[j]);      // (VALU scans, common.h)
   }
   __syncthreads();
-  if (lane == (REV ? 0 : 63)) {
+  if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) lds[w * EM_JMAX + j] = v[j];
+    for (int j = 0; j < JT; ++j) lds[w * EM_JMAX + j] = tot[j];
   }
   __syncthreads();
 #pragma unroll

@@ -2328,6 +2328,56 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd_w(const float2* __rest
   }
 }
 
+// sums over the 64 lanes of up to 32 values per lane (v[0 .. min(NV, 32) - 1]) by a halving exchange on the VALU: at
+// distance 32 the lower half-wave keeps values 0..15 and the upper 16..31 -- v_permlane32_swap hands each half the other's
+// sixteen in one instruction per pair --, v_permlane16_swap does the same between the rows of 16 lanes for 8 values, and
+// inside the rows DPP (row_ror:8, row_half_mirror, quad_perm) pairs the lanes for 4, 2, 1 values and the last pair:
+// ~70 VALU instructions and no LDS traffic, against six ds_bpermute + six adds per value.  Lane l returns sum l >> 1.
+template <int CTRL>
+__device__ __forceinline__ float dpp_pair_sum(float v) {          // v + v of the lane CTRL pairs this one with
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int NV>
+__device__ __forceinline__ float wave_sums_transposed32(const float (&v)[NV]) {
+  const int lane = threadIdx.x & 63;
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    // first operand: what the LOWER half keeps (value i), second: what the UPPER half keeps (value i + 16); the swap
+    // trades the first's upper 32 lanes for the second's lower 32
+    const unsigned lo_v = __float_as_uint(i < NV ? v[i < NV ? i : 0] : 0.f);
+    const unsigned hi_v = __float_as_uint(i + 16 < NV ? v[i + 16 < NV ? i + 16 : 0] : 0.f);
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_v, hi_v, false, false);
+    a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {          // even rows keep a[i], odd rows a[i + 8]: the first's odd rows for the second's even rows
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 8]), false, false);
+    a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const bool hi = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s0 = dpp_pair_sum<0x128>(a[i]), s1 = dpp_pair_sum<0x128>(a[i + 4]);      // row_ror:8
+      a[i] = hi ? s1 : s0;
+    }
+  }
+  {
+    const bool hi = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float s0 = dpp_pair_sum<0x141>(a[i]), s1 = dpp_pair_sum<0x141>(a[i + 2]);      // row_half_mirror
+      a[i] = hi ? s1 : s0;
+    }
+  }
+  {
+    const float s0 = dpp_pair_sum<0x4e>(a[0]), s1 = dpp_pair_sum<0x4e>(a[1]);              // quad_perm:[2,3,0,1]
+    a[0] = (lane & 2) ? s1 : s0;
+  }
+  return dpp_pair_sum<0xb1>(a[0]);                                                         // quad_perm:[1,0,3,2]
+}
+
 // Both gradients of the SH output stage from ONE pass over gH (nper = 1, 4, 9, 16: ambisonics orders 0..3).  A workgroup
 // owns SHF_TB bins; its four waves split the receivers, lane = bin.  Per receiver a thread loads its nper gradient
 // values (coalesced 512-byte rows), accumulates acc[n] += w[b][n] gH'[b][l(n)] in registers (static indices: g and l are
@@ -2344,7 +2394,7 @@ __global__ __launch_bounds__(256) void k_compose_sh_bwd_fused(const float2* __re
                                                               const float2* __restrict__ gH,
                                                               float2* __restrict__ gY,
                                                               float* __restrict__ partial) {
-  constexpr int MAXG = NPER <= 4 ? 8 : 4;              // groups the accumulators are sized for
+  constexpr int MAXG = NPER <= 4 ? 8 : 32 / NPER;      // groups the accumulators are sized for (at most 32 lines)
   constexpr int NL = MAXG * NPER;
   const int N = G * NPER, NS = N + 1 + (N & 1);
   float2* yt = compose_lds;                              // [SHF_TB][NS]
@@ -2379,23 +2429,26 @@ __global__ __launch_bounds__(256) void k_compose_sh_bwd_fused(const float2* __re
       gh[l] = v;
     }
     const float* swb = sw + b * N;
-    float mine = 0.f;
+    float dot[NL];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
-      if (g < G) {
 #pragma unroll
-        for (int l = 0; l < NPER; ++l) {
-          const int n = g * NPER + l;
+      for (int l = 0; l < NPER; ++l) {
+        const int n = g * NPER + l;
+        dot[n] = 0.f;
+        if (g < G) {
           const float s = swb[n];
           acc[n].x += s * gh[l].x;
           acc[n].y += s * gh[l].y;
           const float2 y = yrow[n];
-          const float v = wave_sum(gh[l].x * y.x + gh[l].y * y.y);
-          if (lane == n) mine = v;
+          dot[n] = gh[l].x * y.x + gh[l].y * y.y;
         }
       }
     }
-    if (lane < N) prow[(size_t)b * N + lane] = mine * c[lane];
+    // the sums over the wave's 64 bins of all lines at once
+    static_assert(NL <= 32, "the halving exchange takes 32 values");
+    const float mine = wave_sums_transposed32<NL>(dot);
+    if (!(lane & 1) && (lane >> 1) < N) prow[(size_t)b * N + (lane >> 1)] = mine * c[lane >> 1];
   }
   // acc over the four waves: 2, 3 -> LDS -> 0, 1; 1 -> LDS -> 0
   if (wv >= 2) {
@@ -2465,7 +2518,7 @@ static int compose_sh_bwd_fused(const float2* Y, int K, int G, const float* c, c
 // (the fused pass takes nper in {1, 4, 9, 16}, lane-indexed rows of N <= 64 lines and what fits the LDS)
 static bool compose_sh_fused_ok(int K, int G, int nper, int B) {
   if (nper != 1 && nper != 4 && nper != 9 && nper != 16) return false;
-  const int maxg = nper <= 4 ? 8 : 4;
+  const int maxg = nper <= 4 ? 8 : 32 / nper;
   const int N = G * nper, NS = N + 1 + (N & 1);
   if (G > maxg || N > 64) return false;
   const size_t lds = ((size_t)SHF_TB * NS + (size_t)2 * N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);

@@ -69,3 +69,33 @@ class OracleGridTrainer:
         total.backward()
         self.optimizer.step()
         return total.item(), {k: float(v.detach()) for k, v in losses.items()}
+
+
+
+def directional_band_step(state: Dict[str, torch.Tensor], delays, analysis_matrix, z, norm_pos, amps, envelopes,
+                          num_groups: int, n_per_group: int, num_fourier_features: int, mix_samps: int, edc_samps: int,
+                          edc_weight: float = 1.0):
+    """Forward, directional EDC loss and backward of ONE band-step of the directional model on the CPU (test
+    infrastructure / bench cpu_baseline; reference model.py:1043-1094, trainer.py:853-865, losses.py:333-371): the
+    reference's arithmetic under autograd -- complex128 resolvent by torch.linalg.inv, float64 elsewhere.
+    ``state``: the module's state dict (CPU tensors).  Returns (loss, H_sh, H_dir, {parameter name: gradient})."""
+    sd = {k: v.detach().cpu().clone() for k, v in state.items()}
+    prm = {k: sd[k].clone().requires_grad_(True) for k in ('input_gains', 'output_gains', 'feedback_loop.M')}
+    root = 'sh_output_scalars.mlp.model.'
+    idx = sorted({int(k[len(root):].split('.')[0]) for k in sd if k.startswith(root)})
+    lin, norm = [], []
+    for i in idx:
+        w = sd[f'{root}{i}.weight'].clone().requires_grad_(True)
+        b_ = sd[f'{root}{i}.bias'].clone().requires_grad_(True)
+        (lin if w.ndim == 2 else norm).append((w, b_))
+        prm[f'{root}{i}.weight'], prm[f'{root}{i}.bias'] = w, b_
+    dl = torch.as_tensor(delays, dtype=torch.float32)
+    Amat = orc.coupled_feedback_matrix(prm['feedback_loop.M'], sd['feedback_loop.alpha'])
+    P = orc.feedback_loop_forward(z, dl, sd['delay_filters'], Amat)
+    enc = orc.sinusoidal_encoding(norm_pos, num_fourier_features)
+    w_sh = orc.normalise_sh_weights(orc.mlp_forward(enc, lin, norm).reshape(-1, num_groups, n_per_group))
+    H_sh = orc.directional_forward(z, prm['input_gains'], prm['output_gains'], w_sh, P, num_groups, n_per_group)
+    H_dir = orc.sh_to_directional(torch.as_tensor(analysis_matrix), H_sh)
+    loss = edc_weight * orc.directional_edc_loss(H_dir, amps, envelopes, mix_samps, edc_samps)
+    loss.backward()
+    return loss.detach(), H_sh.detach(), H_dir.detach(), {k: v.grad for k, v in prm.items() if v.grad is not None}

@@ -361,34 +361,19 @@ def test_directional_full_size_forward_backward_vs_oracle():
     loss = crit(H_dir, amps.to(DEV))
     loss.backward()
 
-    # ---- oracle (CPU, float64 / complex128 with the reference's casts)
-    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    prm = {k: sd[k].clone().requires_grad_(True) for k in ('input_gains', 'output_gains', 'feedback_loop.M')}
-    root = 'sh_output_scalars.mlp.model.'
-    idx = sorted({int(k[len(root):].split('.')[0]) for k in sd if k.startswith(root)})
-    lin, norm = [], []
-    for i in idx:
-        w, b_ = sd[f'{root}{i}.weight'].clone().requires_grad_(True), sd[f'{root}{i}.bias'].clone().requires_grad_(True)
-        (lin if w.ndim == 2 else norm).append((w, b_))
-        prm[f'{root}{i}.weight'], prm[f'{root}{i}.bias'] = w, b_
-    dl = torch.tensor(delays, dtype=torch.float32)
-    Amat = orc.coupled_feedback_matrix(prm['feedback_loop.M'], sd['feedback_loop.alpha'])
-    P = orc.feedback_loop_forward(z, dl, sd['delay_filters'], Amat)
-    enc = orc.sinusoidal_encoding(pos, 4)
-    w_sh = orc.normalise_sh_weights(orc.mlp_forward(enc, lin, norm).reshape(-1, Gd, L))
-    H_sh_o = orc.directional_forward(z, prm['input_gains'], prm['output_gains'], w_sh, P, Gd, L)
-    H_dir_o = orc.sh_to_directional(torch.tensor(A), H_sh_o)
-    loss_o = orc.directional_edc_loss(H_dir_o, amps, crit.envelopes.cpu(), orc.ms_to_samps(mix_ms, FS),
-                                      orc.ms_to_samps(edc_len_ms, FS))
-    loss_o.backward()
+    # ---- oracle (CPU, float64 / complex128 with the reference's casts): oracle/cpu_trainer.directional_band_step
+    from oracle.cpu_trainer import directional_band_step
+    loss_o, H_sh_o, H_dir_o, grads_o = directional_band_step(net.state_dict(), delays, A, z, pos, amps, crit.envelopes.cpu(),
+                                                             Gd, L, 4, orc.ms_to_samps(mix_ms, FS),
+                                                             orc.ms_to_samps(edc_len_ms, FS))
 
     assert rel_err(H_sh.detach().cpu(), H_sh_o.detach()) < LOSS_TOL
     assert rel_err(H_dir.detach().cpu(), H_dir_o.detach()) < LOSS_TOL
     assert abs(loss.item() - loss_o.item()) < LOSS_TOL * abs(loss_o.item())
     for name, p_ in net.named_parameters():
-        if name not in prm or prm[name].grad is None:
+        if name not in grads_o:
             continue
-        ref = prm[name].grad.numpy()
+        ref = grads_o[name].numpy()
         err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
         assert err < GRAD_TOL, (name, err)
 
@@ -399,8 +384,8 @@ def test_directional_full_size_forward_backward_vs_oracle():
     loss2.backward()
     assert abs(loss2.item() - loss_o.item()) < LOSS_TOL * abs(loss_o.item())
     for name, p_ in net.named_parameters():
-        if name not in prm or prm[name].grad is None:
+        if name not in grads_o:
             continue
-        ref = prm[name].grad.numpy()
+        ref = grads_o[name].numpy()
         err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
         assert err < GRAD_TOL, ('forward_sh', name, err)
