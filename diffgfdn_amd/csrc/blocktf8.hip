@@ -244,10 +244,8 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
       }
       // ... and over the four lanes that hold the other S1 of the same bin
 #ifndef T8_DIAG_NO_SHFL
-      s.x += __shfl_xor(s.x, 16, 64);
-      s.y += __shfl_xor(s.y, 16, 64);
-      s.x += __shfl_xor(s.x, 32, 64);
-      s.y += __shfl_xor(s.y, 32, 64);
+      s.x = xor32_sum(xor16_sum(s.x));          // (v_permlane16/32_swap: VALU, no LDS crossbar)
+      s.y = xor32_sum(xor16_sum(s.y));
 #endif
       if (q == cg) val[p] = s;          // bin 16 cg + cidx = this lane
     }

@@ -38,6 +38,31 @@ __device__ __forceinline__ float db_pow(float x) {
 }
 
 // sum over the 64 lanes of a wavefront
+// Cross-lane sums on the VALU (DPP inside the rows of 16 lanes, v_permlane16_swap / v_permlane32_swap of gfx950 between
+// rows and half-waves).  __shfl_* compile to ds_bpermute_b32, which issues on the LDS pipe with its latency: a butterfly of
+// six of them per value made the reductions of several kernels LDS-bound.
+template <int CTRL>
+__device__ __forceinline__ float dpp_pair_sum(float v) {          // v + v of the lane CTRL pairs this one with
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xor16_sum(float x) {             // x(l) + x(l ^ 16)
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x) {             // x(l) + x(l ^ 32)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the 64 lanes, the same bits in every lane (every level adds two values that its lanes share).  ALL 64 lanes
+// must be active: a lane whose partner is switched off keeps its own value in the swaps.
+__device__ __forceinline__ float wave_sum_full(float v) {
+  v = dpp_pair_sum<0x128>(v);           // row_ror:8
+  v = dpp_pair_sum<0x124>(v);           // row_ror:4
+  v = dpp_pair_sum<0x122>(v);           // row_ror:2
+  v = dpp_pair_sum<0x121>(v);           // row_ror:1
+  return xor32_sum(xor16_sum(v));
+}
+// the general form (partial waves, divergent callers: a switched-off lane counts as zero)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

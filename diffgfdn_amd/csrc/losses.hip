@@ -511,12 +511,10 @@ __device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2
 __device__ __forceinline__ void block_scan_multi2(float2 (&v)[EDC_S], float2 (&tot)[EDC_S], float2* lds) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int s = 0; s < EDC_S; ++s) {
-      const float ox = __shfl_up(v[s].x, off, 64), oy = __shfl_up(v[s].y, off, 64);
-      if (lane >= off) { v[s].x += ox; v[s].y += oy; }
-    }
+  for (int s = 0; s < EDC_S; ++s) {
+    float tx, ty;
+    v[s].x = wave_scan_incl(v[s].x, tx);
+    v[s].y = wave_scan_incl(v[s].y, ty);
   }
   __syncthreads();
   if (lane == 63) {

@@ -13,12 +13,9 @@ __device__ __forceinline__ void block_scan_multi(float (&v)[EDC_S], float (&tot)
                                                  float* lds /* >= 16*EDC_S floats */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int s = 0; s < EDC_S; ++s) {
-      float o = __shfl_up(v[s], off, 64);
-      if (lane >= off) v[s] += o;
-    }
+  for (int s = 0; s < EDC_S; ++s) {
+    float t;
+    v[s] = wave_scan_incl(v[s], t);      // (DPP + readlane: VALU, no LDS crossbar -- common.h)
   }
   __syncthreads();
   if (lane == 63) {

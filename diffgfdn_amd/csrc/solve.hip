@@ -2333,10 +2333,6 @@ __global__ __launch_bounds__(SH_TB) void k_compose_sh_bwd_w(const float2* __rest
 // sixteen in one instruction per pair --, v_permlane16_swap does the same between the rows of 16 lanes for 8 values, and
 // inside the rows DPP (row_ror:8, row_half_mirror, quad_perm) pairs the lanes for 4, 2, 1 values and the last pair:
 // ~70 VALU instructions and no LDS traffic, against six ds_bpermute + six adds per value.  Lane l returns sum l >> 1.
-template <int CTRL>
-__device__ __forceinline__ float dpp_pair_sum(float v) {          // v + v of the lane CTRL pairs this one with
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
 template <int NV>
 __device__ __forceinline__ float wave_sums_transposed32(const float (&v)[NV]) {
   const int lane = threadIdx.x & 63;
@@ -2382,12 +2378,12 @@ __device__ __forceinline__ float wave_sums_transposed32(const float (&v)[NV]) {
 // owns SHF_TB bins; its four waves split the receivers, lane = bin.  Per receiver a thread loads its nper gradient
 // values (coalesced 512-byte rows), accumulates acc[n] += w[b][n] gH'[b][l(n)] in registers (static indices: g and l are
 // unrolled) and forms Re(conj(gH') Y[k][n]), summed over the wave's 64 bins -> one partial row of gw per (tile, b).
-// The waves' acc are then summed through LDS (two rounds), wave 0 writes gY through the staged Y tile and the tile's
+// The waves' acc are then summed through LDS (wave 3 -> 2 -> 1 -> 0), wave 0 writes gY through the staged Y tile and the tile's
 // partial of gc.  1025 workgroups x 4 waves instead of 513 x 2 that looped over every receiver, and the second launch
 // (k_compose_sh_bwd_w, another 151 MB read of gH) is gone.
 #define SHF_TB 64
 template <int NPER>
-__global__ __launch_bounds__(256) void k_compose_sh_bwd_fused(const float2* __restrict__ Y, int K, int G,
+__global__ __launch_bounds__(256, 4) void k_compose_sh_bwd_fused(const float2* __restrict__ Y, int K, int G,
                                                               const float* __restrict__ c,
                                                               const float* __restrict__ w, int B,
                                                               const float2* __restrict__ filt,
@@ -2398,8 +2394,8 @@ __global__ __launch_bounds__(256) void k_compose_sh_bwd_fused(const float2* __re
   constexpr int NL = MAXG * NPER;
   const int N = G * NPER, NS = N + 1 + (N & 1);
   float2* yt = compose_lds;                              // [SHF_TB][NS]
-  float2* red = yt + SHF_TB * NS;                        // [2][N][SHF_TB]
-  float* sw = (float*)(red + 2 * N * SHF_TB);            // [B][N]
+  float2* red = yt + SHF_TB * NS;                        // [N][SHF_TB]
+  float* sw = (float*)(red + N * SHF_TB);                // [B][N]
   const int tile = blockIdx.x, k0 = tile * SHF_TB;
   const int nbin = K - k0 < SHF_TB ? K - k0 : SHF_TB;
   const size_t base = (size_t)k0 * N;
@@ -2450,29 +2446,26 @@ __global__ __launch_bounds__(256) void k_compose_sh_bwd_fused(const float2* __re
     const float mine = wave_sums_transposed32<NL>(dot);
     if (!(lane & 1) && (lane >> 1) < N) prow[(size_t)b * N + (lane >> 1)] = mine * c[lane >> 1];
   }
-  // acc over the four waves: 2, 3 -> LDS -> 0, 1; 1 -> LDS -> 0
-  if (wv >= 2) {
+  // acc over the four waves through ONE (N, 64) buffer: 3 -> 2 -> 1 -> 0 (fixed order ((a3 + a2) + a1) + a0)
+#pragma unroll 1
+  for (int src = 3; src >= 1; --src) {
+    if (wv == src) {
 #pragma unroll
-    for (int n = 0; n < NL; ++n) if (n < N) red[((wv - 2) * N + n) * SHF_TB + lane] = acc[n];
-  }
-  __syncthreads();
-  if (wv < 2) {
+      for (int n = 0; n < NL; ++n) if (n < N) red[n * SHF_TB + lane] = acc[n];
+    }
+    __syncthreads();
+    if (wv == src - 1) {
 #pragma unroll
-    for (int n = 0; n < NL; ++n) if (n < N) { const float2 o = red[(wv * N + n) * SHF_TB + lane]; acc[n].x += o.x; acc[n].y += o.y; }
+      for (int n = 0; n < NL; ++n) if (n < N) { const float2 o = red[n * SHF_TB + lane]; acc[n].x += o.x; acc[n].y += o.y; }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wv == 1) {
-#pragma unroll
-    for (int n = 0; n < NL; ++n) if (n < N) red[n * SHF_TB + lane] = acc[n];
-  }
-  __syncthreads();
   if (wv == 0) {
     float mine = 0.f;
 #pragma unroll
     for (int n = 0; n < NL; ++n) {
       if (n < N) {
-        const float2 o = red[n * SHF_TB + lane];
-        const float2 a = make_float2(acc[n].x + o.x, acc[n].y + o.y);
+        const float2 a = acc[n];
         const float2 y = yrow[n];
         const float v = wave_sum(valid ? (a.x * y.x + a.y * y.y) : 0.f);
         if (lane == n) mine = v;
@@ -2506,7 +2499,7 @@ template <int NPER>
 static int compose_sh_bwd_fused(const float2* Y, int K, int G, const float* c, const float* w, int B, const float2* filt,
                                 const float2* gH, float2* gY, float* gc, float* gw, float* work, hipStream_t s) {
   const int N = G * NPER, NS = N + 1 + (N & 1), ntiles = (K + SHF_TB - 1) / SHF_TB;
-  const size_t lds = ((size_t)SHF_TB * NS + (size_t)2 * N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);
+  const size_t lds = ((size_t)SHF_TB * NS + (size_t)N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);
   int rc = ensure_dyn_lds(k_compose_sh_bwd_fused<NPER>, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k_compose_sh_bwd_fused<NPER>, dim3(ntiles), dim3(256), lds, s, Y, K, G, c, w, B, filt, gH, gY, work);
@@ -2521,7 +2514,7 @@ static bool compose_sh_fused_ok(int K, int G, int nper, int B) {
   const int maxg = nper <= 4 ? 8 : 32 / nper;
   const int N = G * nper, NS = N + 1 + (N & 1);
   if (G > maxg || N > 64) return false;
-  const size_t lds = ((size_t)SHF_TB * NS + (size_t)2 * N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);
+  const size_t lds = ((size_t)SHF_TB * NS + (size_t)N * SHF_TB) * sizeof(float2) + (size_t)B * N * sizeof(float);
   return lds <= 64 * 1024 && (K + SHF_TB - 1) / SHF_TB <= GFDN_SH_MAX_TILES * (SH_TB / SHF_TB);
 }
 
