@@ -73,6 +73,8 @@ class FusedBankStep:
     # The gains pass it removes runs beside the records pass on the side stream, off the main chain, while the
     # accumulation lengthens a pass that is ON it.
     fold_gains = False
+    # the optimiser update on the side stream behind the gain network's backward (single process)
+    adam_on_side = os.environ.get('GFDN_ADAM_ON_SIDE', '1') == '1'
     # STFT -> EDR and the EDC term as ONE launch, one workgroup per item (gfdn_decay_items_fwd) instead of the pair STFT,
     # the EDR column kernel and the three EDC scans.
     fuse_decay = os.environ.get('GFDN_FUSE_DECAY', '0') == '1'      # (OFF: measured slower; the switch is for same-box A/B runs)
@@ -433,12 +435,22 @@ class FusedBankStep:
                 torch.autograd.graph.increment_version(tr.optimizer._params)
                 sums_total = (sums, total)
                 return self._finish_pipe(pipe, sums_total, out3, nb, main, side, side2)
-            main.wait_event(ev['mlpb'])
             tr.optimizer._packed = True               # the flat gradient buffer is complete
-            if opt_step:
-                red = self.finish(allreduce)
-                if red is not None:
-                    sums, total = red
+            if opt_step and allreduce is None and side2 is not None and self.adam_on_side:
+                # single process: the update runs on the branch that finishes LAST (the gain network's backward), behind
+                # an event of the main stream that was signalled earlier -- a wait on a long-signalled event is free,
+                # while the main stream, idle when the side branch signals, would pay the 8-12 us of a cross-queue wake-up
+                ev_pg = torch.cuda.Event()
+                ev_pg.record()
+                with on_side2():
+                    torch.cuda.current_stream().wait_event(ev_pg)
+                    self.finish(None)
+            else:
+                main.wait_event(ev['mlpb'])
+                if opt_step:
+                    red = self.finish(allreduce)
+                    if red is not None:
+                        sums, total = red
         else:
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
