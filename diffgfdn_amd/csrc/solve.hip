@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd(SolveArgs a, const float2* __
 }
 
 // ------------------------------------------------------------------------------------------
-// Blocks of 9 ... 12 lines (the directional model: 9 SH channels per group): NP = n lanes per system, PACKED -- 64 / NP
+// Blocks of 10 ... 12 lines: NP = n lanes per system, PACKED -- 64 / NP
 // systems per wavefront (7 for n = 9) instead of the 4 that the power-of-two kernel above fits with 16 lanes each, seven
 // of them idle.  Lane groups of a non-power-of-two size have no xor butterfly: the pivot search reads the NP candidates
 // with NP shuffles (every lane of the group reaches the same choice, ties to the lowest row as above) and rows are
@@ -468,6 +468,255 @@ __global__ __launch_bounds__(256) void k_solve_bwd_pk(SolveArgs a, const float2*
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Blocks of 9 lines (the directional model: 9 SH channels per group): THREE ROWS PER LANE.  A system of NP rows
+// sits on LPS = ceil(NP / 3) lanes (lane t holds rows t, t + LPS, t + 2 LPS), 64 / LPS systems per wavefront: 21 for
+// n = 9.  What limits the lane-parallel elimination is the LDS crossbar: every value that crosses lanes is a
+// ds_bpermute_b32 for the whole wave, and with one row per lane a 9 x 9 solve costs 189 of them per 7 systems (pivot
+// search 9 per column, pivot row 2 (9 - j) + 2).  With three rows per lane the pivot search is a local compare plus LPS
+// exchanges of ONE key (|a|^2 with the row number in its four low mantissa bits), the pivot row still costs
+// 2 (9 - j) + 2 exchanges -- but now per 21 systems: 6.4 instead of 27 crossbar operations per system, and the
+// elimination arithmetic per system is unchanged.  Partial pivoting by magnitude (ties and magnitudes equal to 19 bits:
+// the lowest row), virtual row exchange as in the kernels above; results agree with them to rounding.
+// ------------------------------------------------------------------------------------------
+#define RL_R 3
+template <int NP>
+struct RlLane {
+  static constexpr int LPS = (NP + RL_R - 1) / RL_R, GPW = 64 / LPS;
+  static_assert(LPS * RL_R == NP, "every lane of a system holds RL_R rows");
+  int t, base, grp;
+  bool ok;
+  __device__ __forceinline__ RlLane() {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g0 = lane / LPS;
+    ok = g0 < GPW;                        // (the lanes left over at the end of the wave shadow the last system: same
+    const int gl = ok ? g0 : GPW - 1;     //  control flow, nothing stored)
+    base = gl * LPS;
+    t = lane - g0 * LPS;
+    grp = wv * GPW + gl;
+  }
+};
+// row r of  diag(zeta) - A  (swap: of diag(zeta) - A^T), A (NP, NP) in LDS
+template <int NP>
+__device__ __forceinline__ void rl_build_row(float2 (&row)[NP], const float* sA, int r, bool swap, float2 diag) {
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    const float av = swap ? sA[c * NP + r] : sA[r * NP + c];
+    row[c] = make_float2((c == r ? diag.x : 0.f) - av, c == r ? diag.y : 0.f);
+  }
+}
+
+// (by value: a conditional expression over array ELEMENTS is an lvalue -- the compiler selects the address, the index becomes
+// dynamic and the whole row array moves to scratch)
+__device__ __forceinline__ float2 rl_pick(int q, float2 a0, float2 a1, float2 a2) {
+  return make_float2(q == 0 ? a0.x : (q == 1 ? a1.x : a2.x), q == 0 ? a0.y : (q == 1 ? a1.y : a2.y));
+}
+// On return row q of the lane (global row t + LPS q) is the pivot row of column pivcol[q] and x[pivcol[q]] = rhs[q] pivinv[q].
+// n = NP exactly (the dispatch guarantees it): no guards on the order in the body.
+template <int NP>
+__device__ __forceinline__ void gauss_jordan_rl(float2 (&row)[RL_R][NP], float2 (&rhs)[RL_R], int t, int base,
+                                                int (&pivcol)[RL_R], float2 (&pivinv)[RL_R]) {
+  constexpr int LPS = RlLane<NP>::LPS;
+  bool used[RL_R];
+#pragma unroll
+  for (int q = 0; q < RL_R; ++q) {
+    used[q] = false;
+    pivcol[q] = 0;
+    pivinv[q] = make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    // the lane's candidate: largest |a_qj|^2 among its unused rows, row number in the low bits (15 - row: ties go to the
+    // lowest row; a candidate's key is never 0)
+    unsigned key = 0u;
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) {
+      const float mag = row[q][j].x * row[q][j].x + row[q][j].y * row[q][j].y;
+      const unsigned kq = (__float_as_uint(mag) & ~15u) | (unsigned)(15 - (t + LPS * q));
+      key = (!used[q] && kq > key) ? kq : key;
+    }
+    unsigned best = 0u;
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+      const unsigned o = (unsigned)__shfl((int)key, base + i, 64);
+      best = o > best ? o : best;
+    }
+    const int brow = 15 - (int)(best & 15u), bq = brow / LPS, bl = brow - bq * LPS;
+    float2 pr[NP];
+#pragma unroll
+    for (int c = j; c < NP; ++c) {
+      const float2 sel = rl_pick(bq, row[0][c], row[1][c], row[2][c]);
+      pr[c].x = __shfl(sel.x, base + bl, 64);
+      pr[c].y = __shfl(sel.y, base + bl, 64);
+    }
+    const float2 rsel = rl_pick(bq, rhs[0], rhs[1], rhs[2]);
+    float2 prhs;
+    prhs.x = __shfl(rsel.x, base + bl, 64);
+    prhs.y = __shfl(rsel.y, base + bl, 64);
+    const float2 inv = cinv(pr[j]);
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) {
+      const bool piv = t + LPS * q == brow;
+      used[q] = used[q] || piv;
+      pivcol[q] = piv ? j : pivcol[q];
+      pivinv[q] = make_float2(piv ? inv.x : pivinv[q].x, piv ? inv.y : pivinv[q].y);
+      // (the pivot row itself takes f = 0: no branch)
+      float2 f = cmul(row[q][j], inv);
+      f = make_float2(piv ? 0.f : f.x, piv ? 0.f : f.y);
+#pragma unroll
+      for (int c = j + 1; c < NP; ++c) {
+        row[q][c].x -= f.x * pr[c].x - f.y * pr[c].y;
+        row[q][c].y -= f.x * pr[c].y + f.y * pr[c].x;
+      }
+      rhs[q].x -= f.x * prhs.x - f.y * prhs.y;
+      rhs[q].y -= f.x * prhs.y + f.y * prhs.x;
+      row[q][j] = make_float2(piv ? row[q][j].x : 0.f, piv ? row[q][j].y : 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (column by column: scheduled across columns the exchanges pile up in registers)
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve_fwd_rl(SolveArgs a, float2* __restrict__ Y) {
+  constexpr int LPS = RlLane<NP>::LPS, SPB = 4 * RlLane<NP>::GPW;
+  __shared__ float s_A[NP * NP];
+  const RlLane<NP> L;
+  const int blk = blockIdx.y, N = a.nblk * NP;
+  for (int e = threadIdx.x; e < NP * NP; e += blockDim.x) s_A[e] = a.A[(size_t)blk * NP * NP + e];
+  __syncthreads();
+  const int k = blockIdx.x * SPB + L.grp;
+  const bool valid = L.ok && k < a.K;
+  const int kk = k < a.K ? k : a.K - 1;
+  float2 row[RL_R][NP], rhs[RL_R], pivinv[RL_R];
+  int pivcol[RL_R];
+#pragma unroll
+  for (int q = 0; q < RL_R; ++q) {
+    const int r = L.t + LPS * q, i = blk * NP + r;
+    const float2 zeta = zeta_abs(a, kk, i, Cx<float2>::zeta(a.turns, a.logr, kk, a.delays[i], Cx<float2>::ig(a, i)));
+    rl_build_row<NP>(row[q], s_A, r, a.transpose != 0, zeta);
+    rhs[q] = make_float2(a.b[i], 0.f);
+  }
+  gauss_jordan_rl<NP>(row, rhs, L.t, L.base, pivcol, pivinv);
+  if (valid) {
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) Y[(size_t)k * N + blk * NP + pivcol[q]] = cmul(rhs[q], pivinv[q]);
+  }
+}
+
+template <int NP, bool SAVED>
+__global__ __launch_bounds__(256) void k_solve_bwd_rl(SolveArgs a, const float2* __restrict__ gY,
+                                                      const float2* __restrict__ Ysaved,
+                                                      float* __restrict__ partial) {
+  constexpr int LPS = RlLane<NP>::LPS, GPW = RlLane<NP>::GPW, SPB = 4 * GPW;
+  // natural-order solutions of the wave's systems (every wave reads only what it wrote: LDS operations of a wave execute
+  // in order, no block barrier inside the loop); one more slot set for the lanes that shadow the last system
+  __shared__ float2 s_y[(SPB + 4) * NP], s_w[(SPB + 4) * NP];
+  __shared__ float s_acc[SPB * NP * (NP + 2)];
+  __shared__ float s_A[NP * NP];
+  const RlLane<NP> L;
+  const int t = L.t, grp = L.grp, base = L.base;
+  const int blk = blockIdx.y, N = a.nblk * NP;
+  const bool tr = a.transpose != 0;
+  for (int e = threadIdx.x; e < NP * NP; e += blockDim.x) s_A[e] = a.A[(size_t)blk * NP * NP + e];
+  __syncthreads();
+  int li[RL_R];
+  float m_i[RL_R], b_i[RL_R], ig_i[RL_R];
+#pragma unroll
+  for (int q = 0; q < RL_R; ++q) {
+    li[q] = blk * NP + t + LPS * q;
+    m_i[q] = a.delays[li[q]];
+    b_i[q] = a.b[li[q]];
+    ig_i[q] = Cx<float2>::ig(a, li[q]);
+  }
+  float acc[RL_R][NP], accb[RL_R], accg[RL_R];
+#pragma unroll
+  for (int q = 0; q < RL_R; ++q) {
+    accb[q] = 0.f;
+    accg[q] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) acc[q][c] = 0.f;
+  }
+  // (shadow lanes write their copies into the spare slot set of their wave)
+  const int slot = L.ok ? grp : SPB + (threadIdx.x >> 6);
+  float2* sy = s_y + slot * NP;
+  float2* sw = s_w + slot * NP;
+
+#pragma unroll 1
+  for (int k0 = blockIdx.x * SPB; k0 < a.K; k0 += gridDim.x * SPB) {
+    const int k = k0 + grp;
+    const bool valid = L.ok && k < a.K;
+    const int kk = k < a.K ? k : a.K - 1;
+    float2 zpow[RL_R], zeta[RL_R], row[RL_R][NP], rhs[RL_R], pivinv[RL_R];
+    int pivcol[RL_R];
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) {
+      zpow[q] = Cx<float2>::zeta(a.turns, a.logr, kk, m_i[q], 1.0f);
+      zeta[q] = zeta_abs(a, kk, li[q], cscale(zpow[q], ig_i[q]));
+    }
+    if (SAVED) {
+#pragma unroll
+      for (int q = 0; q < RL_R; ++q) sy[t + LPS * q] = Ysaved[(size_t)kk * N + li[q]];
+    } else {
+#pragma unroll
+      for (int q = 0; q < RL_R; ++q) {
+        rl_build_row<NP>(row[q], s_A, t + LPS * q, tr, zeta[q]);
+        rhs[q] = make_float2(b_i[q], 0.f);
+      }
+      gauss_jordan_rl<NP>(row, rhs, t, base, pivcol, pivinv);
+#pragma unroll
+      for (int q = 0; q < RL_R; ++q) sy[pivcol[q]] = cmul(rhs[q], pivinv[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) {
+      rl_build_row<NP>(row[q], s_A, t + LPS * q, !tr, cconj(zeta[q]));
+      rhs[q] = gY[(size_t)kk * N + li[q]];
+    }
+    gauss_jordan_rl<NP>(row, rhs, t, base, pivcol, pivinv);
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) sw[pivcol[q]] = cmul(rhs[q], pivinv[q]);
+    // gT_ij = -w_i conj(y_j);  T = D - A  (or D - A^T)
+    //   transpose=0: gA[i][j] = Re(w_i conj(y_j));  transpose=1: gA[i][j] = Re(w_j conj(y_i))
+    const float2* so = tr ? sw : sy;
+    float2 other[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) other[c] = so[c];
+    const float live = valid ? 1.0f : 0.f;
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) {
+      const float2 ynat = cscale(sy[t + LPS * q], live), wnat = cscale(sw[t + LPS * q], live);
+      const float2 mine = tr ? ynat : wnat;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) acc[q][c] += mine.x * other[c].x + mine.y * other[c].y;
+      accb[q] += wnat.x;
+      // g inv_gamma_i = Re(conj(gT_ii) z^m) = -Re(conj(w_i) y_i z^m)
+      const float2 yz = cmul(ynat, zpow[q]);
+      accg[q] -= wnat.x * yz.x + wnat.y * yz.y;
+    }
+  }
+  // deterministic reduction over the SPB lane groups of this block
+  if (L.ok) {
+#pragma unroll
+    for (int q = 0; q < RL_R; ++q) {
+      const int r = t + LPS * q;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) s_acc[(grp * NP + r) * (NP + 2) + c] = acc[q][c];
+      s_acc[(grp * NP + r) * (NP + 2) + NP] = accb[q];
+      s_acc[(grp * NP + r) * (NP + 2) + NP + 1] = accg[q];
+    }
+  }
+  __syncthreads();
+  constexpr int per = NP * NP + 2 * NP;
+  float* out = partial + ((size_t)blockIdx.x * a.nblk + blk) * per;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    int rr, cc;
+    if (e < NP * NP) { rr = e / NP; cc = e % NP; }
+    else if (e < NP * NP + NP) { rr = e - NP * NP; cc = NP; }
+    else { rr = e - NP * NP - NP; cc = NP + 1; }
+    float sum = 0.f;
+    for (int g2 = 0; g2 < SPB; ++g2) sum += s_acc[(g2 * NP + rr) * (NP + 2) + cc];
+    out[e] = sum;
+  }
+}
+
 // out[e] = sum_p partial[p][e]; one 256-thread block per output element, fixed-order tree
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial,
                                                          int nparts, int per,
@@ -496,6 +745,7 @@ __global__ __launch_bounds__(256) void k_solve_bwd_finish(const float* __restric
   else if (o < n * n + n) gb[blk * n + (o - n * n)] = s;
   else gig[blk * n + (o - n * n - n)] = s;
 }
+
 
 
 // ------------------------------------------------------------------------------------------
@@ -1026,13 +1276,13 @@ static int solve_fwd_run(const double* turns, const double* logr, int K, int nbl
   if (!Y) return GFDN_E_BADARG;
   SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz, ig64};
   const int np = pick_np(nper);
-  const int pk = (!precise && nper >= 9 && nper <= 12) ? nper : 0;       // packed lane groups (k_solve_fwd_pk)
-  const int spb = pk ? 4 * (64 / pk) : 256 / np;
+  const int pk = (!precise && nper >= 9 && nper <= 12) ? nper : 0;       // three rows per lane (k_solve_fwd_rl)
+  const int spb = pk == 9 ? 4 * (64 / ((pk + RL_R - 1) / RL_R)) : (pk ? 4 * (64 / pk) : 256 / np);
   dim3 grid((K + spb - 1) / spb, nblk), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (pk) {
     switch (pk) {
-      case 9: hipLaunchKernelGGL(k_solve_fwd_pk<9>, grid, block, 0, s, a, (float2*)Y); break;
+      case 9: hipLaunchKernelGGL(k_solve_fwd_rl<9>, grid, block, 0, s, a, (float2*)Y); break;
       case 10: hipLaunchKernelGGL(k_solve_fwd_pk<10>, grid, block, 0, s, a, (float2*)Y); break;
       case 11: hipLaunchKernelGGL(k_solve_fwd_pk<11>, grid, block, 0, s, a, (float2*)Y); break;
       default: hipLaunchKernelGGL(k_solve_fwd_pk<12>, grid, block, 0, s, a, (float2*)Y); break;
@@ -1143,8 +1393,8 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
   if (!gY || !gA || !gb || !ginv_gamma || !work) return GFDN_E_BADARG;
   SolveArgs a{turns, logr, K, nblk, nper, A, delays, inv_gamma, b, transpose, g_igz, ig64};
   const int np = pick_np(nper);
-  const int pk = (!precise && nper >= 9 && nper <= 12) ? nper : 0;       // packed lane groups (k_solve_bwd_pk)
-  const int spb = pk ? 4 * (64 / pk) : 256 / np;
+  const int pk = (!precise && nper >= 9 && nper <= 12) ? nper : 0;       // three rows per lane (k_solve_bwd_rl)
+  const int spb = pk == 9 ? 4 * (64 / ((pk + RL_R - 1) / RL_R)) : (pk ? 4 * (64 / pk) : 256 / np);
   int nparts = (K + spb - 1) / spb;
   if (nparts > GFDN_PARTIAL_BLOCKS) nparts = GFDN_PARTIAL_BLOCKS;
   const bool lin = !precise && np == 4 && nblk <= S4_MAXBLK;
@@ -1176,7 +1426,10 @@ static int solve_bwd_run(const double* turns, const double* logr, int K, int nbl
   }
   if (pk) {
     switch (pk) {
-      case 9: hipLaunchKernelGGL(k_solve_bwd_pk<9>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
+      case 9:
+        if (Y) hipLaunchKernelGGL((k_solve_bwd_rl<9, true>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial);
+        else hipLaunchKernelGGL((k_solve_bwd_rl<9, false>), grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial);
+        break;
       case 10: hipLaunchKernelGGL(k_solve_bwd_pk<10>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
       case 11: hipLaunchKernelGGL(k_solve_bwd_pk<11>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
       default: hipLaunchKernelGGL(k_solve_bwd_pk<12>, grid, block, 0, s, a, (const float2*)gY, (const float2*)Y, partial); break;
