@@ -539,7 +539,7 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
     sub-band filter -> directional responses (analysis matrix) -> directional EDC loss against the
     common-slope amplitudes, plus the colorless terms."""
 
-    concurrent_branches = False
+    concurrent_branches = os.environ.get('GFDN_DIR_TWO_STREAMS', '1') == '1'
     # directional EDC term on irfft(H_sh) mixed in the time domain (losses.directional_edc_loss.forward_sh) instead of
     # irfft(A H_sh): same numbers to rounding, 3/4 of the transforms at order 2
     mix_in_time = True
@@ -565,11 +565,52 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
             write_wav(os.path.join(str(directory), name), self.net.sample_rate, hc[r].T)
         return (out[0], out[1]) if self.use_colorless_loss else out[0]
 
+    def _side_stream(self):
+        if not self.concurrent_branches or not next(self.net.parameters()).is_cuda:
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def _forward_two_streams(self, data: Dict, filt, side):
+        """The module's forward (model.py:1043-1094) with its two branches on two streams: the sub-FDN branch of the
+        colorless loss (raw-block solve, group sums, spectral + sparsity terms) shares nothing with the SH-domain branch
+        but the parameters and the rotations; its elimination kernels are bound by the LDS crossbar, the other branch's
+        transforms by HBM.  autograd replays each backward operator on its forward stream."""
+        from .functional import SHOutputStage
+        net, cfg = self.net, self.config
+        z = data['z_values']
+        fl = net.feedback_loop
+        fl.new_forward()
+        net.batch_size = data['listener_position'].shape[0]
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fl.group_rotations()                         # (Q, QQ: both branches read them)
+            ready = torch.cuda.Event()
+            ready.record(side)
+            H_sub = net.sub_fdn_output(z)
+            terms = ColorlessTerms.apply(H_sub[0].T.contiguous(), fl.group_rotations(), cfg.use_asym_spectral_loss,
+                                         cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
+                                         shard_loss_scales(self.world_size, 1, 1.0)['colorless'], True)
+        w = net.sh_output_scalars(data, normalise_weights=True)
+        main.wait_event(ready)
+        Y = net.delay_line_responses(z, transpose=True)
+        H_sh = SHOutputStage.apply(Y, net.output_gains.reshape(-1), w.to(torch.float32), net.num_groups,
+                                   net.num_delay_lines_per_group, filt)
+        return H_sh, terms
+
     def _step_losses(self, data: Dict) -> Dict:
         net, cfg = self.net, self.config
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
-        out = net(data, subband_filter=filt)
-        H_sh, H_sub = out if net.use_colorless_loss else (out, None)
+        side = self._side_stream() if (self.use_colorless_loss and net.use_colorless_loss) else None
+        terms = None
+        if side is not None:
+            H_sh, terms = self._forward_two_streams(data, filt, side)
+            H_sub = None
+        else:
+            out = net(data, subband_filter=filt)
+            H_sh, H_sub = out if net.use_colorless_loss else (out, None)
         # (the weight rides the kernel's gradient scale and the term enters the total with factor 1: the backward skips
         # the pass that would multiply the gradient by the upstream scalar)
         crit = self.criterion[0]
@@ -585,9 +626,15 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         if self.use_colorless_loss:
             # spectral + sparsity (last group only, reference :298-313), weighted, / world size: values and both
             # gradients in two launches (the tensor-operator form took 11 forward and 8 backward)
-            terms = ColorlessTerms.apply(H_sub[0].T.contiguous(), net.feedback_loop.group_rotations(),
-                                         cfg.use_asym_spectral_loss, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
-                                         shard_loss_scales(self.world_size, 1, 1.0)['colorless'], True)
+            if terms is None:
+                terms = ColorlessTerms.apply(H_sub[0].T.contiguous(), net.feedback_loop.group_rotations(),
+                                             cfg.use_asym_spectral_loss, cfg.spectral_loss_weight,
+                                             cfg.sparsity_loss_weight,
+                                             shard_loss_scales(self.world_size, 1, 1.0)['colorless'], True)
+            else:
+                torch.cuda.current_stream().wait_stream(side)
+                for t_ in terms:
+                    t_.record_stream(torch.cuda.current_stream())
             total = total + terms[0]
             losses.update({'spectral_loss': terms[1].detach(), 'sparsity_loss': terms[2].detach()})
         losses['_total'] = total
