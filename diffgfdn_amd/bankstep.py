@@ -308,12 +308,20 @@ class FusedBankStep:
                 _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                          dturn=gridK.dturn)
         ev['norm'].record()
-        if pipe is None:
-            main.wait_event(ev['mlp'])
-        elif pipe.ready is not None:
-            main.wait_event(pipe.ready)
+
+        def wait_gains():
+            if pipe is None:
+                main.wait_event(ev['mlp'])
+            elif pipe.ready is not None:
+                main.wait_event(pipe.ready)
+
         fold = (self.fold_output_stage and pairs and K == 65537 and (Btot // nb) % 2 == 0 and G <= 4
                 and self.halves < 2)
+        # the receiver gains come from the side stream: with the output stage folded into the transform the transfer-function
+        # launch below does not read them, and the wait goes behind it -- by then the event was signalled long ago (a wait on
+        # a signalled event is free; in front of the launch the idle main stream paid a cross-queue wake-up of ~12 us)
+        if not fold:
+            wait_gains()
         if big:
             Ts, Tq8 = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=True)
             # (the colorless pass of the 8-line blocks is VALU-bound like this launch: it starts behind it and runs
@@ -338,6 +346,7 @@ class FusedBankStep:
             Tq, H = H, None
 
             def x_fn():
+                wait_gains()
                 x2, h0 = ops.irfft_odd_pairs_compose_fwd(direct, rows, Tq, rgain, filt, K, nb)
                 keep.extend((h0, Tq))
                 return x2
