@@ -73,6 +73,7 @@ class FusedBankStep:
     # The gains pass it removes runs beside the records pass on the side stream, off the main chain, while the
     # accumulation lengthens a pass that is ON it.
     fold_gains = False
+    colorless_behind_scans = os.environ.get('GFDN_COLORLESS_LATE', '1') == '1'      # (blocks of 5..8 lines)
     # the optimiser update on the side stream behind the gain network's backward (single process)
     adam_on_side = os.environ.get('GFDN_ADAM_ON_SIDE', '1') == '1'
     # STFT -> EDR and the EDC term as ONE launch, one workgroup per item (gfdn_decay_items_fwd) instead of the pair STFT,
@@ -352,24 +353,31 @@ class FusedBankStep:
                 return x2
         keep.extend((coef_sub, ework, Q, QQ, coef, rgain, xhat, rstd, scale, H, Ts))
 
-        # ---- colorless pass (spectral loss + dL/drecords of the sub-FDNs, sparsity): on the EDC stream in front of the
-        # scans, beside the output stage and the transform (behind the scans it ran beside the STFT adjoint: same step
-        # time either way, measured)
-        with on_side2():
-            torch.cuda.current_stream().wait_event(ev['norm'])
-            if big:
-                torch.cuda.current_stream().wait_event(ev_ts)
-                grec_sub, loss_g = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
-                                                     cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
-                                                     dturn=gridK.dturn)
-            else:
-                grec_sub, loss_g = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
-                                                    cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
-                                                    dturn=gridK.dturn)
-            out3, gQ = ops.colorless_terms(loss_g, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
-                                           inv_world, want_grad=train, nbands=nb)
-            ev['side'].record()
-        keep.extend((grec_sub, loss_g, out3, gQ))
+        # ---- colorless pass (spectral loss + dL/drecords of the sub-FDNs, sparsity): on the EDC stream.  Blocks of <= 4
+        # lines: in front of the scans, beside the output stage and the transform (behind the scans it ran beside the STFT
+        # adjoint: same step time either way, measured).  Blocks of 5..8 lines: BEHIND the scans -- the pass takes ~200 us
+        # there, and in front of them the EDC gradient reached the odd-frame launch of the STFT adjoint late
+        def colorless_pass():
+            with on_side2():
+                torch.cuda.current_stream().wait_event(ev['norm'])
+                if big:
+                    torch.cuda.current_stream().wait_event(ev_ts)
+                    grec_sub_, loss_g_ = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
+                                                           cfg.use_asym_spectral_loss,
+                                                           cfg.spectral_loss_weight * inv_world, dturn=gridK.dturn)
+                else:
+                    grec_sub_, loss_g_ = ops.tf_colorless(gridK.turns, gridK.logr, coef_sub, delays, n, scale,
+                                                          cfg.use_asym_spectral_loss,
+                                                          cfg.spectral_loss_weight * inv_world, dturn=gridK.dturn)
+                out3_, gQ_ = ops.colorless_terms(loss_g_, Q, cfg.spectral_loss_weight, cfg.sparsity_loss_weight,
+                                                 inv_world, want_grad=train, nbands=nb)
+                ev['side'].record()
+            keep.extend((grec_sub_, loss_g_, out3_, gQ_))
+            return grec_sub_, out3_, gQ_
+
+        late_colorless = big and self.colorless_behind_scans
+        if not late_colorless:
+            grec_sub, out3, gQ = colorless_pass()
 
         # ---- decay losses: irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint, EDC scans beside them
         ev['h'].record()
@@ -381,6 +389,8 @@ class FusedBankStep:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
                                                     start, length, ev, main, side2, x_fn=x_fn, Btot=Btot,
                                                     gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None)
+        if late_colorless:
+            grec_sub, out3, gQ = colorless_pass()
         def report():
             """the reported sums and total (off the gradient path)"""
             s_ = ops.weighted_sums(li_edr, cfg.edr_loss_weight, li_edc, cfg.edc_loss_weight, sum_abs, rows, nb)
