@@ -1343,9 +1343,9 @@ def rownorm_bwd(w, gy, eps: float = 1e-6) -> torch.Tensor:
     return gw
 
 
-def edc_mixed_supported(C: int, J: int) -> bool:
-    """Channel / direction counts gfdn_edc_loss_model_mixed is built for."""
-    return C in (1, 4, 9, 16) and J <= 16
+def edc_mixed_supported(C: int, J: int, S: int = 1) -> bool:
+    """Channel / direction / slope counts gfdn_edc_loss_model_mixed is built for."""
+    return C in (1, 4, 9, 16) and J <= 16 and S <= 8
 
 
 def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None, inv_count: float = 1.0,

@@ -494,7 +494,7 @@ class directional_edc_loss(nn.Module):
         if self.envelopes.device != x_sh.device:
             self.envelopes = self.envelopes.to(x_sh.device)
         amps = amps_true.to(device=x_sh.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
-        if n == 131072 and ops.edc_mixed_supported(C, J):
+        if n == 131072 and ops.edc_mixed_supported(C, J, amps.shape[1]):
             # the J directional samples formed in registers inside the EDC kernels (csrc/edcmix.hip): neither the
             # directional signals nor their gradient exist, the adjoint transform reads the EDC window only
             li, gx_sh = ops.edc_loss_model_mixed(x_sh.view(B, C, n), analysis_matrix, start, L, amps, self.envelopes, None,
