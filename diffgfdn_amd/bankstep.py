@@ -3,18 +3,20 @@ block transfer functions (csrc/blocktf.hip).
 
 What the reference does per batch and band (src/diff_gfdn/trainer.py:373-379, :452-477): ``normalize`` (no-grad
 sub-FDN forward, b, c /= E^(1/4)), forward (model.py:569-625), losses (trainer.py:259-315), ``backward()``,
-``optimizer.step()``.  With zero coupling and blocks of at most four delay lines every one of those stages sees the
+``optimizer.step()``.  With zero coupling and blocks of at most eight delay lines every one of those stages sees the
 feedback loop only through the group transfer functions T_g(z) -- ratios of multilinear polynomials in the phasors
-z^{m_i} with 2 x 16 real coefficients per block -- so the step is
+z^{m_i} with 2 x 16 (<= 4 lines) or 2 x 256 (5..8 lines, evaluated on the matrix cores) real coefficients per block --
+so the step is
 
     main  : [Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g: one launch] -> energy pass -> finish
             (normalize: b, c rescaled in place, scale_g) -> group transfer functions T -> irfft whose first pass forms
             the output stage H from T, the receiver gains and the early-response store (H is never stored) -> STFT
             -> EDR -> STFT adjoint (even frames, then odd frames + EDC gradient) -> irfft adjoint -> output-stage
             adjoint (dL/drecords) -> [records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint: one launch]
-            -> [all-reduce] -> Adam
+            -> [all-reduce -> Adam]
     side2 : gain network forward, mask draw, colorless pass (spectral loss + dL/drecords), sparsity ... EDC scans,
             reported sums ... output-stage adjoint (dL/dgains) -> gain network backward -> next step's receivers
+            -> Adam (single process: the update runs here, behind the branch that finishes last)
 
 33 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
 accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve never exist.  The autograd
@@ -32,8 +34,9 @@ from .losses import shard_loss_scales
 
 
 class FusedBankStep:
-    """Explicit forward / backward of ``BandBankTrainer`` for blocks of <= 4 lines and <= 4 groups per band.
-    ``supported(trainer)`` tells whether a trainer's layout qualifies."""
+    """Explicit forward / backward of ``BandBankTrainer`` for zero-coupling blocks of <= 8 lines and <= 4 groups per band
+    (<= 4 lines: csrc/blocktf.hip; 5..8 lines: csrc/blocktf8.hip).  ``supported(trainer)`` tells whether a trainer's
+    layout qualifies."""
 
     @staticmethod
     def supported(trainer) -> bool:
