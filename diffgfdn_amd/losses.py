@@ -12,8 +12,10 @@ achieved response requires grad and is handed to autograd as a saved tensor.  Th
 (EDR / EDC of the measured RIRs) does not depend on the model: it is computed once per distinct
 target tensor and cached (:class:`DecayTargets`).
 
-Not on the accelerated path (reference defaults leave them off): ERB grouping
-(``use_erb_grouping``), sub-band EDC (``band_centre_hz``), ``reg_loss``.
+Off in every reference configuration: ERB grouping (``edr_loss(use_erb_grouping=True)``: supported at the
+module level on the same kernels around two small matrix products, band matrix = input or the restated Slaney mel bank;
+the trainers' fused steps do not take it), sub-band EDC (``band_centre_hz``) and ``reg_loss`` (NotImplementedError: both
+need time-domain IIR filtering through learned / third-party second-order sections).
 """
 import contextlib
 from typing import Dict, List, Optional, Tuple
@@ -36,6 +38,37 @@ def edr_frequency_weights(sample_rate: float, win_size: int) -> torch.Tensor:
     (the reference passes `bottom, top` into the `top, bottom` slots; reproduced)."""
     freqs = torch.tensor(np.fft.rfftfreq(win_size, d=1.0 / sample_rate))
     return 2.0 + (1.0 - 2.0) / (1 + torch.exp(10 ** (-2.5) * (freqs - 1e3)))
+
+
+def mel_frequencies(n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """Centre frequencies of the Slaney mel scale (librosa.mel_frequencies, htk=False -- the scale behind the
+    reference's ``calc_erb_filters``, losses.py:18-46; librosa itself is not part of this build: restated from its
+    published definition, parity unpinned): linear below 1 kHz (200 / 3 Hz per mel), logarithmic above (step ln 6.4 / 27)."""
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    return mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels))
+
+
+def mel_filterbank(sample_rate: float, nfft: int, num_bands: int, fmin: float = 63.0, fmax: float = 16e3) -> np.ndarray:
+    """(num_bands, nfft / 2 + 1) triangular filters with Slaney area normalisation (librosa.filters.mel defaults, the
+    matrix the reference's ERB grouping multiplies |STFT| with, losses.py:34-38 and :545-551)."""
+    fft_f = np.linspace(0.0, sample_rate / 2.0, 1 + nfft // 2)
+    mel_f = mel_frequencies(num_bands + 2, fmin, fmax)
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0.0, np.minimum(lower, upper))
+    return w * (2.0 / (mel_f[2:num_bands + 2] - mel_f[:num_bands]))[:, None]
 
 
 def _as_batch(X: torch.Tensor) -> torch.Tensor:
@@ -342,10 +375,12 @@ class edr_loss(nn.Module):
 
     def __init__(self, sample_rate: float, win_size: int = 2 ** 12, hop_size: int = 2 ** 11,
                  reduced_pole_radius: Optional[float] = None, use_erb_grouping: bool = False,
-                 time_axis: int = -1, freq_axis: int = -2, use_weight_fn: bool = False):
+                 time_axis: int = -1, freq_axis: int = -2, use_weight_fn: bool = False,
+                 erb_filters=None):
+        """``use_erb_grouping``: the EDR is taken on |STFT| grouped into 64 bands (reference losses.py:545-551).  The
+        reference builds the band matrix with librosa (absent here): pass it as ``erb_filters`` (bands, win / 2 + 1), or
+        leave it to the restated Slaney mel filterbank (`mel_filterbank`, parity unpinned)."""
         super().__init__()
-        if use_erb_grouping:
-            raise NotImplementedError("ERB grouping is off in every north-star config (SURVEY §2b)")
         if hop_size * 2 != win_size:
             raise NotImplementedError("the reference asserts hop == win // 2 (losses.py:524)")
         self.sample_rate = sample_rate
@@ -358,18 +393,72 @@ class edr_loss(nn.Module):
         self.use_weight_fn = use_weight_fn
         self.erb_filters = None
         self.freqs_hz = np.fft.rfftfreq(win_size, d=1.0 / sample_rate)
+        if use_erb_grouping:
+            if erb_filters is None:
+                erb_filters = mel_filterbank(sample_rate, win_size, 2 ** 6)
+                self.freqs_hz = mel_frequencies(2 ** 6, 63.0, 16e3)
+            self.erb_filters = torch.as_tensor(np.asarray(erb_filters), dtype=torch.float32)
+            if self.erb_filters.shape[-1] != win_size // 2 + 1:
+                raise ValueError("erb_filters must be (bands, win_size / 2 + 1)")
         if use_weight_fn:
-            self.frequency_weights = edr_frequency_weights(sample_rate, win_size)
+            if use_erb_grouping:
+                if len(self.freqs_hz) != self.erb_filters.shape[0]:
+                    raise ValueError("frequency weighting of a caller-supplied band matrix needs its band frequencies")
+                f = torch.tensor(self.freqs_hz)
+                self.frequency_weights = 2.0 + (1.0 - 2.0) / (1 + torch.exp(10 ** (-2.5) * (f - 1e3)))
+            else:
+                self.frequency_weights = edr_frequency_weights(sample_rate, win_size)
         self.targets = _default_targets
 
     def forward(self, target_response: torch.Tensor, achieved_response: torch.Tensor) -> torch.Tensor:
         assert target_response.shape == achieved_response.shape
         wf = self.frequency_weights.to(achieved_response.device) if self.use_weight_fn else None
+        if self.use_erb_grouping:
+            return self._forward_erb(target_response, achieved_response, wf)
         total, _, _ = decay_losses(achieved_response, target_response, win=self.win_size,
                                    use_edc=False, freq_weights=wf,
                                    reduced_pole_radius=self.reduced_pole_radius,
                                    targets=self.targets)
         return total
+
+
+    def _forward_erb(self, target_response: torch.Tensor, achieved_response: torch.Tensor, wf) -> torch.Tensor:
+        """EDR loss on |STFT| grouped into bands, S_band = erb_filters |S| (losses.py:545-551), EDR = tail sums of S_band^2
+        (:556-575): the transform, STFT, EDR and loss kernels of the ungrouped path around two small matrix products; the
+        gradient is assembled in the forward and handed to autograd as the saved dloss/dH."""
+        Hb, Tb = _as_batch(achieved_response), _as_batch(target_response)
+        K, win = Hb.shape[-1], self.win_size
+        erb = self.erb_filters.to(Hb.device)
+        want_grad = achieved_response.requires_grad and torch.is_grad_enabled()
+        env = None
+        if self.reduced_pole_radius is not None and self.reduced_pole_radius != 1.0:
+            env = torch.pow(torch.tensor(1.0 / self.reduced_pole_radius, dtype=torch.float64, device=Hb.device),
+                            torch.arange(K, device=Hb.device, dtype=torch.float64)).to(torch.float32)
+
+        def grouped(X, e):
+            x = ops.irfft_odd_fwd(X, K)
+            if e is not None:
+                x = x * e
+            mag = ops.stft_power(x, win).sqrt_()                          # (B, frames, F) |STFT|
+            E = mag @ erb.T                                               # (B, frames, bands)
+            return x, mag, E
+
+        with torch.no_grad():
+            _, _, Et = grouped(Tb.to(torch.complex64), None)
+            T_db, sum_abs = ops.edr_target((Et * Et).contiguous())
+            x, mag, E = grouped(Hb.detach().to(torch.complex64), env)
+            gPe = (E * E).contiguous()
+            li = ops.edr_loss(gPe, T_db, sum_abs, wf, 1.0, want_grad)     # gPe becomes dloss/d(E^2)
+            val = li.sum()
+            if not want_grad:
+                return val
+            gmag = (2.0 * E * gPe) @ erb                                  # d/d|S|
+            gP = torch.where(mag > 0, 0.5 * gmag / mag, torch.zeros_like(mag)).contiguous()
+            gx = ops.stft_power_bwd(x, win, gP, torch.zeros_like(x))
+            if env is not None:
+                gx = gx * env
+            gH = ops.irfft_odd_bwd(gx, K, K)
+        return _ScalarLossWithSavedGrad.apply(achieved_response, val, gH.reshape(achieved_response.shape), False)
 
 
 class edc_loss(nn.Module):

@@ -160,6 +160,11 @@ class Trainer:
         else:
             max_ir_len_ms = float(np.max(np.asarray(net.common_decay_times))) * 1e3
         self.max_ir_len_ms = max_ir_len_ms
+        if trainer_config.use_erb_edr_loss:
+            # (the loss module itself takes the grouping -- losses.edr_loss(use_erb_grouping=True) -- but the fused steps of
+            # these trainers evaluate the ungrouped EDR on the half grid with precomputed targets: fail loudly instead of
+            # training on a different loss than the one configured)
+            raise NotImplementedError("use_erb_edr_loss: the trainers' fused steps evaluate the ungrouped EDR loss")
         if self.use_directional_fdn:
             self.criterion = [directional_edc_loss(net.common_decay_times, max_ir_len_ms,
                                                    net.sample_rate,

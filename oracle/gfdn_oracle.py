@@ -478,14 +478,22 @@ def edr_from_stft(S: torch.Tensor) -> torch.Tensor:
 
 def edr_loss(target: torch.Tensor, achieved: torch.Tensor, win_size: int = 4096,
              hop_size: int = 2048, reduced_pole_radius: Optional[float] = None,
-             freq_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """losses.py:430-495 -- irfft(n = K) (!), STFT, EDR in dB, per-item normalised L1, summed."""
+             freq_weights: Optional[torch.Tensor] = None,
+             erb_filters: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """losses.py:430-495 -- irfft(n = K) (!), STFT, EDR in dB, per-item normalised L1, summed.
+    ``erb_filters`` (bands, F): the ERB grouping of :545-551 -- the STFT is replaced by erb_filters |S| (einsum
+    'nk,bkt->bnt' on the magnitudes) before the EDR."""
     t_rir = torch.fft.irfft(target, target.shape[-1])
     a_rir = torch.fft.irfft(achieved, achieved.shape[-1])
     if reduced_pole_radius is not None:
         a_rir = a_rir * torch.pow(1.0 / reduced_pole_radius, torch.arange(0, a_rir.shape[-1]))
-    t_edr = edr_from_stft(stft_onesided(t_rir, win_size, hop_size))
-    a_edr = edr_from_stft(stft_onesided(a_rir, win_size, hop_size))
+    St, Sa = stft_onesided(t_rir, win_size, hop_size), stft_onesided(a_rir, win_size, hop_size)
+    if erb_filters is not None:
+        eq = 'nk,kt->nt' if St.ndim == 2 else 'nk,bkt->bnt'
+        St = torch.einsum(eq, erb_filters.to(torch.abs(St).dtype), torch.abs(St))
+        Sa = torch.einsum(eq, erb_filters.to(torch.abs(Sa).dtype), torch.abs(Sa))
+    t_edr = edr_from_stft(St)
+    a_edr = edr_from_stft(Sa)
     freq_loss = torch.sum(torch.abs(t_edr - a_edr), dim=-1)
     if freq_weights is not None:
         freq_loss = freq_loss * freq_weights

@@ -363,6 +363,42 @@ def test_f6_directional():
     assert rel_err(crit_default.envelopes, fx["envelopes"]) < 1e-5
 
 
+@pytest.mark.parametrize("weighted,radius", [(False, None), (True, 1.0002)])
+def test_edr_loss_with_erb_grouping(weighted, radius):
+    """edr_loss(use_erb_grouping=True) (reference losses.py:430-495 with :545-551: the EDR of erb_filters |STFT|) against
+    the oracle, value and dloss/dH; the band matrix is an input (librosa is absent), here the restated Slaney mel bank."""
+    from diffgfdn_amd.losses import edr_loss, mel_filterbank, mel_frequencies
+    fs, win, K, B = 16000.0, 512, 4097, 3
+    g = torch.Generator().manual_seed(4)
+    t = torch.arange(K, dtype=torch.float64)
+    rir_t = torch.randn(B, K, generator=g, dtype=torch.float64) * torch.exp(-t / 900.0)
+    rir_a = torch.randn(B, K, generator=g, dtype=torch.float64) * torch.exp(-t / 700.0)
+    # spectra whose irfft(n = K) are those signals: the first (K + 1) / 2 bins of their length-K DFT, zero above
+    def spec(x):
+        X = torch.zeros(B, K, dtype=torch.complex128)
+        X[:, :(K + 1) // 2] = torch.fft.rfft(x, n=K)
+        return X
+    Ht, Ha = spec(rir_t), spec(rir_a)
+    erb = mel_filterbank(fs, win, 16, 63.0, 7000.0)
+    crit = edr_loss(fs, win_size=win, hop_size=win // 2, use_erb_grouping=True, erb_filters=erb,
+                    reduced_pole_radius=radius)
+    wf = None
+    if weighted:
+        f = torch.tensor(mel_frequencies(16, 63.0, 7000.0))
+        wf = 2.0 + (1.0 - 2.0) / (1 + torch.exp(10 ** (-2.5) * (f - 1e3)))
+        crit.use_weight_fn, crit.frequency_weights = True, wf
+    Hr = Ha.clone().requires_grad_()
+    want = orc.edr_loss(Ht, Hr, win, win // 2, radius, wf, torch.tensor(erb))
+    want.backward()
+    Hd = Ha.to(torch.complex64).to(DEV).requires_grad_()
+    got = crit(Ht.to(torch.complex64).to(DEV), Hd)
+    got.backward()
+    assert abs(got.item() - want.item()) < TOL * abs(want.item())
+    gr = Hr.grad[:, :(K + 1) // 2]
+    gd = Hd.grad.cpu().to(torch.complex128)[:, :(K + 1) // 2]
+    assert float((gd - gr).abs().sum() / gr.abs().sum()) < 2e-3      # (L1: sign flips of the |.| at tiny differences)
+
+
 def test_directional_graphed_step_equals_eager_step():
     """DirectionalFDNVarReceiverPosTrainer.graphed: replaying the captured step == host launches (values, state)."""
     from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig

@@ -421,3 +421,29 @@ def test_f14_learnable_decay_times():
     assert rel_err(p.M.grad, fx["grad_feedback_loop.M"]) < 2e-4
     assert rel_err(p.input_gains.grad, fx["grad_input_gains"]) < 2e-4
     assert rel_err(p.output_gains.grad, fx["grad_output_gains"]) < 2e-4
+
+
+def test_restated_mel_filterbank_of_the_erb_grouping():
+    """The band matrix of the reference's ERB grouping (losses.py:18-46: librosa.filters.mel, absent here) as restated in
+    diffgfdn_amd.losses.mel_filterbank: Slaney scale (linear below 1 kHz, 200/3 Hz per mel; log above, ln 6.4 / 27 per mel),
+    triangles between neighbouring centre frequencies, unit area in Hz."""
+    from diffgfdn_amd.losses import mel_filterbank, mel_frequencies
+    f = mel_frequencies(66, 63.0, 16e3)
+    assert abs(f[0] - 63.0) < 1e-9 and abs(f[-1] - 16e3) < 1e-6 and np.all(np.diff(f) > 0)
+    lin = f[f < 1000.0]
+    assert np.allclose(np.diff(lin), np.diff(lin)[0])                       # equal steps below 1 kHz
+    log = f[f >= 1000.0]
+    assert np.allclose(log[1:] / log[:-1], (log[1] / log[0]))               # equal ratios above
+    W = mel_filterbank(48000.0, 4096, 64)
+    assert W.shape == (64, 2049) and W.min() >= 0.0
+    df = 48000.0 / 4096
+    area = W.sum(axis=1) * df
+    assert np.all(np.abs(area[8:] - 1.0) < 0.05)                            # (bands wide enough to be resolved by the grid)
+    peak = np.fft.rfftfreq(4096, 1 / 48000.0)[W.argmax(axis=1)]
+    assert np.all(np.abs(peak - f[1:-1]) <= df)                             # peaks at the centre frequencies
+    # the oracle's grouped EDR runs on it
+    K = 1025
+    H = torch.fft.rfft(torch.randn(2, K, dtype=torch.float64), n=K)
+    Hp = torch.zeros(2, K, dtype=torch.complex128); Hp[:, :H.shape[1]] = H
+    v = orc.edr_loss(Hp, Hp * 0.9, 256, 128, None, None, torch.tensor(mel_filterbank(8000.0, 256, 8, 63.0, 3500.0)))
+    assert torch.isfinite(v) and v.item() > 0
