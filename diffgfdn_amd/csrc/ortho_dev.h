@@ -10,8 +10,22 @@
 // that holds the result (R, or one of the scratch arrays after the ping-pong of the squarings).
 // Every Taylor / squaring step is ONE pass + ONE barrier: the product, its accumulation into R
 // (element e is owned by one thread) and the role swap of the buffers need no second pass.
-__device__ __forceinline__ double* expm_lds(double* A, double* P, double* R, double* T, double* s_tmp,
-                                            int m) {
+// MT > 0: the order is known at compile time -- the inner products are unrolled, so their 2 MT LDS reads are issued
+// together instead of one dependent read-read-FMA round trip per term (a step of the 18 x 18 adjoint took ~2 us that
+// way, 15 steps per call); same terms in the same order: the same bits.  MT = 0: any order.
+template <int MT>
+__device__ __forceinline__ double expm_dot(const double* row, const double* col, int m) {
+  double acc = 0.0;
+  if (MT > 0) {
+#pragma unroll
+    for (int q = 0; q < MT; ++q) acc += row[q] * col[q * MT];
+  } else {
+    for (int q = 0; q < m; ++q) acc += row[q] * col[q * m];
+  }
+  return acc;
+}
+template <int MT>
+__device__ __forceinline__ double* expm_lds_t(double* A, double* P, double* R, double* T, double* s_tmp, int m) {
   // 1-norm = max column sum
   for (int j = threadIdx.x; j < m; j += blockDim.x) {
     double c = 0.0;
@@ -43,9 +57,7 @@ __device__ __forceinline__ double* expm_lds(double* A, double* P, double* R, dou
     const double inv = 1.0 / (double)k;
     for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
       const int i = e / m, j = e - i * m;
-      double acc = 0.0;
-      for (int q = 0; q < m; ++q) acc += Pc[i * m + q] * A[q * m + j];
-      acc *= inv;
+      const double acc = expm_dot<MT>(Pc + i * m, A + j, m) * inv;
       Tc[e] = acc;
       R[e] += acc;
     }
@@ -57,14 +69,22 @@ __device__ __forceinline__ double* expm_lds(double* A, double* P, double* R, dou
   for (int i = 0; i < s; ++i) {
     for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
       const int r = e / m, c = e - r * m;
-      double acc = 0.0;
-      for (int q = 0; q < m; ++q) acc += Rc[r * m + q] * Rc[q * m + c];
-      Sc[e] = acc;
+      Sc[e] = expm_dot<MT>(Rc + r * m, Rc + c, m);
     }
     __syncthreads();
     double* t = Rc; Rc = Sc; Sc = t;
   }
   return Rc;
+}
+__device__ __forceinline__ double* expm_lds(double* A, double* P, double* R, double* T, double* s_tmp, int m) {
+  switch (m) {                                   // (wave-uniform: the orders the models use, 2 n for the adjoint)
+    case 4: return expm_lds_t<4>(A, P, R, T, s_tmp, m);
+    case 8: return expm_lds_t<8>(A, P, R, T, s_tmp, m);
+    case 9: return expm_lds_t<9>(A, P, R, T, s_tmp, m);
+    case 16: return expm_lds_t<16>(A, P, R, T, s_tmp, m);
+    case 18: return expm_lds_t<18>(A, P, R, T, s_tmp, m);
+    default: return expm_lds_t<0>(A, P, R, T, s_tmp, m);
+  }
 }
 
 __device__ __forceinline__ double skew_elem(const float* M, int n, int i, int j) {
