@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_ortho_fwd(const float* __restrict__ M, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_ortho_bwd(const float* __restrict__ M, int n,
+__global__ __launch_bounds__(512) void k_ortho_bwd(const float* __restrict__ M, int n,
                                                    const float* __restrict__ gQ,
                                                    const float* __restrict__ gQQ,
                                                    const float* __restrict__ Qsaved,
@@ -66,7 +66,8 @@ extern "C" int gfdn_ortho_bwd_add(const float* M, int G, int n, const float* gQ,
   if (n > GFDN_MAX_BLOCK || ortho_bwd_lds(n) > 160 * 1024) return GFDN_E_UNSUPPORTED;
   int rc = ensure_dyn_lds(k_ortho_bwd, ortho_bwd_lds(n));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ortho_bwd, dim3(G), dim3(256), ortho_bwd_lds(n), (hipStream_t)stream, M, n, gQ, gQQ, Q, gM_add,
+  // (the adjoint works on 2n x 2n matrices: 324 elements at n = 9 -- one pass of 512 threads per product instead of two of 256)
+  hipLaunchKernelGGL(k_ortho_bwd, dim3(G), dim3(4 * n * n > 256 ? 512 : 256), ortho_bwd_lds(n), (hipStream_t)stream, M, n, gQ, gQQ, Q, gM_add,
                      gM);
   GFDN_LAUNCH_CHECK();
   return 0;
