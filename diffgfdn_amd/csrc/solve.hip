@@ -2636,7 +2636,7 @@ __device__ __forceinline__ float wave_sums_transposed32(const float (&v)[NV]) {
 // (k_compose_sh_bwd_w, another 151 MB read of gH) is gone.
 #define SHF_TB 64
 template <int NPER>
-__global__ __launch_bounds__(256, 4) void k_compose_sh_bwd_fused(const float2* __restrict__ Y, int K, int G,
+__global__ __launch_bounds__(256, NPER <= 9 ? 4 : 2) void k_compose_sh_bwd_fused(const float2* __restrict__ Y, int K, int G,
                                                               const float* __restrict__ c,
                                                               const float* __restrict__ w, int B,
                                                               const float2* __restrict__ filt,

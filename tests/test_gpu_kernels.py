@@ -134,9 +134,13 @@ def test_compose_fwd_bwd(ops, G, nper, B, use_filt, use_direct):
     assert rel_err(grg.cpu(), rg.grad) < 1e-4
 
 
-def test_compose_sh_fwd_bwd(ops):
+@pytest.mark.parametrize("G,nper,B,K", [(3, 9, 4, 777), (3, 9, 32, 4097), (2, 16, 5, 1000), (4, 4, 7, 321), (5, 1, 3, 200),
+                                        (4, 9, 6, 500)])
+def test_compose_sh_fwd_bwd(ops, G, nper, B, K):
+    """SH output stage and its adjoint (model.py:1056-1088): the one-pass backward (64-bin tiles, receivers split over four
+    waves, per-receiver sums by the halving exchange) for 1, 4, 9, 16 channels, and the two-launch fallback (G = 4 at 9
+    channels exceeds the 32 lines the one-pass kernel holds)."""
     torch.manual_seed(5)
-    G, nper, B, K = 3, 9, 4, 777
     N = G * nper
     Y = torch.randn(K, N, dtype=torch.complex128).requires_grad_(True)
     c = torch.randn(N, dtype=torch.float64).requires_grad_(True)
