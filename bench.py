@@ -447,12 +447,30 @@ def run_directional(args, device, rank, world):
         steps.append((tr, tr.graphed(batch).capture(), store))
     gen = torch.Generator().manual_seed(100 + rank)
 
+    # the bands are independent models: their graph replays go round-robin onto ``--dir-streams`` streams, so that one
+    # band's latency-bound stretches (a dozen few-microsecond launches, the serial expm adjoint) run beside another's
+    # bandwidth-bound transforms
+    nstreams = max(1, min(args.dir_streams, nb))
+    lanes = [torch.cuda.Stream(device=device) for _ in range(nstreams)] if nstreams > 1 else None
+
     def one_step():
-        for tr, step, store in steps:
+        main = torch.cuda.current_stream()
+        for i, (tr, step, store) in enumerate(steps):
             sel = torch.randperm(R, generator=gen)[:BATCH].to(device)
-            for k, v in store.items():
-                step.batch[k].copy_(v.index_select(0, sel))
-            out = step()
+            if lanes is None:
+                for k, v in store.items():
+                    step.batch[k].copy_(v.index_select(0, sel))
+                out = step()
+            else:
+                lane = lanes[i % nstreams]
+                lane.wait_stream(main)
+                with torch.cuda.stream(lane):
+                    for k, v in store.items():
+                        step.batch[k].copy_(v.index_select(0, sel))
+                    out = step()
+        if lanes is not None:
+            for lane in lanes:
+                main.wait_stream(lane)
         return out
 
     for _ in range(args.warmup):
@@ -482,10 +500,10 @@ def run_directional(args, device, rank, world):
     out = {'metric': 'RIR-frames/sec', 'value': rirs_per_s * FRAMES, 'unit': 'RIR-frames/s', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'directional DiffGFDN: {nb} octave bands one after another, each {Gd} groups x {L} SH '
+           'config': {'workload': f'directional DiffGFDN: {nb} octave bands (independent models, graph replays round-robin on {nstreams} stream(s)), each {Gd} groups x {L} SH '
                                   f'channels (N = {Gd * L}), {J} directions, {R} receivers, nfft 131072, batch {BATCH} '
                                   'receivers/band/step/GPU; step = SH forward + directional EDC + colorless losses + bwd + '
-                                  'Adam per band, one HIP-graph replay per band', 'bands': nb, 'receivers': R,
+                                  'Adam per band, one HIP-graph replay per band', 'bands': nb, 'receivers': R, 'band_streams': nstreams,
                        'directions': J, 'delay_lines': Gd * L, 'rirs_per_s': rirs_per_s,
                        'ms_per_band_step': 1e3 * elapsed / args.steps / nb,
                        'final_loss': float(total)}}
@@ -571,6 +589,8 @@ def main():
     ap.add_argument('--epoch', action='store_true',
                     help='time whole epochs (19 train + 5 validation steps + checkpoints); --steps = epochs timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dir-streams', type=int, default=2,
+                    help='--config directional: streams the independent bands\' graph replays are spread over')
     ap.add_argument('--captured-allreduce', action='store_true',
                     help='N > 1: capture the RCCL all-reduce inside the step graph (when every rank can)')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
