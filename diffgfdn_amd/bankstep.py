@@ -76,6 +76,7 @@ class FusedBankStep:
     # The gains pass it removes runs beside the records pass on the side stream, off the main chain, while the
     # accumulation lengthens a pass that is ON it.
     fold_gains = False
+    gain_rows_in_mlp = os.environ.get('GFDN_GAIN_ROWS_IN_MLP', '1') == '1'
     colorless_behind_scans = os.environ.get('GFDN_COLORLESS_LATE', '1') == '1'      # (blocks of 5..8 lines)
     # the optimiser update on the side stream behind the gain network's backward (single process)
     adam_on_side = os.environ.get('GFDN_ADAM_ON_SIDE', '1') == '1'
@@ -422,10 +423,17 @@ class FusedBankStep:
                 torch.cuda.current_stream().wait_event(ev['grg'])
                 if fold and self.fold_gains:
                     grg = ops.tf_rows_sum(self._gpart)
+                    ggp = None
+                elif self.gain_rows_in_mlp and ops.mlp_bwd_takes_parts(bank._freq_pi.numel(), Hh, n_hidden, G, Btot // nb):
+                    # the gains pass leaves its per-chunk partial rows; every receiver's wave of the gain network's
+                    # backward sums its own (same order as the row-sum launch that sat between the two, on the path to
+                    # the update)
+                    grg, ggp = None, ops.tf_gain_grad(Ts, gH, G, filt, nb, partial=True)
                 else:
-                    grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
+                    grg, ggp = ops.tf_gain_grad(Ts, gH, G, filt, nb), None
                 ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
-                                  xhat, rstd, grg, rows, nb, out=self.g_w)
+                                  xhat, rstd, grg, rows, nb, out=self.g_w, ggains_parts=ggp)
+                keep.append(ggp)
                 if pipe is not None:
                     # the gain network's range of the flat buffers is stepped HERE, behind its gradient, on this
                     # stream; then the next step's receivers and its receiver gains -- the main stream never waits

@@ -1048,7 +1048,7 @@ extern "C" size_t gfdn_tf_gain_grad_work_bytes(int K, int nbands, int G, int B) 
 
 extern "C" int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave, const float* filt, int ldf,
                                  const float* gH, int ldh, float* grgain, void* work, void* stream) {
-  if (!Tsave || !gH || !grgain || !work || K <= 0 || nbands <= 0 || G <= 0 || B <= 0 || ldh < K ||
+  if (!Tsave || !gH || !work || K <= 0 || nbands <= 0 || G <= 0 || B <= 0 || ldh < K ||
       (filt && nbands > 1 && ldf < K))
     return GFDN_E_BADARG;
   if (G > TF_MAXG || nbands * ((B + TFG_R - 1) / TFG_R) > 65535) return GFDN_E_UNSUPPORTED;
@@ -1057,12 +1057,15 @@ extern "C" int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* T
   hipLaunchKernelGGL(k_tf_gain_grad, dim3(nchunk, nbands * ngrp), dim3(256), 0, s, (const float2*)Tsave, K, G, B,
                      (const float2*)filt, ldf, (const float2*)gH, ldh, (float*)work, ngrp);
   GFDN_LAUNCH_CHECK();
+  if (!grgain) return 0;            // the (nbands B G, gfdn_tf_gain_chunks(K)) partial rows stay in ``work`` for a consumer that
+                                    // sums them itself (gfdn_mlp_gains_banded_bwd_parts)
   const int nrg = nbands * B * G;
   hipLaunchKernelGGL(k_tf_rows_sum, dim3((nrg + 3) / 4), dim3(256), 0, s, (const float*)work, nchunk, nrg, grgain, nrg,
                      (float*)nullptr, (float*)nullptr);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int gfdn_tf_gain_chunks(int K) { return K > 0 ? tf_gain_chunks_host(K) : 0; }
 
 extern "C" int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
                                    const float* coef, const float* delays, const float* Tsave,

@@ -22,6 +22,7 @@ struct MlpDims {
   const long long* rows;        // item b encodes pos[rows[b]] (NULL: pos[b])
   int stage;                    // 1: the packed parameters (+ the receiver's saved activations) fit in LDS
   int Bper;                     // items per band: item b uses the parameter set b / Bper (w is (bands, P))
+  int gparts;                   // > 0: ``ggains`` holds (B G, gparts) partial rows (gfdn_tf_gain_grad without its row sums)
 };
 
 __device__ __forceinline__ size_t mlp_layer_off(const MlpDims& d, int l) {
@@ -361,8 +362,27 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const 
       A0[e] = (float)(q < 3 ? sin(arg) : cos(arg));
     }
   }
+  float gg_row = 0.f;
+  if (d.gparts > 0) {
+    // the gains pass of the output stage's adjoint left (B G, gparts) partial rows: each row summed here by the whole
+    // wave, same terms in the same order as k_tf_rows_sum (blocktf.hip) -- that launch sat on the path to the update
+    for (int g = 0; g < G; ++g) {
+      const float* row = ggains + ((size_t)b * G + g) * d.gparts;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int p = lane;
+      for (; p + 192 < d.gparts; p += 256) {
+        s0 += row[p];
+        s1 += row[p + 64];
+        s2 += row[p + 128];
+        s3 += row[p + 192];
+      }
+      for (; p < d.gparts; p += 64) s0 += row[p];
+      const float sr = wave_sum((s0 + s1) + (s2 + s3));
+      if (lane == g) gg_row = sr;
+    }
+  }
   if (lane < G) {
-    const float gg = ggains[(size_t)b * G + lane];
+    const float gg = d.gparts > 0 ? gg_row : ggains[(size_t)b * G + lane];
     if (d.hi > d.lo) {
       const float sg = (gains[(size_t)b * G + lane] - d.lo) / (d.hi - d.lo);
       DRAW[lane] = gg * (d.hi - d.lo) * sg * (1.0f - sg);
@@ -473,6 +493,7 @@ static int mlp_dims(int B, int F, int H, int n_hidden, int G, float lo, float hi
   d->B = B; d->F = F; d->in_dim = 6 * F; d->H = H; d->nl = 1 + n_hidden; d->G = G; d->lo = lo; d->hi = hi;
   d->rows = nullptr;
   d->Bper = B;
+  d->gparts = 0;
   d->stage = mlp_param_count(*d) <= MLP_STAGE_MAX ? 1 : 0;
   return 0;
 }
@@ -544,17 +565,51 @@ extern "C" int gfdn_mlp_gains_bwd(const double* pos, const long long* pos_rows, 
                                    rstd, ggains, gw, work, stream);
 }
 
+static int mlp_banded_bwd_run(const double* pos, const long long* pos_rows, const float* freq_pi,
+                              const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                              int G, float lo, float hi, const float* gains, const float* xhat,
+                              const float* rstd, const float* ggains, int gparts, float* gw, void* work,
+                              void* stream);
+
+// 1 when gfdn_mlp_gains_banded_bwd_parts takes this network (the wave-per-receiver form applies), else 0
+extern "C" int gfdn_mlp_bwd_takes_parts(int F, int H, int n_hidden, int G, int Bper) {
+  MlpDims d;
+  if (Bper <= 0 || mlp_dims(Bper, F, H, n_hidden, G, 0.f, 0.f, &d)) return 0;
+  return (d.stage && H <= 64 && G <= 64 && Bper % MLP_RB == 0) ? 1 : 0;
+}
+
 extern "C" int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, const float* freq_pi,
                                          const float* w, int nbands, int Bper, int F, int H, int n_hidden,
                                          int G, float lo, float hi, const float* gains, const float* xhat,
                                          const float* rstd, const float* ggains, float* gw, void* work,
                                          void* stream) {
+  return mlp_banded_bwd_run(pos, pos_rows, freq_pi, w, nbands, Bper, F, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains,
+                            0, gw, work, stream);
+}
+// ... with dL/dgains as the (nbands Bper G, gparts) partial rows gfdn_tf_gain_grad leaves when it is called without an
+// output: the row sums happen inside this launch (wave-per-receiver form only: GFDN_E_UNSUPPORTED otherwise)
+extern "C" int gfdn_mlp_gains_banded_bwd_parts(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                               const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                                               int G, float lo, float hi, const float* gains, const float* xhat,
+                                               const float* rstd, const float* ggains_parts, int gparts, float* gw,
+                                               void* work, void* stream) {
+  if (gparts <= 0) return GFDN_E_BADARG;
+  return mlp_banded_bwd_run(pos, pos_rows, freq_pi, w, nbands, Bper, F, H, n_hidden, G, lo, hi, gains, xhat, rstd,
+                            ggains_parts, gparts, gw, work, stream);
+}
+
+static int mlp_banded_bwd_run(const double* pos, const long long* pos_rows, const float* freq_pi,
+                              const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                              int G, float lo, float hi, const float* gains, const float* xhat,
+                              const float* rstd, const float* ggains, int gparts, float* gw, void* work,
+                              void* stream) {
   MlpDims d;
   if (nbands <= 0 || Bper <= 0) return GFDN_E_BADARG;
   const int B = nbands * Bper;
   int rc = mlp_dims(B, F, H, n_hidden, G, lo, hi, &d);
   if (rc) return rc;
   d.Bper = Bper;
+  d.gparts = gparts;
   d.rows = pos_rows;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
@@ -571,6 +626,7 @@ extern "C" int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos
     GFDN_LAUNCH_CHECK();
     return 0;
   }
+  if (gparts > 0) return GFDN_E_UNSUPPORTED;      // (the block-per-receiver form reads summed gradients)
   hipLaunchKernelGGL(k_mlp_bwd, dim3(B), dim3(mlp_threads(d)), mlp_lds_bytes(d), s, d, pos, freq_pi, w, gains, xhat,
                      rstd, ggains, (float*)work);
   GFDN_LAUNCH_CHECK();

@@ -664,9 +664,10 @@ def tf_compose_fwd(turns, logr, coef, delays, nper: int, rgain, scale=None, dire
     return (H, Ts) if save_T else H
 
 
-def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, work=None) -> torch.Tensor:
+def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, work=None, partial: bool = False):
     """grgain (nbands*B, G) = sum_k Re(dL/dH[b][k] conj(filt[k] T'_g[k])); ``Tsave`` (nbands*G, K) from
-    tf_compose_fwd(save_T=True)."""
+    tf_compose_fwd(save_T=True).  ``partial``: skip the sums over the bin chunks and return the (nbands*B*G, chunks)
+    partial rows (a buffer of their own) for ``mlp_gains_bwd(ggains_parts=...)``, which sums them itself."""
     _need_gpu(Tsave, gH)
     Tsave, gH = _c(Tsave), _c(gH)
     Btot, K = gH.shape
@@ -675,6 +676,11 @@ def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, wor
     filt = None if filt is None else _c(filt)
     lib = _lib.load()
     B = Btot // nbands
+    if partial:
+        parts = torch.empty((Btot * G, lib.gfdn_tf_gain_chunks(K)), dtype=_f32, device=gH.device)
+        _lib.check(lib.gfdn_tf_gain_grad(K, nbands, G, B, _p(Tsave), _p(filt), K, _p(gH), K, None, _p(parts), _stream()),
+                   "gfdn_tf_gain_grad")
+        return parts
     grgain = torch.empty((Btot, G), dtype=_f32, device=gH.device) if grgain is None else grgain
     if work is None:
         work = _work(lib.gfdn_tf_gain_grad_work_bytes(K, nbands, G, B), gH.device)
@@ -1527,12 +1533,18 @@ def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi:
     return gains, xhat, rstd
 
 
+def mlp_bwd_takes_parts(F: int, H: int, n_hidden: int, G: int, Bper: int) -> bool:
+    """Whether mlp_gains_bwd(ggains_parts=...) applies to this network and batch (the wave-per-receiver kernel)."""
+    return bool(_lib.load().gfdn_mlp_bwd_takes_parts(int(F), int(H), int(n_hidden), int(G), int(Bper)))
+
+
 def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains, rows=None,
-                  nbands: int = 1, out=None):
-    """-> gw shaped like w (``out``: a contiguous float32 buffer of that size to write it into)."""
-    _need_gpu(pos, w, ggains)
+                  nbands: int = 1, out=None, ggains_parts=None):
+    """-> gw shaped like w (``out``: a contiguous float32 buffer of that size to write it into).  ``ggains_parts`` (in
+    place of ``ggains``): the (B G, chunks) partial rows of ``tf_gain_grad(partial=True)``, summed inside the launch."""
+    _need_gpu(pos, w, ggains if ggains_parts is None else ggains_parts)
     pos = pos.detach().to(torch.float64).contiguous()
-    w, ggains = _f(w), _f(ggains)
+    w = _f(w)
     B, F = (pos.shape[0] if rows is None else rows.numel()), freq_pi.numel()
     rows = _rows(rows, B, pos.shape[0])
     lib = _lib.load()
@@ -1540,6 +1552,16 @@ def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, gg
         raise RuntimeError("mlp_gains_bwd: out must be a contiguous float32 buffer of the parameter count")
     gw = torch.empty_like(w) if out is None else out
     work = _work(lib.gfdn_mlp_bwd_work_bytes(B, F, H, n_hidden, G), pos.device)
+    if ggains_parts is not None:
+        gp = _f(ggains_parts)
+        if gp.dim() != 2 or gp.shape[0] != B * G or B % nbands:
+            raise RuntimeError("mlp_gains_bwd: ggains_parts must be (B G, chunks)")
+        _lib.check(lib.gfdn_mlp_gains_banded_bwd_parts(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,
+                                                       n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat), _p(rstd),
+                                                       _p(gp), gp.shape[1], _p(gw), _p(work), _stream()),
+                   "gfdn_mlp_gains_banded_bwd_parts")
+        return gw
+    ggains = _f(ggains)
     if nbands > 1:
         _lib.check(lib.gfdn_mlp_gains_banded_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,
                                                  n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat),

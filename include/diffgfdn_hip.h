@@ -359,6 +359,9 @@ int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nban
 size_t gfdn_tf_gain_grad_work_bytes(int K, int nbands, int G, int B);
 int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave_c64, const float* filt_c64, int ldf,
                       const float* gH_c64, int ldh, float* grgain, void* work, void* stream);
+/* Columns of the partial rows gfdn_tf_gain_grad leaves in ``work`` when ``grgain`` is NULL ((nbands B G, chunks) floats, row
+ * (band B + b) G + g): the sums over the chunks then belong to the consumer (gfdn_mlp_gains_banded_bwd_parts).          */
+int gfdn_tf_gain_chunks(int K);
 
 /* ---- block transfer functions for blocks of 5..8 lines (BASELINE.json configs[4]: N = 32 = 4 groups x 8 lines) -----
  * csrc/blocktf8.hip.  The same reference maths as the gfdn_tf_* family (feedback_loop.py:326-391 resolvent of one block,
@@ -644,6 +647,15 @@ int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, cons
                               float lo, float hi, const float* gains, const float* xhat,
                               const float* rstd, const float* ggains, float* gw, void* work,
                               void* stream);
+/* The same with dL/dgains handed over as (nbands Bper G, gparts) partial rows (gfdn_tf_gain_grad with grgain = NULL): every
+ * receiver's wave sums its rows itself, same terms in the same order as the separate row-sum launch it replaces.
+ * Wave-per-receiver form only (H, G <= 64, Bper a multiple of 4, parameters staged in LDS): GFDN_E_UNSUPPORTED otherwise. */
+int gfdn_mlp_bwd_takes_parts(int F, int H, int n_hidden, int G, int Bper);      /* 1: the call below takes this network */
+int gfdn_mlp_gains_banded_bwd_parts(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                    const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                                    int G, float lo, float hi, const float* gains, const float* xhat,
+                                    const float* rstd, const float* ggains_parts, int gparts, float* gw,
+                                    void* work, void* stream);
 
 /* Receiver schedule of a replayed epoch (reference trainer.py:373-379: the DataLoader fixes an epoch's batches when the
  * epoch starts): table (len, B) int64 dataset rows uploaded once; each call copies row state[0] mod state[1] into idx

@@ -314,6 +314,30 @@ def test_mlp_gains_fused(ops, B, F, H, n_hidden, G):
         assert rel_err(p.grad.cpu(), r) < 2e-4
 
 
+def test_gain_network_backward_sums_the_gains_pass_rows_itself(ops):
+    """mlp_gains_bwd(ggains_parts=...) on the (B G, chunks) partial rows of tf_gain_grad(partial=True) == the row-sum launch
+    followed by mlp_gains_bwd, bit for bit (same terms in the same order)."""
+    nb, Bper, G, K, F, H, nh = 2, 8, 4, 4099, 20, 16, 4
+    B = nb * Bper
+    g = torch.Generator().manual_seed(9)
+    Ts = torch.randn(nb * G, K, generator=g, dtype=torch.complex64).to(DEV)
+    gH = torch.randn(B, K, generator=g, dtype=torch.complex64).to(DEV)
+    filt = torch.randn(nb, K, generator=g, dtype=torch.complex64).to(DEV)
+    pos = torch.rand(B, 3, generator=g, dtype=torch.float64).to(DEV)
+    from diffgfdn_amd import _lib
+    P = _lib.load().gfdn_mlp_param_count(F, H, nh, G)
+    w = (0.3 * torch.randn(nb, P, generator=g)).to(DEV)
+    freq_pi = (torch.exp(torch.linspace(0.0, np.log(32.0), F)) * np.pi).float().to(DEV)
+    assert ops.mlp_bwd_takes_parts(F, H, nh, G, Bper)
+    gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, nh, G, 0.0, 1.0, None, nb)
+    grg = ops.tf_gain_grad(Ts, gH, G, filt, nb)
+    want = ops.mlp_gains_bwd(pos, freq_pi, w, H, nh, G, 0.0, 1.0, gains, xhat, rstd, grg, None, nb)
+    parts = ops.tf_gain_grad(Ts, gH, G, filt, nb, partial=True)
+    assert torch.equal(ops.tf_rows_sum(parts).reshape(B, G), grg)
+    got = ops.mlp_gains_bwd(pos, freq_pi, w, H, nh, G, 0.0, 1.0, gains, xhat, rstd, None, None, nb, ggains_parts=parts)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("length", [1, 127, 128, 129, 4097, 47360, 131072])
 def test_draw_mask_bit_exact(length):
     """gfdn_draw_mask == the numpy Philox restatement, bit for bit; the counter advances per call."""
