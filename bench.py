@@ -156,13 +156,13 @@ def build_net(device, delays, common_decay_times):
 
 
 def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS, centre_hz: float = 500.0,
-                   room_seed: int = 0, make_trainer: bool = True):
+                   room_seed: int = 0, make_trainer: bool = True, t60max: float = 1.5):
     from diffgfdn_amd.config import DiffGFDNConfig
     from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset, split_dataset
     from diffgfdn_amd.synthetic import synthetic_room
     from diffgfdn_amd.trainer import VarReceiverPosTrainer
 
-    room = synthetic_room(num_receivers, G, FS, 64000, seed=room_seed)
+    room = synthetic_room(num_receivers, G, FS, 64000, seed=room_seed, t60_range=(0.3, t60max))
     ds = RoomDataset(G, FS, room['source_position'], room['receiver_position'], room['rirs'],
                      room['common_decay_times'], nfft=NFFT, device=device)
     data = MultiRIRDataset(device, ds)
@@ -184,8 +184,17 @@ def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS, centre
     return room, data, net, trainer, (train_idx, valid_idx), filt, delays
 
 
+def band_t60max(nbands: int, distinct: bool):
+    """Longest decay time of every band's synthetic room: 1.5 s for all, or -- ``--distinct-t60`` --
+    falling from 1.5 s in the lowest band to 0.6 s in the highest, as measured octave bands do: every band then has its
+    own EDC window (reference trainer.py:56-59)."""
+    if not distinct or nbands == 1:
+        return [1.5] * nbands
+    return [float(v) for v in np.round(np.linspace(1.5, 0.6, nbands), 3)]
+
+
 def build_bank_workload(device, seed: int, centres, num_receivers: int = NUM_RECEIVERS, max_epochs: int = 20,
-                        train_dir='/tmp/gfdn_bench/train'):
+                        train_dir='/tmp/gfdn_bench/train', t60max=None):
     """One model + dataset per octave band (run_subband_training_treble.py:175-204), stacked into a
     band bank.  Returns the 500 Hz band's room / delays / filter for the CPU baseline leg."""
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
@@ -193,7 +202,8 @@ def build_bank_workload(device, seed: int, centres, num_receivers: int = NUM_REC
     cpu_leg = None
     for q, f in enumerate(centres):
         room, data, net, tc, split, filt, delays = build_workload(
-            device, seed + q, num_receivers, centre_hz=f, room_seed=q, make_trainer=False)
+            device, seed + q, num_receivers, centre_hz=f, room_seed=q, make_trainer=False,
+            t60max=1.5 if t60max is None else t60max[q])
         nets.append(net)
         datasets.append(data)
         filts.append(filt)
@@ -206,8 +216,7 @@ def build_bank_workload(device, seed: int, centres, num_receivers: int = NUM_REC
     trainer = BandBankTrainer(bank, tc, subband_filter_freq_resp=torch.stack(filts), process_group=pg,
                               band_names=[int(f) for f in centres])
     sds = BandStackedDataset(datasets, free_sources=True)
-    start, length = trainer._decay_window(K)
-    sds.precompute_decay_targets(WIN, start, length)
+    sds.precompute_decay_targets(WIN, *trainer._target_window(K))
     for d in datasets:                       # only the stacked stores are read from here on
         d.rir_mag_response = d.late_rir_mag_response = None
     sds.rir_mag_response = torch.empty((1, K), dtype=torch.complex64, device=device)   # shape carrier
@@ -605,6 +614,9 @@ def main():
                     help='with --bands 1: the per-band VarReceiverPosTrainer path instead of a one-band bank')
     ap.add_argument('--lines-per-group', type=int, default=NPER,
                     help='delay lines per group (4 groups): 8 gives the N = 32 configuration')
+    ap.add_argument('--distinct-t60', action='store_true',
+                    help='every band gets its own longest decay time (1.5 s ... 0.6 s) and therefore its own EDC window, as '
+                         'the reference\'s per-band datasets do (trainer.py:56-59)')
     ap.add_argument('--bands', type=int, default=len(BAND_CENTRES),
                     help='octave bands stepped together (1 = BASELINE.json configs[1], the 500 Hz band alone)')
     args = ap.parse_args()
@@ -677,7 +689,8 @@ def main():
     else:
         centres = BAND_CENTRES[:nbands] if nbands > 1 else (500.0,)
         (room, delays, filt), data, net, trainer, splits = build_bank_workload(
-            device, 1234, centres, args.receivers, max_epochs=args.warmup + args.steps if args.epoch else 20)
+            device, 1234, centres, args.receivers, max_epochs=args.warmup + args.steps if args.epoch else 20,
+            t60max=band_t60max(len(centres), args.distinct_t60))
 
     epoch_info = None
     if args.epoch:
@@ -811,6 +824,9 @@ def main():
                        'bands': nbands, 'receivers': args.receivers, 'batch_per_band_per_gpu': b_local,
                        'rirs_per_step_per_gpu': nbands * b_local, 'global_batch_per_band': b_local * world,
                        'delay_lines': G * NPER, 'bins': K, 'rirs_per_s': rirs_per_s,
+                       'band_t60max_s': band_t60max(len(centres), args.distinct_t60) if use_bank else [1.5],
+                       'band_edc_windows': ((trainer._band_windows(K) or [trainer._decay_window(K)[1]] * nbands)
+                                            if use_bank else [trainer._decay_window(K)[1]]),
                        'launch': graph_mode, 'rank_devices': rank_devices,
                        'collective': (None if world == 1 else
                                       {'backend': dist.get_backend(), 'library_version': collective_version(),

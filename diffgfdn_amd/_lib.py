@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P = c_void_p
 
@@ -151,6 +151,11 @@ SIGNATURES = {
     "gfdn_edc_loss": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_edc_loss_model": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_draw_mask": (c_int, [ctypes.c_ulonglong, _P, c_int, c_float, _P, _P]),
+    "gfdn_edc_loss_banded": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_float, c_float,
+                                     _P, _P, _P, _P]),
+    "gfdn_edc_loss_pairs_banded": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_float,
+                                           c_float, _P, _P, _P, _P]),
+    "gfdn_draw_mask_banded": (c_int, [ctypes.c_ulonglong, _P, _P, c_int, c_int, c_int, c_float, _P, _P]),
 }
 
 _lib = None

@@ -197,20 +197,29 @@ class BandStackedDataset:
     def __len__(self):
         return self.R
 
-    def precompute_decay_targets(self, win: int, edc_start: int, edc_len: int, chunk: int = 64):
+    def precompute_decay_targets(self, win: int, edc_start: int, edc_len, chunk: int = 64):
+        """``edc_len``: one window length for all bands, or one per band (bands whose longest decay times differ,
+        reference trainer.py:56-59): the stacked EDC store then has rows of the LONGEST window, band q's rows filled up to
+        its own length (the banded EDC kernels read them with that pitch), and its key is (start, (len_0, len_1, ...))."""
+        lens = [int(edc_len)] * self.num_bands if np.isscalar(edc_len) else [int(v) for v in edc_len]
+        if len(lens) != self.num_bands:
+            raise ValueError("precompute_decay_targets: one EDC window length per band")
+        key = (edc_start, lens[0] if len(set(lens)) == 1 else tuple(lens))
         if (self.edr_store is not None and self.edc_store is not None and self.edr_store[0] == win
-                and self.edc_store[0] == (edc_start, edc_len)):
+                and self.edc_store[0] == key):
             return                      # the stacked stores already hold these targets
+        Lmax = max(lens)
         edr_T, edr_s, edc_T = [], [], []
-        for d in self.datasets:
+        for d, L in zip(self.datasets, lens):
             if (d.edr_store is None or d.edc_store is None or d.edr_store[0] != win
-                    or d.edc_store[0] != (edc_start, edc_len)):
-                d.precompute_decay_targets(win, edc_start, edc_len, chunk)
+                    or d.edc_store[0] != (edc_start, L)):
+                d.precompute_decay_targets(win, edc_start, L, chunk)
             edr_T.append(d.edr_store[1])
             edr_s.append(d.edr_store[2])
-            edc_T.append(d.edc_store[1])
+            T = d.edc_store[1]
+            edc_T.append(T if L == Lmax else torch.nn.functional.pad(T, (0, Lmax - L)))
         self.edr_store = (win, torch.cat(edr_T), torch.cat(edr_s))
-        self.edc_store = ((edc_start, edc_len), torch.cat(edc_T))
+        self.edc_store = (key, torch.cat(edc_T).contiguous())
         for d in self.datasets:                  # the stacked copies are the live ones
             d.edr_store = d.edc_store = None
 
@@ -337,14 +346,16 @@ class BandBankTrainer:
         self.optimizer = BandFlatAdam(groups, self.num_bands, extra_slots=3 * self.num_bands)
         bank.relink()                               # the leaves now live in the flat buffer
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=10, gamma=0.1)
-        # one EDC window for all bands (trainer.py:56-59: T60max of the band's decay times)
-        lens = {float(np.max(np.asarray(net.common_decay_times))) * 1e3 if net.common_decay_times is not None
-                else 2000.0 for net in bank.nets}
-        if len(lens) != 1:
-            raise NotImplementedError("BandBankTrainer: bands with different longest decay times have different "
-                                      "EDC windows; train those band by band (subband.train_bands)")
-        self.max_ir_len_ms = lens.pop()
+        # every band's EDC window ends at ITS longest decay time (trainer.py:56-59: max_ir_len_ms = T60max of the band's
+        # decay times; run_subband_training_treble.py:286 gives every band its own dataset's).  The bank's criterion
+        # carries the longest of them; bands with shorter windows are handled by the banded EDC kernels (per-item
+        # window lengths, per-band mask rows: _band_windows / _item_windows)
+        self.band_ir_len_ms = [float(np.max(np.asarray(net.common_decay_times))) * 1e3
+                               if net.common_decay_times is not None else 2000.0 for net in bank.nets]
+        self.max_ir_len_ms = max(self.band_ir_len_ms)
         self.criterion = [None, edc_loss(self.max_ir_len_ms, bank.sample_rate, use_mask=cfg.use_edc_mask)]
+        self._band_criteria = [edc_loss(ms, bank.sample_rate, use_mask=cfg.use_edc_mask) for ms in self.band_ir_len_ms]
+        self._win_cache = {}
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -367,7 +378,43 @@ class BandBankTrainer:
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     def _decay_window(self, K: int):
+        """(start, length of the LONGEST band window) -- the extent the time-domain buffers and mask rows are sized for"""
         return self.criterion[1].window(K)
+
+    def _band_windows(self, K: int) -> Optional[List[int]]:
+        """Per-band EDC window lengths when they differ (None: one window for all bands)."""
+        lens = [c.window(K)[1] for c in self._band_criteria]
+        return None if len(set(lens)) == 1 else lens
+
+    def _target_window(self, K: int):
+        """(start, edc_len) for ``precompute_decay_targets``: edc_len is a list when the bands' windows differ."""
+        start, length = self._decay_window(K)
+        lens = self._band_windows(K)
+        return start, (length if lens is None else lens)
+
+    def _item_windows(self, K: int, Bper: int, device):
+        """(item_len (bands * Bper,) int32, band_len (bands,) int32) on the device for the banded EDC kernels, or
+        (None, None) when all bands share one window; cached (the captured graph holds their pointers)."""
+        lens = self._band_windows(K)
+        if lens is None:
+            return None, None
+        key = (K, Bper, str(device))
+        if key not in self._win_cache:
+            band_len = torch.tensor(lens, dtype=torch.int32, device=device)
+            self._win_cache[key] = (band_len.repeat_interleave(Bper).contiguous(), band_len)
+        return self._win_cache[key]
+
+    def _band_mask_rows(self, keep: Optional[torch.Tensor], K: int, global_batch: int, device) -> torch.Tensor:
+        """(bands, Lmax) pre-normalised EDC weights of bands with different windows: band q keeps the first len_q entries of
+        the 0/1 mask ``keep`` (None: every index) and divides by (global batch x kept among them); zero behind its window."""
+        _, Lmax = self._decay_window(K)
+        lens = self._band_windows(K)
+        k = torch.ones(Lmax, dtype=torch.float32, device=device) if keep is None else keep.to(device=device, dtype=torch.float32)
+        rows = torch.zeros((self.num_bands, Lmax), dtype=torch.float32, device=device)
+        for q, L in enumerate(lens):
+            cnt = k[:L].sum()
+            rows[q, :L] = torch.where(cnt > 0, k[:L] / (cnt * global_batch), torch.zeros_like(k[:L]))
+        return rows
 
     @property
     def _reduced_step_losses(self) -> bool:
@@ -401,20 +448,24 @@ class BandBankTrainer:
             self._filt_u = ((Ku, order is not None), Fu.contiguous())
         return self._filt_u[1]
 
-    def _draw_edc_mask(self, length: int, Bper: int, device, draw_mask: bool = True):
+    def _draw_edc_mask(self, length: int, Bper: int, device, draw_mask: bool = True, K: Optional[int] = None):
         """(maskw, 1 / (global batch x kept indices)) drawn like the reference (losses.py:221-227), the same on all
         ranks."""
         maskw, count = (self.criterion[1].draw_mask(length, device) if draw_mask else (None, float(length)))
         if maskw is not None and self.world_size > 1:
             dist.broadcast(maskw, src=0, group=self.process_group)
             count = float(maskw.sum().item())
+        if K is not None and self._band_windows(K) is not None:
+            # bands with different windows: ONE draw of the longest window, truncated per band; the rows come back
+            # pre-normalised (every band has its own count), so nothing is left to divide by
+            return self._band_mask_rows(maskw, K, Bper * self.world_size, device), 1.0
         return maskw, 1.0 / (Bper * self.world_size * count)
 
     def _fused_step(self, data: Dict, train: bool, draw_mask: bool = True):
         rows = data['row_index']
         K = data['z_values'].shape[-1]
         _, length = self._decay_window(K)
-        maskw, inv = self._draw_edc_mask(length, rows.numel() // self.num_bands, rows.device, draw_mask)
+        maskw, inv = self._draw_edc_mask(length, rows.numel() // self.num_bands, rows.device, draw_mask, K=K)
         losses = self._fused.run(data, maskw, inv, normalize_first=False, train=train, allreduce=self._allreduce)
         losses.pop('_total')
         return sum(losses.values()), losses
@@ -519,8 +570,12 @@ class BandBankTrainer:
                     tail_done = torch.cuda.Event()
                     tail_done.record(side)
         start, length = self._decay_window(K)
+        item_len, _ = self._item_windows(K, Bper, H.device)
         gb = Bper
         if mask_prenorm is not None:
+            maskw, count = mask_prenorm, None
+        elif item_len is not None:
+            mask_prenorm, _ = self._draw_edc_mask(length, Bper, H.device, draw_mask, K=K)     # (bands, Lmax) rows
             maskw, count = mask_prenorm, None
         else:
             maskw, count = (self.criterion[1].draw_mask(length, H.device) if draw_mask else (None, float(length)))
@@ -536,7 +591,7 @@ class BandBankTrainer:
             edc_maskw_prenormalised=mask_prenorm is not None, global_batch=gb,
             edr_target=(edr_t[1], edr_t[2]), edc_target=edc_t[1], side_stream=self._stream('_side2'),
             unit_grad=True, n_time=K, target_rows=rows, nbands=nb, slot_order=order is not None,
-            pairs=pairs_path,
+            pairs=pairs_path, edc_item_len=item_len, edc_items_per_band=Bper,
             join_event=tail_done if (fused and side is not None) else None)
         losses = {'edc_loss': edc_v, 'edr_loss': edr_v, 'spectral_loss': spec.detach(),
                   'sparsity_loss': sparse.detach()}
@@ -610,8 +665,7 @@ class BandBankTrainer:
         if B // world == 0:
             raise ValueError("BandBankTrainer.train: the batch is smaller than the number of ranks")
         K = dataset.z_values.shape[-1]
-        start, length = self._decay_window(K)
-        dataset.precompute_decay_targets(self.stft_win, start, length)
+        dataset.precompute_decay_targets(self.stft_win, *self._target_window(K))
         Bl = B // world                       # this rank's receivers per band of a full batch (global batch B)
         step = self.graphed(dataset, Bl)
         self.train_loss = [[] for _ in range(nb)]

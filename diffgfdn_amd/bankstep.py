@@ -86,7 +86,7 @@ class FusedBankStep:
 
     # ------------------------------------------------------------------------------------------
     def _decay_middle(self, H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc, start, length, ev, main,
-                      side2, x_fn=None, Btot=None, gains=None):
+                      side2, x_fn=None, Btot=None, gains=None, item_len=None, Bper=None):
         """One chain over the whole batch: main: irfft -> STFT -> EDR -> STFT adjoint (even frames, then odd frames +
         EDC gradient) -> irfft adjoint; side2: EDC scans.  Records ev['x'] / ev['edc'] / ev['g']."""
         tr, cfg, keep = self.tr, self.tr.config, self._keep
@@ -99,7 +99,7 @@ class FusedBankStep:
         else:
             x = ops.irfft_odd_fwd(H, K, slots=order is not None)
         ev['x'].record()
-        if pairs and self.fuse_decay and win == 4096 and start + length <= x.shape[1]:
+        if pairs and self.fuse_decay and win == 4096 and start + length <= x.shape[1] and item_len is None:
             # ONE launch per item for STFT -> EDR and the whole EDC term (csrc/decay.hip): |STFT|^2 never reaches memory,
             # the EDR kernel and the three EDC scans do not run; the EDC gradient comes back planar and joins in the
             # odd-frame launch of the STFT adjoint
@@ -132,10 +132,10 @@ class FusedBankStep:
             torch.cuda.current_stream().wait_event(ev['x'])
             if pairs:
                 li_edc, g_edc = ops.edc_loss_pairs(x, Btot, start, length, T_edc, maskw, inv, cfg.edc_loss_weight,
-                                                   train, rows=rows)
+                                                   train, rows=rows, item_len=item_len, items_per_band=Bper)
             else:
                 li_edc, g_edc = ops.edc_loss(x, start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train,
-                                             rows=rows)
+                                             rows=rows, item_len=item_len, items_per_band=Bper)
             ev['edc'].record()
         li_edr = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rows, defer=True)
         keep.extend((x, P, g_edr, li_edc, g_edc, li_edr))
@@ -262,6 +262,12 @@ class FusedBankStep:
         Hh, n_hidden, _, lo, hi = bank._mlp_cfg
         w = bank.output_scalars_w.detach()
         start, length = tr._decay_window(K)
+        # bands whose longest decay times differ have their own EDC windows (reference trainer.py:56-59): per-item window
+        # lengths for the EDC scans, ``maskw`` then holds one pre-normalised row per band
+        item_len, _ = tr._item_windows(K, Btot // nb, z.device)
+        if item_len is not None and (maskw is None or maskw.ndim != 2):
+            raise ValueError("bands with different EDC windows: pass the (bands, window) weight rows of "
+                             "BandBankTrainer._band_mask_rows as maskw")
         edr_t, edc_t = data['edr_target'], data['edc_target']
         T_edr, sum_abs, T_edc = edr_t[1], edr_t[2], edc_t[1]
         win = tr.stft_win
@@ -385,14 +391,15 @@ class FusedBankStep:
 
         # ---- decay losses: irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint, EDC scans beside them
         ev['h'].record()
-        want_halves = self.halves >= 2 and pairs and Btot % 4 == 0 and side is not None
+        want_halves = self.halves >= 2 and pairs and Btot % 4 == 0 and side is not None and item_len is None
         if want_halves:
             li_edr, li_edc, gH = self._decay_middle_halves(H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start,
                                                            length, ev, main, side, side2)
         else:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
                                                     start, length, ev, main, side2, x_fn=x_fn, Btot=Btot,
-                                                    gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None)
+                                                    gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None,
+                                                    item_len=item_len, Bper=Btot // nb)
         if late_colorless:
             grec_sub, out3, gQ = colorless_pass()
         def report():

@@ -277,6 +277,14 @@ __device__ __forceinline__ void edc_scan(int len, float carry, float* lds, G get
   }
 }
 
+// Per-item windows of a band bank (gfdn_edc_loss*_banded): item b's window is [start, start + item_len[b]), its target
+// row has pitch ld_T, and band b / items_per_band reads mask row maskw + band * ld_mask (ld_mask = 0: one shared row).
+// item_len == nullptr: one window ``len`` for every item, targets of pitch ``len`` (the plain entry points).
+struct EdcBands {
+  const int* item_len;
+  int ld_T, items_per_band, ld_mask;
+};
+
 __device__ __forceinline__ void edc_segment(int len, int seg, int* s0, int* slen) {
   int per = (len + EDC_NSEG - 1) / EDC_NSEG;
   per = (per + 3) & ~3;
@@ -289,9 +297,11 @@ __device__ __forceinline__ void edc_segment(int len, int seg, int* s0, int* slen
 // segsum[b][seg] = sum of x^2 over the segment
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_segsum(const float* __restrict__ x, int ld,
                                                             int start, int len,
-                                                            float* __restrict__ segsum) {
+                                                            float* __restrict__ segsum,
+                                                            const int* __restrict__ item_len) {
   __shared__ float s_red[16];
   const int seg = blockIdx.x, b = blockIdx.y;
+  if (item_len) len = item_len[b];          // (per-item windows: band banks whose bands differ in T60max)
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
   const float* xw = x + (size_t)b * ld + start + s0;
@@ -332,19 +342,23 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_fwd(const float* __rest
                                                              float* __restrict__ work,
                                                              float* __restrict__ gx, int batch,
                                                              const float* __restrict__ amps, int S,
-                                                             const float* __restrict__ env, int ld_env) {
+                                                             const float* __restrict__ env, int ld_env,
+                                                             EdcBands eb) {
   __shared__ float s_scan[16 * EDC_S];
   __shared__ float s_red[16];
   const int seg = blockIdx.x, b = blockIdx.y;
   const float* segsum = work;
   float* partial = work + (size_t)batch * EDC_NSEG;
   float* gsum = partial + (size_t)batch * EDC_NSEG;
+  const int ld_T = eb.item_len ? eb.ld_T : len;
+  if (eb.item_len) len = eb.item_len[b];
+  if (maskw && eb.ld_mask) maskw += (size_t)(b / eb.items_per_band) * eb.ld_mask;
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
   const float* xw = x + (size_t)b * ld + start + s0;
   // target: a stored EDC in dB (Tdb), or the common-slope model evaluated on the fly (losses.py:354-359: einsum
   // 'bjk,kt->bjt' of the item's amplitudes with the slope envelopes, then dB) -- amps (items, S), env (S, ld_env)
-  const float* t = Tdb ? Tdb + (trows ? (size_t)trows[b] : (size_t)b) * len + s0 : nullptr;
+  const float* t = Tdb ? Tdb + (trows ? (size_t)trows[b] : (size_t)b) * ld_T + s0 : nullptr;
   const float* am = amps ? amps + (size_t)b * S : nullptr;
   const float* ev = env ? env + s0 : nullptr;
   const float* mw = maskw ? maskw + s0 : nullptr;
@@ -444,9 +458,11 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_seg_bwd(const float* __rest
                                                              int start, int len, float inv_count,
                                                              const float* __restrict__ work,
                                                              float* __restrict__ loss_item,
-                                                             float* __restrict__ gx, int batch) {
+                                                             float* __restrict__ gx, int batch,
+                                                             const int* __restrict__ item_len) {
   __shared__ float s_scan[16 * EDC_S];
   const int seg = blockIdx.x, b = blockIdx.y;
+  if (item_len) len = item_len[b];
   const float* partial = work + (size_t)batch * EDC_NSEG;
   const float* gsum = partial + (size_t)batch * EDC_NSEG;
   if (seg == 0 && threadIdx.x == 0) {
@@ -551,9 +567,11 @@ __device__ __forceinline__ float block_sum2(float2& v, float* lds /* >= 32 float
 
 // work layout (items padded to 2 * pairs): segsum[I][NSEG] | partial[I][NSEG] | gsum[I][NSEG]
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_segsum(const float2* __restrict__ x2, int ld, int start,
-                                                                 int len, float* __restrict__ segsum) {
+                                                                 int len, float* __restrict__ segsum,
+                                                                 const int* __restrict__ item_len) {
   __shared__ float s_red[32];
   const int seg = blockIdx.x, p = blockIdx.y;
+  if (item_len) len = item_len[2 * p];      // (both items of a pair belong to one band: one window)
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
   const float2* xw = x2 + (size_t)p * ld + start + s0;
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float
                                                                   const float* __restrict__ maskw,
                                                                   float inv_count, float gscale,
                                                                   float* __restrict__ work,
-                                                                  float2* __restrict__ gx2, int items) {
+                                                                  float2* __restrict__ gx2, int items, EdcBands eb) {
   __shared__ float2 s_scan[16 * EDC_S];
   __shared__ float s_red[32];
   const int seg = blockIdx.x, p = blockIdx.y;
@@ -585,11 +603,14 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float
   const float* segsum = work;
   float* partial = work + (size_t)I * EDC_NSEG;
   float* gsum = partial + (size_t)I * EDC_NSEG;
+  const int ld_T = eb.item_len ? eb.ld_T : len;
+  if (eb.item_len) len = eb.item_len[b1];
+  if (maskw && eb.ld_mask) maskw += (size_t)(b1 / eb.items_per_band) * eb.ld_mask;
   int s0, sl;
   edc_segment(len, seg, &s0, &sl);
   const float2* xw = x2 + (size_t)p * ld + start + s0;
-  const float* t1 = Tdb + (trows ? (size_t)trows[b1] : (size_t)b1) * len + s0;
-  const float* t2 = two ? Tdb + (trows ? (size_t)trows[b2] : (size_t)b2) * len + s0 : t1;
+  const float* t1 = Tdb + (trows ? (size_t)trows[b1] : (size_t)b1) * ld_T + s0;
+  const float* t2 = two ? Tdb + (trows ? (size_t)trows[b2] : (size_t)b2) * ld_T + s0 : t1;
   const float* mw = maskw ? maskw + s0 : nullptr;
   float2* gw = gx2 ? gx2 + (size_t)p * ld + start + s0 : nullptr;
   float2 acc = make_float2(0.f, 0.f), gacc = make_float2(0.f, 0.f);
@@ -709,11 +730,13 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_bwd(const float
                                                                   int len, float inv_count,
                                                                   const float* __restrict__ work,
                                                                   float* __restrict__ loss_item,
-                                                                  float2* __restrict__ gx2, int items) {
+                                                                  float2* __restrict__ gx2, int items,
+                                                                  const int* __restrict__ item_len) {
   __shared__ float2 s_scan[16 * EDC_S];
   const int seg = blockIdx.x, p = blockIdx.y;
   const int I = 2 * (int)gridDim.y, b1 = 2 * p, b2 = b1 + 1;
   const bool two = b2 < items;
+  if (item_len) len = item_len[b1];
   const float* partial = work + (size_t)I * EDC_NSEG;
   const float* gsum = partial + (size_t)I * EDC_NSEG;
   if (seg == 0 && threadIdx.x == 0) {
@@ -796,10 +819,25 @@ extern "C" int gfdn_edc_target(const float* x, int ld, int batch, int start, int
     return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_edc_segsum, dim3(EDC_NSEG, batch), dim3(EDC_THREADS), 0, s, x, ld, start, len,
-                     (float*)work);
+                     (float*)work, (const int*)nullptr);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_target, dim3(EDC_NSEG, batch), dim3(EDC_THREADS), 0, s, x, ld, start, len,
                      (const float*)work, T_db);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int edc_loss_launch(const float* x, int ld, int batch, int start, int len, const float* T_db,
+                           const long long* target_rows, const float* maskw, float inv_count, float gscale,
+                           float* loss_item, float* gx, void* work, EdcBands eb, hipStream_t s) {
+  dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
+  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work, eb.item_len);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, target_rows, maskw, inv_count, gscale,
+                     (float*)work, gx, batch, (const float*)nullptr, 0, (const float*)nullptr, 0, eb);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
+                     loss_item, gx, batch, eb.item_len);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -810,17 +848,23 @@ extern "C" int gfdn_edc_loss(const float* x, int ld, int batch, int start, int l
                              float* loss_item, float* gx, void* work, void* stream) {
   if (!x || !T_db || !loss_item || !work || batch <= 0 || start < 0 || len <= 0 || start + len > ld)
     return GFDN_E_BADARG;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
-  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, T_db, target_rows, maskw, inv_count, gscale,
-                     (float*)work, gx, batch, (const float*)nullptr, 0, (const float*)nullptr, 0);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
-                     loss_item, gx, batch);
-  GFDN_LAUNCH_CHECK();
-  return 0;
+  return edc_loss_launch(x, ld, batch, start, len, T_db, target_rows, maskw, inv_count, gscale, loss_item, gx, work,
+                         EdcBands{nullptr, len, 1, 0}, (hipStream_t)stream);
+}
+
+// Band bank whose bands have different longest decay times (src/diff_gfdn/trainer.py:56-59: every band's trainer derives
+// its EDC window from ITS T60max; run_subband_training_treble.py:286 gives every band its own decay times): item b's
+// window is [start, start + item_len[b]) with item_len[b] <= max_len (device int32, one entry per item), its target row has
+// pitch ld_T >= max_len, and band b / items_per_band reads the mask row maskw + band * ld_mask (ld_mask = 0: one row).
+extern "C" int gfdn_edc_loss_banded(const float* x, int ld, int batch, int start, int max_len, const int* item_len,
+                                    const float* T_db, int ld_T, const long long* target_rows, const float* maskw,
+                                    int ld_mask, int items_per_band, float inv_count, float gscale, float* loss_item,
+                                    float* gx, void* work, void* stream) {
+  if (!x || !T_db || !item_len || !loss_item || !work || batch <= 0 || start < 0 || max_len <= 0 || start + max_len > ld ||
+      ld_T < max_len || items_per_band <= 0 || ld_mask < 0 || (ld_mask > 0 && ld_mask < max_len))
+    return GFDN_E_BADARG;
+  return edc_loss_launch(x, ld, batch, start, max_len, T_db, target_rows, maskw, inv_count, gscale, loss_item, gx, work,
+                         EdcBands{item_len, ld_T, items_per_band, ld_mask}, (hipStream_t)stream);
 }
 
 // gfdn_edc_loss against the common-slope MODEL instead of a stored target (directional loss, losses.py:354-359):
@@ -834,13 +878,29 @@ extern "C" int gfdn_edc_loss_model(const float* x, int ld, int batch, int start,
     return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(EDC_NSEG, batch), block(EDC_THREADS);
-  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work);
+  hipLaunchKernelGGL(k_edc_segsum, grid, block, 0, s, x, ld, start, len, (float*)work, (const int*)nullptr);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_seg_fwd, grid, block, 0, s, x, ld, start, len, (const float*)nullptr,
-                     (const long long*)nullptr, maskw, inv_count, gscale, (float*)work, gx, batch, amps, S, env, ld_env);
+                     (const long long*)nullptr, maskw, inv_count, gscale, (float*)work, gx, batch, amps, S, env, ld_env,
+                     EdcBands{nullptr, len, 1, 0});
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_edc_seg_bwd, grid, block, 0, s, x, ld, start, len, inv_count, (const float*)work,
-                     loss_item, gx, batch);
+                     loss_item, gx, batch, (const int*)nullptr);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int edc_loss_pairs_launch(const float* x2, int ld, int items, int start, int len, const float* T_db,
+                                 const long long* target_rows, const float* maskw, float inv_count, float gscale,
+                                 float* loss_item, float* gx2, void* work, EdcBands eb, hipStream_t s) {
+  dim3 grid(EDC_NSEG, (items + 1) / 2), block(EDC_THREADS);
+  hipLaunchKernelGGL(k_edc_pair_segsum, grid, block, 0, s, (const float2*)x2, ld, start, len, (float*)work, eb.item_len);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_pair_seg_fwd, grid, block, 0, s, (const float2*)x2, ld, start, len, T_db, target_rows,
+                     maskw, inv_count, gscale, (float*)work, (float2*)gx2, items, eb);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_edc_pair_seg_bwd, grid, block, 0, s, (const float2*)x2, ld, start, len, inv_count,
+                     (const float*)work, loss_item, (float2*)gx2, items, eb.item_len);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -852,17 +912,23 @@ extern "C" int gfdn_edc_loss_pairs(const float* x2, int ld, int items, int start
                                    float* loss_item, float* gx2, void* work, void* stream) {
   if (!x2 || !T_db || !loss_item || !work || items <= 0 || start < 0 || len <= 0 || start + len > ld)
     return GFDN_E_BADARG;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(EDC_NSEG, (items + 1) / 2), block(EDC_THREADS);
-  hipLaunchKernelGGL(k_edc_pair_segsum, grid, block, 0, s, (const float2*)x2, ld, start, len, (float*)work);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_pair_seg_fwd, grid, block, 0, s, (const float2*)x2, ld, start, len, T_db, target_rows,
-                     maskw, inv_count, gscale, (float*)work, (float2*)gx2, items);
-  GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_pair_seg_bwd, grid, block, 0, s, (const float2*)x2, ld, start, len, inv_count,
-                     (const float*)work, loss_item, (float2*)gx2, items);
-  GFDN_LAUNCH_CHECK();
-  return 0;
+  return edc_loss_pairs_launch(x2, ld, items, start, len, T_db, target_rows, maskw, inv_count, gscale, loss_item, gx2,
+                               work, EdcBands{nullptr, len, 1, 0}, (hipStream_t)stream);
+}
+
+// gfdn_edc_loss_banded on pair-interleaved signals: both items of a pair belong to one band (items_per_band even), so a
+// pair has ONE window.
+extern "C" int gfdn_edc_loss_pairs_banded(const float* x2, int ld, int items, int start, int max_len,
+                                          const int* item_len, const float* T_db, int ld_T,
+                                          const long long* target_rows, const float* maskw, int ld_mask,
+                                          int items_per_band, float inv_count, float gscale, float* loss_item,
+                                          float* gx2, void* work, void* stream) {
+  if (!x2 || !T_db || !item_len || !loss_item || !work || items <= 0 || start < 0 || max_len <= 0 ||
+      start + max_len > ld || ld_T < max_len || items_per_band <= 0 || (items_per_band & 1) || items % items_per_band ||
+      ld_mask < 0 || (ld_mask > 0 && ld_mask < max_len))
+    return GFDN_E_BADARG;
+  return edc_loss_pairs_launch(x2, ld, items, start, max_len, T_db, target_rows, maskw, inv_count, gscale, loss_item,
+                               gx2, work, EdcBands{item_len, ld_T, items_per_band, ld_mask}, (hipStream_t)stream);
 }
 
 extern "C" int gfdn_abi_version(void) { return GFDN_ABI_VERSION; }
@@ -907,6 +973,53 @@ __global__ __launch_bounds__(1024) void k_draw_mask(unsigned long long seed, uns
     maskw[t] = ((words[t >> 5] >> (t & 31)) & 1u) ? wgt : 0.f;
   __syncthreads();
   if (threadIdx.x == 0) state[0] = step + 1ull;
+}
+
+// One row of weights per band from ONE draw of max(band_len) fair bits (the bits of gfdn_draw_mask at the same seed and
+// step): band q keeps the first band_len[q] of them, maskw[q][t] = kept * scale / (kept among the first band_len[q]), zero
+// behind its window up to the row pitch.  One workgroup: the bits are generated once, then one fixed-order count and
+// one row of stores per band.
+__global__ __launch_bounds__(1024) void k_draw_mask_banded(unsigned long long seed, unsigned long long* state,
+                                                           const int* __restrict__ band_len, int nbands, int max_len,
+                                                           int ld_mask, float scale, float* maskw) {
+  __shared__ unsigned words[MASK_MAX_LEN / 32];
+  __shared__ float red[16];
+  const unsigned long long step = state[0];
+  const int nchunk = (max_len + 127) >> 7;
+  for (int i = threadIdx.x; i < nchunk; i += blockDim.x) {
+    unsigned c[4] = {(unsigned)i, 0u, (unsigned)step, (unsigned)(step >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) words[i * 4 + w] = c[w];
+  }
+  __syncthreads();
+  for (int q = 0; q < nbands; ++q) {
+    const int len = band_len[q] < max_len ? band_len[q] : max_len;
+    const int nw = (len + 31) >> 5;
+    float cnt = 0.f;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+      const int left = len - i * 32;
+      unsigned v = words[i];
+      if (left < 32) v &= (1u << left) - 1u;
+      cnt += (float)__popc(v);
+    }
+    const float count = block_sum(cnt, red);          // exact: integers below 2^24
+    const float wgt = count > 0.f ? scale / count : 0.f;
+    float* row = maskw + (size_t)q * ld_mask;
+    for (int t = threadIdx.x; t < ld_mask; t += blockDim.x)
+      row[t] = (t < len && ((words[t >> 5] >> (t & 31)) & 1u)) ? wgt : 0.f;
+    __syncthreads();                                  // (red is reused by the next band's count)
+  }
+  if (threadIdx.x == 0) state[0] = step + 1ull;
+}
+
+extern "C" int gfdn_draw_mask_banded(unsigned long long seed, unsigned long long* state, const int* band_len, int nbands,
+                                     int max_len, int ld_mask, float scale, float* maskw, void* stream) {
+  if (!state || !band_len || !maskw || nbands <= 0 || max_len <= 0 || max_len > MASK_MAX_LEN || ld_mask < max_len)
+    return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_draw_mask_banded, dim3(1), dim3(1024), 0, (hipStream_t)stream, seed, state, band_len, nbands,
+                     max_len, ld_mask, scale, maskw);
+  return (int)hipGetLastError();
 }
 
 extern "C" int gfdn_draw_mask(unsigned long long seed, unsigned long long* state, int len, float scale,

@@ -122,6 +122,9 @@ class MultiRIRDataset(torch.utils.data.Dataset):
 
     # model-independent loss targets for the whole grid (SURVEY §8d "precomputed once")
     def precompute_decay_targets(self, win: int, edc_start: int, edc_len: int, chunk: int = 64):
+        if (self.edr_store is not None and self.edc_store is not None and self.edr_store[0] == win
+                and self.edc_store[0] == (edc_start, edc_len)):
+            return                      # the stores already hold these targets
         R = len(self)
         nf = ops.stft_nframes(self.rir_mag_response.shape[-1], win)
         T_edr = torch.empty((R, nf, win // 2 + 1), dtype=torch.float32, device=self.device)

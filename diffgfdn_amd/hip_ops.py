@@ -1376,13 +1376,36 @@ def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None
     return loss_item, gx
 
 
+def _edc_bands(item_len, items: int, items_per_band, maskw, length: int, T_db, what: str):
+    """Arguments of the banded EDC entry points: (items_per_band, ld_mask) -- see gfdn_edc_loss_banded.
+    ``maskw`` (bands, >= length) selects per-band mask rows, a vector is shared by all bands."""
+    if item_len.dtype != torch.int32 or not item_len.is_contiguous() or item_len.numel() != items:
+        raise RuntimeError(f"{what}: item_len must be a contiguous int32 tensor with one window length per item")
+    ipb = items if items_per_band is None else int(items_per_band)
+    if ipb <= 0 or items % ipb:
+        raise RuntimeError(f"{what}: items_per_band must divide the number of items")
+    ld_mask = 0
+    if maskw is not None and maskw.ndim == 2:
+        if maskw.shape[0] != items // ipb or maskw.shape[1] < length:
+            raise RuntimeError(f"{what}: per-band mask weights must be (bands, >= window)")
+        ld_mask = maskw.shape[1]
+    elif maskw is not None and maskw.numel() < length:
+        raise RuntimeError(f"{what}: mask weights shorter than the window")
+    if T_db.shape[-1] < length:
+        raise RuntimeError(f"{what}: target rows shorter than the longest window")
+    return ipb, ld_mask
+
+
 def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
-                   gscale: float = 1.0, want_grad: bool = True, rows=None, out=None):
-    """edc_loss on pair-interleaved signals x2 (ceil(items / 2), T, 2) -> loss_item (items,), g2 like x2 or None."""
+                   gscale: float = 1.0, want_grad: bool = True, rows=None, out=None, item_len=None,
+                   items_per_band=None):
+    """edc_loss on pair-interleaved signals x2 (ceil(items / 2), T, 2) -> loss_item (items,), g2 like x2 or None.
+    ``item_len`` (items,) int32: per-item window lengths <= ``length`` (band banks whose bands differ in T60max,
+    gfdn_edc_loss_pairs_banded): T_db rows are then padded to >= length, ``maskw`` may be (bands, >= length)."""
     _need_gpu(x2, T_db)
     T = x2.shape[1]
     rows = _rows(rows, items, T_db.shape[0])
-    if T_db.dtype != _f32 or not T_db.is_contiguous() or T_db.shape[-1] != length \
+    if T_db.dtype != _f32 or not T_db.is_contiguous() or (item_len is None and T_db.shape[-1] != length) \
             or (rows is None and T_db.shape[0] != items):
         raise RuntimeError("edc_loss_pairs: target shape does not match the window")
     maskw = None if maskw is None else _f(maskw)
@@ -1392,6 +1415,13 @@ def edc_loss_pairs(x2, items: int, start: int, length: int, T_db, maskw=None, in
     g2 = torch.empty_like(x2) if want_grad else None      # (the kernel writes zeros for a missing partner)
     lib = _lib.load()
     work = _work(lib.gfdn_edc_work_bytes(items + 1), x2.device)
+    if item_len is not None:
+        ipb, ld_mask = _edc_bands(item_len, items, items_per_band, maskw, length, T_db, "edc_loss_pairs")
+        _lib.check(lib.gfdn_edc_loss_pairs_banded(_p(x2), T, items, start, length, _p(item_len), _p(T_db),
+                                                  T_db.shape[-1], _p(rows), _p(maskw), ld_mask, ipb, float(inv_count),
+                                                  float(gscale), _p(loss_item), _p(g2), _p(work), _stream()),
+                   "gfdn_edc_loss_pairs_banded")
+        return loss_item, g2
     _lib.check(lib.gfdn_edc_loss_pairs(_p(x2), T, items, start, length, _p(T_db), _p(rows), _p(maskw),
                                        float(inv_count), float(gscale), _p(loss_item), _p(g2), _p(work),
                                        _stream()), "gfdn_edc_loss_pairs")
@@ -1461,13 +1491,14 @@ def edc_target(x, start: int, length: int) -> torch.Tensor:
 
 
 def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.0,
-             gscale: float = 1.0, want_grad: bool = True, rows=None):
-    """-> loss_item (batch,), gx (batch, ld) or None.  ``rows``: as in edr_loss."""
+             gscale: float = 1.0, want_grad: bool = True, rows=None, item_len=None, items_per_band=None):
+    """-> loss_item (batch,), gx (batch, ld) or None.  ``rows``: as in edr_loss.  ``item_len`` / ``items_per_band``: as in
+    edc_loss_pairs (gfdn_edc_loss_banded)."""
     _need_gpu(x, T_db)
     x = _f(x)
     batch, ld = x.shape
     rows = _rows(rows, batch, T_db.shape[0])
-    if T_db.dtype != _f32 or not T_db.is_contiguous() or T_db.shape[-1] != length \
+    if T_db.dtype != _f32 or not T_db.is_contiguous() or (item_len is None and T_db.shape[-1] != length) \
             or (rows is None and T_db.shape[0] != batch):
         raise RuntimeError("edc_loss: target shape does not match the window")
     maskw = None if maskw is None else _f(maskw)
@@ -1475,24 +1506,43 @@ def edc_loss(x, start: int, length: int, T_db, maskw=None, inv_count: float = 1.
     gx = torch.empty_like(x) if want_grad else None
     lib = _lib.load()
     work = _work(lib.gfdn_edc_work_bytes(batch), x.device)
+    if item_len is not None:
+        ipb, ld_mask = _edc_bands(item_len, batch, items_per_band, maskw, length, T_db, "edc_loss")
+        _lib.check(lib.gfdn_edc_loss_banded(_p(x), ld, batch, start, length, _p(item_len), _p(T_db), T_db.shape[-1],
+                                            _p(rows), _p(maskw), ld_mask, ipb, float(inv_count), float(gscale),
+                                            _p(loss_item), _p(gx), _p(work), _stream()), "gfdn_edc_loss_banded")
+        return loss_item, gx
     _lib.check(lib.gfdn_edc_loss(_p(x), ld, batch, start, length, _p(T_db), _p(rows), _p(maskw),
                                  float(inv_count), float(gscale), _p(loss_item), _p(gx), _p(work),
                                  _stream()), "gfdn_edc_loss")
     return loss_item, gx
 
 
-def draw_mask(seed: int, state, length: int, scale: float, out=None):
+def draw_mask(seed: int, state, length: int, scale: float, out=None, band_len=None):
     """Fair-coin EDC time mask drawn on the device (counter-based; ``state`` is a 1-element int64
-    step counter that the kernel advances) -> maskw (length,) = kept * scale / count."""
+    step counter that the kernel advances) -> maskw (length,) = kept * scale / count.
+    ``band_len`` (bands,) int32 device tensor: one row per band from the same bits, band q keeping the first
+    band_len[q] <= length of them -> maskw (bands, length) (gfdn_draw_mask_banded)."""
     _need_gpu(state)
     if state.dtype != torch.int64 or state.numel() != 1:
         raise RuntimeError("draw_mask: state must be a 1-element int64 device tensor")
+    lib = _lib.load()
+    if band_len is not None:
+        if band_len.dtype != torch.int32 or not band_len.is_contiguous() or not band_len.is_cuda:
+            raise RuntimeError("draw_mask: band_len must be a contiguous int32 device tensor")
+        nb = band_len.numel()
+        if out is None:
+            out = torch.empty((nb, length), dtype=_f32, device=state.device)
+        if out.dtype != _f32 or tuple(out.shape) != (nb, length) or not out.is_contiguous():
+            raise RuntimeError("draw_mask: out must be a contiguous float32 (bands, length) tensor")
+        _lib.check(lib.gfdn_draw_mask_banded(int(seed) & 0xFFFFFFFFFFFFFFFF, _p(state), _p(band_len), nb, int(length),
+                                             int(length), float(scale), _p(out), _stream()), "gfdn_draw_mask_banded")
+        return out
     if out is None:
         out = torch.empty(length, dtype=_f32, device=state.device)
     _need_gpu(out)
     if out.dtype != _f32 or out.numel() != length or not out.is_contiguous():
         raise RuntimeError("draw_mask: out must be a contiguous float32 tensor of the mask length")
-    lib = _lib.load()
     _lib.check(lib.gfdn_draw_mask(int(seed) & 0xFFFFFFFFFFFFFFFF, _p(state), int(length), float(scale),
                                   _p(out), _stream()), "gfdn_draw_mask")
     return out

@@ -220,7 +220,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                  side_stream: Optional["torch.cuda.Stream"] = None,
                  unit_grad: bool = False, n_time: Optional[int] = None,
                  target_rows: Optional[torch.Tensor] = None, nbands: int = 1, slot_order: bool = False,
-                 pairs: bool = False, join_event=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                 pairs: bool = False, join_event=None, edc_item_len: Optional[torch.Tensor] = None,
+                 edc_items_per_band: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused EDR + EDC evaluation sharing ONE irfft of H and ONE adjoint transform.
 
     Returns (total, w_edr * edr, w_edc * edc) with total = their sum carrying the gradient; the two
@@ -241,7 +242,11 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
     bin 0, column 1 + s = slot s): the transform then needs no gather and dL/dH comes back in the same order.
     ``pairs`` (with slot_order, win 4096, precomputed targets): two items ride one complex transform and the time
     signals stay pair-interleaved (float2) through the STFT / EDC kernels: one 8-byte scatter / gather per slot
-    serves two items and the transform passes move half the work blocks."""
+    serves two items and the transform passes move half the work blocks.
+    ``edc_item_len`` (items,) int32 + ``edc_items_per_band``: per-item EDC window lengths <= ``edc_len`` (band banks whose
+    bands differ in T60max; ``edc_target`` rows padded to ``edc_len``, ``edc_maskw`` (bands, edc_len) pre-normalised)."""
+    if edc_item_len is not None and not (edc_maskw_prenormalised and edc_maskw is not None):
+        raise ValueError("per-item EDC windows take pre-normalised per-band weight rows (every band has its own count)")
     if pairs:
         return _decay_losses_pairs(H, win=win, edr_weight=edr_weight, edc_weight=edc_weight, edc_start=edc_start,
                                    edc_len=edc_len, edc_maskw=edc_maskw, edc_count=edc_count,
@@ -249,7 +254,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
                                    edr_target=edr_target, edc_target=edc_target, side_stream=side_stream,
                                    unit_grad=unit_grad, n_time=n_time, target_rows=target_rows, nbands=nbands,
                                    slot_order=slot_order, freq_weights=freq_weights,
-                                   reduced_pole_radius=reduced_pole_radius, join_event=join_event)
+                                   reduced_pole_radius=reduced_pole_radius, join_event=join_event,
+                                   edc_item_len=edc_item_len, edc_items_per_band=edc_items_per_band)
     if target_rows is not None and (edr_target is None and use_edr or edc_target is None and use_edc):
         raise ValueError("target_rows needs precomputed target stores")
     targets = targets or _default_targets
@@ -281,11 +287,11 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
             side_stream.wait_stream(main)
             with torch.cuda.stream(side_stream):
                 li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad,
-                                          rows=target_rows)
+                                          rows=target_rows, item_len=edc_item_len, items_per_band=edc_items_per_band)
                 x.record_stream(side_stream)
         else:
             li_edc, gx = ops.edc_loss(x, edc_start, L, T_db, edc_maskw, inv, edc_weight, want_grad,
-                                      rows=target_rows)
+                                      rows=target_rows, item_len=edc_item_len, items_per_band=edc_items_per_band)
     if use_edr:
         T_edr, sum_abs = edr_target if edr_target is not None else targets.edr(target, win)
         xe = x if env is None else x * env
@@ -322,7 +328,8 @@ def decay_losses(H: torch.Tensor, target: Optional[torch.Tensor] = None, *, win:
 
 def _decay_losses_pairs(H, *, win, edr_weight, edc_weight, edc_start, edc_len, edc_maskw, edc_count,
                         edc_maskw_prenormalised, global_batch, edr_target, edc_target, side_stream, unit_grad,
-                        n_time, target_rows, nbands, slot_order, freq_weights, reduced_pole_radius, join_event=None):
+                        n_time, target_rows, nbands, slot_order, freq_weights, reduced_pole_radius, join_event=None,
+                        edc_item_len=None, edc_items_per_band=None):
     """decay_losses on pair-interleaved time signals (see there); EDR and EDC both on, targets precomputed.
     ``join_event``: an event of another branch of the step that the loss kernels wait for behind the transform
     (scheduling only: it pulls that branch in front of the loss kernels instead of beside their adjoints)."""
@@ -347,7 +354,7 @@ def _decay_losses_pairs(H, *, win, edr_weight, edc_weight, edc_start, edc_len, e
         side_stream.wait_stream(main)
     with torch.cuda.stream(side_stream) if fork else contextlib.nullcontext():
         li_edc, g_edc = ops.edc_loss_pairs(x2, B, edc_start, L, edc_target, edc_maskw, inv, edc_weight, want_grad,
-                                           rows=target_rows)
+                                           rows=target_rows, item_len=edc_item_len, items_per_band=edc_items_per_band)
         if fork:
             x2.record_stream(side_stream)
     T_edr, sum_abs = edr_target

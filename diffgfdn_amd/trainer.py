@@ -820,14 +820,19 @@ class GraphedTrainStep:
             raise ValueError("batch size must be a multiple of the number of bands")
         self.gb = batch_size // self.num_bands * trainer.world_size
         # replayed launches read the targets through the static index buffer: they must come from
-        # the dataset-level store (a by-pointer cache would go stale under replay)
-        if (dataset.edr_store is None or dataset.edc_store is None
-                or dataset.edr_store[0] != trainer.stft_win
-                or dataset.edc_store[0] != (self.start, self.length)):
-            dataset.precompute_decay_targets(trainer.stft_win, self.start, self.length)
+        # the dataset-level store (a by-pointer cache would go stale under replay).  A band bank whose bands have
+        # different EDC windows keeps targets of per-band lengths and one row of mask weights per band
+        tw = trainer._target_window(K) if hasattr(trainer, '_target_window') else (self.start, self.length)
+        dataset.precompute_decay_targets(trainer.stft_win, *tw)         # (no-op when the stores hold these targets)
+        self.band_len = None
+        if hasattr(trainer, '_item_windows'):
+            _, self.band_len = trainer._item_windows(K, batch_size // self.num_bands, dev)
         self.idx = torch.zeros(batch_size, dtype=torch.long, device=dev)
-        self.maskw = torch.full((self.length,), 1.0 / (self.gb * self.length), dtype=torch.float32,
-                                device=dev)
+        if self.band_len is None:
+            self.maskw = torch.full((self.length,), 1.0 / (self.gb * self.length), dtype=torch.float32, device=dev)
+        else:
+            self.maskw = trainer._band_mask_rows(None, K, self.gb, dev)          # (bands, length): no mask = all kept
+        self._K = K
         # ring of pinned staging buffers: the async H2D copy of step i is only executed when the
         # stream reaches it, so its source must not be rewritten by the host preparing step i+1
         self._ring = [(torch.empty(self.length, dtype=torch.float32).pin_memory(),
@@ -958,7 +963,8 @@ class GraphedTrainStep:
         if self.mask_source == "device" and tr.criterion[1].use_mask:
             # (measured: drawing it on the EDC side stream adds a third branch at the head of the graph
             # and the executor then serialises the whole front: +0.05 ms)
-            ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
+            ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw,
+                          band_len=self.band_len)
         # no gather: the kernels read the dataset-level stores through the static index buffer
         batch = self.ds.collate(self.idx, lean="rows")
         tr.optimizer.zero_grad(set_to_none=True)
@@ -975,7 +981,8 @@ class GraphedTrainStep:
         tr = self.tr
         draw = None
         if self.mask_source == "device" and tr.criterion[1].use_mask:
-            draw = lambda: ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw)
+            draw = lambda: ops.draw_mask(self.mask_seed, self.mask_state, self.length, 1.0 / self.gb, out=self.maskw,
+                                         band_len=self.band_len)
         batch = self.ds.collate(self.idx, lean="rows")
         return tr._fused.run(batch, self.maskw, 1.0, normalize_first=True, train=True, allreduce=tr._allreduce,
                              opt_step=opt_step, mask_draw=draw, tail=self._pick_next, pipe=pipe)
@@ -1143,7 +1150,13 @@ class GraphedTrainStep:
             self.idx.copy_(host_idx, non_blocking=True)
         if crit.use_mask and self.mask_source == "host":
             keep = torch.bernoulli(torch.empty(self.length).uniform_(0, 1))
-            if tr.world_size > 1:
+            if self.band_len is not None:
+                # bands with different windows: one draw of the longest, truncated per band (as the device draw)
+                if tr.world_size > 1:
+                    keep = keep.to(self.maskw.device)
+                    dist.broadcast(keep, src=0, group=tr.process_group)
+                self.maskw.copy_(tr._band_mask_rows(keep, self._K, self.gb, self.maskw.device))
+            elif tr.world_size > 1:
                 # one mask for all ranks: rank 0's draw wins
                 keep = keep.to(self.maskw.device)
                 dist.broadcast(keep, src=0, group=tr.process_group)

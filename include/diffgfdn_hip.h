@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
  * receiver schedule; every entry point of version 1 keeps its signature */
-#define GFDN_ABI_VERSION 4
+#define GFDN_ABI_VERSION 5
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
@@ -589,6 +589,20 @@ int gfdn_edc_target(const float* x, int ld, int batch, int start, int len, float
 int gfdn_edc_loss(const float* x, int ld, int batch, int start, int len, const float* T_db,
                   const long long* target_rows, const float* maskw, float inv_count, float gscale, float* loss_item,
                   float* gx, void* work, void* stream);
+/* Band bank whose bands have different longest decay times (src/diff_gfdn/trainer.py:56-59: every band's trainer derives
+ * max_ir_len_ms -- its EDC window -- from ITS OWN T60max; src/run_subband_training_treble.py:286 hands every band its own
+ * dataset's decay times).  Item b's window is [start, start + item_len[b]) with item_len[b] <= max_len (device int32, one
+ * entry per item); T_db rows have pitch ld_T >= max_len; band b / items_per_band reads the mask row
+ * maskw + band * ld_mask (ld_mask = 0: one row shared by all bands).  _pairs_: the pair-interleaved layout of
+ * gfdn_edc_loss_pairs, both items of a pair in one band (items_per_band even).  Everything else as gfdn_edc_loss.  */
+int gfdn_edc_loss_banded(const float* x, int ld, int batch, int start, int max_len, const int* item_len,
+                         const float* T_db, int ld_T, const long long* target_rows, const float* maskw, int ld_mask,
+                         int items_per_band, float inv_count, float gscale, float* loss_item, float* gx, void* work,
+                         void* stream);
+int gfdn_edc_loss_pairs_banded(const float* x2, int ld, int items, int start, int max_len, const int* item_len,
+                               const float* T_db, int ld_T, const long long* target_rows, const float* maskw,
+                               int ld_mask, int items_per_band, float inv_count, float gscale, float* loss_item,
+                               float* gx2, void* work, void* stream);
 /* gfdn_edc_loss against the common-slope MODEL of the directional loss (losses.py:354-359) instead of a stored target:
  * target EDC of item b = sum_k amps[b][k] env[k][t] (amps (batch, S), env (S, ld_env >= len)), |.| + eps in dB clipped
  * at -200, evaluated inside the scan -- the (batch, len) target and the passes that build it never exist.  */
@@ -618,6 +632,13 @@ int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const flo
  * inv_count = 1.  len <= 131072.                                                                  */
 int gfdn_draw_mask(unsigned long long seed, unsigned long long* state, int len, float scale,
                    float* maskw, void* stream);
+/* One row of weights per band (the windows of gfdn_edc_loss_banded) from ONE draw of max_len bits -- the bits
+ * gfdn_draw_mask draws at the same (seed, step): band q keeps the first band_len[q] (device int32, <= max_len) of them,
+ * maskw[q][t] = bit_t * scale / (kept among the first band_len[q]), zero from band_len[q] to the row pitch
+ * ld_mask >= max_len.  (The reference's band trainers each draw their own mask, losses.py:221-223; sharing the bits
+ * between bands keeps every band's marginal distribution and the equal-length case bit-identical to gfdn_draw_mask.) */
+int gfdn_draw_mask_banded(unsigned long long seed, unsigned long long* state, const int* band_len, int nbands,
+                          int max_len, int ld_mask, float scale, float* maskw, void* stream);
 
 /* ---- receiver-position -> group-gain network  (gain_filters.py:497-534; dnn.py:89-126, :331-400,
  * :21-36).  pos (B,3) float64 normalised coordinates; freq_pi (F) float32 = f32(freq_k * pi);

@@ -37,21 +37,21 @@ def _delays(q):
     return [d + 2 * q for d in base]
 
 
-def _build_net(q):
+def _build_net(q, t60max=0.5):
     from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
     from diffgfdn_amd.model import DiffGFDNVarReceiverPos
     torch.manual_seed(100 + q)
     fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
     of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
-    T60 = np.linspace(0.2, 0.5, G)[None, :]
+    T60 = np.linspace(0.2, t60max, G)[None, :]
     return DiffGFDNVarReceiverPos(FS, G, _delays(q), DEV, fl, of, use_absorption_filters=False,
                                   common_decay_times=T60, use_colorless_loss=True).to(DEV)
 
 
-def _build_data(q, R=12):
+def _build_data(q, R=12, t60max=0.5):
     from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
     from diffgfdn_amd.synthetic import synthetic_room
-    room = synthetic_room(R, G, FS, 5000, seed=10 + q, t60_range=(0.2, 0.5))
+    room = synthetic_room(R, G, FS, 5000, seed=10 + q, t60_range=(0.2, t60max))
     ds = MultiRIRDataset(DEV, RoomDataset(G, FS, room["source_position"], room["receiver_position"],
                                           room["rirs"].copy(), room["common_decay_times"], nfft=NFFT, device=DEV))
     return room, ds
@@ -122,16 +122,19 @@ def test_banded_kernels_equal_plain_kernels():
         assert torch.equal(ws[q], wq)
 
 
-def _bank_setup(mask=True):
+def _bank_setup(mask=True, t60max=None):
+    """``t60max``: one longest decay time per band (None: 0.5 s for all) -- bands that differ in it have EDC windows of
+    different lengths (reference trainer.py:56-59)."""
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
-    nets = [_build_net(q) for q in range(len(BANDS))]
-    data = [_build_data(q) for q in range(len(BANDS))]
+    t60max = [0.5] * len(BANDS) if t60max is None else list(t60max)
+    nets = [_build_net(q, t60max[q]) for q in range(len(BANDS))]
+    data = [_build_data(q, t60max=t60max[q]) for q in range(len(BANDS))]
     filt = torch.tensor(_band_filters(), device=DEV).to(torch.complex64)
     bank = BandBank(nets)
     tr = BandBankTrainer(bank, _tc(mask), subband_filter_freq_resp=filt, stft_win=WIN, band_names=BANDS)
     sds = BandStackedDataset([d for _, d in data])
     start, length = tr._decay_window(NFFT // 2 + 1)
-    sds.precompute_decay_targets(WIN, start, length)
+    sds.precompute_decay_targets(WIN, *tr._target_window(NFFT // 2 + 1))
     return nets, data, filt, bank, tr, sds, (start, length)
 
 
@@ -715,3 +718,133 @@ def test_pair_interleaved_kernels_equal_per_item_kernels(B):
     assert rel_err(split(gep).cpu(), ge.cpu()) < 1e-6
     if B % 2:
         assert float(gep[-1, :, 1].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# Bands whose longest decay times differ: every band's EDC window ends at ITS T60max (reference trainer.py:56-59,
+# run_subband_training_treble.py:286) -- per-item window lengths in the EDC kernels, one row of mask weights per band.
+T60MAX = (0.3, 0.4, 0.5)
+
+
+def _band_rows(seed, step, lens, gb):
+    """(bands, Lmax) pre-normalised weights of gfdn_draw_mask_banded, restated: ONE draw of max(lens) bits, band q
+    keeps the first lens[q] of them and divides by (gb x its own count); plus the kept indices per band."""
+    Lmax = max(lens)
+    bits = (philox_mask(seed, step, Lmax, 1.0)[0] > 0)
+    rows = np.zeros((len(lens), Lmax), dtype=np.float32)
+    keeps = []
+    for q, L in enumerate(lens):
+        b = bits[:L]
+        rows[q, :L] = b.astype(np.float32) * (np.float32(1.0 / gb) / np.float32(b.sum()))
+        keeps.append(torch.argwhere(torch.tensor(b)))
+    return rows, keeps
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_bank_with_distinct_decay_windows_equals_band_steps_and_oracle(fused):
+    """Three bands with T60max = 0.3 / 0.4 / 0.5 s: one bank step (explicit launch sequence and the autograd fallback)
+    against every band's OWN VarReceiverPosTrainer step -- whose EDC window is the band's own -- and against the CPU
+    oracle of the reference step, on the same per-band masks."""
+    from diffgfdn_amd.bandbank import BandBankTrainer
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    from oracle import gfdn_oracle as orc
+    from oracle.cpu_trainer import OracleGridTrainer
+    Kf = NFFT // 2 + 1
+    BandBankTrainer.use_fused = fused
+    try:
+        nets, data, filt, bank, tr, sds, (start, length) = _bank_setup(t60max=T60MAX)
+    finally:
+        BandBankTrainer.use_fused = True
+    assert (tr._fused is not None) == fused
+    lens = tr._band_windows(Kf)
+    assert lens == [int(t * FS) - start for t in T60MAX] and length == max(lens)
+    assert sds.edc_store[0] == (start, tuple(lens)) and sds.edc_store[1].shape[1] == length
+    sels = [[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]]
+    rows_np, keeps = _band_rows(99, 0, lens, 4)
+    mw = torch.tensor(rows_np, device=DEV)
+    sd0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
+    batch = sds.collate(sds.global_rows(sels))
+    if fused:
+        losses = tr._fused.run(batch, mw, 1.0, normalize_first=True, train=True)
+    else:
+        tr.normalize(batch)
+        tr.optimizer.zero_grad(set_to_none=True)
+        losses = tr._step_losses(batch, mask_prenorm=mw, defer_total=True)
+        heads = losses.pop("_heads")
+        torch.autograd.backward(heads, [torch.ones(len(BANDS), device=DEV)] * 2)
+        tr.optimizer.pack_grads()
+        tr.optimizer.step()
+    torch.cuda.synchronize()
+    got = {k: v.detach().cpu().numpy() for k, v in losses.items() if k.endswith("_loss")}
+
+    for q in range(len(BANDS)):
+        ref_net = _build_net(q, T60MAX[q])
+        ref_net.load_state_dict(sd0[q], strict=True)
+        rtr = VarReceiverPosTrainer(ref_net, _tc(True), subband_filter_freq_resp=filt[q], stft_win=WIN, capturable=True)
+        assert rtr._decay_window(Kf) == (start, lens[q])
+        _, ds = _build_data(q, t60max=T60MAX[q])
+        ds.precompute_decay_targets(WIN, start, lens[q])
+        b = ds.collate(sels[q], lean=True)
+        rtr.normalize(b)
+        rtr.optimizer.zero_grad(set_to_none=True)
+        rl = rtr._step_losses(b, mask_prenorm=mw[q, :lens[q]].contiguous())
+        rl.pop("_total").backward()
+        rtr.optimizer.step()
+        for k, v in rl.items():
+            assert abs(float(v) - got[k][q]) <= (1e-5 if fused else 1e-6) * abs(float(v)) + 1e-9, (q, k, float(v), got[k][q])
+        for k, v in ref_net.state_dict().items():
+            assert rel_err(nets[q].state_dict()[k].detach().cpu(), v.detach().cpu()) < (5e-4 if fused else 1e-5), (q, k)
+
+    for q in range(len(BANDS)):
+        room, dq = data[q]
+        sd = sd0[q]
+        lin, norm = [], []
+        for i in range(64):
+            k = f"output_scalars.mlp.model.{i}.weight"
+            if k in sd:
+                (lin if sd[k].ndim == 2 else norm).append((sd[k].clone(), sd[f"output_scalars.mlp.model.{i}.bias"].clone()))
+        p = orc.GridModelParams(FS, _delays(q), G, sd["input_gains"].clone(), sd["output_gains"].clone(),
+                                sd["feedback_loop.M"].clone(), sd["feedback_loop.alpha"].clone(),
+                                np.linspace(0.2, T60MAX[q], G)[None, :], lin, norm, 4)
+        otr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
+                                sparsity_weight=2.0, use_asym=True, win=WIN, hop=WIN // 2,
+                                subband_filter=filt[q].cpu().to(torch.complex128))
+        idx = torch.tensor(sels[q])
+        ob = {"z_values": dq.z_values.cpu(),
+              "norm_listener_position": dq.norm_listener_position[idx].cpu(),
+              "listener_position": dq.listener_positions[idx].cpu(),
+              "target_early_response": dq.early_rir_mag_response[idx].cpu().to(torch.complex128),
+              "target_rir_response": dq.rir_mag_response[idx].cpu().to(torch.complex128)}
+        otr.normalize(ob)
+        _, oparts = otr.train_step(ob, keeps[q])
+        for k, v in oparts.items():
+            assert abs(got[k][q] - v) < 1e-4 * abs(v) + 1e-7, (q, k, got[k][q], v)
+        for name in ("input_gains", "output_gains"):
+            a = getattr(nets[q], name).detach().cpu()
+            assert rel_err(a, getattr(p, name).detach()) < 1e-4, (q, name)
+
+
+def test_graphed_bank_step_with_distinct_decay_windows():
+    """The captured step of a bank with three different EDC windows: the mask rows are drawn on the device per band
+    (gfdn_draw_mask_banded) inside the graph; replays against the explicit step launched from the host with the restated
+    rows: bit-equal gradients and losses."""
+    nets, data, filt, bank, tr, sds, (start, length) = _bank_setup(t60max=T60MAX)
+    lens = tr._band_windows(NFFT // 2 + 1)
+    sel_steps = [[[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]], [[1, 2, 4, 6], [0, 5, 7, 9], [3, 8, 10, 11]]]
+    step = tr.graphed(sds, 4, mask_seed=4711).capture(sds.global_rows(sel_steps[0]))
+    assert step.maskw.shape == (len(BANDS), length)
+    got, got_grad, got_mask = [], [], []
+    for s in sel_steps:
+        got.append({k: v.detach().cpu().numpy().copy() for k, v in step(sds.global_rows(s)).items()})
+        got_grad.append(tr.optimizer.flat_grad.detach().cpu().numpy().copy())
+        got_mask.append(step.maskw.detach().cpu().numpy().copy())
+    nets2, data2, filt2, bank2, tr2, sds2, _ = _bank_setup(t60max=T60MAX)
+    for i, s in enumerate(sel_steps):
+        rows_np, _ = _band_rows(4711, i, lens, 4)
+        assert np.array_equal(got_mask[i], rows_np)              # integer work + one float division: bit-exact
+        out = tr2._fused.run(sds2.collate(sds2.global_rows(s)), torch.tensor(rows_np, device=DEV), 1.0,
+                             normalize_first=True, train=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(tr2.optimizer.flat_grad.cpu().numpy(), got_grad[i]), i
+        for k, v in out.items():
+            assert np.array_equal(v.detach().cpu().numpy(), got[i][k]), (i, k)

@@ -44,12 +44,12 @@ def _filters():
                      for f in CENTRES])
 
 
-def _band(q, delays=None):
+def _band(q, delays=None, t60max=1.5):
     from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
     from diffgfdn_amd.dataloader import MultiRIRDataset, RoomDataset
     from diffgfdn_amd.model import DiffGFDNVarReceiverPos
     from diffgfdn_amd.synthetic import synthetic_room
-    room = synthetic_room(R, G, FS, 40000, seed=40 + q)
+    room = synthetic_room(R, G, FS, 40000, seed=40 + q, t60_range=(0.3, t60max))
     ds = MultiRIRDataset(DEV, RoomDataset(G, FS, room["source_position"], room["receiver_position"], room["rirs"],
                                           room["common_decay_times"], nfft=NFFT, device=DEV))
     torch.manual_seed(200 + q)
@@ -227,6 +227,59 @@ def test_full_size_bank_graph_step_backward_vs_oracle():
         for name in ("input_gains", "output_gains"):
             assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, (q, name)
         print(f"bank band {q} full-size gradient deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_full_size_bank_distinct_decay_windows_vs_oracle():
+    """Three bands whose longest decay times differ (0.6 / 1.0 / 1.5 s: EDC windows of 18 560 / 31 360 / 47 360 samples,
+    reference trainer.py:56-59, run_subband_training_treble.py:286) on the timed path at full size: graph replay of the
+    explicit step (slot order, pair-interleaved signals, banded EDC scans, per-band mask rows drawn on the device) -- every
+    loss term and gradient of every band against the CPU oracle, whose step takes the band's own window and mask."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    from scipy.signal import firwin
+    t60max = (0.6, 1.0, 1.5)
+    centres = (250.0, 1000.0, 2000.0)
+    delays3 = DELAYS + [[647, 719, 821, 919, 1019, 1117, 1217, 1307, 1373, 1409, 1429, 1433, 1439, 1459, 1471, 1597]]
+    bands = [_band(q, delays3[q], t60max[q]) for q in range(3)]
+    filt = torch.tensor(np.stack([np.fft.rfft(firwin(1025, [f / np.sqrt(2), f * np.sqrt(2)], pass_zero=False, fs=FS),
+                                              n=NFFT) for f in centres]), device=DEV).to(torch.complex64)
+    nets = [b_[2] for b_ in bands]
+    sd0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
+    bank = BandBank(nets)
+    tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=centres)
+    assert tr._fused is not None
+    start, length = tr._decay_window(K)
+    lens = tr._band_windows(K)
+    assert lens == [int(t * FS) - start for t in t60max] and length == lens[-1]
+    sds = BandStackedDataset([b_[1] for b_ in bands])
+    sels = [[0, 3], [1, 4], [2, 5]]
+    seed = 8128
+    step = tr.graphed(sds, B, mask_seed=seed).capture(sds.global_rows(sels))
+    out = step(sds.global_rows(sels))
+    torch.cuda.synchronize()
+    bits = philox_mask(seed, 0, length, 1.0)[0] > 0
+    flat = tr.optimizer.flat_grad.detach().cpu().numpy()
+    views, off = {}, 0
+    for p in tr.optimizer._params:
+        views[id(p)] = flat[off:off + p.numel()].reshape(tuple(p.shape))
+        off += p.numel()
+    N = G * NPER
+    for q in range(3):
+        keep = torch.argwhere(torch.tensor(bits[:lens[q]]))
+        parts_hip = {k: float(v[q]) for k, v in out.items() if k.endswith("_loss")}
+        grads_hip = {"input_gains": views[id(bank.input_gains)][q].reshape(N, 1),
+                     "output_gains": views[id(bank.output_gains)][q].reshape(N, 1),
+                     "feedback_loop.M": views[id(bank.feedback_loop_M)][q]}
+        gw, o = views[id(bank.output_scalars_w)][q], 0
+        names = [n_ for n_, _ in nets[q].output_scalars.mlp.model.named_parameters()]
+        for n_, prm in zip(names, bank._mlp_params[q]):
+            grads_hip["output_scalars.mlp.model." + n_] = gw[o:o + prm.numel()].reshape(tuple(prm.shape))
+            o += prm.numel()
+        after_hip = {k: v.detach().cpu().numpy() for k, v in nets[q].state_dict().items()}
+        parts, grads, after = _oracle_step(sd0[q], q, bands[q][0], bands[q][1], sels[q], filt[q], keep, delays3[q])
+        worst = _check(f"windows[{t60max[q]} s]", parts_hip, grads_hip, after_hip,
+                       {k: v.numpy() for k, v in sd0[q].items()}, parts, grads, after)
+        print(f"distinct windows, band {q} (T60max {t60max[q]} s, window {lens[q]}): gradient deviations",
+              {k.replace("output_scalars.mlp.model.", "mlp."): f"{v:.1e}" for k, v in worst.items()})
 
 
 def test_full_size_bench_shape_vs_oracle():

@@ -649,3 +649,56 @@ def test_mfma_contraction_f32_exact_bf16_outside_the_bar(ops):
         err[name] = float((H.cpu().to(torch.complex128) - H_ref).abs().max()) / scale
     assert err["f32"] < 1e-6, err
     assert 1e-3 < err["bf16"] < 1e-2, err
+
+
+def test_edc_banded_windows_equal_per_band_calls():
+    """gfdn_edc_loss_banded / gfdn_edc_loss_pairs_banded (per-item window lengths, padded target rows, one mask row per
+    band) against the plain entry points called band by band with the band's own window: bit-equal losses and gradients;
+    gfdn_draw_mask_banded against the numpy Philox restatement: bit-equal rows."""
+    from diffgfdn_amd import hip_ops as ops
+    from tests.helpers import philox_mask
+    g = torch.Generator(device="cpu").manual_seed(17)
+    nb, Bper, T, start = 3, 4, 9001, 160
+    lens = [2240, 5003, 7777]
+    Lmax = max(lens)
+    x = torch.randn(nb * Bper, T, generator=g).to(DEV)
+    x = x * torch.exp(-torch.arange(T, device=DEV) / 1500.0)
+    R = 7
+    tgt_x = torch.randn(nb * R, T, generator=g).to(DEV) * torch.exp(-torch.arange(T, device=DEV) / 1400.0)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=g)[:Bper]], device=DEV)
+    T_pad = torch.zeros((nb * R, Lmax), dtype=torch.float32, device=DEV)
+    T_band = []
+    for q, L in enumerate(lens):
+        tq = ops.edc_target(tgt_x[q * R:(q + 1) * R].contiguous(), start, L)
+        T_band.append(tq)
+        T_pad[q * R:(q + 1) * R, :L] = tq
+    band_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    item_len = band_len.repeat_interleave(Bper).contiguous()
+    state = torch.zeros(1, dtype=torch.long, device=DEV)
+    mw = ops.draw_mask(1234, state, Lmax, 1.0 / Bper, band_len=band_len)
+    assert int(state.item()) == 1
+    bits = philox_mask(1234, 0, Lmax, 1.0)[0] > 0
+    for q, L in enumerate(lens):
+        want = np.zeros(Lmax, dtype=np.float32)
+        want[:L] = bits[:L].astype(np.float32) * (np.float32(1.0 / Bper) / np.float32(bits[:L].sum()))
+        assert np.array_equal(mw[q].cpu().numpy(), want), q
+    # plain layout
+    li, gx = ops.edc_loss(x, start, Lmax, T_pad, mw, 1.0, 10.0, True, rows=rows, item_len=item_len, items_per_band=Bper)
+    # pair-interleaved layout
+    x2 = torch.stack((x[0::2], x[1::2]), dim=-1).contiguous()
+    li2, g2 = ops.edc_loss_pairs(x2, nb * Bper, start, Lmax, T_pad, mw, 1.0, 10.0, True, rows=rows, item_len=item_len,
+                                 items_per_band=Bper)
+    for q, L in enumerate(lens):
+        sl = slice(q * Bper, (q + 1) * Bper)
+        rq = (rows[sl] - q * R).contiguous()
+        lq, gq = ops.edc_loss(x[sl].contiguous(), start, L, T_band[q], mw[q, :L].contiguous(), 1.0, 10.0, True, rows=rq)
+        assert torch.equal(li[sl], lq) and torch.equal(gx[sl], gq), q
+        # (the pair kernels scan with DPP wave scans, the per-item kernels with shuffles: their gradients agree to
+        # rounding, not to the bit -- so the banded pair call is held against the plain PAIR call of the band)
+        psl = slice(q * Bper // 2, (q + 1) * Bper // 2)
+        lp, gp = ops.edc_loss_pairs(x2[psl].contiguous(), Bper, start, L, T_band[q], mw[q, :L].contiguous(), 1.0, 10.0,
+                                    True, rows=rq)
+        assert torch.equal(li2[sl], lp) and torch.equal(g2[psl], gp), q
+        assert torch.equal(li2[sl], lq), q
+        assert float((g2[psl, :, 0] - gq[0::2]).abs().max()) <= 1e-5 * float(gq.abs().max()), q
+        assert float(gq[:, start + L:].abs().max()) == 0.0 and float(gp[:, start + L:].abs().max()) == 0.0
