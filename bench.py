@@ -465,8 +465,9 @@ def run_directional(args, device, rank, world):
     def one_step():
         main = torch.cuda.current_stream()
         for i, (tr, step, store) in enumerate(steps):
-            sel = torch.randperm(R, generator=gen)[:BATCH].to(device)
+            sel_host = torch.randperm(R, generator=gen)[:BATCH]
             if lanes is None:
+                sel = sel_host.to(device)
                 for k, v in store.items():
                     step.batch[k].copy_(v.index_select(0, sel))
                 out = step()
@@ -474,6 +475,10 @@ def run_directional(args, device, rank, world):
                 lane = lanes[i % nstreams]
                 lane.wait_stream(main)
                 with torch.cuda.stream(lane):
+                    # the indices are created ON the lane that reads them: allocated on the main stream their block would
+                    # return to main's pool while the lane's index_select is still queued behind the previous replay, and
+                    # a later upload could overwrite it (the bug class bandbank.py documents for cross-stream tensors)
+                    sel = sel_host.to(device)
                     for k, v in store.items():
                         step.batch[k].copy_(v.index_select(0, sel))
                     out = step()

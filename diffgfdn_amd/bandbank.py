@@ -223,13 +223,19 @@ class BandStackedDataset:
         for d in self.datasets:                  # the stacked copies are the live ones
             d.edr_store = d.edc_store = None
 
+    def slot_grid(self, bins: torch.Tensor, conj: torch.Tensor) -> torch.Tensor:
+        """z_s (1 + S,) complex128: the frequency grid on the slot order of ``ops.irfft_slot_order`` -- column 0 = bin 0,
+        column 1 + s = bin bins[s], conjugated where conj[s].  Built once, cached."""
+        if getattr(self, '_slot_z', None) is None:
+            z = self.z_values
+            self._slot_z = torch.cat([z[:1], torch.where(conj, z[bins].conj(), z[bins])])
+        return self._slot_z
+
     def slot_ordered(self, bins: torch.Tensor, conj: torch.Tensor):
         """(z_s (1 + S,) complex128, early_s (bands*R, 1 + S) complex64): the frequency grid and the early-response
-        store on the slot-ordered grid of ``ops.irfft_slot_order`` -- column 0 = bin 0, column 1 + s = bin bins[s],
-        conjugated where conj[s] (a real signal's spectrum at conj(z) is the conjugate).  Built once, cached."""
+        store on the slot-ordered grid (a real signal's spectrum at conj(z) is the conjugate).  Built once, cached."""
         if getattr(self, '_slot_cache', None) is None:
-            z = self.z_values
-            zs = torch.cat([z[:1], torch.where(conj, z[bins].conj(), z[bins])])
+            zs = self.slot_grid(bins, conj)
             E = self.early_rir_mag_response
             out = torch.empty((E.shape[0], 1 + bins.numel()), dtype=E.dtype, device=E.device)
             out[:, 0] = E[:, 0]
@@ -238,6 +244,29 @@ class BandStackedDataset:
                 out[r0:r0 + 512, 1:] = torch.where(conj, blk.conj(), blk)
             self._slot_cache = (zs, out)
         return self._slot_cache
+
+    def direct_time(self, filt: Optional[torch.Tensor], n: int, chunk: int = 128) -> torch.Tensor:
+        """xd (bands*R, n) float32: every receiver's direct path through its band's filter in the TIME domain,
+        xd[band R + r] = irfft(early[r] filt_band, n) -- the part of x = irfft((sum_g gain_g T_g + d) filt, n) (reference
+        model.py:619, trainer.py:459, losses.py:207-213 / :442-445) that no parameter touches.  The transform is linear,
+        so the step adds the band's G transformed group responses to these rows instead of transforming every receiver's
+        spectrum (csrc/linear.hip).  A constant of the dataset like the decay targets: built once, cached per filter."""
+        key = (None if filt is None else (filt.data_ptr(), tuple(filt.shape)), int(n))
+        cache = getattr(self, '_direct_time', None)
+        if cache is None or cache[0] != key:
+            E = self.early_rir_mag_response
+            R, Ku = self.R, (n + 1) // 2
+            if E.shape[0] != self.num_bands * R or E.shape[1] < Ku:
+                raise RuntimeError("direct_time: the early-response store does not match bands x receivers")
+            out = torch.empty((E.shape[0], n), dtype=torch.float32, device=E.device)
+            for q in range(self.num_bands):
+                f = None if filt is None else filt[q, :Ku].to(torch.complex64)
+                for r0 in range(q * R, (q + 1) * R, chunk):
+                    r1 = min(r0 + chunk, (q + 1) * R)
+                    H = E[r0:r1, :Ku].to(torch.complex64)
+                    out[r0:r1] = ops.irfft_odd_fwd((H * f) if f is not None else H.contiguous(), n)
+            self._direct_time = (key, out)
+        return self._direct_time[1]
 
     def global_rows(self, per_band: Sequence[Sequence[int]]) -> List[int]:
         """per_band[q] = receiver indices of band q's batch -> band-major global rows."""
@@ -369,8 +398,9 @@ class BandBankTrainer:
         self._fused = FusedBankStep(self) if (self.use_fused and FusedBankStep.supported(self)) else None
         if self.use_fused and self._fused is None and self.rank == 0:
             import warnings
-            warnings.warn("BandBankTrainer: this layout (more than 4 lines per group, more than 4 groups per band or more "
-                          "than 64 blocks in the bank) is outside the explicit block-transfer-function step; the bank "
+            warnings.warn("BandBankTrainer: this layout (more than 8 lines per group -- more than 4 off the unit circle --, "
+                          "more than 4 groups per band or more than 64 blocks in the bank) is outside the explicit "
+                          "block-transfer-function step; the bank "
                           "steps through the per-bin elimination kernels under autograd (same results, slower)",
                           RuntimeWarning, stacklevel=2)
         # leaves are first touched on one stream and receive gradients from the other by design (§5.1): the

@@ -40,7 +40,11 @@ class FusedBankStep:
 
     @staticmethod
     def supported(trainer) -> bool:
+        """Blocks of <= 4 lines: any grid; blocks of 5..8 lines: grids on the unit circle only (``run`` refuses others, and
+        the trainer's configuration is the only place that knows before the first batch arrives)."""
         bank = trainer.net
+        if bank.num_delay_lines_per_group > 4 and getattr(trainer.config, 'reduced_pole_radius', 1.0) != 1.0:
+            return False
         return (bank.num_delay_lines_per_group <= 8 and bank.num_groups <= 4
                 and bank.num_bands * bank.num_groups <= 64)
 
@@ -68,6 +72,14 @@ class FusedBankStep:
     # (-2 %) for 13 more launches -- the chains run in phase, each kind of unit stays contended -- so it is off.
     halves = 1
 
+    # The output stage in the TIME domain (csrc/linear.hip): the inverse transform is linear and neither the group transfer
+    # functions nor the band's filter depend on the receiver, so x[b] = xd[row_b] + sum_g rgain[b][g] irfft(s_g T_g filt) with
+    # xd = irfft(direct filt) a constant of the dataset (BandStackedDataset.direct_time).  A step then runs G forward and G
+    # adjoint transforms per band instead of one per receiver (28 instead of 224 at the north-star size), dL/drgain is a
+    # dot product over the time samples and the records pass reads G adjoint spectra per band.  Supersedes the folded
+    # output stage below, which stays as the cross-check (tests/test_gpu_bank.py) and for chained steps (``pipe``).
+    linear_transforms = os.environ.get('GFDN_LINEAR', '1') == '1'
+
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
     # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
     fold_output_stage = True
@@ -84,11 +96,21 @@ class FusedBankStep:
     # the EDR column kernel and the three EDC scans.
     fuse_decay = os.environ.get('GFDN_FUSE_DECAY', '0') == '1'      # (OFF: measured slower; the switch is for same-box A/B runs)
 
+    def _eye_rows(self, nb: int, G: int, device) -> torch.Tensor:
+        """(nb * G, G): "receiver" g of every band with gain 1 on group g -- what turns the output-stage kernels into
+        H_g = T_g filt and its adjoint (cached: captured graphs hold its pointer)"""
+        key = (nb, G, str(device))
+        if getattr(self, '_eye_cache', None) is None or self._eye_cache[0] != key:
+            self._eye_cache = (key, torch.eye(G, dtype=torch.float32, device=device).repeat(nb, 1).contiguous())
+        return self._eye_cache[1]
+
     # ------------------------------------------------------------------------------------------
     def _decay_middle(self, H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc, start, length, ev, main,
-                      side2, x_fn=None, Btot=None, gains=None, item_len=None, Bper=None):
+                      side2, x_fn=None, Btot=None, gains=None, item_len=None, Bper=None, lin=False):
         """One chain over the whole batch: main: irfft -> STFT -> EDR -> STFT adjoint (even frames, then odd frames +
-        EDC gradient) -> irfft adjoint; side2: EDC scans.  Records ev['x'] / ev['edc'] / ev['g']."""
+        EDC gradient) -> irfft adjoint; side2: EDC scans.  Records ev['x'] / ev['edc'] / ev['g'].
+        ``lin``: the time-domain output stage -- the chain stops at dL/dx, returned as (g, None) (pair-interleaved, merged)
+        or (g_edc, g_edr) in place of dL/dH."""
         tr, cfg, keep = self.tr, self.tr.config, self._keep
         Btot, win = (H.shape[0] if Btot is None else Btot), tr.stft_win
         on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
@@ -148,7 +170,9 @@ class FusedBankStep:
                 main.wait_event(ev['edc'])
                 ops.stft_power_pairs_bwd(x, Btot, win, P, base=g_edc, out=g, phase=1)
                 ev['g'].record()
-                if gains is not None:     # (the gains pass of the output stage's adjoint rides the last pass)
+                if lin:
+                    gH = (g, None)
+                elif gains is not None:     # (the gains pass of the output stage's adjoint rides the last pass)
                     gH, self._gpart = ops.irfft_odd_pairs_bwd(g, K, Btot, gains=gains)
                     keep.append(self._gpart)
                 else:
@@ -158,8 +182,11 @@ class FusedBankStep:
                 g_edr = ops.stft_power_bwd(x, win, P, g_edr)
                 main.wait_event(ev['edc'])
                 ev['g'].record()
-                gH = ops.irfft_odd_bwd(g_edc, K, (K + 1) // 2 if order is not None else H.shape[1], g_edr,
-                                       slots=order is not None)
+                if lin:
+                    gH = (g_edc, g_edr)
+                else:
+                    gH = ops.irfft_odd_bwd(g_edc, K, (K + 1) // 2 if order is not None else H.shape[1], g_edr,
+                                           slots=order is not None)
             keep.append(gH)
         else:
             main.wait_event(ev['edc'])
@@ -252,7 +279,11 @@ class FusedBankStep:
         gridK = FrequencyGrid.of(z)
         order = ops.irfft_slot_order(K, z.device) if (tr.use_slot_order and 'dataset' in data) else None
         Ku = (K + 1) // 2 if K % 2 == 1 else K
-        if order is not None:
+        lin = (self.linear_transforms and pipe is None and self.halves < 2 and G <= 4
+               and hasattr(data.get('dataset'), 'direct_time') and not (self.fuse_decay or self.fold_gains))
+        if lin:
+            zu, direct = (data['dataset'].slot_grid(*order) if order is not None else z[:Ku]), None
+        elif order is not None:
             zu, direct = data['dataset'].slot_ordered(*order)
         else:
             zu, direct = z[:Ku], data['target_early_response'][:, :Ku]
@@ -287,7 +318,9 @@ class FusedBankStep:
         # cores; unit-circle grids)
         big = n > 4
         if big and (gridK.logr is not None):
-            raise NotImplementedError("blocks of more than four lines: the explicit step takes grids on the unit circle")
+            raise NotImplementedError("blocks of more than four lines: the explicit step takes grids on the unit circle "
+                                      "(set BandBankTrainer.use_fused = False to step this bank through the per-bin "
+                                      "elimination kernels under autograd)")
         if big:
             Q, QQ = ops.ortho_fwd(M, True, True)
             coef, coef_sub = ops.tf8_coefs(QQ, ig, b, c, A1=M)
@@ -327,13 +360,36 @@ class FusedBankStep:
                 main.wait_event(pipe.ready)
 
         fold = (self.fold_output_stage and pairs and K == 65537 and (Btot // nb) % 2 == 0 and G <= 4
-                and self.halves < 2)
+                and self.halves < 2 and not lin)
         # the receiver gains come from the side stream: with the output stage folded into the transform the transfer-function
         # launch below does not read them, and the wait goes behind it -- by then the event was signalled long ago (a wait on
         # a signalled event is free; in front of the launch the idle main stream paid a cross-queue wake-up of ~12 us)
-        if not fold:
+        if not fold and not lin:
             wait_gains()
-        if big:
+        x_fn = None
+        tau = eye = None
+        tau_pairs = order is not None
+        if lin:
+            # group responses through the band's filter -> G time signals per band; the receivers' signals are formed from
+            # them and the dataset's transformed direct paths in one streaming pass (csrc/linear.hip)
+            eye = self._eye_rows(nb, G, z.device)
+            xd = data['dataset'].direct_time(tr.subband_filter_freq_resp, K)
+            if big:
+                Ts, _ = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=False)
+                ev_ts = torch.cuda.Event()
+                ev_ts.record()
+                Hg = Ts if filt is None else (Ts.view(nb, G, -1) * filt.view(nb, 1, -1)).reshape(nb * G, -1)
+            else:
+                Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, scale, None, filt, None, nb,
+                                            save_T=True, want_H=True)
+            tau = ops.irfft_odd_fwd(Hg, K, slots=order is not None, pairs=tau_pairs)
+            H = Hg
+
+            def x_fn():
+                wait_gains()
+                return ops.lin_combine_fwd(xd, rows, tau, rgain, nb, K, tau_pairs, pairs)
+            keep.extend((tau, xd))
+        elif big:
             Ts, Tq8 = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=True)
             # (the colorless pass of the 8-line blocks is VALU-bound like this launch: it starts behind it and runs
             # beside the memory-bound transform instead -- measured: tsave 105 -> 55 us in the step)
@@ -352,7 +408,6 @@ class FusedBankStep:
         else:
             H, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, rgain, scale, direct, filt, rows, nb,
                                        save_T=True, want_H=not fold)
-        x_fn = None
         if fold:
             Tq, H = H, None
 
@@ -399,7 +454,7 @@ class FusedBankStep:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
                                                     start, length, ev, main, side2, x_fn=x_fn, Btot=Btot,
                                                     gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None,
-                                                    item_len=item_len, Bper=Btot // nb)
+                                                    item_len=item_len, Bper=Btot // nb, lin=lin)
         if late_colorless:
             grec_sub, out3, gQ = colorless_pass()
         def report():
@@ -413,10 +468,23 @@ class FusedBankStep:
             # 50 us instead of 29 + 45 one after the other.  The reported sums go in front of the gains pass (their
             # inputs are long complete; behind it they would sit on the path to Adam).
             ev['grg'].record()                    # (dL/dH complete)
-            if big:
-                grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rgain, gH, filt, nb)
+            if lin:
+                # time-domain adjoint: gamma_g = sum_b rgain[b][g] dL/dx[b] (G signals per band) -> their adjoint transform
+                # = dL/d(T_g filt) -> the records pass at "B = G receivers with identity gains"
+                gsig, gsig_b = gH
+                gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b)
+                if tau_pairs:
+                    gHg = ops.irfft_odd_pairs_bwd(gam, K, nb * G)
+                else:
+                    gHg = ops.irfft_odd_bwd(gam, K, Ku, None, slots=False)
+                keep.extend((gam, gHg, eye))
+                gH_rec, rg_rec = gHg, eye
             else:
-                grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rgain, gH, Ts, filt, nb, partial=True)
+                gH_rec, rg_rec = gH, rgain
+            if big:
+                grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb)
+            else:
+                grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True)
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
                 sums, total = report()
@@ -427,8 +495,16 @@ class FusedBankStep:
                     slots = tr.optimizer.extra.view(3, nb)
                     torch.stack((sums.reshape(nb, 3)[:, 1], sums.reshape(nb, 3)[:, 2], out3.reshape(nb, 3)[:, 0]),
                                 out=slots)
-                torch.cuda.current_stream().wait_event(ev['grg'])
-                if fold and self.fold_gains:
+                if not lin:
+                    torch.cuda.current_stream().wait_event(ev['grg'])
+                if lin:
+                    # dL/drgain[b][g] = <dL/dx[b], tau_g>: partial rows over the time samples
+                    ggp = ops.lin_gain_dots(gsig, tau, nb, Btot, G, K, pairs, tau_pairs, gxb=gsig_b)
+                    grg = None
+                    if not (self.gain_rows_in_mlp
+                            and ops.mlp_bwd_takes_parts(bank._freq_pi.numel(), Hh, n_hidden, G, Btot // nb)):
+                        grg, ggp = ops.tf_rows_sum(ggp).view(Btot, G), None
+                elif fold and self.fold_gains:
                     grg = ops.tf_rows_sum(self._gpart)
                     ggp = None
                 elif self.gain_rows_in_mlp and ops.mlp_bwd_takes_parts(bank._freq_pi.numel(), Hh, n_hidden, G, Btot // nb):

@@ -1019,6 +1019,72 @@ def irfft_odd_pairs_compose_fwd(direct, rows, T, rgain, filt, n: int, nbands: in
     return x2, h0
 
 
+# ---- the output stage in the time domain (csrc/linear.hip) -----------------------------------------------------------
+def lin_combine_fwd(xd, rows, tau, rgain, nbands: int, n: int, tau_pairs: bool, out_pairs: bool):
+    """x[b] = xd[rows[b]] + sum_g rgain[b][g] tau[band(b) G + g] over n time samples.  xd (R, >= n) float32 store of the
+    transformed direct paths, tau the nbands*G transformed group responses -- (ceil(S / 2), n, 2) pair-interleaved
+    (``tau_pairs``, what irfft_odd_fwd(pairs=True) returns) or (S, n); rgain (items, G).  Returns x2 (ceil(items / 2),
+    n, 2) pair-interleaved (``out_pairs``) or x (items, n)."""
+    _need_gpu(xd, tau, rgain)
+    xd, tau, rgain = _f(xd), _f(tau), _f(rgain)
+    items, G = rgain.shape
+    S = nbands * G
+    if items % nbands or xd.dim() != 2 or xd.shape[1] < n:
+        raise RuntimeError("lin_combine_fwd: rgain (nbands * B, G), xd (R, >= n)")
+    if tuple(tau.shape) != (((S + 1) // 2, n, 2) if tau_pairs else (S, n)):
+        raise RuntimeError("lin_combine_fwd: tau does not hold nbands * G signals of n samples in the stated layout")
+    rows = _rows(rows, items, xd.shape[0])
+    if rows is None and xd.shape[0] != items:
+        raise RuntimeError("lin_combine_fwd: xd must have one row per item (or pass rows)")
+    x = torch.empty(((items + 1) // 2, n, 2) if out_pairs else (items, n), dtype=_f32, device=xd.device)
+    _lib.check(_lib.load().gfdn_lin_combine_fwd(_p(xd), xd.stride(0), _p(rows), _p(tau), n, int(tau_pairs), _p(rgain),
+                                                nbands, items // nbands, G, n, _p(x), n, int(out_pairs), _stream()),
+               "gfdn_lin_combine_fwd")
+    return x
+
+
+def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, gxb=None):
+    """gamma[band G + g] = sum_{b in band} rgain[b][g] (gx[b] [+ gxb[b]]): the signals whose adjoint transform is
+    dL/d(T_g filt).  gx: (ceil(items / 2), n, 2) pair-interleaved (``in_pairs``) or (items, n); result in the layout
+    ``out_pairs`` asks for (what irfft_odd_pairs_bwd / irfft_odd_bwd take)."""
+    _need_gpu(gx, rgain)
+    gx, rgain = _f(gx), _f(rgain)
+    items, G = rgain.shape
+    S = nbands * G
+    if items % nbands or tuple(gx.shape) != (((items + 1) // 2, n, 2) if in_pairs else (items, n)):
+        raise RuntimeError("lin_gamma: gradient signals do not match rgain (nbands * B, G) in the stated layout")
+    if gxb is not None:
+        gxb = _f(gxb)
+        if gxb.shape != gx.shape:
+            raise RuntimeError("lin_gamma: gxb must have the shape of gx")
+    gamma = torch.empty(((S + 1) // 2, n, 2) if out_pairs else (S, n), dtype=_f32, device=gx.device)
+    if out_pairs and S % 2:
+        gamma[-1].zero_()                  # (the missing partner of the last signal)
+    _lib.check(_lib.load().gfdn_lin_gamma(_p(gx), _p(gxb), n, int(in_pairs), _p(rgain), nbands, items // nbands, G, n,
+                                          _p(gamma), n, int(out_pairs), _stream()), "gfdn_lin_gamma")
+    return gamma
+
+
+def lin_gain_dots(gx, tau, nbands: int, items: int, G: int, n: int, in_pairs: bool, tau_pairs: bool, gxb=None):
+    """(items * G, chunks) partial rows of dL/drgain[b][g] = <gx[b] [+ gxb[b]], tau[band(b) G + g]> for
+    ``mlp_gains_bwd(ggains_parts=...)`` (tf_rows_sum of them = dL/drgain)."""
+    _need_gpu(gx, tau)
+    gx, tau = _f(gx), _f(tau)
+    S = nbands * G
+    if items % nbands or tuple(gx.shape) != (((items + 1) // 2, n, 2) if in_pairs else (items, n)) \
+            or tuple(tau.shape) != (((S + 1) // 2, n, 2) if tau_pairs else (S, n)):
+        raise RuntimeError("lin_gain_dots: signals do not match the stated layouts")
+    if gxb is not None:
+        gxb = _f(gxb)
+        if gxb.shape != gx.shape:
+            raise RuntimeError("lin_gain_dots: gxb must have the shape of gx")
+    lib = _lib.load()
+    parts = torch.empty((items * G, lib.gfdn_lin_gain_chunks(n)), dtype=_f32, device=gx.device)
+    _lib.check(lib.gfdn_lin_gain_dots(_p(gx), _p(gxb), n, int(in_pairs), _p(tau), n, int(tau_pairs), nbands,
+                                      items // nbands, G, n, _p(parts), _stream()), "gfdn_lin_gain_dots")
+    return parts
+
+
 def tf_rows_sum(part: torch.Tensor) -> torch.Tensor:
     """part (..., cols) float32 -> sums over the last axis (one wavefront per row, fixed order)."""
     _need_gpu(part)

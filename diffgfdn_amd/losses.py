@@ -140,6 +140,20 @@ class DecayTargets:
 _default_targets = DecayTargets()
 
 
+# ``unit_grad=True`` promises that the loss enters the final scalar with weight 1 (the saved dloss/dH is handed on as it
+# is, one pass over it saved).  The promise is CHECKED wherever a host read is allowed -- outside stream capture -- so a
+# caller that rescales the total (gradient accumulation, loss scaling, a 1 / world factor) gets an error instead of an
+# unscaled EDC gradient next to correctly scaled colorless gradients.
+CHECK_UNIT_GRAD = True
+
+
+def _assert_unit_upstream(g: torch.Tensor):
+    if CHECK_UNIT_GRAD and g.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if not bool(torch.all(g == 1)):
+            raise RuntimeError("decay losses were evaluated with unit_grad=True but their total is back-propagated with an "
+                               "upstream gradient other than 1: evaluate them with unit_grad=False to rescale the total")
+
+
 class _ScalarLossWithSavedGrad(torch.autograd.Function):
     """loss value + precomputed dloss/dH (saved) -> autograd node."""
 
@@ -154,6 +168,7 @@ class _ScalarLossWithSavedGrad(torch.autograd.Function):
     def backward(ctx, g):
         (gH,) = ctx.saved_tensors
         if ctx.unit_grad:            # caller guarantees d(total)/d(loss) == 1: skip a pass over gH
+            _assert_unit_upstream(g)
             return gH.reshape(ctx.h_shape), None, None, None
         return (gH * g).reshape(ctx.h_shape), None, None, None
 
@@ -186,6 +201,7 @@ class _DecayTotal(torch.autograd.Function):
         if g is None:
             return (None,) * 10
         if ctx.unit_grad:
+            _assert_unit_upstream(g)
             return (gH.reshape(ctx.h_shape),) + (None,) * 9
         return ((gH * g).reshape(ctx.h_shape),) + (None,) * 9
 

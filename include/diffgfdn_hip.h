@@ -492,6 +492,31 @@ int gfdn_edc_loss_pairs(const float* x2, int ld, int items, int start, int len, 
                         const long long* target_rows, const float* maskw, float inv_count, float gscale,
                         float* loss_item, float* gx2, void* work, void* stream);
 
+/* ---- The output stage in the TIME domain (csrc/linear.hip).  The reference forms H[b] = (sum_g gain[b][g] T_g + d[b]) filt
+ * per receiver (src/diff_gfdn/model.py:583-619, trainer.py:459) and transforms every H[b] inside the decay losses
+ * (losses.py:207-213, :442-445: irfft(H, n = K)).  The transform is linear and T_g, filt do not depend on the receiver:
+ *     x[b] = irfft(d[b] filt) + sum_g gain[b][g] irfft(T_g filt) = xd[row_b] + sum_g gain[b][g] tau_g,
+ * xd a constant of the dataset (transformed once per receiver, like the decay targets) and tau the G transformed group
+ * responses of the band -- a step runs G forward and G adjoint transforms per band instead of one per receiver.
+ *   gfdn_lin_combine_fwd : x (items = nbands B) from xd (rows, ld_xd >= n) [row indirection: item b reads row rows[b]],
+ *                          tau (nbands G signals) and rgain (items, G);
+ *   gfdn_lin_gamma       : gamma[band G + g] = sum_{b in band} rgain[b][g] (gx[b] [+ gxb[b]]) -- the G signals per band
+ *                          whose adjoint transform is dL/d(T_g filt);
+ *   gfdn_lin_gain_dots   : part[((band B + b) G + g) chunks + chunk] = partial sums over the samples of
+ *                          dL/dgain[b][g] = <gx[b] [+ gxb[b]], tau[band G + g]>, chunks = gfdn_lin_gain_chunks(n)
+ *                          (the rows gfdn_mlp_gains_banded_bwd_parts sums itself).
+ * Layout flags (*_pairs): 1 = two signals interleaved sample by sample, (ceil(S / 2), ld, 2) float, as the pair
+ * transforms and the pair STFT / EDC kernels use (items 2p, 2p + 1 in one pair; with in_pairs B must be even and
+ * gxb NULL); 0 = (S, ld) float.  G <= 4; B G <= 256 for gfdn_lin_gamma.  All sums in fixed order.                       */
+int gfdn_lin_gain_chunks(int n);
+int gfdn_lin_combine_fwd(const float* xd, int ld_xd, const long long* rows, const float* tau, int ld_tau, int tau_pairs,
+                         const float* rgain, int nbands, int B, int G, int n, float* x, int ld_x, int out_pairs,
+                         void* stream);
+int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* rgain, int nbands, int B, int G,
+                   int n, float* gamma, int ld_o, int out_pairs, void* stream);
+int gfdn_lin_gain_dots(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* tau, int ld_tau,
+                       int tau_pairs, int nbands, int B, int G, int n, float* part, void* stream);
+
 /* Fused decay-loss forward, one workgroup per item (csrc/decay.hip; win = 4096): replaces gfdn_stft_power_pairs ->
  * gfdn_edr_loss and gfdn_edc_loss_pairs on the training path.  Restates src/diff_gfdn/losses.py:430-495 (edr_loss),
  * :501-575 (get_stft_torch, get_edr_from_stft), :201-238 (edc_loss), :187-199 (schroeder_backward_integral) with the

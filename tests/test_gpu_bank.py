@@ -263,6 +263,9 @@ def test_pipelined_chain_equals_single_steps(S):
     B = 4
     batches = [[1, 5, 7, 10], [0, 2, 3, 11], [4, 6, 8, 9], [2, 3, 5, 7], [11, 0, 9, 1], [3, 4, 5, 6], [7, 8, 9, 10]]
     rows = [stacked.global_rows([b] * len(BANDS)) for b in batches]
+    # (the chained steps form the output stage in the frequency domain; the single steps are held to the same form here,
+    # since the time-domain output stage agrees with it to rounding only -- that comparison has its own test)
+    ta._fused.linear_transforms = tb._fused.linear_transforms = False
     sa = ta.graphed(stacked, B, mask_seed=5)
     sb = tb.graphed(stacked, B, mask_seed=5)
     sa.pipe_steps, sb.pipe_steps = 0, S
@@ -848,3 +851,41 @@ def test_graphed_bank_step_with_distinct_decay_windows():
         assert np.array_equal(tr2.optimizer.flat_grad.cpu().numpy(), got_grad[i]), i
         for k, v in out.items():
             assert np.array_equal(v.detach().cpu().numpy(), got[i][k]), (i, k)
+
+
+@pytest.mark.parametrize("t60max", [None, T60MAX])
+def test_time_domain_output_stage_equals_spectral_output_stage(t60max):
+    """The explicit step with the output stage in the time domain (csrc/linear.hip: G transforms per band, receivers'
+    signals combined from the transformed group responses and the dataset's transformed direct paths) against the same
+    step with the output stage formed per receiver in the frequency domain and one transform per receiver: the maps
+    commute, so losses and every gradient agree to float32 rounding."""
+    from diffgfdn_amd.bankstep import FusedBankStep
+    sels = [[0, 3, 5, 7], [1, 2, 8, 11], [4, 6, 9, 10]]
+    res = {}
+    for lin in (True, False):
+        nets, data, filt, bank, tr, sds, (start, length) = _bank_setup(t60max=t60max)
+        tr._fused.linear_transforms = lin
+        Kf = NFFT // 2 + 1
+        lens = tr._band_windows(Kf)
+        if lens is None:
+            mw = torch.tensor(philox_mask(5, 0, length, 1.0 / 4)[0], device=DEV)
+        else:
+            mw = torch.tensor(_band_rows(5, 0, lens, 4)[0], device=DEV)
+        out = tr._fused.run(sds.collate(sds.global_rows(sels)), mw, 1.0, normalize_first=True, train=True, opt_step=False)
+        torch.cuda.synchronize()
+        res[lin] = ({k: v.detach().cpu().numpy().copy() for k, v in out.items()},
+                    {id_: g.copy() for id_, g in zip(("c", "b", "M", "w"), _grad_views(tr))})
+    assert FusedBankStep.linear_transforms
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=2e-6, atol=0), (k, res[True][0][k], v)
+    for k, g in res[False][1].items():
+        assert np.abs(res[True][1][k] - g).max() <= 2e-5 * np.abs(g).max(), (k, np.abs(res[True][1][k] - g).max(), np.abs(g).max())
+
+
+def _grad_views(tr):
+    flat = tr.optimizer.flat_grad.detach().cpu().numpy()
+    out, off = [], 0
+    for p in tr.optimizer._params:
+        out.append(flat[off:off + p.numel()])
+        off += p.numel()
+    return out

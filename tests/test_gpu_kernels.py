@@ -702,3 +702,60 @@ def test_edc_banded_windows_equal_per_band_calls():
         assert torch.equal(li2[sl], lq), q
         assert float((g2[psl, :, 0] - gq[0::2]).abs().max()) <= 1e-5 * float(gq.abs().max()), q
         assert float(gq[:, start + L:].abs().max()) == 0.0 and float(gp[:, start + L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("G,B,n", [(4, 6, 4099), (3, 4, 1031), (4, 32, 65537)])
+def test_linear_output_stage_kernels(G, B, n):
+    """csrc/linear.hip -- the output stage in the time domain: x = xd[rows] + sum_g rgain tau_g, gamma_g = sum_b rgain
+    dL/dx_b, dL/drgain = <dL/dx_b, tau_g> -- in every layout combination (pair-interleaved / plain) against float64
+    torch on the same inputs."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(G * 1000 + B)
+    nb, R = 3, B + 5
+    items, S = nb * B, nb * G
+    xd = torch.randn(nb * R, n, generator=gen).to(DEV)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=gen)[:B]], device=DEV)
+    tau = torch.randn(S, n, generator=gen).to(DEV)
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    gx = torch.randn(items, n, generator=gen).to(DEV)
+    gxb = torch.randn(items, n, generator=gen).to(DEV)
+
+    def to_pairs(a):
+        m = a.shape[0]
+        if m % 2:
+            a = torch.cat([a, torch.zeros_like(a[:1])])
+        return torch.stack((a[0::2], a[1::2]), dim=-1).contiguous()
+
+    def from_pairs(a2, m):
+        out = torch.empty((2 * a2.shape[0], a2.shape[1]), dtype=a2.dtype, device=a2.device)
+        out[0::2], out[1::2] = a2[..., 0], a2[..., 1]
+        return out[:m]
+
+    band = torch.arange(items, device=DEV) // B
+    tau_b = tau.double().view(nb, G, n)[band]                                         # (items, G, n)
+    x_ref = xd.double()[rows] + (rgain.double()[:, :, None] * tau_b).sum(1)
+    for tau_pairs in (False, True):
+        tin = to_pairs(tau) if tau_pairs else tau
+        for out_pairs in (False, True):
+            x = ops.lin_combine_fwd(xd, rows, tin, rgain, nb, n, tau_pairs, out_pairs)
+            xg = from_pairs(x, items) if out_pairs else x
+            assert rel_err(xg.cpu(), x_ref.cpu()) < 2e-6, (tau_pairs, out_pairs)
+            if out_pairs and items % 2:
+                assert float(x[-1, :, 1].abs().max()) == 0.0
+    for two in (False, True):
+        gsum = gx.double() + (gxb.double() if two else 0.0)
+        gam_ref = (rgain.double().view(nb, B, G, 1) * gsum.view(nb, B, 1, n)).sum(1).reshape(S, n)
+        dots_ref = (gsum[:, None, :] * tau_b).sum(-1)                                  # (items, G)
+        for in_pairs in (False, True):
+            if in_pairs and (two or B % 2):
+                continue
+            gin = to_pairs(gx) if in_pairs else gx
+            for out_pairs in (False, True):
+                gam = ops.lin_gamma(gin, rgain, nb, n, in_pairs, out_pairs, gxb=gxb if two else None)
+                gg = from_pairs(gam, S) if out_pairs else gam
+                assert rel_err(gg.cpu(), gam_ref.cpu()) < 5e-6, (two, in_pairs, out_pairs)
+            for tau_pairs in (False, True):
+                tin = to_pairs(tau) if tau_pairs else tau
+                parts = ops.lin_gain_dots(gin, tin, nb, items, G, n, in_pairs, tau_pairs, gxb=gxb if two else None)
+                dots = ops.tf_rows_sum(parts).view(items, G)
+                assert rel_err(dots.cpu(), dots_ref.cpu()) < 2e-5, (two, in_pairs, tau_pairs)

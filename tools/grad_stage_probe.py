@@ -32,7 +32,7 @@ def spy_bwd(turns, logr, coef, delays, n, rgain, gH, Ts, filt, nb, **kw):
 
 def spy_oc(M, ig, b, c, *a, **kw):
     out = orig_oc(M, ig, b, c, *a, **kw)
-    cap.update(ig=ig.clone(), b_old=b.clone(), c_old=c.clone(), QQ=out[1].clone())
+    cap.update(ig=ig.clone(), b_old=b.clone(), c_old=c.clone(), QQ=out[1].clone(), M=M.clone(), Q=out[0].clone())
     return out
 
 
@@ -94,3 +94,56 @@ print('  |dL/dQQ| largest entry', float(QQ.grad.abs().max()), ' |dL/db| ', float
 print('  |dL/dM| largest entry (whole step, after the expm adjoint + skew projection)', float(gM_step.abs().max()),
       ' -> a 1e-6 error of dL/dQQ relative to ITS largest entry is',
       f'{1e-6 * float(QQ.grad.abs().max()) / float(gM_step.abs().max()):.1e}', 'of the largest entry of dL/dM')
+
+
+# ---- round 4: which part of the records path carries the error?  (i) the kernel's records against float64 sums of the same
+# per-bin terms; (ii) the EXACT records rounded to float32 through the kernel's float64 map -> dL/dQQ: the floor that
+# float32 STORAGE of the records sets; (iii) the same through the expm adjoint: the stage's share of the error of dL/dM
+with torch.no_grad():
+    turns = cap['turns'].double()
+    rec_exact = torch.zeros((G, 32), dtype=torch.float64, device=dev)
+    coef64 = cap['coef'].double()
+    filt = cap['filt'].reshape(-1).to(torch.complex128) if cap['filt'] is not None else None
+    for q in range(G):
+        m = delays[q * n:(q + 1) * n]
+        e1 = [torch.polar(torch.ones_like(turns), 2 * np.pi * ((turns * m[i]) % 1.0)) for i in range(n)]
+        eS = []
+        for S in range(16):
+            v = torch.ones_like(e1[0])
+            for i in range(n):
+                if (S >> i) & 1:
+                    v = v * e1[i]
+            eS.append(v)
+        eS = torch.stack(eS)                                               # (16, Ku)
+        den = (coef64[q, 16:32, None] * eS).sum(0)
+        acc = (cap['rgain'][:, q].double().to(torch.complex128)[:, None] * W).sum(0)
+        if filt is not None:
+            acc = acc * filt.conj()
+        u = acc * (1.0 / den).conj()
+        v = u * T.detach()[q].conj()
+        rec_exact[q, :16] = (u[None, :] * eS.conj()).real.sum(1)
+        rec_exact[q, 16:] = -(v[None, :] * eS.conj()).real.sum(1)
+        rec_exact[q, 15] = 0.0
+    gk = grec.double().reshape(G, 32)
+    scale_rec = rec_exact.abs().max(dim=1, keepdim=True).values
+    print('(i) kernel records vs float64 sums of the same terms: worst entry relative to the block\'s largest record',
+          f'{float(((gk - rec_exact).abs() / scale_rec).max()):.2e}',
+          '; float32 rounding of the exact records alone:',
+          f'{float(((rec_exact.float().double() - rec_exact).abs() / scale_rec).max()):.2e}')
+    gA_x, _, gb_x, gc_x = ops.tf_coefs_bwd(cap['QQ'], cap['ig'], rec_exact.float().contiguous(), bp.detach().float(),
+                                           cp.detach().float())
+    print('(ii) exact records rounded to float32 -> float64 map: dL/dQQ', f'{dev_rel(gA_x, QQ.grad):.2e}',
+          ' dL/db', f'{dev_rel(gb_x, bp.grad):.2e}', ' dL/dc', f'{dev_rel(gc_x, cp.grad):.2e}')
+
+# (iii) through the expm adjoint (dL/dM of THIS linear functional only)
+M64 = cap['M'].double().requires_grad_()
+Sk = torch.triu(M64, 1)
+Qm = torch.linalg.matrix_exp(Sk - Sk.transpose(-1, -2))
+(Qm @ Qm * QQ.grad).sum().backward()
+gM_ref = M64.grad
+gM_k = ops.ortho_bwd(cap['M'], None, gA.contiguous(), cap['Q'])
+gM_x = ops.ortho_bwd(cap['M'], None, gA_x.contiguous(), cap['Q'])
+gM_f32in = ops.ortho_bwd(cap['M'], None, QQ.grad.float().contiguous(), cap['Q'])
+print('(iii) dL/dM of this functional, relative to its largest entry', float(gM_ref.abs().max()), ': kernel records',
+      f'{dev_rel(gM_k, gM_ref):.2e}', '; exact records rounded to float32', f'{dev_rel(gM_x, gM_ref):.2e}',
+      '; exact dL/dQQ rounded to float32', f'{dev_rel(gM_f32in, gM_ref):.2e}')
