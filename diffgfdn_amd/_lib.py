@@ -152,8 +152,11 @@ SIGNATURES = {
     "gfdn_edc_loss_model": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_draw_mask": (c_int, [ctypes.c_ulonglong, _P, c_int, c_float, _P, _P]),
     "gfdn_lin_gain_chunks": (c_int, [c_int]),
+    "gfdn_stft_power_pairs_lin": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_lin_combine_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
-    "gfdn_lin_gamma": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "gfdn_lin_gamma": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
+    "gfdn_irfft_odd_time_slots": (c_int, [c_int, _P]),
+    "gfdn_irfft_odd_pairs_bwd_tslots": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_lin_gain_dots": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "gfdn_edc_loss_banded": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_float, c_float,
                                      _P, _P, _P, _P]),

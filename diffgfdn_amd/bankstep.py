@@ -79,6 +79,11 @@ class FusedBankStep:
     # dot product over the time samples and the records pass reads G adjoint spectra per band.  Supersedes the folded
     # output stage below, which stays as the cross-check (tests/test_gpu_bank.py) and for chained steps (``pipe``).
     linear_transforms = os.environ.get('GFDN_LINEAR', '1') == '1'
+    # ... with the combine pass folded into the STFT's load (gfdn_stft_power_pairs_lin): x is stored by the launch that
+    # first reads it.  Measured same-box: 0.565 against 0.549 ms -- the fused launch takes 73 us against 46 + 42, but the EDC
+    # scans, which ran beside the STFT and the EDR kernel, now start behind it and run beside the STFT adjoint instead
+    # (even-frame launch 50 -> 86 us)
+    combine_in_stft = os.environ.get('GFDN_COMBINE_IN_STFT', '0') == '1'      # (OFF: measured slower, see below)
 
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
     # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
@@ -114,8 +119,11 @@ class FusedBankStep:
         tr, cfg, keep = self.tr, self.tr.config, self._keep
         Btot, win = (H.shape[0] if Btot is None else Btot), tr.stft_win
         on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
+        P = None
         if x_fn is not None:              # (the output stage rides the transform's first pass: H is never stored)
             x = x_fn()
+            if isinstance(x, tuple):      # (... or the STFT's load, which then also returns |STFT|^2)
+                x, P = x
         elif pairs:
             x = ops.irfft_odd_fwd(H, K, slots=True, pairs=True)
         else:
@@ -145,7 +153,8 @@ class FusedBankStep:
                 ev['g'].record()
             return li_edr, li_edc, gH
         if pairs:
-            P = ops.stft_power_pairs(x, Btot, win)
+            if P is None:
+                P = ops.stft_power_pairs(x, Btot, win)
             g_edr = None
         else:
             g_edr = torch.empty_like(x) if train else None
@@ -387,6 +396,8 @@ class FusedBankStep:
 
             def x_fn():
                 wait_gains()
+                if pairs and tau_pairs and self.combine_in_stft and win == 4096 and not self.fuse_decay:
+                    return ops.stft_power_pairs_lin(xd, rows, tau, rgain, nb, K, win)
                 return ops.lin_combine_fwd(xd, rows, tau, rgain, nb, K, tau_pairs, pairs)
             keep.extend((tau, xd))
         elif big:
@@ -472,9 +483,10 @@ class FusedBankStep:
                 # time-domain adjoint: gamma_g = sum_b rgain[b][g] dL/dx[b] (G signals per band) -> their adjoint transform
                 # = dL/d(T_g filt) -> the records pass at "B = G receivers with identity gains"
                 gsig, gsig_b = gH
-                gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b)
+                sot = ops.irfft_slot_of_time(K, z.device) if tau_pairs else None
+                gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b, slot_of_time=sot)
                 if tau_pairs:
-                    gHg = ops.irfft_odd_pairs_bwd(gam, K, nb * G)
+                    gHg = ops.irfft_odd_pairs_bwd(gam, K, nb * G, tslots=sot is not None)
                 else:
                     gHg = ops.irfft_odd_bwd(gam, K, Ku, None, slots=False)
                 keep.extend((gam, gHg, eye))

@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_tf_compose_bwd_rec(TfCompose a, const f
   float* out = gpart + (size_t)(band * G + w) * TF_REC * nparts + blockIdx.x;
 #pragma unroll
   for (int S = 0; S < 16; ++S) {
-    const float p = wave_sum(aP[S]), q = wave_sum(aQ[S]);
+    const float p = wave_sum_full(aP[S]), q = wave_sum_full(aQ[S]);       // (whole waves reach this point: VALU sums)
     if (lane == 0) {
       out[(size_t)S * nparts] = p;
       out[(size_t)(16 + S) * nparts] = q;

@@ -371,6 +371,8 @@ struct BluArgs {
   int pair;             // slot mode only: items 2b, 2b+1 share one transform; time signals pair-interleaved (float2)
   int items;            // number of items (rows of the spectrum side)
   int slot;             // Rader + col128: the SPECTRUM side is in slot order (gfdn_irfft_odd_slot_order): no gather / scatter
+  int tslots;           // pair adjoint: the TIME side arrives in slot order too -- in[0] = sample 0, in[1 + s] = sample
+                        // iperm[s] (gfdn_lin_gamma writes it so): coalesced loads instead of the gather
   const float2* chirp;  // n
   const float2* chat;   // L, [k1][k2]
   float2* work;         // batch * L
@@ -843,7 +845,8 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
     const float2* G2 = a.in2 ? (const float2*)a.in2 + (size_t)b * a.ld_in : nullptr;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int src = a.iperm[(l + 8 * k) * L2 + c0 + c];
+      const int sidx = (l + 8 * k) * L2 + c0 + c;
+      const int src = a.tslots ? 1 + sidx : a.iperm[sidx];
       float2 gv = G[src];
       if (G2) { const float2 g2 = G2[src]; gv.x += g2.x; gv.y += g2.y; }
       v[k] = gv;
@@ -903,11 +906,17 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
     const float invL = 1.0f / (float)L, invn = 1.0f / (float)g.n;
     float sum1 = 0.f, sum2 = 0.f;
     const bool folder = tb == 0 && threadIdx.x == 0;
-    if (folder) {                        // t = 0 / k = 0 terms (fixed order)
-      for (int e = 0; e < a.nedge; ++e) {
-        sum1 += a.edge[(size_t)b1 * a.nedge + e];
-        if (two) sum2 += a.edge[(size_t)(b1 + 1) * a.nedge + e];
+    if (tb == 0 && wave == 0) {
+      // t = 0 / k = 0 terms: the tiles' partial sums folded by the whole wave in a fixed order (one thread walking the
+      // 64 partials was a serial chain of dependent loads -- invisible beside 112 pairs, the critical path of a launch
+      // that transforms the 14 pairs of group signals)
+      float e1 = 0.f, e2 = 0.f;
+      for (int e = lane; e < a.nedge; e += 64) {
+        e1 += a.edge[(size_t)b1 * a.nedge + e];
+        if (two) e2 += a.edge[(size_t)(b1 + 1) * a.nedge + e];
       }
+      sum1 = wave_sum(e1);
+      sum2 = wave_sum(e2);
     }
     col128_fft(v, bufs + wave * CW_LDS, l, c, -1.0f);
     if (!a.adjoint) {
@@ -1047,7 +1056,7 @@ static bool slot_order_ok(int n) {
 
 static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
                    int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7,
-                   const float* in2 = nullptr, int slot = 0, const BluCompose* cmp = nullptr) {
+                   const float* in2 = nullptr, int slot = 0, const BluCompose* cmp = nullptr, int tslots = 0) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
   const bool rader = rader_ok(n);
@@ -1078,6 +1087,8 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   a.items = batch;
   a.slot = slot ? 1 : 0;
   a.pair = slot == 2 ? 1 : 0;
+  a.tslots = tslots ? 1 : 0;
+  if (tslots && !(slot == 2 && adjoint && !in2)) return GFDN_E_BADARG;
   if (slot && !slot_order_ok(n)) return GFDN_E_UNSUPPORTED;
   if (a.pair) a.batch = (batch + 1) / 2;          // work blocks = item pairs
   a.adjoint = adjoint;
@@ -1194,6 +1205,26 @@ extern "C" int gfdn_irfft_odd_pairs_compose_fwd(const void* table, int n, const 
 extern "C" int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* gx2, const float* gx2b, int ldo,
                                         int batch, float* gXs, int ldx, void* work, void* stream) {
   return blu_run(table, n, gx2, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, gx2b, 2);
+}
+
+// ... with the time side in slot order as well: gx2s[p][0] = the pair's sample 0, gx2s[p][1 + s] = its sample at time
+// gfdn_irfft_odd_time_slots()[s] -- what gfdn_lin_gamma writes when it is handed the inverse of that table; the first pass
+// then loads coalesced rows instead of gathering 8-byte samples
+extern "C" int gfdn_irfft_odd_pairs_bwd_tslots(const void* table, int n, const float* gx2s, int ldo, int batch, float* gXs,
+                                               int ldx, void* work, void* stream) {
+  return blu_run(table, n, gx2s, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, nullptr, 2, nullptr, 1);
+}
+// time index of convolution slot s (s < n - 1): times[s] = g^-s mod n, the table the pair transforms scatter / gather by
+extern "C" int gfdn_irfft_odd_time_slots(int n, int* times) {
+  if (!times) return GFDN_E_BADARG;
+  if (n < 3 || !slot_order_ok(n)) return GFDN_E_UNSUPPORTED;
+  const int N = n - 1;
+  unsigned long long v = 1;
+  for (int a = 0; a < N; ++a) {            // g^a at slot (N - a) % N
+    times[(N - a) % N] = (int)v;
+    v = mulmod(v, 3, (unsigned long long)n);
+  }
+  return 0;
 }
 
 // The paired adjoint transform with the GAINS pass of the output stage's adjoint folded into its last pass: besides
@@ -1523,6 +1554,122 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power(const float2* __
       if (two) P2[f] = sb.x * sb.x + sb.y * sb.y;
     }
   }
+}
+
+// The time-domain output stage folded into the STFT's load (csrc/linear.hip has the stand-alone form): the pair's samples
+//   x[b][t] = xd[rows[b]][t] + sum_g rgain[b][g] tau[band G + g][t]
+// are formed where the frame is loaded -- two 4-byte loads of the dataset's transformed direct paths and the band's group
+// signals (pair-interleaved, (ceil(S / 2), ld_tau) float2; a band's signals are shared by all of its receivers: cache
+// hits) -- and stored once as the pair-interleaved signal x2 that the EDC scans and the STFT adjoint read: every frame
+// stores its first hop, the last frame its second as well.  The stand-alone combine pass (117 MB of traffic and a launch
+// on the critical chain) does not run.
+struct StftLin {
+  const float* xd;             // (R, ld_xd) float: transformed direct paths
+  int ld_xd;
+  const long long* rows;       // item -> row of xd (NULL: identity)
+  const float2* tau2;          // pair-interleaved group signals
+  int ld_tau;
+  const float* rgain;          // (items, G)
+  int B, G;
+  float2* x2;                  // out: (pairs, ld) pair-interleaved signals
+};
+
+__global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_lin(StftLin L, int ld, int T, int nframes, int items,
+                                                                 float* __restrict__ P) {
+  if (STFT_PAIR_PRIO) __builtin_amdgcn_s_setprio(STFT_PAIR_PRIO);
+  float2* buf = dyn_lds;
+  const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
+  const int b1 = 2 * p, b2 = b1 + 1;
+  const bool two = b2 < items;
+  const int G = L.G, band1 = b1 / L.B, band2 = two ? b2 / L.B : band1;
+  const float* d1 = L.xd + (size_t)(L.rows ? L.rows[b1] : b1) * L.ld_xd;
+  const float* d2 = two ? L.xd + (size_t)(L.rows ? L.rows[b2] : b2) * L.ld_xd : d1;
+  float rg1[4], rg2[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    rg1[g] = g < G ? L.rgain[(size_t)b1 * G + g] : 0.f;
+    rg2[g] = (g < G && two) ? L.rgain[(size_t)b2 * G + g] : 0.f;
+  }
+  // both items in one band whose signals fill whole pairs (the band bank: B even, G even): two 8-byte loads per sample
+  const bool quad = band1 == band2 && !((band1 * G) & 1) && !(G & 1);
+  const float2* tq = L.tau2 + (size_t)((band1 * G) >> 1) * L.ld_tau;
+  const float* tf = (const float*)L.tau2;
+  float sn, cs;
+  sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
+  const float2 w1 = make_float2(cs, -sn);
+  float2* xo = L.x2 + (size_t)p * ld;
+  const bool last = m == nframes - 1;
+  float2 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float sk, ck;
+    sincospif((float)k * 0.125f, &sk, &ck);
+    const float h = 0.5f - 0.5f * (cs * ck - sn * sk);
+    const int t = m * 2048 + i + 256 * k;
+    float2 v = make_float2(0.f, 0.f);
+    if (t < T) {
+      v = make_float2(d1[t], two ? d2[t] : 0.f);
+      if (quad) {
+        const float2 t01 = tq[t], t23 = G > 2 ? tq[L.ld_tau + t] : make_float2(0.f, 0.f);
+        v.x += rg1[0] * t01.x;
+        v.x += rg1[1] * t01.y;
+        v.x += rg1[2] * t23.x;
+        v.x += rg1[3] * t23.y;
+        v.y += rg2[0] * t01.x;
+        v.y += rg2[1] * t01.y;
+        v.y += rg2[2] * t23.x;
+        v.y += rg2[3] * t23.y;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g < G) {
+            const int s1 = band1 * G + g, s2 = band2 * G + g;
+            v.x += rg1[g] * tf[((size_t)(s1 >> 1) * L.ld_tau + t) * 2 + (s1 & 1)];
+            if (two) v.y += rg2[g] * tf[((size_t)(s2 >> 1) * L.ld_tau + t) * 2 + (s2 & 1)];
+          }
+        }
+      }
+      if (k < 8 || last) xo[t] = v;
+    }
+    a[k] = make_float2(h * v.x, h * v.y);
+  }
+  fft4096(a, buf, i, w1, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+  __syncthreads();
+  float* P1 = P + ((size_t)b1 * nframes + m) * nf;
+  float* P2 = P1 + (size_t)nframes * nf;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const float2 zf = a[u], zc = buf[S4K_PAD((4096 - f) & 4095)];
+      const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+      P1[f] = sa.x * sa.x + sa.y * sa.y;
+      if (two) P2[f] = sb.x * sb.x + sb.y * sb.y;
+    }
+  }
+}
+
+// x2 (ceil(items / 2), ld >= T, 2) and P (items, nframes, 2049) from the transformed direct paths, the band's group signals
+// and the receiver gains (see StftLin); win = 4096, tau pair-interleaved.  The frames of the STFT cover
+// [0, 2048 (nframes + 1)): T must not exceed that (gfdn_stft_nframes pads T to a whole number of hops).
+extern "C" int gfdn_stft_power_pairs_lin(const float* xd, int ld_xd, const long long* rows, const float* tau2, int ld_tau,
+                                         const float* rgain, int nbands, int B, int G, int T, int win, float* x2, int ld,
+                                         float* P, void* stream) {
+  if (!xd || !tau2 || !rgain || !x2 || !P || nbands <= 0 || B <= 0 || G <= 0 || T <= 0 || ld < T || ld_xd < T || ld_tau < T)
+    return GFDN_E_BADARG;
+  if (win != 4096 || G > 4) return GFDN_E_UNSUPPORTED;
+  const int nframes = gfdn_stft_nframes(T, win);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  const int items = nbands * B;
+  StftLin L{xd, ld_xd, rows, (const float2*)tau2, ld_tau, rgain, B, G, (float2*)x2};
+  hipLaunchKernelGGL(k_stft4k_pair_power_lin, dim3(nframes, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                     (hipStream_t)stream, L, ld, T, nframes, items, P);
+  GFDN_LAUNCH_CHECK();
+  return 0;
 }
 
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void k_lin_combine_fwd(const float* __restrict
 template <bool IN_PAIRS, bool OUT_PAIRS>
 __global__ __launch_bounds__(256) void k_lin_gamma(const float* __restrict__ gx, const float* __restrict__ gxb, int ld_g,
                                                    const float* __restrict__ rgain, int B, int G, int n,
-                                                   float* __restrict__ gamma, int ld_o) {
+                                                   float* __restrict__ gamma, int ld_o,
+                                                   const int* __restrict__ slot_of_time) {
   __shared__ float s_rg[256];                     // the band's gains (B G <= 256)
   const int band = blockIdx.y;
   for (int i = threadIdx.x; i < B * G; i += 256) s_rg[i] = rgain[(size_t)band * B * G + i];
@@ -182,6 +183,32 @@ __global__ __launch_bounds__(256) void k_lin_gamma(const float* __restrict__ gx,
         }
       }
     }
+  }
+  if (OUT_PAIRS && slot_of_time) {
+    // the adjoint pair transform's own order (gfdn_irfft_odd_pairs_bwd_tslots): sample 0 first, then the sample of time t
+    // at 1 + slot_of_time[t] -- the scatter happens here, on G signals per band, instead of a gather in the transform
+#pragma unroll
+    for (int u = 0; u < LIN_V; ++u) {
+      const int t = t0 + u;
+      if (t < n) {
+        const size_t pos = t == 0 ? 0 : 1 + (size_t)slot_of_time[t];
+        if (!((band * G) & 1) && !(G & 1)) {          // whole output pairs: 8-byte stores
+#pragma unroll
+          for (int g = 0; g < LIN_MAXG; g += 2)
+            if (g < G)
+              ((float2*)gamma)[(size_t)((band * G + g) >> 1) * ld_o + pos] = make_float2(acc[g][u], acc[g + 1][u]);
+        } else {
+#pragma unroll
+          for (int g = 0; g < LIN_MAXG; ++g) {
+            if (g < G) {
+              const int s = band * G + g;
+              gamma[((size_t)(s >> 1) * ld_o + pos) * 2 + (s & 1)] = acc[g][u];
+            }
+          }
+        }
+      }
+    }
+    return;
   }
   if (OUT_PAIRS && full && !((band * G) & 1) && !(G & 1)) {
     // the band's signals fill whole output pairs: 32-byte stores of (gamma_g, gamma_g+1) for four samples
@@ -338,14 +365,16 @@ extern "C" int gfdn_lin_combine_fwd(const float* xd, int ld_xd, const long long*
 }
 
 extern "C" int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* rgain, int nbands,
-                              int B, int G, int n, float* gamma, int ld_o, int out_pairs, void* stream) {
+                              int B, int G, int n, float* gamma, int ld_o, int out_pairs, const int* slot_of_time,
+                              void* stream) {
   if (!gx || !rgain || !gamma || nbands <= 0 || B <= 0 || G <= 0 || n <= 0 || ld_g < n || ld_o < n) return GFDN_E_BADARG;
+  if (slot_of_time && !out_pairs) return GFDN_E_BADARG;
   if (G > LIN_MAXG || B * G > 256 || nbands > 65535) return GFDN_E_UNSUPPORTED;
   if (in_pairs && ((B & 1) || gxb)) return GFDN_E_BADARG;        // (pairs never straddle bands; one merged gradient)
   dim3 grid((n + 256 * LIN_V - 1) / (256 * LIN_V), nbands), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LIN_GAM(IP, OP) \
-  hipLaunchKernelGGL((k_lin_gamma<IP, OP>), grid, block, 0, s, gx, gxb, ld_g, rgain, B, G, n, gamma, ld_o)
+  hipLaunchKernelGGL((k_lin_gamma<IP, OP>), grid, block, 0, s, gx, gxb, ld_g, rgain, B, G, n, gamma, ld_o, slot_of_time)
   if (in_pairs) { if (out_pairs) LIN_GAM(true, true); else LIN_GAM(true, false); }
   else { if (out_pairs) LIN_GAM(false, true); else LIN_GAM(false, false); }
 #undef LIN_GAM

@@ -1043,10 +1043,32 @@ def lin_combine_fwd(xd, rows, tau, rgain, nbands: int, n: int, tau_pairs: bool, 
     return x
 
 
-def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, gxb=None):
+_time_slots = {}
+
+
+def irfft_slot_of_time(n: int, device):
+    """(n,) int32 on ``device``: slot_of_time[t] = the convolution slot whose time index is t (t >= 1; entry 0 unused) --
+    the inverse of gfdn_irfft_odd_time_slots -- or None when the length has no slot-order path."""
+    key = (int(n), str(device))
+    if key not in _time_slots:
+        import ctypes
+        times = (ctypes.c_int * max(int(n) - 1, 1))()
+        rc = _lib.load().gfdn_irfft_odd_time_slots(int(n), times) if n >= 3 and n % 2 == 1 else -2
+        if rc == 0:
+            tt = torch.tensor(list(times), dtype=torch.int64)
+            inv = torch.zeros(int(n), dtype=torch.int32)
+            inv[tt] = torch.arange(int(n) - 1, dtype=torch.int32)
+            _time_slots[key] = inv.to(device)
+        else:
+            _time_slots[key] = None
+    return _time_slots[key]
+
+
+def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, gxb=None, slot_of_time=None):
     """gamma[band G + g] = sum_{b in band} rgain[b][g] (gx[b] [+ gxb[b]]): the signals whose adjoint transform is
     dL/d(T_g filt).  gx: (ceil(items / 2), n, 2) pair-interleaved (``in_pairs``) or (items, n); result in the layout
-    ``out_pairs`` asks for (what irfft_odd_pairs_bwd / irfft_odd_bwd take)."""
+    ``out_pairs`` asks for (what irfft_odd_pairs_bwd / irfft_odd_bwd take).  ``slot_of_time`` (irfft_slot_of_time): the
+    pair-interleaved result in the adjoint transform's own order, for irfft_odd_pairs_bwd(tslots=True)."""
     _need_gpu(gx, rgain)
     gx, rgain = _f(gx), _f(rgain)
     items, G = rgain.shape
@@ -1060,8 +1082,10 @@ def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, g
     gamma = torch.empty(((S + 1) // 2, n, 2) if out_pairs else (S, n), dtype=_f32, device=gx.device)
     if out_pairs and S % 2:
         gamma[-1].zero_()                  # (the missing partner of the last signal)
+    if slot_of_time is not None and (not out_pairs or slot_of_time.dtype != torch.int32 or slot_of_time.numel() != n):
+        raise RuntimeError("lin_gamma: slot_of_time is an int32 table of n entries for the pair-interleaved output")
     _lib.check(_lib.load().gfdn_lin_gamma(_p(gx), _p(gxb), n, int(in_pairs), _p(rgain), nbands, items // nbands, G, n,
-                                          _p(gamma), n, int(out_pairs), _stream()), "gfdn_lin_gamma")
+                                          _p(gamma), n, int(out_pairs), _p(slot_of_time), _stream()), "gfdn_lin_gamma")
     return gamma
 
 
@@ -1085,6 +1109,27 @@ def lin_gain_dots(gx, tau, nbands: int, items: int, G: int, n: int, in_pairs: bo
     return parts
 
 
+def stft_power_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, win: int):
+    """lin_combine_fwd(..., tau_pairs=True, out_pairs=True) folded into the load of stft_power_pairs: returns (x2
+    (ceil(items / 2), n, 2), P (items, nframes, win / 2 + 1)) in ONE launch (win = 4096)."""
+    _need_gpu(xd, tau2, rgain)
+    xd, tau2, rgain = _f(xd), _f(tau2), _f(rgain)
+    items, G = rgain.shape
+    S = nbands * G
+    if items % nbands or xd.dim() != 2 or xd.shape[1] < n or tuple(tau2.shape) != ((S + 1) // 2, n, 2):
+        raise RuntimeError("stft_power_pairs_lin: rgain (nbands * B, G), xd (R, >= n), tau2 (ceil(nbands G / 2), n, 2)")
+    rows = _rows(rows, items, xd.shape[0])
+    if rows is None and xd.shape[0] != items:
+        raise RuntimeError("stft_power_pairs_lin: xd must have one row per item (or pass rows)")
+    nf = stft_nframes(n, win)
+    x2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=xd.device)
+    P = torch.empty((items, nf, win // 2 + 1), dtype=_f32, device=xd.device)
+    _lib.check(_lib.load().gfdn_stft_power_pairs_lin(_p(xd), xd.stride(0), _p(rows), _p(tau2), n, _p(rgain), nbands,
+                                                     items // nbands, G, n, win, _p(x2), n, _p(P), _stream()),
+               "gfdn_stft_power_pairs_lin")
+    return x2, P
+
+
 def tf_rows_sum(part: torch.Tensor) -> torch.Tensor:
     """part (..., cols) float32 -> sums over the last axis (one wavefront per row, fixed order)."""
     _need_gpu(part)
@@ -1095,7 +1140,7 @@ def tf_rows_sum(part: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None):
+def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None, tslots: bool = False):
     """Adjoint of irfft_odd_fwd(slots=True, pairs=True): g2 (ceil(batch / 2), n, 2) f32 pair-interleaved gradients
     [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order (``out``: where to write it).
     ``gains`` = (Tquad (nbands, (n+1)/2, 4), filt (nbands, (n+1)/2) or None, nbands, G): the gains pass of the output
@@ -1112,6 +1157,12 @@ def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None):
         raise RuntimeError("irfft_odd_pairs_bwd: out must be a contiguous complex64 (batch, (n + 1) / 2) tensor")
     gX = torch.empty((batch, ldx), dtype=_c64, device=g2.device) if out is None else out
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), g2.device)
+    if tslots:                             # (g2 in the transform's own order: lin_gamma(slot_of_time=...))
+        if g2b is not None or gains is not None:
+            raise RuntimeError("irfft_odd_pairs_bwd(tslots=True) takes one gradient signal")
+        _lib.check(lib.gfdn_irfft_odd_pairs_bwd_tslots(_p(table), n, _p(g2), n, batch, _p(gX), ldx, _p(work), _stream()),
+                   "gfdn_irfft_odd_pairs_bwd_tslots")
+        return gX
     if gains is not None:
         Tq, filt, nbands, G = gains
         Tq = _c(Tq)

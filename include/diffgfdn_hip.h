@@ -513,9 +513,22 @@ int gfdn_lin_combine_fwd(const float* xd, int ld_xd, const long long* rows, cons
                          const float* rgain, int nbands, int B, int G, int n, float* x, int ld_x, int out_pairs,
                          void* stream);
 int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* rgain, int nbands, int B, int G,
-                   int n, float* gamma, int ld_o, int out_pairs, void* stream);
+                   int n, float* gamma, int ld_o, int out_pairs, const int* slot_of_time, void* stream);
+/* slot_of_time (n ints, device; out_pairs only; NULL: time order): gamma is written in the adjoint pair transform's own
+ * order -- sample 0 first, the sample of time t >= 1 at 1 + slot_of_time[t], slot_of_time the inverse of
+ * gfdn_irfft_odd_time_slots -- for gfdn_irfft_odd_pairs_bwd_tslots, whose first pass then loads coalesced rows.           */
+int gfdn_irfft_odd_time_slots(int n, int* times);
+int gfdn_irfft_odd_pairs_bwd_tslots(const void* table, int n, const float* gx2s, int ldo, int batch, float* gXs_c64,
+                                    int ldx, void* work, void* stream);
 int gfdn_lin_gain_dots(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* tau, int ld_tau,
                        int tau_pairs, int nbands, int B, int G, int n, float* part, void* stream);
+
+/* gfdn_lin_combine_fwd folded into the load of gfdn_stft_power_pairs (win = 4096; tau pair-interleaved): forms the pair's
+ * samples where the frame is loaded, stores them once as x2 (ceil(items / 2), ld >= T, 2) for the EDC scans and the STFT
+ * adjoint, and writes P (items, nframes, 2049) = |STFT|^2 -- the stand-alone combine pass does not run.                  */
+int gfdn_stft_power_pairs_lin(const float* xd, int ld_xd, const long long* rows, const float* tau2, int ld_tau,
+                              const float* rgain, int nbands, int B, int G, int T, int win, float* x2, int ld, float* P,
+                              void* stream);
 
 /* Fused decay-loss forward, one workgroup per item (csrc/decay.hip; win = 4096): replaces gfdn_stft_power_pairs ->
  * gfdn_edr_loss and gfdn_edc_loss_pairs on the training path.  Restates src/diff_gfdn/losses.py:430-495 (edr_loss),

@@ -759,3 +759,44 @@ def test_linear_output_stage_kernels(G, B, n):
                 parts = ops.lin_gain_dots(gin, tin, nb, items, G, n, in_pairs, tau_pairs, gxb=gxb if two else None)
                 dots = ops.tf_rows_sum(parts).view(items, G)
                 assert rel_err(dots.cpu(), dots_ref.cpu()) < 2e-5, (two, in_pairs, tau_pairs)
+
+
+@pytest.mark.parametrize("G,B,n", [(4, 6, 65537), (3, 4, 9001), (2, 2, 4096)])
+def test_stft_with_combine_folded_in(G, B, n):
+    """gfdn_stft_power_pairs_lin (the time-domain output stage formed in the STFT's load, x2 stored by the same launch)
+    against gfdn_lin_combine_fwd followed by gfdn_stft_power_pairs: the same signals and the same |STFT|^2."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(G * 100 + B)
+    nb, R = 3, B + 3
+    items, S = nb * B, nb * G
+    xd = torch.randn(nb * R, n, generator=gen).to(DEV)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=gen)[:B]], device=DEV)
+    tau = torch.randn(S + (S % 2), n, generator=gen).to(DEV)
+    tau2 = torch.stack((tau[0::2], tau[1::2]), dim=-1).contiguous()
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    x_ref = ops.lin_combine_fwd(xd, rows, tau2, rgain, nb, n, True, True)
+    P_ref = ops.stft_power_pairs(x_ref, items, 4096)
+    x2, P = ops.stft_power_pairs_lin(xd, rows, tau2, rgain, nb, n, 4096)
+    assert rel_err(x2.cpu(), x_ref.cpu()) < 1e-6
+    assert rel_err(P.cpu(), P_ref.cpu()) < 1e-5
+
+
+def test_gamma_in_transform_order_equals_gathering_adjoint():
+    """lin_gamma(slot_of_time=...) + irfft_odd_pairs_bwd(tslots=True) (the scatter on the G signals per band, coalesced
+    loads in the transform's first pass) against lin_gamma + irfft_odd_pairs_bwd (time order, gather in the transform):
+    the same adjoint spectra to the last bit."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    n, nb, B, G = 65537, 3, 4, 4
+    items = nb * B
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    g2 = torch.randn(items // 2, n, 2, generator=gen).to(DEV)
+    sot = ops.irfft_slot_of_time(n, torch.device(DEV))
+    assert sot is not None and sot.shape == (n,)
+    gam = ops.lin_gamma(g2, rgain, nb, n, True, True)
+    gam_s = ops.lin_gamma(g2, rgain, nb, n, True, True, slot_of_time=sot)
+    assert torch.equal(gam_s[:, 0], gam[:, 0])
+    assert torch.equal(gam_s[:, 1:][:, sot[1:].long()], gam[:, 1:])
+    a = ops.irfft_odd_pairs_bwd(gam, n, nb * G)
+    b = ops.irfft_odd_pairs_bwd(gam_s, n, nb * G, tslots=True)
+    assert torch.equal(a, b)
