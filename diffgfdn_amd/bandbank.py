@@ -268,6 +268,26 @@ class BandStackedDataset:
             self._direct_time = (key, out)
         return self._direct_time[1]
 
+    def direct_stft(self, filt: Optional[torch.Tensor], n: int, win: int, chunk: int = 64) -> torch.Tensor:
+        """Sd (bands*R, nframes, win / 2 + 1) complex64: the STFT (Hann ``win``, hop win / 2, as losses.py:501-553) of every
+        row of ``direct_time`` -- the short-time spectrum of a receiver's signal is Sd[row] + sum_g gain_g STFT(tau_g) (the
+        STFT is linear), which is what the EDR kernels of csrc/edrlin.hip compose on the fly.  Built once, cached."""
+        key = (None if filt is None else (filt.data_ptr(), tuple(filt.shape)), int(n), int(win))
+        cache = getattr(self, '_direct_stft', None)
+        if cache is None or cache[0] != key:
+            xd = self.direct_time(filt, n)
+            rows = xd.shape[0]
+            out = torch.empty((rows, ops.stft_nframes(n, win), win // 2 + 1), dtype=torch.complex64, device=xd.device)
+            for r0 in range(0, rows, chunk):
+                blk = xd[r0:r0 + chunk]
+                m = blk.shape[0]
+                if m % 2:
+                    blk = torch.cat([blk, torch.zeros_like(blk[:1])])
+                x2 = torch.stack((blk[0::2], blk[1::2]), dim=-1).contiguous()
+                out[r0:r0 + m] = ops.stft_pairs_spectrum(x2, m, win)
+            self._direct_stft = (key, out)
+        return self._direct_stft[1]
+
     def global_rows(self, per_band: Sequence[Sequence[int]]) -> List[int]:
         """per_band[q] = receiver indices of band q's batch -> band-major global rows."""
         if len(per_band) != self.num_bands or len({len(s) for s in per_band}) != 1:

@@ -79,6 +79,18 @@ class FusedBankStep:
     # dot product over the time samples and the records pass reads G adjoint spectra per band.  Supersedes the folded
     # output stage below, which stays as the cross-check (tests/test_gpu_bank.py) and for chained steps (``pipe``).
     linear_transforms = os.environ.get('GFDN_LINEAR', '1') == '1'
+    # ... and the EDR loss on linearly COMPOSED short-time spectra (csrc/edrlin.hip): the STFT is linear too, so a receiver's
+    # spectrum is Sd[row] + sum_g rgain[b][g] STFT(tau_g) with Sd a constant of the dataset (BandStackedDataset.direct_stft).
+    # A step runs G forward and G adjoint STFTs per band; per receiver only streaming arithmetic on (frame, frequency) cells
+    # is left, the EDC scans form their samples on the fly (gfdn_edc_loss_pairs_lin) and the receivers' signals are never
+    # stored.
+    spectral_edr = os.environ.get('GFDN_SPECTRAL_EDR', '1') == '1'
+    # ... with the sum of the gradient spectra over the band's receivers inside the EDR launch (k_edr_lin_fused)
+    # (OFF: 213 us against 99 + 83 for the two launches -- one 128 KB workgroup per CU keeps too few loads in flight and
+    # starves the colorless pass beside it of LDS; csrc/edrlin.hip)
+    edr_one_launch = os.environ.get('GFDN_EDR_ONE_LAUNCH', '0') == '1'
+    # ... and the G sums of the EDC gradient signals together with the EDC part of dL/drgain in one sweep over the window
+    gamma_dots_one_launch = os.environ.get('GFDN_GAMMA_DOTS_ONE_LAUNCH', '1') == '1'
     # ... with the combine pass folded into the STFT's load (gfdn_stft_power_pairs_lin): x is stored by the launch that
     # first reads it.  Measured same-box: 0.565 against 0.549 ms -- the fused launch takes 73 us against 46 + 42, but the EDC
     # scans, which ran beside the STFT and the EDR kernel, now start behind it and run beside the STFT adjoint instead
@@ -201,6 +213,50 @@ class FusedBankStep:
             main.wait_event(ev['edc'])
             ev['g'].record()
         return li_edr, li_edc, gH
+
+    def _decay_middle_spec(self, data, K, rows, rgain, tau, xd, maskw, inv, train, T_edr, sum_abs, T_edc, start, length,
+                           item_len, nb, G, ev, main, side2, wait_gains):
+        """The decay losses without per-receiver transforms of any kind (csrc/edrlin.hip, xlin_dev.h):
+            main : STFT of the band's G group signals -> EDR loss on composed spectra (loss partials, dL/d|S|^2, EDR part of
+                   dL/drgain) -> gradient spectra summed over the band's receivers -> their adjoint STFT (EDR part of dL/dtau)
+            side2: EDC scans on samples formed where they are read (-> dL/dx of the EDC term, pair-interleaved)
+        Returns (li_edr partials, li_edc, (g_edc, gam_edr, parts) or None); records ev['x'] / ev['edc'] / ev['g']."""
+        tr, cfg, keep = self.tr, self.tr.config, self._keep
+        Btot, win = rows.numel(), tr.stft_win
+        ds = data['dataset']
+        Sd = ds.direct_stft(tr.subband_filter_freq_resp, K, win)
+        on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
+        ev['x'].record()                                     # (tau complete)
+        Stau = ops.stft_pairs_spectrum(tau, nb * G, win)
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['x'])
+            li_edc, g_edc = ops.edc_loss_pairs_lin(xd, rows, tau, rgain, nb, K, start, length, T_edc, maskw, inv,
+                                                   cfg.edc_loss_weight, train, trows=rows, item_len=item_len,
+                                                   fill_outside=not self.gamma_dots_one_launch)
+            ev['edc'].record()
+        wait_gains()
+        nch = ops.lin_gamma_dots_tiles(K) if self.gamma_dots_one_launch else ops.lin_gain_chunks(K)
+        parts = None
+        if train:
+            parts = torch.empty((Btot * G, nch + ops.edr_lin_parts(win // 2 + 1, fused=self.edr_one_launch)),
+                                dtype=torch.float32, device=rows.device)
+        gP = Gs = None
+        if train and self.edr_one_launch:
+            li_edr, Gs = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, dots=parts,
+                                               col0=nch)
+        else:
+            li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
+                                          dots=parts, col0=nch)
+        ev['g'].record()                                     # (EDR partials and the EDR columns of ``parts`` complete)
+        keep.extend((Sd, Stau, li_edc, g_edc, li_edr, gP, parts))
+        if not train:
+            main.wait_event(ev['edc'])
+            return li_edr, li_edc, None
+        if Gs is None:
+            Gs = ops.edr_lin_gsum(Sd, rows, Stau, rgain, nb, gP)
+        gam_edr = ops.stft_pairs_spectrum_bwd(Gs, K, nb * G, win)
+        keep.extend((Gs, gam_edr))
+        return li_edr, li_edc, (g_edc, gam_edr, parts)
 
     def _decay_middle_halves(self, H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start, length, ev, main, side,
                              side2):
@@ -377,6 +433,7 @@ class FusedBankStep:
             wait_gains()
         x_fn = None
         tau = eye = None
+        spec = False
         tau_pairs = order is not None
         if lin:
             # group responses through the band's filter -> G time signals per band; the receivers' signals are formed from
@@ -393,6 +450,8 @@ class FusedBankStep:
                                             save_T=True, want_H=True)
             tau = ops.irfft_odd_fwd(Hg, K, slots=order is not None, pairs=tau_pairs)
             H = Hg
+            spec = (self.spectral_edr and pairs and tau_pairs and win == 4096 and (Btot // nb) % 2 == 0
+                    and hasattr(data['dataset'], 'direct_stft'))
 
             def x_fn():
                 wait_gains()
@@ -451,14 +510,23 @@ class FusedBankStep:
             keep.extend((grec_sub_, loss_g_, out3_, gQ_))
             return grec_sub_, out3_, gQ_
 
-        late_colorless = big and self.colorless_behind_scans
+        # (spectral-EDR step: the same holds for the small blocks -- in front of the scans the VALU-bound pass ran beside the
+        # latency-bound transforms of the G group signals, which sit on the critical chain: 18.6 against 9.6 us for the
+        # row pass; behind them it runs beside the memory-bound EDR kernels)
+        late_colorless = (big or spec) and self.colorless_behind_scans
         if not late_colorless:
             grec_sub, out3, gQ = colorless_pass()
 
         # ---- decay losses: irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint, EDC scans beside them
         ev['h'].record()
         want_halves = self.halves >= 2 and pairs and Btot % 4 == 0 and side is not None and item_len is None
-        if want_halves:
+        spec_bw = None
+        if spec:
+            li_edr, li_edc, spec_bw = self._decay_middle_spec(data, K, rows, rgain, tau, xd, maskw, inv, train, T_edr,
+                                                              sum_abs, T_edc, start, length, item_len, nb, G, ev, main,
+                                                              side2, wait_gains)
+            gH = None
+        elif want_halves:
             li_edr, li_edc, gH = self._decay_middle_halves(H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start,
                                                            length, ev, main, side, side2)
         else:
@@ -482,9 +550,25 @@ class FusedBankStep:
             if lin:
                 # time-domain adjoint: gamma_g = sum_b rgain[b][g] dL/dx[b] (G signals per band) -> their adjoint transform
                 # = dL/d(T_g filt) -> the records pass at "B = G receivers with identity gains"
-                gsig, gsig_b = gH
                 sot = ops.irfft_slot_of_time(K, z.device) if tau_pairs else None
-                gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b, slot_of_time=sot)
+                if spec:
+                    # dL/dtau = [EDC part: sum_b rgain dL/dx_b of the scans] + [EDR part: adjoint STFT of the band's G
+                    # gradient spectra, already summed over the receivers]
+                    gsig, gsig_b, gam_edr, parts = spec_bw[0], None, spec_bw[1], spec_bw[2]
+                    main.wait_event(ev['edc'])
+                    if self.gamma_dots_one_launch:
+                        # one sweep over the EDC gradient signals (their window only): the G sums per band AND the EDC part
+                        # of dL/drgain
+                        _, band_len = tr._item_windows(K, Btot // nb, z.device)
+                        gam = ops.lin_gamma_dots(gsig, rgain, nb, K, tau, parts, start, length, base=gam_edr,
+                                                 slot_of_time=sot, band_win_len=band_len)
+                    else:
+                        gam = ops.lin_gamma(gsig, rgain, nb, K, True, True, slot_of_time=sot, base=gam_edr)
+                    ev_gam = torch.cuda.Event()
+                    ev_gam.record()
+                else:
+                    gsig, gsig_b = gH
+                    gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b, slot_of_time=sot)
                 if tau_pairs:
                     gHg = ops.irfft_odd_pairs_bwd(gam, K, nb * G, tslots=sot is not None)
                 else:
@@ -511,7 +595,14 @@ class FusedBankStep:
                     torch.cuda.current_stream().wait_event(ev['grg'])
                 if lin:
                     # dL/drgain[b][g] = <dL/dx[b], tau_g>: partial rows over the time samples
-                    ggp = ops.lin_gain_dots(gsig, tau, nb, Btot, G, K, pairs, tau_pairs, gxb=gsig_b)
+                    if spec:          # (the EDR part of the rows was left by the EDR kernel; the EDC part joins it)
+                        # behind the gamma pass: both stream the same 59 MB, and the gamma pass heads the critical chain
+                        # (side by side: 40 us for it instead of 15)
+                        torch.cuda.current_stream().wait_event(ev_gam)
+                        ggp = parts if self.gamma_dots_one_launch else \
+                            ops.lin_gain_dots(gsig, tau, nb, Btot, G, K, True, True, out=parts)
+                    else:
+                        ggp = ops.lin_gain_dots(gsig, tau, nb, Btot, G, K, pairs, tau_pairs, gxb=gsig_b)
                     grg = None
                     if not (self.gain_rows_in_mlp
                             and ops.mlp_bwd_takes_parts(bank._freq_pi.numel(), Hh, n_hidden, G, Btot // nb)):

@@ -1,0 +1,545 @@
+// The EDR loss on LINEARLY COMPOSED short-time spectra, for gfx950.
+//
+// Reference maths (orchidas/DiffGFDN, src/diff_gfdn/losses.py:430-495, :501-575): the EDR loss takes the STFT (Hann 4096,
+// hop 2048) of x[b] = irfft(H[b], n = K), its power |S|^2, Schroeder-integrates it over the frames, compares in dB.
+// With the output stage in the time domain (linear.hip), x[b] = xd[row_b] + sum_g gain[b][g] tau_g, and the STFT is linear:
+//        S[b] = STFT(xd[row_b]) + sum_g gain[b][g] STFT(tau_g) = Sd[row_b] + sum_g gain[b][g] Stau_g .
+// Sd is a constant of the dataset (one STFT per receiver, once, like the decay targets) and Stau are G short STFTs per
+// band and step.  The 224 forward STFTs and the 224 adjoint STFTs of a step (two 4096-point FFTs per frame pair each way)
+// do not run; what runs per receiver is streaming arithmetic on (frame, frequency) cells:
+//   k_edr_lin_cols : per (receiver, frequency): compose S over the frames, |S|^2, tail sums, dB, |difference| -> loss
+//                    partials, dL/d|S|^2 (gP, real) and -- in the same descending sweep -- the EDR part of
+//                    dL/dgain[b][g] = Re sum_cells conj(Stau_g) dL/dS,  dL/dS = 2 gP S   (tail sums of Re(conj(Stau_g) S))
+//   k_edr_lin_gsum : per (band, cell): Gsum_g = sum_b gain[b][g] dL/dS[b] -- the G gradient spectra per band whose adjoint
+//                    STFT (k_stft4k_pair_spec_bwd, 14 signal pairs) is the EDR part of dL/dtau_g
+//   k_stft4k_pair_spec(_bwd) : STFT of pair-interleaved signals to complex one-sided spectra, and its adjoint from
+//                    gradient spectra (the forms of fft.hip's k_stft4k_pair_power(_bwd) without the |.|^2 stage).
+// All sums in fixed order (bitwise reproducible).
+#include "common.h"
+#include "fft4k_dev.h"
+
+extern __shared__ float2 edl_lds[];
+
+#define EDL_RF 32
+#define EDL_MAXG 4
+
+struct EdrLin {
+  const float2* Sd;            // (R, nframes, nfreq) complex: STFT of the transformed direct paths
+  const long long* rows;       // item -> row of Sd, Tdb, sum_abs (NULL: identity)
+  const float2* Stau;          // (nbands * G, nframes, nfreq) complex: STFT of the band's group signals
+  const float* rgain;          // (items, G)
+  int B, G;
+  const float* Tdb;            // (R, nframes, nfreq) target EDR in dB
+  const float* sum_abs;        // (R) sum |target EDR|
+};
+
+// One thread per (receiver, frequency) column, one descending sweep over the frames (see the body).
+// (Measured alternatives, same box: the group spectra of a 64-frequency tile staged in LDS for 8 receivers per workgroup --
+// 64 KB, two workgroups per CU -- 175 us against 99; the whole band per workgroup with the receivers' gradient spectra summed
+// through an LDS exchange, k_edr_lin_fused below -- 128 KB, one workgroup per CU -- 213 us and it starves the colorless pass
+// beside it of LDS: both keep far fewer loads in flight than 2016 independent workgroups do.)
+//   part[b][fblk] = sum_{f in block, m} |T - EDR| (to be divided by sum_abs, as gfdn_edr_loss(defer))
+//   gP (items, nframes, nfreq) = gscale / sum_abs dloss/d|S|^2
+//   dots[(b G + g) ld_dots + col0 + fblk] = partial of the EDR part of dL/dgain[b][g]
+#define EDL_FT 64
+__global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int nfreq, float gscale, int want_grad,
+                                                      float* __restrict__ gP, float* __restrict__ part,
+                                                      float* __restrict__ dots, int ld_dots, int col0, int nslices) {
+  __shared__ float s_red[16];
+  // XCD-aware map: workgroups are dealt round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2.  The B
+  // receivers that share a (band, 256-frequency block) slice of the group spectra (G x nframes x 256 complex = 262 KB) are
+  // given ids of ONE residue class mod 8, slice after slice -- with the plain (block, receiver) grid every XCD touched every
+  // slice (14.7 MB of group spectra against a 4 MB L2: 0.9 GB of refetches per launch, 309 us, and the EDC scans beside
+  // it slowed fourfold).
+  const int G = a.G, B = a.B, fblk = (nfreq + 255) / 256;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (j / B), bl = j - (j / B) * B;
+  if (slice >= nslices) return;
+  const int band = slice / fblk, fb = slice - band * fblk;
+  const int b = band * B + bl;
+  const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
+  const size_t cells = (size_t)nframes * nfreq;
+  float rg[EDL_MAXG];
+#pragma unroll
+  for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
+  const float gs = want_grad ? gscale / a.sum_abs[row] : 0.f;
+  float acc = 0.f, dacc[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
+  const int f = fb * 256 + threadIdx.x;
+  if (f < nfreq) {
+    const float2* sd = a.Sd + row * cells + f;
+    const float2* st = a.Stau + (size_t)band * G * cells + f;
+    const float* t = a.Tdb + row * cells + f;
+    // ONE descending sweep over the frames: the frame's spectra (direct path, G group spectra) and target are loaded where
+    // they are used -- the compiler keeps the loads of the next frames in flight across the dB chain of the current one --
+    // S composed in registers, tail energy, dB, |difference|, dL/dE_m; and with the same loads the EDR part of
+    //   dL/dgain[b][g] = 2 sum_m gP_m Re(conj(Stau_g[m]) S[m]),  gP_m = sum_{m' <= m} dL/dE_m'
+    //                  = 2 sum_m' dL/dE_m' sum_{m >= m'} Re(conj(Stau_g[m]) S[m])        (tail sums, like the energy)
+    // (Measured: with the 64 HBM loads issued up front and the group spectra read in two separate passes the launch took
+    // 282-310 us instead of 99 and slowed the EDC scans beside it fourfold: twice the cache traffic in 16 KB strides.)
+    float gE[EDL_RF];
+    float E = 0.f, ct[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = EDL_RF - 1; m >= 0; --m) {
+      gE[m] = 0.f;
+      if (m < nframes) {
+        float2 sv = sd[(size_t)m * nfreq];
+        float2 tg[EDL_MAXG];
+#pragma unroll
+        for (int g = 0; g < EDL_MAXG; ++g) {
+          tg[g] = g < G ? st[(size_t)g * cells + (size_t)m * nfreq] : make_float2(0.f, 0.f);
+          sv.x += rg[g] * tg[g].x;
+          sv.y += rg[g] * tg[g].y;
+        }
+        const float tvm = t[(size_t)m * nfreq];
+        E += sv.x * sv.x + sv.y * sv.y;
+        const float lin = fabsf(E) + F32_EPS;
+        const float raw = 10.0f * log10f(lin);
+        const float d = fmaxf(raw, -200.0f);
+        const float diff = tvm - d;
+        acc += fabsf(diff);
+        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+        const float ge = -sg * dE * gs;
+        gE[m] = ge;
+#pragma unroll
+        for (int g = 0; g < EDL_MAXG; ++g) {
+          ct[g] += tg[g].x * sv.x + tg[g].y * sv.y;
+          dacc[g] += ge * ct[g];
+        }
+      }
+    }
+    if (want_grad) {
+      float* gp = gP + (size_t)b * cells + f;
+      float run = 0.f;
+#pragma unroll
+      for (int m = 0; m < EDL_RF; ++m) {
+        if (m < nframes) {
+          run += gE[m];                                          // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m'
+          gp[(size_t)m * nfreq] = run;
+        }
+      }
+    }
+  }
+  acc = block_sum(acc, s_red);
+  if (threadIdx.x == 0) part[(size_t)b * fblk + fb] = acc;
+  if (want_grad && dots) {
+#pragma unroll
+    for (int g = 0; g < EDL_MAXG; ++g) {
+      if (g < G) {
+        const float v = block_sum(2.0f * dacc[g], s_red);
+        if (threadIdx.x == 0) dots[((size_t)b * G + g) * ld_dots + col0 + fb] = v;
+      }
+    }
+  }
+}
+
+// The same columns with the gradient spectra summed over the band's receivers IN the launch: one workgroup = one band x
+// EDL_FT frequencies x ALL receivers of the band, four at a time (one per wave).  Behind its column a wave leaves
+// dL/dS = 2 gP S (nframes complex per lane) in an LDS exchange block; after a barrier the 256 threads re-partition --
+// thread (lane, wave w) owns the frames 8 w .. 8 w + 7 of its frequency -- and add the four receivers' terms
+// gain[b][g] dL/dS[b] into 4 x 8 complex register accumulators, in receiver order (fixed: bitwise reproducible).  dL/d|S|^2
+// is never written and the transformed direct paths are read once: 235 MB less traffic per step than the two launches
+// (k_edr_lin_cols + k_edr_lin_gsum), which stay as the cross-check and for the value-only pass.
+__global__ __launch_bounds__(256, 1) void k_edr_lin_fused(EdrLin a, int nframes, int nfreq, float gscale,
+                                                          float* __restrict__ part, float* __restrict__ dots, int ld_dots,
+                                                          int col0, float2* __restrict__ Gsum) {
+  const int G = a.G, B = a.B, tile = blockIdx.x, ntiles = gridDim.x, band = blockIdx.y;
+  float2* lt = edl_lds;                                   // [g][m][EDL_FT]: the band's group spectra of the tile
+  float2* ex = lt + (size_t)G * nframes * EDL_FT;         // [wave][m][EDL_FT]: dL/dS of the four receivers of a round
+  const size_t cells = (size_t)nframes * nfreq;
+  const int f0 = tile * EDL_FT;
+  for (int idx = threadIdx.x; idx < G * nframes * EDL_FT; idx += 256) {
+    const int ff = idx & (EDL_FT - 1), gm = idx / EDL_FT;
+    lt[idx] = f0 + ff < nfreq ? a.Stau[(size_t)band * G * cells + (size_t)gm * nfreq + f0 + ff] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int f = f0 + lane;
+  const bool live = f < nfreq;
+  const int fc = live ? f : nfreq - 1;
+  float2 Ga[EDL_MAXG][8];
+#pragma unroll
+  for (int g = 0; g < EDL_MAXG; ++g)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) Ga[g][q] = make_float2(0.f, 0.f);
+  const int nrounds = (B + 3) / 4;
+  for (int rd = 0; rd < nrounds; ++rd) {
+    const int bl = rd * 4 + wave;
+    float2* exw = ex + (size_t)wave * nframes * EDL_FT + lane;
+    if (bl < B) {
+      const int b = band * B + bl;
+      const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
+      float rg[EDL_MAXG];
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
+      const float gs = gscale / a.sum_abs[row];
+      const float2* sd = a.Sd + row * cells + fc;
+      const float* t = a.Tdb + row * cells + fc;
+      float2 s[EDL_RF];
+      float tv[EDL_RF];
+#pragma unroll
+      for (int m = 0; m < EDL_RF; ++m) {
+        s[m] = m < nframes ? sd[(size_t)m * nfreq] : make_float2(0.f, 0.f);
+        tv[m] = m < nframes ? t[(size_t)m * nfreq] : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) {
+        if (g < G) {
+#pragma unroll
+          for (int m = 0; m < EDL_RF; ++m) {
+            if (m < nframes) {
+              const float2 tg = lt[(g * nframes + m) * EDL_FT + lane];
+              s[m].x += rg[g] * tg.x;
+              s[m].y += rg[g] * tg.y;
+            }
+          }
+        }
+      }
+      float acc = 0.f, E = 0.f;
+#pragma unroll
+      for (int m = EDL_RF - 1; m >= 0; --m) {
+        if (m < nframes) {
+          E += s[m].x * s[m].x + s[m].y * s[m].y;
+          const float lin = fabsf(E) + F32_EPS;
+          const float raw = 10.0f * log10f(lin);
+          const float d = fmaxf(raw, -200.0f);
+          const float diff = tv[m] - d;
+          acc += fabsf(diff);
+          const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+          const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+          tv[m] = -sg * dE * gs;
+        }
+      }
+      acc = wave_sum_full(live ? acc : 0.f);
+      if (lane == 0) part[(size_t)b * ntiles + tile] = acc;
+      float run = 0.f;
+#pragma unroll
+      for (int m = 0; m < EDL_RF; ++m) {
+        if (m < nframes) {
+          run += tv[m];
+          tv[m] = run;
+          const float p2 = live ? 2.0f * run : 0.f;
+          exw[(size_t)m * EDL_FT] = make_float2(p2 * s[m].x, p2 * s[m].y);      // dL/dS[b][m][f]
+        }
+      }
+      if (dots) {
+#pragma unroll
+        for (int g = 0; g < EDL_MAXG; ++g) {
+          if (g < G) {
+            float da = 0.f;
+#pragma unroll
+            for (int m = 0; m < EDL_RF; ++m) {
+              if (m < nframes) {
+                const float2 tg = lt[(g * nframes + m) * EDL_FT + lane];
+                da += tv[m] * (tg.x * s[m].x + tg.y * s[m].y);
+              }
+            }
+            da = wave_sum_full(live ? 2.0f * da : 0.f);
+            if (lane == 0) dots[((size_t)b * G + g) * ld_dots + col0 + tile] = da;
+          }
+        }
+      }
+    } else {
+      for (int m = 0; m < nframes; ++m) exw[(size_t)m * EDL_FT] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    // frames 8 wave .. 8 wave + 7 of this lane's frequency: the round's receivers in order
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int b2 = rd * 4 + w2;
+      if (b2 < B) {
+        float r2[EDL_MAXG];
+#pragma unroll
+        for (int g = 0; g < EDL_MAXG; ++g) r2[g] = g < G ? a.rgain[((size_t)band * B + b2) * G + g] : 0.f;
+        const float2* e2 = ex + (size_t)w2 * nframes * EDL_FT + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int m = 8 * wave + q;
+          if (m < nframes) {
+            const float2 d = e2[(size_t)m * EDL_FT];
+#pragma unroll
+            for (int g = 0; g < EDL_MAXG; ++g) {
+              Ga[g][q].x += r2[g] * d.x;
+              Ga[g][q].y += r2[g] * d.y;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+#pragma unroll
+    for (int g = 0; g < EDL_MAXG; ++g) {
+      if (g < G) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int m = 8 * wave + q;
+          if (m < nframes) Gsum[((size_t)band * G + g) * cells + (size_t)m * nfreq + f] = Ga[g][q];
+        }
+      }
+    }
+  }
+}
+
+// Gsum[band G + g][cell] = sum_{b in band} gain[b][g] 2 gP[b][cell] S[b][cell],  S[b] = Sd[row_b] + sum_g' gain[b][g'] Stau_g'
+//                        = sum_b gain[b][g] 2 gP[b] Sd[row_b]  +  sum_g' (sum_b gain[b][g] gain[b][g'] 2 gP[b]) Stau_g'
+// -- one thread per (band, cell), the band's receivers in index order
+__global__ __launch_bounds__(256) void k_edr_lin_gsum(EdrLin a, const float* __restrict__ gP, int nframes, int nfreq,
+                                                      float2* __restrict__ Gsum) {
+  __shared__ float s_rg[256];
+  __shared__ long long s_row[64];
+  const int band = blockIdx.y, G = a.G, B = a.B;
+  for (int i = threadIdx.x; i < B * G; i += 256) s_rg[i] = a.rgain[(size_t)band * B * G + i];
+  for (int i = threadIdx.x; i < B; i += 256) s_row[i] = a.rows ? a.rows[band * B + i] : (long long)(band * B + i);
+  __syncthreads();
+  const size_t cells = (size_t)nframes * nfreq;
+  const size_t cell = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (cell >= cells) return;
+  float2 A[EDL_MAXG];
+  float W[EDL_MAXG][EDL_MAXG];
+#pragma unroll
+  for (int g = 0; g < EDL_MAXG; ++g) {
+    A[g] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < EDL_MAXG; ++h) W[g][h] = 0.f;
+  }
+  const int i0 = band * B;
+#pragma unroll 8
+  for (int b = 0; b < B; ++b) {
+    const float2 sd = a.Sd[(size_t)s_row[b] * cells + cell];
+    const float p2 = 2.0f * gP[(size_t)(i0 + b) * cells + cell];
+#pragma unroll
+    for (int g = 0; g < EDL_MAXG; ++g) {
+      if (g < G) {
+        const float r = s_rg[b * G + g] * p2;
+        A[g].x += r * sd.x;
+        A[g].y += r * sd.y;
+#pragma unroll
+        for (int h = g; h < EDL_MAXG; ++h)
+          if (h < G) W[g][h] += r * s_rg[b * G + h];
+      }
+    }
+  }
+  float2 st[EDL_MAXG];
+#pragma unroll
+  for (int g = 0; g < EDL_MAXG; ++g)
+    st[g] = g < G ? a.Stau[((size_t)band * G + g) * cells + cell] : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int g = 0; g < EDL_MAXG; ++g) {
+    if (g < G) {
+      float2 o = A[g];
+#pragma unroll
+      for (int h = 0; h < EDL_MAXG; ++h) {
+        if (h < G) {
+          const float w = h >= g ? W[g][h] : W[h][g];
+          o.x += w * st[h].x;
+          o.y += w * st[h].y;
+        }
+      }
+      Gsum[((size_t)band * G + g) * cells + cell] = o;
+    }
+  }
+}
+
+// ---- STFT (Hann 4096, hop 2048, periodic window) of pair-interleaved signals to complex one-sided spectra --------------
+__device__ __forceinline__ void edl_load_pair(const float2* __restrict__ x2, int T, int m, int i, float2 (&a)[16],
+                                              float2& w1) {
+  float sn, cs;
+  sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
+  w1 = make_float2(cs, -sn);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float sk, ck;
+    sincospif((float)k * 0.125f, &sk, &ck);
+    const float h = 0.5f - 0.5f * (cs * ck - sn * sk);
+    const int t = m * 2048 + i + 256 * k;
+    const float2 v = t < T ? x2[t] : make_float2(0.f, 0.f);
+    a[k] = make_float2(h * v.x, h * v.y);
+  }
+}
+
+// S (items, nframes, 2049) complex: S[2p] from the .x signal of pair p, S[2p + 1] from its .y signal
+__global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec(const float2* __restrict__ x2, int ld, int T, int nframes,
+                                                            int items, float2* __restrict__ S) {
+  float2* buf = edl_lds;
+  const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
+  const int b1 = 2 * p;
+  const bool two = b1 + 1 < items;
+  float2 a[16], w1;
+  edl_load_pair(x2 + (size_t)p * ld, T, m, i, a, w1);
+  fft4096(a, buf, i, w1, 1.0f);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
+  __syncthreads();
+  float2* S1 = S + ((size_t)b1 * nframes + m) * nf;
+  float2* S2 = S1 + (size_t)nframes * nf;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const float2 zf = a[u], zc = buf[S4K_PAD((4096 - f) & 4095)];
+      // S_a = (Z_f + conj Z_{W-f}) / 2 ; S_b = (Z_f - conj Z_{W-f}) / (2i)
+      S1[f] = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      if (two) S2[f] = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+    }
+  }
+}
+
+// (cos, sin)(u pi / 8), u = 0..15: the Hann window of the adjoint's epilogue by angle addition
+__constant__ float2 c_edl_hann[16] = {
+    {1.0f, 0.0f}, {0.92387953251128674f, 0.38268343236508977f}, {0.70710678118654752f, 0.70710678118654752f},
+    {0.38268343236508977f, 0.92387953251128674f}, {0.0f, 1.0f}, {-0.38268343236508977f, 0.92387953251128674f},
+    {-0.70710678118654752f, 0.70710678118654752f}, {-0.92387953251128674f, 0.38268343236508977f}, {-1.0f, 0.0f},
+    {-0.92387953251128674f, -0.38268343236508977f}, {-0.70710678118654752f, -0.70710678118654752f},
+    {-0.38268343236508977f, -0.92387953251128674f}, {0.0f, -1.0f}, {0.38268343236508977f, -0.92387953251128674f},
+    {0.70710678118654752f, -0.70710678118654752f}, {0.92387953251128674f, -0.38268343236508977f}};
+
+// Adjoint: gx2 (pairs, ld) = [base2 +] STFT^T(Gs), Gs (items, nframes, 2049) the gradient w.r.t. the one-sided spectra.
+// Frames of one parity tile the time axis without overlap: the even launch STORES base + contribution (base alone where no
+// even frame reaches), the odd launch adds with a plain read-modify-write -- no atomics, no cleared buffer.
+__global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2* __restrict__ Gs, int ld, int T,
+                                                                int nframes, int items, const float2* base2,
+                                                                float2* gx2, int parity) {
+  float2* buf = edl_lds;
+  const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
+  const int b1 = 2 * p;
+  const bool two = b1 + 1 < items;
+  const float2* ga = Gs + ((size_t)b1 * nframes + m) * nf;
+  const float2* gb = ga + (size_t)nframes * nf;
+  float sn, cs;
+  sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
+  const float2 w1 = make_float2(cs, -sn);
+  // U = Ga_sym + i Gb_sym: the pair (f, W - f) is written by exactly one thread
+#pragma unroll 3
+  for (int u = 0; u < 9; ++u) {
+    const int f = i + 256 * u;
+    if (u < 8 || i == 0) {
+      const int fc = (4096 - f) & 4095;
+      const float2 Ga = ga[f], Gb = two ? gb[f] : make_float2(0.f, 0.f);
+      if (f == 0 || f == 2048) {
+        buf[S4K_PAD(f)] = make_float2(Ga.x, Gb.x);                                       // real-only bins
+      } else {
+        buf[S4K_PAD(f)] = make_float2(0.5f * (Ga.x - Gb.y), 0.5f * (Ga.y + Gb.x));       // U_f
+        buf[S4K_PAD(fc)] = make_float2(0.5f * (Ga.x + Gb.y), 0.5f * (-Ga.y + Gb.x));     // U_{W-f}
+      }
+    }
+  }
+  __syncthreads();
+  float2 a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = buf[S4K_PAD(i + 256 * k)];
+  __syncthreads();
+  fft4096(a, buf, i, w1, -1.0f);
+  float2* g = gx2 + (size_t)p * ld;
+  const float2* bs = base2 ? base2 + (size_t)p * ld : nullptr;
+  const float2* src = parity ? g : bs;
+  const int tlim = parity ? T : ld;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int j = i + 256 * u, t = m * 2048 + j;
+    if (t < tlim) {
+      const float2 o = src ? src[t] : make_float2(0.f, 0.f);
+      const float hw = t < T ? 0.5f - 0.5f * (w1.x * c_edl_hann[u].x + w1.y * c_edl_hann[u].y) : 0.f;
+      g[t] = make_float2(o.x + hw * a[u].x, o.y + (two ? hw * a[u].y : 0.f));
+    }
+  }
+  if (!parity && m + 2 >= nframes)
+    for (int t = (m + 2) * 2048 + i; t < ld; t += S4K_T) g[t] = src ? src[t] : make_float2(0.f, 0.f);
+}
+
+static int edl_nframes(int T) {
+  const int Tp = ((T + 2047) / 2048) * 2048;
+  return Tp < 4096 ? 0 : (Tp - 4096) / 2048 + 1;
+}
+
+extern "C" int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, void* stream) {
+  if (!x2 || !S_c64 || items <= 0 || T <= 0 || ld < T) return GFDN_E_BADARG;
+  if (win != 4096) return GFDN_E_UNSUPPORTED;
+  const int nframes = edl_nframes(T);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_stft4k_pair_spec, dim3(nframes, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                     (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, (float2*)S_c64);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2,
+                                            int ld, void* stream) {
+  if (!G_c64 || !gx2 || items <= 0 || T <= 0 || ld < T || base2 == gx2) return GFDN_E_BADARG;
+  if (win != 4096) return GFDN_E_UNSUPPORTED;
+  const int nframes = edl_nframes(T);
+  if (nframes <= 0) return GFDN_E_BADARG;
+  for (int parity = 0; parity < 2; ++parity) {
+    const int nb = (nframes + 1 - parity) / 2;
+    if (nb == 0) continue;
+    hipLaunchKernelGGL(k_stft4k_pair_spec_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                       (hipStream_t)stream, (const float2*)G_c64, ld, T, nframes, items, (const float2*)base2,
+                       (float2*)gx2, parity);
+    GFDN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// partial-sum columns per item: frequency blocks of 256 (gfdn_edr_lin_loss) or tiles of 64 (gfdn_edr_lin_loss_gsum)
+extern "C" int gfdn_edr_lin_parts(int nfreq) { return nfreq > 0 ? (nfreq + 255) / 256 : 0; }
+extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return nfreq > 0 ? (nfreq + EDL_FT - 1) / EDL_FT : 0; }
+
+// EDR loss of nbands x B receivers on composed spectra (see the head of this file).  part (items, gfdn_edr_lin_parts):
+// loss partials as gfdn_edr_loss(loss_item = NULL) leaves them; want_grad: gP (items, nframes, nfreq) and the EDR part of
+// dL/dgain as partial rows dots[(b G + g) ld_dots + col0 .. + gfdn_edr_lin_parts) (dots may be NULL).
+extern "C" int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
+                                 int nbands, int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq,
+                                 float gscale, int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0,
+                                 void* stream) {
+  if (!Sd_c64 || !Stau_c64 || !rgain || !T_db || !sum_abs || !part || nbands <= 0 || B <= 0 || G <= 0 || nframes <= 0 ||
+      nfreq <= 0 || (want_grad && !gP))
+    return GFDN_E_BADARG;
+  const int fblk = (nfreq + 255) / 256;
+  if (G > EDL_MAXG || nframes > EDL_RF || nbands * B > 65535) return GFDN_E_UNSUPPORTED;
+  if (dots && (col0 < 0 || ld_dots < col0 + fblk)) return GFDN_E_BADARG;
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs};
+  const int nslices = nbands * fblk;
+  hipLaunchKernelGGL(k_edr_lin_cols, dim3(8 * ((nslices + 7) / 8) * B), dim3(256), 0, (hipStream_t)stream, a, nframes, nfreq,
+                     gscale, want_grad, gP, part, dots, ld_dots, col0, nslices);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// gfdn_edr_lin_loss(want_grad) and gfdn_edr_lin_gsum as ONE launch (k_edr_lin_fused): part and dots as there, Gsum
+// (nbands G, nframes, nfreq) complex; dL/d|S|^2 is never written.
+extern "C" int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
+                                      int nbands, int B, int G, const float* T_db, const float* sum_abs, int nframes,
+                                      int nfreq, float gscale, float* part, float* dots, int ld_dots, int col0,
+                                      float* Gsum_c64, void* stream) {
+  if (!Sd_c64 || !Stau_c64 || !rgain || !T_db || !sum_abs || !part || !Gsum_c64 || nbands <= 0 || B <= 0 || G <= 0 ||
+      nframes <= 0 || nfreq <= 0)
+    return GFDN_E_BADARG;
+  const int ntiles = (nfreq + EDL_FT - 1) / EDL_FT;
+  if (G > EDL_MAXG || nframes > EDL_RF || nbands > 65535) return GFDN_E_UNSUPPORTED;
+  if (dots && (col0 < 0 || ld_dots < col0 + ntiles)) return GFDN_E_BADARG;
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs};
+  const size_t lds = (size_t)(G + 4) * nframes * EDL_FT * sizeof(float2);
+  int rc = ensure_dyn_lds(k_edr_lin_fused, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_edr_lin_fused, dim3(ntiles, nbands), dim3(256), lds, (hipStream_t)stream, a, nframes, nfreq, gscale,
+                     part, dots, ld_dots, col0, (float2*)Gsum_c64);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Gsum (nbands G, nframes, nfreq) complex = sum over the band's receivers of gain[b][g] dL/dS[b] (dL/dS = 2 gP S)
+extern "C" int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
+                                 int nbands, int B, int G, const float* gP, int nframes, int nfreq, float* Gsum_c64,
+                                 void* stream) {
+  if (!Sd_c64 || !Stau_c64 || !rgain || !gP || !Gsum_c64 || nbands <= 0 || B <= 0 || G <= 0 || nframes <= 0 || nfreq <= 0)
+    return GFDN_E_BADARG;
+  if (G > EDL_MAXG || B * G > 256 || B > 64 || nbands > 65535) return GFDN_E_UNSUPPORTED;
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, nullptr, nullptr};
+  const size_t cells = (size_t)nframes * nfreq;
+  hipLaunchKernelGGL(k_edr_lin_gsum, dim3((unsigned)((cells + 255) / 256), nbands), dim3(256), 0, (hipStream_t)stream, a, gP,
+                     nframes, nfreq, (float2*)Gsum_c64);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}

@@ -120,7 +120,8 @@ template <bool IN_PAIRS, bool OUT_PAIRS>
 __global__ __launch_bounds__(256) void k_lin_gamma(const float* __restrict__ gx, const float* __restrict__ gxb, int ld_g,
                                                    const float* __restrict__ rgain, int B, int G, int n,
                                                    float* __restrict__ gamma, int ld_o,
-                                                   const int* __restrict__ slot_of_time) {
+                                                   const int* __restrict__ slot_of_time,
+                                                   const float* __restrict__ base, int ld_b) {
   __shared__ float s_rg[256];                     // the band's gains (B G <= 256)
   const int band = blockIdx.y;
   for (int i = threadIdx.x; i < B * G; i += 256) s_rg[i] = rgain[(size_t)band * B * G + i];
@@ -184,6 +185,19 @@ __global__ __launch_bounds__(256) void k_lin_gamma(const float* __restrict__ gx,
       }
     }
   }
+  if (OUT_PAIRS && base) {
+    // another part of the same gradient signals, already summed per group (pair-interleaved, time order): the EDR part,
+    // which the adjoint STFT of the G gradient spectra per band left (edrlin.hip)
+#pragma unroll
+    for (int g = 0; g < LIN_MAXG; ++g) {
+      if (g < G) {
+        const int s = band * G + g;
+#pragma unroll
+        for (int u = 0; u < LIN_V; ++u)
+          if (t0 + u < n) acc[g][u] += base[((size_t)(s >> 1) * ld_b + t0 + u) * 2 + (s & 1)];
+      }
+    }
+  }
   if (OUT_PAIRS && slot_of_time) {
     // the adjoint pair transform's own order (gfdn_irfft_odd_pairs_bwd_tslots): sample 0 first, then the sample of time t
     // at 1 + slot_of_time[t] -- the scatter happens here, on G signals per band, instead of a gather in the transform
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(256) void k_lin_gamma(const float* __restrict__ gx,
 template <bool IN_PAIRS, bool TAU_PAIRS>
 __global__ __launch_bounds__(256) void k_lin_gain_dots(const float* __restrict__ gx, const float* __restrict__ gxb,
                                                        int ld_g, const float* __restrict__ tau, int ld_tau, int B, int G,
-                                                       int n, float* __restrict__ part, int ngrp) {
+                                                       int n, float* __restrict__ part, int ngrp, int ld_part) {
   __shared__ float s_red[4][LIN_R * LIN_MAXG];
   const int band = blockIdx.y / ngrp, b0 = (blockIdx.y - band * ngrp) * LIN_R;
   const int nr = B - b0 < LIN_R ? B - b0 : LIN_R;
@@ -334,9 +348,148 @@ __global__ __launch_bounds__(256) void k_lin_gain_dots(const float* __restrict__
     const int r = threadIdx.x / LIN_MAXG, g = threadIdx.x % LIN_MAXG;
     if (r < nr && g < G) {
       const float v = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
-      part[((size_t)(band * B + b0 + r) * G + g) * gridDim.x + blockIdx.x] = v;
+      part[((size_t)(band * B + b0 + r) * G + g) * ld_part + blockIdx.x] = v;
     }
   }
+}
+
+// gfdn_lin_gamma and gfdn_lin_gain_dots as ONE sweep over the pair-interleaved gradient signals of the EDC term, which are
+// nonzero on the EDC window [w0, w0 + wlen) only (samples outside it are neither read nor required to hold zeros):
+//   gamma[band G + g][t] = base[band G + g][t] + sum_{b in band} rgain[b][g] gx[b][t]     (transform order: slot_of_time)
+//   part[((band B + b) G + g) ld_part + tile] = sum_{t in tile} gx[b][t] tau[band G + g][t]
+// one workgroup = one band x 1024 samples; the 8 dot products of a receiver pair are folded over the workgroup by VALU wave
+// sums and one LDS hand-over at the end (fixed order).  wlen_band (optional, device): per-band window lengths.
+__global__ __launch_bounds__(256) void k_lin_gamma_dots(const float2* __restrict__ g2, int ld_g,
+                                                        const float* __restrict__ rgain, int B, int G, int n,
+                                                        const float2* __restrict__ tau2, int ld_tau,
+                                                        const float* __restrict__ base, int ld_b,
+                                                        const int* __restrict__ slot_of_time, float* __restrict__ gamma,
+                                                        int ld_o, float* __restrict__ part, int ld_part, int w0, int wlen,
+                                                        const int* __restrict__ wlen_band) {
+  __shared__ float s_rg[256];
+  __shared__ float s_dot[4][256];                 // [wave][pair * 8 + item * 4 + g]  (B / 2 <= 32 pairs)
+  const int band = blockIdx.y, tile = blockIdx.x;
+  for (int i = threadIdx.x; i < B * G; i += 256) s_rg[i] = rgain[(size_t)band * B * G + i];
+  __syncthreads();
+  if (wlen_band) wlen = wlen_band[band];
+  const int t0 = (tile * 256 + threadIdx.x) * LIN_V;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile_lo = tile * 256 * LIN_V, tile_hi = tile_lo + 256 * LIN_V;
+  const bool tile_in = tile_hi > w0 && tile_lo < w0 + wlen;          // (workgroup-uniform)
+  float acc[LIN_MAXG][LIN_V];
+#pragma unroll
+  for (int g = 0; g < LIN_MAXG; ++g)
+#pragma unroll
+    for (int u = 0; u < LIN_V; ++u) acc[g][u] = 0.f;
+  const int npairs = B / 2;
+  if (tile_in) {
+    bool in[LIN_V];
+#pragma unroll
+    for (int u = 0; u < LIN_V; ++u) in[u] = t0 + u >= w0 && t0 + u < w0 + wlen && t0 + u < n;
+    const bool full = in[0] && in[LIN_V - 1];
+    float tv[LIN_MAXG][LIN_V];
+#pragma unroll
+    for (int g = 0; g < LIN_MAXG; ++g)
+#pragma unroll
+      for (int u = 0; u < LIN_V; ++u) {
+        const int s = band * G + g;
+        tv[g][u] = (g < G && in[u]) ? ((const float*)tau2)[((size_t)(s >> 1) * ld_tau + t0 + u) * 2 + (s & 1)] : 0.f;
+      }
+    const float2* gb = g2 + (size_t)(band * B / 2) * ld_g;
+    for (int pp = 0; pp < npairs; ++pp) {
+      float2 q[4];
+      if (full) {
+        ld4_f2(gb + (size_t)pp * ld_g + t0, q);
+      } else {
+#pragma unroll
+        for (int u = 0; u < LIN_V; ++u) q[u] = in[u] ? gb[(size_t)pp * ld_g + t0 + u] : make_float2(0.f, 0.f);
+      }
+      float d1[LIN_MAXG], d2[LIN_MAXG];
+#pragma unroll
+      for (int g = 0; g < LIN_MAXG; ++g) {
+        const float ra = g < G ? s_rg[(2 * pp) * G + g] : 0.f, rb = g < G ? s_rg[(2 * pp + 1) * G + g] : 0.f;
+        d1[g] = d2[g] = 0.f;
+#pragma unroll
+        for (int u = 0; u < LIN_V; ++u) {
+          acc[g][u] += ra * q[u].x;
+          acc[g][u] += rb * q[u].y;
+          d1[g] += q[u].x * tv[g][u];
+          d2[g] += q[u].y * tv[g][u];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < LIN_MAXG; ++g) {
+        const float a1 = wave_sum_full(d1[g]), a2 = wave_sum_full(d2[g]);
+        if (lane == 0) {
+          s_dot[wave][pp * 8 + g] = a1;
+          s_dot[wave][pp * 8 + 4 + g] = a2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < npairs * 8) {
+    const int pp = threadIdx.x >> 3, it = (threadIdx.x >> 2) & 1, g = threadIdx.x & 3;
+    if (g < G) {
+      const float v = tile_in ? (s_dot[0][threadIdx.x] + s_dot[1][threadIdx.x]) + (s_dot[2][threadIdx.x] + s_dot[3][threadIdx.x])
+                              : 0.f;
+      part[((size_t)(band * B + 2 * pp + it) * G + g) * ld_part + tile] = v;
+    }
+  }
+  if (t0 >= n) return;
+  if (base) {
+#pragma unroll
+    for (int g = 0; g < LIN_MAXG; ++g) {
+      if (g < G) {
+        const int s = band * G + g;
+#pragma unroll
+        for (int u = 0; u < LIN_V; ++u)
+          if (t0 + u < n) acc[g][u] += base[((size_t)(s >> 1) * ld_b + t0 + u) * 2 + (s & 1)];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < LIN_V; ++u) {
+    const int t = t0 + u;
+    if (t < n) {
+      const size_t pos = slot_of_time ? (t == 0 ? 0 : 1 + (size_t)slot_of_time[t]) : (size_t)t;
+      if (!((band * G) & 1) && !(G & 1)) {
+#pragma unroll
+        for (int g = 0; g < LIN_MAXG; g += 2)
+          if (g < G)
+            ((float2*)gamma)[(size_t)((band * G + g) >> 1) * ld_o + pos] = make_float2(acc[g][u], acc[g + 1][u]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < LIN_MAXG; ++g) {
+          if (g < G) {
+            const int s = band * G + g;
+            gamma[((size_t)(s >> 1) * ld_o + pos) * 2 + (s & 1)] = acc[g][u];
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int gfdn_lin_gamma_dots_tiles(int n) { return n > 0 ? (n + 256 * LIN_V - 1) / (256 * LIN_V) : 0; }
+
+// all signals pair-interleaved: gx2 (nbands B / 2, ld_g), tau2 / base2 / gamma (ceil(nbands G / 2), .); B even, B <= 64;
+// part rows of pitch ld_part >= gfdn_lin_gamma_dots_tiles(n).
+extern "C" int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nbands, int B, int G, int n,
+                                   const float* tau2, int ld_tau, const float* base2, int ld_b, const int* slot_of_time,
+                                   float* gamma, int ld_o, float* part, int ld_part, int win_start, int win_len,
+                                   const int* band_win_len, void* stream) {
+  if (!gx2 || !rgain || !tau2 || !gamma || !part || nbands <= 0 || B <= 0 || G <= 0 || n <= 0 || ld_g < n || ld_tau < n ||
+      ld_o < n || (base2 && (ld_b < n || base2 == gamma)) || win_start < 0 || win_len <= 0 || win_start + win_len > n)
+    return GFDN_E_BADARG;
+  const int tiles = (n + 256 * LIN_V - 1) / (256 * LIN_V);
+  if (ld_part < tiles) return GFDN_E_BADARG;
+  if (G > LIN_MAXG || (B & 1) || B > 64 || B * G > 256 || nbands > 65535) return GFDN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_lin_gamma_dots, dim3(tiles, nbands), dim3(256), 0, (hipStream_t)stream, (const float2*)gx2, ld_g, rgain,
+                     B, G, n, (const float2*)tau2, ld_tau, base2, ld_b, slot_of_time, gamma, ld_o, part, ld_part, win_start,
+                     win_len, band_win_len);
+  GFDN_LAUNCH_CHECK();
+  return 0;
 }
 
 static int lin_chunks_host(int n) {
@@ -366,15 +519,17 @@ extern "C" int gfdn_lin_combine_fwd(const float* xd, int ld_xd, const long long*
 
 extern "C" int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* rgain, int nbands,
                               int B, int G, int n, float* gamma, int ld_o, int out_pairs, const int* slot_of_time,
-                              void* stream) {
+                              const float* base2, int ld_b, void* stream) {
   if (!gx || !rgain || !gamma || nbands <= 0 || B <= 0 || G <= 0 || n <= 0 || ld_g < n || ld_o < n) return GFDN_E_BADARG;
-  if (slot_of_time && !out_pairs) return GFDN_E_BADARG;
+  if ((slot_of_time || base2) && !out_pairs) return GFDN_E_BADARG;
+  if (base2 && (ld_b < n || base2 == gamma)) return GFDN_E_BADARG;
   if (G > LIN_MAXG || B * G > 256 || nbands > 65535) return GFDN_E_UNSUPPORTED;
   if (in_pairs && ((B & 1) || gxb)) return GFDN_E_BADARG;        // (pairs never straddle bands; one merged gradient)
   dim3 grid((n + 256 * LIN_V - 1) / (256 * LIN_V), nbands), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LIN_GAM(IP, OP) \
-  hipLaunchKernelGGL((k_lin_gamma<IP, OP>), grid, block, 0, s, gx, gxb, ld_g, rgain, B, G, n, gamma, ld_o, slot_of_time)
+  hipLaunchKernelGGL((k_lin_gamma<IP, OP>), grid, block, 0, s, gx, gxb, ld_g, rgain, B, G, n, gamma, ld_o, slot_of_time, \
+                     base2, ld_b)
   if (in_pairs) { if (out_pairs) LIN_GAM(true, true); else LIN_GAM(true, false); }
   else { if (out_pairs) LIN_GAM(false, true); else LIN_GAM(false, false); }
 #undef LIN_GAM
@@ -383,15 +538,17 @@ extern "C" int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int i
 }
 
 extern "C" int gfdn_lin_gain_dots(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* tau, int ld_tau,
-                                  int tau_pairs, int nbands, int B, int G, int n, float* part, void* stream) {
-  if (!gx || !tau || !part || nbands <= 0 || B <= 0 || G <= 0 || n <= 0 || ld_g < n || ld_tau < n) return GFDN_E_BADARG;
+                                  int tau_pairs, int nbands, int B, int G, int n, float* part, int ld_part, void* stream) {
+  if (!gx || !tau || !part || nbands <= 0 || B <= 0 || G <= 0 || n <= 0 || ld_g < n || ld_tau < n ||
+      ld_part < lin_chunks_host(n))
+    return GFDN_E_BADARG;
   const int ngrp = (B + LIN_R - 1) / LIN_R;
   if (G > LIN_MAXG || nbands * ngrp > 65535) return GFDN_E_UNSUPPORTED;
   if (in_pairs && ((B & 1) || gxb)) return GFDN_E_BADARG;
   dim3 grid(lin_chunks_host(n), nbands * ngrp), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LIN_DOT(IP, TP) \
-  hipLaunchKernelGGL((k_lin_gain_dots<IP, TP>), grid, block, 0, s, gx, gxb, ld_g, tau, ld_tau, B, G, n, part, ngrp)
+  hipLaunchKernelGGL((k_lin_gain_dots<IP, TP>), grid, block, 0, s, gx, gxb, ld_g, tau, ld_tau, B, G, n, part, ngrp, ld_part)
   if (in_pairs) { if (tau_pairs) LIN_DOT(true, true); else LIN_DOT(true, false); }
   else { if (tau_pairs) LIN_DOT(false, true); else LIN_DOT(false, false); }
 #undef LIN_DOT

@@ -9,6 +9,7 @@
 // All cross-thread sums use fixed-order reductions (no float atomics): bitwise reproducible.
 #include "common.h"
 #include "scan_dev.h"
+#include "xlin_dev.h"
 
 // out[r] = scale * sum_c part[r][c] * (rowscale ? 1/rowscale[r] : 1)
 __global__ void k_row_sum(const float* __restrict__ part, int rows, int cols,
@@ -566,9 +567,11 @@ __device__ __forceinline__ float block_sum2(float2& v, float* lds /* >= 32 float
 }
 
 // work layout (items padded to 2 * pairs): segsum[I][NSEG] | partial[I][NSEG] | gsum[I][NSEG]
+template <bool LIN>
 __global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_segsum(const float2* __restrict__ x2, int ld, int start,
                                                                  int len, float* __restrict__ segsum,
-                                                                 const int* __restrict__ item_len) {
+                                                                 const int* __restrict__ item_len, XLin xl, int items,
+                                                                 float2* __restrict__ xout) {
   __shared__ float s_red[32];
   const int seg = blockIdx.x, p = blockIdx.y;
   if (item_len) len = item_len[2 * p];      // (both items of a pair belong to one band: one window)
@@ -576,6 +579,18 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_segsum(const float2* _
   edc_segment(len, seg, &s0, &sl);
   const float2* xw = x2 + (size_t)p * ld + start + s0;
   float2 acc = make_float2(0.f, 0.f);
+  if (LIN) {
+    // the samples formed on the fly (xlin_dev.h) and -- the one place they are ever written -- stored on the window for
+    // the two scans behind this launch (the scans themselves composing them: 189 registers, 138 us against 47)
+    const XPair xp = xpair_init(xl, p, items);
+    float2* xo = xout + (size_t)p * ld + start + s0;
+    for (int i = threadIdx.x; i < sl; i += blockDim.x) {
+      const float2 v = xpair_load1(xp, start + s0 + i);
+      xo[i] = v;
+      acc.x += v.x * v.x;
+      acc.y += v.y * v.y;
+    }
+  } else
   for (int i = threadIdx.x; i < sl; i += blockDim.x) {
     const float2 v = xw[i];
     acc.x += v.x * v.x;
@@ -588,16 +603,20 @@ __global__ __launch_bounds__(EDC_THREADS) void k_edc_pair_segsum(const float2* _
   }
 }
 
-__global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float2* __restrict__ x2, int ld, int start,
+template <bool LIN>
+__global__ __launch_bounds__(EDC_THREADS, LIN ? 2 : 4) void k_edc_pair_seg_fwd(const float2* __restrict__ x2, int ld, int start,
                                                                   int len, const float* __restrict__ Tdb,
                                                                   const long long* __restrict__ trows,
                                                                   const float* __restrict__ maskw,
                                                                   float inv_count, float gscale,
                                                                   float* __restrict__ work,
-                                                                  float2* __restrict__ gx2, int items, EdcBands eb) {
+                                                                  float2* __restrict__ gx2, int items, EdcBands eb,
+                                                                  XLin xl) {
   __shared__ float2 s_scan[16 * EDC_S];
   __shared__ float s_red[32];
   const int seg = blockIdx.x, p = blockIdx.y;
+  XPair xp;
+  if (LIN) xp = xpair_init(xl, p, items);
   const int I = 2 * (int)gridDim.y, b1 = 2 * p, b2 = b1 + 1;
   const bool two = b2 < items;
   const float* segsum = work;
@@ -630,7 +649,8 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float
       if (ilo >= 0) {
         float2 xv[4];
         float t4[4];
-        ld4_f2(xw + ilo, xv);
+        if (LIN) xpair_load4(xp, start + s0 + ilo, xv);
+        else ld4_f2(xw + ilo, xv);
 #pragma unroll
         for (int u = 0; u < EDC_V; ++u) val[s][u] = make_float2(xv[3 - u].x * xv[3 - u].x, xv[3 - u].y * xv[3 - u].y);
         ld4_f(t1 + ilo, t4);
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float
 #pragma unroll
         for (int u = 0; u < EDC_V; ++u) {
           const int i = sl - 1 - j0 - u;
-          const float2 v = i >= 0 ? xw[i] : make_float2(0.f, 0.f);
+          const float2 v = i >= 0 ? (LIN ? xpair_load1(xp, start + s0 + i) : xw[i]) : make_float2(0.f, 0.f);
           val[s][u] = make_float2(v.x * v.x, v.y * v.y);
           ta[s][u] = i >= 0 ? t1[i] : 0.f;
           tb[s][u] = (i >= 0 && two) ? t2[i] : 0.f;
@@ -726,14 +746,18 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_fwd(const float
   }
 }
 
-__global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_bwd(const float2* __restrict__ x2, int ld, int start,
+template <bool LIN>
+__global__ __launch_bounds__(EDC_THREADS, LIN ? 3 : 4) void k_edc_pair_seg_bwd(const float2* __restrict__ x2, int ld, int start,
                                                                   int len, float inv_count,
                                                                   const float* __restrict__ work,
                                                                   float* __restrict__ loss_item,
                                                                   float2* __restrict__ gx2, int items,
-                                                                  const int* __restrict__ item_len) {
+                                                                  const int* __restrict__ item_len, XLin xl,
+                                                                  int fill_outside) {
   __shared__ float2 s_scan[16 * EDC_S];
   const int seg = blockIdx.x, p = blockIdx.y;
+  XPair xp;
+  if (LIN) xp = xpair_init(xl, p, items);
   const int I = 2 * (int)gridDim.y, b1 = 2 * p, b2 = b1 + 1;
   const bool two = b2 < items;
   if (item_len) len = item_len[b1];
@@ -765,13 +789,14 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_bwd(const float
       const int j0 = tile * EDC_TILE + s * EDC_SUB + threadIdx.x * EDC_V;
       if (j0 + EDC_V <= sl) {
         ld4_f2(gw + j0, val[s]);
-        ld4_f2(xw + j0, xs[s]);
+        if (LIN) xpair_load4(xp, start + s0 + j0, xs[s]);
+        else ld4_f2(xw + j0, xs[s]);
       } else {
 #pragma unroll
         for (int u = 0; u < EDC_V; ++u) {
           const bool in = j0 + u < sl;
           val[s][u] = in ? gw[j0 + u] : make_float2(0.f, 0.f);
-          xs[s][u] = in ? xw[j0 + u] : make_float2(0.f, 0.f);
+          xs[s][u] = in ? (LIN ? xpair_load1(xp, start + s0 + j0 + u) : xw[j0 + u]) : make_float2(0.f, 0.f);
         }
       }
       float2 run = make_float2(0.f, 0.f);
@@ -804,6 +829,7 @@ __global__ __launch_bounds__(EDC_THREADS, 4) void k_edc_pair_seg_bwd(const float
     carry = base;
     __syncthreads();
   }
+  if (!fill_outside) return;            // (a consumer that reads the window only: gfdn_lin_gamma_dots)
   float2* g = gx2 + (size_t)p * ld;
   if (seg == 0)
     for (int i = threadIdx.x; i < start; i += blockDim.x) g[i] = make_float2(0.f, 0.f);
@@ -892,17 +918,50 @@ extern "C" int gfdn_edc_loss_model(const float* x, int ld, int batch, int start,
 
 static int edc_loss_pairs_launch(const float* x2, int ld, int items, int start, int len, const float* T_db,
                                  const long long* target_rows, const float* maskw, float inv_count, float gscale,
-                                 float* loss_item, float* gx2, void* work, EdcBands eb, hipStream_t s) {
+                                 float* loss_item, float* gx2, void* work, EdcBands eb, hipStream_t s,
+                                 XLin xl = XLin{nullptr, 0, nullptr, nullptr, 0, nullptr, 1, 0}, int fill_outside = 1) {
   dim3 grid(EDC_NSEG, (items + 1) / 2), block(EDC_THREADS);
-  hipLaunchKernelGGL(k_edc_pair_segsum, grid, block, 0, s, (const float2*)x2, ld, start, len, (float*)work, eb.item_len);
+  if (xl.xd) {
+    // x2 here: scratch (pairs, ld) that receives the window samples from the first launch
+    hipLaunchKernelGGL(k_edc_pair_segsum<true>, grid, block, 0, s, (const float2*)x2, ld, start, len, (float*)work,
+                       eb.item_len, xl, items, (float2*)x2);
+    GFDN_LAUNCH_CHECK();
+    xl.xd = nullptr;
+  }
+  else {
+  hipLaunchKernelGGL(k_edc_pair_segsum<false>, grid, block, 0, s, (const float2*)x2, ld, start, len, (float*)work,
+                     eb.item_len, xl, items, (float2*)nullptr);
+  }
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_pair_seg_fwd, grid, block, 0, s, (const float2*)x2, ld, start, len, T_db, target_rows,
-                     maskw, inv_count, gscale, (float*)work, (float2*)gx2, items, eb);
+  hipLaunchKernelGGL(k_edc_pair_seg_fwd<false>, grid, block, 0, s, (const float2*)x2, ld, start, len, T_db, target_rows,
+                     maskw, inv_count, gscale, (float*)work, (float2*)gx2, items, eb, xl);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_edc_pair_seg_bwd, grid, block, 0, s, (const float2*)x2, ld, start, len, inv_count,
-                     (const float*)work, loss_item, (float2*)gx2, items, eb.item_len);
+  hipLaunchKernelGGL(k_edc_pair_seg_bwd<false>, grid, block, 0, s, (const float2*)x2, ld, start, len, inv_count,
+                     (const float*)work, loss_item, (float2*)gx2, items, eb.item_len, xl, fill_outside);
   GFDN_LAUNCH_CHECK();
   return 0;
+}
+
+// gfdn_edc_loss_pairs[_banded] on signals x[b] = xd[rows[b]] + sum_g rgain[b][g] tau[band G + g] (the time-domain output
+// stage, gfdn_lin_combine_fwd) formed by the first of the three launches, which stores them ON THE WINDOW ONLY into the
+// scratch xwin2 (pairs, ld) for the two scans -- xd (R, ld_xd >= ld) float with
+// row indirection xrows, tau2 pair-interleaved (ld_tau >= ld), rgain (items, G), items = nbands B.  ld = the signals'
+// length (the pitch of gx2); item_len / ld_T / ld_mask / B as in gfdn_edc_loss_pairs_banded (item_len NULL: one window
+// max_len, T_db rows of pitch max_len).
+extern "C" int gfdn_edc_loss_pairs_lin(const float* xd, int ld_xd, const long long* xrows, const float* tau2, int ld_tau,
+                                       const float* rgain, int nbands, int B, int G, int ld, int start, int max_len,
+                                       const int* item_len, const float* T_db, int ld_T, const long long* target_rows,
+                                       const float* maskw, int ld_mask, float inv_count, float gscale, float* loss_item,
+                                       float* gx2, int fill_outside, float* xwin2, void* work, void* stream) {
+  if (!xd || !tau2 || !rgain || !T_db || !loss_item || !work || !xwin2 || nbands <= 0 || B <= 0 || G <= 0 || G > 4 || start < 0 ||
+      max_len <= 0 || start + max_len > ld || ld_xd < ld || ld_tau < ld || ld_mask < 0 || (ld_mask > 0 && ld_mask < max_len))
+    return GFDN_E_BADARG;
+  if (item_len && (ld_T < max_len || (B & 1))) return GFDN_E_BADARG;
+  const int items = nbands * B;
+  XLin xl{xd, ld_xd, xrows, (const float2*)tau2, ld_tau, rgain, B, G};
+  return edc_loss_pairs_launch(xwin2, ld, items, start, max_len, T_db, target_rows, maskw, inv_count, gscale, loss_item,
+                               gx2, work, item_len ? EdcBands{item_len, ld_T, B, ld_mask} : EdcBands{nullptr, max_len, 1, 0},
+                               (hipStream_t)stream, xl, fill_outside);
 }
 
 // work: gfdn_edc_work_bytes(items + 1)  (per-item slots for 2 * ceil(items / 2) items)

@@ -1064,7 +1064,7 @@ def irfft_slot_of_time(n: int, device):
     return _time_slots[key]
 
 
-def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, gxb=None, slot_of_time=None):
+def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, gxb=None, slot_of_time=None, base=None):
     """gamma[band G + g] = sum_{b in band} rgain[b][g] (gx[b] [+ gxb[b]]): the signals whose adjoint transform is
     dL/d(T_g filt).  gx: (ceil(items / 2), n, 2) pair-interleaved (``in_pairs``) or (items, n); result in the layout
     ``out_pairs`` asks for (what irfft_odd_pairs_bwd / irfft_odd_bwd take).  ``slot_of_time`` (irfft_slot_of_time): the
@@ -1084,12 +1084,16 @@ def lin_gamma(gx, rgain, nbands: int, n: int, in_pairs: bool, out_pairs: bool, g
         gamma[-1].zero_()                  # (the missing partner of the last signal)
     if slot_of_time is not None and (not out_pairs or slot_of_time.dtype != torch.int32 or slot_of_time.numel() != n):
         raise RuntimeError("lin_gamma: slot_of_time is an int32 table of n entries for the pair-interleaved output")
+    if base is not None:                   # (a part of the same signals already summed per group: time order, pairs)
+        if not out_pairs or base.dtype != _f32 or not base.is_contiguous() or tuple(base.shape) != ((S + 1) // 2, n, 2):
+            raise RuntimeError("lin_gamma: base must be pair-interleaved (ceil(S / 2), n, 2) float32")
     _lib.check(_lib.load().gfdn_lin_gamma(_p(gx), _p(gxb), n, int(in_pairs), _p(rgain), nbands, items // nbands, G, n,
-                                          _p(gamma), n, int(out_pairs), _p(slot_of_time), _stream()), "gfdn_lin_gamma")
+                                          _p(gamma), n, int(out_pairs), _p(slot_of_time), _p(base), n, _stream()),
+               "gfdn_lin_gamma")
     return gamma
 
 
-def lin_gain_dots(gx, tau, nbands: int, items: int, G: int, n: int, in_pairs: bool, tau_pairs: bool, gxb=None):
+def lin_gain_dots(gx, tau, nbands: int, items: int, G: int, n: int, in_pairs: bool, tau_pairs: bool, gxb=None, out=None):
     """(items * G, chunks) partial rows of dL/drgain[b][g] = <gx[b] [+ gxb[b]], tau[band(b) G + g]> for
     ``mlp_gains_bwd(ggains_parts=...)`` (tf_rows_sum of them = dL/drgain)."""
     _need_gpu(gx, tau)
@@ -1103,10 +1107,196 @@ def lin_gain_dots(gx, tau, nbands: int, items: int, G: int, n: int, in_pairs: bo
         if gxb.shape != gx.shape:
             raise RuntimeError("lin_gain_dots: gxb must have the shape of gx")
     lib = _lib.load()
-    parts = torch.empty((items * G, lib.gfdn_lin_gain_chunks(n)), dtype=_f32, device=gx.device)
+    nch = lib.gfdn_lin_gain_chunks(n)
+    if out is None:
+        parts = torch.empty((items * G, nch), dtype=_f32, device=gx.device)
+    else:                                  # (a wider buffer whose first columns receive these partial sums)
+        parts = out
+        if parts.dtype != _f32 or not parts.is_contiguous() or parts.dim() != 2 or parts.shape[0] != items * G \
+                or parts.shape[1] < nch:
+            raise RuntimeError("lin_gain_dots: out must be (items * G, >= chunks) contiguous float32")
     _lib.check(lib.gfdn_lin_gain_dots(_p(gx), _p(gxb), n, int(in_pairs), _p(tau), n, int(tau_pairs), nbands,
-                                      items // nbands, G, n, _p(parts), _stream()), "gfdn_lin_gain_dots")
+                                      items // nbands, G, n, _p(parts), parts.shape[1], _stream()), "gfdn_lin_gain_dots")
     return parts
+
+
+def lin_gamma_dots_tiles(n: int) -> int:
+    return _lib.load().gfdn_lin_gamma_dots_tiles(int(n))
+
+
+def lin_gamma_dots(g2, rgain, nbands: int, n: int, tau2, parts, win_start: int, win_len: int, base=None,
+                   slot_of_time=None, band_win_len=None):
+    """lin_gamma (pairs in, pairs out, ``base``, ``slot_of_time``) and lin_gain_dots in ONE sweep over gradient signals
+    that are nonzero on [win_start, win_start + win_len) only (``band_win_len``: per-band lengths, int32 device): samples
+    outside the window are not read.  ``parts`` (items * G, >= lin_gamma_dots_tiles(n)) receives the dot-product partial sums
+    in its first columns.  Returns gamma."""
+    _need_gpu(g2, rgain, tau2, parts)
+    g2, rgain, tau2 = _f(g2), _f(rgain), _f(tau2)
+    items, G = rgain.shape
+    S = nbands * G
+    lib = _lib.load()
+    tiles = lib.gfdn_lin_gamma_dots_tiles(n)
+    if items % nbands or tuple(g2.shape) != (items // 2, n, 2) or tuple(tau2.shape) != ((S + 1) // 2, n, 2) \
+            or parts.dtype != _f32 or not parts.is_contiguous() or parts.shape[0] != items * G or parts.shape[1] < tiles:
+        raise RuntimeError("lin_gamma_dots: shapes do not match")
+    gamma = torch.empty(((S + 1) // 2, n, 2), dtype=_f32, device=g2.device)
+    if S % 2:
+        gamma[-1].zero_()
+    if base is not None and (base.dtype != _f32 or not base.is_contiguous() or base.shape != gamma.shape):
+        raise RuntimeError("lin_gamma_dots: base must be shaped like gamma")
+    _lib.check(lib.gfdn_lin_gamma_dots(_p(g2), n, _p(rgain), nbands, items // nbands, G, n, _p(tau2), n, _p(base), n,
+                                       _p(slot_of_time), _p(gamma), n, _p(parts), parts.shape[1], int(win_start),
+                                       int(win_len), _p(band_win_len), _stream()), "gfdn_lin_gamma_dots")
+    return gamma
+
+
+def lin_gain_chunks(n: int) -> int:
+    return _lib.load().gfdn_lin_gain_chunks(int(n))
+
+
+# ---- the EDR loss on linearly composed short-time spectra (csrc/edrlin.hip) ------------------------------------------
+def stft_pairs_spectrum(x2, items: int, win: int) -> torch.Tensor:
+    """x2 (ceil(items / 2), T, 2) pair-interleaved signals -> S (items, nframes, win / 2 + 1) complex64 (win = 4096)."""
+    _need_gpu(x2)
+    if x2.dtype != _f32 or not x2.is_contiguous() or x2.dim() != 3 or x2.shape[2] != 2 or x2.shape[0] != (items + 1) // 2:
+        raise RuntimeError("stft_pairs_spectrum: x2 must be contiguous float32 (ceil(items / 2), T, 2)")
+    T = x2.shape[1]
+    S = torch.empty((items, stft_nframes(T, win), win // 2 + 1), dtype=_c64, device=x2.device)
+    _lib.check(_lib.load().gfdn_stft_pairs_spectrum(_p(x2), T, T, items, win, _p(S), _stream()),
+               "gfdn_stft_pairs_spectrum")
+    return S
+
+
+def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None) -> torch.Tensor:
+    """Adjoint of stft_pairs_spectrum: gradient spectra G (items, nframes, win / 2 + 1) complex64 -> gx2
+    (ceil(items / 2), n, 2) [+ base, same layout]."""
+    _need_gpu(G)
+    G = _c(G)
+    if tuple(G.shape) != (items, stft_nframes(n, win), win // 2 + 1):
+        raise RuntimeError("stft_pairs_spectrum_bwd: G must be (items, nframes, win / 2 + 1)")
+    gx2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=G.device)
+    if base is not None and (base.dtype != _f32 or not base.is_contiguous() or base.shape != gx2.shape):
+        raise RuntimeError("stft_pairs_spectrum_bwd: base must be shaped like the result")
+    _lib.check(_lib.load().gfdn_stft_pairs_spectrum_bwd(_p(G), n, items, win, _p(base), _p(gx2), n, _stream()),
+               "gfdn_stft_pairs_spectrum_bwd")
+    return gx2
+
+
+def edr_lin_parts(nfreq: int, fused: bool = False) -> int:
+    lib = _lib.load()
+    return lib.gfdn_edr_lin_fused_parts(int(nfreq)) if fused else lib.gfdn_edr_lin_parts(int(nfreq))
+
+
+def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, want_grad: bool = True,
+                 dots=None, col0: int = 0):
+    """EDR loss of items whose short-time spectra are Sd[rows[b]] + sum_g rgain[b][g] Stau[band(b) G + g] -- never formed in
+    memory.  Sd (R, nframes, nfreq) c64, T_db (R, nframes, nfreq) f32 and sum_abs (R) share the row indirection.
+    Returns (part (items, edr_lin_parts) -- the deferred partial sums of edr_loss(defer=True) --, gP (items, nframes, nfreq)
+    = gscale / sum_abs dloss/d|S|^2 or None).  ``dots`` (items * G, >= col0 + edr_lin_parts): receives the EDR part of
+    dL/drgain as partial sums in columns [col0, col0 + edr_lin_parts)."""
+    _need_gpu(Sd, Stau, rgain, T_db)
+    Sd, Stau, rgain = _c(Sd), _c(Stau), _f(rgain)
+    items, G = rgain.shape
+    R, nframes, nfreq = Sd.shape
+    if items % nbands or tuple(Stau.shape) != (nbands * G, nframes, nfreq) or tuple(T_db.shape) != (R, nframes, nfreq) \
+            or T_db.dtype != _f32 or not T_db.is_contiguous() or sum_abs.numel() != R:
+        raise RuntimeError("edr_lin_loss: Sd / T_db (R, nframes, nfreq), Stau (nbands * G, nframes, nfreq), sum_abs (R)")
+    rows = _rows(rows, items, R)
+    if rows is None and R != items:
+        raise RuntimeError("edr_lin_loss: one row per item (or pass rows)")
+    lib = _lib.load()
+    fblk = lib.gfdn_edr_lin_parts(nfreq)
+    part = torch.empty((items, fblk), dtype=_f32, device=Sd.device)
+    gP = torch.empty((items, nframes, nfreq), dtype=_f32, device=Sd.device) if want_grad else None
+    ld = 0
+    if dots is not None:
+        if dots.dtype != _f32 or not dots.is_contiguous() or dots.dim() != 2 or dots.shape[0] != items * G \
+                or dots.shape[1] < col0 + fblk:
+            raise RuntimeError("edr_lin_loss: dots must be (items * G, >= col0 + parts) contiguous float32")
+        ld = dots.shape[1]
+    _lib.check(lib.gfdn_edr_lin_loss(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(T_db),
+                                     _p(_f(sum_abs)), nframes, nfreq, float(gscale), int(want_grad), _p(gP), _p(part),
+                                     _p(dots if want_grad else None), ld, int(col0), _stream()), "gfdn_edr_lin_loss")
+    return part, gP
+
+
+def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, dots=None, col0: int = 0):
+    """edr_lin_loss(want_grad=True) and edr_lin_gsum as ONE launch -> (part, Gsum): the band's receivers are summed inside
+    the workgroup, dL/d|S|^2 is never written."""
+    _need_gpu(Sd, Stau, rgain, T_db)
+    Sd, Stau, rgain = _c(Sd), _c(Stau), _f(rgain)
+    items, G = rgain.shape
+    R, nframes, nfreq = Sd.shape
+    if items % nbands or tuple(Stau.shape) != (nbands * G, nframes, nfreq) or tuple(T_db.shape) != (R, nframes, nfreq) \
+            or T_db.dtype != _f32 or not T_db.is_contiguous() or sum_abs.numel() != R:
+        raise RuntimeError("edr_lin_loss_gsum: Sd / T_db (R, nframes, nfreq), Stau (nbands * G, nframes, nfreq), sum_abs (R)")
+    rows = _rows(rows, items, R)
+    if rows is None and R != items:
+        raise RuntimeError("edr_lin_loss_gsum: one row per item (or pass rows)")
+    lib = _lib.load()
+    fblk = lib.gfdn_edr_lin_fused_parts(nfreq)
+    part = torch.empty((items, fblk), dtype=_f32, device=Sd.device)
+    Gs = torch.empty((nbands * G, nframes, nfreq), dtype=_c64, device=Sd.device)
+    ld = 0
+    if dots is not None:
+        if dots.dtype != _f32 or not dots.is_contiguous() or dots.dim() != 2 or dots.shape[0] != items * G \
+                or dots.shape[1] < col0 + fblk:
+            raise RuntimeError("edr_lin_loss_gsum: dots must be (items * G, >= col0 + parts) contiguous float32")
+        ld = dots.shape[1]
+    _lib.check(lib.gfdn_edr_lin_loss_gsum(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(T_db),
+                                          _p(_f(sum_abs)), nframes, nfreq, float(gscale), _p(part), _p(dots), ld, int(col0),
+                                          _p(Gs), _stream()), "gfdn_edr_lin_loss_gsum")
+    return part, Gs
+
+
+def edr_lin_gsum(Sd, rows, Stau, rgain, nbands: int, gP) -> torch.Tensor:
+    """Gsum (nbands * G, nframes, nfreq) complex64 = sum over the band's items of rgain[b][g] 2 gP[b] S[b] -- the gradient
+    spectra whose adjoint STFT is the EDR part of dL/dtau."""
+    _need_gpu(Sd, Stau, rgain, gP)
+    Sd, Stau, rgain, gP = _c(Sd), _c(Stau), _f(rgain), _f(gP)
+    items, G = rgain.shape
+    R, nframes, nfreq = Sd.shape
+    if items % nbands or tuple(Stau.shape) != (nbands * G, nframes, nfreq) or tuple(gP.shape) != (items, nframes, nfreq):
+        raise RuntimeError("edr_lin_gsum: shapes do not match")
+    rows = _rows(rows, items, R)
+    Gs = torch.empty((nbands * G, nframes, nfreq), dtype=_c64, device=Sd.device)
+    _lib.check(_lib.load().gfdn_edr_lin_gsum(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(gP),
+                                             nframes, nfreq, _p(Gs), _stream()), "gfdn_edr_lin_gsum")
+    return Gs
+
+
+def edc_loss_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, start: int, length: int, T_db, maskw=None,
+                       inv_count: float = 1.0, gscale: float = 1.0, want_grad: bool = True, trows=None, item_len=None,
+                       fill_outside: bool = True):
+    """edc_loss_pairs on signals that are never stored (x[b] = xd[rows[b]] + sum_g rgain[b][g] tau[band G + g], formed where
+    the scans read them) -> (loss_item (items,), g2 (ceil(items / 2), n, 2) or None).  ``fill_outside=False``: g2 is
+    written on each item's window only (a consumer that reads nothing else: lin_gamma_dots)."""
+    _need_gpu(xd, tau2, rgain, T_db)
+    xd, tau2, rgain = _f(xd), _f(tau2), _f(rgain)
+    items, G = rgain.shape
+    S = nbands * G
+    if items % nbands or xd.shape[1] < n or tuple(tau2.shape) != ((S + 1) // 2, n, 2):
+        raise RuntimeError("edc_loss_pairs_lin: rgain (nbands * B, G), xd (R, >= n), tau2 (ceil(nbands G / 2), n, 2)")
+    rows = _rows(rows, items, xd.shape[0])
+    trows = _rows(trows, items, T_db.shape[0])
+    if T_db.dtype != _f32 or not T_db.is_contiguous() or (item_len is None and T_db.shape[-1] != length) \
+            or (trows is None and T_db.shape[0] != items):
+        raise RuntimeError("edc_loss_pairs_lin: target shape does not match the window")
+    maskw = None if maskw is None else _f(maskw)
+    ld_mask = 0
+    B = items // nbands
+    if item_len is not None:
+        _, ld_mask = _edc_bands(item_len, items, B, maskw, length, T_db, "edc_loss_pairs_lin")
+    loss_item = torch.empty(items, dtype=_f32, device=xd.device)
+    g2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=xd.device) if want_grad else None
+    xw = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=xd.device)       # (window samples, written by the launch)
+    lib = _lib.load()
+    work = _work(lib.gfdn_edc_work_bytes(items + 1), xd.device)
+    _lib.check(lib.gfdn_edc_loss_pairs_lin(_p(xd), xd.stride(0), _p(rows), _p(tau2), n, _p(rgain), nbands, B, G, n, start,
+                                           length, _p(item_len), _p(T_db), T_db.shape[-1], _p(trows), _p(maskw), ld_mask,
+                                           float(inv_count), float(gscale), _p(loss_item), _p(g2), int(fill_outside), _p(xw),
+                                           _p(work), _stream()), "gfdn_edc_loss_pairs_lin")
+    return loss_item, g2
 
 
 def stft_power_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, win: int):

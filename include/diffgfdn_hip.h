@@ -513,7 +513,10 @@ int gfdn_lin_combine_fwd(const float* xd, int ld_xd, const long long* rows, cons
                          const float* rgain, int nbands, int B, int G, int n, float* x, int ld_x, int out_pairs,
                          void* stream);
 int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* rgain, int nbands, int B, int G,
-                   int n, float* gamma, int ld_o, int out_pairs, const int* slot_of_time, void* stream);
+                   int n, float* gamma, int ld_o, int out_pairs, const int* slot_of_time, const float* base2, int ld_b,
+                   void* stream);
+/* base2 (out_pairs only; NULL: none): signals in gamma's pair-interleaved layout, TIME order, pitch ld_b, added to the
+ * sums -- the part of the same gradient signals that is already summed per group (gfdn_stft_pairs_spectrum_bwd).         */
 /* slot_of_time (n ints, device; out_pairs only; NULL: time order): gamma is written in the adjoint pair transform's own
  * order -- sample 0 first, the sample of time t >= 1 at 1 + slot_of_time[t], slot_of_time the inverse of
  * gfdn_irfft_odd_time_slots -- for gfdn_irfft_odd_pairs_bwd_tslots, whose first pass then loads coalesced rows.           */
@@ -521,7 +524,58 @@ int gfdn_irfft_odd_time_slots(int n, int* times);
 int gfdn_irfft_odd_pairs_bwd_tslots(const void* table, int n, const float* gx2s, int ldo, int batch, float* gXs_c64,
                                     int ldx, void* work, void* stream);
 int gfdn_lin_gain_dots(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* tau, int ld_tau,
-                       int tau_pairs, int nbands, int B, int G, int n, float* part, void* stream);
+                       int tau_pairs, int nbands, int B, int G, int n, float* part, int ld_part, void* stream);
+/* (part rows have pitch ld_part >= gfdn_lin_gain_chunks(n): further columns may hold other partial sums of the same
+ * gradients, e.g. gfdn_edr_lin_loss's)                                                                                 */
+
+/* gfdn_lin_gamma (pair-interleaved in and out, base2, slot_of_time) and gfdn_lin_gain_dots as ONE sweep over gradient
+ * signals that are nonzero on the window [win_start, win_start + win_len) only (band_win_len: optional per-band lengths,
+ * device int32): samples outside the window are not read.  part rows of pitch ld_part hold gfdn_lin_gamma_dots_tiles(n)
+ * partial sums per (item, group).                                                                                        */
+int gfdn_lin_gamma_dots_tiles(int n);
+int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nbands, int B, int G, int n, const float* tau2,
+                        int ld_tau, const float* base2, int ld_b, const int* slot_of_time, float* gamma, int ld_o,
+                        float* part, int ld_part, int win_start, int win_len, const int* band_win_len, void* stream);
+
+/* ---- The EDR loss on linearly composed short-time spectra (csrc/edrlin.hip).  With the output stage in the time domain
+ * the STFT of a receiver's signal is Sd[row_b] + sum_g gain[b][g] Stau_g (the STFT is linear): Sd = the STFT of the
+ * transformed direct paths, a constant of the dataset; Stau = the STFT of the band's G group signals.  The per-receiver
+ * STFTs of src/diff_gfdn/losses.py:501-553 and their adjoints do not run; losses.py:556-575, :478-492 (EDR, dB, L1 ratio)
+ * are evaluated per (receiver, frequency) column on the composed spectra:
+ *   gfdn_stft_pairs_spectrum      : S (items, nframes, 2049) complex from pair-interleaved signals (win = 4096);
+ *   gfdn_edr_lin_loss             : loss partials part (items, gfdn_edr_lin_parts(nfreq)) (as gfdn_edr_loss without
+ *                                   loss_item), gP (items, nframes, nfreq) = gscale / sum_abs dloss/d|S|^2, and the EDR part
+ *                                   of dL/dgain[b][g] as partial rows dots[(b G + g) ld_dots + col0 + j];
+ *   gfdn_edr_lin_gsum             : Gsum (nbands G, nframes, nfreq) complex = sum_{b in band} gain[b][g] 2 gP[b] S[b];
+ *   gfdn_stft_pairs_spectrum_bwd  : gx2 = [base2 +] adjoint STFT of gradient spectra G (items, nframes, 2049) -- with
+ *                                   G = Gsum: the EDR part of dL/dtau.
+ * rows: item -> row of Sd / T_db / sum_abs (NULL: identity).  G <= 4, nframes <= 32.                                    */
+int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, void* stream);
+int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2, int ld,
+                                 void* stream);
+int gfdn_edr_lin_parts(int nfreq);            /* partial-sum columns of gfdn_edr_lin_loss */
+int gfdn_edr_lin_fused_parts(int nfreq);      /* ... of gfdn_edr_lin_loss_gsum            */
+int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
+                      int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
+                      int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0, void* stream);
+int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
+                      int B, int G, const float* gP, int nframes, int nfreq, float* Gsum_c64, void* stream);
+/* gfdn_edr_lin_loss(want_grad = 1) + gfdn_edr_lin_gsum in ONE launch: the band's receivers are summed inside the workgroup
+ * (fixed order), dL/d|S|^2 is never written and Sd is read once.                                                          */
+int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
+                           int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
+                           float* part, float* dots, int ld_dots, int col0, float* Gsum_c64, void* stream);
+/* gfdn_edc_loss_pairs[_banded] on signals x[b] = xd[xrows[b]] + sum_g rgain[b][g] tau[band G + g] formed by the first of its
+ * three launches (segment energies), which stores them on the EDC window only into the scratch xwin2 (ceil(items / 2), ld, 2)
+ * for the two scans (tau2 pair-interleaved).  ld = the signals' length = pitch of gx2 and xwin2; item_len NULL: one window
+ * max_len for all items and T_db rows of pitch max_len; else as gfdn_edc_loss_pairs_banded with items_per_band = B.       */
+int gfdn_edc_loss_pairs_lin(const float* xd, int ld_xd, const long long* xrows, const float* tau2, int ld_tau,
+                            const float* rgain, int nbands, int B, int G, int ld, int start, int max_len,
+                            const int* item_len, const float* T_db, int ld_T, const long long* target_rows,
+                            const float* maskw, int ld_mask, float inv_count, float gscale, float* loss_item, float* gx2,
+                            int fill_outside, float* xwin2, void* work, void* stream);
+/* (fill_outside = 0: gx2 is written on the item's window only -- for a consumer that reads nothing else,
+ * gfdn_lin_gamma_dots; 1: zeros outside the window, as gfdn_edc_loss_pairs)                                              */
 
 /* gfdn_lin_combine_fwd folded into the load of gfdn_stft_power_pairs (win = 4096; tau pair-interleaved): forms the pair's
  * samples where the frame is loaded, stores them once as x2 (ceil(items / 2), ld >= T, 2) for the EDC scans and the STFT

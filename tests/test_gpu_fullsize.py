@@ -358,6 +358,35 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
           {k.replace("output_scalars.mlp.model.", "mlp."): f"{v:.1e}" for k, v in worst_all.items()})
 
 
+def test_composed_spectra_step_equals_stored_signal_step_full_size():
+    """K = 65 537, two bands: the explicit step with the EDR loss on composed short-time spectra and the EDC scans on samples
+    formed on the fly (csrc/edrlin.hip: no per-receiver STFT, the receivers' signals never stored) against the same step
+    with the receivers' signals stored and transformed per receiver (FusedBankStep.spectral_edr = False): the maps are
+    linear and commute -- losses to 2e-6, gradients to rounding."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    res = {}
+    for spec in (True, False):
+        bands = [_band(q) for q in range(2)]
+        filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
+        bank = BandBank([b_[2] for b_ in bands])
+        tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=CENTRES)
+        tr._fused.spectral_edr = spec
+        sds = BandStackedDataset([b_[1] for b_ in bands])
+        step = tr.graphed(sds, B, mask_seed=99).capture(sds.global_rows([[0, 3], [1, 4]]))
+        out = step(sds.global_rows([[2, 5], [0, 3]]))
+        torch.cuda.synchronize()
+        res[spec] = ({k: v.detach().cpu().numpy().copy() for k, v in out.items()},
+                     tr.optimizer.flat_grad.detach().cpu().numpy().copy(),
+                     [(p.numel()) for p in tr.optimizer._params])
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=2e-6, atol=0), (k, res[True][0][k], v)
+    off = 0
+    for i, cnt in enumerate(res[False][2]):
+        a, b = res[True][1][off:off + cnt], res[False][1][off:off + cnt]
+        assert np.abs(a - b).max() <= (5e-4 if i == 2 else 3e-5) * np.abs(b).max(), (i, np.abs(a - b).max(), np.abs(b).max())
+        off += cnt
+
+
 def test_time_domain_output_stage_equals_folded_output_stage_full_size():
     """K = 65 537, two bands: the explicit step with the output stage in the time domain (4 pair-transformed group
     responses per band + the dataset's transformed direct paths, csrc/linear.hip) against the step that forms H per

@@ -800,3 +800,146 @@ def test_gamma_in_transform_order_equals_gathering_adjoint():
     a = ops.irfft_odd_pairs_bwd(gam, n, nb * G)
     b = ops.irfft_odd_pairs_bwd(gam_s, n, nb * G, tslots=True)
     assert torch.equal(a, b)
+
+
+def _to_pairs(a):
+    if a.shape[0] % 2:
+        a = torch.cat([a, torch.zeros_like(a[:1])])
+    return torch.stack((a[0::2], a[1::2]), dim=-1).contiguous()
+
+
+@pytest.mark.parametrize("items,T", [(6, 65537), (3, 20000)])
+def test_stft_pairs_spectrum_and_adjoint(items, T):
+    """gfdn_stft_pairs_spectrum against torch.stft (Hann 4096 periodic, hop 2048, center=False, one-sided, the signal
+    zero-padded to whole hops: losses.py:512-535) in float64, and gfdn_stft_pairs_spectrum_bwd against the adjoint
+    identity <STFT x, G> = <x, STFT^T G> (+ the base it adds)."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(items)
+    x = torch.randn(items, T, generator=gen).to(DEV)
+    x2 = _to_pairs(x)
+    S = ops.stft_pairs_spectrum(x2, items, 4096)
+    Tp = ((T + 2047) // 2048) * 2048
+    xp = torch.nn.functional.pad(x.double().cpu(), (0, Tp - T))
+    ref = torch.stft(xp, 4096, hop_length=2048, window=torch.hann_window(4096, dtype=torch.float64), center=False,
+                     onesided=True, return_complex=True).transpose(1, 2)                  # (items, frames, 2049)
+    assert tuple(S.shape) == tuple(ref.shape)
+    assert rel_err(S.cpu(), ref) < 2e-6
+    G = torch.view_as_complex(torch.randn(items, S.shape[1], 2049, 2, generator=gen).to(DEV))
+    base = torch.randn((items + 1) // 2, T, 2, generator=gen).to(DEV)
+    g2 = ops.stft_pairs_spectrum_bwd(G, T, items, 4096, base=base)
+    gx = g2 - base
+    lhs = (ref.real * G.real.double().cpu() + ref.imag * G.imag.double().cpu()).sum(dim=(1, 2))
+    for b in range(items):
+        rhs = (x[b].double().cpu() * gx[b // 2, :, b % 2].double().cpu()).sum()
+        assert abs(float(lhs[b] - rhs)) < 2e-5 * abs(float(lhs[b])) + 1e-3, (b, float(lhs[b]), float(rhs))
+    if items % 2:
+        assert float(gx[-1, :, 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("G,B", [(4, 4), (3, 2)])
+def test_edr_loss_on_composed_spectra(G, B):
+    """gfdn_edr_lin_loss / gfdn_edr_lin_gsum (EDR on S = Sd[row] + sum_g rgain Stau_g, never stored) against the stored
+    form: compose S in torch, |S|^2 through gfdn_edr_loss, the gain gradients and the summed gradient spectra in float64."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(7 * G + B)
+    nb, R, nfr, nf = 2, B + 3, 32, 2049
+    items, S_ = nb * B, nb * G
+    Sd = torch.view_as_complex(torch.randn(nb * R, nfr, nf, 2, generator=gen).to(DEV))
+    Stau = torch.view_as_complex(torch.randn(S_, nfr, nf, 2, generator=gen).to(DEV))
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=gen)[:B]], device=DEV)
+    Pt = torch.rand(nb * R, nfr, nf, generator=gen).to(DEV) * 3 + 0.1
+    T_db, sum_abs = ops.edr_target(Pt.clone())
+    band = torch.arange(items, device=DEV) // B
+    Sc = Sd[rows] + (rgain.to(torch.complex64)[:, :, None, None] * Stau.view(nb, G, nfr, nf)[band]).sum(1)
+    P = (Sc.real ** 2 + Sc.imag ** 2).contiguous()
+    li_ref = ops.edr_loss(P, T_db, sum_abs, None, 1.5, True, rows=rows)          # P becomes gP
+    nch = 5
+    parts = torch.zeros(items * G, nch + ops.edr_lin_parts(nf), device=DEV)
+    part, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, True, dots=parts, col0=nch)
+    li = part.sum(1) / sum_abs[rows]
+    assert rel_err(li.cpu(), li_ref.cpu()) < 2e-6
+    assert rel_err(gP.cpu(), P.cpu()) < 1e-5
+    assert float(parts[:, :nch].abs().max()) == 0.0
+    dS = 2.0 * P.double()[..., None] * torch.view_as_real(Sc).double()            # dL/dS as (re, im)
+    dS = torch.view_as_complex(dS.contiguous())
+    dots_ref = (Stau.view(nb, G, nfr, nf)[band].to(torch.complex128).conj() * dS[:, None]).real.sum(dim=(2, 3))
+    assert rel_err(parts[:, nch:].sum(1).view(items, G).cpu(), dots_ref.cpu()) < 2e-5
+    Gs = ops.edr_lin_gsum(Sd, rows, Stau, rgain, nb, gP)
+    Gs_ref = (rgain.double().view(nb, B, G, 1, 1) * dS.view(nb, B, 1, nfr, nf)).sum(1).reshape(S_, nfr, nf)
+    assert rel_err(Gs.cpu(), Gs_ref.cpu()) < 2e-5
+    part2, none = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, False)
+    assert none is None and torch.equal(part2, part)
+    # the same as ONE launch (receivers summed inside the workgroup)
+    parts3 = torch.zeros(items * G, nch + ops.edr_lin_parts(nf, fused=True), device=DEV)
+    part3, Gs3 = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, dots=parts3, col0=nch)
+    assert rel_err((part3.sum(1) / sum_abs[rows]).cpu(), li_ref.cpu()) < 2e-6
+    assert rel_err(parts3[:, nch:].sum(1).view(items, G).cpu(), dots_ref.cpu()) < 2e-5
+    assert rel_err(Gs3.cpu(), Gs_ref.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("banded", [False, True])
+def test_edc_scans_on_signals_formed_on_the_fly(banded):
+    """gfdn_edc_loss_pairs_lin (samples = xd[row] + sum_g rgain tau_g formed where the scans read them) against
+    gfdn_lin_combine_fwd followed by gfdn_edc_loss_pairs[_banded] on the stored signals."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    nb, B, G, n, R, start = 3, 4, 4, 20011, 6, 160
+    items, S_ = nb * B, nb * G
+    decay = torch.exp(-torch.arange(n) / 3000.0)
+    xd = (torch.randn(nb * R, n, generator=gen) * decay).to(DEV)
+    tau2 = _to_pairs((torch.randn(S_, n, generator=gen) * decay).to(DEV))
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=gen)[:B]], device=DEV)
+    lens = [9000, 15003, 19000] if banded else [19000] * nb
+    Lmax = max(lens)
+    tgt = (torch.randn(nb * R, n, generator=gen) * decay).to(DEV)
+    T_db = torch.zeros(nb * R, Lmax, device=DEV)
+    for q, L in enumerate(lens):
+        T_db[q * R:(q + 1) * R, :L] = ops.edc_target(tgt[q * R:(q + 1) * R].contiguous(), start, L)
+    item_len = torch.tensor(lens, dtype=torch.int32, device=DEV).repeat_interleave(B).contiguous() if banded else None
+    mw = (torch.rand(nb, Lmax, generator=gen) > 0.5).float().to(DEV) / 100.0
+    mw = mw if banded else mw[0].contiguous()
+    x2 = ops.lin_combine_fwd(xd, rows, tau2, rgain, nb, n, True, True)
+    li_ref, g_ref = ops.edc_loss_pairs(x2, items, start, Lmax, T_db, mw, 1.0, 10.0, True, rows=rows, item_len=item_len,
+                                       items_per_band=B)
+    li, g2 = ops.edc_loss_pairs_lin(xd, rows, tau2, rgain, nb, n, start, Lmax, T_db, mw, 1.0, 10.0, True, trows=rows,
+                                    item_len=item_len)
+    assert rel_err(li.cpu(), li_ref.cpu()) < 2e-6
+    assert rel_err(g2.cpu(), g_ref.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("banded", [False, True])
+def test_gamma_and_dots_in_one_sweep(banded):
+    """gfdn_lin_gamma_dots (G sums per band and dL/drgain dot products in one sweep over the window of the gradient
+    signals, samples outside it never read) against gfdn_lin_gamma + gfdn_lin_gain_dots on signals that hold zeros outside
+    the window."""
+    from diffgfdn_amd import hip_ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    n, nb, B, G, w0 = 65537, 3, 6, 4, 640
+    items, S_ = nb * B, nb * G
+    lens = [18560, 31360, 47360] if banded else [47360] * nb
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    g2 = torch.randn(items // 2, n, 2, generator=gen).to(DEV)
+    tau2 = torch.randn(S_ // 2, n, 2, generator=gen).to(DEV)
+    base = torch.randn(S_ // 2, n, 2, generator=gen).to(DEV)
+    gz = g2.clone()
+    for q, L in enumerate(lens):
+        gz[q * B // 2:(q + 1) * B // 2, :w0] = 0
+        gz[q * B // 2:(q + 1) * B // 2, w0 + L:] = 0
+    g2p = g2.clone()                                  # poison outside the windows: must never be read
+    for q, L in enumerate(lens):
+        g2p[q * B // 2:(q + 1) * B // 2, :w0] = float("nan")
+        g2p[q * B // 2:(q + 1) * B // 2, w0 + L:] = float("nan")
+    sot = ops.irfft_slot_of_time(n, torch.device(DEV))
+    gam_ref = ops.lin_gamma(gz, rgain, nb, n, True, True, slot_of_time=sot, base=base)
+    dots_ref = ops.tf_rows_sum(ops.lin_gain_dots(gz, tau2, nb, items, G, n, True, True)).view(items, G)
+    tiles = ops.lin_gamma_dots_tiles(n)
+    parts = torch.full((items * G, tiles + 3), 7.0, device=DEV)
+    band_len = torch.tensor(lens, dtype=torch.int32, device=DEV) if banded else None
+    gam = ops.lin_gamma_dots(g2p, rgain, nb, n, tau2, parts, w0, max(lens), base=base, slot_of_time=sot,
+                             band_win_len=band_len)
+    assert torch.equal(gam, gam_ref)
+    assert float((parts[:, tiles:] - 7.0).abs().max()) == 0.0
+    dots = parts[:, :tiles].sum(1).view(items, G)
+    assert rel_err(dots.cpu(), dots_ref.cpu()) < 1e-5
