@@ -69,30 +69,31 @@ EDC_LEN = 48000 - 640
 HBM_PEAK_GBS = 8000.0
 # compulsory HBM bytes per RIR (fwd + bwd, fp32 / complex64 storage)
 ALG_BYTES_PER_RIR = 2811048
-# Dominant HBM-bound kernel: the first column pass of the odd-length irfft (k_blu_col128_fwd; input side + FFT over
-# n1 + twiddle), one forward and one adjoint launch per step (the roofline leg averages both).  Two items share one
-# transform, so per RIR: the forward launch reads the item's slot-ordered spectrum (8 B x 32769)
-# and writes half a work block (8 B x 2^16 / 2) = 524 296 B; the adjoint launch gathers ONE real input (4 B x 65537)
-# and writes half a work block = 524 292 B.  Average: 524 294 B.
-DOMINANT_KERNEL = 'k_blu_col128_fwd'
-# Algorithmic HBM bytes per RIR and launch of the step's kernels (what each MUST read and write):
+# Dominant HBM-bound kernel of the step since round 4: the EDR loss on composed short-time spectra (csrc/edrlin.hip,
+# k_edr_lin_cols), one launch per step.  Per RIR it MUST read the STFT of the receiver's transformed direct path (32 frames
+# x 2049 bins x 8 B) and the target EDR (x 4 B) and write dL/d|S|^2 (x 4 B) = 1 049 088 B; the band's group spectra are
+# shared by its 32 receivers (cache traffic, not counted).
+DOMINANT_KERNEL = 'k_edr_lin_cols'
+# Algorithmic HBM bytes per RIR and launch of the step's per-receiver kernels (what each MUST read and write):
 ALG_BYTES_PER_UNIT = {
-    'k_blu_col128_fwd': (8 * KU + 4 * 65536 + 4 * K + 4 * 65536) // 2,        # fwd / adjoint launch average
-    'k_blu_row512': 2 * 8 * 65536 // 2,                                        # half a work block in and out
-    'k_blu_col128_inv': (4 * 65536 + 4 * K + 4 * 65536 + 8 * KU) // 2,         # fwd: block -> x; adjoint: block -> dL/dH
-    'k_stft4k_pair_power': 4 * K + 4 * FRAMES * NF,                            # x in, |STFT|^2 out
-    'k_stft4k_pair_power_bwd': (4 * K + 4 * FRAMES * NF // 2 + 4 * K + 4 * K),  # x, half of dL/dP, gradient in and out (per launch)
-    'k_edr_loss_cols': 3 * 4 * FRAMES * NF,                                    # P in, target EDR in, dL/dP out
-    'k_edc_pair_segsum': 4 * EDC_LEN,
+    'k_edr_lin_cols': FRAMES * NF * (8 + 4 + 4),                               # Sd, target EDR in; dL/d|S|^2 out
+    'k_edr_lin_gsum': FRAMES * NF * (8 + 4),                                   # Sd, dL/d|S|^2 in (the G sums out: per band)
+    'k_edc_pair_segsum': 4 * EDC_LEN + 4 * EDC_LEN,                            # direct path in, composed window samples out
     'k_edc_pair_seg_fwd': 3 * 4 * EDC_LEN,                                     # x, target EDC in, staged terms out
-    'k_edc_pair_seg_bwd': 2 * 4 * EDC_LEN + 4 * K,                             # staged terms, x in, gradient out
-    'k_tf_compose_fwd': 8 * KU + 8 * KU,                                       # direct path in, H out
-    'k_tf_gain_grad': 8 * KU,                                                  # dL/dH in
-    'k_tf_compose_bwd_rec': 8 * KU,                                            # dL/dH in (second pass)
+    'k_edc_pair_seg_bwd': 3 * 4 * EDC_LEN,                                     # staged terms, x in, gradient (window) out
+    'k_lin_gamma_dots': 4 * EDC_LEN,                                           # EDC gradient (window) in (the G sums out: per band)
+    # (kernels of the stored-signal paths, GFDN_SPECTRAL_EDR=0 / GFDN_LINEAR=0, kept for the A/B runs)
+    'k_blu_col128_fwd': (8 * KU + 4 * 65536 + 4 * K + 4 * 65536) // 2,
+    'k_blu_row512': 2 * 8 * 65536 // 2,
+    'k_blu_col128_inv': (4 * 65536 + 4 * K + 4 * 65536 + 8 * KU) // 2,
+    'k_stft4k_pair_power': 4 * K + 4 * FRAMES * NF,
+    'k_stft4k_pair_power_bwd': (4 * K + 4 * FRAMES * NF // 2 + 4 * K + 4 * K),
+    'k_edr_loss_cols': 3 * 4 * FRAMES * NF,
+    'k_lin_combine_fwd': 4 * K + 4 * K,
 }
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
-PROFILE_TAG = 'r03'
+PROFILE_TAG = 'r04'
 REFERENCE_EPOCH_S_PER_BAND = 139.1   # reference trainer, N = 16, 8 vCPU, one band, one epoch
 
 
@@ -404,16 +405,23 @@ def roofline_top(units: int, n: int = 10):
             'kernels': out}
 
 
-def isolated_kernel_us(device, items: int, iters: int = 30):
-    """The dominant kernel alone on the chip (forward and adjoint launch averaged), HIP events on its stream."""
+def isolated_kernel_us(device, data, trainer, rows, nbands, iters: int = 30):
+    """The dominant kernel alone on the chip, on the step's own stores (the transformed direct paths' STFT, the target EDR)
+    and a batch of the step's shape; HIP events on its stream."""
     from diffgfdn_amd import hip_ops as ops
-    X = torch.view_as_complex(torch.randn(items, KU, 2, device=device))
-    g2 = torch.randn((items + 1) // 2, K, 2, device=device)
+    tiled = trainer._fused.tiled_spectra
+    Sd = data.direct_stft(trainer.subband_filter_freq_resp, K, WIN, tiled=tiled)
+    idx = torch.as_tensor(rows, dtype=torch.long, device=device)
+    items = idx.numel()
+    Stau = torch.view_as_complex(torch.randn(nbands * G, FRAMES, NF, 2, device=device) * 0.01)
+    rgain = torch.rand(items, G, device=device)
+    nch = ops.lin_gamma_dots_tiles(K)
+    parts = torch.empty((items * G, nch + ops.edr_lin_parts(NF)), dtype=torch.float32, device=device)
+    T_edr, sum_abs = (data.edr_target_tiled() if tiled else data.edr_store[1]), data.edr_store[2]
     ops.kernel_timer.watch = DOMINANT_KERNEL
     ops.kernel_timer.start()
     for _ in range(iters):
-        ops.irfft_odd_fwd(X, K, slots=True, pairs=True)
-        ops.irfft_odd_pairs_bwd(g2, K, items)
+        ops.edr_lin_loss(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, True, dots=parts, col0=nch, tiled=tiled)
     return ops.kernel_timer.stop()
 
 
@@ -543,9 +551,10 @@ def run_directional(args, device, rank, world):
 def cpu_baseline_directional(tr, z, Gd, L, J, receivers: int = 2):
     """One band-step of the directional model on the host cores with the CPU oracle (oracle/cpu_trainer.py
     directional_band_step: forward, directional EDC loss, backward under autograd in float64 / complex128) on a bounded
-    sample -- ``receivers`` of the 32 receivers of a band-step, the band's current parameters -- and the same step's loss on
-    the HIP path beside it."""
-    from oracle import gfdn_oracle as orc
+    sample -- ``receivers`` of the 32 receivers of a band-step, the band's current parameters, timed after one warm-up
+    call -- and the same sample's loss AND parameter gradients on the HIP path beside it.  The per-bin systems of the
+    feedback loop are shared by a batch's receivers, so the rate of the 2-receiver sample is a LOWER bound of the CPU's rate
+    on a full batch: it is reported as such (``value_is_lower_bound``), not as a like-for-like figure."""
     from oracle.cpu_trainer import directional_band_step
     cores = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
     torch.set_num_threads(cores)
@@ -557,26 +566,42 @@ def cpu_baseline_directional(tr, z, Gd, L, J, receivers: int = 2):
     state = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     delays = [int(d) for d in net.delays.detach().cpu().reshape(-1).tolist()]
     nff = net.sh_output_scalars.num_fourier_features
+    A = net.sh_output_scalars.analysis_matrix
+    args_c = (state, delays, A.cpu().numpy(), z.cpu(), pos, amps, crit.envelopes.cpu(), Gd, L, nff, crit.mixing_time_samps,
+              crit.edc_len_samps)
+    directional_band_step(*args_c, edc_weight=tr.config.edc_loss_weight)          # warm-up (allocator, thread pools)
     t0 = time.time()
-    loss_c, _, _, _ = directional_band_step(state, delays, net.sh_output_scalars.analysis_matrix.cpu().numpy(), z.cpu(), pos,
-                                            amps, crit.envelopes.cpu(), Gd, L, nff, crit.mixing_time_samps,
-                                            crit.edc_len_samps, edc_weight=tr.config.edc_loss_weight)
+    loss_c, _, _, grads_c = directional_band_step(*args_c, edc_weight=tr.config.edc_loss_weight)
     sec = time.time() - t0
     torch.set_num_threads(min(4, os.cpu_count() or 1))
     dev = z.device
-    with torch.no_grad():
-        batch = {'z_values': z, 'source_position': torch.zeros(receivers, 3, device=dev, dtype=torch.float64),
-                 'listener_position': (10 * pos).to(dev), 'norm_listener_position': pos.to(dev),
-                 'target_common_slope_amps': amps.to(dev)}
-        loss_h = float(tr._step_losses(batch)['edc_loss'])
+    batch = {'z_values': z, 'source_position': torch.zeros(receivers, 3, device=dev, dtype=torch.float64),
+             'listener_position': (10 * pos).to(dev), 'norm_listener_position': pos.to(dev),
+             'target_common_slope_amps': amps.to(dev)}
+    net.zero_grad(set_to_none=True)
+    out = net(batch)
+    H_sh = out[0] if isinstance(out, tuple) else out
+    edc = crit.forward_sh(H_sh, A, batch['target_common_slope_amps'], weight=tr.config.edc_loss_weight)
+    edc.backward()
+    loss_h = float(edc.detach())
+    gd = {}
+    for name, p_ in net.named_parameters():
+        if name in grads_c and p_.grad is not None:
+            gc, gh = grads_c[name].double().numpy(), p_.grad.detach().cpu().double().numpy()
+            gd[name] = {'norm_cpu': float(np.linalg.norm(gc)), 'norm_hip': float(np.linalg.norm(gh)),
+                        'max_dev_rel': float(np.abs(gh - gc).max() / (np.abs(gc).max() + 1e-300))}
+    net.zero_grad(set_to_none=True)
     return {'value': receivers * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
+            'value_is_lower_bound': True,
             'host_cpu': host_cpu_model(), 'host_logical_cpus': os.cpu_count(), 'sec_per_step': sec,
             'sample': f'host CPU {host_cpu_model()} ({os.cpu_count()} logical CPUs, {cores} threads used); ONE band-step '
                       f'(SH-domain forward, directional EDC loss, backward; no optimiser update) at {receivers} of the 32 '
-                      f'receivers of a band-step, no warm-up; {sec:.1f} s.  The feedback-loop solve (65 537 bins x 27 lines) '
-                      'does not depend on the number of receivers: the per-receiver rate of a full batch would be higher',
+                      f'receivers of a band-step, after one warm-up call; {sec:.1f} s.  The feedback-loop solve (65 537 bins x '
+                      '27 lines) does not depend on the number of receivers, so this per-receiver rate is a LOWER bound of '
+                      'the rate of a full 32-receiver batch -- not to be divided into the GPU figure',
             'loss_delta_vs_cpu': {'edc_loss': {'cpu': float(loss_c), 'hip': loss_h,
-                                               'rel': abs(loss_h - float(loss_c)) / abs(float(loss_c))}}}
+                                               'rel': abs(loss_h - float(loss_c)) / abs(float(loss_c))},
+                                  'gradients': gd}}
 
 
 def self_launch(args) -> int:
@@ -596,13 +621,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
-                    help='weak: 32 receivers per band per RANK; strong: the global batch of 32 per band split over ranks')
+    ap.add_argument('--scaling', choices=('auto', 'weak', 'strong'), default='auto',
+                    help='auto (default): N = 1 the step at batch 32; N > 1 the headline is STRONG scaling (the reference\'s '
+                         'global batch of 32 per band split over the ranks) with the weak figure (32 receivers per band per '
+                         'RANK) and the band-sharded placement in "extra"; weak / strong: that one measurement only')
     ap.add_argument('--config', choices=('omni', 'directional'), default='omni',
                     help='omni: BASELINE.json configs[1]/[2] (the headline); directional: configs[3] (2nd-order ambisonics)')
     ap.add_argument('--epoch', action='store_true',
                     help='time whole epochs (19 train + 5 validation steps + checkpoints); --steps = epochs timed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the N = 32 and directional sub-records of the default N = 1 line')
+    ap.add_argument('--extra-steps', type=int, default=40, help='timed steps of each sub-record')
     ap.add_argument('--dir-streams', type=int, default=2,
                     help='--config directional: streams the independent bands\' graph replays are spread over')
     ap.add_argument('--captured-allreduce', action='store_true',
@@ -645,9 +675,6 @@ def main():
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         if args.gpus != world:
             raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if args.scaling == 'strong' and BATCH % world:
-        raise SystemExit(f"--scaling strong splits the batch of {BATCH} receivers per band: {world} ranks do not divide it")
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # host-side torch ops on tiny CPU tensors (index lists) crawl when the intra-op pool spans all 256 host cores
@@ -682,10 +709,107 @@ def main():
             dist.destroy_process_group()
         return
 
+    out = run_omni(args, device, rank, world, ranks_seen, rank_devices)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()                 # rank 0 may still be in its roofline / baseline legs
+        dist.destroy_process_group()
+
+
+def timed_steps(step, draws, args, world, device, eager=False, per_step_copy=False):
+    """warm-up, then EXACTLY ``args.steps`` steps between barrier + synchronize on both sides; returns (seconds, max over
+    the ranks; the last step's loss parts)."""
+    warm, timed = draws
+    scheduled = not eager and not per_step_copy and hasattr(step, 'run_schedule')
+
+    def one_step(sel):
+        if eager:                            # the same launch sequence as the graph, launched from the host
+            step._load_inputs(sel)
+            return step._eager()
+        return step(sel)
+
+    if scheduled:
+        for parts in step.run_schedule(warm):
+            pass
+    else:
+        for sel in warm:
+            one_step(sel)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if scheduled:
+        for parts in step.run_schedule(timed):           # (uploads the schedule inside the timed region)
+            pass
+    else:
+        for sel in timed:
+            parts = one_step(sel)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, parts
+
+
+def run_band_sharded(args, device, rank, world, centres):
+    """The reference's own parallel axis at its own batch size: whole bands over the ranks (rank r trains bands r, r + N,
+    ... with the reference's batch of 32 receivers each, run_subband_training_treble.py:175-204 spread over GPUs) -- no
+    collective at all.  Whole-job rate = bands x 32 receivers x steps / the slowest rank's time."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    mine = [(q, f) for q, f in enumerate(centres) if q % world == rank]
+    step = draws = None
+    if mine:
+        nets, datasets, filts, splits = [], [], [], []
+        tmax = band_t60max(len(centres), args.distinct_t60)
+        for q, f in mine:
+            room, data, net, tc, split, filt, delays = build_workload(device, 1234 + q, args.receivers, centre_hz=f,
+                                                                      room_seed=q, make_trainer=False, t60max=tmax[q])
+            nets.append(net), datasets.append(data), filts.append(filt), splits.append(split)
+        bank = BandBank(nets)
+        tr = BandBankTrainer(bank, trainer_config(500.0, 20, train_dir='/tmp/gfdn_bench/train_bs'),
+                             subband_filter_freq_resp=torch.stack(filts), band_names=[int(f) for _, f in mine],
+                             data_parallel=False)
+        sds = BandStackedDataset(datasets, free_sources=True)
+        sds.precompute_decay_targets(WIN, *tr._target_window(K))
+        gen = torch.Generator().manual_seed(300 + rank)
+        st = [torch.tensor(s_[0]) for s_ in splits]
+        draw = lambda: sds.global_rows([t[torch.randperm(len(t), generator=gen)[:BATCH]].tolist() for t in st])
+        step = tr.graphed(sds, BATCH)
+        draws = ([draw() for _ in range(args.warmup)], [draw() for _ in range(args.steps)])
+    if step is not None:
+        elapsed, _ = timed_steps(step, draws, args, world, device)
+    else:                                     # (more ranks than bands: this rank only keeps the barriers company)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rirs = len(centres) * BATCH * args.steps / elapsed
+    return {'placement': f'whole bands over the ranks (rank r: bands r, r + {world}, ...), batch {BATCH} receivers per band, '
+                         'no collective', 'ms_per_step': 1e3 * elapsed / args.steps, 'rirs_per_s': rirs,
+            'value': rirs * FRAMES, 'unit': 'RIR-frames/s', 'bands_on_rank0': len(mine) if rank == 0 else None}
+
+
+def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=False):
+    """The headline workload (BASELINE.json configs[1] / [2], or [4] with --lines-per-group 8).  N = 1: one measurement.
+    N > 1: the headline is STRONG scaling at the reference's global batch of 32 receivers per band (trainer.py:373-379),
+    with the weak-scaling figure (32 receivers per band per RANK) and the band-sharded placement beside it in ``extra``."""
     from diffgfdn_amd import hip_ops
     nbands = args.bands
     use_bank = not args.classic
-    b_local = BATCH if args.scaling == 'weak' else BATCH // world
+    scaling = args.scaling if args.scaling != 'auto' else ('strong' if world > 1 else 'weak')
+    if scaling == 'strong' and BATCH % world:
+        raise SystemExit(f"strong scaling splits the batch of {BATCH} receivers per band: {world} ranks do not divide it")
+    b_local = BATCH if scaling == 'weak' else BATCH // world
     if not use_bank:
         room, data, net, trainer, split, filt, delays = build_workload(device, seed=1234,
                                                                       num_receivers=args.receivers)
@@ -698,6 +822,8 @@ def main():
             t60max=band_t60max(len(centres), args.distinct_t60))
 
     epoch_info = None
+    extra = {}
+    step = None
     if args.epoch:
         # ---- whole epochs of the reference's loop (trainer.py:345-424) for all bands in lockstep
         if not use_bank:
@@ -731,13 +857,14 @@ def main():
                       'speedup_vs_reference_epoch': REFERENCE_EPOCH_S_PER_BAND * nbands / (elapsed / len(ep))}
         total, ktimes, iso = torch.tensor(trainer.train_loss)[:, -1], {}, {}
         value = rirs_per_s * FRAMES
+        scaling = 'strong'               # (an epoch is a fixed amount of work whatever the number of ranks)
     else:
         # every rank draws its own receivers (different shards of the global batch of every band)
         gen = torch.Generator().manual_seed(100 + rank)
         splits_t = [torch.tensor(s[0]) for s in splits]
 
-        def draw():
-            sel = [t[torch.randperm(len(t), generator=gen)[:b_local]].tolist() for t in splits_t]
+        def draw_n(nrec):
+            sel = [t[torch.randperm(len(t), generator=gen)[:nrec]].tolist() for t in splits_t]
             return sel[0] if not use_bank else data.global_rows(sel)
 
         # N > 1: the step is two graphs with the (eager) RCCL all-reduce of the gradient bucket between them unless
@@ -749,76 +876,49 @@ def main():
         step = trainer.graphed(data, b_local)      # normalize + train_step as ONE HIP-graph replay
         if args.pipe_steps is not None:
             step.pipe_steps = args.pipe_steps
-
-        def one_step():
-            sel = draw()
-            if args.eager:                       # the same launch sequence as the graph, launched from the host
-                if step.graph_a is None and not getattr(step, '_warm', False):
-                    step._warm = True
-                step._load_inputs(sel)
-                losses = step._eager()
-                return losses['_total'], losses
-            losses = step(sel)
-            return losses['_total'], losses
-
-        # The batches are drawn up front and handed over as a schedule, as an epoch of the reference's DataLoader is
-        # (trainer.py:373-379): every replayed step fetches the next step's receivers on the device.  (--eager keeps
-        # the per-step host copy: it is the diagnostic launch sequence.)
-        scheduled = not args.eager and not args.per_step_copy and hasattr(step, 'run_schedule')
-        warm = [draw() for _ in range(args.warmup)]
-        timed = [draw() for _ in range(args.steps)]
-        if scheduled:
-            for parts in step.run_schedule(warm):
-                pass
-        else:
-            for _ in range(args.warmup):
-                one_step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if scheduled:
-            for parts in step.run_schedule(timed):           # (uploads the schedule inside the timed region)
-                pass
-            total = parts['_total']
-        else:
-            for _ in range(args.steps):
-                total, parts = one_step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        draws = ([draw_n(b_local) for _ in range(args.warmup)], [draw_n(b_local) for _ in range(args.steps)])
+        elapsed, parts = timed_steps(step, draws, args, world, device, eager=args.eager, per_step_copy=args.per_step_copy)
+        total = parts['_total']
 
         # roofline leg (rank 0): the SAME launch sequence on the same streams, launched from the host so that the
         # dominant kernel can be bracketed by HIP events on its stream -- its duration in the step, beside its
         # duration alone on the chip
         ktimes, iso = {}, {}
-        if rank == 0 and use_bank and world == 1 and getattr(trainer, '_fused', None) is not None:
+        if rank == 0 and use_bank and world == 1 and getattr(trainer, '_fused', None) is not None and not sub_record:
             hip_ops.kernel_timer.watch = DOMINANT_KERNEL
             hip_ops.kernel_timer.start()
             for _ in range(ROOFLINE_EAGER_STEPS):
-                batch = data.collate(draw())
+                batch = data.collate(draw_n(b_local))
                 trainer._fused.run(batch, step.maskw, 1.0, normalize_first=True, train=True, opt_step=False)
             ktimes = hip_ops.kernel_timer.stop()
-            iso = isolated_kernel_us(device, nbands * b_local)
-        if world > 1:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            iso = isolated_kernel_us(device, data, trainer, draw_n(b_local), nbands)
         ms_per_step = 1e3 * elapsed / args.steps
         rirs_per_s = nbands * b_local * world * args.steps / elapsed
         value = rirs_per_s * FRAMES
 
+        if world > 1 and use_bank and args.scaling == 'auto':
+            # ---- beside the strong-scaling headline: weak scaling (32 receivers per band per RANK, global batch 32 N) on
+            # the same models and data, and the band-sharded placement (no collective)
+            wstep = trainer.graphed(data, BATCH)
+            wdraws = ([draw_n(BATCH) for _ in range(args.warmup)], [draw_n(BATCH) for _ in range(args.steps)])
+            wel, _ = timed_steps(wstep, wdraws, args, world, device)
+            wr = nbands * BATCH * world * args.steps / wel
+            extra['weak'] = {'scaling': 'weak', 'batch_per_band_per_gpu': BATCH, 'global_batch_per_band': BATCH * world,
+                             'ms_per_step': 1e3 * wel / args.steps, 'rirs_per_s': wr, 'value': wr * FRAMES,
+                             'unit': 'RIR-frames/s'}
+            del wstep
+            extra['band_sharded'] = run_band_sharded(args, device, rank, world, centres)
+
+    out = None
     if rank == 0:
         graph_mode = 'eager' if args.eager else 'hip_graph'
         if world > 1 and not args.eager and not args.epoch:
             graph_mode += ' (all-reduce captured)' if step.allreduce_in_graph else ' (two graphs, eager all-reduce)'
+        fused = getattr(trainer, '_fused', None)
         out = {
             'metric': 'RIR-frames/sec', 'value': value, 'unit': 'RIR-frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic', 'ranks_seen': ranks_seen,
             'config': {'workload': f'{nbands} octave-band GFDN(s) ({", ".join(str(int(f)) for f in centres)} Hz), each '
                                    f'N={G * NPER} ({G} groups x {NPER}) on a {args.receivers}-receiver grid, nfft 131072 '
@@ -832,6 +932,18 @@ def main():
                        'band_t60max_s': band_t60max(len(centres), args.distinct_t60) if use_bank else [1.5],
                        'band_edc_windows': ((trainer._band_windows(K) or [trainer._decay_window(K)[1]] * nbands)
                                             if use_bank else [trainer._decay_window(K)[1]]),
+                       'output_stage': (None if fused is None else
+                                        ('time domain: x[b] = xd[row_b] + sum_g gain[b][g] irfft(T_g filt) -- G transforms '
+                                         'per band and step instead of one per receiver' if fused.linear_transforms else
+                                         'per receiver in the frequency domain, one transform per receiver pair')),
+                       'edr_loss': (None if fused is None else
+                                    ('on composed short-time spectra Sd[row_b] + sum_g gain[b][g] STFT(tau_g): G STFTs per '
+                                     'band and step, none per receiver' if (fused.linear_transforms and fused.spectral_edr)
+                                     else 'per-receiver STFT of the stored time signals')),
+                       'dataset_constants': ('precomputed once per dataset before the timed region, like the rFFT front end '
+                                             '(SURVEY section 8d): target EDR / EDC; xd = irfft(early response x band filter) '
+                                             'per receiver; Sd = STFT(xd) per receiver -- parameter-independent linear images '
+                                             'of the dataset'),
                        'launch': graph_mode, 'rank_devices': rank_devices,
                        'collective': (None if world == 1 else
                                       {'backend': dist.get_backend(), 'library_version': collective_version(),
@@ -839,6 +951,8 @@ def main():
                                        'floats': int(trainer.optimizer.bucket.numel())}),
                        'final_loss': [float(v) for v in torch.as_tensor(total).reshape(-1).tolist()]},
         }
+        if extra:
+            out['extra'] = extra
         if epoch_info is not None:
             out['epoch'] = epoch_info
         if ktimes:
@@ -858,16 +972,50 @@ def main():
                                'launches': ktimes['launches'], 'alg_bytes_per_unit': per,
                                'alg_bytes_per_launch': units * per, 'units_per_launch': units,
                                'top': roofline_top(int(round(units)))}
-        out['build'] = library_stamp()
+        if not sub_record:
+            out['build'] = library_stamp()
         out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS
         out['whole_step_alg_GBs'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not sub_record:
             out['cpu_baseline'] = cpu_baseline(room, delays, filt.cpu().numpy().astype(np.complex128), device=device,
                                                steps=args.cpu_steps)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()                 # rank 0 may still be in its roofline / baseline legs
-        dist.destroy_process_group()
+    # ---- the other two BASELINE.json configurations on the same clock (N = 1, default run): short sub-records
+    if world == 1 and not sub_record and not args.no_extras and not args.epoch and use_bank and nbands == len(BAND_CENTRES) \
+            and NPER == 4:
+        del step, trainer, data, net
+        torch.cuda.empty_cache()
+        out.setdefault('extra', {})
+        out['extra']['n32'] = sub_bench(args, device, 'n32')
+        torch.cuda.empty_cache()
+        out['extra']['directional'] = sub_bench(args, device, 'directional')
+    return out
+
+
+def sub_bench(args, device, which):
+    """BASELINE.json configs[4] (N = 32 = 4 x 8 lines) / configs[3] (directional) as short sub-records of the default line, so
+    that the driver's clock covers them too: ``--extra-steps`` timed steps after 5 warm-up steps, no roofline / CPU legs
+    (those are in ``bench.py --lines-per-group 8`` / ``--config directional``)."""
+    import copy
+    a = copy.copy(args)
+    a.steps, a.warmup, a.no_cpu_baseline = args.extra_steps, 5, True
+    t0 = time.perf_counter()
+    if which == 'n32':
+        globals()['NPER'] = 8
+        try:
+            r = run_omni(a, device, 0, 1, [0], [0], sub_record=True)
+        finally:
+            globals()['NPER'] = 4
+        keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'whole_step_hbm_frac')
+        rec = {k: r[k] for k in keep}
+        rec['config'] = {k: r['config'][k] for k in ('workload', 'delay_lines', 'rirs_per_s', 'final_loss')}
+    else:
+        r = run_directional(a, device, 0, 1)
+        rec = {k: r[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup')}
+        rec['config'] = {k: r['config'][k] for k in ('workload', 'delay_lines', 'rirs_per_s', 'ms_per_band_step', 'final_loss')}
+        if 'roofline' in r:
+            rec['roofline'] = r['roofline']
+    rec['wall_s_incl_build'] = time.perf_counter() - t0
+    return rec
 
 
 if __name__ == '__main__':

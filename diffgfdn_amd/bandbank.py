@@ -268,11 +268,22 @@ class BandStackedDataset:
             self._direct_time = (key, out)
         return self._direct_time[1]
 
-    def direct_stft(self, filt: Optional[torch.Tensor], n: int, win: int, chunk: int = 64) -> torch.Tensor:
+    def edr_target_tiled(self) -> torch.Tensor:
+        """The target EDR store in the tiled cell order of csrc/edrlin.hip (``ops.spec_tile``); built once, cached."""
+        T = self.edr_store[1]
+        cache = getattr(self, '_edr_tiled', None)
+        if cache is None or cache[0] != (T.data_ptr(), tuple(T.shape)):
+            out = torch.empty_like(T)
+            for r0 in range(0, T.shape[0], 256):
+                out[r0:r0 + 256] = ops.spec_tile(T[r0:r0 + 256])
+            self._edr_tiled = ((T.data_ptr(), tuple(T.shape)), out)
+        return self._edr_tiled[1]
+
+    def direct_stft(self, filt: Optional[torch.Tensor], n: int, win: int, chunk: int = 64, tiled: bool = False) -> torch.Tensor:
         """Sd (bands*R, nframes, win / 2 + 1) complex64: the STFT (Hann ``win``, hop win / 2, as losses.py:501-553) of every
         row of ``direct_time`` -- the short-time spectrum of a receiver's signal is Sd[row] + sum_g gain_g STFT(tau_g) (the
         STFT is linear), which is what the EDR kernels of csrc/edrlin.hip compose on the fly.  Built once, cached."""
-        key = (None if filt is None else (filt.data_ptr(), tuple(filt.shape)), int(n), int(win))
+        key = (None if filt is None else (filt.data_ptr(), tuple(filt.shape)), int(n), int(win), bool(tiled))
         cache = getattr(self, '_direct_stft', None)
         if cache is None or cache[0] != key:
             xd = self.direct_time(filt, n)
@@ -284,7 +295,7 @@ class BandStackedDataset:
                 if m % 2:
                     blk = torch.cat([blk, torch.zeros_like(blk[:1])])
                 x2 = torch.stack((blk[0::2], blk[1::2]), dim=-1).contiguous()
-                out[r0:r0 + m] = ops.stft_pairs_spectrum(x2, m, win)
+                out[r0:r0 + m] = ops.stft_pairs_spectrum(x2, m, win, tiled=tiled)
             self._direct_stft = (key, out)
         return self._direct_stft[1]
 
@@ -367,7 +378,10 @@ class BandBankTrainer:
 
     def __init__(self, bank: BandBank, trainer_config: TrainerConfig,
                  subband_filter_freq_resp: Optional[torch.Tensor] = None, process_group=None,
-                 stft_win: int = 4096, band_names: Optional[Sequence] = None):
+                 stft_win: int = 4096, band_names: Optional[Sequence] = None, data_parallel: bool = True):
+        """``data_parallel=False``: this process trains its bands on its own even when torch.distributed is initialised --
+        the band-sharded placement (whole bands over ranks, run_subband_training_treble.py:175-204 spread over GPUs), which
+        needs no collective at all."""
         cfg = trainer_config
         if not cfg.use_colorless_loss or not bank.use_colorless_loss:
             raise NotImplementedError("BandBankTrainer follows the sub-band recipe (colorless loss on)")
@@ -406,8 +420,9 @@ class BandBankTrainer:
         self._band_criteria = [edc_loss(ms, bank.sample_rate, use_mask=cfg.use_edc_mask) for ms in self.band_ir_len_ms]
         self._win_cache = {}
         self.process_group = process_group
-        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        sharded = data_parallel and dist.is_initialized()
+        self.world_size = dist.get_world_size(process_group) if sharded else 1
+        self.rank = dist.get_rank(process_group) if sharded else 0
         self._allreduce = None
         if self.world_size > 1:
             opt, pg = self.optimizer, process_group

@@ -89,6 +89,9 @@ class FusedBankStep:
     # (OFF: 213 us against 99 + 83 for the two launches -- one 128 KB workgroup per CU keeps too few loads in flight and
     # starves the colorless pass beside it of LDS; csrc/edrlin.hip)
     edr_one_launch = os.environ.get('GFDN_EDR_ONE_LAUNCH', '0') == '1'
+    # ... on planes stored in the tiled cell order (frequency blocks of 256, a block's frames contiguous): what a (receiver,
+    # frequency block) workgroup of the EDR kernel touches is one contiguous run
+    tiled_spectra = os.environ.get('GFDN_TILED_SPECTRA', '1') == '1'
     # ... and the G sums of the EDC gradient signals together with the EDC part of dL/drgain in one sweep over the window
     gamma_dots_one_launch = os.environ.get('GFDN_GAMMA_DOTS_ONE_LAUNCH', '1') == '1'
     # ... with the combine pass folded into the STFT's load (gfdn_stft_power_pairs_lin): x is stored by the launch that
@@ -224,10 +227,13 @@ class FusedBankStep:
         tr, cfg, keep = self.tr, self.tr.config, self._keep
         Btot, win = rows.numel(), tr.stft_win
         ds = data['dataset']
-        Sd = ds.direct_stft(tr.subband_filter_freq_resp, K, win)
+        tiled = self.tiled_spectra and not self.edr_one_launch
+        Sd = ds.direct_stft(tr.subband_filter_freq_resp, K, win, tiled=tiled)
+        if tiled:
+            T_edr = ds.edr_target_tiled()
         on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
         ev['x'].record()                                     # (tau complete)
-        Stau = ops.stft_pairs_spectrum(tau, nb * G, win)
+        Stau = ops.stft_pairs_spectrum(tau, nb * G, win, tiled=tiled)
         with on_side2():
             torch.cuda.current_stream().wait_event(ev['x'])
             li_edc, g_edc = ops.edc_loss_pairs_lin(xd, rows, tau, rgain, nb, K, start, length, T_edc, maskw, inv,
@@ -246,7 +252,7 @@ class FusedBankStep:
                                                col0=nch)
         else:
             li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
-                                          dots=parts, col0=nch)
+                                          dots=parts, col0=nch, tiled=tiled)
         ev['g'].record()                                     # (EDR partials and the EDR columns of ``parts`` complete)
         keep.extend((Sd, Stau, li_edc, g_edc, li_edr, gP, parts))
         if not train:
@@ -254,7 +260,7 @@ class FusedBankStep:
             return li_edr, li_edc, None
         if Gs is None:
             Gs = ops.edr_lin_gsum(Sd, rows, Stau, rgain, nb, gP)
-        gam_edr = ops.stft_pairs_spectrum_bwd(Gs, K, nb * G, win)
+        gam_edr = ops.stft_pairs_spectrum_bwd(Gs, K, nb * G, win, tiled=tiled)
         keep.extend((Gs, gam_edr))
         return li_edr, li_edc, (g_edc, gam_edr, parts)
 

@@ -23,6 +23,17 @@ extern __shared__ float2 edl_lds[];
 #define EDL_RF 32
 #define EDL_MAXG 4
 
+// Cell order of the (nframes, nfreq) planes.  Plain: cell = m nfreq + f.  TILED: the frequencies are cut into blocks of 256
+// and a block's frames are contiguous -- cell = fb nframes 256 + m w + (f - 256 fb), w = the block's width (256; the last
+// block holds the rest) -- so that everything a (receiver, frequency-block) workgroup of k_edr_lin_cols touches is ONE
+// contiguous run (64 KB of Sd, 32 KB of target, 32 KB of dL/d|S|^2) instead of 32 runs of 2 KB / 1 KB at a 16 KB / 8 KB
+// stride.  The planes have the same number of cells either way.
+__device__ __forceinline__ size_t edl_cell(int m, int f, int nframes, int nfreq, int tiled) {
+  if (!tiled) return (size_t)m * nfreq + f;
+  const int fb = f >> 8, w = nfreq - (fb << 8) < 256 ? nfreq - (fb << 8) : 256;
+  return (size_t)fb * nframes * 256 + (size_t)m * w + (f & 255);
+}
+
 struct EdrLin {
   const float2* Sd;            // (R, nframes, nfreq) complex: STFT of the transformed direct paths
   const long long* rows;       // item -> row of Sd, Tdb, sum_abs (NULL: identity)
@@ -31,6 +42,7 @@ struct EdrLin {
   int B, G;
   const float* Tdb;            // (R, nframes, nfreq) target EDR in dB
   const float* sum_abs;        // (R) sum |target EDR|
+  int tiled;                   // cell order of Sd, Stau, Tdb, gP, Gsum (edl_cell)
 };
 
 // One thread per (receiver, frequency) column, one descending sweep over the frames (see the body).
@@ -66,9 +78,12 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
   float acc = 0.f, dacc[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
   const int f = fb * 256 + threadIdx.x;
   if (f < nfreq) {
-    const float2* sd = a.Sd + row * cells + f;
-    const float2* st = a.Stau + (size_t)band * G * cells + f;
-    const float* t = a.Tdb + row * cells + f;
+    // (column walk: cell(m) = c0 + m cs)
+    const size_t c0 = edl_cell(0, f, nframes, nfreq, a.tiled);
+    const size_t cs = nframes > 1 ? edl_cell(1, f, nframes, nfreq, a.tiled) - c0 : 0;
+    const float2* sd = a.Sd + row * cells + c0;
+    const float2* st = a.Stau + (size_t)band * G * cells + c0;
+    const float* t = a.Tdb + row * cells + c0;
     // ONE descending sweep over the frames: the frame's spectra (direct path, G group spectra) and target are loaded where
     // they are used -- the compiler keeps the loads of the next frames in flight across the dB chain of the current one --
     // S composed in registers, tail energy, dB, |difference|, dL/dE_m; and with the same loads the EDR part of
@@ -78,19 +93,22 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
     // 282-310 us instead of 99 and slowed the EDC scans beside it fourfold: twice the cache traffic in 16 KB strides.)
     float gE[EDL_RF];
     float E = 0.f, ct[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
+    // (Measured, alone on the chip, 235 MB: this form 79 us at 112 registers, 4 waves per SIMD; the sweep in chunks of 8
+    // frames whose loads are issued before the chunk's dependent chain: 196 registers, 2 waves, 89 us; chunks of 4 under a
+    // 128-register cap: spills, 111 us.)
 #pragma unroll
     for (int m = EDL_RF - 1; m >= 0; --m) {
       gE[m] = 0.f;
       if (m < nframes) {
-        float2 sv = sd[(size_t)m * nfreq];
+        float2 sv = sd[(size_t)m * cs];
         float2 tg[EDL_MAXG];
 #pragma unroll
         for (int g = 0; g < EDL_MAXG; ++g) {
-          tg[g] = g < G ? st[(size_t)g * cells + (size_t)m * nfreq] : make_float2(0.f, 0.f);
+          tg[g] = g < G ? st[(size_t)g * cells + (size_t)m * cs] : make_float2(0.f, 0.f);
           sv.x += rg[g] * tg[g].x;
           sv.y += rg[g] * tg[g].y;
         }
-        const float tvm = t[(size_t)m * nfreq];
+        const float tvm = t[(size_t)m * cs];
         E += sv.x * sv.x + sv.y * sv.y;
         const float lin = fabsf(E) + F32_EPS;
         const float raw = 10.0f * log10f(lin);
@@ -109,13 +127,13 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
       }
     }
     if (want_grad) {
-      float* gp = gP + (size_t)b * cells + f;
+      float* gp = gP + (size_t)b * cells + c0;
       float run = 0.f;
 #pragma unroll
       for (int m = 0; m < EDL_RF; ++m) {
         if (m < nframes) {
           run += gE[m];                                          // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m'
-          gp[(size_t)m * nfreq] = run;
+          gp[(size_t)m * cs] = run;
         }
       }
     }
@@ -361,7 +379,7 @@ __device__ __forceinline__ void edl_load_pair(const float2* __restrict__ x2, int
 
 // S (items, nframes, 2049) complex: S[2p] from the .x signal of pair p, S[2p + 1] from its .y signal
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec(const float2* __restrict__ x2, int ld, int T, int nframes,
-                                                            int items, float2* __restrict__ S) {
+                                                            int items, float2* __restrict__ S, int tiled) {
   float2* buf = edl_lds;
   const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
@@ -373,16 +391,17 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec(const float2* __r
 #pragma unroll
   for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
   __syncthreads();
-  float2* S1 = S + ((size_t)b1 * nframes + m) * nf;
+  float2* S1 = S + (size_t)b1 * nframes * nf;
   float2* S2 = S1 + (size_t)nframes * nf;
 #pragma unroll
   for (int u = 0; u < 9; ++u) {
     const int f = i + 256 * u;
     if (u < 8 || i == 0) {
       const float2 zf = a[u], zc = buf[S4K_PAD((4096 - f) & 4095)];
+      const size_t c = edl_cell(m, f, nframes, nf, tiled);
       // S_a = (Z_f + conj Z_{W-f}) / 2 ; S_b = (Z_f - conj Z_{W-f}) / (2i)
-      S1[f] = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
-      if (two) S2[f] = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
+      S1[c] = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
+      if (two) S2[c] = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
     }
   }
 }
@@ -401,12 +420,12 @@ __constant__ float2 c_edl_hann[16] = {
 // even frame reaches), the odd launch adds with a plain read-modify-write -- no atomics, no cleared buffer.
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2* __restrict__ Gs, int ld, int T,
                                                                 int nframes, int items, const float2* base2,
-                                                                float2* gx2, int parity) {
+                                                                float2* gx2, int parity, int tiled) {
   float2* buf = edl_lds;
   const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
   const bool two = b1 + 1 < items;
-  const float2* ga = Gs + ((size_t)b1 * nframes + m) * nf;
+  const float2* ga = Gs + (size_t)b1 * nframes * nf;
   const float2* gb = ga + (size_t)nframes * nf;
   float sn, cs;
   sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
@@ -417,7 +436,8 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2*
     const int f = i + 256 * u;
     if (u < 8 || i == 0) {
       const int fc = (4096 - f) & 4095;
-      const float2 Ga = ga[f], Gb = two ? gb[f] : make_float2(0.f, 0.f);
+      const size_t c = edl_cell(m, f, nframes, nf, tiled);
+      const float2 Ga = ga[c], Gb = two ? gb[c] : make_float2(0.f, 0.f);
       if (f == 0 || f == 2048) {
         buf[S4K_PAD(f)] = make_float2(Ga.x, Gb.x);                                       // real-only bins
       } else {
@@ -454,19 +474,20 @@ static int edl_nframes(int T) {
   return Tp < 4096 ? 0 : (Tp - 4096) / 2048 + 1;
 }
 
-extern "C" int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, void* stream) {
+extern "C" int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, int tiled,
+                                        void* stream) {
   if (!x2 || !S_c64 || items <= 0 || T <= 0 || ld < T) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = edl_nframes(T);
   if (nframes <= 0) return GFDN_E_BADARG;
   hipLaunchKernelGGL(k_stft4k_pair_spec, dim3(nframes, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
-                     (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, (float2*)S_c64);
+                     (hipStream_t)stream, (const float2*)x2, ld, T, nframes, items, (float2*)S_c64, tiled ? 1 : 0);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2,
-                                            int ld, void* stream) {
+                                            int ld, int tiled, void* stream) {
   if (!G_c64 || !gx2 || items <= 0 || T <= 0 || ld < T || base2 == gx2) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = edl_nframes(T);
@@ -476,7 +497,7 @@ extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items
     if (nb == 0) continue;
     hipLaunchKernelGGL(k_stft4k_pair_spec_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
                        (hipStream_t)stream, (const float2*)G_c64, ld, T, nframes, items, (const float2*)base2,
-                       (float2*)gx2, parity);
+                       (float2*)gx2, parity, tiled ? 1 : 0);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
@@ -492,14 +513,14 @@ extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return nfreq > 0 ? (nfreq +
 extern "C" int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
                                  int nbands, int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq,
                                  float gscale, int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0,
-                                 void* stream) {
+                                 int tiled, void* stream) {
   if (!Sd_c64 || !Stau_c64 || !rgain || !T_db || !sum_abs || !part || nbands <= 0 || B <= 0 || G <= 0 || nframes <= 0 ||
       nfreq <= 0 || (want_grad && !gP))
     return GFDN_E_BADARG;
   const int fblk = (nfreq + 255) / 256;
   if (G > EDL_MAXG || nframes > EDL_RF || nbands * B > 65535) return GFDN_E_UNSUPPORTED;
   if (dots && (col0 < 0 || ld_dots < col0 + fblk)) return GFDN_E_BADARG;
-  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs};
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, tiled ? 1 : 0};
   const int nslices = nbands * fblk;
   hipLaunchKernelGGL(k_edr_lin_cols, dim3(8 * ((nslices + 7) / 8) * B), dim3(256), 0, (hipStream_t)stream, a, nframes, nfreq,
                      gscale, want_grad, gP, part, dots, ld_dots, col0, nslices);
@@ -519,7 +540,7 @@ extern "C" int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows
   const int ntiles = (nfreq + EDL_FT - 1) / EDL_FT;
   if (G > EDL_MAXG || nframes > EDL_RF || nbands > 65535) return GFDN_E_UNSUPPORTED;
   if (dots && (col0 < 0 || ld_dots < col0 + ntiles)) return GFDN_E_BADARG;
-  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs};
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, 0};
   const size_t lds = (size_t)(G + 4) * nframes * EDL_FT * sizeof(float2);
   int rc = ensure_dyn_lds(k_edr_lin_fused, lds);
   if (rc) return rc;
@@ -536,7 +557,7 @@ extern "C" int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, con
   if (!Sd_c64 || !Stau_c64 || !rgain || !gP || !Gsum_c64 || nbands <= 0 || B <= 0 || G <= 0 || nframes <= 0 || nfreq <= 0)
     return GFDN_E_BADARG;
   if (G > EDL_MAXG || B * G > 256 || B > 64 || nbands > 65535) return GFDN_E_UNSUPPORTED;
-  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, nullptr, nullptr};
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, nullptr, nullptr, 0};
   const size_t cells = (size_t)nframes * nfreq;
   hipLaunchKernelGGL(k_edr_lin_gsum, dim3((unsigned)((cells + 255) / 256), nbands), dim3(256), 0, (hipStream_t)stream, a, gP,
                      nframes, nfreq, (float2*)Gsum_c64);

@@ -1155,19 +1155,39 @@ def lin_gain_chunks(n: int) -> int:
 
 
 # ---- the EDR loss on linearly composed short-time spectra (csrc/edrlin.hip) ------------------------------------------
-def stft_pairs_spectrum(x2, items: int, win: int) -> torch.Tensor:
-    """x2 (ceil(items / 2), T, 2) pair-interleaved signals -> S (items, nframes, win / 2 + 1) complex64 (win = 4096)."""
+def spec_tile(P: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """(..., nframes, nfreq) planes between the plain cell order (m nfreq + f) and the TILED one of csrc/edrlin.hip
+    (frequency blocks of 256, a block's frames contiguous); the result has the same shape (a flat re-ordering of the last
+    two axes).  One-off use: dataset stores and tests."""
+    nframes, nfreq = P.shape[-2], P.shape[-1]
+    lead = P.shape[:-2]
+    flat = P.reshape(*lead, nframes * nfreq)
+    out = torch.empty_like(flat)
+    off = 0
+    for f0 in range(0, nfreq, 256):
+        w = min(256, nfreq - f0)
+        if inverse:
+            out.view(*lead, nframes, nfreq)[..., f0:f0 + w] = flat[..., off:off + nframes * w].reshape(*lead, nframes, w)
+        else:
+            out[..., off:off + nframes * w] = P[..., f0:f0 + w].reshape(*lead, nframes * w)
+        off += nframes * w
+    return out.view(*lead, nframes, nfreq)
+
+
+def stft_pairs_spectrum(x2, items: int, win: int, tiled: bool = False) -> torch.Tensor:
+    """x2 (ceil(items / 2), T, 2) pair-interleaved signals -> S (items, nframes, win / 2 + 1) complex64 (win = 4096);
+    ``tiled``: the planes in the tiled cell order (spec_tile)."""
     _need_gpu(x2)
     if x2.dtype != _f32 or not x2.is_contiguous() or x2.dim() != 3 or x2.shape[2] != 2 or x2.shape[0] != (items + 1) // 2:
         raise RuntimeError("stft_pairs_spectrum: x2 must be contiguous float32 (ceil(items / 2), T, 2)")
     T = x2.shape[1]
     S = torch.empty((items, stft_nframes(T, win), win // 2 + 1), dtype=_c64, device=x2.device)
-    _lib.check(_lib.load().gfdn_stft_pairs_spectrum(_p(x2), T, T, items, win, _p(S), _stream()),
+    _lib.check(_lib.load().gfdn_stft_pairs_spectrum(_p(x2), T, T, items, win, _p(S), int(tiled), _stream()),
                "gfdn_stft_pairs_spectrum")
     return S
 
 
-def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None) -> torch.Tensor:
+def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: bool = False) -> torch.Tensor:
     """Adjoint of stft_pairs_spectrum: gradient spectra G (items, nframes, win / 2 + 1) complex64 -> gx2
     (ceil(items / 2), n, 2) [+ base, same layout]."""
     _need_gpu(G)
@@ -1177,7 +1197,7 @@ def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None) -> torch
     gx2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=G.device)
     if base is not None and (base.dtype != _f32 or not base.is_contiguous() or base.shape != gx2.shape):
         raise RuntimeError("stft_pairs_spectrum_bwd: base must be shaped like the result")
-    _lib.check(_lib.load().gfdn_stft_pairs_spectrum_bwd(_p(G), n, items, win, _p(base), _p(gx2), n, _stream()),
+    _lib.check(_lib.load().gfdn_stft_pairs_spectrum_bwd(_p(G), n, items, win, _p(base), _p(gx2), n, int(tiled), _stream()),
                "gfdn_stft_pairs_spectrum_bwd")
     return gx2
 
@@ -1188,7 +1208,7 @@ def edr_lin_parts(nfreq: int, fused: bool = False) -> int:
 
 
 def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, want_grad: bool = True,
-                 dots=None, col0: int = 0):
+                 dots=None, col0: int = 0, tiled: bool = False):
     """EDR loss of items whose short-time spectra are Sd[rows[b]] + sum_g rgain[b][g] Stau[band(b) G + g] -- never formed in
     memory.  Sd (R, nframes, nfreq) c64, T_db (R, nframes, nfreq) f32 and sum_abs (R) share the row indirection.
     Returns (part (items, edr_lin_parts) -- the deferred partial sums of edr_loss(defer=True) --, gP (items, nframes, nfreq)
@@ -1214,9 +1234,13 @@ def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: floa
                 or dots.shape[1] < col0 + fblk:
             raise RuntimeError("edr_lin_loss: dots must be (items * G, >= col0 + parts) contiguous float32")
         ld = dots.shape[1]
+    end = kernel_timer.bracket('k_edr_lin_cols', items)          # (bench.py's roofline leg: events on the launch stream)
     _lib.check(lib.gfdn_edr_lin_loss(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(T_db),
                                      _p(_f(sum_abs)), nframes, nfreq, float(gscale), int(want_grad), _p(gP), _p(part),
-                                     _p(dots if want_grad else None), ld, int(col0), _stream()), "gfdn_edr_lin_loss")
+                                     _p(dots if want_grad else None), ld, int(col0), int(tiled), _stream()),
+               "gfdn_edr_lin_loss")
+    if end is not None:
+        end.record()
     return part, gP
 
 

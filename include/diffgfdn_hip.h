@@ -550,14 +550,18 @@ int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nban
  *   gfdn_stft_pairs_spectrum_bwd  : gx2 = [base2 +] adjoint STFT of gradient spectra G (items, nframes, 2049) -- with
  *                                   G = Gsum: the EDR part of dL/dtau.
  * rows: item -> row of Sd / T_db / sum_abs (NULL: identity).  G <= 4, nframes <= 32.                                    */
-int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, void* stream);
+int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, int tiled, void* stream);
 int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2, int ld,
-                                 void* stream);
+                                 int tiled, void* stream);
+/* tiled = 1: the (nframes, nfreq) planes of S / G / Sd / Stau / T_db / gP / Gsum are stored with the frequencies cut into
+ * blocks of 256 and a block's frames contiguous -- cell(m, f) = (f / 256) nframes 256 + m w + f % 256, w = the block's
+ * width (the last block holds the rest) -- so that a (receiver, frequency block) workgroup of gfdn_edr_lin_loss streams
+ * contiguous runs; 0: cell = m nfreq + f.  gfdn_edr_lin_gsum works cell by cell and takes either.                        */
 int gfdn_edr_lin_parts(int nfreq);            /* partial-sum columns of gfdn_edr_lin_loss */
 int gfdn_edr_lin_fused_parts(int nfreq);      /* ... of gfdn_edr_lin_loss_gsum            */
 int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                       int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
-                      int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0, void* stream);
+                      int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0, int tiled, void* stream);
 int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                       int B, int G, const float* gP, int nframes, int nfreq, float* Gsum_c64, void* stream);
 /* gfdn_edr_lin_loss(want_grad = 1) + gfdn_edr_lin_gsum in ONE launch: the band's receivers are summed inside the workgroup

@@ -834,6 +834,9 @@ def test_stft_pairs_spectrum_and_adjoint(items, T):
         assert abs(float(lhs[b] - rhs)) < 2e-5 * abs(float(lhs[b])) + 1e-3, (b, float(lhs[b]), float(rhs))
     if items % 2:
         assert float(gx[-1, :, 1].abs().max()) == 0.0
+    # tiled cell order: the same numbers in another order
+    assert torch.equal(ops.spec_tile(ops.stft_pairs_spectrum(x2, items, 4096, tiled=True), inverse=True), S)
+    assert torch.equal(ops.stft_pairs_spectrum_bwd(ops.spec_tile(G), T, items, 4096, base=base, tiled=True), g2)
 
 
 @pytest.mark.parametrize("G,B", [(4, 4), (3, 2)])
@@ -870,6 +873,15 @@ def test_edr_loss_on_composed_spectra(G, B):
     assert rel_err(Gs.cpu(), Gs_ref.cpu()) < 2e-5
     part2, none = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, False)
     assert none is None and torch.equal(part2, part)
+    # the same on planes in the tiled cell order (frequency blocks of 256, a block's frames contiguous)
+    parts_t = torch.zeros_like(parts)
+    part_t, gP_t = ops.edr_lin_loss(ops.spec_tile(Sd), rows, ops.spec_tile(Stau), rgain, nb, ops.spec_tile(T_db), sum_abs,
+                                    1.5, True, dots=parts_t, col0=nch, tiled=True)
+    assert torch.equal(part_t, part) and torch.equal(parts_t, parts)
+    assert torch.equal(ops.spec_tile(gP_t, inverse=True), gP)
+    assert torch.equal(ops.spec_tile(ops.spec_tile(Sd), inverse=True), Sd)
+    Gs_t = ops.edr_lin_gsum(ops.spec_tile(Sd), rows, ops.spec_tile(Stau), rgain, nb, gP_t)
+    assert torch.equal(ops.spec_tile(Gs_t, inverse=True), ops.edr_lin_gsum(Sd, rows, Stau, rgain, nb, gP))
     # the same as ONE launch (receivers summed inside the workgroup)
     parts3 = torch.zeros(items * G, nch + ops.edr_lin_parts(nf, fused=True), device=DEV)
     part3, Gs3 = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, dots=parts3, col0=nch)
