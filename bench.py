@@ -364,7 +364,7 @@ def pmc_traffic_bytes(kernel: str, table: str = 'pmc_hbm_bytes.csv'):
     path = _profile(table)
     if path is None:
         return None
-    rows = [r for r in csv.DictReader(open(path)) if r['kernel'] == kernel]
+    rows = [r for r in csv.DictReader(open(path)) if r['kernel'].split('<')[0] == kernel]
     if not rows:
         return None
     r = max(rows, key=lambda r_: int(r_['launches']))

@@ -14,7 +14,7 @@
 #include "common.h"
 
 #define SOS_T 256
-#define SOS_MAX_S 12          // sections per cascade (the SVF equaliser has 11)
+#define SOS_MAX_S 24          // sections per cascade (the SVF equaliser has 11; input x output filter of one group: 22)
 #define SOS_MAX_G 8           // cascades (groups) per receiver
 #define SOS_BCH 8             // receivers per workgroup in the dL/dT launch
 #define SOS_KPT 4             // bins per thread in the dL/dcoef launch

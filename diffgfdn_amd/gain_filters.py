@@ -155,6 +155,15 @@ class SVF_from_MLP(nn.Module):
         w = self.mlp.model[0].weight
         return sos_cascade_response(x['z_values'].to(w.device), self.biquad_coefficients(x))
 
+    @torch.no_grad()
+    def get_param_dict(self, x: Dict) -> Dict:
+        """{'svf_params': (B, G, S, 2) constrained [resonance, gain dB], 'biquad_coeffs': (B, G, S, 6)} as numpy arrays
+        (reference gain_filters.py:404-433: what its inference scripts save per position)."""
+        coef = self.biquad_coefficients(x)
+        raw = self.svf_params
+        prm = torch.stack((torch.sigmoid(raw[..., 0]) * (1.0 - 1e-6) + 1e-6, torch.sigmoid(raw[..., 1]) * 12.0 - 6.0), dim=-1)
+        return {'svf_params': prm.squeeze().cpu().numpy(), 'biquad_coeffs': coef.squeeze().cpu().numpy()}
+
     def forward(self, x: Dict) -> torch.Tensor:
         return self.group_responses(x).repeat_interleave(self.num_delay_lines_per_group, dim=1)
 

@@ -549,6 +549,24 @@ class directional_edc_loss(nn.Module):
                                      dtype=torch.float32)
         self.register_buffer('envelopes', torch.as_tensor(envelopes, dtype=torch.float32),
                              persistent=False)
+        # (seed, state, maskw) of a device-side mask generator (ops.draw_mask): when set, every masked evaluation draws its
+        # time mask on the device -- no host read, so the step can be captured into a HIP graph (GraphedModuleStep)
+        self.device_mask = None
+
+    def _time_mask(self, L: int, device):
+        """(maskw or None, what the kernel divides by beyond the weights): losses.py:355-360 draws
+        argwhere(bernoulli(U(0, 1))) over the window on the host; with ``device_mask`` the same fair bits come from the
+        counter-based device generator and the weights arrive divided by the kept count."""
+        if not self.use_mask:
+            return None, float(L)
+        if self.device_mask is not None:
+            seed, state, maskw = self.device_mask
+            if maskw.numel() != L:
+                raise ValueError("device_mask: the weight buffer does not match the EDC window")
+            ops.draw_mask(seed, state, L, 1.0, out=maskw)
+            return maskw, 1.0
+        keep = torch.bernoulli(torch.empty(L).uniform_(0, 1))
+        return keep.to(device=device, dtype=torch.float32), float(keep.sum().item())
 
     def forward(self, H_pred: torch.Tensor, amps_true: torch.Tensor, weight: float = 1.0,
                 unit_grad: bool = False) -> torch.Tensor:
@@ -569,11 +587,7 @@ class directional_edc_loss(nn.Module):
         # true EDC from the common-slope amplitudes (einsum 'bjk,kt->bjt'), then dB
         if self.envelopes.device != x.device:              # (once: a host -> device copy cannot be graph-captured)
             self.envelopes = self.envelopes.to(x.device)
-        if self.use_mask:
-            keep = torch.bernoulli(torch.empty(L).uniform_(0, 1))
-            maskw, count = keep.to(device=x.device, dtype=torch.float32), float(keep.sum().item())
-        else:
-            maskw, count = None, float(L)
+        maskw, count = self._time_mask(L, x.device)
         # (the einsum 'bjk,kt->bjt' of the amplitudes with the envelopes, |.| + eps, dB and the clip at -200 happen
         # inside the EDC scan: the (B J, L) target and the six passes over it that built it never exist)
         amps = amps_true.to(device=x.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
@@ -599,8 +613,6 @@ class directional_edc_loss(nn.Module):
         L = min(self.edc_len_samps, n - start)
         if L <= 0:
             raise ValueError("EDC window starts beyond the impulse-response length")
-        if self.use_mask:
-            raise NotImplementedError("forward_sh: the randomly masked variant goes through forward()")
         want_grad = H_sh.requires_grad and torch.is_grad_enabled()
         x_sh = ops.irfft_pow2_fwd(H_sh.reshape(B * C, K), n)                       # (B C, n)
         if self.envelopes.device != x_sh.device:
@@ -609,8 +621,9 @@ class directional_edc_loss(nn.Module):
         if n == 131072 and ops.edc_mixed_supported(C, J, amps.shape[1]):
             # the J directional samples formed in registers inside the EDC kernels (csrc/edcmix.hip): neither the
             # directional signals nor their gradient exist, the adjoint transform reads the EDC window only
-            li, gx_sh = ops.edc_loss_model_mixed(x_sh.view(B, C, n), analysis_matrix, start, L, amps, self.envelopes, None,
-                                                 1.0 / (B * J * float(L)), float(weight), want_grad)
+            maskw, count = self._time_mask(L, x_sh.device)
+            li, gx_sh = ops.edc_loss_model_mixed(x_sh.view(B, C, n), analysis_matrix, start, L, amps, self.envelopes, maskw,
+                                                 1.0 / (B * J * count), float(weight), want_grad)
             val = li.sum()                                     # (the kernel's items carry the weight)
             if not want_grad:
                 return val
@@ -619,7 +632,8 @@ class directional_edc_loss(nn.Module):
         # pairs of real samples as complex numbers: the streaming mix kernel of the spectra serves the signals too
         x_dir = ops.sh_to_directional(analysis_matrix, torch.view_as_complex(x_sh.view(B, C, n // 2, 2)), False)
         x_dir = torch.view_as_real(x_dir).view(B * J, n)
-        li, gx = ops.edc_loss_model(x_dir, start, L, amps, self.envelopes, None, 1.0 / (B * J * float(L)), float(weight),
+        maskw, count = self._time_mask(L, x_dir.device)
+        li, gx = ops.edc_loss_model(x_dir, start, L, amps, self.envelopes, maskw, 1.0 / (B * J * count), float(weight),
                                     want_grad)
         val = li.sum() if weight == 1.0 else li.sum() * float(weight)
         if not want_grad:

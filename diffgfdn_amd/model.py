@@ -266,6 +266,14 @@ class DiffGFDNVarReceiverPos(DiffGFDN):
         return out
 
 
+def _scaled_first_section(coef: torch.Tensor, gain: torch.Tensor) -> torch.Tensor:
+    """coef (B, G, S, 6) biquad cascades with the first section's numerator times gain (B, G): the cascade's response
+    times a real gain, without touching the kernel's interface."""
+    scale = torch.ones_like(coef)
+    scale[:, :, 0, :3] = gain.to(coef.dtype)[:, :, None]
+    return coef * scale
+
+
 class DiffGFDNVarSourceReceiverPos(DiffGFDN):
     """GFDN for a grid of source AND receiver positions: per-group input gains from the source position and
     output gains from the receiver position, one MLP each (reference model.py:303-452).
@@ -284,28 +292,38 @@ class DiffGFDNVarSourceReceiverPos(DiffGFDN):
         super().__init__(sample_rate, num_groups, delays, device, feedback_loop_config,
                          use_absorption_filters, learn_common_decay_times, common_decay_times,
                          band_centre_hz, colorless_fdn_params, use_colorless_loss)
-        if output_filter_config.use_svfs or input_filter_config.use_svfs:
-            raise NotImplementedError("SVF input/output filters: SURVEY §8 f-2 (next)")
-        self.use_svf_in_output = False
-        self.use_svf_in_input = False
+        # SVF cascades from an MLP on either side (reference :347-400): the side's group factor becomes a (B, G, K) filter
+        # response instead of a (B, G) gain -- same attribute names as the reference (output_filters / input_filters)
+        self.use_svf_in_output = output_filter_config.use_svfs
+        self.use_svf_in_input = input_filter_config.use_svfs
         n = self.num_delay_lines_per_group
-        self.output_scalars = Gains_from_MLP(
-            self.num_groups, n, output_filter_config.num_fourier_features,
-            output_filter_config.num_hidden_layers, output_filter_config.num_neurons_per_layer,
-            output_filter_config.encoding_type, position_type="output_gains")
-        self.input_scalars = Gains_from_MLP(
-            self.num_groups, n, input_filter_config.num_fourier_features,
-            input_filter_config.num_hidden_layers, input_filter_config.num_neurons_per_layer,
-            input_filter_config.encoding_type, position_type="input_gains")
+
+        def side(cfg, position_type):
+            if cfg.use_svfs:
+                return SVF_from_MLP(self.sample_rate, self.num_groups, n, cfg.num_fourier_features, cfg.num_hidden_layers,
+                                    cfg.num_neurons_per_layer, cfg.encoding_type, cfg.compress_pole_factor,
+                                    position_type=position_type)
+            return Gains_from_MLP(self.num_groups, n, cfg.num_fourier_features, cfg.num_hidden_layers,
+                                  cfg.num_neurons_per_layer, cfg.encoding_type, position_type=position_type)
+        if self.use_svf_in_output:
+            self.output_filters = side(output_filter_config, "output_gains")
+        else:
+            self.output_scalars = side(output_filter_config, "output_gains")
+        if self.use_svf_in_input:
+            self.input_filters = side(input_filter_config, "input_gains")
+        else:
+            self.input_scalars = side(input_filter_config, "input_gains")
 
     def forward(self, x: Dict, subband_filter: Optional[torch.Tensor] = None):
         z = x['z_values']
         self.feedback_loop.new_forward()
         self.batch_size = x['listener_position'].shape[0]
         G, n = self.num_groups, self.num_delay_lines_per_group
+        fl = self.feedback_loop
+        if self.use_svf_in_output or self.use_svf_in_input:
+            return self._forward_filters(x, subband_filter)
         r = self.output_scalars.group_gains(x).to(torch.float32)          # (B, G) from the receiver position
         s = self.input_scalars.group_gains(x).to(torch.float32)           # (B, G) from the source position
-        fl = self.feedback_loop
         if fl.uncoupled:
             Y = self.delay_line_responses(z)
             H = OutputStage.apply(Y, self.output_gains.reshape(-1), r * s, n, x['target_early_response'],
@@ -327,10 +345,49 @@ class DiffGFDNVarSourceReceiverPos(DiffGFDN):
             return H, self.sub_fdn_output(z)
         return H
 
+    def _forward_filters(self, x: Dict, subband_filter: Optional[torch.Tensor] = None):
+        """SVF filters on the input and / or the output side (reference :423-432: C = output_filters(x) C_init,
+        B = input_filters(x) B_init): H[b,k] = sum_{g,g'} Fo[b,g,k] Fi[b,g',k] T[k,g,g'] + d[b,k] with the group transfer
+        functions T = c_g^T P_{g g'} b_{g'} of the shared per-bin solve.  Zero coupling (T diagonal): the two sides' cascades
+        of a group are ONE cascade of up to 22 sections (a side with scalar gains scales the other side's first
+        numerator), evaluated inside the contraction kernel (csrc/svf.hip, SosOutputStage) -- the (B, G, K) filter responses
+        never exist.  With coupling: the responses are evaluated (sos_cascade_response) and contracted by torch ops."""
+        from .gain_filters import sos_cascade_response
+        z = x['z_values']
+        T = self.group_transfer(z)                                                   # (K, G, G')
+        co = self.output_filters.biquad_coefficients(x) if self.use_svf_in_output else None      # (B, G, S, 6)
+        ci = self.input_filters.biquad_coefficients(x) if self.use_svf_in_input else None
+        r = None if self.use_svf_in_output else self.output_scalars.group_gains(x).to(torch.float32)
+        s = None if self.use_svf_in_input else self.input_scalars.group_gains(x).to(torch.float32)
+        if self.feedback_loop.uncoupled:
+            if co is not None and ci is not None:
+                coef = torch.cat((co, ci), dim=2)
+            elif co is not None:
+                coef = _scaled_first_section(co, s)
+            else:
+                coef = _scaled_first_section(ci, r)
+            H = SosOutputStage.apply(coef.contiguous(), T.sum(-1).contiguous(), x['target_early_response'], z)
+        else:
+            K = z.shape[-1]
+            Fo = sos_cascade_response(z, co) if co is not None else r.to(torch.complex64)[:, :, None].expand(-1, -1, K)
+            Fi = sos_cascade_response(z, ci) if ci is not None else s.to(torch.complex64)[:, :, None].expand(-1, -1, K)
+            H = torch.einsum('bgk,bhk,kgh->bk', Fo, Fi, T.to(torch.complex64)) + x['target_early_response']
+        if subband_filter is not None:
+            H = H * subband_filter
+        if self.use_colorless_loss:
+            return H, self.sub_fdn_output(z)
+        return H
+
     @torch.no_grad()
     def get_param_dict_inference(self, data: Dict) -> Dict:
-        return {'output_scalars': self.output_scalars.get_param_dict(data)['gains'],
-                'input_scalars': self.input_scalars.get_param_dict(data)['gains']}
+        out = {}
+        for name, svf in (('output', self.use_svf_in_output), ('input', self.use_svf_in_input)):
+            if svf:
+                prm = getattr(self, f'{name}_filters').get_param_dict(data)
+                out[f'{name}_svf_params'], out[f'{name}_biquad_coeffs'] = prm['svf_params'], prm['biquad_coeffs']
+            else:
+                out[f'{name}_scalars'] = getattr(self, f'{name}_scalars').get_param_dict(data)['gains']
+        return out
 
 
 class DiffGFDNSinglePos(DiffGFDN):

@@ -549,9 +549,9 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
     # irfft(A H_sh): same numbers to rounding, 3/4 of the transforms at order 2
     mix_in_time = True
 
-    def graphed(self, example_batch: Dict) -> "GraphedModuleStep":
+    def graphed(self, example_batch: Dict, mask_seed: Optional[int] = None) -> "GraphedModuleStep":
         """train_step on batches shaped like ``example_batch`` as one HIP-graph replay."""
-        return GraphedModuleStep(self, example_batch)
+        return GraphedModuleStep(self, example_batch, mask_seed)
 
     def convert_ambi_rir_to_directional_rir(self, H_sh: torch.Tensor) -> torch.Tensor:
         """einsum('jl,blk->bjk', A_sh, H_sh)  (reference :853-865) as one streaming kernel."""
@@ -619,7 +619,7 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         # (the weight rides the kernel's gradient scale and the term enters the total with factor 1: the backward skips
         # the pass that would multiply the gradient by the upstream scalar)
         crit = self.criterion[0]
-        if self.mix_in_time and not crit.use_mask:
+        if self.mix_in_time:
             # SH -> directional conversion behind the inverse transform (linear maps commute): C transforms per receiver
             edc = crit.forward_sh(H_sh, net.sh_output_scalars.analysis_matrix, data['target_common_slope_amps'],
                                   weight=cfg.edc_loss_weight, unit_grad=True)
@@ -731,14 +731,27 @@ class GraphedModuleStep:
     ``__call__`` refreshes in place; warm-up and capture run on ONE private stream -- autograd pins every
     parameter's AccumulateGrad node to the stream of its first backward, and a capture that has to hop to another
     stream and back dies in hipStreamEndCapture (ROCm 7.2).  Needs ``capturable=True`` (flat Adam with device-side
-    step counter and learning rates) and a loss path without host reads (``use_edc_mask=False``: the reference
-    draws that mask on the host)."""
+    step counter and learning rates) and a loss path without host reads: with ``use_edc_mask`` the directional trainer's
+    time mask (reference losses.py:287-292, :355-360: drawn on the host every step) is drawn INSIDE the graph by the
+    counter-based device generator (``mask_seed``; the bits of ``gfdn_draw_mask`` at (seed, replay number))."""
 
-    def __init__(self, trainer, example_batch: Dict):
+    def __init__(self, trainer, example_batch: Dict, mask_seed: Optional[int] = None):
         if not trainer.capturable:
             raise ValueError("build the trainer with capturable=True to replay steps from a graph")
+        self.mask_state = None
         if getattr(trainer.config, 'use_edc_mask', False):
-            raise NotImplementedError("GraphedModuleStep: use_edc_mask draws on the host every step")
+            crit = trainer.criterion[0]
+            if not isinstance(crit, directional_edc_loss):
+                raise NotImplementedError("GraphedModuleStep: a device-side EDC mask exists for the directional loss only")
+            K = example_batch['z_values'].shape[-1]
+            L = min(crit.edc_len_samps, 2 * (K - 1) - crit.mixing_time_samps)
+            dev = example_batch['z_values'].device
+            if mask_seed is None:
+                mask_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.long).item())   # torch.manual_seed governs it
+            self.mask_seed = int(mask_seed)
+            self.mask_state = torch.zeros(1, dtype=torch.long, device=dev)
+            self.maskw = torch.zeros(L, dtype=torch.float32, device=dev)
+            crit.device_mask = (self.mask_seed, self.mask_state, self.maskw)
         self.tr = trainer
         self.batch = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self.stream = torch.cuda.Stream()
@@ -758,6 +771,8 @@ class GraphedModuleStep:
                 p.data.copy_(sp)
             for t, st in zip(tr.optimizer.state_tensors(), saved_s):
                 t.copy_(st)
+            if self.mask_state is not None:
+                self.mask_state.zero_()                        # (the warm-up draws leave no trace either)
             tr.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

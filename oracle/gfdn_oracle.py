@@ -360,6 +360,27 @@ def var_source_receiver_forward(z: torch.Tensor, input_gains: torch.Tensor, outp
     return torch.einsum('bmk, bmk -> bk', Htemp, Bm) + direct              # :444
 
 
+def var_source_receiver_forward_filters(z: torch.Tensor, input_gains: torch.Tensor, output_gains: torch.Tensor,
+                                        receiver_side: torch.Tensor, source_side: torch.Tensor, P: torch.Tensor,
+                                        direct: torch.Tensor, n_per_group: int) -> torch.Tensor:
+    """model.py:402-452 (DiffGFDNVarSourceReceiverPos.forward) with SVF filters on either side (constructor branches
+    :347-400): ``receiver_side`` / ``source_side`` are the per-group factors of C / B -- (B, G, K) complex cascade responses
+    of SVF_from_MLP (gain_filters.py:334-402; every delay line of a group carries its group's filter, :396-400) or (B, G)
+    real MLP gains (:497-534).  P (K,N,N) c64; direct (B,K) c128."""
+    Bsz, N, K = receiver_side.shape[0], input_gains.shape[0], len(z)
+    C_init = to_complex(output_gains.expand(Bsz, N, K))                     # :416-418
+    B_init = to_complex(input_gains.expand(Bsz, N, K))                      # :419-421
+
+    def per_line(f):
+        if f.dim() == 2:                                                    # scalar gains: :427 / :432
+            return to_complex(f.repeat_interleave(n_per_group, dim=1).unsqueeze(-1).repeat(1, 1, K))
+        return f.repeat_interleave(n_per_group, dim=1)                      # filters: :425 / :430
+    C = per_line(receiver_side) * C_init
+    Bm = per_line(source_side) * B_init
+    Htemp = torch.einsum('knb, knm -> kmb', C.permute(-1, 1, 0), P).permute(-1, 1, 0)   # :437-438
+    return torch.einsum('bmk, bmk -> bk', Htemp, Bm) + direct              # :444
+
+
 def colorless_fdn_forward(z: torch.Tensor, delays: torch.Tensor, gamma: torch.Tensor,
                           input_gains: torch.Tensor, output_gains: torch.Tensor, W: torch.Tensor):
     """colorless_fdn/model.py:63-92 (ColorlessFDN.forward): one group, dense feedback matrix

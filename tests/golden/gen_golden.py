@@ -378,6 +378,41 @@ def gen_f8_source_receiver():
     print('F8 done')
 
 
+def gen_f16_source_receiver_svf():
+    """DiffGFDNVarSourceReceiverPos with SVF filters from MLPs on the input (source position) and the output (receiver
+    position) side (model.py:305-400 constructor branches, :402-452 forward; gain_filters.py:262-402), zero coupling and
+    learnable coupling; plus the mixed case (SVF output filters, scalar input gains)."""
+    fs, nfft, G, nper, B = 8000.0, 512, 2, 4, 3
+    delays = prime_delays(G * nper, lo=160, hi=400, seed=8)
+    for tag, zero, svf_in in (('zc', True, True), ('cp', False, True), ('mixed', True, False)):
+        batch, T60 = synth_batch(B, nfft, fs, G, 450, 61, T60=[0.3, 0.6])
+        rng = np.random.RandomState(78)
+        batch['source_position'] = torch.tensor(rng.uniform(0, 1, (B, 3)))
+        torch.manual_seed(33)
+        np.random.seed(33)
+        fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=zero)
+        of = OutputFilterConfig(use_svfs=True, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                                compress_pole_factor=0.98)
+        inf = OutputFilterConfig(use_svfs=svf_in, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                                 compress_pole_factor=0.98)
+        net = DiffGFDNVarSourceReceiverPos(fs, G, delays, 'cpu', fl, of, inf, use_absorption_filters=False,
+                                           learn_common_decay_times=False,
+                                           common_decay_times=np.asarray(T60)[None, :], use_colorless_loss=True)
+        H, (Hout, _) = net(batch)
+        loss = (H.abs() ** 2).sum()
+        loss.backward()
+        out = {'fs': fs, 'nfft': nfft, 'G': G, 'nper': nper, 'delays': np.array(delays), 'T60': T60,
+               'zero_coupling': zero, 'svf_in': svf_in, 'H': c2np(H), 'Hout': c2np(Hout), 'loss': loss.item(),
+               'Co': c2np(net.output_filters(batch)[:, ::nper, :])}
+        if svf_in:
+            out['Ci'] = c2np(net.input_filters(batch)[:, ::nper, :])
+        out.update(batch_to_np(batch))
+        out.update(state_np(net))
+        out.update({'grad_' + k: c2np(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+        np.savez_compressed(os.path.join(HERE, f'f16_source_receiver_svf_{tag}.npz'), **out)
+    print('F16 done')
+
+
 def gen_f9_colorless_fdn():
     """ColorlessFDN prototype (colorless_fdn/model.py:12-111) + the trainer's loss and normalisation
     (colorless_fdn/trainer.py:95-143)."""
@@ -640,6 +675,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'r3':           # only the fixture added in round 3
         gen_f15_full_band_and_filter_absorption()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'r4':           # only the fixture added in round 4
+        gen_f16_source_receiver_svf()
+        sys.exit(0)
     gen_f1_feedback_loop()
     # small: nfft 512 (K = 257, Fermat prime -> prime-length irfft quirk), scaled STFT
     gen_f2_f3_f4('n12_k257', G=3, nper=4, nfft=512, fs=2000.0, B=4, T=400, win=64, hop=32)
@@ -660,3 +698,4 @@ if __name__ == '__main__':
     gen_f2_f3_f4('n32_k1025', G=4, nper=8, nfft=2048, fs=8000.0, B=3, T=2000, win=256, hop=128, seed=13)
     gen_f14_learnable_decay_times()
     gen_f15_full_band_and_filter_absorption()
+    gen_f16_source_receiver_svf()

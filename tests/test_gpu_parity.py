@@ -399,8 +399,10 @@ def test_edr_loss_with_erb_grouping(weighted, radius):
     assert float((gd - gr).abs().sum() / gr.abs().sum()) < 2e-3      # (L1: sign flips of the |.| at tiny differences)
 
 
-def test_directional_graphed_step_equals_eager_step():
-    """DirectionalFDNVarReceiverPosTrainer.graphed: replaying the captured step == host launches (values, state)."""
+@pytest.mark.parametrize("mask", [False, True])
+def test_directional_graphed_step_equals_eager_step(mask):
+    """DirectionalFDNVarReceiverPosTrainer.graphed: replaying the captured step == host launches (values, state) -- also
+    with the random EDC time mask (reference losses.py:355-360), which the captured step draws on the device."""
     from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
     from diffgfdn_amd.model import DiffDirectionalFDNVarReceiverPos
     from diffgfdn_amd.trainer import DirectionalFDNVarReceiverPosTrainer
@@ -417,13 +419,19 @@ def test_directional_graphed_step_equals_eager_step():
                                                use_colorless_loss=True, analysis_matrix=fx["analysis_matrix"])
         net.load_state_dict(_state(fx), strict=True)
         net = net.to(DEV)
-        tc = TrainerConfig(use_colorless_loss=True, edc_loss_weight=1.0, use_edc_mask=False, lr=1e-3, io_lr=1e-2,
+        tc = TrainerConfig(use_colorless_loss=True, edc_loss_weight=1.0, use_edc_mask=mask, lr=1e-3, io_lr=1e-2,
                            train_dir="/tmp/gfdn_t", ir_dir="/tmp/gfdn_a", device="cuda")
         tr = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
-        tr.criterion[0].edc_len_samps = int(float(fx["edc_len_ms"]) * 1e-3 * fs)
-        tr.criterion[0].envelopes = torch.tensor(fx["envelopes"], dtype=torch.float32)
+        crit = tr.criterion[0]
+        crit.edc_len_samps = int(float(fx["edc_len_ms"]) * 1e-3 * fs)
+        crit.envelopes = torch.tensor(fx["envelopes"], dtype=torch.float32)
+        assert crit.use_mask == mask
         vals = []
-        step = tr.graphed(batch0) if mode == "graph" else None
+        step = tr.graphed(batch0, mask_seed=4242) if mode == "graph" else None
+        if mask and mode == "eager":          # the same device generator, launched from the host
+            K = batch0["z_values"].shape[-1]
+            L = min(crit.edc_len_samps, 2 * (K - 1) - crit.mixing_time_samps)
+            crit.device_mask = (4242, torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(L, device=DEV))
         for i in range(3):
             b = dict(batch0)
             b["target_common_slope_amps"] = batch0["target_common_slope_amps"] * (1.0 + 0.1 * i)
@@ -433,6 +441,43 @@ def test_directional_graphed_step_equals_eager_step():
     assert np.allclose(res["eager"][0], res["graph"][0], rtol=1e-5), res
     for k, v in res["eager"][1].items():
         assert rel_err(res["graph"][1][k], v) < 1e-5, k
+    if mask:
+        assert int(step.mask_state.item()) == 3          # (one draw per replay; the warm-up draws were undone)
+
+
+@pytest.mark.parametrize("tag", ["zc", "cp", "mixed"])
+def test_f16_source_receiver_svf_model(tag):
+    """DiffGFDNVarSourceReceiverPos with SVF filters from MLPs (reference model.py:347-452): the reference's state dict
+    loads with strict=True; H, the sub-FDN responses and every parameter gradient of the reference's forward / backward.
+    zc: zero coupling, both sides SVF -- one 22-section cascade per (position, group) inside the contraction kernel;
+    cp: learnable coupling (G x G group transfer functions, responses contracted by tensor operations);
+    mixed: SVF output filters, scalar input gains (the gain scales the cascade's first numerator)."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarSourceReceiverPos
+    fx = load(f"f16_source_receiver_svf_{tag}.npz")
+    fs, G = float(fx["fs"]), int(fx["G"])
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=bool(fx["zero_coupling"]))
+    of = OutputFilterConfig(use_svfs=True, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4,
+                            compress_pole_factor=0.98)
+    inf = OutputFilterConfig(use_svfs=bool(fx["svf_in"]), num_hidden_layers=2, num_neurons_per_layer=16,
+                             num_fourier_features=4, compress_pole_factor=0.98)
+    net = DiffGFDNVarSourceReceiverPos(fs, G, fx["delays"].tolist(), DEV, fl, of, inf, use_absorption_filters=False,
+                                       learn_common_decay_times=False, common_decay_times=fx["T60"][None, :],
+                                       use_colorless_loss=True)
+    net.load_state_dict(_state(fx), strict=True)
+    net = net.to(DEV)
+    batch = _to_dev(batch_from(fx))
+    H, (Hout, _) = net(batch)
+    assert rel_err(H.detach().cpu(), fx["H"]) < 1e-4
+    assert rel_err(Hout.detach().cpu(), fx["Hout"]) < 1e-4
+    (H.abs() ** 2).sum().backward()
+    for name, p_ in net.named_parameters():
+        key = "grad_" + name
+        if key in fx:
+            assert p_.grad is not None, name
+            assert rel_err(p_.grad.detach().cpu(), fx[key]) < 2e-3, (name, rel_err(p_.grad.detach().cpu(), fx[key]))
+    out = net.get_param_dict_inference(batch)
+    assert out["output_biquad_coeffs"].shape[-2:] == (11, 6)
 
 
 def test_f7_front_end():

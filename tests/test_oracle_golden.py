@@ -253,6 +253,39 @@ def test_f8_source_receiver_forward(tag):
     assert rel_err(H.detach().numpy(), fx["H"]) < 1e-6
 
 
+@pytest.mark.parametrize("tag", ["zc", "cp", "mixed"])
+def test_f16_source_receiver_svf_forward(tag):
+    """oracle var_source_receiver_forward_filters vs the reference's DiffGFDNVarSourceReceiverPos with SVF filters from
+    MLPs on the output side and (zc, cp) on the input side (model.py:347-400, :402-452); "mixed": scalar input gains."""
+    from tests.helpers import mlp_from_state
+    fx = load(f"f16_source_receiver_svf_{tag}.npz")
+    batch = batch_from(fx)
+    G, nper, fs = int(fx["G"]), int(fx["nper"]), float(fx["fs"])
+    M, alpha = torch.tensor(fx["sd_feedback_loop.M"]), torch.tensor(fx["sd_feedback_loop.alpha"])
+    delays = torch.tensor(fx["delays"], dtype=torch.float32)
+    z = batch["z_values"]
+    gamma = torch.cat([orc.decay_times_to_gain_per_sample(torch.tensor(fx["T60"][g]), delays[g * nper:(g + 1) * nper], fs)
+                       for g in range(G)])
+    A = orc.coupled_feedback_matrix(M, alpha if tag == "cp" else torch.zeros_like(alpha))
+    P = orc.feedback_loop_forward(z, delays, gamma, A)
+    lin_o, norm_o = mlp_from_state(fx, root="output_filters.mlp.model.")
+    raw_o = orc.mlp_forward(orc.sinusoidal_encoding(batch["listener_position"], 4), lin_o, norm_o)
+    Co = orc.svf_group_responses(z, fs, raw_o.view(-1, G, 11, 2), 0.98)
+    assert rel_err(Co.detach().numpy(), fx["Co"]) < 2e-6
+    if bool(fx["svf_in"]):
+        lin_i, norm_i = mlp_from_state(fx, root="input_filters.mlp.model.")
+        raw_i = orc.mlp_forward(orc.sinusoidal_encoding(batch["source_position"], 4), lin_i, norm_i)
+        Ci = orc.svf_group_responses(z, fs, raw_i.view(-1, G, 11, 2), 0.98)
+        assert rel_err(Ci.detach().numpy(), fx["Ci"]) < 2e-6
+    else:
+        lin_i, norm_i = mlp_from_state(fx, root="input_scalars.mlp.model.")
+        enc = orc.sinusoidal_encoding(batch["source_position"], 4)
+        Ci = orc.scaled_sigmoid(orc.mlp_forward(enc, lin_i, norm_i).view(-1), -1.0, 1.0).view(-1, G)
+    H = orc.var_source_receiver_forward_filters(z, torch.tensor(fx["sd_input_gains"]), torch.tensor(fx["sd_output_gains"]),
+                                                Co, Ci, P, batch["target_early_response"], nper)
+    assert rel_err(H.detach().numpy(), fx["H"]) < 2e-6
+
+
 def test_f9_colorless_fdn_forward():
     """oracle colorless_fdn_forward vs the reference's ColorlessFDN (colorless_fdn/model.py:63-92)."""
     fx = load("f9_colorless_fdn.npz")

@@ -2,7 +2,7 @@
 usage: python tools/make_profiles.py [round_tag]   (default r03)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 src = os.path.join(ROOT, 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -106,9 +106,20 @@ Algorithmic bytes per launch {dom.get('alg_bytes_per_launch', 0)/1e6:.2f} MB -> 
     # HBM traffic of one step: the kernels of the replayed step (timeline) x the PMC traffic of their launches (per
     # kernel the grid with most launches = the step's)
     f.write("\n## HBM traffic per step (PMC, 2 x FETCH_SIZE + WRITE_SIZE)\n\n| kernel | launches per step | MB per launch | MB per step |\n|---|---|---|---|\n")
+    # the grid a kernel is launched with INSIDE the replayed steps (the stats run's trace): the PMC row of that grid is
+    # the step's -- the same kernels also run on other grids in the one-off dataset precompute
+    step_grid = {}
+    for r in trows[lo + 1:hi + 1]:
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        g = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+        step_grid.setdefault(k, collections.Counter())[g] += 1
     best = {}
     for (k, g), d in pmc.items():
-        if k not in best or d['launches'] > best[k]['launches']:
+        want = step_grid.get(k)
+        if want is not None:
+            if g == want.most_common(1)[0][0]:
+                best[k] = d
+        elif k not in best or d['launches'] > best[k]['launches']:
             best[k] = d
     counts = collections.Counter()
     for line in tl.splitlines():
