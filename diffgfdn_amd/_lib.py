@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P = c_void_p
 
@@ -130,6 +130,12 @@ SIGNATURES = {
     "gfdn_edc_mixed_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_edc_loss_model_mixed": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
                                           c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_dirlin_tiles": (c_int, [c_int]),
+    "gfdn_dirlin_line_tiles": (c_int, [c_int]),
+    "gfdn_dirlin_lines_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "gfdn_dirlin_lines_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "gfdn_dirlin_combine": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "gfdn_dirlin_gamma_dots": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_rfft_pow2": (c_int, [c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_sh_to_directional": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_stft_nframes": (c_int, [c_int, c_int]),

@@ -1707,6 +1707,70 @@ def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None
     return loss_item, gx
 
 
+# ---- the directional output stage in the time domain (csrc/dirlin.hip) -----------------------------------------------
+def dirlin_supported(G: int, nper: int) -> bool:
+    """Group / line counts the gfdn_dirlin_* kernels are built for."""
+    return 1 <= G <= 4 and G * nper <= 64
+
+
+def dirlin_lines_fwd(Y, c, filt=None) -> torch.Tensor:
+    """Z (N, K) complex64 = c_n filt_k Y[k][n]: the delay-line responses Y (K, N) of the transposed solve as the N rows the
+    inverse transform takes (model.py:1056-1088 without the receivers' weights)."""
+    _need_gpu(Y, c, filt)
+    Y, c = _c(Y), _f(c)
+    filt = None if filt is None else _c(filt)
+    K, N = Y.shape
+    Z = torch.empty((N, K), dtype=_c64, device=Y.device)
+    _lib.check(_lib.load().gfdn_dirlin_lines_fwd(_p(Y), K, N, _p(c), _p(filt), _p(Z), K, _stream()),
+               "gfdn_dirlin_lines_fwd")
+    return Z
+
+
+def dirlin_lines_bwd(Y, c, filt, gZ):
+    """(gY (K, N) complex64, gc (N,)) from gZ (N, K) = dL/dZ of dirlin_lines_fwd."""
+    _need_gpu(Y, c, filt, gZ)
+    Y, c, gZ = _c(Y), _f(c), _c(gZ)
+    filt = None if filt is None else _c(filt)
+    K, N = Y.shape
+    lib = _lib.load()
+    gY = torch.empty_like(Y)
+    gc = torch.empty(N, dtype=_f32, device=Y.device)
+    part = torch.empty(N * lib.gfdn_dirlin_line_tiles(K), dtype=_f32, device=Y.device)
+    _lib.check(lib.gfdn_dirlin_lines_bwd(_p(Y), K, N, _p(c), _p(filt), _p(gZ), gZ.shape[1], _p(gY), _p(gc), _p(part),
+                                         _stream()), "gfdn_dirlin_lines_bwd")
+    return gY, gc
+
+
+def dirlin_combine(tau, start: int, length: int, w, G: int, nper: int) -> torch.Tensor:
+    """x (B, nper, ceil4(length)) f32: the receivers' SH-domain signals on the window [start, start + length) from the
+    N = G nper line signals tau (N, n) and the SH weights w (B, N): x[b][l] = sum_g w[b][g nper + l] tau[g nper + l]."""
+    _need_gpu(tau, w)
+    tau, w = _f(tau), _f(w)
+    B = w.shape[0]
+    if tau.shape[0] != G * nper or w.shape[1] != G * nper:
+        raise RuntimeError("dirlin_combine: tau (G nper, n), w (B, G nper)")
+    Lp = (length + 3) & ~3
+    x = torch.empty((B, nper, Lp), dtype=_f32, device=tau.device)
+    _lib.check(_lib.load().gfdn_dirlin_combine(_p(tau), tau.shape[1], start, length, _p(w), B, G, nper, _p(x), Lp,
+                                               _stream()), "gfdn_dirlin_combine")
+    return x
+
+
+def dirlin_gamma_dots(gx, length: int, tau, start: int, w, G: int, nper: int):
+    """Adjoint of dirlin_combine: (gtau (N, n) -- WRITTEN ON THE WINDOW ONLY, for irfft_pow2_bwd(..., window=) --, gw (B, N))
+    from gx (B, nper, >= length)."""
+    _need_gpu(gx, tau, w)
+    gx, tau, w = _f(gx), _f(tau), _f(w)
+    B, N = w.shape
+    lib = _lib.load()
+    gtau = torch.empty_like(tau)
+    gw = torch.empty((B, N), dtype=_f32, device=tau.device)
+    part = torch.empty(B * N * lib.gfdn_dirlin_tiles(length), dtype=_f32, device=tau.device)
+    _lib.check(lib.gfdn_dirlin_gamma_dots(_p(gx), gx.shape[-1], length, _p(tau), tau.shape[1], start, _p(w), B, G, nper,
+                                          _p(gtau), tau.shape[1], _p(gw), _p(part), _stream()), "gfdn_dirlin_gamma_dots")
+    return gtau, gw
+
+
 def _edc_bands(item_len, items: int, items_per_band, maskw, length: int, T_db, what: str):
     """Arguments of the banded EDC entry points: (items_per_band, ld_mask) -- see gfdn_edc_loss_banded.
     ``maskw`` (bands, >= length) selects per-band mask rows, a vector is shared by all bands."""

@@ -173,6 +173,27 @@ class _ScalarLossWithSavedGrad(torch.autograd.Function):
         return (gH * g).reshape(ctx.h_shape), None, None, None
 
 
+class _ScalarLossWithSavedGrads(torch.autograd.Function):
+    """loss value + precomputed gradients of several inputs (saved) -> autograd node."""
+
+    @staticmethod
+    def forward(ctx, loss_value, unit_grad, *inputs_and_grads):
+        k = len(inputs_and_grads) // 2
+        ctx.save_for_backward(*inputs_and_grads[k:])
+        ctx.meta = [(t.shape, t.dtype) for t in inputs_and_grads[:k]]
+        ctx.unit_grad = unit_grad
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.unit_grad:
+            _assert_unit_upstream(g)
+            out = [t.to(dt).reshape(sh) for t, (sh, dt) in zip(ctx.saved_tensors, ctx.meta)]
+        else:
+            out = [(t * g).to(dt).reshape(sh) for t, (sh, dt) in zip(ctx.saved_tensors, ctx.meta)]
+        return (None, None, *out, *([None] * len(out)))
+
+
 class _DecayTotal(torch.autograd.Function):
     """[w_edr sum(edr_items) + w_edc sum(edc_items), w_edr sum(.), w_edc sum(.)] as three 0-dim outputs
     of ONE bookkeeping launch, the first carrying the precomputed dloss/dH.  The outputs are created
@@ -641,3 +662,42 @@ class directional_edc_loss(nn.Module):
         gx_sh = ops.sh_to_directional(analysis_matrix, torch.view_as_complex(gx.view(B, J, n // 2, 2)), True)
         gH = ops.irfft_pow2_bwd(torch.view_as_real(gx_sh).view(B * C, n), n).reshape(B, C, K)
         return _ScalarLossWithSavedGrad.apply(H_sh, val, gH, unit_grad)
+
+    def lines_supported(self, K: int, G: int, nper: int, J: int, S: int) -> bool:
+        """Shapes forward_lines takes (otherwise: SHOutputStage + forward_sh)."""
+        return 2 * (K - 1) == 131072 and ops.dirlin_supported(G, nper) and ops.edc_mixed_supported(nper, J, S)
+
+    def forward_lines(self, Y: torch.Tensor, c: torch.Tensor, w: torch.Tensor, G: int, nper: int,
+                      filt: Optional[torch.Tensor], analysis_matrix: torch.Tensor, amps_true: torch.Tensor,
+                      weight: float = 1.0, unit_grad: bool = False) -> torch.Tensor:
+        """``forward_sh(SHOutputStage(Y, c, w, filt), A, amps_true)`` (reference model.py:1056-1088, trainer.py:853-865,
+        losses.py:333-371) with the output stage behind the inverse transform as well: H_sh[b][l] is linear in the receiver's
+        SH weights, irfft(H_sh[b][l]) = sum_g w[b][g nper + l] irfft(c_n filt Y[:, n]) -- the N = G nper line responses are
+        transformed (27 instead of 288 transforms at order 2, three groups, 32 receivers), the receivers' SH signals are
+        formed on the EDC window only, and the adjoint runs the same way back (csrc/dirlin.hip).  Y (K, N) complex: the
+        delay-line responses of the transposed solve; c (N,) output gains; w (B, N) SH weights; A (J, nper)."""
+        K, N = Y.shape
+        B = w.shape[0]
+        J = analysis_matrix.shape[0]
+        n = 2 * (K - 1)
+        start = self.mixing_time_samps
+        L = min(self.edc_len_samps, n - start)
+        if L <= 0:
+            raise ValueError("EDC window starts beyond the impulse-response length")
+        want_grad = (Y.requires_grad or c.requires_grad or w.requires_grad) and torch.is_grad_enabled()
+        tau = ops.irfft_pow2_fwd(ops.dirlin_lines_fwd(Y, c, filt), n)                   # (N, n)
+        if self.envelopes.device != tau.device:
+            self.envelopes = self.envelopes.to(tau.device)
+        amps = amps_true.to(device=tau.device, dtype=torch.float32).reshape(B * J, -1).contiguous()
+        wf = w.detach().reshape(B, N)                          # ((B, G, nper) from the weights network)
+        x_sh = ops.dirlin_combine(tau, start, L, wf, G, nper)                           # (B, nper, ceil4(L)): the window
+        maskw, count = self._time_mask(L, tau.device)
+        li, gx_sh = ops.edc_loss_model_mixed(x_sh, analysis_matrix, 0, L, amps, self.envelopes, maskw,
+                                             1.0 / (B * J * count), float(weight), want_grad)
+        val = li.sum()                                         # (the kernel's items carry the weight)
+        if not want_grad:
+            return val
+        gtau, gw = ops.dirlin_gamma_dots(gx_sh, L, tau, start, wf, G, nper)
+        gZ = ops.irfft_pow2_bwd(gtau, n, window=(start, start + L))
+        gY, gc = ops.dirlin_lines_bwd(Y, c, filt, gZ)
+        return _ScalarLossWithSavedGrads.apply(val, unit_grad, Y, c, w, gY, gc, gw)

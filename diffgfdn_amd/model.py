@@ -488,15 +488,20 @@ class DiffDirectionalFDNVarReceiverPos(DiffGFDN):
         """H_sh (B, (order+1)^2, K)   (reference :1043-1094).  NB the reference contracts the FIRST
         index of P with b (einsum 'knm,bnk->bmk'), i.e. P^T b -> transpose solve."""
         z = x['z_values']
-        self.feedback_loop.new_forward()
-        self.batch_size = x['listener_position'].shape[0]
-        w = self.sh_output_scalars(x, normalise_weights=True)
-        Y = self.delay_line_responses(z, transpose=True)
-        H = SHOutputStage.apply(Y, self.output_gains.reshape(-1), w.to(torch.float32),
-                                self.num_groups, self.num_delay_lines_per_group, subband_filter)
+        Y, c, w = self.output_stage_inputs(x)
+        H = SHOutputStage.apply(Y, c, w, self.num_groups, self.num_delay_lines_per_group, subband_filter)
         if self.use_colorless_loss:
             return H, self.sub_fdn_output(z)
         return H
+
+    def output_stage_inputs(self, x: Dict):
+        """(Y (K, N) delay-line responses of the transposed solve, c (N,) output gains, w (B, N) SH weights): what the SH
+        output stage (reference :1056-1088) is linear in -- the trainer's time-domain output stage starts from these."""
+        self.feedback_loop.new_forward()
+        self.batch_size = x['listener_position'].shape[0]
+        w = self.sh_output_scalars(x, normalise_weights=True)
+        Y = self.delay_line_responses(x['z_values'], transpose=True)
+        return Y, self.output_gains.reshape(-1), w.to(torch.float32)
 
     @torch.no_grad()
     def get_param_dict_inference(self, data: Dict, normalise_weights: bool = False) -> Dict:

@@ -548,6 +548,9 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
     # directional EDC term on irfft(H_sh) mixed in the time domain (losses.directional_edc_loss.forward_sh) instead of
     # irfft(A H_sh): same numbers to rounding, 3/4 of the transforms at order 2
     mix_in_time = True
+    # ... and the SH output stage behind the transform as well (losses.directional_edc_loss.forward_lines): the N line
+    # responses are transformed instead of the B (order + 1)^2 receiver responses, which never exist
+    lines_in_time = os.environ.get('GFDN_DIR_LINES', '1') == '1'
 
     def graphed(self, example_batch: Dict, mask_seed: Optional[int] = None) -> "GraphedModuleStep":
         """train_step on batches shaped like ``example_batch`` as one HIP-graph replay."""
@@ -577,7 +580,16 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
             self._side = torch.cuda.Stream()
         return self._side
 
-    def _forward_two_streams(self, data: Dict, filt, side):
+    def _use_lines(self, data: Dict) -> bool:
+        net = self.net
+        if not (self.mix_in_time and self.lines_in_time and next(net.parameters()).is_cuda):
+            return False
+        amps = data['target_common_slope_amps']
+        J = net.sh_output_scalars.analysis_matrix.shape[0]
+        return self.criterion[0].lines_supported(data['z_values'].shape[0], net.num_groups,
+                                                 net.num_delay_lines_per_group, J, amps.shape[-1])
+
+    def _forward_two_streams(self, data: Dict, filt, side, lines: bool = False):
         """The module's forward (model.py:1043-1094) with its two branches on two streams: the sub-FDN branch of the
         colorless loss (raw-block solve, group sums, spectral + sparsity terms) shares nothing with the SH-domain branch
         but the parameters and the rotations; its elimination kernels are bound by the LDS crossbar, the other branch's
@@ -601,6 +613,8 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         w = net.sh_output_scalars(data, normalise_weights=True)
         main.wait_event(ready)
         Y = net.delay_line_responses(z, transpose=True)
+        if lines:
+            return (Y, net.output_gains.reshape(-1), w.to(torch.float32)), terms
         H_sh = SHOutputStage.apply(Y, net.output_gains.reshape(-1), w.to(torch.float32), net.num_groups,
                                    net.num_delay_lines_per_group, filt)
         return H_sh, terms
@@ -610,16 +624,26 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
         filt = self.subband_filter_freq_resp if self.subband_process_config is not None else None
         side = self._side_stream() if (self.use_colorless_loss and net.use_colorless_loss) else None
         terms = None
+        lines = self._use_lines(data)
         if side is not None:
-            H_sh, terms = self._forward_two_streams(data, filt, side)
+            H_sh, terms = self._forward_two_streams(data, filt, side, lines)
             H_sub = None
+        elif lines:
+            H_sh = net.output_stage_inputs(data)
+            H_sub = net.sub_fdn_output(data['z_values']) if net.use_colorless_loss else None
         else:
             out = net(data, subband_filter=filt)
             H_sh, H_sub = out if net.use_colorless_loss else (out, None)
         # (the weight rides the kernel's gradient scale and the term enters the total with factor 1: the backward skips
         # the pass that would multiply the gradient by the upstream scalar)
         crit = self.criterion[0]
-        if self.mix_in_time:
+        if lines:
+            # the whole chain between the line responses and the EDC functional is linear: N transforms, not B (order + 1)^2
+            Y, c, w = H_sh
+            edc = crit.forward_lines(Y, c, w, net.num_groups, net.num_delay_lines_per_group, filt,
+                                     net.sh_output_scalars.analysis_matrix, data['target_common_slope_amps'],
+                                     weight=cfg.edc_loss_weight, unit_grad=True)
+        elif self.mix_in_time:
             # SH -> directional conversion behind the inverse transform (linear maps commute): C transforms per receiver
             edc = crit.forward_sh(H_sh, net.sh_output_scalars.analysis_matrix, data['target_common_slope_amps'],
                                   weight=cfg.edc_loss_weight, unit_grad=True)

@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
  * receiver schedule; every entry point of version 1 keeps its signature */
-#define GFDN_ABI_VERSION 5
+#define GFDN_ABI_VERSION 6
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
@@ -716,6 +716,31 @@ size_t gfdn_edc_mixed_work_bytes(int B, int J, int len);
 int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,
                               const float* amps, int S, const float* env, int ld_env, const float* maskw,
                               float inv_count, float gscale, float* loss_item, float* gx_sh, void* work, void* stream);
+
+/* ---- The directional model's output stage in the time domain (csrc/dirlin.hip; reference model.py:1056-1088,
+ * trainer.py:853-865, losses.py:333-371).  H_sh[b][l] = filt sum_g w[b][g nper + l] c[g nper + l] Y[:, g nper + l] is linear
+ * in the receiver's SH weights, so irfft(H_sh[b][l]) = sum_g w[b][g nper + l] tau[g nper + l] with the N = G nper LINE
+ * signals tau[n] = irfft(c_n filt Y[:, n]): N transforms per step instead of B nper, no (B, nper, K) responses.
+ *   gfdn_dirlin_lines_fwd  : Z (N, ldz >= K) complex = c_n filt_k Y[k][n]  (Y (K, N) complex bin-major, filt NULL: none);
+ *   gfdn_dirlin_combine    : x (B nper, ld_x) float, WINDOW samples only: x[b nper + l][t] = sum_g w[b][g nper + l]
+ *                            tau[g nper + l][start + t], t < len (ld_x a multiple of 4, >= len rounded up to 4; x 16-byte
+ *                            aligned) -- the signals gfdn_edc_loss_model_mixed takes with start = 0;
+ *   gfdn_dirlin_gamma_dots : from gx (B nper, ld_g) on the window: gtau (N, ld_o)[n][start + t] = sum_b w[b][n]
+ *                            gx[b nper + l(n)][t] (written on the window only: gfdn_irfft_pow2_bwd_window) and
+ *                            gw (B, N) = <gx[b nper + l(n)], tau[n]>; part: B N gfdn_dirlin_tiles(len) floats;
+ *   gfdn_dirlin_lines_bwd  : gY (K, N) = c_n conj(filt_k) gZ[n][k], gc (N) = sum_k Re(gZ conj(filt Y));
+ *                            gc_part: N gfdn_dirlin_line_tiles(K) floats.
+ * G <= 4, N <= 64.  All sums in fixed order.                                                                           */
+int gfdn_dirlin_tiles(int len);
+int gfdn_dirlin_line_tiles(int K);
+int gfdn_dirlin_lines_fwd(const float* Y_c64, int K, int N, const float* c, const float* filt_c64, float* Z_c64, int ldz,
+                          void* stream);
+int gfdn_dirlin_lines_bwd(const float* Y_c64, int K, int N, const float* c, const float* filt_c64, const float* gZ_c64,
+                          int ldz, float* gY_c64, float* gc, float* gc_part, void* stream);
+int gfdn_dirlin_combine(const float* tau, int ld_tau, int start, int len, const float* w, int B, int G, int nper,
+                        float* x, int ld_x, void* stream);
+int gfdn_dirlin_gamma_dots(const float* gx, int ld_g, int len, const float* tau, int ld_tau, int start, const float* w,
+                           int B, int G, int nper, float* gtau, int ld_o, float* gw, float* part, void* stream);
 
 /* ---- EDC time mask on the device  (losses.py:221-227: mask = argwhere(bernoulli(U(0,1))) over the
  * window -- marginally every index is kept with probability 1/2, independently).

@@ -510,3 +510,18 @@ def test_directional_full_size_forward_backward_vs_oracle():
         ref = grads_o[name].numpy()
         err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
         assert err < GRAD_TOL, ('forward_sh', name, err)
+
+    # ---- the timed route: the output stage behind the transform too (directional_edc_loss.forward_lines: the 27 line
+    # responses are transformed, the receivers' signals formed on the EDC window): same loss, same gradients
+    net.zero_grad(set_to_none=True)
+    assert crit.lines_supported(K, Gd, L, J, Gd)
+    Y, c, w = net.output_stage_inputs(batch)
+    loss3 = crit.forward_lines(Y, c, w, Gd, L, None, Adev, amps.to(DEV))
+    loss3.backward()
+    assert abs(loss3.item() - loss_o.item()) < LOSS_TOL * abs(loss_o.item())
+    for name, p_ in net.named_parameters():
+        if name not in grads_o:
+            continue
+        ref = grads_o[name].numpy()
+        err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < GRAD_TOL, ('forward_lines', name, err)

@@ -955,3 +955,66 @@ def test_gamma_and_dots_in_one_sweep(banded):
     assert float((parts[:, tiles:] - 7.0).abs().max()) == 0.0
     dots = parts[:, :tiles].sum(1).view(items, G)
     assert rel_err(dots.cpu(), dots_ref.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("G,order,B,J,filt", [(3, 2, 5, 12, True), (2, 1, 9, 6, False), (4, 0, 3, 1, True)])
+def test_directional_output_stage_in_the_time_domain(ops, G, order, B, J, filt):
+    """csrc/dirlin.hip against the chain it replaces -- SH output stage (model.py:1056-1088) -> irfft of the B (order + 1)^2
+    responses -> directional EDC loss on the mixed signals (trainer.py:853-865, losses.py:333-371): the same loss and the
+    same gradients w.r.t. the line responses, the output gains and the SH weights from N = G (order + 1)^2 transforms;
+    and every kernel of it against float64 tensor algebra.  Receiver counts off the 8-receiver register chunk, a window
+    that is no multiple of 4 samples and starts at an odd sample."""
+    from diffgfdn_amd.functional import SHOutputStage
+    from diffgfdn_amd.losses import directional_edc_loss
+    def re_(a, b):
+        return rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    fs, K = 48000, 65537
+    n = 2 * (K - 1)
+    nper = (order + 1) ** 2
+    N = G * nper
+    g_ = torch.Generator(device='cpu').manual_seed(5 + G)
+    Y = (torch.randn(K, N, 2, generator=g_) * torch.exp(-torch.arange(K)[:, None, None] / 40000.0)).to(DEV)
+    Y = torch.view_as_complex(Y.contiguous()).requires_grad_(True)
+    c = (torch.rand(N, generator=g_) + 0.5).to(DEV).requires_grad_(True)
+    w = torch.randn(B, N, generator=g_).to(DEV).requires_grad_(True)
+    f = torch.view_as_complex(torch.randn(K, 2, generator=g_).to(DEV)) if filt else None
+    A = torch.randn(J, nper, generator=g_).to(DEV)
+    amps = (torch.rand(B, J, G, generator=g_) + 0.1).to(DEV)
+    T60 = np.linspace(0.5, 1.1, G)[None, :]
+    crit = directional_edc_loss(T60, 1234.57, fs, mixing_time_ms=20.03)
+    start = crit.mixing_time_samps
+    L = min(crit.edc_len_samps, n - start)
+    assert start % 2 == 1 and L % 4 != 0, (start, L)
+    assert crit.lines_supported(K, G, nper, J, G)
+
+    # -- kernels against float64 algebra
+    Z = ops.dirlin_lines_fwd(Y, c, f)
+    Zr = (Y.detach().to(torch.complex128) * c.detach().double()[None, :]).T
+    if f is not None:
+        Zr = Zr * f.to(torch.complex128)[None, :]
+    assert re_(Z, Zr) < 1e-6
+    tau = ops.irfft_pow2_fwd(Z, n)
+    x = ops.dirlin_combine(tau, start, L, w, G, nper)
+    xr = torch.einsum('bgl,glt->blt', w.detach().double().view(B, G, nper), tau.double().view(G, nper, n)[:, :, start:start + L])
+    assert re_(x[:, :, :L], xr) < 1e-6
+    gx = torch.randn(B, nper, x.shape[-1], generator=g_).to(DEV)
+    gtau, gw = ops.dirlin_gamma_dots(gx, L, tau, start, w, G, nper)
+    gtr = torch.einsum('bgl,blt->glt', w.detach().double().view(B, G, nper), gx[:, :, :L].double()).reshape(N, L)
+    assert re_(gtau[:, start:start + L], gtr) < 1e-6
+    gwr = torch.einsum('blt,glt->bgl', gx[:, :, :L].double(), tau.double().view(G, nper, n)[:, :, start:start + L]).reshape(B, N)
+    assert re_(gw, gwr) < 1e-5
+    gZ = torch.view_as_complex(torch.randn(N, K, 2, generator=g_).to(DEV))
+    gY, gc = ops.dirlin_lines_bwd(Y, c, f, gZ)
+    u = gZ.to(torch.complex128) * (f.to(torch.complex128).conj()[None, :] if f is not None else 1.0)
+    assert re_(gY, (u * c.detach().double()[:, None]).T) < 1e-6
+    gcr = (u * Y.detach().to(torch.complex128).T.conj()).real.sum(1)
+    assert re_(gc, gcr) < 1e-5
+
+    # -- the whole chain against the chain it replaces
+    ref = crit.forward_sh(SHOutputStage.apply(Y, c, w, G, nper, f), A, amps)
+    gr = torch.autograd.grad(ref, (Y, c, w))
+    val = crit.forward_lines(Y, c, w, G, nper, f, A, amps)
+    gl = torch.autograd.grad(val, (Y, c, w))
+    assert abs(val.item() - ref.item()) < 1e-5 * abs(ref.item()), (val.item(), ref.item())
+    for name, a, b in zip(('Y', 'c', 'w'), gl, gr):
+        assert re_(a, b) < 1e-4, (name, re_(a, b))
