@@ -507,9 +507,11 @@ def run_directional(args, device, rank, world):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # roofline leg: the power-of-two irfft of the 32 x 9 SH-domain responses (both passes), in the step
+    # roofline leg: the backward kernel of the directional EDC loss (the largest HBM-bound launch of the band-step since the
+    # transforms run on the 27 line responses), in the step
     tr, step, store = steps[0]
-    hip_ops.kernel_timer.watch = 'irfft_pow2_fwd'
+    lines = tr._use_lines(step.batch)
+    hip_ops.kernel_timer.watch = 'k_em_bwd' if lines else 'irfft_pow2_fwd'
     hip_ops.kernel_timer.start()
     for _ in range(10):
         tr.train_step(step.batch)
@@ -524,12 +526,29 @@ def run_directional(args, device, rank, world):
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': f'directional DiffGFDN: {nb} octave bands (independent models, graph replays round-robin on {nstreams} stream(s)), each {Gd} groups x {L} SH '
                                   f'channels (N = {Gd * L}), {J} directions, {R} receivers, nfft 131072, batch {BATCH} '
-                                  'receivers/band/step/GPU; step = SH forward + directional EDC + colorless losses + bwd + '
+                                  'receivers/band/step/GPU; step = line responses + 27 line transforms + directional EDC + colorless losses + bwd + '
                                   'Adam per band, one HIP-graph replay per band', 'bands': nb, 'receivers': R, 'band_streams': nstreams,
                        'directions': J, 'delay_lines': Gd * L, 'rirs_per_s': rirs_per_s,
                        'ms_per_band_step': 1e3 * elapsed / args.steps / nb,
                        'final_loss': float(total)}}
-    if kt:
+    if kt and lines:
+        crit = tr.criterion[0]
+        win = min(crit.edc_len_samps, NFFT - crit.mixing_time_samps)
+        units = kt['units_per_launch']                      # receivers per launch
+        per = 2 * L * win * 4                               # the receiver's 9 SH signals on the EDC window in, their gradient out
+        us = kt['avg_ms'] * 1e3
+        out['roofline'] = {'bound': 'hbm', 'achieved': units * per / us / 1e3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': units * per / us / 1e3 / HBM_PEAK_GBS,
+                           'traffic': pmc_traffic_bytes('k_em_bwd', 'directional_pmc_hbm_bytes.csv'),
+                           'traffic_source': f'profiles/{PROFILE_TAG}_directional_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE, '
+                                             'separate --pmc runs)',
+                           'kernel': 'k_em_bwd<9, 12> (directional EDC loss, backward: dL/dEDC recomputed, prefix scans of the 12 '
+                                     'directions in registers, gradient mixed back to the 9 SH channels)',
+                           'avg_launch_us': us, 'launches': kt['launches'], 'alg_bytes_per_unit': per,
+                           'units_per_launch': units, 'edc_window_samples': win,
+                           'measured': 'HIP events around the one kernel (gfdn_edc_loss_model_mixed_stages) in 10 host-launched '
+                                       'steps'}
+    elif kt:
         units = kt['units_per_launch']                      # SH-domain responses per launch (32 receivers x 9 channels)
         per = 8 * K + 2 * 8 * 65536 + 4 * NFFT              # spectrum in, work block out and in, samples out
         us = kt['avg_ms'] * 1e3
@@ -579,9 +598,14 @@ def cpu_baseline_directional(tr, z, Gd, L, J, receivers: int = 2):
              'listener_position': (10 * pos).to(dev), 'norm_listener_position': pos.to(dev),
              'target_common_slope_amps': amps.to(dev)}
     net.zero_grad(set_to_none=True)
-    out = net(batch)
-    H_sh = out[0] if isinstance(out, tuple) else out
-    edc = crit.forward_sh(H_sh, A, batch['target_common_slope_amps'], weight=tr.config.edc_loss_weight)
+    if tr._use_lines(batch):              # (the timed route: the output stage behind the transform, csrc/dirlin.hip)
+        Y, c, w = net.output_stage_inputs(batch)
+        edc = crit.forward_lines(Y, c, w, Gd, L, None, A, batch['target_common_slope_amps'],
+                                 weight=tr.config.edc_loss_weight)
+    else:
+        out = net(batch)
+        H_sh = out[0] if isinstance(out, tuple) else out
+        edc = crit.forward_sh(H_sh, A, batch['target_common_slope_amps'], weight=tr.config.edc_loss_weight)
     edc.backward()
     loss_h = float(edc.detach())
     gd = {}
@@ -913,7 +937,8 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
     if rank == 0:
         graph_mode = 'eager' if args.eager else 'hip_graph'
         if world > 1 and not args.eager and not args.epoch:
-            graph_mode += ' (all-reduce captured)' if step.allreduce_in_graph else ' (two graphs, eager all-reduce)'
+            graph_mode += ((f' (all-reduce captured: {step.collective_probe_nodes} graph node(s) in the capture probe)')
+                           if step.allreduce_in_graph else ' (two graphs, eager all-reduce)')
         fused = getattr(trainer, '_fused', None)
         out = {
             'metric': 'RIR-frames/sec', 'value': value, 'unit': 'RIR-frames/s', 'n_gpus': world,

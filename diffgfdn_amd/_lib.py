@@ -136,6 +136,8 @@ SIGNATURES = {
     "gfdn_dirlin_lines_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "gfdn_dirlin_combine": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P]),
     "gfdn_dirlin_gamma_dots": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "gfdn_edc_loss_model_mixed_stages": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
+                                                 c_float, c_float, _P, _P, _P, c_int, _P]),
     "gfdn_rfft_pow2": (c_int, [c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_sh_to_directional": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_stft_nframes": (c_int, [c_int, c_int]),

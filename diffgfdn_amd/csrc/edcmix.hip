@@ -302,9 +302,17 @@ extern "C" size_t gfdn_edc_mixed_work_bytes(int B, int J, int len) {
   return (size_t)3 * B * J * nseg * sizeof(float);
 }
 
+// stages: 1 = the forward chain (energies, carries, loss, carries), 2 = the backward kernel
 template <int C, int JT>
-static int em_run(EmArgs a, hipStream_t s) {
+static int em_run(EmArgs a, hipStream_t s, int stages) {
   dim3 grid(a.nseg, a.B), block(EM_T);
+  if (!(stages & 1)) {
+    if ((stages & 2) && a.gx) {
+      hipLaunchKernelGGL((k_em_bwd<C, JT>), grid, block, 0, s, a);
+      GFDN_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   hipLaunchKernelGGL((k_em_segsum<C, JT>), grid, block, 0, s, a);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_em_carry, dim3(a.B * a.J), dim3(64), 0, s, a.seg, a.nseg, 1, (const float*)nullptr, 0.f,
@@ -315,23 +323,24 @@ static int em_run(EmArgs a, hipStream_t s) {
   hipLaunchKernelGGL(k_em_carry, dim3(a.B * a.J), dim3(64), 0, s, a.gs, a.nseg, 0, (const float*)a.part,
                      a.inv_count * a.gscale, a.loss_item);
   GFDN_LAUNCH_CHECK();
-  if (a.gx) {
+  if ((stages & 2) && a.gx) {
     hipLaunchKernelGGL((k_em_bwd<C, JT>), grid, block, 0, s, a);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
 }
 template <int C>
-static int em_run_c(const EmArgs& a, hipStream_t s) {
-  if (a.J <= 8) return em_run<C, 8>(a, s);
-  if (a.J <= 12) return em_run<C, 12>(a, s);
-  return em_run<C, 16>(a, s);
+static int em_run_c(const EmArgs& a, hipStream_t s, int stages) {
+  if (a.J <= 8) return em_run<C, 8>(a, s, stages);
+  if (a.J <= 12) return em_run<C, 12>(a, s, stages);
+  return em_run<C, 16>(a, s, stages);
 }
 
-extern "C" int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,
-                                         const float* amps, int S, const float* env, int ld_env, const float* maskw,
-                                         float inv_count, float gscale, float* loss_item, float* gx_sh, void* work,
-                                         void* stream) {
+extern "C" int gfdn_edc_loss_model_mixed_stages(const float* x_sh, int ld, int B, int C, const float* A, int J, int start,
+                                                int len, const float* amps, int S, const float* env, int ld_env,
+                                                const float* maskw, float inv_count, float gscale, float* loss_item,
+                                                float* gx_sh, void* work, int stages, void* stream) {
+  if ((stages & ~3) || !stages) return GFDN_E_BADARG;
   if (!x_sh || !A || !amps || !env || !loss_item || !work || B <= 0 || C <= 0 || J <= 0 || start < 0 || len <= 0 ||
       start + len > ld || S <= 0 || ld_env < len)
     return GFDN_E_BADARG;
@@ -346,10 +355,18 @@ extern "C" int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C
   a.loss_item = loss_item; a.gx = gx_sh;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
-    case 1: return em_run_c<1>(a, s);
-    case 4: return em_run_c<4>(a, s);
-    case 9: return em_run_c<9>(a, s);
-    case 16: return em_run_c<16>(a, s);
+    case 1: return em_run_c<1>(a, s, stages);
+    case 4: return em_run_c<4>(a, s, stages);
+    case 9: return em_run_c<9>(a, s, stages);
+    case 16: return em_run_c<16>(a, s, stages);
     default: return GFDN_E_UNSUPPORTED;
   }
+}
+
+extern "C" int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,
+                                         const float* amps, int S, const float* env, int ld_env, const float* maskw,
+                                         float inv_count, float gscale, float* loss_item, float* gx_sh, void* work,
+                                         void* stream) {
+  return gfdn_edc_loss_model_mixed_stages(x_sh, ld, B, C, A, J, start, len, amps, S, env, ld_env, maskw, inv_count, gscale,
+                                          loss_item, gx_sh, work, 3, stream);
 }

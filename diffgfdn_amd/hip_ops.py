@@ -1701,9 +1701,16 @@ def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None
     gx = torch.empty_like(x_sh) if want_grad else None
     lib = _lib.load()
     work = _work(lib.gfdn_edc_mixed_work_bytes(B, J, length), x_sh.device)
-    _lib.check(lib.gfdn_edc_loss_model_mixed(_p(x_sh), T, B, C, _p(A), J, start, length, _p(amps), S, _p(env),
-                                             env.shape[1], _p(maskw), float(inv_count), float(gscale), _p(loss_item),
-                                             _p(gx), _p(work), _stream()), "gfdn_edc_loss_model_mixed")
+    args = (_p(x_sh), T, B, C, _p(A), J, start, length, _p(amps), S, _p(env), env.shape[1], _p(maskw), float(inv_count),
+            float(gscale), _p(loss_item), _p(gx), _p(work))
+    if want_grad and kernel_timer.active and kernel_timer.watch == 'k_em_bwd':     # events around the one kernel
+        _lib.check(lib.gfdn_edc_loss_model_mixed_stages(*args, 1, _stream()), "gfdn_edc_loss_model_mixed_stages[1]")
+        end = kernel_timer.bracket('k_em_bwd', B)
+        _lib.check(lib.gfdn_edc_loss_model_mixed_stages(*args, 2, _stream()), "gfdn_edc_loss_model_mixed_stages[2]")
+        if end is not None:
+            end.record()
+        return loss_item, gx
+    _lib.check(lib.gfdn_edc_loss_model_mixed(*args, _stream()), "gfdn_edc_loss_model_mixed")
     return loss_item, gx
 
 

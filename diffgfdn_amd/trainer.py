@@ -827,6 +827,19 @@ class GraphedModuleStep:
         return self.out
 
 
+def _graph_node_count(graph: "torch.cuda.CUDAGraph") -> Optional[int]:
+    """Number of nodes of a captured graph (hipGraphGetNodes on the raw handle; the graph must have been created with
+    keep_graph=True).  None if the runtime does not answer."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        n = ctypes.c_size_t(0)
+        rc = hip.hipGraphGetNodes(ctypes.c_void_p(graph.raw_cuda_graph()), None, ctypes.byref(n))
+        return int(n.value) if rc == 0 else None
+    except (OSError, AttributeError, RuntimeError):
+        return None
+
+
 class GraphedTrainStep:
     """One optimiser step (collate -> normalize -> forward -> losses -> backward -> [all-reduce] ->
     Adam) captured into HIP graphs and replayed: ~400 kernel launches per step collapse into one
@@ -889,6 +902,7 @@ class GraphedTrainStep:
             mask_seed = int(seed_t.item())
         self.mask_seed = int(mask_seed)
         self.graph_a = self.graph_b = self.graph_p = None
+        self.collective_probe_nodes = None        # nodes the probe's captured all-reduce left in its graph (None: no probe)
         self.losses = None
         # receiver schedule (load_schedule / run_next): the batches of an epoch live on the device and every step ends
         # by fetching the next step's receivers into ``idx`` -- no host copy in front of a replay
@@ -1162,9 +1176,12 @@ class GraphedTrainStep:
             dist.all_reduce(probe, group=pg)                     # communicator set up outside the capture
             torch.cuda.synchronize()
             probe.fill_(1.0)
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(g):
                 dist.all_reduce(probe, group=pg)
+            # how many nodes the captured collective left in the graph (0 on a one-rank group, where the library
+            # makes an in-place all-reduce a no-op: such a probe says nothing about capturing a collective)
+            self.collective_probe_nodes = _graph_node_count(g)
             g.replay()
             torch.cuda.synchronize()
             ok = bool((probe == float(dist.get_world_size(pg))).all().item())

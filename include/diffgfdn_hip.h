@@ -716,6 +716,13 @@ size_t gfdn_edc_mixed_work_bytes(int B, int J, int len);
 int gfdn_edc_loss_model_mixed(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,
                               const float* amps, int S, const float* env, int ld_env, const float* maskw,
                               float inv_count, float gscale, float* loss_item, float* gx_sh, void* work, void* stream);
+/* The same in two separately launched stages (bit mask; 3 = gfdn_edc_loss_model_mixed): 1 = the forward chain (segment
+ * energies, carries, loss, carries; work keeps the carries), 2 = the backward kernel k_em_bwd alone (after a stage-1 call on
+ * the same arguments and work) -- so that a caller can put events around the one kernel (bench.py's roofline leg).     */
+int gfdn_edc_loss_model_mixed_stages(const float* x_sh, int ld, int B, int C, const float* A, int J, int start, int len,
+                                     const float* amps, int S, const float* env, int ld_env, const float* maskw,
+                                     float inv_count, float gscale, float* loss_item, float* gx_sh, void* work, int stages,
+                                     void* stream);
 
 /* ---- The directional model's output stage in the time domain (csrc/dirlin.hip; reference model.py:1056-1088,
  * trainer.py:853-865, losses.py:333-371).  H_sh[b][l] = filt sum_g w[b][g nper + l] c[g nper + l] Y[:, g nper + l] is linear

@@ -74,11 +74,14 @@ class OracleGridTrainer:
 
 def directional_band_step(state: Dict[str, torch.Tensor], delays, analysis_matrix, z, norm_pos, amps, envelopes,
                           num_groups: int, n_per_group: int, num_fourier_features: int, mix_samps: int, edc_samps: int,
-                          edc_weight: float = 1.0):
+                          edc_weight: float = 1.0, colorless: Optional[Dict] = None):
     """Forward, directional EDC loss and backward of ONE band-step of the directional model on the CPU (test
     infrastructure / bench cpu_baseline; reference model.py:1043-1094, trainer.py:853-865, losses.py:333-371): the
     reference's arithmetic under autograd -- complex128 resolvent by torch.linalg.inv, float64 elsewhere.
-    ``state``: the module's state dict (CPU tensors).  Returns (loss, H_sh, H_dir, {parameter name: gradient})."""
+    ``state``: the module's state dict (CPU tensors).  Returns (loss, H_sh, H_dir, {parameter name: gradient}).
+    ``colorless`` = {'spectral_weight', 'sparsity_weight', 'use_asym'}: the colorless terms of the trainer's step on the raw
+    sub-FDNs are added to the total (trainer.py:298-313: spectral term per group, sparsity term of the LAST group only, as
+    the reference's loop leaves it); the return value then carries a fifth entry, the dict of the three terms."""
     sd = {k: v.detach().cpu().clone() for k, v in state.items()}
     prm = {k: sd[k].clone().requires_grad_(True) for k in ('input_gains', 'output_gains', 'feedback_loop.M')}
     root = 'sh_output_scalars.mlp.model.'
@@ -97,5 +100,18 @@ def directional_band_step(state: Dict[str, torch.Tensor], delays, analysis_matri
     H_sh = orc.directional_forward(z, prm['input_gains'], prm['output_gains'], w_sh, P, num_groups, n_per_group)
     H_dir = orc.sh_to_directional(torch.as_tensor(analysis_matrix), H_sh)
     loss = edc_weight * orc.directional_edc_loss(H_dir, amps, envelopes, mix_samps, edc_samps)
-    loss.backward()
-    return loss.detach(), H_sh.detach(), H_dir.detach(), {k: v.grad for k, v in prm.items() if v.grad is not None}
+    if colorless is None:
+        loss.backward()
+        return loss.detach(), H_sh.detach(), H_dir.detach(), {k: v.grad for k, v in prm.items() if v.grad is not None}
+    Hs, _ = orc.sub_fdn_output(z, prm['feedback_loop.M'], prm['input_gains'], prm['output_gains'], dl)
+    crit = orc.amse_loss if colorless.get('use_asym', False) else orc.mse_loss
+    spec = 0.0
+    for k in range(num_groups):
+        hk = Hs[..., k]
+        spec = spec + colorless['spectral_weight'] * crit(hk, torch.ones_like(hk))
+        spars = colorless['sparsity_weight'] * orc.sparsity_loss(orc.ortho_param(prm['feedback_loop.M'][k]))
+    terms = {'edc_loss': loss.detach(), 'spectral_loss': spec.detach(), 'sparsity_loss': spars.detach()}
+    total = loss + spec + spars
+    total.backward()
+    return (total.detach(), H_sh.detach(), H_dir.detach(), {k: v.grad for k, v in prm.items() if v.grad is not None},
+            terms)

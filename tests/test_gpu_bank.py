@@ -551,6 +551,7 @@ def test_bank_allreduce_captured_inside_the_graph():
             step = tr.graphed(sds, 4, mask_seed=5).capture(sds.global_rows(sel[0]))
             if mode == "in_graph":
                 assert step.allreduce_in_graph and step.graph_b is None
+                probe_nodes = step.collective_probe_nodes
             if mode == "split":
                 assert step.graph_b is not None
             vals = []
@@ -565,6 +566,13 @@ def test_bank_allreduce_captured_inside_the_graph():
             for q in range(len(BANDS)):
                 for k, v in out["single"][1][q].items():
                     assert torch.equal(v, out[mode][1][q][k]), (mode, q, k)
+        # What this proves: the step's structure with the collective inside the graph, and that the reported losses come
+        # back from the reduced slots.  Whether a COLLECTIVE was captured is a separate question: on a one-rank group RCCL
+        # turns the in-place all-reduce into nothing and the probe's graph has no node -- then there is nothing to assert.
+        if not probe_nodes:
+            pytest.skip(f"the one-rank all-reduce left {probe_nodes} node(s) in the probe graph: values and structure were "
+                        "checked above, capture of a real collective needs more than one rank (driver's N > 1 bench)")
+        assert probe_nodes >= 1
     finally:
         if created:
             dist.destroy_process_group()

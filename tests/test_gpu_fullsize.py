@@ -525,3 +525,58 @@ def test_directional_full_size_forward_backward_vs_oracle():
         ref = grads_o[name].numpy()
         err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
         assert err < GRAD_TOL, ('forward_lines', name, err)
+
+
+def test_directional_full_size_trainer_step_with_colorless_terms_vs_oracle():
+    """The directional trainer's own step at BASELINE.json configs[3]'s size WITH the colorless terms (reference
+    trainer.py:690-921, :298-313), as bench.py times it: line responses -> 27 line transforms -> directional EDC loss on
+    the window (csrc/dirlin.hip, csrc/edcmix.hip) on the main stream, the raw sub-FDN branch with the spectral and sparsity
+    terms on the side stream; every term and every parameter gradient against the oracle's autograd."""
+    from diffgfdn_amd.config import (CouplingMatrixType, DiffGFDNConfig, FeedbackLoopConfig, OutputFilterConfig,
+                                     TrainerConfig)
+    from diffgfdn_amd.model import DiffDirectionalFDNVarReceiverPos
+    from diffgfdn_amd.trainer import DirectionalFDNVarReceiverPosTrainer
+    Gd, order, J, Bd = 3, 2, 12, 2
+    L = (order + 1) ** 2
+    rng = np.random.RandomState(13)
+    torch.manual_seed(78)
+    delays = DiffGFDNConfig(num_groups=Gd, num_delay_lines=Gd * L, sample_rate=FS, seed=4712).delay_length_samps
+    fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
+    A = rng.randn(J, L).astype(np.float32)
+    T60 = np.linspace(0.5, 1.2, Gd)
+    net = DiffDirectionalFDNVarReceiverPos(FS, Gd, delays, DEV, fl, of, ambi_order=order,
+                                           common_decay_times=T60[None, :], use_colorless_loss=True,
+                                           analysis_matrix=A).to(DEV)
+    tc = TrainerConfig(use_colorless_loss=True, use_asym_spectral_loss=True, edc_loss_weight=10.0,
+                       spectral_loss_weight=1.5, sparsity_loss_weight=2.0, use_edc_mask=False, lr=1e-3, io_lr=1e-2,
+                       device='cuda', train_dir='/tmp/gfdn_t/dirc', ir_dir='/tmp/gfdn_a/dirc')
+    tr = DirectionalFDNVarReceiverPosTrainer(net, tc)
+    z = torch.exp(1j * np.pi * torch.arange(K, dtype=torch.float64) / (K - 1))
+    pos = torch.tensor(rng.uniform(0, 1, (Bd, 3)))
+    amps = torch.tensor(rng.uniform(0.1, 1.0, (Bd, J, Gd)))
+    batch = {'z_values': z.to(DEV), 'listener_position': (10 * pos).to(DEV), 'norm_listener_position': pos.to(DEV),
+             'source_position': torch.zeros(Bd, 3, dtype=torch.float64, device=DEV),
+             'target_common_slope_amps': amps.to(DEV)}
+    assert tr._use_lines(batch) and tr._side_stream() is not None
+    crit = tr.criterion[0]
+    net.zero_grad(set_to_none=True)
+    losses = tr._step_losses(batch)
+    total = losses.pop('_total')
+    total.backward()
+    torch.cuda.synchronize()
+
+    from oracle.cpu_trainer import directional_band_step
+    tot_o, _, _, grads_o, terms_o = directional_band_step(
+        net.state_dict(), delays, A, z, pos, amps, crit.envelopes.cpu(), Gd, L, 4, crit.mixing_time_samps,
+        crit.edc_len_samps, edc_weight=10.0,
+        colorless={'spectral_weight': 1.5, 'sparsity_weight': 2.0, 'use_asym': True})
+    for k, v in terms_o.items():
+        assert abs(float(losses[k]) - float(v)) < LOSS_TOL * abs(float(v)), (k, float(losses[k]), float(v))
+    assert abs(float(total) - float(tot_o)) < LOSS_TOL * abs(float(tot_o))
+    for name, p_ in net.named_parameters():
+        if name not in grads_o:
+            continue
+        ref = grads_o[name].numpy()
+        err = np.abs(p_.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < GRAD_TOL, (name, err)
