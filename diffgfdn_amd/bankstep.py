@@ -85,10 +85,11 @@ class FusedBankStep:
     # is left, the EDC scans form their samples on the fly (gfdn_edc_loss_pairs_lin) and the receivers' signals are never
     # stored.
     spectral_edr = os.environ.get('GFDN_SPECTRAL_EDR', '1') == '1'
-    # ... with the sum of the gradient spectra over the band's receivers inside the EDR launch (k_edr_lin_fused)
-    # (OFF: 213 us against 99 + 83 for the two launches -- one 128 KB workgroup per CU keeps too few loads in flight and
-    # starves the colorless pass beside it of LDS; csrc/edrlin.hip)
-    edr_one_launch = os.environ.get('GFDN_EDR_ONE_LAUNCH', '0') == '1'
+    # ... with the sum of the gradient spectra over the band's receivers inside the EDR launch (k_edr_lin_band: a thread owns
+    # cells of the band's plane and walks the receivers; dL/d|S|^2 never exists, the direct-path spectra are read once), the
+    # band's receivers cut into ``edr_receiver_runs`` runs for more loads in flight
+    edr_one_launch = os.environ.get('GFDN_EDR_ONE_LAUNCH', '1') == '1'
+    edr_receiver_runs = int(os.environ.get('GFDN_EDR_RUNS', '2'))
     # ... on planes stored in the tiled cell order (frequency blocks of 256, a block's frames contiguous): what a (receiver,
     # frequency block) workgroup of the EDR kernel touches is one contiguous run
     tiled_spectra = os.environ.get('GFDN_TILED_SPECTRA', '1') == '1'
@@ -227,7 +228,7 @@ class FusedBankStep:
         tr, cfg, keep = self.tr, self.tr.config, self._keep
         Btot, win = rows.numel(), tr.stft_win
         ds = data['dataset']
-        tiled = self.tiled_spectra and not self.edr_one_launch
+        tiled = self.tiled_spectra
         Sd = ds.direct_stft(tr.subband_filter_freq_resp, K, win, tiled=tiled)
         if tiled:
             T_edr = ds.edr_target_tiled()
@@ -249,7 +250,7 @@ class FusedBankStep:
         gP = Gs = None
         if train and self.edr_one_launch:
             li_edr, Gs = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, dots=parts,
-                                               col0=nch)
+                                               col0=nch, tiled=tiled, nsplit=self.edr_receiver_runs)
         else:
             li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
                                           dots=parts, col0=nch, tiled=tiled)

@@ -12,6 +12,8 @@
 //                    dL/dgain[b][g] = Re sum_cells conj(Stau_g) dL/dS,  dL/dS = 2 gP S   (tail sums of Re(conj(Stau_g) S))
 //   k_edr_lin_gsum : per (band, cell): Gsum_g = sum_b gain[b][g] dL/dS[b] -- the G gradient spectra per band whose adjoint
 //                    STFT (k_stft4k_pair_spec_bwd, 14 signal pairs) is the EDR part of dL/dtau_g
+//   k_edr_lin_band : both of the above in ONE launch (the training step's): threads own cells of the band's plane and walk
+//                    the band's receivers; dL/d|S|^2 never reaches memory, the direct-path spectra are read once
 //   k_stft4k_pair_spec(_bwd) : STFT of pair-interleaved signals to complex one-sided spectra, and its adjoint from
 //                    gradient spectra (the forms of fft.hip's k_stft4k_pair_power(_bwd) without the |.|^2 stage).
 // All sums in fixed order (bitwise reproducible).
@@ -46,10 +48,12 @@ struct EdrLin {
 };
 
 // One thread per (receiver, frequency) column, one descending sweep over the frames (see the body).
+// The training step runs k_edr_lin_band below instead (receivers summed in the launch); this kernel serves the value-only pass
+// (validation) and is the cross-check of the tests.
 // (Measured alternatives, same box: the group spectra of a 64-frequency tile staged in LDS for 8 receivers per workgroup --
 // 64 KB, two workgroups per CU -- 175 us against 99; the whole band per workgroup with the receivers' gradient spectra summed
-// through an LDS exchange, k_edr_lin_fused below -- 128 KB, one workgroup per CU -- 213 us and it starves the colorless pass
-// beside it of LDS: both keep far fewer loads in flight than 2016 independent workgroups do.)
+// through a 64 KB LDS exchange beside 64 KB of staged group spectra -- one workgroup per CU -- 213 us, and it starves the
+// colorless pass beside it of LDS: both keep far fewer loads in flight than 2016 independent workgroups do.)
 //   part[b][fblk] = sum_{f in block, m} |T - EDR| (to be divided by sum_abs, as gfdn_edr_loss(defer))
 //   gP (items, nframes, nfreq) = gscale / sum_abs dloss/d|S|^2
 //   dots[(b G + g) ld_dots + col0 + fblk] = partial of the EDR part of dL/dgain[b][g]
@@ -151,150 +155,166 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
   }
 }
 
-// The same columns with the gradient spectra summed over the band's receivers IN the launch: one workgroup = one band x
-// EDL_FT frequencies x ALL receivers of the band, four at a time (one per wave).  Behind its column a wave leaves
-// dL/dS = 2 gP S (nframes complex per lane) in an LDS exchange block; after a barrier the 256 threads re-partition --
-// thread (lane, wave w) owns the frames 8 w .. 8 w + 7 of its frequency -- and add the four receivers' terms
-// gain[b][g] dL/dS[b] into 4 x 8 complex register accumulators, in receiver order (fixed: bitwise reproducible).  dL/d|S|^2
-// is never written and the transformed direct paths are read once: 235 MB less traffic per step than the two launches
-// (k_edr_lin_cols + k_edr_lin_gsum), which stay as the cross-check and for the value-only pass.
-__global__ __launch_bounds__(256, 1) void k_edr_lin_fused(EdrLin a, int nframes, int nfreq, float gscale,
-                                                          float* __restrict__ part, float* __restrict__ dots, int ld_dots,
-                                                          int col0, float2* __restrict__ Gsum) {
-  const int G = a.G, B = a.B, tile = blockIdx.x, ntiles = gridDim.x, band = blockIdx.y;
-  float2* lt = edl_lds;                                   // [g][m][EDL_FT]: the band's group spectra of the tile
-  float2* ex = lt + (size_t)G * nframes * EDL_FT;         // [wave][m][EDL_FT]: dL/dS of the four receivers of a round
-  const size_t cells = (size_t)nframes * nfreq;
-  const int f0 = tile * EDL_FT;
-  for (int idx = threadIdx.x; idx < G * nframes * EDL_FT; idx += 256) {
-    const int ff = idx & (EDL_FT - 1), gm = idx / EDL_FT;
-    lt[idx] = f0 + ff < nfreq ? a.Stau[(size_t)band * G * cells + (size_t)gm * nfreq + f0 + ff] : make_float2(0.f, 0.f);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int f = f0 + lane;
+// The same loss with the gradient spectra summed over the band's receivers IN the launch, without dL/d|S|^2 in memory and
+// with the transformed direct paths read once (176 MB per step instead of the 426 MB of k_edr_lin_cols + k_edr_lin_gsum).
+// A thread OWNS cells of the band's (frame, frequency) plane -- lane = one of EDB_FT = 64 frequencies, wave w = the frames
+// 4 w .. 4 w + 3 -- keeps the band's G group spectra of its cells (32 registers) and its share of the G gradient spectra
+// (32 accumulator registers) for the whole launch, and walks the band's receivers: per receiver it loads its 4 cells of the
+// direct-path spectrum and the target, composes S, and the two scans along the frames (tail energy; prefix sums of
+// dL/dE) run inside the thread over its 4 frames and across the 8 waves through two 2 KB LDS exchanges (one barrier each).
+// The receivers are added in index order: bitwise reproducible.  ``nsplit`` > 1: the receivers of a band are cut into nsplit
+// runs handled by different workgroups (more loads in flight), each writing its own partial planes Gsum[split]; the adjoint
+// STFT adds them on load.
+// (Round-4 history: the first fused form -- one receiver per wave, the gradient spectra summed through a 64 KB LDS exchange,
+// the group spectra staged in another 64 KB -- took 213 us at one workgroup per CU)
+//   part[b][tile]                           : loss partials (sum |T - EDR| of the tile's cells)
+//   dots[(b G + g) ld_dots + col0 + tile]   : partials of the EDR part of dL/dgain[b][g]
+#define EDB_FT 64
+#define EDB_W 8
+#define EDB_Q 4
+// value v of receiver b: 0 = the loss partial, 1 + g = the partial of dL/dgain[b][g] -- the eight waves' sums in wave order
+__device__ __forceinline__ void edb_flush(const float (*r)[EDL_MAXG + 1], int v, int b, int G, int tile,
+                                          float* __restrict__ part, int ld_part, float* __restrict__ dots, int ld_dots,
+                                          int col0) {
+  float s = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < EDB_W; ++w2) s += r[w2][v];
+  if (v == 0) part[(size_t)b * ld_part + tile] = s;
+  else if (dots) dots[((size_t)b * G + (v - 1)) * ld_dots + col0 + tile] = s;
+}
+__global__ __launch_bounds__(EDB_FT * EDB_W, 4) void k_edr_lin_band(EdrLin a, int nframes, int nfreq, float gscale,
+                                                                    float* __restrict__ part, int ld_part,
+                                                                    float* __restrict__ dots, int ld_dots, int col0,
+                                                                    float2* __restrict__ Gsum, int nsplit, int nbands) {
+  __shared__ float exA[EDB_W][EDB_FT], exB[EDB_W][EDB_FT];
+  __shared__ float red[2][EDB_W][EDL_MAXG + 1];             // per receiver parity: the waves' loss / gain-gradient sums
+  const int G = a.G, B = a.B, tile = blockIdx.x, band = blockIdx.y, split = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int f = tile * EDB_FT + lane;
   const bool live = f < nfreq;
   const int fc = live ? f : nfreq - 1;
-  float2 Ga[EDL_MAXG][8];
+  const size_t cells = (size_t)nframes * nfreq;
+  unsigned cq[EDB_Q];                                       // (cell index inside a plane: 32 bits; the row bases are uniform)
+  bool mv[EDB_Q];
+#pragma unroll
+  for (int q = 0; q < EDB_Q; ++q) {
+    const int m = EDB_Q * w + q;
+    mv[q] = m < nframes;
+    cq[q] = (unsigned)edl_cell(mv[q] ? m : 0, fc, nframes, nfreq, a.tiled);
+  }
+  float2 st[EDL_MAXG][EDB_Q], Ga[EDL_MAXG][EDB_Q];
 #pragma unroll
   for (int g = 0; g < EDL_MAXG; ++g)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) Ga[g][q] = make_float2(0.f, 0.f);
-  const int nrounds = (B + 3) / 4;
-  for (int rd = 0; rd < nrounds; ++rd) {
-    const int bl = rd * 4 + wave;
-    float2* exw = ex + (size_t)wave * nframes * EDL_FT + lane;
-    if (bl < B) {
-      const int b = band * B + bl;
-      const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
-      float rg[EDL_MAXG];
+    for (int q = 0; q < EDB_Q; ++q) {
+      st[g][q] = (g < G && mv[q]) ? (a.Stau + ((size_t)band * G + g) * cells)[cq[q]] : make_float2(0.f, 0.f);
+      Ga[g][q] = make_float2(0.f, 0.f);
+    }
+  const int bper = (B + nsplit - 1) / nsplit;
+  const int b_lo = split * bper, b_hi = b_lo + bper < B ? b_lo + bper : B;
+  // software pipeline: the next receiver's cells are loaded before the current one's dependent chain
+  float2 sn[EDB_Q];
+  float tn[EDB_Q];
+  auto fetch = [&](int bl) {
+    const int b = band * B + bl;
+    const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
+    const float2* sdr = a.Sd + row * cells;
+    const float* tdr = a.Tdb + row * cells;
 #pragma unroll
-      for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
-      const float gs = gscale / a.sum_abs[row];
-      const float2* sd = a.Sd + row * cells + fc;
-      const float* t = a.Tdb + row * cells + fc;
-      float2 s[EDL_RF];
-      float tv[EDL_RF];
+    for (int q = 0; q < EDB_Q; ++q) {
+      sn[q] = mv[q] ? sdr[cq[q]] : make_float2(0.f, 0.f);
+      tn[q] = mv[q] ? tdr[cq[q]] : 0.f;
+    }
+  };
+  if (b_lo < b_hi) fetch(b_lo);
+  for (int bl = b_lo; bl < b_hi; ++bl) {
+    const int b = band * B + bl;
+    const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
+    float rg[EDL_MAXG];
 #pragma unroll
-      for (int m = 0; m < EDL_RF; ++m) {
-        s[m] = m < nframes ? sd[(size_t)m * nfreq] : make_float2(0.f, 0.f);
-        tv[m] = m < nframes ? t[(size_t)m * nfreq] : 0.f;
-      }
+    for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
+    const float gs = gscale / a.sum_abs[row];
+    float2 sv[EDB_Q];
+    float tv[EDB_Q], pw[EDB_Q];
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) {
+      sv[q] = sn[q];
+      tv[q] = tn[q];
 #pragma unroll
       for (int g = 0; g < EDL_MAXG; ++g) {
-        if (g < G) {
-#pragma unroll
-          for (int m = 0; m < EDL_RF; ++m) {
-            if (m < nframes) {
-              const float2 tg = lt[(g * nframes + m) * EDL_FT + lane];
-              s[m].x += rg[g] * tg.x;
-              s[m].y += rg[g] * tg.y;
-            }
-          }
-        }
+        sv[q].x += rg[g] * st[g][q].x;
+        sv[q].y += rg[g] * st[g][q].y;
       }
-      float acc = 0.f, E = 0.f;
-#pragma unroll
-      for (int m = EDL_RF - 1; m >= 0; --m) {
-        if (m < nframes) {
-          E += s[m].x * s[m].x + s[m].y * s[m].y;
-          const float lin = fabsf(E) + F32_EPS;
-          const float raw = 10.0f * log10f(lin);
-          const float d = fmaxf(raw, -200.0f);
-          const float diff = tv[m] - d;
-          acc += fabsf(diff);
-          const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-          const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
-          tv[m] = -sg * dE * gs;
-        }
-      }
-      acc = wave_sum_full(live ? acc : 0.f);
-      if (lane == 0) part[(size_t)b * ntiles + tile] = acc;
-      float run = 0.f;
-#pragma unroll
-      for (int m = 0; m < EDL_RF; ++m) {
-        if (m < nframes) {
-          run += tv[m];
-          tv[m] = run;
-          const float p2 = live ? 2.0f * run : 0.f;
-          exw[(size_t)m * EDL_FT] = make_float2(p2 * s[m].x, p2 * s[m].y);      // dL/dS[b][m][f]
-        }
-      }
-      if (dots) {
-#pragma unroll
-        for (int g = 0; g < EDL_MAXG; ++g) {
-          if (g < G) {
-            float da = 0.f;
-#pragma unroll
-            for (int m = 0; m < EDL_RF; ++m) {
-              if (m < nframes) {
-                const float2 tg = lt[(g * nframes + m) * EDL_FT + lane];
-                da += tv[m] * (tg.x * s[m].x + tg.y * s[m].y);
-              }
-            }
-            da = wave_sum_full(live ? 2.0f * da : 0.f);
-            if (lane == 0) dots[((size_t)b * G + g) * ld_dots + col0 + tile] = da;
-          }
-        }
-      }
-    } else {
-      for (int m = 0; m < nframes; ++m) exw[(size_t)m * EDL_FT] = make_float2(0.f, 0.f);
+      pw[q] = sv[q].x * sv[q].x + sv[q].y * sv[q].y;
     }
+    if (bl + 1 < b_hi) fetch(bl + 1);
+#pragma unroll
+    for (int q = EDB_Q - 1; q >= 0; --q) tot += pw[q];
+    exA[w][lane] = tot;
     __syncthreads();
-    // frames 8 wave .. 8 wave + 7 of this lane's frequency: the round's receivers in order
+    // (behind this barrier every wave has left the previous receiver's sums in red[(bl - 1) & 1]: one thread per value adds
+    // the eight in wave order; the buffer is written again two receivers -- four barriers -- later)
+    if (bl > b_lo && threadIdx.x <= G) edb_flush(red[(bl - 1 - b_lo) & 1], threadIdx.x, band * B + bl - 1, G, tile, part,
+                                                 ld_part, dots, ld_dots, col0);
+    float E = 0.f;                                           // energy of the frames behind this thread's
+    for (int w2 = EDB_W - 1; w2 > w; --w2) E += exA[w2][lane];
+    float acc = 0.f, ge[EDB_Q], gtot = 0.f;
 #pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const int b2 = rd * 4 + w2;
-      if (b2 < B) {
-        float r2[EDL_MAXG];
-#pragma unroll
-        for (int g = 0; g < EDL_MAXG; ++g) r2[g] = g < G ? a.rgain[((size_t)band * B + b2) * G + g] : 0.f;
-        const float2* e2 = ex + (size_t)w2 * nframes * EDL_FT + lane;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int m = 8 * wave + q;
-          if (m < nframes) {
-            const float2 d = e2[(size_t)m * EDL_FT];
-#pragma unroll
-            for (int g = 0; g < EDL_MAXG; ++g) {
-              Ga[g][q].x += r2[g] * d.x;
-              Ga[g][q].y += r2[g] * d.y;
-            }
-          }
-        }
+    for (int q = EDB_Q - 1; q >= 0; --q) {
+      ge[q] = 0.f;
+      if (mv[q]) {
+        E += pw[q];
+        const float lin = fabsf(E) + F32_EPS;
+        const float raw = 10.0f * log10f(lin);
+        const float d = fmaxf(raw, -200.0f);
+        const float diff = tv[q] - d;
+        acc += fabsf(diff);
+        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+        ge[q] = -sg * dE * gs;
       }
     }
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) gtot += ge[q];
+    exB[w][lane] = gtot;
     __syncthreads();
+    float run = 0.f;                                         // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m'
+    for (int w2 = 0; w2 < w; ++w2) run += exB[w2][lane];
+    float da[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) {
+      run += ge[q];
+      const float p2 = 2.0f * run;
+      const float2 dS = make_float2(p2 * sv[q].x, p2 * sv[q].y);
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) {
+        Ga[g][q].x += rg[g] * dS.x;
+        Ga[g][q].y += rg[g] * dS.y;
+        da[g] += st[g][q].x * dS.x + st[g][q].y * dS.y;
+      }
+    }
+    acc = wave_sum_full(live ? acc : 0.f);
+    if (lane == 0) red[(bl - b_lo) & 1][w][0] = acc;
+#pragma unroll
+    for (int g = 0; g < EDL_MAXG; ++g) {
+      if (g < G) {
+        const float v = wave_sum_full(live ? da[g] : 0.f);
+        if (lane == 0) red[(bl - b_lo) & 1][w][1 + g] = v;
+      }
+    }
   }
+  __syncthreads();
+  if (b_lo < b_hi && threadIdx.x <= G) edb_flush(red[(b_hi - 1 - b_lo) & 1], threadIdx.x, band * B + b_hi - 1, G, tile, part,
+                                                 ld_part, dots, ld_dots, col0);
   if (live) {
+    float2* out = Gsum + (size_t)split * nbands * G * cells;
 #pragma unroll
     for (int g = 0; g < EDL_MAXG; ++g) {
       if (g < G) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int m = 8 * wave + q;
-          if (m < nframes) Gsum[((size_t)band * G + g) * cells + (size_t)m * nfreq + f] = Ga[g][q];
-        }
+        for (int q = 0; q < EDB_Q; ++q)
+          if (mv[q]) (out + ((size_t)band * G + g) * cells)[cq[q]] = Ga[g][q];
       }
     }
   }
@@ -420,7 +440,7 @@ __constant__ float2 c_edl_hann[16] = {
 // even frame reaches), the odd launch adds with a plain read-modify-write -- no atomics, no cleared buffer.
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2* __restrict__ Gs, int ld, int T,
                                                                 int nframes, int items, const float2* base2,
-                                                                float2* gx2, int parity, int tiled) {
+                                                                float2* gx2, int parity, int tiled, int nsplit) {
   float2* buf = edl_lds;
   const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
@@ -437,7 +457,12 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2*
     if (u < 8 || i == 0) {
       const int fc = (4096 - f) & 4095;
       const size_t c = edl_cell(m, f, nframes, nf, tiled);
-      const float2 Ga = ga[c], Gb = two ? gb[c] : make_float2(0.f, 0.f);
+      float2 Ga = ga[c], Gb = two ? gb[c] : make_float2(0.f, 0.f);
+      for (int sp = 1; sp < nsplit; ++sp) {                  // partial planes of k_edr_lin_band, in order
+        const size_t o = (size_t)sp * items * nframes * nf + c;
+        Ga = cadd(Ga, ga[o]);
+        if (two) Gb = cadd(Gb, gb[o]);
+      }
       if (f == 0 || f == 2048) {
         buf[S4K_PAD(f)] = make_float2(Ga.x, Gb.x);                                       // real-only bins
       } else {
@@ -487,8 +512,8 @@ extern "C" int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int item
 }
 
 extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2,
-                                            int ld, int tiled, void* stream) {
-  if (!G_c64 || !gx2 || items <= 0 || T <= 0 || ld < T || base2 == gx2) return GFDN_E_BADARG;
+                                            int ld, int tiled, int nsplit, void* stream) {
+  if (!G_c64 || !gx2 || items <= 0 || T <= 0 || ld < T || base2 == gx2 || nsplit <= 0) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = edl_nframes(T);
   if (nframes <= 0) return GFDN_E_BADARG;
@@ -497,7 +522,7 @@ extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items
     if (nb == 0) continue;
     hipLaunchKernelGGL(k_stft4k_pair_spec_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
                        (hipStream_t)stream, (const float2*)G_c64, ld, T, nframes, items, (const float2*)base2,
-                       (float2*)gx2, parity, tiled ? 1 : 0);
+                       (float2*)gx2, parity, tiled ? 1 : 0, nsplit);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
@@ -505,7 +530,7 @@ extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items
 
 // partial-sum columns per item: frequency blocks of 256 (gfdn_edr_lin_loss) or tiles of 64 (gfdn_edr_lin_loss_gsum)
 extern "C" int gfdn_edr_lin_parts(int nfreq) { return nfreq > 0 ? (nfreq + 255) / 256 : 0; }
-extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return nfreq > 0 ? (nfreq + EDL_FT - 1) / EDL_FT : 0; }
+extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return nfreq > 0 ? (nfreq + EDB_FT - 1) / EDB_FT : 0; }
 
 // EDR loss of nbands x B receivers on composed spectra (see the head of this file).  part (items, gfdn_edr_lin_parts):
 // loss partials as gfdn_edr_loss(loss_item = NULL) leaves them; want_grad: gP (items, nframes, nfreq) and the EDR part of
@@ -528,24 +553,23 @@ extern "C" int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, con
   return 0;
 }
 
-// gfdn_edr_lin_loss(want_grad) and gfdn_edr_lin_gsum as ONE launch (k_edr_lin_fused): part and dots as there, Gsum
-// (nbands G, nframes, nfreq) complex; dL/d|S|^2 is never written.
+// gfdn_edr_lin_loss(want_grad) and gfdn_edr_lin_gsum as ONE launch (k_edr_lin_band): part (items, ld_part >=
+// gfdn_edr_lin_fused_parts) and dots columns [col0, col0 + gfdn_edr_lin_fused_parts) as there, Gsum (nsplit, nbands G, nframes,
+// nfreq) complex partial planes (their sum over the first index is gfdn_edr_lin_gsum's output; the adjoint STFT takes nsplit);
+// dL/d|S|^2 is never written.
 extern "C" int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
                                       int nbands, int B, int G, const float* T_db, const float* sum_abs, int nframes,
-                                      int nfreq, float gscale, float* part, float* dots, int ld_dots, int col0,
-                                      float* Gsum_c64, void* stream) {
+                                      int nfreq, float gscale, float* part, int ld_part, float* dots, int ld_dots, int col0,
+                                      float* Gsum_c64, int nsplit, int tiled, void* stream) {
   if (!Sd_c64 || !Stau_c64 || !rgain || !T_db || !sum_abs || !part || !Gsum_c64 || nbands <= 0 || B <= 0 || G <= 0 ||
-      nframes <= 0 || nfreq <= 0)
+      nframes <= 0 || nfreq <= 0 || nsplit <= 0 || nsplit > B)
     return GFDN_E_BADARG;
-  const int ntiles = (nfreq + EDL_FT - 1) / EDL_FT;
-  if (G > EDL_MAXG || nframes > EDL_RF || nbands > 65535) return GFDN_E_UNSUPPORTED;
-  if (dots && (col0 < 0 || ld_dots < col0 + ntiles)) return GFDN_E_BADARG;
-  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, 0};
-  const size_t lds = (size_t)(G + 4) * nframes * EDL_FT * sizeof(float2);
-  int rc = ensure_dyn_lds(k_edr_lin_fused, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_edr_lin_fused, dim3(ntiles, nbands), dim3(256), lds, (hipStream_t)stream, a, nframes, nfreq, gscale,
-                     part, dots, ld_dots, col0, (float2*)Gsum_c64);
+  const int ntiles = (nfreq + EDB_FT - 1) / EDB_FT, nparts = ntiles;
+  if (G > EDL_MAXG || nframes > EDB_W * EDB_Q || nbands > 65535 || nsplit > 64) return GFDN_E_UNSUPPORTED;
+  if (ld_part < nparts || (dots && (col0 < 0 || ld_dots < col0 + nparts))) return GFDN_E_BADARG;
+  EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, tiled ? 1 : 0};
+  hipLaunchKernelGGL(k_edr_lin_band, dim3(ntiles, nbands, nsplit), dim3(EDB_FT * EDB_W), 0, (hipStream_t)stream, a, nframes,
+                     nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -1189,16 +1189,20 @@ def stft_pairs_spectrum(x2, items: int, win: int, tiled: bool = False) -> torch.
 
 def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: bool = False) -> torch.Tensor:
     """Adjoint of stft_pairs_spectrum: gradient spectra G (items, nframes, win / 2 + 1) complex64 -> gx2
-    (ceil(items / 2), n, 2) [+ base, same layout]."""
+    (ceil(items / 2), n, 2) [+ base, same layout].  G (nsplit, items, nframes, win / 2 + 1): partial sets, added in order
+    where they are loaded (edr_lin_loss_gsum)."""
     _need_gpu(G)
     G = _c(G)
-    if tuple(G.shape) != (items, stft_nframes(n, win), win // 2 + 1):
-        raise RuntimeError("stft_pairs_spectrum_bwd: G must be (items, nframes, win / 2 + 1)")
+    nsplit = 1
+    if G.dim() == 4:
+        nsplit, G = G.shape[0], G.reshape(G.shape[0] * G.shape[1], G.shape[2], G.shape[3])
+    if tuple(G.shape) != (nsplit * items, stft_nframes(n, win), win // 2 + 1):
+        raise RuntimeError("stft_pairs_spectrum_bwd: G must be ([nsplit,] items, nframes, win / 2 + 1)")
     gx2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=G.device)
     if base is not None and (base.dtype != _f32 or not base.is_contiguous() or base.shape != gx2.shape):
         raise RuntimeError("stft_pairs_spectrum_bwd: base must be shaped like the result")
-    _lib.check(_lib.load().gfdn_stft_pairs_spectrum_bwd(_p(G), n, items, win, _p(base), _p(gx2), n, int(tiled), _stream()),
-               "gfdn_stft_pairs_spectrum_bwd")
+    _lib.check(_lib.load().gfdn_stft_pairs_spectrum_bwd(_p(G), n, items, win, _p(base), _p(gx2), n, int(tiled), int(nsplit),
+                                                        _stream()), "gfdn_stft_pairs_spectrum_bwd")
     return gx2
 
 
@@ -1244,9 +1248,12 @@ def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: floa
     return part, gP
 
 
-def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, dots=None, col0: int = 0):
-    """edr_lin_loss(want_grad=True) and edr_lin_gsum as ONE launch -> (part, Gsum): the band's receivers are summed inside
-    the workgroup, dL/d|S|^2 is never written."""
+def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, dots=None, col0: int = 0,
+                      tiled: bool = False, nsplit: int = 1):
+    """edr_lin_loss(want_grad=True) and edr_lin_gsum as ONE launch (k_edr_lin_band) -> (part (items, edr_lin_parts(fused)),
+    Gsum (nsplit, nbands G, nframes, nfreq)): a thread owns cells of the band's plane and walks the band's receivers,
+    dL/d|S|^2 is never written, Sd is read once.  The band's receivers are cut into ``nsplit`` runs, one partial plane set
+    each: stft_pairs_spectrum_bwd adds them."""
     _need_gpu(Sd, Stau, rgain, T_db)
     Sd, Stau, rgain = _c(Sd), _c(Stau), _f(rgain)
     items, G = rgain.shape
@@ -1260,16 +1267,19 @@ def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale:
     lib = _lib.load()
     fblk = lib.gfdn_edr_lin_fused_parts(nfreq)
     part = torch.empty((items, fblk), dtype=_f32, device=Sd.device)
-    Gs = torch.empty((nbands * G, nframes, nfreq), dtype=_c64, device=Sd.device)
+    Gs = torch.empty((nsplit, nbands * G, nframes, nfreq), dtype=_c64, device=Sd.device)
     ld = 0
     if dots is not None:
         if dots.dtype != _f32 or not dots.is_contiguous() or dots.dim() != 2 or dots.shape[0] != items * G \
                 or dots.shape[1] < col0 + fblk:
             raise RuntimeError("edr_lin_loss_gsum: dots must be (items * G, >= col0 + parts) contiguous float32")
         ld = dots.shape[1]
+    end = kernel_timer.bracket('k_edr_lin_band', items)          # (bench.py's roofline leg: events on the launch stream)
     _lib.check(lib.gfdn_edr_lin_loss_gsum(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(T_db),
-                                          _p(_f(sum_abs)), nframes, nfreq, float(gscale), _p(part), _p(dots), ld, int(col0),
-                                          _p(Gs), _stream()), "gfdn_edr_lin_loss_gsum")
+                                          _p(_f(sum_abs)), nframes, nfreq, float(gscale), _p(part), fblk, _p(dots), ld,
+                                          int(col0), _p(Gs), int(nsplit), int(tiled), _stream()), "gfdn_edr_lin_loss_gsum")
+    if end is not None:
+        end.record()
     return part, Gs
 
 

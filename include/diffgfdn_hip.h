@@ -552,7 +552,9 @@ int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nban
  * rows: item -> row of Sd / T_db / sum_abs (NULL: identity).  G <= 4, nframes <= 32.                                    */
 int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, int tiled, void* stream);
 int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2, int ld,
-                                 int tiled, void* stream);
+                                 int tiled, int nsplit, void* stream);
+/* nsplit >= 1: G holds nsplit partial sets (nsplit, items, nframes, 2049) that are added, in order, where they are loaded
+ * (the partial planes of gfdn_edr_lin_loss_gsum).                                                                       */
 /* tiled = 1: the (nframes, nfreq) planes of S / G / Sd / Stau / T_db / gP / Gsum are stored with the frequencies cut into
  * blocks of 256 and a block's frames contiguous -- cell(m, f) = (f / 256) nframes 256 + m w + f % 256, w = the block's
  * width (the last block holds the rest) -- so that a (receiver, frequency block) workgroup of gfdn_edr_lin_loss streams
@@ -564,11 +566,15 @@ int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* S
                       int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0, int tiled, void* stream);
 int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                       int B, int G, const float* gP, int nframes, int nfreq, float* Gsum_c64, void* stream);
-/* gfdn_edr_lin_loss(want_grad = 1) + gfdn_edr_lin_gsum in ONE launch: the band's receivers are summed inside the workgroup
- * (fixed order), dL/d|S|^2 is never written and Sd is read once.                                                          */
+/* gfdn_edr_lin_loss(want_grad = 1) + gfdn_edr_lin_gsum in ONE launch (k_edr_lin_band): a thread owns cells of the band's
+ * (frame, frequency) plane and walks the band's receivers (fixed order), the scans along the frames run across the
+ * workgroup's waves; dL/d|S|^2 is never written and Sd is read once.  part (items, ld_part >= gfdn_edr_lin_fused_parts);
+ * dots columns [col0, col0 + gfdn_edr_lin_fused_parts); Gsum (nsplit, nbands G, nframes, nfreq): the band's receivers cut
+ * into nsplit runs with one partial plane set each (gfdn_stft_pairs_spectrum_bwd adds them); tiled as above.            */
 int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                            int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
-                           float* part, float* dots, int ld_dots, int col0, float* Gsum_c64, void* stream);
+                           float* part, int ld_part, float* dots, int ld_dots, int col0, float* Gsum_c64, int nsplit,
+                           int tiled, void* stream);
 /* gfdn_edc_loss_pairs[_banded] on signals x[b] = xd[xrows[b]] + sum_g rgain[b][g] tau[band G + g] formed by the first of its
  * three launches (segment energies), which stores them on the EDC window only into the scratch xwin2 (ceil(items / 2), ld, 2)
  * for the two scans (tau2 pair-interleaved).  ld = the signals' length = pitch of gx2 and xwin2; item_len NULL: one window

@@ -887,7 +887,20 @@ def test_edr_loss_on_composed_spectra(G, B):
     part3, Gs3 = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, dots=parts3, col0=nch)
     assert rel_err((part3.sum(1) / sum_abs[rows]).cpu(), li_ref.cpu()) < 2e-6
     assert rel_err(parts3[:, nch:].sum(1).view(items, G).cpu(), dots_ref.cpu()) < 2e-5
-    assert rel_err(Gs3.cpu(), Gs_ref.cpu()) < 2e-5
+    assert tuple(Gs3.shape) == (1, S_, nfr, nf)
+    assert rel_err(Gs3[0].cpu(), Gs_ref.cpu()) < 2e-5
+    # ... on tiled planes, the band's receivers cut into two runs with one partial plane set each
+    parts4 = torch.zeros_like(parts3)
+    part4, Gs4 = ops.edr_lin_loss_gsum(ops.spec_tile(Sd), rows, ops.spec_tile(Stau), rgain, nb, ops.spec_tile(T_db), sum_abs,
+                                       1.5, dots=parts4, col0=nch, tiled=True, nsplit=2)
+    assert torch.equal(part4, part3) and torch.equal(parts4, parts3)
+    assert tuple(Gs4.shape) == (2, S_, nfr, nf)
+    assert rel_err(ops.spec_tile(Gs4.sum(0), inverse=True).cpu(), Gs_ref.cpu()) < 2e-5
+    # the adjoint STFT adds the partial sets where it loads them
+    T = 2048 * (nfr + 1)
+    g_one = ops.stft_pairs_spectrum_bwd(Gs4.sum(0), T, S_, 4096, tiled=True)
+    g_two = ops.stft_pairs_spectrum_bwd(Gs4, T, S_, 4096, tiled=True)
+    assert rel_err(g_two.cpu(), g_one.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("banded", [False, True])

@@ -1,8 +1,11 @@
 """Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/<tag>_*).
-usage: python tools/make_profiles.py [round_tag]   (default r03)"""
+usage: python tools/make_profiles.py [round_tag] [--pre]   (default r04)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+# --pre: the tables bench.py reads at run time only (kernel stats, PMC bytes, timeline, in-step durations) -- run on the
+# GPU box between the profiled runs and the final bench run, so that the bench line is computed from the same call's tables
+PRE = '--pre' in sys.argv[2:]
 src = os.path.join(ROOT, 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -11,9 +14,10 @@ def one(pattern):
     return max(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
 
 # 1. bench line
-line = [l for l in open(os.path.join(src, f'{tag}_bench_n1.json')) if l.startswith('{')][-1]
-bench = json.loads(line)
-open(os.path.join(dst, f'{tag}_bench_n1.json'), 'w').write(line)
+if not PRE:
+    line = [l for l in open(os.path.join(src, f'{tag}_bench_n1.json')) if l.startswith('{')][-1]
+    bench = json.loads(line)
+    open(os.path.join(dst, f'{tag}_bench_n1.json'), 'w').write(line)
 # 2. kernel stats
 stats = one(f'{tag}_stats/**/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
@@ -58,6 +62,8 @@ with open(os.path.join(dst, f'{tag}_step_kernel_durations.csv'), 'w') as f:
     for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write(f"{k},{cnt / nsteps:.2f},{us / cnt:.2f},{us / nsteps:.2f}\n")
 step_span = (int(trows[hi]['End_Timestamp']) - int(trows[lo]['End_Timestamp'])) / 1e3 / nsteps
+if PRE:
+    sys.exit(0)
 # 5. README
 dom = bench.get('roofline', {})
 name = dom.get('kernel', '')
