@@ -573,7 +573,7 @@ def test_directional_full_size_trainer_step_with_colorless_terms_vs_oracle():
         colorless={'spectral_weight': 1.5, 'sparsity_weight': 2.0, 'use_asym': True})
     for k, v in terms_o.items():
         assert abs(float(losses[k]) - float(v)) < LOSS_TOL * abs(float(v)), (k, float(losses[k]), float(v))
-    assert abs(float(total) - float(tot_o)) < LOSS_TOL * abs(float(tot_o))
+    assert abs(float(total.detach()) - float(tot_o)) < LOSS_TOL * abs(float(tot_o))
     for name, p_ in net.named_parameters():
         if name not in grads_o:
             continue
