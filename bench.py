@@ -373,7 +373,12 @@ def pmc_traffic_bytes(kernel: str, table: str = 'pmc_hbm_bytes.csv'):
     return int(float(r['hbm_traffic_MB']) * 1e6)
 
 
-def roofline_top(units: int, n: int = 10):
+# kernels whose unit is a SIGNAL of the launch, not a RIR: in the linear step (the default) the transforms run on the bands'
+# G group signals (nbands x G per launch), with GFDN_LINEAR=0 on the receivers' signals
+SIGNAL_KERNELS = ('k_blu_col128_fwd', 'k_blu_row512', 'k_blu_col128_inv')
+
+
+def roofline_top(units: int, n: int = 10, signals: int = None):
     """The kernels of the REPLAYED step by time per step (profiles/<tag>_step_kernel_durations.csv: durations inside 100
     consecutive graph replays, nothing else) with algorithmic bytes, measured traffic and fractions; the whole-run
     rocprofv3 average (which also covers host-launched, isolated and one-off launches) is kept beside each."""
@@ -394,7 +399,7 @@ def roofline_top(units: int, n: int = 10):
              'us_per_step': float(r['us_per_step']), 'whole_run_avg_us': run_avg.get(name)}
         per = ALG_BYTES_PER_UNIT.get(name)
         if per is not None:
-            alg = per * units
+            alg = per * (signals if (signals is not None and name in SIGNAL_KERNELS) else units)
             e.update({'alg_bytes_per_launch': alg, 'achieved_GBs': alg / us / 1e3, 'frac': alg / us / 1e3 / HBM_PEAK_GBS})
             tr = pmc_traffic_bytes(name)
             if tr:
@@ -426,7 +431,7 @@ def isolated_kernel_us(device, data, trainer, rows, nbands, iters: int = 30):
     for _ in range(iters):
         if one:
             ops.edr_lin_loss_gsum(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, dots=parts, col0=nch, tiled=tiled,
-                                  nsplit=trainer._fused.edr_receiver_runs)
+                                  nsplit=trainer._fused._edr_runs(nbands, items // nbands))
         else:
             ops.edr_lin_loss(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, True, dots=parts, col0=nch, tiled=tiled)
     return ops.kernel_timer.stop()
@@ -1003,7 +1008,8 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
                                'isolated_frac': (units * per / (iso['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso else None,
                                'launches': ktimes['launches'], 'alg_bytes_per_unit': per,
                                'alg_bytes_per_launch': units * per, 'units_per_launch': units,
-                               'top': roofline_top(int(round(units)))}
+                               'top': roofline_top(int(round(units)),
+                                                   signals=(nbands * G if getattr(fused, 'linear_transforms', False) else None))}
         if not sub_record:
             out['build'] = library_stamp()
         out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS

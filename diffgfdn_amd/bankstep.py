@@ -89,7 +89,17 @@ class FusedBankStep:
     # cells of the band's plane and walks the receivers; dL/d|S|^2 never exists, the direct-path spectra are read once), the
     # band's receivers cut into ``edr_receiver_runs`` runs for more loads in flight
     edr_one_launch = os.environ.get('GFDN_EDR_ONE_LAUNCH', '1') == '1'
-    edr_receiver_runs = int(os.environ.get('GFDN_EDR_RUNS', '2'))
+    # (0 = by the number of bands: the launch has 33 frequency tiles x bands x runs workgroups and wants about two per CU --
+    # 2 runs for the 7-band bank, 16 for a single band)
+    edr_receiver_runs = int(os.environ.get('GFDN_EDR_RUNS', '0'))
+
+    def _edr_runs(self, nbands: int, B: int) -> int:
+        if self.edr_receiver_runs > 0:
+            return min(self.edr_receiver_runs, B)
+        runs = 1
+        while runs * 2 <= max(1, B // 2) and 33 * nbands * runs < 448:
+            runs *= 2
+        return runs
     # ... on planes stored in the tiled cell order (frequency blocks of 256, a block's frames contiguous): what a (receiver,
     # frequency block) workgroup of the EDR kernel touches is one contiguous run
     tiled_spectra = os.environ.get('GFDN_TILED_SPECTRA', '1') == '1'
@@ -250,7 +260,7 @@ class FusedBankStep:
         gP = Gs = None
         if train and self.edr_one_launch:
             li_edr, Gs = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, dots=parts,
-                                               col0=nch, tiled=tiled, nsplit=self.edr_receiver_runs)
+                                               col0=nch, tiled=tiled, nsplit=self._edr_runs(nb, Btot // nb))
         else:
             li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
                                           dots=parts, col0=nch, tiled=tiled)

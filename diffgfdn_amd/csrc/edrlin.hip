@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
 #define EDB_FT 64
 #define EDB_W 8
 #define EDB_Q 4
+#define EDB_DB_PER_LOG2 3.0102999566398120f      // 10 log10(x) = EDB_DB_PER_LOG2 log2(x)
 // value v of receiver b: 0 = the loss partial, 1 + g = the partial of dL/dgain[b][g] -- the eight waves' sums in wave order
 __device__ __forceinline__ void edb_flush(const float (*r)[EDL_MAXG + 1], int v, int b, int G, int tile,
                                           float* __restrict__ part, int ld_part, float* __restrict__ dots, int ld_dots,
@@ -265,13 +266,15 @@ __global__ __launch_bounds__(EDB_FT * EDB_W, 4) void k_edr_lin_band(EdrLin a, in
       ge[q] = 0.f;
       if (mv[q]) {
         E += pw[q];
+        // (v_log_f32 / v_rcp_f32, 1 ulp each: the launch is bound by its VALU work -- about 90 instructions per cell at four
+        // cycles per wave instruction -- and the library log10f and the exact division were a quarter of them)
         const float lin = fabsf(E) + F32_EPS;
-        const float raw = 10.0f * log10f(lin);
+        const float raw = EDB_DB_PER_LOG2 * __builtin_amdgcn_logf(lin);
         const float d = fmaxf(raw, -200.0f);
         const float diff = tv[q] - d;
         acc += fabsf(diff);
         const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __builtin_amdgcn_rcpf(lin) : 0.f;
         ge[q] = -sg * dE * gs;
       }
     }

@@ -27,7 +27,9 @@ CENTRES = (250.0, 1000.0)
 DELAYS = [[641, 701, 809, 907, 1009, 1103, 1201, 1301, 1399, 1409, 1423, 1427, 1429, 1433, 1439, 1601],
           [643, 709, 811, 911, 1013, 1109, 1213, 1303, 1381, 1411, 1423, 1427, 1447, 1451, 1453, 1601]]
 LOSS_TOL, GRAD_TOL = 1e-4, 2e-3
-GRAD_TOL_M = 1e-3        # dL/dM of the timed bench shape (tightened when the float64 tail lands: DESIGN.md section 2)
+# dL/dM of the timed bench shape per lines-per-group: what is measured (round 4: 3.6e-4 at N = 16, 7.9e-4 at N = 32, the float32
+# transforms upstream of the records are the floor -- DESIGN.md section 2 (iv), profiles/r04_grad_stage_probe.txt) plus margin
+GRAD_TOL_M = {4: 6e-4, 8: 1e-3}
 # BASELINE.json configs[4]: N = 32 = 4 groups x 8 lines (mutually prime delays, as DiffGFDNConfig draws them)
 DELAYS32 = [571, 593, 613, 631, 653, 673, 691, 709, 733, 751, 769, 787, 809, 827, 853, 877, 907, 929, 947, 967, 983, 1009,
             1031, 1051, 1069, 1091, 1109, 1129, 1151, 1171, 1193, 1213]
@@ -347,7 +349,7 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
             parts, grads, after = _oracle_step(sd0[q], q, rooms[q], datas[q], sels[q], filts[q], keep, delays_l[q], nfeat)
             worst = _check(f"bench[N={N}, {int(centres[q])} Hz]", parts_hip, grads_hip, after_hip,
                            {k: v.numpy() for k, v in sd0[q].items()}, parts, grads, after, grad_tol=2e-4,
-                           grad_tol_M=GRAD_TOL_M)
+                           grad_tol_M=GRAD_TOL_M[nper])
             for name in ("input_gains", "output_gains"):
                 assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, (q, name)
             for k, v in worst.items():
