@@ -473,8 +473,14 @@ def run_directional(args, device, rank, world):
         idx = torch.arange(BATCH, device=device)
         batch = {'z_values': z, 'source_position': torch.zeros(BATCH, 3, device=device, dtype=torch.float64)}
         batch.update({k: v[idx].clone() for k, v in store.items()})
-        steps.append((tr, tr.graphed(batch).capture(), store))
+        steps.append((tr, batch if args.dir_bank else tr.graphed(batch).capture(), store))
     gen = torch.Generator().manual_seed(100 + rank)
+    bank = None
+    if args.dir_bank:
+        # trainer.DirectionalBank: ONE graph steps all bands (dealt onto ``--dir-streams`` lanes inside the capture)
+        from diffgfdn_amd.trainer import DirectionalBank
+        bank = DirectionalBank([t for t, _, _ in steps], [b for _, b, _ in steps], lanes=args.dir_streams).capture()
+        steps = [(t, st, store) for (t, _, store), st in zip(steps, bank.steps)]
 
     # the bands are independent models: their graph replays go round-robin onto ``--dir-streams`` streams, so that one
     # band's latency-bound stretches (a dozen few-microsecond launches, the serial expm adjoint) run beside another's
@@ -484,6 +490,12 @@ def run_directional(args, device, rank, world):
 
     def one_step():
         main = torch.cuda.current_stream()
+        if bank is not None:
+            for tr, step, store in steps:
+                sel = torch.randperm(R, generator=gen)[:BATCH].to(device)
+                for k, v in store.items():
+                    step.batch[k].copy_(v.index_select(0, sel))
+            return bank()[-1]
         for i, (tr, step, store) in enumerate(steps):
             sel_host = torch.randperm(R, generator=gen)[:BATCH]
             if lanes is None:
@@ -536,10 +548,10 @@ def run_directional(args, device, rank, world):
     out = {'metric': 'RIR-frames/sec', 'value': rirs_per_s * FRAMES, 'unit': 'RIR-frames/s', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'directional DiffGFDN: {nb} octave bands (independent models, graph replays round-robin on {nstreams} stream(s)), each {Gd} groups x {L} SH '
+           'config': {'workload': f'directional DiffGFDN: {nb} octave bands (independent models; ' + ('ONE graph for all bands, bands on ' if bank is not None else 'graph replays round-robin on ') + f'{nstreams} stream(s)), each {Gd} groups x {L} SH '
                                   f'channels (N = {Gd * L}), {J} directions, {R} receivers, nfft 131072, batch {BATCH} '
                                   'receivers/band/step/GPU; step = line responses + 27 line transforms + directional EDC + colorless losses + bwd + '
-                                  'Adam per band, one HIP-graph replay per band', 'bands': nb, 'receivers': R, 'band_streams': nstreams,
+                                  'Adam per band', 'bank': bank is not None, 'bands': nb, 'receivers': R, 'band_streams': nstreams,
                        'directions': J, 'delay_lines': Gd * L, 'rirs_per_s': rirs_per_s,
                        'ms_per_band_step': 1e3 * elapsed / args.steps / nb,
                        'final_loss': float(total)}}
@@ -669,8 +681,14 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the N = 32 and directional sub-records of the default N = 1 line')
     ap.add_argument('--extra-steps', type=int, default=40, help='timed steps of each sub-record')
-    ap.add_argument('--dir-streams', type=int, default=2,
-                    help='--config directional: streams the independent bands\' graph replays are spread over')
+    ap.add_argument('--dir-bank', type=int, default=1,
+                    help='directional config: 1 (default) = trainer.DirectionalBank, ONE graph steps all bands; 0 = one graph '
+                         'per band, replayed round-robin on --dir-streams streams')
+    ap.add_argument('--dir-streams', type=int, default=4,
+                    help='--config directional: lanes the bands are dealt onto inside the bank\'s graph (--dir-bank 1), or '
+                         'streams the bands\' own graph replays are spread over (--dir-bank 0); measured same-box: one graph '
+                         'per band on 2 streams 0.56-0.58 ms per band-step, the bank on 2 / 3 / 4 / 7 lanes 0.48 / 0.45 / 0.44 / '
+                         '0.44')
     ap.add_argument('--captured-allreduce', action='store_true',
                     help='N > 1: capture the RCCL all-reduce inside the step graph (when every rank can)')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')

@@ -827,6 +827,99 @@ class GraphedModuleStep:
         return self.out
 
 
+class DirectionalBank:
+    """The octave bands' directional trainers (reference run_subband_training_treble.py:175-204 builds one
+    ``DirectionalFDNVarReceiverPosTrainer`` per band and trains them one after another) stepped TOGETHER: every band's
+    ``train_step`` is captured into ONE HIP graph, the bands dealt round-robin onto ``lanes`` streams inside the capture, so
+    that one replay steps all bands and one band's latency-bound stretches (the crossbar-bound 9 x 9 eliminations, a dozen
+    launches of a few microseconds) run beside another band's bandwidth-bound kernels without the host launching seven
+    graphs.  The bands stay independent models with their own parameters, optimiser state and loss modules -- this is a bank
+    at the level of the GRAPH, not of the launch (a launch per stage for all bands would need the band dimension in every
+    kernel of the directional step, as ``bandbank.BandBank`` has for the omnidirectional model).
+    ``batches``: one batch dict per band; they live in static device buffers that ``__call__`` refreshes in place."""
+
+    def __init__(self, trainers, example_batches, lanes: int = 2, mask_seed: Optional[int] = None):
+        if len(trainers) != len(example_batches) or not trainers:
+            raise ValueError("DirectionalBank: one example batch per band trainer")
+        self.steps = [GraphedModuleStep(tr, b, None if mask_seed is None else mask_seed + q)
+                      for q, (tr, b) in enumerate(zip(trainers, example_batches))]
+        self.lanes = [torch.cuda.Stream() for _ in range(max(1, min(int(lanes), len(trainers))))]
+        self.root = self.lanes[0]          # (the capture's origin is the first lane: a separate origin stream that only
+        #                                     forks and joins makes hipStreamEndCapture of ROCm 7.2 segfault)
+        # ... and so does a forked lane that forks again: the bands on the lanes beside the first run their colorless branch
+        # on the lane itself, not on the trainer's side stream (the bands of the OTHER lane run beside it anyway)
+        for q, tr in enumerate(trainers):
+            if q % len(self.lanes):
+                tr.concurrent_branches = False
+        self.graph = None
+        self.out = None
+
+    @property
+    def batches(self):
+        return [st.batch for st in self.steps]
+
+    def _lane(self, q: int):
+        return self.lanes[q % len(self.lanes)]
+
+    def capture(self):
+        cur = torch.cuda.current_stream()
+        # warm-up per band ON ITS LANE (autograd pins every parameter's AccumulateGrad node to the stream of its first
+        # backward), leaving no trace -- as GraphedModuleStep.capture
+        for q, st in enumerate(self.steps):
+            tr, lane = st.tr, self._lane(q)
+            params = list(tr.net.parameters())
+            saved_p = [p.detach().clone() for p in params]
+            saved_s = [t.detach().clone() for t in tr.optimizer.state_tensors()]
+            lane.wait_stream(cur)
+            with torch.cuda.stream(lane):
+                for _ in range(3):
+                    tr.train_step(st.batch)
+                for p, sp in zip(params, saved_p):
+                    p.data.copy_(sp)
+                for t, s_ in zip(tr.optimizer.state_tensors(), saved_s):
+                    t.copy_(s_)
+                if st.mask_state is not None:
+                    st.mask_state.zero_()
+                tr.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        outs = [None] * len(self.steps)
+        with torch.cuda.graph(self.graph, stream=self.root):
+            for lane in self.lanes[1:]:
+                lane.wait_stream(self.root)                    # fork
+            for q, st in enumerate(self.steps):
+                with torch.cuda.stream(self._lane(q)):
+                    outs[q] = st.tr.train_step(st.batch)
+            for lane in self.lanes[1:]:
+                self.root.wait_stream(lane)                    # join
+        self.out = outs
+        from .functional import FrequencyGrid
+        self._grids = list(FrequencyGrid._cache.values())
+        torch.cuda.synchronize()
+        return self
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                torch.cuda.synchronize()
+        except Exception:        # noqa: BLE001
+            pass
+
+    def __call__(self, batches=None):
+        if batches is not None:
+            for st, batch in zip(self.steps, batches):
+                if batch is None:
+                    continue
+                for k, v in batch.items():
+                    dst = st.batch.get(k)
+                    if torch.is_tensor(v) and torch.is_tensor(dst) and v.data_ptr() != dst.data_ptr():
+                        dst.copy_(v, non_blocking=True)
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        return self.out
+
+
 def _graph_node_count(graph: "torch.cuda.CUDAGraph") -> Optional[int]:
     """Number of nodes of a captured graph (hipGraphGetNodes on the raw handle; the graph must have been created with
     keep_graph=True).  None if the runtime does not answer."""

@@ -445,6 +445,63 @@ def test_directional_graphed_step_equals_eager_step(mask):
         assert int(step.mask_state.item()) == 3          # (one draw per replay; the warm-up draws were undone)
 
 
+def test_directional_bank_equals_band_steps():
+    """trainer.DirectionalBank: three bands' directional trainers (different parameters, targets and decay times) stepped by
+    ONE graph with the bands on two lanes == every band's own host-launched train_step, bit for bit (values and state) --
+    the bands are independent models, the graph only changes who launches what beside what."""
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig, TrainerConfig
+    from diffgfdn_amd.model import DiffDirectionalFDNVarReceiverPos
+    from diffgfdn_amd.trainer import DirectionalBank, DirectionalFDNVarReceiverPosTrainer
+    fx = load("f6_directional.npz")
+    fs = float(fx["fs"])
+    batch0 = _to_dev(batch_from(fx))
+    nb = 3
+
+    def build():
+        trs, batches = [], []
+        for q in range(nb):
+            torch.manual_seed(900 + q)
+            fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+            of = OutputFilterConfig(use_svfs=False, num_hidden_layers=1, num_neurons_per_layer=8, num_fourier_features=3)
+            net = DiffDirectionalFDNVarReceiverPos(fs, int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
+                                                   ambi_order=int(fx["order"]),
+                                                   common_decay_times=(fx["T60"] * (1.0 + 0.15 * q))[None, :],
+                                                   use_colorless_loss=True, analysis_matrix=fx["analysis_matrix"])
+            sd = _state(fx)
+            if q:                                          # (band q > 0: the fixture's parameters, perturbed)
+                g = torch.Generator().manual_seed(77 + q)
+                sd = {k: (v + 0.05 * torch.randn(v.shape, generator=g).to(v.dtype) if v.is_floating_point() and
+                          k in ("input_gains", "output_gains", "feedback_loop.M") else v) for k, v in sd.items()}
+            net.load_state_dict(sd, strict=True)
+            net = net.to(DEV)
+            tc = TrainerConfig(use_colorless_loss=True, edc_loss_weight=1.0 + q, use_edc_mask=False, lr=1e-3, io_lr=1e-2,
+                               train_dir=f"/tmp/gfdn_t/db{q}", ir_dir=f"/tmp/gfdn_a/db{q}", device="cuda")
+            tr = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
+            crit = tr.criterion[0]
+            crit.edc_len_samps = int(float(fx["edc_len_ms"]) * 1e-3 * fs)
+            b = dict(batch0)
+            b["target_common_slope_amps"] = torch.tensor(fx["amps"]).to(DEV) * (1.0 + 0.2 * q)
+            trs.append(tr), batches.append(b)
+        return trs, batches
+
+    res = {}
+    for mode in ("eager", "bank"):
+        trs, batches = build()
+        bank = DirectionalBank(trs, batches, lanes=2).capture() if mode == "bank" else None
+        vals = []
+        for i in range(3):
+            bs = [dict(b, target_common_slope_amps=b["target_common_slope_amps"] * (1.0 + 0.1 * i)) for b in batches]
+            outs = bank(bs) if bank is not None else [tr.train_step(b) for tr, b in zip(trs, bs)]
+            torch.cuda.synchronize()
+            vals.append([float(o[0]) for o in outs])
+        res[mode] = (vals, [{k: v.detach().cpu().clone() for k, v in tr.net.state_dict().items()} for tr in trs])
+    assert len({round(v, 3) for v in res["eager"][0][0]}) == nb          # (the bands really differ)
+    assert np.allclose(res["eager"][0], res["bank"][0], rtol=1e-6, atol=0), res
+    for q in range(nb):
+        for k, v in res["eager"][1][q].items():
+            assert rel_err(res["bank"][1][q][k], v) < 1e-6, (q, k)
+
+
 @pytest.mark.parametrize("tag", ["zc", "cp", "mixed"])
 def test_f16_source_receiver_svf_model(tag):
     """DiffGFDNVarSourceReceiverPos with SVF filters from MLPs (reference model.py:347-452): the reference's state dict
