@@ -778,12 +778,15 @@ class GraphedModuleStep:
             crit.device_mask = (self.mask_seed, self.mask_state, self.maskw)
         self.tr = trainer
         self.batch = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
-        self.stream = torch.cuda.Stream()
+        self.stream = None                 # (created by capture(): torch hands streams out of a pool of 32 round-robin, and
+        #                                     a DirectionalBank's steps never capture on their own)
         self.graph = None
         self.out = None
 
     def capture(self):
         tr = self.tr
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
         params = list(tr.net.parameters())
         saved_p = [p.detach().clone() for p in params]
         saved_s = [t.detach().clone() for t in tr.optimizer.state_tensors()]
@@ -843,7 +846,27 @@ class DirectionalBank:
             raise ValueError("DirectionalBank: one example batch per band trainer")
         self.steps = [GraphedModuleStep(tr, b, None if mask_seed is None else mask_seed + q)
                       for q, (tr, b) in enumerate(zip(trainers, example_batches))]
-        self.lanes = [torch.cuda.Stream() for _ in range(max(1, min(int(lanes), len(trainers))))]
+        # torch hands streams out of a pool of 32 per device, round-robin: in a process that has created many, two "new"
+        # streams can be the SAME stream -- a lane that aliases another lane or a band's side stream turns the fork / join
+        # pattern below into one the capture rejects ("unjoined work").  Every stream of the bank is checked to be distinct.
+        taken = set()
+
+        def fresh():
+            for _ in range(64):
+                st = torch.cuda.Stream()
+                if st.cuda_stream not in taken:
+                    taken.add(st.cuda_stream)
+                    return st
+            raise RuntimeError("DirectionalBank: no distinct stream left in the pool")
+
+        self.lanes = [fresh() for _ in range(max(1, min(int(lanes), len(trainers))))]
+        for q, tr in enumerate(trainers):
+            if q % len(self.lanes) == 0 and getattr(tr, 'concurrent_branches', False):
+                tr._side = fresh()                             # (the first lane's bands keep their side stream)
+        if os.environ.get('GFDN_DBG_STREAMS'):
+            print('[DirectionalBank] lanes', [hex(l.cuda_stream) for l in self.lanes], 'sides',
+                  [hex(tr._side.cuda_stream) for tr in trainers if getattr(tr, '_side', None) is not None],
+                  'current', hex(torch.cuda.current_stream().cuda_stream), flush=True)
         self.root = self.lanes[0]          # (the capture's origin is the first lane: a separate origin stream that only
         #                                     forks and joins makes hipStreamEndCapture of ROCm 7.2 segfault)
         # ... and so does a forked lane that forks again: the bands on the lanes beside the first run their colorless branch
