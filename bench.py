@@ -74,10 +74,12 @@ ALG_BYTES_PER_RIR = 2811048
 # x 2049 bins x 8 B) and the target EDR (x 4 B) = 786 816 B; the band's group spectra in and the band's gradient spectra out
 # (29 MB per launch together) are shared by the band's 32 receivers and NOT counted.  (GFDN_EDR_ONE_LAUNCH=0: the two-launch
 # form k_edr_lin_cols + k_edr_lin_gsum, which also writes and re-reads dL/d|S|^2.)
-DOMINANT_KERNEL = 'k_edr_lin_band' if os.environ.get('GFDN_EDR_ONE_LAUNCH', '1') == '1' else 'k_edr_lin_cols'
+DOMINANT_KERNEL = (('k_edr_lin_wave' if os.environ.get('GFDN_EDR_FORM', '1') == '1' else 'k_edr_lin_band')
+                   if os.environ.get('GFDN_EDR_ONE_LAUNCH', '1') == '1' else 'k_edr_lin_cols')
 # Algorithmic HBM bytes per RIR and launch of the step's per-receiver kernels (what each MUST read and write):
 ALG_BYTES_PER_UNIT = {
     'k_edr_lin_band': FRAMES * NF * (8 + 4),                                   # Sd, target EDR in (the G sums out: per band)
+    'k_edr_lin_wave': FRAMES * NF * (8 + 4),                                   # (the same launch without barriers)
     'k_edr_lin_cols': FRAMES * NF * (8 + 4 + 4),                               # Sd, target EDR in; dL/d|S|^2 out
     'k_edr_lin_gsum': FRAMES * NF * (8 + 4),                                   # Sd, dL/d|S|^2 in (the G sums out: per band)
     'k_edc_pair_segsum': 4 * EDC_LEN + 4 * EDC_LEN,                            # direct path in, composed window samples out
@@ -424,14 +426,16 @@ def isolated_kernel_us(device, data, trainer, rows, nbands, iters: int = 30):
     rgain = torch.rand(items, G, device=device)
     nch = ops.lin_gamma_dots_tiles(K)
     one = trainer._fused.edr_one_launch
-    parts = torch.empty((items * G, nch + ops.edr_lin_parts(NF, fused=one)), dtype=torch.float32, device=device)
+    parts = torch.empty((items * G, nch + ops.edr_lin_parts(NF, fused=one, form=trainer._fused.edr_band_form)),
+                        dtype=torch.float32, device=device)
     T_edr, sum_abs = (data.edr_target_tiled() if tiled else data.edr_store[1]), data.edr_store[2]
     ops.kernel_timer.watch = DOMINANT_KERNEL
     ops.kernel_timer.start()
     for _ in range(iters):
         if one:
             ops.edr_lin_loss_gsum(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, dots=parts, col0=nch, tiled=tiled,
-                                  nsplit=trainer._fused._edr_runs(nbands, items // nbands))
+                                  nsplit=trainer._fused._edr_runs(nbands, items // nbands),
+                                  form=trainer._fused.edr_band_form)
         else:
             ops.edr_lin_loss(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, True, dots=parts, col0=nch, tiled=tiled)
     return ops.kernel_timer.stop()

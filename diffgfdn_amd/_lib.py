@@ -174,7 +174,8 @@ SIGNATURES = {
                                   c_int, c_int, _P]),
     "gfdn_edr_lin_gsum": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "gfdn_edr_lin_loss_gsum": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, _P,
-                                       c_int, c_int, _P, c_int, c_int, _P]),
+                                       c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "gfdn_edr_lin_band_parts": (c_int, [c_int, c_int]),
     "gfdn_edc_loss_pairs_lin": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int,
                                         _P, _P, c_int, c_float, c_float, _P, _P, c_int, _P, _P, _P]),
     "gfdn_irfft_odd_time_slots": (c_int, [c_int, _P]),

@@ -92,6 +92,9 @@ class FusedBankStep:
     # (0 = by the number of bands: the launch has 33 frequency tiles x bands x runs workgroups and wants about two per CU --
     # 2 runs for the 7-band bank, 16 for a single band)
     edr_receiver_runs = int(os.environ.get('GFDN_EDR_RUNS', '0'))
+    # form of that launch: 0 = k_edr_lin_band (64 frequencies x 8 waves of 4 frames; LDS exchanges, two barriers per receiver),
+    # 1 = k_edr_lin_wave (a wave = 8 frequencies x all frames; the scans inside the wave, no LDS, no barriers)
+    edr_band_form = int(os.environ.get('GFDN_EDR_FORM', '1'))
 
     def _edr_runs(self, nbands: int, B: int) -> int:
         if self.edr_receiver_runs > 0:
@@ -255,12 +258,14 @@ class FusedBankStep:
         nch = ops.lin_gamma_dots_tiles(K) if self.gamma_dots_one_launch else ops.lin_gain_chunks(K)
         parts = None
         if train:
-            parts = torch.empty((Btot * G, nch + ops.edr_lin_parts(win // 2 + 1, fused=self.edr_one_launch)),
+            parts = torch.empty((Btot * G, nch + ops.edr_lin_parts(win // 2 + 1, fused=self.edr_one_launch,
+                                                                   form=self.edr_band_form)),
                                 dtype=torch.float32, device=rows.device)
         gP = Gs = None
         if train and self.edr_one_launch:
             li_edr, Gs = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, dots=parts,
-                                               col0=nch, tiled=tiled, nsplit=self._edr_runs(nb, Btot // nb))
+                                               col0=nch, tiled=tiled, nsplit=self._edr_runs(nb, Btot // nb),
+                                               form=self.edr_band_form)
         else:
             li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
                                           dots=parts, col0=nch, tiled=tiled)

@@ -323,6 +323,175 @@ __global__ __launch_bounds__(EDB_FT * EDB_W, 4) void k_edr_lin_band(EdrLin a, in
   }
 }
 
+// The same launch WITHOUT barriers (form 1 of gfdn_edr_lin_loss_gsum): a WAVE owns 8 frequencies x all 32 frames -- lane =
+// (frame group fg = lane >> 3, frequency fl = lane & 7), the thread owns the frames 4 fg .. 4 fg + 3 of its frequency as
+// before -- so the two scans along the frames run inside the wave on the VALU: the pair (fg, fg ^ 1) by one DPP row rotation,
+// the four rows of sixteen lanes by v_permlane16_swap / v_permlane32_swap (three swaps give every lane the four row totals);
+// direct sums only, no total-minus-prefix.  No LDS, no __syncthreads: the waves of a workgroup (4 waves = 32 adjacent
+// frequencies, so that the 128-byte lines of a frame row are shared inside the workgroup) run independently.  Measured
+// against form 0 (eight waves per 64 frequencies, two 2 KB LDS exchanges and two barriers per receiver): bench.py / DESIGN.md
+// section 4.3.  The partial sums are per WAVE: gfdn_edr_lin_band_parts(nfreq, 1) = 4 ceil(nfreq / 32) columns per receiver.
+#define EDW_F 8                     // frequencies per wave
+#define EDW_WG 4                    // waves per workgroup
+__device__ __forceinline__ float edw_partner(float v) {     // the value of lane ^ 8 (the other frame group of the pair)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));      // row_ror:8
+}
+// p = a value that is the same in the 16 lanes' two frame groups ... of every row r: returns (P0, P1, P2, P3) of the four rows
+__device__ __forceinline__ void edw_rows(float p, float (&P)[4]) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+  // a[0] = [p0, p0, p2, p2] (even rows over their pair), a[1] = [p1, p1, p3, p3]
+  const auto e = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);      // [p0 x4], [p2 x4]
+  const auto o = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false);      // [p1 x4], [p3 x4]
+  P[0] = __uint_as_float(e[0]); P[2] = __uint_as_float(e[1]);
+  P[1] = __uint_as_float(o[0]); P[3] = __uint_as_float(o[1]);
+}
+__global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int nframes, int nfreq, float gscale,
+                                                                 float* __restrict__ part, int ld_part,
+                                                                 float* __restrict__ dots, int ld_dots, int col0,
+                                                                 float2* __restrict__ Gsum, int nsplit, int nbands) {
+  const int G = a.G, B = a.B, band = blockIdx.y, split = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fg = lane >> 3, fl = lane & 7, row = lane >> 4;
+  const bool odd = fg & 1;
+  const int col = blockIdx.x * EDW_WG + wv;                 // the wave's column of partial sums
+  const int f = col * EDW_F + fl;
+  const bool live = f < nfreq;
+  const int fc = live ? f : nfreq - 1;
+  const size_t cells = (size_t)nframes * nfreq;
+  unsigned cq[EDB_Q];
+  bool mv[EDB_Q];
+#pragma unroll
+  for (int q = 0; q < EDB_Q; ++q) {
+    const int m = EDB_Q * fg + q;
+    mv[q] = m < nframes;
+    cq[q] = (unsigned)edl_cell(mv[q] ? m : 0, fc, nframes, nfreq, a.tiled);
+  }
+  float2 st[EDL_MAXG][EDB_Q], Ga[EDL_MAXG][EDB_Q];
+#pragma unroll
+  for (int g = 0; g < EDL_MAXG; ++g)
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) {
+      st[g][q] = (g < G && mv[q]) ? (a.Stau + ((size_t)band * G + g) * cells)[cq[q]] : make_float2(0.f, 0.f);
+      Ga[g][q] = make_float2(0.f, 0.f);
+    }
+  const int bper = (B + nsplit - 1) / nsplit;
+  const int b_lo = split * bper, b_hi = b_lo + bper < B ? b_lo + bper : B;
+  float2 sn[EDB_Q];
+  float tn[EDB_Q];
+  auto fetch = [&](int bl) {
+    const int b = band * B + bl;
+    const size_t rw = a.rows ? (size_t)a.rows[b] : (size_t)b;
+    const float2* sdr = a.Sd + rw * cells;
+    const float* tdr = a.Tdb + rw * cells;
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) {
+      sn[q] = mv[q] ? sdr[cq[q]] : make_float2(0.f, 0.f);
+      tn[q] = mv[q] ? tdr[cq[q]] : 0.f;
+    }
+  };
+  if (b_lo < b_hi) fetch(b_lo);
+  for (int bl = b_lo; bl < b_hi; ++bl) {
+    const int b = band * B + bl;
+    const size_t rw = a.rows ? (size_t)a.rows[b] : (size_t)b;
+    float rg[EDL_MAXG];
+#pragma unroll
+    for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
+    const float gs = gscale / a.sum_abs[rw];
+    float2 sv[EDB_Q];
+    float tv[EDB_Q], pw[EDB_Q];
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) {
+      sv[q] = sn[q];
+      tv[q] = tn[q];
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) {
+        sv[q].x += rg[g] * st[g][q].x;
+        sv[q].y += rg[g] * st[g][q].y;
+      }
+      pw[q] = sv[q].x * sv[q].x + sv[q].y * sv[q].y;
+    }
+    if (bl + 1 < b_hi) fetch(bl + 1);
+#pragma unroll
+    for (int q = EDB_Q - 1; q >= 0; --q) tot += pw[q];
+    // energy of the frames BEHIND this thread's: the partner group if it is the later one, and the later rows
+    float E;
+    {
+      const float pt = edw_partner(tot);
+      float P[4];
+      edw_rows(tot + pt, P);
+      E = odd ? 0.f : pt;
+      E += row < 3 ? P[3] : 0.f;
+      E += row < 2 ? P[2] : 0.f;
+      E += row < 1 ? P[1] : 0.f;
+    }
+    float acc = 0.f, ge[EDB_Q], gtot = 0.f;
+#pragma unroll
+    for (int q = EDB_Q - 1; q >= 0; --q) {
+      ge[q] = 0.f;
+      if (mv[q]) {
+        E += pw[q];
+        const float lin = fabsf(E) + F32_EPS;
+        const float raw = EDB_DB_PER_LOG2 * __builtin_amdgcn_logf(lin);
+        const float dd = fmaxf(raw, -200.0f);
+        const float diff = tv[q] - dd;
+        acc += fabsf(diff);
+        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
+        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __builtin_amdgcn_rcpf(lin) : 0.f;
+        ge[q] = -sg * dE * gs;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) gtot += ge[q];
+    // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m': the earlier rows, the partner group if it is the earlier one
+    float run;
+    {
+      const float pt = edw_partner(gtot);
+      float P[4];
+      edw_rows(gtot + pt, P);
+      run = row > 0 ? P[0] : 0.f;
+      run += row > 1 ? P[1] : 0.f;
+      run += row > 2 ? P[2] : 0.f;
+      run += odd ? pt : 0.f;
+    }
+    float da[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < EDB_Q; ++q) {
+      run += ge[q];
+      const float p2 = 2.0f * run;
+      const float2 dS = make_float2(p2 * sv[q].x, p2 * sv[q].y);
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) {
+        Ga[g][q].x += rg[g] * dS.x;
+        Ga[g][q].y += rg[g] * dS.y;
+        da[g] += st[g][q].x * dS.x + st[g][q].y * dS.y;
+      }
+    }
+    acc = wave_sum_full(live ? acc : 0.f);
+    if (lane == 0) part[(size_t)b * ld_part + col] = acc;
+    if (dots) {
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) {
+        if (g < G) {
+          const float v = wave_sum_full(live ? da[g] : 0.f);
+          if (lane == 0) dots[((size_t)b * G + g) * ld_dots + col0 + col] = v;
+        }
+      }
+    }
+  }
+  if (live) {
+    float2* out = Gsum + (size_t)split * nbands * G * cells;
+#pragma unroll
+    for (int g = 0; g < EDL_MAXG; ++g) {
+      if (g < G) {
+#pragma unroll
+        for (int q = 0; q < EDB_Q; ++q)
+          if (mv[q]) (out + ((size_t)band * G + g) * cells)[cq[q]] = Ga[g][q];
+      }
+    }
+  }
+}
+
 // Gsum[band G + g][cell] = sum_{b in band} gain[b][g] 2 gP[b][cell] S[b][cell],  S[b] = Sd[row_b] + sum_g' gain[b][g'] Stau_g'
 //                        = sum_b gain[b][g] 2 gP[b] Sd[row_b]  +  sum_g' (sum_b gain[b][g] gain[b][g'] 2 gP[b]) Stau_g'
 // -- one thread per (band, cell), the band's receivers in index order
@@ -533,7 +702,12 @@ extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items
 
 // partial-sum columns per item: frequency blocks of 256 (gfdn_edr_lin_loss) or tiles of 64 (gfdn_edr_lin_loss_gsum)
 extern "C" int gfdn_edr_lin_parts(int nfreq) { return nfreq > 0 ? (nfreq + 255) / 256 : 0; }
-extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return nfreq > 0 ? (nfreq + EDB_FT - 1) / EDB_FT : 0; }
+extern "C" int gfdn_edr_lin_band_parts(int nfreq, int form) {
+  if (nfreq <= 0) return 0;
+  if (form == 1) return EDW_WG * ((nfreq + EDW_F * EDW_WG - 1) / (EDW_F * EDW_WG));      // one column per wave of 8 frequencies
+  return (nfreq + EDB_FT - 1) / EDB_FT;
+}
+extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return gfdn_edr_lin_band_parts(nfreq, 0); }
 
 // EDR loss of nbands x B receivers on composed spectra (see the head of this file).  part (items, gfdn_edr_lin_parts):
 // loss partials as gfdn_edr_loss(loss_item = NULL) leaves them; want_grad: gP (items, nframes, nfreq) and the EDR part of
@@ -563,16 +737,20 @@ extern "C" int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, con
 extern "C" int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
                                       int nbands, int B, int G, const float* T_db, const float* sum_abs, int nframes,
                                       int nfreq, float gscale, float* part, int ld_part, float* dots, int ld_dots, int col0,
-                                      float* Gsum_c64, int nsplit, int tiled, void* stream) {
+                                      float* Gsum_c64, int nsplit, int tiled, int form, void* stream) {
   if (!Sd_c64 || !Stau_c64 || !rgain || !T_db || !sum_abs || !part || !Gsum_c64 || nbands <= 0 || B <= 0 || G <= 0 ||
-      nframes <= 0 || nfreq <= 0 || nsplit <= 0 || nsplit > B)
+      nframes <= 0 || nfreq <= 0 || nsplit <= 0 || nsplit > B || form < 0 || form > 1)
     return GFDN_E_BADARG;
-  const int ntiles = (nfreq + EDB_FT - 1) / EDB_FT, nparts = ntiles;
+  const int nparts = gfdn_edr_lin_band_parts(nfreq, form);
   if (G > EDL_MAXG || nframes > EDB_W * EDB_Q || nbands > 65535 || nsplit > 64) return GFDN_E_UNSUPPORTED;
   if (ld_part < nparts || (dots && (col0 < 0 || ld_dots < col0 + nparts))) return GFDN_E_BADARG;
   EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, tiled ? 1 : 0};
-  hipLaunchKernelGGL(k_edr_lin_band, dim3(ntiles, nbands, nsplit), dim3(EDB_FT * EDB_W), 0, (hipStream_t)stream, a, nframes,
-                     nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
+  if (form == 1)
+    hipLaunchKernelGGL(k_edr_lin_wave, dim3(nparts / EDW_WG, nbands, nsplit), dim3(64 * EDW_WG), 0, (hipStream_t)stream, a,
+                       nframes, nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
+  else
+    hipLaunchKernelGGL(k_edr_lin_band, dim3(nparts, nbands, nsplit), dim3(EDB_FT * EDB_W), 0, (hipStream_t)stream, a, nframes,
+                       nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

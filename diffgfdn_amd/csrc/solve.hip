@@ -2976,12 +2976,16 @@ extern "C" int gfdn_colorless_terms(const float* loss_g, int G, const float* Q, 
 
 // out = { wa * sum(a) + wb * sum(b), wa * sum(a), wb * sum(b) }   (either input may be NULL);
 // item i of a = (sum of its a_cols partials) / a_div[a_rows ? a_rows[i] : i]  (a_div optional)
-__global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ a, int a_cols,
-                                                      const float* __restrict__ a_div,
-                                                      const long long* __restrict__ a_rows, float wa,
-                                                      const float* __restrict__ b, float wb, int n,
-                                                      float* __restrict__ out) {
-  float sa = 0.f, sb = 0.f;
+// WS_T / 64 waves per band: a wave sums the partial columns of its items (lanes stride the columns, VALU wave sum: fixed
+// order), the waves' sums are added in wave order.  (One lane walking a row of 264 columns per item took 51 us on the side
+// stream and held the gain network's backward up; with <= 33 columns the old thread-per-item form took 6 us.)
+#define WS_T 512
+__global__ __launch_bounds__(WS_T) void k_weighted_sums(const float* __restrict__ a, int a_cols,
+                                                        const float* __restrict__ a_div,
+                                                        const long long* __restrict__ a_rows, float wa,
+                                                        const float* __restrict__ b, float wb, int n,
+                                                        float* __restrict__ out) {
+  __shared__ float s_a[WS_T / 64], s_b[WS_T / 64];
   {   // one block per band: its n items, its three outputs
     const size_t i0 = (size_t)blockIdx.x * n;
     if (a) a += i0 * a_cols;
@@ -2990,25 +2994,33 @@ __global__ __launch_bounds__(64) void k_weighted_sums(const float* __restrict__ 
     if (b) b += i0;
     out += (size_t)blockIdx.x * 3;
   }
-  for (int i = threadIdx.x; i < n; i += 64) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float sa = 0.f, sb = 0.f;
+  for (int i = w; i < n; i += WS_T / 64) {
     if (a) {
       float v = 0.f;
-      for (int c = 0; c < a_cols; ++c) v += a[(size_t)i * a_cols + c];
+      for (int c = lane; c < a_cols; c += 64) v += a[(size_t)i * a_cols + c];
+      v = wave_sum_full(v);
       if (a_div) v /= a_div[a_rows ? a_rows[i] : i];
-      sa += v;
+      sa += v;                                            // (the same value in every lane)
     }
     if (b) sb += b[i];
   }
-  sa = wave_sum(sa) * wa;
-  sb = wave_sum(sb) * wb;
-  if (threadIdx.x == 0) { out[0] = sa + sb; out[1] = sa; out[2] = sb; }
+  if (lane == 0) { s_a[w] = sa; s_b[w] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    for (int q = 0; q < WS_T / 64; ++q) { ta += s_a[q]; tb += s_b[q]; }
+    ta *= wa; tb *= wb;
+    out[0] = ta + tb; out[1] = ta; out[2] = tb;
+  }
 }
 
 extern "C" int gfdn_weighted_sums_banded(const float* a, int a_cols, const float* a_div, const long long* a_rows,
                                          float wa, const float* b, float wb, int n, int nbands, float* out3,
                                          void* stream) {
   if ((!a && !b) || !out3 || n <= 0 || nbands <= 0 || (a && a_cols <= 0)) return GFDN_E_BADARG;
-  hipLaunchKernelGGL(k_weighted_sums, dim3(nbands), dim3(64), 0, (hipStream_t)stream, a, a_cols, a_div, a_rows,
+  hipLaunchKernelGGL(k_weighted_sums, dim3(nbands), dim3(WS_T), 0, (hipStream_t)stream, a, a_cols, a_div, a_rows,
                      wa, b, wb, n, out3);
   GFDN_LAUNCH_CHECK();
   return 0;

@@ -1206,9 +1206,10 @@ def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: b
     return gx2
 
 
-def edr_lin_parts(nfreq: int, fused: bool = False) -> int:
+def edr_lin_parts(nfreq: int, fused: bool = False, form: int = 0) -> int:
+    """Partial-sum columns per item of edr_lin_loss (``fused`` False) / edr_lin_loss_gsum in the given ``form``."""
     lib = _lib.load()
-    return lib.gfdn_edr_lin_fused_parts(int(nfreq)) if fused else lib.gfdn_edr_lin_parts(int(nfreq))
+    return lib.gfdn_edr_lin_band_parts(int(nfreq), int(form)) if fused else lib.gfdn_edr_lin_parts(int(nfreq))
 
 
 def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, want_grad: bool = True,
@@ -1249,7 +1250,7 @@ def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: floa
 
 
 def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, dots=None, col0: int = 0,
-                      tiled: bool = False, nsplit: int = 1):
+                      tiled: bool = False, nsplit: int = 1, form: int = 0):
     """edr_lin_loss(want_grad=True) and edr_lin_gsum as ONE launch (k_edr_lin_band) -> (part (items, edr_lin_parts(fused)),
     Gsum (nsplit, nbands G, nframes, nfreq)): a thread owns cells of the band's plane and walks the band's receivers,
     dL/d|S|^2 is never written, Sd is read once.  The band's receivers are cut into ``nsplit`` runs, one partial plane set
@@ -1265,7 +1266,7 @@ def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale:
     if rows is None and R != items:
         raise RuntimeError("edr_lin_loss_gsum: one row per item (or pass rows)")
     lib = _lib.load()
-    fblk = lib.gfdn_edr_lin_fused_parts(nfreq)
+    fblk = lib.gfdn_edr_lin_band_parts(nfreq, int(form))
     part = torch.empty((items, fblk), dtype=_f32, device=Sd.device)
     Gs = torch.empty((nsplit, nbands * G, nframes, nfreq), dtype=_c64, device=Sd.device)
     ld = 0
@@ -1274,10 +1275,11 @@ def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale:
                 or dots.shape[1] < col0 + fblk:
             raise RuntimeError("edr_lin_loss_gsum: dots must be (items * G, >= col0 + parts) contiguous float32")
         ld = dots.shape[1]
-    end = kernel_timer.bracket('k_edr_lin_band', items)          # (bench.py's roofline leg: events on the launch stream)
+    end = kernel_timer.bracket('k_edr_lin_wave' if form else 'k_edr_lin_band', items)      # (bench.py's roofline leg)
     _lib.check(lib.gfdn_edr_lin_loss_gsum(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(T_db),
                                           _p(_f(sum_abs)), nframes, nfreq, float(gscale), _p(part), fblk, _p(dots), ld,
-                                          int(col0), _p(Gs), int(nsplit), int(tiled), _stream()), "gfdn_edr_lin_loss_gsum")
+                                          int(col0), _p(Gs), int(nsplit), int(tiled), int(form), _stream()),
+               "gfdn_edr_lin_loss_gsum")
     if end is not None:
         end.record()
     return part, Gs

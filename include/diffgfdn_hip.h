@@ -560,7 +560,8 @@ int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, 
  * width (the last block holds the rest) -- so that a (receiver, frequency block) workgroup of gfdn_edr_lin_loss streams
  * contiguous runs; 0: cell = m nfreq + f.  gfdn_edr_lin_gsum works cell by cell and takes either.                        */
 int gfdn_edr_lin_parts(int nfreq);            /* partial-sum columns of gfdn_edr_lin_loss */
-int gfdn_edr_lin_fused_parts(int nfreq);      /* ... of gfdn_edr_lin_loss_gsum            */
+int gfdn_edr_lin_fused_parts(int nfreq);      /* ... of gfdn_edr_lin_loss_gsum, form 0    */
+int gfdn_edr_lin_band_parts(int nfreq, int form);   /* ... of gfdn_edr_lin_loss_gsum by form */
 int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                       int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
                       int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0, int tiled, void* stream);
@@ -574,7 +575,11 @@ int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, const float* S
 int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                            int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
                            float* part, int ld_part, float* dots, int ld_dots, int col0, float* Gsum_c64, int nsplit,
-                           int tiled, void* stream);
+                           int tiled, int form, void* stream);
+/* form 0 (k_edr_lin_band): workgroup = 64 frequencies x 8 waves of 4 frames, the scans along the frames across the waves through
+ * LDS (two barriers per receiver); form 1 (k_edr_lin_wave): a wave = 8 frequencies x all frames, the scans inside the wave on
+ * the VALU (DPP / permlane swaps), no LDS, no barriers; partial-sum columns per receiver: gfdn_edr_lin_band_parts(nfreq, form)
+ * (33 / 260 at nfreq = 2049).  Same numbers up to the order of the cross-group scan sums.                                  */
 /* gfdn_edc_loss_pairs[_banded] on signals x[b] = xd[xrows[b]] + sum_g rgain[b][g] tau[band G + g] formed by the first of its
  * three launches (segment energies), which stores them on the EDC window only into the scratch xwin2 (ceil(items / 2), ld, 2)
  * for the two scans (tau2 pair-interleaved).  ld = the signals' length = pitch of gx2 and xwin2; item_len NULL: one window

@@ -896,6 +896,17 @@ def test_edr_loss_on_composed_spectra(G, B):
     assert torch.equal(part4, part3) and torch.equal(parts4, parts3)
     assert tuple(Gs4.shape) == (2, S_, nfr, nf)
     assert rel_err(ops.spec_tile(Gs4.sum(0), inverse=True).cpu(), Gs_ref.cpu()) < 2e-5
+    # ... and in the form without barriers (a wave = 8 frequencies x all frames, scans on the VALU)
+    parts5 = torch.zeros(items * G, nch + ops.edr_lin_parts(nf, fused=True, form=1), device=DEV)
+    for tl in (False, True):
+        tile = ops.spec_tile if tl else (lambda t: t)
+        part5, Gs5 = ops.edr_lin_loss_gsum(tile(Sd), rows, tile(Stau), rgain, nb, tile(T_db), sum_abs, 1.5, dots=parts5,
+                                           col0=nch, tiled=tl, nsplit=1 + tl, form=1)
+        assert part5.shape[1] == 260
+        assert rel_err((part5.sum(1) / sum_abs[rows]).cpu(), li_ref.cpu()) < 2e-6
+        assert rel_err(parts5[:, nch:].sum(1).view(items, G).cpu(), dots_ref.cpu()) < 2e-5
+        G5 = Gs5.sum(0)
+        assert rel_err((ops.spec_tile(G5, inverse=True) if tl else G5).cpu(), Gs_ref.cpu()) < 2e-5
     # the adjoint STFT adds the partial sets where it loads them
     T = 2048 * (nfr + 1)
     g_one = ops.stft_pairs_spectrum_bwd(Gs4.sum(0), T, S_, 4096, tiled=True)
