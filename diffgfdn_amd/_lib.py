@@ -165,9 +165,9 @@ SIGNATURES = {
     "gfdn_lin_gamma": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_lin_gamma_dots_tiles": (c_int, [c_int]),
     "gfdn_lin_gamma_dots": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int,
-                                    c_int, c_int, _P, _P]),
+                                    c_int, c_int, _P, _P, _P]),
     "gfdn_stft_pairs_spectrum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
-    "gfdn_stft_pairs_spectrum_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "gfdn_stft_pairs_spectrum_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
     "gfdn_edr_lin_parts": (c_int, [c_int]),
     "gfdn_edr_lin_fused_parts": (c_int, [c_int]),
     "gfdn_edr_lin_loss": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, c_int,

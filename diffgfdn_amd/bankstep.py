@@ -108,6 +108,9 @@ class FusedBankStep:
     tiled_spectra = os.environ.get('GFDN_TILED_SPECTRA', '1') == '1'
     # ... and the G sums of the EDC gradient signals together with the EDC part of dL/drgain in one sweep over the window
     gamma_dots_one_launch = os.environ.get('GFDN_GAMMA_DOTS_ONE_LAUNCH', '1') == '1'
+    # ... and the adjoint STFT of the gradient spectra as ONE launch for all frames (odd frames to a second signal set that the
+    # gamma sweep adds) instead of the even-frame launch with the odd-frame launch behind it
+    adjoint_stft_one_launch = os.environ.get('GFDN_ADJ_STFT_ONE_LAUNCH', '1') == '1'
     # ... with the combine pass folded into the STFT's load (gfdn_stft_power_pairs_lin): x is stored by the launch that
     # first reads it.  Measured same-box: 0.565 against 0.549 ms -- the fused launch takes 73 us against 46 + 42, but the EDC
     # scans, which ran beside the STFT and the EDR kernel, now start behind it and run beside the STFT adjoint instead
@@ -276,7 +279,9 @@ class FusedBankStep:
             return li_edr, li_edc, None
         if Gs is None:
             Gs = ops.edr_lin_gsum(Sd, rows, Stau, rgain, nb, gP)
-        gam_edr = ops.stft_pairs_spectrum_bwd(Gs, K, nb * G, win, tiled=tiled)
+        # (one launch for all frames: the odd frames' contributions go to a second signal set that the gamma sweep adds)
+        one = self.adjoint_stft_one_launch and self.gamma_dots_one_launch
+        gam_edr = ops.stft_pairs_spectrum_bwd(Gs, K, nb * G, win, tiled=tiled, split_parity=one)
         keep.extend((Gs, gam_edr))
         return li_edr, li_edc, (g_edc, gam_edr, parts)
 
@@ -582,8 +587,9 @@ class FusedBankStep:
                         # one sweep over the EDC gradient signals (their window only): the G sums per band AND the EDC part
                         # of dL/drgain
                         _, band_len = tr._item_windows(K, Btot // nb, z.device)
-                        gam = ops.lin_gamma_dots(gsig, rgain, nb, K, tau, parts, start, length, base=gam_edr,
-                                                 slot_of_time=sot, band_win_len=band_len)
+                        ge_a, ge_b = gam_edr if isinstance(gam_edr, tuple) else (gam_edr, None)
+                        gam = ops.lin_gamma_dots(gsig, rgain, nb, K, tau, parts, start, length, base=ge_a,
+                                                 slot_of_time=sot, band_win_len=band_len, base_b=ge_b)
                     else:
                         gam = ops.lin_gamma(gsig, rgain, nb, K, True, True, slot_of_time=sot, base=gam_edr)
                     ev_gam = torch.cuda.Event()

@@ -610,11 +610,21 @@ __constant__ float2 c_edl_hann[16] = {
 // Adjoint: gx2 (pairs, ld) = [base2 +] STFT^T(Gs), Gs (items, nframes, 2049) the gradient w.r.t. the one-sided spectra.
 // Frames of one parity tile the time axis without overlap: the even launch STORES base + contribution (base alone where no
 // even frame reaches), the odd launch adds with a plain read-modify-write -- no atomics, no cleared buffer.
+// parity 2: ALL frames in one launch, the odd frames' contributions STORED to a second signal set gx2b (zeros where no odd
+// frame reaches) instead of added into gx2 -- no second launch behind the first; the consumer adds the two sets
+// (gfdn_lin_gamma_dots: base2 + base2b).
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2* __restrict__ Gs, int ld, int T,
                                                                 int nframes, int items, const float2* base2,
-                                                                float2* gx2, int parity, int tiled, int nsplit) {
+                                                                float2* gx2, int parity, int tiled, int nsplit,
+                                                                float2* gx2b) {
   float2* buf = edl_lds;
-  const int p = blockIdx.y, m = 2 * blockIdx.x + parity, nf = 2049, i = threadIdx.x;
+  const bool both = parity == 2;
+  const int m = both ? (int)blockIdx.x : 2 * (int)blockIdx.x + parity;
+  if (both) {
+    parity = m & 1;
+    if (parity) { gx2 = gx2b; base2 = nullptr; }
+  }
+  const int p = blockIdx.y, nf = 2049, i = threadIdx.x;
   const int b1 = 2 * p;
   const bool two = b1 + 1 < items;
   const float2* ga = Gs + (size_t)b1 * nframes * nf;
@@ -651,8 +661,9 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2*
   fft4096(a, buf, i, w1, -1.0f);
   float2* g = gx2 + (size_t)p * ld;
   const float2* bs = base2 ? base2 + (size_t)p * ld : nullptr;
-  const float2* src = parity ? g : bs;
-  const int tlim = parity ? T : ld;
+  const bool store = both || !parity;                       // (this launch defines the samples it reaches; else: adds)
+  const float2* src = store ? bs : g;
+  const int tlim = store ? ld : T;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int j = i + 256 * u, t = m * 2048 + j;
@@ -662,8 +673,10 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2*
       g[t] = make_float2(o.x + hw * a[u].x, o.y + (two ? hw * a[u].y : 0.f));
     }
   }
-  if (!parity && m + 2 >= nframes)
+  if (store && m + 2 >= nframes)
     for (int t = (m + 2) * 2048 + i; t < ld; t += S4K_T) g[t] = src ? src[t] : make_float2(0.f, 0.f);
+  if (both && m == 1)                                       // (no odd frame reaches the first hop)
+    for (int t = i; t < 2048 && t < ld; t += S4K_T) g[t] = make_float2(0.f, 0.f);
 }
 
 static int edl_nframes(int T) {
@@ -684,17 +697,25 @@ extern "C" int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int item
 }
 
 extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2,
-                                            int ld, int tiled, int nsplit, void* stream) {
-  if (!G_c64 || !gx2 || items <= 0 || T <= 0 || ld < T || base2 == gx2 || nsplit <= 0) return GFDN_E_BADARG;
+                                            int ld, int tiled, int nsplit, float* gx2b, void* stream) {
+  if (!G_c64 || !gx2 || items <= 0 || T <= 0 || ld < T || base2 == gx2 || nsplit <= 0 || gx2b == gx2) return GFDN_E_BADARG;
   if (win != 4096) return GFDN_E_UNSUPPORTED;
   const int nframes = edl_nframes(T);
   if (nframes <= 0) return GFDN_E_BADARG;
+  if (gx2b) {                       // one launch: even frames -> gx2 (+ base2), odd frames -> gx2b
+    if (nframes < 2) return GFDN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_stft4k_pair_spec_bwd, dim3(nframes, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
+                       (hipStream_t)stream, (const float2*)G_c64, ld, T, nframes, items, (const float2*)base2,
+                       (float2*)gx2, 2, tiled ? 1 : 0, nsplit, (float2*)gx2b);
+    GFDN_LAUNCH_CHECK();
+    return 0;
+  }
   for (int parity = 0; parity < 2; ++parity) {
     const int nb = (nframes + 1 - parity) / 2;
     if (nb == 0) continue;
     hipLaunchKernelGGL(k_stft4k_pair_spec_bwd, dim3(nb, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
                        (hipStream_t)stream, (const float2*)G_c64, ld, T, nframes, items, (const float2*)base2,
-                       (float2*)gx2, parity, tiled ? 1 : 0, nsplit);
+                       (float2*)gx2, parity, tiled ? 1 : 0, nsplit, (float2*)nullptr);
     GFDN_LAUNCH_CHECK();
   }
   return 0;

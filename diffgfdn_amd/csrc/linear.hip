@@ -365,7 +365,8 @@ __global__ __launch_bounds__(256) void k_lin_gamma_dots(const float2* __restrict
                                                         const float* __restrict__ base, int ld_b,
                                                         const int* __restrict__ slot_of_time, float* __restrict__ gamma,
                                                         int ld_o, float* __restrict__ part, int ld_part, int w0, int wlen,
-                                                        const int* __restrict__ wlen_band) {
+                                                        const int* __restrict__ wlen_band,
+                                                        const float* __restrict__ base_b) {
   __shared__ float s_rg[256];
   __shared__ float s_dot[4][256];                 // [wave][pair * 8 + item * 4 + g]  (B / 2 <= 32 pairs)
   const int band = blockIdx.y, tile = blockIdx.x;
@@ -444,7 +445,10 @@ __global__ __launch_bounds__(256) void k_lin_gamma_dots(const float2* __restrict
         const int s = band * G + g;
 #pragma unroll
         for (int u = 0; u < LIN_V; ++u)
-          if (t0 + u < n) acc[g][u] += base[((size_t)(s >> 1) * ld_b + t0 + u) * 2 + (s & 1)];
+          if (t0 + u < n) {
+            const size_t o = ((size_t)(s >> 1) * ld_b + t0 + u) * 2 + (s & 1);
+            acc[g][u] += base_b ? base[o] + base_b[o] : base[o];
+          }
       }
     }
   }
@@ -478,16 +482,17 @@ extern "C" int gfdn_lin_gamma_dots_tiles(int n) { return n > 0 ? (n + 256 * LIN_
 extern "C" int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nbands, int B, int G, int n,
                                    const float* tau2, int ld_tau, const float* base2, int ld_b, const int* slot_of_time,
                                    float* gamma, int ld_o, float* part, int ld_part, int win_start, int win_len,
-                                   const int* band_win_len, void* stream) {
+                                   const int* band_win_len, const float* base2b, void* stream) {
   if (!gx2 || !rgain || !tau2 || !gamma || !part || nbands <= 0 || B <= 0 || G <= 0 || n <= 0 || ld_g < n || ld_tau < n ||
-      ld_o < n || (base2 && (ld_b < n || base2 == gamma)) || win_start < 0 || win_len <= 0 || win_start + win_len > n)
+      ld_o < n || (base2 && (ld_b < n || base2 == gamma)) || win_start < 0 || win_len <= 0 || win_start + win_len > n ||
+      (base2b && (!base2 || base2b == gamma)))
     return GFDN_E_BADARG;
   const int tiles = (n + 256 * LIN_V - 1) / (256 * LIN_V);
   if (ld_part < tiles) return GFDN_E_BADARG;
   if (G > LIN_MAXG || (B & 1) || B > 64 || B * G > 256 || nbands > 65535) return GFDN_E_UNSUPPORTED;
   hipLaunchKernelGGL(k_lin_gamma_dots, dim3(tiles, nbands), dim3(256), 0, (hipStream_t)stream, (const float2*)gx2, ld_g, rgain,
                      B, G, n, (const float2*)tau2, ld_tau, base2, ld_b, slot_of_time, gamma, ld_o, part, ld_part, win_start,
-                     win_len, band_win_len);
+                     win_len, band_win_len, base2b);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

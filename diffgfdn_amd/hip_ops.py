@@ -1125,7 +1125,7 @@ def lin_gamma_dots_tiles(n: int) -> int:
 
 
 def lin_gamma_dots(g2, rgain, nbands: int, n: int, tau2, parts, win_start: int, win_len: int, base=None,
-                   slot_of_time=None, band_win_len=None):
+                   slot_of_time=None, band_win_len=None, base_b=None):
     """lin_gamma (pairs in, pairs out, ``base``, ``slot_of_time``) and lin_gain_dots in ONE sweep over gradient signals
     that are nonzero on [win_start, win_start + win_len) only (``band_win_len``: per-band lengths, int32 device): samples
     outside the window are not read.  ``parts`` (items * G, >= lin_gamma_dots_tiles(n)) receives the dot-product partial sums
@@ -1142,11 +1142,12 @@ def lin_gamma_dots(g2, rgain, nbands: int, n: int, tau2, parts, win_start: int, 
     gamma = torch.empty(((S + 1) // 2, n, 2), dtype=_f32, device=g2.device)
     if S % 2:
         gamma[-1].zero_()
-    if base is not None and (base.dtype != _f32 or not base.is_contiguous() or base.shape != gamma.shape):
-        raise RuntimeError("lin_gamma_dots: base must be shaped like gamma")
+    for bb in (base, base_b):
+        if bb is not None and (bb.dtype != _f32 or not bb.is_contiguous() or bb.shape != gamma.shape):
+            raise RuntimeError("lin_gamma_dots: base / base_b must be shaped like gamma")
     _lib.check(lib.gfdn_lin_gamma_dots(_p(g2), n, _p(rgain), nbands, items // nbands, G, n, _p(tau2), n, _p(base), n,
                                        _p(slot_of_time), _p(gamma), n, _p(parts), parts.shape[1], int(win_start),
-                                       int(win_len), _p(band_win_len), _stream()), "gfdn_lin_gamma_dots")
+                                       int(win_len), _p(band_win_len), _p(base_b), _stream()), "gfdn_lin_gamma_dots")
     return gamma
 
 
@@ -1187,7 +1188,7 @@ def stft_pairs_spectrum(x2, items: int, win: int, tiled: bool = False) -> torch.
     return S
 
 
-def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: bool = False) -> torch.Tensor:
+def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: bool = False, split_parity: bool = False):
     """Adjoint of stft_pairs_spectrum: gradient spectra G (items, nframes, win / 2 + 1) complex64 -> gx2
     (ceil(items / 2), n, 2) [+ base, same layout].  G (nsplit, items, nframes, win / 2 + 1): partial sets, added in order
     where they are loaded (edr_lin_loss_gsum)."""
@@ -1201,9 +1202,10 @@ def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: b
     gx2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=G.device)
     if base is not None and (base.dtype != _f32 or not base.is_contiguous() or base.shape != gx2.shape):
         raise RuntimeError("stft_pairs_spectrum_bwd: base must be shaped like the result")
+    gx2b = torch.empty_like(gx2) if split_parity else None     # (split_parity: ONE launch, returns (gx2, gx2b): their sum)
     _lib.check(_lib.load().gfdn_stft_pairs_spectrum_bwd(_p(G), n, items, win, _p(base), _p(gx2), n, int(tiled), int(nsplit),
-                                                        _stream()), "gfdn_stft_pairs_spectrum_bwd")
-    return gx2
+                                                        _p(gx2b), _stream()), "gfdn_stft_pairs_spectrum_bwd")
+    return (gx2, gx2b) if split_parity else gx2
 
 
 def edr_lin_parts(nfreq: int, fused: bool = False, form: int = 0) -> int:

@@ -535,7 +535,8 @@ int gfdn_lin_gain_dots(const float* gx, const float* gxb, int ld_g, int in_pairs
 int gfdn_lin_gamma_dots_tiles(int n);
 int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nbands, int B, int G, int n, const float* tau2,
                         int ld_tau, const float* base2, int ld_b, const int* slot_of_time, float* gamma, int ld_o,
-                        float* part, int ld_part, int win_start, int win_len, const int* band_win_len, void* stream);
+                        float* part, int ld_part, int win_start, int win_len, const int* band_win_len, const float* base2b,
+                        void* stream);
 
 /* ---- The EDR loss on linearly composed short-time spectra (csrc/edrlin.hip).  With the output stage in the time domain
  * the STFT of a receiver's signal is Sd[row_b] + sum_g gain[b][g] Stau_g (the STFT is linear): Sd = the STFT of the
@@ -552,7 +553,10 @@ int gfdn_lin_gamma_dots(const float* gx2, int ld_g, const float* rgain, int nban
  * rows: item -> row of Sd / T_db / sum_abs (NULL: identity).  G <= 4, nframes <= 32.                                    */
 int gfdn_stft_pairs_spectrum(const float* x2, int ld, int T, int items, int win, float* S_c64, int tiled, void* stream);
 int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, const float* base2, float* gx2, int ld,
-                                 int tiled, int nsplit, void* stream);
+                                 int tiled, int nsplit, float* gx2b, void* stream);
+/* gx2b (NULL: two launches, the odd frames added into gx2 behind the even ones): ONE launch, the odd frames' contributions
+ * STORED to gx2b (layout of gx2; zeros where no odd frame reaches) -- the adjoint is gx2 + gx2b, which gfdn_lin_gamma_dots
+ * adds where it reads its base (base2b).                                                                                 */
 /* nsplit >= 1: G holds nsplit partial sets (nsplit, items, nframes, 2049) that are added, in order, where they are loaded
  * (the partial planes of gfdn_edr_lin_loss_gsum).                                                                       */
 /* tiled = 1: the (nframes, nfreq) planes of S / G / Sd / Stau / T_db / gP / Gsum are stored with the frequencies cut into

@@ -834,6 +834,10 @@ def test_stft_pairs_spectrum_and_adjoint(items, T):
         assert abs(float(lhs[b] - rhs)) < 2e-5 * abs(float(lhs[b])) + 1e-3, (b, float(lhs[b]), float(rhs))
     if items % 2:
         assert float(gx[-1, :, 1].abs().max()) == 0.0
+    # all frames in one launch: even frames (+ base) and odd frames as two signal sets whose sum is the adjoint
+    ga, gb = ops.stft_pairs_spectrum_bwd(G, T, items, 4096, base=base, split_parity=True)
+    assert rel_err((ga + gb).cpu(), g2.cpu()) < 1e-6
+    assert float(gb[:, :2048].abs().max()) == 0.0
     # tiled cell order: the same numbers in another order
     assert torch.equal(ops.spec_tile(ops.stft_pairs_spectrum(x2, items, 4096, tiled=True), inverse=True), S)
     assert torch.equal(ops.stft_pairs_spectrum_bwd(ops.spec_tile(G), T, items, 4096, base=base, tiled=True), g2)
@@ -979,6 +983,11 @@ def test_gamma_and_dots_in_one_sweep(banded):
     assert float((parts[:, tiles:] - 7.0).abs().max()) == 0.0
     dots = parts[:, :tiles].sum(1).view(items, G)
     assert rel_err(dots.cpu(), dots_ref.cpu()) < 1e-5
+    # a base given as two signal sets (the one-launch adjoint STFT's even / odd frames): their sum is the base
+    half = (0.5 * base).contiguous()
+    gam2 = ops.lin_gamma_dots(g2p, rgain, nb, n, tau2, parts, w0, max(lens), base=half, slot_of_time=sot,
+                              band_win_len=band_len, base_b=half)
+    assert rel_err(gam2.cpu(), gam_ref.cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("G,order,B,J,filt", [(3, 2, 5, 12, True), (2, 1, 9, 6, False), (4, 0, 3, 1, True)])
