@@ -733,13 +733,6 @@ def main():
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         if args.gpus != world:
             raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    args._directional_record = None
-    if (world == 1 and args.config == 'omni' and not args.no_extras and not args.epoch and not args.classic
-            and args.bands == len(BAND_CENTRES) and NPER == 4):
-        # (never from under a profiler: its preloaded library has initialised the GPU before this program started)
-        profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith('ROCPROF') for k in os.environ)
-        if not profiled:
-            args._directional_record = directional_child(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     # host-side torch ops on tiny CPU tensors (index lists) crawl when the intra-op pool spans all 256 host cores
@@ -1054,30 +1047,8 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
         out.setdefault('extra', {})
         out['extra']['n32'] = sub_bench(args, device, 'n32')
         torch.cuda.empty_cache()
-        if args._directional_record is not None:
-            out['extra']['directional'] = sub_bench(args, device, 'directional')
+        out['extra']['directional'] = sub_bench(args, device, 'directional')
     return out
-
-
-def directional_child(args):
-    """`extra.directional` of the default line, measured by `bench.py --config directional` in a CHILD process that runs to its
-    end BEFORE this process makes its first GPU call (the two never share the GPU, and nothing is spawned from a process that
-    has initialised it).  Why a process of its own: the bank's capture (seven band steps forked onto four lanes of one graph)
-    ends in hipErrorStreamCaptureUnjoined in a process that has captured and replayed the omnidirectional steps before it
-    (ROCm 7.2; distinct streams checked, cause not found), while it is reliable in a process of its own -- which is also how
-    `bench.py --config directional` and a training run use it."""
-    cmd = [sys.executable, os.path.abspath(__file__), '--config', 'directional', '--no-cpu-baseline', '--steps',
-           str(args.extra_steps), '--warmup', '5', '--receivers', str(args.receivers), '--dir-bank', str(args.dir_bank),
-           '--dir-streams', str(args.dir_streams)]
-    t0 = time.perf_counter()
-    cp = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    lines = [l for l in cp.stdout.splitlines() if l.startswith('{')]
-    if cp.returncode != 0 or not lines:
-        raise SystemExit(f"bench.py: the directional sub-record failed (rc {cp.returncode}):\n{cp.stderr[-3000:]}")
-    r = json.loads(lines[-1])
-    r['measured_in'] = 'child process, before the parent\'s first GPU call: ' + ' '.join(cmd[1:])
-    r['child_wall_s'] = time.perf_counter() - t0
-    return r
 
 
 def sub_bench(args, device, which):
@@ -1098,13 +1069,12 @@ def sub_bench(args, device, which):
         rec = {k: r[k] for k in keep}
         rec['config'] = {k: r['config'][k] for k in ('workload', 'delay_lines', 'rirs_per_s', 'final_loss')}
     else:
-        r = args._directional_record          # (measured by main() in a child process BEFORE this one touched the GPU)
+        r = run_directional(a, device, 0, 1)
         rec = {k: r[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup')}
-        rec['measured_in'] = r['measured_in']
         rec['config'] = {k: r['config'][k] for k in ('workload', 'delay_lines', 'rirs_per_s', 'ms_per_band_step', 'final_loss')}
         if 'roofline' in r:
             rec['roofline'] = r['roofline']
-    rec['wall_s_incl_build'] = r.get('child_wall_s', time.perf_counter() - t0) if which != 'n32' else time.perf_counter() - t0
+    rec['wall_s_incl_build'] = time.perf_counter() - t0
     return rec
 
 

@@ -127,8 +127,12 @@ __device__ __forceinline__ float block_sum(float v, float* lds /* >= 16 floats *
 // launches under HIP graph capture -- make no runtime API call.
 static inline int ensure_dyn_lds_ptr(const void* fn, size_t bytes) {
   if (bytes <= 48 * 1024) return 0;
-  static const void* fns[32];
-  static size_t granted[32];
+  // (a kernel that does not fit in the table would call hipFuncSetAttribute on EVERY launch -- also under graph capture,
+  // where the runtime refuses runtime API calls: the table is per translation unit and sized far above the number of
+  // kernels with more than 48 KB of dynamic LDS in any of them)
+  constexpr int SLOTS = 512;
+  static const void* fns[SLOTS];
+  static size_t granted[SLOTS];
   static int count = 0;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
@@ -138,7 +142,7 @@ static inline int ensure_dyn_lds_ptr(const void* fn, size_t bytes) {
   if (slot >= 0 && bytes <= granted[slot]) return 0;
   int rc = (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (rc != 0) return rc;
-  if (slot < 0 && count < 32) { slot = count++; fns[slot] = fn; }
+  if (slot < 0 && count < SLOTS) { slot = count++; fns[slot] = fn; }
   if (slot >= 0) granted[slot] = bytes;
   return 0;
 }

@@ -19,6 +19,7 @@ class FrequencyGrid:
     it to the delay lengths every forward (feedback_loop.py:330)."""
 
     _cache = {}
+    _capacity = 64
 
     def __init__(self, z: torch.Tensor):
         self.K = z.numel()
@@ -40,8 +41,17 @@ class FrequencyGrid:
         key = (z.data_ptr(), z.numel(), z._version, str(z.device))
         g = cls._cache.get(key)
         if g is None:
-            if len(cls._cache) > 8:
-                cls._cache.clear()
+            if torch.cuda.is_current_stream_capturing():
+                # (building a grid reads the device: a step must have met its z BEFORE it is captured -- the warm-up does)
+                raise RuntimeError("FrequencyGrid: first use of this z_values tensor inside a stream capture; run the step "
+                                   "once before capturing it")
+            # Oldest entry out, one at a time.  (The cache used to be CLEARED at nine entries: seven bands' steps, each with
+            # its own copy of z, in a process whose cache already held a few grids lost the first bands' entries during the
+            # later bands' warm-up -- and then built them again, with their host reads, inside the capture:
+            # hipErrorStreamCaptureUnsupported / ...Unjoined.)  Steps keep the grids they recorded pointers of alive
+            # themselves (GraphedModuleStep._grids).
+            while len(cls._cache) >= cls._capacity:
+                cls._cache.pop(next(iter(cls._cache)))
             g = cls(z)
             cls._cache[key] = g
         return g
