@@ -843,13 +843,13 @@ def test_stft_pairs_spectrum_and_adjoint(items, T):
     assert torch.equal(ops.stft_pairs_spectrum_bwd(ops.spec_tile(G), T, items, 4096, base=base, tiled=True), g2)
 
 
-@pytest.mark.parametrize("G,B", [(4, 4), (3, 2)])
-def test_edr_loss_on_composed_spectra(G, B):
+@pytest.mark.parametrize("G,B,nfr", [(4, 4, 32), (3, 2, 32), (2, 3, 13)])
+def test_edr_loss_on_composed_spectra(G, B, nfr):
     """gfdn_edr_lin_loss / gfdn_edr_lin_gsum (EDR on S = Sd[row] + sum_g rgain Stau_g, never stored) against the stored
     form: compose S in torch, |S|^2 through gfdn_edr_loss, the gain gradients and the summed gradient spectra in float64."""
     from diffgfdn_amd import hip_ops as ops
     gen = torch.Generator(device="cpu").manual_seed(7 * G + B)
-    nb, R, nfr, nf = 2, B + 3, 32, 2049
+    nb, R, nf = 2, B + 3, 2049            # (nfr = 13: frame groups of the one-launch kernels only partly filled; B = 3: runs 2 + 1)
     items, S_ = nb * B, nb * G
     Sd = torch.view_as_complex(torch.randn(nb * R, nfr, nf, 2, generator=gen).to(DEV))
     Stau = torch.view_as_complex(torch.randn(S_, nfr, nf, 2, generator=gen).to(DEV))
