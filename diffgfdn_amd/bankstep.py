@@ -127,6 +127,12 @@ class FusedBankStep:
     fold_gains = False
     gain_rows_in_mlp = os.environ.get('GFDN_GAIN_ROWS_IN_MLP', '1') == '1'
     colorless_behind_scans = os.environ.get('GFDN_COLORLESS_LATE', '1') == '1'      # (blocks of 5..8 lines)
+    # ... or on a stream of its own, started as soon as the normalisation is known, so that the VALU-bound pass runs beside
+    # the transforms of the group signals and the memory-bound middle instead of beside the gamma sweep, the adjoint
+    # transform and the records pass at the tail of the critical chain.  OFF: measured same-box 0.393 -> 0.418-0.424 ms at
+    # N = 16 and 0.702 -> 0.784 ms at N = 32 -- what it takes from the head of the chain (group responses, the latency-bound
+    # 28-signal transforms) is more than what it gives back at the tail
+    colorless_own_stream = os.environ.get('GFDN_COLORLESS_STREAM', '0') == '1'
     # the optimiser update on the side stream behind the gain network's backward (single process)
     adam_on_side = os.environ.get('GFDN_ADAM_ON_SIDE', '1') == '1'
     # STFT -> EDR and the EDC term as ONE launch, one workgroup per item (gfdn_decay_items_fwd) instead of the pair STFT,
@@ -519,8 +525,12 @@ class FusedBankStep:
         # lines: in front of the scans, beside the output stage and the transform (behind the scans it ran beside the STFT
         # adjoint: same step time either way, measured).  Blocks of 5..8 lines: BEHIND the scans -- the pass takes ~200 us
         # there, and in front of them the EDC gradient reached the odd-frame launch of the STFT adjoint late
+        own_cl = (self.colorless_own_stream and side is not None and pipe is None
+                  and not (self.halves >= 2 and pairs and Btot % 4 == 0 and item_len is None))
+        on_cl = on_side if own_cl else on_side2
+
         def colorless_pass():
-            with on_side2():
+            with on_cl():
                 torch.cuda.current_stream().wait_event(ev['norm'])
                 if big:
                     torch.cuda.current_stream().wait_event(ev_ts)
@@ -540,7 +550,7 @@ class FusedBankStep:
         # (spectral-EDR step: the same holds for the small blocks -- in front of the scans the VALU-bound pass ran beside the
         # latency-bound transforms of the G group signals, which sit on the critical chain: 18.6 against 9.6 us for the
         # row pass; behind them it runs beside the memory-bound EDR kernels)
-        late_colorless = (big or spec) and self.colorless_behind_scans
+        late_colorless = (big or spec) and self.colorless_behind_scans and not own_cl
         if not late_colorless:
             grec_sub, out3, gQ = colorless_pass()
 
@@ -611,6 +621,8 @@ class FusedBankStep:
                 grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True)
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
+                if own_cl:
+                    torch.cuda.current_stream().wait_event(ev['side'])       # (the colorless terms the totals include)
                 sums, total = report()
                 if allreduce is not None:
                     # data-parallel: this rank's loss terms ride the gradient bucket -- [EDR | EDC | colorless share]
@@ -698,6 +710,8 @@ class FusedBankStep:
         else:
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
+                if own_cl:
+                    torch.cuda.current_stream().wait_event(ev['side'])
                 sums, total = report()
         keep.extend((sums, total))
         if nb > 1:
