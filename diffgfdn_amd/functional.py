@@ -22,6 +22,10 @@ class FrequencyGrid:
     _capacity = 64
 
     def __init__(self, z: torch.Tensor):
+        # (the cache key is the tensor's ADDRESS and version: the entry keeps the tensor alive, so that the allocator cannot
+        # hand its block to another z of the same length while the entry exists -- a freed grid's address reused by a
+        # different grid was a false hit waiting to happen: wrong phasors, H off by 4e-3 in one test order)
+        self.z = z
         self.K = z.numel()
         self.turns, logr = ops.zprep(z)
         # the unit circle is by far the common case: skip the radius factor entirely
