@@ -127,6 +127,9 @@ class FusedBankStep:
     fold_gains = False
     gain_rows_in_mlp = os.environ.get('GFDN_GAIN_ROWS_IN_MLP', '1') == '1'
     colorless_behind_scans = os.environ.get('GFDN_COLORLESS_LATE', '1') == '1'      # (blocks of 5..8 lines)
+    # (blocks of <= 4 lines on the spectral-EDR step: behind the scans as well.  In front of them: 0.387-0.390 against
+    # 0.392-0.393 ms on one box, 0.394-0.396 against 0.392-0.398 on another -- inside the noise, the position stays)
+    colorless_late_small = os.environ.get('GFDN_COLORLESS_LATE_SMALL', '1') == '1'
     # ... or on a stream of its own, started as soon as the normalisation is known, so that the VALU-bound pass runs beside
     # the transforms of the group signals and the memory-bound middle instead of beside the gamma sweep, the adjoint
     # transform and the records pass at the tail of the critical chain.  OFF: measured same-box 0.393 -> 0.418-0.424 ms at
@@ -550,7 +553,7 @@ class FusedBankStep:
         # (spectral-EDR step: the same holds for the small blocks -- in front of the scans the VALU-bound pass ran beside the
         # latency-bound transforms of the G group signals, which sit on the critical chain: 18.6 against 9.6 us for the
         # row pass; behind them it runs beside the memory-bound EDR kernels)
-        late_colorless = (big or spec) and self.colorless_behind_scans and not own_cl
+        late_colorless = (big or (spec and self.colorless_late_small)) and self.colorless_behind_scans and not own_cl
         if not late_colorless:
             grec_sub, out3, gQ = colorless_pass()
 
