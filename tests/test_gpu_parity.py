@@ -445,7 +445,8 @@ def test_directional_graphed_step_equals_eager_step(mask):
         assert int(step.mask_state.item()) == 3          # (one draw per replay; the warm-up draws were undone)
 
 
-def test_directional_bank_equals_band_steps():
+@pytest.mark.parametrize("mask", [False, True])
+def test_directional_bank_equals_band_steps(mask):
     """trainer.DirectionalBank: three bands' directional trainers (different parameters, targets and decay times) stepped by
     ONE graph with the bands on two lanes == every band's own host-launched train_step, bit for bit (values and state) --
     the bands are independent models, the graph only changes who launches what beside what."""
@@ -474,7 +475,7 @@ def test_directional_bank_equals_band_steps():
                           k in ("input_gains", "output_gains", "feedback_loop.M") else v) for k, v in sd.items()}
             net.load_state_dict(sd, strict=True)
             net = net.to(DEV)
-            tc = TrainerConfig(use_colorless_loss=True, edc_loss_weight=1.0 + q, use_edc_mask=False, lr=1e-3, io_lr=1e-2,
+            tc = TrainerConfig(use_colorless_loss=True, edc_loss_weight=1.0 + q, use_edc_mask=mask, lr=1e-3, io_lr=1e-2,
                                train_dir=f"/tmp/gfdn_t/db{q}", ir_dir=f"/tmp/gfdn_a/db{q}", device="cuda")
             tr = DirectionalFDNVarReceiverPosTrainer(net, tc, capturable=True)
             crit = tr.criterion[0]
@@ -487,7 +488,13 @@ def test_directional_bank_equals_band_steps():
     res = {}
     for mode in ("eager", "bank"):
         trs, batches = build()
-        bank = DirectionalBank(trs, batches, lanes=2).capture() if mode == "bank" else None
+        bank = DirectionalBank(trs, batches, lanes=2, mask_seed=977).capture() if mode == "bank" else None
+        if mask and mode == "eager":          # (the bank's device generators, band q seeded 977 + q, launched from the host)
+            for q, tr in enumerate(trs):
+                crit = tr.criterion[0]
+                K_ = batches[q]["z_values"].shape[-1]
+                L_ = min(crit.edc_len_samps, 2 * (K_ - 1) - crit.mixing_time_samps)
+                crit.device_mask = (977 + q, torch.zeros(1, dtype=torch.long, device=DEV), torch.zeros(L_, device=DEV))
         vals = []
         for i in range(3):
             bs = [dict(b, target_common_slope_amps=b["target_common_slope_amps"] * (1.0 + 0.1 * i)) for b in batches]
