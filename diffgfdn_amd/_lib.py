@@ -130,6 +130,8 @@ SIGNATURES = {
     "gfdn_edc_mixed_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_edc_loss_model_mixed": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P,
                                           c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_group_sums_fwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "gfdn_group_sums_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_dirlin_tiles": (c_int, [c_int]),
     "gfdn_dirlin_line_tiles": (c_int, [c_int]),
     "gfdn_dirlin_lines_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P]),

@@ -224,6 +224,91 @@ __global__ __launch_bounds__(DL_T) void k_dl_gamma_dots(const float* __restrict_
   }
 }
 
+// ---- group sums of the raw sub-FDN responses (reference model.py:243-250: Hout[k][g] = sum_{n in g} c_n y_n[k]) --------
+// The colorless branch of every model needs only these G sums; through the general output stage (G "receivers" with identity
+// gains, gfdn_compose_fwd / _bwd) the backward alone took 48 us per band-step of the directional model for 28 MB of traffic.
+//   k_gs_fwd : S (G, K) = sum over the group's lines of c_n Y[k][n]          (Y (K, N) bin-major, N = G nper)
+//   k_gs_bwd : gY[k][n] = c_n gS[g(n)][k],  per-tile partial sums of gc_n = sum_k Re(conj(gS[g(n)][k]) Y[k][n])
+__global__ __launch_bounds__(256) void k_gs_fwd(const float2* __restrict__ Y, int K, int G, int nper,
+                                                const float* __restrict__ c, float2* __restrict__ S) {
+  const int N = G * nper, NS = N + 1 + (N & 1);
+  float2* yt = dl_lds;                                  // [DL_TB][NS]
+  const int k0 = blockIdx.x * DL_TB;
+  const int nbin = K - k0 < DL_TB ? K - k0 : DL_TB;
+  const size_t base = (size_t)k0 * N;
+  for (int e = threadIdx.x; e < nbin * N; e += 256) {
+    const int kq = e / N, n = e - kq * N;
+    yt[kq * NS + n] = cscale(Y[base + e], c[n]);
+  }
+  __syncthreads();
+  const int kq = threadIdx.x & (DL_TB - 1);
+  if (kq >= nbin) return;
+  for (int g = threadIdx.x / DL_TB; g < G; g += 256 / DL_TB) {
+    float2 acc = make_float2(0.f, 0.f);
+    for (int l = 0; l < nper; ++l) acc = cadd(acc, yt[kq * NS + g * nper + l]);
+    S[(size_t)g * K + k0 + kq] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gs_bwd(const float2* __restrict__ Y, int K, int G, int nper,
+                                                const float* __restrict__ c, const float2* __restrict__ gS,
+                                                float2* __restrict__ gY, float* __restrict__ gc_part, int ntiles) {
+  const int N = G * nper;
+  float2* gt = dl_lds;                                  // [G][DL_TB]: gS of the tile
+  float* pr = (float*)(gt + G * DL_TB);                 // [DL_TB][N + 1]
+  const int k0 = blockIdx.x * DL_TB;
+  const int nbin = K - k0 < DL_TB ? K - k0 : DL_TB;
+  for (int e = threadIdx.x; e < G * DL_TB; e += 256) {
+    const int g = e / DL_TB, q = e - g * DL_TB;
+    gt[e] = q < nbin ? gS[(size_t)g * K + k0 + q] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  const size_t base = (size_t)k0 * N;
+  for (int e = threadIdx.x; e < DL_TB * N; e += 256) {
+    const int q = e / N, n = e - q * N;
+    float p = 0.f;
+    if (q < nbin) {
+      const float2 g = gt[(n / nper) * DL_TB + q], y = Y[base + e];
+      gY[base + e] = cscale(g, c[n]);
+      p = g.x * y.x + g.y * y.y;
+    }
+    pr[q * (N + 1) + n] = p;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float s = 0.f;
+    for (int q = 0; q < DL_TB; ++q) s += pr[q * (N + 1) + threadIdx.x];
+    gc_part[(size_t)threadIdx.x * ntiles + blockIdx.x] = s;
+  }
+}
+
+extern "C" int gfdn_group_sums_fwd(const float* Y, int K, int G, int nper, const float* c, float* S, void* stream) {
+  if (!Y || !c || !S || K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  const int N = G * nper;
+  if (N > 64) return GFDN_E_UNSUPPORTED;
+  const int NS = N + 1 + (N & 1);
+  hipLaunchKernelGGL(k_gs_fwd, dim3((K + DL_TB - 1) / DL_TB), dim3(256), (size_t)DL_TB * NS * sizeof(float2),
+                     (hipStream_t)stream, (const float2*)Y, K, G, nper, c, (float2*)S);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_group_sums_bwd(const float* Y, int K, int G, int nper, const float* c, const float* gS, float* gY,
+                                   float* gc, float* gc_part, void* stream) {
+  if (!Y || !c || !gS || !gY || !gc || !gc_part || K <= 0 || G <= 0 || nper <= 0) return GFDN_E_BADARG;
+  const int N = G * nper;
+  if (N > 64) return GFDN_E_UNSUPPORTED;
+  const int ntiles = (K + DL_TB - 1) / DL_TB;
+  const size_t lds = (size_t)G * DL_TB * sizeof(float2) + (size_t)DL_TB * (N + 1) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gs_bwd, dim3(ntiles), dim3(256), lds, s, (const float2*)Y, K, G, nper, c, (const float2*)gS,
+                     (float2*)gY, gc_part, ntiles);
+  GFDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_dl_rowsum, dim3(N), dim3(64), 0, s, (const float*)gc_part, ntiles, ntiles, gc);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int gfdn_dirlin_tiles(int len) { return len > 0 ? (len + DL_TILE - 1) / DL_TILE : 0; }
 extern "C" int gfdn_dirlin_line_tiles(int K) { return K > 0 ? (K + DL_TB - 1) / DL_TB : 0; }

@@ -243,6 +243,23 @@ class OutputStage(torch.autograd.Function):
         return gY, gc.to(c.dtype).reshape(c.shape), grg.to(rgain.dtype), None, None, None, None, None
 
 
+class GroupSums(torch.autograd.Function):
+    """S (G, K) = sum_{n in g} c_n Y[k][n]: the sub-FDN group responses (model.py:243-250) without the receiver machinery
+    of the general output stage."""
+
+    @staticmethod
+    def forward(ctx, Y, c, G: int, nper: int):
+        ctx.save_for_backward(Y, c)
+        ctx.G, ctx.nper = G, nper
+        return ops.group_sums_fwd(Y, c, G, nper)
+
+    @staticmethod
+    def backward(ctx, gS):
+        Y, c = ctx.saved_tensors
+        gY, gc = ops.group_sums_bwd(Y, c, ctx.G, ctx.nper, gS.contiguous())
+        return gY, gc.to(c.dtype).reshape(c.shape), None, None
+
+
 class SHOutputStage(torch.autograd.Function):
     """H_sh[b][l][k] = filt[k] * sum_g w[b][g][l] c_{g,l} Y[k][g nper + l]  (model.py:1056-1088)."""
 

@@ -1728,6 +1728,36 @@ def edc_loss_model_mixed(x_sh, A, start: int, length: int, amps, env, maskw=None
     return loss_item, gx
 
 
+def group_sums_supported(G: int, nper: int) -> bool:
+    return G * nper <= 64
+
+
+def group_sums_fwd(Y, c, G: int, nper: int) -> torch.Tensor:
+    """S (G, K) complex64 = sum over the group's lines of c_n Y[k][n]  (model.py:243-250)."""
+    _need_gpu(Y, c)
+    Y, c = _c(Y), _f(c)
+    K, N = Y.shape
+    if N != G * nper or c.numel() != N:
+        raise RuntimeError("group_sums_fwd: Y (K, G nper), c (G nper,)")
+    S = torch.empty((G, K), dtype=_c64, device=Y.device)
+    _lib.check(_lib.load().gfdn_group_sums_fwd(_p(Y), K, G, nper, _p(c), _p(S), _stream()), "gfdn_group_sums_fwd")
+    return S
+
+
+def group_sums_bwd(Y, c, G: int, nper: int, gS):
+    """(gY (K, N), gc (N,)) from gS (G, K)."""
+    _need_gpu(Y, c, gS)
+    Y, c, gS = _c(Y), _f(c), _c(gS)
+    K, N = Y.shape
+    lib = _lib.load()
+    gY = torch.empty_like(Y)
+    gc = torch.empty(N, dtype=_f32, device=Y.device)
+    part = torch.empty(N * lib.gfdn_dirlin_line_tiles(K), dtype=_f32, device=Y.device)
+    _lib.check(lib.gfdn_group_sums_bwd(_p(Y), K, G, nper, _p(c), _p(gS), _p(gY), _p(gc), _p(part), _stream()),
+               "gfdn_group_sums_bwd")
+    return gY, gc
+
+
 # ---- the directional output stage in the time domain (csrc/dirlin.hip) -----------------------------------------------
 def dirlin_supported(G: int, nper: int) -> bool:
     """Group / line counts the gfdn_dirlin_* kernels are built for."""

@@ -20,7 +20,8 @@ from torch import nn
 
 from .config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
 from .feedback_loop import FeedbackLoop, decay_times_to_gain_per_sample
-from .functional import FrequencyGrid, OutputStage, ResolventSolve, SHOutputStage, SosOutputStage
+from . import hip_ops as ops
+from .functional import FrequencyGrid, GroupSums, OutputStage, ResolventSolve, SHOutputStage, SosOutputStage
 from .gain_filters import (Directional_Beamforming_Weights_from_MLP, Gains_from_MLP, SVF_from_MLP,
                            svf_cascade_response, svf_cutoff_frequencies)
 
@@ -159,8 +160,11 @@ class DiffGFDN(nn.Module):
     def sub_fdn_group_sums(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """(S (G, K), Ysub (K, N)):  S[g][k] = sum_{n in g} c_n y^(g)_n[k] = Hout[k, g]."""
         Ysub = self.sub_fdn_responses(z)
-        S = OutputStage.apply(Ysub, self.output_gains.reshape(-1), self._eye,
-                              self.num_delay_lines_per_group, None, None)
+        if ops.group_sums_supported(self.num_groups, self.num_delay_lines_per_group):
+            S = GroupSums.apply(Ysub, self.output_gains.reshape(-1), self.num_groups, self.num_delay_lines_per_group)
+        else:
+            S = OutputStage.apply(Ysub, self.output_gains.reshape(-1), self._eye,
+                                  self.num_delay_lines_per_group, None, None)
         return S, Ysub
 
     # ``Hout_per_del`` (N, K, G) of :meth:`sub_fdn_output` costs five passes over a 42 MB tensor at K = 65 537, N = 27 and

@@ -764,6 +764,14 @@ int gfdn_dirlin_combine(const float* tau, int ld_tau, int start, int len, const 
 int gfdn_dirlin_gamma_dots(const float* gx, int ld_g, int len, const float* tau, int ld_tau, int start, const float* w,
                            int B, int G, int nper, float* gtau, int ld_o, float* gw, float* part, void* stream);
 
+/* ---- group sums of the sub-FDN responses (model.py:243-250: Hout[k][g] = sum_{n in g} c_n y_n[k]): S (G, K) complex from
+ * Y (K, N = G nper) complex bin-major; backward: gY (K, N) = c_n gS[g(n)][k], gc (N) = sum_k Re(conj(gS) Y)
+ * (gc_part: N gfdn_dirlin_line_tiles(K) floats).  The G-receivers-with-identity-gains form of gfdn_compose_fwd / _bwd
+ * without the receiver machinery.  N <= 64.                                                                            */
+int gfdn_group_sums_fwd(const float* Y_c64, int K, int G, int nper, const float* c, float* S_c64, void* stream);
+int gfdn_group_sums_bwd(const float* Y_c64, int K, int G, int nper, const float* c, const float* gS_c64, float* gY_c64,
+                        float* gc, float* gc_part, void* stream);
+
 /* ---- EDC time mask on the device  (losses.py:221-227: mask = argwhere(bernoulli(U(0,1))) over the
  * window -- marginally every index is kept with probability 1/2, independently).
  * Counter-based draw: bit t of the mask is bit (t mod 128) of Philox4x32-10(counter = (t / 128, 0,

@@ -1051,3 +1051,28 @@ def test_directional_output_stage_in_the_time_domain(ops, G, order, B, J, filt):
     assert abs(val.item() - ref.item()) < 1e-5 * abs(ref.item()), (val.item(), ref.item())
     for name, a, b in zip(('Y', 'c', 'w'), gl, gr):
         assert re_(a, b) < 1e-4, (name, re_(a, b))
+
+
+@pytest.mark.parametrize("G,nper,K", [(3, 9, 65537), (4, 4, 4097), (2, 16, 1000), (1, 1, 77)])
+def test_group_sums_of_subfdn_responses(ops, G, nper, K):
+    """gfdn_group_sums_fwd / _bwd (model.py:243-250: Hout[k][g] = sum_{n in g} c_n y_n[k]) against float64 tensor algebra and
+    against the general output stage with identity gains, which they replace in the colorless branch."""
+    from diffgfdn_amd.functional import GroupSums, OutputStage
+    g_ = torch.Generator(device="cpu").manual_seed(11 * G + nper)
+    N = G * nper
+    Y = torch.view_as_complex(torch.randn(K, N, 2, generator=g_)).to(DEV).requires_grad_(True)
+    c = (torch.rand(N, generator=g_) + 0.5).to(DEV).requires_grad_(True)
+    S = GroupSums.apply(Y, c, G, nper)
+    Sr = (Y.detach().to(torch.complex128) * c.detach().double()).reshape(K, G, nper).sum(-1).T
+    assert rel_err(S.detach().cpu().numpy(), Sr.cpu().numpy()) < 1e-6
+    gS = torch.view_as_complex(torch.randn(G, K, 2, generator=g_)).to(DEV)
+    gY, gc = torch.autograd.grad(S, (Y, c), gS)
+    gYr = (gS.to(torch.complex128).T.reshape(K, G, 1) * c.detach().double().reshape(1, G, nper)).reshape(K, N)
+    gcr = (gS.to(torch.complex128).T.reshape(K, G, 1).conj() * Y.detach().to(torch.complex128).reshape(K, G, nper)).real.sum(0)
+    assert rel_err(gY.cpu().numpy(), gYr.cpu().numpy()) < 1e-6
+    assert rel_err(gc.cpu().numpy(), gcr.reshape(-1).cpu().numpy()) < 1e-5
+    eye = torch.eye(G, device=DEV)
+    S2 = OutputStage.apply(Y, c, eye, nper, None, None)
+    gY2, gc2 = torch.autograd.grad(S2, (Y, c), gS)
+    assert rel_err(S.detach().cpu().numpy(), S2.detach().cpu().numpy()) < 1e-6
+    assert rel_err(gY.cpu().numpy(), gY2.cpu().numpy()) < 1e-6 and rel_err(gc.cpu().numpy(), gc2.cpu().numpy()) < 1e-5
