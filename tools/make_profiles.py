@@ -72,7 +72,7 @@ with open(os.path.join(dst, 'README.md'), 'w') as f:
     f.write(f"""# profiles/ -- round {tag[1:]}
 All `{tag}_*` files come from ONE `gpurun` call (`bash tools/run_measurements.sh {tag}`) on one MI355X (gfx950, ROCm 7.2);
 `bench.py` is the command the driver runs (N = 1, workload = the 7-band configuration BASELINE.json's metric is quoted
-on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` / `r02_*` files are the previous rounds', kept for comparison.
+on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r03_*` files are the previous rounds', kept for comparison.
 
 | file | command | what it holds |
 |---|---|---|
