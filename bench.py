@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the DiffGFDN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--epoch]
+    python bench.py --gpus N --steps K --warmup W [--scaling auto|weak|strong] [--epoch]
 
 With N > 1 and no launcher around it (WORLD_SIZE unset) the script starts its own N ranks -- a child
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` -- BEFORE anything touches
@@ -18,10 +18,13 @@ alone (the 500 Hz band).
 One "step" = what the reference's training loop does per batch (trainer.py:373-379), for every band: normalize
 (no-grad sub-FDN forward + in-place rescale of b, c) + train_step (forward, losses, backward, [all-reduce], Adam).
 Inputs are resident in HBM before the timed region.  Metric: RIR-frames/s = bands x receivers x 32 EDR frames /
-second, summed over ranks.  ``--scaling weak`` (default): every rank steps its own 32 receivers per band (global
-batch 32 N per band); ``--scaling strong``: the reference's global batch of 32 per band is split over the ranks.
-Either way the gradients of all bands and the per-band loss terms are summed by ONE all-reduce of one flat buffer,
-captured inside the step's HIP graph.
+second, summed over ranks.  ``--scaling auto`` (default): N = 1 the step at batch 32 ("weak"); N > 1 the headline is
+STRONG scaling -- the reference's global batch of 32 per band split over the ranks -- with the weak figure (every rank
+steps its own 32 receivers per band, global batch 32 N) and the band-sharded placement (whole bands over the ranks, no
+collective) beside it in ``extra``; ``--scaling weak`` / ``strong``: that one figure only.  Either way the gradients of all
+bands and the per-band loss terms are summed by ONE all-reduce of one flat buffer, between the step's two graphs (or inside
+one graph with ``--captured-allreduce``).  At N = 1 the default line also carries the N = 32 configuration and the
+directional configuration as short sub-records (``extra.n32``, ``extra.directional``).
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel.  ``achieved`` uses its duration IN THE STEP: the same launch
