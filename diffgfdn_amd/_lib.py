@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P = c_void_p
 
@@ -80,7 +80,17 @@ SIGNATURES = {
                                     _P]),
     "gfdn_tf_compose_parts": (c_int, [c_int]),
     "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
+    "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P,
+                                    _P]),
+    "gfdn_tf_tail": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                             _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
+    "gfdn_irfft_odd_pairs_bwd_tslots3": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_odd_pairs_fwd_scaled": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, c_int, _P, c_int, _P]),
+    "gfdn_edc_lin_one_max_len": (c_int, []),
+    "gfdn_edc_lin_one": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P,
+                                 c_int, c_float, c_float, _P, _P, c_int, _P, c_int, c_int, _P]),
+    "gfdn_lin_gamma_win": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int,
+                                   _P]),
     "gfdn_tf_gain_grad_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfdn_tf_gain_grad": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_tf8_coefs": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -497,6 +497,8 @@ class BandBankTrainer:
     @torch.no_grad()
     def normalize(self, data: Dict):
         self.net.normalize(data['z_values'])
+        if self._fused is not None:
+            self._fused.invalidate_records()        # (b, c rescaled in place: the explicit step's kept records are stale)
 
     def _filter_on(self, Ku: int, order) -> Optional[torch.Tensor]:
         """(bands, Ku) sub-band filter responses on the bins the main branch is evaluated on (slot order when the
@@ -540,6 +542,8 @@ class BandBankTrainer:
         """Forward + losses of one band-major batch (rows = data['row_index'], bands x B items);
         stream structure as VarReceiverPosTrainer._step_losses."""
         bank, cfg, nb = self.net, self.config, self.num_bands
+        if normalize_first and self._fused is not None:
+            self._fused.invalidate_records()        # (this path rescales b, c in place too)
         z = data['z_values']
         rows = data['row_index']
         Btot = rows.numel()

@@ -67,6 +67,53 @@ class FusedBankStep:
         self.w_range = opt.flat_range(bank.output_scalars_w)
         if self.w_range[1] != opt.flat_grad.numel():
             raise RuntimeError("the gain network's parameters must close the flat buffers (BandBankTrainer's group order)")
+        self._off = (opt.flat_range(bank.feedback_loop_M)[0], opt.flat_range(bank.input_gains)[0],
+                     opt.flat_range(bank.output_gains)[0])
+        # Q, QQ and the two record sets of the CURRENT parameters (blocks of <= 4 lines): the fused tail of a training step
+        # leaves the next step's here, so that a step does not start with their launch
+        self._rec = None
+        self._rec_valid = False
+        self._rec_versions = None
+
+    # -- records that outlive a step -------------------------------------------------------------------------------------
+    def _records(self):
+        if self._rec is None:
+            bank = self.tr.net
+            nblk, n = bank.num_bands * bank.num_groups, bank.num_delay_lines_per_group
+            dev = bank.input_gains.device
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            self._rec = (mk(nblk, n, n), mk(nblk, n, n), mk(nblk, 32), mk(nblk, 32))
+        return self._rec
+
+    def _versions(self):
+        bank = self.tr.net
+        leaves = [bank.feedback_loop_M, bank.input_gains, bank.output_gains]
+        for net in getattr(bank, 'nets', ()):              # (the bands' own modules hold views of the stacked leaves)
+            leaves.extend(p for name, p in net.named_parameters() if 'output_scalars' not in name)
+        return tuple(p._version for p in leaves)
+
+    def records_ok(self) -> bool:
+        """Whether the kept records belong to the current parameters (host-side bookkeeping: every path of this package that
+        changes M, b, c calls :meth:`invalidate_records` or bumps a tensor version)"""
+        return self._rec_valid and self._rec_versions == self._versions()
+
+    def invalidate_records(self):
+        self._rec_valid = False
+
+    @torch.no_grad()
+    def prime_records(self):
+        """Records of the current parameters into the kept buffers (one launch on the current stream)"""
+        bank = self.tr.net
+        if bank.num_delay_lines_per_group > 4:
+            return
+        ops.tf_ortho_coefs(bank._blocks().detach(), bank.inv_gamma, bank.input_gains.data.view(-1),
+                           bank.output_gains.data.view(-1), out=self._records())
+        self._rec_valid, self._rec_versions = True, self._versions()
+
+    def ensure_records(self):
+        """In front of a graph replay whose capture found valid records (and therefore holds no records launch)"""
+        if self._rec is not None and not self.records_ok():
+            self.prime_records()
 
     # 2: the loss middle as two half-batch chains on two streams.  Measured on the 7-band step: 0.692 vs 0.705 ms
     # (-2 %) for 13 more launches -- the chains run in phase, each kind of unit stays contended -- so it is off.
@@ -116,6 +163,19 @@ class FusedBankStep:
     # scans, which ran beside the STFT and the EDR kernel, now start behind it and run beside the STFT adjoint instead
     # (even-frame launch 50 -> 86 us)
     combine_in_stft = os.environ.get('GFDN_COMBINE_IN_STFT', '0') == '1'      # (OFF: measured slower, see below)
+
+    # Round 5.  (a) The EDC term as ONE register-resident launch per receiver (csrc/edcone.hip: compose, both scans, dB stage,
+    # dL/dx and the EDC part of dL/drgain without staging the window samples or dL/dEDC through memory) and the light gamma
+    # sweep behind it (no dot products left to do) in place of the three scan launches + gfdn_lin_gamma_dots.
+    edc_one_launch = os.environ.get('GFDN_EDC_ONE', '1') == '1'
+    # (b) normalize OFF the critical chain: T is bilinear in b, c and the transform is linear, so the normalisation scale can
+    # join the group signals where the forward transform's LAST pass stores them.  The energy pass then runs on the side
+    # stream beside the group responses and the transform's first two passes instead of in front of them (~28 us of chain).
+    scale_late = os.environ.get('GFDN_SCALE_LATE', '1') == '1'
+    # (c) tail and head as one launch (single process): records -> parameter gradients -> Adam on the blocks' own M, b, c
+    # -> the NEXT step's Q, QQ and record sets (csrc/blocktf.hip k_tf_tail); the gain network's range of the flat buffers is
+    # stepped on the side stream behind its own backward.  A step then starts with the group responses.
+    fused_tail = os.environ.get('GFDN_FUSED_TAIL', '1') == '1'
 
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
     # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
@@ -259,20 +319,29 @@ class FusedBankStep:
             T_edr = ds.edr_target_tiled()
         on_side2 = (lambda: torch.cuda.stream(side2)) if side2 is not None else _null
         ev['x'].record()                                     # (tau complete)
-        Stau = ops.stft_pairs_spectrum(tau, nb * G, win, tiled=tiled)
-        with on_side2():
-            torch.cuda.current_stream().wait_event(ev['x'])
-            li_edc, g_edc = ops.edc_loss_pairs_lin(xd, rows, tau, rgain, nb, K, start, length, T_edc, maskw, inv,
-                                                   cfg.edc_loss_weight, train, trows=rows, item_len=item_len,
-                                                   fill_outside=not self.gamma_dots_one_launch)
-            ev['edc'].record()
-        wait_gains()
-        nch = ops.lin_gamma_dots_tiles(K) if self.gamma_dots_one_launch else ops.lin_gain_chunks(K)
+        edc_one = self._edc_one(length, G)
+        nch = 1 if edc_one else (ops.lin_gamma_dots_tiles(K) if self.gamma_dots_one_launch else ops.lin_gain_chunks(K))
         parts = None
         if train:
+            # partial rows of dL/drgain: [EDC dot products | EDR columns]; the gain network's backward sums them
             parts = torch.empty((Btot * G, nch + ops.edr_lin_parts(win // 2 + 1, fused=self.edr_one_launch,
                                                                    form=self.edr_band_form)),
                                 dtype=torch.float32, device=rows.device)
+        Stau = ops.stft_pairs_spectrum(tau, nb * G, win, tiled=tiled)
+        with on_side2():
+            torch.cuda.current_stream().wait_event(ev['x'])
+            if edc_one:
+                # ONE launch, one workgroup per receiver: loss, dL/dx on the window (plain rows) and the EDC column of
+                # ``parts``
+                li_edc, g_edc = ops.edc_lin_one(xd, rows, tau, rgain, nb, K, start, length, T_edc, maskw, inv,
+                                                cfg.edc_loss_weight, train, trows=rows, item_len=item_len, dots=parts,
+                                                col=0)
+            else:
+                li_edc, g_edc = ops.edc_loss_pairs_lin(xd, rows, tau, rgain, nb, K, start, length, T_edc, maskw, inv,
+                                                       cfg.edc_loss_weight, train, trows=rows, item_len=item_len,
+                                                       fill_outside=not self.gamma_dots_one_launch)
+            ev['edc'].record()
+        wait_gains()
         gP = Gs = None
         if train and self.edr_one_launch:
             li_edr, Gs = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, dots=parts,
@@ -293,6 +362,9 @@ class FusedBankStep:
         gam_edr = ops.stft_pairs_spectrum_bwd(Gs, K, nb * G, win, tiled=tiled, split_parity=one)
         keep.extend((Gs, gam_edr))
         return li_edr, li_edc, (g_edc, gam_edr, parts)
+
+    def _edc_one(self, length: int, G: int) -> bool:
+        return self.edc_one_launch and self.gamma_dots_one_launch and ops.edc_lin_one_supported(length, G)
 
     def _decay_middle_halves(self, H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start, length, ev, main, side,
                              side2):
@@ -380,7 +452,8 @@ class FusedBankStep:
         gridK = FrequencyGrid.of(z)
         order = ops.irfft_slot_order(K, z.device) if (tr.use_slot_order and 'dataset' in data) else None
         Ku = (K + 1) // 2 if K % 2 == 1 else K
-        lin = (self.linear_transforms and pipe is None and self.halves < 2 and G <= 4
+        # (receiver counts beyond what the sums over a band's receivers take fall through to the stored-signal chain)
+        lin = (self.linear_transforms and pipe is None and self.halves < 2 and ops.lin_supported(Btot // nb, G)
                and hasattr(data.get('dataset'), 'direct_time') and not (self.fuse_decay or self.fold_gains))
         if lin:
             zu, direct = (data['dataset'].slot_grid(*order) if order is not None else z[:Ku]), None
@@ -410,7 +483,6 @@ class FusedBankStep:
         # ---- head.  main: records of the raw blocks -> energy pass -> finish (normalize, trainer.py:317-332);
         # side: rotations + records of the damped loop (taken at the gains BEFORE the rescale and scaled afterwards:
         # T is bilinear in b, c, T(b', c') = scale T(b, c)); side2: receiver gains (gain_filters.py:497-536), mask
-        ev['start'].record()
         # (the head is a serial chain on the main stream: forking the rotations off it and joining again costs more
         # than the 10 us they take.  Captured BEFORE the fork below: the graph lays its hardware queues out along a
         # depth-first walk of the nodes in capture order, and the chain captured first keeps its queue through every
@@ -422,16 +494,31 @@ class FusedBankStep:
             raise NotImplementedError("blocks of more than four lines: the explicit step takes grids on the unit circle "
                                       "(set BandBankTrainer.use_fused = False to step this bank through the per-bin "
                                       "elimination kernels under autograd)")
+        use_tail = (self.fused_tail and train and opt_step and allreduce is None and pipe is None and not big
+                    and side2 is not None and self.adam_on_side)
         if big:
             Q, QQ = ops.ortho_fwd(M, True, True)
             coef, coef_sub = ops.tf8_coefs(QQ, ig, b, c, A1=M)
         else:
-            Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
+            # (the fused tail of the previous training step left them; anything else that touched M, b, c since made
+            # the bookkeeping say so)
+            if not self.records_ok():
+                ops.tf_ortho_coefs(M, ig, b, c, out=self._records())
+            Q, QQ, coef, coef_sub = self._records()
+            self._rec_valid = False           # (until this step's end says otherwise)
+        ev['start'].record()                  # (the side stream's energy pass reads the raw blocks' records)
         if pipe is not None and (not train or allreduce is not None or not opt_step or side2 is None):
             raise ValueError("a pipelined step is a single-process training step with its optimiser update")
+        # the normalisation scale joins the group signals behind the transform: energy pass on the side stream
+        late = (self.scale_late and lin and order is not None and normalize_first and not big and side2 is not None)
+        scale = None
         with on_side2():
             if pipe is None or pipe.first:
                 torch.cuda.current_stream().wait_event(ev['start'])
+            if late:
+                _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
+                                         dturn=gridK.dturn)
+                ev['norm'].record()
             if pipe is None:
                 rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
                                                       G, lo, hi, rows, nb)
@@ -445,14 +532,15 @@ class FusedBankStep:
             if mask_draw is not None:
                 mask_draw()
             ev['mask'].record()
-        scale = ework = None
-        if normalize_first:
+        ework = None
+        if normalize_first and not late:
             if big:
                 _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c, dturn=gridK.dturn)
             else:
                 _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                          dturn=gridK.dturn)
-        ev['norm'].record()
+        if not late:
+            ev['norm'].record()
 
         def wait_gains():
             if pipe is None:
@@ -482,11 +570,17 @@ class FusedBankStep:
                 ev_ts.record()
                 Hg = Ts if filt is None else (Ts.view(nb, G, -1) * filt.view(nb, 1, -1)).reshape(nb * G, -1)
             else:
-                Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, scale, None, filt, None, nb,
-                                            save_T=True, want_H=True)
-            tau = ops.irfft_odd_fwd(Hg, K, slots=order is not None, pairs=tau_pairs)
+                Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, None if late else scale, None,
+                                            filt, None, nb, save_T=True, want_H=True)
+            if late:
+                # (the wait sits in front of the LAST pass, the only reader of the scale: by then the side stream's energy
+                # pass is long done and the wait is free)
+                tau = ops.irfft_odd_fwd(Hg, K, slots=True, pairs=True, oscale=scale,
+                                        before_last=lambda: main.wait_event(ev['norm']))
+            else:
+                tau = ops.irfft_odd_fwd(Hg, K, slots=order is not None, pairs=tau_pairs)
             H = Hg
-            spec = (self.spectral_edr and pairs and tau_pairs and win == 4096 and (Btot // nb) % 2 == 0
+            spec = (self.spectral_edr and pairs and tau_pairs and win == 4096 and ops.spec_supported(Btot // nb, G)
                     and hasattr(data['dataset'], 'direct_stft'))
 
             def x_fn():
@@ -582,6 +676,8 @@ class FusedBankStep:
             return s_, ((s_[:, 0] + out3[:, 0]) if nb > 1 else (s_[0] + out3[0]))
 
         if train:
+            if use_tail and not torch.cuda.is_current_stream_capturing():
+                tr.optimizer.sync_lr()            # (both Adam launches of the split update read the device table)
             # ---- backward of the output stage.  Its two passes are independent and both stream dL/dH: the records pass
             # stays on the main stream, the gains pass (-> gain network backward) runs beside it on side2 -- together
             # 50 us instead of 29 + 45 one after the other.  The reported sums go in front of the gains pass (their
@@ -601,8 +697,12 @@ class FusedBankStep:
                         # of dL/drgain
                         _, band_len = tr._item_windows(K, Btot // nb, z.device)
                         ge_a, ge_b = gam_edr if isinstance(gam_edr, tuple) else (gam_edr, None)
-                        gam = ops.lin_gamma_dots(gsig, rgain, nb, K, tau, parts, start, length, base=ge_a,
-                                                 slot_of_time=sot, band_win_len=band_len, base_b=ge_b)
+                        if self._edc_one(length, G):
+                            gam = ops.lin_gamma_win(gsig, rgain, nb, K, start, length, base=ge_a, base_b=ge_b,
+                                                    slot_of_time=sot, band_win_len=band_len)
+                        else:
+                            gam = ops.lin_gamma_dots(gsig, rgain, nb, K, tau, parts, start, length, base=ge_a,
+                                                     slot_of_time=sot, band_win_len=band_len, base_b=ge_b)
                     else:
                         gam = ops.lin_gamma(gsig, rgain, nb, K, True, True, slot_of_time=sot, base=gam_edr)
                     ev_gam = torch.cuda.Event()
@@ -621,7 +721,8 @@ class FusedBankStep:
             if big:
                 grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb)
             else:
-                grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True)
+                grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True,
+                                          tscale=scale if late else None)
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
                 if own_cl:
@@ -675,6 +776,10 @@ class FusedBankStep:
                     pipe.ready_next = torch.cuda.Event()
                     pipe.ready_next.record()
                 else:
+                    if use_tail:
+                        # the gain network's range of the flat buffers, straight behind its gradient on this stream (its
+                        # own step counter: no ordering with the main stream's fused tail)
+                        tr.optimizer.step_range(*self.w_range, second=True)
                     ev['mlpb'].record()
                     if tail is not None:
                         tail()            # (every reader of ``rows`` is ordered before this point: main's are in
@@ -684,6 +789,10 @@ class FusedBankStep:
             if big:
                 ops.tf8_param_grads(QQ, ig, grec, b, c, M, A1=M, part1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
                                     gM=self.g_M)
+            elif use_tail:
+                # ... -> Adam on the blocks' own M, b, c -> the NEXT step's Q, QQ and record sets, in the same launch
+                ops.tf_tail(QQ, ig, grec, grec_sub, b, c, M, gQ, Q, self.g_b, self.g_c, self.g_M.view(-1), tr.optimizer,
+                            *self._off, *self._records())
             else:
                 ops.tf_param_grads(QQ, ig, grec, b, c, M, A1=M, grec1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
                                    gM=self.g_M)
@@ -695,7 +804,12 @@ class FusedBankStep:
                 sums_total = (sums, total)
                 return self._finish_pipe(pipe, sums_total, out3, nb, main, side, side2)
             tr.optimizer._packed = True               # the flat gradient buffer is complete
-            if opt_step and allreduce is None and side2 is not None and self.adam_on_side:
+            if use_tail:
+                # both ranges of the flat buffers are stepped (main: fused tail; side2: the gain network's own launch)
+                tr.optimizer._packed = False
+                torch.autograd.graph.increment_version(tr.optimizer._params)
+                self._rec_valid, self._rec_versions = True, self._versions()
+            elif opt_step and allreduce is None and side2 is not None and self.adam_on_side:
                 # single process: the update runs on the branch that finishes LAST (the gain network's backward), behind
                 # an event of the main stream that was signalled earlier -- a wait on a long-signalled event is free,
                 # while the main stream, idle when the side branch signals, would pay the 8-12 us of a cross-queue wake-up
@@ -727,6 +841,8 @@ class FusedBankStep:
             if s_ is not None:
                 main.wait_stream(s_)
         keep.clear()          # every consumer is ordered before the next step's first launch on each stream
+        if not big and not train and not normalize_first:
+            self._rec_valid, self._rec_versions = True, self._versions()      # (nothing touched M, b, c)
         return losses
 
 

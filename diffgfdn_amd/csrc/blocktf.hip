@@ -135,33 +135,31 @@ __device__ double tf_det(const double* a, const int* ri, const int* ci, int t) {
 }
 
 // sA[0] = A (zero-padded 4 x 4), sA[1] = A - b c^T, sig[i] = 1 / gamma_i, all float64
-// (Ablk: the block's n x n matrix, global or LDS)
-__device__ __forceinline__ void tf_stage_block(const float* Ablk, const float* __restrict__ b,
-                                               const float* __restrict__ c, const float* __restrict__ ig,
-                                               int blk, int n, int tid, double (*sA)[16], double* sig) {
+// (Ablk: the block's n x n matrix; bblk, cblk, igblk: the block's n gains -- global or LDS)
+__device__ __forceinline__ void tf_stage_block(const float* Ablk, const float* bblk, const float* cblk,
+                                               const float* igblk, int n, int tid, double (*sA)[16], double* sig) {
   if (tid < 16) {
     const int i = tid >> 2, j = tid & 3;
     const bool in = i < n && j < n;
     const double a = in ? (double)Ablk[i * n + j] : 0.0;
-    const double bc = in ? (double)b[blk * n + i] * (double)c[blk * n + j] : 0.0;
+    const double bc = in ? (double)bblk[i] * (double)cblk[j] : 0.0;
     sA[0][tid] = a;
     sA[1][tid] = a - bc;
   }
-  if (tid < 4) sig[tid] = (tid < n && ig) ? (double)ig[blk * n + tid] : 1.0;
+  if (tid < 4) sig[tid] = (tid < n && igblk) ? (double)igblk[tid] : 1.0;
 }
 
 // Records of block blk for one or two sets (A1blk = NULL: one) sharing b, c, by threads tid < 64 of a workgroup (every
-// thread must call it: barriers).  A0blk / A1blk: the block's matrices (global or LDS).
+// thread must call it: barriers).  A0blk / A1blk: the block's matrices, bblk / cblk: its gains (global or LDS).
 __device__ __forceinline__ void tf_coefs_block(const float* A0blk, const float* __restrict__ ig0,
                                                float* __restrict__ coef0, const float* A1blk,
                                                const float* __restrict__ ig1, float* __restrict__ coef1,
-                                               const float* __restrict__ b, const float* __restrict__ c, int blk, int n,
-                                               int tid) {
+                                               const float* bblk, const float* cblk, int blk, int n, int tid) {
   __shared__ double sA[2][2][16], sq[2][2][16], sig[2][4];
   const int nsets = A1blk ? 2 : 1;
   if (tid < 64) {
-    tf_stage_block(A0blk, b, c, ig0, blk, n, tid, sA[0], sig[0]);
-    if (nsets == 2) tf_stage_block(A1blk, b, c, ig1, blk, n, tid, sA[1], sig[1]);
+    tf_stage_block(A0blk, bblk, cblk, ig0 ? ig0 + blk * n : nullptr, n, tid, sA[0], sig[0]);
+    if (nsets == 2) tf_stage_block(A1blk, bblk, cblk, ig1 ? ig1 + blk * n : nullptr, n, tid, sA[1], sig[1]);
   }
   __syncthreads();
   if (tid < 32 * nsets) {
@@ -194,8 +192,8 @@ __global__ __launch_bounds__(64) void k_tf_coefs(const float* __restrict__ A0, c
                                                  const float* __restrict__ ig1, float* __restrict__ coef1,
                                                  const float* __restrict__ b, const float* __restrict__ c, int n) {
   const int blk = blockIdx.x;
-  tf_coefs_block(A0 + (size_t)blk * n * n, ig0, coef0, A1 ? A1 + (size_t)blk * n * n : nullptr, ig1, coef1, b, c, blk, n,
-                 threadIdx.x);
+  tf_coefs_block(A0 + (size_t)blk * n * n, ig0, coef0, A1 ? A1 + (size_t)blk * n * n : nullptr, ig1, coef1, b + blk * n,
+                 c + blk * n, blk, n, threadIdx.x);
 }
 
 // Head of the band bank's step in ONE launch, one workgroup per group: Q = expm(skew(M)), QQ = Q Q (k_ortho_fwd), then
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(256) void k_tf_ortho_coefs(const float* __restrict_
     lQQ[e] = v;
   }
   __syncthreads();
-  tf_coefs_block(lQQ, ig0, coef0, coef1 ? Mg : nullptr, nullptr, coef1, b, c, blk, n, threadIdx.x);
+  tf_coefs_block(lQQ, ig0, coef0, coef1 ? Mg : nullptr, nullptr, coef1, b + blk * n, c + blk * n, blk, n, threadIdx.x);
 }
 
 extern "C" int gfdn_tf_coefs_fwd(const float* A, const float* b, const float* c, const float* inv_gamma,
@@ -282,8 +280,11 @@ __device__ __forceinline__ void tf_coefs_bwd_block(const TfBwdSet& s0, const TfB
   __shared__ double sA[2][2][16], sig[2][4], sgq[2][2][16], sgA[2][2][16], spart[4][64];
   const int nsets = s1.A ? 2 : 1;
   if (tid < 64) {
-    tf_stage_block(s0.A + (size_t)blk * n * n, b, c, s0.ig, blk, n, tid, sA[0], sig[0]);
-    if (nsets == 2) tf_stage_block(s1.A + (size_t)blk * n * n, b, c, s1.ig, blk, n, tid, sA[1], sig[1]);
+    tf_stage_block(s0.A + (size_t)blk * n * n, b + blk * n, c + blk * n, s0.ig ? s0.ig + blk * n : nullptr, n, tid, sA[0],
+                   sig[0]);
+    if (nsets == 2)
+      tf_stage_block(s1.A + (size_t)blk * n * n, b + blk * n, c + blk * n, s1.ig ? s1.ig + blk * n : nullptr, n, tid,
+                     sA[1], sig[1]);
   }
   __syncthreads();
   if (tid < 32 * nsets) {
@@ -435,6 +436,134 @@ extern "C" int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, con
   // the barriers of the later stages cost nothing measurable)
   hipLaunchKernelGGL(k_tf_param_grads, dim3(nblk), dim3(256), lds, (hipStream_t)stream, s0, s1, nparts0, b, c, nper, M, gQ,
                      Q, gb, gc, gM);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// The tail of the band bank's step AND the head of the next one in ONE launch (single-process training: nothing sits
+// between the gradients and the update), one workgroup per block (group):
+//   k_tf_param_grads (above) -> Adam on the block's own entries of M, b, c (trainer.py:475; maths of optim.hip's k_adam:
+//   the flat buffers' element i of the three leaves at offM + blk n n + e, offb + blk n + i, offc + blk n + j)
+//   -> k_tf_ortho_coefs on the UPDATED block: Q, QQ and both record sets of the next step.
+// A step then neither starts with the records launch nor ends with the optimiser launch for these leaves: the chain
+// records pass -> [this] -> next step's group responses has one launch where it had three and two stream joins.  The update
+// reads t = step_count + 1; the LAST workgroup to finish writes t back (every workgroup read it before reporting in) and
+// re-arms the counter.  The rest of the flat buffer (the gain network) is stepped by its own launch on its own counter
+// (FlatAdam.step_range(second=True)).  The updated values go to the next records through LDS, not back through memory.
+struct TfAdam {
+  float* p;                    // flat parameters
+  float* m;
+  float* v;
+  const unsigned char* seg;
+  const float* lr_seg;
+  float* step_count;
+  unsigned int* block_counter;
+  int offM, offb, offc;
+  float b1, b2, eps;
+};
+
+__device__ __forceinline__ float tf_adam_elem(const TfAdam& ad, int i, float gi, float bc1, float bc2_sqrt) {
+  const float mi = ad.m[i] + (gi - ad.m[i]) * (1.0f - ad.b1);
+  const float vi = ad.v[i] * ad.b2 + gi * gi * (1.0f - ad.b2);
+  ad.m[i] = mi;
+  ad.v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
+  const float pn = ad.p[i] - (ad.lr_seg[ad.seg[i]] / bc1) * (mi / denom);
+  ad.p[i] = pn;
+  return pn;
+}
+
+__global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int nparts0, const float* b, const float* c,
+                                                 int n, const float* M, const float* gQ, const float* Q, float* gb,
+                                                 float* gc, float* gM, TfAdam ad, float* Qn, float* QQn, float* coef0,
+                                                 float* coef1) {
+  extern __shared__ double tfp_lds[];
+  __shared__ float srec[TF_REC], sG[2][16], sM[16], sb[4], sc[4], lQQ[16];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const float t = ad.step_count[0] + 1.0f;
+  if (nparts0 > 1) {
+    const int lane = tid & 63, nw = blockDim.x >> 6;
+    for (int r = tid >> 6; r < TF_REC; r += nw) {
+      const float* row = s0.grec + ((size_t)blk * TF_REC + r) * nparts0;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int p = lane;
+      for (; p + 192 < nparts0; p += 256) {
+        a0 += row[p];
+        a1 += row[p + 64];
+        a2 += row[p + 128];
+        a3 += row[p + 192];
+      }
+      for (; p < nparts0; p += 64) a0 += row[p];
+      const float sum = wave_sum((a0 + a1) + (a2 + a3));
+      if (lane == 0) srec[r] = sum;
+    }
+  } else if (tid < TF_REC) {
+    srec[tid] = s0.grec[(size_t)blk * TF_REC + tid];
+  }
+  __syncthreads();
+  tf_coefs_bwd_block(s0, s1, srec, s1.grec ? s1.grec + (size_t)blk * TF_REC : nullptr, b, c, n, blk, tid, gb, gc, sG[0],
+                     sG[1]);
+  __syncthreads();
+  const size_t off = (size_t)blk * n * n;
+  ortho_bwd_group(tfp_lds, M + off, n, gQ ? gQ + off : nullptr, sG[0], Q ? Q + off : nullptr, s1.A ? sG[1] : nullptr,
+                  gM + off);
+  // ---- Adam on the block's own entries: every element is updated by the thread that wrote its gradient
+  // (tf_coefs_bwd_block: dL/db[i] by thread 32 + i, dL/dc[j] by thread 48 + j; ortho_bwd_group: dL/dM[e] by thread e)
+  const float bc1 = 1.0f - powf(ad.b1, t), bc2_sqrt = sqrtf(1.0f - powf(ad.b2, t));
+  if (tid < n * n) sM[tid] = tf_adam_elem(ad, ad.offM + (int)off + tid, gM[off + tid], bc1, bc2_sqrt);
+  if (tid >= 32 && tid < 32 + n) sb[tid - 32] = tf_adam_elem(ad, ad.offb + blk * n + tid - 32, gb[blk * n + tid - 32], bc1, bc2_sqrt);
+  if (tid >= 48 && tid < 48 + n) sc[tid - 48] = tf_adam_elem(ad, ad.offc + blk * n + tid - 48, gc[blk * n + tid - 48], bc1, bc2_sqrt);
+  __syncthreads();
+  // ---- the next step's head on the updated block (k_tf_ortho_coefs)
+  {
+    double* A = tfp_lds;
+    double* P = A + n * n;
+    double* R = P + n * n;
+    double* T = R + n * n;
+    double* tmp = T + n * n;
+    for (int e = tid; e < n * n; e += blockDim.x) A[e] = skew_elem(sM, n, e / n, e % n);
+    __syncthreads();
+    const double* E = expm_lds(A, P, R, T, tmp, n);
+    for (int e = tid; e < n * n; e += blockDim.x) {
+      Qn[off + e] = (float)E[e];
+      const int i = e / n, j = e - i * n;
+      double acc = 0.0;
+      for (int q = 0; q < n; ++q) acc += E[i * n + q] * E[q * n + j];
+      const float v = (float)acc;
+      QQn[off + e] = v;
+      lQQ[e] = v;
+    }
+    __syncthreads();
+    tf_coefs_block(lQQ, s0.ig, coef0, sM, nullptr, coef1, sb, sc, blk, n, tid);
+  }
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(ad.block_counter, 1u) == gridDim.x - 1) {
+      ad.step_count[0] = t;
+      ad.block_counter[0] = 0u;
+    }
+  }
+}
+
+extern "C" int gfdn_tf_tail(const float* A0, const float* inv_gamma0, const float* grec0, int nparts0, const float* A1,
+                            const float* grec1, const float* b, const float* c, int nblk, int nper, const float* M,
+                            const float* gQ, const float* Q, float* gb, float* gc, float* gM, float* flat_p, float* flat_m,
+                            float* flat_v, const unsigned char* seg, const float* lr_seg, float* step_count,
+                            unsigned int* block_counter, int offM, int offb, int offc, float beta1, float beta2, float eps,
+                            float* Q_next, float* QQ_next, float* coef_next, float* coef_sub_next, void* stream) {
+  if (!A0 || !grec0 || !A1 || !grec1 || !b || !c || !M || !gM || !gb || !gc || !flat_p || !flat_m || !flat_v || !seg ||
+      !lr_seg || !step_count || !block_counter || !Q_next || !QQ_next || !coef_next || !coef_sub_next || nblk <= 0 ||
+      nper <= 0 || nparts0 <= 0 || offM < 0 || offb < 0 || offc < 0)
+    return GFDN_E_BADARG;
+  if (nper > 4) return GFDN_E_UNSUPPORTED;
+  TfBwdSet s0{A0, inv_gamma0, grec0, nullptr};
+  TfBwdSet s1{A1, nullptr, grec1, nullptr};
+  TfAdam ad{flat_p, flat_m, flat_v, seg, lr_seg, step_count, block_counter, offM, offb, offc, beta1, beta2, eps};
+  size_t lds = ortho_bwd_lds_doubles(nper);
+  const size_t lds_head = (size_t)4 * nper * nper + nper + 2;
+  if (lds_head > lds) lds = lds_head;
+  hipLaunchKernelGGL(k_tf_tail, dim3(nblk), dim3(256), lds * sizeof(double), (hipStream_t)stream, s0, s1, nparts0, b, c, nper,
+                     M, gQ, Q, gb, gc, gM, ad, Q_next, QQ_next, coef_next, coef_sub_next);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -977,6 +1106,9 @@ __global__ __launch_bounds__(256) void k_tf_compose_bwd_rec(TfCompose a, const f
   float aP[16], aQ[16];
 #pragma unroll
   for (int S = 0; S < 16; ++S) aP[S] = aQ[S] = 0.f;
+  // (a.scale: Tsave holds the UNSCALED functions -- the step's normalisation scale joined the group signals behind the
+  // transform -- and T' = scale T is formed here)
+  const float tsc = a.scale ? a.scale[band * G + w] : 1.0f;
   const int ntiles = (a.K + TFB_T - 1) / TFB_T;
   for (int tile = blockIdx.x; tile < ntiles; tile += nparts) {
     const int k = tile * TFB_T + lane;
@@ -1005,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_tf_compose_bwd_rec(TfCompose a, const f
       den.y += Q[S] * e[S].y;
     }
     const float2 u = cmulc(acc, cinv(den));             // dL/dT' conj(1 / Den)
-    const float2 v = cmulc(u, Tp[kk]);
+    const float2 v = cmulc(u, a.scale ? cscale(Tp[kk], tsc) : Tp[kk]);
     aP[0] += u.x;
     aQ[0] -= v.x;
 #pragma unroll
@@ -1068,13 +1200,13 @@ extern "C" int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* T
 extern "C" int gfdn_tf_gain_chunks(int K) { return K > 0 ? tf_gain_chunks_host(K) : 0; }
 
 extern "C" int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
-                                   const float* coef, const float* delays, const float* Tsave,
+                                   const float* coef, const float* delays, const float* Tsave, const float* tscale,
                                    const float* rgain, int B, const float* filt, int ldf, const float* gH,
                                    int ldh, float* grec, void* work, void* stream) {
   int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
   if (rc) return rc;
   if (!Tsave || !gH || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
-  TfCompose a{turns, logr, K, G, nper, B, coef, delays, nullptr, rgain, (const float2*)filt, ldf};
+  TfCompose a{turns, logr, K, G, nper, B, coef, delays, tscale, rgain, (const float2*)filt, ldf};
   const int nparts = tf_compose_parts_host(K);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_tf_compose_bwd_rec, dim3(nparts, nbands), dim3(256), 0, s, a, (const float2*)Tsave,

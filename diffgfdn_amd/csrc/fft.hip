@@ -378,6 +378,8 @@ struct BluArgs {
   float2* work;         // batch * L
   int adjoint;          // 0: X -> x ; 1: gx -> gX
   const float* in2;     // adjoint only: optional second real input, summed in on load (in + in2)
+  const float* in3;     // pair adjoint in slot order only: a third input, summed in on load
+  const float* oscale;  // pair forward only: per-item factors on the time signals (NULL: 1)
   // forward: in = X (complex, ld_in), out = x (real, ld_out); adjoint: in = gx (real), out = gX (complex)
   const void* in;
   int ld_in;
@@ -843,12 +845,14 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
     // adjoint: the pair-interleaved real gradients ARE the complex input G1 + i G2
     const float2* G = (const float2*)a.in + (size_t)b * a.ld_in;
     const float2* G2 = a.in2 ? (const float2*)a.in2 + (size_t)b * a.ld_in : nullptr;
+    const float2* G3 = a.in3 ? (const float2*)a.in3 + (size_t)b * a.ld_in : nullptr;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int sidx = (l + 8 * k) * L2 + c0 + c;
       const int src = a.tslots ? 1 + sidx : a.iperm[sidx];
       float2 gv = G[src];
       if (G2) { const float2 g2 = G2[src]; gv.x += g2.x; gv.y += g2.y; }
+      if (G3) { const float2 g3 = G3[src]; gv.x += g3.x; gv.y += g3.y; }
       v[k] = gv;
       edge += gv.x;
       edge2 += gv.y;
@@ -925,18 +929,22 @@ __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
       const float x01 = a.cmp.T ? a.cmp.h0[b1] : X[(size_t)b1 * a.ld_in].x;
       const float x02 = two ? (a.cmp.T ? a.cmp.h0[b1 + 1] : X[(size_t)(b1 + 1) * a.ld_in].x) : 0.f;
       float2* xo = (float2*)a.out + (size_t)b * a.ld_out;
+      // (per-item factors: the band bank's normalisation scale joins its group signals here, off the chain that produced
+      // the spectra -- bankstep.py)
+      const float n1s = a.oscale ? invn * a.oscale[b1] : invn, n2s = (a.oscale && two) ? invn * a.oscale[b1 + 1] : invn;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n1 = l + 8 * (q >> 3) + 16 * (q & 7);
-        xo[a.iperm[n1 * L2 + c0 + c]] = make_float2((x01 + v[q].x * invL) * invn, (x02 + v[q].y * invL) * invn);
+        xo[a.iperm[n1 * L2 + c0 + c]] = make_float2((x01 + v[q].x * invL) * n1s, (x02 + v[q].y * invL) * n2s);
       }
-      if (folder) xo[0] = make_float2((x01 + 2.0f * sum1) * invn, (x02 + 2.0f * sum2) * invn);
+      if (folder) xo[0] = make_float2((x01 + 2.0f * sum1) * n1s, (x02 + 2.0f * sum2) * n2s);
     } else {
       // W = W1 + i W2 with W_j[s + L/2] = conj(W_j[s]) (real inputs, kernel symmetry): the two gradients
       // separate from the slot pair (s, s + L/2) = rows (n1, n1 + 64), held by this lane (q, q ^ 4)
       const float2* G = (const float2*)a.in + (size_t)b * a.ld_in;
       float2 g0 = G[0];
       if (a.in2) { const float2 t2 = ((const float2*)a.in2 + (size_t)b * a.ld_in)[0]; g0.x += t2.x; g0.y += t2.y; }
+      if (a.in3) { const float2 t3 = ((const float2*)a.in3 + (size_t)b * a.ld_in)[0]; g0.x += t3.x; g0.y += t3.y; }
       const float sc = 2.0f * invL * invn;
       float2* o1 = (float2*)a.out + (size_t)b1 * a.ld_out;
       float2* o2 = o1 + a.ld_out;
@@ -1056,7 +1064,8 @@ static bool slot_order_ok(int n) {
 
 static int blu_run(const void* table, int n, const void* in, int ld_in, int batch, void* out,
                    int ld_out, void* work, int adjoint, hipStream_t s, int stages = 7,
-                   const float* in2 = nullptr, int slot = 0, const BluCompose* cmp = nullptr, int tslots = 0) {
+                   const float* in2 = nullptr, int slot = 0, const BluCompose* cmp = nullptr, int tslots = 0,
+                   const float* in3 = nullptr, const float* oscale = nullptr) {
   if (!table || !in || !out || !work) return GFDN_E_BADARG;
   if (n < 3 || (n & 1) == 0 || batch <= 0) return GFDN_E_BADARG;
   const bool rader = rader_ok(n);
@@ -1088,12 +1097,15 @@ static int blu_run(const void* table, int n, const void* in, int ld_in, int batc
   a.slot = slot ? 1 : 0;
   a.pair = slot == 2 ? 1 : 0;
   a.tslots = tslots ? 1 : 0;
-  if (tslots && !(slot == 2 && adjoint && !in2)) return GFDN_E_BADARG;
+  if (tslots && !(slot == 2 && adjoint)) return GFDN_E_BADARG;
+  if ((in3 && !(tslots && in2)) || (oscale && !(slot == 2 && !adjoint))) return GFDN_E_BADARG;
   if (slot && !slot_order_ok(n)) return GFDN_E_UNSUPPORTED;
   if (a.pair) a.batch = (batch + 1) / 2;          // work blocks = item pairs
   a.adjoint = adjoint;
   a.in = in;
   a.in2 = adjoint ? in2 : nullptr;
+  a.in3 = adjoint ? in3 : nullptr;
+  a.oscale = oscale;
   a.ld_in = ld_in;
   a.out = out;
   a.ld_out = ld_out;
@@ -1182,6 +1194,16 @@ extern "C" int gfdn_irfft_odd_pairs_fwd(const void* table, int n, const float* X
                                         float* x2, int ldo, void* work, void* stream) {
   return blu_run(table, n, Xs, ldx, batch, x2, ldo, work, 0, (hipStream_t)stream, 7, nullptr, 2);
 }
+// ... with per-item factors on the time signals (oscale: batch floats; the factor of a signal multiplies all its samples)
+// stages: 7 = the whole transform; 3 = the first two passes, 4 = the last one (the only one that reads oscale: a caller whose
+// factors come from another stream waits for them between the two calls)
+extern "C" int gfdn_irfft_odd_pairs_fwd_scaled(const void* table, int n, const float* Xs, int ldx, int batch,
+                                               const float* oscale, float* x2, int ldo, void* work, int stages,
+                                               void* stream) {
+  if (!(stages & 7)) return GFDN_E_BADARG;
+  return blu_run(table, n, Xs, ldx, batch, x2, ldo, work, 0, (hipStream_t)stream, stages & 7, nullptr, 2, nullptr, 0, nullptr,
+                 oscale);
+}
 // The paired forward transform with the output stage of the block-transfer-function step folded into its first pass:
 // x2 = irfft_n(H) for H[b][k] = (sum_g rgain[b][g] T[band * G + g][k] + direct[rows[b]][k]) * filt[band][k], items
 // band-major (batch = nbands * Bper), every array slot-ordered with column 0 = bin 0; H itself is never stored.
@@ -1213,6 +1235,13 @@ extern "C" int gfdn_irfft_odd_pairs_bwd(const void* table, int n, const float* g
 extern "C" int gfdn_irfft_odd_pairs_bwd_tslots(const void* table, int n, const float* gx2s, int ldo, int batch, float* gXs,
                                                int ldx, void* work, void* stream) {
   return blu_run(table, n, gx2s, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, nullptr, 2, nullptr, 1);
+}
+// ... as the SUM of up to three slot-ordered inputs (b, c optional; c only with b), added where the first pass loads them:
+// parts of one gradient signal that were produced by different launches need no merge pass in front of the transform
+extern "C" int gfdn_irfft_odd_pairs_bwd_tslots3(const void* table, int n, const float* gx2s_a, const float* gx2s_b,
+                                                const float* gx2s_c, int ldo, int batch, float* gXs, int ldx, void* work,
+                                                void* stream) {
+  return blu_run(table, n, gx2s_a, ldo, batch, gXs, ldx, work, 1, (hipStream_t)stream, 7, gx2s_b, 2, nullptr, 1, gx2s_c);
 }
 // time index of convolution slot s (s < n - 1): times[s] = g^-s mod n, the table the pair transforms scatter / gather by
 extern "C" int gfdn_irfft_odd_time_slots(int n, int* times) {

@@ -690,11 +690,14 @@ def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, wor
 
 
 def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=None, nbands: int = 1, work=None,
-                   partial: bool = False):
+                   partial: bool = False, tscale=None):
     """-> grec (nbands*G, 32): gradient records of the scaled records; ``Tsave``: the forward's saved group transfer
     functions (tf_compose_fwd(save_T=True)).  ``partial``: skip the sum over the workgroups' partial rows and return
-    them (nbands*G, 32, parts) for ``tf_param_grads``, which sums them itself."""
+    them (nbands*G, 32, parts) for ``tf_param_grads``, which sums them itself.  ``tscale`` (nbands*G,): ``Tsave`` holds the
+    UNSCALED functions and T' = tscale T is formed where they are read."""
     _need_gpu(turns, coef, rgain, gH, Tsave)
+    if tscale is not None and (tscale.dtype != _f32 or not tscale.is_contiguous() or tscale.numel() != coef.shape[0]):
+        raise RuntimeError("tf_compose_bwd: tscale must be a contiguous float32 vector with one factor per block")
     coef, delays, rgain, gH, Tsave = _f(coef), _f(delays), _f(rgain), _c(gH), _c(Tsave)
     K = turns.numel()
     Btot, G = rgain.shape
@@ -711,7 +714,7 @@ def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=
         if work is None:
             work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G), coef.device)
     _lib.check(lib.gfdn_tf_compose_bwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays), _p(Tsave),
-                                       _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(work),
+                                       _p(tscale), _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(work),
                                        _stream()), "gfdn_tf_compose_bwd")
     return work if partial else grec
 
@@ -743,16 +746,49 @@ def tf_param_grads(A0, ig0, grec0, b, c, M, A1=None, ig1=None, grec1=None, gQ=No
     return gM, gb, gc
 
 
-def tf_ortho_coefs(M, ig, b, c, sub: bool = True):
+def tf_tail(QQ, ig, grec0, grec1, b, c, M, gQ, Q, gb, gc, gM, opt, offM: int, offb: int, offc: int, Q_next, QQ_next,
+            coef_next, coef_sub_next):
+    """tf_param_grads + Adam on the blocks' own entries of M, b, c + tf_ortho_coefs of the updated blocks in ONE launch
+    (csrc/blocktf.hip k_tf_tail).  ``grec0`` (nblk, 32, parts) partial rows of the records pass, ``grec1`` (nblk, 32) the
+    raw blocks' summed records; ``b``, ``c``, ``M``: the flat parameter buffer's views of the leaves (updated in place);
+    ``opt``: the FlatAdam whose buffers hold them at the element offsets ``offM`` / ``offb`` / ``offc``; the ``*_next``
+    arrays receive the next step's Q, QQ and record sets (they may be the arrays this step read)."""
+    _need_gpu(QQ, grec0, b, c, M)
+    nblk, n, _ = QQ.shape
+    nparts0 = 1 if grec0.dim() == 2 else grec0.shape[2]
+    ig = None if ig is None else _f(ig).reshape(-1)
+    for t in (QQ, grec0, grec1, b, c, M, gQ, Q, gb, gc, gM, Q_next, QQ_next, coef_next, coef_sub_next):
+        if t is not None and (t.dtype != _f32 or not t.is_contiguous()):
+            raise RuntimeError("tf_tail: contiguous float32 tensors expected")
+    if tuple(grec0.shape[:2]) != (nblk, 32) or tuple(grec1.shape) != (nblk, 32) or M.numel() != nblk * n * n \
+            or b.numel() != nblk * n or c.numel() != nblk * n:
+        raise RuntimeError("tf_tail: records must be (nblk, 32[, parts]), M (nblk, n, n), b / c (nblk n)")
+    fp = opt.flat_param
+    for off, t in ((offM, M), (offb, b), (offc, c)):
+        if fp.data_ptr() + 4 * off != t.data_ptr():
+            raise RuntimeError("tf_tail: the leaves must be the flat buffer's views at the stated offsets")
+    b1, b2 = opt.defaults['betas']
+    _lib.check(_lib.load().gfdn_tf_tail(_p(QQ), _p(ig), _p(grec0), nparts0, _p(M), _p(grec1), _p(b), _p(c), nblk, n, _p(M),
+                                        _p(gQ), _p(Q), _p(gb), _p(gc), _p(gM), _p(fp), _p(opt.exp_avg), _p(opt.exp_avg_sq),
+                                        _p(opt.seg), _p(opt.lr_seg), _p(opt.step_count), _p(opt._block_counter), int(offM),
+                                        int(offb), int(offc), float(b1), float(b2), float(opt.defaults['eps']),
+                                        _p(Q_next), _p(QQ_next), _p(coef_next), _p(coef_sub_next), _stream()),
+               "gfdn_tf_tail")
+
+
+def tf_ortho_coefs(M, ig, b, c, sub: bool = True, out=None):
     """Head of the block-transfer-function step in one launch: (Q, QQ, coef of (QQ, 1 / gamma), coef_sub of (M, 1) or
-    None) -- ``ortho_fwd`` + ``tf_coefs2`` with the same numbers."""
+    None) -- ``ortho_fwd`` + ``tf_coefs2`` with the same numbers.  ``out`` = (Q, QQ, coef, coef_sub): where to write them."""
     _need_gpu(M, b, c)
     M, b, c = _f(M), _f(b).reshape(-1), _f(c).reshape(-1)
     nblk, n, _ = M.shape
     ig = None if ig is None else _f(ig).reshape(-1)
-    Q, QQ = torch.empty_like(M), torch.empty_like(M)
-    coef = torch.empty((nblk, 32), dtype=_f32, device=M.device)
-    coef_sub = torch.empty((nblk, 32), dtype=_f32, device=M.device) if sub else None
+    if out is not None:
+        Q, QQ, coef, coef_sub = out
+    else:
+        Q, QQ = torch.empty_like(M), torch.empty_like(M)
+        coef = torch.empty((nblk, 32), dtype=_f32, device=M.device)
+        coef_sub = torch.empty((nblk, 32), dtype=_f32, device=M.device) if sub else None
     _lib.check(_lib.load().gfdn_tf_ortho_coefs(_p(M), _p(ig), _p(b), _p(c), nblk, n, _p(Q), _p(QQ), _p(coef),
                                                _p(coef_sub), _stream()), "gfdn_tf_ortho_coefs")
     return Q, QQ, coef, coef_sub
@@ -952,12 +988,16 @@ def irfft_slot_order(n: int, device):
     return _slot_orders[key]
 
 
-def irfft_odd_fwd(X, n: int, slots: bool = False, pairs: bool = False) -> torch.Tensor:
+def irfft_odd_fwd(X, n: int, slots: bool = False, pairs: bool = False, oscale=None, before_last=None) -> torch.Tensor:
     """X (batch, >= (n+1)/2) c64 -> x (batch, n) float32 = torch.fft.irfft(X, n), n odd.
     ``slots``: X is in slot order (irfft_slot_order): X[:, 0] = bin 0, X[:, 1 + s] = slot s.
     ``pairs`` (with slots): two items per transform; returns x2 (ceil(batch / 2), n, 2) float32, item 2p in
-    [..., 0], item 2p + 1 in [..., 1] (zeros for the missing partner of an odd batch)."""
+    [..., 0], item 2p + 1 in [..., 1] (zeros for the missing partner of an odd batch).
+    ``oscale`` (pairs only; (batch,) float32): x[item] = oscale[item] * irfft(X[item]), applied where the last pass stores;
+    ``before_last``: callable run between the second and the last pass (e.g. the wait for the stream that produces oscale)."""
     _need_gpu(X)
+    if oscale is not None and not pairs:
+        raise RuntimeError("irfft_odd_fwd: oscale goes with pairs=True")
     if pairs:
         if not slots:
             raise RuntimeError("irfft_odd_fwd(pairs=True) takes slot-ordered spectra")
@@ -967,6 +1007,17 @@ def irfft_odd_fwd(X, n: int, slots: bool = False, pairs: bool = False) -> torch.
         table = bluestein_table(n, X.device)
         x2 = torch.empty(((batch + 1) // 2, n, 2), dtype=_f32, device=X.device)
         work = _work(lib.gfdn_bluestein_work_bytes(n, batch), X.device)
+        if oscale is not None:
+            if oscale.dtype != _f32 or not oscale.is_contiguous() or oscale.numel() != batch:
+                raise RuntimeError("irfft_odd_fwd: oscale must be a contiguous float32 vector with one factor per item")
+            args = (_p(table), n, _p(X), ldx, batch, _p(oscale), _p(x2), n, _p(work))
+            if before_last is None:
+                _lib.check(lib.gfdn_irfft_odd_pairs_fwd_scaled(*args, 7, _stream()), "gfdn_irfft_odd_pairs_fwd_scaled")
+            else:
+                _lib.check(lib.gfdn_irfft_odd_pairs_fwd_scaled(*args, 3, _stream()), "gfdn_irfft_odd_pairs_fwd_scaled")
+                before_last()
+                _lib.check(lib.gfdn_irfft_odd_pairs_fwd_scaled(*args, 4, _stream()), "gfdn_irfft_odd_pairs_fwd_scaled")
+            return x2
         if kernel_timer.active and kernel_timer.watch in _BLU_STAGES:
             _staged_bluestein(lib, table, n, X, None, ldx, batch, x2, n, work, 0, 2)
             return x2
@@ -1118,6 +1169,18 @@ def lin_gain_dots(gx, tau, nbands: int, items: int, G: int, n: int, in_pairs: bo
     _lib.check(lib.gfdn_lin_gain_dots(_p(gx), _p(gxb), n, int(in_pairs), _p(tau), n, int(tau_pairs), nbands,
                                       items // nbands, G, n, _p(parts), parts.shape[1], _stream()), "gfdn_lin_gain_dots")
     return parts
+
+
+def lin_supported(B: int, G: int) -> bool:
+    """Receivers per band x groups the time-domain output stage's sums take (gfdn_lin_gamma*: the band's gains sit in a
+    256-entry LDS table)."""
+    return 0 < G <= 4 and 0 < B and B * G <= 256
+
+
+def spec_supported(B: int, G: int) -> bool:
+    """... and the EDR loss on composed spectra with the receiver sums (gfdn_edr_lin_*, gfdn_lin_gamma_dots): whole receiver
+    pairs, at most 64 receivers per band."""
+    return lin_supported(B, G) and B % 2 == 0 and B <= 64
 
 
 def lin_gamma_dots_tiles(n: int) -> int:
@@ -1337,6 +1400,73 @@ def edc_loss_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, start: int, l
     return loss_item, g2
 
 
+def edc_lin_one_supported(length: int, G: int) -> bool:
+    """Whether edc_lin_one takes a window of ``length`` samples and G groups per band."""
+    return 0 < length <= _lib.load().gfdn_edc_lin_one_max_len() and 0 < G <= 4
+
+
+def edc_lin_one(xd, rows, tau2, rgain, nbands: int, n: int, start: int, length: int, T_db, maskw=None,
+                inv_count: float = 1.0, gscale: float = 1.0, want_grad: bool = True, trows=None, item_len=None,
+                dots=None, col: int = 0):
+    """The EDC term on x[b] = xd[rows[b]] + sum_g rgain[b][g] tau[band G + g] in ONE launch, one workgroup per item
+    (csrc/edcone.hip) -> (loss_item (items,), gx (items, length) or None): gx[b][j] = dL/dx[b][start + j] on the item's
+    window (columns behind a shorter per-item window are not written).  ``dots`` (items * G, cols) float32: column ``col``
+    receives the EDC part of dL/drgain, <dL/dx[b], tau_g>."""
+    _need_gpu(xd, tau2, rgain, T_db)
+    xd, tau2, rgain = _f(xd), _f(tau2), _f(rgain)
+    items, G = rgain.shape
+    S = nbands * G
+    if items % nbands or xd.shape[1] < n or tuple(tau2.shape) != ((S + 1) // 2, n, 2):
+        raise RuntimeError("edc_lin_one: rgain (nbands * B, G), xd (R, >= n), tau2 (ceil(nbands G / 2), n, 2)")
+    rows = _rows(rows, items, xd.shape[0])
+    trows = _rows(trows, items, T_db.shape[0])
+    if T_db.dtype != _f32 or not T_db.is_contiguous() or (item_len is None and T_db.shape[-1] != length) \
+            or (trows is None and T_db.shape[0] != items) or start + length > n:
+        raise RuntimeError("edc_lin_one: target shape does not match the window")
+    maskw = None if maskw is None else _f(maskw)
+    ld_mask = 0
+    B = items // nbands
+    if item_len is not None:
+        _, ld_mask = _edc_bands(item_len, items, B, maskw, length, T_db, "edc_lin_one")
+    elif maskw is not None and maskw.numel() < length:
+        raise RuntimeError("edc_lin_one: mask weights shorter than the window")
+    if dots is not None and (dots.dtype != _f32 or not dots.is_contiguous() or dots.dim() != 2
+                             or dots.shape[0] != items * G or not 0 <= col < dots.shape[1]):
+        raise RuntimeError("edc_lin_one: dots must be a contiguous float32 (items * G, cols) tensor, col inside it")
+    loss_item = torch.empty(items, dtype=_f32, device=xd.device)
+    gx = torch.empty((items, length), dtype=_f32, device=xd.device) if want_grad else None
+    _lib.check(_lib.load().gfdn_edc_lin_one(_p(xd), xd.stride(0), _p(rows), _p(tau2), n, _p(rgain), nbands, B, G, int(start),
+                                            int(length), _p(item_len), _p(T_db), T_db.shape[-1], _p(trows), _p(maskw),
+                                            ld_mask, float(inv_count), float(gscale), _p(loss_item), _p(gx), int(length),
+                                            _p(dots if want_grad else None), 0 if dots is None else dots.shape[1], int(col),
+                                            _stream()), "gfdn_edc_lin_one")
+    return loss_item, gx
+
+
+def lin_gamma_win(gx, rgain, nbands: int, n: int, win_start: int, win_len: int, base=None, base_b=None,
+                  slot_of_time=None, band_win_len=None) -> torch.Tensor:
+    """gamma (ceil(nbands G / 2), n, 2) = [base + base_b +] sum_b rgain[b][g] gx[b] with gx (items, >= win_len) the
+    window-only rows of edc_lin_one (sample win_start + j at column j); ``slot_of_time``: written in the adjoint pair
+    transform's slot order (irfft_odd_pairs_bwd(tslots=True))."""
+    _need_gpu(gx, rgain)
+    rgain = _f(rgain)
+    items, G = rgain.shape
+    S = nbands * G
+    if gx.dtype != _f32 or not gx.is_contiguous() or gx.dim() != 2 or gx.shape[0] != items or gx.shape[1] < win_len \
+            or items % nbands:
+        raise RuntimeError("lin_gamma_win: gx must be a contiguous float32 (items, >= win_len) tensor")
+    gamma = torch.empty(((S + 1) // 2, n, 2), dtype=_f32, device=gx.device)
+    if S % 2:
+        gamma[-1].zero_()
+    for bb in (base, base_b):
+        if bb is not None and (bb.dtype != _f32 or not bb.is_contiguous() or bb.shape != gamma.shape):
+            raise RuntimeError("lin_gamma_win: base / base_b must be shaped like gamma")
+    _lib.check(_lib.load().gfdn_lin_gamma_win(_p(gx), gx.shape[1], _p(rgain), nbands, items // nbands, G, n, int(win_start),
+                                              int(win_len), _p(band_win_len), _p(base), _p(base_b), n, _p(slot_of_time),
+                                              _p(gamma), n, _stream()), "gfdn_lin_gamma_win")
+    return gamma
+
+
 def stft_power_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, win: int):
     """lin_combine_fwd(..., tau_pairs=True, out_pairs=True) folded into the load of stft_power_pairs: returns (x2
     (ceil(items / 2), n, 2), P (items, nframes, win / 2 + 1)) in ONE launch (win = 4096)."""
@@ -1368,14 +1498,14 @@ def tf_rows_sum(part: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None, tslots: bool = False):
+def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None, tslots: bool = False, g2c=None):
     """Adjoint of irfft_odd_fwd(slots=True, pairs=True): g2 (ceil(batch / 2), n, 2) f32 pair-interleaved gradients
     [+ g2b, summed on load] -> gX (batch, (n + 1) / 2) c64 in slot order (``out``: where to write it).
     ``gains`` = (Tquad (nbands, (n+1)/2, 4), filt (nbands, (n+1)/2) or None, nbands, G): the gains pass of the output
     stage's adjoint rides the last pass -- returns (gX, gpart (batch, G, parts)); tf_rows_sum(gpart) = dL/drgain."""
     _need_gpu(g2)
     npairs = (batch + 1) // 2
-    for t in (g2, g2b):
+    for t in (g2, g2b, g2c):
         if t is not None and (t.dtype != _f32 or not t.is_contiguous() or tuple(t.shape) != (npairs, n, 2)):
             raise RuntimeError("irfft_odd_pairs_bwd: pair-interleaved float32 gradients (pairs, n, 2) expected")
     lib = _lib.load()
@@ -1386,11 +1516,17 @@ def irfft_odd_pairs_bwd(g2, n: int, batch: int, g2b=None, out=None, gains=None, 
     gX = torch.empty((batch, ldx), dtype=_c64, device=g2.device) if out is None else out
     work = _work(lib.gfdn_bluestein_work_bytes(n, batch), g2.device)
     if tslots:                             # (g2 in the transform's own order: lin_gamma(slot_of_time=...))
-        if g2b is not None or gains is not None:
-            raise RuntimeError("irfft_odd_pairs_bwd(tslots=True) takes one gradient signal")
+        if gains is not None or (g2c is not None and g2b is None):
+            raise RuntimeError("irfft_odd_pairs_bwd(tslots=True) takes up to three gradient signals (g2, g2b, g2c)")
+        if g2b is not None:                # (parts of one gradient signal, all slot-ordered: summed where they are loaded)
+            _lib.check(lib.gfdn_irfft_odd_pairs_bwd_tslots3(_p(table), n, _p(g2), _p(g2b), _p(g2c), n, batch, _p(gX), ldx,
+                                                            _p(work), _stream()), "gfdn_irfft_odd_pairs_bwd_tslots3")
+            return gX
         _lib.check(lib.gfdn_irfft_odd_pairs_bwd_tslots(_p(table), n, _p(g2), n, batch, _p(gX), ldx, _p(work), _stream()),
                    "gfdn_irfft_odd_pairs_bwd_tslots")
         return gX
+    if g2c is not None:
+        raise RuntimeError("irfft_odd_pairs_bwd: g2c goes with tslots=True")
     if gains is not None:
         Tq, filt, nbands, G = gains
         Tq = _c(Tq)

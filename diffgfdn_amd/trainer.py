@@ -1026,6 +1026,13 @@ class GraphedTrainStep:
         self.sched = torch.zeros((self.sched_cap, batch_size), dtype=torch.long, device=dev)
         self.sched_state = torch.tensor([0, 1], dtype=torch.long, device=dev)        # {position, length}
 
+    def _ensure_records(self):
+        """The explicit bank step's graph starts from the records its previous replay left (bankstep.FusedBankStep): if
+        anything else has touched the parameters since, rebuild them in front of the replay."""
+        fused = getattr(self.tr, '_fused', None)
+        if fused is not None:
+            fused.ensure_records()
+
     # -- receiver schedule --------------------------------------------------------------------
     def _pick_next(self):
         ops.pick_rows(self.sched, self.sched_state, self.idx)
@@ -1049,6 +1056,7 @@ class GraphedTrainStep:
         if self.graph_a is None:
             self.capture(None)
         self._load_inputs(None)
+        self._ensure_records()
         self.graph_a.replay()
         if self.graph_b is not None:
             self.tr._allreduce()
@@ -1199,6 +1207,10 @@ class GraphedTrainStep:
             self.sched_state.copy_(saved_sched[0])
             self.idx.copy_(saved_sched[1])
             tr.optimizer.zero_grad(set_to_none=True)
+            if getattr(tr, '_fused', None) is not None:
+                # the explicit step keeps the records of the current parameters between steps (its fused tail leaves the
+                # next step's): those of the restored parameters, so that the capture holds no records launch
+                tr._fused.prime_records()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         fused = getattr(tr, '_fused', None) is not None
@@ -1345,6 +1357,7 @@ class GraphedTrainStep:
         if self.graph_a is None:
             self.capture(indices)
         self._load_inputs(indices)
+        self._ensure_records()
         self.graph_a.replay()
         if self.graph_b is not None:
             self.tr._allreduce()

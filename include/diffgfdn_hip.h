@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
  * receiver schedule; every entry point of version 1 keeps its signature */
-#define GFDN_ABI_VERSION 6
+#define GFDN_ABI_VERSION 7
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
@@ -333,6 +333,20 @@ int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, const float* g
                         const float* inv_gamma1, const float* grec1, const float* b, const float* c, int nblk,
                         int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc, float* gM,
                         void* stream);
+/* gfdn_tf_param_grads + Adam on the blocks' own parameters + gfdn_tf_ortho_coefs of the NEXT step in one launch (single-
+ * process training; reference src/diff_gfdn/trainer.py:452-477 backward -> optimizer.step, then :373-379 the next batch's
+ * normalize / forward): after the gradients (written to gb, gc, gM as above) workgroup blk updates elements
+ * offM + blk nper^2 + e, offb + blk nper + i, offc + blk nper + j of the flat Adam buffers (maths of gfdn_adam_step at
+ * t = step_count + 1; the last workgroup writes t back and re-arms block_counter) and leaves Q, QQ and both record sets of
+ * the UPDATED block in Q_next / QQ_next / coef_next / coef_sub_next (which may be the arrays the step read: a block's
+ * workgroup is their only reader at that point).  b, c, M are the flat buffer's views of those leaves.  A1 = the raw
+ * blocks (no 1 / gamma), grec1 their summed records.                                                                    */
+int gfdn_tf_tail(const float* A0, const float* inv_gamma0, const float* grec0, int nparts0, const float* A1,
+                 const float* grec1, const float* b, const float* c, int nblk, int nper, const float* M, const float* gQ,
+                 const float* Q, float* gb, float* gc, float* gM, float* flat_p, float* flat_m, float* flat_v,
+                 const unsigned char* seg, const float* lr_seg, float* step_count, unsigned int* block_counter, int offM,
+                 int offb, int offc, float beta1, float beta2, float eps, float* Q_next, float* QQ_next, float* coef_next,
+                 float* coef_sub_next, void* stream);
 /* out[r] = sum_p part[r * cols + p]: one wavefront per row, fixed order */
 int gfdn_tf_rows_sum(const float* part, int cols, int rows, float* out, void* stream);
 int gfdn_tf_parts(int K, int nblk);
@@ -353,9 +367,12 @@ int gfdn_tf_compose_fwd(const double* turns, const double* logr, int K, int nban
 int gfdn_tf_compose_parts(int K);   /* partial rows per record entry that gfdn_tf_compose_bwd(grec = NULL) leaves in work */
 size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G);
 int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
-                        const float* coef, const float* delays, const float* Tsave_c64, const float* rgain, int B,
-                        const float* filt_c64, int ldf, const float* gH_c64, int ldh, float* grec, void* work,
-                        void* stream);
+                        const float* coef, const float* delays, const float* Tsave_c64, const float* tscale,
+                        const float* rgain, int B, const float* filt_c64, int ldf, const float* gH_c64, int ldh,
+                        float* grec, void* work, void* stream);
+/* tscale (nbands * G floats or NULL): Tsave holds the UNSCALED group transfer functions (gfdn_tf_compose_fwd with scale =
+ * NULL) and T' = tscale T is formed where the records pass reads them -- for a step whose normalisation scale joins the
+ * group signals behind the transform (gfdn_irfft_odd_pairs_fwd_scaled).                                                  */
 size_t gfdn_tf_gain_grad_work_bytes(int K, int nbands, int G, int B);
 int gfdn_tf_gain_grad(int K, int nbands, int G, int B, const float* Tsave_c64, const float* filt_c64, int ldf,
                       const float* gH_c64, int ldh, float* grgain, void* work, void* stream);
@@ -523,6 +540,16 @@ int gfdn_lin_gamma(const float* gx, const float* gxb, int ld_g, int in_pairs, co
 int gfdn_irfft_odd_time_slots(int n, int* times);
 int gfdn_irfft_odd_pairs_bwd_tslots(const void* table, int n, const float* gx2s, int ldo, int batch, float* gXs_c64,
                                     int ldx, void* work, void* stream);
+/* ... of the SUM of up to three slot-ordered inputs (b, c optional; c only with b), added where the first pass loads them:
+ * parts of one gradient signal left by different launches need no merge pass in front of the transform                   */
+int gfdn_irfft_odd_pairs_bwd_tslots3(const void* table, int n, const float* gx2s_a, const float* gx2s_b,
+                                     const float* gx2s_c, int ldo, int batch, float* gXs_c64, int ldx, void* work,
+                                     void* stream);
+/* gfdn_irfft_odd_pairs_fwd with per-item factors on the time signals (oscale: batch floats, device; x2 = oscale[item] *
+ * irfft(Xs[item])), applied where the last pass stores.  stages: 7 = the whole transform; 3 = its first two passes, 4 = the
+ * last one, the only reader of oscale (a caller whose factors come from another stream waits between the two calls)       */
+int gfdn_irfft_odd_pairs_fwd_scaled(const void* table, int n, const float* Xs_c64, int ldx, int batch, const float* oscale,
+                                    float* x2, int ldo, void* work, int stages, void* stream);
 int gfdn_lin_gain_dots(const float* gx, const float* gxb, int ld_g, int in_pairs, const float* tau, int ld_tau,
                        int tau_pairs, int nbands, int B, int G, int n, float* part, int ld_part, void* stream);
 /* (part rows have pitch ld_part >= gfdn_lin_gain_chunks(n): further columns may hold other partial sums of the same
@@ -595,6 +622,26 @@ int gfdn_edc_loss_pairs_lin(const float* xd, int ld_xd, const long long* xrows, 
                             int fill_outside, float* xwin2, void* work, void* stream);
 /* (fill_outside = 0: gx2 is written on the item's window only -- for a consumer that reads nothing else,
  * gfdn_lin_gamma_dots; 1: zeros outside the window, as gfdn_edc_loss_pairs)                                              */
+
+/* The EDC term of the linear step in ONE launch (csrc/edcone.hip; src/diff_gfdn/losses.py:187-238): one workgroup per
+ * item keeps the item's window x[b] = xd[xrows[b]] + sum_g rgain[b][g] tau[band G + g] in registers and runs both scans,
+ * the dB stage and the gradient without staging anything through memory.  Inputs as gfdn_edc_loss_pairs_lin (T_db rows of
+ * pitch ld_T, item_len NULL: max_len for all; maskw row band * ld_mask).  Outputs: loss_item (items); gx (items, ld_gx
+ * >= max_len; NULL: none) = dL/dx on the item's window, sample start + j at column j (columns >= the item's length are
+ * not written); dots (NULL: none): dots[(item G + g) ld_dots + col] = <dL/dx, tau_g>, the EDC part of dL/drgain.
+ * max_len <= gfdn_edc_lin_one_max_len(), G <= 4.                                                                          */
+int gfdn_edc_lin_one_max_len(void);
+int gfdn_edc_lin_one(const float* xd, int ld_xd, const long long* xrows, const float* tau2, int ld_tau, const float* rgain,
+                     int nbands, int B, int G, int start, int max_len, const int* item_len, const float* T_db, int ld_T,
+                     const long long* target_rows, const float* maskw, int ld_mask, float inv_count, float gscale,
+                     float* loss_item, float* gx, int ld_gx, float* dots, int ld_dots, int col, void* stream);
+/* gamma2[band G + g][pos(t)] = base2a + base2b + sum_{b in band} rgain[b][g] gx[b][t - win_start] (the sum on the band's
+ * window only): gfdn_lin_gamma_dots without the dot products, on the window-only rows gfdn_edc_lin_one leaves.  gamma2 and
+ * the bases pair-interleaved (ceil(nbands G / 2), ld, 2); pos = the adjoint pair transform's slot order when slot_of_time
+ * is given (as gfdn_lin_gamma), else t.                                                                                   */
+int gfdn_lin_gamma_win(const float* gx, int ld_g, const float* rgain, int nbands, int B, int G, int n, int win_start,
+                       int win_len, const int* band_win_len, const float* base2a, const float* base2b, int ld_b,
+                       const int* slot_of_time, float* gamma2, int ld_o, void* stream);
 
 /* gfdn_lin_combine_fwd folded into the load of gfdn_stft_power_pairs (win = 4096; tau pair-interleaved): forms the pair's
  * samples where the frame is loaded, stores them once as x2 (ceil(items / 2), ld >= T, 2) for the EDC scans and the STFT
