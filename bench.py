@@ -701,6 +701,8 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--pipe-steps', type=int, default=None,
                     help='steps per graph of the pipelined chain (even; 0: one step per graph); default: the trainer\'s')
+    ap.add_argument('--chain-steps', type=int, default=None,
+                    help='explicit bank steps per replayed graph (GraphedTrainStep.chain_steps; default: the trainer\'s)')
     ap.add_argument('--per-step-copy', action='store_true',
                     help='hand every step its receivers by a host copy in front of the replay (diagnostic; default: the '
                          'batches go to the device as one schedule)')
@@ -937,6 +939,8 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
         step = trainer.graphed(data, b_local)      # normalize + train_step as ONE HIP-graph replay
         if args.pipe_steps is not None:
             step.pipe_steps = args.pipe_steps
+        if args.chain_steps is not None:
+            step.chain_steps = args.chain_steps
         draws = ([draw_n(b_local) for _ in range(args.warmup)], [draw_n(b_local) for _ in range(args.steps)])
         elapsed, parts = timed_steps(step, draws, args, world, device, eager=args.eager, per_step_copy=args.per_step_copy)
         total = parts['_total']

@@ -89,6 +89,7 @@ SIGNATURES = {
     "gfdn_edc_lin_one_max_len": (c_int, []),
     "gfdn_edc_lin_one": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P,
                                  c_int, c_float, c_float, _P, _P, c_int, _P, c_int, c_int, _P]),
+    "gfdn_lin_merge_slots": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_lin_gamma_win": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int,
                                    _P]),
     "gfdn_tf_gain_grad_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

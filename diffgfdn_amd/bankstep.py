@@ -176,6 +176,10 @@ class FusedBankStep:
     # -> the NEXT step's Q, QQ and record sets (csrc/blocktf.hip k_tf_tail); the gain network's range of the flat buffers is
     # stepped on the side stream behind its own backward.  A step then starts with the group responses.
     fused_tail = os.environ.get('GFDN_FUSED_TAIL', '1') == '1'
+    # (d) the EDC part of dL/dtau summed over the band's receivers on the side stream, straight behind the EDC launch; the
+    # main chain merges it with the adjoint STFT's two signal sets (three small arrays) into the transform's slot order
+    gamma_split = os.environ.get('GFDN_GAMMA_SPLIT', '1') == '1'
+    colorless_at_tail = os.environ.get('GFDN_COLORLESS_TAIL', '0') == '1'      # (OFF: measured 0.375 against 0.357 ms -- it stretches the adjoint transform's passes)
 
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
     # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
@@ -340,6 +344,11 @@ class FusedBankStep:
                 li_edc, g_edc = ops.edc_loss_pairs_lin(xd, rows, tau, rgain, nb, K, start, length, T_edc, maskw, inv,
                                                        cfg.edc_loss_weight, train, trows=rows, item_len=item_len,
                                                        fill_outside=not self.gamma_dots_one_launch)
+            if edc_one and train and self.gamma_split:
+                # the EDC part of dL/dtau right here, beside the EDR launch: the main chain then merges three small signal
+                # sets behind the adjoint STFT instead of sweeping the receivers' gradient rows (42 MB) there
+                _, band_len = tr._item_windows(K, Btot // nb, rows.device)
+                g_edc = (g_edc, ops.lin_gamma_win(g_edc, rgain, nb, K, start, length, band_win_len=band_len))
             ev['edc'].record()
         wait_gains()
         gP = Gs = None
@@ -350,7 +359,10 @@ class FusedBankStep:
         else:
             li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
                                           dots=parts, col0=nch, tiled=tiled)
-        ev['g'].record()                                     # (EDR partials and the EDR columns of ``parts`` complete)
+        if not (train and self.gamma_dots_one_launch):
+            # (training: the side stream's consumers of the EDR partials wait for the LATER event behind the gamma merge --
+            # one edge from the main chain to the side stream instead of two; an edge costs the main chain ~4 us)
+            ev['g'].record()                                 # (EDR partials and the EDR columns of ``parts`` complete)
         keep.extend((Sd, Stau, li_edc, g_edc, li_edr, gP, parts))
         if not train:
             main.wait_event(ev['edc'])
@@ -461,8 +473,6 @@ class FusedBankStep:
             zu, direct = data['dataset'].slot_ordered(*order)
         else:
             zu, direct = z[:Ku], data['target_early_response'][:, :Ku]
-        gridU = FrequencyGrid.of(zu)
-        filt = tr._filter_on(Ku, order)
         inv_world = shard_loss_scales(tr.world_size, 1, 1.0)['colorless']
         Hh, n_hidden, _, lo, hi = bank._mlp_cfg
         w = bank.output_scalars_w.detach()
@@ -502,7 +512,9 @@ class FusedBankStep:
         else:
             # (the fused tail of the previous training step left them; anything else that touched M, b, c since made
             # the bookkeeping say so)
-            if not self.records_ok():
+            # (a training step WITHOUT the fused tail always evaluates them: captured into a graph it would otherwise replay on
+            # records nobody refreshes)
+            if not (self.records_ok() and (use_tail or not train)):
                 ops.tf_ortho_coefs(M, ig, b, c, out=self._records())
             Q, QQ, coef, coef_sub = self._records()
             self._rec_valid = False           # (until this step's end says otherwise)
@@ -512,6 +524,16 @@ class FusedBankStep:
         # the normalisation scale joins the group signals behind the transform: energy pass on the side stream
         late = (self.scale_late and lin and order is not None and normalize_first and not big and side2 is not None)
         scale = None
+        Hg = Ts = None
+        gridU = FrequencyGrid.of(zu)
+        filt = tr._filter_on(Ku, order)
+        if late:
+            # the main chain's first launch is captured BEFORE anything is forked off: the graph lays its hardware queues out
+            # along the capture order, and a chain whose head is captured behind a side stream's first launch starts every
+            # replay on the second queue (measured: 29 us between the last kernel of a step and the group responses of the
+            # next one, against ~6)
+            Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, self._eye_rows(nb, G, z.device), None, None,
+                                        filt, None, nb, save_T=True, want_H=True)
         with on_side2():
             if pipe is None or pipe.first:
                 torch.cuda.current_stream().wait_event(ev['start'])
@@ -569,9 +591,9 @@ class FusedBankStep:
                 ev_ts = torch.cuda.Event()
                 ev_ts.record()
                 Hg = Ts if filt is None else (Ts.view(nb, G, -1) * filt.view(nb, 1, -1)).reshape(nb * G, -1)
-            else:
-                Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, None if late else scale, None,
-                                            filt, None, nb, save_T=True, want_H=True)
+            elif not late:
+                Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, scale, None, filt, None, nb,
+                                            save_T=True, want_H=True)
             if late:
                 # (the wait sits in front of the LAST pass, the only reader of the scale: by then the side stream's energy
                 # pass is long done and the wait is free)
@@ -628,7 +650,8 @@ class FusedBankStep:
 
         def colorless_pass():
             with on_cl():
-                torch.cuda.current_stream().wait_event(ev['norm'])
+                if not (late and not own_cl):      # (recorded on this very stream: no wait -- a captured wait of a stream
+                    torch.cuda.current_stream().wait_event(ev['norm'])      # for its own event is asking for trouble)
                 if big:
                     torch.cuda.current_stream().wait_event(ev_ts)
                     grec_sub_, loss_g_ = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
@@ -668,7 +691,11 @@ class FusedBankStep:
                                                     start, length, ev, main, side2, x_fn=x_fn, Btot=Btot,
                                                     gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None,
                                                     item_len=item_len, Bper=Btot // nb, lin=lin)
-        if late_colorless:
+        # (e) ... or at the TAIL: behind the merge of dL/dtau, beside the adjoint transforms and the records pass (launches of a
+        # few workgroups) instead of beside the adjoint STFT and the merge, which it stretched (32 against 20 us, 16 against 8)
+        tail_colorless = (late_colorless and self.colorless_at_tail and train and lin and spec and not big
+                          and self.gamma_dots_one_launch)
+        if late_colorless and not tail_colorless:
             grec_sub, out3, gQ = colorless_pass()
         def report():
             """the reported sums and total (off the gradient path)"""
@@ -697,7 +724,9 @@ class FusedBankStep:
                         # of dL/drgain
                         _, band_len = tr._item_windows(K, Btot // nb, z.device)
                         ge_a, ge_b = gam_edr if isinstance(gam_edr, tuple) else (gam_edr, None)
-                        if self._edc_one(length, G):
+                        if isinstance(gsig, tuple):         # (rows, their sums per group: bankstep.gamma_split)
+                            gam = ops.lin_merge_slots(gsig[1], ge_a, ge_b, sot)
+                        elif self._edc_one(length, G):
                             gam = ops.lin_gamma_win(gsig, rgain, nb, K, start, length, base=ge_a, base_b=ge_b,
                                                     slot_of_time=sot, band_win_len=band_len)
                         else:
@@ -707,6 +736,10 @@ class FusedBankStep:
                         gam = ops.lin_gamma(gsig, rgain, nb, K, True, True, slot_of_time=sot, base=gam_edr)
                     ev_gam = torch.cuda.Event()
                     ev_gam.record()
+                    if tail_colorless:
+                        with on_side2():
+                            torch.cuda.current_stream().wait_event(ev_gam)
+                        grec_sub, out3, gQ = colorless_pass()
                 else:
                     gsig, gsig_b = gH
                     gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b, slot_of_time=sot)
@@ -724,7 +757,10 @@ class FusedBankStep:
                 grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True,
                                           tscale=scale if late else None)
             with on_side2():
-                torch.cuda.current_stream().wait_event(ev['g'])
+                if spec and self.gamma_dots_one_launch:
+                    torch.cuda.current_stream().wait_event(ev_gam)           # (behind the EDR launch as well)
+                else:
+                    torch.cuda.current_stream().wait_event(ev['g'])
                 if own_cl:
                     torch.cuda.current_stream().wait_event(ev['side'])       # (the colorless terms the totals include)
                 sums, total = report()

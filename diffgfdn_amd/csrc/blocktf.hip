@@ -380,6 +380,33 @@ extern "C" int gfdn_tf_coefs_bwd(const float* A0, const float* inv_gamma0, const
   return 0;
 }
 
+// srec[r] = sum_p rows[r * nparts + p] for the TF_REC record rows of one block, by the 4 wavefronts of a 256-thread
+// workgroup: wave w takes rows w, w + 4, ... -- the loads of its eight rows are issued together (they were eight dependent
+// load -> crossbar-sum round trips, a third of the tail kernel's time), the sums in the order of k_tf_rows_sum.
+__device__ __forceinline__ void tf_sum_record_rows(const float* __restrict__ rows, int nparts, float* srec) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc[TF_REC / 4];
+#pragma unroll
+  for (int q = 0; q < TF_REC / 4; ++q) {
+    const float* row = rows + (size_t)(w + 4 * q) * nparts;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = lane;
+    for (; p + 192 < nparts; p += 256) {
+      a0 += row[p];
+      a1 += row[p + 64];
+      a2 += row[p + 128];
+      a3 += row[p + 192];
+    }
+    for (; p < nparts; p += 64) a0 += row[p];
+    acc[q] = (a0 + a1) + (a2 + a3);
+  }
+#pragma unroll
+  for (int q = 0; q < TF_REC / 4; ++q) {
+    const float sum = wave_sum_full(acc[q]);            // (whole waves: VALU sums)
+    if (lane == 0) srec[w + 4 * q] = sum;
+  }
+}
+
 // The tail of the band bank's backward in ONE launch, one workgroup per block (group): sum the partial record rows of
 // the output-stage adjoint (gpart0[(blk * 32 + e) * nparts0 + p], as k_tf_compose_bwd_rec leaves them; nparts0 = 1:
 // summed records), records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) as k_tf_coefs_bwd, then the adjoint of
@@ -395,21 +422,7 @@ __global__ __launch_bounds__(256) void k_tf_param_grads(TfBwdSet s0, TfBwdSet s1
   __shared__ float srec[TF_REC], sG[2][16];
   const int blk = blockIdx.x, tid = threadIdx.x;
   if (nparts0 > 1) {
-    const int lane = tid & 63, nw = blockDim.x >> 6;
-    for (int r = tid >> 6; r < TF_REC; r += nw) {
-      const float* row = s0.grec + ((size_t)blk * TF_REC + r) * nparts0;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int p = lane;
-      for (; p + 192 < nparts0; p += 256) {
-        a0 += row[p];
-        a1 += row[p + 64];
-        a2 += row[p + 128];
-        a3 += row[p + 192];
-      }
-      for (; p < nparts0; p += 64) a0 += row[p];
-      const float sum = wave_sum((a0 + a1) + (a2 + a3));
-      if (lane == 0) srec[r] = sum;
-    }
+    tf_sum_record_rows(s0.grec + (size_t)blk * TF_REC * nparts0, nparts0, srec);
   } else if (tid < TF_REC) {
     srec[tid] = s0.grec[(size_t)blk * TF_REC + tid];
   }
@@ -463,12 +476,10 @@ struct TfAdam {
 };
 
 __device__ __forceinline__ float tf_adam_elem(const TfAdam& ad, int i, float gi, float bc1, float bc2_sqrt) {
-  const float mi = ad.m[i] + (gi - ad.m[i]) * (1.0f - ad.b1);
-  const float vi = ad.v[i] * ad.b2 + gi * gi * (1.0f - ad.b2);
+  float mi = ad.m[i], vi = ad.v[i];
+  const float pn = adam_elem(ad.p[i], gi, mi, vi, ad.lr_seg[ad.seg[i]], bc1, bc2_sqrt, ad.b1, ad.b2, ad.eps);
   ad.m[i] = mi;
   ad.v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + ad.eps;
-  const float pn = ad.p[i] - (ad.lr_seg[ad.seg[i]] / bc1) * (mi / denom);
   ad.p[i] = pn;
   return pn;
 }
@@ -482,21 +493,7 @@ __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int n
   const int blk = blockIdx.x, tid = threadIdx.x;
   const float t = ad.step_count[0] + 1.0f;
   if (nparts0 > 1) {
-    const int lane = tid & 63, nw = blockDim.x >> 6;
-    for (int r = tid >> 6; r < TF_REC; r += nw) {
-      const float* row = s0.grec + ((size_t)blk * TF_REC + r) * nparts0;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int p = lane;
-      for (; p + 192 < nparts0; p += 256) {
-        a0 += row[p];
-        a1 += row[p + 64];
-        a2 += row[p + 128];
-        a3 += row[p + 192];
-      }
-      for (; p < nparts0; p += 64) a0 += row[p];
-      const float sum = wave_sum((a0 + a1) + (a2 + a3));
-      if (lane == 0) srec[r] = sum;
-    }
+    tf_sum_record_rows(s0.grec + (size_t)blk * TF_REC * nparts0, nparts0, srec);
   } else if (tid < TF_REC) {
     srec[tid] = s0.grec[(size_t)blk * TF_REC + tid];
   }
@@ -586,7 +583,7 @@ __global__ __launch_bounds__(256) void k_tf_rows_sum(const float* __restrict__ p
     s3 += row[p + 192];
   }
   for (; p < cols; p += 64) s0 += row[p];
-  const float s = wave_sum((s0 + s1) + (s2 + s3));
+  const float s = wave_sum_full((s0 + s1) + (s2 + s3));            // (a wave is wholly in or out of range)
   if (lane == 0) {
     if (r < n0) {
       out0[r] = s;

@@ -37,6 +37,18 @@ __device__ __forceinline__ float db_pow(float x) {
   return fmaxf(y, -200.0f);
 }
 
+// One element of the Adam update (torch.optim.Adam without amsgrad / weight decay; reference trainer.py:475) with every
+// rounding pinned -- two kernels step ranges of one flat buffer (optim.hip k_adam, blocktf.hip k_tf_tail) and must agree
+// to the bit whatever the compiler would contract:  m <- m + (g - m)(1 - b1);  v <- v b2 + g g (1 - b2);
+// p <- p - (lr / bc1) m / (sqrt(v) / bc2_sqrt + eps).  Returns the new parameter.
+__device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v, float lr, float bc1, float bc2_sqrt,
+                                           float b1, float b2, float eps) {
+  m = __fmaf_rn(g - m, 1.0f - b1, m);
+  v = __fmaf_rn(__fmul_rn(g, g), 1.0f - b2, __fmul_rn(v, b2));
+  const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+  return __fsub_rn(p, __fmul_rn(__fdiv_rn(lr, bc1), __fdiv_rn(m, denom)));
+}
+
 // sum over the 64 lanes of a wavefront
 // Cross-lane sums on the VALU (DPP inside the rows of 16 lanes, v_permlane16_swap / v_permlane32_swap of gfx950 between
 // rows and half-waves).  __shfl_* compile to ds_bpermute_b32, which issues on the LDS pipe with its latency: a butterfly of

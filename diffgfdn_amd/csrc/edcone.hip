@@ -32,6 +32,9 @@
 #define E1_NT 12                     // tiles per window: L <= 49152
 #define E1_NL 7                      // tiles whose dL/dEDC values wait in LDS (the others in registers; 6: two spills)
 #define E1_MAXG 4
+#ifndef E1_SB
+#define E1_SB 2                       // tiles per scheduling group (their loads are in flight together)
+#endif
 
 struct Edc1Args {
   const float* xd;             // (R, ld_xd): transformed direct paths
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
       }
       // (one workgroup = 1024 threads per CU: one tile's loads per thread in flight saturate the memory system; the
       // scheduler hoisting several tiles' loads only cost registers)
-      if (k & 1) __builtin_amdgcn_sched_barrier(0);
+      if ((k % E1_SB) == E1_SB - 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- suffix sums of x^2 (prefix over the scan elements): wave level on the VALU, waves and tiles through s_w
@@ -207,13 +210,15 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
           const int v = E1_V - 1 - u;
           run += xs[k][v] * xs[k][v];
           if (jlo + v >= 0) {
+            // (hardware log2 / reciprocal, 1 ulp each: the dB stage is a quarter of the launch's instructions with the
+            // library forms, and the launch is bound by instruction issue, not by memory -- 127 MB in 53 us)
             const float edc = ex[k] + run;
             const float lin = fabsf(edc) + F32_EPS;
-            const float raw = 10.0f * log10f(lin);
+            const float raw = 3.0102999566398120f * __log2f(lin);        // 10 log10(lin)
             const float diff = t4[v] - fmaxf(raw, -200.0f);
             acc += m4[v] * fabsf(diff);
             const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-            const float dE = (raw > -200.0f) ? TEN_OVER_LN10 / lin : 0.f;
+            const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __frcp_rn(lin) : 0.f;
             gv[v] = -sg * dE * m4[v] * gcoef;
           }
         }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
 #pragma unroll
         for (int v = 0; v < E1_V; ++v) gq[k >= E1_NL ? k - E1_NL : 0][v] = gv[v];
       }
-      if (k & 1) __builtin_amdgcn_sched_barrier(0);
+      if ((k % E1_SB) == E1_SB - 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (a.gx || a.dots) {
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
           }
         }
       }
-      if (k & 1) __builtin_amdgcn_sched_barrier(0);
+      if ((k % E1_SB) == E1_SB - 1) __builtin_amdgcn_sched_barrier(0);
     }
     if (a.dots) {
 #pragma unroll
@@ -456,6 +461,62 @@ extern "C" int gfdn_lin_gamma_win(const float* gx, int ld_g, const float* rgain,
   hipLaunchKernelGGL(k_lin_gamma_win, dim3((n + 256 * GW_V - 1) / (256 * GW_V), nbands), dim3(256), 0, (hipStream_t)stream,
                      gx, ld_g, rgain, B, G, n, win_start, win_len, band_win_len, base2a, base2b, ld_b, slot_of_time, gamma2,
                      ld_o);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[r][pos(t)] = a[r][t] + b[r][t] + c[r][t] for pair-interleaved signal rows (float2 per sample; b, c optional), pos = the
+// adjoint pair transform's slot order (sample 0 first, the sample of time t >= 1 at 1 + slot_of_time[t]): the parts of
+// dL/dtau that different launches left (EDC part summed over the receivers, the adjoint STFT's even / odd frames) merged
+// and permuted in one small pass in front of the adjoint transform.
+__global__ __launch_bounds__(256) void k_lin_merge_slots(const float2* __restrict__ a, const float2* __restrict__ b,
+                                                         const float2* __restrict__ c, int n, int ld,
+                                                         const int* __restrict__ slot_of_time, float2* __restrict__ out,
+                                                         int ld_o) {
+  const int r = blockIdx.y;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t0 >= n) return;
+  const size_t o = (size_t)r * ld;
+  float2 v[4];
+  if (t0 + 4 <= n) {
+    ld4_f2(a + o + t0, v);
+    if (b) {
+      float2 w[4];
+      ld4_f2(b + o + t0, w);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v[u].x += w[u].x; v[u].y += w[u].y; }
+    }
+    if (c) {
+      float2 w[4];
+      ld4_f2(c + o + t0, w);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v[u].x += w[u].x; v[u].y += w[u].y; }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = make_float2(0.f, 0.f);
+      if (t0 + u < n) {
+        v[u] = a[o + t0 + u];
+        if (b) { v[u].x += b[o + t0 + u].x; v[u].y += b[o + t0 + u].y; }
+        if (c) { v[u].x += c[o + t0 + u].x; v[u].y += c[o + t0 + u].y; }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int t = t0 + u;
+    if (t < n) out[(size_t)r * ld_o + (slot_of_time ? (t == 0 ? 0 : 1 + slot_of_time[t]) : t)] = v[u];
+  }
+}
+
+extern "C" int gfdn_lin_merge_slots(const float* a2, const float* b2, const float* c2, int rows, int n, int ld,
+                                    const int* slot_of_time, float* out2, int ld_o, void* stream) {
+  if (!a2 || !out2 || rows <= 0 || n <= 0 || ld < n || ld_o < n || out2 == a2 || out2 == b2 || out2 == c2 || (c2 && !b2))
+    return GFDN_E_BADARG;
+  if (rows > 65535) return GFDN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_lin_merge_slots, dim3((n + 1023) / 1024, rows), dim3(256), 0, (hipStream_t)stream, (const float2*)a2,
+                     (const float2*)b2, (const float2*)c2, n, ld, slot_of_time, (float2*)out2, ld_o);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

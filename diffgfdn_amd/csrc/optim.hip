@@ -24,13 +24,10 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ p, const floa
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // lerp, as torch does
-    const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+    float mi = m[i], vi = v[i];
+    p[i] = adam_elem(p[i], g[i], mi, vi, lr_seg[seg[i]], bc1, bc2_sqrt, b1, b2, eps);      // (lerp, as torch does)
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr_seg[seg[i]] / bc1) * (mi / denom);
   }
   if (advance) {
     __syncthreads();

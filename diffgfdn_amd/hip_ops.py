@@ -1467,6 +1467,20 @@ def lin_gamma_win(gx, rgain, nbands: int, n: int, win_start: int, win_len: int, 
     return gamma
 
 
+def lin_merge_slots(a2, b2=None, c2=None, slot_of_time=None) -> torch.Tensor:
+    """a2 [+ b2 [+ c2]] -- pair-interleaved signal rows (rows, n, 2) -- written in the adjoint pair transform's slot order
+    (``slot_of_time``; None: time order)."""
+    _need_gpu(a2)
+    for t in (a2, b2, c2):
+        if t is not None and (t.dtype != _f32 or not t.is_contiguous() or t.shape != a2.shape or t.dim() != 3
+                              or t.shape[2] != 2):
+            raise RuntimeError("lin_merge_slots: contiguous float32 (rows, n, 2) tensors of one shape expected")
+    out = torch.empty_like(a2)
+    _lib.check(_lib.load().gfdn_lin_merge_slots(_p(a2), _p(b2), _p(c2), a2.shape[0], a2.shape[1], a2.shape[1],
+                                                _p(slot_of_time), _p(out), a2.shape[1], _stream()), "gfdn_lin_merge_slots")
+    return out
+
+
 def stft_power_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, win: int):
     """lin_combine_fwd(..., tau_pairs=True, out_pairs=True) folded into the load of stft_power_pairs: returns (x2
     (ceil(items / 2), n, 2), P (items, nframes, win / 2 + 1)) in ONE launch (win = 4096)."""

@@ -643,6 +643,12 @@ int gfdn_lin_gamma_win(const float* gx, int ld_g, const float* rgain, int nbands
                        int win_len, const int* band_win_len, const float* base2a, const float* base2b, int ld_b,
                        const int* slot_of_time, float* gamma2, int ld_o, void* stream);
 
+/* out2[r][pos(t)] = a2[r][t] + b2[r][t] + c2[r][t] over `rows` pair-interleaved signal rows (ld / ld_o float2 per row;
+ * b2, c2 optional, c2 only with b2), pos as gfdn_lin_gamma's slot_of_time (NULL: t): parts of one gradient signal left by
+ * different launches, merged into the adjoint pair transform's slot order                                                  */
+int gfdn_lin_merge_slots(const float* a2, const float* b2, const float* c2, int rows, int n, int ld, const int* slot_of_time,
+                         float* out2, int ld_o, void* stream);
+
 /* gfdn_lin_combine_fwd folded into the load of gfdn_stft_power_pairs (win = 4096; tau pair-interleaved): forms the pair's
  * samples where the frame is loaded, stores them once as x2 (ceil(items / 2), ld >= T, 2) for the EDC scans and the STFT
  * adjoint, and writes P (items, nframes, 2049) = |STFT|^2 -- the stand-alone combine pass does not run.                  */

@@ -277,3 +277,22 @@ def test_fused_tail_equals_separate_launches(ops, n):
         assert float(opt_b.step_count) == step + 1 and float(opt_b.step_count2) == step + 1
         for got, want in zip(rec_b, rec_a):
             assert torch.equal(got, want), step
+
+
+def test_merge_into_slot_order(ops):
+    """gfdn_lin_merge_slots: a + b + c of pair-interleaved rows written in the adjoint transform's slot order == the sum
+    scattered by torch; one and two inputs; time order without the table."""
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    n, rows = 65537, 5
+    a, b, c = (torch.randn(rows, n, 2, generator=gen).to(DEV) for _ in range(3))
+    sot = ops.irfft_slot_of_time(n, torch.device(DEV))
+    pos = torch.cat([torch.zeros(1, dtype=torch.long, device=DEV), 1 + sot[1:].long()])
+    for parts in ((a,), (a, b), (a, b, c)):
+        want = torch.empty_like(a)
+        tot = parts[0]
+        for p in parts[1:]:
+            tot = tot + p
+        want[:, pos] = tot
+        got = ops.lin_merge_slots(*parts, slot_of_time=sot)
+        assert torch.equal(got, want)
+        assert torch.equal(ops.lin_merge_slots(*parts), tot)
