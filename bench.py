@@ -72,6 +72,10 @@ EDC_LEN = 48000 - 640
 HBM_PEAK_GBS = 8000.0
 # compulsory HBM bytes per RIR (fwd + bwd, fp32 / complex64 storage)
 ALG_BYTES_PER_RIR = 2811048
+# ... and what the LINEAR step (rounds 4-5) has to move per RIR: the receiver's transformed direct path as short-time spectra
+# (32 x 2049 x 8 B) and on the EDC window (4 x 47 360 B), the target EDR (32 x 2049 x 4 B) and the target EDC (4 x 47 360 B);
+# everything else of the step is per band (group signals, records), not per receiver
+LINEAR_ALG_BYTES_PER_RIR = FRAMES * NF * (8 + 4) + 2 * 4 * EDC_LEN          # = 1 165 696
 # Dominant HBM-bound kernel of the step since round 4: the EDR loss on composed short-time spectra (csrc/edrlin.hip,
 # k_edr_lin_band), one launch per step.  Per RIR it MUST read the STFT of the receiver's transformed direct path (32 frames
 # x 2049 bins x 8 B) and the target EDR (x 4 B) = 786 816 B; the band's group spectra in and the band's gradient spectra out
@@ -89,6 +93,9 @@ ALG_BYTES_PER_UNIT = {
     'k_edc_pair_seg_fwd': 3 * 4 * EDC_LEN,                                     # x, target EDC in, staged terms out
     'k_edc_pair_seg_bwd': 3 * 4 * EDC_LEN,                                     # staged terms, x in, gradient (window) out
     'k_lin_gamma_dots': 4 * EDC_LEN,                                           # EDC gradient (window) in (the G sums out: per band)
+    # round 5: the EDC term in one launch per receiver (csrc/edcone.hip) and the light sum over the band's receivers
+    'k_edc_lin_one': 3 * 4 * EDC_LEN,                                          # direct path, target EDC in; dL/dx (window) out
+    'k_lin_gamma_win': 4 * EDC_LEN,                                            # dL/dx (window) in (the G sums out: per band)
     # (kernels of the stored-signal paths, GFDN_SPECTRAL_EDR=0 / GFDN_LINEAR=0, kept for the A/B runs)
     'k_blu_col128_fwd': (8 * KU + 4 * 65536 + 4 * K + 4 * 65536) // 2,
     'k_blu_row512': 2 * 8 * 65536 // 2,
@@ -100,7 +107,7 @@ ALG_BYTES_PER_UNIT = {
 }
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
-PROFILE_TAG = 'r04'
+PROFILE_TAG = 'r05'
 REFERENCE_EPOCH_S_PER_BAND = 139.1   # reference trainer, N = 16, 8 vCPU, one band, one epoch
 
 
@@ -376,6 +383,16 @@ def pmc_traffic_bytes(kernel: str, table: str = 'pmc_hbm_bytes.csv'):
         return None
     r = max(rows, key=lambda r_: int(r_['launches']))
     return int(float(r['hbm_traffic_MB']) * 1e6)
+
+
+def step_traffic():
+    """PMC traffic (2 x FETCH_SIZE + WRITE_SIZE) summed over the launches of ONE replayed 7-band step, from the committed
+    profiles (tools/make_profiles.py writes it beside the per-kernel table) or None"""
+    path = _profile('step_traffic.json')
+    if path is None:
+        return None
+    with open(path) as f:
+        return json.load(f)
 
 
 # kernels whose unit is a SIGNAL of the launch, not a RIR: in the linear step (the default) the transforms run on the bands'
@@ -676,6 +693,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='timed regions of --steps steps each (N = 1; ms_per_step is the MEDIAN region, the spread is in '
+                         'extra.repeat_spread): a 20-step region of this workload is an 8 ms sample')
     ap.add_argument('--scaling', choices=('auto', 'weak', 'strong'), default='auto',
                     help='auto (default): N = 1 the step at batch 32; N > 1 the headline is STRONG scaling (the reference\'s '
                          'global batch of 32 per band split over the ranks) with the weak figure (32 receivers per band per '
@@ -780,9 +800,10 @@ def main():
         dist.destroy_process_group()
 
 
-def timed_steps(step, draws, args, world, device, eager=False, per_step_copy=False):
+def timed_steps(step, draws, args, world, device, eager=False, per_step_copy=False, repeats=1, spread=None):
     """warm-up, then EXACTLY ``args.steps`` steps between barrier + synchronize on both sides; returns (seconds, max over
-    the ranks; the last step's loss parts)."""
+    the ranks; the last step's loss parts).  ``repeats`` > 1: that many such regions back to back (the same receivers), the
+    MEDIAN region's seconds returned and min / max / median per step left in ``spread``."""
     warm, timed = draws
     scheduled = not eager and not per_step_copy and hasattr(step, 'run_schedule')
 
@@ -798,27 +819,34 @@ def timed_steps(step, draws, args, world, device, eager=False, per_step_copy=Fal
     else:
         for sel in warm:
             one_step(sel)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if scheduled:
-        for parts in step.run_schedule(timed):           # (uploads the schedule inside the timed region)
-            pass
-    else:
-        for sel in timed:
-            parts = one_step(sel)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed, parts
+    regions = []
+    for _ in range(max(1, int(repeats))):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if scheduled:
+            for parts in step.run_schedule(timed):           # (uploads the schedule inside the timed region)
+                pass
+        else:
+            for sel in timed:
+                parts = one_step(sel)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        regions.append(elapsed)
+    if spread is not None:
+        spread.update({'regions': len(regions), 'steps_per_region': len(timed),
+                       'ms_per_step_min': 1e3 * min(regions) / len(timed), 'ms_per_step_max': 1e3 * max(regions) / len(timed),
+                       'ms_per_step_median': 1e3 * float(np.median(regions)) / len(timed)})
+    return float(np.median(regions)), parts
 
 
 def run_band_sharded(args, device, rank, world, centres):
@@ -828,6 +856,7 @@ def run_band_sharded(args, device, rank, world, centres):
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
     mine = [(q, f) for q, f in enumerate(centres) if q % world == rank]
     step = draws = None
+    vrirs, vsec = 0, 0.0
     if mine:
         nets, datasets, filts, splits = [], [], [], []
         tmax = band_t60max(len(centres), args.distinct_t60)
@@ -848,18 +877,55 @@ def run_band_sharded(args, device, rank, world, centres):
         draws = ([draw() for _ in range(args.warmup)], [draw() for _ in range(args.steps)])
     if step is not None:
         elapsed, _ = timed_steps(step, draws, args, world, device)
-    else:                                     # (more ranks than bands: this rank only keeps the barriers company)
+    else:
+        # more ranks than bands (7 bands on 8 GPUs): the HYBRID placement -- a rank without a band takes the purely parallel
+        # side work of the reference's loop, validation passes (trainer.py:389-397: forward + losses, no gradient, no
+        # exchange), on a band of its own copy while the others train; it keeps the training ranks' barriers
+        vrirs = 0
+        vtr = vbatch = None
+        try:
+            q = rank % len(centres)
+            tmax = band_t60max(len(centres), args.distinct_t60)
+            room, data, net, tc, split, filt, delays = build_workload(device, 1234 + q, args.receivers, centre_hz=centres[q],
+                                                                      room_seed=q, make_trainer=False, t60max=tmax[q])
+            vbank = BandBank([net])
+            vtr = BandBankTrainer(vbank, trainer_config(500.0, 20, train_dir='/tmp/gfdn_bench/train_bs'),
+                                  subband_filter_freq_resp=torch.stack([filt]), band_names=[int(centres[q])],
+                                  data_parallel=False)
+            vsds = BandStackedDataset([data], free_sources=True)
+            vsds.precompute_decay_targets(WIN, *vtr._target_window(K))
+            vbatch = vsds.collate(vsds.global_rows([list(split[1][:BATCH])]))
+            vtr.valid_step(vbatch)                # (warm-up: lazy stores, kernels)
+        except Exception as e:                    # noqa: BLE001 -- the side work must never cost the training ranks their line
+            print(f'[bench] rank {rank}: validation side work not started ({type(e).__name__}: {e})', file=sys.stderr)
+            vtr = None
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
+        if vtr is not None:
+            for _ in range(args.steps):           # (as many validation batches as the others take training steps)
+                vtr.valid_step(vbatch)
+                vrirs += BATCH
+            torch.cuda.synchronize()
+        vsec = time.perf_counter() - t0
         dist.barrier()
         t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rirs = len(centres) * BATCH * args.steps / elapsed
-    return {'placement': f'whole bands over the ranks (rank r: bands r, r + {world}, ...), batch {BATCH} receivers per band, '
-                         'no collective', 'ms_per_step': 1e3 * elapsed / args.steps, 'rirs_per_s': rirs,
-            'value': rirs * FRAMES, 'unit': 'RIR-frames/s', 'bands_on_rank0': len(mine) if rank == 0 else None}
+    out = {'placement': f'whole bands over the ranks (rank r: bands r, r + {world}, ...), batch {BATCH} receivers per band, '
+                        'no collective', 'ms_per_step': 1e3 * elapsed / args.steps, 'rirs_per_s': rirs,
+           'value': rirs * FRAMES, 'unit': 'RIR-frames/s', 'bands_on_rank0': len(mine) if rank == 0 else None}
+    if world > len(centres):
+        # validation RIRs the band-less ranks processed inside the same interval (summed over them)
+        v = torch.tensor([float(vrirs) if not mine else 0.0, float(vsec) if not mine else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        out['hybrid'] = {'placement': f'{len(centres)} ranks train one band each, {world - len(centres)} rank(s) run validation '
+                                      'passes (forward + losses of 32-receiver batches, host-launched) meanwhile: no exchange',
+                         'validation_rirs_in_interval': float(v[0].item()),
+                         'validation_rirs_per_s': (float(v[0].item()) / float(v[1].item())) if float(v[1].item()) > 0 else 0.0,
+                         'training_rirs_per_s': rirs}
+    return out
 
 
 def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=False):
@@ -942,7 +1008,11 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
         if args.chain_steps is not None:
             step.chain_steps = args.chain_steps
         draws = ([draw_n(b_local) for _ in range(args.warmup)], [draw_n(b_local) for _ in range(args.steps)])
-        elapsed, parts = timed_steps(step, draws, args, world, device, eager=args.eager, per_step_copy=args.per_step_copy)
+        spread = {}
+        elapsed, parts = timed_steps(step, draws, args, world, device, eager=args.eager, per_step_copy=args.per_step_copy,
+                                     repeats=(args.repeats if (world == 1 and not sub_record) else 1), spread=spread)
+        if spread.get('regions', 1) > 1:
+            extra['repeat_spread'] = spread
         total = parts['_total']
 
         # roofline leg (rank 0): the SAME launch sequence on the same streams, launched from the host so that the
@@ -1043,6 +1113,15 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
             out['build'] = library_stamp()
         out['whole_step_hbm_frac'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS
         out['whole_step_alg_GBs'] = rirs_per_s / world * ALG_BYTES_PER_RIR / 1e9
+        # what the step really moves: the bytes the linear step has to move per RIR (LINEAR_ALG_BYTES_PER_RIR) and, measured,
+        # the PMC traffic of the replayed step's launches (profiles/<tag>_step_traffic.json, tools/make_profiles.py)
+        out['linear_alg_bytes_per_rir'] = LINEAR_ALG_BYTES_PER_RIR
+        out['linear_alg_hbm_frac'] = rirs_per_s / world * LINEAR_ALG_BYTES_PER_RIR / 1e9 / HBM_PEAK_GBS
+        st = step_traffic()
+        if st is not None and use_bank and nbands == len(BAND_CENTRES) and NPER == 4 and not sub_record:
+            out['step_traffic_bytes'] = st['bytes_per_step']
+            out['step_traffic_frac'] = st['bytes_per_step'] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out['step_traffic_source'] = st['source']
         if world == 1 and not args.no_cpu_baseline and not sub_record:
             out['cpu_baseline'] = cpu_baseline(room, delays, filt.cpu().numpy().astype(np.complex128), device=device,
                                                steps=args.cpu_steps)

@@ -1,8 +1,8 @@
 """profiles/<tag>_directional_* from the raw rocprofv3 output of tools/run_dir_measurements.sh (gpurun_out/<tag>_dir_*).
-usage: python tools/make_dir_profiles.py [round_tag]   (default r03)"""
+usage: python tools/make_dir_profiles.py [round_tag]   (default r05)"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 src, dst = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
 
 
@@ -46,9 +46,14 @@ for kind, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     for k, v in acc.items():
         pmc[k][ctr] = sum(v) / len(v)
         pmc[k]['launches'] = len(v)
-with open(os.path.join(dst, f'{tag}_directional_pmc_hbm_bytes.csv'), 'w') as f:
-    f.write('kernel,grid_size,launches,FETCH_SIZE_KB_raw,WRITE_SIZE_KB,read_MB_x2_corrected,write_MB,hbm_traffic_MB\n')
+with open(os.path.join(dst, f'{tag}_directional_pmc_hbm_bytes.csv'), 'w', newline='') as f:
+    # (csv.writer quotes kernel names that carry commas -- `k_em_bwd<9, 12>` unquoted shifted every column, and the bench line
+    # read the write bytes as the traffic)
+    wcsv = csv.writer(f)
+    wcsv.writerow(['kernel', 'grid_size', 'launches', 'FETCH_SIZE_KB_raw', 'WRITE_SIZE_KB', 'read_MB_x2_corrected', 'write_MB',
+                   'hbm_traffic_MB'])
     for (k, g), d in sorted(pmc.items()):
         fe, wr = d.get('FETCH_SIZE', 0.0), d.get('WRITE_SIZE', 0.0)
-        f.write(f"{k},{g},{d['launches']},{fe:.1f},{wr:.1f},{2*fe*1024/1e6:.2f},{wr*1024/1e6:.2f},{(2*fe+wr)*1024/1e6:.2f}\n")
+        wcsv.writerow([k, g, d['launches'], f'{fe:.1f}', f'{wr:.1f}', f'{2*fe*1024/1e6:.2f}', f'{wr*1024/1e6:.2f}',
+                       f'{(2*fe+wr)*1024/1e6:.2f}'])
 print(open(os.path.join(dst, f'{tag}_directional_kernels.txt')).read())

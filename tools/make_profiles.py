@@ -1,8 +1,8 @@
 """Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/<tag>_*).
-usage: python tools/make_profiles.py [round_tag] [--pre]   (default r04)"""
+usage: python tools/make_profiles.py [round_tag] [--pre]   (default r05)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 # --pre: the tables bench.py reads at run time only (kernel stats, PMC bytes, timeline, in-step durations) -- run on the
 # GPU box between the profiled runs and the final bench run, so that the bench line is computed from the same call's tables
 PRE = '--pre' in sys.argv[2:]
@@ -33,11 +33,15 @@ for kind, ctr in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
     for k, v in acc.items():
         pmc[k][ctr] = sum(v) / len(v)
         pmc[k]['launches'] = len(v)
-with open(os.path.join(dst, f'{tag}_pmc_hbm_bytes.csv'), 'w') as f:
-    f.write('kernel,grid_size,launches,FETCH_SIZE_KB_raw,WRITE_SIZE_KB,read_MB_x2_corrected,write_MB,hbm_traffic_MB\n')
+with open(os.path.join(dst, f'{tag}_pmc_hbm_bytes.csv'), 'w', newline='') as f:
+    # (csv.writer: template kernels carry commas in their names -- an unquoted `k_em_bwd<9, 12>` shifted every column)
+    wcsv = csv.writer(f)
+    wcsv.writerow(['kernel', 'grid_size', 'launches', 'FETCH_SIZE_KB_raw', 'WRITE_SIZE_KB', 'read_MB_x2_corrected', 'write_MB',
+                   'hbm_traffic_MB'])
     for (k, g), d in sorted(pmc.items()):
         fe, wr = d.get('FETCH_SIZE', 0.0), d.get('WRITE_SIZE', 0.0)
-        f.write(f"{k},{g},{d['launches']},{fe:.1f},{wr:.1f},{2*fe*1024/1e6:.2f},{wr*1024/1e6:.2f},{(2*fe+wr)*1024/1e6:.2f}\n")
+        wcsv.writerow([k, g, d['launches'], f'{fe:.1f}', f'{wr:.1f}', f'{2*fe*1024/1e6:.2f}', f'{wr*1024/1e6:.2f}',
+                       f'{(2*fe+wr)*1024/1e6:.2f}'])
 # 4. one replayed step as a timeline
 tl = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'timeline.py'), os.path.join(src, f'{tag}_stats'), '100'],
                     capture_output=True, text=True).stdout
@@ -49,7 +53,7 @@ open(os.path.join(dst, f'{tag}_graph_step_timeline.txt'), 'w').write(
 trace = one(f'{tag}_stats/**/*kernel_trace.csv')
 trows = list(csv.DictReader(open(trace)))
 trows.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(trows) if r['Kernel_Name'].startswith('k_adam(')]
+adam = [i for i, r in enumerate(trows) if r['Kernel_Name'].startswith('k_adam(')]          # (one launch per step)
 lo, hi = adam[60], adam[160]
 nsteps = 100
 agg = collections.defaultdict(lambda: [0, 0.0])
@@ -57,11 +61,39 @@ for r in trows[lo + 1:hi + 1]:
     k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
     agg[k][0] += 1
     agg[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-with open(os.path.join(dst, f'{tag}_step_kernel_durations.csv'), 'w') as f:
-    f.write('kernel,launches_per_step,avg_us_in_step,us_per_step\n')
+with open(os.path.join(dst, f'{tag}_step_kernel_durations.csv'), 'w', newline='') as f:
+    wcsv = csv.writer(f)
+    wcsv.writerow(['kernel', 'launches_per_step', 'avg_us_in_step', 'us_per_step'])
     for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        f.write(f"{k},{cnt / nsteps:.2f},{us / cnt:.2f},{us / nsteps:.2f}\n")
+        wcsv.writerow([k, f'{cnt / nsteps:.2f}', f'{us / cnt:.2f}', f'{us / nsteps:.2f}'])
 step_span = (int(trows[hi]['End_Timestamp']) - int(trows[lo]['End_Timestamp'])) / 1e3 / nsteps
+# 4c. HBM traffic of ONE replayed step: launches per step of every kernel (100 replayed steps of the stats run) x the PMC
+# traffic per launch of the grid it is launched with INSIDE those steps (the same kernels also run on other grids in the
+# one-off dataset precompute) -- what bench.py reports as step_traffic_bytes
+step_grid, step_count = {}, collections.Counter()
+for r in trows[lo + 1:hi + 1]:
+    k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    g = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])
+    step_grid.setdefault(k, collections.Counter())[g] += 1
+    step_count[k] += 1
+per_kernel, tot_step = [], 0.0
+for k, grids in step_grid.items():
+    g = grids.most_common(1)[0][0]
+    d = pmc.get((k, g))
+    if d is None:                      # (a grid the eager PMC runs did not see: the kernel's most frequent grid there)
+        cands = [(v['launches'], v) for (kk, gg), v in pmc.items() if kk == k]
+        d = max(cands, key=lambda c: c[0])[1] if cands else None
+    if d is None:
+        continue
+    mb = (2 * d.get('FETCH_SIZE', 0.0) + d.get('WRITE_SIZE', 0.0)) * 1024 / 1e6
+    per_kernel.append({'kernel': k, 'launches_per_step': step_count[k] / nsteps, 'MB_per_launch': round(mb, 3),
+                       'MB_per_step': round(mb * step_count[k] / nsteps, 3)})
+    tot_step += mb * step_count[k] / nsteps
+per_kernel.sort(key=lambda e: -e['MB_per_step'])
+json.dump({'bytes_per_step': int(tot_step * 1e6), 'source': f'profiles/{tag}_step_traffic.json = sum over the launches of one '
+           f'replayed step of 2 x FETCH_SIZE + WRITE_SIZE per launch (profiles/{tag}_pmc_hbm_bytes.csv, separate --pmc passes) '
+           f'x launches per step (100 replayed steps of the stats run)', 'per_kernel': per_kernel},
+          open(os.path.join(dst, f'{tag}_step_traffic.json'), 'w'), indent=1)
 if PRE:
     sys.exit(0)
 # 5. README
@@ -146,5 +178,7 @@ Algorithmic bytes per launch {dom.get('alg_bytes_per_launch', 0)/1e6:.2f} MB -> 
         tot += mb * c
     for t_, nm, c, mb in sorted(rowsout, reverse=True):
         f.write(f"| `{nm}` | {c} | {mb:.1f} | {t_:.1f} |\n")
-    f.write(f"\nSum over the step's launches: **{tot / 1e3:.2f} GB** (algorithmic: {224 * 2811048 / 1e9:.2f} GB; round 1: 2.47 GB).\n")
+    f.write(f"\nSum over the step's launches: **{tot / 1e3:.2f} GB** (SURVEY section 8d bytes: {224 * 2811048 / 1e9:.2f} GB; what the linear "
+            f"step has to move: {224 * 1165696 / 1e9:.2f} GB; round 4: 0.97 GB; round 1: 2.47 GB).  `{tag}_step_traffic.json` holds the same "
+            f"sum built from 100 replayed steps' launch counts: {tot_step / 1e3:.2f} GB.\n")
 print(open(os.path.join(dst, 'README.md')).read()[-3500:])
