@@ -239,7 +239,7 @@ def build_bank_workload(device, seed: int, centres, num_receivers: int = NUM_REC
     return cpu_leg, sds, bank, trainer, splits
 
 
-def hip_step_at(init, rirs, pos, delays, room, filt_np, keep, device):
+def hip_step_at(init, rirs, pos, delays, room, filt_np, keep, device, want_objects: bool = False):
     """Loss terms and gradients of the TIMED path (one-band bank, explicit step, slot order, pair-interleaved signals)
     at the parameters / batch / EDC mask the CPU baseline starts from: the other side of ``loss_delta_vs_cpu``."""
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
@@ -274,13 +274,15 @@ def hip_step_at(init, rirs, pos, delays, room, filt_np, keep, device):
     for p in opt._params:
         grads[names[id(p)]] = opt.flat_grad[off:off + p.numel()].detach().cpu().double().numpy().copy()
         off += p.numel()
+    if want_objects:
+        return losses, grads, tr, bank, sds
     return losses, grads
 
 
-def cpu_baseline(room, delays, filt_np, steps: int = 2, device=None):
-    """The same optimiser step on the host cores with the CPU oracle (reference restatement); with ``device`` also
-    the loss terms and gradients of the timed HIP path on the same parameters, batch and EDC mask
-    (``loss_delta_vs_cpu``, the metric's "EDR loss delta vs ref")."""
+def cpu_reference_step(room, delays, filt_np, steps: int = 2):
+    """``steps`` + 1 optimiser steps of ONE band on the host cores with the CPU oracle (the first is the warm-up and the one
+    whose loss terms and gradients are kept).  Returns a dict: times (s per step), first (loss terms), keep0 (EDC mask),
+    grads0 (gradients at the initial, normalized parameters), init (those parameters), rirs / pos (the batch), cores."""
     from oracle import gfdn_oracle as orc
     from oracle.cpu_trainer import OracleGridTrainer
     cores = min(CPU_BASELINE_THREADS, os.cpu_count() or 1)
@@ -336,6 +338,18 @@ def cpu_baseline(room, delays, filt_np, steps: int = 2, device=None):
                       'output_gains': p.output_gains.grad.reshape(-1).double().numpy().copy(),
                       'M': p.M.grad.reshape(-1).double().numpy().copy(),
                       'mlp': torch.cat(packed).double().numpy().copy()}
+    return {'times': times, 'first': first, 'keep0': keep0, 'grads0': grads0, 'init': init, 'rirs': rirs, 'pos': pos[idx],
+            'cores': cores}
+
+
+def cpu_baseline(room, delays, filt_np, steps: int = 2, device=None):
+    """The same optimiser step on the host cores with the CPU oracle (reference restatement); with ``device`` also
+    the loss terms and gradients of the timed HIP path on the same parameters, batch and EDC mask
+    (``loss_delta_vs_cpu``, the metric's "EDR loss delta vs ref")."""
+    ref = cpu_reference_step(room, delays, filt_np, steps)
+    times, first, keep0, grads0, init, rirs, cores = (ref[k] for k in ('times', 'first', 'keep0', 'grads0', 'init', 'rirs',
+                                                                         'cores'))
+    pos_idx = ref['pos']
     sec = float(np.mean(times[1:]))
     out = {'value': BATCH * FRAMES / sec, 'unit': 'RIR-frames/s', 'cores': cores, 'kind': 'port',
            'host_cpu': host_cpu_model(), 'host_logical_cpus': os.cpu_count(),
@@ -347,7 +361,7 @@ def cpu_baseline(room, delays, filt_np, steps: int = 2, device=None):
                      '(SURVEY §8d "targets precomputed once")',
            'sec_per_step': sec}
     if device is not None:
-        ours, g_hip = hip_step_at(init, rirs, pos[idx], delays, room, filt_np, keep0, device)
+        ours, g_hip = hip_step_at(init, rirs, pos_idx, delays, room, filt_np, keep0, device)
         delta = {k: {'cpu': first[k], 'hip': ours[k], 'rel': abs(ours[k] - first[k]) / abs(first[k])}
                  for k in ('edr_loss', 'edc_loss', 'spectral_loss', 'sparsity_loss')}
         tot_c, tot_h = sum(first.values()), sum(ours.values())
