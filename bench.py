@@ -76,17 +76,14 @@ ALG_BYTES_PER_RIR = 2811048
 # (32 x 2049 x 8 B) and on the EDC window (4 x 47 360 B), the target EDR (32 x 2049 x 4 B) and the target EDC (4 x 47 360 B);
 # everything else of the step is per band (group signals, records), not per receiver
 LINEAR_ALG_BYTES_PER_RIR = FRAMES * NF * (8 + 4) + 2 * 4 * EDC_LEN          # = 1 165 696
-# Dominant HBM-bound kernel of the step since round 4: the EDR loss on composed short-time spectra (csrc/edrlin.hip,
-# k_edr_lin_band), one launch per step.  Per RIR it MUST read the STFT of the receiver's transformed direct path (32 frames
-# x 2049 bins x 8 B) and the target EDR (x 4 B) = 786 816 B; the band's group spectra in and the band's gradient spectra out
-# (29 MB per launch together) are shared by the band's 32 receivers and NOT counted.  (GFDN_EDR_ONE_LAUNCH=0: the two-launch
-# form k_edr_lin_cols + k_edr_lin_gsum, which also writes and re-reads dL/d|S|^2.)
-DOMINANT_KERNEL = (('k_edr_lin_wave' if os.environ.get('GFDN_EDR_FORM', '1') == '1' else 'k_edr_lin_band')
-                   if os.environ.get('GFDN_EDR_ONE_LAUNCH', '1') == '1' else 'k_edr_lin_cols')
+# Dominant HBM-bound kernel of the step since round 4: the EDR loss on composed short-time spectra with the sums over the
+# band's receivers (csrc/edrlin.hip, k_edr_lin_wave), one launch per step.  Per RIR it MUST read the STFT of the receiver's
+# transformed direct path (32 frames x 2049 bins x 8 B) and the target EDR (x 4 B) = 786 816 B; the band's group spectra in
+# and the band's gradient spectra out (29 MB per launch together) are shared by the band's 32 receivers and NOT counted.
+DOMINANT_KERNEL = 'k_edr_lin_wave'
 # Algorithmic HBM bytes per RIR and launch of the step's per-receiver kernels (what each MUST read and write):
 ALG_BYTES_PER_UNIT = {
-    'k_edr_lin_band': FRAMES * NF * (8 + 4),                                   # Sd, target EDR in (the G sums out: per band)
-    'k_edr_lin_wave': FRAMES * NF * (8 + 4),                                   # (the same launch without barriers)
+    'k_edr_lin_wave': FRAMES * NF * (8 + 4),                                   # Sd, target EDR in (the G sums out: per band)
     'k_edr_lin_cols': FRAMES * NF * (8 + 4 + 4),                               # Sd, target EDR in; dL/d|S|^2 out
     'k_edr_lin_gsum': FRAMES * NF * (8 + 4),                                   # Sd, dL/d|S|^2 in (the G sums out: per band)
     'k_edc_pair_segsum': 4 * EDC_LEN + 4 * EDC_LEN,                            # direct path in, composed window samples out
@@ -96,7 +93,7 @@ ALG_BYTES_PER_UNIT = {
     # round 5: the EDC term in one launch per receiver (csrc/edcone.hip) and the light sum over the band's receivers
     'k_edc_lin_one': 3 * 4 * EDC_LEN,                                          # direct path, target EDC in; dL/dx (window) out
     'k_lin_gamma_win': 4 * EDC_LEN,                                            # dL/dx (window) in (the G sums out: per band)
-    # (kernels of the stored-signal paths, GFDN_SPECTRAL_EDR=0 / GFDN_LINEAR=0, kept for the A/B runs)
+    # (kernels of the stored-signal paths: FusedBankStep.spectral_edr / linear_transforms = False)
     'k_blu_col128_fwd': (8 * KU + 4 * 65536 + 4 * K + 4 * 65536) // 2,
     'k_blu_row512': 2 * 8 * 65536 // 2,
     'k_blu_col128_inv': (4 * 65536 + 4 * K + 4 * 65536 + 8 * KU) // 2,
@@ -410,7 +407,7 @@ def step_traffic():
 
 
 # kernels whose unit is a SIGNAL of the launch, not a RIR: in the linear step (the default) the transforms run on the bands'
-# G group signals (nbands x G per launch), with GFDN_LINEAR=0 on the receivers' signals
+# G group signals (nbands x G per launch), on the stored-signal path on the receivers' signals
 SIGNAL_KERNELS = ('k_blu_col128_fwd', 'k_blu_row512', 'k_blu_col128_inv')
 
 
@@ -460,7 +457,7 @@ def isolated_kernel_us(device, data, trainer, rows, nbands, iters: int = 30):
     rgain = torch.rand(items, G, device=device)
     nch = ops.lin_gamma_dots_tiles(K)
     one = trainer._fused.edr_one_launch
-    parts = torch.empty((items * G, nch + ops.edr_lin_parts(NF, fused=one, form=trainer._fused.edr_band_form)),
+    parts = torch.empty((items * G, nch + ops.edr_lin_parts(NF, fused=one)),
                         dtype=torch.float32, device=device)
     T_edr, sum_abs = (data.edr_target_tiled() if tiled else data.edr_store[1]), data.edr_store[2]
     ops.kernel_timer.watch = DOMINANT_KERNEL
@@ -468,8 +465,7 @@ def isolated_kernel_us(device, data, trainer, rows, nbands, iters: int = 30):
     for _ in range(iters):
         if one:
             ops.edr_lin_loss_gsum(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, dots=parts, col0=nch, tiled=tiled,
-                                  nsplit=trainer._fused._edr_runs(nbands, items // nbands),
-                                  form=trainer._fused.edr_band_form)
+                                  nsplit=trainer._fused._edr_runs(nbands, items // nbands))
         else:
             ops.edr_lin_loss(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, True, dots=parts, col0=nch, tiled=tiled)
     return ops.kernel_timer.stop()
@@ -735,8 +731,6 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no HIP graph)')
     ap.add_argument('--pipe-steps', type=int, default=None,
                     help='steps per graph of the pipelined chain (even; 0: one step per graph); default: the trainer\'s')
-    ap.add_argument('--chain-steps', type=int, default=None,
-                    help='explicit bank steps per replayed graph (GraphedTrainStep.chain_steps; default: the trainer\'s)')
     ap.add_argument('--per-step-copy', action='store_true',
                     help='hand every step its receivers by a host copy in front of the replay (diagnostic; default: the '
                          'batches go to the device as one schedule)')
@@ -1019,8 +1013,6 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
         step = trainer.graphed(data, b_local)      # normalize + train_step as ONE HIP-graph replay
         if args.pipe_steps is not None:
             step.pipe_steps = args.pipe_steps
-        if args.chain_steps is not None:
-            step.chain_steps = args.chain_steps
         draws = ([draw_n(b_local) for _ in range(args.warmup)], [draw_n(b_local) for _ in range(args.steps)])
         spread = {}
         elapsed, parts = timed_steps(step, draws, args, world, device, eager=args.eager, per_step_copy=args.per_step_copy,

@@ -127,9 +127,6 @@ SIGNATURES = {
     "gfdn_stft_power_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gfdn_stft_power_pairs_bwd_phase": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
-    "gfdn_stft_power_pairs_bwd_planar": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P]),
-    "gfdn_decay_items_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, c_float,
-                                     c_float, c_int, _P, _P, _P, _P, _P]),
     "gfdn_edc_loss_pairs": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),
@@ -173,7 +170,6 @@ SIGNATURES = {
     "gfdn_edc_loss_model": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_draw_mask": (c_int, [ctypes.c_ulonglong, _P, c_int, c_float, _P, _P]),
     "gfdn_lin_gain_chunks": (c_int, [c_int]),
-    "gfdn_stft_power_pairs_lin": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_lin_combine_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "gfdn_lin_gamma": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, c_int, _P]),
     "gfdn_lin_gamma_dots_tiles": (c_int, [c_int]),
@@ -182,13 +178,12 @@ SIGNATURES = {
     "gfdn_stft_pairs_spectrum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "gfdn_stft_pairs_spectrum_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
     "gfdn_edr_lin_parts": (c_int, [c_int]),
-    "gfdn_edr_lin_fused_parts": (c_int, [c_int]),
     "gfdn_edr_lin_loss": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, c_int,
                                   c_int, c_int, _P]),
     "gfdn_edr_lin_gsum": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "gfdn_edr_lin_loss_gsum": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, _P,
-                                       c_int, c_int, _P, c_int, c_int, c_int, _P]),
-    "gfdn_edr_lin_band_parts": (c_int, [c_int, c_int]),
+                                       c_int, c_int, _P, c_int, c_int, _P]),
+    "gfdn_edr_lin_band_parts": (c_int, [c_int]),
     "gfdn_edc_loss_pairs_lin": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int,
                                         _P, _P, c_int, c_float, c_float, _P, _P, c_int, _P, _P, _P]),
     "gfdn_irfft_odd_time_slots": (c_int, [c_int, _P]),

@@ -23,7 +23,6 @@ accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve
 path of ``BandBankTrainer._step_losses`` (per-bin elimination kernels) stays as the general fallback and as the
 cross-check of this one (tests/test_gpu_bank.py).
 """
-import os
 from typing import Dict, Optional
 
 import torch
@@ -115,33 +114,28 @@ class FusedBankStep:
         if self._rec is not None and not self.records_ok():
             self.prime_records()
 
-    # 2: the loss middle as two half-batch chains on two streams.  Measured on the 7-band step: 0.692 vs 0.705 ms
-    # (-2 %) for 13 more launches -- the chains run in phase, each kind of unit stays contended -- so it is off.
-    halves = 1
-
+    # ---- forms of the step.  Plain class attributes: the defaults are the timed path; tests switch single ones off to check a
+    # form against the one it replaced (tests/test_gpu_bank.py, tests/test_gpu_fullsize.py).  What was measured and did not
+    # pay is described in DESIGN.md section 4.3, not kept here.
+    #
     # The output stage in the TIME domain (csrc/linear.hip): the inverse transform is linear and neither the group transfer
     # functions nor the band's filter depend on the receiver, so x[b] = xd[row_b] + sum_g rgain[b][g] irfft(s_g T_g filt) with
     # xd = irfft(direct filt) a constant of the dataset (BandStackedDataset.direct_time).  A step then runs G forward and G
     # adjoint transforms per band instead of one per receiver (28 instead of 224 at the north-star size), dL/drgain is a
-    # dot product over the time samples and the records pass reads G adjoint spectra per band.  Supersedes the folded
-    # output stage below, which stays as the cross-check (tests/test_gpu_bank.py) and for chained steps (``pipe``).
-    linear_transforms = os.environ.get('GFDN_LINEAR', '1') == '1'
+    # dot product over the time samples and the records pass reads G adjoint spectra per band.  Off: the folded output
+    # stage below (round 3's path; also what receiver counts outside the linear kernels' limits and chained steps take).
+    linear_transforms = True
     # ... and the EDR loss on linearly COMPOSED short-time spectra (csrc/edrlin.hip): the STFT is linear too, so a receiver's
     # spectrum is Sd[row] + sum_g rgain[b][g] STFT(tau_g) with Sd a constant of the dataset (BandStackedDataset.direct_stft).
     # A step runs G forward and G adjoint STFTs per band; per receiver only streaming arithmetic on (frame, frequency) cells
-    # is left, the EDC scans form their samples on the fly (gfdn_edc_loss_pairs_lin) and the receivers' signals are never
-    # stored.
-    spectral_edr = os.environ.get('GFDN_SPECTRAL_EDR', '1') == '1'
-    # ... with the sum of the gradient spectra over the band's receivers inside the EDR launch (k_edr_lin_band: a thread owns
+    # is left and the receivers' signals are never stored.
+    spectral_edr = True
+    # ... with the sum of the gradient spectra over the band's receivers inside the EDR launch (k_edr_lin_wave: a thread owns
     # cells of the band's plane and walks the receivers; dL/d|S|^2 never exists, the direct-path spectra are read once), the
-    # band's receivers cut into ``edr_receiver_runs`` runs for more loads in flight
-    edr_one_launch = os.environ.get('GFDN_EDR_ONE_LAUNCH', '1') == '1'
-    # (0 = by the number of bands: the launch has 33 frequency tiles x bands x runs workgroups and wants about two per CU --
-    # 2 runs for the 7-band bank, 16 for a single band)
-    edr_receiver_runs = int(os.environ.get('GFDN_EDR_RUNS', '0'))
-    # form of that launch: 0 = k_edr_lin_band (64 frequencies x 8 waves of 4 frames; LDS exchanges, two barriers per receiver),
-    # 1 = k_edr_lin_wave (a wave = 8 frequencies x all frames; the scans inside the wave, no LDS, no barriers)
-    edr_band_form = int(os.environ.get('GFDN_EDR_FORM', '1'))
+    # band's receivers cut into runs for more loads in flight.  Off: the value-only column kernel + the sum as two launches
+    # (the cross-check form)
+    edr_one_launch = True
+    edr_receiver_runs = 0         # (0 = by the number of bands: about two workgroups per CU -- 2 runs for 7 bands, 16 for one)
 
     def _edr_runs(self, nbands: int, B: int) -> int:
         if self.edr_receiver_runs > 0:
@@ -152,59 +146,42 @@ class FusedBankStep:
         return runs
     # ... on planes stored in the tiled cell order (frequency blocks of 256, a block's frames contiguous): what a (receiver,
     # frequency block) workgroup of the EDR kernel touches is one contiguous run
-    tiled_spectra = os.environ.get('GFDN_TILED_SPECTRA', '1') == '1'
+    tiled_spectra = True
     # ... and the G sums of the EDC gradient signals together with the EDC part of dL/drgain in one sweep over the window
-    gamma_dots_one_launch = os.environ.get('GFDN_GAMMA_DOTS_ONE_LAUNCH', '1') == '1'
+    gamma_dots_one_launch = True
     # ... and the adjoint STFT of the gradient spectra as ONE launch for all frames (odd frames to a second signal set that the
     # gamma sweep adds) instead of the even-frame launch with the odd-frame launch behind it
-    adjoint_stft_one_launch = os.environ.get('GFDN_ADJ_STFT_ONE_LAUNCH', '1') == '1'
-    # ... with the combine pass folded into the STFT's load (gfdn_stft_power_pairs_lin): x is stored by the launch that
-    # first reads it.  Measured same-box: 0.565 against 0.549 ms -- the fused launch takes 73 us against 46 + 42, but the EDC
-    # scans, which ran beside the STFT and the EDR kernel, now start behind it and run beside the STFT adjoint instead
-    # (even-frame launch 50 -> 86 us)
-    combine_in_stft = os.environ.get('GFDN_COMBINE_IN_STFT', '0') == '1'      # (OFF: measured slower, see below)
+    adjoint_stft_one_launch = True
 
     # Round 5.  (a) The EDC term as ONE register-resident launch per receiver (csrc/edcone.hip: compose, both scans, dB stage,
     # dL/dx and the EDC part of dL/drgain without staging the window samples or dL/dEDC through memory) and the light gamma
-    # sweep behind it (no dot products left to do) in place of the three scan launches + gfdn_lin_gamma_dots.
-    edc_one_launch = os.environ.get('GFDN_EDC_ONE', '1') == '1'
+    # sweep behind it (no dot products left to do) in place of the three scan launches + gfdn_lin_gamma_dots (which stay
+    # for windows beyond the launch's 49 152 samples).
+    edc_one_launch = True
     # (b) normalize OFF the critical chain: T is bilinear in b, c and the transform is linear, so the normalisation scale can
     # join the group signals where the forward transform's LAST pass stores them.  The energy pass then runs on the side
     # stream beside the group responses and the transform's first two passes instead of in front of them (~28 us of chain).
-    scale_late = os.environ.get('GFDN_SCALE_LATE', '1') == '1'
+    scale_late = True
     # (c) tail and head as one launch (single process): records -> parameter gradients -> Adam on the blocks' own M, b, c
     # -> the NEXT step's Q, QQ and record sets (csrc/blocktf.hip k_tf_tail); the gain network's range of the flat buffers is
     # stepped on the side stream behind its own backward.  A step then starts with the group responses.
-    fused_tail = os.environ.get('GFDN_FUSED_TAIL', '1') == '1'
+    fused_tail = True
     # (d) the EDC part of dL/dtau summed over the band's receivers on the side stream, straight behind the EDC launch; the
     # main chain merges it with the adjoint STFT's two signal sets (three small arrays) into the transform's slot order
-    gamma_split = os.environ.get('GFDN_GAMMA_SPLIT', '1') == '1'
-    colorless_at_tail = os.environ.get('GFDN_COLORLESS_TAIL', '0') == '1'      # (OFF: measured 0.375 against 0.357 ms -- it stretches the adjoint transform's passes)
+    gamma_split = True
 
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
-    # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back.
+    # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back
+    # (the stored-signal path, linear_transforms = False).
     fold_output_stage = True
     # The mirror image -- the gains pass of the adjoint inside the LAST pass of the adjoint transform
     # (gfdn_irfft_odd_pairs_gains_bwd: dL/dH used while it is in registers) -- is OFF: measured 0.676 against 0.664 ms.
-    # The gains pass it removes runs beside the records pass on the side stream, off the main chain, while the
-    # accumulation lengthens a pass that is ON it.
     fold_gains = False
-    gain_rows_in_mlp = os.environ.get('GFDN_GAIN_ROWS_IN_MLP', '1') == '1'
-    colorless_behind_scans = os.environ.get('GFDN_COLORLESS_LATE', '1') == '1'      # (blocks of 5..8 lines)
-    # (blocks of <= 4 lines on the spectral-EDR step: behind the scans as well.  In front of them: 0.387-0.390 against
-    # 0.392-0.393 ms on one box, 0.394-0.396 against 0.392-0.398 on another -- inside the noise, the position stays)
-    colorless_late_small = os.environ.get('GFDN_COLORLESS_LATE_SMALL', '1') == '1'
-    # ... or on a stream of its own, started as soon as the normalisation is known, so that the VALU-bound pass runs beside
-    # the transforms of the group signals and the memory-bound middle instead of beside the gamma sweep, the adjoint
-    # transform and the records pass at the tail of the critical chain.  OFF: measured same-box 0.393 -> 0.418-0.424 ms at
-    # N = 16 and 0.702 -> 0.784 ms at N = 32 -- what it takes from the head of the chain (group responses, the latency-bound
-    # 28-signal transforms) is more than what it gives back at the tail
-    colorless_own_stream = os.environ.get('GFDN_COLORLESS_STREAM', '0') == '1'
+    gain_rows_in_mlp = True
+    colorless_behind_scans = True      # (blocks of 5..8 lines: the colorless pass behind the EDC launches)
+    colorless_late_small = True        # (blocks of <= 4 lines on the spectral-EDR step: behind them as well)
     # the optimiser update on the side stream behind the gain network's backward (single process)
-    adam_on_side = os.environ.get('GFDN_ADAM_ON_SIDE', '1') == '1'
-    # STFT -> EDR and the EDC term as ONE launch, one workgroup per item (gfdn_decay_items_fwd) instead of the pair STFT,
-    # the EDR column kernel and the three EDC scans.
-    fuse_decay = os.environ.get('GFDN_FUSE_DECAY', '0') == '1'      # (OFF: measured slower; the switch is for same-box A/B runs)
+    adam_on_side = True
 
     def _eye_rows(self, nb: int, G: int, device) -> torch.Tensor:
         """(nb * G, G): "receiver" g of every band with gain 1 on group g -- what turns the output-stage kernels into
@@ -234,29 +211,6 @@ class FusedBankStep:
         else:
             x = ops.irfft_odd_fwd(H, K, slots=order is not None)
         ev['x'].record()
-        if pairs and self.fuse_decay and win == 4096 and start + length <= x.shape[1] and item_len is None:
-            # ONE launch per item for STFT -> EDR and the whole EDC term (csrc/decay.hip): |STFT|^2 never reaches memory,
-            # the EDR kernel and the three EDC scans do not run; the EDC gradient comes back planar and joins in the
-            # odd-frame launch of the STFT adjoint
-            main.wait_event(ev['mask'])
-            gP, li_edr, li_edc, dxe = ops.decay_items_fwd(x, Btot, win, T_edr, sum_abs, rows, None, cfg.edr_loss_weight,
-                                                          start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train)
-            ev['edc'].record()
-            keep.extend((x, gP, li_edr, li_edc, dxe))
-            gH = None
-            if train:
-                g = ops.stft_power_pairs_bwd_planar(x, Btot, win, gP, 0)
-                ops.stft_power_pairs_bwd_planar(x, Btot, win, gP, 1, out=g, base=dxe, start=start)
-                ev['g'].record()
-                if gains is not None:
-                    gH, self._gpart = ops.irfft_odd_pairs_bwd(g, K, Btot, gains=gains)
-                    keep.append(self._gpart)
-                else:
-                    gH = ops.irfft_odd_pairs_bwd(g, K, Btot)
-                keep.extend((g, gH))
-            else:
-                ev['g'].record()
-            return li_edr, li_edc, gH
         if pairs:
             if P is None:
                 P = ops.stft_power_pairs(x, Btot, win)
@@ -328,8 +282,7 @@ class FusedBankStep:
         parts = None
         if train:
             # partial rows of dL/drgain: [EDC dot products | EDR columns]; the gain network's backward sums them
-            parts = torch.empty((Btot * G, nch + ops.edr_lin_parts(win // 2 + 1, fused=self.edr_one_launch,
-                                                                   form=self.edr_band_form)),
+            parts = torch.empty((Btot * G, nch + ops.edr_lin_parts(win // 2 + 1, fused=self.edr_one_launch)),
                                 dtype=torch.float32, device=rows.device)
         Stau = ops.stft_pairs_spectrum(tau, nb * G, win, tiled=tiled)
         with on_side2():
@@ -354,8 +307,7 @@ class FusedBankStep:
         gP = Gs = None
         if train and self.edr_one_launch:
             li_edr, Gs = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, dots=parts,
-                                               col0=nch, tiled=tiled, nsplit=self._edr_runs(nb, Btot // nb),
-                                               form=self.edr_band_form)
+                                               col0=nch, tiled=tiled, nsplit=self._edr_runs(nb, Btot // nb))
         else:
             li_edr, gP = ops.edr_lin_loss(Sd, rows, Stau, rgain, nb, T_edr, sum_abs, cfg.edr_loss_weight, train,
                                           dots=parts, col0=nch, tiled=tiled)
@@ -377,54 +329,6 @@ class FusedBankStep:
 
     def _edc_one(self, length: int, G: int) -> bool:
         return self.edc_one_launch and self.gamma_dots_one_launch and ops.edc_lin_one_supported(length, G)
-
-    def _decay_middle_halves(self, H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start, length, ev, main, side,
-                             side2):
-        """The same kernels on two halves of the batch as two independent chains (first half on the main stream, second
-        on ``side``): every stage of the middle is either memory-bound (transform passes, EDR columns, EDC scans) or
-        VALU-bound (the 4096-point FFTs of the STFT and its adjoint), and two chains out of step fill one kind of unit
-        with the other chain's other kind of work.  Items are independent through the whole middle (pairs do not
-        straddle the halves): the numbers are those of the single chain."""
-        tr, cfg, keep = self.tr, self.tr.config, self._keep
-        Btot, win = H.shape[0], tr.stft_win
-        h = Btot // 2
-        ldx = H.shape[1]
-        li_edr = torch.empty((Btot, ops.edr_partial_cols(Btot, win // 2 + 1)), dtype=torch.float32, device=H.device)
-        li_edc = torch.empty(Btot, dtype=torch.float32, device=H.device)
-        gH = torch.empty((Btot, ldx), dtype=torch.complex64, device=H.device) if train else None
-        ev_h, ev_b = ev['h'], torch.cuda.Event()          # (ev['h']: H complete)
-
-        def chain(lo):
-            Hh, rw = H[lo:lo + h], rows[lo:lo + h].contiguous()
-            x = ops.irfft_odd_fwd(Hh, K, slots=True, pairs=True)
-            P = ops.stft_power_pairs(x, h, win)
-            le = ops.edr_loss(P, T_edr, sum_abs, None, cfg.edr_loss_weight, train, rows=rw, defer=True,
-                              out=li_edr[lo:lo + h])
-            lc, g_edc = ops.edc_loss_pairs(x, h, start, length, T_edc, maskw, inv, cfg.edc_loss_weight, train, rows=rw,
-                                           out=li_edc[lo:lo + h])
-            keep.extend((x, P, le, lc, g_edc, rw))
-            if train:
-                g = ops.stft_power_pairs_bwd(x, h, win, P, base=g_edc, out=g_edc)
-                ops.irfft_odd_pairs_bwd(g, K, h, out=gH[lo:lo + h])
-
-        # (first half captured first: it keeps the main chain's hardware queue; the mask is drawn on side2 at the head
-        # of the step, both chains read it)
-        main.wait_event(ev['mask'])
-        chain(0)
-        if self.halves == 3:             # (debug: both chains on the main stream)
-            chain(h)
-        else:
-            with torch.cuda.stream(side):
-                torch.cuda.current_stream().wait_event(ev_h)
-                torch.cuda.current_stream().wait_event(ev['mask'])
-                chain(h)
-                ev_b.record()
-            main.wait_event(ev_b)
-        ev['x'].record()
-        ev['edc'].record()
-        ev['g'].record()
-        keep.extend((li_edr, li_edc, gH))
-        return li_edr, li_edc, gH
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -465,8 +369,8 @@ class FusedBankStep:
         order = ops.irfft_slot_order(K, z.device) if (tr.use_slot_order and 'dataset' in data) else None
         Ku = (K + 1) // 2 if K % 2 == 1 else K
         # (receiver counts beyond what the sums over a band's receivers take fall through to the stored-signal chain)
-        lin = (self.linear_transforms and pipe is None and self.halves < 2 and ops.lin_supported(Btot // nb, G)
-               and hasattr(data.get('dataset'), 'direct_time') and not (self.fuse_decay or self.fold_gains))
+        lin = (self.linear_transforms and pipe is None and ops.lin_supported(Btot // nb, G)
+               and hasattr(data.get('dataset'), 'direct_time') and not self.fold_gains)
         if lin:
             zu, direct = (data['dataset'].slot_grid(*order) if order is not None else z[:Ku]), None
         elif order is not None:
@@ -571,7 +475,7 @@ class FusedBankStep:
                 main.wait_event(pipe.ready)
 
         fold = (self.fold_output_stage and pairs and K == 65537 and (Btot // nb) % 2 == 0 and G <= 4
-                and self.halves < 2 and not lin)
+                and not lin)
         # the receiver gains come from the side stream: with the output stage folded into the transform the transfer-function
         # launch below does not read them, and the wait goes behind it -- by then the event was signalled long ago (a wait on
         # a signalled event is free; in front of the launch the idle main stream paid a cross-queue wake-up of ~12 us)
@@ -607,8 +511,6 @@ class FusedBankStep:
 
             def x_fn():
                 wait_gains()
-                if pairs and tau_pairs and self.combine_in_stft and win == 4096 and not self.fuse_decay:
-                    return ops.stft_power_pairs_lin(xd, rows, tau, rgain, nb, K, win)
                 return ops.lin_combine_fwd(xd, rows, tau, rgain, nb, K, tau_pairs, pairs)
             keep.extend((tau, xd))
         elif big:
@@ -644,13 +546,10 @@ class FusedBankStep:
         # lines: in front of the scans, beside the output stage and the transform (behind the scans it ran beside the STFT
         # adjoint: same step time either way, measured).  Blocks of 5..8 lines: BEHIND the scans -- the pass takes ~200 us
         # there, and in front of them the EDC gradient reached the odd-frame launch of the STFT adjoint late
-        own_cl = (self.colorless_own_stream and side is not None and pipe is None
-                  and not (self.halves >= 2 and pairs and Btot % 4 == 0 and item_len is None))
-        on_cl = on_side if own_cl else on_side2
 
         def colorless_pass():
-            with on_cl():
-                if not (late and not own_cl):      # (recorded on this very stream: no wait -- a captured wait of a stream
+            with on_side2():
+                if not late:                       # (recorded on this very stream: no wait -- a captured wait of a stream
                     torch.cuda.current_stream().wait_event(ev['norm'])      # for its own event is asking for trouble)
                 if big:
                     torch.cuda.current_stream().wait_event(ev_ts)
@@ -670,32 +569,24 @@ class FusedBankStep:
         # (spectral-EDR step: the same holds for the small blocks -- in front of the scans the VALU-bound pass ran beside the
         # latency-bound transforms of the G group signals, which sit on the critical chain: 18.6 against 9.6 us for the
         # row pass; behind them it runs beside the memory-bound EDR kernels)
-        late_colorless = (big or (spec and self.colorless_late_small)) and self.colorless_behind_scans and not own_cl
+        late_colorless = (big or (spec and self.colorless_late_small)) and self.colorless_behind_scans
         if not late_colorless:
             grec_sub, out3, gQ = colorless_pass()
 
         # ---- decay losses: irfft -> STFT -> EDR -> STFT adjoint -> irfft adjoint, EDC scans beside them
         ev['h'].record()
-        want_halves = self.halves >= 2 and pairs and Btot % 4 == 0 and side is not None and item_len is None
         spec_bw = None
         if spec:
             li_edr, li_edc, spec_bw = self._decay_middle_spec(data, K, rows, rgain, tau, xd, maskw, inv, train, T_edr,
                                                               sum_abs, T_edc, start, length, item_len, nb, G, ev, main,
                                                               side2, wait_gains)
             gH = None
-        elif want_halves:
-            li_edr, li_edc, gH = self._decay_middle_halves(H, K, rows, maskw, inv, train, T_edr, sum_abs, T_edc, start,
-                                                           length, ev, main, side, side2)
         else:
             li_edr, li_edc, gH = self._decay_middle(H, K, rows, maskw, inv, train, order, pairs, T_edr, sum_abs, T_edc,
                                                     start, length, ev, main, side2, x_fn=x_fn, Btot=Btot,
                                                     gains=(Tq, filt, nb, G) if (fold and train and self.fold_gains) else None,
                                                     item_len=item_len, Bper=Btot // nb, lin=lin)
-        # (e) ... or at the TAIL: behind the merge of dL/dtau, beside the adjoint transforms and the records pass (launches of a
-        # few workgroups) instead of beside the adjoint STFT and the merge, which it stretched (32 against 20 us, 16 against 8)
-        tail_colorless = (late_colorless and self.colorless_at_tail and train and lin and spec and not big
-                          and self.gamma_dots_one_launch)
-        if late_colorless and not tail_colorless:
+        if late_colorless:
             grec_sub, out3, gQ = colorless_pass()
         def report():
             """the reported sums and total (off the gradient path)"""
@@ -736,10 +627,6 @@ class FusedBankStep:
                         gam = ops.lin_gamma(gsig, rgain, nb, K, True, True, slot_of_time=sot, base=gam_edr)
                     ev_gam = torch.cuda.Event()
                     ev_gam.record()
-                    if tail_colorless:
-                        with on_side2():
-                            torch.cuda.current_stream().wait_event(ev_gam)
-                        grec_sub, out3, gQ = colorless_pass()
                 else:
                     gsig, gsig_b = gH
                     gam = ops.lin_gamma(gsig, rgain, nb, K, pairs, tau_pairs, gxb=gsig_b, slot_of_time=sot)
@@ -761,8 +648,6 @@ class FusedBankStep:
                     torch.cuda.current_stream().wait_event(ev_gam)           # (behind the EDR launch as well)
                 else:
                     torch.cuda.current_stream().wait_event(ev['g'])
-                if own_cl:
-                    torch.cuda.current_stream().wait_event(ev['side'])       # (the colorless terms the totals include)
                 sums, total = report()
                 if allreduce is not None:
                     # data-parallel: this rank's loss terms ride the gradient bucket -- [EDR | EDC | colorless share]
@@ -863,8 +748,6 @@ class FusedBankStep:
         else:
             with on_side2():
                 torch.cuda.current_stream().wait_event(ev['g'])
-                if own_cl:
-                    torch.cuda.current_stream().wait_event(ev['side'])
                 sums, total = report()
         keep.extend((sums, total))
         if nb > 1:

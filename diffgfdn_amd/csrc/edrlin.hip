@@ -12,7 +12,7 @@
 //                    dL/dgain[b][g] = Re sum_cells conj(Stau_g) dL/dS,  dL/dS = 2 gP S   (tail sums of Re(conj(Stau_g) S))
 //   k_edr_lin_gsum : per (band, cell): Gsum_g = sum_b gain[b][g] dL/dS[b] -- the G gradient spectra per band whose adjoint
 //                    STFT (k_stft4k_pair_spec_bwd, 14 signal pairs) is the EDR part of dL/dtau_g
-//   k_edr_lin_band : both of the above in ONE launch (the training step's): threads own cells of the band's plane and walk
+//   k_edr_lin_wave : both of the above in ONE launch (the training step's): threads own cells of the band's plane and walk
 //                    the band's receivers; dL/d|S|^2 never reaches memory, the direct-path spectra are read once
 //   k_stft4k_pair_spec(_bwd) : STFT of pair-interleaved signals to complex one-sided spectra, and its adjoint from
 //                    gradient spectra (the forms of fft.hip's k_stft4k_pair_power(_bwd) without the |.|^2 stage).
@@ -48,7 +48,7 @@ struct EdrLin {
 };
 
 // One thread per (receiver, frequency) column, one descending sweep over the frames (see the body).
-// The training step runs k_edr_lin_band below instead (receivers summed in the launch); this kernel serves the value-only pass
+// The training step runs k_edr_lin_wave below instead (receivers summed in the launch); this kernel serves the value-only pass
 // (validation) and is the cross-check of the tests.
 // (Measured alternatives, same box: the group spectra of a 64-frequency tile staged in LDS for 8 receivers per workgroup --
 // 64 KB, two workgroups per CU -- 175 us against 99; the whole band per workgroup with the receivers' gradient spectra summed
@@ -157,180 +157,30 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
 
 // The same loss with the gradient spectra summed over the band's receivers IN the launch, without dL/d|S|^2 in memory and
 // with the transformed direct paths read once (176 MB per step instead of the 426 MB of k_edr_lin_cols + k_edr_lin_gsum).
-// A thread OWNS cells of the band's (frame, frequency) plane -- lane = one of EDB_FT = 64 frequencies, wave w = the frames
-// 4 w .. 4 w + 3 -- keeps the band's G group spectra of its cells (32 registers) and its share of the G gradient spectra
-// (32 accumulator registers) for the whole launch, and walks the band's receivers: per receiver it loads its 4 cells of the
-// direct-path spectrum and the target, composes S, and the two scans along the frames (tail energy; prefix sums of
-// dL/dE) run inside the thread over its 4 frames and across the 8 waves through two 2 KB LDS exchanges (one barrier each).
+// A thread OWNS cells of the band's (frame, frequency) plane -- four consecutive frames of one frequency -- keeps the band's G
+// group spectra of its cells (32 registers) and its share of the G gradient spectra (32 accumulator registers) for the whole
+// launch, and walks the band's receivers: per receiver it loads its 4 cells of the direct-path spectrum and the target,
+// composes S, and runs the two scans along the frames (tail energy; prefix sums of dL/dE) inside the thread over its 4 frames
+// and across the frame groups inside the WAVE (k_edr_lin_wave below).
 // The receivers are added in index order: bitwise reproducible.  ``nsplit`` > 1: the receivers of a band are cut into nsplit
 // runs handled by different workgroups (more loads in flight), each writing its own partial planes Gsum[split]; the adjoint
 // STFT adds them on load.
 // (Round-4 history: the first fused form -- one receiver per wave, the gradient spectra summed through a 64 KB LDS exchange,
-// the group spectra staged in another 64 KB -- took 213 us at one workgroup per CU)
+// the group spectra staged in another 64 KB -- took 213 us at one workgroup per CU; the second -- the frame scans across
+// eight waves through LDS and two barriers per receiver -- 75 us against this form's 59: DESIGN.md section 4.3.)
 //   part[b][tile]                           : loss partials (sum |T - EDR| of the tile's cells)
 //   dots[(b G + g) ld_dots + col0 + tile]   : partials of the EDR part of dL/dgain[b][g]
-#define EDB_FT 64
-#define EDB_W 8
-#define EDB_Q 4
+#define EDB_Q 4                     // frames per thread
 #define EDB_DB_PER_LOG2 3.0102999566398120f      // 10 log10(x) = EDB_DB_PER_LOG2 log2(x)
-// value v of receiver b: 0 = the loss partial, 1 + g = the partial of dL/dgain[b][g] -- the eight waves' sums in wave order
-__device__ __forceinline__ void edb_flush(const float (*r)[EDL_MAXG + 1], int v, int b, int G, int tile,
-                                          float* __restrict__ part, int ld_part, float* __restrict__ dots, int ld_dots,
-                                          int col0) {
-  float s = 0.f;
-#pragma unroll
-  for (int w2 = 0; w2 < EDB_W; ++w2) s += r[w2][v];
-  if (v == 0) part[(size_t)b * ld_part + tile] = s;
-  else if (dots) dots[((size_t)b * G + (v - 1)) * ld_dots + col0 + tile] = s;
-}
-__global__ __launch_bounds__(EDB_FT * EDB_W, 4) void k_edr_lin_band(EdrLin a, int nframes, int nfreq, float gscale,
-                                                                    float* __restrict__ part, int ld_part,
-                                                                    float* __restrict__ dots, int ld_dots, int col0,
-                                                                    float2* __restrict__ Gsum, int nsplit, int nbands) {
-  __shared__ float exA[EDB_W][EDB_FT], exB[EDB_W][EDB_FT];
-  __shared__ float red[2][EDB_W][EDL_MAXG + 1];             // per receiver parity: the waves' loss / gain-gradient sums
-  const int G = a.G, B = a.B, tile = blockIdx.x, band = blockIdx.y, split = blockIdx.z;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int f = tile * EDB_FT + lane;
-  const bool live = f < nfreq;
-  const int fc = live ? f : nfreq - 1;
-  const size_t cells = (size_t)nframes * nfreq;
-  unsigned cq[EDB_Q];                                       // (cell index inside a plane: 32 bits; the row bases are uniform)
-  bool mv[EDB_Q];
-#pragma unroll
-  for (int q = 0; q < EDB_Q; ++q) {
-    const int m = EDB_Q * w + q;
-    mv[q] = m < nframes;
-    cq[q] = (unsigned)edl_cell(mv[q] ? m : 0, fc, nframes, nfreq, a.tiled);
-  }
-  float2 st[EDL_MAXG][EDB_Q], Ga[EDL_MAXG][EDB_Q];
-#pragma unroll
-  for (int g = 0; g < EDL_MAXG; ++g)
-#pragma unroll
-    for (int q = 0; q < EDB_Q; ++q) {
-      st[g][q] = (g < G && mv[q]) ? (a.Stau + ((size_t)band * G + g) * cells)[cq[q]] : make_float2(0.f, 0.f);
-      Ga[g][q] = make_float2(0.f, 0.f);
-    }
-  const int bper = (B + nsplit - 1) / nsplit;
-  const int b_lo = split * bper, b_hi = b_lo + bper < B ? b_lo + bper : B;
-  // software pipeline: the next receiver's cells are loaded before the current one's dependent chain
-  float2 sn[EDB_Q];
-  float tn[EDB_Q];
-  auto fetch = [&](int bl) {
-    const int b = band * B + bl;
-    const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
-    const float2* sdr = a.Sd + row * cells;
-    const float* tdr = a.Tdb + row * cells;
-#pragma unroll
-    for (int q = 0; q < EDB_Q; ++q) {
-      sn[q] = mv[q] ? sdr[cq[q]] : make_float2(0.f, 0.f);
-      tn[q] = mv[q] ? tdr[cq[q]] : 0.f;
-    }
-  };
-  if (b_lo < b_hi) fetch(b_lo);
-  for (int bl = b_lo; bl < b_hi; ++bl) {
-    const int b = band * B + bl;
-    const size_t row = a.rows ? (size_t)a.rows[b] : (size_t)b;
-    float rg[EDL_MAXG];
-#pragma unroll
-    for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
-    const float gs = gscale / a.sum_abs[row];
-    float2 sv[EDB_Q];
-    float tv[EDB_Q], pw[EDB_Q];
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < EDB_Q; ++q) {
-      sv[q] = sn[q];
-      tv[q] = tn[q];
-#pragma unroll
-      for (int g = 0; g < EDL_MAXG; ++g) {
-        sv[q].x += rg[g] * st[g][q].x;
-        sv[q].y += rg[g] * st[g][q].y;
-      }
-      pw[q] = sv[q].x * sv[q].x + sv[q].y * sv[q].y;
-    }
-    if (bl + 1 < b_hi) fetch(bl + 1);
-#pragma unroll
-    for (int q = EDB_Q - 1; q >= 0; --q) tot += pw[q];
-    exA[w][lane] = tot;
-    __syncthreads();
-    // (behind this barrier every wave has left the previous receiver's sums in red[(bl - 1) & 1]: one thread per value adds
-    // the eight in wave order; the buffer is written again two receivers -- four barriers -- later)
-    if (bl > b_lo && threadIdx.x <= G) edb_flush(red[(bl - 1 - b_lo) & 1], threadIdx.x, band * B + bl - 1, G, tile, part,
-                                                 ld_part, dots, ld_dots, col0);
-    float E = 0.f;                                           // energy of the frames behind this thread's
-    for (int w2 = EDB_W - 1; w2 > w; --w2) E += exA[w2][lane];
-    float acc = 0.f, ge[EDB_Q], gtot = 0.f;
-#pragma unroll
-    for (int q = EDB_Q - 1; q >= 0; --q) {
-      ge[q] = 0.f;
-      if (mv[q]) {
-        E += pw[q];
-        // (v_log_f32 / v_rcp_f32, 1 ulp each: the launch is bound by its VALU work -- about 90 instructions per cell at four
-        // cycles per wave instruction -- and the library log10f and the exact division were a quarter of them)
-        const float lin = fabsf(E) + F32_EPS;
-        const float raw = EDB_DB_PER_LOG2 * __builtin_amdgcn_logf(lin);
-        const float d = fmaxf(raw, -200.0f);
-        const float diff = tv[q] - d;
-        acc += fabsf(diff);
-        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __builtin_amdgcn_rcpf(lin) : 0.f;
-        ge[q] = -sg * dE * gs;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < EDB_Q; ++q) gtot += ge[q];
-    exB[w][lane] = gtot;
-    __syncthreads();
-    float run = 0.f;                                         // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m'
-    for (int w2 = 0; w2 < w; ++w2) run += exB[w2][lane];
-    float da[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < EDB_Q; ++q) {
-      run += ge[q];
-      const float p2 = 2.0f * run;
-      const float2 dS = make_float2(p2 * sv[q].x, p2 * sv[q].y);
-#pragma unroll
-      for (int g = 0; g < EDL_MAXG; ++g) {
-        Ga[g][q].x += rg[g] * dS.x;
-        Ga[g][q].y += rg[g] * dS.y;
-        da[g] += st[g][q].x * dS.x + st[g][q].y * dS.y;
-      }
-    }
-    acc = wave_sum_full(live ? acc : 0.f);
-    if (lane == 0) red[(bl - b_lo) & 1][w][0] = acc;
-#pragma unroll
-    for (int g = 0; g < EDL_MAXG; ++g) {
-      if (g < G) {
-        const float v = wave_sum_full(live ? da[g] : 0.f);
-        if (lane == 0) red[(bl - b_lo) & 1][w][1 + g] = v;
-      }
-    }
-  }
-  __syncthreads();
-  if (b_lo < b_hi && threadIdx.x <= G) edb_flush(red[(b_hi - 1 - b_lo) & 1], threadIdx.x, band * B + b_hi - 1, G, tile, part,
-                                                 ld_part, dots, ld_dots, col0);
-  if (live) {
-    float2* out = Gsum + (size_t)split * nbands * G * cells;
-#pragma unroll
-    for (int g = 0; g < EDL_MAXG; ++g) {
-      if (g < G) {
-#pragma unroll
-        for (int q = 0; q < EDB_Q; ++q)
-          if (mv[q]) (out + ((size_t)band * G + g) * cells)[cq[q]] = Ga[g][q];
-      }
-    }
-  }
-}
-
-// The same launch WITHOUT barriers (form 1 of gfdn_edr_lin_loss_gsum): a WAVE owns 8 frequencies x all 32 frames -- lane =
+// k_edr_lin_wave: a WAVE owns 8 frequencies x all 32 frames -- lane =
 // (frame group fg = lane >> 3, frequency fl = lane & 7), the thread owns the frames 4 fg .. 4 fg + 3 of its frequency as
 // before -- so the two scans along the frames run inside the wave on the VALU: the pair (fg, fg ^ 1) by one DPP row rotation,
 // the four rows of sixteen lanes by v_permlane16_swap / v_permlane32_swap (three swaps give every lane the four row totals);
 // direct sums only, no total-minus-prefix.  No LDS, no __syncthreads: the waves of a workgroup (4 waves = 32 adjacent
-// frequencies, so that the 128-byte lines of a frame row are shared inside the workgroup) run independently.  Measured
-// against form 0 (eight waves per 64 frequencies, two 2 KB LDS exchanges and two barriers per receiver): bench.py / DESIGN.md
-// section 4.3.  The partial sums are per WAVE: gfdn_edr_lin_band_parts(nfreq, 1) = 4 ceil(nfreq / 32) columns per receiver.
+// frequencies, so that the 128-byte lines of a frame row are shared inside the workgroup) run independently.  (The form it
+// replaced -- eight waves per 64 frequencies, the scans across the waves through two 2 KB LDS exchanges and two barriers per
+// receiver -- took 75 us alone against 59: DESIGN.md section 4.3.)  The partial sums are per WAVE:
+// gfdn_edr_lin_band_parts(nfreq) = 4 ceil(nfreq / 32) columns per receiver.
 #define EDW_F 8                     // frequencies per wave
 #define EDW_WG 4                    // waves per workgroup
 __device__ __forceinline__ float edw_partner(float v) {     // the value of lane ^ 8 (the other frame group of the pair)
@@ -640,7 +490,7 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_spec_bwd(const float2*
       const int fc = (4096 - f) & 4095;
       const size_t c = edl_cell(m, f, nframes, nf, tiled);
       float2 Ga = ga[c], Gb = two ? gb[c] : make_float2(0.f, 0.f);
-      for (int sp = 1; sp < nsplit; ++sp) {                  // partial planes of k_edr_lin_band, in order
+      for (int sp = 1; sp < nsplit; ++sp) {                  // partial planes of k_edr_lin_wave, in order
         const size_t o = (size_t)sp * items * nframes * nf + c;
         Ga = cadd(Ga, ga[o]);
         if (two) Gb = cadd(Gb, gb[o]);
@@ -723,12 +573,10 @@ extern "C" int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items
 
 // partial-sum columns per item: frequency blocks of 256 (gfdn_edr_lin_loss) or tiles of 64 (gfdn_edr_lin_loss_gsum)
 extern "C" int gfdn_edr_lin_parts(int nfreq) { return nfreq > 0 ? (nfreq + 255) / 256 : 0; }
-extern "C" int gfdn_edr_lin_band_parts(int nfreq, int form) {
+extern "C" int gfdn_edr_lin_band_parts(int nfreq) {
   if (nfreq <= 0) return 0;
-  if (form == 1) return EDW_WG * ((nfreq + EDW_F * EDW_WG - 1) / (EDW_F * EDW_WG));      // one column per wave of 8 frequencies
-  return (nfreq + EDB_FT - 1) / EDB_FT;
+  return EDW_WG * ((nfreq + EDW_F * EDW_WG - 1) / (EDW_F * EDW_WG));      // one column per wave of 8 frequencies
 }
-extern "C" int gfdn_edr_lin_fused_parts(int nfreq) { return gfdn_edr_lin_band_parts(nfreq, 0); }
 
 // EDR loss of nbands x B receivers on composed spectra (see the head of this file).  part (items, gfdn_edr_lin_parts):
 // loss partials as gfdn_edr_loss(loss_item = NULL) leaves them; want_grad: gP (items, nframes, nfreq) and the EDR part of
@@ -751,27 +599,23 @@ extern "C" int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, con
   return 0;
 }
 
-// gfdn_edr_lin_loss(want_grad) and gfdn_edr_lin_gsum as ONE launch (k_edr_lin_band): part (items, ld_part >=
-// gfdn_edr_lin_fused_parts) and dots columns [col0, col0 + gfdn_edr_lin_fused_parts) as there, Gsum (nsplit, nbands G, nframes,
+// gfdn_edr_lin_loss(want_grad) and gfdn_edr_lin_gsum as ONE launch (k_edr_lin_wave): part (items, ld_part >=
+// gfdn_edr_lin_band_parts) and dots columns [col0, col0 + gfdn_edr_lin_band_parts) as there, Gsum (nsplit, nbands G, nframes,
 // nfreq) complex partial planes (their sum over the first index is gfdn_edr_lin_gsum's output; the adjoint STFT takes nsplit);
 // dL/d|S|^2 is never written.
 extern "C" int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain,
                                       int nbands, int B, int G, const float* T_db, const float* sum_abs, int nframes,
                                       int nfreq, float gscale, float* part, int ld_part, float* dots, int ld_dots, int col0,
-                                      float* Gsum_c64, int nsplit, int tiled, int form, void* stream) {
+                                      float* Gsum_c64, int nsplit, int tiled, void* stream) {
   if (!Sd_c64 || !Stau_c64 || !rgain || !T_db || !sum_abs || !part || !Gsum_c64 || nbands <= 0 || B <= 0 || G <= 0 ||
-      nframes <= 0 || nfreq <= 0 || nsplit <= 0 || nsplit > B || form < 0 || form > 1)
+      nframes <= 0 || nfreq <= 0 || nsplit <= 0 || nsplit > B)
     return GFDN_E_BADARG;
-  const int nparts = gfdn_edr_lin_band_parts(nfreq, form);
-  if (G > EDL_MAXG || nframes > EDB_W * EDB_Q || nbands > 65535 || nsplit > 64) return GFDN_E_UNSUPPORTED;
+  const int nparts = gfdn_edr_lin_band_parts(nfreq);
+  if (G > EDL_MAXG || nframes > EDL_RF || nbands > 65535 || nsplit > 64) return GFDN_E_UNSUPPORTED;
   if (ld_part < nparts || (dots && (col0 < 0 || ld_dots < col0 + nparts))) return GFDN_E_BADARG;
   EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, tiled ? 1 : 0};
-  if (form == 1)
-    hipLaunchKernelGGL(k_edr_lin_wave, dim3(nparts / EDW_WG, nbands, nsplit), dim3(64 * EDW_WG), 0, (hipStream_t)stream, a,
-                       nframes, nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
-  else
-    hipLaunchKernelGGL(k_edr_lin_band, dim3(nparts, nbands, nsplit), dim3(EDB_FT * EDB_W), 0, (hipStream_t)stream, a, nframes,
-                       nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
+  hipLaunchKernelGGL(k_edr_lin_wave, dim3(nparts / EDW_WG, nbands, nsplit), dim3(64 * EDW_WG), 0, (hipStream_t)stream, a,
+                     nframes, nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -1585,122 +1585,6 @@ __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power(const float2* __
   }
 }
 
-// The time-domain output stage folded into the STFT's load (csrc/linear.hip has the stand-alone form): the pair's samples
-//   x[b][t] = xd[rows[b]][t] + sum_g rgain[b][g] tau[band G + g][t]
-// are formed where the frame is loaded -- two 4-byte loads of the dataset's transformed direct paths and the band's group
-// signals (pair-interleaved, (ceil(S / 2), ld_tau) float2; a band's signals are shared by all of its receivers: cache
-// hits) -- and stored once as the pair-interleaved signal x2 that the EDC scans and the STFT adjoint read: every frame
-// stores its first hop, the last frame its second as well.  The stand-alone combine pass (117 MB of traffic and a launch
-// on the critical chain) does not run.
-struct StftLin {
-  const float* xd;             // (R, ld_xd) float: transformed direct paths
-  int ld_xd;
-  const long long* rows;       // item -> row of xd (NULL: identity)
-  const float2* tau2;          // pair-interleaved group signals
-  int ld_tau;
-  const float* rgain;          // (items, G)
-  int B, G;
-  float2* x2;                  // out: (pairs, ld) pair-interleaved signals
-};
-
-__global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_lin(StftLin L, int ld, int T, int nframes, int items,
-                                                                 float* __restrict__ P) {
-  if (STFT_PAIR_PRIO) __builtin_amdgcn_s_setprio(STFT_PAIR_PRIO);
-  float2* buf = dyn_lds;
-  const int p = blockIdx.y, m = blockIdx.x, nf = 2049, i = threadIdx.x;
-  const int b1 = 2 * p, b2 = b1 + 1;
-  const bool two = b2 < items;
-  const int G = L.G, band1 = b1 / L.B, band2 = two ? b2 / L.B : band1;
-  const float* d1 = L.xd + (size_t)(L.rows ? L.rows[b1] : b1) * L.ld_xd;
-  const float* d2 = two ? L.xd + (size_t)(L.rows ? L.rows[b2] : b2) * L.ld_xd : d1;
-  float rg1[4], rg2[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    rg1[g] = g < G ? L.rgain[(size_t)b1 * G + g] : 0.f;
-    rg2[g] = (g < G && two) ? L.rgain[(size_t)b2 * G + g] : 0.f;
-  }
-  // both items in one band whose signals fill whole pairs (the band bank: B even, G even): two 8-byte loads per sample
-  const bool quad = band1 == band2 && !((band1 * G) & 1) && !(G & 1);
-  const float2* tq = L.tau2 + (size_t)((band1 * G) >> 1) * L.ld_tau;
-  const float* tf = (const float*)L.tau2;
-  float sn, cs;
-  sincospif(2.0f * (float)i / 4096.0f, &sn, &cs);
-  const float2 w1 = make_float2(cs, -sn);
-  float2* xo = L.x2 + (size_t)p * ld;
-  const bool last = m == nframes - 1;
-  float2 a[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    float sk, ck;
-    sincospif((float)k * 0.125f, &sk, &ck);
-    const float h = 0.5f - 0.5f * (cs * ck - sn * sk);
-    const int t = m * 2048 + i + 256 * k;
-    float2 v = make_float2(0.f, 0.f);
-    if (t < T) {
-      v = make_float2(d1[t], two ? d2[t] : 0.f);
-      if (quad) {
-        const float2 t01 = tq[t], t23 = G > 2 ? tq[L.ld_tau + t] : make_float2(0.f, 0.f);
-        v.x += rg1[0] * t01.x;
-        v.x += rg1[1] * t01.y;
-        v.x += rg1[2] * t23.x;
-        v.x += rg1[3] * t23.y;
-        v.y += rg2[0] * t01.x;
-        v.y += rg2[1] * t01.y;
-        v.y += rg2[2] * t23.x;
-        v.y += rg2[3] * t23.y;
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (g < G) {
-            const int s1 = band1 * G + g, s2 = band2 * G + g;
-            v.x += rg1[g] * tf[((size_t)(s1 >> 1) * L.ld_tau + t) * 2 + (s1 & 1)];
-            if (two) v.y += rg2[g] * tf[((size_t)(s2 >> 1) * L.ld_tau + t) * 2 + (s2 & 1)];
-          }
-        }
-      }
-      if (k < 8 || last) xo[t] = v;
-    }
-    a[k] = make_float2(h * v.x, h * v.y);
-  }
-  fft4096(a, buf, i, w1, 1.0f);
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 16; ++u) buf[S4K_PAD(i + 256 * u)] = a[u];
-  __syncthreads();
-  float* P1 = P + ((size_t)b1 * nframes + m) * nf;
-  float* P2 = P1 + (size_t)nframes * nf;
-#pragma unroll
-  for (int u = 0; u < 9; ++u) {
-    const int f = i + 256 * u;
-    if (u < 8 || i == 0) {
-      const float2 zf = a[u], zc = buf[S4K_PAD((4096 - f) & 4095)];
-      const float2 sa = make_float2(0.5f * (zf.x + zc.x), 0.5f * (zf.y - zc.y));
-      const float2 sb = make_float2(0.5f * (zf.y + zc.y), -0.5f * (zf.x - zc.x));
-      P1[f] = sa.x * sa.x + sa.y * sa.y;
-      if (two) P2[f] = sb.x * sb.x + sb.y * sb.y;
-    }
-  }
-}
-
-// x2 (ceil(items / 2), ld >= T, 2) and P (items, nframes, 2049) from the transformed direct paths, the band's group signals
-// and the receiver gains (see StftLin); win = 4096, tau pair-interleaved.  The frames of the STFT cover
-// [0, 2048 (nframes + 1)): T must not exceed that (gfdn_stft_nframes pads T to a whole number of hops).
-extern "C" int gfdn_stft_power_pairs_lin(const float* xd, int ld_xd, const long long* rows, const float* tau2, int ld_tau,
-                                         const float* rgain, int nbands, int B, int G, int T, int win, float* x2, int ld,
-                                         float* P, void* stream) {
-  if (!xd || !tau2 || !rgain || !x2 || !P || nbands <= 0 || B <= 0 || G <= 0 || T <= 0 || ld < T || ld_xd < T || ld_tau < T)
-    return GFDN_E_BADARG;
-  if (win != 4096 || G > 4) return GFDN_E_UNSUPPORTED;
-  const int nframes = gfdn_stft_nframes(T, win);
-  if (nframes <= 0) return GFDN_E_BADARG;
-  const int items = nbands * B;
-  StftLin L{xd, ld_xd, rows, (const float2*)tau2, ld_tau, rgain, B, G, (float2*)x2};
-  hipLaunchKernelGGL(k_stft4k_pair_power_lin, dim3(nframes, (items + 1) / 2), dim3(S4K_T), S4K_LDS * sizeof(float2),
-                     (hipStream_t)stream, L, ld, T, nframes, items, P);
-  GFDN_LAUNCH_CHECK();
-  return 0;
-}
-
 __global__ __launch_bounds__(S4K_T, 3) void k_stft4k_pair_power_bwd(const float2* __restrict__ x2, int ld, int T,
                                                                  int nframes, int items,
                                                                  const float* __restrict__ gP,
@@ -1839,15 +1723,6 @@ extern "C" int gfdn_stft_power_pairs_bwd_phase(const float* x2, int ld, int T, i
   if (phase != 0 && phase != 1) return GFDN_E_BADARG;
   if (phase == 1 && gx2 == base2) return GFDN_E_BADARG;
   return stft_pairs_bwd_run(x2, ld, T, items, win, gP, phase ? base2 : nullptr, gx2, 1 << phase, 1, stream);
-}
-
-extern "C" int gfdn_stft_power_pairs_bwd_planar(const float* x2, int ld, int T, int items, int win, const float* gP,
-                                                const float* pbase, int pstart, int plen, float* gx2, int phase,
-                                                void* stream) {
-  if (phase != 0 && phase != 1) return GFDN_E_BADARG;
-  if (phase == 1 && pbase && (pstart < 0 || plen <= 0)) return GFDN_E_BADARG;
-  return stft_pairs_bwd_run(x2, ld, T, items, win, gP, nullptr, gx2, 1 << phase, 1, stream, phase ? pbase : nullptr,
-                            pstart, plen);
 }
 
 static size_t stft_lds(int W) { return ((size_t)2 * W + W / 4) * sizeof(float2); }

@@ -1271,10 +1271,10 @@ def stft_pairs_spectrum_bwd(G, n: int, items: int, win: int, base=None, tiled: b
     return (gx2, gx2b) if split_parity else gx2
 
 
-def edr_lin_parts(nfreq: int, fused: bool = False, form: int = 0) -> int:
-    """Partial-sum columns per item of edr_lin_loss (``fused`` False) / edr_lin_loss_gsum in the given ``form``."""
+def edr_lin_parts(nfreq: int, fused: bool = False) -> int:
+    """Partial-sum columns per item of edr_lin_loss (``fused`` False) / edr_lin_loss_gsum."""
     lib = _lib.load()
-    return lib.gfdn_edr_lin_band_parts(int(nfreq), int(form)) if fused else lib.gfdn_edr_lin_parts(int(nfreq))
+    return lib.gfdn_edr_lin_band_parts(int(nfreq)) if fused else lib.gfdn_edr_lin_parts(int(nfreq))
 
 
 def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, want_grad: bool = True,
@@ -1315,8 +1315,8 @@ def edr_lin_loss(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: floa
 
 
 def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale: float = 1.0, dots=None, col0: int = 0,
-                      tiled: bool = False, nsplit: int = 1, form: int = 0):
-    """edr_lin_loss(want_grad=True) and edr_lin_gsum as ONE launch (k_edr_lin_band) -> (part (items, edr_lin_parts(fused)),
+                      tiled: bool = False, nsplit: int = 1):
+    """edr_lin_loss(want_grad=True) and edr_lin_gsum as ONE launch (k_edr_lin_wave) -> (part (items, edr_lin_parts(fused)),
     Gsum (nsplit, nbands G, nframes, nfreq)): a thread owns cells of the band's plane and walks the band's receivers,
     dL/d|S|^2 is never written, Sd is read once.  The band's receivers are cut into ``nsplit`` runs, one partial plane set
     each: stft_pairs_spectrum_bwd adds them."""
@@ -1331,7 +1331,7 @@ def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale:
     if rows is None and R != items:
         raise RuntimeError("edr_lin_loss_gsum: one row per item (or pass rows)")
     lib = _lib.load()
-    fblk = lib.gfdn_edr_lin_band_parts(nfreq, int(form))
+    fblk = lib.gfdn_edr_lin_band_parts(nfreq)
     part = torch.empty((items, fblk), dtype=_f32, device=Sd.device)
     Gs = torch.empty((nsplit, nbands * G, nframes, nfreq), dtype=_c64, device=Sd.device)
     ld = 0
@@ -1340,10 +1340,10 @@ def edr_lin_loss_gsum(Sd, rows, Stau, rgain, nbands: int, T_db, sum_abs, gscale:
                 or dots.shape[1] < col0 + fblk:
             raise RuntimeError("edr_lin_loss_gsum: dots must be (items * G, >= col0 + parts) contiguous float32")
         ld = dots.shape[1]
-    end = kernel_timer.bracket('k_edr_lin_wave' if form else 'k_edr_lin_band', items)      # (bench.py's roofline leg)
+    end = kernel_timer.bracket('k_edr_lin_wave', items)      # (bench.py's roofline leg)
     _lib.check(lib.gfdn_edr_lin_loss_gsum(_p(Sd), _p(rows), _p(Stau), _p(rgain), nbands, items // nbands, G, _p(T_db),
                                           _p(_f(sum_abs)), nframes, nfreq, float(gscale), _p(part), fblk, _p(dots), ld,
-                                          int(col0), _p(Gs), int(nsplit), int(tiled), int(form), _stream()),
+                                          int(col0), _p(Gs), int(nsplit), int(tiled), _stream()),
                "gfdn_edr_lin_loss_gsum")
     if end is not None:
         end.record()
@@ -1479,27 +1479,6 @@ def lin_merge_slots(a2, b2=None, c2=None, slot_of_time=None) -> torch.Tensor:
     _lib.check(_lib.load().gfdn_lin_merge_slots(_p(a2), _p(b2), _p(c2), a2.shape[0], a2.shape[1], a2.shape[1],
                                                 _p(slot_of_time), _p(out), a2.shape[1], _stream()), "gfdn_lin_merge_slots")
     return out
-
-
-def stft_power_pairs_lin(xd, rows, tau2, rgain, nbands: int, n: int, win: int):
-    """lin_combine_fwd(..., tau_pairs=True, out_pairs=True) folded into the load of stft_power_pairs: returns (x2
-    (ceil(items / 2), n, 2), P (items, nframes, win / 2 + 1)) in ONE launch (win = 4096)."""
-    _need_gpu(xd, tau2, rgain)
-    xd, tau2, rgain = _f(xd), _f(tau2), _f(rgain)
-    items, G = rgain.shape
-    S = nbands * G
-    if items % nbands or xd.dim() != 2 or xd.shape[1] < n or tuple(tau2.shape) != ((S + 1) // 2, n, 2):
-        raise RuntimeError("stft_power_pairs_lin: rgain (nbands * B, G), xd (R, >= n), tau2 (ceil(nbands G / 2), n, 2)")
-    rows = _rows(rows, items, xd.shape[0])
-    if rows is None and xd.shape[0] != items:
-        raise RuntimeError("stft_power_pairs_lin: xd must have one row per item (or pass rows)")
-    nf = stft_nframes(n, win)
-    x2 = torch.empty(((items + 1) // 2, n, 2), dtype=_f32, device=xd.device)
-    P = torch.empty((items, nf, win // 2 + 1), dtype=_f32, device=xd.device)
-    _lib.check(_lib.load().gfdn_stft_power_pairs_lin(_p(xd), xd.stride(0), _p(rows), _p(tau2), n, _p(rgain), nbands,
-                                                     items // nbands, G, n, win, _p(x2), n, _p(P), _stream()),
-               "gfdn_stft_power_pairs_lin")
-    return x2, P
 
 
 def tf_rows_sum(part: torch.Tensor) -> torch.Tensor:
@@ -1745,62 +1724,6 @@ def stft_power_pairs_bwd(x2, items: int, win: int, gP, base=None, out=None, phas
     T = x2.shape[1]
     _lib.check(_lib.load().gfdn_stft_power_pairs_bwd(_p(x2), T, T, items, win, _p(gP), _p(base), _p(out),
                                                      _stream()), "gfdn_stft_power_pairs_bwd")
-    return out
-
-
-def decay_items_fwd(x2, items: int, win: int, T_edr, sum_abs, rows, wf, edr_gscale: float, start: int, length: int,
-                    T_edc, maskw, inv_count: float, edc_gscale: float, want_grad: bool = True):
-    """Fused decay-loss forward on pair-interleaved signals x2 (ceil(items / 2), T, 2) (csrc/decay.hip): |STFT|^2 ->
-    EDR term, Schroeder EDC term and both dB-stage adjoints in ONE launch, one workgroup per item.
-    -> (gP (items, nframes, win/2+1) = d(edr term)/d|STFT|^2 or None, edr_part (items, 1) = sum |dEDR| per item, to
-    be divided by sum_abs[rows] (weighted_sums), edc_loss (items,), dxe (items, length) = d(edc term)/dx over the
-    window [start, start + length) or None)."""
-    _need_gpu(x2, T_edr, T_edc, sum_abs)
-    if x2.dtype != _f32 or not x2.is_contiguous() or x2.dim() != 3 or x2.shape[2] != 2 or x2.shape[0] != (items + 1) // 2:
-        raise RuntimeError("decay_items_fwd: x2 must be contiguous float32 (ceil(items / 2), T, 2)")
-    T = x2.shape[1]
-    nf = stft_nframes(T, win)
-    nfreq = win // 2 + 1
-    rows = _rows(rows, items, T_edr.shape[0])
-    if T_edr.dtype != _f32 or not T_edr.is_contiguous() or tuple(T_edr.shape[1:]) != (nf, nfreq) \
-            or sum_abs.numel() != T_edr.shape[0] or (rows is None and T_edr.shape[0] != items):
-        raise RuntimeError("decay_items_fwd: EDR target shape does not match the achieved EDR")
-    if T_edc.dtype != _f32 or not T_edc.is_contiguous() or T_edc.shape[-1] != length \
-            or T_edc.shape[0] != T_edr.shape[0]:
-        raise RuntimeError("decay_items_fwd: EDC target shape does not match the window / the EDR store")
-    wf = None if wf is None else _f(wf)
-    maskw = None if maskw is None else _f(maskw)
-    dev = x2.device
-    gP = torch.empty((items, nf, nfreq), dtype=_f32, device=dev) if want_grad else None
-    dxe = torch.empty((items, length), dtype=_f32, device=dev) if want_grad else None
-    part = torch.empty((items, 1), dtype=_f32, device=dev)
-    edc = torch.empty(items, dtype=_f32, device=dev)
-    _lib.check(_lib.load().gfdn_decay_items_fwd(_p(x2), T, T, items, win, _p(T_edr), _p(_f(sum_abs)), _p(rows), _p(wf),
-                                                float(edr_gscale), int(start), int(length), _p(T_edc), _p(maskw),
-                                                float(inv_count), float(edc_gscale), int(want_grad), _p(gP), _p(part),
-                                                _p(edc), _p(dxe), _stream()), "gfdn_decay_items_fwd")
-    return gP, part, edc, dxe
-
-
-def stft_power_pairs_bwd_planar(x2, items: int, win: int, gP, phase: int, out=None, base=None, start: int = 0):
-    """One launch of the pair STFT adjoint (phase 0: even frames, stores; phase 1: odd frames, adds) with a PLANAR base
-    gradient added by the second one: ``base`` (items, length) float32 = another gradient w.r.t. the samples
-    [start, start + length) of every item (decay_items_fwd's dxe), zero elsewhere."""
-    _need_gpu(x2, gP)
-    out = torch.empty_like(x2) if out is None else out
-    if out.dtype != _f32 or not out.is_contiguous() or out.shape != x2.shape:
-        raise RuntimeError("stft_power_pairs_bwd_planar: out must be shaped like x2")
-    plen = 0
-    if base is not None:
-        if base.dtype != _f32 or not base.is_contiguous() or base.dim() != 2 or base.shape[0] != items:
-            raise RuntimeError("stft_power_pairs_bwd_planar: base must be contiguous float32 (items, length)")
-        plen = base.shape[1]
-        if start < 0 or start + plen > x2.shape[1]:
-            raise RuntimeError("stft_power_pairs_bwd_planar: the base window leaves the signal")
-    T = x2.shape[1]
-    _lib.check(_lib.load().gfdn_stft_power_pairs_bwd_planar(_p(x2), T, T, items, win, _p(gP), _p(base), int(start),
-                                                            int(plen), _p(out), int(phase), _stream()),
-               "gfdn_stft_power_pairs_bwd_planar")
     return out
 
 

@@ -1017,7 +1017,7 @@ class GraphedTrainStep:
                 dist.broadcast(seed_t, src=0, group=trainer.process_group)
             mask_seed = int(seed_t.item())
         self.mask_seed = int(mask_seed)
-        self.graph_a = self.graph_b = self.graph_p = self.graph_c = None
+        self.graph_a = self.graph_b = self.graph_p = None
         self._tail_in_graph = False
         self.collective_probe_nodes = None        # nodes the probe's captured all-reduce left in its graph (None: no probe)
         self.losses = None
@@ -1068,37 +1068,6 @@ class GraphedTrainStep:
             self.graph_b.replay()
         return self.losses
 
-    # -- several explicit steps per graph -------------------------------------------------------------------------------
-    # Steps per replayed graph (1: one step per graph).  The explicit bank step ends on the main stream (fused tail) and the
-    # next one starts there (group responses): inside one graph the boundary between two steps is a same-queue launch
-    # boundary, between two graphs it is the end of one graph launch and the start of the next.  The steps are the single
-    # steps, bit for bit (tests/test_gpu_fullsize.py).
-    chain_steps = 1
-
-    def _chain_ok(self) -> bool:
-        tr = self.tr
-        return (self.chain_steps >= 2 and getattr(tr, '_fused', None) is not None and tr._allreduce is None
-                and not (tr.criterion[1].use_mask and self.mask_source == "host"))
-
-    def capture_chain(self):
-        """Record ``chain_steps`` consecutive explicit steps as ONE graph (every step fetches the next one's receivers from
-        the loaded schedule, as the single-step graph does)."""
-        if self.graph_a is None:
-            self.capture(None)                      # (warm-up of every kernel, lazy initialisations)
-        rng_state = torch.get_rng_state()
-        self._ensure_records()
-        torch.cuda.synchronize()
-        self.graph_c = torch.cuda.CUDAGraph()
-        losses = []
-        with torch.cuda.graph(self.graph_c, pool=self.graph_a.pool(), stream=self._capture_stream):
-            for _ in range(self.chain_steps):
-                losses.append(dict(self._fused_fwd_bwd(opt_step=True)))
-        self.chain_losses = losses
-        from .functional import FrequencyGrid
-        self._grids = list(FrequencyGrid._cache.values())
-        torch.set_rng_state(rng_state)
-        return self
-
     def run_schedule(self, batches):
         """Generator over the steps of ``batches`` (any number: uploaded in chunks of ``sched_cap``).  Where the
         pipelined chain applies (:meth:`_pipe_ok`) the steps run ``pipe_steps`` at a time from one graph and the rest
@@ -1118,16 +1087,6 @@ class GraphedTrainStep:
                     for losses in self.pipe_losses:
                         yield losses
                     done += S
-            C = self.chain_steps
-            if self._chain_ok() and n - done >= C:
-                if self.graph_c is None:
-                    self.capture_chain()
-                while n - done >= C:
-                    self._ensure_records()
-                    self.graph_c.replay()
-                    for losses in self.chain_losses:
-                        yield losses
-                    done += C
             for _ in range(n - done):
                 yield self.run_next()
 
@@ -1312,7 +1271,7 @@ class GraphedTrainStep:
         # a graph executable must not be destroyed while its last launch is still in flight (its kernel-argument
         # buffers go with it): drain the device first
         try:
-            if self.graph_a is not None or self.graph_p is not None or self.graph_c is not None:
+            if self.graph_a is not None or self.graph_p is not None:
                 torch.cuda.synchronize()
         except Exception:        # noqa: BLE001 -- interpreter shutdown
             pass

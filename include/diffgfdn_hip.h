@@ -591,26 +591,22 @@ int gfdn_stft_pairs_spectrum_bwd(const float* G_c64, int T, int items, int win, 
  * width (the last block holds the rest) -- so that a (receiver, frequency block) workgroup of gfdn_edr_lin_loss streams
  * contiguous runs; 0: cell = m nfreq + f.  gfdn_edr_lin_gsum works cell by cell and takes either.                        */
 int gfdn_edr_lin_parts(int nfreq);            /* partial-sum columns of gfdn_edr_lin_loss */
-int gfdn_edr_lin_fused_parts(int nfreq);      /* ... of gfdn_edr_lin_loss_gsum, form 0    */
-int gfdn_edr_lin_band_parts(int nfreq, int form);   /* ... of gfdn_edr_lin_loss_gsum by form */
+int gfdn_edr_lin_band_parts(int nfreq);       /* ... of gfdn_edr_lin_loss_gsum (one per wave of 8 frequencies) */
 int gfdn_edr_lin_loss(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                       int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
                       int want_grad, float* gP, float* part, float* dots, int ld_dots, int col0, int tiled, void* stream);
 int gfdn_edr_lin_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                       int B, int G, const float* gP, int nframes, int nfreq, float* Gsum_c64, void* stream);
-/* gfdn_edr_lin_loss(want_grad = 1) + gfdn_edr_lin_gsum in ONE launch (k_edr_lin_band): a thread owns cells of the band's
- * (frame, frequency) plane and walks the band's receivers (fixed order), the scans along the frames run across the
- * workgroup's waves; dL/d|S|^2 is never written and Sd is read once.  part (items, ld_part >= gfdn_edr_lin_fused_parts);
- * dots columns [col0, col0 + gfdn_edr_lin_fused_parts); Gsum (nsplit, nbands G, nframes, nfreq): the band's receivers cut
+/* gfdn_edr_lin_loss(want_grad = 1) + gfdn_edr_lin_gsum in ONE launch (k_edr_lin_wave): a thread owns cells of the band's
+ * (frame, frequency) plane and walks the band's receivers (fixed order); a wave = 8 frequencies x all frames, the scans
+ * along the frames inside the wave on the VALU (DPP / permlane swaps), no LDS, no barriers; dL/d|S|^2 is never written and
+ * Sd is read once.  part (items, ld_part >= gfdn_edr_lin_band_parts(nfreq)); dots columns [col0, col0 +
+ * gfdn_edr_lin_band_parts(nfreq)) (260 at nfreq = 2049); Gsum (nsplit, nbands G, nframes, nfreq): the band's receivers cut
  * into nsplit runs with one partial plane set each (gfdn_stft_pairs_spectrum_bwd adds them); tiled as above.            */
 int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows, const float* Stau_c64, const float* rgain, int nbands,
                            int B, int G, const float* T_db, const float* sum_abs, int nframes, int nfreq, float gscale,
                            float* part, int ld_part, float* dots, int ld_dots, int col0, float* Gsum_c64, int nsplit,
-                           int tiled, int form, void* stream);
-/* form 0 (k_edr_lin_band): workgroup = 64 frequencies x 8 waves of 4 frames, the scans along the frames across the waves through
- * LDS (two barriers per receiver); form 1 (k_edr_lin_wave): a wave = 8 frequencies x all frames, the scans inside the wave on
- * the VALU (DPP / permlane swaps), no LDS, no barriers; partial-sum columns per receiver: gfdn_edr_lin_band_parts(nfreq, form)
- * (33 / 260 at nfreq = 2049).  Same numbers up to the order of the cross-group scan sums.                                  */
+                           int tiled, void* stream);
 /* gfdn_edc_loss_pairs[_banded] on signals x[b] = xd[xrows[b]] + sum_g rgain[b][g] tau[band G + g] formed by the first of its
  * three launches (segment energies), which stores them on the EDC window only into the scratch xwin2 (ceil(items / 2), ld, 2)
  * for the two scans (tau2 pair-interleaved).  ld = the signals' length = pitch of gx2 and xwin2; item_len NULL: one window
@@ -648,37 +644,6 @@ int gfdn_lin_gamma_win(const float* gx, int ld_g, const float* rgain, int nbands
  * different launches, merged into the adjoint pair transform's slot order                                                  */
 int gfdn_lin_merge_slots(const float* a2, const float* b2, const float* c2, int rows, int n, int ld, const int* slot_of_time,
                          float* out2, int ld_o, void* stream);
-
-/* gfdn_lin_combine_fwd folded into the load of gfdn_stft_power_pairs (win = 4096; tau pair-interleaved): forms the pair's
- * samples where the frame is loaded, stores them once as x2 (ceil(items / 2), ld >= T, 2) for the EDC scans and the STFT
- * adjoint, and writes P (items, nframes, 2049) = |STFT|^2 -- the stand-alone combine pass does not run.                  */
-int gfdn_stft_power_pairs_lin(const float* xd, int ld_xd, const long long* rows, const float* tau2, int ld_tau,
-                              const float* rgain, int nbands, int B, int G, int T, int win, float* x2, int ld, float* P,
-                              void* stream);
-
-/* Fused decay-loss forward, one workgroup per item (csrc/decay.hip; win = 4096): replaces gfdn_stft_power_pairs ->
- * gfdn_edr_loss and gfdn_edc_loss_pairs on the training path.  Restates src/diff_gfdn/losses.py:430-495 (edr_loss),
- * :501-575 (get_stft_torch, get_edr_from_stft), :201-238 (edc_loss), :187-199 (schroeder_backward_integral) with the
- * element-wise arithmetic of the unfused kernels.  The item walks its frames last to first, |STFT|^2 of eight frames at
- * a time staying in LDS; |STFT|^2 never reaches memory.
- *   x2 (ceil(items / 2), ld) float2 pair-interleaved signals of T samples; T_edr_db (rows, nframes, 2049), sum_abs
- *   (rows), T_edc_db (rows, len): the target stores, item b compares against row target_rows[b] (NULL: b); wf (2049)
- *   or NULL: frequency weights (losses.py:419-428); maskw (len) or NULL: EDC time weights.
- *   edr_part[b] = sum_{f,m} wf |EDR_t - EDR_a| (divide by sum_abs[row]: gfdn_weighted_sums with one column);
- *   edc_loss_item[b] = inv_count * sum_t maskw |EDC_t - EDC_a|.
- *   want_grad: gP (items, nframes, 2049) = edr_gscale / sum_abs * d(edr term)/d|STFT|^2 (input of the STFT adjoint);
- *   dxe (items, len) = edc_gscale * d(edc term)/dx over the samples [start, start + len) (planar, per item).
- * gfdn_stft_power_pairs_bwd_planar: gfdn_stft_power_pairs_bwd_phase whose second launch (phase 1) adds that planar
- * base (rows of plen floats covering [pstart, pstart + plen), zero elsewhere) instead of a pair-interleaved one.   */
-int gfdn_decay_items_fwd(const float* x2, int ld, int T, int items, int win,
-                         const float* T_edr_db, const float* sum_abs, const long long* target_rows,
-                         const float* wf, float edr_gscale,
-                         int start, int len, const float* T_edc_db, const float* maskw, float inv_count,
-                         float edc_gscale, int want_grad,
-                         float* gP, float* edr_part, float* edc_loss_item, float* dxe, void* stream);
-int gfdn_stft_power_pairs_bwd_planar(const float* x2, int ld, int T, int items, int win, const float* gP,
-                                     const float* pbase, int pstart, int plen, float* gx2, int phase,
-                                     void* stream);
 
 /* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
  * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so

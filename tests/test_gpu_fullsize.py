@@ -493,34 +493,6 @@ def test_time_domain_output_stage_equals_folded_output_stage_full_size():
         off += cnt
 
 
-def test_half_batch_chains_equal_single_chain():
-    """The loss middle as two half-batch chains on two streams (bankstep.FusedBankStep.halves) against the single
-    chain: items are independent through the middle, so losses and gradients must agree to the last bit."""
-    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
-    from diffgfdn_amd.bankstep import FusedBankStep
-    res = {}
-    for halves in (2, 1):
-        bands = [_band(q) for q in range(2)]
-        filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
-        bank = BandBank([b_[2] for b_ in bands])
-        tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=CENTRES)
-        tr._fused.halves = halves
-        tr._fused.linear_transforms = False       # (the half-batch chains take H from the stored output stage)
-        tr._fused.fold_output_stage = False
-        sds = BandStackedDataset([b_[1] for b_ in bands])
-        start, length = tr._decay_window(K)
-        sds.precompute_decay_targets(4096, start, length)
-        step = tr.graphed(sds, B, mask_seed=99).capture(sds.global_rows([[0, 3], [1, 4]]))
-        out = step(sds.global_rows([[2, 5], [0, 3]]))
-        torch.cuda.synchronize()
-        res[halves] = ({k: v.detach().cpu().numpy().copy() for k, v in out.items()},
-                       tr.optimizer.flat_grad.detach().cpu().numpy().copy())
-    assert FusedBankStep.halves == 1          # (the default: see bankstep.py)
-    for k, v in res[1][0].items():
-        assert np.array_equal(res[2][0][k], v), k
-    assert np.array_equal(res[2][1], res[1][1])
-
-
 def test_directional_full_size_forward_backward_vs_oracle():
     """BASELINE.json configs[3] at its own size (K = 65 537, irfft n = 131 072; 3 groups x 9 SH channels, 12 directions,
     2 receivers): SH-domain response, directional responses, directional EDC loss and EVERY parameter gradient of the

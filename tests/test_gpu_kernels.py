@@ -761,26 +761,6 @@ def test_linear_output_stage_kernels(G, B, n):
                 assert rel_err(dots.cpu(), dots_ref.cpu()) < 2e-5, (two, in_pairs, tau_pairs)
 
 
-@pytest.mark.parametrize("G,B,n", [(4, 6, 65537), (3, 4, 9001), (2, 2, 4096)])
-def test_stft_with_combine_folded_in(G, B, n):
-    """gfdn_stft_power_pairs_lin (the time-domain output stage formed in the STFT's load, x2 stored by the same launch)
-    against gfdn_lin_combine_fwd followed by gfdn_stft_power_pairs: the same signals and the same |STFT|^2."""
-    from diffgfdn_amd import hip_ops as ops
-    gen = torch.Generator(device="cpu").manual_seed(G * 100 + B)
-    nb, R = 3, B + 3
-    items, S = nb * B, nb * G
-    xd = torch.randn(nb * R, n, generator=gen).to(DEV)
-    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=gen)[:B]], device=DEV)
-    tau = torch.randn(S + (S % 2), n, generator=gen).to(DEV)
-    tau2 = torch.stack((tau[0::2], tau[1::2]), dim=-1).contiguous()
-    rgain = torch.randn(items, G, generator=gen).to(DEV)
-    x_ref = ops.lin_combine_fwd(xd, rows, tau2, rgain, nb, n, True, True)
-    P_ref = ops.stft_power_pairs(x_ref, items, 4096)
-    x2, P = ops.stft_power_pairs_lin(xd, rows, tau2, rgain, nb, n, 4096)
-    assert rel_err(x2.cpu(), x_ref.cpu()) < 1e-6
-    assert rel_err(P.cpu(), P_ref.cpu()) < 1e-5
-
-
 def test_gamma_in_transform_order_equals_gathering_adjoint():
     """lin_gamma(slot_of_time=...) + irfft_odd_pairs_bwd(tslots=True) (the scatter on the G signals per band, coalesced
     loads in the transform's first pass) against lin_gamma + irfft_odd_pairs_bwd (time order, gather in the transform):
@@ -901,11 +881,11 @@ def test_edr_loss_on_composed_spectra(G, B, nfr):
     assert tuple(Gs4.shape) == (2, S_, nfr, nf)
     assert rel_err(ops.spec_tile(Gs4.sum(0), inverse=True).cpu(), Gs_ref.cpu()) < 2e-5
     # ... and in the form without barriers (a wave = 8 frequencies x all frames, scans on the VALU)
-    parts5 = torch.zeros(items * G, nch + ops.edr_lin_parts(nf, fused=True, form=1), device=DEV)
+    parts5 = torch.zeros(items * G, nch + ops.edr_lin_parts(nf, fused=True), device=DEV)
     for tl in (False, True):
         tile = ops.spec_tile if tl else (lambda t: t)
         part5, Gs5 = ops.edr_lin_loss_gsum(tile(Sd), rows, tile(Stau), rgain, nb, tile(T_db), sum_abs, 1.5, dots=parts5,
-                                           col0=nch, tiled=tl, nsplit=1 + tl, form=1)
+                                           col0=nch, tiled=tl, nsplit=1 + tl)
         assert part5.shape[1] == 260
         assert rel_err((part5.sum(1) / sum_abs[rows]).cpu(), li_ref.cpu()) < 2e-6
         assert rel_err(parts5[:, nch:].sum(1).view(items, G).cpu(), dots_ref.cpu()) < 2e-5
