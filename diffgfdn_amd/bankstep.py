@@ -410,6 +410,12 @@ class FusedBankStep:
                                       "elimination kernels under autograd)")
         use_tail = (self.fused_tail and train and opt_step and allreduce is None and pipe is None and not big
                     and side2 is not None and self.adam_on_side)
+        # the normalisation scale joins the group signals behind the transform: energy pass on the side stream
+        late = (self.scale_late and lin and order is not None and normalize_first and not big and side2 is not None)
+        if not late:
+            # (the side stream's head -- receiver gains, mask -- needs nothing of this step: forked off BEFORE the records launch,
+            # so that the main chain's launches below stay first in capture order and keep its hardware queue)
+            ev['start'].record()
         if big:
             Q, QQ = ops.ortho_fwd(M, True, True)
             coef, coef_sub = ops.tf8_coefs(QQ, ig, b, c, A1=M)
@@ -422,11 +428,10 @@ class FusedBankStep:
                 ops.tf_ortho_coefs(M, ig, b, c, out=self._records())
             Q, QQ, coef, coef_sub = self._records()
             self._rec_valid = False           # (until this step's end says otherwise)
-        ev['start'].record()                  # (the side stream's energy pass reads the raw blocks' records)
+        if late:
+            ev['start'].record()              # (the side stream's energy pass reads the raw blocks' records)
         if pipe is not None and (not train or allreduce is not None or not opt_step or side2 is None):
             raise ValueError("a pipelined step is a single-process training step with its optimiser update")
-        # the normalisation scale joins the group signals behind the transform: energy pass on the side stream
-        late = (self.scale_late and lin and order is not None and normalize_first and not big and side2 is not None)
         scale = None
         Hg = Ts = None
         gridU = FrequencyGrid.of(zu)
@@ -438,6 +443,16 @@ class FusedBankStep:
             # next one, against ~6)
             Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, self._eye_rows(nb, G, z.device), None, None,
                                         filt, None, nb, save_T=True, want_H=True)
+        ework = None
+        if normalize_first and not late:
+            # (captured in front of the side stream's first launch: see above)
+            if big:
+                _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c, dturn=gridK.dturn)
+            else:
+                _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
+                                         dturn=gridK.dturn)
+        if not late:
+            ev['norm'].record()
         with on_side2():
             if pipe is None or pipe.first:
                 torch.cuda.current_stream().wait_event(ev['start'])
@@ -458,15 +473,6 @@ class FusedBankStep:
             if mask_draw is not None:
                 mask_draw()
             ev['mask'].record()
-        ework = None
-        if normalize_first and not late:
-            if big:
-                _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c, dturn=gridK.dturn)
-            else:
-                _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
-                                         dturn=gridK.dturn)
-        if not late:
-            ev['norm'].record()
 
         def wait_gains():
             if pipe is None:
@@ -482,7 +488,7 @@ class FusedBankStep:
         if not fold and not lin:
             wait_gains()
         x_fn = None
-        tau = eye = None
+        tau = eye = Dinv8 = None
         spec = False
         tau_pairs = order is not None
         if lin:
@@ -491,10 +497,13 @@ class FusedBankStep:
             eye = self._eye_rows(nb, G, z.device)
             xd = data['dataset'].direct_time(tr.subband_filter_freq_resp, K)
             if big:
-                Ts, _ = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=False)
+                # (the group responses through the band's filter written by the same launch: no tensor operation between the
+                # transfer functions and the transform)
+                Ts, _, Hg, Dinv8 = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=False, filt=filt,
+                                                 want_H=True)
+                keep.append(Dinv8)
                 ev_ts = torch.cuda.Event()
                 ev_ts.record()
-                Hg = Ts if filt is None else (Ts.view(nb, G, -1) * filt.view(nb, 1, -1)).reshape(nb * G, -1)
             elif not late:
                 Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, scale, None, filt, None, nb,
                                             save_T=True, want_H=True)
@@ -639,7 +648,9 @@ class FusedBankStep:
             else:
                 gH_rec, rg_rec = gH, rgain
             if big:
-                grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb)
+                # (the linear step's adjoint runs on the grid of the forward pass: its saved T' and 1 / Q come back)
+                grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb,
+                                           saved=(Ts, Dinv8) if lin else None)
             else:
                 grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True,
                                           tscale=scale if late else None)

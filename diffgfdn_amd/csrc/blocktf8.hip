@@ -155,6 +155,8 @@ struct T8Args {
   // T8_TSAVE
   float2* Tsave;             // (nblk, K)
   float2* Tquad;             // (nblk / G, K, 4) or NULL
+  float2* Hout;              // (nblk, K) or NULL: T' filt (band row nblk / G of filt) -- the group responses through the band's filter
+  float2* Dsave;             // (nblk, K) or NULL: 1 / Q of the bin, for the adjoint pass of the same grid (Tin / Din below)
   int G;
   // T8_COLORLESS
   int asym;
@@ -167,6 +169,9 @@ struct T8Args {
   const float2* filt;        // (nblk / G, ldf) or NULL
   int ldf, B;
   float* part;               // T8_ENERGY: [blk * nparts + p]; heavy modes: [(blk * T8_GREC + e) * nparts + p]
+  // T8_BWD: the forward pass's saved T' and 1 / Q of the same grid (both or neither): the two polynomials are not evaluated again
+  const float2* Tin;
+  const float2* Din;
 };
 
 enum { T8_ENERGY = 0, T8_TSAVE = 1, T8_COLORLESS = 2, T8_BWD = 3 };
@@ -255,6 +260,9 @@ __device__ __forceinline__ void t8_polys(const float (&A)[NP][4], const float2* 
 template <int MODE>
 __global__ __launch_bounds__(64 * T8_WAVES, 8 / T8_WAVES) void k_tf8_pass(T8Args a) {
   __shared__ float s_red[T8_WAVES][T8_GREC + 1];
+  // (the adjoint pass and the forward pass of the group responses are links of the step's critical chain; the colorless pass
+  // -- the same VALU-bound template on twice the bins -- runs beside them on the side stream: they take issue priority)
+  if (MODE == T8_BWD || MODE == T8_TSAVE) __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int blk = blockIdx.y, n = a.nper, K = a.K;
   float2* E1 = t8_lds + wv * T8_IMG;
@@ -334,15 +342,24 @@ __global__ __launch_bounds__(64 * T8_WAVES, 8 / T8_WAVES) void k_tf8_pass(T8Args
     t8_stage_subsets(ph[4], ph[5], ph[6], ph[7], E2, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave's own LDS image: no block barrier)
-    float2 val[2];
-    t8_polys<2>(AL, E1, E2, lane, val);
-    const float2 dinv = cinv(val[0]);
-    const float2 t = cmul(val[1], dinv);                     // T' = P / Q at the current gains
+    float2 dinv, t;
+    if (MODE == T8_BWD && a.Tin) {
+      // (the forward pass of this grid left them: 64 MFMAs and the dot products with e1 less per 64 bins)
+      t = a.Tin[(size_t)blk * K + kk];
+      dinv = a.Din[(size_t)blk * K + kk];
+    } else {
+      float2 val[2];
+      t8_polys<2>(AL, E1, E2, lane, val);
+      dinv = cinv(val[0]);
+      t = cmul(val[1], dinv);                                // T' = P / Q at the current gains
+    }
     if (MODE == T8_ENERGY) {
       if (live) acc0 += t.x * t.x + t.y * t.y;
     } else if (MODE == T8_TSAVE) {
       if (live) {
         a.Tsave[(size_t)blk * K + k] = t;
+        if (a.Hout) a.Hout[(size_t)blk * K + k] = a.filt ? cmul(t, a.filt[(size_t)band * a.ldf + k]) : t;
+        if (a.Dsave) a.Dsave[(size_t)blk * K + k] = dinv;
         if (a.Tquad) {
           float2* qd = a.Tquad + ((size_t)band * K + k) * 4;
           qd[g] = t;
@@ -502,13 +519,14 @@ extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, c
 
 extern "C" int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef,
                               const float* delays, const float* c, const float* scale, float* Tsave, float* Tquad,
-                              void* stream) {
+                              const float* filt_c64, int ldf, float* Hout_c64, float* Dinv_c64, void* stream) {
   int rc = t8_ok(turns, K, nbands * G, nper, coef, delays, c);
   if (rc) return rc;
-  if (!Tsave || G <= 0 || G > 4) return GFDN_E_BADARG;
+  if (!Tsave || G <= 0 || G > 4 || (filt_c64 && ldf < K)) return GFDN_E_BADARG;
   T8Args a{};
   a.turns = turns; a.K = K; a.nblk = nbands * G; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
   a.Tsave = (float2*)Tsave; a.Tquad = (float2*)Tquad; a.G = G;
+  a.Hout = (float2*)Hout_c64; a.filt = (const float2*)filt_c64; a.ldf = ldf; a.Dsave = (float2*)Dinv_c64;
   return t8_launch<T8_TSAVE>(a, (hipStream_t)stream);
 }
 
@@ -533,15 +551,17 @@ extern "C" int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper
 
 extern "C" int gfdn_tf8_compose_bwd(const double* turns, int K, int nbands, int G, int nper, const float* coef,
                                     const float* delays, const float* c, const float* scale, const float* rgain, int B,
-                                    const float* filt_c64, int ldf, const float* gH_c64, int ldh, float* part,
-                                    void* stream) {
+                                    const float* filt_c64, int ldf, const float* gH_c64, int ldh,
+                                    const float* Tsave_c64, const float* Dinv_c64, float* part, void* stream) {
   int rc = t8_ok(turns, K, nbands * G, nper, coef, delays, c);
   if (rc) return rc;
-  if (!rgain || !gH_c64 || !part || G <= 0 || G > 4 || B <= 0 || ldh < K || (filt_c64 && ldf < K)) return GFDN_E_BADARG;
+  if (!rgain || !gH_c64 || !part || G <= 0 || G > 4 || B <= 0 || ldh < K || (filt_c64 && ldf < K) ||
+      (!Tsave_c64) != (!Dinv_c64))
+    return GFDN_E_BADARG;
   T8Args a{};
   a.turns = turns; a.K = K; a.nblk = nbands * G; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
   a.G = G; a.rgain = rgain; a.gH = (const float2*)gH_c64; a.ldh = ldh; a.filt = (const float2*)filt_c64; a.ldf = ldf;
-  a.B = B; a.part = part;
+  a.B = B; a.part = part; a.Tin = (const float2*)Tsave_c64; a.Din = (const float2*)Dinv_c64;
   return t8_launch<T8_BWD>(a, (hipStream_t)stream);
 }
 

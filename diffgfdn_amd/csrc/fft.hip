@@ -359,6 +359,11 @@ struct BluCompose {
   float* gpart;
 };
 
+// A launch of at most this many transforms (the linear step's group signals: 14 pairs at 7 bands) is a link of the step's
+// critical chain that runs beside long VALU-bound side-stream passes (colorless pass, energy pass): its waves take issue
+// priority over theirs (measured at N = 32, where the colorless pass of the 8-line blocks stretched the adjoint transform's
+// three passes from 30 to 92 us).  Launches of hundreds of transforms fill the chip themselves and stay at the default.
+#define BLU_PRIO_BATCH 32
 struct BluArgs {
   BluGeom g;
   BluCompose cmp;
@@ -633,6 +638,7 @@ __device__ __forceinline__ void row512_fft(float2 (&a)[8], float2* buf, const fl
 
 __global__ __launch_bounds__(256) void k_blu_row512(BluArgs a) {
   const BluGeom g = a.g;
+  if (a.batch <= BLU_PRIO_BATCH) __builtin_amdgcn_s_setprio(3);      // (see BLU_PRIO_BATCH)
   const int L2 = 512, L = g.L;
   float2* tw4 = dyn_lds;                    // 128 entries: W_512^j, j < 128
   float2* thi = tw4 + 128;
@@ -755,6 +761,7 @@ __device__ __forceinline__ void col128_fft(float2 (&v)[16], float2* buf, int l, 
 
 __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
   const BluGeom g = a.g;
+  if (a.batch <= BLU_PRIO_BATCH) __builtin_amdgcn_s_setprio(3);      // (see BLU_PRIO_BATCH)
   const int L2 = g.L2, L = g.L;
   float2* thi = dyn_lds;
   float2* tlo = thi + ((L >> TW_LOBITS) > 0 ? (L >> TW_LOBITS) : 1);
@@ -893,6 +900,7 @@ __global__ __launch_bounds__(256) void k_blu_col128_fwd(BluArgs a) {
 
 __global__ __launch_bounds__(256) void k_blu_col128_inv(BluArgs a) {
   const BluGeom g = a.g;
+  if (a.batch <= BLU_PRIO_BATCH) __builtin_amdgcn_s_setprio(3);      // (see BLU_PRIO_BATCH)
   const int L2 = g.L2, L = g.L;
   float2* bufs = dyn_lds;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

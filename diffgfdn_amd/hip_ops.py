@@ -837,19 +837,28 @@ def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False, 
     return energy, scale
 
 
-def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, quad: bool = True):
-    """Scaled group transfer functions T' (nbands * G, K) complex64 [+ Tquad (nbands, K, 4)] from the records."""
+def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, quad: bool = True, filt=None,
+              want_H: bool = False):
+    """Scaled group transfer functions T' (nbands * G, K) complex64 [+ Tquad (nbands, K, 4)] from the records.
+    ``want_H``: returns (Ts, Tq, Hg, Dinv) with Hg = T' filt (``filt`` (nbands, K) complex64 or None) and Dinv = 1 / Q per
+    bin (what tf8_compose_bwd on the same grid takes back with Ts), written by the same launch."""
     _need_gpu(turns, coef, delays, c)
     coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
     K = turns.numel()
     if coef.shape[0] != nbands * G:
         raise RuntimeError("tf8_tsave: records do not match nbands x G blocks")
     scale = None if scale is None else _f(scale)
+    filt = None if filt is None else _c(filt)
+    if filt is not None and filt.numel() != nbands * K:
+        raise RuntimeError("tf8_tsave: filt must hold K bins per band")
     Ts = torch.empty((nbands * G, K), dtype=_c64, device=coef.device)
     Tq = torch.empty((nbands, K, 4), dtype=_c64, device=coef.device) if quad else None
+    Hg = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if want_H else None
+    Dinv = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if want_H else None
     _lib.check(_lib.load().gfdn_tf8_tsave(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c), _p(scale), _p(Ts),
-                                          _p(Tq), _stream()), "gfdn_tf8_tsave")
-    return Ts, Tq
+                                          _p(Tq), _p(filt if want_H else None), K, _p(Hg), _p(Dinv), _stream()),
+               "gfdn_tf8_tsave")
+    return (Ts, Tq, Hg, Dinv) if want_H else (Ts, Tq)
 
 
 def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: float, dturn: float = 0.0):
@@ -868,8 +877,9 @@ def tf8_colorless(turns, coef, delays, nper: int, c, scale, asym: bool, gscale: 
     return part, loss
 
 
-def tf8_compose_bwd(turns, coef, delays, nper: int, c, scale, rgain, gH, filt=None, nbands: int = 1):
-    """Gradient records (nbands * G, 512, parts) of the output stage from dL/dH (nbands * B, K)."""
+def tf8_compose_bwd(turns, coef, delays, nper: int, c, scale, rgain, gH, filt=None, nbands: int = 1, saved=None):
+    """Gradient records (nbands * G, 512, parts) of the output stage from dL/dH (nbands * B, K).  ``saved`` = (Ts, Dinv) of
+    tf8_tsave(want_H=True) on the SAME grid: the pass reads T' and 1 / Q instead of evaluating the polynomials again."""
     _need_gpu(turns, coef, delays, c, rgain, gH)
     coef, delays, c, rgain, gH = _f(coef), _f(delays), _f(c).reshape(-1), _f(rgain), _c(gH)
     K = turns.numel()
@@ -881,9 +891,15 @@ def tf8_compose_bwd(turns, coef, delays, nper: int, c, scale, rgain, gH, filt=No
         raise RuntimeError("tf8_compose_bwd: filt must hold K bins per band")
     lib = _lib.load()
     part = torch.empty((nbands * G, 512, lib.gfdn_tf8_parts(K)), dtype=_f32, device=coef.device)
+    Ts = Dinv = None
+    if saved is not None:
+        Ts, Dinv = saved
+        for t in (Ts, Dinv):
+            if t.dtype != _c64 or not t.is_contiguous() or tuple(t.shape) != (nbands * G, K):
+                raise RuntimeError("tf8_compose_bwd: saved = (Ts, Dinv), contiguous complex64 (nbands * G, K)")
     _lib.check(lib.gfdn_tf8_compose_bwd(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c),
                                         _p(None if scale is None else _f(scale)), _p(rgain), Btot // nbands, _p(filt), K,
-                                        _p(gH), gH.stride(0), _p(part), _stream()), "gfdn_tf8_compose_bwd")
+                                        _p(gH), gH.stride(0), _p(Ts), _p(Dinv), _p(part), _stream()), "gfdn_tf8_compose_bwd")
     return part
 
 

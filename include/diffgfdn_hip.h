@@ -410,13 +410,19 @@ size_t gfdn_tf8_part_bytes(int nblk, int K);
 int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays, float* b,
                     float* c, float* energy, float* scale, void* work, double dturn, void* stream);
 int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
-                   const float* c, const float* scale, float* Tsave_c64, float* Tquad_c64, void* stream);
+                   const float* c, const float* scale, float* Tsave_c64, float* Tquad_c64, const float* filt_c64, int ldf,
+                   float* Hout_c64, float* Dinv_c64, void* stream);
+/* Hout (nbands G, K; NULL: none) = T' filt with band row blk / G of filt (nbands, ldf; NULL: Hout = T'): the group responses
+ * through the band's filter, what the time-domain output stage transforms (no tensor operation between the two).
+ * Dinv (nbands G, K; NULL: none) = 1 / Q per bin: with Tsave what gfdn_tf8_compose_bwd on the SAME grid takes back
+ * (Tsave_c64, Dinv_c64: both or neither) instead of evaluating the two polynomials again.                               */
 int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
                        const float* c, const float* scale, int asym, float gscale, float* part, float* lossp,
                        float* loss, double dturn, void* stream);
 int gfdn_tf8_compose_bwd(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
                          const float* c, const float* scale, const float* rgain, int B, const float* filt_c64, int ldf,
-                         const float* gH_c64, int ldh, float* part, void* stream);
+                         const float* gH_c64, int ldh, const float* Tsave_c64, const float* Dinv_c64, float* part,
+                         void* stream);
 size_t gfdn_tf8_param_grads_work_bytes(int nblk);
 int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* part0, int nparts0, const float* A1,
                          const float* inv_gamma1, const float* part1, int nparts1, const float* b, const float* c,

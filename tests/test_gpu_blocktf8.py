@@ -139,3 +139,12 @@ def test_output_stage_adjoint_through_the_parameterisation(n, G, nbands, B, K):
     assert rel_err(gb.cpu().numpy(), bp.grad.numpy()) < 2e-4
     assert rel_err(gc.cpu().numpy(), cp.grad.numpy()) < 2e-4
     assert rel_err(gM.cpu().numpy(), Mr.grad.numpy()) < 5e-4
+    # round 5: the forward pass leaves T' filt and 1 / Q beside T'; the adjoint pass that takes T' and 1 / Q back instead of
+    # evaluating the two polynomials again accumulates the same records
+    Ts2, _, Hg, Dinv = ops.tf8_tsave(turns, coef, delays.to(DEV), n, cnow, s.to(DEV), nbands, G, quad=False,
+                                     filt=filt.to(DEV), want_H=True)
+    assert torch.equal(Ts2, Ts)
+    assert rel_err(Hg.cpu().numpy(), (Ts.view(nbands, G, K) * filt.to(DEV)[:, None, :]).reshape(nblk, K).cpu().numpy()) < 1e-6
+    part2 = ops.tf8_compose_bwd(turns, coef, delays.to(DEV), n, cnow, s.to(DEV), rgain.to(DEV), W.to(DEV), filt.to(DEV),
+                                nbands, saved=(Ts2, Dinv))
+    assert rel_err(part2.sum(-1).cpu().numpy(), part.sum(-1).cpu().numpy()) < 1e-6
