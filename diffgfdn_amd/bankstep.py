@@ -135,15 +135,14 @@ class FusedBankStep:
     # band's receivers cut into runs for more loads in flight.  Off: the value-only column kernel + the sum as two launches
     # (the cross-check form)
     edr_one_launch = True
-    edr_receiver_runs = 0         # (0 = by the number of bands: about two workgroups per CU -- 2 runs for 7 bands, 16 for one)
+    # (0 = two runs: measured same-box, 7 bands: 1 / 2 / 4 runs 0.379 / 0.358 / 0.370 ms; one band: 2 / 4 / 8 / 16 runs 0.222 /
+    # 0.227 / 0.229 / 0.229 ms -- every run is one more set of partial planes for the adjoint STFT to add on load)
+    edr_receiver_runs = 0
 
     def _edr_runs(self, nbands: int, B: int) -> int:
         if self.edr_receiver_runs > 0:
             return min(self.edr_receiver_runs, B)
-        runs = 1
-        while runs * 2 <= max(1, B // 2) and 33 * nbands * runs < 448:
-            runs *= 2
-        return runs
+        return 2 if B >= 4 else 1
     # ... on planes stored in the tiled cell order (frequency blocks of 256, a block's frames contiguous): what a (receiver,
     # frequency block) workgroup of the EDR kernel touches is one contiguous run
     tiled_spectra = True
