@@ -743,11 +743,18 @@ def main():
     ap.add_argument('--distinct-t60', action='store_true',
                     help='every band gets its own longest decay time (1.5 s ... 0.6 s) and therefore its own EDC window, as '
                          'the reference\'s per-band datasets do (trainer.py:56-59)')
+    ap.add_argument('--batch', type=int, default=BATCH,
+                    help='receivers per band and step on one GPU (the reference trains with 32, trainer.py:373-379; other '
+                         'values measure what a rank of a strong-scaling job steps: DESIGN.md section 7)')
     ap.add_argument('--bands', type=int, default=len(BAND_CENTRES),
                     help='octave bands stepped together (1 = BASELINE.json configs[1], the 500 Hz band alone)')
     args = ap.parse_args()
     if args.lines_per_group != NPER:
         globals()['NPER'] = args.lines_per_group
+    if args.batch != BATCH:
+        if args.batch < 2 or args.batch % 2:
+            raise SystemExit("--batch: an even number of receivers per band (receiver pairs share a transform)")
+        globals()['BATCH'] = args.batch
     if not 1 <= args.bands <= len(BAND_CENTRES):
         raise SystemExit(f"--bands must be 1..{len(BAND_CENTRES)}")
     if args.classic and args.bands != 1:
