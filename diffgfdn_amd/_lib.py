@@ -98,13 +98,20 @@ SIGNATURES = {
     "gfdn_tf8_parts": (c_int, [c_int]),
     "gfdn_tf8_part_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_tf8_energy": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_double, _P]),
-    "gfdn_tf8_tsave": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "gfdn_tf8_tsave": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "gfdn_tf8_colorless": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_double, _P]),
     "gfdn_tf8_compose_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P,
                                      _P, _P, _P]),
     "gfdn_tf8_param_grads_work_bytes": (c_size_t, [c_int]),
     "gfdn_tf8_param_grads": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                      _P]),
+    "gfdn_tfp_parts": (c_int, []),
+    "gfdn_tfp_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "gfdn_tfp_energy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gfdn_tfp_colorless": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, c_int, _P, _P, _P, _P,
+                                   _P]),
+    "gfdn_tfp_compose_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, _P, c_int,
+                                     _P, c_int, _P, _P, _P]),
     "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_exp_contract_mfma": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),

@@ -168,6 +168,10 @@ class FusedBankStep:
     # (d) the EDC part of dL/dtau summed over the band's receivers on the side stream, straight behind the EDC launch; the
     # main chain merges it with the adjoint STFT's two signal sets (three small arrays) into the transform's slot order
     gamma_split = True
+    # (e) blocks of 5..8 lines: the polynomial passes as real transforms of the coefficient sequences (csrc/polyfft.hip) where
+    # the delay lengths are integers and the grid is the reference's rfftfreq grid -- ~45 transform-flops per bin and
+    # polynomial instead of 512 products; the matrix-core passes (csrc/blocktf8.hip) stay for every other grid
+    transform_polys = True
 
     # The output stage H = (sum_g rgain s_g T_g + direct) filt formed INSIDE the first pass of the forward transform
     # (gfdn_irfft_odd_pairs_compose_fwd) from the saved group transfer functions: H is neither written nor read back
@@ -411,13 +415,30 @@ class FusedBankStep:
                     and side2 is not None and self.adam_on_side)
         # the normalisation scale joins the group signals behind the transform: energy pass on the side stream
         late = (self.scale_late and lin and order is not None and normalize_first and not big and side2 is not None)
-        if not late:
+        # blocks of 5..8 lines, integer delay lengths on the reference's own grid: normalize, the colorless pass and both
+        # adjoints as real transforms of the coefficient sequences (csrc/polyfft.hip), normalize and the colorless pass on the
+        # side stream; the forward group responses stay on the matrix-core pass (the dB stages of the decay losses need its
+        # rounding: see that file).  The scale joins behind the transform, as ``late`` for the 4-line blocks
+        tfp = None
+        if (big and self.transform_polys and lin and order is not None and gridK.rfft_nfft and side2 is not None
+                and normalize_first):
+            T_seq = ops.tfp_plan(delays, n, gridK.rfft_nfft)
+            sob = ops.tfp_slot_of_bin(K, z.device)
+            if T_seq is not None and sob is not None:
+                tfp = (gridK.rfft_nfft, sob, T_seq)
+        late8 = tfp is not None
+        if not late and not late8:
             # (the side stream's head -- receiver gains, mask -- needs nothing of this step: forked off BEFORE the records launch,
             # so that the main chain's launches below stay first in capture order and keep its hardware queue)
             ev['start'].record()
+        c_head = c
         if big:
             Q, QQ = ops.ortho_fwd(M, True, True)
             coef, coef_sub = ops.tf8_coefs(QQ, ig, b, c, A1=M)
+            if late8:
+                # the side stream's normalize rescales the gains in place while the main stream's pass reads them: a snapshot
+                c_head = c.detach().clone()
+                keep.append(c_head)
         else:
             # (the fused tail of the previous training step left them; anything else that touched M, b, c since made
             # the bookkeeping say so)
@@ -427,7 +448,7 @@ class FusedBankStep:
                 ops.tf_ortho_coefs(M, ig, b, c, out=self._records())
             Q, QQ, coef, coef_sub = self._records()
             self._rec_valid = False           # (until this step's end says otherwise)
-        if late:
+        if late or late8:
             ev['start'].record()              # (the side stream's energy pass reads the raw blocks' records)
         if pipe is not None and (not train or allreduce is not None or not opt_step or side2 is None):
             raise ValueError("a pipelined step is a single-process training step with its optimiser update")
@@ -442,16 +463,25 @@ class FusedBankStep:
             # next one, against ~6)
             Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, self._eye_rows(nb, G, z.device), None, None,
                                         filt, None, nb, save_T=True, want_H=True)
+        Dinv8 = None
+        if late8:
+            # (as above: captured before the fork.  The grid in bin order -- T and 1 / Q where the adjoint's spectra are formed
+            # --, the group responses through the band's filter scattered to the transform's slot order; unscaled: the
+            # snapshot of the gains)
+            Ts, _, Hg, Dinv8 = ops.tf8_tsave(gridK.turns[:Ku], coef, delays, n, c_head, None, nb, G, quad=False, filt=filt,
+                                             want_H=True, hslot=tfp[1])
+            keep.append(Dinv8)
         ework = None
-        if normalize_first and not late:
+        if normalize_first and not late and not late8:
             # (captured in front of the side stream's first launch: see above)
             if big:
                 _, scale = ops.tf8_energy(gridK.turns, coef_sub, delays, n, b, c, dturn=gridK.dturn)
             else:
                 _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                          dturn=gridK.dturn)
-        if not late:
+        if not late and not late8:
             ev['norm'].record()
+        Xsub = None
         with on_side2():
             if pipe is None or pipe.first:
                 torch.cuda.current_stream().wait_event(ev['start'])
@@ -459,6 +489,12 @@ class FusedBankStep:
                 _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                          dturn=gridK.dturn)
                 ev['norm'].record()
+            elif late8:
+                nblk8 = nb * G
+                Xsub = ops.tfp_forward(coef_sub, delays, c, n, tfp[0], tfp[2])
+                _, scale = ops.tfp_energy(Xsub[:nblk8], Xsub[nblk8:], n, b, c)
+                ev['norm'].record()
+                keep.append(Xsub)
             if pipe is None:
                 rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
                                                       G, lo, hi, rows, nb)
@@ -487,7 +523,7 @@ class FusedBankStep:
         if not fold and not lin:
             wait_gains()
         x_fn = None
-        tau = eye = Dinv8 = None
+        tau = eye = None
         spec = False
         tau_pairs = order is not None
         if lin:
@@ -495,7 +531,9 @@ class FusedBankStep:
             # them and the dataset's transformed direct paths in one streaming pass (csrc/linear.hip)
             eye = self._eye_rows(nb, G, z.device)
             xd = data['dataset'].direct_time(tr.subband_filter_freq_resp, K)
-            if big:
+            if late8:
+                pass                          # (launched above)
+            elif big:
                 # (the group responses through the band's filter written by the same launch: no tensor operation between the
                 # transfer functions and the transform)
                 Ts, _, Hg, Dinv8 = ops.tf8_tsave(gridU.turns, coef, delays, n, c, scale, nb, G, quad=False, filt=filt,
@@ -506,7 +544,7 @@ class FusedBankStep:
             elif not late:
                 Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, scale, None, filt, None, nb,
                                             save_T=True, want_H=True)
-            if late:
+            if late or late8:
                 # (the wait sits in front of the LAST pass, the only reader of the scale: by then the side stream's energy
                 # pass is long done and the wait is free)
                 tau = ops.irfft_odd_fwd(Hg, K, slots=True, pairs=True, oscale=scale,
@@ -557,9 +595,12 @@ class FusedBankStep:
 
         def colorless_pass():
             with on_side2():
-                if not late:                       # (recorded on this very stream: no wait -- a captured wait of a stream
+                if not late and not late8:         # (recorded on this very stream: no wait -- a captured wait of a stream
                     torch.cuda.current_stream().wait_event(ev['norm'])      # for its own event is asking for trouble)
-                if big:
+                if late8:
+                    grec_sub_, loss_g_ = ops.tfp_colorless(Xsub[:nb * G], Xsub[nb * G:], tfp[0], n, delays, scale,
+                                                           cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world)
+                elif big:
                     torch.cuda.current_stream().wait_event(ev_ts)
                     grec_sub_, loss_g_ = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
                                                            cfg.use_asym_spectral_loss,
@@ -646,7 +687,9 @@ class FusedBankStep:
                 gH_rec, rg_rec = gHg, eye
             else:
                 gH_rec, rg_rec = gH, rgain
-            if big:
+            if late8:
+                grec = ops.tfp_compose_bwd(tfp[0], nb, G, n, delays, Ku, tfp[1], gH_rec, filt, Ts, Dinv8, tscale=scale)
+            elif big:
                 # (the linear step's adjoint runs on the grid of the forward pass: its saved T' and 1 / Q come back)
                 grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb,
                                            saved=(Ts, Dinv8) if lin else None)

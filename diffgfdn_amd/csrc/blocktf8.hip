@@ -157,6 +157,8 @@ struct T8Args {
   float2* Tquad;             // (nblk / G, K, 4) or NULL
   float2* Hout;              // (nblk, K) or NULL: T' filt (band row nblk / G of filt) -- the group responses through the band's filter
   float2* Dsave;             // (nblk, K) or NULL: 1 / Q of the bin, for the adjoint pass of the same grid (Tin / Din below)
+  const int* hslot;          // NULL, or (K): column of bin k in Hout (and in filt), bit 31: the column holds the conjugate --
+                             // the grid in bin order, the group responses in the slot order of the odd-length transform
   int G;
   // T8_COLORLESS
   int asym;
@@ -358,7 +360,11 @@ __global__ __launch_bounds__(64 * T8_WAVES, 8 / T8_WAVES) void k_tf8_pass(T8Args
     } else if (MODE == T8_TSAVE) {
       if (live) {
         a.Tsave[(size_t)blk * K + k] = t;
-        if (a.Hout) a.Hout[(size_t)blk * K + k] = a.filt ? cmul(t, a.filt[(size_t)band * a.ldf + k]) : t;
+        if (a.Hout) {
+          const int so = a.hslot ? a.hslot[k] : k, col = so & 0x7fffffff;
+          const float2 ts = so < 0 ? cconj(t) : t;               // (the response at conj(z) is the conjugate)
+          a.Hout[(size_t)blk * K + col] = a.filt ? cmul(ts, a.filt[(size_t)band * a.ldf + col]) : ts;
+        }
         if (a.Dsave) a.Dsave[(size_t)blk * K + k] = dinv;
         if (a.Tquad) {
           float2* qd = a.Tquad + ((size_t)band * K + k) * 4;
@@ -519,14 +525,15 @@ extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, c
 
 extern "C" int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef,
                               const float* delays, const float* c, const float* scale, float* Tsave, float* Tquad,
-                              const float* filt_c64, int ldf, float* Hout_c64, float* Dinv_c64, void* stream) {
+                              const float* filt_c64, int ldf, float* Hout_c64, float* Dinv_c64, const int* hslot,
+                              void* stream) {
   int rc = t8_ok(turns, K, nbands * G, nper, coef, delays, c);
   if (rc) return rc;
   if (!Tsave || G <= 0 || G > 4 || (filt_c64 && ldf < K)) return GFDN_E_BADARG;
   T8Args a{};
   a.turns = turns; a.K = K; a.nblk = nbands * G; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
   a.Tsave = (float2*)Tsave; a.Tquad = (float2*)Tquad; a.G = G;
-  a.Hout = (float2*)Hout_c64; a.filt = (const float2*)filt_c64; a.ldf = ldf; a.Dsave = (float2*)Dinv_c64;
+  a.Hout = (float2*)Hout_c64; a.filt = (const float2*)filt_c64; a.ldf = ldf; a.Dsave = (float2*)Dinv_c64; a.hslot = hslot;
   return t8_launch<T8_TSAVE>(a, (hipStream_t)stream);
 }
 

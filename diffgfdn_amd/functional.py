@@ -39,6 +39,14 @@ class FrequencyGrid:
             k = torch.arange(self.K, dtype=torch.float64, device=self.turns.device)
             if d != 0.0 and bool(((self.turns - (self.turns[0] + k * d)).abs().max() < 1e-13).item()):
                 self.dturn = d
+        # the reference's own grid, bins 0 .. nfft / 2 of an nfft-point transform with nfft a power of two: z_k^m is a root of
+        # unity of order nfft for integer m -- polynomials in z with integer degrees are then real transforms of their
+        # coefficient sequences (csrc/polyfft.hip).  0: any other grid
+        self.rfft_nfft = 0
+        nfft = 2 * (self.K - 1)
+        if (self.dturn != 0.0 and nfft >= 16 and nfft & (nfft - 1) == 0 and abs(self.dturn * nfft - 1.0) < 1e-12
+                and float(self.turns[0].item()) == 0.0):
+            self.rfft_nfft = nfft
 
     @classmethod
     def of(cls, z: torch.Tensor) -> "FrequencyGrid":

@@ -838,10 +838,12 @@ def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False, 
 
 
 def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, quad: bool = True, filt=None,
-              want_H: bool = False):
+              want_H: bool = False, hslot=None):
     """Scaled group transfer functions T' (nbands * G, K) complex64 [+ Tquad (nbands, K, 4)] from the records.
     ``want_H``: returns (Ts, Tq, Hg, Dinv) with Hg = T' filt (``filt`` (nbands, K) complex64 or None) and Dinv = 1 / Q per
-    bin (what tf8_compose_bwd on the same grid takes back with Ts), written by the same launch."""
+    bin (what tf8_compose_bwd on the same grid takes back with Ts), written by the same launch.  ``hslot`` (K,) int32
+    (tfp_slot_of_bin): the grid is in BIN order, Hg (and ``filt``) in the slot order of the odd-length transform -- column
+    hslot[k] & 0x7fffffff, conjugated where bit 31 is set."""
     _need_gpu(turns, coef, delays, c)
     coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
     K = turns.numel()
@@ -856,8 +858,8 @@ def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, qua
     Hg = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if want_H else None
     Dinv = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if want_H else None
     _lib.check(_lib.load().gfdn_tf8_tsave(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c), _p(scale), _p(Ts),
-                                          _p(Tq), _p(filt if want_H else None), K, _p(Hg), _p(Dinv), _stream()),
-               "gfdn_tf8_tsave")
+                                          _p(Tq), _p(filt if want_H else None), K, _p(Hg), _p(Dinv),
+                                          _p(hslot if want_H else None), _stream()), "gfdn_tf8_tsave")
     return (Ts, Tq, Hg, Dinv) if want_H else (Ts, Tq)
 
 
@@ -927,6 +929,129 @@ def tf8_param_grads(A0, ig0, part0, b, c, M, A1=None, ig1=None, part1=None, gQ=N
                                         _p(None if Q is None else _f(Q)), _p(gb), _p(gc), _p(gM), _p(work), _stream()),
                "gfdn_tf8_param_grads")
     return gM, gb, gc
+
+
+# ---- the 8-line block transfer functions on the rfftfreq grid by fast transforms (csrc/polyfft.hip) ----
+_tfp_plans = {}
+_tfp_slots = {}
+
+
+def tfp_plan(delays, nper: int, nfft: int):
+    """Samples per coefficient sequence (max degree + 1, rounded up to 256, <= nfft) when every delay length is a
+    non-negative integer (the reference's are: config.py:131-140), else None.  Reads the device once per delays tensor."""
+    key = (delays.data_ptr(), delays._version, delays.numel(), int(nper), int(nfft), str(delays.device))
+    if key not in _tfp_plans:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("tfp_plan: first use of this delays tensor inside a stream capture; run the step once before")
+        d = delays.detach().to(torch.float64).cpu().reshape(-1, nper)
+        T = None
+        if nfft >= 16 and nfft & (nfft - 1) == 0 and bool((d == d.round()).all()) and bool((d >= 0).all()):
+            T = int(min(nfft, ((int(d.sum(1).max().item()) + 256) // 256) * 256))
+        while len(_tfp_plans) >= 64:
+            _tfp_plans.pop(next(iter(_tfp_plans)))
+        # (the entry keeps the tensor alive: the key is its ADDRESS, and a freed tensor's block handed to another delays
+        # tensor of the same size would be a false hit -- rows too short for the new degrees)
+        _tfp_plans[key] = (T, delays)
+    return _tfp_plans[key][0]
+
+
+def tfp_slot_of_bin(n: int, device):
+    """(Ku,) int32: column of bin k in the slot-ordered spectrum of irfft(X, n), n odd (column 0 = bin 0, 1 + s = slot s of
+    irfft_slot_order), bit 31 set where the slot holds the conjugate -- or None when the length has no slot order."""
+    key = (int(n), str(device))
+    if key not in _tfp_slots:
+        order = irfft_slot_order(n, device)
+        if order is None:
+            _tfp_slots[key] = None
+        else:
+            bins, conj = order[0].cpu(), order[1].cpu()
+            col = torch.zeros((int(n) + 1) // 2, dtype=torch.int64)
+            col[bins] = torch.arange(1, bins.numel() + 1, dtype=torch.int64) | (conj.to(torch.int64) << 31)
+            col = torch.where(col >= 2 ** 31, col - 2 ** 32, col)
+            _tfp_slots[key] = col.to(torch.int32).to(device)
+    return _tfp_slots[key]
+
+
+def tfp_forward(coef, delays, c, nper: int, nfft: int, T: int) -> torch.Tensor:
+    """X (2 nblk, nfft / 2 + 1) complex64 = rfft of the coefficient sequences [Q | P] of one record set: Q(z_k) =
+    conj(X[blk][k]), P(z_k) = conj(X[nblk + blk][k]) on z_k = e^{2 pi i k / nfft}.  P is formed with the gains ``c`` as they
+    are NOW (before normalize's rescale)."""
+    _need_gpu(coef, delays, c)
+    coef, delays, c = _f(coef), _f(delays), _f(c).reshape(-1)
+    nblk = coef.shape[0]
+    K = nfft // 2 + 1
+    lib = _lib.load()
+    seq = torch.empty((2 * nblk, T), dtype=_f32, device=coef.device)
+    X = torch.empty((2 * nblk, K), dtype=_c64, device=coef.device)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), coef.device)
+    _lib.check(lib.gfdn_tfp_forward(nfft, nblk, nper, _p(coef), _p(delays), _p(c), T, _p(seq), _p(X), K, _p(work), _stream()),
+               "gfdn_tfp_forward")
+    return X
+
+
+def tfp_energy(Xq, Xp, nper: int, b, c, want_energy: bool = False):
+    """normalize (trainer.py:317-332) on the transformed sequences of the raw sub-FDN blocks (rows Xq, Xp of tfp_forward):
+    -> (energy or None, scale = E^(-1/2)); b, c (float32, contiguous) are divided by E^(1/4) IN PLACE."""
+    _need_gpu(Xq, Xp, b, c)
+    nblk, K = Xq.shape
+    for t in (b, c):
+        if t.dtype != _f32 or not t.is_contiguous() or t.numel() != nblk * nper:
+            raise RuntimeError("tfp_energy: gains must be contiguous float32 of nblk * nper elements")
+    if Xq.stride(0) != Xp.stride(0) or Xq.stride(1) != 1 or Xp.stride(1) != 1:
+        raise RuntimeError("tfp_energy: rows of one tfp_forward result")
+    lib = _lib.load()
+    energy = torch.empty(nblk, dtype=_f32, device=Xq.device) if want_energy else None
+    scale = torch.empty(nblk, dtype=_f32, device=Xq.device)
+    work = torch.empty(nblk * lib.gfdn_tfp_parts(), dtype=_f32, device=Xq.device)
+    _lib.check(lib.gfdn_tfp_energy(_p(Xq), _p(Xp), Xq.stride(0), K, nblk, nper, _p(b), _p(c), _p(energy), _p(scale), _p(work),
+                                   _stream()), "gfdn_tfp_energy")
+    return energy, scale
+
+
+def tfp_colorless(Xq, Xp, nfft: int, nper: int, delays, scale, asym: bool, gscale: float):
+    """tf8_colorless on the transformed sequences -> (part (nblk, 512, 1) gradient records, loss (nblk,))."""
+    _need_gpu(Xq, Xp, delays)
+    nblk, K = Xq.shape
+    if K != nfft // 2 + 1 or Xq.stride(0) != Xp.stride(0):
+        raise RuntimeError("tfp_colorless: rows of one tfp_forward result on nfft / 2 + 1 bins")
+    lib = _lib.load()
+    dev = Xq.device
+    UV = torch.empty((2 * nblk, K), dtype=_c64, device=dev)
+    x = torch.empty((2 * nblk, nfft), dtype=_f32, device=dev)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), dev)
+    part = torch.empty((nblk, 512, 1), dtype=_f32, device=dev)
+    lossp = torch.empty(nblk * lib.gfdn_tfp_parts(), dtype=_f32, device=dev)
+    loss = torch.empty(nblk, dtype=_f32, device=dev)
+    _lib.check(lib.gfdn_tfp_colorless(_p(Xq), _p(Xp), Xq.stride(0), nfft, nblk, nper, _p(_f(delays)),
+                                      _p(None if scale is None else _f(scale)), int(asym), float(gscale), _p(UV), _p(x), nfft,
+                                      _p(work), _p(part), _p(lossp), _p(loss), _stream()), "gfdn_tfp_colorless")
+    return part, loss
+
+
+def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, slot_of_bin, gH, filt, Tnat, Dnat, tscale=None):
+    """Gradient records (nbands * G, 512, 1) of the damped blocks from gH (nbands * G, >= Ku) = dL/d(T'_g filt) on the slot
+    order (the linear step's adjoint transform output); Tnat, Dnat (nbands * G, Ku): tf8_tsave's Ts, Dinv on the bins
+    0 .. Ku - 1 in bin order (``hslot``); ``tscale``: Tnat holds the unscaled functions, T' = tscale Tnat."""
+    _need_gpu(gH, Tnat, Dnat, delays)
+    nblk = nbands * G
+    gH = _c(gH)
+    filt = None if filt is None else _c(filt)
+    if gH.shape[0] != nblk or gH.shape[1] < Ku or tuple(Tnat.shape) != (nblk, Ku) or tuple(Dnat.shape) != (nblk, Ku):
+        raise RuntimeError("tfp_compose_bwd: shapes do not match nbands x G blocks on Ku bins")
+    if filt is not None and filt.numel() != nbands * Ku:
+        raise RuntimeError("tfp_compose_bwd: filt must hold Ku slots per band")
+    lib = _lib.load()
+    dev = gH.device
+    K = nfft // 2 + 1
+    UV = torch.empty((2 * nblk, K), dtype=_c64, device=dev)
+    x = torch.empty((2 * nblk, nfft), dtype=_f32, device=dev)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), dev)
+    part = torch.empty((nblk, 512, 1), dtype=_f32, device=dev)
+    _lib.check(lib.gfdn_tfp_compose_bwd(nfft, nbands, G, nper, _p(_f(delays)), Ku, _p(slot_of_bin), _p(gH), gH.stride(0), _p(filt),
+                                        Ku, _p(Tnat), _p(Dnat), _p(None if tscale is None else _f(tscale)), _p(UV), K, _p(x),
+                                        nfft, _p(work), _p(part), _stream()),
+               "gfdn_tfp_compose_bwd")
+    return part
 
 
 def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):

@@ -411,9 +411,12 @@ int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float*
                     float* c, float* energy, float* scale, void* work, double dturn, void* stream);
 int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
                    const float* c, const float* scale, float* Tsave_c64, float* Tquad_c64, const float* filt_c64, int ldf,
-                   float* Hout_c64, float* Dinv_c64, void* stream);
+                   float* Hout_c64, float* Dinv_c64, const int* hslot, void* stream);
 /* Hout (nbands G, K; NULL: none) = T' filt with band row blk / G of filt (nbands, ldf; NULL: Hout = T'): the group responses
  * through the band's filter, what the time-domain output stage transforms (no tensor operation between the two).
+ * hslot (K; NULL: Hout in grid order): column of grid point k in Hout and filt, bit 31 set where that column holds the
+ * conjugate -- the grid in BIN order (Tsave, Dinv: what gfdn_tfp_compose_bwd reads), the group responses in the slot
+ * order of the odd-length transform (gfdn_irfft_odd_slot_order).
  * Dinv (nbands G, K; NULL: none) = 1 / Q per bin: with Tsave what gfdn_tf8_compose_bwd on the SAME grid takes back
  * (Tsave_c64, Dinv_c64: both or neither) instead of evaluating the two polynomials again.                               */
 int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
@@ -428,6 +431,39 @@ int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* 
                          const float* inv_gamma1, const float* part1, int nparts1, const float* b, const float* c,
                          int nblk, int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc,
                          float* gM, void* work, void* stream);
+/* ---- polynomial passes of the same blocks on the reference's own grid by fast transforms (csrc/polyfft.hip).
+ * Preconditions: INTEGER delay lengths (config.py:131-140) and the grid z_k = e^{2 pi i k / nfft}, k = 0 .. nfft / 2
+ * (dataloader.py:552-566), nfft = 2^p: then Q(z_k) = conj(rfft(q, nfft)[k]) for the real sequence q[m] = sum of the
+ * coefficients of degree m mod nfft (<= 256 non-zero samples), and the gradient records are 256 samples of two inverse real
+ * transforms.  Records / scaling convention of gfdn_tf8_* (sequences from the gains BEFORE normalize's rescale; T' = scale T).
+ * Used for normalize, the colorless pass and BOTH adjoints; the FORWARD group responses of the damped loop stay on
+ * gfdn_tf8_tsave: a float32 transform carries an absolute error of ~1e-6 |q|, which next to the loop's poles (small |Q|)
+ * is 1e-5 of T -- 100 x the rounding of the direct evaluation, and it reaches dL/dM through the dB stages of the decay
+ * losses (measured: 1.15e-3 against 7.6e-4 of its largest entry; the adjoints are linear in 1 / Q and do not care).
+ *   gfdn_tfp_forward    : X (2 nblk, ldx >= nfft / 2 + 1) complex64 = rfft of the sequences [Q | P] of ONE record set (nblk
+ *                         rows each).  T: samples per sequence kept in seq (2 nblk, T): max degree + 1 <= T <= nfft.
+ *                         work: gfdn_irfft_pow2_work_bytes(nfft, 2 nblk).
+ *   gfdn_tfp_energy     : normalize on rows (Xq, Xp) of the raw sub-FDN blocks, K = nfft / 2 + 1 bins: energy (or NULL),
+ *                         scale = E^(-1/2), b, c /= E^(1/4) in place.  work: nblk * gfdn_tfp_parts() floats.
+ *   gfdn_tfp_colorless  : gfdn_tf8_colorless on the transformed sequences: loss[blk], gradient records part (nblk, 512)
+ *                         (ONE partial row: nparts = 1 for gfdn_tf8_param_grads).  UV (2 nblk, ldx) complex64, x (2 nblk, ldt >=
+ *                         nfft) float, work: gfdn_irfft_pow2_work_bytes(nfft, 2 nblk), lossp: nblk * gfdn_tfp_parts() floats.
+ *   gfdn_tfp_compose_bwd: gH (nblk, ldh) = dL/d(T'_g filt) on the slot order (slot_of_bin: gfdn_tf8_tsave's hslot) -> gradient
+ *                         records part (nblk, 512) of the damped blocks (the linear step's adjoint: one gradient row per
+ *                         group).  Tnat, Dnat (nblk, Ku): gfdn_tf8_tsave's Tsave / Dinv on bins 0 .. Ku - 1 in bin order;
+ *                         tscale (nblk; or NULL): Tnat holds the UNSCALED functions, T' = tscale Tnat.                   */
+int gfdn_tfp_parts(void);
+int gfdn_tfp_forward(int nfft, int nblk, int nper, const float* coef, const float* delays, const float* c, int T, float* seq,
+                     float* X_c64, int ldx, void* work, void* stream);
+int gfdn_tfp_energy(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, int nper, float* b, float* c,
+                    float* energy, float* scale, void* work, void* stream);
+int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int ldx, int nfft, int nblk, int nper, const float* delays,
+                       const float* scale, int asym, float gscale, float* UV_c64, float* x, int ldt, void* work, float* part,
+                       float* lossp, float* loss, void* stream);
+int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const float* delays, int Ku, const int* slot_of_bin,
+                         const float* gH_c64, int ldh, const float* filt_c64, int ldf, const float* Tnat_c64,
+                         const float* Dnat_c64, const float* tscale, float* UV_c64, int ldx, float* x, int ldt, void* work,
+                         float* part, void* stream);
 
 /* ---- measurement kernel for BASELINE.json configs[4] ("fp32 vs bf16 feedback-matmul on MFMA") ------------------
  * The reference's dense formulation (feedback_loop.py:389-391 explicit resolvent P (K, N, N); model.py:615-619

@@ -115,6 +115,8 @@ def _check(tag, parts_hip, grads_hip, after_hip, before, parts, grads, after, gr
         gh = np.asarray(grads_hip[k], dtype=np.float64).reshape(-1)
         go = g.numpy().astype(np.float64).reshape(-1)
         worst[k] = np.abs(gh - go).max() / (np.abs(go).max() + 1e-300)
+        if k == "feedback_loop.M":
+            print(f"[parity] {tag}: dL/dM max deviation {worst[k]:.3e} of its largest entry")
         assert worst[k] < (grad_tol_M if (grad_tol_M is not None and k == "feedback_loop.M") else grad_tol), \
             (tag, k, worst[k])
         # Adam's first step moves every entry by lr g / (|g| + eps): the update of M (which normalize leaves alone) is
@@ -414,6 +416,35 @@ def test_round5_step_equals_round4_step_full_size():
     for i, cnt in enumerate(res[False][2]):
         a, b = res[True][1][off:off + cnt], res[False][1][off:off + cnt]
         assert np.abs(a - b).max() <= (5e-4 if i == 2 else 3e-5) * np.abs(b).max(), (i, np.abs(a - b).max(), np.abs(b).max())
+        off += cnt
+
+
+def test_transform_passes_equal_matrix_core_passes_full_size_n32():
+    """K = 65 537, two bands of 4 x 8 lines, one replayed step: the polynomial passes of the 8-line blocks as real transforms
+    of their coefficient sequences (csrc/polyfft.hip) against the same step on the matrix-core passes (csrc/blocktf8.hip):
+    losses to 2e-5, gradients to the rounding of 1 / Q next to the loop's poles."""
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    res = {}
+    for new in (True, False):
+        bands = [_band(q, delays=[d + 2 * q for d in DELAYS32]) for q in range(2)]
+        filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
+        bank = BandBank([b_[2] for b_ in bands])
+        assert bank.num_delay_lines_per_group == 8
+        tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=CENTRES)
+        f = tr._fused
+        f.transform_polys = new
+        sds = BandStackedDataset([b_[1] for b_ in bands])
+        step = tr.graphed(sds, B, mask_seed=99).capture(sds.global_rows([[0, 3], [1, 4]]))
+        out = step(sds.global_rows([[2, 5], [0, 3]]))
+        torch.cuda.synchronize()
+        res[new] = ({k: v.detach().cpu().numpy().copy() for k, v in out.items()},
+                    tr.optimizer.flat_grad.detach().cpu().numpy().copy(), [p.numel() for p in tr.optimizer._params])
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=2e-5, atol=0), (k, res[True][0][k], v)
+    off = 0
+    for i, cnt in enumerate(res[False][2]):
+        a, b = res[True][1][off:off + cnt], res[False][1][off:off + cnt]
+        assert np.abs(a - b).max() <= (1e-3 if i == 2 else 1e-4) * np.abs(b).max(), (i, np.abs(a - b).max(), np.abs(b).max())
         off += cnt
 
 
