@@ -56,6 +56,8 @@ SIGNATURES = {
     "gfdn_mlp_gains_banded_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_mlp_gains_banded_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_mlp_gains_banded_bwd_parts": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "gfdn_mlp_gains_banded_bwd_parts_scaled": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                                       _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "gfdn_tf_gain_chunks": (c_int, [c_int]),
     "gfdn_mlp_bwd_takes_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gfdn_subfdn_normalize_work_bytes": (c_size_t, [c_int]),
@@ -75,13 +77,15 @@ SIGNATURES = {
     "gfdn_tf_gpart_bytes": (c_size_t, [c_int]),
     "gfdn_tf_eval": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tf_energy": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_double, _P]),
+    "gfdn_tf_energy_gains": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_double, _P, _P, c_int, c_int,
+                                     _P]),
     "gfdn_tf_colorless": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_float, _P, _P, _P, c_double, _P]),
     "gfdn_tf_compose_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P,
                                     _P]),
     "gfdn_tf_compose_parts": (c_int, [c_int]),
     "gfdn_tf_compose_bwd_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfdn_tf_compose_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P,
-                                    _P]),
+                                    c_int, _P]),
     "gfdn_tf_tail": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     "gfdn_irfft_odd_pairs_bwd_tslots3": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
@@ -107,11 +111,13 @@ SIGNATURES = {
                                      _P]),
     "gfdn_tfp_parts": (c_int, []),
     "gfdn_tfp_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
-    "gfdn_tfp_energy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gfdn_tfp_energy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gfdn_tfp_colorless": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, c_int, _P, _P, _P, _P,
                                    _P]),
-    "gfdn_tfp_compose_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, _P, c_int,
-                                     _P, c_int, _P, _P, _P]),
+    "gfdn_tfp_compose_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P,
+                                     c_int, _P, c_int, _P, _P, _P]),
+    "gfdn_tf8_tail": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                              _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_exp_contract_mfma": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),

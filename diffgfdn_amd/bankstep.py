@@ -6,22 +6,28 @@ sub-FDN forward, b, c /= E^(1/4)), forward (model.py:569-625), losses (trainer.p
 ``optimizer.step()``.  With zero coupling and blocks of at most eight delay lines every one of those stages sees the
 feedback loop only through the group transfer functions T_g(z) -- ratios of multilinear polynomials in the phasors
 z^{m_i} with 2 x 16 (<= 4 lines) or 2 x 256 (5..8 lines, evaluated on the matrix cores) real coefficients per block --
-so the step is
+so the step is (the timed form: the linear step with all of round 5's arrangements; DESIGN.md section 5 has the launch
+sequence with times, the class attributes below select the older forms for cross-checks)
 
-    main  : [Q, QQ = expm -> records of Q_g Q_g and of the raw blocks M_g: one launch] -> energy pass -> finish
-            (normalize: b, c rescaled in place, scale_g) -> group transfer functions T -> irfft whose first pass forms
-            the output stage H from T, the receiver gains and the early-response store (H is never stored) -> STFT
-            -> EDR -> STFT adjoint (even frames, then odd frames + EDC gradient) -> irfft adjoint -> output-stage
-            adjoint (dL/drecords) -> [records -> (dL/dQQ, dL/dM_raw, dL/db, dL/dc) -> expm adjoint: one launch]
-            -> [all-reduce -> Adam]
-    side2 : gain network forward, mask draw, colorless pass (spectral loss + dL/drecords), sparsity ... EDC scans,
-            reported sums ... output-stage adjoint (dL/dgains) -> gain network backward -> next step's receivers
-            -> Adam (single process: the update runs here, behind the branch that finishes last)
+    main  : group responses T_g filt of the band's G groups from the PERSISTENT records (left by the previous step's tail)
+            -> their inverse transform (3 passes; unscaled: normalize's scale sits in the receiver gains) -> their STFT
+            -> [gains] EDR loss on spectra composed per receiver as Sd[row] + sum_g gain[b][g] STFT(tau_g), with the sums of
+            the gradient spectra over the band's receivers in the same launch -> adjoint STFT -> merge with the EDC part
+            -> adjoint transform (3 passes) -> records pass -> tail: parameter gradients -> Adam on M, b, c -> the NEXT
+            step's Q, Q Q and record sets (one launch)
+    side2 : energy pass (normalize) -> gain network forward -> finish (b, c rescaled, scale, gains x scale) -> mask draw
+            -> [group signals] EDC term (one register-resident launch per receiver) -> sum of dL/dx over the band's
+            receivers -> colorless pass + sparsity terms -> reported sums -> gain network backward -> its Adam range
+            -> next step's receivers
 
-33 launches per step of all bands; every gradient lands directly in the optimiser's flat gradient buffer (no
-accumulate / pack kernels), the (K, N) delay-line responses of the per-bin solve never exist.  The autograd
-path of ``BandBankTrainer._step_losses`` (per-bin elimination kernels) stays as the general fallback and as the
-cross-check of this one (tests/test_gpu_bank.py).
+Blocks of 5..8 lines: the same with the coefficient records (csrc/blocktf8.hip) in place of the persistent records, the
+forward group responses on the matrix cores and normalize / colorless pass / both adjoints as real transforms of the
+coefficient sequences (csrc/polyfft.hip) where the delay lengths are integers on the reference's own grid.
+
+28 launches per step of all bands (4-line blocks); every gradient lands directly in the optimiser's flat gradient buffer (no
+accumulate / pack kernels), neither the (K, N) delay-line responses of the per-bin solve nor any per-receiver spectrum or
+time signal exists.  The autograd path of ``BandBankTrainer._step_losses`` (per-bin elimination kernels) stays as the
+general fallback and as the cross-check of this one (tests/test_gpu_bank.py).
 """
 from typing import Dict, Optional
 
@@ -81,7 +87,12 @@ class FusedBankStep:
             nblk, n = bank.num_bands * bank.num_groups, bank.num_delay_lines_per_group
             dev = bank.input_gains.device
             mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-            self._rec = (mk(nblk, n, n), mk(nblk, n, n), mk(nblk, 32), mk(nblk, 32))
+            if n > 4:
+                # blocks of 5..8 lines: Q, Q Q and the snapshot of the output gains the forward pass reads (the coefficient
+                # records themselves are a launch of 500 workgroups at the step's head: csrc/blocktf8.hip)
+                self._rec = (mk(nblk, n, n), mk(nblk, n, n), mk(nblk * n))
+            else:
+                self._rec = (mk(nblk, n, n), mk(nblk, n, n), mk(nblk, 32), mk(nblk, 32))
         return self._rec
 
     def _versions(self):
@@ -104,6 +115,12 @@ class FusedBankStep:
         """Records of the current parameters into the kept buffers (one launch on the current stream)"""
         bank = self.tr.net
         if bank.num_delay_lines_per_group > 4:
+            Q, QQ, cs = self._records()
+            q, qq = ops.ortho_fwd(bank._blocks().detach(), True, True)
+            Q.copy_(q)
+            QQ.copy_(qq)
+            cs.copy_(bank.output_gains.data.view(-1))
+            self._rec_valid, self._rec_versions = True, self._versions()
             return
         ops.tf_ortho_coefs(bank._blocks().detach(), bank.inv_gamma, bank.input_gains.data.view(-1),
                            bank.output_gains.data.view(-1), out=self._records())
@@ -161,6 +178,13 @@ class FusedBankStep:
     # join the group signals where the forward transform's LAST pass stores them.  The energy pass then runs on the side
     # stream beside the group responses and the transform's first two passes instead of in front of them (~28 us of chain).
     scale_late = True
+    # ... and INSIDE the receiver gains (round 5, late in the round): H = sum_g gain[b][g] (s_g T_g) + direct is linear in
+    # both factors, so the finish launch of the energy pass stores gain s beside the gains (the gain network's forward runs in
+    # front of the energy pass on the side stream), every launch of the linear step takes those as the receiver gains on group
+    # signals of the UNSCALED functions, the network's backward multiplies its incoming rows by s and the records pass divides
+    # dL/dT by s.  The transform's last pass then waits for nothing (it waited ~18 us for the scale: the side stream's start-up
+    # inside a graph is ~20 us, the energy pass 26 -- later than the transform's first two passes take).
+    scale_in_gains = True
     # (c) tail and head as one launch (single process): records -> parameter gradients -> Adam on the blocks' own M, b, c
     # -> the NEXT step's Q, QQ and record sets (csrc/blocktf.hip k_tf_tail); the gain network's range of the flat buffers is
     # stepped on the side stream behind its own backward.  A step then starts with the group responses.
@@ -411,8 +435,9 @@ class FusedBankStep:
             raise NotImplementedError("blocks of more than four lines: the explicit step takes grids on the unit circle "
                                       "(set BandBankTrainer.use_fused = False to step this bank through the per-bin "
                                       "elimination kernels under autograd)")
-        use_tail = (self.fused_tail and train and opt_step and allreduce is None and pipe is None and not big
-                    and side2 is not None and self.adam_on_side)
+        tail_ok = (self.fused_tail and train and opt_step and allreduce is None and pipe is None and side2 is not None
+                   and self.adam_on_side)
+        use_tail = tail_ok and not big
         # the normalisation scale joins the group signals behind the transform: energy pass on the side stream
         late = (self.scale_late and lin and order is not None and normalize_first and not big and side2 is not None)
         # blocks of 5..8 lines, integer delay lengths on the reference's own grid: normalize, the colorless pass and both
@@ -427,18 +452,25 @@ class FusedBankStep:
             if T_seq is not None and sob is not None:
                 tfp = (gridK.rfft_nfft, sob, T_seq)
         late8 = tfp is not None
+        use_tail8 = tail_ok and late8                 # (8-line blocks: csrc/blocktf8.hip k_tf8_tail)
         if not late and not late8:
             # (the side stream's head -- receiver gains, mask -- needs nothing of this step: forked off BEFORE the records launch,
             # so that the main chain's launches below stay first in capture order and keep its hardware queue)
             ev['start'].record()
         c_head = c
         if big:
-            Q, QQ = ops.ortho_fwd(M, True, True)
+            if use_tail8 and self.records_ok():
+                # (the previous step's tail left the rotations of the current blocks and the snapshot of the output gains)
+                Q, QQ, c_head = self._records()
+            else:
+                Q, QQ = ops.ortho_fwd(M, True, True)
+                if late8:
+                    # the side stream's normalize rescales the gains in place while the main stream's pass reads them: a
+                    # snapshot
+                    c_head = c.detach().clone()
+                    keep.append(c_head)
+            self._rec_valid = False           # (until this step's end says otherwise)
             coef, coef_sub = ops.tf8_coefs(QQ, ig, b, c, A1=M)
-            if late8:
-                # the side stream's normalize rescales the gains in place while the main stream's pass reads them: a snapshot
-                c_head = c.detach().clone()
-                keep.append(c_head)
         else:
             # (the fused tail of the previous training step left them; anything else that touched M, b, c since made
             # the bookkeeping say so)
@@ -450,6 +482,12 @@ class FusedBankStep:
             self._rec_valid = False           # (until this step's end says otherwise)
         if late or late8:
             ev['start'].record()              # (the side stream's energy pass reads the raw blocks' records)
+        spec_ok = (lin and self.spectral_edr and pairs and order is not None and win == 4096
+                   and ops.spec_supported(Btot // nb, G) and hasattr(data['dataset'], 'direct_stft'))
+        # the normalisation scale inside the receiver gains (scale_in_gains above)
+        gfold = ((late or late8) and self.scale_in_gains and pipe is None and spec_ok and train
+                 and self.gamma_dots_one_launch and self.gain_rows_in_mlp
+                 and ops.mlp_bwd_takes_parts(bank._freq_pi.numel(), Hh, n_hidden, G, Btot // nb))
         if pipe is not None and (not train or allreduce is not None or not opt_step or side2 is None):
             raise ValueError("a pipelined step is a single-process training step with its optimiser update")
         scale = None
@@ -485,17 +523,40 @@ class FusedBankStep:
         with on_side2():
             if pipe is None or pipe.first:
                 torch.cuda.current_stream().wait_event(ev['start'])
+            rgain0 = None
+            if gfold and big:
+                # 8-line blocks: the gain network FIRST (it needs nothing of this step), the transforms and the energy pass behind
+                # it; the finish launch stores the gains times the scale -- rgain, what the step's launches take; rgain0, the
+                # network's own output, is what its backward reads.  (4-line blocks: in front of the energy pass it measured
+                # 0.355 against 0.352 ms, the same as no fold at all)
+                rgain0, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
+                                                       G, lo, hi, rows, nb)
+                keep.append(rgain0)
             if late:
-                _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
-                                         dturn=gridK.dturn)
+                if gfold:
+                    # (4-line blocks: the pass over the bins, the gain network, then the finish with the gains)
+                    ework = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, phase=1, dturn=gridK.dturn)
+                    rgain0, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
+                                                           G, lo, hi, rows, nb)
+                    keep.append(rgain0)
+                    _, scale, rgain = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
+                                                    work=ework, phase=2, dturn=gridK.dturn, gains=rgain0, G=G)
+                else:
+                    _, scale = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
+                                             dturn=gridK.dturn)
                 ev['norm'].record()
             elif late8:
                 nblk8 = nb * G
                 Xsub = ops.tfp_forward(coef_sub, delays, c, n, tfp[0], tfp[2])
-                _, scale = ops.tfp_energy(Xsub[:nblk8], Xsub[nblk8:], n, b, c)
+                if gfold:
+                    _, scale, rgain = ops.tfp_energy(Xsub[:nblk8], Xsub[nblk8:], n, b, c, gains=rgain0, G=G)
+                else:
+                    _, scale = ops.tfp_energy(Xsub[:nblk8], Xsub[nblk8:], n, b, c)
                 ev['norm'].record()
                 keep.append(Xsub)
-            if pipe is None:
+            if gfold:
+                ev['mlp'].record()
+            elif pipe is None:
                 rgain, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
                                                       G, lo, hi, rows, nb)
                 ev['mlp'].record()
@@ -544,16 +605,16 @@ class FusedBankStep:
             elif not late:
                 Hg, Ts = ops.tf_compose_fwd(gridU.turns, gridU.logr, coef, delays, n, eye, scale, None, filt, None, nb,
                                             save_T=True, want_H=True)
-            if late or late8:
-                # (the wait sits in front of the LAST pass, the only reader of the scale: by then the side stream's energy
-                # pass is long done and the wait is free)
+            if gfold:
+                tau = ops.irfft_odd_fwd(Hg, K, slots=True, pairs=True)     # (signals of the unscaled functions: no wait)
+            elif late or late8:
+                # (the wait sits in front of the LAST pass, the only reader of the scale)
                 tau = ops.irfft_odd_fwd(Hg, K, slots=True, pairs=True, oscale=scale,
                                         before_last=lambda: main.wait_event(ev['norm']))
             else:
                 tau = ops.irfft_odd_fwd(Hg, K, slots=order is not None, pairs=tau_pairs)
             H = Hg
-            spec = (self.spectral_edr and pairs and tau_pairs and win == 4096 and ops.spec_supported(Btot // nb, G)
-                    and hasattr(data['dataset'], 'direct_stft'))
+            spec = spec_ok
 
             def x_fn():
                 wait_gains()
@@ -643,7 +704,7 @@ class FusedBankStep:
             return s_, ((s_[:, 0] + out3[:, 0]) if nb > 1 else (s_[0] + out3[0]))
 
         if train:
-            if use_tail and not torch.cuda.is_current_stream_capturing():
+            if (use_tail or use_tail8) and not torch.cuda.is_current_stream_capturing():
                 tr.optimizer.sync_lr()            # (both Adam launches of the split update read the device table)
             # ---- backward of the output stage.  Its two passes are independent and both stream dL/dH: the records pass
             # stays on the main stream, the gains pass (-> gain network backward) runs beside it on side2 -- together
@@ -688,14 +749,15 @@ class FusedBankStep:
             else:
                 gH_rec, rg_rec = gH, rgain
             if late8:
-                grec = ops.tfp_compose_bwd(tfp[0], nb, G, n, delays, Ku, tfp[1], gH_rec, filt, Ts, Dinv8, tscale=scale)
+                grec = ops.tfp_compose_bwd(tfp[0], nb, G, n, delays, Ku, tfp[1], gH_rec, filt, Ts, Dinv8, tscale=scale,
+                                           gain_fold=gfold)
             elif big:
                 # (the linear step's adjoint runs on the grid of the forward pass: its saved T' and 1 / Q come back)
                 grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb,
                                            saved=(Ts, Dinv8) if lin else None)
             else:
                 grec = ops.tf_compose_bwd(gridU.turns, gridU.logr, coef, delays, n, rg_rec, gH_rec, Ts, filt, nb, partial=True,
-                                          tscale=scale if late else None)
+                                          tscale=scale if late else None, gain_fold=gfold and late)
             with on_side2():
                 if spec and self.gamma_dots_one_launch:
                     torch.cuda.current_stream().wait_event(ev_gam)           # (behind the EDR launch as well)
@@ -735,8 +797,9 @@ class FusedBankStep:
                     grg, ggp = None, ops.tf_gain_grad(Ts, gH, G, filt, nb, partial=True)
                 else:
                     grg, ggp = ops.tf_gain_grad(Ts, gH, G, filt, nb), None
-                ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi, rgain,
-                                  xhat, rstd, grg, rows, nb, out=self.g_w, ggains_parts=ggp)
+                ops.mlp_gains_bwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden, G, lo, hi,
+                                  rgain0 if gfold else rgain, xhat, rstd, grg, rows, nb, out=self.g_w, ggains_parts=ggp,
+                                  colscale=scale if gfold else None)
                 keep.append(ggp)
                 if pipe is not None:
                     # the gain network's range of the flat buffers is stepped HERE, behind its gradient, on this
@@ -750,7 +813,7 @@ class FusedBankStep:
                     pipe.ready_next = torch.cuda.Event()
                     pipe.ready_next.record()
                 else:
-                    if use_tail:
+                    if use_tail or use_tail8:
                         # the gain network's range of the flat buffers, straight behind its gradient on this stream (its
                         # own step counter: no ordering with the main stream's fused tail)
                         tr.optimizer.step_range(*self.w_range, second=True)
@@ -760,7 +823,11 @@ class FusedBankStep:
                                           # front of ev['grg'], this stream's are its own earlier launches)
             main.wait_event(ev['side'])          # (signalled long ago; dropping it measured no gain: 0.667 vs 0.663 ms)
             # records (partial rows of the records pass + the colorless pass's) -> dL/dM, dL/db, dL/dc: one launch
-            if big:
+            if use_tail8:
+                # ... -> Adam on the blocks' own M, b, c -> the NEXT step's Q, Q Q and gain snapshot, in the same launch
+                ops.tf8_tail(QQ, ig, grec, grec_sub, b, c, M, gQ, Q, self.g_b, self.g_c, self.g_M, tr.optimizer, *self._off,
+                             *self._records())
+            elif big:
                 ops.tf8_param_grads(QQ, ig, grec, b, c, M, A1=M, part1=grec_sub, gQ=gQ, Q=Q, gb=self.g_b, gc=self.g_c,
                                     gM=self.g_M)
             elif use_tail:
@@ -778,7 +845,7 @@ class FusedBankStep:
                 sums_total = (sums, total)
                 return self._finish_pipe(pipe, sums_total, out3, nb, main, side, side2)
             tr.optimizer._packed = True               # the flat gradient buffer is complete
-            if use_tail:
+            if use_tail or use_tail8:
                 # both ranges of the flat buffers are stepped (main: fused tail; side2: the gain network's own launch)
                 tr.optimizer._packed = False
                 torch.autograd.graph.increment_version(tr.optimizer._params)

@@ -463,27 +463,6 @@ extern "C" int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, con
 // reads t = step_count + 1; the LAST workgroup to finish writes t back (every workgroup read it before reporting in) and
 // re-arms the counter.  The rest of the flat buffer (the gain network) is stepped by its own launch on its own counter
 // (FlatAdam.step_range(second=True)).  The updated values go to the next records through LDS, not back through memory.
-struct TfAdam {
-  float* p;                    // flat parameters
-  float* m;
-  float* v;
-  const unsigned char* seg;
-  const float* lr_seg;
-  float* step_count;
-  unsigned int* block_counter;
-  int offM, offb, offc;
-  float b1, b2, eps;
-};
-
-__device__ __forceinline__ float tf_adam_elem(const TfAdam& ad, int i, float gi, float bc1, float bc2_sqrt) {
-  float mi = ad.m[i], vi = ad.v[i];
-  const float pn = adam_elem(ad.p[i], gi, mi, vi, ad.lr_seg[ad.seg[i]], bc1, bc2_sqrt, ad.b1, ad.b2, ad.eps);
-  ad.m[i] = mi;
-  ad.v[i] = vi;
-  ad.p[i] = pn;
-  return pn;
-}
-
 __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int nparts0, const float* b, const float* c,
                                                  int n, const float* M, const float* gQ, const float* Q, float* gb,
                                                  float* gc, float* gM, TfAdam ad, float* Qn, float* QQn, float* coef0,
@@ -749,9 +728,13 @@ __global__ __launch_bounds__(256) void k_tf_energy_runs(TfArgs a, double dturn, 
 
 // E = sum / K -> energy, scale = E^(-1/2) (what T and the numerator coefficients scale by once b, c are
 // divided by E^(1/4): trainer.py:317-332), and the in-place rescale of b, c
+// gains / gains_scaled ((nblk / G) Bper, G) or NULL: column g % G of band g / G of the receiver gains times the block's scale
+// (the scale folded into the gains: see gfdn_tf_energy_gains)
 __global__ __launch_bounds__(256) void k_tf_energy_finish(const float* __restrict__ partial, int nparts, int K,
                                                           int nper, float* __restrict__ b, float* __restrict__ c,
-                                                          float* __restrict__ energy, float* __restrict__ scale) {
+                                                          float* __restrict__ energy, float* __restrict__ scale,
+                                                          const float* __restrict__ gains, float* __restrict__ gains_scaled,
+                                                          int Bper, int G) {
   __shared__ float s_red[16];
   const int g = blockIdx.x;
   float s = 0.f;
@@ -761,6 +744,14 @@ __global__ __launch_bounds__(256) void k_tf_energy_finish(const float* __restric
   if (threadIdx.x == 0) {
     if (energy) energy[g] = E;
     if (scale) scale[g] = 1.0f / sqrtf(E);
+  }
+  if (gains_scaled) {
+    const float sc = 1.0f / sqrtf(E);
+    const int band = g / G, col = g - band * G;
+    for (int r = threadIdx.x; r < Bper; r += 256) {
+      const size_t i = ((size_t)band * Bper + r) * G + col;
+      gains_scaled[i] = gains[i] * sc;
+    }
   }
   if (b && c) {
     const float d = powf(E, 0.25f);
@@ -775,9 +766,29 @@ extern "C" size_t gfdn_tf_work_bytes(int nblk) {
   return (size_t)TF_MAX_PARTS * (nblk > 0 ? nblk : 1) * sizeof(float);
 }
 
+static int tf_energy_run(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                         const float* delays, float* b, float* c, float* energy, float* scale, void* work, int phase,
+                         double dturn, const float* gains, float* gains_scaled, int Bper, int G, void* stream);
 extern "C" int gfdn_tf_energy(const double* turns, const double* logr, int K, int nblk, int nper,
                               const float* coef, const float* delays, float* b, float* c, float* energy,
                               float* scale, void* work, int phase, double dturn, void* stream) {
+  return tf_energy_run(turns, logr, K, nblk, nper, coef, delays, b, c, energy, scale, work, phase, dturn, nullptr, nullptr, 0, 0,
+                       stream);
+}
+// ... whose finish also stores gains_scaled[band Bper + r][g] = gains[..][g] scale[band G + g] (nblk = bands x G blocks): the
+// normalisation scale folded into the receiver gains -- H = sum_g gain[b][g] (s_g T_g) + direct is linear in both -- so that
+// the launches of the linear step can run on group signals of the UNSCALED functions and nothing waits for the scale
+extern "C" int gfdn_tf_energy_gains(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                                    const float* delays, float* b, float* c, float* energy, float* scale, void* work,
+                                    int phase, double dturn, const float* gains, float* gains_scaled, int Bper, int G,
+                                    void* stream) {
+  if (!gains || !gains_scaled || Bper <= 0 || G <= 0 || nblk % G || !(phase & 2)) return GFDN_E_BADARG;
+  return tf_energy_run(turns, logr, K, nblk, nper, coef, delays, b, c, energy, scale, work, phase, dturn, gains, gains_scaled, Bper,
+                       G, stream);
+}
+static int tf_energy_run(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                         const float* delays, float* b, float* c, float* energy, float* scale, void* work, int phase,
+                         double dturn, const float* gains, float* gains_scaled, int Bper, int G, void* stream) {
   int rc = tf_args_ok(turns, K, nblk, nper, coef, delays);
   if (rc) return rc;
   if (!work || (!b) != (!c) || !(phase & 3)) return GFDN_E_BADARG;
@@ -793,7 +804,7 @@ extern "C" int gfdn_tf_energy(const double* turns, const double* logr, int K, in
   }
   if (phase & 2) {
     hipLaunchKernelGGL(k_tf_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, nparts, K, nper, b, c,
-                       energy, scale);
+                       energy, scale, gains, gains_scaled, Bper, G);
     GFDN_LAUNCH_CHECK();
   }
   return 0;
@@ -926,6 +937,8 @@ struct TfCompose {
   const float* rgain;
   const float2* filt;
   int ldf;
+  int fold;                  // records pass with a.scale: gH is dL/d(T filt) of the UNSCALED functions (the scale sits in the
+                             // receiver gains): dL/dT' = dL/dT / scale
 };
 
 #define TFC_BCH 8
@@ -1106,6 +1119,7 @@ __global__ __launch_bounds__(256) void k_tf_compose_bwd_rec(TfCompose a, const f
   // (a.scale: Tsave holds the UNSCALED functions -- the step's normalisation scale joined the group signals behind the
   // transform -- and T' = scale T is formed here)
   const float tsc = a.scale ? a.scale[band * G + w] : 1.0f;
+  const float itsc = 1.0f / tsc;
   const int ntiles = (a.K + TFB_T - 1) / TFB_T;
   for (int tile = blockIdx.x; tile < ntiles; tile += nparts) {
     const int k = tile * TFB_T + lane;
@@ -1133,8 +1147,14 @@ __global__ __launch_bounds__(256) void k_tf_compose_bwd_rec(TfCompose a, const f
       den.x += Q[S] * e[S].x;
       den.y += Q[S] * e[S].y;
     }
-    const float2 u = cmulc(acc, cinv(den));             // dL/dT' conj(1 / Den)
-    const float2 v = cmulc(u, a.scale ? cscale(Tp[kk], tsc) : Tp[kk]);
+    float2 u = cmulc(acc, cinv(den));                   // dL/dT' conj(1 / Den)
+    float2 v;
+    if (a.fold) {                                       // (acc = scale dL/dT': v = u' conj(scale T) = u conj(T), u' = u / scale)
+      v = cmulc(u, Tp[kk]);
+      u = cscale(u, itsc);
+    } else {
+      v = cmulc(u, a.scale ? cscale(Tp[kk], tsc) : Tp[kk]);
+    }
     aP[0] += u.x;
     aQ[0] -= v.x;
 #pragma unroll
@@ -1199,11 +1219,11 @@ extern "C" int gfdn_tf_gain_chunks(int K) { return K > 0 ? tf_gain_chunks_host(K
 extern "C" int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
                                    const float* coef, const float* delays, const float* Tsave, const float* tscale,
                                    const float* rgain, int B, const float* filt, int ldf, const float* gH,
-                                   int ldh, float* grec, void* work, void* stream) {
+                                   int ldh, float* grec, void* work, int gain_fold, void* stream) {
   int rc = tf_compose_ok(turns, K, nbands, G, nper, B, coef, delays, rgain);
   if (rc) return rc;
-  if (!Tsave || !gH || !work || ldh < K || (filt && nbands > 1 && ldf < K)) return GFDN_E_BADARG;
-  TfCompose a{turns, logr, K, G, nper, B, coef, delays, tscale, rgain, (const float2*)filt, ldf};
+  if (!Tsave || !gH || !work || ldh < K || (filt && nbands > 1 && ldf < K) || (gain_fold && !tscale)) return GFDN_E_BADARG;
+  TfCompose a{turns, logr, K, G, nper, B, coef, delays, tscale, rgain, (const float2*)filt, ldf, gain_fold ? 1 : 0};
   const int nparts = tf_compose_parts_host(K);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_tf_compose_bwd_rec, dim3(nparts, nbands), dim3(256), 0, s, a, (const float2*)Tsave,

@@ -786,6 +786,74 @@ __global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict
                   gM + off);
 }
 
+// The same tail with the optimiser and the next step's rotations inside (as k_tf_tail for the 4-line blocks): partial rows ->
+// gradients -> Adam on the block's own entries of M, b, c (every element by the thread that wrote its gradient:
+// dL/db[i] thread 128 + i, dL/dc[j] thread 192 + j, dL/dM[e] thread e) -> Q = expm(skew(M_new)), Q Q and a snapshot of the
+// updated output gains (what the next step's forward pass reads while its normalize rescales them) -- one workgroup per
+// block; the last one advances the step counter.
+__global__ __launch_bounds__(256) void k_tf8_tail(const float* __restrict__ part0, const float* __restrict__ part1, int n,
+                                                  const float* __restrict__ M, const float* __restrict__ gQ,
+                                                  const float* __restrict__ Q, float* __restrict__ gb,
+                                                  float* __restrict__ gc, float* __restrict__ gM, int half2, TfAdam ad,
+                                                  float* __restrict__ Qn, float* __restrict__ QQn,
+                                                  float* __restrict__ c_next) {
+  extern __shared__ double t8p_lds[];
+  __shared__ float srec[2][T8_ACC], sG[2][64], sM[64];
+  const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+  const float t = ad.step_count[0] + 1.0f;
+  for (int r = tid >> 6; r < 2 * T8_ACC; r += nw) {
+    const int set = r / T8_ACC, e = r - set * T8_ACC;
+    const float* p = set ? part1 : part0;
+    float s = 0.f;
+    if (lane == 0) s = p[(size_t)blk * T8_ACC + e] + p[(size_t)blk * T8_ACC + e + half2];
+    if (lane == 0) srec[set][e] = s;
+  }
+  __syncthreads();
+  if (tid < 2 * n * n) {
+    const int set = tid / (n * n), e = tid - set * n * n, i = e / n, j = e - i * n;
+    sG[set][e] = srec[set][i * 8 + j];
+  } else if (tid >= 128 && tid < 128 + n) {
+    const int i = tid - 128;
+    gb[blk * n + i] = srec[0][64 + i] + srec[1][64 + i];
+  } else if (tid >= 192 && tid < 192 + n) {
+    const int j = tid - 192;
+    gc[blk * n + j] = srec[0][72 + j] + srec[1][72 + j];
+  }
+  __syncthreads();
+  const size_t off = (size_t)blk * n * n;
+  ortho_bwd_group(t8p_lds, M + off, n, gQ ? gQ + off : nullptr, sG[0], Q ? Q + off : nullptr, sG[1], gM + off);
+  const float bc1 = 1.0f - powf(ad.b1, t), bc2_sqrt = sqrtf(1.0f - powf(ad.b2, t));
+  if (tid < n * n) sM[tid] = tf_adam_elem(ad, ad.offM + (int)off + tid, gM[off + tid], bc1, bc2_sqrt);
+  if (tid >= 128 && tid < 128 + n) tf_adam_elem(ad, ad.offb + blk * n + tid - 128, gb[blk * n + tid - 128], bc1, bc2_sqrt);
+  if (tid >= 192 && tid < 192 + n)
+    c_next[blk * n + tid - 192] = tf_adam_elem(ad, ad.offc + blk * n + tid - 192, gc[blk * n + tid - 192], bc1, bc2_sqrt);
+  __syncthreads();
+  {
+    double* A = t8p_lds;
+    double* P = A + n * n;
+    double* R = P + n * n;
+    double* T = R + n * n;
+    double* tmp = T + n * n;
+    for (int e = tid; e < n * n; e += blockDim.x) A[e] = skew_elem(sM, n, e / n, e % n);
+    __syncthreads();
+    const double* E = expm_lds(A, P, R, T, tmp, n);
+    for (int e = tid; e < n * n; e += blockDim.x) {
+      Qn[off + e] = (float)E[e];
+      const int i = e / n, j = e - i * n;
+      double acc = 0.0;
+      for (int q = 0; q < n; ++q) acc += E[i * n + q] * E[q * n + j];
+      QQn[off + e] = (float)acc;
+    }
+  }
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(ad.block_counter, 1u) == gridDim.x - 1) {
+      ad.step_count[0] = t;
+      ad.block_counter[0] = 0u;
+    }
+  }
+}
+
 extern "C" size_t gfdn_tf8_param_grads_work_bytes(int nblk) { return (size_t)4 * (nblk > 0 ? nblk : 1) * T8_ACC * sizeof(float); }
 
 extern "C" int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* part0, int nparts0,
@@ -807,6 +875,36 @@ extern "C" int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, co
   if (rc) return rc;
   hipLaunchKernelGGL(k_tf8_param_grads, dim3(nblk), dim3(256), lds, s, (const float*)out0, 1, A1 ? (const float*)out1 : nullptr,
                      1, (const float*)nullptr, nper, M, gQ, Q, gb, gc, gM, nblk * 2 * T8_ACC);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// gfdn_tf8_param_grads with the optimiser update of the blocks' own M, b, c (flat buffers of gfdn_adam_step at the element
+// offsets offM / offb / offc; same roundings: adam_elem) and the next step's Q, Q Q and output-gain snapshot in the same
+// launch (k_tf8_tail).  Both record sets are required.
+extern "C" int gfdn_tf8_tail(const float* A0, const float* inv_gamma0, const float* part0, int nparts0, const float* A1,
+                             const float* part1, int nparts1, const float* b, const float* c, int nblk, int nper,
+                             const float* M, const float* gQ, const float* Q, float* gb, float* gc, float* gM, void* work,
+                             float* flat_p, float* flat_m, float* flat_v, const unsigned char* seg, const float* lr_seg,
+                             float* step_count, unsigned int* block_counter, int offM, int offb, int offc, float beta1,
+                             float beta2, float eps, float* Q_next, float* QQ_next, float* c_next, void* stream) {
+  if (!A0 || !part0 || !A1 || !part1 || !b || !c || !M || !gb || !gc || !gM || !work || !flat_p || !flat_m || !flat_v || !seg ||
+      !lr_seg || !step_count || !block_counter || !Q_next || !QQ_next || !c_next || nblk <= 0 || nper <= 0 || nparts0 <= 0 ||
+      nparts1 <= 0 || offM < 0 || offb < 0 || offc < 0)
+    return GFDN_E_BADARG;
+  if (nper > 8) return GFDN_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* out0 = (float*)work;
+  float* out1 = out0 + (size_t)nblk * T8_ACC;
+  hipLaunchKernelGGL(k_tf8_rec_grads, dim3(nblk, 2, 2), dim3(256), 0, s, A0, inv_gamma0, part0, nparts0, A1,
+                     (const float*)nullptr, part1, nparts1, b, c, nper, out0, out1);
+  GFDN_LAUNCH_CHECK();
+  TfAdam ad{flat_p, flat_m, flat_v, seg, lr_seg, step_count, block_counter, offM, offb, offc, beta1, beta2, eps};
+  const size_t lds = ortho_bwd_lds_doubles(nper) * sizeof(double);
+  int rc = ensure_dyn_lds(k_tf8_tail, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tf8_tail, dim3(nblk), dim3(256), lds, s, (const float*)out0, (const float*)out1, nper, M, gQ, Q, gb, gc,
+                     gM, nblk * 2 * T8_ACC, ad, Q_next, QQ_next, c_next);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -49,6 +49,30 @@ __device__ __forceinline__ float adam_elem(float p, float g, float& m, float& v,
   return __fsub_rn(p, __fmul_rn(__fdiv_rn(lr, bc1), __fdiv_rn(m, denom)));
 }
 
+// The flat optimiser buffers (optim.hip) as a kernel argument: the tails of the bank's step (blocktf.hip k_tf_tail,
+// blocktf8.hip k_tf8_tail) step the blocks' own entries of M, b, c themselves, straight behind their gradients.
+struct TfAdam {
+  float* p;                    // flat parameters
+  float* m;
+  float* v;
+  const unsigned char* seg;
+  const float* lr_seg;
+  float* step_count;
+  unsigned int* block_counter;
+  int offM, offb, offc;
+  float b1, b2, eps;
+};
+
+__device__ __forceinline__ float tf_adam_elem(const TfAdam& ad, int i, float gi, float bc1, float bc2_sqrt) {
+  float mi = ad.m[i], vi = ad.v[i];
+  const float pn = adam_elem(ad.p[i], gi, mi, vi, ad.lr_seg[ad.seg[i]], bc1, bc2_sqrt, ad.b1, ad.b2, ad.eps);
+  ad.m[i] = mi;
+  ad.v[i] = vi;
+  ad.p[i] = pn;
+  return pn;
+}
+
+
 // sum over the 64 lanes of a wavefront
 // Cross-lane sums on the VALU (DPP inside the rows of 16 lanes, v_permlane16_swap / v_permlane32_swap of gfx950 between
 // rows and half-waves).  __shfl_* compile to ds_bpermute_b32, which issues on the LDS pipe with its latency: a butterfly of

@@ -23,6 +23,9 @@ struct MlpDims {
   int stage;                    // 1: the packed parameters (+ the receiver's saved activations) fit in LDS
   int Bper;                     // items per band: item b uses the parameter set b / Bper (w is (bands, P))
   int gparts;                   // > 0: ``ggains`` holds (B G, gparts) partial rows (gfdn_tf_gain_grad without its row sums)
+  // (wave-per-receiver backward) column scales s[band G + g] (normalize's scale of the band's groups, trainer.py:317-332,
+  // folded into the receiver gains: gfdn_tf_energy_gains): ``ggains`` holds dL/d(gains s), multiplied by s first
+  const float* colscale;
 };
 
 __device__ __forceinline__ size_t mlp_layer_off(const MlpDims& d, int l) {
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const 
     }
   }
   if (lane < G) {
-    const float gg = d.gparts > 0 ? gg_row : ggains[(size_t)b * G + lane];
+    float gg = d.gparts > 0 ? gg_row : ggains[(size_t)b * G + lane];
+    if (d.colscale) gg *= d.colscale[(b / d.Bper) * G + lane];
     if (d.hi > d.lo) {
       const float sg = (gains[(size_t)b * G + lane] - d.lo) / (d.hi - d.lo);
       DRAW[lane] = gg * (d.hi - d.lo) * sg * (1.0f - sg);
@@ -494,6 +498,7 @@ static int mlp_dims(int B, int F, int H, int n_hidden, int G, float lo, float hi
   d->rows = nullptr;
   d->Bper = B;
   d->gparts = 0;
+  d->colscale = nullptr;
   d->stage = mlp_param_count(*d) <= MLP_STAGE_MAX ? 1 : 0;
   return 0;
 }
@@ -569,7 +574,7 @@ static int mlp_banded_bwd_run(const double* pos, const long long* pos_rows, cons
                               const float* w, int nbands, int Bper, int F, int H, int n_hidden,
                               int G, float lo, float hi, const float* gains, const float* xhat,
                               const float* rstd, const float* ggains, int gparts, float* gw, void* work,
-                              void* stream);
+                              void* stream, const float* colscale = nullptr);
 
 // 1 when gfdn_mlp_gains_banded_bwd_parts takes this network (the wave-per-receiver form applies), else 0
 extern "C" int gfdn_mlp_bwd_takes_parts(int F, int H, int n_hidden, int G, int Bper) {
@@ -597,12 +602,22 @@ extern "C" int gfdn_mlp_gains_banded_bwd_parts(const double* pos, const long lon
   return mlp_banded_bwd_run(pos, pos_rows, freq_pi, w, nbands, Bper, F, H, n_hidden, G, lo, hi, gains, xhat, rstd,
                             ggains_parts, gparts, gw, work, stream);
 }
+// ... where the partial rows hold dL/d(gains colscale): every row sum is multiplied by colscale[band G + g] first
+extern "C" int gfdn_mlp_gains_banded_bwd_parts_scaled(const double* pos, const long long* pos_rows, const float* freq_pi,
+                                                      const float* w, int nbands, int Bper, int F, int H, int n_hidden,
+                                                      int G, float lo, float hi, const float* gains, const float* xhat,
+                                                      const float* rstd, const float* ggains_parts, int gparts,
+                                                      const float* colscale, float* gw, void* work, void* stream) {
+  if (gparts <= 0 || !colscale) return GFDN_E_BADARG;
+  return mlp_banded_bwd_run(pos, pos_rows, freq_pi, w, nbands, Bper, F, H, n_hidden, G, lo, hi, gains, xhat, rstd,
+                            ggains_parts, gparts, gw, work, stream, colscale);
+}
 
 static int mlp_banded_bwd_run(const double* pos, const long long* pos_rows, const float* freq_pi,
                               const float* w, int nbands, int Bper, int F, int H, int n_hidden,
                               int G, float lo, float hi, const float* gains, const float* xhat,
                               const float* rstd, const float* ggains, int gparts, float* gw, void* work,
-                              void* stream) {
+                              void* stream, const float* colscale) {
   MlpDims d;
   if (nbands <= 0 || Bper <= 0) return GFDN_E_BADARG;
   const int B = nbands * Bper;
@@ -611,6 +626,7 @@ static int mlp_banded_bwd_run(const double* pos, const long long* pos_rows, cons
   d.Bper = Bper;
   d.gparts = gparts;
   d.rows = pos_rows;
+  d.colscale = colscale;
   if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const size_t P = mlp_param_count(d);

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void k_pf_energy(const float2* __restrict__ Xq
 }
 __global__ __launch_bounds__(256) void k_pf_energy_finish(const float* __restrict__ partial, int nparts, int K, int nper,
                                                           float* __restrict__ b, float* __restrict__ c,
-                                                          float* __restrict__ energy, float* __restrict__ scale) {
+                                                          float* __restrict__ energy, float* __restrict__ scale,
+                                                          const float* __restrict__ gains, float* __restrict__ gains_scaled,
+                                                          int Bper, int G) {
   __shared__ float s_r[16];
   const int g = blockIdx.x;
   float s = 0.f;
@@ -125,6 +127,14 @@ __global__ __launch_bounds__(256) void k_pf_energy_finish(const float* __restric
     if (energy) energy[g] = E;
     if (scale) scale[g] = 1.0f / sqrtf(E);
   }
+  if (gains_scaled) {                 // (the scale folded into the receiver gains: gfdn_tf_energy_gains)
+    const float sc = 1.0f / sqrtf(E);
+    const int band = g / G, col = g - band * G;
+    for (int r = threadIdx.x; r < Bper; r += 256) {
+      const size_t i = ((size_t)band * Bper + r) * G + col;
+      gains_scaled[i] = gains[i] * sc;
+    }
+  }
   const float d = powf(E, 0.25f);
   for (int i = threadIdx.x; i < nper; i += 256) {
     b[g * nper + i] /= d;
@@ -133,13 +143,16 @@ __global__ __launch_bounds__(256) void k_pf_energy_finish(const float* __restric
 }
 
 extern "C" int gfdn_tfp_energy(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, int nper, float* b,
-                               float* c, float* energy, float* scale, void* work, void* stream) {
+                               float* c, float* energy, float* scale, void* work, const float* gains, float* gains_scaled,
+                               int Bper, int G, void* stream) {
   if (!Xq_c64 || !Xp_c64 || !b || !c || !scale || !work || K <= 0 || ldx < K || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
+  if (gains_scaled && (!gains || Bper <= 0 || G <= 0 || nblk % G)) return GFDN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_pf_energy, dim3(PF_PARTS, nblk), dim3(256), 0, s, (const float2*)Xq_c64, (const float2*)Xp_c64, ldx, K,
                      (float*)work);
   GFDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_pf_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, PF_PARTS, K, nper, b, c, energy, scale);
+  hipLaunchKernelGGL(k_pf_energy_finish, dim3(nblk), dim3(256), 0, s, (const float*)work, PF_PARTS, K, nper, b, c, energy, scale,
+                     gains, gains_scaled, Bper, G);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
@@ -218,7 +231,8 @@ __global__ __launch_bounds__(256) void k_pf_bwd_spectra(const float2* __restrict
                                                         int ldf, const float2* __restrict__ Tnat,
                                                         const float2* __restrict__ Dnat, int G, int Ku, int K,
                                                         const int* __restrict__ slot_of_bin, int nblk,
-                                                        const float* __restrict__ tscale, float2* __restrict__ UV, int ldx) {
+                                                        const float* __restrict__ tscale, int fold,
+                                                        float2* __restrict__ UV, int ldx) {
   const int blk = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
   float2 u = make_float2(0.f, 0.f), v = u;
@@ -229,10 +243,15 @@ __global__ __launch_bounds__(256) void k_pf_bwd_spectra(const float2* __restrict
     if (filt) g = cmulc(g, filt[(size_t)band * ldf + col]);            // dL/dT' of the slot
     if (so < 0) g = cconj(g);                                          // ... of the bin: Re(conj(g_s) dT_s), T_s = conj(T_k)
     const float2 dinv = Dnat[(size_t)blk * Ku + k];
-    const float2 t = cscale(Tnat[(size_t)blk * Ku + k], tscale ? tscale[blk] : 1.0f);
+    const float ts = tscale ? tscale[blk] : 1.0f;
     const float w = (k == 0 || k == K - 1) ? 2.0f * (float)(K - 1) : (float)(K - 1);
     u = cscale(make_float2(g.x * dinv.x + g.y * dinv.y, g.x * dinv.y - g.y * dinv.x), w);       // w conj(g) / Q
-    v = cmul(u, t);
+    if (fold) {                        // g = scale dL/dT' (the scale sits in the receiver gains): v = -(u / s)(s T), u' = u / s
+      v = cmul(u, Tnat[(size_t)blk * Ku + k]);
+      u = cscale(u, 1.0f / ts);
+    } else {
+      v = cmul(u, cscale(Tnat[(size_t)blk * Ku + k], ts));
+    }
     v = make_float2(-v.x, -v.y);
   }
   UV[(size_t)blk * ldx + k] = u;
@@ -241,18 +260,18 @@ __global__ __launch_bounds__(256) void k_pf_bwd_spectra(const float2* __restrict
 
 extern "C" int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const float* delays, int Ku, const int* slot_of_bin,
                                     const float* gH_c64, int ldh, const float* filt_c64, int ldf, const float* Tnat_c64,
-                                    const float* Dnat_c64, const float* tscale, float* UV_c64, int ldx, float* x, int ldt,
-                                    void* work, float* part, void* stream) {
+                                    const float* Dnat_c64, const float* tscale, int gain_fold, float* UV_c64, int ldx,
+                                    float* x, int ldt, void* work, float* part, void* stream) {
   if (!delays || !slot_of_bin || !gH_c64 || !Tnat_c64 || !Dnat_c64 || !UV_c64 || !x || !work || !part || nbands <= 0 || G <= 0 ||
       nper <= 0 || nfft < 16 || (nfft & (nfft - 1)) || Ku <= 0 || Ku > nfft / 2 + 1 || ldh < Ku || (filt_c64 && ldf < Ku) ||
-      ldx < nfft / 2 + 1 || ldt < nfft)
+      ldx < nfft / 2 + 1 || ldt < nfft || (gain_fold && !tscale))
     return GFDN_E_BADARG;
   if (nper > 8) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int K = nfft / 2 + 1, nblk = nbands * G;
   hipLaunchKernelGGL(k_pf_bwd_spectra, dim3((K + 255) / 256, nblk), dim3(256), 0, s, (const float2*)gH_c64, ldh,
                      (const float2*)filt_c64, ldf, (const float2*)Tnat_c64, (const float2*)Dnat_c64, G, Ku, K, slot_of_bin, nblk,
-                     tscale, (float2*)UV_c64, ldx);
+                     tscale, gain_fold ? 1 : 0, (float2*)UV_c64, ldx);
   GFDN_LAUNCH_CHECK();
   int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
   if (rc) return rc;

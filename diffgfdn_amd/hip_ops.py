@@ -585,10 +585,12 @@ def tf_eval(turns, logr, coef, delays, nper: int, scale=None) -> torch.Tensor:
 
 
 def tf_energy(turns, logr, coef, delays, nper: int, b=None, c=None, want_energy=True, want_scale=True, work=None,
-              phase: int = 3, energy=None, scale=None, dturn: float = 0.0):
+              phase: int = 3, energy=None, scale=None, dturn: float = 0.0, gains=None, G: int = 0):
     """energy (nblk) = mean_k |T|^2, scale = energy^(-1/2); b, c (float32, contiguous): rescaled in place.
     ``phase``: 1 = only the pass over the bins (partial sums into ``work``; returns work), 2 = only the finish
-    from that ``work``, 3 = both.  ``dturn`` != 0: the grid is uniform on the unit circle with that step (turns)."""
+    from that ``work``, 3 = both.  ``dturn`` != 0: the grid is uniform on the unit circle with that step (turns).
+    ``gains`` (bands * Bper, G) with nblk = bands * G: returns (energy, scale, gains_scaled) with gains_scaled[band Bper + r][g]
+    = gains[...][g] scale[band G + g], written by the finish launch (the scale folded into the receiver gains)."""
     _need_gpu(turns, coef, delays)
     coef, delays = _f(coef), _f(delays)
     nblk, K = coef.shape[0], turns.numel()
@@ -600,6 +602,15 @@ def tf_energy(turns, logr, coef, delays, nper: int, b=None, c=None, want_energy=
         energy = torch.empty(nblk, dtype=_f32, device=coef.device) if (want_energy and energy is None) else energy
         scale = torch.empty(nblk, dtype=_f32, device=coef.device) if (want_scale and scale is None) else scale
     work = _work(lib.gfdn_tf_work_bytes(nblk), coef.device) if work is None else work
+    if gains is not None:
+        if not (phase & 2) or G <= 0 or nblk % G or gains.dtype != _f32 or not gains.is_contiguous() or gains.shape[1] != G \
+                or gains.shape[0] % (nblk // G):
+            raise RuntimeError("tf_energy: gains (bands * Bper, G) float32 contiguous with nblk = bands * G, with the finish")
+        gs = torch.empty_like(gains)
+        _lib.check(lib.gfdn_tf_energy_gains(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(b), _p(c), _p(energy),
+                                            _p(scale), _p(work), int(phase), float(dturn), _p(gains), _p(gs),
+                                            gains.shape[0] // (nblk // G), G, _stream()), "gfdn_tf_energy_gains")
+        return energy, scale, gs
     _lib.check(lib.gfdn_tf_energy(_p(turns), _p(logr), K, nblk, nper, _p(coef), _p(delays), _p(b), _p(c), _p(energy),
                                   _p(scale), _p(work), int(phase), float(dturn), _stream()), "gfdn_tf_energy")
     return work if phase == 1 else (energy, scale)
@@ -690,11 +701,12 @@ def tf_gain_grad(Tsave, gH, G: int, filt=None, nbands: int = 1, grgain=None, wor
 
 
 def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=None, nbands: int = 1, work=None,
-                   partial: bool = False, tscale=None):
+                   partial: bool = False, tscale=None, gain_fold: bool = False):
     """-> grec (nbands*G, 32): gradient records of the scaled records; ``Tsave``: the forward's saved group transfer
     functions (tf_compose_fwd(save_T=True)).  ``partial``: skip the sum over the workgroups' partial rows and return
     them (nbands*G, 32, parts) for ``tf_param_grads``, which sums them itself.  ``tscale`` (nbands*G,): ``Tsave`` holds the
-    UNSCALED functions and T' = tscale T is formed where they are read."""
+    UNSCALED functions and T' = tscale T is formed where they are read; ``gain_fold`` (with tscale): the scale sits in the
+    receiver gains (tf_energy(gains=)) and gH is the gradient w.r.t. the UNSCALED group responses."""
     _need_gpu(turns, coef, rgain, gH, Tsave)
     if tscale is not None and (tscale.dtype != _f32 or not tscale.is_contiguous() or tscale.numel() != coef.shape[0]):
         raise RuntimeError("tf_compose_bwd: tscale must be a contiguous float32 vector with one factor per block")
@@ -715,7 +727,7 @@ def tf_compose_bwd(turns, logr, coef, delays, nper: int, rgain, gH, Tsave, filt=
             work = _work(lib.gfdn_tf_compose_bwd_work_bytes(K, nbands, G), coef.device)
     _lib.check(lib.gfdn_tf_compose_bwd(_p(turns), _p(logr), K, nbands, G, nper, _p(coef), _p(delays), _p(Tsave),
                                        _p(tscale), _p(rgain), Btot // nbands, _p(filt), K, _p(gH), K, _p(grec), _p(work),
-                                       _stream()), "gfdn_tf_compose_bwd")
+                                       int(bool(gain_fold)), _stream()), "gfdn_tf_compose_bwd")
     return work if partial else grec
 
 
@@ -989,9 +1001,10 @@ def tfp_forward(coef, delays, c, nper: int, nfft: int, T: int) -> torch.Tensor:
     return X
 
 
-def tfp_energy(Xq, Xp, nper: int, b, c, want_energy: bool = False):
+def tfp_energy(Xq, Xp, nper: int, b, c, want_energy: bool = False, gains=None, G: int = 0):
     """normalize (trainer.py:317-332) on the transformed sequences of the raw sub-FDN blocks (rows Xq, Xp of tfp_forward):
-    -> (energy or None, scale = E^(-1/2)); b, c (float32, contiguous) are divided by E^(1/4) IN PLACE."""
+    -> (energy or None, scale = E^(-1/2)); b, c (float32, contiguous) are divided by E^(1/4) IN PLACE.  ``gains``: as
+    tf_energy's (returns a third element, the scaled gains)."""
     _need_gpu(Xq, Xp, b, c)
     nblk, K = Xq.shape
     for t in (b, c):
@@ -1003,9 +1016,16 @@ def tfp_energy(Xq, Xp, nper: int, b, c, want_energy: bool = False):
     energy = torch.empty(nblk, dtype=_f32, device=Xq.device) if want_energy else None
     scale = torch.empty(nblk, dtype=_f32, device=Xq.device)
     work = torch.empty(nblk * lib.gfdn_tfp_parts(), dtype=_f32, device=Xq.device)
+    gs = None
+    if gains is not None:
+        if G <= 0 or nblk % G or gains.dtype != _f32 or not gains.is_contiguous() or gains.shape[1] != G \
+                or gains.shape[0] % (nblk // G):
+            raise RuntimeError("tfp_energy: gains (bands * Bper, G) float32 contiguous with nblk = bands * G")
+        gs = torch.empty_like(gains)
     _lib.check(lib.gfdn_tfp_energy(_p(Xq), _p(Xp), Xq.stride(0), K, nblk, nper, _p(b), _p(c), _p(energy), _p(scale), _p(work),
-                                   _stream()), "gfdn_tfp_energy")
-    return energy, scale
+                                   _p(gains), _p(gs), 0 if gains is None else gains.shape[0] // (nblk // G), int(G), _stream()),
+               "gfdn_tfp_energy")
+    return (energy, scale) if gains is None else (energy, scale, gs)
 
 
 def tfp_colorless(Xq, Xp, nfft: int, nper: int, delays, scale, asym: bool, gscale: float):
@@ -1028,7 +1048,8 @@ def tfp_colorless(Xq, Xp, nfft: int, nper: int, delays, scale, asym: bool, gscal
     return part, loss
 
 
-def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, slot_of_bin, gH, filt, Tnat, Dnat, tscale=None):
+def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, slot_of_bin, gH, filt, Tnat, Dnat, tscale=None,
+                    gain_fold: bool = False):
     """Gradient records (nbands * G, 512, 1) of the damped blocks from gH (nbands * G, >= Ku) = dL/d(T'_g filt) on the slot
     order (the linear step's adjoint transform output); Tnat, Dnat (nbands * G, Ku): tf8_tsave's Ts, Dinv on the bins
     0 .. Ku - 1 in bin order (``hslot``); ``tscale``: Tnat holds the unscaled functions, T' = tscale Tnat."""
@@ -1048,10 +1069,38 @@ def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, 
     work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), dev)
     part = torch.empty((nblk, 512, 1), dtype=_f32, device=dev)
     _lib.check(lib.gfdn_tfp_compose_bwd(nfft, nbands, G, nper, _p(_f(delays)), Ku, _p(slot_of_bin), _p(gH), gH.stride(0), _p(filt),
-                                        Ku, _p(Tnat), _p(Dnat), _p(None if tscale is None else _f(tscale)), _p(UV), K, _p(x),
-                                        nfft, _p(work), _p(part), _stream()),
+                                        Ku, _p(Tnat), _p(Dnat), _p(None if tscale is None else _f(tscale)),
+                                        int(bool(gain_fold)), _p(UV), K, _p(x), nfft, _p(work), _p(part), _stream()),
                "gfdn_tfp_compose_bwd")
     return part
+
+
+def tf8_tail(QQ, ig, part0, part1, b, c, M, gQ, Q, gb, gc, gM, opt, offM: int, offb: int, offc: int, Q_next, QQ_next, c_next):
+    """tf8_param_grads + Adam on the blocks' own entries of M, b, c + the next step's Q, Q Q and output-gain snapshot in ONE
+    launch behind the cofactor maps (csrc/blocktf8.hip k_tf8_tail).  ``part0`` / ``part1`` (nblk, 512, parts): gradient
+    records of the damped blocks (A0 = Q Q, 1 / gamma) and of the raw blocks (A1 = M); ``b``, ``c``, ``M``: the flat parameter
+    buffer's views of the leaves (updated in place); ``opt``: the FlatAdam that holds them at the element offsets."""
+    _need_gpu(QQ, part0, part1, b, c, M)
+    nblk, n, _ = M.shape
+    ig = None if ig is None else _f(ig).reshape(-1)
+    for t in (QQ, part0, part1, b, c, M, gQ, Q, gb, gc, gM, Q_next, QQ_next, c_next):
+        if t is not None and (t.dtype != _f32 or not t.is_contiguous()):
+            raise RuntimeError("tf8_tail: contiguous float32 tensors expected")
+    if part0.dim() != 3 or tuple(part0.shape[:2]) != (nblk, 512) or part1.dim() != 3 or tuple(part1.shape[:2]) != (nblk, 512) \
+            or b.numel() != nblk * n or c.numel() != nblk * n or c_next.numel() != nblk * n:
+        raise RuntimeError("tf8_tail: records must be (nblk, 512, parts), b / c / c_next (nblk n)")
+    fp = opt.flat_param
+    for off, t in ((offM, M), (offb, b), (offc, c)):
+        if fp.data_ptr() + 4 * off != t.data_ptr():
+            raise RuntimeError("tf8_tail: the leaves must be the flat buffer's views at the stated offsets")
+    lib = _lib.load()
+    work = torch.empty(lib.gfdn_tf8_param_grads_work_bytes(nblk) // 4, dtype=_f32, device=M.device)
+    b1, b2 = opt.defaults['betas']
+    _lib.check(lib.gfdn_tf8_tail(_p(QQ), _p(ig), _p(part0), part0.shape[2], _p(M), _p(part1), part1.shape[2], _p(b), _p(c), nblk,
+                                 n, _p(M), _p(gQ), _p(Q), _p(gb), _p(gc), _p(gM), _p(work), _p(fp), _p(opt.exp_avg),
+                                 _p(opt.exp_avg_sq), _p(opt.seg), _p(opt.lr_seg), _p(opt.step_count), _p(opt._block_counter),
+                                 int(offM), int(offb), int(offc), float(b1), float(b2), float(opt.defaults['eps']),
+                                 _p(Q_next), _p(QQ_next), _p(c_next), _stream()), "gfdn_tf8_tail")
 
 
 def tf_coefs_bwd(A0, ig0, grec0, b, c, A1=None, ig1=None, grec1=None, gA0=None, gA1=None, gb=None, gc=None):
@@ -2249,7 +2298,7 @@ def mlp_bwd_takes_parts(F: int, H: int, n_hidden: int, G: int, Bper: int) -> boo
 
 
 def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, ggains, rows=None,
-                  nbands: int = 1, out=None, ggains_parts=None):
+                  nbands: int = 1, out=None, ggains_parts=None, colscale=None):
     """-> gw shaped like w (``out``: a contiguous float32 buffer of that size to write it into).  ``ggains_parts`` (in
     place of ``ggains``): the (B G, chunks) partial rows of ``tf_gain_grad(partial=True)``, summed inside the launch."""
     _need_gpu(pos, w, ggains if ggains_parts is None else ggains_parts)
@@ -2266,11 +2315,20 @@ def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, gg
         gp = _f(ggains_parts)
         if gp.dim() != 2 or gp.shape[0] != B * G or B % nbands:
             raise RuntimeError("mlp_gains_bwd: ggains_parts must be (B G, chunks)")
+        if colscale is not None:          # (the rows hold dL/d(gains colscale): tf_energy(gains=))
+            _lib.check(lib.gfdn_mlp_gains_banded_bwd_parts_scaled(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F,
+                                                                  H, n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat),
+                                                                  _p(rstd), _p(gp), gp.shape[1], _p(colscale), _p(gw),
+                                                                  _p(work), _stream()),
+                       "gfdn_mlp_gains_banded_bwd_parts_scaled")
+            return gw
         _lib.check(lib.gfdn_mlp_gains_banded_bwd_parts(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,
                                                        n_hidden, G, float(lo), float(hi), _p(gains), _p(xhat), _p(rstd),
                                                        _p(gp), gp.shape[1], _p(gw), _p(work), _stream()),
                    "gfdn_mlp_gains_banded_bwd_parts")
         return gw
+    if colscale is not None:
+        raise RuntimeError("mlp_gains_bwd: colscale goes with ggains_parts (the wave-per-receiver form)")
     ggains = _f(ggains)
     if nbands > 1:
         _lib.check(lib.gfdn_mlp_gains_banded_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, H,

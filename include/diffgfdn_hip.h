@@ -357,6 +357,15 @@ int gfdn_tf_eval(const double* turns, const double* logr, int K, int nblk, int n
 int gfdn_tf_energy(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
                    const float* delays, float* b, float* c, float* energy, float* scale, void* work,
                    int phase, double dturn, void* stream);
+/* ... whose finish also stores gains_scaled[band Bper + r][g] = gains[band Bper + r][g] scale[band G + g] (nblk = bands x G):
+ * the normalisation scale folded into the receiver gains (trainer.py:317-332: T' = scale T, and H = sum_g gain[b][g] T'_g +
+ * direct is linear in both), so that the launches of the linear step run on group signals of the UNSCALED functions with
+ * gains_scaled as their receiver gains and nothing on the transform's stream waits for the scale; the gain network's backward
+ * then takes dL/d(gains_scaled) (gfdn_mlp_gains_banded_bwd_parts_scaled), the records pass divides dL/dT by the scale
+ * (gfdn_tf_compose_bwd gain_fold).  phase 3 (both) or 2 (the finish alone, behind gfdn_tf_energy(phase = 1)).             */
+int gfdn_tf_energy_gains(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
+                         const float* delays, float* b, float* c, float* energy, float* scale, void* work, int phase,
+                         double dturn, const float* gains, float* gains_scaled, int Bper, int G, void* stream);
 int gfdn_tf_colorless(const double* turns, const double* logr, int K, int nblk, int nper, const float* coef,
                       const float* delays, const float* scale, int asym, float gscale, float* grec,
                       float* loss, void* work, double dturn, void* stream);
@@ -369,7 +378,9 @@ size_t gfdn_tf_compose_bwd_work_bytes(int K, int nbands, int G);
 int gfdn_tf_compose_bwd(const double* turns, const double* logr, int K, int nbands, int G, int nper,
                         const float* coef, const float* delays, const float* Tsave_c64, const float* tscale,
                         const float* rgain, int B, const float* filt_c64, int ldf, const float* gH_c64, int ldh,
-                        float* grec, void* work, void* stream);
+                        float* grec, void* work, int gain_fold, void* stream);
+/* gain_fold (with tscale): the normalisation scale sits in the receiver gains (gfdn_tf_energy_gains), the group
+ * signals are those of the UNSCALED functions and gH is dL/d(T filt): dL/dT' = dL/dT / tscale.                            */
 /* tscale (nbands * G floats or NULL): Tsave holds the UNSCALED group transfer functions (gfdn_tf_compose_fwd with scale =
  * NULL) and T' = tscale T is formed where the records pass reads them -- for a step whose normalisation scale joins the
  * group signals behind the transform (gfdn_irfft_odd_pairs_fwd_scaled).                                                  */
@@ -431,6 +442,16 @@ int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* 
                          const float* inv_gamma1, const float* part1, int nparts1, const float* b, const float* c,
                          int nblk, int nper, const float* M, const float* gQ, const float* Q, float* gb, float* gc,
                          float* gM, void* work, void* stream);
+/* gfdn_tf8_param_grads with the optimiser update of the blocks' own M, b, c (the flat buffers of gfdn_adam_step at the element
+ * offsets offM / offb / offc; torch.optim.Adam of trainer.py:475 with the same roundings) and the NEXT step's Q = expm(skew(M)),
+ * Q Q and a snapshot c_next of the updated output gains in the same launch: the step's tail and most of its next head
+ * (gfdn_tf_tail for blocks of 5..8 lines; gfdn_tf8_coefs stays a launch of its own).  Both record sets are required.   */
+int gfdn_tf8_tail(const float* A0, const float* inv_gamma0, const float* part0, int nparts0, const float* A1, const float* part1,
+                  int nparts1, const float* b, const float* c, int nblk, int nper, const float* M, const float* gQ,
+                  const float* Q, float* gb, float* gc, float* gM, void* work, float* flat_p, float* flat_m, float* flat_v,
+                  const unsigned char* seg, const float* lr_seg, float* step_count, unsigned int* block_counter, int offM,
+                  int offb, int offc, float beta1, float beta2, float eps, float* Q_next, float* QQ_next, float* c_next,
+                  void* stream);
 /* ---- polynomial passes of the same blocks on the reference's own grid by fast transforms (csrc/polyfft.hip).
  * Preconditions: INTEGER delay lengths (config.py:131-140) and the grid z_k = e^{2 pi i k / nfft}, k = 0 .. nfft / 2
  * (dataloader.py:552-566), nfft = 2^p: then Q(z_k) = conj(rfft(q, nfft)[k]) for the real sequence q[m] = sum of the
@@ -444,26 +465,29 @@ int gfdn_tf8_param_grads(const float* A0, const float* inv_gamma0, const float* 
  *                         rows each).  T: samples per sequence kept in seq (2 nblk, T): max degree + 1 <= T <= nfft.
  *                         work: gfdn_irfft_pow2_work_bytes(nfft, 2 nblk).
  *   gfdn_tfp_energy     : normalize on rows (Xq, Xp) of the raw sub-FDN blocks, K = nfft / 2 + 1 bins: energy (or NULL),
- *                         scale = E^(-1/2), b, c /= E^(1/4) in place.  work: nblk * gfdn_tfp_parts() floats.
+ *                         scale = E^(-1/2), b, c /= E^(1/4) in place.  work: nblk * gfdn_tfp_parts() floats.  gains /
+ *                         gains_scaled ((nblk / G) Bper, G; or NULL): as gfdn_tf_energy_gains.
  *   gfdn_tfp_colorless  : gfdn_tf8_colorless on the transformed sequences: loss[blk], gradient records part (nblk, 512)
  *                         (ONE partial row: nparts = 1 for gfdn_tf8_param_grads).  UV (2 nblk, ldx) complex64, x (2 nblk, ldt >=
  *                         nfft) float, work: gfdn_irfft_pow2_work_bytes(nfft, 2 nblk), lossp: nblk * gfdn_tfp_parts() floats.
  *   gfdn_tfp_compose_bwd: gH (nblk, ldh) = dL/d(T'_g filt) on the slot order (slot_of_bin: gfdn_tf8_tsave's hslot) -> gradient
  *                         records part (nblk, 512) of the damped blocks (the linear step's adjoint: one gradient row per
  *                         group).  Tnat, Dnat (nblk, Ku): gfdn_tf8_tsave's Tsave / Dinv on bins 0 .. Ku - 1 in bin order;
- *                         tscale (nblk; or NULL): Tnat holds the UNSCALED functions, T' = tscale Tnat.                   */
+ *                         tscale (nblk; or NULL): Tnat holds the UNSCALED functions, T' = tscale Tnat; gain_fold: as
+ *                         gfdn_tf_compose_bwd's.                                                                          */
 int gfdn_tfp_parts(void);
 int gfdn_tfp_forward(int nfft, int nblk, int nper, const float* coef, const float* delays, const float* c, int T, float* seq,
                      float* X_c64, int ldx, void* work, void* stream);
 int gfdn_tfp_energy(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, int nper, float* b, float* c,
-                    float* energy, float* scale, void* work, void* stream);
+                    float* energy, float* scale, void* work, const float* gains, float* gains_scaled, int Bper, int G,
+                    void* stream);
 int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int ldx, int nfft, int nblk, int nper, const float* delays,
                        const float* scale, int asym, float gscale, float* UV_c64, float* x, int ldt, void* work, float* part,
                        float* lossp, float* loss, void* stream);
 int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const float* delays, int Ku, const int* slot_of_bin,
                          const float* gH_c64, int ldh, const float* filt_c64, int ldf, const float* Tnat_c64,
-                         const float* Dnat_c64, const float* tscale, float* UV_c64, int ldx, float* x, int ldt, void* work,
-                         float* part, void* stream);
+                         const float* Dnat_c64, const float* tscale, int gain_fold, float* UV_c64, int ldx, float* x, int ldt,
+                         void* work, float* part, void* stream);
 
 /* ---- measurement kernel for BASELINE.json configs[4] ("fp32 vs bf16 feedback-matmul on MFMA") ------------------
  * The reference's dense formulation (feedback_loop.py:389-391 explicit resolvent P (K, N, N); model.py:615-619
@@ -888,6 +912,13 @@ int gfdn_mlp_gains_banded_bwd_parts(const double* pos, const long long* pos_rows
                                     int G, float lo, float hi, const float* gains, const float* xhat,
                                     const float* rstd, const float* ggains_parts, int gparts, float* gw,
                                     void* work, void* stream);
+/* normalize's scale folded into the receiver gains (gfdn_tf_energy_gains): the partial rows hold dL/d(gains colscale), every
+ * row sum is multiplied by colscale[band G + g] first.  Wave-per-receiver form only (gfdn_mlp_bwd_takes_parts).             */
+int gfdn_mlp_gains_banded_bwd_parts_scaled(const double* pos, const long long* pos_rows, const float* freq_pi, const float* w,
+                                           int nbands, int Bper, int F, int H, int n_hidden, int G, float lo, float hi,
+                                           const float* gains, const float* xhat, const float* rstd,
+                                           const float* ggains_parts, int gparts, const float* colscale, float* gw, void* work,
+                                           void* stream);
 
 /* Receiver schedule of a replayed epoch (reference trainer.py:373-379: the DataLoader fixes an epoch's batches when the
  * epoch starts): table (len, B) int64 dataset rows uploaded once; each call copies row state[0] mod state[1] into idx

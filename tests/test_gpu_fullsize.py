@@ -448,17 +448,19 @@ def test_transform_passes_equal_matrix_core_passes_full_size_n32():
         off += cnt
 
 
-def test_fused_tail_steps_equal_separate_launches_full_size():
+@pytest.mark.parametrize("nper", [4, 8])
+def test_fused_tail_steps_equal_separate_launches_full_size(nper):
     """Three replayed steps with a host-launched validation step between the second and the third, the step's last launch
-    leaving the next step's records (k_tf_tail, no records launch at the head) against the same steps with parameter
-    gradients, Adam and records as separate launches: the same arithmetic -- every loss of every step, the parameters and
-    both Adam moments after the third step bit for bit -- and the kept records equal a fresh evaluation at the end."""
+    leaving the next step's records (k_tf_tail / k_tf8_tail, no records launch at the head) against the same steps with
+    parameter gradients, Adam and records as separate launches: the same arithmetic -- every loss of every step, the
+    parameters and both Adam moments after the third step bit for bit -- and the kept records equal a fresh evaluation at the
+    end.  nper = 8: blocks of 8 lines (Q, Q Q and the snapshot of the output gains are what is kept)."""
     from diffgfdn_amd import hip_ops as ops
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
     res = {}
     sched = [[[2, 5], [0, 3]], [[1, 4], [2, 5]], [[0, 2], [3, 4]]]
     for fusedtail in (True, False):
-        bands = [_band(q) for q in range(2)]
+        bands = [_band(q, delays=None if nper == 4 else [d + 2 * q for d in DELAYS32]) for q in range(2)]
         filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
         bank = BandBank([b_[2] for b_ in bands])
         tr = BandBankTrainer(bank, _tc(), subband_filter_freq_resp=filt, band_names=CENTRES)
@@ -479,8 +481,11 @@ def test_fused_tail_steps_equal_separate_launches_full_size():
         assert float(opt.step_count) == 3.0 and float(opt.step_count2) == 3.0
         if fusedtail:
             assert f.records_ok()
-            fresh = ops.tf_ortho_coefs(bank._blocks().detach(), bank.inv_gamma, bank.input_gains.data.view(-1),
-                                       bank.output_gains.data.view(-1))
+            if nper == 4:
+                fresh = ops.tf_ortho_coefs(bank._blocks().detach(), bank.inv_gamma, bank.input_gains.data.view(-1),
+                                           bank.output_gains.data.view(-1))
+            else:
+                fresh = (*ops.ortho_fwd(bank._blocks().detach(), True, True), bank.output_gains.data.view(-1))
             for got, want in zip(f._records(), fresh):
                 assert torch.equal(got, want)
         res[fusedtail] = (outs, opt.flat_param.detach().cpu().numpy().copy(), opt.exp_avg.detach().cpu().numpy().copy(),

@@ -95,6 +95,11 @@ def test_energy_and_colorless_equal_matrix_core_passes(nfft, nper):
         e64 = torch.tensor((np.abs(Pv / Qv) ** 2).mean(axis=1), device=e_got.device)
         assert ((e_got.double() - e64).abs() / e64).max() < 3e-4
         assert ((e_got.double() - e64).abs() / e64).max() < 3 * ((e_ref.double() - e64).abs() / e64).max() + 3e-5
+    gains = torch.rand(s['nbands'] * 5, s['G'], device=e_got.device)
+    b3, c3 = s['b'].clone(), s['c'].clone()
+    e3, sc3, gsc = ops.tfp_energy(Xq, Xp, nper, b3, c3, want_energy=True, gains=gains, G=s['G'])
+    assert torch.equal(e3, e_got) and torch.equal(sc3, sc_got) and torch.equal(b3, b2)
+    assert torch.equal(gsc, gains * sc_got.reshape(s['nbands'], 1, s['G']).expand(-1, 5, -1).reshape(-1, s['G']))
     torch.testing.assert_close(e_got, e_ref, rtol=3e-4, atol=0)
     torch.testing.assert_close(sc_got, sc_ref, rtol=2e-4, atol=0)
     torch.testing.assert_close(b2, b1, rtol=1e-4, atol=0)
@@ -153,3 +158,7 @@ def test_output_stage_in_slot_order_and_adjoint_by_transforms(nfft, nper):
     part_got = ops.tfp_compose_bwd(nfft, nbands, G, nper, s['delays'], Ku, col, gH, filt, Tn, Dn, tscale=scale).sum(-1)
     tol = 2e-4 * part_ref.abs().max()
     assert (part_got - part_ref).abs().max() < tol, ((part_got - part_ref).abs().max(), tol)
+    # the scale in the receiver gains: s dL/dT' comes in
+    part_fold = ops.tfp_compose_bwd(nfft, nbands, G, nper, s['delays'], Ku, col, (gH * scale[:, None]).contiguous(), filt, Tn, Dn,
+                                    tscale=scale, gain_fold=True).sum(-1)
+    assert (part_fold - part_got).abs().max() < 2e-5 * part_got.abs().max()

@@ -296,3 +296,69 @@ def test_merge_into_slot_order(ops):
         got = ops.lin_merge_slots(*parts, slot_of_time=sot)
         assert torch.equal(got, want)
         assert torch.equal(ops.lin_merge_slots(*parts), tot)
+
+
+def test_gain_network_backward_with_the_scale_in_the_gains(ops):
+    """mlp_gains_bwd(ggains_parts, colscale) on rows of dL/d(gains s) == the backward on the rows times s
+    (bankstep.FusedBankStep.scale_in_gains)."""
+    from diffgfdn_amd import _lib
+    nb, Bper, G, F, H, nh, chunks = 3, 8, 4, 20, 16, 2, 37
+    B = nb * Bper
+    g = torch.Generator().manual_seed(21)
+    pos = torch.rand(B, 3, generator=g, dtype=torch.float64).to(DEV)
+    P = _lib.load().gfdn_mlp_param_count(F, H, nh, G)
+    w = (0.3 * torch.randn(nb, P, generator=g)).to(DEV)
+    freq_pi = (torch.exp(torch.linspace(0.0, np.log(32.0), F)) * np.pi).float().to(DEV)
+    s = (0.5 + torch.rand(nb * G, generator=g)).to(DEV)
+    assert ops.mlp_bwd_takes_parts(F, H, nh, G, Bper)
+    gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, nh, G, 0.0, 1.0, None, nb)
+    srow = s.reshape(nb, 1, G).expand(nb, Bper, G).reshape(B, G)
+    parts = torch.randn(B * G, chunks, generator=g).to(DEV)
+    want = ops.mlp_gains_bwd(pos, freq_pi, w, H, nh, G, 0.0, 1.0, gains, xhat, rstd, None, None, nb,
+                             ggains_parts=(parts * srow.reshape(-1, 1)).contiguous())
+    got = ops.mlp_gains_bwd(pos, freq_pi, w, H, nh, G, 0.0, 1.0, gains, xhat, rstd, None, None, nb, ggains_parts=parts,
+                            colscale=s)
+    assert rel_err(got.cpu(), want.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("n", [4, 3])
+def test_energy_finish_stores_the_scaled_gains(ops, n):
+    """tf_energy(gains=): same energy / scale / rescaled b, c as without, and gains * scale per (band, group) column, exactly."""
+    gen = torch.Generator(device="cpu").manual_seed(31 + n)
+    nb, G, K, Bper = 2, 4, 4097, 6
+    nblk = nb * G
+    M, b, c, ig = _bank_blocks(gen, nblk, n)
+    z = torch.tensor(np.exp(1j * 2 * np.pi * np.fft.rfftfreq(2 * (K - 1))))
+    turns, logr = ops.zprep(z.to(DEV))
+    delays = torch.tensor(np.random.RandomState(9).randint(600, 1600, nblk * n).astype(np.float32)).to(DEV)
+    Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
+    gains = torch.rand(nb * Bper, G, generator=gen).to(DEV)
+    b1, c1, b2, c2 = b.clone(), c.clone(), b.clone(), c.clone()
+    e1, s1 = ops.tf_energy(turns, None, coef_sub, delays, n, b1, c1, dturn=0.5 / (K - 1))
+    e2, s2, gs = ops.tf_energy(turns, None, coef_sub, delays, n, b2, c2, dturn=0.5 / (K - 1), gains=gains, G=G)
+    assert torch.equal(e1, e2) and torch.equal(s1, s2) and torch.equal(b1, b2) and torch.equal(c1, c2)
+    srow = s1.reshape(nb, 1, G).expand(nb, Bper, G).reshape(nb * Bper, G)
+    assert torch.equal(gs, gains * srow)
+
+
+@pytest.mark.parametrize("n", [4, 3])
+def test_records_pass_with_the_scale_in_the_gains(ops, n):
+    """gfdn_tf_compose_bwd(tscale, gain_fold) on s dL/dT' == the pass on dL/dT' (what the adjoint transform hands over when the
+    group signals are those of the unscaled functions and the receiver gains carry the scale)."""
+    gen = torch.Generator(device="cpu").manual_seed(17 + n)
+    nb, G, K = 2, 4, 4097
+    nblk = nb * G
+    M, b, c, ig = _bank_blocks(gen, nblk, n)
+    z = torch.tensor(np.exp(1j * 2 * np.pi * np.fft.rfftfreq(2 * (K - 1))))
+    turns, logr = ops.zprep(z.to(DEV))
+    delays = torch.tensor(np.random.RandomState(5).randint(600, 1600, nblk * n).astype(np.float32)).to(DEV)
+    Q, QQ, coef, coef_sub = ops.tf_ortho_coefs(M, ig, b, c)
+    scale = (0.5 + torch.rand(nblk, generator=gen)).to(DEV)
+    eye = torch.eye(G, device=DEV).repeat(nb, 1).contiguous()
+    filt = torch.view_as_complex(torch.randn(nb, K, 2, generator=gen).to(DEV)).contiguous()
+    _, Ts_u = ops.tf_compose_fwd(turns, None, coef, delays, n, eye, None, None, filt, None, nb, save_T=True)
+    gH = torch.view_as_complex(torch.randn(nblk, K, 2, generator=gen).to(DEV)).contiguous()
+    ref = ops.tf_compose_bwd(turns, None, coef, delays, n, eye, gH, Ts_u, filt, nb, tscale=scale)
+    got = ops.tf_compose_bwd(turns, None, coef, delays, n, eye, (gH * scale[:, None]).contiguous(), Ts_u, filt, nb, tscale=scale,
+                             gain_fold=True)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-6
