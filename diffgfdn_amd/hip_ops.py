@@ -953,7 +953,7 @@ def tfp_plan(delays, nper: int, nfft: int):
     non-negative integer (the reference's are: config.py:131-140), else None.  Reads the device once per delays tensor."""
     key = (delays.data_ptr(), delays._version, delays.numel(), int(nper), int(nfft), str(delays.device))
     if key not in _tfp_plans:
-        if torch.cuda.is_current_stream_capturing():
+        if delays.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("tfp_plan: first use of this delays tensor inside a stream capture; run the step once before")
         d = delays.detach().to(torch.float64).cpu().reshape(-1, nper)
         T = None
