@@ -265,7 +265,8 @@ class BandStackedDataset:
                     r1 = min(r0 + chunk, (q + 1) * R)
                     H = E[r0:r1, :Ku].to(torch.complex64)
                     out[r0:r1] = ops.irfft_odd_fwd((H * f) if f is not None else H.contiguous(), n)
-            self._direct_time = (key, out)
+            self._direct_time = (key, out, filt)          # (the entry keeps the filter alive: the key is its ADDRESS, and a
+                                                          # freed filter's block handed to another one would be a false hit)
         return self._direct_time[1]
 
     def edr_target_tiled(self) -> torch.Tensor:
@@ -276,7 +277,7 @@ class BandStackedDataset:
             out = torch.empty_like(T)
             for r0 in range(0, T.shape[0], 256):
                 out[r0:r0 + 256] = ops.spec_tile(T[r0:r0 + 256])
-            self._edr_tiled = ((T.data_ptr(), tuple(T.shape)), out)
+            self._edr_tiled = ((T.data_ptr(), tuple(T.shape)), out, T)
         return self._edr_tiled[1]
 
     def direct_stft(self, filt: Optional[torch.Tensor], n: int, win: int, chunk: int = 64, tiled: bool = False) -> torch.Tensor:
@@ -296,7 +297,7 @@ class BandStackedDataset:
                     blk = torch.cat([blk, torch.zeros_like(blk[:1])])
                 x2 = torch.stack((blk[0::2], blk[1::2]), dim=-1).contiguous()
                 out[r0:r0 + m] = ops.stft_pairs_spectrum(x2, m, win, tiled=tiled)
-            self._direct_stft = (key, out)
+            self._direct_stft = (key, out, filt)
         return self._direct_stft[1]
 
     def global_rows(self, per_band: Sequence[Sequence[int]]) -> List[int]:

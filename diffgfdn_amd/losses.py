@@ -144,11 +144,18 @@ _default_targets = DecayTargets()
 # is, one pass over it saved).  The promise is CHECKED wherever a host read is allowed -- outside stream capture -- so a
 # caller that rescales the total (gradient accumulation, loss scaling, a 1 / world factor) gets an error instead of an
 # unscaled EDC gradient next to correctly scaled colorless gradients.
-CHECK_UNIT_GRAD = True
+# The check reads the device (a host sync inside backward: it drains the stream and serialises the side-stream overlap the
+# eager multi-stream steps are built around), so it runs for the FIRST calls of a process only -- a caller that rescales the
+# total does so from its first step on -- and again whenever CHECK_UNIT_GRAD is set to an integer number of further calls.
+# (A stream capture cannot be checked; its warm-up steps are eager and are.)
+CHECK_UNIT_GRAD = 8
 
 
 def _assert_unit_upstream(g: torch.Tensor):
+    global CHECK_UNIT_GRAD
     if CHECK_UNIT_GRAD and g.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if CHECK_UNIT_GRAD is not True:
+            CHECK_UNIT_GRAD = int(CHECK_UNIT_GRAD) - 1
         if not bool(torch.all(g == 1)):
             raise RuntimeError("decay losses were evaluated with unit_grad=True but their total is back-propagated with an "
                                "upstream gradient other than 1: evaluate them with unit_grad=False to rescale the total")

@@ -544,13 +544,14 @@ class DirectionalFDNVarReceiverPosTrainer(Trainer):
     sub-band filter -> directional responses (analysis matrix) -> directional EDC loss against the
     common-slope amplitudes, plus the colorless terms."""
 
-    concurrent_branches = os.environ.get('GFDN_DIR_TWO_STREAMS', '1') == '1'
+    # the sub-FDN branch of the colorless loss on a side stream beside the SH-domain forward (False: one stream)
+    concurrent_branches = True
     # directional EDC term on irfft(H_sh) mixed in the time domain (losses.directional_edc_loss.forward_sh) instead of
     # irfft(A H_sh): same numbers to rounding, 3/4 of the transforms at order 2
     mix_in_time = True
     # ... and the SH output stage behind the transform as well (losses.directional_edc_loss.forward_lines): the N line
     # responses are transformed instead of the B (order + 1)^2 receiver responses, which never exist
-    lines_in_time = os.environ.get('GFDN_DIR_LINES', '1') == '1'
+    lines_in_time = True
 
     def graphed(self, example_batch: Dict, mask_seed: Optional[int] = None) -> "GraphedModuleStep":
         """train_step on batches shaped like ``example_batch`` as one HIP-graph replay."""
@@ -775,7 +776,9 @@ class GraphedModuleStep:
             self.mask_seed = int(mask_seed)
             self.mask_state = torch.zeros(1, dtype=torch.long, device=dev)
             self.maskw = torch.zeros(L, dtype=torch.float32, device=dev)
-            crit.device_mask = (self.mask_seed, self.mask_state, self.maskw)
+            self._crit = crit              # (the device generator is installed on the criterion around warm-up and capture
+            #                                 only -- device_mask_scope --: eager steps and validation on the same trainer
+            #                                 keep the host draw that torch.manual_seed governs)
         self.tr = trainer
         self.batch = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self.stream = None                 # (created by capture(): torch hands streams out of a pool of 32 round-robin, and
@@ -783,7 +786,24 @@ class GraphedModuleStep:
         self.graph = None
         self.out = None
 
+    @contextlib.contextmanager
+    def device_mask_scope(self):
+        """The criterion draws its EDC time mask from this step's device generator inside the block"""
+        if self.mask_state is None:
+            yield
+            return
+        prev = self._crit.device_mask
+        self._crit.device_mask = (self.mask_seed, self.mask_state, self.maskw)
+        try:
+            yield
+        finally:
+            self._crit.device_mask = prev
+
     def capture(self):
+        with self.device_mask_scope():
+            return self._capture()
+
+    def _capture(self):
         tr = self.tr
         if self.stream is None:
             self.stream = torch.cuda.Stream()
@@ -860,13 +880,11 @@ class DirectionalBank:
             raise RuntimeError("DirectionalBank: no distinct stream left in the pool")
 
         self.lanes = [fresh() for _ in range(max(1, min(int(lanes), len(trainers))))]
+        # (the bank rearranges its trainers' streams and branches: what they had is put back by close())
+        self._restore = [(tr, getattr(tr, 'concurrent_branches', False), getattr(tr, '_side', None)) for tr in trainers]
         for q, tr in enumerate(trainers):
             if q % len(self.lanes) == 0 and getattr(tr, 'concurrent_branches', False):
                 tr._side = fresh()                             # (the first lane's bands keep their side stream)
-        if os.environ.get('GFDN_DBG_STREAMS'):
-            print('[DirectionalBank] lanes', [hex(l.cuda_stream) for l in self.lanes], 'sides',
-                  [hex(tr._side.cuda_stream) for tr in trainers if getattr(tr, '_side', None) is not None],
-                  'current', hex(torch.cuda.current_stream().cuda_stream), flush=True)
         self.root = self.lanes[0]          # (the capture's origin is the first lane: a separate origin stream that only
         #                                     forks and joins makes hipStreamEndCapture of ROCm 7.2 segfault)
         # ... and so does a forked lane that forks again: the bands on the lanes beside the first run their colorless branch
@@ -877,6 +895,16 @@ class DirectionalBank:
         self.graph = None
         self.out = None
 
+    def close(self):
+        """Hands the trainers back as they came: their own side streams and ``concurrent_branches`` (the captured graph keeps
+        replaying on the bank's lanes; eager steps of a trainer run as before the bank was built)."""
+        for tr, branches, side in self._restore:
+            if hasattr(tr, 'concurrent_branches'):
+                tr.concurrent_branches = branches
+            if side is not None or hasattr(tr, '_side'):
+                tr._side = side
+        self._restore = []
+
     @property
     def batches(self):
         return [st.batch for st in self.steps]
@@ -885,6 +913,12 @@ class DirectionalBank:
         return self.lanes[q % len(self.lanes)]
 
     def capture(self):
+        with contextlib.ExitStack() as scopes:
+            for st in self.steps:
+                scopes.enter_context(st.device_mask_scope())
+            return self._capture()
+
+    def _capture(self):
         cur = torch.cuda.current_stream()
         # warm-up per band ON ITS LANE (autograd pins every parameter's AccumulateGrad node to the stream of its first
         # backward), leaving no trace -- as GraphedModuleStep.capture
