@@ -391,12 +391,15 @@ def test_composed_spectra_step_equals_stored_signal_step_full_size():
         off += cnt
 
 
-def test_round5_step_equals_round4_step_full_size():
+@pytest.mark.parametrize("per_band", [2, 4])
+def test_round5_step_equals_round4_step_full_size(per_band):
     """K = 65 537, two bands, one replayed step: the step with the one-launch EDC term (csrc/edcone.hip), the normalisation
     scale joining behind the transform and the fused tail / head (k_tf_tail) against the same step with the three switched
-    off (round 4's launch sequence): losses to 5e-6, gradients to rounding (dL/dM: DESIGN.md section 2)."""
+    off (round 4's launch sequence): losses to 5e-6, gradients to rounding (dL/dM: DESIGN.md section 2).  per_band = 4: the
+    wave-per-receiver gain network, with which the scale sits INSIDE the receiver gains (FusedBankStep.scale_in_gains)."""
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
     res = {}
+    sel0, sel1 = ([[0, 3], [1, 4]], [[2, 5], [0, 3]]) if per_band == 2 else ([[0, 3, 1, 5], [1, 4, 2, 0]], [[2, 5, 0, 4], [0, 3, 5, 1]])
     for new in (True, False):
         bands = [_band(q) for q in range(2)]
         filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
@@ -405,8 +408,8 @@ def test_round5_step_equals_round4_step_full_size():
         f = tr._fused
         f.edc_one_launch = f.scale_late = f.fused_tail = new
         sds = BandStackedDataset([b_[1] for b_ in bands])
-        step = tr.graphed(sds, B, mask_seed=99).capture(sds.global_rows([[0, 3], [1, 4]]))
-        out = step(sds.global_rows([[2, 5], [0, 3]]))
+        step = tr.graphed(sds, per_band, mask_seed=99).capture(sds.global_rows(sel0))
+        out = step(sds.global_rows(sel1))
         torch.cuda.synchronize()
         res[new] = ({k: v.detach().cpu().numpy().copy() for k, v in out.items()},
                     tr.optimizer.flat_grad.detach().cpu().numpy().copy(), [p.numel() for p in tr.optimizer._params])
@@ -419,12 +422,15 @@ def test_round5_step_equals_round4_step_full_size():
         off += cnt
 
 
-def test_transform_passes_equal_matrix_core_passes_full_size_n32():
+@pytest.mark.parametrize("per_band", [2, 4])
+def test_transform_passes_equal_matrix_core_passes_full_size_n32(per_band):
     """K = 65 537, two bands of 4 x 8 lines, one replayed step: the polynomial passes of the 8-line blocks as real transforms
     of their coefficient sequences (csrc/polyfft.hip) against the same step on the matrix-core passes (csrc/blocktf8.hip):
     losses to 2e-5, gradients to the rounding of 1 / Q next to the loop's poles."""
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
     res = {}
+    # (per_band = 4: the wave-per-receiver gain network -- the scale inside the receiver gains on the transform path)
+    sel0, sel1 = ([[0, 3], [1, 4]], [[2, 5], [0, 3]]) if per_band == 2 else ([[0, 3, 1, 5], [1, 4, 2, 0]], [[2, 5, 0, 4], [0, 3, 5, 1]])
     for new in (True, False):
         bands = [_band(q, delays=[d + 2 * q for d in DELAYS32]) for q in range(2)]
         filt = torch.tensor(_filters(), device=DEV).to(torch.complex64)
@@ -434,8 +440,8 @@ def test_transform_passes_equal_matrix_core_passes_full_size_n32():
         f = tr._fused
         f.transform_polys = new
         sds = BandStackedDataset([b_[1] for b_ in bands])
-        step = tr.graphed(sds, B, mask_seed=99).capture(sds.global_rows([[0, 3], [1, 4]]))
-        out = step(sds.global_rows([[2, 5], [0, 3]]))
+        step = tr.graphed(sds, per_band, mask_seed=99).capture(sds.global_rows(sel0))
+        out = step(sds.global_rows(sel1))
         torch.cuda.synchronize()
         res[new] = ({k: v.detach().cpu().numpy().copy() for k, v in out.items()},
                     tr.optimizer.flat_grad.detach().cpu().numpy().copy(), [p.numel() for p in tr.optimizer._params])
