@@ -104,7 +104,7 @@ with open(os.path.join(dst, 'README.md'), 'w') as f:
     f.write(f"""# profiles/ -- round {tag[1:]}
 All `{tag}_*` files come from ONE `gpurun` call (`bash tools/run_measurements.sh {tag}`) on one MI355X (gfx950, ROCm 7.2);
 `bench.py` is the command the driver runs (N = 1, workload = the 7-band configuration BASELINE.json's metric is quoted
-on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r03_*` files are the previous rounds', kept for comparison.
+on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r04_*` files are the previous rounds', kept for comparison.
 
 | file | command | what it holds |
 |---|---|---|
@@ -114,10 +114,11 @@ on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r03_*`
 | `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
 | `{tag}_step_kernel_durations.csv` | from the kernel trace of the stats run | per kernel: launches per step, average duration and microseconds per step over 100 consecutive REPLAYED steps only (what `roofline.top` of the bench line is built from) |
 | `{tag}_directional_bench.json`, `{tag}_directional_kernels.txt`, `{tag}_directional_pmc_hbm_bytes.csv` | `bash tools/run_dir_measurements.sh {tag}` (its own gpurun call) + `python tools/make_dir_profiles.py {tag}` | BASELINE.json configs[3]: the bench line of `python bench.py --config directional` (roofline block of `k_em_bwd` with PMC traffic, CPU baseline with loss and gradient deviations), kernel totals of the graph-replayed band-steps, PMC bytes per launch of its kernels |
-| `{tag}_n32_kernels.txt` | `bash tools/run_n32_profile.sh` (its own gpurun call) | kernel totals of the replayed 7-band step at N = 32 (configs[4]) |
+| `{tag}_n32_kernels.txt`, `{tag}_n32_timeline.txt`, `{tag}_n32_kernels_stage1.txt` | `bash tools/run_r5_aux.sh` (`tools/run_n32_profile.sh` + `tools/timeline.py`; its own gpurun call) | kernel totals and one replayed step of the 7-band step at N = 32 (configs[4]); `_stage1`: the same before the polynomial passes became transforms |
+| `{tag}_step_traffic.json` | this script | the PMC traffic of ALL launches of one replayed step (`step_traffic_bytes` of the bench line) |
 | `r02_mfma_experiment.json` (round 2; not repeated since: the kernels it times did not change) | `python tools/mfma_experiment.py` (its own gpurun call) | configs[4]'s bf16 / f32 MFMA contraction against the solve path: time and deviation of H |
-| `{tag}_grad_stage_probe.txt` | `python tools/grad_stage_probe.py` (its own gpurun call) | where the float32 deviation of dL/dM enters, stage by stage |
-| `{tag}_graph_step_timeline_linear_v1.txt`, `_spectral_v1.txt` | as `{tag}_graph_step_timeline.txt`, earlier in the round | the replayed step after the time-domain output stage (0.527 ms) and after the EDR loss on composed spectra (0.473 ms): the intermediate states DESIGN.md's round-4 history cites |
+| `{tag}_grad_stage_probe.txt` | `python tests/grad_stage_probe.py` (its own gpurun call) | where the float32 deviation of dL/dM enters, stage by stage |
+| `r04_graph_step_timeline_linear_v1.txt`, `_spectral_v1.txt` | as `r04_graph_step_timeline.txt`, earlier in round 4 | the replayed step after the time-domain output stage (0.527 ms) and after the EDR loss on composed spectra (0.473 ms): the intermediate states DESIGN.md's round-4 history cites |
 
 `bench.py` reads `{tag}_pmc_hbm_bytes.csv` (`roofline.traffic`), `{tag}_step_kernel_durations.csv` (`roofline.top`: in-step
 durations) and `{tag}_bench_kernel_stats.csv` (whole-run averages beside them) at run time, so every fraction in the bench
