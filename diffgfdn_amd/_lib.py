@@ -221,6 +221,11 @@ def load():
         raise RuntimeError(
             f"diffgfdn_amd: HIP library not built ({LIB_PATH}); run `make -C diffgfdn_amd/csrc` "
             "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    # PyTorch first: it brings its own copy of the HIP runtime, and the library must bind to THAT copy (the streams and
+    # device pointers it is handed come from it).  Loaded the other way round -- __graft_entry__.build() followed by smoke()
+    # in one process did -- the library pulls in the system's runtime, torch then loads a second one, and every launch
+    # returns hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
