@@ -110,7 +110,7 @@ SIGNATURES = {
     "gfdn_tf8_param_grads": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                      _P]),
     "gfdn_tfp_parts": (c_int, []),
-    "gfdn_tfp_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
+    "gfdn_tfp_forward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_tfp_energy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gfdn_tfp_colorless": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, c_int, _P, _P, _P, _P,
                                    _P]),
@@ -118,6 +118,11 @@ SIGNATURES = {
                                      c_int, _P, c_int, _P, _P, _P]),
     "gfdn_tf8_tail": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                               _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_tf9_coefs": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "gfdn_tf9_rec_grads_work_bytes": (c_size_t, [c_int]),
+    "gfdn_tf9_rec_grads": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "gfdn_tfp_ratio_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "gfdn_tfp_ratio_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_exp_contract_mfma": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),

@@ -27,32 +27,35 @@
 // adjoints are linear in 1 / Q: none of them notices.
 #include "common.h"
 
-#define PF_REC (9 * 256)
-#define PF_GREC 512
 #define PF_PARTS 64
+// blocks of <= 8 lines: 256 subsets, records (9, 256) (csrc/blocktf8.hip); 9 lines: 512 subsets, records (10, 512)
+// (csrc/blocktf9.hip).  L = number of subset bits
+static inline int pf_bits(int nper) { return nper <= 8 ? 8 : 9; }
+static inline bool pf_nsub_ok(int nsub, int nper) { return (nsub == 256 && nper <= 8) || (nsub == 512 && nper <= 9); }
 
 extern "C" int gfdn_tfp_parts(void) { return PF_PARTS; }
 
 __device__ __forceinline__ int pf_degree(const float* __restrict__ delays, int blk, int n, int S, int nfft) {
   int m = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 9; ++i)
     if (i < n && ((S >> i) & 1)) m += (int)rintf(delays[blk * n + i]);
   return m & (nfft - 1);                 // z_k^nfft = 1
 }
 
 // grid (nblk, 2 polynomials): the sequence of one polynomial, T samples (zero but for <= 256 of them).  Subsets of equal
-// degree are added in ascending subset order by the first of them (fixed order, no atomics): the 256 keys (degree, subset)
-// are sorted in LDS (bitonic, 36 compare-exchange stages), equal degrees then sit side by side.
-__global__ __launch_bounds__(256) void k_pf_sparse(const float* __restrict__ coefs, const float* __restrict__ delays,
+// degree are added in ascending subset order by the first of them (fixed order, no atomics): the keys (degree, subset)
+// are sorted in LDS (bitonic, 36 compare-exchange stages at 256 subsets), equal degrees then sit side by side.
+__global__ __launch_bounds__(512) void k_pf_sparse(const float* __restrict__ coefs, const float* __restrict__ delays,
                                                    const float* __restrict__ c, int nblk, int n, int nfft, int T,
                                                    float* __restrict__ seq) {
-  __shared__ unsigned key[256];
-  __shared__ float sv[256];
+  __shared__ unsigned key[512];
+  __shared__ float sv[512];
+  const int nsub = blockDim.x, L = nsub == 512 ? 9 : 8;             // (one thread per subset)
   const int blk = blockIdx.x, poly = blockIdx.y, S = threadIdx.x;
-  const float* coef = coefs + (size_t)blk * PF_REC;
+  const float* coef = coefs + (size_t)blk * (L + 1) * nsub;
   float* row = seq + ((size_t)blockIdx.y * nblk + blk) * T;
-  for (int t = S; t < T; t += 256) row[t] = 0.f;
+  for (int t = S; t < T; t += nsub) row[t] = 0.f;
   const int m = pf_degree(delays, blk, n, S, nfft);
   float v;
   if (poly == 0) {
@@ -60,12 +63,12 @@ __global__ __launch_bounds__(256) void k_pf_sparse(const float* __restrict__ coe
   } else {
     v = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v += (i < n ? c[blk * n + i] : 0.f) * coef[(1 + i) * 256 + S];
+    for (int i = 0; i < 9; ++i) v += (i < n ? c[blk * n + i] * coef[(1 + i) * nsub + S] : 0.f);
   }
-  key[S] = ((unsigned)m << 8) | (unsigned)S;
+  key[S] = ((unsigned)m << 9) | (unsigned)S;
   sv[S] = v;
   __syncthreads();
-  for (int k = 2; k <= 256; k <<= 1)
+  for (int k = 2; k <= nsub; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       const int p = S ^ j;
       if (p > S) {
@@ -76,21 +79,22 @@ __global__ __launch_bounds__(256) void k_pf_sparse(const float* __restrict__ coe
       __syncthreads();
     }
   const unsigned mine = key[S];
-  if (S == 0 || (key[S - 1] >> 8) != (mine >> 8)) {            // first of its degree: sums the run (ascending subsets)
-    float s = sv[mine & 255u];
-    for (int q = S + 1; q < 256 && (key[q] >> 8) == (mine >> 8); ++q) s += sv[key[q] & 255u];
-    row[mine >> 8] = s;
+  if (S == 0 || (key[S - 1] >> 9) != (mine >> 9)) {            // first of its degree: sums the run (ascending subsets)
+    float s = sv[mine & 511u];
+    for (int q = S + 1; q < nsub && (key[q] >> 9) == (mine >> 9); ++q) s += sv[key[q] & 511u];
+    row[mine >> 9] = s;
   }
 }
 
-extern "C" int gfdn_tfp_forward(int nfft, int nblk, int nper, const float* coef, const float* delays, const float* c, int T,
-                                float* seq, float* X_c64, int ldx, void* work, void* stream) {
+extern "C" int gfdn_tfp_forward(int nfft, int nblk, int nper, int nsub, const float* coef, const float* delays, const float* c,
+                                int T, float* seq, float* X_c64, int ldx, void* work, void* stream) {
+  if (!pf_nsub_ok(nsub, nper)) return nper > 9 ? GFDN_E_UNSUPPORTED : GFDN_E_BADARG;
   if (!coef || !delays || !c || !seq || !X_c64 || !work || nblk <= 0 || nper <= 0 || nfft < 16 || (nfft & (nfft - 1)) ||
       T <= 0 || T > nfft || ldx < nfft / 2 + 1)
     return GFDN_E_BADARG;
-  if (nper > 8) return GFDN_E_UNSUPPORTED;
+  if (nper > 9) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_pf_sparse, dim3(nblk, 2), dim3(256), 0, s, coef, delays, c, nblk, nper, nfft, T, seq);
+  hipLaunchKernelGGL(k_pf_sparse, dim3(nblk, 2), dim3(nsub), 0, s, coef, delays, c, nblk, nper, nfft, T, seq);
   GFDN_LAUNCH_CHECK();
   return gfdn_rfft_pow2(nfft, seq, T, T, 2 * nblk, X_c64, ldx, work, stream);
 }
@@ -158,16 +162,16 @@ extern "C" int gfdn_tfp_energy(const float* Xq_c64, const float* Xp_c64, int ldx
 }
 
 // ------------------------------------------------------------------------------------------
-// gradient records from the two inverse transforms: part[blk * 512 + S] = G_u[blk][m_S], part[.. + 256 + S] = G_v[blk][m_S]
+// gradient records from the two inverse transforms: part[blk * 2 nsub + S] = G_u[blk][m_S], part[.. + nsub + S] = G_v[blk][m_S]
 // (x: rows [0, nblk) = G_u, [nblk, 2 nblk) = G_v)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pf_gather(const float* __restrict__ x, int ldt, const float* __restrict__ delays,
+__global__ __launch_bounds__(512) void k_pf_gather(const float* __restrict__ x, int ldt, const float* __restrict__ delays,
                                                    int nblk, int n, int nfft, float* __restrict__ part) {
-  const int blk = blockIdx.x, S = threadIdx.x;
+  const int blk = blockIdx.x, S = threadIdx.x, nsub = blockDim.x;
   const bool absent = (S >> n) != 0;
   const int m = pf_degree(delays, blk, n, S, nfft);
-  part[(size_t)blk * PF_GREC + S] = absent ? 0.f : x[(size_t)blk * ldt + m];
-  part[(size_t)blk * PF_GREC + 256 + S] = absent ? 0.f : x[(size_t)(nblk + blk) * ldt + m];
+  part[(size_t)blk * 2 * nsub + S] = absent ? 0.f : x[(size_t)blk * ldt + m];
+  part[(size_t)blk * 2 * nsub + nsub + S] = absent ? 0.f : x[(size_t)(nblk + blk) * ldt + m];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -209,7 +213,7 @@ extern "C" int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int 
   if (!Xq_c64 || !Xp_c64 || !delays || !UV_c64 || !x || !work || !part || !lossp || !loss || nblk <= 0 || nper <= 0 ||
       nfft < 16 || (nfft & (nfft - 1)) || ldx < nfft / 2 + 1 || ldt < nfft)
     return GFDN_E_BADARG;
-  if (nper > 8) return GFDN_E_UNSUPPORTED;
+  if (nper > 8) return GFDN_E_UNSUPPORTED;          // (the records of csrc/blocktf8.hip: 256 subsets)
   hipStream_t s = (hipStream_t)stream;
   const int K = nfft / 2 + 1;
   hipLaunchKernelGGL(k_pf_colorless, dim3(PF_PARTS, nblk), dim3(256), 0, s, (const float2*)Xq_c64, (const float2*)Xp_c64, ldx, K,
@@ -217,7 +221,7 @@ extern "C" int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int 
   GFDN_LAUNCH_CHECK();
   int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(256), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
+  hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(1 << pf_bits(nper)), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
   GFDN_LAUNCH_CHECK();
   return gfdn_tf_rows_sum(lossp, PF_PARTS, nblk, loss, stream);
 }
@@ -266,7 +270,7 @@ extern "C" int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const
       nper <= 0 || nfft < 16 || (nfft & (nfft - 1)) || Ku <= 0 || Ku > nfft / 2 + 1 || ldh < Ku || (filt_c64 && ldf < Ku) ||
       ldx < nfft / 2 + 1 || ldt < nfft || (gain_fold && !tscale))
     return GFDN_E_BADARG;
-  if (nper > 8) return GFDN_E_UNSUPPORTED;
+  if (nper > 8) return GFDN_E_UNSUPPORTED;          // (the records of csrc/blocktf8.hip: 256 subsets)
   hipStream_t s = (hipStream_t)stream;
   const int K = nfft / 2 + 1, nblk = nbands * G;
   hipLaunchKernelGGL(k_pf_bwd_spectra, dim3((K + 255) / 256, nblk), dim3(256), 0, s, (const float2*)gH_c64, ldh,
@@ -275,7 +279,63 @@ extern "C" int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const
   GFDN_LAUNCH_CHECK();
   int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(256), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
+  hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(1 << pf_bits(nper)), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// The transfer functions themselves and the adjoint of T = P / Q, for callers that keep their own loss on T (the directional
+// model's colorless branch under autograd: model.py:209-252 through sub_fdn_group_sums): T (nblk, K) and 1 / Q (nblk, K) from
+// the transformed sequences; gT = dL/dT in the convention dL = sum_k Re(conj(gT_k) dT_k) -> gradient records.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pf_ratio_fwd(const float2* __restrict__ Xq, const float2* __restrict__ Xp, int ldx,
+                                                      int K, float2* __restrict__ T, float2* __restrict__ D) {
+  const int blk = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float2 q = cconj(Xq[(size_t)blk * ldx + k]), p = cconj(Xp[(size_t)blk * ldx + k]);
+  const float2 dinv = cinv(q);
+  T[(size_t)blk * K + k] = cmul(p, dinv);
+  D[(size_t)blk * K + k] = dinv;
+}
+__global__ __launch_bounds__(256) void k_pf_ratio_bwd(const float2* __restrict__ gT, int ldg, const float2* __restrict__ T,
+                                                      const float2* __restrict__ D, int K, int nblk,
+                                                      float2* __restrict__ UV, int ldx) {
+  const int blk = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float2 g = gT[(size_t)blk * ldg + k], dinv = D[(size_t)blk * K + k], t = T[(size_t)blk * K + k];
+  const float w = (k == 0 || k == K - 1) ? 2.0f * (float)(K - 1) : (float)(K - 1);
+  const float2 u = cscale(make_float2(g.x * dinv.x + g.y * dinv.y, g.x * dinv.y - g.y * dinv.x), w);       // w conj(g) / Q
+  const float2 v = cmul(u, t);
+  UV[(size_t)blk * ldx + k] = u;
+  UV[(size_t)(nblk + blk) * ldx + k] = make_float2(-v.x, -v.y);
+}
+
+extern "C" int gfdn_tfp_ratio_fwd(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, float* T_c64,
+                                  float* Dinv_c64, void* stream) {
+  if (!Xq_c64 || !Xp_c64 || !T_c64 || !Dinv_c64 || K <= 0 || ldx < K || nblk <= 0) return GFDN_E_BADARG;
+  hipLaunchKernelGGL(k_pf_ratio_fwd, dim3((K + 255) / 256, nblk), dim3(256), 0, (hipStream_t)stream, (const float2*)Xq_c64,
+                     (const float2*)Xp_c64, ldx, K, (float2*)T_c64, (float2*)Dinv_c64);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gfdn_tfp_ratio_bwd(int nfft, int nblk, int nper, int nsub, const float* delays, const float* gT_c64, int ldg,
+                                  const float* T_c64, const float* Dinv_c64, float* UV_c64, int ldx, float* x, int ldt,
+                                  void* work, float* part, void* stream) {
+  if (!delays || !gT_c64 || !T_c64 || !Dinv_c64 || !UV_c64 || !x || !work || !part || nblk <= 0 || nper <= 0 || nfft < 16 ||
+      (nfft & (nfft - 1)) || ldg < nfft / 2 + 1 || ldx < nfft / 2 + 1 || ldt < nfft)
+    return GFDN_E_BADARG;
+  if (!pf_nsub_ok(nsub, nper)) return nper > 9 ? GFDN_E_UNSUPPORTED : GFDN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int K = nfft / 2 + 1;
+  hipLaunchKernelGGL(k_pf_ratio_bwd, dim3((K + 255) / 256, nblk), dim3(256), 0, s, (const float2*)gT_c64, ldg,
+                     (const float2*)T_c64, (const float2*)Dinv_c64, K, nblk, (float2*)UV_c64, ldx);
+  GFDN_LAUNCH_CHECK();
+  int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(nsub), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -268,6 +268,33 @@ class GroupSums(torch.autograd.Function):
         return gY, gc.to(c.dtype).reshape(c.shape), None, None
 
 
+class SubFdnTransforms(torch.autograd.Function):
+    """S (G, K) = c_g^T (D(z) - M_g)^{-1} b_g, the un-damped group responses of the colorless branch (model.py:209-252), for
+    zero-coupling blocks of up to nine lines with INTEGER delay lengths on the reference's rfftfreq grid: numerator and
+    determinant polynomials as real transforms of their coefficient sequences, the adjoint as a gather from two inverse
+    transforms and a float64 cofactor map (csrc/blocktf9.hip, csrc/polyfft.hip) -- in place of the per-bin n x n complex
+    eliminations of ``ResolventSolve`` + ``GroupSums``, which hold the whole chip for their two launches."""
+
+    @staticmethod
+    def forward(ctx, M, b, c, delays, nper: int, nfft: int, T_seq: int):
+        coef = ops.tf9_coefs(M, None, b)
+        X = ops.tfp_forward(coef, delays, c, nper, nfft, T_seq)
+        nblk = M.shape[0]
+        S, Dinv = ops.tfp_ratio_fwd(X[:nblk], X[nblk:])
+        ctx.save_for_backward(M, b, c, delays, S, Dinv)
+        ctx.meta = (nper, nfft)
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        M, b, c, delays, S, Dinv = ctx.saved_tensors
+        nper, nfft = ctx.meta
+        part = ops.tfp_ratio_bwd(nfft, nper, delays, gS, S, Dinv)
+        gA, gb, gc = ops.tf9_rec_grads(M, None, part, b, c)
+        return gA.to(M.dtype).reshape(M.shape), gb.to(b.dtype).reshape(b.shape), gc.to(c.dtype).reshape(c.shape), None, None, \
+            None, None
+
+
 class SHOutputStage(torch.autograd.Function):
     """H_sh[b][l][k] = filt[k] * sum_g w[b][g][l] c_{g,l} Y[k][g nper + l]  (model.py:1056-1088)."""
 

@@ -996,8 +996,9 @@ def tfp_forward(coef, delays, c, nper: int, nfft: int, T: int) -> torch.Tensor:
     seq = torch.empty((2 * nblk, T), dtype=_f32, device=coef.device)
     X = torch.empty((2 * nblk, K), dtype=_c64, device=coef.device)
     work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), coef.device)
-    _lib.check(lib.gfdn_tfp_forward(nfft, nblk, nper, _p(coef), _p(delays), _p(c), T, _p(seq), _p(X), K, _p(work), _stream()),
-               "gfdn_tfp_forward")
+    nsub = coef.shape[-1]                 # (256: the records of tf8_coefs, 512: of tf9_coefs)
+    _lib.check(lib.gfdn_tfp_forward(nfft, nblk, nper, nsub, _p(coef), _p(delays), _p(c), T, _p(seq), _p(X), K, _p(work),
+                                    _stream()), "gfdn_tfp_forward")
     return X
 
 
@@ -1072,6 +1073,69 @@ def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, 
                                         Ku, _p(Tnat), _p(Dnat), _p(None if tscale is None else _f(tscale)),
                                         int(bool(gain_fold)), _p(UV), K, _p(x), nfft, _p(work), _p(part), _stream()),
                "gfdn_tfp_compose_bwd")
+    return part
+
+
+def tf9_coefs(A, ig, b):
+    """Coefficient records (nblk, 10, 512) float32 of blocks of up to nine lines: the determinant polynomial of
+    X = D Gamma^-1 - A and the nine numerators of y = X^-1 b (csrc/blocktf9.hip)."""
+    _need_gpu(A, b)
+    A, b = _f(A), _f(b).reshape(-1)
+    nblk, n, _ = A.shape
+    if n > 9 or b.numel() != nblk * n:
+        raise RuntimeError("tf9_coefs: blocks of at most nine lines, b (nblk n)")
+    ig = None if ig is None else _f(ig).reshape(-1)
+    coef = torch.empty((nblk, 10, 512), dtype=_f32, device=A.device)
+    _lib.check(_lib.load().gfdn_tf9_coefs(_p(A), _p(ig), _p(b), nblk, n, _p(coef), _stream()), "gfdn_tf9_coefs")
+    return coef
+
+
+def tf9_rec_grads(A, ig, grec, b, c):
+    """Gradient records (nblk, 1024[, 1]) of blocks of up to nine lines -> (dL/dA (nblk, n, n), dL/db, dL/dc (nblk n))."""
+    _need_gpu(A, grec, b, c)
+    A, b, c, grec = _f(A), _f(b).reshape(-1), _f(c).reshape(-1), _f(grec)
+    nblk, n, _ = A.shape
+    if grec.numel() != nblk * 1024:
+        raise RuntimeError("tf9_rec_grads: records must be (nblk, 1024)")
+    ig = None if ig is None else _f(ig).reshape(-1)
+    lib = _lib.load()
+    gA = torch.empty_like(A)
+    gb = torch.empty(nblk * n, dtype=_f32, device=A.device)
+    gc = torch.empty(nblk * n, dtype=_f32, device=A.device)
+    work = _work(lib.gfdn_tf9_rec_grads_work_bytes(nblk), A.device)
+    _lib.check(lib.gfdn_tf9_rec_grads(_p(A), _p(ig), _p(grec), _p(b), _p(c), nblk, n, _p(gA), _p(gb), _p(gc), _p(work),
+                                      _stream()), "gfdn_tf9_rec_grads")
+    return gA, gb, gc
+
+
+def tfp_ratio_fwd(Xq, Xp):
+    """(T, Dinv) (nblk, K) complex64 = (P / Q, 1 / Q) on the grid from the transformed sequences (rows of tfp_forward)."""
+    _need_gpu(Xq, Xp)
+    nblk, K = Xq.shape
+    if Xq.stride(0) != Xp.stride(0) or Xq.stride(1) != 1:
+        raise RuntimeError("tfp_ratio_fwd: rows of one tfp_forward result")
+    T = torch.empty((nblk, K), dtype=_c64, device=Xq.device)
+    D = torch.empty((nblk, K), dtype=_c64, device=Xq.device)
+    _lib.check(_lib.load().gfdn_tfp_ratio_fwd(_p(Xq), _p(Xp), Xq.stride(0), K, nblk, _p(T), _p(D), _stream()), "gfdn_tfp_ratio_fwd")
+    return T, D
+
+
+def tfp_ratio_bwd(nfft: int, nper: int, delays, gT, T, Dinv, nsub: int = 512):
+    """Gradient records (nblk, 2 nsub) (nsub = 256: subsets of tf8_coefs' records, 512: of tf9_coefs') of T = P / Q from gT =
+    dL/dT (nblk, K), dL = sum_k Re(conj(gT_k) dT_k): two inverse real transforms and a gather (csrc/polyfft.hip)."""
+    _need_gpu(gT, T, Dinv, delays)
+    gT = _c(gT)
+    nblk, K = T.shape
+    if K != nfft // 2 + 1 or tuple(gT.shape) != (nblk, K):
+        raise RuntimeError("tfp_ratio_bwd: gT and T on the nfft / 2 + 1 bins of the grid")
+    lib = _lib.load()
+    dev = T.device
+    UV = torch.empty((2 * nblk, K), dtype=_c64, device=dev)
+    x = torch.empty((2 * nblk, nfft), dtype=_f32, device=dev)
+    work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), dev)
+    part = torch.empty((nblk, 2 * nsub), dtype=_f32, device=dev)
+    _lib.check(lib.gfdn_tfp_ratio_bwd(nfft, nblk, nper, int(nsub), _p(_f(delays)), _p(gT), K, _p(T), _p(Dinv), _p(UV), K, _p(x), nfft,
+                                      _p(work), _p(part), _stream()), "gfdn_tfp_ratio_bwd")
     return part
 
 

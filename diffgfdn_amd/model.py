@@ -157,8 +157,24 @@ class DiffGFDN(nn.Module):
         return ResolventSolve.apply(M, self._ones, self.input_gains.reshape(-1), grid,
                                     self.delay_buffer, False)
 
+    # The group responses of the colorless branch by real transforms of the blocks' coefficient sequences instead of per-bin
+    # eliminations (functional.SubFdnTransforms): needs integer delay lengths on the reference's rfftfreq grid and a caller
+    # that does not ask for the per-delay-line responses; on for the directional model, whose 9 x 9 eliminations are the
+    # largest kernels of its step
+    sub_fdn_by_transforms = False
+
     def sub_fdn_group_sums(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(S (G, K), Ysub (K, N)):  S[g][k] = sum_{n in g} c_n y^(g)_n[k] = Hout[k, g]."""
+        """(S (G, K), Ysub (K, N)):  S[g][k] = sum_{n in g} c_n y^(g)_n[k] = Hout[k, g].  (Ysub: None on the transform path)"""
+        n = self.num_delay_lines_per_group
+        if self.sub_fdn_by_transforms and not self.per_delay_output and n <= 9 and z.is_cuda:
+            grid = FrequencyGrid.of(z)
+            T_seq = ops.tfp_plan(self.delay_buffer, n, grid.rfft_nfft) if grid.rfft_nfft else None
+            if T_seq is not None:
+                from .functional import SubFdnTransforms
+                M = self.feedback_loop.M
+                S = SubFdnTransforms.apply(M.reshape(self.num_groups, n, n), self.input_gains.reshape(-1),
+                                           self.output_gains.reshape(-1), self.delay_buffer, n, grid.rfft_nfft, T_seq)
+                return S, None
         Ysub = self.sub_fdn_responses(z)
         if ops.group_sums_supported(self.num_groups, self.num_delay_lines_per_group):
             S = GroupSums.apply(Ysub, self.output_gains.reshape(-1), self.num_groups, self.num_delay_lines_per_group)
@@ -464,6 +480,8 @@ class DiffGFDNSinglePos(DiffGFDN):
 
 class DiffDirectionalFDNVarReceiverPos(DiffGFDN):
     """Directional FDN with SH-domain output gains (reference :975-1126)."""
+
+    sub_fdn_by_transforms = True
 
     def __init__(self, sample_rate: int, num_groups: int, delays: List[int], device: torch.device,
                  feedback_loop_config: FeedbackLoopConfig, output_filter_config: OutputFilterConfig,

@@ -462,7 +462,7 @@ int gfdn_tf8_tail(const float* A0, const float* inv_gamma0, const float* part0, 
  * is 1e-5 of T -- 100 x the rounding of the direct evaluation, and it reaches dL/dM through the dB stages of the decay
  * losses (measured: 1.15e-3 against 7.6e-4 of its largest entry; the adjoints are linear in 1 / Q and do not care).
  *   gfdn_tfp_forward    : X (2 nblk, ldx >= nfft / 2 + 1) complex64 = rfft of the sequences [Q | P] of ONE record set (nblk
- *                         rows each).  T: samples per sequence kept in seq (2 nblk, T): max degree + 1 <= T <= nfft.
+ *                         rows each; nsub = 256: records (nblk, 9, 256) of gfdn_tf8_coefs, nsub = 512: (nblk, 10, 512) of gfdn_tf9_coefs).  T: samples per sequence kept in seq (2 nblk, T): max degree + 1 <= T <= nfft.
  *                         work: gfdn_irfft_pow2_work_bytes(nfft, 2 nblk).
  *   gfdn_tfp_energy     : normalize on rows (Xq, Xp) of the raw sub-FDN blocks, K = nfft / 2 + 1 bins: energy (or NULL),
  *                         scale = E^(-1/2), b, c /= E^(1/4) in place.  work: nblk * gfdn_tfp_parts() floats.  gains /
@@ -475,9 +475,30 @@ int gfdn_tf8_tail(const float* A0, const float* inv_gamma0, const float* part0, 
  *                         group).  Tnat, Dnat (nblk, Ku): gfdn_tf8_tsave's Tsave / Dinv on bins 0 .. Ku - 1 in bin order;
  *                         tscale (nblk; or NULL): Tnat holds the UNSCALED functions, T' = tscale Tnat; gain_fold: as
  *                         gfdn_tf_compose_bwd's.                                                                          */
+/* ---- blocks of up to NINE lines (the directional model, BASELINE.json configs[3]: N = 27 = 3 x 9; csrc/blocktf9.hip): the
+ * coefficient records and the records -> parameters map of the gfdn_tf8_* family with 512 subsets, for ONE record set.
+ *   gfdn_tf9_coefs    : coef (nblk, 10, 512) float32 of (A, 1/gamma or NULL): [0] the determinant polynomial, [1 + i] the
+ *                       numerator of y_i = (X^-1 b)_i (float64 determinants of the masked 9 x 9 matrices).
+ *   gfdn_tf9_rec_grads: gradient records grec (nblk, 1024) = dL/dP_S | dL/dQ_S -> dL/dA (nblk, n, n), dL/db, dL/dc (nblk n)
+ *                       w.r.t. the gains b, c given (cofactors of the masked n x n and bordered (n + 1) x (n + 1) matrices,
+ *                       float64).  work: gfdn_tf9_rec_grads_work_bytes(nblk).
+ * The evaluation on the grid and its adjoint: gfdn_tfp_forward + gfdn_tfp_ratio_fwd / _bwd below (nper <= 9).              */
+int gfdn_tf9_coefs(const float* A, const float* inv_gamma, const float* b, int nblk, int nper, float* coef, void* stream);
+size_t gfdn_tf9_rec_grads_work_bytes(int nblk);
+int gfdn_tf9_rec_grads(const float* A, const float* inv_gamma, const float* grec, const float* b, const float* c, int nblk,
+                       int nper, float* gA, float* gb, float* gc, void* work, void* stream);
+/*   gfdn_tfp_ratio_fwd  : T (nblk, K) = P / Q and Dinv (nblk, K) = 1 / Q on the grid from the transformed sequences (rows Xq, Xp
+ *                         of gfdn_tfp_forward) -- the un-damped group responses S_g(z) of the colorless branch, model.py:209-252.
+ *   gfdn_tfp_ratio_bwd  : gT (nblk, ldg) = dL/dT with dL = sum_k Re(conj(gT_k) dT_k) -> gradient records part (nblk, 2 nsub)
+ *                         (nsub as gfdn_tfp_forward's; 512: what gfdn_tf9_rec_grads takes).  UV (2 nblk, ldx), x (2 nblk,
+ *                         ldt >= nfft), work: gfdn_irfft_pow2_work_bytes(nfft, 2 nblk).                                     */
+int gfdn_tfp_ratio_fwd(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, float* T_c64, float* Dinv_c64,
+                       void* stream);
+int gfdn_tfp_ratio_bwd(int nfft, int nblk, int nper, int nsub, const float* delays, const float* gT_c64, int ldg, const float* T_c64,
+                       const float* Dinv_c64, float* UV_c64, int ldx, float* x, int ldt, void* work, float* part, void* stream);
 int gfdn_tfp_parts(void);
-int gfdn_tfp_forward(int nfft, int nblk, int nper, const float* coef, const float* delays, const float* c, int T, float* seq,
-                     float* X_c64, int ldx, void* work, void* stream);
+int gfdn_tfp_forward(int nfft, int nblk, int nper, int nsub, const float* coef, const float* delays, const float* c, int T,
+                     float* seq, float* X_c64, int ldx, void* work, void* stream);
 int gfdn_tfp_energy(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, int nper, float* b, float* c,
                     float* energy, float* scale, void* work, const float* gains, float* gains_scaled, int Bper, int G,
                     void* stream);
