@@ -171,9 +171,10 @@ __device__ __forceinline__ double t9_wave_sum_d(double v) {
   return v;
 }
 
-// Gradient records -> (dL/dA, dL/db, dL/dc), float64.  grid (nblk, 2): y = 0 the masked n x n matrices (dL/dQ_S -> dL/dA),
-// y = 1 the bordered (n + 1) x (n + 1) ones (dL/dP_S -> dL/dA, dL/db, dL/dc); 256 threads, two subsets each (one wavefront per
-// SIMD: the 10 x 10 inversion lives in 200 registers); out[(half nblk + blk) 99 + e], the two halves added by k_tf9_finish.
+// Gradient records -> (dL/dA, dL/db, dL/dc), float64.  grid (nblk, 2, 2): y = 0 the masked n x n matrices (dL/dQ_S -> dL/dA),
+// y = 1 the bordered (n + 1) x (n + 1) ones (dL/dP_S -> dL/dA, dL/db, dL/dc); z = which 256 of the 512 subsets; 256 threads,
+// one subset each (one wavefront per SIMD: the 10 x 10 inversion lives in 200 registers; with both halves of the subsets in
+// one workgroup the launch took 81 us on the step's chain); out[((2 half + z) nblk + blk) 99 + e], added by k_tf9_finish.
 __global__ __launch_bounds__(256) void k_tf9_rec_grads(const float* __restrict__ A, const float* __restrict__ ig,
                                                        const float* __restrict__ grec, const float* __restrict__ b,
                                                        const float* __restrict__ c, int n, float* __restrict__ out) {
@@ -191,9 +192,8 @@ __global__ __launch_bounds__(256) void k_tf9_rec_grads(const float* __restrict__
   }
   for (int e = tid; e < 4 * T9_ACC; e += 256) sred[e / T9_ACC][e % T9_ACC] = 0.0;
   __syncthreads();
-#pragma unroll 1
-  for (int rnd = 0; rnd < 2; ++rnd) {
-    const int S = tid + 256 * rnd;
+  {
+    const int S = tid + 256 * (int)blockIdx.z;
     const bool absent = (S >> n) != 0, full = S == (1 << n) - 1;      // (the full set's coefficients are constants)
     double igp = 1.0;
 #pragma unroll
@@ -253,15 +253,17 @@ __global__ __launch_bounds__(256) void k_tf9_rec_grads(const float* __restrict__
   }
   __syncthreads();
   if (tid < T9_ACC)
-    out[((size_t)half * gridDim.x + blk) * T9_ACC + tid] = (float)((sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]));
+    out[((size_t)(2 * half + blockIdx.z) * gridDim.x + blk) * T9_ACC + tid] =
+        (float)((sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]));
 }
 
-// the two halves added -> dL/dA (nblk, n, n), dL/db, dL/dc (nblk n)
+// the four partial sets added -> dL/dA (nblk, n, n), dL/db, dL/dc (nblk n)
 __global__ __launch_bounds__(128) void k_tf9_finish(const float* __restrict__ part, int nblk, int n, float* __restrict__ gA,
                                                     float* __restrict__ gb, float* __restrict__ gc) {
   const int blk = blockIdx.x, e = threadIdx.x;
   if (e >= T9_ACC) return;
-  const float v = part[(size_t)blk * T9_ACC + e] + part[((size_t)nblk + blk) * T9_ACC + e];
+  const float v = (part[(size_t)blk * T9_ACC + e] + part[((size_t)nblk + blk) * T9_ACC + e]) +
+                  (part[((size_t)2 * nblk + blk) * T9_ACC + e] + part[((size_t)3 * nblk + blk) * T9_ACC + e]);
   if (e < T9_L * T9_L) {
     const int i = e / T9_L, j = e - i * T9_L;
     if (i < n && j < n) gA[(size_t)blk * n * n + i * n + j] = v;
@@ -274,14 +276,14 @@ __global__ __launch_bounds__(128) void k_tf9_finish(const float* __restrict__ pa
   }
 }
 
-extern "C" size_t gfdn_tf9_rec_grads_work_bytes(int nblk) { return (size_t)2 * (nblk > 0 ? nblk : 1) * T9_ACC * sizeof(float); }
+extern "C" size_t gfdn_tf9_rec_grads_work_bytes(int nblk) { return (size_t)4 * (nblk > 0 ? nblk : 1) * T9_ACC * sizeof(float); }
 
 extern "C" int gfdn_tf9_rec_grads(const float* A, const float* inv_gamma, const float* grec, const float* b, const float* c,
                                   int nblk, int nper, float* gA, float* gb, float* gc, void* work, void* stream) {
   if (!A || !grec || !b || !c || !gA || !gb || !gc || !work || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > T9_L) return GFDN_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_tf9_rec_grads, dim3(nblk, 2), dim3(256), 0, s, A, inv_gamma, grec, b, c, nper, (float*)work);
+  hipLaunchKernelGGL(k_tf9_rec_grads, dim3(nblk, 2, 2), dim3(256), 0, s, A, inv_gamma, grec, b, c, nper, (float*)work);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_tf9_finish, dim3(nblk), dim3(128), 0, s, (const float*)work, nblk, nper, gA, gb, gc);
   GFDN_LAUNCH_CHECK();
