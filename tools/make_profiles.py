@@ -115,6 +115,7 @@ on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r04_*`
 | `{tag}_step_kernel_durations.csv` | from the kernel trace of the stats run | per kernel: launches per step, average duration and microseconds per step over 100 consecutive REPLAYED steps only (what `roofline.top` of the bench line is built from) |
 | `{tag}_directional_bench.json`, `{tag}_directional_kernels.txt`, `{tag}_directional_pmc_hbm_bytes.csv` | `bash tools/run_dir_measurements.sh {tag}` (its own gpurun call) + `python tools/make_dir_profiles.py {tag}` | BASELINE.json configs[3]: the bench line of `python bench.py --config directional` (roofline block of `k_em_bwd` with PMC traffic, CPU baseline with loss and gradient deviations), kernel totals of the graph-replayed band-steps, PMC bytes per launch of its kernels |
 | `{tag}_n32_kernels.txt`, `{tag}_n32_timeline.txt`, `{tag}_n32_kernels_stage1.txt` | `bash tools/run_r5_aux.sh` (`tools/run_n32_profile.sh` + `tools/timeline.py`; its own gpurun call) | kernel totals and one replayed step of the 7-band step at N = 32 (configs[4]); `_stage1`: the same before the polynomial passes became transforms |
+| `{tag}_ab_same_box.txt` | `bash tools/run_r5_ab_final.sh` (its own gpurun call) | every switch of the round flipped once on the final code, one box: the same-box A/B figures DESIGN.md sections 4.0.5 / 4.0.6 quote |
 | `{tag}_step_traffic.json` | this script | the PMC traffic of ALL launches of one replayed step (`step_traffic_bytes` of the bench line) |
 | `r02_mfma_experiment.json` (round 2; not repeated since: the kernels it times did not change) | `python tools/mfma_experiment.py` (its own gpurun call) | configs[4]'s bf16 / f32 MFMA contraction against the solve path: time and deviation of H |
 | `{tag}_grad_stage_probe.txt` | `python tests/grad_stage_probe.py` (its own gpurun call) | where the float32 deviation of dL/dM enters, stage by stage |
