@@ -102,7 +102,7 @@ SIGNATURES = {
     "gfdn_tf8_parts": (c_int, [c_int]),
     "gfdn_tf8_part_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_tf8_energy": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_double, _P]),
-    "gfdn_tf8_tsave": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_double, _P]),
+    "gfdn_tf8_tsave": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "gfdn_tf8_colorless": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_double, _P]),
     "gfdn_tf8_compose_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P,
                                      _P, _P, _P]),

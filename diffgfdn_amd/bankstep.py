@@ -507,7 +507,7 @@ class FusedBankStep:
             # --, the group responses through the band's filter scattered to the transform's slot order; unscaled: the
             # snapshot of the gains)
             Ts, _, Hg, Dinv8 = ops.tf8_tsave(gridK.turns[:Ku], coef, delays, n, c_head, None, nb, G, quad=False, filt=filt,
-                                             want_H=True, hslot=tfp[1], dturn=gridK.dturn)
+                                             want_H=True, hslot=tfp[1])
             keep.append(Dinv8)
         ework = None
         if normalize_first and not late and not late8:

@@ -147,7 +147,6 @@ struct T8Args {
   const double* turns;
   double dturn;              // != 0: the grid is uniform on the unit circle with this step (turns[k] = turns[0] + k dturn):
                              // a wavefront then steps its phasors from tile to tile by constant rotations
-  int exact_mask;            // (uniform grids) a wavefront's phasors are exact on its tiles iter & exact_mask == 0, stepped between
   int K, nblk, nper;
   const float* coef;         // (nblk, 9, 256)
   const float* delays;       // (nblk * nper)
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(64 * T8_WAVES, 8 / T8_WAVES) void k_tf8_pass(T8Args
 #ifdef T8_DIAG_NO_PHASE
     if (iter == 0) {
 #else
-    if (a.dturn == 0.0 || (iter & a.exact_mask) == 0 || !live) {
+    if (a.dturn == 0.0 || (iter & 7) == 0 || !live) {
 #endif
 #pragma unroll
       for (int r = 0; r < 8; ++r) ph[r] = t8_zpow(a.turns, kk, m[r]);
@@ -514,7 +513,7 @@ extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, c
   if (rc) return rc;
   if (!work || !b) return GFDN_E_BADARG;
   T8Args a{};
-  a.turns = turns; a.dturn = dturn; a.exact_mask = 7; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = nullptr;
+  a.turns = turns; a.dturn = dturn; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = nullptr;
   a.part = (float*)work;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = t8_launch<T8_ENERGY>(a, s))) return rc;
@@ -527,7 +526,7 @@ extern "C" int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, c
 extern "C" int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef,
                               const float* delays, const float* c, const float* scale, float* Tsave, float* Tquad,
                               const float* filt_c64, int ldf, float* Hout_c64, float* Dinv_c64, const int* hslot,
-                              double dturn, void* stream) {
+                              void* stream) {
   int rc = t8_ok(turns, K, nbands * G, nper, coef, delays, c);
   if (rc) return rc;
   if (!Tsave || G <= 0 || G > 4 || (filt_c64 && ldf < K)) return GFDN_E_BADARG;
@@ -535,9 +534,6 @@ extern "C" int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int
   a.turns = turns; a.K = K; a.nblk = nbands * G; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
   a.Tsave = (float2*)Tsave; a.Tquad = (float2*)Tquad; a.G = G;
   a.Hout = (float2*)Hout_c64; a.filt = (const float2*)filt_c64; a.ldf = ldf; a.Dsave = (float2*)Dinv_c64; a.hslot = hslot;
-  // (a uniform grid: exact phasors on every SECOND tile of a wavefront, one rotation step between -- 6e-8 of rounding, far
-  // below what the forward responses tolerate (polyfft.hip); the energy / colorless passes take seven steps)
-  a.dturn = dturn; a.exact_mask = 1;
   return t8_launch<T8_TSAVE>(a, (hipStream_t)stream);
 }
 
@@ -553,7 +549,7 @@ extern "C" int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper
   if (rc) return rc;
   if (!part || !lossp || !loss) return GFDN_E_BADARG;
   T8Args a{};
-  a.turns = turns; a.dturn = dturn; a.exact_mask = 7; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
+  a.turns = turns; a.dturn = dturn; a.K = K; a.nblk = nblk; a.nper = nper; a.coef = coef; a.delays = delays; a.c = c; a.scale = scale;
   a.asym = asym; a.gscale = gscale; a.part = part; a.lossp = lossp;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = t8_launch<T8_COLORLESS>(a, s))) return rc;

@@ -850,7 +850,7 @@ def tf8_energy(turns, coef, delays, nper: int, b, c, want_energy: bool = False, 
 
 
 def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, quad: bool = True, filt=None,
-              want_H: bool = False, hslot=None, dturn: float = 0.0):
+              want_H: bool = False, hslot=None):
     """Scaled group transfer functions T' (nbands * G, K) complex64 [+ Tquad (nbands, K, 4)] from the records.
     ``want_H``: returns (Ts, Tq, Hg, Dinv) with Hg = T' filt (``filt`` (nbands, K) complex64 or None) and Dinv = 1 / Q per
     bin (what tf8_compose_bwd on the same grid takes back with Ts), written by the same launch.  ``hslot`` (K,) int32
@@ -871,7 +871,7 @@ def tf8_tsave(turns, coef, delays, nper: int, c, scale, nbands: int, G: int, qua
     Dinv = torch.empty((nbands * G, K), dtype=_c64, device=coef.device) if want_H else None
     _lib.check(_lib.load().gfdn_tf8_tsave(_p(turns), K, nbands, G, nper, _p(coef), _p(delays), _p(c), _p(scale), _p(Ts),
                                           _p(Tq), _p(filt if want_H else None), K, _p(Hg), _p(Dinv),
-                                          _p(hslot if want_H else None), float(dturn), _stream()), "gfdn_tf8_tsave")
+                                          _p(hslot if want_H else None), _stream()), "gfdn_tf8_tsave")
     return (Ts, Tq, Hg, Dinv) if want_H else (Ts, Tq)
 
 

@@ -422,13 +422,12 @@ int gfdn_tf8_energy(const double* turns, int K, int nblk, int nper, const float*
                     float* c, float* energy, float* scale, void* work, double dturn, void* stream);
 int gfdn_tf8_tsave(const double* turns, int K, int nbands, int G, int nper, const float* coef, const float* delays,
                    const float* c, const float* scale, float* Tsave_c64, float* Tquad_c64, const float* filt_c64, int ldf,
-                   float* Hout_c64, float* Dinv_c64, const int* hslot, double dturn, void* stream);
+                   float* Hout_c64, float* Dinv_c64, const int* hslot, void* stream);
 /* Hout (nbands G, K; NULL: none) = T' filt with band row blk / G of filt (nbands, ldf; NULL: Hout = T'): the group responses
  * through the band's filter, what the time-domain output stage transforms (no tensor operation between the two).
  * hslot (K; NULL: Hout in grid order): column of grid point k in Hout and filt, bit 31 set where that column holds the
  * conjugate -- the grid in BIN order (Tsave, Dinv: what gfdn_tfp_compose_bwd reads), the group responses in the slot
- * order of the odd-length transform (gfdn_irfft_odd_slot_order).  dturn != 0: the grid is uniform with that step in turns:
- * every second tile of a wavefront evaluates its phasors exactly, the one between is one rotation step away.
+ * order of the odd-length transform (gfdn_irfft_odd_slot_order).
  * Dinv (nbands G, K; NULL: none) = 1 / Q per bin: with Tsave what gfdn_tf8_compose_bwd on the SAME grid takes back
  * (Tsave_c64, Dinv_c64: both or neither) instead of evaluating the two polynomials again.                               */
 int gfdn_tf8_colorless(const double* turns, int K, int nblk, int nper, const float* coef, const float* delays,
