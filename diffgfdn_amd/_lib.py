@@ -112,17 +112,17 @@ SIGNATURES = {
     "gfdn_tfp_parts": (c_int, []),
     "gfdn_tfp_forward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_tfp_energy": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
-    "gfdn_tfp_colorless": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, c_int, _P, _P, _P, _P,
-                                   _P]),
-    "gfdn_tfp_compose_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, _P,
-                                     c_int, _P, c_int, _P, _P, _P]),
+    "gfdn_tfp_colorless": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, c_int, _P, _P, c_int, _P, _P, _P,
+                                   _P, _P]),
+    "gfdn_tfp_compose_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int,
+                                     _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_tf8_tail": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                               _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P]),
     "gfdn_tf9_coefs": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "gfdn_tf9_rec_grads_work_bytes": (c_size_t, [c_int]),
     "gfdn_tf9_rec_grads": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "gfdn_tfp_ratio_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
-    "gfdn_tfp_ratio_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),
+    "gfdn_tfp_ratio_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "gfdn_ortho_bwd_add": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gfdn_exp_contract_mfma": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "gfdn_weighted_sums": (c_int, [_P, c_int, _P, _P, c_float, _P, c_float, c_int, _P, _P]),
@@ -149,6 +149,7 @@ SIGNATURES = {
     "gfdn_irfft_odd_stages": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "gfdn_irfft_pow2_work_bytes": (c_size_t, [c_int, c_int]),
     "gfdn_irfft_pow2_fwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_pow2_fwd_band": (c_int, [c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "gfdn_irfft_pow2_bwd": (c_int, [c_int, _P, c_int, c_int, _P, c_int, _P, _P]),
     "gfdn_rownorm_fwd": (c_int, [_P, c_int, c_int, c_float, _P, _P]),
     "gfdn_rownorm_bwd": (c_int, [_P, c_int, c_int, c_float, _P, _P, _P]),

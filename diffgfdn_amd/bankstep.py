@@ -660,7 +660,8 @@ class FusedBankStep:
                     torch.cuda.current_stream().wait_event(ev['norm'])      # for its own event is asking for trouble)
                 if late8:
                     grec_sub_, loss_g_ = ops.tfp_colorless(Xsub[:nb * G], Xsub[nb * G:], tfp[0], n, delays, scale,
-                                                           cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world)
+                                                           cfg.use_asym_spectral_loss, cfg.spectral_loss_weight * inv_world,
+                                                           T=tfp[2])
                 elif big:
                     torch.cuda.current_stream().wait_event(ev_ts)
                     grec_sub_, loss_g_ = ops.tf8_colorless(gridK.turns, coef_sub, delays, n, c, scale,
@@ -750,7 +751,7 @@ class FusedBankStep:
                 gH_rec, rg_rec = gH, rgain
             if late8:
                 grec = ops.tfp_compose_bwd(tfp[0], nb, G, n, delays, Ku, tfp[1], gH_rec, filt, Ts, Dinv8, tscale=scale,
-                                           gain_fold=gfold)
+                                           gain_fold=gfold, T=tfp[2])
             elif big:
                 # (the linear step's adjoint runs on the grid of the forward pass: its saved T' and 1 / Q come back)
                 grec = ops.tf8_compose_bwd(gridU.turns, coef, delays, n, c, scale, rg_rec, gH_rec, filt, nb,

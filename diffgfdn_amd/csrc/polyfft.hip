@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void k_pf_colorless(const float2* __restrict__
 }
 
 extern "C" int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int ldx, int nfft, int nblk, int nper,
-                                  const float* delays, const float* scale, int asym, float gscale, float* UV_c64, float* x,
-                                  int ldt, void* work, float* part, float* lossp, float* loss, void* stream) {
+                                  const float* delays, const float* scale, int asym, float gscale, int T, float* UV_c64,
+                                  float* x, int ldt, void* work, float* part, float* lossp, float* loss, void* stream) {
   if (!Xq_c64 || !Xp_c64 || !delays || !UV_c64 || !x || !work || !part || !lossp || !loss || nblk <= 0 || nper <= 0 ||
       nfft < 16 || (nfft & (nfft - 1)) || ldx < nfft / 2 + 1 || ldt < nfft)
     return GFDN_E_BADARG;
@@ -219,7 +219,8 @@ extern "C" int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int 
   hipLaunchKernelGGL(k_pf_colorless, dim3(PF_PARTS, nblk), dim3(256), 0, s, (const float2*)Xq_c64, (const float2*)Xp_c64, ldx, K,
                      nblk, scale, asym, gscale, (float2*)UV_c64, lossp);
   GFDN_LAUNCH_CHECK();
-  int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
+  if (T <= 0 || T > nfft) return GFDN_E_BADARG;
+  int rc = gfdn_irfft_pow2_fwd_band(nfft, UV_c64, ldx, K, 2 * nblk, x, ldt, T, work, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(1 << pf_bits(nper)), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
   GFDN_LAUNCH_CHECK();
@@ -235,10 +236,10 @@ __global__ __launch_bounds__(256) void k_pf_bwd_spectra(const float2* __restrict
                                                         int ldf, const float2* __restrict__ Tnat,
                                                         const float2* __restrict__ Dnat, int G, int Ku, int K,
                                                         const int* __restrict__ slot_of_bin, int nblk,
-                                                        const float* __restrict__ tscale, int fold,
+                                                        const float* __restrict__ tscale, int fold, int kfill,
                                                         float2* __restrict__ UV, int ldx) {
   const int blk = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
+  if (k >= kfill) return;               // (kfill = Ku where the inverse transform skips the bins above, else K: zeros there)
   float2 u = make_float2(0.f, 0.f), v = u;
   if (k < Ku) {
     const int band = blk / G;
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(256) void k_pf_bwd_spectra(const float2* __restrict
 
 extern "C" int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const float* delays, int Ku, const int* slot_of_bin,
                                     const float* gH_c64, int ldh, const float* filt_c64, int ldf, const float* Tnat_c64,
-                                    const float* Dnat_c64, const float* tscale, int gain_fold, float* UV_c64, int ldx,
-                                    float* x, int ldt, void* work, float* part, void* stream) {
+                                    const float* Dnat_c64, const float* tscale, int gain_fold, int T, float* UV_c64,
+                                    int ldx, float* x, int ldt, void* work, float* part, void* stream) {
   if (!delays || !slot_of_bin || !gH_c64 || !Tnat_c64 || !Dnat_c64 || !UV_c64 || !x || !work || !part || nbands <= 0 || G <= 0 ||
       nper <= 0 || nfft < 16 || (nfft & (nfft - 1)) || Ku <= 0 || Ku > nfft / 2 + 1 || ldh < Ku || (filt_c64 && ldf < Ku) ||
       ldx < nfft / 2 + 1 || ldt < nfft || (gain_fold && !tscale))
@@ -273,11 +274,16 @@ extern "C" int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const
   if (nper > 8) return GFDN_E_UNSUPPORTED;          // (the records of csrc/blocktf8.hip: 256 subsets)
   hipStream_t s = (hipStream_t)stream;
   const int K = nfft / 2 + 1, nblk = nbands * G;
-  hipLaunchKernelGGL(k_pf_bwd_spectra, dim3((K + 255) / 256, nblk), dim3(256), 0, s, (const float2*)gH_c64, ldh,
+  if (T <= 0 || T > nfft) return GFDN_E_BADARG;
+  // (nfft = 131 072: the inverse transform's first pass does not read the bins from Ku on and its last pass stores the T
+  // samples the gather reads; other lengths run the whole transform on a zero-filled upper band)
+  const bool band = nfft == 131072;
+  const int kfill = band ? Ku : K;
+  hipLaunchKernelGGL(k_pf_bwd_spectra, dim3((kfill + 255) / 256, nblk), dim3(256), 0, s, (const float2*)gH_c64, ldh,
                      (const float2*)filt_c64, ldf, (const float2*)Tnat_c64, (const float2*)Dnat_c64, G, Ku, K, slot_of_bin, nblk,
-                     tscale, gain_fold ? 1 : 0, (float2*)UV_c64, ldx);
+                     tscale, gain_fold ? 1 : 0, kfill, (float2*)UV_c64, ldx);
   GFDN_LAUNCH_CHECK();
-  int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
+  int rc = gfdn_irfft_pow2_fwd_band(nfft, UV_c64, ldx, band ? Ku : K, 2 * nblk, x, ldt, T, work, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(1 << pf_bits(nper)), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
   GFDN_LAUNCH_CHECK();
@@ -322,7 +328,7 @@ extern "C" int gfdn_tfp_ratio_fwd(const float* Xq_c64, const float* Xp_c64, int 
 }
 
 extern "C" int gfdn_tfp_ratio_bwd(int nfft, int nblk, int nper, int nsub, const float* delays, const float* gT_c64, int ldg,
-                                  const float* T_c64, const float* Dinv_c64, float* UV_c64, int ldx, float* x, int ldt,
+                                  const float* T_c64, const float* Dinv_c64, int T, float* UV_c64, int ldx, float* x, int ldt,
                                   void* work, float* part, void* stream) {
   if (!delays || !gT_c64 || !T_c64 || !Dinv_c64 || !UV_c64 || !x || !work || !part || nblk <= 0 || nper <= 0 || nfft < 16 ||
       (nfft & (nfft - 1)) || ldg < nfft / 2 + 1 || ldx < nfft / 2 + 1 || ldt < nfft)
@@ -333,7 +339,8 @@ extern "C" int gfdn_tfp_ratio_bwd(int nfft, int nblk, int nper, int nsub, const 
   hipLaunchKernelGGL(k_pf_ratio_bwd, dim3((K + 255) / 256, nblk), dim3(256), 0, s, (const float2*)gT_c64, ldg,
                      (const float2*)T_c64, (const float2*)Dinv_c64, K, nblk, (float2*)UV_c64, ldx);
   GFDN_LAUNCH_CHECK();
-  int rc = gfdn_irfft_pow2_fwd(nfft, UV_c64, ldx, 2 * nblk, x, ldt, work, stream);
+  if (T <= 0 || T > nfft) return GFDN_E_BADARG;
+  int rc = gfdn_irfft_pow2_fwd_band(nfft, UV_c64, ldx, K, 2 * nblk, x, ldt, T, work, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pf_gather, dim3(nblk), dim3(nsub), 0, s, (const float*)x, ldt, delays, nblk, nper, nfft, part);
   GFDN_LAUNCH_CHECK();

@@ -291,7 +291,9 @@ __device__ __forceinline__ bool pw_item_map(int batch, int& tile, int& b) {
 static int pw_grid(int batch) { return ((batch + 7) / 8) * 8 * 16; }
 
 // inverse pass A: columns k1 = c0 + cc, Z formed on load, inverse transform over k2, twiddle e^(+2 pi i n2 k1 / m), work[n2][k1]
-__global__ __launch_bounds__(256) void k_pw_inv_a(const float2* __restrict__ X, int ldx, float2* __restrict__ work, int batch) {
+// kvalid: bins k >= kvalid count as zero and are not read (a spectrum that ends below the Nyquist bin: csrc/polyfft.hip)
+__global__ __launch_bounds__(256) void k_pw_inv_a(const float2* __restrict__ X, int ldx, float2* __restrict__ work, int batch,
+                                                  int kvalid) {
   constexpr int m = 65536, n = 131072;
   float2* buf = dyn_lds;
   int tile, b;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void k_pw_inv_a(const float2* __restrict__ X, 
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int k = k1 + 256 * (r + 16 * j);
-    float2 x = Xb[k], bc = Xb[m - k];
+    float2 x = k < kvalid ? Xb[k] : make_float2(0.f, 0.f), bc = m - k < kvalid ? Xb[m - k] : make_float2(0.f, 0.f);
     bc.y = -bc.y;
     if (k == 0) { x.y = 0.f; bc.y = 0.f; }                // irfft ignores Im X[0], Im X[n/2]
     const float2 e = cadd(x, bc);
@@ -318,7 +320,9 @@ __global__ __launch_bounds__(256) void k_pw_inv_a(const float2* __restrict__ X, 
   for (int s_ = 0; s_ < 16; ++s_) wk[(size_t)(r + 16 * s_) * 256] = a[s_];
 }
 // inverse pass B: rows n2 = r0 + rr, inverse transform over k1, (x[2j], x[2j+1]) = z[j] / n with j = n1 256 + n2
-__global__ __launch_bounds__(256) void k_pw_inv_b(const float2* __restrict__ work, float* __restrict__ x, int ldo, int batch) {
+// tout: only the samples t < tout are stored (a caller that gathers from the head of the signal)
+__global__ __launch_bounds__(256) void k_pw_inv_b(const float2* __restrict__ work, float* __restrict__ x, int ldo, int batch,
+                                                  int tout) {
   constexpr int m = 65536, n = 131072;
   float2* buf = dyn_lds;
   int tile, b;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256) void k_pw_inv_b(const float2* __restrict__ wor
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int n1 = nlo + 16 * i;
-    xb[(size_t)n1 * 256] = buf[n1 * PW_TP + (threadIdx.x & 15)];
+    if (n1 * 512 < tout) xb[(size_t)n1 * 256] = buf[n1 * PW_TP + (threadIdx.x & 15)];      // (samples 2 (n1 256 + n2), + 1)
   }
 }
 // forward pass A: columns n2 = c0 + cc, z[j] = (x[2j], x[2j+1]) (zero beyond T), transform over n1, twiddle, work[k1][n2]
@@ -426,8 +430,22 @@ extern "C" size_t gfdn_irfft_pow2_work_bytes(int n, int batch) {
   return (size_t)batch * n * sizeof(float2);       // (the half-length transform uses the first half)
 }
 
+static int p2_inverse_real(int n, const float* X, int ldx, int batch, float* x, int ldo, void* work, void* stream, int kvalid,
+                           int tout);
 extern "C" int gfdn_irfft_pow2_fwd(int n, const float* X, int ldx, int batch, float* x, int ldo,
                                    void* work, void* stream) {
+  return p2_inverse_real(n, X, ldx, batch, x, ldo, work, stream, n / 2 + 1, n);
+}
+// ... of spectra that vanish from bin kvalid on (those bins are not read: they may be uninitialised), storing the samples
+// t < tout only (rounded up to 512; the rest of x is left as it is).  n = 131 072: the register-resident passes skip the
+// loads / stores; other lengths run the full transform (the limits are then hints).
+extern "C" int gfdn_irfft_pow2_fwd_band(int n, const float* X, int ldx, int kvalid, int batch, float* x, int ldo, int tout,
+                                        void* work, void* stream) {
+  if (kvalid <= 0 || kvalid > n / 2 + 1 || tout <= 0 || tout > n) return GFDN_E_BADARG;
+  return p2_inverse_real(n, X, ldx, batch, x, ldo, work, stream, kvalid, tout);
+}
+static int p2_inverse_real(int n, const float* X, int ldx, int batch, float* x, int ldo, void* work, void* stream, int kvalid,
+                           int tout) {
   if (!X || !x || !work || n < 16 || (n & (n - 1)) || batch <= 0) return GFDN_E_BADARG;
   if (ldx < n / 2 + 1 || ldo < n) return GFDN_E_BADARG;
   P2Geom g = p2_geom(n);
@@ -435,9 +453,10 @@ extern "C" int gfdn_irfft_pow2_fwd(int n, const float* X, int ldx, int batch, fl
   hipStream_t s = (hipStream_t)stream;
   if (pw_ok(g) && (ldo & 1) == 0) {
     hipLaunchKernelGGL(k_pw_inv_a, dim3(pw_grid(batch)), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)X, ldx, (float2*)work,
-                       batch);
+                       batch, kvalid);
     GFDN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pw_inv_b, dim3(pw_grid(batch)), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)work, x, ldo, batch);
+    hipLaunchKernelGGL(k_pw_inv_b, dim3(pw_grid(batch)), dim3(256), PW_LDS * sizeof(float2), s, (const float2*)work, x, ldo, batch,
+                       tout);
     GFDN_LAUNCH_CHECK();
     return 0;
   }

@@ -282,14 +282,14 @@ class SubFdnTransforms(torch.autograd.Function):
         nblk = M.shape[0]
         S, Dinv = ops.tfp_ratio_fwd(X[:nblk], X[nblk:])
         ctx.save_for_backward(M, b, c, delays, S, Dinv)
-        ctx.meta = (nper, nfft)
+        ctx.meta = (nper, nfft, T_seq)
         return S
 
     @staticmethod
     def backward(ctx, gS):
         M, b, c, delays, S, Dinv = ctx.saved_tensors
-        nper, nfft = ctx.meta
-        part = ops.tfp_ratio_bwd(nfft, nper, delays, gS, S, Dinv)
+        nper, nfft, T_seq = ctx.meta
+        part = ops.tfp_ratio_bwd(nfft, nper, delays, gS, S, Dinv, T_seq=T_seq)
         gA, gb, gc = ops.tf9_rec_grads(M, None, part, b, c)
         return gA.to(M.dtype).reshape(M.shape), gb.to(b.dtype).reshape(b.shape), gc.to(c.dtype).reshape(c.shape), None, None, \
             None, None

@@ -1029,8 +1029,9 @@ def tfp_energy(Xq, Xp, nper: int, b, c, want_energy: bool = False, gains=None, G
     return (energy, scale) if gains is None else (energy, scale, gs)
 
 
-def tfp_colorless(Xq, Xp, nfft: int, nper: int, delays, scale, asym: bool, gscale: float):
-    """tf8_colorless on the transformed sequences -> (part (nblk, 512, 1) gradient records, loss (nblk,))."""
+def tfp_colorless(Xq, Xp, nfft: int, nper: int, delays, scale, asym: bool, gscale: float, T: Optional[int] = None):
+    """tf8_colorless on the transformed sequences -> (part (nblk, 512, 1) gradient records, loss (nblk,)).  ``T``: the
+    samples per sequence of tfp_forward (tfp_plan): what the gather reads of the inverse transforms (default: all)."""
     _need_gpu(Xq, Xp, delays)
     nblk, K = Xq.shape
     if K != nfft // 2 + 1 or Xq.stride(0) != Xp.stride(0):
@@ -1044,13 +1045,14 @@ def tfp_colorless(Xq, Xp, nfft: int, nper: int, delays, scale, asym: bool, gscal
     lossp = torch.empty(nblk * lib.gfdn_tfp_parts(), dtype=_f32, device=dev)
     loss = torch.empty(nblk, dtype=_f32, device=dev)
     _lib.check(lib.gfdn_tfp_colorless(_p(Xq), _p(Xp), Xq.stride(0), nfft, nblk, nper, _p(_f(delays)),
-                                      _p(None if scale is None else _f(scale)), int(asym), float(gscale), _p(UV), _p(x), nfft,
-                                      _p(work), _p(part), _p(lossp), _p(loss), _stream()), "gfdn_tfp_colorless")
+                                      _p(None if scale is None else _f(scale)), int(asym), float(gscale),
+                                      int(nfft if T is None else T), _p(UV), _p(x), nfft, _p(work), _p(part), _p(lossp), _p(loss),
+                                      _stream()), "gfdn_tfp_colorless")
     return part, loss
 
 
 def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, slot_of_bin, gH, filt, Tnat, Dnat, tscale=None,
-                    gain_fold: bool = False):
+                    gain_fold: bool = False, T: Optional[int] = None):
     """Gradient records (nbands * G, 512, 1) of the damped blocks from gH (nbands * G, >= Ku) = dL/d(T'_g filt) on the slot
     order (the linear step's adjoint transform output); Tnat, Dnat (nbands * G, Ku): tf8_tsave's Ts, Dinv on the bins
     0 .. Ku - 1 in bin order (``hslot``); ``tscale``: Tnat holds the unscaled functions, T' = tscale Tnat."""
@@ -1071,7 +1073,8 @@ def tfp_compose_bwd(nfft: int, nbands: int, G: int, nper: int, delays, Ku: int, 
     part = torch.empty((nblk, 512, 1), dtype=_f32, device=dev)
     _lib.check(lib.gfdn_tfp_compose_bwd(nfft, nbands, G, nper, _p(_f(delays)), Ku, _p(slot_of_bin), _p(gH), gH.stride(0), _p(filt),
                                         Ku, _p(Tnat), _p(Dnat), _p(None if tscale is None else _f(tscale)),
-                                        int(bool(gain_fold)), _p(UV), K, _p(x), nfft, _p(work), _p(part), _stream()),
+                                        int(bool(gain_fold)), int(nfft if T is None else T), _p(UV), K, _p(x), nfft, _p(work),
+                                        _p(part), _stream()),
                "gfdn_tfp_compose_bwd")
     return part
 
@@ -1120,7 +1123,7 @@ def tfp_ratio_fwd(Xq, Xp):
     return T, D
 
 
-def tfp_ratio_bwd(nfft: int, nper: int, delays, gT, T, Dinv, nsub: int = 512):
+def tfp_ratio_bwd(nfft: int, nper: int, delays, gT, T, Dinv, nsub: int = 512, T_seq: Optional[int] = None):
     """Gradient records (nblk, 2 nsub) (nsub = 256: subsets of tf8_coefs' records, 512: of tf9_coefs') of T = P / Q from gT =
     dL/dT (nblk, K), dL = sum_k Re(conj(gT_k) dT_k): two inverse real transforms and a gather (csrc/polyfft.hip)."""
     _need_gpu(gT, T, Dinv, delays)
@@ -1134,7 +1137,8 @@ def tfp_ratio_bwd(nfft: int, nper: int, delays, gT, T, Dinv, nsub: int = 512):
     x = torch.empty((2 * nblk, nfft), dtype=_f32, device=dev)
     work = _work(lib.gfdn_irfft_pow2_work_bytes(nfft, 2 * nblk), dev)
     part = torch.empty((nblk, 2 * nsub), dtype=_f32, device=dev)
-    _lib.check(lib.gfdn_tfp_ratio_bwd(nfft, nblk, nper, int(nsub), _p(_f(delays)), _p(gT), K, _p(T), _p(Dinv), _p(UV), K, _p(x), nfft,
+    _lib.check(lib.gfdn_tfp_ratio_bwd(nfft, nblk, nper, int(nsub), _p(_f(delays)), _p(gT), K, _p(T), _p(Dinv),
+                                      int(nfft if T_seq is None else T_seq), _p(UV), K, _p(x), nfft,
                                       _p(work), _p(part), _stream()), "gfdn_tfp_ratio_bwd")
     return part
 

@@ -495,7 +495,10 @@ int gfdn_tf9_rec_grads(const float* A, const float* inv_gamma, const float* grec
 int gfdn_tfp_ratio_fwd(const float* Xq_c64, const float* Xp_c64, int ldx, int K, int nblk, float* T_c64, float* Dinv_c64,
                        void* stream);
 int gfdn_tfp_ratio_bwd(int nfft, int nblk, int nper, int nsub, const float* delays, const float* gT_c64, int ldg, const float* T_c64,
-                       const float* Dinv_c64, float* UV_c64, int ldx, float* x, int ldt, void* work, float* part, void* stream);
+                       const float* Dinv_c64, int T, float* UV_c64, int ldx, float* x, int ldt, void* work, float* part,
+                       void* stream);
+/* T (gfdn_tfp_colorless, _compose_bwd, _ratio_bwd): the samples per sequence of gfdn_tfp_forward -- the gathers read the inverse
+ * transforms' first T samples only, and at nfft = 131 072 only those are stored (gfdn_irfft_pow2_fwd_band).                 */
 int gfdn_tfp_parts(void);
 int gfdn_tfp_forward(int nfft, int nblk, int nper, int nsub, const float* coef, const float* delays, const float* c, int T,
                      float* seq, float* X_c64, int ldx, void* work, void* stream);
@@ -503,12 +506,12 @@ int gfdn_tfp_energy(const float* Xq_c64, const float* Xp_c64, int ldx, int K, in
                     float* energy, float* scale, void* work, const float* gains, float* gains_scaled, int Bper, int G,
                     void* stream);
 int gfdn_tfp_colorless(const float* Xq_c64, const float* Xp_c64, int ldx, int nfft, int nblk, int nper, const float* delays,
-                       const float* scale, int asym, float gscale, float* UV_c64, float* x, int ldt, void* work, float* part,
-                       float* lossp, float* loss, void* stream);
+                       const float* scale, int asym, float gscale, int T, float* UV_c64, float* x, int ldt, void* work,
+                       float* part, float* lossp, float* loss, void* stream);
 int gfdn_tfp_compose_bwd(int nfft, int nbands, int G, int nper, const float* delays, int Ku, const int* slot_of_bin,
                          const float* gH_c64, int ldh, const float* filt_c64, int ldf, const float* Tnat_c64,
-                         const float* Dnat_c64, const float* tscale, int gain_fold, float* UV_c64, int ldx, float* x, int ldt,
-                         void* work, float* part, void* stream);
+                         const float* Dnat_c64, const float* tscale, int gain_fold, int T, float* UV_c64, int ldx, float* x,
+                         int ldt, void* work, float* part, void* stream);
 
 /* ---- measurement kernel for BASELINE.json configs[4] ("fp32 vs bf16 feedback-matmul on MFMA") ------------------
  * The reference's dense formulation (feedback_loop.py:389-391 explicit resolvent P (K, N, N); model.py:615-619
@@ -754,6 +757,11 @@ int gfdn_rownorm_bwd(const float* w, int rows, int len, float eps, const float* 
 size_t gfdn_irfft_pow2_work_bytes(int n, int batch);
 int gfdn_irfft_pow2_fwd(int n, const float* X_c64, int ldx, int batch, float* x, int ldo,
                         void* work, void* stream);
+/* ... of spectra that vanish from bin kvalid on (those bins are NOT read: they may be uninitialised), storing only the samples
+ * t < tout (rounded up to a multiple of 512; the rest of x keeps what it held).  n = 131 072 skips the loads / stores; other
+ * lengths run the whole transform and READ every bin (the caller zero-fills the upper band there).                           */
+int gfdn_irfft_pow2_fwd_band(int n, const float* X_c64, int ldx, int kvalid, int batch, float* x, int ldo, int tout, void* work,
+                             void* stream);
 int gfdn_irfft_pow2_bwd(int n, const float* gx, int ldo, int batch, float* gX_c64, int ldx,
                         void* work, void* stream);
 /* The adjoint for a gradient that vanishes outside the samples [t_lo, t_hi) (the EDC window of losses.py:344-346): nothing

@@ -107,7 +107,8 @@ def test_energy_and_colorless_equal_matrix_core_passes(nfft, nper):
     for asym in (False, True):
         part_ref, loss_ref = ops.tf8_colorless(s['turns'], s['coef_sub'], s['delays'], nper, c1, sc_ref, asym, 0.7,
                                                dturn=s['dturn'])
-        part_got, loss_got = ops.tfp_colorless(Xq, Xp, nfft, nper, s['delays'], sc_ref, asym, 0.7)
+        # (asym: the gather's T samples only; symmetric: the whole signals)
+        part_got, loss_got = ops.tfp_colorless(Xq, Xp, nfft, nper, s['delays'], sc_ref, asym, 0.7, T=T if asym else None)
         torch.testing.assert_close(loss_got, loss_ref, rtol=3e-4, atol=1e-7)
         ref = part_ref.sum(-1)
         got = part_got.sum(-1)
@@ -155,7 +156,8 @@ def test_output_stage_in_slot_order_and_adjoint_by_transforms(nfft, nper):
     eye = torch.eye(G, device=dev).repeat(nbands, 1)
     part_ref = ops.tf8_compose_bwd(tslot, s['coef'], s['delays'], nper, c_new, scale, eye, gH, filt, nbands,
                                    saved=(Ts_ref, Dinv_ref)).sum(-1)
-    part_got = ops.tfp_compose_bwd(nfft, nbands, G, nper, s['delays'], Ku, col, gH, filt, Tn, Dn, tscale=scale).sum(-1)
+    part_got = ops.tfp_compose_bwd(nfft, nbands, G, nper, s['delays'], Ku, col, gH, filt, Tn, Dn, tscale=scale,
+                                   T=ops.tfp_plan(s['delays'], nper, nfft)).sum(-1)
     tol = 2e-4 * part_ref.abs().max()
     assert (part_got - part_ref).abs().max() < tol, ((part_got - part_ref).abs().max(), tol)
     # the scale in the receiver gains: s dL/dT' comes in
