@@ -13,7 +13,7 @@ mk() { # name file sed-expr
   /opt/rocm/bin/hipcc $FLAGS -c _v_$1.hip -o /tmp/v_$1.o
   rm -f _v_$1.hip
   OBJS=""
-  for f in solve ortho fft pow2 losses optim mlp svf blocktf mfma_exp; do
+  for f in $(sed -n 's/^SRCS *:= *//p' Makefile | sed 's/\.hip//g'); do
     if [ "$f.hip" = "$2" ]; then OBJS="$OBJS /tmp/v_$1.o"; else OBJS="$OBJS $f.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT/libv_$1.so
