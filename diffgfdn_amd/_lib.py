@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffgfdn_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P = c_void_p
 
@@ -94,6 +94,11 @@ SIGNATURES = {
     "gfdn_edc_lin_one": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P,
                                  c_int, c_float, c_float, _P, _P, c_int, _P, c_int, c_int, _P]),
     "gfdn_lin_merge_slots": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "gfdn_f64_fft_work_bytes": (c_size_t, [c_int, c_int]),
+    "gfdn_irfft_odd_f64_length": (c_int, [c_int]),
+    "gfdn_rfft_pow2_f64": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "gfdn_irfft_odd_f64_plan": (c_int, [c_int, _P, _P, _P]),
+    "gfdn_irfft_odd_f64": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "gfdn_lin_gamma_win": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int,
                                    _P]),
     "gfdn_tf_gain_grad_work_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -187,6 +187,8 @@ class BandStackedDataset:
         self.norm_listener_position = torch.cat([d.norm_listener_position for d in datasets])
         self.listener_positions = torch.cat([d.listener_positions for d in datasets])
         self.early_rir_mag_response = torch.cat([d.early_rir_mag_response for d in datasets])
+        et = [getattr(d, 'early_rir_time', None) for d in datasets]
+        self.early_rir_time = torch.cat(et) if all(t is not None and t.shape[1] == et[0].shape[1] for t in et) else None
         self.rir_mag_response = ds0.rir_mag_response          # shape carrier (K); targets come from the stores
         self.source_position = ds0.source_position
         self.edr_store = self.edc_store = None
@@ -245,13 +247,17 @@ class BandStackedDataset:
             self._slot_cache = (zs, out)
         return self._slot_cache
 
+    # the direct-path store of the linear step built with float64 transforms (csrc/fft64.hip); False: the float32 transforms
+    # of csrc/fft.hip (rounds 4-5; the cross-check of tests/test_gpu_round6.py)
+    direct_time_f64 = True
+
     def direct_time(self, filt: Optional[torch.Tensor], n: int, chunk: int = 128) -> torch.Tensor:
         """xd (bands*R, n) float32: every receiver's direct path through its band's filter in the TIME domain,
         xd[band R + r] = irfft(early[r] filt_band, n) -- the part of x = irfft((sum_g gain_g T_g + d) filt, n) (reference
         model.py:619, trainer.py:459, losses.py:207-213 / :442-445) that no parameter touches.  The transform is linear,
         so the step adds the band's G transformed group responses to these rows instead of transforming every receiver's
         spectrum (csrc/linear.hip).  A constant of the dataset like the decay targets: built once, cached per filter."""
-        key = (None if filt is None else (filt.data_ptr(), tuple(filt.shape)), int(n))
+        key = (None if filt is None else (filt.data_ptr(), tuple(filt.shape)), int(n), bool(self.direct_time_f64))
         cache = getattr(self, '_direct_time', None)
         if cache is None or cache[0] != key:
             E = self.early_rir_mag_response
@@ -259,7 +265,23 @@ class BandStackedDataset:
             if E.shape[0] != self.num_bands * R or E.shape[1] < Ku:
                 raise RuntimeError("direct_time: the early-response store does not match bands x receivers")
             out = torch.empty((E.shape[0], n), dtype=torch.float32, device=E.device)
+            # Round 6: the store in FLOAT64, rounded to float32 once.  The reference transforms complex128 spectra
+            # (losses.py:442-445, model.py:618-619) of a float64 rfft (dataloader.py:250); a float32 transform leaves 3e-7 of a
+            # row's largest sample on every sample, which is percent-level on the last tenth of the EDC window and reached
+            # dL/dM through the dB stages.  Built once per dataset: csrc/fft64.hip, speed irrelevant.
+            f64 = self.direct_time_f64 and n >= 3 and (n & 1)
+            Et = self.early_rir_time if f64 else None
+            nfft = 2 * (E.shape[1] - 1)
+            if Et is not None and (nfft < 2 or nfft & (nfft - 1) or Et.shape[0] != E.shape[0] or Et.shape[1] > nfft):
+                Et = None                 # (no time-domain store that matches: the complex64 spectra, transformed in float64)
             for q in range(self.num_bands):
+                if f64:
+                    f = None if filt is None else filt[q, :Ku].to(torch.complex128).contiguous()
+                    for r0 in range(q * R, (q + 1) * R, 32):
+                        r1 = min(r0 + 32, (q + 1) * R)
+                        X = ops.rfft_pow2_f64(Et[r0:r1], nfft, Ku) if Et is not None else E[r0:r1, :Ku].to(torch.complex128)
+                        out[r0:r1] = ops.irfft_odd_f64(X, n, filt=f)
+                    continue
                 f = None if filt is None else filt[q, :Ku].to(torch.complex64)
                 for r0 in range(q * R, (q + 1) * R, chunk):
                     r1 = min(r0 + chunk, (q + 1) * R)

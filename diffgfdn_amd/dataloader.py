@@ -81,6 +81,9 @@ class RoomDataset:
         self.rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
         self.early_rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
         self.late_rir_mag_response = torch.empty((R, K), dtype=torch.complex64, device=dev)
+        # the early responses in the TIME domain, float64 (5 MB at 838 receivers): what the band bank's float64 build of its
+        # direct-path store starts from (BandStackedDataset.direct_time; the reference's rfft runs in float64, :250)
+        self.early_rir_time = torch.empty((R, mix), dtype=torch.float64, device=dev)
         fade_out = torch.tensor(w[win // 2:], device=dev)
         fade_in = torch.tensor(w[:win // 2], device=dev)
         rfft = lambda t: ops.rfft_pow2(t.to(torch.float32).contiguous(), nfft)
@@ -93,6 +96,7 @@ class RoomDataset:
             blk[:, mix:mix + win // 2] *= fade_in
             self.late_rir_mag_response[r0:r0 + chunk] = rfft(blk[:, mix:])
             self.early_rir_mag_response[r0:r0 + chunk] = rfft(blk[:, :mix])
+            self.early_rir_time[r0:r0 + chunk] = blk[:, :mix]
             if isinstance(self.rirs, np.ndarray):
                 self.rirs[r0:r0 + chunk] = blk.cpu().numpy()     # keep the in-place side effect
 
@@ -111,6 +115,7 @@ class MultiRIRDataset(torch.utils.data.Dataset):
         self.rir_mag_response = room_data.rir_mag_response
         self.late_rir_mag_response = room_data.late_rir_mag_response
         self.early_rir_mag_response = room_data.early_rir_mag_response
+        self.early_rir_time = getattr(room_data, 'early_rir_time', None)       # (R, mixing time) float64, or None
         self.edr_store = None     # (T_db (R,frames,F), sum_abs (R,)) once precomputed
         self.edc_store = None     # ((start, length), T_db (R,length))
 
@@ -119,6 +124,19 @@ class MultiRIRDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx: int):
         return int(idx)
+
+    def early_response_c128(self, idx) -> torch.Tensor:
+        """The early responses of the receivers ``idx`` as the reference holds them: complex128 rfft of the float64 early
+        RIRs (dataloader.py:250, :300-325) -- from the time-domain store through the float64 transform of csrc/fft64.hip
+        (the resident ``early_rir_mag_response`` is its complex64 rounding of a float32 transform: 1e-6 of a row's rms).
+        Falls back to that store where the dataset was not built from time signals."""
+        K = self.z_values.shape[-1]
+        nfft = 2 * (K - 1)
+        Et = self.early_rir_time
+        if Et is None or nfft < 2 or nfft & (nfft - 1) or Et.shape[1] > nfft:
+            return self.early_rir_mag_response[idx].to(torch.complex128)
+        idx = torch.as_tensor(idx, device=Et.device).reshape(-1)
+        return ops.rfft_pow2_f64(Et[idx].contiguous(), nfft, K)
 
     # model-independent loss targets for the whole grid (SURVEY §8d "precomputed once")
     def precompute_decay_targets(self, win: int, edc_start: int, edc_len: int, chunk: int = 64):

@@ -1894,6 +1894,60 @@ def rfft_pow2(x, n: int) -> torch.Tensor:
     return X
 
 
+def rfft_pow2_f64(x, n: int, kout: Optional[int] = None) -> torch.Tensor:
+    """x (batch, T <= n) float64 -> the first ``kout`` (default n / 2 + 1) bins of rfft(x, n) as complex128 (csrc/fft64.hip:
+    float64 radix-2 passes -- dataset constants only, speed is not the point)."""
+    _need_gpu(x)
+    if x.dtype != torch.float64 or x.dim() != 2 or n < 2 or n & (n - 1):
+        raise RuntimeError("rfft_pow2_f64: a (batch, T) float64 tensor and a power-of-two length expected")
+    x = x.contiguous()
+    batch, T = x.shape
+    kout = n // 2 + 1 if kout is None else int(kout)
+    lib = _lib.load()
+    X = torch.empty((batch, kout), dtype=torch.complex128, device=x.device)
+    work = _work(lib.gfdn_f64_fft_work_bytes(batch, n), x.device)
+    _lib.check(lib.gfdn_rfft_pow2_f64(_p(x), T, T, batch, n, _p(X), kout, _p(work), _stream()), "gfdn_rfft_pow2_f64")
+    return X
+
+
+_IRFFT64_PLANS = {}
+
+
+def irfft_odd_f64(X, n: int, filt=None, out_dtype=torch.float32, chunk: int = 32) -> torch.Tensor:
+    """X (batch, >= (n + 1) / 2) complex128 [times ``filt`` (>= (n + 1) / 2) complex128] -> irfft(., n) for an odd n, evaluated
+    in float64 (Bluestein on radix-2 double passes, csrc/fft64.hip) and rounded ONCE to ``out_dtype`` (float32 / float64).
+    For stores that are built once per dataset (BandStackedDataset.direct_time): the reference's irfft runs on complex128
+    spectra (losses.py:207-213, :442-445)."""
+    _need_gpu(X)
+    if X.dtype != torch.complex128 or X.dim() != 2 or n < 3 or not (n & 1) or X.shape[1] < (n + 1) // 2:
+        raise RuntimeError("irfft_odd_f64: a (batch, >= (n + 1) / 2) complex128 tensor and an odd length expected")
+    if filt is not None and (filt.dtype != torch.complex128 or filt.numel() < (n + 1) // 2 or not filt.is_contiguous()):
+        raise RuntimeError("irfft_odd_f64: filt must be a contiguous complex128 vector with at least (n + 1) / 2 entries")
+    if out_dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("irfft_odd_f64: float32 or float64 output")
+    X = X.contiguous()
+    lib = _lib.load()
+    M = lib.gfdn_irfft_odd_f64_length(n)
+    key = (n, str(X.device))
+    if key not in _IRFFT64_PLANS:
+        bhat = torch.empty(M, dtype=torch.complex128, device=X.device)
+        work = _work(lib.gfdn_f64_fft_work_bytes(1, M), X.device)
+        _lib.check(lib.gfdn_irfft_odd_f64_plan(n, _p(bhat), _p(work), _stream()), "gfdn_irfft_odd_f64_plan")
+        _IRFFT64_PLANS[key] = bhat
+    bhat = _IRFFT64_PLANS[key]
+    batch = X.shape[0]
+    out = torch.empty((batch, n), dtype=out_dtype, device=X.device)
+    work = _work(lib.gfdn_f64_fft_work_bytes(min(chunk, batch), M), X.device)
+    for r0 in range(0, batch, chunk):
+        r1 = min(r0 + chunk, batch)
+        o = out[r0:r1]
+        _lib.check(lib.gfdn_irfft_odd_f64(_p(X[r0:r1]), X.stride(0), _p(filt), r1 - r0, n, _p(bhat),
+                                          _p(o) if out_dtype == torch.float32 else None,
+                                          _p(o) if out_dtype == torch.float64 else None, n, _p(work), _stream()),
+                   "gfdn_irfft_odd_f64")
+    return out
+
+
 def sh_to_directional(A, H, adjoint: bool = False) -> torch.Tensor:
     """A (J,C) real, H (B,C,K) complex -> (B,J,K); adjoint maps (B,J,K) -> (B,C,K)."""
     _need_gpu(A, H)

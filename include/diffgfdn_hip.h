@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: the gfdn_tf_* block-transfer-function entry points, the transforms with the output stage folded in, the device-side
  * receiver schedule; every entry point of version 1 keeps its signature */
-#define GFDN_ABI_VERSION 7
+#define GFDN_ABI_VERSION 8
 #define GFDN_E_BADARG (-1)
 #define GFDN_E_UNSUPPORTED (-2)
 #define GFDN_MAX_BLOCK 32      /* largest dense block the per-bin solver takes        */
@@ -734,6 +734,24 @@ int gfdn_lin_gamma_win(const float* gx, int ld_g, const float* rgain, int nbands
  * different launches, merged into the adjoint pair transform's slot order                                                  */
 int gfdn_lin_merge_slots(const float* a2, const float* b2, const float* c2, int rows, int n, int ld, const int* slot_of_time,
                          float* out2, int ld_o, void* stream);
+
+/* Float64 transforms for DATASET CONSTANTS (csrc/fft64.hip, round 6): the reference's rfft runs in float64
+ * (src/diff_gfdn/dataloader.py:250, :300-325) and its irfft(H, n = K) on complex128 spectra (losses.py:207-213, :442-445);
+ * the linear step's direct-path store xd = irfft(early filt, n) is built once per dataset, so accuracy is free there.
+ *   gfdn_rfft_pow2_f64:      X (rows, kout) complex128 = the first kout bins of rfft(x[:, :len] zero-padded, nfft = 2^p)
+ *   gfdn_irfft_odd_f64_plan: bhat (M) complex128 = the chirp spectrum of Bluestein's algorithm for the odd length n,
+ *                            M = gfdn_irfft_odd_f64_length(n); work: gfdn_f64_fft_work_bytes(1, M)
+ *   gfdn_irfft_odd_f64:      out (rows, ldo) = irfft(X [filt], n) on the bins 0 .. (n - 1) / 2 of the complex128 rows X
+ *                            (pitch ldx; filt (>= (n + 1) / 2) complex128 multiplies every row; NULL: none), written as
+ *                            float32 (out32) and / or float64 (out64); work: gfdn_f64_fft_work_bytes(rows, M).
+ * Radix-2 passes through memory on double2, twiddles and chirps from exactly reduced integer phases.                        */
+size_t gfdn_f64_fft_work_bytes(int rows, int M);
+int gfdn_irfft_odd_f64_length(int n);
+int gfdn_rfft_pow2_f64(const double* x, int ldx, int len, int rows, int nfft, double* X_c128, int kout, void* work,
+                       void* stream);
+int gfdn_irfft_odd_f64_plan(int n, double* bhat_c128, void* work, void* stream);
+int gfdn_irfft_odd_f64(const double* X_c128, int ldx, const double* filt_c128, int rows, int n, const double* bhat_c128,
+                       float* out32, double* out64, int ldo, void* work, void* stream);
 
 /* Measurement hook: the same transform launched stage by stage (stages: bit 0 column pass +
  * chirp, bit 1 row pass with the chirp-spectrum product, bit 2 inverse column pass + epilogue) so

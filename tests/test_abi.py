@@ -33,7 +33,8 @@ def test_header_and_ctypes_table_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in _header_functions():
         assert hasattr(lib, name), name
-    assert lib.gfdn_abi_version() == 7
+    from diffgfdn_amd import _lib as _l
+    assert lib.gfdn_abi_version() == _l.ABI_VERSION == 8
 
 
 def test_host_side_queries(lib):

@@ -201,7 +201,7 @@ def test_bank_step_equals_band_steps_and_oracle():
         ob = {"z_values": dq.z_values.cpu(),
               "norm_listener_position": dq.norm_listener_position[idx].cpu(),
               "listener_position": dq.listener_positions[idx].cpu(),
-              "target_early_response": dq.early_rir_mag_response[idx].cpu().to(torch.complex128),
+              "target_early_response": dq.early_response_c128(idx).cpu(),
               "target_rir_response": dq.rir_mag_response[idx].cpu().to(torch.complex128)}
         otr.normalize(ob)
         ototal, oparts = otr.train_step(ob, keep)
@@ -824,7 +824,7 @@ def test_bank_with_distinct_decay_windows_equals_band_steps_and_oracle(fused):
         ob = {"z_values": dq.z_values.cpu(),
               "norm_listener_position": dq.norm_listener_position[idx].cpu(),
               "listener_position": dq.listener_positions[idx].cpu(),
-              "target_early_response": dq.early_rir_mag_response[idx].cpu().to(torch.complex128),
+              "target_early_response": dq.early_response_c128(idx).cpu(),
               "target_rir_response": dq.rir_mag_response[idx].cpu().to(torch.complex128)}
         otr.normalize(ob)
         _, oparts = otr.train_step(ob, keeps[q])

@@ -29,7 +29,7 @@ DELAYS = [[641, 701, 809, 907, 1009, 1103, 1201, 1301, 1399, 1409, 1423, 1427, 1
 LOSS_TOL, GRAD_TOL = 1e-4, 2e-3
 # dL/dM of the timed bench shape per lines-per-group: what is measured (round 4: 3.6e-4 at N = 16, 7.9e-4 at N = 32, the float32
 # transforms upstream of the records are the floor -- DESIGN.md section 2 (iv), profiles/r04_grad_stage_probe.txt) plus margin
-GRAD_TOL_M = {4: 6e-4, 8: 1e-3}
+GRAD_TOL_M = {4: 2.7e-4, 8: 4.5e-4}        # (measured worst band 1.8e-4 / 2.9e-4 with the float64 direct-path store + 50 %)
 # BASELINE.json configs[4]: N = 32 = 4 groups x 8 lines (mutually prime delays, as DiffGFDNConfig draws them)
 DELAYS32 = [571, 593, 613, 631, 653, 673, 691, 709, 733, 751, 769, 787, 809, 827, 853, 877, 907, 929, 947, 967, 983, 1009,
             1031, 1051, 1069, 1091, 1109, 1129, 1151, 1171, 1193, 1213]
@@ -93,7 +93,7 @@ def _oracle_step(sd, q, room, ds, sel, filt_q, keep, delays=None, n_fourier=4):
     ob = {"z_values": ds.z_values.cpu(),
           "norm_listener_position": ds.norm_listener_position[idx].cpu(),
           "listener_position": ds.listener_positions[idx].cpu(),
-          "target_early_response": ds.early_rir_mag_response[idx].cpu().to(torch.complex128),
+          "target_early_response": ds.early_response_c128(idx).cpu(),
           "target_rir_response": ds.rir_mag_response[idx].cpu().to(torch.complex128)}
     otr.normalize(ob)
     _, parts = otr.train_step(ob, keep)
