@@ -60,6 +60,10 @@ SIGNATURES = {
                                                        _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "gfdn_tf_gain_chunks": (c_int, [c_int]),
     "gfdn_mlp_bwd_takes_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "gfdn_mlp_bands_sizes": (c_int, [c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "gfdn_mlp_gains_bands_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "gfdn_mlp_gains_bands_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P,
+                                         c_int, _P, _P, _P, _P]),
     "gfdn_subfdn_normalize_work_bytes": (c_size_t, [c_int]),
     "gfdn_subfdn_normalize": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gfdn_subfdn_colorless_work_bytes": (c_size_t, [c_int, c_int]),

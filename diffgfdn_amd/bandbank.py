@@ -49,7 +49,8 @@ class BandBank(nn.Module):
 
     Stacked leaves (what autograd and Adam see):
         input_gains, output_gains (bands, N);  feedback_loop_M (bands, G, n, n);
-        output_scalars_w (bands, P) -- every band's MLP parameters packed in named_parameters() order.
+        output_scalars_w (bands, P) -- every band's MLP parameters packed in named_parameters() order (bands whose networks
+        differ in size: ONE vector, band after band).
     The names keep the substrings the reference selects learning-rate groups by
     (trainer.py:157-216: 'input_gains', 'output_gains', 'output_scalars' -> io_lr, the rest -> lr)."""
 
@@ -84,21 +85,34 @@ class BandBank(nn.Module):
         self.sample_rate = n0.sample_rate
         self.use_colorless_loss = all(net.use_colorless_loss for net in nets)
         N = G * n
-        gm = n0.output_scalars
-        lin = [m for m in gm.mlp.model if isinstance(m, nn.Linear)]
-        self._mlp_cfg = (lin[0].out_features, len(lin) - 2, gm.encoder.num_fourier_features,
-                         float(gm.scaled_sigmoid.lower_limit), float(gm.scaled_sigmoid.upper_limit))
+        # every band's gain network: (neurons per layer, hidden layers).  The reference's sub-band driver sizes them per band
+        # (run_subband_training_treble.py:61-73: 1 x 8, 1 x 16, 5 x 16, 3 x 128); features and output limits are shared
+        cfgs = []
+        for net in nets:
+            gm = net.output_scalars
+            lin = [m for m in gm.mlp.model if isinstance(m, nn.Linear)]
+            if any(l.out_features != lin[0].out_features for l in lin[:-1]):
+                raise NotImplementedError("BandBank: gain networks with one width for all hidden layers")
+            cfgs.append((lin[0].out_features, len(lin) - 2, gm.encoder.num_fourier_features,
+                         float(gm.scaled_sigmoid.lower_limit), float(gm.scaled_sigmoid.upper_limit)))
+        if any(c[2:] != cfgs[0][2:] for c in cfgs):
+            raise ValueError("BandBank: the bands' gain networks must share the Fourier features and the output limits")
+        self.mixed_networks = any(c[:2] != cfgs[0][:2] for c in cfgs)
+        # (H, hidden layers, F, lo, hi): ints for a bank of equal networks, one tuple entry per band otherwise -- the
+        # kernels' wrappers (hip_ops.mlp_gains_*) take either
+        self._mlp_cfg = ((tuple(c[0] for c in cfgs), tuple(c[1] for c in cfgs)) + cfgs[0][2:]) if self.mixed_networks \
+            else cfgs[0]
         self._mlp_params = [[p for m in net.output_scalars.mlp.model for p in m.parameters()] for net in nets]
-        shapes = [tuple(p.shape) for p in self._mlp_params[0]]
-        for ps in self._mlp_params:
-            if [tuple(p.shape) for p in ps] != shapes:
-                raise ValueError("BandBank: the bands' gain networks must have the same layer sizes")
         with torch.no_grad():
             self.input_gains = nn.Parameter(torch.stack([net.input_gains.detach().reshape(N) for net in nets]))
             self.output_gains = nn.Parameter(torch.stack([net.output_gains.detach().reshape(N) for net in nets]))
             self.feedback_loop_M = nn.Parameter(torch.stack([net.feedback_loop.M.detach() for net in nets]))
-            self.output_scalars_w = nn.Parameter(torch.stack(
-                [torch.cat([p.detach().reshape(-1) for p in ps]) for ps in self._mlp_params]))
+            packed = [torch.cat([p.detach().reshape(-1) for p in ps]) for ps in self._mlp_params]
+            # equal networks: (bands, P); mixed: the bands' packed sets one after the other in ONE vector
+            self.output_scalars_w = nn.Parameter(torch.cat(packed) if self.mixed_networks else torch.stack(packed))
+            self._w_off = [0]
+            for t in packed:
+                self._w_off.append(self._w_off[-1] + t.numel())
             self.register_buffer('delays', torch.cat([net.delay_buffer.to(torch.float32) for net in nets]),
                                  persistent=False)
             self.register_buffer('inv_gamma', torch.cat(
@@ -121,10 +135,11 @@ class BandBank(nn.Module):
             net.input_gains.data = self.input_gains.data[i].view(N, 1)
             net.output_gains.data = self.output_gains.data[i].view(N, 1)
             net.feedback_loop.M.data = self.feedback_loop_M.data[i]
-            off = 0
+            off = self._w_off[i]
+            wflat = self.output_scalars_w.data.view(-1)
             for p in self._mlp_params[i]:
                 k = p.numel()
-                p.data = self.output_scalars_w.data[i, off:off + k].view(p.shape)
+                p.data = wflat[off:off + k].view(p.shape)
                 off += k
 
     def band_state_dict(self, band: int) -> Dict[str, torch.Tensor]:

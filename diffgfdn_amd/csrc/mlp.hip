@@ -41,10 +41,10 @@ __host__ __device__ static inline size_t mlp_param_count(const MlpDims& d) {
 
 extern __shared__ float mlp_lds[];
 
-__device__ __forceinline__ void mlp_encode(const MlpDims& d, const double* __restrict__ pos,
+__device__ __forceinline__ void mlp_encode(const MlpDims& d, int b, const double* __restrict__ pos,
                                            const float* __restrict__ freq_pi, float* a) {
   // dnn.py:112-124: per frequency k: [sin(f_k pi x) (3) | cos(f_k pi x) (3)], stored as float32
-  const double* p = pos + (d.rows ? (size_t)d.rows[blockIdx.x] : (size_t)blockIdx.x) * 3;
+  const double* p = pos + (d.rows ? (size_t)d.rows[b] : (size_t)b) * 3;
   for (int e = threadIdx.x; e < d.in_dim; e += blockDim.x) {
     const int k = e / 6, r = e - 6 * k;
     const double arg = (double)freq_pi[k] * p[r % 3];
@@ -52,25 +52,22 @@ __device__ __forceinline__ void mlp_encode(const MlpDims& d, const double* __res
   }
 }
 
-__global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __restrict__ pos,
-                                                   const float* __restrict__ freq_pi,
-                                                   const float* __restrict__ w,
-                                                   float* __restrict__ gains,     // (B, G)
-                                                   float* __restrict__ xhat,      // (B, nl, H)
-                                                   float* __restrict__ rstd) {    // (B, nl)
+// One receiver (item b) by a whole workgroup.  w: the band's packed parameters; xout / rout: where this receiver's saved
+// activations (nl, H) / (nl) go.
+__device__ __forceinline__ void mlp_fwd_block(const MlpDims& d, int b, const double* __restrict__ pos,
+                                              const float* __restrict__ freq_pi, const float* __restrict__ w,
+                                              float* __restrict__ gains, float* __restrict__ xout,
+                                              float* __restrict__ rout) {
   const int amax = d.in_dim > d.H ? d.in_dim : d.H;
   float* a = mlp_lds;            // current activations
   float* h = a + amax;           // pre-norm outputs
   float* red = h + d.H;          // 16 floats
-  const int b = blockIdx.x, H = d.H;
-  w += (size_t)(b / d.Bper) * mlp_param_count(d);
+  const int H = d.H;
   // small networks: ONE round of global loads brings every parameter into LDS; the layer chain then
   // never waits on memory again (it was one dependent global-load latency per layer)
   // Likewise the saved activations go to LDS first and to memory once at the end: every
   // __syncthreads() waits for ALL outstanding global stores of the wave (vmcnt covers stores on
   // gfx9), so a store inside the layer loop costs a full write round trip per barrier.
-  float* xout = xhat + (size_t)b * d.nl * H;
-  float* rout = rstd + (size_t)b * d.nl;
   float* xs = xout;
   float* rsv = rout;
   if (d.stage) {
@@ -81,7 +78,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
     xs = wl + P;
     rsv = xs + d.nl * H;
   }
-  mlp_encode(d, pos, freq_pi, a);
+  mlp_encode(d, b, pos, freq_pi, a);
   __syncthreads();
   for (int l = 0; l < d.nl; ++l) {
     const int n_in = l == 0 ? d.in_dim : H;
@@ -91,7 +88,19 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
     const float* beta = gamma + H;
     float hv = 0.f;
     const int j = threadIdx.x;
-    if (j < H) {
+    if (!d.stage) {
+      // parameters in memory (layers of 128 neurons: 266 KB per band): the waves take the neurons, the LANES the inputs --
+      // one coalesced row read per neuron (a thread per neuron walks its own row: every load touches H cache lines)
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+      for (int jj = wv; jj < H; jj += nw) {
+        float part = 0.f;
+        for (int i = lane; i < n_in; i += 64) part += W[(size_t)jj * n_in + i] * a[i];
+        part = wave_sum(part);
+        if (lane == 0) h[jj] = part + bias[jj];
+      }
+      __syncthreads();
+      if (j < H) hv = h[j];
+    } else if (j < H) {
       hv = bias[j];
       for (int i = 0; i < n_in; ++i) hv += W[(size_t)j * n_in + i] * a[i];
     }
@@ -122,6 +131,17 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __re
   }
 }
 
+__global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __restrict__ pos,
+                                                   const float* __restrict__ freq_pi,
+                                                   const float* __restrict__ w,
+                                                   float* __restrict__ gains,     // (B, G)
+                                                   float* __restrict__ xhat,      // (B, nl, H)
+                                                   float* __restrict__ rstd) {    // (B, nl)
+  const int b = blockIdx.x;
+  mlp_fwd_block(d, b, pos, freq_pi, w + (size_t)(b / d.Bper) * mlp_param_count(d), gains,
+                xhat + (size_t)b * d.nl * d.H, rstd + (size_t)b * d.nl);
+}
+
 // ------------------------------------------------------------------------------------------
 // Layers of at most 64 neurons (the north-star network: 120 -> 16 x 6 -> 4): ONE WAVEFRONT per receiver, MLP_RB
 // receivers per workgroup, the packed parameters staged in LDS once per workgroup.  A receiver's layer chain is a
@@ -137,24 +157,23 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_fwd_waves(MlpDims d, const double* __restrict__ pos,
-                                                               const float* __restrict__ freq_pi,
-                                                               const float* __restrict__ w,
-                                                               float* __restrict__ gains,     // (B, G)
-                                                               float* __restrict__ xhat,      // (B, nl, H)
-                                                               float* __restrict__ rstd) {    // (B, nl)
+// MLP_RB receivers b0 .. b0 + MLP_RB - 1 of ONE band, a wave each.  w: the band's packed parameters; xhat_b0 / rstd_b0: where
+// receiver b0's saved activations go (the others follow at (nl, H) / (nl) each).
+__device__ __forceinline__ void mlp_fwd_waves(const MlpDims& d, int b0, const double* __restrict__ pos,
+                                              const float* __restrict__ freq_pi, const float* __restrict__ w,
+                                              float* __restrict__ gains, float* __restrict__ xhat_b0,
+                                              float* __restrict__ rstd_b0) {
   // a few workgroups of dependent 16-wide steps, launched beside kernels that fill every SIMD with VALU work (the
   // energy pass; the output-stage adjoint): without priority the chain advances at the SIMD's round-robin share
   __builtin_amdgcn_s_setprio(3);
   const int H = d.H, nl = d.nl, P = (int)mlp_param_count(d);
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int b = blockIdx.x * MLP_RB + r;
+  const int b = b0 + r;
   const int amax = d.in_dim > H ? d.in_dim : H;
   float* wl = mlp_lds;
   float* a = wl + P + (size_t)r * (amax + nl * H + nl);      // this receiver's current activations
   float* xs = a + amax;                          // saved activations: collected here, written once at the end
   float* rsv = xs + nl * H;
-  w += (size_t)(b / d.Bper) * P;                 // (all receivers of a workgroup belong to one band)
   for (int p = threadIdx.x; p < P; p += blockDim.x) wl[p] = w[p];
   {
     const double* pp = pos + (d.rows ? (size_t)d.rows[b] : (size_t)b) * 3;
@@ -196,30 +215,38 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_fwd_waves(MlpDims d, const 
     for (int i = 0; i < H; ++i) raw += Wout[(size_t)lane * H + i] * a[i];
     gains[(size_t)b * d.G + lane] = d.hi > d.lo ? d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw))) : raw;
   }
-  for (int p = lane; p < nl * H; p += 64) xhat[(size_t)b * nl * H + p] = xs[p];
-  if (lane < nl) rstd[(size_t)b * nl + lane] = rsv[lane];
+  for (int p = lane; p < nl * H; p += 64) xhat_b0[(size_t)r * nl * H + p] = xs[p];
+  if (lane < nl) rstd_b0[(size_t)r * nl + lane] = rsv[lane];
 }
 
-__global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __restrict__ pos,
-                                                   const float* __restrict__ freq_pi,
-                                                   const float* __restrict__ w,
-                                                   const float* __restrict__ gains,
-                                                   const float* __restrict__ xhat,
-                                                   const float* __restrict__ rstd,
-                                                   const float* __restrict__ ggains,   // (B, G)
-                                                   float* __restrict__ partial) {      // (B, P)
+__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_fwd_waves(MlpDims d, const double* __restrict__ pos,
+                                                               const float* __restrict__ freq_pi,
+                                                               const float* __restrict__ w,
+                                                               float* __restrict__ gains,     // (B, G)
+                                                               float* __restrict__ xhat,      // (B, nl, H)
+                                                               float* __restrict__ rstd) {    // (B, nl)
+  const int b0 = blockIdx.x * MLP_RB;            // (all receivers of a workgroup belong to one band)
+  mlp_fwd_waves(d, b0, pos, freq_pi, w + (size_t)(b0 / d.Bper) * mlp_param_count(d), gains,
+                xhat + (size_t)b0 * d.nl * d.H, rstd + (size_t)b0 * d.nl);
+}
+
+// One receiver (item b) by a whole workgroup.  w: the band's packed parameters; xhat / rstd: this receiver's saved
+// activations; gout: its row of parameter-gradient partials (P).  ggains: (B, G) summed gradients, or with d.gparts > 0 the
+// (B G, gparts) partial rows, summed here by one thread per group in column order (fixed, but not the wave form's order).
+__device__ __forceinline__ void mlp_bwd_block(const MlpDims& d, int b, const double* __restrict__ pos,
+                                              const float* __restrict__ freq_pi, const float* __restrict__ w,
+                                              const float* __restrict__ gains, const float* __restrict__ xhat,
+                                              const float* __restrict__ rstd, const float* __restrict__ ggains,
+                                              float* __restrict__ gout) {
   const int amax = d.in_dim > d.H ? d.in_dim : d.H;
   float* aprev = mlp_lds;        // activations entering the current layer
   float* da = aprev + amax;      // gradient w.r.t. the current layer's output (H)
   float* dh = da + d.H;          // gradient w.r.t. the linear output (H)
   float* draw = dh + d.H;        // (G)
   float* red = draw + d.G;       // 16
-  const int b = blockIdx.x, H = d.H, G = d.G;
+  const int H = d.H, G = d.G;
   const size_t P = mlp_param_count(d);
-  w += (size_t)(b / d.Bper) * P;
-  float* gp = partial + (size_t)b * P;
-  xhat += (size_t)b * d.nl * H;
-  rstd += (size_t)b * d.nl;
+  float* gp = gout;
   if (d.stage) {                 // parameters and this receiver's saved activations -> LDS, one load round
     float* wl = red + 16;
     float* xl = wl + P;
@@ -233,11 +260,20 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
   }
   // output layer
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float gg;
+    if (d.gparts > 0) {
+      const float* row = ggains + ((size_t)b * G + g) * d.gparts;
+      gg = 0.f;
+      for (int p = 0; p < d.gparts; ++p) gg += row[p];
+    } else {
+      gg = ggains[(size_t)b * G + g];
+    }
+    if (d.colscale) gg *= d.colscale[(b / d.Bper) * G + g];
     if (d.hi > d.lo) {
       const float sg = (gains[(size_t)b * G + g] - d.lo) / (d.hi - d.lo);
-      draw[g] = ggains[(size_t)b * G + g] * (d.hi - d.lo) * sg * (1.0f - sg);
+      draw[g] = gg * (d.hi - d.lo) * sg * (1.0f - sg);
     } else {
-      draw[g] = ggains[(size_t)b * G + g];
+      draw[g] = gg;
     }
   }
   {
@@ -291,7 +327,7 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
     }
     // activations that entered this layer
     if (l == 0) {
-      mlp_encode(d, pos, freq_pi, aprev);
+      mlp_encode(d, b, pos, freq_pi, aprev);
     } else {
       const float* Wp = w + mlp_layer_off(d, l - 1);
       const int n_in_p = (l - 1) == 0 ? d.in_dim : H;
@@ -314,9 +350,22 @@ __global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __re
     __syncthreads();
   }
   if (d.stage) {
-    float* gout = partial + (size_t)b * P;
     for (int p = threadIdx.x; p < (int)P; p += blockDim.x) gout[p] = gp[p];
   }
+}
+
+__global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpDims d, const double* __restrict__ pos,
+                                                   const float* __restrict__ freq_pi,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ gains,
+                                                   const float* __restrict__ xhat,
+                                                   const float* __restrict__ rstd,
+                                                   const float* __restrict__ ggains,   // (B, G)
+                                                   float* __restrict__ partial) {      // (B, P)
+  const int b = blockIdx.x;
+  const size_t P = mlp_param_count(d);
+  mlp_bwd_block(d, b, pos, freq_pi, w + (size_t)(b / d.Bper) * P, gains, xhat + (size_t)b * d.nl * d.H,
+                rstd + (size_t)b * d.nl, ggains, partial + (size_t)b * P);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -330,18 +379,17 @@ __host__ __device__ static inline int mlp_rb_stride(const MlpDims& d) {
   return d.in_dim + 4 * d.nl * d.H + d.nl + d.G;
 }
 
-__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const double* __restrict__ pos,
-                                                               const float* __restrict__ freq_pi,
-                                                               const float* __restrict__ w,
-                                                               const float* __restrict__ gains,
-                                                               const float* __restrict__ xhat,
-                                                               const float* __restrict__ rstd,
-                                                               const float* __restrict__ ggains,   // (B, G)
-                                                               float* __restrict__ partial) {      // (B / MLP_RB, P)
+// MLP_RB receivers b0 .. of ONE band, a wave each (w: the band's packed parameters; xhat_b0 / rstd_b0: receiver b0's saved
+// activations; gout: the workgroup's row of parameter-gradient partials (P))
+__device__ __forceinline__ void mlp_bwd_waves(const MlpDims& d, int b0, const double* __restrict__ pos,
+                                              const float* __restrict__ freq_pi, const float* __restrict__ w,
+                                              const float* __restrict__ gains, const float* __restrict__ xhat_b0,
+                                              const float* __restrict__ rstd_b0, const float* __restrict__ ggains,
+                                              float* __restrict__ gout) {
   __builtin_amdgcn_s_setprio(3);                 // (as k_mlp_fwd_waves)
   const int H = d.H, G = d.G, nl = d.nl, P = (int)mlp_param_count(d);
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int b = blockIdx.x * MLP_RB + r;
+  const int b = b0 + r;
   float* wl = mlp_lds;
   const int RS_ = mlp_rb_stride(d);
   float* mine = wl + P + (size_t)r * RS_;
@@ -352,11 +400,10 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const 
   float* DY = DH + nl * H;
   float* RS = DY + nl * H;
   float* DRAW = RS + nl;
-  w += (size_t)(b / d.Bper) * P;                 // (all receivers of a workgroup belong to one band)
   for (int p = threadIdx.x; p < P; p += blockDim.x) wl[p] = w[p];
   // this receiver's saved activations and encoding
-  for (int p = lane; p < nl * H; p += 64) XH[p] = xhat[(size_t)b * nl * H + p];
-  if (lane < nl) RS[lane] = rstd[(size_t)b * nl + lane];
+  for (int p = lane; p < nl * H; p += 64) XH[p] = xhat_b0[(size_t)r * nl * H + p];
+  if (lane < nl) RS[lane] = rstd_b0[(size_t)r * nl + lane];
   {
     const double* pp = pos + (d.rows ? (size_t)d.rows[b] : (size_t)b) * 3;
     for (int e = lane; e < d.in_dim; e += 64) {
@@ -437,7 +484,6 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const 
   __syncthreads();
   // parameter gradients of the workgroup's receivers, fixed order over r
   const float* base = wl + P;
-  float* gout = partial + (size_t)blockIdx.x * P;
   const int offOut = (int)mlp_layer_off(d, nl);
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     float sum = 0.f;
@@ -477,6 +523,20 @@ __global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const 
     }
     gout[p] = sum;
   }
+}
+
+__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bwd_waves(MlpDims d, const double* __restrict__ pos,
+                                                               const float* __restrict__ freq_pi,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ gains,
+                                                               const float* __restrict__ xhat,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ ggains,   // (B, G)
+                                                               float* __restrict__ partial) {      // (B / MLP_RB, P)
+  const int b0 = blockIdx.x * MLP_RB;            // (all receivers of a workgroup belong to one band)
+  const size_t P = mlp_param_count(d);
+  mlp_bwd_waves(d, b0, pos, freq_pi, w + (size_t)(b0 / d.Bper) * P, gains, xhat + (size_t)b0 * d.nl * d.H,
+                rstd + (size_t)b0 * d.nl, ggains, partial + (size_t)blockIdx.x * P);
 }
 
 // gflat[band][p] = sum_{b in band} partial[b][p]   (B items per band, band = blockIdx.y)
@@ -647,6 +707,188 @@ static int mlp_banded_bwd_run(const double* pos, const long long* pos_rows, cons
                      rstd, ggains, (float*)work);
   GFDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((P + 255) / 256), nbands), dim3(256), 0, s, (const float*)work, Bper, P, gw);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Bands with DIFFERENT layer sizes in one launch (round 6).  The reference's sub-band driver gives every band its own gain
+// network -- 63 Hz: 1 x 8, 125 Hz: 1 x 16, 250-1000 Hz: 5 x 16, 2-8 kHz: 3 x 128 hidden layers x neurons
+// (src/run_subband_training_treble.py:61-73) -- which the entry points above (one MlpDims for all bands) cannot take.
+// Here a table holds every band's sizes and offsets; a workgroup finds its band from its id and runs the same device
+// bodies: bands whose packed parameters fit in LDS (<= 64 neurons) a wave per receiver, the others a workgroup per receiver
+// with the parameters read from memory (waves over the neurons, lanes over the inputs: coalesced rows).
+//   w, gw : the bands' packed parameter sets one after the other (band q at woff[q])
+//   xhat  : the bands' (Bper, nl_q, H_q) blocks one after the other;  rstd: their (Bper, nl_q) blocks
+// ------------------------------------------------------------------------------------------
+#define MLP_MAXBANDS 16
+struct MlpBandTab {
+  int nbands;
+  int H[MLP_MAXBANDS], nl[MLP_MAXBANDS], mode[MLP_MAXBANDS];      // mode 0: a wave per receiver, 1: a workgroup per receiver
+  int wg0[MLP_MAXBANDS + 1];                                      // first workgroup of band q
+  int prow[MLP_MAXBANDS];                                         // rows of parameter-gradient partials of band q
+  unsigned woff[MLP_MAXBANDS], xoff[MLP_MAXBANDS], roff[MLP_MAXBANDS], poff[MLP_MAXBANDS], P[MLP_MAXBANDS];
+};
+
+__device__ __forceinline__ int mlp_band_of(const MlpBandTab& t, int wg) {
+  int q = 0;
+  while (q + 1 < t.nbands && wg >= t.wg0[q + 1]) ++q;
+  return q;
+}
+
+__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bands_fwd(MlpDims d, MlpBandTab t, const double* __restrict__ pos,
+                                                               const float* __restrict__ freq_pi,
+                                                               const float* __restrict__ w, float* __restrict__ gains,
+                                                               float* __restrict__ xhat, float* __restrict__ rstd) {
+  const int q = mlp_band_of(t, blockIdx.x), local = blockIdx.x - t.wg0[q];
+  d.H = t.H[q];
+  d.nl = t.nl[q];
+  d.stage = (t.mode[q] == 0 || t.P[q] <= MLP_STAGE_MAX) ? 1 : 0;
+  const size_t per = (size_t)d.nl * d.H;
+  if (t.mode[q] == 0) {
+    const int b0 = q * d.Bper + local * MLP_RB;
+    mlp_fwd_waves(d, b0, pos, freq_pi, w + t.woff[q], gains, xhat + t.xoff[q] + (size_t)local * MLP_RB * per,
+                  rstd + t.roff[q] + (size_t)local * MLP_RB * d.nl);
+  } else {
+    mlp_fwd_block(d, q * d.Bper + local, pos, freq_pi, w + t.woff[q], gains, xhat + t.xoff[q] + (size_t)local * per,
+                  rstd + t.roff[q] + (size_t)local * d.nl);
+  }
+}
+
+__global__ __launch_bounds__(64 * MLP_RB) void k_mlp_bands_bwd(MlpDims d, MlpBandTab t, const double* __restrict__ pos,
+                                                               const float* __restrict__ freq_pi,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ gains,
+                                                               const float* __restrict__ xhat,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ ggains,
+                                                               float* __restrict__ partial) {
+  const int q = mlp_band_of(t, blockIdx.x), local = blockIdx.x - t.wg0[q];
+  d.H = t.H[q];
+  d.nl = t.nl[q];
+  d.stage = (t.mode[q] == 0 || t.P[q] <= MLP_STAGE_MAX) ? 1 : 0;
+  const size_t per = (size_t)d.nl * d.H;
+  float* gout = partial + t.poff[q] + (size_t)local * t.P[q];
+  if (t.mode[q] == 0) {
+    const int b0 = q * d.Bper + local * MLP_RB;
+    mlp_bwd_waves(d, b0, pos, freq_pi, w + t.woff[q], gains, xhat + t.xoff[q] + (size_t)local * MLP_RB * per,
+                  rstd + t.roff[q] + (size_t)local * MLP_RB * d.nl, ggains, gout);
+  } else {
+    mlp_bwd_block(d, q * d.Bper + local, pos, freq_pi, w + t.woff[q], gains, xhat + t.xoff[q] + (size_t)local * per,
+                  rstd + t.roff[q] + (size_t)local * d.nl, ggains, gout);
+  }
+}
+
+// gflat[woff[q] + p] = sum over band q's rows of partials, in row order (band = blockIdx.y)
+__global__ void k_mlp_bands_reduce(MlpBandTab t, const float* __restrict__ partial, float* __restrict__ gflat) {
+  const int q = blockIdx.y;
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= t.P[q]) return;
+  const float* src = partial + t.poff[q] + p;
+  float sum = 0.f;
+  for (int r = 0; r < t.prow[q]; ++r) sum += src[(size_t)r * t.P[q]];
+  gflat[t.woff[q] + p] = sum;
+}
+
+// the table of a bank; returns 0 or an error code.  lds_fwd / lds_bwd: dynamic LDS of the two launches (bytes)
+static int mlp_band_tab(int nbands, int Bper, int F, const int* H, const int* n_hidden, int G, float lo, float hi,
+                        MlpDims* d, MlpBandTab* t, size_t* lds_fwd, size_t* lds_bwd, size_t* nparam, size_t* nxhat,
+                        size_t* nrstd, size_t* npart) {
+  if (nbands <= 0 || Bper <= 0 || !H || !n_hidden) return GFDN_E_BADARG;
+  if (nbands > MLP_MAXBANDS) return GFDN_E_UNSUPPORTED;
+  size_t wo = 0, xo = 0, ro = 0, po = 0, lf = 0, lb = 0;
+  int wg = 0;
+  t->nbands = nbands;
+  for (int q = 0; q < nbands; ++q) {
+    MlpDims dq;
+    int rc = mlp_dims(nbands * Bper, F, H[q], n_hidden[q], G, lo, hi, &dq);
+    if (rc) return rc;
+    if (q == 0) *d = dq;
+    const size_t P = mlp_param_count(dq);
+    const bool waves = dq.stage && H[q] <= 64 && G <= 64 && Bper % MLP_RB == 0;
+    t->H[q] = H[q];
+    t->nl[q] = dq.nl;
+    t->mode[q] = waves ? 0 : 1;
+    t->wg0[q] = wg;
+    t->prow[q] = waves ? Bper / MLP_RB : Bper;
+    t->woff[q] = (unsigned)wo; t->xoff[q] = (unsigned)xo; t->roff[q] = (unsigned)ro; t->poff[q] = (unsigned)po;
+    t->P[q] = (unsigned)P;
+    wg += t->prow[q];
+    wo += P;
+    xo += (size_t)Bper * dq.nl * H[q];
+    ro += (size_t)Bper * dq.nl;
+    po += (size_t)t->prow[q] * P;
+    const int amax = dq.in_dim > H[q] ? dq.in_dim : H[q];
+    const size_t f = waves ? (P + (size_t)MLP_RB * (amax + dq.nl * H[q] + dq.nl)) * sizeof(float) : mlp_lds_bytes(dq);
+    const size_t b = waves ? (P + (size_t)MLP_RB * mlp_rb_stride(dq)) * sizeof(float) : mlp_lds_bytes(dq);
+    if (f > lf) lf = f;
+    if (b > lb) lb = b;
+  }
+  if (po > 0xFFFFFFFFull || xo > 0xFFFFFFFFull) return GFDN_E_UNSUPPORTED;
+  t->wg0[nbands] = wg;
+  d->Bper = Bper;
+  if (lds_fwd) *lds_fwd = lf;
+  if (lds_bwd) *lds_bwd = lb;
+  if (nparam) *nparam = wo;
+  if (nxhat) *nxhat = xo;
+  if (nrstd) *nrstd = ro;
+  if (npart) *npart = po;
+  return 0;
+}
+
+// sizes[0..3] = floats of the packed parameters, of xhat, of rstd, of the backward's work buffer
+extern "C" int gfdn_mlp_bands_sizes(int nbands, int Bper, int F, const int* H, const int* n_hidden, int G, size_t* sizes) {
+  MlpDims d;
+  MlpBandTab t;
+  if (!sizes) return GFDN_E_BADARG;
+  return mlp_band_tab(nbands, Bper, F, H, n_hidden, G, -1.f, 1.f, &d, &t, nullptr, nullptr, sizes, sizes + 1, sizes + 2,
+                      sizes + 3);
+}
+
+extern "C" int gfdn_mlp_gains_bands_fwd(const double* pos, const long long* pos_rows, const float* freq_pi, const float* w,
+                                        int nbands, int Bper, int F, const int* H, const int* n_hidden, int G, float lo,
+                                        float hi, float* gains, float* xhat, float* rstd, void* stream) {
+  MlpDims d;
+  MlpBandTab t;
+  size_t lds = 0;
+  int rc = mlp_band_tab(nbands, Bper, F, H, n_hidden, G, lo, hi, &d, &t, &lds, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  if (!pos || !freq_pi || !w || !gains || !xhat || !rstd) return GFDN_E_BADARG;
+  d.rows = pos_rows;
+  rc = ensure_dyn_lds(k_mlp_bands_fwd, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_mlp_bands_fwd, dim3(t.wg0[nbands]), dim3(64 * MLP_RB), lds, (hipStream_t)stream, d, t, pos, freq_pi, w,
+                     gains, xhat, rstd);
+  GFDN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ggains: (nbands Bper, G) summed gradients (gparts = 0) or the (nbands Bper G, gparts) partial rows of the output stage's
+// adjoint, summed inside the launch; colscale (optional, (nbands G)): every row sum is multiplied by colscale[band G + g]
+extern "C" int gfdn_mlp_gains_bands_bwd(const double* pos, const long long* pos_rows, const float* freq_pi, const float* w,
+                                        int nbands, int Bper, int F, const int* H, const int* n_hidden, int G, float lo,
+                                        float hi, const float* gains, const float* xhat, const float* rstd,
+                                        const float* ggains, int gparts, const float* colscale, float* gw, void* work,
+                                        void* stream) {
+  MlpDims d;
+  MlpBandTab t;
+  size_t lds = 0;
+  int rc = mlp_band_tab(nbands, Bper, F, H, n_hidden, G, lo, hi, &d, &t, nullptr, &lds, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  if (!pos || !freq_pi || !w || !gains || !xhat || !rstd || !ggains || !gw || !work || gparts < 0) return GFDN_E_BADARG;
+  d.rows = pos_rows;
+  d.gparts = gparts;
+  d.colscale = colscale;
+  rc = ensure_dyn_lds(k_mlp_bands_bwd, lds);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mlp_bands_bwd, dim3(t.wg0[nbands]), dim3(64 * MLP_RB), lds, s, d, t, pos, freq_pi, w, gains, xhat,
+                     rstd, ggains, (float*)work);
+  GFDN_LAUNCH_CHECK();
+  unsigned maxP = 0;
+  for (int q = 0; q < nbands; ++q) maxP = t.P[q] > maxP ? t.P[q] : maxP;
+  hipLaunchKernelGGL(k_mlp_bands_reduce, dim3((maxP + 255) / 256, nbands), dim3(256), 0, s, t, (const float*)work, gw);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

@@ -123,6 +123,8 @@ class MlpGains(torch.autograd.Function):
     def forward(ctx, pos, rows, freq_pi, H, n_hidden, G, lo, hi, *params):
         # band-stacked call (BandBank): ONE parameter tensor (nbands, P), each row a packed set
         ctx.nbands = params[0].shape[0] if len(params) == 1 and params[0].dim() == 2 else 1
+        if isinstance(H, (tuple, list)):          # (bands with their own layer sizes: ONE packed vector, band after band)
+            ctx.nbands = len(H)
         w = params[0].detach() if ctx.nbands > 1 or len(params) == 1 else MlpGains._packed(params)
         gains, xhat, rstd = ops.mlp_gains_fwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, rows, ctx.nbands)
         ctx.rows = rows

@@ -2391,6 +2391,24 @@ def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi:
     B, F = (pos.shape[0] if rows is None else rows.numel()), freq_pi.numel()
     rows = _rows(rows, B, pos.shape[0])
     lib = _lib.load()
+    if isinstance(H, (list, tuple)):
+        # bands with their own layer sizes (csrc/mlp.hip k_mlp_bands_*): xhat / rstd are flat, band after band
+        Hs, nh, sizes = _mlp_bands(H, n_hidden, nbands, B, F, G)
+        if w.numel() != sizes[0]:
+            raise RuntimeError("mlp_gains: packed parameter count does not match the bands' layer sizes")
+        if out is not None:
+            gains, xhat, rstd = out
+            if tuple(gains.shape) != (B, G) or xhat.numel() != sizes[1] or rstd.numel() != sizes[2] \
+                    or any(t.dtype != _f32 or not t.is_contiguous() for t in out):
+                raise RuntimeError("mlp_gains_fwd: out = (gains (B, G), xhat, rstd) float32 contiguous of the bands' sizes")
+        else:
+            gains = torch.empty((B, G), dtype=_f32, device=pos.device)
+            xhat = torch.empty(sizes[1], dtype=_f32, device=pos.device)
+            rstd = torch.empty(sizes[2], dtype=_f32, device=pos.device)
+        _lib.check(lib.gfdn_mlp_gains_bands_fwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, Hs, nh, G,
+                                                float(lo), float(hi), _p(gains), _p(xhat), _p(rstd), _stream()),
+                   "gfdn_mlp_gains_bands_fwd")
+        return gains, xhat, rstd
     if w.numel() != nbands * lib.gfdn_mlp_param_count(F, H, n_hidden, G) or B % nbands:
         raise RuntimeError("mlp_gains: packed parameter count does not match the layer sizes")
     nl = 1 + n_hidden
@@ -2414,8 +2432,35 @@ def mlp_gains_fwd(pos, freq_pi, w, H: int, n_hidden: int, G: int, lo: float, hi:
     return gains, xhat, rstd
 
 
-def mlp_bwd_takes_parts(F: int, H: int, n_hidden: int, G: int, Bper: int) -> bool:
-    """Whether mlp_gains_bwd(ggains_parts=...) applies to this network and batch (the wave-per-receiver kernel)."""
+_MLP_BANDS = {}
+
+
+def _mlp_bands(H, n_hidden, nbands: int, B: int, F: int, G: int):
+    """(H array, n_hidden array, sizes (w, xhat, rstd, backward work floats)) of a bank whose bands have their own layer
+    sizes -- ctypes int arrays, cached per shape (the launches read them on the host)"""
+    H, n_hidden = tuple(int(v) for v in H), tuple(int(v) for v in n_hidden)
+    if len(H) != nbands or len(n_hidden) != nbands or B % nbands:
+        raise RuntimeError("mlp_gains: one (H, n_hidden) per band, the same number of items per band")
+    key = (H, n_hidden, B // nbands, F, G)
+    if key not in _MLP_BANDS:
+        Hs, nh = (ctypes.c_int * nbands)(*H), (ctypes.c_int * nbands)(*n_hidden)
+        sizes = (ctypes.c_size_t * 4)()
+        _lib.check(_lib.load().gfdn_mlp_bands_sizes(nbands, B // nbands, F, Hs, nh, G, sizes), "gfdn_mlp_bands_sizes")
+        _MLP_BANDS[key] = (Hs, nh, tuple(int(v) for v in sizes))
+    return _MLP_BANDS[key]
+
+
+def mlp_bands_param_counts(H, n_hidden, F: int, G: int):
+    """packed parameter count of every band's network"""
+    lib = _lib.load()
+    return [int(lib.gfdn_mlp_param_count(int(F), int(h), int(nh), int(G))) for h, nh in zip(H, n_hidden)]
+
+
+def mlp_bwd_takes_parts(F: int, H, n_hidden, G: int, Bper: int) -> bool:
+    """Whether mlp_gains_bwd(ggains_parts=...) applies to this network and batch (the wave-per-receiver kernel; always for
+    the per-band sizes of k_mlp_bands_bwd, which sums the rows in either of its forms)."""
+    if isinstance(H, (list, tuple)):
+        return True
     return bool(_lib.load().gfdn_mlp_bwd_takes_parts(int(F), int(H), int(n_hidden), int(G), int(Bper)))
 
 
@@ -2432,6 +2477,22 @@ def mlp_gains_bwd(pos, freq_pi, w, H, n_hidden, G, lo, hi, gains, xhat, rstd, gg
     if out is not None and (out.dtype != _f32 or not out.is_contiguous() or out.numel() != w.numel()):
         raise RuntimeError("mlp_gains_bwd: out must be a contiguous float32 buffer of the parameter count")
     gw = torch.empty_like(w) if out is None else out
+    if isinstance(H, (list, tuple)):
+        Hs, nh, sizes = _mlp_bands(H, n_hidden, nbands, B, F, G)
+        if w.numel() != sizes[0] or xhat.numel() != sizes[1] or rstd.numel() != sizes[2]:
+            raise RuntimeError("mlp_gains_bwd: buffers do not match the bands' layer sizes")
+        work = _work(4 * sizes[3], pos.device)
+        if ggains_parts is not None:
+            gsrc = _f(ggains_parts)
+            if gsrc.dim() != 2 or gsrc.shape[0] != B * G:
+                raise RuntimeError("mlp_gains_bwd: ggains_parts must be (B G, chunks)")
+            gparts = gsrc.shape[1]
+        else:
+            gsrc, gparts = _f(ggains), 0
+        _lib.check(lib.gfdn_mlp_gains_bands_bwd(_p(pos), _p(rows), _p(freq_pi), _p(w), nbands, B // nbands, F, Hs, nh, G,
+                                                float(lo), float(hi), _p(gains), _p(xhat), _p(rstd), _p(gsrc), gparts,
+                                                _p(colscale), _p(gw), _p(work), _stream()), "gfdn_mlp_gains_bands_bwd")
+        return gw
     work = _work(lib.gfdn_mlp_bwd_work_bytes(B, F, H, n_hidden, G), pos.device)
     if ggains_parts is not None:
         gp = _f(ggains_parts)

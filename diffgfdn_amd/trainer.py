@@ -1158,6 +1158,8 @@ class GraphedTrainStep:
             self.capture(None)                      # (warm-up of every kernel, lazy initialisations)
         bank = self.tr.net
         Hh, n_hidden = bank._mlp_cfg[0], bank._mlp_cfg[1]
+        if bank.mixed_networks:
+            raise NotImplementedError("a pipelined chain of steps takes a bank of equal gain networks")
         dev, G, nl = self.idx.device, bank.num_groups, 1 + n_hidden
         mk = lambda: (torch.empty((self.B, G), dtype=torch.float32, device=dev),
                       torch.empty((self.B, nl, Hh), dtype=torch.float32, device=dev),

@@ -954,6 +954,7 @@ int gfdn_mlp_gains_banded_bwd(const double* pos, const long long* pos_rows, cons
  * receiver's wave sums its rows itself, same terms in the same order as the separate row-sum launch it replaces.
  * Wave-per-receiver form only (H, G <= 64, Bper a multiple of 4, parameters staged in LDS): GFDN_E_UNSUPPORTED otherwise. */
 int gfdn_mlp_bwd_takes_parts(int F, int H, int n_hidden, int G, int Bper);      /* 1: the call below takes this network */
+
 int gfdn_mlp_gains_banded_bwd_parts(const double* pos, const long long* pos_rows, const float* freq_pi,
                                     const float* w, int nbands, int Bper, int F, int H, int n_hidden,
                                     int G, float lo, float hi, const float* gains, const float* xhat,
@@ -966,6 +967,22 @@ int gfdn_mlp_gains_banded_bwd_parts_scaled(const double* pos, const long long* p
                                            const float* gains, const float* xhat, const float* rstd,
                                            const float* ggains_parts, int gparts, const float* colscale, float* gw, void* work,
                                            void* stream);
+
+/* Bands with DIFFERENT layer sizes in ONE launch (round 6): the reference's sub-band driver gives every band its own gain
+ * network (src/run_subband_training_treble.py:61-73: 1 x 8, 1 x 16, 5 x 16, 3 x 128 hidden layers x neurons).  H[q],
+ * n_hidden[q] (host arrays, nbands <= 16): band q's sizes; F, G, lo, hi shared.  w / gw: the bands' packed parameter sets one
+ * after the other; xhat / rstd: the bands' (Bper, nl_q, H_q) / (Bper, nl_q) blocks one after the other.
+ * gfdn_mlp_bands_sizes: sizes[0..3] = floats of w, xhat, rstd and of the backward's work buffer.  Backward: ggains (items, G)
+ * summed gradients (gparts = 0) or (items G, gparts) partial rows summed in the launch; colscale (optional, (nbands G))
+ * multiplies every row sum (normalize's scale folded into the gains, gfdn_tf_energy_gains).                                  */
+int gfdn_mlp_bands_sizes(int nbands, int Bper, int F, const int* H, const int* n_hidden, int G, size_t* sizes);
+int gfdn_mlp_gains_bands_fwd(const double* pos, const long long* pos_rows, const float* freq_pi, const float* w, int nbands,
+                             int Bper, int F, const int* H, const int* n_hidden, int G, float lo, float hi, float* gains,
+                             float* xhat, float* rstd, void* stream);
+int gfdn_mlp_gains_bands_bwd(const double* pos, const long long* pos_rows, const float* freq_pi, const float* w, int nbands,
+                             int Bper, int F, const int* H, const int* n_hidden, int G, float lo, float hi,
+                             const float* gains, const float* xhat, const float* rstd, const float* ggains, int gparts,
+                             const float* colscale, float* gw, void* work, void* stream);
 
 /* Receiver schedule of a replayed epoch (reference trainer.py:373-379: the DataLoader fixes an epoch's batches when the
  * epoch starts): table (len, B) int64 dataset rows uploaded once; each call copies row state[0] mod state[1] into idx

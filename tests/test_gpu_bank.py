@@ -23,6 +23,17 @@ def _need_gpu():
         pytest.skip("needs a GPU")
 
 
+@pytest.fixture
+def float32_direct_store():
+    """the linear step's direct-path store built with the float32 transforms of rounds 4-5: what a test that compares the
+    linear step with the stored-signal step needs (both then see the SAME float32 direct paths; the float64 store of round 6
+    is closer to the reference by the float32 transform's error, 4e-6 on a loss)"""
+    from diffgfdn_amd.bandbank import BandStackedDataset
+    BandStackedDataset.direct_time_f64 = False
+    yield
+    BandStackedDataset.direct_time_f64 = True
+
+
 def _band_filters():
     from scipy.signal import firwin
     out = []
@@ -862,7 +873,7 @@ def test_graphed_bank_step_with_distinct_decay_windows():
 
 
 @pytest.mark.parametrize("t60max", [None, T60MAX])
-def test_time_domain_output_stage_equals_spectral_output_stage(t60max):
+def test_time_domain_output_stage_equals_spectral_output_stage(t60max, float32_direct_store):
     """The explicit step with the output stage in the time domain (csrc/linear.hip: G transforms per band, receivers'
     signals combined from the transformed group responses and the dataset's transformed direct paths) against the same
     step with the output stage formed per receiver in the frequency domain and one transform per receiver: the maps

@@ -41,6 +41,18 @@ def _need_gpu():
         pytest.skip("needs a GPU")
 
 
+@pytest.fixture
+def float32_direct_store():
+    """the linear step's direct-path store built with the float32 transforms of rounds 4-5: what a test that compares the
+    linear step with the stored-signal step needs (both then see the SAME float32 direct paths; the float64 store of round 6
+    is closer to the reference by the float32 transform's error, 4e-6 on a loss)"""
+    from diffgfdn_amd.bandbank import BandStackedDataset
+    BandStackedDataset.direct_time_f64 = False
+    yield
+    BandStackedDataset.direct_time_f64 = True
+
+
+
 def _filters():
     from scipy.signal import firwin
     return np.stack([np.fft.rfft(firwin(1025, [f / np.sqrt(2), f * np.sqrt(2)], pass_zero=False, fs=FS), n=NFFT)
@@ -73,37 +85,25 @@ def _tc():
                                                                         num_fraction_octaves=1))
 
 
-def _oracle_step(sd, q, room, ds, sel, filt_q, keep, delays=None, n_fourier=4):
-    """normalize + train_step of the CPU oracle from the state dict ``sd`` on receivers ``sel``; returns the loss
-    parts, the gradients and the parameters after Adam, keyed like the model's state dict."""
-    lin, norm, names = [], [], []
-    for i in range(64):
-        k = f"output_scalars.mlp.model.{i}.weight"
-        if k in sd:
-            pair = (sd[k].clone(), sd[f"output_scalars.mlp.model.{i}.bias"].clone())
-            (lin if sd[k].ndim == 2 else norm).append(pair)
-            names.append((f"output_scalars.mlp.model.{i}", pair))
-    p = orc.GridModelParams(FS, DELAYS[q] if delays is None else delays, G, sd["input_gains"].clone(),
-                            sd["output_gains"].clone(),
-                            sd["feedback_loop.M"].clone(), sd["feedback_loop.alpha"].clone(),
-                            room["common_decay_times"], lin, norm, n_fourier)
-    otr = OracleGridTrainer(p, lr=1e-3, io_lr=1e-2, edr_weight=1.0, edc_weight=10.0, spectral_weight=1.0,
-                            sparsity_weight=2.0, use_asym=True, subband_filter=filt_q.cpu().to(torch.complex128))
+def _oracle_job(sd, q, room, ds, sel, filt_q, keep, delays=None, n_fourier=4):
+    """what tests/oracle_jobs.grid_step needs for normalize + train_step of the CPU oracle from the state dict ``sd`` on
+    receivers ``sel`` (CPU tensors only)"""
     idx = torch.tensor(sel)
     ob = {"z_values": ds.z_values.cpu(),
           "norm_listener_position": ds.norm_listener_position[idx].cpu(),
           "listener_position": ds.listener_positions[idx].cpu(),
           "target_early_response": ds.early_response_c128(idx).cpu(),
           "target_rir_response": ds.rir_mag_response[idx].cpu().to(torch.complex128)}
-    otr.normalize(ob)
-    _, parts = otr.train_step(ob, keep)
-    grads = {"input_gains": p.input_gains.grad, "output_gains": p.output_gains.grad, "feedback_loop.M": p.M.grad}
-    after = {"input_gains": p.input_gains.detach(), "output_gains": p.output_gains.detach(),
-             "feedback_loop.M": p.M.detach()}
-    for base, (w, bias) in names:
-        grads[base + ".weight"], grads[base + ".bias"] = w.grad, bias.grad
-        after[base + ".weight"], after[base + ".bias"] = w.detach(), bias.detach()
-    return parts, grads, after
+    return {"fs": FS, "delays": DELAYS[q] if delays is None else delays, "G": G,
+            "sd": {k: v.detach().cpu().clone() for k, v in sd.items()}, "common_decay_times": room["common_decay_times"],
+            "n_fourier": n_fourier, "filt": filt_q.cpu().to(torch.complex128), "batch": ob, "keep": keep, "threads": 16}
+
+
+def _oracle_step(sd, q, room, ds, sel, filt_q, keep, delays=None, n_fourier=4):
+    """normalize + train_step of the CPU oracle from the state dict ``sd`` on receivers ``sel``; returns the loss
+    parts, the gradients and the parameters after Adam, keyed like the model's state dict."""
+    from tests.oracle_jobs import grid_step
+    return grid_step(_oracle_job(sd, q, room, ds, sel, filt_q, keep, delays, n_fourier))
 
 
 def _check(tag, parts_hip, grads_hip, after_hip, before, parts, grads, after, grad_tol=None, grad_tol_M=None):
@@ -336,6 +336,10 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, os.cpu_count() or 1))          # (the torch CPU path anti-scales beyond this)
     worst_all = {}
+    # the seven oracle steps side by side in worker processes (tests/oracle_jobs.py)
+    from tests.oracle_jobs import run_grid_steps
+    oracle = run_grid_steps([_oracle_job(sd0[q], q, rooms[q], datas[q], sels[q], filts[q], keep, delays_l[q], nfeat)
+                             for q in range(len(centres))], workers=4)
     try:
         for q in range(len(centres)):
             parts_hip = {k: float(v[q]) for k, v in out.items() if k.endswith("_loss")}
@@ -348,7 +352,7 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
                 grads_hip["output_scalars.mlp.model." + n_] = gw[o:o + prm.numel()].reshape(tuple(prm.shape))
                 o += prm.numel()
             after_hip = {k: v.detach().cpu().numpy() for k, v in nets[q].state_dict().items()}
-            parts, grads, after = _oracle_step(sd0[q], q, rooms[q], datas[q], sels[q], filts[q], keep, delays_l[q], nfeat)
+            parts, grads, after = oracle[q]
             worst = _check(f"bench[N={N}, {int(centres[q])} Hz]", parts_hip, grads_hip, after_hip,
                            {k: v.numpy() for k, v in sd0[q].items()}, parts, grads, after, grad_tol=2e-4,
                            grad_tol_M=GRAD_TOL_M[nper])
@@ -503,7 +507,7 @@ def test_fused_tail_steps_equal_separate_launches_full_size(nper):
         assert np.array_equal(res[True][j], res[False][j]), j
 
 
-def test_time_domain_output_stage_equals_folded_output_stage_full_size():
+def test_time_domain_output_stage_equals_folded_output_stage_full_size(float32_direct_store):
     """K = 65 537, two bands: the explicit step with the output stage in the time domain (4 pair-transformed group
     responses per band + the dataset's transformed direct paths, csrc/linear.hip) against the step that forms H per
     receiver inside the first pass of one transform per receiver pair (round 2/3's timed path): losses to 2e-6, gradients

@@ -88,3 +88,152 @@ def test_direct_path_store_is_float64_accurate(ops):
         ds = sds.datasets[q]
         E = ds.early_response_c128(torch.arange(R)).cpu().numpy()
         assert np.abs(E - np.fft.rfft(early, n=nfft, axis=-1)).max() < 1e-13 * np.abs(E).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# bands with their own gain networks (reference run_subband_training_treble.py:61-73)
+MIXED = [(8, 1), (16, 1), (16, 5), (128, 3)]          # (neurons, hidden layers) per band
+
+
+@pytest.mark.parametrize("Bper", [8, 5])
+def test_gain_networks_of_different_sizes_in_one_launch(ops, Bper):
+    """gfdn_mlp_gains_bands_fwd / _bwd (a table of per-band layer sizes, one launch) == the per-band launches, bit for
+    bit: bands on the wave-per-receiver form (<= 64 neurons, whole groups of 8 receivers) and on the workgroup-per-receiver
+    form (128 neurons: parameters read from memory) in the same launch; summed gradients and partial rows with column
+    scales; float64 torch autograd of the same stack for the 128-neuron band."""
+    g = torch.Generator(device="cpu").manual_seed(7 + Bper)
+    nb, R, G, F = len(MIXED), 11, 3, 20
+    H, nh = [m[0] for m in MIXED], [m[1] for m in MIXED]
+    counts = ops.mlp_bands_param_counts(H, nh, F, G)
+    w = torch.cat([0.3 * torch.randn(c, generator=g) / np.sqrt(h) for c, h in zip(counts, H)]).to(DEV)
+    pos = torch.rand(nb * R, 3, generator=g, dtype=torch.float64).to(DEV)
+    fpi = (torch.exp(torch.linspace(0, np.log(32.0), F)) * np.pi).to(torch.float32).to(DEV)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=g)[:Bper]], device=DEV)
+    gains, xhat, rstd = ops.mlp_gains_fwd(pos, fpi, w, H, nh, G, -1.0, 1.0, rows, nbands=nb)
+    gg = torch.randn(nb * Bper, G, generator=g).to(DEV)
+    parts = torch.randn(nb * Bper * G, 7, generator=g).to(DEV)
+    cs = (torch.rand(nb * G, generator=g) + 0.5).to(DEV)
+    gw = ops.mlp_gains_bwd(pos, fpi, w, H, nh, G, -1.0, 1.0, gains, xhat, rstd, gg, rows, nbands=nb)
+    gwp = ops.mlp_gains_bwd(pos, fpi, w, H, nh, G, -1.0, 1.0, gains, xhat, rstd, None, rows, nbands=nb,
+                            ggains_parts=parts, colscale=cs)
+    wo = xo = ro = 0
+    for q in range(nb):
+        sl = slice(q * Bper, (q + 1) * Bper)
+        rq = rows[sl].contiguous()
+        nl = 1 + nh[q]
+        wq = w[wo:wo + counts[q]].contiguous()
+        gq, xq, sq = ops.mlp_gains_fwd(pos, fpi, wq, H[q], nh[q], G, -1.0, 1.0, rq)
+        assert torch.equal(gains[sl], gq), q
+        assert torch.equal(xhat[xo:xo + Bper * nl * H[q]], xq.reshape(-1)) and torch.equal(rstd[ro:ro + Bper * nl], sq.reshape(-1))
+        gwq = ops.mlp_gains_bwd(pos, fpi, wq, H[q], nh[q], G, -1.0, 1.0, gq, xq, sq, gg[sl].contiguous(), rq)
+        assert torch.equal(gw[wo:wo + counts[q]], gwq), q
+        # partial rows x column scale == the summed, scaled rows (another summation order: float32 rounding)
+        ggq = (parts.view(nb * Bper, G, -1).sum(-1)[sl] * cs[q * G:(q + 1) * G][None, :]).contiguous()
+        gwq2 = ops.mlp_gains_bwd(pos, fpi, wq, H[q], nh[q], G, -1.0, 1.0, gq, xq, sq, ggq, rq)
+        assert float((gwp[wo:wo + counts[q]] - gwq2).abs().max()) <= 2e-5 * float(gwq2.abs().max()), q
+        wo, xo, ro = wo + counts[q], xo + Bper * nl * H[q], ro + Bper * nl
+    # the 128-neuron band against float64 autograd (dnn.py:331-400, gain_filters.py:497-524)
+    q = 3
+    wq = w[sum(counts[:q]):].double().cpu().requires_grad_()
+    x = pos[rows[q * Bper:]].cpu()
+    enc = []
+    for k in range(F):
+        a = float(fpi[k].cpu()) * x
+        enc += [torch.sin(a), torch.cos(a)]
+    a = torch.cat(enc, dim=1).float().double()
+    off, n_in = 0, 6 * F
+    for l in range(1 + nh[q]):
+        W = wq[off:off + H[q] * n_in].view(H[q], n_in)
+        off += H[q] * n_in
+        bias, gamma, beta = wq[off:off + H[q]], wq[off + H[q]:off + 2 * H[q]], wq[off + 2 * H[q]:off + 3 * H[q]]
+        off += 3 * H[q]
+        a = torch.relu(torch.nn.functional.layer_norm(a @ W.T + bias, (H[q],), gamma, beta, 1e-5))
+        n_in = H[q]
+    out = -1.0 + 2.0 * torch.sigmoid(a @ wq[off:off + G * H[q]].view(G, H[q]).T + wq[off + G * H[q]:])
+    assert float((gains[q * Bper:].cpu().double() - out).abs().max()) < 2e-5
+    out.backward(gg[q * Bper:].cpu().double())
+    ref = wq.grad
+    assert float((gw[sum(counts[:q]):].cpu().double() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
+def test_bank_with_the_reference_recipes_gain_networks():
+    """A bank whose bands have the reference's per-band network sizes (1 x 8, 1 x 16, 5 x 16, 3 x 128;
+    run_subband_training_treble.py:61-73): the explicit step (one launch per stage for all bands, the scale inside the
+    gains) == the autograd bank step on the per-bin elimination kernels == every band's own trainer step; the bands'
+    reference-shaped state dicts stay views of the bank's packed vector."""
+    from tests import test_gpu_bank as tb
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
+    from diffgfdn_amd.model import DiffGFDNVarReceiverPos
+    from diffgfdn_amd.trainer import VarReceiverPosTrainer
+    from tests.helpers import philox_mask, rel_err
+    nbands = 3
+    sizes = [(8, 1), (16, 5), (128, 3)]
+
+    def build(q):
+        torch.manual_seed(100 + q)
+        fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
+        of = OutputFilterConfig(use_svfs=False, num_hidden_layers=sizes[q][1], num_neurons_per_layer=sizes[q][0],
+                                num_fourier_features=4)
+        T60 = np.linspace(0.2, 0.5, tb.G)[None, :]
+        return DiffGFDNVarReceiverPos(tb.FS, tb.G, tb._delays(q), DEV, fl, of, use_absorption_filters=False,
+                                      common_decay_times=T60, use_colorless_loss=True).to(DEV)
+
+    sels = [[0, 3, 5, 7, 1, 2, 8, 11], [1, 2, 8, 11, 4, 6, 9, 10], [4, 6, 9, 10, 0, 3, 5, 7]]
+    filt = torch.tensor(tb._band_filters(), device=DEV).to(torch.complex64)
+    res = {}
+    for fused in (True, False):
+        BandBankTrainer.use_fused = fused
+        try:
+            nets = [build(q) for q in range(nbands)]
+            data = [tb._build_data(q) for q in range(nbands)]
+            bank = BandBank(nets)
+            assert bank.mixed_networks and bank.output_scalars_w.dim() == 1
+            tr = BandBankTrainer(bank, tb._tc(True, ), subband_filter_freq_resp=filt, stft_win=tb.WIN, band_names=tb.BANDS)
+        finally:
+            BandBankTrainer.use_fused = True
+        sds = BandStackedDataset([d for _, d in data])
+        start, length = tr._decay_window(tb.NFFT // 2 + 1)
+        sds.precompute_decay_targets(tb.WIN, *tr._target_window(tb.NFFT // 2 + 1))
+        mw = torch.tensor(philox_mask(99, 0, length, 1.0 / 8)[0], device=DEV)
+        sd0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
+        batch = sds.collate(sds.global_rows(sels))
+        if fused:
+            losses = tr._fused.run(batch, mw, 1.0, normalize_first=True, train=True, opt_step=False)
+        else:
+            tr.optimizer.zero_grad(set_to_none=True)
+            losses = tr._step_losses(batch, mask_prenorm=mw, defer_total=True, normalize_first=True)
+            heads = losses.pop("_heads")
+            torch.autograd.backward(heads, [torch.ones(nbands, device=DEV)] * 2)
+            tr.optimizer.pack_grads()
+            losses["_total"] = heads[0].detach() + heads[1].detach()
+        grad = tr.optimizer.flat_grad.detach().cpu().numpy().copy()
+        tr.optimizer.step()
+        res[fused] = ({k: v.detach().cpu().numpy() for k, v in losses.items()}, grad, tr.optimizer, nets, sd0, data,
+                      (start, length), mw)
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=2e-5, atol=1e-7), (k, res[True][0][k], v)
+    ga, gb = res[True][1], res[False][1]
+    off = 0
+    for p in res[False][2]._params:
+        sl = slice(off, off + p.numel())
+        assert np.abs(ga[sl] - gb[sl]).max() < 2e-4 * np.abs(gb[sl]).max(), (off, np.abs(ga[sl] - gb[sl]).max())
+        off += p.numel()
+    # every band's own trainer step from the same start
+    _, _, _, nets, sd0, data, (start, length), mw = res[True]
+    for q in range(nbands):
+        ref_net = build(q)
+        ref_net.load_state_dict(sd0[q], strict=True)
+        rtr = VarReceiverPosTrainer(ref_net, tb._tc(True), subband_filter_freq_resp=filt[q], stft_win=tb.WIN, capturable=True)
+        ds = data[q][1]
+        ds.precompute_decay_targets(tb.WIN, start, length)
+        b = ds.collate(sels[q], lean=True)
+        rtr.normalize(b)
+        rtr.optimizer.zero_grad(set_to_none=True)
+        rl = rtr._step_losses(b, mask_prenorm=mw)
+        rl.pop("_total").backward()
+        rtr.optimizer.step()
+        for k, v in rl.items():
+            assert abs(float(v) - res[True][0][k][q]) <= 2e-5 * abs(float(v)) + 1e-9, (q, k)
+        for k, v in ref_net.state_dict().items():
+            assert rel_err(nets[q].state_dict()[k].detach().cpu(), v.detach().cpu()) < 2e-4, (q, k)
