@@ -157,11 +157,41 @@ def trainer_config(centre_hz: float, max_epochs: int = 20, use_mask: bool = True
                              centre_frequency=centre_hz, frequency_range=(63, 8000), num_fraction_octaves=1))
 
 
-def build_net(device, delays, common_decay_times):
+# ``--recipe reference``: the sub-band driver's OWN configuration (src/run_subband_training_treble.py:61-73, :105-154, :392):
+# eight octave bands 63 Hz ... 8 kHz, N = 12 = 3 groups x 4 lines, every band its own gain network
+REFERENCE_RECIPE_CENTRES = (63.0, 125.0, 250.0, 500.0, 1000.0, 2000.0, 4000.0, 8000.0)
+RECIPE = None
+
+
+def recipe_network(centre_hz: float):
+    """(hidden layers, neurons per layer) of a band's gain network"""
+    if RECIPE != 'reference':
+        return 5, 16                     # (BASELINE.md's homogeneous recipe: the headline)
+    f = int(round(centre_hz))
+    if f == 63:
+        return 1, 8
+    if f == 125:
+        return 1, 16
+    if f in (250, 500, 1000):
+        return 5, 16
+    return 3, 128
+
+
+def recipe_network_of(recipe: str, centre_hz: float):
+    saved = RECIPE
+    globals()['RECIPE'] = recipe
+    try:
+        return recipe_network(centre_hz)
+    finally:
+        globals()['RECIPE'] = saved
+
+
+def build_net(device, delays, common_decay_times, centre_hz: float = 500.0):
     from diffgfdn_amd.config import CouplingMatrixType, FeedbackLoopConfig, OutputFilterConfig
     from diffgfdn_amd.model import DiffGFDNVarReceiverPos
     fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=True)
-    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=5, num_neurons_per_layer=16,
+    hidden, neurons = recipe_network(centre_hz)
+    of = OutputFilterConfig(use_svfs=False, num_hidden_layers=hidden, num_neurons_per_layer=neurons,
                             num_fourier_features=20)
     return DiffGFDNVarReceiverPos(FS, G, delays, device, fl, of, use_absorption_filters=False,
                                   common_decay_times=common_decay_times, use_colorless_loss=True).to(device)
@@ -182,7 +212,7 @@ def build_workload(device, seed: int, num_receivers: int = NUM_RECEIVERS, centre
     np.random.seed(seed)
     cfg = DiffGFDNConfig(num_groups=G, num_delay_lines=G * NPER, sample_rate=FS, seed=23463 + int(centre_hz))
     delays = cfg.delay_length_samps
-    net = build_net(device, delays, room['common_decay_times'])
+    net = build_net(device, delays, room['common_decay_times'], centre_hz)
     tc = trainer_config(centre_hz)
     filt = torch.tensor(octave_band_response(centre_hz, FS, NFFT), device=device).to(torch.complex64)
     train_idx, valid_idx, test_idx = split_dataset(data, 0.8, test_ratio=0.1)
@@ -746,9 +776,17 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH,
                     help='receivers per band and step on one GPU (the reference trains with 32, trainer.py:373-379; other '
                          'values measure what a rank of a strong-scaling job steps: DESIGN.md section 7)')
-    ap.add_argument('--bands', type=int, default=len(BAND_CENTRES),
+    ap.add_argument('--recipe', choices=('baseline', 'reference'), default='baseline',
+                    help='baseline: BASELINE.md\'s configuration (7 bands, N = 16, the 5 x 16 gain network in every band: the '
+                         'headline); reference: the sub-band driver\'s own (run_subband_training_treble.py:61-73, :105-154, '
+                         ':392: 8 bands, N = 12 = 3 x 4, per-band gain networks 1 x 8 / 1 x 16 / 5 x 16 / 3 x 128)')
+    ap.add_argument('--bands', type=int, default=None,
                     help='octave bands stepped together (1 = BASELINE.json configs[1], the 500 Hz band alone)')
     args = ap.parse_args()
+    if args.recipe == 'reference':
+        globals().update(RECIPE='reference', G=3, BAND_CENTRES=REFERENCE_RECIPE_CENTRES)
+    if args.bands is None:
+        args.bands = len(BAND_CENTRES)
     if args.lines_per_group != NPER:
         globals()['NPER'] = args.lines_per_group
     if args.batch != BATCH:
@@ -1143,11 +1181,13 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
                                                steps=args.cpu_steps)
     # ---- the other two BASELINE.json configurations on the same clock (N = 1, default run): short sub-records
     if world == 1 and not sub_record and not args.no_extras and not args.epoch and use_bank and nbands == len(BAND_CENTRES) \
-            and NPER == 4:
+            and NPER == 4 and RECIPE is None:
         del step, trainer, data, net
         torch.cuda.empty_cache()
         out.setdefault('extra', {})
         out['extra']['n32'] = sub_bench(args, device, 'n32')
+        torch.cuda.empty_cache()
+        out['extra']['reference_recipe'] = sub_bench(args, device, 'recipe')
         torch.cuda.empty_cache()
         out['extra']['directional'] = sub_bench(args, device, 'directional')
     return out
@@ -1170,6 +1210,19 @@ def sub_bench(args, device, which):
         keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'whole_step_hbm_frac')
         rec = {k: r[k] for k in keep}
         rec['config'] = {k: r['config'][k] for k in ('workload', 'delay_lines', 'rirs_per_s', 'final_loss')}
+    elif which == 'recipe':
+        saved = (RECIPE, G, BAND_CENTRES)
+        globals().update(RECIPE='reference', G=3, BAND_CENTRES=REFERENCE_RECIPE_CENTRES)
+        a.bands = len(REFERENCE_RECIPE_CENTRES)
+        try:
+            r = run_omni(a, device, 0, 1, [0], [0], sub_record=True)
+        finally:
+            globals().update(RECIPE=saved[0], G=saved[1], BAND_CENTRES=saved[2])
+        rec = {k: r[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'whole_step_hbm_frac')}
+        rec['config'] = {k: r['config'][k] for k in ('workload', 'delay_lines', 'rirs_per_s', 'final_loss')}
+        rec['config']['gain_networks'] = {str(int(f)): '%d x %d' % recipe_network_of('reference', f)
+                                          for f in REFERENCE_RECIPE_CENTRES}
+        rec['config']['ms_per_band_step'] = r['ms_per_step'] / len(REFERENCE_RECIPE_CENTRES)
     else:
         r = run_directional(a, device, 0, 1)
         rec = {k: r[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup')}

@@ -174,6 +174,9 @@ class FusedBankStep:
     # sweep behind it (no dot products left to do) in place of the three scan launches + gfdn_lin_gamma_dots (which stay
     # for windows beyond the launch's 49 152 samples).
     edc_one_launch = True
+    # Round 6: the gain network in front of the energy pass on the side stream (None: only for banks whose bands have their
+    # own network sizes, where the network's launch is the long one)
+    network_first = None
     # (b) normalize OFF the critical chain: T is bilinear in b, c and the transform is linear, so the normalisation scale can
     # join the group signals where the forward transform's LAST pass stores them.  The energy pass then runs on the side
     # stream beside the group responses and the transform's first two passes instead of in front of them (~28 us of chain).
@@ -534,10 +537,18 @@ class FusedBankStep:
                 keep.append(rgain0)
             if late:
                 if gfold:
-                    # (4-line blocks: the pass over the bins, the gain network, then the finish with the gains)
+                    # (4-line blocks: the pass over the bins, the gain network, then the finish with the gains.  A bank with
+                    # the reference's per-band networks -- three bands of 3 x 128 neurons -- runs the network FIRST: its
+                    # launch is the longer of the two (33 us alone, 76 beside the energy pass and the transform passes when
+                    # it started behind the pass: the EDR launch waited 45 us for the gains))
+                    net_first = self.network_first if self.network_first is not None else bool(getattr(bank, 'mixed_networks', False))
+                    if net_first:
+                        rgain0, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh,
+                                                               n_hidden, G, lo, hi, rows, nb)
                     ework = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, phase=1, dturn=gridK.dturn)
-                    rgain0, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh, n_hidden,
-                                                           G, lo, hi, rows, nb)
+                    if not net_first:
+                        rgain0, xhat, rstd = ops.mlp_gains_fwd(data['norm_listener_position'], bank._freq_pi, w, Hh,
+                                                               n_hidden, G, lo, hi, rows, nb)
                     keep.append(rgain0)
                     _, scale, rgain = ops.tf_energy(gridK.turns, gridK.logr, coef_sub, delays, n, b, c, want_energy=False,
                                                     work=ework, phase=2, dturn=gridK.dturn, gains=rgain0, G=G)

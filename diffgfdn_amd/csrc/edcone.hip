@@ -77,24 +77,25 @@ __device__ __forceinline__ void e1_load4(const float* base, int j, float (&o)[E1
 #pragma unroll
   for (int v = 0; v < E1_V; ++v) o[v] = j + v >= 0 ? base[j + v] : 0.f;
 }
-// The two group signals (tau_{2h}, tau_{2h+1}) of the band at the samples j .. j + 3 (zeros for signals >= G and samples
-// j + v < 0).  QUAD: the band's signals fill whole pairs (s0 even, G even): the row `tp` holds the two signals interleaved
-// sample by sample -- two 16-byte loads; else: scalar loads from the pair-interleaved store `tf`.
-template <bool QUAD>
-__device__ __forceinline__ void e1_load_tau2(const float* tp, const float* tf, int ld_tau, int s0, int G, int h, int j,
-                                             float (&ta)[E1_V], float (&tb)[E1_V]) {
-  if (QUAD && j >= 0) {
+// The band's group signals live in the pair-interleaved store tau2 (signal s = row s >> 1, component s & 1).  A band's G <= 4
+// signals s0 .. s0 + G - 1 always lie inside TWO consecutive pair rows -- four SLOTS (row A .x, .y, row B .x, .y) starting at
+// signal s0 & ~1 -- whatever the parity of s0 (an odd G puts every second band on an odd signal: the reference's own layout,
+// N = 12 = 3 groups x 4 lines, run_subband_training_treble.py:109): the kernel works on slots, with gain 0 on a slot that
+// belongs to a neighbouring band, and every load is a 16-byte load of two samples x two signals.  (Round 5 fell back to
+// 4-byte loads for an odd G: 206 us for the launch instead of 100 at 8 bands x 3 groups.)
+// Slot pair h (row A: h = 0, row B: h = 1) at the samples j .. j + 3; samples j + v < 0 do not exist (zeros).
+__device__ __forceinline__ void e1_load_tau2(const float* tp, int j, float (&ta)[E1_V], float (&tb)[E1_V]) {
+  if (j >= 0) {
     const e1f4 q0 = e1_ld(tp, 2u * (unsigned)j), q1 = e1_ld(tp, 2u * (unsigned)j + 4u);
     ta[0] = q0.x; tb[0] = q0.y; ta[1] = q0.z; tb[1] = q0.w;
     ta[2] = q1.x; tb[2] = q1.y; ta[3] = q1.z; tb[3] = q1.w;
     return;
   }
-  const int sa = s0 + 2 * h, sb = sa + 1;
 #pragma unroll
   for (int v = 0; v < E1_V; ++v) {
     const bool in = j + v >= 0;
-    ta[v] = (2 * h < G && in) ? tf[((size_t)(sa >> 1) * ld_tau + (j + v)) * 2 + (sa & 1)] : 0.f;
-    tb[v] = (2 * h + 1 < G && in) ? tf[((size_t)(sb >> 1) * ld_tau + (j + v)) * 2 + (sb & 1)] : 0.f;
+    ta[v] = in ? tp[2 * (j + v)] : 0.f;
+    tb[v] = in ? tp[2 * (j + v) + 1] : 0.f;
   }
 }
 
@@ -105,7 +106,6 @@ __device__ __forceinline__ int e1_opaque(int x) {
   return x;
 }
 
-template <bool QUAD>
 __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
   extern __shared__ float e1_lds[];                // [E1_NL][E1_V][E1_T] staged dL/dEDC | scan tables
   float* s_gq = e1_lds;
@@ -125,13 +125,12 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
   const float* xrow = a.xd + (size_t)(a.xrows ? a.xrows[item] : item) * a.ld_xd + a.start;
   const float* trow = a.Tdb + (size_t)(a.trows ? a.trows[item] : item) * a.ld_T;
   const float* mrow = a.maskw ? a.maskw + (size_t)band * a.ld_mask : nullptr;
-  const int s0 = band * G;
+  const int s0 = band * G, sh = s0 & 1, Gs = G + sh;         // slots in use (<= 4: the launcher checks)
   const float* t01 = (const float*)(a.tau2 + (size_t)(s0 >> 1) * a.ld_tau + a.start);
   const float* t23 = t01 + 2 * (size_t)a.ld_tau;
-  const float* tf = (const float*)(a.tau2 + a.start);
-  float rg[E1_MAXG];
+  float rg[E1_MAXG];                                          // gains by SLOT: zero on a neighbouring band's signal
 #pragma unroll
-  for (int g = 0; g < E1_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)item * G + g] : 0.f;
+  for (int g = 0; g < E1_MAXG; ++g) rg[g] = (g >= sh && g - sh < G) ? a.rgain[(size_t)item * G + g - sh] : 0.f;
 
   // scan element e = k TILE + tid V + u  <->  window sample j = L - 1 - e: the thread's group of tile k holds the samples
   // jlo .. jlo + 3 (sample order v), jlo = L - 4 - k TILE - tid V; samples j < 0 do not exist (zeros)
@@ -147,9 +146,9 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
         e1_load4(xrow, jlo, xs[k]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (2 * h < G) {
+          if (2 * h < Gs) {
             float ta[E1_V], tb[E1_V];
-            e1_load_tau2<QUAD>(h ? t23 : t01, tf, a.ld_tau, s0, G, h, jlo, ta, tb);
+            e1_load_tau2(h ? t23 : t01, jlo, ta, tb);
 #pragma unroll
             for (int v = 0; v < E1_V; ++v) xs[k][v] += rg[2 * h] * ta[v] + rg[2 * h + 1] * tb[v];
           }
@@ -290,9 +289,9 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
         if (a.dots) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            if (2 * h < G) {
+            if (2 * h < Gs) {
               float ta[E1_V], tb[E1_V];
-              e1_load_tau2<QUAD>(h ? t23 : t01, tf, a.ld_tau, s0, G, h, jlo, ta, tb);
+              e1_load_tau2(h ? t23 : t01, jlo, ta, tb);
 #pragma unroll
               for (int v = 0; v < E1_V; ++v) {
                 d[2 * h] += out[v] * ta[v];
@@ -322,7 +321,8 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
 #pragma unroll
     for (int i = 0; i < E1_W; ++i) s += s_red[i * 8 + tid];
     if (tid == 0) a.loss_item[item] = s * a.inv_count;
-    else if (a.dots && tid - 1 < G) a.dots[((size_t)item * G + (tid - 1)) * a.ld_dots + a.col] = s;
+    else if (a.dots && tid - 1 >= sh && tid - 1 - sh < G)     // (slot tid - 1 = group tid - 1 - sh)
+      a.dots[((size_t)item * G + (tid - 1 - sh)) * a.ld_dots + a.col] = s;
   }
 }
 
@@ -341,12 +341,10 @@ extern "C" int gfdn_edc_lin_one(const float* xd, int ld_xd, const long long* xro
   Edc1Args a{xd, ld_xd, xrows, (const float2*)tau2, ld_tau, rgain, B, G, nbands * B, start, max_len, item_len, T_db, ld_T,
              target_rows, maskw, ld_mask, inv_count, gscale, loss_item, gx, ld_gx, dots, ld_dots, col};
   const size_t lds = ((size_t)E1_NL * E1_V * E1_T + 2 * E1_NT * E1_W + E1_W * 8) * sizeof(float);
-  // (the band's signals fill whole pairs of the pair-interleaved store: 16-byte loads of two signals)
-  const bool quad = !(G & 1);
-  int rc = quad ? ensure_dyn_lds(k_edc_lin_one<true>, lds) : ensure_dyn_lds(k_edc_lin_one<false>, lds);
+  // (G = 4: every band starts on an even signal; G <= 3: at most one slot of a neighbouring band in front -- four slots)
+  int rc = ensure_dyn_lds(k_edc_lin_one, lds);
   if (rc) return rc;
-  if (quad) hipLaunchKernelGGL(k_edc_lin_one<true>, dim3(nbands * B), dim3(E1_T), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_edc_lin_one<false>, dim3(nbands * B), dim3(E1_T), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_edc_lin_one, dim3(nbands * B), dim3(E1_T), lds, (hipStream_t)stream, a);
   GFDN_LAUNCH_CHECK();
   return 0;
 }

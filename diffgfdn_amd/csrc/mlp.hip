@@ -52,12 +52,24 @@ __device__ __forceinline__ void mlp_encode(const MlpDims& d, int b, const double
   }
 }
 
+// Parameters that stay in memory (a band of 128-neuron layers: 266 KB): ONE round of loads touches every cache line of the
+// set up front.  A step starts with the parameters cold (the optimiser rewrote them on other CUs), and the layer chain then
+// paid an HBM miss per dependent access -- rows, bias, gamma, beta of every layer: 83 us for the launch from cold caches
+// against 32 warm.  The value is kept alive through a condition that never holds.
+__device__ __forceinline__ float mlp_touch(const float* __restrict__ w, int P) {
+  float t = 0.f;
+  for (int p = threadIdx.x * 32; p < P; p += (int)blockDim.x * 32) t += w[p];
+  return t;
+}
+
 // One receiver (item b) by a whole workgroup.  w: the band's packed parameters; xout / rout: where this receiver's saved
 // activations (nl, H) / (nl) go.
 __device__ __forceinline__ void mlp_fwd_block(const MlpDims& d, int b, const double* __restrict__ pos,
                                               const float* __restrict__ freq_pi, const float* __restrict__ w,
                                               float* __restrict__ gains, float* __restrict__ xout,
                                               float* __restrict__ rout) {
+  // (a chain of dependent steps launched beside kernels that fill every SIMD: see k_mlp_fwd_waves)
+  __builtin_amdgcn_s_setprio(3);
   const int amax = d.in_dim > d.H ? d.in_dim : d.H;
   float* a = mlp_lds;            // current activations
   float* h = a + amax;           // pre-norm outputs
@@ -68,8 +80,12 @@ __device__ __forceinline__ void mlp_fwd_block(const MlpDims& d, int b, const dou
   // Likewise the saved activations go to LDS first and to memory once at the end: every
   // __syncthreads() waits for ALL outstanding global stores of the wave (vmcnt covers stores on
   // gfx9), so a store inside the layer loop costs a full write round trip per barrier.
-  float* xs = xout;
-  float* rsv = rout;
+  float* xs = red + 16;          // (parameters in memory: the saved activations still wait in LDS -- a global store inside the
+  float* rsv = xs + d.nl * H;    // layer loop is a write round trip at every barrier behind it)
+  if (!d.stage) {
+    const float t = mlp_touch(w, (int)mlp_param_count(d));
+    if (t == 1.2345678e38f) rout[0] = t;
+  }
   if (d.stage) {
     float* wl = red + 16;
     const int P = (int)mlp_param_count(d);
@@ -91,12 +107,22 @@ __device__ __forceinline__ void mlp_fwd_block(const MlpDims& d, int b, const dou
     if (!d.stage) {
       // parameters in memory (layers of 128 neurons: 266 KB per band): the waves take the neurons, the LANES the inputs --
       // one coalesced row read per neuron (a thread per neuron walks its own row: every load touches H cache lines)
+      // (eight neurons per round: their row loads are in flight together -- one neuron at a time was one L2 round trip
+      // per neuron, 16 us per layer -- and the wave sums run on the VALU, not through the LDS crossbar)
       const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
-      for (int jj = wv; jj < H; jj += nw) {
-        float part = 0.f;
-        for (int i = lane; i < n_in; i += 64) part += W[(size_t)jj * n_in + i] * a[i];
-        part = wave_sum(part);
-        if (lane == 0) h[jj] = part + bias[jj];
+      for (int j0 = wv * 8; j0 < H; j0 += nw * 8) {
+        float part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          part[u] = 0.f;
+          if (j0 + u < H)
+            for (int i = lane; i < n_in; i += 64) part[u] += W[(size_t)(j0 + u) * n_in + i] * a[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float sum = wave_sum_full(part[u]);
+          if (lane == 0 && j0 + u < H) h[j0 + u] = sum + bias[j0 + u];
+        }
       }
       __syncthreads();
       if (j < H) hv = h[j];
@@ -119,16 +145,28 @@ __device__ __forceinline__ void mlp_fwd_block(const MlpDims& d, int b, const dou
   }
   const float* Wout = w + mlp_layer_off(d, d.nl);
   const float* bout = Wout + (size_t)d.G * H;
-  for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
-    float raw = bout[g];
-    for (int i = 0; i < H; ++i) raw += Wout[(size_t)g * H + i] * a[i];
-    // hi <= lo: no output activation (the SVF network hands its raw outputs to the SVF -> biquad map)
-    gains[(size_t)b * d.G + g] = d.hi > d.lo ? d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw))) : raw;
+  if (!d.stage) {
+    // (parameters in memory: a wave per output, the lanes over its row -- one thread walking a row of 128 weights was 128
+    // dependent loads, 60 us of the launch)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    for (int g = wv; g < d.G; g += nw) {
+      float part = 0.f;
+      for (int i = lane; i < H; i += 64) part += Wout[(size_t)g * H + i] * a[i];
+      const float raw = wave_sum_full(part) + bout[g];
+      if (lane == 0)
+        gains[(size_t)b * d.G + g] = d.hi > d.lo ? d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw))) : raw;
+    }
+  } else {
+    for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
+      float raw = bout[g];
+      for (int i = 0; i < H; ++i) raw += Wout[(size_t)g * H + i] * a[i];
+      // hi <= lo: no output activation (the SVF network hands its raw outputs to the SVF -> biquad map)
+      gains[(size_t)b * d.G + g] = d.hi > d.lo ? d.lo + (d.hi - d.lo) * (1.0f / (1.0f + expf(-raw))) : raw;
+    }
   }
-  if (d.stage) {
-    for (int p = threadIdx.x; p < d.nl * H; p += blockDim.x) xout[p] = xs[p];
-    for (int p = threadIdx.x; p < d.nl; p += blockDim.x) rout[p] = rsv[p];
-  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < d.nl * H; p += blockDim.x) xout[p] = xs[p];
+  for (int p = threadIdx.x; p < d.nl; p += blockDim.x) rout[p] = rsv[p];
 }
 
 __global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpDims d, const double* __restrict__ pos,
@@ -238,6 +276,7 @@ __device__ __forceinline__ void mlp_bwd_block(const MlpDims& d, int b, const dou
                                               const float* __restrict__ gains, const float* __restrict__ xhat,
                                               const float* __restrict__ rstd, const float* __restrict__ ggains,
                                               float* __restrict__ gout) {
+  __builtin_amdgcn_s_setprio(3);
   const int amax = d.in_dim > d.H ? d.in_dim : d.H;
   float* aprev = mlp_lds;        // activations entering the current layer
   float* da = aprev + amax;      // gradient w.r.t. the current layer's output (H)
@@ -247,6 +286,10 @@ __device__ __forceinline__ void mlp_bwd_block(const MlpDims& d, int b, const dou
   const int H = d.H, G = d.G;
   const size_t P = mlp_param_count(d);
   float* gp = gout;
+  if (!d.stage) {
+    const float t = mlp_touch(w, (int)P);
+    if (t == 1.2345678e38f) gout[0] = t;
+  }
   if (d.stage) {                 // parameters and this receiver's saved activations -> LDS, one load round
     float* wl = red + 16;
     float* xl = wl + P;
@@ -337,15 +380,48 @@ __device__ __forceinline__ void mlp_bwd_block(const MlpDims& d, int b, const dou
         aprev[i] = fmaxf(xhat[(size_t)(l - 1) * H + i] * gam_p[i] + bet_p[i], 0.f);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
-      const float ai = aprev[i];
+    if (!d.stage && (int)blockDim.x >= 2 * n_in) {
+      // parameters in memory (128-neuron layers): the workgroup's threads as (neuron group, input) -- with one thread per
+      // input walking all H neurons, 128 threads of 512 made 128 dependent load / store round trips per layer (the launch
+      // took 219 us); here every thread takes H / groups neurons, eight rows in flight, and the partial sums of dL/da
+      // meet in LDS (``red2``: groups x n_in floats behind the vectors, which the launcher sizes)
+      const int ngrp = (int)blockDim.x / n_in, grp = threadIdx.x / n_in, i = threadIdx.x - grp * n_in;
+      float* red2 = red + 16;
       float acc = 0.f;
-      for (int jj = 0; jj < H; ++jj) {
-        const float v = dh[jj];
-        gp[offW + (size_t)jj * n_in + i] = v * ai;      // coalesced over i
-        acc += W[(size_t)jj * n_in + i] * v;
+      if (grp < ngrp) {
+        const float ai = aprev[i];
+        for (int j0 = grp * 8; j0 < H; j0 += ngrp * 8) {
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = j0 + u < H ? W[(size_t)(j0 + u) * n_in + i] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (j0 + u < H) {
+              const float v = dh[j0 + u];
+              gp[offW + (size_t)(j0 + u) * n_in + i] = v * ai;
+              acc += wv[u] * v;
+            }
+          }
+        }
+        red2[grp * n_in + i] = acc;
       }
-      if (l > 0) da[i] = acc;
+      __syncthreads();
+      if (l > 0 && threadIdx.x < n_in) {
+        float sum = 0.f;
+        for (int q = 0; q < ngrp; ++q) sum += red2[q * n_in + threadIdx.x];
+        da[threadIdx.x] = sum;
+      }
+    } else {
+      for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
+        const float ai = aprev[i];
+        float acc = 0.f;
+        for (int jj = 0; jj < H; ++jj) {
+          const float v = dh[jj];
+          gp[offW + (size_t)jj * n_in + i] = v * ai;      // coalesced over i
+          acc += W[(size_t)jj * n_in + i] * v;
+        }
+        if (l > 0) da[i] = acc;
+      }
     }
     __syncthreads();
   }
@@ -575,6 +651,8 @@ static size_t mlp_lds_bytes(const MlpDims& d) {
   const int amax = d.in_dim > d.H ? d.in_dim : d.H;
   size_t n = (size_t)amax + 2 * (size_t)d.H + d.G + 16;
   if (d.stage) n += 2 * mlp_param_count(d) + (size_t)d.nl * d.H + d.nl;   // weights [+ gradient partials] + saved activations
+  else n += 64 * MLP_RB + (size_t)d.nl * d.H + d.nl;                      // partial sums of dL/da (one per thread) /
+                                                                          // saved activations of the forward
   return n * sizeof(float);
 }
 

@@ -64,8 +64,10 @@ static int adam_step_run(float* p, const float* g, float* m, float* v, const uns
     GFDN_LAUNCH_CHECK();
     return 0;
   }
-  int blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  // (eight elements per thread: a workgroup ends with a fence and an atomic on ONE counter -- 800 workgroups of one
+  // element per thread took 31 us for 200 000 parameters, most of it the 800 fences and serialised counter adds)
+  int blocks = (n + 2047) / 2048;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, seg, lr_seg, step_count, n,
                      beta1, beta2, eps, 0, block_counter, mirror);
   GFDN_LAUNCH_CHECK();

@@ -126,7 +126,10 @@ def test_gain_networks_of_different_sizes_in_one_launch(ops, Bper):
         assert torch.equal(gains[sl], gq), q
         assert torch.equal(xhat[xo:xo + Bper * nl * H[q]], xq.reshape(-1)) and torch.equal(rstd[ro:ro + Bper * nl], sq.reshape(-1))
         gwq = ops.mlp_gains_bwd(pos, fpi, wq, H[q], nh[q], G, -1.0, 1.0, gq, xq, sq, gg[sl].contiguous(), rq)
-        assert torch.equal(gw[wo:wo + counts[q]], gwq), q
+        if H[q] <= 64:
+            assert torch.equal(gw[wo:wo + counts[q]], gwq), q
+        else:       # (512 threads split a layer's neurons into four groups, the band's own launch into fewer: another order)
+            assert float((gw[wo:wo + counts[q]] - gwq).abs().max()) <= 1e-5 * float(gwq.abs().max()), q
         # partial rows x column scale == the summed, scaled rows (another summation order: float32 rounding)
         ggq = (parts.view(nb * Bper, G, -1).sum(-1)[sl] * cs[q * G:(q + 1) * G][None, :]).contiguous()
         gwq2 = ops.mlp_gains_bwd(pos, fpi, wq, H[q], nh[q], G, -1.0, 1.0, gq, xq, sq, ggq, rq)
