@@ -287,7 +287,7 @@ def test_full_size_bank_distinct_decay_windows_vs_oracle():
               {k.replace("output_scalars.mlp.model.", "mlp."): f"{v:.1e}" for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("nper", [4, 8])
+@pytest.mark.parametrize("nper", [4, 8, "recipe"])
 def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
     """EXACTLY what bench.py times: 7 octave bands x 32 receivers per step = 224-item launches, the 5 x 16 gain network
     on 20 Fourier features, bench.py's own workload builder, one replay of the captured explicit bank step (slot order,
@@ -298,14 +298,25 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
     cores (csrc/blocktf8.hip: k_tf8_pass<*>, k_tf8_rec_grads) -- the step that configuration's number is measured on.
     Gradients of the gains and of the gain network to 2e-4 of their largest entry, dL/dM to the bound DESIGN.md section 2
     derives (it is the SKEW part of the matrix-exponential adjoint of dL/d(Q Q), whose largest entry is two orders of
-    magnitude above dL/dM's)."""
+    magnitude above dL/dM's).
+    nper = "recipe": ``bench.py --recipe reference`` -- the sub-band driver's OWN configuration
+    (run_subband_training_treble.py:61-73, :105-154, :392): eight bands 63 Hz ... 8 kHz, N = 12 = 3 groups x 4 lines (every
+    second band starts on an odd signal of the pair-interleaved stores), every band its own gain network (1 x 8, 1 x 16,
+    5 x 16, 3 x 128) in ONE bank: k_mlp_bands_fwd / _bwd, the slot form of k_edc_lin_one."""
     import bench
     from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    recipe = nper == "recipe"
+    G = 3 if recipe else 4                        # (shadows the module's G = 4 below)
+    if recipe:
+        nper = 4
+        monkeypatch.setattr(bench, "RECIPE", "reference")
+        monkeypatch.setattr(bench, "G", 3)
+        monkeypatch.setattr(bench, "BAND_CENTRES", bench.REFERENCE_RECIPE_CENTRES)
     monkeypatch.setattr(bench, "NPER", nper)
     dev = torch.device("cuda", 0)
     R7, B7, nfeat = 40, bench.BATCH, 20
     centres = bench.BAND_CENTRES
-    assert len(centres) == 7 and B7 == 32
+    assert len(centres) == (8 if recipe else 7) and B7 == 32
     nets, datas, filts, rooms, delays_l = [], [], [], [], []
     for q, f in enumerate(centres):
         room, data, net, _, _, filt, delays = bench.build_workload(dev, 1234 + q, R7, centre_hz=f, room_seed=q,
@@ -313,7 +324,7 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
         nets.append(net), datas.append(data), filts.append(filt), rooms.append(room), delays_l.append(delays)
     sd0 = [{k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for net in nets]
     bank = BandBank(nets)
-    assert bank.num_delay_lines_per_group == nper and bank.num_delay_lines == 4 * nper
+    assert bank.num_delay_lines_per_group == nper and bank.num_delay_lines == G * nper and bank.mixed_networks == recipe
     tr = BandBankTrainer(bank, bench.trainer_config(500.0, 20, train_dir="/tmp/gfdn_full/t7"),
                          subband_filter_freq_resp=torch.stack(filts), band_names=[int(f) for f in centres])
     assert tr._fused is not None                 # the explicit step, not the autograd fallback
@@ -338,15 +349,19 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
     worst_all = {}
     # the seven oracle steps side by side in worker processes (tests/oracle_jobs.py)
     from tests.oracle_jobs import run_grid_steps
-    oracle = run_grid_steps([_oracle_job(sd0[q], q, rooms[q], datas[q], sels[q], filts[q], keep, delays_l[q], nfeat)
-                             for q in range(len(centres))], workers=4)
+    jobs = [_oracle_job(sd0[q], q, rooms[q], datas[q], sels[q], filts[q], keep, delays_l[q], nfeat)
+            for q in range(len(centres))]
+    for j in jobs:
+        j["G"] = G
+    oracle = run_grid_steps(jobs, workers=4)
     try:
         for q in range(len(centres)):
             parts_hip = {k: float(v[q]) for k, v in out.items() if k.endswith("_loss")}
             grads_hip = {"input_gains": views[id(bank.input_gains)][q].reshape(N, 1),
                          "output_gains": views[id(bank.output_gains)][q].reshape(N, 1),
                          "feedback_loop.M": views[id(bank.feedback_loop_M)][q]}
-            gw, o = views[id(bank.output_scalars_w)][q], 0
+            wflat = views[id(bank.output_scalars_w)].reshape(-1)
+            gw, o = wflat[bank._w_off[q]:bank._w_off[q + 1]], 0
             names = [n_ for n_, _ in nets[q].output_scalars.mlp.model.named_parameters()]
             for n_, prm in zip(names, bank._mlp_params[q]):
                 grads_hip["output_scalars.mlp.model." + n_] = gw[o:o + prm.numel()].reshape(tuple(prm.shape))
@@ -355,7 +370,7 @@ def test_full_size_bench_shape_vs_oracle(nper, monkeypatch):
             parts, grads, after = oracle[q]
             worst = _check(f"bench[N={N}, {int(centres[q])} Hz]", parts_hip, grads_hip, after_hip,
                            {k: v.numpy() for k, v in sd0[q].items()}, parts, grads, after, grad_tol=2e-4,
-                           grad_tol_M=GRAD_TOL_M[nper])
+                           grad_tol_M=GRAD_TOL_M[nper])     # (the recipe's 4-line blocks: the N = 16 bound)
             for name in ("input_gains", "output_gains"):
                 assert rel_err(after_hip[name], after[name].numpy()) < 1e-4, (q, name)
             for k, v in worst.items():
