@@ -958,14 +958,19 @@ def run_band_sharded(args, device, rank, world, centres):
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
+        # The side work must not sit on the training ranks' clock: this rank reports to the closing barrier AT ONCE
+        # (asynchronously) and runs validation batches only until that barrier completes -- i.e. until every training rank
+        # has finished its timed steps -- and its own interval does not enter the maximum over the ranks.  (Round 5 ran
+        # ``steps`` host-launched validation steps between the two barriers: the line's time was max(training, validation).)
+        closing = dist.barrier(async_op=True)
         if vtr is not None:
-            for _ in range(args.steps):           # (as many validation batches as the others take training steps)
+            while not closing.is_completed() and vrirs < 1000 * BATCH * args.steps:
                 vtr.valid_step(vbatch)
                 vrirs += BATCH
             torch.cuda.synchronize()
         vsec = time.perf_counter() - t0
-        dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        closing.wait()
+        t = torch.zeros(1, device=device, dtype=torch.float64)         # (this rank trained nothing: no share in the maximum)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rirs = len(centres) * BATCH * args.steps / elapsed

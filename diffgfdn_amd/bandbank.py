@@ -157,6 +157,9 @@ class BandBank(nn.Module):
         grid = FrequencyGrid.of(z)
         ops.subfdn_normalize(grid.turns, grid.logr, self._blocks().detach(), self.delays,
                              self.input_gains.data.view(-1), self.output_gains.data.view(-1))
+        # (the kernel rescales b, c through raw pointers: say so to whoever keeps derived state of them -- the explicit step's
+        # records that outlive a step compare tensor versions, bankstep.FusedBankStep.records_ok)
+        torch.autograd.graph.increment_version((self.input_gains, self.output_gains))
 
     def rotations(self):
         """(Q, QQ) (bands*G, n, n): Q_g = expm(skew(M_g)), QQ_g = Q_g Q_g (feedback_loop.py:393-404)."""
@@ -827,6 +830,8 @@ class BandBankTrainer:
                 from .trainer import reduce_epoch_losses
                 agg_v = reduce_epoch_losses(agg_v, self.process_group)
             tl = (sum(agg_t.values()) / max(nsteps, 1)).tolist()      # one sync per epoch
+            from .losses import raise_on_unit_grad_violation
+            raise_on_unit_grad_violation()                             # (the autograd path's unit-gradient promise)
             vl = (sum(agg_v.values()) / max(nv, 1)).tolist() if agg_v else [0.0] * nb
             self.individual_train_loss.append({k: (v / max(nsteps, 1)).tolist() for k, v in agg_t.items()})
             self.individual_valid_loss.append({k: (v / max(nv, 1)).tolist() for k, v in agg_v.items()})

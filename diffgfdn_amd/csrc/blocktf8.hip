@@ -791,12 +791,12 @@ __global__ __launch_bounds__(256) void k_tf8_param_grads(const float* __restrict
 // dL/db[i] thread 128 + i, dL/dc[j] thread 192 + j, dL/dM[e] thread e) -> Q = expm(skew(M_new)), Q Q and a snapshot of the
 // updated output gains (what the next step's forward pass reads while its normalize rescales them) -- one workgroup per
 // block; the last one advances the step counter.
+// (no __restrict__ on M, Q, gM, Qn, QQn: M is a view of the flat parameter buffer this launch steps through ``ad``, and the
+// caller hands the SAME buffers as Q / Qn (the records that outlive the step) -- as k_tf_tail of blocktf.hip)
 __global__ __launch_bounds__(256) void k_tf8_tail(const float* __restrict__ part0, const float* __restrict__ part1, int n,
-                                                  const float* __restrict__ M, const float* __restrict__ gQ,
-                                                  const float* __restrict__ Q, float* __restrict__ gb,
-                                                  float* __restrict__ gc, float* __restrict__ gM, int half2, TfAdam ad,
-                                                  float* __restrict__ Qn, float* __restrict__ QQn,
-                                                  float* __restrict__ c_next) {
+                                                  const float* M, const float* __restrict__ gQ, const float* Q,
+                                                  float* __restrict__ gb, float* __restrict__ gc, float* gM, int half2,
+                                                  TfAdam ad, float* Qn, float* QQn, float* __restrict__ c_next) {
   extern __shared__ double t8p_lds[];
   __shared__ float srec[2][T8_ACC], sG[2][64], sM[64];
   const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;

@@ -141,22 +141,34 @@ _default_targets = DecayTargets()
 
 
 # ``unit_grad=True`` promises that the loss enters the final scalar with weight 1 (the saved dloss/dH is handed on as it
-# is, one pass over it saved).  The promise is CHECKED wherever a host read is allowed -- outside stream capture -- so a
-# caller that rescales the total (gradient accumulation, loss scaling, a 1 / world factor) gets an error instead of an
-# unscaled EDC gradient next to correctly scaled colorless gradients.
-# The check reads the device (a host sync inside backward: it drains the stream and serialises the side-stream overlap the
-# eager multi-stream steps are built around), so it runs for the FIRST calls of a process only -- a caller that rescales the
-# total does so from its first step on -- and again whenever CHECK_UNIT_GRAD is set to an integer number of further calls.
-# (A stream capture cannot be checked; its warm-up steps are eager and are.)
-CHECK_UNIT_GRAD = 8
+# is, one pass over it saved).  The promise is CHECKED on EVERY backward call, without a host read: a one-element compare on
+# the device ORs "the upstream gradient was not 1" into a per-device flag (captured into HIP graphs like any other launch, so
+# replayed steps are checked too), and the flag is read where the host synchronises anyway -- the trainers' epoch ends,
+# ``raise_on_unit_grad_violation()`` -- so a caller that rescales the total (gradient accumulation, loss scaling, a 1 / world
+# factor) gets an error instead of an unscaled EDC gradient next to correctly scaled colorless gradients.  (Round 5 read the
+# device inside backward -- a host sync that drains the side streams -- and therefore checked the first eight calls of a
+# process only: a second trainer, or one that enabled a loss scale later, was never checked.)
+_UNIT_GRAD_FLAGS = {}
 
 
 def _assert_unit_upstream(g: torch.Tensor):
-    global CHECK_UNIT_GRAD
-    if CHECK_UNIT_GRAD and g.is_cuda and not torch.cuda.is_current_stream_capturing():
-        if CHECK_UNIT_GRAD is not True:
-            CHECK_UNIT_GRAD = int(CHECK_UNIT_GRAD) - 1
-        if not bool(torch.all(g == 1)):
+    if not g.is_cuda:
+        return
+    key = g.device.index
+    flag = _UNIT_GRAD_FLAGS.get(key)
+    if flag is None:
+        if torch.cuda.is_current_stream_capturing():
+            return                    # (first call inside a capture: no allocation there; the warm-up steps ran before it)
+        flag = _UNIT_GRAD_FLAGS[key] = torch.zeros((), dtype=torch.bool, device=g.device)
+    flag.logical_or_((g != 1).any())
+
+
+def raise_on_unit_grad_violation():
+    """Reads the per-device flags (a host sync: call where the host waits for the device anyway) and raises if a decay loss
+    evaluated with ``unit_grad=True`` was back-propagated with an upstream gradient other than 1 since the last call."""
+    for key, flag in _UNIT_GRAD_FLAGS.items():
+        if bool(flag):
+            flag.zero_()
             raise RuntimeError("decay losses were evaluated with unit_grad=True but their total is back-propagated with an "
                                "upstream gradient other than 1: evaluate them with unit_grad=False to rescale the total")
 

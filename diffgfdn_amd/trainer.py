@@ -298,6 +298,8 @@ class Trainer:
             agg_t = reduce_epoch_losses(agg_t, self.process_group)
             agg_v = reduce_epoch_losses(agg_v, self.process_group)
             agg_t = {k: float(v) / nt for k, v in agg_t.items()}     # one sync per epoch
+            from .losses import raise_on_unit_grad_violation
+            raise_on_unit_grad_violation()                            # (the decay losses' unit-gradient promise, checked here)
             agg_v = {k: float(v) / nv for k, v in agg_v.items()}
             self.train_loss.append(sum(agg_t.values()))
             self.valid_loss.append(sum(agg_v.values()))

@@ -31,3 +31,5 @@ def _drain_device_between_tests(request):
             torch.cuda.synchronize()
             gc.collect()
             torch.cuda.synchronize()
+            from diffgfdn_amd.losses import raise_on_unit_grad_violation
+            raise_on_unit_grad_violation()       # (every decay-loss backward of the test kept its unit-gradient promise)
