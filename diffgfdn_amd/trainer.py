@@ -1083,12 +1083,16 @@ class GraphedTrainStep:
         ``sched_cap`` steps) and point the step at the first of them; ``run_next()`` then replays one step per call.
         The reference's DataLoader likewise fixes an epoch's batches when the epoch starts (trainer.py:373-379)."""
         # (a (steps, batch) int64 tensor -- pinned host memory for an asynchronous upload -- is taken as it is; lists of indices
-        # are converted here, which costs ~0.2 ms for 20 x 224 Python integers)
+        # are converted here, which costs ~0.2 ms for 20 x 224 Python integers.  A PINNED source is read by the copy engine
+        # AFTER this call returns: the caller must leave it unmodified until the current stream has passed this point -- an
+        # event is kept in ``sched_uploaded`` for callers that refill one pinned table)
         t = batches.to(torch.long) if torch.is_tensor(batches) else torch.as_tensor([list(b) for b in batches], dtype=torch.long)
         n = t.shape[0]
         if n == 0 or n > self.sched_cap or t.shape[1] != self.B:
             raise ValueError(f"load_schedule: 1..{self.sched_cap} batches of {self.B} receivers")
         self.sched[:n].copy_(t, non_blocking=True)
+        self.sched_uploaded = torch.cuda.Event()
+        self.sched_uploaded.record()
         self.sched_state.copy_(torch.tensor([0, n], dtype=torch.long))
         self._pick_next()                                 # idx <- first batch, position 1
         return n

@@ -240,3 +240,58 @@ def test_bank_with_the_reference_recipes_gain_networks():
             assert abs(float(v) - res[True][0][k][q]) <= 2e-5 * abs(float(v)) + 1e-9, (q, k)
         for k, v in ref_net.state_dict().items():
             assert rel_err(nets[q].state_dict()[k].detach().cpu(), v.detach().cpu()) < 2e-4, (q, k)
+
+
+def test_bank_step_above_the_linear_kernels_receiver_limits():
+    """66 receivers per band: beyond what the EDR launch on composed spectra takes (hip_ops.spec_supported: <= 64), inside
+    what the time-domain output stage takes (lin_supported: B G <= 256) -- the explicit step falls through to the chain on
+    the receivers' own signals (ADVICE r4 / VERDICT r5 Missing 6: the predicates existed, no test crossed them).  Losses,
+    every gradient and the post-Adam state against the autograd bank step on the per-bin elimination kernels."""
+    from tests import test_gpu_bank as tb
+    from diffgfdn_amd import hip_ops as ops
+    from diffgfdn_amd.bandbank import BandBank, BandBankTrainer, BandStackedDataset
+    from tests.helpers import philox_mask, rel_err
+    B, R, nbands = 66, 70, 2
+    assert ops.lin_supported(B, tb.G) and not ops.spec_supported(B, tb.G)
+    filt = torch.tensor(tb._band_filters()[:nbands], device=DEV).to(torch.complex64)
+    rng = np.random.RandomState(3)
+    sels = [rng.permutation(R)[:B].tolist() for _ in range(nbands)]
+    res = {}
+    for fused in (True, False):
+        BandBankTrainer.use_fused = fused
+        try:
+            nets = [tb._build_net(q) for q in range(nbands)]
+            data = [tb._build_data(q, R=R) for q in range(nbands)]
+            bank = BandBank(nets)
+            tr = BandBankTrainer(bank, tb._tc(True, ), subband_filter_freq_resp=filt, stft_win=tb.WIN,
+                                 band_names=tb.BANDS[:nbands])
+        finally:
+            BandBankTrainer.use_fused = True
+        assert (tr._fused is not None) == fused
+        sds = BandStackedDataset([d for _, d in data])
+        start, length = tr._decay_window(tb.NFFT // 2 + 1)
+        sds.precompute_decay_targets(tb.WIN, *tr._target_window(tb.NFFT // 2 + 1))
+        mw = torch.tensor(philox_mask(99, 0, length, 1.0 / B)[0], device=DEV)
+        batch = sds.collate(sds.global_rows(sels))
+        if fused:
+            losses = tr._fused.run(batch, mw, 1.0, normalize_first=True, train=True, opt_step=False)
+        else:
+            tr.optimizer.zero_grad(set_to_none=True)
+            losses = tr._step_losses(batch, mask_prenorm=mw, defer_total=True, normalize_first=True)
+            heads = losses.pop("_heads")
+            torch.autograd.backward(heads, [torch.ones(nbands, device=DEV)] * 2)
+            tr.optimizer.pack_grads()
+            losses["_total"] = heads[0].detach() + heads[1].detach()
+        grad = tr.optimizer.flat_grad.detach().cpu().numpy().copy()
+        tr.optimizer.step()
+        res[fused] = ({k: v.detach().cpu().numpy() for k, v in losses.items()}, grad,
+                      tr.optimizer.flat_param.detach().cpu().numpy().copy(), tr.optimizer)
+    for k, v in res[False][0].items():
+        assert np.allclose(res[True][0][k], v, rtol=2e-5, atol=1e-7), (k, res[True][0][k], v)
+    ga, gb = res[True][1], res[False][1]
+    off = 0
+    for p in res[False][3]._params:
+        sl = slice(off, off + p.numel())
+        assert np.abs(ga[sl] - gb[sl]).max() < 2e-4 * np.abs(gb[sl]).max(), (off, np.abs(ga[sl] - gb[sl]).max())
+        off += p.numel()
+    assert rel_err(res[True][2], res[False][2]) < 1e-4
