@@ -206,15 +206,11 @@ __global__ __launch_bounds__(256) void k_tf_ortho_coefs(const float* __restrict_
   extern __shared__ double tfh_lds[];
   __shared__ float lQQ[16];
   double* A = tfh_lds;
-  double* P = A + n * n;
-  double* R = P + n * n;
-  double* T = R + n * n;
-  double* tmp = T + n * n;
   const int blk = blockIdx.x;
   const float* Mg = M + (size_t)blk * n * n;
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) A[e] = skew_elem(Mg, n, e / n, e % n);
   __syncthreads();
-  const double* E = expm_lds(A, P, R, T, tmp, n);
+  const double* E = expm_lds(A, n);
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     Q[(size_t)blk * n * n + e] = (float)E[e];
     const int i = e / n, j = e - i * n;
@@ -254,7 +250,7 @@ extern "C" int gfdn_tf_ortho_coefs(const float* M, const float* inv_gamma, const
                                    int nper, float* Q, float* QQ, float* coef, float* coef_sub, void* stream) {
   if (!M || !b || !c || !Q || !QQ || !coef || nblk <= 0 || nper <= 0) return GFDN_E_BADARG;
   if (nper > 4) return GFDN_E_UNSUPPORTED;
-  const size_t lds = ((size_t)4 * nper * nper + nper + 2) * sizeof(double);
+  const size_t lds = expm_lds_doubles(nper) * sizeof(double);
   hipLaunchKernelGGL(k_tf_ortho_coefs, dim3(nblk), dim3(256), lds, (hipStream_t)stream, M, nper, inv_gamma, b, c, Q, QQ,
                      coef, coef_sub);
   GFDN_LAUNCH_CHECK();
@@ -493,13 +489,9 @@ __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int n
   // ---- the next step's head on the updated block (k_tf_ortho_coefs)
   {
     double* A = tfp_lds;
-    double* P = A + n * n;
-    double* R = P + n * n;
-    double* T = R + n * n;
-    double* tmp = T + n * n;
     for (int e = tid; e < n * n; e += blockDim.x) A[e] = skew_elem(sM, n, e / n, e % n);
     __syncthreads();
-    const double* E = expm_lds(A, P, R, T, tmp, n);
+    const double* E = expm_lds(A, n);
     for (int e = tid; e < n * n; e += blockDim.x) {
       Qn[off + e] = (float)E[e];
       const int i = e / n, j = e - i * n;
@@ -536,7 +528,7 @@ extern "C" int gfdn_tf_tail(const float* A0, const float* inv_gamma0, const floa
   TfBwdSet s1{A1, nullptr, grec1, nullptr};
   TfAdam ad{flat_p, flat_m, flat_v, seg, lr_seg, step_count, block_counter, offM, offb, offc, beta1, beta2, eps};
   size_t lds = ortho_bwd_lds_doubles(nper);
-  const size_t lds_head = (size_t)4 * nper * nper + nper + 2;
+  const size_t lds_head = expm_lds_doubles(nper);
   if (lds_head > lds) lds = lds_head;
   hipLaunchKernelGGL(k_tf_tail, dim3(nblk), dim3(256), lds * sizeof(double), (hipStream_t)stream, s0, s1, nparts0, b, c, nper,
                      M, gQ, Q, gb, gc, gM, ad, Q_next, QQ_next, coef_next, coef_sub_next);

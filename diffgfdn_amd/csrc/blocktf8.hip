@@ -830,13 +830,9 @@ __global__ __launch_bounds__(256) void k_tf8_tail(const float* __restrict__ part
   __syncthreads();
   {
     double* A = t8p_lds;
-    double* P = A + n * n;
-    double* R = P + n * n;
-    double* T = R + n * n;
-    double* tmp = T + n * n;
     for (int e = tid; e < n * n; e += blockDim.x) A[e] = skew_elem(sM, n, e / n, e % n);
     __syncthreads();
-    const double* E = expm_lds(A, P, R, T, tmp, n);
+    const double* E = expm_lds(A, n);
     for (int e = tid; e < n * n; e += blockDim.x) {
       Qn[off + e] = (float)E[e];
       const int i = e / n, j = e - i * n;

@@ -17,14 +17,10 @@ extern __shared__ double ortho_lds[];
 __global__ __launch_bounds__(256) void k_ortho_fwd(const float* __restrict__ M, int n,
                                                    float* __restrict__ Q, float* __restrict__ QQ) {
   double* A = ortho_lds;
-  double* P = A + n * n;
-  double* R = P + n * n;
-  double* T = R + n * n;
-  double* tmp = T + n * n;
   const float* Mg = M + (size_t)blockIdx.x * n * n;
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) A[e] = skew_elem(Mg, n, e / n, e % n);
   __syncthreads();
-  const double* E = expm_lds(A, P, R, T, tmp, n);
+  const double* E = expm_lds(A, n);
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     if (Q) Q[(size_t)blockIdx.x * n * n + e] = (float)E[e];
     if (QQ) {
@@ -47,7 +43,7 @@ __global__ __launch_bounds__(512) void k_ortho_bwd(const float* __restrict__ M, 
                   Qsaved ? Qsaved + off : nullptr, gM_add ? gM_add + off : nullptr, gM + off);
 }
 
-static size_t ortho_fwd_lds(int n) { return ((size_t)4 * n * n + n + 2) * sizeof(double); }
+static size_t ortho_fwd_lds(int n) { return expm_lds_doubles(n) * sizeof(double); }
 static size_t ortho_bwd_lds(int n) { return ortho_bwd_lds_doubles(n) * sizeof(double); }
 
 extern "C" int gfdn_ortho_fwd(const float* M, int G, int n, float* Q, float* QQ, void* stream) {
