@@ -81,6 +81,10 @@ LINEAR_ALG_BYTES_PER_RIR = FRAMES * NF * (8 + 4) + 2 * 4 * EDC_LEN          # = 
 # transformed direct path (32 frames x 2049 bins x 8 B) and the target EDR (x 4 B) = 786 816 B; the band's group spectra in
 # and the band's gradient spectra out (29 MB per launch together) are shared by the band's 32 receivers and NOT counted.
 DOMINANT_KERNEL = 'k_edr_lin_wave'
+# ... and beside it, on the side stream, the EDC term's register-resident launch (csrc/edcone.hip, k_edc_lin_one).  The two run
+# beside each other and whichever starts second is stretched: the roofline leg brackets BOTH with HIP events, names the one
+# that is longer in the step (``roofline.kernel``) and reports the pair's window and bytes (``roofline.pair``).
+PAIR_KERNELS = ('k_edr_lin_wave', 'k_edc_lin_one')
 # Algorithmic HBM bytes per RIR and launch of the step's per-receiver kernels (what each MUST read and write):
 ALG_BYTES_PER_UNIT = {
     'k_edr_lin_wave': FRAMES * NF * (8 + 4),                                   # Sd, target EDR in (the G sums out: per band)
@@ -104,7 +108,7 @@ ALG_BYTES_PER_UNIT = {
 }
 ROOFLINE_EAGER_STEPS = 20
 CPU_BASELINE_THREADS = 16            # the torch CPU path anti-scales beyond this on the 2x64-core host
-PROFILE_TAG = 'r05'
+PROFILE_TAG = 'r06'
 REFERENCE_EPOCH_S_PER_BAND = 139.1   # reference trainer, N = 16, 8 vCPU, one band, one epoch
 
 
@@ -426,6 +430,31 @@ def pmc_traffic_bytes(kernel: str, table: str = 'pmc_hbm_bytes.csv'):
     return int(float(r['hbm_traffic_MB']) * 1e6)
 
 
+def replayed_durations():
+    """{kernel: average microseconds inside the replayed step} from the committed kernel trace, or None"""
+    path = _profile('step_kernel_durations.csv')
+    if path is None:
+        return None
+    return {r['kernel']: float(r['avg_us_in_step']) for r in csv.DictReader(open(path))}
+
+
+def replayed_pair_window():
+    """first start -> last end of the pair in ONE replayed step (profiles/<tag>_graph_step_timeline.txt), microseconds"""
+    path = _profile('graph_step_timeline.txt')
+    if path is None:
+        return None
+    lo, hi = None, None
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 6 and any(k in line for k in PAIR_KERNELS):
+            try:
+                a, b = float(f[0]), float(f[1])
+            except ValueError:
+                continue
+            lo, hi = (a if lo is None else min(lo, a)), (b if hi is None else max(hi, b))
+    return None if lo is None else hi - lo
+
+
 def step_traffic():
     """PMC traffic (2 x FETCH_SIZE + WRITE_SIZE) summed over the launches of ONE replayed 7-band step, from the committed
     profiles (tools/make_profiles.py writes it beside the per-kernel table) or None"""
@@ -498,6 +527,30 @@ def isolated_kernel_us(device, data, trainer, rows, nbands, iters: int = 30):
                                   nsplit=trainer._fused._edr_runs(nbands, items // nbands))
         else:
             ops.edr_lin_loss(Sd, idx, Stau, rgain, nbands, T_edr, sum_abs, 1.0, True, dots=parts, col0=nch, tiled=tiled)
+    return ops.kernel_timer.stop()
+
+
+def isolated_edc_us(device, data, trainer, rows, nbands, iters: int = 30):
+    """k_edc_lin_one alone on the chip on the step's own stores (transformed direct paths, target EDC)"""
+    from diffgfdn_amd import hip_ops as ops
+    xd = data.direct_time(trainer.subband_filter_freq_resp, K)
+    idx = torch.as_tensor(rows, dtype=torch.long, device=device)
+    items = idx.numel()
+    decay = torch.exp(-torch.arange(K, device=device) / 9000.0)
+    tau = torch.randn((nbands * G + 1) // 2, K, 2, device=device) * 0.01 * decay[None, :, None]
+    rgain = torch.rand(items, G, device=device)
+    start, length = trainer._decay_window(K)
+    T_edc = data.edc_store[1]
+    maskw = torch.full((length,), 1.0 / (items * length), dtype=torch.float32, device=device)
+    parts = torch.empty((items * G, 10), dtype=torch.float32, device=device)
+    item_len, _ = trainer._item_windows(K, items // nbands, device)
+    if item_len is not None:
+        maskw = maskw.repeat(nbands, 1).contiguous()
+    ops.kernel_timer.watch = 'k_edc_lin_one'
+    ops.kernel_timer.start()
+    for _ in range(iters):
+        ops.edc_lin_one(xd, idx, tau, rgain, nbands, K, start, length, T_edc, maskw, 1.0, 10.0, True, trows=idx,
+                        item_len=item_len, dots=parts, col=0)
     return ops.kernel_timer.stop()
 
 
@@ -1077,15 +1130,31 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
         # roofline leg (rank 0): the SAME launch sequence on the same streams, launched from the host so that the
         # dominant kernel can be bracketed by HIP events on its stream -- its duration in the step, beside its
         # duration alone on the chip
-        ktimes, iso = {}, {}
+        ktimes, iso, kpair, iso_pair = {}, {}, {}, {}
         if rank == 0 and use_bank and world == 1 and getattr(trainer, '_fused', None) is not None and not sub_record:
-            hip_ops.kernel_timer.watch = DOMINANT_KERNEL
+            hip_ops.kernel_timer.watch = PAIR_KERNELS
             hip_ops.kernel_timer.start()
             for _ in range(ROOFLINE_EAGER_STEPS):
                 batch = data.collate(draw_n(b_local))
                 trainer._fused.run(batch, step.maskw, 1.0, normalize_first=True, train=True, opt_step=False)
-            ktimes = hip_ops.kernel_timer.stop()
-            iso = isolated_kernel_us(device, data, trainer, draw_n(b_local), nbands)
+            kpair = hip_ops.kernel_timer.stop_multi()
+            iso_pair = {'k_edr_lin_wave': isolated_kernel_us(device, data, trainer, draw_n(b_local), nbands)}
+            try:
+                iso_pair['k_edc_lin_one'] = isolated_edc_us(device, data, trainer, draw_n(b_local), nbands)
+            except Exception as e:                               # noqa: BLE001 -- a diagnostic leg
+                print(f'[bench] isolated EDC launch not measured ({type(e).__name__}: {e})', file=sys.stderr)
+            # the kernel the line names: the one that is LONGER in the REPLAYED step (committed kernel trace of the replayed
+            # graph, profiles/<tag>_step_kernel_durations.csv; the host-launched steps of this leg order the two launches
+            # differently); without a profile, the longer of this leg's brackets
+            prof = replayed_durations()
+            if prof and any(k in prof for k in PAIR_KERNELS):
+                named = max((k for k in PAIR_KERNELS if k in prof and k in kpair), key=lambda k: prof[k], default=None)
+            else:
+                named = max((k for k in PAIR_KERNELS if k in kpair), key=lambda k: kpair[k]['avg_ms'], default=None)
+            if named is not None:
+                ktimes = dict(kpair[named])
+                ktimes['event_pair_overhead_ms'] = iso_pair['k_edr_lin_wave'].get('event_pair_overhead_ms', 0.0)
+                iso = iso_pair.get(named, {})
         ms_per_step = 1e3 * elapsed / args.steps
         rirs_per_s = nbands * b_local * world * args.steps / elapsed
         value = rirs_per_s * FRAMES
@@ -1151,13 +1220,34 @@ def run_omni(args, device, rank, world, ranks_seen, rank_devices, sub_record=Fal
         if epoch_info is not None:
             out['epoch'] = epoch_info
         if ktimes:
+            named = ktimes['kernel']
             units = ktimes['units_per_launch']
-            per = ALG_BYTES_PER_UNIT[DOMINANT_KERNEL]
+            per = ALG_BYTES_PER_UNIT[named]
             in_step_us = ktimes['avg_ms'] * 1e3            # the raw bracket: nothing subtracted
             achieved = units * per / (in_step_us * 1e-6) / 1e9
+            pair = None
+            if 'window' in kpair:
+                alg = sum(kpair[k]['units_per_launch'] * ALG_BYTES_PER_UNIT[k] for k in PAIR_KERNELS if k in kpair)
+                trf = [pmc_traffic_bytes(k) for k in PAIR_KERNELS]
+                wus = kpair['window']['avg_ms'] * 1e3
+                pair = {'kernels': {k: {'in_step_us': kpair[k]['avg_ms'] * 1e3,
+                                        'isolated_us': (iso_pair.get(k, {}).get('avg_ms', float('nan')) * 1e3),
+                                        'alg_bytes_per_launch': kpair[k]['units_per_launch'] * ALG_BYTES_PER_UNIT[k],
+                                        'traffic': pmc_traffic_bytes(k)} for k in PAIR_KERNELS if k in kpair},
+                        'window_us': wus, 'alg_bytes': alg, 'achieved_GBs': alg / wus / 1e3,
+                        'frac': alg / wus / 1e3 / HBM_PEAK_GBS,
+                        'window_us_in_replay': replayed_pair_window(),
+                        'frac_in_replay': ((alg / replayed_pair_window() / 1e3 / HBM_PEAK_GBS)
+                                           if replayed_pair_window() else None),
+                        'traffic': (sum(trf) if all(t is not None for t in trf) else None),
+                        'traffic_frac': ((sum(trf) / wus / 1e3 / HBM_PEAK_GBS) if all(t is not None for t in trf) else None),
+                        'what': 'the two memory-heavy launches of the step run beside each other (main / side stream): window '
+                                '= first start to last end of the pair, HIP events, averaged over the host-launched steps'}
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(DOMINANT_KERNEL),
-                               'kernel': DOMINANT_KERNEL, 'avg_launch_us': in_step_us,
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(named),
+                               'kernel': named, 'avg_launch_us': in_step_us, 'pair': pair,
+                               'kernel_chosen': 'the longer of the pair (k_edr_lin_wave, k_edc_lin_one) in the REPLAYED step '
+                                                f'(profiles/{PROFILE_TAG}_step_kernel_durations.csv); both are bracketed live',
                                'measured': 'HIP events on the launch stream around every launch of the kernel during '
                                            f'{ROOFLINE_EAGER_STEPS} steps of the timed launch sequence (host launches, '
                                            'same streams and concurrency as the replayed graph); raw bracket',

@@ -1693,11 +1693,14 @@ def edc_lin_one(xd, rows, tau2, rgain, nbands: int, n: int, start: int, length: 
         raise RuntimeError("edc_lin_one: dots must be a contiguous float32 (items * G, cols) tensor, col inside it")
     loss_item = torch.empty(items, dtype=_f32, device=xd.device)
     gx = torch.empty((items, length), dtype=_f32, device=xd.device) if want_grad else None
+    end = kernel_timer.bracket('k_edc_lin_one', items)       # (bench.py's roofline leg)
     _lib.check(_lib.load().gfdn_edc_lin_one(_p(xd), xd.stride(0), _p(rows), _p(tau2), n, _p(rgain), nbands, B, G, int(start),
                                             int(length), _p(item_len), _p(T_db), T_db.shape[-1], _p(trows), _p(maskw),
                                             ld_mask, float(inv_count), float(gscale), _p(loss_item), _p(gx), int(length),
                                             _p(dots if want_grad else None), 0 if dots is None else dots.shape[1], int(col),
                                             _stream()), "gfdn_edc_lin_one")
+    if end is not None:
+        end.record()
     return loss_item, gx
 
 
@@ -2565,21 +2568,52 @@ class KernelTimer:
         self.active = self.watch is not None
 
     def bracket(self, name: str, units: int):
-        if self.active and name == self.watch:
+        if self.active and (name == self.watch or (isinstance(self.watch, (tuple, set, frozenset)) and name in self.watch)):
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
-            self._events.append((s, e, units))
+            self._events.append((s, e, units, name))
             s.record()
             return e
         return None
+
+    def stop_multi(self):
+        """Several watched kernels (``watch`` = a tuple of names): {name: stats as stop()} plus, under 'window', the span from
+        the first start to the last end over the k-th launches of all watched kernels (they run beside each other on
+        different streams: the k-th launch of each belongs to the k-th step), averaged over the steps."""
+        self.active = False
+        if not self._events:
+            return {}
+        torch.cuda.synchronize()
+        by = {}
+        for s, e, u, name in self._events:
+            by.setdefault(name, []).append((s, e, u))
+        out = {}
+        for name, evs in by.items():
+            ms = [s.elapsed_time(e) for s, e, _ in evs]
+            out[name] = {'kernel': name, 'launches': len(ms), 'avg_ms': sum(ms) / len(ms), 'min_ms': min(ms),
+                         'units_per_launch': sum(u for _, _, u in evs) / len(evs)}
+        names = list(by)
+        n = min(len(v) for v in by.values())
+        if len(names) > 1 and n > 0:
+            spans = []
+            for k in range(n):
+                starts = [by[nm][k][0] for nm in names]
+                ends = [by[nm][k][1] for nm in names]
+                first = starts[0]
+                for s_ in starts[1:]:
+                    if s_.elapsed_time(first) > 0:          # (s_ was recorded before ``first``)
+                        first = s_
+                spans.append(max(first.elapsed_time(e_) for e_ in ends))
+            out['window'] = {'kernels': names, 'avg_ms': sum(spans) / len(spans), 'min_ms': min(spans), 'steps': n}
+        return out
 
     def stop(self):
         self.active = False
         if not self._events:
             return {}
         torch.cuda.synchronize()
-        ms = [s.elapsed_time(e) for s, e, _ in self._events]
-        units = [u for _, _, u in self._events]
+        ms = [ev[0].elapsed_time(ev[1]) for ev in self._events]
+        units = [ev[2] for ev in self._events]
         # what an event pair with NOTHING between its records measures on this stream: the part of
         # every bracket that is not the kernel (reported beside the raw figure, never hidden)
         empty = []

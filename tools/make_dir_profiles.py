@@ -1,8 +1,8 @@
 """profiles/<tag>_directional_* from the raw rocprofv3 output of tools/run_dir_measurements.sh (gpurun_out/<tag>_dir_*).
-usage: python tools/make_dir_profiles.py [round_tag]   (default r05)"""
+usage: python tools/make_dir_profiles.py [round_tag]   (default r06)"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src, dst = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
 
 

@@ -1,8 +1,8 @@
 """Rebuild profiles/ from the raw rocprofv3 output of tools/run_measurements.sh (gpurun_out/<tag>_*).
-usage: python tools/make_profiles.py [round_tag] [--pre]   (default r05)"""
+usage: python tools/make_profiles.py [round_tag] [--pre]   (default r06)"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 # --pre: the tables bench.py reads at run time only (kernel stats, PMC bytes, timeline, in-step durations) -- run on the
 # GPU box between the profiled runs and the final bench run, so that the bench line is computed from the same call's tables
 PRE = '--pre' in sys.argv[2:]

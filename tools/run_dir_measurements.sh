@@ -1,6 +1,6 @@
 # One gpurun call for the directional configuration's records in profiles/:  bash tools/run_dir_measurements.sh [tag]
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 rm -rf $OUT/${TAG}_dir_stats $OUT/${TAG}_dir_pmc_fetch $OUT/${TAG}_dir_pmc_write

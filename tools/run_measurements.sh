@@ -3,7 +3,7 @@
 # then the tables bench.py reads (tools/make_profiles.py --pre, on the box), then the bench run itself -- its line is
 # computed from this call's own tables.
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
