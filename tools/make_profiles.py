@@ -104,7 +104,7 @@ with open(os.path.join(dst, 'README.md'), 'w') as f:
     f.write(f"""# profiles/ -- round {tag[1:]}
 All `{tag}_*` files come from ONE `gpurun` call (`bash tools/run_measurements.sh {tag}`) on one MI355X (gfx950, ROCm 7.2);
 `bench.py` is the command the driver runs (N = 1, workload = the 7-band configuration BASELINE.json's metric is quoted
-on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r04_*` files are the previous rounds', kept for comparison.
+on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r05_*` files are the previous rounds', kept for comparison.
 
 | file | command | what it holds |
 |---|---|---|
@@ -114,12 +114,13 @@ on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r04_*`
 | `{tag}_graph_step_timeline.txt` | from the kernel trace of the stats run | every kernel of one replayed step with start/end and hardware queue |
 | `{tag}_step_kernel_durations.csv` | from the kernel trace of the stats run | per kernel: launches per step, average duration and microseconds per step over 100 consecutive REPLAYED steps only (what `roofline.top` of the bench line is built from) |
 | `{tag}_directional_bench.json`, `{tag}_directional_kernels.txt`, `{tag}_directional_pmc_hbm_bytes.csv` | `bash tools/run_dir_measurements.sh {tag}` (its own gpurun call) + `python tools/make_dir_profiles.py {tag}` | BASELINE.json configs[3]: the bench line of `python bench.py --config directional` (roofline block of `k_em_bwd` with PMC traffic, CPU baseline with loss and gradient deviations), kernel totals of the graph-replayed band-steps, PMC bytes per launch of its kernels |
-| `{tag}_n32_kernels.txt`, `{tag}_n32_timeline.txt`, `{tag}_n32_kernels_stage1.txt` | `bash tools/run_r5_aux.sh` (`tools/run_n32_profile.sh` + `tools/timeline.py`; its own gpurun call) | kernel totals and one replayed step of the 7-band step at N = 32 (configs[4]); `_stage1`: the same before the polynomial passes became transforms (DESIGN.md section 4.0.6, section 8) |
-| `{tag}_ab_same_box.txt` | `bash tools/run_r5_ab_final.sh` (its own gpurun call) | every switch of the round flipped once on the final code, one box: the same-box A/B figures DESIGN.md sections 4.0.5 / 4.0.6 quote |
+| `{tag}_n32_kernels.txt`, `{tag}_n32_timeline.txt` | `bash tools/run_aux.sh {tag}` (`tools/run_n32_profile.sh` + `tools/timeline.py`; its own gpurun call) | kernel totals and one replayed step of the 7-band step at N = 32 (configs[4]) |
+| `{tag}_recipe_bench.json`, `{tag}_recipe_timeline.txt` | `bash tools/run_aux.sh {tag}` | `bench.py --recipe reference`: the sub-band driver's own configuration (8 bands, N = 12, per-band gain networks) in one bank: bench line and one replayed step |
 | `{tag}_step_traffic.json` | this script | the PMC traffic of ALL launches of one replayed step (`step_traffic_bytes` of the bench line) |
+| `r06_edc_band_experiment.txt` | several gpurun calls of round 6 (`tools/run_ab.sh`, `run_probe.sh`, wall-clock stamps from a probe build) | measured negatives of round 6: the EDC term with the band's receivers inside the workgroup, the gain network on a lane of its own, the side stream's tail reordered (DESIGN.md section 4.3) |
+| `r05_ab_same_box.txt`, `r05_grad_stage_probe.txt`, `r05_n32_kernels_stage1.txt` | round 5 | same-box A/B of round 5's switches; where the float32 deviation of dL/dM enters, stage by stage (DESIGN.md section 2); the N = 32 step before its polynomial passes became transforms |
 | `r02_mfma_experiment.json` (round 2; not repeated since: the kernels it times did not change) | `python tools/mfma_experiment.py` (its own gpurun call) | configs[4]'s bf16 / f32 MFMA contraction against the solve path: time and deviation of H |
-| `{tag}_grad_stage_probe.txt` | `python tests/grad_stage_probe.py` (its own gpurun call) | where the float32 deviation of dL/dM enters, stage by stage (DESIGN.md section 2 (iv)) |
-| `r04_graph_step_timeline_linear_v1.txt`, `_spectral_v1.txt` | as `r04_graph_step_timeline.txt`, earlier in round 4 | the replayed step after the time-domain output stage (0.527 ms) and after the EDR loss on composed spectra (0.473 ms): the intermediate states DESIGN.md's round-4 history cites |
+| `r04_graph_step_timeline_linear_v1.txt`, `_spectral_v1.txt` | as `r04_graph_step_timeline.txt`, earlier in round 4 | the replayed step after the time-domain output stage (0.527 ms) and after the EDR loss on composed spectra (0.473 ms) |
 
 `bench.py` reads `{tag}_pmc_hbm_bytes.csv` (`roofline.traffic`), `{tag}_step_kernel_durations.csv` (`roofline.top`: in-step
 durations) and `{tag}_bench_kernel_stats.csv` (whole-run averages beside them) at run time, so every fraction in the bench
@@ -129,7 +130,7 @@ line can be recomputed from this directory.  Replayed step period in the stats r
 `{bench['value']:.0f} {bench['unit']}` = {bench['ms_per_step']:.4f} ms/step on 1 GPU;
 cpu_baseline {bench.get('cpu_baseline', {}).get('value', float('nan')):.1f} {bench['unit']} ({bench.get('cpu_baseline', {}).get('cores')} threads, kind {bench.get('cpu_baseline', {}).get('kind')}).
 
-## Roofline kernel: `{name}`
+## Roofline kernel: `{name}` (the longer of the pair `k_edr_lin_wave` / `k_edc_lin_one` in the replayed step)
 bench.py, in the step (HIP events around every launch during 20 host-launched steps of the timed launch sequence, raw
 bracket): **{dom.get('avg_launch_us', float('nan')):.1f} us**; alone on the chip: {dom.get('isolated_us', float('nan')):.1f} us;
 rocprofv3 average over {drow['Calls'] if drow else '?'} launches of the stats run: **{float(drow['AverageNs'])/1e3 if drow else float('nan'):.1f} us**
@@ -181,6 +182,6 @@ Algorithmic bytes per launch {dom.get('alg_bytes_per_launch', 0)/1e6:.2f} MB -> 
     for t_, nm, c, mb in sorted(rowsout, reverse=True):
         f.write(f"| `{nm}` | {c} | {mb:.1f} | {t_:.1f} |\n")
     f.write(f"\nSum over the step's launches: **{tot / 1e3:.2f} GB** (SURVEY section 8d bytes: {224 * 2811048 / 1e9:.2f} GB; what the linear "
-            f"step has to move: {224 * 1165696 / 1e9:.2f} GB; round 4: 0.97 GB; round 1: 2.47 GB).  `{tag}_step_traffic.json` holds the same "
+            f"step has to move: {224 * 1165696 / 1e9:.2f} GB; round 5: 0.76 GB; round 4: 0.97 GB; round 1: 2.47 GB).  `{tag}_step_traffic.json` holds the same "
             f"sum built from 100 replayed steps' launch counts: {tot_step / 1e3:.2f} GB.\n")
 print(open(os.path.join(dst, 'README.md')).read()[-3500:])
