@@ -207,8 +207,8 @@ def test_bank_step_equals_band_steps_and_oracle():
                                 subband_filter=filt[q].cpu().to(torch.complex128))
         _, dq = data[q]
         idx = torch.tensor(sels[q])
-        # the dataset front end runs in float32 on the device; the oracle takes ITS responses so that
-        # the comparison isolates the step (the front end has its own parity test, F7)
+        # the oracle takes the dataset's own float64 front end (early_response_c128: the float64 transform of the early
+        # RIRs, as the reference's dataloader computes it) so that the comparison isolates the step
         ob = {"z_values": dq.z_values.cpu(),
               "norm_listener_position": dq.norm_listener_position[idx].cpu(),
               "listener_position": dq.listener_positions[idx].cpu(),
