@@ -30,7 +30,9 @@
 #define E1_TILE (E1_T * E1_V)        // 4096 samples
 #define E1_W (E1_T / 64)             // 16 waves
 #define E1_NT 12                     // tiles per window: L <= 49152
-#define E1_NL 7                      // tiles whose dL/dEDC values wait in LDS (the others in registers; 6: two spills)
+#ifndef E1_NL
+#define E1_NL 9                      // tiles whose dL/dEDC values wait in LDS (144 KB; the others in registers)
+#endif
 #define E1_MAXG 4
 #ifndef E1_SB
 #define E1_SB 2                       // tiles per scheduling group (their loads are in flight together)
@@ -63,6 +65,7 @@ struct Edc1Args {
 // base pointers (scalar base + 32-bit vector offset loads).  With 64-bit per-thread pointers per (array, tile) the compiler
 // kept 12 x 6 address pairs alive across the phases and spilled 500 registers.
 typedef float e1f4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float e1q __attribute__((ext_vector_type(4)));                              // (16-byte aligned: LDS slots)
 __device__ __forceinline__ e1f4 e1_ld(const float* base, unsigned idx) {            // base[idx .. idx + 3], base uniform
   return *(const e1f4*)((const char*)base + (size_t)(idx * 4u));
 }
@@ -106,9 +109,47 @@ __device__ __forceinline__ int e1_opaque(int x) {
   return x;
 }
 
+// exclusive prefix (REV: suffix) sums of the E1_NT x E1_W table of wave totals in its flat order, by wave 0
+static_assert(E1_NT * E1_W == 3 * 64, "e1_table_scan: three entries per lane");
+template <bool REV>
+__device__ __forceinline__ void e1_table_scan(const float* s_w, float* s_c, int w, int lane) {
+  if (w != 0) return;
+  const float a0 = s_w[3 * lane], a1 = s_w[3 * lane + 1], a2 = s_w[3 * lane + 2];
+  float tot;
+  if (!REV) {
+    float prev = __shfl_up((a0 + a1) + a2, 1, 64);
+    if (lane == 0) prev = 0.f;
+    const float pre = wave_scan_incl(prev, tot);             // the entries of the lanes in front
+    s_c[3 * lane] = pre;
+    s_c[3 * lane + 1] = pre + a0;
+    s_c[3 * lane + 2] = (pre + a0) + a1;
+  } else {
+    float next = __shfl_down((a2 + a1) + a0, 1, 64);
+    if (lane == 63) next = 0.f;
+    const float post = wave_scan_incl_rev(next, tot);        // the entries of the lanes behind
+    s_c[3 * lane + 2] = post;
+    s_c[3 * lane + 1] = post + a2;
+    s_c[3 * lane] = (post + a2) + a1;
+  }
+}
+
+// (probe builds only, tools/build_probe_lib.sh ... -DE1_TIMING: wall-clock stamps of the phases, 100 MHz)
+#ifdef E1_TIMING
+__device__ unsigned long long e1_times[1024 * 8];
+#define E1_STAMP(slot)                                                                                                   \
+  do {                                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) e1_times[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();      \
+  } while (0)
+extern "C" int gfdn_probe_edc_one_times(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e1_times), sizeof(unsigned long long) * n);
+}
+#else
+#define E1_STAMP(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
-  extern __shared__ float e1_lds[];                // [E1_NL][E1_V][E1_T] staged dL/dEDC | scan tables
-  float* s_gq = e1_lds;
+  extern __shared__ __attribute__((aligned(16))) float e1_lds[];   // [E1_NL][E1_T][E1_V] staged dL/dEDC | scan tables
+  e1q* s_gq = (e1q*)e1_lds;                        // slot (k, tid): the dL/dEDC values of the thread's group
   float* s_w = e1_lds + (size_t)E1_NL * E1_V * E1_T;            // [E1_NT][E1_W]
   float* s_c = s_w + E1_NT * E1_W;                              // [E1_NT][E1_W] sums in front of (tile, wave)
   float* s_red = s_c + E1_NT * E1_W;                            // [E1_W][8]
@@ -120,6 +161,7 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
     item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  E1_STAMP(0);
   const int band = item / a.B, G = a.G;
   const int L = a.item_len ? a.item_len[item] : a.max_len;
   const float* xrow = a.xd + (size_t)(a.xrows ? a.xrows[item] : item) * a.ld_xd + a.start;
@@ -175,24 +217,25 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
     ex[k] = inc - ex[k];                           // elements of the wave in front of this thread's group
   }
   __syncthreads();
-  // (thread (k, wv) of the first E1_NT waves' worth turns the wave totals into the sums in front of wave wv of tile k:
-  // every thread then reads ONE value per tile -- with each thread walking the 16 totals of all tiles the compiler issued
-  // 192 LDS reads up front and spilled)
-  if (tid < E1_NT * E1_W) {
-    const int k = tid / E1_W, wv = tid % E1_W;
-    float pre = 0.f;
-    for (int kk = 0; kk < k; ++kk)
-      for (int i = 0; i < E1_W; ++i) pre += s_w[kk * E1_W + i];
-    for (int i = 0; i < wv; ++i) pre += s_w[k * E1_W + i];
-    s_c[tid] = pre;
-  }
+  E1_STAMP(1);
+  // s_c[k W + wv] = the sum of the wave totals in front of (tile k, wave wv) = the exclusive prefix of the E1_NT x E1_W
+  // table in its flat order: ONE wave, three consecutive entries per lane, the lanes' sums scanned on the VALU.  (Round 5:
+  // thread (k, wv) walked its up to 191 predecessors itself -- dependent LDS reads, 2.7 + 3.4 us of a 46 us launch by the
+  // wall-clock stamps of a probe build; now 0.3 + 0.4.)
+  e1_table_scan<false>(s_w, s_c, w, lane);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < E1_NT; ++k) ex[k] += s_c[k * E1_W + w];
+  E1_STAMP(2);
   // ---- EDC, dB, |difference|, dL/dEDC (staged: tiles < E1_NL in LDS, the others in registers)
   float gq[E1_NT - E1_NL][E1_V];
   float acc = 0.f;
-  const float gcoef = a.inv_count * a.gscale;
+  // (the dB stage is the launch's largest block of arithmetic -- SQ counters of round 6: 3740 vector instructions per wave,
+  // the vector unit busy in 64 % of the launch's cycles -- so it is written for instruction count: hardware log2 and
+  // reciprocal, 1 ulp each (round 5's __frcp_rn is a full division: 11 instructions behind a branch per sample), one
+  // compare shared by the -200 dB floor and its gradient, the constants folded into the time weight, the sign of the
+  // difference copied as a bit, no per-sample branch)
+  const float gneg = -(a.inv_count * a.gscale) * TEN_OVER_LN10;
   {
     const int jb = e1_opaque(jtop);
 #pragma unroll
@@ -203,29 +246,33 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
         float t4[E1_V], m4[E1_V] = {1.f, 1.f, 1.f, 1.f};
         e1_load4(trow, jlo, t4);
         if (mrow) e1_load4(mrow, jlo, m4);
+        if (jlo < 0) {
+          // (the group that holds the window's first sample: a sample that does not exist is x = 0 with time weight 0 --
+          // the arithmetic below needs no per-sample branch)
+#pragma unroll
+          for (int v = 0; v < E1_V; ++v) if (jlo + v < 0) m4[v] = 0.f;
+        }
         float run = 0.f;
 #pragma unroll
         for (int u = 0; u < E1_V; ++u) {
           const int v = E1_V - 1 - u;
           run += xs[k][v] * xs[k][v];
-          if (jlo + v >= 0) {
-            // (hardware log2 / reciprocal, 1 ulp each: the dB stage is a quarter of the launch's instructions with the
-            // library forms, and the launch is bound by instruction issue, not by memory -- 127 MB in 53 us)
-            const float edc = ex[k] + run;
-            const float lin = fabsf(edc) + F32_EPS;
-            const float raw = 3.0102999566398120f * __log2f(lin);        // 10 log10(lin)
-            const float diff = t4[v] - fmaxf(raw, -200.0f);
-            acc += m4[v] * fabsf(diff);
-            const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-            const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __frcp_rn(lin) : 0.f;
-            gv[v] = -sg * dE * m4[v] * gcoef;
-          }
+          const float lin = fabsf(ex[k] + run) + F32_EPS;
+          const float raw = 3.0102999566398120f * __builtin_amdgcn_logf(lin);        // 10 log10(lin)
+          const bool above = raw > -200.0f;
+          const float diff = t4[v] - (above ? raw : -200.0f);
+          acc += m4[v] * fabsf(diff);
+          // dL/dEDC = -sign(diff) (10 / ln 10) / lin x weight x scale; zero on the floor and where the difference vanishes
+          const float mag = __builtin_amdgcn_rcpf(lin) * (m4[v] * gneg);
+          const float sm = __uint_as_float((__float_as_uint(diff) & 0x80000000u) ^ __float_as_uint(mag));   // sign(diff) mag
+          gv[v] = (above && diff != 0.f) ? sm : 0.f;
         }
       }
       ex[k] = ((gv[0] + gv[1]) + gv[2]) + gv[3];   // the group's sum, in sample order
       if (k < E1_NL) {
-#pragma unroll
-        for (int v = 0; v < E1_V; ++v) s_gq[(size_t)(k * E1_V + v) * E1_T + tid] = gv[v];
+        e1q q;
+        q.x = gv[0]; q.y = gv[1]; q.z = gv[2]; q.w = gv[3];
+        s_gq[(size_t)k * E1_T + tid] = q;
       } else {
 #pragma unroll
         for (int v = 0; v < E1_V; ++v) gq[k >= E1_NL ? k - E1_NL : 0][v] = gv[v];
@@ -243,17 +290,12 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
       ex[k] = inc - ex[k];                         // groups of the wave with smaller sample indices (higher lanes)
     }
     __syncthreads();
-    if (tid < E1_NT * E1_W) {
-      const int k = tid / E1_W, wv = tid % E1_W;
-      float pre = 0.f;
-      for (int kk = E1_NT - 1; kk > k; --kk)
-        for (int i = E1_W - 1; i >= 0; --i) pre += s_w[kk * E1_W + i];
-      for (int i = E1_W - 1; i > wv; --i) pre += s_w[k * E1_W + i];
-      s_c[tid] = pre;
-    }
+    E1_STAMP(3);
+    e1_table_scan<true>(s_w, s_c, w, lane);              // (sums BEHIND (tile, wave), walking down from the last entry)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < E1_NT; ++k) ex[k] += s_c[k * E1_W + w];
+    E1_STAMP(4);
     // ---- dL/dx = 2 x cum, stored once; the EDC part of dL/dgain as dot products with the group signals
     float d[E1_MAXG] = {0.f, 0.f, 0.f, 0.f};
     float* grow = a.gx ? a.gx + (size_t)item * a.ld_gx : nullptr;
@@ -264,8 +306,8 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
       if (jlo > -E1_V) {
         float gv[E1_V], out[E1_V];
         if (k < E1_NL) {
-#pragma unroll
-          for (int v = 0; v < E1_V; ++v) gv[v] = s_gq[(size_t)(k * E1_V + v) * E1_T + tid];
+          const e1q q = s_gq[(size_t)k * E1_T + tid];
+          gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w;
         } else {
 #pragma unroll
           for (int v = 0; v < E1_V; ++v) gv[v] = gq[k >= E1_NL ? k - E1_NL : 0][v];
@@ -316,6 +358,7 @@ __global__ __launch_bounds__(E1_T) void k_edc_lin_one(Edc1Args a) {
     if (lane == 0) s_red[w * 8] = s;
   }
   __syncthreads();
+  E1_STAMP(5);
   if (tid < 1 + E1_MAXG) {
     float s = 0.f;
 #pragma unroll

@@ -195,6 +195,20 @@ __device__ __forceinline__ void edw_rows(float p, float (&P)[4]) {
   P[0] = __uint_as_float(e[0]); P[2] = __uint_as_float(e[1]);
   P[1] = __uint_as_float(o[0]); P[3] = __uint_as_float(o[1]);
 }
+// (probe builds only, tools/build_probe_lib.sh ... -DEDW_TIMING: wall-clock stamps per workgroup, 100 MHz)
+#ifdef EDW_TIMING
+__device__ unsigned long long edw_times[1024 * 4];
+#define EDW_STAMP(slot)                                                                                                  \
+  do {                                                                                                                   \
+    const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                                  \
+    if (threadIdx.x == 0 && wg_ < 1024) edw_times[wg_ * 4 + (slot)] = __builtin_amdgcn_s_memrealtime();                   \
+  } while (0)
+extern "C" int gfdn_probe_edr_wave_times(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edw_times), sizeof(unsigned long long) * n);
+}
+#else
+#define EDW_STAMP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int nframes, int nfreq, float gscale,
                                                                  float* __restrict__ part, int ld_part,
                                                                  float* __restrict__ dots, int ld_dots, int col0,
@@ -239,8 +253,10 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       tn[q] = mv[q] ? tdr[cq[q]] : 0.f;
     }
   };
+  EDW_STAMP(0);
   if (b_lo < b_hi) fetch(b_lo);
   for (int bl = b_lo; bl < b_hi; ++bl) {
+    if (bl == b_lo + 1) EDW_STAMP(1);
     const int b = band * B + bl;
     const size_t rw = a.rows ? (size_t)a.rows[b] : (size_t)b;
     float rg[EDL_MAXG];
@@ -329,6 +345,7 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       }
     }
   }
+  EDW_STAMP(2);
   if (live) {
     float2* out = Gsum + (size_t)split * nbands * G * cells;
 #pragma unroll
