@@ -209,6 +209,31 @@ extern "C" int gfdn_probe_edr_wave_times(unsigned long long* host, int n) {
 #else
 #define EDW_STAMP(slot) do { } while (0)
 #endif
+// Round 6: the launch is bound by VECTOR INSTRUCTION ISSUE, not by memory (SQ counters of the round-5 form alone on the chip:
+// 340 vector instructions per wave and receiver, the vector unit busy in 92 % of the waves' cycles, 176 MB in 59 us), so the
+// receiver loop is written for instruction count:
+//   * FULL (all 32 frames exist: the north-star shape): no frame masks -- the round-5 form guarded each of the thread's four
+//     cells with a branch in the loads and another in the dB stage;
+//   * two receivers per trip of the loop, the prefetched cells alternating between two register sets (no copies);
+//   * gscale / sum_abs of the run's receivers computed once (a lane per receiver) and read back by lane index -- it was a full
+//     division per receiver and wave;
+//   * the rows that enter a thread's two scan offsets selected by 0 / 1 lane constants inside one multiply-add each;
+//   * the dot products <Stau_g, dL/dS> accumulated as (x, y) pairs (packed multiply-adds) and their four wave sums taken
+//     TOGETHER: two exchange steps leave every lane with ONE of the four values (15 instructions instead of 32), lanes 0..3
+//     store them;
+//   * the sign of the difference copied as a bit, one compare shared by the -200 dB floor and its gradient, hardware log2 and
+//     reciprocal.
+// Sums are in a fixed order (bitwise reproducible run to run); they are NOT the round-5 order in the dot products.
+typedef float edw2 __attribute__((ext_vector_type(2)));
+// (every multiply-add of the receiver loop is written out: the loop holds its body twice plus a tail copy, and a compiler
+// free to contract them differently would make a receiver's numbers depend on which copy it runs through)
+__device__ __forceinline__ edw2 edw_fma(float s, edw2 a, edw2 c) { return __builtin_elementwise_fma(edw2{s, s}, a, c); }
+__device__ __forceinline__ edw2 edw_fma2(edw2 a, edw2 b, edw2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <int CTRL>
+__device__ __forceinline__ float edw_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <bool FULL>
 __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int nframes, int nfreq, float gscale,
                                                                  float* __restrict__ part, int ld_part,
                                                                  float* __restrict__ dots, int ld_dots, int col0,
@@ -227,59 +252,71 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
 #pragma unroll
   for (int q = 0; q < EDB_Q; ++q) {
     const int m = EDB_Q * fg + q;
-    mv[q] = m < nframes;
+    mv[q] = FULL || m < nframes;
     cq[q] = (unsigned)edl_cell(mv[q] ? m : 0, fc, nframes, nfreq, a.tiled);
   }
-  float2 st[EDL_MAXG][EDB_Q], Ga[EDL_MAXG][EDB_Q];
+  // (a lane beyond the last frequency works on the last column's cells with zero group spectra: its dot products vanish, its
+  // loss partial is masked, its gradient planes are not stored)
+  edw2 st[EDL_MAXG][EDB_Q], Ga[EDL_MAXG][EDB_Q];
 #pragma unroll
   for (int g = 0; g < EDL_MAXG; ++g)
 #pragma unroll
     for (int q = 0; q < EDB_Q; ++q) {
-      st[g][q] = (g < G && mv[q]) ? (a.Stau + ((size_t)band * G + g) * cells)[cq[q]] : make_float2(0.f, 0.f);
-      Ga[g][q] = make_float2(0.f, 0.f);
+      const float2 v = (g < G && mv[q] && live) ? (a.Stau + ((size_t)band * G + g) * cells)[cq[q]] : make_float2(0.f, 0.f);
+      st[g][q] = edw2{v.x, v.y};
+      Ga[g][q] = edw2{0.f, 0.f};
     }
   const int bper = (B + nsplit - 1) / nsplit;
   const int b_lo = split * bper, b_hi = b_lo + bper < B ? b_lo + bper : B;
-  float2 sn[EDB_Q];
-  float tn[EDB_Q];
-  auto fetch = [&](int bl) {
+  // lane constants of the two scans: which row totals lie behind / in front of this thread's frames
+  const float m_lt1 = row < 1 ? 1.f : 0.f, m_lt2 = row < 2 ? 1.f : 0.f, m_lt3 = row < 3 ? 1.f : 0.f;
+  const float m_gt0 = row > 0 ? 1.f : 0.f, m_gt1 = row > 1 ? 1.f : 0.f, m_gt2 = row > 2 ? 1.f : 0.f;
+  const bool bit0 = lane & 1, bit1 = lane & 2;
+  // lanes 0 .. 3 end up with the dot products of the groups 0, 2, 1, 3 (see the exchange below)
+  const int gl = ((lane & 1) << 1) | ((lane >> 1) & 1);
+  edw2 sA[EDB_Q], sB[EDB_Q];
+  float tA[EDB_Q], tB[EDB_Q];
+  auto fetch = [&](int bl, edw2 (&sn)[EDB_Q], float (&tn)[EDB_Q]) {
     const int b = band * B + bl;
     const size_t rw = a.rows ? (size_t)a.rows[b] : (size_t)b;
     const float2* sdr = a.Sd + rw * cells;
     const float* tdr = a.Tdb + rw * cells;
 #pragma unroll
     for (int q = 0; q < EDB_Q; ++q) {
-      sn[q] = mv[q] ? sdr[cq[q]] : make_float2(0.f, 0.f);
-      tn[q] = mv[q] ? tdr[cq[q]] : 0.f;
+      if (FULL || mv[q]) {
+        const float2 v = sdr[cq[q]];
+        sn[q] = edw2{v.x, v.y};
+        tn[q] = tdr[cq[q]];
+      } else {
+        sn[q] = edw2{0.f, 0.f};
+        tn[q] = 0.f;
+      }
     }
   };
-  EDW_STAMP(0);
-  if (b_lo < b_hi) fetch(b_lo);
-  for (int bl = b_lo; bl < b_hi; ++bl) {
-    if (bl == b_lo + 1) EDW_STAMP(1);
+  float gs_tab = 0.f;                  // lane l: -(10 / ln 10) gscale / sum_abs of the receiver (bl & ~63) + l of this run
+  auto body = [&](int bl, const edw2 (&sc)[EDB_Q], const float (&tc)[EDB_Q], edw2 (&sn)[EDB_Q], float (&tn)[EDB_Q]) {
+#pragma clang fp contract(off)
     const int b = band * B + bl;
-    const size_t rw = a.rows ? (size_t)a.rows[b] : (size_t)b;
+    if (((bl - b_lo) & 63) == 0) {
+      const int bt = bl + lane < b_hi ? bl + lane : b_hi - 1;
+      const size_t rt = a.rows ? (size_t)a.rows[band * B + bt] : (size_t)(band * B + bt);
+      gs_tab = -TEN_OVER_LN10 * (gscale / a.sum_abs[rt]);
+    }
+    const float gsn = readlane_f(gs_tab, (bl - b_lo) & 63);
     float rg[EDL_MAXG];
 #pragma unroll
     for (int g = 0; g < EDL_MAXG; ++g) rg[g] = g < G ? a.rgain[(size_t)b * G + g] : 0.f;
-    const float gs = gscale / a.sum_abs[rw];
-    float2 sv[EDB_Q];
-    float tv[EDB_Q], pw[EDB_Q];
-    float tot = 0.f;
+    edw2 sv[EDB_Q];
+    float pw[EDB_Q];
 #pragma unroll
     for (int q = 0; q < EDB_Q; ++q) {
-      sv[q] = sn[q];
-      tv[q] = tn[q];
+      sv[q] = sc[q];
 #pragma unroll
-      for (int g = 0; g < EDL_MAXG; ++g) {
-        sv[q].x += rg[g] * st[g][q].x;
-        sv[q].y += rg[g] * st[g][q].y;
-      }
-      pw[q] = sv[q].x * sv[q].x + sv[q].y * sv[q].y;
+      for (int g = 0; g < EDL_MAXG; ++g) sv[q] = edw_fma(rg[g], st[g][q], sv[q]);
+      pw[q] = fmaf(sv[q].x, sv[q].x, sv[q].y * sv[q].y);
     }
-    if (bl + 1 < b_hi) fetch(bl + 1);
-#pragma unroll
-    for (int q = EDB_Q - 1; q >= 0; --q) tot += pw[q];
+    if (bl + 1 < b_hi) fetch(bl + 1, sn, tn);
+    const float tot = ((pw[3] + pw[2]) + pw[1]) + pw[0];
     // energy of the frames BEHIND this thread's: the partner group if it is the later one, and the later rows
     float E;
     {
@@ -287,64 +324,77 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       float P[4];
       edw_rows(tot + pt, P);
       E = odd ? 0.f : pt;
-      E += row < 3 ? P[3] : 0.f;
-      E += row < 2 ? P[2] : 0.f;
-      E += row < 1 ? P[1] : 0.f;
+      E = fmaf(m_lt3, P[3], E);
+      E = fmaf(m_lt2, P[2], E);
+      E = fmaf(m_lt1, P[1], E);
     }
-    float acc = 0.f, ge[EDB_Q], gtot = 0.f;
+    float acc = 0.f, ge[EDB_Q];
 #pragma unroll
     for (int q = EDB_Q - 1; q >= 0; --q) {
-      ge[q] = 0.f;
-      if (mv[q]) {
-        E += pw[q];
-        const float lin = fabsf(E) + F32_EPS;
-        const float raw = EDB_DB_PER_LOG2 * __builtin_amdgcn_logf(lin);
-        const float dd = fmaxf(raw, -200.0f);
-        const float diff = tv[q] - dd;
+      E += pw[q];
+      const float lin = fabsf(E) + F32_EPS;
+      const float raw = EDB_DB_PER_LOG2 * __builtin_amdgcn_logf(lin);
+      const bool above = raw > -200.0f;
+      const float diff = tc[q] - (above ? raw : -200.0f);
+      // dL/dE = -sign(diff) (10 / ln 10) / lin x gscale / sum_abs; zero on the floor and where the difference vanishes
+      const float mag = __builtin_amdgcn_rcpf(lin) * gsn;
+      const float sm = __uint_as_float((__float_as_uint(diff) & 0x80000000u) ^ __float_as_uint(mag));
+      if (FULL || mv[q]) {
         acc += fabsf(diff);
-        const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-        const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __builtin_amdgcn_rcpf(lin) : 0.f;
-        ge[q] = -sg * dE * gs;
+        ge[q] = (above && diff != 0.f) ? sm : 0.f;
+      } else {
+        ge[q] = 0.f;
       }
     }
-#pragma unroll
-    for (int q = 0; q < EDB_Q; ++q) gtot += ge[q];
+    const float gtot = ((ge[0] + ge[1]) + ge[2]) + ge[3];
     // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m': the earlier rows, the partner group if it is the earlier one
     float run;
     {
       const float pt = edw_partner(gtot);
       float P[4];
       edw_rows(gtot + pt, P);
-      run = row > 0 ? P[0] : 0.f;
-      run += row > 1 ? P[1] : 0.f;
-      run += row > 2 ? P[2] : 0.f;
+      run = m_gt0 * P[0];
+      run = fmaf(m_gt1, P[1], run);
+      run = fmaf(m_gt2, P[2], run);
       run += odd ? pt : 0.f;
     }
-    float da[EDL_MAXG] = {0.f, 0.f, 0.f, 0.f};
+    edw2 da[EDL_MAXG] = {edw2{0.f, 0.f}, edw2{0.f, 0.f}, edw2{0.f, 0.f}, edw2{0.f, 0.f}};
 #pragma unroll
     for (int q = 0; q < EDB_Q; ++q) {
       run += ge[q];
-      const float p2 = 2.0f * run;
-      const float2 dS = make_float2(p2 * sv[q].x, p2 * sv[q].y);
+      const edw2 dS = (2.0f * run) * sv[q];
 #pragma unroll
       for (int g = 0; g < EDL_MAXG; ++g) {
-        Ga[g][q].x += rg[g] * dS.x;
-        Ga[g][q].y += rg[g] * dS.y;
-        da[g] += st[g][q].x * dS.x + st[g][q].y * dS.y;
+        Ga[g][q] = edw_fma(rg[g], dS, Ga[g][q]);
+        da[g] = edw_fma2(st[g][q], dS, da[g]);
       }
     }
     acc = wave_sum_full(live ? acc : 0.f);
     if (lane == 0) part[(size_t)b * ld_part + col] = acc;
     if (dots) {
-#pragma unroll
-      for (int g = 0; g < EDL_MAXG; ++g) {
-        if (g < G) {
-          const float v = wave_sum_full(live ? da[g] : 0.f);
-          if (lane == 0) dots[((size_t)b * G + g) * ld_dots + col0 + col] = v;
-        }
-      }
+      // the four wave sums together: after an exchange with lane ^ 1 a lane holds two of the four values (summed over the
+      // pair), after one with lane ^ 2 a single one (over the quad); the rest of the wave is summed once
+      const float d0 = da[0].x + da[0].y, d1 = da[1].x + da[1].y, d2 = da[2].x + da[2].y, d3 = da[3].x + da[3].y;
+      float kA = bit0 ? d2 : d0, kB = bit0 ? d3 : d1;
+      kA += edw_dpp<0xB1>(bit0 ? d0 : d2);                  // quad_perm:[1,0,3,2]
+      kB += edw_dpp<0xB1>(bit0 ? d1 : d3);
+      float k = bit1 ? kB : kA;
+      k += edw_dpp<0x4E>(bit1 ? kA : kB);                   // quad_perm:[2,3,0,1]
+      k = dpp_pair_sum<0x124>(k);                           // row_ror:4
+      k = dpp_pair_sum<0x128>(k);                           // row_ror:8
+      k = xor32_sum(xor16_sum(k));
+      if (lane < 4 && gl < G) dots[((size_t)b * G + gl) * ld_dots + col0 + col] = k;
     }
+  };
+  EDW_STAMP(0);
+  if (b_lo < b_hi) fetch(b_lo, sA, tA);
+  int bl = b_lo;
+  for (; bl + 1 < b_hi; bl += 2) {
+    if (bl == b_lo + 2) EDW_STAMP(1);
+    body(bl, sA, tA, sB, tB);
+    body(bl + 1, sB, tB, sA, tA);
   }
+  if (bl < b_hi) body(bl, sA, tA, sB, tB);
   EDW_STAMP(2);
   if (live) {
     float2* out = Gsum + (size_t)split * nbands * G * cells;
@@ -353,7 +403,7 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       if (g < G) {
 #pragma unroll
         for (int q = 0; q < EDB_Q; ++q)
-          if (mv[q]) (out + ((size_t)band * G + g) * cells)[cq[q]] = Ga[g][q];
+          if (FULL || mv[q]) (out + ((size_t)band * G + g) * cells)[cq[q]] = make_float2(Ga[g][q].x, Ga[g][q].y);
       }
     }
   }
@@ -631,8 +681,12 @@ extern "C" int gfdn_edr_lin_loss_gsum(const float* Sd_c64, const long long* rows
   if (G > EDL_MAXG || nframes > EDL_RF || nbands > 65535 || nsplit > 64) return GFDN_E_UNSUPPORTED;
   if (ld_part < nparts || (dots && (col0 < 0 || ld_dots < col0 + nparts))) return GFDN_E_BADARG;
   EdrLin a{(const float2*)Sd_c64, rows, (const float2*)Stau_c64, rgain, B, G, T_db, sum_abs, tiled ? 1 : 0};
-  hipLaunchKernelGGL(k_edr_lin_wave, dim3(nparts / EDW_WG, nbands, nsplit), dim3(64 * EDW_WG), 0, (hipStream_t)stream, a,
-                     nframes, nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
+  if (nframes == EDL_RF)
+    hipLaunchKernelGGL(k_edr_lin_wave<true>, dim3(nparts / EDW_WG, nbands, nsplit), dim3(64 * EDW_WG), 0, (hipStream_t)stream,
+                       a, nframes, nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
+  else
+    hipLaunchKernelGGL(k_edr_lin_wave<false>, dim3(nparts / EDW_WG, nbands, nsplit), dim3(64 * EDW_WG), 0, (hipStream_t)stream,
+                       a, nframes, nfreq, gscale, part, ld_part, dots, ld_dots, col0, (float2*)Gsum_c64, nsplit, nbands);
   GFDN_LAUNCH_CHECK();
   return 0;
 }
