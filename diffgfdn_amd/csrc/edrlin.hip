@@ -225,6 +225,13 @@ extern "C" int gfdn_probe_edr_wave_times(unsigned long long* host, int n) {
 //     reciprocal.
 // Sums are in a fixed order (bitwise reproducible run to run); they are NOT the round-5 order in the dot products.
 typedef float edw2 __attribute__((ext_vector_type(2)));
+typedef float edw4 __attribute__((ext_vector_type(4)));
+#ifndef EDW_GA_LDS
+#define EDW_GA_LDS 1                // the gradient-spectrum accumulators in LDS (0: in registers)
+#endif
+#ifndef EDW_AHEAD2
+#define EDW_AHEAD2 1                // prefetch two receivers ahead, into the register set just used up (0: one ahead)
+#endif
 // (every multiply-add of the receiver loop is written out: the loop holds its body twice plus a tail copy, and a compiler
 // free to contract them differently would make a receiver's numbers depend on which copy it runs through)
 __device__ __forceinline__ edw2 edw_fma(float s, edw2 a, edw2 c) { return __builtin_elementwise_fma(edw2{s, s}, a, c); }
@@ -257,14 +264,27 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
   }
   // (a lane beyond the last frequency works on the last column's cells with zero group spectra: its dot products vanish, its
   // loss partial is masked, its gradient planes are not stored)
-  edw2 st[EDL_MAXG][EDB_Q], Ga[EDL_MAXG][EDB_Q];
+#if EDW_GA_LDS
+  // The thread's share of the G gradient spectra (32 accumulators) lives in LDS as eight 16-byte slots per lane, lane-linear
+  // (no bank conflicts), updated by plain read - multiply-add - write (the lane owns its slots): the LDS pipe has nothing
+  // else to do in this kernel, and the 32 registers hold the second set of prefetched cells instead.
+  __shared__ edw4 s_ga[EDW_WG][EDL_MAXG * EDB_Q / 2][64];
+  edw4 (*ga)[64] = s_ga[wv];
+#else
+  edw2 Ga[EDL_MAXG][EDB_Q];
+#endif
+  edw2 st[EDL_MAXG][EDB_Q];
 #pragma unroll
   for (int g = 0; g < EDL_MAXG; ++g)
 #pragma unroll
     for (int q = 0; q < EDB_Q; ++q) {
       const float2 v = (g < G && mv[q] && live) ? (a.Stau + ((size_t)band * G + g) * cells)[cq[q]] : make_float2(0.f, 0.f);
       st[g][q] = edw2{v.x, v.y};
+#if EDW_GA_LDS
+      if (!(q & 1)) ga[(g * EDB_Q + q) / 2][lane] = edw4{0.f, 0.f, 0.f, 0.f};
+#else
       Ga[g][q] = edw2{0.f, 0.f};
+#endif
     }
   const int bper = (B + nsplit - 1) / nsplit;
   const int b_lo = split * bper, b_hi = b_lo + bper < B ? b_lo + bper : B;
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
     }
   };
   float gs_tab = 0.f;                  // lane l: -(10 / ln 10) gscale / sum_abs of the receiver (bl & ~63) + l of this run
-  auto body = [&](int bl, const edw2 (&sc)[EDB_Q], const float (&tc)[EDB_Q], edw2 (&sn)[EDB_Q], float (&tn)[EDB_Q]) {
+  auto body = [&](int bl, edw2 (&sc)[EDB_Q], float (&tc)[EDB_Q], edw2 (&sn)[EDB_Q], float (&tn)[EDB_Q]) {
 #pragma clang fp contract(off)
     const int b = band * B + bl;
     if (((bl - b_lo) & 63) == 0) {
@@ -315,7 +335,9 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       for (int g = 0; g < EDL_MAXG; ++g) sv[q] = edw_fma(rg[g], st[g][q], sv[q]);
       pw[q] = fmaf(sv[q].x, sv[q].x, sv[q].y * sv[q].y);
     }
+#if !EDW_AHEAD2
     if (bl + 1 < b_hi) fetch(bl + 1, sn, tn);
+#endif
     const float tot = ((pw[3] + pw[2]) + pw[1]) + pw[0];
     // energy of the frames BEHIND this thread's: the partner group if it is the later one, and the later rows
     float E;
@@ -346,6 +368,11 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
         ge[q] = 0.f;
       }
     }
+#if EDW_AHEAD2
+    // (this receiver's cells are used up: the cells of the receiver after the next one take their registers -- two sets,
+    // more than one receiver of lead)
+    if (bl + 2 < b_hi) fetch(bl + 2, sc, tc);
+#endif
     const float gtot = ((ge[0] + ge[1]) + ge[2]) + ge[3];
     // dL/d|S_m|^2 = sum_{m' <= m} dL/dE_m': the earlier rows, the partner group if it is the earlier one
     float run;
@@ -359,6 +386,25 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       run += odd ? pt : 0.f;
     }
     edw2 da[EDL_MAXG] = {edw2{0.f, 0.f}, edw2{0.f, 0.f}, edw2{0.f, 0.f}, edw2{0.f, 0.f}};
+#if EDW_GA_LDS
+#pragma unroll
+    for (int q = 0; q < EDB_Q; q += 2) {
+      run += ge[q];
+      const edw2 dS0 = (2.0f * run) * sv[q];
+      run += ge[q + 1];
+      const edw2 dS1 = (2.0f * run) * sv[q + 1];
+#pragma unroll
+      for (int g = 0; g < EDL_MAXG; ++g) {
+        da[g] = edw_fma2(st[g][q], dS0, da[g]);
+        da[g] = edw_fma2(st[g][q + 1], dS1, da[g]);
+        if (g < G) {
+          edw4 v = ga[(g * EDB_Q + q) / 2][lane];
+          const edw2 lo = edw_fma(rg[g], dS0, edw2{v.x, v.y}), hi = edw_fma(rg[g], dS1, edw2{v.z, v.w});
+          ga[(g * EDB_Q + q) / 2][lane] = edw4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < EDB_Q; ++q) {
       run += ge[q];
@@ -369,6 +415,7 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
         da[g] = edw_fma2(st[g][q], dS, da[g]);
       }
     }
+#endif
     acc = wave_sum_full(live ? acc : 0.f);
     if (lane == 0) part[(size_t)b * ld_part + col] = acc;
     if (dots) {
@@ -388,6 +435,9 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
   };
   EDW_STAMP(0);
   if (b_lo < b_hi) fetch(b_lo, sA, tA);
+#if EDW_AHEAD2
+  if (b_lo + 1 < b_hi) fetch(b_lo + 1, sB, tB);
+#endif
   int bl = b_lo;
   for (; bl + 1 < b_hi; bl += 2) {
     if (bl == b_lo + 2) EDW_STAMP(1);
@@ -403,7 +453,14 @@ __global__ __launch_bounds__(64 * EDW_WG, 4) void k_edr_lin_wave(EdrLin a, int n
       if (g < G) {
 #pragma unroll
         for (int q = 0; q < EDB_Q; ++q)
-          if (FULL || mv[q]) (out + ((size_t)band * G + g) * cells)[cq[q]] = make_float2(Ga[g][q].x, Ga[g][q].y);
+          if (FULL || mv[q]) {
+#if EDW_GA_LDS
+            const edw4 v = ga[(g * EDB_Q + q) / 2][lane];
+            (out + ((size_t)band * G + g) * cells)[cq[q]] = (q & 1) ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+#else
+            (out + ((size_t)band * G + g) * cells)[cq[q]] = make_float2(Ga[g][q].x, Ga[g][q].y);
+#endif
+          }
       }
     }
   }
