@@ -53,5 +53,8 @@ else:
     t = np.array(buf, dtype=np.int64).reshape(1024, 4).astype(np.float64) / 100.0
     t0 = t[:, 0].min()
     print("rc", rc); pr("start", t[:, 0] - t0)
-    pr("prologue+iter0", t[:, 1] - t[:, 0]); pr("iters 1..15", t[:, 2] - t[:, 1]); pr("per iter", (t[:, 2] - t[:, 1]) / 15)
+    t = t[t[:, 0] > 0]                     # (910 workgroups of 1024 slots)
+    t0 = t[:, 0].min()
+    pr("start", t[:, 0] - t0)
+    pr("receivers 0, 1", t[:, 1] - t[:, 0]); pr("receivers 2..15", t[:, 2] - t[:, 1]); pr("per receiver", (t[:, 2] - t[:, 1]) / 14)
     pr("end of loop", t[:, 2] - t0)
