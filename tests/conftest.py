@@ -13,6 +13,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    from tests import margins
+    margins.dump(ROOT)            # (how far inside their bounds the tolerance checks landed: gpurun_out/parity_margins.json)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -4,6 +4,7 @@ colorless_fdn/losses.py:20-73): polynomial records + evaluation, normalisation, 
 adjoint, and the tail through the orthogonal parameterisation."""
 import numpy as np
 import pytest
+from tests.margins import within
 import torch
 
 from tests.helpers import rel_err
@@ -138,7 +139,7 @@ def test_output_stage_adjoint_through_the_parameterisation(n, G, nbands, B, K):
     gM, gb, gc = ops.tf8_param_grads(QQ, ig.to(DEV), part, bp.detach().float().to(DEV), cnow, Mdev, Q=Q)
     assert rel_err(gb.cpu().numpy(), bp.grad.numpy()) < 2e-4
     assert rel_err(gc.cpu().numpy(), cp.grad.numpy()) < 2e-4
-    assert rel_err(gM.cpu().numpy(), Mr.grad.numpy()) < 5e-4
+    within(rel_err(gM.cpu().numpy(), Mr.grad.numpy()), 5e-5, "blocktf8 gM")
     # round 5: the forward pass leaves T' filt and 1 / Q beside T'; the adjoint pass that takes T' and 1 / Q back instead of
     # evaluating the two polynomials again accumulates the same records
     Ts2, _, Hg, Dinv = ops.tf8_tsave(turns, coef, delays.to(DEV), n, cnow, s.to(DEV), nbands, G, quad=False,

@@ -3,6 +3,7 @@ group responses on the reference's grid by transforms and the adjoint, against t
 (functional.ResolventSolve + GroupSums: reference feedback_loop.py:326-391, model.py:209-252) and float64 torch."""
 import numpy as np
 import pytest
+from tests.margins import within
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -93,4 +94,4 @@ def test_directional_model_branch_equals_elimination_path():
                     net.output_gains.grad.clone())
     assert (res[True][0] - res[False][0]).abs().max() < 5e-5 * res[False][0].abs().max()
     for a, b_ in zip(res[True][1:], res[False][1:]):
-        assert (a - b_).abs().max() < 5e-4 * b_.abs().max(), ((a - b_).abs().max(), b_.abs().max())
+        within(float((a - b_).abs().max() / b_.abs().max()), 5e-5, "blocktf9")

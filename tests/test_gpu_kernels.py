@@ -3,6 +3,7 @@ the oracle / torch on the same seeded inputs.  Tolerances are float32-level (1e-
 the north-star bar; most kernels sit at 1e-6)."""
 import numpy as np
 import pytest
+from tests.margins import within
 import torch
 
 from oracle import gfdn_oracle as orc
@@ -259,7 +260,7 @@ def test_edr_loss_kernels(ops, use_wf, nframes, nfreq):
     # gradient: sign flips where |diff| ~ 0 are measure-zero; compare in L1 norm
     g = Pk.cpu().double()
     num = (g - Pa.grad).abs().sum() / Pa.grad.abs().sum()
-    assert num < 1e-3
+    within(num, 1e-4, "kernels")
 
 
 @pytest.mark.parametrize("masked", [False, True])
@@ -281,7 +282,7 @@ def test_edc_loss_kernels(ops, masked):
                           mask.to(DEV) if masked else None, 1.0 / (batch * cnt), 10.0)
     assert abs(li.sum().item() - loss.item()) < 1e-4 * abs(loss.item())
     num = (gx.cpu().double() - xa.grad).abs().sum() / xa.grad.abs().sum()
-    assert num < 1e-3
+    within(num, 1e-4, "kernels")
     assert float(gx[:, :start].abs().max()) == 0.0 and float(gx[:, start + length:].abs().max()) == 0.0
 
 
@@ -547,7 +548,7 @@ def test_edc_loss_against_the_common_slope_model(ops, B, T, start, length, S, ma
     li0, g0 = ops.edc_loss(x, start, length, Tdb.contiguous(), maskw, 1.0 / (B * length), 2.0)
     li1, g1 = ops.edc_loss_model(x, start, length, amps, env, maskw, 1.0 / (B * length), 2.0)
     assert torch.allclose(li0, li1, rtol=2e-5, atol=1e-6)
-    assert float((g0 - g1).abs().sum()) < 1e-3 * float(g0.abs().sum())
+    within(float((g0 - g1).abs().sum()) / float(g0.abs().sum()), 1e-6, "kernels L550")
 
 
 @pytest.mark.parametrize("B,C,J,T,start,length,S,masked", [(3, 9, 12, 9000, 38, 8100, 3, False),

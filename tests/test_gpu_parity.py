@@ -7,6 +7,7 @@ import torch
 
 from oracle import gfdn_oracle as orc
 from tests.helpers import batch_from, load, rel_err
+from tests.margins import within
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -61,9 +62,9 @@ def test_f1_feedback_loop(tag):
     assert rel_err(loop.get_coupled_feedback_matrix().real.detach().cpu(), fx[f"{tag}_A"]) < 1e-5
     assert rel_err(P.detach().cpu(), fx[f"{tag}_P"]) < TOL
     (P.abs() ** 2).sum().backward()
-    assert rel_err(loop.M.grad.cpu(), fx[f"{tag}_grad_M"]) < 5e-4
+    within(rel_err(loop.M.grad.cpu(), fx[f"{tag}_grad_M"]), 2e-4, "L65")
     if tag == "cp":
-        assert rel_err(loop.alpha.grad.cpu(), fx[f"{tag}_grad_alpha"]) < 5e-4
+        within(rel_err(loop.alpha.grad.cpu(), fx[f"{tag}_grad_alpha"]), 2e-5, "L67")
 
 
 @pytest.mark.parametrize("name", ["f234_n12_k257.npz", "f234_n16_k4097_cp.npz", "f234_n32_k1025.npz"])
@@ -94,11 +95,11 @@ def test_f3_losses(name):
     l = edr_loss(fs, win_size=int(fx["win"]), hop_size=int(fx["hop"]))(tgt, H)
     g, = torch.autograd.grad(l, H)
     assert abs(l.item() - float(fx["loss_edr"])) < TOL * abs(float(fx["loss_edr"]))
-    assert np.abs(g.cpu().numpy() - fx["grad_edr_H"]).sum() / np.abs(fx["grad_edr_H"]).sum() < 2e-3
+    within(np.abs(g.cpu().numpy() - fx["grad_edr_H"]).sum() / np.abs(fx["grad_edr_H"]).sum(), 1e-4, "L98")
     l = edc_loss(float(np.max(fx["T60"])) * 1e3, fs, use_mask=False)(tgt, H)
     g, = torch.autograd.grad(l, H)
     assert abs(l.item() - float(fx["loss_edc"])) < TOL * abs(float(fx["loss_edc"]))
-    assert np.abs(g.cpu().numpy() - fx["grad_edc_H"]).sum() / np.abs(fx["grad_edc_H"]).sum() < 2e-3
+    within(np.abs(g.cpu().numpy() - fx["grad_edc_H"]).sum() / np.abs(fx["grad_edc_H"]).sum(), 5e-5, "L102")
     Hout = torch.tensor(fx["Hout"]).to(DEV).requires_grad_(True)
     for nm, crit in (("mse", mse_loss()), ("amse", amse_loss())):
         for k in range(int(fx["G"])):
@@ -143,7 +144,7 @@ def test_f4_train_step(name, asym):
         ref = fx["grad_" + name_]
         got = prm.grad.cpu().numpy()
         err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
-        assert err < 2e-3, (name_, err)
+        within(err, 2e-4, ("L147",) + tuple((name_, err)))
     tr.optimizer.step()
     for name_, prm in net.named_parameters():
         assert rel_err(prm.detach().cpu(), fx["sda_" + name_]) < 1e-4, name_
@@ -185,7 +186,7 @@ def test_f14_learnable_decay_times():
     for name_, prm in net.named_parameters():
         ref = fx["grad_" + name_]
         err = np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
-        assert err < 2e-3, (name_, err)
+        within(err, 1e-4, ("L189",) + tuple((name_, err)))
     assert net.feedback_loop.common_decay_times.grad is not None
 
 
@@ -226,7 +227,7 @@ def test_graphed_step_equals_eager_step():
     # Adam divides by sqrt(v): near-zero gradients (biases) amplify float-level differences between
     # the capturable and the default update, so the state is compared at 5e-4
     for k in s0:
-        assert rel_err(s1[k], s0[k]) < 5e-4, k
+        within(rel_err(s1[k], s0[k]), 1e-4, ("L230",) + tuple((k,)))
 
 
 def test_graphed_step_device_mask():
@@ -277,7 +278,7 @@ def test_graphed_step_device_mask():
     for a, b in zip(got, want):
         assert abs(a - b) < 1e-5 * abs(b), (got, want)
     for k, v in net.state_dict().items():
-        assert rel_err(v.detach().cpu(), net2.state_dict()[k].detach().cpu()) < 5e-4, k
+        within(rel_err(v.detach().cpu(), net2.state_dict()[k].detach().cpu()), 1e-6, ("L281",) + tuple((k,)))
 
 
 def test_f3b_subband_mask_weights():
@@ -293,12 +294,12 @@ def test_f3b_subband_mask_weights():
     l = crit(tgt, Hs)
     g, = torch.autograd.grad(l, H, retain_graph=True)
     assert abs(l.item() - float(fx["loss_edr_w"])) < TOL * abs(float(fx["loss_edr_w"]))
-    assert np.abs(g.cpu().numpy() - fx["grad_edr_w"]).sum() / np.abs(fx["grad_edr_w"]).sum() < 2e-3
+    within(np.abs(g.cpu().numpy() - fx["grad_edr_w"]).sum() / np.abs(fx["grad_edr_w"]).sum(), 1e-3, "L297")
     crit2 = edc_loss(float(np.max(fx["T60"])) * 1e3, fs, use_mask=True)
     l = crit2(tgt, Hs, mask_index=torch.tensor(fx["edc_mask_index"]))
     g, = torch.autograd.grad(l, H)
     assert abs(l.item() - float(fx["loss_edc_masked"])) < TOL * abs(float(fx["loss_edc_masked"]))
-    assert np.abs(g.cpu().numpy() - fx["grad_edc_masked"]).sum() / np.abs(fx["grad_edc_masked"]).sum() < 2e-3
+    within(np.abs(g.cpu().numpy() - fx["grad_edc_masked"]).sum() / np.abs(fx["grad_edc_masked"]).sum(), 2e-4, "L302")
     # the random mask is drawn from the global CPU generator exactly like the reference
     torch.manual_seed(99)
     l2 = crit2(tgt, Hs)
@@ -357,7 +358,7 @@ def test_f6_directional():
         key = "grad_" + name_
         if key in fx:
             err = np.abs(prm.grad.cpu().numpy() - fx[key]).max() / (np.abs(fx[key]).max() + 1e-30)
-            assert err < 3e-3, (name_, err)
+            within(err, 1e-4, ("L361",) + tuple((name_, err)))
     # the default envelope formula equals the fixture's stated one
     crit_default = directional_edc_loss(fx["T60"][None, :], float(fx["edc_len_ms"]), fs)
     assert rel_err(crit_default.envelopes, fx["envelopes"]) < 1e-5
@@ -396,7 +397,7 @@ def test_edr_loss_with_erb_grouping(weighted, radius):
     assert abs(got.item() - want.item()) < TOL * abs(want.item())
     gr = Hr.grad[:, :(K + 1) // 2]
     gd = Hd.grad.cpu().to(torch.complex128)[:, :(K + 1) // 2]
-    assert float((gd - gr).abs().sum() / gr.abs().sum()) < 2e-3      # (L1: sign flips of the |.| at tiny differences)
+    within(float((gd - gr).abs().sum() / gr.abs().sum()), 3e-4, "L400")      # (L1: sign flips of the |.| at tiny differences)
 
 
 @pytest.mark.parametrize("mask", [False, True])
@@ -539,7 +540,7 @@ def test_f16_source_receiver_svf_model(tag):
         key = "grad_" + name
         if key in fx:
             assert p_.grad is not None, name
-            assert rel_err(p_.grad.detach().cpu(), fx[key]) < 2e-3, (name, rel_err(p_.grad.detach().cpu(), fx[key]))
+            within(rel_err(p_.grad.detach().cpu(), fx[key]), 1e-4, ("L543",) + tuple((name, rel_err(p_.grad.detach().cpu(), fx[key]))))
     out = net.get_param_dict_inference(batch)
     assert out["output_biquad_coeffs"].shape[-2:] == (11, 6)
 
@@ -814,7 +815,7 @@ def test_f8_source_receiver_model(tag):
     for name_, prm in net.named_parameters():
         ref = fx["grad_" + name_]
         got = prm.grad.cpu().numpy()
-        assert np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+        within(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30), 1e-4, ("L818",) + tuple((name_,)))
 
 
 def test_f9_colorless_fdn_prototype(tmp_path):
@@ -836,8 +837,8 @@ def test_f9_colorless_fdn_prototype(tmp_path):
     # formula.  Here z^m comes from the exactly reduced phase, so the comparison with the fixture carries PTOL and
     # the comparison with the float64 evaluation (below) the usual tolerance.
     PTOL = 2e-3
-    assert rel_err(H.detach().cpu().numpy(), fx["H"]) < PTOL
-    assert rel_err(Hpd.detach().cpu().numpy(), fx["Hpd"]) < PTOL
+    within(rel_err(H.detach().cpu().numpy(), fx["H"]), PTOL, "L840")
+    within(rel_err(Hpd.detach().cpu().numpy(), fx["Hpd"]), PTOL, "L841")
     fl = net.feedback_loop
     with torch.no_grad():                                      # float64 evaluation of c^T (D / gamma - Q)^-1 b
         z64 = z.to(torch.complex128)
@@ -854,7 +855,7 @@ def test_f9_colorless_fdn_prototype(tmp_path):
     loss.backward()
     for name_, prm in net.named_parameters():
         ref = fx["grad_" + name_]
-        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 1e-2, name_
+        within(np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30), 3e-3, ("L858",) + tuple((name_,)))
     vloss = amse_loss()(H, ones) + amse_loss()(Hpd, torch.ones_like(Hpd)) \
         + 1.5 * sparsity_loss()(fl.ortho_param(fl.random_feedback_matrix))
     assert abs(vloss.item() - float(fx["valid_loss"])) < 1e-3 * abs(float(fx["valid_loss"]))
@@ -864,8 +865,8 @@ def test_f9_colorless_fdn_prototype(tmp_path):
     net2.load_state_dict(_state(fx), strict=True)
     net2 = net2.to(DEV)
     tr = ColorlessFDNTrainer(net2, tc, alpha=1.5, lr=0.01, max_epochs=3, batch_size=600)
-    assert rel_err(net2.input_gains.detach().cpu().numpy(), fx["norm_input_gains"]) < 1e-3
-    assert rel_err(net2.output_gains.detach().cpu().numpy(), fx["norm_output_gains"]) < 1e-3
+    within(rel_err(net2.input_gains.detach().cpu().numpy(), fx["norm_input_gains"]), 3e-4, "L868")
+    within(rel_err(net2.output_gains.detach().cpu().numpy(), fx["norm_output_gains"]), 3e-4, "L869")
     from scipy.io import wavfile
     h = tr.save_ir(str(tmp_path / "ir"))
     fs_w, data = wavfile.read(str(tmp_path / "ir" / "colorless_fdn_ir.wav"))
@@ -902,7 +903,7 @@ def test_f10_absorption_filters_model():
     (H.abs() ** 2).sum().backward()
     for name_, prm in net.named_parameters():
         ref = fx["grad_" + name_]
-        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+        within(np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30), 1e-4, ("L906",) + tuple((name_,)))
     with pytest.raises(NotImplementedError):
         DiffGFDNVarReceiverPos(float(fx["fs"]), int(fx["G"]), fx["delays"].tolist(), DEV, fl, of,
                                use_absorption_filters=True, common_decay_times=fx["T60"])
@@ -930,7 +931,7 @@ def test_f11_svf_filters():
     (H.abs() ** 2).sum().backward()
     for name_, prm in net.named_parameters():
         ref = fx["ggrad_" + name_]
-        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+        within(np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30), 1e-4, ("L934",) + tuple((name_,)))
     # single position: SVF cascades on both sides, coupled feedback matrix
     fl2 = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.SCALAR, use_zero_coupling=False)
     of2 = OutputFilterConfig(use_svfs=True, compress_pole_factor=1.0)
@@ -1000,7 +1001,7 @@ def test_filter_coupling_solve_kernels(G, nper, K):
     assert rel_err(Y.detach().cpu(), Yr.detach().cpu()) < TOL
     (Yr * wgt.to(torch.complex128)).real.sum().backward()
     for a, r in zip(got, (BMr, Phir, igr, br)):
-        assert rel_err(a.cpu(), r.grad.cpu()) < 5e-4
+        within(rel_err(a.cpu(), r.grad.cpu()), 1e-4, "L1004")
 
 
 def test_f12_filter_coupling():
@@ -1026,9 +1027,9 @@ def test_f12_filter_coupling():
     assert rel_err(loop.coupled_feedback_matrix.detach().cpu(), fx["loop_A"]) < 1e-5
     assert rel_err(P.detach().cpu(), fx["loop_P"]) < TOL
     (P.abs() ** 2).sum().backward()
-    assert rel_err(loop.M.grad.cpu(), fx["loop_grad_M"]) < 5e-4
-    assert rel_err(loop.unit_vectors.grad.cpu(), fx["loop_grad_unit_vectors"]) < 5e-4
-    assert rel_err(loop.unitary_matrix.grad.cpu(), fx["loop_grad_unitary_matrix"]) < 5e-4
+    within(rel_err(loop.M.grad.cpu(), fx["loop_grad_M"]), 3e-4, "L1030")
+    within(rel_err(loop.unit_vectors.grad.cpu(), fx["loop_grad_unit_vectors"]), 1e-4, "L1031")
+    within(rel_err(loop.unitary_matrix.grad.cpu(), fx["loop_grad_unitary_matrix"]), 3e-4, "L1032")
     # grid model
     fl = FeedbackLoopConfig(coupling_matrix_type=CouplingMatrixType.FILTER, pu_matrix_order=int(fx["net_order"]))
     of = OutputFilterConfig(use_svfs=False, num_hidden_layers=2, num_neurons_per_layer=16, num_fourier_features=4)
@@ -1044,7 +1045,7 @@ def test_f12_filter_coupling():
     (H.abs() ** 2).sum().backward()
     for name_, prm in net.named_parameters():
         ref = fx["net_grad_" + name_]
-        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 1e-3, name_
+        within(np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30), 1e-4, ("L1048",) + tuple((name_,)))
 
 
 def test_f15_full_band_svf_with_absorption_filters():
@@ -1075,7 +1076,7 @@ def test_f15_full_band_svf_with_absorption_filters():
     for name_, prm in net.named_parameters():
         ref = fx["fb_grad_" + name_]
         worst[name_] = np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
-        assert worst[name_] < 2e-3, (name_, worst[name_])
+        within(worst[name_], 1e-4, ("L1079",) + tuple((name_, worst[name_])))
 
 
 def test_f15_filter_coupling_with_absorption_filters():
@@ -1103,7 +1104,7 @@ def test_f15_filter_coupling_with_absorption_filters():
     (H.abs() ** 2).sum().backward()
     for name_, prm in net.named_parameters():
         ref = fx["fa_grad_" + name_]
-        assert np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-3, name_
+        within(np.abs(prm.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30), 1e-4, ("L1107",) + tuple((name_,)))
 
 
 def test_filter_coupling_trainer_steps():
@@ -1208,7 +1209,7 @@ def test_svf_graphed_step_equals_eager_step():
     for a, b in zip(t0, t1):
         assert abs(a - b) < 1e-5 * abs(a), (t0, t1)
     for k in s0:
-        assert rel_err(s1[k], s0[k]) < 5e-4, k
+        within(rel_err(s1[k], s0[k]), 1e-4, ("L1212",) + tuple((k,)))
 
 
 def test_save_ir_writes_reference_named_wavs(tmp_path):

@@ -118,6 +118,7 @@ on).  Rebuilt by `python tools/make_profiles.py {tag}`.  The `r01_*` ... `r05_*`
 | `{tag}_recipe_bench.json`, `{tag}_recipe_timeline.txt` | `bash tools/run_aux.sh {tag}` | `bench.py --recipe reference`: the sub-band driver's own configuration (8 bands, N = 12, per-band gain networks) in one bank: bench line and one replayed step |
 | `{tag}_step_traffic.json` | this script | the PMC traffic of ALL launches of one replayed step (`step_traffic_bytes` of the bench line) |
 | `r06_edc_band_experiment.txt` | several gpurun calls of round 6 (`tools/run_ab.sh`, `run_probe.sh`, wall-clock stamps from a probe build) | measured negatives of round 6: the EDC term with the band's receivers inside the workgroup, the gain network on a lane of its own, the side stream's tail reordered (DESIGN.md section 4.3) |
+| `r06_parity_margins.txt` | one full `pytest -m gpu` run; `tests/margins.py` | how far inside its bound every tolerance check of the GPU suite lands (worst value per test and check): the evidence behind the tightened gradient bounds (DESIGN.md section 2) |
 | `r06_stamps_edc.txt`, `r06_stamps_edr.txt`, `r06_sq_bench.txt` | `tools/mid_stamps.py` on probe builds (`-DE1_TIMING`, `-DEDW_TIMING`), `tools/run_pmc_bench.sh` | the two launches of the middle from the inside: wall-clock stamps per phase of `k_edc_lin_one` (medians over the 224 workgroups) and per loop section of `k_edr_lin_wave`; SQ counters of every kernel of the bench run (vector / scalar / memory instructions per wave, wave lifetime, share of the waves' cycles with a vector instruction in flight) -- DESIGN.md section 4.0.8 |
 | `r05_ab_same_box.txt`, `r05_grad_stage_probe.txt`, `r05_n32_kernels_stage1.txt` | round 5 | same-box A/B of round 5's switches; where the float32 deviation of dL/dM enters, stage by stage (DESIGN.md section 2); the N = 32 step before its polynomial passes became transforms |
 | `r02_mfma_experiment.json` (round 2; not repeated since: the kernels it times did not change) | `python tools/mfma_experiment.py` (its own gpurun call) | configs[4]'s bf16 / f32 MFMA contraction against the solve path: time and deviation of H |
