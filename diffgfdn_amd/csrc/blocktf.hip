@@ -459,6 +459,19 @@ extern "C" int gfdn_tf_param_grads(const float* A0, const float* inv_gamma0, con
 // reads t = step_count + 1; the LAST workgroup to finish writes t back (every workgroup read it before reporting in) and
 // re-arms the counter.  The rest of the flat buffer (the gain network) is stepped by its own launch on its own counter
 // (FlatAdam.step_range(second=True)).  The updated values go to the next records through LDS, not back through memory.
+// (probe builds only, tools/build_probe_lib.sh ... -DTFT_TIMING: wall-clock stamps of the tail's stages, 100 MHz)
+#ifdef TFT_TIMING
+__device__ unsigned long long tft_times[64 * 8];
+#define TFT_STAMP(slot)                                                                                              \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < 64) tft_times[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+extern "C" int gfdn_probe_tf_tail_times(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tft_times), sizeof(unsigned long long) * n);
+}
+#else
+#define TFT_STAMP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int nparts0, const float* b, const float* c,
                                                  int n, const float* M, const float* gQ, const float* Q, float* gb,
                                                  float* gc, float* gM, TfAdam ad, float* Qn, float* QQn, float* coef0,
@@ -467,18 +480,22 @@ __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int n
   __shared__ float srec[TF_REC], sG[2][16], sM[16], sb[4], sc[4], lQQ[16];
   const int blk = blockIdx.x, tid = threadIdx.x;
   const float t = ad.step_count[0] + 1.0f;
+  TFT_STAMP(0);
+  const size_t off = (size_t)blk * n * n;
   if (nparts0 > 1) {
     tf_sum_record_rows(s0.grec + (size_t)blk * TF_REC * nparts0, nparts0, srec);
   } else if (tid < TF_REC) {
     srec[tid] = s0.grec[(size_t)blk * TF_REC + tid];
   }
   __syncthreads();
+  TFT_STAMP(1);
   tf_coefs_bwd_block(s0, s1, srec, s1.grec ? s1.grec + (size_t)blk * TF_REC : nullptr, b, c, n, blk, tid, gb, gc, sG[0],
                      sG[1]);
   __syncthreads();
-  const size_t off = (size_t)blk * n * n;
+  TFT_STAMP(2);
   ortho_bwd_group(tfp_lds, M + off, n, gQ ? gQ + off : nullptr, sG[0], Q ? Q + off : nullptr, s1.A ? sG[1] : nullptr,
                   gM + off);
+  TFT_STAMP(3);
   // ---- Adam on the block's own entries: every element is updated by the thread that wrote its gradient
   // (tf_coefs_bwd_block: dL/db[i] by thread 32 + i, dL/dc[j] by thread 48 + j; ortho_bwd_group: dL/dM[e] by thread e)
   const float bc1 = 1.0f - powf(ad.b1, t), bc2_sqrt = sqrtf(1.0f - powf(ad.b2, t));
@@ -486,6 +503,7 @@ __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int n
   if (tid >= 32 && tid < 32 + n) sb[tid - 32] = tf_adam_elem(ad, ad.offb + blk * n + tid - 32, gb[blk * n + tid - 32], bc1, bc2_sqrt);
   if (tid >= 48 && tid < 48 + n) sc[tid - 48] = tf_adam_elem(ad, ad.offc + blk * n + tid - 48, gc[blk * n + tid - 48], bc1, bc2_sqrt);
   __syncthreads();
+  TFT_STAMP(4);
   // ---- the next step's head on the updated block (k_tf_ortho_coefs)
   {
     double* A = tfp_lds;
@@ -502,8 +520,10 @@ __global__ __launch_bounds__(256) void k_tf_tail(TfBwdSet s0, TfBwdSet s1, int n
       lQQ[e] = v;
     }
     __syncthreads();
+    TFT_STAMP(5);
     tf_coefs_block(lQQ, s0.ig, coef0, sM, nullptr, coef1, sb, sc, blk, n, tid);
   }
+  TFT_STAMP(6);
   if (tid == 0) {
     __threadfence();
     if (atomicAdd(ad.block_counter, 1u) == gridDim.x - 1) {
