@@ -195,7 +195,12 @@ __device__ __forceinline__ void em_edc_grad(const EmArgs& a, int b, int s, int i
 #pragma unroll
     for (int k = 0; k < EM_SMAX; ++k) ev[k][u] = (in && k < a.S) ? a.env[(size_t)k * a.ld_env + i0 + u] : 0.f;
   }
-  const float gsc = a.inv_count * a.gscale;
+  // (the dB stage written for instruction count, as k_edc_lin_one's (edcone.hip): one compare shared by the -200 dB floor and
+  // its gradient, the constants folded into the time weight, the sign of the difference copied as a bit)
+  const float gneg = -(a.inv_count * a.gscale) * TEN_OVER_LN10;
+  float mg[EM_V];
+#pragma unroll
+  for (int u = 0; u < EM_V; ++u) mg[u] = m[u] * gneg;
 #pragma unroll
   for (int j = 0; j < JT; ++j) {
     // (a direction j >= J of the register tile has a zero row of A: x_dir = 0, and is given the amplitudes of direction 0
@@ -212,14 +217,17 @@ __device__ __forceinline__ void em_edc_grad(const EmArgs& a, int b, int s, int i
 #pragma unroll
       for (int k = 0; k < EM_SMAX; ++k)
         if (k < a.S) tl += am[k] * ev[k][u];
-      const float tdb = fmaxf(EM_DB * __log2f(fabsf(live * tl) + F32_EPS), -200.0f);
+      const float traw = EM_DB * __log2f(fabsf(live * tl) + F32_EPS);
+      const float tdb = traw > -200.0f ? traw : -200.0f;
       const float lin = fabsf(run) + F32_EPS;
       const float raw = EM_DB * __log2f(lin);
-      const float diff = tdb - fmaxf(raw, -200.0f);
+      const bool above = raw > -200.0f;
+      const float diff = tdb - (above ? raw : -200.0f);
       lsum[j] += m[u] * fabsf(diff);
-      const float sg = diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f);
-      const float dE = (raw > -200.0f) ? TEN_OVER_LN10 * __builtin_amdgcn_rcpf(lin) : 0.f;
-      g[j][u] = -sg * dE * m[u] * gsc;
+      // dL/dEDC = -sign(diff) (10 / ln 10) / lin x weight x scale; zero on the floor and where the difference vanishes
+      const float mag = __builtin_amdgcn_rcpf(lin) * mg[u];
+      const float sm = __uint_as_float((__float_as_uint(diff) & 0x80000000u) ^ __float_as_uint(mag));
+      g[j][u] = (above && diff != 0.f) ? sm : 0.f;
     }
   }
 }
