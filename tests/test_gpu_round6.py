@@ -295,3 +295,46 @@ def test_bank_step_above_the_linear_kernels_receiver_limits():
         assert np.abs(ga[sl] - gb[sl]).max() < 2e-4 * np.abs(gb[sl]).max(), (off, np.abs(ga[sl] - gb[sl]).max())
         off += p.numel()
     assert rel_err(res[True][2], res[False][2]) < 1e-4
+
+
+@pytest.mark.parametrize("G,B", [(2, 70), (4, 67)])
+def test_edr_one_launch_with_runs_longer_than_a_wave(ops, G, B):
+    """gfdn_edr_lin_loss_gsum with more than 64 receivers in one run of a band (k_edr_lin_wave keeps gscale / sum_abs of a run's
+    receivers a lane each and refills the table every 64 receivers; an odd run length ends in the loop's tail copy): loss partials,
+    the EDR part of dL/drgain and the gradient spectra against a float64 evaluation of losses.py:430-495, and one run against two
+    (the same bits per receiver)."""
+    gen = torch.Generator(device="cpu").manual_seed(10 * G + B)
+    nb, R, nfr, nf = 2, B + 2, 32, 2049
+    items = nb * B
+    Sd = torch.view_as_complex(torch.randn(nb * R, nfr, nf, 2, generator=gen).to(DEV))
+    Stau = torch.view_as_complex(torch.randn(nb * G, nfr, nf, 2, generator=gen).to(DEV))
+    rgain = torch.randn(items, G, generator=gen).to(DEV)
+    rows = torch.tensor([q * R + int(i) for q in range(nb) for i in torch.randperm(R, generator=gen)[:B]], device=DEV)
+    Pt = torch.rand(nb * R, nfr, nf, generator=gen).to(DEV) * 3 + 0.1
+    T_db, sum_abs = ops.edr_target(Pt.clone())
+    nparts = ops.edr_lin_parts(nf, fused=True)
+    parts1 = torch.zeros(items * G, nparts, device=DEV)
+    part1, Gs1 = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, dots=parts1, col0=0, nsplit=1)
+    parts2 = torch.zeros_like(parts1)
+    part2, Gs2 = ops.edr_lin_loss_gsum(Sd, rows, Stau, rgain, nb, T_db, sum_abs, 1.5, dots=parts2, col0=0, nsplit=2)
+    assert torch.equal(part1, part2) and torch.equal(parts1, parts2)
+    # float64: S = Sd[row] + sum_g gain Stau_g; EDR_m = sum_{m' >= m} |S_m'|^2; loss = sum |T - 10 log10(EDR + eps)| / sum |T|
+    band = torch.arange(items, device=DEV) // B
+    S = (Sd[rows].to(torch.complex128)
+         + (rgain.to(torch.complex128)[:, :, None, None] * Stau.view(nb, G, nfr, nf)[band].to(torch.complex128)).sum(1))
+    S = S.detach().requires_grad_(True)
+    P = S.real ** 2 + S.imag ** 2
+    edr = torch.flip(torch.cumsum(torch.flip(P, dims=[1]), dim=1), dims=[1])
+    db = torch.clamp(10.0 * torch.log10(edr.abs() + float(np.finfo(np.float32).eps)), min=-200.0)
+    li = (T_db[rows].double() - db).abs().sum(dim=(1, 2)) / sum_abs[rows].double()
+    (1.5 * li.sum()).backward()
+    dS = S.grad                                                                   # dL/dRe + i dL/dIm
+    assert float(((part1.sum(1) / sum_abs[rows]).double() - li.detach()).abs().max() / li.detach().abs().max()) < 2e-6
+    dots_ref = (Stau.view(nb, G, nfr, nf)[band].to(torch.complex128).conj() * dS[:, None]).real.sum(dim=(2, 3))
+    assert float((parts1.sum(1).view(items, G).double() - dots_ref).abs().max() / dots_ref.abs().max()) < 2e-5
+    # (L1: where a target sits within float32 rounding of the EDR the sign of |.| differs between float32 and float64, and that
+    # cell's column of the gradient with it -- a handful of 8.8 M cells)
+    Gs_ref = (rgain.double().view(nb, B, G, 1, 1) * dS.view(nb, B, 1, nfr, nf)).sum(1).reshape(nb * G, nfr, nf)
+    for Gs in (Gs1.sum(0), Gs2.sum(0)):
+        assert float((Gs.to(torch.complex128) - Gs_ref).abs().sum() / Gs_ref.abs().sum()) < 1e-5
+    assert float((Gs1.sum(0) - Gs2.sum(0)).abs().max() / Gs2.sum(0).abs().max()) < 1e-6
