@@ -14,7 +14,7 @@
 // small LDS table each -- two workgroup barriers per scan for the whole window, against one block scan per 4096-sample tile
 // and three launches (segment energies, forward scan, backward scan; losses.hip k_edc_pair_*) that staged the window
 // samples and dL/dEDC through memory: per receiver 4 L B written + 12 L B read there, L = window length, against 8 L B
-// read (xd, target) + 4 L B written here.  Seven of the twelve tiles of staged dL/dEDC values live in LDS (112 KB; a workgroup owns its CU)
+// read (xd, target) + 4 L B written here.  Nine of the twelve tiles of staged dL/dEDC values live in LDS (144 KB, 16-byte slots; a workgroup owns its CU)
 // so that the thread's registers stay below 128 (four waves per SIMD).
 // The suffix scan runs from the END of the window (small tail energies are summed first) and the prefix scan from its START
 // (the small early terms of dL/dEDC first), as the three-launch form does; sums are in fixed order (bitwise reproducible).

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
 // The same loss with the gradient spectra summed over the band's receivers IN the launch, without dL/d|S|^2 in memory and
 // with the transformed direct paths read once (176 MB per step instead of the 426 MB of k_edr_lin_cols + k_edr_lin_gsum).
 // A thread OWNS cells of the band's (frame, frequency) plane -- four consecutive frames of one frequency -- keeps the band's G
-// group spectra of its cells (32 registers) and its share of the G gradient spectra (32 accumulator registers) for the whole
-// launch, and walks the band's receivers: per receiver it loads its 4 cells of the direct-path spectrum and the target,
+// group spectra of its cells (32 registers) and its share of the G gradient spectra (32 accumulators: registers until round 6,
+// now the lane's own LDS slots) for the whole launch, and walks the band's receivers: per receiver it loads its 4 cells of the direct-path spectrum and the target,
 // composes S, and runs the two scans along the frames (tail energy; prefix sums of dL/dE) inside the thread over its 4 frames
 // and across the frame groups inside the WAVE (k_edr_lin_wave below).
 // The receivers are added in index order: bitwise reproducible.  ``nsplit`` > 1: the receivers of a band are cut into nsplit
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256) void k_edr_lin_cols(EdrLin a, int nframes, int
 // (frame group fg = lane >> 3, frequency fl = lane & 7), the thread owns the frames 4 fg .. 4 fg + 3 of its frequency as
 // before -- so the two scans along the frames run inside the wave on the VALU: the pair (fg, fg ^ 1) by one DPP row rotation,
 // the four rows of sixteen lanes by v_permlane16_swap / v_permlane32_swap (three swaps give every lane the four row totals);
-// direct sums only, no total-minus-prefix.  No LDS, no __syncthreads: the waves of a workgroup (4 waves = 32 adjacent
-// frequencies, so that the 128-byte lines of a frame row are shared inside the workgroup) run independently.  (The form it
+// direct sums only, no total-minus-prefix.  No LDS exchange, no __syncthreads: the waves of a workgroup (4 waves = 32 adjacent
+// frequencies, so that the 128-byte lines of a frame row are shared inside the workgroup: with two or one wave per workgroup
+// the launch takes 61 / 84 us instead of 50) run independently.  (The form it
 // replaced -- eight waves per 64 frequencies, the scans across the waves through two 2 KB LDS exchanges and two barriers per
 // receiver -- took 75 us alone against 59: DESIGN.md section 4.3.)  The partial sums are per WAVE:
 // gfdn_edr_lin_band_parts(nfreq) = 4 ceil(nfreq / 32) columns per receiver.
